@@ -1,0 +1,23 @@
+/* ffhip_internal.h — declarations shared between the plain-C host side and the HIP side of libffhip. */
+#ifndef FFHIP_INTERNAL_H
+#define FFHIP_INTERNAL_H
+#include <stddef.h>
+#include <stdint.h>
+#include "ffhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* printf-style; stores the message returned by ffhip_last_error() (thread-local) */
+void ffhip_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+/* host/sws_tables.c */
+int  ffhip_host_init_filter(int16_t **out_filter, int32_t **out_pos, int xInc, int srcW, int dstW, int one,
+                            int scaler, int flags);
+void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

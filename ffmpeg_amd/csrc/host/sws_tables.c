@@ -1,0 +1,451 @@
+/*
+ * sws_tables.c — host-side (cold path) table generation for the hip swscale arch.
+ *
+ * When libffhip is installed under FFmpeg, the tables come from FFmpeg itself
+ * (ffhip_sws_from_tables).  Stand-alone, this file derives the same tables:
+ *
+ *   - separable filter banks  == initFilter()             libswscale/utils.c:197-612
+ *     with the call-site arguments of ff_sws_init_single_context, utils.c:1250-1251,1393-1396,
+ *     1428-1429,1675-1730 (cpu_flags == 0 => filterAlign 1; default chroma siting => pos 128)
+ *   - yuv2rgb LUT coefficients == ff_yuv2rgb_c_init_tables() libswscale/yuv2rgb.c:717-800
+ *   - converter selection      == ff_get_unscaled_swscale()  libswscale/swscale_unscaled.c:2425-2431
+ *
+ * Integer arithmetic follows the reference step for step because the GPU kernels must consume
+ * bit-identical tables; tests/test_sws_tables.py pins every bank against the reference's.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ffhip.h"
+#include "ffhip_internal.h"
+
+#define REDUCE_CUTOFF 0.002 /* SWS_MAX_REDUCE_CUTOFF, libswscale/swscale.h:447 */
+
+static int ilog2(unsigned v)
+{
+    int n = 0;
+    while (v >>= 1)
+        n++;
+    return n;
+}
+
+static int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
+
+/* round-to-nearest signed division, ties away from zero (ROUNDED_DIV, libavutil/common.h) */
+static int64_t rdiv(int64_t a, int64_t b)
+{
+    return a > 0 ? (a + (b >> 1)) / b : (a - (b >> 1)) / b;
+}
+
+static int scaler_of(int flags, int chroma)
+{
+    static const int order[] = { FFHIP_SWS_FAST_BILINEAR, FFHIP_SWS_BILINEAR, FFHIP_SWS_BICUBIC, 0x8 /* X */,
+                                 FFHIP_SWS_POINT, FFHIP_SWS_AREA, FFHIP_SWS_BICUBLIN, FFHIP_SWS_GAUSS,
+                                 FFHIP_SWS_SINC, FFHIP_SWS_LANCZOS, 0x400 /* SPLINE */ };
+    for (unsigned i = 0; i < sizeof(order) / sizeof(order[0]); i++)
+        if (flags & order[i]) {
+            if (order[i] == FFHIP_SWS_BICUBLIN)
+                return chroma ? FFHIP_SWS_BILINEAR : FFHIP_SWS_BICUBIC;
+            return order[i];
+        }
+    return FFHIP_SWS_BICUBIC; /* SWS_SCALE_AUTO default, utils.c:1226-1234 */
+}
+
+/* raw (un-normalised) weight of one tap at fixed-point distance d (1<<30 == one source sample) */
+static int64_t tap_weight(int scaler, int64_t d, int64_t xInc, int64_t fone)
+{
+    double fd = (double)d * (1.0 / (1 << 30));
+    int64_t w;
+    switch (scaler) {
+    case FFHIP_SWS_BICUBIC: {
+        /* B = 0, C = 0.6 in 24-bit fixed point */
+        const int64_t B = 0;
+        const int64_t C = (int64_t)(0.6 * (1 << 24));
+        if (d >= 1LL << 31) {
+            w = 0;
+        } else {
+            int64_t d2 = (d * d) >> 30;
+            int64_t d3 = (d2 * d) >> 30;
+            if (d < 1LL << 30)
+                w = (12 * (1 << 24) - 9 * B - 6 * C) * d3 + (-18 * (1 << 24) + 12 * B + 6 * C) * d2 +
+                    (6 * (1 << 24) - 2 * B) * (int64_t)(1 << 30);
+            else
+                w = (-B - 6 * C) * d3 + (6 * B + 30 * C) * d2 + (-12 * B - 48 * C) * d +
+                    (8 * B + 24 * C) * (int64_t)(1 << 30);
+        }
+        return w / ((1LL << 54) / fone);
+    }
+    case FFHIP_SWS_BILINEAR:
+        w = (1 << 30) - d;
+        if (w < 0)
+            w = 0;
+        return w * (fone >> 30);
+    case FFHIP_SWS_AREA: {
+        int64_t e = d - (1 << 29);
+        if (e * xInc < -(1LL << (29 + 16)))
+            w = (int64_t)(1.0 * (1LL << (30 + 16)));
+        else if (e * xInc < (1LL << (29 + 16)))
+            w = -e * xInc + (1LL << (29 + 16));
+        else
+            w = 0;
+        return w * (fone >> (30 + 16));
+    }
+    case FFHIP_SWS_GAUSS:
+        return (int64_t)(exp2(-3.0 * fd * fd) * fone);
+    case FFHIP_SWS_SINC:
+        return (int64_t)((d ? sin(fd * M_PI) / (fd * M_PI) : 1.0) * fone);
+    case FFHIP_SWS_LANCZOS: {
+        const double p = 3.0;
+        w = (int64_t)((d ? sin(fd * M_PI) * sin(fd * M_PI / p) / (fd * fd * M_PI * M_PI / p) : 1.0) * fone);
+        if (fd > p)
+            w = 0;
+        return w;
+    }
+    }
+    return 0;
+}
+
+static int support_factor(int scaler)
+{
+    switch (scaler) {
+    case FFHIP_SWS_AREA:     return 1;
+    case FFHIP_SWS_BILINEAR: return 2;
+    case FFHIP_SWS_BICUBIC:  return 4;
+    case FFHIP_SWS_GAUSS:    return 8;
+    case FFHIP_SWS_SINC:     return 20;
+    case FFHIP_SWS_LANCZOS:  return 6;
+    }
+    return -1;
+}
+
+/*
+ * One filter bank.  `one` is 1<<14 (horizontal) or 1<<12 (vertical); srcPos == dstPos == 128.
+ * Returns the tap count, or <0.  *out_filter has (dstW+3)*size entries, *out_pos dstW+3 —
+ * the same over-read padding the reference allocates (utils.c:211,564,590-601).
+ */
+int ffhip_host_init_filter(int16_t **out_filter, int32_t **out_pos, int xInc, int srcW, int dstW, int one,
+                           int scaler, int flags)
+{
+    const int srcPos = 128, dstPos = 128;
+    int ratio_log = srcW / dstW ? ilog2(srcW / dstW) : 0;
+    const int64_t fone = 1LL << (54 - (ratio_log < 8 ? ratio_log : 8));
+    int64_t *w = NULL, *w2 = NULL;
+    int32_t *pos = calloc((size_t)dstW + 3, sizeof(*pos));
+    int taps, i, j;
+
+    if (!pos)
+        return FFHIP_ENOMEM;
+
+    if (abs(xInc - 0x10000) < 10 && srcPos == dstPos) {
+        /* identity */
+        taps = 1;
+        w = calloc(dstW, sizeof(*w));
+        if (!w)
+            goto nomem;
+        for (i = 0; i < dstW; i++) {
+            w[i] = fone;
+            pos[i] = i;
+        }
+    } else if (scaler == FFHIP_SWS_POINT) {
+        int64_t x = (((int64_t)dstPos * xInc) >> 8) - ((srcPos * 0x8000LL) >> 7);
+        taps = 1;
+        w = calloc(dstW, sizeof(*w));
+        if (!w)
+            goto nomem;
+        for (i = 0; i < dstW; i++, x += xInc) {
+            pos[i] = (int32_t)((x + (1 << 15)) >> 16);
+            w[i] = fone;
+        }
+    } else if ((xInc <= (1 << 16) && scaler == FFHIP_SWS_AREA) || scaler == FFHIP_SWS_FAST_BILINEAR) {
+        int64_t x = (((int64_t)dstPos * xInc) >> 8) - ((srcPos * 0x8000LL) >> 7);
+        taps = 2;
+        w = calloc((size_t)dstW * 2, sizeof(*w));
+        if (!w)
+            goto nomem;
+        for (i = 0; i < dstW; i++, x += xInc) {
+            int xx = (int)((x - (1 << 15) + (1 << 15)) >> 16);
+            pos[i] = xx;
+            for (j = 0; j < 2; j++, xx++) {
+                int64_t c = fone - iabs64((int64_t)xx * (1 << 16) - x) * (fone >> 16);
+                w[i * 2 + j] = c < 0 ? 0 : c;
+            }
+        }
+    } else {
+        int sf = support_factor(scaler);
+        int64_t x;
+        if (sf < 0) {
+            free(pos);
+            return FFHIP_EINVAL;
+        }
+        taps = xInc <= (1 << 16) ? 1 + sf : 1 + (sf * srcW + dstW - 1) / dstW;
+        if (taps > srcW - 2)
+            taps = srcW - 2;
+        if (taps < 1)
+            taps = 1;
+        w = calloc((size_t)dstW * taps, sizeof(*w));
+        if (!w)
+            goto nomem;
+        x = (((int64_t)dstPos * xInc) >> 7) - ((srcPos * 0x10000LL) >> 7);
+        for (i = 0; i < dstW; i++, x += 2LL * xInc) {
+            int xx = (int)((x - (taps - 2) * (1LL << 16)) / (1 << 17));
+            pos[i] = xx;
+            for (j = 0; j < taps; j++, xx++) {
+                int64_t d = iabs64(((int64_t)xx * (1 << 17)) - x) << 13;
+                if (xInc > 1 << 16)
+                    d = d * dstW / srcW;
+                w[i * taps + j] = tap_weight(scaler, d, xInc, fone);
+            }
+        }
+    }
+
+    /* no src/dst blur vectors: filter2 == filter */
+    w2 = w;
+    w = NULL;
+    {
+        const int n2 = taps;
+        int need = 0;
+        const double cut = REDUCE_CUTOFF * (double)fone;
+        /* trim near-zero taps: shift rows left while the discarded mass stays under the cut-off and
+         * positions stay non-decreasing; count how many taps the widest row still needs */
+        for (i = dstW - 1; i >= 0; i--) {
+            int64_t *row = w2 + (size_t)i * n2;
+            int keep = n2;
+            int64_t mass = 0;
+            for (j = 0; j < n2; j++) {
+                mass += iabs64(row[0]);
+                if ((double)mass > cut)
+                    break;
+                if (i < dstW - 1 && pos[i] >= pos[i + 1])
+                    break;
+                memmove(row, row + 1, (n2 - 1) * sizeof(*row));
+                row[n2 - 1] = 0;
+                pos[i]++;
+            }
+            mass = 0;
+            for (j = n2 - 1; j > 0; j--) {
+                mass += iabs64(row[j]);
+                if ((double)mass > cut)
+                    break;
+                keep--;
+            }
+            if (keep > need)
+                need = keep;
+        }
+        /* filterAlign == 1 with cpu_flags == 0 */
+        (void)flags;
+        if (need <= 0 || need >= 256) { /* MAX_FILTER_SIZE, swscale_internal.h:55 */
+            free(w2);
+            free(pos);
+            return FFHIP_EINVAL; /* the reference would cascade contexts here (RETCODE_USE_CASCADE) */
+        }
+        w = calloc((size_t)dstW * need, sizeof(*w));
+        if (!w)
+            goto nomem;
+        for (i = 0; i < dstW; i++)
+            for (j = 0; j < need; j++)
+                w[(size_t)i * need + j] = j < n2 ? w2[(size_t)i * n2 + j] : 0;
+        free(w2);
+        w2 = NULL;
+        taps = need;
+    }
+
+    /* fold taps that fall outside [0, srcW) onto the border sample */
+    for (i = 0; i < dstW; i++) {
+        int64_t *row = w + (size_t)i * taps;
+        if (pos[i] < 0) {
+            for (j = 1; j < taps; j++) {
+                int left = j + pos[i] > 0 ? j + pos[i] : 0;
+                row[left] += row[j];
+                row[j] = 0;
+            }
+            pos[i] = 0;
+        }
+        if (pos[i] + taps > srcW) {
+            int shift = pos[i] + (taps - srcW < 0 ? taps - srcW : 0);
+            int64_t acc = 0;
+            for (j = taps - 1; j >= 0; j--)
+                if (pos[i] + j >= srcW) {
+                    acc += row[j];
+                    row[j] = 0;
+                }
+            for (j = taps - 1; j >= 0; j--)
+                row[j] = j < shift ? 0 : row[j - shift];
+            pos[i] -= shift;
+            row[srcW - 1 - pos[i]] += acc;
+        }
+    }
+
+    /* normalise each row to `one` with error feedback between taps */
+    {
+        int16_t *f = calloc(((size_t)dstW + 3) * taps, sizeof(*f));
+        if (!f)
+            goto nomem;
+        for (i = 0; i < dstW; i++) {
+            const int64_t *row = w + (size_t)i * taps;
+            int64_t sum = 0, err = 0;
+            for (j = 0; j < taps; j++)
+                sum += row[j];
+            sum = (sum + one / 2) / one;
+            if (!sum)
+                sum = 1;
+            for (j = 0; j < taps; j++) {
+                int64_t v = row[j] + err;
+                int q = (int)rdiv(v, sum);
+                f[(size_t)i * taps + j] = (int16_t)q;
+                err = v - q * sum;
+            }
+        }
+        for (i = 0; i < 3; i++) {
+            pos[dstW + i] = pos[dstW - 1];
+            memcpy(f + (size_t)(dstW + i) * taps, f + (size_t)(dstW - 1) * taps, taps * sizeof(*f));
+        }
+        *out_filter = f;
+    }
+    *out_pos = pos;
+    free(w);
+    return taps;
+
+nomem:
+    free(w);
+    free(w2);
+    free(pos);
+    return FFHIP_ENOMEM;
+}
+
+/* ITU-R BT.601 row of ff_yuv2rgb_coeffs[] == SWS_CS_DEFAULT (libswscale/yuv2rgb.c:47-59) */
+static const int32_t cs_default[4] = { 104597, 132201, 25675, 53279 };
+
+/* ff_yuv2rgb_c_init_tables() for bpp 24, limited-range source, neutral brightness/contrast/saturation */
+void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange)
+{
+    int64_t crv = cs_default[0], cbu = cs_default[1], cgu = -cs_default[2], cgv = -cs_default[3];
+    int64_t cy = 1 << 16, oy = 0;
+    if (!fullRange) {
+        cy = (cy * 255) / 219;
+        oy = 16 << 16;
+    } else {
+        crv = (crv * 224) / 255;
+        cbu = (cbu * 224) / 255;
+        cgu = (cgu * 224) / 255;
+        cgv = (cgv * 224) / 255;
+    }
+    /* contrast = saturation = 1<<16, brightness = 0: the >>16 / >>32 products are identities */
+    t->yuv2rgb_cy  = cy;
+    t->yuv2rgb_oy  = oy;
+    t->yuv2rgb_crv = ((crv * (1 << 16)) + 0x8000) / cy;
+    t->yuv2rgb_cbu = ((cbu * (1 << 16)) + 0x8000) / cy;
+    t->yuv2rgb_cgu = ((cgu * (1 << 16)) + 0x8000) / cy;
+    t->yuv2rgb_cgv = ((cgv * (1 << 16)) + 0x8000) / cy;
+    t->yuv2rgb_yoffs = (fullRange ? 384 : 326) + 512; /* + YUVRGB_TABLE_LUMA_HEADROOM */
+}
+
+struct FFHipSwsHostTables {
+    FFHipSwsTables t;
+    int16_t *f[4];
+    int32_t *p[4];
+    int unscaled_yuv2rgb;
+};
+
+static int is_yuv(int fmt)
+{
+    return fmt == FFHIP_PIX_FMT_YUV420P || fmt == FFHIP_PIX_FMT_NV12 || fmt == FFHIP_PIX_FMT_NV21;
+}
+static int is_rgb(int fmt) { return fmt == FFHIP_PIX_FMT_RGB24 || fmt == FFHIP_PIX_FMT_BGR24; }
+
+static int ceil_rshift(int a, int b) { return -((-a) >> b); }
+
+FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, int dstW, int dstH,
+                                            int dstFormat, int flags)
+{
+    FFHipSwsHostTables *h;
+    int chrSrcW, chrSrcH, chrDstW, chrDstH, chrDstHSub, chrDstVSub;
+    int64_t lumXInc, lumYInc, chrXInc, chrYInc;
+    int lum_scaler = scaler_of(flags, 0), chr_scaler = scaler_of(flags, 1);
+    int r;
+
+    if (flags & FFHIP_SWS_FAST_BILINEAR) {
+        /* the C path of SWS_FAST_BILINEAR runs ff_hyscale_fast_c, a different horizontal scaler
+         * (libswscale/hscale_fast_bilinear.c) that is not part of this hot path */
+        ffhip_set_error("ffhip_sws: SWS_FAST_BILINEAR is not on the hip path");
+        return NULL;
+    }
+    if (!is_yuv(srcFormat) || (!is_yuv(dstFormat) && !is_rgb(dstFormat)) || srcW < 4 || srcH < 2 || dstW < 2 ||
+        dstH < 2) {
+        ffhip_set_error("ffhip_sws: unsupported conversion %d -> %d (%dx%d -> %dx%d)", srcFormat, dstFormat,
+                        srcW, srcH, dstW, dstH);
+        return NULL;
+    }
+    h = calloc(1, sizeof(*h));
+    if (!h)
+        return NULL;
+    h->t.srcW = srcW; h->t.srcH = srcH; h->t.srcFormat = srcFormat;
+    h->t.dstW = dstW; h->t.dstH = dstH; h->t.dstFormat = dstFormat;
+    h->t.flags = flags;
+
+    /* RGB output without SWS_FULL_CHR_H_INT keeps chroma at half horizontal resolution
+     * (utils.c:1359-1360) and full vertical resolution */
+    chrDstHSub = 1;
+    chrDstVSub = is_rgb(dstFormat) ? 0 : 1;
+    if (is_rgb(dstFormat) && (dstW & 1)) {
+        ffhip_set_error("ffhip_sws: odd RGB width forces SWS_FULL_CHR_H_INT in the reference; not on this path");
+        free(h);
+        return NULL;
+    }
+    chrSrcW = ceil_rshift(srcW, 1);
+    chrSrcH = ceil_rshift(srcH, 1);
+    chrDstW = ceil_rshift(dstW, chrDstHSub);
+    chrDstH = ceil_rshift(dstH, chrDstVSub);
+
+    h->unscaled_yuv2rgb = srcW == dstW && srcH == dstH && srcFormat == FFHIP_PIX_FMT_YUV420P && is_rgb(dstFormat) &&
+                          !(flags & FFHIP_SWS_ACCURATE_RND) && !(dstH & 1);
+
+    lumXInc = (((int64_t)srcW << 16) + (dstW >> 1)) / dstW;
+    lumYInc = (((int64_t)srcH << 16) + (dstH >> 1)) / dstH;
+    chrXInc = (((int64_t)chrSrcW << 16) + (chrDstW >> 1)) / chrDstW;
+    chrYInc = (((int64_t)chrSrcH << 16) + (chrDstH >> 1)) / chrDstH;
+
+    struct { int xInc, s, d, one, scaler; } bank[4] = {
+        { (int)lumXInc, srcW,    dstW,    1 << 14, lum_scaler },
+        { (int)chrXInc, chrSrcW, chrDstW, 1 << 14, chr_scaler },
+        { (int)lumYInc, srcH,    dstH,    1 << 12, lum_scaler },
+        { (int)chrYInc, chrSrcH, chrDstH, 1 << 12, chr_scaler },
+    };
+    FFHipSwsFilter *out[4] = { &h->t.hLum, &h->t.hChr, &h->t.vLum, &h->t.vChr };
+    for (int k = 0; k < 4; k++) {
+        r = ffhip_host_init_filter(&h->f[k], &h->p[k], bank[k].xInc, bank[k].s, bank[k].d, bank[k].one,
+                                   bank[k].scaler, flags);
+        if (r < 0) {
+            ffhip_set_error("ffhip_sws: filter bank %d failed (%d)", k, r);
+            ffhip_sws_tables_free(h);
+            return NULL;
+        }
+        out[k]->filter = h->f[k];
+        out[k]->pos = h->p[k];
+        out[k]->size = r;
+        out[k]->n = bank[k].d;
+    }
+    ffhip_host_yuv2rgb_coeffs(&h->t, 0);
+    return h;
+}
+
+int ffhip_sws_tables_get(const FFHipSwsHostTables *t, FFHipSwsTables *out)
+{
+    if (!t || !out)
+        return FFHIP_EINVAL;
+    *out = t->t;
+    return 0;
+}
+
+int ffhip_sws_tables_is_unscaled_yuv2rgb(const FFHipSwsHostTables *t) { return t ? t->unscaled_yuv2rgb : 0; }
+
+void ffhip_sws_tables_free(FFHipSwsHostTables *t)
+{
+    if (!t)
+        return;
+    for (int k = 0; k < 4; k++) {
+        free(t->f[k]);
+        free(t->p[k]);
+    }
+    free(t);
+}

@@ -1,0 +1,332 @@
+/*
+ * ffhip.h — C-ABI of libffhip.so, the MI355X (gfx950) "hip" arch for FFmpeg's data-parallel DSP loops.
+ *
+ * This is the drop-in boundary.  Every entry point below names the reference
+ * interface it stands in for (file:line relative to the FFmpeg tree).  Plain C: pointers, sizes,
+ * ints.  No torch / C++ types.  INTEGRATION.md shows the few-line `ff_*_init_hip()` stubs a
+ * maintainer adds on the FFmpeg side to bind these.
+ *
+ * Two faces per component (SURVEY.md §7 "granularity mismatch"):
+ *   - signature-exact single-call shims taking HOST pointers: the reference's own function-pointer
+ *     types, installable into SwsInternal / H264DSPContext / H264QpelContext / MECmpContext /
+ *     FFTXCodelet and exercisable by checkasm.  They stage through device scratch and synchronise.
+ *   - batched `_dev` entry points taking DEVICE pointers + a hipStream_t (as void *): the only form
+ *     that can reach the HBM roofline.  Asynchronous on the given stream.
+ *
+ * Return convention: 0 (or a line count where the reference returns one) on success, negative
+ * errno-style (== AVERROR(e) on POSIX) on failure.  FFHIP_ENOSYS when no HIP device is usable —
+ * the caller keeps its C function pointer.  Nothing here silently falls back to a CPU path.
+ */
+#ifndef FFHIP_H
+#define FFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFHIP_EINVAL (-22)
+#define FFHIP_ENOMEM (-12)
+#define FFHIP_ENOSYS (-38)
+#define FFHIP_EIO    (-5)    /* a HIP runtime call failed; ffhip_last_error() has the text */
+
+/* ------------------------------------------------------------------------------------------ */
+/* runtime                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/** Number of usable HIP devices (0 when none / no driver).  Mirrors the role of av_get_cpu_flags()
+ *  & AV_CPU_FLAG_* gating in every ff_*_init_<arch>() (libavutil/cpu.h:32-62). */
+int         ffhip_device_count(void);
+/** Bind the calling thread to a device (one process per GPU; rank -> LOCAL_RANK). */
+int         ffhip_set_device(int device);
+const char *ffhip_last_error(void);
+const char *ffhip_version(void);
+/** Device memory helpers for callers that do not bring their own allocator. */
+int         ffhip_malloc(void **dev_ptr, size_t bytes);
+int         ffhip_free(void *dev_ptr);
+int         ffhip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
+int         ffhip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
+int         ffhip_stream_synchronize(void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* libswscale: hscale / vscale / yuv2rgb                                                      */
+/* ------------------------------------------------------------------------------------------ */
+/* Pixel formats: numeric values are AVPixelFormat's (libavutil/pixfmt.h). */
+#define FFHIP_PIX_FMT_YUV420P 0
+#define FFHIP_PIX_FMT_RGB24   2
+#define FFHIP_PIX_FMT_BGR24   3
+#define FFHIP_PIX_FMT_NV12    23
+#define FFHIP_PIX_FMT_NV21    24
+/* Flags: numeric values are SwsFlags' (libswscale/swscale.h:130-153). */
+#define FFHIP_SWS_FAST_BILINEAR 0x1
+#define FFHIP_SWS_BILINEAR      0x2
+#define FFHIP_SWS_BICUBIC       0x4
+#define FFHIP_SWS_POINT         0x10
+#define FFHIP_SWS_AREA          0x20
+#define FFHIP_SWS_BICUBLIN      0x40
+#define FFHIP_SWS_GAUSS         0x80
+#define FFHIP_SWS_SINC          0x100
+#define FFHIP_SWS_LANCZOS       0x200
+#define FFHIP_SWS_ACCURATE_RND  0x40000
+#define FFHIP_SWS_BITEXACT      0x80000
+
+/**
+ * One separable filter bank as the reference's initFilter() produces it
+ * (libswscale/utils.c:197-612): `filter[n][size]` int16 coefficients, `pos[n]` first source sample.
+ * Horizontal banks sum to ~1<<14, vertical to 1<<12.
+ */
+typedef struct FFHipSwsFilter {
+    const int16_t *filter;
+    const int32_t *pos;
+    int            size;   /* taps per output sample  (SwsInternal.hLumFilterSize ...) */
+    int            n;      /* number of output samples (dstW, chrDstW, dstH, chrDstH)  */
+} FFHipSwsFilter;
+
+/**
+ * What ff_sws_init_swscale_hip(SwsInternal *c) hands over: the context fields the hot path reads
+ * (libswscale/swscale_internal.h:330-700).  All arrays are copied by ffhip_sws_from_tables().
+ */
+typedef struct FFHipSwsTables {
+    int srcW, srcH, srcFormat;
+    int dstW, dstH, dstFormat;
+    int flags;
+    FFHipSwsFilter hLum, hChr, vLum, vChr;   /* c->{h,v}{Lum,Chr}Filter[Pos|Size]           */
+    /* yuv2rgb: the already cy-scaled coefficients the LUTs are built from
+     * (libswscale/yuv2rgb.c:717-800): cy, oy, crv', cbu', cgu', cgv' and the ramp offset yoffs. */
+    int64_t yuv2rgb_cy, yuv2rgb_oy, yuv2rgb_crv, yuv2rgb_cbu, yuv2rgb_cgu, yuv2rgb_cgv;
+    int     yuv2rgb_yoffs;
+} FFHipSwsTables;
+
+typedef struct FFHipSwsContext FFHipSwsContext;
+
+/** Stand-alone construction; same argument meaning as sws_getContext() (libswscale/swscale.h,
+ *  libswscale/utils.c:2043) for the formats above; srcFilter/dstFilter/param are the defaults.
+ *  Filter banks come from our host restatement of initFilter() (cpu_flags == 0 => filterAlign 1).
+ *  Returns NULL (and sets ffhip_last_error) for an unsupported conversion or when no device. */
+FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcFormat,
+                                      int dstW, int dstH, int dstFormat, int flags);
+/** Drop-in construction from FFmpeg's own tables (no filter generation on our side). */
+FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t);
+void             ffhip_sws_freeContext(FFHipSwsContext *c);
+
+/** Host-table generation alone (no device needed): our initFilter().  `which`: 0 hLum 1 hChr 2 vLum
+ *  3 vChr.  Returns filter size or <0; pointers stay valid until ffhip_sws_tables_free().  Used by
+ *  the CPU test-suite to pin the host logic against the reference's tables. */
+typedef struct FFHipSwsHostTables FFHipSwsHostTables;
+FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat,
+                                            int dstW, int dstH, int dstFormat, int flags);
+int  ffhip_sws_tables_get(const FFHipSwsHostTables *t, FFHipSwsTables *out);
+/** 1 when the (src,dst,flags) triple takes the reference's table-driven unscaled converter
+ *  `yuv2rgb_c_24_rgb` (rule at libswscale/swscale_unscaled.c:2425-2431), 0 for ff_swscale(). */
+int  ffhip_sws_tables_is_unscaled_yuv2rgb(const FFHipSwsHostTables *t);
+void ffhip_sws_tables_free(FFHipSwsHostTables *t);
+
+/**
+ * SwsFunc-shaped frame call with HOST pointers — the pointer installed as `c->convert_unscaled`
+ * (typedef at libswscale/swscale_internal.h:99-101; called at libswscale/swscale.c:1185).
+ * Stages src -> device, runs the kernels, copies the written lines back; returns the number of
+ * output lines written (srcSliceH for unscaled, dstH for a whole-frame scaled call) or <0.
+ * Only whole frames (srcSliceY == 0, srcSliceH == srcH) are accepted for scaled contexts.
+ */
+int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], const int srcStride[],
+                    int srcSliceY, int srcSliceH, uint8_t *const dst[], const int dstStride[]);
+
+/**
+ * Batched, device-resident face.  Frame f of plane p starts at src[p] + f*srcFramePitch[p]
+ * (bytes), rows are srcStride[p] bytes apart; likewise dst.  Planes: yuv420p {Y,U,V}, nv12 {Y,UV},
+ * rgb24 {RGB}.  Asynchronous on `stream` (hipStream_t).  Returns 0 or <0.
+ */
+int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes,
+                              const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
+                              void *const dst[4], const int dstStride[4], const size_t dstFramePitch[4],
+                              void *stream);
+
+/** Per-line parity face (device pointers): hyScale/hcScale == hScale8To15_c
+ *  (libswscale/swscale.c:128-142; pointer type swscale_internal.h:648-653), batched over `nlines`
+ *  lines that share one filter bank. */
+int ffhip_sws_hscale8to15_dev(int16_t *dst, int dstW, ptrdiff_t dstPitch, const uint8_t *src, ptrdiff_t srcPitch,
+                              int nlines, const int16_t *filter, const int32_t *filterPos, int filterSize,
+                              void *stream);
+/** yuv2planeX_8_c / yuv2plane1_8_c (libswscale/output.c:468-493; type swscale_internal.h:128-144):
+ *  `nsrc` int16 lines at src + j*srcPitch, one output line. dither is 8 bytes. */
+int ffhip_sws_yuv2planeX8_dev(const int16_t *filter, int filterSize, const int16_t *src, ptrdiff_t srcPitch,
+                              uint8_t *dest, int dstW, const uint8_t *dither8, int offset, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* libavcodec: h264dsp                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+/**
+ * H264DSPContext subset (libavcodec/h264dsp.h:42-117), same member names and signatures, HOST
+ * pointers.  ff_h264dsp_init_hip() below fills it the way ff_h264dsp_init_<arch>() would
+ * (libavcodec/h264dsp.c:155-169).  8-bit only; other depths keep the C pointers.
+ */
+typedef struct FFHipH264DSPContext {
+    void (*v_loop_filter_luma)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
+    void (*h_loop_filter_luma)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
+    void (*v_loop_filter_luma_intra)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta);
+    void (*h_loop_filter_luma_intra)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta);
+    void (*v_loop_filter_chroma)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
+    void (*h_loop_filter_chroma)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
+    void (*v_loop_filter_chroma_intra)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta);
+    void (*h_loop_filter_chroma_intra)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta);
+    void (*idct_add)(uint8_t *dst, int16_t *block, ptrdiff_t stride);
+    void (*idct8_add)(uint8_t *dst, int16_t *block, ptrdiff_t stride);
+    void (*idct_dc_add)(uint8_t *dst, int16_t *block, ptrdiff_t stride);
+    void (*idct8_dc_add)(uint8_t *dst, int16_t *block, ptrdiff_t stride);
+    void (*idct_add16)(uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
+                       const uint8_t nnzc[5 * 8]);
+    void (*idct8_add4)(uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
+                       const uint8_t nnzc[5 * 8]);
+    void (*idct_add16intra)(uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
+                            const uint8_t nnzc[5 * 8]);
+} FFHipH264DSPContext;
+/** Returns 0 and fills every member, or FFHIP_ENOSYS/FFHIP_EINVAL leaving *c untouched. */
+int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int chroma_format_idc);
+
+/** IDCT kinds for the batch face; one kernel per kind == one reference function
+ *  (libavcodec/h264idct_template.c:33,69,145,161). */
+#define FFHIP_H264_IDCT4     0
+#define FFHIP_H264_IDCT8     1
+#define FFHIP_H264_IDCT4_DC  2
+#define FFHIP_H264_IDCT8_DC  3
+/**
+ * n independent blocks: block i adds into dst_base + dst_offset[i] (bytes, rows `stride` apart) from
+ * coefficients blocks + i*(16|64) int16 (transposed storage as the decoder leaves them), then the
+ * coefficients are zeroed — exactly ff_h264_idct{,8}{,_dc}_add_8_c.  Destinations must not overlap.
+ */
+int ffhip_h264_idct_add_batch_dev(int kind, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
+                                  int16_t *blocks, int n, void *stream);
+/**
+ * Macroblock-level dispatchers over a batch of `nmb` macroblocks: idct_add16 / idct8_add4 /
+ * idct_add16intra (libavcodec/h264idct_template.c:177-214).  MB m uses dst_base + mb_offset[m],
+ * blocks + m*256 int16, nnzc + m*40 (indexed through scan8, libavcodec/h264_parse.h:40),
+ * blockoffset[16] shared.  which: 0 add16, 1 idct8_add4, 2 add16intra.
+ */
+int ffhip_h264_idct_add_mb_batch_dev(int which, uint8_t *dst_base, ptrdiff_t stride, const int32_t *mb_offset,
+                                     const int32_t *blockoffset16, int16_t *blocks, const uint8_t *nnzc,
+                                     int nmb, void *stream);
+
+/** Loop-filter kinds == H264DSPContext members (libavcodec/h264dsp_template.c:104-330). */
+#define FFHIP_H264_LF_V_LUMA          0
+#define FFHIP_H264_LF_H_LUMA          1
+#define FFHIP_H264_LF_V_CHROMA        2
+#define FFHIP_H264_LF_H_CHROMA        3
+#define FFHIP_H264_LF_V_LUMA_INTRA    4
+#define FFHIP_H264_LF_H_LUMA_INTRA    5
+#define FFHIP_H264_LF_V_CHROMA_INTRA  6
+#define FFHIP_H264_LF_H_CHROMA_INTRA  7
+/** One edge descriptor of the batch face: everything the reference call takes besides pix/stride. */
+typedef struct FFHipH264Edge {
+    int32_t offset;      /* pix = base + offset                                    */
+    uint8_t kind;        /* FFHIP_H264_LF_*                                         */
+    uint8_t alpha, beta; /* 8-bit tables top out at 255 / 18 (h264_loopfilter.c)   */
+    uint8_t pad;
+    int8_t  tc0[4];
+} FFHipH264Edge;
+/**
+ * n edges whose touched pixels are pairwise DISJOINT (function-level batch, as checkasm's tiles).
+ * Order-dependent frame deblocking is ffhip_h264_deblock_frame_dev().
+ */
+int ffhip_h264_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n,
+                                     void *stream);
+/**
+ * True frame-order luma deblocking of a whole picture (mb_w x mb_h macroblocks): for every MB in
+ * raster order, vertical edges 0..3 left-to-right then horizontal edges 0..3 top-to-bottom, as
+ * ff_h264_filter_mb() orders the h264dsp calls (libavcodec/h264_loopfilter.c:716).
+ * edges[(mb*2 + dir)*4 + e] describes MB mb, dir 0 = vertical edges (h_loop_filter_*), 1 =
+ * horizontal; `kind` selects normal (tc0 used) vs intra, alpha == 0 skips the edge; `offset` ignored.
+ * Implemented as a 2-D wavefront over MBs — bit-exact with the serial order.
+ */
+int ffhip_h264_deblock_frame_dev(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h,
+                                 const FFHipH264Edge *edges, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* libavcodec: h264qpel                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+/** qpel_mc_func (libavcodec/qpeldsp.h:65-67) and H264QpelContext (libavcodec/h264qpel.h:27-30). */
+typedef void (*ffhip_qpel_mc_func)(uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
+typedef struct FFHipH264QpelContext {
+    ffhip_qpel_mc_func put_h264_qpel_pixels_tab[3][16];
+    ffhip_qpel_mc_func avg_h264_qpel_pixels_tab[3][16];
+} FFHipH264QpelContext;
+int ff_h264qpel_init_hip(FFHipH264QpelContext *c, int bit_depth);
+
+/** One motion-compensated block of the batch face (what mc_dir_part() passes, h264_mb.c:206-250). */
+typedef struct FFHipQpelBlock {
+    int32_t dst_offset;  /* into dst plane                                            */
+    int32_t src_offset;  /* into ref plane: integer-pel position of the block origin  */
+    uint8_t mcxy;        /* luma_xy = (mx&3) + ((my&3)<<2)                            */
+    uint8_t size_idx;    /* 0: 16x16, 1: 8x8, 2: 4x4                                   */
+    uint8_t avg;         /* 0 put, 1 avg                                              */
+    uint8_t pad;
+} FFHipQpelBlock;
+/** n blocks, one stride for src & dst (as qpel_mc_func); dst blocks must not overlap. src must be
+ *  readable 2 px left/up and 3 px right/down of each block. */
+int ffhip_h264_qpel_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
+                              const FFHipQpelBlock *blocks, int n, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* libavcodec: me_cmp + full search                                                           */
+/* ------------------------------------------------------------------------------------------ */
+/** me_cmp_func (libavcodec/me_cmp.h:45-48); the context argument is unused by these metrics
+ *  (checkasm passes NULL, tests/checkasm/motion.c:75). */
+typedef int (*ffhip_me_cmp_func)(void *c, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h);
+typedef struct FFHipMECmpContext {
+    ffhip_me_cmp_func sad[2];             /* [0] 16 wide = pix_abs16_c, [1] 8 wide = pix_abs8_c */
+    ffhip_me_cmp_func hadamard8_diff[2];  /* [0] hadamard8_diff16_c, [1] hadamard8_diff8x8_c     */
+    ffhip_me_cmp_func pix_abs[2][1];      /* [w][0] full-pel                                     */
+} FFHipMECmpContext;
+int ff_me_cmp_init_hip(FFHipMECmpContext *c);
+
+#define FFHIP_ME_SAD   0
+#define FFHIP_ME_SATD  1
+/** n independent comparisons: out[i] = cmp(blk1 + off1[i], blk2 + off2[i], stride, h). width 16|8. */
+int ffhip_me_cmp_batch_dev(int kind, int width, int h, const uint8_t *blk1, const int32_t *off1,
+                           const uint8_t *blk2, const int32_t *off2, ptrdiff_t stride, int32_t *out, int n,
+                           void *stream);
+/**
+ * Exhaustive search, semantics of ff_me_search_esa() driven as vf_mestimate does
+ * (libavfilter/motion_estimation.c:78-95, COST_MV :32-40; libavfilter/vf_mestimate.c:101,119-129):
+ * for every mb_size x mb_size block of `cur`, window [x_mb±R]∩[0,(b_w-1)*mb]×[y_mb±R]∩[0,(b_h-1)*mb],
+ * zero-MV evaluated first (and returned at once when its cost is 0), then raster scan with strict <.
+ * cost_kind FFHIP_ME_SAD reproduces the filter bit-exactly; FFHIP_ME_SATD swaps the metric for
+ * hadamard8_diff (libavcodec/me_cmp.c:514-562,933-950) under the same search order.
+ * Outputs per block (raster): mv_out[2*b+{0,1}] = absolute best (x,y) as int16, cost_out[b] u32.
+ * nframes frame pairs, frame f at cur + f*frame_pitch / ref + f*frame_pitch.
+ */
+int ffhip_me_esa_batch_dev(const uint8_t *cur, const uint8_t *ref, int width, int height, ptrdiff_t stride,
+                           size_t frame_pitch, int nframes, int mb_size, int search_param, int cost_kind,
+                           int16_t *mv_out, uint32_t *cost_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* libavutil: av_tx float MDCT                                                                */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct FFHipTXContext FFHipTXContext;
+#define FFHIP_TX_FLOAT_FFT  0   /* == AV_TX_FLOAT_FFT  (libavutil/tx.h:47-132) */
+#define FFHIP_TX_FLOAT_MDCT 1   /* == AV_TX_FLOAT_MDCT                          */
+/** av_tx_fn (libavutil/tx.h:151) with an opaque context of ours in place of AVTXContext. */
+typedef void (*ffhip_tx_fn)(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
+/**
+ * Same argument meaning as av_tx_init() (libavutil/tx.h:169-172, libavutil/tx.c:903): type, inv,
+ * len (MDCT: number of output coefficients of the forward transform, power of two 16..4096 here),
+ * *scale.  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
+ * (libavutil/tx_priv.h:199-237).  *fn receives the single-transform host-pointer shim.
+ */
+int  ffhip_tx_init(FFHipTXContext **ctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,
+                   uint64_t flags);
+void ffhip_tx_uninit(FFHipTXContext **ctx);
+/**
+ * Batched device face: transform t reads in + t*in_pitch floats... pitches in BYTES; out stride is
+ * the av_tx_fn `stride` (bytes between output coefficients; sizeof(float) for contiguous).
+ * Forward MDCT: in = 2*len floats, out = len floats.  Inverse: in = len floats (read with
+ * `in_stride` bytes between coefficients), out = len floats (half-window iMDCT as the reference's
+ * default; libavutil/tx_template.c:1312-1342).
+ */
+int  ffhip_tx_batch_dev(FFHipTXContext *ctx, void *out, size_t out_pitch, const void *in, size_t in_pitch,
+                        ptrdiff_t stride, int ntransforms, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFHIP_H */

@@ -1,0 +1,92 @@
+/*
+ * ffo.h — liboracle.so: plain-C CPU restatement of the reference's hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Loaded by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg as the checker; never by the product.  Parity status: PINNED — every function
+ * is checked bit-exact (float: stated tolerance) against the real reference compiled from
+ * /root/reference (oracle/_ref/libffref.so) in tests/test_oracle_vs_ref.py, and against the
+ * committed fixtures in tests/golden/ that were generated from it.
+ */
+#ifndef FFO_H
+#define FFO_H
+#include <stddef.h>
+#include <stdint.h>
+
+/* AVPixelFormat values (libavutil/pixfmt.h) */
+#define FFO_PIX_FMT_YUV420P 0
+#define FFO_PIX_FMT_RGB24   2
+#define FFO_PIX_FMT_BGR24   3
+#define FFO_PIX_FMT_NV12    23
+#define FFO_PIX_FMT_NV21    24
+
+/* ---- swscale (ffo_sws.c) ---- */
+typedef struct FfoYuv2RgbCoeffs {
+    int64_t cy, oy, crv, cbu, cgu, cgv; /* after the /cy scaling, yuv2rgb.c:793-797 */
+    int     yoffs;
+} FfoYuv2RgbCoeffs;
+typedef struct FfoYuv2RgbLuts {
+    uint8_t ramp[2048];
+    int     rV[1280], gU[1280], gV[1280], bU[1280];
+} FfoYuv2RgbLuts;
+typedef struct FfoSwsFilter {
+    const int16_t *filter;
+    const int32_t *pos;
+    int size, n;
+} FfoSwsFilter;
+typedef struct FfoSwsTables {
+    int srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags;
+    FfoSwsFilter hLum, hChr, vLum, vChr;
+    FfoYuv2RgbCoeffs k;
+} FfoSwsTables;
+
+void ffo_yuv2rgb_luts_init(FfoYuv2RgbLuts *l, const FfoYuv2RgbCoeffs *k);
+int  ffo_yuv420p_to_rgb24(const FfoYuv2RgbLuts *l, int width, const uint8_t *const src[3], const int srcStride[3],
+                          int srcSliceY, int srcSliceH, uint8_t *dst, int dstStride, int bgr);
+void ffo_hscale8to15(int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *pos, int fs);
+void ffo_yuv2planeX8(const int16_t *filter, int fs, const int16_t *const *src, uint8_t *dest, int dstW,
+                     const uint8_t *dither, int offset);
+void ffo_yuv2plane1_8(const int16_t *src, uint8_t *dest, int dstW, const uint8_t *dither, int offset);
+void ffo_yuv2nv12cX(int swap, const uint8_t *dither, const int16_t *filter, int fs, const int16_t *const *u,
+                    const int16_t *const *v, uint8_t *dest, int chrDstW);
+int  ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], const int srcStride[3],
+                         uint8_t *const dst[3], const int dstStride[3]);
+
+/* ---- h264dsp / h264qpel (ffo_h264.c), 8-bit ---- */
+void ffo_h264_idct_add(uint8_t *dst, int16_t *block, ptrdiff_t stride);
+void ffo_h264_idct8_add(uint8_t *dst, int16_t *block, ptrdiff_t stride);
+void ffo_h264_idct_dc_add(uint8_t *dst, int16_t *block, ptrdiff_t stride);
+void ffo_h264_idct8_dc_add(uint8_t *dst, int16_t *block, ptrdiff_t stride);
+void ffo_h264_idct_add16(uint8_t *dst, const int *block_offset, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc);
+void ffo_h264_idct8_add4(uint8_t *dst, const int *block_offset, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc);
+void ffo_h264_idct_add16intra(uint8_t *dst, const int *block_offset, int16_t *block, ptrdiff_t stride,
+                              const uint8_t *nnzc);
+/* which: FFHIP_H264_LF_* numbering (0 v_luma 1 h_luma 2 v_chroma 3 h_chroma, +4 intra) */
+void ffo_h264_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0);
+void ffo_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
+/* frame-order luma deblock, same edge array layout as ffhip_h264_deblock_frame_dev (include/ffhip.h) */
+typedef struct FfoH264Edge {
+    int32_t offset;
+    uint8_t kind, alpha, beta, pad;
+    int8_t  tc0[4];
+} FfoH264Edge;
+void ffo_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges);
+
+/* ---- me_cmp + ESA (ffo_mecmp.c) ---- */
+int      ffo_sad(int width, const uint8_t *a, const uint8_t *b, ptrdiff_t stride, int h);
+int      ffo_hadamard8_diff8x8(const uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
+int      ffo_hadamard8_diff16(const uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h);
+uint64_t ffo_me_search_esa(const uint8_t *cur, const uint8_t *ref, int linesize, int width, int height, int mb_size,
+                           int search_param, int cost_kind, int x_mb, int y_mb, int *mv);
+void     ffo_me_esa_frame(const uint8_t *cur, const uint8_t *ref, int linesize, int width, int height, int mb_size,
+                          int search_param, int cost_kind, int16_t *mv_out, uint32_t *cost_out);
+
+/* ---- av_tx float MDCT (ffo_tx.c) ---- */
+typedef struct FfoTx FfoTx;
+FfoTx *ffo_mdct_create(int inv, int len, float scale);
+void   ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride);
+void   ffo_mdct_free(FfoTx *s);
+/* double-precision cosine-sum definition (ff_tx_mdct_naive_fwd/_inv, tx_template.c:1144-1193) */
+void   ffo_mdct_naive_fwd(int len, double scale, double *out, const float *in);
+void   ffo_mdct_naive_inv(int len, double scale, double *out, const float *in);
+
+#endif

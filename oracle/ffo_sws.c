@@ -1,0 +1,304 @@
+/*
+ * ffo_sws.c — CPU restatement of the reference's swscale hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so; the
+ * product (libffhip.so, ffmpeg_amd/) never does.  Pinned bit-exact against the real reference
+ * (oracle/_ref/libffref.so, built from /root/reference by oracle/refbuild/Makefile) and against the
+ * fixtures under tests/golden/ that were generated from it (tools/make_golden.py).
+ *
+ * Each function names the reference code it restates (paths relative to the FFmpeg tree).
+ * Filter banks and yuv2rgb coefficients are INPUTS: they come from the reference's initFilter()
+ * in the drop-in case, or from ffmpeg_amd/csrc/host/sws_tables.c stand-alone.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ffo.h"
+
+static inline uint8_t clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : (uint8_t)v; }
+
+/* ---------------------------------------------------------------------------------------------
+ * yuv2rgb LUTs: ff_yuv2rgb_c_init_tables() case 24 + fill_table()/fill_gv_table()
+ * libswscale/yuv2rgb.c:680-700,901-912.  One shared clipped luma ramp of 1024+2*512 entries and
+ * four 256+2*512-entry tables of offsets into it, indexed by the chroma sample + 512.
+ * ------------------------------------------------------------------------------------------- */
+#define HEADROOM      512  /* YUVRGB_TABLE_HEADROOM, swscale_internal.h:52 */
+#define LUMA_HEADROOM 512  /* YUVRGB_TABLE_LUMA_HEADROOM, swscale_internal.h:53 */
+#define RAMP_SIZE     (1024 + 2 * LUMA_HEADROOM)
+#define CTAB_SIZE     (256 + 2 * HEADROOM)
+
+void ffo_yuv2rgb_luts_init(FfoYuv2RgbLuts *l, const FfoYuv2RgbCoeffs *k)
+{
+    int64_t yb = -(384 << 16) - LUMA_HEADROOM * k->cy - k->oy;
+    for (int i = 0; i < RAMP_SIZE; i++, yb += k->cy)
+        l->ramp[i] = clip_u8((int)((yb + 0x8000) >> 16));
+    for (int i = 0; i < CTAB_SIZE; i++) {
+        int c = clip_u8(i - HEADROOM);
+        /* fill_table: base = yoffs - (inc >> 9); entry = base + ((c*inc) >> 16) */
+        l->rV[i] = k->yoffs - (int)(k->crv >> 9) + (int)((c * k->crv) >> 16);
+        l->gU[i] = k->yoffs - (int)(k->cgu >> 9) + (int)((c * k->cgu) >> 16);
+        l->bU[i] = k->yoffs - (int)(k->cbu >> 9) + (int)((c * k->cbu) >> 16);
+        /* fill_gv_table: plain offset, no ramp base */
+        l->gV[i] = -(int)(k->cgv >> 9) + (int)((c * k->cgv) >> 16);
+    }
+}
+
+static inline void put_rgb(uint8_t *d, const FfoYuv2RgbLuts *l, int Y, int U, int V, int bgr)
+{
+    int r = l->ramp[l->rV[V + HEADROOM] + Y];
+    int g = l->ramp[l->gU[U + HEADROOM] + l->gV[V + HEADROOM] + Y];
+    int b = l->ramp[l->bU[U + HEADROOM] + Y];
+    d[0] = bgr ? b : r;
+    d[1] = g;
+    d[2] = bgr ? r : b;
+}
+
+/*
+ * yuv2rgb_c_24_rgb / yuv2rgb_c_24_bgr: libswscale/yuv2rgb.c:137-228,530-531.
+ * Two luma rows share one chroma row; 8 pixels per iteration, then a 4- and a 2-pixel tail, so an
+ * odd trailing column is never written.  Returns srcSliceH like the SwsFunc.
+ */
+int ffo_yuv420p_to_rgb24(const FfoYuv2RgbLuts *l, int width, const uint8_t *const src[3],
+                         const int srcStride[3], int srcSliceY, int srcSliceH, uint8_t *dst, int dstStride,
+                         int bgr)
+{
+    int npairs = (width >> 3) * 4 + ((width & 4) ? 2 : 0) + ((width & 2) ? 1 : 0);
+    for (int y = 0; y < srcSliceH; y += 2) {
+        const uint8_t *py0 = src[0] + (ptrdiff_t)y * srcStride[0];
+        const uint8_t *py1 = py0 + srcStride[0];
+        const uint8_t *pu = src[1] + (ptrdiff_t)(y >> 1) * srcStride[1];
+        const uint8_t *pv = src[2] + (ptrdiff_t)(y >> 1) * srcStride[2];
+        uint8_t *d0 = dst + (ptrdiff_t)(y + srcSliceY) * dstStride;
+        uint8_t *d1 = d0 + dstStride;
+        for (int m = 0; m < npairs; m++) {
+            int U = pu[m], V = pv[m];
+            put_rgb(d0 + 6 * m,     l, py0[2 * m],     U, V, bgr);
+            put_rgb(d0 + 6 * m + 3, l, py0[2 * m + 1], U, V, bgr);
+            put_rgb(d1 + 6 * m,     l, py1[2 * m],     U, V, bgr);
+            put_rgb(d1 + 6 * m + 3, l, py1[2 * m + 1], U, V, bgr);
+        }
+    }
+    return srcSliceH;
+}
+
+/* hScale8To15_c: libswscale/swscale.c:128-142 */
+void ffo_hscale8to15(int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *pos, int fs)
+{
+    for (int i = 0; i < dstW; i++) {
+        int acc = 0;
+        for (int j = 0; j < fs; j++)
+            acc += (int)src[pos[i] + j] * filter[fs * i + j];
+        acc >>= 7;
+        dst[i] = (int16_t)(acc < (1 << 15) - 1 ? acc : (1 << 15) - 1);
+    }
+}
+
+/* yuv2planeX_8_c: libswscale/output.c:468-483 (unsigned accumulate, arithmetic >> of the int) */
+void ffo_yuv2planeX8(const int16_t *filter, int fs, const int16_t *const *src, uint8_t *dest, int dstW,
+                     const uint8_t *dither, int offset)
+{
+    for (int i = 0; i < dstW; i++) {
+        uint32_t acc = (uint32_t)dither[(i + offset) & 7] << 12;
+        for (int j = 0; j < fs; j++)
+            acc += (uint32_t)(src[j][i] * filter[j]);
+        dest[i] = clip_u8((int32_t)acc >> 19);
+    }
+}
+
+/* yuv2plane1_8_c: libswscale/output.c:485-493 */
+void ffo_yuv2plane1_8(const int16_t *src, uint8_t *dest, int dstW, const uint8_t *dither, int offset)
+{
+    for (int i = 0; i < dstW; i++)
+        dest[i] = clip_u8((src[i] + dither[(i + offset) & 7]) >> 7);
+}
+
+/* yuv2nv12cX_c: libswscale/output.c:495-529; `swap` = NV21 byte order (isSwappedChroma) */
+void ffo_yuv2nv12cX(int swap, const uint8_t *dither, const int16_t *filter, int fs, const int16_t *const *u,
+                    const int16_t *const *v, uint8_t *dest, int chrDstW)
+{
+    for (int i = 0; i < chrDstW; i++) {
+        uint32_t au = (uint32_t)dither[i & 7] << 12;
+        uint32_t av = (uint32_t)dither[(i + 3) & 7] << 12;
+        for (int j = 0; j < fs; j++) {
+            au += (uint32_t)(u[j][i] * filter[j]);
+            av += (uint32_t)(v[j][i] * filter[j]);
+        }
+        dest[2 * i + (swap ? 1 : 0)] = clip_u8((int32_t)au >> 19);
+        dest[2 * i + (swap ? 0 : 1)] = clip_u8((int32_t)av >> 19);
+    }
+}
+
+/* yuv2rgb_X_c_template + yuv2rgb_write for RGB24/BGR24: libswscale/output.c:1789-1840,1697-1714 */
+static void rgb24_X(const FfoYuv2RgbLuts *l, const int16_t *lf, const int16_t *const *lum, int lfs,
+                    const int16_t *cf, const int16_t *const *cu, const int16_t *const *cv, int cfs, uint8_t *dest,
+                    int dstW, int bgr)
+{
+    for (int i = 0; i < dstW >> 1; i++) {
+        uint32_t y1 = 1 << 18, y2 = 1 << 18, u = 1 << 18, v = 1 << 18;
+        for (int j = 0; j < lfs; j++) {
+            y1 += (uint32_t)(lum[j][2 * i] * (int)lf[j]);
+            y2 += (uint32_t)(lum[j][2 * i + 1] * (int)lf[j]);
+        }
+        for (int j = 0; j < cfs; j++) {
+            u += (uint32_t)(cu[j][i] * (int)cf[j]);
+            v += (uint32_t)(cv[j][i] * (int)cf[j]);
+        }
+        int U = (int32_t)u >> 19, V = (int32_t)v >> 19;
+        put_rgb(dest + 6 * i,     l, (int32_t)y1 >> 19, U, V, bgr);
+        put_rgb(dest + 6 * i + 3, l, (int32_t)y2 >> 19, U, V, bgr);
+    }
+}
+
+/* yuv2rgb_2_c_template: libswscale/output.c:1843-1881 */
+static void rgb24_2(const FfoYuv2RgbLuts *l, const int16_t *const lum[2], const int16_t *const cu[2],
+                    const int16_t *const cv[2], uint8_t *dest, int dstW, int yalpha, int uvalpha, int bgr)
+{
+    int ya1 = 4096 - yalpha, uva1 = 4096 - uvalpha;
+    for (int i = 0; i < dstW >> 1; i++) {
+        int Y1 = (lum[0][2 * i] * ya1 + lum[1][2 * i] * yalpha) >> 19;
+        int Y2 = (lum[0][2 * i + 1] * ya1 + lum[1][2 * i + 1] * yalpha) >> 19;
+        int U = (cu[0][i] * uva1 + cu[1][i] * uvalpha) >> 19;
+        int V = (cv[0][i] * uva1 + cv[1][i] * uvalpha) >> 19;
+        put_rgb(dest + 6 * i,     l, Y1, U, V, bgr);
+        put_rgb(dest + 6 * i + 3, l, Y2, U, V, bgr);
+    }
+}
+
+/* yuv2rgb_1_c_template: libswscale/output.c:1883-1939 */
+static void rgb24_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *const cu[2],
+                    const int16_t *const cv[2], uint8_t *dest, int dstW, int uvalpha, int bgr)
+{
+    int uva1 = 4096 - uvalpha;
+    for (int i = 0; i < dstW >> 1; i++) {
+        int Y1 = (lum[2 * i] + 64) >> 7;
+        int Y2 = (lum[2 * i + 1] + 64) >> 7;
+        int U, V;
+        if (!uvalpha) {
+            U = (cu[0][i] + 64) >> 7;
+            V = (cv[0][i] + 64) >> 7;
+        } else {
+            U = (cu[0][i] * uva1 + cu[1][i] * uvalpha + (128 << 11)) >> 19;
+            V = (cv[0][i] * uva1 + cv[1][i] * uvalpha + (128 << 11)) >> 19;
+        }
+        put_rgb(dest + 6 * i,     l, Y1, U, V, bgr);
+        put_rgb(dest + 6 * i + 3, l, Y2, U, V, bgr);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-frame scaled conversion: the net effect of ff_swscale() (libswscale/swscale.c:263-567) with
+ * its slice ring buffers (slice.c) for 8-bit sources: out = V(H(in)) with table-driven indices.
+ *   H: lum_h_scale/chr_h_scale (hscale.c:39,168) after nv12ToUV_c de-interleave (input.c:936)
+ *   V: lum_planar_vscale / chr_planar_vscale / packed_vscale dispatch (vscale.c:41-171)
+ * dither is sws_pb_64 for <= 8-bit sources (swscale.c:54,385-387).
+ * ------------------------------------------------------------------------------------------- */
+static int is_nv(int fmt) { return fmt == FFO_PIX_FMT_NV12 || fmt == FFO_PIX_FMT_NV21; }
+static int is_rgb(int fmt) { return fmt == FFO_PIX_FMT_RGB24 || fmt == FFO_PIX_FMT_BGR24; }
+
+int ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], const int srcStride[3],
+                        uint8_t *const dst[3], const int dstStride[3])
+{
+    static const uint8_t d64[8] = { 64, 64, 64, 64, 64, 64, 64, 64 };
+    const int srcW = t->srcW, srcH = t->srcH, dstW = t->dstW, dstH = t->dstH;
+    const int chrSrcW = (srcW + 1) >> 1, chrSrcH = (srcH + 1) >> 1;
+    const int chrDstW = t->hChr.n, chrDstH = t->vChr.n;
+    const int lpitch = dstW + 8, cpitch = chrDstW + 8;
+    int16_t *hl = malloc(sizeof(int16_t) * (size_t)lpitch * srcH);
+    int16_t *hu = malloc(sizeof(int16_t) * (size_t)cpitch * chrSrcH);
+    int16_t *hv = malloc(sizeof(int16_t) * (size_t)cpitch * chrSrcH);
+    uint8_t *tu = malloc((size_t)chrSrcW + 8), *tv = malloc((size_t)chrSrcW + 8);
+    const int16_t **rows = malloc(sizeof(*rows) * 3 * (size_t)(t->vLum.size + t->vChr.size + 2));
+    FfoYuv2RgbLuts *luts = NULL;
+    int ret = -1;
+
+    if (!hl || !hu || !hv || !tu || !tv || !rows)
+        goto done;
+
+    for (int y = 0; y < srcH; y++)
+        ffo_hscale8to15(hl + (size_t)y * lpitch, dstW, src[0] + (ptrdiff_t)y * srcStride[0], t->hLum.filter,
+                        t->hLum.pos, t->hLum.size);
+    for (int y = 0; y < chrSrcH; y++) {
+        const uint8_t *pu, *pv;
+        if (is_nv(t->srcFormat)) {
+            const uint8_t *p = src[1] + (ptrdiff_t)y * srcStride[1];
+            int sw = t->srcFormat == FFO_PIX_FMT_NV21;
+            for (int i = 0; i < chrSrcW; i++) {
+                tu[i] = p[2 * i + sw];
+                tv[i] = p[2 * i + !sw];
+            }
+            pu = tu;
+            pv = tv;
+        } else {
+            pu = src[1] + (ptrdiff_t)y * srcStride[1];
+            pv = src[2] + (ptrdiff_t)y * srcStride[2];
+        }
+        ffo_hscale8to15(hu + (size_t)y * cpitch, chrDstW, pu, t->hChr.filter, t->hChr.pos, t->hChr.size);
+        ffo_hscale8to15(hv + (size_t)y * cpitch, chrDstW, pv, t->hChr.filter, t->hChr.pos, t->hChr.size);
+    }
+
+    if (is_rgb(t->dstFormat)) {
+        const int bgr = t->dstFormat == FFO_PIX_FMT_BGR24;
+        const int lfs = t->vLum.size, cfs = t->vChr.size;
+        const int16_t **lr = rows, **ur = rows + lfs + 1, **vr = ur + cfs + 1;
+        luts = malloc(sizeof(*luts));
+        if (!luts)
+            goto done;
+        ffo_yuv2rgb_luts_init(luts, &t->k);
+        for (int y = 0; y < dstH; y++) {
+            /* chrDstVSubSample == 0 for RGB targets, so chroma row index == y */
+            const uint16_t *lf = (const uint16_t *)t->vLum.filter + (size_t)y * lfs;
+            const uint16_t *cf = (const uint16_t *)t->vChr.filter + (size_t)y * cfs;
+            uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
+            for (int j = 0; j < lfs; j++)
+                lr[j] = hl + (size_t)(t->vLum.pos[y] + j) * lpitch;
+            for (int j = 0; j < cfs; j++) {
+                ur[j] = hu + (size_t)(t->vChr.pos[y] + j) * cpitch;
+                vr[j] = hv + (size_t)(t->vChr.pos[y] + j) * cpitch;
+            }
+            if (lfs == 1 && cfs == 1) {
+                rgb24_1(luts, lr[0], ur, vr, d, dstW, 0, bgr);
+            } else if (lfs == 1 && cfs == 2 && cf[1] + cf[0] == 4096 && cf[1] <= 4096U) {
+                rgb24_1(luts, lr[0], ur, vr, d, dstW, cf[1], bgr);
+            } else if (lfs == 2 && cfs == 2 && lf[1] + lf[0] == 4096 && lf[1] <= 4096U && cf[1] + cf[0] == 4096 &&
+                       cf[1] <= 4096U) {
+                rgb24_2(luts, lr, ur, vr, d, dstW, lf[1], cf[1], bgr);
+            } else {
+                rgb24_X(luts, (const int16_t *)lf, lr, lfs, (const int16_t *)cf, ur, vr, cfs, d, dstW, bgr);
+            }
+        }
+    } else {
+        const int lfs = t->vLum.size, cfs = t->vChr.size;
+        const int16_t **lr = rows, **ur = rows + lfs + 1, **vr = ur + cfs + 1;
+        for (int y = 0; y < dstH; y++) {
+            for (int j = 0; j < lfs; j++)
+                lr[j] = hl + (size_t)(t->vLum.pos[y] + j) * lpitch;
+            if (lfs == 1)
+                ffo_yuv2plane1_8(lr[0], dst[0] + (ptrdiff_t)y * dstStride[0], dstW, d64, 0);
+            else
+                ffo_yuv2planeX8(t->vLum.filter + (size_t)y * lfs, lfs, lr, dst[0] + (ptrdiff_t)y * dstStride[0], dstW,
+                                d64, 0);
+        }
+        for (int y = 0; y < chrDstH; y++) {
+            const int16_t *cf = t->vChr.filter + (size_t)y * cfs;
+            for (int j = 0; j < cfs; j++) {
+                ur[j] = hu + (size_t)(t->vChr.pos[y] + j) * cpitch;
+                vr[j] = hv + (size_t)(t->vChr.pos[y] + j) * cpitch;
+            }
+            if (is_nv(t->dstFormat)) {
+                ffo_yuv2nv12cX(t->dstFormat == FFO_PIX_FMT_NV21, d64, cf, cfs, ur, vr,
+                               dst[1] + (ptrdiff_t)y * dstStride[1], chrDstW);
+            } else if (cfs == 1) {
+                ffo_yuv2plane1_8(ur[0], dst[1] + (ptrdiff_t)y * dstStride[1], chrDstW, d64, 0);
+                ffo_yuv2plane1_8(vr[0], dst[2] + (ptrdiff_t)y * dstStride[2], chrDstW, d64, 3);
+            } else {
+                ffo_yuv2planeX8(cf, cfs, ur, dst[1] + (ptrdiff_t)y * dstStride[1], chrDstW, d64, 0);
+                ffo_yuv2planeX8(cf, cfs, vr, dst[2] + (ptrdiff_t)y * dstStride[2], chrDstW, d64, 3);
+            }
+        }
+    }
+    ret = dstH;
+done:
+    free(hl); free(hu); free(hv); free(tu); free(tv); free(rows); free(luts);
+    return ret;
+}

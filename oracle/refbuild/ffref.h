@@ -1,0 +1,61 @@
+/*
+ * ffref.h — flat C accessors onto the REAL reference (FFmpeg) compiled by oracle/refbuild/Makefile.
+ *
+ * TEST INFRASTRUCTURE ONLY: loaded by tests/, tools/make_golden.py and bench.py's cpu_baseline leg.
+ * Never linked or loaded by the product (libffhip.so / ffmpeg_amd).
+ *
+ * The shim exists because the reference's DSP tables are structs of function pointers with
+ * internal layouts; ctypes callers need flat symbols.  Every function forwards to the pointer the
+ * reference's own ff_*_init()/sws_getContext()/av_tx_init() installed with av_force_cpu_flags(0).
+ */
+#ifndef FFREF_H
+#define FFREF_H
+#include <stddef.h>
+#include <stdint.h>
+
+/* ---- libswscale ---- */
+void *ffref_sws_create(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt, int flags, int threads);
+void  ffref_sws_free(void *ctx);
+int   ffref_sws_scale(void *ctx, const uint8_t *const src[], const int srcStride[], int y, int h,
+                      uint8_t *const dst[], const int dstStride[]);
+/* which: 0 hLum 1 hChr 2 vLum 3 vChr.  Returns filter size; *n = number of output samples */
+int   ffref_sws_filter(void *ctx, int which, const int16_t **filter, const int32_t **pos, int *n);
+/* 1 when the context installed a convert_unscaled special converter */
+int   ffref_sws_is_unscaled(void *ctx);
+/* the four (already divided) yuv2rgb table coefficients + y terms the context derived */
+void  ffref_sws_yuv2rgb_tables(void *ctx, const uint8_t **rV, const int **gU, const int **gV, const uint8_t **bU);
+int   ffref_pix_fmt(const char *name);
+/* per-line function pointers of a context */
+void  ffref_sws_hyscale(void *ctx, int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter,
+                        const int32_t *pos, int fs);
+void  ffref_sws_yuv2planeX(void *ctx, const int16_t *filter, int fs, const int16_t **src, uint8_t *dest,
+                           int dstW, const uint8_t *dither, int offset);
+void  ffref_sws_yuv2plane1(void *ctx, const int16_t *src, uint8_t *dest, int dstW, const uint8_t *dither, int offset);
+void  ffref_sws_yuv2nv12cX(void *ctx, int dstFormat, const uint8_t *chrDither, const int16_t *chrFilter, int fs,
+                           const int16_t **chrU, const int16_t **chrV, uint8_t *dest, int dstW);
+
+/* ---- libavcodec h264dsp / h264qpel / me_cmp (8-bit) ---- */
+/* which: 0 idct_add 1 idct8_add 2 idct_dc_add 3 idct8_dc_add */
+void ffref_h264_idct(int which, uint8_t *dst, int16_t *block, ptrdiff_t stride);
+/* which: 0 idct_add16 1 idct8_add4 2 idct_add16intra */
+void ffref_h264_idct_multi(int which, uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
+                           const uint8_t *nnzc);
+void ffref_h264_idct_add8(uint8_t **dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
+                          const uint8_t *nnzc, int chroma_format_idc);
+/* which: 0 v_luma 1 h_luma 2 v_chroma 3 h_chroma (tc0 used); 4 v_luma_intra 5 h_luma_intra 6 v_chroma_intra 7 h_chroma_intra */
+void ffref_h264_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
+/* avg: 0 put 1 avg; size_idx: 0 16x16 1 8x8 2 4x4; mcxy = x + 4*y */
+void ffref_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
+/* kind: 0 sad 1 hadamard8_diff 2 sse ; idx: 0 = 16 wide, 1 = 8 wide */
+int  ffref_me_cmp(int kind, int idx, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h);
+/* libavfilter ESA search (vf_mestimate semantics); returns cost, mv[2] = absolute best position */
+uint64_t ffref_me_search_esa(const uint8_t *cur, const uint8_t *ref, int linesize, int width, int height,
+                             int mb_size, int search_param, int x_mb, int y_mb, int *mv);
+
+/* ---- libavutil av_tx ---- */
+/* type: AVTXType value (0 FLOAT_FFT, 1 FLOAT_MDCT); returns ctx or NULL */
+void *ffref_tx_create(int type, int inv, int len, float scale, uint64_t flags);
+void  ffref_tx_run(void *ctx, void *out, void *in, ptrdiff_t stride);
+void  ffref_tx_free(void *ctx);
+
+#endif

@@ -1,0 +1,217 @@
+/*
+ * ffref_shim.c — flat accessors onto the real reference; see ffref.h.  TEST INFRASTRUCTURE ONLY.
+ * Includes the reference's headers where they lie (-I/root/reference); contains no reference code.
+ */
+#include "config.h"
+#include <string.h>
+#include "libavutil/cpu.h"
+#include "libavutil/log.h"
+#include "libavutil/mem.h"
+#include "libavutil/opt.h"
+#include "libavutil/pixdesc.h"
+#include "libavutil/tx.h"
+#include "libswscale/swscale.h"
+#include "libswscale/swscale_internal.h"
+#include "libavcodec/h264dsp.h"
+#include "libavcodec/h264qpel.h"
+#include "libavcodec/me_cmp.h"
+#include "libavfilter/motion_estimation.h"
+#include "ffref.h"
+
+static void pure_c(void) { av_force_cpu_flags(0); av_log_set_level(AV_LOG_ERROR); }
+
+/* ---- swscale ---- */
+void *ffref_sws_create(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt, int flags, int threads)
+{
+    pure_c();
+    SwsContext *sws = sws_alloc_context();
+    if (!sws)
+        return NULL;
+    av_opt_set_int(sws, "srcw", srcW, 0);
+    av_opt_set_int(sws, "srch", srcH, 0);
+    av_opt_set_int(sws, "src_format", srcFmt, 0);
+    av_opt_set_int(sws, "dstw", dstW, 0);
+    av_opt_set_int(sws, "dsth", dstH, 0);
+    av_opt_set_int(sws, "dst_format", dstFmt, 0);
+    av_opt_set_int(sws, "sws_flags", flags, 0);
+    av_opt_set_int(sws, "threads", threads, 0);
+    if (sws_init_context(sws, NULL, NULL) < 0) {
+        sws_freeContext(sws);
+        return NULL;
+    }
+    return sws;
+}
+void ffref_sws_free(void *ctx) { sws_freeContext(ctx); }
+int ffref_sws_scale(void *ctx, const uint8_t *const src[], const int srcStride[], int y, int h,
+                    uint8_t *const dst[], const int dstStride[])
+{
+    return sws_scale(ctx, src, srcStride, y, h, dst, dstStride);
+}
+static SwsInternal *inner(void *ctx)
+{
+    SwsInternal *c = sws_internal(ctx);
+    if (c->nb_slice_ctx)            /* threaded parent: tables live in the slice contexts */
+        c = sws_internal(c->slice_ctx[0]);
+    return c;
+}
+int ffref_sws_filter(void *ctx, int which, const int16_t **filter, const int32_t **pos, int *n)
+{
+    SwsInternal *c = inner(ctx);
+    switch (which) {
+    case 0: *filter = c->hLumFilter; *pos = c->hLumFilterPos; *n = c->opts.dst_w;  return c->hLumFilterSize;
+    case 1: *filter = c->hChrFilter; *pos = c->hChrFilterPos; *n = c->chrDstW;     return c->hChrFilterSize;
+    case 2: *filter = c->vLumFilter; *pos = c->vLumFilterPos; *n = c->opts.dst_h;  return c->vLumFilterSize;
+    case 3: *filter = c->vChrFilter; *pos = c->vChrFilterPos; *n = c->chrDstH;     return c->vChrFilterSize;
+    }
+    return -1;
+}
+int ffref_sws_is_unscaled(void *ctx) { return inner(ctx)->convert_unscaled != NULL; }
+void ffref_sws_yuv2rgb_tables(void *ctx, const uint8_t **rV, const int **gU, const int **gV, const uint8_t **bU)
+{
+    SwsInternal *c = inner(ctx);
+    for (int i = 0; i < 256 + 2 * YUVRGB_TABLE_HEADROOM; i++) {
+        rV[i] = c->table_rV[i];
+        bU[i] = c->table_bU[i];
+    }
+    *gU = (const int *)c->table_gU;   /* caller treats as opaque; only used for pointer diffs */
+    *gV = c->table_gV;
+}
+int ffref_pix_fmt(const char *name) { return av_get_pix_fmt(name); }
+void ffref_sws_hyscale(void *ctx, int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter,
+                       const int32_t *pos, int fs)
+{
+    SwsInternal *c = inner(ctx);
+    c->hyScale(c, dst, dstW, src, filter, pos, fs);
+}
+void ffref_sws_yuv2planeX(void *ctx, const int16_t *filter, int fs, const int16_t **src, uint8_t *dest,
+                          int dstW, const uint8_t *dither, int offset)
+{
+    inner(ctx)->yuv2planeX(filter, fs, src, dest, dstW, dither, offset);
+}
+void ffref_sws_yuv2plane1(void *ctx, const int16_t *src, uint8_t *dest, int dstW, const uint8_t *dither, int offset)
+{
+    inner(ctx)->yuv2plane1(src, dest, dstW, dither, offset);
+}
+void ffref_sws_yuv2nv12cX(void *ctx, int dstFormat, const uint8_t *chrDither, const int16_t *chrFilter, int fs,
+                          const int16_t **chrU, const int16_t **chrV, uint8_t *dest, int dstW)
+{
+    inner(ctx)->yuv2nv12cX(dstFormat, chrDither, chrFilter, fs, chrU, chrV, dest, dstW);
+}
+
+/* ---- h264dsp / qpel / me_cmp ---- */
+static H264DSPContext   h264;
+static H264DSPContext   h264_422;
+static H264QpelContext  qpel;
+static MECmpContext     mecmp;
+static int dsp_ready;
+static void dsp_init(void)
+{
+    if (dsp_ready)
+        return;
+    pure_c();
+    ff_h264dsp_init(&h264, 8, 1);
+    ff_h264dsp_init(&h264_422, 8, 2);
+    ff_h264qpel_init(&qpel, 8);
+    ff_me_cmp_init(&mecmp, NULL);
+    dsp_ready = 1;
+}
+void ffref_h264_idct(int which, uint8_t *dst, int16_t *block, ptrdiff_t stride)
+{
+    dsp_init();
+    switch (which) {
+    case 0: h264.idct_add(dst, block, stride); break;
+    case 1: h264.idct8_add(dst, block, stride); break;
+    case 2: h264.idct_dc_add(dst, block, stride); break;
+    case 3: h264.idct8_dc_add(dst, block, stride); break;
+    }
+}
+void ffref_h264_idct_multi(int which, uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
+                           const uint8_t *nnzc)
+{
+    dsp_init();
+    switch (which) {
+    case 0: h264.idct_add16(dst, blockoffset, block, stride, nnzc); break;
+    case 1: h264.idct8_add4(dst, blockoffset, block, stride, nnzc); break;
+    case 2: h264.idct_add16intra(dst, blockoffset, block, stride, nnzc); break;
+    }
+}
+void ffref_h264_idct_add8(uint8_t **dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
+                          const uint8_t *nnzc, int chroma_format_idc)
+{
+    dsp_init();
+    (chroma_format_idc == 2 ? &h264_422 : &h264)->idct_add8(dst, blockoffset, block, stride, nnzc);
+}
+void ffref_h264_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0)
+{
+    dsp_init();
+    switch (which) {
+    case 0: h264.v_loop_filter_luma(pix, stride, alpha, beta, tc0); break;
+    case 1: h264.h_loop_filter_luma(pix, stride, alpha, beta, tc0); break;
+    case 2: h264.v_loop_filter_chroma(pix, stride, alpha, beta, tc0); break;
+    case 3: h264.h_loop_filter_chroma(pix, stride, alpha, beta, tc0); break;
+    case 4: h264.v_loop_filter_luma_intra(pix, stride, alpha, beta); break;
+    case 5: h264.h_loop_filter_luma_intra(pix, stride, alpha, beta); break;
+    case 6: h264.v_loop_filter_chroma_intra(pix, stride, alpha, beta); break;
+    case 7: h264.h_loop_filter_chroma_intra(pix, stride, alpha, beta); break;
+    }
+}
+void ffref_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride)
+{
+    dsp_init();
+    (avg ? qpel.avg_h264_qpel_pixels_tab : qpel.put_h264_qpel_pixels_tab)[size_idx][mcxy](dst, src, stride);
+}
+int ffref_me_cmp(int kind, int idx, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
+{
+    dsp_init();
+    switch (kind) {
+    case 0: return mecmp.sad[idx](NULL, blk1, blk2, stride, h);
+    case 1: return mecmp.hadamard8_diff[idx](NULL, blk1, blk2, stride, h);
+    case 2: return mecmp.sse[idx](NULL, blk1, blk2, stride, h);
+    }
+    return -1;
+}
+uint64_t ffref_me_search_esa(const uint8_t *cur, const uint8_t *ref, int linesize, int width, int height,
+                             int mb_size, int search_param, int x_mb, int y_mb, int *mv)
+{
+    /* context set-up as vf_mestimate.c config_input does it */
+    AVMotionEstContext me;
+    int log2 = 0;
+    while ((1 << log2) < mb_size) log2++;
+    int b_w = width >> log2, b_h = height >> log2;
+    memset(&me, 0, sizeof(me));
+    ff_me_init_context(&me, mb_size, search_param, width, height, 0, (b_w - 1) << log2, 0, (b_h - 1) << log2);
+    me.data_cur = (uint8_t *)cur;
+    me.data_ref = (uint8_t *)ref;
+    me.linesize = linesize;
+    mv[0] = x_mb;
+    mv[1] = y_mb;
+    return ff_me_search_esa(&me, x_mb, y_mb, mv);
+}
+
+/* ---- av_tx ---- */
+typedef struct { AVTXContext *s; av_tx_fn fn; } RefTx;
+void *ffref_tx_create(int type, int inv, int len, float scale, uint64_t flags)
+{
+    pure_c();
+    RefTx *t = av_mallocz(sizeof(*t));
+    if (!t)
+        return NULL;
+    if (av_tx_init(&t->s, &t->fn, type, inv, len, &scale, flags) < 0) {
+        av_free(t);
+        return NULL;
+    }
+    return t;
+}
+void ffref_tx_run(void *ctx, void *out, void *in, ptrdiff_t stride)
+{
+    RefTx *t = ctx;
+    t->fn(t->s, out, in, stride);
+}
+void ffref_tx_free(void *ctx)
+{
+    RefTx *t = ctx;
+    if (t) {
+        av_tx_uninit(&t->s);
+        av_free(t);
+    }
+}

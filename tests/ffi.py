@@ -1,0 +1,213 @@
+"""ctypes bindings used by the test-suite (and tools/, bench.py's cpu_baseline leg).
+
+  oracle()  -> oracle/liboracle.so      our CPU restatement            (test infrastructure)
+  ref()     -> oracle/_ref/libffref.so  the real reference, if built   (test infrastructure)
+  The product library is bound in ffmpeg_amd/_lib.py, never here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libffref.so")
+
+PIX = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24}
+SWS_BICUBIC, SWS_BILINEAR, SWS_POINT, SWS_AREA = 4, 2, 0x10, 0x20
+SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
+
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+i16p = C.POINTER(C.c_int16)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+
+
+def ptr(a, t=u8p):
+    return a.ctypes.data_as(t)
+
+
+class OSwsFilter(C.Structure):
+    _fields_ = [("filter", i16p), ("pos", i32p), ("size", C.c_int), ("n", C.c_int)]
+
+
+class OYuv2RgbCoeffs(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("cy", "oy", "crv", "cbu", "cgu", "cgv")] + [("yoffs", C.c_int)]
+
+
+class OSwsTables(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("srcW", "srcH", "srcFormat", "dstW", "dstH", "dstFormat", "flags")] + \
+               [(k, OSwsFilter) for k in ("hLum", "hChr", "vLum", "vChr")] + [("k", OYuv2RgbCoeffs)]
+
+
+class OLuts(C.Structure):
+    _fields_ = [("ramp", C.c_uint8 * 2048), ("rV", C.c_int * 1280), ("gU", C.c_int * 1280),
+                ("gV", C.c_int * 1280), ("bU", C.c_int * 1280)]
+
+
+class OEdge(C.Structure):
+    _fields_ = [("offset", C.c_int32), ("kind", C.c_uint8), ("alpha", C.c_uint8), ("beta", C.c_uint8),
+                ("pad", C.c_uint8), ("tc0", C.c_int8 * 4)]
+
+
+EDGE_DTYPE = np.dtype([("offset", "<i4"), ("kind", "u1"), ("alpha", "u1"), ("beta", "u1"), ("pad", "u1"),
+                       ("tc0", "i1", (4,))])
+QPEL_DTYPE = np.dtype([("dst_offset", "<i4"), ("src_offset", "<i4"), ("mcxy", "u1"), ("size_idx", "u1"),
+                       ("avg", "u1"), ("pad", "u1")])
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            raise RuntimeError("oracle/liboracle.so missing - run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(ORACLE_SO)
+        L.ffo_yuv2rgb_luts_init.argtypes = [C.POINTER(OLuts), C.POINTER(OYuv2RgbCoeffs)]
+        L.ffo_yuv420p_to_rgb24.argtypes = [C.POINTER(OLuts), C.c_int, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int,
+                                           C.c_int, u8p, C.c_int, C.c_int]
+        L.ffo_hscale8to15.argtypes = [i16p, C.c_int, u8p, i16p, i32p, C.c_int]
+        L.ffo_yuv2planeX8.argtypes = [i16p, C.c_int, C.POINTER(i16p), u8p, C.c_int, u8p, C.c_int]
+        L.ffo_yuv2plane1_8.argtypes = [i16p, u8p, C.c_int, u8p, C.c_int]
+        L.ffo_yuv2nv12cX.argtypes = [C.c_int, u8p, i16p, C.c_int, C.POINTER(i16p), C.POINTER(i16p), u8p, C.c_int]
+        L.ffo_sws_scale_frame.argtypes = [C.POINTER(OSwsTables), C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(u8p),
+                                          C.POINTER(C.c_int)]
+        for n in ("ffo_h264_idct_add", "ffo_h264_idct8_add", "ffo_h264_idct_dc_add", "ffo_h264_idct8_dc_add"):
+            getattr(L, n).argtypes = [u8p, i16p, C.c_ssize_t]
+            getattr(L, n).restype = None
+        for n in ("ffo_h264_idct_add16", "ffo_h264_idct8_add4", "ffo_h264_idct_add16intra"):
+            getattr(L, n).argtypes = [u8p, i32p, i16p, C.c_ssize_t, u8p]
+            getattr(L, n).restype = None
+        L.ffo_h264_loop_filter.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, i8p]
+        L.ffo_h264_loop_filter.restype = None
+        L.ffo_h264_qpel.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t]
+        L.ffo_h264_qpel.restype = None
+        L.ffo_h264_deblock_frame.argtypes = [u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
+        L.ffo_h264_deblock_frame.restype = None
+        L.ffo_sad.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]
+        L.ffo_hadamard8_diff8x8.argtypes = [u8p, u8p, C.c_ssize_t]
+        L.ffo_hadamard8_diff16.argtypes = [u8p, u8p, C.c_ssize_t, C.c_int]
+        L.ffo_me_search_esa.argtypes = [u8p, u8p] + [C.c_int] * 8 + [i32p]
+        L.ffo_me_search_esa.restype = C.c_uint64
+        L.ffo_me_esa_frame.argtypes = [u8p, u8p] + [C.c_int] * 6 + [i16p, C.POINTER(C.c_uint32)]
+        L.ffo_me_esa_frame.restype = None
+        L.ffo_mdct_create.argtypes = [C.c_int, C.c_int, C.c_float]
+        L.ffo_mdct_create.restype = C.c_void_p
+        L.ffo_mdct_run.argtypes = [C.c_void_p, f32p, f32p, C.c_ssize_t]
+        L.ffo_mdct_run.restype = None
+        L.ffo_mdct_free.argtypes = [C.c_void_p]
+        L.ffo_mdct_free.restype = None
+        L.ffo_mdct_naive_fwd.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_double), f32p]
+        L.ffo_mdct_naive_inv.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_double), f32p]
+        L.ffo_mdct_naive_fwd.restype = L.ffo_mdct_naive_inv.restype = None
+        _oracle = L
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_SO)
+        L.ffref_sws_create.argtypes = [C.c_int] * 8
+        L.ffref_sws_create.restype = C.c_void_p
+        L.ffref_sws_free.argtypes = [C.c_void_p]
+        L.ffref_sws_free.restype = None
+        L.ffref_sws_scale.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                      C.POINTER(u8p), C.POINTER(C.c_int)]
+        L.ffref_sws_filter.argtypes = [C.c_void_p, C.c_int, C.POINTER(i16p), C.POINTER(i32p), C.POINTER(C.c_int)]
+        L.ffref_sws_is_unscaled.argtypes = [C.c_void_p]
+        L.ffref_sws_hyscale.argtypes = [C.c_void_p, i16p, C.c_int, u8p, i16p, i32p, C.c_int]
+        L.ffref_sws_hyscale.restype = None
+        L.ffref_sws_yuv2planeX.argtypes = [C.c_void_p, i16p, C.c_int, C.POINTER(i16p), u8p, C.c_int, u8p, C.c_int]
+        L.ffref_sws_yuv2planeX.restype = None
+        L.ffref_sws_yuv2plane1.argtypes = [C.c_void_p, i16p, u8p, C.c_int, u8p, C.c_int]
+        L.ffref_sws_yuv2plane1.restype = None
+        L.ffref_sws_yuv2nv12cX.argtypes = [C.c_void_p, C.c_int, u8p, i16p, C.c_int, C.POINTER(i16p), C.POINTER(i16p),
+                                           u8p, C.c_int]
+        L.ffref_sws_yuv2nv12cX.restype = None
+        L.ffref_h264_idct.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+        L.ffref_h264_idct.restype = None
+        L.ffref_h264_idct_multi.argtypes = [C.c_int, u8p, i32p, i16p, C.c_ssize_t, u8p]
+        L.ffref_h264_idct_multi.restype = None
+        L.ffref_h264_loop_filter.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, i8p]
+        L.ffref_h264_loop_filter.restype = None
+        L.ffref_h264_qpel.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t]
+        L.ffref_h264_qpel.restype = None
+        L.ffref_me_cmp.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]
+        L.ffref_me_search_esa.argtypes = [u8p, u8p] + [C.c_int] * 7 + [i32p]
+        L.ffref_me_search_esa.restype = C.c_uint64
+        L.ffref_tx_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64]
+        L.ffref_tx_create.restype = C.c_void_p
+        L.ffref_tx_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t]
+        L.ffref_tx_run.restype = None
+        L.ffref_tx_free.argtypes = [C.c_void_p]
+        L.ffref_tx_free.restype = None
+        _ref = L
+    return _ref
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers shared by tests
+# ---------------------------------------------------------------------------------------------
+def planes(arrs):
+    """list of 2-D uint8 arrays -> (uint8*[4], int[4])"""
+    p = (u8p * 4)()
+    s = (C.c_int * 4)()
+    for i, a in enumerate(arrs):
+        p[i] = ptr(a)
+        s[i] = a.strides[0]
+    return p, s
+
+
+def ref_tables(ctx):
+    """Pull the four filter banks out of a reference SwsContext as numpy copies."""
+    L = ref()
+    out = {}
+    for w, name in enumerate(("hLum", "hChr", "vLum", "vChr")):
+        f, p, n = i16p(), i32p(), C.c_int()
+        fs = L.ffref_sws_filter(ctx, w, C.byref(f), C.byref(p), C.byref(n))
+        out[name] = (np.ctypeslib.as_array(f, (n.value * fs,)).copy(), np.ctypeslib.as_array(p, (n.value,)).copy(), fs,
+                     n.value)
+    return out
+
+
+# BT.601 limited-range defaults the reference derives (yuv2rgb.c:760-800)
+DEFAULT_COEFFS = dict(cy=76309, oy=16 << 16, crv=89830, cbu=113537, cgu=-22049, cgv=-45756, yoffs=838)
+
+
+def make_otables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, banks, coeffs=DEFAULT_COEFFS):
+    """banks: dict name -> (filter int16[], pos int32[], size, n).  Keeps numpy refs alive on the struct."""
+    t = OSwsTables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags)
+    keep = []
+    for name in ("hLum", "hChr", "vLum", "vChr"):
+        f, p, fs, n = banks[name]
+        f = np.ascontiguousarray(f, np.int16)
+        p = np.ascontiguousarray(p, np.int32)
+        keep += [f, p]
+        setattr(t, name, OSwsFilter(ptr(f, i16p), ptr(p, i32p), fs, n))
+    t.k = OYuv2RgbCoeffs(coeffs["cy"], coeffs["oy"], coeffs["crv"], coeffs["cbu"], coeffs["cgu"], coeffs["cgv"],
+                         coeffs["yoffs"])
+    t._keep = keep
+    return t
+
+
+def alloc_frame(fmt, w, h, rng=None, pad=0):
+    """Allocate the planes of one frame (strides = width + pad). Random content when rng is given."""
+    def mk(r, c):
+        a = np.zeros((r, c + pad), np.uint8)
+        if rng is not None:
+            a[:] = rng.integers(0, 256, a.shape, dtype=np.uint8)
+        return a
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    if fmt == PIX["yuv420p"]:
+        return [mk(h, w), mk(ch, cw), mk(ch, cw)]
+    if fmt in (PIX["nv12"], PIX["nv21"]):
+        return [mk(h, w), mk(ch, 2 * cw)]
+    return [mk(h, 3 * w)]

@@ -1,0 +1,301 @@
+"""Pin oracle/ (our CPU restatement) bit-exact against the REAL reference compiled from
+/root/reference (oracle/_ref/libffref.so).  Skipped where that library is absent; the committed
+fixtures in tests/golden/ (generated from it by tools/make_golden.py) cover that case."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import PIX, ptr, u8p, i8p, i16p, i32p, f32p
+
+pytestmark = pytest.mark.skipif(not ffi.have_ref(), reason="oracle/_ref/libffref.so not built")
+
+
+def _ref_convert(srcfmt, sw, sh, dstfmt, dw, dh, flags, src):
+    R = ffi.ref()
+    ctx = R.ffref_sws_create(sw, sh, srcfmt, dw, dh, dstfmt, flags, 1)
+    assert ctx
+    dst = ffi.alloc_frame(dstfmt, dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(dst)
+    assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, dp, ds) == dh
+    banks = None if R.ffref_sws_is_unscaled(ctx) else ffi.ref_tables(ctx)
+    R.ffref_sws_free(ctx)
+    return dst, banks
+
+
+@pytest.mark.parametrize("w,h", [(64, 16), (1920, 1080), (1078, 6), (1076, 4), (30, 2)])
+@pytest.mark.parametrize("dst", ["rgb24", "bgr24"])
+def test_yuv420p_rgb24_table_path(w, h, dst):
+    rng = np.random.default_rng(w * 31 + h)
+    src = ffi.alloc_frame(PIX["yuv420p"], w, h, rng, pad=5)
+    want, banks = _ref_convert(PIX["yuv420p"], w, h, PIX[dst], w, h, ffi.SWS_BICUBIC, src)
+    assert banks is None, "reference should pick the unscaled table converter"
+    O = ffi.oracle()
+    luts = ffi.OLuts()
+    k = ffi.OYuv2RgbCoeffs(*[ffi.DEFAULT_COEFFS[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+    O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
+    got = np.zeros_like(want[0])
+    sp, ss = ffi.planes(src)
+    O.ffo_yuv420p_to_rgb24(C.byref(luts), w, sp, ss, 0, h, ptr(got), got.strides[0], dst == "bgr24")
+    assert np.array_equal(got, want[0])
+
+
+def test_yuv420p_rgb24_exhaustive_yuv():
+    """every (Y,U,V) triple once: 4096x4096 frame would be 16M px; use all U,V with a Y sweep"""
+    w, h = 512, 256
+    y = np.tile(np.arange(256, dtype=np.uint8).repeat(2), (h, 1))[:, :w].copy()
+    y = ((np.arange(w)[None, :] + np.arange(h)[:, None] * 7) & 255).astype(np.uint8)
+    u = np.tile(np.arange(256, dtype=np.uint8), (h // 2, 1)).copy()
+    v = np.tile(np.arange(128, dtype=np.uint8)[:, None] * 2, (1, w // 2)).astype(np.uint8).copy()
+    src = [y, u, v]
+    want, _ = _ref_convert(0, w, h, 2, w, h, 4, src)
+    O = ffi.oracle()
+    luts = ffi.OLuts()
+    k = ffi.OYuv2RgbCoeffs(*[ffi.DEFAULT_COEFFS[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+    O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
+    got = np.zeros_like(want[0])
+    sp, ss = ffi.planes(src)
+    O.ffo_yuv420p_to_rgb24(C.byref(luts), w, sp, ss, 0, h, ptr(got), got.strides[0], 0)
+    assert np.array_equal(got, want[0])
+
+
+SCALE_CASES = [
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_BICUBIC),
+    ("nv12", 160, 90, "nv12", 100, 62, ffi.SWS_BICUBIC),
+    ("nv21", 96, 64, "nv21", 200, 130, ffi.SWS_BILINEAR),
+    ("yuv420p", 128, 72, "yuv420p", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 101, 77, "yuv420p", 333, 191, ffi.SWS_BICUBIC),
+    ("nv12", 128, 72, "yuv420p", 64, 36, ffi.SWS_AREA),
+    ("yuv420p", 128, 72, "nv12", 128, 90, ffi.SWS_POINT | ffi.SWS_ACCURATE_RND),
+    ("yuv420p", 176, 144, "rgb24", 352, 288, ffi.SWS_BICUBIC),
+    ("yuv420p", 176, 144, "bgr24", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND | ffi.SWS_BITEXACT),
+    ("yuv420p", 176, 144, "rgb24", 176, 288, ffi.SWS_BILINEAR),
+    ("nv12", 176, 144, "rgb24", 352, 288, ffi.SWS_BILINEAR),
+    ("yuv420p", 352, 288, "rgb24", 120, 90, ffi.SWS_BICUBIC),
+    ("nv12", 192, 108, "nv12", 384, 216, 0x200),
+]
+
+
+@pytest.mark.parametrize("case", SCALE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_scaled_frame(case):
+    sf, sw, sh, df, dw, dh, flags = case
+    rng = np.random.default_rng(hash(case) & 0xFFFF)
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=3)
+    want, banks = _ref_convert(PIX[sf], sw, sh, PIX[df], dw, dh, flags, src)
+    assert banks is not None
+    t = ffi.make_otables(sw, sh, PIX[sf], dw, dh, PIX[df], flags, banks)
+    got = ffi.alloc_frame(PIX[df], dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(got)
+    assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("fs", [1, 4, 8, 12, 16, 32, 40])
+def test_hscale_adversarial(fs):
+    """checkasm's coefficient torture (tests/checkasm/sw_scale.c:356-458)"""
+    R, O = ffi.ref(), ffi.oracle()
+    ctx = R.ffref_sws_create(64, 16, 0, 128, 32, 0, 4, 1)
+    dstW, srcW = 512, 560
+    rng = np.random.default_rng(fs)
+    src = rng.integers(0, 256, srcW, dtype=np.uint8)
+    filt = rng.integers(-(1 << 14), 1 << 14, (dstW, fs)).astype(np.int16)
+    filt[::3] = -((1 << 14) // max(fs - 1, 1))
+    filt[::3, 0] = (1 << 15) - 1
+    pos = np.sort(rng.integers(0, srcW - fs, dstW)).astype(np.int32)
+    a = np.zeros(dstW, np.int16)
+    b = np.zeros(dstW, np.int16)
+    R.ffref_sws_hyscale(ctx, ptr(a, i16p), dstW, ptr(src), ptr(filt, i16p), ptr(pos, i32p), fs)
+    O.ffo_hscale8to15(ptr(b, i16p), dstW, ptr(src), ptr(filt, i16p), ptr(pos, i32p), fs)
+    R.ffref_sws_free(ctx)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("fs", [1, 2, 4, 8, 16])
+def test_vscale_lines(fs):
+    R, O = ffi.ref(), ffi.oracle()
+    ctx = R.ffref_sws_create(64, 16, 0, 128, 32, PIX["nv12"], 4, 1)
+    dstW = 333
+    rng = np.random.default_rng(fs + 100)
+    lines = rng.integers(-32768, 32768, (fs, dstW + 8)).astype(np.int16)
+    lines2 = rng.integers(-32768, 32768, (fs, dstW + 8)).astype(np.int16)
+    filt = rng.integers(-4096, 8192, fs).astype(np.int16)
+    dither = rng.integers(0, 128, 8, dtype=np.uint8)
+    rows = (i16p * fs)(*[ptr(lines[j], i16p) for j in range(fs)])
+    rows2 = (i16p * fs)(*[ptr(lines2[j], i16p) for j in range(fs)])
+    for off in (0, 3):
+        a = np.zeros(dstW, np.uint8); b = np.zeros(dstW, np.uint8)
+        if fs == 1:
+            R.ffref_sws_yuv2plane1(ctx, rows[0], ptr(a), dstW, ptr(dither), off)
+            O.ffo_yuv2plane1_8(rows[0], ptr(b), dstW, ptr(dither), off)
+        else:
+            R.ffref_sws_yuv2planeX(ctx, ptr(filt, i16p), fs, rows, ptr(a), dstW, ptr(dither), off)
+            O.ffo_yuv2planeX8(ptr(filt, i16p), fs, rows, ptr(b), dstW, ptr(dither), off)
+        assert np.array_equal(a, b)
+    for fmt, swap in ((PIX["nv12"], 0), (PIX["nv21"], 1)):
+        a = np.zeros(2 * dstW, np.uint8); b = np.zeros(2 * dstW, np.uint8)
+        R.ffref_sws_yuv2nv12cX(ctx, fmt, ptr(dither), ptr(filt, i16p), fs, rows, rows2, ptr(a), dstW)
+        O.ffo_yuv2nv12cX(swap, ptr(dither), ptr(filt, i16p), fs, rows, rows2, ptr(b), dstW)
+        assert np.array_equal(a, b)
+    R.ffref_sws_free(ctx)
+
+
+# ---------------------------------------------------------------------------------------------
+def _coef_blocks(rng, n, size):
+    """int16 coefficient blocks spanning the decoder's legal range plus adversarial extremes"""
+    c = rng.integers(-2048, 2048, (n, size * size)).astype(np.int16)
+    c[::7] = rng.integers(-32768, 32768, c[::7].shape).astype(np.int16)
+    c[1::5, 1:] = 0
+    return c
+
+
+@pytest.mark.parametrize("which,size", [(0, 4), (1, 8), (2, 4), (3, 8)])
+def test_h264_idct(which, size):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(which)
+    ofn = [O.ffo_h264_idct_add, O.ffo_h264_idct8_add, O.ffo_h264_idct_dc_add, O.ffo_h264_idct8_dc_add][which]
+    coefs = _coef_blocks(rng, 400, size)
+    for c in coefs:
+        dst = rng.integers(0, 256, (size, 32), dtype=np.uint8)
+        d1, d2, c1, c2 = dst.copy(), dst.copy(), c.copy(), c.copy()
+        R.ffref_h264_idct(which, ptr(d1), ptr(c1, i16p), 32)
+        ofn(ptr(d2), ptr(c2, i16p), 32)
+        assert np.array_equal(d1, d2) and np.array_equal(c1, c2)
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_h264_idct_multi(which):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(10 + which)
+    ofn = [O.ffo_h264_idct_add16, O.ffo_h264_idct8_add4, O.ffo_h264_idct_add16intra][which]
+    bo = np.array([(i & 3) * 4 + (i >> 2) * 4 * 48 for i in range(16)], np.int32)
+    if which == 1:
+        bo = np.array([((i >> 2) & 1) * 8 + (i >> 3) * 8 * 48 for i in range(16)], np.int32)
+    for _ in range(100):
+        blocks = rng.integers(-512, 512, 256).astype(np.int16)
+        nnzc = rng.integers(0, 3, 40, dtype=np.uint8)
+        for i in range(16):
+            if rng.random() < .3:
+                blocks[i * 16 + 1:(i + 1) * 16] = 0
+            if rng.random() < .2:
+                blocks[i * 16] = 0
+        dst = rng.integers(0, 256, (16, 48), dtype=np.uint8)
+        d1, d2, b1, b2 = dst.copy(), dst.copy(), blocks.copy(), blocks.copy()
+        R.ffref_h264_idct_multi(which, ptr(d1), ptr(bo, i32p), ptr(b1, i16p), 48, ptr(nnzc))
+        ofn(ptr(d2), ptr(bo, i32p), ptr(b2, i16p), 48, ptr(nnzc))
+        assert np.array_equal(d1, d2) and np.array_equal(b1, b2)
+
+
+# (alpha, beta, tc0) ladder in the spirit of tests/checkasm/h264dsp.c:394-402
+LF_PARAMS = [(a, b, t) for a, b, t in [(255, 18, 13), (226, 17, 11), (127, 16, 6), (80, 13, 4), (45, 10, 3),
+                                       (28, 8, 1), (17, 6, 1), (9, 3, 0), (4, 2, 0), (0, 0, 0), (255, 18, 0)]]
+
+
+@pytest.mark.parametrize("which", range(8))
+def test_h264_loop_filter(which):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(20 + which)
+    for alpha, beta, t in LF_PARAMS:
+        for rep in range(12):
+            base = rng.integers(0, 256, 1, dtype=np.uint8)[0]
+            spread = [2, 6, 20, 255][rep % 4]
+            img = np.clip(base.astype(int) + rng.integers(-spread, spread + 1, (32, 32)), 0, 255).astype(np.uint8)
+            tc0 = np.array([t, -1 if rep & 1 else t, 0, max(t - 1, 0)], np.int8)
+            a, b = img.copy(), img.copy()
+            off = 8 * 32 + 8
+            pa = C.cast(C.addressof(ptr(a).contents) + off, u8p)
+            pb = C.cast(C.addressof(ptr(b).contents) + off, u8p)
+            R.ffref_h264_loop_filter(which, pa, 32, alpha, beta, ptr(tc0.copy(), i8p))
+            O.ffo_h264_loop_filter(which, pb, 32, alpha, beta, ptr(tc0.copy(), i8p))
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("size_idx", [0, 1, 2])
+@pytest.mark.parametrize("avg", [0, 1])
+def test_h264_qpel(size_idx, avg):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(30 + size_idx * 2 + avg)
+    for mcxy in range(16):
+        for rep in range(3):
+            src = rng.integers(0, 256, (32, 64), dtype=np.uint8)
+            if rep == 2:
+                src = (rng.integers(0, 2, (32, 64)) * 255).astype(np.uint8)
+            dst = rng.integers(0, 256, (32, 64), dtype=np.uint8)
+            a, b = dst.copy(), dst.copy()
+            so = 6 * 64 + 8
+            ps = C.cast(C.addressof(ptr(src).contents) + so, u8p)
+            pa = C.cast(C.addressof(ptr(a).contents) + so, u8p)
+            pb = C.cast(C.addressof(ptr(b).contents) + so, u8p)
+            R.ffref_h264_qpel(avg, size_idx, mcxy, pa, ps, 64)
+            O.ffo_h264_qpel(avg, size_idx, mcxy, pb, ps, 64)
+            assert np.array_equal(a, b), (mcxy, rep)
+
+
+def test_me_cmp():
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(40)
+    a = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    b = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    for _ in range(64):
+        x, y = rng.integers(0, 40, 2)
+        pa = C.cast(C.addressof(ptr(a).contents) + int(y) * 64 + int(x & ~15), u8p)
+        pb = C.cast(C.addressof(ptr(b).contents) + int(y) * 64 + int(x), u8p)
+        for h in (8, 16):
+            assert R.ffref_me_cmp(0, 0, pa, pb, 64, h) == O.ffo_sad(16, pa, pb, 64, h)
+            assert R.ffref_me_cmp(0, 1, pa, pb, 64, h) == O.ffo_sad(8, pa, pb, 64, h)
+            assert R.ffref_me_cmp(1, 0, pa, pb, 64, h) == O.ffo_hadamard8_diff16(pa, pb, 64, h)
+        assert R.ffref_me_cmp(1, 1, pa, pb, 64, 8) == O.ffo_hadamard8_diff8x8(pa, pb, 64)
+
+
+@pytest.mark.parametrize("R_", [3, 7])
+def test_me_search_esa(R_):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(50 + R_)
+    w, h = 96, 64
+    ref_img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    cur = np.roll(ref_img, (2, -3), (0, 1)).copy()
+    cur[:16, :16] = ref_img[:16, :16]               # a zero-cost zero-MV block (early return)
+    cur[20:, 40:] = rng.integers(0, 4, cur[20:, 40:].shape, dtype=np.uint8)   # many ties
+    for by in range(h // 16):
+        for bx in range(w // 16):
+            m1 = np.zeros(2, np.int32); m2 = np.array([bx * 16, by * 16], np.int32)
+            c1 = R.ffref_me_search_esa(ptr(cur), ptr(ref_img), w, w, h, 16, R_, bx * 16, by * 16, ptr(m1, i32p))
+            c2 = O.ffo_me_search_esa(ptr(cur), ptr(ref_img), w, w, h, 16, R_, 0, bx * 16, by * 16, ptr(m2, i32p))
+            assert c1 == c2 and np.array_equal(m1, m2)
+
+
+@pytest.mark.parametrize("len_", [16, 64, 256, 1024, 2048])
+@pytest.mark.parametrize("inv", [0, 1])
+def test_mdct_float(len_, inv):
+    """The restated split-radix recursion reproduces the reference's float results exactly."""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(len_ + inv)
+    scale = 1.0 / len_ if inv else 1.0
+    rc = R.ffref_tx_create(1, inv, len_, scale, 0)
+    oc = O.ffo_mdct_create(inv, len_, scale)
+    assert rc and oc
+    for _ in range(4):
+        x = rng.uniform(-1, 1, 2 * len_ if not inv else len_).astype(np.float32)
+        a = np.zeros(len_, np.float32); b = np.zeros(len_, np.float32)
+        R.ffref_tx_run(rc, ptr(a, f32p), ptr(x.copy(), f32p), 4)
+        O.ffo_mdct_run(oc, ptr(b, f32p), ptr(x, f32p), 4)
+        assert np.array_equal(a, b), np.abs(a - b).max()
+    R.ffref_tx_free(rc); O.ffo_mdct_free(oc)
+
+
+@pytest.mark.parametrize("inv", [0, 1])
+def test_mdct_vs_naive(inv):
+    """the float transform stays within 2^-18 * max|ref| of the double-precision cosine sum"""
+    O = ffi.oracle()
+    n = 256
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, 2 * n if not inv else n).astype(np.float32)
+    oc = O.ffo_mdct_create(inv, n, 1.0)
+    out = np.zeros(n, np.float32); nv = np.zeros(n, np.float64)
+    O.ffo_mdct_run(oc, ptr(out, f32p), ptr(x, f32p), 4)
+    (O.ffo_mdct_naive_inv if inv else O.ffo_mdct_naive_fwd)(n, 1.0, nv.ctypes.data_as(C.POINTER(C.c_double)), ptr(x, f32p))
+    O.ffo_mdct_free(oc)
+    assert np.abs(out - nv).max() <= 2.0 ** -18 * np.abs(nv).max() * 4
