@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its configuration, on N MI355X GPUs of one node.
+
+  step      one pass of the hot path over one batch: 256 nv12 1920x1080 frames -> nv12 3840x2160,
+            SWS_BICUBIC (BASELINE.json configs[1]), inputs and outputs resident in HBM.
+  metric    Mpixels/s of OUTPUT pixels, whole job over all ranks (weak scaling: 256 frames per GPU).
+  roofline  the dominant kernel k_sws_scale_yuv<4,4>: algorithmic bytes per launch
+            (15,552,000 B/frame x frames) / its average duration measured with HIP
+            events on the launch stream, against the 8 TB/s HBM3E peak.
+  cpu_baseline  the reference's own C path (oracle/_ref, kind "reference") or the oracle port, timed
+            on the host cores over a bounded sample of the same workload (rank 0, N=1 only).
+
+N>1 is launched by torchrun (one process per GPU, RCCL): frames shard across ranks with no data-path
+collective; the only collectives are the barriers and the MAX-over-ranks of the timed interval.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SRC_W, SRC_H, DST_W, DST_H = 1920, 1080, 3840, 2160
+NV12 = 23
+BYTES_PER_FRAME = SRC_W * SRC_H * 3 // 2 + DST_W * DST_H * 3 // 2   # 15,552,000
+HBM_PEAK_GBS = 8000.0                                             # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(budget_s=12.0):
+    """Bounded sample of the same conversion on the host cores (checker infrastructure, timed only)."""
+    import ffi
+    rng = np.random.default_rng(2)
+    src = ffi.alloc_frame(NV12, SRC_W, SRC_H, rng)
+    dst = ffi.alloc_frame(NV12, DST_W, DST_H)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(dst)
+    cores = os.cpu_count() or 1
+    if ffi.have_ref():
+        R = ffi.ref()
+        threads = min(cores, 64)
+        ctx = R.ffref_sws_create(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4, threads)
+        R.ffref_sws_scale(ctx, sp, ss, 0, SRC_H, dp, ds)            # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            R.ffref_sws_scale(ctx, sp, ss, 0, SRC_H, dp, ds)
+            n += 1
+            dt = time.perf_counter() - t0
+            if (dt > budget_s and n >= 4) or n >= 2000:
+                break
+        R.ffref_sws_free(ctx)
+        kind = "reference"
+    else:
+        from ffmpeg_amd import swscale as S
+        ht = S.HostTables(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4)
+        t = ffi.make_otables(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4, ht.banks(), ht.coeffs())
+        threads = 1
+        n, t0 = 0, time.perf_counter()
+        while True:
+            ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds)
+            n += 1
+            dt = time.perf_counter() - t0
+            if (dt > budget_s and n >= 2) or n >= 200:
+                break
+        kind = "port"
+    return {"value": round(n * DST_W * DST_H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": kind,
+            "sample": "%d frames nv12 %dx%d->%dx%d bicubic in %.1f s, %d thread(s) of %d host cores, pure C (no SIMD asm)"
+                      % (n, SRC_W, SRC_H, DST_W, DST_H, dt, threads, cores)}
+
+
+def extras(torch, dev):
+    """Secondary hot-path kernels, short runs (rank 0, N=1): yuv420p->rgb24 4K and H.264 idct8."""
+    from ffmpeg_amd import swscale as S, h264
+    out = {}
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    # unscaled yuv420p -> rgb24, 3840x2160, 64-frame batch (4.5 B/pixel)
+    n, w, h = 64, 3840, 2160
+    ctx = S.SwsContext(w, h, 0, w, h, 2, 4)
+    src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(0, w, h)]
+    dst = [torch.empty((n, h, 3 * w), dtype=torch.uint8, device=dev)]
+    for _ in range(2):
+        ctx.scale_batch(src, dst)
+    e0, e1 = ev(), ev()
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        ctx.scale_batch(src, dst)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = n * w * h * 4.5 / (ms * 1e-3) / 1e9
+    out["yuv420p_rgb24_4k"] = {"Mpixels/s": round(n * w * h / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1),
+                               "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "frames": n, "ms": round(ms, 4)}
+    ctx.close()
+    del src, dst
+    # H.264 8x8 IDCT + add over 32 4K luma planes (129,600 blocks each, 384 B/block)
+    planes, stride = 32, 3840
+    nb = planes * 129600
+    plane = torch.randint(0, 256, (planes * 2160, stride), dtype=torch.uint8, device=dev)
+    by, bx = torch.meshgrid(torch.arange(planes * 270, device=dev), torch.arange(480, device=dev), indexing="ij")
+    offs = (by * 8 * stride + bx * 8).to(torch.int32).reshape(-1).contiguous()
+    coefs0 = torch.randint(-512, 512, (nb, 64), dtype=torch.int16, device=dev)
+    coefs = coefs0.clone()
+    h264.idct_add_batch(h264.IDCT8, plane, stride, offs, coefs)
+    tot = 0.0
+    reps = 5
+    for _ in range(reps):
+        coefs.copy_(coefs0)
+        e0, e1 = ev(), ev()
+        e0.record()
+        h264.idct_add_batch(h264.IDCT8, plane, stride, offs, coefs)
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    ms = tot / reps
+    gbs = nb * 384 / (ms * 1e-3) / 1e9
+    out["h264_idct8_add"] = {"Gblocks/s": round(nb / (ms * 1e-3) / 1e9, 3), "GB/s": round(gbs, 1),
+                             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "blocks": nb, "ms": round(ms, 4)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE configs[1]: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ffmpeg_amd import swscale as S, _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (libffhip has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _lib.check(_lib.lib().ffhip_set_device(local_rank), "ffhip_set_device")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.frames
+    ctx = S.SwsContext(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, S.SWS_BICUBIC)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xF0F00002 + rank)                       # SURVEY.md §8d seed, one shard per rank
+    src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev, generator=gen)
+           for r, c in S.plane_shapes(NV12, SRC_W, SRC_H)]
+    dst = [torch.empty((n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(NV12, DST_W, DST_H)]
+    stream = torch.cuda.current_stream()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.scale_batch(src, dst, stream.cuda_stream)
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)                                    # HIP events on the launch stream
+        ctx.scale_batch(src, dst, stream.cuda_stream)
+        e1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(args.steps, 1)
+
+    # sanity outside the timed region: every rank produced non-trivial output
+    chk = torch.stack([d[:2].to(torch.float64).sum() for d in dst]).sum().reshape(1)
+    if world > 1:
+        dist.all_reduce(chk)
+    assert float(chk.item()) > 0
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_px = world * n * DST_W * DST_H * args.steps
+        value = total_px / elapsed / 1e6
+        achieved = n * BYTES_PER_FRAME / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "swscale_nv12_1080p_to_4k_bicubic_Mpixels_per_s", "value": round(value, 1), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "swscale bicubic nv12 1920x1080 -> nv12 3840x2160, %d-frame batch per GPU, "
+                                   "frames resident in HBM (BASELINE.json configs[1])" % n,
+                       "frames_per_gpu": n, "flags": "SWS_BICUBIC", "sharding": "frames/rank, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_sws_scale_yuv<4,4>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_extras:
+            try:
+                line["extras"] = extras(torch, dev)
+            except Exception as e:  # extras never invalidate the headline line
+                line["extras"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

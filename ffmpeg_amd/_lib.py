@@ -1,0 +1,97 @@
+"""ctypes binding of libffhip.so (the product).  Fails loudly when the library is missing: there is
+no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libffhip.so")
+
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+i16p = C.POINTER(C.c_int16)
+i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+
+class SwsFilter(C.Structure):
+    _fields_ = [("filter", i16p), ("pos", i32p), ("size", C.c_int), ("n", C.c_int)]
+
+
+class SwsTables(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("srcW", "srcH", "srcFormat", "dstW", "dstH", "dstFormat", "flags")] + \
+               [(k, SwsFilter) for k in ("hLum", "hChr", "vLum", "vChr")] + \
+               [(k, C.c_int64) for k in ("yuv2rgb_cy", "yuv2rgb_oy", "yuv2rgb_crv", "yuv2rgb_cbu", "yuv2rgb_cgu",
+                                         "yuv2rgb_cgv")] + [("yuv2rgb_yoffs", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libffhip.so once and declare every entry point of include/ffhip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise ImportError("ffmpeg_amd/libffhip.so is missing - build it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    L = C.CDLL(SO)
+    sig = {
+        "ffhip_device_count": (C.c_int, []),
+        "ffhip_set_device": (C.c_int, [C.c_int]),
+        "ffhip_last_error": (C.c_char_p, []),
+        "ffhip_version": (C.c_char_p, []),
+        "ffhip_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+        "ffhip_free": (C.c_int, [vp]),
+        "ffhip_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
+        "ffhip_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
+        "ffhip_stream_synchronize": (C.c_int, [vp]),
+        "ffhip_sws_getContext": (vp, [C.c_int] * 7),
+        "ffhip_sws_from_tables": (vp, [C.POINTER(SwsTables)]),
+        "ffhip_sws_freeContext": (None, [vp]),
+        "ffhip_sws_tables_create": (vp, [C.c_int] * 7),
+        "ffhip_sws_tables_get": (C.c_int, [vp, C.POINTER(SwsTables)]),
+        "ffhip_sws_tables_is_unscaled_yuv2rgb": (C.c_int, [vp]),
+        "ffhip_sws_tables_free": (None, [vp]),
+        "ffhip_sws_scale": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(u8p),
+                                      C.POINTER(C.c_int)]),
+        "ffhip_sws_scale_batch_dev": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int),
+                                                C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_int),
+                                                C.POINTER(C.c_size_t), vp]),
+        "ffhip_sws_hscale8to15_dev": (C.c_int, [vp, C.c_int, C.c_ssize_t, vp, C.c_ssize_t, C.c_int, vp, vp, C.c_int,
+                                                vp]),
+        "ffhip_sws_yuv2planeX8_dev": (C.c_int, [vp, C.c_int, vp, C.c_ssize_t, vp, C.c_int, vp, C.c_int, vp]),
+        "ffhip_h264_idct_add_batch_dev": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, vp, C.c_int, vp]),
+        "ffhip_h264_idct_add_mb_batch_dev": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, vp, vp, vp, C.c_int, vp]),
+        "ffhip_h264_loop_filter_batch_dev": (C.c_int, [vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ffhip_h264_deblock_frame_dev": (C.c_int, [vp, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
+        "ffhip_h264_qpel_batch_dev": (C.c_int, [vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ffhip_me_cmp_batch_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ffhip_me_esa_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_size_t, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, vp, vp, vp]),
+        "ffhip_tx_init": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                    C.c_uint64]),
+        "ffhip_tx_uninit": (None, [C.POINTER(vp)]),
+        "ffhip_tx_batch_dev": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_ssize_t, C.c_int, vp]),
+        "ff_h264dsp_init_hip": (C.c_int, [vp, C.c_int, C.c_int]),
+        "ff_h264qpel_init_hip": (C.c_int, [vp, C.c_int]),
+        "ff_me_cmp_init_hip": (C.c_int, [vp]),
+    }
+    missing = []
+    for name, (res, args) in sig.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    L._missing = missing
+    _lib = L
+    return L
+
+
+def check(rc, what="ffhip call"):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise RuntimeError("%s failed (%s): %s" % (what, rc, lib().ffhip_last_error().decode()))
+    return rc

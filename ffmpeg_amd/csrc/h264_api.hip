@@ -1,0 +1,32 @@
+/*
+ * h264_api.hip — C-ABI entry points of the h264dsp / h264qpel part of libffhip (include/ffhip.h).
+ * Batched device faces first; the signature-exact host shims (ff_h264dsp_init_hip & co) stage one
+ * call's operands through device scratch and are meant for parity harnesses such as checkasm.
+ */
+#include <mutex>
+#include <string.h>
+
+#include "kernels/common.h"
+#include "kernels/h264_kernels.h"
+
+extern "C" int ffhip_h264_idct_add_batch_dev(int kind, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
+                                             int16_t *blocks, int n, void *stream)
+{
+    if (!dst_base || !dst_offset || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_idct_add(kind, dst_base, stride, dst_offset, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_h264_idct_add_mb_batch_dev(int which, uint8_t *dst_base, ptrdiff_t stride, const int32_t *mb_offset,
+                                                const int32_t *blockoffset16, int16_t *blocks, const uint8_t *nnzc,
+                                                int nmb, void *stream)
+{
+    if (!dst_base || !mb_offset || !blockoffset16 || !blocks || !nnzc || nmb < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_idct_add_mb(which, dst_base, stride, mb_offset, blockoffset16, blocks, nnzc, nmb,
+                                         (hipStream_t)stream);
+}

@@ -370,7 +370,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         ffhip_set_error("ffhip_sws: SWS_FAST_BILINEAR is not on the hip path");
         return NULL;
     }
-    if (!is_yuv(srcFormat) || (!is_yuv(dstFormat) && !is_rgb(dstFormat)) || srcW < 4 || srcH < 2 || dstW < 2 ||
+    if (!is_yuv(srcFormat) || (!is_yuv(dstFormat) && !is_rgb(dstFormat)) || srcW < 2 || srcH < 2 || dstW < 2 ||
         dstH < 2) {
         ffhip_set_error("ffhip_sws: unsupported conversion %d -> %d (%dx%d -> %dx%d)", srcFormat, dstFormat,
                         srcW, srcH, dstW, dstH);

@@ -1,0 +1,20 @@
+/* h264_kernels.h — launchers of the h264dsp / h264qpel kernels (internal to libffhip). */
+#ifndef FFHIP_H264_KERNELS_H
+#define FFHIP_H264_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "ffhip.h"
+
+int ffhip_launch_h264_idct_add(int kind, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
+                               int16_t *blocks, int n, hipStream_t stream);
+int ffhip_launch_h264_idct_add_mb(int which, uint8_t *dst_base, ptrdiff_t stride, const int32_t *mb_offset,
+                                  const int32_t *blockoffset16, int16_t *blocks, const uint8_t *nnzc, int nmb,
+                                  hipStream_t stream);
+int ffhip_launch_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n,
+                                  hipStream_t stream);
+int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
+                                    hipStream_t stream);
+int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
+                           hipStream_t stream);
+#endif

@@ -1,0 +1,85 @@
+/* sws_kernels.h — argument blocks and launchers of the swscale kernels (internal to libffhip). */
+#ifndef FFHIP_SWS_KERNELS_H
+#define FFHIP_SWS_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+/* closed-form yuv2rgb constants, all int32 (checked at context creation) */
+struct FFHipYuv2RgbK {
+    int cy;
+    int kb;           /* yb0 + 0x8000 */
+    int crv, cbu, cgu, cgv;
+    int off_r, off_b; /* yoffs - (crv>>9), yoffs - (cbu>>9)            */
+    int off_g;        /* yoffs - (cgu>>9) - (cgv>>9)                   */
+};
+
+struct FFHipYuv2RgbArgs {
+    const uint8_t *y, *u, *v;
+    uint8_t *dst;
+    ptrdiff_t y_stride, u_stride, v_stride, dst_stride;
+    size_t y_fp, u_fp, v_fp, dst_fp; /* frame pitches (bytes) */
+    int wvalid;                      /* width & ~1 */
+    int h;                           /* rows of this slice (even) */
+    int dst_y0;                      /* srcSliceY: first destination row */
+    int nframes;
+    FFHipYuv2RgbK k;
+};
+int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int bgr, hipStream_t stream);
+
+/* one separable bank resident in HBM */
+struct FFHipDevFilter {
+    const int16_t *filter;
+    const int32_t *pos;
+    int size, n;
+};
+
+/*
+ * Fused H+V scaling of one "channel group": C == 1 (a luma plane, or one planar chroma plane) or
+ * C == 2 (U and V together, each possibly interleaved with the other in memory).
+ */
+struct FFHipScalePlaneArgs {
+    const uint8_t *src[2];      /* channel c sample i at src[c][i * src_step] */
+    uint8_t *dst[2];
+    ptrdiff_t src_stride[2], dst_stride[2];
+    size_t src_fp[2], dst_fp[2];
+    int src_step, dst_step;     /* 1 planar, 2 interleaved */
+    int srcW, srcH, dstW, dstH; /* of this channel group */
+    int nframes;
+    FFHipDevFilter h, v;
+    int tw, th;                 /* output tile */
+    int max_cols, max_rows;     /* source footprint of the widest / tallest tile */
+    int tiles_x, tiles_y;
+};
+int ffhip_launch_scale_yuv(const FFHipScalePlaneArgs &lum, const FFHipScalePlaneArgs &chr, hipStream_t stream);
+/* picks tw/th/max_* for a bank pair from HOST copies of the position tables */
+int ffhip_plan_scale_plane(FFHipScalePlaneArgs *a, int channels, const int32_t *hpos_host, const int32_t *vpos_host);
+
+/* Fused H+V scaling + yuv2rgb for packed rgb24/bgr24 output (yuv2rgb{1,2,X} dispatch in-kernel). */
+struct FFHipScaleRgbArgs {
+    const uint8_t *src[3];      /* Y, U, V (U/V may alias an interleaved plane with chr_step 2) */
+    uint8_t *dst;
+    ptrdiff_t src_stride[3], dst_stride;
+    size_t src_fp[3], dst_fp;
+    int chr_step;
+    int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH;
+    int nframes;
+    FFHipDevFilter hl, hc, vl, vc;
+    int tw, th;
+    int max_cols_l, max_rows_l, max_cols_c, max_rows_c;
+    int tiles_x, tiles_y;
+    int bgr;
+    FFHipYuv2RgbK k;
+};
+int ffhip_launch_scale_rgb(const FFHipScaleRgbArgs &a, hipStream_t stream);
+int ffhip_plan_scale_rgb(FFHipScaleRgbArgs *a, const int32_t *hl, const int32_t *hc, const int32_t *vl,
+                         const int32_t *vc);
+
+/* per-line parity faces */
+int ffhip_launch_hscale8to15(int16_t *dst, int dstW, ptrdiff_t dstPitch, const uint8_t *src, ptrdiff_t srcPitch,
+                             int nlines, const int16_t *filter, const int32_t *pos, int fs, hipStream_t stream);
+int ffhip_launch_yuv2planeX8(const int16_t *filter, int fs, const int16_t *src, ptrdiff_t srcPitch, uint8_t *dest,
+                             int dstW, const uint8_t *dither8, int offset, hipStream_t stream);
+
+#endif

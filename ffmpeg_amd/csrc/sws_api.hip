@@ -1,0 +1,372 @@
+/*
+ * sws_api.hip — C-ABI entry points of the swscale part of libffhip (declared in include/ffhip.h).
+ *
+ * Mirrors, for the hot path only:
+ *   sws_getContext()/sws_init_context()  -> ffhip_sws_getContext()      (libswscale/utils.c:1137,2043)
+ *   SwsFunc c->convert_unscaled / whole-frame scale -> ffhip_sws_scale() (swscale_internal.h:99-101, swscale.c:1185)
+ *   batched device-resident frames        -> ffhip_sws_scale_batch_dev() (no reference equivalent)
+ */
+#include <mutex>
+#include <new>
+#include <string.h>
+#include <vector>
+
+#include "kernels/common.h"
+#include "kernels/sws_kernels.h"
+
+struct FFHipSwsContext {
+    FFHipSwsTables t;
+    std::vector<int16_t> f[4];
+    std::vector<int32_t> p[4];
+    void *dev_tables = nullptr;
+    FFHipDevFilter d[4];
+    int unscaled_yuv2rgb = 0;
+    FFHipYuv2RgbK k;
+    int chrSrcW, chrSrcH;
+    FFHipScalePlaneArgs lum, chr;
+    FFHipScaleRgbArgs rgb;
+    /* staging for the host-pointer face */
+    void *stage = nullptr;
+    size_t stage_sz = 0;
+    std::mutex mu;
+};
+
+static bool fmt_yuv(int f) { return f == FFHIP_PIX_FMT_YUV420P || f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
+static bool fmt_nv(int f) { return f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
+static bool fmt_rgb(int f) { return f == FFHIP_PIX_FMT_RGB24 || f == FFHIP_PIX_FMT_BGR24; }
+
+static int make_k(const FFHipSwsTables &t, FFHipYuv2RgbK *k)
+{
+    const int64_t yb0 = -(384LL << 16) - 512 * t.yuv2rgb_cy - t.yuv2rgb_oy;
+    const int64_t lim = 1LL << 19;
+    if (t.yuv2rgb_cy <= 0 || t.yuv2rgb_cy >= lim || llabs(t.yuv2rgb_crv) >= lim || llabs(t.yuv2rgb_cbu) >= lim ||
+        llabs(t.yuv2rgb_cgu) >= lim || llabs(t.yuv2rgb_cgv) >= lim || llabs(yb0) >= (1LL << 30)) {
+        ffhip_set_error("ffhip_sws: yuv2rgb coefficients outside the int32 closed-form range");
+        return FFHIP_EINVAL;
+    }
+    k->cy = (int)t.yuv2rgb_cy;
+    k->kb = (int)(yb0 + 0x8000);
+    k->crv = (int)t.yuv2rgb_crv;
+    k->cbu = (int)t.yuv2rgb_cbu;
+    k->cgu = (int)t.yuv2rgb_cgu;
+    k->cgv = (int)t.yuv2rgb_cgv;
+    k->off_r = t.yuv2rgb_yoffs - (int)(t.yuv2rgb_crv >> 9);
+    k->off_b = t.yuv2rgb_yoffs - (int)(t.yuv2rgb_cbu >> 9);
+    k->off_g = t.yuv2rgb_yoffs - (int)(t.yuv2rgb_cgu >> 9) - (int)(t.yuv2rgb_cgv >> 9);
+    return 0;
+}
+
+extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
+{
+    if (!t || !fmt_yuv(t->srcFormat) || !(fmt_yuv(t->dstFormat) || fmt_rgb(t->dstFormat))) {
+        ffhip_set_error("ffhip_sws: unsupported format pair");
+        return nullptr;
+    }
+    if (fmt_rgb(t->dstFormat) && (t->dstW & 1)) {
+        ffhip_set_error("ffhip_sws: odd RGB width is not on the hip path");
+        return nullptr;
+    }
+    if (!ffhip_have_device()) {
+        ffhip_set_error("ffhip_sws: no HIP device (FFHIP_ENOSYS) - keep the C function pointers");
+        return nullptr;
+    }
+    FFHipSwsContext *c = new (std::nothrow) FFHipSwsContext();
+    if (!c)
+        return nullptr;
+    c->t = *t;
+    c->chrSrcW = (t->srcW + 1) >> 1;
+    c->chrSrcH = (t->srcH + 1) >> 1;
+    c->unscaled_yuv2rgb = t->srcW == t->dstW && t->srcH == t->dstH && t->srcFormat == FFHIP_PIX_FMT_YUV420P &&
+                          fmt_rgb(t->dstFormat) && !(t->flags & FFHIP_SWS_ACCURATE_RND) && !(t->dstH & 1);
+    if (make_k(*t, &c->k) < 0) {
+        delete c;
+        return nullptr;
+    }
+
+    /* copy the banks (with the reference's 3 entries of over-read padding when present is not assumed) */
+    const FFHipSwsFilter *in[4] = { &t->hLum, &t->hChr, &t->vLum, &t->vChr };
+    FFHipSwsFilter *own[4] = { &c->t.hLum, &c->t.hChr, &c->t.vLum, &c->t.vChr };
+    size_t off[4][2], total = 0;
+    for (int i = 0; i < 4; i++) {
+        if (!in[i]->filter || !in[i]->pos || in[i]->size <= 0 || in[i]->n <= 0) {
+            ffhip_set_error("ffhip_sws: filter bank %d missing", i);
+            delete c;
+            return nullptr;
+        }
+        c->f[i].assign(in[i]->filter, in[i]->filter + (size_t)in[i]->n * in[i]->size);
+        c->p[i].assign(in[i]->pos, in[i]->pos + in[i]->n);
+        own[i]->filter = c->f[i].data();
+        own[i]->pos = c->p[i].data();
+        off[i][0] = total; total += (c->f[i].size() * 2 + 15) & ~(size_t)15;
+        off[i][1] = total; total += (c->p[i].size() * 4 + 15) & ~(size_t)15;
+    }
+    if (hipMalloc(&c->dev_tables, total) != hipSuccess) {
+        ffhip_set_error("ffhip_sws: hipMalloc(%zu) for filter banks failed", total);
+        delete c;
+        return nullptr;
+    }
+    for (int i = 0; i < 4; i++) {
+        uint8_t *base = static_cast<uint8_t *>(c->dev_tables);
+        if (hipMemcpy(base + off[i][0], c->f[i].data(), c->f[i].size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(base + off[i][1], c->p[i].data(), c->p[i].size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            ffhip_set_error("ffhip_sws: filter bank upload failed");
+            ffhip_sws_freeContext(c);
+            return nullptr;
+        }
+        c->d[i].filter = reinterpret_cast<const int16_t *>(base + off[i][0]);
+        c->d[i].pos = reinterpret_cast<const int32_t *>(base + off[i][1]);
+        c->d[i].size = in[i]->size;
+        c->d[i].n = in[i]->n;
+    }
+
+    if (c->unscaled_yuv2rgb)
+        return c;
+
+    int r = 0;
+    if (fmt_rgb(t->dstFormat)) {
+        FFHipScaleRgbArgs &a = c->rgb;
+        memset(&a, 0, sizeof(a));
+        a.srcW = t->srcW; a.srcH = t->srcH; a.chrSrcW = c->chrSrcW; a.chrSrcH = c->chrSrcH;
+        a.dstW = t->dstW; a.dstH = t->dstH;
+        a.hl = c->d[0]; a.hc = c->d[1]; a.vl = c->d[2]; a.vc = c->d[3];
+        a.bgr = t->dstFormat == FFHIP_PIX_FMT_BGR24;
+        a.k = c->k;
+        if (a.vc.n != t->dstH || a.hc.n != (t->dstW + 1) / 2) {
+            ffhip_set_error("ffhip_sws: chroma banks do not match a packed-RGB target (need chrDstH == dstH)");
+            ffhip_sws_freeContext(c);
+            return nullptr;
+        }
+        r = ffhip_plan_scale_rgb(&a, c->p[0].data(), c->p[1].data(), c->p[2].data(), c->p[3].data());
+    } else {
+        FFHipScalePlaneArgs &l = c->lum, &ch = c->chr;
+        memset(&l, 0, sizeof(l));
+        memset(&ch, 0, sizeof(ch));
+        l.srcW = t->srcW; l.srcH = t->srcH; l.dstW = t->dstW; l.dstH = t->dstH;
+        l.h = c->d[0]; l.v = c->d[2];
+        ch.srcW = c->chrSrcW; ch.srcH = c->chrSrcH; ch.dstW = c->d[1].n; ch.dstH = c->d[3].n;
+        ch.h = c->d[1]; ch.v = c->d[3];
+        r = ffhip_plan_scale_plane(&l, 1, c->p[0].data(), c->p[2].data());
+        if (!r)
+            r = ffhip_plan_scale_plane(&ch, 2, c->p[1].data(), c->p[3].data());
+    }
+    if (r < 0) {
+        ffhip_sws_freeContext(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat,
+                                                 int flags)
+{
+    FFHipSwsHostTables *h = ffhip_sws_tables_create(srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags);
+    if (!h)
+        return nullptr;
+    FFHipSwsTables t;
+    ffhip_sws_tables_get(h, &t);
+    FFHipSwsContext *c = ffhip_sws_from_tables(&t);
+    ffhip_sws_tables_free(h);
+    return c;
+}
+
+extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
+{
+    if (!c)
+        return;
+    if (c->dev_tables)
+        (void)hipFree(c->dev_tables);
+    if (c->stage)
+        (void)hipFree(c->stage);
+    delete c;
+}
+
+extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4],
+                                         const int srcStride[4], const size_t srcFramePitch[4], void *const dst[4],
+                                         const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c || nframes < 0 || !src || !dst)
+        return FFHIP_EINVAL;
+    const FFHipSwsTables &t = c->t;
+    const uint8_t *s0 = (const uint8_t *)src[0], *s1 = (const uint8_t *)src[1], *s2 = (const uint8_t *)src[2];
+
+    if (c->unscaled_yuv2rgb) {
+        FFHipYuv2RgbArgs a;
+        a.y = s0; a.u = s1; a.v = s2; a.dst = (uint8_t *)dst[0];
+        a.y_stride = srcStride[0]; a.u_stride = srcStride[1]; a.v_stride = srcStride[2]; a.dst_stride = dstStride[0];
+        a.y_fp = srcFramePitch[0]; a.u_fp = srcFramePitch[1]; a.v_fp = srcFramePitch[2]; a.dst_fp = dstFramePitch[0];
+        a.wvalid = t.dstW & ~1; a.h = t.srcH; a.dst_y0 = 0; a.nframes = nframes; a.k = c->k;
+        return ffhip_launch_yuv420p_rgb24(a, t.dstFormat == FFHIP_PIX_FMT_BGR24, stream);
+    }
+
+    /* chroma source description */
+    const uint8_t *cu, *cv;
+    ptrdiff_t cus, cvs;
+    size_t cuf, cvf;
+    int cstep;
+    if (fmt_nv(t.srcFormat)) {
+        const int sw = t.srcFormat == FFHIP_PIX_FMT_NV21;
+        cu = s1 + sw; cv = s1 + !sw;
+        cus = cvs = srcStride[1]; cuf = cvf = srcFramePitch[1]; cstep = 2;
+    } else {
+        cu = s1; cv = s2; cus = srcStride[1]; cvs = srcStride[2]; cuf = srcFramePitch[1]; cvf = srcFramePitch[2];
+        cstep = 1;
+    }
+
+    if (fmt_rgb(t.dstFormat)) {
+        FFHipScaleRgbArgs a = c->rgb;
+        a.src[0] = s0; a.src[1] = cu; a.src[2] = cv;
+        a.src_stride[0] = srcStride[0]; a.src_stride[1] = cus; a.src_stride[2] = cvs;
+        a.src_fp[0] = srcFramePitch[0]; a.src_fp[1] = cuf; a.src_fp[2] = cvf;
+        a.chr_step = cstep;
+        a.dst = (uint8_t *)dst[0]; a.dst_stride = dstStride[0]; a.dst_fp = dstFramePitch[0];
+        a.nframes = nframes;
+        return ffhip_launch_scale_rgb(a, stream);
+    }
+
+    FFHipScalePlaneArgs l = c->lum, ch = c->chr;
+    l.src[0] = l.src[1] = s0; l.src_stride[0] = l.src_stride[1] = srcStride[0];
+    l.src_fp[0] = l.src_fp[1] = srcFramePitch[0]; l.src_step = 1;
+    l.dst[0] = l.dst[1] = (uint8_t *)dst[0]; l.dst_stride[0] = l.dst_stride[1] = dstStride[0];
+    l.dst_fp[0] = l.dst_fp[1] = dstFramePitch[0]; l.dst_step = 1;
+    l.nframes = nframes;
+    ch.src[0] = cu; ch.src[1] = cv; ch.src_stride[0] = cus; ch.src_stride[1] = cvs;
+    ch.src_fp[0] = cuf; ch.src_fp[1] = cvf; ch.src_step = cstep;
+    if (fmt_nv(t.dstFormat)) {
+        const int sw = t.dstFormat == FFHIP_PIX_FMT_NV21;
+        ch.dst[0] = (uint8_t *)dst[1] + sw; ch.dst[1] = (uint8_t *)dst[1] + !sw;
+        ch.dst_stride[0] = ch.dst_stride[1] = dstStride[1];
+        ch.dst_fp[0] = ch.dst_fp[1] = dstFramePitch[1];
+        ch.dst_step = 2;
+    } else {
+        ch.dst[0] = (uint8_t *)dst[1]; ch.dst[1] = (uint8_t *)dst[2];
+        ch.dst_stride[0] = dstStride[1]; ch.dst_stride[1] = dstStride[2];
+        ch.dst_fp[0] = dstFramePitch[1]; ch.dst_fp[1] = dstFramePitch[2];
+        ch.dst_step = 1;
+    }
+    ch.nframes = nframes;
+    return ffhip_launch_scale_yuv(l, ch, stream);
+}
+
+/* ---- host-pointer face ---------------------------------------------------------------------- */
+struct PlaneDesc { int wbytes, rows; };
+
+static int plane_list(int fmt, int w, int h, PlaneDesc out[3])
+{
+    const int cw = (w + 1) >> 1, chh = (h + 1) >> 1;
+    if (fmt == FFHIP_PIX_FMT_YUV420P) { out[0] = { w, h }; out[1] = { cw, chh }; out[2] = { cw, chh }; return 3; }
+    if (fmt_nv(fmt)) { out[0] = { w, h }; out[1] = { 2 * cw, chh }; return 2; }
+    out[0] = { 3 * w, h };
+    return 1;
+}
+
+static hipError_t copy2d(void *dst, ptrdiff_t dpitch, const void *src, ptrdiff_t spitch, size_t wbytes, int rows,
+                         hipMemcpyKind kind)
+{
+    if (dpitch >= (ptrdiff_t)wbytes && spitch >= (ptrdiff_t)wbytes)
+        return hipMemcpy2D(dst, dpitch, src, spitch, wbytes, rows, kind);
+    for (int r = 0; r < rows; r++) { /* negative (bottom-up) strides: swscale.c:1141-1158 */
+        hipError_t e = hipMemcpy((uint8_t *)dst + r * dpitch, (const uint8_t *)src + r * spitch, wbytes, kind);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                               int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    if (!c || !src || !dst || srcSliceH <= 0)
+        return FFHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const FFHipSwsTables &t = c->t;
+    const bool unscaled = c->unscaled_yuv2rgb;
+    if (!unscaled && (srcSliceY != 0 || srcSliceH != t.srcH)) {
+        ffhip_set_error("ffhip_sws_scale: scaled contexts take whole frames");
+        return FFHIP_EINVAL;
+    }
+    if (unscaled && ((srcSliceY | srcSliceH) & 1)) { /* dst_slice_align = 2, swscale_unscaled.c:2430 */
+        ffhip_set_error("ffhip_sws_scale: slices of the unscaled yuv2rgb converter must be 2-line aligned");
+        return FFHIP_EINVAL;
+    }
+    const int srcRows = unscaled ? srcSliceH : t.srcH;
+    PlaneDesc sp[3], dp[3];
+    const int ns = plane_list(t.srcFormat, t.srcW, srcRows, sp);
+    const int nd = plane_list(t.dstFormat, t.dstW, unscaled ? srcSliceH : t.dstH, dp);
+    size_t off_s[3], off_d[3], total = 0;
+    int pitch_s[4] = { 0, 0, 0, 0 }, pitch_d[4] = { 0, 0, 0, 0 };
+    for (int i = 0; i < ns; i++) {
+        pitch_s[i] = (sp[i].wbytes + 255) & ~255;
+        off_s[i] = total;
+        total += (size_t)pitch_s[i] * sp[i].rows + 256;
+    }
+    for (int i = 0; i < nd; i++) {
+        pitch_d[i] = (dp[i].wbytes + 255) & ~255;
+        off_d[i] = total;
+        total += (size_t)pitch_d[i] * dp[i].rows + 256;
+    }
+    if (total > c->stage_sz) {
+        if (c->stage)
+            (void)hipFree(c->stage);
+        c->stage = nullptr;
+        c->stage_sz = 0;
+        if (hipMalloc(&c->stage, total) != hipSuccess) {
+            ffhip_set_error("ffhip_sws_scale: staging hipMalloc(%zu) failed", total);
+            return FFHIP_ENOMEM;
+        }
+        c->stage_sz = total;
+    }
+    uint8_t *base = (uint8_t *)c->stage;
+    const void *dsrc[4] = { 0, 0, 0, 0 };
+    void *ddst[4] = { 0, 0, 0, 0 };
+    size_t fp[4] = { 0, 0, 0, 0 };
+    for (int i = 0; i < ns; i++) {
+        HIP_TRY(copy2d(base + off_s[i], pitch_s[i], src[i], srcStride[i], sp[i].wbytes, sp[i].rows, hipMemcpyHostToDevice));
+        dsrc[i] = base + off_s[i];
+    }
+    for (int i = 0; i < nd; i++)
+        ddst[i] = base + off_d[i];
+    /* an odd RGB trailing column / rows a converter leaves untouched must survive the round trip */
+    if (unscaled && (t.dstW & 1))
+        HIP_TRY(copy2d(base + off_d[0], pitch_d[0], dst[0] + (ptrdiff_t)srcSliceY * dstStride[0], dstStride[0],
+                       dp[0].wbytes, dp[0].rows, hipMemcpyHostToDevice));
+    int r;
+    if (unscaled) {
+        FFHipYuv2RgbArgs a;
+        a.y = (const uint8_t *)dsrc[0]; a.u = (const uint8_t *)dsrc[1]; a.v = (const uint8_t *)dsrc[2];
+        a.dst = (uint8_t *)ddst[0];
+        a.y_stride = pitch_s[0]; a.u_stride = pitch_s[1]; a.v_stride = pitch_s[2]; a.dst_stride = pitch_d[0];
+        a.y_fp = a.u_fp = a.v_fp = a.dst_fp = 0;
+        a.wvalid = t.dstW & ~1; a.h = srcSliceH; a.dst_y0 = 0; a.nframes = 1; a.k = c->k;
+        r = ffhip_launch_yuv420p_rgb24(a, t.dstFormat == FFHIP_PIX_FMT_BGR24, 0);
+    } else {
+        r = ffhip_sws_scale_batch_dev(c, 1, dsrc, pitch_s, fp, ddst, pitch_d, fp, 0);
+    }
+    if (r < 0)
+        return r;
+    HIP_TRY(hipStreamSynchronize(0));
+    for (int i = 0; i < nd; i++) {
+        uint8_t *hd = dst[i] + (unscaled ? (ptrdiff_t)srcSliceY * dstStride[i] : 0);
+        HIP_TRY(copy2d(hd, dstStride[i], base + off_d[i], pitch_d[i], dp[i].wbytes, dp[i].rows, hipMemcpyDeviceToHost));
+    }
+    return unscaled ? srcSliceH : t.dstH;
+}
+
+/* ---- per-line parity faces ------------------------------------------------------------------- */
+extern "C" int ffhip_sws_hscale8to15_dev(int16_t *dst, int dstW, ptrdiff_t dstPitch, const uint8_t *src,
+                                         ptrdiff_t srcPitch, int nlines, const int16_t *filter, const int32_t *filterPos,
+                                         int filterSize, void *stream)
+{
+    if (!dst || !src || !filter || !filterPos || filterSize <= 0)
+        return FFHIP_EINVAL;
+    return ffhip_launch_hscale8to15(dst, dstW, dstPitch, src, srcPitch, nlines, filter, filterPos, filterSize,
+                                    (hipStream_t)stream);
+}
+
+extern "C" int ffhip_sws_yuv2planeX8_dev(const int16_t *filter, int filterSize, const int16_t *src, ptrdiff_t srcPitch,
+                                         uint8_t *dest, int dstW, const uint8_t *dither8, int offset, void *stream)
+{
+    if (!src || !dest || !dither8 || filterSize <= 0 || (filterSize > 1 && !filter))
+        return FFHIP_EINVAL;
+    return ffhip_launch_yuv2planeX8(filter, filterSize, src, srcPitch, dest, dstW, dither8, offset, (hipStream_t)stream);
+}

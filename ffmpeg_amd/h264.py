@@ -1,0 +1,42 @@
+"""Host-side mirror of the reference's H264DSPContext / H264QpelContext batch faces (device tensors)."""
+import ctypes as C
+
+from . import _lib
+
+IDCT4, IDCT8, IDCT4_DC, IDCT8_DC = 0, 1, 2, 3
+
+
+def _stream(stream):
+    import torch
+    return torch.cuda.current_stream().cuda_stream if stream is None else stream
+
+
+def idct_add_batch(kind, dst, stride, dst_offset, blocks, stream=None):
+    """dst: uint8 cuda tensor (plane), dst_offset: int32 [n], blocks: int16 [n, 16|64] (zeroed on return)."""
+    n = dst_offset.numel()
+    return _lib.check(_lib.lib().ffhip_h264_idct_add_batch_dev(kind, dst.data_ptr(), stride, dst_offset.data_ptr(),
+                                                               blocks.data_ptr(), n, _stream(stream)),
+                      "ffhip_h264_idct_add_batch_dev")
+
+
+def idct_add_mb_batch(which, dst, stride, mb_offset, blockoffset16, blocks, nnzc, stream=None):
+    nmb = mb_offset.numel()
+    return _lib.check(_lib.lib().ffhip_h264_idct_add_mb_batch_dev(which, dst.data_ptr(), stride, mb_offset.data_ptr(),
+                                                                  blockoffset16.data_ptr(), blocks.data_ptr(),
+                                                                  nnzc.data_ptr(), nmb, _stream(stream)),
+                      "ffhip_h264_idct_add_mb_batch_dev")
+
+
+def loop_filter_batch(base, stride, edges, n, stream=None):
+    return _lib.check(_lib.lib().ffhip_h264_loop_filter_batch_dev(base.data_ptr(), stride, edges.data_ptr(), n,
+                                                                  _stream(stream)), "ffhip_h264_loop_filter_batch_dev")
+
+
+def deblock_frame(luma, stride, mb_w, mb_h, edges, stream=None):
+    return _lib.check(_lib.lib().ffhip_h264_deblock_frame_dev(luma.data_ptr(), stride, mb_w, mb_h, edges.data_ptr(),
+                                                              _stream(stream)), "ffhip_h264_deblock_frame_dev")
+
+
+def qpel_batch(dst, src, stride, blocks, n, stream=None):
+    return _lib.check(_lib.lib().ffhip_h264_qpel_batch_dev(dst.data_ptr(), src.data_ptr(), stride, blocks.data_ptr(),
+                                                           n, _stream(stream)), "ffhip_h264_qpel_batch_dev")

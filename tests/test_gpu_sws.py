@@ -1,0 +1,204 @@
+"""GPU parity: HIP swscale kernels (through the C-ABI of libffhip.so) vs the oracle, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import PIX, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _upload(arrs, device="cuda:0", n=1):
+    """list of 2-D numpy planes -> list of [n, rows, pitch] cuda tensors (pitch = np stride)"""
+    torch = _torch()
+    out = []
+    for a in arrs:
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        out.append(t.unsqueeze(0).repeat(n, 1, 1).contiguous())
+    return out
+
+
+def _oracle_unscaled(src, w, h, bgr, coeffs=ffi.DEFAULT_COEFFS):
+    O = ffi.oracle()
+    luts = ffi.OLuts()
+    k = ffi.OYuv2RgbCoeffs(*[coeffs[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+    O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
+    out = np.zeros((h, 3 * w), np.uint8)
+    sp, ss = ffi.planes(src)
+    O.ffo_yuv420p_to_rgb24(C.byref(luts), w, sp, ss, 0, h, ptr(out), out.strides[0], bgr)
+    return out
+
+
+@pytest.mark.parametrize("w,h,pad", [(64, 16, 0), (1920, 1080, 0), (1078, 6, 0), (1076, 4, 3), (30, 2, 1),
+                                     (3840, 2160, 0), (2, 2, 0), (18, 4, 0)])
+@pytest.mark.parametrize("dst", ["rgb24", "bgr24"])
+def test_unscaled_yuv420p_rgb24(w, h, pad, dst):
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    rng = np.random.default_rng(w + h)
+    src = ffi.alloc_frame(PIX["yuv420p"], w, h, rng, pad=pad)
+    want = _oracle_unscaled(src, w, h, dst == "bgr24")
+    ctx = S.SwsContext(w, h, PIX["yuv420p"], w, h, PIX[dst], S.SWS_BICUBIC)
+    dsrc = _upload(src)
+    ddst = [torch.zeros((1, h, 3 * w + pad), dtype=torch.uint8, device="cuda:0")]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    got = ddst[0][0, :, :3 * w].cpu().numpy()
+    assert np.array_equal(got, want)
+    # host-pointer SwsFunc face, including a 2-line aligned slice
+    hd = np.zeros((h, 3 * w + pad), np.uint8)
+    assert ctx.scale(src, [hd]) == h
+    assert np.array_equal(hd[:, :3 * w], want)
+    if h >= 8:
+        hd2 = np.zeros_like(hd)
+        y0, hh = 2, 4
+        sl = [src[0][y0:], src[1][y0 // 2:], src[2][y0 // 2:]]
+        assert ctx.scale(sl, [hd2], y0, hh) == hh
+        assert np.array_equal(hd2[y0:y0 + hh, :3 * w], want[y0:y0 + hh]) and not hd2[:y0].any() and not hd2[y0 + hh:].any()
+    ctx.close()
+
+
+def test_unscaled_exhaustive_uv():
+    """all 65536 (U,V) pairs against a moving Y ramp"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    w, h = 512, 256
+    y = ((np.arange(w)[None, :] * 3 + np.arange(h)[:, None] * 7) & 255).astype(np.uint8)
+    u = np.tile(np.arange(256, dtype=np.uint8), (h // 2, 1)).copy()
+    v = np.tile((np.arange(128, dtype=np.uint8) * 2)[:, None], (1, w // 2)).copy()
+    v[:, ::2] += 1
+    src = [y, u, v]
+    want = _oracle_unscaled(src, w, h, 0)
+    ctx = S.SwsContext(w, h, 0, w, h, 2, 4)
+    ddst = [torch.zeros((1, h, 3 * w), dtype=torch.uint8, device="cuda:0")]
+    ctx.scale_batch(_upload(src), ddst)
+    assert np.array_equal(ddst[0][0].cpu().numpy(), want)
+
+
+SCALE_CASES = [
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_BICUBIC, 0),
+    ("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, 0),     # BASELINE configs[1], one frame
+    ("nv12", 160, 90, "nv12", 100, 62, ffi.SWS_BICUBIC, 3),
+    ("nv21", 96, 64, "nv21", 200, 130, ffi.SWS_BILINEAR, 0),
+    ("nv12", 96, 64, "nv21", 200, 130, ffi.SWS_BICUBIC, 1),
+    ("yuv420p", 128, 72, "yuv420p", 256, 144, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 101, 77, "yuv420p", 333, 191, ffi.SWS_BICUBIC, 5),
+    ("nv12", 128, 72, "yuv420p", 64, 36, ffi.SWS_AREA, 0),
+    ("yuv420p", 128, 72, "nv12", 128, 90, ffi.SWS_POINT, 0),
+    ("nv12", 1920, 1080, "nv12", 640, 360, ffi.SWS_BICUBIC, 0),       # 11-tap downscale
+    ("nv12", 192, 108, "nv12", 384, 216, 0x200, 0),                   # lanczos, 6 taps
+    ("nv12", 640, 360, "nv12", 640, 360, ffi.SWS_BICUBIC, 0),         # identity banks
+    ("yuv420p", 176, 144, "rgb24", 352, 288, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 176, 144, "bgr24", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND | ffi.SWS_BITEXACT, 0),
+    ("yuv420p", 176, 144, "rgb24", 176, 288, ffi.SWS_BILINEAR, 0),
+    ("nv12", 176, 144, "rgb24", 352, 288, ffi.SWS_BILINEAR, 2),
+    ("yuv420p", 352, 288, "rgb24", 120, 90, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 1920, 1080, "rgb24", 3840, 2160, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 1920, 1080, "rgb24", 1920, 1080, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
+]
+
+
+@pytest.mark.parametrize("case", SCALE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x_p%d" % c)
+def test_scaled(case):
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    sf, sw, sh, df, dw, dh, flags, pad = case
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=pad)
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    assert not ht.unscaled_yuv2rgb
+    t = ffi.make_otables(sw, sh, PIX[sf], dw, dh, PIX[df], flags, ht.banks(), ht.coeffs())
+    want = ffi.alloc_frame(PIX[df], dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(want)
+    assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+    ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    n = 3
+    dsrc = _upload(src, n=n)
+    ddst = [torch.zeros((n,) + a.shape[:1] + (a.shape[1] + pad,), dtype=torch.uint8, device="cuda:0") for a in want]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        for p, a in enumerate(want):
+            got = ddst[p][f, :, :a.shape[1]].cpu().numpy()
+            assert np.array_equal(got, a), "frame %d plane %d: %d mismatches" % (f, p, (got != a).sum())
+    if sw * sh <= 400 * 400:
+        hd = [np.zeros_like(a) for a in want]
+        assert ctx.scale(src, hd) == dh
+        for a, b in zip(hd, want):
+            assert np.array_equal(a, b)
+    ctx.close()
+
+
+def test_from_tables_dropin():
+    """drop-in construction: the banks are handed over (as FFmpeg would), not generated by us"""
+    from ffmpeg_amd import swscale as S, _lib
+    torch = _torch()
+    sw, sh, dw, dh = 96, 64, 192, 128
+    ht = S.HostTables(sw, sh, 23, dw, dh, 23, 4)
+    ctx = S.SwsContext(sw, sh, 23, dw, dh, 23, 4, tables=ht.t)
+    rng = np.random.default_rng(5)
+    src = ffi.alloc_frame(23, sw, sh, rng)
+    t = ffi.make_otables(sw, sh, 23, dw, dh, 23, 4, ht.banks(), ht.coeffs())
+    want = ffi.alloc_frame(23, dw, dh)
+    sp, ss = ffi.planes(src); dp, ds = ffi.planes(want)
+    ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds)
+    ddst = [torch.zeros((1,) + a.shape, dtype=torch.uint8, device="cuda:0") for a in want]
+    ctx.scale_batch(_upload(src), ddst)
+    for p, a in enumerate(want):
+        assert np.array_equal(ddst[p][0].cpu().numpy(), a)
+
+
+@pytest.mark.parametrize("fs", [1, 4, 8, 16, 40])
+def test_hscale_line_face(fs):
+    """checkasm-style adversarial coefficients through the per-line face"""
+    from ffmpeg_amd import _lib
+    torch = _torch()
+    L = _lib.lib()
+    dstW, srcW, nlines = 512, 560, 3
+    rng = np.random.default_rng(fs)
+    src = rng.integers(0, 256, (nlines, srcW), dtype=np.uint8)
+    filt = rng.integers(-(1 << 14), 1 << 14, (dstW, fs)).astype(np.int16)
+    filt[::3] = -((1 << 14) // max(fs - 1, 1))
+    filt[::3, 0] = (1 << 15) - 1
+    pos = np.sort(rng.integers(0, srcW - fs, dstW)).astype(np.int32)
+    want = np.zeros((nlines, dstW), np.int16)
+    for l in range(nlines):
+        ffi.oracle().ffo_hscale8to15(ptr(want[l], ffi.i16p), dstW, ptr(src[l]), ptr(filt, ffi.i16p), ptr(pos, ffi.i32p), fs)
+    d_src = torch.from_numpy(src).cuda(); d_f = torch.from_numpy(filt).cuda(); d_p = torch.from_numpy(pos).cuda()
+    d_out = torch.zeros((nlines, dstW), dtype=torch.int16, device="cuda:0")
+    _lib.check(L.ffhip_sws_hscale8to15_dev(d_out.data_ptr(), dstW, dstW * 2, d_src.data_ptr(), srcW, nlines,
+                                           d_f.data_ptr(), d_p.data_ptr(), fs, torch.cuda.current_stream().cuda_stream))
+    assert np.array_equal(d_out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("fs", [1, 2, 4, 16])
+def test_vscale_line_face(fs):
+    from ffmpeg_amd import _lib
+    torch = _torch()
+    L = _lib.lib()
+    dstW = 333
+    rng = np.random.default_rng(fs + 9)
+    lines = rng.integers(-32768, 32768, (fs, dstW + 3)).astype(np.int16)
+    filt = rng.integers(-4096, 8192, fs).astype(np.int16)
+    dither = rng.integers(0, 128, 8, dtype=np.uint8)
+    rows = (ffi.i16p * fs)(*[ptr(lines[j], ffi.i16p) for j in range(fs)])
+    for off in (0, 3):
+        want = np.zeros(dstW, np.uint8)
+        if fs == 1:
+            ffi.oracle().ffo_yuv2plane1_8(rows[0], ptr(want), dstW, ptr(dither), off)
+        else:
+            ffi.oracle().ffo_yuv2planeX8(ptr(filt, ffi.i16p), fs, rows, ptr(want), dstW, ptr(dither), off)
+        d_l = torch.from_numpy(lines).cuda(); d_f = torch.from_numpy(filt).cuda(); d_d = torch.from_numpy(dither).cuda()
+        d_o = torch.zeros(dstW, dtype=torch.uint8, device="cuda:0")
+        _lib.check(L.ffhip_sws_yuv2planeX8_dev(d_f.data_ptr(), fs, d_l.data_ptr(), lines.strides[0], d_o.data_ptr(), dstW,
+                                               d_d.data_ptr(), off, torch.cuda.current_stream().cuda_stream))
+        assert np.array_equal(d_o.cpu().numpy(), want)
