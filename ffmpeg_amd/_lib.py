@@ -49,6 +49,7 @@ def lib():
         "ffhip_sws_getContext": (vp, [C.c_int] * 7),
         "ffhip_sws_from_tables": (vp, [C.POINTER(SwsTables)]),
         "ffhip_sws_freeContext": (None, [vp]),
+        "ffhip_sws_fast_path": (C.c_int, [vp]),
         "ffhip_sws_tables_create": (vp, [C.c_int] * 7),
         "ffhip_sws_tables_get": (C.c_int, [vp, C.POINTER(SwsTables)]),
         "ffhip_sws_tables_is_unscaled_yuv2rgb": (C.c_int, [vp]),

@@ -1,0 +1,348 @@
+/*
+ * sws_colwalk.hip — the fast path of the fused H+V scaler for 4-tap x 4-tap banks (bicubic / bilinear
+ * up-scaling: BASELINE config "nv12 1080p -> 4K bicubic"), planar and NV12/NV21 in and out.
+ *
+ * Same arithmetic as sws_scale.hip (hScale8To15_c, libswscale/swscale.c:128-142; yuv2planeX_8_c /
+ * yuv2nv12cX_c, libswscale/output.c:468-529; nv12ToUV_c, input.c:936) but no LDS and no barrier:
+ *
+ *   one WAVE owns 64 lanes x 4 output columns (x NG groups) of a strip of output rows and walks DOWN
+ *   the source rows.  Per source row a lane loads the 8 source bytes its 4 columns read (its 4-tap
+ *   windows start within one dword-aligned 8-byte span: checked on the host, else the LDS-tiled kernel
+ *   runs), computes the 4 horizontal 15-bit samples with v_perm_b32 (bytes -> int16 pairs) +
+ *   v_dot2_i32_i16 against its register-resident coefficients, and keeps for every column the last
+ *   three vertically adjacent int16 PAIRS (h[r-3],h[r-2]) (h[r-2],h[r-1]) (h[r-1],h[r]).  An output row
+ *   whose 4-tap vertical window ends at r is then two more v_dot2 per sample from those pairs against
+ *   the row's (wave-uniform) coefficient pairs, v_ashr_pk_u8_i32 to shift/clamp/pack, one store.
+ *   The 15-bit intermediate lives in registers only; source rows are read once per strip (+3 halo
+ *   rows), HBM traffic = source in + destination out.
+ *
+ * Integer semantics are the reference's: int32 accumulation, >>7 and min(.,32767) then truncation to
+ * int16 for the horizontal pass; unsigned-wrapping int32 accumulation from 64<<12, >>19 (arithmetic),
+ * clip to u8 for the vertical pass.  v_dot2_i32_i16 without clamp is exactly that mod 2^32.
+ */
+#include "common.h"
+#include "sws_kernels.h"
+
+typedef short cw_short2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int cw_dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(cw_short2, a), __builtin_bit_cast(cw_short2, b), c, false);
+}
+
+/* {clip_u8(a >> 19), clip_u8(b >> 19)} in bits 0..15; bits 16..31 are unspecified (see common.h) */
+template <bool PLAIN>
+__device__ __forceinline__ uint32_t cw_pk_u8(int a, int b)
+{
+    uint32_t r;
+    if (PLAIN)
+        r = (uint32_t)clip_u8(a >> 19) | ((uint32_t)clip_u8(b >> 19) << 8);
+    else
+        asm("v_ashr_pk_u8_i32 %0, %1, %2, 19" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+struct CwRaw { uint32_t q[4]; };
+
+/* raw source bytes of one row for this lane: 8 or 16 bytes at row + byte_base (dword aligned) */
+template <int NRAW>
+__device__ __forceinline__ void cw_load(CwRaw &o, int slot, const uint8_t *row, uint32_t byte_base)
+{
+    if (NRAW == 16) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(row + byte_base);
+        o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w;
+    } else {
+        const uint2 w = *reinterpret_cast<const uint2 *>(row + byte_base);
+        o.q[slot] = w.x; o.q[slot + 1] = w.y;
+    }
+}
+
+/*
+ * One unit.  KIND 0: one plane, one 4-column group per lane.  KIND 1: one plane, two adjacent groups
+ * per lane.  KIND 2/3/4: a U/V pair, one group of each per lane — 2: interleaved -> interleaved,
+ * 3: interleaved -> planar, 4: planar -> interleaved (planar -> planar is two KIND 0/1 jobs).
+ * D = source rows in flight (prefetch depth), a multiple of 3 so that the ring of vertical pairs
+ * is indexed statically inside the unrolled row loop.
+ */
+template <int KIND, int D, bool PLAIN>
+__device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, int cb, int lane)
+{
+    constexpr int NG = KIND == 0 ? 1 : 2;           /* groups per lane                 */
+    constexpr int NH = KIND == 1 ? 2 : 1;           /* distinct horizontal descriptors */
+    const int y0 = strip * J.strip_rows;
+    const int y1 = min(y0 + J.strip_rows, J.dstH);
+
+    /* ---- per-lane horizontal descriptors ---------------------------------------------------- */
+    int X0[NH], base[NH];
+    uint32_t sel[NH][8], cf[NH][8];
+#pragma unroll
+    for (int g = 0; g < NH; g++) {
+        X0[g] = ((cb * 64 + lane) * NH + g) * 4;
+        int p[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int xi = min(X0[g] + i, J.dstW - 1);
+            p[i] = J.hp[xi];
+            const uint2 c = *reinterpret_cast<const uint2 *>(J.hf + (size_t)xi * 4);
+            cf[g][2 * i] = c.x;
+            cf[g][2 * i + 1] = c.y;
+        }
+        base[g] = min(min(p[0], p[1]), min(p[2], p[3])) & ~3;
+        /* the 8-byte span of the last lanes would cross the end of the row (srcW % 4 == 0, host-checked):
+         * slide it one dword left — only its upper dword holds bytes these columns select */
+        if (base[g] + 8 > J.srcW)
+            base[g] -= 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t o = (uint32_t)(p[i] - base[g]); /* 0..4, host-checked */
+            sel[g][2 * i]     = 0x0c000c00u | o | ((o + 1) << 16);
+            sel[g][2 * i + 1] = 0x0c000c00u | (o + 2) | ((o + 3) << 16);
+        }
+    }
+    const bool act = X0[0] < J.dstW;
+
+    /* ---- source / destination row addressing ----------------------------------------------- */
+    constexpr bool PAIR = KIND >= 2, sil = KIND == 2 || KIND == 3, dil = KIND == 2 || KIND == 4;
+    const uint8_t *s0 = J.src[0] + (size_t)f * J.sfp[0];
+    const uint8_t *s1 = PAIR ? J.src[1] + (size_t)f * J.sfp[1] : s0;
+    const ptrdiff_t sstride0 = J.sstride[0], sstride1 = J.sstride[1], dstride0 = J.dstride[0], dstride1 = J.dstride[1];
+    const int dstW = J.dstW;
+    /* NV21: V is the first byte of a pair — only the byte selectors change */
+    const uint32_t sel_u = J.src_swap ? 0x07050301u : 0x06040200u, sel_v = J.src_swap ? 0x06040200u : 0x07050301u;
+    const uint32_t sel_uv = J.dst_swap ? 0x04050001u : 0x05040100u;
+    /* unsigned lane offsets: uniform row pointer + 32-bit lane offset addressing */
+    const uint32_t bb0 = sil ? 2 * base[0] : base[0];
+    const uint32_t bb1 = KIND == 1 ? base[1] : bb0;
+
+    auto load_row = [&](CwRaw &o, int r) {
+        if (sil) {
+            cw_load<16>(o, 0, s0 + (ptrdiff_t)r * sstride0, bb0);
+        } else if (PAIR) {
+            cw_load<8>(o, 0, s0 + (ptrdiff_t)r * sstride0, bb0);
+            cw_load<8>(o, 2, s1 + (ptrdiff_t)r * sstride1, bb0);
+        } else {
+            cw_load<8>(o, 0, s0 + (ptrdiff_t)r * sstride0, bb0);
+            if (KIND == 1)
+                cw_load<8>(o, 2, s0 + (ptrdiff_t)r * sstride0, bb1);
+        }
+    };
+
+    /* ring of vertical pairs: slot (k % 3) receives (h[r-1], h[r]) of the row handled at unroll step k */
+    uint32_t Pw[3][NG][4];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                Pw[t][g][i] = 0;
+
+    auto hpass = [&](const CwRaw &w, uint32_t (&Pnew)[NG][4], const uint32_t (&Pprev)[NG][4]) {
+        uint32_t d[NG][2];
+        if (sil) {
+            /* de-interleave: even bytes -> first channel in memory, odd -> second (nv12ToUV_c) */
+            d[0][0] = __builtin_amdgcn_perm(w.q[1], w.q[0], sel_u);
+            d[0][1] = __builtin_amdgcn_perm(w.q[3], w.q[2], sel_u);
+            d[NG - 1][0] = __builtin_amdgcn_perm(w.q[1], w.q[0], sel_v);
+            d[NG - 1][1] = __builtin_amdgcn_perm(w.q[3], w.q[2], sel_v);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                d[g][0] = w.q[2 * g];
+                d[g][1] = w.q[2 * g + 1];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int hg = KIND == 1 ? g : 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t a = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i]);
+                const uint32_t b = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i + 1]);
+                int acc = cw_dot2(a, cf[hg][2 * i], 0);
+                acc = cw_dot2(b, cf[hg][2 * i + 1], acc);
+                const uint32_t h = (uint32_t)min(acc >> 7, 32767);
+                Pnew[g][i] = __builtin_amdgcn_perm(h, Pprev[g][i], 0x05040302); /* (prev.hi16, h.lo16) */
+            }
+        }
+    };
+
+    uint8_t *d0 = J.dst[0] + (size_t)f * J.dfp[0];
+    uint8_t *d1 = PAIR ? J.dst[1] + (size_t)f * J.dfp[1] : d0;
+    const uint32_t dc0 = (dil ? 2 : 1) * X0[0], dc1 = X0[0]; /* this lane's first byte of a row */
+
+    /* Pa = pairs (h[p], h[p+1]), Pb = (h[p+2], h[p+3]) of the row's window */
+    auto emit = [&](int y, uint32_t f01, uint32_t f23, const uint32_t (&Pa)[NG][4], const uint32_t (&Pb)[NG][4]) {
+        int v[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int acc = cw_dot2(Pa[g][i], f01, 64 << 12);
+                v[g][i] = cw_dot2(Pb[g][i], f23, acc);
+            }
+        if (dil) {
+            /* yuv2nv12cX_c: bytes U0 V0 U1 V1 ... (V first for NV21) */
+            constexpr int b = NG - 1;
+            const uint32_t k0 = cw_pk_u8<PLAIN>(v[0][0], v[b][0]), k1 = cw_pk_u8<PLAIN>(v[0][1], v[b][1]);
+            const uint32_t k2 = cw_pk_u8<PLAIN>(v[0][2], v[b][2]), k3 = cw_pk_u8<PLAIN>(v[0][3], v[b][3]);
+            uint2 w;
+            w.x = __builtin_amdgcn_perm(k1, k0, sel_uv);
+            w.y = __builtin_amdgcn_perm(k3, k2, sel_uv);
+            if (act)
+                *reinterpret_cast<uint2 *>(d0 + (ptrdiff_t)y * dstride0 + dc0) = w;
+        } else if (KIND == 1) {
+            /* two adjacent groups: one 8-byte store when both exist (dstW % 4 == 0, host-checked) */
+            uint2 w;
+            w.x = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[0][2], v[0][3]), cw_pk_u8<PLAIN>(v[0][0], v[0][1]), 0x05040100);
+            w.y = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[NG - 1][2], v[NG - 1][3]),
+                                        cw_pk_u8<PLAIN>(v[NG - 1][0], v[NG - 1][1]), 0x05040100);
+            uint8_t *d = d0 + (ptrdiff_t)y * dstride0 + dc0;
+            if (X0[0] + 8 <= dstW)
+                *reinterpret_cast<uint2 *>(d) = w;
+            else if (act)
+                *reinterpret_cast<uint32_t *>(d) = w.x;
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const uint32_t w = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[g][2], v[g][3]),
+                                                         cw_pk_u8<PLAIN>(v[g][0], v[g][1]), 0x05040100);
+                uint8_t *d = g ? d1 + (ptrdiff_t)y * dstride1 + dc1 : d0 + (ptrdiff_t)y * dstride0 + dc0;
+                if (act)
+                    *reinterpret_cast<uint32_t *>(d) = w;
+            }
+        }
+    };
+
+    /* ---- vertical descriptors of the strip's <= 128 output rows: two registers each, read by v_readlane.
+     * Loaded before the row loop so that no vector-memory wait inside it has to drain the prefetches. ---- */
+    int vpl[2];
+    uint32_t vf01[2], vf23[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int y = min(y0 + 64 * k + lane, J.dstH - 1);
+        vpl[k] = J.vp[y];
+        const uint2 c = *reinterpret_cast<const uint2 *>(J.vf + (size_t)y * 4);
+        vf01[k] = c.x;
+        vf23[k] = c.y;
+    }
+
+    /* ---- walk down the source rows ------------------------------------------------------------ */
+    const int ny = y1 - y0;
+    int yy = 0; /* next output row of the strip to emit */
+    int need = __builtin_amdgcn_readlane(vpl[0], 0) + 3;
+    const int rlast = __builtin_amdgcn_readfirstlane(J.vp[y1 - 1]) + 3;
+    int r = need - 3;
+    CwRaw buf[D];
+#pragma unroll
+    for (int k = 0; k < D; k++)
+        load_row(buf[k], min(r + k, rlast));
+    for (; r <= rlast; r += D) {
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const int rr = r + k;
+            /* the prefetch is unconditional (its row index is clamped): a load under the branch would be
+             * copied into place after it, and that copy would wait for the load just issued */
+            const CwRaw cur = buf[k];
+            load_row(buf[k], min(rr + D, rlast));
+            if (rr <= rlast) {
+                hpass(cur, Pw[k % 3], Pw[(k + 2) % 3]);
+                while (yy < ny && need <= rr) {
+                    const bool hi = yy >= 64;
+                    const int ll = yy & 63;
+                    const uint32_t f01 = __builtin_amdgcn_readlane(hi ? vf01[1] : vf01[0], ll);
+                    const uint32_t f23 = __builtin_amdgcn_readlane(hi ? vf23[1] : vf23[0], ll);
+                    emit(y0 + yy, f01, f23, Pw[(k + 1) % 3], Pw[k % 3]);
+                    yy++;
+                    if (yy < ny)
+                        need = __builtin_amdgcn_readlane(yy >= 64 ? vpl[1] : vpl[0], yy & 63) + 3;
+                }
+            }
+        }
+    }
+}
+
+template <int LK, int D, bool PLAIN>
+__global__ __launch_bounds__(256) void k_sws_colwalk(FFHipCwArgs A)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    if (gw >= (long long)A.units_per_frame * A.nframes)
+        return;
+    const int f = (int)(gw / A.units_per_frame);
+    const int u = (int)(gw - (long long)f * A.units_per_frame);
+    int j = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
+    const FFHipCwJob &J = A.job[j];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.kind == 2)
+        cw_unit<2, D, PLAIN>(J, f, strip, cb, lane);
+    else if (J.kind == 3)
+        cw_unit<3, D, PLAIN>(J, f, strip, cb, lane);
+    else if (J.kind == 4)
+        cw_unit<4, D, PLAIN>(J, f, strip, cb, lane);
+    else
+        cw_unit<LK, D, PLAIN>(J, f, strip, cb, lane);
+}
+
+/* ---- host side ---------------------------------------------------------------------------------- */
+/* can a bank pair run on the column walker?  hpos/vpos are host copies. */
+int ffhip_cw_bank_ok(const int32_t *hpos, int hsize, int hn, int srcW, const int32_t *vpos, int vsize, int vn, int srcH)
+{
+    if (hsize != 4 || vsize != 4 || hn <= 0 || (hn & 3) || vn <= 0 || srcW < 8 || (srcW & 3) || srcH < 4)
+        return 0;
+    for (int x0 = 0; x0 < hn; x0 += 4) {
+        int lo = hpos[x0], hi = hpos[x0];
+        for (int i = 1; i < 4; i++) {
+            const int p = hpos[x0 + i < hn ? x0 + i : hn - 1];
+            if (p < lo) lo = p;
+            if (p > hi) hi = p;
+        }
+        if (lo < 0 || hi + 4 > srcW || hi + 3 - (lo & ~3) > 7)
+            return 0;
+    }
+    for (int y = 0; y < vn; y++) {
+        if (vpos[y] < 0 || vpos[y] + 4 > srcH || (y && vpos[y] < vpos[y - 1]))
+            return 0;
+    }
+    return 1;
+}
+
+void ffhip_cw_plan_job(FFHipCwJob *j, int groups_per_lane, int strip_target)
+{
+    const int cols_per_wave = 256 * groups_per_lane;
+    j->ncb = cdiv(j->dstW, cols_per_wave);
+    /* strips of about strip_target (<= 128) output rows, evened out; each strip re-reads 3 halo source rows */
+    if (strip_target > 128) strip_target = 128;
+    const int n = cdiv(j->dstH, strip_target > 0 ? strip_target : 1);
+    j->strip_rows = cdiv(j->dstH, n);
+    j->nstrips = cdiv(j->dstH, j->strip_rows);
+}
+
+int ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    int u = 0;
+    for (int i = 0; i < A.njobs; i++) {
+        A.job[i].unit_begin = u;
+        u += A.job[i].ncb * A.job[i].nstrips;
+    }
+    A.units_per_frame = u;
+    const long long waves = (long long)u * A.nframes;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (A.flags & 1) {
+        hipLaunchKernelGGL((k_sws_colwalk<0, 3, true>), grid, block, 0, stream, A);
+    } else if (luma_groups == 2) {
+        if (depth == 6) hipLaunchKernelGGL((k_sws_colwalk<1, 6, false>), grid, block, 0, stream, A);
+        else            hipLaunchKernelGGL((k_sws_colwalk<1, 3, false>), grid, block, 0, stream, A);
+    } else {
+        if (depth == 6) hipLaunchKernelGGL((k_sws_colwalk<0, 6, false>), grid, block, 0, stream, A);
+        else            hipLaunchKernelGGL((k_sws_colwalk<0, 3, false>), grid, block, 0, stream, A);
+    }
+    LAUNCH_CHECK();
+    return 0;
+}

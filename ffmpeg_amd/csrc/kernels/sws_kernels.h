@@ -56,6 +56,31 @@ int ffhip_launch_scale_yuv(const FFHipScalePlaneArgs &lum, const FFHipScalePlane
 /* picks tw/th/max_* for a bank pair from HOST copies of the position tables */
 int ffhip_plan_scale_plane(FFHipScalePlaneArgs *a, int channels, const int32_t *hpos_host, const int32_t *vpos_host);
 
+
+/*
+ * Column-walking fast path (sws_colwalk.hip) for 4-tap x 4-tap banks.  A launch runs up to three
+ * jobs: kind 0/1 = one plane (1 or 2 column groups per lane), kind 2/3/4 = a U/V pair that is
+ * byte-interleaved (NV12/NV21) on both sides / on the source only / on the destination only.
+ */
+struct FFHipCwJob {
+    const uint8_t *src[2];  /* kind 2: U,V planes, or src[0] = the interleaved plane when src_il   */
+    uint8_t *dst[2];
+    ptrdiff_t sstride[2], dstride[2];
+    size_t sfp[2], dfp[2];
+    int kind, src_swap, dst_swap;               /* *_swap: V is the first byte (NV21)             */
+    int srcW, srcH, dstW, dstH;                   /* in samples of this channel                      */
+    const int16_t *hf; const int32_t *hp;         /* device banks                                    */
+    const int16_t *vf; const int32_t *vp;
+    int ncb, nstrips, strip_rows, unit_begin;
+};
+struct FFHipCwArgs {
+    FFHipCwJob job[3];
+    int njobs, units_per_frame, nframes, flags;   /* flags bit0: plain shift/clamp instead of v_ashr_pk_u8_i32 */
+};
+int  ffhip_cw_bank_ok(const int32_t *hpos, int hsize, int hn, int srcW, const int32_t *vpos, int vsize, int vn, int srcH);
+void ffhip_cw_plan_job(FFHipCwJob *j, int groups_per_lane, int strip_target);
+int  ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t stream);
+
 /* Fused H+V scaling + yuv2rgb for packed rgb24/bgr24 output (yuv2rgb{1,2,X} dispatch in-kernel). */
 struct FFHipScaleRgbArgs {
     const uint8_t *src[3];      /* Y, U, V (U/V may alias an interleaved plane with chr_step 2) */

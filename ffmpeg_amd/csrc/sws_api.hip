@@ -8,6 +8,7 @@
  */
 #include <mutex>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -25,6 +26,7 @@ struct FFHipSwsContext {
     int chrSrcW, chrSrcH;
     FFHipScalePlaneArgs lum, chr;
     FFHipScaleRgbArgs rgb;
+    int cw_ok = 0; /* both bank pairs fit the column-walking fast path (sws_colwalk.hip) */
     /* staging for the host-pointer face */
     void *stage = nullptr;
     size_t stage_sz = 0;
@@ -148,6 +150,10 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         r = ffhip_plan_scale_plane(&l, 1, c->p[0].data(), c->p[2].data());
         if (!r)
             r = ffhip_plan_scale_plane(&ch, 2, c->p[1].data(), c->p[3].data());
+        c->cw_ok = ffhip_cw_bank_ok(c->p[0].data(), c->d[0].size, c->d[0].n, l.srcW, c->p[2].data(), c->d[2].size,
+                                    c->d[2].n, l.srcH) &&
+                   ffhip_cw_bank_ok(c->p[1].data(), c->d[1].size, c->d[1].n, ch.srcW, c->p[3].data(), c->d[3].size,
+                                    c->d[3].n, ch.srcH);
     }
     if (r < 0) {
         ffhip_sws_freeContext(c);
@@ -168,6 +174,8 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
     ffhip_sws_tables_free(h);
     return c;
 }
+
+extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c) { return c ? c->cw_ok : 0; }
 
 extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
 {
@@ -245,6 +253,72 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         ch.dst_step = 1;
     }
     ch.nframes = nframes;
+
+    /* fast path: 4x4-tap banks, dword-aligned planes.  FFHIP_SWS_FAST=0 forces the LDS-tiled kernel;
+     * FFHIP_CW_LUMA_GROUPS / FFHIP_CW_PLAIN select measured variants. */
+    const char *ev = getenv("FFHIP_SWS_FAST");
+    if (c->cw_ok && !(ev && ev[0] == '0')) {
+        uintptr_t al = 0;
+        for (int i = 0; i < 2; i++) {
+            al |= (uintptr_t)l.src[i] | (size_t)l.src_stride[i] | l.src_fp[i] | (uintptr_t)l.dst[i] |
+                  (size_t)l.dst_stride[i] | l.dst_fp[i];
+            al |= (size_t)ch.src_stride[i] | ch.src_fp[i] | (size_t)ch.dst_stride[i] | ch.dst_fp[i];
+            /* an interleaved pair is addressed through its lower pointer */
+            al |= ch.src_step == 2 ? (uintptr_t)(ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1]) : (uintptr_t)ch.src[i];
+            al |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
+        }
+        if (!(al & 3)) {
+            const char *eg = getenv("FFHIP_CW_LUMA_GROUPS"), *ep = getenv("FFHIP_CW_PLAIN");
+            const char *ed = getenv("FFHIP_CW_DEPTH"), *es = getenv("FFHIP_CW_STRIP");
+            const int lg = (eg && eg[0] == '2') && !(ep && ep[0] == '1') ? 2 : 1;
+            const int depth = ed && ed[0] == '6' ? 6 : 3;
+            const int strip = es && atoi(es) > 0 ? atoi(es) : 120;
+            FFHipCwArgs A;
+            memset(&A, 0, sizeof(A));
+            A.nframes = nframes;
+            A.flags = ep && ep[0] == '1' ? 1 : 0;
+            auto bank = [&](FFHipCwJob &j, const FFHipScalePlaneArgs &p) {
+                j.srcW = p.srcW; j.srcH = p.srcH; j.dstW = p.dstW; j.dstH = p.dstH;
+                j.hf = p.h.filter; j.hp = p.h.pos; j.vf = p.v.filter; j.vp = p.v.pos;
+            };
+            FFHipCwJob &jl = A.job[0];
+            bank(jl, l);
+            jl.kind = lg == 2 ? 1 : 0;
+            jl.src[0] = l.src[0]; jl.sstride[0] = l.src_stride[0]; jl.sfp[0] = l.src_fp[0];
+            jl.dst[0] = l.dst[0]; jl.dstride[0] = l.dst_stride[0]; jl.dfp[0] = l.dst_fp[0];
+            ffhip_cw_plan_job(&jl, lg, strip);
+            A.njobs = 1;
+            if (ch.src_step == 1 && ch.dst_step == 1) {
+                for (int k = 0; k < 2; k++) {
+                    FFHipCwJob &j = A.job[A.njobs++];
+                    bank(j, ch);
+                    j.kind = jl.kind;
+                    j.src[0] = ch.src[k]; j.sstride[0] = ch.src_stride[k]; j.sfp[0] = ch.src_fp[k];
+                    j.dst[0] = ch.dst[k]; j.dstride[0] = ch.dst_stride[k]; j.dfp[0] = ch.dst_fp[k];
+                    ffhip_cw_plan_job(&j, lg, strip);
+                }
+            } else {
+                FFHipCwJob &j = A.job[A.njobs++];
+                bank(j, ch);
+                const bool src_il = ch.src_step == 2, dst_il = ch.dst_step == 2;
+                j.kind = src_il && dst_il ? 2 : src_il ? 3 : 4;
+                for (int k = 0; k < 2; k++) {
+                    j.src[k] = ch.src[k]; j.sstride[k] = ch.src_stride[k]; j.sfp[k] = ch.src_fp[k];
+                    j.dst[k] = ch.dst[k]; j.dstride[k] = ch.dst_stride[k]; j.dfp[k] = ch.dst_fp[k];
+                }
+                if (src_il) {
+                    j.src_swap = ch.src[1] < ch.src[0];
+                    j.src[0] = j.src_swap ? ch.src[1] : ch.src[0];
+                }
+                if (dst_il) {
+                    j.dst_swap = ch.dst[1] < ch.dst[0];
+                    j.dst[0] = j.dst_swap ? ch.dst[1] : ch.dst[0];
+                }
+                ffhip_cw_plan_job(&j, 1, strip);
+            }
+            return ffhip_launch_colwalk(A, lg, depth, stream);
+        }
+    }
     return ffhip_launch_scale_yuv(l, ch, stream);
 }
 

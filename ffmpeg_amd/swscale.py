@@ -92,6 +92,11 @@ class SwsContext:
         if not self._c:
             raise ValueError(L.ffhip_last_error().decode())
 
+    @property
+    def fast_path(self):
+        """True when the banks run on the column-walking kernel (ffhip_sws_fast_path)."""
+        return bool(_lib.lib().ffhip_sws_fast_path(self._c))
+
     def close(self):
         if getattr(self, "_c", None) and _lib is not None:
             _lib.lib().ffhip_sws_freeContext(self._c)

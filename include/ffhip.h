@@ -109,6 +109,10 @@ FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcFormat,
 /** Drop-in construction from FFmpeg's own tables (no filter generation on our side). */
 FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t);
 void             ffhip_sws_freeContext(FFHipSwsContext *c);
+/** 1 when the context's banks run on the register-resident column-walking kernel (4-tap x 4-tap banks
+ *  whose 4-column groups read one 8-byte source span; sws_colwalk.hip), 0 when they take the general
+ *  LDS-tiled kernel.  Diagnostic only: results are identical. */
+int              ffhip_sws_fast_path(const FFHipSwsContext *c);
 
 /** Host-table generation alone (no device needed): our initFilter().  `which`: 0 hLum 1 hChr 2 vLum
  *  3 vChr.  Returns filter size or <0; pointers stay valid until ffhip_sws_tables_free().  Used by

@@ -1,0 +1,161 @@
+"""GPU parity of the column-walking fast path of the scaler (sws_colwalk.hip) vs the oracle, bit-exact.
+
+Every case must actually take the fast path (ctx.fast_path) and is run in each measured variant
+(FFHIP_CW_LUMA_GROUPS / FFHIP_CW_DEPTH / FFHIP_CW_PLAIN / FFHIP_CW_STRIP) and, as a cross-check of the
+two kernels against each other, with the fast path disabled (FFHIP_SWS_FAST=0)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import PIX, ptr
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [
+    {},
+    {"FFHIP_CW_LUMA_GROUPS": "2"},
+    {"FFHIP_CW_DEPTH": "6"},
+    {"FFHIP_CW_LUMA_GROUPS": "2", "FFHIP_CW_DEPTH": "6", "FFHIP_CW_STRIP": "37"},
+    {"FFHIP_CW_PLAIN": "1"},
+    {"FFHIP_CW_STRIP": "128"},
+    {"FFHIP_SWS_FAST": "0"},
+]
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _upload_aligned(arrs, n, rng):
+    """planes -> [n, rows, pitch] cuda tensors with a 64-byte aligned pitch and DIFFERENT frames"""
+    torch = _torch()
+    out, host = [], []
+    for a in arrs:
+        pitch = (a.shape[1] + 63) // 64 * 64
+        h = rng.integers(0, 256, (n, a.shape[0], pitch), dtype=np.uint8)
+        h[0, :, :a.shape[1]] = a
+        host.append(h)
+        out.append(torch.from_numpy(h).to("cuda:0"))
+    return out, host
+
+
+def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, n=3, seed=1):
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    rng = np.random.default_rng(seed)
+    for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    if banks is None:
+        banks = ht.banks()
+    t = ffi.make_otables(sw, sh, PIX[sf], dw, dh, PIX[df], flags, banks, ht.coeffs())
+    tabs = None
+    if banks is not None:
+        from ffmpeg_amd import _lib
+        tabs = _lib.SwsTables()
+        C.memmove(C.byref(tabs), C.byref(ht.t), C.sizeof(tabs))
+        keep = []
+        for name in ("hLum", "hChr", "vLum", "vChr"):
+            f, p, fs, nn = banks[name]
+            f = np.ascontiguousarray(f, np.int16); p = np.ascontiguousarray(p, np.int32)
+            keep += [f, p]
+            setattr(tabs, name, _lib.SwsFilter(ptr(f, ffi.i16p), ptr(p, ffi.i32p), fs, nn))
+    ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags, tables=tabs)
+    assert ctx.fast_path, "case does not reach the column walker"
+    first = ffi.alloc_frame(PIX[sf], sw, sh, rng)
+    dsrc, hsrc = _upload_aligned(first, n, rng)
+    shapes = S.plane_shapes(PIX[df], dw, dh)
+    ddst = [torch.full((n, r, (c + 63) // 64 * 64), 0xA5, dtype=torch.uint8, device="cuda:0") for r, c in shapes]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        src = [h[f, :, :a.shape[1]] for h, a in zip(hsrc, first)]
+        src = [np.ascontiguousarray(a) for a in src]
+        want = ffi.alloc_frame(PIX[df], dw, dh)
+        sp, ss = ffi.planes(src)
+        dp, ds = ffi.planes(want)
+        assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+        for p, a in enumerate(want):
+            got = ddst[p][f].cpu().numpy()
+            assert np.array_equal(got[:, :a.shape[1]], a), "frame %d plane %d: %d mismatches" % (
+                f, p, (got[:, :a.shape[1]] != a).sum())
+            assert (got[:, a.shape[1]:] == 0xA5).all(), "wrote past the row end"
+    ctx.close()
+
+
+CASES = [
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_BICUBIC),
+    ("nv21", 192, 108, "nv21", 384, 216, ffi.SWS_BICUBIC),
+    ("nv12", 192, 108, "nv21", 384, 216, ffi.SWS_BICUBIC),
+    ("nv12", 64, 40, "yuv420p", 192, 104, ffi.SWS_BICUBIC),          # interleaved -> planar, 3x / 2.6x
+    ("yuv420p", 128, 72, "nv12", 256, 144, ffi.SWS_BICUBIC),         # planar -> interleaved
+    ("yuv420p", 128, 72, "nv21", 384, 216, ffi.SWS_BICUBIC),
+    ("yuv420p", 128, 72, "yuv420p", 256, 144, ffi.SWS_BICUBIC),      # planar -> planar: three single-plane jobs
+    ("nv12", 1048, 600, "nv12", 2096, 1416, ffi.SWS_BICUBIC),        # several column blocks and strips, ragged last block
+    ("nv12", 16, 8, "nv12", 32, 16, ffi.SWS_BICUBIC),                # a single partial wave
+]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % (k[6:], v) for k, v in e.items()) or "default")
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_fast_path(case, env, monkeypatch):
+    _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF)
+
+
+def test_fast_path_full_size(monkeypatch):
+    """BASELINE configs[1] frame size, two different frames"""
+    _run("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=77)
+    _run("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, env={"FFHIP_CW_LUMA_GROUPS": "2", "FFHIP_CW_DEPTH": "6"},
+         monkeypatch=monkeypatch, n=2, seed=78)
+
+
+def _adversarial_banks(rng, srcW, srcH, dstW, dstH, extreme):
+    """4x4-tap banks with arbitrary (eligible) positions and full-range int16 coefficients: the
+    checkasm recipe (tests/checkasm/sw_scale.c:356-458) pushed through the fused kernel."""
+    def hbank(n, sw):
+        pos = np.zeros(n, np.int32)
+        for g in range(0, n, 4):
+            base = int(rng.integers(0, (sw - 8) // 4 + 1)) * 4
+            lo = int(rng.integers(0, 5))
+            pos[g:g + 4] = base + np.sort(rng.integers(lo, 5, 4))
+        pos = np.minimum(pos, sw - 4)
+        if extreme:
+            f = rng.integers(-32768, 32768, (n, 4)).astype(np.int16)
+            f[::3] = -((1 << 14) // 3)
+            f[::3, 0] = (1 << 15) - 1
+            f[1::7] = 32767
+            f[2::7] = -32768
+        else:
+            f = rng.integers(-3000, 9000, (n, 4)).astype(np.int16)
+        return (f.reshape(-1), pos, 4, n)
+
+    def vbank(n, sh):
+        steps = rng.integers(0, 3, n)
+        pos = np.minimum(np.cumsum(steps), sh - 4).astype(np.int32)
+        if extreme:
+            f = rng.integers(-32768, 32768, (n, 4)).astype(np.int16)
+            f[::5] = 32767
+            f[1::5] = -32768
+        else:
+            f = rng.integers(-1500, 4000, (n, 4)).astype(np.int16)
+        return (f.reshape(-1), pos, 4, n)
+    return {"hLum": hbank(dstW, srcW), "hChr": hbank(dstW // 2, srcW // 2), "vLum": vbank(dstH, srcH),
+            "vChr": vbank(dstH // 2, srcH // 2)}
+
+
+@pytest.mark.parametrize("extreme", [0, 1])
+@pytest.mark.parametrize("env", [{}, {"FFHIP_CW_LUMA_GROUPS": "2", "FFHIP_CW_DEPTH": "6"}, {"FFHIP_CW_PLAIN": "1"}],
+                         ids=["default", "g2d6", "plain"])
+@pytest.mark.parametrize("fmts", [("nv12", "nv12"), ("yuv420p", "nv21"), ("nv21", "yuv420p"), ("yuv420p", "yuv420p")])
+def test_fast_path_adversarial_tables(fmts, env, extreme, monkeypatch):
+    sw, sh, dw, dh = 200, 120, 520, 300
+    rng = np.random.default_rng(extreme * 100 + len(env))
+    banks = _adversarial_banks(rng, sw, sh, dw, dh, extreme)
+    _run(fmts[0], sw, sh, fmts[1], dw, dh, ffi.SWS_BICUBIC, banks=banks, env=env, monkeypatch=monkeypatch, n=2,
+         seed=extreme + 5)
