@@ -267,11 +267,11 @@ __global__ __launch_bounds__(256) void k_sws_colwalk(FFHipCwArgs A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const long long gw = (long long)blockIdx.x * 4 + wave;
-    if (gw >= (long long)A.units_per_frame * A.nframes)
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave; /* < 2^31, checked by the launcher */
+    if (gw >= (uint32_t)A.units_per_frame * (uint32_t)A.nframes)
         return;
-    const int f = (int)(gw / A.units_per_frame);
-    const int u = (int)(gw - (long long)f * A.units_per_frame);
+    const int f = (int)(gw / (uint32_t)A.units_per_frame);
+    const int u = (int)(gw - (uint32_t)f * (uint32_t)A.units_per_frame);
     int j = 0;
     if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
     if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
@@ -333,6 +333,10 @@ int ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t
     }
     A.units_per_frame = u;
     const long long waves = (long long)u * A.nframes;
+    if (waves >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
+        return FFHIP_EINVAL;
+    }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (A.flags & 1) {
         hipLaunchKernelGGL((k_sws_colwalk<0, 3, true>), grid, block, 0, stream, A);

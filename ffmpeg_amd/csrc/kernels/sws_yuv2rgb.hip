@@ -15,6 +15,8 @@
  * 8-B chroma loads, six 16-B stores; a wave covers 1024 consecutive pixels of a row pair.
  * Pixels written per row: width & ~1 (the reference's 8/4/2-pixel loop never writes an odd tail).
  */
+#include <stdlib.h>
+
 #include "common.h"
 #include "sws_kernels.h"
 
@@ -113,6 +115,126 @@ __global__ __launch_bounds__(256) void k_yuv420p_rgb24(FFHipYuv2RgbArgs a)
     }
 }
 
+
+/*
+ * The streaming kernel proper (VEC planes, any width): one WAVE converts a run of up to 64 x 16
+ * pixels of a row pair.  A lane computes its 16 x 2 pixels as before, but the 48 output bytes per row
+ * do not go to memory from the lane that made them (that is a 16-byte store every 48 bytes, three
+ * partial touches of every 128-byte line): they are transposed through a wave-private 3 KiB LDS tile
+ * so that each global_store_dwordx4 of the wave writes 1 KiB of CONTIGUOUS destination.
+ * Shift + clamp + pack is v_ashr_pk_u8_i32 (two channels per instruction), byte pairs are merged with
+ * v_perm_b32; PLAIN keeps the explicit shift/clamp form of the same arithmetic.
+ */
+template <bool PLAIN>
+__device__ __forceinline__ uint32_t pk16(int a, int b)
+{
+    uint32_t r;
+    if (PLAIN)
+        r = (uint32_t)clip_u8(a >> 16) | ((uint32_t)clip_u8(b >> 16) << 8);
+    else
+        asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool BGR, bool PLAIN>
+__global__ __launch_bounds__(256) void k_yuv420p_rgb24_t(FFHipYuv2RgbArgs a)
+{
+    __shared__ uint4 tile[4][192];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int chunks = (a.wvalid + 15) >> 4;
+    const int wpr = (chunks + 63) >> 6; /* waves per row pair */
+    const int rowpairs = a.h >> 1;
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave; /* < 2^31, checked by the launcher */
+    if (gw >= (uint32_t)wpr * (uint32_t)rowpairs * (uint32_t)a.nframes)
+        return;
+    const int wr = (int)(gw % (uint32_t)wpr);
+    const int rp = (int)((gw / (uint32_t)wpr) % (uint32_t)rowpairs);
+    const int f = (int)(gw / ((uint32_t)wpr * (uint32_t)rowpairs));
+    const int x0 = (wr * 64 + lane) << 4;
+    const bool full = x0 + 16 <= a.wvalid;
+    const int nfull = min(max((a.wvalid >> 4) - wr * 64, 0), 64); /* whole 16-pixel chunks of this wave */
+
+    const uint8_t *py0 = a.y + (size_t)f * a.y_fp + (ptrdiff_t)(2 * rp) * a.y_stride;
+    const uint8_t *py1 = py0 + a.y_stride;
+    const uint8_t *pu = a.u + (size_t)f * a.u_fp + (ptrdiff_t)rp * a.u_stride;
+    const uint8_t *pv = a.v + (size_t)f * a.v_fp + (ptrdiff_t)rp * a.v_stride;
+    uint8_t *d0 = a.dst + (size_t)f * a.dst_fp + (ptrdiff_t)(2 * rp + a.dst_y0) * a.dst_stride;
+    uint8_t *d1 = d0 + a.dst_stride;
+    const FFHipYuv2RgbK k = a.k;
+    uint4 *my = tile[wave];
+
+    uint32_t o0[12], o1[12];
+    if (full) {
+        const uint4 y0v = *reinterpret_cast<const uint4 *>(py0 + (uint32_t)x0);
+        const uint4 y1v = *reinterpret_cast<const uint4 *>(py1 + (uint32_t)x0);
+        const uint2 uv = *reinterpret_cast<const uint2 *>(pu + (uint32_t)(x0 >> 1));
+        const uint2 vv = *reinterpret_cast<const uint2 *>(pv + (uint32_t)(x0 >> 1));
+        const uint32_t yw0[4] = { y0v.x, y0v.y, y0v.z, y0v.w };
+        const uint32_t yw1[4] = { y1v.x, y1v.y, y1v.z, y1v.w };
+        const uint32_t uw[2] = { uv.x, uv.y }, vw[2] = { vv.x, vv.y };
+        int v0[48], v1[48]; /* pre-shift value of every output byte of the two rows */
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int U = (uw[m >> 2] >> (8 * (m & 3))) & 0xFF;
+            const int V = (vw[m >> 2] >> (8 * (m & 3))) & 0xFF;
+            const Bases b = chroma_bases(k, U, V);
+            const int c0 = BGR ? b.b : b.r, c2 = BGR ? b.r : b.b;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int p = 2 * m + e;
+                const int Y0 = (yw0[p >> 2] >> (8 * (p & 3))) & 0xFF;
+                const int Y1 = (yw1[p >> 2] >> (8 * (p & 3))) & 0xFF;
+                v0[3 * p] = Y0 * k.cy + c0; v0[3 * p + 1] = Y0 * k.cy + b.g; v0[3 * p + 2] = Y0 * k.cy + c2;
+                v1[3 * p] = Y1 * k.cy + c0; v1[3 * p + 1] = Y1 * k.cy + b.g; v1[3 * p + 2] = Y1 * k.cy + c2;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 12; d++) {
+            o0[d] = __builtin_amdgcn_perm(pk16<PLAIN>(v0[4 * d + 2], v0[4 * d + 3]), pk16<PLAIN>(v0[4 * d], v0[4 * d + 1]),
+                                          0x05040100);
+            o1[d] = __builtin_amdgcn_perm(pk16<PLAIN>(v1[4 * d + 2], v1[4 * d + 3]), pk16<PLAIN>(v1[4 * d], v1[4 * d + 1]),
+                                          0x05040100);
+        }
+    }
+    const uint32_t run = (uint32_t)wr * 3072u; /* byte offset of this wave's run in a destination row */
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+        const uint32_t *o = row ? o1 : o0;
+        if (full) {
+            my[3 * lane + 0] = make_uint4(o[0], o[1], o[2], o[3]);
+            my[3 * lane + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+            my[3 * lane + 2] = make_uint4(o[8], o[9], o[10], o[11]);
+        }
+        wave_sync_lds();
+        uint8_t *drow = (row ? d1 : d0) + run;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int p = lane + 64 * j;
+            if (p < 3 * nfull)
+                *reinterpret_cast<uint4 *>(drow + 16u * (uint32_t)p) = my[p];
+        }
+        wave_sync_lds();
+    }
+    if (!full && x0 < a.wvalid) { /* the ragged last chunk of a row: straight to memory */
+        const int npairs = (a.wvalid - x0) >> 1;
+        for (int m = 0; m < npairs; m++) {
+            const Bases b = chroma_bases(k, pu[(x0 >> 1) + m], pv[(x0 >> 1) + m]);
+            put_px<BGR>(d0 + 3 * x0 + 6 * m,     b, py0[x0 + 2 * m] * k.cy);
+            put_px<BGR>(d0 + 3 * x0 + 6 * m + 3, b, py0[x0 + 2 * m + 1] * k.cy);
+            put_px<BGR>(d1 + 3 * x0 + 6 * m,     b, py1[x0 + 2 * m] * k.cy);
+            put_px<BGR>(d1 + 3 * x0 + 6 * m + 3, b, py1[x0 + 2 * m + 1] * k.cy);
+        }
+    }
+}
+
 int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int bgr, hipStream_t stream)
 {
     const int chunks = (a.wvalid + 15) >> 4;
@@ -123,7 +245,23 @@ int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int bgr, hipStream_t s
                         a.dst_fp) & 15) &&
                      !(((uintptr_t)a.u | (uintptr_t)a.v | (size_t)a.u_stride | (size_t)a.v_stride | a.u_fp | a.v_fp) & 7) &&
                      a.dst_stride > 0;
-    const dim3 block(256), grid((unsigned)((total + 255) / 256));
+    const dim3 block(256);
+    const char *ev = getenv("FFHIP_YUV2RGB_VARIANT"); /* "old": per-lane strided stores; "plain": no v_ashr_pk */
+    const long long waves = (long long)((chunks + 63) >> 6) * (a.h >> 1) * a.nframes;
+    if (vec && waves < (1LL << 31) && !(ev && ev[0] == 'o')) {
+        const dim3 grid((unsigned)((waves + 3) / 4));
+        const bool plain = ev && ev[0] == 'p';
+        if (bgr) {
+            if (plain) hipLaunchKernelGGL((k_yuv420p_rgb24_t<true, true>), grid, block, 0, stream, a);
+            else       hipLaunchKernelGGL((k_yuv420p_rgb24_t<true, false>), grid, block, 0, stream, a);
+        } else {
+            if (plain) hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, true>), grid, block, 0, stream, a);
+            else       hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false>), grid, block, 0, stream, a);
+        }
+        LAUNCH_CHECK();
+        return 0;
+    }
+    const dim3 grid((unsigned)((total + 255) / 256));
     if (bgr) {
         if (vec) hipLaunchKernelGGL((k_yuv420p_rgb24<true, true>), grid, block, 0, stream, a);
         else     hipLaunchKernelGGL((k_yuv420p_rgb24<true, false>), grid, block, 0, stream, a);

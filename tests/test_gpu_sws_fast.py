@@ -159,3 +159,36 @@ def test_fast_path_adversarial_tables(fmts, env, extreme, monkeypatch):
     banks = _adversarial_banks(rng, sw, sh, dw, dh, extreme)
     _run(fmts[0], sw, sh, fmts[1], dw, dh, ffi.SWS_BICUBIC, banks=banks, env=env, monkeypatch=monkeypatch, n=2,
          seed=extreme + 5)
+
+
+# ---------------------------------------------------------------------------------------------
+# unscaled yuv420p -> rgb24: the LDS-transposing streaming kernel, aligned pitches, ragged widths
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["", "plain", "old"])
+@pytest.mark.parametrize("w,h", [(16, 2), (1000, 6), (1048, 4), (2050, 4), (3840, 8), (1920, 1080), (4112, 2), (30, 4)])
+@pytest.mark.parametrize("dst", ["rgb24", "bgr24"])
+def test_unscaled_rgb_transposed(w, h, dst, variant, monkeypatch):
+    from ffmpeg_amd import swscale as S
+    import test_gpu_sws as T
+    torch = _torch()
+    if variant:
+        monkeypatch.setenv("FFHIP_YUV2RGB_VARIANT", variant)
+    else:
+        monkeypatch.delenv("FFHIP_YUV2RGB_VARIANT", raising=False)
+    rng = np.random.default_rng(w * 7 + h)
+    n = 2
+    first = ffi.alloc_frame(PIX["yuv420p"], w, h, rng)
+    dsrc, hsrc = _upload_aligned(first, n, rng)
+    pitch = (3 * w + 63) // 64 * 64
+    ddst = [torch.full((n, h, pitch), 0x5A, dtype=torch.uint8, device="cuda:0")]
+    ctx = S.SwsContext(w, h, PIX["yuv420p"], w, h, PIX[dst], S.SWS_BICUBIC)
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    got = ddst[0].cpu().numpy()
+    for f in range(n):
+        src = [np.ascontiguousarray(hh[f, :, :a.shape[1]]) for hh, a in zip(hsrc, first)]
+        want = T._oracle_unscaled(src, w, h, dst == "bgr24")
+        wv = 3 * (w & ~1)
+        assert np.array_equal(got[f, :, :wv], want[:, :wv]), "frame %d: %d mismatches" % (f, (got[f, :, :wv] != want[:, :wv]).sum())
+        assert (got[f, :, 3 * w:] == 0x5A).all()
+    ctx.close()
