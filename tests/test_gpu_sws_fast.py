@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = [
     {},
-    {"FFHIP_CW_LUMA_GROUPS": "2"},
+    {"FFHIP_CW_LUMA_GROUPS": "1"},
     {"FFHIP_CW_DEPTH": "6"},
-    {"FFHIP_CW_LUMA_GROUPS": "2", "FFHIP_CW_DEPTH": "6", "FFHIP_CW_STRIP": "37"},
+    {"FFHIP_CW_LUMA_GROUPS": "1", "FFHIP_CW_DEPTH": "6", "FFHIP_CW_STRIP": "37"},
     {"FFHIP_CW_PLAIN": "1"},
     {"FFHIP_CW_STRIP": "128"},
     {"FFHIP_SWS_FAST": "0"},
@@ -98,7 +98,7 @@ CASES = [
     ("yuv420p", 128, 72, "nv21", 384, 216, ffi.SWS_BICUBIC),
     ("yuv420p", 128, 72, "yuv420p", 256, 144, ffi.SWS_BICUBIC),      # planar -> planar: three single-plane jobs
     ("nv12", 1048, 600, "nv12", 2096, 1416, ffi.SWS_BICUBIC),        # several column blocks and strips, ragged last block
-    ("nv12", 16, 8, "nv12", 32, 16, ffi.SWS_BICUBIC),                # a single partial wave
+    ("nv12", 32, 16, "nv12", 64, 32, ffi.SWS_BICUBIC),               # a single partial wave
 ]
 
 
@@ -111,7 +111,7 @@ def test_fast_path(case, env, monkeypatch):
 def test_fast_path_full_size(monkeypatch):
     """BASELINE configs[1] frame size, two different frames"""
     _run("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=77)
-    _run("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, env={"FFHIP_CW_LUMA_GROUPS": "2", "FFHIP_CW_DEPTH": "6"},
+    _run("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, env={"FFHIP_CW_LUMA_GROUPS": "1", "FFHIP_CW_DEPTH": "6"},
          monkeypatch=monkeypatch, n=2, seed=78)
 
 
@@ -150,8 +150,8 @@ def _adversarial_banks(rng, srcW, srcH, dstW, dstH, extreme):
 
 
 @pytest.mark.parametrize("extreme", [0, 1])
-@pytest.mark.parametrize("env", [{}, {"FFHIP_CW_LUMA_GROUPS": "2", "FFHIP_CW_DEPTH": "6"}, {"FFHIP_CW_PLAIN": "1"}],
-                         ids=["default", "g2d6", "plain"])
+@pytest.mark.parametrize("env", [{}, {"FFHIP_CW_LUMA_GROUPS": "1", "FFHIP_CW_DEPTH": "6"}, {"FFHIP_CW_PLAIN": "1"}],
+                         ids=["default", "g1d6", "plain"])
 @pytest.mark.parametrize("fmts", [("nv12", "nv12"), ("yuv420p", "nv21"), ("nv21", "yuv420p"), ("yuv420p", "yuv420p")])
 def test_fast_path_adversarial_tables(fmts, env, extreme, monkeypatch):
     sw, sh, dw, dh = 200, 120, 520, 300
