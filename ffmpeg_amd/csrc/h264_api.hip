@@ -30,3 +30,33 @@ extern "C" int ffhip_h264_idct_add_mb_batch_dev(int which, uint8_t *dst_base, pt
     return ffhip_launch_h264_idct_add_mb(which, dst_base, stride, mb_offset, blockoffset16, blocks, nnzc, nmb,
                                          (hipStream_t)stream);
 }
+
+extern "C" int ffhip_h264_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n,
+                                                void *stream)
+{
+    if (!base || !edges || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_loop_filter(base, stride, edges, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_h264_deblock_frame_dev(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h,
+                                            const FFHipH264Edge *edges, void *stream)
+{
+    if (!luma || !edges || mb_w < 0 || mb_h < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_deblock_frame(luma, stride, mb_w, mb_h, edges, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_h264_qpel_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks,
+                                         int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_qpel(dst, src, stride, blocks, n, (hipStream_t)stream);
+}

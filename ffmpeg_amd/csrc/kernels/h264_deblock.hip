@@ -1,0 +1,243 @@
+/*
+ * h264_deblock.hip — H.264 8-bit in-loop deblocking filters.
+ *
+ * Bit-exact restatement of h264_{v,h}_loop_filter_{luma,chroma}[_intra]_8_c
+ * (libavcodec/h264dsp_template.c:104-330): per sample line across an edge,
+ * p3 p2 p1 p0 | q0 q1 q2 q3, normal filter (bS < 4) with per-4-line (luma) / per-2-line (chroma) tc0,
+ * strong filter (bS == 4) without.  Every read of a line happens before any write of that line.
+ *
+ * Two faces:
+ *   k_h264_loop_filter     n edges whose written pixels are pairwise disjoint (the function-level batch,
+ *                          checkasm's 32x16 tiles): 16 lanes per edge, one lane per sample line.
+ *   k_h264_deblock_frame   a whole picture in the decoder's order (libavcodec/h264_loopfilter.c:716):
+ *                          MBs raster, per MB vertical edges 0..3 then horizontal edges 0..3.  Filters of
+ *                          neighbouring MBs overlap, so the order is a true dependency: MB(x,y) needs
+ *                          (x-1,y) and (x+1,y-1).  One WAVE walks one MB row left to right with the current
+ *                          MB + 4 columns / 4 rows of context in an LDS tile; rows hand off through an
+ *                          agent-scope release/acquire progress counter (row y may start MB x once row y-1
+ *                          has published x+2).  Results equal the serial order bit for bit.
+ */
+#include "common.h"
+#include "h264_kernels.h"
+
+struct LfLine { int p3, p2, p1, p0, q0, q1, q2, q3; };
+
+/* Filters one sample line in place; returns the mask of changed taps: bit0 p2, bit1 p1, bit2 p0, bit3 q0,
+ * bit4 q1, bit5 q2.  cls: 0 luma, 1 chroma, 2 luma intra, 3 chroma intra. */
+__device__ __forceinline__ int lf_line(LfLine &v, int cls, int alpha, int beta, int tc0)
+{
+    const int p0 = v.p0, p1 = v.p1, p2 = v.p2, q0 = v.q0, q1 = v.q1, q2 = v.q2;
+    if (abs(p0 - q0) >= alpha || abs(p1 - p0) >= beta || abs(q1 - q0) >= beta)
+        return 0;
+    if (cls == 0) {
+        if (tc0 < 0)
+            return 0;
+        int tc = tc0, m = 4 | 8;
+        if (abs(p2 - p0) < beta) {
+            if (tc0) {
+                v.p1 = p1 + clip3(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0);
+                m |= 2;
+            }
+            tc++;
+        }
+        if (abs(q2 - q0) < beta) {
+            if (tc0) {
+                v.q1 = q1 + clip3(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0);
+                m |= 16;
+            }
+            tc++;
+        }
+        const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+        v.p0 = min(max(p0 + delta, 0), 255);
+        v.q0 = min(max(q0 - delta, 0), 255);
+        return m;
+    }
+    if (cls == 1) {
+        if (tc0 <= 0)
+            return 0;
+        const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc0, tc0);
+        v.p0 = min(max(p0 + delta, 0), 255);
+        v.q0 = min(max(q0 - delta, 0), 255);
+        return 4 | 8;
+    }
+    if (cls == 3) {
+        v.p0 = (2 * p1 + p0 + q1 + 2) >> 2;
+        v.q0 = (2 * q1 + q0 + p1 + 2) >> 2;
+        return 4 | 8;
+    }
+    /* luma intra */
+    int m = 4 | 8;
+    if (abs(p0 - q0) < ((alpha >> 2) + 2)) {
+        if (abs(p2 - p0) < beta) {
+            v.p0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
+            v.p1 = (p2 + p1 + p0 + q0 + 2) >> 2;
+            v.p2 = (2 * v.p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+            m |= 1 | 2;
+        } else {
+            v.p0 = (2 * p1 + p0 + q1 + 2) >> 2;
+        }
+        if (abs(q2 - q0) < beta) {
+            v.q0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
+            v.q1 = (p0 + q0 + q1 + q2 + 2) >> 2;
+            v.q2 = (2 * v.q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+            m |= 16 | 32;
+        } else {
+            v.q0 = (2 * q1 + q0 + p1 + 2) >> 2;
+        }
+    } else {
+        v.p0 = (2 * p1 + p0 + q1 + 2) >> 2;
+        v.q0 = (2 * q1 + q0 + p1 + 2) >> 2;
+    }
+    return m;
+}
+
+/* load / filter / store one line through any byte pointer; xs = step across the edge */
+template <typename P>
+__device__ __forceinline__ void lf_apply(P pix, ptrdiff_t xs, int cls, int alpha, int beta, int tc0)
+{
+    LfLine v;
+    const bool luma = !(cls & 1);
+    v.p1 = pix[-2 * xs]; v.p0 = pix[-xs]; v.q0 = pix[0]; v.q1 = pix[xs];
+    v.p2 = luma ? pix[-3 * xs] : 0; v.q2 = luma ? pix[2 * xs] : 0;
+    v.p3 = cls == 2 ? pix[-4 * xs] : 0; v.q3 = cls == 2 ? pix[3 * xs] : 0;
+    const int m = lf_line(v, cls, alpha, beta, tc0);
+    if (m & 1)  pix[-3 * xs] = (uint8_t)v.p2;
+    if (m & 2)  pix[-2 * xs] = (uint8_t)v.p1;
+    if (m & 4)  pix[-xs] = (uint8_t)v.p0;
+    if (m & 8)  pix[0] = (uint8_t)v.q0;
+    if (m & 16) pix[xs] = (uint8_t)v.q1;
+    if (m & 32) pix[2 * xs] = (uint8_t)v.q2;
+}
+
+/* ---- function-level batch ------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n)
+{
+    const int e = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int d = threadIdx.x & 15;
+    if (e >= n)
+        return;
+    const FFHipH264Edge ed = edges[e];
+    const int kind = ed.kind & 7;
+    const bool chroma = kind & 2, intra = kind & 4, vert_edge = kind & 1; /* h_ filters a vertical edge */
+    if (chroma && d >= 8)
+        return;
+    const ptrdiff_t xs = vert_edge ? 1 : stride, ys = vert_edge ? stride : 1;
+    const int tc0 = intra ? 0 : ed.tc0[chroma ? d >> 1 : d >> 2];
+    lf_apply(base + ed.offset + d * ys, xs, (chroma ? 1 : 0) + (intra ? 2 : 0), ed.alpha, ed.beta, tc0);
+}
+
+int ffhip_launch_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_h264_loop_filter, dim3(cdiv(n, 16)), dim3(256), 0, stream, base, stride, edges, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/* ---- frame order ---------------------------------------------------------------------------------- */
+#define TP 24 /* LDS tile pitch: 4 context columns + 16 + pad */
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h,
+                                                           const FFHipH264Edge *edges, int *progress, int *fail)
+{
+    /* tile[r][c]: r = picture row - (16*my - 4), c = picture column - (16*mx - 4) */
+    __shared__ uint8_t tile[20 * TP];
+    const int my = blockIdx.x, lane = threadIdx.x;
+    uint8_t *rowbase = luma + (ptrdiff_t)my * 16 * stride;
+    for (int mx = 0; mx < mb_w; mx++) {
+        /* ---- wait for the row above: MB (mx+1, my-1) done, i.e. progress[my-1] >= min(mx+2, mb_w) ---- */
+        if (my > 0) {
+            const int want = min(mx + 2, mb_w);
+            int spins = 0;
+            while (__hip_atomic_load(&progress[my - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                    if (lane == 0)
+                        atomicExch(fail, 1);
+                    return;
+                }
+            }
+        }
+        /* ---- bring the context in: the 4 rows above (columns 0..15) and the MB itself ---- */
+        uint8_t *mb = rowbase + mx * 16;
+        if (my > 0) {
+            const int r = lane >> 4, c = lane & 15; /* 4 x 16 */
+            tile[r * TP + 4 + c] = mb[(ptrdiff_t)(r - 4) * stride + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = (lane >> 4) + 4 * k, c = lane & 15; /* 16 x 16 */
+            tile[(r + 4) * TP + 4 + c] = mb[(ptrdiff_t)r * stride + c];
+        }
+        wave_lds_sync();
+        const FFHipH264Edge *e = edges + (size_t)(my * mb_w + mx) * 8;
+        /* ---- vertical edges, left to right: lane = row ---- */
+        for (int k = 0; k < 4; k++) {
+            const FFHipH264Edge ed = e[k];
+            if (lane < 16 && ed.alpha && ed.beta && !(k == 0 && mx == 0)) {
+                const bool intra = ed.kind >= 4;
+                lf_apply(&tile[(lane + 4) * TP + 4 + 4 * k], 1, intra ? 2 : 0, ed.alpha, ed.beta, intra ? 0 : ed.tc0[lane >> 2]);
+            }
+            wave_lds_sync();
+        }
+        /* ---- horizontal edges, top to bottom: lane = column ---- */
+        for (int k = 0; k < 4; k++) {
+            const FFHipH264Edge ed = e[4 + k];
+            if (lane < 16 && ed.alpha && ed.beta && !(k == 0 && my == 0)) {
+                const bool intra = ed.kind >= 4;
+                lf_apply(&tile[(4 + 4 * k) * TP + 4 + lane], TP, intra ? 2 : 0, ed.alpha, ed.beta, intra ? 0 : ed.tc0[lane >> 2]);
+            }
+            wave_lds_sync();
+        }
+        /* ---- write back what this MB may have changed: rows -3..15 x columns -3..15 minus the corner ---- */
+        for (int i = lane; i < 19 * 19; i += 64) {
+            const int r = i / 19 - 3, c = i % 19 - 3;
+            if ((r < 0 && c < 0) || (r < 0 && my == 0) || (c < 0 && mx == 0))
+                continue;
+            mb[(ptrdiff_t)r * stride + c] = tile[(r + 4) * TP + 4 + c];
+        }
+        /* ---- the MB's right 4 columns are the next MB's left context ---- */
+        wave_lds_sync();
+        uint8_t keep = 0;
+        const int kr = lane >> 2, kc = lane & 3; /* 16 rows x 4 cols, plus the 4 context rows below */
+        keep = tile[(kr + 4) * TP + 4 + 12 + kc];
+        uint8_t keep2 = lane < 16 ? tile[(lane >> 2) * TP + 4 + 12 + (lane & 3)] : 0;
+        wave_lds_sync();
+        tile[(kr + 4) * TP + kc] = keep;
+        if (lane < 16)
+            tile[(lane >> 2) * TP + (lane & 3)] = keep2;
+        /* ---- publish ---- */
+        __threadfence();
+        wave_lds_sync();
+        if (lane == 0)
+            __hip_atomic_store(&progress[my], mx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
+                                    hipStream_t stream)
+{
+    if (mb_w <= 0 || mb_h <= 0)
+        return 0;
+    /* progress counters live in a small per-call device allocation (stream-ordered) */
+    int *prog = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&prog), (size_t)(mb_h + 1) * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(prog, 0, (size_t)(mb_h + 1) * sizeof(int), stream));
+    hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h), dim3(64), 0, stream, luma, stride, mb_w, mb_h, edges, prog,
+                       prog + mb_h);
+    hipError_t le = hipGetLastError();
+    HIP_TRY(hipFreeAsync(prog, stream));
+    if (le != hipSuccess) {
+        ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(le), __FILE__, __LINE__);
+        return FFHIP_EIO;
+    }
+    return 0;
+}

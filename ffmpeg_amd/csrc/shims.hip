@@ -1,0 +1,268 @@
+/*
+ * shims.hip — the signature-exact, HOST-pointer faces of h264dsp / h264qpel / me_cmp.
+ *
+ * These are the function pointers an `ff_h264dsp_init_hip()` / `ff_h264qpel_init_hip()` /
+ * `ff_me_cmp_init_hip()` installs next to the x86/neon ones (libavcodec/h264dsp.c:155-169,
+ * h264qpel.c:105-119, me_cmp.c:1014-1026): same names, same argument meaning, same side effects
+ * (coefficient blocks are cleared, dst is updated in place).  One call = one launch: the operands are
+ * staged into device scratch, the SAME kernels as the batched faces run with n = 1, the written
+ * rectangle is copied back.  That is the reference's granularity — right for parity harnesses
+ * (checkasm exercises exactly these pointers), hopeless for speed; throughput comes from the *_batch_dev
+ * entry points.  Thread-safe (one mutex around the shared scratch); no state.
+ */
+#include <mutex>
+#include <string.h>
+
+#include "kernels/common.h"
+#include "kernels/h264_kernels.h"
+#include "kernels/me_kernels.h"
+
+static std::mutex g_shim_mu;
+#define DP 64 /* device row pitch of a staged rectangle */
+
+/* a rectangle rows r0..r1 x columns c0..c1 around host pointer p (row step = stride, may be negative) */
+struct Rect {
+    uint8_t *host;
+    ptrdiff_t stride;
+    int r0, r1, c0, c1;
+    uint8_t *dev; /* device address corresponding to `host` */
+};
+
+static size_t rect_bytes(const Rect &r) { return (size_t)(r.r1 - r.r0 + 1) * DP + 2 * DP; }
+
+static bool rect_up(Rect &r, uint8_t *buf)
+{
+    r.dev = buf + DP - (ptrdiff_t)r.r0 * DP - r.c0; /* row r0 col c0 lands at buf + DP */
+    for (int y = r.r0; y <= r.r1; y++)
+        if (hipMemcpy(r.dev + (ptrdiff_t)y * DP + r.c0, r.host + y * r.stride + r.c0, r.c1 - r.c0 + 1,
+                      hipMemcpyHostToDevice) != hipSuccess)
+            return false;
+    return true;
+}
+
+static bool rect_down(const Rect &r, int r0, int r1, int c0, int c1)
+{
+    for (int y = r0; y <= r1; y++)
+        if (hipMemcpy(r.host + y * r.stride + c0, r.dev + (ptrdiff_t)y * DP + c0, c1 - c0 + 1, hipMemcpyDeviceToHost) !=
+            hipSuccess)
+            return false;
+    return true;
+}
+
+/* ---- h264dsp: single blocks ---------------------------------------------------------------------- */
+static void idct_single(int kind, uint8_t *dst, int16_t *block, ptrdiff_t stride)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const int size = (kind & 1) ? 8 : 4, ncoef = size * size;
+    Rect d = { dst, stride, 0, size - 1, 0, size - 1, nullptr };
+    void *scratch;
+    if (ffhip_scratch_reserve(rect_bytes(d) + 256 + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    int16_t *dblk = (int16_t *)buf;
+    int32_t *doff = (int32_t *)(buf + 128);
+    const int32_t zero = 0;
+    if (!rect_up(d, buf + 256) || hipMemcpy(dblk, block, ncoef * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(doff, &zero, 4, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_h264_idct_add(kind, d.dev, DP, doff, dblk, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    rect_down(d, 0, size - 1, 0, size - 1);
+    (void)hipMemcpy(block, dblk, ncoef * 2, hipMemcpyDeviceToHost);
+}
+static void s_idct_add(uint8_t *d, int16_t *b, ptrdiff_t s) { idct_single(FFHIP_H264_IDCT4, d, b, s); }
+static void s_idct8_add(uint8_t *d, int16_t *b, ptrdiff_t s) { idct_single(FFHIP_H264_IDCT8, d, b, s); }
+static void s_idct_dc_add(uint8_t *d, int16_t *b, ptrdiff_t s) { idct_single(FFHIP_H264_IDCT4_DC, d, b, s); }
+static void s_idct8_dc_add(uint8_t *d, int16_t *b, ptrdiff_t s) { idct_single(FFHIP_H264_IDCT8_DC, d, b, s); }
+
+/* ---- h264dsp: macroblock dispatchers (idct_add16 / idct8_add4 / idct_add16intra) ---------------------- */
+static void idct_mb(int which, uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (stride <= 0 || stride > (1 << 16))
+        return; /* decoders hand these a positive linesize (h264_mb.c:728-779) */
+    const int bs = which == 1 ? 8 : 4;
+    int lo = blockoffset[0], hi = blockoffset[0];
+    for (int i = 0; i < 16; i += (which == 1 ? 4 : 1)) {
+        if (blockoffset[i] < lo) lo = blockoffset[i];
+        if (blockoffset[i] > hi) hi = blockoffset[i];
+    }
+    const size_t span = (size_t)(hi - lo) + (size_t)(bs - 1) * stride + bs;
+    void *scratch;
+    if (ffhip_scratch_reserve(span + 512 + 64 + 64 + 64 + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    int16_t *dblk = (int16_t *)buf;              /* 512 B */
+    int32_t *dbo = (int32_t *)(buf + 512);       /* 64 B  */
+    uint8_t *dnn = buf + 576;                    /* 40 B  */
+    int32_t *dmb = (int32_t *)(buf + 640);       /* 4 B   */
+    uint8_t *dpix = buf + 704;                   /* flat copy of the touched span, same stride */
+    const int32_t mboff = 0;
+    int32_t bo[16];
+    for (int i = 0; i < 16; i++)
+        bo[i] = blockoffset[i] - lo;
+    if (hipMemcpy(dpix, dst + lo, span, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dblk, block, 512, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dbo, bo, 64, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dnn, nnzc, 40, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dmb, &mboff, 4, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_h264_idct_add_mb(which, dpix, stride, dmb, dbo, dblk, dnn, 1, 0) < 0 ||
+        hipStreamSynchronize(0) != hipSuccess)
+        return;
+    for (int i = 0; i < 16; i += (which == 1 ? 4 : 1)) /* only this macroblock's own blocks travel back */
+        if (hipMemcpy2D(dst + blockoffset[i], stride, dpix + bo[i], stride, bs, bs, hipMemcpyDeviceToHost) != hipSuccess)
+            return;
+    (void)hipMemcpy(block, dblk, 512, hipMemcpyDeviceToHost);
+}
+static void s_idct_add16(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { idct_mb(0, d, bo, b, s, n); }
+static void s_idct8_add4(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { idct_mb(1, d, bo, b, s, n); }
+static void s_idct_add16intra(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { idct_mb(2, d, bo, b, s, n); }
+
+/* ---- h264dsp: loop filters --------------------------------------------------------------------------- */
+static void lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const bool chroma = kind & 2, vert_edge = kind & 1;
+    const int along = chroma ? 8 : 16, across = chroma ? 2 : 4; /* samples read each side of the edge */
+    Rect r = { pix, stride, vert_edge ? 0 : -across, vert_edge ? along - 1 : across - 1,
+               vert_edge ? -across : 0, vert_edge ? across - 1 : along - 1, nullptr };
+    void *scratch;
+    if (ffhip_scratch_reserve(rect_bytes(r) + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    FFHipH264Edge e;
+    memset(&e, 0, sizeof(e));
+    e.kind = (uint8_t)kind;
+    e.alpha = (uint8_t)(alpha < 0 ? 0 : alpha > 255 ? 255 : alpha); /* 8-bit tables top out at 255 / 18 */
+    e.beta = (uint8_t)(beta < 0 ? 0 : beta > 255 ? 255 : beta);
+    if (tc0)
+        memcpy(e.tc0, tc0, 4);
+    if (!rect_up(r, buf + 64) || hipMemcpy(buf, &e, sizeof(e), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_h264_loop_filter(r.dev, DP, (const FFHipH264Edge *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    rect_down(r, r.r0, r.r1, r.c0, r.c1);
+}
+static void s_v_lf_luma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { lf_single(FFHIP_H264_LF_V_LUMA, p, s, a, b, t); }
+static void s_h_lf_luma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { lf_single(FFHIP_H264_LF_H_LUMA, p, s, a, b, t); }
+static void s_v_lf_chroma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { lf_single(FFHIP_H264_LF_V_CHROMA, p, s, a, b, t); }
+static void s_h_lf_chroma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { lf_single(FFHIP_H264_LF_H_CHROMA, p, s, a, b, t); }
+static void s_v_lf_luma_i(uint8_t *p, ptrdiff_t s, int a, int b) { lf_single(FFHIP_H264_LF_V_LUMA_INTRA, p, s, a, b, nullptr); }
+static void s_h_lf_luma_i(uint8_t *p, ptrdiff_t s, int a, int b) { lf_single(FFHIP_H264_LF_H_LUMA_INTRA, p, s, a, b, nullptr); }
+static void s_v_lf_chroma_i(uint8_t *p, ptrdiff_t s, int a, int b) { lf_single(FFHIP_H264_LF_V_CHROMA_INTRA, p, s, a, b, nullptr); }
+static void s_h_lf_chroma_i(uint8_t *p, ptrdiff_t s, int a, int b) { lf_single(FFHIP_H264_LF_H_CHROMA_INTRA, p, s, a, b, nullptr); }
+
+extern "C" int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int chroma_format_idc)
+{
+    (void)chroma_format_idc;
+    if (!c)
+        return FFHIP_EINVAL;
+    if (bit_depth != 8)
+        return FFHIP_EINVAL; /* other depths keep the C pointers (h264dsp.c:70-150 selects per depth) */
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    c->v_loop_filter_luma = s_v_lf_luma;                 c->h_loop_filter_luma = s_h_lf_luma;
+    c->v_loop_filter_luma_intra = s_v_lf_luma_i;         c->h_loop_filter_luma_intra = s_h_lf_luma_i;
+    c->v_loop_filter_chroma = s_v_lf_chroma;             c->h_loop_filter_chroma = s_h_lf_chroma;
+    c->v_loop_filter_chroma_intra = s_v_lf_chroma_i;     c->h_loop_filter_chroma_intra = s_h_lf_chroma_i;
+    c->idct_add = s_idct_add;                            c->idct8_add = s_idct8_add;
+    c->idct_dc_add = s_idct_dc_add;                      c->idct8_dc_add = s_idct8_dc_add;
+    c->idct_add16 = s_idct_add16;                        c->idct8_add4 = s_idct8_add4;
+    c->idct_add16intra = s_idct_add16intra;
+    return 0;
+}
+
+/* ---- h264qpel ---------------------------------------------------------------------------------------- */
+static void qpel_single(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const int n = 16 >> size_idx;
+    Rect d = { dst, stride, 0, n - 1, 0, n - 1, nullptr };
+    Rect s = { const_cast<uint8_t *>(src), stride, -2, n + 2, -2, n + 2, nullptr };
+    void *scratch;
+    if (ffhip_scratch_reserve(rect_bytes(d) + rect_bytes(s) + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    if (!rect_up(d, buf + 64) || !rect_up(s, buf + 64 + rect_bytes(d)))
+        return;
+    FFHipQpelBlock b;
+    memset(&b, 0, sizeof(b));
+    /* both rectangles sit in one scratch arena: offsets relative to its start, one shared pitch */
+    b.dst_offset = (int32_t)(d.dev - buf); b.src_offset = (int32_t)(s.dev - buf);
+    b.mcxy = (uint8_t)mcxy; b.size_idx = (uint8_t)size_idx; b.avg = (uint8_t)avg;
+    if (hipMemcpy(buf, &b, sizeof(b), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_h264_qpel(buf, buf, DP, (const FFHipQpelBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    rect_down(d, 0, n - 1, 0, n - 1);
+}
+#define QPEL_FN(op, avg, sz, idx, mc) \
+    static void s_##op##_qpel##sz##_mc##mc(uint8_t *d, const uint8_t *s, ptrdiff_t st) { qpel_single(avg, idx, mc, d, s, st); }
+#define QPEL_16(op, avg, sz, idx) \
+    QPEL_FN(op, avg, sz, idx, 0) QPEL_FN(op, avg, sz, idx, 1) QPEL_FN(op, avg, sz, idx, 2) QPEL_FN(op, avg, sz, idx, 3) \
+    QPEL_FN(op, avg, sz, idx, 4) QPEL_FN(op, avg, sz, idx, 5) QPEL_FN(op, avg, sz, idx, 6) QPEL_FN(op, avg, sz, idx, 7) \
+    QPEL_FN(op, avg, sz, idx, 8) QPEL_FN(op, avg, sz, idx, 9) QPEL_FN(op, avg, sz, idx, 10) QPEL_FN(op, avg, sz, idx, 11) \
+    QPEL_FN(op, avg, sz, idx, 12) QPEL_FN(op, avg, sz, idx, 13) QPEL_FN(op, avg, sz, idx, 14) QPEL_FN(op, avg, sz, idx, 15)
+QPEL_16(put, 0, 16, 0) QPEL_16(put, 0, 8, 1) QPEL_16(put, 0, 4, 2)
+QPEL_16(avg, 1, 16, 0) QPEL_16(avg, 1, 8, 1) QPEL_16(avg, 1, 4, 2)
+#define QPEL_ROW(op, sz) { s_##op##_qpel##sz##_mc0, s_##op##_qpel##sz##_mc1, s_##op##_qpel##sz##_mc2, s_##op##_qpel##sz##_mc3, \
+    s_##op##_qpel##sz##_mc4, s_##op##_qpel##sz##_mc5, s_##op##_qpel##sz##_mc6, s_##op##_qpel##sz##_mc7, s_##op##_qpel##sz##_mc8, \
+    s_##op##_qpel##sz##_mc9, s_##op##_qpel##sz##_mc10, s_##op##_qpel##sz##_mc11, s_##op##_qpel##sz##_mc12, \
+    s_##op##_qpel##sz##_mc13, s_##op##_qpel##sz##_mc14, s_##op##_qpel##sz##_mc15 }
+
+extern "C" int ff_h264qpel_init_hip(FFHipH264QpelContext *c, int bit_depth)
+{
+    if (!c || bit_depth != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    /* table index = X + 4*Y, [0] 16x16 [1] 8x8 [2] 4x4 (h264qpel.c:55-70) */
+    static const ffhip_qpel_mc_func put[3][16] = { QPEL_ROW(put, 16), QPEL_ROW(put, 8), QPEL_ROW(put, 4) };
+    static const ffhip_qpel_mc_func avg[3][16] = { QPEL_ROW(avg, 16), QPEL_ROW(avg, 8), QPEL_ROW(avg, 4) };
+    memcpy(c->put_h264_qpel_pixels_tab, put, sizeof(put));
+    memcpy(c->avg_h264_qpel_pixels_tab, avg, sizeof(avg));
+    return 0;
+}
+
+/* ---- me_cmp --------------------------------------------------------------------------------------------- */
+static int cmp_single(int kind, int width, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const int rows = kind == FFHIP_ME_SATD ? (width == 16 ? (h == 16 ? 16 : 8) : 8) : h;
+    if (rows <= 0)
+        return 0;
+    Rect a = { const_cast<uint8_t *>(blk1), stride, 0, rows - 1, 0, width - 1, nullptr };
+    Rect b = { const_cast<uint8_t *>(blk2), stride, 0, rows - 1, 0, width - 1, nullptr };
+    void *scratch;
+    if (ffhip_scratch_reserve(rect_bytes(a) + rect_bytes(b) + 64, &scratch) < 0)
+        return 0;
+    uint8_t *buf = (uint8_t *)scratch;
+    if (!rect_up(a, buf + 64) || !rect_up(b, buf + 64 + rect_bytes(a)))
+        return 0;
+    const int32_t offs[2] = { (int32_t)(a.dev - buf), (int32_t)(b.dev - buf) };
+    int32_t *d = (int32_t *)buf; /* [0] off1 [1] off2 [2] result */
+    int32_t res = 0;
+    if (hipMemcpy(d, offs, 8, hipMemcpyHostToDevice) != hipSuccess)
+        return 0;
+    if (ffhip_launch_me_cmp(kind, width, kind == FFHIP_ME_SATD ? rows : h, buf, d, buf, d + 1, DP, d + 2, 1, 0) < 0 ||
+        hipMemcpy(&res, d + 2, 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return 0;
+    return res;
+}
+static int s_sad16(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h) { (void)c; return cmp_single(FFHIP_ME_SAD, 16, a, b, s, h); }
+static int s_sad8(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h) { (void)c; return cmp_single(FFHIP_ME_SAD, 8, a, b, s, h); }
+static int s_satd16(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h) { (void)c; return cmp_single(FFHIP_ME_SATD, 16, a, b, s, h); }
+static int s_satd8(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h) { (void)c; return cmp_single(FFHIP_ME_SATD, 8, a, b, s, h); }
+
+extern "C" int ff_me_cmp_init_hip(FFHipMECmpContext *c)
+{
+    if (!c)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    c->sad[0] = s_sad16;             c->sad[1] = s_sad8;
+    c->pix_abs[0][0] = s_sad16;      c->pix_abs[1][0] = s_sad8;      /* ff_me_cmp_init: me_cmp.c:989-1000 */
+    c->hadamard8_diff[0] = s_satd16; c->hadamard8_diff[1] = s_satd8;
+    return 0;
+}

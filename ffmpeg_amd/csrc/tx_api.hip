@@ -1,0 +1,420 @@
+/*
+ * tx_api.hip — libavutil av_tx float MDCT (AV_TX_FLOAT_MDCT, power-of-two lengths) for libffhip.
+ *
+ * Reference path:
+ *   ff_tx_mdct_init / ff_tx_mdct_fwd / ff_tx_mdct_inv      libavutil/tx_template.c:1223-1342
+ *   ff_tx_mdct_gen_exp                                      libavutil/tx_template.c:2107-2134
+ *   split-radix codelets + ff_tx_fft_sr_combine             libavutil/tx_template.c:540-722
+ *   cosine tables ff_tx_tab_N_float                         libavutil/tx_template.c:65-77
+ *   ff_tx_gen_ptwo_revtab / split_radix_permutation         libavutil/tx.c:125-155
+ *
+ * One transform = fold/pre-twiddle into a split-radix-permuted N/2-point complex array, an in-place
+ * N/2-point split-radix FFT, post-twiddle.  The reference recursion  FFT(m) = FFT(m/2) + 2 x FFT(m/4)
+ * + combine(m)  is flattened on the host into one butterfly list per level (all size-2 blocks, then all
+ * size-4 combines, ... up to size N/2: a level only consumes lower levels, blocks of a level are
+ * disjoint).  Every butterfly performs the reference's float operations in the reference's order and
+ * the library is built with -ffp-contract=off, so the results are the reference's, bit for bit.
+ *
+ * GPU design (HBM-bound, 12 KiB moved per forward N=1024 transform for ~25 kFLOP): one WAVE per
+ * transform, several waves per workgroup.  Input is staged HBM -> LDS with coalesced 16-byte loads,
+ * folded + pre-twiddled into the LDS complex array, transformed there level by level (64 butterflies per
+ * wave instruction, wave-local synchronisation only), post-twiddled back into the staging area and
+ * written out with coalesced 16-byte stores.  Twiddles, the permutation and the butterfly lists are
+ * small read-only tables that stay resident in L2.
+ */
+#include <math.h>
+#include <mutex>
+#include <new>
+#include <string.h>
+#include <vector>
+
+#include "kernels/common.h"
+
+struct TxDev {
+    int n, lg;                 /* complex FFT size (= len/2) and its log2                         */
+    const int *map;            /* n                                                                */
+    const float2 *exp;         /* n (forward) or 2n (inverse: [0,n) permuted, [n,2n) natural)       */
+    const float *cos_tab;      /* concatenated per level, cos_off[l] = first entry of level l       */
+    const uint32_t *sched;     /* butterflies: a0 | k << 16, concatenated per level                 */
+    const uint16_t *blocks2;   /* offsets of the size-2 blocks                                      */
+    int nblocks2;
+    int cos_off[16], sched_off[16], sched_cnt[16];
+};
+
+struct FFHipTXContext {
+    int type, inv, len;
+    float scale;
+    TxDev d;
+    void *dev = nullptr;
+    /* host-pointer shim staging */
+    void *stage = nullptr;
+    size_t stage_sz = 0;
+    std::mutex mu;
+};
+
+__device__ __forceinline__ void tx_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* in-place split-radix FFT of z[0..n) held in LDS, one wave */
+__device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, int lane)
+{
+    for (int b = lane; b < d.nblocks2; b += 64) {
+        const int o = d.blocks2[b];
+        const float2 x = z[o], y = z[o + 1];
+        z[o] = make_float2(x.x + y.x, x.y + y.y);
+        z[o + 1] = make_float2(x.x - y.x, x.y - y.y);
+    }
+    for (int l = 2; l <= d.lg; l++) {
+        tx_wave_sync();
+        const int q = 1 << (l - 2);
+        const float *tab = d.cos_tab + d.cos_off[l];
+        const uint32_t *sc = d.sched + d.sched_off[l];
+        for (int b = lane; b < d.sched_cnt[l]; b += 64) {
+            const uint32_t e = sc[b];
+            const int a0 = e & 0xFFFF, k = e >> 16;
+            const float wre = tab[k], wim = tab[q - k], nwim = -wim;
+            const float2 v0 = z[a0], v1 = z[a0 + q], v2 = z[a0 + 2 * q], v3 = z[a0 + 3 * q];
+            /* ff_tx_fft_sr_combine's TRANSFORM: libavutil/tx_template.c:540-586 */
+            const float t1 = v2.x * wre - v2.y * nwim;
+            const float t2 = v2.x * nwim + v2.y * wre;
+            float t5 = v3.x * wre - v3.y * wim;
+            float t6 = v3.x * wim + v3.y * wre;
+            const float t3 = t5 - t1;
+            t5 = t5 + t1;
+            const float t4 = t2 - t6;
+            t6 = t2 + t6;
+            z[a0]         = make_float2(v0.x + t5, v0.y + t6);
+            z[a0 + q]     = make_float2(v1.x + t4, v1.y + t3);
+            z[a0 + 2 * q] = make_float2(v0.x - t5, v0.y - t6);
+            z[a0 + 3 * q] = make_float2(v1.x - t4, v1.y - t3);
+        }
+    }
+    tx_wave_sync();
+}
+
+/*
+ * INV == 0: in = 4n floats (contiguous), out = 2n floats `ostride` elements apart.
+ * INV == 1: in = 2n floats `istride` elements apart, out = 2n floats (contiguous).
+ */
+template <int INV>
+__global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t in_pitch, float *out, size_t out_pitch,
+                                              ptrdiff_t stride, int nt, int waves_per_block, int vec_in, int vec_out)
+{
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * waves_per_block + wave;
+    if (wave >= waves_per_block || t >= nt)
+        return;
+    const int n = d.n, q = n >> 1;
+    const size_t per_wave = (size_t)n * 8 + (size_t)n * 16; /* z + staging (4n floats) */
+    float2 *z = reinterpret_cast<float2 *>(lds_raw + wave * per_wave);
+    float *st = reinterpret_cast<float *>(lds_raw + wave * per_wave + (size_t)n * 8);
+    const float *src = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
+    float *dst = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
+
+    if (!INV) {
+        /* ---- stage the 4n input samples ---- */
+        if (vec_in) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(st);
+            for (int j = lane; j < n; j += 64)
+                d4[j] = s4[j];
+        } else {
+            for (int j = lane; j < 4 * n; j += 64)
+                st[j] = src[j];
+        }
+        tx_wave_sync();
+        /* ---- fold + pre-twiddle, scattered through map (ff_tx_mdct_fwd, tx_template.c:1285-1296) ---- */
+        const int len3 = 3 * n;
+        for (int i = lane; i < n; i += 64) {
+            const int k = 2 * i;
+            float re, im;
+            if (k < n) {
+                re = -st[n + k] + st[n - 1 - k];
+                im = -st[len3 + k] + -st[len3 - 1 - k];
+            } else {
+                re = -st[n + k] + -st[5 * n - 1 - k];
+                im = st[k - n] + -st[len3 - 1 - k];
+            }
+            const float2 e = d.exp[i];
+            z[d.map[i]] = make_float2(re * e.y + im * e.x, re * e.x - im * e.y);
+        }
+        tx_wave_sync();
+        tx_fft_lds(z, d, lane);
+        /* ---- post-twiddle (tx_template.c:1300-1309) ---- */
+        for (int i = lane; i < q; i += 64) {
+            const int i0 = q + i, i1 = q - i - 1;
+            const float2 s1 = z[i1], s0 = z[i0], e0 = d.exp[i0], e1 = d.exp[i1];
+            const float a = s0.x * e0.y - s0.y * e0.x; /* out[2*i1+1] */
+            const float b = s0.x * e0.x + s0.y * e0.y; /* out[2*i0]   */
+            const float c = s1.x * e1.y - s1.y * e1.x; /* out[2*i0+1] */
+            const float f = s1.x * e1.x + s1.y * e1.y; /* out[2*i1]   */
+            if (vec_out) {
+                st[2 * i1 + 1] = a; st[2 * i0] = b; st[2 * i0 + 1] = c; st[2 * i1] = f;
+            } else {
+                dst[(2 * i1 + 1) * stride] = a; dst[2 * i0 * stride] = b;
+                dst[(2 * i0 + 1) * stride] = c; dst[2 * i1 * stride] = f;
+            }
+        }
+    } else {
+        /* ---- stage the 2n coefficients ---- */
+        if (vec_in) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(st);
+            for (int j = lane; j < (n >> 1); j += 64)
+                d4[j] = s4[j];
+        } else {
+            for (int j = lane; j < 2 * n; j += 64)
+                st[j] = src[j * stride];
+        }
+        tx_wave_sync();
+        /* ---- gather + pre-twiddle (ff_tx_mdct_inv, tx_template.c:1321-1328) ---- */
+        for (int i = lane; i < n; i += 64) {
+            const int k = d.map[i] << 1;
+            const float tre = st[2 * n - 1 - k], tim = st[k];
+            const float2 e = d.exp[i];
+            z[i] = make_float2(tre * e.x - tim * e.y, tre * e.y + tim * e.x);
+        }
+        tx_wave_sync();
+        tx_fft_lds(z, d, lane);
+        /* ---- post-twiddle (tx_template.c:1332-1341) ---- */
+        const float2 *ex = d.exp + n;
+        for (int i = lane; i < q; i += 64) {
+            const int i0 = q + i, i1 = q - i - 1;
+            const float2 s1 = make_float2(z[i1].y, z[i1].x), s0 = make_float2(z[i0].y, z[i0].x);
+            const float2 e0 = ex[i0], e1 = ex[i1];
+            const float a = s1.x * e1.y - s1.y * e1.x; /* o[i1].re */
+            const float b = s1.x * e1.x + s1.y * e1.y; /* o[i0].im */
+            const float c = s0.x * e0.y - s0.y * e0.x; /* o[i0].re */
+            const float f = s0.x * e0.x + s0.y * e0.y; /* o[i1].im */
+            if (vec_out) {
+                st[2 * i1] = a; st[2 * i0 + 1] = b; st[2 * i0] = c; st[2 * i1 + 1] = f;
+            } else {
+                dst[2 * i1] = a; dst[2 * i0 + 1] = b; dst[2 * i0] = c; dst[2 * i1 + 1] = f;
+            }
+        }
+    }
+    if (vec_out) {
+        tx_wave_sync();
+        const float4 *s4 = reinterpret_cast<const float4 *>(st);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int j = lane; j < (n >> 1); j += 64)
+            d4[j] = s4[j];
+    }
+}
+
+/* ---- host: tables ------------------------------------------------------------------------------- */
+static int sr_perm(int i, int len, int inv)
+{
+    len >>= 1;
+    if (len <= 1)
+        return i & 1;
+    if (!(i & len))
+        return sr_perm(i, len, inv) * 2;
+    len >>= 1;
+    return sr_perm(i, len, inv) * 4 + 1 - 2 * (!(i & len) ^ inv);
+}
+
+static void sr_schedule(int o, int n, int lg, std::vector<uint32_t> *lev, std::vector<uint16_t> *b2)
+{
+    if (n == 1)
+        return;
+    if (n == 2) {
+        b2->push_back((uint16_t)o);
+        return;
+    }
+    const int q = n >> 2;
+    sr_schedule(o, n >> 1, lg - 1, lev, b2);
+    sr_schedule(o + 2 * q, q, lg - 2, lev, b2);
+    sr_schedule(o + 3 * q, q, lg - 2, lev, b2);
+    for (int k = 0; k < q; k++)
+        lev[lg].push_back((uint32_t)(o + k) | ((uint32_t)k << 16));
+}
+
+extern "C" void ffhip_tx_uninit(FFHipTXContext **pctx)
+{
+    if (!pctx || !*pctx)
+        return;
+    FFHipTXContext *c = *pctx;
+    if (c->dev)
+        (void)hipFree(c->dev);
+    if (c->stage)
+        (void)hipFree(c->stage);
+    delete c;
+    *pctx = nullptr;
+}
+
+static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
+
+extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,
+                             uint64_t flags)
+{
+    (void)flags;
+    if (!pctx || !scale)
+        return FFHIP_EINVAL;
+    *pctx = nullptr;
+    if (type != FFHIP_TX_FLOAT_MDCT) {
+        ffhip_set_error("ffhip_tx_init: only AV_TX_FLOAT_MDCT is on the hip path");
+        return FFHIP_ENOSYS;
+    }
+    if (len < 16 || len > 4096 || (len & (len - 1))) {
+        ffhip_set_error("ffhip_tx_init: len %d not a power of two in 16..4096", len);
+        return FFHIP_EINVAL;
+    }
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    FFHipTXContext *c = new (std::nothrow) FFHipTXContext();
+    if (!c)
+        return FFHIP_ENOMEM;
+    c->type = type; c->inv = !!inv; c->len = len; c->scale = *scale;
+    const int n = len >> 1;
+    int lg = 0;
+    while ((1 << lg) < n)
+        lg++;
+    /* permutation: forward asks for SCATTER, inverse for GATHER (tx_template.c:1231-1233) */
+    std::vector<int> map(n);
+    for (int i = 0; i < n; i++) {
+        const int p = -sr_perm(i, n, c->inv) & (n - 1);
+        if (!c->inv) map[p] = i; else map[i] = p;
+    }
+    /* exp table (ff_tx_mdct_gen_exp) */
+    std::vector<float2> ex(c->inv ? 2 * n : n);
+    {
+        const double sc = *scale;
+        const double theta = (sc < 0 ? n : 0) + 1.0 / 8.0, rt = sqrt(fabs(sc));
+        float2 *e = ex.data() + (c->inv ? n : 0);
+        for (int i = 0; i < n; i++) {
+            const double alpha = M_PI_2 * (i + theta) / n;
+            e[i].x = (float)(cos(alpha) * rt);
+            e[i].y = (float)(sin(alpha) * rt);
+        }
+        if (c->inv)
+            for (int i = 0; i < n; i++)
+                ex[i] = ex[n + map[i]];
+    }
+    /* cosine tables per level (cos(2*pi*k/m), k <= m/4; the last entry is an exact 0) */
+    std::vector<float> cosv;
+    TxDev &d = c->d;
+    memset(&d, 0, sizeof(d));
+    d.n = n; d.lg = lg;
+    for (int l = 2; l <= lg; l++) {
+        const int m = 1 << l;
+        const double freq = 2 * M_PI / m;
+        d.cos_off[l] = (int)cosv.size();
+        for (int i = 0; i < m / 4; i++)
+            cosv.push_back((float)cos(i * freq));
+        cosv.push_back(0.0f);
+    }
+    std::vector<uint32_t> lev[16];
+    std::vector<uint16_t> b2;
+    sr_schedule(0, n, lg, lev, &b2);
+    std::vector<uint32_t> sched;
+    for (int l = 2; l <= lg; l++) {
+        d.sched_off[l] = (int)sched.size();
+        d.sched_cnt[l] = (int)lev[l].size();
+        sched.insert(sched.end(), lev[l].begin(), lev[l].end());
+    }
+    d.nblocks2 = (int)b2.size();
+    /* one device allocation for all tables */
+    size_t off_map = 0, off_exp, off_cos, off_sched, off_b2, total;
+    off_exp = (off_map + map.size() * 4 + 15) & ~(size_t)15;
+    off_cos = (off_exp + ex.size() * 8 + 15) & ~(size_t)15;
+    off_sched = (off_cos + cosv.size() * 4 + 15) & ~(size_t)15;
+    off_b2 = (off_sched + sched.size() * 4 + 15) & ~(size_t)15;
+    total = off_b2 + b2.size() * 2 + 16;
+    std::vector<uint8_t> blob(total, 0);
+    memcpy(blob.data() + off_map, map.data(), map.size() * 4);
+    memcpy(blob.data() + off_exp, ex.data(), ex.size() * 8);
+    memcpy(blob.data() + off_cos, cosv.data(), cosv.size() * 4);
+    memcpy(blob.data() + off_sched, sched.data(), sched.size() * 4);
+    memcpy(blob.data() + off_b2, b2.data(), b2.size() * 2);
+    if (hipMalloc(&c->dev, total) != hipSuccess || hipMemcpy(c->dev, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        ffhip_set_error("ffhip_tx_init: table upload failed");
+        ffhip_tx_uninit(&c);
+        return FFHIP_ENOMEM;
+    }
+    uint8_t *base = (uint8_t *)c->dev;
+    d.map = (const int *)(base + off_map);
+    d.exp = (const float2 *)(base + off_exp);
+    d.cos_tab = (const float *)(base + off_cos);
+    d.sched = (const uint32_t *)(base + off_sched);
+    d.blocks2 = (const uint16_t *)(base + off_b2);
+    *pctx = c;
+    if (fn)
+        *fn = tx_single;
+    return 0;
+}
+
+extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch, const void *in, size_t in_pitch,
+                                  ptrdiff_t stride, int nt, void *stream)
+{
+    if (!c || !out || !in || nt < 0 || (stride % (ptrdiff_t)sizeof(float)))
+        return FFHIP_EINVAL;
+    if (nt == 0)
+        return 0;
+    const int n = c->d.n;
+    const size_t per_wave = (size_t)n * 24;
+    int wpb = (int)((60 * 1024) / per_wave);
+    if (wpb > 4) wpb = 4;
+    if (wpb < 1) {
+        ffhip_set_error("ffhip_tx: len %d does not fit LDS", c->len);
+        return FFHIP_EINVAL;
+    }
+    const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
+    const dim3 grid(cdiv(nt, wpb)), block(64 * wpb);
+    const size_t lds = per_wave * wpb;
+    if (!c->inv) {
+        const int vin = !(((uintptr_t)in | in_pitch) & 15);
+        const int vout = es == 1 && !(((uintptr_t)out | out_pitch) & 15);
+        hipLaunchKernelGGL((k_mdct<0>), grid, block, lds, (hipStream_t)stream, c->d, (const float *)in, in_pitch, (float *)out,
+                           out_pitch, es, nt, wpb, vin, vout);
+    } else {
+        const int vin = es == 1 && !(((uintptr_t)in | in_pitch) & 15);
+        const int vout = !(((uintptr_t)out | out_pitch) & 15);
+        hipLaunchKernelGGL((k_mdct<1>), grid, block, lds, (hipStream_t)stream, c->d, (const float *)in, in_pitch, (float *)out,
+                           out_pitch, es, nt, wpb, vin, vout);
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/* av_tx_fn-shaped single transform with HOST pointers (libavutil/tx.h:151): stage, run, copy back */
+static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
+{
+    std::lock_guard<std::mutex> lk(s->mu);
+    const int len = s->len;
+    const size_t in_elems = s->inv ? (size_t)len : (size_t)2 * len, out_elems = len;
+    const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
+    /* the strided side is packed on the host so that the device sees contiguous data */
+    std::vector<float> hin(in_elems), hout(out_elems);
+    const float *fi = (const float *)in;
+    for (size_t i = 0; i < in_elems; i++)
+        hin[i] = s->inv ? fi[(ptrdiff_t)i * es] : fi[i];
+    const size_t need = (in_elems + out_elems) * sizeof(float) + 64;
+    if (need > s->stage_sz) {
+        if (s->stage)
+            (void)hipFree(s->stage);
+        s->stage = nullptr;
+        s->stage_sz = 0;
+        if (hipMalloc(&s->stage, need) != hipSuccess) {
+            ffhip_set_error("ffhip_tx: staging allocation failed");
+            return;
+        }
+        s->stage_sz = need;
+    }
+    float *din = (float *)s->stage, *dout = din + ((in_elems + 3) & ~(size_t)3);
+    if (hipMemcpy(din, hin.data(), in_elems * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_tx_batch_dev(s, dout, out_elems * sizeof(float), din, in_elems * sizeof(float), sizeof(float), 1, 0) < 0)
+        return;
+    if (hipMemcpy(hout.data(), dout, out_elems * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    float *fo = (float *)out;
+    for (size_t i = 0; i < out_elems; i++)
+        fo[s->inv ? (ptrdiff_t)i : (ptrdiff_t)i * es] = hout[i];
+}

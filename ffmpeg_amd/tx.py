@@ -1,0 +1,46 @@
+"""Host-side mirror of libavutil's av_tx_init()/av_tx_fn for the float MDCT on the hip path.
+
+  TxContext(type, inv, len, scale)   ~ av_tx_init()              libavutil/tx.c:903
+  TxContext.fn(out, in, stride)      ~ av_tx_fn (one transform)  libavutil/tx.h:151   (host numpy)
+  TxContext.batch(out, in, ...)      ~ (batched, HBM-resident)   no reference equivalent
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FLOAT_FFT, FLOAT_MDCT = 0, 1
+_TXFN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t)
+
+
+class TxContext:
+    def __init__(self, type_, inv, len_, scale, flags=0):
+        L = _lib.lib()
+        self.type, self.inv, self.len, self.scale = type_, int(bool(inv)), len_, float(scale)
+        self._c = _lib.vp()
+        fn = _lib.vp()
+        sc = C.c_float(scale)
+        _lib.check(L.ffhip_tx_init(C.byref(self._c), C.byref(fn), type_, self.inv, len_, C.byref(sc), flags), "ffhip_tx_init")
+        self._fn = _TXFN(fn.value)
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c and _lib is not None:
+            _lib.lib().ffhip_tx_uninit(C.byref(self._c))
+        self._c = None
+
+    __del__ = close
+
+    def fn(self, out, inp, stride=4):
+        """One transform on host float32 arrays, exactly av_tx_fn's (s, out, in, stride)."""
+        assert out.dtype == np.float32 and inp.dtype == np.float32
+        self._fn(self._c, out.ctypes.data, inp.ctypes.data, stride)
+
+    def batch(self, out, inp, stride=4, stream=None):
+        """out/inp: 2-D float32 cuda tensors, one transform per row (row pitch = tensor stride)."""
+        import torch
+        nt = inp.shape[0]
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        return _lib.check(_lib.lib().ffhip_tx_batch_dev(self._c, out.data_ptr(), out.stride(0) * 4, inp.data_ptr(),
+                                                        inp.stride(0) * 4, stride, nt, stream), "ffhip_tx_batch_dev")

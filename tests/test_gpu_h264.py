@@ -90,3 +90,131 @@ def test_idct_add_mb_batch(which):
                            torch.from_numpy(nnzc).cuda())
     torch.cuda.synchronize()
     assert np.array_equal(d_plane.cpu().numpy(), want) and np.array_equal(d_b.cpu().numpy(), wb)
+
+
+# ---------------------------------------------------------------------------------------------
+# loop filters, frame-order deblocking, luma qpel
+# ---------------------------------------------------------------------------------------------
+EDGE_DT = np.dtype([("offset", np.int32), ("kind", np.uint8), ("alpha", np.uint8), ("beta", np.uint8), ("pad", np.uint8),
+                    ("tc0", np.int8, 4)])
+# the (alpha, beta, tc0) ladder of tests/checkasm/h264dsp.c:394-402 (indexA/indexB driven), plus extremes
+LADDER = [(a, b, t) for a, b, t in zip([4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28, 32, 36, 40, 45, 50, 56, 63, 71,
+                                        80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255],
+                                       [2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13,
+                                        14, 14, 15, 15, 16, 16, 17, 17, 18],
+                                       [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 6,
+                                        6, 7, 8, 9, 10, 11, 13])]
+
+
+def _smooth_plane(rng, h, w):
+    """pixels with small steps so that the filters' |p0-q0| < alpha conditions fire often"""
+    base = rng.integers(0, 256, (h // 8 + 1, w // 8 + 1)).astype(np.int32)
+    p = np.kron(base, np.ones((8, 8), np.int32))[:h, :w] + rng.integers(-6, 7, (h, w))
+    return np.clip(p, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("kind", range(8))
+def test_loop_filter_batch(kind):
+    from ffmpeg_amd import h264
+    torch = _torch()
+    rng = np.random.default_rng(40 + kind)
+    tiles_x, tiles_y, stride = 24, 18, 24 * 32 + 32
+    plane = _smooth_plane(rng, tiles_y * 16, stride)
+    plane[::3] = rng.integers(0, 256, plane[::3].shape, dtype=np.uint8)
+    n = tiles_x * tiles_y
+    ed = np.zeros(n, EDGE_DT)
+    for i in range(n):
+        ty, tx = divmod(i, tiles_x)
+        a, b, t = LADDER[rng.integers(len(LADDER))]
+        # checkasm layout: a 32x16 tile, edge in its middle (tests/checkasm/h264dsp.c:375-440)
+        if kind & 1:    # h_: vertical edge at column 16 of the tile, 16 (chroma: 8) rows
+            off = (ty * 16) * stride + tx * 32 + 16
+        else:           # v_: horizontal edge at row 8 of the tile, 16 (chroma: 8) columns
+            off = (ty * 16 + 8) * stride + tx * 32 + 8
+        ed[i] = (off, kind, a, b, 0, [rng.integers(-1, t + 2) for _ in range(4)])
+    want = plane.copy()
+    for i in range(n):
+        ffi.oracle().ffo_h264_loop_filter(kind, C.cast(want.ctypes.data + int(ed["offset"][i]), u8p), stride,
+                                          int(ed["alpha"][i]), int(ed["beta"][i]), ptr(ed["tc0"][i].copy(), ffi.i8p))
+    assert (want != plane).sum() > 100
+    d_plane = torch.from_numpy(plane).cuda()
+    d_ed = torch.from_numpy(ed.view(np.uint8).reshape(n, 12)).cuda()
+    h264.loop_filter_batch(d_plane, stride, d_ed, n)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_plane.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("mb_w,mb_h,pad", [(1, 1, 0), (5, 3, 16), (45, 30, 0), (240, 135, 0)])
+def test_deblock_frame(mb_w, mb_h, pad):
+    """frame order (wavefront) == serial order, bit for bit; 240x135 MBs = one 4K luma plane"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    rng = np.random.default_rng(mb_w * 100 + mb_h)
+    stride = mb_w * 16 + pad
+    plane = _smooth_plane(rng, mb_h * 16, stride)
+    n = mb_w * mb_h * 8
+    ed = np.zeros(n, EDGE_DT)
+    lad = np.array(LADDER)
+    sel = rng.integers(0, len(LADDER), n)
+    ed["alpha"], ed["beta"] = lad[sel, 0], lad[sel, 1]
+    ed["kind"] = np.where(rng.random(n) < .25, 4, 0)
+    ed["tc0"] = rng.integers(-1, 5, (n, 4))
+    ed["alpha"][rng.random(n) < .15] = 0            # skipped edges
+    want = plane.copy()
+    ffi.oracle().ffo_h264_deblock_frame(ptr(want), stride, mb_w, mb_h, C.c_void_p(ed.ctypes.data))
+    d_plane = torch.from_numpy(plane).cuda()
+    d_ed = torch.from_numpy(ed.view(np.uint8).reshape(n, 12)).cuda()
+    h264.deblock_frame(d_plane, stride, mb_w, mb_h, d_ed)
+    torch.cuda.synchronize()
+    got = d_plane.cpu().numpy()
+    assert (want != plane).sum() > (10 if mb_w > 1 else 0)
+    assert np.array_equal(got, want), "%d mismatches" % (got != want).sum()
+
+
+QPEL_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy", np.uint8), ("size_idx", np.uint8),
+                    ("avg", np.uint8), ("pad", np.uint8)])
+
+
+@pytest.mark.parametrize("w,h,pad", [(64, 48, 0), (3840, 2160, 0), (208, 96, 5)])
+def test_qpel_batch(w, h, pad):
+    """put/avg x 16 mcXY x 3 sizes mixed in one batch; unaligned reference positions"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    rng = np.random.default_rng(w + pad)
+    P = 32                                                  # reference padding so that MVs may point outside the picture
+    stride = w + 2 * P + pad
+    ref = rng.integers(0, 256, (h + 2 * P, stride), dtype=np.uint8)
+    dst = rng.integers(0, 256, (h + 2 * P, stride), dtype=np.uint8)
+    blocks = []
+    for my in range(h // 16):
+        for mx in range(w // 16):
+            size_idx = int(rng.integers(0, 3)) if w < 1000 else (0 if rng.random() < .9 else int(rng.integers(1, 3)))
+            n = 16 >> size_idx
+            for sy in range(0, 16, n):
+                for sx in range(0, 16, n):
+                    dy, dx = rng.integers(-24, 25, 2)
+                    y, x = P + my * 16 + sy, P + mx * 16 + sx
+                    blocks.append((y * stride + x, (y + dy) * stride + x + dx, rng.integers(0, 16), size_idx,
+                                   rng.integers(0, 2), 0))
+    bl = np.array(blocks, QPEL_DT)
+    n = len(bl)
+    want = dst.copy()
+    O = ffi.oracle()
+    chk = np.arange(n) if n <= 30000 else rng.choice(n, 30000, replace=False)
+    for i in chk:
+        b = bl[i]
+        O.ffo_h264_qpel(int(b["avg"]), int(b["size_idx"]), int(b["mcxy"]), C.cast(want.ctypes.data + int(b["dst_offset"]), u8p),
+                        C.cast(ref.ctypes.data + int(b["src_offset"]), u8p), stride)
+    d_dst, d_ref = torch.from_numpy(dst).cuda(), torch.from_numpy(ref).cuda()
+    d_bl = torch.from_numpy(bl.view(np.uint8).reshape(n, 12)).cuda()
+    h264.qpel_batch(d_dst, d_ref, stride, d_bl, n)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    if n <= 30000:
+        assert np.array_equal(got, want)
+    else:
+        for i in chk:
+            b = bl[i]
+            y, x = divmod(int(b["dst_offset"]), stride)
+            s = 16 >> int(b["size_idx"])
+            assert np.array_equal(got[y:y + s, x:x + s], want[y:y + s, x:x + s]), "block %d mc %d" % (i, b["mcxy"])

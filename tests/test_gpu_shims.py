@@ -1,0 +1,134 @@
+"""GPU parity of the signature-exact host-pointer faces (what ff_*_init_hip() installs into the reference's
+function-pointer tables), checkasm style: random buffers, exact compare, incl. the cleared coefficient block."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import ptr, u8p, i16p, i32p, i8p
+
+pytestmark = pytest.mark.gpu
+
+LF = C.CFUNCTYPE(None, u8p, C.c_ssize_t, C.c_int, C.c_int, i8p)
+LFI = C.CFUNCTYPE(None, u8p, C.c_ssize_t, C.c_int, C.c_int)
+IDCT = C.CFUNCTYPE(None, u8p, i16p, C.c_ssize_t)
+IDCTM = C.CFUNCTYPE(None, u8p, i32p, i16p, C.c_ssize_t, u8p)
+QPEL = C.CFUNCTYPE(None, u8p, u8p, C.c_ssize_t)
+CMP = C.CFUNCTYPE(C.c_int, C.c_void_p, u8p, u8p, C.c_ssize_t, C.c_int)
+
+
+class H264DSP(C.Structure):   # member order of FFHipH264DSPContext (include/ffhip.h)
+    _fields_ = [("v_loop_filter_luma", LF), ("h_loop_filter_luma", LF), ("v_loop_filter_luma_intra", LFI),
+                ("h_loop_filter_luma_intra", LFI), ("v_loop_filter_chroma", LF), ("h_loop_filter_chroma", LF),
+                ("v_loop_filter_chroma_intra", LFI), ("h_loop_filter_chroma_intra", LFI), ("idct_add", IDCT),
+                ("idct8_add", IDCT), ("idct_dc_add", IDCT), ("idct8_dc_add", IDCT), ("idct_add16", IDCTM),
+                ("idct8_add4", IDCTM), ("idct_add16intra", IDCTM)]
+
+
+class H264Qpel(C.Structure):
+    _fields_ = [("put", (QPEL * 16) * 3), ("avg", (QPEL * 16) * 3)]
+
+
+class MECmp(C.Structure):
+    _fields_ = [("sad", CMP * 2), ("hadamard8_diff", CMP * 2), ("pix_abs", (CMP * 1) * 2)]
+
+
+def _lib():
+    from ffmpeg_amd import _lib as L
+    import torch
+    assert torch.cuda.is_available()
+    return L.lib()
+
+
+def test_h264dsp_init_hip():
+    L = _lib()
+    O = ffi.oracle()
+    c = H264DSP()
+    assert L.ff_h264dsp_init_hip(C.byref(c), 10, 1) < 0          # only 8-bit is on the hip path
+    assert L.ff_h264dsp_init_hip(C.byref(c), 8, 1) == 0
+    rng = np.random.default_rng(1)
+    stride = 48
+    # single-block idcts (tests/checkasm/h264dsp.c:175-240)
+    for name, ofn, size in (("idct_add", O.ffo_h264_idct_add, 4), ("idct8_add", O.ffo_h264_idct8_add, 8),
+                            ("idct_dc_add", O.ffo_h264_idct_dc_add, 4), ("idct8_dc_add", O.ffo_h264_idct8_dc_add, 8)):
+        for _ in range(3):
+            dst = rng.integers(0, 256, (16, stride), dtype=np.uint8)
+            blk = rng.integers(-600, 600, size * size).astype(np.int16)
+            wd, wb = dst.copy(), blk.copy()
+            ofn(C.cast(wd.ctypes.data + 2 * stride + 8, u8p), ptr(wb, i16p), stride)
+            getattr(c, name)(C.cast(dst.ctypes.data + 2 * stride + 8, u8p), ptr(blk, i16p), stride)
+            assert np.array_equal(dst, wd) and np.array_equal(blk, wb), name
+    # macroblock dispatchers (tests/checkasm/h264dsp.c:242-326)
+    bo = np.array([(i & 1) * 4 + ((i >> 1) & 1) * 4 * stride + ((i >> 2) & 1) * 8 + (i >> 3) * 8 * stride for i in range(16)],
+                  np.int32)
+    for name, ofn in (("idct_add16", O.ffo_h264_idct_add16), ("idct8_add4", O.ffo_h264_idct8_add4),
+                      ("idct_add16intra", O.ffo_h264_idct_add16intra)):
+        dst = rng.integers(0, 256, (24, stride), dtype=np.uint8)
+        blk = rng.integers(-300, 300, 256).astype(np.int16)
+        blk[16:32] = 0; blk[33:48] = 0
+        nnzc = rng.integers(0, 3, 40, dtype=np.uint8)
+        wd, wb = dst.copy(), blk.copy()
+        ofn(C.cast(wd.ctypes.data + 3 * stride + 4, u8p), ptr(bo, i32p), ptr(wb, i16p), stride, ptr(nnzc))
+        getattr(c, name)(C.cast(dst.ctypes.data + 3 * stride + 4, u8p), ptr(bo, i32p), ptr(blk, i16p), stride, ptr(nnzc))
+        assert np.array_equal(dst, wd) and np.array_equal(blk, wb), name
+    # loop filters (tests/checkasm/h264dsp.c:375-470): 32x16 tile, edge in the middle
+    names = ["v_loop_filter_luma", "h_loop_filter_luma", "v_loop_filter_chroma", "h_loop_filter_chroma",
+             "v_loop_filter_luma_intra", "h_loop_filter_luma_intra", "v_loop_filter_chroma_intra", "h_loop_filter_chroma_intra"]
+    for kind, name in enumerate(names):
+        for alpha, beta, t in ((20, 6, 1), (80, 12, 3), (255, 18, 13)):
+            base = rng.integers(100, 140, (32, 40)).astype(np.uint8)
+            tc0 = np.array([t, -1, 0, t], np.int8)
+            wd = base.copy()
+            off = 16 * 40 + 16
+            O.ffo_h264_loop_filter(kind, C.cast(wd.ctypes.data + off, u8p), 40, alpha, beta, ptr(tc0, i8p))
+            got = base.copy()
+            if kind < 4:
+                getattr(c, name)(C.cast(got.ctypes.data + off, u8p), 40, alpha, beta, ptr(tc0, i8p))
+            else:
+                getattr(c, name)(C.cast(got.ctypes.data + off, u8p), 40, alpha, beta)
+            assert np.array_equal(got, wd), name
+            assert (wd != base).any()
+
+
+def test_h264qpel_init_hip():
+    """tests/checkasm/h264qpel.c:51-82: put/avg x sizes x 16 positions, src and dst buffers compared"""
+    L = _lib()
+    c = H264Qpel()
+    assert L.ff_h264qpel_init_hip(C.byref(c), 8) == 0
+    rng = np.random.default_rng(2)
+    stride = 64
+    for avg in (0, 1):
+        tab = c.avg if avg else c.put
+        for size_idx in range(3):
+            for mc in range(16):
+                src = rng.integers(0, 256, (40, stride), dtype=np.uint8)
+                dst = rng.integers(0, 256, (40, stride), dtype=np.uint8)
+                wd = dst.copy()
+                so, do = 8 * stride + 11, 8 * stride + 16
+                ffi.oracle().ffo_h264_qpel(avg, size_idx, mc, C.cast(wd.ctypes.data + do, u8p),
+                                           C.cast(src.ctypes.data + so, u8p), stride)
+                s0 = src.copy()
+                tab[size_idx][mc](C.cast(dst.ctypes.data + do, u8p), C.cast(src.ctypes.data + so, u8p), stride)
+                assert np.array_equal(dst, wd) and np.array_equal(src, s0), (avg, size_idx, mc)
+
+
+def test_me_cmp_init_hip():
+    """tests/checkasm/motion.c:37-92: the context pointer is NULL"""
+    L = _lib()
+    O = ffi.oracle()
+    c = MECmp()
+    assert L.ff_me_cmp_init_hip(C.byref(c)) == 0
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    b = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    for _ in range(6):
+        y1, x1, y2, x2 = rng.integers(0, 40, 4)
+        x1 = (x1 // 16) * 16
+        pa, pb = C.cast(a.ctypes.data + int(y1) * 64 + int(x1), u8p), C.cast(b.ctypes.data + int(y2) * 64 + int(x2), u8p)
+        for h in (8, 16):
+            assert c.sad[0](None, pa, pb, 64, h) == O.ffo_sad(16, pa, pb, 64, h)
+            assert c.sad[1](None, pa, pb, 64, h) == O.ffo_sad(8, pa, pb, 64, h)
+            assert c.pix_abs[0][0](None, pa, pb, 64, h) == O.ffo_sad(16, pa, pb, 64, h)
+            assert c.hadamard8_diff[0](None, pa, pb, 64, h) == O.ffo_hadamard8_diff16(pa, pb, 64, h)
+        assert c.hadamard8_diff[1](None, pa, pb, 64, 8) == O.ffo_hadamard8_diff8x8(pa, pb, 64)
