@@ -4,7 +4,7 @@
   step      one pass of the hot path over one batch: 256 nv12 1920x1080 frames -> nv12 3840x2160,
             SWS_BICUBIC (BASELINE.json configs[1]), inputs and outputs resident in HBM.
   metric    Mpixels/s of OUTPUT pixels, whole job over all ranks (weak scaling: 256 frames per GPU).
-  roofline  the dominant kernel k_sws_scale_yuv<4,4>: algorithmic bytes per launch
+  roofline  the dominant kernel k_sws_colwalk (one launch per step): algorithmic bytes per launch
             (15,552,000 B/frame x frames) / its average duration measured with HIP
             events on the launch stream, against the 8 TB/s HBM3E peak.
   cpu_baseline  the reference's own C path (oracle/_ref, kind "reference") or the oracle port, timed
@@ -121,6 +121,46 @@ def extras(torch, dev):
     gbs = nb * 384 / (ms * 1e-3) / 1e9
     out["h264_idct8_add"] = {"Gblocks/s": round(nb / (ms * 1e-3) / 1e9, 3), "GB/s": round(gbs, 1),
                              "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "blocks": nb, "ms": round(ms, 4)}
+    del plane, coefs, coefs0, offs
+    # float MDCT-1024 forward, 65,536 transforms (BASELINE configs[3]): 12,288 B per transform
+    from ffmpeg_amd import tx, me
+    nt, ln = 65536, 1024
+    f = tx.TxContext(tx.FLOAT_MDCT, 0, ln, 1.0)
+    tin = torch.rand((nt, 2 * ln), dtype=torch.float32, device=dev)
+    tout = torch.empty((nt, ln), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        f.batch(tout, tin)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(10):
+        f.batch(tout, tin)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    gbs = nt * 12288 / (ms * 1e-3) / 1e9
+    out["mdct1024_fwd"] = {"Mtransforms/s": round(nt / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1),
+                           "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "transforms": nt, "ms": round(ms, 4)}
+    f.close()
+    del tin, tout
+    # exhaustive SAD search, 16x16 blocks, R = 7, 8 pairs of 3840x2160 luma planes (BASELINE configs[4] shape)
+    nf, w, h = 8, 3840, 2160
+    cur = torch.randint(0, 256, (nf, h, w), dtype=torch.uint8, device=dev)
+    ref = torch.roll(cur, shifts=(3, -2), dims=(1, 2)).contiguous()
+    mv = torch.empty((nf, (w // 16) * (h // 16) * 2), dtype=torch.int16, device=dev)
+    cost = torch.empty((nf, (w // 16) * (h // 16)), dtype=torch.int32, device=dev)
+    for kind, name in ((me.SAD, "me_esa_sad_r7"), (me.SATD, "me_esa_satd_r7")):
+        me.esa_batch(cur, ref, w, h, w, w * h, nf, 16, 7, kind, mv, cost)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(3):
+            me.esa_batch(cur, ref, w, h, w, w * h, nf, 16, 7, kind, mv, cost)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        nmb = nf * (w // 16) * (h // 16)
+        out[name] = {"MB-searches/s": round(nmb / (ms * 1e-3), 1), "candidates/s": round(nmb * 225 / (ms * 1e-3), 1),
+                     "frame_pairs": nf, "ms": round(ms, 4)}
+    del cur, ref
     return out
 
 
@@ -205,7 +245,8 @@ def main():
                        "frames_per_gpu": n, "flags": "SWS_BICUBIC", "sharding": "frames/rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "k_sws_scale_yuv<4,4>", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": "k_sws_colwalk<1,3,false>" if ctx.fast_path else "k_sws_scale_yuv<4,4>",
+                         "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME},
         }
         if world == 1 and not args.no_cpu_baseline:
