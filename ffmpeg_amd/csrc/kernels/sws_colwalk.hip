@@ -42,17 +42,73 @@ __device__ __forceinline__ uint32_t cw_pk_u8(int a, int b)
     return r;
 }
 
+
+/*
+ * Hand-scheduled dot products (OPT variant).  hipcc only selects the accumulate-in-place VOP2 form
+ * v_dot2c_i32_i16 for __builtin_amdgcn_sdot2, which costs a v_mov per chain to seed the accumulator;
+ * the VOP3P form v_dot2_i32_i16 takes the seed as a third source (inline 0, or a register).  Hazards are
+ * ours inside asm (gfx90a+/gfx950: a DOT result may feed the SAME opcode as src2 at once, any other VALU
+ * only after 3 wait states — LLVM GCNHazardRecognizer::checkMAIVALUHazards): the 4 chains are interleaved
+ * and the block ends in s_nop 2, so whatever follows is safe.
+ */
+__device__ __forceinline__ void cw_hdots4(int (&d)[4], const uint32_t (&a)[4], const uint32_t (&b)[4], const uint32_t *cf)
+{
+    asm("v_dot2_i32_i16 %0, %4, %12, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %13, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %14, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %15, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %18, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+          "v"(cf[0]), "v"(cf[2]), "v"(cf[4]), "v"(cf[6]), "v"(cf[1]), "v"(cf[3]), "v"(cf[5]), "v"(cf[7]));
+}
+
+/* d[i] = Pa[i] . f01 + Pb[i] . f23 + kround; f01/f23 wave-uniform (one SGPR operand per instruction) */
+__device__ __forceinline__ void cw_vdots4(int (&d)[4], const uint32_t (&pa)[4], const uint32_t (&pb)[4], uint32_t f01,
+                                          uint32_t f23, int kround)
+{
+    asm("v_dot2_i32_i16 %0, %4, %12, %14\n\t"
+        "v_dot2_i32_i16 %1, %5, %12, %14\n\t"
+        "v_dot2_i32_i16 %2, %6, %12, %14\n\t"
+        "v_dot2_i32_i16 %3, %7, %12, %14\n\t"
+        "v_dot2_i32_i16 %0, %8, %13, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %13, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %13, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %13, %3\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]),
+          "s"(f01), "s"(f23), "v"(kround));
+}
+
+typedef short cw_v2i16 __attribute__((ext_vector_type(2)));
+
 struct CwRaw { uint32_t q[4]; };
+
+/* global (address space 1) views: an opaque SGPR pointer would otherwise decay to flat accesses */
+typedef const uint8_t __attribute__((address_space(1))) *cw_gcptr;
+typedef uint8_t __attribute__((address_space(1))) *cw_gptr;
+typedef uint32_t cw_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t cw_u4 __attribute__((ext_vector_type(4)));
+typedef const cw_u2 __attribute__((address_space(1))) *cw_gc2;
+typedef const cw_u4 __attribute__((address_space(1))) *cw_gc4;
+typedef cw_u2 __attribute__((address_space(1))) *cw_g2;
+typedef uint32_t __attribute__((address_space(1))) *cw_g1;
 
 /* raw source bytes of one row for this lane: 8 or 16 bytes at row + byte_base (dword aligned) */
 template <int NRAW>
 __device__ __forceinline__ void cw_load(CwRaw &o, int slot, const uint8_t *row, uint32_t byte_base)
 {
+    cw_gcptr g = (cw_gcptr)row;
     if (NRAW == 16) {
-        const uint4 w = *reinterpret_cast<const uint4 *>(row + byte_base);
+        const cw_u4 w = *(cw_gc4)(g + byte_base);
         o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w;
     } else {
-        const uint2 w = *reinterpret_cast<const uint2 *>(row + byte_base);
+        const cw_u2 w = *(cw_gc2)(g + byte_base);
         o.q[slot] = w.x; o.q[slot + 1] = w.y;
     }
 }
@@ -64,7 +120,7 @@ __device__ __forceinline__ void cw_load(CwRaw &o, int slot, const uint8_t *row, 
  * D = source rows in flight (prefetch depth), a multiple of 3 so that the ring of vertical pairs
  * is indexed statically inside the unrolled row loop.
  */
-template <int KIND, int D, bool PLAIN>
+template <int KIND, int D, bool PLAIN, bool OPT>
 __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, int cb, int lane)
 {
     constexpr int NG = KIND == 0 ? 1 : 2;           /* groups per lane                 */
@@ -114,16 +170,25 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
     const uint32_t bb0 = sil ? 2 * base[0] : base[0];
     const uint32_t bb1 = KIND == 1 ? base[1] : bb0;
 
+    /* OPT: the row pointer is kept opaque in SGPRs so that the access stays `scalar base + 32-bit lane
+     * offset` (global_load saddr form) instead of a per-lane 64-bit multiply-add */
+    auto rowptr = [&](const uint8_t *base, int r, ptrdiff_t stride) {
+        const uint8_t *p = base + (ptrdiff_t)r * stride;
+        if (OPT)
+            asm("" : "+s"(p));
+        return p;
+    };
     auto load_row = [&](CwRaw &o, int r) {
         if (sil) {
-            cw_load<16>(o, 0, s0 + (ptrdiff_t)r * sstride0, bb0);
+            cw_load<16>(o, 0, rowptr(s0, r, sstride0), bb0);
         } else if (PAIR) {
-            cw_load<8>(o, 0, s0 + (ptrdiff_t)r * sstride0, bb0);
-            cw_load<8>(o, 2, s1 + (ptrdiff_t)r * sstride1, bb0);
+            cw_load<8>(o, 0, rowptr(s0, r, sstride0), bb0);
+            cw_load<8>(o, 2, rowptr(s1, r, sstride1), bb0);
         } else {
-            cw_load<8>(o, 0, s0 + (ptrdiff_t)r * sstride0, bb0);
+            const uint8_t *rp = rowptr(s0, r, sstride0);
+            cw_load<8>(o, 0, rp, bb0);
             if (KIND == 1)
-                cw_load<8>(o, 2, s0 + (ptrdiff_t)r * sstride0, bb1);
+                cw_load<8>(o, 2, rp, bb1);
         }
     };
 
@@ -136,6 +201,16 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 Pw[t][g][i] = 0;
+
+    int hprev[NG][4]; /* OPT: last row's (sum >> 7), unsaturated */
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            hprev[g][i] = 0;
+    int kround = 64 << 12; /* OPT: the rounding seed of the vertical sums, pinned in a VGPR */
+    if (OPT)
+        asm volatile("" : "+v"(kround));
 
     auto hpass = [&](const CwRaw &w, uint32_t (&Pnew)[NG][4], const uint32_t (&Pprev)[NG][4]) {
         uint32_t d[NG][2];
@@ -155,14 +230,33 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const int hg = KIND == 1 ? g : 0;
+            if (OPT) {
+                uint32_t a[4], b[4];
+                int acc[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t a = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i]);
-                const uint32_t b = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i + 1]);
-                int acc = cw_dot2(a, cf[hg][2 * i], 0);
-                acc = cw_dot2(b, cf[hg][2 * i + 1], acc);
-                const uint32_t h = (uint32_t)min(acc >> 7, 32767);
-                Pnew[g][i] = __builtin_amdgcn_perm(h, Pprev[g][i], 0x05040302); /* (prev.hi16, h.lo16) */
+                for (int i = 0; i < 4; i++) {
+                    a[i] = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i]);
+                    b[i] = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i + 1]);
+                }
+                cw_hdots4(acc, a, b, cf[hg]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    /* (h[r-1], h[r]) with both halves saturated to int16: equals min(.,32767) + truncation
+                     * because the host has checked that no horizontal sum can fall below -32768 */
+                    const int h = acc[i] >> 7;
+                    Pnew[g][i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[g][i], h));
+                    hprev[g][i] = h;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t a = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i]);
+                    const uint32_t b = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i + 1]);
+                    int acc = cw_dot2(a, cf[hg][2 * i], 0);
+                    acc = cw_dot2(b, cf[hg][2 * i + 1], acc);
+                    const uint32_t h = (uint32_t)min(acc >> 7, 32767);
+                    Pnew[g][i] = __builtin_amdgcn_perm(h, Pprev[g][i], 0x05040302); /* (prev.hi16, h.lo16) */
+                }
             }
         }
     };
@@ -175,41 +269,49 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
     auto emit = [&](int y, uint32_t f01, uint32_t f23, const uint32_t (&Pa)[NG][4], const uint32_t (&Pb)[NG][4]) {
         int v[NG][4];
 #pragma unroll
-        for (int g = 0; g < NG; g++)
+        for (int g = 0; g < NG; g++) {
+            if (OPT) {
+                cw_vdots4(v[g], Pa[g], Pb[g], f01, f23, kround);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int acc = cw_dot2(Pa[g][i], f01, 64 << 12);
-                v[g][i] = cw_dot2(Pb[g][i], f23, acc);
+                for (int i = 0; i < 4; i++) {
+                    const int acc = cw_dot2(Pa[g][i], f01, 64 << 12);
+                    v[g][i] = cw_dot2(Pb[g][i], f23, acc);
+                }
             }
+        }
+        uint8_t *r0p = d0 + (ptrdiff_t)y * dstride0, *r1p = d1 + (ptrdiff_t)y * dstride1;
+        if (OPT)
+            asm("" : "+s"(r0p), "+s"(r1p));
         if (dil) {
             /* yuv2nv12cX_c: bytes U0 V0 U1 V1 ... (V first for NV21) */
             constexpr int b = NG - 1;
             const uint32_t k0 = cw_pk_u8<PLAIN>(v[0][0], v[b][0]), k1 = cw_pk_u8<PLAIN>(v[0][1], v[b][1]);
             const uint32_t k2 = cw_pk_u8<PLAIN>(v[0][2], v[b][2]), k3 = cw_pk_u8<PLAIN>(v[0][3], v[b][3]);
-            uint2 w;
+            cw_u2 w;
             w.x = __builtin_amdgcn_perm(k1, k0, sel_uv);
             w.y = __builtin_amdgcn_perm(k3, k2, sel_uv);
             if (act)
-                *reinterpret_cast<uint2 *>(d0 + (ptrdiff_t)y * dstride0 + dc0) = w;
+                *(cw_g2)((cw_gptr)r0p + dc0) = w;
         } else if (KIND == 1) {
             /* two adjacent groups: one 8-byte store when both exist (dstW % 4 == 0, host-checked) */
-            uint2 w;
+            cw_u2 w;
             w.x = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[0][2], v[0][3]), cw_pk_u8<PLAIN>(v[0][0], v[0][1]), 0x05040100);
             w.y = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[NG - 1][2], v[NG - 1][3]),
                                         cw_pk_u8<PLAIN>(v[NG - 1][0], v[NG - 1][1]), 0x05040100);
-            uint8_t *d = d0 + (ptrdiff_t)y * dstride0 + dc0;
+            cw_gptr d = (cw_gptr)r0p + dc0;
             if (X0[0] + 8 <= dstW)
-                *reinterpret_cast<uint2 *>(d) = w;
+                *(cw_g2)d = w;
             else if (act)
-                *reinterpret_cast<uint32_t *>(d) = w.x;
+                *(cw_g1)d = w.x;
         } else {
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 const uint32_t w = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[g][2], v[g][3]),
                                                          cw_pk_u8<PLAIN>(v[g][0], v[g][1]), 0x05040100);
-                uint8_t *d = g ? d1 + (ptrdiff_t)y * dstride1 + dc1 : d0 + (ptrdiff_t)y * dstride0 + dc0;
+                cw_gptr d = g ? (cw_gptr)r1p + dc1 : (cw_gptr)r0p + dc0;
                 if (act)
-                    *reinterpret_cast<uint32_t *>(d) = w;
+                    *(cw_g1)d = w;
             }
         }
     };
@@ -262,7 +364,7 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
     }
 }
 
-template <int LK, int D, bool PLAIN>
+template <int LK, int D, bool PLAIN, bool OPT>
 __global__ __launch_bounds__(256) void k_sws_colwalk(FFHipCwArgs A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -279,13 +381,13 @@ __global__ __launch_bounds__(256) void k_sws_colwalk(FFHipCwArgs A)
     const int local = u - J.unit_begin;
     const int strip = local / J.ncb, cb = local - strip * J.ncb;
     if (J.kind == 2)
-        cw_unit<2, D, PLAIN>(J, f, strip, cb, lane);
+        cw_unit<2, D, PLAIN, OPT>(J, f, strip, cb, lane);
     else if (J.kind == 3)
-        cw_unit<3, D, PLAIN>(J, f, strip, cb, lane);
+        cw_unit<3, D, PLAIN, OPT>(J, f, strip, cb, lane);
     else if (J.kind == 4)
-        cw_unit<4, D, PLAIN>(J, f, strip, cb, lane);
+        cw_unit<4, D, PLAIN, OPT>(J, f, strip, cb, lane);
     else
-        cw_unit<LK, D, PLAIN>(J, f, strip, cb, lane);
+        cw_unit<LK, D, PLAIN, OPT>(J, f, strip, cb, lane);
 }
 
 /* ---- host side ---------------------------------------------------------------------------------- */
@@ -306,6 +408,19 @@ int ffhip_cw_bank_ok(const int32_t *hpos, int hsize, int hn, int srcW, const int
     }
     for (int y = 0; y < vn; y++) {
         if (vpos[y] < 0 || vpos[y] + 4 > srcH || (y && vpos[y] < vpos[y - 1]))
+            return 0;
+    }
+    return 1;
+}
+
+int ffhip_cw_bank_nowrap(const int16_t *filter, int size, int n)
+{
+    for (int x = 0; x < n; x++) {
+        int neg = 0;
+        for (int j = 0; j < size; j++)
+            if (filter[(size_t)x * size + j] < 0)
+                neg += filter[(size_t)x * size + j];
+        if (255 * neg < -32768 * 128)
             return 0;
     }
     return 1;
@@ -338,15 +453,18 @@ int ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const bool opt = A.flags & 2;
+#define CW_LAUNCH(LK, DD, PL, OP) hipLaunchKernelGGL((k_sws_colwalk<LK, DD, PL, OP>), grid, block, 0, stream, A)
     if (A.flags & 1) {
-        hipLaunchKernelGGL((k_sws_colwalk<0, 3, true>), grid, block, 0, stream, A);
+        CW_LAUNCH(0, 3, true, false);
     } else if (luma_groups == 2) {
-        if (depth == 6) hipLaunchKernelGGL((k_sws_colwalk<1, 6, false>), grid, block, 0, stream, A);
-        else            hipLaunchKernelGGL((k_sws_colwalk<1, 3, false>), grid, block, 0, stream, A);
+        if (depth == 6) { if (opt) CW_LAUNCH(1, 6, false, true); else CW_LAUNCH(1, 6, false, false); }
+        else            { if (opt) CW_LAUNCH(1, 3, false, true); else CW_LAUNCH(1, 3, false, false); }
     } else {
-        if (depth == 6) hipLaunchKernelGGL((k_sws_colwalk<0, 6, false>), grid, block, 0, stream, A);
-        else            hipLaunchKernelGGL((k_sws_colwalk<0, 3, false>), grid, block, 0, stream, A);
+        if (depth == 6) { if (opt) CW_LAUNCH(0, 6, false, true); else CW_LAUNCH(0, 6, false, false); }
+        else            { if (opt) CW_LAUNCH(0, 3, false, true); else CW_LAUNCH(0, 3, false, false); }
     }
+#undef CW_LAUNCH
     LAUNCH_CHECK();
     return 0;
 }

@@ -27,6 +27,7 @@ struct FFHipSwsContext {
     FFHipScalePlaneArgs lum, chr;
     FFHipScaleRgbArgs rgb;
     int cw_ok = 0; /* both bank pairs fit the column-walking fast path (sws_colwalk.hip) */
+    int cw_opt = 0; /* ... and no horizontal sum can wrap int16: the hand-scheduled variant applies */
     /* staging for the host-pointer face */
     void *stage = nullptr;
     size_t stage_sz = 0;
@@ -154,6 +155,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                                     c->d[2].n, l.srcH) &&
                    ffhip_cw_bank_ok(c->p[1].data(), c->d[1].size, c->d[1].n, ch.srcW, c->p[3].data(), c->d[3].size,
                                     c->d[3].n, ch.srcH);
+        c->cw_opt = c->cw_ok && ffhip_cw_bank_nowrap(c->f[0].data(), c->d[0].size, c->d[0].n) &&
+                    ffhip_cw_bank_nowrap(c->f[1].data(), c->d[1].size, c->d[1].n);
     }
     if (r < 0) {
         ffhip_sws_freeContext(c);
@@ -276,7 +279,10 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             FFHipCwArgs A;
             memset(&A, 0, sizeof(A));
             A.nframes = nframes;
+            const char *eo = getenv("FFHIP_CW_OPT");
             A.flags = ep && ep[0] == '1' ? 1 : 0;
+            if (c->cw_opt && !A.flags && !(eo && eo[0] == '0'))
+                A.flags |= 2;
             auto bank = [&](FFHipCwJob &j, const FFHipScalePlaneArgs &p) {
                 j.srcW = p.srcW; j.srcH = p.srcH; j.dstW = p.dstW; j.dstH = p.dstH;
                 j.hf = p.h.filter; j.hp = p.h.pos; j.vf = p.v.filter; j.vp = p.v.pos;

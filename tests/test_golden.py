@@ -1,0 +1,130 @@
+"""The oracle against the committed golden vectors (tests/golden/*.npz, outputs of the real reference written by
+tools/make_golden.py).  Runs anywhere — this is what pins oracle/ on a box without /root/reference."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import ptr, u8p, i8p, i16p, i32p, f32p
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def at(a, off):
+    return C.cast(a.ctypes.data + int(off), u8p)
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def sws_cases():
+    d = load("sws")
+    for i in range(int(d["ncases"][0])):
+        sf, sw, sh, df, dw, dh, fl, unscaled = [int(v) for v in d["c%d_meta" % i]]
+        src = [np.ascontiguousarray(d["c%d_src%d" % (i, p)]) for p in range(3) if "c%d_src%d" % (i, p) in d]
+        dst = [d["c%d_dst%d" % (i, p)] for p in range(3) if "c%d_dst%d" % (i, p) in d]
+        banks = None
+        if not unscaled:
+            banks = {}
+            for name in ("hLum", "hChr", "vLum", "vChr"):
+                fs, n = [int(v) for v in d["c%d_%s_s" % (i, name)]]
+                banks[name] = (d["c%d_%s_f" % (i, name)], d["c%d_%s_p" % (i, name)], fs, n)
+        yield (sf, sw, sh, df, dw, dh, fl, unscaled), src, dst, banks
+
+
+def test_sws_golden():
+    O = ffi.oracle()
+    n = 0
+    for (sf, sw, sh, df, dw, dh, fl, unscaled), src, want, banks in sws_cases():
+        sp, ss = ffi.planes(src)
+        if unscaled:
+            luts = ffi.OLuts()
+            k = ffi.OYuv2RgbCoeffs(*[ffi.DEFAULT_COEFFS[x] for x in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+            O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
+            got = np.zeros_like(want[0])
+            O.ffo_yuv420p_to_rgb24(C.byref(luts), sw, sp, ss, 0, sh, ptr(got), got.strides[0], df == 3)
+            wv = 3 * (sw & ~1)
+            assert np.array_equal(got[:, :wv], want[0][:, :wv])
+        else:
+            t = ffi.make_otables(sw, sh, sf, dw, dh, df, fl, banks)
+            got = ffi.alloc_frame(df, dw, dh)
+            dp, ds = ffi.planes(got)
+            assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b)
+        n += 1
+    assert n >= 8
+
+
+def test_sws_host_tables_golden():
+    """our initFilter() restatement (host logic of the product) reproduces the reference's banks"""
+    from ffmpeg_amd import swscale as S
+    for (sf, sw, sh, df, dw, dh, fl, unscaled), _, _, banks in sws_cases():
+        ht = S.HostTables(sw, sh, sf, dw, dh, df, fl)
+        assert ht.unscaled_yuv2rgb == bool(unscaled)
+        if unscaled:
+            continue
+        for name in ("hLum", "hChr", "vLum", "vChr"):
+            f, p, fs, n = ht.bank(name)
+            rf, rp, rfs, rn = banks[name]
+            assert (fs, n) == (rfs, rn) and np.array_equal(p, rp) and np.array_equal(f, rf), name
+
+
+def test_h264_golden():
+    O = ffi.oracle()
+    d = load("h264")
+    fns = [O.ffo_h264_idct_add, O.ffo_h264_idct8_add, O.ffo_h264_idct_dc_add, O.ffo_h264_idct8_dc_add]
+    for which in range(4):
+        dst, coef = d["idct%d_in_dst" % which].copy(), d["idct%d_in_coef" % which].copy()
+        for i in range(dst.shape[0]):
+            fns[which](ptr(dst[i]), ptr(coef[i], i16p), dst.shape[2])
+        assert np.array_equal(dst, d["idct%d_out_dst" % which]) and np.array_equal(coef, d["idct%d_out_coef" % which])
+    imgs = d["lf_in"].copy()
+    for i, (which, alpha, beta, *tc0) in enumerate(d["lf_par"]):
+        O.ffo_h264_loop_filter(int(which), at(imgs[i], 8 * 32 + 8), 32, int(alpha), int(beta), ptr(np.array(tc0, np.int8), i8p))
+    assert np.array_equal(imgs, d["lf_out"])
+    src = np.ascontiguousarray(d["qpel_src"])
+    for i, (avg, size_idx, mc) in enumerate(d["qpel_par"]):
+        o = d["qpel_dst"].copy()
+        O.ffo_h264_qpel(int(avg), int(size_idx), int(mc), at(o, 6 * 64 + 8), at(src, 6 * 64 + 8), 64)
+        assert np.array_equal(o[6:22, 8:24], d["qpel_out"][i]), (avg, size_idx, mc)
+
+
+def test_me_golden():
+    O = ffi.oracle()
+    d = load("me")
+    a, b = np.ascontiguousarray(d["cmp_a"]), np.ascontiguousarray(d["cmp_b"])
+    for (y1, x1, y2, x2), want in zip(d["cmp_pos"], d["cmp_vals"]):
+        pa, pb = at(a, y1 * 64 + x1), at(b, y2 * 64 + x2)
+        got = [O.ffo_sad(16, pa, pb, 64, 16), O.ffo_sad(16, pa, pb, 64, 8), O.ffo_sad(8, pa, pb, 64, 8),
+               O.ffo_hadamard8_diff16(pa, pb, 64, 16), O.ffo_hadamard8_diff16(pa, pb, 64, 8), O.ffo_hadamard8_diff8x8(pa, pb, 64)]
+        assert got == list(want)
+    cur, ref = np.ascontiguousarray(d["esa_cur"]), np.ascontiguousarray(d["esa_ref"])
+    h, w = cur.shape
+    for Rr in (3, 7):
+        mv = np.zeros((h // 16) * (w // 16) * 2, np.int16)
+        cost = np.zeros((h // 16) * (w // 16), np.uint32)
+        O.ffo_me_esa_frame(ptr(cur), ptr(ref), w, w, h, 16, Rr, 0, ptr(mv, i16p), cost.ctypes.data_as(C.POINTER(C.c_uint32)))
+        assert np.array_equal(mv.reshape(-1, 2), d["esa_mv_r%d" % Rr]) and np.array_equal(cost, d["esa_cost_r%d" % Rr])
+
+
+def test_tx_golden():
+    O = ffi.oracle()
+    d = load("tx")
+    n = 0
+    for key in d["keys"]:
+        key = str(key)
+        _, inv, scale = key.split("_")
+        len_ = int(key.split("_")[0][4:])
+        x, want = d[key + "_in"], d[key + "_out"]
+        s = O.ffo_mdct_create(int(inv), len_, float(scale))
+        for t in range(x.shape[0]):
+            out = np.zeros(len_, np.float32)
+            O.ffo_mdct_run(s, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p), 4)
+            assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), key
+        O.ffo_mdct_free(s)
+        n += 1
+    assert n == 6

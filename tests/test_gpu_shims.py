@@ -76,8 +76,9 @@ def test_h264dsp_init_hip():
     names = ["v_loop_filter_luma", "h_loop_filter_luma", "v_loop_filter_chroma", "h_loop_filter_chroma",
              "v_loop_filter_luma_intra", "h_loop_filter_luma_intra", "v_loop_filter_chroma_intra", "h_loop_filter_chroma_intra"]
     for kind, name in enumerate(names):
+        changed = 0
         for alpha, beta, t in ((20, 6, 1), (80, 12, 3), (255, 18, 13)):
-            base = rng.integers(100, 140, (32, 40)).astype(np.uint8)
+            base = rng.integers(110, 126, (32, 40)).astype(np.uint8)
             tc0 = np.array([t, -1, 0, t], np.int8)
             wd = base.copy()
             off = 16 * 40 + 16

@@ -19,6 +19,8 @@ VARIANTS = [
     {"FFHIP_CW_DEPTH": "6"},
     {"FFHIP_CW_LUMA_GROUPS": "1", "FFHIP_CW_DEPTH": "6", "FFHIP_CW_STRIP": "37"},
     {"FFHIP_CW_PLAIN": "1"},
+    {"FFHIP_CW_OPT": "0"},
+    {"FFHIP_CW_OPT": "0", "FFHIP_CW_DEPTH": "6", "FFHIP_CW_LUMA_GROUPS": "1"},
     {"FFHIP_CW_STRIP": "128"},
     {"FFHIP_SWS_FAST": "0"},
 ]
@@ -47,7 +49,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     from ffmpeg_amd import swscale as S
     torch = _torch()
     rng = np.random.default_rng(seed)
-    for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST"):
+    for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -150,8 +152,8 @@ def _adversarial_banks(rng, srcW, srcH, dstW, dstH, extreme):
 
 
 @pytest.mark.parametrize("extreme", [0, 1])
-@pytest.mark.parametrize("env", [{}, {"FFHIP_CW_LUMA_GROUPS": "1", "FFHIP_CW_DEPTH": "6"}, {"FFHIP_CW_PLAIN": "1"}],
-                         ids=["default", "g1d6", "plain"])
+@pytest.mark.parametrize("env", [{}, {"FFHIP_CW_LUMA_GROUPS": "1", "FFHIP_CW_DEPTH": "6"}, {"FFHIP_CW_PLAIN": "1"},
+                                 {"FFHIP_CW_OPT": "0"}], ids=["default", "g1d6", "plain", "noopt"])
 @pytest.mark.parametrize("fmts", [("nv12", "nv12"), ("yuv420p", "nv21"), ("nv21", "yuv420p"), ("yuv420p", "yuv420p")])
 def test_fast_path_adversarial_tables(fmts, env, extreme, monkeypatch):
     sw, sh, dw, dh = 200, 120, 520, 300

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""tools/make_golden.py — writes tests/golden/*.npz: seeded inputs and the outputs of the REAL reference
+(oracle/_ref/libffref.so, compiled from /root/reference by oracle/refbuild/Makefile) for every row of the hot
+path.  Run in the build container (the reference does not travel); the fixtures do, and pin both the oracle
+(tests/test_golden.py, CPU) and the HIP kernels (tests/test_gpu_golden.py) where the reference is absent."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ffi  # noqa: E402
+from ffi import PIX, ptr, u8p, i8p, i16p, i32p, f32p  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+R = ffi.ref()
+
+
+def at(a, off):
+    return C.cast(a.ctypes.data + int(off), u8p)
+
+
+def sws():
+    d = {}
+    rng = np.random.default_rng(1001)
+    cases = [("yuv420p", 64, 16, "rgb24", 64, 16, 4), ("yuv420p", 62, 8, "bgr24", 62, 8, 4),
+             ("nv12", 96, 54, "nv12", 192, 108, 4), ("nv21", 64, 40, "yuv420p", 160, 88, 4),
+             ("yuv420p", 64, 48, "nv12", 128, 96, 4), ("nv12", 80, 48, "nv12", 48, 32, 4),
+             ("yuv420p", 48, 32, "rgb24", 96, 64, 4), ("yuv420p", 48, 32, "bgr24", 48, 32, 4 | 0x40000 | 0x80000)]
+    for i, (sf, sw, sh, df, dw, dh, fl) in enumerate(cases):
+        src = ffi.alloc_frame(PIX[sf], sw, sh, rng)
+        ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, PIX[df], fl, 1)
+        dst = ffi.alloc_frame(PIX[df], dw, dh)
+        sp, ss = ffi.planes(src)
+        dp, ds = ffi.planes(dst)
+        assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, dp, ds) == dh
+        d["c%d_meta" % i] = np.array([PIX[sf], sw, sh, PIX[df], dw, dh, fl, R.ffref_sws_is_unscaled(ctx)], np.int64)
+        for p, a in enumerate(src):
+            d["c%d_src%d" % (i, p)] = a
+        for p, a in enumerate(dst):
+            d["c%d_dst%d" % (i, p)] = a
+        if not R.ffref_sws_is_unscaled(ctx):
+            for name, (f, pos, fs, n) in ffi.ref_tables(ctx).items():
+                d["c%d_%s_f" % (i, name)] = f
+                d["c%d_%s_p" % (i, name)] = pos
+                d["c%d_%s_s" % (i, name)] = np.array([fs, n], np.int32)
+        R.ffref_sws_free(ctx)
+    d["ncases"] = np.array([len(cases)])
+    np.savez_compressed(os.path.join(OUT, "sws.npz"), **d)
+
+
+def h264():
+    d = {}
+    rng = np.random.default_rng(1002)
+    stride = 32
+    for which, size in ((0, 4), (1, 8), (2, 4), (3, 8)):
+        n = 24
+        coefs = rng.integers(-1500, 1500, (n, size * size)).astype(np.int16)
+        coefs[::5] = rng.integers(-32768, 32768, coefs[::5].shape).astype(np.int16)
+        coefs[1::4, 1:] = 0
+        dst = rng.integers(0, 256, (n, size, stride), dtype=np.uint8)
+        od, oc = dst.copy(), coefs.copy()
+        for i in range(n):
+            R.ffref_h264_idct(which, ptr(od[i]), ptr(oc[i], i16p), stride)
+        d["idct%d_in_dst" % which], d["idct%d_in_coef" % which] = dst, coefs
+        d["idct%d_out_dst" % which], d["idct%d_out_coef" % which] = od, oc
+    lf_in, lf_out, lf_par = [], [], []
+    for which in range(8):
+        for alpha, beta, t in ((255, 18, 13), (127, 16, 6), (45, 10, 3), (17, 6, 1), (9, 3, 0)):
+            base = int(rng.integers(30, 220))
+            img = np.clip(base + rng.integers(-7, 8, (32, 32)), 0, 255).astype(np.uint8)
+            tc0 = np.array([t, -1, 0, max(t - 1, 0)], np.int8)
+            o = img.copy()
+            R.ffref_h264_loop_filter(which, at(o, 8 * 32 + 8), 32, alpha, beta, ptr(tc0.copy(), i8p))
+            lf_in.append(img); lf_out.append(o); lf_par.append([which, alpha, beta] + list(tc0))
+    d["lf_in"], d["lf_out"], d["lf_par"] = np.stack(lf_in), np.stack(lf_out), np.array(lf_par, np.int32)
+    q_out, q_par = [], []
+    src = rng.integers(0, 256, (32, 64), dtype=np.uint8)
+    dst = rng.integers(0, 256, (32, 64), dtype=np.uint8)
+    for avg in (0, 1):
+        for size_idx in range(3):
+            for mc in range(16):
+                o = dst.copy()
+                R.ffref_h264_qpel(avg, size_idx, mc, at(o, 6 * 64 + 8), at(src, 6 * 64 + 8), 64)
+                assert np.array_equal(o[:6], dst[:6]) and np.array_equal(o[22:], dst[22:])
+                q_out.append(o[6:22, 8:24].copy()); q_par.append([avg, size_idx, mc])
+    d["qpel_src"], d["qpel_dst"], d["qpel_out"], d["qpel_par"] = src, dst, np.stack(q_out), np.array(q_par, np.int32)
+    np.savez_compressed(os.path.join(OUT, "h264.npz"), **d)
+
+
+def me():
+    d = {}
+    rng = np.random.default_rng(1003)
+    a = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-20, 21, (64, 64)), 0, 255).astype(np.uint8)
+    pos, vals = [], []
+    for _ in range(40):
+        y1, x1, y2, x2 = [int(v) for v in rng.integers(0, 40, 4)]
+        x1 &= ~15
+        pa, pb = at(a, y1 * 64 + x1), at(b, y2 * 64 + x2)
+        pos.append([y1, x1, y2, x2])
+        vals.append([R.ffref_me_cmp(0, 0, pa, pb, 64, 16), R.ffref_me_cmp(0, 0, pa, pb, 64, 8), R.ffref_me_cmp(0, 1, pa, pb, 64, 8),
+                     R.ffref_me_cmp(1, 0, pa, pb, 64, 16), R.ffref_me_cmp(1, 0, pa, pb, 64, 8), R.ffref_me_cmp(1, 1, pa, pb, 64, 8)])
+    d["cmp_a"], d["cmp_b"], d["cmp_pos"], d["cmp_vals"] = a, b, np.array(pos, np.int32), np.array(vals, np.int32)
+    w, h = 96, 64
+    ref_img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    cur = np.roll(ref_img, (2, -3), (0, 1)).copy()
+    cur[:16, :16] = ref_img[:16, :16]
+    cur[20:, 40:] = rng.integers(0, 4, cur[20:, 40:].shape, dtype=np.uint8)
+    for Rr in (3, 7):
+        mv, cost = [], []
+        for by in range(h // 16):
+            for bx in range(w // 16):
+                m = np.zeros(2, np.int32)
+                c = R.ffref_me_search_esa(ptr(cur), ptr(ref_img), w, w, h, 16, Rr, bx * 16, by * 16, ptr(m, i32p))
+                mv.append(m.copy()); cost.append(c)
+        d["esa_mv_r%d" % Rr], d["esa_cost_r%d" % Rr] = np.array(mv, np.int32), np.array(cost, np.uint64)
+    d["esa_cur"], d["esa_ref"] = cur, ref_img
+    np.savez_compressed(os.path.join(OUT, "me.npz"), **d)
+
+
+def tx():
+    d = {}
+    rng = np.random.default_rng(1004)
+    for len_ in (64, 1024):
+        for inv, scale in ((0, 1.0), (0, 32768.0), (1, 1.0 / len_)):
+            x = rng.uniform(-1, 1, (3, len_ if inv else 2 * len_)).astype(np.float32)
+            rc = R.ffref_tx_create(1, inv, len_, scale, 0)
+            out = np.zeros((3, len_), np.float32)
+            for t in range(3):
+                R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 4)
+            R.ffref_tx_free(rc)
+            key = "mdct%d_%d_%r" % (len_, inv, scale)
+            d[key + "_in"], d[key + "_out"] = x, out
+    d["keys"] = np.array(sorted({k.rsplit("_", 1)[0] for k in d}))
+    np.savez_compressed(os.path.join(OUT, "tx.npz"), **d)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    sws(); h264(); me(); tx()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from ffmpeg_amd import swscale as S  # noqa: E402
 
-KEYS = ("FFHIP_SWS_FAST", "FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP",
+KEYS = ("FFHIP_SWS_FAST", "FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_CW_OPT",
         "FFHIP_YUV2RGB_VARIANT")
 
 
@@ -45,11 +45,11 @@ def main():
     dst = [torch.empty((n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(23, 3840, 2160)]
     byt = n * 15552000
     variants = [{}]
-    for g in ("1", "2"):
-        for d in ("3", "6"):
-            for s in ("60", "120"):
-                variants.append({"FFHIP_CW_LUMA_GROUPS": g, "FFHIP_CW_DEPTH": d, "FFHIP_CW_STRIP": s})
-    variants += [{"FFHIP_CW_STRIP": "30"}, {"FFHIP_CW_PLAIN": "1"}, {"FFHIP_SWS_FAST": "0"}]
+    for o in ("1", "0"):
+        for g in ("1", "2"):
+            for d in ("3", "6"):
+                variants.append({"FFHIP_CW_OPT": o, "FFHIP_CW_LUMA_GROUPS": g, "FFHIP_CW_DEPTH": d})
+    variants += [{"FFHIP_CW_STRIP": "60"}, {"FFHIP_CW_STRIP": "128"}, {"FFHIP_CW_PLAIN": "1"}, {"FFHIP_SWS_FAST": "0"}]
     print("fast path eligible:", ctx.fast_path)
     ref = None
     for env in variants:

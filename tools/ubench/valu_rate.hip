@@ -45,7 +45,7 @@ KERNEL(min_i32, "v_min_i32 %0, %0, %1")
 KERNEL(ashrrev, "v_ashrrev_i32 %0, 7, %0")
 KERNEL(lshl_add, "v_lshl_add_u32 %0, %0, 3, %1")
 KERNEL(fma_f32, "v_fma_f32 %0, %1, %2, %0")
-KERNEL(pk_fma_f32, "v_pk_fma_f32 %0, %1, %2, %0")
+
 KERNEL(bfe_u32, "v_bfe_u32 %0, %0, 8, 8")
 KERNEL(mov_b32, "v_mov_b32 %0, %1")
 KERNEL(cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
@@ -63,7 +63,7 @@ int main()
         I(add_u32), I(dot2c_i32_i16), I(dot4c_i32_i8), I(dot4_u32_u8), I(perm_b32), I(ashr_pk_u8), I(mad_u32_u24),
         I(mad_i32_i24), I(mad_i32_i16), I(mul_lo_u32), I(sad_u8), I(msad_u8), I(sad_u16), I(pk_add_u16),
         I(pk_sub_i16), I(pk_max_i16), I(pk_mad_i16), I(pk_mul_lo_u16), I(med3_i32), I(min_i32), I(ashrrev), I(lshl_add),
-        I(fma_f32), I(pk_fma_f32), I(bfe_u32), I(mov_b32), I(cndmask), I(alignbyte),
+        I(fma_f32), I(bfe_u32), I(mov_b32), I(cndmask), I(alignbyte),
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
