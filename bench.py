@@ -245,7 +245,7 @@ def main():
                        "frames_per_gpu": n, "flags": "SWS_BICUBIC", "sharding": "frames/rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "k_sws_colwalk<1,3,false>" if ctx.fast_path else "k_sws_scale_yuv<4,4>",
+                         "kernel": "k_sws_colwalk<1,6,false,true>" if ctx.fast_path else "k_sws_scale_yuv<4,4>",
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME},
         }
