@@ -231,6 +231,17 @@ def main():
         dist.all_reduce(chk)
     assert float(chk.item()) > 0
 
+    # HBM traffic per launch of the bench kernel from the committed PMC passes (tools/pmc_summary.py): the
+    # counters cannot be read from inside this process; null when no pass of this kernel/batch is on file
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc.json")))
+        for k, v in pm.items():
+            if ctx.fast_path and k.startswith("k_sws_colwalk") and n == 256:
+                traffic = round(v["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_px = world * n * DST_W * DST_H * args.steps
@@ -244,7 +255,7 @@ def main():
                                    "frames resident in HBM (BASELINE.json configs[1])" % n,
                        "frames_per_gpu": n, "flags": "SWS_BICUBIC", "sharding": "frames/rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_sws_colwalk<1,6,false,true>" if ctx.fast_path else "k_sws_scale_yuv<4,4>",
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME},

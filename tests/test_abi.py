@@ -1,0 +1,94 @@
+"""CPU checks of the drop-in boundary: libffhip.so loads, exports every symbol include/ffhip.h declares, and —
+on a box without a HIP device — every entry point refuses loudly (FFHIP_ENOSYS / NULL + error text) instead of
+falling back to a CPU path.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ffmpeg_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ffhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(ffhip_[a-z0-9_]+|ff_[a-z0-9_]+_init_hip)\s*\(", src))
+    names -= {"ffhip_qpel_mc_func", "ffhip_me_cmp_func", "ffhip_tx_fn"}   # typedef'd pointer types
+    return sorted(names)
+
+
+def test_header_symbols_exported():
+    L = C.CDLL(_lib.SO)
+    names = declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert _lib.lib()._missing == []
+    # and the python binding declares every one of them
+    src = open(os.path.join(ROOT, "ffmpeg_amd", "_lib.py")).read()
+    assert not [n for n in names if '"%s"' % n not in src]
+
+
+def test_version_and_error_strings():
+    L = _lib.lib()
+    assert L.ffhip_version().decode()
+    assert isinstance(L.ffhip_last_error(), bytes)
+
+
+@pytest.mark.skipif(_lib.lib().ffhip_device_count() > 0, reason="a HIP device is present: the refusal path is not reachable")
+def test_no_device_means_enosys_not_a_cpu_fallback():
+    L = _lib.lib()
+    ENOSYS = -38
+    assert L.ffhip_device_count() == 0
+    assert not L.ffhip_sws_getContext(64, 32, 0, 64, 32, 2, 4)
+    assert b"no HIP device" in L.ffhip_last_error()
+    ctx, fn, sc = _lib.vp(), _lib.vp(), C.c_float(1.0)
+    assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 1, 0, 1024, C.byref(sc), 0) == ENOSYS and not ctx.value
+    buf = (C.c_uint8 * 4096)()
+    p = C.cast(buf, C.c_void_p)
+    assert L.ff_h264dsp_init_hip(p, 8, 1) == ENOSYS and not any(buf)        # table left untouched
+    assert L.ff_h264qpel_init_hip(p, 8) == ENOSYS and not any(buf)
+    assert L.ff_me_cmp_init_hip(p) == ENOSYS and not any(buf)
+    assert L.ffhip_h264_idct_add_batch_dev(1, p, 64, p, p, 1, None) == ENOSYS
+    assert L.ffhip_h264_qpel_batch_dev(p, p, 64, p, 1, None) == ENOSYS
+    assert L.ffhip_h264_loop_filter_batch_dev(p, 64, p, 1, None) == ENOSYS
+    assert L.ffhip_h264_deblock_frame_dev(p, 64, 1, 1, p, None) == ENOSYS
+    assert L.ffhip_me_cmp_batch_dev(0, 16, 16, p, p, p, p, 64, p, 1, None) == ENOSYS
+    assert L.ffhip_me_esa_batch_dev(p, p, 64, 64, 64, 4096, 1, 16, 7, 0, p, p, None) == ENOSYS
+    vp = C.c_void_p()
+    assert L.ffhip_malloc(C.byref(vp), 16) == ENOSYS
+    from ffmpeg_amd import swscale as S
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        S.SwsContext(64, 32, 0, 64, 32, 2)
+
+
+def test_argument_validation():
+    L = _lib.lib()
+    EINVAL = -22
+    assert L.ffhip_me_cmp_batch_dev(0, 12, 16, None, None, None, None, 64, None, 1, None) == EINVAL
+    assert L.ffhip_me_esa_batch_dev(None, None, 64, 64, 64, 4096, 1, 16, 7, 0, None, None, None) == EINVAL
+    assert L.ffhip_h264_idct_add_batch_dev(1, None, 64, None, None, 1, None) == EINVAL
+    ctx, fn, sc = _lib.vp(), _lib.vp(), C.c_float(1.0)
+    assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 1, 0, 1000, C.byref(sc), 0) == EINVAL      # not a power of two
+    assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 0, 0, 1024, C.byref(sc), 0) == -38         # FFT: not on the hip path
+
+
+def test_host_tables_are_device_free():
+    """filter-bank generation (the host logic of sws_getContext) works without a device and is deterministic"""
+    from ffmpeg_amd import swscale as S
+    a = S.HostTables(1920, 1080, 23, 3840, 2160, 23, S.SWS_BICUBIC)
+    b = S.HostTables(1920, 1080, 23, 3840, 2160, 23, S.SWS_BICUBIC)
+    for name in ("hLum", "hChr", "vLum", "vChr"):
+        fa, pa, sa, na = a.bank(name)
+        fb, pb, sb, nb = b.bank(name)
+        assert sa == 4 and (sa, na) == (sb, nb) and np.array_equal(fa, fb) and np.array_equal(pa, pb)
+        assert (fa.reshape(na, sa).sum(1) == (1 << 14 if name[0] == "h" else 1 << 12)).all()
+    # first rows of the config-2 luma bank as measured from the reference
+    f = a.bank("hLum")[0].reshape(-1, 4)
+    assert f[0].tolist() == [17729, -1345, 0, 0] and f[1].tolist() == [12902, 3943, -461, 0] and f[2].tolist() == [3835, 13894, -1345, 0]
+    assert not a.unscaled_yuv2rgb and S.HostTables(64, 32, 0, 64, 32, 2, 4).unscaled_yuv2rgb
+    assert not S.HostTables(64, 32, 0, 64, 32, 2, 4 | S.SWS_ACCURATE_RND).unscaled_yuv2rgb
