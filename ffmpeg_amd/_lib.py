@@ -35,6 +35,14 @@ def lib():
     if not os.path.exists(SO):
         raise ImportError("ffmpeg_amd/libffhip.so is missing - build it with "
                           "`python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    # In a process that also uses torch, torch's bundled HIP runtime must be the one the process initialises:
+    # libffhip.so's DT_NEEDED libamdhip64.so.7 then binds to the copy torch already loaded (same SONAME).  The
+    # other order loads /opt/rocm's runtime first, torch then brings its own, and two runtimes fight over the
+    # device (torch.cuda.is_available() turns False).  A host without torch (FFmpeg itself) is unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO)
     sig = {
         "ffhip_device_count": (C.c_int, []),

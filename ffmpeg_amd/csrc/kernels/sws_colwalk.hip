@@ -87,6 +87,12 @@ __device__ __forceinline__ void cw_vdots4(int (&d)[4], const uint32_t (&pa)[4], 
 
 typedef short cw_v2i16 __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ uint32_t cw_opaque(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 struct CwRaw { uint32_t q[4]; };
 
 /* global (address space 1) views: an opaque SGPR pointer would otherwise decay to flat accesses */
@@ -104,6 +110,10 @@ template <int NRAW>
 __device__ __forceinline__ void cw_load(CwRaw &o, int slot, const uint8_t *row, uint32_t byte_base)
 {
     cw_gcptr g = (cw_gcptr)row;
+    /* keep the zero-extension of the lane offset next to the access (an empty volatile asm cannot be hoisted out
+     * of the row loop): only then does instruction selection see `uniform base + zext(32-bit lane offset)` and
+     * pick the global_load saddr form instead of a 64-bit VALU add per access */
+    asm volatile("" : "+v"(byte_base));
     if (NRAW == 16) {
         const cw_u4 w = *(cw_gc4)(g + byte_base);
         o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w;
@@ -170,14 +180,7 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
     const uint32_t bb0 = sil ? 2 * base[0] : base[0];
     const uint32_t bb1 = KIND == 1 ? base[1] : bb0;
 
-    /* OPT: the row pointer is kept opaque in SGPRs so that the access stays `scalar base + 32-bit lane
-     * offset` (global_load saddr form) instead of a per-lane 64-bit multiply-add */
-    auto rowptr = [&](const uint8_t *base, int r, ptrdiff_t stride) {
-        const uint8_t *p = base + (ptrdiff_t)r * stride;
-        if (OPT)
-            asm("" : "+s"(p));
-        return p;
-    };
+    auto rowptr = [&](const uint8_t *base, int r, ptrdiff_t stride) { return base + (ptrdiff_t)r * stride; };
     auto load_row = [&](CwRaw &o, int r) {
         if (sil) {
             cw_load<16>(o, 0, rowptr(s0, r, sstride0), bb0);
@@ -266,7 +269,8 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
     const uint32_t dc0 = (dil ? 2 : 1) * X0[0], dc1 = X0[0]; /* this lane's first byte of a row */
 
     /* Pa = pairs (h[p], h[p+1]), Pb = (h[p+2], h[p+3]) of the row's window */
-    auto emit = [&](int y, uint32_t f01, uint32_t f23, const uint32_t (&Pa)[NG][4], const uint32_t (&Pb)[NG][4]) {
+    auto emit = [&](uint8_t *r0p, uint8_t *r1p, uint32_t f01, uint32_t f23, const uint32_t (&Pa)[NG][4],
+                    const uint32_t (&Pb)[NG][4]) {
         int v[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; g++) {
@@ -280,9 +284,6 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
                 }
             }
         }
-        uint8_t *r0p = d0 + (ptrdiff_t)y * dstride0, *r1p = d1 + (ptrdiff_t)y * dstride1;
-        if (OPT)
-            asm("" : "+s"(r0p), "+s"(r1p));
         if (dil) {
             /* yuv2nv12cX_c: bytes U0 V0 U1 V1 ... (V first for NV21) */
             constexpr int b = NG - 1;
@@ -292,14 +293,14 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
             w.x = __builtin_amdgcn_perm(k1, k0, sel_uv);
             w.y = __builtin_amdgcn_perm(k3, k2, sel_uv);
             if (act)
-                *(cw_g2)((cw_gptr)r0p + dc0) = w;
+                *(cw_g2)((cw_gptr)r0p + cw_opaque(dc0)) = w;
         } else if (KIND == 1) {
             /* two adjacent groups: one 8-byte store when both exist (dstW % 4 == 0, host-checked) */
             cw_u2 w;
             w.x = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[0][2], v[0][3]), cw_pk_u8<PLAIN>(v[0][0], v[0][1]), 0x05040100);
             w.y = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[NG - 1][2], v[NG - 1][3]),
                                         cw_pk_u8<PLAIN>(v[NG - 1][0], v[NG - 1][1]), 0x05040100);
-            cw_gptr d = (cw_gptr)r0p + dc0;
+            cw_gptr d = (cw_gptr)r0p + cw_opaque(dc0);
             if (X0[0] + 8 <= dstW)
                 *(cw_g2)d = w;
             else if (act)
@@ -309,7 +310,7 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
             for (int g = 0; g < NG; g++) {
                 const uint32_t w = __builtin_amdgcn_perm(cw_pk_u8<PLAIN>(v[g][2], v[g][3]),
                                                          cw_pk_u8<PLAIN>(v[g][0], v[g][1]), 0x05040100);
-                cw_gptr d = g ? (cw_gptr)r1p + dc1 : (cw_gptr)r0p + dc0;
+                cw_gptr d = g ? (cw_gptr)r1p + cw_opaque(dc1) : (cw_gptr)r0p + cw_opaque(dc0);
                 if (act)
                     *(cw_g1)d = w;
             }
@@ -335,10 +336,42 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
     int need = __builtin_amdgcn_readlane(vpl[0], 0) + 3;
     const int rlast = __builtin_amdgcn_readfirstlane(J.vp[y1 - 1]) + 3;
     int r = need - 3;
+    /* Scalar running pointers (two SALU adds per step instead of a 64-bit multiply per access): pf* = the next
+     * source row to prefetch (stops advancing at rlast, which makes the clamped prefetch unconditional), dr* =
+     * the next destination row.  Kept opaque so they stay in SGPRs. */
+    int pfrow = r;
+    const uint8_t *pf0 = s0 + (ptrdiff_t)r * sstride0, *pf1 = s1 + (ptrdiff_t)r * sstride1;
+    uint8_t *dr0 = d0 + (ptrdiff_t)y0 * dstride0, *dr1 = d1 + (ptrdiff_t)y0 * dstride1;
+    asm("" : "+s"(pf0), "+s"(pf1), "+s"(dr0), "+s"(dr1));
+    auto load_next = [&](CwRaw &o) {
+        if (sil) {
+            cw_load<16>(o, 0, pf0, bb0);
+        } else if (PAIR) {
+            cw_load<8>(o, 0, pf0, bb0);
+            cw_load<8>(o, 2, pf1, bb0);
+        } else {
+            cw_load<8>(o, 0, pf0, bb0);
+            if (KIND == 1)
+                cw_load<8>(o, 2, pf0, bb1);
+        }
+        const bool adv = pfrow < rlast;
+        pfrow = min(pfrow + 1, rlast);
+        pf0 += adv ? sstride0 : 0;
+        pf1 += adv ? sstride1 : 0;
+        asm("" : "+s"(pf0), "+s"(pf1));
+    };
+    /* current descriptor set (rows 0..63 of the strip, then 64..127) */
+    int cvpl = vpl[0];
+    uint32_t cvf01 = vf01[0], cvf23 = vf23[0];
+
     CwRaw buf[D];
 #pragma unroll
-    for (int k = 0; k < D; k++)
-        load_row(buf[k], min(r + k, rlast));
+    for (int k = 0; k < D; k++) {
+        if (OPT)
+            load_next(buf[k]);
+        else
+            load_row(buf[k], min(r + k, rlast));
+    }
     for (; r <= rlast; r += D) {
 #pragma unroll
         for (int k = 0; k < D; k++) {
@@ -346,18 +379,40 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
             /* the prefetch is unconditional (its row index is clamped): a load under the branch would be
              * copied into place after it, and that copy would wait for the load just issued */
             const CwRaw cur = buf[k];
-            load_row(buf[k], min(rr + D, rlast));
+            if (OPT)
+                load_next(buf[k]);
+            else
+                load_row(buf[k], min(rr + D, rlast));
             if (rr <= rlast) {
                 hpass(cur, Pw[k % 3], Pw[(k + 2) % 3]);
                 while (yy < ny && need <= rr) {
-                    const bool hi = yy >= 64;
-                    const int ll = yy & 63;
-                    const uint32_t f01 = __builtin_amdgcn_readlane(hi ? vf01[1] : vf01[0], ll);
-                    const uint32_t f23 = __builtin_amdgcn_readlane(hi ? vf23[1] : vf23[0], ll);
-                    emit(y0 + yy, f01, f23, Pw[(k + 1) % 3], Pw[k % 3]);
-                    yy++;
-                    if (yy < ny)
-                        need = __builtin_amdgcn_readlane(yy >= 64 ? vpl[1] : vpl[0], yy & 63) + 3;
+                    if (OPT) {
+                        const int ll = yy & 63;
+                        emit(dr0, dr1, __builtin_amdgcn_readlane(cvf01, ll), __builtin_amdgcn_readlane(cvf23, ll),
+                             Pw[(k + 1) % 3], Pw[k % 3]);
+                        dr0 += dstride0;
+                        dr1 += dstride1;
+                        asm("" : "+s"(dr0), "+s"(dr1));
+                        yy++;
+                        if (yy == 64) { /* a real (uniform) branch, taken once per strip: not three selects per row */
+                            asm volatile("; second descriptor set");
+                            cvpl = vpl[1];
+                            cvf01 = vf01[1];
+                            cvf23 = vf23[1];
+                        }
+                        if (yy < ny)
+                            need = __builtin_amdgcn_readlane(cvpl, yy & 63) + 3;
+                    } else {
+                        const bool hi = yy >= 64;
+                        const int ll = yy & 63;
+                        const uint32_t f01 = __builtin_amdgcn_readlane(hi ? vf01[1] : vf01[0], ll);
+                        const uint32_t f23 = __builtin_amdgcn_readlane(hi ? vf23[1] : vf23[0], ll);
+                        emit(d0 + (ptrdiff_t)(y0 + yy) * dstride0, d1 + (ptrdiff_t)(y0 + yy) * dstride1, f01, f23,
+                             Pw[(k + 1) % 3], Pw[k % 3]);
+                        yy++;
+                        if (yy < ny)
+                            need = __builtin_amdgcn_readlane(yy >= 64 ? vpl[1] : vpl[0], yy & 63) + 3;
+                    }
                 }
             }
         }

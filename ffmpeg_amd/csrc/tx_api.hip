@@ -25,6 +25,7 @@
 #include <math.h>
 #include <mutex>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -46,6 +47,7 @@ struct FFHipTXContext {
     float scale;
     TxDev d;
     void *dev = nullptr;
+    size_t blob_bytes = 0;   /* size of the table blob at `dev` (multiple of 16) */
     /* host-pointer shim staging */
     void *stage = nullptr;
     size_t stage_sz = 0;
@@ -208,6 +210,98 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
     }
 }
 
+/*
+ * Persistent variant for contiguous, 16-byte aligned batches (what a codec hands over): the workgroup first
+ * copies the context's whole table blob (permutation, exp[], twiddles, butterfly lists: 11-15 KiB for N=1024)
+ * into LDS, then each of its waves loops over transforms.  A transform then touches HBM only for its own
+ * samples; every table access is an LDS read (~100 cycles) instead of a dependent L2 round trip (~500+) per
+ * butterfly level, which is what bounded the one-shot kernel above.
+ */
+template <int INV>
+__global__ __launch_bounds__(256) void k_mdct_l(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch,
+                                                float *out, size_t out_pitch, int nt, int waves_total)
+{
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
+        for (int i = threadIdx.x; i < blob_bytes / 16; i += 256)
+            l4[i] = s4[i];
+    }
+    __syncthreads();
+    /* rebase the table pointers into LDS */
+    TxDev L = d;
+    L.map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    L.exp = reinterpret_cast<const float2 *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
+    L.cos_tab = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    L.sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    L.blocks2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    const int n = d.n, q = n >> 1;
+    const size_t per_wave = (size_t)n * 24;
+    uint8_t *mine = lds_raw + ((blob_bytes + 15) & ~15) + wave * per_wave;
+    float2 *z = reinterpret_cast<float2 *>(mine);
+    float *st = reinterpret_cast<float *>(mine + (size_t)n * 8);
+    float4 *l4 = reinterpret_cast<float4 *>(st);
+    const int nin4 = INV ? n / 2 : n;
+
+    for (int t = blockIdx.x * 4 + wave; t < nt; t += waves_total) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
+        float4 *d4 = reinterpret_cast<float4 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
+        for (int j = lane; j < nin4; j += 64)
+            l4[j] = s4[j];
+        tx_wave_sync();
+        if (!INV) {
+            const int len3 = 3 * n;
+            for (int i = lane; i < n; i += 64) {
+                const int k = 2 * i;
+                float re, im;
+                if (k < n) {
+                    re = -st[n + k] + st[n - 1 - k];
+                    im = -st[len3 + k] + -st[len3 - 1 - k];
+                } else {
+                    re = -st[n + k] + -st[5 * n - 1 - k];
+                    im = st[k - n] + -st[len3 - 1 - k];
+                }
+                const float2 e = L.exp[i];
+                z[L.map[i]] = make_float2(re * e.y + im * e.x, re * e.x - im * e.y);
+            }
+        } else {
+            for (int i = lane; i < n; i += 64) {
+                const int k = L.map[i] << 1;
+                const float tre = st[2 * n - 1 - k], tim = st[k];
+                const float2 e = L.exp[i];
+                z[i] = make_float2(tre * e.x - tim * e.y, tre * e.y + tim * e.x);
+            }
+        }
+        tx_wave_sync();
+        tx_fft_lds(z, L, lane);
+        const float2 *ex = INV ? L.exp + n : L.exp;
+        for (int i = lane; i < q; i += 64) {
+            const int i0 = q + i, i1 = q - i - 1;
+            const float2 e0 = ex[i0], e1 = ex[i1];
+            if (!INV) {
+                const float2 s1 = z[i1], s0 = z[i0];
+                st[2 * i1 + 1] = s0.x * e0.y - s0.y * e0.x;
+                st[2 * i0]     = s0.x * e0.x + s0.y * e0.y;
+                st[2 * i0 + 1] = s1.x * e1.y - s1.y * e1.x;
+                st[2 * i1]     = s1.x * e1.x + s1.y * e1.y;
+            } else {
+                const float2 s1 = make_float2(z[i1].y, z[i1].x), s0 = make_float2(z[i0].y, z[i0].x);
+                st[2 * i1]     = s1.x * e1.y - s1.y * e1.x;
+                st[2 * i0 + 1] = s1.x * e1.x + s1.y * e1.y;
+                st[2 * i0]     = s0.x * e0.y - s0.y * e0.x;
+                st[2 * i1 + 1] = s0.x * e0.x + s0.y * e0.y;
+            }
+        }
+        tx_wave_sync();
+        for (int j = lane; j < n / 2; j += 64)
+            d4[j] = l4[j];
+        tx_wave_sync();
+    }
+}
+
 /* ---- host: tables ------------------------------------------------------------------------------- */
 static int sr_perm(int i, int len, int inv)
 {
@@ -326,7 +420,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     off_cos = (off_exp + ex.size() * 8 + 15) & ~(size_t)15;
     off_sched = (off_cos + cosv.size() * 4 + 15) & ~(size_t)15;
     off_b2 = (off_sched + sched.size() * 4 + 15) & ~(size_t)15;
-    total = off_b2 + b2.size() * 2 + 16;
+    total = (off_b2 + b2.size() * 2 + 16 + 15) & ~(size_t)15;
     std::vector<uint8_t> blob(total, 0);
     memcpy(blob.data() + off_map, map.data(), map.size() * 4);
     memcpy(blob.data() + off_exp, ex.data(), ex.size() * 8);
@@ -338,6 +432,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         ffhip_tx_uninit(&c);
         return FFHIP_ENOMEM;
     }
+    c->blob_bytes = total;
     uint8_t *base = (uint8_t *)c->dev;
     d.map = (const int *)(base + off_map);
     d.exp = (const float2 *)(base + off_exp);
@@ -368,6 +463,26 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     const dim3 grid(cdiv(nt, wpb)), block(64 * wpb);
     const size_t lds = per_wave * wpb;
+    const char *ev = getenv("FFHIP_TX_PERSISTENT");
+    const bool aligned = es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 15);
+    const size_t lds_p = ((c->blob_bytes + 15) & ~(size_t)15) + per_wave * 4;
+    if (aligned && lds_p <= 64 * 1024 && !(ev && ev[0] == '0')) {
+        int cus = 256, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        int blocks = cus * (int)((160 * 1024) / lds_p);
+        if (blocks > (nt + 3) / 4)
+            blocks = (nt + 3) / 4;
+        if (c->inv)
+            hipLaunchKernelGGL((k_mdct_l<1>), dim3(blocks), dim3(256), lds_p, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
+                               (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * 4);
+        else
+            hipLaunchKernelGGL((k_mdct_l<0>), dim3(blocks), dim3(256), lds_p, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
+                               (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * 4);
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (!c->inv) {
         const int vin = !(((uintptr_t)in | in_pitch) & 15);
         const int vout = es == 1 && !(((uintptr_t)out | out_pitch) & 15);
