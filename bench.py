@@ -161,6 +161,57 @@ def extras(torch, dev):
         out[name] = {"MB-searches/s": round(nmb / (ms * 1e-3), 1), "candidates/s": round(nmb * 225 / (ms * 1e-3), 1),
                      "frame_pairs": nf, "ms": round(ms, 4)}
     del cur, ref
+    # H.264 luma qpel: every 16x16 macroblock of 8 4K planes, mixed mcXY, put (BASELINE configs[2]): 2 B / sample
+    import numpy as np
+    nf, w, h, P = 8, 3840, 2160, 32
+    stride = w + 2 * P
+    refp = torch.randint(0, 256, (nf * (h + 2 * P), stride), dtype=torch.uint8, device=dev)
+    dstp = torch.zeros_like(refp)
+    rng = np.random.default_rng(3)
+    my, mx = np.meshgrid(np.arange(h // 16), np.arange(w // 16), indexing="ij")
+    blk = np.zeros(nf * my.size, dtype=np.dtype([("d", np.int32), ("s", np.int32), ("mc", np.uint8), ("sz", np.uint8),
+                                                     ("avg", np.uint8), ("pad", np.uint8)]))
+    for fi in range(nf):
+        base = fi * (h + 2 * P) * stride
+        d = base + (P + my.ravel() * 16) * stride + P + mx.ravel() * 16
+        dy, dx = rng.integers(-24, 25, (2, my.size))
+        sl = slice(fi * my.size, (fi + 1) * my.size)
+        blk["d"][sl] = d
+        blk["s"][sl] = d + dy * stride + dx
+        blk["mc"][sl] = rng.integers(0, 16, my.size)
+    dblk = torch.from_numpy(blk.view(np.uint8).reshape(-1, 12)).to(dev)
+    h264.qpel_batch(dstp, refp, stride, dblk, blk.size)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        h264.qpel_batch(dstp, refp, stride, dblk, blk.size)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    px = blk.size * 256
+    out["h264_qpel16_mixed"] = {"Mpixels/s": round(px / (ms * 1e-3) / 1e6, 1), "GB/s": round(2 * px / (ms * 1e-3) / 1e9, 1),
+                                "hbm_frac": round(2 * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "blocks": int(blk.size),
+                                "ms": round(ms, 4)}
+    del refp, dstp, dblk
+    # frame-order luma deblocking of 8 independent 4K planes (240x135 MBs each), launched back to back
+    mbw, mbh = w // 16, h // 16
+    planes = [torch.randint(100, 140, (h, w), dtype=torch.uint8, device=dev) for _ in range(8)]
+    ed = np.zeros(mbw * mbh * 8, dtype=np.dtype([("o", np.int32), ("k", np.uint8), ("a", np.uint8), ("b", np.uint8),
+                                                     ("p", np.uint8), ("tc", np.int8, 4)]))
+    ed["a"], ed["b"] = 40, 9
+    ed["k"] = np.where(rng.random(ed.size) < .25, 4, 0)
+    ed["tc"] = rng.integers(0, 4, (ed.size, 4))
+    ded = torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).to(dev)
+    h264.deblock_frame(planes[0], w, mbw, mbh, ded)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for pl in planes:
+        h264.deblock_frame(pl, w, mbw, mbh, ded)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / len(planes)
+    out["h264_deblock_frame_4k"] = {"Mpixels/s": round(w * h / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms, 4),
+                                    "note": "decoder order (wavefront), one frame per launch, launches serialised on one stream"}
     return out
 
 

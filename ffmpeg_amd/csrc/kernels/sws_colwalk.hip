@@ -20,6 +20,8 @@
  * int16 for the horizontal pass; unsigned-wrapping int32 accumulation from 64<<12, >>19 (arithmetic),
  * clip to u8 for the vertical pass.  v_dot2_i32_i16 without clamp is exactly that mod 2^32.
  */
+#include <vector>
+
 #include "common.h"
 #include "sws_kernels.h"
 
@@ -443,6 +445,279 @@ __global__ __launch_bounds__(256) void k_sws_colwalk(FFHipCwArgs A)
         cw_unit<4, D, PLAIN, OPT>(J, f, strip, cb, lane);
     else
         cw_unit<LK, D, PLAIN, OPT>(J, f, strip, cb, lane);
+}
+
+/* ================================================================================================== */
+/*
+ * k_sws_mfma — the same scaler with the HORIZONTAL pass on the matrix cores.
+ *
+ * Why: the column walker is bound by integer VALU issue (~7 half-rate instructions per output sample, PMC:
+ * VALU 75-94 % busy), and more than half of that is the horizontal pass (byte unpack + dots + pair
+ * packing).  H[r][x] = sum_k src[r][k] * Bt[k][x] is a banded matrix product; on i8 MFMA the band's zeros
+ * cost nothing that matters (v_mfma_i32_32x32x32_i8: 32K MACs in 32 cycles on a pipe of its own), the byte
+ * unpack disappears (source bytes ARE the A operand), and NV12 de-interleaving is just which k have
+ * non-zero coefficients.  Exactness: int32 accumulation of exact integer products.
+ *   - 14-bit coefficients f = 256*fh + fl (fl signed low byte): two MFMAs chained through
+ *     C2 = (D_hi << 8) + bias;
+ *   - source bytes are unsigned, i8 MFMA is signed: A = src ^ 0x80 (= src - 128), bias = 128 * sum(f)
+ *     per output column restores the difference.
+ * A workgroup owns 16 tiles of 32 horizontal samples (512 luma columns, or 256 chroma columns x {U,V}) of
+ * a strip of output rows and alternates two phases over chunks of 28 source rows:
+ *   H  every wave runs its 4 tiles: 32 A rows = source rows c0..c0+15 (lanes 0-31's results) and
+ *      c0+15..c0+30 (lanes 32-63's) — the D layout (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) then puts
+ *      16 CONSECUTIVE source rows of one column in each lane, so >>7, int16 saturation and the vertical
+ *      pairs (h[r-1], h[r]) are made in registers (v_cvt_pk_i16_i32) and written to LDS as pairs[30][512];
+ *   V  the column walker's vertical pass unchanged (two v_dot2_i32_i16 per sample on pairs, v_ashr_pk_u8_i32,
+ *      8-byte stores), reading its pairs from LDS; the chunk's output rows are split over the 4 waves.
+ * The tile records (B_hi, B_lo in MFMA lane order, bias, window base) are built on the host from the
+ * caller's filter bank (ffhip_mf_build_tiles) and stay resident in registers for the whole strip.
+ */
+typedef int mf_i4 __attribute__((ext_vector_type(4)));
+typedef int mf_i16 __attribute__((ext_vector_type(16)));
+typedef const mf_i4 __attribute__((address_space(1))) *mf_gc4;
+
+#define MF_PR 30      /* pair rows per chunk              */
+#define MF_ADV 28     /* window positions (source rows) a chunk completes */
+#define MF_W 512      /* dwords per pair row              */
+#define MF_REC 2320   /* bytes per tile record            */
+
+template <int PAIR>
+__device__ __forceinline__ void mf_block(const FFHipMfJob &J, int f, int strip, int cb, uint32_t *lds)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, g = lane >> 5;
+
+    /* ---- this wave's four tiles ---- */
+    mf_i4 Bhi[4], Blo[4];
+    int bias[4], kbase[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int t = min(cb * 16 + wave * 4 + q, J.ntiles - 1);
+        const uint8_t *rec = J.tiles + (size_t)t * MF_REC;
+        Bhi[q] = reinterpret_cast<const mf_i4 *>(rec)[lane];
+        Blo[q] = reinterpret_cast<const mf_i4 *>(rec + 1024)[lane];
+        bias[q] = reinterpret_cast<const int *>(rec + 2048)[lane];
+        kbase[q] = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(rec + 2304));
+    }
+    /* A row i = lane & 31 carries source row c0 + 15*half(i) + t(i) (see the header comment) */
+    const int arow = 15 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
+
+    /* ---- vertical-pass lane constants ---- */
+    const int X0 = PAIR ? cb * 256 + 4 * lane : cb * 512 + 8 * lane; /* first column (per channel) */
+    const bool act = X0 < J.dstW;
+    const uint32_t lidx = PAIR ? (uint32_t)((lane >> 2) * 32 + 4 * (lane & 3)) : (uint32_t)(8 * lane);
+    const uint32_t dcol = PAIR ? 2u * (uint32_t)X0 : (uint32_t)X0;
+    const uint32_t sel_uv = J.dst_swap ? 0x04050001u : 0x05040100u;
+    int kround = 64 << 12;
+    asm volatile("" : "+v"(kround));
+
+    const uint8_t *src = J.src + (size_t)f * J.sfp;
+    uint8_t *dst = J.dst + (size_t)f * J.dfp;
+    const int y0 = strip * J.strip_rows, y1 = min(y0 + J.strip_rows, J.dstH);
+    int c0 = __builtin_amdgcn_readfirstlane(J.vp[y0]);
+    /* Descriptors run one chunk ahead of their use so that their L2 round trips hide behind an H phase:
+     * ys_* = first/last output row of the chunk, (vpl, cf) = window start and coefficient pairs of this
+     * wave's rows (row w0 + lane), read later with v_readlane. */
+    int ysb_raw = J.ys[min(c0 + MF_ADV, J.srcH)];
+    int ya = max(__builtin_amdgcn_readfirstlane(J.ys[c0]), y0);
+    int yb = min(__builtin_amdgcn_readfirstlane(ysb_raw), y1);
+    int w0, w1, vpl;
+    uint2 cf;
+    auto load_desc = [&](int from) {
+        const int yl = min(from + lane, J.dstH - 1);
+        vpl = J.vp[yl];
+        cf = *reinterpret_cast<const uint2 *>(J.vf + (size_t)yl * 4);
+    };
+    auto split_rows = [&]() {
+        const int per = (yb - ya + 3) >> 2;
+        w0 = min(ya + wave * per, yb);
+        w1 = min(w0 + per, yb);
+    };
+    split_rows();
+    load_desc(w0);
+
+    for (;;) {
+        const int ysn_raw = J.ys[min(c0 + 2 * MF_ADV, J.srcH)]; /* next chunk's end, needed after this one */
+
+        /* ---------------- H phase ---------------- */
+        {
+            const int srow = min(c0 + arow, J.srcH - 1);
+            const uint8_t *rowp = src + (ptrdiff_t)srow * J.sstride + 16 * g;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                mf_i4 a = *(mf_gc4)((cw_gcptr)rowp + (uint32_t)kbase[q]);
+                a ^= (mf_i4){ (int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080 };
+                mf_i16 acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bhi[q], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)bias[q]);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Blo[q], acc, 0, 0, 0);
+                uint32_t *col = lds + (wave * 4 + q) * 32 + j + (15 * g) * MF_W;
+#pragma unroll
+                for (int t = 1; t < 16; t++)
+                    col[(t - 1) * MF_W] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(acc[t - 1] >> 7, acc[t] >> 7));
+            }
+        }
+        __syncthreads();
+
+        /* ---------------- V phase: this wave's rows [w0, w1) of the chunk ---------------- */
+        for (int yb0 = w0; yb0 < w1; yb0 += 64) {
+            if (yb0 != w0)
+                load_desc(yb0); /* more than 64 rows per wave and chunk: only for > 9x vertical up-scaling */
+            const int cnt = min(64, w1 - yb0);
+            for (int yy = 0; yy < cnt; yy++) {
+                const int p = __builtin_amdgcn_readlane(vpl, yy) - c0; /* pair row holding (h[p], h[p+1]) */
+                const uint32_t f01 = __builtin_amdgcn_readlane(cf.x, yy), f23 = __builtin_amdgcn_readlane(cf.y, yy);
+                const uint32_t *pa = lds + p * MF_W + lidx, *pb = pa + 2 * MF_W;
+                uint32_t Pa[2][4], Pb[2][4];
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(pa), b0 = *reinterpret_cast<const uint4 *>(pb);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(pa + (PAIR ? 16 : 4));
+                const uint4 b1 = *reinterpret_cast<const uint4 *>(pb + (PAIR ? 16 : 4));
+                Pa[0][0] = a0.x; Pa[0][1] = a0.y; Pa[0][2] = a0.z; Pa[0][3] = a0.w;
+                Pa[1][0] = a1.x; Pa[1][1] = a1.y; Pa[1][2] = a1.z; Pa[1][3] = a1.w;
+                Pb[0][0] = b0.x; Pb[0][1] = b0.y; Pb[0][2] = b0.z; Pb[0][3] = b0.w;
+                Pb[1][0] = b1.x; Pb[1][1] = b1.y; Pb[1][2] = b1.z; Pb[1][3] = b1.w;
+                int v[2][4];
+                cw_vdots4(v[0], Pa[0], Pb[0], f01, f23, kround);
+                cw_vdots4(v[1], Pa[1], Pb[1], f01, f23, kround);
+                cw_u2 w;
+                if (PAIR) { /* U0 V0 U1 V1 ... */
+                    w.x = __builtin_amdgcn_perm(cw_pk_u8<false>(v[0][1], v[1][1]), cw_pk_u8<false>(v[0][0], v[1][0]), sel_uv);
+                    w.y = __builtin_amdgcn_perm(cw_pk_u8<false>(v[0][3], v[1][3]), cw_pk_u8<false>(v[0][2], v[1][2]), sel_uv);
+                } else {
+                    w.x = __builtin_amdgcn_perm(cw_pk_u8<false>(v[0][2], v[0][3]), cw_pk_u8<false>(v[0][0], v[0][1]), 0x05040100);
+                    w.y = __builtin_amdgcn_perm(cw_pk_u8<false>(v[1][2], v[1][3]), cw_pk_u8<false>(v[1][0], v[1][1]), 0x05040100);
+                }
+                uint8_t *drow = dst + (ptrdiff_t)(yb0 + yy) * J.dstride;
+                asm("" : "+s"(drow));
+                cw_gptr d = (cw_gptr)drow + cw_opaque(dcol);
+                if (X0 + (PAIR ? 4 : 8) <= J.dstW)
+                    *(cw_g2)d = w;
+                else if (act && !PAIR)
+                    *(cw_g1)d = w.x;
+            }
+        }
+        __syncthreads();
+        if (yb >= y1)
+            break;
+        c0 += MF_ADV;
+        ya = max(__builtin_amdgcn_readfirstlane(ysb_raw), y0);
+        yb = min(__builtin_amdgcn_readfirstlane(ysn_raw), y1);
+        ysb_raw = ysn_raw;
+        split_rows();
+        load_desc(w0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sws_mfma(FFHipMfArgs A)
+{
+    extern __shared__ __align__(16) uint32_t mf_lds[];
+    const uint32_t u0 = blockIdx.x;
+    if (u0 >= (uint32_t)A.units_per_frame * (uint32_t)A.nframes)
+        return;
+    const int f = (int)(u0 / (uint32_t)A.units_per_frame);
+    const int u = (int)(u0 - (uint32_t)f * (uint32_t)A.units_per_frame);
+    int jj = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) jj = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) jj = 2;
+    const FFHipMfJob &J = A.job[jj];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.pair)
+        mf_block<1>(J, f, strip, cb, mf_lds);
+    else
+        mf_block<0>(J, f, strip, cb, mf_lds);
+}
+
+/*
+ * Host: tile records of one horizontal bank in MFMA operand order.  Returns the number of tiles, or -1 when
+ * the bank does not fit (a tile's taps outside its 32-byte window, or a coefficient whose high byte overflows).
+ * pair: the source is a byte-interleaved U/V plane; tile columns 0-15 are U, 16-31 are V samples.
+ */
+int ffhip_mf_build_tiles(std::vector<uint8_t> *out, const int16_t *hf, const int32_t *hp, int n, int srcW, int pair, int src_swap)
+{
+    const int cpt = pair ? 16 : 32;
+    const int ntiles = cdiv(n, cpt);
+    const int rowbytes = pair ? 2 * srcW : srcW;
+    if (rowbytes < 32 || (rowbytes & 3) || (n & 3))
+        return -1;
+    out->assign((size_t)ntiles * MF_REC, 0);
+    for (int t = 0; t < ntiles; t++) {
+        uint8_t *rec = out->data() + (size_t)t * MF_REC;
+        int8_t *bhi = reinterpret_cast<int8_t *>(rec), *blo = reinterpret_cast<int8_t *>(rec + 1024);
+        int32_t *bias = reinterpret_cast<int32_t *>(rec + 2048);
+        const int c_lo = t * cpt, c_hi = c_lo + cpt < n ? c_lo + cpt : n;
+        int first = 1 << 30, last = -1;
+        for (int ch = 0; ch < (pair ? 2 : 1); ch++) {
+            const int off = pair ? (ch ^ (src_swap ? 1 : 0)) : 0;
+            for (int c = c_lo; c < c_hi; c++) {
+                const int b0 = pair ? 2 * hp[c] + off : hp[c], b1 = pair ? 2 * (hp[c] + 3) + off : hp[c] + 3;
+                if (b0 < first) first = b0;
+                if (b1 > last) last = b1;
+            }
+        }
+        int kb = first & ~3;
+        if (kb + 32 > rowbytes)
+            kb = rowbytes - 32;
+        if (first < kb || last >= kb + 32 || kb < 0)
+            return -1;
+        *reinterpret_cast<int32_t *>(rec + 2304) = kb;
+        for (int l = 0; l < 64; l++) {
+            const int jx = l & 31, g = l >> 5;
+            const int ch = pair ? jx >> 4 : 0, c = c_lo + (pair ? (jx & 15) : jx);
+            if (c >= c_hi)
+                continue;
+            const int off = pair ? (ch ^ (src_swap ? 1 : 0)) : 0;
+            if (g == 0) {
+                int sum = 0;
+                for (int k = 0; k < 4; k++)
+                    sum += hf[(size_t)c * 4 + k];
+                bias[l] = bias[l + 32] = 128 * sum;
+            }
+            for (int s = 0; s < 16; s++) {
+                const int byte = kb + 16 * g + s;
+                int tap;
+                if (pair) {
+                    if (((byte - off) & 1) || byte < off)
+                        continue;
+                    tap = (byte - off) / 2 - hp[c];
+                } else {
+                    tap = byte - hp[c];
+                }
+                if (tap < 0 || tap > 3)
+                    continue;
+                const int fv = hf[(size_t)c * 4 + tap];
+                const int fl = ((fv + 128) & 255) - 128, fh = (fv - fl) >> 8;
+                if (fh < -128 || fh > 127)
+                    return -1;
+                bhi[l * 16 + s] = (int8_t)fh;
+                blo[l * 16 + s] = (int8_t)fl;
+            }
+        }
+    }
+    return ntiles;
+}
+
+int ffhip_launch_mfma(FFHipMfArgs &A, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    int u = 0;
+    for (int i = 0; i < A.njobs; i++) {
+        A.job[i].unit_begin = u;
+        u += A.job[i].ncb * A.job[i].nstrips;
+    }
+    A.units_per_frame = u;
+    const long long blocks = (long long)u * A.nframes;
+    if (blocks >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld workgroups)", blocks);
+        return FFHIP_EINVAL;
+    }
+    hipLaunchKernelGGL(k_sws_mfma, dim3((unsigned)blocks), dim3(256), MF_PR * MF_W * 4, stream, A);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 /* ---- host side ---------------------------------------------------------------------------------- */

@@ -84,6 +84,31 @@ int  ffhip_cw_bank_ok(const int32_t *hpos, int hsize, int hn, int srcW, const in
 void ffhip_cw_plan_job(FFHipCwJob *j, int groups_per_lane, int strip_target);
 int  ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t stream);
 
+/*
+ * MFMA-horizontal variant of the fast path (k_sws_mfma in sws_colwalk.hip): a job is one plane or one
+ * byte-interleaved U/V pair (NV12/NV21 in and out).
+ */
+struct FFHipMfJob {
+    const uint8_t *src; uint8_t *dst;
+    ptrdiff_t sstride, dstride;
+    size_t sfp, dfp;
+    int pair, dst_swap;
+    int srcH, dstW, dstH;        /* dstW in samples per channel */
+    const uint8_t *tiles;        /* device: ntiles records of 2320 bytes (ffhip_mf_build_tiles) */
+    const int16_t *vf; const int32_t *vp;
+    const int32_t *ys;           /* device: ys[p] = first output row whose window starts at source row >= p; ys[srcH] = dstH */
+    int ntiles, ncb, nstrips, strip_rows, unit_begin;
+};
+struct FFHipMfArgs {
+    FFHipMfJob job[3];
+    int njobs, units_per_frame, nframes;
+};
+#ifdef __cplusplus
+#include <vector>
+int ffhip_mf_build_tiles(std::vector<uint8_t> *out, const int16_t *hf, const int32_t *hp, int n, int srcW, int pair, int src_swap);
+#endif
+int ffhip_launch_mfma(FFHipMfArgs &A, hipStream_t stream);
+
 /* Fused H+V scaling + yuv2rgb for packed rgb24/bgr24 output (yuv2rgb{1,2,X} dispatch in-kernel). */
 struct FFHipScaleRgbArgs {
     const uint8_t *src[3];      /* Y, U, V (U/V may alias an interleaved plane with chr_step 2) */

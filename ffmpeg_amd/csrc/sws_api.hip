@@ -28,6 +28,11 @@ struct FFHipSwsContext {
     FFHipScaleRgbArgs rgb;
     int cw_ok = 0; /* both bank pairs fit the column-walking fast path (sws_colwalk.hip) */
     int cw_opt = 0; /* ... and no horizontal sum can wrap int16: the hand-scheduled variant applies */
+    /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
+    int mf_ok = 0, mf_chr_pair = 0, mf_ntiles[2] = { 0, 0 };
+    void *mf_dev = nullptr;
+    const uint8_t *mf_tiles[2] = { nullptr, nullptr };
+    const int32_t *mf_ys[2] = { nullptr, nullptr };
     /* staging for the host-pointer face */
     void *stage = nullptr;
     size_t stage_sz = 0;
@@ -157,6 +162,44 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                                     c->d[3].n, ch.srcH);
         c->cw_opt = c->cw_ok && ffhip_cw_bank_nowrap(c->f[0].data(), c->d[0].size, c->d[0].n) &&
                     ffhip_cw_bank_nowrap(c->f[1].data(), c->d[1].size, c->d[1].n);
+        /* MFMA variant: same banks; chroma either byte-interleaved on both sides or planar on both sides */
+        const bool nv_in = fmt_nv(t->srcFormat), nv_out = fmt_nv(t->dstFormat);
+        if (c->cw_opt && nv_in == nv_out) {
+            std::vector<uint8_t> tl, tc;
+            const int nl = ffhip_mf_build_tiles(&tl, c->f[0].data(), c->p[0].data(), c->d[0].n, l.srcW, 0, 0);
+            const int nc = ffhip_mf_build_tiles(&tc, c->f[1].data(), c->p[1].data(), c->d[1].n, ch.srcW, nv_in,
+                                                t->srcFormat == FFHIP_PIX_FMT_NV21);
+            if (nl > 0 && nc > 0) {
+                std::vector<int32_t> ys[2];
+                const int srcHs[2] = { l.srcH, ch.srcH };
+                for (int k = 0; k < 2; k++) {
+                    const std::vector<int32_t> &vp = c->p[2 + k];
+                    ys[k].assign(srcHs[k] + 1, (int32_t)vp.size());
+                    int y = 0;
+                    for (int p = 0; p <= srcHs[k]; p++) {
+                        while (y < (int)vp.size() && vp[y] < p)
+                            y++;
+                        ys[k][p] = y;
+                    }
+                }
+                const size_t o1 = (tl.size() + 255) & ~(size_t)255, o2 = o1 + ((tc.size() + 255) & ~(size_t)255);
+                const size_t o3 = o2 + ((ys[0].size() * 4 + 255) & ~(size_t)255), tot = o3 + ys[1].size() * 4 + 256;
+                if (hipMalloc(&c->mf_dev, tot) == hipSuccess) {
+                    uint8_t *b = static_cast<uint8_t *>(c->mf_dev);
+                    if (hipMemcpy(b, tl.data(), tl.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(b + o1, tc.data(), tc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(b + o2, ys[0].data(), ys[0].size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(b + o3, ys[1].data(), ys[1].size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+                        c->mf_tiles[0] = b; c->mf_tiles[1] = b + o1;
+                        c->mf_ys[0] = reinterpret_cast<const int32_t *>(b + o2);
+                        c->mf_ys[1] = reinterpret_cast<const int32_t *>(b + o3);
+                        c->mf_ntiles[0] = nl; c->mf_ntiles[1] = nc;
+                        c->mf_chr_pair = nv_in;
+                        c->mf_ok = 1;
+                    }
+                }
+            }
+        }
     }
     if (r < 0) {
         ffhip_sws_freeContext(c);
@@ -178,7 +221,22 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
     return c;
 }
 
-extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c) { return c ? c->cw_ok : 0; }
+extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c) { return c ? c->cw_ok + (c->mf_ok ? 2 : 0) : 0; }
+
+extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
+                                         uint8_t *out, size_t out_size)
+{
+    std::vector<uint8_t> v;
+    const int nt = ffhip_mf_build_tiles(&v, filter, pos, n, srcW, pair, src_swap);
+    if (nt < 0)
+        return FFHIP_EINVAL;
+    if (out) {
+        if (out_size < v.size())
+            return FFHIP_ENOMEM;
+        memcpy(out, v.data(), v.size());
+    }
+    return nt;
+}
 
 extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
 {
@@ -186,6 +244,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         return;
     if (c->dev_tables)
         (void)hipFree(c->dev_tables);
+    if (c->mf_dev)
+        (void)hipFree(c->mf_dev);
     if (c->stage)
         (void)hipFree(c->stage);
     delete c;
@@ -271,6 +331,38 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             al |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
         }
         if (!(al & 3)) {
+            const char *em = getenv("FFHIP_SWS_MFMA");
+            if (c->mf_ok && em && em[0] == '1') {
+                /* horizontal pass on the matrix cores (k_sws_mfma) */
+                const char *est = getenv("FFHIP_MF_STRIP");
+                FFHipMfArgs M;
+                memset(&M, 0, sizeof(M));
+                M.nframes = nframes;
+                auto mfjob = [&](const FFHipScalePlaneArgs &p, int which, const uint8_t *src, ptrdiff_t ss, size_t sf, uint8_t *dst,
+                                 ptrdiff_t dsr, size_t df, int pair, int dswap) {
+                    FFHipMfJob &j = M.job[M.njobs++];
+                    j.src = src; j.dst = dst; j.sstride = ss; j.dstride = dsr; j.sfp = sf; j.dfp = df;
+                    j.pair = pair; j.dst_swap = dswap;
+                    j.srcH = p.srcH; j.dstW = p.dstW; j.dstH = p.dstH;
+                    j.tiles = c->mf_tiles[which]; j.vf = p.v.filter; j.vp = p.v.pos; j.ys = c->mf_ys[which];
+                    j.ntiles = c->mf_ntiles[which];
+                    j.ncb = cdiv(j.ntiles, 16);
+                    const int want = est && atoi(est) > 0 ? atoi(est) : p.dstH;
+                    const int ns = cdiv(p.dstH, want);
+                    j.strip_rows = cdiv(p.dstH, ns);
+                    j.nstrips = cdiv(p.dstH, j.strip_rows);
+                };
+                mfjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
+                if (c->mf_chr_pair) {
+                    const uint8_t *sp = ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1];
+                    uint8_t *dp = ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1];
+                    mfjob(ch, 1, sp, ch.src_stride[0], ch.src_fp[0], dp, ch.dst_stride[0], ch.dst_fp[0], 1, ch.dst[1] < ch.dst[0]);
+                } else {
+                    for (int k = 0; k < 2; k++)
+                        mfjob(ch, 1, ch.src[k], ch.src_stride[k], ch.src_fp[k], ch.dst[k], ch.dst_stride[k], ch.dst_fp[k], 0, 0);
+                }
+                return ffhip_launch_mfma(M, stream);
+            }
             const char *eg = getenv("FFHIP_CW_LUMA_GROUPS"), *ep = getenv("FFHIP_CW_PLAIN");
             const char *ed = getenv("FFHIP_CW_DEPTH"), *es = getenv("FFHIP_CW_STRIP");
             const int lg = (eg && eg[0] == '1') || (ep && ep[0] == '1') ? 1 : 2; /* measured: 2 groups/lane is 12 % faster */

@@ -95,7 +95,12 @@ class SwsContext:
     @property
     def fast_path(self):
         """True when the banks run on the column-walking kernel (ffhip_sws_fast_path)."""
-        return bool(_lib.lib().ffhip_sws_fast_path(self._c))
+        return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 1)
+
+    @property
+    def mfma_path(self):
+        """True when the matrix-core horizontal pass (k_sws_mfma) is available for the banks."""
+        return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 2)
 
     def close(self):
         if getattr(self, "_c", None) and _lib is not None:

@@ -111,8 +111,17 @@ FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t);
 void             ffhip_sws_freeContext(FFHipSwsContext *c);
 /** 1 when the context's banks run on the register-resident column-walking kernel (4-tap x 4-tap banks
  *  whose 4-column groups read one 8-byte source span; sws_colwalk.hip), 0 when they take the general
- *  LDS-tiled kernel.  Diagnostic only: results are identical. */
+ *  LDS-tiled kernel; bit 1 set when the matrix-core variant (k_sws_mfma) is available too.  Diagnostic
+ *  only: results are identical. */
 int              ffhip_sws_fast_path(const FFHipSwsContext *c);
+/** Host-side preparation of the matrix-core horizontal pass (no device needed): turns one 4-tap horizontal
+ *  bank (hLumFilter/hLumFilterPos or the chroma pair's) into per-tile MFMA operand records of 2320 bytes —
+ *  B_hi[64 lanes][16], B_lo[64][16] (coefficient = 256*hi + lo, zero outside the band), bias[64] = 128*sum(f),
+ *  window base — for tiles of 32 samples (pair != 0: 16 U + 16 V columns of a byte-interleaved plane,
+ *  src_swap: V first).  Returns the tile count (records written to `out` when non-NULL) or FFHIP_EINVAL when
+ *  the bank does not fit the tiling.  Exposed for the CPU test-suite. */
+int              ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
+                                           uint8_t *out, size_t out_size);
 
 /** Host-table generation alone (no device needed): our initFilter().  `which`: 0 hLum 1 hChr 2 vLum
  *  3 vChr.  Returns filter size or <0; pointers stay valid until ffhip_sws_tables_free().  Used by

@@ -45,11 +45,12 @@ def _upload_aligned(arrs, n, rng):
     return out, host
 
 
-def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, n=3, seed=1):
+def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, n=3, seed=1, need_mfma=False):
     from ffmpeg_amd import swscale as S
     torch = _torch()
     rng = np.random.default_rng(seed)
-    for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT"):
+    for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
+              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -70,6 +71,8 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
             setattr(tabs, name, _lib.SwsFilter(ptr(f, ffi.i16p), ptr(p, ffi.i32p), fs, nn))
     ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags, tables=tabs)
     assert ctx.fast_path, "case does not reach the column walker"
+    if (env or {}).get("FFHIP_SWS_MFMA") == "1" and need_mfma:
+        assert ctx.mfma_path, "case does not reach the matrix-core variant"
     first = ffi.alloc_frame(PIX[sf], sw, sh, rng)
     dsrc, hsrc = _upload_aligned(first, n, rng)
     shapes = S.plane_shapes(PIX[df], dw, dh)
@@ -194,3 +197,37 @@ def test_unscaled_rgb_transposed(w, h, dst, variant, monkeypatch):
         assert np.array_equal(got[f, :, :wv], want[:, :wv]), "frame %d: %d mismatches" % (f, (got[f, :, :wv] != want[:, :wv]).sum())
         assert (got[f, :, 3 * w:] == 0x5A).all()
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the matrix-core horizontal pass (k_sws_mfma): same results, bit for bit
+# ---------------------------------------------------------------------------------------------
+MFMA_CASES = [
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_BICUBIC),
+    ("nv21", 192, 108, "nv21", 384, 216, ffi.SWS_BICUBIC),
+    ("nv12", 192, 108, "nv21", 384, 216, ffi.SWS_BICUBIC),
+    ("yuv420p", 128, 72, "yuv420p", 256, 144, ffi.SWS_BICUBIC),
+    ("nv12", 1048, 600, "nv12", 2096, 1416, ffi.SWS_BICUBIC),        # several column blocks / chunks, ragged last block
+    ("nv12", 64, 40, "nv12", 192, 104, ffi.SWS_BICUBIC),             # 3x / 2.6x
+    ("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC),       # BASELINE configs[1]
+]
+
+
+@pytest.mark.parametrize("strip", ["", "100", "37"])
+@pytest.mark.parametrize("case", MFMA_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_mfma_path(case, strip, monkeypatch):
+    env = {"FFHIP_SWS_MFMA": "1"}
+    if strip:
+        env["FFHIP_MF_STRIP"] = strip
+    _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, n=2, need_mfma=True)
+
+
+@pytest.mark.parametrize("fmts", [("nv12", "nv12"), ("nv21", "nv12"), ("yuv420p", "yuv420p")])
+def test_mfma_path_adversarial_tables(fmts, monkeypatch):
+    """arbitrary eligible positions / coefficients (the non-extreme recipe: horizontal sums cannot wrap int16);
+    banks whose tiles do not fit fall back to the column walker - either way the result is the oracle's"""
+    sw, sh, dw, dh = 200, 120, 520, 300
+    rng = np.random.default_rng(77)
+    banks = _adversarial_banks(rng, sw, sh, dw, dh, 0)
+    _run(fmts[0], sw, sh, fmts[1], dw, dh, ffi.SWS_BICUBIC, banks=banks, env={"FFHIP_SWS_MFMA": "1"}, monkeypatch=monkeypatch,
+         n=2, seed=6)
