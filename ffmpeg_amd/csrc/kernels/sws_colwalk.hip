@@ -537,17 +537,30 @@ __device__ __forceinline__ void mf_block(const FFHipMfJob &J, int f, int strip, 
     split_rows();
     load_desc(w0);
 
+    /* the A operands (source bytes) of a chunk are fetched one chunk ahead, during the previous V phase */
+    mf_i4 anext[4];
+    auto load_a = [&](int cbase) {
+        const int srow = min(cbase + arow, J.srcH - 1);
+        const uint8_t *rowp = src + (ptrdiff_t)srow * J.sstride + 16 * g;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            anext[q] = *(mf_gc4)((cw_gcptr)rowp + (uint32_t)kbase[q]);
+    };
+    load_a(c0);
+
     for (;;) {
         const int ysn_raw = J.ys[min(c0 + 2 * MF_ADV, J.srcH)]; /* next chunk's end, needed after this one */
 
         /* ---------------- H phase ---------------- */
         {
-            const int srow = min(c0 + arow, J.srcH - 1);
-            const uint8_t *rowp = src + (ptrdiff_t)srow * J.sstride + 16 * g;
+            mf_i4 acur[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                acur[q] = anext[q] ^ (mf_i4){ (int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080 };
+            load_a(c0 + MF_ADV); /* in flight across the MFMAs and the whole V phase */
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                mf_i4 a = *(mf_gc4)((cw_gcptr)rowp + (uint32_t)kbase[q]);
-                a ^= (mf_i4){ (int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080 };
+                const mf_i4 a = acur[q];
                 mf_i16 acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bhi[q], acc, 0, 0, 0);
 #pragma unroll
@@ -567,14 +580,22 @@ __device__ __forceinline__ void mf_block(const FFHipMfJob &J, int f, int strip, 
             if (yb0 != w0)
                 load_desc(yb0); /* more than 64 rows per wave and chunk: only for > 9x vertical up-scaling */
             const int cnt = min(64, w1 - yb0);
-            for (int yy = 0; yy < cnt; yy++) {
+            /* the pair rows of output row yy+1 are read while row yy is computed */
+            uint4 na0, na1, nb0, nb1;
+            auto read_pairs = [&](int yy) {
                 const int p = __builtin_amdgcn_readlane(vpl, yy) - c0; /* pair row holding (h[p], h[p+1]) */
-                const uint32_t f01 = __builtin_amdgcn_readlane(cf.x, yy), f23 = __builtin_amdgcn_readlane(cf.y, yy);
                 const uint32_t *pa = lds + p * MF_W + lidx, *pb = pa + 2 * MF_W;
+                na0 = *reinterpret_cast<const uint4 *>(pa);
+                nb0 = *reinterpret_cast<const uint4 *>(pb);
+                na1 = *reinterpret_cast<const uint4 *>(pa + (PAIR ? 16 : 4));
+                nb1 = *reinterpret_cast<const uint4 *>(pb + (PAIR ? 16 : 4));
+            };
+            read_pairs(0);
+            for (int yy = 0; yy < cnt; yy++) {
+                const uint32_t f01 = __builtin_amdgcn_readlane(cf.x, yy), f23 = __builtin_amdgcn_readlane(cf.y, yy);
+                const uint4 a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
+                read_pairs(min(yy + 1, cnt - 1));
                 uint32_t Pa[2][4], Pb[2][4];
-                const uint4 a0 = *reinterpret_cast<const uint4 *>(pa), b0 = *reinterpret_cast<const uint4 *>(pb);
-                const uint4 a1 = *reinterpret_cast<const uint4 *>(pa + (PAIR ? 16 : 4));
-                const uint4 b1 = *reinterpret_cast<const uint4 *>(pb + (PAIR ? 16 : 4));
                 Pa[0][0] = a0.x; Pa[0][1] = a0.y; Pa[0][2] = a0.z; Pa[0][3] = a0.w;
                 Pa[1][0] = a1.x; Pa[1][1] = a1.y; Pa[1][2] = a1.z; Pa[1][3] = a1.w;
                 Pb[0][0] = b0.x; Pb[0][1] = b0.y; Pb[0][2] = b0.z; Pb[0][3] = b0.w;

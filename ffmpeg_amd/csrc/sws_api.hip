@@ -347,7 +347,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                     j.tiles = c->mf_tiles[which]; j.vf = p.v.filter; j.vp = p.v.pos; j.ys = c->mf_ys[which];
                     j.ntiles = c->mf_ntiles[which];
                     j.ncb = cdiv(j.ntiles, 16);
-                    const int want = est && atoi(est) > 0 ? atoi(est) : p.dstH;
+                    const int want = est && atoi(est) > 0 ? atoi(est) : 540;
                     const int ns = cdiv(p.dstH, want);
                     j.strip_rows = cdiv(p.dstH, ns);
                     j.nstrips = cdiv(p.dstH, j.strip_rows);

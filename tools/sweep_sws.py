@@ -45,12 +45,12 @@ def main():
     dst = [torch.empty((n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(23, 3840, 2160)]
     byt = n * 15552000
     variants = [{}]
-    for o in ("1", "0"):
-        for g in ("1", "2"):
-            for d in ("3", "6"):
-                variants.append({"FFHIP_CW_OPT": o, "FFHIP_CW_LUMA_GROUPS": g, "FFHIP_CW_DEPTH": d})
-    variants += [{"FFHIP_SWS_MFMA": "1"}, {"FFHIP_SWS_MFMA": "1", "FFHIP_MF_STRIP": "540"},
-                 {"FFHIP_SWS_MFMA": "1", "FFHIP_MF_STRIP": "216"}]
+    if os.environ.get("SWEEP_FULL"):
+        for o in ("1", "0"):
+            for g in ("1", "2"):
+                for d in ("3", "6"):
+                    variants.append({"FFHIP_CW_OPT": o, "FFHIP_CW_LUMA_GROUPS": g, "FFHIP_CW_DEPTH": d})
+    variants += [{"FFHIP_SWS_MFMA": "1"}] + [{"FFHIP_SWS_MFMA": "1", "FFHIP_MF_STRIP": x} for x in ("1080", "720", "540", "360", "216", "112")]
     variants += [{"FFHIP_CW_STRIP": "60"}, {"FFHIP_CW_STRIP": "128"}, {"FFHIP_CW_PLAIN": "1"}, {"FFHIP_SWS_FAST": "0"}]
     print("fast path eligible:", ctx.fast_path)
     ref = None
