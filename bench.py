@@ -203,6 +203,7 @@ def extras(torch, dev):
     ed["tc"] = rng.integers(0, 4, (ed.size, 4))
     ded = torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).to(dev)
     h264.deblock_frame(planes[0], w, mbw, mbh, ded)
+    torch.cuda.synchronize()
     e0, e1 = ev(), ev()
     e0.record()
     for pl in planes:
@@ -210,8 +211,16 @@ def extras(torch, dev):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / len(planes)
-    out["h264_deblock_frame_4k"] = {"Mpixels/s": round(w * h / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms, 4),
-                                    "note": "decoder order (wavefront), one frame per launch, launches serialised on one stream"}
+    # the same 8 frames on 8 streams: frames are independent, only the order inside a frame is serial
+    streams = [torch.cuda.Stream(device=dev) for _ in planes]
+    t0 = time.perf_counter()
+    for pl, st in zip(planes, streams):
+        h264.deblock_frame(pl, w, mbw, mbh, ded, st.cuda_stream)
+    torch.cuda.synchronize()
+    ms_par = (time.perf_counter() - t0) * 1e3 / len(planes)
+    out["h264_deblock_frame_4k"] = {"Mpixels/s": round(w * h / (ms_par * 1e-3) / 1e6, 1), "ms_per_frame_one_stream": round(ms, 4),
+                                    "ms_per_frame_8_streams": round(ms_par, 4),
+                                    "note": "decoder order (2-D wavefront inside a frame); frames run concurrently on separate streams"}
     return out
 
 

@@ -104,16 +104,32 @@ __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, int lane)
  */
 template <int INV>
 __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t in_pitch, float *out, size_t out_pitch,
-                                              ptrdiff_t stride, int nt, int waves_per_block, int vec_in, int vec_out)
+                                              ptrdiff_t stride, int nt, int waves_per_block, int vec_in, int vec_out,
+                                              int ftab_bytes)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * waves_per_block + wave;
-    if (wave >= waves_per_block || t >= nt)
-        return;
     const int n = d.n, q = n >> 1;
     const size_t per_wave = (size_t)n * 8 + (size_t)n * 16; /* z + staging (4n floats) */
+    if (ftab_bytes) {
+        /* the tables the FFT levels chain through (twiddles, butterfly lists, size-2 list: ~5 KiB at N=1024,
+         * contiguous in the context blob from cos_tab on) go to LDS: a level's list entry -> twiddle -> operands
+         * chain then costs LDS latencies instead of three dependent L2 round trips */
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(d.cos_tab);
+        uint8_t *ft = lds_raw + waves_per_block * per_wave;
+        uint4 *l4 = reinterpret_cast<uint4 *>(ft);
+        for (int i = threadIdx.x; i < ftab_bytes / 16; i += blockDim.x)
+            l4[i] = s4[i];
+        __syncthreads();
+        const uint8_t *g0 = reinterpret_cast<const uint8_t *>(d.cos_tab);
+        d.sched = reinterpret_cast<const uint32_t *>(ft + (reinterpret_cast<const uint8_t *>(d.sched) - g0));
+        d.blocks2 = reinterpret_cast<const uint16_t *>(ft + (reinterpret_cast<const uint8_t *>(d.blocks2) - g0));
+        d.cos_tab = reinterpret_cast<const float *>(ft);
+    }
+    if (wave >= waves_per_block || t >= nt)
+        return;
     float2 *z = reinterpret_cast<float2 *>(lds_raw + wave * per_wave);
     float *st = reinterpret_cast<float *>(lds_raw + wave * per_wave + (size_t)n * 8);
     const float *src = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
@@ -462,7 +478,15 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     }
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     const dim3 grid(cdiv(nt, wpb)), block(64 * wpb);
-    const size_t lds = per_wave * wpb;
+    /* FFT-level tables in LDS when they fit next to the waves' areas (FFHIP_TX_LDSTAB=0 keeps them in L2) */
+    const char *et = getenv("FFHIP_TX_LDSTAB");
+    const size_t ftab_sz = c->blob_bytes - (size_t)((const uint8_t *)c->d.cos_tab - (const uint8_t *)c->dev);
+    int ftab = 0;
+    size_t lds = per_wave * wpb;
+    if (!(et && et[0] == '0') && lds + ftab_sz <= 64 * 1024) {
+        ftab = (int)ftab_sz;
+        lds += ftab_sz;
+    }
     const char *ev = getenv("FFHIP_TX_PERSISTENT");
     const bool aligned = es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 15);
     const size_t lds_p = ((c->blob_bytes + 15) & ~(size_t)15) + per_wave * 4;
@@ -489,12 +513,12 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
         const int vin = !(((uintptr_t)in | in_pitch) & 15);
         const int vout = es == 1 && !(((uintptr_t)out | out_pitch) & 15);
         hipLaunchKernelGGL((k_mdct<0>), grid, block, lds, (hipStream_t)stream, c->d, (const float *)in, in_pitch, (float *)out,
-                           out_pitch, es, nt, wpb, vin, vout);
+                           out_pitch, es, nt, wpb, vin, vout, ftab);
     } else {
         const int vin = es == 1 && !(((uintptr_t)in | in_pitch) & 15);
         const int vout = !(((uintptr_t)out | out_pitch) & 15);
         hipLaunchKernelGGL((k_mdct<1>), grid, block, lds, (hipStream_t)stream, c->d, (const float *)in, in_pitch, (float *)out,
-                           out_pitch, es, nt, wpb, vin, vout);
+                           out_pitch, es, nt, wpb, vin, vout, ftab);
     }
     LAUNCH_CHECK();
     return 0;
