@@ -17,6 +17,9 @@
  *                          agent-scope release/acquire progress counter (row y may start MB x once row y-1
  *                          has published x+2).  Results equal the serial order bit for bit.
  */
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 #include "h264_kernels.h"
 
@@ -148,34 +151,49 @@ __device__ __forceinline__ void wave_lds_sync()
 __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h,
                                                            const FFHipH264Edge *edges, int *progress, int *fail)
 {
-    /* tile[r][c]: r = picture row - (16*my - 4), c = picture column - (16*mx - 4) */
-    __shared__ uint8_t tile[20 * TP];
+    /* tile[r][c]: r = picture row - (16*my - 4), c = picture column - (16*mx - 4); rows are dword aligned */
+    __shared__ __align__(16) uint8_t tile[20 * TP];
     const int my = blockIdx.x, lane = threadIdx.x;
     uint8_t *rowbase = luma + (ptrdiff_t)my * 16 * stride;
+    const bool dw_ok = !(((uintptr_t)luma | (size_t)stride) & 3);
+    const int pr = lane >> 2, pc = 4 * (lane & 3); /* this lane's dword of a 16x16 block */
+    /* the MB's own 16x16 pixels are nobody else's to change before we filter it: fetched one MB ahead */
+    uint32_t own = 0;
+    auto fetch_own = [&](int mx) {
+        const uint8_t *p = rowbase + mx * 16 + (ptrdiff_t)pr * stride + pc;
+        if (dw_ok)
+            own = *reinterpret_cast<const uint32_t *>(p);
+        else
+            own = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    };
+    fetch_own(0);
     for (int mx = 0; mx < mb_w; mx++) {
+        uint8_t *mb = rowbase + mx * 16;
+        *reinterpret_cast<uint32_t *>(&tile[(pr + 4) * TP + 4 + pc]) = own;
+        if (mx + 1 < mb_w)
+            fetch_own(mx + 1);
         /* ---- wait for the row above: MB (mx+1, my-1) done, i.e. progress[my-1] >= min(mx+2, mb_w) ---- */
         if (my > 0) {
             const int want = min(mx + 2, mb_w);
             int spins = 0;
             while (__hip_atomic_load(&progress[my - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
                     if (lane == 0)
                         atomicExch(fail, 1);
                     return;
                 }
             }
-        }
-        /* ---- bring the context in: the 4 rows above (columns 0..15) and the MB itself ---- */
-        uint8_t *mb = rowbase + mx * 16;
-        if (my > 0) {
-            const int r = lane >> 4, c = lane & 15; /* 4 x 16 */
-            tile[r * TP + 4 + c] = mb[(ptrdiff_t)(r - 4) * stride + c];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int r = (lane >> 4) + 4 * k, c = lane & 15; /* 16 x 16 */
-            tile[(r + 4) * TP + 4 + c] = mb[(ptrdiff_t)r * stride + c];
+            /* the 4 rows above, columns 0..15 (written by the wave of row my-1) */
+            if (lane < 16) {
+                const uint8_t *p = mb + (ptrdiff_t)(pr - 4) * stride + pc;
+                uint32_t v;
+                if (dw_ok)
+                    v = *reinterpret_cast<const uint32_t *>(p);
+                else
+                    v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                *reinterpret_cast<uint32_t *>(&tile[pr * TP + 4 + pc]) = v;
+            }
         }
         wave_lds_sync();
         const FFHipH264Edge *e = edges + (size_t)(my * mb_w + mx) * 8;
@@ -197,47 +215,62 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, ptrdif
             }
             wave_lds_sync();
         }
-        /* ---- write back what this MB may have changed: rows -3..15 x columns -3..15 minus the corner ---- */
-        for (int i = lane; i < 19 * 19; i += 64) {
-            const int r = i / 19 - 3, c = i % 19 - 3;
-            if ((r < 0 && c < 0) || (r < 0 && my == 0) || (c < 0 && mx == 0))
-                continue;
-            mb[(ptrdiff_t)r * stride + c] = tile[(r + 4) * TP + 4 + c];
+        /* ---- write back what this MB may have changed: rows -3..-1 x columns 0..15, rows 0..15 x columns -4..15
+         * (column -4 and untouched pixels are rewritten with their own final values; the corner is left alone) ---- */
+        if (dw_ok) {
+            for (int i = lane; i < 16 * 5 + 3 * 4; i += 64) {
+                int r, c;
+                if (i < 80) { r = i / 5; c = 4 * (i % 5) - 4; } else { r = (i - 80) / 4 - 3; c = 4 * ((i - 80) & 3); }
+                if ((c < 0 && mx == 0) || (r < 0 && my == 0))
+                    continue;
+                *reinterpret_cast<uint32_t *>(mb + (ptrdiff_t)r * stride + c) = *reinterpret_cast<const uint32_t *>(&tile[(r + 4) * TP + 4 + c]);
+            }
+        } else {
+            for (int i = lane; i < 19 * 19; i += 64) {
+                const int r = i / 19 - 3, c = i % 19 - 3;
+                if ((r < 0 && c < 0) || (r < 0 && my == 0) || (c < 0 && mx == 0))
+                    continue;
+                mb[(ptrdiff_t)r * stride + c] = tile[(r + 4) * TP + 4 + c];
+            }
         }
-        /* ---- the MB's right 4 columns are the next MB's left context ---- */
+        /* ---- the MB's right 4 columns (and those of the context rows) are the next MB's left context ---- */
         wave_lds_sync();
-        uint8_t keep = 0;
-        const int kr = lane >> 2, kc = lane & 3; /* 16 rows x 4 cols, plus the 4 context rows below */
-        keep = tile[(kr + 4) * TP + 4 + 12 + kc];
-        uint8_t keep2 = lane < 16 ? tile[(lane >> 2) * TP + 4 + 12 + (lane & 3)] : 0;
+        const uint32_t keep = *reinterpret_cast<const uint32_t *>(&tile[(lane < 20 ? lane : 0) * TP + 4 + 12]);
         wave_lds_sync();
-        tile[(kr + 4) * TP + kc] = keep;
-        if (lane < 16)
-            tile[(lane >> 2) * TP + (lane & 3)] = keep2;
-        /* ---- publish ---- */
-        __threadfence();
-        wave_lds_sync();
+        if (lane < 20)
+            *reinterpret_cast<uint32_t *>(&tile[lane * TP]) = keep;
+        /* ---- publish (release: this wave's stores above become visible before the counter does) ---- */
         if (lane == 0)
             __hip_atomic_store(&progress[my], mx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
+/* progress counters: a small ring of slots in one device allocation made on first use (stream-ordered zeroing
+ * per launch); a per-launch hipMallocAsync/hipFreeAsync pair serialises launches across streams */
+#define DB_SLOTS 64
+#define DB_SLOT_INTS 2048
+static int *g_db_pool;
+static std::atomic<unsigned> g_db_next;
+static std::mutex g_db_mu;
 
 int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
                                     hipStream_t stream)
 {
     if (mb_w <= 0 || mb_h <= 0)
         return 0;
-    /* progress counters live in a small per-call device allocation (stream-ordered) */
-    int *prog = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&prog), (size_t)(mb_h + 1) * sizeof(int), stream));
+    if (mb_h + 1 > DB_SLOT_INTS) {
+        ffhip_set_error("ffhip_h264_deblock_frame: %d macroblock rows exceed the supported %d", mb_h, DB_SLOT_INTS - 1);
+        return FFHIP_EINVAL;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_db_mu);
+        if (!g_db_pool)
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_db_pool), (size_t)DB_SLOTS * DB_SLOT_INTS * sizeof(int)));
+    }
+    int *prog = g_db_pool + (size_t)(g_db_next.fetch_add(1) % DB_SLOTS) * DB_SLOT_INTS;
     HIP_TRY(hipMemsetAsync(prog, 0, (size_t)(mb_h + 1) * sizeof(int), stream));
     hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h), dim3(64), 0, stream, luma, stride, mb_w, mb_h, edges, prog,
                        prog + mb_h);
-    hipError_t le = hipGetLastError();
-    HIP_TRY(hipFreeAsync(prog, stream));
-    if (le != hipSuccess) {
-        ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(le), __FILE__, __LINE__);
-        return FFHIP_EIO;
-    }
+    LAUNCH_CHECK();
     return 0;
 }

@@ -478,12 +478,14 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     }
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     const dim3 grid(cdiv(nt, wpb)), block(64 * wpb);
-    /* FFT-level tables in LDS when they fit next to the waves' areas (FFHIP_TX_LDSTAB=0 keeps them in L2) */
+    /* FFT-level tables in LDS when they fit next to the waves' areas (FFHIP_TX_LDSTAB=1) */
     const char *et = getenv("FFHIP_TX_LDSTAB");
     const size_t ftab_sz = c->blob_bytes - (size_t)((const uint8_t *)c->d.cos_tab - (const uint8_t *)c->dev);
     int ftab = 0;
     size_t lds = per_wave * wpb;
-    if (!(et && et[0] == '0') && lds + ftab_sz <= 64 * 1024) {
+    /* measured (round 1): copying 5 KiB per 4-transform workgroup costs more than the L2 chains it saves
+     * (86 vs 154 M transforms/s) - opt-in only */
+    if (et && et[0] == '1' && lds + ftab_sz <= 64 * 1024) {
         ftab = (int)ftab_sz;
         lds += ftab_sz;
     }
