@@ -148,9 +148,14 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h,
-                                                           const FFHipH264Edge *edges, int *progress, int *fail)
+__global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
+                                                           const FFHipH264Edge *edges, int *progress)
 {
+    /* blockIdx.y = frame: frames are independent, each has its own counters (mb_h progress words + a fail flag) */
+    luma += (size_t)blockIdx.y * frame_pitch;
+    edges += (size_t)blockIdx.y * mb_w * mb_h * 8;
+    progress += (size_t)blockIdx.y * (mb_h + 1);
+    int *fail = progress + mb_h;
     /* tile[r][c]: r = picture row - (16*my - 4), c = picture column - (16*mx - 4); rows are dword aligned */
     __shared__ __align__(16) uint8_t tile[20 * TP];
     const int my = blockIdx.x, lane = threadIdx.x;
@@ -253,10 +258,10 @@ static int *g_db_pool;
 static std::atomic<unsigned> g_db_next;
 static std::mutex g_db_mu;
 
-int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
-                                    hipStream_t stream)
+int ffhip_launch_h264_deblock_frames(uint8_t *luma, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                                     const FFHipH264Edge *edges, hipStream_t stream)
 {
-    if (mb_w <= 0 || mb_h <= 0)
+    if (mb_w <= 0 || mb_h <= 0 || nframes <= 0)
         return 0;
     if (mb_h + 1 > DB_SLOT_INTS) {
         ffhip_set_error("ffhip_h264_deblock_frame: %d macroblock rows exceed the supported %d", mb_h, DB_SLOT_INTS - 1);
@@ -267,10 +272,20 @@ int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, i
         if (!g_db_pool)
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_db_pool), (size_t)DB_SLOTS * DB_SLOT_INTS * sizeof(int)));
     }
-    int *prog = g_db_pool + (size_t)(g_db_next.fetch_add(1) % DB_SLOTS) * DB_SLOT_INTS;
-    HIP_TRY(hipMemsetAsync(prog, 0, (size_t)(mb_h + 1) * sizeof(int), stream));
-    hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h), dim3(64), 0, stream, luma, stride, mb_w, mb_h, edges, prog,
-                       prog + mb_h);
-    LAUNCH_CHECK();
+    const int per_launch = DB_SLOT_INTS / (mb_h + 1); /* frames whose counters fit one pool slot */
+    for (int f0 = 0; f0 < nframes; f0 += per_launch) {
+        const int nf = nframes - f0 < per_launch ? nframes - f0 : per_launch;
+        int *prog = g_db_pool + (size_t)(g_db_next.fetch_add(1) % DB_SLOTS) * DB_SLOT_INTS;
+        HIP_TRY(hipMemsetAsync(prog, 0, (size_t)nf * (mb_h + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h, nf), dim3(64), 0, stream, luma + (size_t)f0 * frame_pitch, frame_pitch,
+                           stride, mb_w, mb_h, edges + (size_t)f0 * mb_w * mb_h * 8, prog);
+        LAUNCH_CHECK();
+    }
     return 0;
+}
+
+int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
+                                    hipStream_t stream)
+{
+    return ffhip_launch_h264_deblock_frames(luma, 0, 1, stride, mb_w, mb_h, edges, stream);
 }

@@ -62,10 +62,11 @@ __device__ __forceinline__ void tx_wave_sync()
 }
 
 /* in-place split-radix FFT of z[0..n) held in LDS, one wave */
-__device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, int lane)
+__device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, const float *cos_tab, const uint32_t *sched,
+                                           const uint16_t *blocks2, int lane)
 {
     for (int b = lane; b < d.nblocks2; b += 64) {
-        const int o = d.blocks2[b];
+        const int o = blocks2[b];
         const float2 x = z[o], y = z[o + 1];
         z[o] = make_float2(x.x + y.x, x.y + y.y);
         z[o + 1] = make_float2(x.x - y.x, x.y - y.y);
@@ -73,8 +74,8 @@ __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, int lane)
     for (int l = 2; l <= d.lg; l++) {
         tx_wave_sync();
         const int q = 1 << (l - 2);
-        const float *tab = d.cos_tab + d.cos_off[l];
-        const uint32_t *sc = d.sched + d.sched_off[l];
+        const float *tab = cos_tab + d.cos_off[l];
+        const uint32_t *sc = sched + d.sched_off[l];
         for (int b = lane; b < d.sched_cnt[l]; b += 64) {
             const uint32_t e = sc[b];
             const int a0 = e & 0xFFFF, k = e >> 16;
@@ -113,6 +114,10 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
     const int t = blockIdx.x * waves_per_block + wave;
     const int n = d.n, q = n >> 1;
     const size_t per_wave = (size_t)n * 8 + (size_t)n * 16; /* z + staging (4n floats) */
+    /* (the kernel argument itself must stay untouched: a conditionally modified TxDev is spilled to scratch) */
+    const float *f_cos = d.cos_tab;
+    const uint32_t *f_sched = d.sched;
+    const uint16_t *f_b2 = d.blocks2;
     if (ftab_bytes) {
         /* the tables the FFT levels chain through (twiddles, butterfly lists, size-2 list: ~5 KiB at N=1024,
          * contiguous in the context blob from cos_tab on) go to LDS: a level's list entry -> twiddle -> operands
@@ -124,9 +129,9 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
             l4[i] = s4[i];
         __syncthreads();
         const uint8_t *g0 = reinterpret_cast<const uint8_t *>(d.cos_tab);
-        d.sched = reinterpret_cast<const uint32_t *>(ft + (reinterpret_cast<const uint8_t *>(d.sched) - g0));
-        d.blocks2 = reinterpret_cast<const uint16_t *>(ft + (reinterpret_cast<const uint8_t *>(d.blocks2) - g0));
-        d.cos_tab = reinterpret_cast<const float *>(ft);
+        f_sched = reinterpret_cast<const uint32_t *>(ft + (reinterpret_cast<const uint8_t *>(d.sched) - g0));
+        f_b2 = reinterpret_cast<const uint16_t *>(ft + (reinterpret_cast<const uint8_t *>(d.blocks2) - g0));
+        f_cos = reinterpret_cast<const float *>(ft);
     }
     if (wave >= waves_per_block || t >= nt)
         return;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
             z[d.map[i]] = make_float2(re * e.y + im * e.x, re * e.x - im * e.y);
         }
         tx_wave_sync();
-        tx_fft_lds(z, d, lane);
+        tx_fft_lds(z, d, f_cos, f_sched, f_b2, lane);
         /* ---- post-twiddle (tx_template.c:1300-1309) ---- */
         for (int i = lane; i < q; i += 64) {
             const int i0 = q + i, i1 = q - i - 1;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
             z[i] = make_float2(tre * e.x - tim * e.y, tre * e.y + tim * e.x);
         }
         tx_wave_sync();
-        tx_fft_lds(z, d, lane);
+        tx_fft_lds(z, d, f_cos, f_sched, f_b2, lane);
         /* ---- post-twiddle (tx_template.c:1332-1341) ---- */
         const float2 *ex = d.exp + n;
         for (int i = lane; i < q; i += 64) {
@@ -247,13 +252,12 @@ __global__ __launch_bounds__(256) void k_mdct_l(TxDev d, const uint8_t *blob, in
             l4[i] = s4[i];
     }
     __syncthreads();
-    /* rebase the table pointers into LDS */
-    TxDev L = d;
-    L.map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
-    L.exp = reinterpret_cast<const float2 *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
-    L.cos_tab = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
-    L.sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
-    L.blocks2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    /* rebase the table pointers into LDS (as locals: a modified copy of the argument struct would be spilled) */
+    const int *l_map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    const float2 *l_exp = reinterpret_cast<const float2 *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
+    const float *l_cos = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
     const int n = d.n, q = n >> 1;
     const size_t per_wave = (size_t)n * 24;
     uint8_t *mine = lds_raw + ((blob_bytes + 15) & ~15) + wave * per_wave;
@@ -280,20 +284,20 @@ __global__ __launch_bounds__(256) void k_mdct_l(TxDev d, const uint8_t *blob, in
                     re = -st[n + k] + -st[5 * n - 1 - k];
                     im = st[k - n] + -st[len3 - 1 - k];
                 }
-                const float2 e = L.exp[i];
-                z[L.map[i]] = make_float2(re * e.y + im * e.x, re * e.x - im * e.y);
+                const float2 e = l_exp[i];
+                z[l_map[i]] = make_float2(re * e.y + im * e.x, re * e.x - im * e.y);
             }
         } else {
             for (int i = lane; i < n; i += 64) {
-                const int k = L.map[i] << 1;
+                const int k = l_map[i] << 1;
                 const float tre = st[2 * n - 1 - k], tim = st[k];
-                const float2 e = L.exp[i];
+                const float2 e = l_exp[i];
                 z[i] = make_float2(tre * e.x - tim * e.y, tre * e.y + tim * e.x);
             }
         }
         tx_wave_sync();
-        tx_fft_lds(z, L, lane);
-        const float2 *ex = INV ? L.exp + n : L.exp;
+        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
+        const float2 *ex = INV ? l_exp + n : l_exp;
         for (int i = lane; i < q; i += 64) {
             const int i0 = q + i, i1 = q - i - 1;
             const float2 e0 = ex[i0], e1 = ex[i1];

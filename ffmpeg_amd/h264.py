@@ -37,6 +37,13 @@ def deblock_frame(luma, stride, mb_w, mb_h, edges, stream=None):
                                                               _stream(stream)), "ffhip_h264_deblock_frame_dev")
 
 
+def deblock_frames(luma, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream=None):
+    """nframes independent pictures in one launch (edges: nframes * mb_w*mb_h*8 records)."""
+    return _lib.check(_lib.lib().ffhip_h264_deblock_frames_dev(luma.data_ptr(), frame_pitch, nframes, stride, mb_w, mb_h,
+                                                               edges.data_ptr(), _stream(stream)),
+                      "ffhip_h264_deblock_frames_dev")
+
+
 def qpel_batch(dst, src, stride, blocks, n, stream=None):
     return _lib.check(_lib.lib().ffhip_h264_qpel_batch_dev(dst.data_ptr(), src.data_ptr(), stride, blocks.data_ptr(),
                                                            n, _stream(stream)), "ffhip_h264_qpel_batch_dev")

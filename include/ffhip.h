@@ -253,6 +253,10 @@ int ffhip_h264_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHi
  */
 int ffhip_h264_deblock_frame_dev(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h,
                                  const FFHipH264Edge *edges, void *stream);
+/** The same over `nframes` independent pictures in one launch (frame f at luma + f*frame_pitch, its edges at
+ *  edges + f*mb_w*mb_h*8): the order inside a picture is serial, pictures run side by side. */
+int ffhip_h264_deblock_frames_dev(uint8_t *luma, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                                  const FFHipH264Edge *edges, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: h264qpel                                                                       */

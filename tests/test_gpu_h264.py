@@ -218,3 +218,27 @@ def test_qpel_batch(w, h, pad):
             y, x = divmod(int(b["dst_offset"]), stride)
             s = 16 >> int(b["size_idx"])
             assert np.array_equal(got[y:y + s, x:x + s], want[y:y + s, x:x + s]), "block %d mc %d" % (i, b["mcxy"])
+
+
+def test_deblock_frames_batch():
+    """several pictures in one launch == each picture alone"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    rng = np.random.default_rng(9)
+    nf, mb_w, mb_h = 20, 22, 18
+    stride = mb_w * 16
+    planes = np.stack([_smooth_plane(rng, mb_h * 16, stride) for _ in range(nf)])
+    n = mb_w * mb_h * 8
+    ed = np.zeros(nf * n, EDGE_DT)
+    lad = np.array(LADDER)
+    sel = rng.integers(0, len(LADDER), nf * n)
+    ed["alpha"], ed["beta"] = lad[sel, 0], lad[sel, 1]
+    ed["kind"] = np.where(rng.random(nf * n) < .25, 4, 0)
+    ed["tc0"] = rng.integers(-1, 5, (nf * n, 4))
+    want = planes.copy()
+    for f in range(nf):
+        ffi.oracle().ffo_h264_deblock_frame(ptr(want[f]), stride, mb_w, mb_h, C.c_void_p(ed[f * n:].ctypes.data))
+    d = torch.from_numpy(planes).cuda()
+    h264.deblock_frames(d, mb_h * 16 * stride, nf, stride, mb_w, mb_h, torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), want)
