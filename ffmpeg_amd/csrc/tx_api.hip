@@ -482,22 +482,21 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     }
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     const dim3 grid(cdiv(nt, wpb)), block(64 * wpb);
-    /* FFT-level tables in LDS when they fit next to the waves' areas (FFHIP_TX_LDSTAB=1) */
+    /* FFT-level tables in LDS when they fit next to the waves' areas (FFHIP_TX_LDSTAB=0 keeps them in L2) */
     const char *et = getenv("FFHIP_TX_LDSTAB");
     const size_t ftab_sz = c->blob_bytes - (size_t)((const uint8_t *)c->d.cos_tab - (const uint8_t *)c->dev);
     int ftab = 0;
     size_t lds = per_wave * wpb;
-    /* measured (round 1): copying 5 KiB per 4-transform workgroup costs more than the L2 chains it saves
-     * (86 vs 154 M transforms/s) - opt-in only */
-    if (et && et[0] == '1' && lds + ftab_sz <= 64 * 1024) {
+    /* measured (profiles/r01_sweep_tx.txt): 174 vs 149 M forward transforms/s with the level tables in LDS */
+    if (!(et && et[0] == '0') && lds + ftab_sz <= 64 * 1024) {
         ftab = (int)ftab_sz;
         lds += ftab_sz;
     }
     const char *ev = getenv("FFHIP_TX_PERSISTENT");
     const bool aligned = es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 15);
     const size_t lds_p = ((c->blob_bytes + 15) & ~(size_t)15) + per_wave * 4;
-    /* measured (round E): 127 M transforms/s against 151 M for the one-shot kernel (2 workgroups per CU instead
-     * of 3) - kept for experiments, off unless FFHIP_TX_PERSISTENT=1 */
+    /* measured: on par with the one-shot kernel + LDS level tables (171 vs 174 M transforms/s) at 2 workgroups per
+     * CU instead of 3 - kept for experiments, off unless FFHIP_TX_PERSISTENT=1 */
     if (aligned && lds_p <= 64 * 1024 && ev && ev[0] == '1') {
         int cus = 256, dev = 0;
         hipDeviceProp_t prop;

@@ -43,7 +43,7 @@ def _check(got, want):
         (got.view(np.uint32) != want.view(np.uint32)).sum(), got.size, np.abs(got - want).max())
 
 
-@pytest.mark.parametrize("persistent", ["1", "0", "0-ldstab"])
+@pytest.mark.parametrize("persistent", ["1", "0", "0-l2tab"])
 @pytest.mark.parametrize("inv", [0, 1])
 @pytest.mark.parametrize("len_,scale", [(16, 1.0), (64, 1.0 / 64), (256, -1.0), (1024, 1.0), (1024, 32768.0), (1024, 1.0 / 1024),
                                         (2048, 1.0 / 2048), (4096, 1.0)])
@@ -53,7 +53,7 @@ def test_mdct_batch(inv, len_, scale, persistent, monkeypatch):
     from ffmpeg_amd import tx
     torch = _torch()
     monkeypatch.setenv("FFHIP_TX_PERSISTENT", persistent[0])
-    monkeypatch.setenv("FFHIP_TX_LDSTAB", "1" if persistent.endswith("ldstab") else "0")
+    monkeypatch.setenv("FFHIP_TX_LDSTAB", "0" if persistent.endswith("l2tab") else "1")
     rng = np.random.default_rng(len_ + inv)
     nt = 37 if len_ != 1024 else 5000      # more transforms than resident waves: the persistent loop wraps
     n_in = len_ if inv else 2 * len_
