@@ -453,12 +453,6 @@ __global__ __launch_bounds__(256) void k_sws_colwalk(FFHipCwArgs A)
     cw_kernel_body<LK, D, PLAIN, OPT>(A);
 }
 
-/* the same kernel compiled for 5 waves per SIMD (<= 96 VGPRs): measured variant, FFHIP_CW_WPE=5 */
-template <int LK, int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_sws_colwalk_w5(FFHipCwArgs A)
-{
-    cw_kernel_body<LK, D, false, true>(A);
-}
 
 /* ================================================================================================== */
 /*
@@ -818,12 +812,6 @@ int ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const bool opt = A.flags & 2;
-    if (opt && (A.flags & 4) && luma_groups == 2) {
-        if (depth == 6) hipLaunchKernelGGL((k_sws_colwalk_w5<1, 6>), grid, block, 0, stream, A);
-        else            hipLaunchKernelGGL((k_sws_colwalk_w5<1, 3>), grid, block, 0, stream, A);
-        LAUNCH_CHECK();
-        return 0;
-    }
 #define CW_LAUNCH(LK, DD, PL, OP) hipLaunchKernelGGL((k_sws_colwalk<LK, DD, PL, OP>), grid, block, 0, stream, A)
     if (A.flags & 1) {
         CW_LAUNCH(0, 3, true, false);

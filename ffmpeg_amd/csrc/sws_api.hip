@@ -375,9 +375,6 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             A.flags = ep && ep[0] == '1' ? 1 : 0;
             if (c->cw_opt && !A.flags && !(eo && eo[0] == '0'))
                 A.flags |= 2;
-            const char *ew = getenv("FFHIP_CW_WPE");
-            if (ew && ew[0] == '5')
-                A.flags |= 4;
             auto bank = [&](FFHipCwJob &j, const FFHipScalePlaneArgs &p) {
                 j.srcW = p.srcW; j.srcH = p.srcH; j.dstW = p.dstW; j.dstH = p.dstH;
                 j.hf = p.h.filter; j.hp = p.h.pos; j.vf = p.v.filter; j.vp = p.v.pos;

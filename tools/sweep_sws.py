@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from ffmpeg_amd import swscale as S  # noqa: E402
 
-KEYS = ("FFHIP_CW_WPE", "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_CW_OPT",
+KEYS = ("FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_CW_OPT",
         "FFHIP_YUV2RGB_VARIANT")
 
 
@@ -50,7 +50,7 @@ def main():
             for g in ("1", "2"):
                 for d in ("3", "6"):
                     variants.append({"FFHIP_CW_OPT": o, "FFHIP_CW_LUMA_GROUPS": g, "FFHIP_CW_DEPTH": d})
-    variants += [{"FFHIP_CW_WPE": "5"}, {"FFHIP_CW_WPE": "5", "FFHIP_CW_DEPTH": "3"}, {}]
+    variants += [{}]
     variants += [{"FFHIP_SWS_MFMA": "1"}] + [{"FFHIP_SWS_MFMA": "1", "FFHIP_MF_STRIP": x} for x in ("540",)]
     variants += [{"FFHIP_CW_STRIP": "60"}, {"FFHIP_CW_STRIP": "128"}, {"FFHIP_CW_PLAIN": "1"}, {"FFHIP_SWS_FAST": "0"}]
     print("fast path eligible:", ctx.fast_path)
