@@ -26,6 +26,11 @@ struct FFHipSwsContext {
     int chrSrcW, chrSrcH;
     FFHipScalePlaneArgs lum, chr;
     FFHipScaleRgbArgs rgb;
+    /* banks as the fast path sees them: sizes 1..3 zero-padded to 4 taps (same sums, positions kept in range) */
+    std::vector<int16_t> nf[4];
+    std::vector<int32_t> np[4];
+    void *dev_ntables = nullptr;
+    FFHipDevFilter dn[4];
     int cw_ok = 0; /* both bank pairs fit the column-walking fast path (sws_colwalk.hip) */
     int cw_opt = 0; /* ... and no horizontal sum can wrap int16: the hand-scheduled variant applies */
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
@@ -156,24 +161,66 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         r = ffhip_plan_scale_plane(&l, 1, c->p[0].data(), c->p[2].data());
         if (!r)
             r = ffhip_plan_scale_plane(&ch, 2, c->p[1].data(), c->p[3].data());
-        c->cw_ok = ffhip_cw_bank_ok(c->p[0].data(), c->d[0].size, c->d[0].n, l.srcW, c->p[2].data(), c->d[2].size,
-                                    c->d[2].n, l.srcH) &&
-                   ffhip_cw_bank_ok(c->p[1].data(), c->d[1].size, c->d[1].n, ch.srcW, c->p[3].data(), c->d[3].size,
-                                    c->d[3].n, ch.srcH);
-        c->cw_opt = c->cw_ok && ffhip_cw_bank_nowrap(c->f[0].data(), c->d[0].size, c->d[0].n) &&
-                    ffhip_cw_bank_nowrap(c->f[1].data(), c->d[1].size, c->d[1].n);
+        /* ---- fast-path view of the banks: pad 1..3-tap banks to 4 taps.  Zero taps do not change a sum, so
+         * bilinear / point / area up-scaling and 1:1 format conversion run on the column walker too.  A 1-tap
+         * vertical bank is yuv2plane1_8_c, (h + 64) >> 7 == (64<<12 + h*4096) >> 19: its tap becomes 4096. ---- */
+        {
+            const int limits[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
+            bool ok = true, padded = false;
+            for (int i = 0; i < 4 && ok; i++) {
+                const int fs = c->d[i].size, n = c->d[i].n;
+                if (fs > 4 || limits[i] < 4) { ok = false; break; }
+                if (fs == 4) { c->nf[i] = c->f[i]; c->np[i] = c->p[i]; continue; }
+                padded = true;
+                c->nf[i].assign((size_t)n * 4, 0);
+                c->np[i].resize(n);
+                for (int x = 0; x < n; x++) {
+                    const int pos = c->p[i][x];
+                    const int npos = pos + 4 > limits[i] ? limits[i] - 4 : pos;
+                    if (npos < 0 || pos - npos + fs > 4) { ok = false; break; }
+                    c->np[i][x] = npos;
+                    for (int k = 0; k < fs; k++)
+                        c->nf[i][(size_t)x * 4 + (pos - npos) + k] = (i >= 2 && fs == 1) ? 4096 : c->f[i][(size_t)x * fs + k];
+                }
+            }
+            if (ok) {
+                for (int i = 0; i < 4; i++) {
+                    c->dn[i] = c->d[i];
+                    c->dn[i].size = 4;
+                }
+                if (padded) {
+                    size_t noff[4][2], ntot = 0;
+                    for (int i = 0; i < 4; i++) {
+                        noff[i][0] = ntot; ntot += (c->nf[i].size() * 2 + 15) & ~(size_t)15;
+                        noff[i][1] = ntot; ntot += (c->np[i].size() * 4 + 15) & ~(size_t)15;
+                    }
+                    ok = hipMalloc(&c->dev_ntables, ntot) == hipSuccess;
+                    for (int i = 0; i < 4 && ok; i++) {
+                        uint8_t *nb = static_cast<uint8_t *>(c->dev_ntables);
+                        ok = hipMemcpy(nb + noff[i][0], c->nf[i].data(), c->nf[i].size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+                             hipMemcpy(nb + noff[i][1], c->np[i].data(), c->np[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+                        c->dn[i].filter = reinterpret_cast<const int16_t *>(nb + noff[i][0]);
+                        c->dn[i].pos = reinterpret_cast<const int32_t *>(nb + noff[i][1]);
+                    }
+                }
+            }
+            c->cw_ok = ok && ffhip_cw_bank_ok(c->np[0].data(), 4, c->d[0].n, l.srcW, c->np[2].data(), 4, c->d[2].n, l.srcH) &&
+                       ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, ch.srcW, c->np[3].data(), 4, c->d[3].n, ch.srcH);
+        }
+        c->cw_opt = c->cw_ok && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&
+                    ffhip_cw_bank_nowrap(c->nf[1].data(), 4, c->d[1].n);
         /* MFMA variant: same banks; chroma either byte-interleaved on both sides or planar on both sides */
         const bool nv_in = fmt_nv(t->srcFormat), nv_out = fmt_nv(t->dstFormat);
         if (c->cw_opt && nv_in == nv_out) {
             std::vector<uint8_t> tl, tc;
-            const int nl = ffhip_mf_build_tiles(&tl, c->f[0].data(), c->p[0].data(), c->d[0].n, l.srcW, 0, 0);
-            const int nc = ffhip_mf_build_tiles(&tc, c->f[1].data(), c->p[1].data(), c->d[1].n, ch.srcW, nv_in,
+            const int nl = ffhip_mf_build_tiles(&tl, c->nf[0].data(), c->np[0].data(), c->d[0].n, l.srcW, 0, 0);
+            const int nc = ffhip_mf_build_tiles(&tc, c->nf[1].data(), c->np[1].data(), c->d[1].n, ch.srcW, nv_in,
                                                 t->srcFormat == FFHIP_PIX_FMT_NV21);
             if (nl > 0 && nc > 0) {
                 std::vector<int32_t> ys[2];
                 const int srcHs[2] = { l.srcH, ch.srcH };
                 for (int k = 0; k < 2; k++) {
-                    const std::vector<int32_t> &vp = c->p[2 + k];
+                    const std::vector<int32_t> &vp = c->np[2 + k];
                     ys[k].assign(srcHs[k] + 1, (int32_t)vp.size());
                     int y = 0;
                     for (int p = 0; p <= srcHs[k]; p++) {
@@ -246,6 +293,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->dev_tables);
     if (c->mf_dev)
         (void)hipFree(c->mf_dev);
+    if (c->dev_ntables)
+        (void)hipFree(c->dev_ntables);
     if (c->stage)
         (void)hipFree(c->stage);
     delete c;
@@ -344,7 +393,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                     j.src = src; j.dst = dst; j.sstride = ss; j.dstride = dsr; j.sfp = sf; j.dfp = df;
                     j.pair = pair; j.dst_swap = dswap;
                     j.srcH = p.srcH; j.dstW = p.dstW; j.dstH = p.dstH;
-                    j.tiles = c->mf_tiles[which]; j.vf = p.v.filter; j.vp = p.v.pos; j.ys = c->mf_ys[which];
+                    j.tiles = c->mf_tiles[which]; j.vf = c->dn[2 + which].filter; j.vp = c->dn[2 + which].pos; j.ys = c->mf_ys[which];
                     j.ntiles = c->mf_ntiles[which];
                     j.ncb = cdiv(j.ntiles, 16);
                     const int want = est && atoi(est) > 0 ? atoi(est) : 540;
@@ -376,8 +425,9 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             if (c->cw_opt && !A.flags && !(eo && eo[0] == '0'))
                 A.flags |= 2;
             auto bank = [&](FFHipCwJob &j, const FFHipScalePlaneArgs &p) {
+                const int which = &p == &ch ? 1 : 0; /* the padded 4-tap view of the banks */
                 j.srcW = p.srcW; j.srcH = p.srcH; j.dstW = p.dstW; j.dstH = p.dstH;
-                j.hf = p.h.filter; j.hp = p.h.pos; j.vf = p.v.filter; j.vp = p.v.pos;
+                j.hf = c->dn[which].filter; j.hp = c->dn[which].pos; j.vf = c->dn[2 + which].filter; j.vp = c->dn[2 + which].pos;
             };
             FFHipCwJob &jl = A.job[0];
             bank(jl, l);

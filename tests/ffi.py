@@ -14,7 +14,7 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libffref.so")
 
 PIX = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24}
-SWS_BICUBIC, SWS_BILINEAR, SWS_POINT, SWS_AREA = 4, 2, 0x10, 0x20
+SWS_BICUBIC, SWS_BILINEAR, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 4, 2, 0x10, 0x20, 0x40
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
 
 u8p = C.POINTER(C.c_uint8)

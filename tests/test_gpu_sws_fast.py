@@ -231,3 +231,24 @@ def test_mfma_path_adversarial_tables(fmts, monkeypatch):
     banks = _adversarial_banks(rng, sw, sh, dw, dh, 0)
     _run(fmts[0], sw, sh, fmts[1], dw, dh, ffi.SWS_BICUBIC, banks=banks, env={"FFHIP_SWS_MFMA": "1"}, monkeypatch=monkeypatch,
          n=2, seed=6)
+
+
+# ---------------------------------------------------------------------------------------------
+# banks with fewer than 4 taps ride the fast path zero-padded: bilinear / point up-scaling, 1:1 re-packing
+# ---------------------------------------------------------------------------------------------
+PADDED_CASES = [
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_BILINEAR),          # 2 x 2 taps
+    ("nv21", 96, 64, "nv21", 200, 136, ffi.SWS_BILINEAR),
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_POINT),             # 1 x 1 tap
+    ("yuv420p", 128, 72, "nv12", 128, 72, ffi.SWS_BICUBIC),          # 1:1 planar -> NV12 (identity banks)
+    ("nv12", 640, 360, "yuv420p", 640, 360, ffi.SWS_BICUBIC),        # 1:1 NV12 -> planar
+    ("nv12", 640, 360, "nv12", 640, 360, ffi.SWS_BICUBIC),
+    ("yuv420p", 128, 72, "yuv420p", 256, 216, ffi.SWS_BICUBLIN),     # bicubic luma, bilinear chroma
+    ("nv12", 128, 72, "nv12", 384, 72, ffi.SWS_BICUBIC),             # horizontal only: 1-tap vertical bank
+]
+
+
+@pytest.mark.parametrize("env", [{}, {"FFHIP_CW_OPT": "0"}, {"FFHIP_SWS_MFMA": "1"}], ids=["default", "noopt", "mfma"])
+@pytest.mark.parametrize("case", PADDED_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_fast_path_padded_banks(case, env, monkeypatch):
+    _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, n=2)
