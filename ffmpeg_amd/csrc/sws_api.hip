@@ -176,8 +176,19 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 c->np[i].resize(n);
                 for (int x = 0; x < n; x++) {
                     const int pos = c->p[i][x];
-                    const int npos = pos + 4 > limits[i] ? limits[i] - 4 : pos;
-                    if (npos < 0 || pos - npos + fs > 4) { ok = false; break; }
+                    int npos = pos + 4 > limits[i] ? limits[i] - 4 : pos;
+                    if (i < 2) {
+                        /* horizontal: keep the padded window inside the 8-byte span of its 4-column group (the
+                         * zero taps may sit in front of the real ones as well as behind them) */
+                        const int g0 = x & ~3;
+                        int lo = c->p[i][g0];
+                        for (int k = 1; k < 4 && g0 + k < n; k++)
+                            lo = c->p[i][g0 + k] < lo ? c->p[i][g0 + k] : lo;
+                        const int base = lo & ~3;
+                        if (npos > base + 4)
+                            npos = base + 4;
+                    }
+                    if (npos < 0 || pos < npos || pos - npos + fs > 4) { ok = false; break; }
                     c->np[i][x] = npos;
                     for (int k = 0; k < fs; k++)
                         c->nf[i][(size_t)x * 4 + (pos - npos) + k] = (i >= 2 && fs == 1) ? 4096 : c->f[i][(size_t)x * fs + k];
