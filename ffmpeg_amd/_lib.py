@@ -84,6 +84,10 @@ def lib():
                                     C.c_uint64]),
         "ffhip_tx_uninit": (None, [C.POINTER(vp)]),
         "ffhip_tx_batch_dev": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_ssize_t, C.c_int, vp]),
+        "ffhip_h264_chroma_mc_batch_dev": (C.c_int, [vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ffhip_h264_weight_batch_dev": (C.c_int, [vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ff_h264chroma_init_hip": (C.c_int, [vp, C.c_int]),
+        "ff_h264dsp_weight_init_hip": (C.c_int, [vp, C.c_int]),
         "ff_h264dsp_init_hip": (C.c_int, [vp, C.c_int, C.c_int]),
         "ff_h264qpel_init_hip": (C.c_int, [vp, C.c_int]),
         "ff_me_cmp_init_hip": (C.c_int, [vp]),

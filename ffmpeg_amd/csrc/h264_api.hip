@@ -70,3 +70,23 @@ extern "C" int ffhip_h264_qpel_batch_dev(uint8_t *dst, const uint8_t *src, ptrdi
         return FFHIP_ENOSYS;
     return ffhip_launch_h264_qpel(dst, src, stride, blocks, n, (hipStream_t)stream);
 }
+
+extern "C" int ffhip_h264_chroma_mc_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks,
+                                              int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_chroma_mc(dst, src, stride, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks,
+                                           int n, void *stream)
+{
+    if (!dst || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_weight(dst, src ? src : dst, stride, blocks, n, (hipStream_t)stream);
+}

@@ -19,4 +19,8 @@ int ffhip_launch_h264_deblock_frames(uint8_t *luma, size_t frame_pitch, int nfra
                                      const FFHipH264Edge *edges, hipStream_t stream);
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
                            hipStream_t stream);
+int ffhip_launch_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
+                                hipStream_t stream);
+int ffhip_launch_h264_weight(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
+                             hipStream_t stream);
 #endif

@@ -225,6 +225,92 @@ extern "C" int ff_h264qpel_init_hip(FFHipH264QpelContext *c, int bit_depth)
     return 0;
 }
 
+/* ---- h264chroma / weighted prediction ------------------------------------------------------------------ */
+static void chroma_single(int avg, int w_idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const int w = 8 >> w_idx;
+    if (h <= 0 || h > 16)
+        return;
+    Rect d = { dst, stride, 0, h - 1, 0, w - 1, nullptr };
+    Rect s = { const_cast<uint8_t *>(src), stride, 0, (y & 7) ? h : h - 1, 0, (x & 7) ? w : w - 1, nullptr };
+    void *scratch;
+    if (ffhip_scratch_reserve(rect_bytes(d) + rect_bytes(s) + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    if (!rect_up(d, buf + 64) || !rect_up(s, buf + 64 + rect_bytes(d)))
+        return;
+    FFHipChromaBlock b;
+    memset(&b, 0, sizeof(b));
+    b.dst_offset = (int32_t)(d.dev - buf); b.src_offset = (int32_t)(s.dev - buf);
+    b.w_idx = (uint8_t)w_idx; b.h = (uint8_t)h; b.x = (uint8_t)x; b.y = (uint8_t)y; b.avg = (uint8_t)avg;
+    if (hipMemcpy(buf, &b, sizeof(b), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_h264_chroma_mc(buf, buf, DP, (const FFHipChromaBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    rect_down(d, 0, h - 1, 0, w - 1);
+}
+#define CHROMA_FN(op, avg, idx) \
+    static void s_##op##_chroma##idx(uint8_t *d, const uint8_t *s, ptrdiff_t st, int h, int x, int y) { chroma_single(avg, idx, d, s, st, h, x, y); }
+CHROMA_FN(put, 0, 0) CHROMA_FN(put, 0, 1) CHROMA_FN(put, 0, 2) CHROMA_FN(avg, 1, 0) CHROMA_FN(avg, 1, 1) CHROMA_FN(avg, 1, 2)
+
+extern "C" int ff_h264chroma_init_hip(FFHipH264ChromaContext *c, int bit_depth)
+{
+    if (!c || bit_depth != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    c->put_h264_chroma_pixels_tab[0] = s_put_chroma0; c->put_h264_chroma_pixels_tab[1] = s_put_chroma1;
+    c->put_h264_chroma_pixels_tab[2] = s_put_chroma2;
+    c->avg_h264_chroma_pixels_tab[0] = s_avg_chroma0; c->avg_h264_chroma_pixels_tab[1] = s_avg_chroma1;
+    c->avg_h264_chroma_pixels_tab[2] = s_avg_chroma2;
+    return 0;
+}
+
+static void weight_single(int bi, int w_idx, uint8_t *dst, uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
+                          int weights, int offset)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const int w = 16 >> w_idx;
+    if (height <= 0 || height > 16)
+        return;
+    Rect d = { dst, stride, 0, height - 1, 0, w - 1, nullptr };
+    Rect s = { bi ? src : dst, stride, 0, height - 1, 0, w - 1, nullptr };
+    void *scratch;
+    if (ffhip_scratch_reserve(rect_bytes(d) + rect_bytes(s) + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    if (!rect_up(d, buf + 64) || (bi && !rect_up(s, buf + 64 + rect_bytes(d))))
+        return;
+    FFHipWeightBlock b;
+    memset(&b, 0, sizeof(b));
+    b.dst_offset = (int32_t)(d.dev - buf); b.src_offset = bi ? (int32_t)(s.dev - buf) : b.dst_offset;
+    b.w_idx = (uint8_t)w_idx; b.height = (uint8_t)height; b.log2_denom = (uint8_t)log2_denom; b.bi = (uint8_t)bi;
+    b.weightd = (int16_t)weightd; b.weights = (int16_t)weights; b.offset = (int16_t)offset;
+    if (hipMemcpy(buf, &b, sizeof(b), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_h264_weight(buf, buf, DP, (const FFHipWeightBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    rect_down(d, 0, height - 1, 0, w - 1);
+}
+#define WEIGHT_FN(idx) \
+    static void s_weight##idx(uint8_t *b, ptrdiff_t st, int h, int ld, int w, int o) { weight_single(0, idx, b, nullptr, st, h, ld, w, 0, o); } \
+    static void s_biweight##idx(uint8_t *d, uint8_t *s, ptrdiff_t st, int h, int ld, int wd, int ws, int o) { weight_single(1, idx, d, s, st, h, ld, wd, ws, o); }
+WEIGHT_FN(0) WEIGHT_FN(1) WEIGHT_FN(2) WEIGHT_FN(3)
+
+extern "C" int ff_h264dsp_weight_init_hip(FFHipH264WeightContext *c, int bit_depth)
+{
+    if (!c || bit_depth != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    c->weight_pixels_tab[0] = s_weight0; c->weight_pixels_tab[1] = s_weight1; c->weight_pixels_tab[2] = s_weight2;
+    c->weight_pixels_tab[3] = s_weight3;
+    c->biweight_pixels_tab[0] = s_biweight0; c->biweight_pixels_tab[1] = s_biweight1; c->biweight_pixels_tab[2] = s_biweight2;
+    c->biweight_pixels_tab[3] = s_biweight3;
+    return 0;
+}
+
 /* ---- me_cmp --------------------------------------------------------------------------------------------- */
 static int cmp_single(int kind, int width, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
 {

@@ -47,3 +47,15 @@ def deblock_frames(luma, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream
 def qpel_batch(dst, src, stride, blocks, n, stream=None):
     return _lib.check(_lib.lib().ffhip_h264_qpel_batch_dev(dst.data_ptr(), src.data_ptr(), stride, blocks.data_ptr(),
                                                            n, _stream(stream)), "ffhip_h264_qpel_batch_dev")
+
+
+def chroma_mc_batch(dst, src, stride, blocks, n, stream=None):
+    """blocks: uint8 [n, 16] FFHipChromaBlock records"""
+    return _lib.check(_lib.lib().ffhip_h264_chroma_mc_batch_dev(dst.data_ptr(), src.data_ptr(), stride, blocks.data_ptr(), n,
+                                                                _stream(stream)), "ffhip_h264_chroma_mc_batch_dev")
+
+
+def weight_batch(dst, src, stride, blocks, n, stream=None):
+    """blocks: uint8 [n, 20] FFHipWeightBlock records; src may be None when no record is a biweight"""
+    return _lib.check(_lib.lib().ffhip_h264_weight_batch_dev(dst.data_ptr(), src.data_ptr() if src is not None else None, stride,
+                                                             blocks.data_ptr(), n, _stream(stream)), "ffhip_h264_weight_batch_dev")

@@ -284,6 +284,51 @@ int ffhip_h264_qpel_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride
                               const FFHipQpelBlock *blocks, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* libavcodec: h264chroma + explicit weighted prediction (the first "next" row) */
+/* ------------------------------------------------------------------------------------------ */
+/** h264_chroma_mc_func and H264ChromaContext (libavcodec/h264chroma.h:25-32): tab index 0 = 8 wide, 1 = 4, 2 = 2
+ *  (ff_h264chroma_init, libavcodec/h264chroma.c:38-52); x, y are the eighth-pel fractions. */
+typedef void (*ffhip_h264_chroma_mc_func)(uint8_t *dst, const uint8_t *src, ptrdiff_t srcStride, int h, int x, int y);
+typedef struct FFHipH264ChromaContext {
+    ffhip_h264_chroma_mc_func put_h264_chroma_pixels_tab[4];
+    ffhip_h264_chroma_mc_func avg_h264_chroma_pixels_tab[4];
+} FFHipH264ChromaContext;
+/** Fills entries 0..2 (entry 3, the 1-wide VP9 helper, is left untouched).  8-bit only. */
+int ff_h264chroma_init_hip(FFHipH264ChromaContext *c, int bit_depth);
+
+/** One chroma MC call of the batch face (what mc_dir_part() passes to chroma_op, h264_mb.c:270-300). */
+typedef struct FFHipChromaBlock {
+    int32_t dst_offset, src_offset;
+    uint8_t w_idx;       /* 0: 8 wide, 1: 4, 2: 2 */
+    uint8_t h;           /* rows, <= 16            */
+    uint8_t x, y;        /* eighth-pel fractions   */
+    uint8_t avg, pad[3];
+} FFHipChromaBlock;
+int ffhip_h264_chroma_mc_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
+                                   void *stream);
+
+/** h264_weight_func / h264_biweight_func (libavcodec/h264dsp.h:31-37) and the two tables of H264DSPContext
+ *  (:44-45): index 0 = 16 wide, 1 = 8, 2 = 4, 3 = 2 (libavcodec/h264dsp.c:100-107). */
+typedef void (*ffhip_h264_weight_func)(uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset);
+typedef void (*ffhip_h264_biweight_func)(uint8_t *dst, uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
+                                         int weights, int offset);
+typedef struct FFHipH264WeightContext {
+    ffhip_h264_weight_func   weight_pixels_tab[4];
+    ffhip_h264_biweight_func biweight_pixels_tab[4];
+} FFHipH264WeightContext;
+int ff_h264dsp_weight_init_hip(FFHipH264WeightContext *c, int bit_depth);
+
+/** One weight (bi == 0: dst only, weightd = the weight) or biweight call of the batch face. */
+typedef struct FFHipWeightBlock {
+    int32_t dst_offset, src_offset;
+    uint8_t w_idx;       /* 0: 16 wide, 1: 8, 2: 4, 3: 2 */
+    uint8_t height, log2_denom, bi;
+    int16_t weightd, weights, offset, pad;
+} FFHipWeightBlock;
+int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
+                                void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */
 /* ------------------------------------------------------------------------------------------ */
 /** me_cmp_func (libavcodec/me_cmp.h:45-48); the context argument is unused by these metrics

@@ -63,6 +63,11 @@ void ffo_h264_idct_add16intra(uint8_t *dst, const int *block_offset, int16_t *bl
 /* which: FFHIP_H264_LF_* numbering (0 v_luma 1 h_luma 2 v_chroma 3 h_chroma, +4 intra) */
 void ffo_h264_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0);
 void ffo_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
+/* H264ChromaContext (w = 8|4|2) and H264DSPContext.weight/biweight (w = 16|8|4|2) */
+void ffo_h264_chroma_mc(int avg, int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y);
+void ffo_h264_weight(int w, uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset);
+void ffo_h264_biweight(int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
+                       int weights, int offset);
 /* frame-order luma deblock, same edge array layout as ffhip_h264_deblock_frame_dev (include/ffhip.h) */
 typedef struct FfoH264Edge {
     int32_t offset;

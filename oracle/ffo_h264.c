@@ -328,3 +328,45 @@ void ffo_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t 
         for (int x = 0; x < n; x++)
             dst[y * stride + x] = avg ? A2(dst[y * stride + x], out[y * 16 + x]) : out[y * 16 + x];
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Chroma 1/8-pel bilinear MC: libavcodec/h264chroma_template.c:28-172 (op_put/op_avg :169-170).
+ * x, y in [0,8).  A=(8-x)(8-y) B=x(8-y) C=(8-x)y D=xy; the reference only reads the samples whose
+ * weight is non-zero (three cases), and so do we.
+ * ---------------------------------------------------------------------------------------- */
+void ffo_h264_chroma_mc(int avg, int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y)
+{
+    const int A = (8 - x) * (8 - y), B = x * (8 - y), C = (8 - x) * y, D = x * y;
+    for (int i = 0; i < h; i++, dst += stride, src += stride)
+        for (int k = 0; k < w; k++) {
+            int v;
+            if (D)
+                v = A * src[k] + B * src[k + 1] + C * src[stride + k] + D * src[stride + k + 1];
+            else if (B + C)
+                v = A * src[k] + (B + C) * src[(C ? stride : 1) + k];
+            else
+                v = A * src[k];
+            v = (v + 32) >> 6;
+            dst[k] = (uint8_t)(avg ? (dst[k] + v + 1) >> 1 : v);
+        }
+}
+
+/* Explicit weighted prediction: libavcodec/h264dsp_template.c:30-100 (H264_WEIGHT), 8-bit. */
+void ffo_h264_weight(int w, uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset)
+{
+    offset = (int)((unsigned)offset << log2_denom);
+    if (log2_denom)
+        offset += 1 << (log2_denom - 1);
+    for (int y = 0; y < height; y++, block += stride)
+        for (int x = 0; x < w; x++)
+            block[x] = clip_u8((block[x] * weight + offset) >> log2_denom);
+}
+
+void ffo_h264_biweight(int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
+                       int weights, int offset)
+{
+    offset = (int)((unsigned)((offset + 1) | 1) << log2_denom);
+    for (int y = 0; y < height; y++, dst += stride, src += stride)
+        for (int x = 0; x < w; x++)
+            dst[x] = clip_u8((src[x] * weights + dst[x] * weightd + offset) >> (log2_denom + 1));
+}

@@ -46,6 +46,12 @@ void ffref_h264_idct_add8(uint8_t **dst, const int *blockoffset, int16_t *block,
 void ffref_h264_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
 /* avg: 0 put 1 avg; size_idx: 0 16x16 1 8x8 2 4x4; mcxy = x + 4*y */
 void ffref_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
+/* H264ChromaContext.{put,avg}_h264_chroma_pixels_tab[idx]: idx 0 = 8 wide, 1 = 4, 2 = 2; x,y in 1/8 pel */
+void ffref_h264_chroma(int avg, int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y);
+/* H264DSPContext.weight_h264_pixels_tab[idx] / biweight_h264_pixels_tab[idx]: idx 0 = 16 wide, 1 = 8, 2 = 4, 3 = 2 */
+void ffref_h264_weight(int idx, uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset);
+void ffref_h264_biweight(int idx, uint8_t *dst, uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
+                         int weights, int offset);
 /* kind: 0 sad 1 hadamard8_diff 2 sse ; idx: 0 = 16 wide, 1 = 8 wide */
 int  ffref_me_cmp(int kind, int idx, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h);
 /* libavfilter ESA search (vf_mestimate semantics); returns cost, mv[2] = absolute best position */

@@ -14,6 +14,7 @@
 #include "libswscale/swscale_internal.h"
 #include "libavcodec/h264dsp.h"
 #include "libavcodec/h264qpel.h"
+#include "libavcodec/h264chroma.h"
 #include "libavcodec/me_cmp.h"
 #include "libavfilter/motion_estimation.h"
 #include "ffref.h"
@@ -103,6 +104,7 @@ static H264DSPContext   h264;
 static H264DSPContext   h264_422;
 static H264QpelContext  qpel;
 static MECmpContext     mecmp;
+static H264ChromaContext chroma;
 static int dsp_ready;
 static void dsp_init(void)
 {
@@ -113,6 +115,7 @@ static void dsp_init(void)
     ff_h264dsp_init(&h264_422, 8, 2);
     ff_h264qpel_init(&qpel, 8);
     ff_me_cmp_init(&mecmp, NULL);
+    ff_h264chroma_init(&chroma, 8);
     dsp_ready = 1;
 }
 void ffref_h264_idct(int which, uint8_t *dst, int16_t *block, ptrdiff_t stride)
@@ -159,6 +162,22 @@ void ffref_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_
 {
     dsp_init();
     (avg ? qpel.avg_h264_qpel_pixels_tab : qpel.put_h264_qpel_pixels_tab)[size_idx][mcxy](dst, src, stride);
+}
+void ffref_h264_chroma(int avg, int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y)
+{
+    dsp_init();
+    (avg ? chroma.avg_h264_chroma_pixels_tab : chroma.put_h264_chroma_pixels_tab)[idx](dst, src, stride, h, x, y);
+}
+void ffref_h264_weight(int idx, uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset)
+{
+    dsp_init();
+    h264.weight_pixels_tab[idx](block, stride, height, log2_denom, weight, offset);
+}
+void ffref_h264_biweight(int idx, uint8_t *dst, uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
+                         int weights, int offset)
+{
+    dsp_init();
+    h264.biweight_pixels_tab[idx](dst, src, stride, height, log2_denom, weightd, weights, offset);
 }
 int ffref_me_cmp(int kind, int idx, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
 {

@@ -85,6 +85,12 @@ def oracle():
         L.ffo_h264_loop_filter.restype = None
         L.ffo_h264_qpel.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t]
         L.ffo_h264_qpel.restype = None
+        L.ffo_h264_chroma_mc.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+        L.ffo_h264_chroma_mc.restype = None
+        L.ffo_h264_weight.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffo_h264_weight.restype = None
+        L.ffo_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffo_h264_biweight.restype = None
         L.ffo_h264_deblock_frame.argtypes = [u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
         L.ffo_h264_deblock_frame.restype = None
         L.ffo_sad.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]
@@ -140,6 +146,12 @@ def ref():
         L.ffref_h264_loop_filter.restype = None
         L.ffref_h264_qpel.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t]
         L.ffref_h264_qpel.restype = None
+        L.ffref_h264_chroma.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+        L.ffref_h264_chroma.restype = None
+        L.ffref_h264_weight.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffref_h264_weight.restype = None
+        L.ffref_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffref_h264_biweight.restype = None
         L.ffref_me_cmp.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]
         L.ffref_me_search_esa.argtypes = [u8p, u8p] + [C.c_int] * 7 + [i32p]
         L.ffref_me_search_esa.restype = C.c_uint64

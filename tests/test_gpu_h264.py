@@ -242,3 +242,90 @@ def test_deblock_frames_batch():
     h264.deblock_frames(d, mb_h * 16 * stride, nf, stride, mb_w, mb_h, torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).cuda())
     torch.cuda.synchronize()
     assert np.array_equal(d.cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# chroma 1/8-pel MC and explicit weighted prediction
+# ---------------------------------------------------------------------------------------------
+CHROMA_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("h", np.uint8), ("x", np.uint8),
+                      ("y", np.uint8), ("avg", np.uint8), ("pad", np.uint8, 3)])
+WEIGHT_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("height", np.uint8),
+                      ("log2_denom", np.uint8), ("bi", np.uint8), ("weightd", np.int16), ("weights", np.int16),
+                      ("offset", np.int16), ("pad", np.int16)])
+
+
+@pytest.mark.parametrize("w,h,pad", [(64, 48, 0), (1920, 1080, 0), (200, 96, 3)])
+def test_chroma_mc_batch(w, h, pad):
+    """every 8x8 chroma block of a plane: mixed widths 8/4/2, heights, all (x,y) fractions, put/avg"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    assert CHROMA_DT.itemsize == 16
+    rng = np.random.default_rng(w + pad)
+    P = 16
+    stride = w + 2 * P + pad
+    ref = rng.integers(0, 256, (h + 2 * P, stride), dtype=np.uint8)
+    dst = rng.integers(0, 256, (h + 2 * P, stride), dtype=np.uint8)
+    blocks = []
+    for by in range(h // 8):
+        for bx in range(w // 8):
+            w_idx = int(rng.integers(0, 3))
+            bw = 8 >> w_idx
+            bh = int(rng.choice([2, 4, 8]))
+            for sy in range(0, 8, bh):
+                for sx in range(0, 8, bw):
+                    dy, dx = rng.integers(-8, 9, 2)
+                    y, x = P + by * 8 + sy, P + bx * 8 + sx
+                    blocks.append((y * stride + x, (y + dy) * stride + x + dx, w_idx, bh, rng.integers(0, 8), rng.integers(0, 8),
+                                   rng.integers(0, 2), 0))
+    bl = np.zeros(len(blocks), CHROMA_DT)
+    for i, b in enumerate(blocks):
+        bl[i] = b[:7] + ([0, 0, 0],)
+    n = len(bl)
+    chk = np.arange(n) if n <= 30000 else rng.choice(n, 30000, replace=False)
+    want = dst.copy()
+    for i in chk:
+        b = bl[i]
+        ffi.oracle().ffo_h264_chroma_mc(int(b["avg"]), 8 >> int(b["w_idx"]), C.cast(want.ctypes.data + int(b["dst_offset"]), u8p),
+                                        C.cast(ref.ctypes.data + int(b["src_offset"]), u8p), stride, int(b["h"]), int(b["x"]), int(b["y"]))
+    d_dst, d_ref = torch.from_numpy(dst).cuda(), torch.from_numpy(ref).cuda()
+    h264.chroma_mc_batch(d_dst, d_ref, stride, torch.from_numpy(bl.view(np.uint8).reshape(n, 16)).cuda(), n)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    if n <= 30000:
+        assert np.array_equal(got, want)
+    else:
+        for i in chk:
+            b = bl[i]
+            y, x = divmod(int(b["dst_offset"]), stride)
+            assert np.array_equal(got[y:y + int(b["h"]), x:x + (8 >> int(b["w_idx"]))], want[y:y + int(b["h"]), x:x + (8 >> int(b["w_idx"]))])
+
+
+def test_weight_batch():
+    from ffmpeg_amd import h264
+    torch = _torch()
+    assert WEIGHT_DT.itemsize == 20
+    rng = np.random.default_rng(12)
+    w, h, stride = 256, 128, 272
+    dst = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    src = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    bl = np.zeros((h // 16) * (w // 16), WEIGHT_DT)
+    i = 0
+    for by in range(h // 16):
+        for bx in range(w // 16):
+            bl[i] = (by * 16 * stride + bx * 16, by * 16 * stride + bx * 16, rng.integers(0, 4), rng.choice([2, 4, 8, 16]),
+                     rng.integers(0, 8), rng.integers(0, 2), rng.integers(-128, 128), rng.integers(-128, 128),
+                     rng.integers(-128, 128), 0)
+            i += 1
+    want = dst.copy()
+    for b in bl:
+        pd = C.cast(want.ctypes.data + int(b["dst_offset"]), u8p)
+        if b["bi"]:
+            ffi.oracle().ffo_h264_biweight(16 >> int(b["w_idx"]), pd, C.cast(src.ctypes.data + int(b["src_offset"]), u8p), stride,
+                                           int(b["height"]), int(b["log2_denom"]), int(b["weightd"]), int(b["weights"]), int(b["offset"]))
+        else:
+            ffi.oracle().ffo_h264_weight(16 >> int(b["w_idx"]), pd, stride, int(b["height"]), int(b["log2_denom"]), int(b["weightd"]),
+                                         int(b["offset"]))
+    d_dst, d_src = torch.from_numpy(dst).cuda(), torch.from_numpy(src).cuda()
+    h264.weight_batch(d_dst, d_src, stride, torch.from_numpy(bl.view(np.uint8).reshape(-1, 20)).cuda(), bl.size)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_dst.cpu().numpy(), want)

@@ -30,6 +30,19 @@ class H264Qpel(C.Structure):
     _fields_ = [("put", (QPEL * 16) * 3), ("avg", (QPEL * 16) * 3)]
 
 
+CHROMA = C.CFUNCTYPE(None, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int)
+WEIGHT = C.CFUNCTYPE(None, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int)
+BIWEIGHT = C.CFUNCTYPE(None, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+
+
+class H264Chroma(C.Structure):
+    _fields_ = [("put", CHROMA * 4), ("avg", CHROMA * 4)]
+
+
+class H264Weight(C.Structure):
+    _fields_ = [("weight", WEIGHT * 4), ("biweight", BIWEIGHT * 4)]
+
+
 class MECmp(C.Structure):
     _fields_ = [("sad", CMP * 2), ("hadamard8_diff", CMP * 2), ("pix_abs", (CMP * 1) * 2)]
 
@@ -133,3 +146,38 @@ def test_me_cmp_init_hip():
             assert c.pix_abs[0][0](None, pa, pb, 64, h) == O.ffo_sad(16, pa, pb, 64, h)
             assert c.hadamard8_diff[0](None, pa, pb, 64, h) == O.ffo_hadamard8_diff16(pa, pb, 64, h)
         assert c.hadamard8_diff[1](None, pa, pb, 64, 8) == O.ffo_hadamard8_diff8x8(pa, pb, 64)
+
+
+def test_h264chroma_and_weight_init_hip():
+    """tests/checkasm/h264chroma.c shape for the chroma table; slice-header ranges for the weight tables"""
+    L = _lib()
+    O = ffi.oracle()
+    c = H264Chroma()
+    assert L.ff_h264chroma_init_hip(C.byref(c), 8) == 0
+    rng = np.random.default_rng(4)
+    stride = 48
+    for avg in (0, 1):
+        tab = c.avg if avg else c.put
+        for idx, w in enumerate((8, 4, 2)):
+            for (x, y) in ((0, 0), (3, 0), (0, 5), (7, 7), (4, 2)):
+                src = rng.integers(0, 256, (24, stride), dtype=np.uint8)
+                dst = rng.integers(0, 256, (24, stride), dtype=np.uint8)
+                wd = dst.copy()
+                off = 3 * stride + 8
+                O.ffo_h264_chroma_mc(avg, w, C.cast(wd.ctypes.data + off, u8p), C.cast(src.ctypes.data + off, u8p), stride, 8, x, y)
+                tab[idx](C.cast(dst.ctypes.data + off, u8p), C.cast(src.ctypes.data + off, u8p), stride, 8, x, y)
+                assert np.array_equal(dst, wd), (avg, w, x, y)
+    wc = H264Weight()
+    assert L.ff_h264dsp_weight_init_hip(C.byref(wc), 8) == 0
+    for idx, w in enumerate((16, 8, 4, 2)):
+        for ld, wt, ws, of in ((0, 1, 1, 0), (5, 37, -12, 9), (7, -128, 127, -128), (2, 127, 127, 127)):
+            blk = rng.integers(0, 256, (20, stride), dtype=np.uint8)
+            src = rng.integers(0, 256, (20, stride), dtype=np.uint8)
+            a, b = blk.copy(), blk.copy()
+            O.ffo_h264_weight(w, C.cast(a.ctypes.data + 56, u8p), stride, 16, ld, wt, of)
+            wc.weight[idx](C.cast(b.ctypes.data + 56, u8p), stride, 16, ld, wt, of)
+            assert np.array_equal(a, b), ("weight", w, ld, wt, of)
+            a, b = blk.copy(), blk.copy()
+            O.ffo_h264_biweight(w, C.cast(a.ctypes.data + 56, u8p), C.cast(src.ctypes.data + 56, u8p), stride, 8, ld, wt, ws, of)
+            wc.biweight[idx](C.cast(b.ctypes.data + 56, u8p), C.cast(src.ctypes.data + 56, u8p), stride, 8, ld, wt, ws, of)
+            assert np.array_equal(a, b), ("biweight", w, ld, wt, ws, of)

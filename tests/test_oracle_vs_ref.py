@@ -234,6 +234,46 @@ def test_h264_qpel(size_idx, avg):
             assert np.array_equal(a, b), (mcxy, rep)
 
 
+@pytest.mark.parametrize("avg", [0, 1])
+def test_h264_chroma_mc(avg):
+    """tests/checkasm/h264chroma.c shape: put/avg x widths 8/4/2 x all 64 (x, y) eighth-pel positions"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(60 + avg)
+    for idx, w in enumerate((8, 4, 2)):
+        for h in (2, 4, 8, 16)[:4 if w == 8 else 3]:
+            for y in range(8):
+                for x in range(8):
+                    src = rng.integers(0, 256, (24, 32), dtype=np.uint8)
+                    dst = rng.integers(0, 256, (24, 32), dtype=np.uint8)
+                    a, b = dst.copy(), dst.copy()
+                    off = 2 * 32 + 8
+                    R.ffref_h264_chroma(avg, idx, C.cast(a.ctypes.data + off, u8p), C.cast(src.ctypes.data + off, u8p), 32, h, x, y)
+                    O.ffo_h264_chroma_mc(avg, w, C.cast(b.ctypes.data + off, u8p), C.cast(src.ctypes.data + off, u8p), 32, h, x, y)
+                    assert np.array_equal(a, b), (w, h, x, y)
+
+
+def test_h264_weight_biweight():
+    """tests/checkasm/h264dsp.c has no weight test; the parameter ranges are the slice header's
+    (log2_denom 0..7, weights -128..127, offsets -128..127: libavcodec/h264_parse.c ff_h264_pred_weight_table)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(61)
+    for idx, w in enumerate((16, 8, 4, 2)):
+        for rep in range(60):
+            height = int(rng.choice([2, 4, 8, 16]))
+            ld = int(rng.integers(0, 8))
+            wt, ws, off = [int(v) for v in rng.integers(-128, 128, 3)]
+            blk = rng.integers(0, 256, (20, 32), dtype=np.uint8)
+            src = rng.integers(0, 256, (20, 32), dtype=np.uint8)
+            a, b = blk.copy(), blk.copy()
+            R.ffref_h264_weight(idx, C.cast(a.ctypes.data + 40, u8p), 32, height, ld, wt, off)
+            O.ffo_h264_weight(w, C.cast(b.ctypes.data + 40, u8p), 32, height, ld, wt, off)
+            assert np.array_equal(a, b), ("weight", w, height, ld, wt, off)
+            a, b = blk.copy(), blk.copy()
+            R.ffref_h264_biweight(idx, C.cast(a.ctypes.data + 40, u8p), C.cast(src.ctypes.data + 40, u8p), 32, height, ld, wt, ws, off)
+            O.ffo_h264_biweight(w, C.cast(b.ctypes.data + 40, u8p), C.cast(src.ctypes.data + 40, u8p), 32, height, ld, wt, ws, off)
+            assert np.array_equal(a, b), ("biweight", w, height, ld, wt, ws, off)
+
+
 def test_me_cmp():
     R, O = ffi.ref(), ffi.oracle()
     rng = np.random.default_rng(40)
