@@ -93,6 +93,23 @@ def test_h264_golden():
         assert np.array_equal(o[6:22, 8:24], d["qpel_out"][i]), (avg, size_idx, mc)
 
 
+def test_h264_chroma_weight_golden():
+    O = ffi.oracle()
+    d = load("h264")
+    src = np.ascontiguousarray(d["chroma_src"])
+    for i, (avg, idx, x, y) in enumerate(d["chroma_par"]):
+        o = d["chroma_dst"].copy()
+        O.ffo_h264_chroma_mc(int(avg), 8 >> int(idx), at(o, 2 * 32 + 8), at(src, 2 * 32 + 8), 32, 8, int(x), int(y))
+        assert np.array_equal(o[2:10, 8:16], d["chroma_out"][i]), (avg, idx, x, y)
+    for i, (bi, idx, ld, wt, ws, of) in enumerate(d["weight_par"]):
+        o = d["chroma_dst"].copy()
+        if bi:
+            O.ffo_h264_biweight(16 >> int(idx), at(o, 2 * 32 + 8), at(src, 2 * 32 + 8), 32, 16, int(ld), int(wt), int(ws), int(of))
+        else:
+            O.ffo_h264_weight(16 >> int(idx), at(o, 2 * 32 + 8), 32, 16, int(ld), int(wt), int(of))
+        assert np.array_equal(o[2:18, 8:24], d["weight_out"][i]), (bi, idx, ld, wt, ws, of)
+
+
 def test_me_golden():
     O = ffi.oracle()
     d = load("me")

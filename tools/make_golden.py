@@ -87,6 +87,27 @@ def h264():
                 assert np.array_equal(o[:6], dst[:6]) and np.array_equal(o[22:], dst[22:])
                 q_out.append(o[6:22, 8:24].copy()); q_par.append([avg, size_idx, mc])
     d["qpel_src"], d["qpel_dst"], d["qpel_out"], d["qpel_par"] = src, dst, np.stack(q_out), np.array(q_par, np.int32)
+    # chroma 1/8-pel MC and weighted prediction
+    csrc = rng.integers(0, 256, (24, 32), dtype=np.uint8)
+    cdst = rng.integers(0, 256, (24, 32), dtype=np.uint8)
+    c_out, c_par = [], []
+    for avg in (0, 1):
+        for idx in range(3):
+            for (x, y) in ((0, 0), (5, 0), (0, 3), (7, 7), (2, 6), (4, 4)):
+                o = cdst.copy()
+                R.ffref_h264_chroma(avg, idx, at(o, 2 * 32 + 8), at(csrc, 2 * 32 + 8), 32, 8, x, y)
+                c_out.append(o[2:10, 8:16].copy()); c_par.append([avg, idx, x, y])
+    d["chroma_src"], d["chroma_dst"], d["chroma_out"], d["chroma_par"] = csrc, cdst, np.stack(c_out), np.array(c_par, np.int32)
+    w_out, w_par = [], []
+    for idx in range(4):
+        for ld, wt, ws, of in ((0, 1, 1, 0), (5, 37, -12, 9), (7, -128, 127, -128), (2, 127, 127, 127), (6, 64, 64, 0)):
+            o = cdst.copy()
+            R.ffref_h264_weight(idx, at(o, 2 * 32 + 8), 32, 16, ld, wt, of)
+            w_out.append(o[2:18, 8:24].copy()); w_par.append([0, idx, ld, wt, ws, of])
+            o = cdst.copy()
+            R.ffref_h264_biweight(idx, at(o, 2 * 32 + 8), at(csrc, 2 * 32 + 8), 32, 16, ld, wt, ws, of)
+            w_out.append(o[2:18, 8:24].copy()); w_par.append([1, idx, ld, wt, ws, of])
+    d["weight_out"], d["weight_par"] = np.stack(w_out), np.array(w_par, np.int32)
     np.savez_compressed(os.path.join(OUT, "h264.npz"), **d)
 
 
