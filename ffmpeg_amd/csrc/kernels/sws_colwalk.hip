@@ -456,6 +456,268 @@ __global__ __launch_bounds__(256) void k_sws_colwalk(FFHipCwArgs A)
 
 /* ================================================================================================== */
 /*
+ * k_sws_colwalk_rgb — the column walker with packed rgb24/bgr24 output (yuv2rgb_X_c_template,
+ * libswscale/output.c:1797-1850 via yuv2packedX, vscale.c:126-170) for 4-tap vertical banks.
+ *
+ * A lane owns 8 output pixels (two luma column groups) and the 4 chroma columns under them.  The luma walk
+ * is the statically indexed, D-deep prefetched one of cw_unit; the chroma planes advance far less often
+ * (chrDstH == dstH: 4x vertically for 4:2:0 at 2x), so their ring of vertical pairs simply shifts through
+ * register moves and their source rows are fetched one advance ahead.  Per output row: 16 luma + 16 chroma
+ * vertical dots, the closed-form yuv2rgb of sws_yuv2rgb.hip, v_ashr_pk_u8_i32 pairs, three 8-byte stores
+ * (24 contiguous bytes per lane, 1536 per wave).  Nothing but source rows and RGB rows touches memory.
+ */
+template <int SH>
+__device__ __forceinline__ uint32_t cw_pk_sh(int a, int b)
+{
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "n"(SH));
+    return r;
+}
+
+/* horizontal descriptor of one 4-column group: byte selectors + coefficient pairs, window base (dword aligned) */
+__device__ __forceinline__ int cw_hdesc(uint32_t (&sel)[8], uint32_t (&cf)[8], const int16_t *hf, const int32_t *hp, int X0,
+                                        int n, int srcW)
+{
+    int p[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int xi = min(X0 + i, n - 1);
+        p[i] = hp[xi];
+        const uint2 c = *reinterpret_cast<const uint2 *>(hf + (size_t)xi * 4);
+        cf[2 * i] = c.x;
+        cf[2 * i + 1] = c.y;
+    }
+    int base = min(min(p[0], p[1]), min(p[2], p[3])) & ~3;
+    if (base + 8 > srcW)
+        base -= 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t o = (uint32_t)(p[i] - base);
+        sel[2 * i]     = 0x0c000c00u | o | ((o + 1) << 16);
+        sel[2 * i + 1] = 0x0c000c00u | (o + 2) | ((o + 3) << 16);
+    }
+    return base;
+}
+
+/* 4 horizontal samples of one group from its 8 raw bytes -> (h[r-1], h[r]) pairs, int16-saturated (nowrap banks) */
+__device__ __forceinline__ void cw_hgroup(uint32_t (&Pnew)[4], int (&hprev)[4], uint32_t d0, uint32_t d1, const uint32_t (&sel)[8],
+                                          const uint32_t (&cf)[8])
+{
+    uint32_t a[4], b[4];
+    int acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a[i] = __builtin_amdgcn_perm(d1, d0, sel[2 * i]);
+        b[i] = __builtin_amdgcn_perm(d1, d0, sel[2 * i + 1]);
+    }
+    cw_hdots4(acc, a, b, cf);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int h = acc[i] >> 7;
+        Pnew[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[i], h));
+        hprev[i] = h;
+    }
+}
+
+template <bool SIL, bool BGR, int D>
+__global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t upf = (uint32_t)A.ncb * (uint32_t)A.nstrips;
+    if (gw >= upf * (uint32_t)A.nframes)
+        return;
+    const int f = (int)(gw / upf);
+    const int u = (int)(gw - (uint32_t)f * upf);
+    const int strip = u / A.ncb, cb = u - strip * A.ncb;
+    const int y0 = strip * A.strip_rows;
+    const int y1 = min(y0 + A.strip_rows, A.dstH); /* <= 64 rows: one register per vertical descriptor */
+
+    /* ---- horizontal descriptors: two luma groups, one chroma group ---- */
+    const int X0 = (cb * 64 + lane) * 8;
+    uint32_t lsel[2][8], lcf[2][8], csel[8], ccf[8];
+    const uint32_t lb0 = (uint32_t)cw_hdesc(lsel[0], lcf[0], A.hlf, A.hlp, X0, A.dstW, A.srcW);
+    const uint32_t lb1 = (uint32_t)cw_hdesc(lsel[1], lcf[1], A.hlf, A.hlp, X0 + 4, A.dstW, A.srcW);
+    const uint32_t cbase = (uint32_t)cw_hdesc(csel, ccf, A.hcf, A.hcp, X0 >> 1, A.dstW >> 1, A.chrSrcW);
+    const bool act = X0 < A.dstW; /* dstW % 8 == 0 (host-checked): a lane is all or nothing */
+    const uint32_t cbb = SIL ? 2 * cbase : cbase;
+    const uint32_t sel_u = A.src_swap ? 0x07050301u : 0x06040200u, sel_v = A.src_swap ? 0x06040200u : 0x07050301u;
+
+    const uint8_t *sy = A.src[0] + (size_t)f * A.sfp[0];
+    const uint8_t *su = A.src[1] + (size_t)f * A.sfp[1];
+    const uint8_t *sv = SIL ? su : A.src[2] + (size_t)f * A.sfp[2];
+    const ptrdiff_t ystride = A.sstride[0], ustride = A.sstride[1], vstride = SIL ? A.sstride[1] : A.sstride[2];
+    const ptrdiff_t dstride = A.dstride;
+
+    /* ---- vertical descriptors (wave-uniform per output row, read with v_readlane) ---- */
+    int vpl, cpl;
+    uint32_t lf01, lf23, cf01, cf23;
+    {
+        const int y = min(y0 + lane, A.dstH - 1);
+        vpl = A.vlp[y];
+        cpl = A.vcp[y];
+        const uint2 a = *reinterpret_cast<const uint2 *>(A.vlf + (size_t)y * 4);
+        const uint2 b = *reinterpret_cast<const uint2 *>(A.vcf + (size_t)y * 4);
+        lf01 = a.x; lf23 = a.y; cf01 = b.x; cf23 = b.y;
+    }
+    const FFHipYuv2RgbK K = A.k;
+
+    uint32_t Pw[3][2][4], Ca[2][4], Cm[2][4], Cb[2][4];
+    int hprev[2][4], cprev[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            Pw[0][g][i] = Pw[1][g][i] = Pw[2][g][i] = 0;
+            Ca[g][i] = Cm[g][i] = Cb[g][i] = 0;
+            hprev[g][i] = cprev[g][i] = 0;
+        }
+    int kround = 1 << 18;
+    asm volatile("" : "+v"(kround));
+
+    const int ny = y1 - y0;
+    int yy = 0;
+    int need = __builtin_amdgcn_readlane(vpl, 0) + 3;
+    int cneed = __builtin_amdgcn_readlane(cpl, 0) + 3;
+    const int rlast = __builtin_amdgcn_readfirstlane(A.vlp[y1 - 1]) + 3;
+    const int crlast = __builtin_amdgcn_readfirstlane(A.vcp[y1 - 1]) + 3;
+    int r = need - 3;
+    int ccur = cneed - 4; /* newest chroma row in the ring */
+
+    /* running row pointers (SGPRs) */
+    int pfrow = r, cpfrow = ccur + 1;
+    const uint8_t *pfy = sy + (ptrdiff_t)r * ystride;
+    const uint8_t *pfu = su + (ptrdiff_t)cpfrow * ustride, *pfv = sv + (ptrdiff_t)cpfrow * vstride;
+    uint8_t *dr = A.dst + (size_t)f * A.dfp + (ptrdiff_t)y0 * dstride;
+    asm("" : "+s"(pfy), "+s"(pfu), "+s"(pfv), "+s"(dr));
+    const uint32_t dcol = 3u * (uint32_t)X0;
+
+    auto load_luma = [&](CwRaw &o) {
+        cw_load<8>(o, 0, pfy, lb0);
+        cw_load<8>(o, 2, pfy, lb1);
+        const bool adv = pfrow < rlast;
+        pfrow = min(pfrow + 1, rlast);
+        pfy += adv ? ystride : 0;
+        asm("" : "+s"(pfy));
+    };
+    auto load_chroma = [&](CwRaw &o) {
+        if (SIL) {
+            cw_load<16>(o, 0, pfu, cbb);
+        } else {
+            cw_load<8>(o, 0, pfu, cbb);
+            cw_load<8>(o, 2, pfv, cbb);
+        }
+        const bool adv = cpfrow < crlast;
+        cpfrow = min(cpfrow + 1, crlast);
+        pfu += adv ? ustride : 0;
+        pfv += adv ? vstride : 0;
+        asm("" : "+s"(pfu), "+s"(pfv));
+    };
+
+    CwRaw cnext;
+    load_chroma(cnext);
+    CwRaw buf[D];
+#pragma unroll
+    for (int k = 0; k < D; k++)
+        load_luma(buf[k]);
+
+    auto chroma_advance = [&]() {
+        const CwRaw cur = cnext;
+        load_chroma(cnext);
+        uint32_t u0, u1, v0, v1;
+        if (SIL) {
+            u0 = __builtin_amdgcn_perm(cur.q[1], cur.q[0], sel_u);
+            u1 = __builtin_amdgcn_perm(cur.q[3], cur.q[2], sel_u);
+            v0 = __builtin_amdgcn_perm(cur.q[1], cur.q[0], sel_v);
+            v1 = __builtin_amdgcn_perm(cur.q[3], cur.q[2], sel_v);
+        } else {
+            u0 = cur.q[0]; u1 = cur.q[1]; v0 = cur.q[2]; v1 = cur.q[3];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Ca[g][i] = Cm[g][i];
+                Cm[g][i] = Cb[g][i];
+            }
+        cw_hgroup(Cb[0], cprev[0], u0, u1, csel, ccf);
+        cw_hgroup(Cb[1], cprev[1], v0, v1, csel, ccf);
+        ccur++;
+    };
+
+    auto emit = [&](const uint32_t (&La)[2][4], const uint32_t (&Lb)[2][4], int ll) {
+        const uint32_t f01 = __builtin_amdgcn_readlane(lf01, ll), f23 = __builtin_amdgcn_readlane(lf23, ll);
+        const uint32_t g01 = __builtin_amdgcn_readlane(cf01, ll), g23 = __builtin_amdgcn_readlane(cf23, ll);
+        int Yv[2][4], Uv[4], Vv[4];
+        cw_vdots4(Yv[0], La[0], Lb[0], f01, f23, kround);
+        cw_vdots4(Yv[1], La[1], Lb[1], f01, f23, kround);
+        cw_vdots4(Uv, Ca[0], Cb[0], g01, g23, kround);
+        cw_vdots4(Vv, Ca[1], Cb[1], g01, g23, kround);
+        uint32_t w[6];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            int val[12];
+#pragma unroll
+            for (int mm = 0; mm < 2; mm++) {
+                const int m = 2 * h + mm;
+                const int Uc = min(max(Uv[m] >> 19, 0), 255), Vc = min(max(Vv[m] >> 19, 0), 255);
+                const int br = __mul24(K.off_r + (__mul24(Vc, K.crv) >> 16), K.cy) + K.kb;
+                const int bb = __mul24(K.off_b + (__mul24(Uc, K.cbu) >> 16), K.cy) + K.kb;
+                const int bg = __mul24(K.off_g + (__mul24(Uc, K.cgu) >> 16) +
+                                                            (__mul24(Vc, K.cgv) >> 16), K.cy) + K.kb;
+                const int c0 = BGR ? bb : br, c2 = BGR ? br : bb;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int p = 2 * mm + e;
+                    const int yc = __mul24(Yv[h][p] >> 19, K.cy);
+                    val[3 * p] = yc + c0;
+                    val[3 * p + 1] = yc + bg;
+                    val[3 * p + 2] = yc + c2;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                w[3 * h + d] = __builtin_amdgcn_perm(cw_pk_sh<16>(val[4 * d + 2], val[4 * d + 3]),
+                                                     cw_pk_sh<16>(val[4 * d], val[4 * d + 1]), 0x05040100);
+        }
+        if (act) {
+            cw_gptr d = (cw_gptr)dr + cw_opaque(dcol);
+            cw_u2 s;
+            s.x = w[0]; s.y = w[1]; *(cw_g2)d = s;
+            s.x = w[2]; s.y = w[3]; *(cw_g2)(d + 8) = s;
+            s.x = w[4]; s.y = w[5]; *(cw_g2)(d + 16) = s;
+        }
+        dr += dstride;
+        asm("" : "+s"(dr));
+    };
+
+    for (; r <= rlast; r += D) {
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const int rr = r + k;
+            const CwRaw cur = buf[k];
+            load_luma(buf[k]);
+            if (rr <= rlast) {
+                cw_hgroup(Pw[k % 3][0], hprev[0], cur.q[0], cur.q[1], lsel[0], lcf[0]);
+                cw_hgroup(Pw[k % 3][1], hprev[1], cur.q[2], cur.q[3], lsel[1], lcf[1]);
+                while (yy < ny && need <= rr) {
+                    while (ccur < cneed)
+                        chroma_advance();
+                    emit(Pw[(k + 1) % 3], Pw[k % 3], yy);
+                    yy++;
+                    if (yy < ny) {
+                        need = __builtin_amdgcn_readlane(vpl, yy) + 3;
+                        cneed = __builtin_amdgcn_readlane(cpl, yy) + 3;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* ================================================================================================== */
+/*
  * k_sws_mfma — the same scaler with the HORIZONTAL pass on the matrix cores.
  *
  * Why: the column walker is bound by integer VALU issue (~7 half-rate instructions per output sample, PMC:
@@ -823,6 +1085,28 @@ int ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t
         else            { if (opt) CW_LAUNCH(0, 3, false, true); else CW_LAUNCH(0, 3, false, false); }
     }
 #undef CW_LAUNCH
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    A.ncb = cdiv(A.dstW, 512);
+    const int n = cdiv(A.dstH, 64);
+    A.strip_rows = cdiv(A.dstH, n); /* <= 64 */
+    A.nstrips = cdiv(A.dstH, A.strip_rows);
+    const long long waves = (long long)A.ncb * A.nstrips * A.nframes;
+    if (waves >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
+        return FFHIP_EINVAL;
+    }
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define CWR_LAUNCH(S, B) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3>), grid, block, 0, stream, A)
+    if (A.sil) { if (A.bgr) CWR_LAUNCH(true, true); else CWR_LAUNCH(true, false); }
+    else       { if (A.bgr) CWR_LAUNCH(false, true); else CWR_LAUNCH(false, false); }
+#undef CWR_LAUNCH
     LAUNCH_CHECK();
     return 0;
 }

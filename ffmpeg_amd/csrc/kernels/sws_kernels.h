@@ -129,6 +129,24 @@ int ffhip_launch_scale_rgb(const FFHipScaleRgbArgs &a, hipStream_t stream);
 int ffhip_plan_scale_rgb(FFHipScaleRgbArgs *a, const int32_t *hl, const int32_t *hc, const int32_t *vl,
                          const int32_t *vc);
 
+/*
+ * Column walker with packed rgb24/bgr24 output (k_sws_colwalk_rgb): 4-tap banks on all four axes, dstW % 8 == 0,
+ * chroma vertical bank of dstH rows (chrDstH == dstH), chroma horizontal bank of dstW / 2 columns.
+ */
+struct FFHipCwRgbArgs {
+    const uint8_t *src[3];     /* Y, U, V; sil: src[1] = the byte-interleaved chroma plane */
+    uint8_t *dst;
+    ptrdiff_t sstride[3], dstride;
+    size_t sfp[3], dfp;
+    int sil, src_swap, bgr;
+    int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH;
+    const int16_t *hlf; const int32_t *hlp; const int16_t *hcf; const int32_t *hcp;
+    const int16_t *vlf; const int32_t *vlp; const int16_t *vcf; const int32_t *vcp;
+    int ncb, nstrips, strip_rows, nframes;
+    FFHipYuv2RgbK k;
+};
+int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream);
+
 /* per-line parity faces */
 int ffhip_launch_hscale8to15(int16_t *dst, int dstW, ptrdiff_t dstPitch, const uint8_t *src, ptrdiff_t srcPitch,
                              int nlines, const int16_t *filter, const int32_t *pos, int fs, hipStream_t stream);

@@ -33,6 +33,7 @@ struct FFHipSwsContext {
     FFHipDevFilter dn[4];
     int cw_ok = 0; /* both bank pairs fit the column-walking fast path (sws_colwalk.hip) */
     int cw_opt = 0; /* ... and no horizontal sum can wrap int16: the hand-scheduled variant applies */
+    int cw_rgb = 0; /* packed-RGB target on the column walker (k_sws_colwalk_rgb) */
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
     int mf_ok = 0, mf_chr_pair = 0, mf_ntiles[2] = { 0, 0 };
     void *mf_dev = nullptr;
@@ -67,6 +68,67 @@ static int make_k(const FFHipSwsTables &t, FFHipYuv2RgbK *k)
     k->off_b = t.yuv2rgb_yoffs - (int)(t.yuv2rgb_cbu >> 9);
     k->off_g = t.yuv2rgb_yoffs - (int)(t.yuv2rgb_cgu >> 9) - (int)(t.yuv2rgb_cgv >> 9);
     return 0;
+}
+
+/*
+ * Fast-path view of the banks: pad 1..3-tap banks to 4 taps.  Zero taps do not change a sum, so bilinear / point /
+ * area up-scaling and 1:1 format conversion run on the column walker too.  A 1-tap vertical bank is
+ * yuv2plane1_8_c, (h + 64) >> 7 == (64<<12 + h*4096) >> 19: its tap becomes 4096.  Packed-RGB targets pick
+ * yuv2rgb_{1,2,X} by the vertical sizes (different rounding), so there only 4-tap vertical banks qualify
+ * (pad_vertical = false).  Fills c->nf / c->np / c->dn; false when a bank does not fit.
+ */
+static bool build_fast_view(FFHipSwsContext *c, const int limits[4], bool pad_vertical)
+{
+    bool ok = true, padded = false;
+    for (int i = 0; i < 4 && ok; i++) {
+        const int fs = c->d[i].size, n = c->d[i].n;
+        if (fs > 4 || limits[i] < 4 || (i >= 2 && fs != 4 && !pad_vertical)) { ok = false; break; }
+        if (fs == 4) { c->nf[i] = c->f[i]; c->np[i] = c->p[i]; continue; }
+        padded = true;
+        c->nf[i].assign((size_t)n * 4, 0);
+        c->np[i].resize(n);
+        for (int x = 0; x < n; x++) {
+            const int pos = c->p[i][x];
+            int npos = pos + 4 > limits[i] ? limits[i] - 4 : pos;
+            if (i < 2) {
+                /* horizontal: keep the padded window inside the 8-byte span of its 4-column group (the
+                 * zero taps may sit in front of the real ones as well as behind them) */
+                const int g0 = x & ~3;
+                int lo = c->p[i][g0];
+                for (int k = 1; k < 4 && g0 + k < n; k++)
+                    lo = c->p[i][g0 + k] < lo ? c->p[i][g0 + k] : lo;
+                const int base = lo & ~3;
+                if (npos > base + 4)
+                    npos = base + 4;
+            }
+            if (npos < 0 || pos < npos || pos - npos + fs > 4) { ok = false; break; }
+            c->np[i][x] = npos;
+            for (int k = 0; k < fs; k++)
+                c->nf[i][(size_t)x * 4 + (pos - npos) + k] = (i >= 2 && fs == 1) ? 4096 : c->f[i][(size_t)x * fs + k];
+        }
+    }
+    if (!ok)
+        return false;
+    for (int i = 0; i < 4; i++) {
+        c->dn[i] = c->d[i];
+        c->dn[i].size = 4;
+    }
+    if (padded) {
+        size_t noff[4][2], ntot = 0;
+        for (int i = 0; i < 4; i++) {
+            noff[i][0] = ntot; ntot += (c->nf[i].size() * 2 + 15) & ~(size_t)15;
+            noff[i][1] = ntot; ntot += (c->np[i].size() * 4 + 15) & ~(size_t)15;
+        }
+        ok = hipMalloc(&c->dev_ntables, ntot) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++) {
+            uint8_t *nb = static_cast<uint8_t *>(c->dev_ntables);
+            ok = hipMemcpy(nb + noff[i][0], c->nf[i].data(), c->nf[i].size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(nb + noff[i][1], c->np[i].data(), c->np[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+            c->dn[i].filter = reinterpret_cast<const int16_t *>(nb + noff[i][0]);
+            c->dn[i].pos = reinterpret_cast<const int32_t *>(nb + noff[i][1]);
+        }
+    }
+    return ok;
 }
 
 extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
@@ -150,6 +212,13 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             return nullptr;
         }
         r = ffhip_plan_scale_rgb(&a, c->p[0].data(), c->p[1].data(), c->p[2].data(), c->p[3].data());
+        /* column walker with RGB output: 4-tap vertical banks (yuv2rgb_X), <= 4-tap horizontal banks, no int16 wrap */
+        const int limits[4] = { a.srcW, a.chrSrcW, a.srcH, a.chrSrcH };
+        if (!r && !(t->dstW & 7) && build_fast_view(c, limits, false))
+            c->cw_rgb = ffhip_cw_bank_ok(c->np[0].data(), 4, c->d[0].n, a.srcW, c->np[2].data(), 4, c->d[2].n, a.srcH) &&
+                        ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, a.chrSrcW, c->np[3].data(), 4, c->d[3].n, a.chrSrcH) &&
+                        c->d[1].n * 2 == t->dstW && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&
+                        ffhip_cw_bank_nowrap(c->nf[1].data(), 4, c->d[1].n);
     } else {
         FFHipScalePlaneArgs &l = c->lum, &ch = c->chr;
         memset(&l, 0, sizeof(l));
@@ -161,60 +230,9 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         r = ffhip_plan_scale_plane(&l, 1, c->p[0].data(), c->p[2].data());
         if (!r)
             r = ffhip_plan_scale_plane(&ch, 2, c->p[1].data(), c->p[3].data());
-        /* ---- fast-path view of the banks: pad 1..3-tap banks to 4 taps.  Zero taps do not change a sum, so
-         * bilinear / point / area up-scaling and 1:1 format conversion run on the column walker too.  A 1-tap
-         * vertical bank is yuv2plane1_8_c, (h + 64) >> 7 == (64<<12 + h*4096) >> 19: its tap becomes 4096. ---- */
+        const int limits[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
         {
-            const int limits[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
-            bool ok = true, padded = false;
-            for (int i = 0; i < 4 && ok; i++) {
-                const int fs = c->d[i].size, n = c->d[i].n;
-                if (fs > 4 || limits[i] < 4) { ok = false; break; }
-                if (fs == 4) { c->nf[i] = c->f[i]; c->np[i] = c->p[i]; continue; }
-                padded = true;
-                c->nf[i].assign((size_t)n * 4, 0);
-                c->np[i].resize(n);
-                for (int x = 0; x < n; x++) {
-                    const int pos = c->p[i][x];
-                    int npos = pos + 4 > limits[i] ? limits[i] - 4 : pos;
-                    if (i < 2) {
-                        /* horizontal: keep the padded window inside the 8-byte span of its 4-column group (the
-                         * zero taps may sit in front of the real ones as well as behind them) */
-                        const int g0 = x & ~3;
-                        int lo = c->p[i][g0];
-                        for (int k = 1; k < 4 && g0 + k < n; k++)
-                            lo = c->p[i][g0 + k] < lo ? c->p[i][g0 + k] : lo;
-                        const int base = lo & ~3;
-                        if (npos > base + 4)
-                            npos = base + 4;
-                    }
-                    if (npos < 0 || pos < npos || pos - npos + fs > 4) { ok = false; break; }
-                    c->np[i][x] = npos;
-                    for (int k = 0; k < fs; k++)
-                        c->nf[i][(size_t)x * 4 + (pos - npos) + k] = (i >= 2 && fs == 1) ? 4096 : c->f[i][(size_t)x * fs + k];
-                }
-            }
-            if (ok) {
-                for (int i = 0; i < 4; i++) {
-                    c->dn[i] = c->d[i];
-                    c->dn[i].size = 4;
-                }
-                if (padded) {
-                    size_t noff[4][2], ntot = 0;
-                    for (int i = 0; i < 4; i++) {
-                        noff[i][0] = ntot; ntot += (c->nf[i].size() * 2 + 15) & ~(size_t)15;
-                        noff[i][1] = ntot; ntot += (c->np[i].size() * 4 + 15) & ~(size_t)15;
-                    }
-                    ok = hipMalloc(&c->dev_ntables, ntot) == hipSuccess;
-                    for (int i = 0; i < 4 && ok; i++) {
-                        uint8_t *nb = static_cast<uint8_t *>(c->dev_ntables);
-                        ok = hipMemcpy(nb + noff[i][0], c->nf[i].data(), c->nf[i].size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
-                             hipMemcpy(nb + noff[i][1], c->np[i].data(), c->np[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-                        c->dn[i].filter = reinterpret_cast<const int16_t *>(nb + noff[i][0]);
-                        c->dn[i].pos = reinterpret_cast<const int32_t *>(nb + noff[i][1]);
-                    }
-                }
-            }
+            const bool ok = build_fast_view(c, limits, true);
             c->cw_ok = ok && ffhip_cw_bank_ok(c->np[0].data(), 4, c->d[0].n, l.srcW, c->np[2].data(), 4, c->d[2].n, l.srcH) &&
                        ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, ch.srcW, c->np[3].data(), 4, c->d[3].n, ch.srcH);
         }
@@ -279,7 +297,7 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
     return c;
 }
 
-extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c) { return c ? c->cw_ok + (c->mf_ok ? 2 : 0) : 0; }
+extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c) { return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) : 0; }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
                                          uint8_t *out, size_t out_size)
@@ -352,6 +370,23 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         a.chr_step = cstep;
         a.dst = (uint8_t *)dst[0]; a.dst_stride = dstStride[0]; a.dst_fp = dstFramePitch[0];
         a.nframes = nframes;
+        const char *ev = getenv("FFHIP_SWS_FAST");
+        uintptr_t al = (uintptr_t)s0 | (size_t)srcStride[0] | srcFramePitch[0] | (uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp |
+                       (size_t)cus | (size_t)cvs | cuf | cvf | (uintptr_t)(cstep == 2 ? s1 : cu) | (uintptr_t)(cstep == 2 ? s1 : cv);
+        if (c->cw_rgb && !(ev && ev[0] == '0') && !(al & 3)) {
+            FFHipCwRgbArgs R;
+            memset(&R, 0, sizeof(R));
+            R.src[0] = s0; R.src[1] = cstep == 2 ? s1 : cu; R.src[2] = cstep == 2 ? s1 : cv;
+            R.sstride[0] = srcStride[0]; R.sstride[1] = cus; R.sstride[2] = cvs;
+            R.sfp[0] = srcFramePitch[0]; R.sfp[1] = cuf; R.sfp[2] = cvf;
+            R.dst = a.dst; R.dstride = a.dst_stride; R.dfp = a.dst_fp;
+            R.sil = cstep == 2; R.src_swap = t.srcFormat == FFHIP_PIX_FMT_NV21; R.bgr = a.bgr;
+            R.srcW = a.srcW; R.srcH = a.srcH; R.chrSrcW = a.chrSrcW; R.chrSrcH = a.chrSrcH; R.dstW = a.dstW; R.dstH = a.dstH;
+            R.hlf = c->dn[0].filter; R.hlp = c->dn[0].pos; R.hcf = c->dn[1].filter; R.hcp = c->dn[1].pos;
+            R.vlf = c->dn[2].filter; R.vlp = c->dn[2].pos; R.vcf = c->dn[3].filter; R.vcp = c->dn[3].pos;
+            R.nframes = nframes; R.k = c->k;
+            return ffhip_launch_colwalk_rgb(R, stream);
+        }
         return ffhip_launch_scale_rgb(a, stream);
     }
 

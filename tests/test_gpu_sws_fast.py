@@ -252,3 +252,46 @@ PADDED_CASES = [
 @pytest.mark.parametrize("case", PADDED_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
 def test_fast_path_padded_banks(case, env, monkeypatch):
     _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, n=2)
+
+
+# ---------------------------------------------------------------------------------------------
+# packed rgb24 / bgr24 targets on the column walker (k_sws_colwalk_rgb): yuv2rgb_X_c_template
+RGB_CASES = [
+    ("yuv420p", 128, 72, "rgb24", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 128, 72, "bgr24", 256, 144, ffi.SWS_BICUBIC),
+    ("nv12", 192, 108, "rgb24", 384, 216, ffi.SWS_BICUBIC),
+    ("nv21", 192, 108, "bgr24", 384, 216, ffi.SWS_BICUBIC),
+    ("nv12", 64, 40, "rgb24", 192, 104, ffi.SWS_BICUBIC),             # 3x / 2.6x
+    ("yuv420p", 1048, 600, "rgb24", 2096, 1416, ffi.SWS_BICUBIC),     # several column blocks and strips, ragged last block
+    ("nv12", 32, 16, "bgr24", 64, 32, ffi.SWS_BICUBIC),               # a single partial wave
+    ("yuv420p", 96, 64, "rgb24", 192, 200, ffi.SWS_BICUBIC),          # anisotropic: 2x / 3.125x
+]
+
+
+@pytest.mark.parametrize("env", [{}, {"FFHIP_SWS_FAST": "0"}], ids=["default", "tiled"])
+@pytest.mark.parametrize("case", RGB_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_fast_path_rgb(case, env, monkeypatch):
+    _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF)
+
+
+def test_fast_path_rgb_full_size(monkeypatch):
+    _run("yuv420p", 1920, 1080, "rgb24", 3840, 2160, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=79)
+
+
+@pytest.mark.parametrize("fmts", [("nv12", "rgb24"), ("yuv420p", "bgr24"), ("nv21", "rgb24")])
+def test_fast_path_rgb_adversarial_tables(fmts, monkeypatch):
+    """arbitrary eligible positions, wide coefficients; chroma vertical bank of dstH rows as packed targets need"""
+    sw, sh, dw, dh = 200, 120, 520, 300
+    rng = np.random.default_rng(11)
+    banks = _adversarial_banks(rng, sw, sh, dw, dh, 0)
+    full = _adversarial_banks(rng, sw, sh, dw, 2 * dh, 0)
+    banks["vChr"] = full["vChr"]
+    # unit-gain coefficients with negative lobes: packed output indexes the reference's 2048-entry luma ramp with the
+    # unclamped sample, so gains far above 1 would leave the table (undefined in the reference itself)
+    for name, one in (("hLum", 1 << 14), ("hChr", 1 << 14), ("vLum", 1 << 12), ("vChr", 1 << 12)):
+        _, pos, fs, n = banks[name]
+        g = rng.dirichlet(np.ones(4), n) * 1.2 - 0.05
+        f = np.round(g * one).astype(np.int32)
+        f[:, 3] += one - f.sum(1)
+        banks[name] = (f.astype(np.int16).reshape(-1), pos, fs, n)
+    _run(fmts[0], sw, sh, fmts[1], dw, dh, ffi.SWS_BICUBIC, banks=banks, monkeypatch=monkeypatch, n=2, seed=6)
