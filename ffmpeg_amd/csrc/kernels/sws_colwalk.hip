@@ -7,8 +7,8 @@
  *
  *   one WAVE owns 64 lanes x 4 output columns (x NG groups) of a strip of output rows and walks DOWN
  *   the source rows.  Per source row a lane loads the 8 source bytes its 4 columns read (its 4-tap
- *   windows start within one dword-aligned 8-byte span: checked on the host, else the LDS-tiled kernel
- *   runs), computes the 4 horizontal 15-bit samples with v_perm_b32 (bytes -> int16 pairs) +
+ *   windows start within 4 bytes of each other — any ratio >= 0.75: checked on the host, else the LDS-tiled
+ *   kernel runs; the span is dword aligned whenever the windows allow it, e.g. always at 2x), computes the 4 horizontal 15-bit samples with v_perm_b32 (bytes -> int16 pairs) +
  *   v_dot2_i32_i16 against its register-resident coefficients, and keeps for every column the last
  *   three vertically adjacent int16 PAIRS (h[r-3],h[r-2]) (h[r-2],h[r-1]) (h[r-1],h[r]).  An output row
  *   whose 4-tap vertical window ends at r is then two more v_dot2 per sample from those pairs against
@@ -20,6 +20,7 @@
  * int16 for the horizontal pass; unsigned-wrapping int32 accumulation from 64<<12, >>19 (arithmetic),
  * clip to u8 for the vertical pass.  v_dot2_i32_i16 without clamp is exactly that mod 2^32.
  */
+#include <stdlib.h>
 #include <vector>
 
 #include "common.h"
@@ -126,6 +127,21 @@ __device__ __forceinline__ void cw_load(CwRaw &o, int slot, const uint8_t *row, 
 }
 
 /*
+ * First byte of the 8-byte source span a 4-column group reads per row: dword aligned when the four windows fit
+ * such a span (2x up-scaling: always), else the lowest window start itself — the host has checked that the
+ * starts lie within 4 bytes of each other, and global loads need no alignment.  Spans that would cross the end of
+ * the row slide left (the columns then select from the upper bytes).
+ */
+__device__ __forceinline__ int cw_span_base(const int (&p)[4], int srcW)
+{
+    const int lo = min(min(p[0], p[1]), min(p[2], p[3])), hi = max(max(p[0], p[1]), max(p[2], p[3]));
+    int base = lo & ~3;
+    if (hi + 3 - base > 7)
+        base = lo;
+    return min(base, srcW - 8);
+}
+
+/*
  * One unit.  KIND 0: one plane, one 4-column group per lane.  KIND 1: one plane, two adjacent groups
  * per lane.  KIND 2/3/4: a U/V pair, one group of each per lane — 2: interleaved -> interleaved,
  * 3: interleaved -> planar, 4: planar -> interleaved (planar -> planar is two KIND 0/1 jobs).
@@ -155,11 +171,7 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
             cf[g][2 * i] = c.x;
             cf[g][2 * i + 1] = c.y;
         }
-        base[g] = min(min(p[0], p[1]), min(p[2], p[3])) & ~3;
-        /* the 8-byte span of the last lanes would cross the end of the row (srcW % 4 == 0, host-checked):
-         * slide it one dword left — only its upper dword holds bytes these columns select */
-        if (base[g] + 8 > J.srcW)
-            base[g] -= 4;
+        base[g] = cw_span_base(p, J.srcW);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t o = (uint32_t)(p[i] - base[g]); /* 0..4, host-checked */
@@ -487,9 +499,7 @@ __device__ __forceinline__ int cw_hdesc(uint32_t (&sel)[8], uint32_t (&cf)[8], c
         cf[2 * i] = c.x;
         cf[2 * i + 1] = c.y;
     }
-    int base = min(min(p[0], p[1]), min(p[2], p[3])) & ~3;
-    if (base + 8 > srcW)
-        base -= 4;
+    const int base = cw_span_base(p, srcW);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t o = (uint32_t)(p[i] - base);
@@ -519,9 +529,17 @@ __device__ __forceinline__ void cw_hgroup(uint32_t (&Pnew)[4], int (&hprev)[4], 
     }
 }
 
-template <bool SIL, bool BGR, int D>
+__device__ __forceinline__ void cw_wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool SIL, bool BGR, int D, bool TR>
 __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
 {
+    __shared__ uint32_t tiles[4][384];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
@@ -592,6 +610,9 @@ __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
     uint8_t *dr = A.dst + (size_t)f * A.dfp + (ptrdiff_t)y0 * dstride;
     asm("" : "+s"(pfy), "+s"(pfu), "+s"(pfv), "+s"(dr));
     const uint32_t dcol = 3u * (uint32_t)X0;
+    uint32_t *tile = tiles[wave];
+    const uint32_t tcol = 1536u * (uint32_t)cb + 8u * (uint32_t)lane; /* transposed: this lane's bytes of each 512-byte run */
+    const int nbytes = 3 * min(A.dstW - cb * 512, 512);                /* valid bytes of this wave's row segment (% 24 == 0) */
 
     auto load_luma = [&](CwRaw &o) {
         cw_load<8>(o, 0, pfy, lb0);
@@ -681,7 +702,25 @@ __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
                 w[3 * h + d] = __builtin_amdgcn_perm(cw_pk_sh<16>(val[4 * d + 2], val[4 * d + 3]),
                                                      cw_pk_sh<16>(val[4 * d], val[4 * d + 1]), 0x05040100);
         }
-        if (act) {
+        if (TR) {
+            /* transpose through the wave's 1.5 KiB of LDS: each store instruction then covers 512 contiguous bytes
+             * of the row instead of 8 bytes in every 24 */
+            uint32_t *t = tile + lane * 6;
+            *reinterpret_cast<uint2 *>(t) = make_uint2(w[0], w[1]);
+            *reinterpret_cast<uint2 *>(t + 2) = make_uint2(w[2], w[3]);
+            *reinterpret_cast<uint2 *>(t + 4) = make_uint2(w[4], w[5]);
+            cw_wave_sync_lds();
+            cw_gptr d = (cw_gptr)dr + cw_opaque(tcol);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(tile + i * 128 + lane * 2);
+                cw_u2 s;
+                s.x = v.x; s.y = v.y;
+                if (i * 512 + lane * 8 < nbytes)
+                    *(cw_g2)(d + i * 512) = s;
+            }
+            cw_wave_sync_lds();
+        } else if (act) {
             cw_gptr d = (cw_gptr)dr + cw_opaque(dcol);
             cw_u2 s;
             s.x = w[0]; s.y = w[1]; *(cw_g2)d = s;
@@ -1014,7 +1053,7 @@ int ffhip_launch_mfma(FFHipMfArgs &A, hipStream_t stream)
 /* can a bank pair run on the column walker?  hpos/vpos are host copies. */
 int ffhip_cw_bank_ok(const int32_t *hpos, int hsize, int hn, int srcW, const int32_t *vpos, int vsize, int vn, int srcH)
 {
-    if (hsize != 4 || vsize != 4 || hn <= 0 || (hn & 3) || vn <= 0 || srcW < 8 || (srcW & 3) || srcH < 4)
+    if (hsize != 4 || vsize != 4 || hn <= 0 || (hn & 3) || vn <= 0 || srcW < 8 || srcH < 4)
         return 0;
     for (int x0 = 0; x0 < hn; x0 += 4) {
         int lo = hpos[x0], hi = hpos[x0];
@@ -1023,7 +1062,7 @@ int ffhip_cw_bank_ok(const int32_t *hpos, int hsize, int hn, int srcW, const int
             if (p < lo) lo = p;
             if (p > hi) hi = p;
         }
-        if (lo < 0 || hi + 4 > srcW || hi + 3 - (lo & ~3) > 7)
+        if (lo < 0 || hi + 4 > srcW || hi - lo > 4) /* the group's windows must fit one 8-byte span (cw_span_base) */
             return 0;
     }
     for (int y = 0; y < vn; y++) {
@@ -1103,7 +1142,10 @@ int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream)
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-#define CWR_LAUNCH(S, B) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3>), grid, block, 0, stream, A)
+    const char *et = getenv("FFHIP_CWRGB_DIRECT"); /* measured variant: per-lane 24-byte stores, no LDS transpose */
+    const bool tr = !(et && et[0] == '1');
+#define CWR_LAUNCH(S, B) do { if (tr) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, true>), grid, block, 0, stream, A); \
+                              else hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, false>), grid, block, 0, stream, A); } while (0)
     if (A.sil) { if (A.bgr) CWR_LAUNCH(true, true); else CWR_LAUNCH(true, false); }
     else       { if (A.bgr) CWR_LAUNCH(false, true); else CWR_LAUNCH(false, false); }
 #undef CWR_LAUNCH

@@ -50,7 +50,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     torch = _torch()
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
-              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP"):
+              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -104,6 +104,10 @@ CASES = [
     ("yuv420p", 128, 72, "yuv420p", 256, 144, ffi.SWS_BICUBIC),      # planar -> planar: three single-plane jobs
     ("nv12", 1048, 600, "nv12", 2096, 1416, ffi.SWS_BICUBIC),        # several column blocks and strips, ragged last block
     ("nv12", 32, 16, "nv12", 64, 32, ffi.SWS_BICUBIC),               # a single partial wave
+    ("nv12", 128, 72, "nv12", 192, 108, ffi.SWS_BICUBIC),            # 1.5x: byte-aligned source spans
+    ("yuv420p", 240, 136, "yuv420p", 320, 180, ffi.SWS_BICUBIC),     # 1.33x
+    ("yuv420p", 202, 120, "nv12", 456, 270, ffi.SWS_BICUBIC),        # 2.26x, srcW % 4 != 0, odd chroma width
+    ("nv21", 90, 50, "yuv420p", 200, 110, ffi.SWS_BILINEAR),         # padded banks at a fractional ratio
 ]
 
 
@@ -265,10 +269,13 @@ RGB_CASES = [
     ("yuv420p", 1048, 600, "rgb24", 2096, 1416, ffi.SWS_BICUBIC),     # several column blocks and strips, ragged last block
     ("nv12", 32, 16, "bgr24", 64, 32, ffi.SWS_BICUBIC),               # a single partial wave
     ("yuv420p", 96, 64, "rgb24", 192, 200, ffi.SWS_BICUBIC),          # anisotropic: 2x / 3.125x
+    ("yuv420p", 96, 64, "rgb24", 136, 200, ffi.SWS_BICUBIC),          # 1.42x: byte-aligned source spans
+    ("nv12", 128, 72, "bgr24", 192, 108, ffi.SWS_BICUBIC),            # 1.5x
+    ("yuv420p", 202, 120, "rgb24", 456, 270, ffi.SWS_BICUBIC),        # srcW % 4 != 0, odd chroma width
 ]
 
 
-@pytest.mark.parametrize("env", [{}, {"FFHIP_SWS_FAST": "0"}], ids=["default", "tiled"])
+@pytest.mark.parametrize("env", [{}, {"FFHIP_CWRGB_DIRECT": "1"}, {"FFHIP_SWS_FAST": "0"}], ids=["default", "direct", "tiled"])
 @pytest.mark.parametrize("case", RGB_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
 def test_fast_path_rgb(case, env, monkeypatch):
     _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF)

@@ -43,8 +43,17 @@ def sws(name, sf, sw, sh, df, dw, dh, flags, n):
 sws("nv12 1080p->4K bilinear (padded 2-tap banks)", "nv12", 1920, 1080, "nv12", 3840, 2160, S.SWS_BILINEAR, 128)
 sws("nv12 1080p -> yuv420p 1080p (1:1 re-pack)", "nv12", 1920, 1080, "yuv420p", 1920, 1080, S.SWS_BICUBIC, 128)
 sws("yuv420p 1080p->4K bicubic", "yuv420p", 1920, 1080, "yuv420p", 3840, 2160, S.SWS_BICUBIC, 128)
+sws("nv12 720p->1080p bicubic (1.5x, byte-aligned spans)", "nv12", 1280, 720, "nv12", 1920, 1080, S.SWS_BICUBIC, 256)
+sws("yuv420p 720p->1080p rgb24 bicubic (1.5x)", "yuv420p", 1280, 720, "rgb24", 1920, 1080, S.SWS_BICUBIC, 128)
 sws("nv12 4K->1080p bicubic (8-tap, LDS-tiled kernel)", "nv12", 3840, 2160, "nv12", 1920, 1080, S.SWS_BICUBIC, 32)
-sws("yuv420p 1080p->4K rgb24 bicubic (k_scale_rgb)", "yuv420p", 1920, 1080, "rgb24", 3840, 2160, S.SWS_BICUBIC, 32)
+sws("yuv420p 1080p->4K rgb24 bicubic (k_sws_colwalk_rgb)", "yuv420p", 1920, 1080, "rgb24", 3840, 2160, S.SWS_BICUBIC, 32)
+sws("nv12 1080p->4K bgr24 bicubic (k_sws_colwalk_rgb)", "nv12", 1920, 1080, "bgr24", 3840, 2160, S.SWS_BICUBIC, 32)
+os.environ["FFHIP_CWRGB_DIRECT"] = "1"
+sws("yuv420p 1080p->4K rgb24 bicubic (k_sws_colwalk_rgb, direct stores)", "yuv420p", 1920, 1080, "rgb24", 3840, 2160, S.SWS_BICUBIC, 32)
+del os.environ["FFHIP_CWRGB_DIRECT"]
+os.environ["FFHIP_SWS_FAST"] = "0"
+sws("yuv420p 1080p->4K rgb24 bicubic (k_scale_rgb, LDS-tiled)", "yuv420p", 1920, 1080, "rgb24", 3840, 2160, S.SWS_BICUBIC, 32)
+del os.environ["FFHIP_SWS_FAST"]
 sws("yuv420p 1080p->rgb24 accurate_rnd (k_scale_rgb)", "yuv420p", 1920, 1080, "rgb24", 1920, 1080,
     S.SWS_BICUBIC | S.SWS_ACCURATE_RND | S.SWS_BITEXACT, 64)
 
