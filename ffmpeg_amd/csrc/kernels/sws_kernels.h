@@ -147,6 +147,29 @@ struct FFHipCwRgbArgs {
 };
 int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream);
 
+/*
+ * Wide-bank walker (sws_lwalk.hip): banks padded to 4*ht horizontal and 2*vt vertical taps (ht 2|4, vt 4|8).
+ * A job is one plane or (pair) a U/V pair, byte-interleaved or planar on either side.
+ */
+struct FFHipLwJob {
+    const uint8_t *src[2];   /* sil: src[0] = the interleaved plane */
+    uint8_t *dst[2];         /* dil: dst[0] = the interleaved plane */
+    ptrdiff_t sstride[2], dstride[2];
+    size_t sfp[2], dfp[2];
+    int pair, sil, dil, src_swap, dst_swap;
+    int srcW, srcH, dstW, dstH;                 /* in samples of this channel */
+    const int16_t *hf; const int32_t *hp;       /* device: padded banks */
+    const int16_t *vf; const int32_t *vp;
+    int ncb, nstrips, strip_rows, unit_begin;
+};
+struct FFHipLwArgs {
+    FFHipLwJob job[3];
+    int njobs, units_per_frame, nframes, ht, vt;
+};
+int  ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH);
+void ffhip_lw_plan_job(FFHipLwJob *j);
+int  ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream);
+
 /* per-line parity faces */
 int ffhip_launch_hscale8to15(int16_t *dst, int dstW, ptrdiff_t dstPitch, const uint8_t *src, ptrdiff_t srcPitch,
                              int nlines, const int16_t *filter, const int32_t *pos, int fs, hipStream_t stream);

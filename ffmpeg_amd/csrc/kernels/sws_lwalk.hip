@@ -1,0 +1,357 @@
+/*
+ * sws_lwalk.hip — fused H+V scaler for WIDE banks (5..16 taps on either axis: every down-scaling ratio to 1/4,
+ * and up-scaling with long kernels), planar and NV12/NV21 in and out.
+ *
+ * Same arithmetic as sws_scale.hip / sws_colwalk.hip (hScale8To15_c, libswscale/swscale.c:128-142; yuv2planeX_8_c /
+ * yuv2nv12cX_c, libswscale/output.c:468-529; nv12ToUV_c, input.c:936).  The column walker (sws_colwalk.hip) keeps
+ * everything in registers, which needs every register index static: a column's window must sit in one 8-byte span
+ * and the vertical history is a 3-deep ring.  Wide windows break both, so here the two dynamically indexed
+ * things live in LDS, everything else stays as it was:
+ *
+ *   one WAVE (= one 64-thread workgroup) owns 64 lanes x 4 output columns of a strip of <= 64 output rows and
+ *   walks DOWN the source rows.  Per source row
+ *     1. the wave copies the row segment its 256 columns read (coalesced dword loads, prefetched two rows ahead;
+ *        NV12 is de-interleaved on the way) into its LDS row buffer;
+ *     2. a lane reads each of its columns' windows from there at a dword-aligned DYNAMIC address (HT+1 dwords) and
+ *        turns them into int16 pairs with two v_perm_b32 per 4 taps whose selectors carry the byte phase, then
+ *        v_dot2_i32_i16 against register-resident coefficient pairs: the 15-bit sample h[r];
+ *     3. it appends the vertical pairs (h[r-1], h[r]) of its 4 columns as one 16-byte record to a ring of 2*VT
+ *        source rows in LDS;
+ *     4. every output row whose window ends at r reads VT such records (rows p+1, p+3, ...) and is VT more
+ *        v_dot2 per sample against the row's wave-uniform coefficient pairs, then v_ashr_pk_u8_i32 and one store.
+ *   A wave executes its LDS operations in order, so no barrier is needed anywhere.  HBM traffic = source in +
+ *   destination out (+ 2*VT-1 halo rows per strip).
+ *
+ * Banks are padded on the host to 4*HT horizontal and 2*VT vertical taps (zero taps change no sum).
+ * Integer semantics are the reference's, as in sws_colwalk.hip; the int16 saturation of v_cvt_pk_i16_i32 equals
+ * min(.,32767) + truncation because the host admits only banks whose horizontal sums cannot wrap.
+ */
+#include <stdlib.h>
+
+#include "common.h"
+#include "sws_kernels.h"
+
+typedef short lw_short2 __attribute__((ext_vector_type(2)));
+typedef uint32_t lw_u2 __attribute__((ext_vector_type(2)));
+typedef const uint8_t __attribute__((address_space(1))) *lw_gcptr;
+typedef uint8_t __attribute__((address_space(1))) *lw_gptr;
+typedef const uint32_t __attribute__((address_space(1))) *lw_gc1;
+typedef const lw_u2 __attribute__((address_space(1))) *lw_gc2;
+typedef uint32_t __attribute__((address_space(1))) *lw_g1;
+typedef lw_u2 __attribute__((address_space(1))) *lw_g2;
+
+__device__ __forceinline__ int lw_dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lw_short2, a), __builtin_bit_cast(lw_short2, b), c, false);
+}
+
+__device__ __forceinline__ uint32_t lw_pk_u8(int a, int b)
+{
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 19" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+/* NG = 1: one plane.  NG = 2: a U/V pair (byte-interleaved or planar on either side), same banks for both. */
+template <int HT, int VT, int NL, int NG>
+__device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, int cb, int lane, uint32_t *lds)
+{
+    constexpr int RAWD = NL * 64 + 8;  /* dwords of one row buffer (+ slack: a window read may touch one dword past the segment) */
+    constexpr int RING = 2 * VT;       /* source rows of vertical history */
+    uint32_t *raw = lds;                                        /* [NG][RAWD]            */
+    uint4 *ring = reinterpret_cast<uint4 *>(lds + 2 * RAWD);    /* [NG][RING][64]        */
+    const bool sil = NG == 2 && J.sil, dil = NG == 2 && J.dil;
+    const int y0 = strip * J.strip_rows;
+    const int y1 = min(y0 + J.strip_rows, J.dstH);
+    const int ny = y1 - y0;
+
+    /* ---- horizontal descriptors ---- */
+    const int X0 = (cb * 64 + lane) * 4;
+    const int segb = __builtin_amdgcn_readfirstlane(J.hp[min(cb * 256, J.dstW - 1)]) & ~3;
+    uint32_t cf[4][2 * HT], sel_a[4], sel_b[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int xi = min(X0 + i, J.dstW - 1);
+        const int o = J.hp[xi] - segb;
+        woff[i] = (uint32_t)(o >> 2);
+        const uint32_t s = (uint32_t)(o & 3);
+        sel_a[i] = 0x0c000c00u | s | ((s + 1) << 16);
+        sel_b[i] = 0x0c000c00u | (s + 2) | ((s + 3) << 16);
+        const uint2 *c = reinterpret_cast<const uint2 *>(J.hf + (size_t)xi * (4 * HT));
+#pragma unroll
+        for (int k = 0; k < HT; k++) {
+            const uint2 v = c[k];
+            cf[i][2 * k] = v.x;
+            cf[i][2 * k + 1] = v.y;
+        }
+    }
+    const bool act = X0 < J.dstW;
+
+    /* ---- vertical descriptors of the strip's <= 64 rows ---- */
+    int vpl;
+    uint32_t vcf[VT];
+    {
+        const int y = min(y0 + lane, J.dstH - 1);
+        vpl = J.vp[y];
+        const uint32_t *c = reinterpret_cast<const uint32_t *>(J.vf + (size_t)y * (2 * VT));
+#pragma unroll
+        for (int k = 0; k < VT; k++)
+            vcf[k] = c[k];
+    }
+
+    /* ---- source rows: this lane's dwords of the wave's segment ---- */
+    const uint8_t *s0 = J.src[0] + (size_t)f * J.sfp[0];
+    const uint8_t *s1 = NG == 2 ? J.src[1] + (size_t)f * J.sfp[1] : s0;
+    const ptrdiff_t sstride0 = J.sstride[0], sstride1 = J.sstride[1];
+    uint32_t goff[NL]; /* byte offset in the row of load j (clamped to the last whole unit of the row) */
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        if (sil)
+            goff[j] = (uint32_t)min(2 * segb + 8 * (lane + 64 * j), 2 * J.srcW - 8);
+        else
+            goff[j] = (uint32_t)min(segb + 4 * (lane + 64 * j), (J.srcW - 1) & ~3);
+    }
+    const uint32_t sel_u = J.src_swap ? 0x07050301u : 0x06040200u, sel_v = J.src_swap ? 0x06040200u : 0x07050301u;
+    const uint32_t sel_uv = J.dst_swap ? 0x04050001u : 0x05040100u;
+
+    struct Row { uint32_t q[NG][NL]; };
+    const int rfirst = __builtin_amdgcn_readlane(vpl, 0);
+    const int rlast = __builtin_amdgcn_readfirstlane(J.vp[y1 - 1]) + RING - 1;
+    int pfrow = rfirst;
+    const uint8_t *pf0 = s0 + (ptrdiff_t)rfirst * sstride0, *pf1 = s1 + (ptrdiff_t)rfirst * sstride1;
+    asm("" : "+s"(pf0), "+s"(pf1));
+    auto load_next = [&](Row &o) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            uint32_t off = goff[j];
+            asm volatile("" : "+v"(off));
+            if (sil) {
+                const lw_u2 w = *(lw_gc2)((lw_gcptr)pf0 + off);
+                o.q[0][j] = w.x;
+                o.q[NG - 1][j] = w.y;
+            } else {
+                o.q[0][j] = *(lw_gc1)((lw_gcptr)pf0 + off);
+                if (NG == 2)
+                    o.q[NG - 1][j] = *(lw_gc1)((lw_gcptr)pf1 + off);
+            }
+        }
+        const bool adv = pfrow < rlast;
+        pfrow = min(pfrow + 1, rlast);
+        pf0 += adv ? sstride0 : 0;
+        pf1 += adv ? sstride1 : 0;
+        asm("" : "+s"(pf0), "+s"(pf1));
+    };
+
+    int hprev[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            hprev[g][i] = 0;
+
+    uint8_t *d0 = J.dst[0] + (size_t)f * J.dfp[0] + (ptrdiff_t)y0 * J.dstride[0];
+    uint8_t *d1 = NG == 2 ? J.dst[1] + (size_t)f * J.dfp[1] + (ptrdiff_t)y0 * J.dstride[1] : d0;
+    const ptrdiff_t dstride0 = J.dstride[0], dstride1 = J.dstride[1];
+    asm("" : "+s"(d0), "+s"(d1));
+
+    int yy = 0;
+    int need = rfirst + RING - 1;
+
+    auto process = [&](const Row &cur, int rr) {
+        /* 1. row segment -> LDS (NV12: bytes u0 v0 u1 v1 ... become one dword of U and one of V) */
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            if (sil) {
+                raw[lane + 64 * j] = __builtin_amdgcn_perm(cur.q[1][j], cur.q[0][j], sel_u);
+                raw[RAWD + lane + 64 * j] = __builtin_amdgcn_perm(cur.q[1][j], cur.q[0][j], sel_v);
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+                    raw[g * RAWD + lane + 64 * j] = cur.q[g][j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        /* 2. + 3. horizontal pass of my columns, vertical pairs into the ring */
+        const int slot = rr & (RING - 1);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            uint32_t pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t *w = raw + g * RAWD + woff[i];
+                uint32_t d[HT + 1];
+#pragma unroll
+                for (int k = 0; k <= HT; k++)
+                    d[k] = w[k];
+                int acc = 0;
+#pragma unroll
+                for (int k = 0; k < HT; k++) {
+                    acc = lw_dot2(__builtin_amdgcn_perm(d[k + 1], d[k], sel_a[i]), cf[i][2 * k], acc);
+                    acc = lw_dot2(__builtin_amdgcn_perm(d[k + 1], d[k], sel_b[i]), cf[i][2 * k + 1], acc);
+                }
+                const int h = acc >> 7;
+                pr[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[g][i], h));
+                hprev[g][i] = h;
+            }
+            ring[(g * RING + slot) * 64 + lane] = make_uint4(pr[0], pr[1], pr[2], pr[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        /* 4. output rows whose window ends here */
+        while (yy < ny && need <= rr) {
+            const int p = need - (RING - 1);
+            uint32_t fk[VT];
+#pragma unroll
+            for (int k = 0; k < VT; k++)
+                fk[k] = __builtin_amdgcn_readlane(vcf[k], yy);
+            int v[NG][4];
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    v[g][i] = 64 << 12;
+#pragma unroll
+                for (int k = 0; k < VT; k++) {
+                    const uint4 P = ring[(g * RING + ((p + 1 + 2 * k) & (RING - 1))) * 64 + lane];
+                    v[g][0] = lw_dot2(P.x, fk[k], v[g][0]);
+                    v[g][1] = lw_dot2(P.y, fk[k], v[g][1]);
+                    v[g][2] = lw_dot2(P.z, fk[k], v[g][2]);
+                    v[g][3] = lw_dot2(P.w, fk[k], v[g][3]);
+                }
+            }
+            if (dil) {
+                constexpr int b = NG - 1;
+                lw_u2 w;
+                w.x = __builtin_amdgcn_perm(lw_pk_u8(v[0][1], v[b][1]), lw_pk_u8(v[0][0], v[b][0]), sel_uv);
+                w.y = __builtin_amdgcn_perm(lw_pk_u8(v[0][3], v[b][3]), lw_pk_u8(v[0][2], v[b][2]), sel_uv);
+                if (act)
+                    *(lw_g2)((lw_gptr)d0 + (uint32_t)(2 * X0)) = w;
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const uint32_t w = __builtin_amdgcn_perm(lw_pk_u8(v[g][2], v[g][3]), lw_pk_u8(v[g][0], v[g][1]), 0x05040100);
+                    if (act)
+                        *(lw_g1)((lw_gptr)(g ? d1 : d0) + (uint32_t)X0) = w;
+                }
+            }
+            d0 += dstride0;
+            d1 += dstride1;
+            asm("" : "+s"(d0), "+s"(d1));
+            yy++;
+            if (yy < ny)
+                need = __builtin_amdgcn_readlane(vpl, yy) + RING - 1;
+        }
+    };
+
+    Row b0, b1;
+    load_next(b0);
+    load_next(b1);
+    for (int r = rfirst; r <= rlast; r += 2) {
+        {
+            const Row cur = b0;
+            load_next(b0);
+            process(cur, r);
+        }
+        {
+            const Row cur = b1;
+            load_next(b1);
+            if (r + 1 <= rlast)
+                process(cur, r + 1);
+        }
+    }
+}
+
+template <int HT, int VT, int NL>
+__global__ __launch_bounds__(64) void k_sws_lwalk(FFHipLwArgs A)
+{
+    extern __shared__ __align__(16) uint32_t lw_lds[];
+    const int lane = threadIdx.x;
+    const uint32_t gw = blockIdx.x;
+    const int f = (int)(gw / (uint32_t)A.units_per_frame);
+    const int u = (int)(gw - (uint32_t)f * (uint32_t)A.units_per_frame);
+    int j = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
+    const FFHipLwJob &J = A.job[j];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.pair)
+        lw_unit<HT, VT, NL, 2>(J, f, strip, cb, lane, lw_lds);
+    else
+        lw_unit<HT, VT, NL, 1>(J, f, strip, cb, lane, lw_lds);
+}
+
+/* ---- host side ---------------------------------------------------------------------------------- */
+/*
+ * Can a (padded) bank pair run here?  hpos/vpos are host copies of the padded positions; ht/vt the padded sizes in
+ * units of 4 / 2 taps.  Returns the number of segment loads per lane (NL class: 3 or 5) or 0.
+ */
+int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH)
+{
+    if ((ht != 2 && ht != 4) || (vt != 4 && vt != 8) || hn <= 0 || (hn & 3) || vn <= 0 || srcW < 4 * ht || srcW < 8 ||
+        srcH < 2 * vt)
+        return 0;
+    int span = 0;
+    for (int x = 0; x < hn; x++)
+        if (hpos[x] < 0 || hpos[x] + 4 * ht > srcW || (x && hpos[x] < hpos[x - 1]))
+            return 0;
+    for (int x0 = 0; x0 < hn; x0 += 256) {
+        const int xe = x0 + 255 < hn ? x0 + 255 : hn - 1;
+        const int s = hpos[xe] + 4 * ht - (hpos[x0] & ~3);
+        if (s > span)
+            span = s;
+    }
+    for (int y = 0; y < vn; y++)
+        if (vpos[y] < 0 || vpos[y] + 2 * vt > srcH || (y && vpos[y] < vpos[y - 1]))
+            return 0;
+    const int nl = ht == 2 ? 3 : 5;
+    return span <= nl * 256 ? nl : 0;
+}
+
+void ffhip_lw_plan_job(FFHipLwJob *j)
+{
+    j->ncb = cdiv(j->dstW, 256);
+    const int n = cdiv(j->dstH, 64);
+    j->strip_rows = cdiv(j->dstH, n);
+    j->nstrips = cdiv(j->dstH, j->strip_rows);
+}
+
+int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    int u = 0, pair = 0;
+    for (int i = 0; i < A.njobs; i++) {
+        A.job[i].unit_begin = u;
+        u += A.job[i].ncb * A.job[i].nstrips;
+        pair |= A.job[i].pair;
+    }
+    A.units_per_frame = u;
+    const long long waves = (long long)u * A.nframes;
+    if (waves >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
+        return FFHIP_EINVAL;
+    }
+    const int nl = A.ht == 2 ? 3 : 5;
+    const size_t lds = (size_t)4 * 2 * (nl * 64 + 8) + (size_t)(pair ? 2 : 1) * 2 * A.vt * 64 * 16;
+    const dim3 grid((unsigned)waves), block(64);
+#define LW_LAUNCH(H, V, N)                                                                                   \
+    do {                                                                                                     \
+        static bool attr_done = false;                                                                       \
+        if (!attr_done) {                                                                                    \
+            (void)hipFuncSetAttribute((const void *)k_sws_lwalk<H, V, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            attr_done = true;                                                                                \
+        }                                                                                                    \
+        hipLaunchKernelGGL((k_sws_lwalk<H, V, N>), grid, block, lds, stream, A);                             \
+    } while (0)
+    if (A.ht == 2 && A.vt == 4) LW_LAUNCH(2, 4, 3);
+    else if (A.ht == 2 && A.vt == 8) LW_LAUNCH(2, 8, 3);
+    else if (A.ht == 4 && A.vt == 4) LW_LAUNCH(4, 4, 5);
+    else if (A.ht == 4 && A.vt == 8) LW_LAUNCH(4, 8, 5);
+    else {
+        ffhip_set_error("ffhip_sws: no wide-bank kernel for %d x %d taps", 4 * A.ht, 2 * A.vt);
+        return FFHIP_EINVAL;
+    }
+#undef LW_LAUNCH
+    LAUNCH_CHECK();
+    return 0;
+}

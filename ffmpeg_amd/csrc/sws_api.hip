@@ -34,6 +34,12 @@ struct FFHipSwsContext {
     int cw_ok = 0; /* both bank pairs fit the column-walking fast path (sws_colwalk.hip) */
     int cw_opt = 0; /* ... and no horizontal sum can wrap int16: the hand-scheduled variant applies */
     int cw_rgb = 0; /* packed-RGB target on the column walker (k_sws_colwalk_rgb) */
+    /* wide-bank walker (sws_lwalk.hip): banks padded to 4*lw_ht x 2*lw_vt taps */
+    int lw_ok = 0, lw_ht = 0, lw_vt = 0;
+    std::vector<int16_t> wf[4];
+    std::vector<int32_t> wp[4];
+    void *dev_wtables = nullptr;
+    FFHipDevFilter dw[4];
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
     int mf_ok = 0, mf_chr_pair = 0, mf_ntiles[2] = { 0, 0 };
     void *mf_dev = nullptr;
@@ -129,6 +135,58 @@ static bool build_fast_view(FFHipSwsContext *c, const int limits[4], bool pad_ve
         }
     }
     return ok;
+}
+
+/*
+ * Wide view of the banks for sws_lwalk.hip: all four padded to a common 4*ht horizontal / 2*vt vertical taps, windows
+ * shifted back inside the plane where the padding would leave it (the real taps then sit at the end of the window).
+ */
+static bool build_wide_view(FFHipSwsContext *c, const int limits[4])
+{
+    int ht = 0, vt = 0;
+    for (int i = 0; i < 4; i++) {
+        const int fs = c->d[i].size;
+        if (fs > 16)
+            return false;
+        if (i < 2) ht = fs > 8 ? 4 : (ht > 2 ? ht : 2);
+        else       vt = fs > 8 ? 8 : (vt > 4 ? vt : 4);
+    }
+    for (int i = 0; i < 4; i++) {
+        const int P = i < 2 ? 4 * ht : 2 * vt, fs = c->d[i].size, n = c->d[i].n;
+        if (limits[i] < P)
+            return false;
+        c->wf[i].assign((size_t)n * P, 0);
+        c->wp[i].resize(n);
+        for (int x = 0; x < n; x++) {
+            const int pos = c->p[i][x];
+            const int npos = pos + P > limits[i] ? limits[i] - P : pos;
+            if (pos < 0 || pos + fs > limits[i])
+                return false;
+            c->wp[i][x] = npos;
+            for (int k = 0; k < fs; k++)
+                c->wf[i][(size_t)x * P + (pos - npos) + k] = (i >= 2 && fs == 1) ? 4096 : c->f[i][(size_t)x * fs + k];
+        }
+    }
+    size_t off[4][2], tot = 0;
+    for (int i = 0; i < 4; i++) {
+        off[i][0] = tot; tot += (c->wf[i].size() * 2 + 15) & ~(size_t)15;
+        off[i][1] = tot; tot += (c->wp[i].size() * 4 + 15) & ~(size_t)15;
+    }
+    if (hipMalloc(&c->dev_wtables, tot) != hipSuccess)
+        return false;
+    uint8_t *b = static_cast<uint8_t *>(c->dev_wtables);
+    for (int i = 0; i < 4; i++) {
+        if (hipMemcpy(b + off[i][0], c->wf[i].data(), c->wf[i].size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(b + off[i][1], c->wp[i].data(), c->wp[i].size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return false;
+        c->dw[i].filter = reinterpret_cast<const int16_t *>(b + off[i][0]);
+        c->dw[i].pos = reinterpret_cast<const int32_t *>(b + off[i][1]);
+        c->dw[i].size = i < 2 ? 4 * ht : 2 * vt;
+        c->dw[i].n = c->d[i].n;
+    }
+    c->lw_ht = ht;
+    c->lw_vt = vt;
+    return true;
 }
 
 extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
@@ -238,6 +296,22 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         }
         c->cw_opt = c->cw_ok && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&
                     ffhip_cw_bank_nowrap(c->nf[1].data(), 4, c->d[1].n);
+        /* wide banks (down-scaling, long kernels): the LDS-backed walker; FFHIP_SWS_WIDE=1 builds it for narrow banks
+         * too (parity tests of that kernel on up-scaling cases) */
+        {
+            const char *ew = getenv("FFHIP_SWS_WIDE");
+            if ((!c->cw_ok || (ew && ew[0] == '1')) && build_wide_view(c, limits)) {
+                const int hts[2] = { c->lw_ht, c->lw_ht };
+                bool ok = true;
+                for (int k = 0; k < 2 && ok; k++)
+                    ok = ffhip_lw_bank_ok(c->wp[k].data(), hts[k], c->d[k].n, limits[k], c->wp[2 + k].data(), c->lw_vt, c->d[2 + k].n,
+                                          limits[2 + k]) != 0 &&
+                         ffhip_cw_bank_nowrap(c->wf[k].data(), 4 * c->lw_ht, c->d[k].n);
+                if (fmt_nv(t->srcFormat) && (ch.srcW & 3))
+                    ok = false;
+                c->lw_ok = ok;
+            }
+        }
         /* MFMA variant: same banks; chroma either byte-interleaved on both sides or planar on both sides */
         const bool nv_in = fmt_nv(t->srcFormat), nv_out = fmt_nv(t->dstFormat);
         if (c->cw_opt && nv_in == nv_out) {
@@ -297,7 +371,10 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
     return c;
 }
 
-extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c) { return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) : 0; }
+extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
+{
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) : 0;
+}
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
                                          uint8_t *out, size_t out_size)
@@ -324,6 +401,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->mf_dev);
     if (c->dev_ntables)
         (void)hipFree(c->dev_ntables);
+    if (c->dev_wtables)
+        (void)hipFree(c->dev_wtables);
     if (c->stage)
         (void)hipFree(c->stage);
     delete c;
@@ -511,6 +590,57 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                 ffhip_cw_plan_job(&j, 1, strip);
             }
             return ffhip_launch_colwalk(A, lg, depth, stream);
+        }
+    }
+    /* wide banks: the LDS-backed walker (FFHIP_SWS_WIDE=0 forces the LDS-tiled kernel) */
+    const char *ew = getenv("FFHIP_SWS_WIDE");
+    const bool cw_taken_off = ev && ev[0] == '0';
+    if (c->lw_ok && !(ew && ew[0] == '0') && !(cw_taken_off && !(ew && ew[0] == '1'))) {
+        uintptr_t al = (uintptr_t)l.src[0] | (size_t)l.src_stride[0] | l.src_fp[0] | (uintptr_t)l.dst[0] | (size_t)l.dst_stride[0] |
+                       l.dst_fp[0];
+        for (int i = 0; i < 2; i++) {
+            al |= (size_t)ch.src_stride[i] | ch.src_fp[i] | (size_t)ch.dst_stride[i] | ch.dst_fp[i];
+            al |= ch.src_step == 2 ? (uintptr_t)(ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1]) : (uintptr_t)ch.src[i];
+            al |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
+        }
+        if (!(al & 3)) {
+            FFHipLwArgs W;
+            memset(&W, 0, sizeof(W));
+            W.nframes = nframes; W.ht = c->lw_ht; W.vt = c->lw_vt;
+            auto wbank = [&](FFHipLwJob &j, const FFHipScalePlaneArgs &p, int which) {
+                j.srcW = p.srcW; j.srcH = p.srcH; j.dstW = p.dstW; j.dstH = p.dstH;
+                j.hf = c->dw[which].filter; j.hp = c->dw[which].pos; j.vf = c->dw[2 + which].filter; j.vp = c->dw[2 + which].pos;
+                ffhip_lw_plan_job(&j);
+            };
+            FFHipLwJob &jl = W.job[W.njobs++];
+            jl.src[0] = l.src[0]; jl.sstride[0] = l.src_stride[0]; jl.sfp[0] = l.src_fp[0];
+            jl.dst[0] = l.dst[0]; jl.dstride[0] = l.dst_stride[0]; jl.dfp[0] = l.dst_fp[0];
+            wbank(jl, l, 0);
+            if (ch.src_step == 1 && ch.dst_step == 1) {
+                for (int k = 0; k < 2; k++) {
+                    FFHipLwJob &j = W.job[W.njobs++];
+                    j.src[0] = ch.src[k]; j.sstride[0] = ch.src_stride[k]; j.sfp[0] = ch.src_fp[k];
+                    j.dst[0] = ch.dst[k]; j.dstride[0] = ch.dst_stride[k]; j.dfp[0] = ch.dst_fp[k];
+                    wbank(j, ch, 1);
+                }
+            } else {
+                FFHipLwJob &j = W.job[W.njobs++];
+                j.pair = 1; j.sil = ch.src_step == 2; j.dil = ch.dst_step == 2;
+                for (int k = 0; k < 2; k++) {
+                    j.src[k] = ch.src[k]; j.sstride[k] = ch.src_stride[k]; j.sfp[k] = ch.src_fp[k];
+                    j.dst[k] = ch.dst[k]; j.dstride[k] = ch.dst_stride[k]; j.dfp[k] = ch.dst_fp[k];
+                }
+                if (j.sil) {
+                    j.src_swap = ch.src[1] < ch.src[0];
+                    j.src[0] = j.src_swap ? ch.src[1] : ch.src[0];
+                }
+                if (j.dil) {
+                    j.dst_swap = ch.dst[1] < ch.dst[0];
+                    j.dst[0] = j.dst_swap ? ch.dst[1] : ch.dst[0];
+                }
+                wbank(j, ch, 1);
+            }
+            return ffhip_launch_lwalk(W, stream);
         }
     }
     return ffhip_launch_scale_yuv(l, ch, stream);

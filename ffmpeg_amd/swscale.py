@@ -102,6 +102,11 @@ class SwsContext:
         """True when the matrix-core horizontal pass (k_sws_mfma) is available for the banks."""
         return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 2)
 
+    @property
+    def wide_path(self):
+        """True when the wide-bank walker (k_sws_lwalk: 5..16 taps, down-scaling) is available for the banks."""
+        return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 4)
+
     def close(self):
         if getattr(self, "_c", None) and _lib is not None:
             _lib.lib().ffhip_sws_freeContext(self._c)

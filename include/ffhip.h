@@ -111,8 +111,9 @@ FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t);
 void             ffhip_sws_freeContext(FFHipSwsContext *c);
 /** 1 when the context's banks run on the register-resident column-walking kernel (4-tap x 4-tap banks
  *  whose 4-column groups read one 8-byte source span; sws_colwalk.hip), 0 when they take the general
- *  LDS-tiled kernel; bit 1 set when the matrix-core variant (k_sws_mfma) is available too.  Diagnostic
- *  only: results are identical. */
+ *  LDS-tiled kernel; bit 1 set when the matrix-core variant (k_sws_mfma) is available too; bit 2 set when the
+ *  banks (5..16 taps: down-scaling, long kernels) run on the LDS-backed wide-bank walker (sws_lwalk.hip).
+ *  Diagnostic only: results are identical. */
 int              ffhip_sws_fast_path(const FFHipSwsContext *c);
 /** Host-side preparation of the matrix-core horizontal pass (no device needed): turns one 4-tap horizontal
  *  bank (hLumFilter/hLumFilterPos or the chroma pair's) into per-tile MFMA operand records of 2320 bytes —

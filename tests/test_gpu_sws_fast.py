@@ -45,12 +45,12 @@ def _upload_aligned(arrs, n, rng):
     return out, host
 
 
-def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, n=3, seed=1, need_mfma=False):
+def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, n=3, seed=1, need_mfma=False, need="fast"):
     from ffmpeg_amd import swscale as S
     torch = _torch()
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
-              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT"):
+              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_SWS_WIDE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -70,7 +70,10 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
             keep += [f, p]
             setattr(tabs, name, _lib.SwsFilter(ptr(f, ffi.i16p), ptr(p, ffi.i32p), fs, nn))
     ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags, tables=tabs)
-    assert ctx.fast_path, "case does not reach the column walker"
+    if need == "wide":
+        assert ctx.wide_path, "case does not reach the wide-bank walker"
+    elif need == "fast":
+        assert ctx.fast_path, "case does not reach the column walker"
     if (env or {}).get("FFHIP_SWS_MFMA") == "1" and need_mfma:
         assert ctx.mfma_path, "case does not reach the matrix-core variant"
     first = ffi.alloc_frame(PIX[sf], sw, sh, rng)
@@ -249,6 +252,7 @@ PADDED_CASES = [
     ("nv12", 640, 360, "nv12", 640, 360, ffi.SWS_BICUBIC),
     ("yuv420p", 128, 72, "yuv420p", 256, 216, ffi.SWS_BICUBLIN),     # bicubic luma, bilinear chroma
     ("nv12", 128, 72, "nv12", 384, 72, ffi.SWS_BICUBIC),             # horizontal only: 1-tap vertical bank
+    ("yuv420p", 384, 216, "yuv420p", 192, 108, ffi.SWS_AREA),        # 2x area down-scaling: 2 taps at stride 2
 ]
 
 
@@ -302,3 +306,37 @@ def test_fast_path_rgb_adversarial_tables(fmts, monkeypatch):
         f[:, 3] += one - f.sum(1)
         banks[name] = (f.astype(np.int16).reshape(-1), pos, fs, n)
     _run(fmts[0], sw, sh, fmts[1], dw, dh, ffi.SWS_BICUBIC, banks=banks, monkeypatch=monkeypatch, n=2, seed=6)
+
+
+# ---------------------------------------------------------------------------------------------
+# wide banks (5..16 taps: down-scaling) on the LDS-backed walker (sws_lwalk.hip)
+WIDE_CASES = [
+    ("nv12", 384, 216, "nv12", 192, 108, ffi.SWS_BICUBIC),           # 2x down: 8 x 8 taps
+    ("nv21", 384, 216, "nv21", 192, 108, ffi.SWS_BICUBIC),
+    ("yuv420p", 384, 216, "yuv420p", 192, 108, ffi.SWS_BICUBIC),     # three single-plane jobs
+    ("nv12", 384, 216, "yuv420p", 192, 108, ffi.SWS_BICUBIC),        # interleaved -> planar
+    ("yuv420p", 384, 216, "nv21", 192, 108, ffi.SWS_BICUBIC),        # planar -> interleaved
+    ("nv12", 640, 360, "nv12", 216, 120, ffi.SWS_BICUBIC),           # ~3x down: 12 taps padded to 16
+    ("yuv420p", 640, 368, "nv12", 160, 92, ffi.SWS_BICUBIC),         # 4x down: 16 x 16 taps
+    ("nv12", 480, 270, "nv12", 320, 180, ffi.SWS_BICUBIC),           # 1.5x down: 6 taps padded to 8
+    ("nv12", 2096, 1416, "nv12", 1048, 600, ffi.SWS_BICUBIC),        # several column blocks and strips, ragged last block
+    ("nv12", 384, 216, "nv12", 192, 108, ffi.SWS_BILINEAR),          # 4-tap bank whose windows do not fit the column walker
+    ("yuv420p", 640, 360, "yuv420p", 160, 90 + 2, ffi.SWS_AREA),       # 4x area: 4..5 taps at stride 4
+    ("nv12", 384, 216, "nv12", 512, 108, ffi.SWS_BICUBIC),           # up horizontally, down vertically
+    ("yuv420p", 202, 120, "yuv420p", 104, 60, ffi.SWS_BICUBIC),      # odd chroma width (planar)
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_wide_path(case, monkeypatch):
+    _run(*case, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="wide")
+
+
+@pytest.mark.parametrize("case", CASES[:7], ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_wide_path_on_narrow_banks(case, monkeypatch):
+    """the wide walker forced onto 4-tap up-scaling banks (padded to 8 x 8)"""
+    _run(*case, env={"FFHIP_SWS_WIDE": "1", "FFHIP_SWS_FAST": "0"}, monkeypatch=monkeypatch, seed=3, need="wide")
+
+
+def test_wide_path_full_size(monkeypatch):
+    _run("nv12", 3840, 2160, "nv12", 1920, 1080, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=80, need="wide")
