@@ -157,8 +157,8 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     int yy = 0;
     int need = rfirst + RING - 1;
 
-    auto process = [&](const Row &cur, int rr) {
-        /* 1. row segment -> LDS (NV12: bytes u0 v0 u1 v1 ... become one dword of U and one of V) */
+    /* 1. row segment -> LDS (NV12: bytes u0 v0 u1 v1 ... become one dword of U and one of V) */
+    auto stage = [&](const Row &cur) {
 #pragma unroll
         for (int j = 0; j < NL; j++) {
             if (sil) {
@@ -171,23 +171,33 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
             }
         }
         __builtin_amdgcn_wave_barrier();
-        /* 2. + 3. horizontal pass of my columns, vertical pairs into the ring */
+    };
+    /* 2a. the windows of my columns, read one row AHEAD of their use (a wave's LDS operations execute in order, so the
+     * next row may overwrite the buffer as soon as these reads are issued) */
+    struct Win { uint32_t d[NG][4][HT + 1]; };
+    auto read_windows = [&](Win &w) {
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int k = 0; k <= HT; k++)
+                    w.d[g][i][k] = raw[g * RAWD + woff[i] + k];
+        asm volatile("" ::: "memory");
+    };
+    auto compute = [&](const Win &w, int rr) {
+        /* 2b. + 3. horizontal pass of my columns, vertical pairs into the ring */
         const int slot = rr & (RING - 1);
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             uint32_t pr[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t *w = raw + g * RAWD + woff[i];
-                uint32_t d[HT + 1];
-#pragma unroll
-                for (int k = 0; k <= HT; k++)
-                    d[k] = w[k];
                 int acc = 0;
 #pragma unroll
                 for (int k = 0; k < HT; k++) {
-                    acc = lw_dot2(__builtin_amdgcn_perm(d[k + 1], d[k], sel_a[i]), cf[i][2 * k], acc);
-                    acc = lw_dot2(__builtin_amdgcn_perm(d[k + 1], d[k], sel_b[i]), cf[i][2 * k + 1], acc);
+                    acc = lw_dot2(__builtin_amdgcn_perm(w.d[g][i][k + 1], w.d[g][i][k], sel_a[i]), cf[i][2 * k], acc);
+                    acc = lw_dot2(__builtin_amdgcn_perm(w.d[g][i][k + 1], w.d[g][i][k], sel_b[i]), cf[i][2 * k + 1], acc);
                 }
                 const int h = acc >> 7;
                 pr[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[g][i], h));
@@ -220,17 +230,17 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
             }
             if (dil) {
                 constexpr int b = NG - 1;
-                lw_u2 w;
-                w.x = __builtin_amdgcn_perm(lw_pk_u8(v[0][1], v[b][1]), lw_pk_u8(v[0][0], v[b][0]), sel_uv);
-                w.y = __builtin_amdgcn_perm(lw_pk_u8(v[0][3], v[b][3]), lw_pk_u8(v[0][2], v[b][2]), sel_uv);
+                lw_u2 w2;
+                w2.x = __builtin_amdgcn_perm(lw_pk_u8(v[0][1], v[b][1]), lw_pk_u8(v[0][0], v[b][0]), sel_uv);
+                w2.y = __builtin_amdgcn_perm(lw_pk_u8(v[0][3], v[b][3]), lw_pk_u8(v[0][2], v[b][2]), sel_uv);
                 if (act)
-                    *(lw_g2)((lw_gptr)d0 + (uint32_t)(2 * X0)) = w;
+                    *(lw_g2)((lw_gptr)d0 + (uint32_t)(2 * X0)) = w2;
             } else {
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
-                    const uint32_t w = __builtin_amdgcn_perm(lw_pk_u8(v[g][2], v[g][3]), lw_pk_u8(v[g][0], v[g][1]), 0x05040100);
+                    const uint32_t w1 = __builtin_amdgcn_perm(lw_pk_u8(v[g][2], v[g][3]), lw_pk_u8(v[g][0], v[g][1]), 0x05040100);
                     if (act)
-                        *(lw_g1)((lw_gptr)(g ? d1 : d0) + (uint32_t)X0) = w;
+                        *(lw_g1)((lw_gptr)(g ? d1 : d0) + (uint32_t)X0) = w1;
                 }
             }
             d0 += dstride0;
@@ -242,21 +252,24 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
         }
     };
 
+    /* software pipeline: global rows two ahead in registers, LDS windows one ahead in registers */
     Row b0, b1;
+    Win w0, w1;
     load_next(b0);
     load_next(b1);
+    stage(b0);
+    load_next(b0);
+    read_windows(w0);
     for (int r = rfirst; r <= rlast; r += 2) {
-        {
-            const Row cur = b0;
-            load_next(b0);
-            process(cur, r);
-        }
-        {
-            const Row cur = b1;
-            load_next(b1);
-            if (r + 1 <= rlast)
-                process(cur, r + 1);
-        }
+        stage(b1);
+        load_next(b1);
+        read_windows(w1);
+        compute(w0, r);
+        stage(b0);
+        load_next(b0);
+        read_windows(w0);
+        if (r + 1 <= rlast)
+            compute(w1, r + 1);
     }
 }
 
