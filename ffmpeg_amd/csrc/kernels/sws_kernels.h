@@ -166,7 +166,7 @@ struct FFHipLwArgs {
     FFHipLwJob job[3];
     int njobs, units_per_frame, nframes, ht, vt;
 };
-int  ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH);
+int  ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH, int pair);
 void ffhip_lw_plan_job(FFHipLwJob *j);
 int  ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream);
 

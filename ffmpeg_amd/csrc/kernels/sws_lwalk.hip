@@ -52,25 +52,30 @@ __device__ __forceinline__ uint32_t lw_pk_u8(int a, int b)
     return r;
 }
 
-/* NG = 1: one plane.  NG = 2: a U/V pair (byte-interleaved or planar on either side), same banks for both. */
+/*
+ * NG = 1: one plane, 4 columns per lane.  NG = 2: a U/V pair (byte-interleaved or planar on either side, same banks
+ * for both), 2 columns of each per lane — every unit is 4 samples per lane per row, one 16-byte ring record.
+ */
 template <int HT, int VT, int NL, int NG>
 __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, int cb, int lane, uint32_t *lds)
 {
+    constexpr int CPL = 4 / NG;                      /* columns per lane and channel                      */
+    constexpr int NLG = NG == 2 ? (NL + 1) / 2 : NL; /* segment loads per lane and row (a pair's block is half as wide) */
     constexpr int RAWD = NL * 64 + 8;  /* dwords of one row buffer (+ slack: a window read may touch one dword past the segment) */
     constexpr int RING = 2 * VT;       /* source rows of vertical history */
-    uint32_t *raw = lds;                                        /* [NG][RAWD]            */
-    uint4 *ring = reinterpret_cast<uint4 *>(lds + 2 * RAWD);    /* [NG][RING][64]        */
+    uint32_t *raw = lds;                                        /* [NG][RAWD]        */
+    uint4 *ring = reinterpret_cast<uint4 *>(lds + 2 * RAWD);    /* [RING][64]        */
     const bool sil = NG == 2 && J.sil, dil = NG == 2 && J.dil;
     const int y0 = strip * J.strip_rows;
     const int y1 = min(y0 + J.strip_rows, J.dstH);
     const int ny = y1 - y0;
 
     /* ---- horizontal descriptors ---- */
-    const int X0 = (cb * 64 + lane) * 4;
-    const int segb = __builtin_amdgcn_readfirstlane(J.hp[min(cb * 256, J.dstW - 1)]) & ~3;
-    uint32_t cf[4][2 * HT], sel_a[4], sel_b[4], woff[4];
+    const int X0 = (cb * 64 + lane) * CPL;
+    const int segb = __builtin_amdgcn_readfirstlane(J.hp[min(cb * 64 * CPL, J.dstW - 1)]) & ~3;
+    uint32_t cf[CPL][2 * HT], sel_a[CPL], sel_b[CPL], woff[CPL];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < CPL; i++) {
         const int xi = min(X0 + i, J.dstW - 1);
         const int o = J.hp[xi] - segb;
         woff[i] = (uint32_t)(o >> 2);
@@ -103,9 +108,9 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     const uint8_t *s0 = J.src[0] + (size_t)f * J.sfp[0];
     const uint8_t *s1 = NG == 2 ? J.src[1] + (size_t)f * J.sfp[1] : s0;
     const ptrdiff_t sstride0 = J.sstride[0], sstride1 = J.sstride[1];
-    uint32_t goff[NL]; /* byte offset in the row of load j (clamped to the last whole unit of the row) */
+    uint32_t goff[NLG]; /* byte offset in the row of load j (clamped to the last whole unit of the row) */
 #pragma unroll
-    for (int j = 0; j < NL; j++) {
+    for (int j = 0; j < NLG; j++) {
         if (sil)
             goff[j] = (uint32_t)min(2 * segb + 8 * (lane + 64 * j), 2 * J.srcW - 8);
         else
@@ -114,7 +119,7 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     const uint32_t sel_u = J.src_swap ? 0x07050301u : 0x06040200u, sel_v = J.src_swap ? 0x06040200u : 0x07050301u;
     const uint32_t sel_uv = J.dst_swap ? 0x04050001u : 0x05040100u;
 
-    struct Row { uint32_t q[NG][NL]; };
+    struct Row { uint32_t q[NG][NLG]; };
     const int rfirst = __builtin_amdgcn_readlane(vpl, 0);
     const int rlast = __builtin_amdgcn_readfirstlane(J.vp[y1 - 1]) + RING - 1;
     int pfrow = rfirst;
@@ -122,7 +127,7 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     asm("" : "+s"(pf0), "+s"(pf1));
     auto load_next = [&](Row &o) {
 #pragma unroll
-        for (int j = 0; j < NL; j++) {
+        for (int j = 0; j < NLG; j++) {
             uint32_t off = goff[j];
             asm volatile("" : "+v"(off));
             if (sil) {
@@ -142,12 +147,10 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
         asm("" : "+s"(pf0), "+s"(pf1));
     };
 
-    int hprev[NG][4];
+    int hprev[4];
 #pragma unroll
-    for (int g = 0; g < NG; g++)
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            hprev[g][i] = 0;
+    for (int i = 0; i < 4; i++)
+        hprev[i] = 0;
 
     uint8_t *d0 = J.dst[0] + (size_t)f * J.dfp[0] + (ptrdiff_t)y0 * J.dstride[0];
     uint8_t *d1 = NG == 2 ? J.dst[1] + (size_t)f * J.dfp[1] + (ptrdiff_t)y0 * J.dstride[1] : d0;
@@ -160,7 +163,7 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     /* 1. row segment -> LDS (NV12: bytes u0 v0 u1 v1 ... become one dword of U and one of V) */
     auto stage = [&](const Row &cur) {
 #pragma unroll
-        for (int j = 0; j < NL; j++) {
+        for (int j = 0; j < NLG; j++) {
             if (sil) {
                 raw[lane + 64 * j] = __builtin_amdgcn_perm(cur.q[1][j], cur.q[0][j], sel_u);
                 raw[RAWD + lane + 64 * j] = __builtin_amdgcn_perm(cur.q[1][j], cur.q[0][j], sel_v);
@@ -174,12 +177,12 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     };
     /* 2a. the windows of my columns, read one row AHEAD of their use (a wave's LDS operations execute in order, so the
      * next row may overwrite the buffer as soon as these reads are issued) */
-    struct Win { uint32_t d[NG][4][HT + 1]; };
+    struct Win { uint32_t d[NG][CPL][HT + 1]; };
     auto read_windows = [&](Win &w) {
 #pragma unroll
         for (int g = 0; g < NG; g++)
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < CPL; i++)
 #pragma unroll
                 for (int k = 0; k <= HT; k++)
                     w.d[g][i][k] = raw[g * RAWD + woff[i] + k];
@@ -187,12 +190,11 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     };
     auto compute = [&](const Win &w, int rr) {
         /* 2b. + 3. horizontal pass of my columns, vertical pairs into the ring */
-        const int slot = rr & (RING - 1);
+        uint32_t pr[4];
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            uint32_t pr[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < CPL; i++) {
                 int acc = 0;
 #pragma unroll
                 for (int k = 0; k < HT; k++) {
@@ -200,11 +202,11 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
                     acc = lw_dot2(__builtin_amdgcn_perm(w.d[g][i][k + 1], w.d[g][i][k], sel_b[i]), cf[i][2 * k + 1], acc);
                 }
                 const int h = acc >> 7;
-                pr[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[g][i], h));
-                hprev[g][i] = h;
+                pr[g * CPL + i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[g * CPL + i], h));
+                hprev[g * CPL + i] = h;
             }
-            ring[(g * RING + slot) * 64 + lane] = make_uint4(pr[0], pr[1], pr[2], pr[3]);
         }
+        ring[(rr & (RING - 1)) * 64 + lane] = make_uint4(pr[0], pr[1], pr[2], pr[3]);
         __builtin_amdgcn_wave_barrier();
         /* 4. output rows whose window ends here */
         while (yy < ny && need <= rr) {
@@ -213,35 +215,30 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
 #pragma unroll
             for (int k = 0; k < VT; k++)
                 fk[k] = __builtin_amdgcn_readlane(vcf[k], yy);
-            int v[NG][4];
+            int v[4];
 #pragma unroll
-            for (int g = 0; g < NG; g++) {
+            for (int i = 0; i < 4; i++)
+                v[i] = 64 << 12;
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    v[g][i] = 64 << 12;
-#pragma unroll
-                for (int k = 0; k < VT; k++) {
-                    const uint4 P = ring[(g * RING + ((p + 1 + 2 * k) & (RING - 1))) * 64 + lane];
-                    v[g][0] = lw_dot2(P.x, fk[k], v[g][0]);
-                    v[g][1] = lw_dot2(P.y, fk[k], v[g][1]);
-                    v[g][2] = lw_dot2(P.z, fk[k], v[g][2]);
-                    v[g][3] = lw_dot2(P.w, fk[k], v[g][3]);
-                }
+            for (int k = 0; k < VT; k++) {
+                const uint4 P = ring[((p + 1 + 2 * k) & (RING - 1)) * 64 + lane];
+                v[0] = lw_dot2(P.x, fk[k], v[0]);
+                v[1] = lw_dot2(P.y, fk[k], v[1]);
+                v[2] = lw_dot2(P.z, fk[k], v[2]);
+                v[3] = lw_dot2(P.w, fk[k], v[3]);
             }
-            if (dil) {
-                constexpr int b = NG - 1;
-                lw_u2 w2;
-                w2.x = __builtin_amdgcn_perm(lw_pk_u8(v[0][1], v[b][1]), lw_pk_u8(v[0][0], v[b][0]), sel_uv);
-                w2.y = __builtin_amdgcn_perm(lw_pk_u8(v[0][3], v[b][3]), lw_pk_u8(v[0][2], v[b][2]), sel_uv);
+            if (NG == 1) {
+                const uint32_t w1 = __builtin_amdgcn_perm(lw_pk_u8(v[2], v[3]), lw_pk_u8(v[0], v[1]), 0x05040100);
                 if (act)
-                    *(lw_g2)((lw_gptr)d0 + (uint32_t)(2 * X0)) = w2;
-            } else {
-#pragma unroll
-                for (int g = 0; g < NG; g++) {
-                    const uint32_t w1 = __builtin_amdgcn_perm(lw_pk_u8(v[g][2], v[g][3]), lw_pk_u8(v[g][0], v[g][1]), 0x05040100);
-                    if (act)
-                        *(lw_g1)((lw_gptr)(g ? d1 : d0) + (uint32_t)X0) = w1;
-                }
+                    *(lw_g1)((lw_gptr)d0 + (uint32_t)X0) = w1;
+            } else if (dil) {
+                /* v = U0 U1 V0 V1 -> bytes U0 V0 U1 V1 (V first for NV21) */
+                const uint32_t w1 = __builtin_amdgcn_perm(lw_pk_u8(v[1], v[3]), lw_pk_u8(v[0], v[2]), sel_uv);
+                if (act)
+                    *(lw_g1)((lw_gptr)d0 + (uint32_t)(2 * X0)) = w1;
+            } else if (act) {
+                *(uint16_t __attribute__((address_space(1))) *)((lw_gptr)d0 + (uint32_t)X0) = (uint16_t)lw_pk_u8(v[0], v[1]);
+                *(uint16_t __attribute__((address_space(1))) *)((lw_gptr)d1 + (uint32_t)X0) = (uint16_t)lw_pk_u8(v[2], v[3]);
             }
             d0 += dstride0;
             d1 += dstride1;
@@ -296,19 +293,21 @@ __global__ __launch_bounds__(64) void k_sws_lwalk(FFHipLwArgs A)
 /* ---- host side ---------------------------------------------------------------------------------- */
 /*
  * Can a (padded) bank pair run here?  hpos/vpos are host copies of the padded positions; ht/vt the padded sizes in
- * units of 4 / 2 taps.  Returns the number of segment loads per lane (NL class: 3 or 5) or 0.
+ * units of 4 / 2 taps; pair: the bank serves a U/V pair unit (128 columns per wave).  Returns the NL class (3 or 5)
+ * or 0.
  */
-int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH)
+int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH, int pair)
 {
     if ((ht != 2 && ht != 4) || (vt != 4 && vt != 8) || hn <= 0 || (hn & 3) || vn <= 0 || srcW < 4 * ht || srcW < 8 ||
         srcH < 2 * vt)
         return 0;
+    const int block = pair ? 128 : 256; /* output columns of one wave */
     int span = 0;
     for (int x = 0; x < hn; x++)
         if (hpos[x] < 0 || hpos[x] + 4 * ht > srcW || (x && hpos[x] < hpos[x - 1]))
             return 0;
-    for (int x0 = 0; x0 < hn; x0 += 256) {
-        const int xe = x0 + 255 < hn ? x0 + 255 : hn - 1;
+    for (int x0 = 0; x0 < hn; x0 += block) {
+        const int xe = x0 + block - 1 < hn ? x0 + block - 1 : hn - 1;
         const int s = hpos[xe] + 4 * ht - (hpos[x0] & ~3);
         if (s > span)
             span = s;
@@ -317,13 +316,15 @@ int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_
         if (vpos[y] < 0 || vpos[y] + 2 * vt > srcH || (y && vpos[y] < vpos[y - 1]))
             return 0;
     const int nl = ht == 2 ? 3 : 5;
-    return span <= nl * 256 ? nl : 0;
+    return span <= (pair ? (nl + 1) / 2 : nl) * 256 ? nl : 0;
 }
 
 void ffhip_lw_plan_job(FFHipLwJob *j)
 {
-    j->ncb = cdiv(j->dstW, 256);
-    const int n = cdiv(j->dstH, 64);
+    j->ncb = cdiv(j->dstW, j->pair ? 128 : 256);
+    const char *es = getenv("FFHIP_LW_STRIP"); /* measured variant: shorter strips (more, lighter waves; more halo rows) */
+    const int want = es && atoi(es) > 0 && atoi(es) < 64 ? atoi(es) : 64;
+    const int n = cdiv(j->dstH, want);
     j->strip_rows = cdiv(j->dstH, n);
     j->nstrips = cdiv(j->dstH, j->strip_rows);
 }
@@ -332,11 +333,10 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
 {
     if (A.nframes <= 0)
         return 0;
-    int u = 0, pair = 0;
+    int u = 0;
     for (int i = 0; i < A.njobs; i++) {
         A.job[i].unit_begin = u;
         u += A.job[i].ncb * A.job[i].nstrips;
-        pair |= A.job[i].pair;
     }
     A.units_per_frame = u;
     const long long waves = (long long)u * A.nframes;
@@ -345,7 +345,7 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
         return FFHIP_EINVAL;
     }
     const int nl = A.ht == 2 ? 3 : 5;
-    const size_t lds = (size_t)4 * 2 * (nl * 64 + 8) + (size_t)(pair ? 2 : 1) * 2 * A.vt * 64 * 16;
+    const size_t lds = (size_t)4 * 2 * (nl * 64 + 8) + (size_t)2 * A.vt * 64 * 16;
     const dim3 grid((unsigned)waves), block(64);
 #define LW_LAUNCH(H, V, N)                                                                                   \
     do {                                                                                                     \

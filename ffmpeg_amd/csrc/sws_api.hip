@@ -305,7 +305,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 bool ok = true;
                 for (int k = 0; k < 2 && ok; k++)
                     ok = ffhip_lw_bank_ok(c->wp[k].data(), hts[k], c->d[k].n, limits[k], c->wp[2 + k].data(), c->lw_vt, c->d[2 + k].n,
-                                          limits[2 + k]) != 0 &&
+                                          limits[2 + k], k == 1 && (fmt_nv(t->srcFormat) || fmt_nv(t->dstFormat))) != 0 &&
                          ffhip_cw_bank_nowrap(c->wf[k].data(), 4 * c->lw_ht, c->d[k].n);
                 if (fmt_nv(t->srcFormat) && (ch.srcW & 3))
                     ok = false;
@@ -612,10 +612,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                 j.hf = c->dw[which].filter; j.hp = c->dw[which].pos; j.vf = c->dw[2 + which].filter; j.vp = c->dw[2 + which].pos;
                 ffhip_lw_plan_job(&j);
             };
-            FFHipLwJob &jl = W.job[W.njobs++];
-            jl.src[0] = l.src[0]; jl.sstride[0] = l.src_stride[0]; jl.sfp[0] = l.src_fp[0];
-            jl.dst[0] = l.dst[0]; jl.dstride[0] = l.dst_stride[0]; jl.dfp[0] = l.dst_fp[0];
-            wbank(jl, l, 0);
+            /* the heavier units (a U/V pair is twice a plane) are enumerated first: they start first */
             if (ch.src_step == 1 && ch.dst_step == 1) {
                 for (int k = 0; k < 2; k++) {
                     FFHipLwJob &j = W.job[W.njobs++];
@@ -640,6 +637,10 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                 }
                 wbank(j, ch, 1);
             }
+            FFHipLwJob &jl = W.job[W.njobs++];
+            jl.src[0] = l.src[0]; jl.sstride[0] = l.src_stride[0]; jl.sfp[0] = l.src_fp[0];
+            jl.dst[0] = l.dst[0]; jl.dstride[0] = l.dst_stride[0]; jl.dfp[0] = l.dst_fp[0];
+            wbank(jl, l, 0);
             return ffhip_launch_lwalk(W, stream);
         }
     }
