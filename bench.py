@@ -98,6 +98,28 @@ def extras(torch, dev):
                                "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "frames": n, "ms": round(ms, 4)}
     ctx.close()
     del src, dst
+
+    def sws_case(key, sf, sw, sh, df, dw, dh, n):
+        c = S.SwsContext(sw, sh, sf, dw, dh, df, 4)
+        s_ = [torch.randint(0, 256, (n, r, cc), dtype=torch.uint8, device=dev) for r, cc in S.plane_shapes(sf, sw, sh)]
+        d_ = [torch.empty((n, r, cc), dtype=torch.uint8, device=dev) for r, cc in S.plane_shapes(df, dw, dh)]
+        for _ in range(2):
+            c.scale_batch(s_, d_)
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(5):
+            c.scale_batch(s_, d_)
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) / 5
+        byt = n * (S.frame_bytes(sf, sw, sh) + S.frame_bytes(df, dw, dh))
+        out[key] = {"Mpixels/s": round(n * dw * dh / (t * 1e-3) / 1e6, 1), "GB/s": round(byt / (t * 1e-3) / 1e9, 1),
+                    "hbm_frac": round(byt / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frames": n, "ms": round(t, 4)}
+        c.close()
+
+    # down-scaling (8 x 8-tap banks: the LDS-backed wide walker) and scaled packed-RGB output (column walker + yuv2rgb)
+    sws_case("sws_nv12_4k_to_1080p_bicubic", 23, 3840, 2160, 23, 1920, 1080, 64)
+    sws_case("sws_yuv420p_1080p_to_rgb24_4k_bicubic", 0, 1920, 1080, 2, 3840, 2160, 32)
     # H.264 8x8 IDCT + add over 32 4K luma planes (129,600 blocks each, 384 B/block)
     planes, stride = 32, 3840
     nb = planes * 129600
@@ -319,7 +341,7 @@ def main():
                        "frames_per_gpu": n, "flags": "SWS_BICUBIC", "sharding": "frames/rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_sws_colwalk<1,6,false,true>" if ctx.fast_path else "k_sws_scale_yuv<4,4>",
+                         "kernel": "k_sws_colwalk<1,6,false,true,true>" if ctx.fast_path else "k_sws_scale_yuv<4,4>",
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME},
         }

@@ -148,7 +148,7 @@ __device__ __forceinline__ int cw_span_base(const int (&p)[4], int srcW)
  * D = source rows in flight (prefetch depth), a multiple of 3 so that the ring of vertical pairs
  * is indexed statically inside the unrolled row loop.
  */
-template <int KIND, int D, bool PLAIN, bool OPT>
+template <int KIND, int D, bool PLAIN, bool OPT, bool DUP = false>
 __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, int cb, int lane)
 {
     constexpr int NG = KIND == 0 ? 1 : 2;           /* groups per lane                 */
@@ -252,8 +252,14 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
                 int acc[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    a[i] = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i]);
-                    b[i] = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i + 1]);
+                    if (DUP && i == 2) {
+                        /* columns 1 and 2 of every group read the same window (exact 2x up-scaling, host-checked) */
+                        a[2] = a[1];
+                        b[2] = b[1];
+                    } else {
+                        a[i] = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i]);
+                        b[i] = __builtin_amdgcn_perm(d[g][1], d[g][0], sel[hg][2 * i + 1]);
+                    }
                 }
                 cw_hdots4(acc, a, b, cf[hg]);
 #pragma unroll
@@ -433,7 +439,7 @@ __device__ __forceinline__ void cw_unit(const FFHipCwJob &J, int f, int strip, i
     }
 }
 
-template <int LK, int D, bool PLAIN, bool OPT>
+template <int LK, int D, bool PLAIN, bool OPT, bool DUP>
 __device__ __forceinline__ void cw_kernel_body(const FFHipCwArgs &A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -450,19 +456,19 @@ __device__ __forceinline__ void cw_kernel_body(const FFHipCwArgs &A)
     const int local = u - J.unit_begin;
     const int strip = local / J.ncb, cb = local - strip * J.ncb;
     if (J.kind == 2)
-        cw_unit<2, D, PLAIN, OPT>(J, f, strip, cb, lane);
+        cw_unit<2, D, PLAIN, OPT, DUP>(J, f, strip, cb, lane);
     else if (J.kind == 3)
-        cw_unit<3, D, PLAIN, OPT>(J, f, strip, cb, lane);
+        cw_unit<3, D, PLAIN, OPT, DUP>(J, f, strip, cb, lane);
     else if (J.kind == 4)
-        cw_unit<4, D, PLAIN, OPT>(J, f, strip, cb, lane);
+        cw_unit<4, D, PLAIN, OPT, DUP>(J, f, strip, cb, lane);
     else
-        cw_unit<LK, D, PLAIN, OPT>(J, f, strip, cb, lane);
+        cw_unit<LK, D, PLAIN, OPT, DUP>(J, f, strip, cb, lane);
 }
 
-template <int LK, int D, bool PLAIN, bool OPT>
+template <int LK, int D, bool PLAIN, bool OPT, bool DUP = false>
 __global__ __launch_bounds__(256) void k_sws_colwalk(FFHipCwArgs A)
 {
-    cw_kernel_body<LK, D, PLAIN, OPT>(A);
+    cw_kernel_body<LK, D, PLAIN, OPT, DUP>(A);
 }
 
 
@@ -1072,6 +1078,16 @@ int ffhip_cw_bank_ok(const int32_t *hpos, int hsize, int hn, int srcW, const int
     return 1;
 }
 
+/* 1 when columns 1 and 2 of every 4-column group start at the same source sample with any coefficients (exact 2x
+ * up-scaling): the DUP variant then unpacks that window once */
+int ffhip_cw_bank_dup12(const int32_t *hpos, int hn)
+{
+    for (int x0 = 0; x0 + 3 < hn; x0 += 4)
+        if (hpos[x0 + 1] != hpos[x0 + 2])
+            return 0;
+    return (hn & 3) == 0;
+}
+
 int ffhip_cw_bank_nowrap(const int16_t *filter, int size, int n)
 {
     for (int x = 0; x < n; x++) {
@@ -1117,7 +1133,11 @@ int ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t
     if (A.flags & 1) {
         CW_LAUNCH(0, 3, true, false);
     } else if (luma_groups == 2) {
-        if (depth == 6) { if (opt) CW_LAUNCH(1, 6, false, true); else CW_LAUNCH(1, 6, false, false); }
+        if (depth == 6) {
+            if (opt && (A.flags & 4)) hipLaunchKernelGGL((k_sws_colwalk<1, 6, false, true, true>), grid, block, 0, stream, A);
+            else if (opt) CW_LAUNCH(1, 6, false, true);
+            else CW_LAUNCH(1, 6, false, false);
+        }
         else            { if (opt) CW_LAUNCH(1, 3, false, true); else CW_LAUNCH(1, 3, false, false); }
     } else {
         if (depth == 6) { if (opt) CW_LAUNCH(0, 6, false, true); else CW_LAUNCH(0, 6, false, false); }

@@ -75,11 +75,12 @@ struct FFHipCwJob {
 };
 struct FFHipCwArgs {
     FFHipCwJob job[3];
-    int njobs, units_per_frame, nframes, flags;   /* bit0: plain shift/clamp instead of v_ashr_pk_u8_i32; bit1: OPT variant */
+    int njobs, units_per_frame, nframes, flags;   /* bit0: plain shift/clamp instead of v_ashr_pk_u8_i32; bit1: OPT variant; bit2: DUP (needs OPT) */
 };
 /* 1 when no horizontal sum of the bank can fall below -32768 after >> 7 (then int16 saturation == the
  * reference's min(.,32767) + truncation, which the OPT variant relies on) */
 int  ffhip_cw_bank_nowrap(const int16_t *filter, int size, int n);
+int  ffhip_cw_bank_dup12(const int32_t *hpos, int hn);
 int  ffhip_cw_bank_ok(const int32_t *hpos, int hsize, int hn, int srcW, const int32_t *vpos, int vsize, int vn, int srcH);
 void ffhip_cw_plan_job(FFHipCwJob *j, int groups_per_lane, int strip_target);
 int  ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t stream);

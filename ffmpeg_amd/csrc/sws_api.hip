@@ -33,6 +33,7 @@ struct FFHipSwsContext {
     FFHipDevFilter dn[4];
     int cw_ok = 0; /* both bank pairs fit the column-walking fast path (sws_colwalk.hip) */
     int cw_opt = 0; /* ... and no horizontal sum can wrap int16: the hand-scheduled variant applies */
+    int cw_dup = 0; /* ... and columns 1,2 of every group share a window (exact 2x): one unpack serves both */
     int cw_rgb = 0; /* packed-RGB target on the column walker (k_sws_colwalk_rgb) */
     /* wide-bank walker (sws_lwalk.hip): banks padded to 4*lw_ht x 2*lw_vt taps */
     int lw_ok = 0, lw_ht = 0, lw_vt = 0;
@@ -296,6 +297,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         }
         c->cw_opt = c->cw_ok && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&
                     ffhip_cw_bank_nowrap(c->nf[1].data(), 4, c->d[1].n);
+        c->cw_dup = c->cw_opt && ffhip_cw_bank_dup12(c->np[0].data(), c->d[0].n) && ffhip_cw_bank_dup12(c->np[1].data(), c->d[1].n);
         /* wide banks (down-scaling, long kernels): the LDS-backed walker; FFHIP_SWS_WIDE=1 builds it for narrow banks
          * too (parity tests of that kernel on up-scaling cases) */
         {
@@ -549,6 +551,9 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             A.flags = ep && ep[0] == '1' ? 1 : 0;
             if (c->cw_opt && !A.flags && !(eo && eo[0] == '0'))
                 A.flags |= 2;
+            const char *edup = getenv("FFHIP_CW_DUP");
+            if ((A.flags & 2) && c->cw_dup && !(edup && edup[0] == '0'))
+                A.flags |= 4;
             auto bank = [&](FFHipCwJob &j, const FFHipScalePlaneArgs &p) {
                 const int which = &p == &ch ? 1 : 0; /* the padded 4-tap view of the banks */
                 j.srcW = p.srcW; j.srcH = p.srcH; j.dstW = p.dstW; j.dstH = p.dstH;

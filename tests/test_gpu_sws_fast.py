@@ -22,6 +22,7 @@ VARIANTS = [
     {"FFHIP_CW_OPT": "0"},
     {"FFHIP_CW_OPT": "0", "FFHIP_CW_DEPTH": "6", "FFHIP_CW_LUMA_GROUPS": "1"},
     {"FFHIP_CW_STRIP": "128"},
+    {"FFHIP_CW_DUP": "0"},
     {"FFHIP_SWS_FAST": "0"},
 ]
 
@@ -50,7 +51,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     torch = _torch()
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
-              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_SWS_WIDE"):
+              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_SWS_WIDE", "FFHIP_CW_DUP", "FFHIP_LW_STRIP"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
