@@ -33,8 +33,8 @@
 
 struct TxDev {
     int n, lg;                 /* complex FFT size (= len/2) and its log2                         */
-    const int *map;            /* n                                                                */
-    const float2 *exp;         /* n (forward) or 2n (inverse: [0,n) permuted, [n,2n) natural)       */
+    const int *map;            /* n: where input-order element j goes in the (padded) work array   */
+    const float2 *exp;         /* n entries, natural order                                          */
     const float *cos_tab;      /* concatenated per level, cos_off[l] = first entry of level l       */
     const uint32_t *sched;     /* butterflies: a0 | k << 16, concatenated per level                 */
     const uint16_t *blocks2;   /* offsets of the size-2 blocks                                      */
@@ -53,6 +53,17 @@ struct FFHipTXContext {
     size_t stage_sz = 0;
     std::mutex mu;
 };
+
+/*
+ * LDS layout of the complex work array: element i lives at i + (i >> 5), one pad element per 32 (= per 256-byte row
+ * of the 64 LDS banks).  Every power-of-two operand stride of the split-radix levels then falls on distinct banks for
+ * the 32 lanes an 8-byte access serves per cycle; with the plain layout the low levels (operands of neighbouring
+ * lanes 32..512 bytes apart) serialised 4-16 ways.  The butterfly lists and the forward scatter map carry padded
+ * indices from the host; a level's operand offsets k*q pad independently (no carry across bit 5: blocks are 4q
+ * aligned).
+ */
+#define TX_PAD(i) ((i) + ((i) >> 5))
+__host__ __device__ static inline size_t tx_z_bytes(int n) { return ((size_t)TX_PAD(n) * 8 + 15) & ~(size_t)15; }
 
 __device__ __forceinline__ void tx_wave_sync()
 {
@@ -74,13 +85,14 @@ __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, const floa
     for (int l = 2; l <= d.lg; l++) {
         tx_wave_sync();
         const int q = 1 << (l - 2);
+        const int o1 = TX_PAD(q), o2 = TX_PAD(2 * q), o3 = TX_PAD(3 * q);
         const float *tab = cos_tab + d.cos_off[l];
         const uint32_t *sc = sched + d.sched_off[l];
         for (int b = lane; b < d.sched_cnt[l]; b += 64) {
             const uint32_t e = sc[b];
             const int a0 = e & 0xFFFF, k = e >> 16;
             const float wre = tab[k], wim = tab[q - k], nwim = -wim;
-            const float2 v0 = z[a0], v1 = z[a0 + q], v2 = z[a0 + 2 * q], v3 = z[a0 + 3 * q];
+            const float2 v0 = z[a0], v1 = z[a0 + o1], v2 = z[a0 + o2], v3 = z[a0 + o3];
             /* ff_tx_fft_sr_combine's TRANSFORM: libavutil/tx_template.c:540-586 */
             const float t1 = v2.x * wre - v2.y * nwim;
             const float t2 = v2.x * nwim + v2.y * wre;
@@ -90,10 +102,10 @@ __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, const floa
             t5 = t5 + t1;
             const float t4 = t2 - t6;
             t6 = t2 + t6;
-            z[a0]         = make_float2(v0.x + t5, v0.y + t6);
-            z[a0 + q]     = make_float2(v1.x + t4, v1.y + t3);
-            z[a0 + 2 * q] = make_float2(v0.x - t5, v0.y - t6);
-            z[a0 + 3 * q] = make_float2(v1.x - t4, v1.y - t3);
+            z[a0]      = make_float2(v0.x + t5, v0.y + t6);
+            z[a0 + o1] = make_float2(v1.x + t4, v1.y + t3);
+            z[a0 + o2] = make_float2(v0.x - t5, v0.y - t6);
+            z[a0 + o3] = make_float2(v1.x - t4, v1.y - t3);
         }
     }
     tx_wave_sync();
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * waves_per_block + wave;
     const int n = d.n, q = n >> 1;
-    const size_t per_wave = (size_t)n * 8 + (size_t)n * 16; /* z + staging (4n floats) */
+    const size_t zb = tx_z_bytes(n), per_wave = zb + (size_t)n * 16; /* z (padded) + staging (4n floats) */
     /* (the kernel argument itself must stay untouched: a conditionally modified TxDev is spilled to scratch) */
     const float *f_cos = d.cos_tab;
     const uint32_t *f_sched = d.sched;
@@ -130,13 +142,14 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
         __syncthreads();
         const uint8_t *g0 = reinterpret_cast<const uint8_t *>(d.cos_tab);
         f_sched = reinterpret_cast<const uint32_t *>(ft + (reinterpret_cast<const uint8_t *>(d.sched) - g0));
-        f_b2 = reinterpret_cast<const uint16_t *>(ft + (reinterpret_cast<const uint8_t *>(d.blocks2) - g0));
+        /* (the size-2 block list stays in L2: its 342 bytes would push the workgroup over 42 LDS allocation units of
+         * 1280 bytes, i.e. from 3 workgroups per CU to 2) */
         f_cos = reinterpret_cast<const float *>(ft);
     }
     if (wave >= waves_per_block || t >= nt)
         return;
     float2 *z = reinterpret_cast<float2 *>(lds_raw + wave * per_wave);
-    float *st = reinterpret_cast<float *>(lds_raw + wave * per_wave + (size_t)n * 8);
+    float *st = reinterpret_cast<float *>(lds_raw + wave * per_wave + zb);
     const float *src = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
     float *dst = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
 
@@ -172,13 +185,15 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
         /* ---- post-twiddle (tx_template.c:1300-1309) ---- */
         for (int i = lane; i < q; i += 64) {
             const int i0 = q + i, i1 = q - i - 1;
-            const float2 s1 = z[i1], s0 = z[i0], e0 = d.exp[i0], e1 = d.exp[i1];
+            const float2 s1 = z[TX_PAD(i1)], s0 = z[TX_PAD(i0)], e0 = d.exp[i0], e1 = d.exp[i1];
             const float a = s0.x * e0.y - s0.y * e0.x; /* out[2*i1+1] */
             const float b = s0.x * e0.x + s0.y * e0.y; /* out[2*i0]   */
             const float c = s1.x * e1.y - s1.y * e1.x; /* out[2*i0+1] */
             const float f = s1.x * e1.x + s1.y * e1.y; /* out[2*i1]   */
             if (vec_out) {
-                st[2 * i1 + 1] = a; st[2 * i0] = b; st[2 * i0 + 1] = c; st[2 * i1] = f;
+                /* (2*i1, 2*i1+1) and (2*i0, 2*i0+1) as 8-byte writes: 4-byte writes two floats apart conflict 2 ways */
+                reinterpret_cast<float2 *>(st)[i1] = make_float2(f, a);
+                reinterpret_cast<float2 *>(st)[i0] = make_float2(b, c);
             } else {
                 dst[(2 * i1 + 1) * stride] = a; dst[2 * i0 * stride] = b;
                 dst[(2 * i0 + 1) * stride] = c; dst[2 * i1 * stride] = f;
@@ -196,27 +211,30 @@ __global__ __launch_bounds__(256) void k_mdct(TxDev d, const float *in, size_t i
                 st[j] = src[j * stride];
         }
         tx_wave_sync();
-        /* ---- gather + pre-twiddle (ff_tx_mdct_inv, tx_template.c:1321-1328) ---- */
-        for (int i = lane; i < n; i += 64) {
-            const int k = d.map[i] << 1;
+        /* ---- pre-twiddle (ff_tx_mdct_inv, tx_template.c:1321-1328: z[i] from in[map[i]]) walked in INPUT order j =
+         * map[i] and scattered through the inverse permutation: the staging area is then read in order instead of
+         * through a bit-reversal-like gather (up to 32 lanes on one LDS bank); same operands, same operations ---- */
+        for (int j = lane; j < n; j += 64) {
+            const int k = j << 1;
             const float tre = st[2 * n - 1 - k], tim = st[k];
-            const float2 e = d.exp[i];
-            z[i] = make_float2(tre * e.x - tim * e.y, tre * e.y + tim * e.x);
+            const float2 e = d.exp[j];
+            z[d.map[j]] = make_float2(tre * e.x - tim * e.y, tre * e.y + tim * e.x);
         }
         tx_wave_sync();
         tx_fft_lds(z, d, f_cos, f_sched, f_b2, lane);
         /* ---- post-twiddle (tx_template.c:1332-1341) ---- */
-        const float2 *ex = d.exp + n;
+        const float2 *ex = d.exp;
         for (int i = lane; i < q; i += 64) {
             const int i0 = q + i, i1 = q - i - 1;
-            const float2 s1 = make_float2(z[i1].y, z[i1].x), s0 = make_float2(z[i0].y, z[i0].x);
+            const float2 z1 = z[TX_PAD(i1)], z0 = z[TX_PAD(i0)], s1 = make_float2(z1.y, z1.x), s0 = make_float2(z0.y, z0.x);
             const float2 e0 = ex[i0], e1 = ex[i1];
             const float a = s1.x * e1.y - s1.y * e1.x; /* o[i1].re */
             const float b = s1.x * e1.x + s1.y * e1.y; /* o[i0].im */
             const float c = s0.x * e0.y - s0.y * e0.x; /* o[i0].re */
             const float f = s0.x * e0.x + s0.y * e0.y; /* o[i1].im */
             if (vec_out) {
-                st[2 * i1] = a; st[2 * i0 + 1] = b; st[2 * i0] = c; st[2 * i1 + 1] = f;
+                reinterpret_cast<float2 *>(st)[i1] = make_float2(a, f);
+                reinterpret_cast<float2 *>(st)[i0] = make_float2(c, b);
             } else {
                 dst[2 * i1] = a; dst[2 * i0 + 1] = b; dst[2 * i0] = c; dst[2 * i1 + 1] = f;
             }
@@ -259,10 +277,10 @@ __global__ __launch_bounds__(256) void k_mdct_l(TxDev d, const uint8_t *blob, in
     const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
     const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
     const int n = d.n, q = n >> 1;
-    const size_t per_wave = (size_t)n * 24;
+    const size_t zb = tx_z_bytes(n), per_wave = zb + (size_t)n * 16;
     uint8_t *mine = lds_raw + ((blob_bytes + 15) & ~15) + wave * per_wave;
     float2 *z = reinterpret_cast<float2 *>(mine);
-    float *st = reinterpret_cast<float *>(mine + (size_t)n * 8);
+    float *st = reinterpret_cast<float *>(mine + zb);
     float4 *l4 = reinterpret_cast<float4 *>(st);
     const int nin4 = INV ? n / 2 : n;
 
@@ -288,31 +306,31 @@ __global__ __launch_bounds__(256) void k_mdct_l(TxDev d, const uint8_t *blob, in
                 z[l_map[i]] = make_float2(re * e.y + im * e.x, re * e.x - im * e.y);
             }
         } else {
-            for (int i = lane; i < n; i += 64) {
-                const int k = l_map[i] << 1;
+            for (int j = lane; j < n; j += 64) {
+                const int k = j << 1;
                 const float tre = st[2 * n - 1 - k], tim = st[k];
-                const float2 e = l_exp[i];
-                z[i] = make_float2(tre * e.x - tim * e.y, tre * e.y + tim * e.x);
+                const float2 e = l_exp[j];
+                z[l_map[j]] = make_float2(tre * e.x - tim * e.y, tre * e.y + tim * e.x);
             }
         }
         tx_wave_sync();
         tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
-        const float2 *ex = INV ? l_exp + n : l_exp;
+        const float2 *ex = l_exp;
         for (int i = lane; i < q; i += 64) {
             const int i0 = q + i, i1 = q - i - 1;
             const float2 e0 = ex[i0], e1 = ex[i1];
             if (!INV) {
-                const float2 s1 = z[i1], s0 = z[i0];
-                st[2 * i1 + 1] = s0.x * e0.y - s0.y * e0.x;
-                st[2 * i0]     = s0.x * e0.x + s0.y * e0.y;
-                st[2 * i0 + 1] = s1.x * e1.y - s1.y * e1.x;
-                st[2 * i1]     = s1.x * e1.x + s1.y * e1.y;
+                const float2 s1 = z[TX_PAD(i1)], s0 = z[TX_PAD(i0)];
+                const float a = s0.x * e0.y - s0.y * e0.x, b = s0.x * e0.x + s0.y * e0.y;
+                const float c = s1.x * e1.y - s1.y * e1.x, f = s1.x * e1.x + s1.y * e1.y;
+                reinterpret_cast<float2 *>(st)[i1] = make_float2(f, a);
+                reinterpret_cast<float2 *>(st)[i0] = make_float2(b, c);
             } else {
-                const float2 s1 = make_float2(z[i1].y, z[i1].x), s0 = make_float2(z[i0].y, z[i0].x);
-                st[2 * i1]     = s1.x * e1.y - s1.y * e1.x;
-                st[2 * i0 + 1] = s1.x * e1.x + s1.y * e1.y;
-                st[2 * i0]     = s0.x * e0.y - s0.y * e0.x;
-                st[2 * i1 + 1] = s0.x * e0.x + s0.y * e0.y;
+                const float2 z1 = z[TX_PAD(i1)], z0 = z[TX_PAD(i0)], s1 = make_float2(z1.y, z1.x), s0 = make_float2(z0.y, z0.x);
+                const float a = s1.x * e1.y - s1.y * e1.x, b = s1.x * e1.x + s1.y * e1.y;
+                const float c = s0.x * e0.y - s0.y * e0.x, f = s0.x * e0.x + s0.y * e0.y;
+                reinterpret_cast<float2 *>(st)[i1] = make_float2(a, f);
+                reinterpret_cast<float2 *>(st)[i0] = make_float2(c, b);
             }
         }
         tx_wave_sync();
@@ -339,7 +357,7 @@ static void sr_schedule(int o, int n, int lg, std::vector<uint32_t> *lev, std::v
     if (n == 1)
         return;
     if (n == 2) {
-        b2->push_back((uint16_t)o);
+        b2->push_back((uint16_t)TX_PAD(o));
         return;
     }
     const int q = n >> 2;
@@ -347,7 +365,7 @@ static void sr_schedule(int o, int n, int lg, std::vector<uint32_t> *lev, std::v
     sr_schedule(o + 2 * q, q, lg - 2, lev, b2);
     sr_schedule(o + 3 * q, q, lg - 2, lev, b2);
     for (int k = 0; k < q; k++)
-        lev[lg].push_back((uint32_t)(o + k) | ((uint32_t)k << 16));
+        lev[lg].push_back((uint32_t)TX_PAD(o + k) | ((uint32_t)k << 16));
 }
 
 extern "C" void ffhip_tx_uninit(FFHipTXContext **pctx)
@@ -391,26 +409,28 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     while ((1 << lg) < n)
         lg++;
     /* permutation: forward asks for SCATTER, inverse for GATHER (tx_template.c:1231-1233) */
+    /* (the reference's inverse GATHERs z[i] = f(in[map[i]]); we walk the input in order and scatter through the
+     * inverse permutation, so both directions carry a scatter map here) */
     std::vector<int> map(n);
     for (int i = 0; i < n; i++) {
         const int p = -sr_perm(i, n, c->inv) & (n - 1);
-        if (!c->inv) map[p] = i; else map[i] = p;
+        map[p] = i;
     }
     /* exp table (ff_tx_mdct_gen_exp) */
-    std::vector<float2> ex(c->inv ? 2 * n : n);
+    std::vector<float2> ex(n);
     {
         const double sc = *scale;
         const double theta = (sc < 0 ? n : 0) + 1.0 / 8.0, rt = sqrt(fabs(sc));
-        float2 *e = ex.data() + (c->inv ? n : 0);
+        float2 *e = ex.data();
         for (int i = 0; i < n; i++) {
             const double alpha = M_PI_2 * (i + theta) / n;
             e[i].x = (float)(cos(alpha) * rt);
             e[i].y = (float)(sin(alpha) * rt);
         }
-        if (c->inv)
-            for (int i = 0; i < n; i++)
-                ex[i] = ex[n + map[i]];
     }
+    /* the map scatters into the padded work array */
+    for (int i = 0; i < n; i++)
+        map[i] = TX_PAD(map[i]);
     /* cosine tables per level (cos(2*pi*k/m), k <= m/4; the last entry is an exact 0) */
     std::vector<float> cosv;
     TxDev &d = c->d;
@@ -473,7 +493,7 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     if (nt == 0)
         return 0;
     const int n = c->d.n;
-    const size_t per_wave = (size_t)n * 24;
+    const size_t per_wave = tx_z_bytes(n) + (size_t)n * 16;
     int wpb = (int)((60 * 1024) / per_wave);
     if (wpb > 4) wpb = 4;
     if (wpb < 1) {
@@ -484,7 +504,7 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     const dim3 grid(cdiv(nt, wpb)), block(64 * wpb);
     /* FFT-level tables in LDS when they fit next to the waves' areas (FFHIP_TX_LDSTAB=0 keeps them in L2) */
     const char *et = getenv("FFHIP_TX_LDSTAB");
-    const size_t ftab_sz = c->blob_bytes - (size_t)((const uint8_t *)c->d.cos_tab - (const uint8_t *)c->dev);
+    const size_t ftab_sz = (size_t)((const uint8_t *)c->d.blocks2 - (const uint8_t *)c->d.cos_tab); /* twiddles + butterfly lists */
     int ftab = 0;
     size_t lds = per_wave * wpb;
     /* measured (profiles/r01_sweep_tx.txt): 174 vs 149 M forward transforms/s with the level tables in LDS */
@@ -495,9 +515,10 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     const char *ev = getenv("FFHIP_TX_PERSISTENT");
     const bool aligned = es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 15);
     const size_t lds_p = ((c->blob_bytes + 15) & ~(size_t)15) + per_wave * 4;
-    /* measured: on par with the one-shot kernel + LDS level tables (171 vs 174 M transforms/s) at 2 workgroups per
-     * CU instead of 3 - kept for experiments, off unless FFHIP_TX_PERSISTENT=1 */
-    if (aligned && lds_p <= 64 * 1024 && ev && ev[0] == '1') {
+    /* measured (profiles/r01_sweep_tx.txt, N = 1024): 180 vs 175 M forward and 247 vs 225 M inverse transforms/s against
+     * the one-shot kernel with LDS level tables - the default for aligned contiguous batches; FFHIP_TX_PERSISTENT=0
+     * selects the one-shot kernel */
+    if (aligned && lds_p <= 64 * 1024 && !(ev && ev[0] == '0')) {
         int cus = 256, dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)

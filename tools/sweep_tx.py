@@ -15,7 +15,7 @@ for inv in (0, 1):
     tin = torch.rand((nt, ln if inv else 2 * ln), dtype=torch.float32, device="cuda:0")
     tout = torch.empty((nt, ln), dtype=torch.float32, device="cuda:0")
     ref = None
-    for env in ({}, {"FFHIP_TX_PERSISTENT": "1"}, {"FFHIP_TX_LDSTAB": "1"}):
+    for env in ({}, {"FFHIP_TX_PERSISTENT": "0"}, {"FFHIP_TX_PERSISTENT": "0", "FFHIP_TX_LDSTAB": "0"}):
         for k in ("FFHIP_TX_PERSISTENT", "FFHIP_TX_LDSTAB"):
             os.environ.pop(k, None)
         os.environ.update(env)
