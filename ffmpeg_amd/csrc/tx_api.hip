@@ -39,6 +39,7 @@ struct TxDev {
     const uint32_t *sched;     /* butterflies: a0 | k << 16, concatenated per level                 */
     const uint16_t *blocks2;   /* offsets of the size-2 blocks                                      */
     int nblocks2;
+    int max_cnt, ahead;        /* largest butterfly list of a level; 1: fetch lists/twiddles one level ahead (FFHIP_TX_AHEAD) */
     int cos_off[16], sched_off[16], sched_cnt[16];
 };
 
@@ -72,6 +73,88 @@ __device__ __forceinline__ void tx_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* ff_tx_fft_sr_combine's TRANSFORM (libavutil/tx_template.c:540-586) on one butterfly: the reference's float
+ * operations in the reference's order */
+__device__ __forceinline__ void tx_butterfly(float2 &v0, float2 &v1, float2 &v2, float2 &v3, float wre, float wim)
+{
+    const float nwim = -wim;
+    const float t1 = v2.x * wre - v2.y * nwim;
+    const float t2 = v2.x * nwim + v2.y * wre;
+    float t5 = v3.x * wre - v3.y * wim;
+    float t6 = v3.x * wim + v3.y * wre;
+    const float t3 = t5 - t1;
+    t5 = t5 + t1;
+    const float t4 = t2 - t6;
+    t6 = t2 + t6;
+    const float2 a = v0, b = v1;
+    v0 = make_float2(a.x + t5, a.y + t6);
+    v1 = make_float2(b.x + t4, b.y + t3);
+    v2 = make_float2(a.x - t5, a.y - t6);
+    v3 = make_float2(b.x - t4, b.y - t3);
+}
+
+/*
+ * The levels of the in-place split-radix FFT when no level has more than 64*MI butterflies (N <= 1024: MI = 2).
+ * A level's critical path would be  list entry -> twiddles + operands -> arithmetic -> write-back, i.e. two dependent
+ * LDS round trips before any arithmetic; the list entries and twiddles do not depend on the data, so they are
+ * fetched one level AHEAD, in the shadow of the previous level's arithmetic and barrier.
+ */
+template <int MI>
+__device__ __forceinline__ void tx_fft_levels_ahead(float2 *z, const TxDev &d, const float *cos_tab, const uint32_t *sched, int lane)
+{
+    uint32_t e[MI];
+    float wre[MI], wim[MI];
+    auto load_entries = [&](int l, uint32_t (&E)[MI]) {
+        const uint32_t *sc = sched + d.sched_off[l];
+        const int cnt = d.sched_cnt[l];
+#pragma unroll
+        for (int j = 0; j < MI; j++)
+            E[j] = lane + 64 * j < cnt ? sc[lane + 64 * j] : 0xFFFFFFFFu;
+    };
+    auto load_twiddles = [&](int l, const uint32_t (&E)[MI], float (&R)[MI], float (&I)[MI]) {
+        const int q = 1 << (l - 2);
+        const float *tab = cos_tab + d.cos_off[l];
+#pragma unroll
+        for (int j = 0; j < MI; j++) {
+            const int k = E[j] == 0xFFFFFFFFu ? 0 : (int)(E[j] >> 16);
+            R[j] = tab[k];
+            I[j] = tab[q - k];
+        }
+    };
+    load_entries(2, e);
+    load_twiddles(2, e, wre, wim);
+    for (int l = 2; l <= d.lg; l++) {
+        tx_wave_sync();
+        const int q = 1 << (l - 2);
+        const int o1 = TX_PAD(q), o2 = TX_PAD(2 * q), o3 = TX_PAD(3 * q);
+        float2 v[MI][4];
+#pragma unroll
+        for (int j = 0; j < MI; j++) {
+            const int a0 = e[j] == 0xFFFFFFFFu ? 0 : (int)(e[j] & 0xFFFF);
+            v[j][0] = z[a0]; v[j][1] = z[a0 + o1]; v[j][2] = z[a0 + o2]; v[j][3] = z[a0 + o3];
+        }
+        uint32_t en[MI];
+        float nr[MI], ni[MI];
+        if (l < d.lg)
+            load_entries(l + 1, en);
+#pragma unroll
+        for (int j = 0; j < MI; j++) {
+            tx_butterfly(v[j][0], v[j][1], v[j][2], v[j][3], wre[j], wim[j]);
+            if (e[j] != 0xFFFFFFFFu) {
+                const int a0 = (int)(e[j] & 0xFFFF);
+                z[a0] = v[j][0]; z[a0 + o1] = v[j][1]; z[a0 + o2] = v[j][2]; z[a0 + o3] = v[j][3];
+            }
+        }
+        if (l < d.lg) {
+            load_twiddles(l + 1, en, nr, ni);
+#pragma unroll
+            for (int j = 0; j < MI; j++) {
+                e[j] = en[j]; wre[j] = nr[j]; wim[j] = ni[j];
+            }
+        }
+    }
+}
+
 /* in-place split-radix FFT of z[0..n) held in LDS, one wave */
 __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, const float *cos_tab, const uint32_t *sched,
                                            const uint16_t *blocks2, int lane)
@@ -82,6 +165,11 @@ __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, const floa
         z[o] = make_float2(x.x + y.x, x.y + y.y);
         z[o + 1] = make_float2(x.x - y.x, x.y - y.y);
     }
+    if (d.max_cnt <= 128 && d.ahead) {
+        tx_fft_levels_ahead<2>(z, d, cos_tab, sched, lane);
+        tx_wave_sync();
+        return;
+    }
     for (int l = 2; l <= d.lg; l++) {
         tx_wave_sync();
         const int q = 1 << (l - 2);
@@ -91,21 +179,9 @@ __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, const floa
         for (int b = lane; b < d.sched_cnt[l]; b += 64) {
             const uint32_t e = sc[b];
             const int a0 = e & 0xFFFF, k = e >> 16;
-            const float wre = tab[k], wim = tab[q - k], nwim = -wim;
-            const float2 v0 = z[a0], v1 = z[a0 + o1], v2 = z[a0 + o2], v3 = z[a0 + o3];
-            /* ff_tx_fft_sr_combine's TRANSFORM: libavutil/tx_template.c:540-586 */
-            const float t1 = v2.x * wre - v2.y * nwim;
-            const float t2 = v2.x * nwim + v2.y * wre;
-            float t5 = v3.x * wre - v3.y * wim;
-            float t6 = v3.x * wim + v3.y * wre;
-            const float t3 = t5 - t1;
-            t5 = t5 + t1;
-            const float t4 = t2 - t6;
-            t6 = t2 + t6;
-            z[a0]      = make_float2(v0.x + t5, v0.y + t6);
-            z[a0 + o1] = make_float2(v1.x + t4, v1.y + t3);
-            z[a0 + o2] = make_float2(v0.x - t5, v0.y - t6);
-            z[a0 + o3] = make_float2(v1.x - t4, v1.y - t3);
+            float2 v0 = z[a0], v1 = z[a0 + o1], v2 = z[a0 + o2], v3 = z[a0 + o3];
+            tx_butterfly(v0, v1, v2, v3, tab[k], tab[q - k]);
+            z[a0] = v0; z[a0 + o1] = v1; z[a0 + o2] = v2; z[a0 + o3] = v3;
         }
     }
     tx_wave_sync();
@@ -340,6 +416,91 @@ __global__ __launch_bounds__(256) void k_mdct_l(TxDev d, const uint8_t *blob, in
     }
 }
 
+/*
+ * k_mdct_z — the kernel for contiguous, 8-byte aligned batches: no staging area at all, only the padded work array
+ * (4.1 KiB at N = 1024) per wave, so 20 waves fit a CU instead of 12 (the transform is a chain of dependent LDS round
+ * trips; PMC had LDS 40 %, VALU 30 %, HBM 27 % busy - more waves in flight is what it lacked).
+ *   - fold / pre-twiddle straight from global memory: work-array elements i and n-1-i read the two halves of the
+ *     SAME four (forward) or two (inverse) float2 pairs of the input, so one lane produces both from coalesced 8-byte
+ *     loads and every input byte is loaded exactly once;
+ *   - post-twiddle straight to global memory: outputs (2*i1, 2*i1+1) and (2*i0, 2*i0+1) leave as two coalesced 8-byte
+ *     stores.
+ * Tables (map, exp, twiddles, butterfly lists) are copied to LDS once per workgroup; waves loop over transforms.
+ * Same float operations in the same order as k_mdct.
+ */
+template <int INV>
+__global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch,
+                                                 float *out, size_t out_pitch, int nt, int waves_total)
+{
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
+        for (int i = threadIdx.x; i < blob_bytes / 16; i += blockDim.x)
+            l4[i] = s4[i];
+    }
+    __syncthreads();
+    const int *l_map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    const float2 *l_exp = reinterpret_cast<const float2 *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
+    const float *l_cos = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    const int n = d.n, q = n >> 1;
+    float2 *z = reinterpret_cast<float2 *>(lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(n));
+
+    for (int t = blockIdx.x * (blockDim.x >> 6) + wave; t < nt; t += waves_total) {
+        const float2 *in2 = reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
+        float2 *out2 = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
+        if (!INV) {
+            /* ff_tx_mdct_fwd's fold (tx_template.c:1285-1296), elements i (k = 2i < n) and n-1-i (k >= n) together */
+            for (int i = lane; i < q; i += 64) {
+                const float2 p1 = in2[q + i];          /* x[n+2i],   x[n+2i+1]   */
+                const float2 p2 = in2[q - 1 - i];      /* x[n-2-2i], x[n-1-2i]   */
+                const float2 p3 = in2[3 * q + i];      /* x[3n+2i],  x[3n+2i+1]  */
+                const float2 p4 = in2[3 * q - 1 - i];  /* x[3n-2-2i], x[3n-1-2i] */
+                const int j = n - 1 - i;
+                const float re0 = -p1.x + p2.y, im0 = -p3.x + -p4.y;
+                const float re1 = -p4.x + -p3.y, im1 = p2.x + -p1.y;
+                const float2 e0 = l_exp[i], e1 = l_exp[j];
+                z[l_map[i]] = make_float2(re0 * e0.y + im0 * e0.x, re0 * e0.x - im0 * e0.y);
+                z[l_map[j]] = make_float2(re1 * e1.y + im1 * e1.x, re1 * e1.x - im1 * e1.y);
+            }
+        } else {
+            /* ff_tx_mdct_inv's pre-twiddle (tx_template.c:1321-1328) in input order, elements j and n-1-j together */
+            for (int j = lane; j < q; j += 64) {
+                const float2 f = in2[j];               /* x[2j],      x[2j+1]     */
+                const float2 g = in2[n - 1 - j];       /* x[2n-2-2j], x[2n-1-2j]  */
+                const int j1 = n - 1 - j;
+                const float2 e0 = l_exp[j], e1 = l_exp[j1];
+                z[l_map[j]] = make_float2(g.y * e0.x - f.x * e0.y, g.y * e0.y + f.x * e0.x);
+                z[l_map[j1]] = make_float2(f.y * e1.x - g.x * e1.y, f.y * e1.y + g.x * e1.x);
+            }
+        }
+        tx_wave_sync();
+        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
+        for (int i = lane; i < q; i += 64) {
+            const int i0 = q + i, i1 = q - i - 1;
+            const float2 e0 = l_exp[i0], e1 = l_exp[i1];
+            if (!INV) {
+                const float2 s1 = z[TX_PAD(i1)], s0 = z[TX_PAD(i0)];
+                const float a = s0.x * e0.y - s0.y * e0.x, b = s0.x * e0.x + s0.y * e0.y;
+                const float c = s1.x * e1.y - s1.y * e1.x, f = s1.x * e1.x + s1.y * e1.y;
+                out2[i1] = make_float2(f, a);
+                out2[i0] = make_float2(b, c);
+            } else {
+                const float2 z1 = z[TX_PAD(i1)], z0 = z[TX_PAD(i0)], s1 = make_float2(z1.y, z1.x), s0 = make_float2(z0.y, z0.x);
+                const float a = s1.x * e1.y - s1.y * e1.x, b = s1.x * e1.x + s1.y * e1.y;
+                const float c = s0.x * e0.y - s0.y * e0.x, f = s0.x * e0.x + s0.y * e0.y;
+                out2[i1] = make_float2(a, f);
+                out2[i0] = make_float2(c, b);
+            }
+        }
+        tx_wave_sync();
+    }
+}
+
 /* ---- host: tables ------------------------------------------------------------------------------- */
 static int sr_perm(int i, int len, int inv)
 {
@@ -454,6 +615,12 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         sched.insert(sched.end(), lev[l].begin(), lev[l].end());
     }
     d.nblocks2 = (int)b2.size();
+    for (int l = 2; l <= lg; l++)
+        d.max_cnt = d.sched_cnt[l] > d.max_cnt ? d.sched_cnt[l] : d.max_cnt;
+    {
+        const char *ea = getenv("FFHIP_TX_AHEAD");
+        d.ahead = ea && ea[0] == '1'; /* measured slightly slower (350 vs 345 M transforms/s): opt-in */
+    }
     /* one device allocation for all tables */
     size_t off_map = 0, off_exp, off_cos, off_sched, off_b2, total;
     off_exp = (off_map + map.size() * 4 + 15) & ~(size_t)15;
@@ -511,6 +678,44 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     if (!(et && et[0] == '0') && lds + ftab_sz <= 64 * 1024) {
         ftab = (int)ftab_sz;
         lds += ftab_sz;
+    }
+    /* contiguous 8-byte aligned batches: the staging-free kernel (FFHIP_TX_Z=0 selects the older ones) */
+    {
+        const char *ez = getenv("FFHIP_TX_Z");
+        const char *ew = getenv("FFHIP_TX_WPB");
+        int wpb = ew && atoi(ew) > 0 ? atoi(ew) : 16; /* waves per workgroup: 16 measured best (the table copy is shared) */
+        if (wpb > 16) wpb = 16;
+        size_t lds_z = ((c->blob_bytes + 15) & ~(size_t)15) + tx_z_bytes(n) * wpb;
+        while (wpb > 1 && lds_z > 150 * 1024) {
+            wpb >>= 1;
+            lds_z = ((c->blob_bytes + 15) & ~(size_t)15) + tx_z_bytes(n) * wpb;
+        }
+        if (es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7) && lds_z <= 150 * 1024 && !(ez && ez[0] == '0')) {
+            int cus = 256, dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount;
+            int per_cu = (int)((160 * 1024) / (((lds_z + 1279) / 1280) * 1280));
+            if (per_cu * wpb > 32) per_cu = 32 / wpb;
+            if (per_cu < 1) per_cu = 1;
+            int blocks = cus * per_cu;
+            if (blocks > (nt + wpb - 1) / wpb)
+                blocks = (nt + wpb - 1) / wpb;
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void *)k_mdct_z<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_mdct_z<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_done = true;
+            }
+            if (c->inv)
+                hipLaunchKernelGGL((k_mdct_z<1>), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
+                                   (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+            else
+                hipLaunchKernelGGL((k_mdct_z<0>), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
+                                   (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+            LAUNCH_CHECK();
+            return 0;
+        }
     }
     const char *ev = getenv("FFHIP_TX_PERSISTENT");
     const bool aligned = es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 15);
