@@ -18,6 +18,8 @@
  * one dword.  mcXY is wave-uniform, so only the taps a position needs are computed.
  * Algorithmic traffic 2 B per sample (reference read once + destination write).
  */
+#include <stdlib.h>
+
 #include "common.h"
 #include "h264_kernels.h"
 
@@ -138,12 +140,189 @@ __global__ __launch_bounds__(256) void k_h264_qpel(uint8_t *dst, const uint8_t *
     }
 }
 
+/* ================================================================================================== */
+/*
+ * k_h264_qpel_l — the same functions with the block's source footprint and its horizontal 6-tap sums SHARED through
+ * wave-private LDS (stride % 4 == 0).  In the kernel above every lane filters the six source rows under its samples
+ * horizontally by itself: at the centre positions (J) a horizontal sum is recomputed by the six lanes stacked on it
+ * and the kernel is VALU-bound on that redundancy (PMC: ~130 instructions per sample at mc22).  Here
+ *   1. the wave copies the (size+5) x (size+5) footprint once, as aligned dwords, into LDS (672 B);
+ *   2. if the position needs J, its lanes compute each UNCLIPPED horizontal sum once — packed 16-bit arithmetic, two
+ *      samples per instruction (|tap6| <= 10710 fits int16) — into an int16 LDS plane (672 B);
+ *   3. lane (y, xg) assembles its four samples: J = vertical tap6 over six int16 rows, H from its own row, V from
+ *      the raw rows (packed 16-bit again), F by a funnel shift; quarter positions by the packed rnd_avg32 identity.
+ * A wave executes its LDS operations in order and shares nothing with other waves: no barrier.
+ */
+typedef short qp_s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ qp_s2 qp_pair(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    return __builtin_bit_cast(qp_s2, __builtin_amdgcn_perm(hi, lo, sel));
+}
+__device__ __forceinline__ qp_s2 qp_tap6(qp_s2 a, qp_s2 b, qp_s2 c, qp_s2 d, qp_s2 e, qp_s2 f)
+{
+    return (c + d) * (short)20 - (b + e) * (short)5 + (a + f);
+}
+/* unclipped horizontal sums of the 4 samples whose stream (byte 0 = x-2) is r: (s0,s1) and (s2,s3) as int16 pairs */
+__device__ __forceinline__ void qp_hraw4(const Row12 &r, qp_s2 &lo, qp_s2 &hi)
+{
+    const qp_s2 p01 = qp_pair(r.w[1], r.w[0], 0x0c010c00), p12 = qp_pair(r.w[1], r.w[0], 0x0c020c01);
+    const qp_s2 p23 = qp_pair(r.w[1], r.w[0], 0x0c030c02), p34 = qp_pair(r.w[1], r.w[0], 0x0c040c03);
+    const qp_s2 p45 = qp_pair(r.w[1], r.w[0], 0x0c050c04), p56 = qp_pair(r.w[1], r.w[0], 0x0c060c05);
+    const qp_s2 p67 = qp_pair(r.w[1], r.w[0], 0x0c070c06), p78 = qp_pair(r.w[2], r.w[1], 0x0c040c03);
+    lo = qp_tap6(p01, p12, p23, p34, p45, p56);
+    hi = qp_tap6(p23, p34, p45, p56, p67, p78);
+}
+/* clip_u8((v + 16) >> 5) of four packed int16 sums -> 4 bytes */
+__device__ __forceinline__ uint32_t qp_round5(qp_s2 lo, qp_s2 hi)
+{
+    const qp_s2 k16 = { 16, 16 }, z = { 0, 0 }, m = { 255, 255 };
+    qp_s2 a = (lo + k16) >> (short)5, b = (hi + k16) >> (short)5;
+    a = __builtin_elementwise_min(__builtin_elementwise_max(a, z), m);
+    b = __builtin_elementwise_min(__builtin_elementwise_max(b, z), m);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x06040200);
+}
+
+__global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
+                                                     const FFHipQpelBlock *blocks, int n)
+{
+    __shared__ uint32_t lds[4][21 * 8 + 21 * 8];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= n)
+        return;
+    uint32_t *raw = lds[wave];             /* [row][8] aligned source dwords, row 0 = y-2 */
+    uint32_t *hb = lds[wave] + 21 * 8;     /* [row][8] int16 pairs: unclipped horizontal sums of the block's columns */
+    const FFHipQpelBlock blk = blocks[b];
+    const int size = 16 >> __builtin_amdgcn_readfirstlane((int)blk.size_idx);
+    const int mc = __builtin_amdgcn_readfirstlane((int)blk.mcxy) & 15;
+    const bool avg = __builtin_amdgcn_readfirstlane((int)blk.avg) != 0;
+    const int soff = __builtin_amdgcn_readfirstlane(blk.src_offset), doff = __builtin_amdgcn_readfirstlane(blk.dst_offset);
+    const int per_row = size >> 2, rows = size + 5;
+    const int mx = mc & 3, my = mc >> 2;
+    const bool useJ = (mx == 2 && my != 0) || (my == 2 && mx != 0);
+    const bool useV = (mx != 2 && my != 0) || (mc == 8);
+    const bool useH = (my != 2 && mx != 0) || (mc == 2);
+    const bool vcol1 = mx == 3, hrow1 = my == 3;
+
+    /* ---- 1. footprint -> LDS: rows y-2 .. y+size+2, the aligned dwords that hold bytes x-2 .. x+size+2 ---- */
+    const uint8_t *s0 = src + soff - 2 - 2 * stride;
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 3); /* same for every row: stride % 4 == 0 */
+    const uint8_t *sa = s0 - sh;
+    const int ndw = (int)((sh + size + 5 + 3) >> 2);                     /* <= 7 */
+    for (int t = lane; t < rows * 8; t += 64) {
+        const int r = t >> 3, j = t & 7;
+        if (j < ndw)
+            raw[t] = *reinterpret_cast<const uint32_t *>(sa + (ptrdiff_t)r * stride + 4 * j);
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto stream = [&](int row, int xg) { /* 12 bytes from byte x-2+4*xg of a footprint row */
+        const uint32_t *q = raw + row * 8 + xg;
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        const uint32_t d3 = sh == 3 ? q[3] : 0;
+        Row12 r;
+        r.w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        r.w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        r.w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        return r;
+    };
+
+    /* ---- 2. horizontal sums of every footprint row, once ---- */
+    if (useJ) {
+        for (int t = lane; t < rows * per_row; t += 64) {
+            const int r = t / per_row, xg = t - r * per_row;
+            qp_s2 lo, hi;
+            qp_hraw4(stream(r, xg), lo, hi);
+            *reinterpret_cast<uint2 *>(hb + r * 8 + 2 * xg) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    /* ---- 3. my four samples ---- */
+    const int y = lane / per_row, xg = lane - y * per_row;
+    if (y >= size)
+        return;
+    uint8_t *d = dst + doff + (ptrdiff_t)y * stride + 4 * xg;
+    uint32_t pj = 0, ph = 0, pv = 0, pf = 0;
+    if (useJ) {
+        uint2 h[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            h[k] = *reinterpret_cast<const uint2 *>(hb + (y + k) * 8 + 2 * xg);
+        int v[4];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            auto col = [&](int k) { return __builtin_bit_cast(qp_s2, half ? h[k].y : h[k].x); };
+            const qp_s2 s23 = col(2) + col(3), s14 = col(1) + col(4), s05 = col(0) + col(5); /* |.| <= 21420: int16 */
+            v[2 * half]     = (int)s23.x * 20 - (int)s14.x * 5 + (int)s05.x;
+            v[2 * half + 1] = (int)s23.y * 20 - (int)s14.y * 5 + (int)s05.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            pj |= (uint32_t)clip_u8((v[i] + 512) >> 10) << (8 * i);
+        if (useH) {
+            const uint2 hr = h[hrow1 ? 3 : 2];
+            ph = qp_round5(__builtin_bit_cast(qp_s2, hr.x), __builtin_bit_cast(qp_s2, hr.y));
+        }
+    } else if (useH) {
+        qp_s2 lo, hi;
+        qp_hraw4(stream(y + (hrow1 ? 3 : 2), xg), lo, hi);
+        ph = qp_round5(lo, hi);
+    }
+    if (useV) {
+        /* the column under sample i: stream byte 2 + i (3 + i for the right-hand neighbour) of rows y-2 .. y+3 */
+        const uint32_t o = sh + 2 + (vcol1 ? 1 : 0);
+        qp_s2 c01[6], c23[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint32_t *q = raw + (y + k) * 8 + xg + (o >> 2);
+            const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3);
+            c01[k] = qp_pair(0, w, 0x0c010c00);
+            c23[k] = qp_pair(0, w, 0x0c030c02);
+        }
+        pv = qp_round5(qp_tap6(c01[0], c01[1], c01[2], c01[3], c01[4], c01[5]), qp_tap6(c23[0], c23[1], c23[2], c23[3], c23[4], c23[5]));
+    }
+    {
+        const uint32_t o = sh + (mc == 3 ? 3 : 2);
+        const uint32_t *q = raw + (y + (mc == 12 ? 3 : 2)) * 8 + xg + (o >> 2);
+        pf = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3);
+    }
+    uint32_t out;
+    switch (mc) {
+    case 0:  out = pf; break;
+    case 1: case 3:  out = rnd_avg4(pf, ph); break;
+    case 2:  out = ph; break;
+    case 4: case 12: out = rnd_avg4(pf, pv); break;
+    case 5: case 7: case 13: case 15: out = rnd_avg4(ph, pv); break;
+    case 6: case 14: out = rnd_avg4(ph, pj); break;
+    case 8:  out = pv; break;
+    case 9: case 11: out = rnd_avg4(pv, pj); break;
+    default: out = pj; break; /* 10 */
+    }
+    if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
+        uint32_t *dw = reinterpret_cast<uint32_t *>(d);
+        if (avg)
+            out = rnd_avg4(*dw, out);
+        *dw = out;
+    } else {
+        for (int i = 0; i < 4; i++) {
+            const uint32_t v = (out >> (8 * i)) & 0xFF;
+            d[i] = (uint8_t)(avg ? (d[i] + v + 1) >> 1 : v);
+        }
+    }
+}
+
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
                            hipStream_t stream)
 {
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(k_h264_qpel, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+    const char *eo = getenv("FFHIP_QPEL_OLD"); /* measured variant: the register-only kernel */
+    if (!(stride & 3) && !(eo && eo[0] == '1'))
+        hipLaunchKernelGGL(k_h264_qpel_l, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+    else
+        hipLaunchKernelGGL(k_h264_qpel, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
     LAUNCH_CHECK();
     return 0;
 }
