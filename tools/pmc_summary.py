@@ -40,5 +40,6 @@ for k, cs in acc.items():
                      % (100 * avg.get("SQ_ACTIVE_INST_ANY", 0) / w, 100 * avg.get("SQ_WAIT_INST_ANY", 0) / w,
                         100 * avg.get("SQ_WAIT_ANY", 0) / w))
 open(os.path.join(root, "profiles", tag + "_pmc.txt"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(out_dir, tag + "_pmc.txt"), "w").write("\n".join(lines) + "\n")  # gpurun merges only gpurun_out/ back
 json.dump(js, open(os.path.join(root, "profiles", tag + "_pmc.json"), "w"), indent=1)
 print("\n".join(lines))
