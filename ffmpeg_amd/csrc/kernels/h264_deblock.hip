@@ -171,37 +171,72 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t
         else
             own = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
     };
+    /* the MB's 8 edge records (96 bytes) likewise: one dword per lane, handed to the filters through LDS — read from
+     * global memory inside the edge loops they were eight dependent round trips per macroblock */
+    __shared__ uint32_t edl[24];
+    uint32_t edw = 0;
+    auto fetch_edges = [&](int mx) {
+        if (lane < 24)
+            edw = reinterpret_cast<const uint32_t *>(edges + (size_t)(my * mb_w + mx) * 8)[lane];
+    };
+    /* rows -4..-1 over this MB, written by the wave of row my-1: coherent (agent-scope) loads, because a later MB's
+     * context shares cache lines with an earlier one's and no acquire may lie in between (see `known`) */
+    auto load_top = [&](int mx) {
+        uint32_t v = 0;
+        if (lane < 16) {
+            const uint8_t *p = rowbase + mx * 16 + (ptrdiff_t)(pr - 4) * stride + pc;
+            if (dw_ok)
+                v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        }
+        return v;
+    };
+    int known = 0;          /* last value seen of progress[my-1] (acquire): polled only when it is not enough */
+    bool have_top = false;  /* topv already holds this MB's context rows (fetched while the previous MB was filtered) */
+    uint32_t topv = 0;
     fetch_own(0);
+    fetch_edges(0);
     for (int mx = 0; mx < mb_w; mx++) {
         uint8_t *mb = rowbase + mx * 16;
         *reinterpret_cast<uint32_t *>(&tile[(pr + 4) * TP + 4 + pc]) = own;
-        if (mx + 1 < mb_w)
+        if (lane < 24)
+            edl[lane] = edw;
+        if (mx + 1 < mb_w) {
             fetch_own(mx + 1);
+            fetch_edges(mx + 1);
+        }
         /* ---- wait for the row above: MB (mx+1, my-1) done, i.e. progress[my-1] >= min(mx+2, mb_w) ---- */
         if (my > 0) {
             const int want = min(mx + 2, mb_w);
-            int spins = 0;
-            while (__hip_atomic_load(&progress[my - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
-                    if (lane == 0)
-                        atomicExch(fail, 1);
-                    return;
+            if (!have_top || !dw_ok) {
+                int spins = 0;
+                while (known < want) {
+                    known = __hip_atomic_load(&progress[my - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (known >= want)
+                        break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                        if (lane == 0)
+                            atomicExch(fail, 1);
+                        return;
+                    }
                 }
+                if (!dw_ok) /* byte loads go through L1: always behind a fresh acquire */
+                    known = __hip_atomic_load(&progress[my - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                topv = load_top(mx);
             }
-            /* the 4 rows above, columns 0..15 (written by the wave of row my-1) */
-            if (lane < 16) {
-                const uint8_t *p = mb + (ptrdiff_t)(pr - 4) * stride + pc;
-                uint32_t v;
-                if (dw_ok)
-                    v = *reinterpret_cast<const uint32_t *>(p);
-                else
-                    v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-                *reinterpret_cast<uint32_t *>(&tile[pr * TP + 4 + pc]) = v;
+            if (lane < 16)
+                *reinterpret_cast<uint32_t *>(&tile[pr * TP + 4 + pc]) = topv;
+            /* the next MB's context, if the row above has already published it */
+            have_top = false;
+            if (dw_ok && mx + 1 < mb_w && known >= min(mx + 3, mb_w)) {
+                topv = load_top(mx + 1);
+                have_top = true;
             }
         }
         wave_lds_sync();
-        const FFHipH264Edge *e = edges + (size_t)(my * mb_w + mx) * 8;
+        const FFHipH264Edge *e = reinterpret_cast<const FFHipH264Edge *>(edl);
         /* ---- vertical edges, left to right: lane = row ---- */
         for (int k = 0; k < 4; k++) {
             const FFHipH264Edge ed = e[k];
