@@ -18,6 +18,8 @@
  * registers; the wave then reduces (cost, raster index) with a 64-bit min.  The search is VALU-bound
  * (111 abs-diff per byte of traffic at R=7), not HBM-bound: each frame byte is read from HBM once.
  */
+#include <stdlib.h>
+
 #include "common.h"
 #include "me_kernels.h"
 
@@ -119,7 +121,77 @@ int ffhip_launch_me_cmp(int kind, int width, int h, const uint8_t *blk1, const i
 }
 
 /* ---- exhaustive search: one wave per macroblock --------------------------------------------------- */
-template <int KIND, int MB>
+typedef short me_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short me_u2 __attribute__((ext_vector_type(2)));
+
+/* 8-point Hadamard of 8 bytes down a column (stride bytes apart), packed as four int16 pairs (c0,c1)(c2,c3)... */
+template <typename P>
+__device__ __forceinline__ uint4 me_hadamard_col(P p, int stride)
+{
+    int t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        t[j] = p[j * stride];
+#pragma unroll
+    for (int span = 1; span < 8; span <<= 1)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (!(i & span)) {
+                const int a = t[i], b = t[i + span];
+                t[i] = a + b;
+                t[i + span] = a - b;
+            }
+    uint4 o;
+    o.x = (uint32_t)(t[0] & 0xFFFF) | ((uint32_t)t[1] << 16);
+    o.y = (uint32_t)(t[2] & 0xFFFF) | ((uint32_t)t[3] << 16);
+    o.z = (uint32_t)(t[4] & 0xFFFF) | ((uint32_t)t[5] << 16);
+    o.w = (uint32_t)(t[6] & 0xFFFF) | ((uint32_t)t[7] << 16);
+    return o;
+}
+
+/*
+ * sum |H8 (a - b) H8^T| of one 8x8 block from the VERTICAL Hadamard columns of a and of b (me_hadamard_col): the
+ * transform is separable and exact in integers, so H(a) - H(b) = H(a - b) and the order of the two passes is free.
+ * The horizontal pass runs across the 8 columns on packed int16 pairs (|coefficient| <= 255 * 64 < 2^15); its last
+ * stage and the absolute sum use |p + q| + |p - q| = 2 max(|p|, |q|).  Returns HALF the sum.
+ */
+__device__ __forceinline__ uint32_t me_satd8_cols(const uint4 *va, const uint4 *vb, uint32_t acc)
+{
+    me_s2 d[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint4 a = va[j], b = vb[j];
+        d[j][0] = __builtin_bit_cast(me_s2, a.x) - __builtin_bit_cast(me_s2, b.x);
+        d[j][1] = __builtin_bit_cast(me_s2, a.y) - __builtin_bit_cast(me_s2, b.y);
+        d[j][2] = __builtin_bit_cast(me_s2, a.z) - __builtin_bit_cast(me_s2, b.z);
+        d[j][3] = __builtin_bit_cast(me_s2, a.w) - __builtin_bit_cast(me_s2, b.w);
+    }
+#pragma unroll
+    for (int span = 1; span < 4; span <<= 1)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (!(i & span))
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const me_s2 p = d[i][m], q = d[i + span][m];
+                    d[i][m] = p + q;
+                    d[i + span][m] = p - q;
+                }
+    const me_s2 zero = { 0, 0 };
+    const me_u2 ones = { 1, 1 };
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const me_s2 p = d[i][m], q = d[i + 4][m];
+            const me_s2 ap = __builtin_elementwise_max(p, zero - p), aq = __builtin_elementwise_max(q, zero - q);
+            const me_s2 mx = __builtin_elementwise_max(ap, aq);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(me_u2, mx), ones, acc, false);
+        }
+    return acc;
+}
+
+template <int KIND, int MB, bool SHARE = false>
 __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int height, ptrdiff_t stride,
                                                size_t frame_pitch, int R, int16_t *mv_out, uint32_t *cost_out)
 {
@@ -146,6 +218,21 @@ __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t
         win[r * pitch + c] = rf[(ptrdiff_t)(y0 + r) * stride + x0 + c];
     }
     __syncthreads();
+    /* SATD with SHARED column transforms: the vertical Hadamard of a window column segment (8 rows) serves the 8
+     * candidates that contain it, so it is computed once per macroblock into LDS — va: the current block's columns
+     * per 8-row band, vb[r][c]: window column c, rows r..r+7 */
+    uint4 *va = reinterpret_cast<uint4 *>(lds + ((MB * MB + (2 * R + MB) * pitch + 15) & ~15));
+    uint4 *vb = va + (MB / 8) * MB;
+    const int vrows = wrows - 7;
+    if (SHARE) {
+        for (int i = lane; i < (MB / 8) * MB; i += 64)
+            va[i] = me_hadamard_col(cblk + (i / MB) * 8 * MB + (i % MB), MB);
+        for (int i = lane; i < vrows * wcols; i += 64) {
+            const int r = i / wcols, c = i - r * wcols;
+            vb[i] = me_hadamard_col(win + r * pitch + c, pitch);
+        }
+        __syncthreads();
+    }
 
     uint32_t best = 0xFFFFFFFFu, best_ci = 0xFFFFFFFFu, cost0 = 0;
     const int ci0 = (y_mb - y0) * ncx + (x_mb - x0);
@@ -169,6 +256,14 @@ __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t
             } else {
                 cost = (uint32_t)sad_bytes(cblk, MB, cand, pitch, MB, MB);
             }
+        } else if (SHARE) {
+            uint32_t half = 0;
+#pragma unroll
+            for (int sy = 0; sy < MB / 8; sy++)
+#pragma unroll
+                for (int sx = 0; sx < MB / 8; sx++)
+                    half = me_satd8_cols(va + sy * MB + 8 * sx, vb + (cy + 8 * sy) * wcols + cx + 8 * sx, half);
+            cost = 2 * half;
         } else {
             cost = (uint32_t)satd_block(cblk, MB, cand, pitch, MB, MB);
         }
@@ -223,7 +318,17 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
     if (cost_kind == FFHIP_ME_SAD) {
         if (mb_size == 16) ESA(FFHIP_ME_SAD, 16); else ESA(FFHIP_ME_SAD, 8);
     } else {
-        if (mb_size == 16) ESA(FFHIP_ME_SATD, 16); else ESA(FFHIP_ME_SATD, 8);
+        /* shared column transforms when their LDS plane fits (R <= 24 at 16x16); FFHIP_ME_SATD_SHARE=0: per-candidate */
+        const char *es = getenv("FFHIP_ME_SATD_SHARE");
+        const size_t vsz = ((size_t)(mb_size / 8) * mb_size + (size_t)(2 * R + mb_size - 7) * (2 * R + mb_size)) * 16;
+        const size_t lds_s = ((lds + 15) & ~(size_t)15) + vsz;
+        if (lds_s <= 64 * 1024 && !(es && es[0] == '0')) {
+#define ESAS(M) hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SATD, M, true>), grid, block, lds_s, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out)
+            if (mb_size == 16) ESAS(16); else ESAS(8);
+#undef ESAS
+        } else {
+            if (mb_size == 16) ESA(FFHIP_ME_SATD, 16); else ESA(FFHIP_ME_SATD, 8);
+        }
     }
 #undef ESA
     LAUNCH_CHECK();
