@@ -191,7 +191,7 @@ __device__ __forceinline__ uint32_t me_satd8_cols(const uint4 *va, const uint4 *
     return acc;
 }
 
-template <int KIND, int MB, bool SHARE = false>
+template <int KIND, int MB, bool SHARE = false, int QUAD = 0>
 __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int height, ptrdiff_t stride,
                                                size_t frame_pitch, int R, int16_t *mv_out, uint32_t *cost_out)
 {
@@ -211,11 +211,34 @@ __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t
     uint8_t *win = lds + MB * MB;
     const uint8_t *cf = cur + (size_t)f * frame_pitch, *rf = ref + (size_t)f * frame_pitch;
 
-    for (int i = lane; i < MB * MB; i += 64)
-        cblk[i] = cf[(ptrdiff_t)(y_mb + i / MB) * stride + x_mb + i % MB];
-    for (int i = lane; i < wrows * wcols; i += 64) {
-        const int r = i / wcols, c = i - r * wcols;
-        win[r * pitch + c] = rf[(ptrdiff_t)(y0 + r) * stride + x0 + c];
+    /* staging with dword loads at byte-exact (unaligned) global addresses, no division: lane -> (row, dword) through a
+     * power-of-two dwords-per-row; the dword that would cross the right picture edge is fetched bytewise */
+    {
+        constexpr int DPR = MB / 4;
+        for (int i = lane; i < MB * DPR; i += 64) {
+            const int r = i / DPR, j = i % DPR;
+            const uint8_t *p = cf + (ptrdiff_t)(y_mb + r) * stride + x_mb + 4 * j;
+            uint32_t v;
+            __builtin_memcpy(&v, p, 4);
+            *reinterpret_cast<uint32_t *>(cblk + r * MB + 4 * j) = v;
+        }
+        const int dwr = (wcols + 3) >> 2;
+        int lg = 3;
+        while ((1 << lg) < dwr)
+            lg++;
+        for (int i = lane; i < (wrows << lg); i += 64) {
+            const int r = i >> lg, j = i & ((1 << lg) - 1);
+            if (j < dwr) {
+                const int xb = x0 + 4 * j;
+                const uint8_t *p = rf + (ptrdiff_t)(y0 + r) * stride + xb;
+                uint32_t v;
+                if (xb + 4 <= width)
+                    __builtin_memcpy(&v, p, 4);
+                else
+                    v = (uint32_t)p[0] | (xb + 1 < width ? (uint32_t)p[1] << 8 : 0) | (xb + 2 < width ? (uint32_t)p[2] << 16 : 0);
+                *reinterpret_cast<uint32_t *>(win + r * pitch + 4 * j) = v;
+            }
+        }
     }
     __syncthreads();
     /* SATD with SHARED column transforms: the vertical Hadamard of a window column segment (8 rows) serves the 8
@@ -236,6 +259,70 @@ __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t
 
     uint32_t best = 0xFFFFFFFFu, best_ci = 0xFFFFFFFFu, cost0 = 0;
     const int ci0 = (y_mb - y0) * ncx + (x_mb - x0);
+    int l0 = ci0 & 63; /* the lane that meets the zero-MV candidate */
+    if (QUAD) {
+        /* SAD 16x16, four horizontally adjacent candidates per lane: their rows are the same five ALIGNED window dwords
+         * at byte offsets 0..3, the current block sits in scalar registers (it is the same for every lane) — the
+         * one-candidate-per-lane form spent more on unaligned LDS fetches than on differences */
+        uint32_t cb[16][4];
+#pragma unroll
+        for (int y = 0; y < 16; y++) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(cblk + 16 * y);
+            cb[y][0] = __builtin_amdgcn_readfirstlane(c.x);
+            cb[y][1] = __builtin_amdgcn_readfirstlane(c.y);
+            cb[y][2] = __builtin_amdgcn_readfirstlane(c.z);
+            cb[y][3] = __builtin_amdgcn_readfirstlane(c.w);
+        }
+        const int ngx = (ncx + 3) >> 2;
+        l0 = ((ci0 / ncx) * ngx + ((ci0 % ncx) >> 2)) & 63;
+        for (int g = lane; g < ngx * ncy; g += 64) {
+            const int cy = g / ngx, cx0 = 4 * (g - cy * ngx);
+            /* v_qsad_pk_u16_u8: the four SADs of a 4-byte reference against the four byte positions of an 8-byte
+             * source, accumulated in four packed u16 (a 16x16 SAD is at most 65280) — one instruction per block dword */
+            uint32_t cost[4] = { 0, 0, 0, 0 };
+            if (QUAD == 1) {
+                uint64_t acc = 0;
+#pragma unroll
+                for (int y = 0; y < 16; y++) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(win + (cy + y) * pitch + cx0);
+                    const uint4 d = *reinterpret_cast<const uint4 *>(q);
+                    const uint32_t w[5] = { d.x, d.y, d.z, d.w, q[4] };
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w[j + 1] << 32) | w[j], cb[y][j], acc);
+                }
+                cost[0] = (uint32_t)(acc & 0xFFFF); cost[1] = (uint32_t)((acc >> 16) & 0xFFFF);
+                cost[2] = (uint32_t)((acc >> 32) & 0xFFFF); cost[3] = (uint32_t)(acc >> 48);
+            } else {
+                /* the same with v_sad_u8 on funnel-shifted dwords (constant shifts) */
+#pragma unroll
+                for (int y = 0; y < 16; y++) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(win + (cy + y) * pitch + cx0);
+                    const uint4 d = *reinterpret_cast<const uint4 *>(q);
+                    const uint32_t w[5] = { d.x, d.y, d.z, d.w, q[4] };
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        cost[0] = __builtin_amdgcn_sad_u8(cb[y][j], w[j], cost[0]);
+                        cost[1] = __builtin_amdgcn_sad_u8(cb[y][j], __builtin_amdgcn_alignbyte(w[j + 1], w[j], 1), cost[1]);
+                        cost[2] = __builtin_amdgcn_sad_u8(cb[y][j], __builtin_amdgcn_alignbyte(w[j + 1], w[j], 2), cost[2]);
+                        cost[3] = __builtin_amdgcn_sad_u8(cb[y][j], __builtin_amdgcn_alignbyte(w[j + 1], w[j], 3), cost[3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ci = cy * ncx + cx0 + k;
+                if (cx0 + k < ncx) {
+                    if (ci == ci0)
+                        cost0 = cost[k];
+                    if (cost[k] < best) {
+                        best = cost[k];
+                        best_ci = (uint32_t)ci;
+                    }
+                }
+            }
+        }
+    } else
     for (int ci = lane; ci < ncx * ncy; ci += 64) {
         const int cy = ci / ncx, cx = ci - cy * ncx;
         const uint8_t *cand = win + cy * pitch + cx;
@@ -282,7 +369,6 @@ __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t
         key = o < key ? o : key;
     }
     /* the zero-MV cost lives in exactly one lane */
-    const int l0 = ci0 & 63;
     cost0 = (uint32_t)__shfl((int)cost0, l0, 64);
     if (lane == 0) {
         const uint32_t mc = (uint32_t)(key >> 32), mi = (uint32_t)key;
@@ -316,14 +402,28 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
     const dim3 grid(bw, bh, nframes), block(64);
 #define ESA(K, M) hipLaunchKernelGGL((k_me_esa<K, M>), grid, block, lds, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out)
     if (cost_kind == FFHIP_ME_SAD) {
-        if (mb_size == 16) ESA(FFHIP_ME_SAD, 16); else ESA(FFHIP_ME_SAD, 8);
+        /* measured (4K, 8 frame pairs): R = 7: one candidate per lane 448 M, quad + v_qsad_pk_u16_u8 480 M, quad + v_sad_u8 433 M
+         * MB-searches/s; R = 16: 122 / 116 / 114 M.  v_qsad_pk_u16_u8 issues at about 1/14 rate on gfx950, which eats what
+         * the four-fold saving in LDS reads buys; the quad form is the default only while the candidates fit one pass.
+         * FFHIP_ME_SAD_QUAD = 0 / 1 / 2 forces a form. */
+        const char *eq = getenv("FFHIP_ME_SAD_QUAD");
+        const bool one_pass = ((2 * R + 1 + 3) / 4) * (2 * R + 1) <= 64;
+        if (mb_size == 16 && !eq && !one_pass)
+            ESA(FFHIP_ME_SAD, 16);
+        else if (mb_size == 16 && eq && eq[0] == '2')
+            hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SAD, 16, false, 2>), grid, block, lds, stream, cur, ref, width, height, stride,
+                               frame_pitch, R, mv_out, cost_out);
+        else if (mb_size == 16 && !(eq && eq[0] == '0'))
+            hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SAD, 16, false, 1>), grid, block, lds, stream, cur, ref, width, height, stride,
+                               frame_pitch, R, mv_out, cost_out);
+        else if (mb_size == 16) ESA(FFHIP_ME_SAD, 16); else ESA(FFHIP_ME_SAD, 8);
     } else {
         /* shared column transforms when their LDS plane fits (R <= 24 at 16x16); FFHIP_ME_SATD_SHARE=0: per-candidate */
         const char *es = getenv("FFHIP_ME_SATD_SHARE");
         const size_t vsz = ((size_t)(mb_size / 8) * mb_size + (size_t)(2 * R + mb_size - 7) * (2 * R + mb_size)) * 16;
         const size_t lds_s = ((lds + 15) & ~(size_t)15) + vsz;
         if (lds_s <= 64 * 1024 && !(es && es[0] == '0')) {
-#define ESAS(M) hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SATD, M, true>), grid, block, lds_s, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out)
+#define ESAS(M) hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SATD, M, true, 0>), grid, block, lds_s, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out)
             if (mb_size == 16) ESAS(16); else ESAS(8);
 #undef ESAS
         } else {
