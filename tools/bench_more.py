@@ -45,7 +45,7 @@ sws("nv12 1080p -> yuv420p 1080p (1:1 re-pack)", "nv12", 1920, 1080, "yuv420p", 
 sws("yuv420p 1080p->4K bicubic", "yuv420p", 1920, 1080, "yuv420p", 3840, 2160, S.SWS_BICUBIC, 128)
 sws("nv12 720p->1080p bicubic (1.5x, byte-aligned spans)", "nv12", 1280, 720, "nv12", 1920, 1080, S.SWS_BICUBIC, 256)
 sws("yuv420p 720p->1080p rgb24 bicubic (1.5x)", "yuv420p", 1280, 720, "rgb24", 1920, 1080, S.SWS_BICUBIC, 128)
-sws("nv12 4K->1080p bicubic (8-tap, LDS-tiled kernel)", "nv12", 3840, 2160, "nv12", 1920, 1080, S.SWS_BICUBIC, 32)
+sws("nv12 4K->1080p bicubic (8 x 8 taps, k_sws_lwalk)", "nv12", 3840, 2160, "nv12", 1920, 1080, S.SWS_BICUBIC, 32)
 sws("yuv420p 1080p->4K rgb24 bicubic (k_sws_colwalk_rgb)", "yuv420p", 1920, 1080, "rgb24", 3840, 2160, S.SWS_BICUBIC, 32)
 sws("nv12 1080p->4K bgr24 bicubic (k_sws_colwalk_rgb)", "nv12", 1920, 1080, "bgr24", 3840, 2160, S.SWS_BICUBIC, 32)
 os.environ["FFHIP_CWRGB_DIRECT"] = "1"
