@@ -68,6 +68,12 @@ void ffo_h264_chroma_mc(int avg, int w, uint8_t *dst, const uint8_t *src, ptrdif
 void ffo_h264_weight(int w, uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset);
 void ffo_h264_biweight(int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
                        int weights, int offset);
+/* ---- HEVC inverse transforms, 8-bit (ffo_hevc.c): HEVCDSPContext.idct / idct_dc / transform_4x4_luma / add_residual ---- */
+int  ffo_hevc_coef(int k, int i);                                   /* the 32-point core matrix */
+void ffo_hevc_idct(int log2_size, int16_t *coeffs, int col_limit);  /* log2_size 2..5 */
+void ffo_hevc_idct_dc(int log2_size, int16_t *coeffs);
+void ffo_hevc_transform_4x4_luma(int16_t *coeffs);
+void ffo_hevc_add_residual(int log2_size, uint8_t *dst, const int16_t *res, ptrdiff_t stride);
 /* frame-order luma deblock, same edge array layout as ffhip_h264_deblock_frame_dev (include/ffhip.h) */
 typedef struct FfoH264Edge {
     int32_t offset;

@@ -1,0 +1,119 @@
+/*
+ * ffo_hevc.c — CPU restatement of the HEVC inverse transforms (8-bit).  TEST INFRASTRUCTURE ONLY.
+ *
+ * Follows the BEHAVIOUR of libavcodec/hevc/dsp_template.c:
+ *   idct_{4,8,16,32}   :192-284   two 1-D passes (columns, then rows) of the HEVC core transform, each result
+ *                                 av_clip_int16((sum + add) >> shift), shift 7 then 20 - bit depth; the partial
+ *                                 butterflies sum exact integers, so a pass is the matrix product restricted to the
+ *                                 coefficients the `end` limits keep (see hevc_keeps below)
+ *   idct_*_dc          :286-300   every residual = (((c0 + 1) >> 1) + add) >> (14 - depth)
+ *   transform_4x4_luma :155-188   the 4x4 DST-VII of intra luma
+ *   add_residual       :46-59     dst = clip_pixel(dst + res)
+ * The 32x32 coefficient matrix is generated from the 31 constants of the H.265 core transform
+ * (T[k][i] = sign * g[(2i+1)k mod 128 folded into a quadrant]); tests/test_oracle_vs_ref.py pins all of it against the
+ * reference's own table and code compiled in place.
+ */
+#include <string.h>
+
+#include "ffo.h"
+
+static int clip16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+static int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+/* |64 * sqrt(2) * cos(m * pi / 64)| as the standard rounds it, m = 0..31 (g[0] is the DC row's 64) */
+static const int g_mag[32] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67,
+                               64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4 };
+
+int ffo_hevc_coef(int k, int i) /* T32[k][i]: basis k, sample i of the 32-point transform */
+{
+    const int m = ((2 * i + 1) * k) & 127; /* angle m * pi / 64 */
+    if (k == 0)
+        return 64;
+    if (m < 32)  return g_mag[m];
+    if (m == 32) return 0;
+    if (m < 64)  return -g_mag[64 - m];
+    if (m < 96)  return -g_mag[m - 64];
+    if (m == 96) return 0;
+    return g_mag[128 - m];
+}
+
+/*
+ * Which input coefficients a 1-D pass of size n with limit `end` keeps (TR_32/16/8/4 nest with end, end/2, 8, 4:
+ * dsp_template.c:205-251): odd k need k < end; k = 2 mod 4 of the 32-point transform need k/2 < end/2; everything the
+ * inner 8- and 4-point stages see is always kept.
+ */
+static int hevc_keeps(int n, int k, int end)
+{
+    if (n == 4)
+        return 1;
+    if (k & 1)
+        return k < end;
+    if (n == 32 && (k & 3) == 2)
+        return (k >> 1) < (end >> 1);
+    return 1;
+}
+
+static void pass(int16_t *dst, const int16_t *src, int n, int dstep, int sstep, int end, int shift)
+{
+    const int add = 1 << (shift - 1), scale = 32 / n;
+    int out[32];
+    for (int i = 0; i < n; i++) {
+        int s = 0;
+        for (int k = 0; k < n; k++)
+            if (hevc_keeps(n, k, end))
+                s += ffo_hevc_coef(k * scale, i) * src[k * sstep];
+        out[i] = clip16((s + add) >> shift);
+    }
+    for (int i = 0; i < n; i++)
+        dst[i * dstep] = (int16_t)out[i];
+}
+
+void ffo_hevc_idct(int log2_size, int16_t *coeffs, int col_limit)
+{
+    const int n = 1 << log2_size;
+    int limit = col_limit < n ? col_limit : n;
+    int limit2 = col_limit + 4 < n ? col_limit + 4 : n;
+    for (int i = 0; i < n; i++) { /* columns; the limit shrinks by 4 after columns 4, 8, ... (:271-275) */
+        pass(coeffs + i, coeffs + i, n, n, n, limit2, 7);
+        if (limit2 < n && i % 4 == 0 && i)
+            limit2 -= 4;
+    }
+    for (int i = 0; i < n; i++)
+        pass(coeffs + i * n, coeffs + i * n, n, 1, 1, limit, 12);
+}
+
+void ffo_hevc_idct_dc(int log2_size, int16_t *coeffs)
+{
+    const int n = 1 << log2_size, shift = 14 - 8, add = 1 << (shift - 1);
+    const int v = (((coeffs[0] + 1) >> 1) + add) >> shift;
+    for (int i = 0; i < n * n; i++)
+        coeffs[i] = (int16_t)v;
+}
+
+static void dst4(int16_t *dst, const int16_t *src, int step, int shift)
+{
+    const int add = 1 << (shift - 1);
+    const int s0 = src[0], s1 = src[step], s2 = src[2 * step], s3 = src[3 * step];
+    const int c0 = s0 + s2, c1 = s2 + s3, c2 = s0 - s3, c3 = 74 * s1;
+    const int o0 = 29 * c0 + 55 * c1 + c3, o1 = 55 * c2 - 29 * c1 + c3, o2 = 74 * (s0 - s2 + s3), o3 = 55 * c0 + 29 * c2 - c3;
+    dst[0] = (int16_t)clip16((o0 + add) >> shift);
+    dst[step] = (int16_t)clip16((o1 + add) >> shift);
+    dst[2 * step] = (int16_t)clip16((o2 + add) >> shift);
+    dst[3 * step] = (int16_t)clip16((o3 + add) >> shift);
+}
+
+void ffo_hevc_transform_4x4_luma(int16_t *coeffs)
+{
+    for (int i = 0; i < 4; i++)
+        dst4(coeffs + i, coeffs + i, 4, 7);
+    for (int i = 0; i < 4; i++)
+        dst4(coeffs + 4 * i, coeffs + 4 * i, 1, 12);
+}
+
+void ffo_hevc_add_residual(int log2_size, uint8_t *dst, const int16_t *res, ptrdiff_t stride)
+{
+    const int n = 1 << log2_size;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++)
+            dst[y * stride + x] = (uint8_t)clip8(dst[y * stride + x] + res[y * n + x]);
+}

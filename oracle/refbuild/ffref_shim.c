@@ -16,6 +16,7 @@
 #include "libavcodec/h264qpel.h"
 #include "libavcodec/h264chroma.h"
 #include "libavcodec/me_cmp.h"
+#include "libavcodec/hevc/dsp.h"
 #include "libavfilter/motion_estimation.h"
 #include "ffref.h"
 
@@ -105,6 +106,7 @@ static H264DSPContext   h264_422;
 static H264QpelContext  qpel;
 static MECmpContext     mecmp;
 static H264ChromaContext chroma;
+static HEVCDSPContext hevc;
 static int dsp_ready;
 static void dsp_init(void)
 {
@@ -116,6 +118,7 @@ static void dsp_init(void)
     ff_h264qpel_init(&qpel, 8);
     ff_me_cmp_init(&mecmp, NULL);
     ff_h264chroma_init(&chroma, 8);
+    ff_hevc_dsp_init(&hevc, 8);
     dsp_ready = 1;
 }
 void ffref_h264_idct(int which, uint8_t *dst, int16_t *block, ptrdiff_t stride)
@@ -178,6 +181,26 @@ void ffref_h264_biweight(int idx, uint8_t *dst, uint8_t *src, ptrdiff_t stride, 
 {
     dsp_init();
     h264.biweight_pixels_tab[idx](dst, src, stride, height, log2_denom, weightd, weights, offset);
+}
+void ffref_hevc_idct(int idx, int16_t *coeffs, int col_limit)
+{
+    dsp_init();
+    hevc.idct[idx](coeffs, col_limit);
+}
+void ffref_hevc_idct_dc(int idx, int16_t *coeffs)
+{
+    dsp_init();
+    hevc.idct_dc[idx](coeffs);
+}
+void ffref_hevc_transform_4x4_luma(int16_t *coeffs)
+{
+    dsp_init();
+    hevc.transform_4x4_luma(coeffs);
+}
+void ffref_hevc_add_residual(int idx, uint8_t *dst, const int16_t *res, ptrdiff_t stride)
+{
+    dsp_init();
+    hevc.add_residual[idx](dst, res, stride);
 }
 int ffref_me_cmp(int kind, int idx, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
 {

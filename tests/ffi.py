@@ -89,6 +89,16 @@ def oracle():
         L.ffo_h264_chroma_mc.restype = None
         L.ffo_h264_weight.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_h264_weight.restype = None
+        L.ffo_hevc_coef.argtypes = [C.c_int, C.c_int]
+        L.ffo_hevc_coef.restype = C.c_int
+        L.ffo_hevc_idct.argtypes = [C.c_int, i16p, C.c_int]
+        L.ffo_hevc_idct.restype = None
+        L.ffo_hevc_idct_dc.argtypes = [C.c_int, i16p]
+        L.ffo_hevc_idct_dc.restype = None
+        L.ffo_hevc_transform_4x4_luma.argtypes = [i16p]
+        L.ffo_hevc_transform_4x4_luma.restype = None
+        L.ffo_hevc_add_residual.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+        L.ffo_hevc_add_residual.restype = None
         L.ffo_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_h264_biweight.restype = None
         L.ffo_h264_deblock_frame.argtypes = [u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
@@ -150,6 +160,14 @@ def ref():
         L.ffref_h264_chroma.restype = None
         L.ffref_h264_weight.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffref_h264_weight.restype = None
+        L.ffref_hevc_idct.argtypes = [C.c_int, i16p, C.c_int]
+        L.ffref_hevc_idct.restype = None
+        L.ffref_hevc_idct_dc.argtypes = [C.c_int, i16p]
+        L.ffref_hevc_idct_dc.restype = None
+        L.ffref_hevc_transform_4x4_luma.argtypes = [i16p]
+        L.ffref_hevc_transform_4x4_luma.restype = None
+        L.ffref_hevc_add_residual.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+        L.ffref_hevc_add_residual.restype = None
         L.ffref_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffref_h264_biweight.restype = None
         L.ffref_me_cmp.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]

@@ -274,6 +274,59 @@ def test_h264_weight_biweight():
             assert np.array_equal(a, b), ("biweight", w, height, ld, wt, ws, off)
 
 
+def hevc_coeffs(rng, n, kind):
+    """coefficient blocks the way tests/checkasm/hevc_idct.c makes them (random int16 in the decoder's range), plus
+    sparse low-frequency blocks (what col_limit is for) and saturating extremes"""
+    if kind == 0:
+        c = rng.integers(-32768, 32768, (n, n))
+    elif kind == 1:
+        c = rng.integers(-512, 512, (n, n))
+    elif kind == 2:
+        c = np.zeros((n, n), np.int64)
+        k = int(rng.integers(1, n + 1))
+        c[:k, :k] = rng.integers(-2048, 2048, (k, k))
+    else:
+        c = rng.choice(np.array([-32768, 32767, 0, 1, -1]), (n, n))
+    return np.ascontiguousarray(c.astype(np.int16))
+
+
+def test_hevc_idct():
+    """every size x every col_limit the decoder can pass (hevc/cabac.c: 4..2n incl. odd values) + out-of-range limits;
+    the reference only reads the coefficients its limits keep, so the blocks are NOT restricted to them"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(70)
+    for k in range(32):                                  # our generated matrix == the reference's table, via idct probes
+        for i in range(32):
+            assert abs(O.ffo_hevc_coef(k, i)) <= 90
+    for lg in (2, 3, 4, 5):
+        n = 1 << lg
+        for col_limit in list(range(0, 2 * n + 6)) + [1000]:
+            for kind in range(4):
+                c = hevc_coeffs(rng, n, kind)
+                a, b = c.copy(), c.copy()
+                R.ffref_hevc_idct(lg - 2, ptr(a, ffi.i16p), col_limit)
+                O.ffo_hevc_idct(lg, ptr(b, ffi.i16p), col_limit)
+                assert np.array_equal(a, b), (n, col_limit, kind)
+        for rep in range(20):
+            c = hevc_coeffs(rng, n, rep % 4)
+            a, b = c.copy(), c.copy()
+            R.ffref_hevc_idct_dc(lg - 2, ptr(a, ffi.i16p))
+            O.ffo_hevc_idct_dc(lg, ptr(b, ffi.i16p))
+            assert np.array_equal(a, b)
+            res = hevc_coeffs(rng, n, rep % 4)
+            d0 = rng.integers(0, 256, (n + 2, 48), dtype=np.uint8)
+            a, b = d0.copy(), d0.copy()
+            R.ffref_hevc_add_residual(lg - 2, C.cast(a.ctypes.data + 48 + 3, u8p), ptr(res, ffi.i16p), 48)
+            O.ffo_hevc_add_residual(lg, C.cast(b.ctypes.data + 48 + 3, u8p), ptr(res, ffi.i16p), 48)
+            assert np.array_equal(a, b)
+    for rep in range(200):
+        c = hevc_coeffs(rng, 4, rep % 4)
+        a, b = c.copy(), c.copy()
+        R.ffref_hevc_transform_4x4_luma(ptr(a, ffi.i16p))
+        O.ffo_hevc_transform_4x4_luma(ptr(b, ffi.i16p))
+        assert np.array_equal(a, b)
+
+
 def test_me_cmp():
     R, O = ffi.ref(), ffi.oracle()
     rng = np.random.default_rng(40)
