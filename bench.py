@@ -144,6 +144,38 @@ def extras(torch, dev):
     out["h264_idct8_add"] = {"Gblocks/s": round(nb / (ms * 1e-3) / 1e9, 3), "GB/s": round(gbs, 1),
                              "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "blocks": nb, "ms": round(ms, 4)}
     del plane, coefs, coefs0, offs
+    # HEVC 32x32 and 8x8 inverse transform + add_residual over 4K luma planes (coefficients read + residual written in
+    # place + picture read + written: 6 B per sample)
+    from ffmpeg_amd import hevc
+    for lg, planes in ((5, 16), (3, 8)):
+        nsz = 1 << lg
+        bw, bh = 3840 // nsz, 2160 // nsz
+        ntu = planes * bw * bh
+        tus = np.zeros(ntu, hevc.TU_DTYPE)
+        idx = np.arange(ntu)
+        pl, rem = idx // (bw * bh), idx % (bw * bh)
+        tus["coeff_offset"] = idx * nsz * nsz
+        tus["dst_offset"] = pl * 3840 * 2160 + (rem // bw) * nsz * 3840 + (rem % bw) * nsz
+        tus["col_limit"] = nsz
+        d_t = torch.from_numpy(tus.view(np.uint8).reshape(ntu, 12).copy()).to(dev)
+        c0 = torch.randint(-512, 512, (ntu, nsz * nsz), dtype=torch.int16, device=dev)
+        pic = torch.randint(0, 256, (planes * 2160, 3840), dtype=torch.uint8, device=dev)
+        cc = c0.clone()
+        hevc.idct_batch(hevc.IDCT, lg, cc, pic, 3840, d_t, ntu)
+        tot = 0.0
+        for _ in range(5):
+            cc.copy_(c0)
+            e0, e1 = ev(), ev()
+            e0.record()
+            hevc.idct_batch(hevc.IDCT, lg, cc, pic, 3840, d_t, ntu)
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        ms = tot / 5
+        gbs = ntu * nsz * nsz * 6 / (ms * 1e-3) / 1e9
+        out["hevc_idct%d_add" % nsz] = {"Mblocks/s": round(ntu / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1),
+                                        "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "blocks": ntu, "ms": round(ms, 4)}
+        del cc, c0, pic, d_t
     # float MDCT-1024 forward, 65,536 transforms (BASELINE configs[3]): 12,288 B per transform
     from ffmpeg_amd import tx, me
     nt, ln = 65536, 1024
@@ -184,7 +216,6 @@ def extras(torch, dev):
                      "frame_pairs": nf, "ms": round(ms, 4)}
     del cur, ref
     # H.264 luma qpel: every 16x16 macroblock of 8 4K planes, mixed mcXY, put (BASELINE configs[2]): 2 B / sample
-    import numpy as np
     nf, w, h, P = 8, 3840, 2160, 32
     stride = w + 2 * P
     refp = torch.randint(0, 256, (nf * (h + 2 * P), stride), dtype=torch.uint8, device=dev)

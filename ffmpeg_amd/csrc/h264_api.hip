@@ -90,3 +90,15 @@ extern "C" int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptr
         return FFHIP_ENOSYS;
     return ffhip_launch_h264_weight(dst, src ? src : dst, stride, blocks, n, (hipStream_t)stream);
 }
+
+/* ---- hevcdsp inverse transforms ------------------------------------------------ */
+extern "C" int ffhip_hevc_idct_batch_dev(int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride,
+                                         const FFHipHevcTU *tus, int n, void *stream)
+{
+    if (!coeffs || !tus || n < 0 || kind < FFHIP_HEVC_IDCT || kind > FFHIP_HEVC_ADD_ONLY || log2_size < 2 || log2_size > 5 ||
+        (kind == FFHIP_HEVC_DST_4X4 && log2_size != 2) || (kind == FFHIP_HEVC_ADD_ONLY && !dst))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_idct(kind, log2_size, coeffs, dst, stride, tus, n, (hipStream_t)stream);
+}

@@ -1,0 +1,193 @@
+/*
+ * hevc_idct.hip — HEVC inverse transforms, 8-bit, batched.
+ *
+ * Bit-exact restatement of idct_{4,8,16,32}, idct_*_dc, transform_4x4_luma and add_residual
+ * (libavcodec/hevc/dsp_template.c:46-59,155-188,192-300).  A 1-D pass of the reference is a partial butterfly that sums
+ * exact integers, i.e. the product with the HEVC core matrix restricted to the coefficients its `end` limits keep
+ * (odd k < end; k = 2 mod 4 of the 32-point transform: k/2 < end/2; the inner 8-/4-point stages always), followed by
+ * av_clip_int16((sum + add) >> shift).  col_limit shrinks by 4 after columns 4, 8, ... of the first pass.
+ *
+ * GPU design: a transform unit is N lanes (N = size), 64 / N units per wave, the block staged in wave-private LDS.
+ * Lane (unit, i) transforms column i, then row i: it zeroes the inputs its limit drops (a per-lane select, the limits
+ * differ per unit and column) and accumulates the even and the odd basis functions separately, E_j and O_j, so that
+ * outputs j and N-1-j share their multiplies (N*N/2 per vector).  The matrix entries are wave-uniform: they come
+ * from a __constant__ table through scalar loads and feed v_mad_i32_i24 as SGPR operands.  Residuals are written back
+ * in place (the reference leaves them in coeffs) and added to the picture with packed byte stores.
+ */
+#include "common.h"
+#include "h264_kernels.h"
+
+/* |64 sqrt2 cos(m pi / 64)| as the standard rounds it; T32[k][i] = +-g[fold((2i+1)k mod 128)] */
+__constant__ int8_t hevc_t32[32][32];
+static int8_t hevc_t32_host[32][32];
+static bool hevc_t32_ready;
+
+static void hevc_build_table()
+{
+    static const int g[32] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67,
+                               64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4 };
+    for (int k = 0; k < 32; k++)
+        for (int i = 0; i < 32; i++) {
+            const int m = ((2 * i + 1) * k) & 127;
+            int v;
+            if (k == 0) v = 64;
+            else if (m < 32) v = g[m];
+            else if (m == 32 || m == 96) v = 0;
+            else if (m < 64) v = -g[64 - m];
+            else if (m < 96) v = -g[m - 64];
+            else v = g[128 - m];
+            hevc_t32_host[k][i] = (int8_t)v;
+        }
+}
+
+__device__ __forceinline__ int hevc_clip16(int v) { return min(max(v, -32768), 32767); }
+
+/* one 1-D pass over the vector at src (stride sstep int16) into dst (stride dstep): N outputs */
+template <int N>
+__device__ __forceinline__ void hevc_pass(int16_t *dst, int dstep, const int16_t *src, int sstep, int end, int shift)
+{
+    constexpr int SC = 32 / N;
+    int s[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        bool keep = true;
+        if (N > 4) {
+            if (k & 1) keep = k < end;
+            else if (N == 32 && (k & 3) == 2) keep = (k >> 1) < (end >> 1);
+        }
+        const int v = src[k * sstep];
+        s[k] = keep ? v : 0;
+    }
+    const int add = 1 << (shift - 1);
+#pragma unroll
+    for (int j = 0; j < N / 2; j++) {
+        int e = 0, o = 0;
+#pragma unroll
+        for (int k = 0; k < N; k += 2) {
+            e += (int)hevc_t32[k * SC][j] * s[k];
+            o += (int)hevc_t32[(k + 1) * SC][j] * s[k + 1];
+        }
+        dst[j * dstep] = (int16_t)hevc_clip16((e + o + add) >> shift);
+        dst[(N - 1 - j) * dstep] = (int16_t)hevc_clip16((e - o + add) >> shift);
+    }
+}
+
+__device__ __forceinline__ void hevc_dst4(int16_t *dst, const int16_t *src, int step, int shift)
+{
+    const int add = 1 << (shift - 1);
+    const int s0 = src[0], s1 = src[step], s2 = src[2 * step], s3 = src[3 * step];
+    const int c0 = s0 + s2, c1 = s2 + s3, c2 = s0 - s3, c3 = 74 * s1;
+    dst[0]        = (int16_t)hevc_clip16((29 * c0 + 55 * c1 + c3 + add) >> shift);
+    dst[step]     = (int16_t)hevc_clip16((55 * c2 - 29 * c1 + c3 + add) >> shift);
+    dst[2 * step] = (int16_t)hevc_clip16((74 * (s0 - s2 + s3) + add) >> shift);
+    dst[3 * step] = (int16_t)hevc_clip16((55 * c0 + 29 * c2 - c3 + add) >> shift);
+}
+
+__device__ __forceinline__ void hevc_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int LOG2>
+__global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n)
+{
+    constexpr int N = 1 << LOG2, UPW = 64 / N; /* units per wave */
+    __shared__ __align__(16) int16_t lds[4][64 * N];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int u0 = (blockIdx.x * 4 + wave) * UPW;
+    if (u0 >= n)
+        return;
+    int16_t *blk = lds[wave];
+    const int ul = lane / N, i = lane % N; /* my unit of the wave, my column / row */
+    const int u = u0 + ul;
+    const bool live = u < n;
+    const FFHipHevcTU tu = tus[live ? u : u0];
+    int16_t *cg = coeffs + tu.coeff_offset;
+
+    /* ---- stage the wave's units: UPW blocks of N*N int16, as dwords ---- */
+    constexpr int DW = N * N / 2; /* dwords per unit */
+    for (int t = lane; t < UPW * DW; t += 64) {
+        const int b = t / DW, w = t % DW;
+        if (u0 + b < n)
+            reinterpret_cast<uint32_t *>(blk)[t] = reinterpret_cast<const uint32_t *>(coeffs + tus[u0 + b].coeff_offset)[w];
+    }
+    hevc_wave_sync();
+    int16_t *mine = blk + ul * N * N;
+    if (kind == FFHIP_HEVC_IDCT) {
+        const int limit = min(tu.col_limit, N);
+        /* first pass: column i; limit2 has shrunk by 4 for every column 4, 8, ... before mine while it was < N */
+        int limit2 = min(tu.col_limit + 4, N);
+        for (int c = 4; c < i; c += 4)
+            if (limit2 < N)
+                limit2 -= 4;
+        hevc_pass<N>(mine + i, N, mine + i, N, limit2, 7);
+        hevc_wave_sync();
+        hevc_pass<N>(mine + i * N, 1, mine + i * N, 1, limit, 12);
+    } else if (kind == FFHIP_HEVC_IDCT_DC) {
+        const int v = ((((int)mine[0] + 1) >> 1) + 32) >> 6;
+        hevc_wave_sync();
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            mine[i * N + k] = (int16_t)v;
+    } else if (kind == FFHIP_HEVC_DST_4X4) {
+        if (N == 4) {
+            hevc_dst4(mine + i, mine + i, 4, 7);
+            hevc_wave_sync();
+            hevc_dst4(mine + 4 * i, mine + 4 * i, 1, 12);
+        }
+    }
+    hevc_wave_sync();
+    /* ---- residual back in place; picture += residual (row i of my unit) ---- */
+    if (kind != FFHIP_HEVC_ADD_ONLY) {
+        for (int t = lane; t < UPW * DW; t += 64) {
+            const int b = t / DW, w = t % DW;
+            if (u0 + b < n)
+                reinterpret_cast<uint32_t *>(coeffs + tus[u0 + b].coeff_offset)[w] = reinterpret_cast<const uint32_t *>(blk)[t];
+        }
+    }
+    (void)cg;
+    if (dst && live && tu.dst_offset >= 0) {
+        uint8_t *d = dst + tu.dst_offset + (ptrdiff_t)i * stride;
+        const int16_t *r = mine + i * N;
+#pragma unroll
+        for (int x = 0; x < N; x += 4) {
+            if (!(((uintptr_t)d) & 3)) {
+                const uint32_t p = *reinterpret_cast<const uint32_t *>(d + x);
+                const uint32_t o = pack4(clip_u8((int)(p & 0xFF) + r[x]), clip_u8((int)((p >> 8) & 0xFF) + r[x + 1]),
+                                         clip_u8((int)((p >> 16) & 0xFF) + r[x + 2]), clip_u8((int)(p >> 24) + r[x + 3]));
+                *reinterpret_cast<uint32_t *>(d + x) = o;
+            } else {
+                for (int e = 0; e < 4; e++)
+                    d[x + e] = (uint8_t)clip_u8((int)d[x + e] + r[x + e]);
+            }
+        }
+    }
+}
+
+int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n,
+                           hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    if (!hevc_t32_ready) {
+        hevc_build_table();
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hevc_t32), hevc_t32_host, sizeof(hevc_t32_host)));
+        hevc_t32_ready = true;
+    }
+    const int upw = 64 >> log2_size;
+    const dim3 grid(cdiv(n, 4 * upw)), block(256);
+    switch (log2_size) {
+    case 2: hipLaunchKernelGGL(k_hevc_idct<2>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n); break;
+    case 3: hipLaunchKernelGGL(k_hevc_idct<3>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n); break;
+    case 4: hipLaunchKernelGGL(k_hevc_idct<4>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n); break;
+    case 5: hipLaunchKernelGGL(k_hevc_idct<5>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n); break;
+    default:
+        ffhip_set_error("ffhip_hevc_idct: log2_size %d outside 2..5", log2_size);
+        return FFHIP_EINVAL;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}

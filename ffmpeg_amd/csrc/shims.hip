@@ -311,6 +311,56 @@ extern "C" int ff_h264dsp_weight_init_hip(FFHipH264WeightContext *c, int bit_dep
     return 0;
 }
 
+/* ---- hevcdsp inverse transforms --------------------------------------------------------------------------- */
+/* layout in scratch: [0,64) the TU record, [64, 64+2*n*n) coefficients, then the picture rectangle */
+static void hevc_single(int kind, int log2_size, int16_t *coeffs, int col_limit, uint8_t *dst, ptrdiff_t stride)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const int n = 1 << log2_size;
+    const size_t cbytes = (size_t)n * n * 2;
+    Rect d = { dst, stride, 0, n - 1, 0, n - 1, nullptr };
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + cbytes + (dst ? rect_bytes(d) : 0) + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    if (hipMemcpy(buf + 64, coeffs, cbytes, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (dst && !rect_up(d, buf + 64 + cbytes))
+        return;
+    FFHipHevcTU tu;
+    tu.coeff_offset = 0;
+    tu.dst_offset = dst ? (int32_t)(d.dev - (buf + 64 + cbytes)) : -1;
+    tu.col_limit = col_limit;
+    if (hipMemcpy(buf, &tu, sizeof(tu), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_hevc_idct(kind, log2_size, (int16_t *)(buf + 64), dst ? buf + 64 + cbytes : nullptr, DP, (const FFHipHevcTU *)buf, 1, 0) < 0 ||
+        hipStreamSynchronize(0) != hipSuccess)
+        return;
+    if (kind != FFHIP_HEVC_ADD_ONLY)
+        (void)hipMemcpy(coeffs, buf + 64, cbytes, hipMemcpyDeviceToHost);
+    if (dst)
+        rect_down(d, 0, n - 1, 0, n - 1);
+}
+#define HEVC_FN(idx) \
+    static void s_hevc_idct##idx(int16_t *c, int col_limit) { hevc_single(FFHIP_HEVC_IDCT, idx + 2, c, col_limit, nullptr, 0); } \
+    static void s_hevc_dc##idx(int16_t *c) { hevc_single(FFHIP_HEVC_IDCT_DC, idx + 2, c, 0, nullptr, 0); } \
+    static void s_hevc_add##idx(uint8_t *d, const int16_t *r, ptrdiff_t st) { hevc_single(FFHIP_HEVC_ADD_ONLY, idx + 2, const_cast<int16_t *>(r), 0, d, st); }
+HEVC_FN(0) HEVC_FN(1) HEVC_FN(2) HEVC_FN(3)
+static void s_hevc_dst4(int16_t *c) { hevc_single(FFHIP_HEVC_DST_4X4, 2, c, 0, nullptr, 0); }
+
+extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
+{
+    if (!c || bit_depth != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    c->idct[0] = s_hevc_idct0; c->idct[1] = s_hevc_idct1; c->idct[2] = s_hevc_idct2; c->idct[3] = s_hevc_idct3;
+    c->idct_dc[0] = s_hevc_dc0; c->idct_dc[1] = s_hevc_dc1; c->idct_dc[2] = s_hevc_dc2; c->idct_dc[3] = s_hevc_dc3;
+    c->add_residual[0] = s_hevc_add0; c->add_residual[1] = s_hevc_add1; c->add_residual[2] = s_hevc_add2; c->add_residual[3] = s_hevc_add3;
+    c->transform_4x4_luma = s_hevc_dst4;
+    return 0;
+}
+
 /* ---- me_cmp --------------------------------------------------------------------------------------------- */
 static int cmp_single(int kind, int width, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
 {

@@ -1,0 +1,36 @@
+"""ctypes mirror of the hevcdsp inverse-transform faces of libffhip (include/ffhip.h): HEVCDSPContext.idct / idct_dc /
+transform_4x4_luma / add_residual (libavcodec/hevc/dsp.h:46-61), 8-bit."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+IDCT, IDCT_DC, DST_4X4, ADD_ONLY = 0, 1, 2, 3
+
+#: FFHipHevcTU (include/ffhip.h)
+TU_DTYPE = np.dtype([("coeff_offset", np.int32), ("dst_offset", np.int32), ("col_limit", np.int32)])
+
+
+def _stream(stream):
+    return None if stream is None else C.c_void_p(stream)
+
+
+def idct_batch(kind, log2_size, coeffs, dst, stride, tus, n, stream=None):
+    """coeffs: int16 device tensor (transformed in place); dst: uint8 device tensor or None; tus: uint8 [n, 12] FFHipHevcTU"""
+    return _lib.check(_lib.lib().ffhip_hevc_idct_batch_dev(kind, log2_size, coeffs.data_ptr(), dst.data_ptr() if dst is not None else None,
+                                                           stride, tus.data_ptr(), n, _stream(stream)), "ffhip_hevc_idct_batch_dev")
+
+
+class HEVCDSPContext(C.Structure):
+    """FFHipHEVCDSPContext: host-pointer faces with the reference's signatures"""
+    _fields_ = [("add_residual", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t) * 4),
+                ("transform_4x4_luma", C.CFUNCTYPE(None, C.c_void_p)),
+                ("idct", C.CFUNCTYPE(None, C.c_void_p, C.c_int) * 4),
+                ("idct_dc", C.CFUNCTYPE(None, C.c_void_p) * 4)]
+
+
+def dsp_init(bit_depth=8):
+    c = HEVCDSPContext()
+    _lib.check(_lib.lib().ff_hevc_dsp_init_hip(C.byref(c), bit_depth), "ff_hevc_dsp_init_hip")
+    return c

@@ -330,6 +330,44 @@ int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stri
                                 void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* libavcodec: hevcdsp inverse transforms (north_star's "hevcdsp integer IDCT") */
+/* ------------------------------------------------------------------------------------------ */
+/** The transform members of HEVCDSPContext (libavcodec/hevc/dsp.h:46-61), 8-bit: index = log2_size - 2.
+ *  idct leaves the residual IN PLACE in coeffs (libavcodec/hevc/dsp_template.c:261-284); col_limit bounds the
+ *  non-zero coefficient columns/rows exactly as the reference's partial butterflies use it (coefficients beyond it are
+ *  ignored, not assumed zero). */
+typedef void (*ffhip_hevc_idct_func)(int16_t *coeffs, int col_limit);
+typedef void (*ffhip_hevc_idct_dc_func)(int16_t *coeffs);
+typedef void (*ffhip_hevc_add_residual_func)(uint8_t *dst, const int16_t *res, ptrdiff_t stride);
+typedef struct FFHipHEVCDSPContext {
+    ffhip_hevc_add_residual_func add_residual[4];
+    void (*transform_4x4_luma)(int16_t *coeffs);
+    ffhip_hevc_idct_func    idct[4];
+    ffhip_hevc_idct_dc_func idct_dc[4];
+} FFHipHEVCDSPContext;
+/** ff_hevc_dsp_init_<arch> shape (libavcodec/hevc/dsp.h:127-140).  bit_depth must be 8. */
+int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth);
+
+#define FFHIP_HEVC_IDCT      0   /* idct[log2_size - 2](coeffs, col_limit)     */
+#define FFHIP_HEVC_IDCT_DC   1   /* idct_dc[log2_size - 2](coeffs)             */
+#define FFHIP_HEVC_DST_4X4   2   /* transform_4x4_luma(coeffs), log2_size == 2 */
+#define FFHIP_HEVC_ADD_ONLY  3   /* coeffs already hold the residual           */
+/** One transform unit of the batch face: what hls_residual_coding / hls_transform_unit pass per TU
+ *  (libavcodec/hevc/cabac.c, hevcdec.c). */
+typedef struct FFHipHevcTU {
+    int32_t coeff_offset; /* in int16 units into coeffs: the TU's size*size block, row-major      */
+    int32_t dst_offset;   /* in bytes into dst; < 0: leave the picture alone                      */
+    int32_t col_limit;    /* FFHIP_HEVC_IDCT only                                                 */
+} FFHipHevcTU;
+/**
+ * n transform units of one size and kind: the inverse transform in place in coeffs (device), then, when dst is
+ * non-NULL and the TU's dst_offset >= 0, add_residual[log2_size - 2](dst + dst_offset, residual, stride).
+ * TUs of one call must not overlap in coeffs or dst.
+ */
+int ffhip_hevc_idct_batch_dev(int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride,
+                              const FFHipHevcTU *tus, int n, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */
 /* ------------------------------------------------------------------------------------------ */
 /** me_cmp_func (libavcodec/me_cmp.h:45-48); the context argument is unused by these metrics

@@ -145,3 +145,26 @@ def test_tx_golden():
         O.ffo_mdct_free(s)
         n += 1
     assert n == 6
+
+
+def test_hevc_golden():
+    O = ffi.oracle()
+    d = load("hevc")
+    for lg in (2, 3, 4, 5):
+        blocks, limits = d["in%d" % lg], d["lim%d" % lg]
+        a = blocks.copy()
+        for t in range(len(a)):
+            O.ffo_hevc_idct(lg, ptr(a[t], i16p), int(limits[t]))
+        assert np.array_equal(a, d["idct%d" % lg]), lg
+        a = blocks.copy()
+        for t in range(len(a)):
+            O.ffo_hevc_idct_dc(lg, ptr(a[t], i16p))
+        assert np.array_equal(a, d["dc%d" % lg]), lg
+        o = d["pic%d" % lg].copy()
+        for t in range(len(o)):
+            O.ffo_hevc_add_residual(lg, at(o[t], 48 + 5), ptr(np.ascontiguousarray(blocks[t]), i16p), 48)
+        assert np.array_equal(o, d["add%d" % lg]), lg
+    a = d["in2"].copy()
+    for t in range(len(a)):
+        O.ffo_hevc_transform_4x4_luma(ptr(a[t], i16p))
+    assert np.array_equal(a, d["dst4"])

@@ -151,3 +151,32 @@ def test_tx_golden_gpu():
         got = out.cpu().numpy()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), key
         ctx.close()
+
+
+def test_hevc_golden_gpu():
+    """the HIP transforms on the reference's golden inputs reproduce the reference's outputs"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    d = G.load("hevc")
+    for lg in (2, 3, 4, 5):
+        n = 1 << lg
+        blocks, limits = d["in%d" % lg], d["lim%d" % lg]
+        nt = len(blocks)
+        tus = np.zeros(nt, hevc.TU_DTYPE)
+        tus["coeff_offset"] = np.arange(nt) * n * n
+        tus["dst_offset"] = -1
+        tus["col_limit"] = limits
+        d_t = torch.from_numpy(tus.view(np.uint8).reshape(nt, 12).copy()).cuda()
+        for kind, key in ((hevc.IDCT, "idct%d" % lg), (hevc.IDCT_DC, "dc%d" % lg)) + (((hevc.DST_4X4, "dst4"),) if lg == 2 else ()):
+            d_c = torch.from_numpy(blocks.copy()).cuda()
+            hevc.idct_batch(kind, lg, d_c, None, 0, d_t, nt)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_c.cpu().numpy(), d[key]), key
+        pic = d["pic%d" % lg]
+        tus["dst_offset"] = np.arange(nt) * pic.shape[1] * 48 + 48 + 5
+        d_t = torch.from_numpy(tus.view(np.uint8).reshape(nt, 12).copy()).cuda()
+        d_c = torch.from_numpy(blocks.copy()).cuda()
+        d_p = torch.from_numpy(pic.copy()).cuda()
+        hevc.idct_batch(hevc.ADD_ONLY, lg, d_c, d_p, 48, d_t, nt)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_p.cpu().numpy(), d["add%d" % lg]), lg

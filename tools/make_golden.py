@@ -159,8 +159,58 @@ def tx():
     np.savez_compressed(os.path.join(OUT, "tx.npz"), **d)
 
 
+def hevc():
+    """HEVC inverse transforms: per size 24 blocks (dense / small / sparse / saturating) x col_limits, DC, 4x4 luma DST,
+    add_residual on a padded picture"""
+    rng = np.random.default_rng(9)
+    d = {}
+    for lg in (2, 3, 4, 5):
+        n = 1 << lg
+        blocks, limits = [], []
+        for t in range(24):
+            kind = t % 4
+            if kind == 0:
+                c = rng.integers(-32768, 32768, (n, n))
+            elif kind == 1:
+                c = rng.integers(-512, 512, (n, n))
+            elif kind == 2:
+                c = np.zeros((n, n), np.int64)
+                k = int(rng.integers(1, n + 1))
+                c[:k, :k] = rng.integers(-2048, 2048, (k, k))
+            else:
+                c = rng.choice(np.array([-32768, 32767, 0, 1, -1]), (n, n))
+            blocks.append(c.astype(np.int16))
+            limits.append(int(rng.integers(0, 2 * n + 6)) if t % 5 else 1000)
+        blocks = np.stack(blocks)
+        d["in%d" % lg] = blocks
+        d["lim%d" % lg] = np.array(limits, np.int32)
+        out = blocks.copy()
+        for t in range(24):
+            R.ffref_hevc_idct(lg - 2, ptr(out[t], i16p), limits[t])
+        d["idct%d" % lg] = out
+        out = blocks.copy()
+        for t in range(24):
+            R.ffref_hevc_idct_dc(lg - 2, ptr(out[t], i16p))
+        d["dc%d" % lg] = out
+        pic = rng.integers(0, 256, (24, n + 2, 48), dtype=np.uint8)
+        d["pic%d" % lg] = pic
+        o = pic.copy()
+        for t in range(24):
+            R.ffref_hevc_add_residual(lg - 2, at(o[t], 48 + 5), ptr(blocks[t], i16p), 48)
+        d["add%d" % lg] = o
+    out = d["in2"].copy()
+    for t in range(24):
+        R.ffref_hevc_transform_4x4_luma(ptr(out[t], i16p))
+    d["dst4"] = out
+    np.savez_compressed(os.path.join(OUT, "hevc.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    sws(); h264(); me(); tx()
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        sws(); h264(); me(); tx(); hevc()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
