@@ -10,8 +10,8 @@
  * GPU design: a transform unit is N lanes (N = size), 64 / N units per wave, the block staged in wave-private LDS.
  * Lane (unit, i) transforms column i, then row i: it zeroes the inputs its limit drops (a per-lane select, the limits
  * differ per unit and column) and accumulates the even and the odd basis functions separately, E_j and O_j, so that
- * outputs j and N-1-j share their multiplies (N*N/2 per vector).  The matrix entries are wave-uniform: they come
- * from a __constant__ table through scalar loads and feed v_mad_i32_i24 as SGPR operands.  Residuals are written back
+ * outputs j and N-1-j share their multiplies, two per v_dot2_i32_i16 (N*N/4 instructions per vector).  The matrix
+ * entries are wave-uniform: int16 pairs in a __constant__ table, read with scalar loads and used as SGPR operands.  Residuals are written back
  * in place (the reference leaves them in coeffs) and added to the picture with packed byte stores.
  */
 #include "common.h"
@@ -21,6 +21,11 @@
 __constant__ int8_t hevc_t32[32][32];
 static int8_t hevc_t32_host[32][32];
 static bool hevc_t32_ready;
+/* the same matrix as int16 PAIRS for v_dot2_i32_i16, per transform size N (offset hevc_pk_off(N)): entry [j][q][0] =
+ * (T_N[4q][j], T_N[4q+2][j]) (even basis functions), [j][q][1] = (T_N[4q+1][j], T_N[4q+3][j]) (odd), j < N/2, q < N/4 */
+__constant__ uint32_t hevc_pk[352];
+static uint32_t hevc_pk_host[352];
+__host__ __device__ constexpr int hevc_pk_off(int n) { return n == 4 ? 0 : n == 8 ? 4 : n == 16 ? 4 + 16 : 4 + 16 + 64; }
 
 static void hevc_build_table()
 {
@@ -38,6 +43,16 @@ static void hevc_build_table()
             else v = g[128 - m];
             hevc_t32_host[k][i] = (int8_t)v;
         }
+    for (int n = 4; n <= 32; n *= 2) {
+        const int sc = 32 / n;
+        uint32_t *t = hevc_pk_host + hevc_pk_off(n);
+        for (int j = 0; j < n / 2; j++)
+            for (int q = 0; q < n / 4; q++)
+                for (int odd = 0; odd < 2; odd++) {
+                    const int a = hevc_t32_host[(4 * q + odd) * sc][j], b = hevc_t32_host[(4 * q + 2 + odd) * sc][j];
+                    t[(j * (n / 4) + q) * 2 + odd] = (uint32_t)(a & 0xFFFF) | ((uint32_t)b << 16);
+                }
+    }
 }
 
 __device__ __forceinline__ int hevc_clip16(int v) { return min(max(v, -32768), 32767); }
@@ -59,13 +74,24 @@ __device__ __forceinline__ void hevc_pass(int16_t *dst, int dstep, const int16_t
         s[k] = keep ? v : 0;
     }
     const int add = 1 << (shift - 1);
+    /* inputs as int16 pairs (s[4q], s[4q+2]) and (s[4q+1], s[4q+3]): two multiply-adds per v_dot2_i32_i16 against the
+     * wave-uniform coefficient pairs */
+    typedef short hv_s2 __attribute__((ext_vector_type(2)));
+    hv_s2 pe[N / 4], po[N / 4];
+#pragma unroll
+    for (int q = 0; q < N / 4; q++) {
+        pe[q] = hv_s2{ (short)s[4 * q], (short)s[4 * q + 2] };
+        po[q] = hv_s2{ (short)s[4 * q + 1], (short)s[4 * q + 3] };
+    }
+    const uint32_t *tab = hevc_pk + hevc_pk_off(N);
+    (void)SC;
 #pragma unroll
     for (int j = 0; j < N / 2; j++) {
         int e = 0, o = 0;
 #pragma unroll
-        for (int k = 0; k < N; k += 2) {
-            e += (int)hevc_t32[k * SC][j] * s[k];
-            o += (int)hevc_t32[(k + 1) * SC][j] * s[k + 1];
+        for (int q = 0; q < N / 4; q++) {
+            e = __builtin_amdgcn_sdot2(pe[q], __builtin_bit_cast(hv_s2, tab[(j * (N / 4) + q) * 2]), e, false);
+            o = __builtin_amdgcn_sdot2(po[q], __builtin_bit_cast(hv_s2, tab[(j * (N / 4) + q) * 2 + 1]), o, false);
         }
         dst[j * dstep] = (int16_t)hevc_clip16((e + o + add) >> shift);
         dst[(N - 1 - j) * dstep] = (int16_t)hevc_clip16((e - o + add) >> shift);
@@ -175,6 +201,7 @@ int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *ds
     if (!hevc_t32_ready) {
         hevc_build_table();
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hevc_t32), hevc_t32_host, sizeof(hevc_t32_host)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hevc_pk), hevc_pk_host, sizeof(hevc_pk_host)));
         hevc_t32_ready = true;
     }
     const int upw = 64 >> log2_size;
