@@ -176,6 +176,26 @@ def extras(torch, dev):
         out["hevc_idct%d_add" % nsz] = {"Mblocks/s": round(ntu / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1),
                                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "blocks": ntu, "ms": round(ms, 4)}
         del cc, c0, pic, d_t
+    # vector_fmul_window (the windowing + overlap-add after an IMDCT): 65,536 frames of len 1024 (16,384 B moved each)
+    from ffmpeg_amd import fdsp
+    nv, ln = 65536, 1024
+    a0 = torch.rand((nv, ln), dtype=torch.float32, device=dev)
+    a1 = torch.rand((nv, ln), dtype=torch.float32, device=dev)
+    win = torch.rand((2 * ln,), dtype=torch.float32, device=dev)
+    o = torch.empty((nv, 2 * ln), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        fdsp.batch(fdsp.FMUL_WINDOW, o, a0, a1, win, 0.0, ln)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(10):
+        fdsp.batch(fdsp.FMUL_WINDOW, o, a0, a1, win, 0.0, ln)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    gbs = nv * 16384 / (ms * 1e-3) / 1e9
+    out["fdsp_vector_fmul_window_1024"] = {"Mvectors/s": round(nv / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1),
+                                           "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "vectors": nv, "ms": round(ms, 4)}
+    del a0, a1, win, o
     # float MDCT-1024 forward, 65,536 transforms (BASELINE configs[3]): 12,288 B per transform
     from ffmpeg_amd import tx, me
     nt, ln = 65536, 1024

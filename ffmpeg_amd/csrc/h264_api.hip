@@ -102,3 +102,15 @@ extern "C" int ffhip_hevc_idct_batch_dev(int kind, int log2_size, int16_t *coeff
         return FFHIP_ENOSYS;
     return ffhip_launch_hevc_idct(kind, log2_size, coeffs, dst, stride, tus, n, (hipStream_t)stream);
 }
+
+/* ---- AVFloatDSPContext vector operations ---------------------------------------- */
+extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1,
+                                    size_t pitch1, const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream)
+{
+    static const int need1[7] = { 1, 0, 0, 1, 1, 1, 0 }, need2[7] = { 0, 0, 0, 1, 1, 0, 0 };
+    if (op < 0 || op > FFHIP_FDSP_BUTTERFLIES || !dst || !src0 || len < 0 || nvec < 0 || (need1[op] && !src1) || (need2[op] && !src2))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_fdsp(op, dst, dst_pitch, src0, pitch0, src1, pitch1, src2, pitch2, mul, len, nvec, (hipStream_t)stream);
+}

@@ -361,6 +361,53 @@ extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
     return 0;
 }
 
+/* ---- AVFloatDSPContext ------------------------------------------------------------------------------------ */
+/* operands packed one after another in scratch, each rounded up to 16 bytes */
+static void fdsp_single(int op, float *dst, int dst_n, const float *s0, int n0, const float *s1, int n1, const float *s2, int n2, float mul,
+                        int len)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (len <= 0)
+        return;
+    const size_t bd = ((size_t)dst_n * 4 + 15) & ~(size_t)15, b0 = ((size_t)n0 * 4 + 15) & ~(size_t)15, b1 = ((size_t)n1 * 4 + 15) & ~(size_t)15,
+                 b2 = ((size_t)n2 * 4 + 15) & ~(size_t)15;
+    void *scratch;
+    if (ffhip_scratch_reserve(bd + b0 + b1 + b2 + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    float *dd = (float *)buf, *d0 = (float *)(buf + bd), *d1 = (float *)(buf + bd + b0), *d2 = (float *)(buf + bd + b0 + b1);
+    const bool dst_in = op == FFHIP_FDSP_FMAC_SCALAR || op == FFHIP_FDSP_BUTTERFLIES;
+    if ((dst_in && hipMemcpy(dd, dst, (size_t)dst_n * 4, hipMemcpyHostToDevice) != hipSuccess) ||
+        hipMemcpy(d0, s0, (size_t)n0 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        (s1 && hipMemcpy(d1, s1, (size_t)n1 * 4, hipMemcpyHostToDevice) != hipSuccess) ||
+        (s2 && hipMemcpy(d2, s2, (size_t)n2 * 4, hipMemcpyHostToDevice) != hipSuccess))
+        return;
+    if (ffhip_launch_fdsp(op, dd, 0, d0, 0, s1 ? d1 : nullptr, 0, s2 ? d2 : nullptr, 0, mul, len, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    (void)hipMemcpy(dst, dd, (size_t)dst_n * 4, hipMemcpyDeviceToHost);
+    if (op == FFHIP_FDSP_BUTTERFLIES)
+        (void)hipMemcpy(const_cast<float *>(s0), d0, (size_t)n0 * 4, hipMemcpyDeviceToHost);
+}
+static void s_fd_fmul(float *d, const float *a, const float *b, int n) { fdsp_single(FFHIP_FDSP_FMUL, d, n, a, n, b, n, nullptr, 0, 0, n); }
+static void s_fd_fmac(float *d, const float *a, float m, int n) { fdsp_single(FFHIP_FDSP_FMAC_SCALAR, d, n, a, n, nullptr, 0, nullptr, 0, m, n); }
+static void s_fd_fmuls(float *d, const float *a, float m, int n) { fdsp_single(FFHIP_FDSP_FMUL_SCALAR, d, n, a, n, nullptr, 0, nullptr, 0, m, n); }
+static void s_fd_window(float *d, const float *a, const float *b, const float *w, int n) { fdsp_single(FFHIP_FDSP_FMUL_WINDOW, d, 2 * n, a, n, b, n, w, 2 * n, 0, n); }
+static void s_fd_fmadd(float *d, const float *a, const float *b, const float *c, int n) { fdsp_single(FFHIP_FDSP_FMUL_ADD, d, n, a, n, b, n, c, n, 0, n); }
+static void s_fd_frev(float *d, const float *a, const float *b, int n) { fdsp_single(FFHIP_FDSP_FMUL_REVERSE, d, n, a, n, b, n, nullptr, 0, 0, n); }
+static void s_fd_bfly(float *a, float *b, int n) { fdsp_single(FFHIP_FDSP_BUTTERFLIES, a, n, b, n, nullptr, 0, nullptr, 0, 0, n); }
+
+extern "C" int ff_float_dsp_init_hip(FFHipFloatDSPContext *c)
+{
+    if (!c)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    c->vector_fmul = s_fd_fmul; c->vector_fmac_scalar = s_fd_fmac; c->vector_fmul_scalar = s_fd_fmuls;
+    c->vector_fmul_window = s_fd_window; c->vector_fmul_add = s_fd_fmadd; c->vector_fmul_reverse = s_fd_frev;
+    c->butterflies_float = s_fd_bfly;
+    return 0;
+}
+
 /* ---- me_cmp --------------------------------------------------------------------------------------------- */
 static int cmp_single(int kind, int width, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
 {

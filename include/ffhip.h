@@ -330,6 +330,39 @@ int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stri
                                 void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* libavutil: AVFloatDSPContext vector operations around the MDCT           */
+/* ------------------------------------------------------------------------------------------ */
+/** The float members of AVFloatDSPContext an (I)MDCT pipeline uses (libavutil/float_dsp.h:31-175; windowing and
+ *  overlap-add of AAC & co: imdct -> vector_fmul_window).  Same signatures, host pointers.  scalarproduct_float is not
+ *  offered: its sequential summation order is the result. */
+typedef struct FFHipFloatDSPContext {
+    void (*vector_fmul)(float *dst, const float *src0, const float *src1, int len);
+    void (*vector_fmac_scalar)(float *dst, const float *src, float mul, int len);
+    void (*vector_fmul_scalar)(float *dst, const float *src, float mul, int len);
+    void (*vector_fmul_window)(float *dst, const float *src0, const float *src1, const float *win, int len);
+    void (*vector_fmul_add)(float *dst, const float *src0, const float *src1, const float *src2, int len);
+    void (*vector_fmul_reverse)(float *dst, const float *src0, const float *src1, int len);
+    void (*butterflies_float)(float *v1, float *v2, int len);
+} FFHipFloatDSPContext;
+/** ff_float_dsp_init_<arch>(AVFloatDSPContext *) shape (libavutil/float_dsp.c:153-165). */
+int ff_float_dsp_init_hip(FFHipFloatDSPContext *c);
+
+#define FFHIP_FDSP_FMUL          0   /* dst = src0 * src1                                                   */
+#define FFHIP_FDSP_FMAC_SCALAR   1   /* dst += src0 * mul                                                   */
+#define FFHIP_FDSP_FMUL_SCALAR   2   /* dst = src0 * mul                                                    */
+#define FFHIP_FDSP_FMUL_WINDOW   3   /* dst[2 len] = window(src0[len], src1[len], win = src2[2 len])        */
+#define FFHIP_FDSP_FMUL_ADD      4   /* dst = src0 * src1 + src2                                            */
+#define FFHIP_FDSP_FMUL_REVERSE  5   /* dst[i] = src0[i] * src1[len - 1 - i]                                */
+#define FFHIP_FDSP_BUTTERFLIES   6   /* (dst, src0) = (dst + src0, dst - src0): src0 is WRITTEN             */
+/**
+ * nvec independent vectors of len floats (device pointers): vector v of an operand starts pitch bytes after vector
+ * v - 1; pitch 0 shares one vector across the batch (a window).  Operands an operation does not use may be NULL.
+ * Results are bit-identical to the C reference (no fused multiply-add).
+ */
+int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1, size_t pitch1,
+                         const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* libavcodec: hevcdsp inverse transforms (north_star's "hevcdsp integer IDCT") */
 /* ------------------------------------------------------------------------------------------ */
 /** The transform members of HEVCDSPContext (libavcodec/hevc/dsp.h:46-61), 8-bit: index = log2_size - 2.

@@ -68,6 +68,15 @@ void ffo_h264_chroma_mc(int avg, int w, uint8_t *dst, const uint8_t *src, ptrdif
 void ffo_h264_weight(int w, uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset);
 void ffo_h264_biweight(int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
                        int weights, int offset);
+/* ---- AVFloatDSPContext vector operations (ffo_fdsp.c): op numbering = FFHIP_FDSP_* of include/ffhip.h ---- */
+#define FFO_FDSP_FMUL          0   /* dst = src0 * src1                                   */
+#define FFO_FDSP_FMAC_SCALAR   1   /* dst += src0 * mul                                   */
+#define FFO_FDSP_FMUL_SCALAR   2   /* dst = src0 * mul                                    */
+#define FFO_FDSP_FMUL_WINDOW   3   /* dst[2 len] = overlap window of src0, src1 with src2 */
+#define FFO_FDSP_FMUL_ADD      4   /* dst = src0 * src1 + src2                            */
+#define FFO_FDSP_FMUL_REVERSE  5   /* dst[i] = src0[i] * src1[len-1-i]                    */
+#define FFO_FDSP_BUTTERFLIES   6   /* (dst, src0) = (dst + src0, dst - src0), both written */
+void ffo_fdsp(int op, float *dst, const float *src0, const float *src1, const float *src2, float mul, int len);
 /* ---- HEVC inverse transforms, 8-bit (ffo_hevc.c): HEVCDSPContext.idct / idct_dc / transform_4x4_luma / add_residual ---- */
 int  ffo_hevc_coef(int k, int i);                                   /* the 32-point core matrix */
 void ffo_hevc_idct(int log2_size, int16_t *coeffs, int col_limit);  /* log2_size 2..5 */

@@ -10,6 +10,7 @@
 #include "libavutil/opt.h"
 #include "libavutil/pixdesc.h"
 #include "libavutil/tx.h"
+#include "libavutil/float_dsp.h"
 #include "libswscale/swscale.h"
 #include "libswscale/swscale_internal.h"
 #include "libavcodec/h264dsp.h"
@@ -181,6 +182,22 @@ void ffref_h264_biweight(int idx, uint8_t *dst, uint8_t *src, ptrdiff_t stride, 
 {
     dsp_init();
     h264.biweight_pixels_tab[idx](dst, src, stride, height, log2_denom, weightd, weights, offset);
+}
+void ffref_fdsp(int op, float *dst, const float *src0, const float *src1, const float *src2, float mul, int len)
+{
+    static AVFloatDSPContext *f;
+    pure_c();
+    if (!f)
+        f = avpriv_float_dsp_alloc(0);
+    switch (op) {
+    case 0: f->vector_fmul(dst, src0, src1, len); break;
+    case 1: f->vector_fmac_scalar(dst, src0, mul, len); break;
+    case 2: f->vector_fmul_scalar(dst, src0, mul, len); break;
+    case 3: f->vector_fmul_window(dst, src0, src1, src2, len); break;
+    case 4: f->vector_fmul_add(dst, src0, src1, src2, len); break;
+    case 5: f->vector_fmul_reverse(dst, src0, src1, len); break;
+    case 6: f->butterflies_float(dst, (float *)src0, len); break;
+    }
 }
 void ffref_hevc_idct(int idx, int16_t *coeffs, int col_limit)
 {

@@ -89,6 +89,8 @@ def oracle():
         L.ffo_h264_chroma_mc.restype = None
         L.ffo_h264_weight.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_h264_weight.restype = None
+        L.ffo_fdsp.argtypes = [C.c_int, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
+        L.ffo_fdsp.restype = None
         L.ffo_hevc_coef.argtypes = [C.c_int, C.c_int]
         L.ffo_hevc_coef.restype = C.c_int
         L.ffo_hevc_idct.argtypes = [C.c_int, i16p, C.c_int]
@@ -160,6 +162,8 @@ def ref():
         L.ffref_h264_chroma.restype = None
         L.ffref_h264_weight.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffref_h264_weight.restype = None
+        L.ffref_fdsp.argtypes = [C.c_int, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
+        L.ffref_fdsp.restype = None
         L.ffref_hevc_idct.argtypes = [C.c_int, i16p, C.c_int]
         L.ffref_hevc_idct.restype = None
         L.ffref_hevc_idct_dc.argtypes = [C.c_int, i16p]

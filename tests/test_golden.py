@@ -168,3 +168,15 @@ def test_hevc_golden():
     for t in range(len(a)):
         O.ffo_hevc_transform_4x4_luma(ptr(a[t], i16p))
     assert np.array_equal(a, d["dst4"])
+
+
+def test_fdsp_golden():
+    O = ffi.oracle()
+    d = load("fdsp")
+    for op in range(7):
+        for n in (1024, 37):
+            k = "op%d_n%d_" % (op, n)
+            dst, s0 = d[k + "dst"].copy(), d[k + "s0"].copy()
+            O.ffo_fdsp(op, ptr(dst, f32p), ptr(s0, f32p), ptr(np.ascontiguousarray(d[k + "s1"]), f32p),
+                       ptr(np.ascontiguousarray(d[k + "s2"]), f32p), float(d[k + "mul"][0]), n)
+            assert np.array_equal(dst.view(np.uint32), d[k + "out"]) and np.array_equal(s0.view(np.uint32), d[k + "out0"]), (op, n)

@@ -180,3 +180,17 @@ def test_hevc_golden_gpu():
         hevc.idct_batch(hevc.ADD_ONLY, lg, d_c, d_p, 48, d_t, nt)
         torch.cuda.synchronize()
         assert np.array_equal(d_p.cpu().numpy(), d["add%d" % lg]), lg
+
+
+def test_fdsp_golden_gpu():
+    from ffmpeg_amd import fdsp
+    torch = _torch()
+    d = G.load("fdsp")
+    for op in range(7):
+        for n in (1024, 37):
+            k = "op%d_n%d_" % (op, n)
+            t = [torch.from_numpy(np.ascontiguousarray(d[k + name]).reshape(1, -1)).cuda() for name in ("dst", "s0", "s1", "s2")]
+            fdsp.batch(op, t[0], t[1], t[2], t[3], float(d[k + "mul"][0]), n)
+            torch.cuda.synchronize()
+            assert np.array_equal(t[0].cpu().numpy().reshape(-1).view(np.uint32), d[k + "out"]), (op, n)
+            assert np.array_equal(t[1].cpu().numpy().reshape(-1).view(np.uint32), d[k + "out0"]), (op, n)

@@ -274,6 +274,34 @@ def test_h264_weight_biweight():
             assert np.array_equal(a, b), ("biweight", w, height, ld, wt, ws, off)
 
 
+def fdsp_operands(rng, op, n):
+    """(dst, src0, src1, src2, mul) for FFO_FDSP_* op with len n: values across magnitudes, incl. denormals and signed zeros"""
+    def vec(k):
+        v = (rng.standard_normal(k) * 10.0 ** rng.integers(-6, 7, k)).astype(np.float32)
+        v[::17] = 0.0
+        v[3::29] = -0.0
+        v[5::31] = np.float32(1e-41)
+        return v
+    dst = vec(2 * n if op == 3 else n)
+    src2 = vec(2 * n if op == 3 else n)
+    return dst, vec(n), vec(n), src2, float(np.float32(rng.standard_normal() * 3))
+
+
+def test_float_dsp():
+    """libavutil/float_dsp.c vector ops (tests/checkasm/float_dsp.c shapes: len a multiple of 16 plus ragged lengths)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(90)
+    for op in range(7):
+        for n in (16, 256, 1024, 1000, 4, 1, 37):
+            dst, s0, s1, s2, mul = fdsp_operands(rng, op, n)
+            a, b = dst.copy(), dst.copy()
+            a0, b0 = s0.copy(), s0.copy()
+            R.ffref_fdsp(op, ptr(a, f32p), ptr(a0, f32p), ptr(s1, f32p), ptr(s2, f32p), mul, n)
+            O.ffo_fdsp(op, ptr(b, f32p), ptr(b0, f32p), ptr(s1, f32p), ptr(s2, f32p), mul, n)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (op, n)
+            assert np.array_equal(a0.view(np.uint32), b0.view(np.uint32)), (op, n)
+
+
 def hevc_coeffs(rng, n, kind):
     """coefficient blocks the way tests/checkasm/hevc_idct.c makes them (random int16 in the decoder's range), plus
     sparse low-frequency blocks (what col_limit is for) and saturating extremes"""

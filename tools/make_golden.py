@@ -205,12 +205,28 @@ def hevc():
     np.savez_compressed(os.path.join(OUT, "hevc.npz"), **d)
 
 
+def fdsp():
+    """AVFloatDSPContext vector ops: len 1024 and 37, operands across magnitudes (bit patterns stored as uint32)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_vs_ref import fdsp_operands
+    rng = np.random.default_rng(12)
+    d = {}
+    for op in range(7):
+        for n in (1024, 37):
+            dst, s0, s1, s2, mul = fdsp_operands(rng, op, n)
+            k = "op%d_n%d_" % (op, n)
+            d[k + "dst"], d[k + "s0"], d[k + "s1"], d[k + "s2"], d[k + "mul"] = dst.copy(), s0.copy(), s1, s2, np.array([mul], np.float32)
+            R.ffref_fdsp(op, ptr(dst, f32p), ptr(s0, f32p), ptr(s1, f32p), ptr(s2, f32p), mul, n)
+            d[k + "out"], d[k + "out0"] = dst.view(np.uint32), s0.view(np.uint32)
+    np.savez_compressed(os.path.join(OUT, "fdsp.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); me(); tx(); hevc()
+        sws(); h264(); me(); tx(); hevc(); fdsp()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
