@@ -212,7 +212,12 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t
             if (!have_top || !dw_ok) {
                 int spins = 0;
                 while (known < want) {
-                    known = __hip_atomic_load(&progress[my - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    /* dword-aligned pictures: everything that crosses rows moves with device-scope (cache-bypassing)
+                     * loads and stores, so the hand-off needs ORDER only — the wait on the counter's value before the
+                     * context loads are issued — and no agent-scope acquire, whose L2 invalidate (one per macroblock
+                     * and wave, on all of an XCD's lines) capped the throughput of a batch */
+                    known = dw_ok ? __hip_atomic_load(&progress[my - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : __hip_atomic_load(&progress[my - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                     if (known >= want)
                         break;
                     __builtin_amdgcn_s_sleep(2);
@@ -224,6 +229,8 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t
                 }
                 if (!dw_ok) /* byte loads go through L1: always behind a fresh acquire */
                     known = __hip_atomic_load(&progress[my - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 topv = load_top(mx);
             }
             if (lane < 16)
@@ -263,7 +270,11 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t
                 if (i < 80) { r = i / 5; c = 4 * (i % 5) - 4; } else { r = (i - 80) / 4 - 3; c = 4 * ((i - 80) & 3); }
                 if ((c < 0 && mx == 0) || (r < 0 && my == 0))
                     continue;
-                *reinterpret_cast<uint32_t *>(mb + (ptrdiff_t)r * stride + c) = *reinterpret_cast<const uint32_t *>(&tile[(r + 4) * TP + 4 + c]);
+                /* device-scope (write-through) stores: the release below then finds no dirty lines of ours to write back
+                 * from this XCD's L2 — with plain stores every macroblock's release flushed whatever the whole XCD had
+                 * written since the last one, and that flush rate capped the throughput of a batch */
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(mb + (ptrdiff_t)r * stride + c),
+                                   *reinterpret_cast<const uint32_t *>(&tile[(r + 4) * TP + 4 + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             for (int i = lane; i < 19 * 19; i += 64) {
@@ -280,8 +291,15 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t
         if (lane < 20)
             *reinterpret_cast<uint32_t *>(&tile[lane * TP]) = keep;
         /* ---- publish (release: this wave's stores above become visible before the counter does) ---- */
-        if (lane == 0)
+        if (dw_ok) {
+            /* the write-through stores above are complete (acknowledged) before the counter moves */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            if (lane == 0)
+                __hip_atomic_store(&progress[my], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0) {
             __hip_atomic_store(&progress[my], mx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -144,9 +144,10 @@ def test_loop_filter_batch(kind):
     assert np.array_equal(d_plane.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("mb_w,mb_h,pad", [(1, 1, 0), (5, 3, 16), (45, 30, 0), (240, 135, 0)])
+@pytest.mark.parametrize("mb_w,mb_h,pad", [(1, 1, 0), (5, 3, 16), (7, 4, 3), (45, 30, 0), (240, 135, 0)])
 def test_deblock_frame(mb_w, mb_h, pad):
-    """frame order (wavefront) == serial order, bit for bit; 240x135 MBs = one 4K luma plane"""
+    """frame order (wavefront) == serial order, bit for bit; 240x135 MBs = one 4K luma plane; pad 3: a stride that is not
+    a multiple of 4 takes the byte path with full release/acquire hand-offs"""
     from ffmpeg_amd import h264
     torch = _torch()
     rng = np.random.default_rng(mb_w * 100 + mb_h)
@@ -228,7 +229,7 @@ def test_deblock_frames_batch():
     from ffmpeg_amd import h264
     torch = _torch()
     rng = np.random.default_rng(9)
-    nf, mb_w, mb_h = 20, 22, 18
+    nf, mb_w, mb_h = 24, 60, 34
     stride = mb_w * 16
     planes = np.stack([_smooth_plane(rng, mb_h * 16, stride) for _ in range(nf)])
     n = mb_w * mb_h * 8

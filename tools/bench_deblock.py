@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""tools/bench_deblock.py — frame-order luma deblocking of 4K planes: per-frame time vs frames per launch."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from ffmpeg_amd import h264  # noqa: E402
+
+dev = torch.device("cuda", 0)
+w, h = 3840, 2160
+mbw, mbh = w // 16, h // 16
+rng = np.random.default_rng(3)
+ed = np.zeros(mbw * mbh * 8, dtype=np.dtype([("o", np.int32), ("k", np.uint8), ("a", np.uint8), ("b", np.uint8), ("p", np.uint8),
+                                                 ("tc", np.int8, 4)]))
+ed["a"], ed["b"] = 40, 9
+ed["k"] = np.where(rng.random(ed.size) < .25, 4, 0)
+ed["tc"] = rng.integers(0, 4, (ed.size, 4))
+ded = torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).to(dev)
+for nf in (1, 2, 4, 8, 16, 32, 64):
+    batch = torch.randint(100, 140, (nf, h, w), dtype=torch.uint8, device=dev)
+    dd = ded.repeat(nf, 1)
+    h264.deblock_frames(batch, w * h, nf, w, mbw, mbh, dd)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    h264.deblock_frames(batch, w * h, nf, w, mbw, mbh, dd)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(json.dumps({"frames_per_launch": nf, "ms": round(ms, 3), "ms_per_frame": round(ms / nf, 4),
+                      "Gpixel/s": round(nf * w * h / ms / 1e6, 2)}), flush=True)
