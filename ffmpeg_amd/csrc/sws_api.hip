@@ -80,16 +80,21 @@ static int make_k(const FFHipSwsTables &t, FFHipYuv2RgbK *k)
 /*
  * Fast-path view of the banks: pad 1..3-tap banks to 4 taps.  Zero taps do not change a sum, so bilinear / point /
  * area up-scaling and 1:1 format conversion run on the column walker too.  A 1-tap vertical bank is
- * yuv2plane1_8_c, (h + 64) >> 7 == (64<<12 + h*4096) >> 19: its tap becomes 4096.  Packed-RGB targets pick
- * yuv2rgb_{1,2,X} by the vertical sizes (different rounding), so there only 4-tap vertical banks qualify
- * (pad_vertical = false).  Fills c->nf / c->np / c->dn; false when a bank does not fit.
+ * yuv2plane1_8_c, (h + 64) >> 7 == (64<<12 + h*4096) >> 19: its tap becomes 4096 (planar targets; a packed-RGB
+ * target keeps the bank's own coefficient, which yuv2rgb_X multiplies by).  Fills c->nf / c->np / c->dn; false when
+ * a bank does not fit.
  */
-static bool build_fast_view(FFHipSwsContext *c, const int limits[4], bool pad_vertical)
+static bool build_fast_view(FFHipSwsContext *c, const int limits[4], bool packed_rgb)
 {
     bool ok = true, padded = false;
+    /* packed RGB: the reference picks yuv2rgb_1 / _2 / _X by the vertical sizes (vscale.c:126-170; _1 and _2 round
+     * differently); _X — plain sums, which zero taps do not change — is what it runs as soon as either vertical bank has
+     * 3+ taps, e.g. the unscaled ACCURATE_RND conversion (1-tap luma, 4-tap chroma) */
+    if (packed_rgb && c->d[2].size < 3 && c->d[3].size < 3)
+        return false;
     for (int i = 0; i < 4 && ok; i++) {
         const int fs = c->d[i].size, n = c->d[i].n;
-        if (fs > 4 || limits[i] < 4 || (i >= 2 && fs != 4 && !pad_vertical)) { ok = false; break; }
+        if (fs > 4 || limits[i] < 4) { ok = false; break; }
         if (fs == 4) { c->nf[i] = c->f[i]; c->np[i] = c->p[i]; continue; }
         padded = true;
         c->nf[i].assign((size_t)n * 4, 0);
@@ -111,7 +116,7 @@ static bool build_fast_view(FFHipSwsContext *c, const int limits[4], bool pad_ve
             if (npos < 0 || pos < npos || pos - npos + fs > 4) { ok = false; break; }
             c->np[i][x] = npos;
             for (int k = 0; k < fs; k++)
-                c->nf[i][(size_t)x * 4 + (pos - npos) + k] = (i >= 2 && fs == 1) ? 4096 : c->f[i][(size_t)x * fs + k];
+                c->nf[i][(size_t)x * 4 + (pos - npos) + k] = (i >= 2 && fs == 1 && !packed_rgb) ? 4096 : c->f[i][(size_t)x * fs + k];
         }
     }
     if (!ok)
@@ -273,7 +278,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         r = ffhip_plan_scale_rgb(&a, c->p[0].data(), c->p[1].data(), c->p[2].data(), c->p[3].data());
         /* column walker with RGB output: 4-tap vertical banks (yuv2rgb_X), <= 4-tap horizontal banks, no int16 wrap */
         const int limits[4] = { a.srcW, a.chrSrcW, a.srcH, a.chrSrcH };
-        if (!r && !(t->dstW & 7) && build_fast_view(c, limits, false))
+        if (!r && !(t->dstW & 7) && build_fast_view(c, limits, true))
             c->cw_rgb = ffhip_cw_bank_ok(c->np[0].data(), 4, c->d[0].n, a.srcW, c->np[2].data(), 4, c->d[2].n, a.srcH) &&
                         ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, a.chrSrcW, c->np[3].data(), 4, c->d[3].n, a.chrSrcH) &&
                         c->d[1].n * 2 == t->dstW && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&
@@ -291,7 +296,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             r = ffhip_plan_scale_plane(&ch, 2, c->p[1].data(), c->p[3].data());
         const int limits[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
         {
-            const bool ok = build_fast_view(c, limits, true);
+            const bool ok = build_fast_view(c, limits, false);
             c->cw_ok = ok && ffhip_cw_bank_ok(c->np[0].data(), 4, c->d[0].n, l.srcW, c->np[2].data(), 4, c->d[2].n, l.srcH) &&
                        ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, ch.srcW, c->np[3].data(), 4, c->d[3].n, ch.srcH);
         }

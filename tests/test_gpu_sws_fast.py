@@ -277,6 +277,8 @@ RGB_CASES = [
     ("yuv420p", 96, 64, "rgb24", 136, 200, ffi.SWS_BICUBIC),          # 1.42x: byte-aligned source spans
     ("nv12", 128, 72, "bgr24", 192, 108, ffi.SWS_BICUBIC),            # 1.5x
     ("yuv420p", 202, 120, "rgb24", 456, 270, ffi.SWS_BICUBIC),        # srcW % 4 != 0, odd chroma width
+    ("yuv420p", 176, 144, "bgr24", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND | ffi.SWS_BITEXACT),  # unscaled: 1-tap luma, 4-tap chroma
+    ("nv12", 192, 108, "rgb24", 192, 216, ffi.SWS_BICUBIC),           # vertical only: 1-tap horizontal banks
 ]
 
 

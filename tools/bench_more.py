@@ -54,7 +54,7 @@ del os.environ["FFHIP_CWRGB_DIRECT"]
 os.environ["FFHIP_SWS_FAST"] = "0"
 sws("yuv420p 1080p->4K rgb24 bicubic (k_scale_rgb, LDS-tiled)", "yuv420p", 1920, 1080, "rgb24", 3840, 2160, S.SWS_BICUBIC, 32)
 del os.environ["FFHIP_SWS_FAST"]
-sws("yuv420p 1080p->rgb24 accurate_rnd (k_scale_rgb)", "yuv420p", 1920, 1080, "rgb24", 1920, 1080,
+sws("yuv420p 1080p->rgb24 accurate_rnd (1-tap luma + 4-tap chroma banks: k_sws_colwalk_rgb)", "yuv420p", 1920, 1080, "rgb24", 1920, 1080,
     S.SWS_BICUBIC | S.SWS_ACCURATE_RND | S.SWS_BITEXACT, 64)
 
 # the SwsFunc-shaped host face: PCIe + staging included
