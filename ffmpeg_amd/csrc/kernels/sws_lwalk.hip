@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t lw_pk_u8(int a, int b)
  * NG = 1: one plane, 4 columns per lane.  NG = 2: a U/V pair (byte-interleaved or planar on either side, same banks
  * for both), 2 columns of each per lane — every unit is 4 samples per lane per row, one 16-byte ring record.
  */
-template <int HT, int VT, int NL, int NG>
+template <int HT, int VT, int NL, int NG, bool AHEAD>
 __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, int cb, int lane, uint32_t *lds)
 {
     constexpr int CPL = 4 / NG;                      /* columns per lane and channel                      */
@@ -175,8 +175,8 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
         }
         __builtin_amdgcn_wave_barrier();
     };
-    /* 2a. the windows of my columns, read one row AHEAD of their use (a wave's LDS operations execute in order, so the
-     * next row may overwrite the buffer as soon as these reads are issued) */
+    /* 2a. the windows of my columns (AHEAD: read one row before their use — a wave's LDS operations execute in order, so
+     * the next row may overwrite the buffer as soon as these reads are issued) */
     struct Win { uint32_t d[NG][CPL][HT + 1]; };
     auto read_windows = [&](Win &w) {
 #pragma unroll
@@ -254,6 +254,22 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     Win w0, w1;
     load_next(b0);
     load_next(b1);
+    if (!AHEAD) {
+        /* windows read in the row they are used (the default) */
+        for (int r = rfirst; r <= rlast; r += 2) {
+            stage(b0);
+            load_next(b0);
+            read_windows(w0);
+            compute(w0, r);
+            stage(b1);
+            load_next(b1);
+            if (r + 1 <= rlast) {
+                read_windows(w0);
+                compute(w0, r + 1);
+            }
+        }
+        return;
+    }
     stage(b0);
     load_next(b0);
     read_windows(w0);
@@ -270,7 +286,7 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     }
 }
 
-template <int HT, int VT, int NL>
+template <int HT, int VT, int NL, bool AHEAD>
 __global__ __launch_bounds__(64) void k_sws_lwalk(FFHipLwArgs A)
 {
     extern __shared__ __align__(16) uint32_t lw_lds[];
@@ -285,9 +301,9 @@ __global__ __launch_bounds__(64) void k_sws_lwalk(FFHipLwArgs A)
     const int local = u - J.unit_begin;
     const int strip = local / J.ncb, cb = local - strip * J.ncb;
     if (J.pair)
-        lw_unit<HT, VT, NL, 2>(J, f, strip, cb, lane, lw_lds);
+        lw_unit<HT, VT, NL, 2, AHEAD>(J, f, strip, cb, lane, lw_lds);
     else
-        lw_unit<HT, VT, NL, 1>(J, f, strip, cb, lane, lw_lds);
+        lw_unit<HT, VT, NL, 1, AHEAD>(J, f, strip, cb, lane, lw_lds);
 }
 
 /* ---- host side ---------------------------------------------------------------------------------- */
@@ -347,14 +363,21 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
     const int nl = A.ht == 2 ? 3 : 5;
     const size_t lds = (size_t)4 * 2 * (nl * 64 + 8) + (size_t)2 * A.vt * 64 * 16;
     const dim3 grid((unsigned)waves), block(64);
+    /* measured (nv12 4K -> 1080p / 720p / 540p): reading the windows one row ahead is 1-2 % SLOWER than reading them in
+     * the row they are used (0.78 vs 0.77 ms per 128 frames) — the extra registers cost more than the latency they hide once
+     * the units are light; FFHIP_LW_AHEAD=1 selects the pipelined form */
+    const char *ea = getenv("FFHIP_LW_AHEAD");
+    const bool ahead = ea && ea[0] == '1';
 #define LW_LAUNCH(H, V, N)                                                                                   \
     do {                                                                                                     \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
-            (void)hipFuncSetAttribute((const void *)k_sws_lwalk<H, V, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            (void)hipFuncSetAttribute((const void *)k_sws_lwalk<H, V, N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            (void)hipFuncSetAttribute((const void *)k_sws_lwalk<H, V, N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((k_sws_lwalk<H, V, N>), grid, block, lds, stream, A);                             \
+        if (ahead) hipLaunchKernelGGL((k_sws_lwalk<H, V, N, true>), grid, block, lds, stream, A);            \
+        else       hipLaunchKernelGGL((k_sws_lwalk<H, V, N, false>), grid, block, lds, stream, A);           \
     } while (0)
     if (A.ht == 2 && A.vt == 4) LW_LAUNCH(2, 4, 3);
     else if (A.ht == 2 && A.vt == 8) LW_LAUNCH(2, 8, 3);

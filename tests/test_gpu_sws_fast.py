@@ -51,7 +51,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     torch = _torch()
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
-              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_SWS_WIDE", "FFHIP_CW_DUP", "FFHIP_LW_STRIP"):
+              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_SWS_WIDE", "FFHIP_CW_DUP", "FFHIP_LW_STRIP", "FFHIP_LW_AHEAD"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -330,9 +330,10 @@ WIDE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("ahead", ["0", "1"], ids=["inrow", "ahead"])
 @pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
-def test_wide_path(case, monkeypatch):
-    _run(*case, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="wide")
+def test_wide_path(case, ahead, monkeypatch):
+    _run(*case, env={"FFHIP_LW_AHEAD": ahead}, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="wide")
 
 
 @pytest.mark.parametrize("case", CASES[:7], ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
