@@ -176,6 +176,25 @@ def extras(torch, dev):
         out["hevc_idct%d_add" % nsz] = {"Mblocks/s": round(ntu / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1),
                                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "blocks": ntu, "ms": round(ms, 4)}
         del cc, c0, pic, d_t
+    # complex FFT-1024 forward, 65,536 transforms: 16,384 B per transform
+    from ffmpeg_amd import tx as _tx
+    fctx = _tx.TxContext(_tx.FLOAT_FFT, 0, 1024, 1.0)
+    fin = torch.rand((65536, 2048), dtype=torch.float32, device=dev)
+    fout = torch.empty((65536, 2048), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        fctx.batch(fout, fin)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(10):
+        fctx.batch(fout, fin)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    gbs = 65536 * 16384 / (ms * 1e-3) / 1e9
+    out["fft1024_fwd"] = {"Mtransforms/s": round(65536 / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "transforms": 65536, "ms": round(ms, 4)}
+    fctx.close()
+    del fin, fout
     # vector_fmul_window (the windowing + overlap-add after an IMDCT): 65,536 frames of len 1024 (16,384 B moved each)
     from ffmpeg_amd import fdsp
     nv, ln = 65536, 1024

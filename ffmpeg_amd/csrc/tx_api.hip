@@ -501,6 +501,44 @@ __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, i
     }
 }
 
+/*
+ * k_fft_z — AV_TX_FLOAT_FFT, power-of-two (ff_tx_fft + the split-radix codelets, libavutil/tx_template.c:540-749): the
+ * complex input is read in order (coalesced 8-byte loads) and SCATTERED through the inverse of the reference's gather
+ * permutation into the padded LDS work array, transformed there by the same flattened split-radix network as the MDCT,
+ * and written out in order.  Forward and inverse differ by the permutation only.  16 B moved per complex sample.
+ */
+__global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch,
+                                                float *out, size_t out_pitch, int nt, int waves_total)
+{
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
+        for (int i = threadIdx.x; i < blob_bytes / 16; i += blockDim.x)
+            l4[i] = s4[i];
+    }
+    __syncthreads();
+    const int *l_map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    const float *l_cos = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    const int n = d.n;
+    float2 *z = reinterpret_cast<float2 *>(lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(n));
+    for (int t = blockIdx.x * (blockDim.x >> 6) + wave; t < nt; t += waves_total) {
+        const float2 *in2 = reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
+        float2 *out2 = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
+        for (int j = lane; j < n; j += 64)
+            z[l_map[j]] = in2[j];
+        tx_wave_sync();
+        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
+        for (int i = lane; i < n; i += 64)
+            out2[i] = z[TX_PAD(i)];
+        tx_wave_sync();
+    }
+}
+
 /* ---- host: tables ------------------------------------------------------------------------------- */
 static int sr_perm(int i, int len, int inv)
 {
@@ -548,15 +586,19 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
                              uint64_t flags)
 {
     (void)flags;
-    if (!pctx || !scale)
+    static const float one = 1.0f;
+    if (!pctx || (!scale && type != FFHIP_TX_FLOAT_FFT))
         return FFHIP_EINVAL;
+    if (!scale)
+        scale = &one; /* an FFT takes no scale (av_tx_init accepts NULL there) */
     *pctx = nullptr;
-    if (type != FFHIP_TX_FLOAT_MDCT) {
-        ffhip_set_error("ffhip_tx_init: only AV_TX_FLOAT_MDCT is on the hip path");
+    if (type != FFHIP_TX_FLOAT_MDCT && type != FFHIP_TX_FLOAT_FFT) {
+        ffhip_set_error("ffhip_tx_init: only AV_TX_FLOAT_MDCT and AV_TX_FLOAT_FFT are on the hip path");
         return FFHIP_ENOSYS;
     }
-    if (len < 16 || len > 4096 || (len & (len - 1))) {
-        ffhip_set_error("ffhip_tx_init: len %d not a power of two in 16..4096", len);
+    const bool fft = type == FFHIP_TX_FLOAT_FFT;
+    if (fft ? (len < 4 || len > 2048 || (len & (len - 1))) : (len < 16 || len > 4096 || (len & (len - 1)))) {
+        ffhip_set_error("ffhip_tx_init: len %d not a power of two in %s", len, fft ? "4..2048" : "16..4096");
         return FFHIP_EINVAL;
     }
     if (!ffhip_have_device())
@@ -565,7 +607,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     if (!c)
         return FFHIP_ENOMEM;
     c->type = type; c->inv = !!inv; c->len = len; c->scale = *scale;
-    const int n = len >> 1;
+    const int n = fft ? len : len >> 1; /* complex size of the split-radix network */
     int lg = 0;
     while ((1 << lg) < n)
         lg++;
@@ -578,8 +620,8 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         map[p] = i;
     }
     /* exp table (ff_tx_mdct_gen_exp) */
-    std::vector<float2> ex(n);
-    {
+    std::vector<float2> ex(fft ? 2 : n); /* an FFT has no twiddle table of its own: keep its LDS blob small */
+    if (!fft) {
         const double sc = *scale;
         const double theta = (sc < 0 ? n : 0) + 1.0 / 8.0, rt = sqrt(fabs(sc));
         float2 *e = ex.data();
@@ -660,6 +702,38 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     if (nt == 0)
         return 0;
     const int n = c->d.n;
+    if (c->type == FFHIP_TX_FLOAT_FFT) {
+        /* complex in, complex out, contiguous (av_tx's FFT ignores `stride`); 8-byte aligned rows */
+        if (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7) {
+            ffhip_set_error("ffhip_tx: FFT batches need 8-byte aligned complex rows");
+            return FFHIP_EINVAL;
+        }
+        int wpb = 16;
+        size_t lds_z = ((c->blob_bytes + 15) & ~(size_t)15) + tx_z_bytes(n) * wpb;
+        while (wpb > 1 && lds_z > 150 * 1024) {
+            wpb >>= 1;
+            lds_z = ((c->blob_bytes + 15) & ~(size_t)15) + tx_z_bytes(n) * wpb;
+        }
+        int cus = 256, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        int per_cu = (int)((160 * 1024) / (((lds_z + 1279) / 1280) * 1280));
+        if (per_cu * wpb > 32) per_cu = 32 / wpb;
+        if (per_cu < 1) per_cu = 1;
+        int blocks = cus * per_cu;
+        if (blocks > (nt + wpb - 1) / wpb)
+            blocks = (nt + wpb - 1) / wpb;
+        static bool fft_attr = false;
+        if (!fft_attr) {
+            (void)hipFuncSetAttribute((const void *)k_fft_z, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            fft_attr = true;
+        }
+        hipLaunchKernelGGL(k_fft_z, dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
+                           (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+        LAUNCH_CHECK();
+        return 0;
+    }
     const size_t per_wave = tx_z_bytes(n) + (size_t)n * 16;
     int wpb = (int)((60 * 1024) / per_wave);
     if (wpb > 4) wpb = 4;
@@ -760,13 +834,14 @@ static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
 {
     std::lock_guard<std::mutex> lk(s->mu);
     const int len = s->len;
-    const size_t in_elems = s->inv ? (size_t)len : (size_t)2 * len, out_elems = len;
+    const bool fft = s->type == FFHIP_TX_FLOAT_FFT;
+    const size_t in_elems = fft ? (size_t)2 * len : s->inv ? (size_t)len : (size_t)2 * len, out_elems = fft ? (size_t)2 * len : (size_t)len;
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     /* the strided side is packed on the host so that the device sees contiguous data */
     std::vector<float> hin(in_elems), hout(out_elems);
     const float *fi = (const float *)in;
     for (size_t i = 0; i < in_elems; i++)
-        hin[i] = s->inv ? fi[(ptrdiff_t)i * es] : fi[i];
+        hin[i] = (s->inv && !fft) ? fi[(ptrdiff_t)i * es] : fi[i];
     const size_t need = (in_elems + out_elems) * sizeof(float) + 64;
     if (need > s->stage_sz) {
         if (s->stage)
@@ -782,11 +857,11 @@ static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
     float *din = (float *)s->stage, *dout = din + ((in_elems + 3) & ~(size_t)3);
     if (hipMemcpy(din, hin.data(), in_elems * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return;
-    if (ffhip_tx_batch_dev(s, dout, out_elems * sizeof(float), din, in_elems * sizeof(float), sizeof(float), 1, 0) < 0)
+    if (ffhip_tx_batch_dev(s, dout, ((out_elems * sizeof(float)) + 15) & ~(size_t)15, din, ((in_elems * sizeof(float)) + 15) & ~(size_t)15, sizeof(float), 1, 0) < 0)
         return;
     if (hipMemcpy(hout.data(), dout, out_elems * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         return;
     float *fo = (float *)out;
     for (size_t i = 0; i < out_elems; i++)
-        fo[s->inv ? (ptrdiff_t)i : (ptrdiff_t)i * es] = hout[i];
+        fo[(s->inv || fft) ? (ptrdiff_t)i : (ptrdiff_t)i * es] = hout[i];
 }

@@ -443,8 +443,8 @@ typedef struct FFHipTXContext FFHipTXContext;
 typedef void (*ffhip_tx_fn)(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
 /**
  * Same argument meaning as av_tx_init() (libavutil/tx.h:169-172, libavutil/tx.c:903): type, inv,
- * len (MDCT: number of output coefficients of the forward transform, power of two 16..4096 here),
- * *scale.  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
+ * len (MDCT: number of output coefficients of the forward transform, power of two 16..4096 here; FFT: number of
+ * complex samples, power of two 4..2048), *scale (FFT: ignored, may be NULL).  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
  * (libavutil/tx_priv.h:199-237).  *fn receives the single-transform host-pointer shim.
  */
 int  ffhip_tx_init(FFHipTXContext **ctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,
@@ -455,7 +455,8 @@ void ffhip_tx_uninit(FFHipTXContext **ctx);
  * the av_tx_fn `stride` (bytes between output coefficients; sizeof(float) for contiguous).
  * Forward MDCT: in = 2*len floats, out = len floats.  Inverse: in = len floats (read with
  * `in_stride` bytes between coefficients), out = len floats (half-window iMDCT as the reference's
- * default; libavutil/tx_template.c:1312-1342).
+ * default; libavutil/tx_template.c:1312-1342).  FFT (either direction): in = out = len complex (re, im) floats,
+ * contiguous and 8-byte aligned, `stride` ignored as in the reference (libavutil/tx_template.c:735-749); unnormalised.
  */
 int  ffhip_tx_batch_dev(FFHipTXContext *ctx, void *out, size_t out_pitch, const void *in, size_t in_pitch,
                         ptrdiff_t stride, int ntransforms, void *stream);

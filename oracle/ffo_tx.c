@@ -195,6 +195,38 @@ void ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride)
     free(z);
 }
 
+/*
+ * AV_TX_FLOAT_FFT, power-of-two: the out-of-place wrapper gathers the input through the split-radix permutation
+ * (ff_tx_fft, libavutil/tx_template.c:735-749; map from ff_tx_gen_ptwo_revtab, tx.c:125-155) and runs the same
+ * "no shuffle" split-radix network the MDCT uses; the inverse differs by the permutation only.  Complex interleaved
+ * (re, im) floats in and out, len of each; unnormalised.
+ */
+void ffo_fft_run(int inv, int len, float *out, const float *in)
+{
+    struct FfoTx s;
+    memset(&s, 0, sizeof(s));
+    int lg = 0;
+    while ((1 << lg) < len)
+        lg++;
+    for (int l = 2; l <= lg; l++) {
+        const int m = 1 << l;
+        const double freq = 2 * M_PI / m;
+        s.cos_tab[l] = malloc(sizeof(float) * (m / 4 + 1));
+        for (int i = 0; i < m / 4; i++)
+            s.cos_tab[l][i] = (float)cos(i * freq);
+        s.cos_tab[l][m / 4] = 0;
+    }
+    cpx *z = malloc(sizeof(cpx) * len);
+    const cpx *src = (const cpx *)in;
+    for (int i = 0; i < len; i++)
+        z[i] = src[-sr_perm(i, len, inv) & (len - 1)];
+    sr_fft(&s, z, len, lg);
+    memcpy(out, z, sizeof(cpx) * len);
+    free(z);
+    for (int l = 0; l < 20; l++)
+        free(s.cos_tab[l]);
+}
+
 /* ff_tx_mdct_naive_fwd: tx_template.c:1144-1163 — in 2*len, out len (double results) */
 void ffo_mdct_naive_fwd(int len, double scale, double *out, const float *in)
 {

@@ -59,6 +59,11 @@ def test_no_device_means_enosys_not_a_cpu_fallback():
     assert L.ffhip_h264_deblock_frame_dev(p, 64, 1, 1, p, None) == ENOSYS
     assert L.ffhip_me_cmp_batch_dev(0, 16, 16, p, p, p, p, 64, p, 1, None) == ENOSYS
     assert L.ffhip_me_esa_batch_dev(p, p, 64, 64, 64, 4096, 1, 16, 7, 0, p, p, None) == ENOSYS
+    assert L.ffhip_hevc_idct_batch_dev(0, 3, p, p, 64, p, 1, None) == ENOSYS
+    assert L.ff_hevc_dsp_init_hip(p, 8) == ENOSYS and not any(buf)
+    assert L.ffhip_fdsp_batch_dev(0, p, 0, p, 0, p, 0, None, 0, 0.0, 4, 1, None) == ENOSYS
+    assert L.ff_float_dsp_init_hip(p) == ENOSYS and not any(buf)
+    assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 0, 1, 256, None, 0) == ENOSYS and not ctx.value   # FFT
     vp = C.c_void_p()
     assert L.ffhip_malloc(C.byref(vp), 16) == ENOSYS
     from ffmpeg_amd import swscale as S
@@ -74,7 +79,10 @@ def test_argument_validation():
     assert L.ffhip_h264_idct_add_batch_dev(1, None, 64, None, None, 1, None) == EINVAL
     ctx, fn, sc = _lib.vp(), _lib.vp(), C.c_float(1.0)
     assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 1, 0, 1000, C.byref(sc), 0) == EINVAL      # not a power of two
-    assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 0, 0, 1024, C.byref(sc), 0) == -38         # FFT: not on the hip path
+    assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 0, 0, 1000, C.byref(sc), 0) == EINVAL      # FFT: power of two only
+    assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 2, 0, 1024, C.byref(sc), 0) == -38         # AV_TX_DOUBLE_FFT: not on the hip path
+    assert L.ffhip_hevc_idct_batch_dev(0, 7, None, None, 0, None, 1, None) == EINVAL
+    assert L.ffhip_fdsp_batch_dev(99, None, 0, None, 0, None, 0, None, 0, 0.0, 4, 1, None) == EINVAL
 
 
 def test_host_tables_are_device_free():

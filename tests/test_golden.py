@@ -180,3 +180,15 @@ def test_fdsp_golden():
             O.ffo_fdsp(op, ptr(dst, f32p), ptr(s0, f32p), ptr(np.ascontiguousarray(d[k + "s1"]), f32p),
                        ptr(np.ascontiguousarray(d[k + "s2"]), f32p), float(d[k + "mul"][0]), n)
             assert np.array_equal(dst.view(np.uint32), d[k + "out"]) and np.array_equal(s0.view(np.uint32), d[k + "out0"]), (op, n)
+
+
+def test_fft_golden():
+    O = ffi.oracle()
+    d = load("fft")
+    for len_ in (8, 256, 1024):
+        for inv in (0, 1):
+            x, want = d["fft%d_%d_in" % (len_, inv)], d["fft%d_%d_out" % (len_, inv)]
+            for t in range(x.shape[0]):
+                out = np.zeros(2 * len_, np.float32)
+                O.ffo_fft_run(inv, len_, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p))
+                assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), (len_, inv)

@@ -194,3 +194,17 @@ def test_fdsp_golden_gpu():
             torch.cuda.synchronize()
             assert np.array_equal(t[0].cpu().numpy().reshape(-1).view(np.uint32), d[k + "out"]), (op, n)
             assert np.array_equal(t[1].cpu().numpy().reshape(-1).view(np.uint32), d[k + "out0"]), (op, n)
+
+
+def test_fft_golden_gpu():
+    from ffmpeg_amd import tx
+    torch = _torch()
+    d = G.load("fft")
+    for len_ in (8, 256, 1024):
+        for inv in (0, 1):
+            x, want = d["fft%d_%d_in" % (len_, inv)], d["fft%d_%d_out" % (len_, inv)]
+            ctx = tx.TxContext(tx.FLOAT_FFT, inv, len_, 1.0)
+            out = torch.zeros((x.shape[0], 2 * len_), dtype=torch.float32, device="cuda:0")
+            ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (len_, inv)
+            ctx.close()

@@ -148,3 +148,31 @@ def test_mdct_aac_batch_property():
     inp = d_in[idx].cpu().numpy()
     _check(d_out[idx].cpu().numpy(), _oracle(0, len_, 1.0, inp))
     f.close()
+
+
+@pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("len_", [4, 8, 32, 256, 1024, 2048])
+def test_fft_batch(len_, inv):
+    """AV_TX_FLOAT_FFT, power-of-two: bit-identical to the oracle (= the reference); the host-pointer face too"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    rng = np.random.default_rng(len_ * 2 + inv)
+    nt = 3000 if len_ == 1024 else 41
+    x = (rng.standard_normal((nt, 2 * len_)) * 10.0 ** rng.integers(-3, 4, (nt, 1))).astype(np.float32)
+    x[1] = 0
+    want = np.zeros_like(x)
+    O = ffi.oracle()
+    for t in range(nt):
+        O.ffo_fft_run(inv, len_, ptr(want[t], f32p), ptr(x[t], f32p))
+    ctx = tx.TxContext(tx.FLOAT_FFT, inv, len_, 1.0)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((nt, 2 * len_), dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out, d_in)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "max |diff| %g" % np.abs(got - want).max()
+    one = np.zeros(2 * len_, np.float32)
+    xin = x[0].copy()
+    ctx.fn(one, xin, 8)
+    assert np.array_equal(one.view(np.uint32), want[0].view(np.uint32))
+    ctx.close()

@@ -408,6 +408,24 @@ def test_mdct_float(len_, inv):
 
 
 @pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("len_", [4, 8, 16, 64, 256, 1024, 2048, 4096])
+def test_fft_float(len_, inv):
+    """AV_TX_FLOAT_FFT power-of-two, both directions: bit-identical (tests/checkasm/av_tx.c compares to 5e-4 only)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rc = R.ffref_tx_create(0, inv, len_, 1.0, 0)
+    assert rc
+    rng = np.random.default_rng(len_ + inv)
+    for rep in range(4):
+        x = (rng.standard_normal(2 * len_) * 10.0 ** float(rng.integers(-3, 4))).astype(np.float32)
+        a, b = np.zeros(2 * len_, np.float32), np.zeros(2 * len_, np.float32)
+        xi = x.copy()
+        R.ffref_tx_run(rc, ptr(a, f32p), ptr(xi, f32p), 8)
+        O.ffo_fft_run(inv, len_, ptr(b, f32p), ptr(x, f32p))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    R.ffref_tx_free(rc)
+
+
+@pytest.mark.parametrize("inv", [0, 1])
 def test_mdct_vs_naive(inv):
     """the float transform stays within 2^-18 * max|ref| of the double-precision cosine sum"""
     O = ffi.oracle()

@@ -159,6 +159,22 @@ def tx():
     np.savez_compressed(os.path.join(OUT, "tx.npz"), **d)
 
 
+def fft():
+    """AV_TX_FLOAT_FFT, power-of-two, both directions: 3 transforms per (len, inv)"""
+    d = {}
+    rng = np.random.default_rng(1005)
+    for len_ in (8, 256, 1024):
+        for inv in (0, 1):
+            x = rng.uniform(-1, 1, (3, 2 * len_)).astype(np.float32)
+            rc = R.ffref_tx_create(0, inv, len_, 1.0, 0)
+            out = np.zeros((3, 2 * len_), np.float32)
+            for t in range(3):
+                R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 8)
+            R.ffref_tx_free(rc)
+            d["fft%d_%d_in" % (len_, inv)], d["fft%d_%d_out" % (len_, inv)] = x, out
+    np.savez_compressed(os.path.join(OUT, "fft.npz"), **d)
+
+
 def hevc():
     """HEVC inverse transforms: per size 24 blocks (dense / small / sparse / saturating) x col_limits, DC, 4x4 luma DST,
     add_residual on a padded picture"""
@@ -227,6 +243,6 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); me(); tx(); hevc(); fdsp()
+        sws(); h264(); me(); tx(); fft(); hevc(); fdsp()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
