@@ -103,6 +103,15 @@ extern "C" int ffhip_hevc_idct_batch_dev(int kind, int log2_size, int16_t *coeff
     return ffhip_launch_hevc_idct(kind, log2_size, coeffs, dst, stride, tus, n, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_hevc_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, void *stream)
+{
+    if (!base || !edges || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_loop_filter(base, stride, edges, n, (hipStream_t)stream);
+}
+
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */
 extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1,
                                     size_t pitch1, const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream)

@@ -218,3 +218,90 @@ int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *ds
     LAUNCH_CHECK();
     return 0;
 }
+
+/* ================================================================================================== */
+/*
+ * HEVC deblocking, 8-bit: hevc_{h,v}_loop_filter_{luma,chroma} (libavcodec/hevc/dsp_template.c:834-929) with the
+ * strong / weak / chroma filters of libavcodec/h26x/h2656_deblock_template.c:25-104, batched over edge segments whose
+ * pixels are disjoint (all vertical edges of a picture, then all horizontal ones: HEVC has no order inside a direction).
+ * 8 lanes per segment, one per sample line; the two 4-line groups decide from their lines 0 and 3, which the lanes of a
+ * group exchange with DPP-style shuffles.  Every read of a line happens before any write of it.
+ */
+__device__ __forceinline__ int hv_abs(int v) { return v < 0 ? -v : v; }
+
+__global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n)
+{
+    const int e = (blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int line = threadIdx.x & 7, j = line >> 2, d = line & 3;
+    const bool live = e < n;
+    const FFHipHevcEdge ed = edges[live ? e : 0];
+    const bool vertical = ed.kind & 1, chroma = ed.kind & 2;
+    const ptrdiff_t xs = vertical ? 1 : stride, ys = vertical ? stride : 1;
+    uint8_t *pix = base + ed.offset + (ptrdiff_t)line * ys;
+    const int tc = ed.tc[j], no_p = ed.no_p[j], no_q = ed.no_q[j], beta = ed.beta;
+    int p3 = 0, p2 = 0, p1 = 0, p0 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (live) {
+        p1 = pix[-2 * xs]; p0 = pix[-xs]; q0 = pix[0]; q1 = pix[xs];
+        if (!chroma) {
+            p3 = pix[-4 * xs]; p2 = pix[-3 * xs]; q2 = pix[2 * xs]; q3 = pix[3 * xs];
+        }
+    }
+    if (chroma) {
+        if (live && tc > 0) {
+            const int delta = clip3((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
+            if (!no_p) pix[-xs] = (uint8_t)clip_u8(p0 + delta);
+            if (!no_q) pix[0] = (uint8_t)clip_u8(q0 - delta);
+        }
+        return;
+    }
+    /* decisions of my group from its lines 0 and 3 (all 64 lanes take part in the shuffles) */
+    const int dp = hv_abs(p2 - 2 * p1 + p0), dq = hv_abs(q2 - 2 * q1 + q0);
+    const int flat = hv_abs(p3 - p0) + hv_abs(q3 - q0), step = hv_abs(p0 - q0);
+    const int l0 = (threadIdx.x & 63) & ~3, l3 = l0 + 3;
+    const int dp0 = __shfl(dp, l0, 64), dp3 = __shfl(dp, l3, 64), dq0 = __shfl(dq, l0, 64), dq3 = __shfl(dq, l3, 64);
+    const int flat0 = __shfl(flat, l0, 64), flat3 = __shfl(flat, l3, 64), step0 = __shfl(step, l0, 64), step3 = __shfl(step, l3, 64);
+    (void)d;
+    if (!live)
+        return;
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta)
+        return;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    if (flat0 < beta_3 && step0 < tc25 && flat3 < beta_3 && step3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+        const int t = tc << 1;
+        if (!no_p) {
+            pix[-xs]     = (uint8_t)(p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -t, t));
+            pix[-2 * xs] = (uint8_t)(p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -t, t));
+            pix[-3 * xs] = (uint8_t)(p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -t, t));
+        }
+        if (!no_q) {
+            pix[0]      = (uint8_t)(q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -t, t));
+            pix[xs]     = (uint8_t)(q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -t, t));
+            pix[2 * xs] = (uint8_t)(q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -t, t));
+        }
+    } else {
+        const int side = (beta + (beta >> 1)) >> 3;
+        const int nd_p = dp0 + dp3 < side ? 2 : 1, nd_q = dq0 + dq3 < side ? 2 : 1, tc_2 = tc >> 1;
+        int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+        if (hv_abs(delta) < 10 * tc) {
+            delta = clip3(delta, -tc, tc);
+            if (!no_p) pix[-xs] = (uint8_t)clip_u8(p0 + delta);
+            if (!no_q) pix[0] = (uint8_t)clip_u8(q0 - delta);
+            if (!no_p && nd_p > 1)
+                pix[-2 * xs] = (uint8_t)clip_u8(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2));
+            if (!no_q && nd_q > 1)
+                pix[xs] = (uint8_t)clip_u8(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2));
+        }
+    }
+}
+
+int ffhip_launch_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_hevc_loop_filter, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+static_assert(sizeof(FFHipHevcEdge) == 16, "FFHipHevcEdge is a 16-byte record");
+static_assert(sizeof(FFHipHevcTU) == 12, "FFHipHevcTU is a 12-byte record");

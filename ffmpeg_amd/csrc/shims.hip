@@ -348,6 +348,33 @@ static void hevc_single(int kind, int log2_size, int16_t *coeffs, int col_limit,
 HEVC_FN(0) HEVC_FN(1) HEVC_FN(2) HEVC_FN(3)
 static void s_hevc_dst4(int16_t *c) { hevc_single(FFHIP_HEVC_DST_4X4, 2, c, 0, nullptr, 0); }
 
+/* one edge segment: the 8 lines x 8 samples around it staged as a rectangle (h_: rows -4..3 x cols 0..7, v_: rows 0..7 x cols -4..3) */
+static void hevc_lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const bool vertical = kind & 1;
+    Rect d = { pix, stride, vertical ? 0 : -4, vertical ? 7 : 3, vertical ? -4 : 0, vertical ? 3 : 7, nullptr };
+    void *scratch;
+    if (ffhip_scratch_reserve(rect_bytes(d) + 128, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    if (!rect_up(d, buf + 64))
+        return;
+    FFHipHevcEdge e;
+    memset(&e, 0, sizeof(e));
+    e.offset = (int32_t)(d.dev - buf); e.kind = (uint8_t)kind; e.beta = (uint8_t)beta;
+    for (int j = 0; j < 2; j++) { e.tc[j] = (int16_t)tc[j]; e.no_p[j] = no_p[j]; e.no_q[j] = no_q[j]; }
+    if (hipMemcpy(buf, &e, sizeof(e), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_hevc_loop_filter(buf, DP, (const FFHipHevcEdge *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    rect_down(d, d.r0, d.r1, d.c0, d.c1);
+}
+static void s_hevc_lf_hl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_H_LUMA, p, st, beta, tc, np_, nq); }
+static void s_hevc_lf_vl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_V_LUMA, p, st, beta, tc, np_, nq); }
+static void s_hevc_lf_hc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_H_CHROMA, p, st, 0, tc, np_, nq); }
+static void s_hevc_lf_vc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_V_CHROMA, p, st, 0, tc, np_, nq); }
+
 extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
 {
     if (!c || bit_depth != 8)
@@ -358,6 +385,10 @@ extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
     c->idct_dc[0] = s_hevc_dc0; c->idct_dc[1] = s_hevc_dc1; c->idct_dc[2] = s_hevc_dc2; c->idct_dc[3] = s_hevc_dc3;
     c->add_residual[0] = s_hevc_add0; c->add_residual[1] = s_hevc_add1; c->add_residual[2] = s_hevc_add2; c->add_residual[3] = s_hevc_add3;
     c->transform_4x4_luma = s_hevc_dst4;
+    c->hevc_h_loop_filter_luma = c->hevc_h_loop_filter_luma_c = s_hevc_lf_hl;
+    c->hevc_v_loop_filter_luma = c->hevc_v_loop_filter_luma_c = s_hevc_lf_vl;
+    c->hevc_h_loop_filter_chroma = c->hevc_h_loop_filter_chroma_c = s_hevc_lf_hc;
+    c->hevc_v_loop_filter_chroma = c->hevc_v_loop_filter_chroma_c = s_hevc_lf_vc;
     return 0;
 }
 

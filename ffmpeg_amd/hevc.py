@@ -22,12 +22,30 @@ def idct_batch(kind, log2_size, coeffs, dst, stride, tus, n, stream=None):
                                                            stride, tus.data_ptr(), n, _stream(stream)), "ffhip_hevc_idct_batch_dev")
 
 
+LF_H_LUMA, LF_V_LUMA, LF_H_CHROMA, LF_V_CHROMA = 0, 1, 2, 3
+
+#: FFHipHevcEdge (include/ffhip.h)
+EDGE_DTYPE = np.dtype([("offset", np.int32), ("kind", np.uint8), ("beta", np.uint8), ("no_p", np.uint8, 2), ("no_q", np.uint8, 2),
+                       ("tc", np.int16, 2), ("pad", np.uint8, 2)])
+
+
+def loop_filter_batch(base, stride, edges, n, stream=None):
+    """edges: uint8 [n, 16] FFHipHevcEdge records whose pixels are disjoint (one direction of a picture per call)"""
+    return _lib.check(_lib.lib().ffhip_hevc_loop_filter_batch_dev(base.data_ptr(), stride, edges.data_ptr(), n, _stream(stream)),
+                      "ffhip_hevc_loop_filter_batch_dev")
+
+
 class HEVCDSPContext(C.Structure):
     """FFHipHEVCDSPContext: host-pointer faces with the reference's signatures"""
     _fields_ = [("add_residual", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t) * 4),
                 ("transform_4x4_luma", C.CFUNCTYPE(None, C.c_void_p)),
                 ("idct", C.CFUNCTYPE(None, C.c_void_p, C.c_int) * 4),
-                ("idct_dc", C.CFUNCTYPE(None, C.c_void_p) * 4)]
+                ("idct_dc", C.CFUNCTYPE(None, C.c_void_p) * 4)] + \
+               [(nm, C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+                 if "luma" in nm else C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.c_void_p))
+                for nm in ("hevc_h_loop_filter_luma", "hevc_v_loop_filter_luma", "hevc_h_loop_filter_chroma", "hevc_v_loop_filter_chroma",
+                           "hevc_h_loop_filter_luma_c", "hevc_v_loop_filter_luma_c", "hevc_h_loop_filter_chroma_c",
+                           "hevc_v_loop_filter_chroma_c")]
 
 
 def dsp_init(bit_depth=8):

@@ -372,11 +372,20 @@ int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0
 typedef void (*ffhip_hevc_idct_func)(int16_t *coeffs, int col_limit);
 typedef void (*ffhip_hevc_idct_dc_func)(int16_t *coeffs);
 typedef void (*ffhip_hevc_add_residual_func)(uint8_t *dst, const int16_t *res, ptrdiff_t stride);
+/** hevc_{h,v}_loop_filter_luma / _chroma (hevc/dsp.h:103-124): 8 sample lines along an edge, two groups of 4 with their own
+ *  tc / no_p / no_q.  h_: the edge is horizontal (samples of a line are `stride` apart). */
+typedef void (*ffhip_hevc_lf_luma_func)(uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p,
+                                        const uint8_t *no_q);
+typedef void (*ffhip_hevc_lf_chroma_func)(uint8_t *pix, ptrdiff_t stride, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q);
 typedef struct FFHipHEVCDSPContext {
     ffhip_hevc_add_residual_func add_residual[4];
     void (*transform_4x4_luma)(int16_t *coeffs);
     ffhip_hevc_idct_func    idct[4];
     ffhip_hevc_idct_dc_func idct_dc[4];
+    ffhip_hevc_lf_luma_func   hevc_h_loop_filter_luma, hevc_v_loop_filter_luma;
+    ffhip_hevc_lf_chroma_func hevc_h_loop_filter_chroma, hevc_v_loop_filter_chroma;
+    ffhip_hevc_lf_luma_func   hevc_h_loop_filter_luma_c, hevc_v_loop_filter_luma_c;     /* the decoder's "_c" slots: same functions */
+    ffhip_hevc_lf_chroma_func hevc_h_loop_filter_chroma_c, hevc_v_loop_filter_chroma_c;
 } FFHipHEVCDSPContext;
 /** ff_hevc_dsp_init_<arch> shape (libavcodec/hevc/dsp.h:127-140).  bit_depth must be 8. */
 int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth);
@@ -399,6 +408,27 @@ typedef struct FFHipHevcTU {
  */
 int ffhip_hevc_idct_batch_dev(int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride,
                               const FFHipHevcTU *tus, int n, void *stream);
+
+#define FFHIP_HEVC_LF_H_LUMA    0
+#define FFHIP_HEVC_LF_V_LUMA    1
+#define FFHIP_HEVC_LF_H_CHROMA  2
+#define FFHIP_HEVC_LF_V_CHROMA  3
+/** One edge segment of the batch face: everything a hevc_*_loop_filter_* call takes besides pix/stride. */
+typedef struct FFHipHevcEdge {
+    int32_t offset;      /* pix = base + offset */
+    uint8_t kind;        /* FFHIP_HEVC_LF_* */
+    uint8_t beta;        /* luma only (betatable tops out at 64) */
+    uint8_t no_p[2], no_q[2];
+    int16_t tc[2];
+    uint8_t pad[2];      /* sizeof == 16 */
+} FFHipHevcEdge;
+/**
+ * n edge segments whose touched pixels are pairwise DISJOINT.  HEVC deblocking has no order dependency inside one
+ * direction (edges lie on an 8x8 grid and change at most 3 samples on either side): a picture is one call with all its
+ * vertical edges followed by one call with all its horizontal edges (libavcodec/hevc/filter.c ff_hevc_deblocking_boundary_strengths
+ * / deblocking_filter_CTB).
+ */
+int ffhip_hevc_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */

@@ -83,6 +83,9 @@ void ffo_hevc_idct(int log2_size, int16_t *coeffs, int col_limit);  /* log2_size
 void ffo_hevc_idct_dc(int log2_size, int16_t *coeffs);
 void ffo_hevc_transform_4x4_luma(int16_t *coeffs);
 void ffo_hevc_add_residual(int log2_size, uint8_t *dst, const int16_t *res, ptrdiff_t stride);
+/* hevc_{h,v}_loop_filter_{luma,chroma}: vertical = 1 for hevc_v_* (the edge is vertical); beta unused for chroma */
+void ffo_hevc_loop_filter(int chroma, int vertical, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc,
+                          const uint8_t *no_p, const uint8_t *no_q);
 /* frame-order luma deblock, same edge array layout as ffhip_h264_deblock_frame_dev (include/ffhip.h) */
 typedef struct FfoH264Edge {
     int32_t offset;

@@ -117,3 +117,78 @@ void ffo_hevc_add_residual(int log2_size, uint8_t *dst, const int16_t *res, ptrd
         for (int x = 0; x < n; x++)
             dst[y * stride + x] = (uint8_t)clip8(dst[y * stride + x] + res[y * n + x]);
 }
+
+/*
+ * HEVC deblocking, 8-bit: hevc_{h,v}_loop_filter_{luma,chroma} (libavcodec/hevc/dsp_template.c:834-929) with the
+ * strong / weak / chroma filters of libavcodec/h26x/h2656_deblock_template.c:25-104.  One call covers 8 sample lines
+ * along the edge in two groups of 4; a group's decisions read its lines 0 and 3.  vertical != 0: the edge is vertical
+ * (hevc_v_*: samples of a line are 1 byte apart, lines are stride apart).
+ */
+static int iabs(int v) { return v < 0 ? -v : v; }
+static int clip3i(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+void ffo_hevc_loop_filter(int chroma, int vertical, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc_in,
+                          const uint8_t *no_p_in, const uint8_t *no_q_in)
+{
+    const ptrdiff_t xs = vertical ? 1 : stride, ys = vertical ? stride : 1;
+#define PX(line, k) (pix[(line) * ys + (k) * xs]) /* k = -4..3: p3 p2 p1 p0 | q0 q1 q2 q3 */
+    for (int j = 0; j < 2; j++) {
+        uint8_t *const save = pix;
+        pix += j * 4 * ys;
+        const int tc = tc_in[j], no_p = no_p_in[j], no_q = no_q_in[j];
+        if (chroma) {
+            if (tc > 0)
+                for (int d = 0; d < 4; d++) {
+                    const int p1 = PX(d, -2), p0 = PX(d, -1), q0 = PX(d, 0), q1 = PX(d, 1);
+                    const int delta = clip3i((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
+                    if (!no_p) PX(d, -1) = (uint8_t)clip8(p0 + delta);
+                    if (!no_q) PX(d, 0) = (uint8_t)clip8(q0 - delta);
+                }
+            pix = save;
+            continue;
+        }
+        const int dp0 = iabs(PX(0, -3) - 2 * PX(0, -2) + PX(0, -1)), dq0 = iabs(PX(0, 2) - 2 * PX(0, 1) + PX(0, 0));
+        const int dp3 = iabs(PX(3, -3) - 2 * PX(3, -2) + PX(3, -1)), dq3 = iabs(PX(3, 2) - 2 * PX(3, 1) + PX(3, 0));
+        const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+        if (d0 + d3 < beta) {
+            const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+            if (iabs(PX(0, -4) - PX(0, -1)) + iabs(PX(0, 3) - PX(0, 0)) < beta_3 && iabs(PX(0, -1) - PX(0, 0)) < tc25 &&
+                iabs(PX(3, -4) - PX(3, -1)) + iabs(PX(3, 3) - PX(3, 0)) < beta_3 && iabs(PX(3, -1) - PX(3, 0)) < tc25 &&
+                (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+                const int t = tc << 1; /* the reference passes the same bound three times */
+                for (int d = 0; d < 4; d++) {
+                    const int p3 = PX(d, -4), p2 = PX(d, -3), p1 = PX(d, -2), p0 = PX(d, -1);
+                    const int q0 = PX(d, 0), q1 = PX(d, 1), q2 = PX(d, 2), q3 = PX(d, 3);
+                    if (!no_p) {
+                        PX(d, -1) = (uint8_t)(p0 + clip3i(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -t, t));
+                        PX(d, -2) = (uint8_t)(p1 + clip3i(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -t, t));
+                        PX(d, -3) = (uint8_t)(p2 + clip3i(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -t, t));
+                    }
+                    if (!no_q) {
+                        PX(d, 0) = (uint8_t)(q0 + clip3i(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -t, t));
+                        PX(d, 1) = (uint8_t)(q1 + clip3i(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -t, t));
+                        PX(d, 2) = (uint8_t)(q2 + clip3i(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -t, t));
+                    }
+                }
+            } else {
+                const int side = (beta + (beta >> 1)) >> 3;
+                const int nd_p = dp0 + dp3 < side ? 2 : 1, nd_q = dq0 + dq3 < side ? 2 : 1, tc_2 = tc >> 1;
+                for (int d = 0; d < 4; d++) {
+                    const int p2 = PX(d, -3), p1 = PX(d, -2), p0 = PX(d, -1), q0 = PX(d, 0), q1 = PX(d, 1), q2 = PX(d, 2);
+                    int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+                    if (iabs(delta) < 10 * tc) {
+                        delta = clip3i(delta, -tc, tc);
+                        if (!no_p) PX(d, -1) = (uint8_t)clip8(p0 + delta);
+                        if (!no_q) PX(d, 0) = (uint8_t)clip8(q0 - delta);
+                        if (!no_p && nd_p > 1)
+                            PX(d, -2) = (uint8_t)clip8(p1 + clip3i((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2));
+                        if (!no_q && nd_q > 1)
+                            PX(d, 1) = (uint8_t)clip8(q1 + clip3i((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2));
+                    }
+                }
+            }
+        }
+        pix = save;
+    }
+#undef PX
+}

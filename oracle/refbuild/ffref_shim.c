@@ -219,6 +219,20 @@ void ffref_hevc_add_residual(int idx, uint8_t *dst, const int16_t *res, ptrdiff_
     dsp_init();
     hevc.add_residual[idx](dst, res, stride);
 }
+void ffref_hevc_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q)
+{
+    dsp_init();
+    switch (which) {
+    case 0: hevc.hevc_h_loop_filter_luma(pix, stride, beta, tc, no_p, no_q); break;
+    case 1: hevc.hevc_v_loop_filter_luma(pix, stride, beta, tc, no_p, no_q); break;
+    case 2: hevc.hevc_h_loop_filter_chroma(pix, stride, tc, no_p, no_q); break;
+    case 3: hevc.hevc_v_loop_filter_chroma(pix, stride, tc, no_p, no_q); break;
+    case 4: hevc.hevc_h_loop_filter_luma_c(pix, stride, beta, tc, no_p, no_q); break;
+    case 5: hevc.hevc_v_loop_filter_luma_c(pix, stride, beta, tc, no_p, no_q); break;
+    case 6: hevc.hevc_h_loop_filter_chroma_c(pix, stride, tc, no_p, no_q); break;
+    case 7: hevc.hevc_v_loop_filter_chroma_c(pix, stride, tc, no_p, no_q); break;
+    }
+}
 int ffref_me_cmp(int kind, int idx, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
 {
     dsp_init();

@@ -103,6 +103,8 @@ def oracle():
         L.ffo_hevc_transform_4x4_luma.restype = None
         L.ffo_hevc_add_residual.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
         L.ffo_hevc_add_residual.restype = None
+        L.ffo_hevc_loop_filter.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, i32p, u8p, u8p]
+        L.ffo_hevc_loop_filter.restype = None
         L.ffo_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_h264_biweight.restype = None
         L.ffo_h264_deblock_frame.argtypes = [u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
@@ -174,6 +176,8 @@ def ref():
         L.ffref_hevc_transform_4x4_luma.restype = None
         L.ffref_hevc_add_residual.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
         L.ffref_hevc_add_residual.restype = None
+        L.ffref_hevc_loop_filter.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, i32p, u8p, u8p]
+        L.ffref_hevc_loop_filter.restype = None
         L.ffref_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffref_h264_biweight.restype = None
         L.ffref_me_cmp.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]

@@ -168,6 +168,12 @@ def test_hevc_golden():
     for t in range(len(a)):
         O.ffo_hevc_transform_4x4_luma(ptr(a[t], i16p))
     assert np.array_equal(a, d["dst4"])
+    o = d["lf_in"].copy()
+    for i, (which, beta, t0, t1, p0, p1, q0, q1) in enumerate(d["lf_par"]):
+        off = 4 * 16 + 8 if which & 1 else 8 * 16 + 4
+        O.ffo_hevc_loop_filter(int(which) >> 1, int(which) & 1, at(o[i], off), 16, int(beta), ptr(np.array([t0, t1], np.int32), i32p),
+                               ptr(np.array([p0, p1], np.uint8)), ptr(np.array([q0, q1], np.uint8)))
+    assert np.array_equal(o, d["lf_out"])
 
 
 def test_fdsp_golden():

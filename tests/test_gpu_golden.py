@@ -182,6 +182,23 @@ def test_hevc_golden_gpu():
         assert np.array_equal(d_p.cpu().numpy(), d["add%d" % lg]), lg
 
 
+def test_hevc_lf_golden_gpu():
+    """the HIP loop filters on the reference's golden neighbourhoods (one call per direction: pixels are disjoint)"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    d = G.load("hevc")
+    par = d["lf_par"]
+    n = len(par)
+    ed = np.zeros(n, hevc.EDGE_DTYPE)
+    ed["offset"] = np.arange(n) * 256 + np.where(par[:, 0] & 1, 4 * 16 + 8, 8 * 16 + 4)
+    ed["kind"], ed["beta"] = par[:, 0], par[:, 1]
+    ed["tc"], ed["no_p"], ed["no_q"] = par[:, 2:4], par[:, 4:6], par[:, 6:8]
+    pic = torch.from_numpy(d["lf_in"].copy()).cuda()
+    hevc.loop_filter_batch(pic, 16, torch.from_numpy(ed.view(np.uint8).reshape(n, 16).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    assert np.array_equal(pic.cpu().numpy(), d["lf_out"])
+
+
 def test_fdsp_golden_gpu():
     from ffmpeg_amd import fdsp
     torch = _torch()

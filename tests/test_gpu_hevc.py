@@ -111,3 +111,88 @@ def test_hevc_host_faces():
     c.transform_4x4_luma(a.ctypes.data)
     O.ffo_hevc_transform_4x4_luma(ptr(b, ffi.i16p))
     assert np.array_equal(a, b)
+
+
+def _lf_picture(rng, w, h):
+    """smooth blocks with steps on the 8x8 grid (so that all three filter classes fire) plus noise patches"""
+    pic = np.zeros((h, w), np.int64)
+    for by in range(0, h, 8):
+        for bx in range(0, w, 8):
+            pic[by:by + 8, bx:bx + 8] = rng.integers(30, 220)
+    pic = pic + rng.integers(-2, 3, (h, w))
+    noisy = rng.random((h // 8, w // 8)) < .15
+    pic = np.where(np.kron(noisy, np.ones((8, 8), bool)), rng.integers(0, 256, (h, w)), pic)
+    small = rng.random((h // 8, w // 8)) < .5                       # neighbours a few levels apart: weak / strong filters
+    pic = np.where(np.kron(small, np.ones((8, 8), bool)), 120 + (pic % 9), pic)
+    return np.clip(pic, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("chroma", [0, 1])
+def test_hevc_deblock_picture(chroma):
+    """a picture's worth of edge segments: all vertical edges in one call, then all horizontal ones (the decoder's order),
+    against the oracle applied segment by segment in the same two phases"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    rng = np.random.default_rng(40 + chroma)
+    W, H, pad = 256, 128, 24
+    stride = W + pad
+    pic = np.zeros((H, stride), np.uint8)
+    pic[:, :W] = _lf_picture(rng, W, H)
+    want = pic.copy()
+    O = ffi.oracle()
+    d_pic = torch.from_numpy(pic.copy()).cuda()
+    changed = 0
+    for vertical in (1, 0):
+        segs = []
+        if vertical:
+            for x in range(8, W, 8):
+                for y in range(0, H, 8):
+                    segs.append(y * stride + x)
+        else:
+            for y in range(8, H, 8):
+                for x in range(0, W, 8):
+                    segs.append(y * stride + x)
+        n = len(segs)
+        ed = np.zeros(n, hevc.EDGE_DTYPE)
+        ed["offset"] = segs
+        ed["kind"] = (2 if chroma else 0) + vertical
+        ed["beta"] = rng.integers(0, 65, n)
+        ed["tc"] = rng.integers(0, 25, (n, 2))
+        ed["no_p"] = rng.random((n, 2)) < .1
+        ed["no_q"] = rng.random((n, 2)) < .1
+        before = want.copy()
+        for i in range(n):
+            O.ffo_hevc_loop_filter(chroma, vertical, C.cast(want.ctypes.data + int(ed["offset"][i]), u8p), stride, int(ed["beta"][i]),
+                                   ptr(ed["tc"][i].astype(np.int32), ffi.i32p), ptr(np.ascontiguousarray(ed["no_p"][i])),
+                                   ptr(np.ascontiguousarray(ed["no_q"][i])))
+        changed += int((before != want).sum())
+        hevc.loop_filter_batch(d_pic, stride, torch.from_numpy(ed.view(np.uint8).reshape(n, 16).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    assert changed > 2000
+    assert np.array_equal(d_pic.cpu().numpy(), want)
+
+
+def test_hevc_deblock_host_faces():
+    from ffmpeg_amd import hevc
+    _torch()
+    c = hevc.dsp_init(8)
+    O = ffi.oracle()
+    rng = np.random.default_rng(77)
+    names = ["hevc_h_loop_filter_luma", "hevc_v_loop_filter_luma", "hevc_h_loop_filter_chroma", "hevc_v_loop_filter_chroma"]
+    for rep in range(40):
+        which = rep % 4
+        chroma, vertical = which >> 1, which & 1
+        buf = _lf_picture(rng, 16, 16)
+        beta = int(rng.integers(0, 65))
+        tc = rng.integers(0, 25, 2).astype(np.int32)
+        no_p = (rng.random(2) < .2).astype(np.uint8)
+        no_q = (rng.random(2) < .2).astype(np.uint8)
+        a, b = buf.copy(), buf.copy()
+        off = 4 * 16 + 8 if vertical else 8 * 16 + 4
+        fn = getattr(c, names[which] + ("_c" if rep % 8 >= 4 else ""))
+        if chroma:
+            fn(a.ctypes.data + off, 16, tc.ctypes.data, no_p.ctypes.data, no_q.ctypes.data)
+        else:
+            fn(a.ctypes.data + off, 16, beta, tc.ctypes.data, no_p.ctypes.data, no_q.ctypes.data)
+        O.ffo_hevc_loop_filter(chroma, vertical, C.cast(b.ctypes.data + off, u8p), 16, beta, ptr(tc, ffi.i32p), ptr(no_p), ptr(no_q))
+        assert np.array_equal(a, b), (rep, which)

@@ -355,6 +355,39 @@ def test_hevc_idct():
         assert np.array_equal(a, b)
 
 
+def hevc_lf_case(rng, smooth):
+    """a 16x16 neighbourhood with an edge in the middle + the arguments of one hevc loop-filter call (ranges as the
+    decoder's tables: beta 0..64, tc 0..24, cf. tests/checkasm/hevc_deblock.c)"""
+    if smooth:
+        base = int(rng.integers(20, 230))
+        buf = np.clip(base + rng.integers(-3, 4, (16, 16)) + np.where(np.arange(16)[None, :] >= 8, int(rng.integers(-12, 13)), 0), 0, 255)
+        if rng.random() < .5:
+            buf = buf.T
+    else:
+        buf = rng.integers(0, 256, (16, 16))
+    beta = int(rng.integers(0, 65))
+    tc = rng.integers(0, 25, 2).astype(np.int32)
+    no_p, no_q = rng.integers(0, 2, 2).astype(np.uint8) * (rng.random() < .3), rng.integers(0, 2, 2).astype(np.uint8) * (rng.random() < .3)
+    return np.ascontiguousarray(buf.astype(np.uint8)), beta, tc, no_p.astype(np.uint8), no_q.astype(np.uint8)
+
+
+def test_hevc_loop_filter():
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(75)
+    changed = 0
+    for rep in range(3000):
+        buf, beta, tc, no_p, no_q = hevc_lf_case(rng, rep % 4 != 0)
+        which = rep % 8
+        chroma, vertical = (which >> 1) & 1, which & 1
+        a, b = buf.copy(), buf.copy()
+        off = 4 * 16 + 8 if vertical else 8 * 16 + 4       # vertical edge: 8 lines down from row 4; horizontal: 8 columns from col 4
+        R.ffref_hevc_loop_filter(which, C.cast(a.ctypes.data + off, u8p), 16, beta, ptr(tc, i32p), ptr(no_p), ptr(no_q))
+        O.ffo_hevc_loop_filter(chroma, vertical, C.cast(b.ctypes.data + off, u8p), 16, beta, ptr(tc, i32p), ptr(no_p), ptr(no_q))
+        assert np.array_equal(a, b), (rep, which, beta, tc, no_p, no_q)
+        changed += int((a != buf).any())
+    assert changed > 800
+
+
 def test_me_cmp():
     R, O = ffi.ref(), ffi.oracle()
     rng = np.random.default_rng(40)

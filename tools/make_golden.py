@@ -218,6 +218,20 @@ def hevc():
     for t in range(24):
         R.ffref_hevc_transform_4x4_luma(ptr(out[t], i16p))
     d["dst4"] = out
+    # loop filters: 160 calls on 16x16 neighbourhoods, par = which(0 h_luma 1 v_luma 2 h_chroma 3 v_chroma), beta, tc0, tc1, no_p0/1, no_q0/1
+    from test_oracle_vs_ref import hevc_lf_case
+    bufs, pars = [], []
+    for rep in range(160):
+        buf, beta, tc, no_p, no_q = hevc_lf_case(rng, rep % 4 != 0)
+        bufs.append(buf)
+        pars.append([rep % 4, beta, tc[0], tc[1], no_p[0], no_p[1], no_q[0], no_q[1]])
+    d["lf_in"], d["lf_par"] = np.stack(bufs), np.array(pars, np.int32)
+    o = d["lf_in"].copy()
+    for i, (which, beta, t0, t1, p0, p1, q0, q1) in enumerate(pars):
+        off = 4 * 16 + 8 if which & 1 else 8 * 16 + 4
+        R.ffref_hevc_loop_filter(int(which), at(o[i], off), 16, int(beta), ptr(np.array([t0, t1], np.int32), i32p),
+                                 ptr(np.array([p0, p1], np.uint8)), ptr(np.array([q0, q1], np.uint8)))
+    d["lf_out"] = o
     np.savez_compressed(os.path.join(OUT, "hevc.npz"), **d)
 
 
