@@ -14,13 +14,15 @@
  * entries are wave-uniform: int16 pairs in a __constant__ table, read with scalar loads and used as SGPR operands.  Residuals are written back
  * in place (the reference leaves them in coeffs) and added to the picture with packed byte stores.
  */
+#include <mutex>
+
 #include "common.h"
 #include "h264_kernels.h"
 
 /* |64 sqrt2 cos(m pi / 64)| as the standard rounds it; T32[k][i] = +-g[fold((2i+1)k mod 128)] */
-__constant__ int8_t hevc_t32[32][32];
 static int8_t hevc_t32_host[32][32];
-static bool hevc_t32_ready;
+static std::once_flag hevc_tab_once;
+static hipError_t hevc_tab_err;
 /* the same matrix as int16 PAIRS for v_dot2_i32_i16, per transform size N (offset hevc_pk_off(N)): entry [j][q][0] =
  * (T_N[4q][j], T_N[4q+2][j]) (even basis functions), [j][q][1] = (T_N[4q+1][j], T_N[4q+3][j]) (odd), j < N/2, q < N/4 */
 __constant__ uint32_t hevc_pk[352];
@@ -198,11 +200,13 @@ int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *ds
 {
     if (n <= 0)
         return 0;
-    if (!hevc_t32_ready) {
+    std::call_once(hevc_tab_once, [] {
         hevc_build_table();
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hevc_t32), hevc_t32_host, sizeof(hevc_t32_host)));
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hevc_pk), hevc_pk_host, sizeof(hevc_pk_host)));
-        hevc_t32_ready = true;
+        hevc_tab_err = hipMemcpyToSymbol(HIP_SYMBOL(hevc_pk), hevc_pk_host, sizeof(hevc_pk_host));
+    });
+    if (hevc_tab_err != hipSuccess) {
+        ffhip_set_error("ffhip_hevc_idct: coefficient table upload failed: %s", hipGetErrorString(hevc_tab_err));
+        return FFHIP_EIO;
     }
     const int upw = 64 >> log2_size;
     const dim3 grid(cdiv(n, 4 * upw)), block(256);
@@ -305,3 +309,55 @@ int ffhip_launch_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHe
 }
 static_assert(sizeof(FFHipHevcEdge) == 16, "FFHipHevcEdge is a 16-byte record");
 static_assert(sizeof(FFHipHevcTU) == 12, "FFHipHevcTU is a 12-byte record");
+
+/* ================================================================================================== */
+/*
+ * HEVC sample adaptive offset, 8-bit: sao_band_filter / sao_edge_filter (libavcodec/h26x/h2656_sao_template.c:24-84),
+ * batched: one wave per block, a lane per 4 horizontally adjacent samples.  Band: offset by the sample's 5-bit band when it
+ * is one of the 4 signalled ones.  Edge: sign(c - a) + sign(c - b) against the two neighbours of the class's direction
+ * selects one of 5 offsets.  Pure streaming (2 B per sample).
+ */
+static_assert(sizeof(FFHipHevcSao) == 24, "FFHipHevcSao is a 24-byte record");
+
+__global__ __launch_bounds__(256) void k_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n)
+        return;
+    const FFHipHevcSao k = blocks[b];
+    const int w = k.width, h = k.height, qw = (w + 3) >> 2;
+    const uint8_t *s0 = src + k.src_offset;
+    uint8_t *d0 = dst + k.dst_offset;
+    const int o0 = k.offset_val[0], o1 = k.offset_val[1], o2 = k.offset_val[2], o3 = k.offset_val[3], o4 = k.offset_val[4];
+    static const int8_t dxs[4][2] = { { -1, 1 }, { 0, 0 }, { -1, 1 }, { 1, -1 } }, dys[4][2] = { { 0, 0 }, { -1, 1 }, { -1, 1 }, { -1, 1 } };
+    const int eo = k.cls & 3;
+    const ptrdiff_t a = dxs[eo][0] + dys[eo][0] * ss, bb = dxs[eo][1] + dys[eo][1] * ss;
+    for (int t = lane; t < qw * h; t += 64) {
+        const int y = t / qw, x0 = 4 * (t - y * qw);
+        const uint8_t *p = s0 + (ptrdiff_t)y * ss + x0;
+        uint8_t *q = d0 + (ptrdiff_t)y * sd + x0;
+        const int m = min(4, w - x0);
+        for (int e = 0; e < m; e++) {
+            const int c = p[e];
+            int off;
+            if (k.edge) {
+                const int na = p[e + a], nb = p[e + bb];
+                const int sel = 2 + (c > na) - (c < na) + (c > nb) - (c < nb); /* edge_idx = { 1, 2, 0, 3, 4 } */
+                off = sel == 0 ? o1 : sel == 1 ? o2 : sel == 2 ? o0 : sel == 3 ? o3 : o4;
+            } else {
+                const int band = ((c >> 3) - k.cls) & 31;                        /* 0..3: the signalled bands */
+                off = band == 0 ? o1 : band == 1 ? o2 : band == 2 ? o3 : band == 3 ? o4 : 0;
+            }
+            q[e] = (uint8_t)clip_u8(c + off);
+        }
+    }
+}
+
+int ffhip_launch_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_hevc_sao, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, sd, src, ss, blocks, n);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -375,6 +375,35 @@ static void s_hevc_lf_vl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, 
 static void s_hevc_lf_hc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_H_CHROMA, p, st, 0, tc, np_, nq); }
 static void s_hevc_lf_vc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_V_CHROMA, p, st, 0, tc, np_, nq); }
 
+/* SAO: source rows -1..height (edge: with one column of margin) and the destination block packed at a pitch of 192 bytes */
+static void hevc_sao_single(int edge, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const int16_t *off, int cls, int w, int h)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (w <= 0 || h <= 0 || w > 64 || h > 64)
+        return;
+    const int P = 192, mg = edge ? 1 : 0;
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + (size_t)(h + 2) * P * 2 + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + (size_t)(h + 2) * P;
+    for (int y = -mg; y < h + mg; y++)
+        if (hipMemcpy(dsrc + (size_t)(y + 1) * P + 1 - mg, src + y * ss - mg, w + 2 * mg, hipMemcpyHostToDevice) != hipSuccess)
+            return;
+    FFHipHevcSao k;
+    memset(&k, 0, sizeof(k));
+    k.dst_offset = 0; k.src_offset = P + 1;
+    for (int i = 0; i < 5; i++) k.offset_val[i] = off[i];
+    k.edge = (uint8_t)edge; k.cls = (uint8_t)cls; k.width = (uint8_t)w; k.height = (uint8_t)h;
+    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_hevc_sao(ddst, P, dsrc, P, (const FFHipHevcSao *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    for (int y = 0; y < h; y++)
+        (void)hipMemcpy(dst + y * sd, ddst + (size_t)y * P, w, hipMemcpyDeviceToHost);
+}
+static void s_hevc_sao_band(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const int16_t *o, int lc, int w, int h) { hevc_sao_single(0, d, s, sd, ss, o, lc, w, h); }
+static void s_hevc_sao_edge(uint8_t *d, const uint8_t *s, ptrdiff_t sd, const int16_t *o, int eo, int w, int h) { hevc_sao_single(1, d, s, sd, 192, o, eo, w, h); }
+
 extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
 {
     if (!c || bit_depth != 8)
@@ -389,6 +418,10 @@ extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
     c->hevc_v_loop_filter_luma = c->hevc_v_loop_filter_luma_c = s_hevc_lf_vl;
     c->hevc_h_loop_filter_chroma = c->hevc_h_loop_filter_chroma_c = s_hevc_lf_hc;
     c->hevc_v_loop_filter_chroma = c->hevc_v_loop_filter_chroma_c = s_hevc_lf_vc;
+    for (int i = 0; i < 5; i++) {
+        c->sao_band_filter[i] = s_hevc_sao_band;
+        c->sao_edge_filter[i] = s_hevc_sao_edge;
+    }
     return 0;
 }
 

@@ -35,6 +35,17 @@ def loop_filter_batch(base, stride, edges, n, stream=None):
                       "ffhip_hevc_loop_filter_batch_dev")
 
 
+#: FFHipHevcSao (include/ffhip.h)
+SAO_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("offset_val", np.int16, 5), ("edge", np.uint8), ("cls", np.uint8),
+                      ("width", np.uint8), ("height", np.uint8), ("pad", np.uint8, 2)])
+
+
+def sao_batch(dst, stride_dst, src, stride_src, blocks, n, stream=None):
+    """blocks: uint8 [n, 24] FFHipHevcSao records"""
+    return _lib.check(_lib.lib().ffhip_hevc_sao_batch_dev(dst.data_ptr(), stride_dst, src.data_ptr(), stride_src, blocks.data_ptr(), n,
+                                                          _stream(stream)), "ffhip_hevc_sao_batch_dev")
+
+
 class HEVCDSPContext(C.Structure):
     """FFHipHEVCDSPContext: host-pointer faces with the reference's signatures"""
     _fields_ = [("add_residual", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t) * 4),
@@ -45,7 +56,9 @@ class HEVCDSPContext(C.Structure):
                  if "luma" in nm else C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.c_void_p))
                 for nm in ("hevc_h_loop_filter_luma", "hevc_v_loop_filter_luma", "hevc_h_loop_filter_chroma", "hevc_v_loop_filter_chroma",
                            "hevc_h_loop_filter_luma_c", "hevc_v_loop_filter_luma_c", "hevc_h_loop_filter_chroma_c",
-                           "hevc_v_loop_filter_chroma_c")]
+                           "hevc_v_loop_filter_chroma_c")] + \
+               [("sao_band_filter", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int) * 5),
+                ("sao_edge_filter", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int) * 5)]
 
 
 def dsp_init(bit_depth=8):

@@ -386,6 +386,13 @@ typedef struct FFHipHEVCDSPContext {
     ffhip_hevc_lf_chroma_func hevc_h_loop_filter_chroma, hevc_v_loop_filter_chroma;
     ffhip_hevc_lf_luma_func   hevc_h_loop_filter_luma_c, hevc_v_loop_filter_luma_c;     /* the decoder's "_c" slots: same functions */
     ffhip_hevc_lf_chroma_func hevc_h_loop_filter_chroma_c, hevc_v_loop_filter_chroma_c;
+    /* sample adaptive offset (hevc/dsp.h:63-69; index = width class 8/16/32/48/64, one function for all).  The edge filter
+     * reads its source with the reference's fixed stride of 2*MAX_PB_SIZE + AV_INPUT_BUFFER_PADDING_SIZE = 192 bytes and needs
+     * one sample of margin around the block, as in the reference. */
+    void (*sao_band_filter[5])(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *sao_offset_val,
+                               int sao_left_class, int width, int height);
+    void (*sao_edge_filter[5])(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, const int16_t *sao_offset_val, int eo, int width,
+                               int height);
 } FFHipHEVCDSPContext;
 /** ff_hevc_dsp_init_<arch> shape (libavcodec/hevc/dsp.h:127-140).  bit_depth must be 8. */
 int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth);
@@ -429,6 +436,20 @@ typedef struct FFHipHevcEdge {
  * / deblocking_filter_CTB).
  */
 int ffhip_hevc_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, void *stream);
+
+/** One SAO call of the batch face (a CTB plane or part of one). */
+typedef struct FFHipHevcSao {
+    int32_t dst_offset, src_offset;  /* into dst / src */
+    int16_t offset_val[5];           /* sao_offset_val: [0] unused by the band filter */
+    uint8_t edge;                    /* 0: sao_band_filter, 1: sao_edge_filter */
+    uint8_t cls;                     /* band: sao_left_class (0..31); edge: eo (0 horizontal, 1 vertical, 2 45 deg, 3 135 deg) */
+    uint8_t width, height;           /* 1..64 */
+    uint8_t pad[2];                  /* sizeof == 24 */
+} FFHipHevcSao;
+/** n SAO blocks: dst[..] = clip(src[..] + offset(class)); src and dst are different buffers (the decoder filters from a
+ *  copy), blocks do not overlap in dst; the edge filter reads src one sample beyond the block on every side. */
+int ffhip_hevc_sao_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src, const FFHipHevcSao *blocks,
+                             int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */

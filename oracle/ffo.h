@@ -83,6 +83,11 @@ void ffo_hevc_idct(int log2_size, int16_t *coeffs, int col_limit);  /* log2_size
 void ffo_hevc_idct_dc(int log2_size, int16_t *coeffs);
 void ffo_hevc_transform_4x4_luma(int16_t *coeffs);
 void ffo_hevc_add_residual(int log2_size, uint8_t *dst, const int16_t *res, ptrdiff_t stride);
+/* sao_band_filter / sao_edge_filter (eo 0..3); the reference's edge filter uses stride_src = 192 */
+void ffo_hevc_sao_band(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
+                       int left_class, int width, int height);
+void ffo_hevc_sao_edge(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val, int eo,
+                       int width, int height);
 /* hevc_{h,v}_loop_filter_{luma,chroma}: vertical = 1 for hevc_v_* (the edge is vertical); beta unused for chroma */
 void ffo_hevc_loop_filter(int chroma, int vertical, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc,
                           const uint8_t *no_p, const uint8_t *no_q);

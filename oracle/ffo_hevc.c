@@ -192,3 +192,36 @@ void ffo_hevc_loop_filter(int chroma, int vertical, uint8_t *pix, ptrdiff_t stri
     }
 #undef PX
 }
+
+/*
+ * HEVC sample adaptive offset, 8-bit: sao_band_filter and sao_edge_filter (libavcodec/h26x/h2656_sao_template.c:24-84).
+ * offset_val[0] is unused by the band filter (classes 1..4) and is the "no edge" offset (always 0 from the decoder) of
+ * the edge filter.  The reference's edge filter reads a padded copy of the CTB with a FIXED stride of
+ * 2*MAX_PB_SIZE + AV_INPUT_BUFFER_PADDING_SIZE = 192 bytes; here the stride is an argument (192 reproduces it).
+ */
+void ffo_hevc_sao_band(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
+                       int left_class, int width, int height)
+{
+    int table[32] = { 0 };
+    for (int k = 0; k < 4; k++)
+        table[(k + left_class) & 31] = offset_val[k + 1];
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const int s = src[y * stride_src + x];
+            dst[y * stride_dst + x] = (uint8_t)clip8(s + table[s >> 3]);
+        }
+}
+
+void ffo_hevc_sao_edge(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val, int eo,
+                       int width, int height)
+{
+    static const int idx[5] = { 1, 2, 0, 3, 4 };
+    static const int dx[4][2] = { { -1, 1 }, { 0, 0 }, { -1, 1 }, { 1, -1 } }, dy[4][2] = { { 0, 0 }, { -1, 1 }, { -1, 1 }, { -1, 1 } };
+    const ptrdiff_t a = dx[eo][0] + dy[eo][0] * stride_src, b = dx[eo][1] + dy[eo][1] * stride_src;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const uint8_t *p = src + y * stride_src + x;
+            const int c = p[0], d0 = (c > p[a]) - (c < p[a]), d1 = (c > p[b]) - (c < p[b]);
+            dst[y * stride_dst + x] = (uint8_t)clip8(c + offset_val[idx[2 + d0 + d1]]);
+        }
+}

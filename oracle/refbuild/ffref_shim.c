@@ -219,6 +219,18 @@ void ffref_hevc_add_residual(int idx, uint8_t *dst, const int16_t *res, ptrdiff_
     dsp_init();
     hevc.add_residual[idx](dst, res, stride);
 }
+void ffref_hevc_sao_band(int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
+                         int left_class, int width, int height)
+{
+    dsp_init();
+    hevc.sao_band_filter[idx](dst, src, stride_dst, stride_src, offset_val, left_class, width, height);
+}
+void ffref_hevc_sao_edge(int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, const int16_t *offset_val, int eo, int width,
+                         int height)
+{
+    dsp_init();
+    hevc.sao_edge_filter[idx](dst, src, stride_dst, offset_val, eo, width, height);
+}
 void ffref_hevc_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q)
 {
     dsp_init();

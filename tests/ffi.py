@@ -103,6 +103,10 @@ def oracle():
         L.ffo_hevc_transform_4x4_luma.restype = None
         L.ffo_hevc_add_residual.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
         L.ffo_hevc_add_residual.restype = None
+        L.ffo_hevc_sao_band.argtypes = [u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
+        L.ffo_hevc_sao_band.restype = None
+        L.ffo_hevc_sao_edge.argtypes = [u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
+        L.ffo_hevc_sao_edge.restype = None
         L.ffo_hevc_loop_filter.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, i32p, u8p, u8p]
         L.ffo_hevc_loop_filter.restype = None
         L.ffo_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -176,6 +180,10 @@ def ref():
         L.ffref_hevc_transform_4x4_luma.restype = None
         L.ffref_hevc_add_residual.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
         L.ffref_hevc_add_residual.restype = None
+        L.ffref_hevc_sao_band.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
+        L.ffref_hevc_sao_band.restype = None
+        L.ffref_hevc_sao_edge.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
+        L.ffref_hevc_sao_edge.restype = None
         L.ffref_hevc_loop_filter.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, i32p, u8p, u8p]
         L.ffref_hevc_loop_filter.restype = None
         L.ffref_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

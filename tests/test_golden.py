@@ -174,6 +174,15 @@ def test_hevc_golden():
         O.ffo_hevc_loop_filter(int(which) >> 1, int(which) & 1, at(o[i], off), 16, int(beta), ptr(np.array([t0, t1], np.int32), i32p),
                                ptr(np.array([p0, p1], np.uint8)), ptr(np.array([q0, q1], np.uint8)))
     assert np.array_equal(o, d["lf_out"])
+    for i, (edge, cls, w, h, *off) in enumerate(d["sao_par"]):
+        dst = np.zeros((32, 64), np.uint8)
+        src = np.ascontiguousarray(d["sao_src"][i])
+        o16 = np.array(off, np.int16)
+        if edge:
+            O.ffo_hevc_sao_edge(ptr(dst), at(src, 193), 64, 192, ptr(o16, i16p), int(cls), int(w), int(h))
+        else:
+            O.ffo_hevc_sao_band(ptr(dst), at(src, 193), 64, 192, ptr(o16, i16p), int(cls), int(w), int(h))
+        assert np.array_equal(dst, d["sao_out"][i]), i
 
 
 def test_fdsp_golden():

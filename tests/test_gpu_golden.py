@@ -199,6 +199,23 @@ def test_hevc_lf_golden_gpu():
     assert np.array_equal(pic.cpu().numpy(), d["lf_out"])
 
 
+def test_hevc_sao_golden_gpu():
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    d = G.load("hevc")
+    par = d["sao_par"]
+    n = len(par)
+    rec = np.zeros(n, hevc.SAO_DTYPE)
+    rec["dst_offset"] = np.arange(n) * 32 * 64
+    rec["src_offset"] = np.arange(n) * 34 * 192 + 193
+    rec["edge"], rec["cls"], rec["width"], rec["height"] = par[:, 0], par[:, 1], par[:, 2], par[:, 3]
+    rec["offset_val"] = par[:, 4:9]
+    dst = torch.zeros((n * 32, 64), dtype=torch.uint8, device="cuda:0")
+    hevc.sao_batch(dst, 64, torch.from_numpy(d["sao_src"].copy()).cuda(), 192, torch.from_numpy(rec.view(np.uint8).reshape(n, 24).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy().reshape(n, 32, 64), d["sao_out"])
+
+
 def test_fdsp_golden_gpu():
     from ffmpeg_amd import fdsp
     torch = _torch()

@@ -196,3 +196,68 @@ def test_hevc_deblock_host_faces():
             fn(a.ctypes.data + off, 16, beta, tc.ctypes.data, no_p.ctypes.data, no_q.ctypes.data)
         O.ffo_hevc_loop_filter(chroma, vertical, C.cast(b.ctypes.data + off, u8p), 16, beta, ptr(tc, ffi.i32p), ptr(no_p), ptr(no_q))
         assert np.array_equal(a, b), (rep, which)
+
+
+def test_hevc_sao_batch():
+    """a picture's worth of CTB blocks, band and edge classes mixed, ragged widths/heights, source = a padded copy"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    rng = np.random.default_rng(50)
+    W, H, M = 320, 192, 8                                   # picture and margin of the source copy
+    ss, sd = W + 2 * M + 5, W + 11
+    src = rng.integers(0, 256, (H + 2 * M, ss), dtype=np.uint8)
+    src[M:M + H, M:M + W] = np.clip(128 + np.cumsum(rng.integers(-3, 4, (H, W)), axis=1) % 40 + rng.integers(-2, 3, (H, W)), 0, 255)
+    dst = rng.integers(0, 256, (H, sd), dtype=np.uint8)
+    blocks = []
+    for by in range(0, H, 64):
+        for bx in range(0, W, 64):
+            w, h = min(64, W - bx), min(64, H - by)
+            if rng.random() < .3:
+                w, h = max(1, w - int(rng.integers(0, 9))), max(1, h - int(rng.integers(0, 9)))
+            edge = int(rng.integers(0, 2))
+            off = rng.integers(-7, 8, 5)
+            if edge:
+                off[0] = 0
+            blocks.append((by * sd + bx, (by + M) * ss + bx + M, off, edge, int(rng.integers(0, 4 if edge else 32)), w, h))
+    n = len(blocks)
+    rec = np.zeros(n, hevc.SAO_DTYPE)
+    for i, (do, so, off, edge, cls, w, h) in enumerate(blocks):
+        rec[i] = (do, so, off, edge, cls, w, h, (0, 0))
+    want = dst.copy()
+    O = ffi.oracle()
+    for do, so, off, edge, cls, w, h in blocks:
+        o16 = off.astype(np.int16)
+        if edge:
+            O.ffo_hevc_sao_edge(C.cast(want.ctypes.data + do, u8p), C.cast(src.ctypes.data + so, u8p), sd, ss, ptr(o16, ffi.i16p), cls, w, h)
+        else:
+            O.ffo_hevc_sao_band(C.cast(want.ctypes.data + do, u8p), C.cast(src.ctypes.data + so, u8p), sd, ss, ptr(o16, ffi.i16p), cls, w, h)
+    d_dst, d_src = torch.from_numpy(dst.copy()).cuda(), torch.from_numpy(src).cuda()
+    hevc.sao_batch(d_dst, sd, d_src, ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 24).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    assert (want != dst).sum() > 10000
+    assert np.array_equal(d_dst.cpu().numpy(), want)
+
+
+def test_hevc_sao_host_faces():
+    from ffmpeg_amd import hevc
+    _torch()
+    c = hevc.dsp_init(8)
+    O = ffi.oracle()
+    rng = np.random.default_rng(51)
+    for rep in range(12):
+        w = int(rng.choice([8, 16, 32, 48, 64])); h = int(rng.choice([8, 16, 64]))
+        idx = {8: 0, 16: 1, 32: 2, 48: 3, 64: 4}[w]
+        src = rng.integers(0, 256, (h + 2, 192), dtype=np.uint8)
+        off = rng.integers(-7, 8, 5).astype(np.int16)
+        dst0 = rng.integers(0, 256, (h, 80), dtype=np.uint8)
+        a, b = dst0.copy(), dst0.copy()
+        left = int(rng.integers(0, 32))
+        c.sao_band_filter[idx](a.ctypes.data, src.ctypes.data + 193, 80, 192, off.ctypes.data, left, w, h)
+        O.ffo_hevc_sao_band(ptr(b), C.cast(src.ctypes.data + 193, u8p), 80, 192, ptr(off, ffi.i16p), left, w, h)
+        assert np.array_equal(a, b)
+        off[0] = 0
+        eo = rep % 4
+        a, b = dst0.copy(), dst0.copy()
+        c.sao_edge_filter[idx](a.ctypes.data, src.ctypes.data + 193, 80, off.ctypes.data, eo, w, h)
+        O.ffo_hevc_sao_edge(ptr(b), C.cast(src.ctypes.data + 193, u8p), 80, 192, ptr(off, ffi.i16p), eo, w, h)
+        assert np.array_equal(a, b)

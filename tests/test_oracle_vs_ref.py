@@ -388,6 +388,31 @@ def test_hevc_loop_filter():
     assert changed > 800
 
 
+def test_hevc_sao():
+    """band and edge offsets on CTB-sized blocks (tests/checkasm/hevc_sao.c shapes: widths 8..64, the padded 192-byte source)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(76)
+    for rep in range(120):
+        w = int(rng.choice([8, 16, 32, 48, 64])); h = int(rng.choice([8, 16, 32, 64]))
+        idx = {8: 0, 16: 1, 32: 2, 48: 3, 64: 4}[w]
+        src = rng.integers(0, 256, (h + 2, 192), dtype=np.uint8)
+        if rep % 3 == 0:
+            src[:] = np.clip(128 + rng.integers(-6, 7, src.shape), 0, 255)
+        off = rng.integers(-7, 8, 5).astype(np.int16) * (1 if rep % 5 else 4)
+        dst0 = rng.integers(0, 256, (h, 80), dtype=np.uint8)
+        a, b = dst0.copy(), dst0.copy()
+        left = int(rng.integers(0, 32))
+        R.ffref_hevc_sao_band(idx, ptr(a), C.cast(src.ctypes.data + 192 + 1, u8p), 80, 192, ptr(off, i16p), left, w, h)
+        O.ffo_hevc_sao_band(ptr(b), C.cast(src.ctypes.data + 192 + 1, u8p), 80, 192, ptr(off, i16p), left, w, h)
+        assert np.array_equal(a, b), ("band", rep)
+        off[0] = 0
+        for eo in range(4):
+            a, b = dst0.copy(), dst0.copy()
+            R.ffref_hevc_sao_edge(idx, ptr(a), C.cast(src.ctypes.data + 192 + 1, u8p), 80, ptr(off, i16p), eo, w, h)
+            O.ffo_hevc_sao_edge(ptr(b), C.cast(src.ctypes.data + 192 + 1, u8p), 80, 192, ptr(off, i16p), eo, w, h)
+            assert np.array_equal(a, b), ("edge", rep, eo)
+
+
 def test_me_cmp():
     R, O = ffi.ref(), ffi.oracle()
     rng = np.random.default_rng(40)

@@ -232,6 +232,26 @@ def hevc():
         R.ffref_hevc_loop_filter(int(which), at(o[i], off), 16, int(beta), ptr(np.array([t0, t1], np.int32), i32p),
                                  ptr(np.array([p0, p1], np.uint8)), ptr(np.array([q0, q1], np.uint8)))
     d["lf_out"] = o
+    # SAO: 24 blocks, par = edge, cls, w, h, off0..4; source = padded 192-byte rows (block at row 1, col 1)
+    srcs, pars, outs = [], [], []
+    for rep in range(24):
+        w = int(rng.choice([8, 16, 32, 48, 64])); h = int(rng.choice([8, 16, 32]))
+        src = rng.integers(0, 256, (34, 192), dtype=np.uint8)
+        if rep % 3 == 0:
+            src[:] = np.clip(128 + rng.integers(-6, 7, src.shape), 0, 255)
+        off = rng.integers(-7, 8, 5).astype(np.int16)
+        edge = rep & 1
+        cls = int(rng.integers(0, 4 if edge else 32))
+        if edge:
+            off[0] = 0
+        dst = np.zeros((32, 64), np.uint8)
+        idx = {8: 0, 16: 1, 32: 2, 48: 3, 64: 4}[w]
+        if edge:
+            R.ffref_hevc_sao_edge(idx, ptr(dst), at(src, 193), 64, ptr(off, i16p), cls, w, h)
+        else:
+            R.ffref_hevc_sao_band(idx, ptr(dst), at(src, 193), 64, 192, ptr(off, i16p), cls, w, h)
+        srcs.append(src); outs.append(dst); pars.append([edge, cls, w, h] + [int(v) for v in off])
+    d["sao_src"], d["sao_out"], d["sao_par"] = np.stack(srcs), np.stack(outs), np.array(pars, np.int32)
     np.savez_compressed(os.path.join(OUT, "hevc.npz"), **d)
 
 
