@@ -122,6 +122,16 @@ extern "C" int ffhip_hevc_sao_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, cons
     return ffhip_launch_hevc_sao(dst, stride_dst, src, stride_src, blocks, n, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_hevc_mc_batch_dev(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                       const FFHipHevcMcBlock *blocks, int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_mc(chroma, uni, dst, dststride, src, srcstride, blocks, n, (hipStream_t)stream);
+}
+
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */
 extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1,
                                     size_t pitch1, const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream)

@@ -404,6 +404,42 @@ static void hevc_sao_single(int edge, uint8_t *dst, const uint8_t *src, ptrdiff_
 static void s_hevc_sao_band(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const int16_t *o, int lc, int w, int h) { hevc_sao_single(0, d, s, sd, ss, o, lc, w, h); }
 static void s_hevc_sao_edge(uint8_t *d, const uint8_t *s, ptrdiff_t sd, const int16_t *o, int eo, int w, int h) { hevc_sao_single(1, d, s, sd, 192, o, eo, w, h); }
 
+/* MC: source rows -3..height+4 x columns -3..width+4 at a pitch of 128; destination after it (pixels: pitch 64; int16: 64 elements) */
+static void hevc_mc_single(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
+                           int my, int width)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (width <= 0 || height <= 0 || width > 64 || height > 64)
+        return;
+    const int P = 128, before = chroma ? 1 : 3, after = chroma ? 2 : 4;
+    const size_t sbytes = (size_t)(height + before + after) * P, dbytes = (size_t)height * 64 * (uni ? 1 : 2);
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + sbytes + dbytes + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + sbytes;
+    for (int y = -before; y < height + after; y++)
+        if (hipMemcpy(dsrc + (size_t)(y + before) * P, src + y * srcstride - before, width + before + after, hipMemcpyHostToDevice) != hipSuccess)
+            return;
+    FFHipHevcMcBlock k;
+    k.dst_offset = 0; k.src_offset = before * P + before;
+    k.width = (uint8_t)width; k.height = (uint8_t)height; k.mx = (uint8_t)mx; k.my = (uint8_t)my;
+    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_hevc_mc(chroma, uni, ddst, 64, dsrc, P, (const FFHipHevcMcBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    if (uni) {
+        for (int y = 0; y < height; y++)
+            (void)hipMemcpy((uint8_t *)dst + y * dststride, ddst + (size_t)y * 64, width, hipMemcpyDeviceToHost);
+    } else {
+        for (int y = 0; y < height; y++)
+            (void)hipMemcpy((int16_t *)dst + (size_t)y * 64, ddst + (size_t)y * 128, (size_t)width * 2, hipMemcpyDeviceToHost);
+    }
+}
+static void s_hevc_qpel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(0, 0, d, 0, s, ss, h, (int)mx, (int)my, w); }
+static void s_hevc_epel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(1, 0, d, 0, s, ss, h, (int)mx, (int)my, w); }
+static void s_hevc_qpel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(0, 1, d, ds, s, ss, h, (int)mx, (int)my, w); }
+static void s_hevc_epel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(1, 1, d, ds, s, ss, h, (int)mx, (int)my, w); }
+
 extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
 {
     if (!c || bit_depth != 8)
@@ -422,6 +458,13 @@ extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
         c->sao_band_filter[i] = s_hevc_sao_band;
         c->sao_edge_filter[i] = s_hevc_sao_edge;
     }
+    /* the [!!my][!!mx] slots all take (mx, my): one function per table serves every slot */
+    for (int i = 0; i < 10; i++)
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) {
+                c->put_hevc_qpel[i][a][b] = s_hevc_qpel; c->put_hevc_qpel_uni[i][a][b] = s_hevc_qpel_uni;
+                c->put_hevc_epel[i][a][b] = s_hevc_epel; c->put_hevc_epel_uni[i][a][b] = s_hevc_epel_uni;
+            }
     return 0;
 }
 

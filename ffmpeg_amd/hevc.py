@@ -46,6 +46,17 @@ def sao_batch(dst, stride_dst, src, stride_src, blocks, n, stream=None):
                                                           _stream(stream)), "ffhip_hevc_sao_batch_dev")
 
 
+#: FFHipHevcMcBlock (include/ffhip.h)
+MC_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("width", np.uint8), ("height", np.uint8), ("mx", np.uint8),
+                     ("my", np.uint8)])
+
+
+def mc_batch(chroma, uni, dst, dststride, src, srcstride, blocks, n, stream=None):
+    """blocks: uint8 [n, 12] FFHipHevcMcBlock records; dst: uint8 (uni) or int16 (plain, rows 64 elements apart) device tensor"""
+    return _lib.check(_lib.lib().ffhip_hevc_mc_batch_dev(chroma, uni, dst.data_ptr(), dststride, src.data_ptr(), srcstride, blocks.data_ptr(), n,
+                                                         _stream(stream)), "ffhip_hevc_mc_batch_dev")
+
+
 class HEVCDSPContext(C.Structure):
     """FFHipHEVCDSPContext: host-pointer faces with the reference's signatures"""
     _fields_ = [("add_residual", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t) * 4),
@@ -58,7 +69,11 @@ class HEVCDSPContext(C.Structure):
                            "hevc_h_loop_filter_luma_c", "hevc_v_loop_filter_luma_c", "hevc_h_loop_filter_chroma_c",
                            "hevc_v_loop_filter_chroma_c")] + \
                [("sao_band_filter", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int) * 5),
-                ("sao_edge_filter", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int) * 5)]
+                ("sao_edge_filter", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int) * 5),
+                ("put_hevc_qpel", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
+                ("put_hevc_qpel_uni", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
+                ("put_hevc_epel", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
+                ("put_hevc_epel_uni", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10)]
 
 
 def dsp_init(bit_depth=8):

@@ -393,6 +393,14 @@ typedef struct FFHipHEVCDSPContext {
                                int sao_left_class, int width, int height);
     void (*sao_edge_filter[5])(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, const int16_t *sao_offset_val, int eo, int width,
                                int height);
+    /* uni-directional motion compensation (hevc/dsp.h:74-77,88-92): [width class][!!my][!!mx]; the plain forms write 14-bit
+     * int16 intermediates with a row stride of MAX_PB_SIZE = 64, the _uni forms write pixels */
+    void (*put_hevc_qpel[10][2][2])(int16_t *dst, const uint8_t *src, ptrdiff_t srcstride, int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_qpel_uni[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, intptr_t mx,
+                                        intptr_t my, int width);
+    void (*put_hevc_epel[10][2][2])(int16_t *dst, const uint8_t *src, ptrdiff_t srcstride, int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_epel_uni[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, intptr_t mx,
+                                        intptr_t my, int width);
 } FFHipHEVCDSPContext;
 /** ff_hevc_dsp_init_<arch> shape (libavcodec/hevc/dsp.h:127-140).  bit_depth must be 8. */
 int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth);
@@ -436,6 +444,20 @@ typedef struct FFHipHevcEdge {
  * / deblocking_filter_CTB).
  */
 int ffhip_hevc_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, void *stream);
+
+/** One prediction block of the batch face: what luma_mc_uni / chroma_mc_uni pass per block (libavcodec/hevc/hevcdec.c). */
+typedef struct FFHipHevcMcBlock {
+    int32_t dst_offset;   /* uni: bytes into dst; plain: int16 elements into dst (rows are 64 elements apart) */
+    int32_t src_offset;   /* bytes into src: the block's integer-sample origin */
+    uint8_t width, height;/* 2..64 */
+    uint8_t mx, my;       /* luma: quarter-sample 0..3; chroma: eighth-sample 0..7 */
+} FFHipHevcMcBlock;
+/**
+ * n blocks: put_hevc_{qpel,epel}[..][!!my][!!mx] (uni == 0, dst = int16) or put_hevc_{qpel,epel}_uni (uni != 0, dst = pixels with
+ * dststride).  src must be readable 3 (chroma: 1) samples left/up and 4 (2) right/down of each block.
+ */
+int ffhip_hevc_mc_batch_dev(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                            const FFHipHevcMcBlock *blocks, int n, void *stream);
 
 /** One SAO call of the batch face (a CTB plane or part of one). */
 typedef struct FFHipHevcSao {

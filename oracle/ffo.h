@@ -83,6 +83,9 @@ void ffo_hevc_idct(int log2_size, int16_t *coeffs, int col_limit);  /* log2_size
 void ffo_hevc_idct_dc(int log2_size, int16_t *coeffs);
 void ffo_hevc_transform_4x4_luma(int16_t *coeffs);
 void ffo_hevc_add_residual(int log2_size, uint8_t *dst, const int16_t *res, ptrdiff_t stride);
+/* put_hevc_{qpel,epel}[..][!!my][!!mx] (uni = 0: int16 dst, row stride 64) and put_hevc_{qpel,epel}_uni (uni = 1: pixels) */
+void ffo_hevc_mc(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
+                 int my, int width);
 /* sao_band_filter / sao_edge_filter (eo 0..3); the reference's edge filter uses stride_src = 192 */
 void ffo_hevc_sao_band(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
                        int left_class, int width, int height);

@@ -225,3 +225,58 @@ void ffo_hevc_sao_edge(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, p
             dst[y * stride_dst + x] = (uint8_t)clip8(c + offset_val[idx[2 + d0 + d1]]);
         }
 }
+
+/*
+ * HEVC motion compensation, 8-bit, uni-directional: put_hevc_{qpel,epel}[idx][!!my][!!mx] (14-bit int16 intermediates,
+ * row stride MAX_PB_SIZE = 64) and put_hevc_{qpel,epel}_uni (pixels) — libavcodec/h26x/h2656_inter_template.c:29-58,
+ * 97-245 (luma), 342-485 (chroma), wired in libavcodec/hevc/dsp.c:133-190.  The [!!my][!!mx] table index picks
+ * pixels / h / v / hv; luma filters are the standard's 8-tap quarter-sample set, chroma the 4-tap eighth-sample set.
+ * hv: rows -3..height+3 (chroma: -1..height+1) are filtered horizontally first (no shift at 8 bits), then vertically
+ * with >> 6.
+ */
+static const int8_t hevc_luma_filter[4][8] = { { 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 },
+                                               { 0, 1, -5, 17, 58, -10, 4, -1 } };
+static const int8_t hevc_chroma_filter[8][4] = { { 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 },
+                                                 { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+
+void ffo_hevc_mc(int chroma, int uni, void *dst_, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
+                 int my, int width)
+{
+    const int taps = chroma ? 4 : 8, before = chroma ? 1 : 3;
+    const int8_t *hf = chroma ? hevc_chroma_filter[mx] : hevc_luma_filter[mx];
+    const int8_t *vf = chroma ? hevc_chroma_filter[my] : hevc_luma_filter[my];
+    int16_t *d16 = dst_;
+    uint8_t *d8 = dst_;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int val;
+            if (!mx && !my) {
+                val = src[y * srcstride + x] << 6;
+                if (uni) { /* put_uni_pixels is a copy */
+                    d8[y * dststride + x] = src[y * srcstride + x];
+                    continue;
+                }
+            } else if (mx && !my) {
+                val = 0;
+                for (int t = 0; t < taps; t++)
+                    val += hf[t] * src[y * srcstride + x + t - before];
+            } else if (!mx) {
+                val = 0;
+                for (int t = 0; t < taps; t++)
+                    val += vf[t] * src[(y + t - before) * srcstride + x];
+            } else {
+                int acc = 0;
+                for (int s = 0; s < taps; s++) {
+                    int h = 0;
+                    for (int t = 0; t < taps; t++)
+                        h += hf[t] * src[(y + s - before) * srcstride + x + t - before];
+                    acc += vf[s] * (int16_t)h;
+                }
+                val = acc >> 6;
+            }
+            if (uni)
+                d8[y * dststride + x] = (uint8_t)clip8((val + 32) >> 6);
+            else
+                d16[y * 64 + x] = (int16_t)val;
+        }
+}

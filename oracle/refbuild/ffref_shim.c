@@ -219,6 +219,19 @@ void ffref_hevc_add_residual(int idx, uint8_t *dst, const int16_t *res, ptrdiff_
     dsp_init();
     hevc.add_residual[idx](dst, res, stride);
 }
+void ffref_hevc_mc(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx, int my,
+                   int width)
+{
+    static const int wtab[10] = { 2, 4, 6, 8, 12, 16, 24, 32, 48, 64 }; /* ff_hevc_pel_weight, hevc/hevcdec.c */
+    int idx = 0;
+    dsp_init();
+    while (idx < 9 && wtab[idx] < width)
+        idx++;
+    if (uni)
+        (chroma ? hevc.put_hevc_epel_uni : hevc.put_hevc_qpel_uni)[idx][!!my][!!mx](dst, dststride, src, srcstride, height, mx, my, width);
+    else
+        (chroma ? hevc.put_hevc_epel : hevc.put_hevc_qpel)[idx][!!my][!!mx](dst, src, srcstride, height, mx, my, width);
+}
 void ffref_hevc_sao_band(int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
                          int left_class, int width, int height)
 {

@@ -183,6 +183,12 @@ def test_hevc_golden():
         else:
             O.ffo_hevc_sao_band(ptr(dst), at(src, 193), 64, 192, ptr(o16, i16p), int(cls), int(w), int(h))
         assert np.array_equal(dst, d["sao_out"][i]), i
+    mref = np.ascontiguousarray(d["mc_ref"])
+    for i, (chroma, w, h, mx, my, y0, x0) in enumerate(d["mc_par"]):
+        a16, a8 = np.zeros((64, 64), np.int16), np.zeros((64, 64), np.uint8)
+        O.ffo_hevc_mc(int(chroma), 0, a16.ctypes.data, 0, at(mref, y0 * 96 + x0), 96, int(h), int(mx), int(my), int(w))
+        O.ffo_hevc_mc(int(chroma), 1, a8.ctypes.data, 64, at(mref, y0 * 96 + x0), 96, int(h), int(mx), int(my), int(w))
+        assert np.array_equal(a16, d["mc_out16"][i]) and np.array_equal(a8, d["mc_out8"][i]), i
 
 
 def test_fdsp_golden():

@@ -216,6 +216,28 @@ def test_hevc_sao_golden_gpu():
     assert np.array_equal(dst.cpu().numpy().reshape(n, 32, 64), d["sao_out"])
 
 
+def test_hevc_mc_golden_gpu():
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    d = G.load("hevc")
+    par = d["mc_par"]
+    ref = torch.from_numpy(d["mc_ref"].copy()).cuda()
+    for chroma in (0, 1):
+        sel = np.nonzero(par[:, 0] == chroma)[0]
+        n = len(sel)
+        rec = np.zeros(n, hevc.MC_DTYPE)
+        rec["src_offset"] = par[sel, 5] * 96 + par[sel, 6]
+        rec["width"], rec["height"], rec["mx"], rec["my"] = par[sel, 1], par[sel, 2], par[sel, 3], par[sel, 4]
+        rec["dst_offset"] = np.arange(n) * 4096
+        d_rec = torch.from_numpy(rec.view(np.uint8).reshape(n, 12).copy()).cuda()
+        o16 = torch.zeros((n, 64, 64), dtype=torch.int16, device="cuda:0")
+        hevc.mc_batch(chroma, 0, o16, 0, ref, 96, d_rec, n)
+        o8 = torch.zeros((n, 64, 64), dtype=torch.uint8, device="cuda:0")
+        hevc.mc_batch(chroma, 1, o8, 64, ref, 96, d_rec, n)
+        torch.cuda.synchronize()
+        assert np.array_equal(o16.cpu().numpy(), d["mc_out16"][sel]) and np.array_equal(o8.cpu().numpy(), d["mc_out8"][sel])
+
+
 def test_fdsp_golden_gpu():
     from ffmpeg_amd import fdsp
     torch = _torch()

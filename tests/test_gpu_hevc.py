@@ -261,3 +261,70 @@ def test_hevc_sao_host_faces():
         c.sao_edge_filter[idx](a.ctypes.data, src.ctypes.data + 193, 80, off.ctypes.data, eo, w, h)
         O.ffo_hevc_sao_edge(ptr(b), C.cast(src.ctypes.data + 193, u8p), 80, 192, ptr(off, ffi.i16p), eo, w, h)
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("uni", [0, 1])
+@pytest.mark.parametrize("chroma", [0, 1])
+def test_hevc_mc_batch(chroma, uni):
+    """prediction blocks of all 10 widths x fractional positions in one batch (tests/checkasm/hevc_pel.c shapes)"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    rng = np.random.default_rng(60 + 2 * chroma + uni)
+    W, H, P = 512, 256, 16
+    ss = W + 2 * P + 3
+    ref = rng.integers(0, 256, (H + 2 * P, ss), dtype=np.uint8)
+    ref[:60] = rng.choice(np.array([0, 255], np.uint8), (60, ss))
+    nfrac = 8 if chroma else 4
+    widths = [2, 4, 6, 8, 12, 16, 24, 32, 48, 64]
+    blocks = []
+    for by in range(0, H, 64):
+        for bx in range(0, W, 64):
+            w = int(rng.choice(widths)); h = int(rng.choice([2, 4, 8, 16, 32, 64]))
+            dy, dx = rng.integers(-8, 9, 2)
+            blocks.append((by, bx, (by + P + int(dy)) * ss + bx + P + int(dx), w, h, int(rng.integers(0, nfrac)), int(rng.integers(0, nfrac))))
+    n = len(blocks)
+    rec = np.zeros(n, hevc.MC_DTYPE)
+    O = ffi.oracle()
+    if uni:
+        sd = W + 9
+        dst = rng.integers(0, 256, (H, sd), dtype=np.uint8)
+        want = dst.copy()
+        for i, (by, bx, so, w, h, mx, my) in enumerate(blocks):
+            rec[i] = (by * sd + bx, so, w, h, mx, my)
+            O.ffo_hevc_mc(chroma, 1, want.ctypes.data + by * sd + bx, sd, C.cast(ref.ctypes.data + so, u8p), ss, h, mx, my, w)
+        d_dst = torch.from_numpy(dst.copy()).cuda()
+    else:
+        sd = 0
+        dst = np.full((n, 64, 64), -7, np.int16)
+        want = dst.copy()
+        for i, (by, bx, so, w, h, mx, my) in enumerate(blocks):
+            rec[i] = (i * 4096, so, w, h, mx, my)
+            O.ffo_hevc_mc(chroma, 0, want[i].ctypes.data, 0, C.cast(ref.ctypes.data + so, u8p), ss, h, mx, my, w)
+        d_dst = torch.from_numpy(dst.copy()).cuda()
+    hevc.mc_batch(chroma, uni, d_dst, sd, torch.from_numpy(ref).cuda(), ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 12).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    assert (want != dst).sum() > 1000
+    assert np.array_equal(d_dst.cpu().numpy(), want)
+
+
+def test_hevc_mc_host_faces():
+    from ffmpeg_amd import hevc
+    _torch()
+    c = hevc.dsp_init(8)
+    O = ffi.oracle()
+    rng = np.random.default_rng(61)
+    src = rng.integers(0, 256, (90, 100), dtype=np.uint8)
+    widths = [2, 4, 6, 8, 12, 16, 24, 32, 48, 64]
+    for rep in range(16):
+        chroma = rep & 1
+        idx = int(rng.integers(0, 10)); w = widths[idx]; h = int(rng.choice([2, 8, 64]))
+        mx, my = (int(v) for v in rng.integers(0, 8 if chroma else 4, 2))
+        sp = src.ctypes.data + 10 * 100 + 12
+        a16, b16 = np.zeros((64, 64), np.int16), np.zeros((64, 64), np.int16)
+        (c.put_hevc_epel if chroma else c.put_hevc_qpel)[idx][int(bool(my))][int(bool(mx))](a16.ctypes.data, sp, 100, h, mx, my, w)
+        O.ffo_hevc_mc(chroma, 0, b16.ctypes.data, 0, C.cast(sp, u8p), 100, h, mx, my, w)
+        assert np.array_equal(a16, b16), (chroma, w, h, mx, my)
+        a8, b8 = np.full((64, 72), 9, np.uint8), np.full((64, 72), 9, np.uint8)
+        (c.put_hevc_epel_uni if chroma else c.put_hevc_qpel_uni)[idx][int(bool(my))][int(bool(mx))](a8.ctypes.data, 72, sp, 100, h, mx, my, w)
+        O.ffo_hevc_mc(chroma, 1, b8.ctypes.data, 72, C.cast(sp, u8p), 100, h, mx, my, w)
+        assert np.array_equal(a8, b8), (chroma, w, h, mx, my, "uni")

@@ -388,6 +388,33 @@ def test_hevc_loop_filter():
     assert changed > 800
 
 
+HEVC_WIDTHS = [2, 4, 6, 8, 12, 16, 24, 32, 48, 64]
+
+
+def test_hevc_mc():
+    """put_hevc_{qpel,epel}{,_uni}: every fractional position x the 10 width classes (tests/checkasm/hevc_pel.c shapes)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(78)
+    src = rng.integers(0, 256, (80, 96), dtype=np.uint8)
+    src[:40] = rng.choice(np.array([0, 255], np.uint8), (40, 96))          # extremes: the 14-bit intermediates at their limits
+    for chroma in (0, 1):
+        nfrac = 8 if chroma else 4
+        for w in HEVC_WIDTHS:
+            for mx in range(nfrac):
+                for my in range(nfrac):
+                    h = int(rng.choice([2, 4, 8, 16, 64])) if w > 2 else 2
+                    y0 = int(rng.integers(4, 80 - h - 5)); x0 = int(rng.integers(4, 96 - w - 5))
+                    sp = C.cast(src.ctypes.data + y0 * 96 + x0, u8p)
+                    a16, b16 = np.zeros((64, 64), np.int16), np.zeros((64, 64), np.int16)
+                    R.ffref_hevc_mc(chroma, 0, a16.ctypes.data, 0, sp, 96, h, mx, my, w)
+                    O.ffo_hevc_mc(chroma, 0, b16.ctypes.data, 0, sp, 96, h, mx, my, w)
+                    assert np.array_equal(a16, b16), (chroma, w, mx, my)
+                    a8, b8 = np.full((64, 80), 7, np.uint8), np.full((64, 80), 7, np.uint8)
+                    R.ffref_hevc_mc(chroma, 1, a8.ctypes.data, 80, sp, 96, h, mx, my, w)
+                    O.ffo_hevc_mc(chroma, 1, b8.ctypes.data, 80, sp, 96, h, mx, my, w)
+                    assert np.array_equal(a8, b8), (chroma, w, mx, my, "uni")
+
+
 def test_hevc_sao():
     """band and edge offsets on CTB-sized blocks (tests/checkasm/hevc_sao.c shapes: widths 8..64, the padded 192-byte source)"""
     R, O = ffi.ref(), ffi.oracle()

@@ -252,6 +252,20 @@ def hevc():
             R.ffref_hevc_sao_band(idx, ptr(dst), at(src, 193), 64, 192, ptr(off, i16p), cls, w, h)
         srcs.append(src); outs.append(dst); pars.append([edge, cls, w, h] + [int(v) for v in off])
     d["sao_src"], d["sao_out"], d["sao_par"] = np.stack(srcs), np.stack(outs), np.array(pars, np.int32)
+    # uni-directional MC: one 96x96 reference, 64 blocks, par = chroma, w, h, mx, my, y0, x0; outputs: int16 [64x64] and pixels [64x64]
+    mref = rng.integers(0, 256, (96, 96), dtype=np.uint8)
+    widths = [2, 4, 6, 8, 12, 16, 24, 32, 48, 64]
+    pars, o16, o8 = [], [], []
+    for rep in range(64):
+        chroma = rep & 1
+        w = widths[rep % 10]; h = int(rng.choice([2, 4, 8, 16]))
+        mx, my = (int(v) for v in rng.integers(0, 8 if chroma else 4, 2))
+        y0, x0 = int(rng.integers(4, 96 - h - 5)), int(rng.integers(4, 96 - w - 5))
+        a16, a8 = np.zeros((64, 64), np.int16), np.zeros((64, 64), np.uint8)
+        R.ffref_hevc_mc(chroma, 0, a16.ctypes.data, 0, at(mref, y0 * 96 + x0), 96, h, mx, my, w)
+        R.ffref_hevc_mc(chroma, 1, a8.ctypes.data, 64, at(mref, y0 * 96 + x0), 96, h, mx, my, w)
+        pars.append([chroma, w, h, mx, my, y0, x0]); o16.append(a16); o8.append(a8)
+    d["mc_ref"], d["mc_par"], d["mc_out16"], d["mc_out8"] = mref, np.array(pars, np.int32), np.stack(o16), np.stack(o8)
     np.savez_compressed(os.path.join(OUT, "hevc.npz"), **d)
 
 
