@@ -351,7 +351,10 @@ static int is_yuv(int fmt)
 {
     return fmt == FFHIP_PIX_FMT_YUV420P || fmt == FFHIP_PIX_FMT_NV12 || fmt == FFHIP_PIX_FMT_NV21;
 }
-static int is_rgb(int fmt) { return fmt == FFHIP_PIX_FMT_RGB24 || fmt == FFHIP_PIX_FMT_BGR24; }
+static int is_rgb(int fmt)
+{
+    return fmt == FFHIP_PIX_FMT_RGB24 || fmt == FFHIP_PIX_FMT_BGR24 || (fmt >= FFHIP_PIX_FMT_ARGB && fmt <= FFHIP_PIX_FMT_BGRA);
+}
 
 static int ceil_rshift(int a, int b) { return -((-a) >> b); }
 

@@ -542,7 +542,7 @@ __device__ __forceinline__ void cw_wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool SIL, bool BGR, int D, bool TR>
+template <bool SIL, int LAY, int D, bool TR> /* LAY: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (alpha = 255) */
 __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
 {
     __shared__ uint32_t tiles[4][384];
@@ -681,7 +681,10 @@ __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
         cw_vdots4(Yv[1], La[1], Lb[1], f01, f23, kround);
         cw_vdots4(Uv, Ca[0], Cb[0], g01, g23, kround);
         cw_vdots4(Vv, Ca[1], Cb[1], g01, g23, kround);
-        uint32_t w[6];
+        constexpr bool BGR = LAY == 1;
+        uint32_t w[LAY < 2 ? 6 : 8];
+        int alpha = 255 << 16; /* v_ashr_pk_u8_i32 ..., 16 of it is the alpha byte */
+        asm("" : "+v"(alpha));
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             int val[12];
@@ -703,10 +706,39 @@ __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
                     val[3 * p + 2] = yc + c2;
                 }
             }
+            if (LAY < 2) {
 #pragma unroll
-            for (int d = 0; d < 3; d++)
-                w[3 * h + d] = __builtin_amdgcn_perm(cw_pk_sh<16>(val[4 * d + 2], val[4 * d + 3]),
-                                                     cw_pk_sh<16>(val[4 * d], val[4 * d + 1]), 0x05040100);
+                for (int d = 0; d < 3; d++)
+                    w[3 * h + d] = __builtin_amdgcn_perm(cw_pk_sh<16>(val[4 * d + 2], val[4 * d + 3]),
+                                                         cw_pk_sh<16>(val[4 * d], val[4 * d + 1]), 0x05040100);
+            } else {
+                /* a pixel is a dword: (val[3p], val[3p+1], val[3p+2]) = (R, G, B) pre-shift sums */
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int R = val[3 * p], G = val[3 * p + 1], B = val[3 * p + 2];
+                    uint32_t lo, hi;
+                    if (LAY == 2)      { lo = cw_pk_sh<16>(alpha, R); hi = cw_pk_sh<16>(G, B); }
+                    else if (LAY == 3) { lo = cw_pk_sh<16>(R, G); hi = cw_pk_sh<16>(B, alpha); }
+                    else if (LAY == 4) { lo = cw_pk_sh<16>(alpha, B); hi = cw_pk_sh<16>(G, R); }
+                    else               { lo = cw_pk_sh<16>(B, G); hi = cw_pk_sh<16>(R, alpha); }
+                    w[(LAY < 2 ? 0 : 4 * h) + p] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
+                }
+            }
+        }
+        if (LAY >= 2) {
+            /* 32 contiguous bytes per lane, 2 KiB per wave and row: two aligned 16-byte stores */
+            if (act) {
+                cw_gptr d = (cw_gptr)dr + cw_opaque(4u * (uint32_t)X0);
+                cw_u4 s0, s1;
+                s0.x = w[0]; s0.y = w[1]; s0.z = w[2]; s0.w = w[3];
+                s1.x = w[4 % (LAY < 2 ? 6 : 8)]; s1.y = w[5 % (LAY < 2 ? 6 : 8)]; s1.z = w[6 % (LAY < 2 ? 6 : 8)]; s1.w = w[7 % (LAY < 2 ? 6 : 8)];
+                typedef cw_u4 __attribute__((address_space(1))) *cw_g4;
+                *(cw_g4)d = s0;
+                *(cw_g4)(d + 16) = s1;
+            }
+            dr += dstride;
+            asm("" : "+s"(dr));
+            return;
         }
         if (TR) {
             /* transpose through the wave's 1.5 KiB of LDS: each store instruction then covers 512 contiguous bytes
@@ -1166,8 +1198,27 @@ int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream)
     const bool tr = !(et && et[0] == '1');
 #define CWR_LAUNCH(S, B) do { if (tr) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, true>), grid, block, 0, stream, A); \
                               else hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, false>), grid, block, 0, stream, A); } while (0)
-    if (A.sil) { if (A.bgr) CWR_LAUNCH(true, true); else CWR_LAUNCH(true, false); }
-    else       { if (A.bgr) CWR_LAUNCH(false, true); else CWR_LAUNCH(false, false); }
+#define CWR_LAUNCH32(S, B) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, false>), grid, block, 0, stream, A)
+    if (A.sil) {
+        switch (A.bgr) {
+        case 0: CWR_LAUNCH(true, 0); break;
+        case 1: CWR_LAUNCH(true, 1); break;
+        case 2: CWR_LAUNCH32(true, 2); break;
+        case 3: CWR_LAUNCH32(true, 3); break;
+        case 4: CWR_LAUNCH32(true, 4); break;
+        default: CWR_LAUNCH32(true, 5); break;
+        }
+    } else {
+        switch (A.bgr) {
+        case 0: CWR_LAUNCH(false, 0); break;
+        case 1: CWR_LAUNCH(false, 1); break;
+        case 2: CWR_LAUNCH32(false, 2); break;
+        case 3: CWR_LAUNCH32(false, 3); break;
+        case 4: CWR_LAUNCH32(false, 4); break;
+        default: CWR_LAUNCH32(false, 5); break;
+        }
+    }
+#undef CWR_LAUNCH32
 #undef CWR_LAUNCH
     LAUNCH_CHECK();
     return 0;

@@ -26,7 +26,8 @@ struct FFHipYuv2RgbArgs {
     int nframes;
     FFHipYuv2RgbK k;
 };
-int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int bgr, hipStream_t stream);
+/* packed layout: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (32-bit: alpha = 255) */
+int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_t stream);
 
 /* one separable bank resident in HBM */
 struct FFHipDevFilter {

@@ -479,7 +479,9 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
             for (int i = 0; i < 4; i++) Y[i] = (int32_t)ay[i] >> 19;
             for (int i = 0; i < 2; i++) { U[i] = (int32_t)au[i] >> 19; V[i] = (int32_t)av[i] >> 19; }
         }
-        uint8_t px[12];
+        uint8_t px[16];
+        const int lay = a.bgr; /* 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
+        const int bp = lay < 2 ? 3 : 4;
 #pragma unroll
         for (int m = 0; m < 2; m++) {
             const int Uc = clip_u8(U[m]), Vc = clip_u8(V[m]);
@@ -490,19 +492,27 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
             for (int e = 0; e < 2; e++) {
                 const int yc = Y[2 * m + e] * k.cy;
                 const int r = clip_u8((br + yc) >> 16), g = clip_u8((bg + yc) >> 16), b = clip_u8((bb + yc) >> 16);
-                px[6 * m + 3 * e + 0] = a.bgr ? b : r;
-                px[6 * m + 3 * e + 1] = g;
-                px[6 * m + 3 * e + 2] = a.bgr ? r : b;
+                uint8_t *q = px + bp * (2 * m + e);
+                switch (lay) {
+                case 0: q[0] = r; q[1] = g; q[2] = b; break;
+                case 1: q[0] = b; q[1] = g; q[2] = r; break;
+                case 2: q[0] = 255; q[1] = r; q[2] = g; q[3] = b; break;
+                case 3: q[0] = r; q[1] = g; q[2] = b; q[3] = 255; break;
+                case 4: q[0] = 255; q[1] = b; q[2] = g; q[3] = r; break;
+                default: q[0] = b; q[1] = g; q[2] = r; q[3] = 255; break;
+                }
             }
         }
-        uint8_t *d = a.dst + (size_t)f * a.dst_fp + (ptrdiff_t)(y0 + y) * a.dst_stride + 3 * (x0 + xq);
+        uint8_t *d = a.dst + (size_t)f * a.dst_fp + (ptrdiff_t)(y0 + y) * a.dst_stride + bp * (x0 + xq);
         if ((flags & 4) && npx == 4) {
             uint32_t *dw = reinterpret_cast<uint32_t *>(d);
             dw[0] = pack4(px[0], px[1], px[2], px[3]);
             dw[1] = pack4(px[4], px[5], px[6], px[7]);
             dw[2] = pack4(px[8], px[9], px[10], px[11]);
+            if (bp == 4)
+                dw[3] = pack4(px[12], px[13], px[14], px[15]);
         } else {
-            for (int i = 0; i < 3 * npx; i++)
+            for (int i = 0; i < bp * npx; i++)
                 d[i] = px[i];
         }
     }

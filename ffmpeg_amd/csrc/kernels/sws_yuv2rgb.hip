@@ -235,8 +235,89 @@ __global__ __launch_bounds__(256) void k_yuv420p_rgb24_t(FFHipYuv2RgbArgs a)
     }
 }
 
-int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int bgr, hipStream_t stream)
+/*
+ * 32-bit packed targets (argb / rgba / abgr / bgra, alpha = 255): yuv2rgb_c_32 (libswscale/yuv2rgb.c:522) with its 32-bit
+ * tables (yuv2rgb.c:943-966: the same clipped ramp shifted to the component's byte, 255 in the alpha byte) in closed
+ * form.  A pixel is a dword, so no transposition is needed: one lane = 4 pixels x 2 rows writes one aligned 16-byte
+ * store per row and a wave's store instruction covers 1 KiB of contiguous destination.  5.5 B per pixel, HBM-bound.
+ */
+template <int LAYOUT> /* 2 argb, 3 rgba, 4 abgr, 5 bgra */
+__device__ __forceinline__ uint32_t px32(int r, int g, int b)
 {
+    /* values are the pre-shift sums: v_ashr_pk_u8_i32 does >> 16 and the clamp; 255 << 16 yields the alpha byte */
+    constexpr int A = 255 << 16;
+    uint32_t lo, hi;
+    if (LAYOUT == 2)      { lo = pk16<false>(A, r); hi = pk16<false>(g, b); }
+    else if (LAYOUT == 3) { lo = pk16<false>(r, g); hi = pk16<false>(b, A); }
+    else if (LAYOUT == 4) { lo = pk16<false>(A, b); hi = pk16<false>(g, r); }
+    else                  { lo = pk16<false>(b, g); hi = pk16<false>(r, A); }
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100);
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void put_px32(uint8_t *d, const Bases &b, int ycy)
+{
+    const int r = clip_u8((b.r + ycy) >> 16), g = clip_u8((b.g + ycy) >> 16), bl = clip_u8((b.b + ycy) >> 16);
+    if (LAYOUT == 2)      { d[0] = 255; d[1] = (uint8_t)r; d[2] = (uint8_t)g; d[3] = (uint8_t)bl; }
+    else if (LAYOUT == 3) { d[0] = (uint8_t)r; d[1] = (uint8_t)g; d[2] = (uint8_t)bl; d[3] = 255; }
+    else if (LAYOUT == 4) { d[0] = 255; d[1] = (uint8_t)bl; d[2] = (uint8_t)g; d[3] = (uint8_t)r; }
+    else                  { d[0] = (uint8_t)bl; d[1] = (uint8_t)g; d[2] = (uint8_t)r; d[3] = 255; }
+}
+
+template <int LAYOUT, bool VEC>
+__global__ __launch_bounds__(256) void k_yuv420p_rgb32(FFHipYuv2RgbArgs a)
+{
+    /* one lane = 4 pixels x 2 rows: a dword of each luma row, two bytes of U and of V in, one aligned 16-byte store per
+     * row out — every load and store instruction of a wave covers one contiguous run (256 B of luma, 1 KiB of pixels) */
+    const int chunks = (a.wvalid + 3) >> 2;
+    const int rowpairs = a.h >> 1;
+    const long long total = (long long)chunks * rowpairs * a.nframes;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total)
+        return;
+    const int chunk = (int)(id % chunks);
+    const int rp = (int)((id / chunks) % rowpairs);
+    const int f = (int)(id / ((long long)chunks * rowpairs));
+    const int x0 = chunk << 2;
+    const uint8_t *py0 = a.y + (size_t)f * a.y_fp + (ptrdiff_t)(2 * rp) * a.y_stride + x0;
+    const uint8_t *py1 = py0 + a.y_stride;
+    const uint8_t *pu = a.u + (size_t)f * a.u_fp + (ptrdiff_t)rp * a.u_stride + (x0 >> 1);
+    const uint8_t *pv = a.v + (size_t)f * a.v_fp + (ptrdiff_t)rp * a.v_stride + (x0 >> 1);
+    uint8_t *d0 = a.dst + (size_t)f * a.dst_fp + (ptrdiff_t)(2 * rp + a.dst_y0) * a.dst_stride + 4 * x0;
+    uint8_t *d1 = d0 + a.dst_stride;
+    const FFHipYuv2RgbK k = a.k;
+    if (VEC && x0 + 4 <= a.wvalid) {
+        const uint32_t yw0 = *reinterpret_cast<const uint32_t *>(py0), yw1 = *reinterpret_cast<const uint32_t *>(py1);
+        const uint32_t uw = *reinterpret_cast<const uint16_t *>(pu), vw = *reinterpret_cast<const uint16_t *>(pv);
+        uint32_t o0[4], o1[4];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const Bases b = chroma_bases(k, (int)((uw >> (8 * m)) & 0xFF), (int)((vw >> (8 * m)) & 0xFF));
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int p = 2 * m + e;
+                const int c0 = (int)((yw0 >> (8 * p)) & 0xFF) * k.cy, c1 = (int)((yw1 >> (8 * p)) & 0xFF) * k.cy;
+                o0[p] = px32<LAYOUT>(b.r + c0, b.g + c0, b.b + c0);
+                o1[p] = px32<LAYOUT>(b.r + c1, b.g + c1, b.b + c1);
+            }
+        }
+        *reinterpret_cast<uint4 *>(d0) = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+        *reinterpret_cast<uint4 *>(d1) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    } else {
+        const int npairs = (min(4, a.wvalid - x0)) >> 1;
+        for (int m = 0; m < npairs; m++) {
+            const Bases b = chroma_bases(k, pu[m], pv[m]);
+            put_px32<LAYOUT>(d0 + 8 * m,     b, py0[2 * m] * k.cy);
+            put_px32<LAYOUT>(d0 + 8 * m + 4, b, py0[2 * m + 1] * k.cy);
+            put_px32<LAYOUT>(d1 + 8 * m,     b, py1[2 * m] * k.cy);
+            put_px32<LAYOUT>(d1 + 8 * m + 4, b, py1[2 * m + 1] * k.cy);
+        }
+    }
+}
+
+int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_t stream)
+{
+    const int bgr = layout == 1;
     const int chunks = (a.wvalid + 15) >> 4;
     const long long total = (long long)chunks * (a.h >> 1) * a.nframes;
     if (total <= 0)
@@ -246,6 +327,25 @@ int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int bgr, hipStream_t s
                      !(((uintptr_t)a.u | (uintptr_t)a.v | (size_t)a.u_stride | (size_t)a.v_stride | a.u_fp | a.v_fp) & 7) &&
                      a.dst_stride > 0;
     const dim3 block(256);
+    if (layout >= 2) {
+        const long long total4 = (long long)((a.wvalid + 3) >> 2) * (a.h >> 1) * a.nframes; /* one thread per 4 pixels x 2 rows */
+        const dim3 grid((unsigned)((total4 + 255) / 256));
+        if (total4 >= (1LL << 31) * 256) {
+            ffhip_set_error("ffhip_sws: batch too large for one launch");
+            return FFHIP_EINVAL;
+        }
+#define L32(LY) do { if (vec) hipLaunchKernelGGL((k_yuv420p_rgb32<LY, true>), grid, block, 0, stream, a); \
+                     else hipLaunchKernelGGL((k_yuv420p_rgb32<LY, false>), grid, block, 0, stream, a); } while (0)
+        switch (layout) {
+        case 2: L32(2); break;
+        case 3: L32(3); break;
+        case 4: L32(4); break;
+        default: L32(5); break;
+        }
+#undef L32
+        LAUNCH_CHECK();
+        return 0;
+    }
     const char *ev = getenv("FFHIP_YUV2RGB_VARIANT"); /* "old": per-lane strided stores; "plain": no v_ashr_pk */
     const long long waves = (long long)((chunks + 63) >> 6) * (a.h >> 1) * a.nframes;
     if (vec && waves < (1LL << 31) && !(ev && ev[0] == 'o')) {

@@ -54,7 +54,20 @@ struct FFHipSwsContext {
 
 static bool fmt_yuv(int f) { return f == FFHIP_PIX_FMT_YUV420P || f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
 static bool fmt_nv(int f) { return f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
-static bool fmt_rgb(int f) { return f == FFHIP_PIX_FMT_RGB24 || f == FFHIP_PIX_FMT_BGR24; }
+/* packed layout number of an RGB target (the kernels' `layout` / `bgr` argument): 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
+static int rgb_layout(int f)
+{
+    switch (f) {
+    case FFHIP_PIX_FMT_RGB24: return 0;
+    case FFHIP_PIX_FMT_BGR24: return 1;
+    case FFHIP_PIX_FMT_ARGB:  return 2;
+    case FFHIP_PIX_FMT_RGBA:  return 3;
+    case FFHIP_PIX_FMT_ABGR:  return 4;
+    case FFHIP_PIX_FMT_BGRA:  return 5;
+    }
+    return -1;
+}
+static bool fmt_rgb(int f) { return rgb_layout(f) >= 0; }
 
 static int make_k(const FFHipSwsTables &t, FFHipYuv2RgbK *k)
 {
@@ -268,7 +281,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         a.srcW = t->srcW; a.srcH = t->srcH; a.chrSrcW = c->chrSrcW; a.chrSrcH = c->chrSrcH;
         a.dstW = t->dstW; a.dstH = t->dstH;
         a.hl = c->d[0]; a.hc = c->d[1]; a.vl = c->d[2]; a.vc = c->d[3];
-        a.bgr = t->dstFormat == FFHIP_PIX_FMT_BGR24;
+        a.bgr = rgb_layout(t->dstFormat);
         a.k = c->k;
         if (a.vc.n != t->dstH || a.hc.n != (t->dstW + 1) / 2) {
             ffhip_set_error("ffhip_sws: chroma banks do not match a packed-RGB target (need chrDstH == dstH)");
@@ -431,7 +444,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         a.y_stride = srcStride[0]; a.u_stride = srcStride[1]; a.v_stride = srcStride[2]; a.dst_stride = dstStride[0];
         a.y_fp = srcFramePitch[0]; a.u_fp = srcFramePitch[1]; a.v_fp = srcFramePitch[2]; a.dst_fp = dstFramePitch[0];
         a.wvalid = t.dstW & ~1; a.h = t.srcH; a.dst_y0 = 0; a.nframes = nframes; a.k = c->k;
-        return ffhip_launch_yuv420p_rgb24(a, t.dstFormat == FFHIP_PIX_FMT_BGR24, stream);
+        return ffhip_launch_yuv420p_rgb24(a, rgb_layout(t.dstFormat), stream);
     }
 
     /* chroma source description */
@@ -665,7 +678,7 @@ static int plane_list(int fmt, int w, int h, PlaneDesc out[3])
     const int cw = (w + 1) >> 1, chh = (h + 1) >> 1;
     if (fmt == FFHIP_PIX_FMT_YUV420P) { out[0] = { w, h }; out[1] = { cw, chh }; out[2] = { cw, chh }; return 3; }
     if (fmt_nv(fmt)) { out[0] = { w, h }; out[1] = { 2 * cw, chh }; return 2; }
-    out[0] = { 3 * w, h };
+    out[0] = { (rgb_layout(fmt) < 2 ? 3 : 4) * w, h };
     return 1;
 }
 
@@ -747,7 +760,7 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
         a.y_stride = pitch_s[0]; a.u_stride = pitch_s[1]; a.v_stride = pitch_s[2]; a.dst_stride = pitch_d[0];
         a.y_fp = a.u_fp = a.v_fp = a.dst_fp = 0;
         a.wvalid = t.dstW & ~1; a.h = srcSliceH; a.dst_y0 = 0; a.nframes = 1; a.k = c->k;
-        r = ffhip_launch_yuv420p_rgb24(a, t.dstFormat == FFHIP_PIX_FMT_BGR24, 0);
+        r = ffhip_launch_yuv420p_rgb24(a, rgb_layout(t.dstFormat), 0);
     } else {
         r = ffhip_sws_scale_batch_dev(c, 1, dsrc, pitch_s, fp, ddst, pitch_d, fp, 0);
     }

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-PIX_FMT = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24}
+PIX_FMT = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
 SWS_BILINEAR, SWS_BICUBIC, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 2, 4, 0x10, 0x20, 0x40
 SWS_GAUSS, SWS_SINC, SWS_LANCZOS = 0x80, 0x100, 0x200
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
@@ -26,7 +26,7 @@ def plane_shapes(fmt, w, h):
         return [(h, w), (ch, cw), (ch, cw)]
     if fmt in (PIX_FMT["nv12"], PIX_FMT["nv21"]):
         return [(h, w), (ch, 2 * cw)]
-    return [(h, 3 * w)]
+    return [(h, (3 if fmt in (PIX_FMT["rgb24"], PIX_FMT["bgr24"]) else 4) * w)]
 
 
 def frame_bytes(fmt, w, h):

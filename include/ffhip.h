@@ -58,6 +58,10 @@ int         ffhip_stream_synchronize(void *stream);
 #define FFHIP_PIX_FMT_BGR24   3
 #define FFHIP_PIX_FMT_NV12    23
 #define FFHIP_PIX_FMT_NV21    24
+#define FFHIP_PIX_FMT_ARGB    25   /* packed 8:8:8:8; alpha = 255 (the sources on this path carry none) */
+#define FFHIP_PIX_FMT_RGBA    26
+#define FFHIP_PIX_FMT_ABGR    27
+#define FFHIP_PIX_FMT_BGRA    28
 /* Flags: numeric values are SwsFlags' (libswscale/swscale.h:130-153). */
 #define FFHIP_SWS_FAST_BILINEAR 0x1
 #define FFHIP_SWS_BILINEAR      0x2

@@ -17,6 +17,10 @@
 #define FFO_PIX_FMT_RGB24   2
 #define FFO_PIX_FMT_BGR24   3
 #define FFO_PIX_FMT_NV12    23
+#define FFO_PIX_FMT_ARGB    25
+#define FFO_PIX_FMT_RGBA    26
+#define FFO_PIX_FMT_ABGR    27
+#define FFO_PIX_FMT_BGRA    28
 #define FFO_PIX_FMT_NV21    24
 
 /* ---- swscale (ffo_sws.c) ---- */

@@ -44,14 +44,26 @@ void ffo_yuv2rgb_luts_init(FfoYuv2RgbLuts *l, const FfoYuv2RgbCoeffs *k)
     }
 }
 
+/*
+ * Packed layouts ("bgr" argument of the functions below): 0 rgb24, 1 bgr24, and the 32-bit ones of yuv2rgb_c_32 /
+ * yuv2rgbx32_X (libswscale/yuv2rgb.c:522,943-966; output.c:1697-1714): 2 argb, 3 rgba, 4 abgr, 5 bgra.  Their tables
+ * hold the same clipped ramp shifted to the component's byte, with 255 in the alpha byte for a source without alpha.
+ */
+static inline int px_bytes(int layout) { return layout < 2 ? 3 : 4; }
+
 static inline void put_rgb(uint8_t *d, const FfoYuv2RgbLuts *l, int Y, int U, int V, int bgr)
 {
     int r = l->ramp[l->rV[V + HEADROOM] + Y];
     int g = l->ramp[l->gU[U + HEADROOM] + l->gV[V + HEADROOM] + Y];
     int b = l->ramp[l->bU[U + HEADROOM] + Y];
-    d[0] = bgr ? b : r;
-    d[1] = g;
-    d[2] = bgr ? r : b;
+    switch (bgr) {
+    case 0: d[0] = r; d[1] = g; d[2] = b; break;
+    case 1: d[0] = b; d[1] = g; d[2] = r; break;
+    case 2: d[0] = 255; d[1] = r; d[2] = g; d[3] = b; break;
+    case 3: d[0] = r; d[1] = g; d[2] = b; d[3] = 255; break;
+    case 4: d[0] = 255; d[1] = b; d[2] = g; d[3] = r; break;
+    default: d[0] = b; d[1] = g; d[2] = r; d[3] = 255; break;
+    }
 }
 
 /*
@@ -64,6 +76,7 @@ int ffo_yuv420p_to_rgb24(const FfoYuv2RgbLuts *l, int width, const uint8_t *cons
                          int bgr)
 {
     int npairs = (width >> 3) * 4 + ((width & 4) ? 2 : 0) + ((width & 2) ? 1 : 0);
+    const int bp = px_bytes(bgr);
     for (int y = 0; y < srcSliceH; y += 2) {
         const uint8_t *py0 = src[0] + (ptrdiff_t)y * srcStride[0];
         const uint8_t *py1 = py0 + srcStride[0];
@@ -73,10 +86,10 @@ int ffo_yuv420p_to_rgb24(const FfoYuv2RgbLuts *l, int width, const uint8_t *cons
         uint8_t *d1 = d0 + dstStride;
         for (int m = 0; m < npairs; m++) {
             int U = pu[m], V = pv[m];
-            put_rgb(d0 + 6 * m,     l, py0[2 * m],     U, V, bgr);
-            put_rgb(d0 + 6 * m + 3, l, py0[2 * m + 1], U, V, bgr);
-            put_rgb(d1 + 6 * m,     l, py1[2 * m],     U, V, bgr);
-            put_rgb(d1 + 6 * m + 3, l, py1[2 * m + 1], U, V, bgr);
+            put_rgb(d0 + 2 * bp * m,      l, py0[2 * m],     U, V, bgr);
+            put_rgb(d0 + 2 * bp * m + bp, l, py0[2 * m + 1], U, V, bgr);
+            put_rgb(d1 + 2 * bp * m,      l, py1[2 * m],     U, V, bgr);
+            put_rgb(d1 + 2 * bp * m + bp, l, py1[2 * m + 1], U, V, bgr);
         }
     }
     return srcSliceH;
@@ -145,8 +158,8 @@ static void rgb24_X(const FfoYuv2RgbLuts *l, const int16_t *lf, const int16_t *c
             v += (uint32_t)(cv[j][i] * (int)cf[j]);
         }
         int U = (int32_t)u >> 19, V = (int32_t)v >> 19;
-        put_rgb(dest + 6 * i,     l, (int32_t)y1 >> 19, U, V, bgr);
-        put_rgb(dest + 6 * i + 3, l, (int32_t)y2 >> 19, U, V, bgr);
+        put_rgb(dest + 2 * px_bytes(bgr) * i,                 l, (int32_t)y1 >> 19, U, V, bgr);
+        put_rgb(dest + 2 * px_bytes(bgr) * i + px_bytes(bgr), l, (int32_t)y2 >> 19, U, V, bgr);
     }
 }
 
@@ -160,8 +173,8 @@ static void rgb24_2(const FfoYuv2RgbLuts *l, const int16_t *const lum[2], const 
         int Y2 = (lum[0][2 * i + 1] * ya1 + lum[1][2 * i + 1] * yalpha) >> 19;
         int U = (cu[0][i] * uva1 + cu[1][i] * uvalpha) >> 19;
         int V = (cv[0][i] * uva1 + cv[1][i] * uvalpha) >> 19;
-        put_rgb(dest + 6 * i,     l, Y1, U, V, bgr);
-        put_rgb(dest + 6 * i + 3, l, Y2, U, V, bgr);
+        put_rgb(dest + 2 * px_bytes(bgr) * i,                 l, Y1, U, V, bgr);
+        put_rgb(dest + 2 * px_bytes(bgr) * i + px_bytes(bgr), l, Y2, U, V, bgr);
     }
 }
 
@@ -181,8 +194,8 @@ static void rgb24_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *
             U = (cu[0][i] * uva1 + cu[1][i] * uvalpha + (128 << 11)) >> 19;
             V = (cv[0][i] * uva1 + cv[1][i] * uvalpha + (128 << 11)) >> 19;
         }
-        put_rgb(dest + 6 * i,     l, Y1, U, V, bgr);
-        put_rgb(dest + 6 * i + 3, l, Y2, U, V, bgr);
+        put_rgb(dest + 2 * px_bytes(bgr) * i,                 l, Y1, U, V, bgr);
+        put_rgb(dest + 2 * px_bytes(bgr) * i + px_bytes(bgr), l, Y2, U, V, bgr);
     }
 }
 
@@ -194,7 +207,19 @@ static void rgb24_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *
  * dither is sws_pb_64 for <= 8-bit sources (swscale.c:54,385-387).
  * ------------------------------------------------------------------------------------------- */
 static int is_nv(int fmt) { return fmt == FFO_PIX_FMT_NV12 || fmt == FFO_PIX_FMT_NV21; }
-static int is_rgb(int fmt) { return fmt == FFO_PIX_FMT_RGB24 || fmt == FFO_PIX_FMT_BGR24; }
+static int rgb_layout(int fmt)
+{
+    switch (fmt) {
+    case FFO_PIX_FMT_RGB24: return 0;
+    case FFO_PIX_FMT_BGR24: return 1;
+    case FFO_PIX_FMT_ARGB:  return 2;
+    case FFO_PIX_FMT_RGBA:  return 3;
+    case FFO_PIX_FMT_ABGR:  return 4;
+    case FFO_PIX_FMT_BGRA:  return 5;
+    }
+    return -1;
+}
+static int is_rgb(int fmt) { return rgb_layout(fmt) >= 0; }
 
 int ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], const int srcStride[3],
                         uint8_t *const dst[3], const int dstStride[3])
@@ -238,7 +263,7 @@ int ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], cons
     }
 
     if (is_rgb(t->dstFormat)) {
-        const int bgr = t->dstFormat == FFO_PIX_FMT_BGR24;
+        const int bgr = rgb_layout(t->dstFormat);
         const int lfs = t->vLum.size, cfs = t->vChr.size;
         const int16_t **lr = rows, **ur = rows + lfs + 1, **vr = ur + cfs + 1;
         luts = malloc(sizeof(*luts));

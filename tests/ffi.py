@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libffref.so")
 
-PIX = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24}
+PIX = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
+RGB_LAYOUT = {2: 0, 3: 1, 25: 2, 26: 3, 27: 4, 28: 5}   # AVPixelFormat -> the oracle's packed layout number
 SWS_BICUBIC, SWS_BILINEAR, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 4, 2, 0x10, 0x20, 0x40
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
 
@@ -262,4 +263,4 @@ def alloc_frame(fmt, w, h, rng=None, pad=0):
         return [mk(h, w), mk(ch, cw), mk(ch, cw)]
     if fmt in (PIX["nv12"], PIX["nv21"]):
         return [mk(h, w), mk(ch, 2 * cw)]
-    return [mk(h, 3 * w)]
+    return [mk(h, (3 if fmt in (PIX["rgb24"], PIX["bgr24"]) else 4) * w)]

@@ -45,8 +45,8 @@ def test_sws_golden():
             k = ffi.OYuv2RgbCoeffs(*[ffi.DEFAULT_COEFFS[x] for x in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
             O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
             got = np.zeros_like(want[0])
-            O.ffo_yuv420p_to_rgb24(C.byref(luts), sw, sp, ss, 0, sh, ptr(got), got.strides[0], df == 3)
-            wv = 3 * (sw & ~1)
+            O.ffo_yuv420p_to_rgb24(C.byref(luts), sw, sp, ss, 0, sh, ptr(got), got.strides[0], ffi.RGB_LAYOUT[df])
+            wv = (3 if df in (2, 3) else 4) * (sw & ~1)
             assert np.array_equal(got[:, :wv], want[0][:, :wv])
         else:
             t = ffi.make_otables(sw, sh, sf, dw, dh, df, fl, banks)

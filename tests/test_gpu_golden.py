@@ -41,13 +41,13 @@ def test_sws_golden_gpu():
         torch.cuda.synchronize()
         for p, a in enumerate(want):
             got = ddst[p][0].cpu().numpy()
-            wv = a.shape[1] if not unscaled else 3 * (sw & ~1)
+            wv = a.shape[1] if not unscaled else (3 if df in (2, 3) else 4) * (sw & ~1)
             assert np.array_equal(got[:, :wv], a[:, :wv]), (sf, sw, sh, df, dw, dh, fl, p)
         # and the SwsFunc-shaped host face
         hd = [np.zeros_like(a) for a in want]
         assert ctx.scale(src, hd) == dh
         for a, b in zip(hd, want):
-            wv = a.shape[1] if not unscaled else 3 * (sw & ~1)
+            wv = a.shape[1] if not unscaled else (3 if df in (2, 3) else 4) * (sw & ~1)
             assert np.array_equal(a[:, :wv], b[:, :wv])
         ctx.close()
         n += 1

@@ -31,38 +31,39 @@ def _oracle_unscaled(src, w, h, bgr, coeffs=ffi.DEFAULT_COEFFS):
     luts = ffi.OLuts()
     k = ffi.OYuv2RgbCoeffs(*[coeffs[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
     O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
-    out = np.zeros((h, 3 * w), np.uint8)
+    out = np.zeros((h, (3 if int(bgr) < 2 else 4) * w), np.uint8)   # bgr: the oracle's packed layout number (0 rgb24 .. 5 bgra)
     sp, ss = ffi.planes(src)
-    O.ffo_yuv420p_to_rgb24(C.byref(luts), w, sp, ss, 0, h, ptr(out), out.strides[0], bgr)
+    O.ffo_yuv420p_to_rgb24(C.byref(luts), w, sp, ss, 0, h, ptr(out), out.strides[0], int(bgr))
     return out
 
 
 @pytest.mark.parametrize("w,h,pad", [(64, 16, 0), (1920, 1080, 0), (1078, 6, 0), (1076, 4, 3), (30, 2, 1),
                                      (3840, 2160, 0), (2, 2, 0), (18, 4, 0)])
-@pytest.mark.parametrize("dst", ["rgb24", "bgr24"])
+@pytest.mark.parametrize("dst", ["rgb24", "bgr24", "argb", "rgba", "abgr", "bgra"])
 def test_unscaled_yuv420p_rgb24(w, h, pad, dst):
     from ffmpeg_amd import swscale as S
     torch = _torch()
     rng = np.random.default_rng(w + h)
     src = ffi.alloc_frame(PIX["yuv420p"], w, h, rng, pad=pad)
-    want = _oracle_unscaled(src, w, h, dst == "bgr24")
+    want = _oracle_unscaled(src, w, h, ffi.RGB_LAYOUT[PIX[dst]])
+    bw = want.shape[1]
     ctx = S.SwsContext(w, h, PIX["yuv420p"], w, h, PIX[dst], S.SWS_BICUBIC)
     dsrc = _upload(src)
-    ddst = [torch.zeros((1, h, 3 * w + pad), dtype=torch.uint8, device="cuda:0")]
+    ddst = [torch.zeros((1, h, bw + pad), dtype=torch.uint8, device="cuda:0")]
     ctx.scale_batch(dsrc, ddst)
     torch.cuda.synchronize()
-    got = ddst[0][0, :, :3 * w].cpu().numpy()
+    got = ddst[0][0, :, :bw].cpu().numpy()
     assert np.array_equal(got, want)
     # host-pointer SwsFunc face, including a 2-line aligned slice
-    hd = np.zeros((h, 3 * w + pad), np.uint8)
+    hd = np.zeros((h, bw + pad), np.uint8)
     assert ctx.scale(src, [hd]) == h
-    assert np.array_equal(hd[:, :3 * w], want)
+    assert np.array_equal(hd[:, :bw], want)
     if h >= 8:
         hd2 = np.zeros_like(hd)
         y0, hh = 2, 4
         sl = [src[0][y0:], src[1][y0 // 2:], src[2][y0 // 2:]]
         assert ctx.scale(sl, [hd2], y0, hh) == hh
-        assert np.array_equal(hd2[y0:y0 + hh, :3 * w], want[y0:y0 + hh]) and not hd2[:y0].any() and not hd2[y0 + hh:].any()
+        assert np.array_equal(hd2[y0:y0 + hh, :bw], want[y0:y0 + hh]) and not hd2[:y0].any() and not hd2[y0 + hh:].any()
     ctx.close()
 
 
@@ -102,6 +103,10 @@ SCALE_CASES = [
     ("nv12", 176, 144, "rgb24", 352, 288, ffi.SWS_BILINEAR, 2),
     ("yuv420p", 352, 288, "rgb24", 120, 90, ffi.SWS_BICUBIC, 0),
     ("yuv420p", 1920, 1080, "rgb24", 3840, 2160, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 176, 144, "rgba", 352, 288, ffi.SWS_BICUBIC, 0),
+    ("nv12", 176, 144, "bgra", 352, 288, ffi.SWS_BILINEAR, 2),
+    ("yuv420p", 352, 288, "argb", 120, 90, ffi.SWS_BICUBIC, 0),
+    ("nv21", 176, 144, "abgr", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
     ("yuv420p", 1920, 1080, "rgb24", 1920, 1080, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
 ]
 

@@ -279,6 +279,10 @@ RGB_CASES = [
     ("yuv420p", 202, 120, "rgb24", 456, 270, ffi.SWS_BICUBIC),        # srcW % 4 != 0, odd chroma width
     ("yuv420p", 176, 144, "bgr24", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND | ffi.SWS_BITEXACT),  # unscaled: 1-tap luma, 4-tap chroma
     ("nv12", 192, 108, "rgb24", 192, 216, ffi.SWS_BICUBIC),           # vertical only: 1-tap horizontal banks
+    ("yuv420p", 128, 72, "rgba", 256, 144, ffi.SWS_BICUBIC),          # 32-bit packed targets, alpha = 255
+    ("nv12", 192, 108, "bgra", 384, 216, ffi.SWS_BICUBIC),
+    ("nv21", 128, 72, "argb", 192, 108, ffi.SWS_BICUBIC),
+    ("yuv420p", 1048, 600, "abgr", 2096, 1416, ffi.SWS_BICUBIC),
 ]
 
 

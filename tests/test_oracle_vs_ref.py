@@ -26,7 +26,7 @@ def _ref_convert(srcfmt, sw, sh, dstfmt, dw, dh, flags, src):
 
 
 @pytest.mark.parametrize("w,h", [(64, 16), (1920, 1080), (1078, 6), (1076, 4), (30, 2)])
-@pytest.mark.parametrize("dst", ["rgb24", "bgr24"])
+@pytest.mark.parametrize("dst", ["rgb24", "bgr24", "argb", "rgba", "abgr", "bgra"])
 def test_yuv420p_rgb24_table_path(w, h, dst):
     rng = np.random.default_rng(w * 31 + h)
     src = ffi.alloc_frame(PIX["yuv420p"], w, h, rng, pad=5)
@@ -38,7 +38,7 @@ def test_yuv420p_rgb24_table_path(w, h, dst):
     O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
     got = np.zeros_like(want[0])
     sp, ss = ffi.planes(src)
-    O.ffo_yuv420p_to_rgb24(C.byref(luts), w, sp, ss, 0, h, ptr(got), got.strides[0], dst == "bgr24")
+    O.ffo_yuv420p_to_rgb24(C.byref(luts), w, sp, ss, 0, h, ptr(got), got.strides[0], ffi.RGB_LAYOUT[PIX[dst]])
     assert np.array_equal(got, want[0])
 
 
@@ -74,6 +74,10 @@ SCALE_CASES = [
     ("yuv420p", 176, 144, "rgb24", 176, 288, ffi.SWS_BILINEAR),
     ("nv12", 176, 144, "rgb24", 352, 288, ffi.SWS_BILINEAR),
     ("yuv420p", 352, 288, "rgb24", 120, 90, ffi.SWS_BICUBIC),
+    ("yuv420p", 176, 144, "rgba", 352, 288, ffi.SWS_BICUBIC),
+    ("nv12", 176, 144, "bgra", 352, 288, ffi.SWS_BILINEAR),
+    ("yuv420p", 176, 144, "argb", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND | ffi.SWS_BITEXACT),
+    ("nv21", 176, 144, "abgr", 120, 200, ffi.SWS_BICUBIC),
     ("nv12", 192, 108, "nv12", 384, 216, 0x200),
 ]
 

@@ -28,7 +28,10 @@ def sws():
     cases = [("yuv420p", 64, 16, "rgb24", 64, 16, 4), ("yuv420p", 62, 8, "bgr24", 62, 8, 4),
              ("nv12", 96, 54, "nv12", 192, 108, 4), ("nv21", 64, 40, "yuv420p", 160, 88, 4),
              ("yuv420p", 64, 48, "nv12", 128, 96, 4), ("nv12", 80, 48, "nv12", 48, 32, 4),
-             ("yuv420p", 48, 32, "rgb24", 96, 64, 4), ("yuv420p", 48, 32, "bgr24", 48, 32, 4 | 0x40000 | 0x80000)]
+             ("yuv420p", 48, 32, "rgb24", 96, 64, 4), ("yuv420p", 48, 32, "bgr24", 48, 32, 4 | 0x40000 | 0x80000),
+             # appended later (the earlier cases keep their seeded inputs): 32-bit packed targets
+             ("yuv420p", 64, 16, "bgra", 64, 16, 4), ("yuv420p", 62, 8, "argb", 62, 8, 4),
+             ("nv12", 48, 32, "rgba", 96, 64, 4), ("yuv420p", 48, 32, "abgr", 48, 32, 4 | 0x40000 | 0x80000)]
     for i, (sf, sw, sh, df, dw, dh, fl) in enumerate(cases):
         src = ffi.alloc_frame(PIX[sf], sw, sh, rng)
         ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, PIX[df], fl, 1)
