@@ -129,7 +129,19 @@ extern "C" int ffhip_hevc_mc_batch_dev(int chroma, int uni, void *dst, ptrdiff_t
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    return ffhip_launch_hevc_mc(chroma, uni, dst, dststride, src, srcstride, blocks, n, (hipStream_t)stream);
+    return ffhip_launch_hevc_mc(chroma, uni ? 1 : 0, dst, dststride, src, srcstride, nullptr, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_hevc_mc_w_batch_dev(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                         const int16_t *src2, const FFHipHevcMcWBlock *blocks, int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0 || mode < FFHIP_HEVC_MC_UNI_W || mode > FFHIP_HEVC_MC_BI_W)
+        return FFHIP_EINVAL;
+    if (mode != FFHIP_HEVC_MC_UNI_W && !src2)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_mc(chroma, mode, dst, dststride, src, srcstride, src2, blocks, n, (hipStream_t)stream);
 }
 
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */

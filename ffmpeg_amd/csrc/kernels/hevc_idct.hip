@@ -15,6 +15,7 @@
  * in place (the reference leaves them in coeffs) and added to the picture with packed byte stores.
  */
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #include "h264_kernels.h"
@@ -362,95 +363,3 @@ int ffhip_launch_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdif
     return 0;
 }
 
-/* ================================================================================================== */
-/*
- * HEVC uni-directional motion compensation, 8-bit: put_hevc_{qpel,epel}[..][!!my][!!mx] and put_hevc_{qpel,epel}_uni
- * (libavcodec/h26x/h2656_inter_template.c:29-58,97-245,342-485).  One wave per block; lanes sweep the block's samples.
- * hv positions filter rows -before..height+after horizontally into a wave-private LDS plane of int16 first (no shift at 8
- * bits), then vertically with >> 6 — the reference's two passes.  The first batch kernel of this row: correct, not tuned.
- */
-static_assert(sizeof(FFHipHevcMcBlock) == 12, "FFHipHevcMcBlock is a 12-byte record");
-__constant__ int8_t hevc_lf8[4][8] = { { 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
-__constant__ int8_t hevc_cf4[8][4] = { { 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 },
-                                       { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
-
-template <bool CHROMA, bool UNI>
-__global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
-                                                 const FFHipHevcMcBlock *blocks, int n)
-{
-    constexpr int TAPS = CHROMA ? 4 : 8, BEFORE = CHROMA ? 1 : 3;
-    __shared__ int16_t tmp_all[4][(64 + TAPS - 1) * 64];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= n)
-        return;
-    const FFHipHevcMcBlock k = blocks[b];
-    const int w = k.width, h = k.height, mx = k.mx & (CHROMA ? 7 : 3), my = k.my & (CHROMA ? 7 : 3);
-    const uint8_t *s = src + k.src_offset;
-    int16_t *tmp = tmp_all[wave];
-    int hf[TAPS], vf[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; t++) {
-        hf[t] = CHROMA ? hevc_cf4[mx][t] : hevc_lf8[mx][t];
-        vf[t] = CHROMA ? hevc_cf4[my][t] : hevc_lf8[my][t];
-    }
-    if (mx && my) {
-        for (int i = lane; i < w * (h + TAPS - 1); i += 64) {
-            const int r = i / w, x = i - r * w;
-            const uint8_t *p = s + (ptrdiff_t)(r - BEFORE) * srcstride + x - BEFORE;
-            int acc = 0;
-#pragma unroll
-            for (int t = 0; t < TAPS; t++)
-                acc += hf[t] * p[t];
-            tmp[r * 64 + x] = (int16_t)acc;
-        }
-        hevc_wave_sync();
-    }
-    for (int i = lane; i < w * h; i += 64) {
-        const int y = i / w, x = i - y * w;
-        const uint8_t *p = s + (ptrdiff_t)y * srcstride + x;
-        int val;
-        if (!mx && !my) {
-            val = p[0] << 6;
-        } else if (!my) {
-            val = 0;
-#pragma unroll
-            for (int t = 0; t < TAPS; t++)
-                val += hf[t] * p[t - BEFORE];
-        } else if (!mx) {
-            val = 0;
-#pragma unroll
-            for (int t = 0; t < TAPS; t++)
-                val += vf[t] * p[(ptrdiff_t)(t - BEFORE) * srcstride];
-        } else {
-            int acc = 0;
-#pragma unroll
-            for (int t = 0; t < TAPS; t++)
-                acc += vf[t] * tmp[(y + t) * 64 + x];
-            val = acc >> 6;
-        }
-        if (UNI) {
-            uint8_t *d = static_cast<uint8_t *>(dst_) + k.dst_offset + (ptrdiff_t)y * dststride + x;
-            *d = (!mx && !my) ? p[0] : (uint8_t)clip_u8((val + 32) >> 6);
-        } else {
-            static_cast<int16_t *>(dst_)[(ptrdiff_t)k.dst_offset + y * 64 + x] = (int16_t)val;
-        }
-    }
-}
-
-int ffhip_launch_hevc_mc(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
-                         const FFHipHevcMcBlock *blocks, int n, hipStream_t stream)
-{
-    if (n <= 0)
-        return 0;
-    const dim3 grid(cdiv(n, 4)), block(256);
-    if (chroma) {
-        if (uni) hipLaunchKernelGGL((k_hevc_mc<true, true>), grid, block, 0, stream, dst, dststride, src, srcstride, blocks, n);
-        else     hipLaunchKernelGGL((k_hevc_mc<true, false>), grid, block, 0, stream, dst, dststride, src, srcstride, blocks, n);
-    } else {
-        if (uni) hipLaunchKernelGGL((k_hevc_mc<false, true>), grid, block, 0, stream, dst, dststride, src, srcstride, blocks, n);
-        else     hipLaunchKernelGGL((k_hevc_mc<false, false>), grid, block, 0, stream, dst, dststride, src, srcstride, blocks, n);
-    }
-    LAUNCH_CHECK();
-    return 0;
-}

@@ -404,28 +404,41 @@ static void hevc_sao_single(int edge, uint8_t *dst, const uint8_t *src, ptrdiff_
 static void s_hevc_sao_band(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const int16_t *o, int lc, int w, int h) { hevc_sao_single(0, d, s, sd, ss, o, lc, w, h); }
 static void s_hevc_sao_edge(uint8_t *d, const uint8_t *s, ptrdiff_t sd, const int16_t *o, int eo, int w, int h) { hevc_sao_single(1, d, s, sd, 192, o, eo, w, h); }
 
-/* MC: source rows -3..height+4 x columns -3..width+4 at a pitch of 128; destination after it (pixels: pitch 64; int16: 64 elements) */
+/* MC: source rows -3..height+4 x columns -3..width+4 at a pitch of 128; destination after it (pixels: pitch 64; int16: 64 elements);
+ * modes 2..4 (FFHIP_HEVC_MC_*): src2's height x 64 int16 after the destination */
 static void hevc_mc_single(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
-                           int my, int width)
+                           int my, int width, const int16_t *src2 = nullptr, int denom = 0, int wx0 = 0, int wx1 = 0, int ox = 0)
 {
     std::lock_guard<std::mutex> lk(g_shim_mu);
     if (width <= 0 || height <= 0 || width > 64 || height > 64)
         return;
     const int P = 128, before = chroma ? 1 : 3, after = chroma ? 2 : 4;
     const size_t sbytes = (size_t)(height + before + after) * P, dbytes = (size_t)height * 64 * (uni ? 1 : 2);
+    const size_t s2bytes = uni >= 3 ? (size_t)height * 128 : 0;
     void *scratch;
-    if (ffhip_scratch_reserve(64 + sbytes + dbytes + 64, &scratch) < 0)
+    if (ffhip_scratch_reserve(64 + sbytes + dbytes + s2bytes + 64, &scratch) < 0)
         return;
-    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + sbytes;
+    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + sbytes, *dsrc2 = ddst + dbytes;
+    if (s2bytes && (!src2 || hipMemcpy(dsrc2, src2, s2bytes - (size_t)(64 - width) * 2, hipMemcpyHostToDevice) != hipSuccess))
+        return;
     for (int y = -before; y < height + after; y++)
         if (hipMemcpy(dsrc + (size_t)(y + before) * P, src + y * srcstride - before, width + before + after, hipMemcpyHostToDevice) != hipSuccess)
             return;
-    FFHipHevcMcBlock k;
-    k.dst_offset = 0; k.src_offset = before * P + before;
-    k.width = (uint8_t)width; k.height = (uint8_t)height; k.mx = (uint8_t)mx; k.my = (uint8_t)my;
-    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_hevc_mc(chroma, uni, ddst, 64, dsrc, P, (const FFHipHevcMcBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+    if (uni >= 2) {
+        FFHipHevcMcWBlock k = {};
+        k.src_offset = before * P + before;
+        k.width = (uint8_t)width; k.height = (uint8_t)height; k.mx = (uint8_t)mx; k.my = (uint8_t)my;
+        k.wx0 = (int16_t)wx0; k.wx1 = (int16_t)wx1; k.ox = (int16_t)ox; k.denom = (uint8_t)denom;
+        if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+            return;
+    } else {
+        FFHipHevcMcBlock k;
+        k.dst_offset = 0; k.src_offset = before * P + before;
+        k.width = (uint8_t)width; k.height = (uint8_t)height; k.mx = (uint8_t)mx; k.my = (uint8_t)my;
+        if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+            return;
+    }
+    if (ffhip_launch_hevc_mc(chroma, uni, ddst, 64, dsrc, P, (const int16_t *)dsrc2, buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
         return;
     if (uni) {
         for (int y = 0; y < height; y++)
@@ -439,6 +452,18 @@ static void s_hevc_qpel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intpt
 static void s_hevc_epel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(1, 0, d, 0, s, ss, h, (int)mx, (int)my, w); }
 static void s_hevc_qpel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(0, 1, d, ds, s, ss, h, (int)mx, (int)my, w); }
 static void s_hevc_epel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(1, 1, d, ds, s, ss, h, (int)mx, (int)my, w); }
+#define HEVC_W_SHIMS(name, chroma)                                                                                                          \
+static void s_hevc_##name##_uni_w(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, int denom, int wx, int ox, intptr_t mx,  \
+                                  intptr_t my, int w)                                                                                       \
+{ hevc_mc_single(chroma, FFHIP_HEVC_MC_UNI_W, d, ds, s, ss, h, (int)mx, (int)my, w, nullptr, denom, wx, 0, ox); }                            \
+static void s_hevc_##name##_bi(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, const int16_t *s2, int h, intptr_t mx,             \
+                               intptr_t my, int w)                                                                                          \
+{ hevc_mc_single(chroma, FFHIP_HEVC_MC_BI, d, ds, s, ss, h, (int)mx, (int)my, w, s2); }                                                      \
+static void s_hevc_##name##_bi_w(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, const int16_t *s2, int h, int denom, int wx0,    \
+                                 int wx1, int ox, intptr_t mx, intptr_t my, int w)                                                          \
+{ hevc_mc_single(chroma, FFHIP_HEVC_MC_BI_W, d, ds, s, ss, h, (int)mx, (int)my, w, s2, denom, wx0, wx1, ox); }
+HEVC_W_SHIMS(qpel, 0)
+HEVC_W_SHIMS(epel, 1)
 
 extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
 {
@@ -464,6 +489,9 @@ extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
             for (int b = 0; b < 2; b++) {
                 c->put_hevc_qpel[i][a][b] = s_hevc_qpel; c->put_hevc_qpel_uni[i][a][b] = s_hevc_qpel_uni;
                 c->put_hevc_epel[i][a][b] = s_hevc_epel; c->put_hevc_epel_uni[i][a][b] = s_hevc_epel_uni;
+                c->put_hevc_qpel_uni_w[i][a][b] = s_hevc_qpel_uni_w; c->put_hevc_epel_uni_w[i][a][b] = s_hevc_epel_uni_w;
+                c->put_hevc_qpel_bi[i][a][b] = s_hevc_qpel_bi; c->put_hevc_epel_bi[i][a][b] = s_hevc_epel_bi;
+                c->put_hevc_qpel_bi_w[i][a][b] = s_hevc_qpel_bi_w; c->put_hevc_epel_bi_w[i][a][b] = s_hevc_epel_bi_w;
             }
     return 0;
 }

@@ -57,6 +57,27 @@ def mc_batch(chroma, uni, dst, dststride, src, srcstride, blocks, n, stream=None
                                                          _stream(stream)), "ffhip_hevc_mc_batch_dev")
 
 
+MC_UNI_W, MC_BI, MC_BI_W = 2, 3, 4
+
+#: FFHipHevcMcWBlock (include/ffhip.h)
+MCW_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("src2_offset", np.int32), ("width", np.uint8), ("height", np.uint8),
+                      ("mx", np.uint8), ("my", np.uint8), ("wx0", np.int16), ("wx1", np.int16), ("ox", np.int16), ("denom", np.uint8),
+                      ("pad", np.uint8)])
+
+
+def mc_w_batch(chroma, mode, dst, dststride, src, srcstride, src2, blocks, n, stream=None):
+    """blocks: uint8 [n, 24] FFHipHevcMcWBlock records; src2: int16 device tensor (the other list's put_hevc_* output) or None for uni_w"""
+    return _lib.check(_lib.lib().ffhip_hevc_mc_w_batch_dev(chroma, mode, dst.data_ptr(), dststride, src.data_ptr(), srcstride,
+                                                           src2.data_ptr() if src2 is not None else None, blocks.data_ptr(), n, _stream(stream)),
+                      "ffhip_hevc_mc_w_batch_dev")
+
+
+_UNI_W = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int)
+_BI = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int)
+_BI_W = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t,
+                    C.c_ssize_t, C.c_int)
+
+
 class HEVCDSPContext(C.Structure):
     """FFHipHEVCDSPContext: host-pointer faces with the reference's signatures"""
     _fields_ = [("add_residual", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t) * 4),
@@ -73,7 +94,9 @@ class HEVCDSPContext(C.Structure):
                 ("put_hevc_qpel", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
                 ("put_hevc_qpel_uni", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
                 ("put_hevc_epel", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
-                ("put_hevc_epel_uni", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10)]
+                ("put_hevc_epel_uni", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
+                ("put_hevc_qpel_uni_w", _UNI_W * 2 * 2 * 10), ("put_hevc_qpel_bi", _BI * 2 * 2 * 10), ("put_hevc_qpel_bi_w", _BI_W * 2 * 2 * 10),
+                ("put_hevc_epel_uni_w", _UNI_W * 2 * 2 * 10), ("put_hevc_epel_bi", _BI * 2 * 2 * 10), ("put_hevc_epel_bi_w", _BI_W * 2 * 2 * 10)]
 
 
 def dsp_init(bit_depth=8):

@@ -405,6 +405,19 @@ typedef struct FFHipHEVCDSPContext {
     void (*put_hevc_epel[10][2][2])(int16_t *dst, const uint8_t *src, ptrdiff_t srcstride, int height, intptr_t mx, intptr_t my, int width);
     void (*put_hevc_epel_uni[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, intptr_t mx,
                                         intptr_t my, int width);
+    /* weighted and bi-directional prediction (hevc/dsp.h:78-87,93-101); src2 = the other list's put_hevc_* output (row stride 64) */
+    void (*put_hevc_qpel_uni_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int denom,
+                                          int wx, int ox, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_qpel_bi[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                                       int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_qpel_bi_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                                         int height, int denom, int wx0, int wx1, int ox, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_epel_uni_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int denom,
+                                          int wx, int ox, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_epel_bi[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                                       int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_epel_bi_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                                         int height, int denom, int wx0, int wx1, int ox, intptr_t mx, intptr_t my, int width);
 } FFHipHEVCDSPContext;
 /** ff_hevc_dsp_init_<arch> shape (libavcodec/hevc/dsp.h:127-140).  bit_depth must be 8. */
 int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth);
@@ -462,6 +475,25 @@ typedef struct FFHipHevcMcBlock {
  */
 int ffhip_hevc_mc_batch_dev(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
                             const FFHipHevcMcBlock *blocks, int n, void *stream);
+
+/** Weighted / bi-directional prediction (luma_mc_uni with weights, luma_mc_bi, chroma_mc_bi: libavcodec/hevc/hevcdec.c:1745-1770,
+ *  1795-1860, 1975-2040): one record = the operands of one put_hevc_{qpel,epel}_{uni_w,bi,bi_w} call (hevc/dsp.h:78-101). */
+#define FFHIP_HEVC_MC_UNI_W 2   /* dst = clip(((v * wx0 + 2^(shift-1)) >> shift) + ox), shift = denom + 6          */
+#define FFHIP_HEVC_MC_BI    3   /* dst = clip((v + src2 + 64) >> 7)                                                 */
+#define FFHIP_HEVC_MC_BI_W  4   /* dst = clip((v * wx1 + src2 * wx0 + (ox + 1) << log2Wd) >> (log2Wd + 1))         */
+typedef struct FFHipHevcMcWBlock {
+    int32_t dst_offset;   /* bytes into dst */
+    int32_t src_offset;   /* bytes into src: the block's integer-sample origin */
+    int32_t src2_offset;  /* int16 elements into src2 (the other list's put_hevc_* output, rows 64 elements apart); unused by uni_w */
+    uint8_t width, height;/* 2..64 */
+    uint8_t mx, my;       /* luma: quarter-sample 0..3; chroma: eighth-sample 0..7 */
+    int16_t wx0, wx1;     /* uni_w: wx0 = wx; bi_w: wx0 weights src2, wx1 weights this block (the reference's argument order) */
+    int16_t ox;           /* uni_w: the offset; bi_w: o0 + o1 as the decoder passes it */
+    uint8_t denom;        /* log2 weight denominator (0..7 from the slice header; checkasm goes to 12) */
+    uint8_t pad;          /* sizeof == 24 */
+} FFHipHevcMcWBlock;
+int ffhip_hevc_mc_w_batch_dev(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                              const int16_t *src2, const FFHipHevcMcWBlock *blocks, int n, void *stream);
 
 /** One SAO call of the batch face (a CTB plane or part of one). */
 typedef struct FFHipHevcSao {

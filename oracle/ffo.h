@@ -90,6 +90,8 @@ void ffo_hevc_add_residual(int log2_size, uint8_t *dst, const int16_t *res, ptrd
 /* put_hevc_{qpel,epel}[..][!!my][!!mx] (uni = 0: int16 dst, row stride 64) and put_hevc_{qpel,epel}_uni (uni = 1: pixels) */
 void ffo_hevc_mc(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
                  int my, int width);
+void ffo_hevc_mc_w(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                   int height, int denom, int wx0, int wx1, int ox, int mx, int my, int width);
 /* sao_band_filter / sao_edge_filter (eo 0..3); the reference's edge filter uses stride_src = 192 */
 void ffo_hevc_sao_band(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
                        int left_class, int width, int height);

@@ -280,3 +280,30 @@ void ffo_hevc_mc(int chroma, int uni, void *dst_, ptrdiff_t dststride, const uin
                 d16[y * 64 + x] = (int16_t)val;
         }
 }
+
+/*
+ * Weighted and bi-directional prediction, 8-bit: put_hevc_{qpel,epel}_uni_w (h26x/h2656_inter_template.c:60-88,247-340,487-578),
+ * put_hevc_{qpel,epel}_bi and _bi_w (hevc/dsp_template.c:368-420,432-625,630-815).  The interpolation is ffo_hevc_mc's 14-bit
+ * intermediate; only the output stage differs.  mode: 2 uni_w (wx0 = wx), 3 bi, 4 bi_w; src2 rows are 64 elements apart.
+ */
+void ffo_hevc_mc_w(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                   int height, int denom, int wx0, int wx1, int ox, int mx, int my, int width)
+{
+    int16_t tmp[64 * 64];
+    ffo_hevc_mc(chroma, 0, tmp, 0, src, srcstride, height, mx, my, width);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const int val = tmp[y * 64 + x];
+            int out;
+            if (mode == 2) {
+                const int shift = denom + 6;
+                out = ((val * wx0 + (1 << (shift - 1))) >> shift) + ox;
+            } else if (mode == 3) {
+                out = (val + src2[y * 64 + x] + 64) >> 7;
+            } else {
+                const int log2wd = denom + 6;
+                out = (val * wx1 + src2[y * 64 + x] * wx0 + (ox + 1) * (1 << log2wd)) >> (log2wd + 1);
+            }
+            dst[y * dststride + x] = (uint8_t)clip8(out);
+        }
+}

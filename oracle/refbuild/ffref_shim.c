@@ -232,6 +232,23 @@ void ffref_hevc_mc(int chroma, int uni, void *dst, ptrdiff_t dststride, const ui
     else
         (chroma ? hevc.put_hevc_epel : hevc.put_hevc_qpel)[idx][!!my][!!mx](dst, src, srcstride, height, mx, my, width);
 }
+void ffref_hevc_mc_w(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                     int height, int denom, int wx0, int wx1, int ox, int mx, int my, int width)
+{
+    static const int wtab[10] = { 2, 4, 6, 8, 12, 16, 24, 32, 48, 64 };
+    int idx = 0;
+    dsp_init();
+    while (idx < 9 && wtab[idx] < width)
+        idx++;
+    if (mode == 2)
+        (chroma ? hevc.put_hevc_epel_uni_w : hevc.put_hevc_qpel_uni_w)[idx][!!my][!!mx](dst, dststride, src, srcstride, height, denom, wx0, ox,
+                                                                                        mx, my, width);
+    else if (mode == 3)
+        (chroma ? hevc.put_hevc_epel_bi : hevc.put_hevc_qpel_bi)[idx][!!my][!!mx](dst, dststride, src, srcstride, src2, height, mx, my, width);
+    else
+        (chroma ? hevc.put_hevc_epel_bi_w : hevc.put_hevc_qpel_bi_w)[idx][!!my][!!mx](dst, dststride, src, srcstride, src2, height, denom, wx0,
+                                                                                      wx1, ox, mx, my, width);
+}
 void ffref_hevc_sao_band(int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
                          int left_class, int width, int height)
 {

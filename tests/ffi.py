@@ -106,6 +106,8 @@ def oracle():
         L.ffo_hevc_add_residual.restype = None
         L.ffo_hevc_mc.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_hevc_mc.restype = None
+        L.ffo_hevc_mc_w.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, i16p] + [C.c_int] * 8
+        L.ffo_hevc_mc_w.restype = None
         L.ffo_hevc_sao_band.argtypes = [u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
         L.ffo_hevc_sao_band.restype = None
         L.ffo_hevc_sao_edge.argtypes = [u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
@@ -185,6 +187,8 @@ def ref():
         L.ffref_hevc_add_residual.restype = None
         L.ffref_hevc_mc.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffref_hevc_mc.restype = None
+        L.ffref_hevc_mc_w.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, i16p] + [C.c_int] * 8
+        L.ffref_hevc_mc_w.restype = None
         L.ffref_hevc_sao_band.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
         L.ffref_hevc_sao_band.restype = None
         L.ffref_hevc_sao_edge.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]

@@ -189,6 +189,11 @@ def test_hevc_golden():
         O.ffo_hevc_mc(int(chroma), 0, a16.ctypes.data, 0, at(mref, y0 * 96 + x0), 96, int(h), int(mx), int(my), int(w))
         O.ffo_hevc_mc(int(chroma), 1, a8.ctypes.data, 64, at(mref, y0 * 96 + x0), 96, int(h), int(mx), int(my), int(w))
         assert np.array_equal(a16, d["mc_out16"][i]) and np.array_equal(a8, d["mc_out8"][i]), i
+    src2 = np.ascontiguousarray(d["mcw_src2"])
+    for i, (chroma, mode, w, h, mx, my, y0, x0, den, wx0, wx1, ox) in enumerate(d["mcw_par"].tolist()):
+        a8 = np.zeros((64, 64), np.uint8)
+        O.ffo_hevc_mc_w(chroma, mode, ptr(a8), 64, at(mref, y0 * 96 + x0), 96, ptr(src2, i16p), h, den, wx0, wx1, ox, mx, my, w)
+        assert np.array_equal(a8, d["mcw_out"][i]), ("mcw", i)
 
 
 def test_fdsp_golden():

@@ -238,6 +238,29 @@ def test_hevc_mc_golden_gpu():
         assert np.array_equal(o16.cpu().numpy(), d["mc_out16"][sel]) and np.array_equal(o8.cpu().numpy(), d["mc_out8"][sel])
 
 
+def test_hevc_mc_weighted_golden_gpu():
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    d = G.load("hevc")
+    par = d["mcw_par"]
+    ref = torch.from_numpy(d["mc_ref"].copy()).cuda()
+    src2 = torch.from_numpy(d["mcw_src2"].copy()).cuda()
+    for chroma in (0, 1):
+        for mode in (2, 3, 4):
+            sel = np.nonzero((par[:, 0] == chroma) & (par[:, 1] == mode))[0]
+            n = len(sel)
+            assert n
+            rec = np.zeros(n, hevc.MCW_DTYPE)
+            rec["src_offset"] = par[sel, 6] * 96 + par[sel, 7]
+            rec["width"], rec["height"], rec["mx"], rec["my"] = par[sel, 2], par[sel, 3], par[sel, 4], par[sel, 5]
+            rec["denom"], rec["wx0"], rec["wx1"], rec["ox"] = par[sel, 8], par[sel, 9], par[sel, 10], par[sel, 11]
+            rec["dst_offset"] = np.arange(n) * 4096
+            o8 = torch.zeros((n, 64, 64), dtype=torch.uint8, device="cuda:0")
+            hevc.mc_w_batch(chroma, mode, o8, 64, ref, 96, src2, torch.from_numpy(rec.view(np.uint8).reshape(n, 24).copy()).cuda(), n)
+            torch.cuda.synchronize()
+            assert np.array_equal(o8.cpu().numpy(), d["mcw_out"][sel]), (chroma, mode)
+
+
 def test_fdsp_golden_gpu():
     from ffmpeg_amd import fdsp
     torch = _torch()

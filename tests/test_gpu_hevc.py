@@ -263,14 +263,16 @@ def test_hevc_sao_host_faces():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("old", ["0", "1"])
 @pytest.mark.parametrize("uni", [0, 1])
 @pytest.mark.parametrize("chroma", [0, 1])
-def test_hevc_mc_batch(chroma, uni):
-    """prediction blocks of all 10 widths x fractional positions in one batch (tests/checkasm/hevc_pel.c shapes)"""
+def test_hevc_mc_batch(chroma, uni, old, monkeypatch):
+    """prediction blocks of all 10 widths x fractional positions in one batch (tests/checkasm/hevc_pel.c shapes); both kernels"""
     from ffmpeg_amd import hevc
     torch = _torch()
+    monkeypatch.setenv("FFHIP_HEVC_MC_OLD", old)
     rng = np.random.default_rng(60 + 2 * chroma + uni)
-    W, H, P = 512, 256, 16
+    W, H, P = 512, 1024, 16
     ss = W + 2 * P + 3
     ref = rng.integers(0, 256, (H + 2 * P, ss), dtype=np.uint8)
     ref[:60] = rng.choice(np.array([0, 255], np.uint8), (60, ss))
@@ -286,7 +288,7 @@ def test_hevc_mc_batch(chroma, uni):
     rec = np.zeros(n, hevc.MC_DTYPE)
     O = ffi.oracle()
     if uni:
-        sd = W + 9
+        sd = W + (8 if chroma else 9)     # dword-aligned rows (packed stores) and odd ones (byte stores)
         dst = rng.integers(0, 256, (H, sd), dtype=np.uint8)
         want = dst.copy()
         for i, (by, bx, so, w, h, mx, my) in enumerate(blocks):
@@ -295,11 +297,12 @@ def test_hevc_mc_batch(chroma, uni):
         d_dst = torch.from_numpy(dst.copy()).cuda()
     else:
         sd = 0
-        dst = np.full((n, 64, 64), -7, np.int16)
+        dst = np.full((n, 66, 64), -7, np.int16)
         want = dst.copy()
         for i, (by, bx, so, w, h, mx, my) in enumerate(blocks):
-            rec[i] = (i * 4096, so, w, h, mx, my)
-            O.ffo_hevc_mc(chroma, 0, want[i].ctypes.data, 0, C.cast(ref.ctypes.data + so, u8p), ss, h, mx, my, w)
+            do = i * 66 * 64 + (i & 1)    # every other block off the 8-byte grid
+            rec[i] = (do, so, w, h, mx, my)
+            O.ffo_hevc_mc(chroma, 0, want.ctypes.data + 2 * do, 0, C.cast(ref.ctypes.data + so, u8p), ss, h, mx, my, w)
         d_dst = torch.from_numpy(dst.copy()).cuda()
     hevc.mc_batch(chroma, uni, d_dst, sd, torch.from_numpy(ref).cuda(), ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 12).copy()).cuda(), n)
     torch.cuda.synchronize()
@@ -328,3 +331,86 @@ def test_hevc_mc_host_faces():
         (c.put_hevc_epel_uni if chroma else c.put_hevc_qpel_uni)[idx][int(bool(my))][int(bool(mx))](a8.ctypes.data, 72, sp, 100, h, mx, my, w)
         O.ffo_hevc_mc(chroma, 1, b8.ctypes.data, 72, C.cast(sp, u8p), 100, h, mx, my, w)
         assert np.array_equal(a8, b8), (chroma, w, h, mx, my, "uni")
+
+
+def _weights(rng, rep):
+    """(denom, wx0, wx1, ox): slice-header ranges mixed with tests/checkasm/hevc_pel.c's ladders"""
+    if rep % 3 == 0:
+        return int(rng.choice([0, 7, 12])), int(rng.choice([0, 128, 255])), int(rng.choice([0, 128, 255])), int(rng.choice([0, 255]))
+    d = int(rng.integers(0, 8))
+    return d, (1 << d) + int(rng.integers(-128, 128)), (1 << d) + int(rng.integers(-128, 128)), int(rng.integers(-256, 255))
+
+
+@pytest.mark.parametrize("old", ["0", "1"])
+@pytest.mark.parametrize("mode", [2, 3, 4])
+@pytest.mark.parametrize("chroma", [0, 1])
+def test_hevc_mc_weighted_batch(chroma, mode, old, monkeypatch):
+    """put_hevc_{qpel,epel}_{uni_w,bi,bi_w}: all 10 widths x fractional positions x weights in one batch; both kernels"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    monkeypatch.setenv("FFHIP_HEVC_MC_OLD", old)
+    rng = np.random.default_rng(160 + 8 * chroma + mode)
+    W, H, P = 512, 1024, 16
+    ss = W + 2 * P + 3
+    ref = rng.integers(0, 256, (H + 2 * P, ss), dtype=np.uint8)
+    ref[:60] = rng.choice(np.array([0, 255], np.uint8), (60, ss))
+    nfrac = 8 if chroma else 4
+    widths = [2, 4, 6, 8, 12, 16, 24, 32, 48, 64]
+    sd = W + 8 + (mode & 1)
+    dst = rng.integers(0, 256, (H, sd), dtype=np.uint8)
+    want = dst.copy()
+    blocks = [(by, bx) for by in range(0, H, 64) for bx in range(0, W, 64)]
+    n = len(blocks)
+    src2 = rng.integers(-8192, 16384, (n + 1, 64, 64)).astype(np.int16)
+    src2[::5] = 16383
+    src2[1::7] = -8192
+    flat2 = src2.reshape(-1)
+    rec = np.zeros(n, hevc.MCW_DTYPE)
+    O = ffi.oracle()
+    for i, (by, bx) in enumerate(blocks):
+        w = int(rng.choice(widths)); h = int(rng.choice([2, 4, 8, 16, 32, 64]))
+        dy, dx = (int(v) for v in rng.integers(-8, 9, 2))
+        so = (by + P + dy) * ss + bx + P + dx
+        mx, my = int(rng.integers(0, nfrac)), int(rng.integers(0, nfrac))
+        d, wx0, wx1, ox = _weights(rng, i)
+        o2 = i * 4096 + (1 if i % 3 == 0 else 0)    # a third of the blocks off the 8-byte grid
+        rec[i] = (by * sd + bx, so, o2, w, h, mx, my, wx0, wx1, ox, d, 0)
+        O.ffo_hevc_mc_w(chroma, mode, C.cast(want.ctypes.data + by * sd + bx, u8p), sd, C.cast(ref.ctypes.data + so, u8p), ss,
+                        C.cast(flat2.ctypes.data + 2 * o2, ffi.i16p), h, d, wx0, wx1, ox, mx, my, w)
+    d_dst = torch.from_numpy(dst.copy()).cuda()
+    hevc.mc_w_batch(chroma, mode, d_dst, sd, torch.from_numpy(ref).cuda(), ss, torch.from_numpy(src2).cuda() if mode != 2 else None,
+                    torch.from_numpy(rec.view(np.uint8).reshape(n, 24).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    assert (want != dst).sum() > 1000
+    assert np.array_equal(d_dst.cpu().numpy(), want)
+
+
+def test_hevc_mc_weighted_host_faces():
+    from ffmpeg_amd import hevc
+    _torch()
+    c = hevc.dsp_init(8)
+    O = ffi.oracle()
+    rng = np.random.default_rng(62)
+    src = rng.integers(0, 256, (90, 100), dtype=np.uint8)
+    widths = [2, 4, 6, 8, 12, 16, 24, 32, 48, 64]
+    for rep in range(18):
+        chroma = rep & 1
+        idx = int(rng.integers(0, 10)); w = widths[idx]; h = int(rng.choice([2, 8, 64]))
+        mx, my = (int(v) for v in rng.integers(0, 8 if chroma else 4, 2))
+        a, b = int(bool(my)), int(bool(mx))
+        sp = src.ctypes.data + 10 * 100 + 12
+        # exactly as large as the reference reads: (h - 1) rows of 64 plus w elements
+        src2 = rng.integers(-8192, 16384, (h - 1) * 64 + w).astype(np.int16)
+        full2 = np.zeros(64 * 64, np.int16); full2[:src2.size] = src2
+        d, wx0, wx1, ox = _weights(rng, rep)
+        for mode in (2, 3, 4):
+            a8, b8 = np.full((64, 72), 9, np.uint8), np.full((64, 72), 9, np.uint8)
+            if mode == 2:
+                (c.put_hevc_epel_uni_w if chroma else c.put_hevc_qpel_uni_w)[idx][a][b](a8.ctypes.data, 72, sp, 100, h, d, wx0, ox, mx, my, w)
+            elif mode == 3:
+                (c.put_hevc_epel_bi if chroma else c.put_hevc_qpel_bi)[idx][a][b](a8.ctypes.data, 72, sp, 100, src2.ctypes.data, h, mx, my, w)
+            else:
+                (c.put_hevc_epel_bi_w if chroma else c.put_hevc_qpel_bi_w)[idx][a][b](a8.ctypes.data, 72, sp, 100, src2.ctypes.data, h, d, wx0,
+                                                                                      wx1, ox, mx, my, w)
+            O.ffo_hevc_mc_w(chroma, mode, ptr(b8), 72, C.cast(sp, u8p), 100, ptr(full2, ffi.i16p), h, d, wx0, wx1, ox, mx, my, w)
+            assert np.array_equal(a8, b8), (chroma, mode, w, h, mx, my, d, wx0, wx1, ox)

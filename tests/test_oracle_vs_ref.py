@@ -419,6 +419,41 @@ def test_hevc_mc():
                     assert np.array_equal(a8, b8), (chroma, w, mx, my, "uni")
 
 
+def hevc_weight_case(rng, rep):
+    """(denom, wx0, wx1, ox): the ranges the slice header allows (denom 0..7, w = 2^denom + [-128,127], o in [-128,127]; bi: o0 + o1)
+    mixed with tests/checkasm/hevc_pel.c's ladders (denoms 0/7/12, weights 0/128/255, offsets 0/255)"""
+    if rep % 3 == 0:
+        return int(rng.choice([0, 7, 12])), int(rng.choice([0, 128, 255])), int(rng.choice([0, 128, 255])), int(rng.choice([0, 255]))
+    d = int(rng.integers(0, 8))
+    return d, (1 << d) + int(rng.integers(-128, 128)), (1 << d) + int(rng.integers(-128, 128)), int(rng.integers(-256, 255))
+
+
+def test_hevc_mc_weighted():
+    """put_hevc_{qpel,epel}_{uni_w,bi,bi_w}: every fractional position x the 10 width classes (tests/checkasm/hevc_pel.c shapes)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(79)
+    src = rng.integers(0, 256, (80, 96), dtype=np.uint8)
+    src[:40] = rng.choice(np.array([0, 255], np.uint8), (40, 96))
+    rep = 0
+    for chroma in (0, 1):
+        nfrac = 8 if chroma else 4
+        for w in HEVC_WIDTHS:
+            for mx in range(nfrac):
+                for my in range(nfrac):
+                    h = int(rng.choice([2, 4, 8, 16, 64])) if w > 2 else 2
+                    y0 = int(rng.integers(4, 80 - h - 5)); x0 = int(rng.integers(4, 96 - w - 5))
+                    sp = C.cast(src.ctypes.data + y0 * 96 + x0, u8p)
+                    # the other list's prediction: a put_hevc_* output, i.e. anything in the 14-bit intermediate range
+                    src2 = rng.integers(-8192, 16384, (64, 64)).astype(np.int16) if rep % 4 else np.full((64, 64), 16383 if rep % 8 else -8192, np.int16)
+                    for mode in (2, 3, 4):
+                        rep += 1
+                        d, wx0, wx1, ox = hevc_weight_case(rng, rep)
+                        a8, b8 = np.full((64, 80), 7, np.uint8), np.full((64, 80), 7, np.uint8)
+                        R.ffref_hevc_mc_w(chroma, mode, ptr(a8), 80, sp, 96, ptr(src2, i16p), h, d, wx0, wx1, ox, mx, my, w)
+                        O.ffo_hevc_mc_w(chroma, mode, ptr(b8), 80, sp, 96, ptr(src2, i16p), h, d, wx0, wx1, ox, mx, my, w)
+                        assert np.array_equal(a8, b8), (chroma, mode, w, mx, my, d, wx0, wx1, ox)
+
+
 def test_hevc_sao():
     """band and edge offsets on CTB-sized blocks (tests/checkasm/hevc_sao.c shapes: widths 8..64, the padded 192-byte source)"""
     R, O = ffi.ref(), ffi.oracle()

@@ -71,3 +71,42 @@ d_mc = torch.from_numpy(mc.view(np.uint8).reshape(-1, 12)).to(dev)
 ms = timed(lambda: hevc.mc_batch(0, 1, pic, W, ref, W + 2 * P, d_mc, n))
 print(json.dumps({"case": "hevc put_hevc_qpel_uni, every 16x16 block of %d 4K planes, mixed (mx, my)" % planes, "blocks": n, "ms": round(ms, 4),
                   "Gpixel/s": round(planes * W * H / ms / 1e6, 1), "hbm_frac": round(2 * planes * W * H / ms / 1e6 / 8000, 4)}), flush=True)
+os.environ["FFHIP_HEVC_MC_OLD"] = "1"
+ms_old = timed(lambda: hevc.mc_batch(0, 1, pic, W, ref, W + 2 * P, d_mc, n))
+os.environ["FFHIP_HEVC_MC_OLD"] = "0"
+print(json.dumps({"case": "  same, the first (sample-per-lane) kernel", "ms": round(ms_old, 4), "Gpixel/s": round(planes * W * H / ms_old / 1e6, 1)}),
+      flush=True)
+# ---- bi-directional prediction as the decoder runs it: put_hevc_qpel (list 0 -> int16) then put_hevc_qpel_bi_w / _bi (list 1 + int16 -> pixels)
+# the int16 intermediates packed four 16-wide blocks to a 64-element row group (rows are MAX_PB_SIZE = 64 elements apart)
+tmp16 = torch.empty((n // 4 + 1, 16, 64), dtype=torch.int16, device=dev)
+put = mc.copy()
+put["dst_offset"] = (np.arange(n) // 4) * 1024 + (np.arange(n) % 4) * 16
+d_put = torch.from_numpy(put.view(np.uint8).reshape(-1, 12)).to(dev)
+mw = np.zeros(n, hevc.MCW_DTYPE)
+for f in ("dst_offset", "width", "height"):
+    mw[f] = mc[f]
+mw["src_offset"] = ((by + P + rng.integers(-8, 9, by.shape)) * (W + 2 * P) + bx + P + rng.integers(-8, 9, by.shape)).reshape(-1)
+mw["mx"], mw["my"] = rng.integers(0, 4, n), rng.integers(0, 4, n)
+mw["src2_offset"] = put["dst_offset"]
+mw["denom"], mw["wx0"], mw["wx1"], mw["ox"] = 6, 70, 58, 3
+d_mw = torch.from_numpy(mw.view(np.uint8).reshape(-1, 24)).to(dev)
+for name, mode in (("put_hevc_qpel + put_hevc_qpel_bi", hevc.MC_BI), ("put_hevc_qpel + put_hevc_qpel_bi_w", hevc.MC_BI_W)):
+    def both():
+        hevc.mc_batch(0, 0, tmp16, 0, ref, W + 2 * P, d_put, n)
+        hevc.mc_w_batch(0, mode, pic, W, ref, W + 2 * P, tmp16, d_mw, n)
+    ms = timed(both)
+    print(json.dumps({"case": "hevc %s, every 16x16 block of %d 4K planes" % (name, planes), "blocks": n, "ms": round(ms, 4),
+                      "Gpixel/s": round(planes * W * H / ms / 1e6, 1)}), flush=True)
+ms = timed(lambda: hevc.mc_w_batch(0, hevc.MC_UNI_W, pic, W, ref, W + 2 * P, None, d_mw, n))
+print(json.dumps({"case": "hevc put_hevc_qpel_uni_w, every 16x16 block of %d 4K planes" % planes, "blocks": n, "ms": round(ms, 4),
+                  "Gpixel/s": round(planes * W * H / ms / 1e6, 1)}), flush=True)
+# chroma: 8x8 blocks of the half-size planes, eighth-sample positions
+cm = np.zeros(n, hevc.MC_DTYPE)
+cm["dst_offset"] = ((by // 2) * W + bx // 2).reshape(-1)
+cm["src_offset"] = ((by // 2 + P + rng.integers(-4, 5, by.shape)) * (W + 2 * P) + bx // 2 + P + rng.integers(-4, 5, by.shape)).reshape(-1)
+cm["width"] = cm["height"] = 8
+cm["mx"], cm["my"] = rng.integers(0, 8, n), rng.integers(0, 8, n)
+d_cm = torch.from_numpy(cm.view(np.uint8).reshape(-1, 12)).to(dev)
+ms = timed(lambda: hevc.mc_batch(1, 1, pic, W, ref, W + 2 * P, d_cm, n))
+print(json.dumps({"case": "hevc put_hevc_epel_uni, %d 8x8 chroma blocks, mixed (mx, my)" % n, "blocks": n, "ms": round(ms, 4),
+                  "Gpixel/s": round(n * 64 / ms / 1e6, 1)}), flush=True)

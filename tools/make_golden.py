@@ -269,6 +269,25 @@ def hevc():
         R.ffref_hevc_mc(chroma, 1, a8.ctypes.data, 64, at(mref, y0 * 96 + x0), 96, h, mx, my, w)
         pars.append([chroma, w, h, mx, my, y0, x0]); o16.append(a16); o8.append(a8)
     d["mc_ref"], d["mc_par"], d["mc_out16"], d["mc_out8"] = mref, np.array(pars, np.int32), np.stack(o16), np.stack(o8)
+    # weighted / bi-directional MC on the same reference: par = chroma, mode (2 uni_w, 3 bi, 4 bi_w), w, h, mx, my, y0, x0, denom, wx0, wx1, ox;
+    # one shared 64x64 src2 (the other list's 14-bit intermediates)
+    wrng = np.random.default_rng(111)
+    src2 = wrng.integers(-8192, 16384, (64, 64)).astype(np.int16)
+    pars, outs = [], []
+    for rep in range(60):
+        chroma, mode = rep & 1, 2 + (rep // 2) % 3
+        w = widths[rep % 10]; h = int(wrng.choice([2, 4, 8, 16]))
+        mx, my = (int(v) for v in wrng.integers(0, 8 if chroma else 4, 2))
+        y0, x0 = int(wrng.integers(4, 96 - h - 5)), int(wrng.integers(4, 96 - w - 5))
+        if rep % 3 == 0:
+            den, wx0, wx1, ox = int(wrng.choice([0, 7, 12])), int(wrng.choice([0, 128, 255])), int(wrng.choice([0, 128, 255])), int(wrng.choice([0, 255]))
+        else:
+            den = int(wrng.integers(0, 8))
+            wx0, wx1, ox = (1 << den) + int(wrng.integers(-128, 128)), (1 << den) + int(wrng.integers(-128, 128)), int(wrng.integers(-256, 255))
+        a8 = np.zeros((64, 64), np.uint8)
+        R.ffref_hevc_mc_w(chroma, mode, ptr(a8), 64, at(mref, y0 * 96 + x0), 96, ptr(src2, i16p), h, den, wx0, wx1, ox, mx, my, w)
+        pars.append([chroma, mode, w, h, mx, my, y0, x0, den, wx0, wx1, ox]); outs.append(a8)
+    d["mcw_src2"], d["mcw_par"], d["mcw_out"] = src2, np.array(pars, np.int32), np.stack(outs)
     np.savez_compressed(os.path.join(OUT, "hevc.npz"), **d)
 
 
