@@ -314,39 +314,104 @@ static_assert(sizeof(FFHipHevcTU) == 12, "FFHipHevcTU is a 12-byte record");
 /* ================================================================================================== */
 /*
  * HEVC sample adaptive offset, 8-bit: sao_band_filter / sao_edge_filter (libavcodec/h26x/h2656_sao_template.c:24-84),
- * batched: one wave per block, a lane per 4 horizontally adjacent samples.  Band: offset by the sample's 5-bit band when it
- * is one of the 4 signalled ones.  Edge: sign(c - a) + sign(c - b) against the two neighbours of the class's direction
- * selects one of 5 offsets.  Pure streaming (2 B per sample).
+ * batched: one wave per block, a lane per 4 horizontally adjacent samples = one dword.  Band: offset by the sample's 5-bit band
+ * when it is one of the 4 signalled ones.  Edge: sign(c - a) + sign(c - b) against the two neighbours of the class's direction
+ * selects one of 5 offsets.  Pure streaming (2 B per sample), so the arithmetic is packed: the class index of each of the four
+ * samples becomes a selector byte and ONE v_perm_b32 looks the four offsets up in an 8-entry byte table (offsets stored + 128;
+ * the sample's band / sign sums are computed on even and odd bytes as 2 x 16-bit lanes), the add and the clip run as packed
+ * 16-bit.  Offsets outside int8 (impossible at 8 bits, but the signature is int16) and partial groups take the bytewise path.
  */
 static_assert(sizeof(FFHipHevcSao) == 24, "FFHipHevcSao is a 24-byte record");
+__constant__ uint32_t hevc_inv16[17] = { 0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096 };
+
+/* the packed 16-bit min / max / saturating subtract, spelled out: clang scalarises the generic vector builtins into v_cmp + v_cndmask */
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_subs_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+/* clamp(c - a, -1, 1) + 1 on both 16-bit lanes: 0..2, so that sums of them are plain dword adds (no negative lane to carry) */
+__device__ __forceinline__ uint32_t sao_sign1(uint32_t c1, uint32_t a) /* c1 = c + 0x00010001 */
+{
+    return pk_min_i16(pk_max_i16(pk_sub_i16(c1, a), 0u), 0x00020002u);
+}
+/* clip_u8(c + ob - 128) on both 16-bit lanes (c + ob < 2^16: a plain add is the packed add) */
+__device__ __forceinline__ uint32_t sao_add(uint32_t c, uint32_t ob)
+{
+    return pk_min_i16(pk_subs_u16(c + ob, 0x00800080u), 0x00ff00ffu);
+}
 
 __global__ __launch_bounds__(256) void k_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n)
 {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (b >= n)
         return;
     const FFHipHevcSao k = blocks[b];
-    const int w = k.width, h = k.height, qw = (w + 3) >> 2;
-    const uint8_t *s0 = src + k.src_offset;
-    uint8_t *d0 = dst + k.dst_offset;
-    const int o0 = k.offset_val[0], o1 = k.offset_val[1], o2 = k.offset_val[2], o3 = k.offset_val[3], o4 = k.offset_val[4];
+    const int w = __builtin_amdgcn_readfirstlane((int)k.width), h = __builtin_amdgcn_readfirstlane((int)k.height), qw = (w + 3) >> 2;
+    const bool edge = __builtin_amdgcn_readfirstlane((int)k.edge) != 0;
+    const int cls = __builtin_amdgcn_readfirstlane((int)k.cls);
+    const uint8_t *s0 = src + __builtin_amdgcn_readfirstlane(k.src_offset);
+    uint8_t *d0 = dst + __builtin_amdgcn_readfirstlane(k.dst_offset);
+    int o[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        o[i] = __builtin_amdgcn_readfirstlane((int)k.offset_val[i]);
+    const int o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4];
     static const int8_t dxs[4][2] = { { -1, 1 }, { 0, 0 }, { -1, 1 }, { 1, -1 } }, dys[4][2] = { { 0, 0 }, { -1, 1 }, { -1, 1 }, { -1, 1 } };
-    const int eo = k.cls & 3;
+    const int eo = cls & 3;
     const ptrdiff_t a = dxs[eo][0] + dys[eo][0] * ss, bb = dxs[eo][1] + dys[eo][1] * ss;
+    const int inv = (int)hevc_inv16[min(qw, 16)];
+
+    bool packed = true;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        packed = packed && o[i] >= -128 && o[i] <= 127;
+    /* the offset tables, + 128: edge index = sign sum + 2 -> (o1, o2, o0, o3 | o4); band index = relative band -> (o1..o4 | 0 x 4) */
+    const auto ob = [](int v) { return (uint32_t)((v + 128) & 255); };
+    const uint32_t tlo = edge ? ob(o1) | ob(o2) << 8 | ob(o0) << 16 | ob(o3) << 24 : ob(o1) | ob(o2) << 8 | ob(o3) << 16 | ob(o4) << 24;
+    const uint32_t thi = edge ? ob(o4) | 0x80808000u : 0x80808080u;
+    const bool d_al = ((reinterpret_cast<uintptr_t>(d0) | (uintptr_t)sd) & 3) == 0;
+    const uint32_t rel = (uint32_t)((32 - cls) & 31) * 0x01010101u;
+
     for (int t = lane; t < qw * h; t += 64) {
-        const int y = t / qw, x0 = 4 * (t - y * qw);
+        const int y = (t * inv) >> 16, x0 = 4 * (t - y * qw);
         const uint8_t *p = s0 + (ptrdiff_t)y * ss + x0;
         uint8_t *q = d0 + (ptrdiff_t)y * sd + x0;
         const int m = min(4, w - x0);
+        if (packed && m == 4) {
+            const uint32_t c = *reinterpret_cast<const uint32_t *>(p);
+            const uint32_t ce = c & 0x00ff00ffu, co = (c >> 8) & 0x00ff00ffu;
+            uint32_t sel;
+            if (edge) {
+                const uint32_t na = *reinterpret_cast<const uint32_t *>(p + a), nb = *reinterpret_cast<const uint32_t *>(p + bb);
+                /* sign sums + 2 = 0..4 in each 16-bit lane */
+                const uint32_t ce1 = ce + 0x00010001u, co1 = co + 0x00010001u;
+                const uint32_t se = sao_sign1(ce1, na & 0x00ff00ffu) + sao_sign1(ce1, nb & 0x00ff00ffu);
+                const uint32_t so = sao_sign1(co1, (na >> 8) & 0x00ff00ffu) + sao_sign1(co1, (nb >> 8) & 0x00ff00ffu);
+                sel = se | so << 8;
+            } else {
+                const uint32_t band = (((c >> 3) & 0x1f1f1f1fu) + rel) & 0x1f1f1f1fu;       /* per byte: (band - left_class) & 31 */
+                const uint32_t far = ((band & 0x1c1c1c1cu) + 0x7f7f7f7fu) & 0x80808080u;   /* 0x80 where it is not one of 0..3 */
+                sel = (band & 0x03030303u) | far >> 5;                                       /* those read entries 4..7 = no offset */
+            }
+            const uint32_t of = __builtin_amdgcn_perm(thi, tlo, sel);
+            const uint32_t re = sao_add(ce, of & 0x00ff00ffu), ro = sao_add(co, (of >> 8) & 0x00ff00ffu);
+            const uint32_t out = re | ro << 8;
+            if (d_al) {
+                *reinterpret_cast<uint32_t *>(q) = out;
+            } else {
+                q[0] = (uint8_t)out; q[1] = (uint8_t)(out >> 8); q[2] = (uint8_t)(out >> 16); q[3] = (uint8_t)(out >> 24);
+            }
+            continue;
+        }
         for (int e = 0; e < m; e++) {
             const int c = p[e];
             int off;
-            if (k.edge) {
+            if (edge) {
                 const int na = p[e + a], nb = p[e + bb];
                 const int sel = 2 + (c > na) - (c < na) + (c > nb) - (c < nb); /* edge_idx = { 1, 2, 0, 3, 4 } */
                 off = sel == 0 ? o1 : sel == 1 ? o2 : sel == 2 ? o0 : sel == 3 ? o3 : o4;
             } else {
-                const int band = ((c >> 3) - k.cls) & 31;                        /* 0..3: the signalled bands */
+                const int band = ((c >> 3) - cls) & 31;                          /* 0..3: the signalled bands */
                 off = band == 0 ? o1 : band == 1 ? o2 : band == 2 ? o3 : band == 3 ? o4 : 0;
             }
             q[e] = (uint8_t)clip_u8(c + off);

@@ -198,13 +198,15 @@ def test_hevc_deblock_host_faces():
         assert np.array_equal(a, b), (rep, which)
 
 
-def test_hevc_sao_batch():
-    """a picture's worth of CTB blocks, band and edge classes mixed, ragged widths/heights, source = a padded copy"""
+@pytest.mark.parametrize("aligned", [0, 1])
+def test_hevc_sao_batch(aligned):
+    """a picture's worth of CTB blocks, band and edge classes mixed, ragged widths/heights, source = a padded copy; destination
+    rows on and off the dword grid (packed / bytewise stores), offsets at the int8 limits and beyond them (bytewise arithmetic)"""
     from ffmpeg_amd import hevc
     torch = _torch()
-    rng = np.random.default_rng(50)
-    W, H, M = 320, 192, 8                                   # picture and margin of the source copy
-    ss, sd = W + 2 * M + 5, W + 11
+    rng = np.random.default_rng(50 + aligned)
+    W, H, M = 320, 448, 8                                   # picture and margin of the source copy
+    ss, sd = W + 2 * M + 5, W + (12 if aligned else 11)
     src = rng.integers(0, 256, (H + 2 * M, ss), dtype=np.uint8)
     src[M:M + H, M:M + W] = np.clip(128 + np.cumsum(rng.integers(-3, 4, (H, W)), axis=1) % 40 + rng.integers(-2, 3, (H, W)), 0, 255)
     dst = rng.integers(0, 256, (H, sd), dtype=np.uint8)
@@ -218,6 +220,11 @@ def test_hevc_sao_batch():
             off = rng.integers(-7, 8, 5)
             if edge:
                 off[0] = 0
+            kind = len(blocks) % 5
+            if kind == 3:
+                off = rng.choice(np.array([-128, 127, -100, 90, 0]), 5)     # the packed path's limits
+            elif kind == 4:
+                off = rng.integers(-300, 301, 5)                            # beyond int8: the signature allows it
             blocks.append((by * sd + bx, (by + M) * ss + bx + M, off, edge, int(rng.integers(0, 4 if edge else 32)), w, h))
     n = len(blocks)
     rec = np.zeros(n, hevc.SAO_DTYPE)
