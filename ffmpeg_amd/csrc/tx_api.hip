@@ -43,10 +43,21 @@ struct TxDev {
     int cos_off[16], sched_off[16], sched_cnt[16];
 };
 
+/* 2 * 15 * 2^k MDCT lengths (ff_tx_mdct_pfa_15xM): per-transform geometry and the extra tables of the prime-factor kernel */
+struct TxPfa {
+    int n1, m, G;              /* complex points per transform (15 m), sub-transform size, transforms per wave (G * m = 64) */
+    int magic_q, magic_row;    /* ceil(2^24 / d) for d = n1 / 2 and d = float2 per input row: e / d == (e * magic) >> 24 (e * d < 2^24) */
+    const int *in_map;         /* n1: ((i * 15 + j) -> k, pre-shifted << 1)                              */
+    const int *out_map;        /* n1: CRT output map                                                     */
+    const int *sub_map;        /* m: where sub-transform i's 15-point outputs start                      */
+    const float2 *exp_pre;     /* inverse: n1 entries in (i * 15 + j) order; forward: = exp (natural)    */
+};
+
 struct FFHipTXContext {
     int type, inv, len;
     float scale;
     TxDev d;
+    TxPfa pfa = {};
     void *dev = nullptr;
     size_t blob_bytes = 0;   /* size of the table blob at `dev` (multiple of 16) */
     /* host-pointer shim staging */
@@ -539,6 +550,189 @@ __global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, in
     }
 }
 
+/*
+ * k_mdct_pfa — MDCT lengths 2 * 15 * 2^k (CELT 120..960, AAC-960 240 / 1920): ff_tx_mdct_pfa_15xM_fwd / _inv
+ * (libavutil/tx_template.c:1425-1600), fft15 = 5 x fft3 + 3 x fft5 (:175-245,463-476), bit-identical floats.
+ * A wave takes G transforms at once, G * m = 64: lane (g, i) runs sub-transform i of transform g —
+ *   1. the G input rows are copied into LDS with coalesced 8-byte loads (the Ruritanian input map scatters neighbouring
+ *      lanes 15 points apart: gathered from LDS, not from HBM);
+ *   2. each lane folds / pre-twiddles its 15 points into registers; after a wave barrier the same LDS bytes become the
+ *      work array: the 15-point transform runs in registers and its outputs land at sub_map[i] + d * m;
+ *   3. the 15 * G in-place m-point split-radix transforms are ONE flattened butterfly schedule over the wave's work
+ *      array (the power-of-two kernels' tx_fft_lds, with the union of the arrays' butterfly lists);
+ *   4. post-twiddle through the CRT output map, straight to global memory as 8-byte stores.
+ */
+#define TXBF(x, y, a, b) do { x = (a) - (b); y = (a) + (b); } while (0)
+#define TXCMUL(dre, dim, are, aim, bre, bim) do { (dre) = (are) * (bre) - (aim) * (bim); (dim) = (are) * (bim) + (aim) * (bre); } while (0)
+#define TXSMUL(dre, dim, are, aim, bre, bim) do { (dre) = (are) * (bre) - (aim) * (bim); (dim) = (are) * (bim) - (aim) * (bre); } while (0)
+
+struct TxTab53 { float t[12]; };
+
+/* fft3 (tx_template.c:175-209): in[0..2], out o0, o1, o2 */
+__device__ __forceinline__ void tx_fft3(const TxTab53 &T, const float2 &i0, const float2 &i1, const float2 &i2, float2 &o0, float2 &o1,
+                                        float2 &o2)
+{
+    float2 t0 = i0, t1, t2;
+    TXBF(t1.x, t2.y, i1.y, i2.y);
+    TXBF(t1.y, t2.x, i1.x, i2.x);
+    o0.x = t0.x + t2.x;
+    o0.y = t0.y + t2.y;
+    t1.x = T.t[8] * t1.x;
+    t1.y = T.t[9] * t1.y;
+    t2.x = T.t[10] * t2.x;
+    t2.y = T.t[10] * t2.y;
+    o1.x = t0.x - t2.x + t1.x;
+    o1.y = t0.y - t2.y - t1.y;
+    o2.x = t0.x - t2.x - t1.x;
+    o2.y = t0.y - t2.y + t1.y;
+}
+
+/* DECL_FFT5 (tx_template.c:211-245): in[0..4] -> o[0..4] = out[D0..D4] */
+__device__ __forceinline__ void tx_fft5(const TxTab53 &T, const float2 (&in)[5], float2 (&o)[5])
+{
+    float2 dc = in[0], z0[4], t[6];
+    TXBF(t[1].y, t[0].x, in[1].x, in[4].x);
+    TXBF(t[1].x, t[0].y, in[1].y, in[4].y);
+    TXBF(t[3].y, t[2].x, in[2].x, in[3].x);
+    TXBF(t[3].x, t[2].y, in[2].y, in[3].y);
+    o[0].x = dc.x + t[0].x + t[2].x;
+    o[0].y = dc.y + t[0].y + t[2].y;
+    TXSMUL(t[4].x, t[0].x, T.t[0], T.t[2], t[2].x, t[0].x);
+    TXSMUL(t[4].y, t[0].y, T.t[0], T.t[2], t[2].y, t[0].y);
+    TXCMUL(t[5].x, t[1].x, T.t[4], T.t[6], t[3].x, t[1].x);
+    TXCMUL(t[5].y, t[1].y, T.t[4], T.t[6], t[3].y, t[1].y);
+    TXBF(z0[0].x, z0[3].x, t[0].x, t[1].x);
+    TXBF(z0[0].y, z0[3].y, t[0].y, t[1].y);
+    TXBF(z0[2].x, z0[1].x, t[4].x, t[5].x);
+    TXBF(z0[2].y, z0[1].y, t[4].y, t[5].y);
+    o[1].x = dc.x + z0[3].x;
+    o[1].y = dc.y + z0[0].y;
+    o[2].x = dc.x + z0[2].x;
+    o[2].y = dc.y + z0[1].y;
+    o[3].x = dc.x + z0[1].x;
+    o[3].y = dc.y + z0[2].y;
+    o[4].x = dc.x + z0[0].x;
+    o[4].y = dc.y + z0[3].y;
+}
+
+template <int INV>
+__global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, const uint8_t *blob, int blob_bytes, const float *in,
+                                                   size_t in_pitch, float *out, size_t out_pitch, int nt, int waves_total)
+{
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
+        for (int i = threadIdx.x; i < blob_bytes / 16; i += blockDim.x)
+            l4[i] = s4[i];
+    }
+    __syncthreads();
+    auto lp = [&](const void *p) { return lds_raw + (reinterpret_cast<const uint8_t *>(p) - blob); };
+    const int *l_in = reinterpret_cast<const int *>(lp(P.in_map)), *l_out = reinterpret_cast<const int *>(lp(P.out_map));
+    const int *l_sub = reinterpret_cast<const int *>(lp(P.sub_map));
+    const float2 *l_exp = reinterpret_cast<const float2 *>(lp(d.exp)), *l_pre = reinterpret_cast<const float2 *>(lp(P.exp_pre));
+    const float *l_cos = reinterpret_cast<const float *>(lp(d.cos_tab));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lp(d.sched));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lp(d.blocks2));
+    const int n1 = P.n1, m = P.m, G = P.G, q = n1 >> 1;
+    const int row_f2 = INV ? n1 : 2 * n1;                                     /* float2 elements of an input row */
+    const size_t area = (size_t)(INV ? 1 : 2) * G * n1 * 8 > tx_z_bytes(d.n) ? (size_t)(INV ? 1 : 2) * G * n1 * 8 : tx_z_bytes(d.n);
+    uint8_t *mine = lds_raw + ((blob_bytes + 15) & ~15) + wave * ((area + 15) & ~(size_t)15);
+    float2 *z = reinterpret_cast<float2 *>(mine);                              /* the work array ...                       */
+    const float *st = reinterpret_cast<const float *>(mine);                   /* ... and, before it, the staged input rows */
+    static constexpr int D15[15] = { 0, 6, 12, 3, 9, 10, 1, 7, 13, 4, 5, 11, 2, 8, 14 }; /* fft5_m1 | _m2 | _m3 output slots */
+    const int g = lane >> d.lg, si = lane & (m - 1);
+
+    for (int t0 = (blockIdx.x * (blockDim.x >> 6) + wave) * G; t0 < nt; t0 += waves_total * G) {
+        const int ng = min(G, nt - t0);
+        /* 1. rows -> LDS */
+        for (int e = lane; e < ng * row_f2; e += 64) {
+            const int r = (int)(((uint32_t)e * (uint32_t)P.magic_row) >> 24), c = e - r * row_f2;
+            reinterpret_cast<float2 *>(mine)[e] =
+                reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)(t0 + r) * in_pitch)[c];
+        }
+        tx_wave_sync();
+        /* 2. fold / pre-twiddle this lane's 15 points */
+        float2 f[15];
+        const bool live = g < ng;
+        if (live) {
+            const float *src = st + (size_t)g * row_f2 * 2;
+#pragma unroll
+            for (int j = 0; j < 15; j++) {
+                const int k = l_in[si * 15 + j];
+                if (INV) {
+                    const float tre = src[2 * n1 - 1 - k], tim = src[k];
+                    const float2 e = l_pre[si * 15 + j];
+                    TXCMUL(f[j].x, f[j].y, tre, tim, e.x, e.y);
+                } else {
+                    const int len4 = n1, len3 = 3 * n1;
+                    float tre, tim;
+                    if (k < len4) {
+                        tre = -src[len4 + k] + src[1 * len4 - 1 - k];
+                        tim = -src[len3 + k] + -src[1 * len3 - 1 - k];
+                    } else {
+                        tre = -src[len4 + k] + -src[5 * len4 - 1 - k];
+                        tim = src[-len4 + k] + -src[1 * len3 - 1 - k];
+                    }
+                    const float2 e = l_pre[k >> 1];
+                    TXCMUL(f[j].y, f[j].x, tre, tim, e.x, e.y);
+                }
+            }
+        }
+        tx_wave_sync(); /* every lane has its inputs: the staging bytes become the work array */
+        if (live) {
+            float2 tmp[15];
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+                tx_fft3(T, f[3 * i], f[3 * i + 1], f[3 * i + 2], tmp[i], tmp[i + 5], tmp[i + 10]);
+            const int base = g * n1 + l_sub[si];
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                float2 o[5];
+                const float2 (&ti)[5] = *reinterpret_cast<const float2 (*)[5]>(&tmp[5 * b]);
+                tx_fft5(T, ti, o);
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const int idx = base + D15[5 * b + c] * m;
+                    z[TX_PAD(idx)] = o[c];
+                }
+            }
+        }
+        tx_wave_sync();
+        /* 3. the 15 G sub-transforms */
+        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
+        /* 4. post-twiddle */
+        for (int e = lane; e < ng * q; e += 64) {
+            const int r = (int)(((uint32_t)e * (uint32_t)P.magic_q) >> 24), i = e - r * q;
+            const int i0 = q + i, i1 = q - i - 1;
+            const float2 z0 = z[TX_PAD(r * n1 + l_out[i0])], z1 = z[TX_PAD(r * n1 + l_out[i1])];
+            float2 *out2 = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)(t0 + r) * out_pitch);
+            if (INV) {
+                const float2 e0 = l_exp[i0], e1 = l_exp[i1];
+                const float2 s1 = make_float2(z1.y, z1.x), s0 = make_float2(z0.y, z0.x);
+                float a, b, c, h;
+                TXCMUL(a, b, s1.x, s1.y, e1.y, e1.x); /* z[i1].re, z[i0].im */
+                TXCMUL(c, h, s0.x, s0.y, e0.y, e0.x); /* z[i0].re, z[i1].im */
+                out2[i1] = make_float2(a, h);
+                out2[i0] = make_float2(c, b);
+            } else {
+                const float2 e0 = l_exp[i0], e1 = l_exp[i1];
+                float a, b, c, h;
+                TXCMUL(a, b, z0.x, z0.y, e0.y, e0.x); /* dst[2 i1 + 1], dst[2 i0] */
+                TXCMUL(c, h, z1.x, z1.y, e1.y, e1.x); /* dst[2 i0 + 1], dst[2 i1] */
+                out2[i1] = make_float2(h, a);
+                out2[i0] = make_float2(b, c);
+            }
+        }
+        tx_wave_sync();
+    }
+}
+#undef TXBF
+#undef TXCMUL
+#undef TXSMUL
+
 /* ---- host: tables ------------------------------------------------------------------------------- */
 static int sr_perm(int i, int len, int inv)
 {
@@ -582,6 +776,125 @@ extern "C" void ffhip_tx_uninit(FFHipTXContext **pctx)
 
 static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
 
+static int mulinv(int n, int m)
+{
+    n = n % m;
+    for (int x = 1; x < m; x++)
+        if (((n * x) % m) == 1)
+            return x;
+    return 0;
+}
+
+/* tables of the 15xM prime-factor MDCT (ff_tx_mdct_pfa_init, libavutil/tx_template.c:1425-1469; ff_tx_gen_compound_mapping with
+ * opts == NULL, libavutil/tx.c:75-121; TX_EMBED_INPUT_PFA_MAP, tx_priv.h:275-284; ff_tx_mdct_gen_exp, tx_template.c:2107-2134) */
+static int tx_init_pfa(FFHipTXContext *c, float scale_f)
+{
+    const int n1 = c->len >> 1, m = n1 / 15, G = 64 / m, inv = c->inv;
+    int lg = 0;
+    while ((1 << lg) < m)
+        lg++;
+    std::vector<int> in_map(n1), out_map(n1), sub_map(m);
+    for (int i = 0; i < m; i++)
+        sub_map[-sr_perm(i, m, inv) & (m - 1)] = i; /* the sub-transform's SCATTER revtab */
+    const int m_inv = mulinv(m, 15), n_inv = mulinv(15, m);
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < 15; i++) {
+            in_map[j * 15 + i] = (i * m + j * 15) % n1;
+            out_map[(i * m * m_inv + j * 15 * n_inv) % n1] = i * m + j;
+        }
+    if (inv)
+        for (int i = 0; i < m; i++) {
+            int *p = &in_map[i * 15 + 1];
+            for (int j = 0; j < 7; j++)
+                std::swap(p[j], p[15 - j - 2]);
+        }
+    for (int k = 0; k < n1; k += 15) {
+        int t[15];
+        memcpy(t, &in_map[k], sizeof(t));
+        for (int a = 0; a < 5; a++)
+            for (int b = 0; b < 3; b++)
+                in_map[k + a * 3 + b] = t[(a * 3 + b * 5) % 15];
+    }
+    std::vector<float2> ex(inv ? 2 * n1 : n1);
+    {
+        const double sc = scale_f;
+        const double theta = (sc < 0 ? n1 : 0) + 1.0 / 8.0, rt = sqrt(fabs(sc));
+        float2 *e = ex.data() + (inv ? n1 : 0);
+        for (int i = 0; i < n1; i++) {
+            const double alpha = M_PI_2 * (i + theta) / n1;
+            e[i].x = (float)(cos(alpha) * rt);
+            e[i].y = (float)(sin(alpha) * rt);
+        }
+        if (inv)
+            for (int i = 0; i < n1; i++)
+                ex[i] = ex[n1 + in_map[i]];
+    }
+    for (int i = 0; i < n1; i++)
+        in_map[i] <<= 1;
+    TxDev &d = c->d;
+    memset(&d, 0, sizeof(d));
+    d.n = G * n1; d.lg = lg;
+    std::vector<float> cosv;
+    for (int l = 2; l <= lg; l++) {
+        const int mm = 1 << l;
+        const double freq = 2 * M_PI / mm;
+        d.cos_off[l] = (int)cosv.size();
+        for (int i = 0; i < mm / 4; i++)
+            cosv.push_back((float)cos(i * freq));
+        cosv.push_back(0.0f);
+    }
+    /* one butterfly schedule for the wave's 15 G sub-transforms */
+    std::vector<uint32_t> lev[16];
+    std::vector<uint16_t> b2;
+    for (int g = 0; g < G; g++)
+        for (int a = 0; a < 15; a++)
+            sr_schedule(g * n1 + a * m, m, lg, lev, &b2);
+    std::vector<uint32_t> sched;
+    for (int l = 2; l <= lg; l++) {
+        d.sched_off[l] = (int)sched.size();
+        d.sched_cnt[l] = (int)lev[l].size();
+        sched.insert(sched.end(), lev[l].begin(), lev[l].end());
+        d.max_cnt = d.sched_cnt[l] > d.max_cnt ? d.sched_cnt[l] : d.max_cnt;
+    }
+    d.nblocks2 = (int)b2.size();
+    d.ahead = 0;
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_in = 0, o_out = al(o_in + (size_t)n1 * 4), o_sub = al(o_out + (size_t)n1 * 4), o_exp = al(o_sub + (size_t)m * 4);
+    const size_t o_cos = al(o_exp + ex.size() * 8), o_sched = al(o_cos + cosv.size() * 4), o_b2 = al(o_sched + sched.size() * 4);
+    const size_t total = al(o_b2 + b2.size() * 2 + 16);
+    std::vector<uint8_t> blob(total, 0);
+    memcpy(blob.data() + o_in, in_map.data(), (size_t)n1 * 4);
+    memcpy(blob.data() + o_out, out_map.data(), (size_t)n1 * 4);
+    memcpy(blob.data() + o_sub, sub_map.data(), (size_t)m * 4);
+    memcpy(blob.data() + o_exp, ex.data(), ex.size() * 8);
+    memcpy(blob.data() + o_cos, cosv.data(), cosv.size() * 4);
+    memcpy(blob.data() + o_sched, sched.data(), sched.size() * 4);
+    memcpy(blob.data() + o_b2, b2.data(), b2.size() * 2);
+    if (hipMalloc(&c->dev, total) != hipSuccess || hipMemcpy(c->dev, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        ffhip_set_error("ffhip_tx_init: table upload failed");
+        return FFHIP_ENOMEM;
+    }
+    c->blob_bytes = total;
+    const uint8_t *base = (const uint8_t *)c->dev;
+    TxPfa &P = c->pfa;
+    P.n1 = n1; P.m = m; P.G = G;
+    P.magic_q = (int)(((1u << 24) + (uint32_t)(n1 / 2) - 1) / (uint32_t)(n1 / 2));
+    {
+        const uint32_t row = (uint32_t)(inv ? n1 : 2 * n1);
+        P.magic_row = (int)(((1u << 24) + row - 1) / row);
+    }
+    P.in_map = (const int *)(base + o_in);
+    P.out_map = (const int *)(base + o_out);
+    P.sub_map = (const int *)(base + o_sub);
+    P.exp_pre = (const float2 *)(base + o_exp);
+    d.map = P.in_map;
+    d.exp = (const float2 *)(base + o_exp) + (inv ? n1 : 0); /* the natural-order table of the post-twiddle */
+    d.cos_tab = (const float *)(base + o_cos);
+    d.sched = (const uint32_t *)(base + o_sched);
+    d.blocks2 = (const uint16_t *)(base + o_b2);
+    return 0;
+}
+
 extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,
                              uint64_t flags)
 {
@@ -597,8 +910,11 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         return FFHIP_ENOSYS;
     }
     const bool fft = type == FFHIP_TX_FLOAT_FFT;
-    if (fft ? (len < 4 || len > 2048 || (len & (len - 1))) : (len < 16 || len > 4096 || (len & (len - 1)))) {
-        ffhip_set_error("ffhip_tx_init: len %d not a power of two in %s", len, fft ? "4..2048" : "16..4096");
+    /* 2 * 15 * 2^k, k = 2..6: the lengths av_tx serves with ff_tx_mdct_pfa_15xM (CELT 120..960, AAC-960 240 / 1920) */
+    const bool pfa = !fft && len % 30 == 0 && len / 30 >= 4 && len / 30 <= 64 && !((len / 30) & (len / 30 - 1));
+    if (!pfa && (fft ? (len < 4 || len > 2048 || (len & (len - 1))) : (len < 16 || len > 4096 || (len & (len - 1))))) {
+        ffhip_set_error("ffhip_tx_init: len %d is neither a power of two in %s nor 120 / 240 / 480 / 960 / 1920", len,
+                        fft ? "4..2048" : "16..4096");
         return FFHIP_EINVAL;
     }
     if (!ffhip_have_device())
@@ -607,6 +923,17 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     if (!c)
         return FFHIP_ENOMEM;
     c->type = type; c->inv = !!inv; c->len = len; c->scale = *scale;
+    if (pfa) {
+        const int r = tx_init_pfa(c, *scale);
+        if (r < 0) {
+            ffhip_tx_uninit(&c);
+            return r;
+        }
+        *pctx = c;
+        if (fn)
+            *fn = tx_single;
+        return 0;
+    }
     const int n = fft ? len : len >> 1; /* complex size of the split-radix network */
     int lg = 0;
     while ((1 << lg) < n)
@@ -731,6 +1058,55 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
         }
         hipLaunchKernelGGL(k_fft_z, dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
                            (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (c->pfa.n1) {
+        const TxPfa &P = c->pfa;
+        if (stride != (ptrdiff_t)sizeof(float) || (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7)) {
+            ffhip_set_error("ffhip_tx: the 15xM lengths need contiguous, 8-byte aligned rows");
+            return FFHIP_EINVAL;
+        }
+        size_t area = (size_t)(c->inv ? 1 : 2) * P.G * P.n1 * 8;
+        if (area < tx_z_bytes(n))
+            area = tx_z_bytes(n);
+        area = (area + 15) & ~(size_t)15;
+        const size_t blob_al = (c->blob_bytes + 15) & ~(size_t)15;
+        int wpb = 16;
+        while (wpb > 1 && blob_al + area * wpb > 150 * 1024)
+            wpb >>= 1;
+        const size_t lds_p = blob_al + area * wpb;
+        int cus = 256, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        int per_cu = (int)((160 * 1024) / (((lds_p + 1279) / 1280) * 1280));
+        if (per_cu * wpb > 32) per_cu = 32 / wpb;
+        if (per_cu < 1) per_cu = 1;
+        const int groups = (nt + P.G - 1) / P.G;
+        int blocks = cus * per_cu;
+        if (blocks > (groups + wpb - 1) / wpb)
+            blocks = (groups + wpb - 1) / wpb;
+        static bool pfa_attr = false;
+        if (!pfa_attr) {
+            (void)hipFuncSetAttribute((const void *)k_mdct_pfa<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_mdct_pfa<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            pfa_attr = true;
+        }
+        TxTab53 T;
+        T.t[0] = T.t[1] = (float)cos(2 * M_PI / 5);
+        T.t[2] = T.t[3] = (float)cos(2 * M_PI / 10);
+        T.t[4] = T.t[5] = (float)sin(2 * M_PI / 5);
+        T.t[6] = T.t[7] = (float)sin(2 * M_PI / 10);
+        T.t[8] = T.t[9] = (float)cos(2 * M_PI / 12);
+        T.t[10] = (float)cos(2 * M_PI / 6);
+        T.t[11] = (float)cos(8 * M_PI / 6);
+        if (c->inv)
+            hipLaunchKernelGGL((k_mdct_pfa<1>), dim3(blocks), dim3(64 * wpb), lds_p, (hipStream_t)stream, c->d, P, T, (const uint8_t *)c->dev,
+                               (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+        else
+            hipLaunchKernelGGL((k_mdct_pfa<0>), dim3(blocks), dim3(64 * wpb), lds_p, (hipStream_t)stream, c->d, P, T, (const uint8_t *)c->dev,
+                               (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
         LAUNCH_CHECK();
         return 0;
     }

@@ -26,9 +26,12 @@ typedef struct { float re, im; } cpx;
 struct FfoTx {
     int   len;      /* av_tx len: forward output count */
     int   inv;
-    int  *map;      /* len/2 entries */
+    int  *map;      /* len/2 entries (15xM: in_map, then out_map: 2 * len/2) */
     cpx  *exp;      /* len/2 (fwd) or len (inv) entries */
     float *cos_tab[20]; /* cos_tab[log2 n][k] = cos(2*pi*k/n), k <= n/4 */
+    int   pfa_m;    /* 0: power of two; else len/2 = 15 * pfa_m (ff_tx_mdct_pfa_15xM_*) */
+    int  *sub_map;  /* 15xM: the sub-transform's scatter map (pfa_m entries) */
+    float tab53[12];/* ff_tx_tab_53 */
 };
 
 static int sr_perm(int i, int len, int inv)
@@ -81,8 +84,12 @@ static void sr_fft(const struct FfoTx *s, cpx *z, int n, int lg)
     }
 }
 
+static FfoTx *pfa15_create(int inv, int len, float scale_f);
+
 FfoTx *ffo_mdct_create(int inv, int len, float scale_f)
 {
+    if (len >= 120 && len % 30 == 0 && !((len / 30) & (len / 30 - 1)))
+        return pfa15_create(inv, len, scale_f);
     if (len < 4 || (len & (len - 1)))
         return NULL;
     struct FfoTx *s = calloc(1, sizeof(*s));
@@ -134,13 +141,20 @@ void ffo_mdct_free(FfoTx *s)
     for (int l = 0; l < 20; l++)
         free(s->cos_tab[l]);
     free(s->map);
+    free(s->sub_map);
     free(s->exp);
     free(s);
 }
 
+static void pfa15_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride);
+
 /* stride in bytes, as av_tx_fn; forward: output stride, inverse: input stride */
 void ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride)
 {
+    if (s->pfa_m) {
+        pfa15_run(s, out, in, stride);
+        return;
+    }
     const int n = s->len >> 1, q = s->len >> 2, len3 = 3 * n;
     const cpx *exp = s->exp;
     int lg = 0;
@@ -194,6 +208,229 @@ void ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride)
     }
     free(z);
 }
+
+/*
+ * MDCT lengths 2 * 15 * 2^k (Opus / CELT 120..960, AAC-960 240 and 1920): ff_tx_mdct_pfa_15xM_fwd / _inv, the codelet av_tx picks
+ * for them ("larger factors are better", libavutil/tx.c:391-395).
+ *
+ *   ff_tx_mdct_pfa_init, DECL_COMP_IMDCT / DECL_COMP_MDCT   libavutil/tx_template.c:1425-1600
+ *   fft3, fft5_m1..3, fft15, ff_tx_tab_53                   libavutil/tx_template.c:92-107,175-245,463-476
+ *   ff_tx_gen_compound_mapping (GATHER), mulinv             libavutil/tx.c:34-42,75-121
+ *   TX_EMBED_INPUT_PFA_MAP                                  libavutil/tx_priv.h:275-284
+ *   sub-transform: fftM_ns, in place, SCATTER revtab        libavutil/tx_template.c:590-629, tx.c:136-155
+ * Prime-factor decomposition: M 15-point transforms over the Ruritanian input map (pre-twiddled), then 15 in-place M-point
+ * split-radix transforms, then the post-twiddle through the CRT output map.
+ */
+static int mulinv(int n, int m)
+{
+    n = n % m;
+    for (int x = 1; x < m; x++)
+        if (((n * x) % m) == 1)
+            return x;
+    return 0;
+}
+
+static FfoTx *pfa15_create(int inv, int len, float scale_f)
+{
+    struct FfoTx *s = calloc(1, sizeof(*s));
+    const int n = len >> 1, m = n / 15; /* n = 15 m complex points */
+    const double scale = scale_f;
+    int lg = 0;
+    while ((1 << lg) < m)
+        lg++;
+    s->len = len;
+    s->inv = inv;
+    s->pfa_m = m;
+    for (int l = 2; l <= lg; l++) {
+        const int mm = 1 << l;
+        const double freq = 2 * M_PI / mm;
+        s->cos_tab[l] = malloc(sizeof(float) * (mm / 4 + 1));
+        for (int i = 0; i < mm / 4; i++)
+            s->cos_tab[l][i] = (float)cos(i * freq);
+        s->cos_tab[l][mm / 4] = 0;
+    }
+    s->tab53[0] = s->tab53[1] = (float)cos(2 * M_PI / 5);
+    s->tab53[2] = s->tab53[3] = (float)cos(2 * M_PI / 10);
+    s->tab53[4] = s->tab53[5] = (float)sin(2 * M_PI / 5);
+    s->tab53[6] = s->tab53[7] = (float)sin(2 * M_PI / 10);
+    s->tab53[8] = s->tab53[9] = (float)cos(2 * M_PI / 12);
+    s->tab53[10] = (float)cos(2 * M_PI / 6);
+    s->tab53[11] = (float)cos(8 * M_PI / 6);
+    /* the sub-transform permutes on output: SCATTER revtab of the M-point split-radix FFT */
+    s->sub_map = malloc(sizeof(int) * m);
+    for (int i = 0; i < m; i++)
+        s->sub_map[-sr_perm(i, m, inv) & (m - 1)] = i;
+    /* compound map, opts == NULL: in_map gathers */
+    s->map = malloc(sizeof(int) * 2 * n);
+    int *in_map = s->map, *out_map = s->map + n;
+    const int m_inv = mulinv(m, 15), n_inv = mulinv(15, m);
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < 15; i++) {
+            in_map[j * 15 + i] = (i * m + j * 15) % n;
+            out_map[(i * m * m_inv + j * 15 * n_inv) % n] = i * m + j;
+        }
+    if (inv)
+        for (int i = 0; i < m; i++) {
+            int *in = &in_map[i * 15 + 1]; /* skip the DC */
+            for (int j = 0; j < 7; j++) {
+                const int t = in[j];
+                in[j] = in[15 - j - 2];
+                in[15 - j - 2] = t;
+            }
+        }
+    /* the 15-point transform is itself 3 x 5: embed its input map */
+    for (int k = 0; k < n; k += 15) {
+        int mtmp[15];
+        memcpy(mtmp, &in_map[k], sizeof(mtmp));
+        for (int mm = 0; mm < 5; mm++)
+            for (int nn = 0; nn < 3; nn++)
+                in_map[k + mm * 3 + nn] = mtmp[(mm * 3 + nn * 5) % 15];
+    }
+    {
+        const double theta = (scale < 0 ? n : 0) + 1.0 / 8.0;
+        const double sc = sqrt(fabs(scale));
+        s->exp = malloc(sizeof(cpx) * (inv ? 2 * n : n));
+        cpx *e = s->exp + (inv ? n : 0);
+        for (int i = 0; i < n; i++) {
+            const double alpha = M_PI_2 * (i + theta) / n;
+            e[i].re = (float)(cos(alpha) * sc);
+            e[i].im = (float)(sin(alpha) * sc);
+        }
+        if (inv)
+            for (int i = 0; i < n; i++)
+                s->exp[i] = s->exp[n + in_map[i]];
+    }
+    for (int i = 0; i < n; i++)
+        in_map[i] <<= 1;
+    return s;
+}
+
+#define BF(x, y, a, b) do { x = (a) - (b); y = (a) + (b); } while (0)
+#define CMUL(dre, dim, are, aim, bre, bim) do { (dre) = (are) * (bre) - (aim) * (bim); (dim) = (are) * (bim) + (aim) * (bre); } while (0)
+#define SMUL(dre, dim, are, aim, bre, bim) do { (dre) = (are) * (bre) - (aim) * (bim); (dim) = (are) * (bim) - (aim) * (bre); } while (0)
+
+static void fft3(const float *tab, cpx *out, const cpx *in, int stride)
+{
+    cpx tmp[3];
+    tmp[0] = in[0];
+    BF(tmp[1].re, tmp[2].im, in[1].im, in[2].im);
+    BF(tmp[1].im, tmp[2].re, in[1].re, in[2].re);
+    out[0 * stride].re = tmp[0].re + tmp[2].re;
+    out[0 * stride].im = tmp[0].im + tmp[2].im;
+    tmp[1].re = tab[8] * tmp[1].re;
+    tmp[1].im = tab[9] * tmp[1].im;
+    tmp[2].re = tab[10] * tmp[2].re;
+    tmp[2].im = tab[10] * tmp[2].im;
+    out[1 * stride].re = tmp[0].re - tmp[2].re + tmp[1].re;
+    out[1 * stride].im = tmp[0].im - tmp[2].im - tmp[1].im;
+    out[2 * stride].re = tmp[0].re - tmp[2].re - tmp[1].re;
+    out[2 * stride].im = tmp[0].im - tmp[2].im + tmp[1].im;
+}
+
+/* fft5_m1 / _m2 / _m3: the same butterfly with the outputs at d[0..4] * stride */
+static void fft5(const float *tab, cpx *out, const cpx *in, int stride, const int *d)
+{
+    cpx dc, z0[4], t[6];
+    dc = in[0];
+    BF(t[1].im, t[0].re, in[1].re, in[4].re);
+    BF(t[1].re, t[0].im, in[1].im, in[4].im);
+    BF(t[3].im, t[2].re, in[2].re, in[3].re);
+    BF(t[3].re, t[2].im, in[2].im, in[3].im);
+    out[d[0] * stride].re = dc.re + t[0].re + t[2].re;
+    out[d[0] * stride].im = dc.im + t[0].im + t[2].im;
+    SMUL(t[4].re, t[0].re, tab[0], tab[2], t[2].re, t[0].re);
+    SMUL(t[4].im, t[0].im, tab[0], tab[2], t[2].im, t[0].im);
+    CMUL(t[5].re, t[1].re, tab[4], tab[6], t[3].re, t[1].re);
+    CMUL(t[5].im, t[1].im, tab[4], tab[6], t[3].im, t[1].im);
+    BF(z0[0].re, z0[3].re, t[0].re, t[1].re);
+    BF(z0[0].im, z0[3].im, t[0].im, t[1].im);
+    BF(z0[2].re, z0[1].re, t[4].re, t[5].re);
+    BF(z0[2].im, z0[1].im, t[4].im, t[5].im);
+    out[d[1] * stride].re = dc.re + z0[3].re;
+    out[d[1] * stride].im = dc.im + z0[0].im;
+    out[d[2] * stride].re = dc.re + z0[2].re;
+    out[d[2] * stride].im = dc.im + z0[1].im;
+    out[d[3] * stride].re = dc.re + z0[1].re;
+    out[d[3] * stride].im = dc.im + z0[2].im;
+    out[d[4] * stride].re = dc.re + z0[0].re;
+    out[d[4] * stride].im = dc.im + z0[3].im;
+}
+
+static void fft15(const float *tab, cpx *out, const cpx *in, int stride)
+{
+    static const int d1[5] = { 0, 6, 12, 3, 9 }, d2[5] = { 10, 1, 7, 13, 4 }, d3[5] = { 5, 11, 2, 8, 14 };
+    cpx tmp[15];
+    for (int i = 0; i < 5; i++)
+        fft3(tab, tmp + i, in + i * 3, 5);
+    fft5(tab, out, tmp + 0, stride, d1);
+    fft5(tab, out, tmp + 5, stride, d2);
+    fft5(tab, out, tmp + 10, stride, d3);
+}
+
+static void pfa15_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride)
+{
+    const int n = s->len >> 1, m = s->pfa_m;
+    const int *in_map = s->map, *out_map = s->map + n;
+    const cpx *exp = s->exp;
+    cpx *tmp = malloc(sizeof(cpx) * n), f[15];
+    int lg = 0;
+    while ((1 << lg) < m)
+        lg++;
+    stride /= (ptrdiff_t)sizeof(float);
+    if (s->inv) {
+        const float *in1 = in, *in2 = in + (15 * m * 2 - 1) * stride;
+        cpx *z = (cpx *)out;
+        const int len4 = s->len >> 2;
+        for (int i = 0; i < m; i++) {
+            for (int j = 0; j < 15; j++) {
+                const int k = in_map[i * 15 + j];
+                const cpx t = { in2[-k * stride], in1[k * stride] };
+                CMUL(f[j].re, f[j].im, t.re, t.im, exp[i * 15 + j].re, exp[i * 15 + j].im);
+            }
+            fft15(s->tab53, tmp + s->sub_map[i], f, m);
+        }
+        for (int i = 0; i < 15; i++)
+            sr_fft(s, tmp + m * i, m, lg);
+        exp += n;
+        for (int i = 0; i < len4; i++) {
+            const int i0 = len4 + i, i1 = len4 - i - 1;
+            const int s0 = out_map[i0], s1 = out_map[i1];
+            const cpx src1 = { tmp[s1].im, tmp[s1].re }, src0 = { tmp[s0].im, tmp[s0].re };
+            CMUL(z[i1].re, z[i0].im, src1.re, src1.im, exp[i1].im, exp[i1].re);
+            CMUL(z[i0].re, z[i1].im, src0.re, src0.im, exp[i0].im, exp[i0].re);
+        }
+    } else {
+        const int len4 = n, len3 = len4 * 3, len8 = s->len >> 2;
+        for (int i = 0; i < m; i++) {
+            for (int j = 0; j < 15; j++) {
+                const int k = in_map[i * 15 + j];
+                cpx t;
+                if (k < len4) {
+                    t.re = -in[len4 + k] + in[1 * len4 - 1 - k];
+                    t.im = -in[len3 + k] + -in[1 * len3 - 1 - k];
+                } else {
+                    t.re = -in[len4 + k] + -in[5 * len4 - 1 - k];
+                    t.im = in[-len4 + k] + -in[1 * len3 - 1 - k];
+                }
+                CMUL(f[j].im, f[j].re, t.re, t.im, exp[k >> 1].re, exp[k >> 1].im);
+            }
+            fft15(s->tab53, tmp + s->sub_map[i], f, m);
+        }
+        for (int i = 0; i < 15; i++)
+            sr_fft(s, tmp + m * i, m, lg);
+        for (int i = 0; i < len8; i++) {
+            const int i0 = len8 + i, i1 = len8 - i - 1;
+            const int s0 = out_map[i0], s1 = out_map[i1];
+            const cpx src1 = tmp[s1], src0 = tmp[s0];
+            CMUL(out[(2 * i1 + 1) * stride], out[2 * i0 * stride], src0.re, src0.im, exp[i0].im, exp[i0].re);
+            CMUL(out[(2 * i0 + 1) * stride], out[2 * i1 * stride], src1.re, src1.im, exp[i1].im, exp[i1].re);
+        }
+    }
+    free(tmp);
+}
+#undef BF
+#undef CMUL
+#undef SMUL
 
 /*
  * AV_TX_FLOAT_FFT, power-of-two: the out-of-place wrapper gathers the input through the split-radix permutation

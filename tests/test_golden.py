@@ -144,7 +144,7 @@ def test_tx_golden():
             assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), key
         O.ffo_mdct_free(s)
         n += 1
-    assert n == 6
+    assert n == 12
 
 
 def test_hevc_golden():

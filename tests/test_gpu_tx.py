@@ -176,3 +176,42 @@ def test_fft_batch(len_, inv):
     ctx.fn(one, xin, 8)
     assert np.array_equal(one.view(np.uint32), want[0].view(np.uint32))
     ctx.close()
+
+
+@pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("len_,scale,nt", [(120, 1.0, 1003), (240, 1.0 / 240, 77), (480, -1.0, 61), (960, 1.0 / 960, 4001), (960, 32768.0, 5),
+                                           (1920, 1.0, 300)])
+def test_mdct_pfa15_batch(inv, len_, scale, nt):
+    """2 * 15 * 2^k (CELT 120..960, AAC-960 240 / 1920: ff_tx_mdct_pfa_15xM): bit-identical; batch sizes that leave the last
+    wave's group of G = 64 / m transforms partly filled, and more groups than resident waves"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    rng = np.random.default_rng(len_ + inv)
+    n_in = len_ if inv else 2 * len_
+    inp = (rng.random((nt, n_in), dtype=np.float32) * 2 - 1).astype(np.float32)
+    inp[1] = 0
+    inp[2, ::3] = 1e-30
+    want = _oracle(inv, len_, scale, inp)
+    ctx = tx.TxContext(tx.FLOAT_MDCT, inv, len_, scale)
+    d_in = torch.from_numpy(inp).cuda()
+    d_out = torch.zeros((nt, len_ + 6), dtype=torch.float32, device="cuda:0")   # a row pitch that is not the row length
+    ctx.batch(d_out[:, :len_], d_in)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    _check(np.ascontiguousarray(got[:, :len_]), want)
+    assert not got[:, len_:].any()
+    o1 = np.zeros(len_, np.float32)
+    ctx.fn(o1, inp[nt - 1])
+    _check(o1[None], want[nt - 1:nt])
+    ctx.close()
+
+
+def test_mdct_pfa15_rejects_strided_rows():
+    from ffmpeg_amd import tx
+    torch = _torch()
+    ctx = tx.TxContext(tx.FLOAT_MDCT, 0, 960, 1.0)
+    d_in = torch.zeros((2, 1920), dtype=torch.float32, device="cuda:0")
+    d_out = torch.zeros((2, 1920), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(RuntimeError, match="15xM"):
+        ctx.batch(d_out, d_in, stride=8)
+    ctx.close()

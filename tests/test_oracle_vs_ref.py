@@ -512,10 +512,11 @@ def test_me_search_esa(R_):
             assert c1 == c2 and np.array_equal(m1, m2)
 
 
-@pytest.mark.parametrize("len_", [16, 64, 256, 1024, 2048])
+@pytest.mark.parametrize("len_", [16, 64, 256, 1024, 2048, 120, 240, 480, 960, 1920])
 @pytest.mark.parametrize("inv", [0, 1])
 def test_mdct_float(len_, inv):
-    """The restated split-radix recursion reproduces the reference's float results exactly."""
+    """The restated split-radix recursion (and, for 2 * 15 * 2^k, the 15xM prime-factor codelet: Opus / AAC-960 sizes) reproduces
+    the reference's float results exactly."""
     R, O = ffi.ref(), ffi.oracle()
     rng = np.random.default_rng(len_ + inv)
     scale = 1.0 / len_ if inv else 1.0

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""tools/bench_pfa.py — the 15xM prime-factor MDCT lengths (CELT / AAC-960) on one GPU, HIP events; 65,536 transforms each."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from ffmpeg_amd import tx  # noqa: E402
+
+nt = 65536
+for ln in (120, 240, 480, 960, 1920):
+    for inv in (0, 1):
+        tin = torch.rand((nt, ln if inv else 2 * ln), dtype=torch.float32, device="cuda:0")
+        tout = torch.empty((nt, ln), dtype=torch.float32, device="cuda:0")
+        ctx = tx.TxContext(tx.FLOAT_MDCT, inv, ln, 1.0 / ln if inv else 1.0)
+        for _ in range(2):
+            ctx.batch(tout, tin)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ctx.batch(tout, tin)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        byt = nt * ln * 4 * (2 if inv else 3)
+        print(json.dumps({"len": ln, "inv": inv, "ms": round(ms, 4), "Mtx/s": round(nt / ms / 1e3, 1), "GB/s": round(byt / ms / 1e6, 1),
+                          "hbm_frac": round(byt / ms / 1e6 / 8000, 4)}), flush=True)
+        ctx.close()

@@ -158,6 +158,18 @@ def tx():
             R.ffref_tx_free(rc)
             key = "mdct%d_%d_%r" % (len_, inv, scale)
             d[key + "_in"], d[key + "_out"] = x, out
+    # 15xM prime-factor lengths (CELT 120 / 960, AAC-960 1920), own generator so that the entries above stay as they were
+    rng = np.random.default_rng(1006)
+    for len_ in (120, 960, 1920):
+        for inv, scale in ((0, 1.0), (1, 1.0 / len_)):
+            x = rng.uniform(-1, 1, (3, len_ if inv else 2 * len_)).astype(np.float32)
+            rc = R.ffref_tx_create(1, inv, len_, scale, 0)
+            out = np.zeros((3, len_), np.float32)
+            for t in range(3):
+                R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 4)
+            R.ffref_tx_free(rc)
+            key = "mdct%d_%d_%r" % (len_, inv, scale)
+            d[key + "_in"], d[key + "_out"] = x, out
     d["keys"] = np.array(sorted({k.rsplit("_", 1)[0] for k in d}))
     np.savez_compressed(os.path.join(OUT, "tx.npz"), **d)
 
