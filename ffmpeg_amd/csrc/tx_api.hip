@@ -46,11 +46,10 @@ struct TxDev {
 /* 2 * 15 * 2^k MDCT lengths (ff_tx_mdct_pfa_15xM): per-transform geometry and the extra tables of the prime-factor kernel */
 struct TxPfa {
     int n1, m, G;              /* complex points per transform (15 m), sub-transform size, transforms per wave (G * m = 64) */
-    int magic_q, magic_row;    /* ceil(2^24 / d) for d = n1 / 2 and d = float2 per input row: e / d == (e * magic) >> 24 (e * d < 2^24) */
-    const int *in_map;         /* n1: ((i * 15 + j) -> k, pre-shifted << 1)                              */
+    int magic_q;               /* ceil(2^24 / (n1 / 2)): e / (n1 / 2) == (e * magic) >> 24 for e * n1 / 2 < 2^24 */
+    const int *in_map;         /* n1: ((i * 15 + j) -> k >> 1, the point sub-transform i takes as its j-th input */
     const int *out_map;        /* n1: CRT output map                                                     */
     const int *sub_map;        /* m: where sub-transform i's 15-point outputs start                      */
-    const float2 *exp_pre;     /* inverse: n1 entries in (i * 15 + j) order; forward: = exp (natural)    */
 };
 
 struct FFHipTXContext {
@@ -554,10 +553,11 @@ __global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, in
  * k_mdct_pfa — MDCT lengths 2 * 15 * 2^k (CELT 120..960, AAC-960 240 / 1920): ff_tx_mdct_pfa_15xM_fwd / _inv
  * (libavutil/tx_template.c:1425-1600), fft15 = 5 x fft3 + 3 x fft5 (:175-245,463-476), bit-identical floats.
  * A wave takes G transforms at once, G * m = 64: lane (g, i) runs sub-transform i of transform g —
- *   1. the G input rows are copied into LDS with coalesced 8-byte loads (the Ruritanian input map scatters neighbouring
- *      lanes 15 points apart: gathered from LDS, not from HBM);
- *   2. each lane folds / pre-twiddles its 15 points into registers; after a wave barrier the same LDS bytes become the
- *      work array: the 15-point transform runs in registers and its outputs land at sub_map[i] + d * m;
+ *   1. the fold / pre-twiddle runs in INPUT order with coalesced 8-byte loads (the reference twiddles point k with
+ *      exp[k >> 1] wherever the map sends it, so the value depends on k alone) and parks the points in LDS;
+ *   2. each lane gathers its 15 points through the Ruritanian input map (neighbouring lanes sit 15 points apart: an LDS
+ *      gather, not an HBM one); after a wave barrier the same LDS bytes become the work array: the 15-point transform
+ *      runs in registers and its outputs land at sub_map[i] + d * m;
  *   3. the 15 * G in-place m-point split-radix transforms are ONE flattened butterfly schedule over the wave's work
  *      array (the power-of-two kernels' tx_fft_lds, with the union of the arrays' butterfly lists);
  *   4. post-twiddle through the CRT output map, straight to global memory as 8-byte stores.
@@ -632,56 +632,48 @@ __global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, 
     auto lp = [&](const void *p) { return lds_raw + (reinterpret_cast<const uint8_t *>(p) - blob); };
     const int *l_in = reinterpret_cast<const int *>(lp(P.in_map)), *l_out = reinterpret_cast<const int *>(lp(P.out_map));
     const int *l_sub = reinterpret_cast<const int *>(lp(P.sub_map));
-    const float2 *l_exp = reinterpret_cast<const float2 *>(lp(d.exp)), *l_pre = reinterpret_cast<const float2 *>(lp(P.exp_pre));
+    const float2 *l_exp = reinterpret_cast<const float2 *>(lp(d.exp));
     const float *l_cos = reinterpret_cast<const float *>(lp(d.cos_tab));
     const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lp(d.sched));
     const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lp(d.blocks2));
     const int n1 = P.n1, m = P.m, G = P.G, q = n1 >> 1;
-    const int row_f2 = INV ? n1 : 2 * n1;                                     /* float2 elements of an input row */
-    const size_t area = (size_t)(INV ? 1 : 2) * G * n1 * 8 > tx_z_bytes(d.n) ? (size_t)(INV ? 1 : 2) * G * n1 * 8 : tx_z_bytes(d.n);
-    uint8_t *mine = lds_raw + ((blob_bytes + 15) & ~15) + wave * ((area + 15) & ~(size_t)15);
-    float2 *z = reinterpret_cast<float2 *>(mine);                              /* the work array ...                       */
-    const float *st = reinterpret_cast<const float *>(mine);                   /* ... and, before it, the staged input rows */
+    uint8_t *mine = lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(d.n);
+    float2 *z = reinterpret_cast<float2 *>(mine);  /* the work array; before that, the folded / pre-twiddled points w[g][k >> 1] */
     static constexpr int D15[15] = { 0, 6, 12, 3, 9, 10, 1, 7, 13, 4, 5, 11, 2, 8, 14 }; /* fft5_m1 | _m2 | _m3 output slots */
     const int g = lane >> d.lg, si = lane & (m - 1);
 
     for (int t0 = (blockIdx.x * (blockDim.x >> 6) + wave) * G; t0 < nt; t0 += waves_total * G) {
         const int ng = min(G, nt - t0);
-        /* 1. rows -> LDS */
-        for (int e = lane; e < ng * row_f2; e += 64) {
-            const int r = (int)(((uint32_t)e * (uint32_t)P.magic_row) >> 24), c = e - r * row_f2;
-            reinterpret_cast<float2 *>(mine)[e] =
-                reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)(t0 + r) * in_pitch)[c];
+        /* 1. fold / pre-twiddle in INPUT order (the value of point k depends on k alone: exp[k >> 1] and the samples around it),
+         *    points i and n1-1-i together as in k_mdct_z: coalesced 8-byte loads, every input byte loaded once */
+        for (int e = lane; e < ng * q; e += 64) {
+            const int r = (int)(((uint32_t)e * (uint32_t)P.magic_q) >> 24), i = e - r * q, j = n1 - 1 - i;
+            const float2 *in2 = reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)(t0 + r) * in_pitch);
+            const float2 e0 = l_exp[i], e1 = l_exp[j];
+            float2 *w = z + r * n1;
+            if (!INV) {
+                const float2 p1 = in2[q + i], p2 = in2[q - 1 - i], p3 = in2[3 * q + i], p4 = in2[3 * q - 1 - i];
+                const float re0 = -p1.x + p2.y, im0 = -p3.x + -p4.y;
+                const float re1 = -p4.x + -p3.y, im1 = p2.x + -p1.y;
+                w[i] = make_float2(re0 * e0.y + im0 * e0.x, re0 * e0.x - im0 * e0.y);
+                w[j] = make_float2(re1 * e1.y + im1 * e1.x, re1 * e1.x - im1 * e1.y);
+            } else {
+                const float2 f = in2[i], h = in2[j];
+                w[i] = make_float2(h.y * e0.x - f.x * e0.y, h.y * e0.y + f.x * e0.x);
+                w[j] = make_float2(f.y * e1.x - h.x * e1.y, f.y * e1.y + h.x * e1.x);
+            }
         }
         tx_wave_sync();
-        /* 2. fold / pre-twiddle this lane's 15 points */
+        /* 2. this lane's 15 points, through the Ruritanian input map */
         float2 f[15];
         const bool live = g < ng;
         if (live) {
-            const float *src = st + (size_t)g * row_f2 * 2;
+            const float2 *w = z + g * n1;
 #pragma unroll
-            for (int j = 0; j < 15; j++) {
-                const int k = l_in[si * 15 + j];
-                if (INV) {
-                    const float tre = src[2 * n1 - 1 - k], tim = src[k];
-                    const float2 e = l_pre[si * 15 + j];
-                    TXCMUL(f[j].x, f[j].y, tre, tim, e.x, e.y);
-                } else {
-                    const int len4 = n1, len3 = 3 * n1;
-                    float tre, tim;
-                    if (k < len4) {
-                        tre = -src[len4 + k] + src[1 * len4 - 1 - k];
-                        tim = -src[len3 + k] + -src[1 * len3 - 1 - k];
-                    } else {
-                        tre = -src[len4 + k] + -src[5 * len4 - 1 - k];
-                        tim = src[-len4 + k] + -src[1 * len3 - 1 - k];
-                    }
-                    const float2 e = l_pre[k >> 1];
-                    TXCMUL(f[j].y, f[j].x, tre, tim, e.x, e.y);
-                }
-            }
+            for (int j = 0; j < 15; j++)
+                f[j] = w[l_in[si * 15 + j]];
         }
-        tx_wave_sync(); /* every lane has its inputs: the staging bytes become the work array */
+        tx_wave_sync(); /* every lane has its inputs: the same bytes become the work array */
         if (live) {
             float2 tmp[15];
 #pragma unroll
@@ -815,22 +807,18 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f)
             for (int b = 0; b < 3; b++)
                 in_map[k + a * 3 + b] = t[(a * 3 + b * 5) % 15];
     }
-    std::vector<float2> ex(inv ? 2 * n1 : n1);
+    /* the natural-order table only: the reference's permuted copy for the inverse pre-twiddle is exp[map[i]], i.e. the
+     * twiddle of input point k is exp[k >> 1] in both directions */
+    std::vector<float2> ex(n1);
     {
         const double sc = scale_f;
         const double theta = (sc < 0 ? n1 : 0) + 1.0 / 8.0, rt = sqrt(fabs(sc));
-        float2 *e = ex.data() + (inv ? n1 : 0);
         for (int i = 0; i < n1; i++) {
             const double alpha = M_PI_2 * (i + theta) / n1;
-            e[i].x = (float)(cos(alpha) * rt);
-            e[i].y = (float)(sin(alpha) * rt);
+            ex[i].x = (float)(cos(alpha) * rt);
+            ex[i].y = (float)(sin(alpha) * rt);
         }
-        if (inv)
-            for (int i = 0; i < n1; i++)
-                ex[i] = ex[n1 + in_map[i]];
     }
-    for (int i = 0; i < n1; i++)
-        in_map[i] <<= 1;
     TxDev &d = c->d;
     memset(&d, 0, sizeof(d));
     d.n = G * n1; d.lg = lg;
@@ -879,16 +867,11 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f)
     TxPfa &P = c->pfa;
     P.n1 = n1; P.m = m; P.G = G;
     P.magic_q = (int)(((1u << 24) + (uint32_t)(n1 / 2) - 1) / (uint32_t)(n1 / 2));
-    {
-        const uint32_t row = (uint32_t)(inv ? n1 : 2 * n1);
-        P.magic_row = (int)(((1u << 24) + row - 1) / row);
-    }
     P.in_map = (const int *)(base + o_in);
     P.out_map = (const int *)(base + o_out);
     P.sub_map = (const int *)(base + o_sub);
-    P.exp_pre = (const float2 *)(base + o_exp);
     d.map = P.in_map;
-    d.exp = (const float2 *)(base + o_exp) + (inv ? n1 : 0); /* the natural-order table of the post-twiddle */
+    d.exp = (const float2 *)(base + o_exp);
     d.cos_tab = (const float *)(base + o_cos);
     d.sched = (const uint32_t *)(base + o_sched);
     d.blocks2 = (const uint16_t *)(base + o_b2);
@@ -1067,10 +1050,7 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
             ffhip_set_error("ffhip_tx: the 15xM lengths need contiguous, 8-byte aligned rows");
             return FFHIP_EINVAL;
         }
-        size_t area = (size_t)(c->inv ? 1 : 2) * P.G * P.n1 * 8;
-        if (area < tx_z_bytes(n))
-            area = tx_z_bytes(n);
-        area = (area + 15) & ~(size_t)15;
+        const size_t area = tx_z_bytes(n); /* G * n1 points, padded: the parked inputs (unpadded) fit the same bytes */
         const size_t blob_al = (c->blob_bytes + 15) & ~(size_t)15;
         int wpb = 16;
         while (wpb > 1 && blob_al + area * wpb > 150 * 1024)

@@ -552,8 +552,9 @@ typedef struct FFHipTXContext FFHipTXContext;
 typedef void (*ffhip_tx_fn)(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
 /**
  * Same argument meaning as av_tx_init() (libavutil/tx.h:169-172, libavutil/tx.c:903): type, inv,
- * len (MDCT: number of output coefficients of the forward transform, power of two 16..4096 here; FFT: number of
- * complex samples, power of two 4..2048), *scale (FFT: ignored, may be NULL).  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
+ * len (MDCT: number of output coefficients of the forward transform, power of two 16..4096 or one of the 15xM prime-factor
+ * lengths 120 / 240 / 480 / 960 / 1920 (ff_tx_mdct_pfa_15xM, libavutil/tx_template.c:1425-1600: CELT, AAC-960; their batches
+ * must be contiguous 8-byte aligned rows); FFT: number of complex samples, power of two 4..2048), *scale (FFT: ignored, may be NULL).  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
  * (libavutil/tx_priv.h:199-237).  *fn receives the single-transform host-pointer shim.
  */
 int  ffhip_tx_init(FFHipTXContext **ctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,
