@@ -49,6 +49,7 @@ struct FFHipSwsContext {
     /* staging for the host-pointer face */
     void *stage = nullptr;
     size_t stage_sz = 0;
+    int slice_next = 0;   /* scaled contexts fed in slices: the next source line expected */
     std::mutex mu;
 };
 
@@ -703,9 +704,23 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
     std::lock_guard<std::mutex> lk(c->mu);
     const FFHipSwsTables &t = c->t;
     const bool unscaled = c->unscaled_yuv2rgb;
-    if (!unscaled && (srcSliceY != 0 || srcSliceH != t.srcH)) {
-        ffhip_set_error("ffhip_sws_scale: scaled contexts take whole frames");
-        return FFHIP_EINVAL;
+    /*
+     * Scaled contexts and source slices (sws_scale()'s legacy contract: slices arrive in order, libswscale/swscale.c:1085-1090):
+     * the result must not depend on the slicing (libswscale/tests, tools/scale_slice_test.c).  The fused kernels work on whole
+     * frames, so slices are collected in the context's device staging and the frame is produced when the last one arrives:
+     * the calls before that return 0 output lines, the last one dstH.  Top-to-bottom order only.
+     */
+    const bool sliced = !unscaled && (srcSliceY != 0 || srcSliceH != t.srcH);
+    if (sliced) {
+        if (srcSliceY < 0 || srcSliceY + srcSliceH > t.srcH || (srcSliceY != 0 && srcSliceY != c->slice_next)) {
+            ffhip_set_error("ffhip_sws_scale: slice [%d, +%d) is out of order (next expected line %d of %d)", srcSliceY, srcSliceH,
+                            srcSliceY ? c->slice_next : 0, t.srcH);
+            return FFHIP_EINVAL;
+        }
+        if (srcSliceY & 1) {
+            ffhip_set_error("ffhip_sws_scale: slices of a vertically subsampled source must start on an even line");
+            return FFHIP_EINVAL;
+        }
     }
     if (unscaled && ((srcSliceY | srcSliceH) & 1)) { /* dst_slice_align = 2, swscale_unscaled.c:2430 */
         ffhip_set_error("ffhip_sws_scale: slices of the unscaled yuv2rgb converter must be 2-line aligned");
@@ -743,8 +758,18 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
     void *ddst[4] = { 0, 0, 0, 0 };
     size_t fp[4] = { 0, 0, 0, 0 };
     for (int i = 0; i < ns; i++) {
-        HIP_TRY(copy2d(base + off_s[i], pitch_s[i], src[i], srcStride[i], sp[i].wbytes, sp[i].rows, hipMemcpyHostToDevice));
+        /* a slice brings luma rows [y, y + h) and chroma rows [y >> 1, (y + h + 1) >> 1) (swscale.c:280-283) */
+        const int row0 = !sliced ? 0 : i ? srcSliceY >> 1 : srcSliceY;
+        const int rows = !sliced ? sp[i].rows : i ? ((srcSliceY + srcSliceH + 1) >> 1) - (srcSliceY >> 1) : srcSliceH;
+        HIP_TRY(copy2d(base + off_s[i] + (size_t)row0 * pitch_s[i], pitch_s[i], src[i], srcStride[i], sp[i].wbytes, rows,
+                       hipMemcpyHostToDevice));
         dsrc[i] = base + off_s[i];
+    }
+    if (sliced) {
+        c->slice_next = srcSliceY + srcSliceH;
+        if (c->slice_next < t.srcH)
+            return 0; /* nothing can be written before the frame is complete */
+        c->slice_next = 0;
     }
     for (int i = 0; i < nd; i++)
         ddst[i] = base + off_d[i];

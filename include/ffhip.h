@@ -145,7 +145,10 @@ void ffhip_sws_tables_free(FFHipSwsHostTables *t);
  * (typedef at libswscale/swscale_internal.h:99-101; called at libswscale/swscale.c:1185).
  * Stages src -> device, runs the kernels, copies the written lines back; returns the number of
  * output lines written (srcSliceH for unscaled, dstH for a whole-frame scaled call) or <0.
- * Only whole frames (srcSliceY == 0, srcSliceH == srcH) are accepted for scaled contexts.
+ * Scaled contexts may be fed in source slices the way sws_scale() allows (in order, top to bottom, starting on even lines;
+ * src[] points at the slice's first rows): the slices are collected on the device, the calls before the last return 0 lines
+ * and the last one writes the whole picture and returns dstH — the pixels do not depend on the slicing
+ * (libswscale's tools/scale_slice_test.c property); a slice out of order is FFHIP_EINVAL.
  */
 int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], const int srcStride[],
                     int srcSliceY, int srcSliceH, uint8_t *const dst[], const int dstStride[]);

@@ -140,6 +140,20 @@ def test_scaled(case):
         assert ctx.scale(src, hd) == dh
         for a, b in zip(hd, want):
             assert np.array_equal(a, b)
+        # the result does not depend on how the source is sliced (tools/scale_slice_test.c): three in-order slices; output lines
+        # are reported once the frame is complete
+        if sh >= 12:
+            hd = [np.zeros_like(a) for a in want]
+            cuts = [0, 4, 4 + 2 * ((sh - 4) // 4), sh]
+            rets = []
+            for y0, y1 in zip(cuts[:-1], cuts[1:]):
+                sl = [src[0][y0:]] + [a[y0 // 2:] for a in src[1:]]
+                rets.append(ctx.scale(sl, hd, y0, y1 - y0))
+            assert rets == [0, 0, dh]
+            for a, b in zip(hd, want):
+                assert np.array_equal(a, b)
+            with pytest.raises(RuntimeError, match="out of order"):
+                ctx.scale([src[0][8:]] + [a[4:] for a in src[1:]], hd, 8, 2)
     ctx.close()
 
 
