@@ -550,6 +550,93 @@ __global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, in
 }
 
 /*
+ * k_rdft — AV_TX_FLOAT_RDFT, power-of-two (ff_tx_rdft_r2c / _c2r, libavutil/tx_template.c:1601-1716): len reals <-> len/2 + 1
+ * complex bins through the len/2-point complex FFT of k_fft_z plus the pass that separates / merges the even and odd halves.
+ * r2c: the reals are read as len/2 complex samples and scattered into the work array, transformed, and bins i and len/2 - i
+ * are produced together from the work array straight into global memory; c2r runs the same pass on the way in.  d.exp
+ * holds the reference's table as floats: fact[8], tcos[len/4], tsin[len/4].
+ */
+template <int INV>
+__global__ __launch_bounds__(1024) void k_rdft(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch, float *out,
+                                               size_t out_pitch, int nt, int waves_total)
+{
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
+        for (int i = threadIdx.x; i < blob_bytes / 16; i += blockDim.x)
+            l4[i] = s4[i];
+    }
+    __syncthreads();
+    const int *l_map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    const float *fact = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
+    const float *l_cos = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    const int len2 = d.n, len4 = len2 >> 1;
+    const float *tcos = fact + 8, *tsin = tcos + len4;
+    const float f0 = fact[0], f1 = fact[1], f2 = fact[2], f3 = fact[3], f4 = fact[4], f5 = fact[5], f6 = fact[6], f7 = fact[7];
+    float2 *z = reinterpret_cast<float2 *>(lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(len2));
+    /* bins i and len2 - i (0 < i < len4): the reference's loop body */
+    auto pair = [&](int i, float2 a, float2 b, float2 &oa, float2 &ob) {
+        const float t0r = f4 * (a.x + b.x), t0i = f5 * (a.y - b.y);
+        const float t1r = f6 * (a.y + b.y), t1i = f7 * (a.x - b.x);
+        const float c = tcos[i], sn = tsin[i];
+        const float t2r = t1r * c - t1i * sn, t2i = t1r * sn + t1i * c;
+        oa = make_float2(t0r + t2r, t2i - t0i);
+        ob = make_float2(t0r - t2r, t2i + t0i);
+    };
+    for (int t = blockIdx.x * (blockDim.x >> 6) + wave; t < nt; t += waves_total) {
+        const float2 *in2 = reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
+        float2 *out2 = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
+        if (!INV) {
+            for (int j = lane; j < len2; j += 64)
+                z[l_map[j]] = in2[j];
+        } else {
+            for (int i = lane; i <= len4; i += 64) {
+                if (i == 0) {
+                    const float re = in2[0].x, im = in2[len2].x; /* data[0].im = data[len2].re */
+                    z[l_map[0]] = make_float2(f0 * (re + im), f1 * (re - im));
+                } else if (i == len4) {
+                    const float2 v = in2[len4];
+                    z[l_map[len4]] = make_float2(f2 * v.x, f3 * v.y);
+                } else {
+                    float2 oa, ob;
+                    pair(i, in2[i], in2[len2 - i], oa, ob);
+                    z[l_map[i]] = oa;
+                    z[l_map[len2 - i]] = ob;
+                }
+            }
+        }
+        tx_wave_sync();
+        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
+        if (!INV) {
+            for (int i = lane; i <= len4; i += 64) {
+                if (i == 0) {
+                    const float2 v = z[TX_PAD(0)];
+                    out2[0] = make_float2(f0 * (v.x + v.y), 0.0f);
+                    out2[len2] = make_float2(f1 * (v.x - v.y), 0.0f); /* [0].im moves to the last bin, as convention requires */
+                } else if (i == len4) {
+                    const float2 v = z[TX_PAD(len4)];
+                    out2[len4] = make_float2(f2 * v.x, f3 * v.y);
+                } else {
+                    float2 oa, ob;
+                    pair(i, z[TX_PAD(i)], z[TX_PAD(len2 - i)], oa, ob);
+                    out2[i] = oa;
+                    out2[len2 - i] = ob;
+                }
+            }
+        } else {
+            for (int i = lane; i < len2; i += 64)
+                out2[i] = z[TX_PAD(i)];
+        }
+        tx_wave_sync();
+    }
+}
+
+/*
  * k_mdct_pfa — MDCT lengths 2 * 15 * 2^k (CELT 120..960, AAC-960 240 / 1920): ff_tx_mdct_pfa_15xM_fwd / _inv
  * (libavutil/tx_template.c:1425-1600), fft15 = 5 x fft3 + 3 x fft5 (:175-245,463-476), bit-identical floats.
  * A wave takes G transforms at once, G * m = 64: lane (g, i) runs sub-transform i of transform g —
@@ -888,12 +975,23 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     if (!scale)
         scale = &one; /* an FFT takes no scale (av_tx_init accepts NULL there) */
     *pctx = nullptr;
-    if (type != FFHIP_TX_FLOAT_MDCT && type != FFHIP_TX_FLOAT_FFT) {
-        ffhip_set_error("ffhip_tx_init: only AV_TX_FLOAT_MDCT and AV_TX_FLOAT_FFT are on the hip path");
+    if (type != FFHIP_TX_FLOAT_MDCT && type != FFHIP_TX_FLOAT_FFT && type != FFHIP_TX_FLOAT_RDFT) {
+        ffhip_set_error("ffhip_tx_init: only AV_TX_FLOAT_MDCT, AV_TX_FLOAT_FFT and AV_TX_FLOAT_RDFT are on the hip path");
         return FFHIP_ENOSYS;
     }
-    const bool fft = type == FFHIP_TX_FLOAT_FFT;
+    const bool rdft = type == FFHIP_TX_FLOAT_RDFT;
+    if (rdft && (flags & (FFHIP_TX_REAL_TO_REAL | FFHIP_TX_REAL_TO_IMAGINARY))) {
+        ffhip_set_error("ffhip_tx_init: the half-complex RDFT variants (AV_TX_REAL_TO_REAL / _IMAGINARY) are not on the hip path");
+        return FFHIP_ENOSYS;
+    }
+    if (rdft && (len < 8 || len > 4096 || (len & (len - 1)))) {
+        ffhip_set_error("ffhip_tx_init: RDFT len %d not a power of two in 8..4096", len);
+        return FFHIP_EINVAL;
+    }
+    const bool fft = type == FFHIP_TX_FLOAT_FFT || rdft; /* the RDFT runs a len/2-point FFT */
     /* 2 * 15 * 2^k, k = 2..6: the lengths av_tx serves with ff_tx_mdct_pfa_15xM (CELT 120..960, AAC-960 240 / 1920) */
+    if (rdft)
+        len >>= 1;
     const bool pfa = !fft && len % 30 == 0 && len / 30 >= 4 && len / 30 <= 64 && !((len / 30) & (len / 30 - 1));
     if (!pfa && (fft ? (len < 4 || len > 2048 || (len & (len - 1))) : (len < 16 || len > 4096 || (len & (len - 1))))) {
         ffhip_set_error("ffhip_tx_init: len %d is neither a power of two in %s nor 120 / 240 / 480 / 960 / 1920", len,
@@ -905,7 +1003,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     FFHipTXContext *c = new (std::nothrow) FFHipTXContext();
     if (!c)
         return FFHIP_ENOMEM;
-    c->type = type; c->inv = !!inv; c->len = len; c->scale = *scale;
+    c->type = type; c->inv = !!inv; c->len = rdft ? 2 * len : len; c->scale = *scale;
     if (pfa) {
         const int r = tx_init_pfa(c, *scale);
         if (r < 0) {
@@ -930,8 +1028,25 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         map[p] = i;
     }
     /* exp table (ff_tx_mdct_gen_exp) */
-    std::vector<float2> ex(fft ? 2 : n); /* an FFT has no twiddle table of its own: keep its LDS blob small */
-    if (!fft) {
+    std::vector<float2> ex(rdft ? 4 + n / 2 : fft ? 2 : n); /* an FFT has no twiddle table of its own: keep its LDS blob small */
+    if (rdft) {
+        /* ff_tx_rdft_init (tx_template.c:1601-1655): fact[8], tcos[len/4], tsin[len/4], doubles stored as floats */
+        const int rl = 2 * n, len4 = rl / 4;
+        const double f = 2 * M_PI / rl, m = c->inv ? 2 * (double)*scale : (double)*scale;
+        float *tab = reinterpret_cast<float *>(ex.data());
+        tab[0] = (float)((c->inv ? 0.5 : 1.0) * m);
+        tab[1] = (float)(c->inv ? 0.5 * m : 1.0 * m);
+        tab[2] = (float)m;
+        tab[3] = (float)-m;
+        tab[4] = (float)((0.5 - 0.0) * m);
+        tab[5] = (float)((0.0 - 0.5) * m);
+        tab[6] = (float)((0.5 - c->inv) * m);
+        tab[7] = (float)(-(0.5 - c->inv) * m);
+        for (int i = 0; i < len4; i++) {
+            tab[8 + i] = (float)cos(i * f);
+            tab[8 + len4 + i] = (float)(cos(((rl - i * 4) / 4.0) * f) * (c->inv ? 1 : -1));
+        }
+    } else if (!fft) {
         const double sc = *scale;
         const double theta = (sc < 0 ? n : 0) + 1.0 / 8.0, rt = sqrt(fabs(sc));
         float2 *e = ex.data();
@@ -1012,10 +1127,11 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     if (nt == 0)
         return 0;
     const int n = c->d.n;
-    if (c->type == FFHIP_TX_FLOAT_FFT) {
-        /* complex in, complex out, contiguous (av_tx's FFT ignores `stride`); 8-byte aligned rows */
+    if (c->type == FFHIP_TX_FLOAT_FFT || c->type == FFHIP_TX_FLOAT_RDFT) {
+        /* complex in, complex out, contiguous (av_tx's FFT ignores `stride`); 8-byte aligned rows.  RDFT: len reals on one
+         * side, len/2 + 1 complex bins on the other */
         if (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7) {
-            ffhip_set_error("ffhip_tx: FFT batches need 8-byte aligned complex rows");
+            ffhip_set_error("ffhip_tx: FFT / RDFT batches need 8-byte aligned rows");
             return FFHIP_EINVAL;
         }
         int wpb = 16;
@@ -1037,7 +1153,19 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
         static bool fft_attr = false;
         if (!fft_attr) {
             (void)hipFuncSetAttribute((const void *)k_fft_z, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             fft_attr = true;
+        }
+        if (c->type == FFHIP_TX_FLOAT_RDFT) {
+            if (c->inv)
+                hipLaunchKernelGGL((k_rdft<1>), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
+                                   (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+            else
+                hipLaunchKernelGGL((k_rdft<0>), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
+                                   (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+            LAUNCH_CHECK();
+            return 0;
         }
         hipLaunchKernelGGL(k_fft_z, dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
                            (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
@@ -1190,8 +1318,11 @@ static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
 {
     std::lock_guard<std::mutex> lk(s->mu);
     const int len = s->len;
-    const bool fft = s->type == FFHIP_TX_FLOAT_FFT;
-    const size_t in_elems = fft ? (size_t)2 * len : s->inv ? (size_t)len : (size_t)2 * len, out_elems = fft ? (size_t)2 * len : (size_t)len;
+    const bool rdft = s->type == FFHIP_TX_FLOAT_RDFT;
+    const bool fft = s->type == FFHIP_TX_FLOAT_FFT || rdft;
+    /* RDFT: len reals <-> len/2 + 1 complex bins */
+    const size_t in_elems = rdft ? (size_t)(s->inv ? len + 2 : len) : fft ? (size_t)2 * len : s->inv ? (size_t)len : (size_t)2 * len;
+    const size_t out_elems = rdft ? (size_t)(s->inv ? len : len + 2) : fft ? (size_t)2 * len : (size_t)len;
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     /* the strided side is packed on the host so that the device sees contiguous data */
     std::vector<float> hin(in_elems), hout(out_elems);

@@ -551,13 +551,18 @@ int ffhip_me_esa_batch_dev(const uint8_t *cur, const uint8_t *ref, int width, in
 typedef struct FFHipTXContext FFHipTXContext;
 #define FFHIP_TX_FLOAT_FFT  0   /* == AV_TX_FLOAT_FFT  (libavutil/tx.h:47-132) */
 #define FFHIP_TX_FLOAT_MDCT 1   /* == AV_TX_FLOAT_MDCT                          */
+#define FFHIP_TX_FLOAT_RDFT 6   /* == AV_TX_FLOAT_RDFT (r2c forward, c2r inverse; libavutil/tx.h:70-90) */
+#define FFHIP_TX_REAL_TO_REAL      (1ULL << 3)   /* == AV_TX_REAL_TO_REAL: not on the hip path (ENOSYS)      */
+#define FFHIP_TX_REAL_TO_IMAGINARY (1ULL << 4)   /* == AV_TX_REAL_TO_IMAGINARY: not on the hip path (ENOSYS) */
 /** av_tx_fn (libavutil/tx.h:151) with an opaque context of ours in place of AVTXContext. */
 typedef void (*ffhip_tx_fn)(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
 /**
  * Same argument meaning as av_tx_init() (libavutil/tx.h:169-172, libavutil/tx.c:903): type, inv,
  * len (MDCT: number of output coefficients of the forward transform, power of two 16..4096 or one of the 15xM prime-factor
  * lengths 120 / 240 / 480 / 960 / 1920 (ff_tx_mdct_pfa_15xM, libavutil/tx_template.c:1425-1600: CELT, AAC-960; their batches
- * must be contiguous 8-byte aligned rows); FFT: number of complex samples, power of two 4..2048), *scale (FFT: ignored, may be NULL).  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
+ * must be contiguous 8-byte aligned rows); FFT: number of complex samples, power of two 4..2048; RDFT: number of real samples,
+ * power of two 8..4096 — forward (r2c) reads len floats and writes len/2 + 1 complex bins, inverse (c2r) the other way round,
+ * ff_tx_rdft_r2c / _c2r, libavutil/tx_template.c:1601-1716), *scale (FFT: ignored, may be NULL).  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
  * (libavutil/tx_priv.h:199-237).  *fn receives the single-transform host-pointer shim.
  */
 int  ffhip_tx_init(FFHipTXContext **ctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,

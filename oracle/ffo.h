@@ -124,6 +124,8 @@ void   ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t strid
 void   ffo_mdct_free(FfoTx *s);
 /* AV_TX_FLOAT_FFT, power-of-two len: complex (re, im) floats in and out */
 void   ffo_fft_run(int inv, int len, float *out, const float *in);
+/* AV_TX_FLOAT_RDFT, power-of-two: inv == 0: in = len reals, out = len/2 + 1 complex; inv == 1: the other way round */
+void   ffo_rdft_run(int inv, int len, float scale, float *out, const float *in);
 /* double-precision cosine-sum definition (ff_tx_mdct_naive_fwd/_inv, tx_template.c:1144-1193) */
 void   ffo_mdct_naive_fwd(int len, double scale, double *out, const float *in);
 void   ffo_mdct_naive_inv(int len, double scale, double *out, const float *in);

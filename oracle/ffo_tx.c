@@ -464,6 +464,67 @@ void ffo_fft_run(int inv, int len, float *out, const float *in)
         free(s.cos_tab[l]);
 }
 
+/*
+ * AV_TX_FLOAT_RDFT, power-of-two: ff_tx_rdft_r2c / _c2r (libavutil/tx_template.c:1601-1716).  len real samples <-> len/2 + 1
+ * complex bins through a len/2-point complex FFT (the out-of-place AV_TX_FLOAT_FFT above) and one pass that separates /
+ * merges the even and odd halves.  fact[] and the twiddles are computed in double and stored as float (ff_tx_rdft_init,
+ * :1601-1655).  The reference's c2r works inside its input buffer; this restatement copies it.
+ */
+void ffo_rdft_run(int inv, int len, float scale, float *out, const float *in)
+{
+    const int len2 = len >> 1, len4 = len >> 2;
+    const double f = 2 * M_PI / len, m = inv ? 2 * (double)scale : (double)scale;
+    float fact[8];
+    float *tcos = malloc(sizeof(float) * 2 * len4), *tsin = tcos + len4;
+    cpx *data = malloc(sizeof(cpx) * (len2 + 1)), t[3];
+    fact[0] = (float)((inv ? 0.5 : 1.0) * m);
+    fact[1] = (float)(inv ? 0.5 * m : 1.0 * m);
+    fact[2] = (float)m;
+    fact[3] = (float)-m;
+    fact[4] = (float)((0.5 - 0.0) * m);
+    fact[5] = (float)((0.0 - 0.5) * m);
+    fact[6] = (float)((0.5 - inv) * m);
+    fact[7] = (float)(-(0.5 - inv) * m);
+    for (int i = 0; i < len4; i++) {
+        tcos[i] = (float)cos(i * f);
+        tsin[i] = (float)(cos(((len - i * 4) / 4.0) * f) * (inv ? 1 : -1));
+    }
+    if (!inv) {
+        ffo_fft_run(0, len2, (float *)data, in);
+    } else {
+        memcpy(data, in, sizeof(cpx) * (len2 + 1));
+        data[0].im = data[len2].re;
+    }
+    t[0].re = data[0].re;
+    data[0].re = t[0].re + data[0].im;
+    data[0].im = t[0].re - data[0].im;
+    data[0].re = fact[0] * data[0].re;
+    data[0].im = fact[1] * data[0].im;
+    data[len4].re = fact[2] * data[len4].re;
+    data[len4].im = fact[3] * data[len4].im;
+    for (int i = 1; i < len4; i++) {
+        t[0].re = fact[4] * (data[i].re + data[len2 - i].re);
+        t[0].im = fact[5] * (data[i].im - data[len2 - i].im);
+        t[1].re = fact[6] * (data[i].im + data[len2 - i].im);
+        t[1].im = fact[7] * (data[i].re - data[len2 - i].re);
+        t[2].re = t[1].re * tcos[i] - t[1].im * tsin[i];
+        t[2].im = t[1].re * tsin[i] + t[1].im * tcos[i];
+        data[i].re = t[0].re + t[2].re;
+        data[i].im = t[2].im - t[0].im;
+        data[len2 - i].re = t[0].re - t[2].re;
+        data[len2 - i].im = t[2].im + t[0].im;
+    }
+    if (inv) {
+        ffo_fft_run(1, len2, out, (const float *)data);
+    } else {
+        data[len2].re = data[0].im;
+        data[0].im = data[len2].im = 0;
+        memcpy(out, data, sizeof(cpx) * (len2 + 1));
+    }
+    free(data);
+    free(tcos);
+}
+
 /* ff_tx_mdct_naive_fwd: tx_template.c:1144-1163 — in 2*len, out len (double results) */
 void ffo_mdct_naive_fwd(int len, double scale, double *out, const float *in)
 {

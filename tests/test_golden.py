@@ -218,3 +218,10 @@ def test_fft_golden():
                 out = np.zeros(2 * len_, np.float32)
                 O.ffo_fft_run(inv, len_, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p))
                 assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), (len_, inv)
+    for len_ in (16, 1024):
+        for inv in (0, 1):
+            x, want = d["rdft%d_%d_in" % (len_, inv)], d["rdft%d_%d_out" % (len_, inv)]
+            for t in range(x.shape[0]):
+                out = np.zeros(want.shape[1], np.float32)
+                O.ffo_rdft_run(inv, len_, 1.0, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p))
+                assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), ("rdft", len_, inv)

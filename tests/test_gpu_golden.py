@@ -287,3 +287,17 @@ def test_fft_golden_gpu():
             ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
             assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (len_, inv)
             ctx.close()
+
+
+def test_rdft_golden_gpu():
+    from ffmpeg_amd import tx
+    torch = _torch()
+    d = G.load("fft")
+    for len_ in (16, 1024):
+        for inv in (0, 1):
+            x, want = d["rdft%d_%d_in" % (len_, inv)], d["rdft%d_%d_out" % (len_, inv)]
+            ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, 1.0)
+            out = torch.zeros(want.shape, dtype=torch.float32, device="cuda:0")
+            ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (len_, inv)
+            ctx.close()

@@ -215,3 +215,34 @@ def test_mdct_pfa15_rejects_strided_rows():
     with pytest.raises(RuntimeError, match="15xM"):
         ctx.batch(d_out, d_in, stride=8)
     ctx.close()
+
+
+@pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("len_,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
+def test_rdft_batch(len_, inv, scale):
+    """AV_TX_FLOAT_RDFT, power-of-two: r2c forward (len reals -> len/2 + 1 bins), c2r inverse; bit-identical, host face too"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    rng = np.random.default_rng(len_ * 2 + inv)
+    nt = 3000 if len_ == 1024 else 41
+    n_in, n_out = (len_ + 2, len_) if inv else (len_, len_ + 2)
+    x = (rng.standard_normal((nt, n_in)) * 10.0 ** rng.integers(-3, 4, (nt, 1))).astype(np.float32)
+    if inv:
+        x[:, 1] = x[:, -1] = 0
+    x[1] = 0
+    want = np.zeros((nt, n_out), np.float32)
+    O = ffi.oracle()
+    for t in range(nt):
+        O.ffo_rdft_run(inv, len_, scale, ptr(want[t], f32p), ptr(x[t], f32p))
+    ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, scale)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((nt, n_out + 2), dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out[:, :n_out], d_in)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(np.ascontiguousarray(got[:, :n_out]).view(np.uint32), want.view(np.uint32)), "max |diff| %g" % np.abs(got[:, :n_out] - want).max()
+    assert not got[:, n_out:].any()
+    one = np.zeros(n_out, np.float32)
+    ctx.fn(one, x[3].copy(), 4)
+    assert np.array_equal(one.view(np.uint32), want[3].view(np.uint32))
+    ctx.close()

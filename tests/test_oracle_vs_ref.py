@@ -551,6 +551,26 @@ def test_fft_float(len_, inv):
 
 
 @pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("len_", [8, 16, 64, 512, 1024, 4096])
+def test_rdft_float(len_, inv):
+    """AV_TX_FLOAT_RDFT (r2c / c2r), power-of-two: bit-identical, with and without a scale"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(3 * len_ + inv)
+    for scale in (1.0, 1.0 / len_, -0.37):
+        rc = R.ffref_tx_create(6, inv, len_, scale, 0)      # AV_TX_FLOAT_RDFT = 6 (libavutil/tx.h:90)
+        assert rc
+        for rep in range(3):
+            x = (rng.standard_normal(len_ + 2 if inv else len_) * 10.0 ** float(rng.integers(-3, 4))).astype(np.float32)
+            if inv:
+                x[1] = x[-1] = 0                              # the imaginary parts of the DC and Nyquist bins
+            a, b = np.zeros(len_ if inv else len_ + 2, np.float32), np.zeros(len_ if inv else len_ + 2, np.float32)
+            R.ffref_tx_run(rc, ptr(a, f32p), ptr(x.copy(), f32p), 4)
+            O.ffo_rdft_run(inv, len_, scale, ptr(b, f32p), ptr(x, f32p))
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (scale, rep)
+        R.ffref_tx_free(rc)
+
+
+@pytest.mark.parametrize("inv", [0, 1])
 def test_mdct_vs_naive(inv):
     """the float transform stays within 2^-18 * max|ref| of the double-precision cosine sum"""
     O = ffi.oracle()

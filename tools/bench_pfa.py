@@ -28,3 +28,23 @@ for ln in (120, 240, 480, 960, 1920):
         print(json.dumps({"len": ln, "inv": inv, "ms": round(ms, 4), "Mtx/s": round(nt / ms / 1e3, 1), "GB/s": round(byt / ms / 1e6, 1),
                           "hbm_frac": round(byt / ms / 1e6 / 8000, 4)}), flush=True)
         ctx.close()
+# AV_TX_FLOAT_RDFT: r2c / c2r, 65,536 transforms
+for ln in (1024, 4096):
+    for inv in (0, 1):
+        n_in, n_out = (ln + 2, ln) if inv else (ln, ln + 2)
+        tin = torch.rand((nt, n_in), dtype=torch.float32, device="cuda:0")
+        tout = torch.empty((nt, n_out), dtype=torch.float32, device="cuda:0")
+        ctx = tx.TxContext(tx.FLOAT_RDFT, inv, ln, 1.0)
+        for _ in range(2):
+            ctx.batch(tout, tin)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ctx.batch(tout, tin)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        byt = nt * (n_in + n_out) * 4
+        print(json.dumps({"rdft": ln, "inv": inv, "ms": round(ms, 4), "Mtx/s": round(nt / ms / 1e3, 1), "GB/s": round(byt / ms / 1e6, 1),
+                          "hbm_frac": round(byt / ms / 1e6 / 8000, 4)}), flush=True)
+        ctx.close()

@@ -187,6 +187,19 @@ def fft():
                 R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 8)
             R.ffref_tx_free(rc)
             d["fft%d_%d_in" % (len_, inv)], d["fft%d_%d_out" % (len_, inv)] = x, out
+    # AV_TX_FLOAT_RDFT (type 6): r2c takes len reals -> len/2 + 1 complex, c2r the other way round
+    rng = np.random.default_rng(1007)
+    for len_ in (16, 1024):
+        for inv in (0, 1):
+            x = rng.uniform(-1, 1, (3, len_ + 2 if inv else len_)).astype(np.float32)
+            if inv:
+                x[:, 1] = x[:, -1] = 0
+            rc = R.ffref_tx_create(6, inv, len_, 1.0, 0)
+            out = np.zeros((3, len_ if inv else len_ + 2), np.float32)
+            for t in range(3):
+                R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 4)
+            R.ffref_tx_free(rc)
+            d["rdft%d_%d_in" % (len_, inv)], d["rdft%d_%d_out" % (len_, inv)] = x, out
     np.savez_compressed(os.path.join(OUT, "fft.npz"), **d)
 
 
