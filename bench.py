@@ -319,6 +319,49 @@ def extras(torch, dev):
     out["h264_deblock_frame_4k"] = {"Mpixels/s": round(w * h / (per[32] * 1e-3) / 1e6, 1), "ms_per_frame_one_stream": round(ms, 4),
                                     "ms_per_frame_batch_of_8": round(per[8], 4), "ms_per_frame_batch_of_32": round(per[32], 4),
                                     "note": "decoder order (2-D wavefront inside a frame); a batch runs its frames side by side"}
+    del planes, ded
+    # 15xM prime-factor MDCT, the CELT / AAC-960 frame size: inverse, len 960 (7,680 B moved per transform)
+    nt, ln = 65536, 960
+    f = tx.TxContext(tx.FLOAT_MDCT, 1, ln, 1.0 / ln)
+    tin = torch.rand((nt, ln), dtype=torch.float32, device=dev)
+    tout = torch.empty((nt, ln), dtype=torch.float32, device=dev)
+    f.batch(tout, tin)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(10):
+        f.batch(tout, tin)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    gbs = nt * ln * 8 / (ms * 1e-3) / 1e9
+    out["imdct960_pfa15"] = {"Mtransforms/s": round(nt / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1),
+                             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "transforms": nt, "ms": round(ms, 4)}
+    f.close()
+    del tin, tout
+    # HEVC put_hevc_qpel_uni: every 16x16 block of 8 4K planes, mixed quarter-sample positions: 2 B / sample
+    from ffmpeg_amd import hevc
+    P = 16
+    refp = torch.randint(0, 256, (nf * h + 2 * P, w + 2 * P), dtype=torch.uint8, device=dev)
+    pic = torch.zeros((nf * h, w), dtype=torch.uint8, device=dev)
+    by, bx = np.meshgrid(np.arange(0, nf * h, 16), np.arange(0, w, 16), indexing="ij")
+    mc = np.zeros(by.size, hevc.MC_DTYPE)
+    mc["dst_offset"] = (by * w + bx).reshape(-1)
+    mc["src_offset"] = ((by + P + rng.integers(-8, 9, by.shape)) * (w + 2 * P) + bx + P + rng.integers(-8, 9, by.shape)).reshape(-1)
+    mc["width"] = mc["height"] = 16
+    mc["mx"], mc["my"] = rng.integers(0, 4, by.size), rng.integers(0, 4, by.size)
+    dmc = torch.from_numpy(mc.view(np.uint8).reshape(-1, 12)).to(dev)
+    hevc.mc_batch(0, 1, pic, w, refp, w + 2 * P, dmc, by.size)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        hevc.mc_batch(0, 1, pic, w, refp, w + 2 * P, dmc, by.size)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    px = by.size * 256
+    out["hevc_qpel_uni16_mixed"] = {"Mpixels/s": round(px / (ms * 1e-3) / 1e6, 1), "GB/s": round(2 * px / (ms * 1e-3) / 1e9, 1),
+                                    "hbm_frac": round(2 * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "blocks": int(by.size),
+                                    "ms": round(ms, 4)}
     return out
 
 

@@ -54,6 +54,7 @@ struct TxPfa {
 
 struct FFHipTXContext {
     int type, inv, len;
+    int full = 0;            /* AV_TX_FULL_IMDCT: the inverse writes 2 * len outputs (half transform in the middle, mirrored) */
     float scale;
     TxDev d;
     TxPfa pfa = {};
@@ -812,6 +813,24 @@ __global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, 
 #undef TXCMUL
 #undef TXSMUL
 
+/*
+ * AV_TX_FULL_IMDCT (ff_tx_mdct_inv_full, libavutil/tx_template.c:1391-1408): the half inverse was written to the middle half of
+ * each 2 * len row; the outer quarters are its mirror images, the first one negated.  One thread per float2 of a quarter.
+ */
+__global__ __launch_bounds__(256) void k_imdct_mirror(float *out, size_t out_pitch, int len, int nt)
+{
+    const int q2 = len >> 2; /* float2 per quarter (a quarter = len / 2 floats) */
+    const int i = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+    if (i >= q2 || t >= nt)
+        return;
+    float2 *row = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
+    const int h2 = len >> 1;                       /* float2 per half */
+    const float2 a = row[h2 - 1 - i];              /* dst[len - 2 - 2i], dst[len - 1 - 2i] */
+    const float2 b = row[h2 + i];                  /* dst[len + 2i], dst[len + 2i + 1]     */
+    row[i] = make_float2(-a.y, -a.x);              /* dst[2i] = -dst[len - 1 - 2i], dst[2i + 1] = -dst[len - 2 - 2i] */
+    row[2 * h2 - 1 - i] = make_float2(b.y, b.x);   /* dst[2 len - 2 - 2i] = dst[len + 2i + 1], dst[2 len - 1 - 2i] = dst[len + 2i] */
+}
+
 /* ---- host: tables ------------------------------------------------------------------------------- */
 static int sr_perm(int i, int len, int inv)
 {
@@ -968,7 +987,6 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f)
 extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,
                              uint64_t flags)
 {
-    (void)flags;
     static const float one = 1.0f;
     if (!pctx || (!scale && type != FFHIP_TX_FLOAT_FFT))
         return FFHIP_EINVAL;
@@ -1004,6 +1022,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     if (!c)
         return FFHIP_ENOMEM;
     c->type = type; c->inv = !!inv; c->len = rdft ? 2 * len : len; c->scale = *scale;
+    c->full = type == FFHIP_TX_FLOAT_MDCT && inv && (flags & FFHIP_TX_FULL_IMDCT);
     if (pfa) {
         const int r = tx_init_pfa(c, *scale);
         if (r < 0) {
@@ -1119,6 +1138,9 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     return 0;
 }
 
+static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const void *in, size_t in_pitch, ptrdiff_t stride, int nt,
+                         void *stream);
+
 extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch, const void *in, size_t in_pitch,
                                   ptrdiff_t stride, int nt, void *stream)
 {
@@ -1126,6 +1148,28 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
         return FFHIP_EINVAL;
     if (nt == 0)
         return 0;
+    if (!c->full)
+        return tx_batch_half(c, out, out_pitch, in, in_pitch, stride, nt, stream);
+    /* full inverse: rows of 2 * len floats; the half transform goes to the middle, then the mirror pass */
+    if (((uintptr_t)out | out_pitch) & 7) {
+        ffhip_set_error("ffhip_tx: AV_TX_FULL_IMDCT batches need 8-byte aligned output rows");
+        return FFHIP_EINVAL;
+    }
+    const int r = tx_batch_half(c, (float *)out + c->len / 2, out_pitch, in, in_pitch, stride, nt, stream);
+    if (r < 0)
+        return r;
+    for (int t0 = 0; t0 < nt; t0 += 65535) {
+        const int cnt = nt - t0 < 65535 ? nt - t0 : 65535;
+        hipLaunchKernelGGL(k_imdct_mirror, dim3(cdiv(c->len / 4, 256), cnt), dim3(256), 0, (hipStream_t)stream,
+                           (float *)((uint8_t *)out + (size_t)t0 * out_pitch), out_pitch, c->len, cnt);
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const void *in, size_t in_pitch, ptrdiff_t stride, int nt,
+                         void *stream)
+{
     const int n = c->d.n;
     if (c->type == FFHIP_TX_FLOAT_FFT || c->type == FFHIP_TX_FLOAT_RDFT) {
         /* complex in, complex out, contiguous (av_tx's FFT ignores `stride`); 8-byte aligned rows.  RDFT: len reals on one
@@ -1322,7 +1366,7 @@ static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
     const bool fft = s->type == FFHIP_TX_FLOAT_FFT || rdft;
     /* RDFT: len reals <-> len/2 + 1 complex bins */
     const size_t in_elems = rdft ? (size_t)(s->inv ? len + 2 : len) : fft ? (size_t)2 * len : s->inv ? (size_t)len : (size_t)2 * len;
-    const size_t out_elems = rdft ? (size_t)(s->inv ? len : len + 2) : fft ? (size_t)2 * len : (size_t)len;
+    const size_t out_elems = rdft ? (size_t)(s->inv ? len : len + 2) : fft || s->full ? (size_t)2 * len : (size_t)len;
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     /* the strided side is packed on the host so that the device sees contiguous data */
     std::vector<float> hin(in_elems), hout(out_elems);

@@ -123,6 +123,7 @@ FfoTx *ffo_mdct_create(int inv, int len, float scale);
 void   ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride);
 void   ffo_mdct_free(FfoTx *s);
 /* AV_TX_FLOAT_FFT, power-of-two len: complex (re, im) floats in and out */
+void   ffo_imdct_full_run(const FfoTx *s, float *out, const float *in); /* AV_TX_FULL_IMDCT: 2 * len outputs */
 void   ffo_fft_run(int inv, int len, float *out, const float *in);
 /* AV_TX_FLOAT_RDFT, power-of-two: inv == 0: in = len reals, out = len/2 + 1 complex; inv == 1: the other way round */
 void   ffo_rdft_run(int inv, int len, float scale, float *out, const float *in);

@@ -148,6 +148,18 @@ void ffo_mdct_free(FfoTx *s)
 
 static void pfa15_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride);
 
+/* AV_TX_FULL_IMDCT: ff_tx_mdct_inv_full (libavutil/tx_template.c:1391-1408): the half inverse lands in the middle of the
+ * 2 * len outputs and is mirrored outwards (first quarter negated).  s must be an inverse context; contiguous data. */
+void ffo_imdct_full_run(const FfoTx *s, float *out, const float *in)
+{
+    const int len = s->len << 1, len2 = len >> 1, len4 = len >> 2;
+    ffo_mdct_run(s, out + len4, in, sizeof(float));
+    for (int i = 0; i < len4; i++) {
+        out[i] = -out[len2 - i - 1];
+        out[len - i - 1] = out[len2 + i];
+    }
+}
+
 /* stride in bytes, as av_tx_fn; forward: output stride, inverse: input stride */
 void ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride)
 {

@@ -131,6 +131,8 @@ def oracle():
         L.ffo_mdct_create.restype = C.c_void_p
         L.ffo_mdct_run.argtypes = [C.c_void_p, f32p, f32p, C.c_ssize_t]
         L.ffo_mdct_run.restype = None
+        L.ffo_imdct_full_run.argtypes = [C.c_void_p, f32p, f32p]
+        L.ffo_imdct_full_run.restype = None
         L.ffo_mdct_free.argtypes = [C.c_void_p]
         L.ffo_mdct_free.restype = None
         L.ffo_mdct_naive_fwd.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_double), f32p]

@@ -246,3 +246,34 @@ def test_rdft_batch(len_, inv, scale):
     ctx.fn(one, x[3].copy(), 4)
     assert np.array_equal(one.view(np.uint32), want[3].view(np.uint32))
     ctx.close()
+
+
+@pytest.mark.parametrize("len_,nt", [(16, 9), (256, 70000), (1024, 3000), (120, 200), (960, 1001)])
+def test_imdct_full_batch(len_, nt):
+    """AV_TX_FULL_IMDCT: 2 * len outputs per inverse transform (ff_tx_mdct_inv_full), power-of-two and 15xM lengths; more rows than
+    one mirror launch takes (grid.y)"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    rng = np.random.default_rng(len_)
+    scale = 1.0 / len_
+    x = (rng.random((nt, len_), dtype=np.float32) * 2 - 1).astype(np.float32)
+    O = ffi.oracle()
+    oc = O.ffo_mdct_create(1, len_, scale)
+    chk = sorted(set([0, 1, nt // 2, nt - 1] + list(rng.integers(0, nt, 40))))
+    ctx = tx.TxContext(tx.FLOAT_MDCT, 1, len_, scale, flags=4)
+    d_out = torch.zeros((nt, 2 * len_), dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out, torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for t in chk:
+        want = np.zeros(2 * len_, np.float32)
+        O.ffo_imdct_full_run(oc, ptr(want, f32p), ptr(x[t], f32p))
+        assert np.array_equal(got[t].view(np.uint32), want.view(np.uint32)), t
+    # the mirror property on every row (size-independent): first quarter = -reversed second, last = reversed third
+    h = len_ // 2
+    assert np.array_equal(got[:, :h], -got[:, 2 * h - 1:h - 1:-1]) and np.array_equal(got[:, 3 * h:], got[:, 3 * h - 1:2 * h - 1:-1])
+    one = np.zeros(2 * len_, np.float32)
+    ctx.fn(one, x[1].copy(), 4)
+    assert np.array_equal(one.view(np.uint32), got[1].view(np.uint32))
+    O.ffo_mdct_free(oc)
+    ctx.close()

@@ -550,6 +550,24 @@ def test_fft_float(len_, inv):
     R.ffref_tx_free(rc)
 
 
+@pytest.mark.parametrize("len_", [16, 256, 1024, 120, 960])
+def test_imdct_full(len_):
+    """AV_TX_FULL_IMDCT (flag 1 << 2): the half inverse mirrored to 2 * len outputs"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(len_)
+    scale = 1.0 / len_
+    rc = R.ffref_tx_create(1, 1, len_, scale, 4)
+    oc = O.ffo_mdct_create(1, len_, scale)
+    assert rc and oc
+    for _ in range(3):
+        x = rng.uniform(-1, 1, len_).astype(np.float32)
+        a, b = np.zeros(2 * len_, np.float32), np.zeros(2 * len_, np.float32)
+        R.ffref_tx_run(rc, ptr(a, f32p), ptr(x.copy(), f32p), 4)
+        O.ffo_imdct_full_run(oc, ptr(b, f32p), ptr(x, f32p))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    R.ffref_tx_free(rc); O.ffo_mdct_free(oc)
+
+
 @pytest.mark.parametrize("inv", [0, 1])
 @pytest.mark.parametrize("len_", [8, 16, 64, 512, 1024, 4096])
 def test_rdft_float(len_, inv):
