@@ -95,7 +95,7 @@ extern "C" int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptr
 extern "C" int ffhip_hevc_idct_batch_dev(int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride,
                                          const FFHipHevcTU *tus, int n, void *stream)
 {
-    if (!coeffs || !tus || n < 0 || kind < FFHIP_HEVC_IDCT || kind > FFHIP_HEVC_ADD_ONLY || log2_size < 2 || log2_size > 5 ||
+    if (!coeffs || !tus || n < 0 || kind < FFHIP_HEVC_IDCT || kind > FFHIP_HEVC_RDPCM_V || log2_size < 2 || log2_size > 5 ||
         (kind == FFHIP_HEVC_DST_4X4 && log2_size != 2) || (kind == FFHIP_HEVC_ADD_ONLY && !dst))
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
@@ -120,6 +120,16 @@ extern "C" int ffhip_hevc_sao_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, cons
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     return ffhip_launch_hevc_sao(dst, stride_dst, src, stride_src, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_hevc_sao_restore_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src,
+                                                const FFHipHevcSaoRestore *blocks, int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_sao_restore(dst, stride_dst, src, stride_src, blocks, n, (hipStream_t)stream);
 }
 
 extern "C" int ffhip_hevc_mc_batch_dev(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,

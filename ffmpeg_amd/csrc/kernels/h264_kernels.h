@@ -27,6 +27,8 @@ int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *ds
                            hipStream_t stream);
 int ffhip_launch_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, hipStream_t stream);
 int ffhip_launch_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n, hipStream_t stream);
+int ffhip_launch_hevc_sao_restore(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSaoRestore *blocks, int n,
+                                  hipStream_t stream);
 int ffhip_launch_hevc_mc(int chroma, int mode, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
                          const void *blocks, int n, hipStream_t stream);
 int ffhip_launch_fdsp(int op, float *dst, size_t pd, const float *s0, size_t p0, const float *s1, size_t p1, const float *s2, size_t p2,

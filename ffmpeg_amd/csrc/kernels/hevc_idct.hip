@@ -167,6 +167,23 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
             hevc_wave_sync();
             hevc_dst4(mine + 4 * i, mine + 4 * i, 1, 12);
         }
+    } else if (kind == FFHIP_HEVC_DEQUANT) {
+        /* dequant (hevc/dsp_template.c:127-143), 8 bits: (c + 2^(shift-1)) >> shift, shift = 15 - 8 - log2; lane i = row i */
+        constexpr int shift = 7 - LOG2;
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            mine[i * N + k] = (int16_t)((mine[i * N + k] + (1 << (shift - 1))) >> shift);
+    } else if (kind == FFHIP_HEVC_RDPCM_H || kind == FFHIP_HEVC_RDPCM_V) {
+        /* transform_rdpcm (hevc/dsp_template.c:85-105): running sums in int16 arithmetic along a row (mode 0: lane i = row i)
+         * or down a column (mode 1: lane i = column i) */
+        const int step = kind == FFHIP_HEVC_RDPCM_H ? 1 : N;
+        int16_t *v = mine + (kind == FFHIP_HEVC_RDPCM_H ? i * N : i);
+        int acc = v[0];
+#pragma unroll
+        for (int k = 1; k < N; k++) {
+            acc = (int16_t)(acc + v[k * step]);
+            v[k * step] = (int16_t)acc;
+        }
     }
     hevc_wave_sync();
     /* ---- residual back in place; picture += residual (row i of my unit) ---- */
@@ -428,3 +445,78 @@ int ffhip_launch_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdif
     return 0;
 }
 
+/*
+ * sao_edge_restore[0] / [1] (libavcodec/h26x/h2656_sao_template.c:81-214): after the edge filter, samples on a picture border get
+ * the plain offset sao_offset_val[0] and (variant 1) samples next to slices / tiles that must not be filtered across are put
+ * back.  The reference is a sequence of short loops whose later writes win; here every candidate sample — the columns 0, w-2,
+ * w-1 and the rows 0, h-2, h-1 of the block — evaluates that sequence for itself and keeps the last writer, so the launch has
+ * no ordering inside.  One wave per block.
+ */
+static_assert(sizeof(FFHipHevcSaoRestore) == 20, "FFHipHevcSaoRestore is a 20-byte record");
+__global__ __launch_bounds__(256) void k_hevc_sao_restore(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss,
+                                                          const FFHipHevcSaoRestore *blocks, int n)
+{
+    const int b = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (b >= n)
+        return;
+    const FFHipHevcSaoRestore k = blocks[b];
+    const int W = k.width, H = k.height, eo = k.eo & 3, off = k.offset0;
+    const bool b0 = k.borders & 1, b1 = k.borders & 2, b2 = k.borders & 4, b3 = k.borders & 8;
+    const bool ve0 = k.vert_edge & 1, ve1 = k.vert_edge & 2, he0 = k.horiz_edge & 1, he1 = k.horiz_edge & 2;
+    const bool de0 = k.diag_edge & 1, de1 = k.diag_edge & 2, de2 = k.diag_edge & 4, de3 = k.diag_edge & 8;
+    enum { HORIZ = 0, VERT = 1, D135 = 2, D45 = 3 };
+    /* the running state of the reference after its border loops */
+    const int init_x = (eo != VERT && b0) ? 1 : 0, w = W - ((eo != VERT && b2) ? 1 : 0);
+    const int init_y = (eo != HORIZ && b1) ? 1 : 0, h = H - ((eo != HORIZ && b3) ? 1 : 0);
+    const int s_ul = !de0 && eo == D135 && !b0 && !b1, s_ur = !de1 && eo == D45 && !b1 && !b2;
+    const int s_lr = !de2 && eo == D135 && !b2 && !b3, s_ll = !de3 && eo == D45 && !b0 && !b3;
+    const uint8_t *s0 = src + k.src_offset;
+    uint8_t *d0 = dst + k.dst_offset;
+    for (int t = lane; t < 3 * H + 3 * W; t += 64) {
+        int x, y;
+        if (t < 3 * H) {
+            const int c = t / H;
+            y = t - c * H;
+            x = c == 0 ? 0 : c == 1 ? W - 1 : W - 2;
+        } else {
+            const int r = (t - 3 * H) / W;
+            x = t - 3 * H - r * W;
+            y = r == 0 ? 0 : r == 1 ? H - 1 : H - 2;
+        }
+        if (x < 0 || y < 0)
+            continue;
+        int kind = 0; /* 1: src + offset, 2: src */
+        if (eo != VERT) {
+            if (b0 && x == 0) kind = 1;
+            if (b2 && x == W - 1) kind = 1;
+        }
+        if (eo != HORIZ) {
+            if (b1 && y == 0 && x >= init_x && x < w) kind = 1;
+            if (b3 && y == H - 1 && x >= init_x && x < w) kind = 1;
+        }
+        if (k.variant) {
+            if (ve0 && eo != VERT && x == 0 && y >= init_y + s_ul && y < h - s_ll) kind = 2;
+            if (ve1 && eo != VERT && x == w - 1 && y >= init_y + s_ur && y < h - s_lr) kind = 2;
+            if (he0 && eo != HORIZ && y == 0 && x >= init_x + s_ul && x < w - s_ur) kind = 2;
+            if (he1 && eo != HORIZ && y == h - 1 && x >= init_x + s_ll && x < w - s_lr) kind = 2;
+            if (de0 && eo == D135 && x == 0 && y == 0) kind = 2;
+            if (de1 && eo == D45 && x == w - 1 && y == 0) kind = 2;
+            if (de2 && eo == D135 && x == w - 1 && y == h - 1) kind = 2;
+            if (de3 && eo == D45 && x == 0 && y == h - 1) kind = 2;
+        }
+        if (kind) {
+            const int v = s0[(ptrdiff_t)y * ss + x];
+            d0[(ptrdiff_t)y * sd + x] = (uint8_t)(kind == 1 ? clip_u8(v + off) : v);
+        }
+    }
+}
+
+int ffhip_launch_hevc_sao_restore(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSaoRestore *blocks, int n,
+                                  hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_hevc_sao_restore, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, sd, src, ss, blocks, n);
+    LAUNCH_CHECK();
+    return 0;
+}

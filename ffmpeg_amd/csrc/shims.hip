@@ -452,6 +452,50 @@ static void s_hevc_qpel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intpt
 static void s_hevc_epel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(1, 0, d, 0, s, ss, h, (int)mx, (int)my, w); }
 static void s_hevc_qpel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(0, 1, d, ds, s, ss, h, (int)mx, (int)my, w); }
 static void s_hevc_epel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(1, 1, d, ds, s, ss, h, (int)mx, (int)my, w); }
+static void s_hevc_dequant(int16_t *c, int16_t log2_size) { hevc_single(FFHIP_HEVC_DEQUANT, log2_size, c, 0, nullptr, 0); }
+static void s_hevc_rdpcm(int16_t *c, int16_t log2_size, int mode)
+{
+    hevc_single(mode ? FFHIP_HEVC_RDPCM_V : FFHIP_HEVC_RDPCM_H, log2_size, c, 0, nullptr, 0);
+}
+/* sao_edge_restore: rows of the block at a pitch of 64 for both buffers; only the block's own samples travel */
+static void hevc_restore_single(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao,
+                                const int *borders, int w, int h, int c_idx, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (w <= 0 || h <= 0 || w > 64 || h > 64 || c_idx < 0 || c_idx > 2)
+        return;
+    const int P = 64;
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + 2 * (size_t)h * P + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + (size_t)h * P;
+    if (hipMemcpy2D(dsrc, P, src, ss, w, h, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy2D(ddst, P, dst, sd, w, h, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    FFHipHevcSaoRestore k = {};
+    k.offset0 = sao->offset_val[c_idx][0];
+    k.width = (uint8_t)w; k.height = (uint8_t)h; k.eo = (uint8_t)sao->eo_class[c_idx]; k.variant = (uint8_t)variant;
+    for (int i = 0; i < 4; i++) {
+        k.borders |= (borders[i] != 0) << i;
+        if (variant)
+            k.diag_edge |= (de[i] != 0) << i;
+    }
+    if (variant) {
+        k.vert_edge = (ve[0] != 0) | (ve[1] != 0) << 1;
+        k.horiz_edge = (he[0] != 0) | (he[1] != 0) << 1;
+    }
+    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_hevc_sao_restore(ddst, P, dsrc, P, (const FFHipHevcSaoRestore *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    (void)hipMemcpy2D(dst, sd, ddst, P, w, h, hipMemcpyDeviceToHost);
+}
+static void s_hevc_restore0(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao, const int *b, int w, int h,
+                            int c, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
+{ hevc_restore_single(0, d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
+static void s_hevc_restore1(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao, const int *b, int w, int h,
+                            int c, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
+{ hevc_restore_single(1, d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
 #define HEVC_W_SHIMS(name, chroma)                                                                                                          \
 static void s_hevc_##name##_uni_w(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, int denom, int wx, int ox, intptr_t mx,  \
                                   intptr_t my, int w)                                                                                       \
@@ -475,6 +519,8 @@ extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
     c->idct_dc[0] = s_hevc_dc0; c->idct_dc[1] = s_hevc_dc1; c->idct_dc[2] = s_hevc_dc2; c->idct_dc[3] = s_hevc_dc3;
     c->add_residual[0] = s_hevc_add0; c->add_residual[1] = s_hevc_add1; c->add_residual[2] = s_hevc_add2; c->add_residual[3] = s_hevc_add3;
     c->transform_4x4_luma = s_hevc_dst4;
+    c->dequant = s_hevc_dequant; c->transform_rdpcm = s_hevc_rdpcm;
+    c->sao_edge_restore[0] = s_hevc_restore0; c->sao_edge_restore[1] = s_hevc_restore1;
     c->hevc_h_loop_filter_luma = c->hevc_h_loop_filter_luma_c = s_hevc_lf_hl;
     c->hevc_v_loop_filter_luma = c->hevc_v_loop_filter_luma_c = s_hevc_lf_vl;
     c->hevc_h_loop_filter_chroma = c->hevc_h_loop_filter_chroma_c = s_hevc_lf_hc;

@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _lib
 
-IDCT, IDCT_DC, DST_4X4, ADD_ONLY = 0, 1, 2, 3
+IDCT, IDCT_DC, DST_4X4, ADD_ONLY, DEQUANT, RDPCM_H, RDPCM_V = 0, 1, 2, 3, 4, 5, 6
 
 #: FFHipHevcTU (include/ffhip.h)
 TU_DTYPE = np.dtype([("coeff_offset", np.int32), ("dst_offset", np.int32), ("col_limit", np.int32)])
@@ -57,6 +57,24 @@ def mc_batch(chroma, uni, dst, dststride, src, srcstride, blocks, n, stream=None
                                                          _stream(stream)), "ffhip_hevc_mc_batch_dev")
 
 
+class SAOParams(C.Structure):
+    """FFHipSAOParams == SAOParams (libavcodec/hevc/dsp.h:34-46)"""
+    _fields_ = [("offset_abs", C.c_int * 4 * 3), ("offset_sign", C.c_int * 4 * 3), ("band_position", C.c_uint8 * 3), ("eo_class", C.c_int * 3),
+                ("offset_val", C.c_int16 * 5 * 3), ("type_idx", C.c_uint8 * 3)]
+
+
+#: FFHipHevcSaoRestore (include/ffhip.h)
+RESTORE_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("offset0", np.int16), ("width", np.uint8), ("height", np.uint8),
+                          ("eo", np.uint8), ("variant", np.uint8), ("borders", np.uint8), ("vert_edge", np.uint8), ("horiz_edge", np.uint8),
+                          ("diag_edge", np.uint8), ("pad", np.uint8, 2)])
+
+
+def sao_restore_batch(dst, stride_dst, src, stride_src, blocks, n, stream=None):
+    """blocks: uint8 [n, 20] FFHipHevcSaoRestore records"""
+    return _lib.check(_lib.lib().ffhip_hevc_sao_restore_batch_dev(dst.data_ptr(), stride_dst, src.data_ptr(), stride_src, blocks.data_ptr(), n,
+                                                                  _stream(stream)), "ffhip_hevc_sao_restore_batch_dev")
+
+
 MC_UNI_W, MC_BI, MC_BI_W = 2, 3, 4
 
 #: FFHipHevcMcWBlock (include/ffhip.h)
@@ -95,6 +113,10 @@ class HEVCDSPContext(C.Structure):
                 ("put_hevc_qpel_uni", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
                 ("put_hevc_epel", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
                 ("put_hevc_epel_uni", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int) * 2 * 2 * 10),
+                ("dequant", C.CFUNCTYPE(None, C.c_void_p, C.c_int16)),
+                ("transform_rdpcm", C.CFUNCTYPE(None, C.c_void_p, C.c_int16, C.c_int)),
+                ("sao_edge_restore", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p) * 2),
                 ("put_hevc_qpel_uni_w", _UNI_W * 2 * 2 * 10), ("put_hevc_qpel_bi", _BI * 2 * 2 * 10), ("put_hevc_qpel_bi_w", _BI_W * 2 * 2 * 10),
                 ("put_hevc_epel_uni_w", _UNI_W * 2 * 2 * 10), ("put_hevc_epel_bi", _BI * 2 * 2 * 10), ("put_hevc_epel_bi_w", _BI_W * 2 * 2 * 10)]
 

@@ -379,6 +379,15 @@ int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0
 typedef void (*ffhip_hevc_idct_func)(int16_t *coeffs, int col_limit);
 typedef void (*ffhip_hevc_idct_dc_func)(int16_t *coeffs);
 typedef void (*ffhip_hevc_add_residual_func)(uint8_t *dst, const int16_t *res, ptrdiff_t stride);
+/** SAOParams (libavcodec/hevc/dsp.h:34-46), as sao_edge_restore takes it. */
+typedef struct FFHipSAOParams {
+    int offset_abs[3][4];
+    int offset_sign[3][4];
+    uint8_t band_position[3];
+    int eo_class[3];
+    int16_t offset_val[3][5];
+    uint8_t type_idx[3];
+} FFHipSAOParams;
 /** hevc_{h,v}_loop_filter_luma / _chroma (hevc/dsp.h:103-124): 8 sample lines along an edge, two groups of 4 with their own
  *  tc / no_p / no_q.  h_: the edge is horizontal (samples of a line are `stride` apart). */
 typedef void (*ffhip_hevc_lf_luma_func)(uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p,
@@ -408,6 +417,13 @@ typedef struct FFHipHEVCDSPContext {
     void (*put_hevc_epel[10][2][2])(int16_t *dst, const uint8_t *src, ptrdiff_t srcstride, int height, intptr_t mx, intptr_t my, int width);
     void (*put_hevc_epel_uni[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, intptr_t mx,
                                         intptr_t my, int width);
+    /* the small members (hevc/dsp.h:52-54,70-72): transform-skip scaling, RDPCM running sums, SAO border fix-up.  put_pcm reads a
+     * bitstream (GetBitContext) and stays with the decoder */
+    void (*dequant)(int16_t *coeffs, int16_t log2_size);
+    void (*transform_rdpcm)(int16_t *coeffs, int16_t log2_size, int mode);
+    void (*sao_edge_restore[2])(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const FFHipSAOParams *sao,
+                                const int *borders, int width, int height, int c_idx, const uint8_t *vert_edge,
+                                const uint8_t *horiz_edge, const uint8_t *diag_edge);
     /* weighted and bi-directional prediction (hevc/dsp.h:78-87,93-101); src2 = the other list's put_hevc_* output (row stride 64) */
     void (*put_hevc_qpel_uni_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int denom,
                                           int wx, int ox, intptr_t mx, intptr_t my, int width);
@@ -429,6 +445,9 @@ int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth);
 #define FFHIP_HEVC_IDCT_DC   1   /* idct_dc[log2_size - 2](coeffs)             */
 #define FFHIP_HEVC_DST_4X4   2   /* transform_4x4_luma(coeffs), log2_size == 2 */
 #define FFHIP_HEVC_ADD_ONLY  3   /* coeffs already hold the residual           */
+#define FFHIP_HEVC_DEQUANT   4   /* dequant(coeffs, log2_size): transform-skip scaling (hevc/dsp_template.c:127-143) */
+#define FFHIP_HEVC_RDPCM_H   5   /* transform_rdpcm(coeffs, log2_size, 0): running sums along rows (:85-105)        */
+#define FFHIP_HEVC_RDPCM_V   6   /* transform_rdpcm(coeffs, log2_size, 1): running sums down columns                */
 /** One transform unit of the batch face: what hls_residual_coding / hls_transform_unit pass per TU
  *  (libavcodec/hevc/cabac.c, hevcdec.c). */
 typedef struct FFHipHevcTU {
@@ -503,7 +522,7 @@ typedef struct FFHipHevcSao {
     int32_t dst_offset, src_offset;  /* into dst / src */
     int16_t offset_val[5];           /* sao_offset_val: [0] unused by the band filter */
     uint8_t edge;                    /* 0: sao_band_filter, 1: sao_edge_filter */
-    uint8_t cls;                     /* band: sao_left_class (0..31); edge: eo (0 horizontal, 1 vertical, 2 45 deg, 3 135 deg) */
+    uint8_t cls;                     /* band: sao_left_class (0..31); edge: eo = SAO_EO_* (0 horizontal, 1 vertical, 2 135 deg, 3 45 deg) */
     uint8_t width, height;           /* 1..64 */
     uint8_t pad[2];                  /* sizeof == 24 */
 } FFHipHevcSao;
@@ -511,6 +530,23 @@ typedef struct FFHipHevcSao {
  *  copy), blocks do not overlap in dst; the edge filter reads src one sample beyond the block on every side. */
 int ffhip_hevc_sao_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src, const FFHipHevcSao *blocks,
                              int n, void *stream);
+
+/** One sao_edge_restore[variant] call of the batch face (libavcodec/hevc/filter.c:440-470 builds the operands). */
+typedef struct FFHipHevcSaoRestore {
+    int32_t dst_offset, src_offset;
+    int16_t offset0;      /* sao->offset_val[c_idx][0]                                              */
+    uint8_t width, height;/* 2..64 (the reference indexes column width - 2)                         */
+    uint8_t eo;           /* sao->eo_class[c_idx] = SAO_EO_*: 0 horizontal, 1 vertical, 2 135 degrees, 3 45 degrees */
+    uint8_t variant;      /* 0: sao_edge_restore[0] (borders only), 1: [1] (+ the restore part)     */
+    uint8_t borders;      /* bit i = borders[i] != 0: left, top, right, bottom                     */
+    uint8_t vert_edge;    /* bits 0..1 = vert_edge[0..1]                                            */
+    uint8_t horiz_edge;   /* bits 0..1                                                              */
+    uint8_t diag_edge;    /* bits 0..3                                                              */
+    uint8_t pad[2];       /* sizeof == 20                                                           */
+} FFHipHevcSaoRestore;
+/** n blocks, pairwise disjoint in dst; src and dst as for ffhip_hevc_sao_batch_dev. */
+int ffhip_hevc_sao_restore_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src,
+                                     const FFHipHevcSaoRestore *blocks, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */

@@ -92,6 +92,11 @@ void ffo_hevc_mc(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint
                  int my, int width);
 void ffo_hevc_mc_w(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
                    int height, int denom, int wx0, int wx1, int ox, int mx, int my, int width);
+void ffo_hevc_dequant(int16_t *coeffs, int log2_size);
+void ffo_hevc_transform_rdpcm(int16_t *coeffs, int log2_size, int mode);
+void ffo_hevc_sao_edge_restore(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, int eo, int offset0,
+                               const int *borders, int width, int height, const uint8_t *vert_edge, const uint8_t *horiz_edge,
+                               const uint8_t *diag_edge);
 /* sao_band_filter / sao_edge_filter (eo 0..3); the reference's edge filter uses stride_src = 192 */
 void ffo_hevc_sao_band(uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
                        int left_class, int width, int height);

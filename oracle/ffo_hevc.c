@@ -307,3 +307,87 @@ void ffo_hevc_mc_w(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, cons
             dst[y * dststride + x] = (uint8_t)clip8(out);
         }
 }
+
+/*
+ * The remaining small members of HEVCDSPContext, 8-bit: dequant (transform-skip scaling) and transform_rdpcm
+ * (libavcodec/hevc/dsp_template.c:85-143) and sao_edge_restore[2] (libavcodec/h26x/h2656_sao_template.c:81-214).
+ */
+void ffo_hevc_dequant(int16_t *coeffs, int log2_size)
+{
+    const int shift = 15 - 8 - log2_size, n = 1 << (2 * log2_size);
+    for (int i = 0; i < n; i++)
+        coeffs[i] = (int16_t)((coeffs[i] + (1 << (shift - 1))) >> shift);
+}
+
+void ffo_hevc_transform_rdpcm(int16_t *coeffs, int log2_size, int mode)
+{
+    const int n = 1 << log2_size;
+    if (mode) {
+        for (int y = 1; y < n; y++)
+            for (int x = 0; x < n; x++)
+                coeffs[y * n + x] = (int16_t)(coeffs[y * n + x] + coeffs[(y - 1) * n + x]);
+    } else {
+        for (int y = 0; y < n; y++)
+            for (int x = 1; x < n; x++)
+                coeffs[y * n + x] = (int16_t)(coeffs[y * n + x] + coeffs[y * n + x - 1]);
+    }
+}
+
+/* variant 0 / 1 = sao_edge_restore[0] / [1]; offset0 = sao_offset_val[0]; eo = SAO_EO_*: 0 horizontal, 1 vertical, 2 135 degrees, 3 45 degrees (hevc/hevcdec.h:169-174) */
+void ffo_hevc_sao_edge_restore(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, int eo, int offset0,
+                               const int *borders, int width, int height, const uint8_t *vert_edge, const uint8_t *horiz_edge,
+                               const uint8_t *diag_edge)
+{
+    enum { D135 = 2, D45 = 3 };
+    int init_x = 0, init_y = 0;
+    if (eo != 1) {
+        if (borders[0]) {
+            for (int y = 0; y < height; y++)
+                dst[y * sd] = (uint8_t)clip8(src[y * ss] + offset0);
+            init_x = 1;
+        }
+        if (borders[2]) {
+            for (int y = 0; y < height; y++)
+                dst[y * sd + width - 1] = (uint8_t)clip8(src[y * ss + width - 1] + offset0);
+            width--;
+        }
+    }
+    if (eo != 0) {
+        if (borders[1]) {
+            for (int x = init_x; x < width; x++)
+                dst[x] = (uint8_t)clip8(src[x] + offset0);
+            init_y = 1;
+        }
+        if (borders[3]) {
+            for (int x = init_x; x < width; x++)
+                dst[x + sd * (height - 1)] = (uint8_t)clip8(src[x + ss * (height - 1)] + offset0);
+            height--;
+        }
+    }
+    if (!variant)
+        return;
+    const int save_ul = !diag_edge[0] && eo == D135 && !borders[0] && !borders[1];
+    const int save_ur = !diag_edge[1] && eo == D45 && !borders[1] && !borders[2];
+    const int save_lr = !diag_edge[2] && eo == D135 && !borders[2] && !borders[3];
+    const int save_ll = !diag_edge[3] && eo == D45 && !borders[0] && !borders[3];
+    if (vert_edge[0] && eo != 1)
+        for (int y = init_y + save_ul; y < height - save_ll; y++)
+            dst[y * sd] = src[y * ss];
+    if (vert_edge[1] && eo != 1)
+        for (int y = init_y + save_ur; y < height - save_lr; y++)
+            dst[y * sd + width - 1] = src[y * ss + width - 1];
+    if (horiz_edge[0] && eo != 0)
+        for (int x = init_x + save_ul; x < width - save_ur; x++)
+            dst[x] = src[x];
+    if (horiz_edge[1] && eo != 0)
+        for (int x = init_x + save_ll; x < width - save_lr; x++)
+            dst[(height - 1) * sd + x] = src[(height - 1) * ss + x];
+    if (diag_edge[0] && eo == D135)
+        dst[0] = src[0];
+    if (diag_edge[1] && eo == D45)
+        dst[width - 1] = src[width - 1];
+    if (diag_edge[2] && eo == D135)
+        dst[sd * (height - 1) + width - 1] = src[ss * (height - 1) + width - 1];
+    if (diag_edge[3] && eo == D45)
+        dst[sd * (height - 1)] = src[ss * (height - 1)];
+}

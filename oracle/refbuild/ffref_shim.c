@@ -261,6 +261,27 @@ void ffref_hevc_sao_edge(int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t st
     dsp_init();
     hevc.sao_edge_filter[idx](dst, src, stride_dst, offset_val, eo, width, height);
 }
+void ffref_hevc_dequant(int16_t *coeffs, int log2_size)
+{
+    dsp_init();
+    hevc.dequant(coeffs, log2_size);
+}
+void ffref_hevc_transform_rdpcm(int16_t *coeffs, int log2_size, int mode)
+{
+    dsp_init();
+    hevc.transform_rdpcm(coeffs, log2_size, mode);
+}
+void ffref_hevc_sao_edge_restore(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, int eo, int offset0,
+                                 const int *borders, int width, int height, const uint8_t *vert_edge, const uint8_t *horiz_edge,
+                                 const uint8_t *diag_edge)
+{
+    SAOParams sao;
+    dsp_init();
+    memset(&sao, 0, sizeof(sao));
+    sao.eo_class[0] = eo;
+    sao.offset_val[0][0] = offset0;
+    hevc.sao_edge_restore[variant](dst, src, sd, ss, &sao, borders, width, height, 0, vert_edge, horiz_edge, diag_edge);
+}
 void ffref_hevc_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q)
 {
     dsp_init();

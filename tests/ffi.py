@@ -110,6 +110,12 @@ def oracle():
         L.ffo_hevc_mc.restype = None
         L.ffo_hevc_mc_w.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, i16p] + [C.c_int] * 8
         L.ffo_hevc_mc_w.restype = None
+        L.ffo_hevc_dequant.argtypes = [i16p, C.c_int]
+        L.ffo_hevc_dequant.restype = None
+        L.ffo_hevc_transform_rdpcm.argtypes = [i16p, C.c_int, C.c_int]
+        L.ffo_hevc_transform_rdpcm.restype = None
+        L.ffo_hevc_sao_edge_restore.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, i32p, C.c_int, C.c_int, u8p, u8p, u8p]
+        L.ffo_hevc_sao_edge_restore.restype = None
         L.ffo_hevc_sao_band.argtypes = [u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
         L.ffo_hevc_sao_band.restype = None
         L.ffo_hevc_sao_edge.argtypes = [u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
@@ -193,6 +199,12 @@ def ref():
         L.ffref_hevc_mc.restype = None
         L.ffref_hevc_mc_w.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, i16p] + [C.c_int] * 8
         L.ffref_hevc_mc_w.restype = None
+        L.ffref_hevc_dequant.argtypes = [i16p, C.c_int]
+        L.ffref_hevc_dequant.restype = None
+        L.ffref_hevc_transform_rdpcm.argtypes = [i16p, C.c_int, C.c_int]
+        L.ffref_hevc_transform_rdpcm.restype = None
+        L.ffref_hevc_sao_edge_restore.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, i32p, C.c_int, C.c_int, u8p, u8p, u8p]
+        L.ffref_hevc_sao_edge_restore.restype = None
         L.ffref_hevc_sao_band.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]
         L.ffref_hevc_sao_band.restype = None
         L.ffref_hevc_sao_edge.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, i16p, C.c_int, C.c_int, C.c_int]

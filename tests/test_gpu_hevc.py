@@ -421,3 +421,85 @@ def test_hevc_mc_weighted_host_faces():
                                                                                       wx1, ox, mx, my, w)
             O.ffo_hevc_mc_w(chroma, mode, ptr(b8), 72, C.cast(sp, u8p), 100, ptr(full2, ffi.i16p), h, d, wx0, wx1, ox, mx, my, w)
             assert np.array_equal(a8, b8), (chroma, mode, w, h, mx, my, d, wx0, wx1, ox)
+
+
+@pytest.mark.parametrize("lg", [2, 3, 4, 5])
+def test_hevc_dequant_rdpcm(lg):
+    """dequant and transform_rdpcm (both modes): batch face on 300 units, host faces on one"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    n = 1 << lg
+    rng = np.random.default_rng(300 + lg)
+    nu = 300
+    c0 = rng.integers(-32768, 32768, (nu, n * n)).astype(np.int16)
+    c0[::3] = rng.integers(-300, 301, (len(c0[::3]), n * n))
+    O = ffi.oracle()
+    tus = np.zeros(nu, hevc.TU_DTYPE)
+    tus["coeff_offset"] = np.arange(nu) * n * n
+    tus["dst_offset"] = -1
+    d_tus = torch.from_numpy(tus.view(np.uint8).reshape(nu, 12).copy()).cuda()
+    ctx = hevc.dsp_init(8)
+    for kind, fn in ((hevc.DEQUANT, lambda p: O.ffo_hevc_dequant(p, lg)), (hevc.RDPCM_H, lambda p: O.ffo_hevc_transform_rdpcm(p, lg, 0)),
+                     (hevc.RDPCM_V, lambda p: O.ffo_hevc_transform_rdpcm(p, lg, 1))):
+        want = c0.copy()
+        for u in range(nu):
+            fn(ptr(want[u], ffi.i16p))
+        d_c = torch.from_numpy(c0.copy()).cuda()
+        hevc.idct_batch(kind, lg, d_c, None, 0, d_tus, nu)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_c.cpu().numpy(), want), kind
+        one = c0[7].copy()
+        if kind == hevc.DEQUANT:
+            ctx.dequant(one.ctypes.data, lg)
+        else:
+            ctx.transform_rdpcm(one.ctypes.data, lg, int(kind == hevc.RDPCM_V))
+        assert np.array_equal(one, want[7]), ("host", kind)
+
+
+def _restore_case(rng, rep):
+    p = .5 if rep % 3 else .85
+    return (rep & 1, int(rng.integers(0, 4)), int(rng.integers(-60, 61)), (rng.random(4) < p).astype(np.int32),
+            int(rng.choice([2, 3, 8, 16, 33, 64])), int(rng.choice([2, 3, 8, 16, 33, 64])), (rng.random(2) < p).astype(np.uint8),
+            (rng.random(2) < p).astype(np.uint8), (rng.random(4) < p).astype(np.uint8))
+
+
+def test_hevc_sao_edge_restore():
+    """sao_edge_restore[0] / [1]: 600 blocks with every combination of border / edge flags in one batch, then the host faces"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    rng = np.random.default_rng(310)
+    O = ffi.oracle()
+    nb = 600
+    per_row = 20
+    sd, ss = per_row * 64 + 7, per_row * 64 + 12
+    rows = (nb + per_row - 1) // per_row
+    src = rng.integers(0, 256, (rows * 64, ss), dtype=np.uint8)
+    dst = rng.integers(0, 256, (rows * 64, sd), dtype=np.uint8)
+    want = dst.copy()
+    rec = np.zeros(nb, hevc.RESTORE_DTYPE)
+    cases = []
+    for i in range(nb):
+        var, eo, off, borders, w, h, ve, he, de = _restore_case(rng, i)
+        by, bx = (i // per_row) * 64, (i % per_row) * 64
+        bits = lambda a: int(sum(int(bool(v)) << k for k, v in enumerate(a)))
+        rec[i] = (by * sd + bx, by * ss + bx, off, w, h, eo, var, bits(borders), bits(ve), bits(he), bits(de), (0, 0))
+        O.ffo_hevc_sao_edge_restore(var, C.cast(want.ctypes.data + by * sd + bx, u8p), C.cast(src.ctypes.data + by * ss + bx, u8p), sd, ss, eo, off,
+                                    ptr(borders, ffi.i32p), w, h, ptr(ve), ptr(he), ptr(de))
+        cases.append((var, eo, off, borders, w, h, ve, he, de, by, bx))
+    d_dst, d_src = torch.from_numpy(dst.copy()).cuda(), torch.from_numpy(src).cuda()
+    hevc.sao_restore_batch(d_dst, sd, d_src, ss, torch.from_numpy(rec.view(np.uint8).reshape(nb, 20).copy()).cuda(), nb)
+    torch.cuda.synchronize()
+    assert (want != dst).sum() > 2000
+    got = d_dst.cpu().numpy()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    ctx = hevc.dsp_init(8)
+    for var, eo, off, borders, w, h, ve, he, de, by, bx in cases[:24]:
+        sao = hevc.SAOParams()
+        c_idx = int(rng.integers(0, 3))
+        sao.eo_class[c_idx] = eo
+        sao.offset_val[c_idx][0] = off
+        a = dst[by:by + 64, bx:bx + 64].copy()
+        s_ = src[by:by + 64, bx:bx + 64].copy()
+        ctx.sao_edge_restore[var](a.ctypes.data, s_.ctypes.data, 64, 64, C.addressof(sao), borders.ctypes.data, w, h, c_idx, ve.ctypes.data,
+                                  he.ctypes.data, de.ctypes.data)
+        assert np.array_equal(a, want[by:by + 64, bx:bx + 64]), (var, eo, w, h)

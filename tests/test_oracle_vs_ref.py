@@ -454,6 +454,39 @@ def test_hevc_mc_weighted():
                         assert np.array_equal(a8, b8), (chroma, mode, w, mx, my, d, wx0, wx1, ox)
 
 
+def hevc_restore_case(rng, rep):
+    """(variant, eo, offset0, borders[4], width, height, vert_edge[2], horiz_edge[2], diag_edge[4]) — every flag on and off"""
+    p = .5 if rep % 3 else .85
+    return (rep & 1, int(rng.integers(0, 4)), int(rng.integers(-60, 61)), (rng.random(4) < p).astype(np.int32),
+            int(rng.choice([2, 3, 8, 16, 33, 64])), int(rng.choice([2, 3, 8, 16, 33, 64])), (rng.random(2) < p).astype(np.uint8),
+            (rng.random(2) < p).astype(np.uint8), (rng.random(4) < p).astype(np.uint8))
+
+
+def test_hevc_small_members():
+    """dequant, transform_rdpcm and sao_edge_restore[2] (hevc/dsp_template.c:85-143, h26x/h2656_sao_template.c:81-214)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(90)
+    for lg in (2, 3, 4, 5):
+        n = 1 << lg
+        for rep in range(6):
+            c = rng.integers(-32768, 32768, n * n).astype(np.int16) if rep % 2 else rng.integers(-300, 301, n * n).astype(np.int16)
+            a, b = c.copy(), c.copy()
+            R.ffref_hevc_dequant(ptr(a, i16p), lg); O.ffo_hevc_dequant(ptr(b, i16p), lg)
+            assert np.array_equal(a, b), ("dequant", lg)
+            for mode in (0, 1):
+                a, b = c.copy(), c.copy()
+                R.ffref_hevc_transform_rdpcm(ptr(a, i16p), lg, mode); O.ffo_hevc_transform_rdpcm(ptr(b, i16p), lg, mode)
+                assert np.array_equal(a, b), ("rdpcm", lg, mode)
+    for rep in range(400):
+        var, eo, off, borders, w, h, ve, he, de = hevc_restore_case(rng, rep)
+        src = rng.integers(0, 256, (h, 80), dtype=np.uint8)
+        dst0 = rng.integers(0, 256, (h, 72), dtype=np.uint8)
+        a, b = dst0.copy(), dst0.copy()
+        R.ffref_hevc_sao_edge_restore(var, ptr(a), ptr(src), 72, 80, eo, off, ptr(borders, i32p), w, h, ptr(ve), ptr(he), ptr(de))
+        O.ffo_hevc_sao_edge_restore(var, ptr(b), ptr(src), 72, 80, eo, off, ptr(borders, i32p), w, h, ptr(ve), ptr(he), ptr(de))
+        assert np.array_equal(a, b), ("restore", rep)
+
+
 def test_hevc_sao():
     """band and edge offsets on CTB-sized blocks (tests/checkasm/hevc_sao.c shapes: widths 8..64, the padded 192-byte source)"""
     R, O = ffi.ref(), ffi.oracle()
