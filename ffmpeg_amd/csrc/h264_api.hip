@@ -51,6 +51,16 @@ extern "C" int ffhip_h264_deblock_frame_dev(uint8_t *luma, ptrdiff_t stride, int
     return ffhip_launch_h264_deblock_frame(luma, stride, mb_w, mb_h, edges, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_h264_deblock_frames_chroma_dev(uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                                                    const FFHipH264Edge *edges, void *stream)
+{
+    if (!plane || !edges || mb_w <= 0 || mb_h <= 0 || nframes < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_deblock_frames_chroma(plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, (hipStream_t)stream);
+}
+
 extern "C" int ffhip_h264_deblock_frames_dev(uint8_t *luma, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                                              const FFHipH264Edge *edges, void *stream)
 {

@@ -303,6 +303,109 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t
     }
 }
 
+/*
+ * k_h264_deblock_frame_chroma — one 4:2:0 chroma plane in the decoder's order: per macroblock (8x8 samples) the vertical edges
+ * at x = 0 and 4, then the horizontal ones at y = 0 and 4 (filter_mb_dir filters chroma on the even luma edges,
+ * h264_loopfilter.c:644-700).  Same wavefront as the luma kernel: one wave per macroblock row, MB (x, y) after (x+1, y-1); the
+ * tile is the MB + 4 columns / 2 rows of context; a chroma filter reads two samples and writes one on either side, so the two
+ * edges of a direction touch disjoint samples and run side by side (lanes 0-7 / 8-15).  Dword-aligned planes only: everything
+ * that crosses rows moves with device-scope loads / stores and the hand-off is order-only, as in the luma kernel's fast path.
+ */
+#define CTP 16 /* chroma tile pitch: 4 context columns + 8 + 4 */
+__global__ __launch_bounds__(64) void k_h264_deblock_frame_chroma(uint8_t *plane, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
+                                                                  const FFHipH264Edge *edges, int *progress)
+{
+    plane += (size_t)blockIdx.y * frame_pitch;
+    edges += (size_t)blockIdx.y * mb_w * mb_h * 4;
+    progress += (size_t)blockIdx.y * (mb_h + 1);
+    int *fail = progress + mb_h;
+    /* tile[r][c]: r = row - (8 my - 2), c = column - (8 mx - 4) */
+    __shared__ __align__(16) uint8_t tile[10 * CTP];
+    __shared__ uint32_t edl[12];
+    const int my = blockIdx.x, lane = threadIdx.x;
+    uint8_t *rowbase = plane + (ptrdiff_t)my * 8 * stride;
+    const int pr = lane >> 1, pc = 4 * (lane & 1); /* lanes 0..15: this lane's dword of the 8x8 block */
+    uint32_t own = 0, edw = 0;
+    auto fetch = [&](int mx) {
+        if (lane < 16)
+            own = *reinterpret_cast<const uint32_t *>(rowbase + mx * 8 + (ptrdiff_t)pr * stride + pc);
+        if (lane < 12)
+            edw = reinterpret_cast<const uint32_t *>(edges + (size_t)(my * mb_w + mx) * 4)[lane];
+    };
+    int known = 0;
+    fetch(0);
+    for (int mx = 0; mx < mb_w; mx++) {
+        uint8_t *mb = rowbase + mx * 8;
+        if (lane < 16)
+            *reinterpret_cast<uint32_t *>(&tile[(pr + 2) * CTP + 4 + pc]) = own;
+        if (lane < 12)
+            edl[lane] = edw;
+        if (mx + 1 < mb_w)
+            fetch(mx + 1);
+        if (my > 0) {
+            /* rows -2, -1 over this MB belong to the row above: wait until it has finished MB mx + 1 */
+            const int want = min(mx + 2, mb_w);
+            int spins = 0;
+            while (known < want) {
+                known = __hip_atomic_load(&progress[my - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (known >= want)
+                    break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                    if (lane == 0)
+                        atomicExch(fail, 1);
+                    return;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < 4) {
+                const int r = lane >> 1, c = 4 * (lane & 1);
+                const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(mb + (ptrdiff_t)(r - 2) * stride + c), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                *reinterpret_cast<uint32_t *>(&tile[r * CTP + 4 + c]) = v;
+            }
+        }
+        wave_lds_sync();
+        const FFHipH264Edge *e = reinterpret_cast<const FFHipH264Edge *>(edl);
+        const int k = (lane >> 3) & 1, line = lane & 7;
+        { /* vertical edges at columns 0 and 4: lane = (edge, row) */
+            const FFHipH264Edge ed = e[k];
+            if (lane < 16 && ed.alpha && ed.beta && !(k == 0 && mx == 0)) {
+                const bool intra = ed.kind >= 4;
+                lf_apply(&tile[(line + 2) * CTP + 4 + 4 * k], 1, intra ? 3 : 1, ed.alpha, ed.beta, intra ? 0 : ed.tc0[line >> 1]);
+            }
+        }
+        wave_lds_sync();
+        { /* horizontal edges at rows 0 and 4: lane = (edge, column) */
+            const FFHipH264Edge ed = e[2 + k];
+            if (lane < 16 && ed.alpha && ed.beta && !(k == 0 && my == 0)) {
+                const bool intra = ed.kind >= 4;
+                lf_apply(&tile[(2 + 4 * k) * CTP + 4 + line], CTP, intra ? 3 : 1, ed.alpha, ed.beta, intra ? 0 : ed.tc0[line >> 1]);
+            }
+        }
+        wave_lds_sync();
+        /* write back rows 0..7 x columns -4..7 and row -1 x columns 0..7 (untouched samples keep their values) */
+        if (lane < 26) {
+            int r, c;
+            if (lane < 24) { r = lane / 3; c = 4 * (lane % 3) - 4; } else { r = -1; c = 4 * (lane - 24); }
+            if (!((c < 0 && mx == 0) || (r < 0 && my == 0)))
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(mb + (ptrdiff_t)r * stride + c),
+                                   *reinterpret_cast<const uint32_t *>(&tile[(r + 2) * CTP + 4 + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        /* the MB's right 4 columns are the next MB's left context */
+        wave_lds_sync();
+        const uint32_t keep = *reinterpret_cast<const uint32_t *>(&tile[(lane < 10 ? lane : 0) * CTP + 4 + 4]);
+        wave_lds_sync();
+        if (lane < 10)
+            *reinterpret_cast<uint32_t *>(&tile[lane * CTP]) = keep;
+        /* publish: the write-through stores above are acknowledged before the counter moves */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0)
+            __hip_atomic_store(&progress[my], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 /* progress counters: a small ring of slots in one device allocation made on first use (stream-ordered zeroing
  * per launch); a per-launch hipMallocAsync/hipFreeAsync pair serialises launches across streams */
 #define DB_SLOTS 64
@@ -341,4 +444,34 @@ int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, i
                                     hipStream_t stream)
 {
     return ffhip_launch_h264_deblock_frames(luma, 0, 1, stride, mb_w, mb_h, edges, stream);
+}
+
+int ffhip_launch_h264_deblock_frames_chroma(uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                                            const FFHipH264Edge *edges, hipStream_t stream)
+{
+    if (mb_w <= 0 || mb_h <= 0 || nframes <= 0)
+        return 0;
+    if (((uintptr_t)plane | (size_t)stride | frame_pitch) & 3) {
+        ffhip_set_error("ffhip_h264_deblock_frame_chroma: plane, stride and frame pitch must be 4-byte aligned");
+        return FFHIP_EINVAL;
+    }
+    if (mb_h + 1 > DB_SLOT_INTS) {
+        ffhip_set_error("ffhip_h264_deblock_frame_chroma: %d macroblock rows exceed the supported %d", mb_h, DB_SLOT_INTS - 1);
+        return FFHIP_EINVAL;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_db_mu);
+        if (!g_db_pool)
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_db_pool), (size_t)DB_SLOTS * DB_SLOT_INTS * sizeof(int)));
+    }
+    const int per_launch = DB_SLOT_INTS / (mb_h + 1);
+    for (int f0 = 0; f0 < nframes; f0 += per_launch) {
+        const int nf = nframes - f0 < per_launch ? nframes - f0 : per_launch;
+        int *prog = g_db_pool + (size_t)(g_db_next.fetch_add(1) % DB_SLOTS) * DB_SLOT_INTS;
+        HIP_TRY(hipMemsetAsync(prog, 0, (size_t)nf * (mb_h + 1) * sizeof(int), stream));
+        hipLaunchKernelGGL(k_h264_deblock_frame_chroma, dim3(mb_h, nf), dim3(64), 0, stream, plane + (size_t)f0 * frame_pitch, frame_pitch,
+                           stride, mb_w, mb_h, edges + (size_t)f0 * mb_w * mb_h * 4, prog);
+        LAUNCH_CHECK();
+    }
+    return 0;
 }

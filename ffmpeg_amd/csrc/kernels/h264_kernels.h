@@ -15,6 +15,8 @@ int ffhip_launch_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH2
                                   hipStream_t stream);
 int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
                                     hipStream_t stream);
+int ffhip_launch_h264_deblock_frames_chroma(uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                                            const FFHipH264Edge *edges, hipStream_t stream);
 int ffhip_launch_h264_deblock_frames(uint8_t *luma, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                                      const FFHipH264Edge *edges, hipStream_t stream);
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,

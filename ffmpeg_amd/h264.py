@@ -37,6 +37,13 @@ def deblock_frame(luma, stride, mb_w, mb_h, edges, stream=None):
                                                               _stream(stream)), "ffhip_h264_deblock_frame_dev")
 
 
+def deblock_frames_chroma(plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream=None):
+    """one 4:2:0 chroma plane per frame (8x8 samples per MB), decoder order; edges: uint8 [nframes * mb_w * mb_h * 4, 12]"""
+    return _lib.check(_lib.lib().ffhip_h264_deblock_frames_chroma_dev(plane.data_ptr(), frame_pitch, nframes, stride, mb_w, mb_h,
+                                                                      edges.data_ptr(), _stream(stream)),
+                      "ffhip_h264_deblock_frames_chroma_dev")
+
+
 def deblock_frames(luma, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream=None):
     """nframes independent pictures in one launch (edges: nframes * mb_w*mb_h*8 records)."""
     return _lib.check(_lib.lib().ffhip_h264_deblock_frames_dev(luma.data_ptr(), frame_pitch, nframes, stride, mb_w, mb_h,

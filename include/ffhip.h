@@ -266,6 +266,16 @@ int ffhip_h264_deblock_frame_dev(uint8_t *luma, ptrdiff_t stride, int mb_w, int 
 int ffhip_h264_deblock_frames_dev(uint8_t *luma, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                                   const FFHipH264Edge *edges, void *stream);
 
+/**
+ * The same for one 4:2:0 CHROMA plane (8x8 samples per macroblock; call once for Cb and once for Cr — their alpha / beta / tc0
+ * come from different QPs): per MB the vertical edges at x = 0 and 4, then the horizontal ones at y = 0 and 4, as
+ * filter_mb_dir() filters chroma on the even luma edges (libavcodec/h264_loopfilter.c:644-700).
+ * edges[((f * mb_h * mb_w + mb) * 2 + dir) * 2 + e]; kinds FFHIP_H264_LF_*_CHROMA[_INTRA]; alpha == 0 skips an edge.
+ * plane, stride and frame_pitch must be 4-byte aligned.
+ */
+int ffhip_h264_deblock_frames_chroma_dev(uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                                         const FFHipH264Edge *edges, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: h264qpel                                                                       */
 /* ------------------------------------------------------------------------------------------ */

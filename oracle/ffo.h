@@ -112,6 +112,8 @@ typedef struct FfoH264Edge {
     int8_t  tc0[4];
 } FfoH264Edge;
 void ffo_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges);
+/* one 4:2:0 chroma plane in frame order: edges[(mb * 2 + dir) * 2 + e], edges at 0 and 4 */
+void ffo_h264_deblock_frame_chroma(uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges);
 
 /* ---- me_cmp + ESA (ffo_mecmp.c) ---- */
 int      ffo_sad(int width, const uint8_t *a, const uint8_t *b, ptrdiff_t stride, int h);

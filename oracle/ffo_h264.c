@@ -276,6 +276,32 @@ void ffo_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h,
         }
 }
 
+/*
+ * The same for one 4:2:0 chroma plane: per macroblock (8x8 chroma samples) the vertical edges at x = 0 and 4, then the
+ * horizontal ones at y = 0 and 4 — filter_mb_dir() filters chroma on the even luma edges (h264_loopfilter.c:644-700,
+ * (edge & 1) == 0, dest_cb + 2 * edge).  edges[(mb * 2 + dir) * 2 + e]; kinds: the chroma ones of FFHIP_H264_LF_*.
+ */
+void ffo_h264_deblock_frame_chroma(uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges)
+{
+    for (int my = 0; my < mb_h; my++)
+        for (int mx = 0; mx < mb_w; mx++) {
+            const FfoH264Edge *e = edges + (size_t)(my * mb_w + mx) * 4;
+            uint8_t *mb = plane + (ptrdiff_t)my * 8 * stride + mx * 8;
+            for (int dir = 0; dir < 2; dir++)
+                for (int k = 0; k < 2; k++) {
+                    const FfoH264Edge *ed = e + dir * 2 + k;
+                    uint8_t *pix = dir ? mb + (ptrdiff_t)4 * k * stride : mb + 4 * k;
+                    if (!ed->alpha || !ed->beta)
+                        continue;
+                    if (k == 0 && (dir ? my == 0 : mx == 0))
+                        continue;
+                    const int intra = ed->kind >= 4;
+                    /* dir 0: vertical edge -> h_loop_filter_chroma (3/7); dir 1: horizontal -> v_ (2/6) */
+                    ffo_h264_loop_filter((dir ? 2 : 3) + (intra ? 4 : 0), pix, stride, ed->alpha, ed->beta, ed->tc0);
+                }
+        }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Luma quarter-pel MC: libavcodec/h264qpel_template.c:77-305 (6-tap lowpass), :313-459 (mcXY
  * compositions), :461-465 (rounding), hpel_template.c/pel_template.c (rnd_avg).

@@ -126,6 +126,8 @@ def oracle():
         L.ffo_h264_biweight.restype = None
         L.ffo_h264_deblock_frame.argtypes = [u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
         L.ffo_h264_deblock_frame.restype = None
+        L.ffo_h264_deblock_frame_chroma.argtypes = [u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
+        L.ffo_h264_deblock_frame_chroma.restype = None
         L.ffo_sad.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]
         L.ffo_hadamard8_diff8x8.argtypes = [u8p, u8p, C.c_ssize_t]
         L.ffo_hadamard8_diff16.argtypes = [u8p, u8p, C.c_ssize_t, C.c_int]

@@ -248,6 +248,43 @@ def test_deblock_frames_batch():
     assert np.array_equal(d.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("mb_w,mb_h,nf,pad", [(1, 1, 1, 0), (5, 1, 1, 4), (1, 7, 2, 0), (40, 25, 3, 8), (240, 135, 2, 0)])
+def test_deblock_frame_chroma(mb_w, mb_h, nf, pad):
+    """one 4:2:0 chroma plane per frame in decoder order (wavefront) == the serial order, bit for bit; 240x135 MBs = the chroma
+    plane of a 4K picture; several pictures per launch"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    rng = np.random.default_rng(mb_w * 100 + mb_h + 7)
+    stride = mb_w * 8 + pad
+    planes = np.stack([_smooth_plane(rng, mb_h * 8, stride) for _ in range(nf)])
+    n = mb_w * mb_h * 4
+    ed = np.zeros(nf * n, EDGE_DT)
+    lad = np.array(LADDER)
+    sel = rng.integers(0, len(LADDER), nf * n)
+    ed["alpha"], ed["beta"] = lad[sel, 0], lad[sel, 1]
+    ed["kind"] = np.where(rng.random(nf * n) < .25, 6, 2)       # chroma intra / chroma normal
+    ed["tc0"] = rng.integers(-1, 5, (nf * n, 4))
+    ed["alpha"][rng.random(nf * n) < .15] = 0                     # skipped edges
+    want = planes.copy()
+    for f in range(nf):
+        ffi.oracle().ffo_h264_deblock_frame_chroma(ptr(want[f]), stride, mb_w, mb_h, C.c_void_p(ed[f * n:].ctypes.data))
+    d = torch.from_numpy(planes).cuda()
+    h264.deblock_frames_chroma(d, mb_h * 8 * stride, nf, stride, mb_w, mb_h, torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).cuda())
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    assert (want != planes).sum() > (10 if mb_w > 1 else 0)
+    assert np.array_equal(got, want), "%d mismatches" % (got != want).sum()
+
+
+def test_deblock_frame_chroma_rejects_unaligned():
+    from ffmpeg_amd import h264
+    torch = _torch()
+    d = torch.zeros((16, 19), dtype=torch.uint8, device="cuda:0")
+    ed = torch.zeros((2 * 2 * 4, 12), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(RuntimeError, match="aligned"):
+        h264.deblock_frames_chroma(d, 0, 1, 19, 2, 2, ed)
+
+
 # ---------------------------------------------------------------------------------------------
 # chroma 1/8-pel MC and explicit weighted prediction (SURVEY.md §8 f-2)
 # ---------------------------------------------------------------------------------------------

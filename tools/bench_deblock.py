@@ -33,3 +33,22 @@ for nf in (1, 2, 4, 8, 16, 32, 64):
     ms = e0.elapsed_time(e1)
     print(json.dumps({"frames_per_launch": nf, "ms": round(ms, 3), "ms_per_frame": round(ms / nf, 4),
                       "Gpixel/s": round(nf * w * h / ms / 1e6, 2)}), flush=True)
+# one 4:2:0 chroma plane per frame (1920x1080 samples, 8x8 per MB): decoder order, same wavefront
+cw, ch = w // 2, h // 2
+edc = np.zeros(mbw * mbh * 4, dtype=ed.dtype)
+edc["a"], edc["b"] = 40, 9
+edc["k"] = np.where(rng.random(edc.size) < .25, 6, 2)
+edc["tc"] = rng.integers(0, 4, (edc.size, 4))
+dedc = torch.from_numpy(edc.view(np.uint8).reshape(-1, 12)).to(dev)
+for nf in (1, 8, 32, 64):
+    batch = torch.randint(100, 140, (nf, ch, cw), dtype=torch.uint8, device=dev)
+    dd = dedc.repeat(nf, 1)
+    h264.deblock_frames_chroma(batch, cw * ch, nf, cw, mbw, mbh, dd)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    h264.deblock_frames_chroma(batch, cw * ch, nf, cw, mbw, mbh, dd)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(json.dumps({"chroma_plane_frames_per_launch": nf, "ms": round(ms, 3), "ms_per_plane": round(ms / nf, 4),
+                      "Gpixel/s": round(nf * cw * ch / ms / 1e6, 2)}), flush=True)
