@@ -75,6 +75,15 @@ def lib():
         "ffhip_h264_idct_add_mb_batch_dev": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, vp, vp, vp, C.c_int, vp]),
         "ffhip_h264_loop_filter_batch_dev": (C.c_int, [vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_h264_deblock_frame_dev": (C.c_int, [vp, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
+        "ffhip_h264_picture_create": (C.c_int, [vp, C.c_int, C.c_int]),
+        "ffhip_h264_picture_free": (None, [vp]),
+        "ffhip_h264_picture_begin": (None, [vp]),
+        "ffhip_h264_picture_mc_luma": (C.c_int, [vp, C.c_int, vp]),
+        "ffhip_h264_picture_mc_chroma": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        "ffhip_h264_picture_weight": (C.c_int, [vp, C.c_int, vp]),
+        "ffhip_h264_picture_idct_add": (C.c_int, [vp, C.c_int, C.c_int, C.c_int32, vp]),
+        "ffhip_h264_picture_deblock_mb": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+        "ffhip_h264_picture_flush": (C.c_int, [vp, vp, vp, vp, vp]),
         "ffhip_h264_deblock_frames_chroma_dev": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_deblock_frames_dev": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_qpel_batch_dev": (C.c_int, [vp, vp, C.c_ssize_t, vp, C.c_int, vp]),

@@ -1,0 +1,349 @@
+/*
+ * h264_picture.hip — caller-side batching for the H.264 macroblock loop.
+ *
+ * The reference reconstructs a picture by calling the dsp pointers once per block from hl_decode_mb()
+ * (libavcodec/h264_mb_template.c:41-270: mc_part_std / mc_part_weighted -> qpel + chroma + weight tables, h264_mb.c:206-420;
+ * hl_decode_mb_predict_luma / idct_add, h264_mb.c:612-800) and, a row behind, ff_h264_filter_mb() (h264_loopfilter.c:716).
+ * On a GPU one call per block is ~10^4 times slower than C, so the decoder RECORDS those calls here while it parses the
+ * picture — the same operands it would have passed — and flush() runs them as a handful of launches in the one order that
+ * preserves the reference's data flow:
+ *
+ *     per plane:  MC put -> dst | MC put -> bi-pred scratch | MC avg -> dst | weight / biweight | IDCT + add | deblock (frame order)
+ *
+ * Blocks of one stage are disjoint, stages depend on each other only in that order; deblocking is the decoder-order wavefront.
+ * Records travel in ONE host-to-device copy per picture from a pinned buffer.  Entropy decoding stays on the CPU.
+ */
+#include <new>
+#include <string.h>
+#include <vector>
+
+#include "kernels/common.h"
+#include "kernels/h264_kernels.h"
+
+namespace {
+enum { ST_PUT = 0, ST_TMP = 1, ST_AVG = 2 };
+
+struct Section { size_t off = 0; int n = 0; };
+
+template <typename T>
+size_t place(size_t &total, const std::vector<T> &v, Section &s)
+{
+    total = (total + 15) & ~(size_t)15;
+    s.off = total;
+    s.n = (int)v.size();
+    total += v.size() * sizeof(T);
+    return s.off;
+}
+} // namespace
+
+struct FFHipH264Picture {
+    int mb_w = 0, mb_h = 0;
+    std::vector<FFHipQpelBlock> qpel[3];          /* luma MC by stage                      */
+    std::vector<FFHipChromaBlock> cmc[2][3];      /* chroma MC: plane (Cb, Cr) x stage     */
+    std::vector<FFHipWeightBlock> wt[3];          /* weight / biweight per plane           */
+    std::vector<int32_t> idct_off[3][4];          /* per plane x FFHIP_H264_IDCT* kind     */
+    std::vector<int16_t> idct_coef[3][4];
+    std::vector<FFHipH264Edge> edges[3];          /* whole-picture edge arrays, zero = skip */
+    bool any_edge[3] = { false, false, false };
+    void *pinned = nullptr, *dev = nullptr;
+    size_t pinned_sz = 0, dev_sz = 0;
+    uint8_t *tmp[3] = { nullptr, nullptr, nullptr }; /* bi-prediction scratch planes (sl->bipred_scratchpad) */
+    size_t tmp_sz[3] = { 0, 0, 0 };
+    hipEvent_t copied = nullptr;
+    bool copy_pending = false;
+    /* the chroma planes' deblocking wavefront runs beside the luma one on a second stream, forked and joined with events */
+    hipStream_t aux = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
+extern "C" void ffhip_h264_picture_free(FFHipH264Picture **pp)
+{
+    if (!pp || !*pp)
+        return;
+    FFHipH264Picture *p = *pp;
+    if (p->copy_pending)
+        (void)hipEventSynchronize(p->copied);
+    if (p->copied)
+        (void)hipEventDestroy(p->copied);
+    if (p->aux) {
+        (void)hipStreamSynchronize(p->aux);
+        (void)hipStreamDestroy(p->aux);
+    }
+    if (p->fork)
+        (void)hipEventDestroy(p->fork);
+    if (p->join)
+        (void)hipEventDestroy(p->join);
+    if (p->pinned)
+        (void)hipHostFree(p->pinned);
+    if (p->dev)
+        (void)hipFree(p->dev);
+    for (int i = 0; i < 3; i++)
+        if (p->tmp[i])
+            (void)hipFree(p->tmp[i]);
+    delete p;
+    *pp = nullptr;
+}
+
+extern "C" void ffhip_h264_picture_begin(FFHipH264Picture *p)
+{
+    if (!p)
+        return;
+    for (int s = 0; s < 3; s++) {
+        p->qpel[s].clear();
+        p->cmc[0][s].clear();
+        p->cmc[1][s].clear();
+    }
+    for (int pl = 0; pl < 3; pl++) {
+        p->wt[pl].clear();
+        for (int k = 0; k < 4; k++) {
+            p->idct_off[pl][k].clear();
+            p->idct_coef[pl][k].clear();
+        }
+        if (p->any_edge[pl])
+            memset(p->edges[pl].data(), 0, p->edges[pl].size() * sizeof(FFHipH264Edge));
+        p->any_edge[pl] = false;
+    }
+}
+
+extern "C" int ffhip_h264_picture_create(FFHipH264Picture **pp, int mb_w, int mb_h)
+{
+    if (!pp || mb_w <= 0 || mb_h <= 0)
+        return FFHIP_EINVAL;
+    *pp = nullptr;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    FFHipH264Picture *p = new (std::nothrow) FFHipH264Picture();
+    if (!p)
+        return FFHIP_ENOMEM;
+    p->mb_w = mb_w;
+    p->mb_h = mb_h;
+    const size_t nmb = (size_t)mb_w * mb_h;
+    p->edges[0].assign(nmb * 8, FFHipH264Edge());
+    p->edges[1].assign(nmb * 4, FFHipH264Edge());
+    p->edges[2].assign(nmb * 4, FFHipH264Edge());
+    if (hipEventCreateWithFlags(&p->copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking) != hipSuccess) {
+        ffhip_h264_picture_free(&p);
+        return FFHIP_ENOMEM;
+    }
+    *pp = p;
+    return 0;
+}
+
+/* ---- recording: cheap appends on the host ----------------------------------------------------------- */
+extern "C" int ffhip_h264_picture_mc_luma(FFHipH264Picture *p, int stage, const FFHipQpelBlock *blk)
+{
+    if (!p || !blk || stage < 0 || stage > 2)
+        return FFHIP_EINVAL;
+    FFHipQpelBlock b = *blk;
+    b.avg = stage == ST_AVG;
+    p->qpel[stage].push_back(b);
+    return 0;
+}
+
+extern "C" int ffhip_h264_picture_mc_chroma(FFHipH264Picture *p, int plane, int stage, const FFHipChromaBlock *blk)
+{
+    if (!p || !blk || plane < 1 || plane > 2 || stage < 0 || stage > 2)
+        return FFHIP_EINVAL;
+    FFHipChromaBlock b = *blk;
+    b.avg = stage == ST_AVG;
+    p->cmc[plane - 1][stage].push_back(b);
+    return 0;
+}
+
+extern "C" int ffhip_h264_picture_weight(FFHipH264Picture *p, int plane, const FFHipWeightBlock *blk)
+{
+    if (!p || !blk || plane < 0 || plane > 2)
+        return FFHIP_EINVAL;
+    p->wt[plane].push_back(*blk);
+    return 0;
+}
+
+extern "C" int ffhip_h264_picture_idct_add(FFHipH264Picture *p, int plane, int kind, int32_t dst_offset, int16_t *block)
+{
+    if (!p || !block || plane < 0 || plane > 2 || kind < FFHIP_H264_IDCT4 || kind > FFHIP_H264_IDCT8_DC)
+        return FFHIP_EINVAL;
+    const int ncoef = (kind == FFHIP_H264_IDCT8 || kind == FFHIP_H264_IDCT8_DC) ? 64 : 16;
+    p->idct_off[plane][kind].push_back(dst_offset);
+    std::vector<int16_t> &c = p->idct_coef[plane][kind];
+    c.insert(c.end(), block, block + ncoef);
+    /* the side effect of the dsp function the decoder relies on: coefficients are consumed (h264idct_template.c:66,142,
+     * and block[0] = 0 for the dc forms) */
+    if (kind == FFHIP_H264_IDCT4_DC || kind == FFHIP_H264_IDCT8_DC)
+        block[0] = 0;
+    else
+        memset(block, 0, sizeof(int16_t) * ncoef);
+    return 0;
+}
+
+extern "C" int ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int mb_y, const FFHipH264Edge *e)
+{
+    if (!p || !e || plane < 0 || plane > 2 || mb_x < 0 || mb_x >= p->mb_w || mb_y < 0 || mb_y >= p->mb_h)
+        return FFHIP_EINVAL;
+    const int per = plane ? 4 : 8;
+    memcpy(&p->edges[plane][((size_t)mb_y * p->mb_w + mb_x) * per], e, sizeof(FFHipH264Edge) * per);
+    p->any_edge[plane] = true;
+    return 0;
+}
+
+/* ---- flush ------------------------------------------------------------------------------------------ */
+extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
+                                        void *stream_)
+{
+    if (!p || !dst || !stride || !ref)
+        return FFHIP_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int pl = 0; pl < 3; pl++)
+        if (!dst[pl] || !ref[pl] || stride[pl] <= 0)
+            return FFHIP_EINVAL;
+
+    /* layout of the one staging buffer */
+    size_t total = 0;
+    Section s_qpel[3], s_cmc[2][3], s_wt[3], s_ioff[3][4], s_icoef[3][4], s_edge[3];
+    for (int s = 0; s < 3; s++) {
+        place(total, p->qpel[s], s_qpel[s]);
+        place(total, p->cmc[0][s], s_cmc[0][s]);
+        place(total, p->cmc[1][s], s_cmc[1][s]);
+    }
+    for (int pl = 0; pl < 3; pl++) {
+        place(total, p->wt[pl], s_wt[pl]);
+        for (int k = 0; k < 4; k++) {
+            place(total, p->idct_off[pl][k], s_ioff[pl][k]);
+            place(total, p->idct_coef[pl][k], s_icoef[pl][k]);
+        }
+        if (p->any_edge[pl])
+            place(total, p->edges[pl], s_edge[pl]);
+    }
+    total = (total + 255) & ~(size_t)255;
+    if (p->copy_pending) { /* the previous picture's records are still leaving the pinned buffer */
+        HIP_TRY(hipEventSynchronize(p->copied));
+        p->copy_pending = false;
+    }
+    if (total > p->pinned_sz) {
+        if (p->pinned)
+            (void)hipHostFree(p->pinned);
+        p->pinned = nullptr;
+        p->pinned_sz = 0;
+        const size_t want = total + total / 2;
+        if (hipHostMalloc(&p->pinned, want, hipHostMallocDefault) != hipSuccess) {
+            ffhip_set_error("ffhip_h264_picture_flush: hipHostMalloc(%zu) failed", want);
+            return FFHIP_ENOMEM;
+        }
+        p->pinned_sz = want;
+    }
+    if (total > p->dev_sz) {
+        /* the old buffer may still be read by launches of the previous picture on this stream */
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (p->dev)
+            (void)hipFree(p->dev);
+        p->dev = nullptr;
+        p->dev_sz = 0;
+        const size_t want = total + total / 2;
+        if (hipMalloc(&p->dev, want) != hipSuccess) {
+            ffhip_set_error("ffhip_h264_picture_flush: hipMalloc(%zu) failed", want);
+            return FFHIP_ENOMEM;
+        }
+        p->dev_sz = want;
+    }
+    uint8_t *hb = (uint8_t *)p->pinned, *db = (uint8_t *)p->dev;
+    auto put = [&](const Section &s, const void *src, size_t bytes) {
+        if (bytes)
+            memcpy(hb + s.off, src, bytes);
+    };
+    bool need_tmp[3] = { false, false, false };
+    for (int s = 0; s < 3; s++) {
+        put(s_qpel[s], p->qpel[s].data(), p->qpel[s].size() * sizeof(FFHipQpelBlock));
+        for (int c = 0; c < 2; c++)
+            put(s_cmc[c][s], p->cmc[c][s].data(), p->cmc[c][s].size() * sizeof(FFHipChromaBlock));
+    }
+    need_tmp[0] = !p->qpel[ST_TMP].empty();
+    need_tmp[1] = !p->cmc[0][ST_TMP].empty();
+    need_tmp[2] = !p->cmc[1][ST_TMP].empty();
+    for (int pl = 0; pl < 3; pl++) {
+        put(s_wt[pl], p->wt[pl].data(), p->wt[pl].size() * sizeof(FFHipWeightBlock));
+        for (const FFHipWeightBlock &w : p->wt[pl])
+            need_tmp[pl] = need_tmp[pl] || w.bi;
+        for (int k = 0; k < 4; k++) {
+            put(s_ioff[pl][k], p->idct_off[pl][k].data(), p->idct_off[pl][k].size() * sizeof(int32_t));
+            put(s_icoef[pl][k], p->idct_coef[pl][k].data(), p->idct_coef[pl][k].size() * sizeof(int16_t));
+        }
+        if (p->any_edge[pl])
+            put(s_edge[pl], p->edges[pl].data(), p->edges[pl].size() * sizeof(FFHipH264Edge));
+    }
+    /* bi-prediction scratch planes: same stride as the picture (the MC kernels take one stride for both operands) */
+    for (int pl = 0; pl < 3; pl++) {
+        if (!need_tmp[pl])
+            continue;
+        const size_t rows = (size_t)p->mb_h * (pl ? 8 : 16), need = rows * (size_t)stride[pl] + 64;
+        if (need > p->tmp_sz[pl]) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (p->tmp[pl])
+                (void)hipFree(p->tmp[pl]);
+            p->tmp[pl] = nullptr;
+            p->tmp_sz[pl] = 0;
+            if (hipMalloc((void **)&p->tmp[pl], need) != hipSuccess) {
+                ffhip_set_error("ffhip_h264_picture_flush: scratch plane hipMalloc(%zu) failed", need);
+                return FFHIP_ENOMEM;
+            }
+            p->tmp_sz[pl] = need;
+        }
+    }
+    if (total) {
+        HIP_TRY(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(p->copied, stream));
+        p->copy_pending = true;
+    }
+
+    int r = 0;
+    /* ---- prediction ---- */
+    for (int s = 0; s < 3 && r >= 0; s++) {
+        uint8_t *target = s == ST_TMP ? p->tmp[0] : dst[0];
+        if (s_qpel[s].n)
+            r = ffhip_launch_h264_qpel(target, ref[0], stride[0], (const FFHipQpelBlock *)(db + s_qpel[s].off), s_qpel[s].n, stream);
+        for (int c = 0; c < 2 && r >= 0; c++) {
+            uint8_t *ct = s == ST_TMP ? p->tmp[1 + c] : dst[1 + c];
+            if (s_cmc[c][s].n)
+                r = ffhip_launch_h264_chroma_mc(ct, ref[1 + c], stride[1 + c], (const FFHipChromaBlock *)(db + s_cmc[c][s].off), s_cmc[c][s].n,
+                                                stream);
+        }
+    }
+    for (int pl = 0; pl < 3 && r >= 0; pl++)
+        if (s_wt[pl].n)
+            r = ffhip_launch_h264_weight(dst[pl], p->tmp[pl] ? p->tmp[pl] : dst[pl], stride[pl], (const FFHipWeightBlock *)(db + s_wt[pl].off),
+                                         s_wt[pl].n, stream);
+    /* ---- residual ---- */
+    for (int pl = 0; pl < 3 && r >= 0; pl++)
+        for (int k = 0; k < 4 && r >= 0; k++)
+            if (s_ioff[pl][k].n)
+                r = ffhip_launch_h264_idct_add(k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off),
+                                               (int16_t *)(db + s_icoef[pl][k].off), s_ioff[pl][k].n, stream);
+    /* ---- in-loop filter, decoder order: the planes are independent, and a lone wavefront is a chain of dependent hand-offs
+     * that leaves the GPU mostly idle — the chroma planes run beside the luma plane on the second stream, and as ONE launch
+     * of two "pictures" when Cr follows Cb at a 4-byte aligned distance and both are filtered ---- */
+    if (r < 0)
+        return r;
+    const bool chroma = p->any_edge[1] || p->any_edge[2];
+    if (chroma) {
+        HIP_TRY(hipEventRecord(p->fork, stream));
+        HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
+        const ptrdiff_t gap = dst[2] - dst[1];
+        if (p->any_edge[1] && p->any_edge[2] && stride[1] == stride[2] && gap > 0 && !(gap & 3) &&
+            s_edge[2].off == s_edge[1].off + p->edges[1].size() * sizeof(FFHipH264Edge)) {
+            r = ffhip_launch_h264_deblock_frames_chroma(dst[1], (size_t)gap, 2, stride[1], p->mb_w, p->mb_h,
+                                                        (const FFHipH264Edge *)(db + s_edge[1].off), p->aux);
+        } else {
+            for (int pl = 1; pl < 3 && r >= 0; pl++)
+                if (p->any_edge[pl])
+                    r = ffhip_launch_h264_deblock_frames_chroma(dst[pl], 0, 1, stride[pl], p->mb_w, p->mb_h,
+                                                                (const FFHipH264Edge *)(db + s_edge[pl].off), p->aux);
+        }
+        HIP_TRY(hipEventRecord(p->join, p->aux));
+    }
+    if (r >= 0 && p->any_edge[0])
+        r = ffhip_launch_h264_deblock_frame(dst[0], stride[0], p->mb_w, p->mb_h, (const FFHipH264Edge *)(db + s_edge[0].off), stream);
+    if (chroma)
+        HIP_TRY(hipStreamWaitEvent(stream, p->join, 0));
+    return r < 0 ? r : 0;
+}

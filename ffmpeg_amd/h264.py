@@ -66,3 +66,49 @@ def weight_batch(dst, src, stride, blocks, n, stream=None):
     """blocks: uint8 [n, 20] FFHipWeightBlock records; src may be None when no record is a biweight"""
     return _lib.check(_lib.lib().ffhip_h264_weight_batch_dev(dst.data_ptr(), src.data_ptr() if src is not None else None, stride,
                                                              blocks.data_ptr(), n, _stream(stream)), "ffhip_h264_weight_batch_dev")
+
+
+MC_PUT, MC_TMP, MC_AVG = 0, 1, 2
+
+
+class Picture:
+    """ctypes mirror of FFHipH264Picture: record a picture's per-block dsp calls on the host, flush them as a handful of
+    launches (include/ffhip.h).  Records are numpy structured scalars / arrays of the batch faces' dtypes."""
+
+    def __init__(self, mb_w, mb_h):
+        self._p = _lib.vp()
+        _lib.check(_lib.lib().ffhip_h264_picture_create(C.byref(self._p), mb_w, mb_h), "ffhip_h264_picture_create")
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p:
+            _lib.lib().ffhip_h264_picture_free(C.byref(self._p))
+        self._p = None
+
+    __del__ = close
+
+    def begin(self):
+        _lib.lib().ffhip_h264_picture_begin(self._p)
+
+    def mc_luma(self, stage, rec):
+        return _lib.check(_lib.lib().ffhip_h264_picture_mc_luma(self._p, stage, rec.ctypes.data), "ffhip_h264_picture_mc_luma")
+
+    def mc_chroma(self, plane, stage, rec):
+        return _lib.check(_lib.lib().ffhip_h264_picture_mc_chroma(self._p, plane, stage, rec.ctypes.data), "ffhip_h264_picture_mc_chroma")
+
+    def weight(self, plane, rec):
+        return _lib.check(_lib.lib().ffhip_h264_picture_weight(self._p, plane, rec.ctypes.data), "ffhip_h264_picture_weight")
+
+    def idct_add(self, plane, kind, dst_offset, block):
+        return _lib.check(_lib.lib().ffhip_h264_picture_idct_add(self._p, plane, kind, dst_offset, block.ctypes.data),
+                          "ffhip_h264_picture_idct_add")
+
+    def deblock_mb(self, plane, mb_x, mb_y, edges):
+        return _lib.check(_lib.lib().ffhip_h264_picture_deblock_mb(self._p, plane, mb_x, mb_y, edges.ctypes.data),
+                          "ffhip_h264_picture_deblock_mb")
+
+    def flush(self, dst, strides, ref, stream=None):
+        """dst / ref: three uint8 cuda tensors each (Y, Cb, Cr); strides: their row pitches in bytes"""
+        dp = (C.c_void_p * 3)(*[t.data_ptr() for t in dst])
+        rp = (C.c_void_p * 3)(*[t.data_ptr() for t in ref])
+        st = (C.c_int * 3)(*strides)
+        return _lib.check(_lib.lib().ffhip_h264_picture_flush(self._p, dp, st, rp, _stream(stream)), "ffhip_h264_picture_flush")

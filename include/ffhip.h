@@ -347,6 +347,39 @@ int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stri
                                 void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* libavcodec: caller-side batching for the H.264 macroblock loop           */
+/* ------------------------------------------------------------------------------------------ */
+/**
+ * A picture's worth of per-block dsp calls, recorded on the host while the decoder parses the picture and run as a handful of
+ * launches.  The record functions take the operands hl_decode_mb() passes to the dsp pointers (libavcodec/h264_mb_template.c:41-270,
+ * h264_mb.c:206-420,612-800) and ff_h264_filter_mb() computes (h264_loopfilter.c:716); flush() runs, per plane,
+ *     MC put -> picture | MC put -> bi-prediction scratch | MC avg -> picture | weight / biweight | IDCT + add | deblock (decoder order)
+ * 4:2:0, 8 bits.  All planes of the picture, of the references and the scratch share one stride per plane (qpel_mc_func has one).
+ * ref[pl] is the base the blocks' src_offset counts from — typically the decoded-picture-buffer allocation, so that one base
+ * reaches every reference picture.  One object serves one stream; begin() starts the next picture (flush() does not clear).
+ */
+typedef struct FFHipH264Picture FFHipH264Picture;
+#define FFHIP_H264_MC_PUT 0   /* put into the picture                                              */
+#define FFHIP_H264_MC_TMP 1   /* put into the bi-prediction scratch plane (sl->bipred_scratchpad)  */
+#define FFHIP_H264_MC_AVG 2   /* avg onto the picture: the second list of an unweighted bi-prediction */
+int  ffhip_h264_picture_create(FFHipH264Picture **p, int mb_w, int mb_h);
+void ffhip_h264_picture_free(FFHipH264Picture **p);
+void ffhip_h264_picture_begin(FFHipH264Picture *p);
+/** mc_dir_part(): qpix_op[luma_xy] and chroma_op (h264_mb.c:206-300); blk->avg is set from `stage`. */
+int  ffhip_h264_picture_mc_luma(FFHipH264Picture *p, int stage, const FFHipQpelBlock *blk);
+int  ffhip_h264_picture_mc_chroma(FFHipH264Picture *p, int plane /* 1 Cb, 2 Cr */, int stage, const FFHipChromaBlock *blk);
+/** mc_part_weighted(): weight_op / biweight_op (h264_mb.c:340-420); a biweight's src_offset addresses the scratch plane. */
+int  ffhip_h264_picture_weight(FFHipH264Picture *p, int plane, const FFHipWeightBlock *blk);
+/** idct_add / idct8_add / idct_dc_add / idct8_dc_add: the 16 / 64 coefficients are copied and the caller's block is consumed
+ *  exactly as the dsp function does (zeroed; dc forms: block[0] = 0). */
+int  ffhip_h264_picture_idct_add(FFHipH264Picture *p, int plane, int kind, int32_t dst_offset, int16_t *block);
+/** ff_h264_filter_mb(): the macroblock's edge records, 8 for luma ((dir * 4 + e)), 4 for a chroma plane ((dir * 2 + e)). */
+int  ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int mb_y, const FFHipH264Edge *edges);
+/** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
+int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
+                              void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* libavutil: AVFloatDSPContext vector operations around the MDCT           */
 /* ------------------------------------------------------------------------------------------ */
 /** The float members of AVFloatDSPContext an (I)MDCT pipeline uses (libavutil/float_dsp.h:31-175; windowing and

@@ -1,0 +1,171 @@
+"""GPU parity of the caller-side batching layer: a synthetic 4:2:0 picture is "decoded" macroblock by
+macroblock — every dsp call the reference's hl_decode_mb() / ff_h264_filter_mb() would make is recorded — flushed as a handful
+of launches, and compared with the oracle making the same calls one by one in decoder order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import ptr, u8p
+
+pytestmark = pytest.mark.gpu
+
+QPEL_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy", np.uint8), ("size_idx", np.uint8), ("avg", np.uint8),
+                    ("pad", np.uint8)])
+CHROMA_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("h", np.uint8), ("x", np.uint8),
+                      ("y", np.uint8), ("avg", np.uint8), ("pad", np.uint8, 3)])
+WEIGHT_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("height", np.uint8),
+                      ("log2_denom", np.uint8), ("bi", np.uint8), ("weightd", np.int16), ("weights", np.int16), ("offset", np.int16),
+                      ("pad", np.int16)])
+EDGE_DT = np.dtype([("offset", np.int32), ("kind", np.uint8), ("alpha", np.uint8), ("beta", np.uint8), ("pad", np.uint8), ("tc0", np.int8, 4)])
+LADDER = np.array([(4, 2), (15, 4), (40, 9), (80, 13), (255, 18)])
+IDCT_FN = ["ffo_h264_idct_add", "ffo_h264_idct8_add", "ffo_h264_idct_dc_add", "ffo_h264_idct8_dc_add"]
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _at(a, off):
+    return C.cast(a.ctypes.data + int(off), u8p)
+
+
+def _make_mb(rng, mx, my, W, H, P, sy, sc):
+    """the dsp calls of one macroblock as plain data: ("mc", plane, stage, record), ("w", plane, record), ("idct", plane, kind,
+    offset, block), ("edges", plane, records)"""
+    calls = []
+    inter = rng.random() < .8
+    if inter:
+        parts = [(0, 0, 0)] if rng.random() < .5 else [(1, 0, 0), (1, 8, 0), (1, 0, 8), (1, 8, 8)]
+        for size_idx, px, py in parts:
+            size = 16 >> size_idx
+            mode = str(rng.choice(["uni", "uni_w", "bi", "bi_w"]))
+            x, y = mx * 16 + px, my * 16 + py
+            do, cdo = y * sy + x, (y // 2) * sc + x // 2
+            for li in range(1 if mode.startswith("uni") else 2):
+                stage = 0 if li == 0 else (2 if mode == "bi" else 1)          # FFHIP_H264_MC_PUT / _AVG / _TMP
+                refi = int(rng.integers(0, 2))
+                dy, dx = (int(v) for v in rng.integers(-20, 21, 2))
+                fx, fy = (int(v) for v in rng.integers(0, 4, 2))
+                q = np.zeros(1, QPEL_DT)
+                q[0] = (do, (refi * (H + 2 * P) + P + y + dy) * sy + P + x + dx, fx + 4 * fy, size_idx, 0, 0)
+                calls.append(("mc", 0, stage, q))
+                cw = size // 2
+                for pl in (1, 2):
+                    c = np.zeros(1, CHROMA_DT)
+                    c[0] = (cdo, (refi * (H // 2 + P) + P // 2 + y // 2 + dy // 2) * sc + P // 2 + x // 2 + dx // 2, 0 if cw == 8 else 1, cw,
+                            int(rng.integers(0, 8)), int(rng.integers(0, 8)), 0, (0, 0, 0))
+                    calls.append(("mc", pl, stage, c))
+            if mode.endswith("_w"):
+                den, of = int(rng.integers(0, 8)), int(rng.integers(-20, 21))
+                wd, ws = int(rng.integers(-64, 129)), int(rng.integers(-64, 129))
+                for pl in (0, 1, 2):
+                    bs = size if pl == 0 else size // 2
+                    off = do if pl == 0 else cdo
+                    w = np.zeros(1, WEIGHT_DT)
+                    w[0] = (off, off, {16: 0, 8: 1, 4: 2}[bs], bs, den, int(mode == "bi_w"), wd, ws if mode == "bi_w" else 0, of, 0)
+                    calls.append(("w", pl, w))
+    for pl in (0, 1, 2):
+        bsz, st = (16, sy) if pl == 0 else (8, sc)
+        base = my * bsz * st + mx * bsz
+        use8 = pl == 0 and rng.random() < .3
+        step = 8 if use8 else 4
+        for by in range(0, bsz, step):
+            for bx in range(0, bsz, step):
+                r = rng.random()
+                if r < .55:
+                    continue
+                dc = r > .85
+                kind = (3 if dc else 1) if use8 else (2 if dc else 0)
+                blk = np.zeros(64 if use8 else 16, np.int16)
+                if dc:
+                    blk[0] = rng.integers(-400, 401)
+                else:
+                    blk[:] = rng.integers(-200, 201, blk.size) * (rng.random(blk.size) < .4)
+                calls.append(("idct", pl, kind, base + by * st + bx, blk))
+    for pl in (0, 1, 2):
+        ne = 8 if pl == 0 else 4
+        ed = np.zeros(ne, EDGE_DT)
+        sel = rng.integers(0, len(LADDER), ne)
+        ed["alpha"], ed["beta"] = LADDER[sel, 0], LADDER[sel, 1]
+        ed["kind"] = np.where(rng.random(ne) < (.25 if inter else .9), 4, 0) + (2 if pl else 0)
+        ed["tc0"] = rng.integers(-1, 4, (ne, 4))
+        ed["alpha"][rng.random(ne) < .2] = 0
+        calls.append(("edges", pl, ed))
+    return calls
+
+
+@pytest.mark.parametrize("mb_w,mb_h,pictures", [(6, 4, 3), (40, 22, 1)])
+def test_picture_pipeline(mb_w, mb_h, pictures):
+    from ffmpeg_amd import h264
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(mb_w * 31 + mb_h)
+    P = 32                                                    # reference padding: motion vectors may leave the picture
+    W, H = mb_w * 16, mb_h * 16
+    sy, sc = W + 2 * P, W // 2 + P                            # one stride per plane for picture, references and scratch
+    strides = [sy, sc, sc]
+    # two reference pictures per plane inside ONE allocation (the DPB), reached through src_offset
+    refs = [rng.integers(0, 256, (2 * (H + 2 * P), sy), dtype=np.uint8), rng.integers(0, 256, (2 * (H // 2 + P), sc), dtype=np.uint8),
+            rng.integers(0, 256, (2 * (H // 2 + P), sc), dtype=np.uint8)]
+    d_refs = [torch.from_numpy(r).cuda() for r in refs]
+    pic = h264.Picture(mb_w, mb_h)
+    for it in range(pictures):
+        dst0 = [rng.integers(0, 256, (H, sy), dtype=np.uint8), rng.integers(0, 256, (H // 2, sc), dtype=np.uint8),
+                rng.integers(0, 256, (H // 2, sc), dtype=np.uint8)]
+        want = [a.copy() for a in dst0]
+        tmp = [np.zeros_like(a) for a in dst0]                # the oracle's bi-prediction scratch
+        edges = [np.zeros(mb_w * mb_h * (8 if pl == 0 else 4), EDGE_DT) for pl in range(3)]
+        pic.begin()
+        for my in range(mb_h):
+            for mx in range(mb_w):
+                for call in _make_mb(rng, mx, my, W, H, P, sy, sc):
+                    if call[0] == "mc":
+                        _, pl, stage, rec = call
+                        tgt = tmp[pl] if stage == h264.MC_TMP else want[pl]
+                        r = rec[0]
+                        if pl == 0:
+                            pic.mc_luma(stage, rec)
+                            O.ffo_h264_qpel(int(stage == h264.MC_AVG), int(r["size_idx"]), int(r["mcxy"]), _at(tgt, r["dst_offset"]),
+                                            _at(refs[0], r["src_offset"]), sy)
+                        else:
+                            pic.mc_chroma(pl, stage, rec)
+                            O.ffo_h264_chroma_mc(int(stage == h264.MC_AVG), int(r["h"]), _at(tgt, r["dst_offset"]), _at(refs[pl], r["src_offset"]),
+                                                 sc, int(r["h"]), int(r["x"]), int(r["y"]))
+                    elif call[0] == "w":
+                        _, pl, rec = call
+                        pic.weight(pl, rec)
+                        r = rec[0]
+                        wpx = [16, 8, 4, 2][int(r["w_idx"])]
+                        if r["bi"]:
+                            O.ffo_h264_biweight(wpx, _at(want[pl], r["dst_offset"]), _at(tmp[pl], r["src_offset"]), strides[pl], int(r["height"]),
+                                                int(r["log2_denom"]), int(r["weightd"]), int(r["weights"]), int(r["offset"]))
+                        else:
+                            O.ffo_h264_weight(wpx, _at(want[pl], r["dst_offset"]), strides[pl], int(r["height"]), int(r["log2_denom"]),
+                                              int(r["weightd"]), int(r["offset"]))
+                    elif call[0] == "idct":
+                        _, pl, kind, off, blk = call
+                        host = blk.copy()
+                        pic.idct_add(pl, kind, off, host)
+                        assert host[0] == 0 and (kind >= 2 or not host.any())       # consumed as the dsp function does
+                        ob = blk.copy()
+                        getattr(O, IDCT_FN[kind])(_at(want[pl], off), ob.ctypes.data_as(C.POINTER(C.c_int16)), strides[pl])
+                    else:
+                        _, pl, ed = call
+                        pic.deblock_mb(pl, mx, my, ed)
+                        ne = len(ed)
+                        edges[pl][(my * mb_w + mx) * ne:(my * mb_w + mx + 1) * ne] = ed
+        O.ffo_h264_deblock_frame(ptr(want[0]), sy, mb_w, mb_h, C.c_void_p(edges[0].ctypes.data))
+        for pl in (1, 2):
+            O.ffo_h264_deblock_frame_chroma(ptr(want[pl]), sc, mb_w, mb_h, C.c_void_p(edges[pl].ctypes.data))
+        d_dst = [torch.from_numpy(a.copy()).cuda() for a in dst0]
+        pic.flush(d_dst, strides, d_refs)
+        torch.cuda.synchronize()
+        for pl in range(3):
+            got = d_dst[pl].cpu().numpy()
+            assert (want[pl] != dst0[pl]).sum() > 1000
+            assert np.array_equal(got, want[pl]), "picture %d plane %d: %d mismatches" % (it, pl, (got != want[pl]).sum())
+    pic.close()

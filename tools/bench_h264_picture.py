@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""tools/bench_h264_picture.py — the caller-side batching layer on a 4K P-picture (240x135 MBs, 4:2:0): every macroblock 16x16
+uni-predicted at a random quarter-sample position, about half of its 8x8 luma / a third of its 4x4 chroma blocks carry a
+residual, every edge is filtered.  Times flush() — one record upload + the launches — with HIP events; the recording itself is
+done here through ctypes (a decoder appends records in C)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from ffmpeg_amd import h264  # noqa: E402
+from test_gpu_h264_picture import QPEL_DT, CHROMA_DT, EDGE_DT  # noqa: E402
+
+dev = torch.device("cuda", 0)
+mb_w, mb_h, P = 240, 135, 32
+W, H = mb_w * 16, mb_h * 16
+sy, sc = W + 2 * P, W // 2 + P
+rng = np.random.default_rng(4)
+refs = [torch.randint(0, 256, (H + 2 * P, sy), dtype=torch.uint8, device=dev), torch.randint(0, 256, (H // 2 + P, sc), dtype=torch.uint8, device=dev),
+        torch.randint(0, 256, (H // 2 + P, sc), dtype=torch.uint8, device=dev)]
+dst = [torch.zeros((H, sy), dtype=torch.uint8, device=dev), torch.zeros((H // 2, sc), dtype=torch.uint8, device=dev),
+       torch.zeros((H // 2, sc), dtype=torch.uint8, device=dev)]
+pic = h264.Picture(mb_w, mb_h)
+
+
+def record():
+    pic.begin()
+    n = {"mc": 0, "idct": 0}
+    q, c = np.zeros(1, QPEL_DT), np.zeros(1, CHROMA_DT)
+    ed8, ed4 = np.zeros(8, EDGE_DT), np.zeros(4, EDGE_DT)
+    for e in (ed8, ed4):
+        e["alpha"], e["beta"] = 40, 9
+        e["tc0"] = 1
+    ed4["kind"] = 2
+    blk8, blk4 = np.zeros(64, np.int16), np.zeros(16, np.int16)
+    for my in range(mb_h):
+        for mx in range(mb_w):
+            x, y = mx * 16, my * 16
+            dy, dx = (int(v) for v in rng.integers(-16, 17, 2))
+            q[0] = (y * sy + x, (P + y + dy) * sy + P + x + dx, int(rng.integers(0, 16)), 0, 0, 0)
+            pic.mc_luma(h264.MC_PUT, q)
+            for pl in (1, 2):
+                c[0] = ((y // 2) * sc + x // 2, (P // 2 + y // 2 + dy // 2) * sc + P // 2 + x // 2 + dx // 2, 0, 8, int(rng.integers(0, 8)),
+                        int(rng.integers(0, 8)), 0, (0, 0, 0))
+                pic.mc_chroma(pl, h264.MC_PUT, c)
+            n["mc"] += 3
+            for by in (0, 8):
+                for bx in (0, 8):
+                    if rng.random() < .5:
+                        blk8[:] = 0
+                        blk8[:6] = rng.integers(-80, 81, 6)
+                        pic.idct_add(0, 1, (y + by) * sy + x + bx, blk8)
+                        n["idct"] += 1
+            for pl in (1, 2):
+                for by in (0, 4):
+                    for bx in (0, 4):
+                        if rng.random() < .3:
+                            blk4[:] = 0
+                            blk4[:3] = rng.integers(-80, 81, 3)
+                            pic.idct_add(pl, 0, (y // 2 + by) * sc + x // 2 + bx, blk4)
+                            n["idct"] += 1
+            pic.deblock_mb(0, mx, my, ed8)
+            pic.deblock_mb(1, mx, my, ed4)
+            pic.deblock_mb(2, mx, my, ed4)
+    return n
+
+
+t0 = time.perf_counter()
+counts = record()
+t_rec = time.perf_counter() - t0
+strides = [sy, sc, sc]
+pic.flush(dst, strides, refs)
+torch.cuda.synchronize()
+reps = 10
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter()
+e0.record()
+for _ in range(reps):
+    pic.flush(dst, strides, refs)          # the same records again: flush() does not clear
+e1.record()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / reps * 1e3
+ms = e0.elapsed_time(e1) / reps
+print(json.dumps({"case": "h264 4K P-picture through ffhip_h264_picture_flush (MC + IDCT + frame-order deblock, Y/Cb/Cr)",
+                  "macroblocks": mb_w * mb_h, "mc_calls": counts["mc"], "idct_calls": counts["idct"], "ms_per_picture_gpu": round(ms, 3),
+                  "ms_per_picture_wall": round(wall, 3), "pictures_per_s": round(1e3 / ms, 1),
+                  "python_recording_s": round(t_rec, 2)}), flush=True)
+pic.close()
