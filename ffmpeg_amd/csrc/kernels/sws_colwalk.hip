@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
             Ca[g][i] = Cm[g][i] = Cb[g][i] = 0;
             hprev[g][i] = cprev[g][i] = 0;
         }
-    int kround = 1 << 18;
+    int kround = A.vround;
     asm volatile("" : "+v"(kround));
 
     const int ny = y1 - y0;

@@ -145,6 +145,7 @@ struct FFHipCwRgbArgs {
     const int16_t *hlf; const int32_t *hlp; const int16_t *hcf; const int32_t *hcp;
     const int16_t *vlf; const int32_t *vlp; const int16_t *vcf; const int32_t *vcp;
     int ncb, nstrips, strip_rows, nframes;
+    int vround;                /* seed of the vertical sums: 1 << 18 (yuv2rgb_X, and _1 which equals it), 0 (yuv2rgb_2) */
     FFHipYuv2RgbK k;
 };
 int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream);

@@ -35,6 +35,7 @@ struct FFHipSwsContext {
     int cw_opt = 0; /* ... and no horizontal sum can wrap int16: the hand-scheduled variant applies */
     int cw_dup = 0; /* ... and columns 1,2 of every group share a window (exact 2x): one unpack serves both */
     int cw_rgb = 0; /* packed-RGB target on the column walker (k_sws_colwalk_rgb) */
+    int cw_vround = 1 << 18; /* its vertical rounding seed: yuv2rgb_X / _1: 1 << 18, yuv2rgb_2: 0 */
     /* wide-bank walker (sws_lwalk.hip): banks padded to 4*lw_ht x 2*lw_vt taps */
     int lw_ok = 0, lw_ht = 0, lw_vt = 0;
     std::vector<int16_t> wf[4];
@@ -101,11 +102,40 @@ static int make_k(const FFHipSwsTables &t, FFHipYuv2RgbK *k)
 static bool build_fast_view(FFHipSwsContext *c, const int limits[4], bool packed_rgb)
 {
     bool ok = true, padded = false;
-    /* packed RGB: the reference picks yuv2rgb_1 / _2 / _X by the vertical sizes (vscale.c:126-170; _1 and _2 round
-     * differently); _X — plain sums, which zero taps do not change — is what it runs as soon as either vertical bank has
-     * 3+ taps, e.g. the unscaled ACCURATE_RND conversion (1-tap luma, 4-tap chroma) */
-    if (packed_rgb && c->d[2].size < 3 && c->d[3].size < 3)
-        return false;
+    /*
+     * Packed RGB: the reference picks yuv2rgb_1 / _2 / _X per output row from the vertical sizes and weights
+     * (packed_vscale, vscale.c:126-170).  All three are the same sums with a different rounding seed:
+     *   _X   Y = (sum + (1 << 18)) >> 19 — and plain sums do not change when zero taps pad a bank to 4;
+     *   _1   Y = (l + 64) >> 7 = (l * 4096 + (1 << 18)) >> 19, chroma (u0 * (4096 - a) + u1 * a + (128 << 11)) >> 19: _X's
+     *        formula whenever the single taps are 4096 (output.c:1883-1939);
+     *   _2   the two-tap sums with NO rounding term (output.c:1843-1881), taken when both banks have 2 taps and every row's
+     *        weights are non-negative and sum to 4096 (bilinear).
+     * So the walker serves every shape whose rows agree on the seed; rows that disagree (never seen from initFilter) go to the
+     * general kernel.
+     */
+    if (packed_rgb) {
+        const int lf = c->d[2].size, cf = c->d[3].size;
+        c->cw_vround = 1 << 18;
+        if (lf == 1 || cf == 1) {
+            for (int i = 2; i < 4; i++)
+                if (c->d[i].size == 1)
+                    for (int y = 0; y < c->d[i].n; y++)
+                        if (c->f[i][y] != 4096)
+                            return false;
+        }
+        if (lf == 2 && cf == 2) {
+            int two = 0;
+            const int n = c->d[2].n < c->d[3].n ? c->d[2].n : c->d[3].n; /* chrDstH == dstH for packed targets */
+            for (int y = 0; y < n; y++) {
+                const int l0 = c->f[2][2 * y], l1 = c->f[2][2 * y + 1], c0 = c->f[3][2 * y], c1 = c->f[3][2 * y + 1];
+                two += l0 + l1 == 4096 && (unsigned)l1 <= 4096u && c0 + c1 == 4096 && (unsigned)c1 <= 4096u;
+            }
+            if (two == n)
+                c->cw_vround = 0;
+            else if (two)
+                return false;
+        }
+    }
     for (int i = 0; i < 4 && ok; i++) {
         const int fs = c->d[i].size, n = c->d[i].n;
         if (fs > 4 || limits[i] < 4) { ok = false; break; }
@@ -484,7 +514,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             R.srcW = a.srcW; R.srcH = a.srcH; R.chrSrcW = a.chrSrcW; R.chrSrcH = a.chrSrcH; R.dstW = a.dstW; R.dstH = a.dstH;
             R.hlf = c->dn[0].filter; R.hlp = c->dn[0].pos; R.hcf = c->dn[1].filter; R.hcp = c->dn[1].pos;
             R.vlf = c->dn[2].filter; R.vlp = c->dn[2].pos; R.vcf = c->dn[3].filter; R.vcp = c->dn[3].pos;
-            R.nframes = nframes; R.k = c->k;
+            R.nframes = nframes; R.k = c->k; R.vround = c->cw_vround;
             return ffhip_launch_colwalk_rgb(R, stream);
         }
         return ffhip_launch_scale_rgb(a, stream);

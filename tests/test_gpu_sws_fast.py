@@ -283,6 +283,15 @@ RGB_CASES = [
     ("nv12", 192, 108, "bgra", 384, 216, ffi.SWS_BICUBIC),
     ("nv21", 128, 72, "argb", 192, 108, ffi.SWS_BICUBIC),
     ("yuv420p", 1048, 600, "abgr", 2096, 1416, ffi.SWS_BICUBIC),
+    # the other two templates of packed_vscale on the same walker: yuv2rgb_2 (2-tap banks, rows sum to 4096: no rounding term)
+    ("yuv420p", 128, 72, "rgb24", 256, 144, ffi.SWS_BILINEAR),
+    ("nv12", 192, 108, "bgra", 384, 216, ffi.SWS_BILINEAR),
+    ("yuv420p", 96, 64, "bgr24", 136, 200, ffi.SWS_BILINEAR),
+    ("yuv420p", 1048, 600, "rgb24", 2096, 1416, ffi.SWS_BILINEAR),
+    # ... and yuv2rgb_1 (1-tap luma; chroma 1 or 2 taps): horizontal-only scaling of 4:2:0, point sampling
+    ("yuv420p", 128, 72, "rgb24", 256, 72, ffi.SWS_BILINEAR),
+    ("nv12", 128, 72, "rgb24", 256, 72, ffi.SWS_BICUBIC),
+    ("yuv420p", 128, 72, "rgb24", 256, 144, ffi.SWS_POINT),
 ]
 
 
