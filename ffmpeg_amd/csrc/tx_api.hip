@@ -439,25 +439,28 @@ __global__ __launch_bounds__(256) void k_mdct_l(TxDev d, const uint8_t *blob, in
  * Tables (map, exp, twiddles, butterfly lists) are copied to LDS once per workgroup; waves loop over transforms.
  * Same float operations in the same order as k_mdct.
  */
-template <int INV>
+template <int INV, bool TL>
 __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch,
                                                  float *out, size_t out_pitch, int nt, int waves_total)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    {
+    /* TL: the context's tables are copied to LDS once per workgroup (blob_bytes > 0); otherwise they stay in global memory
+     * (L2-resident) and blob_bytes is 0: large transforms, where the copy would cost the workgroup most of its waves */
+    if (TL) {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
         uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
         for (int i = threadIdx.x; i < blob_bytes / 16; i += blockDim.x)
             l4[i] = s4[i];
+        __syncthreads();
     }
-    __syncthreads();
-    const int *l_map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
-    const float2 *l_exp = reinterpret_cast<const float2 *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
-    const float *l_cos = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
-    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
-    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    const uint8_t *const tbase = TL ? lds_raw : blob;
+    const int *l_map = reinterpret_cast<const int *>(tbase + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    const float2 *l_exp = reinterpret_cast<const float2 *>(tbase + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
+    const float *l_cos = reinterpret_cast<const float *>(tbase + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
     const int n = d.n, q = n >> 1;
     float2 *z = reinterpret_cast<float2 *>(lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(n));
 
@@ -518,23 +521,27 @@ __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, i
  * permutation into the padded LDS work array, transformed there by the same flattened split-radix network as the MDCT,
  * and written out in order.  Forward and inverse differ by the permutation only.  16 B moved per complex sample.
  */
+template <bool TL>
 __global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch,
                                                 float *out, size_t out_pitch, int nt, int waves_total)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    {
+    /* TL: the context's tables are copied to LDS once per workgroup (blob_bytes > 0); otherwise they stay in global memory
+     * (L2-resident) and blob_bytes is 0: large transforms, where the copy would cost the workgroup most of its waves */
+    if (TL) {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
         uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
         for (int i = threadIdx.x; i < blob_bytes / 16; i += blockDim.x)
             l4[i] = s4[i];
+        __syncthreads();
     }
-    __syncthreads();
-    const int *l_map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
-    const float *l_cos = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
-    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
-    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    const uint8_t *const tbase = TL ? lds_raw : blob;
+    const int *l_map = reinterpret_cast<const int *>(tbase + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    const float *l_cos = reinterpret_cast<const float *>(tbase + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
     const int n = d.n;
     float2 *z = reinterpret_cast<float2 *>(lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(n));
     for (int t = blockIdx.x * (blockDim.x >> 6) + wave; t < nt; t += waves_total) {
@@ -557,25 +564,28 @@ __global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, in
  * are produced together from the work array straight into global memory; c2r runs the same pass on the way in.  d.exp
  * holds the reference's table as floats: fact[8], tcos[len/4], tsin[len/4].
  */
-template <int INV>
+template <int INV, bool TL>
 __global__ __launch_bounds__(1024) void k_rdft(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch, float *out,
                                                size_t out_pitch, int nt, int waves_total)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    {
+    /* TL: the context's tables are copied to LDS once per workgroup (blob_bytes > 0); otherwise they stay in global memory
+     * (L2-resident) and blob_bytes is 0: large transforms, where the copy would cost the workgroup most of its waves */
+    if (TL) {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
         uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
         for (int i = threadIdx.x; i < blob_bytes / 16; i += blockDim.x)
             l4[i] = s4[i];
+        __syncthreads();
     }
-    __syncthreads();
-    const int *l_map = reinterpret_cast<const int *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.map) - blob));
-    const float *fact = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
-    const float *l_cos = reinterpret_cast<const float *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
-    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
-    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(lds_raw + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    const uint8_t *const tbase = TL ? lds_raw : blob;
+    const int *l_map = reinterpret_cast<const int *>(tbase + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    const float *fact = reinterpret_cast<const float *>(tbase + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
+    const float *l_cos = reinterpret_cast<const float *>(tbase + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
     const int len2 = d.n, len4 = len2 >> 1;
     const float *tcos = fact + 8, *tsin = tcos + len4;
     const float f0 = fact[0], f1 = fact[1], f2 = fact[2], f3 = fact[3], f4 = fact[4], f5 = fact[5], f6 = fact[6], f7 = fact[7];
@@ -1178,11 +1188,17 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             ffhip_set_error("ffhip_tx: FFT / RDFT batches need 8-byte aligned rows");
             return FFHIP_EINVAL;
         }
+        /* tables in LDS while they are small next to the waves' work arrays; the big transforms (n = 2048: 50 KB of tables,
+         * 17 KB per wave) keep them in L2 and spend the LDS on waves (FFHIP_TX_TABLDS=0/1 forces either) */
+        const char *etl = getenv("FFHIP_TX_TABLDS");
+        const bool tl = etl ? etl[0] == '1' : c->blob_bytes <= 32 * 1024;
+        const size_t blob_lds = tl ? (c->blob_bytes + 15) & ~(size_t)15 : 0;
+        const int blob_arg = tl ? (int)c->blob_bytes : 0;
         int wpb = 16;
-        size_t lds_z = ((c->blob_bytes + 15) & ~(size_t)15) + tx_z_bytes(n) * wpb;
+        size_t lds_z = blob_lds + tx_z_bytes(n) * wpb;
         while (wpb > 1 && lds_z > 150 * 1024) {
             wpb >>= 1;
-            lds_z = ((c->blob_bytes + 15) & ~(size_t)15) + tx_z_bytes(n) * wpb;
+            lds_z = blob_lds + tx_z_bytes(n) * wpb;
         }
         int cus = 256, dev = 0;
         hipDeviceProp_t prop;
@@ -1196,23 +1212,27 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             blocks = (nt + wpb - 1) / wpb;
         static bool fft_attr = false;
         if (!fft_attr) {
-            (void)hipFuncSetAttribute((const void *)k_fft_z, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_rdft<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_rdft<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_fft_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_fft_z<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             fft_attr = true;
         }
         if (c->type == FFHIP_TX_FLOAT_RDFT) {
-            if (c->inv)
-                hipLaunchKernelGGL((k_rdft<1>), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
-                                   (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
-            else
-                hipLaunchKernelGGL((k_rdft<0>), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
-                                   (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+#define TX_LAUNCH(K)                                                                                                                  \
+    hipLaunchKernelGGL((K), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev, blob_arg,       \
+                       (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb)
+            if (c->inv) {
+                if (tl) TX_LAUNCH((k_rdft<1, true>)); else TX_LAUNCH((k_rdft<1, false>));
+            } else {
+                if (tl) TX_LAUNCH((k_rdft<0, true>)); else TX_LAUNCH((k_rdft<0, false>));
+            }
             LAUNCH_CHECK();
             return 0;
         }
-        hipLaunchKernelGGL(k_fft_z, dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
-                           (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+        if (tl) TX_LAUNCH((k_fft_z<true>)); else TX_LAUNCH((k_fft_z<false>));
         LAUNCH_CHECK();
         return 0;
     }
@@ -1287,10 +1307,14 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         const char *ew = getenv("FFHIP_TX_WPB");
         int wpb = ew && atoi(ew) > 0 ? atoi(ew) : 16; /* waves per workgroup: 16 measured best (the table copy is shared) */
         if (wpb > 16) wpb = 16;
-        size_t lds_z = ((c->blob_bytes + 15) & ~(size_t)15) + tx_z_bytes(n) * wpb;
+        const char *etl = getenv("FFHIP_TX_TABLDS");
+        const bool tl = etl ? etl[0] == '1' : c->blob_bytes <= 32 * 1024; /* as for the FFT: big transforms keep their tables in L2 */
+        const size_t blob_lds = tl ? (c->blob_bytes + 15) & ~(size_t)15 : 0;
+        const int blob_arg = tl ? (int)c->blob_bytes : 0;
+        size_t lds_z = blob_lds + tx_z_bytes(n) * wpb;
         while (wpb > 1 && lds_z > 150 * 1024) {
             wpb >>= 1;
-            lds_z = ((c->blob_bytes + 15) & ~(size_t)15) + tx_z_bytes(n) * wpb;
+            lds_z = blob_lds + tx_z_bytes(n) * wpb;
         }
         if (es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7) && lds_z <= 150 * 1024 && !(ez && ez[0] == '0')) {
             int cus = 256, dev = 0;
@@ -1305,16 +1329,17 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
                 blocks = (nt + wpb - 1) / wpb;
             static bool attr_done = false;
             if (!attr_done) {
-                (void)hipFuncSetAttribute((const void *)k_mdct_z<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void *)k_mdct_z<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_mdct_z<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_mdct_z<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_mdct_z<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_mdct_z<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_done = true;
             }
-            if (c->inv)
-                hipLaunchKernelGGL((k_mdct_z<1>), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
-                                   (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
-            else
-                hipLaunchKernelGGL((k_mdct_z<0>), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev,
-                                   (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+            if (c->inv) {
+                if (tl) TX_LAUNCH((k_mdct_z<1, true>)); else TX_LAUNCH((k_mdct_z<1, false>));
+            } else {
+                if (tl) TX_LAUNCH((k_mdct_z<0, true>)); else TX_LAUNCH((k_mdct_z<0, false>));
+            }
             LAUNCH_CHECK();
             return 0;
         }

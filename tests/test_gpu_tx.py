@@ -277,3 +277,40 @@ def test_imdct_full_batch(len_, nt):
     assert np.array_equal(one.view(np.uint32), got[1].view(np.uint32))
     O.ffo_mdct_free(oc)
     ctx.close()
+
+
+@pytest.mark.parametrize("tabs", ["0", "1"])
+@pytest.mark.parametrize("typ,len_,inv", [("mdct", 1024, 0), ("mdct", 4096, 1), ("mdct", 256, 1), ("fft", 256, 0), ("fft", 2048, 1),
+                                          ("rdft", 512, 1), ("rdft", 4096, 0)])
+def test_table_placement(typ, len_, inv, tabs, monkeypatch):
+    """the context's tables in LDS (one copy per workgroup) or left in L2 (FFHIP_TX_TABLDS): same bits either way; the default
+    switches at 32 KB of tables (profiles/r01_sweep_tabs.txt)"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    monkeypatch.setenv("FFHIP_TX_TABLDS", tabs)
+    rng = np.random.default_rng(len_ + inv)
+    O = ffi.oracle()
+    nt = 130
+    if typ == "mdct":
+        x = (rng.random((nt, len_ if inv else 2 * len_), dtype=np.float32) * 2 - 1).astype(np.float32)
+        want = _oracle(inv, len_, 1.0, x)
+        ctx = tx.TxContext(tx.FLOAT_MDCT, inv, len_, 1.0)
+    elif typ == "fft":
+        x = rng.standard_normal((nt, 2 * len_)).astype(np.float32)
+        want = np.zeros_like(x)
+        for t in range(nt):
+            O.ffo_fft_run(inv, len_, ptr(want[t], f32p), ptr(x[t], f32p))
+        ctx = tx.TxContext(tx.FLOAT_FFT, inv, len_, 1.0)
+    else:
+        x = rng.standard_normal((nt, len_ + 2 if inv else len_)).astype(np.float32)
+        if inv:
+            x[:, 1] = x[:, -1] = 0
+        want = np.zeros((nt, len_ if inv else len_ + 2), np.float32)
+        for t in range(nt):
+            O.ffo_rdft_run(inv, len_, 1.0, ptr(want[t], f32p), ptr(x[t], f32p))
+        ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, 1.0)
+    d_out = torch.zeros(want.shape, dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out, torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    ctx.close()
