@@ -132,6 +132,16 @@ extern "C" int ffhip_hevc_sao_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, cons
     return ffhip_launch_hevc_sao(dst, stride_dst, src, stride_src, blocks, n, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_vp9_itxfm_add_batch_dev(int tx, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipVp9TU *tus, int n,
+                                             void *stream)
+{
+    if (!coeffs || !dst || !tus || n < 0 || tx < 0 || tx > 4)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_itxfm(tx, coeffs, dst, stride, tus, n, (hipStream_t)stream);
+}
+
 extern "C" int ffhip_hevc_sao_restore_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src,
                                                 const FFHipHevcSaoRestore *blocks, int n, void *stream)
 {

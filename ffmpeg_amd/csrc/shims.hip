@@ -630,3 +630,43 @@ extern "C" int ff_me_cmp_init_hip(FFHipMECmpContext *c)
     c->hadamard8_diff[0] = s_satd16; c->hadamard8_diff[1] = s_satd8;
     return 0;
 }
+
+/* ---- vp9dsp itxfm_add host faces: the block and the size x size picture rectangle travel through scratch ---- */
+static void vp9_itxfm_single(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const int n = tx == 4 ? 4 : 4 << tx, P = 64;
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + (size_t)n * n * 2 + (size_t)n * P + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch;
+    int16_t *dco = (int16_t *)(buf + 64);
+    uint8_t *ddst = buf + 64 + (size_t)n * n * 2;
+    if (hipMemcpy(dco, block, (size_t)n * n * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy2D(ddst, P, dst, stride, n, n, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    FFHipVp9TU k = {};
+    k.txtp = (uint8_t)txtp; k.dc_only = eob == 1;
+    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_vp9_itxfm(tx, dco, ddst, P, (const FFHipVp9TU *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    (void)hipMemcpy(block, dco, (size_t)n * n * 2, hipMemcpyDeviceToHost);
+    (void)hipMemcpy2D(dst, stride, ddst, P, n, n, hipMemcpyDeviceToHost);
+}
+#define VP9_SHIM(tx, tp) static void s_vp9_itx_##tx##_##tp(uint8_t *d, ptrdiff_t s, int16_t *b, int e) { vp9_itxfm_single(tx, tp, d, s, b, e); }
+#define VP9_SHIMS(tx) VP9_SHIM(tx, 0) VP9_SHIM(tx, 1) VP9_SHIM(tx, 2) VP9_SHIM(tx, 3)
+VP9_SHIMS(0) VP9_SHIMS(1) VP9_SHIMS(2) VP9_SHIMS(3) VP9_SHIMS(4)
+
+extern "C" int ff_vp9dsp_itxfm_init_hip(FFHipVP9ItxfmContext *c, int bpp)
+{
+    if (!c || bpp != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+#define VP9_ROW(tx) c->itxfm_add[tx][0] = s_vp9_itx_##tx##_0; c->itxfm_add[tx][1] = s_vp9_itx_##tx##_1; \
+                    c->itxfm_add[tx][2] = s_vp9_itx_##tx##_2; c->itxfm_add[tx][3] = s_vp9_itx_##tx##_3;
+    VP9_ROW(0) VP9_ROW(1) VP9_ROW(2) VP9_ROW(3) VP9_ROW(4)
+#undef VP9_ROW
+    return 0;
+}

@@ -1,0 +1,30 @@
+"""ctypes mirror of the vp9dsp inverse-transform faces of libffhip (include/ffhip.h): VP9DSPContext.itxfm_add[tx][txtp]
+(libavcodec/vp9dsp.h:71-75), 8 bits."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+#: FFHipVp9TU (include/ffhip.h)
+TU_DTYPE = np.dtype([("coeff_offset", np.int32), ("dst_offset", np.int32), ("txtp", np.uint8), ("dc_only", np.uint8), ("pad", np.uint8, 2)])
+DCT_DCT, DCT_ADST, ADST_DCT, ADST_ADST = 0, 1, 2, 3
+TX_4X4, TX_8X8, TX_16X16, TX_32X32, TX_WHT = 0, 1, 2, 3, 4
+
+
+def itxfm_add_batch(tx, coeffs, dst, stride, tus, n, stream=None):
+    """coeffs: int16 device tensor (consumed); dst: uint8 device tensor; tus: uint8 [n, 12] FFHipVp9TU"""
+    return _lib.check(_lib.lib().ffhip_vp9_itxfm_add_batch_dev(tx, coeffs.data_ptr(), dst.data_ptr(), stride, tus.data_ptr(), n,
+                                                               None if stream is None else C.c_void_p(stream)),
+                      "ffhip_vp9_itxfm_add_batch_dev")
+
+
+class VP9ItxfmContext(C.Structure):
+    """FFHipVP9ItxfmContext: host-pointer faces with the reference's signature"""
+    _fields_ = [("itxfm_add", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int) * 4 * 5)]
+
+
+def dsp_init(bpp=8):
+    c = VP9ItxfmContext()
+    _lib.check(_lib.lib().ff_vp9dsp_itxfm_init_hip(C.byref(c), bpp), "ff_vp9dsp_itxfm_init_hip")
+    return c

@@ -592,6 +592,32 @@ int ffhip_hevc_sao_restore_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, const u
                                      const FFHipHevcSaoRestore *blocks, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* libavcodec: vp9dsp inverse transforms                                    */
+/* ------------------------------------------------------------------------------------------ */
+/** VP9DSPContext.itxfm_add (libavcodec/vp9dsp.h:71-75): [tx][txtp](dst, stride, block, eob); tx 0..3 = TX_4X4..TX_32X32,
+ *  4 = the lossless 4x4 Walsh-Hadamard transform; txtp = enum TxfmType (DCT_DCT 0, DCT_ADST 1, ADST_DCT 2, ADST_ADST 3,
+ *  libavcodec/vp9.h).  The transform adds to dst and consumes the block (zeroed; eob == 1 on DCT_DCT: block[0] only).
+ *  8 bits; host pointers. */
+typedef void (*ffhip_vp9_itxfm_add_func)(uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob);
+typedef struct FFHipVP9ItxfmContext {
+    ffhip_vp9_itxfm_add_func itxfm_add[5][4];
+} FFHipVP9ItxfmContext;
+/** ff_vp9dsp_init_<arch> shape for the itxfm_add table (libavcodec/vp9dsp.c:88-112).  bpp must be 8. */
+int ff_vp9dsp_itxfm_init_hip(FFHipVP9ItxfmContext *c, int bpp);
+
+/** One transform block of the batch face. */
+typedef struct FFHipVp9TU {
+    int32_t coeff_offset; /* int16 elements into coeffs: size * size coefficients, the decoder's layout */
+    int32_t dst_offset;   /* bytes into dst                                                           */
+    uint8_t txtp;         /* enum TxfmType; ignored for 32x32 and the WHT                              */
+    uint8_t dc_only;      /* eob == 1: DCT_DCT takes its dc-only shortcut                              */
+    uint8_t pad[2];       /* sizeof == 12                                                              */
+} FFHipVp9TU;
+/** n blocks of one size (tx as above), pairwise disjoint in coeffs and dst: itxfm_add[tx][txtp] each. */
+int ffhip_vp9_itxfm_add_batch_dev(int tx, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipVp9TU *tus, int n,
+                                  void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */
 /* ------------------------------------------------------------------------------------------ */
 /** me_cmp_func (libavcodec/me_cmp.h:45-48); the context argument is unused by these metrics

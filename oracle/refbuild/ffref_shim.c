@@ -18,6 +18,7 @@
 #include "libavcodec/h264chroma.h"
 #include "libavcodec/me_cmp.h"
 #include "libavcodec/hevc/dsp.h"
+#include "libavcodec/vp9dsp.h"
 #include "libavfilter/motion_estimation.h"
 #include "ffref.h"
 
@@ -260,6 +261,18 @@ void ffref_hevc_sao_edge(int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t st
 {
     dsp_init();
     hevc.sao_edge_filter[idx](dst, src, stride_dst, offset_val, eo, width, height);
+}
+/* ---- vp9dsp: itxfm_add[tx][txtp] (8 bits) ---- */
+void ffref_vp9_itxfm_add(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob)
+{
+    static VP9DSPContext vp9;
+    static int vp9_ready;
+    pure_c();
+    if (!vp9_ready) {
+        ff_vp9dsp_init(&vp9, 8, 1);
+        vp9_ready = 1;
+    }
+    vp9.itxfm_add[tx][txtp](dst, stride, block, eob);
 }
 void ffref_hevc_dequant(int16_t *coeffs, int log2_size)
 {

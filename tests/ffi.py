@@ -110,6 +110,8 @@ def oracle():
         L.ffo_hevc_mc.restype = None
         L.ffo_hevc_mc_w.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, i16p] + [C.c_int] * 8
         L.ffo_hevc_mc_w.restype = None
+        L.ffo_vp9_itxfm_add.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, i16p, C.c_int]
+        L.ffo_vp9_itxfm_add.restype = None
         L.ffo_hevc_dequant.argtypes = [i16p, C.c_int]
         L.ffo_hevc_dequant.restype = None
         L.ffo_hevc_transform_rdpcm.argtypes = [i16p, C.c_int, C.c_int]
@@ -201,6 +203,8 @@ def ref():
         L.ffref_hevc_mc.restype = None
         L.ffref_hevc_mc_w.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, i16p] + [C.c_int] * 8
         L.ffref_hevc_mc_w.restype = None
+        L.ffref_vp9_itxfm_add.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, i16p, C.c_int]
+        L.ffref_vp9_itxfm_add.restype = None
         L.ffref_hevc_dequant.argtypes = [i16p, C.c_int]
         L.ffref_hevc_dequant.restype = None
         L.ffref_hevc_transform_rdpcm.argtypes = [i16p, C.c_int, C.c_int]

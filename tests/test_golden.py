@@ -196,6 +196,17 @@ def test_hevc_golden():
         assert np.array_equal(a8, d["mcw_out"][i]), ("mcw", i)
 
 
+def test_vp9_golden():
+    O = ffi.oracle()
+    d = load("vp9")
+    for tx in range(5):
+        n = 4 if tx == 4 else 4 << tx
+        for i, (txtp, eob) in enumerate(d["tx%d_par" % tx].tolist()):
+            o, b = d["tx%d_dst" % tx][i].copy(), d["tx%d_blk" % tx][i].copy()
+            O.ffo_vp9_itxfm_add(tx, txtp, ptr(o), n, ptr(b, i16p), eob)
+            assert np.array_equal(o, d["tx%d_out" % tx][i]) and np.array_equal(b, d["tx%d_oblk" % tx][i]), (tx, i)
+
+
 def test_fdsp_golden():
     O = ffi.oracle()
     d = load("fdsp")

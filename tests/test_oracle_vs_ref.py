@@ -454,6 +454,41 @@ def test_hevc_mc_weighted():
                         assert np.array_equal(a8, b8), (chroma, mode, w, mx, my, d, wx0, wx1, ox)
 
 
+def vp9_block(rng, n, kind):
+    """coefficient blocks of tests/checkasm/vp9dsp.c's spirit (sparse low-frequency content) plus dense, dc-only and
+    wrap-around ones: the reference's arithmetic is unsigned 32-bit, so every input is defined"""
+    blk = np.zeros(n * n, np.int16)
+    if kind == 0:
+        blk[:] = rng.integers(-1024, 1025, n * n)
+    elif kind == 1:
+        blk[:] = rng.integers(-300, 301, n * n) * (rng.random(n * n) < .2)
+    elif kind == 2:
+        blk[0] = rng.integers(-2000, 2001)
+    elif kind == 3:
+        blk[:] = rng.integers(-8000, 8001, n * n) * (rng.random(n * n) < .05)
+    else:
+        blk[:] = rng.integers(-32768, 32768, n * n)
+    return blk
+
+
+def test_vp9_itxfm_add():
+    """VP9DSPContext.itxfm_add[5][4]: every size x type, dc-only shortcut, block consumption"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(95)
+    for tx in range(5):
+        n = 4 if tx == 4 else 4 << tx
+        for txtp in range(4):
+            for rep in range(40):
+                kind = rep % 5
+                blk = vp9_block(rng, n, kind)
+                eob = 1 if kind == 2 else int(rng.integers(2, n * n + 1))
+                dst0 = rng.integers(0, 256, (n, n + 5), dtype=np.uint8)
+                a, b, ba, bb = dst0.copy(), dst0.copy(), blk.copy(), blk.copy()
+                R.ffref_vp9_itxfm_add(tx, txtp, ptr(a), n + 5, ptr(ba, i16p), eob)
+                O.ffo_vp9_itxfm_add(tx, txtp, ptr(b), n + 5, ptr(bb, i16p), eob)
+                assert np.array_equal(a, b) and np.array_equal(ba, bb), (tx, txtp, rep)
+
+
 def hevc_restore_case(rng, rep):
     """(variant, eo, offset0, borders[4], width, height, vert_edge[2], horiz_edge[2], diag_edge[4]) — every flag on and off"""
     p = .5 if rep % 3 else .85

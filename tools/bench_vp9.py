@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""tools/bench_vp9.py — VP9 itxfm_add batches over 4K luma planes (one GPU, HIP events): every block of a size, types mixed."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from ffmpeg_amd import vp9  # noqa: E402
+
+dev = torch.device("cuda", 0)
+W, H, planes = 3840, 2160, 4
+rng = np.random.default_rng(5)
+for tx in (0, 1, 2, 3):
+    n = 4 << tx
+    hh = (H // n) * n
+    by, bx = np.meshgrid(np.arange(0, planes * hh, n), np.arange(0, W, n), indexing="ij")
+    nb = by.size
+    rec = np.zeros(nb, vp9.TU_DTYPE)
+    rec["coeff_offset"] = np.arange(nb) * n * n
+    rec["dst_offset"] = (by * W + bx).reshape(-1)
+    rec["txtp"] = rng.integers(0, 4, nb)
+    d_rec = torch.from_numpy(rec.view(np.uint8).reshape(nb, 12)).to(dev)
+    pic = torch.randint(0, 256, (planes * hh, W), dtype=torch.uint8, device=dev)
+    src = torch.randint(-300, 301, (nb, n * n), dtype=torch.int16, device=dev)
+    co = src.clone()
+    vp9.itxfm_add_batch(tx, co, pic, W, d_rec, nb)
+    ms = 0.0
+    reps = 5
+    for _ in range(reps):
+        co.copy_(src)                              # the transform consumes its coefficients
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        vp9.itxfm_add_batch(tx, co, pic, W, d_rec, nb)
+        e1.record()
+        torch.cuda.synchronize()
+        ms += e0.elapsed_time(e1) / reps
+    px = nb * n * n
+    byt = px * 6                                   # coefficients read + cleared (2 + 2 B), picture read + written (1 + 1 B)
+    print(json.dumps({"case": "vp9 itxfm_add %dx%d, mixed types, %d 4K planes" % (n, n, planes), "blocks": nb, "ms": round(ms, 4),
+                      "Gpixel/s": round(px / ms / 1e6, 1), "hbm_frac": round(byt / ms / 1e6 / 8000, 4)}), flush=True)

@@ -316,6 +316,29 @@ def hevc():
     np.savez_compressed(os.path.join(OUT, "hevc.npz"), **d)
 
 
+def vp9():
+    """VP9 itxfm_add: per (tx, txtp) 6 blocks (dense / sparse / dc-only / large / wrap-around / sparse); outputs: picture and block"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_vs_ref import vp9_block
+    rng = np.random.default_rng(13)
+    d = {}
+    for tx in range(5):
+        n = 4 if tx == 4 else 4 << tx
+        blks, dsts, outs, oblk, par = [], [], [], [], []
+        for txtp in range(4):
+            for rep in range(6):
+                kind = rep % 5
+                blk = vp9_block(rng, n, kind)
+                eob = 1 if kind == 2 else n * n
+                dst = rng.integers(0, 256, (n, n), dtype=np.uint8)
+                o, b = dst.copy(), blk.copy()
+                R.ffref_vp9_itxfm_add(tx, txtp, ptr(o), n, ptr(b, i16p), eob)
+                blks.append(blk); dsts.append(dst); outs.append(o); oblk.append(b); par.append([txtp, eob])
+        d["tx%d_blk" % tx], d["tx%d_dst" % tx] = np.stack(blks), np.stack(dsts)
+        d["tx%d_out" % tx], d["tx%d_oblk" % tx], d["tx%d_par" % tx] = np.stack(outs), np.stack(oblk), np.array(par, np.int32)
+    np.savez_compressed(os.path.join(OUT, "vp9.npz"), **d)
+
+
 def fdsp():
     """AVFloatDSPContext vector ops: len 1024 and 37, operands across magnitudes (bit patterns stored as uint32)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -338,6 +361,6 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); me(); tx(); fft(); hevc(); fdsp()
+        sws(); h264(); me(); tx(); fft(); hevc(); fdsp(); vp9()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
