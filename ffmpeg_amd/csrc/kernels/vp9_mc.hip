@@ -1,0 +1,246 @@
+/*
+ * vp9_mc.hip — VP9 motion compensation, 8 bits, batched: VP9DSPContext.mc[size][filter][avg][!!mx][!!my]
+ * (libavcodec/vp9dsp_template.c:1966-2293): the three 8-tap filter sets (each pass clip_u8((sum + 64) >> 7), the 2-D form through
+ * 8-bit temporaries of rows -3..h+3), bilinear (a + ((m (b - a) + 8) >> 4)), full-pel copies; put and avg ((dst + v + 1) >> 1).
+ *
+ * Same shape as k_hevc_mc (hevc_mc.hip): one wave per block, a lane owns 4 adjacent samples of a row; the horizontal pass is two
+ * v_dot4_i32_i8 per sample on bytes biased by -128 (every tap set sums to 128: the bias is 128 * 128 seeded into the accumulator),
+ * windows cut with v_alignbyte from one 12-byte load; the rows the vertical pass needs — filtered and clipped, or raw — sit in
+ * wave-private LDS as int16 pairs of vertically adjacent rows, 4 or 5 v_dot2_i32_i16 per sample; 16-column tiles keep the plane
+ * small enough for 8 waves per SIMD.  Rows are read in whole dwords: a block's last group reads 1 byte beyond the right margin
+ * the reference needs.
+ */
+#include "common.h"
+#include "h264_kernels.h"
+
+static_assert(sizeof(FFHipVp9McBlock) == 16, "FFHipVp9McBlock is a 16-byte record");
+typedef short vm_s2 __attribute__((ext_vector_type(2)));
+
+/* generated from ff_vp9_subpel_filters (libavcodec/vp9dsp.c:32-86), [filter 0 smooth / 1 regular / 2 sharp][m]: the 8 taps as two
+ * dwords of int8 for v_dot4_i32_i8 (m = 0 is never used: full-pel positions are copies; its 128 would not fit) */
+__constant__ __attribute__((aligned(16))) uint32_t vp9_h8[48][2] = {
+    { 0x00000000u, 0x00000000u },    { 0x4020fffdu, 0x00fd0126u },    { 0x3f1dfefeu, 0x00fd0229u },    { 0x3f1afefeu, 0x00fc042bu },
+    { 0x3e18fdfeu, 0x00fc052eu },    { 0x3c15fdfeu, 0x00fc0731u },    { 0x3b12fcffu, 0x00fc0933u },    { 0x3910fcffu, 0xfffc0c35u },
+    { 0x370efcffu, 0xfffc0e37u },    { 0x350cfcffu, 0xfffc1039u },    { 0x3309fc00u, 0xfffc123bu },    { 0x3107fc00u, 0xfefd153cu },
+    { 0x2e05fc00u, 0xfefd183eu },    { 0x2b04fc00u, 0xfefe1a3fu },    { 0x2902fd00u, 0xfefe1d3fu },    { 0x2601fd00u, 0xfdff2040u },
+    { 0x00000000u, 0x00000000u },    { 0x7efb0100u, 0x0001fd08u },    { 0x7af603ffu, 0x0002fa12u },    { 0x76f304ffu, 0xff03f71bu },
+    { 0x70f004ffu, 0xff04f525u },    { 0x69ee05ffu, 0xff04f230u },    { 0x61ed05ffu, 0xff05f03au },    { 0x58ed06ffu, 0xff05ee44u },
+    { 0x4eed06ffu, 0xff06ed4eu },    { 0x44ee05ffu, 0xff06ed58u },    { 0x3af005ffu, 0xff05ed61u },    { 0x30f204ffu, 0xff05ee69u },
+    { 0x25f504ffu, 0xff04f070u },    { 0x1bf703ffu, 0xff04f376u },    { 0x12fa0200u, 0xff03f67au },    { 0x08fd0100u, 0x0001fb7eu },
+    { 0x00000000u, 0x00000000u },    { 0x7ff903ffu, 0x0001fd08u },    { 0x7df305feu, 0xff03fa11u },    { 0x79ef07fdu, 0xfe05f61bu },
+    { 0x73ec09fcu, 0xfe06f325u },    { 0x6ce90afcu, 0xfd08f030u },    { 0x64e80afcu, 0xfd09ed3bu },    { 0x5ae80bfcu, 0xfc0aeb46u },
+    { 0x50e90bfcu, 0xfc0be950u },    { 0x46eb0afcu, 0xfc0be85au },    { 0x3bed09fdu, 0xfc0ae864u },    { 0x30f008fdu, 0xfc0ae96cu },
+    { 0x25f306feu, 0xfc09ec73u },    { 0x1bf605feu, 0xfd07ef79u },    { 0x11fa03ffu, 0xfe05f37du },    { 0x08fd0100u, 0xff03f97fu },
+};
+/* the same taps as v_dot2_i32_i16 operands over row pairs: [..][0..4] first row even (c0,c1)..(c6,c7)(0,0); [5..9] odd (0,c0)(c1,c2)..(c7,0) */
+__constant__ __attribute__((aligned(16))) uint32_t vp9_v2[48][12] = {
+    { 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0xfffffffdu, 0x00400020u, 0x00010026u, 0x0000fffdu, 0x00000000u, 0xfffd0000u, 0x0020ffffu, 0x00260040u, 0xfffd0001u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0xfffefffeu, 0x003f001du, 0x00020029u, 0x0000fffdu, 0x00000000u, 0xfffe0000u, 0x001dfffeu, 0x0029003fu, 0xfffd0002u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0xfffefffeu, 0x003f001au, 0x0004002bu, 0x0000fffcu, 0x00000000u, 0xfffe0000u, 0x001afffeu, 0x002b003fu, 0xfffc0004u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0xfffdfffeu, 0x003e0018u, 0x0005002eu, 0x0000fffcu, 0x00000000u, 0xfffe0000u, 0x0018fffdu, 0x002e003eu, 0xfffc0005u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0xfffdfffeu, 0x003c0015u, 0x00070031u, 0x0000fffcu, 0x00000000u, 0xfffe0000u, 0x0015fffdu, 0x0031003cu, 0xfffc0007u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0xfffcffffu, 0x003b0012u, 0x00090033u, 0x0000fffcu, 0x00000000u, 0xffff0000u, 0x0012fffcu, 0x0033003bu, 0xfffc0009u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0xfffcffffu, 0x00390010u, 0x000c0035u, 0xfffffffcu, 0x00000000u, 0xffff0000u, 0x0010fffcu, 0x00350039u, 0xfffc000cu, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0xfffcffffu, 0x0037000eu, 0x000e0037u, 0xfffffffcu, 0x00000000u, 0xffff0000u, 0x000efffcu, 0x00370037u, 0xfffc000eu, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0xfffcffffu, 0x0035000cu, 0x00100039u, 0xfffffffcu, 0x00000000u, 0xffff0000u, 0x000cfffcu, 0x00390035u, 0xfffc0010u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0xfffc0000u, 0x00330009u, 0x0012003bu, 0xfffffffcu, 0x00000000u, 0x00000000u, 0x0009fffcu, 0x003b0033u, 0xfffc0012u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0xfffc0000u, 0x00310007u, 0x0015003cu, 0xfffefffdu, 0x00000000u, 0x00000000u, 0x0007fffcu, 0x003c0031u, 0xfffd0015u, 0x0000fffeu, 0x00000000u, 0x00000000u },
+    { 0xfffc0000u, 0x002e0005u, 0x0018003eu, 0xfffefffdu, 0x00000000u, 0x00000000u, 0x0005fffcu, 0x003e002eu, 0xfffd0018u, 0x0000fffeu, 0x00000000u, 0x00000000u },
+    { 0xfffc0000u, 0x002b0004u, 0x001a003fu, 0xfffefffeu, 0x00000000u, 0x00000000u, 0x0004fffcu, 0x003f002bu, 0xfffe001au, 0x0000fffeu, 0x00000000u, 0x00000000u },
+    { 0xfffd0000u, 0x00290002u, 0x001d003fu, 0xfffefffeu, 0x00000000u, 0x00000000u, 0x0002fffdu, 0x003f0029u, 0xfffe001du, 0x0000fffeu, 0x00000000u, 0x00000000u },
+    { 0xfffd0000u, 0x00260001u, 0x00200040u, 0xfffdffffu, 0x00000000u, 0x00000000u, 0x0001fffdu, 0x00400026u, 0xffff0020u, 0x0000fffdu, 0x00000000u, 0x00000000u },
+    { 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0x00010000u, 0x007efffbu, 0xfffd0008u, 0x00000001u, 0x00000000u, 0x00000000u, 0xfffb0001u, 0x0008007eu, 0x0001fffdu, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0x0003ffffu, 0x007afff6u, 0xfffa0012u, 0x00000002u, 0x00000000u, 0xffff0000u, 0xfff60003u, 0x0012007au, 0x0002fffau, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0x0004ffffu, 0x0076fff3u, 0xfff7001bu, 0xffff0003u, 0x00000000u, 0xffff0000u, 0xfff30004u, 0x001b0076u, 0x0003fff7u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0004ffffu, 0x0070fff0u, 0xfff50025u, 0xffff0004u, 0x00000000u, 0xffff0000u, 0xfff00004u, 0x00250070u, 0x0004fff5u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0005ffffu, 0x0069ffeeu, 0xfff20030u, 0xffff0004u, 0x00000000u, 0xffff0000u, 0xffee0005u, 0x00300069u, 0x0004fff2u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0005ffffu, 0x0061ffedu, 0xfff0003au, 0xffff0005u, 0x00000000u, 0xffff0000u, 0xffed0005u, 0x003a0061u, 0x0005fff0u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0006ffffu, 0x0058ffedu, 0xffee0044u, 0xffff0005u, 0x00000000u, 0xffff0000u, 0xffed0006u, 0x00440058u, 0x0005ffeeu, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0006ffffu, 0x004effedu, 0xffed004eu, 0xffff0006u, 0x00000000u, 0xffff0000u, 0xffed0006u, 0x004e004eu, 0x0006ffedu, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0005ffffu, 0x0044ffeeu, 0xffed0058u, 0xffff0006u, 0x00000000u, 0xffff0000u, 0xffee0005u, 0x00580044u, 0x0006ffedu, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0005ffffu, 0x003afff0u, 0xffed0061u, 0xffff0005u, 0x00000000u, 0xffff0000u, 0xfff00005u, 0x0061003au, 0x0005ffedu, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0004ffffu, 0x0030fff2u, 0xffee0069u, 0xffff0005u, 0x00000000u, 0xffff0000u, 0xfff20004u, 0x00690030u, 0x0005ffeeu, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0004ffffu, 0x0025fff5u, 0xfff00070u, 0xffff0004u, 0x00000000u, 0xffff0000u, 0xfff50004u, 0x00700025u, 0x0004fff0u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0003ffffu, 0x001bfff7u, 0xfff30076u, 0xffff0004u, 0x00000000u, 0xffff0000u, 0xfff70003u, 0x0076001bu, 0x0004fff3u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x00020000u, 0x0012fffau, 0xfff6007au, 0xffff0003u, 0x00000000u, 0x00000000u, 0xfffa0002u, 0x007a0012u, 0x0003fff6u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x00010000u, 0x0008fffdu, 0xfffb007eu, 0x00000001u, 0x00000000u, 0x00000000u, 0xfffd0001u, 0x007e0008u, 0x0001fffbu, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0x0003ffffu, 0x007ffff9u, 0xfffd0008u, 0x00000001u, 0x00000000u, 0xffff0000u, 0xfff90003u, 0x0008007fu, 0x0001fffdu, 0x00000000u, 0x00000000u, 0x00000000u },
+    { 0x0005fffeu, 0x007dfff3u, 0xfffa0011u, 0xffff0003u, 0x00000000u, 0xfffe0000u, 0xfff30005u, 0x0011007du, 0x0003fffau, 0x0000ffffu, 0x00000000u, 0x00000000u },
+    { 0x0007fffdu, 0x0079ffefu, 0xfff6001bu, 0xfffe0005u, 0x00000000u, 0xfffd0000u, 0xffef0007u, 0x001b0079u, 0x0005fff6u, 0x0000fffeu, 0x00000000u, 0x00000000u },
+    { 0x0009fffcu, 0x0073ffecu, 0xfff30025u, 0xfffe0006u, 0x00000000u, 0xfffc0000u, 0xffec0009u, 0x00250073u, 0x0006fff3u, 0x0000fffeu, 0x00000000u, 0x00000000u },
+    { 0x000afffcu, 0x006cffe9u, 0xfff00030u, 0xfffd0008u, 0x00000000u, 0xfffc0000u, 0xffe9000au, 0x0030006cu, 0x0008fff0u, 0x0000fffdu, 0x00000000u, 0x00000000u },
+    { 0x000afffcu, 0x0064ffe8u, 0xffed003bu, 0xfffd0009u, 0x00000000u, 0xfffc0000u, 0xffe8000au, 0x003b0064u, 0x0009ffedu, 0x0000fffdu, 0x00000000u, 0x00000000u },
+    { 0x000bfffcu, 0x005affe8u, 0xffeb0046u, 0xfffc000au, 0x00000000u, 0xfffc0000u, 0xffe8000bu, 0x0046005au, 0x000affebu, 0x0000fffcu, 0x00000000u, 0x00000000u },
+    { 0x000bfffcu, 0x0050ffe9u, 0xffe90050u, 0xfffc000bu, 0x00000000u, 0xfffc0000u, 0xffe9000bu, 0x00500050u, 0x000bffe9u, 0x0000fffcu, 0x00000000u, 0x00000000u },
+    { 0x000afffcu, 0x0046ffebu, 0xffe8005au, 0xfffc000bu, 0x00000000u, 0xfffc0000u, 0xffeb000au, 0x005a0046u, 0x000bffe8u, 0x0000fffcu, 0x00000000u, 0x00000000u },
+    { 0x0009fffdu, 0x003bffedu, 0xffe80064u, 0xfffc000au, 0x00000000u, 0xfffd0000u, 0xffed0009u, 0x0064003bu, 0x000affe8u, 0x0000fffcu, 0x00000000u, 0x00000000u },
+    { 0x0008fffdu, 0x0030fff0u, 0xffe9006cu, 0xfffc000au, 0x00000000u, 0xfffd0000u, 0xfff00008u, 0x006c0030u, 0x000affe9u, 0x0000fffcu, 0x00000000u, 0x00000000u },
+    { 0x0006fffeu, 0x0025fff3u, 0xffec0073u, 0xfffc0009u, 0x00000000u, 0xfffe0000u, 0xfff30006u, 0x00730025u, 0x0009ffecu, 0x0000fffcu, 0x00000000u, 0x00000000u },
+    { 0x0005fffeu, 0x001bfff6u, 0xffef0079u, 0xfffd0007u, 0x00000000u, 0xfffe0000u, 0xfff60005u, 0x0079001bu, 0x0007ffefu, 0x0000fffdu, 0x00000000u, 0x00000000u },
+    { 0x0003ffffu, 0x0011fffau, 0xfff3007du, 0xfffe0005u, 0x00000000u, 0xffff0000u, 0xfffa0003u, 0x007d0011u, 0x0005fff3u, 0x0000fffeu, 0x00000000u, 0x00000000u },
+    { 0x00010000u, 0x0008fffdu, 0xfff9007fu, 0xffff0003u, 0x00000000u, 0x00000000u, 0xfffd0001u, 0x007f0008u, 0x0003fff9u, 0x0000ffffu, 0x00000000u, 0x00000000u },
+};
+
+constexpr int VM_TW = 16, VM_PITCH = 20, VM_PAIRS = 37; /* tile width, dwords per row pair, (64 + 7 + 1) / 2 + 1 row pairs */
+
+__device__ __forceinline__ void vm_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* four horizontally filtered, rounded and clipped samples: p = the first window's first byte (x0 - 3), any alignment */
+__device__ __forceinline__ void vm_hrow4(const uint8_t *p, int clo, int chi, int (&o)[4])
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+    const uint32_t d0 = q[0] ^ 0x80808080u, d1 = q[1] ^ 0x80808080u, d2 = q[2] ^ 0x80808080u;
+    constexpr int seed = 128 * 128 + 64;
+    int s[4];
+    s[0] = __builtin_amdgcn_sdot4((int)d1, chi, __builtin_amdgcn_sdot4((int)d0, clo, seed, false), false);
+    s[1] = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_alignbyte(d2, d1, 1), chi,
+                                  __builtin_amdgcn_sdot4((int)__builtin_amdgcn_alignbyte(d1, d0, 1), clo, seed, false), false);
+    s[2] = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_alignbyte(d2, d1, 2), chi,
+                                  __builtin_amdgcn_sdot4((int)__builtin_amdgcn_alignbyte(d1, d0, 2), clo, seed, false), false);
+    s[3] = __builtin_amdgcn_sdot4((int)__builtin_amdgcn_alignbyte(d2, d1, 3), chi,
+                                  __builtin_amdgcn_sdot4((int)__builtin_amdgcn_alignbyte(d1, d0, 3), clo, seed, false), false);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        o[j] = clip_u8(s[j] >> 7);
+}
+
+__global__ __launch_bounds__(256) void k_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                                const FFHipVp9McBlock *blocks, int n)
+{
+    __shared__ uint32_t tmp_all[4][VM_PAIRS * VM_PITCH];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= n)
+        return;
+    const FFHipVp9McBlock k = blocks[b];
+    const int w = __builtin_amdgcn_readfirstlane((int)k.width), h = __builtin_amdgcn_readfirstlane((int)k.height);
+    const int filter = __builtin_amdgcn_readfirstlane((int)k.filter) & 3;
+    const int mx = __builtin_amdgcn_readfirstlane((int)k.mx) & 15, my = __builtin_amdgcn_readfirstlane((int)k.my) & 15;
+    const bool avg = __builtin_amdgcn_readfirstlane((int)k.avg) != 0;
+    const uint8_t *s = src + __builtin_amdgcn_readfirstlane(k.src_offset);
+    uint8_t *d0 = dst + __builtin_amdgcn_readfirstlane(k.dst_offset);
+    const bool d_al = ((reinterpret_cast<uintptr_t>(d0) | (uintptr_t)dststride) & 3) == 0;
+    uint32_t *tmp = tmp_all[wave];
+    const bool bil = filter == 3;
+    const int fi = (bil ? 0 : filter) * 16;
+
+    /* put / avg of samples x0..x0+3 of row y */
+    auto emit = [&](int y, int x0, const int (&v)[4]) {
+        uint8_t *d = d0 + (ptrdiff_t)y * dststride + x0;
+        uint32_t out = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
+        if (d_al) {
+            if (avg) {
+                const uint32_t o = *reinterpret_cast<const uint32_t *>(d);
+                out = (o | out) - (((o ^ out) & 0xfefefefeu) >> 1); /* (a + b + 1) >> 1 on four bytes */
+            }
+            *reinterpret_cast<uint32_t *>(d) = out;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                d[j] = (uint8_t)(avg ? (d[j] + v[j] + 1) >> 1 : v[j]);
+        }
+    };
+    auto bilin = [](int m, int a, int b2) { return a + ((m * (b2 - a) + 8) >> 4); };
+
+    if (!my) {
+        /* horizontal only (or a copy): no temporaries */
+        const int ng = w >> 2, lg = __builtin_ctz(ng); /* 1, 2, 4, 8 or 16 groups per row */
+        const int clo = (int)vp9_h8[fi + mx][0], chi = (int)vp9_h8[fi + mx][1];
+        for (int i = lane; i < h * ng; i += 64) {
+            const int y = i >> lg, xg = i & (ng - 1);
+            const uint8_t *p = s + (ptrdiff_t)y * srcstride + 4 * xg;
+            int o[4];
+            if (!mx) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+                o[0] = v & 255; o[1] = (v >> 8) & 255; o[2] = (v >> 16) & 255; o[3] = v >> 24;
+            } else if (bil) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+                const int e4 = p[4];
+                const int a0 = v & 255, a1 = (v >> 8) & 255, a2 = (v >> 16) & 255, a3 = v >> 24;
+                o[0] = bilin(mx, a0, a1); o[1] = bilin(mx, a1, a2); o[2] = bilin(mx, a2, a3); o[3] = bilin(mx, a3, e4);
+            } else {
+                vm_hrow4(p - 3, clo, chi, o);
+            }
+            emit(y, 4 * xg, o);
+        }
+        return;
+    }
+    const int before = bil ? 0 : 3, rows = bil ? h + 1 : h + 7;
+    const int clo = (int)vp9_h8[fi + mx][0], chi = (int)vp9_h8[fi + mx][1];
+    uint32_t ce[5], co[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        ce[q] = vp9_v2[fi + my][q];
+        co[q] = vp9_v2[fi + my][5 + q];
+    }
+    for (int tx = 0; tx < w; tx += VM_TW) {
+        const int ngt = min((w - tx) >> 2, VM_TW / 4), sh = ngt == 4 ? 2 : ngt == 2 ? 1 : 0; /* 4, 2 or 1 groups per row */
+        /* rows -before .. of the tile, horizontally filtered (or raw), into the row-pair plane */
+        for (int i = lane; i < rows * ngt; i += 64) {
+            const int r = i >> sh, xg = i & (ngt - 1);
+            const uint8_t *p = s + (ptrdiff_t)(r - before) * srcstride + tx + 4 * xg;
+            int o[4];
+            if (!mx) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+                o[0] = v & 255; o[1] = (v >> 8) & 255; o[2] = (v >> 16) & 255; o[3] = v >> 24;
+            } else if (bil) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+                const int e4 = p[4];
+                const int a0 = v & 255, a1 = (v >> 8) & 255, a2 = (v >> 16) & 255, a3 = v >> 24;
+                o[0] = bilin(mx, a0, a1); o[1] = bilin(mx, a1, a2); o[2] = bilin(mx, a2, a3); o[3] = bilin(mx, a3, e4);
+            } else {
+                vm_hrow4(p - 3, clo, chi, o);
+            }
+            int16_t *t16 = reinterpret_cast<int16_t *>(tmp + (r >> 1) * VM_PITCH + 4 * xg) + (r & 1);
+            t16[0] = (int16_t)o[0]; t16[2] = (int16_t)o[1]; t16[4] = (int16_t)o[2]; t16[6] = (int16_t)o[3];
+        }
+        vm_wave_sync();
+        for (int i = lane; i < h * ngt; i += 64) {
+            const int y = i >> sh, xg = i & (ngt - 1);
+            int v[4];
+            if (bil) {
+                const int16_t *ta = reinterpret_cast<const int16_t *>(tmp + (y >> 1) * VM_PITCH + 4 * xg) + (y & 1);
+                const int16_t *tb = reinterpret_cast<const int16_t *>(tmp + ((y + 1) >> 1) * VM_PITCH + 4 * xg) + ((y + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    v[j] = bilin(my, ta[2 * j], tb[2 * j]);
+            } else {
+                const uint4 *t = reinterpret_cast<const uint4 *>(tmp + (y >> 1) * VM_PITCH + 4 * xg);
+                const bool odd = y & 1;
+                int acc[4] = { 64, 64, 64, 64 };
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const uint4 u = t[q * (VM_PITCH / 4)];
+                    const vm_s2 c = __builtin_bit_cast(vm_s2, odd ? co[q] : ce[q]);
+                    acc[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(vm_s2, u.x), c, acc[0], false);
+                    acc[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(vm_s2, u.y), c, acc[1], false);
+                    acc[2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(vm_s2, u.z), c, acc[2], false);
+                    acc[3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(vm_s2, u.w), c, acc[3], false);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    v[j] = clip_u8(acc[j] >> 7);
+            }
+            emit(y, tx + 4 * xg, v);
+        }
+        vm_wave_sync(); /* the next tile overwrites the plane */
+    }
+}
+
+int ffhip_launch_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9McBlock *blocks, int n,
+                        hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_vp9_mc, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -670,3 +670,59 @@ extern "C" int ff_vp9dsp_itxfm_init_hip(FFHipVP9ItxfmContext *c, int bpp)
 #undef VP9_ROW
     return 0;
 }
+
+/* ---- vp9dsp mc host faces: source rows -3..h+4 x columns -3..w+4 at a pitch of 128, destination w x h at a pitch of 64 ---- */
+static void vp9_mc_single(int width, int filter, int avg, uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (h <= 0 || h > 64)
+        return;
+    const int P = 128, before = 3, after = 4;
+    const size_t sbytes = (size_t)(h + before + after) * P, dbytes = (size_t)h * 64;
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + sbytes + dbytes + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + sbytes;
+    /* only what the reference function of this slot reads: rows / columns beyond the block exist when that axis is filtered */
+    const int ry0 = my ? -before : 0, ry1 = my ? h + after : h, cx0 = mx ? -before : 0, cx1 = mx ? width + after : width;
+    if (hipMemcpy2D(dsrc + (size_t)(ry0 + before) * P + before + cx0, P, src + ry0 * ss + cx0, ss, cx1 - cx0, ry1 - ry0,
+                    hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy2D(ddst, 64, dst, ds, width, h, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    FFHipVp9McBlock k = {};
+    k.src_offset = before * P + before;
+    k.width = (uint8_t)width; k.height = (uint8_t)h; k.filter = (uint8_t)filter; k.mx = (uint8_t)mx; k.my = (uint8_t)my; k.avg = (uint8_t)avg;
+    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_vp9_mc(ddst, 64, dsrc, P, (const FFHipVp9McBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    (void)hipMemcpy2D(dst, ds, ddst, 64, width, h, hipMemcpyDeviceToHost);
+}
+/* the [!!mx][!!my] slots differ only in which fractions are non-zero: a slot's function masks the other one as the reference's
+ * dedicated h / v functions ignore it */
+template <int W, int F, int AVG, int HX, int VY>
+static void s_vp9_mc(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, int mx, int my)
+{
+    vp9_mc_single(W, F, AVG, d, ds, s, ss, h, HX ? mx : 0, VY ? my : 0);
+}
+template <int W, int I>
+static void vp9_mc_fill(FFHipVP9McContext *c)
+{
+#define VP9_MC_F(F) \
+    c->mc[I][F][0][0][0] = s_vp9_mc<W, F, 0, 0, 0>; c->mc[I][F][0][0][1] = s_vp9_mc<W, F, 0, 0, 1>; \
+    c->mc[I][F][0][1][0] = s_vp9_mc<W, F, 0, 1, 0>; c->mc[I][F][0][1][1] = s_vp9_mc<W, F, 0, 1, 1>; \
+    c->mc[I][F][1][0][0] = s_vp9_mc<W, F, 1, 0, 0>; c->mc[I][F][1][0][1] = s_vp9_mc<W, F, 1, 0, 1>; \
+    c->mc[I][F][1][1][0] = s_vp9_mc<W, F, 1, 1, 0>; c->mc[I][F][1][1][1] = s_vp9_mc<W, F, 1, 1, 1>;
+    VP9_MC_F(0) VP9_MC_F(1) VP9_MC_F(2) VP9_MC_F(3)
+#undef VP9_MC_F
+}
+
+extern "C" int ff_vp9dsp_mc_init_hip(FFHipVP9McContext *c, int bpp)
+{
+    if (!c || bpp != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    vp9_mc_fill<64, 0>(c); vp9_mc_fill<32, 1>(c); vp9_mc_fill<16, 2>(c); vp9_mc_fill<8, 3>(c); vp9_mc_fill<4, 4>(c);
+    return 0;
+}

@@ -28,3 +28,26 @@ def dsp_init(bpp=8):
     c = VP9ItxfmContext()
     _lib.check(_lib.lib().ff_vp9dsp_itxfm_init_hip(C.byref(c), bpp), "ff_vp9dsp_itxfm_init_hip")
     return c
+
+
+#: FFHipVp9McBlock (include/ffhip.h)
+MC_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("width", np.uint8), ("height", np.uint8), ("filter", np.uint8),
+                     ("mx", np.uint8), ("my", np.uint8), ("avg", np.uint8), ("pad", np.uint8, 2)])
+FILTER_SMOOTH, FILTER_REGULAR, FILTER_SHARP, FILTER_BILINEAR = 0, 1, 2, 3
+
+
+def mc_batch(dst, dststride, src, srcstride, blocks, n, stream=None):
+    """blocks: uint8 [n, 16] FFHipVp9McBlock records"""
+    return _lib.check(_lib.lib().ffhip_vp9_mc_batch_dev(dst.data_ptr(), dststride, src.data_ptr(), srcstride, blocks.data_ptr(), n,
+                                                        None if stream is None else C.c_void_p(stream)), "ffhip_vp9_mc_batch_dev")
+
+
+class VP9McContext(C.Structure):
+    """FFHipVP9McContext: mc[size][filter][avg][!!mx][!!my]"""
+    _fields_ = [("mc", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int) * 2 * 2 * 2 * 4 * 5)]
+
+
+def mc_init(bpp=8):
+    c = VP9McContext()
+    _lib.check(_lib.lib().ff_vp9dsp_mc_init_hip(C.byref(c), bpp), "ff_vp9dsp_mc_init_hip")
+    return c

@@ -617,6 +617,28 @@ typedef struct FFHipVp9TU {
 int ffhip_vp9_itxfm_add_batch_dev(int tx, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipVp9TU *tus, int n,
                                   void *stream);
 
+/** vp9_mc_func and VP9DSPContext.mc[size 64/32/16/8/4][filter][put/avg][!!mx][!!my] (libavcodec/vp9dsp.h:33-35,115;
+ *  enum FilterMode, libavcodec/vp9.h:64-70: 0 smooth, 1 regular, 2 sharp, 3 bilinear); mx, my in sixteenths. */
+typedef void (*ffhip_vp9_mc_func)(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride, int h, int mx, int my);
+typedef struct FFHipVP9McContext {
+    ffhip_vp9_mc_func mc[5][4][2][2][2];
+} FFHipVP9McContext;
+int ff_vp9dsp_mc_init_hip(FFHipVP9McContext *c, int bpp);
+/** One prediction block of the batch face (what inter_pred / mc_luma_unscaled pass, libavcodec/vp9recon.c). */
+typedef struct FFHipVp9McBlock {
+    int32_t dst_offset, src_offset; /* bytes into dst / src: the block's integer-sample origin */
+    uint8_t width;                  /* 4, 8, 16, 32 or 64 */
+    uint8_t height;                 /* 1..64 */
+    uint8_t filter;                 /* enum FilterMode 0..3 */
+    uint8_t mx, my;                 /* 0..15 */
+    uint8_t avg;                    /* 0 put, 1 avg (compound prediction's second reference) */
+    uint8_t pad[2];                 /* sizeof == 16 */
+} FFHipVp9McBlock;
+/** n blocks, pairwise disjoint in dst; src must be readable 3 samples left/up and 4 right/down of each block (rows are read in
+ *  whole dwords: 1 byte more on the right). */
+int ffhip_vp9_mc_batch_dev(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9McBlock *blocks,
+                           int n, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */
 /* ------------------------------------------------------------------------------------------ */

@@ -94,6 +94,9 @@ void ffo_hevc_mc_w(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, cons
                    int height, int denom, int wx0, int wx1, int ox, int mx, int my, int width);
 /* VP9DSPContext.itxfm_add[tx][txtp], 8 bits (ffo_vp9.c): tx 0..3 = 4x4..32x32, 4 = WHT; consumes the block */
 void ffo_vp9_itxfm_add(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob);
+/* VP9DSPContext.mc[..][filter][avg][!!mx][!!my], 8 bits: filter 0 smooth, 1 regular, 2 sharp, 3 bilinear */
+void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
+                int mx, int my);
 void ffo_hevc_dequant(int16_t *coeffs, int log2_size);
 void ffo_hevc_transform_rdpcm(int16_t *coeffs, int log2_size, int mode);
 void ffo_hevc_sao_edge_restore(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, int eo, int offset0,

@@ -337,3 +337,67 @@ void ffo_vp9_itxfm_add(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t
         }
     }
 }
+
+/*
+ * VP9 motion compensation, 8 bits: VP9DSPContext.mc[size][filter][avg][!!mx][!!my] (libavcodec/vp9dsp_template.c:1966-2293;
+ * taps: ff_vp9_subpel_filters, libavcodec/vp9dsp.c:32-86; enum FilterMode, libavcodec/vp9.h:64-70: 0 smooth, 1 regular,
+ * 2 sharp, 3 bilinear).  Each 8-tap pass is clip_u8((sum + 64) >> 7); the 2-D form filters rows -3..h+3 horizontally into 8-bit
+ * temporaries first.  Bilinear: a + ((m (b - a) + 8) >> 4), rows 0..h.  avg: (dst + v + 1) >> 1.  Stated per output sample.
+ */
+static const int8_t vp9_taps[3][16][8] = {
+    { { 0, 0, 0, 127, 0, 0, 0, 0 }, /* index 0 is never used (full-pel copies); 128 does not fit, see vp9_tap() */
+      { -3, -1, 32, 64, 38, 1, -3, 0 }, { -2, -2, 29, 63, 41, 2, -3, 0 }, { -2, -2, 26, 63, 43, 4, -4, 0 }, { -2, -3, 24, 62, 46, 5, -4, 0 },
+      { -2, -3, 21, 60, 49, 7, -4, 0 }, { -1, -4, 18, 59, 51, 9, -4, 0 }, { -1, -4, 16, 57, 53, 12, -4, -1 }, { -1, -4, 14, 55, 55, 14, -4, -1 },
+      { -1, -4, 12, 53, 57, 16, -4, -1 }, { 0, -4, 9, 51, 59, 18, -4, -1 }, { 0, -4, 7, 49, 60, 21, -3, -2 }, { 0, -4, 5, 46, 62, 24, -3, -2 },
+      { 0, -4, 4, 43, 63, 26, -2, -2 }, { 0, -3, 2, 41, 63, 29, -2, -2 }, { 0, -3, 1, 38, 64, 32, -1, -3 } },
+    { { 0, 0, 0, 127, 0, 0, 0, 0 },
+      { 0, 1, -5, 126, 8, -3, 1, 0 }, { -1, 3, -10, 122, 18, -6, 2, 0 }, { -1, 4, -13, 118, 27, -9, 3, -1 }, { -1, 4, -16, 112, 37, -11, 4, -1 },
+      { -1, 5, -18, 105, 48, -14, 4, -1 }, { -1, 5, -19, 97, 58, -16, 5, -1 }, { -1, 6, -19, 88, 68, -18, 5, -1 }, { -1, 6, -19, 78, 78, -19, 6, -1 },
+      { -1, 5, -18, 68, 88, -19, 6, -1 }, { -1, 5, -16, 58, 97, -19, 5, -1 }, { -1, 4, -14, 48, 105, -18, 5, -1 }, { -1, 4, -11, 37, 112, -16, 4, -1 },
+      { -1, 3, -9, 27, 118, -13, 4, -1 }, { 0, 2, -6, 18, 122, -10, 3, -1 }, { 0, 1, -3, 8, 126, -5, 1, 0 } },
+    { { 0, 0, 0, 127, 0, 0, 0, 0 },
+      { -1, 3, -7, 127, 8, -3, 1, 0 }, { -2, 5, -13, 125, 17, -6, 3, -1 }, { -3, 7, -17, 121, 27, -10, 5, -2 }, { -4, 9, -20, 115, 37, -13, 6, -2 },
+      { -4, 10, -23, 108, 48, -16, 8, -3 }, { -4, 10, -24, 100, 59, -19, 9, -3 }, { -4, 11, -24, 90, 70, -21, 10, -4 }, { -4, 11, -23, 80, 80, -23, 11, -4 },
+      { -4, 10, -21, 70, 90, -24, 11, -4 }, { -3, 9, -19, 59, 100, -24, 10, -4 }, { -3, 8, -16, 48, 108, -23, 10, -4 }, { -2, 6, -13, 37, 115, -20, 9, -4 },
+      { -2, 5, -10, 27, 121, -17, 7, -3 }, { -1, 3, -6, 17, 125, -13, 5, -2 }, { 0, 1, -3, 8, 127, -7, 3, -1 } },
+};
+
+static int vp9_tap8(int filter, int m, const uint8_t *s, ptrdiff_t step)
+{
+    int sum = 64;
+    for (int k = 0; k < 8; k++)
+        sum += vp9_taps[filter][m][k] * s[(k - 3) * step];
+    sum >>= 7;
+    return sum < 0 ? 0 : sum > 255 ? 255 : sum;
+}
+static int vp9_bilin(int m, const uint8_t *s, ptrdiff_t step) { return s[0] + ((m * (s[step] - s[0]) + 8) >> 4); }
+
+/* width 4..64 (multiple of 4), height 1..64, filter 0..3, mx / my 0..15 */
+void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
+                int mx, int my)
+{
+    uint8_t tmp[71 * 64];
+    const int bil = filter == 3;
+    if (mx && my) { /* rows -3..h+3 (bilinear: 0..h) through the horizontal filter */
+        const int r0 = bil ? 0 : -3, rows = bil ? height + 1 : height + 7;
+        for (int r = 0; r < rows; r++)
+            for (int x = 0; x < width; x++) {
+                const uint8_t *s = src + (r + r0) * srcstride + x;
+                tmp[r * 64 + x] = bil ? vp9_bilin(mx, s, 1) : vp9_tap8(filter, mx, s, 1);
+            }
+    }
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const uint8_t *s = src + y * srcstride + x;
+            int v;
+            if (mx && my)
+                v = bil ? vp9_bilin(my, tmp + y * 64 + x, 64) : vp9_tap8(filter, my, tmp + (y + 3) * 64 + x, 64);
+            else if (mx)
+                v = bil ? vp9_bilin(mx, s, 1) : vp9_tap8(filter, mx, s, 1);
+            else if (my)
+                v = bil ? vp9_bilin(my, s, srcstride) : vp9_tap8(filter, my, s, srcstride);
+            else
+                v = s[0];
+            dst[y * dststride + x] = avg ? (dst[y * dststride + x] + v + 1) >> 1 : v;
+        }
+}

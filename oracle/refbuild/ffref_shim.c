@@ -274,6 +274,21 @@ void ffref_vp9_itxfm_add(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16
     }
     vp9.itxfm_add[tx][txtp](dst, stride, block, eob);
 }
+void ffref_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
+                  int mx, int my)
+{
+    static VP9DSPContext vp9;
+    static int vp9_ready;
+    int idx = 0;
+    pure_c();
+    if (!vp9_ready) {
+        ff_vp9dsp_init(&vp9, 8, 1);
+        vp9_ready = 1;
+    }
+    while ((64 >> idx) > width)
+        idx++;
+    vp9.mc[idx][filter][avg][!!mx][!!my](dst, dststride, src, srcstride, height, mx, my);
+}
 void ffref_hevc_dequant(int16_t *coeffs, int log2_size)
 {
     dsp_init();

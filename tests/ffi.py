@@ -112,6 +112,8 @@ def oracle():
         L.ffo_hevc_mc_w.restype = None
         L.ffo_vp9_itxfm_add.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, i16p, C.c_int]
         L.ffo_vp9_itxfm_add.restype = None
+        L.ffo_vp9_mc.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffo_vp9_mc.restype = None
         L.ffo_hevc_dequant.argtypes = [i16p, C.c_int]
         L.ffo_hevc_dequant.restype = None
         L.ffo_hevc_transform_rdpcm.argtypes = [i16p, C.c_int, C.c_int]
@@ -205,6 +207,8 @@ def ref():
         L.ffref_hevc_mc_w.restype = None
         L.ffref_vp9_itxfm_add.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, i16p, C.c_int]
         L.ffref_vp9_itxfm_add.restype = None
+        L.ffref_vp9_mc.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffref_vp9_mc.restype = None
         L.ffref_hevc_dequant.argtypes = [i16p, C.c_int]
         L.ffref_hevc_dequant.restype = None
         L.ffref_hevc_transform_rdpcm.argtypes = [i16p, C.c_int, C.c_int]

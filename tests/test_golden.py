@@ -207,6 +207,17 @@ def test_vp9_golden():
             assert np.array_equal(o, d["tx%d_out" % tx][i]) and np.array_equal(b, d["tx%d_oblk" % tx][i]), (tx, i)
 
 
+def test_vp9_mc_golden():
+    O = ffi.oracle()
+    d = load("vp9")
+    mref = np.ascontiguousarray(d["mc_ref"])
+    for i, (f, avg, w, h, mx, my, y0, x0) in enumerate(d["mc_par"].tolist()):
+        a = d["mc_in"].copy()
+        O.ffo_vp9_mc(f, avg, ptr(a), 64, at(mref, y0 * 96 + x0), 96, w, h, mx, my)
+        assert np.array_equal(a[h:], d["mc_in"][h:]) and np.array_equal(a[:, w:], d["mc_in"][:, w:])
+        assert np.array_equal(a[:h, :w], d["mc_out"][i][:h, :w]), i
+
+
 def test_fdsp_golden():
     O = ffi.oracle()
     d = load("fdsp")

@@ -93,3 +93,87 @@ def test_vp9_golden_gpu():
         torch.cuda.synchronize()
         assert np.array_equal(d_dst.cpu().numpy(), d["tx%d_out" % tx]), tx
         assert np.array_equal(d_co.cpu().numpy(), d["tx%d_oblk" % tx]), tx
+
+
+@pytest.mark.parametrize("aligned", [0, 1])
+def test_vp9_mc_batch(aligned):
+    """a picture's worth of prediction blocks: 5 widths x heights x 4 filters x all (mx, my) classes x put / avg in one batch;
+    destination rows on and off the dword grid"""
+    from ffmpeg_amd import vp9
+    torch = _torch()
+    rng = np.random.default_rng(420 + aligned)
+    W, H, P = 640, 512, 16
+    ss = W + 2 * P + 3
+    sd = W + (8 if aligned else 9)
+    ref = rng.integers(0, 256, (H + 2 * P, ss), dtype=np.uint8)
+    ref[:60] = rng.choice(np.array([0, 255], np.uint8), (60, ss))
+    dst = rng.integers(0, 256, (H, sd), dtype=np.uint8)
+    want = dst.copy()
+    O = ffi.oracle()
+    recs = []
+    for by in range(0, H, 64):
+        for bx in range(0, W, 64):
+            w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+            f, avg = int(rng.integers(0, 4)), int(rng.integers(0, 2))
+            mx, my = (int(v) for v in rng.integers(0, 16, 2))
+            r = rng.random()
+            if r < .15:
+                mx = 0
+            elif r < .3:
+                my = 0
+            elif r < .35:
+                mx = my = 0
+            dy, dx = (int(v) for v in rng.integers(-8, 9, 2))
+            so = (by + P + dy) * ss + bx + P + dx
+            recs.append((by * sd + bx, so, w, h, f, mx, my, avg, (0, 0)))
+            O.ffo_vp9_mc(f, avg, C.cast(want.ctypes.data + by * sd + bx, u8p), sd, C.cast(ref.ctypes.data + so, u8p), ss, w, h, mx, my)
+    n = len(recs)
+    rec = np.array(recs, vp9.MC_DTYPE)
+    d_dst = torch.from_numpy(dst.copy()).cuda()
+    vp9.mc_batch(d_dst, sd, torch.from_numpy(ref).cuda(), ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 16).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    assert (want != dst).sum() > 1000
+    got = d_dst.cpu().numpy()
+    assert np.array_equal(got, want), "%d mismatches, first %s" % ((got != want).sum(), np.argwhere(got != want)[:3])
+
+
+def test_vp9_mc_host_faces():
+    from ffmpeg_amd import vp9
+    _torch()
+    c = vp9.mc_init(8)
+    O = ffi.oracle()
+    rng = np.random.default_rng(421)
+    src = rng.integers(0, 256, (90, 100), dtype=np.uint8)
+    for rep in range(32):
+        idx = rep % 5
+        w = 64 >> idx
+        f, avg = (rep // 5) % 4, rep & 1
+        h = int(rng.choice([2, 8, 64]))
+        mx, my = (int(v) for v in rng.integers(1, 16, 2))
+        hx, vy = (rep >> 1) & 1, (rep >> 2) & 1
+        sp = src.ctypes.data + 10 * 100 + 12
+        d0 = rng.integers(0, 256, (64, 72), dtype=np.uint8)
+        a, b = d0.copy(), d0.copy()
+        c.mc[idx][f][avg][hx][vy](a.ctypes.data, 72, sp, 100, h, mx, my)
+        O.ffo_vp9_mc(f, avg, ptr(b), 72, C.cast(sp, u8p), 100, w, h, mx if hx else 0, my if vy else 0)
+        assert np.array_equal(a, b), (idx, f, avg, hx, vy, h, mx, my)
+
+
+def test_vp9_mc_golden_gpu():
+    from ffmpeg_amd import vp9
+    torch = _torch()
+    d = G.load("vp9")
+    par = d["mc_par"]
+    n = len(par)
+    rec = np.zeros(n, vp9.MC_DTYPE)
+    rec["dst_offset"] = np.arange(n) * 4096
+    rec["src_offset"] = par[:, 6] * 96 + par[:, 7]
+    rec["filter"], rec["avg"], rec["width"], rec["height"], rec["mx"], rec["my"] = par[:, 0], par[:, 1], par[:, 2], par[:, 3], par[:, 4], par[:, 5]
+    base = np.ascontiguousarray(d["mc_in"])
+    d_dst = torch.from_numpy(np.stack([base] * n)).cuda()
+    vp9.mc_batch(d_dst, 64, torch.from_numpy(np.ascontiguousarray(d["mc_ref"])).cuda(), 96, torch.from_numpy(rec.view(np.uint8).reshape(n, 16).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    for i, (f, avg, w, h, mx, my, y0, x0) in enumerate(par.tolist()):
+        assert np.array_equal(got[i][:h, :w], d["mc_out"][i][:h, :w]), i
+        assert np.array_equal(got[i][h:], base[h:]) and np.array_equal(got[i][:, w:], base[:, w:]), i

@@ -489,6 +489,29 @@ def test_vp9_itxfm_add():
                 assert np.array_equal(a, b) and np.array_equal(ba, bb), (tx, txtp, rep)
 
 
+def test_vp9_mc():
+    """VP9DSPContext.mc: 4 filters x put/avg x every (mx, my) class x the 5 widths (tests/checkasm/vp9dsp.c shapes)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(96)
+    src = rng.integers(0, 256, (90, 100), dtype=np.uint8)
+    src[:30] = rng.choice(np.array([0, 255], np.uint8), (30, 100))          # extremes: both clips fire
+    for rep in range(2400):
+        f, avg = int(rng.integers(0, 4)), rep & 1
+        w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([1, 2, 4, 8, 16, 33, 64]))
+        mx, my = (int(v) for v in rng.integers(0, 16, 2))
+        if rep % 5 == 0:
+            mx = 0
+        if rep % 7 == 0:
+            my = 0
+        y0, x0 = int(rng.integers(4, 90 - h - 5)), int(rng.integers(4, 100 - w - 5))
+        sp = C.cast(src.ctypes.data + y0 * 100 + x0, u8p)
+        d0 = rng.integers(0, 256, (64, 72), dtype=np.uint8)
+        a, b = d0.copy(), d0.copy()
+        R.ffref_vp9_mc(f, avg, ptr(a), 72, sp, 100, w, h, mx, my)
+        O.ffo_vp9_mc(f, avg, ptr(b), 72, sp, 100, w, h, mx, my)
+        assert np.array_equal(a, b), (f, avg, w, h, mx, my)
+
+
 def hevc_restore_case(rng, rep):
     """(variant, eo, offset0, borders[4], width, height, vert_edge[2], horiz_edge[2], diag_edge[4]) — every flag on and off"""
     p = .5 if rep % 3 else .85

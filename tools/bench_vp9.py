@@ -42,3 +42,27 @@ for tx in (0, 1, 2, 3):
     byt = px * 6                                   # coefficients read + cleared (2 + 2 B), picture read + written (1 + 1 B)
     print(json.dumps({"case": "vp9 itxfm_add %dx%d, mixed types, %d 4K planes" % (n, n, planes), "blocks": nb, "ms": round(ms, 4),
                       "Gpixel/s": round(px / ms / 1e6, 1), "hbm_frac": round(byt / ms / 1e6 / 8000, 4)}), flush=True)
+# motion compensation: every 16x16 block of the planes, regular / sharp / smooth 8-tap and bilinear mixed, all (mx, my), put
+P = 16
+ref = torch.randint(0, 256, (planes * H + 2 * P, W + 2 * P), dtype=torch.uint8, device=dev)
+pic = torch.zeros((planes * H, W), dtype=torch.uint8, device=dev)
+by, bx = np.meshgrid(np.arange(0, planes * H, 16), np.arange(0, W, 16), indexing="ij")
+n = by.size
+for name, filt in (("8-tap (3 sets mixed)", lambda k: rng.integers(0, 3, k)), ("bilinear", lambda k: np.full(k, 3))):
+    mc = np.zeros(n, vp9.MC_DTYPE)
+    mc["dst_offset"] = (by * W + bx).reshape(-1)
+    mc["src_offset"] = ((by + P + rng.integers(-8, 9, by.shape)) * (W + 2 * P) + bx + P + rng.integers(-8, 9, by.shape)).reshape(-1)
+    mc["width"] = mc["height"] = 16
+    mc["filter"] = filt(n)
+    mc["mx"], mc["my"] = rng.integers(0, 16, n), rng.integers(0, 16, n)
+    d_mc = torch.from_numpy(mc.view(np.uint8).reshape(-1, 16)).to(dev)
+    vp9.mc_batch(pic, W, ref, W + 2 * P, d_mc, n)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        vp9.mc_batch(pic, W, ref, W + 2 * P, d_mc, n)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(json.dumps({"case": "vp9 mc put %s, every 16x16 block of %d 4K planes, mixed (mx, my)" % (name, planes), "blocks": n, "ms": round(ms, 4),
+                      "Gpixel/s": round(planes * W * H / ms / 1e6, 1), "hbm_frac": round(2 * planes * W * H / ms / 1e6 / 8000, 4)}), flush=True)

@@ -336,6 +336,25 @@ def vp9():
                 blks.append(blk); dsts.append(dst); outs.append(o); oblk.append(b); par.append([txtp, eob])
         d["tx%d_blk" % tx], d["tx%d_dst" % tx] = np.stack(blks), np.stack(dsts)
         d["tx%d_out" % tx], d["tx%d_oblk" % tx], d["tx%d_par" % tx] = np.stack(outs), np.stack(oblk), np.array(par, np.int32)
+    # motion compensation: one 96x96 reference, 80 blocks, par = filter, avg, w, h, mx, my, y0, x0; dst in / out [64x64]
+    mref = rng.integers(0, 256, (96, 96), dtype=np.uint8)
+    pars, dout = [], []
+    base = rng.integers(0, 256, (64, 64), dtype=np.uint8)    # every call starts from this destination (avg reads it)
+    for rep in range(80):
+        f, avg = rep % 4, (rep // 4) & 1
+        w = [4, 8, 16, 32, 64][rep % 5]; h = int(rng.choice([2, 4, 8, 16]))
+        mx, my = (int(v) for v in rng.integers(0, 16, 2))
+        if rep % 6 == 0:
+            mx = 0
+        if rep % 9 == 0:
+            my = 0
+        y0, x0 = int(rng.integers(4, 96 - h - 5)), int(rng.integers(4, 96 - w - 5)) if w < 64 else int(rng.integers(4, 27))
+        a = base.copy()
+        R.ffref_vp9_mc(f, avg, ptr(a), 64, at(mref, y0 * 96 + x0), 96, w, h, mx, my)
+        assert np.array_equal(a[h:], base[h:]) and np.array_equal(a[:, w:], base[:, w:])
+        a[h:] = 0; a[:, w:] = 0                               # only the block is stored
+        dout.append(a); pars.append([f, avg, w, h, mx, my, y0, x0])
+    d["mc_ref"], d["mc_par"], d["mc_in"], d["mc_out"] = mref, np.array(pars, np.int32), base, np.stack(dout)
     np.savez_compressed(os.path.join(OUT, "vp9.npz"), **d)
 
 
