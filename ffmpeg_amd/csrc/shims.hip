@@ -726,3 +726,68 @@ extern "C" int ff_vp9dsp_mc_init_hip(FFHipVP9McContext *c, int bpp)
     vp9_mc_fill<64, 0>(c); vp9_mc_fill<32, 1>(c); vp9_mc_fill<16, 2>(c); vp9_mc_fill<8, 3>(c); vp9_mc_fill<4, 4>(c);
     return 0;
 }
+
+/* ---- vp9dsp loop-filter host faces: 16 lines x 16 samples around the edge travel through scratch (pitch 32) ---- */
+static void vp9_lf_single(int nseg, const int wd_idx[2], int dir, uint8_t *dst, ptrdiff_t stride, const int E[2], const int I[2], const int H[2])
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    const int P = 32, lines = 8 * nseg;
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + 32 * P + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch, *d = buf + 64;
+    /* device layout: the edge at column 8 (dir 0: rows = lines) or row 8 (dir 1: columns = lines); only the samples the
+     * reference function of this slot touches travel: 8 on either side for the 16-wide filter, 4 otherwise */
+    const int r = (wd_idx[0] == 2 || (nseg == 2 && wd_idx[1] == 2)) ? 8 : 4;
+    const int rows = dir ? 2 * r : lines, cols = dir ? lines : 2 * r;
+    const uint8_t *h0 = dir ? dst - r * stride : dst - r;
+    uint8_t *dd = dir ? d + (8 - r) * P : d + (8 - r);
+    if (hipMemcpy2D(dd, P, h0, stride, cols, rows, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    FFHipVp9Edge k[2] = {};
+    for (int sgm = 0; sgm < nseg; sgm++) {
+        k[sgm].offset = dir ? 8 * P + 8 * sgm : 8 * sgm * P + 8;
+        k[sgm].wd_idx = (uint8_t)wd_idx[sgm]; k[sgm].dir = (uint8_t)dir;
+        k[sgm].E = (uint8_t)E[sgm]; k[sgm].I = (uint8_t)I[sgm]; k[sgm].H = (uint8_t)H[sgm];
+    }
+    if (hipMemcpy(buf, k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_vp9_loop_filter(d, P, (const FFHipVp9Edge *)buf, nseg, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    (void)hipMemcpy2D((uint8_t *)h0, stride, dd, P, cols, rows, hipMemcpyDeviceToHost);
+}
+template <int WD, int DIR>
+static void s_vp9_lf8(uint8_t *d, ptrdiff_t s, int E, int I, int H)
+{
+    const int w[2] = { WD, 0 }, e[2] = { E, 0 }, i[2] = { I, 0 }, h[2] = { H, 0 };
+    vp9_lf_single(1, w, DIR, d, s, e, i, h);
+}
+template <int DIR>
+static void s_vp9_lf16(uint8_t *d, ptrdiff_t s, int E, int I, int H)
+{
+    const int w[2] = { 2, 2 }, e[2] = { E, E }, i[2] = { I, I }, h[2] = { H, H };
+    vp9_lf_single(2, w, DIR, d, s, e, i, h);
+}
+template <int W1, int W2, int DIR>
+static void s_vp9_lfmix(uint8_t *d, ptrdiff_t s, int E, int I, int H)
+{
+    const int w[2] = { W1, W2 }, e[2] = { E & 0xff, E >> 8 }, i[2] = { I & 0xff, I >> 8 }, h[2] = { H & 0xff, H >> 8 };
+    vp9_lf_single(2, w, DIR, d, s, e, i, h);
+}
+
+extern "C" int ff_vp9dsp_loopfilter_init_hip(FFHipVP9LoopFilterContext *c, int bpp)
+{
+    if (!c || bpp != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    c->loop_filter_8[0][0] = s_vp9_lf8<0, 0>; c->loop_filter_8[0][1] = s_vp9_lf8<0, 1>;
+    c->loop_filter_8[1][0] = s_vp9_lf8<1, 0>; c->loop_filter_8[1][1] = s_vp9_lf8<1, 1>;
+    c->loop_filter_8[2][0] = s_vp9_lf8<2, 0>; c->loop_filter_8[2][1] = s_vp9_lf8<2, 1>;
+    c->loop_filter_16[0] = s_vp9_lf16<0>; c->loop_filter_16[1] = s_vp9_lf16<1>;
+    c->loop_filter_mix2[0][0][0] = s_vp9_lfmix<0, 0, 0>; c->loop_filter_mix2[0][0][1] = s_vp9_lfmix<0, 0, 1>;
+    c->loop_filter_mix2[0][1][0] = s_vp9_lfmix<0, 1, 0>; c->loop_filter_mix2[0][1][1] = s_vp9_lfmix<0, 1, 1>;
+    c->loop_filter_mix2[1][0][0] = s_vp9_lfmix<1, 0, 0>; c->loop_filter_mix2[1][0][1] = s_vp9_lfmix<1, 0, 1>;
+    c->loop_filter_mix2[1][1][0] = s_vp9_lfmix<1, 1, 0>; c->loop_filter_mix2[1][1][1] = s_vp9_lfmix<1, 1, 1>;
+    return 0;
+}

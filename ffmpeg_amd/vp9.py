@@ -51,3 +51,28 @@ def mc_init(bpp=8):
     c = VP9McContext()
     _lib.check(_lib.lib().ff_vp9dsp_mc_init_hip(C.byref(c), bpp), "ff_vp9dsp_mc_init_hip")
     return c
+
+
+#: FFHipVp9Edge (include/ffhip.h)
+EDGE_DTYPE = np.dtype([("offset", np.int32), ("wd_idx", np.uint8), ("dir", np.uint8), ("E", np.uint8), ("I", np.uint8), ("H", np.uint8),
+                       ("pad", np.uint8, 3)])
+
+
+def loop_filter_batch(base, stride, edges, n, stream=None):
+    """edges: uint8 [n, 12] FFHipVp9Edge records (8-sample segments that share no sample)"""
+    return _lib.check(_lib.lib().ffhip_vp9_loop_filter_batch_dev(base.data_ptr(), stride, edges.data_ptr(), n,
+                                                                 None if stream is None else C.c_void_p(stream)),
+                      "ffhip_vp9_loop_filter_batch_dev")
+
+
+_LF = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int)
+
+
+class VP9LoopFilterContext(C.Structure):
+    _fields_ = [("loop_filter_8", _LF * 2 * 3), ("loop_filter_16", _LF * 2), ("loop_filter_mix2", _LF * 2 * 2 * 2)]
+
+
+def lf_init(bpp=8):
+    c = VP9LoopFilterContext()
+    _lib.check(_lib.lib().ff_vp9dsp_loopfilter_init_hip(C.byref(c), bpp), "ff_vp9dsp_loopfilter_init_hip")
+    return c

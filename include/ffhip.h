@@ -639,6 +639,27 @@ typedef struct FFHipVp9McBlock {
 int ffhip_vp9_mc_batch_dev(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9McBlock *blocks,
                            int n, void *stream);
 
+/** The loop-filter tables of VP9DSPContext (libavcodec/vp9dsp.h:76-105): loop_filter_8[width 4/8/16][h col-edge / v row-edge],
+ *  loop_filter_16[dir], loop_filter_mix2[wd1][wd2][dir] (two 8-sample halves, limits packed in the two low bytes). */
+typedef void (*ffhip_vp9_lf_func)(uint8_t *dst, ptrdiff_t stride, int mb_lim, int lim, int hev_thr);
+typedef struct FFHipVP9LoopFilterContext {
+    ffhip_vp9_lf_func loop_filter_8[3][2];
+    ffhip_vp9_lf_func loop_filter_16[2];
+    ffhip_vp9_lf_func loop_filter_mix2[2][2][2];
+} FFHipVP9LoopFilterContext;
+int ff_vp9dsp_loopfilter_init_hip(FFHipVP9LoopFilterContext *c, int bpp);
+/** One 8-sample segment of an edge: what one loop_filter() call of the reference covers (vp9dsp_template.c:1780-1889). */
+typedef struct FFHipVp9Edge {
+    int32_t offset;      /* bytes into the plane: the first q0 sample of the segment */
+    uint8_t wd_idx;      /* 0: 4, 1: 8, 2: 16 */
+    uint8_t dir;         /* 0: column edge (loop_filter_h_*), 1: row edge (loop_filter_v_*) */
+    uint8_t E, I, H;     /* mb_lim, lim, hev_thr */
+    uint8_t pad[3];      /* sizeof == 12 */
+} FFHipVp9Edge;
+/** n segments that share no sample (VP9 orders the overlapping edges of a superblock: column edges left to right, then row
+ *  edges; a caller batches what is disjoint, e.g. every other 8-sample column of wd <= 8 edges). */
+int ffhip_vp9_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */
 /* ------------------------------------------------------------------------------------------ */

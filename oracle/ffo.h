@@ -97,6 +97,8 @@ void ffo_vp9_itxfm_add(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t
 /* VP9DSPContext.mc[..][filter][avg][!!mx][!!my], 8 bits: filter 0 smooth, 1 regular, 2 sharp, 3 bilinear */
 void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
                 int mx, int my);
+/* one 8-sample segment of a VP9 edge: wd 4 | 8 | 16, dir 0 column edge ("h"), 1 row edge ("v") */
+void ffo_vp9_loop_filter(int wd, int dir, uint8_t *dst, ptrdiff_t stride, int E, int I, int H);
 void ffo_hevc_dequant(int16_t *coeffs, int log2_size);
 void ffo_hevc_transform_rdpcm(int16_t *coeffs, int log2_size, int mode);
 void ffo_hevc_sao_edge_restore(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, int eo, int offset0,

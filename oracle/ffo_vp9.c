@@ -401,3 +401,60 @@ void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const ui
             dst[y * dststride + x] = avg ? (dst[y * dststride + x] + v + 1) >> 1 : v;
         }
 }
+
+/*
+ * VP9 loop filter, 8 bits: one 8-sample segment of an edge, loop_filter() (libavcodec/vp9dsp_template.c:1780-1889) as
+ * loop_filter_8[wd][dir], loop_filter_16[dir] (two segments) and loop_filter_mix2[wd1][wd2][dir] (two segments, the limits
+ * packed in the two low bytes) call it (:1891-1966).  dir 0 = "h": a column edge, the segment runs down (next line = + stride,
+ * across = 1); dir 1 = "v": a row edge.  wd = 4, 8 or 16.
+ * The two flat filters are stated as what they are: a window of radius 3 / 7 around the sample over the 8 / 16 samples
+ * p3..q3 / p7..q7 with the ends repeated, the centre counted twice.
+ */
+static int iabs(int v) { return v < 0 ? -v : v; }
+static int clip_i8(int v) { return v < -128 ? -128 : v > 127 ? 127 : v; }
+
+void ffo_vp9_loop_filter(int wd, int dir, uint8_t *dst, ptrdiff_t stride, int E, int I, int H)
+{
+    const ptrdiff_t along = dir ? 1 : stride, across = dir ? stride : 1;
+    for (int i = 0; i < 8; i++, dst += along) {
+        int px[16]; /* p7 .. p0, q0 .. q7 */
+        const int r = wd >= 16 ? 8 : 4;
+        for (int k = -r; k < r; k++)
+            px[8 + k] = dst[k * across];
+        const int p3 = px[4], p2 = px[5], p1 = px[6], p0 = px[7], q0 = px[8], q1 = px[9], q2 = px[10], q3 = px[11];
+        if (!(iabs(p3 - p2) <= I && iabs(p2 - p1) <= I && iabs(p1 - p0) <= I && iabs(q1 - q0) <= I && iabs(q2 - q1) <= I &&
+              iabs(q3 - q2) <= I && iabs(p0 - q0) * 2 + (iabs(p1 - q1) >> 1) <= E))
+            continue;
+        int flat_in = wd >= 8, flat_out = wd >= 16;
+        for (int k = 1; k <= 3 && flat_in; k++)
+            flat_in = iabs(px[7 - k] - p0) <= 1 && iabs(px[8 + k] - q0) <= 1;
+        for (int k = 4; k <= 7 && flat_out; k++)
+            flat_out = iabs(px[7 - k] - p0) <= 1 && iabs(px[8 + k] - q0) <= 1;
+        if (flat_out && flat_in) {
+            for (int c = 1; c <= 14; c++) {
+                int s = px[c] + 8;
+                for (int t = -7; t <= 7; t++)
+                    s += px[c + t < 0 ? 0 : c + t > 15 ? 15 : c + t];
+                dst[(c - 8) * across] = s >> 4;
+            }
+        } else if (flat_in) {
+            for (int c = 5; c <= 10; c++) {
+                int s = px[c] + 4;
+                for (int t = -3; t <= 3; t++)
+                    s += px[c + t < 4 ? 4 : c + t > 11 ? 11 : c + t];
+                dst[(c - 8) * across] = s >> 3;
+            }
+        } else {
+            const int hev = iabs(p1 - p0) > H || iabs(q1 - q0) > H;
+            int f = clip_i8(3 * (q0 - p0) + (hev ? clip_i8(p1 - q1) : 0));
+            const int f1 = (f + 4 > 127 ? 127 : f + 4) >> 3, f2 = (f + 3 > 127 ? 127 : f + 3) >> 3;
+            dst[-across] = clip_px(p0 + f2);
+            dst[0] = clip_px(q0 - f1);
+            if (!hev) {
+                f = (f1 + 1) >> 1;
+                dst[-2 * across] = clip_px(p1 + f);
+                dst[across] = clip_px(q1 - f);
+            }
+        }
+    }
+}

@@ -289,6 +289,23 @@ void ffref_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const 
         idx++;
     vp9.mc[idx][filter][avg][!!mx][!!my](dst, dststride, src, srcstride, height, mx, my);
 }
+/* which 0: loop_filter_8[a][dir], 1: loop_filter_16[dir], 2: loop_filter_mix2[a][b][dir] */
+void ffref_vp9_loop_filter(int which, int a, int b, int dir, uint8_t *dst, ptrdiff_t stride, int E, int I, int H)
+{
+    static VP9DSPContext vp9;
+    static int vp9_ready;
+    pure_c();
+    if (!vp9_ready) {
+        ff_vp9dsp_init(&vp9, 8, 1);
+        vp9_ready = 1;
+    }
+    if (which == 0)
+        vp9.loop_filter_8[a][dir](dst, stride, E, I, H);
+    else if (which == 1)
+        vp9.loop_filter_16[dir](dst, stride, E, I, H);
+    else
+        vp9.loop_filter_mix2[a][b][dir](dst, stride, E, I, H);
+}
 void ffref_hevc_dequant(int16_t *coeffs, int log2_size)
 {
     dsp_init();

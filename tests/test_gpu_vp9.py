@@ -177,3 +177,74 @@ def test_vp9_mc_golden_gpu():
     for i, (f, avg, w, h, mx, my, y0, x0) in enumerate(par.tolist()):
         assert np.array_equal(got[i][:h, :w], d["mc_out"][i][:h, :w]), i
         assert np.array_equal(got[i][h:], base[h:]) and np.array_equal(got[i][:, w:], base[:, w:]), i
+
+
+def test_vp9_loop_filter_batch():
+    """disjoint 8-sample segments all over a plane: both directions, the three widths, limits from wide open to tight; content
+    that reaches the flat16 / flat8 / narrow / hev branches"""
+    from ffmpeg_amd import vp9
+    from test_oracle_vs_ref import vp9_lf_plane
+    torch = _torch()
+    rng = np.random.default_rng(430)
+    gy, gx = 14, 20
+    plane = np.zeros((gy * 48, gx * 48 + 3), np.uint8)
+    for ty in range(gy):
+        for tx in range(gx):
+            plane[ty * 48:(ty + 1) * 48, tx * 48:(tx + 1) * 48] = vp9_lf_plane(rng)
+    stride = plane.shape[1]
+    want = plane.copy()
+    O = ffi.oracle()
+    recs = []
+    WD = [4, 8, 16]
+    for ty in range(gy):
+        for tx in range(gx):
+            d, w = int(rng.integers(0, 2)), int(rng.integers(0, 3))
+            E, I, H = int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16))
+            if (ty + tx) % 3 == 0:
+                E, I = 255, 63
+            nseg = int(rng.integers(1, 3))
+            for sgm in range(nseg):                    # one or two segments along the edge through the tile's centre
+                off = (ty * 48 + 24) * stride + tx * 48 + 24 + 8 * sgm * (1 if d else stride)
+                recs.append((off, w, d, E, I, H, (0, 0, 0)))
+                O.ffo_vp9_loop_filter(WD[w], d, C.cast(want.ctypes.data + off, u8p), stride, E, I, H)
+    n = len(recs)
+    rec = np.array(recs, vp9.EDGE_DTYPE)
+    d_pl = torch.from_numpy(plane.copy()).cuda()
+    vp9.loop_filter_batch(d_pl, stride, torch.from_numpy(rec.view(np.uint8).reshape(n, 12).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    assert (want != plane).sum() > 2000
+    got = d_pl.cpu().numpy()
+    assert np.array_equal(got, want), "%d mismatches" % (got != want).sum()
+
+
+def test_vp9_loop_filter_host_faces():
+    from ffmpeg_amd import vp9
+    from test_oracle_vs_ref import vp9_lf_plane
+    _torch()
+    c = vp9.lf_init(8)
+    O = ffi.oracle()
+    rng = np.random.default_rng(431)
+    WD = [4, 8, 16]
+    for rep in range(36):
+        pl = vp9_lf_plane(rng)
+        a, b = pl.copy(), pl.copy()
+        d = rep & 1
+        E, I, H = (255, 63, int(rng.integers(0, 16))) if rep % 3 == 0 else (int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16)))
+        p0 = 24 * 48 + 24
+        seg2 = 8 * (1 if d else 48)
+        which = rep % 3
+        if which == 0:
+            w = (rep // 3) % 3
+            c.loop_filter_8[w][d](a.ctypes.data + p0, 48, E, I, H)
+            O.ffo_vp9_loop_filter(WD[w], d, C.cast(b.ctypes.data + p0, u8p), 48, E, I, H)
+        elif which == 1:
+            c.loop_filter_16[d](a.ctypes.data + p0, 48, E, I, H)
+            for sgm in range(2):
+                O.ffo_vp9_loop_filter(16, d, C.cast(b.ctypes.data + p0 + sgm * seg2, u8p), 48, E, I, H)
+        else:
+            w1, w2 = (rep // 3) & 1, (rep // 6) & 1
+            E2, I2, H2 = int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16))
+            c.loop_filter_mix2[w1][w2][d](a.ctypes.data + p0, 48, E | E2 << 8, I | I2 << 8, H | H2 << 8)
+            O.ffo_vp9_loop_filter(WD[w1], d, C.cast(b.ctypes.data + p0, u8p), 48, E, I, H)
+            O.ffo_vp9_loop_filter(WD[w2], d, C.cast(b.ctypes.data + p0 + seg2, u8p), 48, E2, I2, H2)
+        assert np.array_equal(a, b), (rep, which, d)

@@ -512,6 +512,54 @@ def test_vp9_mc():
         assert np.array_equal(a, b), (f, avg, w, h, mx, my)
 
 
+def vp9_lf_plane(rng, n=48):
+    """a 48x48 patch around an edge at (24, 24): flat, nearly flat (the flat8 / flat16 decisions sit at |d| <= 1), stepped or noisy on
+    either side — tests/checkasm/vp9dsp.c's randomize_loopfilter_buffers in spirit"""
+    kind = int(rng.integers(0, 5))
+    a, b = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+    if kind < 3:
+        b = int(np.clip(a + rng.integers(-6, 7), 0, 255))
+    p = np.empty((n, n), np.int32)
+    p[:, :n // 2] = a
+    p[:, n // 2:] = b
+    p = p.T.copy() if rng.random() < .5 else p
+    noise = [0, 1, 1, 3, 40][kind]
+    p = p + rng.integers(-noise, noise + 1, (n, n))
+    return np.clip(p, 0, 255).astype(np.uint8)
+
+
+def test_vp9_loop_filter():
+    """loop_filter_8[3][2], loop_filter_16[2] and loop_filter_mix2[2][2][2] against the one-segment oracle"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(97)
+    WD = [4, 8, 16]
+    for rep in range(3000):
+        pl = vp9_lf_plane(rng)
+        E, I, H = int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16))
+        if rep % 3 == 0:
+            E, I = 255, 63                       # wide open: the flat branches decide
+        a, b = pl.copy(), pl.copy()
+        dirn = rep & 1
+        which = rep % 3
+        at_ = lambda arr: C.cast(arr.ctypes.data + 24 * 48 + 24 - (8 if not dirn else 8 * 48) * 0, u8p)
+        seg2 = 8 * (48 if not dirn else 1)       # the second segment of the 16-sample forms
+        if which == 0:
+            w = int(rng.integers(0, 3))
+            R.ffref_vp9_loop_filter(0, w, 0, dirn, at_(a), 48, E, I, H)
+            O.ffo_vp9_loop_filter(WD[w], dirn, at_(b), 48, E, I, H)
+        elif which == 1:
+            R.ffref_vp9_loop_filter(1, 0, 0, dirn, at_(a), 48, E, I, H)
+            O.ffo_vp9_loop_filter(16, dirn, at_(b), 48, E, I, H)
+            O.ffo_vp9_loop_filter(16, dirn, C.cast(b.ctypes.data + 24 * 48 + 24 + seg2, u8p), 48, E, I, H)
+        else:
+            w1, w2 = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            E2, I2, H2 = int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16))
+            R.ffref_vp9_loop_filter(2, w1, w2, dirn, at_(a), 48, E | E2 << 8, I | I2 << 8, H | H2 << 8)
+            O.ffo_vp9_loop_filter(WD[w1], dirn, at_(b), 48, E, I, H)
+            O.ffo_vp9_loop_filter(WD[w2], dirn, C.cast(b.ctypes.data + 24 * 48 + 24 + seg2, u8p), 48, E2, I2, H2)
+        assert np.array_equal(a, b), (rep, which, dirn, E, I, H)
+
+
 def hevc_restore_case(rng, rep):
     """(variant, eo, offset0, borders[4], width, height, vert_edge[2], horiz_edge[2], diag_edge[4]) — every flag on and off"""
     p = .5 if rep % 3 else .85
