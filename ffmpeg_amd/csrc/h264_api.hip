@@ -132,6 +132,16 @@ extern "C" int ffhip_hevc_sao_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, cons
     return ffhip_launch_hevc_sao(dst, stride_dst, src, stride_src, blocks, n, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_vp9_intra_pred_batch_dev(int tx, uint8_t *dst, ptrdiff_t stride, const uint8_t *edges, const FFHipVp9Intra *blocks, int n,
+                                              void *stream)
+{
+    if (!dst || !edges || !blocks || n < 0 || tx < 0 || tx > 3)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_intra(tx, dst, stride, edges, blocks, n, (hipStream_t)stream);
+}
+
 extern "C" int ffhip_vp9_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, void *stream)
 {
     if (!base || !edges || n < 0)

@@ -791,3 +791,47 @@ extern "C" int ff_vp9dsp_loopfilter_init_hip(FFHipVP9LoopFilterContext *c, int b
     c->loop_filter_mix2[1][1][0] = s_vp9_lfmix<1, 1, 0>; c->loop_filter_mix2[1][1][1] = s_vp9_lfmix<1, 1, 1>;
     return 0;
 }
+
+/* ---- vp9dsp intra_pred host faces: the edge line is assembled from exactly the samples the mode reads ---- */
+template <int TX, int MODE>
+static void s_vp9_intra(uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    constexpr int N = 4 << TX;
+    constexpr bool use_top = MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7 || MODE == 9 || MODE == 11;
+    constexpr bool use_left = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 8 || MODE == 9 || MODE == 10;
+    constexpr bool use_tl = MODE == 4 || MODE == 5 || MODE == 6 || MODE == 9;
+    constexpr int ntop = (TX == 0 && (MODE == 3 || MODE == 7)) ? 8 : N;
+    uint8_t e[32 + 1 + 32 + 8] = { 0 };
+    if (use_left) memcpy(e, left, N);
+    if (use_tl) e[N] = top[-1];
+    if (use_top) memcpy(e + N + 1, top, ntop);
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + 128 + (size_t)N * 32 + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch, *de = buf + 64, *dd = de + 128;
+    FFHipVp9Intra k = {};
+    k.mode = MODE;
+    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(de, e, sizeof(e), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_vp9_intra(TX, dd, 32, de, (const FFHipVp9Intra *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    (void)hipMemcpy2D(dst, stride, dd, 32, N, N, hipMemcpyDeviceToHost);
+}
+template <int TX>
+static void vp9_intra_fill(FFHipVP9IntraContext *c)
+{
+#define VI(M) c->intra_pred[TX][M] = s_vp9_intra<TX, M>;
+    VI(0) VI(1) VI(2) VI(3) VI(4) VI(5) VI(6) VI(7) VI(8) VI(9) VI(10) VI(11) VI(12) VI(13) VI(14)
+#undef VI
+}
+
+extern "C" int ff_vp9dsp_intrapred_init_hip(FFHipVP9IntraContext *c, int bpp)
+{
+    if (!c || bpp != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    vp9_intra_fill<0>(c); vp9_intra_fill<1>(c); vp9_intra_fill<2>(c); vp9_intra_fill<3>(c);
+    return 0;
+}

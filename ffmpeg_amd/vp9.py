@@ -76,3 +76,24 @@ def lf_init(bpp=8):
     c = VP9LoopFilterContext()
     _lib.check(_lib.lib().ff_vp9dsp_loopfilter_init_hip(C.byref(c), bpp), "ff_vp9dsp_loopfilter_init_hip")
     return c
+
+
+#: FFHipVp9Intra (include/ffhip.h)
+INTRA_DTYPE = np.dtype([("dst_offset", np.int32), ("edge_offset", np.int32), ("mode", np.uint8), ("pad", np.uint8, 3)])
+
+
+def intra_pred_batch(tx, dst, stride, edges, blocks, n, stream=None):
+    """edges: uint8 device tensor of edge lines (left[0..N-1], corner, top[0..max(N,8)-1] per block); blocks: uint8 [n, 12]"""
+    return _lib.check(_lib.lib().ffhip_vp9_intra_pred_batch_dev(tx, dst.data_ptr(), stride, edges.data_ptr(), blocks.data_ptr(), n,
+                                                                None if stream is None else C.c_void_p(stream)),
+                      "ffhip_vp9_intra_pred_batch_dev")
+
+
+class VP9IntraContext(C.Structure):
+    _fields_ = [("intra_pred", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p) * 15 * 4)]
+
+
+def intra_init(bpp=8):
+    c = VP9IntraContext()
+    _lib.check(_lib.lib().ff_vp9dsp_intrapred_init_hip(C.byref(c), bpp), "ff_vp9dsp_intrapred_init_hip")
+    return c

@@ -660,6 +660,25 @@ typedef struct FFHipVp9Edge {
  *  edges; a caller batches what is disjoint, e.g. every other 8-sample column of wd <= 8 edges). */
 int ffhip_vp9_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, void *stream);
 
+/** VP9DSPContext.intra_pred[tx 4x4..32x32][enum IntraPredMode] (libavcodec/vp9dsp.h:52-55, libavcodec/vp9.h:45-62): left[] runs
+ *  bottom to top, top[-1] is the corner; the 4x4 down-left / vert-left modes read top[0..7]. */
+typedef void (*ffhip_vp9_intra_func)(uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top);
+typedef struct FFHipVP9IntraContext {
+    ffhip_vp9_intra_func intra_pred[4][15];
+} FFHipVP9IntraContext;
+int ff_vp9dsp_intrapred_init_hip(FFHipVP9IntraContext *c, int bpp);
+/** One block of the batch face.  Its neighbours live in `edges` as the edge line: left[0..N-1], the corner, top[0..max(N,8)-1]
+ *  (N + 1 + max(N, 8) bytes at edge_offset) — what the decoder's edge preparation (libavcodec/vp9recon.c, check_intra_mode)
+ *  produces, concatenated. */
+typedef struct FFHipVp9Intra {
+    int32_t dst_offset;   /* bytes into dst */
+    int32_t edge_offset;  /* bytes into edges */
+    uint8_t mode;         /* enum IntraPredMode 0..14 */
+    uint8_t pad[3];       /* sizeof == 12 */
+} FFHipVp9Intra;
+int ffhip_vp9_intra_pred_batch_dev(int tx, uint8_t *dst, ptrdiff_t stride, const uint8_t *edges, const FFHipVp9Intra *blocks, int n,
+                                   void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */
 /* ------------------------------------------------------------------------------------------ */

@@ -458,3 +458,107 @@ void ffo_vp9_loop_filter(int wd, int dir, uint8_t *dst, ptrdiff_t stride, int E,
         }
     }
 }
+
+/*
+ * VP9 intra prediction, 8 bits: VP9DSPContext.intra_pred[tx][mode](dst, stride, left, top)
+ * (libavcodec/vp9dsp_template.c:33-1153; enum IntraPredMode, libavcodec/vp9.h:45-62).  left[] runs bottom to top (left[N-1] is
+ * beside row 0), top[-1] is the corner.  The reference writes every size of every mode out; here each mode is its per-sample rule
+ * over the "edge line" e[] = left[0..N-1], corner, top[0..]: e[k] walks up the left column, round the corner and along the top.
+ */
+static int A2(int a, int b) { return (a + b + 1) >> 1; }
+static int A3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
+
+void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
+{
+    const int n = 4 << tx, lg = 2 + tx;
+    int e[32 + 1 + 64]; /* edge line; the 4x4 down-left / vert-left modes read 8 top samples, nobody reads more than 2n */
+    int dc = 0;
+    const int uses_top = mode == 0 || mode == 2 || mode == 3 || mode == 4 || mode == 5 || mode == 6 || mode == 7 || mode == 9 || mode == 11;
+    const int uses_left = mode == 1 || mode == 2 || mode == 4 || mode == 5 || mode == 6 || mode == 8 || mode == 9 || mode == 10;
+    const int ntop = (tx == 0 && (mode == 3 || mode == 7)) ? 8 : n;
+    memset(e, 0, sizeof(e));
+    if (uses_left)
+        for (int k = 0; k < n; k++)
+            e[k] = left[k];
+    if (mode == 4 || mode == 5 || mode == 6 || mode == 9)
+        e[n] = top[-1];
+    if (uses_top)
+        for (int k = 0; k < ntop; k++)
+            e[n + 1 + k] = top[k];
+    const int *T = e + n + 1; /* T[-1] = corner */
+    if (mode == 2) {
+        for (int k = 0; k < n; k++)
+            dc += e[k] + T[k];
+        dc = (dc + n) >> (lg + 1);
+    } else if (mode == 10 || mode == 11) {
+        for (int k = 0; k < n; k++)
+            dc += mode == 10 ? e[k] : T[k];
+        dc = (dc + n / 2) >> lg;
+    } else if (mode >= 12) {
+        dc = mode == 12 ? 128 : mode == 13 ? 127 : 129;
+    }
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            int v;
+            switch (mode) {
+            case 0: v = T[x]; break;                                                     /* VERT */
+            case 1: v = e[n - 1 - y]; break;                                             /* HOR */
+            case 3: {                                                                    /* DIAG_DOWN_LEFT */
+                const int i = x + y;
+                if (tx == 0)
+                    v = i < 6 ? A3(T[i], T[i + 1], T[i + 2]) : T[7];
+                else
+                    v = i < n - 2 ? A3(T[i], T[i + 1], T[i + 2]) : i == n - 2 ? (T[n - 2] + 3 * T[n - 1] + 2) >> 2 : T[n - 1];
+                break;
+            }
+            case 4: {                                                                    /* DIAG_DOWN_RIGHT: along the edge line */
+                const int i = n - 1 - y + x;
+                v = A3(e[i], e[i + 1], e[i + 2]);
+                break;
+            }
+            case 5: {                                                                    /* VERT_RIGHT */
+                const int i = n / 2 - 1 - (y >> 1) + x;
+                if (i >= n / 2 - 1) {
+                    const int k = n + i - (n / 2 - 1);
+                    v = (y & 1) ? A3(e[k - 1], e[k], e[k + 1]) : A2(e[k], e[k + 1]);
+                } else {
+                    v = (y & 1) ? A3(e[2 * i + 3], e[2 * i + 2], e[2 * i + 1]) : A3(e[2 * i + 4], e[2 * i + 3], e[2 * i + 2]);
+                }
+                break;
+            }
+            case 6: {                                                                    /* HOR_DOWN */
+                const int i = 2 * n - 2 - 2 * y + x;
+                if (i >= 2 * n)
+                    v = A3(e[i - n], e[i - n + 1], e[i - n + 2]);
+                else
+                    v = (i & 1) ? A3(e[(i >> 1) + 2], e[(i >> 1) + 1], e[i >> 1]) : A2(e[(i >> 1) + 1], e[i >> 1]);
+                break;
+            }
+            case 7: {                                                                    /* VERT_LEFT */
+                const int i = (y >> 1) + x;
+                if (tx == 0)
+                    v = (y & 1) ? A3(T[i], T[i + 1], T[i + 2]) : A2(T[i], T[i + 1]);
+                else if (i >= n - 1)
+                    v = T[n - 1];
+                else if (y & 1)
+                    v = i < n - 2 ? A3(T[i], T[i + 1], T[i + 2]) : (T[n - 2] + 3 * T[n - 1] + 2) >> 2;
+                else
+                    v = A2(T[i], T[i + 1]);
+                break;
+            }
+            case 8: {                                                                    /* HOR_UP: left[] counted from index 0 */
+                const int i = 2 * y + x;
+                if (i >= 2 * n - 2)
+                    v = e[n - 1];
+                else if (i == 2 * n - 3)
+                    v = (e[n - 2] + 3 * e[n - 1] + 2) >> 2;
+                else
+                    v = (i & 1) ? A3(e[i >> 1], e[(i >> 1) + 1], e[(i >> 1) + 2]) : A2(e[i >> 1], e[(i >> 1) + 1]);
+                break;
+            }
+            case 9: v = clip_px(T[x] + e[n - 1 - y] - T[-1]); break;                     /* TM */
+            default: v = dc; break;                                                      /* DC, LEFT_DC, TOP_DC, DC_128/127/129 */
+            }
+            dst[y * stride + x] = (uint8_t)v;
+        }
+}

@@ -306,6 +306,17 @@ void ffref_vp9_loop_filter(int which, int a, int b, int dir, uint8_t *dst, ptrdi
     else
         vp9.loop_filter_mix2[a][b][dir](dst, stride, E, I, H);
 }
+void ffref_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
+{
+    static VP9DSPContext vp9;
+    static int vp9_ready;
+    pure_c();
+    if (!vp9_ready) {
+        ff_vp9dsp_init(&vp9, 8, 1);
+        vp9_ready = 1;
+    }
+    vp9.intra_pred[tx][mode](dst, stride, left, top);
+}
 void ffref_hevc_dequant(int16_t *coeffs, int log2_size)
 {
     dsp_init();

@@ -114,6 +114,8 @@ def oracle():
         L.ffo_vp9_itxfm_add.restype = None
         L.ffo_vp9_mc.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_vp9_mc.restype = None
+        L.ffo_vp9_intra_pred.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, u8p]
+        L.ffo_vp9_intra_pred.restype = None
         L.ffo_vp9_loop_filter.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
         L.ffo_vp9_loop_filter.restype = None
         L.ffo_hevc_dequant.argtypes = [i16p, C.c_int]
@@ -211,6 +213,8 @@ def ref():
         L.ffref_vp9_itxfm_add.restype = None
         L.ffref_vp9_mc.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffref_vp9_mc.restype = None
+        L.ffref_vp9_intra_pred.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, u8p]
+        L.ffref_vp9_intra_pred.restype = None
         L.ffref_vp9_loop_filter.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
         L.ffref_vp9_loop_filter.restype = None
         L.ffref_hevc_dequant.argtypes = [i16p, C.c_int]

@@ -248,3 +248,56 @@ def test_vp9_loop_filter_host_faces():
             O.ffo_vp9_loop_filter(WD[w1], d, C.cast(b.ctypes.data + p0, u8p), 48, E, I, H)
             O.ffo_vp9_loop_filter(WD[w2], d, C.cast(b.ctypes.data + p0 + seg2, u8p), 48, E2, I2, H2)
         assert np.array_equal(a, b), (rep, which, d)
+
+
+@pytest.mark.parametrize("tx", range(4))
+def test_vp9_intra_pred_batch(tx):
+    """hundreds of blocks of one size, all 15 modes, edge lines with extreme content; destination rows on and off the dword grid"""
+    from ffmpeg_amd import vp9
+    torch = _torch()
+    rng = np.random.default_rng(440 + tx)
+    n = 4 << tx
+    gx, gy = 30, 12
+    nb = gx * gy
+    stride = gx * n + (4 if tx & 1 else 5)
+    dst = rng.integers(0, 256, (gy * n, stride), dtype=np.uint8)
+    want = dst.copy()
+    slot = n + 1 + max(n, 8)
+    edges = rng.integers(0, 256, (nb, slot), dtype=np.uint8)
+    edges[::4] = rng.choice(np.array([0, 255], np.uint8), (len(edges[::4]), slot))
+    rec = np.zeros(nb, vp9.INTRA_DTYPE)
+    O = ffi.oracle()
+    for b in range(nb):
+        by, bx = divmod(b, gx)
+        mode = b % 15
+        rec[b] = (by * n * stride + bx * n, b * slot, mode, (0, 0, 0))
+        e = edges[b]
+        left = np.ascontiguousarray(e[:n])
+        topbuf = np.zeros(16 + 64, np.uint8)
+        topbuf[15] = e[n]
+        topbuf[16:16 + max(n, 8)] = e[n + 1:]
+        O.ffo_vp9_intra_pred(tx, mode, C.cast(want.ctypes.data + by * n * stride + bx * n, u8p), stride, ptr(left),
+                             C.cast(topbuf.ctypes.data + 16, u8p))
+    d_dst = torch.from_numpy(dst.copy()).cuda()
+    vp9.intra_pred_batch(tx, d_dst, stride, torch.from_numpy(edges).cuda(), torch.from_numpy(rec.view(np.uint8).reshape(nb, 12).copy()).cuda(), nb)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    assert np.array_equal(got, want), "%d mismatches, first %s" % ((got != want).sum(), np.argwhere(got != want)[:3])
+
+
+def test_vp9_intra_pred_host_faces():
+    from ffmpeg_amd import vp9
+    _torch()
+    c = vp9.intra_init(8)
+    O = ffi.oracle()
+    rng = np.random.default_rng(441)
+    for tx in range(4):
+        n = 4 << tx
+        for mode in range(15):
+            left = rng.integers(0, 256, n, dtype=np.uint8)
+            topbuf = rng.integers(0, 256, 16 + 2 * n + 8, dtype=np.uint8)
+            a = rng.integers(0, 256, (n, n + 3), dtype=np.uint8)
+            b = a.copy()
+            c.intra_pred[tx][mode](a.ctypes.data, n + 3, left.ctypes.data, topbuf.ctypes.data + 16)
+            O.ffo_vp9_intra_pred(tx, mode, ptr(b), n + 3, ptr(left), C.cast(topbuf.ctypes.data + 16, u8p))
+            assert np.array_equal(a, b), (tx, mode)

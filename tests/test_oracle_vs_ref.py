@@ -560,6 +560,27 @@ def test_vp9_loop_filter():
         assert np.array_equal(a, b), (rep, which, dirn, E, I, H)
 
 
+def test_vp9_intra_pred():
+    """VP9DSPContext.intra_pred[4][15]: every size x mode (tests/checkasm/vp9dsp.c check_ipred shapes: aligned top with a corner
+    in front and top-right samples behind)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(98)
+    for tx in range(4):
+        n = 4 << tx
+        for mode in range(15):
+            for rep in range(12):
+                left = rng.integers(0, 256, n + 16, dtype=np.uint8)
+                topbuf = rng.integers(0, 256, 16 + 2 * n + 32, dtype=np.uint8)
+                if rep % 3 == 0:
+                    left[:] = rng.choice(np.array([0, 255], np.uint8), left.size); topbuf[:] = rng.choice(np.array([0, 255], np.uint8), topbuf.size)
+                tp = C.cast(topbuf.ctypes.data + 16, u8p)
+                a = rng.integers(0, 256, (n, n + 3), dtype=np.uint8)
+                b = a.copy()
+                R.ffref_vp9_intra_pred(tx, mode, ptr(a), n + 3, ptr(left), tp)
+                O.ffo_vp9_intra_pred(tx, mode, ptr(b), n + 3, ptr(left), tp)
+                assert np.array_equal(a, b), (tx, mode, rep)
+
+
 def hevc_restore_case(rng, rep):
     """(variant, eo, offset0, borders[4], width, height, vert_edge[2], horiz_edge[2], diag_edge[4]) — every flag on and off"""
     p = .5 if rep % 3 else .85
