@@ -29,6 +29,8 @@ int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *ds
                            hipStream_t stream);
 int ffhip_launch_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, hipStream_t stream);
 int ffhip_launch_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n, hipStream_t stream);
+int ffhip_launch_vp9_smc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9ScaledBlock *blocks, int n,
+                         hipStream_t stream);
 int ffhip_launch_vp9_intra(int tx, uint8_t *dst, ptrdiff_t stride, const uint8_t *edges, const FFHipVp9Intra *blocks, int n, hipStream_t stream);
 int ffhip_launch_vp9_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, hipStream_t stream);
 int ffhip_launch_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9McBlock *blocks, int n,

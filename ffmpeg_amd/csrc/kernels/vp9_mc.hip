@@ -244,3 +244,115 @@ int ffhip_launch_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, p
     LAUNCH_CHECK();
     return 0;
 }
+
+/* the taps as int8 per (filter, fraction) for the scaled kernel's lane-varying fractions (fraction 0 = {0,0,0,128,..} is a copy and
+ * never read) */
+__constant__ int8_t vp9_t8[48][8] = {
+    { 0, 0, 0, 0, 0, 0, 0, 0 },
+    { -3, -1, 32, 64, 38, 1, -3, 0 },
+    { -2, -2, 29, 63, 41, 2, -3, 0 },
+    { -2, -2, 26, 63, 43, 4, -4, 0 },
+    { -2, -3, 24, 62, 46, 5, -4, 0 },
+    { -2, -3, 21, 60, 49, 7, -4, 0 },
+    { -1, -4, 18, 59, 51, 9, -4, 0 },
+    { -1, -4, 16, 57, 53, 12, -4, -1 },
+    { -1, -4, 14, 55, 55, 14, -4, -1 },
+    { -1, -4, 12, 53, 57, 16, -4, -1 },
+    { 0, -4, 9, 51, 59, 18, -4, -1 },
+    { 0, -4, 7, 49, 60, 21, -3, -2 },
+    { 0, -4, 5, 46, 62, 24, -3, -2 },
+    { 0, -4, 4, 43, 63, 26, -2, -2 },
+    { 0, -3, 2, 41, 63, 29, -2, -2 },
+    { 0, -3, 1, 38, 64, 32, -1, -3 },
+    { 0, 0, 0, 0, 0, 0, 0, 0 },
+    { 0, 1, -5, 126, 8, -3, 1, 0 },
+    { -1, 3, -10, 122, 18, -6, 2, 0 },
+    { -1, 4, -13, 118, 27, -9, 3, -1 },
+    { -1, 4, -16, 112, 37, -11, 4, -1 },
+    { -1, 5, -18, 105, 48, -14, 4, -1 },
+    { -1, 5, -19, 97, 58, -16, 5, -1 },
+    { -1, 6, -19, 88, 68, -18, 5, -1 },
+    { -1, 6, -19, 78, 78, -19, 6, -1 },
+    { -1, 5, -18, 68, 88, -19, 6, -1 },
+    { -1, 5, -16, 58, 97, -19, 5, -1 },
+    { -1, 4, -14, 48, 105, -18, 5, -1 },
+    { -1, 4, -11, 37, 112, -16, 4, -1 },
+    { -1, 3, -9, 27, 118, -13, 4, -1 },
+    { 0, 2, -6, 18, 122, -10, 3, -1 },
+    { 0, 1, -3, 8, 126, -5, 1, 0 },
+    { 0, 0, 0, 0, 0, 0, 0, 0 },
+    { -1, 3, -7, 127, 8, -3, 1, 0 },
+    { -2, 5, -13, 125, 17, -6, 3, -1 },
+    { -3, 7, -17, 121, 27, -10, 5, -2 },
+    { -4, 9, -20, 115, 37, -13, 6, -2 },
+    { -4, 10, -23, 108, 48, -16, 8, -3 },
+    { -4, 10, -24, 100, 59, -19, 9, -3 },
+    { -4, 11, -24, 90, 70, -21, 10, -4 },
+    { -4, 11, -23, 80, 80, -23, 11, -4 },
+    { -4, 10, -21, 70, 90, -24, 11, -4 },
+    { -3, 9, -19, 59, 100, -24, 10, -4 },
+    { -3, 8, -16, 48, 108, -23, 10, -4 },
+    { -2, 6, -13, 37, 115, -20, 9, -4 },
+    { -2, 5, -10, 27, 121, -17, 7, -3 },
+    { -1, 3, -6, 17, 125, -13, 5, -2 },
+    { 0, 1, -3, 8, 127, -7, 3, -1 },
+};
+
+/*
+ * Scaled motion compensation: VP9DSPContext.smc[size][filter][avg] (vp9dsp_template.c:2362-2540).  The reference picture has
+ * another size: output x samples around column (mx + x dx) >> 4 with the taps of fraction (mx + x dx) & 15, output y around row
+ * (my + y dy) >> 4.  Neighbouring outputs no longer share windows or taps, so this is a plain gather: one wave per block, the
+ * horizontally filtered 8-bit temporaries (up to 135 rows) in wave-private LDS, eight multiply-adds per sample and pass.  Rare in
+ * streams (reference scaling), kept simple.
+ */
+static_assert(sizeof(FFHipVp9ScaledBlock) == 16, "FFHipVp9ScaledBlock is a 16-byte record");
+
+__global__ __launch_bounds__(256) void k_vp9_smc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                                 const FFHipVp9ScaledBlock *blocks, int n)
+{
+    __shared__ uint8_t tmp_all[4][135 * 64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= n)
+        return;
+    const FFHipVp9ScaledBlock k = blocks[b];
+    const int w = k.width, h = k.height, filter = k.filter & 3, mx = k.mx & 15, my = k.my & 15, dx = k.dx, dy = k.dy;
+    const bool avg = k.avg != 0, bil = filter == 3;
+    const int before = bil ? 0 : 3, rows = (((h - 1) * dy + my) >> 4) + (bil ? 2 : 8);
+    const uint8_t *s = src + k.src_offset;
+    uint8_t *d0 = dst + k.dst_offset, *tmp = tmp_all[wave];
+    const int lgw = __builtin_ctz(w);
+    auto tap = [&](int m, const uint8_t *p, ptrdiff_t step) {
+        if (bil)
+            return (int)p[0] + ((m * ((int)p[step] - (int)p[0]) + 8) >> 4);
+        if (!m)
+            return (int)p[0];
+        const int8_t *f = vp9_t8[filter * 16 + m];
+        int sum = 64;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            sum += f[t] * p[(t - 3) * step];
+        return clip_u8(sum >> 7);
+    };
+    for (int i = lane; i < rows * w; i += 64) {
+        const int r = i >> lgw, x = i & (w - 1), pos = mx + x * dx;
+        tmp[r * 64 + x] = (uint8_t)tap(pos & 15, s + (ptrdiff_t)(r - before) * srcstride + (pos >> 4), 1);
+    }
+    vm_wave_sync();
+    for (int i = lane; i < h * w; i += 64) {
+        const int y = i >> lgw, x = i & (w - 1), pos = my + y * dy;
+        const int v = tap(pos & 15, tmp + ((pos >> 4) + before) * 64 + x, 64);
+        uint8_t *d = d0 + (ptrdiff_t)y * dststride + x;
+        *d = (uint8_t)(avg ? (*d + v + 1) >> 1 : v);
+    }
+}
+
+int ffhip_launch_vp9_smc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9ScaledBlock *blocks, int n,
+                         hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_vp9_smc, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -835,3 +835,48 @@ extern "C" int ff_vp9dsp_intrapred_init_hip(FFHipVP9IntraContext *c, int bpp)
     vp9_intra_fill<0>(c); vp9_intra_fill<1>(c); vp9_intra_fill<2>(c); vp9_intra_fill<3>(c);
     return 0;
 }
+
+/* ---- vp9dsp scaled mc host faces: the source rectangle the call reads, at a pitch of 192 ---- */
+template <int W, int F, int AVG>
+static void s_vp9_smc(uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my, int dx, int dy)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (h <= 0 || h > 64 || dx < 1 || dx > 32 || dy < 1 || dy > 32)
+        return;
+    const int P = 192, bil = F == 3, before = bil ? 0 : 3, after = bil ? 1 : 4;
+    const int cols = ((mx + (W - 1) * dx) >> 4) + 1 + before + after, rows = ((my + (h - 1) * dy) >> 4) + 1 + before + after;
+    const size_t sbytes = (size_t)rows * P, dbytes = (size_t)h * 64;
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + sbytes + dbytes + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + sbytes;
+    if (hipMemcpy2D(dsrc, P, src - before * ss - before, ss, cols, rows, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy2D(ddst, 64, dst, ds, W, h, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    FFHipVp9ScaledBlock k = {};
+    k.src_offset = before * P + before;
+    k.width = W; k.height = (uint8_t)h; k.filter = F; k.mx = (uint8_t)mx; k.my = (uint8_t)my; k.avg = AVG; k.dx = (uint8_t)dx; k.dy = (uint8_t)dy;
+    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_vp9_smc(ddst, 64, dsrc, P, (const FFHipVp9ScaledBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    (void)hipMemcpy2D(dst, ds, ddst, 64, W, h, hipMemcpyDeviceToHost);
+}
+template <int W, int I>
+static void vp9_smc_fill(FFHipVP9ScaledMcContext *c)
+{
+    c->smc[I][0][0] = s_vp9_smc<W, 0, 0>; c->smc[I][0][1] = s_vp9_smc<W, 0, 1>;
+    c->smc[I][1][0] = s_vp9_smc<W, 1, 0>; c->smc[I][1][1] = s_vp9_smc<W, 1, 1>;
+    c->smc[I][2][0] = s_vp9_smc<W, 2, 0>; c->smc[I][2][1] = s_vp9_smc<W, 2, 1>;
+    c->smc[I][3][0] = s_vp9_smc<W, 3, 0>; c->smc[I][3][1] = s_vp9_smc<W, 3, 1>;
+}
+
+extern "C" int ff_vp9dsp_scaled_mc_init_hip(FFHipVP9ScaledMcContext *c, int bpp)
+{
+    if (!c || bpp != 8)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    vp9_smc_fill<64, 0>(c); vp9_smc_fill<32, 1>(c); vp9_smc_fill<16, 2>(c); vp9_smc_fill<8, 3>(c); vp9_smc_fill<4, 4>(c);
+    return 0;
+}

@@ -97,3 +97,25 @@ def intra_init(bpp=8):
     c = VP9IntraContext()
     _lib.check(_lib.lib().ff_vp9dsp_intrapred_init_hip(C.byref(c), bpp), "ff_vp9dsp_intrapred_init_hip")
     return c
+
+
+#: FFHipVp9ScaledBlock (include/ffhip.h)
+SMC_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("width", np.uint8), ("height", np.uint8), ("filter", np.uint8),
+                      ("mx", np.uint8), ("my", np.uint8), ("avg", np.uint8), ("dx", np.uint8), ("dy", np.uint8)])
+
+
+def scaled_mc_batch(dst, dststride, src, srcstride, blocks, n, stream=None):
+    """blocks: uint8 [n, 16] FFHipVp9ScaledBlock records"""
+    return _lib.check(_lib.lib().ffhip_vp9_scaled_mc_batch_dev(dst.data_ptr(), dststride, src.data_ptr(), srcstride, blocks.data_ptr(), n,
+                                                               None if stream is None else C.c_void_p(stream)),
+                      "ffhip_vp9_scaled_mc_batch_dev")
+
+
+class VP9ScaledMcContext(C.Structure):
+    _fields_ = [("smc", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int) * 2 * 4 * 5)]
+
+
+def smc_init(bpp=8):
+    c = VP9ScaledMcContext()
+    _lib.check(_lib.lib().ff_vp9dsp_scaled_mc_init_hip(C.byref(c), bpp), "ff_vp9dsp_scaled_mc_init_hip")
+    return c

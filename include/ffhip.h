@@ -639,6 +639,25 @@ typedef struct FFHipVp9McBlock {
 int ffhip_vp9_mc_batch_dev(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9McBlock *blocks,
                            int n, void *stream);
 
+/** vp9_scaled_mc_func and VP9DSPContext.smc[size][filter][put/avg] (libavcodec/vp9dsp.h:36-38,121): prediction from a reference
+ *  picture of another size; dx, dy = the step in sixteenths of a reference sample per output sample (1..32: 16x up to 2x down). */
+typedef void (*ffhip_vp9_scaled_mc_func)(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride, int h, int mx, int my,
+                                         int dx, int dy);
+typedef struct FFHipVP9ScaledMcContext {
+    ffhip_vp9_scaled_mc_func smc[5][4][2];
+} FFHipVP9ScaledMcContext;
+int ff_vp9dsp_scaled_mc_init_hip(FFHipVP9ScaledMcContext *c, int bpp);
+typedef struct FFHipVp9ScaledBlock {
+    int32_t dst_offset, src_offset;
+    uint8_t width, height;          /* 4..64 (a power of two), 1..64 */
+    uint8_t filter, mx, my, avg;    /* as FFHipVp9McBlock */
+    uint8_t dx, dy;                 /* 1..32 */
+} FFHipVp9ScaledBlock;
+/** n blocks, pairwise disjoint in dst; src must be readable 3 samples left/up of the block origin and through column
+ *  ((mx + (w - 1) dx) >> 4) + 4, row ((my + (h - 1) dy) >> 4) + 4. */
+int ffhip_vp9_scaled_mc_batch_dev(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                  const FFHipVp9ScaledBlock *blocks, int n, void *stream);
+
 /** The loop-filter tables of VP9DSPContext (libavcodec/vp9dsp.h:76-105): loop_filter_8[width 4/8/16][h col-edge / v row-edge],
  *  loop_filter_16[dir], loop_filter_mix2[wd1][wd2][dir] (two 8-sample halves, limits packed in the two low bytes). */
 typedef void (*ffhip_vp9_lf_func)(uint8_t *dst, ptrdiff_t stride, int mb_lim, int lim, int hev_thr);

@@ -101,6 +101,9 @@ void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const ui
 void ffo_vp9_loop_filter(int wd, int dir, uint8_t *dst, ptrdiff_t stride, int E, int I, int H);
 /* VP9DSPContext.intra_pred[tx][mode]: tx 0..3, mode = enum IntraPredMode 0..14; top[-1] is the corner, left[] bottom to top */
 void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top);
+/* VP9DSPContext.smc[..][filter][avg]: scaled motion compensation, dx / dy = step in sixteenths of a reference sample */
+void ffo_vp9_smc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
+                 int mx, int my, int dx, int dy);
 void ffo_hevc_dequant(int16_t *coeffs, int log2_size);
 void ffo_hevc_transform_rdpcm(int16_t *coeffs, int log2_size, int mode);
 void ffo_hevc_sao_edge_restore(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, int eo, int offset0,

@@ -562,3 +562,36 @@ void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const 
             dst[y * stride + x] = (uint8_t)v;
         }
 }
+
+/*
+ * VP9 scaled motion compensation, 8 bits: VP9DSPContext.smc[size][filter][avg](dst, dst_stride, ref, ref_stride, h, mx, my, dx, dy)
+ * (libavcodec/vp9dsp_template.c:2362-2540): the reference picture has another size, so the sampling position advances by
+ * dx / dy sixteenths per output sample: output x reads around column (mx + x dx) >> 4 with the taps of fraction (mx + x dx) & 15,
+ * output y around row (my + y dy) >> 4; horizontally filtered 8-bit temporaries first, exactly as the unscaled 2-D form.
+ * Fraction 0 is the tap set { 0, 0, 0, 128, ... }: (128 s + 64) >> 7 = s.
+ */
+static int vp9_tap8s(int filter, int m, const uint8_t *s, ptrdiff_t step)
+{
+    return m ? vp9_tap8(filter, m, s, step) : s[0];
+}
+
+void ffo_vp9_smc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
+                 int mx, int my, int dx, int dy)
+{
+    static uint8_t tmp[135 * 64];
+    const int bil = filter == 3, before = bil ? 0 : 3;
+    const int rows = (((height - 1) * dy + my) >> 4) + (bil ? 2 : 8);
+    for (int r = 0; r < rows; r++)
+        for (int x = 0; x < width; x++) {
+            const int pos = mx + x * dx;
+            const uint8_t *s = src + (r - before) * srcstride + (pos >> 4);
+            tmp[r * 64 + x] = bil ? vp9_bilin(pos & 15, s, 1) : vp9_tap8s(filter, pos & 15, s, 1);
+        }
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const int pos = my + y * dy;
+            const uint8_t *t = tmp + ((pos >> 4) + before) * 64 + x;
+            const int v = bil ? vp9_bilin(pos & 15, t, 64) : vp9_tap8s(filter, pos & 15, t, 64);
+            dst[y * dststride + x] = avg ? (dst[y * dststride + x] + v + 1) >> 1 : v;
+        }
+}

@@ -317,6 +317,21 @@ void ffref_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, cons
     }
     vp9.intra_pred[tx][mode](dst, stride, left, top);
 }
+void ffref_vp9_smc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
+                   int mx, int my, int dx, int dy)
+{
+    static VP9DSPContext vp9;
+    static int vp9_ready;
+    int idx = 0;
+    pure_c();
+    if (!vp9_ready) {
+        ff_vp9dsp_init(&vp9, 8, 1);
+        vp9_ready = 1;
+    }
+    while ((64 >> idx) > width)
+        idx++;
+    vp9.smc[idx][filter][avg](dst, dststride, src, srcstride, height, mx, my, dx, dy);
+}
 void ffref_hevc_dequant(int16_t *coeffs, int log2_size)
 {
     dsp_init();

@@ -114,6 +114,8 @@ def oracle():
         L.ffo_vp9_itxfm_add.restype = None
         L.ffo_vp9_mc.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_vp9_mc.restype = None
+        L.ffo_vp9_smc.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t] + [C.c_int] * 6
+        L.ffo_vp9_smc.restype = None
         L.ffo_vp9_intra_pred.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, u8p]
         L.ffo_vp9_intra_pred.restype = None
         L.ffo_vp9_loop_filter.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
@@ -213,6 +215,8 @@ def ref():
         L.ffref_vp9_itxfm_add.restype = None
         L.ffref_vp9_mc.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffref_vp9_mc.restype = None
+        L.ffref_vp9_smc.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, C.c_ssize_t] + [C.c_int] * 6
+        L.ffref_vp9_smc.restype = None
         L.ffref_vp9_intra_pred.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, u8p]
         L.ffref_vp9_intra_pred.restype = None
         L.ffref_vp9_loop_filter.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]

@@ -301,3 +301,53 @@ def test_vp9_intra_pred_host_faces():
             c.intra_pred[tx][mode](a.ctypes.data, n + 3, left.ctypes.data, topbuf.ctypes.data + 16)
             O.ffo_vp9_intra_pred(tx, mode, ptr(b), n + 3, ptr(left), C.cast(topbuf.ctypes.data + 16, u8p))
             assert np.array_equal(a, b), (tx, mode)
+
+
+def test_vp9_scaled_mc_batch():
+    """scaled prediction blocks: steps from 16x up- to 2x down-scaling of the reference, all filters, put / avg"""
+    from ffmpeg_amd import vp9
+    from test_oracle_vs_ref import vp9_smc_case
+    torch = _torch()
+    rng = np.random.default_rng(450)
+    W, H, P = 640, 384, 8
+    ss = 2 * W + 2 * P + 3                                   # the reference may be twice as large
+    sd = W + 9
+    ref = rng.integers(0, 256, (2 * H + 2 * P + 8, ss), dtype=np.uint8)
+    ref[:60] = rng.choice(np.array([0, 255], np.uint8), (60, ss))
+    dst = rng.integers(0, 256, (H, sd), dtype=np.uint8)
+    want = dst.copy()
+    O = ffi.oracle()
+    recs = []
+    for by in range(0, H, 64):
+        for bx in range(0, W, 64):
+            f, avg, w, h, mx, my, dx, dy = vp9_smc_case(rng)
+            so = (2 * by + P) * ss + 2 * bx + P
+            recs.append((by * sd + bx, so, w, h, f, mx, my, avg, dx, dy))
+            O.ffo_vp9_smc(f, avg, C.cast(want.ctypes.data + by * sd + bx, u8p), sd, C.cast(ref.ctypes.data + so, u8p), ss, w, h, mx, my, dx, dy)
+    n = len(recs)
+    rec = np.array(recs, vp9.SMC_DTYPE)
+    d_dst = torch.from_numpy(dst.copy()).cuda()
+    vp9.scaled_mc_batch(d_dst, sd, torch.from_numpy(ref).cuda(), ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 16).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    assert (want != dst).sum() > 1000
+    assert np.array_equal(got, want), "%d mismatches, first %s" % ((got != want).sum(), np.argwhere(got != want)[:3])
+
+
+def test_vp9_scaled_mc_host_faces():
+    from ffmpeg_amd import vp9
+    from test_oracle_vs_ref import vp9_smc_case
+    _torch()
+    c = vp9.smc_init(8)
+    O = ffi.oracle()
+    rng = np.random.default_rng(451)
+    src = rng.integers(0, 256, (160, 160), dtype=np.uint8)
+    for rep in range(24):
+        f, avg, w, h, mx, my, dx, dy = vp9_smc_case(rng)
+        idx = {64: 0, 32: 1, 16: 2, 8: 3, 4: 4}[w]
+        sp = src.ctypes.data + 6 * 160 + 7
+        d0 = rng.integers(0, 256, (64, 72), dtype=np.uint8)
+        a, b = d0.copy(), d0.copy()
+        c.smc[idx][f][avg](a.ctypes.data, 72, sp, 160, h, mx, my, dx, dy)
+        O.ffo_vp9_smc(f, avg, ptr(b), 72, C.cast(sp, u8p), 160, w, h, mx, my, dx, dy)
+        assert np.array_equal(a, b), (f, avg, w, h, mx, my, dx, dy)

@@ -581,6 +581,30 @@ def test_vp9_intra_pred():
                 assert np.array_equal(a, b), (tx, mode, rep)
 
 
+def vp9_smc_case(rng):
+    """(filter, avg, w, h, mx, my, dx, dy): steps from 16x up-scaling (1) to 2x down-scaling (32) of the reference"""
+    w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+    return (int(rng.integers(0, 4)), int(rng.integers(0, 2)), w, h, int(rng.integers(0, 16)), int(rng.integers(0, 16)),
+            int(rng.choice([1, 8, 11, 16, 20, 27, 32])), int(rng.choice([1, 8, 11, 16, 20, 27, 32])))
+
+
+def test_vp9_smc():
+    """VP9DSPContext.smc: scaled motion compensation, all filters, put / avg"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(99)
+    src = rng.integers(0, 256, (160, 160), dtype=np.uint8)
+    src[:40] = rng.choice(np.array([0, 255], np.uint8), (40, 160))
+    for rep in range(800):
+        f, avg, w, h, mx, my, dx, dy = vp9_smc_case(rng)
+        y0, x0 = int(rng.integers(4, 16)), int(rng.integers(4, 16))
+        sp = C.cast(src.ctypes.data + y0 * 160 + x0, u8p)
+        d0 = rng.integers(0, 256, (64, 72), dtype=np.uint8)
+        a, b = d0.copy(), d0.copy()
+        R.ffref_vp9_smc(f, avg, ptr(a), 72, sp, 160, w, h, mx, my, dx, dy)
+        O.ffo_vp9_smc(f, avg, ptr(b), 72, sp, 160, w, h, mx, my, dx, dy)
+        assert np.array_equal(a, b), (f, avg, w, h, mx, my, dx, dy)
+
+
 def hevc_restore_case(rng, rep):
     """(variant, eo, offset0, borders[4], width, height, vert_edge[2], horiz_edge[2], diag_edge[4]) — every flag on and off"""
     p = .5 if rep % 3 else .85
