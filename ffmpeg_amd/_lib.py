@@ -106,6 +106,8 @@ def lib():
         "ff_vp9dsp_scaled_mc_init_hip": (C.c_int, [vp, C.c_int]),
         "ffhip_vp9_intra_pred_batch_dev": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, vp, C.c_int, vp]),
         "ff_vp9dsp_intrapred_init_hip": (C.c_int, [vp, C.c_int]),
+        "ffhip_h264_pred_batch_dev": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, vp, C.c_int, vp]),
+        "ff_h264_pred_init_hip": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "ffhip_vp9_loop_filter_batch_dev": (C.c_int, [vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ff_vp9dsp_loopfilter_init_hip": (C.c_int, [vp, C.c_int]),
         "ffhip_vp9_mc_batch_dev": (C.c_int, [vp, C.c_ssize_t, vp, C.c_ssize_t, vp, C.c_int, vp]),

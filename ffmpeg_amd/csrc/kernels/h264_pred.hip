@@ -1,0 +1,305 @@
+/*
+ * h264_pred.hip — H.264 intra prediction, 8 bits, 4:2:0, batched and in place: H264PredContext
+ * (libavcodec/h264pred.h:92-116; bodies libavcodec/h264pred_template.c, table libavcodec/h264pred.c:448-538).
+ *
+ * A block's neighbours are staged once into LDS as its "edge line" e[] = the left column bottom-up, the corner, the row above
+ * running on into the top-right block — the samples met walking up the left side, round the corner and along the top.  The nine
+ * directional modes of pred4x4 and pred8x8l are then one set of per-sample rules over that line (pred8x8l over the low-pass
+ * filtered line, h264pred_template.c:822-856); pred8x8 / pred16x16 reduce the line to four quadrant DCs or a plane (a, H, V).
+ * One thread writes 4 samples of a row; 256 / (N*N/4) blocks share a workgroup.  Only the neighbours the mode's C function reads
+ * are loaded (a picture-edge block has no row above to read).  Blocks of a launch are independent: intra prediction chains
+ * through the reconstruction, so the decoder's wavefront orders the launches.
+ *
+ * The lossless _add members (h264pred_template.c:1104-1330) integrate the residual along the prediction direction in wrapping
+ * 8-bit arithmetic: one thread per column (VERT) or row (HOR), which also clears the coefficients it consumed.
+ */
+#include "common.h"
+#include "h264_kernels.h"
+
+static_assert(sizeof(FFHipH264Pred) == 12, "FFHipH264Pred is a 12-byte record");
+
+__device__ __forceinline__ int hp_a2(int a, int b) { return (a + b + 1) >> 1; }
+__device__ __forceinline__ int hp_a3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
+
+/* neighbours a pred4x4 / pred8x8l mode reads: bit0 left, bit1 top, bit2 corner, bit3 top-right (h264pred.h:35-48 order) */
+__device__ __forceinline__ unsigned hp_need(int mode)
+{
+    /* 12 nibbles, mode 0 in the low one: V=2 H=1 DC=3 DDL=a DDR=7 VR=7 HD=7 VL=a HU=1 LEFT_DC=1 TOP_DC=2 DC_128=0 */
+    return (unsigned)(0x0211a777a312ull >> (4 * mode)) & 15u;
+}
+
+template <int N>
+__device__ __forceinline__ int hp_dir_sample(int mode, const int *e, int x, int y, int dc)
+{
+    const int *T = e + N + 1;
+    switch (mode) {
+    case 0: return T[x];
+    case 1: return e[N - 1 - y];
+    case 3: {
+        const int i = x + y;
+        return i < 2 * N - 2 ? hp_a3(T[i], T[i + 1], T[i + 2]) : (T[2 * N - 2] + 3 * T[2 * N - 1] + 2) >> 2;
+    }
+    case 4: {
+        const int i = N - 1 - y + x;
+        return hp_a3(e[i], e[i + 1], e[i + 2]);
+    }
+    case 5: {
+        const int d = 2 * x - y, h = d >> 1;
+        if (d < 0)
+            return hp_a3(e[N + d], e[N + d + 1], e[N + d + 2]);
+        return (d & 1) ? hp_a3(e[N + h], e[N + h + 1], e[N + h + 2]) : hp_a2(e[N + h], e[N + h + 1]);
+    }
+    case 6: {
+        const int d = 2 * y - x, h = d >> 1;
+        if (d < 0)
+            return hp_a3(e[N - d - 2], e[N - d - 1], e[N - d]);
+        return (d & 1) ? hp_a3(e[N - h], e[N - h - 1], e[N - h - 2]) : hp_a2(e[N - h], e[N - h - 1]);
+    }
+    case 7: {
+        const int i = (y >> 1) + x;
+        return (y & 1) ? hp_a3(T[i], T[i + 1], T[i + 2]) : hp_a2(T[i], T[i + 1]);
+    }
+    case 8: {
+        const int i = 2 * y + x, j = N - 1 - (i >> 1);
+        if (i >= 2 * N - 2)
+            return e[0];
+        if (i == 2 * N - 3)
+            return (e[1] + 3 * e[0] + 2) >> 2;
+        return (i & 1) ? hp_a3(e[j], e[j - 1], e[j - 2]) : hp_a2(e[j], e[j - 1]);
+    }
+    default: return dc;
+    }
+}
+
+__device__ __forceinline__ void hp_store4(uint8_t *d, const int *v)
+{
+    if (!(reinterpret_cast<uintptr_t>(d) & 3)) {
+        *reinterpret_cast<uint32_t *>(d) = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            d[j] = (uint8_t)v[j];
+    }
+}
+
+/* pred4x4 (L8 = false, N = 4) and pred8x8l (L8 = true, N = 8) */
+template <bool L8>
+__global__ __launch_bounds__(256) void k_h264_pred_dir(uint8_t *plane, ptrdiff_t stride, const FFHipH264Pred *blocks, int n)
+{
+    constexpr int N = L8 ? 8 : 4, ITEMS = N * N / 4, RPB = 256 / ITEMS, LINE = 3 * N + 1, QW = N / 4;
+    __shared__ int raw[RPB][LINE + 1];
+    __shared__ int flt[L8 ? RPB : 1][LINE + 1];
+    const int r = threadIdx.x / ITEMS, it = threadIdx.x % ITEMS, b = blockIdx.x * RPB + r;
+    const bool valid = b < n;
+    FFHipH264Pred k = {};
+    if (valid)
+        k = blocks[b];
+    const int mode = k.mode;
+    const unsigned need = valid ? hp_need(mode) : 0u;
+    const bool tl = k.flags & FFHIP_H264_PRED_TOPLEFT, tr = k.flags & FFHIP_H264_PRED_TOPRIGHT;
+    uint8_t *src = plane + k.offset;
+    for (int j = it; j < LINE; j += ITEMS) {
+        int v = 0;
+        if (j < N) {
+            if (need & 1)
+                v = src[(ptrdiff_t)(N - 1 - j) * stride - 1];
+        } else if (j == N) {
+            if ((need & 4) || (L8 && tl && (need & 3)))
+                v = src[-stride - 1];
+        } else if (j < 2 * N + 1) {
+            if (need & 2)
+                v = src[j - N - 1 - stride];
+        } else if (L8) {
+            if (tr && ((need & 8) || (j == 2 * N + 1 && (need & 2))))
+                v = src[j - N - 1 - stride];
+        } else if (need & 8) {
+            v = (k.flags & FFHIP_H264_PRED_TR_SPLAT) ? src[3 - stride] : plane[k.aux + (j - 2 * N - 1)];
+        }
+        raw[r][j] = v;
+    }
+    __syncthreads();
+    const int *e = raw[r];
+    if (L8) {
+        /* PREDICT_8x8_LOAD_LEFT / _TOP / _TOPRIGHT / _TOPLEFT (h264pred_template.c:822-856) */
+        const int *w = raw[r];
+        for (int j = it; j < LINE; j += ITEMS) {
+            int v = 0;
+            if (j < 8) {
+                if (need & 1)
+                    v = j == 7 ? hp_a3(tl ? w[8] : w[7], w[7], w[6]) : j == 0 ? (w[1] + 3 * w[0] + 2) >> 2 : hp_a3(w[j + 1], w[j], w[j - 1]);
+            } else if (j == 8) {
+                if (need & 4)
+                    v = hp_a3(w[7], w[8], w[9]);
+            } else if (j < 17) {
+                if (need & 2)
+                    v = j == 9 ? hp_a3(tl ? w[8] : w[9], w[9], w[10]) : j == 16 ? hp_a3(tr ? w[17] : w[16], w[16], w[15]) : hp_a3(w[j - 1], w[j], w[j + 1]);
+            } else if (need & 8) {
+                v = !tr ? w[16] : j == 24 ? (w[23] + 3 * w[24] + 2) >> 2 : hp_a3(w[j - 1], w[j], w[j + 1]);
+            }
+            flt[r][j] = v;
+        }
+        __syncthreads();
+        e = flt[r];
+    }
+    if (!valid)
+        return;
+    int dc = 128;
+    if (mode == 2 || mode == 9 || mode == 10) {
+        int sl = 0, st = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            sl += e[i];
+            st += e[N + 1 + i];
+        }
+        dc = mode == 2 ? (sl + st + N) >> (L8 ? 4 : 3) : ((mode == 9 ? sl : st) + N / 2) >> (L8 ? 3 : 2);
+    }
+    const int y = it / QW, x0 = 4 * (it % QW);
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        v[j] = hp_dir_sample<N>(mode, e, x0 + j, y, dc);
+    hp_store4(src + (ptrdiff_t)y * stride + x0, v);
+}
+
+/* pred8x8 (chroma, N = 8: DC per 4x4 quadrant, the "mad cow" edge variants) and pred16x16 (N = 16) */
+template <int N>
+__global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t stride, const FFHipH264Pred *blocks, int n)
+{
+    constexpr int ITEMS = N * N / 4, RPB = 256 / ITEMS, QW = N / 4, H2 = N / 2;
+    __shared__ int L[RPB][N], T[RPB][N + 1]; /* T[0] is the corner */
+    __shared__ int P[RPB][4];
+    const int r = threadIdx.x / ITEMS, it = threadIdx.x % ITEMS, b = blockIdx.x * RPB + r;
+    const bool valid = b < n;
+    FFHipH264Pred k = {};
+    if (valid)
+        k = blocks[b];
+    const int mode = k.mode;
+    /* modes: 0 DC 1 HOR 2 VERT 3 PLANE 4 LEFT_DC 5 TOP_DC 6 DC_128; pred8x8 also 7 L0T 8 0LT 9 L00 10 0L0 (h264pred.h:67-82) */
+    const bool use_t = valid && (mode == 0 || mode == 2 || mode == 3 || mode == 5 || mode == 7 || mode == 8);
+    const bool use_l = valid && (mode == 0 || mode == 1 || mode == 3 || mode == 4 || mode >= 7);
+    const int lrows = mode == 7 ? 4 : N; /* L0T: pred4x4_dc on the first quadrant reads four rows of the left column */
+    uint8_t *src = plane + k.offset;
+    if (it < N) {
+        L[r][it] = use_l && it < lrows ? src[(ptrdiff_t)it * stride - 1] : 0;
+        T[r][it + 1] = use_t ? src[it - stride] : 0;
+    } else if (it == N) {
+        T[r][0] = valid && mode == 3 ? src[-stride - 1] : 0;
+    }
+    __syncthreads();
+    if (it == 0 && valid) {
+        const int *l = L[r], *t = T[r] + 1;
+        if (mode == 3) {
+            int H = 0, V = 0;
+#pragma unroll
+            for (int i = 1; i <= H2; i++) {
+                H += i * (t[H2 - 1 + i] - t[H2 - 1 - i]);
+                V += i * (l[H2 - 1 + i] - (i == H2 ? t[-1] : l[H2 - 1 - i]));
+            }
+            H = N == 16 ? (5 * H + 32) >> 6 : (17 * H + 16) >> 5;
+            V = N == 16 ? (5 * V + 32) >> 6 : (17 * V + 16) >> 5;
+            P[r][0] = 16 * (l[N - 1] + t[N - 1] + 1) - (H2 - 1) * (V + H);
+            P[r][1] = H;
+            P[r][2] = V;
+        } else if (N == 16) {
+            int sl = 0, st = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                sl += l[i];
+                st += t[i];
+            }
+            P[r][0] = mode == 0 ? (sl + st + 16) >> 5 : mode == 4 ? (sl + 8) >> 4 : mode == 5 ? (st + 8) >> 4 : 128;
+        } else {
+            const int t0 = t[0] + t[1] + t[2] + t[3], t1 = t[4] + t[5] + t[6] + t[7];
+            const int l0 = l[0] + l[1] + l[2] + l[3], l1 = l[4] + l[5] + l[6] + l[7];
+            int q0 = 128, q1 = 128, q2 = 128, q3 = 128;
+            switch (mode) {
+            case 0: q0 = (t0 + l0 + 4) >> 3; q1 = (t1 + 2) >> 2; q2 = (l1 + 2) >> 2; q3 = (t1 + l1 + 4) >> 3; break;
+            case 4: q0 = q1 = (l0 + 2) >> 2; q2 = q3 = (l1 + 2) >> 2; break;
+            case 5: q0 = q2 = (t0 + 2) >> 2; q1 = q3 = (t1 + 2) >> 2; break;
+            case 7: q0 = (t0 + l0 + 4) >> 3; q2 = (t0 + 2) >> 2; q1 = q3 = (t1 + 2) >> 2; break;
+            case 8: q0 = (t0 + 2) >> 2; q1 = (t1 + 2) >> 2; q2 = (l1 + 2) >> 2; q3 = (t1 + l1 + 4) >> 3; break;
+            case 9: q0 = q1 = (l0 + 2) >> 2; break;
+            case 10: q2 = q3 = (l1 + 2) >> 2; break;
+            default: break;
+            }
+            P[r][0] = q0; P[r][1] = q1; P[r][2] = q2; P[r][3] = q3;
+        }
+    }
+    __syncthreads();
+    if (!valid)
+        return;
+    const int y = it / QW, x0 = 4 * (it % QW);
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + j;
+        if (mode == 1)
+            v[j] = L[r][y];
+        else if (mode == 2)
+            v[j] = T[r][x + 1];
+        else if (mode == 3)
+            v[j] = clip_u8((P[r][0] + y * P[r][2] + x * P[r][1]) >> 5);
+        else
+            v[j] = N == 16 ? P[r][0] : P[r][2 * (y >> 2) + (x >> 2)];
+    }
+    hp_store4(src + (ptrdiff_t)y * stride + x0, v);
+}
+
+/* pred4x4_add / pred8x8l_add / pred8x8l_filter_add: thread i owns column i (mode 0, VERT_PRED) or row i (mode 1, HOR_PRED) */
+template <int N, bool FILTER>
+__global__ __launch_bounds__(256) void k_h264_pred_add(uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x, b = gid / N, i = gid % N;
+    if (b >= n)
+        return;
+    const FFHipH264Pred k = blocks[b];
+    uint8_t *pix = plane + k.offset;
+    int16_t *blk = coeffs + k.aux;
+    const bool vert = k.mode == 0;
+    const ptrdiff_t along = vert ? stride : 1, across = vert ? 1 : stride; /* steps along / across the prediction direction */
+    const uint8_t *edge = pix - along;                                        /* the border sample in front of line 0 */
+    unsigned v;
+    if (FILTER) {
+        const bool tl = k.flags & FFHIP_H264_PRED_TOPLEFT, tr = k.flags & FFHIP_H264_PRED_TOPRIGHT;
+        const int c = edge[i * across];
+        if (i == 0)
+            v = hp_a3(tl ? edge[-across] : c, c, edge[across]);
+        else if (i == 7)
+            v = vert ? hp_a3(tr ? edge[8 * across] : c, c, edge[6 * across]) : (edge[6 * across] + 3 * c + 2) >> 2;
+        else
+            v = hp_a3(edge[(i - 1) * across], c, edge[(i + 1) * across]);
+    } else {
+        v = edge[i * across];
+    }
+    const int cal = vert ? N : 1, cac = vert ? 1 : N; /* the same two steps in the coefficient block */
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        v = (v + (unsigned)blk[j * cal + i * cac]) & 255u;
+        pix[j * along + i * across] = (uint8_t)v;
+        blk[j * cal + i * cac] = 0;
+    }
+}
+
+int ffhip_launch_h264_pred(int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    const dim3 block(256);
+    switch (kind) {
+    case FFHIP_H264_PRED4x4:   hipLaunchKernelGGL(k_h264_pred_dir<false>, dim3(cdiv(n, 64)), block, 0, stream, plane, stride, blocks, n); break;
+    case FFHIP_H264_PRED8x8L:  hipLaunchKernelGGL(k_h264_pred_dir<true>, dim3(cdiv(n, 16)), block, 0, stream, plane, stride, blocks, n); break;
+    case FFHIP_H264_PRED8x8:   hipLaunchKernelGGL(k_h264_pred_blk<8>, dim3(cdiv(n, 16)), block, 0, stream, plane, stride, blocks, n); break;
+    case FFHIP_H264_PRED16x16: hipLaunchKernelGGL(k_h264_pred_blk<16>, dim3(cdiv(n, 4)), block, 0, stream, plane, stride, blocks, n); break;
+    case FFHIP_H264_PRED4x4_ADD:
+        hipLaunchKernelGGL((k_h264_pred_add<4, false>), dim3(cdiv(n, 64)), block, 0, stream, plane, stride, coeffs, blocks, n); break;
+    case FFHIP_H264_PRED8x8L_ADD:
+        hipLaunchKernelGGL((k_h264_pred_add<8, false>), dim3(cdiv(n, 32)), block, 0, stream, plane, stride, coeffs, blocks, n); break;
+    case FFHIP_H264_PRED8x8L_FILTER_ADD:
+        hipLaunchKernelGGL((k_h264_pred_add<8, true>), dim3(cdiv(n, 32)), block, 0, stream, plane, stride, coeffs, blocks, n); break;
+    default:
+        ffhip_set_error("ffhip_h264_pred: kind %d outside 0..6", kind);
+        return FFHIP_EINVAL;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -880,3 +880,123 @@ extern "C" int ff_vp9dsp_scaled_mc_init_hip(FFHipVP9ScaledMcContext *c, int bpp)
     vp9_smc_fill<64, 0>(c); vp9_smc_fill<32, 1>(c); vp9_smc_fill<16, 2>(c); vp9_smc_fill<8, 3>(c); vp9_smc_fill<4, 4>(c);
     return 0;
 }
+
+/* ---- h264pred host faces: the picture patch is staged from exactly the neighbours the C member reads ---- */
+/* need: bit0 left column, bit1 row above, bit2 corner, bit3 top-right (4x4: topright[0..3]; 8x8l: T9..15 if has_topright) */
+#define HP_P 64 /* pitch of the staged patch; the block sits at row 1, column 16 */
+static void h264_pred_host(int kind, int mode, int n, unsigned need, int lrows, uint8_t *src, ptrdiff_t stride, const uint8_t *topright,
+                           int has_tl, int has_tr, int16_t *block)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    uint8_t st[17 * HP_P] = { 0 };
+    uint8_t *o = st + HP_P + 16;
+    if (need & 1)
+        for (int y = 0; y < lrows; y++)
+            o[y * HP_P - 1] = src[y * stride - 1];
+    if (need & 2) {
+        memcpy(o - HP_P, src - stride, n);
+        if (kind == FFHIP_H264_PRED8x8L || kind == FFHIP_H264_PRED8x8L_FILTER_ADD) {
+            if (has_tr)
+                o[8 - HP_P] = src[8 - stride];
+            if (has_tr && (need & 8))
+                memcpy(o - HP_P + 9, src - stride + 9, 7);
+        }
+    }
+    if (need & 4)
+        o[-HP_P - 1] = src[-stride - 1];
+    if (kind == FFHIP_H264_PRED4x4 && (need & 8))
+        memcpy(o - HP_P + 32, topright, 4); /* wherever the caller's pointer leads, the record addresses the staged copy */
+    const int ncoef = block ? n * n : 0;
+    void *scratch;
+    if (ffhip_scratch_reserve(64 + sizeof(st) + 128 + 64, &scratch) < 0)
+        return;
+    uint8_t *buf = (uint8_t *)scratch, *dp = buf + 64;
+    int16_t *dc = (int16_t *)(dp + sizeof(st));
+    FFHipH264Pred k = {};
+    k.offset = HP_P + 16;
+    k.aux = kind == FFHIP_H264_PRED4x4 ? 16 + 32 : 0; /* where topright[] was staged: row 0 of the patch */
+    k.mode = (uint8_t)mode;
+    k.flags = (uint8_t)((has_tl ? FFHIP_H264_PRED_TOPLEFT : 0) | (has_tr ? FFHIP_H264_PRED_TOPRIGHT : 0));
+    if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dp, st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ncoef && hipMemcpy(dc, block, ncoef * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_launch_h264_pred(kind, dp, HP_P, dc, (const FFHipH264Pred *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
+        return;
+    if (hipMemcpy2D(src, stride, dp + HP_P + 16, HP_P, n, n, hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    if (ncoef)
+        (void)hipMemcpy(block, dc, ncoef * sizeof(int16_t), hipMemcpyDeviceToHost); /* cleared by the kernel */
+}
+static constexpr unsigned hp_need4(int mode) { return (unsigned)(0x0211a777a312ull >> (4 * mode)) & 15u; } /* as kernels/h264_pred.hip */
+/* pred8x8 / pred16x16: 0 DC 1 HOR 2 VERT 3 PLANE 4 LEFT_DC 5 TOP_DC 6 DC_128 7 L0T 8 0LT 9 L00 10 0L0 */
+static constexpr unsigned hp_need_blk(int mode)
+{
+    return (mode == 0 || mode == 1 || mode == 3 || mode == 4 || mode >= 7 ? 1u : 0u) |
+           (mode == 0 || mode == 2 || mode == 3 || mode == 5 || mode == 7 || mode == 8 ? 2u : 0u) | (mode == 3 ? 4u : 0u);
+}
+template <int MODE>
+static void s_pred4x4(uint8_t *src, const uint8_t *topright, ptrdiff_t stride)
+{
+    h264_pred_host(FFHIP_H264_PRED4x4, MODE, 4, hp_need4(MODE), 4, src, stride, topright, 0, 0, nullptr);
+}
+template <int MODE>
+static void s_pred8x8l(uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride)
+{
+    constexpr unsigned need = hp_need4(MODE);
+    /* the corner is also read by the edge filter when has_topleft (PREDICT_8x8_LOAD_LEFT / _TOP) */
+    h264_pred_host(FFHIP_H264_PRED8x8L, MODE, 8, need | ((has_topleft && (need & 3)) ? 4u : 0u), 8, src, stride, nullptr, has_topleft, has_topright,
+                   nullptr);
+}
+template <int MODE>
+static void s_pred8x8(uint8_t *src, ptrdiff_t stride)
+{
+    h264_pred_host(FFHIP_H264_PRED8x8, MODE, 8, hp_need_blk(MODE), MODE == 7 ? 4 : 8, src, stride, nullptr, 0, 0, nullptr);
+}
+template <int MODE>
+static void s_pred16x16(uint8_t *src, ptrdiff_t stride)
+{
+    h264_pred_host(FFHIP_H264_PRED16x16, MODE, 16, hp_need_blk(MODE), 16, src, stride, nullptr, 0, 0, nullptr);
+}
+template <int KIND, int N, int MODE>
+static void s_pred_add(uint8_t *pix, int16_t *block, ptrdiff_t stride)
+{
+    h264_pred_host(KIND, MODE, N, MODE == 0 ? 2u : 1u, N, pix, stride, nullptr, 0, 0, block);
+}
+template <int MODE>
+static void s_pred8x8l_filter_add(uint8_t *pix, int16_t *block, int has_topleft, int has_topright, ptrdiff_t stride)
+{
+    h264_pred_host(FFHIP_H264_PRED8x8L_FILTER_ADD, MODE, 8, (MODE == 0 ? 2u : 1u) | (has_topleft ? 4u : 0u), 8, pix, stride, nullptr, has_topleft,
+                   MODE == 0 ? has_topright : 0, block);
+}
+/* pred8x8_add / pred16x16_add walk block_offset[] in the C order, each 4x4 seeing what the previous ones wrote
+ * (h264pred_template.c:1262-1330) */
+template <int NB, int MODE8x8>
+static void s_pred_mb_add(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
+{
+    for (int i = 0; i < NB; i++)
+        s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, MODE8x8 == 2 ? 0 : 1>(pix + block_offset[i], block + i * 16, stride);
+}
+
+extern "C" int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc)
+{
+    if (!h || codec_id != FFHIP_CODEC_ID_H264 || bit_depth != 8 || chroma_format_idc > 1)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+#define HP(M) h->pred4x4[M] = s_pred4x4<M>; h->pred8x8l[M] = s_pred8x8l<M>;
+    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10) HP(11)
+#undef HP
+#define HP(M) h->pred8x8[M] = s_pred8x8<M>;
+    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10)
+#undef HP
+#define HP(M) h->pred16x16[M] = s_pred16x16<M>;
+    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6)
+#undef HP
+    h->pred4x4_add[0] = s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, 0>;   h->pred4x4_add[1] = s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, 1>;
+    h->pred8x8l_add[0] = s_pred_add<FFHIP_H264_PRED8x8L_ADD, 8, 0>; h->pred8x8l_add[1] = s_pred_add<FFHIP_H264_PRED8x8L_ADD, 8, 1>;
+    h->pred8x8l_filter_add[0] = s_pred8x8l_filter_add<0>;           h->pred8x8l_filter_add[1] = s_pred8x8l_filter_add<1>;
+    h->pred8x8_add[2] = s_pred_mb_add<4, 2>;    h->pred8x8_add[1] = s_pred_mb_add<4, 1>;
+    h->pred16x16_add[2] = s_pred_mb_add<16, 2>; h->pred16x16_add[1] = s_pred_mb_add<16, 1>;
+    return 0;
+}

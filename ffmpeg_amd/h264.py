@@ -1,6 +1,8 @@
 """Host-side mirror of the reference's H264DSPContext / H264QpelContext batch faces (device tensors)."""
 import ctypes as C
 
+import numpy as np
+
 from . import _lib
 
 IDCT4, IDCT8, IDCT4_DC, IDCT8_DC = 0, 1, 2, 3
@@ -112,3 +114,36 @@ class Picture:
         rp = (C.c_void_p * 3)(*[t.data_ptr() for t in ref])
         st = (C.c_int * 3)(*strides)
         return _lib.check(_lib.lib().ffhip_h264_picture_flush(self._p, dp, st, rp, _stream(stream)), "ffhip_h264_picture_flush")
+
+
+# ---- H264PredContext (include/ffhip.h; libavcodec/h264pred.h:92-116) ----
+PRED4x4, PRED8x8L, PRED8x8, PRED16x16, PRED4x4_ADD, PRED8x8L_ADD, PRED8x8L_FILTER_ADD = range(7)
+PRED_TOPLEFT, PRED_TOPRIGHT, PRED_TR_SPLAT = 1, 2, 4
+CODEC_ID_H264 = 27
+#: FFHipH264Pred
+PRED_DTYPE = np.dtype([("offset", np.int32), ("aux", np.int32), ("mode", np.uint8), ("flags", np.uint8), ("pad", np.uint8, 2)])
+
+
+def pred_batch(kind, plane, stride, blocks, n, coeffs=None, stream=None):
+    """n independent blocks of one kind predicted in place; blocks: uint8 [n, 12] FFHipH264Pred records (device)"""
+    return _lib.check(_lib.lib().ffhip_h264_pred_batch_dev(kind, plane.data_ptr(), stride, None if coeffs is None else coeffs.data_ptr(),
+                                                           blocks.data_ptr(), n, None if stream is None else C.c_void_p(stream)),
+                      "ffhip_h264_pred_batch_dev")
+
+
+class H264PredContext(C.Structure):
+    _fields_ = [("pred4x4", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t) * 15),
+                ("pred8x8l", C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t) * 12),
+                ("pred8x8", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t) * 11),
+                ("pred16x16", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t) * 9),
+                ("pred4x4_add", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t) * 2),
+                ("pred8x8l_add", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t) * 2),
+                ("pred8x8l_filter_add", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t) * 2),
+                ("pred8x8_add", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t) * 3),
+                ("pred16x16_add", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t) * 3)]
+
+
+def pred_init(codec_id=CODEC_ID_H264, bit_depth=8, chroma_format_idc=1):
+    h = H264PredContext()
+    _lib.check(_lib.lib().ff_h264_pred_init_hip(C.byref(h), codec_id, bit_depth, chroma_format_idc), "ff_h264_pred_init_hip")
+    return h

@@ -380,6 +380,57 @@ int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const 
                               void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* libavcodec: H264PredContext — H.264 codec, 8 bits, chroma_format_idc <= 1 */
+/* ------------------------------------------------------------------------------------------ */
+/** H264PredContext (libavcodec/h264pred.h:92-116), the members ff_h264_pred_init() fills for AV_CODEC_ID_H264
+ *  (libavcodec/h264pred.c:448-538): same signatures, host pointers, in place on the picture like the C functions.  Mode indices are
+ *  the reference's (h264pred.h:35-48 for pred4x4 / pred8x8l, :67-82 for pred8x8 / pred16x16); the _add members are filled at
+ *  [VERT_PRED] / [HOR_PRED] resp. [VERT_PRED8x8] / [HOR_PRED8x8] only, as in the reference.  A face reads exactly the neighbours its
+ *  C counterpart reads (a DC_128 call touches none). */
+typedef struct FFHipH264PredContext {
+    void (*pred4x4[9 + 3 + 3])(uint8_t *src, const uint8_t *topright, ptrdiff_t stride);
+    void (*pred8x8l[9 + 3])(uint8_t *src, int topleft, int topright, ptrdiff_t stride);
+    void (*pred8x8[4 + 3 + 4])(uint8_t *src, ptrdiff_t stride);
+    void (*pred16x16[4 + 3 + 2])(uint8_t *src, ptrdiff_t stride);
+    void (*pred4x4_add[2])(uint8_t *pix, int16_t *block, ptrdiff_t stride);
+    void (*pred8x8l_add[2])(uint8_t *pix, int16_t *block, ptrdiff_t stride);
+    void (*pred8x8l_filter_add[2])(uint8_t *pix, int16_t *block, int topleft, int topright, ptrdiff_t stride);
+    void (*pred8x8_add[3])(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
+    void (*pred16x16_add[3])(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
+} FFHipH264PredContext;
+#define FFHIP_CODEC_ID_H264 27 /* AV_CODEC_ID_H264 (libavcodec/codec_id.h:77) */
+/** ff_h264_pred_init_<arch>(H264PredContext *, codec_id, bit_depth, chroma_format_idc) shape (libavcodec/h264pred.h:120-127).
+ *  FFHIP_EINVAL for what this library does not replace (other codecs' variants, > 8 bits, 4:2:2): those keep the C pointers. */
+int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc);
+
+#define FFHIP_H264_PRED4x4             0  /* pred4x4[mode]                                 */
+#define FFHIP_H264_PRED8x8L            1  /* pred8x8l[mode]                                */
+#define FFHIP_H264_PRED8x8             2  /* pred8x8[mode]   (chroma, 4:2:0)               */
+#define FFHIP_H264_PRED16x16           3  /* pred16x16[mode]                               */
+#define FFHIP_H264_PRED4x4_ADD         4  /* pred4x4_add[mode]: mode 0 VERT_PRED, 1 HOR_PRED */
+#define FFHIP_H264_PRED8x8L_ADD        5  /* pred8x8l_add[mode]                            */
+#define FFHIP_H264_PRED8x8L_FILTER_ADD 6  /* pred8x8l_filter_add[mode]                     */
+#define FFHIP_H264_PRED_TOPLEFT   1  /* flags: pred8x8l's has_topleft                                                       */
+#define FFHIP_H264_PRED_TOPRIGHT  2  /* flags: pred8x8l's has_topright                                                      */
+#define FFHIP_H264_PRED_TR_SPLAT  4  /* flags: pred4x4's topright is src[3 - stride] four times (the decoder's substitute when the
+                                        top-right block is unavailable, h264_mb_template.c hl_decode_mb_predict_luma)        */
+/** One block of the batch face, predicted in place from its neighbours in the plane. */
+typedef struct FFHipH264Pred {
+    int32_t offset;   /* bytes into the plane: the block's top-left sample */
+    int32_t aux;      /* PRED4x4: bytes into the plane of topright[0..3] (unless TR_SPLAT); the _ADD kinds: index into coeffs of
+                         the block's first coefficient */
+    uint8_t mode;
+    uint8_t flags;
+    uint8_t pad[2];   /* sizeof == 12 */
+} FFHipH264Pred;
+/** n blocks of one kind whose neighbours are final: intra prediction chains through the reconstruction, so a decoder batches
+ *  what its wavefront allows (all blocks of a launch are read-before-write independent; a launch orders after the previous one
+ *  on the stream).  pred8x8_add / pred16x16_add are 4 / 16 PRED4x4_ADD records at block_offset[], row of blocks by row (VERT) or
+ *  column by column (HOR).  coeffs is used (and the blocks' coefficients cleared) by the _ADD kinds only. */
+int ffhip_h264_pred_batch_dev(int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n,
+                              void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* libavutil: AVFloatDSPContext vector operations around the MDCT           */
 /* ------------------------------------------------------------------------------------------ */
 /** The float members of AVFloatDSPContext an (I)MDCT pipeline uses (libavutil/float_dsp.h:31-175; windowing and

@@ -150,4 +150,15 @@ void   ffo_rdft_run(int inv, int len, float scale, float *out, const float *in);
 void   ffo_mdct_naive_fwd(int len, double scale, double *out, const float *in);
 void   ffo_mdct_naive_inv(int len, double scale, double *out, const float *in);
 
+/* ---- ffo_h264pred.c: H264PredContext, H.264 codec, 8 bits, chroma_format_idc <= 1 (libavcodec/h264pred.h:92-116) ---- */
+void ffo_h264_pred4x4(int mode, uint8_t *src, const uint8_t *topright, ptrdiff_t stride);
+void ffo_h264_pred8x8l(int mode, uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride);
+void ffo_h264_pred8x8(int mode, uint8_t *src, ptrdiff_t stride);
+void ffo_h264_pred16x16(int mode, uint8_t *src, ptrdiff_t stride);
+void ffo_h264_pred4x4_add(int mode, uint8_t *pix, int16_t *block, ptrdiff_t stride);
+void ffo_h264_pred8x8l_add(int mode, uint8_t *pix, int16_t *block, ptrdiff_t stride);
+void ffo_h264_pred8x8l_filter_add(int mode, uint8_t *pix, int16_t *block, int has_topleft, int has_topright, ptrdiff_t stride);
+void ffo_h264_pred8x8_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
+void ffo_h264_pred16x16_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
+
 #endif

@@ -422,3 +422,4 @@ void ffref_tx_free(void *ctx)
         av_free(t);
     }
 }
+

@@ -1,0 +1,48 @@
+/*
+ * ffref_shim_h264pred.c — flat accessors onto the reference's H264PredContext.  TEST INFRASTRUCTURE ONLY.
+ * Its own translation unit: h264pred.h's mode macros (DC_PRED, ...) collide with vp9.h's enum of the same names.
+ * Includes the reference's headers where they lie (-I/root/reference); contains no reference code.
+ */
+#include "config.h"
+#include <stddef.h>
+#include <stdint.h>
+#include "libavutil/cpu.h"
+#include "libavutil/log.h"
+#include "libavcodec/codec_id.h"
+#include "libavcodec/h264pred.h"
+
+static void pure_c(void) { av_force_cpu_flags(0); av_log_set_level(AV_LOG_ERROR); }
+
+/* ---- h264pred: H264PredContext of the H.264 codec, 8 bits, 4:2:0 ---- */
+static H264PredContext *h264pred(void)
+{
+    static H264PredContext h;
+    static int ready;
+    pure_c();
+    if (!ready) {
+        ff_h264_pred_init(&h, AV_CODEC_ID_H264, 8, 1);
+        ready = 1;
+    }
+    return &h;
+}
+void ffref_h264_pred4x4(int mode, uint8_t *src, const uint8_t *topright, ptrdiff_t stride) { h264pred()->pred4x4[mode](src, topright, stride); }
+void ffref_h264_pred8x8l(int mode, uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride)
+{
+    h264pred()->pred8x8l[mode](src, has_topleft, has_topright, stride);
+}
+void ffref_h264_pred8x8(int mode, uint8_t *src, ptrdiff_t stride) { h264pred()->pred8x8[mode](src, stride); }
+void ffref_h264_pred16x16(int mode, uint8_t *src, ptrdiff_t stride) { h264pred()->pred16x16[mode](src, stride); }
+void ffref_h264_pred4x4_add(int mode, uint8_t *pix, int16_t *block, ptrdiff_t stride) { h264pred()->pred4x4_add[mode](pix, block, stride); }
+void ffref_h264_pred8x8l_add(int mode, uint8_t *pix, int16_t *block, ptrdiff_t stride) { h264pred()->pred8x8l_add[mode](pix, block, stride); }
+void ffref_h264_pred8x8l_filter_add(int mode, uint8_t *pix, int16_t *block, int has_topleft, int has_topright, ptrdiff_t stride)
+{
+    h264pred()->pred8x8l_filter_add[mode](pix, block, has_topleft, has_topright, stride);
+}
+void ffref_h264_pred8x8_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
+{
+    h264pred()->pred8x8_add[mode](pix, block_offset, block, stride);
+}
+void ffref_h264_pred16x16_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
+{
+    h264pred()->pred16x16_add[mode](pix, block_offset, block, stride);
+}

@@ -118,6 +118,18 @@ def oracle():
         L.ffo_vp9_smc.restype = None
         L.ffo_vp9_intra_pred.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, u8p]
         L.ffo_vp9_intra_pred.restype = None
+        L.ffo_h264_pred4x4.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t]
+        L.ffo_h264_pred8x8l.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_ssize_t]
+        L.ffo_h264_pred8x8.argtypes = [C.c_int, u8p, C.c_ssize_t]
+        L.ffo_h264_pred16x16.argtypes = [C.c_int, u8p, C.c_ssize_t]
+        L.ffo_h264_pred4x4_add.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+        L.ffo_h264_pred8x8l_add.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+        L.ffo_h264_pred8x8l_filter_add.argtypes = [C.c_int, u8p, i16p, C.c_int, C.c_int, C.c_ssize_t]
+        L.ffo_h264_pred8x8_add.argtypes = [C.c_int, u8p, i32p, i16p, C.c_ssize_t]
+        L.ffo_h264_pred16x16_add.argtypes = [C.c_int, u8p, i32p, i16p, C.c_ssize_t]
+        for _f in ("pred4x4", "pred8x8l", "pred8x8", "pred16x16", "pred4x4_add", "pred8x8l_add", "pred8x8l_filter_add", "pred8x8_add",
+                   "pred16x16_add"):
+            getattr(L, "ffo_h264_" + _f).restype = None
         L.ffo_vp9_loop_filter.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
         L.ffo_vp9_loop_filter.restype = None
         L.ffo_hevc_dequant.argtypes = [i16p, C.c_int]
@@ -219,6 +231,18 @@ def ref():
         L.ffref_vp9_smc.restype = None
         L.ffref_vp9_intra_pred.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, u8p]
         L.ffref_vp9_intra_pred.restype = None
+        L.ffref_h264_pred4x4.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t]
+        L.ffref_h264_pred8x8l.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_ssize_t]
+        L.ffref_h264_pred8x8.argtypes = [C.c_int, u8p, C.c_ssize_t]
+        L.ffref_h264_pred16x16.argtypes = [C.c_int, u8p, C.c_ssize_t]
+        L.ffref_h264_pred4x4_add.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+        L.ffref_h264_pred8x8l_add.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+        L.ffref_h264_pred8x8l_filter_add.argtypes = [C.c_int, u8p, i16p, C.c_int, C.c_int, C.c_ssize_t]
+        L.ffref_h264_pred8x8_add.argtypes = [C.c_int, u8p, i32p, i16p, C.c_ssize_t]
+        L.ffref_h264_pred16x16_add.argtypes = [C.c_int, u8p, i32p, i16p, C.c_ssize_t]
+        for _f in ("pred4x4", "pred8x8l", "pred8x8", "pred16x16", "pred4x4_add", "pred8x8l_add", "pred8x8l_filter_add", "pred8x8_add",
+                   "pred16x16_add"):
+            getattr(L, "ffref_h264_" + _f).restype = None
         L.ffref_vp9_loop_filter.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
         L.ffref_vp9_loop_filter.restype = None
         L.ffref_hevc_dequant.argtypes = [i16p, C.c_int]

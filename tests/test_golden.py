@@ -218,6 +218,32 @@ def test_vp9_mc_golden():
         assert np.array_equal(a[:h, :w], d["mc_out"][i][:h, :w]), i
 
 
+def h264_pred_golden_check(apply, d):
+    """apply(kind, pic, recs, coeffs): every kind's blocks against the stored reference outputs; nothing else may change"""
+    from test_oracle_vs_ref import H264_PRED_KINDS
+    for kind, (n, _, _) in enumerate(H264_PRED_KINDS):
+        recs = d["k%d_rec" % kind]
+        coeffs = d["k%d_coef" % kind].copy() if kind >= 4 else None
+        pic = d["pic"].copy()
+        pic = apply(kind, pic, recs, coeffs)
+        mask = np.ones(pic.shape, bool)
+        for i, (x, y, *_) in enumerate(recs.tolist()):
+            assert np.array_equal(pic[y:y + n, x:x + n], d["k%d_out" % kind][i]), (kind, i, recs[i])
+            mask[y:y + n, x:x + n] = False
+        assert np.array_equal(pic[mask], d["pic"][mask]), kind
+
+
+def test_h264_pred_golden():
+    from test_oracle_vs_ref import h264_pred_apply
+    O = ffi.oracle()
+
+    def apply(kind, pic, recs, coeffs):
+        h264_pred_apply(O, "ffo", kind, pic, recs, coeffs)
+        assert coeffs is None or not coeffs.any()
+        return pic
+    h264_pred_golden_check(apply, load("h264pred"))
+
+
 def test_fdsp_golden():
     O = ffi.oracle()
     d = load("fdsp")

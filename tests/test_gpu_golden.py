@@ -301,3 +301,9 @@ def test_rdft_golden_gpu():
             ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
             assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (len_, inv)
             ctx.close()
+
+
+def test_h264_pred_golden_gpu():
+    """H264PredContext batch kinds against the reference's stored outputs (tests/golden/h264pred.npz)"""
+    from test_gpu_h264_pred import hip_pred_apply
+    G.h264_pred_golden_check(hip_pred_apply, G.load("h264pred"))

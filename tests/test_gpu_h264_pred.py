@@ -1,0 +1,148 @@
+"""GPU parity: H264PredContext (intra prediction, 8 bits, 4:2:0) vs the oracle, through the C ABI - the batch face and the
+signature-exact host faces."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import ptr, u8p, i16p, i32p
+from test_oracle_vs_ref import H264_PRED_KINDS, h264_pred_grid, h264_pred_apply, h264_pred_plane
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def hip_pred_apply(kind, pic, recs, coeffs):
+    """the batch face over (x, y, mode, flags, aux) rows; returns the picture (coeffs updated in place)"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    width = pic.shape[1]
+    rec = np.zeros(len(recs), h264.PRED_DTYPE)
+    rec["offset"] = recs[:, 1] * width + recs[:, 0]
+    rec["aux"], rec["mode"], rec["flags"] = recs[:, 4], recs[:, 2], recs[:, 3]
+    order = np.random.default_rng(len(recs)).permutation(len(recs))        # the order of independent blocks is free
+    d_pic = torch.from_numpy(pic).cuda()
+    d_co = None if coeffs is None else torch.from_numpy(coeffs).cuda()
+    d_rec = torch.from_numpy(rec[order].view(np.uint8).reshape(len(recs), 12).copy()).cuda()
+    h264.pred_batch(kind, d_pic, width, d_rec, len(recs), coeffs=d_co)
+    torch.cuda.synchronize()
+    if coeffs is not None:
+        coeffs[:] = d_co.cpu().numpy()
+    return d_pic.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind", range(7))
+def test_h264_pred_batch(kind):
+    """a picture's worth of independent blocks: every mode and flag combination, random / saturated / smooth content, picture
+    widths on and off the dword grid"""
+    O = ffi.oracle()
+    n = H264_PRED_KINDS[kind][0]
+    for width, height, content in ((1283, 360, 0), (1280, 352, 1), (642, 200, 2)):
+        rng = np.random.default_rng(2650 + 10 * kind + content)
+        if content == 0:
+            pic = rng.integers(0, 256, (height, width), dtype=np.uint8)
+        elif content == 1:
+            pic = rng.choice(np.array([0, 255], np.uint8), (height, width))
+        else:
+            pic = np.clip(np.add.outer(np.arange(height) * 2, np.arange(width) * -1) + 200 + rng.integers(-5, 6, (height, width)), 0, 255).astype(np.uint8)
+        recs = h264_pred_grid(rng, kind, height, width)
+        coeffs = wc = None
+        if kind >= 4:
+            coeffs = rng.integers(-300, 301, (len(recs) + 1) * n * n).astype(np.int16)
+            coeffs[:n * n] = rng.choice(np.array([-32768, 32767], np.int16), n * n)
+            wc = coeffs.copy()
+        want = pic.copy()
+        h264_pred_apply(O, "ffo", kind, want, recs, wc)
+        got = hip_pred_apply(kind, pic.copy(), recs, coeffs)
+        assert (want != pic).sum() > 500
+        assert np.array_equal(got, want), "%d mismatches, first %s" % ((got != want).sum(), np.argwhere(got != want)[:3])
+        if kind >= 4:
+            assert np.array_equal(coeffs, wc) and coeffs[-n * n:].any()      # consumed blocks cleared, the spare one untouched
+
+
+def test_h264_pred_picture_edge():
+    """blocks on the picture's first row / column / corner with the modes a decoder uses there: only existing neighbours are read
+    (the buffer starts at the picture's first sample)"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(2690)
+    width = 64
+    pic = rng.integers(0, 256, (64, width), dtype=np.uint8)
+    #           kind, x, y, mode, flags
+    cases = [(0, 0, 0, 11, 0), (0, 20, 0, 1, 0), (0, 32, 0, 9, 0), (0, 44, 0, 8, 0), (0, 0, 20, 0, 0), (0, 0, 32, 10, 0),
+             (1, 0, 0, 11, 0), (1, 16, 0, 1, 0), (1, 40, 0, 9, 0), (1, 0, 24, 0, 2), (1, 0, 40, 10, 0), (1, 0, 56, 3, 2),
+             (2, 0, 0, 6, 0), (2, 24, 0, 1, 0), (2, 40, 0, 4, 0), (2, 0, 16, 2, 0), (2, 0, 32, 5, 0), (2, 52, 0, 9, 0),
+             (3, 0, 0, 6, 0), (3, 32, 0, 1, 0), (3, 0, 24, 2, 0), (3, 0, 44, 5, 0)]
+    for kind in range(4):
+        recs = np.array([(x, y, m, f, 0) for k, x, y, m, f in cases if k == kind], np.int32)
+        want = pic.copy()
+        h264_pred_apply(O, "ffo", kind, want, recs)
+        got = hip_pred_apply(kind, pic.copy(), recs, None)
+        assert np.array_equal(got, want), kind
+
+
+def test_h264_pred_host_faces():
+    """ff_h264_pred_init_hip(): every member the reference fills for the H.264 codec, called as the decoder calls them"""
+    from ffmpeg_amd import h264
+    _torch()
+    O = ffi.oracle()
+    h = h264.pred_init()
+    rng = np.random.default_rng(2691)
+    at = lambda a: a.ctypes.data + 16 * 48 + 16
+    for kind in range(4):
+        n, nmodes, name = H264_PRED_KINDS[kind]
+        for mode in range(nmodes):
+            for rep in range(2):
+                a = h264_pred_plane(rng, rep + mode); b = a.copy()
+                tr = rng.integers(0, 256, 4, dtype=np.uint8)
+                tl_tr = (1 if mode in (4, 5, 6) else int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+                if kind == 0:
+                    h.pred4x4[mode](at(a), tr.ctypes.data, 48)
+                    O.ffo_h264_pred4x4(mode, C.cast(at(b), u8p), ptr(tr), 48)
+                elif kind == 1:
+                    h.pred8x8l[mode](at(a), tl_tr[0], tl_tr[1], 48)
+                    O.ffo_h264_pred8x8l(mode, C.cast(at(b), u8p), tl_tr[0], tl_tr[1], 48)
+                else:
+                    getattr(h, name)[mode](at(a), 48)
+                    getattr(O, "ffo_h264_" + name)(mode, C.cast(at(b), u8p), 48)
+                assert np.array_equal(a, b), (name, mode, rep)
+    assert not h.pred4x4[12] and not h.pred16x16[7] and not h.pred8x8_add[0]   # members the reference leaves unset stay NULL
+    scan = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (3, 0), (2, 1), (3, 1), (0, 2), (1, 2), (0, 3), (1, 3), (2, 2), (3, 2), (2, 3), (3, 3)]
+    for rep in range(3):
+        for name, n in (("pred4x4_add", 4), ("pred8x8l_add", 8), ("pred8x8l_filter_add", 8)):
+            for mode in (0, 1):
+                a = h264_pred_plane(rng, rep); b = a.copy()
+                ca = rng.integers(-300, 301, n * n).astype(np.int16); cb = ca.copy()
+                if name == "pred8x8l_filter_add":
+                    tl, tr = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                    h.pred8x8l_filter_add[mode](at(a), ca.ctypes.data, tl, tr, 48)
+                    O.ffo_h264_pred8x8l_filter_add(mode, C.cast(at(b), u8p), ptr(cb, i16p), tl, tr, 48)
+                else:
+                    getattr(h, name)[mode](at(a), ca.ctypes.data, 48)
+                    getattr(O, "ffo_h264_" + name)(mode, C.cast(at(b), u8p), ptr(cb, i16p), 48)
+                assert np.array_equal(a, b) and not ca.any(), (name, mode, rep)
+        for name, nb in (("pred8x8_add", 4), ("pred16x16_add", 16)):
+            for mode in (2, 1):
+                a = h264_pred_plane(rng, rep); b = a.copy()
+                ca = rng.integers(-300, 301, nb * 16).astype(np.int16); cb = ca.copy()
+                offs = np.array([4 * x + 4 * y * 48 for x, y in scan[:nb]], np.int32)
+                getattr(h, name)[mode](at(a), offs.ctypes.data, ca.ctypes.data, 48)
+                getattr(O, "ffo_h264_" + name)(mode, C.cast(at(b), u8p), ptr(offs, i32p), ptr(cb, i16p), 48)
+                assert np.array_equal(a, b) and not ca.any(), (name, mode, rep)
+
+
+def test_h264_pred_init_rejects():
+    """what this library does not replace keeps the C pointers: other codecs' variants, > 8 bits, 4:2:2"""
+    from ffmpeg_amd import h264, _lib
+    _torch()
+    hctx = h264.H264PredContext()
+    L = _lib.lib()
+    for args in ((h264.CODEC_ID_H264, 10, 1), (h264.CODEC_ID_H264, 8, 2), (139, 8, 1)):
+        assert L.ff_h264_pred_init_hip(C.byref(hctx), *args) < 0

@@ -581,6 +581,139 @@ def test_vp9_intra_pred():
                 assert np.array_equal(a, b), (tx, mode, rep)
 
 
+def h264_pred_plane(rng, rep):
+    """a 48x48 patch with the block at (16, 16): random, saturated, or smooth (the plane predictor's clip on both sides)"""
+    if rep % 4 == 1:
+        return rng.choice(np.array([0, 255], np.uint8), (48, 48))
+    if rep % 4 == 2:
+        g = np.add.outer(np.arange(48) * int(rng.integers(-9, 10)), np.arange(48) * int(rng.integers(-9, 10))) + int(rng.integers(0, 256))
+        return np.clip(g + rng.integers(-3, 4, (48, 48)), 0, 255).astype(np.uint8)
+    return rng.integers(0, 256, (48, 48), dtype=np.uint8)
+
+
+#: H264PredContext members by size: (name, number of modes filled for the H.264 codec at 8 bits, 4:2:0) - h264pred.c:448-538
+H264_PRED_SETS = (("pred4x4", 12), ("pred8x8l", 12), ("pred8x8", 11), ("pred16x16", 7))
+
+
+def h264_pred_call(L, pref, name, mode, buf, tr, tl_tr):
+    at = C.cast(buf.ctypes.data + 16 * 48 + 16, u8p)
+    if name == "pred4x4":
+        getattr(L, pref + "_h264_pred4x4")(mode, at, ptr(tr), 48)
+    elif name == "pred8x8l":
+        getattr(L, pref + "_h264_pred8x8l")(mode, at, tl_tr[0], tl_tr[1], 48)
+    else:
+        getattr(L, pref + "_h264_" + name)(mode, at, 48)
+
+
+def test_h264_pred():
+    """H264PredContext.pred4x4 / pred8x8l / pred8x8 / pred16x16, every member the H.264 decoder gets (tests/checkasm/h264pred.c
+    walks the same tables); pred4x4's topright is a separate pointer as in the decoder (h264_mb_template.c passes either the row
+    above or a replicated sample)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(2640)
+    for name, nmodes in H264_PRED_SETS:
+        for mode in range(nmodes):
+            for rep in range(16):
+                a = h264_pred_plane(rng, rep)
+                b = a.copy()
+                tr = rng.integers(0, 256, 4, dtype=np.uint8) if rep & 1 else a[15, 20:24].copy()
+                # the diagonal modes that read the corner are only called with it available
+                tl_tr = (1 if mode in (4, 5, 6) else int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+                h264_pred_call(R, "ffref", name, mode, a, tr, tl_tr)
+                h264_pred_call(O, "ffo", name, mode, b, tr, tl_tr)
+                assert np.array_equal(a, b), (name, mode, rep, tl_tr)
+
+
+def test_h264_pred_add():
+    """the lossless members: pred4x4_add / pred8x8l_add / pred8x8l_filter_add [VERT, HOR], pred8x8_add / pred16x16_add
+    [VERT_PRED8x8, HOR_PRED8x8] with the decoder's block_offset tables (h264_slice.c init_scan_tables / h264dec block_offset)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(2641)
+    scan = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (3, 0), (2, 1), (3, 1), (0, 2), (1, 2), (0, 3), (1, 3), (2, 2), (3, 2), (2, 3), (3, 3)]
+    for rep in range(24):
+        lim = 300 if rep % 3 else 32767
+        for name, n in (("pred4x4_add", 4), ("pred8x8l_add", 8), ("pred8x8l_filter_add", 8)):
+            for mode in (0, 1):
+                a = h264_pred_plane(rng, rep); b = a.copy()
+                ca = rng.integers(-lim, lim + 1, n * n).astype(np.int16); cb = ca.copy()
+                at = lambda x: C.cast(x.ctypes.data + 16 * 48 + 16, u8p)
+                if name == "pred8x8l_filter_add":
+                    tl, tr = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                    R.ffref_h264_pred8x8l_filter_add(mode, at(a), ptr(ca, i16p), tl, tr, 48)
+                    O.ffo_h264_pred8x8l_filter_add(mode, at(b), ptr(cb, i16p), tl, tr, 48)
+                else:
+                    getattr(R, "ffref_h264_" + name)(mode, at(a), ptr(ca, i16p), 48)
+                    getattr(O, "ffo_h264_" + name)(mode, at(b), ptr(cb, i16p), 48)
+                assert np.array_equal(a, b) and np.array_equal(ca, cb) and not ca.any(), (name, mode, rep)
+        for name, nb in (("pred8x8_add", 4), ("pred16x16_add", 16)):
+            for mode in (2, 1):
+                a = h264_pred_plane(rng, rep); b = a.copy()
+                ca = rng.integers(-lim, lim + 1, nb * 16).astype(np.int16); cb = ca.copy()
+                offs = np.array([4 * x + 4 * y * 48 for x, y in scan[:nb]], np.int32)
+                at = lambda x: C.cast(x.ctypes.data + 16 * 48 + 16, u8p)
+                getattr(R, "ffref_h264_" + name)(mode, at(a), ptr(offs, i32p), ptr(ca, i16p), 48)
+                getattr(O, "ffo_h264_" + name)(mode, at(b), ptr(offs, i32p), ptr(cb, i16p), 48)
+                assert np.array_equal(a, b) and np.array_equal(ca, cb), (name, mode, rep)
+
+
+#: the batch kinds of include/ffhip.h FFHIP_H264_PRED*: (block size, number of modes, member name)
+H264_PRED_KINDS = ((4, 12, "pred4x4"), (8, 12, "pred8x8l"), (8, 11, "pred8x8"), (16, 7, "pred16x16"),
+                   (4, 2, "pred4x4_add"), (8, 2, "pred8x8l_add"), (8, 2, "pred8x8l_filter_add"))
+
+
+def h264_pred_grid(rng, kind, height, width, count=None):
+    """Independent blocks of one kind on a grid with gaps (3N across for the top-right run, 2N down), so that no block's
+    neighbours are another block's output: rows of (x, y, mode, flags, aux).  flags / aux as FFHipH264Pred: pred8x8l's
+    has_topleft (1) / has_topright (2); pred4x4's topright either at aux (bytes into the plane, stride = width) or replicated
+    (flag 4); the _add kinds' aux = coefficient index."""
+    n, nmodes, _ = H264_PRED_KINDS[kind]
+    recs = []
+    i = 0
+    for y in range(n, height - n + 1, 2 * n):
+        for x in range(n, width - 2 * n + 1, 3 * n):
+            mode = i % nmodes
+            flags, aux = 0, 0
+            if kind in (1, 6):
+                flags = (i // nmodes) & 3
+                if kind == 1 and mode in (4, 5, 6):
+                    flags |= 1                          # the corner modes are only called with it available
+            elif kind == 0:
+                sel = (i // nmodes) % 3
+                if sel == 0:
+                    aux = (y - 1) * width + x + 4       # the row above, as the decoder passes it
+                elif sel == 1:
+                    flags = 4
+                else:
+                    aux = int(rng.integers(0, n - 1)) * width + int(rng.integers(0, width - 4))  # anywhere (the top gap rows)
+            if kind >= 4:
+                aux = i * n * n
+            recs.append((x, y, mode, flags, aux))
+            i += 1
+    return np.array(recs[:count] if count else recs, np.int32)
+
+
+def h264_pred_apply(L, pref, kind, pic, recs, coeffs=None):
+    """run the reference or the oracle over the records, in place on pic (and coeffs)"""
+    n, _, name = H264_PRED_KINDS[kind]
+    width = pic.shape[1]
+    fn = getattr(L, "%s_h264_%s" % (pref, name))
+    for x, y, mode, flags, aux in recs.tolist():
+        at = C.cast(pic.ctypes.data + y * width + x, u8p)
+        if kind == 0:
+            tr = np.full(4, pic[y - 1, x + 3], np.uint8) if flags & 4 else pic.reshape(-1)[aux:aux + 4].copy()
+            fn(mode, at, ptr(tr), width)
+        elif kind == 1:
+            fn(mode, at, flags & 1, (flags >> 1) & 1, width)
+        elif kind in (2, 3):
+            fn(mode, at, width)
+        else:
+            blk = C.cast(coeffs.ctypes.data + 2 * aux, i16p)
+            if kind == 6:
+                fn(mode, at, blk, flags & 1, (flags >> 1) & 1, width)
+            else:
+                fn(mode, at, blk, width)
+
+
 def vp9_smc_case(rng):
     """(filter, avg, w, h, mx, my, dx, dy): steps from 16x up-scaling (1) to 2x down-scaling (32) of the reference"""
     w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))

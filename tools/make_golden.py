@@ -358,6 +358,35 @@ def vp9():
     np.savez_compressed(os.path.join(OUT, "vp9.npz"), **d)
 
 
+def h264pred():
+    """H264PredContext: one 136x200 picture; per batch kind a grid of independent blocks (every mode x flag combination), the
+    reference's output blocks and, for the lossless kinds, the coefficients in"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_vs_ref import H264_PRED_KINDS, h264_pred_grid, h264_pred_apply
+    rng = np.random.default_rng(14)
+    pic = rng.integers(0, 256, (136, 200), dtype=np.uint8)
+    pic[:, 100:] = np.clip(np.add.outer(np.arange(136) * 3, np.arange(100) * -2) + 120 + rng.integers(-4, 5, (136, 100)), 0, 255)
+    pic[64:, :60] = rng.choice(np.array([0, 255], np.uint8), (72, 60))
+    d = {"pic": pic}
+    for kind, (n, nmodes, _) in enumerate(H264_PRED_KINDS):
+        recs = h264_pred_grid(rng, kind, 136, 200, count=min(nmodes * 4, 64))
+        coeffs = None
+        if kind >= 4:
+            coeffs = rng.integers(-300, 301, len(recs) * n * n).astype(np.int16)
+            coeffs[:n * n] = rng.choice(np.array([-32768, 32767], np.int16), n * n)
+            d["k%d_coef" % kind] = coeffs.copy()
+        out = pic.copy()
+        h264_pred_apply(R, "ffref", kind, out, recs, coeffs)
+        assert coeffs is None or not coeffs.any()
+        d["k%d_rec" % kind] = recs
+        d["k%d_out" % kind] = np.stack([out[y:y + n, x:x + n] for x, y, *_ in recs.tolist()])
+        mask = np.ones(pic.shape, bool)
+        for x, y, *_ in recs.tolist():
+            mask[y:y + n, x:x + n] = False
+        assert np.array_equal(out[mask], pic[mask])
+    np.savez_compressed(os.path.join(OUT, "h264pred.npz"), **d)
+
+
 def fdsp():
     """AVFloatDSPContext vector ops: len 1024 and 37, operands across magnitudes (bit patterns stored as uint32)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -380,6 +409,6 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); me(); tx(); fft(); hevc(); fdsp(); vp9()
+        sws(); h264(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
