@@ -660,6 +660,172 @@ __global__ __launch_bounds__(1024) void k_rdft(TxDev d, const uint8_t *blob, int
  *      array (the power-of-two kernels' tx_fft_lds, with the union of the arrays' butterfly lists);
  *   4. post-twiddle through the CRT output map, straight to global memory as 8-byte stores.
  */
+/*
+ * k_dct — AV_TX_FLOAT_DCT, power-of-two (ff_tx_dctII / ff_tx_dctIII, libavutil/tx_template.c:1832-2002): N reals <-> N reals
+ * through the N-point RDFT above, i.e. the N/2-point complex FFT in LDS plus two passes.  One wave per transform.
+ *   DCT-II:  fold in[i], in[N-1-i] into the sequence the RDFT takes (straight into the work array), FFT, the r2c pass, then per
+ *            bin k the rotation by exp[] that yields out[2k] and the term t_k; the odd outputs are the reference's running sum
+ *            out[N-1] = Re X[N/2], out[2k-1] = out[2k+1] + t_k, evaluated by one lane in exactly that order (the order of float
+ *            additions is the result); the other waves of the workgroup hide it.  Outputs leave as coalesced float2.
+ *   DCT-III: the bins the reference builds in place (each from in[2k-1], in[2k], in[2k+1]; bin 0 = in[0], Nyquist = 2 in[N-1])
+ *            are formed on the fly inside the c2r pass, FFT, then the unfold out[i], out[N-1-i] from the work array.
+ * d.exp holds fact[8], tcos[N/4], tsin[N/4] (the RDFT's) followed by the DCT's exp[N + N/2].  acc: N/2 + 1 floats per wave
+ * behind the work array (DCT-II only).
+ */
+template <int INV, bool TL>
+__global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch, float *out,
+                                              size_t out_pitch, int nt, int waves_total)
+{
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    if (TL) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(blob);
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds_raw);
+        for (int i = threadIdx.x; i < blob_bytes / 16; i += blockDim.x)
+            l4[i] = s4[i];
+        __syncthreads();
+    }
+    const uint8_t *const tbase = TL ? lds_raw : blob;
+    const int *l_map = reinterpret_cast<const int *>(tbase + (reinterpret_cast<const uint8_t *>(d.map) - blob));
+    const float *fact = reinterpret_cast<const float *>(tbase + (reinterpret_cast<const uint8_t *>(d.exp) - blob));
+    const float *l_cos = reinterpret_cast<const float *>(tbase + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
+    const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
+    const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    const int len2 = d.n, len4 = len2 >> 1, N = 2 * len2;
+    const float *tcos = fact + 8, *tsin = tcos + len4, *dexp = tsin + len4;
+    const float f0 = fact[0], f1 = fact[1], f2 = fact[2], f3 = fact[3], f4 = fact[4], f5 = fact[5], f6 = fact[6], f7 = fact[7];
+    const size_t per_wave = tx_z_bytes(len2) + (INV ? 0 : (((size_t)len2 + 1) * 4 + 15) & ~(size_t)15);
+    uint8_t *area = lds_raw + ((blob_bytes + 15) & ~15) + wave * per_wave;
+    float2 *z = reinterpret_cast<float2 *>(area);
+    float *zf = reinterpret_cast<float *>(area);
+    float *acc = reinterpret_cast<float *>(area + tx_z_bytes(len2));
+    auto pair = [&](int i, float2 a, float2 b, float2 &oa, float2 &ob) { /* the RDFT's loop body, as in k_rdft */
+        const float t0r = f4 * (a.x + b.x), t0i = f5 * (a.y - b.y);
+        const float t1r = f6 * (a.y + b.y), t1i = f7 * (a.x - b.x);
+        const float c = tcos[i], sn = tsin[i];
+        const float t2r = t1r * c - t1i * sn, t2i = t1r * sn + t1i * c;
+        oa = make_float2(t0r + t2r, t2i - t0i);
+        ob = make_float2(t0r - t2r, t2i + t0i);
+    };
+    for (int t = blockIdx.x * (blockDim.x >> 6) + wave; t < nt; t += waves_total) {
+        const float *x = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
+        float *y = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
+        if (!INV) {
+            /* element c = (y[2c], y[2c+1]) and its mirror len2-1-c = (y[N-2-2c], y[N-1-2c]) from two coalesced float2 loads */
+            const float2 *x2 = reinterpret_cast<const float2 *>(x);
+            for (int c = lane; c < len4; c += 64) {
+                const float2 a = x2[c], b = x2[len2 - 1 - c];
+                const float s0 = dexp[N + 2 * c], s1 = dexp[N + 2 * c + 1];
+                const float p1 = (a.x + b.y) * 0.5f, p2 = (a.x - b.y) * s0;
+                const float q1 = (a.y + b.x) * 0.5f, q2 = (a.y - b.x) * s1;
+                z[l_map[c]] = make_float2(p1 + p2, q1 + q2);
+                z[l_map[len2 - 1 - c]] = make_float2(q1 - q2, p1 - p2);
+            }
+        } else {
+            /* bin k of the sequence ff_tx_dctIII hands the c2r transform */
+            auto bin = [&](int k) {
+                const int j = 2 * k;
+                const float v1 = x[j], v2 = x[j - 1] - x[j + 1];
+                const float e1 = dexp[N - j], e2 = dexp[j];
+                return make_float2(e1 * v2 + e2 * v1, e1 * v1 - e2 * v2);
+            };
+            for (int i = lane; i <= len4; i += 64) {
+                if (i == 0) {
+                    const float re = x[0], im = 2 * x[N - 1];
+                    z[l_map[0]] = make_float2(f0 * (re + im), f1 * (re - im));
+                } else if (i == len4) {
+                    const float2 v = bin(len4);
+                    z[l_map[len4]] = make_float2(f2 * v.x, f3 * v.y);
+                } else {
+                    float2 oa, ob;
+                    pair(i, bin(i), bin(len2 - i), oa, ob);
+                    z[l_map[i]] = oa;
+                    z[l_map[len2 - i]] = ob;
+                }
+            }
+        }
+        tx_wave_sync();
+        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
+        if (!INV) {
+            /* X[k] -> out[2k] (parked in the bin's own slot) and t_k (acc[k]); acc[len2] = Re X[N/2] */
+            auto rot = [&](int k, float2 X) {
+                const float e1 = dexp[N - 2 * k], e2 = dexp[2 * k];
+                acc[k] = e1 * X.x - e2 * X.y;
+                z[TX_PAD(k)].x = e1 * X.y + e2 * X.x;
+            };
+            for (int i = lane; i <= len4; i += 64) {
+                if (i == 0) {
+                    const float2 v = z[TX_PAD(0)];
+                    z[TX_PAD(0)].x = dexp[0] * (f0 * (v.x + v.y));
+                    acc[len2] = f1 * (v.x - v.y);
+                } else if (i == len4) {
+                    const float2 v = z[TX_PAD(len4)];
+                    rot(len4, make_float2(f2 * v.x, f3 * v.y));
+                } else {
+                    float2 oa, ob;
+                    pair(i, z[TX_PAD(i)], z[TX_PAD(len2 - i)], oa, ob);
+                    rot(i, oa);
+                    rot(len2 - i, ob);
+                }
+            }
+            tx_wave_sync();
+            if (lane == 0) {
+                /* acc[k] becomes out[2k - 1].  Every instruction of this one-lane section costs the wave a full issue slot, so
+                 * the chain is bound by instructions per term, not by the adds' latency: eight terms per trip through registers
+                 * (paired LDS reads / writes) measured best — 135 M transforms/s at N = 1024, against 111 M/s with the sums
+                 * written to a separate array and 342 M/s for the DCT-III, which has no such chain */
+                float next = acc[len2];
+                int k = len2 - 1;
+                if (k >= 8) {
+                    float cur[8], nxt[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        cur[j] = acc[k - j];
+                    for (; k >= 16; k -= 8) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            nxt[j] = acc[k - 8 - j];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            next += cur[j];
+                            cur[j] = next;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            acc[k - j] = cur[j];
+                            cur[j] = nxt[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        next += cur[j];
+                        acc[k - j] = next;
+                    }
+                    k -= 8;
+                }
+                for (; k > 0; k--) {
+                    next += acc[k];
+                    acc[k] = next;
+                }
+            }
+            tx_wave_sync();
+            float2 *y2 = reinterpret_cast<float2 *>(y);
+            for (int k = lane; k < len2; k += 64)
+                y2[k] = make_float2(z[TX_PAD(k)].x, acc[k + 1]);
+        } else {
+            for (int i = lane; i < len2; i += 64) {
+                const int j = N - 1 - i;
+                const float a = zf[2 * TX_PAD(i >> 1) + (i & 1)], b = zf[2 * TX_PAD(j >> 1) + (j & 1)];
+                const float t1 = a + b, t2 = (a - b) * dexp[N + i];
+                y[i] = t1 + t2;
+                y[j] = t1 - t2;
+            }
+        }
+        tx_wave_sync();
+    }
+}
+
 #define TXBF(x, y, a, b) do { x = (a) - (b); y = (a) + (b); } while (0)
 #define TXCMUL(dre, dim, are, aim, bre, bim) do { (dre) = (are) * (bre) - (aim) * (bim); (dim) = (are) * (bim) + (aim) * (bre); } while (0)
 #define TXSMUL(dre, dim, are, aim, bre, bim) do { (dre) = (are) * (bre) - (aim) * (bim); (dim) = (are) * (bim) - (aim) * (bre); } while (0)
@@ -1003,17 +1169,21 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     if (!scale)
         scale = &one; /* an FFT takes no scale (av_tx_init accepts NULL there) */
     *pctx = nullptr;
-    if (type != FFHIP_TX_FLOAT_MDCT && type != FFHIP_TX_FLOAT_FFT && type != FFHIP_TX_FLOAT_RDFT) {
-        ffhip_set_error("ffhip_tx_init: only AV_TX_FLOAT_MDCT, AV_TX_FLOAT_FFT and AV_TX_FLOAT_RDFT are on the hip path");
+    if (type != FFHIP_TX_FLOAT_MDCT && type != FFHIP_TX_FLOAT_FFT && type != FFHIP_TX_FLOAT_RDFT && type != FFHIP_TX_FLOAT_DCT) {
+        ffhip_set_error("ffhip_tx_init: only AV_TX_FLOAT_MDCT, AV_TX_FLOAT_FFT, AV_TX_FLOAT_RDFT and AV_TX_FLOAT_DCT are on the hip path");
         return FFHIP_ENOSYS;
     }
-    const bool rdft = type == FFHIP_TX_FLOAT_RDFT;
-    if (rdft && (flags & (FFHIP_TX_REAL_TO_REAL | FFHIP_TX_REAL_TO_IMAGINARY))) {
+    const bool dct = type == FFHIP_TX_FLOAT_DCT;
+    const bool rdft = type == FFHIP_TX_FLOAT_RDFT || dct; /* the DCT-II / -III run on the RDFT of the same length */
+    if (dct && inv)
+        len *= 2; /* ff_tx_dct_init (tx_template.c:1844-1848): the inverse is initialised with half its length ... */
+    const float rscale = dct && inv ? *scale * 0.5f : *scale; /* ... and its RDFT with half the scale */
+    if (rdft && !dct && (flags & (FFHIP_TX_REAL_TO_REAL | FFHIP_TX_REAL_TO_IMAGINARY))) {
         ffhip_set_error("ffhip_tx_init: the half-complex RDFT variants (AV_TX_REAL_TO_REAL / _IMAGINARY) are not on the hip path");
         return FFHIP_ENOSYS;
     }
     if (rdft && (len < 8 || len > 4096 || (len & (len - 1)))) {
-        ffhip_set_error("ffhip_tx_init: RDFT len %d not a power of two in 8..4096", len);
+        ffhip_set_error("ffhip_tx_init: %s len %d not a power of two in 8..4096", dct ? "DCT" : "RDFT", len);
         return FFHIP_EINVAL;
     }
     const bool fft = type == FFHIP_TX_FLOAT_FFT || rdft; /* the RDFT runs a len/2-point FFT */
@@ -1057,11 +1227,11 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         map[p] = i;
     }
     /* exp table (ff_tx_mdct_gen_exp) */
-    std::vector<float2> ex(rdft ? 4 + n / 2 : fft ? 2 : n); /* an FFT has no twiddle table of its own: keep its LDS blob small */
+    std::vector<float2> ex(dct ? 4 + n / 2 + 3 * n / 2 : rdft ? 4 + n / 2 : fft ? 2 : n); /* an FFT has no twiddle table of its own: keep its LDS blob small */
     if (rdft) {
         /* ff_tx_rdft_init (tx_template.c:1601-1655): fact[8], tcos[len/4], tsin[len/4], doubles stored as floats */
         const int rl = 2 * n, len4 = rl / 4;
-        const double f = 2 * M_PI / rl, m = c->inv ? 2 * (double)*scale : (double)*scale;
+        const double f = 2 * M_PI / rl, m = c->inv ? 2 * (double)rscale : (double)rscale;
         float *tab = reinterpret_cast<float *>(ex.data());
         tab[0] = (float)((c->inv ? 0.5 : 1.0) * m);
         tab[1] = (float)(c->inv ? 0.5 * m : 1.0 * m);
@@ -1074,6 +1244,15 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         for (int i = 0; i < len4; i++) {
             tab[8 + i] = (float)cos(i * f);
             tab[8 + len4 + i] = (float)(cos(((rl - i * 4) / 4.0) * f) * (c->inv ? 1 : -1));
+        }
+        if (dct) {
+            /* ff_tx_dct_init (tx_template.c:1856-1870): exp[rl] rotations, exp[rl + rl/2] the fold / unfold weights */
+            float *de = tab + 8 + 2 * len4;
+            const double freq = M_PI / (rl * 2);
+            for (int i = 0; i < rl; i++)
+                de[i] = (float)(cos(i * freq) * (!c->inv + 1));
+            for (int i = 0; i < rl / 2; i++)
+                de[rl + i] = c->inv ? (float)(0.5 / sin((2 * i + 1) * freq)) : (float)cos((rl - 2 * i - 1) * freq);
         }
     } else if (!fft) {
         const double sc = *scale;
@@ -1181,7 +1360,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
                          void *stream)
 {
     const int n = c->d.n;
-    if (c->type == FFHIP_TX_FLOAT_FFT || c->type == FFHIP_TX_FLOAT_RDFT) {
+    if (c->type == FFHIP_TX_FLOAT_FFT || c->type == FFHIP_TX_FLOAT_RDFT || c->type == FFHIP_TX_FLOAT_DCT) {
         /* complex in, complex out, contiguous (av_tx's FFT ignores `stride`); 8-byte aligned rows.  RDFT: len reals on one
          * side, len/2 + 1 complex bins on the other */
         if (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7) {
@@ -1194,11 +1373,13 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         const bool tl = etl ? etl[0] == '1' : c->blob_bytes <= 32 * 1024;
         const size_t blob_lds = tl ? (c->blob_bytes + 15) & ~(size_t)15 : 0;
         const int blob_arg = tl ? (int)c->blob_bytes : 0;
+        /* the forward DCT keeps its running-sum terms behind each wave's work array */
+        const size_t zw = tx_z_bytes(n) + (c->type == FFHIP_TX_FLOAT_DCT && !c->inv ? (((size_t)n + 1) * 4 + 15) & ~(size_t)15 : 0);
         int wpb = 16;
-        size_t lds_z = blob_lds + tx_z_bytes(n) * wpb;
+        size_t lds_z = blob_lds + zw * wpb;
         while (wpb > 1 && lds_z > 150 * 1024) {
             wpb >>= 1;
-            lds_z = blob_lds + tx_z_bytes(n) * wpb;
+            lds_z = blob_lds + zw * wpb;
         }
         int cus = 256, dev = 0;
         hipDeviceProp_t prop;
@@ -1218,6 +1399,10 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             (void)hipFuncSetAttribute((const void *)k_rdft<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_rdft<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_rdft<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             fft_attr = true;
         }
         if (c->type == FFHIP_TX_FLOAT_RDFT) {
@@ -1228,6 +1413,15 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
                 if (tl) TX_LAUNCH((k_rdft<1, true>)); else TX_LAUNCH((k_rdft<1, false>));
             } else {
                 if (tl) TX_LAUNCH((k_rdft<0, true>)); else TX_LAUNCH((k_rdft<0, false>));
+            }
+            LAUNCH_CHECK();
+            return 0;
+        }
+        if (c->type == FFHIP_TX_FLOAT_DCT) {
+            if (c->inv) {
+                if (tl) TX_LAUNCH((k_dct<1, true>)); else TX_LAUNCH((k_dct<1, false>));
+            } else {
+                if (tl) TX_LAUNCH((k_dct<0, true>)); else TX_LAUNCH((k_dct<0, false>));
             }
             LAUNCH_CHECK();
             return 0;
@@ -1387,11 +1581,12 @@ static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
 {
     std::lock_guard<std::mutex> lk(s->mu);
     const int len = s->len;
-    const bool rdft = s->type == FFHIP_TX_FLOAT_RDFT;
-    const bool fft = s->type == FFHIP_TX_FLOAT_FFT || rdft;
-    /* RDFT: len reals <-> len/2 + 1 complex bins */
-    const size_t in_elems = rdft ? (size_t)(s->inv ? len + 2 : len) : fft ? (size_t)2 * len : s->inv ? (size_t)len : (size_t)2 * len;
-    const size_t out_elems = rdft ? (size_t)(s->inv ? len : len + 2) : fft || s->full ? (size_t)2 * len : (size_t)len;
+    const bool rdft = s->type == FFHIP_TX_FLOAT_RDFT, dct = s->type == FFHIP_TX_FLOAT_DCT;
+    const bool fft = s->type == FFHIP_TX_FLOAT_FFT || rdft || dct; /* contiguous on both sides */
+    /* RDFT: len reals <-> len/2 + 1 complex bins; DCT: len reals <-> len reals (the reference's scribbles into its input and
+     * behind the forward output, tx.h:100-102, are not reproduced) */
+    const size_t in_elems = dct ? (size_t)len : rdft ? (size_t)(s->inv ? len + 2 : len) : fft ? (size_t)2 * len : s->inv ? (size_t)len : (size_t)2 * len;
+    const size_t out_elems = dct ? (size_t)len : rdft ? (size_t)(s->inv ? len : len + 2) : fft || s->full ? (size_t)2 * len : (size_t)len;
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     /* the strided side is packed on the host so that the device sees contiguous data */
     std::vector<float> hin(in_elems), hout(out_elems);

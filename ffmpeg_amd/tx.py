@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 
-FLOAT_FFT, FLOAT_MDCT, FLOAT_RDFT = 0, 1, 6
+FLOAT_FFT, FLOAT_MDCT, FLOAT_RDFT, FLOAT_DCT = 0, 1, 6, 9
 _TXFN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t)
 
 

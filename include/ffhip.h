@@ -789,6 +789,8 @@ typedef struct FFHipTXContext FFHipTXContext;
 #define FFHIP_TX_FLOAT_FFT  0   /* == AV_TX_FLOAT_FFT  (libavutil/tx.h:47-132) */
 #define FFHIP_TX_FLOAT_MDCT 1   /* == AV_TX_FLOAT_MDCT                          */
 #define FFHIP_TX_FLOAT_RDFT 6   /* == AV_TX_FLOAT_RDFT (r2c forward, c2r inverse; libavutil/tx.h:70-90) */
+#define FFHIP_TX_FLOAT_DCT  9   /* == AV_TX_FLOAT_DCT: DCT-II forward, DCT-III inverse (libavutil/tx.h:95-104), power of two 8..4096; as with av_tx_init the
+                                   inverse is initialised with half the number of samples it transforms */
 #define FFHIP_TX_FULL_IMDCT        (1ULL << 2)   /* == AV_TX_FULL_IMDCT: an inverse MDCT writes 2 * len outputs (ff_tx_mdct_inv_full,
                                                   * libavutil/tx_template.c:1391-1408); batches: 8-byte aligned rows of 2 * len floats */
 #define FFHIP_TX_REAL_TO_REAL      (1ULL << 3)   /* == AV_TX_REAL_TO_REAL: not on the hip path (ENOSYS)      */

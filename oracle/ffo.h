@@ -146,6 +146,8 @@ void   ffo_imdct_full_run(const FfoTx *s, float *out, const float *in); /* AV_TX
 void   ffo_fft_run(int inv, int len, float *out, const float *in);
 /* AV_TX_FLOAT_RDFT, power-of-two: inv == 0: in = len reals, out = len/2 + 1 complex; inv == 1: the other way round */
 void   ffo_rdft_run(int inv, int len, float scale, float *out, const float *in);
+/* AV_TX_FLOAT_DCT: DCT-II (inv 0) / DCT-III (inv 1) of n real samples, n a power of two (tx_template.c:1832-2002) */
+void   ffo_dct_run(int inv, int n, float scale, float *out, const float *in);
 /* double-precision cosine-sum definition (ff_tx_mdct_naive_fwd/_inv, tx_template.c:1144-1193) */
 void   ffo_mdct_naive_fwd(int len, double scale, double *out, const float *in);
 void   ffo_mdct_naive_inv(int len, double scale, double *out, const float *in);

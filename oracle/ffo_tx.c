@@ -537,6 +537,64 @@ void ffo_rdft_run(int inv, int len, float scale, float *out, const float *in)
     free(tcos);
 }
 
+/*
+ * AV_TX_FLOAT_DCT, power-of-two: ff_tx_dctII (forward) / ff_tx_dctIII (inverse) on top of the RDFT
+ * (libavutil/tx_template.c:1832-2002).  n is the number of real samples (av_tx_init is handed n for the forward and n / 2 for
+ * the inverse transform, ff_tx_dct_init doubles it); the RDFT runs with scale resp. scale / 2.  Tables in double, stored as
+ * float.  The forward transform's odd outputs are a running sum from the Nyquist bin down: the order of those additions is part
+ * of the result.  Out of place here; the reference also clobbers its input, which no caller can rely on.
+ */
+void ffo_dct_run(int inv, int n, float scale, float *out, const float *in)
+{
+    const int h = n / 2;
+    const double freq = M_PI / (n * 2);
+    float *ex = malloc(sizeof(float) * (n + h)), *buf = calloc(n + 2, sizeof(float));
+    for (int i = 0; i < n; i++)
+        ex[i] = (float)(cos(i * freq) * (!inv + 1));
+    for (int i = 0; i < h; i++)
+        ex[n + i] = inv ? (float)(0.5 / sin((2 * i + 1) * freq)) : (float)cos((n - 2 * i - 1) * freq);
+    if (!inv) {
+        float *bins = malloc(sizeof(float) * (n + 2));
+        for (int i = 0; i < h; i++) {
+            const float a = in[i], b = in[n - 1 - i];
+            const float t1 = (a + b) * 0.5f, t2 = (a - b) * ex[n + i];
+            buf[i] = t1 + t2;
+            buf[n - 1 - i] = t1 - t2;
+        }
+        ffo_rdft_run(0, n, scale, bins, buf);
+        float next = bins[n];
+        for (int i = n - 2; i > 0; i -= 2) {
+            const float re = bins[i], im = bins[i + 1];
+            const float t = ex[n - i] * re - ex[i] * im;
+            out[i] = ex[n - i] * im + ex[i] * re;
+            out[i + 1] = next;
+            next += t;
+        }
+        out[0] = ex[0] * bins[0];
+        out[1] = next;
+        free(bins);
+    } else {
+        buf[0] = in[0];
+        buf[1] = in[1];
+        buf[n] = 2 * in[n - 1];
+        buf[n + 1] = 0;
+        for (int i = 2; i < n; i += 2) {
+            const float v1 = in[i], v2 = in[i - 1] - in[i + 1];
+            buf[i + 1] = ex[n - i] * v1 - ex[i] * v2;
+            buf[i] = ex[n - i] * v2 + ex[i] * v1;
+        }
+        ffo_rdft_run(1, n, scale * 0.5f, out, buf);
+        for (int i = 0; i < h; i++) {
+            const float a = out[i], b = out[n - 1 - i];
+            const float t1 = a + b, t2 = (a - b) * ex[n + i];
+            out[i] = t1 + t2;
+            out[n - 1 - i] = t1 - t2;
+        }
+    }
+    free(buf);
+    free(ex);
+}
+
 /* ff_tx_mdct_naive_fwd: tx_template.c:1144-1163 — in 2*len, out len (double results) */
 void ffo_mdct_naive_fwd(int len, double scale, double *out, const float *in)
 {

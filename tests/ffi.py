@@ -94,6 +94,8 @@ def oracle():
         L.ffo_fft_run.restype = None
         L.ffo_rdft_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
         L.ffo_rdft_run.restype = None
+        L.ffo_dct_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
+        L.ffo_dct_run.restype = None
         L.ffo_fdsp.argtypes = [C.c_int, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
         L.ffo_fdsp.restype = None
         L.ffo_hevc_coef.argtypes = [C.c_int, C.c_int]

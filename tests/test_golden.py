@@ -273,3 +273,10 @@ def test_fft_golden():
                 out = np.zeros(want.shape[1], np.float32)
                 O.ffo_rdft_run(inv, len_, 1.0, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p))
                 assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), ("rdft", len_, inv)
+    for n in (16, 1024):
+        for inv in (0, 1):
+            x, want = d["dct%d_%d_in" % (n, inv)], d["dct%d_%d_out" % (n, inv)]
+            for t in range(x.shape[0]):
+                out = np.zeros(n, np.float32)
+                O.ffo_dct_run(inv, n, 1.0, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p))
+                assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), ("dct", n, inv)

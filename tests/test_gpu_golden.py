@@ -303,6 +303,20 @@ def test_rdft_golden_gpu():
             ctx.close()
 
 
+def test_dct_golden_gpu():
+    from ffmpeg_amd import tx
+    torch = _torch()
+    d = G.load("fft")
+    for n in (16, 1024):
+        for inv in (0, 1):
+            x, want = d["dct%d_%d_in" % (n, inv)], d["dct%d_%d_out" % (n, inv)]
+            ctx = tx.TxContext(tx.FLOAT_DCT, inv, n >> inv, 1.0)
+            out = torch.zeros(want.shape, dtype=torch.float32, device="cuda:0")
+            ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (n, inv)
+            ctx.close()
+
+
 def test_h264_pred_golden_gpu():
     """H264PredContext batch kinds against the reference's stored outputs (tests/golden/h264pred.npz)"""
     from test_gpu_h264_pred import hip_pred_apply

@@ -248,6 +248,36 @@ def test_rdft_batch(len_, inv, scale):
     ctx.close()
 
 
+@pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("n,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
+def test_dct_batch(n, inv, scale):
+    """AV_TX_FLOAT_DCT, power-of-two: DCT-II forward / DCT-III inverse of n reals (the inverse initialised with n / 2, as av_tx_init
+    is); bit-identical - the forward transform's odd outputs are a running sum whose order the kernel keeps - host face too"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    rng = np.random.default_rng(n * 2 + inv + 7)
+    nt = 3000 if n == 1024 else 41
+    x = (rng.standard_normal((nt, n)) * 10.0 ** rng.integers(-3, 4, (nt, 1))).astype(np.float32)
+    x[1] = 0
+    want = np.zeros((nt, n), np.float32)
+    O = ffi.oracle()
+    for t in range(nt):
+        O.ffo_dct_run(inv, n, scale, ptr(want[t], f32p), ptr(x[t], f32p))
+    ctx = tx.TxContext(tx.FLOAT_DCT, inv, n >> inv, scale)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((nt, n + 2), dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out[:, :n], d_in)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(np.ascontiguousarray(got[:, :n]).view(np.uint32), want.view(np.uint32)), "max |diff| %g" % np.abs(got[:, :n] - want).max()
+    assert not got[:, n:].any()
+    assert np.array_equal(d_in.cpu().numpy(), x)          # the batch face leaves its input alone
+    one = np.zeros(n, np.float32)
+    ctx.fn(one, x[3].copy(), 4)
+    assert np.array_equal(one.view(np.uint32), want[3].view(np.uint32))
+    ctx.close()
+
+
 @pytest.mark.parametrize("len_,nt", [(16, 9), (256, 70000), (1024, 3000), (120, 200), (960, 1001)])
 def test_imdct_full_batch(len_, nt):
     """AV_TX_FULL_IMDCT: 2 * len outputs per inverse transform (ff_tx_mdct_inv_full), power-of-two and 15xM lengths; more rows than
@@ -281,7 +311,7 @@ def test_imdct_full_batch(len_, nt):
 
 @pytest.mark.parametrize("tabs", ["0", "1"])
 @pytest.mark.parametrize("typ,len_,inv", [("mdct", 1024, 0), ("mdct", 4096, 1), ("mdct", 256, 1), ("fft", 256, 0), ("fft", 2048, 1),
-                                          ("rdft", 512, 1), ("rdft", 4096, 0)])
+                                          ("rdft", 512, 1), ("rdft", 4096, 0), ("dct", 1024, 0), ("dct", 4096, 1), ("dct", 4096, 0)])
 def test_table_placement(typ, len_, inv, tabs, monkeypatch):
     """the context's tables in LDS (one copy per workgroup) or left in L2 (FFHIP_TX_TABLDS): same bits either way; the default
     switches at 32 KB of tables (profiles/r01_sweep_tabs.txt)"""
@@ -301,6 +331,12 @@ def test_table_placement(typ, len_, inv, tabs, monkeypatch):
         for t in range(nt):
             O.ffo_fft_run(inv, len_, ptr(want[t], f32p), ptr(x[t], f32p))
         ctx = tx.TxContext(tx.FLOAT_FFT, inv, len_, 1.0)
+    elif typ == "dct":
+        x = rng.standard_normal((nt, len_)).astype(np.float32)
+        want = np.zeros_like(x)
+        for t in range(nt):
+            O.ffo_dct_run(inv, len_, 1.0, ptr(want[t], f32p), ptr(x[t], f32p))
+        ctx = tx.TxContext(tx.FLOAT_DCT, inv, len_ >> inv, 1.0)
     else:
         x = rng.standard_normal((nt, len_ + 2 if inv else len_)).astype(np.float32)
         if inv:

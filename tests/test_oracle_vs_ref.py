@@ -905,6 +905,46 @@ def test_rdft_float(len_, inv):
         R.ffref_tx_free(rc)
 
 
+@pytest.mark.parametrize("n", [8, 16, 64, 256, 1024, 4096])
+@pytest.mark.parametrize("inv", [0, 1])
+def test_dct_float(n, inv):
+    """AV_TX_FLOAT_DCT (DCT-II forward / DCT-III inverse) of n real samples, power-of-two: bit-identical, including the forward
+    transform's running sum.  av_tx_init is handed n resp. n / 2 (ff_tx_dct_init doubles the inverse's length); the DCT-III reads
+    two samples of padding behind its input and both clobber it (libavutil/tx.h:95-103)"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(5 * n + inv)
+    for scale in (1.0, 1.0 / n, -0.37):
+        rc = R.ffref_tx_create(9, inv, n >> inv, scale, 0)      # AV_TX_FLOAT_DCT = 9 (libavutil/tx.h:104)
+        assert rc
+        for rep in range(3):
+            x = np.zeros(n + 2, np.float32)
+            x[:n] = (rng.standard_normal(n) * 10.0 ** float(rng.integers(-3, 4))).astype(np.float32)
+            a, b = np.zeros(n + 2, np.float32), np.zeros(n + 2, np.float32)
+            R.ffref_tx_run(rc, ptr(a, f32p), ptr(x.copy(), f32p), 4)
+            O.ffo_dct_run(inv, n, scale, ptr(b, f32p), ptr(x, f32p))
+            assert np.array_equal(a[:n].view(np.uint32), b[:n].view(np.uint32)), (scale, rep)
+        R.ffref_tx_free(rc)
+
+
+def test_dct_vs_definition():
+    """the float DCT-II against the double-precision cosine sum it implements (av_tx's scaling: X[k] = 2 sum x[j] cos(pi (2j + 1)
+    k / 2n)), and the DCT-III as its inverse up to a constant factor"""
+    O = ffi.oracle()
+    n = 256
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    j = np.arange(n)
+    want = 2 * np.array([(x.astype(np.float64) * np.cos(np.pi * (2 * j + 1) * k / (2 * n))).sum() for k in range(n)])
+    out = np.zeros(n + 2, np.float32)
+    O.ffo_dct_run(0, n, 1.0, ptr(out, f32p), ptr(x, f32p))
+    assert np.abs(out[:n] - want).max() <= 2.0 ** -18 * np.abs(want).max() * 8
+    back = np.zeros(n + 2, np.float32)
+    src = np.zeros(n + 2, np.float32); src[:n] = out[:n]
+    O.ffo_dct_run(1, n, 1.0, ptr(back, f32p), ptr(src, f32p))
+    ratio = back[:n] / x
+    assert np.allclose(ratio, ratio[0], rtol=1e-3), ratio[:4]
+
+
 @pytest.mark.parametrize("inv", [0, 1])
 def test_mdct_vs_naive(inv):
     """the float transform stays within 2^-18 * max|ref| of the double-precision cosine sum"""

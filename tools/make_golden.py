@@ -200,6 +200,18 @@ def fft():
                 R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 4)
             R.ffref_tx_free(rc)
             d["rdft%d_%d_in" % (len_, inv)], d["rdft%d_%d_out" % (len_, inv)] = x, out
+    # AV_TX_FLOAT_DCT (type 9): DCT-II of n reals; DCT-III initialised with n / 2 (ff_tx_dct_init doubles it), input padded by 2
+    rng = np.random.default_rng(1009)
+    for n in (16, 1024):
+        for inv in (0, 1):
+            x = np.zeros((3, n + 2), np.float32)
+            x[:, :n] = rng.uniform(-1, 1, (3, n)).astype(np.float32)
+            rc = R.ffref_tx_create(9, inv, n >> inv, 1.0, 0)
+            out = np.zeros((3, n + 2), np.float32)
+            for t in range(3):
+                R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 4)
+            R.ffref_tx_free(rc)
+            d["dct%d_%d_in" % (n, inv)], d["dct%d_%d_out" % (n, inv)] = x[:, :n].copy(), out[:, :n].copy()
     np.savez_compressed(os.path.join(OUT, "fft.npz"), **d)
 
 
