@@ -1,0 +1,257 @@
+/*
+ * aac_api.hip — AACDecDSP.imdct_and_windowing of the float AAC decoder, 1024-sample frames, batched and HBM-resident
+ * (libavcodec/aac/aacdec_dsp_template.c:325-387): inverse MDCT(s) -> window -> overlap-add without the
+ * frame leaving the device.
+ *
+ * The reference keeps a per-channel overlap state `saved` and so looks sequential in time.  It is not: the new `saved` is a
+ * function of the current frame's MDCT output buf[] alone, and out[] needs the previous frame's `saved` only.  So a run of frames
+ * is three data-parallel steps —
+ *   1. buf[f]   = one 1024-point or eight 128-point inverse MDCTs (ffhip_tx_batch_dev, one launch per run of equal kind);
+ *   2. tail[f]  = the overlap state frame f leaves behind (k_aac_tail: windowed short-block overlaps or a copy);
+ *   3. out[f]   = overlap of tail[f - 1] (the caller's `saved` for the first frame) with buf[f]'s head under the previous frame's
+ *                 window shape (k_aac_out);
+ * then the last frame's tail is the caller's new `saved`.  Each output sample is one element of an AVFloatDSPContext
+ * .vector_fmul_window call (libavutil/float_dsp.c:79-97) or a copy, evaluated with the same two products and one sum:
+ * bit-identical.  HBM traffic per frame: coeffs 4 KB in, buf 4 KB out + in twice, tail 2 KB out + in, out 4 KB: 24 KB (+8 KB when
+ * a batch with many transient frames is first sorted by transform kind).
+ */
+#include <string.h>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "kernels/common.h"
+
+enum { AAC_ONLY_LONG, AAC_LONG_START, AAC_EIGHT_SHORT, AAC_LONG_STOP }; /* enum WindowSequence, libavcodec/aac.h:63-68 */
+
+struct FFHipAacImdct {
+    FFHipTXContext *tx1024 = nullptr, *tx128 = nullptr;
+    float *win = nullptr;       /* [4][1024]: sine_1024, sine_128, kbd_long_1024, kbd_short_128 */
+    uint8_t *work = nullptr;    /* buf [n][1024] f32, tail [n][512] f32, sorted coeffs [n][1024] f32, pos [n] i32, info [n] u8 */
+    size_t work_frames = 0;
+    std::mutex mu;
+};
+
+/* element e of vector_fmul_window(dst, src0, src1, win, len) */
+__device__ __forceinline__ float aac_wov(const float *src0, const float *src1, const float *win, int len, int e)
+{
+    const bool lo = e < len;
+    const int t = lo ? e : 2 * len - 1 - e;
+    const float a = src0[t], b = src1[len - 1 - t], wi = win[t], wj = win[2 * len - 1 - t];
+    return lo ? a * wj - b * wi : a * wi + b * wj;
+}
+
+/* info byte: sequence | kb << 2 | previous sequence << 3 | previous kb << 5 */
+/* pos: where frame f's buf[] lives when the frames were sorted by transform kind (nullptr: at f) */
+__global__ __launch_bounds__(256) void k_aac_tail(const float *buf, const int *pos, const uint8_t *info, const float *win, float *tail)
+{
+    const int f = blockIdx.x;
+    const float *b = buf + (size_t)(pos ? pos[f] : f) * 1024;
+    const int in = info[f], seq = in & 3;
+    const float *swindow = win + ((in >> 2) & 1 ? 3 : 1) * 1024;
+    for (int s = threadIdx.x; s < 512; s += 256) {
+        float v;
+        if (seq != AAC_EIGHT_SHORT || s >= 448) {
+            v = b[512 + s]; /* LONG_START's two copies (448 + 64 samples) are this one range as well */
+        } else if (s < 64) {
+            v = aac_wov(b + 448, b + 512, swindow, 64, 64 + s);
+        } else {
+            const int q = (s - 64) >> 7, e = (s - 64) & 127;
+            v = aac_wov(b + (4 + q) * 128 + 64, b + (5 + q) * 128, swindow, 64, e);
+        }
+        tail[(size_t)f * 512 + s] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_aac_out(const float *buf, const int *pos, const uint8_t *info, const float *win, const float *tail,
+                                                 const float *saved, int nch, float *out)
+{
+    const int f = blockIdx.x;
+    const float *b = buf + (size_t)(pos ? pos[f] : f) * 1024;
+    const float *sv = f < nch ? saved + (size_t)f * 512 : tail + (size_t)(f - nch) * 512;
+    const int in = info[f], seq = in & 3, pseq = (in >> 3) & 3, pkb = (in >> 5) & 1;
+    const float *swindow = win + ((in >> 2) & 1 ? 3 : 1) * 1024, *lwindow_prev = win + (pkb ? 2 : 0) * 1024, *swindow_prev = win + (pkb ? 3 : 1) * 1024;
+    const bool long_long = (pseq == AAC_ONLY_LONG || pseq == AAC_LONG_STOP) && (seq == AAC_ONLY_LONG || seq == AAC_LONG_START);
+    for (int o = threadIdx.x; o < 1024; o += 256) {
+        float v;
+        if (long_long) {
+            v = aac_wov(sv, b, lwindow_prev, 512, o);
+        } else if (o < 448) {
+            v = sv[o];
+        } else if (o < 576) {
+            v = aac_wov(sv + 448, b, swindow_prev, 64, o - 448);
+        } else if (seq != AAC_EIGHT_SHORT) {
+            v = b[o - 512];
+        } else if (o < 960) {
+            const int q = (o - 576) >> 7;
+            v = aac_wov(b + q * 128 + 64, b + (q + 1) * 128, swindow, 64, (o - 576) & 127);
+        } else {
+            v = aac_wov(b + 448, b + 512, swindow, 64, o - 960);
+        }
+        out[(size_t)f * 1024 + o] = v;
+    }
+}
+
+/* sorted[pos[f]] = coeffs[f]: 16 bytes per thread */
+__global__ __launch_bounds__(256) void k_aac_gather(const float4 *coeffs, const int *pos, float4 *sorted)
+{
+    const int f = blockIdx.x;
+    sorted[(size_t)pos[f] * 256 + threadIdx.x] = coeffs[(size_t)f * 256 + threadIdx.x];
+}
+
+extern "C" void ffhip_aac_imdct_free(FFHipAacImdct **pc)
+{
+    if (!pc || !*pc)
+        return;
+    FFHipAacImdct *c = *pc;
+    ffhip_tx_uninit(&c->tx1024);
+    ffhip_tx_uninit(&c->tx128);
+    if (c->win) (void)hipFree(c->win);
+    if (c->work) (void)hipFree(c->work);
+    delete c;
+    *pc = nullptr;
+}
+
+extern "C" int ffhip_aac_imdct_create(FFHipAacImdct **pc, const float *sine_1024, const float *sine_128, const float *kbd_long_1024,
+                                      const float *kbd_short_128, float scale_1024, float scale_128)
+{
+    if (!pc || !sine_1024 || !sine_128 || !kbd_long_1024 || !kbd_short_128)
+        return FFHIP_EINVAL;
+    *pc = nullptr;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    FFHipAacImdct *c = new (std::nothrow) FFHipAacImdct();
+    if (!c)
+        return FFHIP_ENOMEM;
+    int r = ffhip_tx_init(&c->tx1024, nullptr, FFHIP_TX_FLOAT_MDCT, 1, 1024, &scale_1024, 0);
+    if (r >= 0)
+        r = ffhip_tx_init(&c->tx128, nullptr, FFHIP_TX_FLOAT_MDCT, 1, 128, &scale_128, 0);
+    std::vector<float> w(4 * 1024, 0.0f);
+    memcpy(&w[0], sine_1024, 1024 * sizeof(float));
+    memcpy(&w[1024], sine_128, 128 * sizeof(float));
+    memcpy(&w[2048], kbd_long_1024, 1024 * sizeof(float));
+    memcpy(&w[3072], kbd_short_128, 128 * sizeof(float));
+    if (r >= 0 && (hipMalloc(&c->win, w.size() * sizeof(float)) != hipSuccess ||
+                   hipMemcpy(c->win, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)) {
+        ffhip_set_error("ffhip_aac_imdct_create: window upload failed");
+        r = FFHIP_ENOMEM;
+    }
+    if (r < 0) {
+        ffhip_aac_imdct_free(&c);
+        return r;
+    }
+    *pc = c;
+    return 0;
+}
+
+extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const float *coeffs, float *out, float *saved,
+                                                       const uint8_t *window_sequence, const uint8_t *use_kb_window,
+                                                       const uint8_t *prev_sequence, const uint8_t *prev_kb_window, int nch, int nframes,
+                                                       void *stream)
+{
+    if (!c || !coeffs || !out || !saved || !window_sequence || !use_kb_window || !prev_sequence || !prev_kb_window || nch <= 0 || nframes < 0)
+        return FFHIP_EINVAL;
+    const size_t n = (size_t)nch * nframes;
+    if (!n)
+        return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<uint8_t> info(n);
+    for (size_t i = 0; i < n; i++) {
+        const int ps = i < (size_t)nch ? prev_sequence[i] : window_sequence[i - nch], pk = i < (size_t)nch ? prev_kb_window[i] : use_kb_window[i - nch];
+        if (window_sequence[i] > 3 || ps > 3) {
+            ffhip_set_error("ffhip_aac_imdct_and_windowing: window sequence %d outside 0..3", window_sequence[i] > 3 ? window_sequence[i] : ps);
+            return FFHIP_EINVAL;
+        }
+        info[i] = (uint8_t)(window_sequence[i] | (use_kb_window[i] ? 4 : 0) | ps << 3 | (pk ? 32 : 0));
+    }
+    /* frames of one kind in memory order form runs, one transform launch each; a batch with many transients (runs) is instead
+     * sorted by kind through one gather pass (+8 KB of traffic per frame) and transformed in two launches */
+    size_t runs = 1, nlong = 0;
+    for (size_t i = 0; i < n; i++) {
+        nlong += window_sequence[i] != AAC_EIGHT_SHORT;
+        runs += i && (window_sequence[i] == AAC_EIGHT_SHORT) != (window_sequence[i - 1] == AAC_EIGHT_SHORT);
+    }
+    const bool sort = runs > 8;
+    const size_t per = 1024 * 4 + 512 * 4 + 1024 * 4 + 4 + 1; /* buf, tail, sorted coefficients, pos, info */
+    if (n > c->work_frames) {
+        if (c->work) {
+            (void)hipStreamSynchronize(st); /* a previous call on this stream may still read the old block */
+            (void)hipFree(c->work);
+        }
+        c->work = nullptr;
+        c->work_frames = 0;
+        if (hipMalloc(&c->work, n * per + 64) != hipSuccess) {
+            ffhip_set_error("ffhip_aac_imdct_and_windowing: %zu bytes of work space not available", n * per);
+            return FFHIP_ENOMEM;
+        }
+        c->work_frames = n;
+    }
+    float *buf = (float *)c->work, *tail = buf + c->work_frames * 1024, *sorted = tail + c->work_frames * 512;
+    int *dpos = (int *)(sorted + c->work_frames * 1024);
+    uint8_t *dinfo = (uint8_t *)(dpos + c->work_frames);
+    /* (pageable sources: the copies have been staged by the time the calls return, the vectors may go) */
+    if (hipMemcpyAsync(dinfo, info.data(), n, hipMemcpyHostToDevice, st) != hipSuccess)
+        return FFHIP_EINVAL;
+    if (sort) {
+        std::vector<int> pos(n);
+        size_t il = 0, is = nlong;
+        for (size_t i = 0; i < n; i++)
+            pos[i] = (int)(window_sequence[i] != AAC_EIGHT_SHORT ? il++ : is++);
+        if (hipMemcpyAsync(dpos, pos.data(), n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+            return FFHIP_EINVAL;
+        if (((uintptr_t)coeffs & 15)) {
+            ffhip_set_error("ffhip_aac_imdct_and_windowing: coeffs must be 16-byte aligned");
+            return FFHIP_EINVAL;
+        }
+        hipLaunchKernelGGL(k_aac_gather, dim3((unsigned)n), dim3(256), 0, st, (const float4 *)coeffs, dpos, (float4 *)sorted);
+        int r = nlong ? ffhip_tx_batch_dev(c->tx1024, buf, 4096, sorted, 4096, sizeof(float), (int)nlong, stream) : 0;
+        if (r >= 0 && n > nlong)
+            r = ffhip_tx_batch_dev(c->tx128, buf + nlong * 1024, 512, sorted + nlong * 1024, 512, sizeof(float), (int)(n - nlong) * 8, stream);
+        if (r < 0)
+            return r;
+    } else {
+        dpos = nullptr;
+        for (size_t i = 0; i < n;) {
+            const bool is_short = window_sequence[i] == AAC_EIGHT_SHORT;
+            size_t j = i + 1;
+            while (j < n && (window_sequence[j] == AAC_EIGHT_SHORT) == is_short)
+                j++;
+            const int r = is_short ? ffhip_tx_batch_dev(c->tx128, buf + i * 1024, 512, coeffs + i * 1024, 512, sizeof(float), (int)(j - i) * 8, stream)
+                                   : ffhip_tx_batch_dev(c->tx1024, buf + i * 1024, 4096, coeffs + i * 1024, 4096, sizeof(float), (int)(j - i), stream);
+            if (r < 0)
+                return r;
+            i = j;
+        }
+    }
+    hipLaunchKernelGGL(k_aac_tail, dim3((unsigned)n), dim3(256), 0, st, buf, dpos, dinfo, c->win, tail);
+    hipLaunchKernelGGL(k_aac_out, dim3((unsigned)n), dim3(256), 0, st, buf, dpos, dinfo, c->win, tail, saved, nch, out);
+    LAUNCH_CHECK();
+    if (hipMemcpyAsync(saved, tail + (n - nch) * 512, (size_t)nch * 512 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return FFHIP_EINVAL;
+    return 0;
+}
+
+/* One channel, one frame, host pointers: what a libavcodec/hip/aacdec_init.c wrapper of the reference member calls with
+ * sce->coeffs, ics->window_sequence / use_kb_window, sce->saved, sce->output. */
+extern "C" int ffhip_aac_imdct_and_windowing(FFHipAacImdct *c, const float *coeffs, const int window_sequence[2], const int use_kb_window[2],
+                                             float *saved, float *out)
+{
+    if (!c || !coeffs || !window_sequence || !use_kb_window || !saved || !out)
+        return FFHIP_EINVAL;
+    void *scratch;
+    if (ffhip_scratch_reserve((1024 + 1024 + 512) * sizeof(float), &scratch) < 0)
+        return FFHIP_ENOMEM;
+    float *dco = (float *)scratch, *dout = dco + 1024, *dsv = dout + 1024;
+    if (hipMemcpy(dco, coeffs, 1024 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dsv, saved, 512 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return FFHIP_EINVAL;
+    const uint8_t seq = (uint8_t)window_sequence[0], kb = (uint8_t)use_kb_window[0], pseq = (uint8_t)window_sequence[1], pkb = (uint8_t)use_kb_window[1];
+    const int r = ffhip_aac_imdct_and_windowing_batch_dev(c, dco, dout, dsv, &seq, &kb, &pseq, &pkb, 1, 1, nullptr);
+    if (r < 0)
+        return r;
+    if (hipStreamSynchronize(nullptr) != hipSuccess || hipMemcpy(out, dout, 1024 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(saved, dsv, 512 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        return FFHIP_EINVAL;
+    return 0;
+}

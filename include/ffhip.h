@@ -380,6 +380,31 @@ int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const 
                               void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* libavcodec: AACDecDSP.imdct_and_windowing — float decoder, 1024-sample frames */
+/* ------------------------------------------------------------------------------------------ */
+/** AACDecDSP.imdct_and_windowing (libavcodec/aac/aacdec.h:488, body libavcodec/aac/aacdec_dsp_template.c:325-387): the inverse
+ *  MDCT(s) of a channel's frame, the window and the overlap-add with the previous frame's tail.  The context owns the two inverse
+ *  MDCTs (created with the scales ff_aac_decode_init() gives them, aacdec.c:1267-1285) and a device copy of the four window tables
+ *  the decoder already holds (ff_sine_1024 / ff_sine_128, libavcodec/sinewin.h; ff_aac_kbd_long_1024 / ff_aac_kbd_short_128,
+ *  libavcodec/aactab.h) — handed over by the caller, so that the tables in use are the decoder's own bit for bit. */
+typedef struct FFHipAacImdct FFHipAacImdct;
+int  ffhip_aac_imdct_create(FFHipAacImdct **c, const float *sine_1024, const float *sine_128, const float *kbd_long_1024,
+                            const float *kbd_short_128, float scale_1024, float scale_128);
+void ffhip_aac_imdct_free(FFHipAacImdct **c);
+/** One channel, one frame, host pointers: the member's effect on sce->coeffs / ics.window_sequence[2] / ics.use_kb_window[2]
+ *  ([0] this frame, [1] the previous one) / sce->saved (512 floats in and out) / sce->output (1024 floats). */
+int  ffhip_aac_imdct_and_windowing(FFHipAacImdct *c, const float *coeffs, const int window_sequence[2], const int use_kb_window[2],
+                                   float *saved, float *out);
+/** nframes consecutive frames of nch channels, device pointers, frame-major: coeffs / out [nframes][nch][1024], saved [nch][512]
+ *  in and out.  window_sequence / use_kb_window [nframes][nch] and the state before the first frame, prev_* [nch], are HOST arrays
+ *  (the decoder parses them; enum WindowSequence values, libavcodec/aac.h:63-68).  All frames are processed in parallel: the
+ *  overlap state a frame leaves behind depends on that frame alone.  Asynchronous on `stream`; the host arrays may be released on
+ *  return.  Not reentrant per context. */
+int  ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const float *coeffs, float *out, float *saved,
+                                             const uint8_t *window_sequence, const uint8_t *use_kb_window, const uint8_t *prev_sequence,
+                                             const uint8_t *prev_kb_window, int nch, int nframes, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* libavcodec: H264PredContext — H.264 codec, 8 bits, chroma_format_idc <= 1 */
 /* ------------------------------------------------------------------------------------------ */
 /** H264PredContext (libavcodec/h264pred.h:92-116), the members ff_h264_pred_init() fills for AV_CODEC_ID_H264

@@ -163,4 +163,11 @@ void ffo_h264_pred8x8l_filter_add(int mode, uint8_t *pix, int16_t *block, int ha
 void ffo_h264_pred8x8_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
 void ffo_h264_pred16x16_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
 
+/* ---- ffo_aac.c: AACDecDSP.imdct_and_windowing, float, 1024-sample frames (libavcodec/aac/aacdec_dsp_template.c:325-387) ---- */
+void ffo_aac_sine_window(float *w, int n);
+void ffo_aac_kbd_window(float *w, float alpha, int n);
+/* windows[]: sine_1024, sine_128, kbd_long_1024, kbd_short_128; seq / kb = { this frame, previous frame }; saved[512] in / out */
+void ffo_aac_imdct_and_windowing(const FfoTx *mdct1024, const FfoTx *mdct128, const float *const windows[4], const float *coeffs,
+                                 const int seq[2], const int kb[2], float *saved, float *out);
+
 #endif

@@ -1,0 +1,100 @@
+/*
+ * ffo_aac.c — CPU restatement of AACDecDSP.imdct_and_windowing, float AAC-LC / 1024-sample frames
+ * (libavcodec/aac/aacdec_dsp_template.c:325-387) and of the window tables it reads (libavcodec/sinewin_tablegen.h:57-64,
+ * libavcodec/kbdwin.c:29-56).  TEST INFRASTRUCTURE ONLY: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg are the
+ * only callers.  Pinned bit-exact to the reference's own member built in place (tests/test_oracle_vs_ref.py::test_aac_*); the
+ * Kaiser-Bessel table is pinned to <= 1 ulp only (the reference evaluates I0 with its own rational approximation,
+ * libavutil/mathematics.c av_bessel_i0, this file with the power series), so parity tests take the tables as inputs from
+ * tests/golden/aac.npz — as the hip path takes them from its caller.
+ *
+ * Restated as what it computes rather than as the call sequence: the frame's 1024 "time" samples buf[] (one long or eight short
+ * inverse MDCTs), then out[] = the overlap of the previous frame's tail `saved` with buf's head under the previous frame's window
+ * shape, and the new tail, which depends on buf[] alone.
+ */
+#include <math.h>
+#include <string.h>
+#include "ffo.h"
+
+enum { ONLY_LONG, LONG_START, EIGHT_SHORT, LONG_STOP }; /* enum WindowSequence, libavcodec/aac.h:63-68 */
+
+void ffo_aac_sine_window(float *w, int n)
+{
+    for (int i = 0; i < n; i++)
+        w[i] = sinf((i + 0.5) * (M_PI / (2.0 * n)));
+}
+
+static double bessel_i0(double x)
+{
+    double q = x * x / 4, term = 1, sum = 1;
+    for (int k = 1; k < 500 && term > sum * 1e-18; k++) {
+        term *= q / ((double)k * k);
+        sum += term;
+    }
+    return sum;
+}
+
+void ffo_aac_kbd_window(float *w, float alpha, int n)
+{
+    double t[513], sum = 0, scale = 0;
+    const double a2 = 4 * (alpha * M_PI / n) * (alpha * M_PI / n);
+    for (int i = 0; i <= n / 2; i++) {
+        t[i] = bessel_i0(sqrt(i * (double)(n - i) * a2));
+        scale += t[i] * (1 + (i && i < n / 2));
+    }
+    scale = 1.0 / (scale + 1);
+    for (int i = 0; i < n; i++) {
+        sum += t[i <= n / 2 ? i : n - i];
+        w[i] = (float)sqrt(sum * scale);
+    }
+}
+
+/* AVFloatDSPContext.vector_fmul_window (libavutil/float_dsp.c:79-97): 2 len outputs from len + len inputs under a 2 len window */
+static void window_overlap(float *dst, const float *src0, const float *src1, const float *win, int len)
+{
+    for (int t = 0; t < len; t++) {
+        const float a = src0[t], b = src1[len - 1 - t], wi = win[t], wj = win[2 * len - 1 - t];
+        dst[t] = a * wj - b * wi;
+        dst[2 * len - 1 - t] = a * wi + b * wj;
+    }
+}
+
+/* windows[]: sine_1024, sine_128, kbd_long_1024, kbd_short_128; seq / kb = { this frame, previous frame } */
+void ffo_aac_imdct_and_windowing(const FfoTx *mdct1024, const FfoTx *mdct128, const float *const windows[4], const float *coeffs,
+                                 const int seq[2], const int kb[2], float *saved, float *out)
+{
+    const float *swindow = windows[kb[0] ? 3 : 1], *lwindow_prev = windows[kb[1] ? 2 : 0], *swindow_prev = windows[kb[1] ? 3 : 1];
+    float buf[1024], tail[128];
+    if (seq[0] == EIGHT_SHORT)
+        for (int i = 0; i < 1024; i += 128)
+            ffo_mdct_run(mdct128, buf + i, coeffs + i, sizeof(float));
+    else
+        ffo_mdct_run(mdct1024, buf, coeffs, sizeof(float));
+
+    const int long_prev = seq[1] == ONLY_LONG || seq[1] == LONG_STOP, long_cur = seq[0] == ONLY_LONG || seq[0] == LONG_START;
+    if (long_prev && long_cur) {
+        window_overlap(out, saved, buf, lwindow_prev, 512);
+    } else {
+        memcpy(out, saved, 448 * sizeof(float));
+        if (seq[0] == EIGHT_SHORT) {
+            window_overlap(out + 448, saved + 448, buf, swindow_prev, 64);
+            for (int b = 1; b < 4; b++)
+                window_overlap(out + 448 + b * 128, buf + (b - 1) * 128 + 64, buf + b * 128, swindow, 64);
+            window_overlap(tail, buf + 3 * 128 + 64, buf + 4 * 128, swindow, 64);
+            memcpy(out + 448 + 4 * 128, tail, 64 * sizeof(float));
+        } else {
+            window_overlap(out + 448, saved + 448, buf, swindow_prev, 64);
+            memcpy(out + 576, buf + 64, 448 * sizeof(float));
+        }
+    }
+    if (seq[0] == EIGHT_SHORT) {
+        memcpy(saved, tail + 64, 64 * sizeof(float));
+        for (int b = 4; b < 7; b++)
+            window_overlap(saved + 64 + (b - 4) * 128, buf + b * 128 + 64, buf + (b + 1) * 128, swindow, 64);
+        memcpy(saved + 448, buf + 7 * 128 + 64, 64 * sizeof(float));
+    } else if (seq[0] == LONG_START) {
+        memcpy(saved, buf + 512, 448 * sizeof(float));
+        memcpy(saved + 448, buf + 7 * 128 + 64, 64 * sizeof(float));
+    } else {
+        memcpy(saved, buf + 512, 512 * sizeof(float));
+    }
+}

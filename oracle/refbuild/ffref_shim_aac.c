@@ -1,0 +1,71 @@
+/*
+ * ffref_shim_aac.c — flat accessor onto the reference's AACDecDSP.imdct_and_windowing (float decoder).  TEST INFRASTRUCTURE ONLY.
+ * The member is a static function of libavcodec/aac/aacdec_float.c (through aacdec_dsp_template.c); it is reached the way the
+ * decoder reaches it: ff_aac_decode_init_float() fills AACDecContext.dsp and the window tables, the two inverse MDCTs are
+ * created as ff_aac_decode_init() creates them (aacdec.c:1267-1285).  The rest of the decoder (bitstream, SBR) is stubbed out.
+ * Includes the reference's headers where they lie (-I/root/reference); contains no reference code.
+ */
+#include "config.h"
+#include <string.h>
+#include "libavutil/cpu.h"
+#include "libavutil/log.h"
+#include "libavutil/mem.h"
+#include "libavutil/tx.h"
+#include "libavcodec/avcodec.h"
+#include "libavcodec/aac/aacdec.h"
+#include "libavcodec/aactab.h"
+#include "libavcodec/sinewin.h"
+
+int ff_aac_decode_init_float(AVCodecContext *avctx);
+/* the decoder proper is not part of this build: ff_aac_decode_init_float() ends in it */
+int ff_aac_decode_init(AVCodecContext *avctx) { return 0; }
+void ff_ps_init_common(void) {} /* likewise parametric stereo's tables (aacdec_tab.c:778) */
+void ff_aac_sbr_init(void) {} /* init_tables_float_fn() calls it; SBR is not part of this build */
+
+static AACDecContext *aac(void)
+{
+    static AACDecContext *ac;
+    if (!ac) {
+        av_force_cpu_flags(0);
+        av_log_set_level(AV_LOG_ERROR);
+        AVCodecContext *avctx = av_mallocz(sizeof(*avctx));
+        ac = av_mallocz(sizeof(*ac));
+        avctx->priv_data = ac;
+        ac->avctx = avctx;
+        if (ff_aac_decode_init_float(avctx) < 0)
+            return NULL;
+        float s128 = (1.0 / 128) / 32768.0f, s1024 = (1.0 / 1024) / 32768.0f; /* MDCT_INIT's scale_float */
+        if (av_tx_init(&ac->mdct128, &ac->mdct128_fn, AV_TX_FLOAT_MDCT, 1, 128, &s128, 0) < 0 ||
+            av_tx_init(&ac->mdct1024, &ac->mdct1024_fn, AV_TX_FLOAT_MDCT, 1, 1024, &s1024, 0) < 0)
+            return NULL;
+    }
+    return ac;
+}
+
+/* which: 0 sine_1024, 1 sine_128, 2 kbd_long_1024, 3 kbd_short_128 */
+const float *ffref_aac_window(int which)
+{
+    if (!aac())
+        return NULL;
+    return which == 0 ? ff_sine_1024 : which == 1 ? ff_sine_128 : which == 2 ? ff_aac_kbd_long_1024 : ff_aac_kbd_short_128;
+}
+
+/* one channel, one frame: seq / kb = {current, previous}; saved[512] is the overlap state in and out */
+int ffref_aac_imdct_and_windowing(const float *coeffs, const int seq[2], const int kb[2], float *saved, float *out)
+{
+    AACDecContext *ac = aac();
+    static SingleChannelElement *sce;
+    if (!ac)
+        return -1;
+    if (!sce)
+        sce = av_mallocz(sizeof(*sce));
+    sce->ics.window_sequence[0] = seq[0]; sce->ics.window_sequence[1] = seq[1];
+    sce->ics.use_kb_window[0] = kb[0];    sce->ics.use_kb_window[1] = kb[1];
+    memcpy(sce->coeffs, coeffs, 1024 * sizeof(float));
+    memcpy(sce->saved, saved, 512 * sizeof(float));
+    sce->output = sce->ret_buf;
+    ac->dsp.imdct_and_windowing(ac, sce);
+    memcpy(out, sce->output, 1024 * sizeof(float));
+    memcpy(saved, sce->saved, 512 * sizeof(float));
+    return 0;
+}

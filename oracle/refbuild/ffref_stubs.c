@@ -7,3 +7,5 @@
 #include <stdlib.h>
 #include <stdint.h>
 #define TRAP(name) void name(void) { abort(); }
+/* the AAC decoder around AACDecDSP (bitstream parsing, SBR): aacdec_float.c's proc functions name them */
+TRAP(ff_aac_decode_ics) TRAP(ff_aac_sbr_ctx_alloc_init) TRAP(ff_aac_sbr_ctx_close) TRAP(ff_aac_sbr_decode_extension) TRAP(ff_aac_sbr_apply)

@@ -37,7 +37,7 @@ ONES = {
     # library switches for the components on the hot path
     "CONFIG_SWSCALE", "CONFIG_AVUTIL", "CONFIG_AVCODEC", "CONFIG_SWSCALE_ALPHA", "CONFIG_STATIC",
     "CONFIG_PIC", "CONFIG_GPL", "CONFIG_SAFE_BITSTREAM_READER", "CONFIG_H264DSP", "CONFIG_H264QPEL",
-    "CONFIG_H264CHROMA", "CONFIG_ME_CMP", "CONFIG_VIDEODSP", "CONFIG_UNSTABLE",
+    "CONFIG_H264CHROMA", "CONFIG_ME_CMP", "CONFIG_VIDEODSP", "CONFIG_UNSTABLE", "CONFIG_AAC_DECODER",
 }
 
 TOK = re.compile(r"\b((?:HAVE|CONFIG|ARCH)_[A-Z0-9_]+)\b")

@@ -96,6 +96,12 @@ def oracle():
         L.ffo_rdft_run.restype = None
         L.ffo_dct_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
         L.ffo_dct_run.restype = None
+        L.ffo_aac_sine_window.argtypes = [f32p, C.c_int]
+        L.ffo_aac_sine_window.restype = None
+        L.ffo_aac_kbd_window.argtypes = [f32p, C.c_float, C.c_int]
+        L.ffo_aac_kbd_window.restype = None
+        L.ffo_aac_imdct_and_windowing.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(f32p), f32p, i32p, i32p, f32p, f32p]
+        L.ffo_aac_imdct_and_windowing.restype = None
         L.ffo_fdsp.argtypes = [C.c_int, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
         L.ffo_fdsp.restype = None
         L.ffo_hevc_coef.argtypes = [C.c_int, C.c_int]
@@ -233,6 +239,10 @@ def ref():
         L.ffref_vp9_smc.restype = None
         L.ffref_vp9_intra_pred.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, u8p, u8p]
         L.ffref_vp9_intra_pred.restype = None
+        L.ffref_aac_window.argtypes = [C.c_int]
+        L.ffref_aac_window.restype = f32p
+        L.ffref_aac_imdct_and_windowing.argtypes = [f32p, i32p, i32p, f32p, f32p]
+        L.ffref_aac_imdct_and_windowing.restype = C.c_int
         L.ffref_h264_pred4x4.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t]
         L.ffref_h264_pred8x8l.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_ssize_t]
         L.ffref_h264_pred8x8.argtypes = [C.c_int, u8p, C.c_ssize_t]

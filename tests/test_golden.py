@@ -244,6 +244,30 @@ def test_h264_pred_golden():
     h264_pred_golden_check(apply, load("h264pred"))
 
 
+def aac_golden_windows(d):
+    return [np.ascontiguousarray(d[k]) for k in ("sine_1024", "sine_128", "kbd_long_1024", "kbd_short_128")]
+
+
+def test_aac_golden():
+    """the oracle on the stored frames (decoder's own window tables from the fixture): outputs and final overlap state"""
+    O = ffi.oracle()
+    d = load("aac")
+    win = aac_golden_windows(d)
+    wp = (f32p * 4)(*[ptr(w, f32p) for w in win])
+    m1024, m128 = O.ffo_mdct_create(1, 1024, 2.0 ** -25), O.ffo_mdct_create(1, 128, 2.0 ** -22)
+    saved = d["saved_in"].copy()
+    prev = tuple(int(v) for v in d["prev"])
+    for f in range(len(d["seq"])):
+        s2 = np.array([d["seq"][f], prev[0]], np.int32); k2 = np.array([d["kb"][f], prev[1]], np.int32)
+        out = np.zeros(1024, np.float32)
+        O.ffo_aac_imdct_and_windowing(m1024, m128, wp, ptr(np.ascontiguousarray(d["coeffs"][f]), f32p), ptr(s2, i32p), ptr(k2, i32p),
+                                      ptr(saved, f32p), ptr(out, f32p))
+        assert np.array_equal(out.view(np.uint32), d["out"][f].view(np.uint32)), f
+        prev = (int(d["seq"][f]), int(d["kb"][f]))
+    assert np.array_equal(saved.view(np.uint32), d["saved_out"].view(np.uint32))
+    O.ffo_mdct_free(m1024); O.ffo_mdct_free(m128)
+
+
 def test_fdsp_golden():
     O = ffi.oracle()
     d = load("fdsp")

@@ -1,0 +1,91 @@
+"""GPU parity: AACDecDSP.imdct_and_windowing (float AAC decoder, 1024-sample frames) vs the oracle and the reference's stored
+outputs, through the C ABI.  The window tables are the decoder's own, taken from tests/golden/aac.npz (written from the reference
+built in place) - the hip path receives them from its caller and never computes them."""
+import numpy as np
+import pytest
+
+import ffi
+import test_golden as G
+from test_oracle_vs_ref import aac_sequences, aac_oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_aac_golden_gpu():
+    """the reference's frames: batch face (all frames in one call) and the host face frame by frame"""
+    from ffmpeg_amd import aac
+    torch = _torch()
+    d = G.load("aac")
+    ctx = aac.AacImdct(G.aac_golden_windows(d))
+    nf = len(d["seq"])
+    d_out = torch.zeros((nf, 1, 1024), dtype=torch.float32, device="cuda:0")
+    d_saved = torch.from_numpy(d["saved_in"].copy()).cuda().reshape(1, 512)
+    ctx.batch(torch.from_numpy(np.ascontiguousarray(d["coeffs"])).cuda().reshape(nf, 1, 1024), d_out, d_saved, d["seq"], d["kb"],
+              d["prev"][:1], d["prev"][1:])
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().reshape(nf, 1024).view(np.uint32), d["out"].view(np.uint32))
+    assert np.array_equal(d_saved.cpu().numpy().reshape(512).view(np.uint32), d["saved_out"].view(np.uint32))
+    saved = d["saved_in"].copy()
+    prev = tuple(int(v) for v in d["prev"])
+    for f in range(nf):
+        out = np.zeros(1024, np.float32)
+        ctx.frame(np.ascontiguousarray(d["coeffs"][f]), (int(d["seq"][f]), prev[0]), (int(d["kb"][f]), prev[1]), saved, out)
+        assert np.array_equal(out.view(np.uint32), d["out"][f].view(np.uint32)), f
+        prev = (int(d["seq"][f]), int(d["kb"][f]))
+    assert np.array_equal(saved.view(np.uint32), d["saved_out"].view(np.uint32))
+    ctx.close()
+
+
+@pytest.mark.parametrize("nch,nframes", [(1, 1), (2, 300), (6, 97)])
+def test_aac_imdct_and_windowing_batch(nch, nframes):
+    """channels x frames in one call against the oracle run channel by channel, frame after frame; then a second call continues
+    from the state the first one left (the overlap state and the previous window sequence / shape carry over)"""
+    from ffmpeg_amd import aac
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(2710 + nch)
+    d = G.load("aac")
+    windows = G.aac_golden_windows(d)
+    ctx = aac.AacImdct(windows)
+    total = nframes + 40
+    seq = np.zeros((total, nch), np.uint8); kb = np.zeros((total, nch), np.uint8)
+    for c in range(nch):
+        s, k = aac_sequences(rng, total)
+        seq[:, c], kb[:, c] = s, k
+    coeffs = (rng.standard_normal((total, nch, 1024)) * 3000.0 * 10.0 ** rng.integers(-2, 2, (total, nch, 1))).astype(np.float32)
+    saved0 = (rng.standard_normal((nch, 512)) * 0.1).astype(np.float32)
+    want = np.zeros_like(coeffs)
+    wsaved = saved0.copy()
+    for c in range(nch):
+        sv = wsaved[c].copy()
+        want[:, c] = aac_oracle_run(O, windows, np.ascontiguousarray(coeffs[:, c]), seq[:, c], kb[:, c], sv)   # previous of frame 0: (ONLY_LONG, kb[0])
+        wsaved[c] = sv
+    d_co = torch.from_numpy(coeffs).cuda()
+    d_out = torch.zeros((total, nch, 1024), dtype=torch.float32, device="cuda:0")
+    d_saved = torch.from_numpy(saved0.copy()).cuda()
+    ctx.batch(d_co[:nframes], d_out[:nframes], d_saved, seq[:nframes], kb[:nframes], np.zeros(nch, np.uint8), kb[0])
+    if total > nframes:
+        ctx.batch(d_co[nframes:], d_out[nframes:], d_saved, seq[nframes:], kb[nframes:], seq[nframes - 1], kb[nframes - 1])
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frames differing: %s" % np.argwhere((got != want).any(axis=2))[:5]
+    assert np.array_equal(d_saved.cpu().numpy().view(np.uint32), wsaved.view(np.uint32))
+    assert np.array_equal(d_co.cpu().numpy(), coeffs)          # coefficients are left alone
+    ctx.close()
+
+
+def test_aac_rejects_bad_sequence():
+    from ffmpeg_amd import aac
+    torch = _torch()
+    ctx = aac.AacImdct(G.aac_golden_windows(G.load("aac")))
+    z = torch.zeros((1, 1, 1024), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(RuntimeError, match="window sequence"):
+        ctx.batch(z, z.clone(), torch.zeros((1, 512), dtype=torch.float32, device="cuda:0"), np.array([4], np.uint8), np.array([0], np.uint8),
+                  np.array([0], np.uint8), np.array([0], np.uint8))
+    ctx.close()

@@ -945,6 +945,78 @@ def test_dct_vs_definition():
     assert np.allclose(ratio, ratio[0], rtol=1e-3), ratio[:4]
 
 
+AAC_WINDOWS = ((0, 1024), (1, 128), (2, 1024), (3, 128))       # sine_1024, sine_128, kbd_long_1024, kbd_short_128
+AAC_SCALES = (2.0 ** -25, 2.0 ** -22)                            # MDCT_INIT's scale_float for 1024 / 128 (aacdec.c:1267-1285)
+
+
+def aac_ref_windows():
+    R = ffi.ref()
+    return [np.ctypeslib.as_array(R.ffref_aac_window(w), (n,)).copy() for w, n in AAC_WINDOWS]
+
+
+def aac_sequences(rng, nframes):
+    """a legal window-sequence walk (ISO 14496-3 4.5.2.3.3 transitions) with window shapes switching at random"""
+    nxt = {0: (0, 0, 0, 1), 1: (2,), 2: (2, 2, 3), 3: (0, 0, 1)}
+    seq, kb = [0], [int(rng.integers(0, 2))]
+    for _ in range(nframes - 1):
+        seq.append(int(rng.choice(nxt[seq[-1]])))
+        kb.append(int(rng.integers(0, 2)) if rng.integers(0, 4) == 0 else kb[-1])
+    return np.array(seq, np.int32), np.array(kb, np.int32)
+
+
+def aac_oracle_run(O, windows, coeffs, seq, kb, saved):
+    """frames of one channel through the oracle: coeffs [nf, 1024]; returns out [nf, 1024], saved updated in place"""
+    m1024, m128 = O.ffo_mdct_create(1, 1024, AAC_SCALES[0]), O.ffo_mdct_create(1, 128, AAC_SCALES[1])
+    wp = (f32p * 4)(*[ptr(w, f32p) for w in windows])
+    out = np.zeros_like(coeffs)
+    prev = (0, int(kb[0]))
+    for f in range(len(coeffs)):
+        s2 = np.array([seq[f], prev[0]], np.int32); k2 = np.array([kb[f], prev[1]], np.int32)
+        O.ffo_aac_imdct_and_windowing(m1024, m128, wp, ptr(np.ascontiguousarray(coeffs[f]), f32p), ptr(s2, i32p), ptr(k2, i32p),
+                                      ptr(saved, f32p), ptr(out[f], f32p))
+        prev = (int(seq[f]), int(kb[f]))
+    O.ffo_mdct_free(m1024); O.ffo_mdct_free(m128)
+    return out
+
+
+def test_aac_windows():
+    """the sine tables are bit-identical (same libm), the Kaiser-Bessel ones within 1 ulp (another I0 evaluation)"""
+    O = ffi.oracle()
+    ref = aac_ref_windows()
+    for (w, n), r in zip(AAC_WINDOWS, ref):
+        mine = np.zeros(n, np.float32)
+        if w < 2:
+            O.ffo_aac_sine_window(ptr(mine, f32p), n)
+            assert np.array_equal(mine.view(np.uint32), r.view(np.uint32)), w
+        else:
+            O.ffo_aac_kbd_window(ptr(mine, f32p), 4.0 if n == 1024 else 6.0, n)
+            assert np.abs(mine.view(np.int32).astype(np.int64) - r.view(np.int32)).max() <= 1, w
+
+
+def test_aac_imdct_and_windowing():
+    """AACDecDSP.imdct_and_windowing of the float decoder, frame after frame with the overlap state carried along: every window
+    sequence transition and shape switch, bit-identical"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(2700)
+    windows = aac_ref_windows()
+    nf = 120
+    seq, kb = aac_sequences(rng, nf)
+    assert set(seq.tolist()) == {0, 1, 2, 3}
+    coeffs = (rng.standard_normal((nf, 1024)) * 3000.0 * 10.0 ** rng.integers(-2, 2, (nf, 1))).astype(np.float32)
+    sa = (rng.standard_normal(512) * 0.1).astype(np.float32)
+    sb = sa.copy()
+    got = aac_oracle_run(O, windows, coeffs, seq, kb, sb)
+    prev = (0, int(kb[0]))
+    for f in range(nf):
+        s2 = np.array([seq[f], prev[0]], np.int32); k2 = np.array([kb[f], prev[1]], np.int32)
+        out = np.zeros(1024, np.float32)
+        assert R.ffref_aac_imdct_and_windowing(ptr(np.ascontiguousarray(coeffs[f]), f32p), ptr(s2, i32p), ptr(k2, i32p), ptr(sa, f32p),
+                                               ptr(out, f32p)) == 0
+        assert np.array_equal(out.view(np.uint32), got[f].view(np.uint32)), (f, seq[f], prev)
+        prev = (int(seq[f]), int(kb[f]))
+    assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
+
+
 @pytest.mark.parametrize("inv", [0, 1])
 def test_mdct_vs_naive(inv):
     """the float transform stays within 2^-18 * max|ref| of the double-precision cosine sum"""

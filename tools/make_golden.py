@@ -399,6 +399,31 @@ def h264pred():
     np.savez_compressed(os.path.join(OUT, "h264pred.npz"), **d)
 
 
+def aac():
+    """AACDecDSP.imdct_and_windowing: the decoder's four window tables and 14 consecutive frames of one channel that walk through
+    every window-sequence transition and shape switch; outputs and the overlap state from the reference"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_vs_ref import aac_ref_windows
+    rng = np.random.default_rng(15)
+    win = aac_ref_windows()
+    seq = np.array([0, 0, 1, 2, 2, 3, 0, 1, 2, 3, 1, 2, 3, 0], np.int32)
+    kb = np.array([0, 1, 1, 1, 0, 0, 1, 0, 0, 1, 1, 0, 1, 1], np.int32)
+    nf = len(seq)
+    coeffs = np.round(rng.standard_normal((nf, 1024)) * 2000.0 / (1 + np.arange(1024) / 64.0)).astype(np.float32)
+    saved = (rng.standard_normal(512) * 0.05).astype(np.float32)
+    d = {"sine_1024": win[0], "sine_128": win[1], "kbd_long_1024": win[2], "kbd_short_128": win[3], "seq": seq, "kb": kb, "coeffs": coeffs,
+         "saved_in": saved.copy(), "prev": np.array([3, 1], np.int32)}
+    out = np.zeros((nf, 1024), np.float32)
+    prev = (3, 1)
+    for f in range(nf):
+        s2 = np.array([seq[f], prev[0]], np.int32); k2 = np.array([kb[f], prev[1]], np.int32)
+        assert R.ffref_aac_imdct_and_windowing(ptr(np.ascontiguousarray(coeffs[f]), f32p), ptr(s2, i32p), ptr(k2, i32p), ptr(saved, f32p),
+                                               ptr(out[f], f32p)) == 0
+        prev = (int(seq[f]), int(kb[f]))
+    d["out"], d["saved_out"] = out, saved
+    np.savez_compressed(os.path.join(OUT, "aac.npz"), **d)
+
+
 def fdsp():
     """AVFloatDSPContext vector ops: len 1024 and 37, operands across magnitudes (bit patterns stored as uint32)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -421,6 +446,6 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred()
+        sws(); h264(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -15,11 +15,13 @@ if typ == tx.FLOAT_RDFT:
     n_in, n_out = (ln + 2, ln) if inv else (ln, ln + 2)
 elif typ == tx.FLOAT_FFT:
     n_in = n_out = 2 * ln
+elif typ == tx.FLOAT_DCT:
+    n_in = n_out = ln          # <len> = number of samples; the inverse is initialised with half of it, as av_tx_init is
 else:
     n_in, n_out = (ln, ln) if inv else (2 * ln, ln)
 tin = torch.rand((nt, n_in), dtype=torch.float32, device="cuda:0")
 tout = torch.empty((nt, n_out), dtype=torch.float32, device="cuda:0")
-ctx = tx.TxContext(typ, inv, ln, 1.0)
+ctx = tx.TxContext(typ, inv, ln >> inv if typ == tx.FLOAT_DCT else ln, 1.0)
 for _ in range(6):
     ctx.batch(tout, tin)
 torch.cuda.synchronize()
