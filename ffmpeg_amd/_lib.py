@@ -108,6 +108,8 @@ def lib():
         "ff_vp9dsp_intrapred_init_hip": (C.c_int, [vp, C.c_int]),
         "ffhip_aac_imdct_create": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float]),
         "ffhip_aac_imdct_free": (None, [vp]),
+        "ffhip_aac_tns_filters": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
+        "ffhip_aac_apply_tns_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
         "ffhip_aac_imdct_and_windowing": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "ffhip_aac_imdct_and_windowing_batch_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
         "ffhip_h264_pred_batch_dev": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, vp, C.c_int, vp]),

@@ -52,3 +52,26 @@ class AacImdct:
         return _lib.check(_lib.lib().ffhip_aac_imdct_and_windowing_batch_dev(self._c, coeffs.data_ptr(), out.data_ptr(), saved.data_ptr(),
                                                                              ws.ctypes.data, kb.ctypes.data, ps.ctypes.data, pk.ctypes.data,
                                                                              nch, nframes, stream), "ffhip_aac_imdct_and_windowing_batch_dev")
+
+
+#: FFHipAacTnsFilter (include/ffhip.h)
+TNS_FILTER_DTYPE = np.dtype([("frame", np.int32), ("start", np.int16), ("size", np.int16), ("inc", np.int8), ("order", np.uint8),
+                             ("pad", np.uint8, 2), ("coef", np.float32, 20)])
+
+
+def tns_filters(frame, n_filt, length, direction, order, coef, num_windows, num_swb, swb_offset, tns_max_bands, max_sfb):
+    """apply_tns's walk over windows and filters for one channel-frame: numpy array of FFHipAacTnsFilter records"""
+    rec = np.zeros(32, TNS_FILTER_DTYPE)
+    args = [np.ascontiguousarray(x, np.int32) for x in (n_filt, length, direction, order)]
+    cf = np.ascontiguousarray(coef, np.float32)
+    swb = np.ascontiguousarray(swb_offset, np.uint16)
+    n = _lib.check(_lib.lib().ffhip_aac_tns_filters(rec.ctypes.data, frame, args[0].ctypes.data, args[1].ctypes.data, args[2].ctypes.data,
+                                                    args[3].ctypes.data, cf.ctypes.data, num_windows, num_swb, swb.ctypes.data, tns_max_bands,
+                                                    max_sfb), "ffhip_aac_tns_filters")
+    return rec[:n]
+
+
+def apply_tns_batch(coeffs, filters, nfilters, decode=1, stream=None):
+    """coeffs: float32 cuda tensor [nframes, 1024], filtered in place; filters: uint8 cuda tensor [nfilters, 92]"""
+    return _lib.check(_lib.lib().ffhip_aac_apply_tns_batch_dev(coeffs.data_ptr(), filters.data_ptr(), nfilters, decode,
+                                                               None if stream is None else C.c_void_p(stream)), "ffhip_aac_apply_tns_batch_dev")

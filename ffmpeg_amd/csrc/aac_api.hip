@@ -255,3 +255,110 @@ extern "C" int ffhip_aac_imdct_and_windowing(FFHipAacImdct *c, const float *coef
         return FFHIP_EINVAL;
     return 0;
 }
+
+/* ---- AACDecDSP.apply_tns (aacdec_dsp_template.c:164-223) ------------------------------------------------------------------- */
+static_assert(sizeof(FFHipAacTnsFilter) == 92, "FFHipAacTnsFilter is a 92-byte record");
+
+/* The walk over windows and filters that turns the parsed TemporalNoiseShaping into filter ranges; host side (the fields come
+ * out of the bitstream parser).  Returns the number of records written (<= 32). */
+extern "C" int ffhip_aac_tns_filters(FFHipAacTnsFilter *out, int frame, const int n_filt[8], const int length[8][4], const int direction[8][4],
+                                     const int order[8][4], const float coef[8][4][20], int num_windows, int num_swb,
+                                     const uint16_t *swb_offset, int tns_max_bands, int max_sfb)
+{
+    if (!out || !n_filt || !length || !direction || !order || !coef || !swb_offset || num_windows < 1 || num_windows > 8)
+        return FFHIP_EINVAL;
+    const int lim = tns_max_bands < max_sfb ? tns_max_bands : max_sfb;
+    int n = 0;
+    if (!lim)
+        return 0;
+    for (int w = 0; w < num_windows; w++) {
+        int lo = num_swb;
+        for (int f = 0; f < n_filt[w] && f < 4; f++) {
+            const int hi = lo;
+            lo = hi > length[w][f] ? hi - length[w][f] : 0;
+            const int ord = order[w][f];
+            if (ord <= 0)
+                continue;
+            if (ord > 20) {
+                ffhip_set_error("ffhip_aac_tns_filters: order %d above TNS_MAX_ORDER", ord);
+                return FFHIP_EINVAL;
+            }
+            const int first = swb_offset[lo < lim ? lo : lim], last = swb_offset[hi < lim ? hi : lim];
+            if (last <= first)
+                continue;
+            FFHipAacTnsFilter &r = out[n++];
+            memset(&r, 0, sizeof(r));
+            r.frame = frame;
+            r.size = (int16_t)(last - first);
+            r.inc = direction[w][f] ? -1 : 1;
+            r.start = (int16_t)((direction[w][f] ? last - 1 : first) + w * 128);
+            r.order = (uint8_t)ord;
+            memcpy(r.coef, coef[w][f], ord * sizeof(float));
+        }
+    }
+    return n;
+}
+
+/* One lane per filter: the recursion along frequency is serial, a batch has thousands of filters.  lpc[] and the history stay in
+ * registers (everything is unrolled to TNS_MAX_ORDER with the order as a guard, so no array is indexed dynamically); products and
+ * sums are separate operations in the reference's order. */
+template <bool DECODE>
+__global__ __launch_bounds__(64) void k_aac_tns(float *coeffs, const FFHipAacTnsFilter *filters, int n)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n)
+        return;
+    const FFHipAacTnsFilter *F = filters + g;
+    const int order = F->order, size = F->size, inc = F->inc;
+    float lpc[20], hist[20];
+    /* compute_lpc_coefs(coef, 0, order, lpc, 0, 0, 0, NULL), libavcodec/lpc_functions.h:54-103: the step-up recursion in place */
+#pragma unroll
+    for (int i = 0; i < 20; i++) {
+        lpc[i] = 0.0f;
+        hist[i] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 20; i++) {
+        if (i < order) {
+            const float k = -F->coef[i];
+            lpc[i] = k;
+#pragma unroll
+            for (int j = 0; j < (i + 1) >> 1; j++) {
+                const float f = lpc[j], b = lpc[i - 1 - j];
+                lpc[j] = f + k * b;
+                lpc[i - 1 - j] = b + k * f;
+            }
+        }
+    }
+    float *p = coeffs + (size_t)F->frame * 1024 + F->start;
+    for (int m = 0; m < size; m++, p += inc) {
+        const int lim = m < order ? m : order;
+        const float in = *p;
+        float x = in;
+#pragma unroll
+        for (int i = 0; i < 20; i++)
+            if (i < lim)
+                x = DECODE ? x - hist[i] * lpc[i] : x + hist[i] * lpc[i];
+        *p = x;
+#pragma unroll
+        for (int i = 19; i > 0; i--)
+            hist[i] = hist[i - 1];
+        hist[0] = DECODE ? x : in; /* the all-pole filter feeds back its outputs, the moving average remembers its inputs */
+    }
+}
+
+extern "C" int ffhip_aac_apply_tns_batch_dev(float *coeffs, const FFHipAacTnsFilter *filters, int nfilters, int decode, void *stream)
+{
+    if (!coeffs || !filters || nfilters < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    if (!nfilters)
+        return 0;
+    if (decode)
+        hipLaunchKernelGGL(k_aac_tns<true>, dim3(cdiv(nfilters, 64)), dim3(64), 0, (hipStream_t)stream, coeffs, filters, nfilters);
+    else
+        hipLaunchKernelGGL(k_aac_tns<false>, dim3(cdiv(nfilters, 64)), dim3(64), 0, (hipStream_t)stream, coeffs, filters, nfilters);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -404,6 +404,28 @@ int  ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const float *coef
                                              const uint8_t *window_sequence, const uint8_t *use_kb_window, const uint8_t *prev_sequence,
                                              const uint8_t *prev_kb_window, int nch, int nframes, void *stream);
 
+/** AACDecDSP.apply_tns (libavcodec/aac/aacdec.h, body aacdec_dsp_template.c:164-223), float: one record per TNS filter with a
+ *  non-empty range.  coef[] holds the transmitted reflection coefficients (TemporalNoiseShaping.coef[w][filt]); the LPC
+ *  coefficients are derived on the device as the reference derives them (compute_lpc_coefs, lpc_functions.h:54-103). */
+typedef struct FFHipAacTnsFilter {
+    int32_t frame;      /* channel-frame the filter belongs to: coeffs + frame * 1024 */
+    int16_t start;      /* first coefficient filtered (index into the frame, window offset included) */
+    int16_t size;       /* number of coefficients */
+    int8_t  inc;        /* +1 upwards, -1 downwards (TemporalNoiseShaping.direction) */
+    uint8_t order;      /* 1..20 (TNS_MAX_ORDER) */
+    uint8_t pad[2];
+    float   coef[20];   /* sizeof == 92 */
+} FFHipAacTnsFilter;
+/** apply_tns's walk over windows and filters for one channel-frame (host side, from the parsed TemporalNoiseShaping and the
+ *  IndividualChannelStream fields it reads); writes at most 32 records, returns their number. */
+int ffhip_aac_tns_filters(FFHipAacTnsFilter *out, int frame, const int n_filt[8], const int length[8][4], const int direction[8][4],
+                          const int order[8][4], const float coef[8][4][20], int num_windows, int num_swb, const uint16_t *swb_offset,
+                          int tns_max_bands, int max_sfb);
+/** The filters of a batch of channel-frames, in place on coeffs [nframes][1024] (device); filters is a device array.  decode != 0:
+ *  the decoder's all-pole filter; 0: the moving-average form of the LTP path (apply_ltp, aacdec_dsp_template.c:252-282).  The
+ *  filters of a frame cover disjoint ranges, so all of them run concurrently. */
+int ffhip_aac_apply_tns_batch_dev(float *coeffs, const FFHipAacTnsFilter *filters, int nfilters, int decode, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: H264PredContext — H.264 codec, 8 bits, chroma_format_idc <= 1 */
 /* ------------------------------------------------------------------------------------------ */

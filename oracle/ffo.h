@@ -163,6 +163,11 @@ void ffo_h264_pred8x8l_filter_add(int mode, uint8_t *pix, int16_t *block, int ha
 void ffo_h264_pred8x8_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
 void ffo_h264_pred16x16_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
 
+/* one TNS filter of a channel-frame: `size` coefficients from `start` (index into the frame's 1024) stepping by `inc` */
+typedef struct FfoAacTnsFilter { int start, size, inc, order; float coef[20]; } FfoAacTnsFilter;
+int  ffo_aac_tns_filters(FfoAacTnsFilter *out, const int n_filt[8], const int length[8][4], const int direction[8][4], const int order[8][4],
+                         const float coef[8][4][20], int num_windows, int num_swb, const uint16_t *swb_offset, int tns_max_bands, int max_sfb);
+void ffo_aac_tns_run(float *coef, const FfoAacTnsFilter *r, int decode);
 /* ---- ffo_aac.c: AACDecDSP.imdct_and_windowing, float, 1024-sample frames (libavcodec/aac/aacdec_dsp_template.c:325-387) ---- */
 void ffo_aac_sine_window(float *w, int n);
 void ffo_aac_kbd_window(float *w, float alpha, int n);

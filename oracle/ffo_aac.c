@@ -98,3 +98,63 @@ void ffo_aac_imdct_and_windowing(const FfoTx *mdct1024, const FfoTx *mdct128, co
         memcpy(saved, buf + 512, 512 * sizeof(float));
     }
 }
+
+/*
+ * AACDecDSP.apply_tns, float (libavcodec/aac/aacdec_dsp_template.c:164-223; LPC from the transmitted reflection coefficients:
+ * compute_lpc_coefs, libavcodec/lpc_functions.h:54-103 with normalize = 0).  Restated in two steps: the walk over windows and
+ * filters that yields each filter's range (a "filter record"), and the filter itself on one record.
+ */
+int ffo_aac_tns_filters(FfoAacTnsFilter *out, const int n_filt[8], const int length[8][4], const int direction[8][4], const int order[8][4],
+                        const float coef[8][4][20], int num_windows, int num_swb, const uint16_t *swb_offset, int tns_max_bands, int max_sfb)
+{
+    const int mmm = tns_max_bands < max_sfb ? tns_max_bands : max_sfb;
+    int n = 0;
+    if (!mmm)
+        return 0;
+    for (int w = 0; w < num_windows; w++) {
+        int bottom = num_swb;
+        for (int f = 0; f < n_filt[w]; f++) {
+            const int top = bottom;
+            bottom = top - length[w][f] > 0 ? top - length[w][f] : 0;
+            if (!order[w][f])
+                continue;
+            const int start = swb_offset[bottom < mmm ? bottom : mmm], end = swb_offset[top < mmm ? top : mmm];
+            if (end - start <= 0)
+                continue;
+            FfoAacTnsFilter *r = &out[n++];
+            r->size = end - start;
+            r->inc = direction[w][f] ? -1 : 1;
+            r->start = (direction[w][f] ? end - 1 : start) + w * 128;
+            r->order = order[w][f];
+            memcpy(r->coef, coef[w][f], sizeof(r->coef));
+        }
+    }
+    return n;
+}
+
+void ffo_aac_tns_run(float *coef, const FfoAacTnsFilter *r, int decode)
+{
+    float lpc[20], hist[21] = { 0 };
+    for (int i = 0; i < r->order; i++) { /* the step-up recursion, in place */
+        const float k = -r->coef[i];
+        lpc[i] = k;
+        for (int j = 0; j < (i + 1) >> 1; j++) {
+            const float f = lpc[j], b = lpc[i - 1 - j];
+            lpc[j] = f + k * b;
+            lpc[i - 1 - j] = b + k * f;
+        }
+    }
+    int p = r->start;
+    for (int m = 0; m < r->size; m++, p += r->inc) {
+        const int lim = m < r->order ? m : r->order;
+        float x = coef[p];
+        hist[0] = x; /* MA: the inputs' history; AR: overwritten with the output below */
+        for (int i = 1; i <= lim; i++)
+            x = decode ? x - hist[i] * lpc[i - 1] : x + hist[i] * lpc[i - 1];
+        coef[p] = x;
+        if (decode)
+            hist[0] = x;
+        for (int i = r->order; i > 0; i--)
+            hist[i] = hist[i - 1];
+    }
+}

@@ -69,3 +69,28 @@ int ffref_aac_imdct_and_windowing(const float *coeffs, const int seq[2], const i
     memcpy(saved, sce->saved, 512 * sizeof(float));
     return 0;
 }
+
+/* AACDecDSP.apply_tns on one channel-frame (coef[1024] in place); the arrays are TemporalNoiseShaping's / IndividualChannelStream's */
+int ffref_aac_apply_tns(float *coef, const int n_filt[8], const int length[8][4], const int direction[8][4], const int order[8][4],
+                        const float tcoef[8][4][20], int num_windows, int num_swb, const uint16_t *swb_offset, int tns_max_bands, int max_sfb,
+                        int decode)
+{
+    AACDecContext *ac = aac();
+    static TemporalNoiseShaping tns;
+    static IndividualChannelStream ics;
+    if (!ac)
+        return -1;
+    tns.present = 1;
+    memcpy(tns.n_filt, n_filt, sizeof(tns.n_filt));
+    memcpy(tns.length, length, sizeof(tns.length));
+    memcpy(tns.direction, direction, sizeof(tns.direction));
+    memcpy(tns.order, order, sizeof(tns.order));
+    memcpy(tns.coef, tcoef, sizeof(tns.coef));
+    ics.num_windows = num_windows;
+    ics.num_swb = num_swb;
+    ics.swb_offset = swb_offset;
+    ics.tns_max_bands = tns_max_bands;
+    ics.max_sfb = max_sfb;
+    ac->dsp.apply_tns(coef, &tns, &ics, decode);
+    return 0;
+}

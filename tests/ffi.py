@@ -102,6 +102,10 @@ def oracle():
         L.ffo_aac_kbd_window.restype = None
         L.ffo_aac_imdct_and_windowing.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(f32p), f32p, i32p, i32p, f32p, f32p]
         L.ffo_aac_imdct_and_windowing.restype = None
+        L.ffo_aac_tns_filters.argtypes = [C.c_void_p, i32p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
+        L.ffo_aac_tns_filters.restype = C.c_int
+        L.ffo_aac_tns_run.argtypes = [f32p, C.c_void_p, C.c_int]
+        L.ffo_aac_tns_run.restype = None
         L.ffo_fdsp.argtypes = [C.c_int, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
         L.ffo_fdsp.restype = None
         L.ffo_hevc_coef.argtypes = [C.c_int, C.c_int]
@@ -243,6 +247,8 @@ def ref():
         L.ffref_aac_window.restype = f32p
         L.ffref_aac_imdct_and_windowing.argtypes = [f32p, i32p, i32p, f32p, f32p]
         L.ffref_aac_imdct_and_windowing.restype = C.c_int
+        L.ffref_aac_apply_tns.argtypes = [f32p, i32p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int]
+        L.ffref_aac_apply_tns.restype = C.c_int
         L.ffref_h264_pred4x4.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t]
         L.ffref_h264_pred8x8l.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_ssize_t]
         L.ffref_h264_pred8x8.argtypes = [C.c_int, u8p, C.c_ssize_t]

@@ -6,7 +6,7 @@ import pytest
 
 import ffi
 import test_golden as G
-from test_oracle_vs_ref import aac_sequences, aac_oracle_run
+from test_oracle_vs_ref import aac_sequences, aac_oracle_run, aac_tns_case, aac_tns_filters
 
 pytestmark = pytest.mark.gpu
 
@@ -89,3 +89,40 @@ def test_aac_rejects_bad_sequence():
         ctx.batch(z, z.clone(), torch.zeros((1, 512), dtype=torch.float32, device="cuda:0"), np.array([4], np.uint8), np.array([0], np.uint8),
                   np.array([0], np.uint8), np.array([0], np.uint8))
     ctx.close()
+
+
+@pytest.mark.parametrize("decode", [1, 0])
+def test_aac_apply_tns_batch(decode):
+    """thousands of channel-frames' TNS filters in one launch (long and short windows, both directions, orders 1..20, clipped
+    ranges) against the oracle filter by filter; the host-side range walk against the oracle's; untouched coefficients stay"""
+    from ffmpeg_amd import aac
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(2730 + decode)
+    nframes = 1500
+    coeffs = (rng.standard_normal((nframes, 1024)) * 10.0 ** rng.integers(-2, 4, (nframes, 1))).astype(np.float32)
+    want = coeffs.copy()
+    recs = []
+    for f in range(nframes):
+        c = aac_tns_case(rng, f & 1)
+        mine = aac.tns_filters(f, c["n_filt"], c["length"], c["direction"], c["order"], c["coef"], c["num_windows"], c["num_swb"], c["swb"],
+                               c["tns_max_bands"], c["max_sfb"])
+        ora = aac_tns_filters(O, c)
+        assert len(mine) == len(ora)
+        for a, b in zip(mine, ora):
+            assert (a["start"], a["size"], a["inc"], a["order"]) == (b["start"], b["size"], b["inc"], b["order"])
+            assert np.array_equal(a["coef"][:a["order"]], b["coef"][:b["order"]]) and a["frame"] == f
+        recs.append(mine)
+        row = np.ascontiguousarray(want[f])
+        for r in ora:
+            O.ffo_aac_tns_run(row.ctypes.data_as(ffi.f32p), np.array(r).ctypes.data, decode)
+        want[f] = row
+    rec = np.concatenate(recs)
+    rec = rec[rng.permutation(len(rec))]                       # the order of the records is free
+    assert len(rec) > 1500
+    d_co = torch.from_numpy(coeffs.copy()).cuda()
+    aac.apply_tns_batch(d_co, torch.from_numpy(rec.view(np.uint8).reshape(len(rec), 92).copy()).cuda(), len(rec), decode)
+    torch.cuda.synchronize()
+    got = d_co.cpu().numpy()
+    assert (want != coeffs).sum() > 100000
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frames differing: %s" % np.argwhere((got != want).any(axis=1))[:5].ravel()

@@ -1017,6 +1017,62 @@ def test_aac_imdct_and_windowing():
     assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
 
 
+#: FfoAacTnsFilter (oracle/ffo.h)
+TNS_FILTER_DTYPE = np.dtype([("start", np.int32), ("size", np.int32), ("inc", np.int32), ("order", np.int32), ("coef", np.float32, 20)])
+
+
+def aac_tns_case(rng, short):
+    """TemporalNoiseShaping + the IndividualChannelStream fields apply_tns reads, as the bitstream parser leaves them
+    (decode_tns, aacdec.c): reflection coefficients from the tns_tmp2_map tables' range, orders up to the profile's limit"""
+    nw, n = (8, 128) if short else (1, 1024)
+    num_swb = 14 if short else 49
+    cuts = np.sort(rng.choice(np.arange(4, n, 4), num_swb - 1, replace=False))
+    swb = np.concatenate(([0], cuts, [n])).astype(np.uint16)
+    n_filt = np.zeros(8, np.int32); length = np.zeros((8, 4), np.int32); direction = np.zeros((8, 4), np.int32)
+    order = np.zeros((8, 4), np.int32); coef = np.zeros((8, 4, 20), np.float32)
+    for w in range(nw):
+        n_filt[w] = rng.integers(0, 2 if short else 4)
+        for f in range(n_filt[w]):
+            length[w, f] = rng.integers(1, num_swb)
+            direction[w, f] = rng.integers(0, 2)
+            order[w, f] = rng.integers(0, 8 if short else 21)
+            coef[w, f, :order[w, f]] = np.sin(rng.uniform(-1.4, 1.4, order[w, f])).astype(np.float32)
+    tns_max_bands = int(rng.integers(num_swb // 2, num_swb + 1))
+    max_sfb = int(rng.integers(num_swb // 2, num_swb + 1)) if rng.integers(0, 8) else 0
+    return dict(n_filt=n_filt, length=length, direction=direction, order=order, coef=coef, num_windows=nw, num_swb=num_swb, swb=swb,
+                tns_max_bands=tns_max_bands, max_sfb=max_sfb)
+
+
+def aac_tns_filters(O, c):
+    rec = np.zeros(32, TNS_FILTER_DTYPE)
+    n = O.ffo_aac_tns_filters(rec.ctypes.data, ptr(c["n_filt"], i32p), ptr(c["length"], i32p), ptr(c["direction"], i32p), ptr(c["order"], i32p),
+                              ptr(c["coef"], f32p), c["num_windows"], c["num_swb"], c["swb"].ctypes.data_as(C.POINTER(C.c_uint16)),
+                              c["tns_max_bands"], c["max_sfb"])
+    return rec[:n]
+
+
+def test_aac_apply_tns():
+    """AACDecDSP.apply_tns, float: the decoder's all-pole filter and the LTP path's moving-average one, long and short windows,
+    both directions, orders 0..20, band limits that clip or empty the range - bit-identical"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(2720)
+    nrec = 0
+    for rep in range(300):
+        c = aac_tns_case(rng, rep & 1)
+        decode = int(rep % 3 != 0)
+        a = (rng.standard_normal(1024) * 10.0 ** float(rng.integers(-2, 4))).astype(np.float32)
+        b = a.copy()
+        assert R.ffref_aac_apply_tns(ptr(a, f32p), ptr(c["n_filt"], i32p), ptr(c["length"], i32p), ptr(c["direction"], i32p), ptr(c["order"], i32p),
+                                     ptr(c["coef"], f32p), c["num_windows"], c["num_swb"], c["swb"].ctypes.data_as(C.POINTER(C.c_uint16)),
+                                     c["tns_max_bands"], c["max_sfb"], decode) == 0
+        rec = aac_tns_filters(O, c)
+        nrec += len(rec)
+        for r in rec:
+            O.ffo_aac_tns_run(ptr(b, f32p), r.ctypes.data if hasattr(r, "ctypes") else np.array(r).ctypes.data, decode)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (rep, decode)
+    assert nrec > 300
+
+
 @pytest.mark.parametrize("inv", [0, 1])
 def test_mdct_vs_naive(inv):
     """the float transform stays within 2^-18 * max|ref| of the double-precision cosine sum"""
