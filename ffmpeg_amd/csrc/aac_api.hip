@@ -7,12 +7,14 @@
  * function of the current frame's MDCT output buf[] alone, and out[] needs the previous frame's `saved` only.  So a run of frames
  * is three data-parallel steps —
  *   1. buf[f]   = one 1024-point or eight 128-point inverse MDCTs (ffhip_tx_batch_dev, one launch per run of equal kind);
- *   2. tail[f]  = the overlap state frame f leaves behind (k_aac_tail: windowed short-block overlaps or a copy);
+ *   2. tail[f]  = the overlap state frame f leaves behind (k_aac_tail: windowed short-block overlaps; a long frame's tail is
+ *                 simply the upper half of buf[f] and is read from there);
  *   3. out[f]   = overlap of tail[f - 1] (the caller's `saved` for the first frame) with buf[f]'s head under the previous frame's
  *                 window shape (k_aac_out);
  * then the last frame's tail is the caller's new `saved`.  Each output sample is one element of an AVFloatDSPContext
  * .vector_fmul_window call (libavutil/float_dsp.c:79-97) or a copy, evaluated with the same two products and one sum:
- * bit-identical.  HBM traffic per frame: coeffs 4 KB in, buf 4 KB out + in twice, tail 2 KB out + in, out 4 KB: 24 KB (+8 KB when
+ * bit-identical.  HBM traffic per long frame: coeffs 4 KB in, buf 4 KB out, buf 4 KB + the previous buf's upper 2 KB in, out 4 KB
+ * out: 18 KB (a short frame adds its 2 KB tail out and in and a second read of buf; +8 KB per frame when
  * a batch with many transient frames is first sorted by transform kind).
  */
 #include <string.h>
@@ -32,35 +34,50 @@ struct FFHipAacImdct {
     std::mutex mu;
 };
 
-/* element e of vector_fmul_window(dst, src0, src1, win, len) */
-__device__ __forceinline__ float aac_wov(const float *src0, const float *src1, const float *win, int len, int e)
+__device__ __forceinline__ float4 aac_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 aac_ld4r(const float *p) /* p[3], p[2], p[1], p[0] */
 {
-    const bool lo = e < len;
-    const int t = lo ? e : 2 * len - 1 - e;
-    const float a = src0[t], b = src1[len - 1 - t], wi = win[t], wj = win[2 * len - 1 - t];
-    return lo ? a * wj - b * wi : a * wi + b * wj;
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    return make_float4(v.w, v.z, v.y, v.x);
+}
+
+/* elements e..e+3 (e a multiple of 4) of vector_fmul_window(dst, src0, src1, win, len): four 16-byte loads, the descending
+ * operands reversed in registers; per element the reference's two products and one sum */
+__device__ __forceinline__ float4 aac_wov4(const float *src0, const float *src1, const float *win, int len, int e)
+{
+    if (e < len) {
+        const float4 a = aac_ld4(src0 + e), b = aac_ld4r(src1 + len - 4 - e), wi = aac_ld4(win + e), wj = aac_ld4r(win + 2 * len - 4 - e);
+        return make_float4(a.x * wj.x - b.x * wi.x, a.y * wj.y - b.y * wi.y, a.z * wj.z - b.z * wi.z, a.w * wj.w - b.w * wi.w);
+    }
+    const int t = 2 * len - 4 - e; /* the lowest of the four mirrored positions */
+    const float4 a = aac_ld4r(src0 + t), b = aac_ld4(src1 + len - 4 - t), wi = aac_ld4r(win + t), wj = aac_ld4(win + e);
+    return make_float4(a.x * wi.x + b.x * wj.x, a.y * wi.y + b.y * wj.y, a.z * wi.z + b.z * wj.z, a.w * wi.w + b.w * wj.w);
 }
 
 /* info byte: sequence | kb << 2 | previous sequence << 3 | previous kb << 5 */
-/* pos: where frame f's buf[] lives when the frames were sorted by transform kind (nullptr: at f) */
-__global__ __launch_bounds__(256) void k_aac_tail(const float *buf, const int *pos, const uint8_t *info, const float *win, float *tail)
+/* pos: where frame f's buf[] lives when the frames were sorted by transform kind (nullptr: at f).  One thread = 4 samples. */
+__global__ __launch_bounds__(128) void k_aac_tail(const float *buf, const int *pos, const uint8_t *info, const float *win, float *tail,
+                                                  int first_final)
 {
     const int f = blockIdx.x;
     const float *b = buf + (size_t)(pos ? pos[f] : f) * 1024;
     const int in = info[f], seq = in & 3;
+    /* a long frame's tail is the upper half of its buf[]: k_aac_out reads it there; only the batch's last frames (the state handed
+     * back to the caller) are copied out */
+    if (seq != AAC_EIGHT_SHORT && f < first_final)
+        return;
     const float *swindow = win + ((in >> 2) & 1 ? 3 : 1) * 1024;
-    for (int s = threadIdx.x; s < 512; s += 256) {
-        float v;
-        if (seq != AAC_EIGHT_SHORT || s >= 448) {
-            v = b[512 + s]; /* LONG_START's two copies (448 + 64 samples) are this one range as well */
-        } else if (s < 64) {
-            v = aac_wov(b + 448, b + 512, swindow, 64, 64 + s);
-        } else {
-            const int q = (s - 64) >> 7, e = (s - 64) & 127;
-            v = aac_wov(b + (4 + q) * 128 + 64, b + (5 + q) * 128, swindow, 64, e);
-        }
-        tail[(size_t)f * 512 + s] = v;
+    const int s = 4 * threadIdx.x;
+    float4 v;
+    if (seq != AAC_EIGHT_SHORT || s >= 448) {
+        v = aac_ld4(b + 512 + s); /* LONG_START's two copies (448 + 64 samples) are this one range as well */
+    } else if (s < 64) {
+        v = aac_wov4(b + 448, b + 512, swindow, 64, 64 + s);
+    } else {
+        const int q = (s - 64) >> 7, e = (s - 64) & 127;
+        v = aac_wov4(b + (4 + q) * 128 + 64, b + (5 + q) * 128, swindow, 64, e);
     }
+    *reinterpret_cast<float4 *>(tail + (size_t)f * 512 + s) = v;
 }
 
 __global__ __launch_bounds__(256) void k_aac_out(const float *buf, const int *pos, const uint8_t *info, const float *win, const float *tail,
@@ -68,28 +85,29 @@ __global__ __launch_bounds__(256) void k_aac_out(const float *buf, const int *po
 {
     const int f = blockIdx.x;
     const float *b = buf + (size_t)(pos ? pos[f] : f) * 1024;
-    const float *sv = f < nch ? saved + (size_t)f * 512 : tail + (size_t)(f - nch) * 512;
     const int in = info[f], seq = in & 3, pseq = (in >> 3) & 3, pkb = (in >> 5) & 1;
+    const float *sv = f < nch                    ? saved + (size_t)f * 512
+                      : pseq != AAC_EIGHT_SHORT ? buf + (size_t)(pos ? pos[f - nch] : f - nch) * 1024 + 512
+                                                : tail + (size_t)(f - nch) * 512;
     const float *swindow = win + ((in >> 2) & 1 ? 3 : 1) * 1024, *lwindow_prev = win + (pkb ? 2 : 0) * 1024, *swindow_prev = win + (pkb ? 3 : 1) * 1024;
     const bool long_long = (pseq == AAC_ONLY_LONG || pseq == AAC_LONG_STOP) && (seq == AAC_ONLY_LONG || seq == AAC_LONG_START);
-    for (int o = threadIdx.x; o < 1024; o += 256) {
-        float v;
-        if (long_long) {
-            v = aac_wov(sv, b, lwindow_prev, 512, o);
-        } else if (o < 448) {
-            v = sv[o];
-        } else if (o < 576) {
-            v = aac_wov(sv + 448, b, swindow_prev, 64, o - 448);
-        } else if (seq != AAC_EIGHT_SHORT) {
-            v = b[o - 512];
-        } else if (o < 960) {
-            const int q = (o - 576) >> 7;
-            v = aac_wov(b + q * 128 + 64, b + (q + 1) * 128, swindow, 64, (o - 576) & 127);
-        } else {
-            v = aac_wov(b + 448, b + 512, swindow, 64, o - 960);
-        }
-        out[(size_t)f * 1024 + o] = v;
+    const int o = 4 * threadIdx.x; /* the region borders 448 / 576 / 960 are multiples of 4 */
+    float4 v;
+    if (long_long) {
+        v = aac_wov4(sv, b, lwindow_prev, 512, o);
+    } else if (o < 448) {
+        v = aac_ld4(sv + o);
+    } else if (o < 576) {
+        v = aac_wov4(sv + 448, b, swindow_prev, 64, o - 448);
+    } else if (seq != AAC_EIGHT_SHORT) {
+        v = aac_ld4(b + o - 512);
+    } else if (o < 960) {
+        const int q = (o - 576) >> 7;
+        v = aac_wov4(b + q * 128 + 64, b + (q + 1) * 128, swindow, 64, (o - 576) & 127);
+    } else {
+        v = aac_wov4(b + 448, b + 512, swindow, 64, o - 960);
     }
+    *reinterpret_cast<float4 *>(out + (size_t)f * 1024 + o) = v;
 }
 
 /* sorted[pos[f]] = coeffs[f]: 16 bytes per thread */
@@ -154,6 +172,10 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
     const size_t n = (size_t)nch * nframes;
     if (!n)
         return 0;
+    if (((uintptr_t)coeffs | (uintptr_t)out | (uintptr_t)saved) & 15) {
+        ffhip_set_error("ffhip_aac_imdct_and_windowing: coeffs, out and saved must be 16-byte aligned");
+        return FFHIP_EINVAL;
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     hipStream_t st = (hipStream_t)stream;
     std::vector<uint8_t> info(n);
@@ -200,10 +222,6 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
             pos[i] = (int)(window_sequence[i] != AAC_EIGHT_SHORT ? il++ : is++);
         if (hipMemcpyAsync(dpos, pos.data(), n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
             return FFHIP_EINVAL;
-        if (((uintptr_t)coeffs & 15)) {
-            ffhip_set_error("ffhip_aac_imdct_and_windowing: coeffs must be 16-byte aligned");
-            return FFHIP_EINVAL;
-        }
         hipLaunchKernelGGL(k_aac_gather, dim3((unsigned)n), dim3(256), 0, st, (const float4 *)coeffs, dpos, (float4 *)sorted);
         int r = nlong ? ffhip_tx_batch_dev(c->tx1024, buf, 4096, sorted, 4096, sizeof(float), (int)nlong, stream) : 0;
         if (r >= 0 && n > nlong)
@@ -224,7 +242,7 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
             i = j;
         }
     }
-    hipLaunchKernelGGL(k_aac_tail, dim3((unsigned)n), dim3(256), 0, st, buf, dpos, dinfo, c->win, tail);
+    hipLaunchKernelGGL(k_aac_tail, dim3((unsigned)n), dim3(128), 0, st, buf, dpos, dinfo, c->win, tail, (int)(n - nch));
     hipLaunchKernelGGL(k_aac_out, dim3((unsigned)n), dim3(256), 0, st, buf, dpos, dinfo, c->win, tail, saved, nch, out);
     LAUNCH_CHECK();
     if (hipMemcpyAsync(saved, tail + (n - nch) * 512, (size_t)nch * 512 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -301,15 +319,22 @@ extern "C" int ffhip_aac_tns_filters(FFHipAacTnsFilter *out, int frame, const in
 
 /* One lane per filter: the recursion along frequency is serial, a batch has thousands of filters.  lpc[] and the history stay in
  * registers (everything is unrolled to TNS_MAX_ORDER with the order as a guard, so no array is indexed dynamically); products and
- * sums are separate operations in the reference's order. */
+ * sums are separate operations in the reference's order.  The 64 filters of a wave live in 64 different frames, so a lane walking
+ * its own range would touch a cache line per sample (measured: 2.9 GB of traffic for 0.37 GB of coefficients).  The ranges are
+ * therefore moved in 64-sample chunks through LDS: the wave reads filter j's next 64 samples with one coalesced 256-byte access
+ * (ascending or descending), lane l then filters row l, and the chunk goes back the same way. */
 template <bool DECODE>
 __global__ __launch_bounds__(64) void k_aac_tns(float *coeffs, const FFHipAacTnsFilter *filters, int n)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n)
-        return;
-    const FFHipAacTnsFilter *F = filters + g;
-    const int order = F->order, size = F->size, inc = F->inc;
+    __shared__ float chunk[64][65]; /* row pitch 65: lane l's walk along its row hits bank (l + k) % 32 */
+    __shared__ long long s_off[64];
+    __shared__ int s_inc[64], s_size[64];
+    const int lane = threadIdx.x, g = blockIdx.x * 64 + lane;
+    const FFHipAacTnsFilter *F = filters + (g < n ? g : 0);
+    const int order = g < n ? F->order : 0, size = g < n ? F->size : 0;
+    s_off[lane] = (long long)F->frame * 1024 + F->start;
+    s_inc[lane] = F->inc;
+    s_size[lane] = size;
     float lpc[20], hist[20];
     /* compute_lpc_coefs(coef, 0, order, lpc, 0, 0, 0, NULL), libavcodec/lpc_functions.h:54-103: the step-up recursion in place */
 #pragma unroll
@@ -330,20 +355,38 @@ __global__ __launch_bounds__(64) void k_aac_tns(float *coeffs, const FFHipAacTns
             }
         }
     }
-    float *p = coeffs + (size_t)F->frame * 1024 + F->start;
-    for (int m = 0; m < size; m++, p += inc) {
-        const int lim = m < order ? m : order;
-        const float in = *p;
-        float x = in;
+    int longest = size;
 #pragma unroll
-        for (int i = 0; i < 20; i++)
-            if (i < lim)
-                x = DECODE ? x - hist[i] * lpc[i] : x + hist[i] * lpc[i];
-        *p = x;
+    for (int d = 32; d > 0; d >>= 1) {
+        const int o = __shfl_xor(longest, d);
+        longest = o > longest ? o : longest;
+    }
+    __syncthreads();
+    for (int c = 0; c < longest; c += 64) {
+        for (int j = 0; j < 64; j++)
+            if (c + lane < s_size[j])
+                chunk[j][lane] = coeffs[s_off[j] + (long long)(c + lane) * s_inc[j]];
+        __syncthreads();
+        const int end = size - c < 64 ? size - c : 64;
+        for (int k = 0; k < end; k++) {
+            const int m = c + k, lim = m < order ? m : order;
+            const float in = chunk[lane][k];
+            float x = in;
 #pragma unroll
-        for (int i = 19; i > 0; i--)
-            hist[i] = hist[i - 1];
-        hist[0] = DECODE ? x : in; /* the all-pole filter feeds back its outputs, the moving average remembers its inputs */
+            for (int i = 0; i < 20; i++)
+                if (i < lim)
+                    x = DECODE ? x - hist[i] * lpc[i] : x + hist[i] * lpc[i];
+            chunk[lane][k] = x;
+#pragma unroll
+            for (int i = 19; i > 0; i--)
+                hist[i] = hist[i - 1];
+            hist[0] = DECODE ? x : in; /* the all-pole filter feeds back its outputs, the moving average remembers its inputs */
+        }
+        __syncthreads();
+        for (int j = 0; j < 64; j++)
+            if (c + lane < s_size[j])
+                coeffs[s_off[j] + (long long)(c + lane) * s_inc[j]] = chunk[j][lane];
+        __syncthreads();
     }
 }
 

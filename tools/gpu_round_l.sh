@@ -15,6 +15,8 @@ timeout 300 python tools/bench_pfa.py > $OUT/bench_pfa.log 2>&1
 tail -3 $OUT/bench_pfa.log
 timeout 200 python tools/bench_h264_pred.py > $OUT/bench_h264_pred.log 2>&1
 tail -4 $OUT/bench_h264_pred.log
+timeout 200 python tools/bench_aac.py > $OUT/bench_aac.log 2>&1
+tail -3 $OUT/bench_aac.log
 cd /tmp && export TMPDIR=/tmp
 for c in "1024 0" "1024 1"; do
     set -- $c
