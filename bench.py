@@ -362,6 +362,49 @@ def extras(torch, dev):
     out["hevc_qpel_uni16_mixed"] = {"Mpixels/s": round(px / (ms * 1e-3) / 1e6, 1), "GB/s": round(2 * px / (ms * 1e-3) / 1e9, 1),
                                     "hbm_frac": round(2 * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "blocks": int(by.size),
                                     "ms": round(ms, 4)}
+    del refp, pic
+    # AAC imdct_and_windowing: 65,536 all-long channel-frames (2 channels), inverse MDCT -> window -> overlap-add resident in HBM:
+    # 18,432 B per channel-frame (ffmpeg_amd/csrc/aac_api.hip).  Window tables: the decoder's own, from the committed fixture.
+    from ffmpeg_amd import aac
+    gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "aac.npz"))
+    actx = aac.AacImdct([gd[k] for k in ("sine_1024", "sine_128", "kbd_long_1024", "kbd_short_128")])
+    nch, nfr = 2, 32768
+    aco = torch.randn((nfr, nch, 1024), dtype=torch.float32, device=dev) * 1000
+    aout = torch.empty_like(aco)
+    asv = torch.zeros((nch, 512), dtype=torch.float32, device=dev)
+    aseq, az = np.zeros((nfr, nch), np.uint8), np.zeros(nch, np.uint8)
+    for _ in range(2):
+        actx.batch(aco, aout, asv, aseq, aseq + 1, az, az)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        actx.batch(aco, aout, asv, aseq, aseq + 1, az, az)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    gbs = nch * nfr * 18432 / (ms * 1e-3) / 1e9
+    out["aac_imdct_and_windowing_long"] = {"Mframes/s": round(nch * nfr / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1),
+                                           "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "channel_frames": nch * nfr, "ms": round(ms, 4)}
+    actx.close()
+    del aco, aout
+    # float DCT-III (AV_TX_FLOAT_DCT inverse), N = 1024, 65,536 transforms: 8,192 B per transform
+    nt, ln = 65536, 1024
+    f = tx.TxContext(tx.FLOAT_DCT, 1, ln >> 1, 1.0)
+    tin = torch.rand((nt, ln), dtype=torch.float32, device=dev)
+    tout = torch.empty((nt, ln), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        f.batch(tout, tin)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(10):
+        f.batch(tout, tin)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    gbs = nt * 8192 / (ms * 1e-3) / 1e9
+    out["dct3_1024"] = {"Mtransforms/s": round(nt / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "transforms": nt, "ms": round(ms, 4)}
+    f.close()
     return out
 
 

@@ -21,12 +21,12 @@ cd /tmp && export TMPDIR=/tmp
 for c in "1024 0" "1024 1"; do
     set -- $c
     rm -rf /tmp/prof_dct
-    timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_dct -o dct -- python $R/tools/run_tx.py $1 $2 9 > /dev/null 2>&1
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dct -o dct -- python $R/tools/run_tx.py $1 $2 9 > /dev/null 2>&1
     f=$(find /tmp/prof_dct -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && cp $f $OUT/dct$1_$2_kernel_stats.csv
 done
 rm -rf /tmp/prof_pred
-timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_pred -o pred -- python $R/tools/bench_h264_pred.py > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pred -o pred -- python $R/tools/bench_h264_pred.py > /dev/null 2>&1
 f=$(find /tmp/prof_pred -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $OUT/h264_pred_kernel_stats.csv
 ls $OUT | tail -20
