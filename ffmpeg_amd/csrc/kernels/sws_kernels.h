@@ -87,6 +87,32 @@ void ffhip_cw_plan_job(FFHipCwJob *j, int groups_per_lane, int strip_target);
 int  ffhip_launch_colwalk(FFHipCwArgs &A, int luma_groups, int depth, hipStream_t stream);
 
 /*
+ * Exact-2x fast path (sws_up2.hip): 4-tap banks re-expressed on the regular windows of the edge-replicated rows.
+ * A job is one plane (pair 0: 8 output columns per lane) or one byte-interleaved U/V pair (pair 1: 4 + 4 per lane).
+ */
+struct FFHipUp2Job {
+    const uint8_t *src; uint8_t *dst;   /* pair: the interleaved plane (the lower of the two channel pointers) */
+    ptrdiff_t sstride, dstride;
+    size_t sfp, dfp;
+    int pair, swap;                     /* swap: the channel at the EVEN destination bytes sits at the ODD source bytes */
+    int srcW, srcH;                     /* samples per channel; the destination is 2 srcW x 2 srcH */
+    int ngroups;                        /* 8-byte destination groups per row: plane srcW / 4, pair srcW / 2 */
+    const uint32_t *hfv;                /* device: virtual horizontal bank, 2 srcW x 2 dwords */
+    const uint32_t *vfv;                /* device: virtual vertical bank, row y at dwords 2 (y + 1): (2 srcH + 18) x 2 dwords, 16-byte aligned */
+    int ncb, nstrips, steps_per_strip, unit_begin;
+};
+struct FFHipUp2Args {
+    FFHipUp2Job job[3];
+    int njobs, units_per_pack, npacks, nframes, fshift; /* a wave serves 1 << fshift frames (64 >> fshift lanes each) */
+};
+#ifdef __cplusplus
+#include <vector>
+int  ffhip_up2_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, std::vector<uint32_t> *out);
+#endif
+void ffhip_up2_plan_job(FFHipUp2Job *j, int lanes_per_frame, int want_steps);
+int  ffhip_launch_up2(FFHipUp2Args &A, int depth, int hipk, hipStream_t stream);
+
+/*
  * MFMA-horizontal variant of the fast path (k_sws_mfma in sws_colwalk.hip): a job is one plane or one
  * byte-interleaved U/V pair (NV12/NV21 in and out).
  */

@@ -1,0 +1,415 @@
+/*
+ * sws_up2.hip — the fused H+V scaler for EXACT 2x up-scaling with 4-tap banks in both directions (bicubic / bilinear /
+ * point 1080p -> 4K: BASELINE config "swscale bicubic 1080p->4K nv12, 256-frame batch"), planes and byte-interleaved
+ * U/V pairs (NV12 / NV21) in and out.
+ *
+ * Arithmetic: hScale8To15_c (libswscale/swscale.c:128-142), nv12ToUV_c (input.c:936), yuv2planeX_8_c / yuv2nv12cX_c
+ * (output.c:468-529) — int32 sums, >> 7 and min(., 32767) for the horizontal pass, the 64 << 12 seed, >> 19 and the clip
+ * to 8 bits for the vertical one.  Same results as sws_colwalk.hip / sws_scale.hip, bit for bit (tests/test_gpu_sws_fast.py).
+ *
+ * What exact 2x buys over the general column walker (sws_colwalk.hip, 7.0 VALU instructions per output sample, VALU-bound):
+ *
+ *  - Window positions are REGULAR: output x = 2j + ph reads source samples j - 2 + ph .. j + 1 + ph.  initFilter()
+ *    (libswscale/utils.c:519-561) folds the taps that fall outside the row onto the first / last sample, i.e. the bank
+ *    is the regular one over an edge-REPLICATED row — with its own, renormalised coefficients in the three columns next
+ *    to either edge.  The host re-expresses every bank row as four coefficients on the regular window of the replicated
+ *    row (ffhip_up2_virtual_bank, verified tap by tap, else this kernel is not used), so a lane needs no position
+ *    table and no byte selectors of its own: 8 adjacent output columns read 8 adjacent source bytes, and the SEVEN
+ *    distinct (s[k], s[k+1]) int16 pairs of those bytes serve all sixteen v_dot2_i32_i16 of the row (12 v_perm_b32 per 8
+ *    samples in the general kernel).  Replication is a 2-instruction fix-up that only the waves at a row's ends execute.
+ *  - The vertical schedule is STATIC: after source row r both output rows 2r-3 and 2r-2 are due, and both read rows
+ *    r-3 .. r (clamped = replicated).  No `need` bookkeeping, no v_readlane: the rows' coefficient pairs arrive through
+ *    scalar loads (one s_load_dwordx8 per two steps) and sit in SGPRs, the one scalar operand a VOP3P instruction takes.
+ *  - The two halves of an output dword are written by v_ashr_pk_u8_i32 and v_ashr_pk_u8_i32 op_sel:[0,0,0,1] (the
+ *    high-half form keeps the low half): no merging v_perm.  Dots, shifts and packs of a row are one hand-scheduled asm
+ *    block in which every DOT result is consumed >= 3 instructions after it was written (the gfx950 DOT hazard).
+ *  - Source rows are consumed in place (the prefetch of a buffer slot is issued after its row was filtered): no copies.
+ *
+ * Per 16 output samples: 39 (horizontal, once per source row) + 2 x 20 (vertical) VALU instructions = 4.9 per sample.
+ *
+ * Geometry: a wave owns 64 lanes x 8 output bytes of a strip of rows and walks down the source rows.  When a row does
+ * not fill a whole number of waves (3840 columns = 7.5 x 512) the wave is split between 2 or 4 FRAMES of the batch
+ * (the same strip and columns of frames f, f+1: identical schedule, the frame pitch is part of the lane offset), so no
+ * lane idles at the right edge.
+ */
+#include <stdlib.h>
+#include <vector>
+
+#include "common.h"
+#include "sws_kernels.h"
+
+typedef uint32_t up_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t up_u3 __attribute__((ext_vector_type(3)));
+typedef uint32_t up_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t up_u8 __attribute__((ext_vector_type(8)));
+typedef up_u3 __attribute__((aligned(4))) up_u3a;
+typedef const uint8_t __attribute__((address_space(1))) *up_gcp;
+typedef uint8_t __attribute__((address_space(1))) *up_gp;
+typedef const up_u3a __attribute__((address_space(1))) *up_gc3;
+typedef up_u2 __attribute__((address_space(1))) *up_g2;
+typedef const up_u8 __attribute__((address_space(4))) *up_cc8; /* constant address space: scalar loads */
+
+struct UpRaw { uint32_t q[3]; };
+
+/*
+ * Four horizontal samples: d[i] = (pa[i] . ca[i] + pb[i] . cb[i]) >> 7.  The two DOT chains per sample are interleaved
+ * four wide; each result is shifted three instructions after its last DOT wrote it, and leaves the block as the
+ * result of a plain VALU instruction.
+ */
+__device__ __forceinline__ void up_h4(int (&d)[4], uint32_t pa0, uint32_t pa1, uint32_t pa2, uint32_t pa3, uint32_t pb0,
+                                      uint32_t pb1, uint32_t pb2, uint32_t pb3, const uint32_t *cf)
+{
+    asm("v_dot2_i32_i16 %0, %4, %12, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %13, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %14, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %15, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %18, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "v_ashrrev_i32 %0, 7, %0\n\t"
+        "v_ashrrev_i32 %1, 7, %1\n\t"
+        "v_ashrrev_i32 %2, 7, %2\n\t"
+        "v_ashrrev_i32 %3, 7, %3"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3), "v"(pb0), "v"(pb1), "v"(pb2), "v"(pb3),
+          "v"(cf[0]), "v"(cf[2]), "v"(cf[4]), "v"(cf[6]), "v"(cf[1]), "v"(cf[3]), "v"(cf[5]), "v"(cf[7]));
+}
+
+/*
+ * One output row of 8 samples: t[i] = kround + pa[i] . f01 + pb[i] . f23, bytes clip_u8(t[i] >> 19) packed in sample order.
+ * HIPK: the upper halves are written by the op_sel form of v_ashr_pk_u8_i32; else merged with v_perm_b32.
+ */
+template <bool HIPK>
+__device__ __forceinline__ void up_v8(uint32_t &w0, uint32_t &w1, const uint32_t (&pa)[8], const uint32_t (&pb)[8], uint32_t f01,
+                                      uint32_t f23, int kround)
+{
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    if (HIPK) {
+        asm("v_dot2_i32_i16 %2, %10, %26, %28\n\t"
+            "v_dot2_i32_i16 %3, %11, %26, %28\n\t"
+            "v_dot2_i32_i16 %4, %12, %26, %28\n\t"
+            "v_dot2_i32_i16 %5, %13, %26, %28\n\t"
+            "v_dot2_i32_i16 %6, %14, %26, %28\n\t"
+            "v_dot2_i32_i16 %7, %15, %26, %28\n\t"
+            "v_dot2_i32_i16 %8, %16, %26, %28\n\t"
+            "v_dot2_i32_i16 %9, %17, %26, %28\n\t"
+            "v_dot2_i32_i16 %2, %18, %27, %2\n\t"
+            "v_dot2_i32_i16 %3, %19, %27, %3\n\t"
+            "v_dot2_i32_i16 %4, %20, %27, %4\n\t"
+            "v_dot2_i32_i16 %5, %21, %27, %5\n\t"
+            "v_dot2_i32_i16 %6, %22, %27, %6\n\t"
+            "v_dot2_i32_i16 %7, %23, %27, %7\n\t"
+            "v_dot2_i32_i16 %8, %24, %27, %8\n\t"
+            "v_dot2_i32_i16 %9, %25, %27, %9\n\t"
+            "v_ashr_pk_u8_i32 %0, %2, %3, 19\n\t"
+            "v_ashr_pk_u8_i32 %1, %6, %7, 19\n\t"
+            "v_ashr_pk_u8_i32 %0, %4, %5, 19 op_sel:[0,0,0,1]\n\t"
+            "v_ashr_pk_u8_i32 %1, %8, %9, 19 op_sel:[0,0,0,1]"
+            : "=&v"(w0), "=&v"(w1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+            : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7]),
+              "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]), "v"(pb[6]), "v"(pb[7]),
+              "s"(f01), "s"(f23), "v"(kround));
+    } else {
+        asm("v_dot2_i32_i16 %0, %8, %24, %26\n\t"
+            "v_dot2_i32_i16 %1, %9, %24, %26\n\t"
+            "v_dot2_i32_i16 %2, %10, %24, %26\n\t"
+            "v_dot2_i32_i16 %3, %11, %24, %26\n\t"
+            "v_dot2_i32_i16 %4, %12, %24, %26\n\t"
+            "v_dot2_i32_i16 %5, %13, %24, %26\n\t"
+            "v_dot2_i32_i16 %6, %14, %24, %26\n\t"
+            "v_dot2_i32_i16 %7, %15, %24, %26\n\t"
+            "v_dot2_i32_i16 %0, %16, %25, %0\n\t"
+            "v_dot2_i32_i16 %1, %17, %25, %1\n\t"
+            "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
+            "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
+            "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
+            "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
+            "v_dot2_i32_i16 %6, %22, %25, %6\n\t"
+            "v_dot2_i32_i16 %7, %23, %25, %7\n\t"
+            "v_ashr_pk_u8_i32 %0, %0, %1, 19\n\t"
+            "v_ashr_pk_u8_i32 %2, %2, %3, 19\n\t"
+            "v_ashr_pk_u8_i32 %4, %4, %5, 19\n\t"
+            "v_ashr_pk_u8_i32 %6, %6, %7, 19"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+            : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7]),
+              "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]), "v"(pb[6]), "v"(pb[7]),
+              "s"(f01), "s"(f23), "v"(kround));
+        w0 = __builtin_amdgcn_perm((uint32_t)t2, (uint32_t)t0, 0x05040100);
+        w1 = __builtin_amdgcn_perm((uint32_t)t6, (uint32_t)t4, 0x05040100);
+    }
+}
+
+/*
+ * One unit = one wave.  PAIR 0: a plane, 8 output columns per lane.  PAIR 1: a byte-interleaved U/V pair, 4 + 4 output
+ * samples per lane.  Either way a lane reads the 12 source bytes at 4g - 4 of every source row and writes the 8
+ * destination bytes at 8g of two destination rows per source row (g = the lane's group in the row).
+ * D = source rows in flight (3 or 6); the ring of vertical pairs has 3 slots, so D | 6 keeps every index static.
+ */
+template <int PAIR, int D, bool HIPK>
+__device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int pack, int strip, int cb, int lane, int fshift, int nframes)
+{
+    const int lpf = 64 >> fshift;                 /* lanes per frame */
+    const int fsub = lane >> (6 - fshift);
+    const int gl = lane & (lpf - 1);
+    const int graw = cb * lpf + gl, fraw = (pack << fshift) + fsub;
+    const bool act = graw < J.ngroups && fraw < nframes;
+    const int g = min(graw, J.ngroups - 1);
+    const int fs = fraw < nframes ? fsub : 0;     /* idle lanes shadow valid ones */
+    const bool lb = g == 0, rb = g == J.ngroups - 1;
+    const bool border = cb == 0 || cb == J.ncb - 1; /* wave-uniform */
+
+    const uint32_t soff = (uint32_t)fs * (uint32_t)J.sfp + (uint32_t)(lb ? 0 : rb ? 4 * g - 8 : 4 * g - 4);
+    const uint32_t doff = (uint32_t)fs * (uint32_t)J.dfp + 8u * (uint32_t)g;
+
+    /* ---- horizontal coefficients of this lane's columns (virtual bank: regular windows of the replicated row) ---- */
+    constexpr int NCF = PAIR ? 8 : 16;
+    uint32_t cf[NCF];
+    {
+        const up_u4 *p = reinterpret_cast<const up_u4 *>(J.hfv) + (size_t)g * (NCF / 4);
+#pragma unroll
+        for (int i = 0; i < NCF / 4; i++) {
+            const up_u4 v = p[i];
+            cf[4 * i] = v.x; cf[4 * i + 1] = v.y; cf[4 * i + 2] = v.z; cf[4 * i + 3] = v.w;
+        }
+    }
+    /* byte selectors: (s[k], s[k+1]) as an int16 pair.  Plane: adjacent bytes, sample b_k = byte k + 2 of the span.
+     * Pair: bytes 2k (+1 for the channel that sits at the odd bytes) and 2k + 2. */
+    const uint32_t par = PAIR ? (J.swap ? 0x00010001u : 0u) : 0u;
+    const uint32_t sA0 = 0x0c020c00u + par, sA1 = 0x0c040c02u + par, sA2 = 0x0c060c04u + par; /* first output channel  */
+    const uint32_t sB0 = 0x0c030c01u - par, sB1 = 0x0c050c03u - par, sB2 = 0x0c070c05u - par; /* second output channel */
+    const uint32_t fixl = PAIR ? 0x01000100u : 0x00000000u, fixr = PAIR ? 0x03020302u : 0x03030303u;
+
+    /* ---- row addressing: scalar running pointers + 32-bit lane offsets ---- */
+    const int S = J.steps_per_strip;
+    const int a = 1 + strip * S, b = min(a + S, J.srcH + 2); /* this strip's steps: step r emits rows 2r-3 and 2r-2 */
+    const uint8_t *sbase = J.src + (size_t)(pack << fshift) * J.sfp;
+    uint8_t *dbase = J.dst + (size_t)(pack << fshift) * J.dfp;
+    const ptrdiff_t sstride = J.sstride, dstride = J.dstride;
+    const int srcH = J.srcH, dstH = 2 * J.srcH;
+    int pr = a - 3;                                               /* next source row to fetch (unclamped) */
+    const uint8_t *pf = sbase + (ptrdiff_t)min(max(pr, 0), srcH - 1) * sstride;
+    uint8_t *dr = dbase + (ptrdiff_t)(2 * a - 3) * dstride;      /* row 2a-3 (row -1 of the first strip is never stored) */
+    asm("" : "+s"(pf), "+s"(dr));
+
+    auto load_next = [&](UpRaw &o) {
+        uint32_t off = soff;
+        asm volatile("" : "+v"(off)); /* keeps `uniform base + zext(lane offset)` next to the access: saddr addressing */
+        const up_u3 w = *(up_gc3)((up_gcp)pf + off);
+        o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z;
+        pr++;
+        pf += (pr >= 1 && pr <= srcH - 1) ? sstride : 0; /* rows above / below the plane replicate the edge row */
+        asm("" : "+s"(pf));
+    };
+
+    uint32_t ring[3][8];
+    int hprev[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        hprev[i] = 0;
+    int kround = 64 << 12;
+    asm volatile("" : "+v"(kround));
+
+    /* horizontal pass of one source row: 8 samples, appended to the ring as (h[r-1], h[r]) pairs (int16-saturated:
+     * equals min(., 32767) + truncation because no sum of the bank can fall below -32768, host-checked) */
+    auto hpass = [&](const UpRaw &w, uint32_t (&Pnew)[8]) {
+        uint32_t v0 = w.q[0], v1 = w.q[1], v2 = w.q[2];
+        if (border) {
+            /* edge replication: the first / last lane of a row loaded its span one dword further inside */
+            const uint32_t f0 = __builtin_amdgcn_perm(w.q[0], w.q[0], fixl), f2 = __builtin_amdgcn_perm(w.q[2], w.q[2], fixr);
+            v0 = lb ? f0 : rb ? w.q[1] : w.q[0];
+            v1 = lb ? w.q[0] : rb ? w.q[2] : w.q[1];
+            v2 = lb ? w.q[1] : rb ? f2 : w.q[2];
+        }
+        int h[8];
+        if (PAIR) {
+            /* channel samples u0..u5 at bytes 0,2,..,10 (or 1,3,..,11); pair k = (u_k, u_k+1) */
+            const uint32_t a0 = __builtin_amdgcn_perm(v1, v0, sA0), a1 = __builtin_amdgcn_perm(v1, v0, sA1);
+            const uint32_t a2 = __builtin_amdgcn_perm(v1, v0, sA2), a3 = __builtin_amdgcn_perm(v2, v1, sA1);
+            const uint32_t a4 = __builtin_amdgcn_perm(v2, v1, sA2);
+            const uint32_t b0 = __builtin_amdgcn_perm(v1, v0, sB0), b1 = __builtin_amdgcn_perm(v1, v0, sB1);
+            const uint32_t b2 = __builtin_amdgcn_perm(v1, v0, sB2), b3 = __builtin_amdgcn_perm(v2, v1, sB1);
+            const uint32_t b4 = __builtin_amdgcn_perm(v2, v1, sB2);
+            int ha[4], hb[4];
+            /* output column c of a channel: window offset o = (c >> 1) + (c & 1) -> pairs o and o + 2 */
+            up_h4(ha, a0, a1, a1, a2, a2, a3, a3, a4, cf);
+            up_h4(hb, b0, b1, b1, b2, b2, b3, b3, b4, cf);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                h[2 * i] = ha[i];
+                h[2 * i + 1] = hb[i];
+            }
+        } else {
+            /* samples b0..b7 = bytes 2..9 of the span */
+            const uint32_t p0 = __builtin_amdgcn_perm(v1, v0, 0x0c030c02u), p1 = __builtin_amdgcn_perm(v1, v0, 0x0c040c03u);
+            const uint32_t p2 = __builtin_amdgcn_perm(v1, v0, 0x0c050c04u), p3 = __builtin_amdgcn_perm(v1, v0, 0x0c060c05u);
+            const uint32_t p4 = __builtin_amdgcn_perm(v1, v0, 0x0c070c06u), p5 = __builtin_amdgcn_perm(v2, v1, 0x0c040c03u);
+            const uint32_t p6 = __builtin_amdgcn_perm(v2, v1, 0x0c050c04u);
+            int hl[4], hh[4];
+            up_h4(hl, p0, p1, p1, p2, p2, p3, p3, p4, cf);
+            up_h4(hh, p2, p3, p3, p4, p4, p5, p5, p6, cf + 8);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                h[i] = hl[i];
+                h[4 + i] = hh[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            Pnew[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[i], h[i]));
+            hprev[i] = h[i];
+        }
+    };
+
+    UpRaw buf[D];
+#pragma unroll
+    for (int k = 0; k < D; k++)
+        load_next(buf[k]);
+    /* rows a-3, a-2, a-1: fill the ring */
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        hpass(buf[k % D], ring[k]);
+        load_next(buf[k % D]);
+    }
+
+    /* vertical coefficient pairs: row y of the virtual bank at dwords 2 (y + 1), 2 (y + 1) + 1; a step reads rows
+     * 2r-3, 2r-2 = 4 consecutive dwords from 4r - 4; two steps per scalar load */
+    const uint32_t *vt = J.vfv;
+    for (int r = a; r < b; r += 6) {
+        up_u8 c8[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            c8[q] = *(up_cc8)(vt + 4 * (r + 2 * q) - 4);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            UpRaw &w = buf[(k + 3) % D];
+            if (r + k < b) { /* uniform */
+                hpass(w, ring[k % 3]);
+                const up_u8 cc = c8[k >> 1];
+                const uint32_t fb01 = k & 1 ? cc.s4 : cc.s0, fb23 = k & 1 ? cc.s5 : cc.s1;
+                const uint32_t fa01 = k & 1 ? cc.s6 : cc.s2, fa23 = k & 1 ? cc.s7 : cc.s3;
+                const int y = 2 * (r + k) - 3;
+                uint32_t w0, w1;
+                up_v8<HIPK>(w0, w1, ring[(k + 1) % 3], ring[k % 3], fb01, fb23, kround);
+                uint32_t off = doff;
+                asm volatile("" : "+v"(off));
+                if (act && y >= 0) {
+                    up_u2 s; s.x = w0; s.y = w1;
+                    *(up_g2)((up_gp)dr + off) = s;
+                }
+                up_v8<HIPK>(w0, w1, ring[(k + 1) % 3], ring[k % 3], fa01, fa23, kround);
+                if (act && y + 1 < dstH) {
+                    up_u2 s; s.x = w0; s.y = w1;
+                    *(up_g2)((up_gp)(dr + dstride) + off) = s;
+                }
+                dr += 2 * dstride;
+                asm("" : "+s"(dr));
+            }
+            load_next(w);
+        }
+    }
+}
+
+template <int D, bool HIPK>
+__global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
+    if (gw >= (uint32_t)A.units_per_pack * (uint32_t)A.npacks)
+        return;
+    const int pack = (int)(gw / (uint32_t)A.units_per_pack);
+    const int u = (int)(gw - (uint32_t)pack * (uint32_t)A.units_per_pack);
+    int j = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
+    const FFHipUp2Job &J = A.job[j];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.pair)
+        up2_unit<1, D, HIPK>(J, pack, strip, cb, lane, A.fshift, A.nframes);
+    else
+        up2_unit<0, D, HIPK>(J, pack, strip, cb, lane, A.fshift, A.nframes);
+}
+
+/* ================================================================================================== */
+/* host side */
+
+/*
+ * Re-express a 4-tap bank of an exact 2x up-scale as coefficients on the REGULAR windows of the edge-replicated row:
+ * output x reads samples clamp(s0 + k), s0 = (x >> 1) - 2 + (x & 1), k = 0..3.  Every non-zero tap of the bank row must
+ * sit on one of those samples; taps the reference folded onto the edge sample land on one of the replicas.  Output: n_dst x 2
+ * dwords, (c0, c1) (c2, c3) as int16 pairs.  Returns 0 when the bank is not of this shape.
+ */
+int ffhip_up2_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, std::vector<uint32_t> *out)
+{
+    if (n_dst != 2 * n_src || n_src < 4)
+        return 0;
+    out->assign((size_t)n_dst * 2, 0);
+    for (int x = 0; x < n_dst; x++) {
+        const int s0 = (x >> 1) - 2 + (x & 1);
+        int16_t v[4] = { 0, 0, 0, 0 };
+        bool used[4] = { false, false, false, false };
+        for (int i = 0; i < 4; i++) {
+            const int16_t c = filter[(size_t)x * 4 + i];
+            if (!c)
+                continue;
+            const int p = pos[x] + i;
+            if (p < 0 || p >= n_src)
+                return 0;
+            int k = 0;
+            for (; k < 4; k++) {
+                int q = s0 + k;
+                q = q < 0 ? 0 : q >= n_src ? n_src - 1 : q;
+                if (q == p && !used[k])
+                    break;
+            }
+            if (k == 4)
+                return 0;
+            used[k] = true;
+            v[k] = c;
+        }
+        (*out)[2 * (size_t)x] = (uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
+        (*out)[2 * (size_t)x + 1] = (uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+    }
+    return 1;
+}
+
+/* strips of `want` steps (a multiple of 6: the row loop is unrolled six times), evened out over the plane */
+void ffhip_up2_plan_job(FFHipUp2Job *j, int lanes_per_frame, int want)
+{
+    const int steps = j->srcH + 1;
+    int n = cdiv(steps, want);
+    int s = cdiv(cdiv(steps, n), 6) * 6;
+    j->steps_per_strip = s;
+    j->nstrips = cdiv(steps, s);
+    j->ncb = cdiv(j->ngroups, lanes_per_frame);
+}
+
+int ffhip_launch_up2(FFHipUp2Args &A, int depth, int hipk, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    int u = 0;
+    for (int i = 0; i < A.njobs; i++) {
+        A.job[i].unit_begin = u;
+        u += A.job[i].ncb * A.job[i].nstrips;
+    }
+    A.units_per_pack = u;
+    A.npacks = (A.nframes + (1 << A.fshift) - 1) >> A.fshift;
+    const long long waves = (long long)u * A.npacks;
+    if (waves >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
+        return FFHIP_EINVAL;
+    }
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (depth == 3) {
+        if (hipk) hipLaunchKernelGGL((k_sws_up2<3, true>), grid, block, 0, stream, A);
+        else      hipLaunchKernelGGL((k_sws_up2<3, false>), grid, block, 0, stream, A);
+    } else {
+        if (hipk) hipLaunchKernelGGL((k_sws_up2<6, true>), grid, block, 0, stream, A);
+        else      hipLaunchKernelGGL((k_sws_up2<6, false>), grid, block, 0, stream, A);
+    }
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -42,6 +42,10 @@ struct FFHipSwsContext {
     std::vector<int32_t> wp[4];
     void *dev_wtables = nullptr;
     FFHipDevFilter dw[4];
+    /* exact-2x fast path (sws_up2.hip): virtual banks (regular windows of the edge-replicated rows) on the device */
+    int up2_ok = 0;
+    void *up2_dev = nullptr;
+    const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
     int mf_ok = 0, mf_chr_pair = 0, mf_ntiles[2] = { 0, 0 };
     void *mf_dev = nullptr;
@@ -54,6 +58,11 @@ struct FFHipSwsContext {
     std::mutex mu;
 };
 
+static bool em_forced()
+{
+    const char *em = getenv("FFHIP_SWS_MFMA");
+    return em && em[0] == '1';
+}
 static bool fmt_yuv(int f) { return f == FFHIP_PIX_FMT_YUV420P || f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
 static bool fmt_nv(int f) { return f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
 /* packed layout number of an RGB target (the kernels' `layout` / `bgr` argument): 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
@@ -347,6 +356,41 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         c->cw_opt = c->cw_ok && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&
                     ffhip_cw_bank_nowrap(c->nf[1].data(), 4, c->d[1].n);
         c->cw_dup = c->cw_opt && ffhip_cw_bank_dup12(c->np[0].data(), c->d[0].n) && ffhip_cw_bank_dup12(c->np[1].data(), c->d[1].n);
+        /* exact 2x in both directions, chroma laid out alike on both sides: the static-schedule kernel (sws_up2.hip) */
+        if (c->cw_opt && l.dstW == 2 * l.srcW && l.dstH == 2 * l.srcH && ch.dstW == 2 * ch.srcW && ch.dstH == 2 * ch.srcH &&
+            fmt_nv(t->srcFormat) == fmt_nv(t->dstFormat) && !(l.srcW & 3) && l.srcW >= 8 &&
+            (fmt_nv(t->srcFormat) ? !(ch.srcW & 1) && ch.srcW >= 4 : !(ch.srcW & 3) && ch.srcW >= 8)) {
+            std::vector<uint32_t> vb[4];
+            const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
+            bool ok = true;
+            for (int i = 0; i < 4 && ok; i++)
+                ok = ffhip_up2_virtual_bank(c->nf[i].data(), c->np[i].data(), c->d[i].n, nsrc[i], &vb[i]) != 0;
+            if (ok) {
+                /* vertical banks: one leading row (y = -1) and 17 trailing ones of zeros (the row loop reads ahead) */
+                for (int i = 2; i < 4; i++) {
+                    std::vector<uint32_t> pv((size_t)(c->d[i].n + 18) * 2, 0);
+                    memcpy(pv.data() + 2, vb[i].data(), vb[i].size() * 4);
+                    vb[i].swap(pv);
+                }
+                size_t uo[4], ut = 0;
+                for (int i = 0; i < 4; i++) {
+                    uo[i] = ut;
+                    ut += (vb[i].size() * 4 + 255) & ~(size_t)255;
+                }
+                if (hipMalloc(&c->up2_dev, ut) == hipSuccess) {
+                    uint8_t *b = static_cast<uint8_t *>(c->up2_dev);
+                    for (int i = 0; i < 4 && ok; i++)
+                        ok = hipMemcpy(b + uo[i], vb[i].data(), vb[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+                    if (ok) {
+                        c->up2_h[0] = reinterpret_cast<const uint32_t *>(b + uo[0]);
+                        c->up2_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
+                        c->up2_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
+                        c->up2_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
+                        c->up2_ok = 1;
+                    }
+                }
+            }
+        }
         /* wide banks (down-scaling, long kernels): the LDS-backed walker; FFHIP_SWS_WIDE=1 builds it for narrow banks
          * too (parity tests of that kernel on up-scaling cases) */
         {
@@ -424,7 +468,7 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -442,6 +486,15 @@ extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *p
     return nt;
 }
 
+extern "C" int ffhip_sws_up2_virtual_bank_host(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, uint32_t *out)
+{
+    std::vector<uint32_t> v;
+    if (!filter || !pos || !out || !ffhip_up2_virtual_bank(filter, pos, n_dst, n_src, &v))
+        return 0;
+    memcpy(out, v.data(), v.size() * 4);
+    return 1;
+}
+
 extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
 {
     if (!c)
@@ -450,6 +503,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->dev_tables);
     if (c->mf_dev)
         (void)hipFree(c->mf_dev);
+    if (c->up2_dev)
+        (void)hipFree(c->up2_dev);
     if (c->dev_ntables)
         (void)hipFree(c->dev_ntables);
     if (c->dev_wtables)
@@ -554,6 +609,62 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             /* an interleaved pair is addressed through its lower pointer */
             al |= ch.src_step == 2 ? (uintptr_t)(ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1]) : (uintptr_t)ch.src[i];
             al |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
+        }
+        const char *eu = getenv("FFHIP_SWS_UP2");
+        if (!(al & 3) && c->up2_ok && !(eu && eu[0] == '0') && !(em_forced())) {
+            /* exact 2x: static schedule, regular windows (sws_up2.hip).  FFHIP_SWS_UP2=0 takes the general column walker. */
+            FFHipUp2Args U;
+            memset(&U, 0, sizeof(U));
+            U.nframes = nframes;
+            auto upjob = [&](const FFHipScalePlaneArgs &p, int which, const uint8_t *src, ptrdiff_t ss, size_t sf, uint8_t *dst,
+                             ptrdiff_t dsr, size_t df, int pair, int swap) {
+                FFHipUp2Job &j = U.job[U.njobs++];
+                j.src = src; j.dst = dst; j.sstride = ss; j.dstride = dsr; j.sfp = sf; j.dfp = df;
+                j.pair = pair; j.swap = swap;
+                j.srcW = p.srcW; j.srcH = p.srcH;
+                j.ngroups = pair ? p.srcW / 2 : p.srcW / 4;
+                j.hfv = c->up2_h[which]; j.vfv = c->up2_v[which];
+            };
+            upjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
+            if (ch.src_step == 2) {
+                const bool ssw = ch.src[1] < ch.src[0], dsw = ch.dst[1] < ch.dst[0];
+                upjob(ch, 1, ssw ? ch.src[1] : ch.src[0], ch.src_stride[0], ch.src_fp[0], dsw ? ch.dst[1] : ch.dst[0],
+                      ch.dst_stride[0], ch.dst_fp[0], 1, ssw != dsw);
+            } else {
+                for (int k = 0; k < 2; k++)
+                    upjob(ch, 1, ch.src[k], ch.src_stride[k], ch.src_fp[k], ch.dst[k], ch.dst_stride[k], ch.dst_fp[k], 0, 0);
+            }
+            /* frames per wave: the split that wastes the fewest lanes at the right edge of the widest job's rows;
+             * lane offsets (frame pitch included) must stay below 2^32 */
+            const char *ef = getenv("FFHIP_UP2_FSHIFT"), *es = getenv("FFHIP_UP2_STRIP"), *ed = getenv("FFHIP_UP2_DEPTH");
+            const char *ek = getenv("FFHIP_UP2_HIPK");
+            int best = 0;
+            double bestw = 1e30;
+            for (int fsft = 0; fsft <= 2; fsft++) {
+                const int lpf = 64 >> fsft;
+                bool fits = true;
+                double w = 0;
+                for (int i = 0; i < U.njobs; i++) {
+                    const FFHipUp2Job &j = U.job[i];
+                    const unsigned long long span_s = (unsigned long long)((1 << fsft) - 1) * j.sfp + (unsigned long long)j.srcH * (size_t)(j.sstride < 0 ? -j.sstride : j.sstride);
+                    const unsigned long long span_d = (unsigned long long)((1 << fsft) - 1) * j.dfp + 2ull * j.srcH * (size_t)(j.dstride < 0 ? -j.dstride : j.dstride);
+                    if (span_s >= (1ull << 31) || span_d >= (1ull << 31))
+                        fits = false;
+                    w += (double)cdiv(j.ngroups, lpf) * lpf * j.srcH;
+                }
+                if (nframes < (1 << fsft) && fsft)
+                    fits = false;
+                if (fits && w < bestw) { bestw = w; best = fsft; }
+            }
+            U.fshift = ef && ef[0] >= '0' && ef[0] <= '2' ? ef[0] - '0' : best;
+            bool neg = false;
+            for (int i = 0; i < U.njobs; i++)
+                neg = neg || U.job[i].sstride < 0 || U.job[i].dstride < 0;
+            if (!neg) {
+                for (int i = 0; i < U.njobs; i++)
+                    ffhip_up2_plan_job(&U.job[i], 64 >> U.fshift, es && atoi(es) > 0 ? atoi(es) : 60);
+                return ffhip_launch_up2(U, ed && ed[0] == '3' ? 3 : 6, !(ek && ek[0] == '0'), stream);
+            }
         }
         if (!(al & 3)) {
             const char *em = getenv("FFHIP_SWS_MFMA");

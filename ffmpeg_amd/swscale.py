@@ -107,6 +107,11 @@ class SwsContext:
         """True when the wide-bank walker (k_sws_lwalk: 5..16 taps, down-scaling) is available for the banks."""
         return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 4)
 
+    @property
+    def up2_path(self):
+        """True when the static-schedule exact-2x kernel (k_sws_up2) serves the banks."""
+        return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 8)
+
     def close(self):
         if getattr(self, "_c", None) and _lib is not None:
             _lib.lib().ffhip_sws_freeContext(self._c)

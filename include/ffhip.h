@@ -116,7 +116,8 @@ void             ffhip_sws_freeContext(FFHipSwsContext *c);
 /** 1 when the context's banks run on the register-resident column-walking kernel (4-tap x 4-tap banks
  *  whose 4-column groups read one 8-byte source span; sws_colwalk.hip), 0 when they take the general
  *  LDS-tiled kernel; bit 1 set when the matrix-core variant (k_sws_mfma) is available too; bit 2 set when the
- *  banks (5..16 taps: down-scaling, long kernels) run on the LDS-backed wide-bank walker (sws_lwalk.hip).
+ *  banks (5..16 taps: down-scaling, long kernels) run on the LDS-backed wide-bank walker (sws_lwalk.hip); bit 3 set when
+ *  the conversion is an exact 2x up-scale served by the static-schedule kernel (sws_up2.hip).
  *  Diagnostic only: results are identical. */
 int              ffhip_sws_fast_path(const FFHipSwsContext *c);
 /** Host-side preparation of the matrix-core horizontal pass (no device needed): turns one 4-tap horizontal
@@ -127,6 +128,13 @@ int              ffhip_sws_fast_path(const FFHipSwsContext *c);
  *  the bank does not fit the tiling.  Exposed for the CPU test-suite. */
 int              ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
                                            uint8_t *out, size_t out_size);
+
+/** Host-side preparation of the exact-2x kernel (no device needed): re-expresses a 4-tap bank of a 2x up-scale (n_dst ==
+ *  2 n_src) as four coefficients per output on the REGULAR window start (x >> 1) - 2 + (x & 1) of the edge-replicated row —
+ *  what initFilter()'s border fold (libswscale/utils.c:519-561) amounts to.  out: n_dst x 2 dwords, (c0, c1) (c2, c3) as
+ *  int16 pairs.  Returns 1, or 0 when some tap of the bank does not sit on its regular window (the kernel is then not
+ *  used).  Exposed for the CPU test-suite. */
+int              ffhip_sws_up2_virtual_bank_host(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, uint32_t *out);
 
 /** Host-table generation alone (no device needed): our initFilter().  `which`: 0 hLum 1 hChr 2 vLum
  *  3 vChr.  Returns filter size or <0; pointers stay valid until ffhip_sws_tables_free().  Used by

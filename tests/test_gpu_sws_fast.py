@@ -50,6 +50,10 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     from ffmpeg_amd import swscale as S
     torch = _torch()
     rng = np.random.default_rng(seed)
+    for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_HIPK"):
+        monkeypatch.delenv(k, raising=False)
+    if need != "up2":
+        monkeypatch.setenv("FFHIP_SWS_UP2", "0")   # these tests are about the general kernels; test_up2* covers sws_up2.hip
     for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
               "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_SWS_WIDE", "FFHIP_CW_DUP", "FFHIP_LW_STRIP", "FFHIP_LW_AHEAD"):
         monkeypatch.delenv(k, raising=False)
@@ -71,7 +75,9 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
             keep += [f, p]
             setattr(tabs, name, _lib.SwsFilter(ptr(f, ffi.i16p), ptr(p, ffi.i32p), fs, nn))
     ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags, tables=tabs)
-    if need == "wide":
+    if need == "up2":
+        assert ctx.up2_path, "case does not reach the exact-2x kernel"
+    elif need == "wide":
         assert ctx.wide_path, "case does not reach the wide-bank walker"
     elif need == "fast":
         assert ctx.fast_path, "case does not reach the column walker"
@@ -126,6 +132,83 @@ def test_fast_path_full_size(monkeypatch):
     _run("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=77)
     _run("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, env={"FFHIP_CW_LUMA_GROUPS": "1", "FFHIP_CW_DEPTH": "6"},
          monkeypatch=monkeypatch, n=2, seed=78)
+
+
+# ---------------------------------------------------------------------------------------------
+# exact 2x up-scaling on the static-schedule kernel (sws_up2.hip): BASELINE configs[1]'s shape
+# ---------------------------------------------------------------------------------------------
+UP2_CASES = [
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_BICUBIC),
+    ("nv21", 192, 108, "nv21", 384, 216, ffi.SWS_BICUBIC),
+    ("nv12", 192, 108, "nv21", 384, 216, ffi.SWS_BICUBIC),           # the channels swap bytes on the way
+    ("nv21", 192, 108, "nv12", 384, 216, ffi.SWS_BICUBIC),
+    ("yuv420p", 128, 72, "yuv420p", 256, 144, ffi.SWS_BICUBIC),      # three single-plane jobs
+    ("nv12", 1048, 600, "nv12", 2096, 1200, ffi.SWS_BICUBIC),        # several column blocks and strips, ragged last block
+    ("nv12", 32, 16, "nv12", 64, 32, ffi.SWS_BICUBIC),               # a single partial wave; chroma rows of 4 groups
+    ("nv12", 16, 8, "nv12", 32, 16, ffi.SWS_BICUBIC),                # the smallest planes the kernel takes
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_BILINEAR),          # 2-tap banks zero-padded to 4
+    ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_POINT),             # 1-tap banks
+    ("yuv420p", 136, 72, "yuv420p", 272, 144, ffi.SWS_BICUBLIN),     # bicubic luma, bilinear chroma
+    ("nv12", 520, 90, "nv12", 1040, 180, ffi.SWS_BICUBIC),           # 130 luma groups: 2.03 waves per row
+]
+UP2_VARIANTS = [
+    {},
+    {"FFHIP_UP2_FSHIFT": "0"},
+    {"FFHIP_UP2_FSHIFT": "1", "FFHIP_UP2_DEPTH": "3"},
+    {"FFHIP_UP2_FSHIFT": "2", "FFHIP_UP2_STRIP": "12"},
+    {"FFHIP_UP2_HIPK": "0"},
+    {"FFHIP_UP2_STRIP": "6", "FFHIP_UP2_DEPTH": "3", "FFHIP_UP2_HIPK": "0"},
+    {"FFHIP_UP2_STRIP": "1000"},
+]
+
+
+@pytest.mark.parametrize("env", UP2_VARIANTS, ids=lambda e: ",".join("%s=%s" % (k[10:], v) for k, v in e.items()) or "default")
+@pytest.mark.parametrize("case", UP2_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_up2(case, env, monkeypatch):
+    _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="up2")
+
+
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_up2_odd_batches(n, monkeypatch):
+    """a wave shared by 2 or 4 frames with the batch ending inside it"""
+    for fs in ("1", "2"):
+        _run("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_BICUBIC, env={"FFHIP_UP2_FSHIFT": fs}, monkeypatch=monkeypatch, n=n,
+             seed=n, need="up2")
+
+
+def test_up2_full_size(monkeypatch):
+    """BASELINE configs[1] frame size, different frames"""
+    _run("nv12", 1920, 1080, "nv12", 3840, 2160, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=177, need="up2")
+    _run("yuv420p", 1920, 1080, "yuv420p", 3840, 2160, ffi.SWS_BICUBIC, env={"FFHIP_UP2_DEPTH": "3"}, monkeypatch=monkeypatch,
+         n=3, seed=178, need="up2")
+
+
+def test_up2_saturating_content(monkeypatch):
+    """rows of 0 / 255 runs drive the bicubic sums past 32767 (min(., 32767) in hScale8To15_c) and below 0 (clip)"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    monkeypatch.delenv("FFHIP_SWS_UP2", raising=False)
+    sw, sh = 256, 64
+    ht = S.HostTables(sw, sh, PIX["nv12"], 2 * sw, 2 * sh, PIX["nv12"], ffi.SWS_BICUBIC)
+    t = ffi.make_otables(sw, sh, PIX["nv12"], 2 * sw, 2 * sh, PIX["nv12"], ffi.SWS_BICUBIC, ht.banks(), ht.coeffs())
+    ctx = S.SwsContext(sw, sh, PIX["nv12"], 2 * sw, 2 * sh, PIX["nv12"], ffi.SWS_BICUBIC)
+    assert ctx.up2_path
+    rng = np.random.default_rng(9)
+    y = np.where(rng.integers(0, 2, (sh, sw)) > 0, 255, 0).astype(np.uint8)
+    y[::2] = np.repeat(np.where(rng.integers(0, 2, (sh // 2, sw // 4)) > 0, 255, 0).astype(np.uint8), 4, axis=1)
+    uv = np.where(rng.integers(0, 2, (sh // 2, sw)) > 0, 255, 0).astype(np.uint8)
+    dsrc = [torch.from_numpy(y[None].copy()).to("cuda:0"), torch.from_numpy(uv[None].copy()).to("cuda:0")]
+    ddst = [torch.zeros((1, 2 * sh, 2 * sw), dtype=torch.uint8, device="cuda:0"),
+            torch.zeros((1, sh, 2 * sw), dtype=torch.uint8, device="cuda:0")]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    want = ffi.alloc_frame(PIX["nv12"], 2 * sw, 2 * sh)
+    sp, ss = ffi.planes([y, uv])
+    dp, ds = ffi.planes(want)
+    assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == 2 * sh
+    for p, a in enumerate(want):
+        assert np.array_equal(ddst[p][0].cpu().numpy(), a)
+    ctx.close()
 
 
 def _adversarial_banks(rng, srcW, srcH, dstW, dstH, extreme):

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from ffmpeg_amd import swscale as S  # noqa: E402
 
-KEYS = ("FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_CW_OPT",
+KEYS = ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_HIPK", "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_CW_OPT",
         "FFHIP_YUV2RGB_VARIANT")
 
 
@@ -45,15 +45,21 @@ def main():
     dst = [torch.empty((n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(23, 3840, 2160)]
     byt = n * 15552000
     variants = [{}]
+    if ctx.up2_path:
+        variants += [{"FFHIP_UP2_DEPTH": "3"}, {"FFHIP_UP2_HIPK": "0"}, {"FFHIP_UP2_FSHIFT": "0"}, {"FFHIP_UP2_FSHIFT": "2"}]
+        variants += [{"FFHIP_UP2_STRIP": x} for x in ("30", "120", "240", "544")]
+        variants += [{"FFHIP_UP2_STRIP": "120", "FFHIP_UP2_DEPTH": "3"}, {"FFHIP_SWS_UP2": "0"}]
     if os.environ.get("SWEEP_FULL"):
         for o in ("1", "0"):
             for g in ("1", "2"):
                 for d in ("3", "6"):
                     variants.append({"FFHIP_CW_OPT": o, "FFHIP_CW_LUMA_GROUPS": g, "FFHIP_CW_DEPTH": d})
     variants += [{}]
-    variants += [{"FFHIP_SWS_MFMA": "1"}] + [{"FFHIP_SWS_MFMA": "1", "FFHIP_MF_STRIP": x} for x in ("540",)]
-    variants += [{"FFHIP_CW_STRIP": "60"}, {"FFHIP_CW_STRIP": "128"}, {"FFHIP_CW_PLAIN": "1"}, {"FFHIP_SWS_FAST": "0"}]
-    print("fast path eligible:", ctx.fast_path)
+    if os.environ.get("SWEEP_OLD"):
+        old = {"FFHIP_SWS_UP2": "0"}
+        variants += [dict(old, FFHIP_SWS_MFMA="1"), dict(old, FFHIP_CW_STRIP="60"), dict(old, FFHIP_CW_STRIP="128"),
+                     dict(old, FFHIP_CW_PLAIN="1"), dict(old, FFHIP_SWS_FAST="0")]
+    print("fast path eligible:", ctx.fast_path, "exact-2x kernel:", ctx.up2_path)
     ref = None
     for env in variants:
         setenv(env)
