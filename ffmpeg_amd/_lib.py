@@ -58,6 +58,7 @@ def lib():
         "ffhip_sws_from_tables": (vp, [C.POINTER(SwsTables)]),
         "ffhip_sws_freeContext": (None, [vp]),
         "ffhip_sws_fast_path": (C.c_int, [vp]),
+        "ffhip_membw_probe": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
         "ffhip_sws_up2_virtual_bank_host": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
         "ffhip_sws_mfma_tiles_host": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]),
         "ffhip_sws_tables_create": (vp, [C.c_int] * 7),

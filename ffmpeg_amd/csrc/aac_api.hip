@@ -257,6 +257,7 @@ extern "C" int ffhip_aac_imdct_and_windowing(FFHipAacImdct *c, const float *coef
 {
     if (!c || !coeffs || !window_sequence || !use_kb_window || !saved || !out)
         return FFHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(ffhip_scratch_mutex()); /* the arena is shared with every other host-pointer face */
     void *scratch;
     if (ffhip_scratch_reserve((1024 + 1024 + 512) * sizeof(float), &scratch) < 0)
         return FFHIP_ENOMEM;

@@ -52,8 +52,15 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
 }
 #endif
 
-/* one lazily created scratch arena per process for the host-pointer (signature-exact) faces */
+/* one lazily created scratch arena per process for the host-pointer (signature-exact) faces; every user holds
+ * ffhip_scratch_mutex() from its reserve to its last copy-back */
 int   ffhip_scratch_reserve(size_t bytes, void **dev);
+#ifdef __cplusplus
+#include <mutex>
+std::mutex &ffhip_scratch_mutex(void);
+#endif
+/* called wherever a process-global device resource is created: pins ffhip_set_device() to that device from then on */
+void  ffhip_note_device_resources(void);
 int   ffhip_have_device(void);
 
 #endif

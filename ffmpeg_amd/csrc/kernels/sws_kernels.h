@@ -99,18 +99,20 @@ struct FFHipUp2Job {
     int ngroups;                        /* 8-byte destination groups per row: plane srcW / 4, pair srcW / 2 */
     const uint32_t *hfv;                /* device: virtual horizontal bank, 2 srcW x 2 dwords */
     const uint32_t *vfv;                /* device: virtual vertical bank, row y at dwords 2 (y + 1): (2 srcH + 18) x 2 dwords, 16-byte aligned */
-    int ncb, nstrips, steps_per_strip, unit_begin;
+    int nfull, upj;                     /* full 64-lane column blocks per row; units per (pack of frames, strip) */
+    int nstrips, steps_per_strip, unit_begin;
 };
 struct FFHipUp2Args {
     FFHipUp2Job job[3];
-    int njobs, units_per_pack, npacks, nframes, fshift; /* a wave serves 1 << fshift frames (64 >> fshift lanes each) */
+    int njobs, units_per_pack, npacks, nframes, fshift; /* a pack = 1 << fshift frames; they share the ragged-end blocks (64 >> fshift lanes each) */
+    int xcd;                                            /* XCD-contiguous unit order */
 };
 #ifdef __cplusplus
 #include <vector>
 int  ffhip_up2_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, std::vector<uint32_t> *out);
 #endif
 void ffhip_up2_plan_job(FFHipUp2Job *j, int lanes_per_frame, int want_steps);
-int  ffhip_launch_up2(FFHipUp2Args &A, int depth, int hipk, hipStream_t stream);
+int  ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream);
 
 /*
  * MFMA-horizontal variant of the fast path (k_sws_mfma in sws_colwalk.hip): a job is one plane or one

@@ -28,9 +28,10 @@
  * Per 16 output samples: 39 (horizontal, once per source row) + 2 x 20 (vertical) VALU instructions = 4.9 per sample.
  *
  * Geometry: a wave owns 64 lanes x 8 output bytes of a strip of rows and walks down the source rows.  When a row does
- * not fill a whole number of waves (3840 columns = 7.5 x 512) the wave is split between 2 or 4 FRAMES of the batch
- * (the same strip and columns of frames f, f+1: identical schedule, the frame pitch is part of the lane offset), so no
- * lane idles at the right edge.
+ * not fill a whole number of waves (3840 columns = 7.5 x 512) the column blocks at the ragged right end are shared by 2 or
+ * 4 FRAMES of the batch (the same strip and columns of frames f, f+1: identical schedule, the frame pitch is part of the
+ * lane offset), so no lane idles there; every other wave stays inside one frame — 512 contiguous bytes per store
+ * instruction (measured with the arithmetic taken out: 256-byte pieces cost 7 % of the bandwidth).
  */
 #include <stdlib.h>
 #include <vector>
@@ -77,67 +78,38 @@ __device__ __forceinline__ void up_h4(int (&d)[4], uint32_t pa0, uint32_t pa1, u
 }
 
 /*
- * One output row of 8 samples: t[i] = kround + pa[i] . f01 + pb[i] . f23, bytes clip_u8(t[i] >> 19) packed in sample order.
- * HIPK: the upper halves are written by the op_sel form of v_ashr_pk_u8_i32; else merged with v_perm_b32.
+ * One output row of 8 samples: t[i] = kround + pa[i] . f01 + pb[i] . f23, bytes clip_u8(t[i] >> 19) packed in sample order;
+ * the upper halves of the two dwords are written by the op_sel form of v_ashr_pk_u8_i32 (it keeps the lower half: verified on
+ * the hardware by the parity tests, a v_perm_b32 merge gives the same bytes).
  */
-template <bool HIPK>
 __device__ __forceinline__ void up_v8(uint32_t &w0, uint32_t &w1, const uint32_t (&pa)[8], const uint32_t (&pb)[8], uint32_t f01,
                                       uint32_t f23, int kround)
 {
     int t0, t1, t2, t3, t4, t5, t6, t7;
-    if (HIPK) {
-        asm("v_dot2_i32_i16 %2, %10, %26, %28\n\t"
-            "v_dot2_i32_i16 %3, %11, %26, %28\n\t"
-            "v_dot2_i32_i16 %4, %12, %26, %28\n\t"
-            "v_dot2_i32_i16 %5, %13, %26, %28\n\t"
-            "v_dot2_i32_i16 %6, %14, %26, %28\n\t"
-            "v_dot2_i32_i16 %7, %15, %26, %28\n\t"
-            "v_dot2_i32_i16 %8, %16, %26, %28\n\t"
-            "v_dot2_i32_i16 %9, %17, %26, %28\n\t"
-            "v_dot2_i32_i16 %2, %18, %27, %2\n\t"
-            "v_dot2_i32_i16 %3, %19, %27, %3\n\t"
-            "v_dot2_i32_i16 %4, %20, %27, %4\n\t"
-            "v_dot2_i32_i16 %5, %21, %27, %5\n\t"
-            "v_dot2_i32_i16 %6, %22, %27, %6\n\t"
-            "v_dot2_i32_i16 %7, %23, %27, %7\n\t"
-            "v_dot2_i32_i16 %8, %24, %27, %8\n\t"
-            "v_dot2_i32_i16 %9, %25, %27, %9\n\t"
-            "v_ashr_pk_u8_i32 %0, %2, %3, 19\n\t"
-            "v_ashr_pk_u8_i32 %1, %6, %7, 19\n\t"
-            "v_ashr_pk_u8_i32 %0, %4, %5, 19 op_sel:[0,0,0,1]\n\t"
-            "v_ashr_pk_u8_i32 %1, %8, %9, 19 op_sel:[0,0,0,1]"
-            : "=&v"(w0), "=&v"(w1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
-            : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7]),
-              "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]), "v"(pb[6]), "v"(pb[7]),
-              "s"(f01), "s"(f23), "v"(kround));
-    } else {
-        asm("v_dot2_i32_i16 %0, %8, %24, %26\n\t"
-            "v_dot2_i32_i16 %1, %9, %24, %26\n\t"
-            "v_dot2_i32_i16 %2, %10, %24, %26\n\t"
-            "v_dot2_i32_i16 %3, %11, %24, %26\n\t"
-            "v_dot2_i32_i16 %4, %12, %24, %26\n\t"
-            "v_dot2_i32_i16 %5, %13, %24, %26\n\t"
-            "v_dot2_i32_i16 %6, %14, %24, %26\n\t"
-            "v_dot2_i32_i16 %7, %15, %24, %26\n\t"
-            "v_dot2_i32_i16 %0, %16, %25, %0\n\t"
-            "v_dot2_i32_i16 %1, %17, %25, %1\n\t"
-            "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
-            "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
-            "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
-            "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
-            "v_dot2_i32_i16 %6, %22, %25, %6\n\t"
-            "v_dot2_i32_i16 %7, %23, %25, %7\n\t"
-            "v_ashr_pk_u8_i32 %0, %0, %1, 19\n\t"
-            "v_ashr_pk_u8_i32 %2, %2, %3, 19\n\t"
-            "v_ashr_pk_u8_i32 %4, %4, %5, 19\n\t"
-            "v_ashr_pk_u8_i32 %6, %6, %7, 19"
-            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
-            : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7]),
-              "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]), "v"(pb[6]), "v"(pb[7]),
-              "s"(f01), "s"(f23), "v"(kround));
-        w0 = __builtin_amdgcn_perm((uint32_t)t2, (uint32_t)t0, 0x05040100);
-        w1 = __builtin_amdgcn_perm((uint32_t)t6, (uint32_t)t4, 0x05040100);
-    }
+    asm("v_dot2_i32_i16 %2, %10, %26, %28\n\t"
+        "v_dot2_i32_i16 %3, %11, %26, %28\n\t"
+        "v_dot2_i32_i16 %4, %12, %26, %28\n\t"
+        "v_dot2_i32_i16 %5, %13, %26, %28\n\t"
+        "v_dot2_i32_i16 %6, %14, %26, %28\n\t"
+        "v_dot2_i32_i16 %7, %15, %26, %28\n\t"
+        "v_dot2_i32_i16 %8, %16, %26, %28\n\t"
+        "v_dot2_i32_i16 %9, %17, %26, %28\n\t"
+        "v_dot2_i32_i16 %2, %18, %27, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %27, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %27, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %27, %5\n\t"
+        "v_dot2_i32_i16 %6, %22, %27, %6\n\t"
+        "v_dot2_i32_i16 %7, %23, %27, %7\n\t"
+        "v_dot2_i32_i16 %8, %24, %27, %8\n\t"
+        "v_dot2_i32_i16 %9, %25, %27, %9\n\t"
+        "v_ashr_pk_u8_i32 %0, %2, %3, 19\n\t"
+        "v_ashr_pk_u8_i32 %1, %6, %7, 19\n\t"
+        "v_ashr_pk_u8_i32 %0, %4, %5, 19 op_sel:[0,0,0,1]\n\t"
+        "v_ashr_pk_u8_i32 %1, %8, %9, 19 op_sel:[0,0,0,1]"
+        : "=&v"(w0), "=&v"(w1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7]),
+          "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]), "v"(pb[6]), "v"(pb[7]),
+          "s"(f01), "s"(f23), "v"(kround));
 }
 
 /*
@@ -146,18 +118,21 @@ __device__ __forceinline__ void up_v8(uint32_t &w0, uint32_t &w1, const uint32_t
  * destination bytes at 8g of two destination rows per source row (g = the lane's group in the row).
  * D = source rows in flight (3 or 6); the ring of vertical pairs has 3 slots, so D | 6 keeps every index static.
  */
-template <int PAIR, int D, bool HIPK>
-__device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int pack, int strip, int cb, int lane, int fshift, int nframes)
+template <int PAIR, int D, int VAR>
+__device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int fshift, int gbase, int strip, int lane, int nframes)
 {
+    /* measurement-only variants (wrong output; tools/sweep_sws.py): 16 never stores, 32 re-reads one source row (48 = both: the
+     * arithmetic alone), 64 moves the bytes without arithmetic (the memory pattern alone) */
+    constexpr bool DBG_NOST = VAR & 16, DBG_ROW0 = VAR & 32, DBG_COPY = VAR & 64;
     const int lpf = 64 >> fshift;                 /* lanes per frame */
     const int fsub = lane >> (6 - fshift);
     const int gl = lane & (lpf - 1);
-    const int graw = cb * lpf + gl, fraw = (pack << fshift) + fsub;
+    const int graw = gbase + gl, fraw = frame0 + fsub;
     const bool act = graw < J.ngroups && fraw < nframes;
     const int g = min(graw, J.ngroups - 1);
     const int fs = fraw < nframes ? fsub : 0;     /* idle lanes shadow valid ones */
     const bool lb = g == 0, rb = g == J.ngroups - 1;
-    const bool border = cb == 0 || cb == J.ncb - 1; /* wave-uniform */
+    const bool border = gbase == 0 || gbase + lpf >= J.ngroups; /* wave-uniform */
 
     const uint32_t soff = (uint32_t)fs * (uint32_t)J.sfp + (uint32_t)(lb ? 0 : rb ? 4 * g - 8 : 4 * g - 4);
     const uint32_t doff = (uint32_t)fs * (uint32_t)J.dfp + 8u * (uint32_t)g;
@@ -183,8 +158,8 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int pack, int str
     /* ---- row addressing: scalar running pointers + 32-bit lane offsets ---- */
     const int S = J.steps_per_strip;
     const int a = 1 + strip * S, b = min(a + S, J.srcH + 2); /* this strip's steps: step r emits rows 2r-3 and 2r-2 */
-    const uint8_t *sbase = J.src + (size_t)(pack << fshift) * J.sfp;
-    uint8_t *dbase = J.dst + (size_t)(pack << fshift) * J.dfp;
+    const uint8_t *sbase = J.src + (size_t)frame0 * J.sfp;
+    uint8_t *dbase = J.dst + (size_t)frame0 * J.dfp;
     const ptrdiff_t sstride = J.sstride, dstride = J.dstride;
     const int srcH = J.srcH, dstH = 2 * J.srcH;
     int pr = a - 3;                                               /* next source row to fetch (unclamped) */
@@ -198,7 +173,8 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int pack, int str
         const up_u3 w = *(up_gc3)((up_gcp)pf + off);
         o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z;
         pr++;
-        pf += (pr >= 1 && pr <= srcH - 1) ? sstride : 0; /* rows above / below the plane replicate the edge row */
+        if (!DBG_ROW0)
+            pf += (pr >= 1 && pr <= srcH - 1) ? sstride : 0; /* rows above / below the plane replicate the edge row */
         asm("" : "+s"(pf));
     };
 
@@ -284,22 +260,25 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int pack, int str
         for (int k = 0; k < 6; k++) {
             UpRaw &w = buf[(k + 3) % D];
             if (r + k < b) { /* uniform */
-                hpass(w, ring[k % 3]);
+                if (!DBG_COPY)
+                    hpass(w, ring[k % 3]);
                 const up_u8 cc = c8[k >> 1];
                 const uint32_t fb01 = k & 1 ? cc.s4 : cc.s0, fb23 = k & 1 ? cc.s5 : cc.s1;
                 const uint32_t fa01 = k & 1 ? cc.s6 : cc.s2, fa23 = k & 1 ? cc.s7 : cc.s3;
                 const int y = 2 * (r + k) - 3;
-                uint32_t w0, w1;
-                up_v8<HIPK>(w0, w1, ring[(k + 1) % 3], ring[k % 3], fb01, fb23, kround);
+                uint32_t w0, w1, a0, a1;
+                if (DBG_COPY) { w0 = w.q[0] + fb01; w1 = w.q[1] + fb23; a0 = w.q[1] + fa01; a1 = w.q[2] + fa23; }
+                else up_v8(w0, w1, ring[(k + 1) % 3], ring[k % 3], fb01, fb23, kround);
                 uint32_t off = doff;
                 asm volatile("" : "+v"(off));
-                if (act && y >= 0) {
+                if (act && y >= 0 && (!DBG_NOST || (w0 == 0x12345678u && w1 == 0x9abcdef0u))) {
                     up_u2 s; s.x = w0; s.y = w1;
                     *(up_g2)((up_gp)dr + off) = s;
                 }
-                up_v8<HIPK>(w0, w1, ring[(k + 1) % 3], ring[k % 3], fa01, fa23, kround);
-                if (act && y + 1 < dstH) {
-                    up_u2 s; s.x = w0; s.y = w1;
+                if (!DBG_COPY)
+                    up_v8(a0, a1, ring[(k + 1) % 3], ring[k % 3], fa01, fa23, kround);
+                if (act && y + 1 < dstH && (!DBG_NOST || (a0 == 0x12345678u && a1 == 0x9abcdef0u))) {
+                    up_u2 s; s.x = a0; s.y = a1;
                     *(up_g2)((up_gp)(dr + dstride) + off) = s;
                 }
                 dr += 2 * dstride;
@@ -310,12 +289,20 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int pack, int str
     }
 }
 
-template <int D, bool HIPK>
+template <int D, int VAR> /* VAR: 0 the product; 16 / 48 / 64 measurement only (see up2_unit) */
 __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
+    uint32_t blk = blockIdx.x;
+    if (A.xcd) {
+        /* workgroup b runs on XCD b % 8 (observed, not promised: speed only).  Give every XCD one contiguous eighth of the
+         * units, in order, so that the waves sharing source lines (adjacent column blocks, the 3 halo rows of adjacent
+         * strips) meet in one L2. */
+        const uint32_t nb = gridDim.x, x = blk & 7u, sl = blk >> 3, q = nb >> 3, r = nb & 7u;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sl;
+    }
+    const uint32_t gw = blk * 4u + (uint32_t)wave;
     if (gw >= (uint32_t)A.units_per_pack * (uint32_t)A.npacks)
         return;
     const int pack = (int)(gw / (uint32_t)A.units_per_pack);
@@ -325,11 +312,25 @@ __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
     if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
     const FFHipUp2Job &J = A.job[j];
     const int local = u - J.unit_begin;
-    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    /* units of a (pack, strip): the full 64-lane column blocks of each of the pack's frames, then the blocks at the ragged
+     * right end of the rows, which the pack's frames share lane block by lane block */
+    const int strip = local / J.upj, idx = local - strip * J.upj;
+    const int nf = J.nfull << A.fshift;
+    int frame0 = pack << A.fshift, fsh = 0, gbase;
+    if (idx < nf) {
+        const int fsub = idx / J.nfull;
+        frame0 += fsub;
+        gbase = (idx - fsub * J.nfull) * 64;
+        if (frame0 >= A.nframes)
+            return;
+    } else {
+        fsh = A.fshift;
+        gbase = J.nfull * 64 + (idx - nf) * (64 >> fsh);
+    }
     if (J.pair)
-        up2_unit<1, D, HIPK>(J, pack, strip, cb, lane, A.fshift, A.nframes);
+        up2_unit<1, D, VAR>(J, frame0, fsh, gbase, strip, lane, A.nframes);
     else
-        up2_unit<0, D, HIPK>(J, pack, strip, cb, lane, A.fshift, A.nframes);
+        up2_unit<0, D, VAR>(J, frame0, fsh, gbase, strip, lane, A.nframes);
 }
 
 /* ================================================================================================== */
@@ -383,17 +384,23 @@ void ffhip_up2_plan_job(FFHipUp2Job *j, int lanes_per_frame, int want)
     int s = cdiv(cdiv(steps, n), 6) * 6;
     j->steps_per_strip = s;
     j->nstrips = cdiv(steps, s);
-    j->ncb = cdiv(j->ngroups, lanes_per_frame);
+    if (lanes_per_frame == 64) {
+        j->nfull = 0; /* one frame per wave throughout: every block is a "tail" block of 64 lanes */
+        j->upj = cdiv(j->ngroups, 64);
+    } else {
+        j->nfull = j->ngroups / 64;
+        j->upj = j->nfull * (64 / lanes_per_frame) + cdiv(j->ngroups - j->nfull * 64, lanes_per_frame);
+    }
 }
 
-int ffhip_launch_up2(FFHipUp2Args &A, int depth, int hipk, hipStream_t stream)
+int ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream)
 {
     if (A.nframes <= 0)
         return 0;
     int u = 0;
     for (int i = 0; i < A.njobs; i++) {
         A.job[i].unit_begin = u;
-        u += A.job[i].ncb * A.job[i].nstrips;
+        u += A.job[i].upj * A.job[i].nstrips;
     }
     A.units_per_pack = u;
     A.npacks = (A.nframes + (1 << A.fshift) - 1) >> A.fshift;
@@ -403,13 +410,17 @@ int ffhip_launch_up2(FFHipUp2Args &A, int depth, int hipk, hipStream_t stream)
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (depth == 3) {
-        if (hipk) hipLaunchKernelGGL((k_sws_up2<3, true>), grid, block, 0, stream, A);
-        else      hipLaunchKernelGGL((k_sws_up2<3, false>), grid, block, 0, stream, A);
-    } else {
-        if (hipk) hipLaunchKernelGGL((k_sws_up2<6, true>), grid, block, 0, stream, A);
-        else      hipLaunchKernelGGL((k_sws_up2<6, false>), grid, block, 0, stream, A);
+#define UP2_LAUNCH(DD, VV) hipLaunchKernelGGL((k_sws_up2<DD, VV>), grid, block, 0, stream, A)
+#define UP2_CASE(VV) case VV: if (depth == 3) UP2_LAUNCH(3, VV); else UP2_LAUNCH(6, VV); break
+    switch (var) {
+    UP2_CASE(0);
+    UP2_CASE(16); UP2_CASE(48); UP2_CASE(64); /* measurement only */
+    default:
+        ffhip_set_error("ffhip_sws: exact-2x kernel variant %d is not built", var);
+        return FFHIP_EINVAL;
     }
+#undef UP2_CASE
+#undef UP2_LAUNCH
     LAUNCH_CHECK();
     return 0;
 }

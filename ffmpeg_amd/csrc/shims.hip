@@ -17,7 +17,7 @@
 #include "kernels/h264_kernels.h"
 #include "kernels/me_kernels.h"
 
-static std::mutex g_shim_mu;
+static std::mutex &g_shim_mu = ffhip_scratch_mutex(); /* the arena's one lock (runtime.hip) */
 #define DP 64 /* device row pitch of a staged rectangle */
 
 /* a rectangle rows r0..r1 x columns c0..c1 around host pointer p (row step = stride, may be negative) */

@@ -637,7 +637,8 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             /* frames per wave: the split that wastes the fewest lanes at the right edge of the widest job's rows;
              * lane offsets (frame pitch included) must stay below 2^32 */
             const char *ef = getenv("FFHIP_UP2_FSHIFT"), *es = getenv("FFHIP_UP2_STRIP"), *ed = getenv("FFHIP_UP2_DEPTH");
-            const char *ek = getenv("FFHIP_UP2_HIPK");
+            const char *ev2 = getenv("FFHIP_UP2_VAR"), *ex = getenv("FFHIP_UP2_XCD");
+            U.xcd = !(ex && ex[0] == '0');
             int best = 0;
             double bestw = 1e30;
             for (int fsft = 0; fsft <= 2; fsft++) {
@@ -650,11 +651,13 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                     const unsigned long long span_d = (unsigned long long)((1 << fsft) - 1) * j.dfp + 2ull * j.srcH * (size_t)(j.dstride < 0 ? -j.dstride : j.dstride);
                     if (span_s >= (1ull << 31) || span_d >= (1ull << 31))
                         fits = false;
-                    w += (double)cdiv(j.ngroups, lpf) * lpf * j.srcH;
+                    /* waves per frame and strip: the full blocks, plus this frame's share of the shared ragged-end blocks */
+                    const int nfull = fsft ? j.ngroups / 64 : 0;
+                    w += ((double)nfull + (double)cdiv(j.ngroups - nfull * 64, lpf) / (1 << fsft)) * j.srcH;
                 }
                 if (nframes < (1 << fsft) && fsft)
                     fits = false;
-                if (fits && w < bestw) { bestw = w; best = fsft; }
+                if (fits && w < bestw - 1e-9) { bestw = w; best = fsft; }
             }
             U.fshift = ef && ef[0] >= '0' && ef[0] <= '2' ? ef[0] - '0' : best;
             bool neg = false;
@@ -663,7 +666,8 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             if (!neg) {
                 for (int i = 0; i < U.njobs; i++)
                     ffhip_up2_plan_job(&U.job[i], 64 >> U.fshift, es && atoi(es) > 0 ? atoi(es) : 60);
-                return ffhip_launch_up2(U, ed && ed[0] == '3' ? 3 : 6, !(ek && ek[0] == '0'), stream);
+                /* FFHIP_UP2_VAR: 0 the product; 16 / 48 / 64 = measurement-only builds (no stores / arithmetic only / bytes only) */
+                return ffhip_launch_up2(U, ed && ed[0] == '6' ? 6 : 3, ev2 ? atoi(ev2) : 0, stream);
             }
         }
         if (!(al & 3)) {

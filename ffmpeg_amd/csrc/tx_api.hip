@@ -1404,6 +1404,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             (void)hipFuncSetAttribute((const void *)k_dct<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_dct<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             fft_attr = true;
+            ffhip_note_device_resources();
         }
         if (c->type == FFHIP_TX_FLOAT_RDFT) {
 #define TX_LAUNCH(K)                                                                                                                  \
@@ -1458,6 +1459,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             (void)hipFuncSetAttribute((const void *)k_mdct_pfa<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_mdct_pfa<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             pfa_attr = true;
+            ffhip_note_device_resources();
         }
         TxTab53 T;
         T.t[0] = T.t[1] = (float)cos(2 * M_PI / 5);
@@ -1528,6 +1530,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
                 (void)hipFuncSetAttribute((const void *)k_mdct_z<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_mdct_z<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_done = true;
+                ffhip_note_device_resources();
             }
             if (c->inv) {
                 if (tl) TX_LAUNCH((k_mdct_z<1, true>)); else TX_LAUNCH((k_mdct_z<1, false>));

@@ -38,8 +38,14 @@ extern "C" {
 /** Number of usable HIP devices (0 when none / no driver).  Mirrors the role of av_get_cpu_flags()
  *  & AV_CPU_FLAG_* gating in every ff_*_init_<arch>() (libavutil/cpu.h:32-62). */
 int         ffhip_device_count(void);
-/** Bind the calling thread to a device (one process per GPU; rank -> LOCAL_RANK). */
+/** Bind the calling thread to a device (one process per GPU; rank -> LOCAL_RANK).  Call it before any other entry point:
+ *  once the process holds device resources (staging arena, deblocking progress pool, ...) on one device, selecting a
+ *  different one returns FFHIP_EINVAL. */
 int         ffhip_set_device(int device);
+/** Streaming-bandwidth probe of the current device (measurement aid: bench.py reports the box's achievable roofs beside
+ *  the 8 TB/s spec).  pattern 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p->4K scaler's mix);
+ *  `bytes` per buffer; *gbps = bytes moved per second / 1e9 over `reps` launches (HIP events). */
+int         ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gbps);
 const char *ffhip_last_error(void);
 const char *ffhip_version(void);
 /** Device memory helpers for callers that do not bring their own allocator. */

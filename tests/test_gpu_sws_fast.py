@@ -50,7 +50,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     from ffmpeg_amd import swscale as S
     torch = _torch()
     rng = np.random.default_rng(seed)
-    for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_HIPK"):
+    for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD"):
         monkeypatch.delenv(k, raising=False)
     if need != "up2":
         monkeypatch.setenv("FFHIP_SWS_UP2", "0")   # these tests are about the general kernels; test_up2* covers sws_up2.hip
@@ -154,11 +154,12 @@ UP2_CASES = [
 UP2_VARIANTS = [
     {},
     {"FFHIP_UP2_FSHIFT": "0"},
-    {"FFHIP_UP2_FSHIFT": "1", "FFHIP_UP2_DEPTH": "3"},
+    {"FFHIP_UP2_FSHIFT": "1", "FFHIP_UP2_DEPTH": "6"},
     {"FFHIP_UP2_FSHIFT": "2", "FFHIP_UP2_STRIP": "12"},
-    {"FFHIP_UP2_HIPK": "0"},
-    {"FFHIP_UP2_STRIP": "6", "FFHIP_UP2_DEPTH": "3", "FFHIP_UP2_HIPK": "0"},
+    {"FFHIP_UP2_STRIP": "6", "FFHIP_UP2_DEPTH": "6"},
     {"FFHIP_UP2_STRIP": "1000"},
+    {"FFHIP_UP2_XCD": "0", "FFHIP_UP2_FSHIFT": "1"},
+    {"FFHIP_UP2_XCD": "0", "FFHIP_UP2_FSHIFT": "2", "FFHIP_UP2_DEPTH": "6"},
 ]
 
 

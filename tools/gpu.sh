@@ -5,6 +5,7 @@
 #   "smoke"                       __graft_entry__.smoke()
 #   "bench [bench.py args]"       python bench.py <args>             (the JSON line lands in gpurun_out/bench.json)
 #   "py <script> [args]"          python <script> <args>
+#   "sh <command> [args]"         any command (e.g. a tools/ubench binary)
 #   "prof <tag> <script> [args]"  rocprofv3 --kernel-trace --stats of `python <script> <args>`; the kernel stats CSV is
 #                                 copied to gpurun_out/<tag>_kernel_stats.csv
 #   "pmc <tag> <script> [args]"   the three PMC passes (FETCH_SIZE / WRITE_SIZE / SQ set), each its own rocprofv3 run with
@@ -29,6 +30,7 @@ for step in "$@"; do
     test)  (cd $R && timeout $T python -m pytest tests -m gpu -q -x "$@" 2>&1 | tail -25) | tee $log ;;
     smoke) (cd $R && timeout $T python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -5) | tee $log ;;
     bench) (cd $R && timeout $T python bench.py "$@" 2>&1 | tail -3) | tee $log; grep '^{' $log | tail -1 > $OUT/bench.json ;;
+    sh)    (cd $R && timeout $T "$@" 2>&1 | tail -${PY_TAIL:-60}) | tee $log ;;
     py)    (cd $R && timeout $T python "$@" 2>&1 | tail -${PY_TAIL:-60}) | tee $log ;;
     prof)  tag=$1; shift
            (cd /tmp && rm -rf $OUT/prof_$tag && timeout $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -o run -- python $R/"$@" > $log 2>&1)
