@@ -4,14 +4,20 @@
   step      one pass of the hot path over one batch: 256 nv12 1920x1080 frames -> nv12 3840x2160,
             SWS_BICUBIC (BASELINE.json configs[1]), inputs and outputs resident in HBM.
   metric    Mpixels/s of OUTPUT pixels, whole job over all ranks (weak scaling: 256 frames per GPU).
-  roofline  the dominant kernel k_sws_colwalk (one launch per step): algorithmic bytes per launch
+  roofline  the dominant kernel k_sws_up2 (one launch per step): algorithmic bytes per launch
             (15,552,000 B/frame x frames) / its average duration measured with HIP
-            events on the launch stream, against the 8 TB/s HBM3E peak.
+            events on the launch stream, against the 8 TB/s HBM3E peak; `achievable` = this box's
+            streaming roofs by traffic mix (ffhip_membw_probe), the yardstick beside the spec peak.
+  idct      BASELINE's second metric (IDCT Gblocks/s at 1/2/4/8 GPUs): h264 idct8_add over 32 4K luma
+            planes per rank, summed over ranks, in the same line.
   cpu_baseline  the reference's own C path (oracle/_ref, kind "reference") or the oracle port, timed
-            on the host cores over a bounded sample of the same workload (rank 0, N=1 only).
+            on the host cores over bounded samples of the same workloads (rank 0, N=1 only): swscale on
+            1 thread / slice-threaded / frame-parallel on all cores, idct8_add on 1 thread / all cores.
 
 N>1 is launched by torchrun (one process per GPU, RCCL): frames shard across ranks with no data-path
-collective; the only collectives are the barriers and the MAX-over-ranks of the timed interval.
+collective; the only collectives are the barriers and the MAX-over-ranks of the timed interval.  With
+N>1 the line also carries `strong`: a rank-0 batch scattered over RCCL, converted and gathered back
+(ffmpeg_amd/dist.py), each phase timed on its own — the path BASELINE's north_star describes.
 """
 import argparse
 import ctypes as C
@@ -32,8 +38,8 @@ BYTES_PER_FRAME = SRC_W * SRC_H * 3 // 2 + DST_W * DST_H * 3 // 2   # 15,552,000
 HBM_PEAK_GBS = 8000.0                                             # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(budget_s=12.0):
-    """Bounded sample of the same conversion on the host cores (checker infrastructure, timed only)."""
+def cpu_baseline(budget_s=5.0):
+    """Bounded samples of the same work on the host cores (checker infrastructure, timed only)."""
     import ffi
     rng = np.random.default_rng(2)
     src = ffi.alloc_frame(NV12, SRC_W, SRC_H, rng)
@@ -41,25 +47,12 @@ def cpu_baseline(budget_s=12.0):
     sp, ss = ffi.planes(src)
     dp, ds = ffi.planes(dst)
     cores = os.cpu_count() or 1
-    if ffi.have_ref():
-        R = ffi.ref()
-        threads = min(cores, 64)
-        ctx = R.ffref_sws_create(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4, threads)
-        R.ffref_sws_scale(ctx, sp, ss, 0, SRC_H, dp, ds)            # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            R.ffref_sws_scale(ctx, sp, ss, 0, SRC_H, dp, ds)
-            n += 1
-            dt = time.perf_counter() - t0
-            if (dt > budget_s and n >= 4) or n >= 2000:
-                break
-        R.ffref_sws_free(ctx)
-        kind = "reference"
-    else:
+    px = DST_W * DST_H
+    what = "nv12 %dx%d->%dx%d bicubic" % (SRC_W, SRC_H, DST_W, DST_H)
+    if not ffi.have_ref():
         from ffmpeg_amd import swscale as S
         ht = S.HostTables(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4)
         t = ffi.make_otables(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4, ht.banks(), ht.coeffs())
-        threads = 1
         n, t0 = 0, time.perf_counter()
         while True:
             ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds)
@@ -67,10 +60,60 @@ def cpu_baseline(budget_s=12.0):
             dt = time.perf_counter() - t0
             if (dt > budget_s and n >= 2) or n >= 200:
                 break
-        kind = "port"
-    return {"value": round(n * DST_W * DST_H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": kind,
-            "sample": "%d frames nv12 %dx%d->%dx%d bicubic in %.1f s, %d thread(s) of %d host cores, pure C (no SIMD asm)"
-                      % (n, SRC_W, SRC_H, DST_W, DST_H, dt, threads, cores)}
+        return {"value": round(n * px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                "sample": "%d frames %s in %.1f s, 1 thread of %d host cores, pure C (oracle port)" % (n, what, dt, cores)}
+    R = ffi.ref()
+
+    def run_sws(threads, budget):
+        ctx = R.ffref_sws_create(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4, threads)
+        R.ffref_sws_scale(ctx, sp, ss, 0, SRC_H, dp, ds)            # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            R.ffref_sws_scale(ctx, sp, ss, 0, SRC_H, dp, ds)
+            n += 1
+            dt = time.perf_counter() - t0
+            if (dt > budget and n >= 3) or n >= 2000:
+                break
+        R.ffref_sws_free(ctx)
+        return {"value": round(n * px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": threads,
+                "sample": "%d frames %s in %.1f s, %d thread(s)" % (n, what, dt, threads)}
+
+    legs = {"sws_1_thread": run_sws(1, 2.0), "sws_slice_threads": run_sws(min(cores, 64), 3.0)}
+    # frame-parallel: one single-threaded context and one frame per thread (a batch of independent frames on all cores)
+    if hasattr(R, "ffref_sws_scale_frames_mt"):
+        nt = min(cores, 256)
+        ctxs = (C.c_void_p * nt)(*[R.ffref_sws_create(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4, 1) for _ in range(nt)])
+        dsts = [ffi.alloc_frame(NV12, DST_W, DST_H) for _ in range(nt)]
+        dps = [ffi.planes(d)[0] for d in dsts]
+        sarr = (C.c_void_p * nt)(*[C.cast(sp, C.c_void_p).value] * nt)
+        darr = (C.c_void_p * nt)(*[C.cast(d, C.c_void_p).value for d in dps])
+        reps = 2
+        R.ffref_sws_scale_frames_mt(ctxs, sarr, ss, darr, ds, SRC_H, nt, 1)
+        t0 = time.perf_counter()
+        R.ffref_sws_scale_frames_mt(ctxs, sarr, ss, darr, ds, SRC_H, nt, reps)
+        dt = time.perf_counter() - t0
+        for c in ctxs:
+            R.ffref_sws_free(c)
+        legs["sws_frame_parallel"] = {"value": round(nt * reps * px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": nt,
+                                      "sample": "%d frames %s in %.1f s, %d single-threaded contexts side by side" % (nt * reps, what, dt, nt)}
+        del dsts, dps
+    # h264 idct8_add over 4K luma planes (129,600 blocks each): 1 thread, then a static split over all cores
+    if hasattr(R, "ffref_h264_idct_batch"):
+        for key, th, planes in (("idct8_1_thread", 1, 2), ("idct8_all_cores", min(cores, 1024), 32)):
+            n = planes * 129600
+            pic = rng.integers(0, 256, (planes * 2160, 3840), dtype=np.uint8)
+            by, bx = np.meshgrid(np.arange(planes * 270), np.arange(480), indexing="ij")
+            off = (by * 8 * 3840 + bx * 8).astype(np.int32).ravel()
+            blk = rng.integers(-512, 512, (n, 64), dtype=np.int16)
+            t0 = time.perf_counter()
+            R.ffref_h264_idct_batch(1, ffi.ptr(pic), 3840, ffi.ptr(off, ffi.i32p), ffi.ptr(blk, ffi.i16p), n, th)
+            dt = time.perf_counter() - t0
+            legs[key] = {"value": round(n / dt / 1e9, 5), "unit": "Gblocks/s", "cores": th,
+                         "sample": "%d 8x8 blocks (ff_h264_idct8_add_8_c over %d 4K luma planes) in %.2f s, %d thread(s)" % (n, planes, dt, th)}
+            del pic, off, blk
+    best = max((legs[k] for k in legs if k.startswith("sws_")), key=lambda l: l["value"])
+    return {"value": best["value"], "unit": "Mpixels/s", "cores": best["cores"], "kind": "reference",
+            "sample": best["sample"] + " of %d host cores, pure C (no SIMD asm: nasm absent)" % cores, "host_cores": cores, "legs": legs}
 
 
 def extras(torch, dev):
@@ -117,6 +160,19 @@ def extras(torch, dev):
                     "hbm_frac": round(byt / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frames": n, "ms": round(t, 4)}
         c.close()
 
+    # the host-pointer face of the bench conversion (SwsFunc shape: pageable host planes in and out, staging and PCIe included):
+    # SURVEY.md §8d's end-to-end figure, reported beside — never as — the resident-frame rate
+    hc = S.SwsContext(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4)
+    hs = [np.random.default_rng(5).integers(0, 256, (r, c), dtype=np.uint8) for r, c in S.plane_shapes(NV12, SRC_W, SRC_H)]
+    hd = [np.zeros((r, c), np.uint8) for r, c in S.plane_shapes(NV12, DST_W, DST_H)]
+    hc.scale(hs, hd)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        hc.scale(hs, hd)
+    t = (time.perf_counter() - t0) / 5
+    out["sws_host_pointer_end_to_end"] = {"Mpixels/s": round(DST_W * DST_H / t / 1e6, 1), "ms_per_frame": round(t * 1e3, 3),
+                                          "note": "ffhip_sws_scale on pageable host memory, one frame per call: H2D + kernel + D2H"}
+    hc.close()
     # down-scaling (8 x 8-tap banks: the LDS-backed wide walker) and scaled packed-RGB output (column walker + yuv2rgb)
     sws_case("sws_nv12_4k_to_1080p_bicubic", 23, 3840, 2160, 23, 1920, 1080, 64)
     sws_case("sws_yuv420p_1080p_to_rgb24_4k_bicubic", 0, 1920, 1080, 2, 3840, 2160, 32)
@@ -251,8 +307,12 @@ def extras(torch, dev):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         nmb = nf * (w // 16) * (h // 16)
+        # roof of this path: packed-SAD issue — v_sad_u8 scores 4 abs-diffs per lane at 0.547 wave-instructions
+        # per ns per SIMD (profiles/r01_valu_rate_ubench.txt) x 1024 SIMDs x 64 lanes = 1.43e14 abs-diff/s
+        ad = nmb * 225 * 256 / (ms * 1e-3)
         out[name] = {"MB-searches/s": round(nmb / (ms * 1e-3), 1), "candidates/s": round(nmb * 225 / (ms * 1e-3), 1),
-                     "frame_pairs": nf, "ms": round(ms, 4)}
+                     "abs_diff/s": float("%.4g" % ad), "sad_issue_roof_frac": round(ad / 1.434e14, 4),
+                     "hbm_frac": round(nf * 2 * w * h / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frame_pairs": nf, "ms": round(ms, 4)}
     del cur, ref
     # H.264 luma qpel: every 16x16 macroblock of 8 4K planes, mixed mcXY, put (BASELINE configs[2]): 2 B / sample
     nf, w, h, P = 8, 3840, 2160, 32
@@ -408,6 +468,84 @@ def extras(torch, dev):
     return out
 
 
+def idct_leg(torch, dist, dev, world, reps=5):
+    """BASELINE's second metric at every N: h264 idct8_add over 32 4K luma planes per rank (129,600 blocks each, 384 B per
+    block), ranks independent (blocks shard with no collective), barrier + synchronize on both sides, MAX over ranks."""
+    from ffmpeg_amd import h264
+    planes, stride = 32, 3840
+    nb = planes * 129600
+    plane = torch.randint(0, 256, (planes * 2160, stride), dtype=torch.uint8, device=dev)
+    by, bx = torch.meshgrid(torch.arange(planes * 270, device=dev), torch.arange(480, device=dev), indexing="ij")
+    offs = (by * 8 * stride + bx * 8).to(torch.int32).reshape(-1).contiguous()
+    coefs0 = torch.randint(-512, 512, (nb, 64), dtype=torch.int16, device=dev)
+    bufs = [coefs0.clone() for _ in range(reps + 1)]             # the call clears its coefficients: one fresh copy per rep
+    h264.idct_add_batch(h264.IDCT8, plane, stride, offs, bufs[reps])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        h264.idct_add_batch(h264.IDCT8, plane, stride, offs, bufs[i])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms = el / reps * 1e3
+    gbs = nb * 384 / (ms * 1e-3) / 1e9
+    return {"metric": "h264_idct8_add_Gblocks_per_s", "value": round(world * nb / (ms * 1e-3) / 1e9, 3), "unit": "Gblocks/s",
+            "blocks_per_gpu": nb, "ms_per_pass": round(ms, 4), "hbm_frac_per_gpu": round(gbs / HBM_PEAK_GBS, 4),
+            "note": "32 4K luma planes per rank, coefficients + picture resident in HBM, bit-exact vs the C reference (tests)"}
+
+
+def strong_leg(torch, dist, dev, ctx, S, rank, world, n_total, reps=3):
+    """The batch starts and ends on rank 0: scatter the source planes over RCCL (point-to-point sends, xGMI), convert the
+    shard, gather the converted planes back.  Phases separated by barriers and timed on their own."""
+    from ffmpeg_amd import dist as D
+    full = None
+    if rank == 0:
+        g = torch.Generator(device=dev)
+        g.manual_seed(0xF0F00002)
+        full = [torch.randint(0, 256, (n_total, r, c), dtype=torch.uint8, device=dev, generator=g)
+                for r, c in S.plane_shapes(NV12, SRC_W, SRC_H)]
+    tmpl = [torch.empty((0, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(NV12, SRC_W, SRC_H)]
+    lo, hi = D.shard_range(n_total, rank, world)
+    dst = [torch.empty((hi - lo, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(NV12, DST_W, DST_H)]
+    ts = [0.0, 0.0, 0.0]
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(reps + 1):
+        sync()
+        t0 = time.perf_counter()
+        shard = [D.scatter_batch(full[p] if rank == 0 else tmpl[p], n_total) for p in range(2)]
+        sync()
+        t1 = time.perf_counter()
+        if hi > lo:
+            ctx.scale_batch(shard, dst)
+        sync()
+        t2 = time.perf_counter()
+        out = [D.gather_batch(dst[p], n_total) for p in range(2)]
+        sync()
+        t3 = time.perf_counter()
+        if it:                                                    # first round warms the RCCL channels up
+            ts = [ts[0] + t1 - t0, ts[1] + t2 - t1, ts[2] + t3 - t2]
+        del shard, out
+    ts = [x / reps * 1e3 for x in ts]
+    px = n_total * DST_W * DST_H
+    in_b = n_total * SRC_W * SRC_H * 3 // 2
+    out_b = n_total * DST_W * DST_H * 3 // 2
+    return {"frames_total": n_total, "scatter_ms": round(ts[0], 3), "convert_ms": round(ts[1], 3), "gather_ms": round(ts[2], 3),
+            "scatter_GB/s": round(in_b * (world - 1) / world / ts[0] / 1e6, 1), "gather_GB/s": round(out_b * (world - 1) / world / ts[2] / 1e6, 1),
+            "Mpixels/s_convert_only": round(px / ts[1] / 1e3, 1), "Mpixels/s_end_to_end": round(px / sum(ts) / 1e3, 1),
+            "note": "rank 0 holds the batch; ceil(n/world) contiguous frames per rank; p2p isend/recv over RCCL, no reduction"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -416,6 +554,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the RCCL scatter/convert/gather leg at N>1")
     args = ap.parse_args()
 
     import torch
@@ -475,16 +614,34 @@ def main():
         dist.all_reduce(chk)
     assert float(chk.item()) > 0
 
+    # BASELINE's second metric, every N; then (N>1) the scatter -> convert -> gather path over RCCL
+    idct = idct_leg(torch, dist, dev, world)
+    strong = None
+    if world > 1 and not args.no_strong:
+        del src, dst
+        torch.cuda.empty_cache()
+        strong = strong_leg(torch, dist, dev, ctx, S, rank, world, n)
+
     # HBM traffic per launch of the bench kernel from the committed PMC passes (tools/pmc_summary.py): the
     # counters cannot be read from inside this process; null when no pass of this kernel/batch is on file
+    kname = "k_sws_up2<3, 0>" if ctx.up2_path else "k_sws_colwalk<1,6,false,true,true>" if ctx.fast_path else "k_sws_scale_yuv<4,4>"
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_pmc.json")))
         for k, v in pm.items():
-            if ctx.fast_path and k.startswith("k_sws_colwalk") and n == 256:
+            if k.split("<")[0] == kname.split("<")[0] and n == 256:
                 traffic = round(v["traffic_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
+
+    # this box's streaming roofs by traffic mix (the achievable yardstick beside the 8 TB/s spec peak)
+    achievable = None
+    if rank == 0:
+        achievable = {}
+        for pat, name in ((2, "copy"), (1, "write"), (3, "read1_write4_the_scalers_mix"), (0, "read")):
+            g = C.c_double(0)
+            if _lib.lib().ffhip_membw_probe(pat, 2 << 30, 10, C.byref(g)) == 0:
+                achievable[name] = round(g.value, 1)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -500,10 +657,15 @@ def main():
                        "frames_per_gpu": n, "flags": "SWS_BICUBIC", "sharding": "frames/rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_sws_colwalk<1,6,false,true,true>" if ctx.fast_path else "k_sws_scale_yuv<4,4>",
-                         "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME},
+                         "kernel": kname, "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": n * BYTES_PER_FRAME,
+                         "achievable_GB/s": achievable,
+                         "frac_of_achievable_mix": round(achieved / achievable["read1_write4_the_scalers_mix"], 4)
+                         if achievable and achievable.get("read1_write4_the_scalers_mix") else None},
+            "idct": idct,
         }
+        if strong is not None:
+            line["strong"] = strong
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_extras:

@@ -20,6 +20,17 @@ def shard_sizes(n_items, world):
     return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
 
 
+def shard_frame_pairs(n_frames, rank, world):
+    """Motion search over a sequence: pair p searches frame p+1 in frame p, p in [0, n_frames-1).
+    Pairs shard contiguously like everything else; a rank's pairs [plo, phi) read frames [plo, phi] — its own range plus ONE
+    halo frame (the first reference frame of the next rank is this rank's last current frame).
+    Returns (plo, phi, flo, fhi): the pair range and the half-open frame range to hold (empty when the rank has no pair)."""
+    plo, phi = shard_range(max(n_frames - 1, 0), rank, world)
+    if phi <= plo:
+        return plo, phi, plo, plo
+    return plo, phi, plo, phi + 1
+
+
 def init_process_group(backend=None, device=None):
     """Reads RANK / WORLD_SIZE / MASTER_* from the environment (torchrun); 127.0.0.1 rendezvous by default."""
     import torch
@@ -37,17 +48,17 @@ def init_process_group(backend=None, device=None):
     return rank, world
 
 
-def scatter_batch(full, n_items, src=0):
-    """Rank `src` holds `full` ([n_items, ...]); every rank returns its own [hi-lo, ...] shard.
+def scatter_ranges(full, ranges, src=0):
+    """Rank `src` holds `full` ([n, ...]); rank r returns full[ranges[r][0]:ranges[r][1]] (ranges may overlap: halos).
     Implemented with point-to-point sends (xGMI is point-to-point: root egress is the bound, 7 links x ~153 GB/s)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    lo, hi = shard_range(n_items, rank, world)
+    lo, hi = ranges[rank]
     if rank == src:
         reqs = []
         for r in range(world):
-            rlo, rhi = shard_range(n_items, r, world)
+            rlo, rhi = ranges[r]
             if r != src and rhi > rlo:
                 reqs.append(dist.isend(full[rlo:rhi].contiguous(), dst=r))
         mine = full[lo:hi].clone()
@@ -59,6 +70,20 @@ def scatter_batch(full, n_items, src=0):
     if hi > lo:
         dist.recv(out, src=src)
     return out
+
+
+def scatter_batch(full, n_items, src=0):
+    """Rank `src` holds `full` ([n_items, ...]); every rank returns its own [hi-lo, ...] shard (shard_range)."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    return scatter_ranges(full, [shard_range(n_items, r, world) for r in range(world)], src)
+
+
+def scatter_frames_for_pairs(full, n_frames, src=0):
+    """Frames of a sequence for the motion search: every rank gets the frames of its pairs, halo frame included."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    return scatter_ranges(full, [shard_frame_pairs(n_frames, r, world)[2:] for r in range(world)], src)
 
 
 def gather_batch(shard, n_items, dst=0):

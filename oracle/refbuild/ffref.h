@@ -37,6 +37,10 @@ void  ffref_sws_yuv2nv12cX(void *ctx, int dstFormat, const uint8_t *chrDither, c
 /* ---- libavcodec h264dsp / h264qpel / me_cmp (8-bit) ---- */
 /* which: 0 idct_add 1 idct8_add 2 idct_dc_add 3 idct8_dc_add */
 void ffref_h264_idct(int which, uint8_t *dst, int16_t *block, ptrdiff_t stride);
+/* CPU-baseline runners: a batch split statically over pthreads (disjoint blocks / independent frames) */
+int  ffref_h264_idct_batch(int which, uint8_t *dst, ptrdiff_t stride, const int32_t *off, int16_t *blk, int n, int threads);
+int  ffref_sws_scale_frames_mt(void *const *ctxs, const uint8_t *const *const *srcs, const int *ss, uint8_t *const *const *dsts,
+                               const int *ds, int srcH, int threads, int reps);
 /* which: 0 idct_add16 1 idct8_add4 2 idct_add16intra */
 void ffref_h264_idct_multi(int which, uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
                            const uint8_t *nnzc);

@@ -133,6 +133,75 @@ void ffref_h264_idct(int which, uint8_t *dst, int16_t *block, ptrdiff_t stride)
     case 3: h264.idct8_dc_add(dst, block, stride); break;
     }
 }
+/* ---- CPU-baseline runners (bench.py): the reference's own pointers over a batch, split statically over pthreads ---- */
+#include <pthread.h>
+typedef struct { int which; uint8_t *dst; ptrdiff_t stride; const int32_t *off; int16_t *blk; int lo, hi; } IdctJob;
+static void *idct_worker(void *p)
+{
+    IdctJob *j = p;
+    const int step = j->which == 1 || j->which == 3 ? 64 : 16;
+    for (int i = j->lo; i < j->hi; i++) {
+        uint8_t *d = j->dst + j->off[i];
+        int16_t *b = j->blk + (size_t)i * step;
+        switch (j->which) {
+        case 0: h264.idct_add(d, b, j->stride); break;
+        case 1: h264.idct8_add(d, b, j->stride); break;
+        case 2: h264.idct_dc_add(d, b, j->stride); break;
+        default: h264.idct8_dc_add(d, b, j->stride); break;
+        }
+    }
+    return NULL;
+}
+/* which as ffref_h264_idct(); block i is added at dst + off[i]; blocks are disjoint, so any split is the serial result */
+int ffref_h264_idct_batch(int which, uint8_t *dst, ptrdiff_t stride, const int32_t *off, int16_t *blk, int n, int threads)
+{
+    dsp_init();
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    pthread_t th[1024];
+    IdctJob job[1024];
+    const int per = (n + threads - 1) / threads;
+    int started = 0;
+    for (int t = 0; t < threads; t++) {
+        int lo = t * per, hi = lo + per > n ? n : lo + per;
+        if (lo >= hi) break;
+        job[t] = (IdctJob){ which, dst, stride, off, blk, lo, hi };
+        if (threads == 1) { idct_worker(&job[t]); return 0; }
+        if (pthread_create(&th[t], NULL, idct_worker, &job[t])) break;
+        started++;
+    }
+    for (int t = 0; t < started; t++)
+        pthread_join(th[t], NULL);
+    return started;
+}
+
+typedef struct { void *ctx; const uint8_t *const *src; const int *ss; uint8_t *const *dst; const int *ds; int h, reps; } SwsJob;
+static void *sws_worker(void *p)
+{
+    SwsJob *j = p;
+    for (int r = 0; r < j->reps; r++)
+        sws_scale(j->ctx, j->src, j->ss, 0, j->h, j->dst, j->ds);
+    return NULL;
+}
+/* frame-parallel scaling: `threads` single-threaded contexts, each converting its own frame `reps` times (the way a
+ * batch of independent frames uses all host cores; ffref_sws_create(..., threads) is the slice-threaded alternative) */
+int ffref_sws_scale_frames_mt(void *const *ctxs, const uint8_t *const *const *srcs, const int *ss, uint8_t *const *const *dsts,
+                              const int *ds, int srcH, int threads, int reps)
+{
+    pthread_t th[1024];
+    SwsJob job[1024];
+    if (threads > 1024) threads = 1024;
+    int started = 0;
+    for (int t = 0; t < threads; t++) {
+        job[t] = (SwsJob){ ctxs[t], srcs[t], ss, dsts[t], ds, srcH, reps };
+        if (pthread_create(&th[t], NULL, sws_worker, &job[t])) break;
+        started++;
+    }
+    for (int t = 0; t < started; t++)
+        pthread_join(th[t], NULL);
+    return started;
+}
+
 void ffref_h264_idct_multi(int which, uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
                            const uint8_t *nnzc)
 {

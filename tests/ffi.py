@@ -198,6 +198,10 @@ def ref():
         L.ffref_sws_free.restype = None
         L.ffref_sws_scale.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                       C.POINTER(u8p), C.POINTER(C.c_int)]
+        if hasattr(L, "ffref_h264_idct_batch"):
+            L.ffref_h264_idct_batch.argtypes = [C.c_int, u8p, C.c_ssize_t, i32p, i16p, C.c_int, C.c_int]
+            L.ffref_sws_scale_frames_mt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
+                                                    C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
         L.ffref_sws_filter.argtypes = [C.c_void_p, C.c_int, C.POINTER(i16p), C.POINTER(i32p), C.POINTER(C.c_int)]
         L.ffref_sws_is_unscaled.argtypes = [C.c_void_p]
         L.ffref_sws_hyscale.argtypes = [C.c_void_p, i16p, C.c_int, u8p, i16p, i32p, C.c_int]

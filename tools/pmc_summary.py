@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_summary.py <gpurun_out> <tag> — folds the rocprofv3 PMC passes of tools/gpu_round_*.sh into
+"""tools/pmc_summary.py <gpurun_out> <tag> — folds the rocprofv3 PMC passes of tools/gpu.sh into
 profiles/<tag>_pmc.txt (readable) and profiles/<tag>_pmc.json (what bench.py reports as roofline.traffic).
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB units; the x2 is the gfx950 correction for wide
 coalesced reads given in MI355X_MICROARCH.md's HBM section; WRITE_SIZE is taken as reported)."""
@@ -42,4 +42,5 @@ for k, cs in acc.items():
 open(os.path.join(root, "profiles", tag + "_pmc.txt"), "w").write("\n".join(lines) + "\n")
 open(os.path.join(out_dir, tag + "_pmc.txt"), "w").write("\n".join(lines) + "\n")  # gpurun merges only gpurun_out/ back
 json.dump(js, open(os.path.join(root, "profiles", tag + "_pmc.json"), "w"), indent=1)
+json.dump(js, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1)
 print("\n".join(lines))
