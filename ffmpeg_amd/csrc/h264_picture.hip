@@ -198,6 +198,12 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
     for (int pl = 0; pl < 3; pl++)
         if (!dst[pl] || !ref[pl] || stride[pl] <= 0)
             return FFHIP_EINVAL;
+    /* a finished deblocking wavefront (an earlier picture's) that lost a hand-off is reported now rather than never */
+    {
+        const int r = ffhip_h264_deblock_check();
+        if (r < 0)
+            return r;
+    }
 
     /* layout of the one staging buffer */
     size_t total = 0;

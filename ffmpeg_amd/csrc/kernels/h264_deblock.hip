@@ -17,8 +17,8 @@
  *                          agent-scope release/acquire progress counter (row y may start MB x once row y-1
  *                          has published x+2).  Results equal the serial order bit for bit.
  */
-#include <atomic>
 #include <mutex>
+#include <stdlib.h>
 
 #include "common.h"
 #include "h264_kernels.h"
@@ -149,13 +149,12 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
-                                                           const FFHipH264Edge *edges, int *progress)
+                                                           const FFHipH264Edge *edges, int *progress, int *fail)
 {
-    /* blockIdx.y = frame: frames are independent, each has its own counters (mb_h progress words + a fail flag) */
+    /* blockIdx.y = frame: frames are independent, each has its own counters (mb_h progress words; one spare) */
     luma += (size_t)blockIdx.y * frame_pitch;
     edges += (size_t)blockIdx.y * mb_w * mb_h * 8;
     progress += (size_t)blockIdx.y * (mb_h + 1);
-    int *fail = progress + mb_h;
     /* tile[r][c]: r = picture row - (16*my - 4), c = picture column - (16*mx - 4); rows are dword aligned */
     __shared__ __align__(16) uint8_t tile[20 * TP];
     const int my = blockIdx.x, lane = threadIdx.x;
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
                         if (lane == 0)
-                            atomicExch(fail, 1);
+                            __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         return;
                     }
                 }
@@ -304,174 +303,489 @@ __global__ __launch_bounds__(64) void k_h264_deblock_frame(uint8_t *luma, size_t
 }
 
 /*
- * k_h264_deblock_frame_chroma — one 4:2:0 chroma plane in the decoder's order: per macroblock (8x8 samples) the vertical edges
- * at x = 0 and 4, then the horizontal ones at y = 0 and 4 (filter_mb_dir filters chroma on the even luma edges,
- * h264_loopfilter.c:644-700).  Same wavefront as the luma kernel: one wave per macroblock row, MB (x, y) after (x+1, y-1); the
- * tile is the MB + 4 columns / 2 rows of context; a chroma filter reads two samples and writes one on either side, so the two
- * edges of a direction touch disjoint samples and run side by side (lanes 0-7 / 8-15).  Dword-aligned planes only: everything
- * that crosses rows moves with device-scope loads / stores and the hand-off is order-only, as in the luma kernel's fast path.
+ * k_h264_deblock_band — the same decoder-order wavefront, built around the time of ONE macroblock.
+ *
+ * A picture is a chain of ~mb_w + 2 mb_h dependent macroblocks and a macroblock is a chain of 8 filters (every edge reads
+ * samples the previous one wrote): the picture's time is (mb_w + 2 mb_h) x the time one wave needs for one macroblock.  Measured
+ * on the frame kernel above (tools/db_exp.py): 5.5 us per macroblock, of which 4 us are the filters themselves (~2000 issued
+ * instructions: byte loads / stores around every edge, per-lane control flow, edge records fetched through LDS), 1.2 us the
+ * tile bookkeeping and only the rest the hand-off.  Hence:
+ *   - a pass keeps its line in REGISTERS across its edges: lane = row for the vertical edges (the row's samples arrive as
+ *     dwords), lane = column for the horizontal ones; the tile is touched once per pass, no barrier between edges;
+ *   - the macroblock's edge records arrive through SCALAR loads one macroblock ahead: alpha / beta / kind are SGPRs, the
+ *     skip and intra decisions are scalar branches, the filters themselves are branch-free (selects, v_sad_u32, v_med3);
+ *   - two tiles alternate: the left context of a macroblock is simply the previous tile's last dword column (no copy), and
+ *     the store list of a step is FIXED per lane (its rows' first NDW-1 dwords + the previous macroblock's last dword, final
+ *     now that this macroblock's left-edge filter has run): one store instruction for the rows, one for the context rows.
+ * Rows inside a BAND of W consecutive macroblock rows (one workgroup, wave w = row W b + w; W = 4: one wave per SIMD, the waves
+ * are latency-bound and must not share an issue port) hand off through LDS: wave w publishes the bottom CTX rows of each
+ * macroblock into a ring of R slots (first NDW-1 dwords at step x, the last dword a step later) and bumps its LDS progress
+ * word; wave w+1 spins on it (MB x may start when x + 2 macroblocks of the row above are done), and finishes the CTX-1
+ * rows above itself: every picture byte is written once, by the wave that gives it its final value.  A producer never runs
+ * more than R macroblocks ahead (it checks the consumer's progress before reusing a slot).  Only the last row of a band talks
+ * to the next band through memory, with the frame kernel's protocol (write-through stores, acknowledged, then a device-scope
+ * counter).
+ * CHROMA: one 4:2:0 chroma plane, 8x8 samples per macroblock, edges at 0 and 4 (the even luma edges, filter_mb_dir
+ * h264_loopfilter.c:644-700).  Dword-aligned planes only (the byte path stays on k_h264_deblock_frame).
  */
-#define CTP 16 /* chroma tile pitch: 4 context columns + 8 + 4 */
-__global__ __launch_bounds__(64) void k_h264_deblock_frame_chroma(uint8_t *plane, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
-                                                                  const FFHipH264Edge *edges, int *progress)
+#define DB_R 16      /* ring slots per row boundary */
+
+__device__ __forceinline__ int db_sad(int a, int b)
 {
+    int d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+/* one sample line across one edge, in registers, branch-free; v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3.  Same arithmetic as lf_line
+ * (h264dsp_template.c:104-330): `if (tc0) p1 += clip(..., -tc0, tc0)` is the unconditional form because the clip range is empty
+ * when tc0 == 0. */
+template <bool CHROMA>
+__device__ __forceinline__ void db_normal(int (&v)[8], int alpha, int beta, int tc0)
+{
+    const int p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6];
+    /* `&`, not `&&`: no short-circuit control flow — the lanes of an edge take every path anyway */
+    int c = (int)(db_sad(p0, q0) < alpha) & (int)(db_sad(p1, p0) < beta) & (int)(db_sad(q1, q0) < beta);
+    if (CHROMA) {
+        c &= (int)(tc0 > 0);
+        const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc0, tc0);
+        v[3] = c ? clip3(p0 + delta, 0, 255) : p0;
+        v[4] = c ? clip3(q0 - delta, 0, 255) : q0;
+        return;
+    }
+    c &= (int)(tc0 >= 0);
+    const int ap = db_sad(p2, p0) < beta, aq = db_sad(q2, q0) < beta;
+    const int avg = (p0 + q0 + 1) >> 1;
+    const int dp = clip3(((p2 + avg) >> 1) - p1, -tc0, tc0), dq = clip3(((q2 + avg) >> 1) - q1, -tc0, tc0);
+    const int tc = tc0 + ap + aq;
+    const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+    v[2] = (c & ap) ? p1 + dp : p1;
+    v[5] = (c & aq) ? q1 + dq : q1;
+    v[3] = c ? clip3(p0 + delta, 0, 255) : p0;
+    v[4] = c ? clip3(q0 - delta, 0, 255) : q0;
+}
+
+template <bool CHROMA>
+__device__ __forceinline__ void db_intra(int (&v)[8], int alpha, int beta)
+{
+    const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
+    const int d0 = db_sad(p0, q0);
+    const int c = (int)(d0 < alpha) & (int)(db_sad(p1, p0) < beta) & (int)(db_sad(q1, q0) < beta);
+    const int wp0 = (2 * p1 + p0 + q1 + 2) >> 2, wq0 = (2 * q1 + q0 + p1 + 2) >> 2; /* the weak forms */
+    if (CHROMA) {
+        v[3] = c ? wp0 : p0;
+        v[4] = c ? wq0 : q0;
+        return;
+    }
+    const int strong = d0 < ((alpha >> 2) + 2);
+    const int sp = c & strong & (int)(db_sad(p2, p0) < beta), sq = c & strong & (int)(db_sad(q2, q0) < beta);
+    const int s4 = p0 + q0;
+    v[3] = sp ? (p2 + 2 * p1 + 2 * s4 + q1 + 4) >> 3 : c ? wp0 : p0;
+    v[2] = sp ? (p2 + p1 + s4 + 2) >> 2 : p1;
+    v[1] = sp ? (2 * p3 + 3 * p2 + p1 + s4 + 4) >> 3 : p2;
+    v[4] = sq ? (p1 + 2 * s4 + 2 * q1 + q2 + 4) >> 3 : c ? wq0 : q0;
+    v[5] = sq ? (s4 + q1 + q2 + 2) >> 2 : q1;
+    v[6] = sq ? (2 * q3 + 3 * q2 + q1 + s4 + 4) >> 3 : q2;
+}
+
+typedef uint32_t db_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t db_u8 __attribute__((ext_vector_type(8)));
+typedef const db_u4 __attribute__((address_space(4))) *db_cc4;
+typedef const db_u8 __attribute__((address_space(4))) *db_cc8;
+
+template <bool CHROMA, int DB_W> /* DB_W: waves (macroblock rows) per band */
+__global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
+                                                                 const FFHipH264Edge *edges, int *gprog, int nbands, int *fail, int fault)
+{
+    constexpr int MB = CHROMA ? 8 : 16;          /* samples per macroblock side */
+    constexpr int CTX = CHROMA ? 2 : 4;          /* context rows above a macroblock */
+    constexpr int NDW = MB / 4;                  /* dwords per macroblock row */
+    constexpr int NE = CHROMA ? 4 : 8;           /* edge records per macroblock */
+    constexpr int TPP = MB + 4;                  /* tile pitch (an odd number of dwords: rows fall into different banks) */
+    constexpr int TR = MB + CTX;                 /* tile rows: context rows first */
+    constexpr int TSZ = TR * TPP;
+    __shared__ __align__(16) uint8_t tiles[DB_W][2 * TSZ];
+    __shared__ uint32_t ring[DB_W][DB_R][CTX * NDW];
+    __shared__ int lprog[DB_W + 1];
+
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int band = blockIdx.x, my = band * DB_W + w;
     plane += (size_t)blockIdx.y * frame_pitch;
-    edges += (size_t)blockIdx.y * mb_w * mb_h * 4;
-    progress += (size_t)blockIdx.y * (mb_h + 1);
-    int *fail = progress + mb_h;
-    /* tile[r][c]: r = row - (8 my - 2), c = column - (8 mx - 4) */
-    __shared__ __align__(16) uint8_t tile[10 * CTP];
-    __shared__ uint32_t edl[12];
-    const int my = blockIdx.x, lane = threadIdx.x;
-    uint8_t *rowbase = plane + (ptrdiff_t)my * 8 * stride;
-    const int pr = lane >> 1, pc = 4 * (lane & 1); /* lanes 0..15: this lane's dword of the 8x8 block */
-    uint32_t own = 0, edw = 0;
+    edges += (size_t)blockIdx.y * mb_w * mb_h * NE;
+    gprog += (size_t)blockIdx.y * nbands;
+    if (lane == 0)
+        lprog[w] = 0;
+    if (threadIdx.x == 0)
+        lprog[DB_W] = 0;
+    __syncthreads();
+    if (my >= mb_h)
+        return;
+    uint8_t *tbase = tiles[w];
+    uint8_t *rowbase = plane + (ptrdiff_t)my * MB * stride;
+    const bool has_below = my + 1 < mb_h;
+    const bool to_lds = has_below && w + 1 < DB_W;      /* the row below is this workgroup's */
+    const bool to_mem = has_below && w + 1 == DB_W;     /* ... the next workgroup's */
+    const bool from_lds = my > 0 && w > 0;              /* else (my > 0): from the band above, through memory */
+    const int rlast = to_lds ? MB - CTX : MB - 1;       /* last own row this wave gives its final value */
+
+    /* ---- per-lane constants.  (pr, ps): this lane's row / dword slot of the MB x NDW grid (lanes 0 .. MB NDW - 1) ---- */
+    const int pr = lane / NDW, ps = lane % NDW;
+    const bool in_mb = lane < MB * NDW;
+    const int lown = (pr + CTX) * TPP + 4 * ps;                         /* tile offset of the lane's own dword */
+    const ptrdiff_t gown = (ptrdiff_t)pr * stride + 4 * ps;            /* ... its picture offset inside the macroblock */
+    /* store list, own rows: slots 0 .. NDW-2 = this macroblock's dwords, slot NDW-1 = the previous macroblock's last dword */
+    const bool sprev = ps == NDW - 1;
+    const int lst = (pr + CTX) * TPP + (sprev ? MB - 4 : 4 * ps);
+    const ptrdiff_t gst = (ptrdiff_t)pr * stride + (sprev ? -4 : 4 * ps);
+    const bool st_row = in_mb && pr <= rlast;
+    /* store list, context rows -(CTX-1) .. -1: all NDW dwords of this macroblock (lanes 0 .. (CTX-1) NDW - 1) */
+    const int cr = lane / NDW + 1;                                      /* tile row 1 .. CTX-1 */
+    const bool st_ctx = my > 0 && lane < (CTX - 1) * NDW;
+    const int lctx = cr * TPP + 4 * ps;
+    const ptrdiff_t gctx = (ptrdiff_t)(cr - CTX) * stride + 4 * ps;
+    /* ring (bottom CTX rows = tile rows MB .. MB+CTX-1): lanes 0 .. CTX NDW - 1 */
+    const bool in_ring = lane < CTX * NDW;
+    const int lring = (MB + lane / NDW) * TPP + (sprev ? MB - 4 : 4 * ps);
+    const int tcsh = 8 * (CHROMA ? (lane & 7) >> 1 : (lane & 15) >> 2); /* this line's tc0 byte of an edge record */
+
+    /* The next macroblock's own samples are fetched a step ahead.  The load is issued from inline asm and awaited by an explicit
+     * s_waitcnt vmcnt(N), N = the store instructions issued after it: the compiler's own wait would be vmcnt(0) — a drain of the
+     * step's picture stores, i.e. a round trip to L2 per macroblock on the picture's critical path. */
+    uint32_t own = 0;
+    const uint8_t *ownp = rowbase + (in_mb ? gown : 0);
     auto fetch = [&](int mx) {
-        if (lane < 16)
-            own = *reinterpret_cast<const uint32_t *>(rowbase + mx * 8 + (ptrdiff_t)pr * stride + pc);
-        if (lane < 12)
-            edw = reinterpret_cast<const uint32_t *>(edges + (size_t)(my * mb_w + mx) * 4)[lane];
+        const uint8_t *p = ownp + mx * MB;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(own) : "v"(p) : "memory");
     };
-    int known = 0;
+    /* edge records of a macroblock: NE x 3 dwords through the scalar cache */
+    const uint32_t *erow = reinterpret_cast<const uint32_t *>(edges + (size_t)my * mb_w * NE);
+    uint32_t en[3 * NE];
+    auto fetch_edges = [&](int mx) { /* issued at the top of the macroblock's own step: the wait for the row above hides it */
+        const uint32_t *p = erow + (size_t)mx * 3 * NE;
+        if (CHROMA) {
+            const db_u8 a = *(db_cc8)p;
+            const db_u4 b = *(db_cc4)(p + 8);
+            en[0] = a.s0; en[1] = a.s1; en[2] = a.s2; en[3] = a.s3; en[4] = a.s4; en[5] = a.s5; en[6] = a.s6; en[7] = a.s7;
+            en[8] = b.x; en[9] = b.y; en[10] = b.z; en[11] = b.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const db_u8 a = *(db_cc8)(p + 8 * q);
+                en[8 * q] = a.s0; en[8 * q + 1] = a.s1; en[8 * q + 2] = a.s2; en[8 * q + 3] = a.s3;
+                en[8 * q + 4] = a.s4; en[8 * q + 5] = a.s5; en[8 * q + 6] = a.s6; en[8 * q + 7] = a.s7;
+            }
+        }
+    };
+    int known = 0, kbelow = 0;
     fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(own) : : "memory"); /* the first one has no stores behind it */
     for (int mx = 0; mx < mb_w; mx++) {
-        uint8_t *mb = rowbase + mx * 8;
-        if (lane < 16)
-            *reinterpret_cast<uint32_t *>(&tile[(pr + 2) * CTP + 4 + pc]) = own;
-        if (lane < 12)
-            edl[lane] = edw;
-        if (mx + 1 < mb_w)
+        uint8_t *mb = rowbase + mx * MB;
+        uint8_t *cur = tbase + (mx & 1) * TSZ, *prev = tbase + ((mx & 1) ^ 1) * TSZ;
+        const bool last = mx + 1 == mb_w;
+        fetch_edges(mx);
+        const uint32_t (&ec)[3 * NE] = en;
+        /* stores issued since the fetch: the rows' (always), the context rows' (my > 0); rows that hand off through memory
+         * have drained everything at their publish */
+        if (fault & 2)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(own) : : "memory");
+        else if (my > 0)
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(own) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(own) : : "memory");
+        if (in_mb)
+            *reinterpret_cast<uint32_t *>(cur + lown) = own;
+        if (!last)
             fetch(mx + 1);
+        /* ---- context rows: the row above must have finished macroblock mx + 1 ---- */
         if (my > 0) {
-            /* rows -2, -1 over this MB belong to the row above: wait until it has finished MB mx + 1 */
-            const int want = min(mx + 2, mb_w);
+            const int want = (fault & 8) ? 0 : min(mx + 2, mb_w);
             int spins = 0;
             while (known < want) {
-                known = __hip_atomic_load(&progress[my - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                known = from_lds ? __hip_atomic_load(&lprog[w - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                 : __hip_atomic_load(&gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (known >= want)
                     break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
                     if (lane == 0)
-                        atomicExch(fail, 1);
+                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     return;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane < 4) {
-                const int r = lane >> 1, c = 4 * (lane & 1);
-                const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(mb + (ptrdiff_t)(r - 2) * stride + c), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                *reinterpret_cast<uint32_t *>(&tile[r * CTP + 4 + c]) = v;
+            if (in_ring) {
+                uint32_t v;
+                if (from_lds)
+                    v = ring[w - 1][mx % DB_R][lane];
+                else /* written write-through by the band above: device-scope (L1-bypassing) loads */
+                    v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(mb + (ptrdiff_t)(lane / NDW - CTX) * stride + 4 * ps),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *reinterpret_cast<uint32_t *>(cur + (lane / NDW) * TPP + 4 * ps) = v;
             }
         }
         wave_lds_sync();
-        const FFHipH264Edge *e = reinterpret_cast<const FFHipH264Edge *>(edl);
-        const int k = (lane >> 3) & 1, line = lane & 7;
-        { /* vertical edges at columns 0 and 4: lane = (edge, row) */
-            const FFHipH264Edge ed = e[k];
-            if (lane < 16 && ed.alpha && ed.beta && !(k == 0 && mx == 0)) {
-                const bool intra = ed.kind >= 4;
-                lf_apply(&tile[(line + 2) * CTP + 4 + 4 * k], 1, intra ? 3 : 1, ed.alpha, ed.beta, intra ? 0 : ed.tc0[line >> 1]);
+        /* ---- vertical edges, left to right: lane = row; samples -4 .. MB-1 of the row ---- */
+        if (lane < MB && !(fault & 4)) {
+            uint8_t *trow = cur + (lane + CTX) * TPP, *tprev = prev + (lane + CTX) * TPP + MB - 4;
+            int x[MB + 4];
+#pragma unroll
+            for (int d = 0; d < NDW + 1; d++) {
+                const uint32_t v = d ? *reinterpret_cast<const uint32_t *>(trow + 4 * d - 4) : *reinterpret_cast<const uint32_t *>(tprev);
+                x[4 * d] = v & 255; x[4 * d + 1] = (v >> 8) & 255; x[4 * d + 2] = (v >> 16) & 255; x[4 * d + 3] = v >> 24;
+            }
+#pragma unroll
+            for (int k = 0; k < NDW; k++) {
+                const uint32_t rec = ec[3 * k + 1], tcw = ec[3 * k + 2];
+                const int alpha = (rec >> 8) & 255, beta = (rec >> 16) & 255;
+                if (alpha && beta && !(k == 0 && mx == 0)) { /* scalar */
+                    int v[8] = { x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3], x[4 * k + 4], x[4 * k + 5], x[4 * k + 6], x[4 * k + 7] };
+                    if ((rec & 255) >= 4)
+                        db_intra<CHROMA>(v, alpha, beta);
+                    else
+                        db_normal<CHROMA>(v, alpha, beta, (int)(int8_t)(tcw >> tcsh));
+#pragma unroll
+                    for (int i = 1; i < 7; i++)
+                        x[4 * k + i] = v[i];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < NDW + 1; d++) {
+                const uint32_t v = (uint32_t)x[4 * d] | ((uint32_t)x[4 * d + 1] << 8) | ((uint32_t)x[4 * d + 2] << 16) | ((uint32_t)x[4 * d + 3] << 24);
+                if (d)
+                    *reinterpret_cast<uint32_t *>(trow + 4 * d - 4) = v;
+                else
+                    *reinterpret_cast<uint32_t *>(tprev) = v;
             }
         }
         wave_lds_sync();
-        { /* horizontal edges at rows 0 and 4: lane = (edge, column) */
-            const FFHipH264Edge ed = e[2 + k];
-            if (lane < 16 && ed.alpha && ed.beta && !(k == 0 && my == 0)) {
-                const bool intra = ed.kind >= 4;
-                lf_apply(&tile[(2 + 4 * k) * CTP + 4 + line], CTP, intra ? 3 : 1, ed.alpha, ed.beta, intra ? 0 : ed.tc0[line >> 1]);
+        /* ---- horizontal edges, top to bottom: lane = column; y[i] = row i - 4 (chroma: rows -2 .. 7, y[0], y[1] unused) ---- */
+        if (lane < MB && !(fault & 4)) {
+            uint8_t *tcol = cur + lane;
+            int y[MB + 4];
+#pragma unroll
+            for (int r = 0; r < MB + 4; r++)
+                y[r] = r >= 4 - CTX ? tcol[(r - (4 - CTX)) * TPP] : 0;
+#pragma unroll
+            for (int k = 0; k < NDW; k++) {
+                const uint32_t rec = ec[3 * (NDW + k) + 1], tcw = ec[3 * (NDW + k) + 2];
+                const int alpha = (rec >> 8) & 255, beta = (rec >> 16) & 255;
+                if (alpha && beta && !(k == 0 && my == 0)) {
+                    int v[8] = { y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3], y[4 * k + 4], y[4 * k + 5], y[4 * k + 6], y[4 * k + 7] };
+                    if ((rec & 255) >= 4)
+                        db_intra<CHROMA>(v, alpha, beta);
+                    else
+                        db_normal<CHROMA>(v, alpha, beta, (int)(int8_t)(tcw >> tcsh));
+#pragma unroll
+                    for (int i = 1; i < 7; i++)
+                        y[4 * k + i] = v[i];
+                }
+            }
+            /* rows a horizontal filter can have changed: all but the first context row and the last row of the block */
+#pragma unroll
+            for (int r = 5 - CTX; r < MB + 3; r++)
+                tcol[(r - (4 - CTX)) * TPP] = (uint8_t)y[r];
+        }
+        wave_lds_sync();
+        /* ---- the picture: everything this macroblock has made final (see the header) ---- */
+        if (!(fault & 2)) {
+            if (st_row && !(sprev && mx == 0)) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>((sprev ? prev : cur) + lst);
+                uint32_t *g = reinterpret_cast<uint32_t *>(mb + gst);
+                if (to_mem)
+                    __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    *g = v;
+            }
+            if (st_ctx)
+                *reinterpret_cast<uint32_t *>(mb + gctx) = *reinterpret_cast<const uint32_t *>(cur + lctx);
+            if (last && st_row && sprev) { /* the row's last dword column: no macroblock to its right will touch it */
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(cur + lst);
+                uint32_t *g = reinterpret_cast<uint32_t *>(mb + gst + MB);
+                if (to_mem)
+                    __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    *g = v;
             }
         }
-        wave_lds_sync();
-        /* write back rows 0..7 x columns -4..7 and row -1 x columns 0..7 (untouched samples keep their values) */
-        if (lane < 26) {
-            int r, c;
-            if (lane < 24) { r = lane / 3; c = 4 * (lane % 3) - 4; } else { r = -1; c = 4 * (lane - 24); }
-            if (!((c < 0 && mx == 0) || (r < 0 && my == 0)))
-                __hip_atomic_store(reinterpret_cast<uint32_t *>(mb + (ptrdiff_t)r * stride + c),
-                                   *reinterpret_cast<const uint32_t *>(&tile[(r + 2) * CTP + 4 + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        /* ---- the row below, inside the band: bottom CTX rows into the ring ---- */
+        if (to_lds) {
+            if (mx >= DB_R) { /* slot reuse: the consumer must be done with macroblock mx - DB_R */
+                int spins = 0;
+                while (kbelow < mx - DB_R + 1) {
+                    kbelow = __hip_atomic_load(&lprog[w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (kbelow >= mx - DB_R + 1)
+                        break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 24)) {
+                        if (lane == 0)
+                            __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        return;
+                    }
+                }
+            }
+            if (in_ring) {
+                if (!sprev)
+                    ring[w][mx % DB_R][lane] = *reinterpret_cast<const uint32_t *>(cur + lring);
+                else if (mx > 0)
+                    ring[w][(mx - 1) % DB_R][lane] = *reinterpret_cast<const uint32_t *>(prev + lring);
+                if (last && sprev)
+                    ring[w][mx % DB_R][lane] = *reinterpret_cast<const uint32_t *>(cur + lring);
+            }
         }
-        /* the MB's right 4 columns are the next MB's left context */
-        wave_lds_sync();
-        const uint32_t keep = *reinterpret_cast<const uint32_t *>(&tile[(lane < 10 ? lane : 0) * CTP + 4 + 4]);
-        wave_lds_sync();
-        if (lane < 10)
-            *reinterpret_cast<uint32_t *>(&tile[lane * CTP]) = keep;
-        /* publish: the write-through stores above are acknowledged before the counter moves */
+        /* ---- publish (fault & 1: test hook — rows never publish, so the row below must time out and report) ---- */
+        if (fault & 1)
+            continue;
+        if (to_mem) {
+            /* the write-through stores above are complete (acknowledged) before the counter moves.  A macroblock's last dword
+             * column is stored a step later, which the consumer's `x + 2 macroblocks done` already accounts for */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            if (lane == 0)
+                __hip_atomic_store(&gprog[band], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0)
-            __hip_atomic_store(&progress[my], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) /* rows that hand off through memory publish here too: the row above paces its ring by this word */
+            __hip_atomic_store(&lprog[w], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-/* progress counters: a small ring of slots in one device allocation made on first use (stream-ordered zeroing
- * per launch); a per-launch hipMallocAsync/hipFreeAsync pair serialises launches across streams */
+/*
+ * Progress counters of the launches in flight: a ring of slots in one device allocation made on first use, zeroed in
+ * stream order per launch.  A slot is taken again only after the launch that used it has finished (an event per slot),
+ * and every slot has a FAIL word in pinned host memory that the kernels set on a spin timeout (never in a correct run:
+ * a lost hand-off).  The words are checked when a slot is reused and by ffhip_h264_deblock_check() — which
+ * ffhip_stream_synchronize() and the picture pipeline's flush call — so a partly filtered picture is reported
+ * (FFHIP_EIO), not returned silently.
+ */
 #define DB_SLOTS 64
 #define DB_SLOT_INTS 2048
+struct DbSlot { hipEvent_t done; bool used; };
 static int *g_db_pool;
-static std::atomic<unsigned> g_db_next;
+static int *g_db_fail; /* pinned host, one word per slot */
+static DbSlot g_db_slot[DB_SLOTS];
+static unsigned g_db_next;
+static bool g_db_failed;
 static std::mutex g_db_mu;
+
+static int db_pool_init()
+{
+    if (g_db_pool)
+        return 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_db_pool), (size_t)DB_SLOTS * DB_SLOT_INTS * sizeof(int)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g_db_fail), DB_SLOTS * sizeof(int), hipHostMallocMapped));
+    for (int i = 0; i < DB_SLOTS; i++) {
+        g_db_fail[i] = 0;
+        HIP_TRY(hipEventCreateWithFlags(&g_db_slot[i].done, hipEventDisableTiming));
+        g_db_slot[i].used = false;
+    }
+    ffhip_note_device_resources();
+    return 0;
+}
+
+/* under g_db_mu: next slot whose previous launch has finished; its counters and fail word */
+static int db_slot_acquire(int **prog, int **fail, int *slot)
+{
+    int r = db_pool_init();
+    if (r < 0)
+        return r;
+    const int i = (int)(g_db_next++ % DB_SLOTS);
+    if (g_db_slot[i].used) {
+        HIP_TRY(hipEventSynchronize(g_db_slot[i].done));
+        if (g_db_fail[i]) {
+            g_db_fail[i] = 0;
+            g_db_failed = true;
+        }
+    }
+    g_db_slot[i].used = true;
+    *prog = g_db_pool + (size_t)i * DB_SLOT_INTS;
+    *fail = g_db_fail + i;
+    *slot = i;
+    return 0;
+}
+
+int ffhip_h264_deblock_check(void)
+{
+    std::lock_guard<std::mutex> lk(g_db_mu);
+    if (g_db_fail)
+        for (int i = 0; i < DB_SLOTS; i++)
+            if (g_db_slot[i].used && hipEventQuery(g_db_slot[i].done) == hipSuccess && g_db_fail[i]) {
+                g_db_fail[i] = 0;
+                g_db_failed = true;
+            }
+    if (g_db_failed) {
+        g_db_failed = false;
+        ffhip_set_error("ffhip_h264_deblock: a frame-order deblocking launch timed out waiting for a row hand-off; its picture is only partly filtered");
+        return FFHIP_EIO;
+    }
+    return 0;
+}
+
+static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                          const FFHipH264Edge *edges, hipStream_t stream)
+{
+    if (mb_w <= 0 || mb_h <= 0 || nframes <= 0)
+        return 0;
+    const bool aligned = !(((uintptr_t)plane | (size_t)stride | frame_pitch) & 3);
+    if (chroma && !aligned) {
+        ffhip_set_error("ffhip_h264_deblock_frame_chroma: plane, stride and frame pitch must be 4-byte aligned");
+        return FFHIP_EINVAL;
+    }
+    const char *eo = getenv("FFHIP_DEBLOCK_OLD"); /* the per-row-workgroup kernel (measurement / cross-check) */
+    const char *ef = getenv("FFHIP_DEBLOCK_FAULT"); /* test hook: lost hand-offs -> timeout -> FFHIP_EIO at the next check */
+    const int fault = ef ? atoi(ef) : 0; /* 1: the test hook; 2 no stores, 4 no filters, 8 no waiting: timing experiments (wrong output) */
+    const bool band = aligned && !(eo && eo[0] == '1' && !chroma);
+    /* rows per band.  A lone picture is latency-bound: 4 = one wave per SIMD, the waves of a band must not share an issue port
+     * (measured 1.9 ms vs 2.4 ms per 4K plane).  A batch that fills the chip anyway is throughput-bound: 16 keeps 15 of 16
+     * hand-offs in LDS (32 planes: 2.9 ms vs 4.9 ms).  FFHIP_DEBLOCK_BAND = 4 / 8 / 16 overrides. */
+    const char *ew = getenv("FFHIP_DEBLOCK_BAND");
+    const int bw = ew && atoi(ew) == 16 ? 16 : ew && atoi(ew) == 8 ? 8 : ew && atoi(ew) == 4 ? 4 :
+                   (long long)nframes * mb_h > 2048 ? 16 : 4;
+    const int nbands = cdiv(mb_h, bw);
+    const int per_frame = band ? nbands : mb_h + 1;
+    if (per_frame > DB_SLOT_INTS) {
+        ffhip_set_error("ffhip_h264_deblock_frame: %d macroblock rows exceed the supported %d", mb_h, DB_SLOT_INTS - 1);
+        return FFHIP_EINVAL;
+    }
+    const int ne = chroma ? 4 : 8;
+    const int per_launch = DB_SLOT_INTS / per_frame; /* frames whose counters fit one pool slot */
+    for (int f0 = 0; f0 < nframes; f0 += per_launch) {
+        const int nf = nframes - f0 < per_launch ? nframes - f0 : per_launch;
+        std::lock_guard<std::mutex> lk(g_db_mu);
+        int *prog, *fail, slot;
+        const int r = db_slot_acquire(&prog, &fail, &slot);
+        if (r < 0)
+            return r;
+        HIP_TRY(hipMemsetAsync(prog, 0, (size_t)nf * per_frame * sizeof(int), stream));
+        uint8_t *pl = plane + (size_t)f0 * frame_pitch;
+        const FFHipH264Edge *ed = edges + (size_t)f0 * mb_w * mb_h * ne;
+        if (!band)
+            hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h, nf), dim3(64), 0, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, fail);
+#define DB_LAUNCH(CH, W) hipLaunchKernelGGL((k_h264_deblock_band<CH, W>), dim3(nbands, nf), dim3(64 * W), 0, stream, pl, frame_pitch, stride, \
+                                            mb_w, mb_h, ed, prog, nbands, fail, fault)
+        else if (chroma) { if (bw == 16) DB_LAUNCH(true, 16); else if (bw == 8) DB_LAUNCH(true, 8); else DB_LAUNCH(true, 4); }
+        else             { if (bw == 16) DB_LAUNCH(false, 16); else if (bw == 8) DB_LAUNCH(false, 8); else DB_LAUNCH(false, 4); }
+#undef DB_LAUNCH
+        LAUNCH_CHECK();
+        HIP_TRY(hipEventRecord(g_db_slot[slot].done, stream));
+    }
+    return 0;
+}
 
 int ffhip_launch_h264_deblock_frames(uint8_t *luma, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                                      const FFHipH264Edge *edges, hipStream_t stream)
 {
-    if (mb_w <= 0 || mb_h <= 0 || nframes <= 0)
-        return 0;
-    if (mb_h + 1 > DB_SLOT_INTS) {
-        ffhip_set_error("ffhip_h264_deblock_frame: %d macroblock rows exceed the supported %d", mb_h, DB_SLOT_INTS - 1);
-        return FFHIP_EINVAL;
-    }
-    {
-        std::lock_guard<std::mutex> lk(g_db_mu);
-        if (!g_db_pool)
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_db_pool), (size_t)DB_SLOTS * DB_SLOT_INTS * sizeof(int)));
-    }
-    const int per_launch = DB_SLOT_INTS / (mb_h + 1); /* frames whose counters fit one pool slot */
-    for (int f0 = 0; f0 < nframes; f0 += per_launch) {
-        const int nf = nframes - f0 < per_launch ? nframes - f0 : per_launch;
-        int *prog = g_db_pool + (size_t)(g_db_next.fetch_add(1) % DB_SLOTS) * DB_SLOT_INTS;
-        HIP_TRY(hipMemsetAsync(prog, 0, (size_t)nf * (mb_h + 1) * sizeof(int), stream));
-        hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h, nf), dim3(64), 0, stream, luma + (size_t)f0 * frame_pitch, frame_pitch,
-                           stride, mb_w, mb_h, edges + (size_t)f0 * mb_w * mb_h * 8, prog);
-        LAUNCH_CHECK();
-    }
-    return 0;
+    return deblock_frames(false, luma, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream);
 }
 
 int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
                                     hipStream_t stream)
 {
-    return ffhip_launch_h264_deblock_frames(luma, 0, 1, stride, mb_w, mb_h, edges, stream);
+    return deblock_frames(false, luma, 0, 1, stride, mb_w, mb_h, edges, stream);
 }
 
 int ffhip_launch_h264_deblock_frames_chroma(uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                                             const FFHipH264Edge *edges, hipStream_t stream)
 {
-    if (mb_w <= 0 || mb_h <= 0 || nframes <= 0)
-        return 0;
-    if (((uintptr_t)plane | (size_t)stride | frame_pitch) & 3) {
-        ffhip_set_error("ffhip_h264_deblock_frame_chroma: plane, stride and frame pitch must be 4-byte aligned");
-        return FFHIP_EINVAL;
-    }
-    if (mb_h + 1 > DB_SLOT_INTS) {
-        ffhip_set_error("ffhip_h264_deblock_frame_chroma: %d macroblock rows exceed the supported %d", mb_h, DB_SLOT_INTS - 1);
-        return FFHIP_EINVAL;
-    }
-    {
-        std::lock_guard<std::mutex> lk(g_db_mu);
-        if (!g_db_pool)
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_db_pool), (size_t)DB_SLOTS * DB_SLOT_INTS * sizeof(int)));
-    }
-    const int per_launch = DB_SLOT_INTS / (mb_h + 1);
-    for (int f0 = 0; f0 < nframes; f0 += per_launch) {
-        const int nf = nframes - f0 < per_launch ? nframes - f0 : per_launch;
-        int *prog = g_db_pool + (size_t)(g_db_next.fetch_add(1) % DB_SLOTS) * DB_SLOT_INTS;
-        HIP_TRY(hipMemsetAsync(prog, 0, (size_t)nf * (mb_h + 1) * sizeof(int), stream));
-        hipLaunchKernelGGL(k_h264_deblock_frame_chroma, dim3(mb_h, nf), dim3(64), 0, stream, plane + (size_t)f0 * frame_pitch, frame_pitch,
-                           stride, mb_w, mb_h, edges + (size_t)f0 * mb_w * mb_h * 4, prog);
-        LAUNCH_CHECK();
-    }
-    return 0;
+    return deblock_frames(true, plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream);
 }

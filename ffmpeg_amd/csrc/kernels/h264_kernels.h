@@ -13,6 +13,8 @@ int ffhip_launch_h264_idct_add_mb(int which, uint8_t *dst_base, ptrdiff_t stride
                                   hipStream_t stream);
 int ffhip_launch_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n,
                                   hipStream_t stream);
+/* FFHIP_EIO (once) when a frame-order deblocking launch that has finished reported a lost hand-off; else 0 */
+int ffhip_h264_deblock_check(void);
 int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
                                     hipStream_t stream);
 int ffhip_launch_h264_deblock_frames_chroma(uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,

@@ -88,10 +88,11 @@ extern "C" int ffhip_memcpy_d2h(void *d, const void *s, size_t n)
     HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost));
     return 0;
 }
+int ffhip_h264_deblock_check(void);
 extern "C" int ffhip_stream_synchronize(void *stream)
 {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return 0;
+    return ffhip_h264_deblock_check(); /* a finished deblocking launch that lost a hand-off is reported here, not dropped */
 }
 
 /* grow-only arena of the host-pointer faces.  ONE mutex guards it for every user: a face holds ffhip_scratch_mutex() for its

@@ -53,6 +53,8 @@ int         ffhip_malloc(void **dev_ptr, size_t bytes);
 int         ffhip_free(void *dev_ptr);
 int         ffhip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int         ffhip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
+/** hipStreamSynchronize; also the point where a frame-order deblocking launch that timed out on a row hand-off (never in a
+ *  correct run) is reported: FFHIP_EIO once, ffhip_last_error() has the text — its picture is only partly filtered. */
 int         ffhip_stream_synchronize(void *stream);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -224,6 +224,31 @@ def test_qpel_batch(w, h, pad, old, monkeypatch):
             assert np.array_equal(got[y:y + s, x:x + s], want[y:y + s, x:x + s]), "block %d mc %d" % (i, b["mcxy"])
 
 
+def test_deblock_frame_row_kernel_agrees(monkeypatch):
+    """FFHIP_DEBLOCK_OLD=1: the one-workgroup-per-row kernel (the byte path of unaligned strides) on an aligned picture"""
+    monkeypatch.setenv("FFHIP_DEBLOCK_OLD", "1")
+    test_deblock_frame(40, 37, 0)
+
+
+def test_deblock_lost_handoff_is_reported(monkeypatch):
+    """a wavefront that never receives a hand-off must time out and be REPORTED at the next synchronisation point, not leave a
+    partly filtered picture behind silently (FFHIP_DEBLOCK_FAULT=1: rows do not publish their progress)"""
+    from ffmpeg_amd import h264, _lib
+    torch = _torch()
+    L = _lib.lib()
+    assert L.ffhip_stream_synchronize(None) == 0
+    mb_w, mb_h = 4, 3
+    plane = torch.zeros((mb_h * 16, mb_w * 16), dtype=torch.uint8, device="cuda:0")
+    ed = torch.zeros((mb_w * mb_h * 8, 12), dtype=torch.uint8, device="cuda:0")
+    monkeypatch.setenv("FFHIP_DEBLOCK_FAULT", "1")
+    h264.deblock_frame(plane, mb_w * 16, mb_w, mb_h, ed)
+    monkeypatch.delenv("FFHIP_DEBLOCK_FAULT")
+    assert L.ffhip_stream_synchronize(None) == -5                       # FFHIP_EIO
+    assert b"hand-off" in L.ffhip_last_error()
+    assert L.ffhip_stream_synchronize(None) == 0                       # reported once
+    test_deblock_frame(5, 4, 0)                                          # and the pool keeps working
+
+
 def test_deblock_frames_batch():
     """several pictures in one launch == each picture alone"""
     from ffmpeg_amd import h264
