@@ -58,6 +58,10 @@ def lib():
         "ffhip_sws_from_tables": (vp, [C.POINTER(SwsTables)]),
         "ffhip_sws_freeContext": (None, [vp]),
         "ffhip_sws_fast_path": (C.c_int, [vp]),
+        "ff_sws_init_swscale_hip": (C.c_int, [vp, C.c_int, C.c_int]),
+        "ffhip_sws_yuv2packed1": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+        "ffhip_sws_yuv2packed2": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ffhip_sws_yuv2packedX": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int]),
         "ffhip_membw_probe": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
         "ffhip_sws_up2_virtual_bank_host": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
         "ffhip_sws_mfma_tiles_host": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]),
@@ -74,6 +78,10 @@ def lib():
                                                 vp]),
         "ffhip_sws_yuv2planeX8_dev": (C.c_int, [vp, C.c_int, vp, C.c_ssize_t, vp, C.c_int, vp, C.c_int, vp]),
         "ffhip_h264_idct_add_batch_dev": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, vp, C.c_int, vp]),
+        "ffhip_shim_fallbacks": (C.c_long, []),
+        "ffhip_h264_idct_add8_batch_dev": (C.c_int, [vp, vp, C.c_ssize_t, vp, vp, vp, vp, C.c_int, vp]),
+        "ffhip_h264_luma_dc_dequant_idct_batch_dev": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_int, vp]),
+        "ffhip_h264_chroma_dc_dequant_idct_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
         "ffhip_h264_idct_add_mb_batch_dev": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, vp, vp, vp, C.c_int, vp]),
         "ffhip_h264_loop_filter_batch_dev": (C.c_int, [vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_h264_deblock_frame_dev": (C.c_int, [vp, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),

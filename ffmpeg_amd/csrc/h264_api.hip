@@ -31,6 +31,36 @@ extern "C" int ffhip_h264_idct_add_mb_batch_dev(int which, uint8_t *dst_base, pt
                                          (hipStream_t)stream);
 }
 
+extern "C" int ffhip_h264_idct_add8_batch_dev(uint8_t *cb_base, uint8_t *cr_base, ptrdiff_t stride, const int32_t *mb_offset,
+                                              const int32_t *blockoffset48, int16_t *blocks, const uint8_t *nnzc, int nmb, void *stream)
+{
+    if (!cb_base || !cr_base || !mb_offset || !blockoffset48 || !blocks || !nnzc || nmb < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_idct_add8(cb_base, cr_base, stride, mb_offset, blockoffset48, blocks, nnzc, nmb, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_h264_luma_dc_dequant_idct_batch_dev(int16_t *output, size_t out_pitch, const int16_t *input, size_t in_pitch,
+                                                         const int32_t *qmul, int n, void *stream)
+{
+    if (!output || !input || !qmul || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_luma_dc_dequant(output, out_pitch, input, in_pitch, qmul, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_h264_chroma_dc_dequant_idct_batch_dev(int16_t *blocks, const int32_t *block_offset, const int32_t *qmul, int n,
+                                                           void *stream)
+{
+    if (!blocks || !block_offset || !qmul || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_chroma_dc_dequant(blocks, block_offset, qmul, n, (hipStream_t)stream);
+}
+
 extern "C" int ffhip_h264_loop_filter_batch_dev(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n,
                                                 void *stream)
 {

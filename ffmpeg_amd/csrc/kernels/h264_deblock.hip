@@ -448,14 +448,39 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
     const int lring = (MB + lane / NDW) * TPP + (sprev ? MB - 4 : 4 * ps);
     const int tcsh = 8 * (CHROMA ? (lane & 7) >> 1 : (lane & 15) >> 2); /* this line's tc0 byte of an edge record */
 
-    /* The next macroblock's own samples are fetched a step ahead.  The load is issued from inline asm and awaited by an explicit
-     * s_waitcnt vmcnt(N), N = the store instructions issued after it: the compiler's own wait would be vmcnt(0) — a drain of the
-     * step's picture stores, i.e. a round trip to L2 per macroblock on the picture's critical path. */
+    /* The next macroblock's own samples are fetched a step ahead; the wait for them is a vmcnt(0), i.e. it also drains
+     * whatever stores are in flight.  So the picture stores of a macroblock are issued at the START of the next step (its tile
+     * is still there: two tiles alternate), together with the fetch: by the next wait, a whole macroblock later, they are
+     * long acknowledged, and no round trip to L2 sits on the picture's critical path. */
     uint32_t own = 0;
-    const uint8_t *ownp = rowbase + (in_mb ? gown : 0);
     auto fetch = [&](int mx) {
-        const uint8_t *p = ownp + mx * MB;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(own) : "v"(p) : "memory");
+        if (in_mb)
+            own = *reinterpret_cast<const uint32_t *>(rowbase + mx * MB + gown);
+    };
+    /* picture stores of macroblock m (tile `tm`) and of the last dword column of macroblock m - 1 (tile `tp`): everything they
+     * have made final (see the header) */
+    auto flush = [&](int m, const uint8_t *tm, const uint8_t *tp, bool row_end) {
+        if (fault & 2)
+            return;
+        uint8_t *mb = rowbase + m * MB;
+        if (st_row && !(sprev && m == 0)) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>((sprev ? tp : tm) + lst);
+            uint32_t *g = reinterpret_cast<uint32_t *>(mb + gst);
+            if (to_mem)
+                __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                *g = v;
+        }
+        if (st_ctx)
+            *reinterpret_cast<uint32_t *>(mb + gctx) = *reinterpret_cast<const uint32_t *>(tm + lctx);
+        if (row_end && st_row && sprev) { /* the row's last dword column: no macroblock to its right will touch it */
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(tm + lst);
+            uint32_t *g = reinterpret_cast<uint32_t *>(mb + gst + MB);
+            if (to_mem)
+                __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                *g = v;
+        }
     };
     /* edge records of a macroblock: NE x 3 dwords through the scalar cache */
     const uint32_t *erow = reinterpret_cast<const uint32_t *>(edges + (size_t)my * mb_w * NE);
@@ -478,28 +503,32 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
     };
     int known = 0, kbelow = 0;
     fetch(0);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(own) : : "memory"); /* the first one has no stores behind it */
     for (int mx = 0; mx < mb_w; mx++) {
-        uint8_t *mb = rowbase + mx * MB;
+        const uint8_t *mb = rowbase + mx * MB;
         uint8_t *cur = tbase + (mx & 1) * TSZ, *prev = tbase + ((mx & 1) ^ 1) * TSZ;
         const bool last = mx + 1 == mb_w;
         fetch_edges(mx);
         const uint32_t (&ec)[3 * NE] = en;
-        /* stores issued since the fetch: the rows' (always), the context rows' (my > 0); rows that hand off through memory
-         * have drained everything at their publish */
-        if (fault & 2)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(own) : : "memory");
-        else if (my > 0)
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(own) : : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(1)" : "+v"(own) : : "memory");
+        const uint32_t mine = own;   /* the wait for the fetch: everything issued a step ago is complete now */
+        if (to_mem && mx >= 3 && !(fault & 1)) {
+            /* through memory to the next band: the stores issued at the top of the previous step (macroblock mx - 2's rows,
+             * mx - 3's last dword column) are acknowledged: macroblocks < mx - 2 are complete in memory */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            if (lane == 0)
+                __hip_atomic_store(&gprog[band], mx - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (mx > 0)
+            flush(mx - 1, prev, cur, false); /* before the tile of macroblock mx - 2 (`cur`) is overwritten */
         if (in_mb)
-            *reinterpret_cast<uint32_t *>(cur + lown) = own;
+            *reinterpret_cast<uint32_t *>(cur + lown) = mine;
         if (!last)
             fetch(mx + 1);
         /* ---- context rows: the row above must have finished macroblock mx + 1 ---- */
         if (my > 0) {
-            const int want = (fault & 8) ? 0 : min(mx + 2, mb_w);
+            /* LDS progress counts finished steps (the ring slot's last dword arrives a step late); the memory progress counts
+             * macroblocks complete in memory */
+            const int want = (fault & 8) ? 0 : from_lds ? min(mx + 2, mb_w) : mx + 1;
             int spins = 0;
             while (known < want) {
                 known = from_lds ? __hip_atomic_load(&lprog[w - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -587,27 +616,6 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
                 tcol[(r - (4 - CTX)) * TPP] = (uint8_t)y[r];
         }
         wave_lds_sync();
-        /* ---- the picture: everything this macroblock has made final (see the header) ---- */
-        if (!(fault & 2)) {
-            if (st_row && !(sprev && mx == 0)) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>((sprev ? prev : cur) + lst);
-                uint32_t *g = reinterpret_cast<uint32_t *>(mb + gst);
-                if (to_mem)
-                    __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else
-                    *g = v;
-            }
-            if (st_ctx)
-                *reinterpret_cast<uint32_t *>(mb + gctx) = *reinterpret_cast<const uint32_t *>(cur + lctx);
-            if (last && st_row && sprev) { /* the row's last dword column: no macroblock to its right will touch it */
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(cur + lst);
-                uint32_t *g = reinterpret_cast<uint32_t *>(mb + gst + MB);
-                if (to_mem)
-                    __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else
-                    *g = v;
-            }
-        }
         /* ---- the row below, inside the band: bottom CTX rows into the ring ---- */
         if (to_lds) {
             if (mx >= DB_R) { /* slot reuse: the consumer must be done with macroblock mx - DB_R */
@@ -636,17 +644,18 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
         /* ---- publish (fault & 1: test hook — rows never publish, so the row below must time out and report) ---- */
         if (fault & 1)
             continue;
-        if (to_mem) {
-            /* the write-through stores above are complete (acknowledged) before the counter moves.  A macroblock's last dword
-             * column is stored a step later, which the consumer's `x + 2 macroblocks done` already accounts for */
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            if (lane == 0)
-                __hip_atomic_store(&gprog[band], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) /* rows that hand off through memory publish here too: the row above paces its ring by this word */
             __hip_atomic_store(&lprog[w], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    /* the last macroblock's stores, its row-end dword column included */
+    wave_lds_sync();
+    flush(mb_w - 1, tbase + ((mb_w - 1) & 1) * TSZ, tbase + (((mb_w - 1) & 1) ^ 1) * TSZ, true);
+    if (to_mem && !(fault & 1)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0)
+            __hip_atomic_store(&gprog[band], mb_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

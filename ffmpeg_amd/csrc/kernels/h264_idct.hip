@@ -233,6 +233,25 @@ __global__ __launch_bounds__(NT) void k_h264_idct_dc_add(uint8_t *dst_base, ptrd
     dc_add_regs<N>(dc, dst_base + dst_offset[i], stride);
 }
 
+/* add_pixels4_clear / add_pixels8_clear (the lossless transform bypass), h264addpx_template.c:28-74: dst += residual with 8-bit
+ * wrap-around (no clip), then the residual is cleared.  One thread per block. */
+template <int N>
+__global__ __launch_bounds__(NT) void k_h264_add_pixels_clear(uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
+                                                              int16_t *blocks, int n)
+{
+    const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+    if (i >= n)
+        return;
+    int16_t *b = blocks + i * (N * N);
+    uint8_t *dst = dst_base + dst_offset[i];
+    for (int y = 0; y < N; y++)
+#pragma unroll
+        for (int x = 0; x < N; x++) {
+            dst[y * stride + x] = (uint8_t)(dst[y * stride + x] + (unsigned)b[y * N + x]);
+            b[y * N + x] = 0;
+        }
+}
+
 int ffhip_launch_h264_idct_add(int kind, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
                                int16_t *blocks, int n, hipStream_t stream)
 {
@@ -253,6 +272,12 @@ int ffhip_launch_h264_idct_add(int kind, uint8_t *dst_base, ptrdiff_t stride, co
         break;
     case FFHIP_H264_IDCT8_DC:
         hipLaunchKernelGGL((k_h264_idct_dc_add<8>), grid, block, 0, stream, dst_base, stride, dst_offset, blocks, n);
+        break;
+    case FFHIP_H264_ADD_PIXELS4_CLEAR:
+        hipLaunchKernelGGL((k_h264_add_pixels_clear<4>), grid, block, 0, stream, dst_base, stride, dst_offset, blocks, n);
+        break;
+    case FFHIP_H264_ADD_PIXELS8_CLEAR:
+        hipLaunchKernelGGL((k_h264_add_pixels_clear<8>), grid, block, 0, stream, dst_base, stride, dst_offset, blocks, n);
         break;
     default:
         return FFHIP_EINVAL;
@@ -347,6 +372,107 @@ int ffhip_launch_h264_idct_add_mb(int which, uint8_t *dst_base, ptrdiff_t stride
     } else {
         return FFHIP_EINVAL;
     }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/* ---- idct_add8 (4:2:0): the four 4x4 blocks of Cb and of Cr of every macroblock (h264idct_template.c:216-228) ------------- */
+/* one thread per chroma block: q = 0..7 -> plane j = 1 + q / 4, block i = 16 j + q % 4; nnzc is the decoder's 15 x 8 cache */
+__global__ __launch_bounds__(NT) void k_h264_idct_add8(uint8_t *cb_base, uint8_t *cr_base, ptrdiff_t stride, const int32_t *mb_offset,
+                                                       const int32_t *blockoffset48, int16_t *blocks, const uint8_t *nnzc, int nmb, int dst_vec)
+{
+    const long long id = (long long)blockIdx.x * NT + threadIdx.x;
+    if (id >= (long long)nmb * 8)
+        return;
+    const int mb = (int)(id >> 3), q = (int)(id & 7), j = 1 + (q >> 2), i = 16 * j + (q & 3), k = q & 3;
+    const int sc = 4 + (k & 1) + (5 * j + 1 + (k >> 1)) * 8;    /* scan8[i], libavcodec/h264_parse.h:45-50 */
+    int16_t *b = blocks + ((size_t)mb * 48 + i) * 16;
+    uint8_t *dst = (j == 1 ? cb_base : cr_base) + mb_offset[mb] + blockoffset48[i];
+    if (nnzc[(size_t)mb * 120 + sc]) {
+        uint4 *g = reinterpret_cast<uint4 *>(b);
+        const uint4 c0 = g[0], c1 = g[1];
+        g[0] = make_uint4(0, 0, 0, 0);
+        g[1] = make_uint4(0, 0, 0, 0);
+        idct4_add_regs(c0, c1, dst, stride, dst_vec && !((uintptr_t)dst & 3));
+    } else if (b[0]) {
+        const int v = (b[0] + 32) >> 6;
+        b[0] = 0;
+        dc_add_regs<4>(v, dst, stride);
+    }
+}
+
+int ffhip_launch_h264_idct_add8(uint8_t *cb_base, uint8_t *cr_base, ptrdiff_t stride, const int32_t *mb_offset, const int32_t *blockoffset48,
+                                int16_t *blocks, const uint8_t *nnzc, int nmb, hipStream_t stream)
+{
+    if (nmb <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_h264_idct_add8, dim3(cdiv(nmb * 8, NT)), dim3(NT), 0, stream, cb_base, cr_base, stride, mb_offset, blockoffset48,
+                       blocks, nnzc, nmb, !(((uintptr_t)cb_base | (uintptr_t)cr_base | (size_t)stride) & 3));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/* ---- DC transforms with dequantisation (h264idct_template.c:259-293, 323-345) ----------------------------------------------- */
+/* luma: one thread per macroblock: 4x4 Hadamard of input[16], results scattered to the DC positions of output[256] */
+__global__ __launch_bounds__(NT) void k_h264_luma_dc_dequant(int16_t *output, size_t out_pitch, const int16_t *input, size_t in_pitch,
+                                                             const int32_t *qmul, int n)
+{
+    const long long m = (long long)blockIdx.x * NT + threadIdx.x;
+    if (m >= n)
+        return;
+    const int16_t *in = input + m * in_pitch;
+    int16_t *out = output + m * out_pitch;
+    const uint32_t q = (uint32_t)qmul[m];
+    int t[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int z0 = in[4 * i] + in[4 * i + 1], z1 = in[4 * i] - in[4 * i + 1], z2 = in[4 * i + 2] - in[4 * i + 3], z3 = in[4 * i + 2] + in[4 * i + 3];
+        t[4 * i] = z0 + z3; t[4 * i + 1] = z0 - z3; t[4 * i + 2] = z1 - z2; t[4 * i + 3] = z1 + z2;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int o = (i & 1) * 32 + (i >> 1) * 128;  /* x_offset[] = { 0, 2*16, 8*16, 10*16 } */
+        const uint32_t z0 = (uint32_t)t[i] + (uint32_t)t[8 + i], z1 = (uint32_t)t[i] - (uint32_t)t[8 + i];
+        const uint32_t z2 = (uint32_t)t[4 + i] - (uint32_t)t[12 + i], z3 = (uint32_t)t[4 + i] + (uint32_t)t[12 + i];
+        out[o]      = (int16_t)((int)((z0 + z3) * q + 128) >> 8);
+        out[16 + o] = (int16_t)((int)((z1 + z2) * q + 128) >> 8);
+        out[64 + o] = (int16_t)((int)((z1 - z2) * q + 128) >> 8);
+        out[80 + o] = (int16_t)((int)((z0 - z3) * q + 128) >> 8);
+    }
+}
+
+/* chroma (4:2:0): one thread per plane of a macroblock, in place on block[0], [16], [32], [48] */
+__global__ __launch_bounds__(NT) void k_h264_chroma_dc_dequant(int16_t *blocks, const int32_t *block_offset, const int32_t *qmul, int n)
+{
+    const long long m = (long long)blockIdx.x * NT + threadIdx.x;
+    if (m >= n)
+        return;
+    int16_t *b = blocks + block_offset[m];
+    const uint32_t q = (uint32_t)qmul[m];
+    uint32_t a = (uint32_t)(int)b[0], bb = (uint32_t)(int)b[16], c = (uint32_t)(int)b[32], d = (uint32_t)(int)b[48];
+    const uint32_t e = a - bb;
+    a = a + bb; bb = c - d; c = c + d;
+    b[0]  = (int16_t)((int)((a + c) * q) >> 7);
+    b[16] = (int16_t)((int)((e + bb) * q) >> 7);
+    b[32] = (int16_t)((int)((a - c) * q) >> 7);
+    b[48] = (int16_t)((int)((e - bb) * q) >> 7);
+}
+
+int ffhip_launch_h264_luma_dc_dequant(int16_t *output, size_t out_pitch, const int16_t *input, size_t in_pitch, const int32_t *qmul, int n,
+                                      hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_h264_luma_dc_dequant, dim3(cdiv(n, NT)), dim3(NT), 0, stream, output, out_pitch, input, in_pitch, qmul, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int ffhip_launch_h264_chroma_dc_dequant(int16_t *blocks, const int32_t *block_offset, const int32_t *qmul, int n, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_h264_chroma_dc_dequant, dim3(cdiv(n, NT)), dim3(NT), 0, stream, blocks, block_offset, qmul, n);
     LAUNCH_CHECK();
     return 0;
 }

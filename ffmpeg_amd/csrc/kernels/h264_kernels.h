@@ -11,6 +11,11 @@ int ffhip_launch_h264_idct_add(int kind, uint8_t *dst_base, ptrdiff_t stride, co
 int ffhip_launch_h264_idct_add_mb(int which, uint8_t *dst_base, ptrdiff_t stride, const int32_t *mb_offset,
                                   const int32_t *blockoffset16, int16_t *blocks, const uint8_t *nnzc, int nmb,
                                   hipStream_t stream);
+int ffhip_launch_h264_idct_add8(uint8_t *cb_base, uint8_t *cr_base, ptrdiff_t stride, const int32_t *mb_offset, const int32_t *blockoffset48,
+                                int16_t *blocks, const uint8_t *nnzc, int nmb, hipStream_t stream);
+int ffhip_launch_h264_luma_dc_dequant(int16_t *output, size_t out_pitch, const int16_t *input, size_t in_pitch, const int32_t *qmul, int n,
+                                      hipStream_t stream);
+int ffhip_launch_h264_chroma_dc_dequant(int16_t *blocks, const int32_t *block_offset, const int32_t *qmul, int n, hipStream_t stream);
 int ffhip_launch_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n,
                                   hipStream_t stream);
 /* FFHIP_EIO (once) when a frame-order deblocking launch that has finished reported a lost hand-off; else 0 */

@@ -204,6 +204,12 @@ int  ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream);
 /* per-line parity faces */
 int ffhip_launch_hscale8to15(int16_t *dst, int dstW, ptrdiff_t dstPitch, const uint8_t *src, ptrdiff_t srcPitch,
                              int nlines, const int16_t *filter, const int32_t *pos, int fs, hipStream_t stream);
+int ffhip_launch_yuv2nv12cX(int swap, const uint8_t *dither8, const int16_t *filter, int fs, const int16_t *usrc, const int16_t *vsrc,
+                            ptrdiff_t srcPitch, uint8_t *dest, int chrDstW, hipStream_t stream);
+/* mode 0 yuv2rgb_X, 1 _2, 2 _1; lines at base + j * pitch bytes */
+int ffhip_launch_yuv2packed_line(int mode, const int16_t *lf, const int16_t *lum, int lfs, const int16_t *cf, const int16_t *cu,
+                                 const int16_t *cv, int cfs, ptrdiff_t pitch, int yalpha, int uvalpha, uint8_t *dest, int dstW, int layout,
+                                 const FFHipYuv2RgbK &k, hipStream_t stream);
 int ffhip_launch_yuv2planeX8(const int16_t *filter, int fs, const int16_t *src, ptrdiff_t srcPitch, uint8_t *dest,
                              int dstW, const uint8_t *dither8, int offset, hipStream_t stream);
 

@@ -652,3 +652,112 @@ int ffhip_launch_yuv2planeX8(const int16_t *filter, int fs, const int16_t *src, 
     LAUNCH_CHECK();
     return 0;
 }
+
+/* yuv2nv12cX_c (libswscale/output.c:500-529): one interleaved chroma line from fs int16 U lines and fs int16 V lines
+ * (lines at usrc / vsrc + j * srcPitch bytes); swap: V first (NV21) */
+__global__ void k_yuv2nv12cX(int swap, const uint8_t *dither, const int16_t *filter, int fs, const int16_t *usrc, const int16_t *vsrc,
+                             ptrdiff_t srcPitch, uint8_t *dest, int chrDstW)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chrDstW)
+        return;
+    uint32_t au = (uint32_t)dither[i & 7] << 12, av = (uint32_t)dither[(i + 3) & 7] << 12;
+    for (int j = 0; j < fs; j++) {
+        const int c = filter[j];
+        au += (uint32_t)(*reinterpret_cast<const int16_t *>(reinterpret_cast<const uint8_t *>(usrc) + j * srcPitch + 2 * (ptrdiff_t)i) * c);
+        av += (uint32_t)(*reinterpret_cast<const int16_t *>(reinterpret_cast<const uint8_t *>(vsrc) + j * srcPitch + 2 * (ptrdiff_t)i) * c);
+    }
+    dest[2 * i + (swap ? 1 : 0)] = (uint8_t)clip_u8((int32_t)au >> 19);
+    dest[2 * i + (swap ? 0 : 1)] = (uint8_t)clip_u8((int32_t)av >> 19);
+}
+
+int ffhip_launch_yuv2nv12cX(int swap, const uint8_t *dither8, const int16_t *filter, int fs, const int16_t *usrc, const int16_t *vsrc,
+                            ptrdiff_t srcPitch, uint8_t *dest, int chrDstW, hipStream_t stream)
+{
+    if (chrDstW <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_yuv2nv12cX, dim3(cdiv(chrDstW, 256)), dim3(256), 0, stream, swap, dither8, filter, fs, usrc, vsrc, srcPitch, dest, chrDstW);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/*
+ * One packed RGB line from int16 luma / chroma lines: yuv2rgb_X_c_template / _2_ / _1_ (libswscale/output.c:1789-1939) with the
+ * closed form of the reference's table lookup (sws_yuv2rgb.hip).  mode 0: X (lfs luma lines x lf[], cfs chroma lines x cf[]);
+ * mode 1: _2 (two lines each, weights 4096 - alpha / alpha, no rounding term); mode 2: _1 (one luma line; chroma one line when
+ * uvalpha == 0, else two).  One thread per pixel PAIR (the pair shares its chroma sample).  layout as everywhere: 0 rgb24 ... 5 bgra.
+ */
+__global__ void k_yuv2packed_line(int mode, const int16_t *lf, const int16_t *lum, int lfs, const int16_t *cf, const int16_t *cu,
+                                  const int16_t *cv, int cfs, ptrdiff_t pitch, int yalpha, int uvalpha, uint8_t *dest, int dstW, int layout,
+                                  FFHipYuv2RgbK k)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (dstW >> 1))
+        return;
+    auto L = [&](const int16_t *base, int j, int x) {
+        return (int)*reinterpret_cast<const int16_t *>(reinterpret_cast<const uint8_t *>(base) + j * pitch + 2 * (ptrdiff_t)x);
+    };
+    int Y1, Y2, U, V;
+    if (mode == 0) {
+        uint32_t y1 = 1 << 18, y2 = 1 << 18, u = 1 << 18, v = 1 << 18;
+        for (int j = 0; j < lfs; j++) {
+            y1 += (uint32_t)(L(lum, j, 2 * i) * (int)lf[j]);
+            y2 += (uint32_t)(L(lum, j, 2 * i + 1) * (int)lf[j]);
+        }
+        for (int j = 0; j < cfs; j++) {
+            u += (uint32_t)(L(cu, j, i) * (int)cf[j]);
+            v += (uint32_t)(L(cv, j, i) * (int)cf[j]);
+        }
+        Y1 = (int32_t)y1 >> 19; Y2 = (int32_t)y2 >> 19; U = (int32_t)u >> 19; V = (int32_t)v >> 19;
+    } else if (mode == 1) {
+        const int ya1 = 4096 - yalpha, uva1 = 4096 - uvalpha;
+        Y1 = (L(lum, 0, 2 * i) * ya1 + L(lum, 1, 2 * i) * yalpha) >> 19;
+        Y2 = (L(lum, 0, 2 * i + 1) * ya1 + L(lum, 1, 2 * i + 1) * yalpha) >> 19;
+        U = (L(cu, 0, i) * uva1 + L(cu, 1, i) * uvalpha) >> 19;
+        V = (L(cv, 0, i) * uva1 + L(cv, 1, i) * uvalpha) >> 19;
+    } else {
+        const int uva1 = 4096 - uvalpha;
+        Y1 = (L(lum, 0, 2 * i) + 64) >> 7;
+        Y2 = (L(lum, 0, 2 * i + 1) + 64) >> 7;
+        if (!uvalpha) {
+            U = (L(cu, 0, i) + 64) >> 7;
+            V = (L(cv, 0, i) + 64) >> 7;
+        } else {
+            U = (L(cu, 0, i) * uva1 + L(cu, 1, i) * uvalpha + (128 << 11)) >> 19;
+            V = (L(cv, 0, i) * uva1 + L(cv, 1, i) * uvalpha + (128 << 11)) >> 19;
+        }
+    }
+    /* the reference indexes its tables with U, V as they are (they are in range for any sane bank); the closed form clips as the
+     * fused kernels do */
+    const int Uc = clip_u8(U), Vc = clip_u8(V);
+    const int br = k.kb + (k.off_r + ((Vc * k.crv) >> 16)) * k.cy;
+    const int bb = k.kb + (k.off_b + ((Uc * k.cbu) >> 16)) * k.cy;
+    const int bg = k.kb + (k.off_g + ((Uc * k.cgu) >> 16) + ((Vc * k.cgv) >> 16)) * k.cy;
+    const int bp = layout < 2 ? 3 : 4;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int yc = (e ? Y2 : Y1) * k.cy;
+        const int r = clip_u8((br + yc) >> 16), g = clip_u8((bg + yc) >> 16), b = clip_u8((bb + yc) >> 16);
+        uint8_t *q = dest + (size_t)bp * (2 * i + e);
+        switch (layout) {
+        case 0: q[0] = r; q[1] = g; q[2] = b; break;
+        case 1: q[0] = b; q[1] = g; q[2] = r; break;
+        case 2: q[0] = 255; q[1] = r; q[2] = g; q[3] = b; break;
+        case 3: q[0] = r; q[1] = g; q[2] = b; q[3] = 255; break;
+        case 4: q[0] = 255; q[1] = b; q[2] = g; q[3] = r; break;
+        default: q[0] = b; q[1] = g; q[2] = r; q[3] = 255; break;
+        }
+    }
+}
+
+int ffhip_launch_yuv2packed_line(int mode, const int16_t *lf, const int16_t *lum, int lfs, const int16_t *cf, const int16_t *cu,
+                                 const int16_t *cv, int cfs, ptrdiff_t pitch, int yalpha, int uvalpha, uint8_t *dest, int dstW, int layout,
+                                 const FFHipYuv2RgbK &k, hipStream_t stream)
+{
+    if (dstW < 2)
+        return 0;
+    hipLaunchKernelGGL(k_yuv2packed_line, dim3(cdiv(dstW >> 1, 256)), dim3(256), 0, stream, mode, lf, lum, lfs, cf, cu, cv, cfs, pitch, yalpha,
+                       uvalpha, dest, dstW, layout, k);
+    LAUNCH_CHECK();
+    return 0;
+}

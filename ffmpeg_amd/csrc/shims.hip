@@ -1,23 +1,38 @@
 /*
- * shims.hip — the signature-exact, HOST-pointer faces of h264dsp / h264qpel / me_cmp.
+ * shims.hip — the signature-exact, HOST-pointer faces of h264dsp / h264qpel / h264chroma / h264pred / hevcdsp / vp9dsp / me_cmp /
+ * float_dsp.
  *
- * These are the function pointers an `ff_h264dsp_init_hip()` / `ff_h264qpel_init_hip()` /
- * `ff_me_cmp_init_hip()` installs next to the x86/neon ones (libavcodec/h264dsp.c:155-169,
- * h264qpel.c:105-119, me_cmp.c:1014-1026): same names, same argument meaning, same side effects
- * (coefficient blocks are cleared, dst is updated in place).  One call = one launch: the operands are
- * staged into device scratch, the SAME kernels as the batched faces run with n = 1, the written
- * rectangle is copied back.  That is the reference's granularity — right for parity harnesses
- * (checkasm exercises exactly these pointers), hopeless for speed; throughput comes from the *_batch_dev
- * entry points.  Thread-safe (one mutex around the shared scratch); no state.
+ * These are the function pointers an `ff_h264dsp_init_hip()` / `ff_h264qpel_init_hip()` / `ff_me_cmp_init_hip()` ... installs next
+ * to the x86/neon ones (libavcodec/h264dsp.c:155-169, h264qpel.c:105-119, me_cmp.c:1014-1026): same names, same argument
+ * meaning, same side effects (coefficient blocks are cleared, dst is updated in place).  One call = one launch: the operands are
+ * staged into device scratch, the SAME kernels as the batched faces run with n = 1, the results travel back.  That is the
+ * reference's granularity — right for parity harnesses (checkasm exercises exactly these pointers), hopeless for speed;
+ * throughput comes from the *_batch_dev entry points.
+ *
+ * These signatures cannot report an error, so a face must never fail silently:
+ *   - every ff_*_init_hip() REMEMBERS the table it displaces (the reference calls an arch init with the C functions already
+ *     in place), and a call that cannot run on the device — a HIP error anywhere, an argument outside the staged range, or
+ *     FFHIP_FAULT=1 (test hook) — is answered by the displaced C function; ffhip_shim_fallbacks() counts them, and a face
+ *     with nothing to fall back on records the member's name in ffhip_last_error();
+ *   - host memory is written only after everything has come back: the whole scratch arena returns in ONE device-to-host copy
+ *     into a host bounce buffer, results are committed from there (a failure can therefore not leave half a block behind for
+ *     the C function to run on top of).
+ * Thread-safe: one mutex (runtime.hip) guards the arena and the bounce buffer for a whole stage / run / copy-back sequence.
  */
+#include <atomic>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #include "kernels/common.h"
 #include "kernels/h264_kernels.h"
 #include "kernels/me_kernels.h"
 
-static std::mutex &g_shim_mu = ffhip_scratch_mutex(); /* the arena's one lock (runtime.hip) */
+#include "kernels/shim_arena.h"
+
+extern "C" long ffhip_shim_fallbacks(void) { return g_fallbacks.load(); }
+
 #define DP 64 /* device row pitch of a staged rectangle */
 
 /* a rectangle rows r0..r1 x columns c0..c1 around host pointer p (row step = stride, may be negative) */
@@ -33,54 +48,62 @@ static size_t rect_bytes(const Rect &r) { return (size_t)(r.r1 - r.r0 + 1) * DP 
 static bool rect_up(Rect &r, uint8_t *buf)
 {
     r.dev = buf + DP - (ptrdiff_t)r.r0 * DP - r.c0; /* row r0 col c0 lands at buf + DP */
+    const int w = r.c1 - r.c0 + 1, h = r.r1 - r.r0 + 1;
+    if (r.stride >= w) /* one 2-D copy; bottom-up pictures (negative strides) go row by row */
+        return hipMemcpy2D(r.dev + (ptrdiff_t)r.r0 * DP + r.c0, DP, r.host + r.r0 * r.stride + r.c0, r.stride, w, h, hipMemcpyHostToDevice) ==
+               hipSuccess;
     for (int y = r.r0; y <= r.r1; y++)
-        if (hipMemcpy(r.dev + (ptrdiff_t)y * DP + r.c0, r.host + y * r.stride + r.c0, r.c1 - r.c0 + 1,
-                      hipMemcpyHostToDevice) != hipSuccess)
+        if (hipMemcpy(r.dev + (ptrdiff_t)y * DP + r.c0, r.host + y * r.stride + r.c0, w, hipMemcpyHostToDevice) != hipSuccess)
             return false;
     return true;
 }
 
-static bool rect_down(const Rect &r, int r0, int r1, int c0, int c1)
+/* commit rows r0..r1 x columns c0..c1 of a staged rectangle from the bounce buffer (after Arena::down()) */
+static void rect_commit(const Arena &A, const Rect &r, int r0, int r1, int c0, int c1)
 {
     for (int y = r0; y <= r1; y++)
-        if (hipMemcpy(r.host + y * r.stride + c0, r.dev + (ptrdiff_t)y * DP + c0, c1 - c0 + 1, hipMemcpyDeviceToHost) !=
-            hipSuccess)
-            return false;
-    return true;
+        memcpy(r.host + y * r.stride + c0, A.host(r.dev + (ptrdiff_t)y * DP + c0), c1 - c0 + 1);
+}
+static void commit2d(const Arena &A, void *dst, ptrdiff_t dstride, const void *dev, ptrdiff_t dpitch, size_t wbytes, int rows)
+{
+    for (int y = 0; y < rows; y++)
+        memcpy(static_cast<uint8_t *>(dst) + y * dstride, A.host(static_cast<const uint8_t *>(dev) + y * dpitch), wbytes);
 }
 
 /* ---- h264dsp: single blocks ---------------------------------------------------------------------- */
-static void idct_single(int kind, uint8_t *dst, int16_t *block, ptrdiff_t stride)
+static bool idct_single(int kind, uint8_t *dst, int16_t *block, ptrdiff_t stride)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
-    const int size = (kind & 1) ? 8 : 4, ncoef = size * size;
+    const int size = (kind & 1) ? 8 : 4, ncoef = size * size; /* IDCT4 0, IDCT8 1, IDCT4_DC 2, IDCT8_DC 3, ADD_PIXELS4 4, ADD_PIXELS8 5 */
     Rect d = { dst, stride, 0, size - 1, 0, size - 1, nullptr };
-    void *scratch;
-    if (ffhip_scratch_reserve(rect_bytes(d) + 256 + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(rect_bytes(d) + 256 + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     int16_t *dblk = (int16_t *)buf;
     int32_t *doff = (int32_t *)(buf + 128);
     const int32_t zero = 0;
     if (!rect_up(d, buf + 256) || hipMemcpy(dblk, block, ncoef * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(doff, &zero, 4, hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_h264_idct_add(kind, d.dev, DP, doff, dblk, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    rect_down(d, 0, size - 1, 0, size - 1);
-    (void)hipMemcpy(block, dblk, ncoef * 2, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_h264_idct_add(kind, d.dev, DP, doff, dblk, 1, 0) < 0 || !A.down())
+        return false;
+    rect_commit(A, d, 0, size - 1, 0, size - 1);
+    memcpy(block, A.host(dblk), ncoef * 2); /* cleared by the kernel */
+    return true;
 }
-static void s_idct_add(uint8_t *d, int16_t *b, ptrdiff_t s) { idct_single(FFHIP_H264_IDCT4, d, b, s); }
-static void s_idct8_add(uint8_t *d, int16_t *b, ptrdiff_t s) { idct_single(FFHIP_H264_IDCT8, d, b, s); }
-static void s_idct_dc_add(uint8_t *d, int16_t *b, ptrdiff_t s) { idct_single(FFHIP_H264_IDCT4_DC, d, b, s); }
-static void s_idct8_dc_add(uint8_t *d, int16_t *b, ptrdiff_t s) { idct_single(FFHIP_H264_IDCT8_DC, d, b, s); }
+static FFHipH264DSPContext g_fb_h264; /* the C functions ff_h264dsp_init_hip() displaced */
+static void s_idct_add(uint8_t *d, int16_t *b, ptrdiff_t s) { if (!idct_single(FFHIP_H264_IDCT4, d, b, s)) SHIM_FB(g_fb_h264, idct_add, d, b, s); }
+static void s_idct8_add(uint8_t *d, int16_t *b, ptrdiff_t s) { if (!idct_single(FFHIP_H264_IDCT8, d, b, s)) SHIM_FB(g_fb_h264, idct8_add, d, b, s); }
+static void s_idct_dc_add(uint8_t *d, int16_t *b, ptrdiff_t s) { if (!idct_single(FFHIP_H264_IDCT4_DC, d, b, s)) SHIM_FB(g_fb_h264, idct_dc_add, d, b, s); }
+static void s_idct8_dc_add(uint8_t *d, int16_t *b, ptrdiff_t s) { if (!idct_single(FFHIP_H264_IDCT8_DC, d, b, s)) SHIM_FB(g_fb_h264, idct8_dc_add, d, b, s); }
+static void s_add_pixels4(uint8_t *d, int16_t *b, ptrdiff_t s) { if (!idct_single(FFHIP_H264_ADD_PIXELS4_CLEAR, d, b, s)) SHIM_FB(g_fb_h264, add_pixels4_clear, d, b, s); }
+static void s_add_pixels8(uint8_t *d, int16_t *b, ptrdiff_t s) { if (!idct_single(FFHIP_H264_ADD_PIXELS8_CLEAR, d, b, s)) SHIM_FB(g_fb_h264, add_pixels8_clear, d, b, s); }
 
 /* ---- h264dsp: macroblock dispatchers (idct_add16 / idct8_add4 / idct_add16intra) ---------------------- */
-static void idct_mb(int which, uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc)
+static bool idct_mb(int which, uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     if (stride <= 0 || stride > (1 << 16))
-        return; /* decoders hand these a positive linesize (h264_mb.c:728-779) */
+        return false; /* decoders hand these a positive linesize (h264_mb.c:728-779); anything else is the C function's */
     const int bs = which == 1 ? 8 : 4;
     int lo = blockoffset[0], hi = blockoffset[0];
     for (int i = 0; i < 16; i += (which == 1 ? 4 : 1)) {
@@ -88,10 +111,10 @@ static void idct_mb(int which, uint8_t *dst, const int *blockoffset, int16_t *bl
         if (blockoffset[i] > hi) hi = blockoffset[i];
     }
     const size_t span = (size_t)(hi - lo) + (size_t)(bs - 1) * stride + bs;
-    void *scratch;
-    if (ffhip_scratch_reserve(span + 512 + 64 + 64 + 64 + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(span + 512 + 64 + 64 + 64 + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     int16_t *dblk = (int16_t *)buf;              /* 512 B */
     int32_t *dbo = (int32_t *)(buf + 512);       /* 64 B  */
     uint8_t *dnn = buf + 576;                    /* 40 B  */
@@ -106,31 +129,104 @@ static void idct_mb(int which, uint8_t *dst, const int *blockoffset, int16_t *bl
         hipMemcpy(dbo, bo, 64, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dnn, nnzc, 40, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dmb, &mboff, 4, hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_h264_idct_add_mb(which, dpix, stride, dmb, dbo, dblk, dnn, 1, 0) < 0 ||
-        hipStreamSynchronize(0) != hipSuccess)
-        return;
+        return false;
+    if (ffhip_launch_h264_idct_add_mb(which, dpix, stride, dmb, dbo, dblk, dnn, 1, 0) < 0 || !A.down())
+        return false;
     for (int i = 0; i < 16; i += (which == 1 ? 4 : 1)) /* only this macroblock's own blocks travel back */
-        if (hipMemcpy2D(dst + blockoffset[i], stride, dpix + bo[i], stride, bs, bs, hipMemcpyDeviceToHost) != hipSuccess)
-            return;
-    (void)hipMemcpy(block, dblk, 512, hipMemcpyDeviceToHost);
+        commit2d(A, dst + blockoffset[i], stride, dpix + bo[i], stride, bs, bs);
+    memcpy(block, A.host(dblk), 512);
+    return true;
 }
-static void s_idct_add16(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { idct_mb(0, d, bo, b, s, n); }
-static void s_idct8_add4(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { idct_mb(1, d, bo, b, s, n); }
-static void s_idct_add16intra(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { idct_mb(2, d, bo, b, s, n); }
+static void s_idct_add16(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { if (!idct_mb(0, d, bo, b, s, n)) SHIM_FB(g_fb_h264, idct_add16, d, bo, b, s, n); }
+static void s_idct8_add4(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { if (!idct_mb(1, d, bo, b, s, n)) SHIM_FB(g_fb_h264, idct8_add4, d, bo, b, s, n); }
+static void s_idct_add16intra(uint8_t *d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[5 * 8]) { if (!idct_mb(2, d, bo, b, s, n)) SHIM_FB(g_fb_h264, idct_add16intra, d, bo, b, s, n); }
+
+/* idct_add8 (4:2:0): the two chroma planes' four blocks, blocks 16..19 / 32..35 of the macroblock's coefficient array, staged like
+ * idct_mb (the span of each plane's four blocks, the 768 coefficients, the 48 offsets, the 15 x 8 cache) */
+static bool idct_add8_gpu(uint8_t **dest, const int *blockoffset, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc)
+{
+    if (stride <= 0 || stride > (1 << 16))
+        return false;
+    int lo[2], hi[2];
+    for (int j = 0; j < 2; j++) {
+        lo[j] = hi[j] = blockoffset[16 * (j + 1)];
+        for (int i = 16 * (j + 1); i < 16 * (j + 1) + 4; i++) {
+            if (blockoffset[i] < lo[j]) lo[j] = blockoffset[i];
+            if (blockoffset[i] > hi[j]) hi[j] = blockoffset[i];
+        }
+    }
+    const size_t span[2] = { (size_t)(hi[0] - lo[0]) + 3 * (size_t)stride + 4, (size_t)(hi[1] - lo[1]) + 3 * (size_t)stride + 4 };
+    const size_t sp0 = (span[0] + 63) & ~(size_t)63, sp1 = (span[1] + 63) & ~(size_t)63;
+    Arena A(1536 + 192 + 128 + 64 + sp0 + sp1 + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
+    int16_t *dblk = (int16_t *)buf;              /* 1536 B */
+    int32_t *dbo = (int32_t *)(buf + 1536);      /* 192 B  */
+    uint8_t *dnn = buf + 1728;                   /* 120 B  */
+    int32_t *dmb = (int32_t *)(buf + 1856);      /* 4 B    */
+    uint8_t *dpix[2] = { buf + 1920, buf + 1920 + sp0 };
+    const int32_t mboff = 0;
+    int32_t bo[48] = { 0 };
+    for (int j = 0; j < 2; j++)
+        for (int i = 16 * (j + 1); i < 16 * (j + 1) + 4; i++)
+            bo[i] = blockoffset[i] - lo[j];
+    if (hipMemcpy(dpix[0], dest[0] + lo[0], span[0], hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dpix[1], dest[1] + lo[1], span[1], hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dblk, block, 1536, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dbo, bo, 192, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dnn, nnzc, 120, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dmb, &mboff, 4, hipMemcpyHostToDevice) != hipSuccess)
+        return false;
+    if (ffhip_launch_h264_idct_add8(dpix[0], dpix[1], stride, dmb, dbo, dblk, dnn, 1, 0) < 0 || !A.down())
+        return false;
+    for (int j = 0; j < 2; j++)
+        for (int i = 16 * (j + 1); i < 16 * (j + 1) + 4; i++)
+            commit2d(A, dest[j] + blockoffset[i], stride, dpix[j] + bo[i], stride, 4, 4);
+    memcpy(block + 256, A.host(dblk + 256), 2 * 256 * sizeof(int16_t)); /* the chroma planes' coefficients (cleared where consumed) */
+    return true;
+}
+static void s_idct_add8(uint8_t **d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[15 * 8]) { if (!idct_add8_gpu(d, bo, b, s, n)) SHIM_FB(g_fb_h264, idct_add8, d, bo, b, s, n); }
+
+/* the DC transforms: 16 (luma) / 4 (chroma) values in, dequantised values out */
+static bool dc_dequant_gpu(int luma, int16_t *output, int16_t *input, int qmul)
+{
+    Arena A(512 + 64 + 64 + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
+    int16_t *dout = (int16_t *)buf, *din = (int16_t *)(buf + 512);
+    int32_t *dq = (int32_t *)(buf + 576), *doff = (int32_t *)(buf + 608);
+    const int32_t q = qmul, zero = 0;
+    if (hipMemcpy(dq, &q, 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(doff, &zero, 4, hipMemcpyHostToDevice) != hipSuccess)
+        return false;
+    if (luma) {
+        if (hipMemcpy(din, input, 32, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dout, output, 512, hipMemcpyHostToDevice) != hipSuccess ||
+            ffhip_launch_h264_luma_dc_dequant(dout, 256, din, 16, dq, 1, 0) < 0 || !A.down())
+            return false;
+        for (int i = 0; i < 16; i++) /* the 16 DC positions are all the function writes */
+            output[16 * i] = reinterpret_cast<const int16_t *>(A.host(dout))[16 * i];
+    } else {
+        if (hipMemcpy(dout, output, 128, hipMemcpyHostToDevice) != hipSuccess || ffhip_launch_h264_chroma_dc_dequant(dout, doff, dq, 1, 0) < 0 ||
+            !A.down())
+            return false;
+        for (int i = 0; i < 4; i++)
+            output[16 * i] = reinterpret_cast<const int16_t *>(A.host(dout))[16 * i];
+    }
+    return true;
+}
+static void s_luma_dc_dequant(int16_t *o, int16_t *i, int q) { if (!dc_dequant_gpu(1, o, i, q)) SHIM_FB(g_fb_h264, luma_dc_dequant_idct, o, i, q); }
+static void s_chroma_dc_dequant(int16_t *b, int q) { if (!dc_dequant_gpu(0, b, nullptr, q)) SHIM_FB(g_fb_h264, chroma_dc_dequant_idct, b, q); }
 
 /* ---- h264dsp: loop filters --------------------------------------------------------------------------- */
-static void lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0)
+static bool lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const bool chroma = kind & 2, vert_edge = kind & 1;
     const int along = chroma ? 8 : 16, across = chroma ? 2 : 4; /* samples read each side of the edge */
     Rect r = { pix, stride, vert_edge ? 0 : -across, vert_edge ? along - 1 : across - 1,
                vert_edge ? -across : 0, vert_edge ? across - 1 : along - 1, nullptr };
-    void *scratch;
-    if (ffhip_scratch_reserve(rect_bytes(r) + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(rect_bytes(r) + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     FFHipH264Edge e;
     memset(&e, 0, sizeof(e));
     e.kind = (uint8_t)kind;
@@ -139,66 +235,79 @@ static void lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int b
     if (tc0)
         memcpy(e.tc0, tc0, 4);
     if (!rect_up(r, buf + 64) || hipMemcpy(buf, &e, sizeof(e), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_h264_loop_filter(r.dev, DP, (const FFHipH264Edge *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    rect_down(r, r.r0, r.r1, r.c0, r.c1);
+        return false;
+    if (ffhip_launch_h264_loop_filter(r.dev, DP, (const FFHipH264Edge *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    rect_commit(A, r, r.r0, r.r1, r.c0, r.c1);
+    return true;
 }
-static void s_v_lf_luma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { lf_single(FFHIP_H264_LF_V_LUMA, p, s, a, b, t); }
-static void s_h_lf_luma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { lf_single(FFHIP_H264_LF_H_LUMA, p, s, a, b, t); }
-static void s_v_lf_chroma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { lf_single(FFHIP_H264_LF_V_CHROMA, p, s, a, b, t); }
-static void s_h_lf_chroma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { lf_single(FFHIP_H264_LF_H_CHROMA, p, s, a, b, t); }
-static void s_v_lf_luma_i(uint8_t *p, ptrdiff_t s, int a, int b) { lf_single(FFHIP_H264_LF_V_LUMA_INTRA, p, s, a, b, nullptr); }
-static void s_h_lf_luma_i(uint8_t *p, ptrdiff_t s, int a, int b) { lf_single(FFHIP_H264_LF_H_LUMA_INTRA, p, s, a, b, nullptr); }
-static void s_v_lf_chroma_i(uint8_t *p, ptrdiff_t s, int a, int b) { lf_single(FFHIP_H264_LF_V_CHROMA_INTRA, p, s, a, b, nullptr); }
-static void s_h_lf_chroma_i(uint8_t *p, ptrdiff_t s, int a, int b) { lf_single(FFHIP_H264_LF_H_CHROMA_INTRA, p, s, a, b, nullptr); }
+static void s_v_lf_luma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { if (!lf_single(FFHIP_H264_LF_V_LUMA, p, s, a, b, t)) SHIM_FB(g_fb_h264, v_loop_filter_luma, p, s, a, b, t); }
+static void s_h_lf_luma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { if (!lf_single(FFHIP_H264_LF_H_LUMA, p, s, a, b, t)) SHIM_FB(g_fb_h264, h_loop_filter_luma, p, s, a, b, t); }
+static void s_v_lf_chroma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { if (!lf_single(FFHIP_H264_LF_V_CHROMA, p, s, a, b, t)) SHIM_FB(g_fb_h264, v_loop_filter_chroma, p, s, a, b, t); }
+static void s_h_lf_chroma(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) { if (!lf_single(FFHIP_H264_LF_H_CHROMA, p, s, a, b, t)) SHIM_FB(g_fb_h264, h_loop_filter_chroma, p, s, a, b, t); }
+static void s_v_lf_luma_i(uint8_t *p, ptrdiff_t s, int a, int b) { if (!lf_single(FFHIP_H264_LF_V_LUMA_INTRA, p, s, a, b, nullptr)) SHIM_FB(g_fb_h264, v_loop_filter_luma_intra, p, s, a, b); }
+static void s_h_lf_luma_i(uint8_t *p, ptrdiff_t s, int a, int b) { if (!lf_single(FFHIP_H264_LF_H_LUMA_INTRA, p, s, a, b, nullptr)) SHIM_FB(g_fb_h264, h_loop_filter_luma_intra, p, s, a, b); }
+static void s_v_lf_chroma_i(uint8_t *p, ptrdiff_t s, int a, int b) { if (!lf_single(FFHIP_H264_LF_V_CHROMA_INTRA, p, s, a, b, nullptr)) SHIM_FB(g_fb_h264, v_loop_filter_chroma_intra, p, s, a, b); }
+static void s_h_lf_chroma_i(uint8_t *p, ptrdiff_t s, int a, int b) { if (!lf_single(FFHIP_H264_LF_H_CHROMA_INTRA, p, s, a, b, nullptr)) SHIM_FB(g_fb_h264, h_loop_filter_chroma_intra, p, s, a, b); }
 
 extern "C" int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int chroma_format_idc)
 {
-    (void)chroma_format_idc;
     if (!c)
         return FFHIP_EINVAL;
-    if (bit_depth != 8)
-        return FFHIP_EINVAL; /* other depths keep the C pointers (h264dsp.c:70-150 selects per depth) */
+    if (bit_depth != 8 || chroma_format_idc > 1)
+        return FFHIP_EINVAL; /* other depths / 4:2:2 keep the C pointers (h264dsp.c:70-150 selects per depth and chroma format) */
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    c->v_loop_filter_luma = s_v_lf_luma;                 c->h_loop_filter_luma = s_h_lf_luma;
-    c->v_loop_filter_luma_intra = s_v_lf_luma_i;         c->h_loop_filter_luma_intra = s_h_lf_luma_i;
-    c->v_loop_filter_chroma = s_v_lf_chroma;             c->h_loop_filter_chroma = s_h_lf_chroma;
-    c->v_loop_filter_chroma_intra = s_v_lf_chroma_i;     c->h_loop_filter_chroma_intra = s_h_lf_chroma_i;
-    c->idct_add = s_idct_add;                            c->idct8_add = s_idct8_add;
-    c->idct_dc_add = s_idct_dc_add;                      c->idct8_dc_add = s_idct8_dc_add;
-    c->idct_add16 = s_idct_add16;                        c->idct8_add4 = s_idct8_add4;
-    c->idct_add16intra = s_idct_add16intra;
+    FFHipH264DSPContext o = *c;
+    o.v_loop_filter_luma = s_v_lf_luma;                 o.h_loop_filter_luma = s_h_lf_luma;
+    o.v_loop_filter_luma_intra = s_v_lf_luma_i;         o.h_loop_filter_luma_intra = s_h_lf_luma_i;
+    o.v_loop_filter_chroma = s_v_lf_chroma;             o.h_loop_filter_chroma = s_h_lf_chroma;
+    o.v_loop_filter_chroma_intra = s_v_lf_chroma_i;     o.h_loop_filter_chroma_intra = s_h_lf_chroma_i;
+    o.idct_add = s_idct_add;                            o.idct8_add = s_idct8_add;
+    o.idct_dc_add = s_idct_dc_add;                      o.idct8_dc_add = s_idct8_dc_add;
+    o.idct_add16 = s_idct_add16;                        o.idct8_add4 = s_idct8_add4;
+    o.idct_add16intra = s_idct_add16intra;              o.idct_add8 = s_idct_add8;
+    o.luma_dc_dequant_idct = s_luma_dc_dequant;         o.chroma_dc_dequant_idct = s_chroma_dc_dequant;
+    o.add_pixels4_clear = s_add_pixels4;                o.add_pixels8_clear = s_add_pixels8;
+    fb_snapshot(g_fb_h264, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- h264qpel ---------------------------------------------------------------------------------------- */
-static void qpel_single(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride)
+static bool qpel_single(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const int n = 16 >> size_idx;
     Rect d = { dst, stride, 0, n - 1, 0, n - 1, nullptr };
-    Rect s = { const_cast<uint8_t *>(src), stride, -2, n + 2, -2, n + 2, nullptr };
-    void *scratch;
-    if (ffhip_scratch_reserve(rect_bytes(d) + rect_bytes(s) + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
-    if (!rect_up(d, buf + 64) || !rect_up(s, buf + 64 + rect_bytes(d)))
-        return;
+    /* only what the reference function of this slot reads: the 6-tap margin exists on an axis only when that axis is
+     * filtered (mc00 / mc0y / mcx0 read no margin on the other one; mc_dir_part emulates edges only then, h264_mb.c:206-300) */
+    const bool fx = mcxy & 3, fy = mcxy >> 2;
+    Rect s = { const_cast<uint8_t *>(src), stride, fy ? -2 : 0, fy ? n + 2 : n - 1, fx ? -2 : 0, fx ? n + 2 : n - 1, nullptr };
+    Rect full = s;
+    full.r0 = -2; full.r1 = n + 2; full.c0 = -2; full.c1 = n + 2; /* the device tile always has the margin (unread part: whatever) */
+    Arena A(rect_bytes(d) + rect_bytes(full) + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
+    /* the (possibly margin-less) source rectangle lands where a full-margin one would: row -2, column -2 at the tile's origin */
+    if (!rect_up(d, buf + 64) || !rect_up(s, buf + 64 + rect_bytes(d) + (size_t)(s.r0 + 2) * DP + (s.c0 + 2)))
+        return false;
     FFHipQpelBlock b;
     memset(&b, 0, sizeof(b));
     /* both rectangles sit in one scratch arena: offsets relative to its start, one shared pitch */
     b.dst_offset = (int32_t)(d.dev - buf); b.src_offset = (int32_t)(s.dev - buf);
     b.mcxy = (uint8_t)mcxy; b.size_idx = (uint8_t)size_idx; b.avg = (uint8_t)avg;
     if (hipMemcpy(buf, &b, sizeof(b), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_h264_qpel(buf, buf, DP, (const FFHipQpelBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    rect_down(d, 0, n - 1, 0, n - 1);
+        return false;
+    if (ffhip_launch_h264_qpel(buf, buf, DP, (const FFHipQpelBlock *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    rect_commit(A, d, 0, n - 1, 0, n - 1);
+    return true;
 }
+static FFHipH264QpelContext g_fb_qpel;
 #define QPEL_FN(op, avg, sz, idx, mc) \
-    static void s_##op##_qpel##sz##_mc##mc(uint8_t *d, const uint8_t *s, ptrdiff_t st) { qpel_single(avg, idx, mc, d, s, st); }
+    static void s_##op##_qpel##sz##_mc##mc(uint8_t *d, const uint8_t *s, ptrdiff_t st) \
+    { if (!qpel_single(avg, idx, mc, d, s, st)) SHIM_FB(g_fb_qpel, op##_h264_qpel_pixels_tab[idx][mc], d, s, st); }
 #define QPEL_16(op, avg, sz, idx) \
     QPEL_FN(op, avg, sz, idx, 0) QPEL_FN(op, avg, sz, idx, 1) QPEL_FN(op, avg, sz, idx, 2) QPEL_FN(op, avg, sz, idx, 3) \
     QPEL_FN(op, avg, sz, idx, 4) QPEL_FN(op, avg, sz, idx, 5) QPEL_FN(op, avg, sz, idx, 6) QPEL_FN(op, avg, sz, idx, 7) \
@@ -220,38 +329,43 @@ extern "C" int ff_h264qpel_init_hip(FFHipH264QpelContext *c, int bit_depth)
     /* table index = X + 4*Y, [0] 16x16 [1] 8x8 [2] 4x4 (h264qpel.c:55-70) */
     static const ffhip_qpel_mc_func put[3][16] = { QPEL_ROW(put, 16), QPEL_ROW(put, 8), QPEL_ROW(put, 4) };
     static const ffhip_qpel_mc_func avg[3][16] = { QPEL_ROW(avg, 16), QPEL_ROW(avg, 8), QPEL_ROW(avg, 4) };
-    memcpy(c->put_h264_qpel_pixels_tab, put, sizeof(put));
-    memcpy(c->avg_h264_qpel_pixels_tab, avg, sizeof(avg));
+    FFHipH264QpelContext o = *c;
+    memcpy(o.put_h264_qpel_pixels_tab, put, sizeof(put));
+    memcpy(o.avg_h264_qpel_pixels_tab, avg, sizeof(avg));
+    fb_snapshot(g_fb_qpel, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- h264chroma / weighted prediction ------------------------------------------------------------------ */
-static void chroma_single(int avg, int w_idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y)
+static bool chroma_single(int avg, int w_idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const int w = 8 >> w_idx;
     if (h <= 0 || h > 16)
-        return;
+        return false;
     Rect d = { dst, stride, 0, h - 1, 0, w - 1, nullptr };
     Rect s = { const_cast<uint8_t *>(src), stride, 0, (y & 7) ? h : h - 1, 0, (x & 7) ? w : w - 1, nullptr };
-    void *scratch;
-    if (ffhip_scratch_reserve(rect_bytes(d) + rect_bytes(s) + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(rect_bytes(d) + rect_bytes(s) + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     if (!rect_up(d, buf + 64) || !rect_up(s, buf + 64 + rect_bytes(d)))
-        return;
+        return false;
     FFHipChromaBlock b;
     memset(&b, 0, sizeof(b));
     b.dst_offset = (int32_t)(d.dev - buf); b.src_offset = (int32_t)(s.dev - buf);
     b.w_idx = (uint8_t)w_idx; b.h = (uint8_t)h; b.x = (uint8_t)x; b.y = (uint8_t)y; b.avg = (uint8_t)avg;
     if (hipMemcpy(buf, &b, sizeof(b), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_h264_chroma_mc(buf, buf, DP, (const FFHipChromaBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    rect_down(d, 0, h - 1, 0, w - 1);
+        return false;
+    if (ffhip_launch_h264_chroma_mc(buf, buf, DP, (const FFHipChromaBlock *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    rect_commit(A, d, 0, h - 1, 0, w - 1);
+    return true;
 }
+static FFHipH264ChromaContext g_fb_chroma;
 #define CHROMA_FN(op, avg, idx) \
-    static void s_##op##_chroma##idx(uint8_t *d, const uint8_t *s, ptrdiff_t st, int h, int x, int y) { chroma_single(avg, idx, d, s, st, h, x, y); }
+    static void s_##op##_chroma##idx(uint8_t *d, const uint8_t *s, ptrdiff_t st, int h, int x, int y) \
+    { if (!chroma_single(avg, idx, d, s, st, h, x, y)) SHIM_FB(g_fb_chroma, op##_h264_chroma_pixels_tab[idx], d, s, st, h, x, y); }
 CHROMA_FN(put, 0, 0) CHROMA_FN(put, 0, 1) CHROMA_FN(put, 0, 2) CHROMA_FN(avg, 1, 0) CHROMA_FN(avg, 1, 1) CHROMA_FN(avg, 1, 2)
 
 extern "C" int ff_h264chroma_init_hip(FFHipH264ChromaContext *c, int bit_depth)
@@ -260,42 +374,48 @@ extern "C" int ff_h264chroma_init_hip(FFHipH264ChromaContext *c, int bit_depth)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    c->put_h264_chroma_pixels_tab[0] = s_put_chroma0; c->put_h264_chroma_pixels_tab[1] = s_put_chroma1;
-    c->put_h264_chroma_pixels_tab[2] = s_put_chroma2;
-    c->avg_h264_chroma_pixels_tab[0] = s_avg_chroma0; c->avg_h264_chroma_pixels_tab[1] = s_avg_chroma1;
-    c->avg_h264_chroma_pixels_tab[2] = s_avg_chroma2;
+    FFHipH264ChromaContext o = *c;
+    o.put_h264_chroma_pixels_tab[0] = s_put_chroma0; o.put_h264_chroma_pixels_tab[1] = s_put_chroma1;
+    o.put_h264_chroma_pixels_tab[2] = s_put_chroma2;
+    o.avg_h264_chroma_pixels_tab[0] = s_avg_chroma0; o.avg_h264_chroma_pixels_tab[1] = s_avg_chroma1;
+    o.avg_h264_chroma_pixels_tab[2] = s_avg_chroma2;
+    fb_snapshot(g_fb_chroma, *c, o);
+    *c = o;
     return 0;
 }
 
-static void weight_single(int bi, int w_idx, uint8_t *dst, uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
+static bool weight_single(int bi, int w_idx, uint8_t *dst, uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
                           int weights, int offset)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const int w = 16 >> w_idx;
     if (height <= 0 || height > 16)
-        return;
+        return false;
     Rect d = { dst, stride, 0, height - 1, 0, w - 1, nullptr };
     Rect s = { bi ? src : dst, stride, 0, height - 1, 0, w - 1, nullptr };
-    void *scratch;
-    if (ffhip_scratch_reserve(rect_bytes(d) + rect_bytes(s) + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(rect_bytes(d) + rect_bytes(s) + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     if (!rect_up(d, buf + 64) || (bi && !rect_up(s, buf + 64 + rect_bytes(d))))
-        return;
+        return false;
     FFHipWeightBlock b;
     memset(&b, 0, sizeof(b));
     b.dst_offset = (int32_t)(d.dev - buf); b.src_offset = bi ? (int32_t)(s.dev - buf) : b.dst_offset;
     b.w_idx = (uint8_t)w_idx; b.height = (uint8_t)height; b.log2_denom = (uint8_t)log2_denom; b.bi = (uint8_t)bi;
     b.weightd = (int16_t)weightd; b.weights = (int16_t)weights; b.offset = (int16_t)offset;
     if (hipMemcpy(buf, &b, sizeof(b), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_h264_weight(buf, buf, DP, (const FFHipWeightBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    rect_down(d, 0, height - 1, 0, w - 1);
+        return false;
+    if (ffhip_launch_h264_weight(buf, buf, DP, (const FFHipWeightBlock *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    rect_commit(A, d, 0, height - 1, 0, w - 1);
+    return true;
 }
+static FFHipH264WeightContext g_fb_weight;
 #define WEIGHT_FN(idx) \
-    static void s_weight##idx(uint8_t *b, ptrdiff_t st, int h, int ld, int w, int o) { weight_single(0, idx, b, nullptr, st, h, ld, w, 0, o); } \
-    static void s_biweight##idx(uint8_t *d, uint8_t *s, ptrdiff_t st, int h, int ld, int wd, int ws, int o) { weight_single(1, idx, d, s, st, h, ld, wd, ws, o); }
+    static void s_weight##idx(uint8_t *b, ptrdiff_t st, int h, int ld, int w, int o) \
+    { if (!weight_single(0, idx, b, nullptr, st, h, ld, w, 0, o)) SHIM_FB(g_fb_weight, weight_pixels_tab[idx], b, st, h, ld, w, o); } \
+    static void s_biweight##idx(uint8_t *d, uint8_t *s, ptrdiff_t st, int h, int ld, int wd, int ws, int o) \
+    { if (!weight_single(1, idx, d, s, st, h, ld, wd, ws, o)) SHIM_FB(g_fb_weight, biweight_pixels_tab[idx], d, s, st, h, ld, wd, ws, o); }
 WEIGHT_FN(0) WEIGHT_FN(1) WEIGHT_FN(2) WEIGHT_FN(3)
 
 extern "C" int ff_h264dsp_weight_init_hip(FFHipH264WeightContext *c, int bit_depth)
@@ -304,174 +424,208 @@ extern "C" int ff_h264dsp_weight_init_hip(FFHipH264WeightContext *c, int bit_dep
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    c->weight_pixels_tab[0] = s_weight0; c->weight_pixels_tab[1] = s_weight1; c->weight_pixels_tab[2] = s_weight2;
-    c->weight_pixels_tab[3] = s_weight3;
-    c->biweight_pixels_tab[0] = s_biweight0; c->biweight_pixels_tab[1] = s_biweight1; c->biweight_pixels_tab[2] = s_biweight2;
-    c->biweight_pixels_tab[3] = s_biweight3;
+    FFHipH264WeightContext o = *c;
+    o.weight_pixels_tab[0] = s_weight0; o.weight_pixels_tab[1] = s_weight1; o.weight_pixels_tab[2] = s_weight2;
+    o.weight_pixels_tab[3] = s_weight3;
+    o.biweight_pixels_tab[0] = s_biweight0; o.biweight_pixels_tab[1] = s_biweight1; o.biweight_pixels_tab[2] = s_biweight2;
+    o.biweight_pixels_tab[3] = s_biweight3;
+    fb_snapshot(g_fb_weight, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- hevcdsp inverse transforms --------------------------------------------------------------------------- */
 /* layout in scratch: [0,64) the TU record, [64, 64+2*n*n) coefficients, then the picture rectangle */
-static void hevc_single(int kind, int log2_size, int16_t *coeffs, int col_limit, uint8_t *dst, ptrdiff_t stride)
+static bool hevc_single(int kind, int log2_size, int16_t *coeffs, int col_limit, uint8_t *dst, ptrdiff_t stride)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const int n = 1 << log2_size;
     const size_t cbytes = (size_t)n * n * 2;
     Rect d = { dst, stride, 0, n - 1, 0, n - 1, nullptr };
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + cbytes + (dst ? rect_bytes(d) : 0) + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(64 + cbytes + (dst ? rect_bytes(d) : 0) + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     if (hipMemcpy(buf + 64, coeffs, cbytes, hipMemcpyHostToDevice) != hipSuccess)
-        return;
+        return false;
     if (dst && !rect_up(d, buf + 64 + cbytes))
-        return;
+        return false;
     FFHipHevcTU tu;
     tu.coeff_offset = 0;
     tu.dst_offset = dst ? (int32_t)(d.dev - (buf + 64 + cbytes)) : -1;
     tu.col_limit = col_limit;
     if (hipMemcpy(buf, &tu, sizeof(tu), hipMemcpyHostToDevice) != hipSuccess)
-        return;
+        return false;
     if (ffhip_launch_hevc_idct(kind, log2_size, (int16_t *)(buf + 64), dst ? buf + 64 + cbytes : nullptr, DP, (const FFHipHevcTU *)buf, 1, 0) < 0 ||
-        hipStreamSynchronize(0) != hipSuccess)
-        return;
+        !A.down())
+        return false;
     if (kind != FFHIP_HEVC_ADD_ONLY)
-        (void)hipMemcpy(coeffs, buf + 64, cbytes, hipMemcpyDeviceToHost);
+        memcpy(coeffs, A.host(buf + 64), cbytes);
     if (dst)
-        rect_down(d, 0, n - 1, 0, n - 1);
+        rect_commit(A, d, 0, n - 1, 0, n - 1);
+    return true;
 }
+static FFHipHEVCDSPContext g_fb_hevc;
 #define HEVC_FN(idx) \
-    static void s_hevc_idct##idx(int16_t *c, int col_limit) { hevc_single(FFHIP_HEVC_IDCT, idx + 2, c, col_limit, nullptr, 0); } \
-    static void s_hevc_dc##idx(int16_t *c) { hevc_single(FFHIP_HEVC_IDCT_DC, idx + 2, c, 0, nullptr, 0); } \
-    static void s_hevc_add##idx(uint8_t *d, const int16_t *r, ptrdiff_t st) { hevc_single(FFHIP_HEVC_ADD_ONLY, idx + 2, const_cast<int16_t *>(r), 0, d, st); }
+    static void s_hevc_idct##idx(int16_t *c, int col_limit) \
+    { if (!hevc_single(FFHIP_HEVC_IDCT, idx + 2, c, col_limit, nullptr, 0)) SHIM_FB(g_fb_hevc, idct[idx], c, col_limit); } \
+    static void s_hevc_dc##idx(int16_t *c) { if (!hevc_single(FFHIP_HEVC_IDCT_DC, idx + 2, c, 0, nullptr, 0)) SHIM_FB(g_fb_hevc, idct_dc[idx], c); } \
+    static void s_hevc_add##idx(uint8_t *d, const int16_t *r, ptrdiff_t st) \
+    { if (!hevc_single(FFHIP_HEVC_ADD_ONLY, idx + 2, const_cast<int16_t *>(r), 0, d, st)) SHIM_FB(g_fb_hevc, add_residual[idx], d, r, st); }
 HEVC_FN(0) HEVC_FN(1) HEVC_FN(2) HEVC_FN(3)
-static void s_hevc_dst4(int16_t *c) { hevc_single(FFHIP_HEVC_DST_4X4, 2, c, 0, nullptr, 0); }
+static void s_hevc_dst4(int16_t *c) { if (!hevc_single(FFHIP_HEVC_DST_4X4, 2, c, 0, nullptr, 0)) SHIM_FB(g_fb_hevc, transform_4x4_luma, c); }
 
 /* one edge segment: the 8 lines x 8 samples around it staged as a rectangle (h_: rows -4..3 x cols 0..7, v_: rows 0..7 x cols -4..3) */
-static void hevc_lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q)
+static bool hevc_lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const bool vertical = kind & 1;
     Rect d = { pix, stride, vertical ? 0 : -4, vertical ? 7 : 3, vertical ? -4 : 0, vertical ? 3 : 7, nullptr };
-    void *scratch;
-    if (ffhip_scratch_reserve(rect_bytes(d) + 128, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(rect_bytes(d) + 128);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     if (!rect_up(d, buf + 64))
-        return;
+        return false;
     FFHipHevcEdge e;
     memset(&e, 0, sizeof(e));
     e.offset = (int32_t)(d.dev - buf); e.kind = (uint8_t)kind; e.beta = (uint8_t)beta;
     for (int j = 0; j < 2; j++) { e.tc[j] = (int16_t)tc[j]; e.no_p[j] = no_p[j]; e.no_q[j] = no_q[j]; }
     if (hipMemcpy(buf, &e, sizeof(e), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_hevc_loop_filter(buf, DP, (const FFHipHevcEdge *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    rect_down(d, d.r0, d.r1, d.c0, d.c1);
+        return false;
+    if (ffhip_launch_hevc_loop_filter(buf, DP, (const FFHipHevcEdge *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    rect_commit(A, d, d.r0, d.r1, d.c0, d.c1);
+    return true;
 }
-static void s_hevc_lf_hl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_H_LUMA, p, st, beta, tc, np_, nq); }
-static void s_hevc_lf_vl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_V_LUMA, p, st, beta, tc, np_, nq); }
-static void s_hevc_lf_hc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_H_CHROMA, p, st, 0, tc, np_, nq); }
-static void s_hevc_lf_vc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq) { hevc_lf_single(FFHIP_HEVC_LF_V_CHROMA, p, st, 0, tc, np_, nq); }
+static void s_hevc_lf_hl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
+{ if (!hevc_lf_single(FFHIP_HEVC_LF_H_LUMA, p, st, beta, tc, np_, nq)) SHIM_FB(g_fb_hevc, hevc_h_loop_filter_luma, p, st, beta, tc, np_, nq); }
+static void s_hevc_lf_vl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
+{ if (!hevc_lf_single(FFHIP_HEVC_LF_V_LUMA, p, st, beta, tc, np_, nq)) SHIM_FB(g_fb_hevc, hevc_v_loop_filter_luma, p, st, beta, tc, np_, nq); }
+static void s_hevc_lf_hc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
+{ if (!hevc_lf_single(FFHIP_HEVC_LF_H_CHROMA, p, st, 0, tc, np_, nq)) SHIM_FB(g_fb_hevc, hevc_h_loop_filter_chroma, p, st, tc, np_, nq); }
+static void s_hevc_lf_vc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
+{ if (!hevc_lf_single(FFHIP_HEVC_LF_V_CHROMA, p, st, 0, tc, np_, nq)) SHIM_FB(g_fb_hevc, hevc_v_loop_filter_chroma, p, st, tc, np_, nq); }
 
 /* SAO: source rows -1..height (edge: with one column of margin) and the destination block packed at a pitch of 192 bytes */
-static void hevc_sao_single(int edge, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const int16_t *off, int cls, int w, int h)
+static bool hevc_sao_single(int edge, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const int16_t *off, int cls, int w, int h)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     if (w <= 0 || h <= 0 || w > 64 || h > 64)
-        return;
+        return false;
     const int P = 192, mg = edge ? 1 : 0;
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + (size_t)(h + 2) * P * 2 + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + (size_t)(h + 2) * P;
-    for (int y = -mg; y < h + mg; y++)
-        if (hipMemcpy(dsrc + (size_t)(y + 1) * P + 1 - mg, src + y * ss - mg, w + 2 * mg, hipMemcpyHostToDevice) != hipSuccess)
-            return;
+    Arena A(64 + (size_t)(h + 2) * P * 2 + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + (size_t)(h + 2) * P;
+    if (ss >= w + 2 * mg) {
+        if (hipMemcpy2D(dsrc + (size_t)(1 - mg) * P + 1 - mg, P, src - mg * ss - mg, ss, w + 2 * mg, h + 2 * mg, hipMemcpyHostToDevice) != hipSuccess)
+            return false;
+    } else {
+        for (int y = -mg; y < h + mg; y++)
+            if (hipMemcpy(dsrc + (size_t)(y + 1) * P + 1 - mg, src + y * ss - mg, w + 2 * mg, hipMemcpyHostToDevice) != hipSuccess)
+                return false;
+    }
     FFHipHevcSao k;
     memset(&k, 0, sizeof(k));
     k.dst_offset = 0; k.src_offset = P + 1;
     for (int i = 0; i < 5; i++) k.offset_val[i] = off[i];
     k.edge = (uint8_t)edge; k.cls = (uint8_t)cls; k.width = (uint8_t)w; k.height = (uint8_t)h;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_hevc_sao(ddst, P, dsrc, P, (const FFHipHevcSao *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    for (int y = 0; y < h; y++)
-        (void)hipMemcpy(dst + y * sd, ddst + (size_t)y * P, w, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_hevc_sao(ddst, P, dsrc, P, (const FFHipHevcSao *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    commit2d(A, dst, sd, ddst, P, w, h);
+    return true;
 }
-static void s_hevc_sao_band(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const int16_t *o, int lc, int w, int h) { hevc_sao_single(0, d, s, sd, ss, o, lc, w, h); }
-static void s_hevc_sao_edge(uint8_t *d, const uint8_t *s, ptrdiff_t sd, const int16_t *o, int eo, int w, int h) { hevc_sao_single(1, d, s, sd, 192, o, eo, w, h); }
+/* the reference's table index of a block width: sao_tab[(FFALIGN(width, 8) >> 3) - 1] (libavcodec/hevc/filter.c) */
+static int hevc_sao_tab(int w) { static const uint8_t t[8] = { 0, 1, 2, 2, 3, 3, 4, 4 }; const int k = ((w + 7) >> 3) - 1; return t[k < 0 ? 0 : k > 7 ? 7 : k]; }
+static void s_hevc_sao_band(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const int16_t *o, int lc, int w, int h)
+{ if (!hevc_sao_single(0, d, s, sd, ss, o, lc, w, h)) SHIM_FB(g_fb_hevc, sao_band_filter[hevc_sao_tab(w)], d, s, sd, ss, o, lc, w, h); }
+static void s_hevc_sao_edge(uint8_t *d, const uint8_t *s, ptrdiff_t sd, const int16_t *o, int eo, int w, int h)
+{ if (!hevc_sao_single(1, d, s, sd, 192, o, eo, w, h)) SHIM_FB(g_fb_hevc, sao_edge_filter[hevc_sao_tab(w)], d, s, sd, o, eo, w, h); }
 
 /* MC: source rows -3..height+4 x columns -3..width+4 at a pitch of 128; destination after it (pixels: pitch 64; int16: 64 elements);
  * modes 2..4 (FFHIP_HEVC_MC_*): src2's height x 64 int16 after the destination */
-static void hevc_mc_single(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
+static bool hevc_mc_single(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
                            int my, int width, const int16_t *src2 = nullptr, int denom = 0, int wx0 = 0, int wx1 = 0, int ox = 0)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     if (width <= 0 || height <= 0 || width > 64 || height > 64)
-        return;
+        return false;
     const int P = 128, before = chroma ? 1 : 3, after = chroma ? 2 : 4;
     const size_t sbytes = (size_t)(height + before + after) * P, dbytes = (size_t)height * 64 * (uni ? 1 : 2);
     const size_t s2bytes = uni >= 3 ? (size_t)height * 128 : 0;
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + sbytes + dbytes + s2bytes + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + sbytes, *dsrc2 = ddst + dbytes;
+    Arena A(64 + sbytes + dbytes + s2bytes + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + sbytes, *dsrc2 = ddst + dbytes;
     if (s2bytes && (!src2 || hipMemcpy(dsrc2, src2, s2bytes - (size_t)(64 - width) * 2, hipMemcpyHostToDevice) != hipSuccess))
-        return;
-    for (int y = -before; y < height + after; y++)
-        if (hipMemcpy(dsrc + (size_t)(y + before) * P, src + y * srcstride - before, width + before + after, hipMemcpyHostToDevice) != hipSuccess)
-            return;
+        return false;
+    {
+        /* only what the reference function of this slot reads: margins exist on an axis only when that axis is filtered */
+        const int by = my ? before : 0, ay = my ? after : 0, bx = mx ? before : 0, ax = mx ? after : 0;
+        const int cols = width + bx + ax, rows = height + by + ay;
+        uint8_t *d0 = dsrc + (size_t)(before - by) * P + (before - bx);
+        const uint8_t *s0 = src - by * srcstride - bx;
+        if (srcstride >= cols) {
+            if (hipMemcpy2D(d0, P, s0, srcstride, cols, rows, hipMemcpyHostToDevice) != hipSuccess)
+                return false;
+        } else {
+            for (int y = 0; y < rows; y++)
+                if (hipMemcpy(d0 + (size_t)y * P, s0 + y * srcstride, cols, hipMemcpyHostToDevice) != hipSuccess)
+                    return false;
+        }
+    }
     if (uni >= 2) {
         FFHipHevcMcWBlock k = {};
         k.src_offset = before * P + before;
         k.width = (uint8_t)width; k.height = (uint8_t)height; k.mx = (uint8_t)mx; k.my = (uint8_t)my;
         k.wx0 = (int16_t)wx0; k.wx1 = (int16_t)wx1; k.ox = (int16_t)ox; k.denom = (uint8_t)denom;
         if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-            return;
+            return false;
     } else {
         FFHipHevcMcBlock k;
         k.dst_offset = 0; k.src_offset = before * P + before;
         k.width = (uint8_t)width; k.height = (uint8_t)height; k.mx = (uint8_t)mx; k.my = (uint8_t)my;
         if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-            return;
+            return false;
     }
-    if (ffhip_launch_hevc_mc(chroma, uni, ddst, 64, dsrc, P, (const int16_t *)dsrc2, buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    if (uni) {
-        for (int y = 0; y < height; y++)
-            (void)hipMemcpy((uint8_t *)dst + y * dststride, ddst + (size_t)y * 64, width, hipMemcpyDeviceToHost);
-    } else {
-        for (int y = 0; y < height; y++)
-            (void)hipMemcpy((int16_t *)dst + (size_t)y * 64, ddst + (size_t)y * 128, (size_t)width * 2, hipMemcpyDeviceToHost);
-    }
+    if (ffhip_launch_hevc_mc(chroma, uni, ddst, 64, dsrc, P, (const int16_t *)dsrc2, buf, 1, 0) < 0 || !A.down())
+        return false;
+    if (uni)
+        commit2d(A, dst, dststride, ddst, 64, width, height);
+    else
+        commit2d(A, dst, 128, ddst, 128, (size_t)width * 2, height); /* int16 rows of MAX_PB_SIZE = 64 elements */
+    return true;
 }
-static void s_hevc_qpel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(0, 0, d, 0, s, ss, h, (int)mx, (int)my, w); }
-static void s_hevc_epel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(1, 0, d, 0, s, ss, h, (int)mx, (int)my, w); }
-static void s_hevc_qpel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(0, 1, d, ds, s, ss, h, (int)mx, (int)my, w); }
-static void s_hevc_epel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w) { hevc_mc_single(1, 1, d, ds, s, ss, h, (int)mx, (int)my, w); }
-static void s_hevc_dequant(int16_t *c, int16_t log2_size) { hevc_single(FFHIP_HEVC_DEQUANT, log2_size, c, 0, nullptr, 0); }
+/* table slot of a call: [ff_hevc_pel_weight[width]][!!my][!!mx] (libavcodec/hevc/dsp.c, hevcdec.c) */
+static int hevc_pw(int w) { return w <= 2 ? 0 : w <= 4 ? 1 : w <= 6 ? 2 : w <= 8 ? 3 : w <= 12 ? 4 : w <= 16 ? 5 : w <= 24 ? 6 : w <= 32 ? 7 : w <= 48 ? 8 : 9; }
+#define HEVC_SLOT(tab, w, mx, my) tab[hevc_pw(w)][(my) != 0][(mx) != 0]
+static void s_hevc_qpel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
+{ if (!hevc_mc_single(0, 0, d, 0, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_qpel, w, mx, my), d, s, ss, h, mx, my, w); }
+static void s_hevc_epel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
+{ if (!hevc_mc_single(1, 0, d, 0, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_epel, w, mx, my), d, s, ss, h, mx, my, w); }
+static void s_hevc_qpel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
+{ if (!hevc_mc_single(0, 1, d, ds, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_qpel_uni, w, mx, my), d, ds, s, ss, h, mx, my, w); }
+static void s_hevc_epel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
+{ if (!hevc_mc_single(1, 1, d, ds, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_epel_uni, w, mx, my), d, ds, s, ss, h, mx, my, w); }
+static void s_hevc_dequant(int16_t *c, int16_t log2_size) { if (!hevc_single(FFHIP_HEVC_DEQUANT, log2_size, c, 0, nullptr, 0)) SHIM_FB(g_fb_hevc, dequant, c, log2_size); }
 static void s_hevc_rdpcm(int16_t *c, int16_t log2_size, int mode)
 {
-    hevc_single(mode ? FFHIP_HEVC_RDPCM_V : FFHIP_HEVC_RDPCM_H, log2_size, c, 0, nullptr, 0);
+    if (!hevc_single(mode ? FFHIP_HEVC_RDPCM_V : FFHIP_HEVC_RDPCM_H, log2_size, c, 0, nullptr, 0))
+        SHIM_FB(g_fb_hevc, transform_rdpcm, c, log2_size, mode);
 }
 /* sao_edge_restore: rows of the block at a pitch of 64 for both buffers; only the block's own samples travel */
-static void hevc_restore_single(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao,
+static bool hevc_restore_single(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao,
                                 const int *borders, int w, int h, int c_idx, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     if (w <= 0 || h <= 0 || w > 64 || h > 64 || c_idx < 0 || c_idx > 2)
-        return;
+        return false;
     const int P = 64;
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + 2 * (size_t)h * P + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + (size_t)h * P;
+    Arena A(64 + 2 * (size_t)h * P + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + (size_t)h * P;
     if (hipMemcpy2D(dsrc, P, src, ss, w, h, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy2D(ddst, P, dst, sd, w, h, hipMemcpyHostToDevice) != hipSuccess)
-        return;
+        return false;
     FFHipHevcSaoRestore k = {};
     k.offset0 = sao->offset_val[c_idx][0];
     k.width = (uint8_t)w; k.height = (uint8_t)h; k.eo = (uint8_t)sao->eo_class[c_idx]; k.variant = (uint8_t)variant;
@@ -485,27 +639,31 @@ static void hevc_restore_single(int variant, uint8_t *dst, const uint8_t *src, p
         k.horiz_edge = (he[0] != 0) | (he[1] != 0) << 1;
     }
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_hevc_sao_restore(ddst, P, dsrc, P, (const FFHipHevcSaoRestore *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    (void)hipMemcpy2D(dst, sd, ddst, P, w, h, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_hevc_sao_restore(ddst, P, dsrc, P, (const FFHipHevcSaoRestore *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    commit2d(A, dst, sd, ddst, P, w, h);
+    return true;
 }
 static void s_hevc_restore0(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao, const int *b, int w, int h,
                             int c, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
-{ hevc_restore_single(0, d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
+{ if (!hevc_restore_single(0, d, s, sd, ss, sao, b, w, h, c, ve, he, de)) SHIM_FB(g_fb_hevc, sao_edge_restore[0], d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
 static void s_hevc_restore1(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao, const int *b, int w, int h,
                             int c, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
-{ hevc_restore_single(1, d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
+{ if (!hevc_restore_single(1, d, s, sd, ss, sao, b, w, h, c, ve, he, de)) SHIM_FB(g_fb_hevc, sao_edge_restore[1], d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
 #define HEVC_W_SHIMS(name, chroma)                                                                                                          \
 static void s_hevc_##name##_uni_w(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, int denom, int wx, int ox, intptr_t mx,  \
                                   intptr_t my, int w)                                                                                       \
-{ hevc_mc_single(chroma, FFHIP_HEVC_MC_UNI_W, d, ds, s, ss, h, (int)mx, (int)my, w, nullptr, denom, wx, 0, ox); }                            \
+{ if (!hevc_mc_single(chroma, FFHIP_HEVC_MC_UNI_W, d, ds, s, ss, h, (int)mx, (int)my, w, nullptr, denom, wx, 0, ox))                       \
+      SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_##name##_uni_w, w, mx, my), d, ds, s, ss, h, denom, wx, ox, mx, my, w); }                         \
 static void s_hevc_##name##_bi(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, const int16_t *s2, int h, intptr_t mx,             \
                                intptr_t my, int w)                                                                                          \
-{ hevc_mc_single(chroma, FFHIP_HEVC_MC_BI, d, ds, s, ss, h, (int)mx, (int)my, w, s2); }                                                      \
+{ if (!hevc_mc_single(chroma, FFHIP_HEVC_MC_BI, d, ds, s, ss, h, (int)mx, (int)my, w, s2))                                                 \
+      SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_##name##_bi, w, mx, my), d, ds, s, ss, s2, h, mx, my, w); }                                       \
 static void s_hevc_##name##_bi_w(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, const int16_t *s2, int h, int denom, int wx0,    \
                                  int wx1, int ox, intptr_t mx, intptr_t my, int w)                                                          \
-{ hevc_mc_single(chroma, FFHIP_HEVC_MC_BI_W, d, ds, s, ss, h, (int)mx, (int)my, w, s2, denom, wx0, wx1, ox); }
+{ if (!hevc_mc_single(chroma, FFHIP_HEVC_MC_BI_W, d, ds, s, ss, h, (int)mx, (int)my, w, s2, denom, wx0, wx1, ox))                          \
+      SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_##name##_bi_w, w, mx, my), d, ds, s, ss, s2, h, denom, wx0, wx1, ox, mx, my, w); }
 HEVC_W_SHIMS(qpel, 0)
 HEVC_W_SHIMS(epel, 1)
 
@@ -515,67 +673,71 @@ extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    c->idct[0] = s_hevc_idct0; c->idct[1] = s_hevc_idct1; c->idct[2] = s_hevc_idct2; c->idct[3] = s_hevc_idct3;
-    c->idct_dc[0] = s_hevc_dc0; c->idct_dc[1] = s_hevc_dc1; c->idct_dc[2] = s_hevc_dc2; c->idct_dc[3] = s_hevc_dc3;
-    c->add_residual[0] = s_hevc_add0; c->add_residual[1] = s_hevc_add1; c->add_residual[2] = s_hevc_add2; c->add_residual[3] = s_hevc_add3;
-    c->transform_4x4_luma = s_hevc_dst4;
-    c->dequant = s_hevc_dequant; c->transform_rdpcm = s_hevc_rdpcm;
-    c->sao_edge_restore[0] = s_hevc_restore0; c->sao_edge_restore[1] = s_hevc_restore1;
-    c->hevc_h_loop_filter_luma = c->hevc_h_loop_filter_luma_c = s_hevc_lf_hl;
-    c->hevc_v_loop_filter_luma = c->hevc_v_loop_filter_luma_c = s_hevc_lf_vl;
-    c->hevc_h_loop_filter_chroma = c->hevc_h_loop_filter_chroma_c = s_hevc_lf_hc;
-    c->hevc_v_loop_filter_chroma = c->hevc_v_loop_filter_chroma_c = s_hevc_lf_vc;
+    FFHipHEVCDSPContext o = *c;
+    o.idct[0] = s_hevc_idct0; o.idct[1] = s_hevc_idct1; o.idct[2] = s_hevc_idct2; o.idct[3] = s_hevc_idct3;
+    o.idct_dc[0] = s_hevc_dc0; o.idct_dc[1] = s_hevc_dc1; o.idct_dc[2] = s_hevc_dc2; o.idct_dc[3] = s_hevc_dc3;
+    o.add_residual[0] = s_hevc_add0; o.add_residual[1] = s_hevc_add1; o.add_residual[2] = s_hevc_add2; o.add_residual[3] = s_hevc_add3;
+    o.transform_4x4_luma = s_hevc_dst4;
+    o.dequant = s_hevc_dequant; o.transform_rdpcm = s_hevc_rdpcm;
+    o.sao_edge_restore[0] = s_hevc_restore0; o.sao_edge_restore[1] = s_hevc_restore1;
+    o.hevc_h_loop_filter_luma = o.hevc_h_loop_filter_luma_c = s_hevc_lf_hl;
+    o.hevc_v_loop_filter_luma = o.hevc_v_loop_filter_luma_c = s_hevc_lf_vl;
+    o.hevc_h_loop_filter_chroma = o.hevc_h_loop_filter_chroma_c = s_hevc_lf_hc;
+    o.hevc_v_loop_filter_chroma = o.hevc_v_loop_filter_chroma_c = s_hevc_lf_vc;
     for (int i = 0; i < 5; i++) {
-        c->sao_band_filter[i] = s_hevc_sao_band;
-        c->sao_edge_filter[i] = s_hevc_sao_edge;
+        o.sao_band_filter[i] = s_hevc_sao_band;
+        o.sao_edge_filter[i] = s_hevc_sao_edge;
     }
     /* the [!!my][!!mx] slots all take (mx, my): one function per table serves every slot */
     for (int i = 0; i < 10; i++)
         for (int a = 0; a < 2; a++)
             for (int b = 0; b < 2; b++) {
-                c->put_hevc_qpel[i][a][b] = s_hevc_qpel; c->put_hevc_qpel_uni[i][a][b] = s_hevc_qpel_uni;
-                c->put_hevc_epel[i][a][b] = s_hevc_epel; c->put_hevc_epel_uni[i][a][b] = s_hevc_epel_uni;
-                c->put_hevc_qpel_uni_w[i][a][b] = s_hevc_qpel_uni_w; c->put_hevc_epel_uni_w[i][a][b] = s_hevc_epel_uni_w;
-                c->put_hevc_qpel_bi[i][a][b] = s_hevc_qpel_bi; c->put_hevc_epel_bi[i][a][b] = s_hevc_epel_bi;
-                c->put_hevc_qpel_bi_w[i][a][b] = s_hevc_qpel_bi_w; c->put_hevc_epel_bi_w[i][a][b] = s_hevc_epel_bi_w;
+                o.put_hevc_qpel[i][a][b] = s_hevc_qpel; o.put_hevc_qpel_uni[i][a][b] = s_hevc_qpel_uni;
+                o.put_hevc_epel[i][a][b] = s_hevc_epel; o.put_hevc_epel_uni[i][a][b] = s_hevc_epel_uni;
+                o.put_hevc_qpel_uni_w[i][a][b] = s_hevc_qpel_uni_w; o.put_hevc_epel_uni_w[i][a][b] = s_hevc_epel_uni_w;
+                o.put_hevc_qpel_bi[i][a][b] = s_hevc_qpel_bi; o.put_hevc_epel_bi[i][a][b] = s_hevc_epel_bi;
+                o.put_hevc_qpel_bi_w[i][a][b] = s_hevc_qpel_bi_w; o.put_hevc_epel_bi_w[i][a][b] = s_hevc_epel_bi_w;
             }
+    fb_snapshot(g_fb_hevc, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- AVFloatDSPContext ------------------------------------------------------------------------------------ */
 /* operands packed one after another in scratch, each rounded up to 16 bytes */
-static void fdsp_single(int op, float *dst, int dst_n, const float *s0, int n0, const float *s1, int n1, const float *s2, int n2, float mul,
+static bool fdsp_single(int op, float *dst, int dst_n, const float *s0, int n0, const float *s1, int n1, const float *s2, int n2, float mul,
                         int len)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     if (len <= 0)
-        return;
+        return false;
     const size_t bd = ((size_t)dst_n * 4 + 15) & ~(size_t)15, b0 = ((size_t)n0 * 4 + 15) & ~(size_t)15, b1 = ((size_t)n1 * 4 + 15) & ~(size_t)15,
                  b2 = ((size_t)n2 * 4 + 15) & ~(size_t)15;
-    void *scratch;
-    if (ffhip_scratch_reserve(bd + b0 + b1 + b2 + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(bd + b0 + b1 + b2 + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     float *dd = (float *)buf, *d0 = (float *)(buf + bd), *d1 = (float *)(buf + bd + b0), *d2 = (float *)(buf + bd + b0 + b1);
     const bool dst_in = op == FFHIP_FDSP_FMAC_SCALAR || op == FFHIP_FDSP_BUTTERFLIES;
     if ((dst_in && hipMemcpy(dd, dst, (size_t)dst_n * 4, hipMemcpyHostToDevice) != hipSuccess) ||
         hipMemcpy(d0, s0, (size_t)n0 * 4, hipMemcpyHostToDevice) != hipSuccess ||
         (s1 && hipMemcpy(d1, s1, (size_t)n1 * 4, hipMemcpyHostToDevice) != hipSuccess) ||
         (s2 && hipMemcpy(d2, s2, (size_t)n2 * 4, hipMemcpyHostToDevice) != hipSuccess))
-        return;
-    if (ffhip_launch_fdsp(op, dd, 0, d0, 0, s1 ? d1 : nullptr, 0, s2 ? d2 : nullptr, 0, mul, len, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    (void)hipMemcpy(dst, dd, (size_t)dst_n * 4, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_fdsp(op, dd, 0, d0, 0, s1 ? d1 : nullptr, 0, s2 ? d2 : nullptr, 0, mul, len, 1, 0) < 0 || !A.down())
+        return false;
+    memcpy(dst, A.host(dd), (size_t)dst_n * 4);
     if (op == FFHIP_FDSP_BUTTERFLIES)
-        (void)hipMemcpy(const_cast<float *>(s0), d0, (size_t)n0 * 4, hipMemcpyDeviceToHost);
+        memcpy(const_cast<float *>(s0), A.host(d0), (size_t)n0 * 4);
+    return true;
 }
-static void s_fd_fmul(float *d, const float *a, const float *b, int n) { fdsp_single(FFHIP_FDSP_FMUL, d, n, a, n, b, n, nullptr, 0, 0, n); }
-static void s_fd_fmac(float *d, const float *a, float m, int n) { fdsp_single(FFHIP_FDSP_FMAC_SCALAR, d, n, a, n, nullptr, 0, nullptr, 0, m, n); }
-static void s_fd_fmuls(float *d, const float *a, float m, int n) { fdsp_single(FFHIP_FDSP_FMUL_SCALAR, d, n, a, n, nullptr, 0, nullptr, 0, m, n); }
-static void s_fd_window(float *d, const float *a, const float *b, const float *w, int n) { fdsp_single(FFHIP_FDSP_FMUL_WINDOW, d, 2 * n, a, n, b, n, w, 2 * n, 0, n); }
-static void s_fd_fmadd(float *d, const float *a, const float *b, const float *c, int n) { fdsp_single(FFHIP_FDSP_FMUL_ADD, d, n, a, n, b, n, c, n, 0, n); }
-static void s_fd_frev(float *d, const float *a, const float *b, int n) { fdsp_single(FFHIP_FDSP_FMUL_REVERSE, d, n, a, n, b, n, nullptr, 0, 0, n); }
-static void s_fd_bfly(float *a, float *b, int n) { fdsp_single(FFHIP_FDSP_BUTTERFLIES, a, n, b, n, nullptr, 0, nullptr, 0, 0, n); }
+static FFHipFloatDSPContext g_fb_fdsp;
+static void s_fd_fmul(float *d, const float *a, const float *b, int n) { if (!fdsp_single(FFHIP_FDSP_FMUL, d, n, a, n, b, n, nullptr, 0, 0, n)) SHIM_FB(g_fb_fdsp, vector_fmul, d, a, b, n); }
+static void s_fd_fmac(float *d, const float *a, float m, int n) { if (!fdsp_single(FFHIP_FDSP_FMAC_SCALAR, d, n, a, n, nullptr, 0, nullptr, 0, m, n)) SHIM_FB(g_fb_fdsp, vector_fmac_scalar, d, a, m, n); }
+static void s_fd_fmuls(float *d, const float *a, float m, int n) { if (!fdsp_single(FFHIP_FDSP_FMUL_SCALAR, d, n, a, n, nullptr, 0, nullptr, 0, m, n)) SHIM_FB(g_fb_fdsp, vector_fmul_scalar, d, a, m, n); }
+static void s_fd_window(float *d, const float *a, const float *b, const float *w, int n) { if (!fdsp_single(FFHIP_FDSP_FMUL_WINDOW, d, 2 * n, a, n, b, n, w, 2 * n, 0, n)) SHIM_FB(g_fb_fdsp, vector_fmul_window, d, a, b, w, n); }
+static void s_fd_fmadd(float *d, const float *a, const float *b, const float *c, int n) { if (!fdsp_single(FFHIP_FDSP_FMUL_ADD, d, n, a, n, b, n, c, n, 0, n)) SHIM_FB(g_fb_fdsp, vector_fmul_add, d, a, b, c, n); }
+static void s_fd_frev(float *d, const float *a, const float *b, int n) { if (!fdsp_single(FFHIP_FDSP_FMUL_REVERSE, d, n, a, n, b, n, nullptr, 0, 0, n)) SHIM_FB(g_fb_fdsp, vector_fmul_reverse, d, a, b, n); }
+static void s_fd_bfly(float *a, float *b, int n) { if (!fdsp_single(FFHIP_FDSP_BUTTERFLIES, a, n, b, n, nullptr, 0, nullptr, 0, 0, n)) SHIM_FB(g_fb_fdsp, butterflies_float, a, b, n); }
 
 extern "C" int ff_float_dsp_init_hip(FFHipFloatDSPContext *c)
 {
@@ -583,41 +745,58 @@ extern "C" int ff_float_dsp_init_hip(FFHipFloatDSPContext *c)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    c->vector_fmul = s_fd_fmul; c->vector_fmac_scalar = s_fd_fmac; c->vector_fmul_scalar = s_fd_fmuls;
-    c->vector_fmul_window = s_fd_window; c->vector_fmul_add = s_fd_fmadd; c->vector_fmul_reverse = s_fd_frev;
-    c->butterflies_float = s_fd_bfly;
+    FFHipFloatDSPContext o = *c;
+    o.vector_fmul = s_fd_fmul; o.vector_fmac_scalar = s_fd_fmac; o.vector_fmul_scalar = s_fd_fmuls;
+    o.vector_fmul_window = s_fd_window; o.vector_fmul_add = s_fd_fmadd; o.vector_fmul_reverse = s_fd_frev;
+    o.butterflies_float = s_fd_bfly;
+    fb_snapshot(g_fb_fdsp, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- me_cmp --------------------------------------------------------------------------------------------- */
-static int cmp_single(int kind, int width, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h)
+static bool cmp_single(int kind, int width, const uint8_t *blk1, const uint8_t *blk2, ptrdiff_t stride, int h, int *result)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const int rows = kind == FFHIP_ME_SATD ? (width == 16 ? (h == 16 ? 16 : 8) : 8) : h;
-    if (rows <= 0)
-        return 0;
+    if (rows <= 0) {
+        *result = 0;
+        return true;
+    }
     Rect a = { const_cast<uint8_t *>(blk1), stride, 0, rows - 1, 0, width - 1, nullptr };
     Rect b = { const_cast<uint8_t *>(blk2), stride, 0, rows - 1, 0, width - 1, nullptr };
-    void *scratch;
-    if (ffhip_scratch_reserve(rect_bytes(a) + rect_bytes(b) + 64, &scratch) < 0)
-        return 0;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(rect_bytes(a) + rect_bytes(b) + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     if (!rect_up(a, buf + 64) || !rect_up(b, buf + 64 + rect_bytes(a)))
-        return 0;
+        return false;
     const int32_t offs[2] = { (int32_t)(a.dev - buf), (int32_t)(b.dev - buf) };
     int32_t *d = (int32_t *)buf; /* [0] off1 [1] off2 [2] result */
-    int32_t res = 0;
     if (hipMemcpy(d, offs, 8, hipMemcpyHostToDevice) != hipSuccess)
-        return 0;
-    if (ffhip_launch_me_cmp(kind, width, kind == FFHIP_ME_SATD ? rows : h, buf, d, buf, d + 1, DP, d + 2, 1, 0) < 0 ||
-        hipMemcpy(&res, d + 2, 4, hipMemcpyDeviceToHost) != hipSuccess)
-        return 0;
-    return res;
+        return false;
+    if (ffhip_launch_me_cmp(kind, width, kind == FFHIP_ME_SATD ? rows : h, buf, d, buf, d + 1, DP, d + 2, 1, 0) < 0 || !A.down())
+        return false;
+    *result = reinterpret_cast<const int32_t *>(A.host(d))[2];
+    return true;
 }
-static int s_sad16(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h) { (void)c; return cmp_single(FFHIP_ME_SAD, 16, a, b, s, h); }
-static int s_sad8(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h) { (void)c; return cmp_single(FFHIP_ME_SAD, 8, a, b, s, h); }
-static int s_satd16(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h) { (void)c; return cmp_single(FFHIP_ME_SATD, 16, a, b, s, h); }
-static int s_satd8(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h) { (void)c; return cmp_single(FFHIP_ME_SATD, 8, a, b, s, h); }
+static FFHipMECmpContext g_fb_me;
+/* an int-returning face: the displaced function's value, or 0 (and the recorded error) when there is none */
+#define CMP_SHIM(name, kind, width, member)                                                                   \
+    static int name(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h)                          \
+    {                                                                                                         \
+        int r = 0;                                                                                            \
+        if (cmp_single(kind, width, a, b, s, h, &r))                                                          \
+            return r;                                                                                         \
+        const bool have_ = g_fb_me.member != nullptr;                                                         \
+        shim_note(#member, have_);                                                                            \
+        return have_ ? g_fb_me.member(c, a, b, s, h) : 0;                                                     \
+    }
+CMP_SHIM(s_sad16, FFHIP_ME_SAD, 16, sad[0])
+CMP_SHIM(s_sad8, FFHIP_ME_SAD, 8, sad[1])
+CMP_SHIM(s_pixabs16, FFHIP_ME_SAD, 16, pix_abs[0][0])
+CMP_SHIM(s_pixabs8, FFHIP_ME_SAD, 8, pix_abs[1][0])
+CMP_SHIM(s_satd16, FFHIP_ME_SATD, 16, hadamard8_diff[0])
+CMP_SHIM(s_satd8, FFHIP_ME_SATD, 8, hadamard8_diff[1])
 
 extern "C" int ff_me_cmp_init_hip(FFHipMECmpContext *c)
 {
@@ -625,36 +804,41 @@ extern "C" int ff_me_cmp_init_hip(FFHipMECmpContext *c)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    c->sad[0] = s_sad16;             c->sad[1] = s_sad8;
-    c->pix_abs[0][0] = s_sad16;      c->pix_abs[1][0] = s_sad8;      /* ff_me_cmp_init: me_cmp.c:989-1000 */
-    c->hadamard8_diff[0] = s_satd16; c->hadamard8_diff[1] = s_satd8;
+    FFHipMECmpContext o = *c;
+    o.sad[0] = s_sad16;              o.sad[1] = s_sad8;
+    o.pix_abs[0][0] = s_pixabs16;    o.pix_abs[1][0] = s_pixabs8;    /* ff_me_cmp_init: me_cmp.c:989-1000 */
+    o.hadamard8_diff[0] = s_satd16;  o.hadamard8_diff[1] = s_satd8;
+    fb_snapshot(g_fb_me, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- vp9dsp itxfm_add host faces: the block and the size x size picture rectangle travel through scratch ---- */
-static void vp9_itxfm_single(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob)
+static bool vp9_itxfm_single(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const int n = tx == 4 ? 4 : 4 << tx, P = 64;
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + (size_t)n * n * 2 + (size_t)n * P + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch;
+    Arena A(64 + (size_t)n * n * 2 + (size_t)n * P + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf;
     int16_t *dco = (int16_t *)(buf + 64);
     uint8_t *ddst = buf + 64 + (size_t)n * n * 2;
     if (hipMemcpy(dco, block, (size_t)n * n * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy2D(ddst, P, dst, stride, n, n, hipMemcpyHostToDevice) != hipSuccess)
-        return;
+        return false;
     FFHipVp9TU k = {};
     k.txtp = (uint8_t)txtp; k.dc_only = eob == 1;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_vp9_itxfm(tx, dco, ddst, P, (const FFHipVp9TU *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    (void)hipMemcpy(block, dco, (size_t)n * n * 2, hipMemcpyDeviceToHost);
-    (void)hipMemcpy2D(dst, stride, ddst, P, n, n, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_vp9_itxfm(tx, dco, ddst, P, (const FFHipVp9TU *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    memcpy(block, A.host(dco), (size_t)n * n * 2);
+    commit2d(A, dst, stride, ddst, P, n, n);
+    return true;
 }
-#define VP9_SHIM(tx, tp) static void s_vp9_itx_##tx##_##tp(uint8_t *d, ptrdiff_t s, int16_t *b, int e) { vp9_itxfm_single(tx, tp, d, s, b, e); }
+static FFHipVP9ItxfmContext g_fb_vp9itx;
+#define VP9_SHIM(tx, tp) static void s_vp9_itx_##tx##_##tp(uint8_t *d, ptrdiff_t s, int16_t *b, int e) \
+    { if (!vp9_itxfm_single(tx, tp, d, s, b, e)) SHIM_FB(g_fb_vp9itx, itxfm_add[tx][tp], d, s, b, e); }
 #define VP9_SHIMS(tx) VP9_SHIM(tx, 0) VP9_SHIM(tx, 1) VP9_SHIM(tx, 2) VP9_SHIM(tx, 3)
 VP9_SHIMS(0) VP9_SHIMS(1) VP9_SHIMS(2) VP9_SHIMS(3) VP9_SHIMS(4)
 
@@ -664,55 +848,60 @@ extern "C" int ff_vp9dsp_itxfm_init_hip(FFHipVP9ItxfmContext *c, int bpp)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-#define VP9_ROW(tx) c->itxfm_add[tx][0] = s_vp9_itx_##tx##_0; c->itxfm_add[tx][1] = s_vp9_itx_##tx##_1; \
-                    c->itxfm_add[tx][2] = s_vp9_itx_##tx##_2; c->itxfm_add[tx][3] = s_vp9_itx_##tx##_3;
+    FFHipVP9ItxfmContext o = *c;
+#define VP9_ROW(tx) o.itxfm_add[tx][0] = s_vp9_itx_##tx##_0; o.itxfm_add[tx][1] = s_vp9_itx_##tx##_1; \
+                    o.itxfm_add[tx][2] = s_vp9_itx_##tx##_2; o.itxfm_add[tx][3] = s_vp9_itx_##tx##_3;
     VP9_ROW(0) VP9_ROW(1) VP9_ROW(2) VP9_ROW(3) VP9_ROW(4)
 #undef VP9_ROW
+    fb_snapshot(g_fb_vp9itx, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- vp9dsp mc host faces: source rows -3..h+4 x columns -3..w+4 at a pitch of 128, destination w x h at a pitch of 64 ---- */
-static void vp9_mc_single(int width, int filter, int avg, uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my)
+static bool vp9_mc_single(int width, int filter, int avg, uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     if (h <= 0 || h > 64)
-        return;
+        return false;
     const int P = 128, before = 3, after = 4;
     const size_t sbytes = (size_t)(h + before + after) * P, dbytes = (size_t)h * 64;
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + sbytes + dbytes + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + sbytes;
+    Arena A(64 + sbytes + dbytes + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + sbytes;
     /* only what the reference function of this slot reads: rows / columns beyond the block exist when that axis is filtered */
     const int ry0 = my ? -before : 0, ry1 = my ? h + after : h, cx0 = mx ? -before : 0, cx1 = mx ? width + after : width;
     if (hipMemcpy2D(dsrc + (size_t)(ry0 + before) * P + before + cx0, P, src + ry0 * ss + cx0, ss, cx1 - cx0, ry1 - ry0,
                     hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy2D(ddst, 64, dst, ds, width, h, hipMemcpyHostToDevice) != hipSuccess)
-        return;
+        return false;
     FFHipVp9McBlock k = {};
     k.src_offset = before * P + before;
     k.width = (uint8_t)width; k.height = (uint8_t)h; k.filter = (uint8_t)filter; k.mx = (uint8_t)mx; k.my = (uint8_t)my; k.avg = (uint8_t)avg;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_vp9_mc(ddst, 64, dsrc, P, (const FFHipVp9McBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    (void)hipMemcpy2D(dst, ds, ddst, 64, width, h, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_vp9_mc(ddst, 64, dsrc, P, (const FFHipVp9McBlock *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    commit2d(A, dst, ds, ddst, 64, width, h);
+    return true;
 }
+static FFHipVP9McContext g_fb_vp9mc;
 /* the [!!mx][!!my] slots differ only in which fractions are non-zero: a slot's function masks the other one as the reference's
  * dedicated h / v functions ignore it */
-template <int W, int F, int AVG, int HX, int VY>
+template <int W, int I, int F, int AVG, int HX, int VY>
 static void s_vp9_mc(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, int mx, int my)
 {
-    vp9_mc_single(W, F, AVG, d, ds, s, ss, h, HX ? mx : 0, VY ? my : 0);
+    if (!vp9_mc_single(W, F, AVG, d, ds, s, ss, h, HX ? mx : 0, VY ? my : 0))
+        SHIM_FB(g_fb_vp9mc, mc[I][F][AVG][HX][VY], d, ds, s, ss, h, mx, my);
 }
 template <int W, int I>
 static void vp9_mc_fill(FFHipVP9McContext *c)
 {
 #define VP9_MC_F(F) \
-    c->mc[I][F][0][0][0] = s_vp9_mc<W, F, 0, 0, 0>; c->mc[I][F][0][0][1] = s_vp9_mc<W, F, 0, 0, 1>; \
-    c->mc[I][F][0][1][0] = s_vp9_mc<W, F, 0, 1, 0>; c->mc[I][F][0][1][1] = s_vp9_mc<W, F, 0, 1, 1>; \
-    c->mc[I][F][1][0][0] = s_vp9_mc<W, F, 1, 0, 0>; c->mc[I][F][1][0][1] = s_vp9_mc<W, F, 1, 0, 1>; \
-    c->mc[I][F][1][1][0] = s_vp9_mc<W, F, 1, 1, 0>; c->mc[I][F][1][1][1] = s_vp9_mc<W, F, 1, 1, 1>;
+    c->mc[I][F][0][0][0] = s_vp9_mc<W, I, F, 0, 0, 0>; c->mc[I][F][0][0][1] = s_vp9_mc<W, I, F, 0, 0, 1>; \
+    c->mc[I][F][0][1][0] = s_vp9_mc<W, I, F, 0, 1, 0>; c->mc[I][F][0][1][1] = s_vp9_mc<W, I, F, 0, 1, 1>; \
+    c->mc[I][F][1][0][0] = s_vp9_mc<W, I, F, 1, 0, 0>; c->mc[I][F][1][0][1] = s_vp9_mc<W, I, F, 1, 0, 1>; \
+    c->mc[I][F][1][1][0] = s_vp9_mc<W, I, F, 1, 1, 0>; c->mc[I][F][1][1][1] = s_vp9_mc<W, I, F, 1, 1, 1>;
     VP9_MC_F(0) VP9_MC_F(1) VP9_MC_F(2) VP9_MC_F(3)
 #undef VP9_MC_F
 }
@@ -723,19 +912,21 @@ extern "C" int ff_vp9dsp_mc_init_hip(FFHipVP9McContext *c, int bpp)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    vp9_mc_fill<64, 0>(c); vp9_mc_fill<32, 1>(c); vp9_mc_fill<16, 2>(c); vp9_mc_fill<8, 3>(c); vp9_mc_fill<4, 4>(c);
+    FFHipVP9McContext o = *c;
+    vp9_mc_fill<64, 0>(&o); vp9_mc_fill<32, 1>(&o); vp9_mc_fill<16, 2>(&o); vp9_mc_fill<8, 3>(&o); vp9_mc_fill<4, 4>(&o);
+    fb_snapshot(g_fb_vp9mc, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- vp9dsp loop-filter host faces: 16 lines x 16 samples around the edge travel through scratch (pitch 32) ---- */
-static void vp9_lf_single(int nseg, const int wd_idx[2], int dir, uint8_t *dst, ptrdiff_t stride, const int E[2], const int I[2], const int H[2])
+static bool vp9_lf_single(int nseg, const int wd_idx[2], int dir, uint8_t *dst, ptrdiff_t stride, const int E[2], const int I[2], const int H[2])
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     const int P = 32, lines = 8 * nseg;
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + 32 * P + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch, *d = buf + 64;
+    Arena A(64 + 32 * P + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf, *d = buf + 64;
     /* device layout: the edge at column 8 (dir 0: rows = lines) or row 8 (dir 1: columns = lines); only the samples the
      * reference function of this slot touches travel: 8 on either side for the 16-wide filter, 4 otherwise */
     const int r = (wd_idx[0] == 2 || (nseg == 2 && wd_idx[1] == 2)) ? 8 : 4;
@@ -743,7 +934,7 @@ static void vp9_lf_single(int nseg, const int wd_idx[2], int dir, uint8_t *dst, 
     const uint8_t *h0 = dir ? dst - r * stride : dst - r;
     uint8_t *dd = dir ? d + (8 - r) * P : d + (8 - r);
     if (hipMemcpy2D(dd, P, h0, stride, cols, rows, hipMemcpyHostToDevice) != hipSuccess)
-        return;
+        return false;
     FFHipVp9Edge k[2] = {};
     for (int sgm = 0; sgm < nseg; sgm++) {
         k[sgm].offset = dir ? 8 * P + 8 * sgm : 8 * sgm * P + 8;
@@ -751,28 +942,33 @@ static void vp9_lf_single(int nseg, const int wd_idx[2], int dir, uint8_t *dst, 
         k[sgm].E = (uint8_t)E[sgm]; k[sgm].I = (uint8_t)I[sgm]; k[sgm].H = (uint8_t)H[sgm];
     }
     if (hipMemcpy(buf, k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_vp9_loop_filter(d, P, (const FFHipVp9Edge *)buf, nseg, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    (void)hipMemcpy2D((uint8_t *)h0, stride, dd, P, cols, rows, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_vp9_loop_filter(d, P, (const FFHipVp9Edge *)buf, nseg, 0) < 0 || !A.down())
+        return false;
+    commit2d(A, (uint8_t *)h0, stride, dd, P, cols, rows);
+    return true;
 }
+static FFHipVP9LoopFilterContext g_fb_vp9lf;
 template <int WD, int DIR>
 static void s_vp9_lf8(uint8_t *d, ptrdiff_t s, int E, int I, int H)
 {
     const int w[2] = { WD, 0 }, e[2] = { E, 0 }, i[2] = { I, 0 }, h[2] = { H, 0 };
-    vp9_lf_single(1, w, DIR, d, s, e, i, h);
+    if (!vp9_lf_single(1, w, DIR, d, s, e, i, h))
+        SHIM_FB(g_fb_vp9lf, loop_filter_8[WD][DIR], d, s, E, I, H);
 }
 template <int DIR>
 static void s_vp9_lf16(uint8_t *d, ptrdiff_t s, int E, int I, int H)
 {
     const int w[2] = { 2, 2 }, e[2] = { E, E }, i[2] = { I, I }, h[2] = { H, H };
-    vp9_lf_single(2, w, DIR, d, s, e, i, h);
+    if (!vp9_lf_single(2, w, DIR, d, s, e, i, h))
+        SHIM_FB(g_fb_vp9lf, loop_filter_16[DIR], d, s, E, I, H);
 }
 template <int W1, int W2, int DIR>
 static void s_vp9_lfmix(uint8_t *d, ptrdiff_t s, int E, int I, int H)
 {
     const int w[2] = { W1, W2 }, e[2] = { E & 0xff, E >> 8 }, i[2] = { I & 0xff, I >> 8 }, h[2] = { H & 0xff, H >> 8 };
-    vp9_lf_single(2, w, DIR, d, s, e, i, h);
+    if (!vp9_lf_single(2, w, DIR, d, s, e, i, h))
+        SHIM_FB(g_fb_vp9lf, loop_filter_mix2[W1][W2][DIR], d, s, E, I, H);
 }
 
 extern "C" int ff_vp9dsp_loopfilter_init_hip(FFHipVP9LoopFilterContext *c, int bpp)
@@ -781,22 +977,25 @@ extern "C" int ff_vp9dsp_loopfilter_init_hip(FFHipVP9LoopFilterContext *c, int b
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    c->loop_filter_8[0][0] = s_vp9_lf8<0, 0>; c->loop_filter_8[0][1] = s_vp9_lf8<0, 1>;
-    c->loop_filter_8[1][0] = s_vp9_lf8<1, 0>; c->loop_filter_8[1][1] = s_vp9_lf8<1, 1>;
-    c->loop_filter_8[2][0] = s_vp9_lf8<2, 0>; c->loop_filter_8[2][1] = s_vp9_lf8<2, 1>;
-    c->loop_filter_16[0] = s_vp9_lf16<0>; c->loop_filter_16[1] = s_vp9_lf16<1>;
-    c->loop_filter_mix2[0][0][0] = s_vp9_lfmix<0, 0, 0>; c->loop_filter_mix2[0][0][1] = s_vp9_lfmix<0, 0, 1>;
-    c->loop_filter_mix2[0][1][0] = s_vp9_lfmix<0, 1, 0>; c->loop_filter_mix2[0][1][1] = s_vp9_lfmix<0, 1, 1>;
-    c->loop_filter_mix2[1][0][0] = s_vp9_lfmix<1, 0, 0>; c->loop_filter_mix2[1][0][1] = s_vp9_lfmix<1, 0, 1>;
-    c->loop_filter_mix2[1][1][0] = s_vp9_lfmix<1, 1, 0>; c->loop_filter_mix2[1][1][1] = s_vp9_lfmix<1, 1, 1>;
+    FFHipVP9LoopFilterContext o = *c;
+    o.loop_filter_8[0][0] = s_vp9_lf8<0, 0>; o.loop_filter_8[0][1] = s_vp9_lf8<0, 1>;
+    o.loop_filter_8[1][0] = s_vp9_lf8<1, 0>; o.loop_filter_8[1][1] = s_vp9_lf8<1, 1>;
+    o.loop_filter_8[2][0] = s_vp9_lf8<2, 0>; o.loop_filter_8[2][1] = s_vp9_lf8<2, 1>;
+    o.loop_filter_16[0] = s_vp9_lf16<0>; o.loop_filter_16[1] = s_vp9_lf16<1>;
+    o.loop_filter_mix2[0][0][0] = s_vp9_lfmix<0, 0, 0>; o.loop_filter_mix2[0][0][1] = s_vp9_lfmix<0, 0, 1>;
+    o.loop_filter_mix2[0][1][0] = s_vp9_lfmix<0, 1, 0>; o.loop_filter_mix2[0][1][1] = s_vp9_lfmix<0, 1, 1>;
+    o.loop_filter_mix2[1][0][0] = s_vp9_lfmix<1, 0, 0>; o.loop_filter_mix2[1][0][1] = s_vp9_lfmix<1, 0, 1>;
+    o.loop_filter_mix2[1][1][0] = s_vp9_lfmix<1, 1, 0>; o.loop_filter_mix2[1][1][1] = s_vp9_lfmix<1, 1, 1>;
+    fb_snapshot(g_fb_vp9lf, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- vp9dsp intra_pred host faces: the edge line is assembled from exactly the samples the mode reads ---- */
+static FFHipVP9IntraContext g_fb_vp9intra;
 template <int TX, int MODE>
-static void s_vp9_intra(uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
+static bool vp9_intra_gpu(uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     constexpr int N = 4 << TX;
     constexpr bool use_top = MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7 || MODE == 9 || MODE == 11;
     constexpr bool use_left = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 8 || MODE == 9 || MODE == 10;
@@ -806,17 +1005,24 @@ static void s_vp9_intra(uint8_t *dst, ptrdiff_t stride, const uint8_t *left, con
     if (use_left) memcpy(e, left, N);
     if (use_tl) e[N] = top[-1];
     if (use_top) memcpy(e + N + 1, top, ntop);
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + 128 + (size_t)N * 32 + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch, *de = buf + 64, *dd = de + 128;
+    Arena A(64 + 128 + (size_t)N * 32 + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf, *de = buf + 64, *dd = de + 128;
     FFHipVp9Intra k = {};
     k.mode = MODE;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(de, e, sizeof(e), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_vp9_intra(TX, dd, 32, de, (const FFHipVp9Intra *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    (void)hipMemcpy2D(dst, stride, dd, 32, N, N, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_vp9_intra(TX, dd, 32, de, (const FFHipVp9Intra *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    commit2d(A, dst, stride, dd, 32, N, N);
+    return true;
+}
+template <int TX, int MODE>
+static void s_vp9_intra(uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
+{
+    if (!vp9_intra_gpu<TX, MODE>(dst, stride, left, top))
+        SHIM_FB(g_fb_vp9intra, intra_pred[TX][MODE], dst, stride, left, top);
 }
 template <int TX>
 static void vp9_intra_fill(FFHipVP9IntraContext *c)
@@ -832,43 +1038,53 @@ extern "C" int ff_vp9dsp_intrapred_init_hip(FFHipVP9IntraContext *c, int bpp)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    vp9_intra_fill<0>(c); vp9_intra_fill<1>(c); vp9_intra_fill<2>(c); vp9_intra_fill<3>(c);
+    FFHipVP9IntraContext o = *c;
+    vp9_intra_fill<0>(&o); vp9_intra_fill<1>(&o); vp9_intra_fill<2>(&o); vp9_intra_fill<3>(&o);
+    fb_snapshot(g_fb_vp9intra, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- vp9dsp scaled mc host faces: the source rectangle the call reads, at a pitch of 192 ---- */
+static FFHipVP9ScaledMcContext g_fb_vp9smc;
 template <int W, int F, int AVG>
-static void s_vp9_smc(uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my, int dx, int dy)
+static bool vp9_smc_gpu(uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my, int dx, int dy)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     if (h <= 0 || h > 64 || dx < 1 || dx > 32 || dy < 1 || dy > 32)
-        return;
+        return false;
     const int P = 192, bil = F == 3, before = bil ? 0 : 3, after = bil ? 1 : 4;
     const int cols = ((mx + (W - 1) * dx) >> 4) + 1 + before + after, rows = ((my + (h - 1) * dy) >> 4) + 1 + before + after;
     const size_t sbytes = (size_t)rows * P, dbytes = (size_t)h * 64;
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + sbytes + dbytes + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch, *dsrc = buf + 64, *ddst = dsrc + sbytes;
+    Arena A(64 + sbytes + dbytes + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + sbytes;
     if (hipMemcpy2D(dsrc, P, src - before * ss - before, ss, cols, rows, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy2D(ddst, 64, dst, ds, W, h, hipMemcpyHostToDevice) != hipSuccess)
-        return;
+        return false;
     FFHipVp9ScaledBlock k = {};
     k.src_offset = before * P + before;
     k.width = W; k.height = (uint8_t)h; k.filter = F; k.mx = (uint8_t)mx; k.my = (uint8_t)my; k.avg = AVG; k.dx = (uint8_t)dx; k.dy = (uint8_t)dy;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_vp9_smc(ddst, 64, dsrc, P, (const FFHipVp9ScaledBlock *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    (void)hipMemcpy2D(dst, ds, ddst, 64, W, h, hipMemcpyDeviceToHost);
+        return false;
+    if (ffhip_launch_vp9_smc(ddst, 64, dsrc, P, (const FFHipVp9ScaledBlock *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    commit2d(A, dst, ds, ddst, 64, W, h);
+    return true;
+}
+template <int W, int I, int F, int AVG>
+static void s_vp9_smc(uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my, int dx, int dy)
+{
+    if (!vp9_smc_gpu<W, F, AVG>(dst, ds, src, ss, h, mx, my, dx, dy))
+        SHIM_FB(g_fb_vp9smc, smc[I][F][AVG], dst, ds, src, ss, h, mx, my, dx, dy);
 }
 template <int W, int I>
 static void vp9_smc_fill(FFHipVP9ScaledMcContext *c)
 {
-    c->smc[I][0][0] = s_vp9_smc<W, 0, 0>; c->smc[I][0][1] = s_vp9_smc<W, 0, 1>;
-    c->smc[I][1][0] = s_vp9_smc<W, 1, 0>; c->smc[I][1][1] = s_vp9_smc<W, 1, 1>;
-    c->smc[I][2][0] = s_vp9_smc<W, 2, 0>; c->smc[I][2][1] = s_vp9_smc<W, 2, 1>;
-    c->smc[I][3][0] = s_vp9_smc<W, 3, 0>; c->smc[I][3][1] = s_vp9_smc<W, 3, 1>;
+    c->smc[I][0][0] = s_vp9_smc<W, I, 0, 0>; c->smc[I][0][1] = s_vp9_smc<W, I, 0, 1>;
+    c->smc[I][1][0] = s_vp9_smc<W, I, 1, 0>; c->smc[I][1][1] = s_vp9_smc<W, I, 1, 1>;
+    c->smc[I][2][0] = s_vp9_smc<W, I, 2, 0>; c->smc[I][2][1] = s_vp9_smc<W, I, 2, 1>;
+    c->smc[I][3][0] = s_vp9_smc<W, I, 3, 0>; c->smc[I][3][1] = s_vp9_smc<W, I, 3, 1>;
 }
 
 extern "C" int ff_vp9dsp_scaled_mc_init_hip(FFHipVP9ScaledMcContext *c, int bpp)
@@ -877,17 +1093,19 @@ extern "C" int ff_vp9dsp_scaled_mc_init_hip(FFHipVP9ScaledMcContext *c, int bpp)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    vp9_smc_fill<64, 0>(c); vp9_smc_fill<32, 1>(c); vp9_smc_fill<16, 2>(c); vp9_smc_fill<8, 3>(c); vp9_smc_fill<4, 4>(c);
+    FFHipVP9ScaledMcContext o = *c;
+    vp9_smc_fill<64, 0>(&o); vp9_smc_fill<32, 1>(&o); vp9_smc_fill<16, 2>(&o); vp9_smc_fill<8, 3>(&o); vp9_smc_fill<4, 4>(&o);
+    fb_snapshot(g_fb_vp9smc, *c, o);
+    *c = o;
     return 0;
 }
 
 /* ---- h264pred host faces: the picture patch is staged from exactly the neighbours the C member reads ---- */
 /* need: bit0 left column, bit1 row above, bit2 corner, bit3 top-right (4x4: topright[0..3]; 8x8l: T9..15 if has_topright) */
 #define HP_P 64 /* pitch of the staged patch; the block sits at row 1, column 16 */
-static void h264_pred_host(int kind, int mode, int n, unsigned need, int lrows, uint8_t *src, ptrdiff_t stride, const uint8_t *topright,
+static bool h264_pred_host(int kind, int mode, int n, unsigned need, int lrows, uint8_t *src, ptrdiff_t stride, const uint8_t *topright,
                            int has_tl, int has_tr, int16_t *block)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     uint8_t st[17 * HP_P] = { 0 };
     uint8_t *o = st + HP_P + 16;
     if (need & 1)
@@ -907,10 +1125,10 @@ static void h264_pred_host(int kind, int mode, int n, unsigned need, int lrows, 
     if (kind == FFHIP_H264_PRED4x4 && (need & 8))
         memcpy(o - HP_P + 32, topright, 4); /* wherever the caller's pointer leads, the record addresses the staged copy */
     const int ncoef = block ? n * n : 0;
-    void *scratch;
-    if (ffhip_scratch_reserve(64 + sizeof(st) + 128 + 64, &scratch) < 0)
-        return;
-    uint8_t *buf = (uint8_t *)scratch, *dp = buf + 64;
+    Arena A(64 + sizeof(st) + 128 + 64);
+    if (!A.ok)
+        return false;
+    uint8_t *buf = A.buf, *dp = buf + 64;
     int16_t *dc = (int16_t *)(dp + sizeof(st));
     FFHipH264Pred k = {};
     k.offset = HP_P + 16;
@@ -918,16 +1136,17 @@ static void h264_pred_host(int kind, int mode, int n, unsigned need, int lrows, 
     k.mode = (uint8_t)mode;
     k.flags = (uint8_t)((has_tl ? FFHIP_H264_PRED_TOPLEFT : 0) | (has_tr ? FFHIP_H264_PRED_TOPRIGHT : 0));
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dp, st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess)
-        return;
+        return false;
     if (ncoef && hipMemcpy(dc, block, ncoef * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess)
-        return;
-    if (ffhip_launch_h264_pred(kind, dp, HP_P, dc, (const FFHipH264Pred *)buf, 1, 0) < 0 || hipStreamSynchronize(0) != hipSuccess)
-        return;
-    if (hipMemcpy2D(src, stride, dp + HP_P + 16, HP_P, n, n, hipMemcpyDeviceToHost) != hipSuccess)
-        return;
+        return false;
+    if (ffhip_launch_h264_pred(kind, dp, HP_P, dc, (const FFHipH264Pred *)buf, 1, 0) < 0 || !A.down())
+        return false;
+    commit2d(A, src, stride, dp + HP_P + 16, HP_P, n, n);
     if (ncoef)
-        (void)hipMemcpy(block, dc, ncoef * sizeof(int16_t), hipMemcpyDeviceToHost); /* cleared by the kernel */
+        memcpy(block, A.host(dc), ncoef * sizeof(int16_t)); /* cleared by the kernel */
+    return true;
 }
+static FFHipH264PredContext g_fb_pred;
 static constexpr unsigned hp_need4(int mode) { return (unsigned)(0x0211a777a312ull >> (4 * mode)) & 15u; } /* as kernels/h264_pred.hip */
 /* pred8x8 / pred16x16: 0 DC 1 HOR 2 VERT 3 PLANE 4 LEFT_DC 5 TOP_DC 6 DC_128 7 L0T 8 0LT 9 L00 10 0L0 */
 static constexpr unsigned hp_need_blk(int mode)
@@ -938,36 +1157,44 @@ static constexpr unsigned hp_need_blk(int mode)
 template <int MODE>
 static void s_pred4x4(uint8_t *src, const uint8_t *topright, ptrdiff_t stride)
 {
-    h264_pred_host(FFHIP_H264_PRED4x4, MODE, 4, hp_need4(MODE), 4, src, stride, topright, 0, 0, nullptr);
+    if (!h264_pred_host(FFHIP_H264_PRED4x4, MODE, 4, hp_need4(MODE), 4, src, stride, topright, 0, 0, nullptr))
+        SHIM_FB(g_fb_pred, pred4x4[MODE], src, topright, stride);
 }
 template <int MODE>
 static void s_pred8x8l(uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride)
 {
     constexpr unsigned need = hp_need4(MODE);
     /* the corner is also read by the edge filter when has_topleft (PREDICT_8x8_LOAD_LEFT / _TOP) */
-    h264_pred_host(FFHIP_H264_PRED8x8L, MODE, 8, need | ((has_topleft && (need & 3)) ? 4u : 0u), 8, src, stride, nullptr, has_topleft, has_topright,
-                   nullptr);
+    if (!h264_pred_host(FFHIP_H264_PRED8x8L, MODE, 8, need | ((has_topleft && (need & 3)) ? 4u : 0u), 8, src, stride, nullptr, has_topleft,
+                        has_topright, nullptr))
+        SHIM_FB(g_fb_pred, pred8x8l[MODE], src, has_topleft, has_topright, stride);
 }
 template <int MODE>
 static void s_pred8x8(uint8_t *src, ptrdiff_t stride)
 {
-    h264_pred_host(FFHIP_H264_PRED8x8, MODE, 8, hp_need_blk(MODE), MODE == 7 ? 4 : 8, src, stride, nullptr, 0, 0, nullptr);
+    if (!h264_pred_host(FFHIP_H264_PRED8x8, MODE, 8, hp_need_blk(MODE), MODE == 7 ? 4 : 8, src, stride, nullptr, 0, 0, nullptr))
+        SHIM_FB(g_fb_pred, pred8x8[MODE], src, stride);
 }
 template <int MODE>
 static void s_pred16x16(uint8_t *src, ptrdiff_t stride)
 {
-    h264_pred_host(FFHIP_H264_PRED16x16, MODE, 16, hp_need_blk(MODE), 16, src, stride, nullptr, 0, 0, nullptr);
+    if (!h264_pred_host(FFHIP_H264_PRED16x16, MODE, 16, hp_need_blk(MODE), 16, src, stride, nullptr, 0, 0, nullptr))
+        SHIM_FB(g_fb_pred, pred16x16[MODE], src, stride);
 }
 template <int KIND, int N, int MODE>
 static void s_pred_add(uint8_t *pix, int16_t *block, ptrdiff_t stride)
 {
-    h264_pred_host(KIND, MODE, N, MODE == 0 ? 2u : 1u, N, pix, stride, nullptr, 0, 0, block);
+    if (!h264_pred_host(KIND, MODE, N, MODE == 0 ? 2u : 1u, N, pix, stride, nullptr, 0, 0, block)) {
+        if (KIND == FFHIP_H264_PRED4x4_ADD) SHIM_FB(g_fb_pred, pred4x4_add[MODE], pix, block, stride);
+        else                                SHIM_FB(g_fb_pred, pred8x8l_add[MODE], pix, block, stride);
+    }
 }
 template <int MODE>
 static void s_pred8x8l_filter_add(uint8_t *pix, int16_t *block, int has_topleft, int has_topright, ptrdiff_t stride)
 {
-    h264_pred_host(FFHIP_H264_PRED8x8L_FILTER_ADD, MODE, 8, (MODE == 0 ? 2u : 1u) | (has_topleft ? 4u : 0u), 8, pix, stride, nullptr, has_topleft,
-                   MODE == 0 ? has_topright : 0, block);
+    if (!h264_pred_host(FFHIP_H264_PRED8x8L_FILTER_ADD, MODE, 8, (MODE == 0 ? 2u : 1u) | (has_topleft ? 4u : 0u), 8, pix, stride, nullptr,
+                        has_topleft, MODE == 0 ? has_topright : 0, block))
+        SHIM_FB(g_fb_pred, pred8x8l_filter_add[MODE], pix, block, has_topleft, has_topright, stride);
 }
 /* pred8x8_add / pred16x16_add walk block_offset[] in the C order, each 4x4 seeing what the previous ones wrote
  * (h264pred_template.c:1262-1330) */
@@ -984,19 +1211,22 @@ extern "C" int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int 
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-#define HP(M) h->pred4x4[M] = s_pred4x4<M>; h->pred8x8l[M] = s_pred8x8l<M>;
+    FFHipH264PredContext o = *h;
+#define HP(M) o.pred4x4[M] = s_pred4x4<M>; o.pred8x8l[M] = s_pred8x8l<M>;
     HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10) HP(11)
 #undef HP
-#define HP(M) h->pred8x8[M] = s_pred8x8<M>;
+#define HP(M) o.pred8x8[M] = s_pred8x8<M>;
     HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10)
 #undef HP
-#define HP(M) h->pred16x16[M] = s_pred16x16<M>;
+#define HP(M) o.pred16x16[M] = s_pred16x16<M>;
     HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6)
 #undef HP
-    h->pred4x4_add[0] = s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, 0>;   h->pred4x4_add[1] = s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, 1>;
-    h->pred8x8l_add[0] = s_pred_add<FFHIP_H264_PRED8x8L_ADD, 8, 0>; h->pred8x8l_add[1] = s_pred_add<FFHIP_H264_PRED8x8L_ADD, 8, 1>;
-    h->pred8x8l_filter_add[0] = s_pred8x8l_filter_add<0>;           h->pred8x8l_filter_add[1] = s_pred8x8l_filter_add<1>;
-    h->pred8x8_add[2] = s_pred_mb_add<4, 2>;    h->pred8x8_add[1] = s_pred_mb_add<4, 1>;
-    h->pred16x16_add[2] = s_pred_mb_add<16, 2>; h->pred16x16_add[1] = s_pred_mb_add<16, 1>;
+    o.pred4x4_add[0] = s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, 0>;   o.pred4x4_add[1] = s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, 1>;
+    o.pred8x8l_add[0] = s_pred_add<FFHIP_H264_PRED8x8L_ADD, 8, 0>; o.pred8x8l_add[1] = s_pred_add<FFHIP_H264_PRED8x8L_ADD, 8, 1>;
+    o.pred8x8l_filter_add[0] = s_pred8x8l_filter_add<0>;           o.pred8x8l_filter_add[1] = s_pred8x8l_filter_add<1>;
+    o.pred8x8_add[2] = s_pred_mb_add<4, 2>;    o.pred8x8_add[1] = s_pred_mb_add<4, 1>;
+    o.pred16x16_add[2] = s_pred_mb_add<16, 2>; o.pred16x16_add[1] = s_pred_mb_add<16, 1>;
+    fb_snapshot(g_fb_pred, *h, o);
+    *h = o;
     return 0;
 }

@@ -14,6 +14,7 @@
 
 #include "kernels/common.h"
 #include "kernels/sws_kernels.h"
+#include "kernels/shim_arena.h"
 
 struct FFHipSwsContext {
     FFHipSwsTables t;
@@ -961,4 +962,185 @@ extern "C" int ffhip_sws_yuv2planeX8_dev(const int16_t *filter, int filterSize, 
     if (!src || !dest || !dither8 || filterSize <= 0 || (filterSize > 1 && !filter))
         return FFHIP_EINVAL;
     return ffhip_launch_yuv2planeX8(filter, filterSize, src, srcPitch, dest, dstW, dither8, offset, (hipStream_t)stream);
+}
+
+/* ---- signature-exact per-line host faces (swscale_internal.h:128-266, 648-653; installed by ff_sws_init_swscale_<arch>(),
+ * swscale.c:697-714): what tests/checkasm/sw_scale.c exercises.  One call = one launch through the scratch arena; a call that
+ * cannot run on the device is answered by the displaced C function (kernels/shim_arena.h). -------------------------------- */
+static FFHipSwsLineContext g_fb_line;
+
+static bool hscale_line_gpu(int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *filterPos, int filterSize)
+{
+    if (dstW <= 0 || filterSize <= 0 || filterSize > 4096)
+        return false;
+    int span = 0; /* source bytes the line reads: the windows are in bounds of the (padded) line by construction */
+    for (int i = 0; i < dstW; i++)
+        if (filterPos[i] < 0)
+            return false;
+        else if (filterPos[i] + filterSize > span)
+            span = filterPos[i] + filterSize;
+    const size_t bs = ((size_t)span + 63) & ~(size_t)63, bf = ((size_t)dstW * filterSize * 2 + 63) & ~(size_t)63;
+    const size_t bp = ((size_t)dstW * 4 + 63) & ~(size_t)63, bd = ((size_t)dstW * 2 + 63) & ~(size_t)63;
+    Arena A(bs + bf + bp + bd);
+    if (!A.ok)
+        return false;
+    uint8_t *dsrc = A.buf, *df = dsrc + bs, *dp = df + bf, *dd = dp + bp;
+    if (hipMemcpy(dsrc, src, span, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(df, filter, (size_t)dstW * filterSize * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dp, filterPos, (size_t)dstW * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return false;
+    if (ffhip_launch_hscale8to15((int16_t *)dd, dstW, 0, dsrc, 0, 1, (const int16_t *)df, (const int32_t *)dp, filterSize, 0) < 0 || !A.down())
+        return false;
+    memcpy(dst, A.host(dd), (size_t)dstW * 2);
+    return true;
+}
+static void s_hyscale(void *c, int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *filterPos, int filterSize)
+{ if (!hscale_line_gpu(dst, dstW, src, filter, filterPos, filterSize)) SHIM_FB(g_fb_line, hyScale, c, dst, dstW, src, filter, filterPos, filterSize); }
+static void s_hcscale(void *c, int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *filterPos, int filterSize)
+{ if (!hscale_line_gpu(dst, dstW, src, filter, filterPos, filterSize)) SHIM_FB(g_fb_line, hcScale, c, dst, dstW, src, filter, filterPos, filterSize); }
+
+/* nsrc int16 lines of n samples each, packed at a pitch of `pitch` bytes from `at` */
+static bool lines_up(uint8_t *at, size_t pitch, const int16_t *const *src, int nsrc, int n)
+{
+    for (int j = 0; j < nsrc; j++)
+        if (!src[j] || hipMemcpy(at + j * pitch, src[j], (size_t)n * 2, hipMemcpyHostToDevice) != hipSuccess)
+            return false;
+    return true;
+}
+
+static bool planex_line_gpu(const int16_t *filter, int filterSize, const int16_t *const *src, uint8_t *dest, int dstW, const uint8_t *dither,
+                            int offset)
+{
+    if (dstW <= 0 || filterSize <= 0 || filterSize > 256 || !dither)
+        return false;
+    const size_t pitch = ((size_t)dstW * 2 + 63) & ~(size_t)63, bd = ((size_t)dstW + 63) & ~(size_t)63;
+    Arena A(64 + 512 + pitch * filterSize + bd);
+    if (!A.ok)
+        return false;
+    uint8_t *ddi = A.buf, *df = ddi + 64, *dl = df + 512, *dd = dl + pitch * filterSize;
+    if (hipMemcpy(ddi, dither, 8, hipMemcpyHostToDevice) != hipSuccess ||
+        (filter && hipMemcpy(df, filter, (size_t)filterSize * 2, hipMemcpyHostToDevice) != hipSuccess) || !lines_up(dl, pitch, src, filterSize, dstW))
+        return false;
+    if (ffhip_launch_yuv2planeX8((const int16_t *)df, filterSize, (const int16_t *)dl, (ptrdiff_t)pitch, dd, dstW, ddi, offset, 0) < 0 || !A.down())
+        return false;
+    memcpy(dest, A.host(dd), dstW);
+    return true;
+}
+static void s_yuv2plane1(const int16_t *src, uint8_t *dest, int dstW, const uint8_t *dither, int offset)
+{ if (!planex_line_gpu(nullptr, 1, &src, dest, dstW, dither, offset)) SHIM_FB(g_fb_line, yuv2plane1, src, dest, dstW, dither, offset); }
+static void s_yuv2planex(const int16_t *filter, int filterSize, const int16_t **src, uint8_t *dest, int dstW, const uint8_t *dither, int offset)
+{
+    /* a 1-tap call is NOT yuv2plane1 (its arithmetic is (src * filter + dither << 12) >> 19): the kernel's fs == 1 form is plane1's,
+     * so single taps take the general loop through a second, zero tap */
+    bool ok;
+    if (filterSize == 1) {
+        const int16_t f2[2] = { filter[0], 0 };
+        const int16_t *s2[2] = { src[0], src[0] };
+        ok = planex_line_gpu(f2, 2, s2, dest, dstW, dither, offset);
+    } else {
+        ok = filter && planex_line_gpu(filter, filterSize, src, dest, dstW, dither, offset);
+    }
+    if (!ok)
+        SHIM_FB(g_fb_line, yuv2planeX, filter, filterSize, src, dest, dstW, dither, offset);
+}
+
+static bool nv12cx_line_gpu(int dstFormat, const uint8_t *chrDither, const int16_t *chrFilter, int chrFilterSize, const int16_t *const *chrUSrc,
+                            const int16_t *const *chrVSrc, uint8_t *dest, int chrDstW)
+{
+    if (chrDstW <= 0 || chrFilterSize <= 0 || chrFilterSize > 256 || !fmt_nv(dstFormat) || !chrDither || !chrFilter)
+        return false;
+    const size_t pitch = ((size_t)chrDstW * 2 + 63) & ~(size_t)63, bd = ((size_t)chrDstW * 2 + 63) & ~(size_t)63;
+    Arena A(64 + 512 + 2 * pitch * chrFilterSize + bd);
+    if (!A.ok)
+        return false;
+    uint8_t *ddi = A.buf, *df = ddi + 64, *du = df + 512, *dv = du + pitch * chrFilterSize, *dd = dv + pitch * chrFilterSize;
+    if (hipMemcpy(ddi, chrDither, 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(df, chrFilter, (size_t)chrFilterSize * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        !lines_up(du, pitch, chrUSrc, chrFilterSize, chrDstW) || !lines_up(dv, pitch, chrVSrc, chrFilterSize, chrDstW))
+        return false;
+    if (ffhip_launch_yuv2nv12cX(dstFormat == FFHIP_PIX_FMT_NV21, ddi, (const int16_t *)df, chrFilterSize, (const int16_t *)du, (const int16_t *)dv,
+                                (ptrdiff_t)pitch, dd, chrDstW, 0) < 0 || !A.down())
+        return false;
+    memcpy(dest, A.host(dd), (size_t)chrDstW * 2);
+    return true;
+}
+static void s_yuv2nv12cx(int dstFormat, const uint8_t *chrDither, const int16_t *chrFilter, int chrFilterSize, const int16_t **chrUSrc,
+                         const int16_t **chrVSrc, uint8_t *dest, int dstW)
+{
+    if (!nv12cx_line_gpu(dstFormat, chrDither, chrFilter, chrFilterSize, chrUSrc, chrVSrc, dest, dstW))
+        SHIM_FB(g_fb_line, yuv2nv12cX, dstFormat, chrDither, chrFilter, chrFilterSize, chrUSrc, chrVSrc, dest, dstW);
+}
+
+extern "C" int ff_sws_init_swscale_hip(FFHipSwsLineContext *lc, int srcFormat, int dstFormat)
+{
+    if (!lc || !fmt_yuv(srcFormat) || !(fmt_yuv(dstFormat) || fmt_rgb(dstFormat)))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    FFHipSwsLineContext o = *lc;
+    o.hyScale = s_hyscale; /* 8-bit sources: hScale8To15_c (swscale.c:608-611) */
+    o.hcScale = s_hcscale;
+    if (fmt_yuv(dstFormat)) { /* 8-bit planar / NV targets: yuv2plane1_8_c, yuv2planeX_8_c, yuv2nv12cX_c (output.c:3261-3275) */
+        o.yuv2plane1 = s_yuv2plane1;
+        o.yuv2planeX = s_yuv2planex;
+        if (fmt_nv(dstFormat))
+            o.yuv2nv12cX = s_yuv2nv12cx;
+    }
+    fb_snapshot(g_fb_line, *lc, o);
+    *lc = o;
+    return 0;
+}
+
+/* yuv2packed1 / yuv2packed2 / yuv2packedX (swscale_internal.h:201-266) for the packed RGB targets: these read the context's yuv2rgb
+ * tables, so their first argument is OUR context where the reference passes its SwsInternal, and they RETURN their status —
+ * the FFmpeg-side wrapper calls the C function it displaced when that is negative. */
+static int packed_line(FFHipSwsContext *c, int mode, const int16_t *lf, const int16_t *const *lum, int lfs, const int16_t *cf,
+                       const int16_t *const *cu, const int16_t *const *cv, int cfs, uint8_t *dest, int dstW, int yalpha, int uvalpha)
+{
+    if (!c || !dest || !lum || !cu || !cv || dstW < 2 || (dstW & 1) || lfs < 1 || cfs < 1 || lfs > 256 || cfs > 256 || !fmt_rgb(c->t.dstFormat))
+        return FFHIP_EINVAL;
+    const int lay = rgb_layout(c->t.dstFormat), bpp = lay < 2 ? 3 : 4, cw = dstW >> 1;
+    const size_t pitch = ((size_t)dstW * 2 + 63) & ~(size_t)63, bd = ((size_t)dstW * bpp + 63) & ~(size_t)63;
+    Arena A(1024 + pitch * (lfs + 2 * cfs) + bd);
+    if (!A.ok)
+        return FFHIP_EIO;
+    uint8_t *dlf = A.buf, *dcf = dlf + 512, *dl = dcf + 512, *du = dl + pitch * lfs, *dv = du + pitch * cfs, *dd = dv + pitch * cfs;
+    if ((lf && hipMemcpy(dlf, lf, (size_t)lfs * 2, hipMemcpyHostToDevice) != hipSuccess) ||
+        (cf && hipMemcpy(dcf, cf, (size_t)cfs * 2, hipMemcpyHostToDevice) != hipSuccess) || !lines_up(dl, pitch, lum, lfs, dstW) ||
+        !lines_up(du, pitch, cu, cfs, cw) || !lines_up(dv, pitch, cv, cfs, cw))
+        return FFHIP_EIO;
+    if (ffhip_launch_yuv2packed_line(mode, (const int16_t *)dlf, (const int16_t *)dl, lfs, (const int16_t *)dcf, (const int16_t *)du,
+                                     (const int16_t *)dv, cfs, (ptrdiff_t)pitch, yalpha, uvalpha, dd, dstW, lay, c->k, 0) < 0 || !A.down())
+        return FFHIP_EIO;
+    memcpy(dest, A.host(dd), (size_t)dstW * bpp);
+    return 0;
+}
+
+extern "C" int ffhip_sws_yuv2packedX(FFHipSwsContext *c, const int16_t *lumFilter, const int16_t **lumSrc, int lumFilterSize,
+                                     const int16_t *chrFilter, const int16_t **chrUSrc, const int16_t **chrVSrc, int chrFilterSize,
+                                     const int16_t **alpSrc, uint8_t *dest, int dstW, int y)
+{
+    (void)alpSrc; (void)y; /* no alpha plane among the supported sources; y only matters to the dithered 8-bit-and-below targets */
+    if (!lumFilter || !chrFilter)
+        return FFHIP_EINVAL;
+    return packed_line(c, 0, lumFilter, lumSrc, lumFilterSize, chrFilter, chrUSrc, chrVSrc, chrFilterSize, dest, dstW, 0, 0);
+}
+
+extern "C" int ffhip_sws_yuv2packed2(FFHipSwsContext *c, const int16_t *lumSrc[2], const int16_t *chrUSrc[2], const int16_t *chrVSrc[2],
+                                     const int16_t *alpSrc[2], uint8_t *dest, int dstW, int yalpha, int uvalpha, int y)
+{
+    (void)alpSrc; (void)y;
+    if ((unsigned)yalpha > 4096u || (unsigned)uvalpha > 4096u)
+        return FFHIP_EINVAL;
+    return packed_line(c, 1, nullptr, lumSrc, 2, nullptr, chrUSrc, chrVSrc, 2, dest, dstW, yalpha, uvalpha);
+}
+
+extern "C" int ffhip_sws_yuv2packed1(FFHipSwsContext *c, const int16_t *lumSrc, const int16_t *chrUSrc[2], const int16_t *chrVSrc[2],
+                                     const int16_t *alpSrc, uint8_t *dest, int dstW, int uvalpha, int y)
+{
+    (void)alpSrc; (void)y;
+    if ((unsigned)uvalpha > 4096u || !lumSrc)
+        return FFHIP_EINVAL;
+    const int16_t *const l1[1] = { lumSrc };
+    return packed_line(c, 2, nullptr, l1, 1, nullptr, chrUSrc, chrVSrc, uvalpha ? 2 : 1, dest, dstW, 0, uvalpha);
 }

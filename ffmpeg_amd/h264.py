@@ -5,7 +5,7 @@ import numpy as np
 
 from . import _lib
 
-IDCT4, IDCT8, IDCT4_DC, IDCT8_DC = 0, 1, 2, 3
+IDCT4, IDCT8, IDCT4_DC, IDCT8_DC, ADD_PIXELS4_CLEAR, ADD_PIXELS8_CLEAR = 0, 1, 2, 3, 4, 5
 
 
 def _stream(stream):
@@ -19,6 +19,29 @@ def idct_add_batch(kind, dst, stride, dst_offset, blocks, stream=None):
     return _lib.check(_lib.lib().ffhip_h264_idct_add_batch_dev(kind, dst.data_ptr(), stride, dst_offset.data_ptr(),
                                                                blocks.data_ptr(), n, _stream(stream)),
                       "ffhip_h264_idct_add_batch_dev")
+
+
+def idct_add8_batch(cb, cr, stride, mb_offset, blockoffset48, blocks, nnzc, stream=None):
+    """idct_add8 (4:2:0) over a batch: blocks int16 [nmb, 768] (sl->mb), nnzc uint8 [nmb, 120], blockoffset48 int32 [48]."""
+    nmb = mb_offset.numel()
+    return _lib.check(_lib.lib().ffhip_h264_idct_add8_batch_dev(cb.data_ptr(), cr.data_ptr(), stride, mb_offset.data_ptr(),
+                                                                blockoffset48.data_ptr(), blocks.data_ptr(), nnzc.data_ptr(), nmb,
+                                                                _stream(stream)), "ffhip_h264_idct_add8_batch_dev")
+
+
+def luma_dc_dequant_batch(output, inp, qmul, stream=None):
+    """output int16 [n, 256], inp int16 [n, 16], qmul int32 [n]"""
+    n = qmul.numel()
+    return _lib.check(_lib.lib().ffhip_h264_luma_dc_dequant_idct_batch_dev(output.data_ptr(), output.stride(0), inp.data_ptr(), inp.stride(0),
+                                                                           qmul.data_ptr(), n, _stream(stream)),
+                      "ffhip_h264_luma_dc_dequant_idct_batch_dev")
+
+
+def chroma_dc_dequant_batch(blocks, block_offset, qmul, stream=None):
+    """in place on blocks[block_offset[m] + {0, 16, 32, 48}]"""
+    n = qmul.numel()
+    return _lib.check(_lib.lib().ffhip_h264_chroma_dc_dequant_idct_batch_dev(blocks.data_ptr(), block_offset.data_ptr(), qmul.data_ptr(), n,
+                                                                             _stream(stream)), "ffhip_h264_chroma_dc_dequant_idct_batch_dev")
 
 
 def idct_add_mb_batch(which, dst, stride, mb_offset, blockoffset16, blocks, nnzc, stream=None):

@@ -190,6 +190,37 @@ int ffhip_sws_hscale8to15_dev(int16_t *dst, int dstW, ptrdiff_t dstPitch, const 
 int ffhip_sws_yuv2planeX8_dev(const int16_t *filter, int filterSize, const int16_t *src, ptrdiff_t srcPitch,
                               uint8_t *dest, int dstW, const uint8_t *dither8, int offset, void *stream);
 
+/**
+ * The per-line members an ff_sws_init_swscale_<arch>() installs (libswscale/swscale.c:697-714; template x86/swscale.c), with the
+ * reference's exact signatures, HOST pointers — what tests/checkasm/sw_scale.c:109-458 exercises:
+ *   hyScale / hcScale   swscale_internal.h:648-653 (8-bit sources: hScale8To15_c, swscale.c:128-142); `c` is passed through untouched
+ *   yuv2plane1          :128 (yuv2plane1_8_c, output.c:482-493)        yuv2planeX   :144 (yuv2planeX_8_c, output.c:468-480)
+ *   yuv2nv12cX          :164 (yuv2nv12cX_c, output.c:500-529)
+ * One call = one launch through device scratch; lines may be over-read exactly as far as the reference's may (filterPos + filterSize).
+ */
+typedef struct FFHipSwsLineContext {
+    void (*hyScale)(void *c, int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *filterPos, int filterSize);
+    void (*hcScale)(void *c, int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *filterPos, int filterSize);
+    void (*yuv2plane1)(const int16_t *src, uint8_t *dest, int dstW, const uint8_t *dither, int offset);
+    void (*yuv2planeX)(const int16_t *filter, int filterSize, const int16_t **src, uint8_t *dest, int dstW, const uint8_t *dither, int offset);
+    void (*yuv2nv12cX)(int dstFormat, const uint8_t *chrDither, const int16_t *chrFilter, int chrFilterSize, const int16_t **chrUSrc,
+                       const int16_t **chrVSrc, uint8_t *dest, int dstW);
+} FFHipSwsLineContext;
+/** Fills the members that apply to the format pair (8-bit yuv420p / nv12 / nv21 sources; planar, NV or packed-RGB targets) and
+ *  remembers the ones it displaces as fallbacks (see ff_h264dsp_init_hip).  Returns 0, FFHIP_EINVAL or FFHIP_ENOSYS. */
+int ff_sws_init_swscale_hip(FFHipSwsLineContext *c, int srcFormat, int dstFormat);
+/** yuv2packed1 / yuv2packed2 / yuv2packedX (swscale_internal.h:201-266) for the packed RGB targets (yuv2rgb_{1,2,X}_c_template,
+ *  output.c:1789-1939): the reference's argument lists, except that the first argument is this library's context (the members
+ *  read the yuv2rgb tables of the context) and that they return 0 or a negative FFHIP_E* — the caller then runs the C member.
+ *  dstW even; alpSrc / y are accepted and unused (no alpha plane among the supported sources, no dithered target). */
+int ffhip_sws_yuv2packed1(FFHipSwsContext *c, const int16_t *lumSrc, const int16_t *chrUSrc[2], const int16_t *chrVSrc[2],
+                          const int16_t *alpSrc, uint8_t *dest, int dstW, int uvalpha, int y);
+int ffhip_sws_yuv2packed2(FFHipSwsContext *c, const int16_t *lumSrc[2], const int16_t *chrUSrc[2], const int16_t *chrVSrc[2],
+                          const int16_t *alpSrc[2], uint8_t *dest, int dstW, int yalpha, int uvalpha, int y);
+int ffhip_sws_yuv2packedX(FFHipSwsContext *c, const int16_t *lumFilter, const int16_t **lumSrc, int lumFilterSize,
+                          const int16_t *chrFilter, const int16_t **chrUSrc, const int16_t **chrVSrc, int chrFilterSize,
+                          const int16_t **alpSrc, uint8_t *dest, int dstW, int y);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: h264dsp                                                                        */
 /* ------------------------------------------------------------------------------------------ */
@@ -217,9 +248,24 @@ typedef struct FFHipH264DSPContext {
                        const uint8_t nnzc[5 * 8]);
     void (*idct_add16intra)(uint8_t *dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
                             const uint8_t nnzc[5 * 8]);
+    void (*idct_add8)(uint8_t **dst, const int *blockoffset, int16_t *block, ptrdiff_t stride,
+                      const uint8_t nnzc[15 * 8]);                                   /* h264dsp.h:96-98 (4:2:0) */
+    void (*luma_dc_dequant_idct)(int16_t *output, int16_t *input, int qmul);         /* h264dsp.h:102-103 */
+    void (*chroma_dc_dequant_idct)(int16_t *block, int qmul);                        /* h264dsp.h:104 (4:2:0) */
+    void (*add_pixels8_clear)(uint8_t *dst, int16_t *block, ptrdiff_t stride);      /* h264dsp.h:107 */
+    void (*add_pixels4_clear)(uint8_t *dst, int16_t *block, ptrdiff_t stride);      /* h264dsp.h:108 */
 } FFHipH264DSPContext;
-/** Returns 0 and fills every member, or FFHIP_ENOSYS/FFHIP_EINVAL leaving *c untouched. */
+/**
+ * Fills every member, the way ff_h264dsp_init_<arch>() does at the end of ff_h264dsp_init() (libavcodec/h264dsp.c:155-169):
+ * *c arrives holding the C functions (or NULL members) — the hip faces REMEMBER them, and a call that cannot run on the device
+ * (a HIP error, an argument outside the staged range, or FFHIP_FAULT=1 in the environment: the test hook) is answered by the
+ * displaced C function instead of returning with dst untouched; ffhip_shim_fallbacks() counts such calls.  The same holds for
+ * every ff_*_init_hip() below.  Returns 0, or FFHIP_ENOSYS / FFHIP_EINVAL leaving *c untouched.  4:2:0 / 8-bit only.
+ */
 int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int chroma_format_idc);
+/** Calls a host-pointer face answered through the displaced C pointer so far (and, when there was none to call, left undone:
+ *  ffhip_last_error() has the member's name). */
+long ffhip_shim_fallbacks(void);
 
 /** IDCT kinds for the batch face; one kernel per kind == one reference function
  *  (libavcodec/h264idct_template.c:33,69,145,161). */
@@ -227,6 +273,8 @@ int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int chroma_format
 #define FFHIP_H264_IDCT8     1
 #define FFHIP_H264_IDCT4_DC  2
 #define FFHIP_H264_IDCT8_DC  3
+#define FFHIP_H264_ADD_PIXELS4_CLEAR 4   /* add_pixels4_clear / add_pixels8_clear: dst += block (8-bit wrap-around), block cleared */
+#define FFHIP_H264_ADD_PIXELS8_CLEAR 5   /* (h264addpx_template.c:28-74; the lossless transform bypass) */
 /**
  * n independent blocks: block i adds into dst_base + dst_offset[i] (bytes, rows `stride` apart) from
  * coefficients blocks + i*(16|64) int16 (transposed storage as the decoder leaves them), then the
@@ -243,6 +291,18 @@ int ffhip_h264_idct_add_batch_dev(int kind, uint8_t *dst_base, ptrdiff_t stride,
 int ffhip_h264_idct_add_mb_batch_dev(int which, uint8_t *dst_base, ptrdiff_t stride, const int32_t *mb_offset,
                                      const int32_t *blockoffset16, int16_t *blocks, const uint8_t *nnzc,
                                      int nmb, void *stream);
+
+/** idct_add8 (4:2:0, h264idct_template.c:216-228) over `nmb` macroblocks: blocks + m*768 int16 are the decoder's sl->mb (3 x 256),
+ *  of which blocks 16..19 (Cb) and 32..35 (Cr) are used; nnzc + m*120 is the 15 x 8 non-zero-count cache (scan8 indexing);
+ *  blockoffset48[i] as the decoder's block_offset[]; Cb / Cr block i of MB m lands at c?_base + mb_offset[m] + blockoffset48[i]. */
+int ffhip_h264_idct_add8_batch_dev(uint8_t *cb_base, uint8_t *cr_base, ptrdiff_t stride, const int32_t *mb_offset,
+                                   const int32_t *blockoffset48, int16_t *blocks, const uint8_t *nnzc, int nmb, void *stream);
+/** luma_dc_dequant_idct (h264idct_template.c:259-293) for n macroblocks: input + m*in_pitch (16 DC values), output + m*out_pitch
+ *  (the macroblock's 256 coefficients: the 16 results land on the blocks' DC positions), qmul[m].  Pitches in int16 units. */
+int ffhip_h264_luma_dc_dequant_idct_batch_dev(int16_t *output, size_t out_pitch, const int16_t *input, size_t in_pitch,
+                                              const int32_t *qmul, int n, void *stream);
+/** chroma_dc_dequant_idct (4:2:0, h264idct_template.c:323-345), in place on blocks[block_offset[m] + {0,16,32,48}], qmul[m]. */
+int ffhip_h264_chroma_dc_dequant_idct_batch_dev(int16_t *blocks, const int32_t *block_offset, const int32_t *qmul, int n, void *stream);
 
 /** Loop-filter kinds == H264DSPContext members (libavcodec/h264dsp_template.c:104-330). */
 #define FFHIP_H264_LF_V_LUMA          0

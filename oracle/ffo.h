@@ -52,6 +52,13 @@ void ffo_yuv2planeX8(const int16_t *filter, int fs, const int16_t *const *src, u
 void ffo_yuv2plane1_8(const int16_t *src, uint8_t *dest, int dstW, const uint8_t *dither, int offset);
 void ffo_yuv2nv12cX(int swap, const uint8_t *dither, const int16_t *filter, int fs, const int16_t *const *u,
                     const int16_t *const *v, uint8_t *dest, int chrDstW);
+/* one packed RGB line: yuv2rgb_{X,2,1}_c_template (libswscale/output.c:1789-1939); layout 0 rgb24 1 bgr24 2 argb 3 rgba 4 abgr 5 bgra */
+void ffo_yuv2rgb_X(const FfoYuv2RgbLuts *l, const int16_t *lf, const int16_t *const *lum, int lfs, const int16_t *cf,
+                   const int16_t *const *cu, const int16_t *const *cv, int cfs, uint8_t *dest, int dstW, int layout);
+void ffo_yuv2rgb_2(const FfoYuv2RgbLuts *l, const int16_t *const lum[2], const int16_t *const cu[2], const int16_t *const cv[2], uint8_t *dest,
+                   int dstW, int yalpha, int uvalpha, int layout);
+void ffo_yuv2rgb_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *const cu[2], const int16_t *const cv[2], uint8_t *dest, int dstW,
+                   int uvalpha, int layout);
 int  ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], const int srcStride[3],
                          uint8_t *const dst[3], const int dstStride[3]);
 
@@ -64,6 +71,10 @@ void ffo_h264_idct_add16(uint8_t *dst, const int *block_offset, int16_t *block, 
 void ffo_h264_idct8_add4(uint8_t *dst, const int *block_offset, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc);
 void ffo_h264_idct_add16intra(uint8_t *dst, const int *block_offset, int16_t *block, ptrdiff_t stride,
                               const uint8_t *nnzc);
+void ffo_h264_idct_add8(uint8_t **dest, const int *block_offset, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc);
+void ffo_h264_luma_dc_dequant_idct(int16_t *output, int16_t *input, int qmul);
+void ffo_h264_chroma_dc_dequant_idct(int16_t *block, int qmul);
+void ffo_h264_add_pixels_clear(int n, uint8_t *dst, int16_t *block, ptrdiff_t stride);
 /* which: FFHIP_H264_LF_* numbering (0 v_luma 1 h_luma 2 v_chroma 3 h_chroma, +4 intra) */
 void ffo_h264_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0);
 void ffo_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride);

@@ -127,6 +127,62 @@ void ffo_h264_idct_add16intra(uint8_t *dst, const int *bo, int16_t *block, ptrdi
             ffo_h264_idct_dc_add(dst + bo[i], block + i * 16, stride);
     }
 }
+/* position of chroma 4x4 block i (16..19, 32..35) in the 15-row nnz cache: the chroma rows of scan8[], h264_parse.h:45-52 */
+static int scan8_chroma(int i)
+{
+    const int k = i & 15, row = (i >> 4) * 5 + 1; /* plane 1: cache rows 6,7; plane 2: rows 11,12 */
+    return 4 + (k & 1) + ((k >> 2) & 1) * 2 + (row + ((k >> 1) & 1)) * 8;
+}
+/* ff_h264_idct_add8_8_c (4:2:0), h264idct_template.c:216-228: the four 4x4 blocks of each chroma plane; dest[0] Cb, dest[1] Cr */
+void ffo_h264_idct_add8(uint8_t **dest, const int *bo, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc)
+{
+    for (int j = 1; j < 3; j++)
+        for (int i = j * 16; i < j * 16 + 4; i++) {
+            if (nnzc[scan8_chroma(i)])
+                ffo_h264_idct_add(dest[j - 1] + bo[i], block + i * 16, stride);
+            else if (block[i * 16])
+                ffo_h264_idct_dc_add(dest[j - 1] + bo[i], block + i * 16, stride);
+        }
+}
+/* ff_h264_luma_dc_dequant_idct_8_c, h264idct_template.c:259-293: 4x4 Hadamard of the 16 luma DC values, dequantised, scattered to
+ * the DC positions of the macroblock's 16 blocks (unsigned wrap-around products, arithmetic >> 8) */
+void ffo_h264_luma_dc_dequant_idct(int16_t *output, int16_t *input, int qmul)
+{
+    static const uint8_t x_offset[4] = { 0, 2 * 16, 8 * 16, 10 * 16 };
+    int temp[16];
+    for (int i = 0; i < 4; i++) {
+        const int z0 = input[4 * i + 0] + input[4 * i + 1], z1 = input[4 * i + 0] - input[4 * i + 1];
+        const int z2 = input[4 * i + 2] - input[4 * i + 3], z3 = input[4 * i + 2] + input[4 * i + 3];
+        temp[4 * i + 0] = z0 + z3; temp[4 * i + 1] = z0 - z3; temp[4 * i + 2] = z1 - z2; temp[4 * i + 3] = z1 + z2;
+    }
+    for (int i = 0; i < 4; i++) {
+        const int o = x_offset[i];
+        const unsigned z0 = (unsigned)temp[i] + temp[8 + i], z1 = (unsigned)temp[i] - temp[8 + i];
+        const unsigned z2 = (unsigned)temp[4 + i] - temp[12 + i], z3 = (unsigned)temp[4 + i] + temp[12 + i];
+        output[16 * 0 + o] = (int16_t)((int)((z0 + z3) * (unsigned)qmul + 128) >> 8);
+        output[16 * 1 + o] = (int16_t)((int)((z1 + z2) * (unsigned)qmul + 128) >> 8);
+        output[16 * 4 + o] = (int16_t)((int)((z1 - z2) * (unsigned)qmul + 128) >> 8);
+        output[16 * 5 + o] = (int16_t)((int)((z0 - z3) * (unsigned)qmul + 128) >> 8);
+    }
+}
+/* ff_h264_chroma_dc_dequant_idct_8_c (4:2:0), h264idct_template.c:323-345: 2x2 Hadamard of the DCs at block[0,16,32,48] */
+void ffo_h264_chroma_dc_dequant_idct(int16_t *block, int qmul)
+{
+    unsigned a = block[0], b = block[16], c = block[32], d = block[48], e;
+    e = a - b; a = a + b; b = c - d; c = c + d;
+    block[0]  = (int16_t)((int)((a + c) * (unsigned)qmul) >> 7);
+    block[16] = (int16_t)((int)((e + b) * (unsigned)qmul) >> 7);
+    block[32] = (int16_t)((int)((a - c) * (unsigned)qmul) >> 7);
+    block[48] = (int16_t)((int)((e - b) * (unsigned)qmul) >> 7);
+}
+/* ff_h264_add_pixels4_8_c / ff_h264_add_pixels8_8_c (the lossless bypass), h264addpx_template.c:28-74: wrap-around add, then clear */
+void ffo_h264_add_pixels_clear(int n, uint8_t *dst, int16_t *block, ptrdiff_t stride)
+{
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++)
+            dst[y * stride + x] = (uint8_t)(dst[y * stride + x] + (unsigned)block[y * n + x]);
+    memset(block, 0, sizeof(int16_t) * n * n);
+}
 void ffo_h264_idct8_add4(uint8_t *dst, const int *bo, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc)
 {
     for (int i = 0; i < 16; i += 4) {

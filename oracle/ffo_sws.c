@@ -199,6 +199,23 @@ static void rgb24_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *
     }
 }
 
+/* the three packed-output members, one line (yuv2packedX / yuv2packed2 / yuv2packed1 of a packed-RGB context) */
+void ffo_yuv2rgb_X(const FfoYuv2RgbLuts *l, const int16_t *lf, const int16_t *const *lum, int lfs, const int16_t *cf,
+                   const int16_t *const *cu, const int16_t *const *cv, int cfs, uint8_t *dest, int dstW, int layout)
+{
+    rgb24_X(l, lf, lum, lfs, cf, cu, cv, cfs, dest, dstW, layout);
+}
+void ffo_yuv2rgb_2(const FfoYuv2RgbLuts *l, const int16_t *const lum[2], const int16_t *const cu[2], const int16_t *const cv[2], uint8_t *dest,
+                   int dstW, int yalpha, int uvalpha, int layout)
+{
+    rgb24_2(l, lum, cu, cv, dest, dstW, yalpha, uvalpha, layout);
+}
+void ffo_yuv2rgb_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *const cu[2], const int16_t *const cv[2], uint8_t *dest, int dstW,
+                   int uvalpha, int layout)
+{
+    rgb24_1(l, lum, cu, cv, dest, dstW, uvalpha, layout);
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Whole-frame scaled conversion: the net effect of ff_swscale() (libswscale/swscale.c:263-567) with
  * its slice ring buffers (slice.c) for 8-bit sources: out = V(H(in)) with table-driven indices.

@@ -36,7 +36,16 @@ void  ffref_sws_yuv2nv12cX(void *ctx, int dstFormat, const uint8_t *chrDither, c
 
 /* ---- libavcodec h264dsp / h264qpel / me_cmp (8-bit) ---- */
 /* which: 0 idct_add 1 idct8_add 2 idct_dc_add 3 idct8_dc_add */
+void ffref_sws_yuv2packedX(void *ctx, const int16_t *lumFilter, const int16_t **lumSrc, int lumFilterSize, const int16_t *chrFilter,
+                           const int16_t **chrUSrc, const int16_t **chrVSrc, int chrFilterSize, uint8_t *dest, int dstW, int y);
+void ffref_sws_yuv2packed2(void *ctx, const int16_t *lumSrc[2], const int16_t *chrUSrc[2], const int16_t *chrVSrc[2], uint8_t *dest, int dstW,
+                           int yalpha, int uvalpha, int y);
+void ffref_sws_yuv2packed1(void *ctx, const int16_t *lumSrc, const int16_t *chrUSrc[2], const int16_t *chrVSrc[2], uint8_t *dest, int dstW,
+                           int uvalpha, int y);
 void ffref_h264_idct(int which, uint8_t *dst, int16_t *block, ptrdiff_t stride);
+void ffref_h264_luma_dc_dequant_idct(int16_t *output, int16_t *input, int qmul);
+void ffref_h264_chroma_dc_dequant_idct(int16_t *block, int qmul);
+void ffref_h264_add_pixels_clear(int n, uint8_t *dst, int16_t *block, ptrdiff_t stride);
 /* CPU-baseline runners: a batch split statically over pthreads (disjoint blocks / independent frames) */
 int  ffref_h264_idct_batch(int which, uint8_t *dst, ptrdiff_t stride, const int32_t *off, int16_t *blk, int n, int threads);
 int  ffref_sws_scale_frames_mt(void *const *ctxs, const uint8_t *const *const *srcs, const int *ss, uint8_t *const *const *dsts,

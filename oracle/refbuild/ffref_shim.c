@@ -102,6 +102,26 @@ void ffref_sws_yuv2nv12cX(void *ctx, int dstFormat, const uint8_t *chrDither, co
     inner(ctx)->yuv2nv12cX(dstFormat, chrDither, chrFilter, fs, chrU, chrV, dest, dstW);
 }
 
+/* the packed-output members of a context whose target is packed RGB (yuv2rgb_{1,2,X}_c_template via the YUV2RGBWRAPPER macros) */
+void ffref_sws_yuv2packedX(void *ctx, const int16_t *lumFilter, const int16_t **lumSrc, int lumFilterSize, const int16_t *chrFilter,
+                           const int16_t **chrUSrc, const int16_t **chrVSrc, int chrFilterSize, uint8_t *dest, int dstW, int y)
+{
+    SwsInternal *c = inner(ctx);
+    c->yuv2packedX(c, lumFilter, lumSrc, lumFilterSize, chrFilter, chrUSrc, chrVSrc, chrFilterSize, NULL, dest, dstW, y);
+}
+void ffref_sws_yuv2packed2(void *ctx, const int16_t *lumSrc[2], const int16_t *chrUSrc[2], const int16_t *chrVSrc[2], uint8_t *dest, int dstW,
+                           int yalpha, int uvalpha, int y)
+{
+    SwsInternal *c = inner(ctx);
+    c->yuv2packed2(c, lumSrc, chrUSrc, chrVSrc, NULL, dest, dstW, yalpha, uvalpha, y);
+}
+void ffref_sws_yuv2packed1(void *ctx, const int16_t *lumSrc, const int16_t *chrUSrc[2], const int16_t *chrVSrc[2], uint8_t *dest, int dstW,
+                           int uvalpha, int y)
+{
+    SwsInternal *c = inner(ctx);
+    c->yuv2packed1(c, lumSrc, chrUSrc, chrVSrc, NULL, dest, dstW, uvalpha, y);
+}
+
 /* ---- h264dsp / qpel / me_cmp ---- */
 static H264DSPContext   h264;
 static H264DSPContext   h264_422;
@@ -217,6 +237,13 @@ void ffref_h264_idct_add8(uint8_t **dst, const int *blockoffset, int16_t *block,
 {
     dsp_init();
     (chroma_format_idc == 2 ? &h264_422 : &h264)->idct_add8(dst, blockoffset, block, stride, nnzc);
+}
+void ffref_h264_luma_dc_dequant_idct(int16_t *output, int16_t *input, int qmul) { dsp_init(); h264.luma_dc_dequant_idct(output, input, qmul); }
+void ffref_h264_chroma_dc_dequant_idct(int16_t *block, int qmul) { dsp_init(); h264.chroma_dc_dequant_idct(block, qmul); }
+void ffref_h264_add_pixels_clear(int n, uint8_t *dst, int16_t *block, ptrdiff_t stride)
+{
+    dsp_init();
+    if (n == 8) h264.add_pixels8_clear(dst, block, stride); else h264.add_pixels4_clear(dst, block, stride);
 }
 void ffref_h264_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0)
 {

@@ -74,6 +74,12 @@ def oracle():
         L.ffo_yuv2planeX8.argtypes = [i16p, C.c_int, C.POINTER(i16p), u8p, C.c_int, u8p, C.c_int]
         L.ffo_yuv2plane1_8.argtypes = [i16p, u8p, C.c_int, u8p, C.c_int]
         L.ffo_yuv2nv12cX.argtypes = [C.c_int, u8p, i16p, C.c_int, C.POINTER(i16p), C.POINTER(i16p), u8p, C.c_int]
+        pp = C.POINTER(i16p)
+        L.ffo_yuv2rgb_X.argtypes = [C.POINTER(OLuts), i16p, pp, C.c_int, i16p, pp, pp, C.c_int, u8p, C.c_int, C.c_int]
+        L.ffo_yuv2rgb_2.argtypes = [C.POINTER(OLuts), pp, pp, pp, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffo_yuv2rgb_1.argtypes = [C.POINTER(OLuts), i16p, pp, pp, u8p, C.c_int, C.c_int, C.c_int]
+        for f in (L.ffo_yuv2rgb_X, L.ffo_yuv2rgb_2, L.ffo_yuv2rgb_1):
+            f.restype = None
         L.ffo_sws_scale_frame.argtypes = [C.POINTER(OSwsTables), C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(u8p),
                                           C.POINTER(C.c_int)]
         for n in ("ffo_h264_idct_add", "ffo_h264_idct8_add", "ffo_h264_idct_dc_add", "ffo_h264_idct8_dc_add"):
@@ -82,6 +88,14 @@ def oracle():
         for n in ("ffo_h264_idct_add16", "ffo_h264_idct8_add4", "ffo_h264_idct_add16intra"):
             getattr(L, n).argtypes = [u8p, i32p, i16p, C.c_ssize_t, u8p]
             getattr(L, n).restype = None
+        L.ffo_h264_idct_add8.argtypes = [C.POINTER(u8p), i32p, i16p, C.c_ssize_t, u8p]
+        L.ffo_h264_idct_add8.restype = None
+        L.ffo_h264_luma_dc_dequant_idct.argtypes = [i16p, i16p, C.c_int]
+        L.ffo_h264_luma_dc_dequant_idct.restype = None
+        L.ffo_h264_chroma_dc_dequant_idct.argtypes = [i16p, C.c_int]
+        L.ffo_h264_chroma_dc_dequant_idct.restype = None
+        L.ffo_h264_add_pixels_clear.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+        L.ffo_h264_add_pixels_clear.restype = None
         L.ffo_h264_loop_filter.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, i8p]
         L.ffo_h264_loop_filter.restype = None
         L.ffo_h264_qpel.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t]
@@ -202,6 +216,13 @@ def ref():
             L.ffref_h264_idct_batch.argtypes = [C.c_int, u8p, C.c_ssize_t, i32p, i16p, C.c_int, C.c_int]
             L.ffref_sws_scale_frames_mt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                                     C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
+        if hasattr(L, "ffref_sws_yuv2packedX"):
+            pp = C.POINTER(i16p)
+            L.ffref_sws_yuv2packedX.argtypes = [C.c_void_p, i16p, pp, C.c_int, i16p, pp, pp, C.c_int, u8p, C.c_int, C.c_int]
+            L.ffref_sws_yuv2packed2.argtypes = [C.c_void_p, pp, pp, pp, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+            L.ffref_sws_yuv2packed1.argtypes = [C.c_void_p, i16p, pp, pp, u8p, C.c_int, C.c_int, C.c_int]
+            for f in (L.ffref_sws_yuv2packedX, L.ffref_sws_yuv2packed2, L.ffref_sws_yuv2packed1):
+                f.restype = None
         L.ffref_sws_filter.argtypes = [C.c_void_p, C.c_int, C.POINTER(i16p), C.POINTER(i32p), C.POINTER(C.c_int)]
         L.ffref_sws_is_unscaled.argtypes = [C.c_void_p]
         L.ffref_sws_hyscale.argtypes = [C.c_void_p, i16p, C.c_int, u8p, i16p, i32p, C.c_int]
@@ -217,6 +238,15 @@ def ref():
         L.ffref_h264_idct.restype = None
         L.ffref_h264_idct_multi.argtypes = [C.c_int, u8p, i32p, i16p, C.c_ssize_t, u8p]
         L.ffref_h264_idct_multi.restype = None
+        L.ffref_h264_idct_add8.argtypes = [C.POINTER(u8p), i32p, i16p, C.c_ssize_t, u8p, C.c_int]
+        L.ffref_h264_idct_add8.restype = None
+        if hasattr(L, "ffref_h264_luma_dc_dequant_idct"):
+            L.ffref_h264_luma_dc_dequant_idct.argtypes = [i16p, i16p, C.c_int]
+            L.ffref_h264_luma_dc_dequant_idct.restype = None
+            L.ffref_h264_chroma_dc_dequant_idct.argtypes = [i16p, C.c_int]
+            L.ffref_h264_chroma_dc_dequant_idct.restype = None
+            L.ffref_h264_add_pixels_clear.argtypes = [C.c_int, u8p, i16p, C.c_ssize_t]
+            L.ffref_h264_add_pixels_clear.restype = None
         L.ffref_h264_loop_filter.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, i8p]
         L.ffref_h264_loop_filter.restype = None
         L.ffref_h264_qpel.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t]

@@ -93,6 +93,19 @@ def test_h264_golden():
         assert np.array_equal(o[6:22, 8:24], d["qpel_out"][i]), (avg, size_idx, mc)
 
 
+def test_h264_misc_golden():
+    """idct_add8, luma / chroma dc_dequant_idct, add_pixels{4,8}_clear: oracle == the reference's committed outputs"""
+    from test_oracle_vs_ref import h264_misc_apply
+    g = load("h264_misc")
+    bo, stride = g["bo"], int(g["stride"])
+    names = ("cb", "cr", "blocks", "out", "dc", "cdc", "px4", "res4", "px8", "res8")
+    for i in range(int(g["n"])):
+        k = {key: (int(g["in%d_%s" % (i, key)]) if key == "qmul" else g["in%d_%s" % (i, key)])
+             for key in ("blocks", "nnzc", "cb", "cr", "dc", "out", "cdc", "qmul", "px", "res")}
+        for nm, v in zip(names, h264_misc_apply(ffi.oracle(), "ffo", bo, stride, k)):
+            assert np.array_equal(v, g["out%d_%s" % (i, nm)]), (i, nm)
+
+
 def test_h264_chroma_weight_golden():
     O = ffi.oracle()
     d = load("h264")

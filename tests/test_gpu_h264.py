@@ -224,6 +224,64 @@ def test_qpel_batch(w, h, pad, old, monkeypatch):
             assert np.array_equal(got[y:y + s, x:x + s], want[y:y + s, x:x + s]), "block %d mc %d" % (i, b["mcxy"])
 
 
+def test_idct_add8_dc_dequant_add_pixels_batches():
+    """the batch faces of idct_add8 / luma + chroma dc_dequant_idct / add_pixels{4,8}_clear: many macroblocks per launch == the
+    oracle one call at a time (h264idct_template.c:216-345, h264addpx_template.c)"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(31)
+    mbw, mbh, stride = 12, 7, 128
+    nmb = mbw * mbh
+    bo = np.array([(i & 1) * 4 + ((i >> 1) & 1) * 4 * stride for i in range(48)], np.int32)
+    planes = [rng.integers(0, 256, (mbh * 8, stride), dtype=np.uint8) for _ in range(2)]
+    blocks = rng.integers(-400, 400, (nmb, 768)).astype(np.int16)
+    blocks[rng.random((nmb, 768)) < .5] = 0
+    nnzc = rng.integers(0, 2, (nmb, 120), dtype=np.uint8)
+    mboff = np.array([(m // mbw) * 8 * stride + (m % mbw) * 8 for m in range(nmb)], np.int32)
+    want, wb = [a.copy() for a in planes], blocks.copy()
+    for m in range(nmb):
+        dp = (ffi.u8p * 2)(*[C.cast(a.ctypes.data + int(mboff[m]), ffi.u8p) for a in want])
+        O.ffo_h264_idct_add8(dp, ptr(bo, i32p), ptr(wb[m], i16p), stride, ptr(nnzc[m]))
+    d = [torch.from_numpy(a).cuda() for a in planes]
+    db = torch.from_numpy(blocks).cuda()
+    h264.idct_add8_batch(d[0], d[1], stride, torch.from_numpy(mboff).cuda(), torch.from_numpy(bo).cuda(), db, torch.from_numpy(nnzc).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(d[0].cpu().numpy(), want[0]) and np.array_equal(d[1].cpu().numpy(), want[1])
+    assert np.array_equal(db.cpu().numpy(), wb) and (want[0] != planes[0]).any()
+    # DC transforms
+    n = 5000
+    qmul = rng.choice([16, 208, 1024, 14000, 65535, -9], n).astype(np.int32)
+    inp = rng.integers(-4000, 4000, (n, 16)).astype(np.int16)
+    out = rng.integers(-50, 50, (n, 256)).astype(np.int16)
+    wo = out.copy()
+    for m in range(n):
+        O.ffo_h264_luma_dc_dequant_idct(ptr(wo[m], i16p), ptr(inp[m].copy(), i16p), int(qmul[m]))
+    do = torch.from_numpy(out).cuda()
+    h264.luma_dc_dequant_batch(do, torch.from_numpy(inp).cuda(), torch.from_numpy(qmul).cuda())
+    cblk = rng.integers(-4000, 4000, (n, 64)).astype(np.int16)
+    wc = cblk.copy()
+    for m in range(n):
+        O.ffo_h264_chroma_dc_dequant_idct(ptr(wc[m], i16p), int(qmul[m]))
+    dcb = torch.from_numpy(cblk).cuda()
+    h264.chroma_dc_dequant_batch(dcb, torch.arange(n, dtype=torch.int32, device="cuda") * 64, torch.from_numpy(qmul).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(do.cpu().numpy(), wo) and np.array_equal(dcb.cpu().numpy(), wc)
+    # the lossless bypass
+    for kind, nn in ((h264.ADD_PIXELS4_CLEAR, 4), (h264.ADD_PIXELS8_CLEAR, 8)):
+        plane = rng.integers(0, 256, (64, 256), dtype=np.uint8)
+        nb = (64 // nn) * (256 // nn)
+        offs = np.array([(b // (256 // nn)) * nn * 256 + (b % (256 // nn)) * nn for b in range(nb)], np.int32)
+        res = rng.integers(-300, 300, (nb, nn * nn)).astype(np.int16)
+        wp, wr = plane.copy(), res.copy()
+        for b in range(nb):
+            O.ffo_h264_add_pixels_clear(nn, C.cast(wp.ctypes.data + int(offs[b]), ffi.u8p), ptr(wr[b], i16p), 256)
+        dp_, dr = torch.from_numpy(plane).cuda(), torch.from_numpy(res).cuda()
+        h264.idct_add_batch(kind, dp_, 256, torch.from_numpy(offs).cuda(), dr)
+        torch.cuda.synchronize()
+        assert np.array_equal(dp_.cpu().numpy(), wp) and not dr.cpu().numpy().any()
+
+
 def test_deblock_frame_row_kernel_agrees(monkeypatch):
     """FFHIP_DEBLOCK_OLD=1: the one-workgroup-per-row kernel (the byte path of unaligned strides) on an aligned picture"""
     monkeypatch.setenv("FFHIP_DEBLOCK_OLD", "1")

@@ -147,6 +147,55 @@ def test_vscale_lines(fs):
     R.ffref_sws_free(ctx)
 
 
+def packed_line_inputs(rng, dstW, lfs, cfs):
+    """int16 luma / chroma lines in the 15-bit range a horizontal pass produces, unit-gain vertical banks with negative lobes
+    (the reference indexes its 2048-entry luma ramp with the unclamped sample: gains far above 1 leave the table)"""
+    lum = rng.integers(0, 32768, (max(lfs, 2), dstW + 8)).astype(np.int16)
+    cu = rng.integers(0, 32768, (max(cfs, 2), dstW // 2 + 8)).astype(np.int16)
+    cv = rng.integers(0, 32768, (max(cfs, 2), dstW // 2 + 8)).astype(np.int16)
+
+    def bank(n):
+        g = rng.dirichlet(np.ones(n)) * 1.16 - 0.16 / n
+        f = np.round(g * 4096).astype(np.int32)
+        f[-1] += 4096 - f.sum()
+        return f.astype(np.int16)
+    return lum, cu, cv, bank(lfs), bank(cfs)
+
+
+@pytest.mark.parametrize("dst", ["rgb24", "bgr24", "argb", "rgba", "abgr", "bgra"])
+def test_packed_lines(dst):
+    """yuv2packedX / yuv2packed2 / yuv2packed1 of a packed-RGB context (yuv2rgb_{X,2,1}_c_template): oracle == reference"""
+    R, O = ffi.ref(), ffi.oracle()
+    ctx = R.ffref_sws_create(64, 16, PIX["yuv420p"], 128, 32, PIX[dst], 4, 1)
+    luts = ffi.OLuts()
+    k = ffi.OYuv2RgbCoeffs(*[ffi.DEFAULT_COEFFS[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+    O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
+    lay, bpp, dstW = ffi.RGB_LAYOUT[PIX[dst]], (3 if dst in ("rgb24", "bgr24") else 4), 330
+    rng = np.random.default_rng(ffi.RGB_LAYOUT[PIX[dst]] + 40)
+    for lfs, cfs in ((4, 4), (1, 4), (2, 2), (8, 3)):
+        lum, cu, cv, lf, cf = packed_line_inputs(rng, dstW, lfs, cfs)
+        rl = (i16p * lfs)(*[ptr(lum[j], i16p) for j in range(lfs)])
+        ru = (i16p * cfs)(*[ptr(cu[j], i16p) for j in range(cfs)])
+        rv = (i16p * cfs)(*[ptr(cv[j], i16p) for j in range(cfs)])
+        a, b = np.zeros(dstW * bpp + 8, np.uint8), np.zeros(dstW * bpp + 8, np.uint8)
+        R.ffref_sws_yuv2packedX(ctx, ptr(lf, i16p), rl, lfs, ptr(cf, i16p), ru, rv, cfs, ptr(a), dstW, 5)
+        O.ffo_yuv2rgb_X(C.byref(luts), ptr(lf, i16p), rl, lfs, ptr(cf, i16p), ru, rv, cfs, ptr(b), dstW, lay)
+        assert np.array_equal(a, b) and a.any()
+    lum, cu, cv, _, _ = packed_line_inputs(rng, dstW, 2, 2)
+    r2 = [(i16p * 2)(ptr(x[0], i16p), ptr(x[1], i16p)) for x in (lum, cu, cv)]
+    for ya, uva in ((0, 0), (1234, 4000), (4096, 2048)):
+        a, b = np.zeros(dstW * bpp + 8, np.uint8), np.zeros(dstW * bpp + 8, np.uint8)
+        R.ffref_sws_yuv2packed2(ctx, r2[0], r2[1], r2[2], ptr(a), dstW, ya, uva, 5)
+        O.ffo_yuv2rgb_2(C.byref(luts), r2[0], r2[1], r2[2], ptr(b), dstW, ya, uva, lay)
+        assert np.array_equal(a, b)
+    for uva in (0, 1000, 4096):
+        a, b = np.zeros(dstW * bpp + 8, np.uint8), np.zeros(dstW * bpp + 8, np.uint8)
+        R.ffref_sws_yuv2packed1(ctx, ptr(lum[0], i16p), r2[1], r2[2], ptr(a), dstW, uva, 5)
+        O.ffo_yuv2rgb_1(C.byref(luts), ptr(lum[0], i16p), r2[1], r2[2], ptr(b), dstW, uva, lay)
+        assert np.array_equal(a, b)
+    R.ffref_sws_free(ctx)
+
+
 # ---------------------------------------------------------------------------------------------
 def _coef_blocks(rng, n, size):
     """int16 coefficient blocks spanning the decoder's legal range plus adversarial extremes"""
@@ -191,6 +240,58 @@ def test_h264_idct_multi(which):
         R.ffref_h264_idct_multi(which, ptr(d1), ptr(bo, i32p), ptr(b1, i16p), 48, ptr(nnzc))
         ofn(ptr(d2), ptr(bo, i32p), ptr(b2, i16p), 48, ptr(nnzc))
         assert np.array_equal(d1, d2) and np.array_equal(b1, b2)
+
+
+def h264_misc_cases(rng, n=60):
+    """inputs of idct_add8 / luma + chroma dc_dequant_idct / add_pixels{4,8}_clear (shared with tools/make_golden.py)"""
+    stride = 32
+    bo = np.array([(i & 1) * 4 + ((i >> 1) & 1) * 4 * stride + ((i >> 2) & 1) * 8 for i in range(48)], np.int32)
+    cases = []
+    for _ in range(n):
+        blocks = rng.integers(-512, 512, 768).astype(np.int16)
+        for i in list(range(16, 20)) + list(range(32, 36)):
+            if rng.random() < .4:
+                blocks[i * 16 + 1:(i + 1) * 16] = 0
+            if rng.random() < .2:
+                blocks[i * 16] = 0
+        cases.append(dict(blocks=blocks, nnzc=rng.integers(0, 2, 120, dtype=np.uint8),
+                          cb=rng.integers(0, 256, (12, stride), dtype=np.uint8), cr=rng.integers(0, 256, (12, stride), dtype=np.uint8),
+                          dc=rng.integers(-4000, 4000, 16).astype(np.int16), out=rng.integers(-50, 50, 256).astype(np.int16),
+                          cdc=rng.integers(-4000, 4000, 64).astype(np.int16), qmul=int(rng.choice([16, 208, 1024, 14000, 65535, -9])),
+                          px=rng.integers(0, 256, (8, stride), dtype=np.uint8), res=rng.integers(-400, 400, 64).astype(np.int16)))
+    return bo, stride, cases
+
+
+def h264_misc_apply(L, prefix, bo, stride, k):
+    """runs the five members on copies of case k through library L (`ffo` oracle / `ffref` reference); returns the outputs"""
+    cb, cr, blocks = k["cb"].copy(), k["cr"].copy(), k["blocks"].copy()
+    dp = (ffi.u8p * 2)(ptr(cb), ptr(cr))
+    if prefix == "ffo":
+        L.ffo_h264_idct_add8(dp, ptr(bo, i32p), ptr(blocks, i16p), stride, ptr(k["nnzc"]))
+    else:
+        L.ffref_h264_idct_add8(dp, ptr(bo, i32p), ptr(blocks, i16p), stride, ptr(k["nnzc"]), 1)
+    out, dc, cdc = k["out"].copy(), k["dc"].copy(), k["cdc"].copy()
+    getattr(L, prefix + "_h264_luma_dc_dequant_idct")(ptr(out, i16p), ptr(dc, i16p), k["qmul"])
+    getattr(L, prefix + "_h264_chroma_dc_dequant_idct")(ptr(cdc, i16p), k["qmul"])
+    res = []
+    for n in (4, 8):
+        px, r = k["px"].copy(), k["res"][:n * n].copy()
+        getattr(L, prefix + "_h264_add_pixels_clear")(n, ptr(px), ptr(r, i16p), stride)
+        res += [px, r]
+    return [cb, cr, blocks, out, dc, cdc] + res
+
+
+def test_h264_idct_add8_dc_dequant_add_pixels():
+    """the h264dsp members a macroblock needs beside the IDCTs: oracle == reference, bit for bit"""
+    R, O = ffi.ref(), ffi.oracle()
+    bo, stride, cases = h264_misc_cases(np.random.default_rng(77))
+    changed = 0
+    for k in cases:
+        a, b = h264_misc_apply(R, "ffref", bo, stride, k), h264_misc_apply(O, "ffo", bo, stride, k)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        changed += int((a[0] != k["cb"]).any()) + int((a[3] != k["out"]).any())
+    assert changed > len(cases)
 
 
 # (alpha, beta, tc0) ladder in the spirit of tests/checkasm/h264dsp.c:394-402

@@ -114,6 +114,21 @@ def h264():
     np.savez_compressed(os.path.join(OUT, "h264.npz"), **d)
 
 
+def h264_misc():
+    """idct_add8 / dc_dequant_idct / add_pixels_clear: inputs + the reference's outputs (tests/golden/h264_misc.npz)"""
+    from test_oracle_vs_ref import h264_misc_cases, h264_misc_apply
+    R = ffi.ref()
+    bo, stride, cases = h264_misc_cases(np.random.default_rng(0xF0F0_0013), n=12)
+    d = {"bo": bo, "stride": np.int32(stride), "n": np.int32(len(cases))}
+    names = ("cb", "cr", "blocks", "out", "dc", "cdc", "px4", "res4", "px8", "res8")
+    for i, k in enumerate(cases):
+        for key, v in k.items():
+            d["in%d_%s" % (i, key)] = np.asarray(v)
+        for nm, v in zip(names, h264_misc_apply(R, "ffref", bo, stride, k)):
+            d["out%d_%s" % (i, nm)] = v
+    np.savez_compressed(os.path.join(OUT, "h264_misc.npz"), **d)
+
+
 def me():
     d = {}
     rng = np.random.default_rng(1003)
@@ -446,6 +461,6 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
