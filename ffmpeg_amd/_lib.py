@@ -62,6 +62,14 @@ def lib():
         "ffhip_sws_yuv2packed1": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
         "ffhip_sws_yuv2packed2": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "ffhip_sws_yuv2packedX": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int]),
+        "ffhip_sws_uops_compile": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+        "ffhip_sws_uops_free": (None, [C.POINTER(vp)]),
+        "ffhip_sws_uops_block_size": (C.c_int, [vp]),
+        "ffhip_sws_uops_source": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_size_t]),
+        "ffhip_sws_uops_check": (C.c_int, [vp, C.c_int]),
+        "ffhip_sws_uops_set_fallback": (None, [vp, vp, vp]),
+        "ffhip_sws_uops_func": (None, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ffhip_sws_uops_run_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
         "ffhip_membw_probe": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
         "ffhip_sws_up2_virtual_bank_host": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
         "ffhip_sws_mfma_tiles_host": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]),

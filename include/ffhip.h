@@ -943,6 +943,120 @@ void ffhip_tx_uninit(FFHipTXContext **ctx);
 int  ffhip_tx_batch_dev(FFHipTXContext *ctx, void *out, size_t out_pitch, const void *in, size_t in_pitch,
                         ptrdiff_t stride, int ntransforms, void *stream);
 
+/* =====================================================================================================================
+ * swscale SwsOpBackend "hip" (SURVEY.md §8 f-1): the micro-op lists libswscale's new format layer hands a backend
+ * (SwsOpBackend.compile / .compile_uops, libswscale/ops_dispatch.h:135-156) become one generated gfx950 kernel each.
+ *
+ * The structs below are LAYOUT-IDENTICAL to the reference's (the FFmpeg-side stub passes its own pointers through a cast and
+ * static_asserts the sizes; oracle/refbuild/ffref_shim_ops.c holds those asserts for this repository's tests):
+ *   FFHipSwsPixel == SwsPixel (uops.h:81-88), FFHipSwsFilterWeights == SwsFilterWeights (filters.h:83-121),
+ *   FFHipSwsUOp == SwsUOp (uops.h:262-281), FFHipSwsOpExec == SwsOpExec (ops_dispatch.h:36-85);
+ *   FFHIP_SWS_PIXEL_* == SwsPixelType (uops.h:43-50), FFHIP_SWS_UOP_* == SwsUOpType (uops.h:129-184).
+ * Semantics of every micro-op are the C template backend's (libswscale/uops_tmpl.c, compiled without FP contraction,
+ * uops_backend.c:24-35): results are bit-identical to backend_c for every type, floats included.
+ * ===================================================================================================================== */
+#define FFHIP_ENOTSUP (-95)   /* == AVERROR(ENOTSUP): the caller tries its next backend / splits the list (ops_dispatch.c:744-766) */
+
+enum { FFHIP_SWS_PIXEL_NONE = 0, FFHIP_SWS_PIXEL_U8, FFHIP_SWS_PIXEL_U16, FFHIP_SWS_PIXEL_U32, FFHIP_SWS_PIXEL_F32 };
+enum {
+    FFHIP_SWS_UOP_INVALID = 0,
+    FFHIP_SWS_UOP_READ_PLANAR, FFHIP_SWS_UOP_READ_PLANAR_FH, FFHIP_SWS_UOP_READ_PLANAR_FV, FFHIP_SWS_UOP_READ_PLANAR_FV_FMA,
+    FFHIP_SWS_UOP_READ_PACKED, FFHIP_SWS_UOP_READ_NIBBLE, FFHIP_SWS_UOP_READ_BIT, FFHIP_SWS_UOP_READ_PALETTE,
+    FFHIP_SWS_UOP_WRITE_PLANAR, FFHIP_SWS_UOP_WRITE_PACKED, FFHIP_SWS_UOP_WRITE_NIBBLE, FFHIP_SWS_UOP_WRITE_BIT,
+    FFHIP_SWS_UOP_RW_SHUFFLE, FFHIP_SWS_UOP_PERMUTE, FFHIP_SWS_UOP_COPY,
+    FFHIP_SWS_UOP_SWAP_BYTES, FFHIP_SWS_UOP_EXPAND_BIT, FFHIP_SWS_UOP_EXPAND_PAIR, FFHIP_SWS_UOP_EXPAND_QUAD,
+    FFHIP_SWS_UOP_TO_U8, FFHIP_SWS_UOP_TO_U16, FFHIP_SWS_UOP_TO_U32, FFHIP_SWS_UOP_TO_F32,
+    FFHIP_SWS_UOP_SCALE, FFHIP_SWS_UOP_ADD, FFHIP_SWS_UOP_MIN, FFHIP_SWS_UOP_MAX,
+    FFHIP_SWS_UOP_UNPACK, FFHIP_SWS_UOP_PACK, FFHIP_SWS_UOP_LSHIFT, FFHIP_SWS_UOP_RSHIFT, FFHIP_SWS_UOP_CLEAR,
+    FFHIP_SWS_UOP_LINEAR, FFHIP_SWS_UOP_LINEAR_FMA, FFHIP_SWS_UOP_DITHER, FFHIP_SWS_UOP_LUT_3D,
+    FFHIP_SWS_UOP_TYPE_NB
+};
+#define FFHIP_SWS_FILTER_SCALE (1 << 14)          /* SWS_FILTER_SCALE, filters.h:39 */
+
+typedef union FFHipSwsPixel { char data[4]; uint8_t u8; uint16_t u16; uint32_t u32; float f32; } FFHipSwsPixel;
+
+typedef struct FFHipSwsFilterWeights {
+    int     filter_size;              /* taps per output sample */
+    int    *weights;                  /* [dst_size][filter_size], scaled by FFHIP_SWS_FILTER_SCALE */
+    size_t  num_weights;
+    int    *offsets;                  /* first source sample of every output sample */
+    int     src_size, dst_size;
+    double  virtual_size, offset;
+    char    name[16];
+    int     sum_positive, sum_negative;
+} FFHipSwsFilterWeights;
+
+typedef union FFHipSwsUOpParams {
+    struct { uint8_t clear_value, read_size, write_size; } shuffle;
+    struct { int32_t type; } filter;                               /* READ_PLANAR_FH / _FV: type the result is stored as */
+    struct { uint8_t amount; } shift;
+    struct { int32_t num_moves; int8_t dst[6], src[6]; } move;     /* PERMUTE / COPY; register -1 is a temporary */
+    struct { uint8_t pattern[4]; } pack;
+    struct { uint8_t one, zero; } clear;
+    struct { uint32_t one, zero, exact; } lin;                     /* bit 5 * row + column */
+    struct { uint8_t y_offset[4]; uint8_t size_log2; } dither;
+    struct { int32_t dynamic; } lut3d;
+} FFHipSwsUOpParams;
+
+typedef struct FFHipSwsUOp {
+    int32_t type;                     /* FFHIP_SWS_PIXEL_* */
+    int32_t uop;                      /* FFHIP_SWS_UOP_* */
+    uint8_t mask;                     /* components, bit c */
+    FFHipSwsUOpParams par;
+    union {
+        FFHipSwsFilterWeights *kernel;
+        FFHipSwsPixel *ptr;           /* DITHER: (1 << size_log2) columns, (1 << size_log2) + max(y_offset) rows */
+        FFHipSwsPixel scalar;
+        FFHipSwsPixel vec4[4];
+        FFHipSwsPixel mat4[4][5];
+        struct { int8_t mask[16]; uint8_t pixels; } shuffle;
+        const void *lut3d;
+        void *opaque;
+    } data;
+} FFHipSwsUOp;
+
+typedef struct FFHipSwsOpExec {
+    const uint8_t *in[4];
+    uint8_t *out[4];
+    ptrdiff_t in_stride[4], out_stride[4];
+    ptrdiff_t in_bump[4], out_bump[4];
+    int32_t width, height, slice_y, slice_h;
+    int32_t block_size_in[4], block_size_out[4];
+    uint8_t in_sub_y[4], out_sub_y[4], in_sub_x[4], out_sub_x[4];
+    int32_t *in_bump_y;               /* READ_PLANAR_FV: extra source lines after output line y (absolute y) */
+    int32_t *in_offset_x;             /* READ_PLANAR_FH: byte offset of the first tap of output sample x (absolute x) */
+} FFHipSwsOpExec;
+
+/** SwsOpFunc (ops_dispatch.h:93-99). */
+typedef void (*FFHipSwsOpFunc)(const FFHipSwsOpExec *exec, const void *priv, int bx_start, int y_start, int bx_end, int y_end);
+
+typedef struct FFHipSwsUOps FFHipSwsUOps;   /* one compiled micro-op list: what SwsCompiledOp.priv holds */
+
+/** SwsOpBackend.compile_uops (ops_dispatch.h:148): generates, compiles (hiprtc, cached by program text) and loads the kernel of
+ *  the list.  FFHIP_ENOTSUP for lists this backend does not take (LUT_3D, RW_SHUFFLE and the _FMA variants — a translation with
+ *  flags 0, which is what bit-exactness with backend_c needs, never emits the latter two), FFHIP_EINVAL for malformed ones,
+ *  FFHIP_ENOSYS without a device. */
+int  ffhip_sws_uops_compile(const FFHipSwsUOp *uops, int num_uops, FFHipSwsUOps **out);
+void ffhip_sws_uops_free(FFHipSwsUOps **p);
+/** SwsCompiledOp.block_size: pixels per block of bx_start / bx_end — 1, or what makes a block whole bytes (8 for the 1-bit,
+ *  2 for the 4-bit reads and writes).  over_read / over_write are 0 for every list: no thread touches a byte outside the blocks. */
+int  ffhip_sws_uops_block_size(const FFHipSwsUOps *p);
+/** The program text the list compiles to (diagnostics, and the CPU-side test of the generator); returns its length or < 0. */
+int  ffhip_sws_uops_source(const FFHipSwsUOp *uops, int num_uops, char *buf, size_t size);
+/** Generates and compiles the program without loading it (no device needed): 0, FFHIP_ENOTSUP, FFHIP_EINVAL or FFHIP_EIO. */
+int  ffhip_sws_uops_check(const FFHipSwsUOp *uops, int num_uops);
+/** What the void face below runs when the device fails under it (the same list compiled by the caller's C backend). */
+void ffhip_sws_uops_set_fallback(FFHipSwsUOps *p, FFHipSwsOpFunc func, const void *priv);
+/** SwsCompiledOp.func for software frames: HOST pointers in `exec`, priv = the FFHipSwsUOps.  Stages exactly the bytes the
+ *  C backend would read, runs the kernel, commits exactly the bytes it would write. */
+void ffhip_sws_uops_func(const FFHipSwsOpExec *exec, const void *priv, int bx_start, int y_start, int bx_end, int y_end);
+/** The device-resident face (an AV_PIX_FMT_HIP frame pool, SwsPass.run of an opaque compiled op): `exec->in / out` are DEVICE
+ *  pointers, the two small tables (in_bump_y, in_offset_x) stay host arrays as the dispatcher built them.  `nframes` pictures
+ *  that share the geometry run in one launch, plane i of picture f at in[i] + f * in_frame_pitch[i] (NULL pitches: 1 picture).
+ *  Asynchronous on `stream`. */
+int  ffhip_sws_uops_run_dev(FFHipSwsUOps *p, const FFHipSwsOpExec *exec, int bx_start, int y_start, int bx_end, int y_end,
+                            int nframes, const ptrdiff_t *in_frame_pitch, const ptrdiff_t *out_frame_pitch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

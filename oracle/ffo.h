@@ -186,4 +186,13 @@ void ffo_aac_kbd_window(float *w, float alpha, int n);
 void ffo_aac_imdct_and_windowing(const FfoTx *mdct1024, const FfoTx *mdct128, const float *const windows[4], const float *coeffs,
                                  const int seq[2], const int kb[2], float *saved, float *out);
 
+/* ---- swscale micro-op lists (ffo_sws_uops.c): the five entry points of include/ffhip.h's SwsOpBackend section, on the CPU ---- */
+struct FFHipSwsUOp;
+struct FFHipSwsOpExec;
+typedef struct FfoSwsUOps FfoSwsUOps;
+int  ffo_sws_uops_compile(const struct FFHipSwsUOp *uops, int n, FfoSwsUOps **out);
+void ffo_sws_uops_free(FfoSwsUOps **p);
+int  ffo_sws_uops_block_size(const FfoSwsUOps *p);
+void ffo_sws_uops_func(const struct FFHipSwsOpExec *e, const void *priv, int bx_start, int y_start, int bx_end, int y_end);
+
 #endif

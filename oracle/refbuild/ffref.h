@@ -77,4 +77,24 @@ void *ffref_tx_create(int type, int inv, int len, float scale, uint64_t flags);
 void  ffref_tx_run(void *ctx, void *out, void *in, ptrdiff_t stride);
 void  ffref_tx_free(void *ctx);
 
+/* ---- libswscale op backends (ffref_shim_ops.c): the `hip` SwsOpBackend inside the reference's own dispatch ---- */
+struct FFHipSwsUOp;
+struct FFHipSwsOpExec;
+#define FFREF_SWS_BACKEND_C      (1 << 1)   /* SWS_BACKEND_C */
+#define FFREF_SWS_BACKEND_MEMCPY (1 << 2)   /* SWS_BACKEND_MEMCPY */
+#define FFREF_SWS_BACKEND_HIP    (1 << 6)   /* the bit ffref_shim_ops.c gives backend_hip */
+/* the five functions behind backend_hip: ffhip_sws_uops_{compile,free,block_size,func,set_fallback} or the oracle's */
+int  ffref_sws_hip_bind(void *compile, void *free_, void *block_size, void *func, void *set_fallback);
+long ffref_sws_hip_count(int what);   /* 0: lists the bound backend compiled, 1: lists it declined; < 0: reset */
+int  ffref_sws_frame_convert(int backends, int flags, int scaler, int dither, int threads,
+                             int sw, int sh, int sfmt, const uint8_t *const src[4], const int sstride[4],
+                             int dw, int dh, int dfmt, uint8_t *const dst[4], const int dstride[4]);
+int  ffref_sws_uops_run_c(const struct FFHipSwsUOp *uops, int n, const struct FFHipSwsOpExec *exec, int x_start, int y_start, int x_end,
+                          int y_end);
+int  ffref_sws_filter_generate(int scaler, int src_size, int dst_size, int *filter_size, int *weights, int weights_cap, int *offsets);
+/* instance idx of the table of micro-ops backend_c implements (uops_macros.h); returns the number of instances */
+int  ffref_sws_uop_instance(int idx, struct FFHipSwsUOp *out, char *name, int cap);
+int  ffref_image_layout(int fmt, int w, int h, int align, int linesize[4], int lines[4]);
+int  ffref_sws_describe_uops(int flags, int scaler, int sw, int sh, int sfmt, int dw, int dh, int dfmt, char *buf, int cap);
+
 #endif

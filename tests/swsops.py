@@ -1,0 +1,440 @@
+"""ctypes mirrors of the SwsOpBackend boundary (include/ffhip.h: FFHipSwsUOp, FFHipSwsOpExec ...) and the test shapes of
+tests/checkasm/sw_ops.c: one micro-op between a planar read and a planar write, 64 pixels x 16 lines, value ranges per micro-op.
+Test infrastructure."""
+import ctypes as C
+
+import numpy as np
+
+U8, U16, U32, F32 = 1, 2, 3, 4
+NP = {U8: np.uint8, U16: np.uint16, U32: np.uint32, F32: np.float32}
+SIZE = {U8: 1, U16: 2, U32: 4, F32: 4}
+INT_OF = {1: U8, 2: U16, 4: U32}
+(READ_PLANAR, READ_PLANAR_FH, READ_PLANAR_FV, READ_PLANAR_FV_FMA, READ_PACKED, READ_NIBBLE, READ_BIT, READ_PALETTE, WRITE_PLANAR,
+ WRITE_PACKED, WRITE_NIBBLE, WRITE_BIT, RW_SHUFFLE, PERMUTE, COPY, SWAP_BYTES, EXPAND_BIT, EXPAND_PAIR, EXPAND_QUAD, TO_U8, TO_U16,
+ TO_U32, TO_F32, SCALE, ADD, MIN, MAX, UNPACK, PACK, LSHIFT, RSHIFT, CLEAR, LINEAR, LINEAR_FMA, DITHER, LUT_3D) = range(1, 37)
+READS = (READ_PLANAR, READ_PLANAR_FH, READ_PLANAR_FV, READ_PACKED, READ_NIBBLE, READ_BIT, READ_PALETTE)
+WRITES = (WRITE_PLANAR, WRITE_PACKED, WRITE_NIBBLE, WRITE_BIT)
+PIXELS, LINES = 64, 16
+STRIDE = PIXELS * 16           # sizeof(uint32_t[4]) per pixel, as checkasm's planes
+
+
+class Pixel(C.Union):
+    _fields_ = [("data", C.c_char * 4), ("u8", C.c_uint8), ("u16", C.c_uint16), ("u32", C.c_uint32), ("f32", C.c_float)]
+
+
+class FilterWeights(C.Structure):
+    _fields_ = [("filter_size", C.c_int), ("weights", C.POINTER(C.c_int)), ("num_weights", C.c_size_t), ("offsets", C.POINTER(C.c_int)),
+                ("src_size", C.c_int), ("dst_size", C.c_int), ("virtual_size", C.c_double), ("offset", C.c_double),
+                ("name", C.c_char * 16), ("sum_positive", C.c_int), ("sum_negative", C.c_int)]
+
+
+class _Shuffle(C.Structure):
+    _fields_ = [("clear_value", C.c_uint8), ("read_size", C.c_uint8), ("write_size", C.c_uint8)]
+
+
+class _Filter(C.Structure):
+    _fields_ = [("type", C.c_int32)]
+
+
+class _Shift(C.Structure):
+    _fields_ = [("amount", C.c_uint8)]
+
+
+class _Move(C.Structure):
+    _fields_ = [("num_moves", C.c_int32), ("dst", C.c_int8 * 6), ("src", C.c_int8 * 6)]
+
+
+class _Pack(C.Structure):
+    _fields_ = [("pattern", C.c_uint8 * 4)]
+
+
+class _Clear(C.Structure):
+    _fields_ = [("one", C.c_uint8), ("zero", C.c_uint8)]
+
+
+class _Lin(C.Structure):
+    _fields_ = [("one", C.c_uint32), ("zero", C.c_uint32), ("exact", C.c_uint32)]
+
+
+class _Dither(C.Structure):
+    _fields_ = [("y_offset", C.c_uint8 * 4), ("size_log2", C.c_uint8)]
+
+
+class _Lut3d(C.Structure):
+    _fields_ = [("dynamic", C.c_int32)]
+
+
+class Par(C.Union):
+    _fields_ = [("shuffle", _Shuffle), ("filter", _Filter), ("shift", _Shift), ("move", _Move), ("pack", _Pack), ("clear", _Clear),
+                ("lin", _Lin), ("dither", _Dither), ("lut3d", _Lut3d)]
+
+
+class _ShuffleMask(C.Structure):
+    _fields_ = [("mask", C.c_int8 * 16), ("pixels", C.c_uint8)]
+
+
+class Data(C.Union):
+    _fields_ = [("kernel", C.POINTER(FilterWeights)), ("ptr", C.POINTER(Pixel)), ("scalar", Pixel), ("vec4", Pixel * 4),
+                ("mat4", (Pixel * 5) * 4), ("shuffle", _ShuffleMask), ("lut3d", C.c_void_p), ("opaque", C.c_void_p)]
+
+
+class UOp(C.Structure):
+    _fields_ = [("type", C.c_int32), ("uop", C.c_int32), ("mask", C.c_uint8), ("par", Par), ("data", Data)]
+
+
+class Exec(C.Structure):
+    _fields_ = [("in_", C.c_void_p * 4), ("out", C.c_void_p * 4), ("in_stride", C.c_ssize_t * 4), ("out_stride", C.c_ssize_t * 4),
+                ("in_bump", C.c_ssize_t * 4), ("out_bump", C.c_ssize_t * 4), ("width", C.c_int32), ("height", C.c_int32),
+                ("slice_y", C.c_int32), ("slice_h", C.c_int32), ("block_size_in", C.c_int32 * 4), ("block_size_out", C.c_int32 * 4),
+                ("in_sub_y", C.c_uint8 * 4), ("out_sub_y", C.c_uint8 * 4), ("in_sub_x", C.c_uint8 * 4), ("out_sub_x", C.c_uint8 * 4),
+                ("in_bump_y", C.POINTER(C.c_int32)), ("in_offset_x", C.POINTER(C.c_int32))]
+
+
+assert C.sizeof(UOp) == 112 and C.sizeof(Exec) == 272 and C.sizeof(FilterWeights) == 80
+
+OPFUNC = C.CFUNCTYPE(None, C.POINTER(Exec), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
+
+
+def declare(L, prefix):
+    """argtypes of the five entry points, `ffhip_sws_uops_` (libffhip) or `ffo_sws_uops_` (oracle)"""
+    g = lambda n: getattr(L, prefix + n)   # noqa: E731
+    g("compile").argtypes = [C.POINTER(UOp), C.c_int, C.POINTER(C.c_void_p)]
+    g("free").argtypes = [C.POINTER(C.c_void_p)]
+    g("free").restype = None
+    g("block_size").argtypes = [C.c_void_p]
+    g("func").argtypes = [C.POINTER(Exec), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    g("func").restype = None
+    g("set_fallback").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    g("set_fallback").restype = None
+    return g
+
+
+def declare_ref(R):
+    R.ffref_sws_hip_bind.argtypes = [C.c_void_p] * 5
+    R.ffref_sws_hip_count.argtypes = [C.c_int]
+    R.ffref_sws_hip_count.restype = C.c_long
+    R.ffref_sws_frame_convert.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_void_p), C.POINTER(C.c_int)] + [C.c_int] * 3 + \
+        [C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    R.ffref_sws_uops_run_c.argtypes = [C.POINTER(UOp), C.c_int, C.POINTER(Exec), C.c_int, C.c_int, C.c_int, C.c_int]
+    R.ffref_sws_filter_generate.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    R.ffref_sws_uop_instance.argtypes = [C.c_int, C.POINTER(UOp), C.c_char_p, C.c_int]
+    R.ffref_pix_fmt.argtypes = [C.c_char_p]
+    R.ffref_image_layout.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    R.ffref_sws_describe_uops.argtypes = [C.c_int] * 8 + [C.c_char_p, C.c_int]
+    return R
+
+
+def bind(R, L, prefix):
+    """make backend_hip of the reference build call the five entry points of L"""
+    f = lambda n: C.cast(getattr(L, prefix + n), C.c_void_p)   # noqa: E731
+    R.ffref_sws_hip_bind(f("compile"), f("free"), f("block_size"), f("func"), f("set_fallback"))
+
+
+def unbind(R):
+    R.ffref_sws_hip_bind(None, None, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+class Kernel:
+    """a filter kernel and the storage it points into"""
+
+    def __init__(self, weights, offsets, filter_size, src_size):
+        self.w = np.ascontiguousarray(weights, np.int32)
+        self.o = np.ascontiguousarray(offsets, np.int32)
+        self.c = FilterWeights(filter_size=filter_size, weights=self.w.ctypes.data_as(C.POINTER(C.c_int)), num_weights=self.w.size,
+                               offsets=self.o.ctypes.data_as(C.POINTER(C.c_int)), src_size=src_size, dst_size=self.o.size)
+
+
+def synthetic_kernel(rng, dst_size, src_size, filter_size):
+    """weights summing to SWS_FILTER_SCALE with negative lobes; what ff_sws_filter_generate produces has this shape (filters.c)"""
+    fs = min(filter_size, src_size)
+    w = np.zeros((dst_size, fs), np.int32)
+    for i in range(dst_size):
+        g = rng.dirichlet(np.ones(fs)) * 1.3 - 0.3 / fs
+        w[i] = np.round(g * 16384)
+        w[i, -1] += 16384 - w[i].sum()
+    off = np.clip(np.round((np.arange(dst_size) + 0.5) * src_size / dst_size - fs / 2), 0, src_size - fs).astype(np.int32)
+    return Kernel(w, off, fs, src_size)
+
+
+def ref_kernel(R, scaler, src_size, dst_size):
+    fs = C.c_int()
+    w = np.zeros(dst_size * 256, np.int32)
+    o = np.zeros(dst_size, np.int32)
+    assert R.ffref_sws_filter_generate(scaler, src_size, dst_size, C.byref(fs), w.ctypes.data_as(C.POINTER(C.c_int)), w.size,
+                                       o.ctypes.data_as(C.POINTER(C.c_int))) == 0
+    return Kernel(w[:dst_size * fs.value].reshape(dst_size, fs.value), o, fs.value, src_size)
+
+
+def rnd_normal_f32(rng, n):
+    """checkasm's rndf(): uniformly random bits that are a normal float"""
+    out = np.empty(n, np.uint32)
+    k = 0
+    while k < n:
+        b = rng.integers(0, 1 << 32, n - k, dtype=np.uint64).astype(np.uint32)
+        e = (b >> 23) & 0xFF
+        b = b[(e != 0) & (e != 255)]
+        out[k:k + b.size] = b
+        k += b.size
+    return out.view(np.float32)
+
+
+def fill(rng, typ, nbytes, rng_max):
+    """checkasm's fill8/16/32/32f: `rng_max` 0 = every bit pattern (floats: every normal number)"""
+    n = nbytes // SIZE[typ]
+    if typ == F32:
+        return (rnd_normal_f32(rng, n) if not rng_max else (rng.random(n) * rng_max).astype(np.float32)).view(np.uint8)
+    hi = (1 << (8 * SIZE[typ])) - 1
+    return rng.integers(0, (rng_max if rng_max and rng_max < hi else hi) + 1, n, dtype=np.uint64).astype(NP[typ]).view(np.uint8)
+
+
+def rndpx(rng, typ):
+    p = Pixel()
+    if typ == F32:
+        p.f32 = float(rnd_normal_f32(rng, 1)[0])
+    else:
+        p.u32 = int(rng.integers(0, 1 << (8 * SIZE[typ])))
+    return p
+
+
+class Case:
+    """one list + the planes it runs on, checkasm-shaped (sw_ops.c:291-380: read, micro-op, write)"""
+
+    def __init__(self, name, uops, keep, type_in, type_out, planes_in, planes_out, bits_in, bits_out, ranges):
+        self.name, self.keep = name, keep
+        self.uops = (UOp * len(uops))(*uops)
+        self.type_in, self.type_out, self.planes_in, self.planes_out = type_in, type_out, planes_in, planes_out
+        self.bits_in, self.bits_out, self.ranges = bits_in, bits_out, ranges
+
+    def planes(self, rng):
+        src = np.zeros((4, LINES, STRIDE), np.uint8)
+        for p in range(4):
+            if self.planes_in >> p & 1:
+                src[p] = fill(rng, self.type_in, LINES * STRIDE, self.ranges[p]).reshape(LINES, STRIDE)
+        return src
+
+    def execute(self, src, dst, pixels=PIXELS, lines=LINES, x0=0, block=1, off=0):
+        """the SwsOpExec of sw_ops.c:196-236 over src / dst ((4, LINES, STRIDE) uint8 arrays); `off` shifts the planes by bytes"""
+        e = Exec(width=PIXELS, height=LINES, slice_h=LINES)
+        rd = self.uops[0]
+        read_size, write_size = pixels * self.bits_in >> 3, pixels * self.bits_out >> 3
+        for i in range(4):
+            e.in_[i] = src[i].ctypes.data + off + (x0 * self.bits_in >> 3 if rd.uop != READ_PLANAR_FH else 0)
+            e.out[i] = dst[i].ctypes.data + off + (x0 * self.bits_out >> 3)
+            e.in_stride[i] = e.out_stride[i] = STRIDE
+            e.in_bump[i], e.out_bump[i] = STRIDE - read_size, STRIDE - write_size
+            e.block_size_in[i], e.block_size_out[i] = block * self.bits_in >> 3, block * self.bits_out >> 3
+        if rd.uop == READ_PALETTE:
+            e.in_[1] = src[1].ctypes.data
+            e.in_bump[1] = e.in_stride[1] = 0
+        self._tabs = []
+        if rd.uop == READ_PLANAR_FV:
+            o = np.ctypeslib.as_array(rd.data.kernel.contents.offsets, (LINES,))
+            b = np.zeros(LINES, np.int32)
+            b[:-1] = o[1:] - o[:-1] - 1
+            self._tabs.append(b)
+            e.in_bump_y = b.ctypes.data_as(C.POINTER(C.c_int32))
+        if rd.uop == READ_PLANAR_FH:
+            o = np.ctypeslib.as_array(rd.data.kernel.contents.offsets, (PIXELS,))
+            b = (o * self.bits_in >> 3).astype(np.int32)
+            self._tabs.append(b)
+            e.in_offset_x = b.ctypes.data_as(C.POINTER(C.c_int32))
+        return e
+
+    def compare(self, a, b):
+        """the planes a list writes, as its output type; NaNs of any payload are one value (IEEE leaves the payload open)"""
+        n = PIXELS * self.bits_out >> 3
+        for p in range(4):
+            if not self.planes_out >> p & 1:
+                continue
+            x, y = a[p][:, :n], b[p][:, :n]
+            if self.type_out == F32:
+                xf, yf = x.copy().view(np.float32), y.copy().view(np.float32)
+                same = (x.copy().view(np.uint32) == y.copy().view(np.uint32)) | (np.isnan(xf) & np.isnan(yf))
+                if not same.all():
+                    return "plane %d: %d floats differ" % (p, (~same).sum())
+            elif not np.array_equal(x, y):
+                return "plane %d: %d bytes differ" % (p, (x != y).sum())
+            if not np.array_equal(a[p][:, n:], b[p][:, n:]):
+                return "plane %d: bytes outside the line were written" % p
+        return None
+
+
+def _mk(typ, uop, mask=0xF, **kw):
+    u = UOp(type=typ, uop=uop, mask=mask)
+    for k, v in kw.items():
+        setattr(u, k, v)
+    return u
+
+
+def case_of(rng, name, u, R=None, scaler_kernels=True):
+    """the checkasm test of one micro-op instance (sw_ops.c:291-640): the data it needs, the read / write around it, the ranges.
+    Returns a list of Cases (filters: several kernels) — empty for instances the hip backend declines (LUT_3D)."""
+    typ, op, keep = u.type, u.uop, []
+    t_in = t_out = typ
+    if TO_U8 <= op <= TO_F32:
+        t_out = U8 + (op - TO_U8)
+    elif op == EXPAND_PAIR:
+        t_out = U16
+    elif op == EXPAND_QUAD:
+        t_out = U32
+    elif op in (READ_PLANAR_FH, READ_PLANAR_FV):
+        t_out = u.par.filter.type
+    bits_in, bits_out = 8 * SIZE[t_in], 8 * SIZE[t_out]
+    planes_in = planes_out = 0
+    ranges = [0, 0, 0, 0]
+    if op in (READ_PLANAR, READ_PLANAR_FH, READ_PLANAR_FV):
+        planes_in = u.mask
+    elif op == WRITE_PLANAR:
+        planes_out = u.mask
+    elif op == READ_PACKED:
+        planes_in, bits_in = 1, bits_in * bin(u.mask).count("1")
+    elif op == WRITE_PACKED:
+        planes_out, bits_out = 1, bits_out * bin(u.mask).count("1")
+    elif op == READ_NIBBLE:
+        planes_in, bits_in = 1, 4
+    elif op == WRITE_NIBBLE:
+        planes_out, bits_out = 1, 4
+    elif op == READ_BIT:
+        planes_in, bits_in = 1, 1
+    elif op == WRITE_BIT:
+        planes_out, bits_out = 1, 1
+    elif op == READ_PALETTE:
+        planes_in, bits_in = 3, 8
+    mask_in = mask_out = 0xF
+    # the per-micro-op ranges and data of check_* (sw_ops.c:470-640)
+    if op in READS:
+        mask_in = mask_out = u.mask
+    elif op in WRITES:
+        mask_in = mask_out = u.mask
+        ranges = [1 if op == WRITE_BIT else 15 if op == WRITE_NIBBLE else 255] * 4      # check_write, sw_ops.c:494-502
+    elif op in (PERMUTE, COPY):
+        mask_out = u.mask
+    elif op == EXPAND_BIT:
+        ranges = [1] * 4
+    elif TO_U8 <= op <= TO_F32 or op in (EXPAND_PAIR, EXPAND_QUAD):
+        mask_in = mask_out = u.mask
+        isz, osz = SIZE[t_in], SIZE[t_out]
+        r = (1 << (8 * osz)) - 1
+        if isz < osz or t_out == F32:
+            r = 0
+        ranges = [r] * 4
+    elif op == SCALE:
+        u.data.scalar = rndpx(rng, typ)
+        if typ != F32:
+            s = u.data.scalar.u32 & ((1 << (8 * SIZE[typ])) - 1)
+            ranges = [((1 << (8 * SIZE[typ])) - 1) // (s if s else 1)] * 4
+    elif op == ADD:
+        u.data.scalar = rndpx(rng, typ)      # check_scalar: only element 0 is random, the rest of the vec4 stays 0
+    elif op in (MIN, MAX, CLEAR):
+        for i in range(4):
+            u.data.vec4[i] = rndpx(rng, typ)
+    elif op == UNPACK:
+        total = sum(u.par.pack.pattern)
+        ranges = [(1 << total) - 1] * 4
+        mask_in, mask_out = 1, u.mask
+    elif op == PACK:
+        ranges = [(1 << b) - 1 for b in u.par.pack.pattern]
+        mask_in, mask_out = u.mask, 1
+    elif op == LINEAR:
+        for i in range(4):
+            for j in range(5):
+                bit = 1 << (5 * i + j)
+                if u.par.lin.zero & bit:
+                    u.data.mat4[i][j].u32 = 0
+                elif u.par.lin.one & bit:
+                    if typ == F32:
+                        u.data.mat4[i][j].f32 = 1.0
+                    else:
+                        u.data.mat4[i][j].u32 = 1
+                else:
+                    u.data.mat4[i][j] = rndpx(rng, typ)
+    elif op == DITHER:
+        size = 1 << u.par.dither.size_log2
+        mo = max(u.par.dither.y_offset[c] for c in range(4))
+        m = np.zeros((size + mo) * size, np.uint32)
+        m[:size * size] = rnd_normal_f32(rng, size * size).view(np.uint32) if typ == F32 else \
+            rng.integers(0, 1 << (8 * SIZE[typ]), size * size, dtype=np.uint64).astype(np.uint32)
+        m[size * size:] = m[:size * mo]
+        keep.append(m)
+        u.data.ptr = m.ctypes.data_as(C.POINTER(Pixel))
+    elif op == LUT_3D:
+        return []
+
+    def wrap(u, kern=None, nm=name):
+        uops = []
+        pin, pout, bi, bo = planes_in, planes_out, bits_in, bits_out
+        if not pin:
+            pin, bi = mask_in, 8 * SIZE[t_in]
+            uops.append(_mk(INT_OF[SIZE[t_in]], READ_PLANAR))
+        uops.append(u)
+        if not pout:
+            pout, bo = mask_out, 8 * SIZE[t_out]
+            uops.append(_mk(INT_OF[SIZE[t_out]], WRITE_PLANAR))
+        return Case(nm, uops, keep + [kern], t_in, t_out, pin, pout, bi, bo, ranges)
+
+    if op in (READ_PLANAR_FH, READ_PLANAR_FV):
+        out = []
+        dst = LINES if op == READ_PLANAR_FV else PIXELS
+        src = 1
+        while src <= dst:
+            kerns = [synthetic_kernel(rng, dst, src, 4)]
+            if R is not None and scaler_kernels:
+                kerns += [ref_kernel(R, 3, src, dst), ref_kernel(R, 6, src, dst)]   # SWS_SCALE_POINT, SWS_SCALE_SINC (sw_ops.c:511-514)
+            for ki, k in enumerate(kerns):
+                v = UOp.from_buffer_copy(u)
+                v.data.kernel = C.pointer(k.c)
+                out.append(wrap(v, k, "%s_%d_%d" % (name, src, ki)))
+            src <<= 1
+        return out
+    return [wrap(u)]
+
+
+def instances(R):
+    """(name, UOp) of every instance backend_c implements"""
+    u, nm = UOp(), C.create_string_buffer(64)
+    n = R.ffref_sws_uop_instance(-1, C.byref(u), nm, 64)
+    out = []
+    for i in range(n):
+        u = UOp()
+        R.ffref_sws_uop_instance(i, C.byref(u), nm, 64)
+        out.append((nm.value.decode(), u))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+class Picture:
+    """planes of a w x h picture in any pixel format the reference knows (av_image_fill_linesizes / _plane_sizes)"""
+
+    def __init__(self, R, fmt_name, w, h, rng=None, align=64, pad=0, slack=0):
+        """`slack`: bytes added to every line (room for a dispatcher to run whole blocks without its padded-copy tail path)"""
+        self.fmt = R.ffref_pix_fmt(fmt_name.encode())
+        assert self.fmt >= 0, fmt_name
+        ls, ln = (C.c_int * 4)(), (C.c_int * 4)()
+        assert R.ffref_image_layout(self.fmt, w, h, 1, ls, ln) > 0
+        ls = [(v + slack + align - 1) // align * align if v else 0 for v in ls]
+        self.w, self.h, self.linesize, self.lines = w, h, list(ls), list(ln)
+        self.planes = []
+        for i in range(4):
+            n = self.linesize[i] * self.lines[i]
+            self.planes.append((rng.integers(0, 256, n + pad, dtype=np.uint8) if rng is not None else np.zeros(n + pad, np.uint8)) if n else None)
+        if fmt_name == "pal8":                   # plane 1 is the 256-entry palette (linesize 0)
+            self.planes[1] = rng.integers(0, 256, 1024, dtype=np.uint8) if rng is not None else np.zeros(1024, np.uint8)
+        self.data = (C.c_void_p * 4)(*[p.ctypes.data if p is not None else None for p in self.planes])
+        self.strides = (C.c_int * 4)(*self.linesize)
+
+    def payload(self, R):
+        """the bytes of every line that belong to the picture (the padding of a line is nobody's)"""
+        ls, ln = (C.c_int * 4)(), (C.c_int * 4)()
+        R.ffref_image_layout(self.fmt, self.w, self.h, 1, ls, ln)
+        return [self.planes[i][:self.linesize[i] * self.lines[i]].reshape(self.lines[i], self.linesize[i])[:, :ls[i]] for i in range(4)
+                if self.planes[i] is not None and self.linesize[i]]
+
+
+def convert(R, backends, src, dst, flags=0, scaler=-1, dither=-1, threads=1):
+    return R.ffref_sws_frame_convert(backends, flags, scaler, dither, threads, src.w, src.h, src.fmt, src.data, src.strides,
+                                     dst.w, dst.h, dst.fmt, dst.data, dst.strides)
+
+
+BACKEND_C, BACKEND_MEMCPY, BACKEND_HIP = 2, 4, 64
+
