@@ -438,3 +438,181 @@ def convert(R, backends, src, dst, flags=0, scaler=-1, dither=-1, threads=1):
 
 BACKEND_C, BACKEND_MEMCPY, BACKEND_HIP = 2, 4, 64
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# micro-op lists of real conversions, captured from the reference's graph and stored as fixtures (tests/golden/sws_uops_*.npz)
+# ---------------------------------------------------------------------------------------------------------------------------------
+COMPILE_CB = C.CFUNCTYPE(C.c_int, C.POINTER(UOp), C.c_int, C.POINTER(C.c_void_p))
+
+
+def capture_lists(R, O, sf, df, size, **kw):
+    """the lists the reference's dispatch compiles for a conversion, in order (those the oracle backend accepts; a declined list is
+    split by the reference and its parts come back).  Returns [(uops bytes (n, 112), {index: side arrays})]"""
+    declare(O, "ffo_sws_uops_")
+    got = []
+
+    def compile_cb(uops, n, out):
+        r = O.ffo_sws_uops_compile(uops, n, out)
+        if r == 0:
+            raw = np.frombuffer(C.string_at(uops, n * C.sizeof(UOp)), np.uint8).reshape(n, C.sizeof(UOp)).copy()
+            side = {}
+            for i in range(n):
+                u = uops[i]
+                if u.uop in (READ_PLANAR_FH, READ_PLANAR_FV):
+                    k = u.data.kernel.contents
+                    side[i] = ("kernel", np.ctypeslib.as_array(k.weights, (k.dst_size * k.filter_size,)).copy(),
+                               np.ctypeslib.as_array(k.offsets, (k.dst_size,)).copy(), np.array([k.filter_size, k.src_size], np.int32))
+                elif u.uop == DITHER:
+                    size_ = 1 << u.par.dither.size_log2
+                    rows = size_ + max(u.par.dither.y_offset[c] for c in range(4))
+                    side[i] = ("dither", np.ctypeslib.as_array(C.cast(u.data.ptr, C.POINTER(C.c_uint32)), (rows * size_,)).copy())
+            got.append((raw, side))
+        return r
+    cb = COMPILE_CB(compile_cb)
+    f = lambda n: C.cast(getattr(O, "ffo_sws_uops_" + n), C.c_void_p)   # noqa: E731
+    R.ffref_sws_hip_bind(C.cast(cb, C.c_void_p), f("free"), f("block_size"), f("func"), f("set_fallback"))
+    try:
+        sw, sh, dw, dh = size
+        src, dst = Picture(R, sf, sw, sh), Picture(R, df, dw, dh)
+        assert convert(R, BACKEND_HIP | BACKEND_MEMCPY, src, dst, **kw) >= 0
+    finally:
+        unbind(R)
+    return got
+
+
+def pack_lists(lists):
+    """-> dict of arrays for np.savez"""
+    out = {"count": np.array([len(lists)], np.int32)}
+    for k, (raw, side) in enumerate(lists):
+        out["l%d" % k] = raw
+        for i, s in side.items():
+            if s[0] == "kernel":
+                out["l%d_k%d_w" % (k, i)], out["l%d_k%d_o" % (k, i)], out["l%d_k%d_m" % (k, i)] = s[1], s[2], s[3]
+            else:
+                out["l%d_d%d" % (k, i)] = s[1]
+    return out
+
+
+class UOpList:
+    """a list rebuilt from its fixture: the UOp array plus the arrays its pointers point into"""
+
+    def __init__(self, z, k):
+        raw = np.ascontiguousarray(z["l%d" % k])
+        self.n = raw.shape[0]
+        self.uops = (UOp * self.n).from_buffer_copy(raw.tobytes())
+        self.keep = []
+        for i in range(self.n):
+            u = self.uops[i]
+            if u.uop in (READ_PLANAR_FH, READ_PLANAR_FV):
+                meta = z["l%d_k%d_m" % (k, i)]
+                kern = Kernel(z["l%d_k%d_w" % (k, i)], z["l%d_k%d_o" % (k, i)], int(meta[0]), int(meta[1]))
+                self.keep.append(kern)
+                u.data.kernel = C.pointer(kern.c)
+            elif u.uop == DITHER:
+                m = np.ascontiguousarray(z["l%d_d%d" % (k, i)], np.uint32)
+                self.keep.append(m)
+                u.data.ptr = m.ctypes.data_as(C.POINTER(Pixel))
+
+    @property
+    def read(self):
+        return self.uops[0]
+
+    @property
+    def write(self):
+        return self.uops[self.n - 1]
+
+
+class _Prefixed:
+    def __init__(self, z, prefix):
+        self.z, self.p = z, prefix
+
+    def __getitem__(self, k):
+        return self.z[self.p + k]
+
+
+def load_lists(z, prefix=""):
+    z = _Prefixed(z, prefix)
+    return [UOpList(z, k) for k in range(int(z["count"][0]))]
+
+
+def golden_cases(path):
+    """tests/golden/sws_uops.npz -> [(name, size, UOpList, [src planes], [dst planes])]"""
+    z = np.load(path)
+    out = []
+    for j in range(int(z["ncases"][0])):
+        p = "c%d_" % j
+        src = [z[p + "src%d" % i] for i in range(4) if p + "src%d" % i in z]
+        dst = [z[p + "dst%d" % i] for i in range(4) if p + "dst%d" % i in z]
+        out.append((bytes(z[p + "name"]).decode(), tuple(int(v) for v in z[p + "size"]), load_lists(z, p)[0], src, dst))
+    return out
+
+
+def run_golden(func, handle, block, lst, size, src, dst_shapes, pad=64):
+    """one whole picture through `func` (an SwsOpFunc on host memory); returns the destination planes"""
+    sw, sh, dw, dh = size
+    sp = [np.zeros((a.shape[0], a.shape[1] + pad), np.uint8) for a in src]
+    for a, b in zip(sp, src):
+        a[:, :b.shape[1]] = b
+    dp = [np.zeros((s[0], s[1] + pad), np.uint8) for s in dst_shapes]
+    e = plain_exec(lst, [a.ctypes.data for a in sp], [a.shape[1] for a in sp], [a.ctypes.data for a in dp], [a.shape[1] for a in dp],
+                   dw, dh, block)
+    func(C.byref(e), handle, 0, 0, (dw + block - 1) // block, dh)
+    return [a[:, :s[1]] for a, s in zip(dp, dst_shapes)], dp
+
+
+def rw_geometry(u):
+    """(planes mask, bits per pixel per plane) of a read or write micro-op"""
+    ts = 8 * SIZE[u.type]
+    el = 4 if u.mask & 8 else 3 if u.mask & 4 else 2 if u.mask & 2 else 1
+    if u.uop in (READ_PLANAR, READ_PLANAR_FH, READ_PLANAR_FV, WRITE_PLANAR):
+        return u.mask, ts
+    if u.uop in (READ_PACKED, WRITE_PACKED):
+        return 1, ts * el
+    if u.uop in (READ_NIBBLE, WRITE_NIBBLE):
+        return 1, 4
+    if u.uop in (READ_BIT, WRITE_BIT):
+        return 1, 1
+    return 3, 8       # palette
+
+
+def plain_exec(lst, src_planes, src_strides, dst_planes, dst_strides, w, h, block=1):
+    """the SwsOpExec of one whole picture for an unfiltered or filtered list, as op_pass_setup builds it (ops_dispatch.c:207-290,
+    620-690): planes are integer addresses (host or device)"""
+    e = Exec(width=w, height=h, slice_h=h)
+    rd, wr = lst.read, lst.write
+    _, bi = rw_geometry(rd)
+    _, bo = rw_geometry(wr)
+    keep = []
+    nb = (w + block - 1) // block
+    for i in range(4):
+        e.in_[i] = src_planes[i] if i < len(src_planes) else None
+        e.out[i] = dst_planes[i] if i < len(dst_planes) else None
+        e.in_stride[i] = src_strides[i] if i < len(src_strides) else 0
+        e.out_stride[i] = dst_strides[i] if i < len(dst_strides) else 0
+        e.block_size_in[i], e.block_size_out[i] = block * bi >> 3, block * bo >> 3
+        e.in_bump[i] = e.in_stride[i] - nb * e.block_size_in[i]
+        e.out_bump[i] = e.out_stride[i] - nb * e.block_size_out[i]
+    if rd.uop == READ_PLANAR_FV:
+        k = rd.data.kernel.contents
+        o = np.ctypeslib.as_array(k.offsets, (k.dst_size,))
+        b = np.zeros(k.dst_size, np.int32)
+        b[:-1] = o[1:] - o[:-1] - 1
+        keep.append(b)
+        e.in_bump_y = b.ctypes.data_as(C.POINTER(C.c_int32))
+        for i in range(4):
+            if e.in_[i]:
+                e.in_[i] += int(o[0]) * e.in_stride[i]
+    elif rd.uop == READ_PLANAR_FH:
+        k = rd.data.kernel.contents
+        o = np.ctypeslib.as_array(k.offsets, (k.dst_size,))
+        n = nb * block
+        b = np.full(n, int(o[-1]) * bi >> 3, np.int32)
+        b[:k.dst_size] = o.astype(np.int64) * bi >> 3
+        keep.append(b)
+        e.in_offset_x = b.ctypes.data_as(C.POINTER(C.c_int32))
+        for i in range(4):
+            e.block_size_in[i] = 0
+            e.in_bump[i] = e.in_stride[i]
+    e._keep = keep
+    return e

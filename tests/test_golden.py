@@ -317,3 +317,19 @@ def test_fft_golden():
                 out = np.zeros(n, np.float32)
                 O.ffo_dct_run(inv, n, 1.0, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p))
                 assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), ("dct", n, inv)
+
+
+def test_sws_uops_golden():
+    """SwsOpBackend row: the oracle's interpreter on the micro-op lists of real conversions == backend_c's committed output"""
+    import swsops as S
+    O = ffi.oracle()
+    g = S.declare(O, "ffo_sws_uops_")
+    cases = S.golden_cases(os.path.join(os.path.dirname(__file__), "golden", "sws_uops.npz"))
+    assert len(cases) >= 10
+    for name, size, lst, src, dst in cases:
+        h = C.c_void_p()
+        assert g("compile")(lst.uops, lst.n, C.byref(h)) == 0, name
+        got, _ = S.run_golden(g("func"), h, g("block_size")(h), lst, size, src, [d.shape for d in dst])
+        g("free")(C.byref(h))
+        for i, (a, b) in enumerate(zip(got, dst)):
+            assert np.array_equal(a, b), (name, size, "plane %d: %d bytes differ" % (i, (a != b).sum()))

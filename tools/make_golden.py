@@ -455,12 +455,51 @@ def fdsp():
     np.savez_compressed(os.path.join(OUT, "fdsp.npz"), **d)
 
 
+SWS_UOPS_CASES = [   # conversions the reference compiles into ONE micro-op list with planes in natural order
+    ("yuv444p", "rgb24", (70, 9, 70, 9), {}), ("rgb24", "yuv444p", (70, 9, 70, 9), {}), ("rgb565le", "rgb24", (66, 5, 66, 5), {}),
+    ("rgb24", "rgb565le", (66, 5, 66, 5), {}), ("gray", "monob", (64, 6, 64, 6), {}), ("yuv444p10le", "rgb48le", (34, 4, 34, 4), {}),
+    ("gbrpf32le", "gbrpf32le", (48, 6, 96, 6), {}), ("yuv444p", "yuv444p", (64, 12, 64, 24), {"scaler": 1}),
+    ("gray", "gray", (40, 8, 96, 8), {}), ("rgba", "argb", (33, 3, 33, 3), {}), ("yuv444p", "rgb24", (64, 8, 128, 8), {}),
+]
+
+
+def sws_uops():
+    """SwsOpBackend row: the micro-op lists of real conversions as the reference's graph cuts them, a seeded
+    source picture, and backend_c's output for it"""
+    import swsops as S
+    S.declare_ref(R)
+    O = ffi.oracle()
+    d = {"ncases": np.array([len(SWS_UOPS_CASES)], np.int32)}
+    for j, (sf, df, size, kw) in enumerate(SWS_UOPS_CASES):
+        lists = S.capture_lists(R, O, sf, df, size, **kw)
+        assert len(lists) == 1, (sf, df, size, len(lists))
+        for k, v in S.pack_lists(lists).items():
+            d["c%d_%s" % (j, k)] = v
+        rng = np.random.default_rng(900 + j)
+        sw, sh, dw, dh = size
+        src, dst = S.Picture(R, sf, sw, sh, slack=1024), S.Picture(R, df, dw, dh, slack=1024)
+        for rows in src.payload(R):
+            if sf == "gbrpf32le":
+                rows[:] = rng.random((rows.shape[0], rows.shape[1] // 4)).astype(np.float32).view(np.uint8)
+            else:
+                rows[:] = rng.integers(0, 256, rows.shape, dtype=np.uint8)
+        S.unbind(R)
+        assert S.convert(R, S.BACKEND_C | S.BACKEND_MEMCPY, src, dst, **kw) >= 0
+        d["c%d_size" % j] = np.array(size, np.int32)
+        d["c%d_name" % j] = np.frombuffer(("%s %s" % (sf, df)).encode(), np.uint8)
+        for i, rows in enumerate(src.payload(R)):
+            d["c%d_src%d" % (j, i)] = rows.copy()
+        for i, rows in enumerate(dst.payload(R)):
+            d["c%d_dst%d" % (j, i)] = rows.copy()
+    np.savez_compressed(os.path.join(OUT, "sws_uops.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
