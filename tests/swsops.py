@@ -225,7 +225,7 @@ class Case:
             e.in_bump[i], e.out_bump[i] = STRIDE - read_size, STRIDE - write_size
             e.block_size_in[i], e.block_size_out[i] = block * self.bits_in >> 3, block * self.bits_out >> 3
         if rd.uop == READ_PALETTE:
-            e.in_[1] = src[1].ctypes.data
+            e.in_[1] = src[1].ctypes.data + off
             e.in_bump[1] = e.in_stride[1] = 0
         self._tabs = []
         if rd.uop == READ_PLANAR_FV:
