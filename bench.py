@@ -465,7 +465,50 @@ def extras(torch, dev):
     out["dct3_1024"] = {"Mtransforms/s": round(nt / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                         "transforms": nt, "ms": round(ms, 4)}
     f.close()
+    out.update(sws_ops_leg(torch, dev))
     return out
+
+
+def sws_ops_leg(torch, dev):
+    """SwsOpBackend `hip`: micro-op lists of real conversions (tests/golden/sws_uops.npz, as the reference's graph
+    cut them) on device-resident 4K pictures, 16 per launch.  Algorithmic bytes: what the read and the write of the list move."""
+    from ffmpeg_amd import swsops as O
+    res = {}
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "sws_uops.npz"))
+    want = {"yuv444p rgb24": "sws_ops_yuv444p_rgb24_4k", "rgb24 yuv444p": "sws_ops_rgb24_yuv444p_4k", "rgba argb": "sws_ops_rgba_argb_4k",
+            "yuv444p10le rgb48le": "sws_ops_yuv444p10_rgb48_4k"}
+    w, h, nf = 3840, 2160, 16
+    for j in range(int(z["ncases"][0])):
+        name = bytes(z["c%d_name" % j]).decode()
+        size = tuple(int(v) for v in z["c%d_size" % j])
+        if name not in want or size[0] != size[2] or size[1] != size[3] or want[name] in res:
+            continue
+        lst = O.load_lists(z, "c%d_" % j)[0]
+        cu = O.CompiledUOps(lst.uops, lst.n)
+        pin, bin_ = O.rw_geometry(lst.read)
+        pout, bout = O.rw_geometry(lst.write)
+        ls_in, ls_out = w * bin_ // 8, w * bout // 8
+        src = [torch.randint(0, 256, (nf, h, ls_in), dtype=torch.uint8, device=dev) for c in range(4) if pin >> c & 1]
+        dst = [torch.empty((nf, h, ls_out), dtype=torch.uint8, device=dev) for c in range(4) if pout >> c & 1]
+        e = O.plain_exec(lst, [t.data_ptr() for t in src], [ls_in] * len(src), [t.data_ptr() for t in dst], [ls_out] * len(dst), w, h,
+                         cu.block_size)
+        ip, op = [h * ls_in] * len(src) + [0] * (4 - len(src)), [h * ls_out] * len(dst) + [0] * (4 - len(dst))
+        for _ in range(2):
+            cu.run_dev(e, w, h, nf, ip, op)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            cu.run_dev(e, w, h, nf, ip, op)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        byt = nf * h * (ls_in * len(src) + ls_out * len(dst))
+        res[want[name]] = {"Mpixels/s": round(nf * w * h / (ms * 1e-3) / 1e6, 1), "GB/s": round(byt / (ms * 1e-3) / 1e9, 1),
+                           "hbm_frac": round(byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frames": nf, "ms": round(ms, 4),
+                           "uops": lst.n}
+        cu.close()
+        del src, dst
+    return res
 
 
 def idct_leg(torch, dist, dev, world, reps=5):

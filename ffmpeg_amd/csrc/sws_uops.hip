@@ -135,9 +135,14 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
       "template <> __device__ __forceinline__ u32 put<f32>(f32 v) { return __builtin_bit_cast(u32, v); }\n"
       "#define V %d\n"
       "#define EACH for (int i = 0; i < V; i++)\n"
-      "template <bool FULL> __device__ __forceinline__ void body(const KArgs &a, const u8 *const *in, u8 *const *out, const int p,\n"
-      "                                                          const int n, const int xabs, const int yabs)\n{\n"
-      "    u32 r[4][V] = {}; u32 tmp[V] = {}; (void)tmp; (void)xabs; (void)yabs; (void)in;\n", MAXDATA, V);
+      "typedef u32 u32v __attribute__((ext_vector_type(V)));\n"
+      "/* FULL: all V pixels of the thread exist; XAL: the thread's first pixel is a multiple of V in the picture */\n"
+      "template <bool FULL, bool XAL> __device__ __forceinline__ void body(const KArgs &a, const u8 *__restrict__ in0,\n"
+      "    const u8 *__restrict__ in1, const u8 *__restrict__ in2, const u8 *__restrict__ in3, u8 *__restrict__ out0,\n"
+      "    u8 *__restrict__ out1, u8 *__restrict__ out2, u8 *__restrict__ out3, const int p, const int n, const int xabs, const int yabs)\n{\n"
+      "    u32 r[4][V] = {}; u32 tmp[V] = {};\n"
+      "    (void)tmp; (void)xabs; (void)yabs; (void)in0; (void)in1; (void)in2; (void)in3; (void)out0; (void)out1; (void)out2; (void)out3;\n",
+      MAXDATA, V);
 
     for (int k = 0; k < n_uops; k++) {
         const FFHipSwsUOp &u = uops[k];
@@ -149,7 +154,7 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
         case FFHIP_SWS_UOP_READ_PLANAR:
             FOR_MASK(c) {
                 pl.adv_in[c] = 8 * ts;
-                o("    { %s v[V]; const u8 *s = in[%d] + (long)p * %d;\n"
+                o("    { %s v[V]; const u8 *s = in%d + (long)p * %d;\n"
                   "      if (FULL) __builtin_memcpy(v, s, sizeof v); else EACH if (i < n) __builtin_memcpy(&v[i], s + i * %d, %d); else v[i] = 0;\n"
                   "      EACH r[%d][i] = put<%s>(v[i]); }\n", T, c, ts, ts, ts, c, T);
             }
@@ -157,7 +162,7 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
         case FFHIP_SWS_UOP_READ_PACKED: {
             const int el = (u.mask & 8) ? 4 : (u.mask & 4) ? 3 : (u.mask & 2) ? 2 : 1;
             pl.adv_in[0] = 8 * ts * el;
-            o("    { %s v[V * %d]; const u8 *s = in[0] + (long)p * %d;\n"
+            o("    { %s v[V * %d]; const u8 *s = in0 + (long)p * %d;\n"
               "      if (FULL) __builtin_memcpy(v, s, sizeof v); else for (int i = 0; i < V * %d; i++) if (i < n * %d) __builtin_memcpy(&v[i], s + i * %d, %d); else v[i] = 0;\n",
               T, el, ts * el, el, el, ts, ts);
             FOR_MASK(c) if (c < el) o("      EACH r[%d][i] = put<%s>(v[%d * i + %d]);\n", c, T, el, c);
@@ -168,20 +173,20 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
             if (u.type != FFHIP_SWS_PIXEL_U8)
                 BAD("sws uops: 4-bit read of a %s plane", T);
             pl.adv_in[0] = 4;
-            o("    EACH if (i < n) { const u8 b = in[0][(p + i) >> 1]; r[0][i] = (i & 1) ? (b & 0xF) : (b >> 4); }\n");
+            o("    EACH if (i < n) { const u8 b = in0[(p + i) >> 1]; r[0][i] = (i & 1) ? (b & 0xF) : (b >> 4); }\n");
             break;
         case FFHIP_SWS_UOP_READ_BIT:
             if (u.type != FFHIP_SWS_PIXEL_U8)
                 BAD("sws uops: 1-bit read of a %s plane", T);
             pl.adv_in[0] = 1;
-            o("    EACH if (i < n) { const u8 b = in[0][(p + i) >> 3]; r[0][i] = (b >> (7 - (i & 7))) & 1; }\n");
+            o("    EACH if (i < n) { const u8 b = in0[(p + i) >> 3]; r[0][i] = (b >> (7 - (i & 7))) & 1; }\n");
             break;
         case FFHIP_SWS_UOP_READ_PALETTE:
             if (u.type != FFHIP_SWS_PIXEL_U8)
                 BAD("sws uops: palette read of a %s plane", T);
             pl.adv_in[0] = 8;
             pl.palette = true;
-            o("    EACH if (i < n) { const u8 *e = in[1] + 4 * (int)in[0][p + i]; r[0][i] = e[0]; r[1][i] = e[1]; r[2][i] = e[2]; r[3][i] = e[3]; }\n");
+            o("    EACH if (i < n) { const u8 *e = in1 + 4 * (int)in0[p + i]; r[0][i] = e[0]; r[1][i] = e[1]; r[2][i] = e[2]; r[3][i] = e[3]; }\n");
             break;
         case FFHIP_SWS_UOP_READ_PLANAR_FH: {
             const FFHipSwsFilterWeights *f = u.data.kernel;
@@ -199,7 +204,7 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
             const char *acc = u.type == FFHIP_SWS_PIXEL_U8 ? "i32" : u.type == FFHIP_SWS_PIXEL_F32 ? "f32" : "i64";
             o("    EACH if (i < n) { const i32 *wt = (const i32 *)a.data[%d] + (long)%d * (xabs + i); const i32 off = a.offx[xabs + i];\n", d, f->filter_size);
             FOR_MASK(c) {
-                o("      { const u8 *s = in[%d] + off; %s acc = 0;\n"
+                o("      { const u8 *s = in%d + off; %s acc = 0;\n"
                   "        for (int j = 0; j < %d; j++) { %s t; __builtin_memcpy(&t, s + j * %d, %d); acc += wt[j] * t; }\n"
                   "        r[%d][i] = put<f32>((f32)acc * %s); }\n",
                   c, acc, f->filter_size, T, ts, ts, c, "__builtin_bit_cast(f32, 0x38800000u)" /* 1.0f / 16384 */);
@@ -224,7 +229,7 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
             o("    { const f32 *wt = (const f32 *)a.data[%d] + (long)%d * yabs;\n", d, f->filter_size);
             FOR_MASK(c) {
                 pl.adv_in[c] = 8 * ts;
-                o("      { f32 acc[V]; EACH acc[i] = 0.0f; const u8 *s = in[%d] + (long)p * %d;\n"
+                o("      { f32 acc[V]; EACH acc[i] = 0.0f; const u8 *s = in%d + (long)p * %d;\n"
                   "        for (int j = 0; j < %d; j++, s += a.in_stride[%d]) { const f32 w = wt[j]; %s v[V];\n"
                   "          if (FULL) __builtin_memcpy(v, s, sizeof v); else EACH if (i < n) __builtin_memcpy(&v[i], s + i * %d, %d); else v[i] = 0;\n"
                   "          EACH acc[i] += w * v[i]; }\n"
@@ -237,7 +242,7 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
         case FFHIP_SWS_UOP_WRITE_PLANAR:
             FOR_MASK(c) {
                 pl.adv_out[c] = 8 * ts;
-                o("    { %s v[V]; EACH v[i] = get<%s>(r[%d][i]); u8 *d = out[%d] + (long)p * %d;\n"
+                o("    { %s v[V]; EACH v[i] = get<%s>(r[%d][i]); u8 *d = out%d + (long)p * %d;\n"
                   "      if (FULL) __builtin_memcpy(d, v, sizeof v); else EACH if (i < n) __builtin_memcpy(d + i * %d, &v[i], %d); }\n",
                   T, T, c, c, ts, ts, ts);
             }
@@ -245,7 +250,7 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
         case FFHIP_SWS_UOP_WRITE_PACKED: {
             const int el = (u.mask & 8) ? 4 : (u.mask & 4) ? 3 : (u.mask & 2) ? 2 : 1;
             pl.adv_out[0] = 8 * ts * el;
-            o("    { %s v[V * %d]; u8 *d = out[0] + (long)p * %d;\n", T, el, ts * el);
+            o("    { %s v[V * %d]; u8 *d = out0 + (long)p * %d;\n", T, el, ts * el);
             bool all = true;
             for (int c = 0; c < el; c++)
                 if (u.mask >> c & 1)
@@ -267,13 +272,13 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
             if (u.type != FFHIP_SWS_PIXEL_U8)
                 BAD("sws uops: 4-bit write of a %s plane", T);
             pl.adv_out[0] = 4;
-            o("    for (int i = 0; i < V; i += 2) if (i < n) out[0][(p + i) >> 1] = (u8)(get<u8>(r[0][i]) << 4 | get<u8>(r[0][i + 1]));\n");
+            o("    for (int i = 0; i < V; i += 2) if (i < n) out0[(p + i) >> 1] = (u8)(get<u8>(r[0][i]) << 4 | get<u8>(r[0][i + 1]));\n");
             break;
         case FFHIP_SWS_UOP_WRITE_BIT:
             if (u.type != FFHIP_SWS_PIXEL_U8)
                 BAD("sws uops: 1-bit write of a %s plane", T);
             pl.adv_out[0] = 1;
-            o("    if (n > 0) { u32 b = 0; EACH b |= (u32)get<u8>(r[0][i]) << (7 - i); out[0][p >> 3] = (u8)b; }\n");
+            o("    if (n > 0) { u32 b = 0; EACH b |= (u32)get<u8>(r[0][i]) << (7 - i); out0[p >> 3] = (u8)b; }\n");
             break;
         /* ---- register moves (uops_tmpl.c:357-407): sequential, register -1 is the temporary ---- */
         case FFHIP_SWS_UOP_PERMUTE:
@@ -374,9 +379,15 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
             if (d < 0)
                 BAD("sws uops: too many data buffers");
             /* uops_tmpl.c:737-765: row (y & (size - 1)) + y_offset[c], column x & (size - 1) */
+            /* the V columns of a thread are adjacent and, when the thread starts on a multiple of V, do not wrap: one vector load */
             o("    { const u32 *m = (const u32 *)a.data[%d] + (yabs & %d) * %d;\n", d, size - 1, size);
-            FOR_MASK(c) o("      EACH { %s x = get<%s>(r[%d][i]); x += get<%s>(m[%d + ((xabs + i) & %d)]); r[%d][i] = put<%s>(x); }\n", T, T, c, T,
-                          u.par.dither.y_offset[c] * size, size - 1, c, T);
+            FOR_MASK(c) {
+                o("      { u32 dv[V]; const u32 *mr = m + %d;\n", u.par.dither.y_offset[c] * size);
+                if (size >= V)
+                    o("        if (XAL) { const u32v t = *(const u32v *)(mr + (xabs & %d)); EACH dv[i] = t[i]; } else\n", size - 1);
+                o("        EACH dv[i] = mr[(xabs + i) & %d];\n", size - 1);
+                o("        EACH { %s x = get<%s>(r[%d][i]); x += get<%s>(dv[i]); r[%d][i] = put<%s>(x); } }\n", T, T, c, T, c, T);
+            }
             o("    }\n");
             break;
         }
@@ -409,21 +420,37 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
             BAD("sws uops: unknown micro-op %d", u.uop);
         }
     }
-    /* one thread: V adjacent pixels of one line; 64 x 4 threads: 256 pixels of 4 lines; z: the picture of a batch */
+    /* one thread: V adjacent pixels of one line; 64 x 4 threads: 256 pixels of 4 lines (a wave is one line: the line number, the
+     * plane pointers of the line and the dither row live in SGPRs); z: the picture of a batch */
+    int used_in = 0, used_out = 0;
+    for (int c = 0; c < 4; c++) {
+        used_in |= (pl.adv_in[c] || (pl.fh_mask >> c & 1)) << c;
+        used_out |= (pl.adv_out[c] != 0) << c;
+    }
+    if (pl.palette)
+        used_in |= 2;
     o("}\n"
       "extern \"C\" __global__ __launch_bounds__(256) void sws_uops(const KArgs a)\n{\n"
       "    const int p = (blockIdx.x * 64 + threadIdx.x) * V;\n"
       "    if (p >= a.npx) return;\n"
       "    const int n = a.npx - p < V ? a.npx - p : V;\n"
-      "    for (int rr = blockIdx.y * 4 + threadIdx.y; rr < a.ny; rr += gridDim.y * 4) {\n"
-      "        const u8 *in[4]; u8 *out[4];\n"
-      "        const long skip = a.rowtab ? a.rowtab[rr] : 0;\n"
-      "        for (int c = 0; c < 4; c++) {\n"
-      "            in[c]  = a.in[c]  + blockIdx.z * a.in_pitch[c]  + rr * a.in_step[c] + skip * a.in_stride[c];\n"
-      "            out[c] = a.out[c] + blockIdx.z * a.out_pitch[c] + rr * a.out_step[c];\n"
-      "        }\n"
-      "        if (n == V) body<true>(a, in, out, p, n, a.x0 + p, a.y0 + rr);\n"
-      "        else        body<false>(a, in, out, p, n, a.x0 + p, a.y0 + rr);\n"
+      "    const bool xal = !(a.x0 & (V - 1));\n"
+      "    for (int rr = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y); rr < a.ny; rr += gridDim.y * 4) {\n"
+      "        const long skip = a.rowtab ? a.rowtab[rr] : 0; (void)skip;\n");
+    for (int c = 0; c < 4; c++) {
+        if (used_in >> c & 1)
+            o("        const u8 *in%d = a.in[%d] + blockIdx.z * a.in_pitch[%d] + rr * a.in_step[%d] + skip * a.in_stride[%d];\n", c, c, c, c, c);
+        else
+            o("        const u8 *in%d = nullptr;\n", c);
+        if (used_out >> c & 1)
+            o("        u8 *out%d = a.out[%d] + blockIdx.z * a.out_pitch[%d] + rr * a.out_step[%d];\n", c, c, c, c);
+        else
+            o("        u8 *out%d = nullptr;\n", c);
+    }
+    o("        const int xabs = a.x0 + p, yabs = a.y0 + rr;\n"
+      "#define BODY(F, X) body<F, X>(a, in0, in1, in2, in3, out0, out1, out2, out3, p, n, xabs, yabs)\n"
+      "        if (n == V) { if (xal) BODY(true, true); else BODY(true, false); }\n"
+      "        else        { if (xal) BODY(false, true); else BODY(false, false); }\n"
       "    }\n"
       "}\n");
     pl.src = std::move(o.s);
@@ -616,7 +643,13 @@ int launch(FFHipSwsUOps *p, KArgs &a, int nframes, hipStream_t st)
     if (a.npx <= 0 || a.ny <= 0 || nframes <= 0)
         return 0;
     const int groups = cdiv(a.npx, p->plan.V);
-    unsigned gy = cdiv(a.ny, 4);
+    /* lines per thread: a wave that converts 256 pixels and retires is mostly launch and address set-up; 8 lines per thread keeps
+     * >= 4 workgroups per CU in flight on pictures from SD up, smaller jobs fall back to fewer lines */
+    static const int rows_env = getenv("FFHIP_UOPS_ROWS") ? atoi(getenv("FFHIP_UOPS_ROWS")) : 0;
+    int rows = rows_env > 0 ? rows_env : 8;
+    while (rows > 1 && (long)cdiv(groups, 64) * cdiv(a.ny, 4 * rows) * nframes < 2048)
+        rows >>= 1;
+    unsigned gy = cdiv(a.ny, 4 * rows);
     if (gy > 16384)
         gy = 16384;
     size_t sz = sizeof a;
