@@ -11,6 +11,7 @@ i8p = C.POINTER(C.c_int8)
 i16p = C.POINTER(C.c_int16)
 i32p = C.POINTER(C.c_int32)
 vp = C.c_void_p
+EINVAL, ENOMEM, ENOSYS, EIO = -22, -12, -38, -5   # FFHIP_E* (include/ffhip.h)
 
 
 class SwsFilter(C.Structure):
@@ -102,6 +103,9 @@ def lib():
         "ffhip_h264_picture_idct_add": (C.c_int, [vp, C.c_int, C.c_int, C.c_int32, vp]),
         "ffhip_h264_picture_deblock_mb": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
         "ffhip_h264_picture_flush": (C.c_int, [vp, vp, vp, vp, vp]),
+        "ffhip_h264_picture_intra_mb": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        "ffhip_h264_intra_pack": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int32]),
+        "ffhip_h264_intra_frame_dev": (C.c_int, [vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp, vp, vp]),
         "ffhip_h264_deblock_frames_chroma_dev": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_deblock_frames_dev": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_qpel_batch_dev": (C.c_int, [vp, vp, C.c_ssize_t, vp, C.c_int, vp]),

@@ -8,11 +8,15 @@
  * picture — the same operands it would have passed — and flush() runs them as a handful of launches in the one order that
  * preserves the reference's data flow:
  *
- *     per plane:  MC put -> dst | MC put -> bi-pred scratch | MC avg -> dst | weight / biweight | IDCT + add | deblock (frame order)
+ *     per plane:  MC put -> dst | MC put -> bi-pred scratch | MC avg -> dst | weight / biweight | IDCT + add |
+ *                 intra macroblocks (all planes, reconstruction wavefront) | deblock (frame order)
  *
- * Blocks of one stage are disjoint, stages depend on each other only in that order; deblocking is the decoder-order wavefront.
+ * Blocks of one stage are disjoint, stages depend on each other only in that order.  Intra macroblocks predict from their
+ * neighbours' reconstructed, unfiltered samples — inter neighbours are complete after the residual stage, intra ones chain
+ * through k_h264_intra_frame's wavefront (kernels/h264_intra.hip); deblocking is the decoder-order wavefront behind it.
  * Records travel in ONE host-to-device copy per picture from a pinned buffer.  Entropy decoding stays on the CPU.
  */
+#include <algorithm>
 #include <new>
 #include <string.h>
 #include <vector>
@@ -43,6 +47,10 @@ struct FFHipH264Picture {
     std::vector<FFHipWeightBlock> wt[3];          /* weight / biweight per plane           */
     std::vector<int32_t> idct_off[3][4];          /* per plane x FFHIP_H264_IDCT* kind     */
     std::vector<int16_t> idct_coef[3][4];
+    std::vector<FFHipH264IntraMB> intra;          /* intra macroblocks in recording order   */
+    std::vector<int16_t> intra_coef;              /* their packed coefficient runs          */
+    std::vector<FFHipH264IntraMB> intra_sorted;   /* flush(): by (mb_y, mb_x)               */
+    std::vector<int32_t> intra_rows;              /* flush(): mb_h + 1 row starts           */
     std::vector<FFHipH264Edge> edges[3];          /* whole-picture edge arrays, zero = skip */
     bool any_edge[3] = { false, false, false };
     void *pinned = nullptr, *dev = nullptr;
@@ -93,6 +101,8 @@ extern "C" void ffhip_h264_picture_begin(FFHipH264Picture *p)
         p->cmc[0][s].clear();
         p->cmc[1][s].clear();
     }
+    p->intra.clear();
+    p->intra_coef.clear();
     for (int pl = 0; pl < 3; pl++) {
         p->wt[pl].clear();
         for (int k = 0; k < 4; k++) {
@@ -188,6 +198,126 @@ extern "C" int ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int
     return 0;
 }
 
+/* scan8[] (libavcodec/h264_parse.h:40-57): luma block i, chroma block k of plane pl (1 Cb, 2 Cr), and the three DC entries */
+static int scan8_luma(int i) { return 4 + (i & 1) + ((i >> 2) & 1) * 2 + (1 + ((i >> 1) & 1) + ((i >> 3) & 1) * 2) * 8; }
+static int scan8_chroma(int pl, int k) { return 4 + (k & 1) + (5 * pl + 1 + (k >> 1)) * 8; }
+
+extern "C" int ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_t *mb, const int16_t *mb_luma_dc, const uint8_t *pcm,
+                                     int16_t *coefs, int32_t *ncoefs, int32_t cap)
+{
+    if (!rec || !coefs || !ncoefs || rec->type > FFHIP_H264_INTRA_PCM || *ncoefs < 0)
+        return FFHIP_EINVAL;
+    FFHipH264IntraMB &R = *rec;
+    R.flags = 0;
+    memset(R.pad, 0, sizeof(R.pad));
+    memset(R.nnz, 0, sizeof(R.nnz));
+    memset(R.luma_dc, 0, sizeof(R.luma_dc));
+    R.blocks = 0;
+    int32_t n = (*ncoefs + 7) & ~7; /* runs start on 16 bytes */
+    if ((int64_t)n + 384 > cap)
+        return FFHIP_ENOMEM;
+    for (int32_t i = *ncoefs; i < n; i++)
+        coefs[i] = 0;
+    R.coef = n;
+    if (R.type == FFHIP_H264_INTRA_PCM) {
+        if (!pcm)
+            return FFHIP_EINVAL;
+        memcpy(coefs + n, pcm, 384);
+        *ncoefs = n + 192;
+        return 0;
+    }
+    if (!nnzc || !mb)
+        return FFHIP_EINVAL;
+    /* a block travels when the dsp function hl_decode_mb() would call on it reads it; the caller's copy is consumed the way that
+     * function consumes it: zeroed by idct_add / idct8_add (h264idct_template.c:66,142), [0] = 0 by the dc forms (:150,166) */
+    auto take = [&](int16_t *b, int cnt, bool full) {
+        memcpy(coefs + n, b, sizeof(int16_t) * cnt);
+        n += cnt;
+        if (full)
+            memset(b, 0, sizeof(int16_t) * cnt);
+        else
+            b[0] = 0;
+    };
+    if (R.type == FFHIP_H264_INTRA_4x4) {
+        for (int i = 0; i < 16; i++) {
+            const int nnz = nnzc[scan8_luma(i)];
+            R.nnz[i] = (uint8_t)nnz;
+            if (nnz) {
+                R.blocks |= 1u << i;
+                take(mb + i * 16, 16, !(nnz == 1 && mb[i * 16]));
+            }
+        }
+    } else if (R.type == FFHIP_H264_INTRA_8x8) {
+        for (int i = 0; i < 16; i += 4) {
+            const int nnz = nnzc[scan8_luma(i)];
+            R.nnz[i] = (uint8_t)nnz;
+            if (nnz) {
+                R.blocks |= 1u << i;
+                take(mb + i * 16, 64, !(nnz == 1 && mb[i * 16]));
+            }
+        }
+    } else {
+        if (nnzc[0]) { /* scan8[LUMA_DC_BLOCK_INDEX]: luma_dc_dequant_idct writes the 16 DC positions of sl->mb (h264_mb.c:707-711) */
+            if (!mb_luma_dc)
+                return FFHIP_EINVAL;
+            R.flags |= FFHIP_H264_INTRA_LUMA_DC;
+            memcpy(R.luma_dc, mb_luma_dc, sizeof(R.luma_dc));
+        }
+        for (int i = 0; i < 16; i++) { /* idct_add16intra (h264idct_template.c:191-200) */
+            const int nnz = nnzc[scan8_luma(i)];
+            R.nnz[i] = (uint8_t)nnz;
+            if (nnz || mb[i * 16]) {
+                R.blocks |= 1u << i;
+                take(mb + i * 16, 16, nnz != 0);
+            }
+        }
+    }
+    if (R.cbp & 0x30) { /* chroma_dc_dequant_idct + idct_add8 (h264_mb_template.c:246-258, h264idct_template.c:216-228) */
+        for (int pl = 1; pl < 3; pl++) {
+            if (nnzc[40 * pl]) /* scan8[CHROMA_DC_BLOCK_INDEX + pl - 1] */
+                R.flags |= (uint8_t)(FFHIP_H264_INTRA_CB_DC << (pl - 1));
+            for (int k = 0; k < 4; k++) {
+                int16_t *b = mb + 256 * pl + 16 * k;
+                const int nnz = nnzc[scan8_chroma(pl, k)];
+                R.nnz[16 + 4 * (pl - 1) + k] = (uint8_t)nnz;
+                if (nnz || b[0]) {
+                    R.blocks |= 1u << (16 + 4 * (pl - 1) + k);
+                    take(b, 16, nnz != 0);
+                }
+            }
+        }
+    }
+    *ncoefs = n;
+    return 0;
+}
+
+extern "C" int ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264IntraMB *d, const uint8_t *nnzc, int16_t *mb,
+                                           const int16_t *mb_luma_dc, const uint8_t *pcm)
+{
+    if (!p || !d || d->mb_x < 0 || d->mb_x >= p->mb_w || d->mb_y < 0 || d->mb_y >= p->mb_h)
+        return FFHIP_EINVAL;
+    FFHipH264IntraMB R = *d;
+    std::vector<int16_t> &c = p->intra_coef;
+    if (c.size() > (size_t)INT32_MAX - 1024)
+        return FFHIP_EINVAL;
+    int32_t n = (int32_t)c.size();
+    c.resize((size_t)n + 400);
+    const int r = ffhip_h264_intra_pack(&R, nnzc, mb, mb_luma_dc, pcm, c.data(), &n, (int32_t)c.size());
+    c.resize((size_t)n);
+    if (r < 0)
+        return r;
+    p->intra.push_back(R);
+    return 0;
+}
+
+extern "C" int ffhip_h264_intra_frame_dev(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t stride_y, ptrdiff_t stride_c, int mb_w, int mb_h,
+                                          const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, void *stream)
+{
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_intra_frame(y, cb, cr, stride_y, stride_c, mb_w, mb_h, recs, row_start, coefs, (hipStream_t)stream);
+}
+
 /* ---- flush ------------------------------------------------------------------------------------------ */
 extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                                         void *stream_)
@@ -207,7 +337,30 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
 
     /* layout of the one staging buffer */
     size_t total = 0;
-    Section s_qpel[3], s_cmc[2][3], s_wt[3], s_ioff[3][4], s_icoef[3][4], s_edge[3];
+    Section s_qpel[3], s_cmc[2][3], s_wt[3], s_ioff[3][4], s_icoef[3][4], s_edge[3], s_intra, s_irows, s_intracoef;
+    if (!p->intra.empty()) {
+        /* the wavefront walks a row's intra macroblocks left to right: by (mb_y, mb_x), one record per macroblock */
+        p->intra_sorted = p->intra;
+        std::stable_sort(p->intra_sorted.begin(), p->intra_sorted.end(), [](const FFHipH264IntraMB &a, const FFHipH264IntraMB &b) {
+            return a.mb_y != b.mb_y ? a.mb_y < b.mb_y : a.mb_x < b.mb_x;
+        });
+        p->intra_rows.assign((size_t)p->mb_h + 1, 0);
+        for (size_t i = 0; i < p->intra_sorted.size(); i++) {
+            const FFHipH264IntraMB &a = p->intra_sorted[i];
+            if (i && a.mb_y == p->intra_sorted[i - 1].mb_y && a.mb_x == p->intra_sorted[i - 1].mb_x) {
+                ffhip_set_error("ffhip_h264_picture_flush: macroblock (%d, %d) recorded twice as intra", a.mb_x, a.mb_y);
+                return FFHIP_EINVAL;
+            }
+            p->intra_rows[(size_t)a.mb_y + 1]++;
+        }
+        for (int r = 0; r < p->mb_h; r++)
+            p->intra_rows[(size_t)r + 1] += p->intra_rows[r];
+        if (p->intra_coef.empty())
+            p->intra_coef.assign(8, 0); /* a picture of coefficient-free intra macroblocks still hands the kernel a base */
+        place(total, p->intra_sorted, s_intra);
+        place(total, p->intra_rows, s_irows);
+        place(total, p->intra_coef, s_intracoef);
+    }
     for (int s = 0; s < 3; s++) {
         place(total, p->qpel[s], s_qpel[s]);
         place(total, p->cmc[0][s], s_cmc[0][s]);
@@ -258,6 +411,11 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
         if (bytes)
             memcpy(hb + s.off, src, bytes);
     };
+    if (!p->intra.empty()) {
+        put(s_intra, p->intra_sorted.data(), p->intra_sorted.size() * sizeof(FFHipH264IntraMB));
+        put(s_irows, p->intra_rows.data(), p->intra_rows.size() * sizeof(int32_t));
+        put(s_intracoef, p->intra_coef.data(), p->intra_coef.size() * sizeof(int16_t));
+    }
     bool need_tmp[3] = { false, false, false };
     for (int s = 0; s < 3; s++) {
         put(s_qpel[s], p->qpel[s].data(), p->qpel[s].size() * sizeof(FFHipQpelBlock));
@@ -325,6 +483,11 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
             if (s_ioff[pl][k].n)
                 r = ffhip_launch_h264_idct_add(k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off),
                                                (int16_t *)(db + s_icoef[pl][k].off), s_ioff[pl][k].n, stream);
+    /* ---- intra macroblocks: every inter macroblock is complete now; one wavefront over the three planes ---- */
+    if (r >= 0 && !p->intra.empty())
+        r = ffhip_launch_h264_intra_frame(dst[0], dst[1], dst[2], stride[0], stride[1], p->mb_w, p->mb_h,
+                                          (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
+                                          (const int16_t *)(db + s_intracoef.off), stream);
     /* ---- in-loop filter, decoder order: the planes are independent, and a lone wavefront is a chain of dependent hand-offs
      * that leaves the GPU mostly idle — the chroma planes run beside the luma plane on the second stream, and as ONE launch
      * of two "pictures" when Cr follows Cb at a 4-byte aligned distance and both are filtered ---- */

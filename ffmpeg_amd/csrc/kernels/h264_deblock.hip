@@ -730,6 +730,37 @@ int ffhip_h264_deblock_check(void)
     return 0;
 }
 
+/* The same counters serve the intra reconstruction wavefront (h264_intra.hip): `nints` zeroed progress words + the fail word of
+ * a slot.  On success the pool stays locked until ffhip_h264_wavefront_slot_done() has recorded the slot's event behind the
+ * launch. */
+int ffhip_h264_wavefront_slot(int nints, int **prog, int **fail, int *slot, hipStream_t stream)
+{
+    if (nints > DB_SLOT_INTS) {
+        ffhip_set_error("ffhip_h264: %d macroblock rows exceed the supported %d", nints - 1, DB_SLOT_INTS - 1);
+        return FFHIP_EINVAL;
+    }
+    g_db_mu.lock();
+    int r = db_slot_acquire(prog, fail, slot);
+    if (r >= 0 && hipMemsetAsync(*prog, 0, (size_t)nints * sizeof(int), stream) != hipSuccess) {
+        ffhip_set_error("ffhip_h264: hipMemsetAsync of the progress counters failed");
+        r = FFHIP_EIO;
+    }
+    if (r < 0)
+        g_db_mu.unlock();
+    return r;
+}
+
+int ffhip_h264_wavefront_slot_done(int slot, hipStream_t stream)
+{
+    const hipError_t e = hipEventRecord(g_db_slot[slot].done, stream);
+    g_db_mu.unlock();
+    if (e != hipSuccess) {
+        ffhip_set_error("ffhip_h264: hipEventRecord failed: %s", hipGetErrorString(e));
+        return FFHIP_EIO;
+    }
+    return 0;
+}
+
 static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                           const FFHipH264Edge *edges, hipStream_t stream)
 {

@@ -1,0 +1,153 @@
+/*
+ * h264_intra.hip — the intra reconstruction wavefront of the H.264 picture pipeline.
+ *
+ * Intra prediction reads the reconstructed (not yet deblocked) samples of the macroblocks to the left, above-left, above and
+ * above-right, and inside a macroblock chains through the residual add from block to block (hl_decode_mb(),
+ * libavcodec/h264_mb_template.c:151-262; hl_decode_mb_predict_luma, libavcodec/h264_mb.c:612-735).  A picture's intra macroblocks
+ * are therefore one dependency graph, not a batch: per-level launches would cost ~10^4 launches per 4K I-picture.  Here ONE launch
+ * walks it: one wave per macroblock row steps through the row's intra macroblocks left to right (the inter macroblocks of the
+ * picture are complete when this launch starts — their prediction and residual stages ran before it); macroblock (x, y) starts
+ * once row y - 1 has finished every macroblock up to x + 1.  A row publishes "all macroblocks left of X are done" where X is
+ * its next intra macroblock, so a P-picture's few intra macroblocks cost a few hand-offs, and an I-picture is the full
+ * mb_w + 2 mb_h chain.  All three planes of a macroblock are reconstructed in the same step on an LDS tile (h264_intra_mb.h:
+ * the phases of one macroblock, shared with the CPU emulation that pins them against the oracle).
+ *
+ * Hand-off between rows: the protocol of k_h264_deblock_frame (h264_deblock.hip) — everything that crosses rows moves with
+ * device-scope relaxed loads and stores (the 8 XCDs' L2s are not coherent with each other), stores are acknowledged
+ * (s_waitcnt 0) before the row's counter moves, and the counter's value is awaited before the neighbour loads are issued.
+ */
+#include "common.h"
+#include "h264_intra_mb.h"
+#include "h264_kernels.h"
+
+static_assert(sizeof(FFHipH264IntraMB) == 108, "FFHipH264IntraMB is a 108-byte record");
+
+namespace {
+__device__ __forceinline__ void imb_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct ImbWave {
+    int lane;
+    template <class F>
+    __device__ __forceinline__ void run(F body)
+    {
+        body(lane);
+        imb_wave_sync();
+    }
+};
+
+__device__ __forceinline__ uint32_t ld_dev(const uint8_t *p)
+{
+    return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_dev(uint8_t *p, uint32_t v)
+{
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+} // namespace
+
+__global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                                         const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs,
+                                                         int *progress, int *fail)
+{
+    __shared__ __align__(16) ImbTile T;
+    __shared__ __align__(16) FFHipH264IntraMB R;
+    const int my = blockIdx.x, lane = threadIdx.x;
+    int k = row_start[my];
+    const int kend = row_start[my + 1];
+    /* nothing of this row is pending left of its first intra macroblock */
+    if (lane == 0)
+        __hip_atomic_store(&progress[my], k < kend ? (int)recs[k].mb_x : mb_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int known = 0; /* last value seen of progress[my - 1] */
+    ImbWave X{ lane };
+    for (; k < kend; k++) {
+        if (lane < (int)(sizeof(FFHipH264IntraMB) / 4))
+            reinterpret_cast<uint32_t *>(&R)[lane] = reinterpret_cast<const uint32_t *>(recs + k)[lane];
+        const int next = k + 1 < kend ? (int)recs[k + 1].mb_x : mb_w;
+        imb_wave_sync();
+        const int mx = R.mb_x;
+        /* ---- the row above has finished macroblock mx + 1 ---- */
+        if (my > 0) {
+            const int want = min(mx + 2, mb_w);
+            int spins = 0;
+            while (known < want) {
+                known = __hip_atomic_load(&progress[my - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (known >= want)
+                    break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                    if (lane == 0)
+                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* the neighbour loads are issued after the counter was seen */
+        }
+        /* ---- neighbours into the tile, one dword per lane; what lies outside the picture reads as 0 ---- */
+        uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16;
+        uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 };
+        const bool has_l = mx > 0, has_t = my > 0, has_r = mx + 1 < mb_w;
+        if (lane < 8) { /* the row above: columns -4 .. 27 */
+            const int c = 4 * lane - 4;
+            const bool ok = has_t && (c >= 0 || has_l) && (c < 16 || has_r);
+            *reinterpret_cast<uint32_t *>(&T.y[imb_yi(-1, c)]) = ok ? ld_dev(ymb - sy + c) : 0u;
+        } else if (lane < 24) { /* the column to the left, and zeros right of the macroblock (a top-right block that does not exist) */
+            const int r = lane - 8;
+            *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, -4)]) = has_l ? ld_dev(ymb + (ptrdiff_t)r * sy - 4) : 0u;
+            *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, 16)]) = 0u;
+            *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, 20)]) = 0u;
+        } else if (lane < 30) {
+            const int p = (lane - 24) / 3, c = 4 * ((lane - 24) % 3) - 4;
+            const bool ok = has_t && (c >= 0 || has_l);
+            *reinterpret_cast<uint32_t *>(&T.c[p][imb_ci(-1, c)]) = ok ? ld_dev(cmb[p] - sc + c) : 0u;
+        } else if (lane < 46) {
+            const int p = (lane - 30) >> 3, r = (lane - 30) & 7;
+            *reinterpret_cast<uint32_t *>(&T.c[p][imb_ci(r, -4)]) = has_l ? ld_dev(cmb[p] + (ptrdiff_t)r * sc - 4) : 0u;
+        }
+        imb_wave_sync();
+        imb_reconstruct(X, T, R, coefs);
+        /* ---- the macroblock leaves the tile: 64 + 32 dwords, write-through ---- */
+        st_dev(ymb + (ptrdiff_t)(lane >> 2) * sy + 4 * (lane & 3), *reinterpret_cast<const uint32_t *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]));
+        if (lane < 32) {
+            const int p = lane >> 4, r = (lane >> 1) & 7, c = 4 * (lane & 1);
+            st_dev(cmb[p] + (ptrdiff_t)r * sc + c, *reinterpret_cast<const uint32_t *>(&T.c[p][imb_ci(r, c)]));
+        }
+        /* acknowledged before the counter moves */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0)
+            __hip_atomic_store(&progress[my], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        imb_wave_sync(); /* R and the tile are rewritten by the next step */
+    }
+}
+
+int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                  const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream)
+{
+    if (mb_w <= 0 || mb_h <= 0)
+        return 0;
+    if (!y || !cb || !cr || !recs || !row_start || !coefs) {
+        ffhip_set_error("ffhip_h264_intra_frame: null argument");
+        return FFHIP_EINVAL;
+    }
+    if (((uintptr_t)y | (uintptr_t)cb | (uintptr_t)cr | (size_t)sy | (size_t)sc) & 3) {
+        ffhip_set_error("ffhip_h264_intra_frame: planes and strides must be 4-byte aligned");
+        return FFHIP_EINVAL;
+    }
+    int *prog, *fail, slot;
+    const int r = ffhip_h264_wavefront_slot(mb_h + 1, &prog, &fail, &slot, stream);
+    if (r < 0)
+        return r;
+    hipLaunchKernelGGL(k_h264_intra_frame, dim3(mb_h), dim3(64), 0, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog, fail);
+    const hipError_t e = hipGetLastError();
+    const int r2 = ffhip_h264_wavefront_slot_done(slot, stream);
+    if (e != hipSuccess) {
+        ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+        return FFHIP_EIO;
+    }
+    return r2;
+}

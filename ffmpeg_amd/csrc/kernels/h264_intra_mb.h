@@ -1,0 +1,450 @@
+/*
+ * h264_intra_mb.h — reconstruction of ONE intra macroblock (8 bits, 4:2:0, frame macroblock, no transform bypass): what
+ * hl_decode_mb() does between the two xchg_mb_border() calls and after them (libavcodec/h264_mb_template.c:151-262,
+ * hl_decode_mb_predict_luma / hl_decode_mb_idct_luma libavcodec/h264_mb.c:612-760):
+ *
+ *     pred8x8[chroma_pred_mode] on Cb, Cr
+ *     Intra4x4:            16 x ( pred4x4[dir]  -> idct_add / idct_dc_add )            in block order 0..15
+ *     Intra4x4 + 8x8 DCT:   4 x ( pred8x8l[dir] -> idct8_add / idct8_dc_add )
+ *     Intra16x16:          pred16x16[mode], luma_dc_dequant_idct, idct_add16intra
+ *     chroma (cbp & 0x30): chroma_dc_dequant_idct per plane, idct_add8
+ *
+ * on a TILE: the macroblock's samples plus the neighbours the predictors read (the row above running on into the top-right
+ * macroblock, the column to the left, the corner).  The code is a sequence of PHASES; inside a phase the 64 lanes are independent
+ * (no lane reads what another lane writes in the same phase), between phases the tile is synchronised.  The phase bodies are
+ * plain C++ shared by the two things that run them:
+ *
+ *   - k_h264_intra_frame (h264_intra.hip): one wave per macroblock row, tile in LDS, a phase = body(lane) + wave barrier;
+ *   - the host emulation (oracle/emul_h264_intra.cpp, test infrastructure): a phase = for (lane = 0..63) body(lane) — it pins
+ *     this logic against the oracle's restatement of hl_decode_mb() on the CPU, where there is no GPU to run the kernel.
+ *
+ * The prediction rules are the per-sample rules over the block's edge line that h264_pred.hip uses (h264pred_template.c).
+ */
+#ifndef FFHIP_H264_INTRA_MB_H
+#define FFHIP_H264_INTRA_MB_H
+#include <stdint.h>
+
+#include "ffhip.h"
+
+#if defined(__HIPCC__)
+#define IMB_FN __host__ __device__ __forceinline__
+#else
+#define IMB_FN static inline
+#endif
+
+/* ---- prediction rules over the edge line e[]: left column bottom-up, corner, row above, top-right ---- */
+IMB_FN int hp_a2(int a, int b) { return (a + b + 1) >> 1; }
+IMB_FN int hp_a3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
+
+/* neighbours a pred4x4 / pred8x8l mode reads: bit0 left, bit1 top, bit2 corner, bit3 top-right (h264pred.h:35-48 order) */
+IMB_FN unsigned hp_need(int mode)
+{
+    /* 12 nibbles, mode 0 in the low one: V=2 H=1 DC=3 DDL=a DDR=7 VR=7 HD=7 VL=a HU=1 LEFT_DC=1 TOP_DC=2 DC_128=0 */
+    return (unsigned)(0x0211a777a312ull >> (4 * mode)) & 15u;
+}
+
+template <int N>
+IMB_FN int hp_dir_sample(int mode, const int *e, int x, int y, int dc)
+{
+    const int *T = e + N + 1;
+    switch (mode) {
+    case 0: return T[x];
+    case 1: return e[N - 1 - y];
+    case 3: {
+        const int i = x + y;
+        return i < 2 * N - 2 ? hp_a3(T[i], T[i + 1], T[i + 2]) : (T[2 * N - 2] + 3 * T[2 * N - 1] + 2) >> 2;
+    }
+    case 4: {
+        const int i = N - 1 - y + x;
+        return hp_a3(e[i], e[i + 1], e[i + 2]);
+    }
+    case 5: {
+        const int d = 2 * x - y, h = d >> 1;
+        if (d < 0)
+            return hp_a3(e[N + d], e[N + d + 1], e[N + d + 2]);
+        return (d & 1) ? hp_a3(e[N + h], e[N + h + 1], e[N + h + 2]) : hp_a2(e[N + h], e[N + h + 1]);
+    }
+    case 6: {
+        const int d = 2 * y - x, h = d >> 1;
+        if (d < 0)
+            return hp_a3(e[N - d - 2], e[N - d - 1], e[N - d]);
+        return (d & 1) ? hp_a3(e[N - h], e[N - h - 1], e[N - h - 2]) : hp_a2(e[N - h], e[N - h - 1]);
+    }
+    case 7: {
+        const int i = (y >> 1) + x;
+        return (y & 1) ? hp_a3(T[i], T[i + 1], T[i + 2]) : hp_a2(T[i], T[i + 1]);
+    }
+    case 8: {
+        const int i = 2 * y + x, j = N - 1 - (i >> 1);
+        if (i >= 2 * N - 2)
+            return e[0];
+        if (i == 2 * N - 3)
+            return (e[1] + 3 * e[0] + 2) >> 2;
+        return (i & 1) ? hp_a3(e[j], e[j - 1], e[j - 2]) : hp_a2(e[j], e[j - 1]);
+    }
+    default: return dc;
+    }
+}
+
+/* the DC of modes 2 (both sides), 9 (LEFT_DC), 10 (TOP_DC); 128 otherwise */
+template <int N>
+IMB_FN int hp_dir_dc(int mode, const int *e)
+{
+    if (mode != 2 && mode != 9 && mode != 10)
+        return 128;
+    int sl = 0, st = 0;
+    for (int i = 0; i < N; i++) {
+        sl += e[i];
+        st += e[N + 1 + i];
+    }
+    return mode == 2 ? (sl + st + N) >> (N == 8 ? 4 : 3) : ((mode == 9 ? sl : st) + N / 2) >> (N == 8 ? 3 : 2);
+}
+
+/* PREDICT_8x8_LOAD_LEFT / _TOP / _TOPRIGHT / _TOPLEFT (h264pred_template.c:822-856): entry j of the low-pass filtered line from
+ * the raw line w[0..24]; entries the mode does not read are 0 */
+IMB_FN int hp_filter8(const int *w, int j, unsigned need, bool tl, bool tr)
+{
+    if (j < 8) {
+        if (!(need & 1))
+            return 0;
+        return j == 7 ? hp_a3(tl ? w[8] : w[7], w[7], w[6]) : j == 0 ? (w[1] + 3 * w[0] + 2) >> 2 : hp_a3(w[j + 1], w[j], w[j - 1]);
+    }
+    if (j == 8)
+        return (need & 4) ? hp_a3(w[7], w[8], w[9]) : 0;
+    if (j < 17) {
+        if (!(need & 2))
+            return 0;
+        return j == 9 ? hp_a3(tl ? w[8] : w[9], w[9], w[10]) : j == 16 ? hp_a3(tr ? w[17] : w[16], w[16], w[15]) : hp_a3(w[j - 1], w[j], w[j + 1]);
+    }
+    if (!(need & 8))
+        return 0;
+    return !tr ? w[16] : j == 24 ? (w[23] + 3 * w[24] + 2) >> 2 : hp_a3(w[j - 1], w[j], w[j + 1]);
+}
+
+/* ---- the tile ---- */
+struct ImbTile {
+    uint8_t y[17 * 32];    /* luma:   sample (r, c), r = -1..15, c = -4..27, at [(r + 1) * 32 + c + 4] */
+    uint8_t c[2][9 * 16];  /* chroma: sample (r, c), r = -1..7,  c = -4..11, at [(r + 1) * 16 + c + 4] */
+    int e[28], ef[28];     /* a block's edge line, raw and low-pass filtered (pred8x8l) */
+    int t8[64];            /* first pass of an 8x8 inverse transform */
+    int dcq[16];           /* luma_dc_dequant_idct's results by block */
+};
+
+IMB_FN int imb_yi(int r, int c) { return (r + 1) * 32 + c + 4; }
+IMB_FN int imb_ci(int r, int c) { return (r + 1) * 16 + c + 4; }
+IMB_FN int imb_clip_u8(int v)
+{
+    int r = v < 0 ? 0 : v > 255 ? 255 : v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(r)); /* keeps hipcc from folding neighbouring clips into v_ashr_pk_u8_i32 (common.h: its upper half is not zero) */
+#endif
+    return r;
+}
+IMB_FN int imb_popc(uint32_t v) { return __builtin_popcount(v); }
+
+/* position of 4x4 block i inside the macroblock (h->block_offset[i], h264_slice.c init_scan_tables / block_offset) */
+IMB_FN int imb_bx(int i) { return 4 * ((i & 1) + ((i >> 2) & 1) * 2); }
+IMB_FN int imb_by(int i) { return 4 * (((i >> 1) & 1) + ((i >> 3) & 1) * 2); }
+
+/* coefficients of luma block i (0..15; 8x8 transform: i = 0, 4, 8, 12, 64 coefficients) / chroma block 16 + k (Cb), 20 + k (Cr)
+ * in the macroblock's packed run; nullptr when the block was all zero and not stored */
+IMB_FN const int16_t *imb_block(const FFHipH264IntraMB &R, const int16_t *coefs, int bit)
+{
+    if (!((R.blocks >> bit) & 1u))
+        return nullptr;
+    const int lsz = R.type == FFHIP_H264_INTRA_8x8 ? 64 : 16;
+    const uint32_t below = R.blocks & ((1u << bit) - 1u);
+    return coefs + R.coef + imb_popc(below & 0xFFFFu) * lsz + imb_popc(below >> 16) * 16;
+}
+
+/* output k of the 4-point butterfly of ff_h264_idct_add (h264idct_template.c:39-64): modulo 2^32, arithmetic shifts */
+IMB_FN int imb_bfly4(int k, int s0, int s1, int s2, int s3)
+{
+    const uint32_t e0 = (uint32_t)s0 + (uint32_t)s2, e1 = (uint32_t)s0 - (uint32_t)s2;
+    const uint32_t o0 = (uint32_t)(s1 >> 1) - (uint32_t)s3, o1 = (uint32_t)s1 + (uint32_t)(s3 >> 1);
+    return (int)(k == 0 ? e0 + o1 : k == 1 ? e1 + o0 : k == 2 ? e1 - o0 : e0 - o1);
+}
+
+/* what ff_h264_idct_add adds to sample (x, y) of its block; b[0] is passed separately (Intra16x16 puts the dequantised DC there) */
+IMB_FN int imb_idct4_at(const int16_t *b, int b0, int x, int y)
+{
+    int r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int s0 = j == 0 ? (int16_t)(b0 + 32) : (b ? b[j] : 0);
+        r[j] = (int16_t)imb_bfly4(x, s0, b ? b[j + 4] : 0, b ? b[j + 8] : 0, b ? b[j + 12] : 0); /* the first pass stores int16 */
+    }
+    return imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
+}
+
+/* one 8-point pass of ff_h264_idct8_add (h264idct_template.c:69-143) */
+IMB_FN void imb_idct8_1d(const int in[8], uint32_t out[8])
+{
+    const uint32_t a0 = (uint32_t)in[0] + (uint32_t)in[4];
+    const uint32_t a2 = (uint32_t)in[0] - (uint32_t)in[4];
+    const uint32_t a4 = (uint32_t)(in[2] >> 1) - (uint32_t)in[6];
+    const uint32_t a6 = (uint32_t)(in[6] >> 1) + (uint32_t)in[2];
+    const uint32_t b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    const int a1 = (int)(-(uint32_t)in[3] + (uint32_t)in[5] - (uint32_t)in[7] - (uint32_t)(in[7] >> 1));
+    const int a3 = (int)((uint32_t)in[1] + (uint32_t)in[7] - (uint32_t)in[3] - (uint32_t)(in[3] >> 1));
+    const int a5 = (int)(-(uint32_t)in[1] + (uint32_t)in[7] + (uint32_t)in[5] + (uint32_t)(in[5] >> 1));
+    const int a7 = (int)((uint32_t)in[3] + (uint32_t)in[5] + (uint32_t)in[1] + (uint32_t)(in[1] >> 1));
+    const uint32_t b1 = (uint32_t)(a7 >> 2) + (uint32_t)a1;
+    const uint32_t b3 = (uint32_t)a3 + (uint32_t)(a5 >> 2);
+    const uint32_t b5 = (uint32_t)(a3 >> 2) - (uint32_t)a5;
+    const uint32_t b7 = (uint32_t)a7 - (uint32_t)(a1 >> 2);
+    out[0] = b0 + b7; out[7] = b0 - b7;
+    out[1] = b2 + b5; out[6] = b2 - b5;
+    out[2] = b4 + b3; out[5] = b4 - b3;
+    out[3] = b6 + b1; out[4] = b6 - b1;
+}
+
+/* pred8x8 (N = 8, with the one-sided "mad cow" DC variants) / pred16x16 (N = 16) sample (x, y); t / l index the tile's row above
+ * and left column through TOP(i) / LEFT(i), i = -1 the corner (h264pred_template.c:389-820; modes h264pred.h:67-82) */
+template <int N, class Top, class Left>
+IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT)
+{
+    constexpr int H2 = N / 2;
+    if (mode == 1)
+        return LEFT(y);
+    if (mode == 2)
+        return TOP(x);
+    if (mode == 3) {
+        int H = 0, V = 0;
+        for (int i = 1; i <= H2; i++) {
+            H += i * (TOP(H2 - 1 + i) - TOP(H2 - 1 - i));
+            V += i * (LEFT(H2 - 1 + i) - (i == H2 ? TOP(-1) : LEFT(H2 - 1 - i)));
+        }
+        H = N == 16 ? (5 * H + 32) >> 6 : (17 * H + 16) >> 5;
+        V = N == 16 ? (5 * V + 32) >> 6 : (17 * V + 16) >> 5;
+        const int a = 16 * (LEFT(N - 1) + TOP(N - 1) + 1) - (H2 - 1) * (V + H);
+        return imb_clip_u8((a + y * V + x * H) >> 5);
+    }
+    if (N == 16) {
+        int sl = 0, st = 0;
+        for (int i = 0; i < 16; i++) {
+            sl += (mode == 0 || mode == 4) ? LEFT(i) : 0;
+            st += (mode == 0 || mode == 5) ? TOP(i) : 0;
+        }
+        return mode == 0 ? (sl + st + 16) >> 5 : mode == 4 ? (sl + 8) >> 4 : mode == 5 ? (st + 8) >> 4 : 128;
+    }
+    const bool ut = mode == 0 || mode == 5 || mode == 7 || mode == 8, ul = mode == 0 || mode == 4 || mode >= 7;
+    int t0 = 0, t1 = 0, l0 = 0, l1 = 0;
+    for (int i = 0; i < 4; i++) {
+        t0 += ut ? TOP(i) : 0;
+        t1 += ut ? TOP(4 + i) : 0;
+        l0 += ul ? LEFT(i) : 0;
+        l1 += (ul && mode != 7) ? LEFT(4 + i) : 0;
+    }
+    int q0 = 128, q1 = 128, q2 = 128, q3 = 128;
+    switch (mode) {
+    case 0: q0 = (t0 + l0 + 4) >> 3; q1 = (t1 + 2) >> 2; q2 = (l1 + 2) >> 2; q3 = (t1 + l1 + 4) >> 3; break;
+    case 4: q0 = q1 = (l0 + 2) >> 2; q2 = q3 = (l1 + 2) >> 2; break;
+    case 5: q0 = q2 = (t0 + 2) >> 2; q1 = q3 = (t1 + 2) >> 2; break;
+    case 7: q0 = (t0 + l0 + 4) >> 3; q2 = (t0 + 2) >> 2; q1 = q3 = (t1 + 2) >> 2; break;
+    case 8: q0 = (t0 + 2) >> 2; q1 = (t1 + 2) >> 2; q2 = (l1 + 2) >> 2; q3 = (t1 + l1 + 4) >> 3; break;
+    case 9: q0 = q1 = (l0 + 2) >> 2; break;
+    case 10: q2 = q3 = (l1 + 2) >> 2; break;
+    default: break;
+    }
+    return (y >> 2) ? ((x >> 2) ? q3 : q2) : ((x >> 2) ? q1 : q0);
+}
+
+/*
+ * The macroblock, phase by phase.  X.run(body) runs body(lane) for the 64 lanes and synchronises the tile.
+ * T holds the neighbours (unavailable ones as 0) on entry and the reconstructed macroblock on return.
+ */
+template <class X>
+IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const int16_t *coefs)
+{
+    if (R.type == FFHIP_H264_INTRA_PCM) {
+        /* the samples as they stand in the bitstream: 256 luma, 64 Cb, 64 Cr bytes (h264_mb_template.c:137-150) */
+        const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coefs + R.coef);
+        x.run([&](int lane) {
+            for (int j = 0; j < 4; j++)
+                T.y[imb_yi(lane >> 2, 4 * (lane & 3) + j)] = pcm[16 * (lane >> 2) + 4 * (lane & 3) + j];
+            if (lane < 32)
+                for (int j = 0; j < 4; j++)
+                    T.c[lane >> 4][imb_ci((lane >> 1) & 7, 4 * (lane & 1) + j)] = pcm[256 + 64 * (lane >> 4) + 4 * (lane & 15) + j];
+        });
+        return;
+    }
+    /* ---- chroma: pred8x8 on both planes, then chroma_dc_dequant_idct + idct_add8 when cbp & 0x30; lane = 4 samples of a row.
+     *      Intra16x16 also dequantises its 16 luma DCs here (lanes 32..47) ---- */
+    x.run([&](int lane) {
+        if (lane < 32) {
+            const int p = lane >> 4, yy = (lane >> 1) & 7, x0 = 4 * (lane & 1);
+            const uint8_t *tc = T.c[p];
+            auto TOP = [&](int i) { return (int)tc[imb_ci(-1, i)]; };
+            auto LEFT = [&](int i) { return (int)tc[imb_ci(i, -1)]; };
+            const int k = (yy >> 2) * 2 + (x0 >> 2); /* chroma block 16 + k / 32 + k */
+            int dc = 0;
+            bool full = false, dconly = false;
+            const int16_t *b = nullptr;
+            if (R.cbp & 0x30) {
+                b = imb_block(R, coefs, 16 + 4 * p + k);
+                dc = b ? b[0] : 0;
+                if (R.flags & (FFHIP_H264_INTRA_CB_DC << p)) {
+                    /* chroma_dc_dequant_idct (h264idct_template.c:323-345) on the four DCs of the plane */
+                    int d4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int16_t *bq = imb_block(R, coefs, 16 + 4 * p + q);
+                        d4[q] = bq ? bq[0] : 0;
+                    }
+                    const uint32_t qm = (uint32_t)R.qmul[1 + p];
+                    uint32_t a = (uint32_t)d4[0], bb = (uint32_t)d4[1], c = (uint32_t)d4[2], d = (uint32_t)d4[3];
+                    const uint32_t e = a - bb;
+                    a = a + bb; bb = c - d; c = c + d;
+                    const uint32_t v = k == 0 ? a + c : k == 1 ? e + bb : k == 2 ? a - c : e - bb;
+                    dc = (int16_t)((int)(v * qm) >> 7);
+                }
+                full = R.nnz[16 + 4 * p + k] != 0;
+                dconly = !full && dc != 0;
+            }
+            for (int j = 0; j < 4; j++) {
+                int v = imb_pred_blk<8>(R.chroma_pred, x0 + j, yy, TOP, LEFT);
+                if (full)
+                    v = imb_clip_u8(v + imb_idct4_at(b, dc, j, yy & 3));
+                else if (dconly)
+                    v = imb_clip_u8(v + ((dc + 32) >> 6));
+                T.c[p][imb_ci(yy, x0 + j)] = (uint8_t)v;
+            }
+        } else if (lane < 48 && R.type == FFHIP_H264_INTRA_16x16 && (R.flags & FFHIP_H264_INTRA_LUMA_DC)) {
+            /* luma_dc_dequant_idct (h264idct_template.c:259-293): lane 32 + o computes output o of the 4x4 Hadamard */
+            const int o = lane - 32, i = o & 3, w = o >> 2; /* second-pass column i, output w of { z0+z3, z1+z2, z1-z2, z0-z3 } */
+            int t[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int a = R.luma_dc[4 * r], b = R.luma_dc[4 * r + 1], c = R.luma_dc[4 * r + 2], d = R.luma_dc[4 * r + 3];
+                const int z0 = a + b, z1 = a - b, z2 = c - d, z3 = c + d;
+                t[r] = i == 0 ? z0 + z3 : i == 1 ? z0 - z3 : i == 2 ? z1 - z2 : z1 + z2;
+            }
+            const uint32_t z0 = (uint32_t)t[0] + (uint32_t)t[2], z1 = (uint32_t)t[0] - (uint32_t)t[2];
+            const uint32_t z2 = (uint32_t)t[1] - (uint32_t)t[3], z3 = (uint32_t)t[1] + (uint32_t)t[3];
+            const uint32_t v = w == 0 ? z0 + z3 : w == 1 ? z1 + z2 : w == 2 ? z1 - z2 : z0 - z3;
+            /* output[16 * {0, 1, 4, 5}[w] + x_offset[i]], x_offset = {0, 32, 128, 160}: as a block number */
+            const int blk = (w == 0 ? 0 : w == 1 ? 1 : w == 2 ? 4 : 5) + (i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 8 : 10);
+            T.dcq[blk] = (int16_t)((int)(v * (uint32_t)R.qmul[0] + 128) >> 8);
+        }
+    });
+
+    if (R.type == FFHIP_H264_INTRA_16x16) {
+        /* pred16x16 + idct_add16intra (h264idct_template.c:191-200): lane = row (lane & 3) of block (lane >> 2) */
+        x.run([&](int lane) {
+            const int i = lane >> 2, yy = imb_by(i) + (lane & 3), x0 = imb_bx(i);
+            auto TOP = [&](int k) { return (int)T.y[imb_yi(-1, k)]; };
+            auto LEFT = [&](int k) { return (int)T.y[imb_yi(k, -1)]; };
+            const int16_t *b = imb_block(R, coefs, i);
+            const int dc = (R.flags & FFHIP_H264_INTRA_LUMA_DC) ? T.dcq[i] : (b ? b[0] : 0);
+            const bool full = R.nnz[i] != 0, dconly = !full && dc != 0;
+            for (int j = 0; j < 4; j++) {
+                int v = imb_pred_blk<16>(R.pred16, x0 + j, yy, TOP, LEFT);
+                if (full)
+                    v = imb_clip_u8(v + imb_idct4_at(b, dc, j, lane & 3));
+                else if (dconly)
+                    v = imb_clip_u8(v + ((dc + 32) >> 6));
+                T.y[imb_yi(yy, x0 + j)] = (uint8_t)v;
+            }
+        });
+        return;
+    }
+
+    if (R.type == FFHIP_H264_INTRA_4x4) {
+        for (int i = 0; i < 16; i++) {
+            const int bx = imb_bx(i), by = imb_by(i), mode = R.pred4[i];
+            /* the block's edge line; top-right: the samples themselves or, when the block there is not decoded yet / outside,
+             * the last sample of the row above four times (hl_decode_mb_predict_luma, h264_mb.c:672-689) */
+            const bool tr_avail = (R.topright_avail << i) & 0x8000;
+            x.run([&](int lane) {
+                if (lane < 13) {
+                    int v;
+                    if (lane < 4)
+                        v = T.y[imb_yi(by + 3 - lane, bx - 1)];
+                    else if (lane < 9)
+                        v = T.y[imb_yi(by - 1, bx + lane - 5)];
+                    else
+                        v = T.y[imb_yi(by - 1, tr_avail ? bx + lane - 5 : bx + 3)];
+                    T.e[lane] = v;
+                }
+            });
+            x.run([&](int lane) {
+                if (lane < 16) {
+                    const int xx = lane & 3, yy = lane >> 2;
+                    int v = hp_dir_sample<4>(mode, T.e, xx, yy, hp_dir_dc<4>(mode, T.e));
+                    const int nnz = R.nnz[i];
+                    if (nnz) {
+                        const int16_t *b = imb_block(R, coefs, i);
+                        const int dc = b ? b[0] : 0;
+                        if (nnz == 1 && dc)
+                            v = imb_clip_u8(v + ((dc + 32) >> 6));
+                        else
+                            v = imb_clip_u8(v + imb_idct4_at(b, dc, xx, yy));
+                    }
+                    T.y[imb_yi(by + yy, bx + xx)] = (uint8_t)v;
+                }
+            });
+        }
+        return;
+    }
+
+    /* Intra4x4 with the 8x8 transform: pred8x8l over the filtered edge line, idct8_add / idct8_dc_add */
+    for (int i = 0; i < 16; i += 4) {
+        const int bx = imb_bx(i), by = imb_by(i), mode = R.pred4[i], nnz = R.nnz[i];
+        const bool tl = (R.topleft_avail << i) & 0x8000, tr = (R.topright_avail << i) & 0x4000;
+        const unsigned need = hp_need(mode);
+        const int16_t *b = nnz ? imb_block(R, coefs, i) : nullptr;
+        const int dc = b ? b[0] : 0;
+        const bool dconly = nnz == 1 && dc, full = nnz && !dconly;
+        x.run([&](int lane) {
+            if (lane < 25) {
+                int v;
+                if (lane < 8)
+                    v = T.y[imb_yi(by + 7 - lane, bx - 1)];
+                else
+                    v = T.y[imb_yi(by - 1, bx + lane - 9)];
+                T.e[lane] = v;
+            } else if (lane >= 32 && lane < 40 && full) {
+                /* first pass of the inverse transform: transform j works on block[j + 8 k], results stored as int16 */
+                const int j = lane - 32;
+                int in[8];
+                uint32_t out[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    in[k] = b ? b[j + 8 * k] : 0;
+                if (j == 0)
+                    in[0] = (int16_t)(in[0] + 32);
+                imb_idct8_1d(in, out);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    T.t8[j + 8 * k] = (int16_t)out[k];
+            }
+        });
+        x.run([&](int lane) {
+            if (lane < 25)
+                T.ef[lane] = hp_filter8(T.e, lane, need, tl, tr);
+        });
+        x.run([&](int lane) {
+            const int xx = lane & 7, yy = lane >> 3;
+            int v = hp_dir_sample<8>(mode, T.ef, xx, yy, hp_dir_dc<8>(mode, T.ef));
+            if (full) {
+                /* second pass: transform xx works on block[8 xx + k], output yy goes to dst[xx + yy * stride] */
+                int in[8];
+                uint32_t out[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    in[k] = T.t8[8 * xx + k];
+                imb_idct8_1d(in, out);
+                uint32_t o = out[0];
+#pragma unroll
+                for (int k = 1; k < 8; k++)
+                    o = yy == k ? out[k] : o;
+                v = imb_clip_u8(v + ((int)o >> 6));
+            } else if (dconly) {
+                v = imb_clip_u8(v + ((dc + 32) >> 6));
+            }
+            T.y[imb_yi(by + yy, bx + xx)] = (uint8_t)v;
+        });
+    }
+}
+#endif

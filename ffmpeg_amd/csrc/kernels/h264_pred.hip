@@ -14,62 +14,13 @@
  * 8-bit arithmetic: one thread per column (VERT) or row (HOR), which also clears the coefficients it consumed.
  */
 #include "common.h"
+#include "h264_intra_mb.h"
 #include "h264_kernels.h"
 
 static_assert(sizeof(FFHipH264Pred) == 12, "FFHipH264Pred is a 12-byte record");
 
-__device__ __forceinline__ int hp_a2(int a, int b) { return (a + b + 1) >> 1; }
-__device__ __forceinline__ int hp_a3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
-
-/* neighbours a pred4x4 / pred8x8l mode reads: bit0 left, bit1 top, bit2 corner, bit3 top-right (h264pred.h:35-48 order) */
-__device__ __forceinline__ unsigned hp_need(int mode)
-{
-    /* 12 nibbles, mode 0 in the low one: V=2 H=1 DC=3 DDL=a DDR=7 VR=7 HD=7 VL=a HU=1 LEFT_DC=1 TOP_DC=2 DC_128=0 */
-    return (unsigned)(0x0211a777a312ull >> (4 * mode)) & 15u;
-}
-
-template <int N>
-__device__ __forceinline__ int hp_dir_sample(int mode, const int *e, int x, int y, int dc)
-{
-    const int *T = e + N + 1;
-    switch (mode) {
-    case 0: return T[x];
-    case 1: return e[N - 1 - y];
-    case 3: {
-        const int i = x + y;
-        return i < 2 * N - 2 ? hp_a3(T[i], T[i + 1], T[i + 2]) : (T[2 * N - 2] + 3 * T[2 * N - 1] + 2) >> 2;
-    }
-    case 4: {
-        const int i = N - 1 - y + x;
-        return hp_a3(e[i], e[i + 1], e[i + 2]);
-    }
-    case 5: {
-        const int d = 2 * x - y, h = d >> 1;
-        if (d < 0)
-            return hp_a3(e[N + d], e[N + d + 1], e[N + d + 2]);
-        return (d & 1) ? hp_a3(e[N + h], e[N + h + 1], e[N + h + 2]) : hp_a2(e[N + h], e[N + h + 1]);
-    }
-    case 6: {
-        const int d = 2 * y - x, h = d >> 1;
-        if (d < 0)
-            return hp_a3(e[N - d - 2], e[N - d - 1], e[N - d]);
-        return (d & 1) ? hp_a3(e[N - h], e[N - h - 1], e[N - h - 2]) : hp_a2(e[N - h], e[N - h - 1]);
-    }
-    case 7: {
-        const int i = (y >> 1) + x;
-        return (y & 1) ? hp_a3(T[i], T[i + 1], T[i + 2]) : hp_a2(T[i], T[i + 1]);
-    }
-    case 8: {
-        const int i = 2 * y + x, j = N - 1 - (i >> 1);
-        if (i >= 2 * N - 2)
-            return e[0];
-        if (i == 2 * N - 3)
-            return (e[1] + 3 * e[0] + 2) >> 2;
-        return (i & 1) ? hp_a3(e[j], e[j - 1], e[j - 2]) : hp_a2(e[j], e[j - 1]);
-    }
-    default: return dc;
-    }
-}
+/* hp_a2 / hp_a3 / hp_need / hp_dir_sample: the per-sample rules over the edge line, shared with the picture pipeline's intra
+ * reconstruction (h264_intra_mb.h) */
 
 __device__ __forceinline__ void hp_store4(uint8_t *d, const int *v)
 {

@@ -127,6 +127,13 @@ class Picture:
         return _lib.check(_lib.lib().ffhip_h264_picture_idct_add(self._p, plane, kind, dst_offset, block.ctypes.data),
                           "ffhip_h264_picture_idct_add")
 
+    def intra_mb(self, rec, nnzc, mb, luma_dc=None, pcm=None):
+        """rec: one FFHipH264IntraMB (numpy structured, the decoder-side fields set); nnzc: uint8[120]; mb: int16[768], consumed"""
+        return _lib.check(_lib.lib().ffhip_h264_picture_intra_mb(self._p, rec.ctypes.data, None if nnzc is None else nnzc.ctypes.data,
+                                                                 None if mb is None else mb.ctypes.data,
+                                                                 None if luma_dc is None else luma_dc.ctypes.data,
+                                                                 None if pcm is None else pcm.ctypes.data), "ffhip_h264_picture_intra_mb")
+
     def deblock_mb(self, plane, mb_x, mb_y, edges):
         return _lib.check(_lib.lib().ffhip_h264_picture_deblock_mb(self._p, plane, mb_x, mb_y, edges.ctypes.data),
                           "ffhip_h264_picture_deblock_mb")

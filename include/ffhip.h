@@ -429,7 +429,8 @@ int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stri
  * A picture's worth of per-block dsp calls, recorded on the host while the decoder parses the picture and run as a handful of
  * launches.  The record functions take the operands hl_decode_mb() passes to the dsp pointers (libavcodec/h264_mb_template.c:41-270,
  * h264_mb.c:206-420,612-800) and ff_h264_filter_mb() computes (h264_loopfilter.c:716); flush() runs, per plane,
- *     MC put -> picture | MC put -> bi-prediction scratch | MC avg -> picture | weight / biweight | IDCT + add | deblock (decoder order)
+ *     MC put -> picture | MC put -> bi-prediction scratch | MC avg -> picture | weight / biweight | IDCT + add |
+ *     intra macroblocks (reconstruction wavefront, all three planes) | deblock (decoder order)
  * 4:2:0, 8 bits.  All planes of the picture, of the references and the scratch share one stride per plane (qpel_mc_func has one).
  * ref[pl] is the base the blocks' src_offset counts from — typically the decoded-picture-buffer allocation, so that one base
  * reaches every reference picture.  One object serves one stream; begin() starts the next picture (flush() does not clear).
@@ -451,6 +452,59 @@ int  ffhip_h264_picture_weight(FFHipH264Picture *p, int plane, const FFHipWeight
 int  ffhip_h264_picture_idct_add(FFHipH264Picture *p, int plane, int kind, int32_t dst_offset, int16_t *block);
 /** ff_h264_filter_mb(): the macroblock's edge records, 8 for luma ((dir * 4 + e)), 4 for a chroma plane ((dir * 2 + e)). */
 int  ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int mb_y, const FFHipH264Edge *edges);
+/**
+ * An INTRA macroblock: what hl_decode_mb() does for IS_INTRA(mb_type) (libavcodec/h264_mb_template.c:137-262 with
+ * hl_decode_mb_predict_luma / hl_decode_mb_idct_luma, libavcodec/h264_mb.c:612-760) as ONE record.  Intra prediction reads the
+ * reconstructed, not yet deblocked samples of the left / top-left / top / top-right macroblocks and chains through the residual
+ * add from block to block, so these records are not a batch of independent calls: flush() runs them as a reconstruction
+ * WAVEFRONT (one wave per macroblock row; an intra macroblock starts when the row above has finished the macroblock up and to the
+ * right) after the inter macroblocks' prediction and residual stages and before deblocking — the order of the reference's
+ * data flow, whose in-loop filter runs behind reconstruction on samples intra prediction never sees (xchg_mb_border,
+ * h264_mb.c:528-597).  Fields are the decoder's H264SliceContext state of the macroblock.  8 bits, 4:2:0, frame macroblocks;
+ * the lossless transform bypass (qscale 0 with sps->transform_bypass) is not taken: keep such a picture on the C path.
+ */
+#define FFHIP_H264_INTRA_16x16 0   /* IS_INTRA16x16(mb_type)                                                         */
+#define FFHIP_H264_INTRA_4x4   1   /* IS_INTRA4x4(mb_type) && !IS_8x8DCT(mb_type)                                    */
+#define FFHIP_H264_INTRA_8x8   2   /* IS_INTRA4x4(mb_type) &&  IS_8x8DCT(mb_type): pred8x8l + the 8x8 transform      */
+#define FFHIP_H264_INTRA_PCM   3   /* IS_INTRA_PCM(mb_type): sl->intra_pcm_ptr's 384 bytes                            */
+#define FFHIP_H264_INTRA_LUMA_DC 1 /* flags, set by ffhip_h264_picture_intra_mb() from the cache: nnz[scan8[LUMA_DC_BLOCK_INDEX]] */
+#define FFHIP_H264_INTRA_CB_DC   2 /*   nnz[scan8[CHROMA_DC_BLOCK_INDEX + 0]] */
+#define FFHIP_H264_INTRA_CR_DC   4 /*   nnz[scan8[CHROMA_DC_BLOCK_INDEX + 1]] */
+typedef struct FFHipH264IntraMB {
+    int16_t  mb_x, mb_y;
+    uint8_t  type;            /* FFHIP_H264_INTRA_*                                                                  */
+    uint8_t  pred16;          /* sl->intra16x16_pred_mode (after ff_h264_check_intra_pred_mode)                      */
+    uint8_t  chroma_pred;     /* sl->chroma_pred_mode (likewise)                                                     */
+    uint8_t  cbp;             /* sl->cbp & 0x3f                                                                      */
+    uint16_t topleft_avail;   /* sl->topleft_samples_available  (h264_mvpred.h:599-639)                              */
+    uint16_t topright_avail;  /* sl->topright_samples_available                                                      */
+    uint8_t  pred4[16];       /* sl->intra4x4_pred_mode_cache[scan8[i]], i = 0..15 (8x8: entries 0, 4, 8, 12)        */
+    int32_t  qmul[3];         /* pps->dequant4_coeff[0][qscale][0], [1][chroma_qp[0]][0], [2][chroma_qp[1]][0]       */
+    /* ---- filled in by ffhip_h264_picture_intra_mb() ---- */
+    uint8_t  flags;           /* FFHIP_H264_INTRA_LUMA_DC | _CB_DC | _CR_DC                                          */
+    uint8_t  pad[3];
+    uint8_t  nnz[24];         /* non_zero_count_cache[scan8[i]]: luma i = 0..15, Cb 16..19 at [16..19], Cr 32..35 at [20..23] */
+    int32_t  coef;            /* the macroblock's run in the picture's packed coefficient array (int16 units)         */
+    uint32_t blocks;          /* which blocks the run holds, in this order: bit i luma block i (8x8: bits 0, 4, 8, 12, 64
+                                 coefficients each), bit 16 + k Cb block k, bit 20 + k Cr block k                     */
+    int16_t  luma_dc[16];     /* sl->mb_luma_dc[0] (Intra16x16)                                                      */
+} FFHipH264IntraMB;           /* sizeof == 108 */
+/** Records one intra macroblock: *mb with the fields above `flags` set.  non_zero_count_cache: the decoder's 15 x 8 cache
+ *  (scan8 indexing, libavcodec/h264_parse.h:40-57).  mb: sl->mb (3 x 256 int16; Cb at 256, Cr at 512), CONSUMED the way the dsp
+ *  functions hl_decode_mb() calls consume it (blocks zeroed after idct_add, [0] after idct_dc_add).  mb_luma_dc: sl->mb_luma_dc[0]
+ *  (Intra16x16 with a coded DC block, else may be NULL).  pcm: sl->intra_pcm_ptr (FFHIP_H264_INTRA_PCM, else NULL). */
+int  ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264IntraMB *mb_desc, const uint8_t *non_zero_count_cache,
+                                 int16_t *mb, const int16_t *mb_luma_dc, const uint8_t *pcm);
+/** The host side of the record alone (no device involved; ffhip_h264_picture_intra_mb() is this + an append): fills the fields
+ *  from `flags` down and appends the macroblock's coefficient run to coefs[*ncoefs ...] (capacity `cap` int16; a run is at most
+ *  391 of them), advancing *ncoefs.  FFHIP_ENOMEM when the run does not fit. */
+int  ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *non_zero_count_cache, int16_t *mb, const int16_t *mb_luma_dc,
+                           const uint8_t *pcm, int16_t *coefs, int32_t *ncoefs, int32_t cap);
+/** The intra reconstruction wavefront alone, on records already in device memory (what flush() launches): recs sorted by
+ *  (mb_y, mb_x), row_start[mb_h + 1] indexes them by macroblock row, coefs is the packed coefficient array.  Planes and strides
+ *  4-byte aligned.  Asynchronous on `stream`; a lost hand-off is reported by the next flush / ffhip_stream_synchronize. */
+int  ffhip_h264_intra_frame_dev(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t stride_y, ptrdiff_t stride_c, int mb_w, int mb_h,
+                                const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, void *stream);
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
 int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                               void *stream);

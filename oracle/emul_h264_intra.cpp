@@ -1,0 +1,74 @@
+/*
+ * emul_h264_intra.cpp — TEST INFRASTRUCTURE ONLY.  Runs the phase bodies of ffmpeg_amd/csrc/kernels/h264_intra_mb.h — the
+ * code k_h264_intra_frame executes per macroblock on the GPU — on the CPU: a phase is a loop over the 64 lanes, the tile is
+ * plain memory, macroblocks are walked in raster order (a valid serialisation of the kernel's wavefront).  tests/ compare it
+ * with oracle/ffo_h264.c's restatement of hl_decode_mb() (itself pinned to the reference's ff_h264_hl_decode_mb), so the
+ * kernel's per-macroblock logic is pinned where no GPU is present; the GPU tests then cover what is left — the hand-off between
+ * rows and the tile's loads and stores.
+ */
+#include <stdint.h>
+#include <string.h>
+
+#include "../ffmpeg_amd/csrc/kernels/h264_intra_mb.h"
+
+namespace {
+struct EmulWave {
+    template <class F>
+    void run(F body)
+    {
+        for (int lane = 0; lane < 64; lane++)
+            body(lane);
+    }
+};
+} // namespace
+
+extern "C" int ffemul_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                       const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs)
+{
+    EmulWave X;
+    for (int my = 0; my < mb_h; my++)
+        for (int k = row_start[my]; k < row_start[my + 1]; k++) {
+            const FFHipH264IntraMB &R = recs[k];
+            const int mx = R.mb_x;
+            if (R.mb_y != my || mx < 0 || mx >= mb_w || (k > row_start[my] && recs[k - 1].mb_x >= mx))
+                return -1;
+            ImbTile T;
+            memset(&T, 0xA5, sizeof(T)); /* whatever the phases do not write first must not matter */
+            uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16;
+            uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 };
+            const bool has_l = mx > 0, has_t = my > 0, has_r = mx + 1 < mb_w;
+            /* the kernel's tile fill, dword by dword */
+            for (int lane = 0; lane < 46; lane++) {
+                uint32_t v = 0;
+                if (lane < 8) {
+                    const int c = 4 * lane - 4;
+                    if (has_t && (c >= 0 || has_l) && (c < 16 || has_r))
+                        memcpy(&v, ymb - sy + c, 4);
+                    memcpy(&T.y[imb_yi(-1, c)], &v, 4);
+                } else if (lane < 24) {
+                    const int r = lane - 8;
+                    if (has_l)
+                        memcpy(&v, ymb + (ptrdiff_t)r * sy - 4, 4);
+                    memcpy(&T.y[imb_yi(r, -4)], &v, 4);
+                    memset(&T.y[imb_yi(r, 16)], 0, 8);
+                } else if (lane < 30) {
+                    const int p = (lane - 24) / 3, c = 4 * ((lane - 24) % 3) - 4;
+                    if (has_t && (c >= 0 || has_l))
+                        memcpy(&v, cmb[p] - sc + c, 4);
+                    memcpy(&T.c[p][imb_ci(-1, c)], &v, 4);
+                } else {
+                    const int p = (lane - 30) >> 3, r = (lane - 30) & 7;
+                    if (has_l)
+                        memcpy(&v, cmb[p] + (ptrdiff_t)r * sc - 4, 4);
+                    memcpy(&T.c[p][imb_ci(r, -4)], &v, 4);
+                }
+            }
+            imb_reconstruct(X, T, R, coefs);
+            for (int r = 0; r < 16; r++)
+                memcpy(ymb + (ptrdiff_t)r * sy, &T.y[imb_yi(r, 0)], 16);
+            for (int p = 0; p < 2; p++)
+                for (int r = 0; r < 8; r++)
+                    memcpy(cmb[p] + (ptrdiff_t)r * sc, &T.c[p][imb_ci(r, 0)], 8);
+        }
+    return 0;
+}

@@ -452,3 +452,86 @@ void ffo_h264_biweight(int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride
         for (int x = 0; x < w; x++)
             dst[x] = clip_u8((src[x] * weights + dst[x] * weightd + offset) >> (log2_denom + 1));
 }
+
+/* ------------------------------------------------------------------------------------------
+ * hl_decode_mb(), the IS_INTRA branch, SIMPLE / 8 bits / 4:2:0 / frame macroblock / no transform bypass
+ * (libavcodec/h264_mb_template.c:137-262 with hl_decode_mb_predict_luma and hl_decode_mb_idct_luma,
+ * libavcodec/h264_mb.c:612-760): the dsp calls one intra macroblock makes, in the reference's order, on the oracle's restatements
+ * of those members.  Arguments are the H264SliceContext fields the reference reads: intra4x4_pred_mode[i] =
+ * sl->intra4x4_pred_mode_cache[scan8[i]], nnzc = sl->non_zero_count_cache (15 x 8), mb = sl->mb (3 x 256), qmul[3] =
+ * dequant4_coeff[0][qscale][0], [1][chroma_qp[0]][0], [2][chroma_qp[1]][0]; type as FFHIP_H264_INTRA_* (include/ffhip.h).
+ * ---------------------------------------------------------------------------------------- */
+void ffo_h264_hl_decode_intra_mb(uint8_t *dest_y, uint8_t *dest_cb, uint8_t *dest_cr, ptrdiff_t linesize, ptrdiff_t uvlinesize,
+                                 int type, int intra16x16_pred_mode, int chroma_pred_mode, const uint8_t *intra4x4_pred_mode,
+                                 unsigned topleft_samples_available, unsigned topright_samples_available, const uint8_t *nnzc,
+                                 int cbp, int16_t *mb, int16_t *mb_luma_dc, const int *qmul, const uint8_t *intra_pcm_ptr)
+{
+    int block_offset[48];
+    /* h264_slice.c init: block_offset[i] luma, [16 + i] / [32 + i] chroma (4:2:0: only the first four of each are used) */
+    for (int i = 0; i < 16; i++) {
+        const int x = 4 * ((i & 1) + ((i >> 2) & 1) * 2), y = 4 * (((i >> 1) & 1) + ((i >> 3) & 1) * 2);
+        block_offset[i] = x + y * (int)linesize;
+        block_offset[16 + i] = block_offset[32 + i] = x + y * (int)uvlinesize;
+    }
+    if (type == 3) { /* IS_INTRA_PCM, h264_mb_template.c:137-150 */
+        for (int i = 0; i < 16; i++)
+            memcpy(dest_y + i * linesize, intra_pcm_ptr + i * 16, 16);
+        for (int i = 0; i < 8; i++) {
+            memcpy(dest_cb + i * uvlinesize, intra_pcm_ptr + 256 + i * 8, 8);
+            memcpy(dest_cr + i * uvlinesize, intra_pcm_ptr + 256 + 64 + i * 8, 8);
+        }
+        return;
+    }
+    ffo_h264_pred8x8(chroma_pred_mode, dest_cb, uvlinesize);
+    ffo_h264_pred8x8(chroma_pred_mode, dest_cr, uvlinesize);
+    /* hl_decode_mb_predict_luma */
+    if (type == 2) {
+        for (int i = 0; i < 16; i += 4) {
+            uint8_t *ptr = dest_y + block_offset[i];
+            const int dir = intra4x4_pred_mode[i], nnz = nnzc[scan8_luma[i]];
+            ffo_h264_pred8x8l(dir, ptr, (topleft_samples_available << i) & 0x8000, (topright_samples_available << i) & 0x4000, linesize);
+            if (nnz) {
+                if (nnz == 1 && mb[i * 16])
+                    ffo_h264_idct8_dc_add(ptr, mb + i * 16, linesize);
+                else
+                    ffo_h264_idct8_add(ptr, mb + i * 16, linesize);
+            }
+        }
+    } else if (type == 1) {
+        for (int i = 0; i < 16; i++) {
+            uint8_t *ptr = dest_y + block_offset[i];
+            const int dir = intra4x4_pred_mode[i], nnz = nnzc[scan8_luma[i]];
+            uint32_t tr;
+            const uint8_t *topright = NULL;
+            if (dir == 3 || dir == 7) { /* DIAG_DOWN_LEFT_PRED, VERT_LEFT_PRED */
+                if (!((topright_samples_available << i) & 0x8000)) {
+                    tr = ptr[3 - linesize] * 0x01010101u;
+                    topright = (const uint8_t *)&tr;
+                } else {
+                    topright = ptr + 4 - linesize;
+                }
+            }
+            ffo_h264_pred4x4(dir, ptr, topright, linesize);
+            if (nnz) {
+                if (nnz == 1 && mb[i * 16])
+                    ffo_h264_idct_dc_add(ptr, mb + i * 16, linesize);
+                else
+                    ffo_h264_idct_add(ptr, mb + i * 16, linesize);
+            }
+        }
+    } else {
+        ffo_h264_pred16x16(intra16x16_pred_mode, dest_y, linesize);
+        if (nnzc[0]) /* scan8[LUMA_DC_BLOCK_INDEX] */
+            ffo_h264_luma_dc_dequant_idct(mb, mb_luma_dc, qmul[0]);
+        /* hl_decode_mb_idct_luma */
+        ffo_h264_idct_add16intra(dest_y, block_offset, mb, linesize, nnzc);
+    }
+    if (cbp & 0x30) {
+        uint8_t *dest[2] = { dest_cb, dest_cr };
+        if (nnzc[5 * 8]) /* scan8[CHROMA_DC_BLOCK_INDEX + 0] */
+            ffo_h264_chroma_dc_dequant_idct(mb + 256, qmul[1]);
+        if (nnzc[10 * 8])
+            ffo_h264_chroma_dc_dequant_idct(mb + 512, qmul[2]);
+        ffo_h264_idct_add8(dest, block_offset, mb, uvlinesize, nnzc);
+    }
+}

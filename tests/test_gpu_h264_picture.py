@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import ffi
+import h264_intra_gen as G
 from ffi import ptr, u8p
 
 pytestmark = pytest.mark.gpu
@@ -33,10 +34,22 @@ def _at(a, off):
     return C.cast(a.ctypes.data + int(off), u8p)
 
 
-def _make_mb(rng, mx, my, W, H, P, sy, sc):
+def _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra=0.0):
     """the dsp calls of one macroblock as plain data: ("mc", plane, stage, record), ("w", plane, record), ("idct", plane, kind,
-    offset, block), ("edges", plane, records)"""
+    offset, block), ("edges", plane, records); an intra macroblock is ("intra", decoder state) + its edges"""
     calls = []
+    if rng.random() < p_intra:
+        calls.append(("intra", G.make_intra_mb(rng, mx, my, W // 16, H // 16)))
+        for pl in (0, 1, 2):
+            ne = 8 if pl == 0 else 4
+            ed = np.zeros(ne, EDGE_DT)
+            sel = rng.integers(0, len(LADDER), ne)
+            ed["alpha"], ed["beta"] = LADDER[sel, 0], LADDER[sel, 1]
+            ed["kind"] = 4 + (2 if pl else 0)             # bS 4 / 3 around an intra macroblock: the intra filters
+            ed["tc0"] = rng.integers(-1, 4, (ne, 4))
+            ed["alpha"][rng.random(ne) < .2] = 0
+            calls.append(("edges", pl, ed))
+        return calls
     inter = rng.random() < .8
     if inter:
         parts = [(0, 0, 0)] if rng.random() < .5 else [(1, 0, 0), (1, 8, 0), (1, 0, 8), (1, 8, 8)]
@@ -98,12 +111,13 @@ def _make_mb(rng, mx, my, W, H, P, sy, sc):
     return calls
 
 
-@pytest.mark.parametrize("mb_w,mb_h,pictures", [(6, 4, 3), (40, 22, 1)])
-def test_picture_pipeline(mb_w, mb_h, pictures):
+@pytest.mark.parametrize("mb_w,mb_h,pictures,p_intra", [(6, 4, 3, 0.0), (40, 22, 1, 0.0), (6, 4, 4, .3), (40, 22, 1, .15), (11, 7, 2, 1.0),
+                                                         (120, 68, 1, 1.0)])
+def test_picture_pipeline(mb_w, mb_h, pictures, p_intra):
     from ffmpeg_amd import h264
     torch = _torch()
     O = ffi.oracle()
-    rng = np.random.default_rng(mb_w * 31 + mb_h)
+    rng = np.random.default_rng(mb_w * 31 + mb_h + int(p_intra * 100))
     P = 32                                                    # reference padding: motion vectors may leave the picture
     W, H = mb_w * 16, mb_h * 16
     sy, sc = W + 2 * P, W // 2 + P                            # one stride per plane for picture, references and scratch
@@ -122,8 +136,15 @@ def test_picture_pipeline(mb_w, mb_h, pictures):
         pic.begin()
         for my in range(mb_h):
             for mx in range(mb_w):
-                for call in _make_mb(rng, mx, my, W, H, P, sy, sc):
-                    if call[0] == "mc":
+                for call in _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra):
+                    if call[0] == "intra":
+                        # hl_decode_mb() on the oracle's picture now (decoder order); the record runs in flush()'s wavefront
+                        d = call[1]
+                        mb_o = G.oracle_decode(O, d, want, strides)
+                        mb_p = d["mb"].copy()
+                        pic.intra_mb(G.to_record(d), d["nnzc"], mb_p, d["luma_dc"], d["pcm"])
+                        assert d["type"] == G.PCM or np.array_equal(mb_p, mb_o)       # sl->mb consumed as the dsp functions do
+                    elif call[0] == "mc":
                         _, pl, stage, rec = call
                         tgt = tmp[pl] if stage == h264.MC_TMP else want[pl]
                         r = rec[0]

@@ -1,0 +1,130 @@
+"""CPU pins of the picture pipeline's intra reconstruction, no GPU involved:
+
+  1. oracle/ffo_h264.c's ffo_h264_hl_decode_intra_mb() == the reference's own ff_h264_hl_decode_mb() (libavcodec/h264_mb.c:802,
+     compiled in place, driven by oracle/refbuild/ffref_shim_h264mb.c) — samples and the consumed sl->mb;
+  2. the product's HOST side (ffhip_h264_intra_pack: which blocks travel, flags, the caller's coefficients consumed as the dsp
+     functions consume them) against the oracle's post-state;
+  3. the kernel's per-macroblock logic (kernels/h264_intra_mb.h, the code k_h264_intra_frame runs on the GPU) executed by
+     oracle/libffemul.so lane by lane on the CPU == the oracle, on whole pictures in decoder order.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ffi
+import h264_intra_gen as G
+
+EMUL_SO = os.path.join(ffi.ROOT, "oracle", "libffemul.so")
+
+
+def _planes(rng, mb_w, mb_h, pad=0):
+    sy, sc = mb_w * 16 + pad, mb_w * 8 + pad
+    return [rng.integers(0, 256, (mb_h * 16, sy), dtype=np.uint8), rng.integers(0, 256, (mb_h * 8, sc), dtype=np.uint8),
+            rng.integers(0, 256, (mb_h * 8, sc), dtype=np.uint8)], [sy, sc, sc]
+
+
+@pytest.mark.skipif(not os.path.exists(ffi.REF_SO), reason="oracle/_ref not built")
+@pytest.mark.parametrize("mtype", [G.I16, G.I4, G.I8, G.PCM])
+def test_oracle_hl_decode_mb_vs_reference(mtype):
+    O, R = ffi.oracle(), ffi.ref()
+    rng = np.random.default_rng(1000 + mtype)
+    mb_w, mb_h = 5, 4
+    u8 = C.POINTER(C.c_uint8)
+    for it in range(400 if mtype != G.PCM else 20):
+        mx, my = int(rng.integers(0, mb_w)), int(rng.integers(0, mb_h))
+        planes, st = _planes(rng, mb_w, mb_h, pad=int(rng.choice([0, 16])))
+        d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, mtype)
+        want = [p.copy() for p in planes]
+        mb_ref = d["mb"].copy()
+        dc = d["luma_dc"].copy()
+        at = [want[0].ctypes.data + my * 16 * st[0] + mx * 16, want[1].ctypes.data + my * 8 * st[1] + mx * 8,
+              want[2].ctypes.data + my * 8 * st[2] + mx * 8]
+        R.ffref_h264_hl_decode_intra_mb(C.cast(at[0], u8), C.cast(at[1], u8), C.cast(at[2], u8), st[0], st[1], mx, my, mb_w, d["type"],
+                                        d["pred16"], d["chroma_pred"], G._p(d["pred4"], C.c_uint8), d["topleft"], d["topright"],
+                                        G._p(d["nnzc"], C.c_uint8), d["cbp"], G._p(mb_ref, C.c_int16), G._p(dc, C.c_int16),
+                                        G._p(d["qmul"], C.c_int), G._p(d["pcm"], C.c_uint8))
+        got = [p.copy() for p in planes]
+        mb_o = G.oracle_decode(O, d, got, st)
+        for pl in range(3):
+            assert np.array_equal(got[pl], want[pl]), "type %d iteration %d plane %d" % (mtype, it, pl)
+            assert (want[pl] != planes[pl]).any()
+        if mtype != G.PCM:
+            assert np.array_equal(mb_o, mb_ref), "consumed coefficients differ (type %d iteration %d)" % (mtype, it)
+
+
+def _pack(L, d, coefs, ncoef):
+    rec = G.to_record(d)
+    mb = d["mb"].copy()
+    n = C.c_int32(ncoef)
+    r = L.ffhip_h264_intra_pack(rec.ctypes.data, d["nnzc"].ctypes.data, mb.ctypes.data, d["luma_dc"].ctypes.data,
+                                G._p(d["pcm"], C.c_uint8), G._p(coefs, C.c_int16), C.byref(n), C.c_int32(coefs.size))
+    assert r == 0
+    return rec, mb, n.value
+
+
+def _decode_picture(rng, mb_w, mb_h, frac, pad):
+    """a picture's intra macroblocks through oracle (planes `want`) and through pack + emulation (planes `got`)"""
+    from ffmpeg_amd import _lib
+    L = _lib.lib()
+    L.ffhip_h264_intra_pack.restype = C.c_int
+    E = C.CDLL(EMUL_SO)
+    O = ffi.oracle()
+    planes, st = _planes(rng, mb_w, mb_h, pad)
+    want = [p.copy() for p in planes]
+    recs, coefs, ncoef = [], np.zeros(mb_w * mb_h * 400 + 64, np.int16), 0
+    rows = np.zeros(mb_h + 1, np.int32)
+    for my in range(mb_h):
+        for mx in range(mb_w):
+            if rng.random() >= frac:
+                continue
+            d = G.make_intra_mb(rng, mx, my, mb_w, mb_h)
+            mb_o = G.oracle_decode(O, d, want, st)
+            rec, mb_p, ncoef = _pack(L, d, coefs, ncoef)
+            if d["type"] != G.PCM:
+                assert np.array_equal(mb_p, mb_o), "host side consumed sl->mb differently from the dsp functions at (%d, %d)" % (mx, my)
+            recs.append(rec)
+            rows[my + 1] += 1
+    rows = np.cumsum(rows).astype(np.int32)
+    recs = np.concatenate(recs) if recs else np.zeros(0, G.INTRA_DT)
+    got = [p.copy() for p in planes]
+    u8 = C.POINTER(C.c_uint8)
+    r = E.ffemul_h264_intra_frame(got[0].ctypes.data_as(u8), got[1].ctypes.data_as(u8), got[2].ctypes.data_as(u8), C.c_ssize_t(st[0]),
+                                  C.c_ssize_t(st[1]), mb_w, mb_h, C.c_void_p(recs.ctypes.data), G._p(rows, C.c_int32), G._p(coefs, C.c_int16))
+    assert r == 0
+    return planes, want, got, len(recs)
+
+
+@pytest.mark.parametrize("mb_w,mb_h,frac,pad", [(1, 1, 1.0, 0), (2, 3, 1.0, 4), (8, 6, 1.0, 0), (9, 5, .35, 12), (20, 12, 1.0, 0)])
+def test_kernel_logic_emulated_on_cpu_equals_oracle(mb_w, mb_h, frac, pad):
+    if not os.path.exists(EMUL_SO):
+        pytest.skip("oracle/libffemul.so not built")
+    rng = np.random.default_rng(mb_w * 100 + mb_h)
+    for it in range(6 if mb_w * mb_h < 100 else 2):
+        planes, want, got, n = _decode_picture(rng, mb_w, mb_h, frac, pad)
+        for pl in range(3):
+            bad = np.argwhere(got[pl] != want[pl])
+            assert not len(bad), "picture %d plane %d: %d mismatches, first at row %d column %d (%d intra macroblocks)" % (
+                it, pl, len(bad), bad[0][0], bad[0][1], n)
+        if n:
+            assert (want[0] != planes[0]).any()
+
+
+def test_intra_pack_rejects_bad_arguments():
+    from ffmpeg_amd import _lib
+    L = _lib.lib()
+    L.ffhip_h264_intra_pack.restype = C.c_int
+    rng = np.random.default_rng(5)
+    d = G.make_intra_mb(rng, 1, 1, 4, 4, G.I4)
+    rec = G.to_record(d)
+    coefs = np.zeros(64, np.int16)      # too small for a run
+    n = C.c_int32(0)
+    mb = d["mb"].copy()
+    r = L.ffhip_h264_intra_pack(C.c_void_p(rec.ctypes.data), G._p(d["nnzc"], C.c_uint8), G._p(mb, C.c_int16), None, None,
+                                G._p(coefs, C.c_int16), C.byref(n), C.c_int32(coefs.size))
+    assert r == _lib.ENOMEM and n.value == 0 and np.array_equal(mb, d["mb"])
+    rec["type"] = 7
+    big = np.zeros(1024, np.int16)
+    assert L.ffhip_h264_intra_pack(C.c_void_p(rec.ctypes.data), G._p(d["nnzc"], C.c_uint8), G._p(mb, C.c_int16), None, None,
+                                   G._p(big, C.c_int16), C.byref(n), C.c_int32(big.size)) == _lib.EINVAL

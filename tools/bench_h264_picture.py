@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 from ffmpeg_amd import h264  # noqa: E402
+import h264_intra_gen as G  # noqa: E402
 from test_gpu_h264_picture import QPEL_DT, CHROMA_DT, EDGE_DT  # noqa: E402
 
 dev = torch.device("cuda", 0)
@@ -71,10 +72,52 @@ def record():
     return n
 
 
+def record_intra(frac):
+    """an I-picture (frac = 1) or the intra macroblocks of a P-picture: intra macroblocks only, deblocking recorded for all"""
+    pic.begin()
+    n = 0
+    ed8, ed4 = np.zeros(8, EDGE_DT), np.zeros(4, EDGE_DT)
+    for e in (ed8, ed4):
+        e["alpha"], e["beta"] = 40, 9
+        e["kind"] = 4
+    ed4["kind"] = 6
+    for my in range(mb_h):
+        for mx in range(mb_w):
+            if rng.random() < frac:
+                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h)
+                pic.intra_mb(G.to_record(d), d["nnzc"], d["mb"], d["luma_dc"], d["pcm"])
+                n += 1
+            pic.deblock_mb(0, mx, my, ed8)
+            pic.deblock_mb(1, mx, my, ed4)
+            pic.deblock_mb(2, mx, my, ed4)
+    return n
+
+
+def timed(reps=10):
+    pic.flush(dst, strides, refs)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        pic.flush(dst, strides, refs)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+strides = [sy, sc, sc]
+if "--intra" in sys.argv:
+    for frac in (1.0, .1):
+        n = record_intra(frac)
+        ms = timed()
+        print(json.dumps({"case": "h264 4K picture, %d%% intra macroblocks (Intra16x16 / 4x4 / 8x8 mixed, residuals): reconstruction "
+                                  "wavefront + frame-order deblock through ffhip_h264_picture_flush" % round(100 * frac),
+                          "intra_macroblocks": n, "ms_per_picture_gpu": round(ms, 3), "pictures_per_s": round(1e3 / ms, 1)}), flush=True)
+    sys.exit(0)
+
 t0 = time.perf_counter()
 counts = record()
 t_rec = time.perf_counter() - t0
-strides = [sy, sc, sc]
 pic.flush(dst, strides, refs)
 torch.cuda.synchronize()
 reps = 10
