@@ -147,14 +147,20 @@ IMB_FN int imb_bx(int i) { return 4 * ((i & 1) + ((i >> 2) & 1) * 2); }
 IMB_FN int imb_by(int i) { return 4 * (((i >> 1) & 1) + ((i >> 3) & 1) * 2); }
 
 /* coefficients of luma block i (0..15; 8x8 transform: i = 0, 4, 8, 12, 64 coefficients) / chroma block 16 + k (Cb), 20 + k (Cr)
- * in the macroblock's packed run; nullptr when the block was all zero and not stored */
-IMB_FN const int16_t *imb_block(const FFHipH264IntraMB &R, const int16_t *coefs, int bit)
+ * in the macroblock's packed run (run = the picture's coefficient array + R.coef, or a copy of the run); nullptr when the block was all zero and not stored */
+IMB_FN const int16_t *imb_block(const FFHipH264IntraMB &R, const int16_t *run, int bit)
 {
     if (!((R.blocks >> bit) & 1u))
         return nullptr;
     const int lsz = R.type == FFHIP_H264_INTRA_8x8 ? 64 : 16;
     const uint32_t below = R.blocks & ((1u << bit) - 1u);
-    return coefs + R.coef + imb_popc(below & 0xFFFFu) * lsz + imb_popc(below >> 16) * 16;
+    return run + imb_popc(below & 0xFFFFu) * lsz + imb_popc(below >> 16) * 16;
+}
+
+/* int16 entries of a macroblock's run */
+IMB_FN int imb_run_len(int type, uint32_t blocks)
+{
+    return type == FFHIP_H264_INTRA_PCM ? 192 : imb_popc(blocks & 0xFFFFu) * (type == FFHIP_H264_INTRA_8x8 ? 64 : 16) + imb_popc(blocks >> 16) * 16;
 }
 
 /* output k of the 4-point butterfly of ff_h264_idct_add (h264idct_template.c:39-64): modulo 2^32, arithmetic shifts */
@@ -255,11 +261,11 @@ IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT)
  * T holds the neighbours (unavailable ones as 0) on entry and the reconstructed macroblock on return.
  */
 template <class X>
-IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const int16_t *coefs)
+IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const int16_t *coefs /* the macroblock's run */)
 {
     if (R.type == FFHIP_H264_INTRA_PCM) {
         /* the samples as they stand in the bitstream: 256 luma, 64 Cb, 64 Cr bytes (h264_mb_template.c:137-150) */
-        const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coefs + R.coef);
+        const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coefs);
         x.run([&](int lane) {
             for (int j = 0; j < 4; j++)
                 T.y[imb_yi(lane >> 2, 4 * (lane & 3) + j)] = pcm[16 * (lane >> 2) + 4 * (lane & 3) + j];

@@ -63,7 +63,7 @@ extern "C" int ffemul_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, 
                     memcpy(&T.c[p][imb_ci(r, -4)], &v, 4);
                 }
             }
-            imb_reconstruct(X, T, R, coefs);
+            imb_reconstruct(X, T, R, coefs + R.coef);
             for (int r = 0; r < 16; r++)
                 memcpy(ymb + (ptrdiff_t)r * sy, &T.y[imb_yi(r, 0)], 16);
             for (int p = 0; p < 2; p++)
