@@ -253,6 +253,71 @@ extern "C" int ffhip_hevc_mc_w_batch_dev(int chroma, int mode, uint8_t *dst, ptr
     return ffhip_launch_hevc_mc(chroma, mode, dst, dststride, src, srcstride, src2, blocks, n, (hipStream_t)stream);
 }
 
+/* ---- hevcdsp above 8 bits: the same batch faces with the depth the reference instantiates its templates for ---------------- */
+static bool hevc_bd_ok(int bd) { return bd == 8 || bd == 10 || bd == 12; }
+
+extern "C" int ffhip_hevc_idct_batch_dev_hbd(int bit_depth, int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride,
+                                             const FFHipHevcTU *tus, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !coeffs || !tus || n < 0 || kind < FFHIP_HEVC_IDCT || kind > FFHIP_HEVC_RDPCM_V || log2_size < 2 ||
+        log2_size > 5 || (kind == FFHIP_HEVC_DST_4X4 && log2_size != 2) || (kind == FFHIP_HEVC_ADD_ONLY && !dst))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_idct_bd(bit_depth, kind, log2_size, coeffs, dst, stride, tus, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_hevc_loop_filter_batch_dev_hbd(int bit_depth, uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !base || !edges || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_loop_filter_bd(bit_depth, base, stride, edges, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_hevc_sao_batch_dev_hbd(int bit_depth, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src,
+                                            const FFHipHevcSao *blocks, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_sao_bd(bit_depth, dst, stride_dst, src, stride_src, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_hevc_sao_restore_batch_dev_hbd(int bit_depth, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src,
+                                                    const FFHipHevcSaoRestore *blocks, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_sao_restore_bd(bit_depth, dst, stride_dst, src, stride_src, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_hevc_mc_batch_dev_hbd(int bit_depth, int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src,
+                                           ptrdiff_t srcstride, const FFHipHevcMcBlock *blocks, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_mc_bd(bit_depth, chroma, uni ? 1 : 0, dst, dststride, src, srcstride, nullptr, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_hevc_mc_w_batch_dev_hbd(int bit_depth, int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src,
+                                             ptrdiff_t srcstride, const int16_t *src2, const FFHipHevcMcWBlock *blocks, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !dst || !src || !blocks || n < 0 || mode < FFHIP_HEVC_MC_UNI_W || mode > FFHIP_HEVC_MC_BI_W)
+        return FFHIP_EINVAL;
+    if (mode != FFHIP_HEVC_MC_UNI_W && !src2)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_hevc_mc_bd(bit_depth, chroma, mode, dst, dststride, src, srcstride, src2, blocks, n, (hipStream_t)stream);
+}
+
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */
 extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1,
                                     size_t pitch1, const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream)

@@ -40,6 +40,16 @@ int ffhip_launch_h264_weight(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
 int ffhip_launch_h264_pred(int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n, hipStream_t stream);
 int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n,
                            hipStream_t stream);
+/* the hevcdsp kernels at bit depth 8 / 10 / 12 (16-bit samples above 8, strides and offsets in bytes) */
+int ffhip_launch_hevc_idct_bd(int bd, int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n,
+                              hipStream_t stream);
+int ffhip_launch_hevc_loop_filter_bd(int bd, uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, hipStream_t stream);
+int ffhip_launch_hevc_sao_bd(int bd, uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n,
+                             hipStream_t stream);
+int ffhip_launch_hevc_sao_restore_bd(int bd, uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSaoRestore *blocks,
+                                     int n, hipStream_t stream);
+int ffhip_launch_hevc_mc_bd(int bd, int chroma, int mode, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                            const int16_t *src2, const void *blocks, int n, hipStream_t stream);
 int ffhip_launch_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, hipStream_t stream);
 int ffhip_launch_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n, hipStream_t stream);
 int ffhip_launch_vp9_smc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9ScaledBlock *blocks, int n,

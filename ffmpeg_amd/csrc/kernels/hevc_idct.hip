@@ -119,8 +119,10 @@ __device__ __forceinline__ void hevc_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* bd: the depth the template was instantiated for in the reference (hevc/dsp.c:133-196): it sets the second-pass shift 20 - bd, the
+ * DC shift 14 - bd, dequant's 15 - bd - log2 and the pixel type / clip of add_residual (uint16_t above 8 bits, stride in bytes) */
 template <int LOG2>
-__global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n)
+__global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n, int bd)
 {
     constexpr int N = 1 << LOG2, UPW = 64 / N; /* units per wave */
     __shared__ __align__(16) int16_t lds[4][64 * N];
@@ -154,9 +156,9 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
                 limit2 -= 4;
         hevc_pass<N>(mine + i, N, mine + i, N, limit2, 7);
         hevc_wave_sync();
-        hevc_pass<N>(mine + i * N, 1, mine + i * N, 1, limit, 12);
+        hevc_pass<N>(mine + i * N, 1, mine + i * N, 1, limit, 20 - bd);
     } else if (kind == FFHIP_HEVC_IDCT_DC) {
-        const int v = ((((int)mine[0] + 1) >> 1) + 32) >> 6;
+        const int v = ((((int)mine[0] + 1) >> 1) + (1 << (13 - bd))) >> (14 - bd);
         hevc_wave_sync();
 #pragma unroll
         for (int k = 0; k < N; k++)
@@ -165,14 +167,17 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
         if (N == 4) {
             hevc_dst4(mine + i, mine + i, 4, 7);
             hevc_wave_sync();
-            hevc_dst4(mine + 4 * i, mine + 4 * i, 1, 12);
+            hevc_dst4(mine + 4 * i, mine + 4 * i, 1, 20 - bd);
         }
     } else if (kind == FFHIP_HEVC_DEQUANT) {
-        /* dequant (hevc/dsp_template.c:127-143), 8 bits: (c + 2^(shift-1)) >> shift, shift = 15 - 8 - log2; lane i = row i */
-        constexpr int shift = 7 - LOG2;
+        /* dequant (hevc/dsp_template.c:110-143): (c + 2^(shift-1)) >> shift, shift = 15 - bd - log2; nothing at shift 0, and above
+         * 10 bits a negative shift is a left shift of the coefficient read as uint16; lane i = row i */
+        const int shift = 15 - bd - LOG2;
 #pragma unroll
-        for (int k = 0; k < N; k++)
-            mine[i * N + k] = (int16_t)((mine[i * N + k] + (1 << (shift - 1))) >> shift);
+        for (int k = 0; k < N; k++) {
+            const int c = mine[i * N + k];
+            mine[i * N + k] = (int16_t)(shift > 0 ? (c + (1 << (shift - 1))) >> shift : shift < 0 ? (int)((uint32_t)(uint16_t)c << -shift) : c);
+        }
     } else if (kind == FFHIP_HEVC_RDPCM_H || kind == FFHIP_HEVC_RDPCM_V) {
         /* transform_rdpcm (hevc/dsp_template.c:85-105): running sums in int16 arithmetic along a row (mode 0: lane i = row i)
          * or down a column (mode 1: lane i = column i) */
@@ -195,7 +200,22 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
         }
     }
     (void)cg;
-    if (dst && live && tu.dst_offset >= 0) {
+    if (dst && live && tu.dst_offset >= 0 && bd > 8) {
+        uint16_t *d = reinterpret_cast<uint16_t *>(dst + tu.dst_offset + (ptrdiff_t)i * stride);
+        const int16_t *r = mine + i * N;
+        const int maxv = (1 << bd) - 1;
+        if (!(reinterpret_cast<uintptr_t>(d) & 3)) {
+#pragma unroll
+            for (int x = 0; x < N; x += 2) {
+                const uint32_t p = *reinterpret_cast<const uint32_t *>(d + x);
+                const int a = min(max((int)(p & 0xFFFF) + r[x], 0), maxv), b = min(max((int)(p >> 16) + r[x + 1], 0), maxv);
+                *reinterpret_cast<uint32_t *>(d + x) = (uint32_t)a | (uint32_t)b << 16;
+            }
+        } else {
+            for (int x = 0; x < N; x++)
+                d[x] = (uint16_t)min(max((int)d[x] + r[x], 0), maxv);
+        }
+    } else if (dst && live && tu.dst_offset >= 0) {
         uint8_t *d = dst + tu.dst_offset + (ptrdiff_t)i * stride;
         const int16_t *r = mine + i * N;
 #pragma unroll
@@ -216,8 +236,18 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
 int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n,
                            hipStream_t stream)
 {
+    return ffhip_launch_hevc_idct_bd(8, kind, log2_size, coeffs, dst, stride, tus, n, stream);
+}
+
+int ffhip_launch_hevc_idct_bd(int bd, int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n,
+                              hipStream_t stream)
+{
     if (n <= 0)
         return 0;
+    if (bd != 8 && bd != 10 && bd != 12) {
+        ffhip_set_error("ffhip_hevc: bit depth %d (8, 10 and 12 are built)", bd);
+        return FFHIP_EINVAL;
+    }
     std::call_once(hevc_tab_once, [] {
         hevc_build_table();
         hevc_tab_err = hipMemcpyToSymbol(HIP_SYMBOL(hevc_pk), hevc_pk_host, sizeof(hevc_pk_host));
@@ -229,10 +259,10 @@ int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *ds
     const int upw = 64 >> log2_size;
     const dim3 grid(cdiv(n, 4 * upw)), block(256);
     switch (log2_size) {
-    case 2: hipLaunchKernelGGL(k_hevc_idct<2>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n); break;
-    case 3: hipLaunchKernelGGL(k_hevc_idct<3>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n); break;
-    case 4: hipLaunchKernelGGL(k_hevc_idct<4>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n); break;
-    case 5: hipLaunchKernelGGL(k_hevc_idct<5>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n); break;
+    case 2: hipLaunchKernelGGL(k_hevc_idct<2>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n, bd); break;
+    case 3: hipLaunchKernelGGL(k_hevc_idct<3>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n, bd); break;
+    case 4: hipLaunchKernelGGL(k_hevc_idct<4>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n, bd); break;
+    case 5: hipLaunchKernelGGL(k_hevc_idct<5>, grid, block, 0, stream, kind, coeffs, dst, stride, tus, n, bd); break;
     default:
         ffhip_set_error("ffhip_hevc_idct: log2_size %d outside 2..5", log2_size);
         return FFHIP_EINVAL;
@@ -251,16 +281,21 @@ int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *ds
  */
 __device__ __forceinline__ int hv_abs(int v) { return v < 0 ? -v : v; }
 
-__global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n)
+/* PIX = uint8_t (bd 8) / uint16_t: beta and tc arrive in 8-bit units and are scaled as the reference's templates scale them
+ * (beta <<= BIT_DEPTH - 8, tc = _tc[j] << (BIT_DEPTH - 8): hevc/dsp_template.c:845,862,907); stride and offsets in bytes */
+template <typename PIX>
+__global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, int bd)
 {
+    const int maxv = (1 << bd) - 1;
+    auto clipp = [&](int v) { return min(max(v, 0), maxv); };
     const int e = (blockIdx.x * 256 + threadIdx.x) >> 3;
     const int line = threadIdx.x & 7, j = line >> 2, d = line & 3;
     const bool live = e < n;
     const FFHipHevcEdge ed = edges[live ? e : 0];
     const bool vertical = ed.kind & 1, chroma = ed.kind & 2;
-    const ptrdiff_t xs = vertical ? 1 : stride, ys = vertical ? stride : 1;
-    uint8_t *pix = base + ed.offset + (ptrdiff_t)line * ys;
-    const int tc = ed.tc[j], no_p = ed.no_p[j], no_q = ed.no_q[j], beta = ed.beta;
+    const ptrdiff_t st = stride / (ptrdiff_t)sizeof(PIX), xs = vertical ? 1 : st, ys = vertical ? st : 1;
+    PIX *pix = reinterpret_cast<PIX *>(base + ed.offset) + (ptrdiff_t)line * ys;
+    const int tc = ed.tc[j] << (bd - 8), no_p = ed.no_p[j], no_q = ed.no_q[j], beta = ed.beta << (bd - 8);
     int p3 = 0, p2 = 0, p1 = 0, p0 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (live) {
         p1 = pix[-2 * xs]; p0 = pix[-xs]; q0 = pix[0]; q1 = pix[xs];
@@ -271,8 +306,8 @@ __global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff
     if (chroma) {
         if (live && tc > 0) {
             const int delta = clip3((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
-            if (!no_p) pix[-xs] = (uint8_t)clip_u8(p0 + delta);
-            if (!no_q) pix[0] = (uint8_t)clip_u8(q0 - delta);
+            if (!no_p) pix[-xs] = (PIX)clipp(p0 + delta);
+            if (!no_q) pix[0] = (PIX)clipp(q0 - delta);
         }
         return;
     }
@@ -292,14 +327,14 @@ __global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff
     if (flat0 < beta_3 && step0 < tc25 && flat3 < beta_3 && step3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
         const int t = tc << 1;
         if (!no_p) {
-            pix[-xs]     = (uint8_t)(p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -t, t));
-            pix[-2 * xs] = (uint8_t)(p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -t, t));
-            pix[-3 * xs] = (uint8_t)(p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -t, t));
+            pix[-xs]     = (PIX)(p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -t, t));
+            pix[-2 * xs] = (PIX)(p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -t, t));
+            pix[-3 * xs] = (PIX)(p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -t, t));
         }
         if (!no_q) {
-            pix[0]      = (uint8_t)(q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -t, t));
-            pix[xs]     = (uint8_t)(q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -t, t));
-            pix[2 * xs] = (uint8_t)(q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -t, t));
+            pix[0]      = (PIX)(q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -t, t));
+            pix[xs]     = (PIX)(q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -t, t));
+            pix[2 * xs] = (PIX)(q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -t, t));
         }
     } else {
         const int side = (beta + (beta >> 1)) >> 3;
@@ -307,21 +342,33 @@ __global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff
         int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
         if (hv_abs(delta) < 10 * tc) {
             delta = clip3(delta, -tc, tc);
-            if (!no_p) pix[-xs] = (uint8_t)clip_u8(p0 + delta);
-            if (!no_q) pix[0] = (uint8_t)clip_u8(q0 - delta);
+            if (!no_p) pix[-xs] = (PIX)clipp(p0 + delta);
+            if (!no_q) pix[0] = (PIX)clipp(q0 - delta);
             if (!no_p && nd_p > 1)
-                pix[-2 * xs] = (uint8_t)clip_u8(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2));
+                pix[-2 * xs] = (PIX)clipp(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2));
             if (!no_q && nd_q > 1)
-                pix[xs] = (uint8_t)clip_u8(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2));
+                pix[xs] = (PIX)clipp(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2));
         }
     }
 }
 
 int ffhip_launch_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, hipStream_t stream)
 {
+    return ffhip_launch_hevc_loop_filter_bd(8, base, stride, edges, n, stream);
+}
+
+int ffhip_launch_hevc_loop_filter_bd(int bd, uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, hipStream_t stream)
+{
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(k_hevc_loop_filter, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n);
+    if (bd == 8)
+        hipLaunchKernelGGL(k_hevc_loop_filter<uint8_t>, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n, 8);
+    else if ((bd == 10 || bd == 12) && !(((uintptr_t)base | (size_t)stride) & 1))
+        hipLaunchKernelGGL(k_hevc_loop_filter<uint16_t>, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n, bd);
+    else {
+        ffhip_set_error("ffhip_hevc_loop_filter: bit depth %d (8, 10, 12) / 16-bit planes must be 2-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
     LAUNCH_CHECK();
     return 0;
 }
@@ -436,6 +483,55 @@ __global__ __launch_bounds__(256) void k_hevc_sao(uint8_t *dst, ptrdiff_t sd, co
     }
 }
 
+/* the same two filters on uint16_t samples (bd 10 / 12): band = (sample >> (bd - 5)) & 31 (h2656_sao_template.c:33), a lane per
+ * two samples = one dword where the rows allow, offsets as they arrive (the decoder has scaled them by << (bd - min(bd, 10))) */
+__global__ __launch_bounds__(256) void k_hevc_sao16(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n,
+                                                    int bd)
+{
+    const int b = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (b >= n)
+        return;
+    const FFHipHevcSao k = blocks[b];
+    const int w = k.width, h = k.height, cls = k.cls, eo = cls & 3, maxv = (1 << bd) - 1, bshift = bd - 5;
+    const bool edge = k.edge != 0;
+    static const int8_t dxs[4][2] = { { -1, 1 }, { 0, 0 }, { -1, 1 }, { 1, -1 } }, dys[4][2] = { { 0, 0 }, { -1, 1 }, { -1, 1 }, { -1, 1 } };
+    const ptrdiff_t sp = ss / 2, a = dxs[eo][0] + dys[eo][0] * sp, bb = dxs[eo][1] + dys[eo][1] * sp;
+    const uint16_t *s0 = reinterpret_cast<const uint16_t *>(src + k.src_offset);
+    uint8_t *d0 = dst + k.dst_offset;
+    const int o0 = k.offset_val[0], o1 = k.offset_val[1], o2 = k.offset_val[2], o3 = k.offset_val[3], o4 = k.offset_val[4];
+    for (int t = lane; t < w * h; t += 64) {
+        const int y = t / w, x = t - y * w;
+        const uint16_t *p = s0 + (ptrdiff_t)y * sp + x;
+        const int c = p[0];
+        int off;
+        if (edge) {
+            const int na = p[a], nb = p[bb];
+            const int sel = 2 + (c > na) - (c < na) + (c > nb) - (c < nb); /* edge_idx = { 1, 2, 0, 3, 4 } */
+            off = sel == 0 ? o1 : sel == 1 ? o2 : sel == 2 ? o0 : sel == 3 ? o3 : o4;
+        } else {
+            const int band = (((c >> bshift) & 31) - cls) & 31;           /* 0..3: the signalled bands */
+            off = band == 0 ? o1 : band == 1 ? o2 : band == 2 ? o3 : band == 3 ? o4 : 0;
+        }
+        reinterpret_cast<uint16_t *>(d0 + (ptrdiff_t)y * sd)[x] = (uint16_t)min(max(c + off, 0), maxv);
+    }
+}
+
+int ffhip_launch_hevc_sao_bd(int bd, uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n,
+                             hipStream_t stream)
+{
+    if (bd == 8)
+        return ffhip_launch_hevc_sao(dst, sd, src, ss, blocks, n, stream);
+    if (n <= 0)
+        return 0;
+    if ((bd != 10 && bd != 12) || (((uintptr_t)dst | (uintptr_t)src | (size_t)sd | (size_t)ss) & 1)) {
+        ffhip_set_error("ffhip_hevc_sao: bit depth %d (8, 10, 12) / 16-bit planes must be 2-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
+    hipLaunchKernelGGL(k_hevc_sao16, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, sd, src, ss, blocks, n, bd);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int ffhip_launch_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSao *blocks, int n, hipStream_t stream)
 {
     if (n <= 0)
@@ -453,9 +549,11 @@ int ffhip_launch_hevc_sao(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdif
  * no ordering inside.  One wave per block.
  */
 static_assert(sizeof(FFHipHevcSaoRestore) == 20, "FFHipHevcSaoRestore is a 20-byte record");
+template <typename PIX>
 __global__ __launch_bounds__(256) void k_hevc_sao_restore(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss,
-                                                          const FFHipHevcSaoRestore *blocks, int n)
+                                                          const FFHipHevcSaoRestore *blocks, int n, int bd)
 {
+    const int maxv = (1 << bd) - 1;
     const int b = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (b >= n)
         return;
@@ -505,8 +603,8 @@ __global__ __launch_bounds__(256) void k_hevc_sao_restore(uint8_t *dst, ptrdiff_
             if (de3 && eo == D45 && x == 0 && y == h - 1) kind = 2;
         }
         if (kind) {
-            const int v = s0[(ptrdiff_t)y * ss + x];
-            d0[(ptrdiff_t)y * sd + x] = (uint8_t)(kind == 1 ? clip_u8(v + off) : v);
+            const int v = reinterpret_cast<const PIX *>(s0 + (ptrdiff_t)y * ss)[x];
+            reinterpret_cast<PIX *>(d0 + (ptrdiff_t)y * sd)[x] = (PIX)(kind == 1 ? min(max(v + off, 0), maxv) : v);
         }
     }
 }
@@ -514,9 +612,22 @@ __global__ __launch_bounds__(256) void k_hevc_sao_restore(uint8_t *dst, ptrdiff_
 int ffhip_launch_hevc_sao_restore(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSaoRestore *blocks, int n,
                                   hipStream_t stream)
 {
+    return ffhip_launch_hevc_sao_restore_bd(8, dst, sd, src, ss, blocks, n, stream);
+}
+
+int ffhip_launch_hevc_sao_restore_bd(int bd, uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSaoRestore *blocks,
+                                     int n, hipStream_t stream)
+{
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(k_hevc_sao_restore, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, sd, src, ss, blocks, n);
+    if (bd == 8)
+        hipLaunchKernelGGL(k_hevc_sao_restore<uint8_t>, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, sd, src, ss, blocks, n, 8);
+    else if ((bd == 10 || bd == 12) && !(((uintptr_t)dst | (uintptr_t)src | (size_t)sd | (size_t)ss) & 1))
+        hipLaunchKernelGGL(k_hevc_sao_restore<uint16_t>, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, sd, src, ss, blocks, n, bd);
+    else {
+        ffhip_set_error("ffhip_hevc_sao_restore: bit depth %d (8, 10, 12) / 16-bit planes must be 2-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
     LAUNCH_CHECK();
     return 0;
 }

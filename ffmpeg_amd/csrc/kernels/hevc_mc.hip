@@ -248,10 +248,13 @@ __global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride
  * 24-byte weighted record.
  */
 static_assert(sizeof(FFHipHevcMcWBlock) == 24, "FFHipHevcMcWBlock is a 24-byte record");
-template <bool CHROMA, int MODE>
+template <typename PIX, bool CHROMA, int MODE>
 __global__ __launch_bounds__(256) void k_hevc_mc_s(void *dst_, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
-                                                 const int16_t *src2, const void *blocks_, int n)
+                                                 const int16_t *src2, const void *blocks_, int n, int bd)
 {
+    /* PIX = uint8_t (bd 8) / uint16_t (bd 10, 12; strides and offsets stay in bytes).  Above 8 bits the one-dimensional sums drop
+     * bd - 8 bits, the unfiltered copy gains 14 - bd, and every output stage shifts by its 8-bit amount minus (bd - 8), offsets
+     * scaled by << (bd - 8) (h2656_inter_template.c:29-88,113-245; hevc/dsp_template.c:368-440) */
     constexpr bool UNI = MODE == 1;
     using Rec = typename std::conditional<(MODE >= 2), FFHipHevcMcWBlock, FFHipHevcMcBlock>::type;
     const Rec *blocks = static_cast<const Rec *>(blocks_);
@@ -263,15 +266,17 @@ __global__ __launch_bounds__(256) void k_hevc_mc_s(void *dst_, ptrdiff_t dststri
         return;
     const Rec k = blocks[b];
     const int w = k.width, h = k.height, mx = k.mx & (CHROMA ? 7 : 3), my = k.my & (CHROMA ? 7 : 3);
+    const int sh1 = bd - 8, shu = 14 - bd, maxv = (1 << bd) - 1;
+    const ptrdiff_t sst = srcstride / (ptrdiff_t)sizeof(PIX);
     int wx0 = 0, wx1 = 0, wofs = 0, wsh = 0, ox = 0;
     const int16_t *s2 = nullptr;
     if constexpr (MODE >= 2) {
-        wx0 = k.wx0; wx1 = k.wx1; ox = k.ox;
-        wsh = k.denom + 6;                                   /* uni_w: shift = denom + 14 - 8;  bi_w: log2Wd = denom + 6 */
+        wx0 = k.wx0; wx1 = k.wx1; ox = k.ox * (1 << sh1);
+        wsh = k.denom + shu;                                 /* uni_w: shift = denom + 14 - bd;  bi_w: log2Wd = denom + 14 - bd */
         wofs = MODE == 2 ? 1 << (wsh - 1) : (ox + 1) << wsh;
         s2 = src2 + k.src2_offset;
     }
-    const uint8_t *s = src + k.src_offset;
+    const PIX *s = reinterpret_cast<const PIX *>(src + k.src_offset);
     int16_t *tmp = tmp_all[wave];
     int hf[TAPS], vf[TAPS];
 #pragma unroll
@@ -282,31 +287,33 @@ __global__ __launch_bounds__(256) void k_hevc_mc_s(void *dst_, ptrdiff_t dststri
     if (mx && my) {
         for (int i = lane; i < w * (h + TAPS - 1); i += 64) {
             const int r = i / w, x = i - r * w;
-            const uint8_t *p = s + (ptrdiff_t)(r - BEFORE) * srcstride + x - BEFORE;
+            const PIX *p = s + (ptrdiff_t)(r - BEFORE) * sst + x - BEFORE;
             int acc = 0;
 #pragma unroll
             for (int t = 0; t < TAPS; t++)
                 acc += hf[t] * p[t];
-            tmp[r * 64 + x] = (int16_t)acc;
+            tmp[r * 64 + x] = (int16_t)(acc >> sh1);
         }
         hevc_wave_sync();
     }
     for (int i = lane; i < w * h; i += 64) {
         const int y = i / w, x = i - y * w;
-        const uint8_t *p = s + (ptrdiff_t)y * srcstride + x;
+        const PIX *p = s + (ptrdiff_t)y * sst + x;
         int val;
         if (!mx && !my) {
-            val = p[0] << 6;
+            val = p[0] << shu;
         } else if (!my) {
             val = 0;
 #pragma unroll
             for (int t = 0; t < TAPS; t++)
                 val += hf[t] * p[t - BEFORE];
+            val >>= sh1;
         } else if (!mx) {
             val = 0;
 #pragma unroll
             for (int t = 0; t < TAPS; t++)
-                val += vf[t] * p[(ptrdiff_t)(t - BEFORE) * srcstride];
+                val += vf[t] * p[(ptrdiff_t)(t - BEFORE) * sst];
+            val >>= sh1;
         } else {
             int acc = 0;
 #pragma unroll
@@ -315,17 +322,17 @@ __global__ __launch_bounds__(256) void k_hevc_mc_s(void *dst_, ptrdiff_t dststri
             val = acc >> 6;
         }
         if constexpr (MODE >= 1) {
-            uint8_t *d = static_cast<uint8_t *>(dst_) + k.dst_offset + (ptrdiff_t)y * dststride + x;
+            PIX *d = reinterpret_cast<PIX *>(static_cast<uint8_t *>(dst_) + k.dst_offset + (ptrdiff_t)y * dststride) + x;
             int out;
             if constexpr (UNI)
-                out = (!mx && !my) ? p[0] : (val + 32) >> 6;
+                out = (!mx && !my) ? p[0] : (val + (1 << (shu - 1))) >> shu;
             else if constexpr (MODE == 2)
                 out = ((val * wx0 + wofs) >> wsh) + ox;
             else if constexpr (MODE == 3)
-                out = (val + s2[y * 64 + x] + 64) >> 7;
+                out = (val + s2[y * 64 + x] + (1 << shu)) >> (shu + 1);
             else
                 out = (val * wx1 + s2[y * 64 + x] * wx0 + wofs) >> (wsh + 1);
-            *d = (uint8_t)clip_u8(out);
+            *d = (PIX)min(max(out, 0), maxv);
         } else {
             static_cast<int16_t *>(dst_)[(ptrdiff_t)k.dst_offset + y * 64 + x] = (int16_t)val;
         }
@@ -339,7 +346,7 @@ static void hevc_mc_launch(int mode, bool old, void *dst, ptrdiff_t dststride, c
     const dim3 grid(cdiv(n, 4)), block(256);
 #define MC_CASE(M)                                                                                                                  \
     case M:                                                                                                                         \
-        if (old) hipLaunchKernelGGL((k_hevc_mc_s<CHROMA, M>), grid, block, 0, stream, dst, dststride, src, srcstride, src2, blocks, n); \
+        if (old) hipLaunchKernelGGL((k_hevc_mc_s<uint8_t, CHROMA, M>), grid, block, 0, stream, dst, dststride, src, srcstride, src2, blocks, n, 8); \
         else     hipLaunchKernelGGL((k_hevc_mc<CHROMA, M>), grid, block, 0, stream, dst, dststride, src, srcstride, src2, blocks, n);   \
         break;
     switch (mode) {
@@ -362,6 +369,40 @@ int ffhip_launch_hevc_mc(int chroma, int mode, void *dst, ptrdiff_t dststride, c
         hevc_mc_launch<true>(mode, old, dst, dststride, src, srcstride, src2, blocks, n, stream);
     else
         hevc_mc_launch<false>(mode, old, dst, dststride, src, srcstride, src2, blocks, n, stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/* 16-bit samples (bd 10 / 12): the sample-per-lane kernel on uint16_t */
+template <bool CHROMA>
+static void hevc_mc_launch16(int mode, int bd, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                             const void *blocks, int n, hipStream_t stream)
+{
+    const dim3 grid(cdiv(n, 4)), block(256);
+#define MC_CASE(M) case M: hipLaunchKernelGGL((k_hevc_mc_s<uint16_t, CHROMA, M>), grid, block, 0, stream, dst, dststride, src, srcstride, src2, blocks, n, bd); break;
+    switch (mode) {
+    MC_CASE(0) MC_CASE(1) MC_CASE(2) MC_CASE(3)
+    default:
+    MC_CASE(4)
+    }
+#undef MC_CASE
+}
+
+int ffhip_launch_hevc_mc_bd(int bd, int chroma, int mode, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                            const int16_t *src2, const void *blocks, int n, hipStream_t stream)
+{
+    if (bd == 8)
+        return ffhip_launch_hevc_mc(chroma, mode, dst, dststride, src, srcstride, src2, blocks, n, stream);
+    if (n <= 0)
+        return 0;
+    if ((bd != 10 && bd != 12) || (((uintptr_t)dst | (uintptr_t)src | (size_t)dststride | (size_t)srcstride) & 1)) {
+        ffhip_set_error("ffhip_hevc_mc: bit depth %d (8, 10, 12) / 16-bit planes must be 2-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
+    if (chroma)
+        hevc_mc_launch16<true>(mode, bd, dst, dststride, src, srcstride, src2, blocks, n, stream);
+    else
+        hevc_mc_launch16<false>(mode, bd, dst, dststride, src, srcstride, src2, blocks, n, stream);
     LAUNCH_CHECK();
     return 0;
 }

@@ -1,5 +1,6 @@
 """ctypes mirror of the hevcdsp inverse-transform faces of libffhip (include/ffhip.h): HEVCDSPContext.idct / idct_dc /
-transform_4x4_luma / add_residual (libavcodec/hevc/dsp.h:46-61), 8-bit."""
+transform_4x4_luma / add_residual (libavcodec/hevc/dsp.h:46-61).  bit_depth = 8 (uint8 planes) or 10 / 12 (uint16 planes; strides and
+record offsets stay in bytes): the *_hbd entry points."""
 import ctypes as C
 
 import numpy as np
@@ -16,10 +17,11 @@ def _stream(stream):
     return None if stream is None else C.c_void_p(stream)
 
 
-def idct_batch(kind, log2_size, coeffs, dst, stride, tus, n, stream=None):
-    """coeffs: int16 device tensor (transformed in place); dst: uint8 device tensor or None; tus: uint8 [n, 12] FFHipHevcTU"""
-    return _lib.check(_lib.lib().ffhip_hevc_idct_batch_dev(kind, log2_size, coeffs.data_ptr(), dst.data_ptr() if dst is not None else None,
-                                                           stride, tus.data_ptr(), n, _stream(stream)), "ffhip_hevc_idct_batch_dev")
+def idct_batch(kind, log2_size, coeffs, dst, stride, tus, n, stream=None, bit_depth=8):
+    """coeffs: int16 device tensor (transformed in place); dst: uint8 / uint16 device tensor or None; tus: uint8 [n, 12] FFHipHevcTU"""
+    return _lib.check(_lib.lib().ffhip_hevc_idct_batch_dev_hbd(bit_depth, kind, log2_size, coeffs.data_ptr(),
+                                                               dst.data_ptr() if dst is not None else None, stride, tus.data_ptr(), n,
+                                                               _stream(stream)), "ffhip_hevc_idct_batch_dev_hbd")
 
 
 LF_H_LUMA, LF_V_LUMA, LF_H_CHROMA, LF_V_CHROMA = 0, 1, 2, 3
@@ -29,10 +31,13 @@ EDGE_DTYPE = np.dtype([("offset", np.int32), ("kind", np.uint8), ("beta", np.uin
                        ("tc", np.int16, 2), ("pad", np.uint8, 2)])
 
 
-def loop_filter_batch(base, stride, edges, n, stream=None):
+def loop_filter_batch(base, stride, edges, n, stream=None, bit_depth=8):
     """edges: uint8 [n, 16] FFHipHevcEdge records whose pixels are disjoint (one direction of a picture per call)"""
-    return _lib.check(_lib.lib().ffhip_hevc_loop_filter_batch_dev(base.data_ptr(), stride, edges.data_ptr(), n, _stream(stream)),
-                      "ffhip_hevc_loop_filter_batch_dev")
+    if bit_depth == 8:
+        return _lib.check(_lib.lib().ffhip_hevc_loop_filter_batch_dev(base.data_ptr(), stride, edges.data_ptr(), n, _stream(stream)),
+                          "ffhip_hevc_loop_filter_batch_dev")
+    return _lib.check(_lib.lib().ffhip_hevc_loop_filter_batch_dev_hbd(bit_depth, base.data_ptr(), stride, edges.data_ptr(), n, _stream(stream)),
+                      "ffhip_hevc_loop_filter_batch_dev_hbd")
 
 
 #: FFHipHevcSao (include/ffhip.h)
@@ -40,10 +45,13 @@ SAO_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("offs
                       ("width", np.uint8), ("height", np.uint8), ("pad", np.uint8, 2)])
 
 
-def sao_batch(dst, stride_dst, src, stride_src, blocks, n, stream=None):
+def sao_batch(dst, stride_dst, src, stride_src, blocks, n, stream=None, bit_depth=8):
     """blocks: uint8 [n, 24] FFHipHevcSao records"""
-    return _lib.check(_lib.lib().ffhip_hevc_sao_batch_dev(dst.data_ptr(), stride_dst, src.data_ptr(), stride_src, blocks.data_ptr(), n,
-                                                          _stream(stream)), "ffhip_hevc_sao_batch_dev")
+    if bit_depth == 8:
+        return _lib.check(_lib.lib().ffhip_hevc_sao_batch_dev(dst.data_ptr(), stride_dst, src.data_ptr(), stride_src, blocks.data_ptr(), n,
+                                                              _stream(stream)), "ffhip_hevc_sao_batch_dev")
+    return _lib.check(_lib.lib().ffhip_hevc_sao_batch_dev_hbd(bit_depth, dst.data_ptr(), stride_dst, src.data_ptr(), stride_src, blocks.data_ptr(),
+                                                              n, _stream(stream)), "ffhip_hevc_sao_batch_dev_hbd")
 
 
 #: FFHipHevcMcBlock (include/ffhip.h)
@@ -51,10 +59,13 @@ MC_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("width
                      ("my", np.uint8)])
 
 
-def mc_batch(chroma, uni, dst, dststride, src, srcstride, blocks, n, stream=None):
-    """blocks: uint8 [n, 12] FFHipHevcMcBlock records; dst: uint8 (uni) or int16 (plain, rows 64 elements apart) device tensor"""
-    return _lib.check(_lib.lib().ffhip_hevc_mc_batch_dev(chroma, uni, dst.data_ptr(), dststride, src.data_ptr(), srcstride, blocks.data_ptr(), n,
-                                                         _stream(stream)), "ffhip_hevc_mc_batch_dev")
+def mc_batch(chroma, uni, dst, dststride, src, srcstride, blocks, n, stream=None, bit_depth=8):
+    """blocks: uint8 [n, 12] FFHipHevcMcBlock records; dst: pixels (uni) or int16 (plain, rows 64 elements apart) device tensor"""
+    if bit_depth == 8:
+        return _lib.check(_lib.lib().ffhip_hevc_mc_batch_dev(chroma, uni, dst.data_ptr(), dststride, src.data_ptr(), srcstride, blocks.data_ptr(),
+                                                             n, _stream(stream)), "ffhip_hevc_mc_batch_dev")
+    return _lib.check(_lib.lib().ffhip_hevc_mc_batch_dev_hbd(bit_depth, chroma, uni, dst.data_ptr(), dststride, src.data_ptr(), srcstride,
+                                                             blocks.data_ptr(), n, _stream(stream)), "ffhip_hevc_mc_batch_dev_hbd")
 
 
 class SAOParams(C.Structure):
@@ -69,10 +80,13 @@ RESTORE_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("
                           ("diag_edge", np.uint8), ("pad", np.uint8, 2)])
 
 
-def sao_restore_batch(dst, stride_dst, src, stride_src, blocks, n, stream=None):
+def sao_restore_batch(dst, stride_dst, src, stride_src, blocks, n, stream=None, bit_depth=8):
     """blocks: uint8 [n, 20] FFHipHevcSaoRestore records"""
-    return _lib.check(_lib.lib().ffhip_hevc_sao_restore_batch_dev(dst.data_ptr(), stride_dst, src.data_ptr(), stride_src, blocks.data_ptr(), n,
-                                                                  _stream(stream)), "ffhip_hevc_sao_restore_batch_dev")
+    if bit_depth == 8:
+        return _lib.check(_lib.lib().ffhip_hevc_sao_restore_batch_dev(dst.data_ptr(), stride_dst, src.data_ptr(), stride_src, blocks.data_ptr(),
+                                                                      n, _stream(stream)), "ffhip_hevc_sao_restore_batch_dev")
+    return _lib.check(_lib.lib().ffhip_hevc_sao_restore_batch_dev_hbd(bit_depth, dst.data_ptr(), stride_dst, src.data_ptr(), stride_src,
+                                                                      blocks.data_ptr(), n, _stream(stream)), "ffhip_hevc_sao_restore_batch_dev_hbd")
 
 
 MC_UNI_W, MC_BI, MC_BI_W = 2, 3, 4
@@ -83,11 +97,14 @@ MCW_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("src2
                       ("pad", np.uint8)])
 
 
-def mc_w_batch(chroma, mode, dst, dststride, src, srcstride, src2, blocks, n, stream=None):
+def mc_w_batch(chroma, mode, dst, dststride, src, srcstride, src2, blocks, n, stream=None, bit_depth=8):
     """blocks: uint8 [n, 24] FFHipHevcMcWBlock records; src2: int16 device tensor (the other list's put_hevc_* output) or None for uni_w"""
-    return _lib.check(_lib.lib().ffhip_hevc_mc_w_batch_dev(chroma, mode, dst.data_ptr(), dststride, src.data_ptr(), srcstride,
-                                                           src2.data_ptr() if src2 is not None else None, blocks.data_ptr(), n, _stream(stream)),
-                      "ffhip_hevc_mc_w_batch_dev")
+    s2 = src2.data_ptr() if src2 is not None else None
+    if bit_depth == 8:
+        return _lib.check(_lib.lib().ffhip_hevc_mc_w_batch_dev(chroma, mode, dst.data_ptr(), dststride, src.data_ptr(), srcstride, s2,
+                                                               blocks.data_ptr(), n, _stream(stream)), "ffhip_hevc_mc_w_batch_dev")
+    return _lib.check(_lib.lib().ffhip_hevc_mc_w_batch_dev_hbd(bit_depth, chroma, mode, dst.data_ptr(), dststride, src.data_ptr(), srcstride, s2,
+                                                               blocks.data_ptr(), n, _stream(stream)), "ffhip_hevc_mc_w_batch_dev_hbd")
 
 
 _UNI_W = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int)

@@ -819,6 +819,26 @@ typedef struct FFHipHevcSaoRestore {
 int ffhip_hevc_sao_restore_batch_dev(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src,
                                      const FFHipHevcSaoRestore *blocks, int n, void *stream);
 
+/**
+ * hevcdsp above 8 bits (Main10 / Main12 streams): the batch faces above with the BIT_DEPTH the reference instantiates its templates
+ * for (libavcodec/hevc/dsp.c:133-196; bit_depth_template.c: pixel = uint16_t, av_clip_pixel to (1 << bit_depth) - 1).  bit_depth
+ * 8, 10 or 12; 8 is the face without the suffix.  Records are unchanged: pixel offsets and strides stay in BYTES as in the
+ * reference's signatures (16-bit planes 2-byte aligned); beta / tc / SAO offsets / weights are the values the decoder passes —
+ * the scaling by << (bit_depth - 8) happens inside, where the reference's templates do it (hevc/dsp_template.c:845,862,907;
+ * h2656_inter_template.c:72; dsp_template.c:408).  Coefficients and the put_hevc_* intermediates are int16 at every depth.
+ */
+int ffhip_hevc_idct_batch_dev_hbd(int bit_depth, int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride,
+                                  const FFHipHevcTU *tus, int n, void *stream);
+int ffhip_hevc_loop_filter_batch_dev_hbd(int bit_depth, uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, void *stream);
+int ffhip_hevc_sao_batch_dev_hbd(int bit_depth, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src,
+                                 const FFHipHevcSao *blocks, int n, void *stream);
+int ffhip_hevc_sao_restore_batch_dev_hbd(int bit_depth, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *src, ptrdiff_t stride_src,
+                                         const FFHipHevcSaoRestore *blocks, int n, void *stream);
+int ffhip_hevc_mc_batch_dev_hbd(int bit_depth, int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                const FFHipHevcMcBlock *blocks, int n, void *stream);
+int ffhip_hevc_mc_w_batch_dev_hbd(int bit_depth, int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src,
+                                  ptrdiff_t srcstride, const int16_t *src2, const FFHipHevcMcWBlock *blocks, int n, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: vp9dsp inverse transforms                                    */
 /* ------------------------------------------------------------------------------------------ */

@@ -92,6 +92,25 @@ void ffo_h264_biweight(int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride
 #define FFO_FDSP_FMUL_REVERSE  5   /* dst[i] = src0[i] * src1[len-1-i]                    */
 #define FFO_FDSP_BUTTERFLIES   6   /* (dst, src0) = (dst + src0, dst - src0), both written */
 void ffo_fdsp(int op, float *dst, const float *src0, const float *src1, const float *src2, float mul, int len);
+/* ---- hevcdsp at a given bit depth (8, 10, 12): pixels are uint16_t above 8 bits, strides in BYTES (ffo_hevc.c) ---- */
+void ffo_hevc_idct_bd(int bd, int log2_size, int16_t *coeffs, int col_limit);
+void ffo_hevc_idct_dc_bd(int bd, int log2_size, int16_t *coeffs);
+void ffo_hevc_transform_4x4_luma_bd(int bd, int16_t *coeffs);
+void ffo_hevc_add_residual_bd(int bd, int log2_size, uint8_t *dst, const int16_t *res, ptrdiff_t stride);
+void ffo_hevc_dequant_bd(int bd, int16_t *coeffs, int log2_size);
+void ffo_hevc_loop_filter_bd(int bd, int chroma, int vertical, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc,
+                             const uint8_t *no_p, const uint8_t *no_q);
+void ffo_hevc_sao_band_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
+                          int left_class, int width, int height);
+void ffo_hevc_sao_edge_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, const int16_t *offset_val,
+                          int eo, int width, int height);
+void ffo_hevc_sao_edge_restore_bd(int bd, int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, int eo, int offset0,
+                                  const int *borders, int width, int height, const uint8_t *vert_edge, const uint8_t *horiz_edge,
+                                  const uint8_t *diag_edge);
+void ffo_hevc_mc_bd(int bd, int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
+                    int my, int width);
+void ffo_hevc_mc_w_bd(int bd, int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                      const int16_t *src2, int height, int denom, int wx0, int wx1, int ox, int mx, int my, int width);
 /* ---- HEVC inverse transforms, 8-bit (ffo_hevc.c): HEVCDSPContext.idct / idct_dc / transform_4x4_luma / add_residual ---- */
 int  ffo_hevc_coef(int k, int i);                                   /* the 32-point core matrix */
 void ffo_hevc_idct(int log2_size, int16_t *coeffs, int col_limit);  /* log2_size 2..5 */

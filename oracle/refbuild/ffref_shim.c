@@ -143,6 +143,13 @@ static void dsp_init(void)
     ff_hevc_dsp_init(&hevc, 8);
     dsp_ready = 1;
 }
+/* the depth the ffref_hevc_* calls below run at: HEVCDSPContext is re-initialised the way the decoder does per SPS
+ * (ff_hevc_dsp_init(&s->hevcdsp, sps->bit_depth), hevc/hevcdec.c); pixels are uint16_t above 8 bits */
+void ffref_hevc_set_bit_depth(int bit_depth)
+{
+    dsp_init();
+    ff_hevc_dsp_init(&hevc, bit_depth);
+}
 void ffref_h264_idct(int which, uint8_t *dst, int16_t *block, ptrdiff_t stride)
 {
     dsp_init();

@@ -122,6 +122,9 @@ def oracle():
         L.ffo_aac_tns_run.restype = None
         L.ffo_fdsp.argtypes = [C.c_int, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
         L.ffo_fdsp.restype = None
+        L.ffo_h264_hl_decode_intra_mb.argtypes = [u8p, u8p, u8p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, C.c_int, u8p, C.c_uint, C.c_uint,
+                                                  u8p, C.c_int, i16p, i16p, i32p, u8p]
+        L.ffo_h264_hl_decode_intra_mb.restype = None
         L.ffo_hevc_coef.argtypes = [C.c_int, C.c_int]
         L.ffo_hevc_coef.restype = C.c_int
         L.ffo_hevc_idct.argtypes = [C.c_int, i16p, C.c_int]
@@ -170,6 +173,14 @@ def oracle():
         L.ffo_hevc_sao_edge.restype = None
         L.ffo_hevc_loop_filter.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, i32p, u8p, u8p]
         L.ffo_hevc_loop_filter.restype = None
+        # the same members at a given bit depth: a leading `bd`, pixels uint16 above 8 bits, strides in bytes
+        for name in ("idct", "idct_dc", "transform_4x4_luma", "add_residual", "mc", "mc_w", "sao_edge_restore", "sao_band",
+                     "sao_edge", "loop_filter"):
+            f8, fb = getattr(L, "ffo_hevc_" + name), getattr(L, "ffo_hevc_" + name + "_bd")
+            fb.argtypes = [C.c_int] + list(f8.argtypes)
+            fb.restype = None
+        L.ffo_hevc_dequant_bd.argtypes = [C.c_int, i16p, C.c_int]
+        L.ffo_hevc_dequant_bd.restype = None
         L.ffo_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_h264_biweight.restype = None
         L.ffo_h264_deblock_frame.argtypes = [u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
@@ -309,6 +320,12 @@ def ref():
         L.ffref_hevc_sao_edge.restype = None
         L.ffref_hevc_loop_filter.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, i32p, u8p, u8p]
         L.ffref_hevc_loop_filter.restype = None
+        if hasattr(L, "ffref_hevc_set_bit_depth"):
+            L.ffref_hevc_set_bit_depth.argtypes = [C.c_int]
+            L.ffref_hevc_set_bit_depth.restype = None
+        if hasattr(L, "ffref_h264_hl_decode_intra_mb"):
+            L.ffref_h264_hl_decode_intra_mb.argtypes = [u8p, u8p, u8p] + [C.c_int] * 8 + [u8p, C.c_uint, C.c_uint, u8p, C.c_int, i16p, i16p, i32p, u8p]
+            L.ffref_h264_hl_decode_intra_mb.restype = C.c_int
         L.ffref_h264_biweight.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffref_h264_biweight.restype = None
         L.ffref_me_cmp.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]

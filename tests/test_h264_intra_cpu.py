@@ -44,7 +44,7 @@ def test_oracle_hl_decode_mb_vs_reference(mtype):
         R.ffref_h264_hl_decode_intra_mb(C.cast(at[0], u8), C.cast(at[1], u8), C.cast(at[2], u8), st[0], st[1], mx, my, mb_w, d["type"],
                                         d["pred16"], d["chroma_pred"], G._p(d["pred4"], C.c_uint8), d["topleft"], d["topright"],
                                         G._p(d["nnzc"], C.c_uint8), d["cbp"], G._p(mb_ref, C.c_int16), G._p(dc, C.c_int16),
-                                        G._p(d["qmul"], C.c_int), G._p(d["pcm"], C.c_uint8))
+                                        G._p(d["qmul"], C.c_int32), G._p(d["pcm"], C.c_uint8))
         got = [p.copy() for p in planes]
         mb_o = G.oracle_decode(O, d, got, st)
         for pl in range(3):
