@@ -434,13 +434,19 @@ extern "C" int ff_h264dsp_weight_init_hip(FFHipH264WeightContext *c, int bit_dep
     return 0;
 }
 
-/* ---- hevcdsp inverse transforms --------------------------------------------------------------------------- */
+/* ---- hevcdsp: every face exists per bit depth (8: uint8_t samples; 10 / 12: uint16_t, hevc/dsp.c:133-196) — the members carry
+ * no context, so the depth is baked into the function like the reference's template instantiations.  ps = bytes per sample; the
+ * staged rectangles and pitches below are in bytes. ------------------------------------------------------------------------- */
+static constexpr int hevc_bdi(int bd) { return bd == 8 ? 0 : bd == 10 ? 1 : 2; }
+static FFHipHEVCDSPContext g_fb_hevc[3];
+#define HEVC_FB(BD) g_fb_hevc[hevc_bdi(BD)]
+
 /* layout in scratch: [0,64) the TU record, [64, 64+2*n*n) coefficients, then the picture rectangle */
-static bool hevc_single(int kind, int log2_size, int16_t *coeffs, int col_limit, uint8_t *dst, ptrdiff_t stride)
+static bool hevc_single(int bd, int kind, int log2_size, int16_t *coeffs, int col_limit, uint8_t *dst, ptrdiff_t stride)
 {
-    const int n = 1 << log2_size;
+    const int n = 1 << log2_size, ps = bd > 8 ? 2 : 1;
     const size_t cbytes = (size_t)n * n * 2;
-    Rect d = { dst, stride, 0, n - 1, 0, n - 1, nullptr };
+    Rect d = { dst, stride, 0, n - 1, 0, n * ps - 1, nullptr };
     Arena A(64 + cbytes + (dst ? rect_bytes(d) : 0) + 64);
     if (!A.ok)
         return false;
@@ -455,30 +461,30 @@ static bool hevc_single(int kind, int log2_size, int16_t *coeffs, int col_limit,
     tu.col_limit = col_limit;
     if (hipMemcpy(buf, &tu, sizeof(tu), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_hevc_idct(kind, log2_size, (int16_t *)(buf + 64), dst ? buf + 64 + cbytes : nullptr, DP, (const FFHipHevcTU *)buf, 1, 0) < 0 ||
+    if (ffhip_launch_hevc_idct_bd(bd, kind, log2_size, (int16_t *)(buf + 64), dst ? buf + 64 + cbytes : nullptr, DP, (const FFHipHevcTU *)buf, 1, 0) < 0 ||
         !A.down())
         return false;
     if (kind != FFHIP_HEVC_ADD_ONLY)
         memcpy(coeffs, A.host(buf + 64), cbytes);
     if (dst)
-        rect_commit(A, d, 0, n - 1, 0, n - 1);
+        rect_commit(A, d, 0, n - 1, 0, n * ps - 1);
     return true;
 }
-static FFHipHEVCDSPContext g_fb_hevc;
-#define HEVC_FN(idx) \
-    static void s_hevc_idct##idx(int16_t *c, int col_limit) \
-    { if (!hevc_single(FFHIP_HEVC_IDCT, idx + 2, c, col_limit, nullptr, 0)) SHIM_FB(g_fb_hevc, idct[idx], c, col_limit); } \
-    static void s_hevc_dc##idx(int16_t *c) { if (!hevc_single(FFHIP_HEVC_IDCT_DC, idx + 2, c, 0, nullptr, 0)) SHIM_FB(g_fb_hevc, idct_dc[idx], c); } \
-    static void s_hevc_add##idx(uint8_t *d, const int16_t *r, ptrdiff_t st) \
-    { if (!hevc_single(FFHIP_HEVC_ADD_ONLY, idx + 2, const_cast<int16_t *>(r), 0, d, st)) SHIM_FB(g_fb_hevc, add_residual[idx], d, r, st); }
-HEVC_FN(0) HEVC_FN(1) HEVC_FN(2) HEVC_FN(3)
-static void s_hevc_dst4(int16_t *c) { if (!hevc_single(FFHIP_HEVC_DST_4X4, 2, c, 0, nullptr, 0)) SHIM_FB(g_fb_hevc, transform_4x4_luma, c); }
+template <int BD, int IDX> static void s_hevc_idct(int16_t *c, int col_limit)
+{ if (!hevc_single(BD, FFHIP_HEVC_IDCT, IDX + 2, c, col_limit, nullptr, 0)) SHIM_FB(HEVC_FB(BD), idct[IDX], c, col_limit); }
+template <int BD, int IDX> static void s_hevc_dc(int16_t *c)
+{ if (!hevc_single(BD, FFHIP_HEVC_IDCT_DC, IDX + 2, c, 0, nullptr, 0)) SHIM_FB(HEVC_FB(BD), idct_dc[IDX], c); }
+template <int BD, int IDX> static void s_hevc_add(uint8_t *d, const int16_t *r, ptrdiff_t st)
+{ if (!hevc_single(BD, FFHIP_HEVC_ADD_ONLY, IDX + 2, const_cast<int16_t *>(r), 0, d, st)) SHIM_FB(HEVC_FB(BD), add_residual[IDX], d, r, st); }
+template <int BD> static void s_hevc_dst4(int16_t *c)
+{ if (!hevc_single(BD, FFHIP_HEVC_DST_4X4, 2, c, 0, nullptr, 0)) SHIM_FB(HEVC_FB(BD), transform_4x4_luma, c); }
 
 /* one edge segment: the 8 lines x 8 samples around it staged as a rectangle (h_: rows -4..3 x cols 0..7, v_: rows 0..7 x cols -4..3) */
-static bool hevc_lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q)
+static bool hevc_lf_single(int bd, int kind, uint8_t *pix, ptrdiff_t stride, int beta, const int32_t *tc, const uint8_t *no_p, const uint8_t *no_q)
 {
     const bool vertical = kind & 1;
-    Rect d = { pix, stride, vertical ? 0 : -4, vertical ? 7 : 3, vertical ? -4 : 0, vertical ? 3 : 7, nullptr };
+    const int ps = bd > 8 ? 2 : 1;
+    Rect d = { pix, stride, vertical ? 0 : -4, vertical ? 7 : 3, vertical ? -4 * ps : 0, vertical ? 4 * ps - 1 : 8 * ps - 1, nullptr };
     Arena A(rect_bytes(d) + 128);
     if (!A.ok)
         return false;
@@ -491,66 +497,67 @@ static bool hevc_lf_single(int kind, uint8_t *pix, ptrdiff_t stride, int beta, c
     for (int j = 0; j < 2; j++) { e.tc[j] = (int16_t)tc[j]; e.no_p[j] = no_p[j]; e.no_q[j] = no_q[j]; }
     if (hipMemcpy(buf, &e, sizeof(e), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_hevc_loop_filter(buf, DP, (const FFHipHevcEdge *)buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_hevc_loop_filter_bd(bd, buf, DP, (const FFHipHevcEdge *)buf, 1, 0) < 0 || !A.down())
         return false;
     rect_commit(A, d, d.r0, d.r1, d.c0, d.c1);
     return true;
 }
-static void s_hevc_lf_hl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
-{ if (!hevc_lf_single(FFHIP_HEVC_LF_H_LUMA, p, st, beta, tc, np_, nq)) SHIM_FB(g_fb_hevc, hevc_h_loop_filter_luma, p, st, beta, tc, np_, nq); }
-static void s_hevc_lf_vl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
-{ if (!hevc_lf_single(FFHIP_HEVC_LF_V_LUMA, p, st, beta, tc, np_, nq)) SHIM_FB(g_fb_hevc, hevc_v_loop_filter_luma, p, st, beta, tc, np_, nq); }
-static void s_hevc_lf_hc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
-{ if (!hevc_lf_single(FFHIP_HEVC_LF_H_CHROMA, p, st, 0, tc, np_, nq)) SHIM_FB(g_fb_hevc, hevc_h_loop_filter_chroma, p, st, tc, np_, nq); }
-static void s_hevc_lf_vc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
-{ if (!hevc_lf_single(FFHIP_HEVC_LF_V_CHROMA, p, st, 0, tc, np_, nq)) SHIM_FB(g_fb_hevc, hevc_v_loop_filter_chroma, p, st, tc, np_, nq); }
+template <int BD> static void s_hevc_lf_hl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
+{ if (!hevc_lf_single(BD, FFHIP_HEVC_LF_H_LUMA, p, st, beta, tc, np_, nq)) SHIM_FB(HEVC_FB(BD), hevc_h_loop_filter_luma, p, st, beta, tc, np_, nq); }
+template <int BD> static void s_hevc_lf_vl(uint8_t *p, ptrdiff_t st, int beta, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
+{ if (!hevc_lf_single(BD, FFHIP_HEVC_LF_V_LUMA, p, st, beta, tc, np_, nq)) SHIM_FB(HEVC_FB(BD), hevc_v_loop_filter_luma, p, st, beta, tc, np_, nq); }
+template <int BD> static void s_hevc_lf_hc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
+{ if (!hevc_lf_single(BD, FFHIP_HEVC_LF_H_CHROMA, p, st, 0, tc, np_, nq)) SHIM_FB(HEVC_FB(BD), hevc_h_loop_filter_chroma, p, st, tc, np_, nq); }
+template <int BD> static void s_hevc_lf_vc(uint8_t *p, ptrdiff_t st, const int32_t *tc, const uint8_t *np_, const uint8_t *nq)
+{ if (!hevc_lf_single(BD, FFHIP_HEVC_LF_V_CHROMA, p, st, 0, tc, np_, nq)) SHIM_FB(HEVC_FB(BD), hevc_v_loop_filter_chroma, p, st, tc, np_, nq); }
 
-/* SAO: source rows -1..height (edge: with one column of margin) and the destination block packed at a pitch of 192 bytes */
-static bool hevc_sao_single(int edge, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const int16_t *off, int cls, int w, int h)
+/* SAO: source rows -1..height (edge: with one sample of margin) and the destination block packed at a pitch of 192 bytes */
+static bool hevc_sao_single(int bd, int edge, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const int16_t *off, int cls, int w, int h)
 {
     if (w <= 0 || h <= 0 || w > 64 || h > 64)
         return false;
-    const int P = 192, mg = edge ? 1 : 0;
+    const int P = 192, mg = edge ? 1 : 0, ps = bd > 8 ? 2 : 1;
     Arena A(64 + (size_t)(h + 2) * P * 2 + 64);
     if (!A.ok)
         return false;
     uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + (size_t)(h + 2) * P;
-    if (ss >= w + 2 * mg) {
-        if (hipMemcpy2D(dsrc + (size_t)(1 - mg) * P + 1 - mg, P, src - mg * ss - mg, ss, w + 2 * mg, h + 2 * mg, hipMemcpyHostToDevice) != hipSuccess)
+    const size_t rowb = (size_t)(w + 2 * mg) * ps;
+    if (ss >= (ptrdiff_t)rowb) {
+        if (hipMemcpy2D(dsrc + (size_t)(1 - mg) * P + (1 - mg) * ps, P, src - mg * ss - mg * ps, ss, rowb, h + 2 * mg, hipMemcpyHostToDevice) != hipSuccess)
             return false;
     } else {
         for (int y = -mg; y < h + mg; y++)
-            if (hipMemcpy(dsrc + (size_t)(y + 1) * P + 1 - mg, src + y * ss - mg, w + 2 * mg, hipMemcpyHostToDevice) != hipSuccess)
+            if (hipMemcpy(dsrc + (size_t)(y + 1) * P + (1 - mg) * ps, src + y * ss - mg * ps, rowb, hipMemcpyHostToDevice) != hipSuccess)
                 return false;
     }
     FFHipHevcSao k;
     memset(&k, 0, sizeof(k));
-    k.dst_offset = 0; k.src_offset = P + 1;
+    k.dst_offset = 0; k.src_offset = P + ps;
     for (int i = 0; i < 5; i++) k.offset_val[i] = off[i];
     k.edge = (uint8_t)edge; k.cls = (uint8_t)cls; k.width = (uint8_t)w; k.height = (uint8_t)h;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_hevc_sao(ddst, P, dsrc, P, (const FFHipHevcSao *)buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_hevc_sao_bd(bd, ddst, P, dsrc, P, (const FFHipHevcSao *)buf, 1, 0) < 0 || !A.down())
         return false;
-    commit2d(A, dst, sd, ddst, P, w, h);
+    commit2d(A, dst, sd, ddst, P, (size_t)w * ps, h);
     return true;
 }
 /* the reference's table index of a block width: sao_tab[(FFALIGN(width, 8) >> 3) - 1] (libavcodec/hevc/filter.c) */
 static int hevc_sao_tab(int w) { static const uint8_t t[8] = { 0, 1, 2, 2, 3, 3, 4, 4 }; const int k = ((w + 7) >> 3) - 1; return t[k < 0 ? 0 : k > 7 ? 7 : k]; }
-static void s_hevc_sao_band(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const int16_t *o, int lc, int w, int h)
-{ if (!hevc_sao_single(0, d, s, sd, ss, o, lc, w, h)) SHIM_FB(g_fb_hevc, sao_band_filter[hevc_sao_tab(w)], d, s, sd, ss, o, lc, w, h); }
-static void s_hevc_sao_edge(uint8_t *d, const uint8_t *s, ptrdiff_t sd, const int16_t *o, int eo, int w, int h)
-{ if (!hevc_sao_single(1, d, s, sd, 192, o, eo, w, h)) SHIM_FB(g_fb_hevc, sao_edge_filter[hevc_sao_tab(w)], d, s, sd, o, eo, w, h); }
+template <int BD> static void s_hevc_sao_band(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const int16_t *o, int lc, int w, int h)
+{ if (!hevc_sao_single(BD, 0, d, s, sd, ss, o, lc, w, h)) SHIM_FB(HEVC_FB(BD), sao_band_filter[hevc_sao_tab(w)], d, s, sd, ss, o, lc, w, h); }
+template <int BD> static void s_hevc_sao_edge(uint8_t *d, const uint8_t *s, ptrdiff_t sd, const int16_t *o, int eo, int w, int h)
+{ if (!hevc_sao_single(BD, 1, d, s, sd, 192, o, eo, w, h)) SHIM_FB(HEVC_FB(BD), sao_edge_filter[hevc_sao_tab(w)], d, s, sd, o, eo, w, h); }
 
-/* MC: source rows -3..height+4 x columns -3..width+4 at a pitch of 128; destination after it (pixels: pitch 64; int16: 64 elements);
- * modes 2..4 (FFHIP_HEVC_MC_*): src2's height x 64 int16 after the destination */
-static bool hevc_mc_single(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
+/* MC: source rows -3..height+4 x columns -3..width+4 at a pitch of 128 samples; destination after it (pixels: pitch 64 samples;
+ * int16: 64 elements); modes 2..4 (FFHIP_HEVC_MC_*): src2's height x 64 int16 after the destination */
+static bool hevc_mc_single(int bd, int chroma, int uni, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int height, int mx,
                            int my, int width, const int16_t *src2 = nullptr, int denom = 0, int wx0 = 0, int wx1 = 0, int ox = 0)
 {
     if (width <= 0 || height <= 0 || width > 64 || height > 64)
         return false;
-    const int P = 128, before = chroma ? 1 : 3, after = chroma ? 2 : 4;
-    const size_t sbytes = (size_t)(height + before + after) * P, dbytes = (size_t)height * 64 * (uni ? 1 : 2);
+    const int ps = bd > 8 ? 2 : 1, P = 128 * ps, DPX = 64 * ps, before = chroma ? 1 : 3, after = chroma ? 2 : 4;
+    const size_t sbytes = (size_t)(height + before + after) * P, dbytes = (size_t)height * (uni ? DPX : 128);
     const size_t s2bytes = uni >= 3 ? (size_t)height * 128 : 0;
     Arena A(64 + sbytes + dbytes + s2bytes + 64);
     if (!A.ok)
@@ -562,35 +569,35 @@ static bool hevc_mc_single(int chroma, int uni, void *dst, ptrdiff_t dststride, 
         /* only what the reference function of this slot reads: margins exist on an axis only when that axis is filtered */
         const int by = my ? before : 0, ay = my ? after : 0, bx = mx ? before : 0, ax = mx ? after : 0;
         const int cols = width + bx + ax, rows = height + by + ay;
-        uint8_t *d0 = dsrc + (size_t)(before - by) * P + (before - bx);
-        const uint8_t *s0 = src - by * srcstride - bx;
-        if (srcstride >= cols) {
-            if (hipMemcpy2D(d0, P, s0, srcstride, cols, rows, hipMemcpyHostToDevice) != hipSuccess)
+        uint8_t *d0 = dsrc + (size_t)(before - by) * P + (size_t)(before - bx) * ps;
+        const uint8_t *s0 = src - by * srcstride - bx * ps;
+        if (srcstride >= (ptrdiff_t)cols * ps) {
+            if (hipMemcpy2D(d0, P, s0, srcstride, (size_t)cols * ps, rows, hipMemcpyHostToDevice) != hipSuccess)
                 return false;
         } else {
             for (int y = 0; y < rows; y++)
-                if (hipMemcpy(d0 + (size_t)y * P, s0 + y * srcstride, cols, hipMemcpyHostToDevice) != hipSuccess)
+                if (hipMemcpy(d0 + (size_t)y * P, s0 + y * srcstride, (size_t)cols * ps, hipMemcpyHostToDevice) != hipSuccess)
                     return false;
         }
     }
     if (uni >= 2) {
         FFHipHevcMcWBlock k = {};
-        k.src_offset = before * P + before;
+        k.src_offset = before * P + before * ps;
         k.width = (uint8_t)width; k.height = (uint8_t)height; k.mx = (uint8_t)mx; k.my = (uint8_t)my;
         k.wx0 = (int16_t)wx0; k.wx1 = (int16_t)wx1; k.ox = (int16_t)ox; k.denom = (uint8_t)denom;
         if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
             return false;
     } else {
         FFHipHevcMcBlock k;
-        k.dst_offset = 0; k.src_offset = before * P + before;
+        k.dst_offset = 0; k.src_offset = before * P + before * ps;
         k.width = (uint8_t)width; k.height = (uint8_t)height; k.mx = (uint8_t)mx; k.my = (uint8_t)my;
         if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
             return false;
     }
-    if (ffhip_launch_hevc_mc(chroma, uni, ddst, 64, dsrc, P, (const int16_t *)dsrc2, buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_hevc_mc_bd(bd, chroma, uni, ddst, DPX, dsrc, P, (const int16_t *)dsrc2, buf, 1, 0) < 0 || !A.down())
         return false;
     if (uni)
-        commit2d(A, dst, dststride, ddst, 64, width, height);
+        commit2d(A, dst, dststride, ddst, DPX, (size_t)width * ps, height);
     else
         commit2d(A, dst, 128, ddst, 128, (size_t)width * 2, height); /* int16 rows of MAX_PB_SIZE = 64 elements */
     return true;
@@ -598,33 +605,34 @@ static bool hevc_mc_single(int chroma, int uni, void *dst, ptrdiff_t dststride, 
 /* table slot of a call: [ff_hevc_pel_weight[width]][!!my][!!mx] (libavcodec/hevc/dsp.c, hevcdec.c) */
 static int hevc_pw(int w) { return w <= 2 ? 0 : w <= 4 ? 1 : w <= 6 ? 2 : w <= 8 ? 3 : w <= 12 ? 4 : w <= 16 ? 5 : w <= 24 ? 6 : w <= 32 ? 7 : w <= 48 ? 8 : 9; }
 #define HEVC_SLOT(tab, w, mx, my) tab[hevc_pw(w)][(my) != 0][(mx) != 0]
-static void s_hevc_qpel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
-{ if (!hevc_mc_single(0, 0, d, 0, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_qpel, w, mx, my), d, s, ss, h, mx, my, w); }
-static void s_hevc_epel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
-{ if (!hevc_mc_single(1, 0, d, 0, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_epel, w, mx, my), d, s, ss, h, mx, my, w); }
-static void s_hevc_qpel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
-{ if (!hevc_mc_single(0, 1, d, ds, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_qpel_uni, w, mx, my), d, ds, s, ss, h, mx, my, w); }
-static void s_hevc_epel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
-{ if (!hevc_mc_single(1, 1, d, ds, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_epel_uni, w, mx, my), d, ds, s, ss, h, mx, my, w); }
-static void s_hevc_dequant(int16_t *c, int16_t log2_size) { if (!hevc_single(FFHIP_HEVC_DEQUANT, log2_size, c, 0, nullptr, 0)) SHIM_FB(g_fb_hevc, dequant, c, log2_size); }
-static void s_hevc_rdpcm(int16_t *c, int16_t log2_size, int mode)
+template <int BD> static void s_hevc_qpel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
+{ if (!hevc_mc_single(BD, 0, 0, d, 0, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(HEVC_FB(BD), HEVC_SLOT(put_hevc_qpel, w, mx, my), d, s, ss, h, mx, my, w); }
+template <int BD> static void s_hevc_epel(int16_t *d, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
+{ if (!hevc_mc_single(BD, 1, 0, d, 0, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(HEVC_FB(BD), HEVC_SLOT(put_hevc_epel, w, mx, my), d, s, ss, h, mx, my, w); }
+template <int BD> static void s_hevc_qpel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
+{ if (!hevc_mc_single(BD, 0, 1, d, ds, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(HEVC_FB(BD), HEVC_SLOT(put_hevc_qpel_uni, w, mx, my), d, ds, s, ss, h, mx, my, w); }
+template <int BD> static void s_hevc_epel_uni(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, intptr_t mx, intptr_t my, int w)
+{ if (!hevc_mc_single(BD, 1, 1, d, ds, s, ss, h, (int)mx, (int)my, w)) SHIM_FB(HEVC_FB(BD), HEVC_SLOT(put_hevc_epel_uni, w, mx, my), d, ds, s, ss, h, mx, my, w); }
+template <int BD> static void s_hevc_dequant(int16_t *c, int16_t log2_size)
+{ if (!hevc_single(BD, FFHIP_HEVC_DEQUANT, log2_size, c, 0, nullptr, 0)) SHIM_FB(HEVC_FB(BD), dequant, c, log2_size); }
+template <int BD> static void s_hevc_rdpcm(int16_t *c, int16_t log2_size, int mode)
 {
-    if (!hevc_single(mode ? FFHIP_HEVC_RDPCM_V : FFHIP_HEVC_RDPCM_H, log2_size, c, 0, nullptr, 0))
-        SHIM_FB(g_fb_hevc, transform_rdpcm, c, log2_size, mode);
+    if (!hevc_single(BD, mode ? FFHIP_HEVC_RDPCM_V : FFHIP_HEVC_RDPCM_H, log2_size, c, 0, nullptr, 0))
+        SHIM_FB(HEVC_FB(BD), transform_rdpcm, c, log2_size, mode);
 }
-/* sao_edge_restore: rows of the block at a pitch of 64 for both buffers; only the block's own samples travel */
-static bool hevc_restore_single(int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao,
+/* sao_edge_restore: rows of the block at a pitch of 64 samples for both buffers; only the block's own samples travel */
+static bool hevc_restore_single(int bd, int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao,
                                 const int *borders, int w, int h, int c_idx, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
 {
     if (w <= 0 || h <= 0 || w > 64 || h > 64 || c_idx < 0 || c_idx > 2)
         return false;
-    const int P = 64;
+    const int ps = bd > 8 ? 2 : 1, P = 64 * ps;
     Arena A(64 + 2 * (size_t)h * P + 64);
     if (!A.ok)
         return false;
     uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + (size_t)h * P;
-    if (hipMemcpy2D(dsrc, P, src, ss, w, h, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy2D(ddst, P, dst, sd, w, h, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy2D(dsrc, P, src, ss, (size_t)w * ps, h, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy2D(ddst, P, dst, sd, (size_t)w * ps, h, hipMemcpyHostToDevice) != hipSuccess)
         return false;
     FFHipHevcSaoRestore k = {};
     k.offset0 = sao->offset_val[c_idx][0];
@@ -640,65 +648,78 @@ static bool hevc_restore_single(int variant, uint8_t *dst, const uint8_t *src, p
     }
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_hevc_sao_restore(ddst, P, dsrc, P, (const FFHipHevcSaoRestore *)buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_hevc_sao_restore_bd(bd, ddst, P, dsrc, P, (const FFHipHevcSaoRestore *)buf, 1, 0) < 0 || !A.down())
         return false;
-    commit2d(A, dst, sd, ddst, P, w, h);
+    commit2d(A, dst, sd, ddst, P, (size_t)w * ps, h);
     return true;
 }
-static void s_hevc_restore0(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao, const int *b, int w, int h,
-                            int c, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
-{ if (!hevc_restore_single(0, d, s, sd, ss, sao, b, w, h, c, ve, he, de)) SHIM_FB(g_fb_hevc, sao_edge_restore[0], d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
-static void s_hevc_restore1(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao, const int *b, int w, int h,
-                            int c, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
-{ if (!hevc_restore_single(1, d, s, sd, ss, sao, b, w, h, c, ve, he, de)) SHIM_FB(g_fb_hevc, sao_edge_restore[1], d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
+template <int BD, int VAR>
+static void s_hevc_restore(uint8_t *d, const uint8_t *s, ptrdiff_t sd, ptrdiff_t ss, const FFHipSAOParams *sao, const int *b, int w, int h,
+                           int c, const uint8_t *ve, const uint8_t *he, const uint8_t *de)
+{ if (!hevc_restore_single(BD, VAR, d, s, sd, ss, sao, b, w, h, c, ve, he, de)) SHIM_FB(HEVC_FB(BD), sao_edge_restore[VAR], d, s, sd, ss, sao, b, w, h, c, ve, he, de); }
 #define HEVC_W_SHIMS(name, chroma)                                                                                                          \
+template <int BD>                                                                                                                           \
 static void s_hevc_##name##_uni_w(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, int denom, int wx, int ox, intptr_t mx,  \
                                   intptr_t my, int w)                                                                                       \
-{ if (!hevc_mc_single(chroma, FFHIP_HEVC_MC_UNI_W, d, ds, s, ss, h, (int)mx, (int)my, w, nullptr, denom, wx, 0, ox))                       \
-      SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_##name##_uni_w, w, mx, my), d, ds, s, ss, h, denom, wx, ox, mx, my, w); }                         \
+{ if (!hevc_mc_single(BD, chroma, FFHIP_HEVC_MC_UNI_W, d, ds, s, ss, h, (int)mx, (int)my, w, nullptr, denom, wx, 0, ox))                   \
+      SHIM_FB(HEVC_FB(BD), HEVC_SLOT(put_hevc_##name##_uni_w, w, mx, my), d, ds, s, ss, h, denom, wx, ox, mx, my, w); }                       \
+template <int BD>                                                                                                                           \
 static void s_hevc_##name##_bi(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, const int16_t *s2, int h, intptr_t mx,             \
                                intptr_t my, int w)                                                                                          \
-{ if (!hevc_mc_single(chroma, FFHIP_HEVC_MC_BI, d, ds, s, ss, h, (int)mx, (int)my, w, s2))                                                 \
-      SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_##name##_bi, w, mx, my), d, ds, s, ss, s2, h, mx, my, w); }                                       \
+{ if (!hevc_mc_single(BD, chroma, FFHIP_HEVC_MC_BI, d, ds, s, ss, h, (int)mx, (int)my, w, s2))                                             \
+      SHIM_FB(HEVC_FB(BD), HEVC_SLOT(put_hevc_##name##_bi, w, mx, my), d, ds, s, ss, s2, h, mx, my, w); }                                     \
+template <int BD>                                                                                                                           \
 static void s_hevc_##name##_bi_w(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, const int16_t *s2, int h, int denom, int wx0,    \
                                  int wx1, int ox, intptr_t mx, intptr_t my, int w)                                                          \
-{ if (!hevc_mc_single(chroma, FFHIP_HEVC_MC_BI_W, d, ds, s, ss, h, (int)mx, (int)my, w, s2, denom, wx0, wx1, ox))                          \
-      SHIM_FB(g_fb_hevc, HEVC_SLOT(put_hevc_##name##_bi_w, w, mx, my), d, ds, s, ss, s2, h, denom, wx0, wx1, ox, mx, my, w); }
+{ if (!hevc_mc_single(BD, chroma, FFHIP_HEVC_MC_BI_W, d, ds, s, ss, h, (int)mx, (int)my, w, s2, denom, wx0, wx1, ox))                      \
+      SHIM_FB(HEVC_FB(BD), HEVC_SLOT(put_hevc_##name##_bi_w, w, mx, my), d, ds, s, ss, s2, h, denom, wx0, wx1, ox, mx, my, w); }
 HEVC_W_SHIMS(qpel, 0)
 HEVC_W_SHIMS(epel, 1)
 
-extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
+template <int BD>
+static void hevc_fill(FFHipHEVCDSPContext &o)
 {
-    if (!c || bit_depth != 8)
-        return FFHIP_EINVAL;
-    if (!ffhip_have_device())
-        return FFHIP_ENOSYS;
-    FFHipHEVCDSPContext o = *c;
-    o.idct[0] = s_hevc_idct0; o.idct[1] = s_hevc_idct1; o.idct[2] = s_hevc_idct2; o.idct[3] = s_hevc_idct3;
-    o.idct_dc[0] = s_hevc_dc0; o.idct_dc[1] = s_hevc_dc1; o.idct_dc[2] = s_hevc_dc2; o.idct_dc[3] = s_hevc_dc3;
-    o.add_residual[0] = s_hevc_add0; o.add_residual[1] = s_hevc_add1; o.add_residual[2] = s_hevc_add2; o.add_residual[3] = s_hevc_add3;
-    o.transform_4x4_luma = s_hevc_dst4;
-    o.dequant = s_hevc_dequant; o.transform_rdpcm = s_hevc_rdpcm;
-    o.sao_edge_restore[0] = s_hevc_restore0; o.sao_edge_restore[1] = s_hevc_restore1;
-    o.hevc_h_loop_filter_luma = o.hevc_h_loop_filter_luma_c = s_hevc_lf_hl;
-    o.hevc_v_loop_filter_luma = o.hevc_v_loop_filter_luma_c = s_hevc_lf_vl;
-    o.hevc_h_loop_filter_chroma = o.hevc_h_loop_filter_chroma_c = s_hevc_lf_hc;
-    o.hevc_v_loop_filter_chroma = o.hevc_v_loop_filter_chroma_c = s_hevc_lf_vc;
+    o.idct[0] = s_hevc_idct<BD, 0>; o.idct[1] = s_hevc_idct<BD, 1>; o.idct[2] = s_hevc_idct<BD, 2>; o.idct[3] = s_hevc_idct<BD, 3>;
+    o.idct_dc[0] = s_hevc_dc<BD, 0>; o.idct_dc[1] = s_hevc_dc<BD, 1>; o.idct_dc[2] = s_hevc_dc<BD, 2>; o.idct_dc[3] = s_hevc_dc<BD, 3>;
+    o.add_residual[0] = s_hevc_add<BD, 0>; o.add_residual[1] = s_hevc_add<BD, 1>; o.add_residual[2] = s_hevc_add<BD, 2>;
+    o.add_residual[3] = s_hevc_add<BD, 3>;
+    o.transform_4x4_luma = s_hevc_dst4<BD>;
+    o.dequant = s_hevc_dequant<BD>; o.transform_rdpcm = s_hevc_rdpcm<BD>;
+    o.sao_edge_restore[0] = s_hevc_restore<BD, 0>; o.sao_edge_restore[1] = s_hevc_restore<BD, 1>;
+    o.hevc_h_loop_filter_luma = o.hevc_h_loop_filter_luma_c = s_hevc_lf_hl<BD>;
+    o.hevc_v_loop_filter_luma = o.hevc_v_loop_filter_luma_c = s_hevc_lf_vl<BD>;
+    o.hevc_h_loop_filter_chroma = o.hevc_h_loop_filter_chroma_c = s_hevc_lf_hc<BD>;
+    o.hevc_v_loop_filter_chroma = o.hevc_v_loop_filter_chroma_c = s_hevc_lf_vc<BD>;
     for (int i = 0; i < 5; i++) {
-        o.sao_band_filter[i] = s_hevc_sao_band;
-        o.sao_edge_filter[i] = s_hevc_sao_edge;
+        o.sao_band_filter[i] = s_hevc_sao_band<BD>;
+        o.sao_edge_filter[i] = s_hevc_sao_edge<BD>;
     }
     /* the [!!my][!!mx] slots all take (mx, my): one function per table serves every slot */
     for (int i = 0; i < 10; i++)
         for (int a = 0; a < 2; a++)
             for (int b = 0; b < 2; b++) {
-                o.put_hevc_qpel[i][a][b] = s_hevc_qpel; o.put_hevc_qpel_uni[i][a][b] = s_hevc_qpel_uni;
-                o.put_hevc_epel[i][a][b] = s_hevc_epel; o.put_hevc_epel_uni[i][a][b] = s_hevc_epel_uni;
-                o.put_hevc_qpel_uni_w[i][a][b] = s_hevc_qpel_uni_w; o.put_hevc_epel_uni_w[i][a][b] = s_hevc_epel_uni_w;
-                o.put_hevc_qpel_bi[i][a][b] = s_hevc_qpel_bi; o.put_hevc_epel_bi[i][a][b] = s_hevc_epel_bi;
-                o.put_hevc_qpel_bi_w[i][a][b] = s_hevc_qpel_bi_w; o.put_hevc_epel_bi_w[i][a][b] = s_hevc_epel_bi_w;
+                o.put_hevc_qpel[i][a][b] = s_hevc_qpel<BD>; o.put_hevc_qpel_uni[i][a][b] = s_hevc_qpel_uni<BD>;
+                o.put_hevc_epel[i][a][b] = s_hevc_epel<BD>; o.put_hevc_epel_uni[i][a][b] = s_hevc_epel_uni<BD>;
+                o.put_hevc_qpel_uni_w[i][a][b] = s_hevc_qpel_uni_w<BD>; o.put_hevc_epel_uni_w[i][a][b] = s_hevc_epel_uni_w<BD>;
+                o.put_hevc_qpel_bi[i][a][b] = s_hevc_qpel_bi<BD>; o.put_hevc_epel_bi[i][a][b] = s_hevc_epel_bi<BD>;
+                o.put_hevc_qpel_bi_w[i][a][b] = s_hevc_qpel_bi_w<BD>; o.put_hevc_epel_bi_w[i][a][b] = s_hevc_epel_bi_w<BD>;
             }
-    fb_snapshot(g_fb_hevc, *c, o);
+}
+
+extern "C" int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth)
+{
+    if (!c || (bit_depth != 8 && bit_depth != 10 && bit_depth != 12))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    FFHipHEVCDSPContext o = *c;
+    if (bit_depth == 8)
+        hevc_fill<8>(o);
+    else if (bit_depth == 10)
+        hevc_fill<10>(o);
+    else
+        hevc_fill<12>(o);
+    fb_snapshot(g_fb_hevc[hevc_bdi(bit_depth)], *c, o);
     *c = o;
     return 0;
 }

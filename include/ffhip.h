@@ -709,7 +709,8 @@ typedef struct FFHipHEVCDSPContext {
     void (*put_hevc_epel_bi_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
                                          int height, int denom, int wx0, int wx1, int ox, intptr_t mx, intptr_t my, int width);
 } FFHipHEVCDSPContext;
-/** ff_hevc_dsp_init_<arch> shape (libavcodec/hevc/dsp.h:127-140).  bit_depth must be 8. */
+/** ff_hevc_dsp_init_<arch> shape (libavcodec/hevc/dsp.h:127-140).  bit_depth 8, 10 or 12 (the depth is baked into the installed
+ *  functions, as the reference's per-BIT_DEPTH instantiations are); FFHIP_EINVAL for 9 and above 12: those keep the C pointers. */
 int ff_hevc_dsp_init_hip(FFHipHEVCDSPContext *c, int bit_depth);
 
 #define FFHIP_HEVC_IDCT      0   /* idct[log2_size - 2](coeffs, col_limit)     */

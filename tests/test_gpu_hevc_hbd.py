@@ -300,3 +300,106 @@ def test_hevc_mc_weighted_batch_hbd(chroma, mode, bd):
     got = back(d_d, dst0)
     assert (want != dst0).sum() > 1000
     assert np.array_equal(got, want), "%d mismatches" % (got != want).sum()
+
+
+@pytest.mark.parametrize("bd", DEPTHS)
+def test_hevc_host_faces_hbd(bd):
+    """ff_hevc_dsp_init_hip(c, 10 / 12): the reference's signatures with host pointers on uint16 planes — what checkasm's
+    hevc_idct / hevc_add_res / hevc_deblock / hevc_sao / hevc_pel drive at these depths"""
+    from ffmpeg_amd import hevc
+    from test_oracle_vs_ref import hevc_weight_case
+    from test_oracle_vs_ref_hbd import lf_case
+    _torch()
+    c = hevc.dsp_init(bd)
+    O = ffi.oracle()
+    rng = np.random.default_rng(500 + bd)
+    sc = 1 << (bd - 8)
+    for lg in (2, 3, 4, 5):
+        n = 1 << lg
+        for rep in range(4):
+            col_limit = int(rng.integers(0, 2 * n + 4))
+            blk = _coeffs(rng, n, rep % 4)
+            a, b = blk.copy(), blk.copy()
+            c.idct[lg - 2](a.ctypes.data, col_limit)
+            O.ffo_hevc_idct_bd(bd, lg, ptr(b, i16p), col_limit)
+            assert np.array_equal(a, b), (n, col_limit)
+            a, b = blk.copy(), blk.copy()
+            c.idct_dc[lg - 2](a.ctypes.data)
+            O.ffo_hevc_idct_dc_bd(bd, lg, ptr(b, i16p))
+            assert np.array_equal(a, b)
+            a, b = blk.copy(), blk.copy()
+            c.dequant(a.ctypes.data, lg)
+            O.ffo_hevc_dequant_bd(bd, ptr(b, i16p), lg)
+            assert np.array_equal(a, b)
+            res = _coeffs(rng, n, rep % 4)
+            pic = pix(rng, (n + 4, 50), bd, rep % 2 == 0)
+            pa, pb = pic.copy(), pic.copy()
+            c.add_residual[lg - 2](pa.ctypes.data + 2 * (2 * 50 + 3), res.ctypes.data, 100)
+            O.ffo_hevc_add_residual_bd(bd, lg, at(pb, 2 * (2 * 50 + 3)), ptr(res, i16p), 100)
+            assert np.array_equal(pa, pb)
+    blk = _coeffs(rng, 4, 0)
+    a, b = blk.copy(), blk.copy()
+    c.transform_4x4_luma(a.ctypes.data)
+    O.ffo_hevc_transform_4x4_luma_bd(bd, ptr(b, i16p))
+    assert np.array_equal(a, b)
+    # deblocking
+    members = [c.hevc_h_loop_filter_luma, c.hevc_v_loop_filter_luma, c.hevc_h_loop_filter_chroma, c.hevc_v_loop_filter_chroma]
+    changed = 0
+    for rep in range(60):
+        buf, beta, tc, no_p, no_q = lf_case(rng, rep % 4 != 0, bd)
+        which = rep % 4
+        chroma, vertical = (which >> 1) & 1, which & 1
+        a, b = buf.copy(), buf.copy()
+        off = 2 * ((4 * 16 + 8) if vertical else (8 * 16 + 4))
+        if chroma:
+            members[which](a.ctypes.data + off, 32, tc.ctypes.data, no_p.ctypes.data, no_q.ctypes.data)
+        else:
+            members[which](a.ctypes.data + off, 32, beta, tc.ctypes.data, no_p.ctypes.data, no_q.ctypes.data)
+        O.ffo_hevc_loop_filter_bd(bd, chroma, vertical, at(b, off), 32, beta, ptr(tc, i32p), ptr(no_p), ptr(no_q))
+        assert np.array_equal(a, b), (rep, which)
+        changed += int((a != buf).any())
+    assert changed > 10
+    # SAO (the edge filter's source stride is the reference's fixed 192 bytes)
+    for rep in range(12):
+        w, h = int(rng.choice([8, 16, 33, 64])), int(rng.choice([4, 17, 64]))
+        idx = [0, 1, 2, 2, 3, 3, 4, 4][((w + 7) >> 3) - 1]
+        off = (rng.integers(-31, 32, 5) * sc).astype(np.int16)
+        off[0] = 0
+        src = pix(rng, (h + 2, 96), bd)
+        d0 = pix(rng, (h, 80), bd)
+        a, b = d0.copy(), d0.copy()
+        lc = int(rng.integers(0, 32))
+        c.sao_band_filter[idx](a.ctypes.data, src.ctypes.data + 2 * 97, 160, 192, off.ctypes.data, lc, w, h)
+        O.ffo_hevc_sao_band_bd(bd, ptr(b), at(src, 2 * 97), 160, 192, ptr(off, i16p), lc, w, h)
+        assert np.array_equal(a, b), ("band", rep)
+        eo = rep % 4
+        a, b = d0.copy(), d0.copy()
+        c.sao_edge_filter[idx](a.ctypes.data, src.ctypes.data + 2 * 97, 160, off.ctypes.data, eo, w, h)
+        O.ffo_hevc_sao_edge_bd(bd, ptr(b), at(src, 2 * 97), 160, 192, ptr(off, i16p), eo, w, h)
+        assert np.array_equal(a, b), ("edge", rep)
+    # motion compensation: every output stage
+    src = pix(rng, (90, 100), bd, extremes=True)
+    for rep in range(16):
+        chroma = rep & 1
+        idx = int(rng.integers(0, 10)); w = WIDTHS[idx]; h = int(rng.choice([2, 8, 64]))
+        mx, my = (int(v) for v in rng.integers(0, 8 if chroma else 4, 2))
+        sp = src.ctypes.data + 2 * (10 * 100 + 12)
+        slot = (int(bool(my)), int(bool(mx)))
+        a16, b16 = np.zeros((64, 64), np.int16), np.zeros((64, 64), np.int16)
+        (c.put_hevc_epel if chroma else c.put_hevc_qpel)[idx][slot[0]][slot[1]](a16.ctypes.data, sp, 200, h, mx, my, w)
+        O.ffo_hevc_mc_bd(bd, chroma, 0, b16.ctypes.data, 0, C.cast(sp, u8p), 200, h, mx, my, w)
+        assert np.array_equal(a16, b16), (chroma, w, h, mx, my)
+        a, b = np.full((64, 72), 9, np.uint16), np.full((64, 72), 9, np.uint16)
+        (c.put_hevc_epel_uni if chroma else c.put_hevc_qpel_uni)[idx][slot[0]][slot[1]](a.ctypes.data, 144, sp, 200, h, mx, my, w)
+        O.ffo_hevc_mc_bd(bd, chroma, 1, b.ctypes.data, 144, C.cast(sp, u8p), 200, h, mx, my, w)
+        assert np.array_equal(a, b), (chroma, w, h, mx, my, "uni")
+        src2 = rng.integers(-8192, 16384, (64, 64)).astype(np.int16)
+        d, wx0, wx1, ox = hevc_weight_case(rng, rep)
+        a, b = np.full((64, 72), 9, np.uint16), np.full((64, 72), 9, np.uint16)
+        (c.put_hevc_epel_bi_w if chroma else c.put_hevc_qpel_bi_w)[idx][slot[0]][slot[1]](a.ctypes.data, 144, sp, 200, src2.ctypes.data, h, d, wx0, wx1,
+                                                                                         ox, mx, my, w)
+        O.ffo_hevc_mc_w_bd(bd, chroma, 4, ptr(b), 144, C.cast(sp, u8p), 200, ptr(src2, i16p), h, d, wx0, wx1, ox, mx, my, w)
+        assert np.array_equal(a, b), (chroma, w, h, mx, my, "bi_w")
+    assert hevc.dsp_init(8) is not None
+    with pytest.raises(RuntimeError):
+        hevc.dsp_init(9)
