@@ -105,7 +105,7 @@ class Picture:
         _lib.check(_lib.lib().ffhip_h264_picture_create(C.byref(self._p), mb_w, mb_h), "ffhip_h264_picture_create")
 
     def close(self):
-        if getattr(self, "_p", None) is not None and self._p:
+        if getattr(self, "_p", None) is not None and self._p and _lib is not None:   # _lib is gone during interpreter shutdown
             _lib.lib().ffhip_h264_picture_free(C.byref(self._p))
         self._p = None
 
