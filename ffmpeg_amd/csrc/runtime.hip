@@ -125,7 +125,7 @@ int ffhip_scratch_reserve(size_t bytes, void **dev)
 
 /* ---- achievable-bandwidth probe (bench.py: the box's streaming roofs beside the 8 TB/s spec) ---- */
 typedef uint32_t bw_u4 __attribute__((ext_vector_type(4)));
-template <int MODE> /* 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p -> 4K scaler's mix) */
+template <int MODE> /* 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p -> 4K scaler's mix), 4 read n/2 + write n (yuv420p -> rgb24's) */
 __global__ __launch_bounds__(256) void k_membw(const bw_u4 *__restrict__ src, bw_u4 *__restrict__ dst, size_t n16, uint32_t *sink)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void k_membw(const bw_u4 *__restrict__ src, bw
             v = src[i];
         if (MODE == 3 && (i & 3) == 0)
             v = src[i >> 2];
+        if (MODE == 4 && (i & 1) == 0)
+            v = src[i >> 1];
         if (MODE == 0)
             acc += v;
         else
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void k_membw(const bw_u4 *__restrict__ src, bw
 
 extern "C" int ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gbps)
 {
-    if (pattern < 0 || pattern > 3 || bytes < (1u << 20) || reps < 1 || !gbps)
+    if (pattern < 0 || pattern > 4 || bytes < (1u << 20) || reps < 1 || !gbps)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
@@ -163,7 +165,8 @@ extern "C" int ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gb
         case 0: hipLaunchKernelGGL((k_membw<0>), g, t, 0, 0, a, b, bytes / 16, sink); break;
         case 1: hipLaunchKernelGGL((k_membw<1>), g, t, 0, 0, a, b, bytes / 16, sink); break;
         case 2: hipLaunchKernelGGL((k_membw<2>), g, t, 0, 0, a, b, bytes / 16, sink); break;
-        default: hipLaunchKernelGGL((k_membw<3>), g, t, 0, 0, a, b, bytes / 16, sink); break;
+        case 3: hipLaunchKernelGGL((k_membw<3>), g, t, 0, 0, a, b, bytes / 16, sink); break;
+        default: hipLaunchKernelGGL((k_membw<4>), g, t, 0, 0, a, b, bytes / 16, sink); break;
         }
     };
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess)
@@ -182,7 +185,7 @@ extern "C" int ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gb
         hipGetLastError() != hipSuccess)
         goto done;
     {
-        const double moved = pattern == 2 ? 2.0 * bytes : pattern == 3 ? 1.25 * bytes : (double)bytes;
+        const double moved = pattern == 2 ? 2.0 * bytes : pattern == 3 ? 1.25 * bytes : pattern == 4 ? 1.5 * bytes : (double)bytes;
         *gbps = moved * reps / (ms * 1e-3) / 1e9;
     }
     r = 0;

@@ -43,7 +43,7 @@ int         ffhip_device_count(void);
  *  different one returns FFHIP_EINVAL. */
 int         ffhip_set_device(int device);
 /** Streaming-bandwidth probe of the current device (measurement aid: bench.py reports the box's achievable roofs beside
- *  the 8 TB/s spec).  pattern 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p->4K scaler's mix);
+ *  the 8 TB/s spec).  pattern 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p->4K scaler's mix), 4 read n/2 + write n (yuv420p->rgb24's);
  *  `bytes` per buffer; *gbps = bytes moved per second / 1e9 over `reps` launches (HIP events). */
 int         ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gbps);
 const char *ffhip_last_error(void);
