@@ -313,183 +313,13 @@ __global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t
     }
 }
 
-/* ================================================================================================== */
-/*
- * k_h264_qpel_p — k_h264_qpel_l as a software pipeline.  One block per wave is a chain of three dependent round trips —
- * descriptor, footprint, then ~200 instructions at one wave's issue rate — and a wave that lives for one block pays all
- * three in full (measured: 660 Gpixel/s = 16.5 % of HBM with every wave slot of the chip occupied).  Here a wave walks blocks
- * i, i + S, i + 2S, ... (S = the launch's wave count): while block i is assembled from LDS, the footprint of block i + S is already
- * in flight into registers and the descriptor of block i + 2S behind it.  Prefetches are unconditional (indices clamped to the
- * last block) so that no load waits under a branch.  The arithmetic of a block is k_h264_qpel_l's, statement for statement.
- */
-struct QpelGeo { int size, mc, soff, doff; bool avg; };
-__device__ __forceinline__ QpelGeo qp_geo(const FFHipQpelBlock &b)
-{
-    QpelGeo g;
-    g.size = 16 >> __builtin_amdgcn_readfirstlane((int)b.size_idx);
-    g.mc = __builtin_amdgcn_readfirstlane((int)b.mcxy) & 15;
-    g.avg = __builtin_amdgcn_readfirstlane((int)b.avg) != 0;
-    g.soff = __builtin_amdgcn_readfirstlane(b.src_offset);
-    g.doff = __builtin_amdgcn_readfirstlane(b.dst_offset);
-    return g;
-}
-/* the lane's three footprint dwords (slots lane, lane + 64, lane + 128 of the [row][8] tile); out-of-footprint slots re-read a valid one */
-__device__ __forceinline__ void qp_fetch(const uint8_t *src, ptrdiff_t stride, const QpelGeo &g, int lane, uint32_t (&fw)[3])
-{
-    const uint8_t *s0 = src + g.soff - 2 - 2 * stride;
-    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 3);
-    const uint8_t *sa = s0 - sh;
-    const int rows = g.size + 5, ndw = (int)((sh + g.size + 5 + 3) >> 2);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int t = lane + 64 * k, r = min(t >> 3, rows - 1), j = min(t & 7, ndw - 1);
-        fw[k] = *reinterpret_cast<const uint32_t *>(sa + (ptrdiff_t)r * stride + 4 * j);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_h264_qpel_p(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
-                                                     const FFHipQpelBlock *__restrict__ blocks, int n)
-{
-    __shared__ uint32_t lds[4][21 * 8 + 21 * 8 + 8];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const int S = (int)gridDim.x * 4;
-    int i = blockIdx.x * 4 + wave;
-    if (i >= n)
-        return;
-    uint32_t *raw = lds[wave];             /* [row][8] aligned source dwords, row 0 = y-2 (slots 168..191 of the fetch are spill-over) */
-    uint32_t *hb = lds[wave] + 21 * 8;     /* [row][8] int16 pairs: unclipped horizontal sums of the block's columns */
-    QpelGeo g = qp_geo(blocks[i]);
-    uint32_t fw[3];
-    qp_fetch(src, stride, g, lane, fw);
-    FFHipQpelBlock dnext = blocks[min(i + S, n - 1)];
-    for (; i < n; i += S) {
-        const int size = g.size, mc = g.mc, per_row = size >> 2, rows = size + 5;
-        const bool avg = g.avg;
-        const int mx = mc & 3, my = mc >> 2;
-        const bool useJ = (mx == 2 && my != 0) || (my == 2 && mx != 0);
-        const bool useV = (mx != 2 && my != 0) || (mc == 8);
-        const bool useH = (my != 2 && mx != 0) || (mc == 2);
-        const bool vcol1 = mx == 3, hrow1 = my == 3;
-        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src + g.soff - 2 - 2 * stride) & 3);
-        const int doff = g.doff;
-        /* ---- 1. this block's footprint: registers -> LDS ---- */
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            if (lane + 64 * k < rows * 8)
-                raw[lane + 64 * k] = fw[k];
-        __builtin_amdgcn_wave_barrier();
-        /* ---- the next block's footprint leaves now, the descriptor after it behind it ---- */
-        g = qp_geo(dnext);
-        qp_fetch(src, stride, g, lane, fw);
-        dnext = blocks[min(i + 2 * S, n - 1)];
-
-        auto stream = [&](int row, int xg) { /* 12 bytes from byte x-2+4*xg of a footprint row */
-            const uint32_t *q = raw + row * 8 + xg;
-            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-            const uint32_t d3 = sh == 3 ? q[3] : 0;
-            Row12 r;
-            r.w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-            r.w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-            r.w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
-            return r;
-        };
-        /* ---- 2. horizontal sums of every footprint row, once ---- */
-        if (useJ) {
-            for (int t = lane; t < rows * per_row; t += 64) {
-                const int r = t / per_row, xg = t - r * per_row;
-                qp_s2 lo, hi;
-                qp_hraw4(stream(r, xg), lo, hi);
-                *reinterpret_cast<uint2 *>(hb + r * 8 + 2 * xg) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        /* ---- 3. my four samples ---- */
-        const int y = lane / per_row, xg = lane - y * per_row;
-        if (y < size) {
-            uint8_t *d = dst + doff + (ptrdiff_t)y * stride + 4 * xg;
-            uint32_t pj = 0, ph = 0, pv = 0, pf = 0;
-            if (useJ) {
-                uint2 h[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    h[k] = *reinterpret_cast<const uint2 *>(hb + (y + k) * 8 + 2 * xg);
-                int v[4];
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    auto col = [&](int k) { return __builtin_bit_cast(qp_s2, half ? h[k].y : h[k].x); };
-                    const qp_s2 s23 = col(2) + col(3), s14 = col(1) + col(4), s05 = col(0) + col(5); /* |.| <= 21420: int16 */
-                    v[2 * half]     = (int)s23.x * 20 - (int)s14.x * 5 + (int)s05.x;
-                    v[2 * half + 1] = (int)s23.y * 20 - (int)s14.y * 5 + (int)s05.y;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    pj |= (uint32_t)clip_u8((v[k] + 512) >> 10) << (8 * k);
-                if (useH) {
-                    const uint2 hr = h[hrow1 ? 3 : 2];
-                    ph = qp_round5(__builtin_bit_cast(qp_s2, hr.x), __builtin_bit_cast(qp_s2, hr.y));
-                }
-            } else if (useH) {
-                qp_s2 lo, hi;
-                qp_hraw4(stream(y + (hrow1 ? 3 : 2), xg), lo, hi);
-                ph = qp_round5(lo, hi);
-            }
-            if (useV) {
-                const uint32_t o = sh + 2 + (vcol1 ? 1 : 0);
-                qp_s2 c01[6], c23[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const uint32_t *q = raw + (y + k) * 8 + xg + (o >> 2);
-                    const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3);
-                    c01[k] = qp_pair(0, w, 0x0c010c00);
-                    c23[k] = qp_pair(0, w, 0x0c030c02);
-                }
-                pv = qp_round5(qp_tap6(c01[0], c01[1], c01[2], c01[3], c01[4], c01[5]), qp_tap6(c23[0], c23[1], c23[2], c23[3], c23[4], c23[5]));
-            }
-            {
-                const uint32_t o = sh + (mc == 3 ? 3 : 2);
-                const uint32_t *q = raw + (y + (mc == 12 ? 3 : 2)) * 8 + xg + (o >> 2);
-                pf = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3);
-            }
-            uint32_t out;
-            switch (mc) {
-            case 0:  out = pf; break;
-            case 1: case 3:  out = rnd_avg4(pf, ph); break;
-            case 2:  out = ph; break;
-            case 4: case 12: out = rnd_avg4(pf, pv); break;
-            case 5: case 7: case 13: case 15: out = rnd_avg4(ph, pv); break;
-            case 6: case 14: out = rnd_avg4(ph, pj); break;
-            case 8:  out = pv; break;
-            case 9: case 11: out = rnd_avg4(pv, pj); break;
-            default: out = pj; break; /* 10 */
-            }
-            if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
-                uint32_t *dw = reinterpret_cast<uint32_t *>(d);
-                if (avg)
-                    out = rnd_avg4(*dw, out);
-                *dw = out;
-            } else {
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t v = (out >> (8 * k)) & 0xFF;
-                    d[k] = (uint8_t)(avg ? (d[k] + v + 1) >> 1 : v);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier(); /* the tile is rewritten by the next block */
-    }
-}
-
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
                            hipStream_t stream)
 {
     if (n <= 0)
         return 0;
-    const char *eo = getenv("FFHIP_QPEL_OLD"); /* measured variants: 1 the register-only kernel, 2 one block per wave (k_h264_qpel_l) */
-    const char *ew = getenv("FFHIP_QPEL_WGS"); /* workgroups of the pipelined kernel (default: 8 per CU) */
-    const int wgs = ew && atoi(ew) > 0 ? atoi(ew) : 2048;
-    if (!(stride & 3) && !(eo && eo[0] == '1') && !(eo && eo[0] == '2') && n >= 4 * wgs)
-        hipLaunchKernelGGL(k_h264_qpel_p, dim3(wgs), dim3(256), 0, stream, dst, src, stride, blocks, n);
-    else if (!(stride & 3) && !(eo && eo[0] == '1'))
+    const char *eo = getenv("FFHIP_QPEL_OLD"); /* measured variant: the register-only kernel */
+    if (!(stride & 3) && !(eo && eo[0] == '1'))
         hipLaunchKernelGGL(k_h264_qpel_l, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
     else
         hipLaunchKernelGGL(k_h264_qpel, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);

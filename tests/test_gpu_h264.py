@@ -176,19 +176,14 @@ QPEL_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy",
                     ("avg", np.uint8), ("pad", np.uint8)])
 
 
-@pytest.mark.parametrize("old", ["0", "1", "2", "p7"], ids=["default", "regs", "lds", "pipelined-7wg"])
+@pytest.mark.parametrize("old", ["0", "1"], ids=["lds", "regs"])
 @pytest.mark.parametrize("w,h,pad", [(64, 48, 0), (3840, 2160, 0), (208, 96, 5), (208, 96, 12)])
 def test_qpel_batch(w, h, pad, old, monkeypatch):
-    """put/avg x 16 mcXY x 3 sizes mixed in one batch; unaligned reference positions; all three kernels (the LDS-sharing
-    ones need stride % 4 == 0, pad 5 falls back to the register-only kernel; the pipelined one walks several blocks per
-    wave: 7 workgroups force that — and a ragged tail — on the small pictures too)"""
+    """put/avg x 16 mcXY x 3 sizes mixed in one batch; unaligned reference positions; both kernels (the LDS-sharing
+    one needs stride % 4 == 0, pad 5 falls back to the register-only kernel)"""
     from ffmpeg_amd import h264
     torch = _torch()
-    if old == "p7":
-        monkeypatch.setenv("FFHIP_QPEL_OLD", "0")
-        monkeypatch.setenv("FFHIP_QPEL_WGS", "7")
-    else:
-        monkeypatch.setenv("FFHIP_QPEL_OLD", old)
+    monkeypatch.setenv("FFHIP_QPEL_OLD", old)
     rng = np.random.default_rng(w + pad)
     P = 32                                                  # reference padding so that MVs may point outside the picture
     stride = w + 2 * P + pad

@@ -38,14 +38,9 @@ def blocks(mc):
     return torch.from_numpy(b.view(np.uint8).reshape(len(b), 12)).to(dev), len(b)
 
 
-VARIANTS = [("pipelined", "0", None), ("pipelined wgs=1024", "0", "1024"), ("pipelined wgs=4096", "0", "4096"), ("lds", "2", None), ("regs", "1", None)]
-for name, old, wgs in VARIANTS:
+for old in ("0", "1"):
     os.environ["FFHIP_QPEL_OLD"] = old
-    if wgs:
-        os.environ["FFHIP_QPEL_WGS"] = wgs
-    else:
-        os.environ.pop("FFHIP_QPEL_WGS", None)
-    for mc in ((-1, 0, 2, 8, 10, 5, 9) if wgs is None else (-1, 0, 10)):
+    for mc in (-1, 0, 2, 8, 10, 5, 9):
         d_bl, n = blocks(mc)
         for _ in range(2):
             h264.qpel_batch(dst, ref, stride, d_bl, n)
@@ -57,5 +52,5 @@ for name, old, wgs in VARIANTS:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         px = n * 256
-        print(json.dumps({"kernel": name, "mcxy": "mixed" if mc < 0 else mc, "blocks": n, "ms": round(ms, 4),
+        print(json.dumps({"kernel": "regs" if old == "1" else "lds", "mcxy": "mixed" if mc < 0 else mc, "blocks": n, "ms": round(ms, 4),
                           "Gpixel/s": round(px / ms / 1e6, 1), "hbm_frac": round(2 * px / ms / 1e6 / 8000, 4)}), flush=True)
