@@ -15,6 +15,7 @@
  * in place (the reference leaves them in coeffs) and added to the picture with packed byte stores.
  */
 #include <mutex>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -233,6 +234,150 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
     }
 }
 
+/* ================================================================================================== */
+/*
+ * k_hevc_idct32_mfma — the 32x32 inverse transform on the matrix cores (north_star: "MFMA only if the product genuinely becomes
+ * a dense contraction" — this one is: a 32x32 int8 matrix, |T| <= 90, times a 32x32 int16 block, twice).
+ * One wave per transform unit, v_mfma_i32_32x32x32_i8 (A: lane = row l & 31, 16 K-bytes of group l >> 5; B: lane = column; D: lane =
+ * column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5) for r = 0..15).  int16 data is split into a signed high byte and a low byte
+ * biased by -128 (i8 MFMA is signed x signed): sum T x = 256 sum T hi + sum T (lo - 128) + 128 sum T, the last term a per-output
+ * constant seeded into the accumulator between the two MFMAs, so a pass is  acc = mfma(hi); acc = (acc << 8) + bias; acc = mfma(lo').
+ *   pass 1 (columns)  D1 = X^T . T: lane (c, g) loads X[16 g + s][c], s = 0..15, zeroes what its column's limit drops; the result
+ *                     leaves lane (j, g) holding Y[j][c] for the 16 c of ITS row set — which is exactly an A operand of
+ *   pass 2 (rows)     D2 = Y . T  with K enumerated in that order: the B table of pass 2 is T with its rows permuted to match, so the
+ *                     first pass's registers go back in after >> 7, clip, the second limit's zeroing and the byte split — no LDS, no
+ *                     transposition.
+ * Exact: int32 accumulation of exact products, |sums| <= 32 * 90 * 32768 < 2^31.  Residuals are written back in place, then added
+ * to the picture (8-bit or 16-bit samples).  The VALU kernel above needs N^2/4 = 256 v_dot2 per vector with a scalar coefficient
+ * load behind each (measured 14 % of the dot issue rate); here the contraction costs 4 MFMAs per block.
+ */
+typedef int hm_i4 __attribute__((ext_vector_type(4)));
+typedef int hm_i16 __attribute__((ext_vector_type(16)));
+struct HevcMfmaTab { int8_t b1[64][16], b2[64][16]; int32_t sum[32]; }; /* sum[j] = 128 * sum_k T[k][j] */
+static HevcMfmaTab *g_hm_tab;
+static std::once_flag hm_once;
+static hipError_t hm_err;
+
+__device__ __forceinline__ bool hm_keep(int k, int end) /* hevc_pass<32>'s rule */
+{
+    return (k & 1) ? k < end : ((k & 3) == 2 ? (k >> 1) < (end >> 1) : true);
+}
+/* 16 int16 values -> the high-byte plane and the (low byte - 128) plane, 4 bytes per dword in order */
+__device__ __forceinline__ void hm_split(const int (&v)[16], hm_i4 &hi, hm_i4 &lo)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t p01 = ((uint32_t)v[4 * q] & 0xFFFFu) | ((uint32_t)v[4 * q + 1] << 16);
+        const uint32_t p23 = ((uint32_t)v[4 * q + 2] & 0xFFFFu) | ((uint32_t)v[4 * q + 3] << 16);
+        hi[q] = (int)__builtin_amdgcn_perm(p23, p01, 0x07050301u);
+        lo[q] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hevc_idct32_mfma(int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n, int bd,
+                                                          const HevcMfmaTab *tab)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + wave;
+    if (u >= n)
+        return;
+    const FFHipHevcTU tu = tus[u];
+    const int col_limit = __builtin_amdgcn_readfirstlane(tu.col_limit);
+    int16_t *X = coeffs + __builtin_amdgcn_readfirstlane(tu.coeff_offset);
+    const int c = lane & 31, g = lane >> 5;
+    const hm_i4 B1 = reinterpret_cast<const hm_i4 *>(tab->b1)[lane], B2 = reinterpret_cast<const hm_i4 *>(tab->b2)[lane];
+    const int sum_t = tab->sum[c];
+    /* ---- pass 1: my column c, rows 16 g .. 16 g + 15; limit2 has shrunk by 4 for every column 4, 8, ... before mine ---- */
+    int limit2 = min(col_limit + 4, 32);
+    for (int q = 4; q < c; q += 4)
+        if (limit2 < 32)
+            limit2 -= 4;
+    int v[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const int k = 16 * g + s, x = X[k * 32 + c];
+        v[s] = hm_keep(k, limit2) ? x : 0;
+    }
+    hm_i4 ahi, alo;
+    hm_split(v, ahi, alo);
+    hm_i16 acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, B1, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)(sum_t + 64));
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, B1, acc, 0, 0, 0);
+    /* ---- Y[j = c][cc], cc = (r & 3) + 8 (r >> 2) + 4 g: >> 7, clip, the second pass's limit ---- */
+    const int limit = min(col_limit, 32);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int cc = (r & 3) + 8 * (r >> 2) + 4 * g;
+        const int y = hevc_clip16(acc[r] >> 7);
+        v[r] = hm_keep(cc, limit) ? y : 0;
+    }
+    hm_split(v, ahi, alo);
+    const int shift2 = 20 - bd;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        acc[r] = 0;
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, B2, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)(sum_t + (1 << (shift2 - 1))));
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, B2, acc, 0, 0, 0);
+    /* ---- Z[j][m = c], j = (r & 3) + 8 (r >> 2) + 4 g: residual back in place, picture += residual ---- */
+    const bool add = dst && tu.dst_offset >= 0;
+    const int maxv = (1 << bd) - 1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * g;
+        const int z = hevc_clip16(acc[r] >> shift2);
+        X[j * 32 + c] = (int16_t)z;
+        if (add) {
+            uint8_t *row = dst + tu.dst_offset + (ptrdiff_t)j * stride;
+            if (bd > 8) {
+                uint16_t *d = reinterpret_cast<uint16_t *>(row) + c;
+                *d = (uint16_t)min(max((int)*d + z, 0), maxv);
+            } else {
+                row[c] = (uint8_t)min(max((int)row[c] + z, 0), 255);
+            }
+        }
+    }
+}
+
+static int hm_tab_init()
+{
+    std::call_once(hm_once, [] {
+        std::call_once(hevc_tab_once, [] {
+            hevc_build_table();
+            hevc_tab_err = hipMemcpyToSymbol(HIP_SYMBOL(hevc_pk), hevc_pk_host, sizeof(hevc_pk_host));
+        });
+        static HevcMfmaTab h;
+        for (int l = 0; l < 64; l++) {
+            const int j = l & 31, g = l >> 5;
+            for (int s = 0; s < 16; s++) {
+                h.b1[l][s] = hevc_t32_host[16 * g + s][j];                              /* T[k = 16 g + s][j]               */
+                h.b2[l][s] = hevc_t32_host[(s & 3) + 8 * (s >> 2) + 4 * g][j];        /* T[c = the D row of register s][m] */
+            }
+        }
+        for (int j = 0; j < 32; j++) {
+            int t = 0;
+            for (int k = 0; k < 32; k++)
+                t += hevc_t32_host[k][j];
+            h.sum[j] = 128 * t;
+        }
+        hm_err = hipMalloc(reinterpret_cast<void **>(&g_hm_tab), sizeof(h));
+        if (hm_err == hipSuccess)
+            hm_err = hipMemcpy(g_hm_tab, &h, sizeof(h), hipMemcpyHostToDevice);
+        if (hm_err == hipSuccess)
+            ffhip_note_device_resources();
+    });
+    if (hm_err != hipSuccess || hevc_tab_err != hipSuccess) {
+        ffhip_set_error("ffhip_hevc_idct: table upload failed");
+        return FFHIP_EIO;
+    }
+    return 0;
+}
+
 int ffhip_launch_hevc_idct(int kind, int log2_size, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n,
                            hipStream_t stream)
 {
@@ -255,6 +400,17 @@ int ffhip_launch_hevc_idct_bd(int bd, int kind, int log2_size, int16_t *coeffs, 
     if (hevc_tab_err != hipSuccess) {
         ffhip_set_error("ffhip_hevc_idct: coefficient table upload failed: %s", hipGetErrorString(hevc_tab_err));
         return FFHIP_EIO;
+    }
+    {
+        const char *eo = getenv("FFHIP_HEVC_IDCT32_VALU"); /* measured variant: the dot2 kernel for 32x32 as well */
+        if (kind == FFHIP_HEVC_IDCT && log2_size == 5 && !(eo && eo[0] == '1')) {
+            const int r = hm_tab_init();
+            if (r < 0)
+                return r;
+            hipLaunchKernelGGL(k_hevc_idct32_mfma, dim3(cdiv(n, 4)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd, g_hm_tab);
+            LAUNCH_CHECK();
+            return 0;
+        }
     }
     const int upw = 64 >> log2_size;
     const dim3 grid(cdiv(n, 4 * upw)), block(256);
