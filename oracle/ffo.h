@@ -123,6 +123,14 @@ void ffo_hevc_mc(int chroma, int uni, void *dst, ptrdiff_t dststride, const uint
 void ffo_hevc_mc_w(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
                    int height, int denom, int wx0, int wx1, int ox, int mx, int my, int width);
 /* VP9DSPContext.itxfm_add[tx][txtp], 8 bits (ffo_vp9.c): tx 0..3 = 4x4..32x32, 4 = WHT; consumes the block */
+/* vp9dsp above 8 bits (10, 12): uint16_t pixels, int32 coefficients, strides in bytes (ffo_vp9.c) */
+void ffo_vp9_itxfm_add_bd(int bd, int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int32_t *block, int eob);
+void ffo_vp9_mc_bd(int bd, int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width,
+                   int height, int mx, int my);
+void ffo_vp9_smc_bd(int bd, int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width,
+                    int height, int mx, int my, int dx, int dy);
+void ffo_vp9_loop_filter_bd(int bd, int wd, int dir, uint8_t *dst, ptrdiff_t stride, int E, int I, int H);
+void ffo_vp9_intra_pred_bd(int bd, int tx, int mode, uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top);
 void ffo_vp9_itxfm_add(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob);
 /* VP9DSPContext.mc[..][filter][avg][!!mx][!!my], 8 bits: filter 0 smooth, 1 regular, 2 sharp, 3 bilinear */
 void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,

@@ -17,286 +17,35 @@
 
 #include "ffo.h"
 
+#define ST int32_t
+#define UT uint32_t
+#define FN(x) x
+#include "ffo_vp9_tx.inc"
+#undef ST
+#undef UT
+#undef FN
+#define ST int64_t
+#define UT uint64_t
+#define FN(x) x##_w64
+#include "ffo_vp9_tx.inc"
+#undef ST
+#undef UT
+#undef FN
 typedef uint32_t u32;
 #define R14(x) ((int32_t)((u32)(x) + (1u << 13)) >> 14)
 
-/* (a c - b s, a s + b c), each rounded */
-static void rot(int32_t a, int32_t b, u32 c, u32 s, int32_t *lo, int32_t *hi)
-{
-    *lo = R14((u32)a * c - (u32)b * s);
-    *hi = R14((u32)a * s + (u32)b * c);
-}
-/* (-(a s + b c), a c - b s), each rounded: the negation happens before the rounding */
-static void nrot(int32_t a, int32_t b, u32 c, u32 s, int32_t *lo, int32_t *hi)
-{
-    *lo = R14(-((u32)a * s + (u32)b * c));
-    *hi = R14((u32)a * c - (u32)b * s);
-}
-/* ((a - b), (a + b)) / sqrt 2 */
-static void half(int32_t a, int32_t b, int32_t *lo, int32_t *hi)
-{
-    *lo = R14(((u32)a - (u32)b) * 11585u);
-    *hi = R14(((u32)a + (u32)b) * 11585u);
-}
-
-/* ---- inverse DCT: even part by recursion, odd parts below; o[] of an odd part is ordered so that out[i] = e[i] + o[i] ---- */
-static void idct2_even(int32_t x0, int32_t x1, int32_t *e) /* the 2-point core: x0, x1 = inputs 0 and N/2 */
-{
-    half(x0, x1, &e[1], &e[0]);
-}
-
-static void idct4_core(const int32_t *x, int32_t *out) /* x[0..3] natural order */
-{
-    int32_t e[2], t2, t3;
-    idct2_even(x[0], x[2], e);
-    rot(x[1], x[3], 6270, 15137, &t2, &t3);
-    out[0] = e[0] + t3;
-    out[1] = e[1] + t2;
-    out[2] = e[1] - t2;
-    out[3] = e[0] - t3;
-}
-
-static void odd8(const int32_t *x, int32_t *o) /* x = inputs 1, 3, 5, 7 */
-{
-    int32_t a4, a7, a5, a6, d5, d6;
-    rot(x[0], x[3], 3196, 16069, &a4, &a7);
-    rot(x[2], x[1], 13623, 9102, &a5, &a6);
-    o[3] = a4 + a5;
-    d5 = a4 - a5;
-    o[0] = a7 + a6;
-    d6 = a7 - a6;
-    half(d6, d5, &o[2], &o[1]);
-}
-
-static void odd16(const int32_t *x, int32_t *o) /* x = inputs 1, 3, ..., 15 */
-{
-    int32_t a[8], t[8]; /* a[k] = t(8+k)a, t[k] = t(8+k) of the listing */
-    rot(x[0], x[7], 1606, 16305, &a[0], &a[7]);
-    rot(x[4], x[3], 12665, 10394, &a[1], &a[6]);
-    rot(x[2], x[5], 7723, 14449, &a[2], &a[5]);
-    rot(x[6], x[1], 15679, 4756, &a[3], &a[4]);
-    t[0] = a[0] + a[1]; t[1] = a[0] - a[1]; t[2] = a[3] - a[2]; t[3] = a[3] + a[2];
-    t[4] = a[4] + a[5]; t[5] = a[4] - a[5]; t[6] = a[7] - a[6]; t[7] = a[7] + a[6];
-    rot(t[6], t[1], 6270, 15137, &a[1], &a[6]);
-    nrot(t[5], t[2], 6270, 15137, &a[2], &a[5]);
-    a[0] = t[0] + t[3]; a[3] = t[0] - t[3];
-    t[1] = a[1] + a[2]; t[2] = a[1] - a[2];
-    a[4] = t[7] - t[4]; a[7] = t[7] + t[4];
-    t[5] = a[6] - a[5]; t[6] = a[6] + a[5];
-    half(t[5], t[2], &a[2], &a[5]);
-    half(a[4], a[3], &t[3], &t[4]);
-    o[0] = a[7]; o[1] = t[6]; o[2] = a[5]; o[3] = t[4]; o[4] = t[3]; o[5] = a[2]; o[6] = t[1]; o[7] = a[0];
-}
-
-static void odd32(const int32_t *x, int32_t *o) /* x = inputs 1, 3, ..., 31 */
-{
-    int32_t a[16], t[16]; /* index k stands for t(16+k) */
-    rot(x[0], x[15], 804, 16364, &a[0], &a[15]);
-    rot(x[8], x[7], 12140, 11003, &a[1], &a[14]);
-    rot(x[4], x[11], 7005, 14811, &a[2], &a[13]);
-    rot(x[12], x[3], 15426, 5520, &a[3], &a[12]);
-    rot(x[2], x[13], 3981, 15893, &a[4], &a[11]);
-    rot(x[10], x[5], 14053, 8423, &a[5], &a[10]);
-    rot(x[6], x[9], 9760, 13160, &a[6], &a[9]);
-    rot(x[14], x[1], 16207, 2404, &a[7], &a[8]);
-    for (int k = 0; k < 16; k += 4) { /* pairs (k, k+1) sum / difference, (k+2, k+3) mirrored */
-        t[k] = a[k] + a[k + 1];
-        t[k + 1] = a[k] - a[k + 1];
-        t[k + 2] = a[k + 3] - a[k + 2];
-        t[k + 3] = a[k + 3] + a[k + 2];
-    }
-    rot(t[14], t[1], 3196, 16069, &a[1], &a[14]);
-    nrot(t[13], t[2], 3196, 16069, &a[2], &a[13]);
-    rot(t[10], t[5], 13623, 9102, &a[5], &a[10]);
-    nrot(t[9], t[6], 13623, 9102, &a[6], &a[9]);
-    a[0] = t[0] + t[3];   a[3] = t[0] - t[3];
-    t[1] = a[1] + a[2];   t[2] = a[1] - a[2];
-    a[4] = t[7] - t[4];   a[7] = t[7] + t[4];
-    t[5] = a[6] - a[5];   t[6] = a[6] + a[5];
-    a[8] = t[8] + t[11];  a[11] = t[8] - t[11];
-    t[9] = a[9] + a[10];  t[10] = a[9] - a[10];
-    a[12] = t[15] - t[12]; a[15] = t[15] + t[12];
-    t[13] = a[14] - a[13]; t[14] = a[14] + a[13];
-    rot(t[13], t[2], 6270, 15137, &a[2], &a[13]);
-    rot(a[12], a[3], 6270, 15137, &t[3], &t[12]);
-    nrot(a[11], a[4], 6270, 15137, &t[4], &t[11]);
-    nrot(t[10], t[5], 6270, 15137, &a[5], &a[10]);
-    {
-        int32_t n[16];
-        n[0] = a[0] + a[7];    n[7] = a[0] - a[7];
-        n[1] = t[1] + t[6];    n[6] = t[1] - t[6];
-        n[2] = a[2] + a[5];    n[5] = a[2] - a[5];
-        n[3] = t[3] + t[4];    n[4] = t[3] - t[4];
-        n[8] = a[15] - a[8];   n[15] = a[15] + a[8];
-        n[9] = t[14] - t[9];   n[14] = t[14] + t[9];
-        n[10] = a[13] - a[10]; n[13] = a[13] + a[10];
-        n[11] = t[12] - t[11]; n[12] = t[12] + t[11];
-        half(n[11], n[4], &n[4], &n[11]);
-        half(n[10], n[5], &n[5], &n[10]);
-        half(n[9], n[6], &n[6], &n[9]);
-        half(n[8], n[7], &n[7], &n[8]);
-        for (int k = 0; k < 16; k++)
-            o[k] = n[15 - k];
-    }
-}
-
-static void idct_n(int n, const int32_t *x, int32_t *out)
-{
-    if (n == 4) {
-        idct4_core(x, out);
-        return;
-    }
-    int32_t ev[16], od[16], e[16], o[16];
-    for (int k = 0; k < n / 2; k++) {
-        ev[k] = x[2 * k];
-        od[k] = x[2 * k + 1];
-    }
-    idct_n(n / 2, ev, e);
-    if (n == 8)
-        odd8(od, o);
-    else if (n == 16)
-        odd16(od, o);
-    else
-        odd32(od, o);
-    for (int k = 0; k < n / 2; k++) {
-        out[k] = e[k] + o[k];
-        out[n - 1 - k] = e[k] - o[k];
-    }
-}
-
-/* ---- inverse ADST ---- */
-static void iadst4(const int32_t *x, int32_t *out)
-{
-    const u32 x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
-    const u32 t0 = 5283u * x0 + 15212u * x2 + 9929u * x3;
-    const u32 t1 = 9929u * x0 - 5283u * x2 - 15212u * x3;
-    const u32 t2 = 13377u * (x0 - x2 + x3);
-    const u32 t3 = 13377u * x1;
-    out[0] = R14(t0 + t3);
-    out[1] = R14(t1 + t3);
-    out[2] = R14(t2);
-    out[3] = R14(t0 + t1 - t3);
-}
-
-static void iadst8(const int32_t *x, int32_t *out)
-{
-    static const u32 c[4][2] = { { 16305, 1606 }, { 14449, 7723 }, { 10394, 12665 }, { 4756, 15679 } };
-    u32 p[8];
-    int32_t t[8];
-    for (int k = 0; k < 4; k++) { /* pairs (x[7-2k], x[2k]) */
-        const u32 a = x[7 - 2 * k], b = x[2 * k];
-        p[2 * k] = c[k][0] * a + c[k][1] * b;
-        p[2 * k + 1] = c[k][1] * a - c[k][0] * b;
-    }
-    for (int k = 0; k < 4; k++) {
-        t[k] = R14(p[k] + p[k + 4]);
-        t[k + 4] = R14(p[k] - p[k + 4]);
-    }
-    {
-        const u32 q4 = 15137u * (u32)t[4] + 6270u * (u32)t[5], q5 = 6270u * (u32)t[4] - 15137u * (u32)t[5];
-        const u32 q6 = 15137u * (u32)t[7] - 6270u * (u32)t[6], q7 = 6270u * (u32)t[7] + 15137u * (u32)t[6];
-        const int32_t s2 = t[0] - t[2], s3 = t[1] - t[3];
-        const int32_t s6 = R14(q4 - q6), s7 = R14(q5 - q7);
-        out[0] = t[0] + t[2];
-        out[7] = -(t[1] + t[3]);
-        out[1] = -R14(q4 + q6);
-        out[6] = R14(q5 + q7);
-        out[3] = -R14(((u32)s2 + (u32)s3) * 11585u);
-        out[4] = R14(((u32)s2 - (u32)s3) * 11585u);
-        out[2] = R14(((u32)s6 + (u32)s7) * 11585u);
-        out[5] = -R14(((u32)s6 - (u32)s7) * 11585u);
-    }
-}
-
-static void iadst16(const int32_t *x, int32_t *out)
-{
-    static const u32 c[8][2] = { { 16364, 804 }, { 15893, 3981 }, { 14811, 7005 }, { 13160, 9760 },
-                                 { 11003, 12140 }, { 8423, 14053 }, { 5520, 15426 }, { 2404, 16207 } };
-    u32 p[16], q[16];
-    int32_t a[16], t[16];
-    for (int k = 0; k < 8; k++) { /* pairs (x[15-2k], x[2k]) */
-        const u32 u = x[15 - 2 * k], v = x[2 * k];
-        p[2 * k] = c[k][0] * u + c[k][1] * v;
-        p[2 * k + 1] = c[k][1] * u - c[k][0] * v;
-    }
-    for (int k = 0; k < 8; k++) {
-        a[k] = R14(p[k] + p[k + 8]);
-        a[k + 8] = R14(p[k] - p[k + 8]);
-    }
-    q[8] = (u32)a[8] * 16069u + (u32)a[9] * 3196u;
-    q[9] = (u32)a[8] * 3196u - (u32)a[9] * 16069u;
-    q[10] = (u32)a[10] * 9102u + (u32)a[11] * 13623u;
-    q[11] = (u32)a[10] * 13623u - (u32)a[11] * 9102u;
-    q[12] = (u32)a[13] * 16069u - (u32)a[12] * 3196u;
-    q[13] = (u32)a[13] * 3196u + (u32)a[12] * 16069u;
-    q[14] = (u32)a[15] * 9102u - (u32)a[14] * 13623u;
-    q[15] = (u32)a[15] * 13623u + (u32)a[14] * 9102u;
-    for (int k = 0; k < 4; k++) {
-        t[k] = a[k] + a[k + 4];
-        t[k + 4] = a[k] - a[k + 4];
-        a[k + 8] = R14(q[k + 8] + q[k + 12]);
-        a[k + 12] = R14(q[k + 8] - q[k + 12]);
-    }
-    {
-        const u32 r4 = (u32)t[4] * 15137u + (u32)t[5] * 6270u, r5 = (u32)t[4] * 6270u - (u32)t[5] * 15137u;
-        const u32 r6 = (u32)t[7] * 15137u - (u32)t[6] * 6270u, r7 = (u32)t[7] * 6270u + (u32)t[6] * 15137u;
-        const u32 r12 = (u32)a[12] * 15137u + (u32)a[13] * 6270u, r13 = (u32)a[12] * 6270u - (u32)a[13] * 15137u;
-        const u32 r14 = (u32)a[15] * 15137u - (u32)a[14] * 6270u, r15 = (u32)a[15] * 6270u + (u32)a[14] * 15137u;
-        const int32_t s2 = t[0] - t[2], s3 = t[1] - t[3];
-        const int32_t s6 = R14(r4 - r6), s7 = R14(r5 - r7);
-        const int32_t s10 = a[8] - a[10], s11 = a[9] - a[11];
-        const int32_t s14 = R14(r12 - r14), s15 = R14(r13 - r15);
-        out[0] = t[0] + t[2];
-        out[15] = -(t[1] + t[3]);
-        out[3] = -R14(r4 + r6);
-        out[12] = R14(r5 + r7);
-        out[1] = -(a[8] + a[10]);
-        out[14] = a[9] + a[11];
-        out[2] = R14(r12 + r14);
-        out[13] = -R14(r13 + r15);
-        out[7] = R14(-((u32)s2 + (u32)s3) * 11585u);
-        out[8] = R14(((u32)s2 - (u32)s3) * 11585u);
-        out[4] = R14(((u32)s7 + (u32)s6) * 11585u);
-        out[11] = R14(((u32)s7 - (u32)s6) * 11585u);
-        out[6] = R14(((u32)s11 + (u32)s10) * 11585u);
-        out[9] = R14(((u32)s11 - (u32)s10) * 11585u);
-        out[5] = R14(-((u32)s14 + (u32)s15) * 11585u);
-        out[10] = R14(((u32)s14 - (u32)s15) * 11585u);
-    }
-}
-
-/* lossless mode: the Walsh-Hadamard transform (:1719-1750); pass 0 scales its inputs down by 4 */
-static void iwht4(const int32_t *x, int32_t *out, int pass)
-{
-    int32_t t0 = x[0], t1 = x[3], t2 = x[1], t3 = x[2], t4;
-    if (!pass) {
-        t0 >>= 2; t1 >>= 2; t2 >>= 2; t3 >>= 2;
-    }
-    t0 += t2;
-    t3 -= t1;
-    t4 = (t0 - t3) >> 1;
-    t1 = t4 - t1;
-    t2 = t4 - t2;
-    t0 -= t1;
-    t3 += t2;
-    out[0] = t0; out[1] = t1; out[2] = t2; out[3] = t3;
-}
-
-static void tx1d(int kind, int n, const int32_t *x, int32_t *out, int pass)
-{
-    if (kind == 2)
-        iwht4(x, out, pass);
-    else if (kind == 0)
-        idct_n(n, x, out);
-    else if (n == 4)
-        iadst4(x, out);
-    else if (n == 8)
-        iadst8(x, out);
-    else
-        iadst16(x, out);
-}
-
 static uint8_t clip_px(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+/* pixel access by bit depth (bit_depth_template.c): uint8_t at 8 bits, uint16_t above; i counts SAMPLES from a byte pointer */
+static inline int pget(const uint8_t *p, ptrdiff_t i, int bd) { return bd > 8 ? ((const uint16_t *)p)[i] : p[i]; }
+static inline void pput(uint8_t *p, ptrdiff_t i, int v, int bd)
+{
+    if (bd > 8)
+        ((uint16_t *)p)[i] = (uint16_t)v;
+    else
+        p[i] = (uint8_t)v;
+}
+static int clipp(int v, int bd) { const int m = (1 << bd) - 1; return v < 0 ? 0 : v > m ? m : v; }
+static ptrdiff_t spx(ptrdiff_t stride_bytes, int bd) { return bd > 8 ? stride_bytes / 2 : stride_bytes; }
 
 /*
  * itxfm_add[tx][txtp](dst, stride, block, eob): tx 0..3 = 4x4 .. 32x32, 4 = lossless 4x4 WHT; txtp 0 DCT_DCT, 1 DCT_ADST,
@@ -338,6 +87,43 @@ void ffo_vp9_itxfm_add(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t
     }
 }
 
+/* the same members above 8 bits: dctcoef = int32_t (the block argument points at int32 coefficients), dctint = int64_t, pixels
+ * uint16_t clipped to (1 << bd) - 1, stride in bytes (vp9dsp_template.c:1155-1195 with BIT_DEPTH 10 / 12) */
+void ffo_vp9_itxfm_add_bd(int bd, int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int32_t *block, int eob)
+{
+    const int wht = tx == 4, n = wht ? 4 : 4 << tx, bits = wht ? 0 : tx == 0 ? 4 : tx == 1 ? 5 : 6;
+    const int first = wht ? 2 : (tx == 3 ? 0 : (txtp == 1 || txtp == 3)), second = wht ? 2 : (tx == 3 ? 0 : (txtp == 2 || txtp == 3));
+    int32_t tmp[32 * 32];
+    stride = spx(stride, bd);
+    if (!wht && !first && !second && eob == 1) {
+        const int t = (int)((((((int64_t)block[0] * 11585 + (1 << 13)) >> 14) * 11585) + (1 << 13)) >> 14);
+        block[0] = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++)
+                pput(dst, j * stride + i, clipp(pget(dst, j * stride + i, bd) + (bits ? (int)((unsigned)t + (1u << (bits - 1))) >> bits : t), bd), bd);
+        return;
+    }
+    for (int i = 0; i < n; i++) {
+        int64_t x[32], o[32];
+        for (int k = 0; k < n; k++)
+            x[k] = block[i + k * n];
+        tx1d_w64(first, n, x, o, 0);
+        for (int k = 0; k < n; k++)
+            tmp[i * n + k] = (int32_t)o[k];
+    }
+    memset(block, 0, sizeof(int32_t) * n * n);
+    for (int i = 0; i < n; i++) {
+        int64_t x[32], o[32];
+        for (int k = 0; k < n; k++)
+            x[k] = tmp[i + k * n];
+        tx1d_w64(second, n, x, o, 1);
+        for (int j = 0; j < n; j++) {
+            const int32_t v = (int32_t)o[j]; /* out[] is dctcoef too */
+            pput(dst, j * stride + i, clipp(pget(dst, j * stride + i, bd) + (bits ? (int)((unsigned)v + (1u << (bits - 1))) >> bits : v), bd), bd);
+        }
+    }
+}
+
 /*
  * VP9 motion compensation, 8 bits: VP9DSPContext.mc[size][filter][avg][!!mx][!!my] (libavcodec/vp9dsp_template.c:1966-2293;
  * taps: ff_vp9_subpel_filters, libavcodec/vp9dsp.c:32-86; enum FilterMode, libavcodec/vp9.h:64-70: 0 smooth, 1 regular,
@@ -362,44 +148,56 @@ static const int8_t vp9_taps[3][16][8] = {
       { -2, 5, -10, 27, 121, -17, 7, -3 }, { -1, 3, -6, 17, 125, -13, 5, -2 }, { 0, 1, -3, 8, 127, -7, 3, -1 } },
 };
 
-static int vp9_tap8(int filter, int m, const uint8_t *s, ptrdiff_t step)
+/* s + i: sample i of a plane of depth bd (byte pointer, sample index) */
+static int vp9_tap8(int bd, int filter, int m, const uint8_t *s, ptrdiff_t i, ptrdiff_t step)
 {
     int sum = 64;
     for (int k = 0; k < 8; k++)
-        sum += vp9_taps[filter][m][k] * s[(k - 3) * step];
-    sum >>= 7;
-    return sum < 0 ? 0 : sum > 255 ? 255 : sum;
+        sum += vp9_taps[filter][m][k] * pget(s, i + (k - 3) * step, bd);
+    return clipp(sum >> 7, bd);
 }
-static int vp9_bilin(int m, const uint8_t *s, ptrdiff_t step) { return s[0] + ((m * (s[step] - s[0]) + 8) >> 4); }
-
-/* width 4..64 (multiple of 4), height 1..64, filter 0..3, mx / my 0..15 */
-void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
-                int mx, int my)
+static int vp9_bilin(int bd, int m, const uint8_t *s, ptrdiff_t i, ptrdiff_t step)
 {
-    uint8_t tmp[71 * 64];
+    return pget(s, i, bd) + ((m * (pget(s, i + step, bd) - pget(s, i, bd)) + 8) >> 4);
+}
+
+/* width 4..64 (multiple of 4), height 1..64, filter 0..3, mx / my 0..15; above 8 bits the temporaries are pixels of that depth */
+void ffo_vp9_mc_bd(int bd, int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width,
+                   int height, int mx, int my)
+{
+    uint16_t tmp16[71 * 64];
+    uint8_t tmp8[71 * 64];
+    uint8_t *tmp = bd > 8 ? (uint8_t *)tmp16 : tmp8;
     const int bil = filter == 3;
+    srcstride = spx(srcstride, bd);
+    dststride = spx(dststride, bd);
     if (mx && my) { /* rows -3..h+3 (bilinear: 0..h) through the horizontal filter */
         const int r0 = bil ? 0 : -3, rows = bil ? height + 1 : height + 7;
         for (int r = 0; r < rows; r++)
             for (int x = 0; x < width; x++) {
-                const uint8_t *s = src + (r + r0) * srcstride + x;
-                tmp[r * 64 + x] = bil ? vp9_bilin(mx, s, 1) : vp9_tap8(filter, mx, s, 1);
+                const ptrdiff_t at = (r + r0) * srcstride + x;
+                pput(tmp, r * 64 + x, bil ? vp9_bilin(bd, mx, src, at, 1) : vp9_tap8(bd, filter, mx, src, at, 1), bd);
             }
     }
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
-            const uint8_t *s = src + y * srcstride + x;
+            const ptrdiff_t at = y * srcstride + x;
             int v;
             if (mx && my)
-                v = bil ? vp9_bilin(my, tmp + y * 64 + x, 64) : vp9_tap8(filter, my, tmp + (y + 3) * 64 + x, 64);
+                v = bil ? vp9_bilin(bd, my, tmp, y * 64 + x, 64) : vp9_tap8(bd, filter, my, tmp, (y + 3) * 64 + x, 64);
             else if (mx)
-                v = bil ? vp9_bilin(mx, s, 1) : vp9_tap8(filter, mx, s, 1);
+                v = bil ? vp9_bilin(bd, mx, src, at, 1) : vp9_tap8(bd, filter, mx, src, at, 1);
             else if (my)
-                v = bil ? vp9_bilin(my, s, srcstride) : vp9_tap8(filter, my, s, srcstride);
+                v = bil ? vp9_bilin(bd, my, src, at, srcstride) : vp9_tap8(bd, filter, my, src, at, srcstride);
             else
-                v = s[0];
-            dst[y * dststride + x] = avg ? (dst[y * dststride + x] + v + 1) >> 1 : v;
+                v = pget(src, at, bd);
+            pput(dst, y * dststride + x, avg ? (pget(dst, y * dststride + x, bd) + v + 1) >> 1 : v, bd);
         }
+}
+void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
+                int mx, int my)
+{
+    ffo_vp9_mc_bd(8, filter, avg, dst, dststride, src, srcstride, width, height, mx, my);
 }
 
 /*
@@ -411,52 +209,63 @@ void ffo_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const ui
  * p3..q3 / p7..q7 with the ends repeated, the centre counted twice.
  */
 static int iabs(int v) { return v < 0 ? -v : v; }
-static int clip_i8(int v) { return v < -128 ? -128 : v > 127 ? 127 : v; }
 
-void ffo_vp9_loop_filter(int wd, int dir, uint8_t *dst, ptrdiff_t stride, int E, int I, int H)
+static int clip_sp(int v, int bits) { const int lo = -(1 << bits), hi = (1 << bits) - 1; return v < lo ? lo : v > hi ? hi : v; } /* av_clip_intp2 */
+
+/* E, I, H arrive in 8-bit units and are scaled by << (bd - 8), the flatness threshold is 1 << (bd - 8) (:1784-1788) */
+void ffo_vp9_loop_filter_bd(int bd, int wd, int dir, uint8_t *dst_, ptrdiff_t stride, int E, int I, int H)
 {
-    const ptrdiff_t along = dir ? 1 : stride, across = dir ? stride : 1;
+    const ptrdiff_t st = spx(stride, bd), along = dir ? 1 : st, across = dir ? st : 1;
+    const int F = 1 << (bd - 8), fmax = (1 << (bd - 1)) - 1;
+    ptrdiff_t dst = 0;
+    E <<= bd - 8;
+    I <<= bd - 8;
+    H <<= bd - 8;
     for (int i = 0; i < 8; i++, dst += along) {
         int px[16]; /* p7 .. p0, q0 .. q7 */
         const int r = wd >= 16 ? 8 : 4;
         for (int k = -r; k < r; k++)
-            px[8 + k] = dst[k * across];
+            px[8 + k] = pget(dst_, dst + k * across, bd);
         const int p3 = px[4], p2 = px[5], p1 = px[6], p0 = px[7], q0 = px[8], q1 = px[9], q2 = px[10], q3 = px[11];
         if (!(iabs(p3 - p2) <= I && iabs(p2 - p1) <= I && iabs(p1 - p0) <= I && iabs(q1 - q0) <= I && iabs(q2 - q1) <= I &&
               iabs(q3 - q2) <= I && iabs(p0 - q0) * 2 + (iabs(p1 - q1) >> 1) <= E))
             continue;
         int flat_in = wd >= 8, flat_out = wd >= 16;
         for (int k = 1; k <= 3 && flat_in; k++)
-            flat_in = iabs(px[7 - k] - p0) <= 1 && iabs(px[8 + k] - q0) <= 1;
+            flat_in = iabs(px[7 - k] - p0) <= F && iabs(px[8 + k] - q0) <= F;
         for (int k = 4; k <= 7 && flat_out; k++)
-            flat_out = iabs(px[7 - k] - p0) <= 1 && iabs(px[8 + k] - q0) <= 1;
+            flat_out = iabs(px[7 - k] - p0) <= F && iabs(px[8 + k] - q0) <= F;
         if (flat_out && flat_in) {
             for (int c = 1; c <= 14; c++) {
                 int s = px[c] + 8;
                 for (int t = -7; t <= 7; t++)
                     s += px[c + t < 0 ? 0 : c + t > 15 ? 15 : c + t];
-                dst[(c - 8) * across] = s >> 4;
+                pput(dst_, dst + (c - 8) * across, s >> 4, bd);
             }
         } else if (flat_in) {
             for (int c = 5; c <= 10; c++) {
                 int s = px[c] + 4;
                 for (int t = -3; t <= 3; t++)
                     s += px[c + t < 4 ? 4 : c + t > 11 ? 11 : c + t];
-                dst[(c - 8) * across] = s >> 3;
+                pput(dst_, dst + (c - 8) * across, s >> 3, bd);
             }
         } else {
             const int hev = iabs(p1 - p0) > H || iabs(q1 - q0) > H;
-            int f = clip_i8(3 * (q0 - p0) + (hev ? clip_i8(p1 - q1) : 0));
-            const int f1 = (f + 4 > 127 ? 127 : f + 4) >> 3, f2 = (f + 3 > 127 ? 127 : f + 3) >> 3;
-            dst[-across] = clip_px(p0 + f2);
-            dst[0] = clip_px(q0 - f1);
+            int f = clip_sp(3 * (q0 - p0) + (hev ? clip_sp(p1 - q1, bd - 1) : 0), bd - 1);
+            const int f1 = (f + 4 > fmax ? fmax : f + 4) >> 3, f2 = (f + 3 > fmax ? fmax : f + 3) >> 3;
+            pput(dst_, dst - across, clipp(p0 + f2, bd), bd);
+            pput(dst_, dst, clipp(q0 - f1, bd), bd);
             if (!hev) {
                 f = (f1 + 1) >> 1;
-                dst[-2 * across] = clip_px(p1 + f);
-                dst[across] = clip_px(q1 - f);
+                pput(dst_, dst - 2 * across, clipp(p1 + f, bd), bd);
+                pput(dst_, dst + across, clipp(q1 - f, bd), bd);
             }
         }
     }
+}
+void ffo_vp9_loop_filter(int wd, int dir, uint8_t *dst, ptrdiff_t stride, int E, int I, int H)
+{
+    ffo_vp9_loop_filter_bd(8, wd, dir, dst, stride, E, I, H);
 }
 
 /*
@@ -468,8 +277,9 @@ void ffo_vp9_loop_filter(int wd, int dir, uint8_t *dst, ptrdiff_t stride, int E,
 static int A2(int a, int b) { return (a + b + 1) >> 1; }
 static int A3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
 
-void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
+void ffo_vp9_intra_pred_bd(int bd, int tx, int mode, uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
 {
+    stride = spx(stride, bd);
     const int n = 4 << tx, lg = 2 + tx;
     int e[32 + 1 + 64]; /* edge line; the 4x4 down-left / vert-left modes read 8 top samples, nobody reads more than 2n */
     int dc = 0;
@@ -479,12 +289,12 @@ void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const 
     memset(e, 0, sizeof(e));
     if (uses_left)
         for (int k = 0; k < n; k++)
-            e[k] = left[k];
+            e[k] = pget(left, k, bd);
     if (mode == 4 || mode == 5 || mode == 6 || mode == 9)
-        e[n] = top[-1];
+        e[n] = pget(top, -1, bd);
     if (uses_top)
         for (int k = 0; k < ntop; k++)
-            e[n + 1 + k] = top[k];
+            e[n + 1 + k] = pget(top, k, bd);
     const int *T = e + n + 1; /* T[-1] = corner */
     if (mode == 2) {
         for (int k = 0; k < n; k++)
@@ -495,7 +305,7 @@ void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const 
             dc += mode == 10 ? e[k] : T[k];
         dc = (dc + n / 2) >> lg;
     } else if (mode >= 12) {
-        dc = mode == 12 ? 128 : mode == 13 ? 127 : 129;
+        dc = (128 << (bd - 8)) + (mode == 12 ? 0 : mode == 13 ? -1 : 1);
     }
     for (int y = 0; y < n; y++)
         for (int x = 0; x < n; x++) {
@@ -556,11 +366,15 @@ void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const 
                     v = (i & 1) ? A3(e[i >> 1], e[(i >> 1) + 1], e[(i >> 1) + 2]) : A2(e[i >> 1], e[(i >> 1) + 1]);
                 break;
             }
-            case 9: v = clip_px(T[x] + e[n - 1 - y] - T[-1]); break;                     /* TM */
+            case 9: v = clipp(T[x] + e[n - 1 - y] - T[-1], bd); break;                     /* TM */
             default: v = dc; break;                                                      /* DC, LEFT_DC, TOP_DC, DC_128/127/129 */
             }
-            dst[y * stride + x] = (uint8_t)v;
+            pput(dst, y * stride + x, v, bd);
         }
+}
+void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
+{
+    ffo_vp9_intra_pred_bd(8, tx, mode, dst, stride, left, top);
 }
 
 /*
@@ -570,28 +384,37 @@ void ffo_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const 
  * output y around row (my + y dy) >> 4; horizontally filtered 8-bit temporaries first, exactly as the unscaled 2-D form.
  * Fraction 0 is the tap set { 0, 0, 0, 128, ... }: (128 s + 64) >> 7 = s.
  */
-static int vp9_tap8s(int filter, int m, const uint8_t *s, ptrdiff_t step)
+static int vp9_tap8s(int bd, int filter, int m, const uint8_t *s, ptrdiff_t i, ptrdiff_t step)
 {
-    return m ? vp9_tap8(filter, m, s, step) : s[0];
+    return m ? vp9_tap8(bd, filter, m, s, i, step) : pget(s, i, bd);
 }
 
-void ffo_vp9_smc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
-                 int mx, int my, int dx, int dy)
+void ffo_vp9_smc_bd(int bd, int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width,
+                    int height, int mx, int my, int dx, int dy)
 {
-    static uint8_t tmp[135 * 64];
+    static uint16_t tmp16[135 * 64];
+    static uint8_t tmp8[135 * 64];
+    uint8_t *tmp = bd > 8 ? (uint8_t *)tmp16 : tmp8;
     const int bil = filter == 3, before = bil ? 0 : 3;
     const int rows = (((height - 1) * dy + my) >> 4) + (bil ? 2 : 8);
+    srcstride = spx(srcstride, bd);
+    dststride = spx(dststride, bd);
     for (int r = 0; r < rows; r++)
         for (int x = 0; x < width; x++) {
             const int pos = mx + x * dx;
-            const uint8_t *s = src + (r - before) * srcstride + (pos >> 4);
-            tmp[r * 64 + x] = bil ? vp9_bilin(pos & 15, s, 1) : vp9_tap8s(filter, pos & 15, s, 1);
+            const ptrdiff_t at = (r - before) * srcstride + (pos >> 4);
+            pput(tmp, r * 64 + x, bil ? vp9_bilin(bd, pos & 15, src, at, 1) : vp9_tap8s(bd, filter, pos & 15, src, at, 1), bd);
         }
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
             const int pos = my + y * dy;
-            const uint8_t *t = tmp + ((pos >> 4) + before) * 64 + x;
-            const int v = bil ? vp9_bilin(pos & 15, t, 64) : vp9_tap8s(filter, pos & 15, t, 64);
-            dst[y * dststride + x] = avg ? (dst[y * dststride + x] + v + 1) >> 1 : v;
+            const ptrdiff_t at = ((pos >> 4) + before) * 64 + x;
+            const int v = bil ? vp9_bilin(bd, pos & 15, tmp, at, 64) : vp9_tap8s(bd, filter, pos & 15, tmp, at, 64);
+            pput(dst, y * dststride + x, avg ? (pget(dst, y * dststride + x, bd) + v + 1) >> 1 : v, bd);
         }
+}
+void ffo_vp9_smc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
+                 int mx, int my, int dx, int dy)
+{
+    ffo_vp9_smc_bd(8, filter, avg, dst, dststride, src, srcstride, width, height, mx, my, dx, dy);
 }

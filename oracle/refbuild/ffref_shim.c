@@ -365,75 +365,60 @@ void ffref_hevc_sao_edge(int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t st
     dsp_init();
     hevc.sao_edge_filter[idx](dst, src, stride_dst, offset_val, eo, width, height);
 }
-/* ---- vp9dsp: itxfm_add[tx][txtp] (8 bits) ---- */
+/* ---- vp9dsp (ff_vp9dsp_init(dsp, bpp, bitexact)): one context per depth, the ffref_vp9_* calls run at the selected one; above
+ * 8 bits pixels are uint16_t and itxfm_add's block points at int32 coefficients ---- */
+static int vp9_bd = 8;
+static VP9DSPContext *vp9_ctx(void)
+{
+    static VP9DSPContext ctx[3];
+    static int ready[3];
+    const int i = vp9_bd == 8 ? 0 : vp9_bd == 10 ? 1 : 2;
+    pure_c();
+    if (!ready[i]) {
+        ff_vp9dsp_init(&ctx[i], vp9_bd, 1);
+        ready[i] = 1;
+    }
+    return &ctx[i];
+}
+void ffref_vp9_set_bit_depth(int bit_depth) { vp9_bd = bit_depth; }
 void ffref_vp9_itxfm_add(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob)
 {
-    static VP9DSPContext vp9;
-    static int vp9_ready;
-    pure_c();
-    if (!vp9_ready) {
-        ff_vp9dsp_init(&vp9, 8, 1);
-        vp9_ready = 1;
-    }
-    vp9.itxfm_add[tx][txtp](dst, stride, block, eob);
+    VP9DSPContext *const v9 = vp9_ctx();
+    v9->itxfm_add[tx][txtp](dst, stride, block, eob);
 }
 void ffref_vp9_mc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
                   int mx, int my)
 {
-    static VP9DSPContext vp9;
-    static int vp9_ready;
     int idx = 0;
-    pure_c();
-    if (!vp9_ready) {
-        ff_vp9dsp_init(&vp9, 8, 1);
-        vp9_ready = 1;
-    }
+    VP9DSPContext *const v9 = vp9_ctx();
     while ((64 >> idx) > width)
         idx++;
-    vp9.mc[idx][filter][avg][!!mx][!!my](dst, dststride, src, srcstride, height, mx, my);
+    v9->mc[idx][filter][avg][!!mx][!!my](dst, dststride, src, srcstride, height, mx, my);
 }
 /* which 0: loop_filter_8[a][dir], 1: loop_filter_16[dir], 2: loop_filter_mix2[a][b][dir] */
 void ffref_vp9_loop_filter(int which, int a, int b, int dir, uint8_t *dst, ptrdiff_t stride, int E, int I, int H)
 {
-    static VP9DSPContext vp9;
-    static int vp9_ready;
-    pure_c();
-    if (!vp9_ready) {
-        ff_vp9dsp_init(&vp9, 8, 1);
-        vp9_ready = 1;
-    }
+    VP9DSPContext *const v9 = vp9_ctx();
     if (which == 0)
-        vp9.loop_filter_8[a][dir](dst, stride, E, I, H);
+        v9->loop_filter_8[a][dir](dst, stride, E, I, H);
     else if (which == 1)
-        vp9.loop_filter_16[dir](dst, stride, E, I, H);
+        v9->loop_filter_16[dir](dst, stride, E, I, H);
     else
-        vp9.loop_filter_mix2[a][b][dir](dst, stride, E, I, H);
+        v9->loop_filter_mix2[a][b][dir](dst, stride, E, I, H);
 }
 void ffref_vp9_intra_pred(int tx, int mode, uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
 {
-    static VP9DSPContext vp9;
-    static int vp9_ready;
-    pure_c();
-    if (!vp9_ready) {
-        ff_vp9dsp_init(&vp9, 8, 1);
-        vp9_ready = 1;
-    }
-    vp9.intra_pred[tx][mode](dst, stride, left, top);
+    VP9DSPContext *const v9 = vp9_ctx();
+    v9->intra_pred[tx][mode](dst, stride, left, top);
 }
 void ffref_vp9_smc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width, int height,
                    int mx, int my, int dx, int dy)
 {
-    static VP9DSPContext vp9;
-    static int vp9_ready;
     int idx = 0;
-    pure_c();
-    if (!vp9_ready) {
-        ff_vp9dsp_init(&vp9, 8, 1);
-        vp9_ready = 1;
-    }
+    VP9DSPContext *const v9 = vp9_ctx();
     while ((64 >> idx) > width)
         idx++;
-    vp9.smc[idx][filter][avg](dst, dststride, src, srcstride, height, mx, my, dx, dy);
+    v9->smc[idx][filter][avg](dst, dststride, src, srcstride, height, mx, my, dx, dy);
 }
 void ffref_hevc_dequant(int16_t *coeffs, int log2_size)
 {

@@ -170,3 +170,152 @@ def test_hevc_mc_hbd(depth):
                         R.ffref_hevc_mc_w(chroma, mode, ptr(a), 160, sp, 192, ptr(src2, i16p), h, d, wx0, wx1, ox, mx, my, w)
                         O.ffo_hevc_mc_w_bd(depth, chroma, mode, ptr(b), 160, sp, 192, ptr(src2, i16p), h, d, wx0, wx1, ox, mx, my, w)
                         assert np.array_equal(a, b), (chroma, mode, w, mx, my, d, wx0, wx1, ox)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# vp9dsp above 8 bits (ff_vp9dsp_init(dsp, 10 / 12, bitexact): vp9dsp_10bpp.c / vp9dsp_12bpp.c instantiate vp9dsp_template.c;
+# pixels uint16_t, itxfm_add's block holds int32 coefficients, dctint = int64_t)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def vdepth(request):
+    R = ffi.ref()
+    R.ffref_vp9_set_bit_depth(request.param)
+    yield request.param
+    R.ffref_vp9_set_bit_depth(8)
+
+
+def vp9_block32(rng, n, kind, bd):
+    """int32 coefficient blocks: the range a bd-bit stream can produce is about 2^(bd + 8); sparse, dense, dc-only, extreme"""
+    lim = 1 << (bd + 7)
+    blk = np.zeros(n * n, np.int32)
+    if kind == 0:
+        blk[:] = rng.integers(-lim // 32, lim // 32 + 1, n * n)
+    elif kind == 1:
+        blk[:] = rng.integers(-lim // 64, lim // 64 + 1, n * n) * (rng.random(n * n) < .2)
+    elif kind == 2:
+        blk[0] = rng.integers(-lim // 8, lim // 8 + 1)
+    elif kind == 3:
+        blk[:] = rng.integers(-lim // 4, lim // 4 + 1, n * n) * (rng.random(n * n) < .05)
+    else:
+        blk[:] = rng.integers(-lim, lim, n * n)
+    return blk
+
+
+@pytest.mark.parametrize("vdepth", DEPTHS, indirect=True)
+def test_vp9_itxfm_add_hbd(vdepth):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(950 + vdepth)
+    for tx in range(5):
+        n = 4 if tx == 4 else 4 << tx
+        for txtp in range(4):
+            for rep in range(30):
+                kind = rep % 5
+                blk = vp9_block32(rng, n, kind, vdepth)
+                eob = 1 if kind == 2 else int(rng.integers(2, n * n + 1))
+                dst0 = pix(rng, (n, n + 5), vdepth, rep % 2 == 0)
+                a, b, ba, bb = dst0.copy(), dst0.copy(), blk.copy(), blk.copy()
+                R.ffref_vp9_itxfm_add(tx, txtp, ptr(a), 2 * (n + 5), C.cast(ba.ctypes.data, i16p), eob)
+                O.ffo_vp9_itxfm_add_bd(vdepth, tx, txtp, ptr(b), 2 * (n + 5), ptr(bb, i32p), eob)
+                assert np.array_equal(a, b) and np.array_equal(ba, bb), (tx, txtp, rep)
+
+
+@pytest.mark.parametrize("vdepth", DEPTHS, indirect=True)
+def test_vp9_mc_hbd(vdepth):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(960 + vdepth)
+    src = pix(rng, (150, 170), vdepth, extremes=False)
+    src[:40] = rng.choice(np.array([0, (1 << vdepth) - 1], np.uint16), (40, 170))
+    for rep in range(1500):
+        f, avg = int(rng.integers(0, 4)), rep & 1
+        w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([1, 2, 4, 8, 16, 33, 64]))
+        mx, my = (int(v) for v in rng.integers(0, 16, 2))
+        if rep % 5 == 0:
+            mx = 0
+        if rep % 7 == 0:
+            my = 0
+        y0, x0 = int(rng.integers(4, 150 - h - 5)), int(rng.integers(4, 170 - w - 5))
+        sp = at(src, y0, x0)
+        d0 = pix(rng, (64, 72), vdepth)
+        a, b = d0.copy(), d0.copy()
+        R.ffref_vp9_mc(f, avg, ptr(a), 144, sp, 340, w, h, mx, my)
+        O.ffo_vp9_mc_bd(vdepth, f, avg, ptr(b), 144, sp, 340, w, h, mx, my)
+        assert np.array_equal(a, b), (f, avg, w, h, mx, my)
+    for rep in range(300):                               # scaled: steps 1..32 sixteenths (16x up to 2x down)
+        f, avg = int(rng.integers(0, 4)), rep & 1
+        w = int(rng.choice([4, 8, 16, 32, 64])); h = int(rng.choice([2, 4, 8, 16, 33, 64]))
+        mx, my = (int(v) for v in rng.integers(0, 16, 2))
+        dx, dy = (int(v) for v in rng.integers(1, 33, 2))
+        sp = at(src, 4, 4)
+        d0 = pix(rng, (64, 72), vdepth)
+        a, b = d0.copy(), d0.copy()
+        R.ffref_vp9_smc(f, avg, ptr(a), 144, sp, 340, w, h, mx, my, dx, dy)
+        O.ffo_vp9_smc_bd(vdepth, f, avg, ptr(b), 144, sp, 340, w, h, mx, my, dx, dy)
+        assert np.array_equal(a, b), ("scaled", f, avg, w, h, mx, my, dx, dy)
+
+
+def vp9_lf_plane16(rng, bd, n=48):
+    sc = 1 << (bd - 8)
+    kind = int(rng.integers(0, 5))
+    a, b = int(rng.integers(0, 256)) * sc, int(rng.integers(0, 256)) * sc
+    if kind < 3:
+        b = int(np.clip(a + rng.integers(-6 * sc, 6 * sc + 1), 0, (1 << bd) - 1))
+    p = np.empty((n, n), np.int64)
+    p[:, :n // 2] = a
+    p[:, n // 2:] = b
+    p = p.T.copy() if rng.random() < .5 else p
+    noise = [0, 1, sc, 3 * sc, 40 * sc][kind]
+    p = p + rng.integers(-noise, noise + 1, (n, n))
+    return np.clip(p, 0, (1 << bd) - 1).astype(np.uint16)
+
+
+@pytest.mark.parametrize("vdepth", DEPTHS, indirect=True)
+def test_vp9_loop_filter_hbd(vdepth):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(970 + vdepth)
+    WD = [4, 8, 16]
+    for rep in range(2400):
+        pl = vp9_lf_plane16(rng, vdepth)
+        E, I, H = int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16))
+        if rep % 3 == 0:
+            E, I = 255, 63
+        a, b = pl.copy(), pl.copy()
+        dirn = rep & 1
+        which = rep % 3
+        seg2 = 8 * (48 if not dirn else 1)
+        if which == 0:
+            w = int(rng.integers(0, 3))
+            R.ffref_vp9_loop_filter(0, w, 0, dirn, at(a, 24, 24), 96, E, I, H)
+            O.ffo_vp9_loop_filter_bd(vdepth, WD[w], dirn, at(b, 24, 24), 96, E, I, H)
+        elif which == 1:
+            R.ffref_vp9_loop_filter(1, 0, 0, dirn, at(a, 24, 24), 96, E, I, H)
+            O.ffo_vp9_loop_filter_bd(vdepth, 16, dirn, at(b, 24, 24), 96, E, I, H)
+            O.ffo_vp9_loop_filter_bd(vdepth, 16, dirn, C.cast(b.ctypes.data + 2 * (24 * 48 + 24 + seg2), u8p), 96, E, I, H)
+        else:
+            w1, w2 = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            E2, I2, H2 = int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16))
+            R.ffref_vp9_loop_filter(2, w1, w2, dirn, at(a, 24, 24), 96, E | E2 << 8, I | I2 << 8, H | H2 << 8)
+            O.ffo_vp9_loop_filter_bd(vdepth, WD[w1], dirn, at(b, 24, 24), 96, E, I, H)
+            O.ffo_vp9_loop_filter_bd(vdepth, WD[w2], dirn, C.cast(b.ctypes.data + 2 * (24 * 48 + 24 + seg2), u8p), 96, E2, I2, H2)
+        assert np.array_equal(a, b), (rep, which, dirn, E, I, H)
+
+
+@pytest.mark.parametrize("vdepth", DEPTHS, indirect=True)
+def test_vp9_intra_pred_hbd(vdepth):
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(980 + vdepth)
+    mx = (1 << vdepth) - 1
+    for tx in range(4):
+        n = 4 << tx
+        for mode in range(15):
+            for rep in range(8):
+                left = rng.integers(0, mx + 1, n + 16).astype(np.uint16)
+                topbuf = rng.integers(0, mx + 1, 16 + 2 * n + 32).astype(np.uint16)
+                if rep % 3 == 0:
+                    left[:] = rng.choice(np.array([0, mx], np.uint16), left.size)
+                    topbuf[:] = rng.choice(np.array([0, mx], np.uint16), topbuf.size)
+                tp = C.cast(topbuf.ctypes.data + 32, u8p)
+                a = pix(rng, (n, n + 3), vdepth)
+                b = a.copy()
+                R.ffref_vp9_intra_pred(tx, mode, ptr(a), 2 * (n + 3), ptr(left), tp)
+                O.ffo_vp9_intra_pred_bd(vdepth, tx, mode, ptr(b), 2 * (n + 3), ptr(left), tp)
+                assert np.array_equal(a, b), (tx, mode, rep)
