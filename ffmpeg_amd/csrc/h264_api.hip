@@ -318,6 +318,56 @@ extern "C" int ffhip_hevc_mc_w_batch_dev_hbd(int bit_depth, int chroma, int mode
     return ffhip_launch_hevc_mc_bd(bit_depth, chroma, mode, dst, dststride, src, srcstride, src2, blocks, n, (hipStream_t)stream);
 }
 
+/* ---- vp9dsp above 8 bits: the same batch faces at the depth ff_vp9dsp_init(dsp, bpp, ...) instantiates its template for ------- */
+extern "C" int ffhip_vp9_itxfm_add_batch_dev_hbd(int bit_depth, int tx, void *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipVp9TU *tus, int n,
+                                                 void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !coeffs || !dst || !tus || n < 0 || tx < 0 || tx > 4)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_itxfm_bd(bit_depth, tx, coeffs, dst, stride, tus, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_vp9_mc_batch_dev_hbd(int bit_depth, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                          const FFHipVp9McBlock *blocks, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_mc_bd(bit_depth, dst, dststride, src, srcstride, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_vp9_scaled_mc_batch_dev_hbd(int bit_depth, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                                 const FFHipVp9ScaledBlock *blocks, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_smc_bd(bit_depth, dst, dststride, src, srcstride, blocks, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_vp9_loop_filter_batch_dev_hbd(int bit_depth, uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !base || !edges || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_loop_filter_bd(bit_depth, base, stride, edges, n, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_vp9_intra_pred_batch_dev_hbd(int bit_depth, int tx, uint8_t *dst, ptrdiff_t stride, const uint8_t *edges,
+                                                  const FFHipVp9Intra *blocks, int n, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !dst || !edges || !blocks || n < 0 || tx < 0 || tx > 3)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_intra_bd(bit_depth, tx, dst, stride, edges, blocks, n, (hipStream_t)stream);
+}
+
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */
 extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1,
                                     size_t pitch1, const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream)

@@ -1,5 +1,5 @@
 /*
- * vp9_lf.hip — VP9 loop filter, 8 bits, batched: loop_filter() of libavcodec/vp9dsp_template.c:1780-1889,
+ * vp9_lf.hip — VP9 loop filter, 8 / 10 / 12 bits, batched: loop_filter() of libavcodec/vp9dsp_template.c:1780-1889,
  * the body of loop_filter_8[wd][dir], loop_filter_16[dir] and loop_filter_mix2[wd1][wd2][dir] (:1891-1966).
  * A record is one 8-sample segment of an edge; 8 lanes per segment, one per sample line; every read of a line happens before
  * any write of it.  The flat filters are evaluated as windows: radius 3 over p3..q3 (radius 7 over p7..q7) around the sample with
@@ -12,18 +12,22 @@
 static_assert(sizeof(FFHipVp9Edge) == 12, "FFHipVp9Edge is a 12-byte record");
 
 __device__ __forceinline__ int vl_abs(int v) { return v < 0 ? -v : v; }
-__device__ __forceinline__ int vl_clip8(int v) { return min(max(v, -128), 127); }
 
-__global__ __launch_bounds__(256) void k_vp9_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n)
+/* PIX = uint8_t (bd 8) / uint16_t; E, I, H arrive in 8-bit units and are scaled by << (bd - 8), the flatness threshold is
+ * 1 << (bd - 8), the filter value clips to bd - 1 signed bits (vp9dsp_template.c:1784-1788,1866-1878); stride and offsets in bytes */
+template <typename PIX>
+__global__ __launch_bounds__(256) void k_vp9_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, int bd)
 {
     const int e = (blockIdx.x * 256 + threadIdx.x) >> 3, line = threadIdx.x & 7;
     if (e >= n)
         return;
     const FFHipVp9Edge ed = edges[e];
     const int wd = ed.wd_idx == 0 ? 4 : ed.wd_idx == 1 ? 8 : 16;
-    const ptrdiff_t along = ed.dir ? 1 : stride, across = ed.dir ? stride : 1;
-    uint8_t *pix = base + ed.offset + line * along;
-    const int E = ed.E, I = ed.I, H = ed.H;
+    const ptrdiff_t st = stride / (ptrdiff_t)sizeof(PIX), along = ed.dir ? 1 : st, across = ed.dir ? st : 1;
+    PIX *pix = reinterpret_cast<PIX *>(base + ed.offset) + line * along;
+    const int sh = bd - 8, E = ed.E << sh, I = ed.I << sh, H = ed.H << sh, F = 1 << sh, fmax = (1 << (bd - 1)) - 1, maxv = (1 << bd) - 1;
+    auto clipf = [&](int v) { return min(max(v, -fmax - 1), fmax); };
+    auto clipp = [&](int v) { return min(max(v, 0), maxv); };
     int px[16]; /* p7 .. p0, q0 .. q7 */
 #pragma unroll
     for (int k = 0; k < 16; k++)
@@ -35,10 +39,10 @@ __global__ __launch_bounds__(256) void k_vp9_loop_filter(uint8_t *base, ptrdiff_
     bool flat_in = wd >= 8, flat_out = wd >= 16;
 #pragma unroll
     for (int k = 1; k <= 3; k++)
-        flat_in = flat_in && vl_abs(px[7 - k] - p0) <= 1 && vl_abs(px[8 + k] - q0) <= 1;
+        flat_in = flat_in && vl_abs(px[7 - k] - p0) <= F && vl_abs(px[8 + k] - q0) <= F;
 #pragma unroll
     for (int k = 4; k <= 7; k++)
-        flat_out = flat_out && vl_abs(px[7 - k] - p0) <= 1 && vl_abs(px[8 + k] - q0) <= 1;
+        flat_out = flat_out && vl_abs(px[7 - k] - p0) <= F && vl_abs(px[8 + k] - q0) <= F;
     if (flat_out && flat_in) {
         /* window sums of radius 7 with clamped ends: s(c+1) = s(c) + px[min(c+8, 15)] - px[max(c-7, 0)] */
         int s = 8 * px[0];
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void k_vp9_loop_filter(uint8_t *base, ptrdiff_
         s -= px[0];
 #pragma unroll
         for (int c = 1; c <= 14; c++) {
-            pix[(c - 8) * across] = (uint8_t)((s + px[c] + 8) >> 4);
+            pix[(c - 8) * across] = (PIX)((s + px[c] + 8) >> 4);
             s += px[c + 8 > 15 ? 15 : c + 8] - px[c - 7 < 0 ? 0 : c - 7];
         }
     } else if (flat_in) {
@@ -56,28 +60,40 @@ __global__ __launch_bounds__(256) void k_vp9_loop_filter(uint8_t *base, ptrdiff_
         int s = 3 * px[4] + px[5] + px[6] + px[7] + px[8]; /* window of c = 5: indices 2..8 clamped to 4..11 */
 #pragma unroll
         for (int c = 5; c <= 10; c++) {
-            pix[(c - 8) * across] = (uint8_t)((s + px[c] + 4) >> 3);
+            pix[(c - 8) * across] = (PIX)((s + px[c] + 4) >> 3);
             s += px[c + 4 > 11 ? 11 : c + 4] - px[c - 3 < 4 ? 4 : c - 3];
         }
     } else {
         const bool hev = vl_abs(p1 - p0) > H || vl_abs(q1 - q0) > H;
-        int f = vl_clip8(3 * (q0 - p0) + (hev ? vl_clip8(p1 - q1) : 0));
-        const int f1 = min(f + 4, 127) >> 3, f2 = min(f + 3, 127) >> 3;
-        pix[-across] = (uint8_t)clip_u8(p0 + f2);
-        pix[0] = (uint8_t)clip_u8(q0 - f1);
+        int f = clipf(3 * (q0 - p0) + (hev ? clipf(p1 - q1) : 0));
+        const int f1 = min(f + 4, fmax) >> 3, f2 = min(f + 3, fmax) >> 3;
+        pix[-across] = (PIX)clipp(p0 + f2);
+        pix[0] = (PIX)clipp(q0 - f1);
         if (!hev) {
             f = (f1 + 1) >> 1;
-            pix[-2 * across] = (uint8_t)clip_u8(p1 + f);
-            pix[across] = (uint8_t)clip_u8(q1 - f);
+            pix[-2 * across] = (PIX)clipp(p1 + f);
+            pix[across] = (PIX)clipp(q1 - f);
         }
     }
 }
 
 int ffhip_launch_vp9_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, hipStream_t stream)
 {
+    return ffhip_launch_vp9_loop_filter_bd(8, base, stride, edges, n, stream);
+}
+
+int ffhip_launch_vp9_loop_filter_bd(int bd, uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, hipStream_t stream)
+{
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(k_vp9_loop_filter, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n);
+    if (bd == 8)
+        hipLaunchKernelGGL(k_vp9_loop_filter<uint8_t>, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n, 8);
+    else if ((bd == 10 || bd == 12) && !(((uintptr_t)base | (size_t)stride) & 1))
+        hipLaunchKernelGGL(k_vp9_loop_filter<uint16_t>, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n, bd);
+    else {
+        ffhip_set_error("ffhip_vp9_loop_filter: bit depth %d (8, 10, 12) / 16-bit planes must be 2-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
     LAUNCH_CHECK();
     return 0;
 }

@@ -307,52 +307,96 @@ __constant__ int8_t vp9_t8[48][8] = {
  */
 static_assert(sizeof(FFHipVp9ScaledBlock) == 16, "FFHipVp9ScaledBlock is a 16-byte record");
 
-__global__ __launch_bounds__(256) void k_vp9_smc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
-                                                 const FFHipVp9ScaledBlock *blocks, int n)
+/* PIX = uint8_t / uint16_t (temporaries are samples of that depth, clipped to (1 << bd) - 1); WPB waves (blocks) per workgroup: the
+ * 135-row temporaries of 16-bit samples do not fit four to an LDS allocation.  UNSCALED: records are FFHipVp9McBlock (dx = dy = 16) —
+ * the plain mc[][][][][] table above 8 bits runs here too: at a step of 16 the scaled form IS the unscaled one (a zero fraction's tap
+ * set is the identity), with one difference that matters to a decoder: no margin row / column is read on an axis whose fraction is 0. */
+template <typename PIX, int WPB, bool UNSCALED>
+__global__ __launch_bounds__(64 * WPB) void k_vp9_smc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                                      const FFHipVp9ScaledBlock *blocks, int n, int bd)
 {
-    __shared__ uint8_t tmp_all[4][135 * 64];
+    __shared__ PIX tmp_all[WPB][135 * 64];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
+    const int b = blockIdx.x * WPB + wave;
     if (b >= n)
         return;
     const FFHipVp9ScaledBlock k = blocks[b];
-    const int w = k.width, h = k.height, filter = k.filter & 3, mx = k.mx & 15, my = k.my & 15, dx = k.dx, dy = k.dy;
+    const int w = k.width, h = k.height, filter = k.filter & 3, mx = k.mx & 15, my = k.my & 15, dx = UNSCALED ? 16 : k.dx, dy = UNSCALED ? 16 : k.dy;
     const bool avg = k.avg != 0, bil = filter == 3;
-    const int before = bil ? 0 : 3, rows = (((h - 1) * dy + my) >> 4) + (bil ? 2 : 8);
-    const uint8_t *s = src + k.src_offset;
-    uint8_t *d0 = dst + k.dst_offset, *tmp = tmp_all[wave];
+    const int maxv = (1 << bd) - 1;
+    const bool flat_v = UNSCALED && my == 0; /* the vertical pass is the identity: rows 0 .. h - 1 only */
+    const int before = (bil || flat_v) ? 0 : 3, rows = flat_v ? h : (((h - 1) * dy + my) >> 4) + (bil ? 2 : 8);
+    const ptrdiff_t sst = srcstride / (ptrdiff_t)sizeof(PIX);
+    const PIX *s = reinterpret_cast<const PIX *>(src + k.src_offset);
+    PIX *tmp = tmp_all[wave];
     const int lgw = __builtin_ctz(w);
-    auto tap = [&](int m, const uint8_t *p, ptrdiff_t step) {
-        if (bil)
-            return (int)p[0] + ((m * ((int)p[step] - (int)p[0]) + 8) >> 4);
+    auto tap = [&](int m, const PIX *p, ptrdiff_t step) {
         if (!m)
             return (int)p[0];
+        if (bil)
+            return (int)p[0] + ((m * ((int)p[step] - (int)p[0]) + 8) >> 4);
         const int8_t *f = vp9_t8[filter * 16 + m];
         int sum = 64;
 #pragma unroll
         for (int t = 0; t < 8; t++)
             sum += f[t] * p[(t - 3) * step];
-        return clip_u8(sum >> 7);
+        return min(max(sum >> 7, 0), maxv);
     };
     for (int i = lane; i < rows * w; i += 64) {
         const int r = i >> lgw, x = i & (w - 1), pos = mx + x * dx;
-        tmp[r * 64 + x] = (uint8_t)tap(pos & 15, s + (ptrdiff_t)(r - before) * srcstride + (pos >> 4), 1);
+        tmp[r * 64 + x] = (PIX)tap(pos & 15, s + (ptrdiff_t)(r - before) * sst + (pos >> 4), 1);
     }
     vm_wave_sync();
     for (int i = lane; i < h * w; i += 64) {
         const int y = i >> lgw, x = i & (w - 1), pos = my + y * dy;
         const int v = tap(pos & 15, tmp + ((pos >> 4) + before) * 64 + x, 64);
-        uint8_t *d = d0 + (ptrdiff_t)y * dststride + x;
-        *d = (uint8_t)(avg ? (*d + v + 1) >> 1 : v);
+        PIX *d = reinterpret_cast<PIX *>(dst + k.dst_offset + (ptrdiff_t)y * dststride) + x;
+        *d = (PIX)(avg ? (*d + v + 1) >> 1 : v);
     }
 }
 
 int ffhip_launch_vp9_smc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9ScaledBlock *blocks, int n,
                          hipStream_t stream)
 {
+    return ffhip_launch_vp9_smc_bd(8, dst, dststride, src, srcstride, blocks, n, stream);
+}
+
+static bool vp9_hbd_ok(int bd, const void *a, const void *b, ptrdiff_t sa, ptrdiff_t sb)
+{
+    return (bd == 10 || bd == 12) && !(((uintptr_t)a | (uintptr_t)b | (size_t)sa | (size_t)sb) & 1);
+}
+
+int ffhip_launch_vp9_smc_bd(int bd, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9ScaledBlock *blocks,
+                            int n, hipStream_t stream)
+{
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(k_vp9_smc, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
+    if (bd == 8)
+        hipLaunchKernelGGL((k_vp9_smc<uint8_t, 4, false>), dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n, 8);
+    else if (vp9_hbd_ok(bd, dst, src, dststride, srcstride))
+        hipLaunchKernelGGL((k_vp9_smc<uint16_t, 2, false>), dim3(cdiv(n, 2)), dim3(128), 0, stream, dst, dststride, src, srcstride, blocks, n, bd);
+    else {
+        ffhip_set_error("ffhip_vp9_scaled_mc: bit depth %d (8, 10, 12) / 16-bit planes must be 2-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int ffhip_launch_vp9_mc_bd(int bd, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9McBlock *blocks, int n,
+                           hipStream_t stream)
+{
+    if (bd == 8)
+        return ffhip_launch_vp9_mc(dst, dststride, src, srcstride, blocks, n, stream);
+    if (n <= 0)
+        return 0;
+    if (!vp9_hbd_ok(bd, dst, src, dststride, srcstride)) {
+        ffhip_set_error("ffhip_vp9_mc: bit depth %d (8, 10, 12) / 16-bit planes must be 2-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
+    static_assert(sizeof(FFHipVp9McBlock) == sizeof(FFHipVp9ScaledBlock), "the two records share their layout up to `avg`");
+    hipLaunchKernelGGL((k_vp9_smc<uint16_t, 2, true>), dim3(cdiv(n, 2)), dim3(128), 0, stream, dst, dststride, src, srcstride,
+                       reinterpret_cast<const FFHipVp9ScaledBlock *>(blocks), n, bd);
     LAUNCH_CHECK();
     return 0;
 }

@@ -12,8 +12,15 @@ DCT_DCT, DCT_ADST, ADST_DCT, ADST_ADST = 0, 1, 2, 3
 TX_4X4, TX_8X8, TX_16X16, TX_32X32, TX_WHT = 0, 1, 2, 3, 4
 
 
-def itxfm_add_batch(tx, coeffs, dst, stride, tus, n, stream=None):
-    """coeffs: int16 device tensor (consumed); dst: uint8 device tensor; tus: uint8 [n, 12] FFHipVp9TU"""
+def _st(stream):
+    return None if stream is None else C.c_void_p(stream)
+
+
+def itxfm_add_batch(tx, coeffs, dst, stride, tus, n, stream=None, bit_depth=8):
+    """coeffs: int16 (bit_depth 8) / int32 (10, 12) device tensor (consumed); dst: device tensor of samples; tus: uint8 [n, 12] FFHipVp9TU"""
+    if bit_depth != 8:
+        return _lib.check(_lib.lib().ffhip_vp9_itxfm_add_batch_dev_hbd(bit_depth, tx, coeffs.data_ptr(), dst.data_ptr(), stride, tus.data_ptr(),
+                                                                       n, _st(stream)), "ffhip_vp9_itxfm_add_batch_dev_hbd")
     return _lib.check(_lib.lib().ffhip_vp9_itxfm_add_batch_dev(tx, coeffs.data_ptr(), dst.data_ptr(), stride, tus.data_ptr(), n,
                                                                None if stream is None else C.c_void_p(stream)),
                       "ffhip_vp9_itxfm_add_batch_dev")
@@ -36,8 +43,11 @@ MC_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("width
 FILTER_SMOOTH, FILTER_REGULAR, FILTER_SHARP, FILTER_BILINEAR = 0, 1, 2, 3
 
 
-def mc_batch(dst, dststride, src, srcstride, blocks, n, stream=None):
+def mc_batch(dst, dststride, src, srcstride, blocks, n, stream=None, bit_depth=8):
     """blocks: uint8 [n, 16] FFHipVp9McBlock records"""
+    if bit_depth != 8:
+        return _lib.check(_lib.lib().ffhip_vp9_mc_batch_dev_hbd(bit_depth, dst.data_ptr(), dststride, src.data_ptr(), srcstride,
+                                                                blocks.data_ptr(), n, _st(stream)), "ffhip_vp9_mc_batch_dev_hbd")
     return _lib.check(_lib.lib().ffhip_vp9_mc_batch_dev(dst.data_ptr(), dststride, src.data_ptr(), srcstride, blocks.data_ptr(), n,
                                                         None if stream is None else C.c_void_p(stream)), "ffhip_vp9_mc_batch_dev")
 
@@ -58,8 +68,11 @@ EDGE_DTYPE = np.dtype([("offset", np.int32), ("wd_idx", np.uint8), ("dir", np.ui
                        ("pad", np.uint8, 3)])
 
 
-def loop_filter_batch(base, stride, edges, n, stream=None):
+def loop_filter_batch(base, stride, edges, n, stream=None, bit_depth=8):
     """edges: uint8 [n, 12] FFHipVp9Edge records (8-sample segments that share no sample)"""
+    if bit_depth != 8:
+        return _lib.check(_lib.lib().ffhip_vp9_loop_filter_batch_dev_hbd(bit_depth, base.data_ptr(), stride, edges.data_ptr(), n, _st(stream)),
+                          "ffhip_vp9_loop_filter_batch_dev_hbd")
     return _lib.check(_lib.lib().ffhip_vp9_loop_filter_batch_dev(base.data_ptr(), stride, edges.data_ptr(), n,
                                                                  None if stream is None else C.c_void_p(stream)),
                       "ffhip_vp9_loop_filter_batch_dev")
@@ -82,8 +95,11 @@ def lf_init(bpp=8):
 INTRA_DTYPE = np.dtype([("dst_offset", np.int32), ("edge_offset", np.int32), ("mode", np.uint8), ("pad", np.uint8, 3)])
 
 
-def intra_pred_batch(tx, dst, stride, edges, blocks, n, stream=None):
-    """edges: uint8 device tensor of edge lines (left[0..N-1], corner, top[0..max(N,8)-1] per block); blocks: uint8 [n, 12]"""
+def intra_pred_batch(tx, dst, stride, edges, blocks, n, stream=None, bit_depth=8):
+    """edges: device tensor of edge lines (left[0..N-1], corner, top[0..max(N,8)-1] per block; samples of the depth); blocks: uint8 [n, 12]"""
+    if bit_depth != 8:
+        return _lib.check(_lib.lib().ffhip_vp9_intra_pred_batch_dev_hbd(bit_depth, tx, dst.data_ptr(), stride, edges.data_ptr(),
+                                                                        blocks.data_ptr(), n, _st(stream)), "ffhip_vp9_intra_pred_batch_dev_hbd")
     return _lib.check(_lib.lib().ffhip_vp9_intra_pred_batch_dev(tx, dst.data_ptr(), stride, edges.data_ptr(), blocks.data_ptr(), n,
                                                                 None if stream is None else C.c_void_p(stream)),
                       "ffhip_vp9_intra_pred_batch_dev")
@@ -104,8 +120,11 @@ SMC_DTYPE = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("widt
                       ("mx", np.uint8), ("my", np.uint8), ("avg", np.uint8), ("dx", np.uint8), ("dy", np.uint8)])
 
 
-def scaled_mc_batch(dst, dststride, src, srcstride, blocks, n, stream=None):
+def scaled_mc_batch(dst, dststride, src, srcstride, blocks, n, stream=None, bit_depth=8):
     """blocks: uint8 [n, 16] FFHipVp9ScaledBlock records"""
+    if bit_depth != 8:
+        return _lib.check(_lib.lib().ffhip_vp9_scaled_mc_batch_dev_hbd(bit_depth, dst.data_ptr(), dststride, src.data_ptr(), srcstride,
+                                                                       blocks.data_ptr(), n, _st(stream)), "ffhip_vp9_scaled_mc_batch_dev_hbd")
     return _lib.check(_lib.lib().ffhip_vp9_scaled_mc_batch_dev(dst.data_ptr(), dststride, src.data_ptr(), srcstride, blocks.data_ptr(), n,
                                                                None if stream is None else C.c_void_p(stream)),
                       "ffhip_vp9_scaled_mc_batch_dev")

@@ -946,6 +946,25 @@ typedef struct FFHipVp9Intra {
 } FFHipVp9Intra;
 int ffhip_vp9_intra_pred_batch_dev(int tx, uint8_t *dst, ptrdiff_t stride, const uint8_t *edges, const FFHipVp9Intra *blocks, int n,
                                    void *stream);
+/**
+ * vp9dsp above 8 bits (profiles 2 / 3): the batch faces above at the bpp ff_vp9dsp_init(dsp, bpp, bitexact) instantiates its template
+ * for (libavcodec/vp9dsp.c:88-112, vp9dsp_10bpp.c / vp9dsp_12bpp.c).  bit_depth 8, 10 or 12.  Samples are uint16_t above 8 bits,
+ * itxfm_add's coefficients int32_t (the reference's dctcoef; FFHipVp9TU.coeff_offset counts coefficients) and its butterflies run
+ * in 64 bits (dctint = int64_t); record offsets and strides stay in BYTES; E / I / H of the loop filter are the 8-bit-unit values
+ * the decoder passes (scaled by << (bit_depth - 8) inside, vp9dsp_template.c:1784-1788); FFHipVp9Intra.edge_offset addresses an
+ * edge line of uint16_t samples.
+ */
+int ffhip_vp9_itxfm_add_batch_dev_hbd(int bit_depth, int tx, void *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipVp9TU *tus, int n,
+                                      void *stream);
+int ffhip_vp9_mc_batch_dev_hbd(int bit_depth, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                               const FFHipVp9McBlock *blocks, int n, void *stream);
+int ffhip_vp9_scaled_mc_batch_dev_hbd(int bit_depth, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                      const FFHipVp9ScaledBlock *blocks, int n, void *stream);
+int ffhip_vp9_loop_filter_batch_dev_hbd(int bit_depth, uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, void *stream);
+int ffhip_vp9_intra_pred_batch_dev_hbd(int bit_depth, int tx, uint8_t *dst, ptrdiff_t stride, const uint8_t *edges,
+                                       const FFHipVp9Intra *blocks, int n, void *stream);
+
+
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: me_cmp + full search                                                           */
