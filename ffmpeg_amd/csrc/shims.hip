@@ -834,116 +834,125 @@ extern "C" int ff_me_cmp_init_hip(FFHipMECmpContext *c)
     return 0;
 }
 
-/* ---- vp9dsp itxfm_add host faces: the block and the size x size picture rectangle travel through scratch ---- */
-static bool vp9_itxfm_single(int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob)
+/* ---- vp9dsp: every face per bit depth (8: uint8_t samples, int16 coefficients; 10 / 12: uint16_t, int32 — vp9dsp_10bpp.c /
+ * vp9dsp_12bpp.c), the depth baked into the function like the reference's instantiations.  ps = bytes per sample. ---- */
+#define VP9_FB(tab, BD) tab[hevc_bdi(BD)]
+
+/* itxfm_add: the block and the size x size picture rectangle travel through scratch */
+static bool vp9_itxfm_single(int bd, int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int16_t *block, int eob)
 {
-    const int n = tx == 4 ? 4 : 4 << tx, P = 64;
-    Arena A(64 + (size_t)n * n * 2 + (size_t)n * P + 64);
+    const int n = tx == 4 ? 4 : 4 << tx, ps = bd > 8 ? 2 : 1, P = 64 * ps;
+    const size_t cbytes = (size_t)n * n * (bd > 8 ? 4 : 2);
+    Arena A(64 + cbytes + (size_t)n * P + 64);
     if (!A.ok)
         return false;
     uint8_t *buf = A.buf;
-    int16_t *dco = (int16_t *)(buf + 64);
-    uint8_t *ddst = buf + 64 + (size_t)n * n * 2;
-    if (hipMemcpy(dco, block, (size_t)n * n * 2, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy2D(ddst, P, dst, stride, n, n, hipMemcpyHostToDevice) != hipSuccess)
+    uint8_t *dco = buf + 64;
+    uint8_t *ddst = buf + 64 + cbytes;
+    if (hipMemcpy(dco, block, cbytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy2D(ddst, P, dst, stride, (size_t)n * ps, n, hipMemcpyHostToDevice) != hipSuccess)
         return false;
     FFHipVp9TU k = {};
     k.txtp = (uint8_t)txtp; k.dc_only = eob == 1;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_vp9_itxfm(tx, dco, ddst, P, (const FFHipVp9TU *)buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_vp9_itxfm_bd(bd, tx, dco, ddst, P, (const FFHipVp9TU *)buf, 1, 0) < 0 || !A.down())
         return false;
-    memcpy(block, A.host(dco), (size_t)n * n * 2);
-    commit2d(A, dst, stride, ddst, P, n, n);
+    memcpy(block, A.host(dco), cbytes);
+    commit2d(A, dst, stride, ddst, P, (size_t)n * ps, n);
     return true;
 }
-static FFHipVP9ItxfmContext g_fb_vp9itx;
-#define VP9_SHIM(tx, tp) static void s_vp9_itx_##tx##_##tp(uint8_t *d, ptrdiff_t s, int16_t *b, int e) \
-    { if (!vp9_itxfm_single(tx, tp, d, s, b, e)) SHIM_FB(g_fb_vp9itx, itxfm_add[tx][tp], d, s, b, e); }
-#define VP9_SHIMS(tx) VP9_SHIM(tx, 0) VP9_SHIM(tx, 1) VP9_SHIM(tx, 2) VP9_SHIM(tx, 3)
-VP9_SHIMS(0) VP9_SHIMS(1) VP9_SHIMS(2) VP9_SHIMS(3) VP9_SHIMS(4)
+static FFHipVP9ItxfmContext g_fb_vp9itx[3];
+template <int BD, int TX, int TP>
+static void s_vp9_itx(uint8_t *d, ptrdiff_t s, int16_t *b, int e)
+{ if (!vp9_itxfm_single(BD, TX, TP, d, s, b, e)) SHIM_FB(VP9_FB(g_fb_vp9itx, BD), itxfm_add[TX][TP], d, s, b, e); }
+template <int BD>
+static void vp9_itx_fill(FFHipVP9ItxfmContext &o)
+{
+#define VP9_ROW(tx) o.itxfm_add[tx][0] = s_vp9_itx<BD, tx, 0>; o.itxfm_add[tx][1] = s_vp9_itx<BD, tx, 1>; \
+                    o.itxfm_add[tx][2] = s_vp9_itx<BD, tx, 2>; o.itxfm_add[tx][3] = s_vp9_itx<BD, tx, 3>;
+    VP9_ROW(0) VP9_ROW(1) VP9_ROW(2) VP9_ROW(3) VP9_ROW(4)
+#undef VP9_ROW
+}
+#define VP9_INIT_BODY(CTX, FILL, FB)                                          \
+    if (!c || (bpp != 8 && bpp != 10 && bpp != 12))                           \
+        return FFHIP_EINVAL;                                                  \
+    if (!ffhip_have_device())                                                 \
+        return FFHIP_ENOSYS;                                                  \
+    CTX o = *c;                                                               \
+    if (bpp == 8) FILL(8) else if (bpp == 10) FILL(10) else FILL(12)          \
+    fb_snapshot(FB[hevc_bdi(bpp)], *c, o);                                    \
+    *c = o;                                                                   \
+    return 0;
 
 extern "C" int ff_vp9dsp_itxfm_init_hip(FFHipVP9ItxfmContext *c, int bpp)
 {
-    if (!c || bpp != 8)
-        return FFHIP_EINVAL;
-    if (!ffhip_have_device())
-        return FFHIP_ENOSYS;
-    FFHipVP9ItxfmContext o = *c;
-#define VP9_ROW(tx) o.itxfm_add[tx][0] = s_vp9_itx_##tx##_0; o.itxfm_add[tx][1] = s_vp9_itx_##tx##_1; \
-                    o.itxfm_add[tx][2] = s_vp9_itx_##tx##_2; o.itxfm_add[tx][3] = s_vp9_itx_##tx##_3;
-    VP9_ROW(0) VP9_ROW(1) VP9_ROW(2) VP9_ROW(3) VP9_ROW(4)
-#undef VP9_ROW
-    fb_snapshot(g_fb_vp9itx, *c, o);
-    *c = o;
-    return 0;
+#define F_(B) vp9_itx_fill<B>(o);
+    VP9_INIT_BODY(FFHipVP9ItxfmContext, F_, g_fb_vp9itx)
+#undef F_
 }
 
-/* ---- vp9dsp mc host faces: source rows -3..h+4 x columns -3..w+4 at a pitch of 128, destination w x h at a pitch of 64 ---- */
-static bool vp9_mc_single(int width, int filter, int avg, uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my)
+/* mc: source rows -3..h+4 x columns -3..w+4 at a pitch of 128 samples, destination w x h at a pitch of 64 samples */
+static bool vp9_mc_single(int bd, int width, int filter, int avg, uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx,
+                          int my)
 {
     if (h <= 0 || h > 64)
         return false;
-    const int P = 128, before = 3, after = 4;
-    const size_t sbytes = (size_t)(h + before + after) * P, dbytes = (size_t)h * 64;
+    const int ps = bd > 8 ? 2 : 1, P = 128 * ps, DPX = 64 * ps, before = 3, after = 4;
+    const size_t sbytes = (size_t)(h + before + after) * P, dbytes = (size_t)h * DPX;
     Arena A(64 + sbytes + dbytes + 64);
     if (!A.ok)
         return false;
     uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + sbytes;
     /* only what the reference function of this slot reads: rows / columns beyond the block exist when that axis is filtered */
     const int ry0 = my ? -before : 0, ry1 = my ? h + after : h, cx0 = mx ? -before : 0, cx1 = mx ? width + after : width;
-    if (hipMemcpy2D(dsrc + (size_t)(ry0 + before) * P + before + cx0, P, src + ry0 * ss + cx0, ss, cx1 - cx0, ry1 - ry0,
-                    hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy2D(ddst, 64, dst, ds, width, h, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy2D(dsrc + (size_t)(ry0 + before) * P + (size_t)(before + cx0) * ps, P, src + ry0 * ss + cx0 * ps, ss, (size_t)(cx1 - cx0) * ps,
+                    ry1 - ry0, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy2D(ddst, DPX, dst, ds, (size_t)width * ps, h, hipMemcpyHostToDevice) != hipSuccess)
         return false;
     FFHipVp9McBlock k = {};
-    k.src_offset = before * P + before;
+    k.src_offset = before * P + before * ps;
     k.width = (uint8_t)width; k.height = (uint8_t)h; k.filter = (uint8_t)filter; k.mx = (uint8_t)mx; k.my = (uint8_t)my; k.avg = (uint8_t)avg;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_vp9_mc(ddst, 64, dsrc, P, (const FFHipVp9McBlock *)buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_vp9_mc_bd(bd, ddst, DPX, dsrc, P, (const FFHipVp9McBlock *)buf, 1, 0) < 0 || !A.down())
         return false;
-    commit2d(A, dst, ds, ddst, 64, width, h);
+    commit2d(A, dst, ds, ddst, DPX, (size_t)width * ps, h);
     return true;
 }
-static FFHipVP9McContext g_fb_vp9mc;
+static FFHipVP9McContext g_fb_vp9mc[3];
 /* the [!!mx][!!my] slots differ only in which fractions are non-zero: a slot's function masks the other one as the reference's
  * dedicated h / v functions ignore it */
-template <int W, int I, int F, int AVG, int HX, int VY>
+template <int BD, int W, int I, int F, int AVG, int HX, int VY>
 static void s_vp9_mc(uint8_t *d, ptrdiff_t ds, const uint8_t *s, ptrdiff_t ss, int h, int mx, int my)
 {
-    if (!vp9_mc_single(W, F, AVG, d, ds, s, ss, h, HX ? mx : 0, VY ? my : 0))
-        SHIM_FB(g_fb_vp9mc, mc[I][F][AVG][HX][VY], d, ds, s, ss, h, mx, my);
+    if (!vp9_mc_single(BD, W, F, AVG, d, ds, s, ss, h, HX ? mx : 0, VY ? my : 0))
+        SHIM_FB(VP9_FB(g_fb_vp9mc, BD), mc[I][F][AVG][HX][VY], d, ds, s, ss, h, mx, my);
 }
-template <int W, int I>
+template <int BD, int W, int I>
 static void vp9_mc_fill(FFHipVP9McContext *c)
 {
 #define VP9_MC_F(F) \
-    c->mc[I][F][0][0][0] = s_vp9_mc<W, I, F, 0, 0, 0>; c->mc[I][F][0][0][1] = s_vp9_mc<W, I, F, 0, 0, 1>; \
-    c->mc[I][F][0][1][0] = s_vp9_mc<W, I, F, 0, 1, 0>; c->mc[I][F][0][1][1] = s_vp9_mc<W, I, F, 0, 1, 1>; \
-    c->mc[I][F][1][0][0] = s_vp9_mc<W, I, F, 1, 0, 0>; c->mc[I][F][1][0][1] = s_vp9_mc<W, I, F, 1, 0, 1>; \
-    c->mc[I][F][1][1][0] = s_vp9_mc<W, I, F, 1, 1, 0>; c->mc[I][F][1][1][1] = s_vp9_mc<W, I, F, 1, 1, 1>;
+    c->mc[I][F][0][0][0] = s_vp9_mc<BD, W, I, F, 0, 0, 0>; c->mc[I][F][0][0][1] = s_vp9_mc<BD, W, I, F, 0, 0, 1>; \
+    c->mc[I][F][0][1][0] = s_vp9_mc<BD, W, I, F, 0, 1, 0>; c->mc[I][F][0][1][1] = s_vp9_mc<BD, W, I, F, 0, 1, 1>; \
+    c->mc[I][F][1][0][0] = s_vp9_mc<BD, W, I, F, 1, 0, 0>; c->mc[I][F][1][0][1] = s_vp9_mc<BD, W, I, F, 1, 0, 1>; \
+    c->mc[I][F][1][1][0] = s_vp9_mc<BD, W, I, F, 1, 1, 0>; c->mc[I][F][1][1][1] = s_vp9_mc<BD, W, I, F, 1, 1, 1>;
     VP9_MC_F(0) VP9_MC_F(1) VP9_MC_F(2) VP9_MC_F(3)
 #undef VP9_MC_F
 }
 
 extern "C" int ff_vp9dsp_mc_init_hip(FFHipVP9McContext *c, int bpp)
 {
-    if (!c || bpp != 8)
-        return FFHIP_EINVAL;
-    if (!ffhip_have_device())
-        return FFHIP_ENOSYS;
-    FFHipVP9McContext o = *c;
-    vp9_mc_fill<64, 0>(&o); vp9_mc_fill<32, 1>(&o); vp9_mc_fill<16, 2>(&o); vp9_mc_fill<8, 3>(&o); vp9_mc_fill<4, 4>(&o);
-    fb_snapshot(g_fb_vp9mc, *c, o);
-    *c = o;
-    return 0;
+#define F_(B) { vp9_mc_fill<B, 64, 0>(&o); vp9_mc_fill<B, 32, 1>(&o); vp9_mc_fill<B, 16, 2>(&o); vp9_mc_fill<B, 8, 3>(&o); vp9_mc_fill<B, 4, 4>(&o); }
+    VP9_INIT_BODY(FFHipVP9McContext, F_, g_fb_vp9mc)
+#undef F_
 }
 
-/* ---- vp9dsp loop-filter host faces: 16 lines x 16 samples around the edge travel through scratch (pitch 32) ---- */
-static bool vp9_lf_single(int nseg, const int wd_idx[2], int dir, uint8_t *dst, ptrdiff_t stride, const int E[2], const int I[2], const int H[2])
+/* loop filter: 16 lines x 16 samples around the edge travel through scratch (pitch 32 samples) */
+static bool vp9_lf_single(int bd, int nseg, const int wd_idx[2], int dir, uint8_t *dst, ptrdiff_t stride, const int E[2], const int I[2],
+                          const int H[2])
 {
-    const int P = 32, lines = 8 * nseg;
+    const int ps = bd > 8 ? 2 : 1, P = 32 * ps, lines = 8 * nseg;
     Arena A(64 + 32 * P + 64);
     if (!A.ok)
         return false;
@@ -952,173 +961,162 @@ static bool vp9_lf_single(int nseg, const int wd_idx[2], int dir, uint8_t *dst, 
      * reference function of this slot touches travel: 8 on either side for the 16-wide filter, 4 otherwise */
     const int r = (wd_idx[0] == 2 || (nseg == 2 && wd_idx[1] == 2)) ? 8 : 4;
     const int rows = dir ? 2 * r : lines, cols = dir ? lines : 2 * r;
-    const uint8_t *h0 = dir ? dst - r * stride : dst - r;
-    uint8_t *dd = dir ? d + (8 - r) * P : d + (8 - r);
-    if (hipMemcpy2D(dd, P, h0, stride, cols, rows, hipMemcpyHostToDevice) != hipSuccess)
+    const uint8_t *h0 = dir ? dst - r * stride : dst - r * ps;
+    uint8_t *dd = dir ? d + (8 - r) * P : d + (8 - r) * ps;
+    if (hipMemcpy2D(dd, P, h0, stride, (size_t)cols * ps, rows, hipMemcpyHostToDevice) != hipSuccess)
         return false;
     FFHipVp9Edge k[2] = {};
     for (int sgm = 0; sgm < nseg; sgm++) {
-        k[sgm].offset = dir ? 8 * P + 8 * sgm : 8 * sgm * P + 8;
+        k[sgm].offset = dir ? 8 * P + 8 * sgm * ps : 8 * sgm * P + 8 * ps;
         k[sgm].wd_idx = (uint8_t)wd_idx[sgm]; k[sgm].dir = (uint8_t)dir;
         k[sgm].E = (uint8_t)E[sgm]; k[sgm].I = (uint8_t)I[sgm]; k[sgm].H = (uint8_t)H[sgm];
     }
     if (hipMemcpy(buf, k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_vp9_loop_filter(d, P, (const FFHipVp9Edge *)buf, nseg, 0) < 0 || !A.down())
+    if (ffhip_launch_vp9_loop_filter_bd(bd, d, P, (const FFHipVp9Edge *)buf, nseg, 0) < 0 || !A.down())
         return false;
-    commit2d(A, (uint8_t *)h0, stride, dd, P, cols, rows);
+    commit2d(A, (uint8_t *)h0, stride, dd, P, (size_t)cols * ps, rows);
     return true;
 }
-static FFHipVP9LoopFilterContext g_fb_vp9lf;
-template <int WD, int DIR>
+static FFHipVP9LoopFilterContext g_fb_vp9lf[3];
+template <int BD, int WD, int DIR>
 static void s_vp9_lf8(uint8_t *d, ptrdiff_t s, int E, int I, int H)
 {
     const int w[2] = { WD, 0 }, e[2] = { E, 0 }, i[2] = { I, 0 }, h[2] = { H, 0 };
-    if (!vp9_lf_single(1, w, DIR, d, s, e, i, h))
-        SHIM_FB(g_fb_vp9lf, loop_filter_8[WD][DIR], d, s, E, I, H);
+    if (!vp9_lf_single(BD, 1, w, DIR, d, s, e, i, h))
+        SHIM_FB(VP9_FB(g_fb_vp9lf, BD), loop_filter_8[WD][DIR], d, s, E, I, H);
 }
-template <int DIR>
+template <int BD, int DIR>
 static void s_vp9_lf16(uint8_t *d, ptrdiff_t s, int E, int I, int H)
 {
     const int w[2] = { 2, 2 }, e[2] = { E, E }, i[2] = { I, I }, h[2] = { H, H };
-    if (!vp9_lf_single(2, w, DIR, d, s, e, i, h))
-        SHIM_FB(g_fb_vp9lf, loop_filter_16[DIR], d, s, E, I, H);
+    if (!vp9_lf_single(BD, 2, w, DIR, d, s, e, i, h))
+        SHIM_FB(VP9_FB(g_fb_vp9lf, BD), loop_filter_16[DIR], d, s, E, I, H);
 }
-template <int W1, int W2, int DIR>
+template <int BD, int W1, int W2, int DIR>
 static void s_vp9_lfmix(uint8_t *d, ptrdiff_t s, int E, int I, int H)
 {
     const int w[2] = { W1, W2 }, e[2] = { E & 0xff, E >> 8 }, i[2] = { I & 0xff, I >> 8 }, h[2] = { H & 0xff, H >> 8 };
-    if (!vp9_lf_single(2, w, DIR, d, s, e, i, h))
-        SHIM_FB(g_fb_vp9lf, loop_filter_mix2[W1][W2][DIR], d, s, E, I, H);
+    if (!vp9_lf_single(BD, 2, w, DIR, d, s, e, i, h))
+        SHIM_FB(VP9_FB(g_fb_vp9lf, BD), loop_filter_mix2[W1][W2][DIR], d, s, E, I, H);
+}
+template <int BD>
+static void vp9_lf_fill(FFHipVP9LoopFilterContext &o)
+{
+    o.loop_filter_8[0][0] = s_vp9_lf8<BD, 0, 0>; o.loop_filter_8[0][1] = s_vp9_lf8<BD, 0, 1>;
+    o.loop_filter_8[1][0] = s_vp9_lf8<BD, 1, 0>; o.loop_filter_8[1][1] = s_vp9_lf8<BD, 1, 1>;
+    o.loop_filter_8[2][0] = s_vp9_lf8<BD, 2, 0>; o.loop_filter_8[2][1] = s_vp9_lf8<BD, 2, 1>;
+    o.loop_filter_16[0] = s_vp9_lf16<BD, 0>; o.loop_filter_16[1] = s_vp9_lf16<BD, 1>;
+    o.loop_filter_mix2[0][0][0] = s_vp9_lfmix<BD, 0, 0, 0>; o.loop_filter_mix2[0][0][1] = s_vp9_lfmix<BD, 0, 0, 1>;
+    o.loop_filter_mix2[0][1][0] = s_vp9_lfmix<BD, 0, 1, 0>; o.loop_filter_mix2[0][1][1] = s_vp9_lfmix<BD, 0, 1, 1>;
+    o.loop_filter_mix2[1][0][0] = s_vp9_lfmix<BD, 1, 0, 0>; o.loop_filter_mix2[1][0][1] = s_vp9_lfmix<BD, 1, 0, 1>;
+    o.loop_filter_mix2[1][1][0] = s_vp9_lfmix<BD, 1, 1, 0>; o.loop_filter_mix2[1][1][1] = s_vp9_lfmix<BD, 1, 1, 1>;
 }
 
 extern "C" int ff_vp9dsp_loopfilter_init_hip(FFHipVP9LoopFilterContext *c, int bpp)
 {
-    if (!c || bpp != 8)
-        return FFHIP_EINVAL;
-    if (!ffhip_have_device())
-        return FFHIP_ENOSYS;
-    FFHipVP9LoopFilterContext o = *c;
-    o.loop_filter_8[0][0] = s_vp9_lf8<0, 0>; o.loop_filter_8[0][1] = s_vp9_lf8<0, 1>;
-    o.loop_filter_8[1][0] = s_vp9_lf8<1, 0>; o.loop_filter_8[1][1] = s_vp9_lf8<1, 1>;
-    o.loop_filter_8[2][0] = s_vp9_lf8<2, 0>; o.loop_filter_8[2][1] = s_vp9_lf8<2, 1>;
-    o.loop_filter_16[0] = s_vp9_lf16<0>; o.loop_filter_16[1] = s_vp9_lf16<1>;
-    o.loop_filter_mix2[0][0][0] = s_vp9_lfmix<0, 0, 0>; o.loop_filter_mix2[0][0][1] = s_vp9_lfmix<0, 0, 1>;
-    o.loop_filter_mix2[0][1][0] = s_vp9_lfmix<0, 1, 0>; o.loop_filter_mix2[0][1][1] = s_vp9_lfmix<0, 1, 1>;
-    o.loop_filter_mix2[1][0][0] = s_vp9_lfmix<1, 0, 0>; o.loop_filter_mix2[1][0][1] = s_vp9_lfmix<1, 0, 1>;
-    o.loop_filter_mix2[1][1][0] = s_vp9_lfmix<1, 1, 0>; o.loop_filter_mix2[1][1][1] = s_vp9_lfmix<1, 1, 1>;
-    fb_snapshot(g_fb_vp9lf, *c, o);
-    *c = o;
-    return 0;
+#define F_(B) vp9_lf_fill<B>(o);
+    VP9_INIT_BODY(FFHipVP9LoopFilterContext, F_, g_fb_vp9lf)
+#undef F_
 }
 
-/* ---- vp9dsp intra_pred host faces: the edge line is assembled from exactly the samples the mode reads ---- */
-static FFHipVP9IntraContext g_fb_vp9intra;
-template <int TX, int MODE>
+/* intra_pred: the edge line is assembled from exactly the samples the mode reads */
+static FFHipVP9IntraContext g_fb_vp9intra[3];
+template <int BD, int TX, int MODE>
 static bool vp9_intra_gpu(uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
 {
-    constexpr int N = 4 << TX;
+    constexpr int N = 4 << TX, PS = BD > 8 ? 2 : 1;
     constexpr bool use_top = MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7 || MODE == 9 || MODE == 11;
     constexpr bool use_left = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 8 || MODE == 9 || MODE == 10;
     constexpr bool use_tl = MODE == 4 || MODE == 5 || MODE == 6 || MODE == 9;
     constexpr int ntop = (TX == 0 && (MODE == 3 || MODE == 7)) ? 8 : N;
-    uint8_t e[32 + 1 + 32 + 8] = { 0 };
-    if (use_left) memcpy(e, left, N);
-    if (use_tl) e[N] = top[-1];
-    if (use_top) memcpy(e + N + 1, top, ntop);
-    Arena A(64 + 128 + (size_t)N * 32 + 64);
+    uint8_t e[(32 + 1 + 32 + 8) * PS] = { 0 };
+    if (use_left) memcpy(e, left, N * PS);
+    if (use_tl) memcpy(e + N * PS, top - PS, PS);
+    if (use_top) memcpy(e + (N + 1) * PS, top, ntop * PS);
+    constexpr int P = 32 * PS;
+    Arena A(64 + 256 + (size_t)N * P + 64);
     if (!A.ok)
         return false;
-    uint8_t *buf = A.buf, *de = buf + 64, *dd = de + 128;
+    uint8_t *buf = A.buf, *de = buf + 64, *dd = de + 256;
     FFHipVp9Intra k = {};
     k.mode = MODE;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(de, e, sizeof(e), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_vp9_intra(TX, dd, 32, de, (const FFHipVp9Intra *)buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_vp9_intra_bd(BD, TX, dd, P, de, (const FFHipVp9Intra *)buf, 1, 0) < 0 || !A.down())
         return false;
-    commit2d(A, dst, stride, dd, 32, N, N);
+    commit2d(A, dst, stride, dd, P, (size_t)N * PS, N);
     return true;
 }
-template <int TX, int MODE>
+template <int BD, int TX, int MODE>
 static void s_vp9_intra(uint8_t *dst, ptrdiff_t stride, const uint8_t *left, const uint8_t *top)
 {
-    if (!vp9_intra_gpu<TX, MODE>(dst, stride, left, top))
-        SHIM_FB(g_fb_vp9intra, intra_pred[TX][MODE], dst, stride, left, top);
+    if (!vp9_intra_gpu<BD, TX, MODE>(dst, stride, left, top))
+        SHIM_FB(VP9_FB(g_fb_vp9intra, BD), intra_pred[TX][MODE], dst, stride, left, top);
 }
-template <int TX>
+template <int BD, int TX>
 static void vp9_intra_fill(FFHipVP9IntraContext *c)
 {
-#define VI(M) c->intra_pred[TX][M] = s_vp9_intra<TX, M>;
+#define VI(M) c->intra_pred[TX][M] = s_vp9_intra<BD, TX, M>;
     VI(0) VI(1) VI(2) VI(3) VI(4) VI(5) VI(6) VI(7) VI(8) VI(9) VI(10) VI(11) VI(12) VI(13) VI(14)
 #undef VI
 }
 
 extern "C" int ff_vp9dsp_intrapred_init_hip(FFHipVP9IntraContext *c, int bpp)
 {
-    if (!c || bpp != 8)
-        return FFHIP_EINVAL;
-    if (!ffhip_have_device())
-        return FFHIP_ENOSYS;
-    FFHipVP9IntraContext o = *c;
-    vp9_intra_fill<0>(&o); vp9_intra_fill<1>(&o); vp9_intra_fill<2>(&o); vp9_intra_fill<3>(&o);
-    fb_snapshot(g_fb_vp9intra, *c, o);
-    *c = o;
-    return 0;
+#define F_(B) { vp9_intra_fill<B, 0>(&o); vp9_intra_fill<B, 1>(&o); vp9_intra_fill<B, 2>(&o); vp9_intra_fill<B, 3>(&o); }
+    VP9_INIT_BODY(FFHipVP9IntraContext, F_, g_fb_vp9intra)
+#undef F_
 }
 
-/* ---- vp9dsp scaled mc host faces: the source rectangle the call reads, at a pitch of 192 ---- */
-static FFHipVP9ScaledMcContext g_fb_vp9smc;
-template <int W, int F, int AVG>
+/* scaled mc: the source rectangle the call reads, at a pitch of 192 samples */
+static FFHipVP9ScaledMcContext g_fb_vp9smc[3];
+template <int BD, int W, int F, int AVG>
 static bool vp9_smc_gpu(uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my, int dx, int dy)
 {
     if (h <= 0 || h > 64 || dx < 1 || dx > 32 || dy < 1 || dy > 32)
         return false;
-    const int P = 192, bil = F == 3, before = bil ? 0 : 3, after = bil ? 1 : 4;
+    constexpr int PS = BD > 8 ? 2 : 1;
+    const int P = 192 * PS, DPX = 64 * PS, bil = F == 3, before = bil ? 0 : 3, after = bil ? 1 : 4;
     const int cols = ((mx + (W - 1) * dx) >> 4) + 1 + before + after, rows = ((my + (h - 1) * dy) >> 4) + 1 + before + after;
-    const size_t sbytes = (size_t)rows * P, dbytes = (size_t)h * 64;
+    const size_t sbytes = (size_t)rows * P, dbytes = (size_t)h * DPX;
     Arena A(64 + sbytes + dbytes + 64);
     if (!A.ok)
         return false;
     uint8_t *buf = A.buf, *dsrc = buf + 64, *ddst = dsrc + sbytes;
-    if (hipMemcpy2D(dsrc, P, src - before * ss - before, ss, cols, rows, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy2D(ddst, 64, dst, ds, W, h, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy2D(dsrc, P, src - before * ss - before * PS, ss, (size_t)cols * PS, rows, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy2D(ddst, DPX, dst, ds, (size_t)W * PS, h, hipMemcpyHostToDevice) != hipSuccess)
         return false;
     FFHipVp9ScaledBlock k = {};
-    k.src_offset = before * P + before;
+    k.src_offset = before * P + before * PS;
     k.width = W; k.height = (uint8_t)h; k.filter = F; k.mx = (uint8_t)mx; k.my = (uint8_t)my; k.avg = AVG; k.dx = (uint8_t)dx; k.dy = (uint8_t)dy;
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_vp9_smc(ddst, 64, dsrc, P, (const FFHipVp9ScaledBlock *)buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_vp9_smc_bd(BD, ddst, DPX, dsrc, P, (const FFHipVp9ScaledBlock *)buf, 1, 0) < 0 || !A.down())
         return false;
-    commit2d(A, dst, ds, ddst, 64, W, h);
+    commit2d(A, dst, ds, ddst, DPX, (size_t)W * PS, h);
     return true;
 }
-template <int W, int I, int F, int AVG>
+template <int BD, int W, int I, int F, int AVG>
 static void s_vp9_smc(uint8_t *dst, ptrdiff_t ds, const uint8_t *src, ptrdiff_t ss, int h, int mx, int my, int dx, int dy)
 {
-    if (!vp9_smc_gpu<W, F, AVG>(dst, ds, src, ss, h, mx, my, dx, dy))
-        SHIM_FB(g_fb_vp9smc, smc[I][F][AVG], dst, ds, src, ss, h, mx, my, dx, dy);
+    if (!vp9_smc_gpu<BD, W, F, AVG>(dst, ds, src, ss, h, mx, my, dx, dy))
+        SHIM_FB(VP9_FB(g_fb_vp9smc, BD), smc[I][F][AVG], dst, ds, src, ss, h, mx, my, dx, dy);
 }
-template <int W, int I>
+template <int BD, int W, int I>
 static void vp9_smc_fill(FFHipVP9ScaledMcContext *c)
 {
-    c->smc[I][0][0] = s_vp9_smc<W, I, 0, 0>; c->smc[I][0][1] = s_vp9_smc<W, I, 0, 1>;
-    c->smc[I][1][0] = s_vp9_smc<W, I, 1, 0>; c->smc[I][1][1] = s_vp9_smc<W, I, 1, 1>;
-    c->smc[I][2][0] = s_vp9_smc<W, I, 2, 0>; c->smc[I][2][1] = s_vp9_smc<W, I, 2, 1>;
-    c->smc[I][3][0] = s_vp9_smc<W, I, 3, 0>; c->smc[I][3][1] = s_vp9_smc<W, I, 3, 1>;
+    c->smc[I][0][0] = s_vp9_smc<BD, W, I, 0, 0>; c->smc[I][0][1] = s_vp9_smc<BD, W, I, 0, 1>;
+    c->smc[I][1][0] = s_vp9_smc<BD, W, I, 1, 0>; c->smc[I][1][1] = s_vp9_smc<BD, W, I, 1, 1>;
+    c->smc[I][2][0] = s_vp9_smc<BD, W, I, 2, 0>; c->smc[I][2][1] = s_vp9_smc<BD, W, I, 2, 1>;
+    c->smc[I][3][0] = s_vp9_smc<BD, W, I, 3, 0>; c->smc[I][3][1] = s_vp9_smc<BD, W, I, 3, 1>;
 }
 
 extern "C" int ff_vp9dsp_scaled_mc_init_hip(FFHipVP9ScaledMcContext *c, int bpp)
 {
-    if (!c || bpp != 8)
-        return FFHIP_EINVAL;
-    if (!ffhip_have_device())
-        return FFHIP_ENOSYS;
-    FFHipVP9ScaledMcContext o = *c;
-    vp9_smc_fill<64, 0>(&o); vp9_smc_fill<32, 1>(&o); vp9_smc_fill<16, 2>(&o); vp9_smc_fill<8, 3>(&o); vp9_smc_fill<4, 4>(&o);
-    fb_snapshot(g_fb_vp9smc, *c, o);
-    *c = o;
-    return 0;
+#define F_(B) { vp9_smc_fill<B, 64, 0>(&o); vp9_smc_fill<B, 32, 1>(&o); vp9_smc_fill<B, 16, 2>(&o); vp9_smc_fill<B, 8, 3>(&o); vp9_smc_fill<B, 4, 4>(&o); }
+    VP9_INIT_BODY(FFHipVP9ScaledMcContext, F_, g_fb_vp9smc)
+#undef F_
 }
 
 /* ---- h264pred host faces: the picture patch is staged from exactly the neighbours the C member reads ---- */

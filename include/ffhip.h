@@ -851,7 +851,7 @@ typedef void (*ffhip_vp9_itxfm_add_func)(uint8_t *dst, ptrdiff_t stride, int16_t
 typedef struct FFHipVP9ItxfmContext {
     ffhip_vp9_itxfm_add_func itxfm_add[5][4];
 } FFHipVP9ItxfmContext;
-/** ff_vp9dsp_init_<arch> shape for the itxfm_add table (libavcodec/vp9dsp.c:88-112).  bpp must be 8. */
+/** ff_vp9dsp_init_<arch> shape for the itxfm_add table (libavcodec/vp9dsp.c:88-112).  bpp 8, 10 or 12 (baked into the installed functions; above 8 bits samples are uint16_t and blocks hold int32 coefficients). */
 int ff_vp9dsp_itxfm_init_hip(FFHipVP9ItxfmContext *c, int bpp);
 
 /** One transform block of the batch face. */

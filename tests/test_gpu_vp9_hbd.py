@@ -199,3 +199,93 @@ def test_vp9_intra_pred_batch_hbd(tx, bd):
     torch.cuda.synchronize()
     got = back(d_dst, dst)
     assert np.array_equal(got, want), "%d mismatches, first %s" % ((got != want).sum(), np.argwhere(got != want)[:3])
+
+
+@pytest.mark.parametrize("bd", DEPTHS)
+def test_vp9_host_faces_hbd(bd):
+    """ff_vp9dsp_*_init_hip(c, 10 / 12): the reference's signatures with host pointers on uint16 planes / int32 blocks"""
+    from ffmpeg_amd import vp9
+    from test_oracle_vs_ref import vp9_smc_case
+    _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(700 + bd)
+    mxv = (1 << bd) - 1
+    # itxfm_add
+    c = vp9.dsp_init(bd)
+    for tx in range(5):
+        n = 4 if tx == 4 else 4 << tx
+        for txtp in range(4):
+            for kind in (1, 2):
+                blk = vp9_block32(rng, n, kind, bd)
+                eob = 1 if kind == 2 else n * n
+                dst0 = pix(rng, (n, n + 7), bd)
+                a, b, ba, bb = dst0.copy(), dst0.copy(), blk.copy(), blk.copy()
+                c.itxfm_add[tx][txtp](a.ctypes.data, 2 * (n + 7), ba.ctypes.data, eob)
+                O.ffo_vp9_itxfm_add_bd(bd, tx, txtp, ptr(b), 2 * (n + 7), ptr(bb, i32p), eob)
+                assert np.array_equal(a, b) and np.array_equal(ba, bb), (tx, txtp, kind)
+    # mc
+    c = vp9.mc_init(bd)
+    src = pix(rng, (90, 100), bd, extremes=True)
+    for rep in range(32):
+        idx = rep % 5
+        w = 64 >> idx
+        f, avg = (rep // 5) % 4, rep & 1
+        h = int(rng.choice([2, 8, 64]))
+        mx, my = (int(v) for v in rng.integers(1, 16, 2))
+        hx, vy = (rep >> 1) & 1, (rep >> 2) & 1
+        sp = src.ctypes.data + 2 * (10 * 100 + 12)
+        d0 = pix(rng, (64, 72), bd)
+        a, b = d0.copy(), d0.copy()
+        c.mc[idx][f][avg][hx][vy](a.ctypes.data, 144, sp, 200, h, mx, my)
+        O.ffo_vp9_mc_bd(bd, f, avg, ptr(b), 144, C.cast(sp, u8p), 200, w, h, mx if hx else 0, my if vy else 0)
+        assert np.array_equal(a, b), (idx, f, avg, hx, vy, h, mx, my)
+    # loop filter
+    c = vp9.lf_init(bd)
+    WD = [4, 8, 16]
+    for rep in range(36):
+        pl = vp9_lf_plane16(rng, bd)
+        a, b = pl.copy(), pl.copy()
+        d = rep & 1
+        E, I, H = (255, 63, int(rng.integers(0, 16))) if rep % 3 == 0 else (int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16)))
+        p0 = 2 * (24 * 48 + 24)
+        seg2 = 2 * 8 * (1 if d else 48)
+        which = rep % 3
+        if which == 0:
+            w = (rep // 3) % 3
+            c.loop_filter_8[w][d](a.ctypes.data + p0, 96, E, I, H)
+            O.ffo_vp9_loop_filter_bd(bd, WD[w], d, at(b, p0), 96, E, I, H)
+        elif which == 1:
+            c.loop_filter_16[d](a.ctypes.data + p0, 96, E, I, H)
+            for sgm in range(2):
+                O.ffo_vp9_loop_filter_bd(bd, 16, d, at(b, p0 + sgm * seg2), 96, E, I, H)
+        else:
+            w1, w2 = (rep // 3) & 1, (rep // 6) & 1
+            E2, I2, H2 = int(rng.integers(0, 256)), int(rng.integers(0, 64)), int(rng.integers(0, 16))
+            c.loop_filter_mix2[w1][w2][d](a.ctypes.data + p0, 96, E | E2 << 8, I | I2 << 8, H | H2 << 8)
+            O.ffo_vp9_loop_filter_bd(bd, WD[w1], d, at(b, p0), 96, E, I, H)
+            O.ffo_vp9_loop_filter_bd(bd, WD[w2], d, at(b, p0 + seg2), 96, E2, I2, H2)
+        assert np.array_equal(a, b), (rep, which, d)
+    # intra prediction
+    c = vp9.intra_init(bd)
+    for tx in range(4):
+        n = 4 << tx
+        for mode in range(15):
+            left = rng.integers(0, mxv + 1, n).astype(np.uint16)
+            topbuf = rng.integers(0, mxv + 1, 16 + 2 * n + 8).astype(np.uint16)
+            a = pix(rng, (n, n + 3), bd)
+            b = a.copy()
+            c.intra_pred[tx][mode](a.ctypes.data, 2 * (n + 3), left.ctypes.data, topbuf.ctypes.data + 32)
+            O.ffo_vp9_intra_pred_bd(bd, tx, mode, ptr(b), 2 * (n + 3), ptr(left), C.cast(topbuf.ctypes.data + 32, u8p))
+            assert np.array_equal(a, b), (tx, mode)
+    # scaled mc
+    c = vp9.smc_init(bd)
+    src = pix(rng, (160, 160), bd)
+    for rep in range(24):
+        f, avg, w, h, mx, my, dx, dy = vp9_smc_case(rng)
+        idx = {64: 0, 32: 1, 16: 2, 8: 3, 4: 4}[w]
+        sp = src.ctypes.data + 2 * (6 * 160 + 7)
+        d0 = pix(rng, (64, 72), bd)
+        a, b = d0.copy(), d0.copy()
+        c.smc[idx][f][avg](a.ctypes.data, 144, sp, 320, h, mx, my, dx, dy)
+        O.ffo_vp9_smc_bd(bd, f, avg, ptr(b), 144, C.cast(sp, u8p), 320, w, h, mx, my, dx, dy)
+        assert np.array_equal(a, b), (f, avg, w, h, mx, my, dx, dy)
