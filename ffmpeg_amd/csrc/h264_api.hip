@@ -368,6 +368,16 @@ extern "C" int ffhip_vp9_intra_pred_batch_dev_hbd(int bit_depth, int tx, uint8_t
     return ffhip_launch_vp9_intra_bd(bit_depth, tx, dst, stride, edges, blocks, n, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y, ptrdiff_t stride_uv, int sb_cols,
+                                              int sb_rows, const FFHipVp9LfSb *tables, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !y || !u || !v || !tables || sb_cols < 0 || sb_rows < 0 || sb_rows > 2047)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_lf_frame(bit_depth, y, u, v, stride_y, stride_uv, sb_cols, sb_rows, tables, (hipStream_t)stream);
+}
+
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */
 extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1,
                                     size_t pitch1, const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream)

@@ -78,6 +78,29 @@ def loop_filter_batch(base, stride, edges, n, stream=None, bit_depth=8):
                       "ffhip_vp9_loop_filter_batch_dev")
 
 
+def lf_sb_tables(filters, sb_cols, sb_rows, lim_lut, mblim_lut):
+    """host side of the decoder-order loop filter: filters = uint8 numpy [sb_rows * sb_cols, 192] VP9Filter records in raster
+    order, the frame's filter_lut (uint8 [64] each) -> uint32 numpy [sb_rows * sb_cols, 320] FFHipVp9LfSb tables (4:2:0)"""
+    import numpy as np
+    filters = np.ascontiguousarray(filters, np.uint8).reshape(sb_rows * sb_cols, 192)
+    lim_lut, mblim_lut = np.ascontiguousarray(lim_lut, np.uint8), np.ascontiguousarray(mblim_lut, np.uint8)
+    out = np.zeros((sb_rows * sb_cols, 320), np.uint32)
+    L = _lib.lib()
+    for r in range(sb_rows):
+        for c in range(sb_cols):
+            k = r * sb_cols + c
+            _lib.check(L.ffhip_vp9_lf_sb_tables(out[k].ctypes.data, filters[k].ctypes.data, 8 * r, 8 * c, 1, 1, lim_lut.ctypes.data,
+                                                mblim_lut.ctypes.data), "ffhip_vp9_lf_sb_tables")
+    return out
+
+
+def loopfilter_frame(y, u, v, stride_y, stride_uv, sb_cols, sb_rows, tables, stream=None, bit_depth=8):
+    """ff_vp9_loopfilter_sb over a picture in the decoder's order, one launch: y / u / v device tensors (planes padded to whole
+    superblocks), strides in bytes, tables = device uint32 [sb_rows * sb_cols, 320] from lf_sb_tables"""
+    return _lib.check(_lib.lib().ffhip_vp9_loopfilter_frame_dev(bit_depth, y.data_ptr(), u.data_ptr(), v.data_ptr(), stride_y, stride_uv, sb_cols,
+                                                                sb_rows, tables.data_ptr(), _st(stream)), "ffhip_vp9_loopfilter_frame_dev")
+
+
 _LF = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int)
 
 

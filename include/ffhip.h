@@ -947,6 +947,33 @@ typedef struct FFHipVp9Intra {
 int ffhip_vp9_intra_pred_batch_dev(int tx, uint8_t *dst, ptrdiff_t stride, const uint8_t *edges, const FFHipVp9Intra *blocks, int n,
                                    void *stream);
 /**
+ * The VP9 loop filter in SUPERBLOCK (decoder) order: ff_vp9_loopfilter_sb() (libavcodec/vp9lpf.c:180-203) for a whole picture.
+ * The function-level batch above takes segments that share no sample; a decoder's edges overlap (a 16-wide filter reaches 8
+ * samples either way, and a superblock's left / top edges rewrite its neighbours' samples), so the picture is a dependency graph:
+ * per plane all column edges of a superblock, then all its row edges, superblocks in raster order.  Here a superblock's VP9Filter
+ * becomes a table of 8-line segments per edge position on the host (ffhip_vp9_lf_sb_tables, device-free) and one launch walks the
+ * picture as a wavefront (one wave per superblock row; superblock (x, y) starts when row y - 1 has finished x + 1), all three
+ * planes in the same step.  4:2:0; bit_depth 8, 10 or 12.
+ */
+typedef struct FFHipVp9Filter {          /* == VP9Filter (libavcodec/vp9dec.h:79-83) */
+    uint8_t level[8 * 8];
+    uint8_t mask[2 /* 0 = y, 1 = uv */][2 /* 0 = col, 1 = row */][8 /* rows */][4 /* 0 = 16, 1 = 8, 2 = 4, 3 = inner 4 */];
+} FFHipVp9Filter;
+typedef struct FFHipVp9LfSb {            /* entry: bit 31 valid, 24..25 width (0: 4, 1: 8, 2: 16), 16..23 H, 8..15 I (lim), 0..7 E (mblim) */
+    uint32_t y[2][16][8];                /* [0 column edges / 1 row edges][position: 4 p samples along the filter axis][segment of 8 lines] */
+    uint32_t uv[2][8][4];                /* the same for both chroma planes (32 x 32 samples) */
+} FFHipVp9LfSb;
+/** Host side: the tables of the superblock at (row, col) — in 8-sample units, as the reference passes them (superblock (r, c): row =
+ *  8 r, col = 8 c; only "is it the first" matters) — from its VP9Filter and the frame's filter_lut (vp9.c:683-697). */
+int ffhip_vp9_lf_sb_tables(FFHipVp9LfSb *out, const FFHipVp9Filter *lflvl, int row, int col, int ss_h, int ss_v, const uint8_t *lim_lut,
+                           const uint8_t *mblim_lut);
+/** One picture: planes of sb_cols x sb_rows superblocks (64 x 64 luma / 32 x 32 chroma samples each: the decoder's frames are
+ *  padded to that), tables[sb_rows * sb_cols] in device memory in raster order.  Planes and strides 4-byte aligned.  Asynchronous on
+ *  `stream`; a lost hand-off is reported by ffhip_stream_synchronize. */
+int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y, ptrdiff_t stride_uv, int sb_cols,
+                                   int sb_rows, const FFHipVp9LfSb *tables, void *stream);
+
+/**
  * vp9dsp above 8 bits (profiles 2 / 3): the batch faces above at the bpp ff_vp9dsp_init(dsp, bpp, bitexact) instantiates its template
  * for (libavcodec/vp9dsp.c:88-112, vp9dsp_10bpp.c / vp9dsp_12bpp.c).  bit_depth 8, 10 or 12.  Samples are uint16_t above 8 bits,
  * itxfm_add's coefficients int32_t (the reference's dctcoef; FFHipVp9TU.coeff_offset counts coefficients) and its butterflies run

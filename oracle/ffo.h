@@ -124,6 +124,8 @@ void ffo_hevc_mc_w(int chroma, int mode, uint8_t *dst, ptrdiff_t dststride, cons
                    int height, int denom, int wx0, int wx1, int ox, int mx, int my, int width);
 /* VP9DSPContext.itxfm_add[tx][txtp], 8 bits (ffo_vp9.c): tx 0..3 = 4x4..32x32, 4 = WHT; consumes the block */
 /* vp9dsp above 8 bits (10, 12): uint16_t pixels, int32 coefficients, strides in bytes (ffo_vp9.c) */
+void ffo_vp9_loopfilter_sb(int bd, int ss_h, int ss_v, const uint8_t *lflvl_level, const uint8_t *lflvl_mask, int row, int col, uint8_t *y,
+                           uint8_t *u, uint8_t *v, ptrdiff_t ls_y, ptrdiff_t ls_uv, const uint8_t *lim_lut, const uint8_t *mblim_lut);
 void ffo_vp9_itxfm_add_bd(int bd, int tx, int txtp, uint8_t *dst, ptrdiff_t stride, int32_t *block, int eob);
 void ffo_vp9_mc_bd(int bd, int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, int width,
                    int height, int mx, int my);

@@ -418,3 +418,120 @@ void ffo_vp9_smc(int filter, int avg, uint8_t *dst, ptrdiff_t dststride, const u
 {
     ffo_vp9_smc_bd(8, filter, avg, dst, dststride, src, srcstride, width, height, mx, my, dx, dy);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * ff_vp9_loopfilter_sb() (libavcodec/vp9lpf.c:27-203): the loop filter of ONE 64x64 superblock in the decoder's order — per
+ * plane all column edges (filter_plane_cols, :27-99), then all row edges (filter_plane_rows, :101-178) — restated call for call:
+ * every dsp call of the reference (loop_filter_16 / loop_filter_8[wd] / loop_filter_mix2[wd1][wd2]) is the one or two 8-sample
+ * segments it stands for, on ffo_vp9_loop_filter_bd, in the same order.  lflvl_level = VP9Filter.level[64], lflvl_mask =
+ * VP9Filter.mask[2][2][8][4]; lim_lut / mblim_lut = VP9Context.filter_lut (vp9.c:683-697); planes and strides in bytes;
+ * (row, col) in 8-sample units as the reference passes them (superblock (r, c) -> row = 8 r, col = 8 c).
+ * ---------------------------------------------------------------------------------------- */
+static void lf_seg(int bd, int wd, int dir, uint8_t *p, ptrdiff_t ls, int L, const uint8_t *lim_lut, const uint8_t *mblim_lut)
+{
+    ffo_vp9_loop_filter_bd(bd, wd, dir, p, ls, mblim_lut[L], lim_lut[L], L >> 4);
+}
+
+static void lf_plane_cols(int bd, int col, int ss_h, int ss_v, const uint8_t *lvl, const uint8_t (*mask)[4], uint8_t *dst, ptrdiff_t ls,
+                          const uint8_t *lim_lut, const uint8_t *mblim_lut)
+{
+    const int bpp = bd > 8 ? 2 : 1;
+    for (int y = 0; y < 8; y += 2 << ss_v, dst += 16 * ls, lvl += 16 << ss_v) {
+        uint8_t *ptr = dst;
+        const uint8_t *l = lvl, *hmask1 = mask[y], *hmask2 = mask[y + 1 + ss_v];
+        const unsigned hm1 = hmask1[0] | hmask1[1] | hmask1[2], hm13 = hmask1[3];
+        const unsigned hm2 = hmask2[1] | hmask2[2], hm23 = hmask2[3];
+        const unsigned hm = hm1 | hm2 | hm13 | hm23;
+        for (unsigned x = 1; hm & ~(x - 1); x <<= 1, ptr += 8 * bpp >> ss_h) {
+            if (col || x > 1) {
+                if (hm1 & x) {
+                    const int L = *l;
+                    if (hmask1[0] & x) {
+                        lf_seg(bd, 16, 0, ptr, ls, L, lim_lut, mblim_lut);
+                        if (hmask2[0] & x) /* loop_filter_16: both halves with the first one's level */
+                            lf_seg(bd, 16, 0, ptr + 8 * ls, ls, L, lim_lut, mblim_lut);
+                    } else if (hm2 & x) { /* loop_filter_mix2 */
+                        lf_seg(bd, (hmask1[1] & x) ? 8 : 4, 0, ptr, ls, L, lim_lut, mblim_lut);
+                        lf_seg(bd, (hmask2[1] & x) ? 8 : 4, 0, ptr + 8 * ls, ls, l[8 << ss_v], lim_lut, mblim_lut);
+                    } else {
+                        lf_seg(bd, (hmask1[1] & x) ? 8 : 4, 0, ptr, ls, L, lim_lut, mblim_lut);
+                    }
+                } else if (hm2 & x) {
+                    lf_seg(bd, (hmask2[1] & x) ? 8 : 4, 0, ptr + 8 * ls, ls, l[8 << ss_v], lim_lut, mblim_lut);
+                }
+            }
+            if (ss_h) {
+                if (x & 0xAA)
+                    l += 2;
+            } else {
+                if (hm13 & x) {
+                    lf_seg(bd, 4, 0, ptr + 4 * bpp, ls, *l, lim_lut, mblim_lut);
+                    if (hm23 & x)
+                        lf_seg(bd, 4, 0, ptr + 4 * bpp + 8 * ls, ls, l[8 << ss_v], lim_lut, mblim_lut);
+                } else if (hm23 & x) {
+                    lf_seg(bd, 4, 0, ptr + 8 * ls + 4 * bpp, ls, l[8 << ss_v], lim_lut, mblim_lut);
+                }
+                l++;
+            }
+        }
+    }
+}
+
+static void lf_plane_rows(int bd, int row, int ss_h, int ss_v, const uint8_t *lvl, const uint8_t (*mask)[4], uint8_t *dst, ptrdiff_t ls,
+                          const uint8_t *lim_lut, const uint8_t *mblim_lut)
+{
+    const int bpp = bd > 8 ? 2 : 1;
+    for (int y = 0; y < 8; y++, dst += 8 * ls >> ss_v) {
+        uint8_t *ptr = dst;
+        const uint8_t *l = lvl, *vmask = mask[y];
+        const unsigned vm = vmask[0] | vmask[1] | vmask[2], vm3 = vmask[3];
+        for (unsigned x = 1; vm & ~(x - 1); x <<= (2 << ss_h), ptr += 16 * bpp, l += 2 << ss_h) {
+            const unsigned x2 = x << (1 + ss_h);
+            if (row || y) {
+                if (vm & x) {
+                    const int L = *l;
+                    if (vmask[0] & x) {
+                        lf_seg(bd, 16, 1, ptr, ls, L, lim_lut, mblim_lut);
+                        if (vmask[0] & x2)
+                            lf_seg(bd, 16, 1, ptr + 8 * bpp, ls, L, lim_lut, mblim_lut);
+                    } else if (vm & x2) {
+                        lf_seg(bd, (vmask[1] & x) ? 8 : 4, 1, ptr, ls, L, lim_lut, mblim_lut);
+                        lf_seg(bd, (vmask[1] & x2) ? 8 : 4, 1, ptr + 8 * bpp, ls, l[1 + ss_h], lim_lut, mblim_lut);
+                    } else {
+                        lf_seg(bd, (vmask[1] & x) ? 8 : 4, 1, ptr, ls, L, lim_lut, mblim_lut);
+                    }
+                } else if (vm & x2) {
+                    lf_seg(bd, (vmask[1] & x2) ? 8 : 4, 1, ptr + 8 * bpp, ls, l[1 + ss_h], lim_lut, mblim_lut);
+                }
+            }
+            if (!ss_v) {
+                if (vm3 & x) {
+                    lf_seg(bd, 4, 1, ptr + ls * 4, ls, *l, lim_lut, mblim_lut);
+                    if (vm3 & x2)
+                        lf_seg(bd, 4, 1, ptr + ls * 4 + 8 * bpp, ls, l[1 + ss_h], lim_lut, mblim_lut);
+                } else if (vm3 & x2) {
+                    lf_seg(bd, 4, 1, ptr + ls * 4 + 8 * bpp, ls, l[1 + ss_h], lim_lut, mblim_lut);
+                }
+            }
+        }
+        if (ss_v) {
+            if (y & 1)
+                lvl += 16;
+        } else {
+            lvl += 8;
+        }
+    }
+}
+
+void ffo_vp9_loopfilter_sb(int bd, int ss_h, int ss_v, const uint8_t *lflvl_level, const uint8_t *lflvl_mask, int row, int col, uint8_t *y,
+                           uint8_t *u, uint8_t *v, ptrdiff_t ls_y, ptrdiff_t ls_uv, const uint8_t *lim_lut, const uint8_t *mblim_lut)
+{
+    const uint8_t(*m)[2][8][4] = (const uint8_t(*)[2][8][4])lflvl_mask; /* mask[2][2][8][4] */
+    const uint8_t(*uv)[8][4] = m[ss_h | ss_v];
+    lf_plane_cols(bd, col, 0, 0, lflvl_level, m[0][0], y, ls_y, lim_lut, mblim_lut);
+    lf_plane_rows(bd, row, 0, 0, lflvl_level, m[0][1], y, ls_y, lim_lut, mblim_lut);
+    lf_plane_cols(bd, col, ss_h, ss_v, lflvl_level, uv[0], u, ls_uv, lim_lut, mblim_lut);
+    lf_plane_rows(bd, row, ss_h, ss_v, lflvl_level, uv[1], u, ls_uv, lim_lut, mblim_lut);
+    lf_plane_cols(bd, col, ss_h, ss_v, lflvl_level, uv[0], v, ls_uv, lim_lut, mblim_lut);
+    lf_plane_rows(bd, row, ss_h, ss_v, lflvl_level, uv[1], v, ls_uv, lim_lut, mblim_lut);
+}

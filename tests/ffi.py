@@ -165,6 +165,8 @@ def oracle():
             f8, fb = getattr(L, "ffo_vp9_" + name), getattr(L, "ffo_vp9_" + name + "_bd")
             fb.argtypes = [C.c_int] + list(f8.argtypes)
             fb.restype = None
+        L.ffo_vp9_loopfilter_sb.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_int, C.c_int, u8p, u8p, u8p, C.c_ssize_t, C.c_ssize_t, u8p, u8p]
+        L.ffo_vp9_loopfilter_sb.restype = None
         L.ffo_vp9_itxfm_add_bd.argtypes = [C.c_int, C.c_int, C.c_int, u8p, C.c_ssize_t, i32p, C.c_int]
         L.ffo_vp9_itxfm_add_bd.restype = None
         L.ffo_hevc_dequant.argtypes = [i16p, C.c_int]
@@ -326,6 +328,9 @@ def ref():
         L.ffref_hevc_sao_edge.restype = None
         L.ffref_hevc_loop_filter.argtypes = [C.c_int, u8p, C.c_ssize_t, C.c_int, i32p, u8p, u8p]
         L.ffref_hevc_loop_filter.restype = None
+        if hasattr(L, "ffref_vp9_loopfilter_sb"):
+            L.ffref_vp9_loopfilter_sb.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_int, C.c_int, u8p, u8p, u8p, C.c_int, C.c_int, u8p, u8p]
+            L.ffref_vp9_loopfilter_sb.restype = C.c_int
         if hasattr(L, "ffref_vp9_set_bit_depth"):
             L.ffref_vp9_set_bit_depth.argtypes = [C.c_int]
             L.ffref_vp9_set_bit_depth.restype = None

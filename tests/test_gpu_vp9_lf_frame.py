@@ -1,0 +1,69 @@
+"""GPU parity of the VP9 loop filter in the decoder's order: ffhip_vp9_loopfilter_frame_dev — one launch for a
+picture, superblocks as a wavefront — vs the oracle's ffo_vp9_loopfilter_sb called superblock by superblock in raster order
+(pinned to the reference's ff_vp9_loopfilter_sb in tests/test_vp9_lf_sb_cpu.py).  Bit-exact at 8, 10 and 12 bits."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import ptr, u8p
+import vp9_lf_gen as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _plane(rng, h, w, pad, bd):
+    base = np.cumsum(rng.integers(-2, 3, (h, w + pad)), axis=1) + np.cumsum(rng.integers(-2, 3, (h, 1)), axis=0) + (1 << 7)
+    base = (base << (bd - 8)) + rng.integers(0, (1 << (bd - 8)) + 1, (h, w + pad))
+    base[rng.integers(0, h, 40), :] += 9 << (bd - 8)                                 # a few real edges
+    return np.clip(base, 0, (1 << bd) - 1).astype(np.uint8 if bd == 8 else np.uint16)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("sbc,sbr,kind", [(9, 5, "structured"), (9, 5, "bits0"), (7, 6, "bits1"), (1, 1, "structured"), (1, 7, "bits1"), (12, 1, "structured"),
+                                          (2, 40, "bits2"), (30, 17, "structured")])
+def test_vp9_loopfilter_frame(sbc, sbr, kind, bd):
+    import torch
+    from ffmpeg_amd import vp9
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(1000 * sbc + 10 * sbr + bd + len(kind))
+    lim, mblim = G.filter_lut(int(rng.integers(0, 8)))
+    cols, rows = 8 * sbc - int(rng.integers(0, 4)), 8 * sbr - int(rng.integers(0, 4))
+    planes = [_plane(rng, 64 * sbr, 64 * sbc, 12, bd), _plane(rng, 32 * sbr, 32 * sbc, 4, bd), _plane(rng, 32 * sbr, 32 * sbc, 4, bd)]
+    before = [p.copy() for p in planes]
+    filt = np.zeros(sbr * sbc, G.FILTER_DT)
+    O = ffi.oracle()
+    for r in range(sbr):
+        for c in range(sbc):
+            f = G.structured(rng, r, c, cols, rows) if kind == "structured" else G.random_bits(rng, int(kind[-1]))
+            filt[r * sbc + c] = f
+            level, mask = np.ascontiguousarray(f["level"]), np.ascontiguousarray(f["mask"])
+            at = [p.ctypes.data + r * (64 >> (k > 0)) * p.strides[0] + c * (64 >> (k > 0)) * p.itemsize for k, p in enumerate(planes)]
+            O.ffo_vp9_loopfilter_sb(bd, 1, 1, ptr(level, u8p), ptr(mask, u8p), 8 * r, 8 * c, *(C.cast(a, u8p) for a in at),
+                                    planes[0].strides[0], planes[1].strides[0], ptr(lim, u8p), ptr(mblim, u8p))
+    tabs = vp9.lf_sb_tables(filt.view(np.uint8).reshape(sbr * sbc, 192), sbc, sbr, lim, mblim)
+    dev = [torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).cuda() for b in before]
+    d_tabs = torch.from_numpy(tabs.view(np.int32)).cuda()
+    vp9.loopfilter_frame(dev[0], dev[1], dev[2], before[0].strides[0], before[1].strides[0], sbc, sbr, d_tabs, bit_depth=bd)
+    torch.cuda.synchronize()
+    from ffmpeg_amd import _lib
+    assert _lib.lib().ffhip_stream_synchronize(None) == 0
+    changed = 0
+    for d, want, b in zip(dev, planes, before):
+        got = d.cpu().numpy().view(want.dtype).reshape(want.shape)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (bad[:5], len(bad))
+        changed += int((want != b).sum())
+    assert changed > (20 * sbc * sbr if sbc * sbr > 8 else 0)
+
+
+def test_vp9_loopfilter_frame_rejects():
+    import torch
+    from ffmpeg_amd import vp9
+    y = torch.zeros(64 * 64 + 8, dtype=torch.uint8, device="cuda")
+    t = torch.zeros(320, dtype=torch.int32, device="cuda")
+    with pytest.raises(Exception):
+        vp9.loopfilter_frame(y, y, y, 64, 32, 1, 1, t, bit_depth=9)
+    with pytest.raises(Exception):
+        vp9.loopfilter_frame(y[1:], y, y, 64, 32, 1, 1, t)          # misaligned plane
