@@ -368,14 +368,14 @@ extern "C" int ffhip_vp9_intra_pred_batch_dev_hbd(int bit_depth, int tx, uint8_t
     return ffhip_launch_vp9_intra_bd(bit_depth, tx, dst, stride, edges, blocks, n, (hipStream_t)stream);
 }
 
-extern "C" int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y, ptrdiff_t stride_uv, int sb_cols,
-                                              int sb_rows, const FFHipVp9LfSb *tables, void *stream)
+extern "C" int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y, ptrdiff_t stride_uv, int cols,
+                                              int rows, const FFHipVp9LfSb *tables, void *stream)
 {
-    if (!hevc_bd_ok(bit_depth) || !y || !u || !v || !tables || sb_cols < 0 || sb_rows < 0 || sb_rows > 2047)
+    if (!hevc_bd_ok(bit_depth) || !y || !u || !v || !tables || cols < 0 || rows < 0 || rows > 8 * 2047)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    return ffhip_launch_vp9_lf_frame(bit_depth, y, u, v, stride_y, stride_uv, sb_cols, sb_rows, tables, (hipStream_t)stream);
+    return ffhip_launch_vp9_lf_frame(bit_depth, y, u, v, stride_y, stride_uv, cols, rows, tables, (hipStream_t)stream);
 }
 
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */

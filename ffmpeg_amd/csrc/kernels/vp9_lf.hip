@@ -133,7 +133,7 @@ struct Vp9LfTile {
 };
 
 template <typename PIX>
-__global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, uint8_t *pv, ptrdiff_t sy, ptrdiff_t suv, int sb_cols, int sb_rows,
+__global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, uint8_t *pv, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
                                                      const FFHipVp9LfSb *tabs, int *progress, int *fail, int bd)
 {
     using T = Vp9LfTile<PIX>;
@@ -149,8 +149,11 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
     auto ld_dev = [](const uint8_t *p) { return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto st_dev = [](uint8_t *p, uint32_t v) { __hip_atomic_store(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     uint32_t *ty32 = reinterpret_cast<uint32_t *>(tile.y);
-    int known = 0;
+    const int sb_cols = (cols + 7) >> 3;
+    const int hl = min(64, 8 * rows - 64 * row), hc = hl >> 1; /* the picture may end inside the last superblocks: nothing is read or */
+    int known = 0;                                             /* written beyond its cols x rows 8x8 blocks (the reference never does) */
     for (int col = 0; col < sb_cols; col++) {
+        const int wl = min(64, 8 * cols - 64 * col), wc = wl >> 1;
         /* ---- the superblock's tables ---- */
         {
             const uint32_t *g = reinterpret_cast<const uint32_t *>(tabs + (size_t)row * sb_cols + col);
@@ -180,15 +183,13 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
         uint8_t *ysb = py + (ptrdiff_t)row * 64 * sy + (ptrdiff_t)col * 64 * PS;
         uint8_t *csb[2] = { pu + (ptrdiff_t)row * 32 * suv + (ptrdiff_t)col * 32 * PS, pv + (ptrdiff_t)row * 32 * suv + (ptrdiff_t)col * 32 * PS };
         {
-            constexpr int DPR = 72 / SPD; /* dwords per tile row that hold picture samples (columns -8..63) */
             const int r0 = row ? -8 : 0, c0 = col ? -8 : 0;
-            const int ndw = (64 - c0) / SPD, nrow = 64 - r0;
+            const int ndw = (wl - c0) / SPD, nrow = hl - r0;
             for (int t = lane; t < nrow * ndw; t += 64) {
                 const int r = r0 + t / ndw, d = t % ndw, c = c0 + d * SPD;
                 ty32[((r + 8) * T::PY + c + 8) / SPD] = ld_dev(ysb + (ptrdiff_t)r * sy + (ptrdiff_t)c * PS);
             }
-            (void)DPR;
-            const int cndw = (32 - c0) / SPD, cnrow = 32 - r0;
+            const int cndw = (wc - c0) / SPD, cnrow = hc - r0;
             for (int t = lane; t < 2 * cnrow * cndw; t += 64) {
                 const int p = t / (cnrow * cndw), u = t % (cnrow * cndw), r = r0 + u / cndw, c = c0 + (u % cndw) * SPD;
                 reinterpret_cast<uint32_t *>(tile.c[p])[((r + 8) * T::PC + c + 8) / SPD] = ld_dev(csb[p] + (ptrdiff_t)r * suv + (ptrdiff_t)c * PS);
@@ -234,24 +235,24 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
         /* ---- picture <- tile: rows 0..63 x columns -8..63 (column edges reach into the left neighbour) and rows -7..-1 x
          *      columns 0..63 (row edges reach into the upper one); write-through ---- */
         {
-            const int c0 = col ? -8 : 0, ndw = (64 - c0) / SPD;
-            for (int t = lane; t < 64 * ndw; t += 64) {
+            const int c0 = col ? -8 : 0, ndw = (wl - c0) / SPD;
+            for (int t = lane; t < hl * ndw; t += 64) {
                 const int r = t / ndw, c = c0 + (t % ndw) * SPD;
                 st_dev(ysb + (ptrdiff_t)r * sy + (ptrdiff_t)c * PS, ty32[((r + 8) * T::PY + c + 8) / SPD]);
             }
             if (row)
-                for (int t = lane; t < 7 * (64 / SPD); t += 64) {
-                    const int r = -7 + t / (64 / SPD), c = (t % (64 / SPD)) * SPD;
+                for (int t = lane; t < 7 * (wl / SPD); t += 64) {
+                    const int r = -7 + t / (wl / SPD), c = (t % (wl / SPD)) * SPD;
                     st_dev(ysb + (ptrdiff_t)r * sy + (ptrdiff_t)c * PS, ty32[((r + 8) * T::PY + c + 8) / SPD]);
                 }
-            const int cndw = (32 - c0) / SPD;
-            for (int t = lane; t < 2 * 32 * cndw; t += 64) {
-                const int p = t / (32 * cndw), u = t % (32 * cndw), r = u / cndw, c = c0 + (u % cndw) * SPD;
+            const int cndw = (wc - c0) / SPD;
+            for (int t = lane; t < 2 * hc * cndw; t += 64) {
+                const int p = t / (hc * cndw), u = t % (hc * cndw), r = u / cndw, c = c0 + (u % cndw) * SPD;
                 st_dev(csb[p] + (ptrdiff_t)r * suv + (ptrdiff_t)c * PS, reinterpret_cast<const uint32_t *>(tile.c[p])[((r + 8) * T::PC + c + 8) / SPD]);
             }
             if (row)
-                for (int t = lane; t < 2 * 7 * (32 / SPD); t += 64) {
-                    const int p = t / (7 * (32 / SPD)), u = t % (7 * (32 / SPD)), r = -7 + u / (32 / SPD), c = (u % (32 / SPD)) * SPD;
+                for (int t = lane; t < 2 * 7 * (wc / SPD); t += 64) {
+                    const int p = t / (7 * (wc / SPD)), u = t % (7 * (wc / SPD)), r = -7 + u / (wc / SPD), c = (u % (wc / SPD)) * SPD;
                     st_dev(csb[p] + (ptrdiff_t)r * suv + (ptrdiff_t)c * PS, reinterpret_cast<const uint32_t *>(tile.c[p])[((r + 8) * T::PC + c + 8) / SPD]);
                 }
         }
@@ -264,10 +265,11 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
     }
 }
 
-int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int sb_cols, int sb_rows,
+int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
                               const FFHipVp9LfSb *tabs, hipStream_t stream)
 {
-    if (sb_cols <= 0 || sb_rows <= 0)
+    const int sb_rows = (rows + 7) >> 3;
+    if (cols <= 0 || rows <= 0)
         return 0;
     if ((bd != 8 && bd != 10 && bd != 12) || (((uintptr_t)y | (uintptr_t)u | (uintptr_t)v | (size_t)sy | (size_t)suv) & 3)) {
         ffhip_set_error("ffhip_vp9_loopfilter_frame: bit depth %d (8, 10, 12); planes and strides must be 4-byte aligned", bd);
@@ -278,9 +280,9 @@ int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdif
     if (r < 0)
         return r;
     if (bd == 8)
-        hipLaunchKernelGGL(k_vp9_lf_frame<uint8_t>, dim3(sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, sb_cols, sb_rows, tabs, prog, fail, 8);
+        hipLaunchKernelGGL(k_vp9_lf_frame<uint8_t>, dim3(sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8);
     else
-        hipLaunchKernelGGL(k_vp9_lf_frame<uint16_t>, dim3(sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, sb_cols, sb_rows, tabs, prog, fail, bd);
+        hipLaunchKernelGGL(k_vp9_lf_frame<uint16_t>, dim3(sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, bd);
     const hipError_t e = hipGetLastError();
     const int r2 = ffhip_h264_wavefront_slot_done(slot, stream);
     if (e != hipSuccess) {

@@ -94,11 +94,11 @@ def lf_sb_tables(filters, sb_cols, sb_rows, lim_lut, mblim_lut):
     return out
 
 
-def loopfilter_frame(y, u, v, stride_y, stride_uv, sb_cols, sb_rows, tables, stream=None, bit_depth=8):
-    """ff_vp9_loopfilter_sb over a picture in the decoder's order, one launch: y / u / v device tensors (planes padded to whole
-    superblocks), strides in bytes, tables = device uint32 [sb_rows * sb_cols, 320] from lf_sb_tables"""
-    return _lib.check(_lib.lib().ffhip_vp9_loopfilter_frame_dev(bit_depth, y.data_ptr(), u.data_ptr(), v.data_ptr(), stride_y, stride_uv, sb_cols,
-                                                                sb_rows, tables.data_ptr(), _st(stream)), "ffhip_vp9_loopfilter_frame_dev")
+def loopfilter_frame(y, u, v, stride_y, stride_uv, cols, rows, tables, stream=None, bit_depth=8):
+    """ff_vp9_loopfilter_sb over a picture of cols x rows 8x8 blocks in the decoder's order, one launch: y / u / v device tensors,
+    strides in bytes, tables = device uint32 [sb_rows * sb_cols, 320] from lf_sb_tables (sb_* = (* + 7) >> 3)"""
+    return _lib.check(_lib.lib().ffhip_vp9_loopfilter_frame_dev(bit_depth, y.data_ptr(), u.data_ptr(), v.data_ptr(), stride_y, stride_uv, cols,
+                                                                rows, tables.data_ptr(), _st(stream)), "ffhip_vp9_loopfilter_frame_dev")
 
 
 _LF = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int)

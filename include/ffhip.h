@@ -967,11 +967,13 @@ typedef struct FFHipVp9LfSb {            /* entry: bit 31 valid, 24..25 width (0
  *  8 r, col = 8 c; only "is it the first" matters) — from its VP9Filter and the frame's filter_lut (vp9.c:683-697). */
 int ffhip_vp9_lf_sb_tables(FFHipVp9LfSb *out, const FFHipVp9Filter *lflvl, int row, int col, int ss_h, int ss_v, const uint8_t *lim_lut,
                            const uint8_t *mblim_lut);
-/** One picture: planes of sb_cols x sb_rows superblocks (64 x 64 luma / 32 x 32 chroma samples each: the decoder's frames are
- *  padded to that), tables[sb_rows * sb_cols] in device memory in raster order.  Planes and strides 4-byte aligned.  Asynchronous on
- *  `stream`; a lost hand-off is reported by ffhip_stream_synchronize. */
-int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y, ptrdiff_t stride_uv, int sb_cols,
-                                   int sb_rows, const FFHipVp9LfSb *tables, void *stream);
+/** One picture of cols x rows 8x8 blocks (VP9Context.cols / .rows: (width + 7) >> 3, (height + 7) >> 3), i.e. (cols + 7) >> 3 by
+ *  (rows + 7) >> 3 superblocks; tables[sb_rows * sb_cols] in device memory in raster order.  Nothing outside the picture's
+ *  8 cols x 8 rows luma samples (half of that per chroma plane) is read or written — the reference touches no more, and the
+ *  decoder's frame buffers are not padded to whole superblocks.  Planes and strides 4-byte aligned.  Asynchronous on `stream`; a
+ *  lost hand-off is reported by ffhip_stream_synchronize. */
+int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y, ptrdiff_t stride_uv, int cols,
+                                   int rows, const FFHipVp9LfSb *tables, void *stream);
 
 /**
  * vp9dsp above 8 bits (profiles 2 / 3): the batch faces above at the bpp ff_vp9dsp_init(dsp, bpp, bitexact) instantiates its template

@@ -40,13 +40,13 @@ y, u, v = plane(64 * sbr, 64 * sbc), plane(32 * sbr, 32 * sbc), plane(32 * sbr, 
 d_tabs = torch.from_numpy(tabs.view(np.int32)).cuda()
 sy, suv = 64 * sbc * ps, 32 * sbc * ps
 for _ in range(3):
-    vp9.loopfilter_frame(y, u, v, sy, suv, sbc, sbr, d_tabs, bit_depth=bd)
+    vp9.loopfilter_frame(y, u, v, sy, suv, 8 * sbc, 8 * sbr, d_tabs, bit_depth=bd)
 torch.cuda.synchronize()
 N = 20
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(N):
-    vp9.loopfilter_frame(y, u, v, sy, suv, sbc, sbr, d_tabs, bit_depth=bd)
+    vp9.loopfilter_frame(y, u, v, sy, suv, 8 * sbc, 8 * sbr, d_tabs, bit_depth=bd)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / N
