@@ -124,43 +124,93 @@ int ffhip_launch_vp9_loop_filter_bd(int bd, uint8_t *base, ptrdiff_t stride, con
  * U and V ride in the same wave (lanes 0..31 / 32..63).  The superblock lives in an LDS tile with its 8 context samples to the
  * left and above; everything it may have changed is written back once.
  */
-template <typename PIX>
-struct Vp9LfTile {
-    static constexpr int PY = 76, PC = 44;  /* row pitches in samples: odd dword counts at 8 bits */
-    PIX y[72 * PY];                         /* rows -8..63, columns -8..63: sample (r, c) at [(r + 8) * PY + c + 8] */
-    PIX c[2][40 * PC];                      /* rows -8..31, columns -8..31 */
-    uint32_t tab[320];                      /* FFHipVp9LfSb */
+/* a rectangle of NR rows x ND dwords between the picture and an LDS tile, one dword per lane and step, all loads of a region in
+ * flight before the first lands in LDS; only rows < nr and dwords < nd exist.  DEV: device-scope (the samples another wave wrote) */
+template <int ND, int NR, bool DEV>
+struct Vp9LfRegion {
+    static constexpr int K = (ND * NR + 63) / 64;
+    __device__ __forceinline__ static void issue(uint32_t (&v)[K], const uint8_t *g, ptrdiff_t gstride, int nr, int nd, int lane)
+    {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int t = lane + 64 * k, r = t / ND, d = t % ND;
+            v[k] = 0;
+            if (r < nr && d < nd && t < ND * NR) {
+                const uint32_t *a = reinterpret_cast<const uint32_t *>(g + r * gstride + 4 * d);
+                v[k] = DEV ? __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *a;
+            }
+        }
+    }
+    __device__ __forceinline__ static void commit(const uint32_t (&v)[K], uint32_t *lds, int pitch, int nr, int nd, int lane)
+    {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int t = lane + 64 * k, r = t / ND, d = t % ND;
+            if (r < nr && d < nd && t < ND * NR)
+                lds[r * pitch + d] = v[k];
+        }
+    }
+    /* picture <- tile, write-through */
+    __device__ __forceinline__ static void store(const uint32_t *lds, int pitch, uint8_t *g, ptrdiff_t gstride, int nr, int nd, int lane)
+    {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int t = lane + 64 * k, r = t / ND, d = t % ND;
+            if (r < nr && d < nd && t < ND * NR)
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(g + r * gstride + 4 * d), lds[r * pitch + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 };
 
-template <typename PIX>
-__global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, uint8_t *pv, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
-                                                     const FFHipVp9LfSb *tabs, int *progress, int *fail, int bd)
+/* one superblock row of luma (CHROMA = false: 64 lanes = the 64 lines of one plane) or of both chroma planes (CHROMA = true: U in
+ * lanes 0..31, V in 32..63).  Luma and chroma never meet in the loop filter, so they are separate waves with separate counters:
+ * the critical path of a picture is the luma chain alone. */
+template <typename PIX, bool CHROMA>
+__device__ __forceinline__ void vp9_lf_sb_row(uint8_t *p0, uint8_t *p1, ptrdiff_t stride, int cols, int rows, int row, const FFHipVp9LfSb *tabs,
+                                              int *progress, int *fail, int bd)
 {
-    using T = Vp9LfTile<PIX>;
-    constexpr int PS = (int)sizeof(PIX), SPD = 4 / PS; /* samples per dword */
-    __shared__ __align__(16) T tile;
-    const int row = blockIdx.x, lane = threadIdx.x;
+    constexpr int PS = (int)sizeof(PIX), SPD = 4 / PS;             /* samples per dword */
+    constexpr int N = CHROMA ? 32 : 64, NP = CHROMA ? 2 : 1;       /* samples per superblock side, planes in the wave */
+    constexpr int P = CHROMA ? 44 : 76;                            /* tile row pitch in samples: an odd dword count at 8 bits */
+    constexpr int NPOS = N / 4, NSEG = N / 8, TW = 2 * NPOS * NSEG; /* edge positions, 8-line segments, table words */
+    constexpr int TOFF = CHROMA ? 256 : 0, TK = (TW + 63) / 64;
+    constexpr int DN = N / SPD, D8 = 8 / SPD, PD = P / SPD;
+    __shared__ __align__(16) PIX tile[NP][(N + 8) * P];            /* rows -8..N-1, columns -8..N-1: sample (r, c) at [(r + 8) * P + c + 8] */
+    __shared__ uint32_t tab[TW];                                   /* [0 column / 1 row edges][position][segment] */
+    using In = Vp9LfRegion<DN, N, false>;   /* the superblock's own samples: nobody has touched them in this launch yet */
+    using Left = Vp9LfRegion<D8, N, true>;  /* 8 columns of the left neighbour: this wave's previous step rewrote them */
+    using Top = Vp9LfRegion<DN, 8, true>;   /* 8 rows of the upper neighbour: the row above rewrote them */
+    using Top7 = Vp9LfRegion<DN, 7, true>;
+    const int lane = threadIdx.x, pl = CHROMA ? lane >> 5 : 0, line = CHROMA ? lane & 31 : lane;
     const int sh = bd - 8, F = 1 << sh, fmax = (1 << (bd - 1)) - 1, maxv = (1 << bd) - 1;
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto ld_dev = [](const uint8_t *p) { return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto st_dev = [](uint8_t *p, uint32_t v) { __hip_atomic_store(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    uint32_t *ty32 = reinterpret_cast<uint32_t *>(tile.y);
     const int sb_cols = (cols + 7) >> 3;
-    const int hl = min(64, 8 * rows - 64 * row), hc = hl >> 1; /* the picture may end inside the last superblocks: nothing is read or */
-    int known = 0;                                             /* written beyond its cols x rows 8x8 blocks (the reference never does) */
-    for (int col = 0; col < sb_cols; col++) {
-        const int wl = min(64, 8 * cols - 64 * col), wc = wl >> 1;
-        /* ---- the superblock's tables ---- */
-        {
-            const uint32_t *g = reinterpret_cast<const uint32_t *>(tabs + (size_t)row * sb_cols + col);
+    /* the picture may end inside the last superblocks: nothing is read or written beyond its cols x rows 8x8 blocks (the
+     * reference never does, and frame buffers are not padded to superblocks) */
+    const int h = min(N, (CHROMA ? 4 : 8) * rows - N * row);
+    uint8_t *const prow[2] = { p0 + (ptrdiff_t)row * N * stride, p1 + (ptrdiff_t)row * N * stride };
+    uint32_t *t32[2] = { reinterpret_cast<uint32_t *>(tile[0]), reinterpret_cast<uint32_t *>(tile[NP - 1]) };
+    /* the next superblock's own samples and tables travel while this one is filtered */
+    uint32_t nin[NP][In::K], ntab[TK];
+    auto prefetch = [&](int col) {
+        const int w = min(N, (CHROMA ? 4 : 8) * cols - N * col);
 #pragma unroll
-            for (int k = 0; k < 5; k++)
-                tile.tab[lane + 64 * k] = g[lane + 64 * k];
-        }
+        for (int q = 0; q < NP; q++)
+            In::issue(nin[q], prow[q] + (ptrdiff_t)col * N * PS, stride, h, w / SPD, lane);
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(tabs + (size_t)row * sb_cols + col) + TOFF;
+#pragma unroll
+        for (int k = 0; k < TK; k++)
+            ntab[k] = lane + 64 * k < TW ? g[lane + 64 * k] : 0;
+    };
+    prefetch(0);
+    int known = 0;
+    for (int col = 0; col < sb_cols; col++) {
+        const int w = min(N, (CHROMA ? 4 : 8) * cols - N * col);
+        uint8_t *sb[2] = { prow[0] + (ptrdiff_t)col * N * PS, prow[1] + (ptrdiff_t)col * N * PS };
         /* ---- the row above has finished superblock col + 1 ---- */
         if (row > 0) {
             const int want = min(col + 2, sb_cols);
@@ -178,26 +228,34 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        /* ---- tile <- picture: rows -8..63 (the 8 above only below the first superblock row) x columns -8..63 (the 8 to the
-         *      left only right of the first superblock), as dwords; everything else of the tile is never read ---- */
-        uint8_t *ysb = py + (ptrdiff_t)row * 64 * sy + (ptrdiff_t)col * 64 * PS;
-        uint8_t *csb[2] = { pu + (ptrdiff_t)row * 32 * suv + (ptrdiff_t)col * 32 * PS, pv + (ptrdiff_t)row * 32 * suv + (ptrdiff_t)col * 32 * PS };
+        /* ---- tile <- picture: the prefetched N x N, the 8 columns to the left (right of the first superblock), the 8 rows above
+         *      (below the first superblock row; the corner is never read); everything else of the tile is never read ---- */
         {
-            const int r0 = row ? -8 : 0, c0 = col ? -8 : 0;
-            const int ndw = (wl - c0) / SPD, nrow = hl - r0;
-            for (int t = lane; t < nrow * ndw; t += 64) {
-                const int r = r0 + t / ndw, d = t % ndw, c = c0 + d * SPD;
-                ty32[((r + 8) * T::PY + c + 8) / SPD] = ld_dev(ysb + (ptrdiff_t)r * sy + (ptrdiff_t)c * PS);
+            uint32_t vl[NP][Left::K], vt[NP][Top::K];
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                if (col)
+                    Left::issue(vl[q], sb[q] - 8 * PS, stride, h, D8, lane);
+                if (row)
+                    Top::issue(vt[q], sb[q] - 8 * stride, stride, 8, w / SPD, lane);
             }
-            const int cndw = (wc - c0) / SPD, cnrow = hc - r0;
-            for (int t = lane; t < 2 * cnrow * cndw; t += 64) {
-                const int p = t / (cnrow * cndw), u = t % (cnrow * cndw), r = r0 + u / cndw, c = c0 + (u % cndw) * SPD;
-                reinterpret_cast<uint32_t *>(tile.c[p])[((r + 8) * T::PC + c + 8) / SPD] = ld_dev(csb[p] + (ptrdiff_t)r * suv + (ptrdiff_t)c * PS);
+#pragma unroll
+            for (int k = 0; k < TK; k++)
+                if (lane + 64 * k < TW)
+                    tab[lane + 64 * k] = ntab[k];
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                In::commit(nin[q], t32[q] + 8 * PD + D8, PD, h, w / SPD, lane);
+                if (col)
+                    Left::commit(vl[q], t32[q] + 8 * PD, PD, h, D8, lane);
+                if (row)
+                    Top::commit(vt[q], t32[q] + D8, PD, 8, w / SPD, lane);
             }
         }
         wave_sync();
-        auto entry_ok = [](uint32_t e) { return (e >> 31) != 0; };
-        /* one line of one entry: base = the line's first sample (position 0 of the filter axis), step = distance along that axis */
+        if (col + 1 < sb_cols)
+            prefetch(col + 1);
+        /* one line of one entry: line0 = the line's sample at position 0 of the filter axis, step = distance along that axis */
         auto run = [&](PIX *line0, int step, int pos, uint32_t e) {
             const int wd = ((e >> 24) & 3) == 0 ? 4 : ((e >> 24) & 3) == 1 ? 8 : 16;
             PIX *pix = line0 + 4 * pos * step;
@@ -208,53 +266,29 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
             vp9_lf_line(px, wd, (int)(e & 0xFF) << sh, (int)((e >> 8) & 0xFF) << sh, (int)((e >> 16) & 0xFF) << sh, F, fmax, maxv,
                         [&](int k, int v) { pix[(k - 8) * step] = (PIX)v; });
         };
-        /* ---- column edges: lane = sample row of luma (64) / of U (lanes 0..31) and V (32..63) ---- */
-        for (int p = 0; p < 16; p++) {
-            const uint32_t e = tile.tab[p * 8 + (lane >> 3)];
-            if (entry_ok(e))
-                run(tile.y + (lane + 8) * T::PY + 8, 1, p, e);
-        }
-        for (int p = 0; p < 8; p++) {
-            const uint32_t e = tile.tab[256 + p * 4 + ((lane & 31) >> 3)];
-            if (entry_ok(e))
-                run(tile.c[lane >> 5] + ((lane & 31) + 8) * T::PC + 8, 1, p, e);
+        /* ---- column edges: lane = sample row, walking its row's positions left to right by itself ---- */
+        for (int p = 0; p < NPOS; p++) {
+            const uint32_t e = tab[p * NSEG + (line >> 3)];
+            if (e >> 31)
+                run(tile[pl] + (line + 8) * P + 8, 1, p, e);
         }
         wave_sync();
         /* ---- row edges: lane = sample column ---- */
-        for (int p = 0; p < 16; p++) {
-            const uint32_t e = tile.tab[128 + p * 8 + (lane >> 3)];
-            if (entry_ok(e))
-                run(tile.y + 8 * T::PY + lane + 8, T::PY, p, e);
-        }
-        for (int p = 0; p < 8; p++) {
-            const uint32_t e = tile.tab[288 + p * 4 + ((lane & 31) >> 3)];
-            if (entry_ok(e))
-                run(tile.c[lane >> 5] + 8 * T::PC + (lane & 31) + 8, T::PC, p, e);
+        for (int p = 0; p < NPOS; p++) {
+            const uint32_t e = tab[(NPOS + p) * NSEG + (line >> 3)];
+            if (e >> 31)
+                run(tile[pl] + 8 * P + line + 8, P, p, e);
         }
         wave_sync();
-        /* ---- picture <- tile: rows 0..63 x columns -8..63 (column edges reach into the left neighbour) and rows -7..-1 x
-         *      columns 0..63 (row edges reach into the upper one); write-through ---- */
-        {
-            const int c0 = col ? -8 : 0, ndw = (wl - c0) / SPD;
-            for (int t = lane; t < hl * ndw; t += 64) {
-                const int r = t / ndw, c = c0 + (t % ndw) * SPD;
-                st_dev(ysb + (ptrdiff_t)r * sy + (ptrdiff_t)c * PS, ty32[((r + 8) * T::PY + c + 8) / SPD]);
-            }
+        /* ---- picture <- tile: rows 0..N-1 x columns -8..N-1 (column edges reach into the left neighbour) and rows -7..-1 x
+         *      columns 0..N-1 (row edges reach into the upper one); write-through ---- */
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            In::store(t32[q] + 8 * PD + D8, PD, sb[q], stride, h, w / SPD, lane);
+            if (col)
+                Left::store(t32[q] + 8 * PD, PD, sb[q] - 8 * PS, stride, h, D8, lane);
             if (row)
-                for (int t = lane; t < 7 * (wl / SPD); t += 64) {
-                    const int r = -7 + t / (wl / SPD), c = (t % (wl / SPD)) * SPD;
-                    st_dev(ysb + (ptrdiff_t)r * sy + (ptrdiff_t)c * PS, ty32[((r + 8) * T::PY + c + 8) / SPD]);
-                }
-            const int cndw = (wc - c0) / SPD;
-            for (int t = lane; t < 2 * hc * cndw; t += 64) {
-                const int p = t / (hc * cndw), u = t % (hc * cndw), r = u / cndw, c = c0 + (u % cndw) * SPD;
-                st_dev(csb[p] + (ptrdiff_t)r * suv + (ptrdiff_t)c * PS, reinterpret_cast<const uint32_t *>(tile.c[p])[((r + 8) * T::PC + c + 8) / SPD]);
-            }
-            if (row)
-                for (int t = lane; t < 2 * 7 * (wc / SPD); t += 64) {
-                    const int p = t / (7 * (wc / SPD)), u = t % (7 * (wc / SPD)), r = -7 + u / (wc / SPD), c = (u % (wc / SPD)) * SPD;
-                    st_dev(csb[p] + (ptrdiff_t)r * suv + (ptrdiff_t)c * PS, reinterpret_cast<const uint32_t *>(tile.c[p])[((r + 8) * T::PC + c + 8) / SPD]);
-                }
+                Top7::store(t32[q] + PD + D8, PD, sb[q] - 7 * stride, stride, 7, w / SPD, lane);
         }
         /* acknowledged before the counter moves */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -263,6 +297,18 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
             __hip_atomic_store(&progress[row], col + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wave_sync(); /* the tile and the tables are rewritten by the next step */
     }
+}
+
+/* blocks 0 .. sb_rows-1: luma rows (the long chain first), sb_rows .. 2 sb_rows-1: chroma rows */
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, uint8_t *pv, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
+                                                     const FFHipVp9LfSb *tabs, int *progress, int *fail, int bd)
+{
+    const int sb_rows = (rows + 7) >> 3;
+    if ((int)blockIdx.x < sb_rows)
+        vp9_lf_sb_row<PIX, false>(py, py, sy, cols, rows, blockIdx.x, tabs, progress, fail, bd);
+    else
+        vp9_lf_sb_row<PIX, true>(pu, pv, suv, cols, rows, blockIdx.x - sb_rows, tabs, progress + sb_rows, fail, bd);
 }
 
 int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
@@ -276,13 +322,13 @@ int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdif
         return FFHIP_EINVAL;
     }
     int *prog, *fail, slot;
-    const int r = ffhip_h264_wavefront_slot(sb_rows + 1, &prog, &fail, &slot, stream);
+    const int r = ffhip_h264_wavefront_slot(2 * sb_rows + 1, &prog, &fail, &slot, stream);
     if (r < 0)
         return r;
     if (bd == 8)
-        hipLaunchKernelGGL(k_vp9_lf_frame<uint8_t>, dim3(sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8);
+        hipLaunchKernelGGL(k_vp9_lf_frame<uint8_t>, dim3(2 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8);
     else
-        hipLaunchKernelGGL(k_vp9_lf_frame<uint16_t>, dim3(sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, bd);
+        hipLaunchKernelGGL(k_vp9_lf_frame<uint16_t>, dim3(2 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, bd);
     const hipError_t e = hipGetLastError();
     const int r2 = ffhip_h264_wavefront_slot_done(slot, stream);
     if (e != hipSuccess) {
