@@ -150,6 +150,13 @@ def lib():
         "ffhip_hevc_mc_batch_dev_hbd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_hevc_sao_restore_batch_dev_hbd": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_hevc_mc_w_batch_dev_hbd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, vp, C.c_ssize_t, vp, vp, C.c_int, vp]),
+        "ffhip_aac_ms_bands": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]),
+        "ffhip_aac_is_bands": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+        "ffhip_aac_ltp_bands": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+        "ffhip_aac_band_ops_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+        "ffhip_aac_ltp_init": (C.c_int, [vp, C.c_float]),
+        "ffhip_aac_ltp_predict_batch_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+        "ffhip_aac_update_ltp_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
         "ffhip_vp9_lf_sb_tables": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
         "ffhip_vp9_loopfilter_frame_dev": (C.c_int, [C.c_int, vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_vp9_itxfm_add_batch_dev_hbd": (C.c_int, [C.c_int, C.c_int, vp, vp, C.c_ssize_t, vp, C.c_int, vp]),

@@ -13,6 +13,8 @@ from . import _lib
 ONLY_LONG_SEQUENCE, LONG_START_SEQUENCE, EIGHT_SHORT_SEQUENCE, LONG_STOP_SEQUENCE = range(4)   # libavcodec/aac.h:63-68
 #: MDCT_INIT's scale_float for the 1024- and 128-point inverse transforms (aacdec.c:1267-1285)
 SCALE_1024, SCALE_128 = 2.0 ** -25, 2.0 ** -22
+#: the forward LTP transform's scale_float (aacdec.c:1288-1291)
+SCALE_LTP = -32786.0 * 2 + 36
 
 
 class AacImdct:
@@ -52,6 +54,65 @@ class AacImdct:
         return _lib.check(_lib.lib().ffhip_aac_imdct_and_windowing_batch_dev(self._c, coeffs.data_ptr(), out.data_ptr(), saved.data_ptr(),
                                                                              ws.ctypes.data, kb.ctypes.data, ps.ctypes.data, pk.ctypes.data,
                                                                              nch, nframes, stream), "ffhip_aac_imdct_and_windowing_batch_dev")
+
+
+    # -- long-term prediction (AACDecDSP.apply_ltp / update_ltp) on this context's windows and work space
+    def ltp_init(self, scale_ltp=SCALE_LTP):
+        return _lib.check(_lib.lib().ffhip_aac_ltp_init(self._c, scale_ltp), "ffhip_aac_ltp_init")
+
+    def ltp_predict(self, ltp_state, pred_freq, recs, n, stream=None):
+        """ltp_state: float32 cuda [nch, 3072]; pred_freq: float32 cuda [n, 1024] out; recs: uint8 cuda [n, 16] FFHipAacLtp"""
+        return _lib.check(_lib.lib().ffhip_aac_ltp_predict_batch_dev(self._c, ltp_state.data_ptr(), pred_freq.data_ptr(), recs.data_ptr(), n,
+                                                                     None if stream is None else C.c_void_p(stream)), "ffhip_aac_ltp_predict_batch_dev")
+
+    def update_ltp(self, ltp_state, out, nch, stream=None):
+        """after batch(): ltp_state float32 cuda [nch, 3072] in and out, out = the last frame's samples [nch, 1024]"""
+        return _lib.check(_lib.lib().ffhip_aac_update_ltp_batch_dev(self._c, ltp_state.data_ptr(), out.data_ptr(), nch,
+                                                                    None if stream is None else C.c_void_p(stream)), "ffhip_aac_update_ltp_batch_dev")
+
+
+#: FFHipAacBandOp / FFHipAacLtp (include/ffhip.h)
+BAND_OP_DTYPE = np.dtype([("frame0", np.int32), ("frame1", np.int32), ("start", np.int16), ("len", np.int16), ("scale", np.float32),
+                          ("kind", np.uint8), ("pad", np.uint8, 3)])
+LTP_DTYPE = np.dtype([("state", np.int32), ("lag", np.int16), ("seq0", np.uint8), ("kb", np.uint8), ("coef", np.float32), ("pad", np.int32)])
+BAND_MS, BAND_INTENSITY, BAND_ADD = 0, 1, 2
+
+
+def _p(a, dt):
+    a = np.ascontiguousarray(a, dt)
+    return a, a.ctypes.data
+
+
+def ms_bands(frame0, frame1, num_window_groups, group_len, max_sfb_ste, ms_mask, band_type0, band_type1, swb_offset):
+    """apply_mid_side_stereo's walk over one channel pair: numpy array of FFHipAacBandOp records"""
+    rec = np.zeros(64, BAND_OP_DTYPE)
+    keep = [_p(group_len, np.uint8), _p(ms_mask, np.uint8), _p(band_type0, np.int32), _p(band_type1, np.int32), _p(swb_offset, np.uint16)]
+    n = _lib.check(_lib.lib().ffhip_aac_ms_bands(rec.ctypes.data, frame0, frame1, num_window_groups, keep[0][1], max_sfb_ste, keep[1][1],
+                                                 keep[2][1], keep[3][1], keep[4][1]), "ffhip_aac_ms_bands")
+    return rec[:n]
+
+
+def is_bands(frame0, frame1, num_window_groups, group_len, max_sfb, ms_present, ms_mask, band_type1, sf1, swb_offset):
+    """apply_intensity_stereo's walk over one channel pair"""
+    rec = np.zeros(128, BAND_OP_DTYPE)
+    keep = [_p(group_len, np.uint8), _p(ms_mask, np.uint8), _p(band_type1, np.int32), _p(sf1, np.float32), _p(swb_offset, np.uint16)]
+    n = _lib.check(_lib.lib().ffhip_aac_is_bands(rec.ctypes.data, frame0, frame1, num_window_groups, keep[0][1], max_sfb, ms_present, keep[1][1],
+                                                 keep[2][1], keep[3][1], keep[4][1]), "ffhip_aac_is_bands")
+    return rec[:n]
+
+
+def ltp_bands(frame, pred_frame, max_sfb, used, swb_offset):
+    """the band-wise add that ends apply_ltp"""
+    rec = np.zeros(20, BAND_OP_DTYPE)
+    keep = [_p(used, np.int8), _p(swb_offset, np.uint16)]
+    n = _lib.check(_lib.lib().ffhip_aac_ltp_bands(rec.ctypes.data, frame, pred_frame, max_sfb, keep[0][1], keep[1][1]), "ffhip_aac_ltp_bands")
+    return rec[:n]
+
+
+def band_ops_batch(a, b, ops, n, stream=None):
+    """a / b: float32 cuda tensors of channel-frames [., 1024]; ops: uint8 cuda tensor [n, 20]"""
+    return _lib.check(_lib.lib().ffhip_aac_band_ops_batch_dev(a.data_ptr(), b.data_ptr(), ops.data_ptr(), n,
+                                                              None if stream is None else C.c_void_p(stream)), "ffhip_aac_band_ops_batch_dev")
 
 
 #: FFHipAacTnsFilter (include/ffhip.h)

@@ -27,7 +27,12 @@
 enum { AAC_ONLY_LONG, AAC_LONG_START, AAC_EIGHT_SHORT, AAC_LONG_STOP }; /* enum WindowSequence, libavcodec/aac.h:63-68 */
 
 struct FFHipAacImdct {
-    FFHipTXContext *tx1024 = nullptr, *tx128 = nullptr;
+    FFHipTXContext *tx1024 = nullptr, *tx128 = nullptr, *tx_ltp = nullptr;
+    float *ltp_in = nullptr;    /* [ltp_frames][2048]: the windowed predictions before the forward MDCT */
+    size_t ltp_frames = 0;
+    size_t last_n = 0;          /* the frames of the last imdct_and_windowing_batch_dev call: buf / tail / info / pos still hold them */
+    int last_nch = 0;
+    bool last_sorted = false;
     float *win = nullptr;       /* [4][1024]: sine_1024, sine_128, kbd_long_1024, kbd_short_128 */
     uint8_t *work = nullptr;    /* buf [n][1024] f32, tail [n][512] f32, sorted coeffs [n][1024] f32, pos [n] i32, info [n] u8 */
     size_t work_frames = 0;
@@ -124,6 +129,8 @@ extern "C" void ffhip_aac_imdct_free(FFHipAacImdct **pc)
     FFHipAacImdct *c = *pc;
     ffhip_tx_uninit(&c->tx1024);
     ffhip_tx_uninit(&c->tx128);
+    ffhip_tx_uninit(&c->tx_ltp);
+    if (c->ltp_in) (void)hipFree(c->ltp_in);
     if (c->win) (void)hipFree(c->win);
     if (c->work) (void)hipFree(c->work);
     delete c;
@@ -203,6 +210,7 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
         }
         c->work = nullptr;
         c->work_frames = 0;
+        c->last_n = 0;
         if (hipMalloc(&c->work, n * per + 64) != hipSuccess) {
             ffhip_set_error("ffhip_aac_imdct_and_windowing: %zu bytes of work space not available", n * per);
             return FFHIP_ENOMEM;
@@ -247,6 +255,9 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
     LAUNCH_CHECK();
     if (hipMemcpyAsync(saved, tail + (n - nch) * 512, (size_t)nch * 512 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return FFHIP_EINVAL;
+    c->last_n = n;
+    c->last_nch = nch;
+    c->last_sorted = sort;
     return 0;
 }
 
@@ -403,6 +414,289 @@ extern "C" int ffhip_aac_apply_tns_batch_dev(float *coeffs, const FFHipAacTnsFil
         hipLaunchKernelGGL(k_aac_tns<true>, dim3(cdiv(nfilters, 64)), dim3(64), 0, (hipStream_t)stream, coeffs, filters, nfilters);
     else
         hipLaunchKernelGGL(k_aac_tns<false>, dim3(cdiv(nfilters, 64)), dim3(64), 0, (hipStream_t)stream, coeffs, filters, nfilters);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+
+/* ---- AACDecDSP.apply_mid_side_stereo / apply_intensity_stereo (aacdec_dsp_template.c:83-160) and apply_ltp's final add
+ *      (:276-280): band ranges ------------------------------------------------------------------------------------------------ */
+static_assert(sizeof(FFHipAacBandOp) == 20, "FFHipAacBandOp is a 20-byte record");
+enum { AAC_NOISE_BT = 13, AAC_INTENSITY_BT2 = 14, AAC_INTENSITY_BT = 15 }; /* enum BandType, libavcodec/aac.h:66-78 */
+
+static FFHipAacBandOp band_op(int kind, int frame0, int frame1, int start, int len, float scale)
+{
+    FFHipAacBandOp r;
+    memset(&r, 0, sizeof(r));
+    r.frame0 = frame0;
+    r.frame1 = frame1;
+    r.start = (int16_t)start;
+    r.len = (int16_t)len;
+    r.scale = scale;
+    r.kind = (uint8_t)kind;
+    return r;
+}
+
+static bool aac_groups_ok(int num_window_groups, const uint8_t *group_len, int max_sfb, const char *who)
+{
+    int windows = 0;
+    for (int g = 0; g < num_window_groups && g < 8; g++)
+        windows += group_len[g];
+    if (num_window_groups < 1 || num_window_groups > 8 || windows > 8 || max_sfb < 0 || num_window_groups * max_sfb > 128) {
+        ffhip_set_error("%s: %d window groups of %d windows, max_sfb %d", who, num_window_groups, windows, max_sfb);
+        return false;
+    }
+    return true;
+}
+
+/* the walk of apply_mid_side_stereo; consecutive bands of a window that all qualify become one range (butterflies on adjacent
+ * ranges are butterflies on their union).  At most 64 records (8 windows x (max_sfb + 1) / 2 runs). */
+extern "C" int ffhip_aac_ms_bands(FFHipAacBandOp *out, int frame0, int frame1, int num_window_groups, const uint8_t *group_len, int max_sfb_ste,
+                                  const uint8_t *ms_mask, const int *band_type0, const int *band_type1, const uint16_t *swb_offset)
+{
+    if (!out || !group_len || !ms_mask || !band_type0 || !band_type1 || !swb_offset ||
+        !aac_groups_ok(num_window_groups, group_len, max_sfb_ste, "ffhip_aac_ms_bands"))
+        return FFHIP_EINVAL;
+    int n = 0, window0 = 0;
+    for (int g = 0; g < num_window_groups; g++) {
+        for (int sfb = 0; sfb < max_sfb_ste;) {
+            auto on = [&](int b) {
+                const int idx = g * max_sfb_ste + b;
+                return ms_mask[idx] && band_type0[idx] < AAC_NOISE_BT && band_type1[idx] < AAC_NOISE_BT;
+            };
+            if (!on(sfb)) {
+                sfb++;
+                continue;
+            }
+            int end = sfb + 1;
+            while (end < max_sfb_ste && on(end))
+                end++;
+            for (int w = 0; w < group_len[g]; w++)
+                out[n++] = band_op(FFHIP_AAC_BAND_MS, frame0, frame1, (window0 + w) * 128 + swb_offset[sfb], swb_offset[end] - swb_offset[sfb], 0.0f);
+            sfb = end;
+        }
+        window0 += group_len[g];
+    }
+    return n;
+}
+
+/* the walk of apply_intensity_stereo: one record per intensity band and window (<= 128) */
+extern "C" int ffhip_aac_is_bands(FFHipAacBandOp *out, int frame0, int frame1, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                                  int ms_present, const uint8_t *ms_mask, const int *band_type1, const float *sf1, const uint16_t *swb_offset)
+{
+    if (!out || !group_len || !ms_mask || !band_type1 || !sf1 || !swb_offset ||
+        !aac_groups_ok(num_window_groups, group_len, max_sfb, "ffhip_aac_is_bands"))
+        return FFHIP_EINVAL;
+    int n = 0, window0 = 0;
+    for (int g = 0; g < num_window_groups; g++) {
+        for (int sfb = 0; sfb < max_sfb; sfb++) {
+            const int idx = g * max_sfb + sfb;
+            if (band_type1[idx] != AAC_INTENSITY_BT && band_type1[idx] != AAC_INTENSITY_BT2)
+                continue;
+            int c = -1 + 2 * (band_type1[idx] - 14);
+            if (ms_present)
+                c *= 1 - 2 * ms_mask[idx];
+            const float scale = c * sf1[idx];
+            for (int w = 0; w < group_len[g]; w++)
+                out[n++] = band_op(FFHIP_AAC_BAND_INTENSITY, frame0, frame1, (window0 + w) * 128 + swb_offset[sfb],
+                                   swb_offset[sfb + 1] - swb_offset[sfb], scale);
+        }
+        window0 += group_len[g];
+    }
+    return n;
+}
+
+/* apply_ltp's last loop: coeffs[frame] += predFreq[pred_frame] on the used bands below min(max_sfb, MAX_LTP_LONG_SFB); runs of
+ * used bands merged (<= 20 records) */
+extern "C" int ffhip_aac_ltp_bands(FFHipAacBandOp *out, int frame, int pred_frame, int max_sfb, const int8_t *used, const uint16_t *swb_offset)
+{
+    if (!out || !used || !swb_offset || max_sfb < 0)
+        return FFHIP_EINVAL;
+    const int lim = max_sfb < 40 ? max_sfb : 40;
+    int n = 0;
+    for (int sfb = 0; sfb < lim;) {
+        if (!used[sfb]) {
+            sfb++;
+            continue;
+        }
+        int end = sfb + 1;
+        while (end < lim && used[end])
+            end++;
+        out[n++] = band_op(FFHIP_AAC_BAND_ADD, frame, pred_frame, swb_offset[sfb], swb_offset[end] - swb_offset[sfb], 0.0f);
+        sfb = end;
+    }
+    return n;
+}
+
+/* one wave per record; each element is the reference's own one or two float operations */
+__global__ __launch_bounds__(256) void k_aac_band_ops(float *a, float *b, const FFHipAacBandOp *ops, int n)
+{
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= n)
+        return;
+    const FFHipAacBandOp op = ops[o];
+    float *pa = a + (size_t)op.frame0 * 1024 + op.start, *pb = b + (size_t)op.frame1 * 1024 + op.start;
+    for (int i = lane; i < op.len; i += 64) {
+        const float x = pa[i], y = pb[i];
+        if (op.kind == FFHIP_AAC_BAND_MS) {
+            pa[i] = x + y;
+            pb[i] = x - y;
+        } else if (op.kind == FFHIP_AAC_BAND_INTENSITY) {
+            pb[i] = x * op.scale;
+        } else {
+            pa[i] = x + y;
+        }
+    }
+}
+
+extern "C" int ffhip_aac_band_ops_batch_dev(float *a, float *b, const FFHipAacBandOp *ops, int n, void *stream)
+{
+    if (!a || !b || !ops || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    if (!n)
+        return 0;
+    hipLaunchKernelGGL(k_aac_band_ops, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, a, b, ops, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/* ---- AACDecDSP.apply_ltp's prediction (aacdec_dsp_template.c:252-272 with windowing_and_mdct_ltp, :225-247) ------------------- */
+static_assert(sizeof(FFHipAacLtp) == 16, "FFHipAacLtp is a 16-byte record");
+
+/* in[r][0..2047]: the delayed, scaled, windowed state; one thread = 4 samples (every region border is a multiple of 4) */
+__global__ __launch_bounds__(256) void k_aac_ltp_window(const float *ltp_state, const FFHipAacLtp *recs, const float *win, float *in)
+{
+    const FFHipAacLtp r = recs[blockIdx.x];
+    const float *st = ltp_state + (size_t)r.state * 3072;
+    const int kb0 = r.kb & 1, kb1 = (r.kb >> 1) & 1;
+    const float *lwindow = win + (kb0 ? 2 : 0) * 1024, *swindow = win + (kb0 ? 3 : 1) * 1024;
+    const float *lwindow_prev = win + (kb1 ? 2 : 0) * 1024, *swindow_prev = win + (kb1 ? 3 : 1) * 1024;
+    const int num_samples = r.lag < 1024 ? r.lag + 1024 : 2048;
+    float *dst = in + (size_t)blockIdx.x * 2048;
+    for (int s = 4 * threadIdx.x; s < 2048; s += 1024) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = s + k;
+            float x = i < num_samples ? st[i + 2048 - r.lag] * r.coef : 0.0f;
+            if (i < 1024) {
+                if (r.seq0 != AAC_LONG_STOP)
+                    x = x * lwindow_prev[i];
+                else if (i < 448)
+                    x = 0.0f;
+                else if (i < 576)
+                    x = x * swindow_prev[i - 448];
+            } else {
+                const int j = i - 1024;
+                if (r.seq0 != AAC_LONG_START)
+                    x = x * lwindow[1023 - j];
+                else if (j >= 576)
+                    x = 0.0f;
+                else if (j >= 448)
+                    x = x * swindow[127 - (j - 448)];
+            }
+            v[k] = x;
+        }
+        *reinterpret_cast<float4 *>(dst + s) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+extern "C" int ffhip_aac_ltp_init(FFHipAacImdct *c, float scale_ltp)
+{
+    if (!c)
+        return FFHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    ffhip_tx_uninit(&c->tx_ltp);
+    return ffhip_tx_init(&c->tx_ltp, nullptr, FFHIP_TX_FLOAT_MDCT, 0, 1024, &scale_ltp, 0);
+}
+
+extern "C" int ffhip_aac_ltp_predict_batch_dev(FFHipAacImdct *c, const float *ltp_state, float *pred_freq, const FFHipAacLtp *recs, int n,
+                                               void *stream)
+{
+    if (!c || !ltp_state || !pred_freq || !recs || n < 0)
+        return FFHIP_EINVAL;
+    if (!n)
+        return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->tx_ltp) {
+        ffhip_set_error("ffhip_aac_ltp_predict: ffhip_aac_ltp_init() has not created the forward MDCT");
+        return FFHIP_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)n > c->ltp_frames) {
+        if (c->ltp_in) {
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(c->ltp_in);
+        }
+        c->ltp_in = nullptr;
+        c->ltp_frames = 0;
+        if (hipMalloc(&c->ltp_in, (size_t)n * 2048 * sizeof(float)) != hipSuccess) {
+            ffhip_set_error("ffhip_aac_ltp_predict: %zu bytes of work space not available", (size_t)n * 2048 * sizeof(float));
+            return FFHIP_ENOMEM;
+        }
+        c->ltp_frames = n;
+    }
+    hipLaunchKernelGGL(k_aac_ltp_window, dim3(n), dim3(256), 0, st, ltp_state, recs, c->win, c->ltp_in);
+    LAUNCH_CHECK();
+    return ffhip_tx_batch_dev(c->tx_ltp, pred_freq, 4096, c->ltp_in, 8192, sizeof(float), n, stream);
+}
+
+/* ---- AACDecDSP.update_ltp (aacdec_dsp_template.c:287-320) on the frames the last imdct_and_windowing_batch_dev call ended with:
+ *      their inverse-MDCT output (ac->buf_mdct) and overlap state are still in the context's work space -------------------------- */
+__global__ __launch_bounds__(256) void k_aac_update_ltp(const float *buf, const int *pos, const uint8_t *info, const float *win, const float *tail,
+                                                        int first, const float *out, float *ltp_state)
+{
+    const int ch = blockIdx.x, f = first + ch;
+    const float *b = buf + (size_t)(pos ? pos[f] : f) * 1024, *sv = tail + (size_t)f * 512, *o = out + (size_t)ch * 1024;
+    float *st = ltp_state + (size_t)ch * 3072;
+    const int in = info[f], seq = in & 3, kb = (in >> 2) & 1;
+    const float *lwindow = win + (kb ? 2 : 0) * 1024, *swindow = win + (kb ? 3 : 1) * 1024;
+    const int s = 4 * threadIdx.x;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = s + k;
+        float x;
+        if (seq == AAC_EIGHT_SHORT || seq == AAC_LONG_START) {
+            if (i < 448)
+                x = seq == AAC_EIGHT_SHORT ? sv[i] : b[512 + i];
+            else if (i < 512)
+                x = b[960 + (i - 448)] * swindow[64 + 63 - (i - 448)];
+            else if (i < 576)
+                x = b[1023 - (i - 512)] * swindow[63 - (i - 512)];
+            else
+                x = 0.0f;
+        } else {
+            x = i < 512 ? b[512 + i] * lwindow[512 + 511 - i] : b[1023 - (i - 512)] * lwindow[511 - (i - 512)];
+        }
+        v[k] = x;
+    }
+    const float4 mid = aac_ld4(st + 1024 + s), now = aac_ld4(o + s);
+    *reinterpret_cast<float4 *>(st + s) = mid;
+    *reinterpret_cast<float4 *>(st + 1024 + s) = now;
+    *reinterpret_cast<float4 *>(st + 2048 + s) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+extern "C" int ffhip_aac_update_ltp_batch_dev(FFHipAacImdct *c, float *ltp_state, const float *out, int nch, void *stream)
+{
+    if (!c || !ltp_state || !out || nch <= 0)
+        return FFHIP_EINVAL;
+    if (((uintptr_t)ltp_state | (uintptr_t)out) & 15) {
+        ffhip_set_error("ffhip_aac_update_ltp: ltp_state and out must be 16-byte aligned");
+        return FFHIP_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->last_n || c->last_nch != nch) {
+        ffhip_set_error("ffhip_aac_update_ltp: follows an imdct_and_windowing_batch_dev call of the same %d channels on this context", nch);
+        return FFHIP_EINVAL;
+    }
+    const float *buf = (const float *)c->work, *tail = buf + c->work_frames * 1024, *sorted = tail + c->work_frames * 512;
+    const int *dpos = (const int *)(sorted + c->work_frames * 1024);
+    const uint8_t *dinfo = (const uint8_t *)(dpos + c->work_frames);
+    hipLaunchKernelGGL(k_aac_update_ltp, dim3(nch), dim3(256), 0, (hipStream_t)stream, buf, c->last_sorted ? dpos : nullptr, dinfo, c->win, tail,
+                       (int)(c->last_n - nch), out, ltp_state);
     LAUNCH_CHECK();
     return 0;
 }

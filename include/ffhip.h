@@ -556,6 +556,57 @@ int ffhip_aac_tns_filters(FFHipAacTnsFilter *out, int frame, const int n_filt[8]
  *  filters of a frame cover disjoint ranges, so all of them run concurrently. */
 int ffhip_aac_apply_tns_batch_dev(float *coeffs, const FFHipAacTnsFilter *filters, int nfilters, int decode, void *stream);
 
+/** AACDecDSP.apply_mid_side_stereo / apply_intensity_stereo (aacdec_dsp_template.c:83-160), float, and the band-wise add that ends
+ *  apply_ltp (:276-280): one record per range of coefficients.  The host walks (window groups, scalefactor bands, band types, the
+ *  M/S mask — the fields decode_cpe / decode_ics leave in ChannelElement / IndividualChannelStream) produce the records; the ranges
+ *  of one channel pair are disjoint (M/S bands have band_type < NOISE_BT, intensity bands 14 / 15), so a pair's M/S and intensity
+ *  records — and any number of pairs — run in one launch. */
+enum { FFHIP_AAC_BAND_MS = 0,         /* butterflies_float: a, b = a + b, a - b          (libavutil/float_dsp.c:112-122) */
+       FFHIP_AAC_BAND_INTENSITY = 1,  /* vector_fmul_scalar: b = a * scale               (libavutil/float_dsp.c:45-51)   */
+       FFHIP_AAC_BAND_ADD = 2 };      /* a += b                                          (apply_ltp's last loop)         */
+typedef struct FFHipAacBandOp {
+    int32_t frame0;     /* a = base_a + frame0 * 1024 + start */
+    int32_t frame1;     /* b = base_b + frame1 * 1024 + start */
+    int16_t start, len;
+    float   scale;
+    uint8_t kind;
+    uint8_t pad[3];     /* sizeof == 20 */
+} FFHipAacBandOp;
+/** apply_mid_side_stereo's walk: cpe->ch[0].ics grouping, cpe->max_sfb_ste, cpe->ms_mask, both channels' band_type (enum BandType
+ *  as int, 128 entries each).  Writes at most 64 records, returns their number. */
+int ffhip_aac_ms_bands(FFHipAacBandOp *out, int frame0, int frame1, int num_window_groups, const uint8_t *group_len, int max_sfb_ste,
+                       const uint8_t *ms_mask, const int *band_type0, const int *band_type1, const uint16_t *swb_offset);
+/** apply_intensity_stereo's walk: cpe->ch[1].ics grouping and max_sfb, ms_present, cpe->ms_mask, ch[1].band_type and ch[1].sf.
+ *  At most 128 records. */
+int ffhip_aac_is_bands(FFHipAacBandOp *out, int frame0, int frame1, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                       int ms_present, const uint8_t *ms_mask, const int *band_type1, const float *sf1, const uint16_t *swb_offset);
+/** apply_ltp's last loop: coeffs[frame] += predFreq[pred_frame] on ltp->used bands below min(max_sfb, MAX_LTP_LONG_SFB).  At most
+ *  20 records. */
+int ffhip_aac_ltp_bands(FFHipAacBandOp *out, int frame, int pred_frame, int max_sfb, const int8_t *used, const uint16_t *swb_offset);
+/** The records of a batch on device arrays a / b of channel-frames (1024 floats each; the same array for the stereo tools,
+ *  coeffs / predFreq for the LTP add); ops is a device array. */
+int ffhip_aac_band_ops_batch_dev(float *a, float *b, const FFHipAacBandOp *ops, int n, void *stream);
+
+/** AACDecDSP.apply_ltp (aacdec_dsp_template.c:252-282) as its three steps: (1) ffhip_aac_ltp_predict_batch_dev — the delayed state
+ *  times ltp->coef, windowing_and_mdct_ltp (:225-247) and the forward 1024-point MDCT (created by ffhip_aac_ltp_init with the scale
+ *  ff_aac_decode_init gives it, aacdec.c:1288-1291) -> predFreq; (2) ffhip_aac_apply_tns_batch_dev(predFreq, filters, n, 0) when
+ *  the channel has TNS; (3) ffhip_aac_band_ops_batch_dev with ffhip_aac_ltp_bands' records.  A frame's prediction needs the
+ *  previous frame's output, so a batch is one frame of many channels / streams, not many frames of one. */
+typedef struct FFHipAacLtp {
+    int32_t state;      /* the channel: ltp_state + state * 3072 */
+    int16_t lag;        /* LongTermPrediction.lag (0..2047) */
+    uint8_t seq0;       /* ics.window_sequence[0]; never EIGHT_SHORT_SEQUENCE (apply_ltp does nothing there: send no record) */
+    uint8_t kb;         /* ics.use_kb_window[0] | use_kb_window[1] << 1 */
+    float   coef;       /* LongTermPrediction.coef */
+    int32_t pad;        /* sizeof == 16; record r writes pred_freq + r * 1024 */
+} FFHipAacLtp;
+int ffhip_aac_ltp_init(FFHipAacImdct *c, float scale_ltp);
+int ffhip_aac_ltp_predict_batch_dev(FFHipAacImdct *c, const float *ltp_state, float *pred_freq, const FFHipAacLtp *recs, int n, void *stream);
+/** AACDecDSP.update_ltp (aacdec_dsp_template.c:287-320) for the nch channels whose frame the preceding
+ *  ffhip_aac_imdct_and_windowing_batch_dev call on this context ended with (its inverse-MDCT output — ac->buf_mdct — and overlap
+ *  state are still in the context): ltp_state [nch][3072] in and out, out [nch][1024] = that frame's output samples. */
+int ffhip_aac_update_ltp_batch_dev(FFHipAacImdct *c, float *ltp_state, const float *out, int nch, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: H264PredContext — H.264 codec, 8 bits, chroma_format_idc <= 1 */
 /* ------------------------------------------------------------------------------------------ */

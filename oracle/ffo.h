@@ -208,6 +208,16 @@ typedef struct FfoAacTnsFilter { int start, size, inc, order; float coef[20]; } 
 int  ffo_aac_tns_filters(FfoAacTnsFilter *out, const int n_filt[8], const int length[8][4], const int direction[8][4], const int order[8][4],
                          const float coef[8][4][20], int num_windows, int num_swb, const uint16_t *swb_offset, int tns_max_bands, int max_sfb);
 void ffo_aac_tns_run(float *coef, const FfoAacTnsFilter *r, int decode);
+/* ---- ffo_aac.c: the stereo tools and long-term prediction of AACDecDSP, float (aacdec_dsp_template.c:83-160,225-320) ---- */
+void ffo_aac_apply_mid_side_stereo(float *ch0, float *ch1, int num_window_groups, const uint8_t *group_len, int max_sfb_ste,
+                                   const uint8_t *ms_mask, const int *band_type0, const int *band_type1, const uint16_t *swb_offset);
+void ffo_aac_apply_intensity_stereo(const float *coef0, float *coef1, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                                    int ms_present, const uint8_t *ms_mask, const int *band_type1, const float *sf1, const uint16_t *swb_offset);
+void ffo_aac_apply_ltp(const FfoTx *mdct_ltp, const float *const windows[4], float *coeffs, const float *ltp_state, int lag, float coef,
+                       const int8_t *used, const int seq[2], const int kb[2], int max_sfb, const uint16_t *swb_offset,
+                       const FfoAacTnsFilter *tns, int ntns, float *predFreq);
+void ffo_aac_update_ltp(const float *const windows[4], float *ltp_state, const float *buf_mdct, const float *saved, const float *output,
+                        int seq0, int kb0);
 /* ---- ffo_aac.c: AACDecDSP.imdct_and_windowing, float, 1024-sample frames (libavcodec/aac/aacdec_dsp_template.c:325-387) ---- */
 void ffo_aac_sine_window(float *w, int n);
 void ffo_aac_kbd_window(float *w, float alpha, int n);

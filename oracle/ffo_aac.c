@@ -158,3 +158,118 @@ void ffo_aac_tns_run(float *coef, const FfoAacTnsFilter *r, int decode)
             hist[i] = hist[i - 1];
     }
 }
+
+/*
+ * The stereo tools and long-term prediction of AACDecDSP, float (test infrastructure like the rest of this file).
+ */
+
+/* AACDecDSP.apply_mid_side_stereo (aacdec_dsp_template.c:83-111); the band loop body is AVFloatDSPContext.butterflies_float
+ * (libavutil/float_dsp.c:112-122).  band_type*: enum BandType per (group, sfb) (libavcodec/aac.h:66-78: NOISE_BT = 13) */
+void ffo_aac_apply_mid_side_stereo(float *ch0, float *ch1, int num_window_groups, const uint8_t *group_len, int max_sfb_ste,
+                                   const uint8_t *ms_mask, const int *band_type0, const int *band_type1, const uint16_t *swb_offset)
+{
+    for (int g = 0; g < num_window_groups; g++) {
+        for (int sfb = 0; sfb < max_sfb_ste; sfb++) {
+            const int idx = g * max_sfb_ste + sfb;
+            if (!ms_mask[idx] || band_type0[idx] >= 13 || band_type1[idx] >= 13)
+                continue;
+            for (int w = 0; w < group_len[g]; w++)
+                for (int i = swb_offset[sfb]; i < swb_offset[sfb + 1]; i++) {
+                    float *a = ch0 + w * 128 + i, *b = ch1 + w * 128 + i;
+                    const float t = *a - *b;
+                    *a += *b;
+                    *b = t;
+                }
+        }
+        ch0 += group_len[g] * 128;
+        ch1 += group_len[g] * 128;
+    }
+}
+
+/* AACDecDSP.apply_intensity_stereo (aacdec_dsp_template.c:120-160): INTENSITY_BT2 = 14 (out of phase), INTENSITY_BT = 15; the band
+ * loop body is vector_fmul_scalar (libavutil/float_dsp.c:45-51) */
+void ffo_aac_apply_intensity_stereo(const float *coef0, float *coef1, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                                    int ms_present, const uint8_t *ms_mask, const int *band_type1, const float *sf1, const uint16_t *swb_offset)
+{
+    for (int g = 0; g < num_window_groups; g++) {
+        for (int sfb = 0; sfb < max_sfb; sfb++) {
+            const int idx = g * max_sfb + sfb;
+            if (band_type1[idx] != 14 && band_type1[idx] != 15)
+                continue;
+            int c = -1 + 2 * (band_type1[idx] - 14);
+            if (ms_present)
+                c *= 1 - 2 * ms_mask[idx];
+            const float scale = c * sf1[idx];
+            for (int w = 0; w < group_len[g]; w++)
+                for (int i = swb_offset[sfb]; i < swb_offset[sfb + 1]; i++)
+                    coef1[w * 128 + i] = coef0[w * 128 + i] * scale;
+        }
+        coef0 += group_len[g] * 128;
+        coef1 += group_len[g] * 128;
+    }
+}
+
+/* AACDecDSP.apply_ltp (aacdec_dsp_template.c:252-282) with windowing_and_mdct_ltp (:225-247) inlined; mdct_ltp: the forward
+ * 1024-point MDCT of ff_aac_decode_init (aacdec.c:1288-1291); tns: the channel's filter records (ffo_aac_tns_filters), ntns = 0
+ * when sce->tns.present is 0; predFreq[1024] is handed back for inspection */
+void ffo_aac_apply_ltp(const FfoTx *mdct_ltp, const float *const windows[4], float *coeffs, const float *ltp_state, int lag, float coef,
+                       const int8_t *used, const int seq[2], const int kb[2], int max_sfb, const uint16_t *swb_offset,
+                       const FfoAacTnsFilter *tns, int ntns, float *predFreq)
+{
+    if (seq[0] == EIGHT_SHORT)
+        return;
+    const float *lwindow = windows[kb[0] ? 2 : 0], *swindow = windows[kb[0] ? 3 : 1];
+    const float *lwindow_prev = windows[kb[1] ? 2 : 0], *swindow_prev = windows[kb[1] ? 3 : 1];
+    float in[2048];
+    const int num_samples = lag < 1024 ? lag + 1024 : 2048;
+    for (int i = 0; i < 2048; i++)
+        in[i] = i < num_samples ? ltp_state[i + 2048 - lag] * coef : 0.0f;
+    if (seq[0] != LONG_STOP) {
+        for (int i = 0; i < 1024; i++)
+            in[i] = in[i] * lwindow_prev[i];
+    } else {
+        memset(in, 0, 448 * sizeof(float));
+        for (int i = 0; i < 128; i++)
+            in[448 + i] = in[448 + i] * swindow_prev[i];
+    }
+    if (seq[0] != LONG_START) {
+        for (int i = 0; i < 1024; i++)
+            in[1024 + i] = in[1024 + i] * lwindow[1023 - i];
+    } else {
+        for (int i = 0; i < 128; i++)
+            in[1024 + 448 + i] = in[1024 + 448 + i] * swindow[127 - i];
+        memset(in + 1024 + 576, 0, 448 * sizeof(float));
+    }
+    ffo_mdct_run(mdct_ltp, predFreq, in, sizeof(float));
+    for (int k = 0; k < ntns; k++)
+        ffo_aac_tns_run(predFreq, &tns[k], 0);
+    for (int sfb = 0; sfb < (max_sfb < 40 ? max_sfb : 40); sfb++)
+        if (used[sfb])
+            for (int i = swb_offset[sfb]; i < swb_offset[sfb + 1]; i++)
+                coeffs[i] += predFreq[i];
+}
+
+/* AACDecDSP.update_ltp (aacdec_dsp_template.c:287-320): buf_mdct = the frame's inverse-MDCT output (ac->buf_mdct after
+ * imdct_and_windowing), saved / output = the channel's overlap state and samples after it; ltp_state[3072] in and out */
+void ffo_aac_update_ltp(const float *const windows[4], float *ltp_state, const float *buf_mdct, const float *saved, const float *output,
+                        int seq0, int kb0)
+{
+    const float *lwindow = windows[kb0 ? 2 : 0], *swindow = windows[kb0 ? 3 : 1];
+    float saved_ltp[1024];
+    if (seq0 == EIGHT_SHORT || seq0 == LONG_START) {
+        memcpy(saved_ltp, seq0 == EIGHT_SHORT ? saved : buf_mdct + 512, (seq0 == EIGHT_SHORT ? 512 : 448) * sizeof(float));
+        memset(saved_ltp + 576, 0, 448 * sizeof(float));
+        for (int i = 0; i < 64; i++)
+            saved_ltp[448 + i] = buf_mdct[960 + i] * swindow[64 + 63 - i];
+        for (int i = 0; i < 64; i++)
+            saved_ltp[512 + i] = buf_mdct[1023 - i] * swindow[63 - i];
+    } else {
+        for (int i = 0; i < 512; i++)
+            saved_ltp[i] = buf_mdct[512 + i] * lwindow[512 + 511 - i];
+        for (int i = 0; i < 512; i++)
+            saved_ltp[512 + i] = buf_mdct[1023 - i] * lwindow[511 - i];
+    }
+    memmove(ltp_state, ltp_state + 1024, 1024 * sizeof(float));
+    memcpy(ltp_state + 1024, output, 1024 * sizeof(float));
+    memcpy(ltp_state + 2048, saved_ltp, 1024 * sizeof(float));
+}

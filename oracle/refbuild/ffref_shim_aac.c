@@ -94,3 +94,124 @@ int ffref_aac_apply_tns(float *coef, const int n_filt[8], const int length[8][4]
     ac->dsp.apply_tns(coef, &tns, &ics, decode);
     return 0;
 }
+
+/* ---- the stereo tools and long-term prediction (AACDecDSP.apply_mid_side_stereo / apply_intensity_stereo / apply_ltp /
+ *      update_ltp): the members run on a ChannelElement filled in from flat arguments ---- */
+static ChannelElement *cpe_scratch(void)
+{
+    static ChannelElement *cpe;
+    if (!cpe)
+        cpe = av_mallocz(sizeof(*cpe));
+    return cpe;
+}
+
+static void ics_groups(IndividualChannelStream *ics, int num_window_groups, const uint8_t *group_len, int max_sfb, const uint16_t *swb_offset)
+{
+    ics->num_window_groups = num_window_groups;
+    memcpy(ics->group_len, group_len, num_window_groups);
+    ics->max_sfb = max_sfb;
+    ics->swb_offset = swb_offset;
+}
+
+int ffref_aac_apply_mid_side_stereo(float *ch0, float *ch1, int num_window_groups, const uint8_t *group_len, int max_sfb_ste,
+                                    const uint8_t *ms_mask, const int *band_type0, const int *band_type1, const uint16_t *swb_offset)
+{
+    AACDecContext *ac = aac();
+    ChannelElement *cpe = cpe_scratch();
+    if (!ac || !cpe)
+        return -1;
+    ics_groups(&cpe->ch[0].ics, num_window_groups, group_len, max_sfb_ste, swb_offset);
+    cpe->max_sfb_ste = max_sfb_ste;
+    memcpy(cpe->ms_mask, ms_mask, 128);
+    for (int i = 0; i < 128; i++) {
+        cpe->ch[0].band_type[i] = band_type0[i];
+        cpe->ch[1].band_type[i] = band_type1[i];
+    }
+    memcpy(cpe->ch[0].coeffs, ch0, 1024 * sizeof(float));
+    memcpy(cpe->ch[1].coeffs, ch1, 1024 * sizeof(float));
+    ac->dsp.apply_mid_side_stereo(ac, cpe);
+    memcpy(ch0, cpe->ch[0].coeffs, 1024 * sizeof(float));
+    memcpy(ch1, cpe->ch[1].coeffs, 1024 * sizeof(float));
+    return 0;
+}
+
+int ffref_aac_apply_intensity_stereo(const float *coef0, float *coef1, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                                     int ms_present, const uint8_t *ms_mask, const int *band_type1, const float *sf1,
+                                     const uint16_t *swb_offset)
+{
+    AACDecContext *ac = aac();
+    ChannelElement *cpe = cpe_scratch();
+    if (!ac || !cpe)
+        return -1;
+    ics_groups(&cpe->ch[1].ics, num_window_groups, group_len, max_sfb, swb_offset);
+    memcpy(cpe->ms_mask, ms_mask, 128);
+    for (int i = 0; i < 128; i++)
+        cpe->ch[1].band_type[i] = band_type1[i];
+    memcpy(cpe->ch[1].sf, sf1, 128 * sizeof(float));
+    memcpy(cpe->ch[0].coeffs, coef0, 1024 * sizeof(float));
+    memcpy(cpe->ch[1].coeffs, coef1, 1024 * sizeof(float));
+    ac->dsp.apply_intensity_stereo(ac, cpe, ms_present);
+    memcpy(coef1, cpe->ch[1].coeffs, 1024 * sizeof(float));
+    return 0;
+}
+
+/* tns_present = 0: no TNS on the prediction; otherwise the TemporalNoiseShaping arrays as in ffref_aac_apply_tns */
+int ffref_aac_apply_ltp(float *coeffs, const float *ltp_state, int lag, float coef, const int8_t *used, const int seq[2], const int kb[2],
+                        int max_sfb, int num_swb, int tns_max_bands, const uint16_t *swb_offset, int tns_present, const int n_filt[8],
+                        const int length[8][4], const int direction[8][4], const int order[8][4], const float tcoef[8][4][20], float *predFreq)
+{
+    AACDecContext *ac = aac();
+    SingleChannelElement *sce = &cpe_scratch()->ch[0];
+    if (!ac)
+        return -1;
+    if (!ac->mdct_ltp) {
+        float s = -32786.0 * 2 + 36; /* ff_aac_decode_init's scale_float for the LTP transform (aacdec.c:1288-1291) */
+        if (av_tx_init(&ac->mdct_ltp, &ac->mdct_ltp_fn, AV_TX_FLOAT_MDCT, 0, 1024, &s, 0) < 0)
+            return -1;
+    }
+    memset(&sce->ics, 0, sizeof(sce->ics));
+    sce->ics.window_sequence[0] = seq[0]; sce->ics.window_sequence[1] = seq[1];
+    sce->ics.use_kb_window[0] = kb[0];    sce->ics.use_kb_window[1] = kb[1];
+    sce->ics.max_sfb = max_sfb;
+    sce->ics.num_swb = num_swb;
+    sce->ics.num_windows = 1;
+    sce->ics.tns_max_bands = tns_max_bands;
+    sce->ics.swb_offset = swb_offset;
+    sce->ics.ltp.present = 1;
+    sce->ics.ltp.lag = lag;
+    sce->ics.ltp.coef = coef;
+    memcpy(sce->ics.ltp.used, used, MAX_LTP_LONG_SFB);
+    sce->tns.present = tns_present;
+    if (tns_present) {
+        memcpy(sce->tns.n_filt, n_filt, sizeof(sce->tns.n_filt));
+        memcpy(sce->tns.length, length, sizeof(sce->tns.length));
+        memcpy(sce->tns.direction, direction, sizeof(sce->tns.direction));
+        memcpy(sce->tns.order, order, sizeof(sce->tns.order));
+        memcpy(sce->tns.coef, tcoef, sizeof(sce->tns.coef));
+    }
+    memcpy(sce->coeffs, coeffs, 1024 * sizeof(float));
+    memcpy(sce->ltp_state, ltp_state, 3072 * sizeof(float));
+    sce->output = sce->ret_buf;
+    ac->dsp.apply_ltp(ac, sce);
+    memcpy(coeffs, sce->coeffs, 1024 * sizeof(float));
+    memcpy(predFreq, ac->buf_mdct, 1024 * sizeof(float));
+    return 0;
+}
+
+int ffref_aac_update_ltp(float *ltp_state, const float *buf_mdct, const float *saved, const float *output, int seq0, int kb0)
+{
+    AACDecContext *ac = aac();
+    SingleChannelElement *sce = &cpe_scratch()->ch[0];
+    if (!ac)
+        return -1;
+    sce->ics.window_sequence[0] = seq0;
+    sce->ics.use_kb_window[0] = kb0;
+    memcpy(ac->buf_mdct, buf_mdct, 1024 * sizeof(float));
+    memcpy(sce->saved, saved, 512 * sizeof(float));
+    sce->output = sce->ret_buf;
+    memcpy(sce->output, output, 1024 * sizeof(float));
+    memcpy(sce->ltp_state, ltp_state, 3072 * sizeof(float));
+    ac->dsp.update_ltp(ac, sce);
+    memcpy(ltp_state, sce->ltp_state, 3072 * sizeof(float));
+    return 0;
+}

@@ -120,6 +120,16 @@ def oracle():
         L.ffo_aac_tns_filters.restype = C.c_int
         L.ffo_aac_tns_run.argtypes = [f32p, C.c_void_p, C.c_int]
         L.ffo_aac_tns_run.restype = None
+        u16p_ = C.POINTER(C.c_uint16)
+        L.ffo_aac_apply_mid_side_stereo.argtypes = [f32p, f32p, C.c_int, u8p, C.c_int, u8p, i32p, i32p, u16p_]
+        L.ffo_aac_apply_mid_side_stereo.restype = None
+        L.ffo_aac_apply_intensity_stereo.argtypes = [f32p, f32p, C.c_int, u8p, C.c_int, C.c_int, u8p, i32p, f32p, u16p_]
+        L.ffo_aac_apply_intensity_stereo.restype = None
+        L.ffo_aac_apply_ltp.argtypes = [C.c_void_p, C.POINTER(f32p), f32p, f32p, C.c_int, C.c_float, C.POINTER(C.c_int8), i32p, i32p, C.c_int, u16p_,
+                                        C.c_void_p, C.c_int, f32p]
+        L.ffo_aac_apply_ltp.restype = None
+        L.ffo_aac_update_ltp.argtypes = [C.POINTER(f32p), f32p, f32p, f32p, f32p, C.c_int, C.c_int]
+        L.ffo_aac_update_ltp.restype = None
         L.ffo_fdsp.argtypes = [C.c_int, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
         L.ffo_fdsp.restype = None
         L.ffo_h264_hl_decode_intra_mb.argtypes = [u8p, u8p, u8p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, C.c_int, u8p, C.c_uint, C.c_uint,
@@ -302,6 +312,17 @@ def ref():
         L.ffref_aac_imdct_and_windowing.restype = C.c_int
         L.ffref_aac_apply_tns.argtypes = [f32p, i32p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int]
         L.ffref_aac_apply_tns.restype = C.c_int
+        if hasattr(L, "ffref_aac_apply_ltp"):
+            u16p_ = C.POINTER(C.c_uint16)
+            L.ffref_aac_apply_mid_side_stereo.argtypes = [f32p, f32p, C.c_int, u8p, C.c_int, u8p, i32p, i32p, u16p_]
+            L.ffref_aac_apply_mid_side_stereo.restype = C.c_int
+            L.ffref_aac_apply_intensity_stereo.argtypes = [f32p, f32p, C.c_int, u8p, C.c_int, C.c_int, u8p, i32p, f32p, u16p_]
+            L.ffref_aac_apply_intensity_stereo.restype = C.c_int
+            L.ffref_aac_apply_ltp.argtypes = [f32p, f32p, C.c_int, C.c_float, C.POINTER(C.c_int8), i32p, i32p, C.c_int, C.c_int, C.c_int, u16p_, C.c_int,
+                                              i32p, i32p, i32p, i32p, f32p, f32p]
+            L.ffref_aac_apply_ltp.restype = C.c_int
+            L.ffref_aac_update_ltp.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int]
+            L.ffref_aac_update_ltp.restype = C.c_int
         L.ffref_h264_pred4x4.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t]
         L.ffref_h264_pred8x8l.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_ssize_t]
         L.ffref_h264_pred8x8.argtypes = [C.c_int, u8p, C.c_ssize_t]

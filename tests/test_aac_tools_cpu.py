@@ -1,0 +1,156 @@
+"""AACDecDSP's stereo tools and long-term prediction, CPU side: the oracle's restatements
+(oracle/ffo_aac.c) against the reference's own members run in place (oracle/_ref: aacdec_dsp_template.c:83-160,225-320 through
+ff_aac_decode_init_float's dsp table) — bit-identical."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import ptr, f32p, i32p, u8p
+import aac_gen as A
+from test_oracle_vs_ref import aac_tns_case, aac_tns_filters
+
+u16p = C.POINTER(C.c_uint16)
+i8p = C.POINTER(C.c_int8)
+
+
+def _ref():
+    R = ffi.ref()
+    if R is None or not hasattr(R, "ffref_aac_apply_ltp"):
+        pytest.skip("oracle/_ref not built")
+    return R
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def ref_windows(R):
+    return [np.ctypeslib.as_array(R.ffref_aac_window(k), (n,)).copy() for k, n in ((0, 1024), (1, 128), (2, 1024), (3, 128))]
+
+
+@pytest.mark.parametrize("short", [0, 1])
+def test_mid_side_and_intensity(short):
+    R, O = _ref(), ffi.oracle()
+    rng = np.random.default_rng(3100 + short)
+    touched = 0
+    for rep in range(200):
+        c = A.cpe(rng, short)
+        a0, a1 = A.spectrum(rng), A.spectrum(rng)
+        b0, b1 = a0.copy(), a1.copy()
+        args = (c["num_window_groups"], ptr(c["group_len"], u8p), c["max_sfb"], ptr(c["ms_mask"], u8p), ptr(c["band_type0"], i32p),
+                ptr(c["band_type1"], i32p), ptr(c["swb"], u16p))
+        assert R.ffref_aac_apply_mid_side_stereo(ptr(a0, f32p), ptr(a1, f32p), *args) == 0
+        O.ffo_aac_apply_mid_side_stereo(ptr(b0, f32p), ptr(b1, f32p), *args)
+        args = (c["num_window_groups"], ptr(c["group_len"], u8p), c["max_sfb"], c["ms_present"], ptr(c["ms_mask"], u8p),
+                ptr(c["band_type1"], i32p), ptr(c["sf1"], f32p), ptr(c["swb"], u16p))
+        before = a1.copy()
+        assert R.ffref_aac_apply_intensity_stereo(ptr(a0, f32p), ptr(a1, f32p), *args) == 0
+        O.ffo_aac_apply_intensity_stereo(ptr(b0, f32p), ptr(b1, f32p), *args)
+        assert np.array_equal(bits(a0), bits(b0)) and np.array_equal(bits(a1), bits(b1))
+        touched += int((bits(a1) != bits(before)).sum())
+    assert touched > 10000
+
+
+def test_apply_ltp():
+    R, O = _ref(), ffi.oracle()
+    rng = np.random.default_rng(3110)
+    win = ref_windows(R)
+    wp = (f32p * 4)(*[ptr(w, f32p) for w in win])
+    m = O.ffo_mdct_create(0, 1024, np.float32(-32786.0 * 2 + 36))
+    changed = 0
+    for rep in range(120):
+        c = A.ltp(rng)
+        if rep % 10 == 9:
+            c["seq"][0] = A.EIGHT_SHORT                     # the member does nothing on short windows
+        t = aac_tns_case(rng, 0)
+        t["swb"], t["num_swb"], t["max_sfb"] = c["swb"], c["num_swb"], c["max_sfb"]
+        present = int(rep % 3 != 0)
+        a = A.spectrum(rng)
+        b = a.copy()
+        pa, pb = np.zeros(1024, np.float32), np.zeros(1024, np.float32)
+        assert R.ffref_aac_apply_ltp(ptr(a, f32p), ptr(c["ltp_state"], f32p), c["lag"], c["coef"], ptr(c["used"], i8p), ptr(c["seq"], i32p),
+                                     ptr(c["kb"], i32p), c["max_sfb"], c["num_swb"], t["tns_max_bands"], ptr(c["swb"], u16p), present,
+                                     ptr(t["n_filt"], i32p), ptr(t["length"], i32p), ptr(t["direction"], i32p), ptr(t["order"], i32p),
+                                     ptr(t["coef"], f32p), ptr(pa, f32p)) == 0
+        rec = aac_tns_filters(O, t) if present else np.zeros(0, np.uint8)
+        O.ffo_aac_apply_ltp(m, wp, ptr(b, f32p), ptr(c["ltp_state"], f32p), c["lag"], c["coef"], ptr(c["used"], i8p), ptr(c["seq"], i32p),
+                            ptr(c["kb"], i32p), c["max_sfb"], ptr(c["swb"], u16p), rec.ctypes.data if len(rec) else None, len(rec), ptr(pb, f32p))
+        if c["seq"][0] != A.EIGHT_SHORT:
+            assert np.array_equal(bits(pa), bits(pb)), rep
+        assert np.array_equal(bits(a), bits(b)), rep
+        changed += int((bits(a) != bits(A.spectrum(np.random.default_rng(0)))).any())
+    O.ffo_mdct_free(m)
+    assert changed
+
+
+def test_update_ltp():
+    R, O = _ref(), ffi.oracle()
+    rng = np.random.default_rng(3120)
+    win = ref_windows(R)
+    wp = (f32p * 4)(*[ptr(w, f32p) for w in win])
+    for rep in range(64):
+        seq0, kb0 = rep & 3, (rep >> 2) & 1
+        buf, saved, out = A.spectrum(rng), A.spectrum(rng)[:512].copy(), A.spectrum(rng)
+        sa = (rng.standard_normal(3072) * 100).astype(np.float32)
+        sb = sa.copy()
+        assert R.ffref_aac_update_ltp(ptr(sa, f32p), ptr(buf, f32p), ptr(saved, f32p), ptr(out, f32p), seq0, kb0) == 0
+        O.ffo_aac_update_ltp(wp, ptr(sb, f32p), ptr(buf, f32p), ptr(saved, f32p), ptr(out, f32p), seq0, kb0)
+        assert np.array_equal(bits(sa), bits(sb)), (seq0, kb0)
+
+
+def run_band_ops(rec, a, b):
+    """FFHipAacBandOp records on host arrays of channel-frames, element by element as the kernel does"""
+    for r in rec:
+        x = a[r["frame0"], r["start"]:r["start"] + r["len"]].copy()
+        y = b[r["frame1"], r["start"]:r["start"] + r["len"]].copy()
+        if r["kind"] == 0:
+            a[r["frame0"], r["start"]:r["start"] + r["len"]] = x + y
+            b[r["frame1"], r["start"]:r["start"] + r["len"]] = x - y
+        elif r["kind"] == 1:
+            b[r["frame1"], r["start"]:r["start"] + r["len"]] = x * r["scale"]
+        else:
+            a[r["frame0"], r["start"]:r["start"] + r["len"]] = x + y
+
+
+@pytest.mark.parametrize("short", [0, 1])
+def test_band_walks_vs_oracle(short):
+    """the product's host walks (ffhip_aac_ms_bands / is_bands / ltp_bands: no device involved) executed on host arrays == the oracle"""
+    from ffmpeg_amd import aac
+    O = ffi.oracle()
+    rng = np.random.default_rng(3130 + short)
+    nrec = 0
+    for rep in range(150):
+        c = A.cpe(rng, short)
+        fr = np.stack([A.spectrum(rng) for _ in range(4)])
+        want = fr.copy()
+        args = (c["num_window_groups"], ptr(c["group_len"], u8p), c["max_sfb"], ptr(c["ms_mask"], u8p), ptr(c["band_type0"], i32p),
+                ptr(c["band_type1"], i32p), ptr(c["swb"], u16p))
+        O.ffo_aac_apply_mid_side_stereo(ptr(want[1], f32p), ptr(want[3], f32p), *args)
+        O.ffo_aac_apply_intensity_stereo(ptr(want[1], f32p), ptr(want[3], f32p), c["num_window_groups"], ptr(c["group_len"], u8p), c["max_sfb"],
+                                         c["ms_present"], ptr(c["ms_mask"], u8p), ptr(c["band_type1"], i32p), ptr(c["sf1"], f32p), ptr(c["swb"], u16p))
+        rec = np.concatenate([aac.ms_bands(1, 3, c["num_window_groups"], c["group_len"], c["max_sfb"], c["ms_mask"], c["band_type0"],
+                                           c["band_type1"], c["swb"]),
+                              aac.is_bands(1, 3, c["num_window_groups"], c["group_len"], c["max_sfb"], c["ms_present"], c["ms_mask"],
+                                           c["band_type1"], c["sf1"], c["swb"])])
+        nrec += len(rec)
+        run_band_ops(rec, fr, fr)
+        assert np.array_equal(bits(fr), bits(want)), rep
+    assert nrec > 500
+    from ffmpeg_amd import _lib
+    assert _lib.lib().ffhip_aac_ms_bands(None, 0, 1, 1, None, 1, None, None, None, None) < 0
+
+
+def test_ltp_bands_walk():
+    from ffmpeg_amd import aac
+    rng = np.random.default_rng(3140)
+    for rep in range(50):
+        c = A.ltp(rng)
+        co, pred = A.spectrum(rng)[None].copy(), A.spectrum(rng)[None].copy()
+        want = co.copy()
+        for sfb in range(min(c["max_sfb"], 40)):
+            if c["used"][sfb]:
+                want[0, c["swb"][sfb]:c["swb"][sfb + 1]] += pred[0, c["swb"][sfb]:c["swb"][sfb + 1]]
+        run_band_ops(aac.ltp_bands(0, 0, c["max_sfb"], c["used"], c["swb"]), co, pred)
+        assert np.array_equal(bits(co), bits(want))
