@@ -43,13 +43,15 @@ struct TxDev {
     int cos_off[16], sched_off[16], sched_cnt[16];
 };
 
-/* 2 * 15 * 2^k MDCT lengths (ff_tx_mdct_pfa_15xM): per-transform geometry and the extra tables of the prime-factor kernel */
+/* 2 * F * 2^k MDCT lengths, F = 3, 5, 7, 9, 15 (ff_tx_mdct_pfa_<F>xM): per-transform geometry and the extra tables of the
+ * prime-factor kernel */
 struct TxPfa {
-    int n1, m, G;              /* complex points per transform (15 m), sub-transform size, transforms per wave (G * m = 64) */
+    int n1, m, G;              /* complex points per transform (F m), sub-transform size, transforms per wave (G * m = 64; 1 for m >= 64) */
+    int F;                     /* the small factor */
     int magic_q;               /* ceil(2^24 / (n1 / 2)): e / (n1 / 2) == (e * magic) >> 24 for e * n1 / 2 < 2^24 */
-    const int *in_map;         /* n1: ((i * 15 + j) -> k >> 1, the point sub-transform i takes as its j-th input */
+    const int *in_map;         /* n1: ((i * F + j) -> k >> 1, the point sub-transform i takes as its j-th input */
     const int *out_map;        /* n1: CRT output map                                                     */
-    const int *sub_map;        /* m: where sub-transform i's 15-point outputs start                      */
+    const int *sub_map;        /* m: where sub-transform i's F-point outputs start                       */
 };
 
 struct FFHipTXContext {
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
 #define TXCMUL(dre, dim, are, aim, bre, bim) do { (dre) = (are) * (bre) - (aim) * (bim); (dim) = (are) * (bim) + (aim) * (bre); } while (0)
 #define TXSMUL(dre, dim, are, aim, bre, bim) do { (dre) = (are) * (bre) - (aim) * (bim); (dim) = (are) * (bim) - (aim) * (bre); } while (0)
 
-struct TxTab53 { float t[12]; };
+struct TxTab53 { float t[12]; float t7[6]; float t9[8]; }; /* ff_tx_tab_53, ff_tx_tab_7, ff_tx_tab_9 (tx_template.c:92-130) */
 
 /* fft3 (tx_template.c:175-209): in[0..2], out o0, o1, o2 */
 __device__ __forceinline__ void tx_fft3(const TxTab53 &T, const float2 &i0, const float2 &i1, const float2 &i2, float2 &o0, float2 &o1,
@@ -879,7 +881,106 @@ __device__ __forceinline__ void tx_fft5(const TxTab53 &T, const float2 (&in)[5],
     o[4].y = dc.y + z0[3].y;
 }
 
-template <int INV>
+/* fft7 (tx_template.c:250-340, float branch) on the sums p[k] / differences q[k] of the mirrored inputs in[k+1], in[6-k]: output
+ * pair (k, 7 - k) is dc + C_k -/+ S_k with C / S three-term expressions evaluated in the reference's term order; t7 = (re, im)
+ * pairs: cs[k] = t7[2k], sn[k] = t7[2k+1] */
+__device__ __forceinline__ void tx_fft7(const TxTab53 &T, const float2 (&in)[7], float2 (&o)[7])
+{
+    const float c0 = T.t7[0], c1 = T.t7[2], c2 = T.t7[4], s0 = T.t7[1], s1 = T.t7[3], s2 = T.t7[5];
+    float2 p[3], q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        p[k] = make_float2(in[k + 1].x + in[6 - k].x, in[k + 1].y + in[6 - k].y);
+        q[k] = make_float2(in[k + 1].x - in[6 - k].x, in[k + 1].y - in[6 - k].y);
+    }
+    o[0] = make_float2(in[0].x + p[0].x + p[1].x + p[2].x, in[0].y + p[0].y + p[1].y + p[2].y);
+    const float2 z0 = make_float2(c0 * p[0].x - c2 * p[2].x - c1 * p[1].x, c0 * p[0].y - c1 * p[1].y - c2 * p[2].y);
+    const float2 z1 = make_float2(c0 * p[2].x - c1 * p[0].x - c2 * p[1].x, c0 * p[2].y - c1 * p[0].y - c2 * p[1].y);
+    const float2 z2 = make_float2(c0 * p[1].x - c2 * p[0].x - c1 * p[2].x, c0 * p[1].y - c2 * p[0].y - c1 * p[2].y);
+    /* a[k]: what pair k adds to / takes from z[k] (x: to the real part, y: to the imaginary part) */
+    const float2 a0 = make_float2(s2 * q[2].y + s1 * q[1].y + s0 * q[0].y, s0 * q[0].x + s1 * q[1].x + s2 * q[2].x);
+    const float2 a1 = make_float2(s0 * q[2].y + s2 * q[1].y - s1 * q[0].y, s2 * q[1].x + s0 * q[2].x - s1 * q[0].x);
+    const float2 a2 = make_float2(s2 * q[0].y + s1 * q[2].y - s0 * q[1].y, s2 * q[0].x + s1 * q[2].x - s0 * q[1].x);
+    const float dre = in[0].x, dim = in[0].y;
+    o[1] = make_float2(dre + (z0.x + a0.x), dim + (z0.y - a0.y));
+    o[6] = make_float2(dre + (z0.x - a0.x), dim + (z0.y + a0.y));
+    o[2] = make_float2(dre + (z1.x - a1.x), dim + (z1.y + a1.y));
+    o[5] = make_float2(dre + (z1.x + a1.x), dim + (z1.y - a1.y));
+    o[3] = make_float2(dre + (z2.x + a2.x), dim + (z2.y - a2.y));
+    o[4] = make_float2(dre + (z2.x - a2.x), dim + (z2.y + a2.y));
+}
+
+/* fft9 (tx_template.c:342-461, float branch); t9 = (re, im) pairs */
+__device__ __forceinline__ void tx_fft9(const TxTab53 &T, const float2 (&in)[9], float2 (&o)[9])
+{
+    const float t0r = T.t9[0], t0i = T.t9[1], t1r = T.t9[2], t1i = T.t9[3], t2r = T.t9[4], t2i = T.t9[5], t3r = T.t9[6], t3i = T.t9[7];
+    float2 p[4], q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        p[k] = make_float2(in[k + 1].x + in[8 - k].x, in[k + 1].y + in[8 - k].y);
+        q[k] = make_float2(in[k + 1].x - in[8 - k].x, in[k + 1].y - in[8 - k].y);
+    }
+    const float2 w0 = make_float2(p[0].x - p[3].x, p[0].y - p[3].y), w1 = make_float2(p[1].x - p[3].x, p[1].y - p[3].y);
+    const float2 w2 = make_float2(q[0].x - q[3].x, q[0].y - q[3].y), w3 = make_float2(q[1].x + q[3].x, q[1].y + q[3].y);
+    float2 z0 = make_float2(in[0].x + p[2].x, in[0].y + p[2].y);
+    const float2 z1 = make_float2(p[0].x + p[1].x + p[3].x, p[0].y + p[1].y + p[3].y);
+    o[0] = make_float2(z0.x + z1.x, z0.y + z1.y);
+    float2 x[5], y[5];
+    y[3] = make_float2(t0i * (q[0].x - q[1].x + q[3].x), t0i * (q[0].y - q[1].y + q[3].y));
+    x[3] = make_float2(z0.x + t0r * z1.x, z0.y + t0r * z1.y);
+    z0 = make_float2(in[0].x + t0r * p[2].x, in[0].y + t0r * p[2].y);
+    x[1] = make_float2(t1r * w0.x + t2i * w1.x, t1r * w0.y + t2i * w1.y);
+    x[2] = make_float2(t2i * w0.x - t3r * w1.x, t2i * w0.y - t3r * w1.y);
+    y[1] = make_float2(t1i * w2.x + t2r * w3.x, t1i * w2.y + t2r * w3.y);
+    y[2] = make_float2(t2r * w2.x - t3i * w3.x, t2r * w2.y - t3i * w3.y);
+    y[0] = make_float2(t0i * q[2].x, t0i * q[2].y);
+    x[4] = make_float2(x[1].x + x[2].x, x[1].y + x[2].y);
+    y[4] = make_float2(y[1].x - y[2].x, y[1].y - y[2].y);
+    x[1] = make_float2(z0.x + x[1].x, z0.y + x[1].y);
+    y[1] = make_float2(y[0].x + y[1].x, y[0].y + y[1].y);
+    x[2] = make_float2(z0.x + x[2].x, z0.y + x[2].y);
+    y[2] = make_float2(y[2].x - y[0].x, y[2].y - y[0].y);
+    x[4] = make_float2(z0.x - x[4].x, z0.y - x[4].y);
+    y[4] = make_float2(y[0].x - y[4].x, y[0].y - y[4].y);
+#pragma unroll
+    for (int k = 1; k <= 4; k++) {
+        o[k] = make_float2(x[k].x + y[k].y, x[k].y - y[k].x);
+        o[9 - k] = make_float2(x[k].x - y[k].y, x[k].y + y[k].x);
+    }
+}
+
+/* the F-point transform of a sub-transform's inputs; o[d] is the output the reference writes at out[d * stride] */
+template <int F>
+__device__ __forceinline__ void tx_fft_small(const TxTab53 &T, const float2 (&f)[F], float2 (&o)[F])
+{
+    if constexpr (F == 3) {
+        tx_fft3(T, f[0], f[1], f[2], o[0], o[1], o[2]);
+    } else if constexpr (F == 5) {
+        tx_fft5(T, f, o);
+    } else if constexpr (F == 7) {
+        tx_fft7(T, f, o);
+    } else if constexpr (F == 9) {
+        tx_fft9(T, f, o);
+    } else { /* fft15 = 5 x fft3 + fft5_m1 | _m2 | _m3 (tx_template.c:463-476) */
+        constexpr int D15[15] = { 0, 6, 12, 3, 9, 10, 1, 7, 13, 4, 5, 11, 2, 8, 14 }; /* the three fft5s' output slots */
+        float2 tmp[15];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+            tx_fft3(T, f[3 * i], f[3 * i + 1], f[3 * i + 2], tmp[i], tmp[i + 5], tmp[i + 10]);
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            float2 r[5];
+            const float2 (&ti)[5] = *reinterpret_cast<const float2 (*)[5]>(&tmp[5 * b]);
+            tx_fft5(T, ti, r);
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                o[D15[5 * b + c]] = r[c];
+        }
+    }
+}
+
+/* C: sub-transforms per lane (1 while m <= 64; 4 covers m = 128 and 256 with G = 1) */
+template <int INV, int F, int C>
 __global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, const uint8_t *blob, int blob_bytes, const float *in,
                                                    size_t in_pitch, float *out, size_t out_pitch, int nt, int waves_total)
 {
@@ -903,8 +1004,7 @@ __global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, 
     const int n1 = P.n1, m = P.m, G = P.G, q = n1 >> 1;
     uint8_t *mine = lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(d.n);
     float2 *z = reinterpret_cast<float2 *>(mine);  /* the work array; before that, the folded / pre-twiddled points w[g][k >> 1] */
-    static constexpr int D15[15] = { 0, 6, 12, 3, 9, 10, 1, 7, 13, 4, 5, 11, 2, 8, 14 }; /* fft5_m1 | _m2 | _m3 output slots */
-    const int g = lane >> d.lg, si = lane & (m - 1);
+    const int g = lane >> d.lg, si = lane & (m - 1); /* m >= 64: g = 0, si = lane */
 
     for (int t0 = (blockIdx.x * (blockDim.x >> 6) + wave) * G; t0 < nt; t0 += waves_total * G) {
         const int ng = min(G, nt - t0);
@@ -928,36 +1028,35 @@ __global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, 
             }
         }
         tx_wave_sync();
-        /* 2. this lane's 15 points, through the Ruritanian input map */
-        float2 f[15];
-        const bool live = g < ng;
-        if (live) {
-            const float2 *w = z + g * n1;
+        /* 2. this lane's F points per sub-transform, through the Ruritanian input map */
+        float2 f[C][F];
 #pragma unroll
-            for (int j = 0; j < 15; j++)
-                f[j] = w[l_in[si * 15 + j]];
+        for (int c = 0; c < C; c++) {
+            const int sc = si + 64 * c;
+            if (g < ng && sc < m) {
+                const float2 *w = z + g * n1;
+#pragma unroll
+                for (int j = 0; j < F; j++)
+                    f[c][j] = w[l_in[sc * F + j]];
+            }
         }
         tx_wave_sync(); /* every lane has its inputs: the same bytes become the work array */
-        if (live) {
-            float2 tmp[15];
 #pragma unroll
-            for (int i = 0; i < 5; i++)
-                tx_fft3(T, f[3 * i], f[3 * i + 1], f[3 * i + 2], tmp[i], tmp[i + 5], tmp[i + 10]);
-            const int base = g * n1 + l_sub[si];
+        for (int c = 0; c < C; c++) {
+            const int sc = si + 64 * c;
+            if (g < ng && sc < m) {
+                float2 o[F];
+                tx_fft_small<F>(T, f[c], o);
+                const int base = g * n1 + l_sub[sc];
 #pragma unroll
-            for (int b = 0; b < 3; b++) {
-                float2 o[5];
-                const float2 (&ti)[5] = *reinterpret_cast<const float2 (*)[5]>(&tmp[5 * b]);
-                tx_fft5(T, ti, o);
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    const int idx = base + D15[5 * b + c] * m;
-                    z[TX_PAD(idx)] = o[c];
+                for (int dd = 0; dd < F; dd++) {
+                    const int idx = base + dd * m;
+                    z[TX_PAD(idx)] = o[dd];
                 }
             }
         }
         tx_wave_sync();
-        /* 3. the 15 G sub-transforms */
+        /* 3. the F G sub-transforms */
         tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
         /* 4. post-twiddle */
         for (int e = lane; e < ng * q; e += 64) {
@@ -1061,34 +1160,35 @@ static int mulinv(int n, int m)
 
 /* tables of the 15xM prime-factor MDCT (ff_tx_mdct_pfa_init, libavutil/tx_template.c:1425-1469; ff_tx_gen_compound_mapping with
  * opts == NULL, libavutil/tx.c:75-121; TX_EMBED_INPUT_PFA_MAP, tx_priv.h:275-284; ff_tx_mdct_gen_exp, tx_template.c:2107-2134) */
-static int tx_init_pfa(FFHipTXContext *c, float scale_f)
+static int tx_init_pfa(FFHipTXContext *c, float scale_f, int F)
 {
-    const int n1 = c->len >> 1, m = n1 / 15, G = 64 / m, inv = c->inv;
+    const int n1 = c->len >> 1, m = n1 / F, G = m < 64 ? 64 / m : 1, inv = c->inv;
     int lg = 0;
     while ((1 << lg) < m)
         lg++;
     std::vector<int> in_map(n1), out_map(n1), sub_map(m);
     for (int i = 0; i < m; i++)
         sub_map[-sr_perm(i, m, inv) & (m - 1)] = i; /* the sub-transform's SCATTER revtab */
-    const int m_inv = mulinv(m, 15), n_inv = mulinv(15, m);
+    const int m_inv = mulinv(m, F), n_inv = mulinv(F, m);
     for (int j = 0; j < m; j++)
-        for (int i = 0; i < 15; i++) {
-            in_map[j * 15 + i] = (i * m + j * 15) % n1;
-            out_map[(i * m * m_inv + j * 15 * n_inv) % n1] = i * m + j;
+        for (int i = 0; i < F; i++) {
+            in_map[j * F + i] = (i * m + j * F) % n1;
+            out_map[(i * m * m_inv + j * F * n_inv) % n1] = i * m + j;
         }
     if (inv)
         for (int i = 0; i < m; i++) {
-            int *p = &in_map[i * 15 + 1];
-            for (int j = 0; j < 7; j++)
-                std::swap(p[j], p[15 - j - 2]);
+            int *p = &in_map[i * F + 1];
+            for (int j = 0; j < (F - 1) >> 1; j++)
+                std::swap(p[j], p[F - j - 2]);
         }
-    for (int k = 0; k < n1; k += 15) {
-        int t[15];
-        memcpy(t, &in_map[k], sizeof(t));
-        for (int a = 0; a < 5; a++)
-            for (int b = 0; b < 3; b++)
-                in_map[k + a * 3 + b] = t[(a * 3 + b * 5) % 15];
-    }
+    if (F == 15) /* the 15-point transform is itself 3 x 5: its input map is embedded (TX_EMBED_INPUT_PFA_MAP) */
+        for (int k = 0; k < n1; k += 15) {
+            int t[15];
+            memcpy(t, &in_map[k], sizeof(t));
+            for (int a = 0; a < 5; a++)
+                for (int b = 0; b < 3; b++)
+                    in_map[k + a * 3 + b] = t[(a * 3 + b * 5) % 15];
+        }
     /* the natural-order table only: the reference's permuted copy for the inverse pre-twiddle is exp[map[i]], i.e. the
      * twiddle of input point k is exp[k >> 1] in both directions */
     std::vector<float2> ex(n1);
@@ -1113,11 +1213,11 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f)
             cosv.push_back((float)cos(i * freq));
         cosv.push_back(0.0f);
     }
-    /* one butterfly schedule for the wave's 15 G sub-transforms */
+    /* one butterfly schedule for the wave's F G sub-transforms */
     std::vector<uint32_t> lev[16];
     std::vector<uint16_t> b2;
     for (int g = 0; g < G; g++)
-        for (int a = 0; a < 15; a++)
+        for (int a = 0; a < F; a++)
             sr_schedule(g * n1 + a * m, m, lg, lev, &b2);
     std::vector<uint32_t> sched;
     for (int l = 2; l <= lg; l++) {
@@ -1147,7 +1247,7 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f)
     c->blob_bytes = total;
     const uint8_t *base = (const uint8_t *)c->dev;
     TxPfa &P = c->pfa;
-    P.n1 = n1; P.m = m; P.G = G;
+    P.n1 = n1; P.m = m; P.G = G; P.F = F;
     P.magic_q = (int)(((1u << 24) + (uint32_t)(n1 / 2) - 1) / (uint32_t)(n1 / 2));
     P.in_map = (const int *)(base + o_in);
     P.out_map = (const int *)(base + o_out);
@@ -1190,9 +1290,21 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     /* 2 * 15 * 2^k, k = 2..6: the lengths av_tx serves with ff_tx_mdct_pfa_15xM (CELT 120..960, AAC-960 240 / 1920) */
     if (rdft)
         len >>= 1;
-    const bool pfa = !fft && len % 30 == 0 && len / 30 >= 4 && len / 30 <= 64 && !((len / 30) & (len / 30 - 1));
+    /* ... and 2 * F * 2^k for F = 9, 7, 5, 3 (ff_tx_mdct_pfa_<F>xM: 96 / 768-sample AAC frames, Siren's 320, ...), sub-transform
+     * sizes 4..256 (4..64 for 15): the factorisation of len / 2 into an odd F and a power of two is unique, so this is the codelet
+     * av_tx_init picks ("larger factors are generally better", libavutil/tx.c) */
+    int pfa_f = 0;
+    if (!fft) {
+        static const int factors[5] = { 15, 9, 7, 5, 3 };
+        for (int i = 0; i < 5 && !pfa_f; i++) {
+            const int f2 = 2 * factors[i], m = len / f2;
+            if (len % f2 == 0 && m >= 4 && m <= (factors[i] == 15 ? 64 : 256) && !(m & (m - 1)))
+                pfa_f = factors[i];
+        }
+    }
+    const bool pfa = pfa_f != 0;
     if (!pfa && (fft ? (len < 4 || len > 2048 || (len & (len - 1))) : (len < 16 || len > 4096 || (len & (len - 1))))) {
-        ffhip_set_error("ffhip_tx_init: len %d is neither a power of two in %s nor 120 / 240 / 480 / 960 / 1920", len,
+        ffhip_set_error("ffhip_tx_init: len %d is neither a power of two in %s nor 2 * {3, 5, 7, 9} * 2^k (k = 2..8) nor 2 * 15 * 2^k (k = 2..6)", len,
                         fft ? "4..2048" : "16..4096");
         return FFHIP_EINVAL;
     }
@@ -1204,7 +1316,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     c->type = type; c->inv = !!inv; c->len = rdft ? 2 * len : len; c->scale = *scale;
     c->full = type == FFHIP_TX_FLOAT_MDCT && inv && (flags & FFHIP_TX_FULL_IMDCT);
     if (pfa) {
-        const int r = tx_init_pfa(c, *scale);
+        const int r = tx_init_pfa(c, *scale, pfa_f);
         if (r < 0) {
             ffhip_tx_uninit(&c);
             return r;
@@ -1434,7 +1546,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
     if (c->pfa.n1) {
         const TxPfa &P = c->pfa;
         if (stride != (ptrdiff_t)sizeof(float) || (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7)) {
-            ffhip_set_error("ffhip_tx: the 15xM lengths need contiguous, 8-byte aligned rows");
+            ffhip_set_error("ffhip_tx: the prime-factor lengths need contiguous, 8-byte aligned rows");
             return FFHIP_EINVAL;
         }
         const size_t area = tx_z_bytes(n); /* G * n1 points, padded: the parked inputs (unpadded) fit the same bytes */
@@ -1454,13 +1566,6 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         int blocks = cus * per_cu;
         if (blocks > (groups + wpb - 1) / wpb)
             blocks = (groups + wpb - 1) / wpb;
-        static bool pfa_attr = false;
-        if (!pfa_attr) {
-            (void)hipFuncSetAttribute((const void *)k_mdct_pfa<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_mdct_pfa<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            pfa_attr = true;
-            ffhip_note_device_resources();
-        }
         TxTab53 T;
         T.t[0] = T.t[1] = (float)cos(2 * M_PI / 5);
         T.t[2] = T.t[3] = (float)cos(2 * M_PI / 10);
@@ -1469,12 +1574,41 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         T.t[8] = T.t[9] = (float)cos(2 * M_PI / 12);
         T.t[10] = (float)cos(2 * M_PI / 6);
         T.t[11] = (float)cos(8 * M_PI / 6);
-        if (c->inv)
-            hipLaunchKernelGGL((k_mdct_pfa<1>), dim3(blocks), dim3(64 * wpb), lds_p, (hipStream_t)stream, c->d, P, T, (const uint8_t *)c->dev,
-                               (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
-        else
-            hipLaunchKernelGGL((k_mdct_pfa<0>), dim3(blocks), dim3(64 * wpb), lds_p, (hipStream_t)stream, c->d, P, T, (const uint8_t *)c->dev,
-                               (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb);
+        T.t7[0] = (float)cos(2 * M_PI / 7);  T.t7[1] = (float)sin(2 * M_PI / 7);
+        T.t7[2] = (float)sin(2 * M_PI / 28); T.t7[3] = (float)cos(2 * M_PI / 28);
+        T.t7[4] = (float)cos(2 * M_PI / 14); T.t7[5] = (float)sin(2 * M_PI / 14);
+        T.t9[0] = (float)cos(2 * M_PI / 3);  T.t9[1] = (float)sin(2 * M_PI / 3);
+        T.t9[2] = (float)cos(2 * M_PI / 9);  T.t9[3] = (float)sin(2 * M_PI / 9);
+        T.t9[4] = (float)cos(2 * M_PI / 36); T.t9[5] = (float)sin(2 * M_PI / 36);
+        T.t9[6] = T.t9[2] + T.t9[5];
+        T.t9[7] = T.t9[3] - T.t9[4];
+        const int big = P.m > 64;
+#define PFA_GO(INV_, F_, C_)                                                                                                               \
+    do {                                                                                                                                   \
+        static bool attr = false;                                                                                                          \
+        if (!attr) {                                                                                                                       \
+            (void)hipFuncSetAttribute((const void *)k_mdct_pfa<INV_, F_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+            attr = true;                                                                                                                   \
+            ffhip_note_device_resources();                                                                                                 \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL((k_mdct_pfa<INV_, F_, C_>), dim3(blocks), dim3(64 * wpb), lds_p, (hipStream_t)stream, c->d, P, T,              \
+                           (const uint8_t *)c->dev, (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt,         \
+                           blocks * wpb);                                                                                                  \
+    } while (0)
+#define PFA_F(F_)                                                                                                                          \
+    do {                                                                                                                                   \
+        if (c->inv) { if (big) PFA_GO(1, F_, 4); else PFA_GO(1, F_, 1); }                                                                  \
+        else        { if (big) PFA_GO(0, F_, 4); else PFA_GO(0, F_, 1); }                                                                  \
+    } while (0)
+        switch (P.F) {
+        case 3:  PFA_F(3); break;
+        case 5:  PFA_F(5); break;
+        case 7:  PFA_F(7); break;
+        case 9:  PFA_F(9); break;
+        default: if (c->inv) PFA_GO(1, 15, 1); else PFA_GO(0, 15, 1); break;
+        }
+#undef PFA_F
+#undef PFA_GO
         LAUNCH_CHECK();
         return 0;
     }

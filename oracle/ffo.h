@@ -179,6 +179,7 @@ void     ffo_me_esa_frame(const uint8_t *cur, const uint8_t *ref, int linesize, 
 /* ---- av_tx float MDCT (ffo_tx.c) ---- */
 typedef struct FfoTx FfoTx;
 FfoTx *ffo_mdct_create(int inv, int len, float scale);
+int    ffo_mdct_pfa_factor(int len); /* 0: power-of-two codelet; else the N of ff_tx_mdct_pfa_NxM av_tx picks */
 void   ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride);
 void   ffo_mdct_free(FfoTx *s);
 /* AV_TX_FLOAT_FFT, power-of-two len: complex (re, im) floats in and out */

@@ -29,9 +29,11 @@ struct FfoTx {
     int  *map;      /* len/2 entries (15xM: in_map, then out_map: 2 * len/2) */
     cpx  *exp;      /* len/2 (fwd) or len (inv) entries */
     float *cos_tab[20]; /* cos_tab[log2 n][k] = cos(2*pi*k/n), k <= n/4 */
-    int   pfa_m;    /* 0: power of two; else len/2 = 15 * pfa_m (ff_tx_mdct_pfa_15xM_*) */
-    int  *sub_map;  /* 15xM: the sub-transform's scatter map (pfa_m entries) */
+    int   pfa_m;    /* 0: power of two; else len/2 = pfa_f * pfa_m (ff_tx_mdct_pfa_<f>xM_*) */
+    int   pfa_f;    /* the prime-factor codelet's small factor: 3, 5, 7, 9 or 15 */
+    int  *sub_map;  /* NxM: the sub-transform's scatter map (pfa_m entries) */
     float tab53[12];/* ff_tx_tab_53 */
+    float tab7[6], tab9[8]; /* ff_tx_tab_7, ff_tx_tab_9 */
 };
 
 static int sr_perm(int i, int len, int inv)
@@ -84,12 +86,25 @@ static void sr_fft(const struct FfoTx *s, cpx *z, int n, int lg)
     }
 }
 
-static FfoTx *pfa15_create(int inv, int len, float scale_f);
+static FfoTx *pfa_create(int inv, int len, int factor, float scale_f);
+
+/* which ff_tx_mdct_pfa_<N>xM codelet av_tx_init ends up with for len/2 = N * 2^k (candidates DECL_COMP_MDCT(3 / 5 / 7 / 9 / 15),
+ * libavutil/tx_template.c:1595-1599, ranked in libavutil/tx.c:get_codelet_prio "larger factors are generally better"): 0 = none */
+int ffo_mdct_pfa_factor(int len)
+{
+    static const int f[5] = { 15, 9, 7, 5, 3 };
+    for (int i = 0; i < 5; i++) {
+        const int m = len / (2 * f[i]);
+        if (len % (2 * f[i]) == 0 && m >= 2 && !(m & (m - 1)))
+            return f[i];
+    }
+    return 0;
+}
 
 FfoTx *ffo_mdct_create(int inv, int len, float scale_f)
 {
-    if (len >= 120 && len % 30 == 0 && !((len / 30) & (len / 30 - 1)))
-        return pfa15_create(inv, len, scale_f);
+    if (ffo_mdct_pfa_factor(len))
+        return pfa_create(inv, len, ffo_mdct_pfa_factor(len), scale_f);
     if (len < 4 || (len & (len - 1)))
         return NULL;
     struct FfoTx *s = calloc(1, sizeof(*s));
@@ -146,7 +161,7 @@ void ffo_mdct_free(FfoTx *s)
     free(s);
 }
 
-static void pfa15_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride);
+static void pfa_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride);
 
 /* AV_TX_FULL_IMDCT: ff_tx_mdct_inv_full (libavutil/tx_template.c:1391-1408): the half inverse lands in the middle of the
  * 2 * len outputs and is mirrored outwards (first quarter negated).  s must be an inverse context; contiguous data. */
@@ -164,7 +179,7 @@ void ffo_imdct_full_run(const FfoTx *s, float *out, const float *in)
 void ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride)
 {
     if (s->pfa_m) {
-        pfa15_run(s, out, in, stride);
+        pfa_run(s, out, in, stride);
         return;
     }
     const int n = s->len >> 1, q = s->len >> 2, len3 = 3 * n;
@@ -242,10 +257,10 @@ static int mulinv(int n, int m)
     return 0;
 }
 
-static FfoTx *pfa15_create(int inv, int len, float scale_f)
+static FfoTx *pfa_create(int inv, int len, int F, float scale_f)
 {
     struct FfoTx *s = calloc(1, sizeof(*s));
-    const int n = len >> 1, m = n / 15; /* n = 15 m complex points */
+    const int n = len >> 1, m = n / F; /* n = F m complex points */
     const double scale = scale_f;
     int lg = 0;
     while ((1 << lg) < m)
@@ -253,6 +268,7 @@ static FfoTx *pfa15_create(int inv, int len, float scale_f)
     s->len = len;
     s->inv = inv;
     s->pfa_m = m;
+    s->pfa_f = F;
     for (int l = 2; l <= lg; l++) {
         const int mm = 1 << l;
         const double freq = 2 * M_PI / mm;
@@ -268,6 +284,15 @@ static FfoTx *pfa15_create(int inv, int len, float scale_f)
     s->tab53[8] = s->tab53[9] = (float)cos(2 * M_PI / 12);
     s->tab53[10] = (float)cos(2 * M_PI / 6);
     s->tab53[11] = (float)cos(8 * M_PI / 6);
+    /* ff_tx_init_tab_7 / _9 (tx_template.c:110-130): pairs (re, im) */
+    s->tab7[0] = (float)cos(2 * M_PI / 7);  s->tab7[1] = (float)sin(2 * M_PI / 7);
+    s->tab7[2] = (float)sin(2 * M_PI / 28); s->tab7[3] = (float)cos(2 * M_PI / 28);
+    s->tab7[4] = (float)cos(2 * M_PI / 14); s->tab7[5] = (float)sin(2 * M_PI / 14);
+    s->tab9[0] = (float)cos(2 * M_PI / 3);  s->tab9[1] = (float)sin(2 * M_PI / 3);
+    s->tab9[2] = (float)cos(2 * M_PI / 9);  s->tab9[3] = (float)sin(2 * M_PI / 9);
+    s->tab9[4] = (float)cos(2 * M_PI / 36); s->tab9[5] = (float)sin(2 * M_PI / 36);
+    s->tab9[6] = s->tab9[2] + s->tab9[5];
+    s->tab9[7] = s->tab9[3] - s->tab9[4];
     /* the sub-transform permutes on output: SCATTER revtab of the M-point split-radix FFT */
     s->sub_map = malloc(sizeof(int) * m);
     for (int i = 0; i < m; i++)
@@ -275,29 +300,30 @@ static FfoTx *pfa15_create(int inv, int len, float scale_f)
     /* compound map, opts == NULL: in_map gathers */
     s->map = malloc(sizeof(int) * 2 * n);
     int *in_map = s->map, *out_map = s->map + n;
-    const int m_inv = mulinv(m, 15), n_inv = mulinv(15, m);
+    const int m_inv = mulinv(m, F), n_inv = mulinv(F, m);
     for (int j = 0; j < m; j++)
-        for (int i = 0; i < 15; i++) {
-            in_map[j * 15 + i] = (i * m + j * 15) % n;
-            out_map[(i * m * m_inv + j * 15 * n_inv) % n] = i * m + j;
+        for (int i = 0; i < F; i++) {
+            in_map[j * F + i] = (i * m + j * F) % n;
+            out_map[(i * m * m_inv + j * F * n_inv) % n] = i * m + j;
         }
     if (inv)
         for (int i = 0; i < m; i++) {
-            int *in = &in_map[i * 15 + 1]; /* skip the DC */
-            for (int j = 0; j < 7; j++) {
+            int *in = &in_map[i * F + 1]; /* skip the DC */
+            for (int j = 0; j < (F - 1) >> 1; j++) {
                 const int t = in[j];
-                in[j] = in[15 - j - 2];
-                in[15 - j - 2] = t;
+                in[j] = in[F - j - 2];
+                in[F - j - 2] = t;
             }
         }
     /* the 15-point transform is itself 3 x 5: embed its input map */
-    for (int k = 0; k < n; k += 15) {
-        int mtmp[15];
-        memcpy(mtmp, &in_map[k], sizeof(mtmp));
-        for (int mm = 0; mm < 5; mm++)
-            for (int nn = 0; nn < 3; nn++)
-                in_map[k + mm * 3 + nn] = mtmp[(mm * 3 + nn * 5) % 15];
-    }
+    if (F == 15)
+        for (int k = 0; k < n; k += 15) {
+            int mtmp[15];
+            memcpy(mtmp, &in_map[k], sizeof(mtmp));
+            for (int mm = 0; mm < 5; mm++)
+                for (int nn = 0; nn < 3; nn++)
+                    in_map[k + mm * 3 + nn] = mtmp[(mm * 3 + nn * 5) % 15];
+        }
     {
         const double theta = (scale < 0 ? n : 0) + 1.0 / 8.0;
         const double sc = sqrt(fabs(scale));
@@ -379,9 +405,138 @@ static void fft15(const float *tab, cpx *out, const cpx *in, int stride)
     fft5(tab, out, tmp + 10, stride, d3);
 }
 
-static void pfa15_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride)
+/*
+ * fft7 (tx_template.c:250-340, float branch).  The 7-point DFT on the sums p[k] = in[k+1] + in[6-k] and differences
+ * m[k] = in[k+1] - in[6-k] of the mirrored inputs: output pair (k, 7 - k) is dc + C_k -/+ i S_k, each C / S a three-term
+ * expression whose term ORDER is the reference's (float addition is not associative): rows below list (table entry, operand)
+ * in evaluation order, the sign applying to the product.  tab = { c1, s1, s3', c3', c2', s2' } with the reference's odd
+ * angle choices (ff_tx_init_tab_7).
+ */
+static void fft7(const float *tab, cpx *out, const cpx *in, int stride)
 {
-    const int n = s->len >> 1, m = s->pfa_m;
+    const float c[3] = { tab[0], tab[2], tab[4] }, sn[3] = { tab[1], tab[3], tab[5] };
+    float pre[3], pim[3], mre[3], mim[3];
+    for (int k = 0; k < 3; k++) {
+        pre[k] = in[k + 1].re + in[6 - k].re;
+        pim[k] = in[k + 1].im + in[6 - k].im;
+        mre[k] = in[k + 1].re - in[6 - k].re;
+        mim[k] = in[k + 1].im - in[6 - k].im;
+    }
+    out[0].re = in[0].re + pre[0] + pre[1] + pre[2];
+    out[0].im = in[0].im + pim[0] + pim[1] + pim[2];
+    /* cosine parts: z[k] = c0 * p[a] - c[b1] * p[b2] - c[c1] * p[c2] */
+    static const int zre[3][5] = { { 0, 2, 2, 1, 1 }, { 2, 1, 0, 2, 1 }, { 1, 2, 0, 1, 2 } };
+    static const int zim[3][5] = { { 0, 1, 1, 2, 2 }, { 2, 1, 0, 2, 1 }, { 1, 2, 0, 1, 2 } };
+    float zr[3], zi[3];
+    for (int k = 0; k < 3; k++) {
+        zr[k] = c[0] * pre[zre[k][0]] - c[zre[k][1]] * pre[zre[k][2]] - c[zre[k][3]] * pre[zre[k][4]];
+        zi[k] = c[0] * pim[zim[k][0]] - c[zim[k][1]] * pim[zim[k][2]] - c[zim[k][3]] * pim[zim[k][4]];
+    }
+    /* sine parts */
+    const float t0re = sn[2] * mim[0] + sn[1] * mim[2] - sn[0] * mim[1];
+    const float t2re = sn[0] * mim[2] + sn[2] * mim[1] - sn[1] * mim[0];
+    const float t4re = sn[2] * mim[2] + sn[1] * mim[1] + sn[0] * mim[0];
+    const float t0im = sn[0] * mre[0] + sn[1] * mre[1] + sn[2] * mre[2];
+    const float t2im = sn[2] * mre[1] + sn[0] * mre[2] - sn[1] * mre[0];
+    const float t4im = sn[2] * mre[0] + sn[1] * mre[2] - sn[0] * mre[1];
+    const float are[3] = { t4re, t2re, t0re }, aim[3] = { t0im, t2im, t4im };
+    const float dre = in[0].re, dim_ = in[0].im;
+    for (int k = 0; k < 3; k++) {
+        const float lo_re = zr[k] - are[k], hi_re = zr[k] + are[k], lo_im = zi[k] - aim[k], hi_im = zi[k] + aim[k];
+        /* outputs 1, 3 take (re +, im -), output 2 the opposite; the mirrored output the other pair */
+        const int o = k == 0 ? 1 : k == 1 ? 2 : 3;
+        if (k == 1) {
+            out[o * stride].re = dre + lo_re;
+            out[o * stride].im = dim_ + hi_im;
+            out[(7 - o) * stride].re = dre + hi_re;
+            out[(7 - o) * stride].im = dim_ + lo_im;
+        } else {
+            out[o * stride].re = dre + hi_re;
+            out[o * stride].im = dim_ + lo_im;
+            out[(7 - o) * stride].re = dre + lo_re;
+            out[(7 - o) * stride].im = dim_ + hi_im;
+        }
+    }
+}
+
+/* fft9 (tx_template.c:342-461, float branch): 3 x 3 with the twiddles folded in; tab = ff_tx_tab_9 as (re, im) pairs */
+static void fft9(const float *tab, cpx *out, const cpx *in, int stride)
+{
+    const float t0r = tab[0], t0i = tab[1], t1r = tab[2], t1i = tab[3], t2r = tab[4], t2i = tab[5], t3r = tab[6], t3i = tab[7];
+    cpx p[4], q[4]; /* sums / differences of in[k+1], in[8-k] */
+    for (int k = 0; k < 4; k++) {
+        p[k].re = in[k + 1].re + in[8 - k].re;
+        p[k].im = in[k + 1].im + in[8 - k].im;
+        q[k].re = in[k + 1].re - in[8 - k].re;
+        q[k].im = in[k + 1].im - in[8 - k].im;
+    }
+    const cpx w0 = { p[0].re - p[3].re, p[0].im - p[3].im }, w1 = { p[1].re - p[3].re, p[1].im - p[3].im };
+    const cpx w2 = { q[0].re - q[3].re, q[0].im - q[3].im }, w3 = { q[1].re + q[3].re, q[1].im + q[3].im };
+    cpx z0 = { in[0].re + p[2].re, in[0].im + p[2].im };
+    const cpx z1 = { p[0].re + p[1].re + p[3].re, p[0].im + p[1].im + p[3].im };
+    out[0].re = z0.re + z1.re;
+    out[0].im = z0.im + z1.im;
+    cpx x[5], y[5];
+    y[3].re = t0i * (q[0].re - q[1].re + q[3].re);
+    y[3].im = t0i * (q[0].im - q[1].im + q[3].im);
+    x[3].re = z0.re + t0r * z1.re;
+    x[3].im = z0.im + t0r * z1.im;
+    z0.re = in[0].re + t0r * p[2].re;
+    z0.im = in[0].im + t0r * p[2].im;
+    x[1].re = t1r * w0.re + t2i * w1.re;
+    x[1].im = t1r * w0.im + t2i * w1.im;
+    x[2].re = t2i * w0.re - t3r * w1.re;
+    x[2].im = t2i * w0.im - t3r * w1.im;
+    y[1].re = t1i * w2.re + t2r * w3.re;
+    y[1].im = t1i * w2.im + t2r * w3.im;
+    y[2].re = t2r * w2.re - t3i * w3.re;
+    y[2].im = t2r * w2.im - t3i * w3.im;
+    y[0].re = t0i * q[2].re;
+    y[0].im = t0i * q[2].im;
+    x[4].re = x[1].re + x[2].re;
+    x[4].im = x[1].im + x[2].im;
+    y[4].re = y[1].re - y[2].re;
+    y[4].im = y[1].im - y[2].im;
+    x[1].re = z0.re + x[1].re;
+    x[1].im = z0.im + x[1].im;
+    y[1].re = y[0].re + y[1].re;
+    y[1].im = y[0].im + y[1].im;
+    x[2].re = z0.re + x[2].re;
+    x[2].im = z0.im + x[2].im;
+    y[2].re = y[2].re - y[0].re;
+    y[2].im = y[2].im - y[0].im;
+    x[4].re = z0.re - x[4].re;
+    x[4].im = z0.im - x[4].im;
+    y[4].re = y[0].re - y[4].re;
+    y[4].im = y[0].im - y[4].im;
+    for (int k = 1; k <= 4; k++) {
+        out[k * stride].re = x[k].re + y[k].im;
+        out[k * stride].im = x[k].im - y[k].re;
+        out[(9 - k) * stride].re = x[k].re - y[k].im;
+        out[(9 - k) * stride].im = x[k].im + y[k].re;
+    }
+}
+
+static void fft5_plain(const float *tab, cpx *out, const cpx *in, int stride)
+{
+    static const int d[5] = { 0, 1, 2, 3, 4 };
+    fft5(tab, out, in, stride, d);
+}
+
+static void fft_small(const FfoTx *s, cpx *out, const cpx *in, int stride)
+{
+    switch (s->pfa_f) {
+    case 3:  fft3(s->tab53, out, in, stride);       break;
+    case 5:  fft5_plain(s->tab53, out, in, stride); break;
+    case 7:  fft7(s->tab7, out, in, stride);        break;
+    case 9:  fft9(s->tab9, out, in, stride);        break;
+    default: fft15(s->tab53, out, in, stride);      break;
+    }
+}
+
+static void pfa_run(const FfoTx *s, float *out, const float *in, ptrdiff_t stride)
+{
+    const int n = s->len >> 1, m = s->pfa_m, F = s->pfa_f;
     const int *in_map = s->map, *out_map = s->map + n;
     const cpx *exp = s->exp;
     cpx *tmp = malloc(sizeof(cpx) * n), f[15];
@@ -390,18 +545,18 @@ static void pfa15_run(const FfoTx *s, float *out, const float *in, ptrdiff_t str
         lg++;
     stride /= (ptrdiff_t)sizeof(float);
     if (s->inv) {
-        const float *in1 = in, *in2 = in + (15 * m * 2 - 1) * stride;
+        const float *in1 = in, *in2 = in + (F * m * 2 - 1) * stride;
         cpx *z = (cpx *)out;
         const int len4 = s->len >> 2;
         for (int i = 0; i < m; i++) {
-            for (int j = 0; j < 15; j++) {
-                const int k = in_map[i * 15 + j];
+            for (int j = 0; j < F; j++) {
+                const int k = in_map[i * F + j];
                 const cpx t = { in2[-k * stride], in1[k * stride] };
-                CMUL(f[j].re, f[j].im, t.re, t.im, exp[i * 15 + j].re, exp[i * 15 + j].im);
+                CMUL(f[j].re, f[j].im, t.re, t.im, exp[i * F + j].re, exp[i * F + j].im);
             }
-            fft15(s->tab53, tmp + s->sub_map[i], f, m);
+            fft_small(s, tmp + s->sub_map[i], f, m);
         }
-        for (int i = 0; i < 15; i++)
+        for (int i = 0; i < F; i++)
             sr_fft(s, tmp + m * i, m, lg);
         exp += n;
         for (int i = 0; i < len4; i++) {
@@ -414,8 +569,8 @@ static void pfa15_run(const FfoTx *s, float *out, const float *in, ptrdiff_t str
     } else {
         const int len4 = n, len3 = len4 * 3, len8 = s->len >> 2;
         for (int i = 0; i < m; i++) {
-            for (int j = 0; j < 15; j++) {
-                const int k = in_map[i * 15 + j];
+            for (int j = 0; j < F; j++) {
+                const int k = in_map[i * F + j];
                 cpx t;
                 if (k < len4) {
                     t.re = -in[len4 + k] + in[1 * len4 - 1 - k];
@@ -426,9 +581,9 @@ static void pfa15_run(const FfoTx *s, float *out, const float *in, ptrdiff_t str
                 }
                 CMUL(f[j].im, f[j].re, t.re, t.im, exp[k >> 1].re, exp[k >> 1].im);
             }
-            fft15(s->tab53, tmp + s->sub_map[i], f, m);
+            fft_small(s, tmp + s->sub_map[i], f, m);
         }
-        for (int i = 0; i < 15; i++)
+        for (int i = 0; i < F; i++)
             sr_fft(s, tmp + m * i, m, lg);
         for (int i = 0; i < len8; i++) {
             const int i0 = len8 + i, i1 = len8 - i - 1;

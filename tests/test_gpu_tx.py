@@ -206,13 +206,51 @@ def test_mdct_pfa15_batch(inv, len_, scale, nt):
     ctx.close()
 
 
+@pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("f", [3, 5, 7, 9])
+@pytest.mark.parametrize("m,nt", [(4, 1003), (8, 61), (16, 333), (32, 77), (64, 2001), (128, 150), (256, 301)])
+def test_mdct_pfa_3579_batch(f, m, nt, inv):
+    """2 * F * 2^k, F = 3 / 5 / 7 / 9 (ff_tx_mdct_pfa_<F>xM: 96- and 768-sample AAC frames = 3 x 32 / 3 x 256, Siren's 320 = 5 x 64
+    ...): bit-identical to the oracle (itself pinned to the codelet av_tx_init picks); sub-transform sizes with several transforms per
+    wave (m < 64) and several sub-transforms per lane (m > 64)"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    len_ = 2 * f * m
+    scale = (1.0, 1.0 / len_, -0.37)[(f + m) % 3]
+    rng = np.random.default_rng(len_ + inv)
+    n_in = len_ if inv else 2 * len_
+    inp = ((rng.random((nt, n_in), dtype=np.float32) * 2 - 1) * 10.0 ** rng.integers(-2, 3, (nt, 1))).astype(np.float32)
+    inp[1] = 0
+    want = _oracle(inv, len_, scale, inp)
+    ctx = tx.TxContext(tx.FLOAT_MDCT, inv, len_, scale)
+    d_in = torch.from_numpy(inp).cuda()
+    d_out = torch.zeros((nt, len_ + 6), dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out[:, :len_], d_in)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    _check(np.ascontiguousarray(got[:, :len_]), want)
+    assert not got[:, len_:].any()
+    o1 = np.zeros(len_, np.float32)
+    ctx.fn(o1, inp[nt - 1])
+    _check(o1[None], want[nt - 1:nt])
+    ctx.close()
+
+
+def test_mdct_pfa_unsupported_lengths():
+    from ffmpeg_amd import tx
+    _torch()
+    for len_ in (2 * 15 * 128, 2 * 3 * 512, 2 * 11 * 16, 2 * 3 * 2, 2 * 45 * 4):
+        with pytest.raises(RuntimeError):
+            tx.TxContext(tx.FLOAT_MDCT, 0, len_, 1.0)
+
+
 def test_mdct_pfa15_rejects_strided_rows():
     from ffmpeg_amd import tx
     torch = _torch()
     ctx = tx.TxContext(tx.FLOAT_MDCT, 0, 960, 1.0)
     d_in = torch.zeros((2, 1920), dtype=torch.float32, device="cuda:0")
     d_out = torch.zeros((2, 1920), dtype=torch.float32, device="cuda:0")
-    with pytest.raises(RuntimeError, match="15xM"):
+    with pytest.raises(RuntimeError, match="prime-factor"):
         ctx.batch(d_out, d_in, stride=8)
     ctx.close()
 

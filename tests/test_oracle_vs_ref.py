@@ -950,6 +950,32 @@ def test_mdct_float(len_, inv):
     R.ffref_tx_free(rc); O.ffo_mdct_free(oc)
 
 
+PFA_LENS = [2 * f * m for f in (3, 5, 7, 9) for m in (4, 8, 16, 32, 64, 128, 256)]           # ff_tx_mdct_pfa_{3,5,7,9}xM
+
+
+@pytest.mark.parametrize("len_", PFA_LENS + [2 * 3 * 2, 2 * 9 * 512, 2 * 5 * 1024])
+@pytest.mark.parametrize("inv", [0, 1])
+def test_mdct_float_pfa_3579(len_, inv):
+    """DECL_COMP_MDCT(3 / 5 / 7 / 9) (libavutil/tx_template.c:1595-1598; fft7 / fft9 :250-461): the codelet av_tx_init picks for
+    len / 2 = N * 2^k is the one the oracle restates (96 / 768-sample AAC frames = 3 x 32 / 3 x 256, Siren's 320 = 5 x 64, ...),
+    negative scales included - bit-identical"""
+    R, O = ffi.ref(), ffi.oracle()
+    ffi_int = O.ffo_mdct_pfa_factor(len_)
+    assert ffi_int in (3, 5, 7, 9)
+    rng = np.random.default_rng(7 * len_ + inv)
+    for scale in (1.0 / len_ if inv else 1.0, -0.013):
+        rc = R.ffref_tx_create(1, inv, len_, scale, 0)
+        oc = O.ffo_mdct_create(inv, len_, scale)
+        assert rc and oc
+        for _ in range(3):
+            x = (rng.uniform(-1, 1, 2 * len_ if not inv else len_) * 10.0 ** float(rng.integers(-2, 3))).astype(np.float32)
+            a = np.zeros(len_, np.float32); b = np.zeros(len_, np.float32)
+            R.ffref_tx_run(rc, ptr(a, f32p), ptr(x.copy(), f32p), 4)
+            O.ffo_mdct_run(oc, ptr(b, f32p), ptr(x, f32p), 4)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (scale, np.abs(a - b).max())
+        R.ffref_tx_free(rc); O.ffo_mdct_free(oc)
+
+
 @pytest.mark.parametrize("inv", [0, 1])
 @pytest.mark.parametrize("len_", [4, 8, 16, 64, 256, 1024, 2048, 4096])
 def test_fft_float(len_, inv):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/bench_pfa.py — the 15xM prime-factor MDCT lengths (CELT / AAC-960) on one GPU, HIP events; 65,536 transforms each."""
+"""tools/bench_pfa.py — the prime-factor MDCT lengths (15xM: CELT / AAC-960; 3xM: 96- / 768-sample AAC frames; 5xM: Siren;
+7xM / 9xM) on one GPU, HIP events; 65,536 transforms each."""
 import json
 import os
 import sys
@@ -10,7 +11,8 @@ import torch  # noqa: E402
 from ffmpeg_amd import tx  # noqa: E402
 
 nt = 65536
-for ln in (120, 240, 480, 960, 1920):
+LENS = (120, 240, 480, 960, 1920, 192, 1536, 640, 896, 1152, 4608)
+for ln in LENS:
     for inv in (0, 1):
         tin = torch.rand((nt, ln if inv else 2 * ln), dtype=torch.float32, device="cuda:0")
         tout = torch.empty((nt, ln), dtype=torch.float32, device="cuda:0")
