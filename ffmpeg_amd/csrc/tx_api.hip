@@ -710,10 +710,17 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
         oa = make_float2(t0r + t2r, t2i - t0i);
         ob = make_float2(t0r - t2r, t2i + t0i);
     };
-    for (int t = blockIdx.x * (blockDim.x >> 6) + wave; t < nt; t += waves_total) {
+    /* the workgroup's waves step together (the forward transform's running sums are evaluated for all of them at once, below):
+     * wave w takes transform t0 + w; a wave past the end of the batch only keeps the barriers company */
+    const int W = blockDim.x >> 6;
+    for (int t0 = blockIdx.x * W; t0 < nt; t0 += waves_total) {
+        const int t = t0 + wave;
+        const bool active = t < nt;
+        if (INV && !active)
+            continue; /* (no barriers on the inverse path) */
         const float *x = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
         float *y = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
-        if (!INV) {
+        if (!INV && active) {
             /* element c = (y[2c], y[2c+1]) and its mirror len2-1-c = (y[N-2-2c], y[N-1-2c]) from two coalesced float2 loads */
             const float2 *x2 = reinterpret_cast<const float2 *>(x);
             for (int c = lane; c < len4; c += 64) {
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
                 z[l_map[c]] = make_float2(p1 + p2, q1 + q2);
                 z[l_map[len2 - 1 - c]] = make_float2(q1 - q2, p1 - p2);
             }
-        } else {
+        } else if (INV) {
             /* bin k of the sequence ff_tx_dctIII hands the c2r transform */
             auto bin = [&](int k) {
                 const int j = 2 * k;
@@ -748,8 +755,10 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
             }
         }
         tx_wave_sync();
-        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
+        if (INV || active)
+            tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
         if (!INV) {
+          if (active) {
             /* X[k] -> out[2k] (parked in the bin's own slot) and t_k (acc[k]); acc[len2] = Re X[N/2] */
             auto rot = [&](int k, float2 X) {
                 const float e1 = dexp[N - 2 * k], e2 = dexp[2 * k];
@@ -771,47 +780,46 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
                     rot(len2 - i, ob);
                 }
             }
-            tx_wave_sync();
-            if (lane == 0) {
-                /* acc[k] becomes out[2k - 1].  Every instruction of this one-lane section costs the wave a full issue slot, so
-                 * the chain is bound by instructions per term, not by the adds' latency: eight terms per trip through registers
-                 * (paired LDS reads / writes) measured best — 135 M transforms/s at N = 1024, against 111 M/s with the sums
-                 * written to a separate array and 342 M/s for the DCT-III, which has no such chain */
-                float next = acc[len2];
+          }
+            /* acc[k] becomes out[2k - 1]: out[N - 1] = Re X[N/2], out[2k - 1] = out[2k + 1] + t_k — a chain of float additions whose
+             * order is the result, so nothing inside a transform runs it in parallel.  Across transforms it does: lane w of the
+             * workgroup's first wave walks the chain of wave w's transform, the W chains cost the instruction slots of one
+             * (round 1 had every wave walk its own with one live lane: 138 M transforms/s at N = 1024 against 342 M/s for the
+             * DCT-III, which has no such chain).  Eight terms per trip through registers. */
+            __syncthreads();
+            if (wave == 0 && lane < W && t0 + lane < nt) {
+                float *a = reinterpret_cast<float *>(lds_raw + ((blob_bytes + 15) & ~15) + lane * per_wave + tx_z_bytes(len2));
+                /* eight terms per trip: two 16-byte LDS reads (the next trip's, issued ahead), eight dependent adds each writing
+                 * the sum in place of its term, two 16-byte writes (len2 >= 8: a[len2 - 8 .. len2 - 1] is 16-byte aligned) */
+                float next = a[len2];
                 int k = len2 - 1;
-                if (k >= 8) {
-                    float cur[8], nxt[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        cur[j] = acc[k - j];
-                    for (; k >= 16; k -= 8) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            nxt[j] = acc[k - 8 - j];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            next += cur[j];
-                            cur[j] = next;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            acc[k - j] = cur[j];
-                            cur[j] = nxt[j];
-                        }
+                if (len2 < 8) { /* N = 8 */
+                    for (; k > 0; k--) {
+                        next += a[k];
+                        a[k] = next;
                     }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        next += cur[j];
-                        acc[k - j] = next;
-                    }
-                    k -= 8;
+                } else {
+                float4 lo = *reinterpret_cast<const float4 *>(a + k - 7), hi = *reinterpret_cast<const float4 *>(a + k - 3);
+                for (; k >= 15; k -= 8) {
+                    const float4 nlo = *reinterpret_cast<const float4 *>(a + k - 15), nhi = *reinterpret_cast<const float4 *>(a + k - 11);
+                    hi.w = next + hi.w; hi.z = hi.w + hi.z; hi.y = hi.z + hi.y; hi.x = hi.y + hi.x;
+                    lo.w = hi.x + lo.w; lo.z = lo.w + lo.z; lo.y = lo.z + lo.y; lo.x = lo.y + lo.x;
+                    next = lo.x;
+                    *reinterpret_cast<float4 *>(a + k - 3) = hi;
+                    *reinterpret_cast<float4 *>(a + k - 7) = lo;
+                    lo = nlo;
+                    hi = nhi;
                 }
-                for (; k > 0; k--) {
-                    next += acc[k];
-                    acc[k] = next;
+                /* the last trip: a[0 .. 7]; a[0] takes no part (out[-1] does not exist) */
+                hi.w = next + hi.w; hi.z = hi.w + hi.z; hi.y = hi.z + hi.y; hi.x = hi.y + hi.x;
+                lo.w = hi.x + lo.w; lo.z = lo.w + lo.z; lo.y = lo.z + lo.y;
+                *reinterpret_cast<float4 *>(a + 4) = hi;
+                *reinterpret_cast<float4 *>(a) = lo;
                 }
             }
-            tx_wave_sync();
+            __syncthreads();
+            if (!active)
+                continue;
             float2 *y2 = reinterpret_cast<float2 *>(y);
             for (int k = lane; k < len2; k += 64)
                 y2[k] = make_float2(z[TX_PAD(k)].x, acc[k + 1]);
@@ -1487,7 +1495,12 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         const int blob_arg = tl ? (int)c->blob_bytes : 0;
         /* the forward DCT keeps its running-sum terms behind each wave's work array */
         const size_t zw = tx_z_bytes(n) + (c->type == FFHIP_TX_FLOAT_DCT && !c->inv ? (((size_t)n + 1) * 4 + 15) & ~(size_t)15 : 0);
-        int wpb = 16;
+        /* the forward DCT's workgroups meet at two barriers per transform (the running sums): two or three smaller ones per CU
+         * overlap one's chain with another's transforms */
+        const char *ewpb = getenv("FFHIP_DCT_WPB");
+        int wpb = c->type == FFHIP_TX_FLOAT_DCT && !c->inv ? (ewpb ? atoi(ewpb) : 8) : 16;
+        if (wpb < 1 || wpb > 16 || (wpb & (wpb - 1)))
+            wpb = 8;
         size_t lds_z = blob_lds + zw * wpb;
         while (wpb > 1 && lds_z > 150 * 1024) {
             wpb >>= 1;
