@@ -18,13 +18,17 @@ SCALE_LTP = -32786.0 * 2 + 36
 
 
 class AacImdct:
-    def __init__(self, windows, scale_1024=SCALE_1024, scale_128=SCALE_128):
-        """windows: (sine_1024, sine_128, kbd_long_1024, kbd_short_128) float32 arrays - the decoder's own tables"""
+    def __init__(self, windows, scale_1024=None, scale_128=None, frame_len=1024):
+        """windows: (sine_<L>, sine_<L/8>, kbd_long_<L>, kbd_short_<L/8>) float32 arrays - the decoder's own tables; frame_len L =
+        1024, 960 (imdct_and_windowing_960) or 768 (_768); the scales default to MDCT_INIT's (1 / len) / 32768"""
         w = [np.ascontiguousarray(x, np.float32) for x in windows]
-        assert [x.size for x in w] == [1024, 128, 1024, 128]
+        assert [x.size for x in w] == [frame_len, frame_len // 8, frame_len, frame_len // 8]
+        scale_1024 = (1.0 / frame_len) / 32768.0 if scale_1024 is None else scale_1024
+        scale_128 = (8.0 / frame_len) / 32768.0 if scale_128 is None else scale_128
+        self.frame_len = frame_len
         self._c = _lib.vp()
-        _lib.check(_lib.lib().ffhip_aac_imdct_create(C.byref(self._c), w[0].ctypes.data, w[1].ctypes.data, w[2].ctypes.data, w[3].ctypes.data,
-                                                     scale_1024, scale_128), "ffhip_aac_imdct_create")
+        _lib.check(_lib.lib().ffhip_aac_imdct_create_len(C.byref(self._c), frame_len, w[0].ctypes.data, w[1].ctypes.data, w[2].ctypes.data,
+                                                         w[3].ctypes.data, scale_1024, scale_128), "ffhip_aac_imdct_create_len")
 
     def close(self):
         if getattr(self, "_c", None) is not None and self._c and _lib is not None:
@@ -37,7 +41,7 @@ class AacImdct:
         """one channel, one frame on host float32 arrays; window_sequence / use_kb_window = (this frame, previous frame)"""
         seq = (C.c_int * 2)(*window_sequence)
         kb = (C.c_int * 2)(*use_kb_window)
-        assert coeffs.dtype == saved.dtype == out.dtype == np.float32 and coeffs.size >= 1024 and saved.size >= 512 and out.size >= 1024
+        assert coeffs.dtype == saved.dtype == out.dtype == np.float32 and coeffs.size >= 1024 and saved.size >= self.frame_len // 2 and out.size >= self.frame_len
         return _lib.check(_lib.lib().ffhip_aac_imdct_and_windowing(self._c, coeffs.ctypes.data, seq, kb, saved.ctypes.data, out.ctypes.data),
                           "ffhip_aac_imdct_and_windowing")
 

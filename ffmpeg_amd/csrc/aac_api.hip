@@ -33,7 +33,8 @@ struct FFHipAacImdct {
     size_t last_n = 0;          /* the frames of the last imdct_and_windowing_batch_dev call: buf / tail / info / pos still hold them */
     int last_nch = 0;
     bool last_sorted = false;
-    float *win = nullptr;       /* [4][1024]: sine_1024, sine_128, kbd_long_1024, kbd_short_128 */
+    int L = 1024, in_short = 128; /* frame length (1024, 960, 768) and the distance of a short window's coefficients in a frame */
+    float *win = nullptr;       /* [4][1024]: sine_<L>, sine_<L/8>, kbd_long_<L>, kbd_short_<L/8> */
     uint8_t *work = nullptr;    /* buf [n][1024] f32, tail [n][512] f32, sorted coeffs [n][1024] f32, pos [n] i32, info [n] u8 */
     size_t work_frames = 0;
     std::mutex mu;
@@ -62,10 +63,11 @@ __device__ __forceinline__ float4 aac_wov4(const float *src0, const float *src1,
 /* info byte: sequence | kb << 2 | previous sequence << 3 | previous kb << 5 */
 /* pos: where frame f's buf[] lives when the frames were sorted by transform kind (nullptr: at f).  One thread = 4 samples. */
 __global__ __launch_bounds__(128) void k_aac_tail(const float *buf, const int *pos, const uint8_t *info, const float *win, float *tail,
-                                                  int first_final)
+                                                  int first_final, int L)
 {
+    const int H = L >> 1, S = L >> 3, S2 = S >> 1, A = H - S2; /* 1024: 512, 128, 64, 448 */
     const int f = blockIdx.x;
-    const float *b = buf + (size_t)(pos ? pos[f] : f) * 1024;
+    const float *b = buf + (size_t)(pos ? pos[f] : f) * L;
     const int in = info[f], seq = in & 3;
     /* a long frame's tail is the upper half of its buf[]: k_aac_out reads it there; only the batch's last frames (the state handed
      * back to the caller) are copied out */
@@ -73,53 +75,66 @@ __global__ __launch_bounds__(128) void k_aac_tail(const float *buf, const int *p
         return;
     const float *swindow = win + ((in >> 2) & 1 ? 3 : 1) * 1024;
     const int s = 4 * threadIdx.x;
+    if (s >= H)
+        return;
     float4 v;
-    if (seq != AAC_EIGHT_SHORT || s >= 448) {
-        v = aac_ld4(b + 512 + s); /* LONG_START's two copies (448 + 64 samples) are this one range as well */
-    } else if (s < 64) {
-        v = aac_wov4(b + 448, b + 512, swindow, 64, 64 + s);
+    if (seq != AAC_EIGHT_SHORT || s >= A) {
+        v = aac_ld4(b + H + s); /* LONG_START's two copies (A + S2 samples) are this one range as well */
+    } else if (s < S2) {
+        v = aac_wov4(b + 3 * S + S2, b + 4 * S, swindow, S2, S2 + s);
     } else {
-        const int q = (s - 64) >> 7, e = (s - 64) & 127;
-        v = aac_wov4(b + (4 + q) * 128 + 64, b + (5 + q) * 128, swindow, 64, e);
+        const int q = (s - S2) / S, e = (s - S2) - q * S;
+        v = aac_wov4(b + (4 + q) * S + S2, b + (5 + q) * S, swindow, S2, e);
     }
     *reinterpret_cast<float4 *>(tail + (size_t)f * 512 + s) = v;
 }
 
 __global__ __launch_bounds__(256) void k_aac_out(const float *buf, const int *pos, const uint8_t *info, const float *win, const float *tail,
-                                                 const float *saved, int nch, float *out)
+                                                 const float *saved, int nch, float *out, int L)
 {
+    const int H = L >> 1, S = L >> 3, S2 = S >> 1, A = H - S2;
     const int f = blockIdx.x;
-    const float *b = buf + (size_t)(pos ? pos[f] : f) * 1024;
+    const float *b = buf + (size_t)(pos ? pos[f] : f) * L;
     const int in = info[f], seq = in & 3, pseq = (in >> 3) & 3, pkb = (in >> 5) & 1;
     const float *sv = f < nch                    ? saved + (size_t)f * 512
-                      : pseq != AAC_EIGHT_SHORT ? buf + (size_t)(pos ? pos[f - nch] : f - nch) * 1024 + 512
+                      : pseq != AAC_EIGHT_SHORT ? buf + (size_t)(pos ? pos[f - nch] : f - nch) * L + H
                                                 : tail + (size_t)(f - nch) * 512;
     const float *swindow = win + ((in >> 2) & 1 ? 3 : 1) * 1024, *lwindow_prev = win + (pkb ? 2 : 0) * 1024, *swindow_prev = win + (pkb ? 3 : 1) * 1024;
     const bool long_long = (pseq == AAC_ONLY_LONG || pseq == AAC_LONG_STOP) && (seq == AAC_ONLY_LONG || seq == AAC_LONG_START);
-    const int o = 4 * threadIdx.x; /* the region borders 448 / 576 / 960 are multiples of 4 */
+    const int o = 4 * threadIdx.x; /* the region borders (1024: 448 / 576 / 960) are multiples of 4 at every frame length */
+    if (o >= L)
+        return;
     float4 v;
     if (long_long) {
-        v = aac_wov4(sv, b, lwindow_prev, 512, o);
-    } else if (o < 448) {
+        v = aac_wov4(sv, b, lwindow_prev, H, o);
+    } else if (o < A) {
         v = aac_ld4(sv + o);
-    } else if (o < 576) {
-        v = aac_wov4(sv + 448, b, swindow_prev, 64, o - 448);
+    } else if (o < A + S) {
+        v = aac_wov4(sv + A, b, swindow_prev, S2, o - A);
     } else if (seq != AAC_EIGHT_SHORT) {
-        v = aac_ld4(b + o - 512);
-    } else if (o < 960) {
-        const int q = (o - 576) >> 7;
-        v = aac_wov4(b + q * 128 + 64, b + (q + 1) * 128, swindow, 64, (o - 576) & 127);
+        v = aac_ld4(b + o - H);
+    } else if (o < A + 4 * S) {
+        const int q = (o - A - S) / S;
+        v = aac_wov4(b + q * S + S2, b + (q + 1) * S, swindow, S2, (o - A - S) - q * S);
     } else {
-        v = aac_wov4(b + 448, b + 512, swindow, 64, o - 960);
+        v = aac_wov4(b + 3 * S + S2, b + 4 * S, swindow, S2, o - (A + 4 * S));
     }
     *reinterpret_cast<float4 *>(out + (size_t)f * 1024 + o) = v;
 }
 
-/* sorted[pos[f]] = coeffs[f]: 16 bytes per thread */
-__global__ __launch_bounds__(256) void k_aac_gather(const float4 *coeffs, const int *pos, float4 *sorted)
+/* sorted[pos[f]] = coeffs[f], compacted to L floats per frame (a short frame's eight windows, `in_short` apart in the caller's
+ * frame, S apart here): 16 bytes per thread */
+__global__ __launch_bounds__(256) void k_aac_gather(const float *coeffs, const int *pos, const uint8_t *info, float *sorted, int L, int in_short)
 {
-    const int f = blockIdx.x;
-    sorted[(size_t)pos[f] * 256 + threadIdx.x] = coeffs[(size_t)f * 256 + threadIdx.x];
+    const int f = blockIdx.x, i = 4 * threadIdx.x, S = L >> 3;
+    if (i >= L)
+        return;
+    int src = i;
+    if ((info[f] & 3) == AAC_EIGHT_SHORT) {
+        const int w = i / S;
+        src = w * in_short + (i - w * S);
+    }
+    *reinterpret_cast<float4 *>(sorted + (size_t)pos[f] * L + i) = aac_ld4(coeffs + (size_t)f * 1024 + src);
 }
 
 extern "C" void ffhip_aac_imdct_free(FFHipAacImdct **pc)
@@ -137,25 +152,32 @@ extern "C" void ffhip_aac_imdct_free(FFHipAacImdct **pc)
     *pc = nullptr;
 }
 
-extern "C" int ffhip_aac_imdct_create(FFHipAacImdct **pc, const float *sine_1024, const float *sine_128, const float *kbd_long_1024,
-                                      const float *kbd_short_128, float scale_1024, float scale_128)
+extern "C" int ffhip_aac_imdct_create_len(FFHipAacImdct **pc, int frame_len, const float *sine_long, const float *sine_short,
+                                          const float *kbd_long, const float *kbd_short, float scale_long, float scale_short)
 {
-    if (!pc || !sine_1024 || !sine_128 || !kbd_long_1024 || !kbd_short_128)
+    if (!pc || !sine_long || !sine_short || !kbd_long || !kbd_short)
         return FFHIP_EINVAL;
     *pc = nullptr;
+    if (frame_len != 1024 && frame_len != 960 && frame_len != 768) {
+        ffhip_set_error("ffhip_aac_imdct_create: frame length %d (1024, 960, 768)", frame_len);
+        return FFHIP_EINVAL;
+    }
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     FFHipAacImdct *c = new (std::nothrow) FFHipAacImdct();
     if (!c)
         return FFHIP_ENOMEM;
-    int r = ffhip_tx_init(&c->tx1024, nullptr, FFHIP_TX_FLOAT_MDCT, 1, 1024, &scale_1024, 0);
+    const int L = frame_len, S = L / 8;
+    c->L = L;
+    c->in_short = L == 768 ? 96 : 128; /* imdct_and_windowing_768 reads in + i * 96, the other two in + i * 128 */
+    int r = ffhip_tx_init(&c->tx1024, nullptr, FFHIP_TX_FLOAT_MDCT, 1, L, &scale_long, 0);
     if (r >= 0)
-        r = ffhip_tx_init(&c->tx128, nullptr, FFHIP_TX_FLOAT_MDCT, 1, 128, &scale_128, 0);
+        r = ffhip_tx_init(&c->tx128, nullptr, FFHIP_TX_FLOAT_MDCT, 1, S, &scale_short, 0);
     std::vector<float> w(4 * 1024, 0.0f);
-    memcpy(&w[0], sine_1024, 1024 * sizeof(float));
-    memcpy(&w[1024], sine_128, 128 * sizeof(float));
-    memcpy(&w[2048], kbd_long_1024, 1024 * sizeof(float));
-    memcpy(&w[3072], kbd_short_128, 128 * sizeof(float));
+    memcpy(&w[0], sine_long, L * sizeof(float));
+    memcpy(&w[1024], sine_short, S * sizeof(float));
+    memcpy(&w[2048], kbd_long, L * sizeof(float));
+    memcpy(&w[3072], kbd_short, S * sizeof(float));
     if (r >= 0 && (hipMalloc(&c->win, w.size() * sizeof(float)) != hipSuccess ||
                    hipMemcpy(c->win, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)) {
         ffhip_set_error("ffhip_aac_imdct_create: window upload failed");
@@ -167,6 +189,12 @@ extern "C" int ffhip_aac_imdct_create(FFHipAacImdct **pc, const float *sine_1024
     }
     *pc = c;
     return 0;
+}
+
+extern "C" int ffhip_aac_imdct_create(FFHipAacImdct **pc, const float *sine_1024, const float *sine_128, const float *kbd_long_1024,
+                                      const float *kbd_short_128, float scale_1024, float scale_128)
+{
+    return ffhip_aac_imdct_create_len(pc, 1024, sine_1024, sine_128, kbd_long_1024, kbd_short_128, scale_1024, scale_128);
 }
 
 extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const float *coeffs, float *out, float *saved,
@@ -201,7 +229,8 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
         nlong += window_sequence[i] != AAC_EIGHT_SHORT;
         runs += i && (window_sequence[i] == AAC_EIGHT_SHORT) != (window_sequence[i - 1] == AAC_EIGHT_SHORT);
     }
-    const bool sort = runs > 8;
+    const int L = c->L, S = L / 8;
+    const bool sort = runs > 8 || L != 1024; /* the other frame lengths always compact their frames to L floats */
     const size_t per = 1024 * 4 + 512 * 4 + 1024 * 4 + 4 + 1; /* buf, tail, sorted coefficients, pos, info */
     if (n > c->work_frames) {
         if (c->work) {
@@ -230,10 +259,11 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
             pos[i] = (int)(window_sequence[i] != AAC_EIGHT_SHORT ? il++ : is++);
         if (hipMemcpyAsync(dpos, pos.data(), n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
             return FFHIP_EINVAL;
-        hipLaunchKernelGGL(k_aac_gather, dim3((unsigned)n), dim3(256), 0, st, (const float4 *)coeffs, dpos, (float4 *)sorted);
-        int r = nlong ? ffhip_tx_batch_dev(c->tx1024, buf, 4096, sorted, 4096, sizeof(float), (int)nlong, stream) : 0;
+        hipLaunchKernelGGL(k_aac_gather, dim3((unsigned)n), dim3(256), 0, st, coeffs, dpos, dinfo, sorted, L, c->in_short);
+        int r = nlong ? ffhip_tx_batch_dev(c->tx1024, buf, (size_t)L * 4, sorted, (size_t)L * 4, sizeof(float), (int)nlong, stream) : 0;
         if (r >= 0 && n > nlong)
-            r = ffhip_tx_batch_dev(c->tx128, buf + nlong * 1024, 512, sorted + nlong * 1024, 512, sizeof(float), (int)(n - nlong) * 8, stream);
+            r = ffhip_tx_batch_dev(c->tx128, buf + nlong * L, (size_t)S * 4, sorted + nlong * L, (size_t)S * 4, sizeof(float), (int)(n - nlong) * 8,
+                                   stream);
         if (r < 0)
             return r;
     } else {
@@ -250,10 +280,11 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
             i = j;
         }
     }
-    hipLaunchKernelGGL(k_aac_tail, dim3((unsigned)n), dim3(128), 0, st, buf, dpos, dinfo, c->win, tail, (int)(n - nch));
-    hipLaunchKernelGGL(k_aac_out, dim3((unsigned)n), dim3(256), 0, st, buf, dpos, dinfo, c->win, tail, saved, nch, out);
+    hipLaunchKernelGGL(k_aac_tail, dim3((unsigned)n), dim3(128), 0, st, buf, dpos, dinfo, c->win, tail, (int)(n - nch), L);
+    hipLaunchKernelGGL(k_aac_out, dim3((unsigned)n), dim3(256), 0, st, buf, dpos, dinfo, c->win, tail, saved, nch, out, L);
     LAUNCH_CHECK();
-    if (hipMemcpyAsync(saved, tail + (n - nch) * 512, (size_t)nch * 512 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    if (hipMemcpy2DAsync(saved, 512 * sizeof(float), tail + (n - nch) * 512, 512 * sizeof(float), (size_t)(L / 2) * sizeof(float), (size_t)nch,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess)
         return FFHIP_EINVAL;
     c->last_n = n;
     c->last_nch = nch;
@@ -274,14 +305,14 @@ extern "C" int ffhip_aac_imdct_and_windowing(FFHipAacImdct *c, const float *coef
         return FFHIP_ENOMEM;
     float *dco = (float *)scratch, *dout = dco + 1024, *dsv = dout + 1024;
     if (hipMemcpy(dco, coeffs, 1024 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dsv, saved, 512 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(dsv, saved, (size_t)(c->L / 2) * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return FFHIP_EINVAL;
     const uint8_t seq = (uint8_t)window_sequence[0], kb = (uint8_t)use_kb_window[0], pseq = (uint8_t)window_sequence[1], pkb = (uint8_t)use_kb_window[1];
     const int r = ffhip_aac_imdct_and_windowing_batch_dev(c, dco, dout, dsv, &seq, &kb, &pseq, &pkb, 1, 1, nullptr);
     if (r < 0)
         return r;
-    if (hipStreamSynchronize(nullptr) != hipSuccess || hipMemcpy(out, dout, 1024 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(saved, dsv, 512 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipStreamSynchronize(nullptr) != hipSuccess || hipMemcpy(out, dout, (size_t)c->L * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(saved, dsv, (size_t)(c->L / 2) * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         return FFHIP_EINVAL;
     return 0;
 }
@@ -688,6 +719,10 @@ extern "C" int ffhip_aac_update_ltp_batch_dev(FFHipAacImdct *c, float *ltp_state
         return FFHIP_EINVAL;
     }
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->L != 1024) {
+        ffhip_set_error("ffhip_aac_update_ltp: long-term prediction runs on 1024-sample frames only (as apply_ltp / update_ltp do)");
+        return FFHIP_EINVAL;
+    }
     if (!c->last_n || c->last_nch != nch) {
         ffhip_set_error("ffhip_aac_update_ltp: follows an imdct_and_windowing_batch_dev call of the same %d channels on this context", nch);
         return FFHIP_EINVAL;

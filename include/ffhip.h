@@ -520,6 +520,14 @@ int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const 
 typedef struct FFHipAacImdct FFHipAacImdct;
 int  ffhip_aac_imdct_create(FFHipAacImdct **c, const float *sine_1024, const float *sine_128, const float *kbd_long_1024,
                             const float *kbd_short_128, float scale_1024, float scale_128);
+/** The same for the other frame lengths: 960 (AACDecDSP.imdct_and_windowing_960, aacdec_dsp_template.c:453-512; DAB+ / DRM) and 768
+ *  (_768, :389-448); the tables are sine_<len>, sine_<len / 8>, the KBD windows of alpha 4 / 6 at those sizes, the scales those of
+ *  mdct960 / mdct120 resp. mdct768 / mdct96 (aacdec.c:1278-1284).  Row pitches stay those of the 1024 case — coeffs / out rows 1024
+ *  floats (sce->coeffs / sce->output are that wide whatever the frame length; a short window's coefficients sit 128 apart in a 960
+ *  frame, 96 apart in a 768 one, as the reference reads them), saved 512 per channel — of which the first len / len / len / 2 are
+ *  used.  Long-term prediction exists at 1024 only. */
+int  ffhip_aac_imdct_create_len(FFHipAacImdct **c, int frame_len, const float *sine_long, const float *sine_short, const float *kbd_long,
+                                const float *kbd_short, float scale_long, float scale_short);
 void ffhip_aac_imdct_free(FFHipAacImdct **c);
 /** One channel, one frame, host pointers: the member's effect on sce->coeffs / ics.window_sequence[2] / ics.use_kb_window[2]
  *  ([0] this frame, [1] the previous one) / sce->saved (512 floats in and out) / sce->output (1024 floats). */

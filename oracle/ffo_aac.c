@@ -58,45 +58,54 @@ static void window_overlap(float *dst, const float *src0, const float *src1, con
     }
 }
 
-/* windows[]: sine_1024, sine_128, kbd_long_1024, kbd_short_128; seq / kb = { this frame, previous frame } */
-void ffo_aac_imdct_and_windowing(const FfoTx *mdct1024, const FfoTx *mdct128, const float *const windows[4], const float *coeffs,
-                                 const int seq[2], const int kb[2], float *saved, float *out)
+/* windows[]: sine_<L>, sine_<L/8>, kbd_long_<L>, kbd_short_<L/8>; seq / kb = { this frame, previous frame }.
+ * L = 1024: imdct_and_windowing (aacdec_dsp_template.c:325-387); 960: _960 (:453-512; a short window's coefficients sit 128 apart:
+ * in_short_stride = 128); 768: _768 (:389-448; 96 apart).  saved holds L / 2, out L samples. */
+void ffo_aac_imdct_and_windowing_len(int L, int in_short_stride, const FfoTx *mdct_long, const FfoTx *mdct_short, const float *const windows[4],
+                                     const float *coeffs, const int seq[2], const int kb[2], float *saved, float *out)
 {
+    const int H = L / 2, S = L / 8, S2 = S / 2, A = H - S2; /* 1024: 512, 128, 64, 448 */
     const float *swindow = windows[kb[0] ? 3 : 1], *lwindow_prev = windows[kb[1] ? 2 : 0], *swindow_prev = windows[kb[1] ? 3 : 1];
     float buf[1024], tail[128];
     if (seq[0] == EIGHT_SHORT)
-        for (int i = 0; i < 1024; i += 128)
-            ffo_mdct_run(mdct128, buf + i, coeffs + i, sizeof(float));
+        for (int i = 0; i < 8; i++)
+            ffo_mdct_run(mdct_short, buf + i * S, coeffs + i * in_short_stride, sizeof(float));
     else
-        ffo_mdct_run(mdct1024, buf, coeffs, sizeof(float));
+        ffo_mdct_run(mdct_long, buf, coeffs, sizeof(float));
 
     const int long_prev = seq[1] == ONLY_LONG || seq[1] == LONG_STOP, long_cur = seq[0] == ONLY_LONG || seq[0] == LONG_START;
     if (long_prev && long_cur) {
-        window_overlap(out, saved, buf, lwindow_prev, 512);
+        window_overlap(out, saved, buf, lwindow_prev, H);
     } else {
-        memcpy(out, saved, 448 * sizeof(float));
+        memcpy(out, saved, A * sizeof(float));
         if (seq[0] == EIGHT_SHORT) {
-            window_overlap(out + 448, saved + 448, buf, swindow_prev, 64);
+            window_overlap(out + A, saved + A, buf, swindow_prev, S2);
             for (int b = 1; b < 4; b++)
-                window_overlap(out + 448 + b * 128, buf + (b - 1) * 128 + 64, buf + b * 128, swindow, 64);
-            window_overlap(tail, buf + 3 * 128 + 64, buf + 4 * 128, swindow, 64);
-            memcpy(out + 448 + 4 * 128, tail, 64 * sizeof(float));
+                window_overlap(out + A + b * S, buf + (b - 1) * S + S2, buf + b * S, swindow, S2);
+            window_overlap(tail, buf + 3 * S + S2, buf + 4 * S, swindow, S2);
+            memcpy(out + A + 4 * S, tail, S2 * sizeof(float));
         } else {
-            window_overlap(out + 448, saved + 448, buf, swindow_prev, 64);
-            memcpy(out + 576, buf + 64, 448 * sizeof(float));
+            window_overlap(out + A, saved + A, buf, swindow_prev, S2);
+            memcpy(out + A + S, buf + S2, A * sizeof(float));
         }
     }
     if (seq[0] == EIGHT_SHORT) {
-        memcpy(saved, tail + 64, 64 * sizeof(float));
+        memcpy(saved, tail + S2, S2 * sizeof(float));
         for (int b = 4; b < 7; b++)
-            window_overlap(saved + 64 + (b - 4) * 128, buf + b * 128 + 64, buf + (b + 1) * 128, swindow, 64);
-        memcpy(saved + 448, buf + 7 * 128 + 64, 64 * sizeof(float));
+            window_overlap(saved + S2 + (b - 4) * S, buf + b * S + S2, buf + (b + 1) * S, swindow, S2);
+        memcpy(saved + A, buf + 7 * S + S2, S2 * sizeof(float));
     } else if (seq[0] == LONG_START) {
-        memcpy(saved, buf + 512, 448 * sizeof(float));
-        memcpy(saved + 448, buf + 7 * 128 + 64, 64 * sizeof(float));
+        memcpy(saved, buf + H, A * sizeof(float));
+        memcpy(saved + A, buf + 7 * S + S2, S2 * sizeof(float));
     } else {
-        memcpy(saved, buf + 512, 512 * sizeof(float));
+        memcpy(saved, buf + H, H * sizeof(float));
     }
+}
+
+void ffo_aac_imdct_and_windowing(const FfoTx *mdct1024, const FfoTx *mdct128, const float *const windows[4], const float *coeffs,
+                                 const int seq[2], const int kb[2], float *saved, float *out)
+{
+    ffo_aac_imdct_and_windowing_len(1024, 128, mdct1024, mdct128, windows, coeffs, seq, kb, saved, out);
 }
 
 /*

@@ -215,3 +215,55 @@ int ffref_aac_update_ltp(float *ltp_state, const float *buf_mdct, const float *s
     memcpy(ltp_state, sce->ltp_state, 3072 * sizeof(float));
     return 0;
 }
+
+/* ---- the 960- and 768-sample frame variants (AACDecDSP.imdct_and_windowing_960 / _768).  Their window tables are file-static in
+ *      aacdec_float.c; the same public generators fill copies here (ff_sine_window_init / ff_kbd_window_init, as
+ *      init_tables_float_fn does for 960 / 120, aacdec_float.c:63-67), so what the caller is handed is bit for bit what the member
+ *      uses ---- */
+#include "libavcodec/kbdwin.h"
+const float *ffref_aac_window_len(int L, int which)
+{
+    static float tab[4][1024], zero[1024];
+    static int done;
+    if (L == 768) /* this reference never fills sine_768 / sine_96 / aac_kbd_long_768 / aac_kbd_short_96 (file-static, no
+                   * ff_*_window_init call anywhere in libavcodec): the member runs on all-zero tables, and so must its checker */
+        return zero;
+    if (L != 960)
+        return NULL;
+    if (!done) {
+        ff_sine_window_init(tab[0], 960);
+        ff_sine_window_init(tab[1], 120);
+        ff_kbd_window_init(tab[2], 4.0, 960);
+        ff_kbd_window_init(tab[3], 6.0, 120);
+        done = 1;
+    }
+    return tab[which & 3];
+}
+
+int ffref_aac_imdct_and_windowing_len(int L, const float *coeffs, const int seq[2], const int kb[2], float *saved, float *out)
+{
+    AACDecContext *ac = aac();
+    SingleChannelElement *sce = &cpe_scratch()->ch[0];
+    if (!ac || (L != 960 && L != 768))
+        return -1;
+    if (!ac->mdct960) {
+        float s96 = (1.0 / 96) / 32768.0f, s120 = (1.0 / 120) / 32768.0f, s768 = (1.0 / 768) / 32768.0f, s960 = (1.0 / 960) / 32768.0f;
+        if (av_tx_init(&ac->mdct96, &ac->mdct96_fn, AV_TX_FLOAT_MDCT, 1, 96, &s96, 0) < 0 ||
+            av_tx_init(&ac->mdct120, &ac->mdct120_fn, AV_TX_FLOAT_MDCT, 1, 120, &s120, 0) < 0 ||
+            av_tx_init(&ac->mdct768, &ac->mdct768_fn, AV_TX_FLOAT_MDCT, 1, 768, &s768, 0) < 0 ||
+            av_tx_init(&ac->mdct960, &ac->mdct960_fn, AV_TX_FLOAT_MDCT, 1, 960, &s960, 0) < 0)
+            return -1;
+    }
+    sce->ics.window_sequence[0] = seq[0]; sce->ics.window_sequence[1] = seq[1];
+    sce->ics.use_kb_window[0] = kb[0];    sce->ics.use_kb_window[1] = kb[1];
+    memcpy(sce->coeffs, coeffs, 1024 * sizeof(float));
+    memcpy(sce->saved, saved, (L / 2) * sizeof(float));
+    sce->output = sce->ret_buf;
+    if (L == 960)
+        ac->dsp.imdct_and_windowing_960(ac, sce);
+    else
+        ac->dsp.imdct_and_windowing_768(ac, sce);
+    memcpy(out, sce->output, L * sizeof(float));
+    memcpy(saved, sce->saved, (L / 2) * sizeof(float));
+    return 0;
+}

@@ -154,3 +154,36 @@ def test_ltp_bands_walk():
                 want[0, c["swb"][sfb]:c["swb"][sfb + 1]] += pred[0, c["swb"][sfb]:c["swb"][sfb + 1]]
         run_band_ops(aac.ltp_bands(0, 0, c["max_sfb"], c["used"], c["swb"]), co, pred)
         assert np.array_equal(bits(co), bits(want))
+
+
+@pytest.mark.parametrize("L", [960, 768])
+def test_imdct_and_windowing_960_768(L):
+    """AACDecDSP.imdct_and_windowing_960 / _768 (aacdec_dsp_template.c:389-512): the oracle's length-generic restatement against the
+    members over every window-sequence transition.  960: the decoder's sine / KBD tables (regenerated by the same public
+    functions).  768: this reference leaves its 768 / 96 tables zero-initialised (never filled), so the comparison runs on zero
+    tables - it pins the inverse transforms, the copies and the state hand-over, not the window products."""
+    R, O = _ref(), ffi.oracle()
+    if not hasattr(R, "ffref_aac_imdct_and_windowing_len"):
+        pytest.skip("oracle/_ref predates the 960 / 768 shim")
+    rng = np.random.default_rng(3150 + L)
+    S = L // 8
+    win = [np.ctypeslib.as_array(R.ffref_aac_window_len(L, k), (n,)).copy() for k, n in ((0, L), (1, S), (2, L), (3, S))]
+    if L == 960:
+        assert all(np.abs(w).max() > .9 for w in win)
+    wp = (f32p * 4)(*[ptr(w, f32p) for w in win])
+    ml, ms = O.ffo_mdct_create(1, L, np.float32((1.0 / L) / 32768.0)), O.ffo_mdct_create(1, S, np.float32((1.0 / S) / 32768.0))
+    sa = (rng.standard_normal(L // 2) * .1).astype(np.float32)
+    sb = sa.copy()
+    prev = (0, 0)
+    for f in range(200):
+        seq, kb = int(rng.integers(0, 4)), int(rng.integers(0, 2))
+        co = A.spectrum(rng) * np.float32(100)
+        s2, k2 = np.array([seq, prev[0]], np.int32), np.array([kb, prev[1]], np.int32)
+        oa, ob = np.zeros(L, np.float32), np.zeros(L, np.float32)
+        assert R.ffref_aac_imdct_and_windowing_len(L, ptr(co, f32p), ptr(s2, i32p), ptr(k2, i32p), ptr(sa, f32p), ptr(oa, f32p)) == 0
+        O.ffo_aac_imdct_and_windowing_len(L, 128 if L == 960 else 96, ml, ms, wp, ptr(co, f32p), ptr(s2, i32p), ptr(k2, i32p), ptr(sb, f32p),
+                                          ptr(ob, f32p))
+        assert np.array_equal(bits(oa), bits(ob)), (f, seq, prev)
+        assert np.array_equal(bits(sa), bits(sb)), (f, seq, prev)
+        prev = (seq, kb)
+    O.ffo_mdct_free(ml); O.ffo_mdct_free(ms)

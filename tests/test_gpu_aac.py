@@ -126,3 +126,61 @@ def test_aac_apply_tns_batch(decode):
     got = d_co.cpu().numpy()
     assert (want != coeffs).sum() > 100000
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frames differing: %s" % np.argwhere((got != want).any(axis=1))[:5].ravel()
+
+
+@pytest.mark.parametrize("L", [960, 768])
+@pytest.mark.parametrize("nch,nframes", [(1, 1), (2, 150), (5, 64)])
+def test_aac_imdct_and_windowing_960_768(L, nch, nframes):
+    """AACDecDSP.imdct_and_windowing_960 / _768 (frame lengths of DAB+ / DRM and of USAC's 768 mode): the batch face against the
+    oracle's length-generic restatement (pinned to the reference's members in tests/test_aac_tools_cpu.py) channel by channel, frame
+    after frame, a second call continuing from the first one's state; then the host face.  The transforms are the prime-factor ones
+    (15 x 32 / 15 x 4 resp. 3 x 128 / 3 x 16)."""
+    from ffmpeg_amd import aac
+    import ctypes as C
+    from ffi import ptr, f32p, i32p
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(2750 + L + nch)
+    S = L // 8
+    windows = [np.zeros(L, np.float32), np.zeros(S, np.float32), np.zeros(L, np.float32), np.zeros(S, np.float32)]
+    O.ffo_aac_sine_window(ptr(windows[0], f32p), L); O.ffo_aac_sine_window(ptr(windows[1], f32p), S)
+    O.ffo_aac_kbd_window(ptr(windows[2], f32p), 4.0, L); O.ffo_aac_kbd_window(ptr(windows[3], f32p), 6.0, S)
+    wp = (f32p * 4)(*[ptr(w, f32p) for w in windows])
+    ml, ms = O.ffo_mdct_create(1, L, np.float32((1.0 / L) / 32768.0)), O.ffo_mdct_create(1, S, np.float32((1.0 / S) / 32768.0))
+    ctx = aac.AacImdct(windows, frame_len=L)
+    total = nframes + 23
+    seq = np.zeros((total, nch), np.uint8); kb = np.zeros((total, nch), np.uint8)
+    for c in range(nch):
+        seq[:, c], kb[:, c] = aac_sequences(rng, total)
+    coeffs = (rng.standard_normal((total, nch, 1024)) * 3000.0 * 10.0 ** rng.integers(-2, 2, (total, nch, 1))).astype(np.float32)
+    saved0 = np.zeros((nch, 512), np.float32)
+    saved0[:, :L // 2] = (rng.standard_normal((nch, L // 2)) * 0.1).astype(np.float32)
+    want = np.zeros((total, nch, 1024), np.float32)
+    wsaved = saved0.copy()
+    for c in range(nch):
+        prev = (0, int(kb[0, c]))
+        for f in range(total):
+            s2, k2 = np.array([seq[f, c], prev[0]], np.int32), np.array([kb[f, c], prev[1]], np.int32)
+            O.ffo_aac_imdct_and_windowing_len(L, 128 if L == 960 else 96, ml, ms, wp, ptr(np.ascontiguousarray(coeffs[f, c]), f32p),
+                                              ptr(s2, i32p), ptr(k2, i32p), ptr(wsaved[c], f32p), ptr(want[f, c], f32p))
+            prev = (int(seq[f, c]), int(kb[f, c]))
+    d_co = torch.from_numpy(coeffs).cuda()
+    d_out = torch.zeros((total, nch, 1024), dtype=torch.float32, device="cuda:0")
+    d_saved = torch.from_numpy(saved0.copy()).cuda()
+    ctx.batch(d_co[:nframes], d_out[:nframes], d_saved, seq[:nframes], kb[:nframes], np.zeros(nch, np.uint8), kb[0])
+    ctx.batch(d_co[nframes:], d_out[nframes:], d_saved, seq[nframes:], kb[nframes:], seq[nframes - 1], kb[nframes - 1])
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frames differing: %s" % np.argwhere((got != want).any(axis=2))[:5]
+    assert not got[:, :, L:].any()
+    assert np.array_equal(d_saved.cpu().numpy().view(np.uint32), wsaved.view(np.uint32))
+    # host face, one channel
+    sv = saved0[0, :L // 2].copy()
+    prev = (0, int(kb[0, 0]))
+    for f in range(min(total, 12)):
+        out = np.zeros(L, np.float32)
+        ctx.frame(np.ascontiguousarray(coeffs[f, 0]), (int(seq[f, 0]), prev[0]), (int(kb[f, 0]), prev[1]), sv, out)
+        assert np.array_equal(out.view(np.uint32), want[f, 0, :L].view(np.uint32)), f
+        prev = (int(seq[f, 0]), int(kb[f, 0]))
+    O.ffo_mdct_free(ml); O.ffo_mdct_free(ms)
+    ctx.close()
