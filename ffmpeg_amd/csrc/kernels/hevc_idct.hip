@@ -274,9 +274,55 @@ __device__ __forceinline__ void hm_split(const int (&v)[16], hm_i4 &hi, hm_i4 &l
     }
 }
 
+/* the residual row segment z[0..NS-1] added to NS picture samples at d (8-bit or 16-bit), as wide as d's alignment allows */
+template <int NS>
+__device__ __forceinline__ void hm_add_row(uint8_t *d8, const int (&z)[NS], int bd)
+{
+    if (bd > 8) {
+        const int maxv = (1 << bd) - 1;
+        uint16_t *d = reinterpret_cast<uint16_t *>(d8);
+        if (!(reinterpret_cast<uintptr_t>(d) & 15)) {
+#pragma unroll
+            for (int q = 0; q < NS / 8; q++) {
+                const uint4 p = reinterpret_cast<const uint4 *>(d)[q];
+                const uint32_t pw[4] = { p.x, p.y, p.z, p.w };
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    o[k] = (uint32_t)min(max((int)(pw[k] & 0xFFFF) + z[8 * q + 2 * k], 0), maxv) |
+                           (uint32_t)min(max((int)(pw[k] >> 16) + z[8 * q + 2 * k + 1], 0), maxv) << 16;
+                reinterpret_cast<uint4 *>(d)[q] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; k++)
+                d[k] = (uint16_t)min(max((int)d[k] + z[k], 0), maxv);
+        }
+    } else if (!(reinterpret_cast<uintptr_t>(d8) & 7)) {
+#pragma unroll
+        for (int q = 0; q < NS / 8; q++) {
+            const uint2 p = reinterpret_cast<const uint2 *>(d8)[q];
+            const int *zz = &z[8 * q];
+            const uint32_t o0 = pack4(clip_u8((int)(p.x & 0xFF) + zz[0]), clip_u8((int)((p.x >> 8) & 0xFF) + zz[1]),
+                                      clip_u8((int)((p.x >> 16) & 0xFF) + zz[2]), clip_u8((int)(p.x >> 24) + zz[3]));
+            const uint32_t o1 = pack4(clip_u8((int)(p.y & 0xFF) + zz[4]), clip_u8((int)((p.y >> 8) & 0xFF) + zz[5]),
+                                      clip_u8((int)((p.y >> 16) & 0xFF) + zz[6]), clip_u8((int)(p.y >> 24) + zz[7]));
+            reinterpret_cast<uint2 *>(d8)[q] = make_uint2(o0, o1);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+            d8[k] = (uint8_t)clip_u8((int)d8[k] + z[k]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_hevc_idct32_mfma(int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n, int bd,
                                                           const HevcMfmaTab *tab)
 {
+    /* the matrix core wants a lane to hold (part of) a COLUMN of the unit and hands back columns; memory wants rows.  Both
+     * transpositions go through 2 KB of LDS per wave: a lane moves 32 contiguous bytes of a coefficient row in and out and 16
+     * picture samples, instead of sixteen 2-byte accesses each way plus sixteen byte-wide read-modify-writes */
+    __shared__ __align__(16) int16_t lds[4][1024];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + wave;
     if (u >= n)
@@ -284,6 +330,20 @@ __global__ __launch_bounds__(256) void k_hevc_idct32_mfma(int16_t *coeffs, uint8
     const FFHipHevcTU tu = tus[u];
     const int col_limit = __builtin_amdgcn_readfirstlane(tu.col_limit);
     int16_t *X = coeffs + __builtin_amdgcn_readfirstlane(tu.coeff_offset);
+    int16_t *L = lds[wave];
+    /* row view: lane = (row rr, half rh): 16 samples */
+    const int rr = lane >> 1, rh = lane & 1;
+    int16_t *rowp = X + rr * 32 + 16 * rh;
+    const bool al16 = !(reinterpret_cast<uintptr_t>(X) & 15);
+    if (al16) {
+        reinterpret_cast<uint4 *>(L + rr * 32 + 16 * rh)[0] = reinterpret_cast<const uint4 *>(rowp)[0];
+        reinterpret_cast<uint4 *>(L + rr * 32 + 16 * rh)[1] = reinterpret_cast<const uint4 *>(rowp)[1];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            reinterpret_cast<uint32_t *>(L + rr * 32 + 16 * rh)[k] = reinterpret_cast<const uint32_t *>(rowp)[k];
+    }
+    hevc_wave_sync();
     const int c = lane & 31, g = lane >> 5;
     const hm_i4 B1 = reinterpret_cast<const hm_i4 *>(tab->b1)[lane], B2 = reinterpret_cast<const hm_i4 *>(tab->b2)[lane];
     const int sum_t = tab->sum[c];
@@ -295,7 +355,7 @@ __global__ __launch_bounds__(256) void k_hevc_idct32_mfma(int16_t *coeffs, uint8
     int v[16];
 #pragma unroll
     for (int s = 0; s < 16; s++) {
-        const int k = 16 * g + s, x = X[k * 32 + c];
+        const int k = 16 * g + s, x = L[k * 32 + c];
         v[s] = hm_keep(k, limit2) ? x : 0;
     }
     hm_i4 ahi, alo;
@@ -324,25 +384,150 @@ __global__ __launch_bounds__(256) void k_hevc_idct32_mfma(int16_t *coeffs, uint8
     for (int r = 0; r < 16; r++)
         acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)(sum_t + (1 << (shift2 - 1))));
     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, B2, acc, 0, 0, 0);
-    /* ---- Z[j][m = c], j = (r & 3) + 8 (r >> 2) + 4 g: residual back in place, picture += residual ---- */
-    const bool add = dst && tu.dst_offset >= 0;
-    const int maxv = (1 << bd) - 1;
+    /* ---- Z[j][m = c], j = (r & 3) + 8 (r >> 2) + 4 g: back through LDS into rows; residual in place, picture += residual ---- */
+    hevc_wave_sync(); /* every lane has read its inputs */
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int j = (r & 3) + 8 * (r >> 2) + 4 * g;
-        const int z = hevc_clip16(acc[r] >> shift2);
-        X[j * 32 + c] = (int16_t)z;
-        if (add) {
-            uint8_t *row = dst + tu.dst_offset + (ptrdiff_t)j * stride;
-            if (bd > 8) {
-                uint16_t *d = reinterpret_cast<uint16_t *>(row) + c;
-                *d = (uint16_t)min(max((int)*d + z, 0), maxv);
+        L[j * 32 + c] = (int16_t)hevc_clip16(acc[r] >> shift2);
+    }
+    hevc_wave_sync();
+    const uint4 r0 = reinterpret_cast<const uint4 *>(L + rr * 32 + 16 * rh)[0], r1 = reinterpret_cast<const uint4 *>(L + rr * 32 + 16 * rh)[1];
+    const uint32_t rw[8] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
+    if (al16) {
+        reinterpret_cast<uint4 *>(rowp)[0] = r0;
+        reinterpret_cast<uint4 *>(rowp)[1] = r1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            reinterpret_cast<uint32_t *>(rowp)[k] = rw[k];
+    }
+    if (!dst || tu.dst_offset < 0)
+        return;
+    int z[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        z[2 * k] = (int)(int16_t)(rw[k] & 0xFFFF);
+        z[2 * k + 1] = (int)(int16_t)(rw[k] >> 16);
+    }
+    hm_add_row<16>(dst + tu.dst_offset + (ptrdiff_t)rr * stride + 16 * rh * (bd > 8 ? 2 : 1), z, bd);
+}
+
+/*
+ * k_hevc_idct16_mfma — two 16x16 units per wave on the same v_mfma_i32_32x32x32_i8: the operands are BLOCK-DIAGONAL (unit b in
+ * rows / columns 16 b .. 16 b + 15), and so is K: of a lane's 16 K-slots, slots 8 b .. 8 b + 7 belong to unit b.  Lane (row c' = 16 b + c,
+ * group g) therefore carries 8 values of ITS unit (pass 1: X_b[8 g + t][c], t = 0..7) and whatever in the other 8 slots — those meet
+ * only B entries of the other unit's columns, i.e. they land in the off-diagonal quadrants of D, which nobody reads.  The D
+ * registers a lane needs are r = 8 b .. 8 b + 7 (rows 16 b + (r & 3) + 8 ((r >> 2) & 1) + 4 g), and they ARE the A operand of pass 2
+ * in place, with the second B table's rows permuted to that order — as in the 32x32 kernel: no LDS, no transposition.  Half of
+ * the matrix core's work is thrown away; what is bought is the VALU: 64 v_dot2 per vector and a scalar load behind each.
+ */
+__global__ __launch_bounds__(256) void k_hevc_idct16_mfma(int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n, int bd,
+                                                          const HevcMfmaTab *tab)
+{
+    /* the matrix core wants a lane to hold a COLUMN of its unit and hands back a column; memory wants rows.  Both transpositions go
+     * through 1 KB of LDS per wave: a lane moves 16 contiguous bytes of a coefficient row in and out and 8 picture samples, instead
+     * of eight 2-byte accesses each way plus eight byte-wide read-modify-writes (measured: 1.56 -> 1.80 G units/s; a wave
+     * looping over unit pairs with the next pair in flight was SLOWER than one pair per wave: 1.59) */
+    __shared__ __align__(16) int16_t lds[4][2 * 256];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int u0 = (blockIdx.x * 4 + wave) * 2;
+    if (u0 >= n)
+        return;
+    int16_t *L = lds[wave];
+    /* row view of the wave's two units: lane = (unit rb, row rr, half rh): 8 samples */
+    const int rb = lane >> 5, rr = (lane >> 1) & 15, rh = lane & 1;
+    const bool rlive = u0 + rb < n;
+    const FFHipHevcTU rtu = tus[rlive ? u0 + rb : u0];
+    int16_t *rowp = coeffs + rtu.coeff_offset + rr * 16 + 8 * rh;
+    const bool al16 = !(reinterpret_cast<uintptr_t>(rowp) & 15);
+    {
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (rlive) {
+            if (al16) {
+                raw = *reinterpret_cast<const uint4 *>(rowp);
             } else {
-                row[c] = (uint8_t)min(max((int)row[c] + z, 0), 255);
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(rowp);
+                raw = make_uint4(p[0], p[1], p[2], p[3]);
             }
         }
+        *reinterpret_cast<uint4 *>(L + rb * 256 + rr * 16 + 8 * rh) = raw;
     }
+    hevc_wave_sync();
+    /* column view: my unit, my column (pass 1) / row (pass 2) / column (output) */
+    const int cp = lane & 31, g = lane >> 5, b = cp >> 4, c = cp & 15;
+    const hm_i4 B1 = reinterpret_cast<const hm_i4 *>(tab->b1)[lane], B2 = reinterpret_cast<const hm_i4 *>(tab->b2)[lane];
+    const int sum_t = tab->sum[cp];
+    const int col_limit = __shfl(rtu.col_limit, 32 * b, 64); /* unit b's descriptor sits in the lanes of row-view unit b */
+    /* ---- pass 1: column c of unit b, rows 8 g .. 8 g + 7 in slots 8 b .. 8 b + 7 ---- */
+    int limit2 = min(col_limit + 4, 16);
+    for (int q = 4; q < c; q += 4)
+        if (limit2 < 16)
+            limit2 -= 4;
+    int v[16];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int k = 8 * g + t, x = L[b * 256 + k * 16 + c];
+        const int val = ((k & 1) && k >= limit2) ? 0 : x; /* hevc_pass<16>'s rule: odd inputs beyond the limit are dropped */
+        v[t] = b ? 0 : val;
+        v[8 + t] = b ? val : 0;
+    }
+    hm_i4 ahi, alo;
+    hm_split(v, ahi, alo);
+    hm_i16 acc = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, B1, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)(sum_t + 64));
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, B1, acc, 0, 0, 0);
+    /* ---- Y_b[j = c][cc], cc = (r & 3) + 8 ((r >> 2) & 1) + 4 g for r = 8 b .. 8 b + 7: >> 7, clip, the second pass's limit ---- */
+    const int limit = min(col_limit, 16);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int cc = (r & 3) + 8 * ((r >> 2) & 1) + 4 * g;
+        const int y = hevc_clip16(acc[r] >> 7);
+        v[r] = ((r >> 3) == b && !((cc & 1) && cc >= limit)) ? y : 0;
+    }
+    hm_split(v, ahi, alo);
+    const int shift2 = 20 - bd;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        acc[r] = 0;
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, B2, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        acc[r] = (int)(((uint32_t)acc[r] << 8) + (uint32_t)(sum_t + (1 << (shift2 - 1))));
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, B2, acc, 0, 0, 0);
+    /* ---- Z_b[j][m = c], j = (r & 3) + 8 ((r >> 2) & 1) + 4 g for r = 8 b .. 8 b + 7: back through LDS into rows ---- */
+    hevc_wave_sync(); /* every lane has read its inputs */
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int j = (t & 3) + 8 * (t >> 2) + 4 * g;
+        L[b * 256 + j * 16 + c] = (int16_t)hevc_clip16((b ? acc[8 + t] : acc[t]) >> shift2);
+    }
+    hevc_wave_sync();
+    if (!rlive)
+        return;
+    const uint4 res = *reinterpret_cast<const uint4 *>(L + rb * 256 + rr * 16 + 8 * rh);
+    if (al16) {
+        *reinterpret_cast<uint4 *>(rowp) = res;
+    } else {
+        uint32_t *p = reinterpret_cast<uint32_t *>(rowp);
+        p[0] = res.x; p[1] = res.y; p[2] = res.z; p[3] = res.w;
+    }
+    if (!dst || rtu.dst_offset < 0)
+        return;
+    const uint32_t rw[4] = { res.x, res.y, res.z, res.w };
+    int z[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        z[2 * k] = (int)(int16_t)(rw[k] & 0xFFFF);
+        z[2 * k + 1] = (int)(int16_t)(rw[k] >> 16);
+    }
+    hm_add_row<8>(dst + rtu.dst_offset + (ptrdiff_t)rr * stride + 8 * rh * (bd > 8 ? 2 : 1), z, bd);
 }
+
+static HevcMfmaTab *g_hm_tab16;
 
 static int hm_tab_init()
 {
@@ -368,6 +553,27 @@ static int hm_tab_init()
         hm_err = hipMalloc(reinterpret_cast<void **>(&g_hm_tab), sizeof(h));
         if (hm_err == hipSuccess)
             hm_err = hipMemcpy(g_hm_tab, &h, sizeof(h), hipMemcpyHostToDevice);
+        /* the block-diagonal pair of 16-point matrices (T16[k][j] = T32[2 k][j]): slot s of group g belongs to unit s >> 3 and is
+         * row 8 g + (s & 7) of T16 in pass 1, row (s & 3) + 8 ((s >> 2) & 1) + 4 g in pass 2 */
+        static HevcMfmaTab h16;
+        for (int l = 0; l < 64; l++) {
+            const int jp = l & 31, g = l >> 5, j = jp & 15;
+            for (int sl = 0; sl < 16; sl++) {
+                const bool mine = (sl >> 3) == (jp >> 4);
+                h16.b1[l][sl] = mine ? hevc_t32_host[2 * (8 * g + (sl & 7))][j] : 0;
+                h16.b2[l][sl] = mine ? hevc_t32_host[2 * ((sl & 3) + 8 * ((sl >> 2) & 1) + 4 * g)][j] : 0;
+            }
+        }
+        for (int jp = 0; jp < 32; jp++) {
+            int t = 0;
+            for (int k = 0; k < 16; k++)
+                t += hevc_t32_host[2 * k][jp & 15];
+            h16.sum[jp] = 128 * t;
+        }
+        if (hm_err == hipSuccess)
+            hm_err = hipMalloc(reinterpret_cast<void **>(&g_hm_tab16), sizeof(h16));
+        if (hm_err == hipSuccess)
+            hm_err = hipMemcpy(g_hm_tab16, &h16, sizeof(h16), hipMemcpyHostToDevice);
         if (hm_err == hipSuccess)
             ffhip_note_device_resources();
     });
@@ -408,6 +614,15 @@ int ffhip_launch_hevc_idct_bd(int bd, int kind, int log2_size, int16_t *coeffs, 
             if (r < 0)
                 return r;
             hipLaunchKernelGGL(k_hevc_idct32_mfma, dim3(cdiv(n, 4)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd, g_hm_tab);
+            LAUNCH_CHECK();
+            return 0;
+        }
+        const char *e16 = getenv("FFHIP_HEVC_IDCT16_VALU");
+        if (kind == FFHIP_HEVC_IDCT && log2_size == 4 && !(e16 && e16[0] == '1')) {
+            const int r = hm_tab_init();
+            if (r < 0)
+                return r;
+            hipLaunchKernelGGL(k_hevc_idct16_mfma, dim3(cdiv(n, 8)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd, g_hm_tab16);
             LAUNCH_CHECK();
             return 0;
         }
