@@ -120,6 +120,48 @@ __device__ __forceinline__ void hevc_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* the residual row segment z[0..NS-1] added to NS picture samples at d (8-bit or 16-bit), as wide as d's alignment allows */
+template <int NS>
+__device__ __forceinline__ void hm_add_row(uint8_t *d8, const int (&z)[NS], int bd)
+{
+    if (bd > 8) {
+        const int maxv = (1 << bd) - 1;
+        uint16_t *d = reinterpret_cast<uint16_t *>(d8);
+        if (!(reinterpret_cast<uintptr_t>(d) & 15)) {
+#pragma unroll
+            for (int q = 0; q < NS / 8; q++) {
+                const uint4 p = reinterpret_cast<const uint4 *>(d)[q];
+                const uint32_t pw[4] = { p.x, p.y, p.z, p.w };
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    o[k] = (uint32_t)min(max((int)(pw[k] & 0xFFFF) + z[8 * q + 2 * k], 0), maxv) |
+                           (uint32_t)min(max((int)(pw[k] >> 16) + z[8 * q + 2 * k + 1], 0), maxv) << 16;
+                reinterpret_cast<uint4 *>(d)[q] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; k++)
+                d[k] = (uint16_t)min(max((int)d[k] + z[k], 0), maxv);
+        }
+    } else if (!(reinterpret_cast<uintptr_t>(d8) & 7)) {
+#pragma unroll
+        for (int q = 0; q < NS / 8; q++) {
+            const uint2 p = reinterpret_cast<const uint2 *>(d8)[q];
+            const int *zz = &z[8 * q];
+            const uint32_t o0 = pack4(clip_u8((int)(p.x & 0xFF) + zz[0]), clip_u8((int)((p.x >> 8) & 0xFF) + zz[1]),
+                                      clip_u8((int)((p.x >> 16) & 0xFF) + zz[2]), clip_u8((int)(p.x >> 24) + zz[3]));
+            const uint32_t o1 = pack4(clip_u8((int)(p.y & 0xFF) + zz[4]), clip_u8((int)((p.y >> 8) & 0xFF) + zz[5]),
+                                      clip_u8((int)((p.y >> 16) & 0xFF) + zz[6]), clip_u8((int)(p.y >> 24) + zz[7]));
+            reinterpret_cast<uint2 *>(d8)[q] = make_uint2(o0, o1);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+            d8[k] = (uint8_t)clip_u8((int)d8[k] + z[k]);
+    }
+}
+
 /* bd: the depth the template was instantiated for in the reference (hevc/dsp.c:133-196): it sets the second-pass shift 20 - bd, the
  * DC shift 14 - bd, dequant's 15 - bd - log2 and the pixel type / clip of add_residual (uint16_t above 8 bits, stride in bytes) */
 template <int LOG2>
@@ -139,12 +181,22 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
     const FFHipHevcTU tu = tus[live ? u : u0];
     int16_t *cg = coeffs + tu.coeff_offset;
 
-    /* ---- stage the wave's units: UPW blocks of N*N int16, as dwords ---- */
+    /* ---- stage the wave's units: UPW blocks of N*N int16, 16 bytes per lane and step where the block is 16-byte aligned (one
+     *      descriptor read and one load per lane for 8x8), else as dwords ---- */
     constexpr int DW = N * N / 2; /* dwords per unit */
-    for (int t = lane; t < UPW * DW; t += 64) {
-        const int b = t / DW, w = t % DW;
-        if (u0 + b < n)
-            reinterpret_cast<uint32_t *>(blk)[t] = reinterpret_cast<const uint32_t *>(coeffs + tus[u0 + b].coeff_offset)[w];
+    constexpr int Q4 = DW / 4;    /* 16-byte pieces per unit */
+    for (int t = lane; t < UPW * Q4; t += 64) {
+        const int b = t / Q4, w = t % Q4;
+        if (u0 + b < n) {
+            const int16_t *g = coeffs + tus[u0 + b].coeff_offset;
+            if (!(reinterpret_cast<uintptr_t>(g) & 15)) {
+                reinterpret_cast<uint4 *>(blk)[t] = reinterpret_cast<const uint4 *>(g)[w];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    reinterpret_cast<uint32_t *>(blk)[4 * t + k] = reinterpret_cast<const uint32_t *>(g)[4 * w + k];
+            }
+        }
     }
     hevc_wave_sync();
     int16_t *mine = blk + ul * N * N;
@@ -194,42 +246,42 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
     hevc_wave_sync();
     /* ---- residual back in place; picture += residual (row i of my unit) ---- */
     if (kind != FFHIP_HEVC_ADD_ONLY) {
-        for (int t = lane; t < UPW * DW; t += 64) {
-            const int b = t / DW, w = t % DW;
-            if (u0 + b < n)
-                reinterpret_cast<uint32_t *>(coeffs + tus[u0 + b].coeff_offset)[w] = reinterpret_cast<const uint32_t *>(blk)[t];
+        for (int t = lane; t < UPW * Q4; t += 64) {
+            const int b = t / Q4, w = t % Q4;
+            if (u0 + b < n) {
+                int16_t *g = coeffs + tus[u0 + b].coeff_offset;
+                if (!(reinterpret_cast<uintptr_t>(g) & 15)) {
+                    reinterpret_cast<uint4 *>(g)[w] = reinterpret_cast<const uint4 *>(blk)[t];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        reinterpret_cast<uint32_t *>(g)[4 * w + k] = reinterpret_cast<const uint32_t *>(blk)[4 * t + k];
+                }
+            }
         }
     }
     (void)cg;
-    if (dst && live && tu.dst_offset >= 0 && bd > 8) {
-        uint16_t *d = reinterpret_cast<uint16_t *>(dst + tu.dst_offset + (ptrdiff_t)i * stride);
-        const int16_t *r = mine + i * N;
-        const int maxv = (1 << bd) - 1;
-        if (!(reinterpret_cast<uintptr_t>(d) & 3)) {
-#pragma unroll
-            for (int x = 0; x < N; x += 2) {
-                const uint32_t p = *reinterpret_cast<const uint32_t *>(d + x);
-                const int a = min(max((int)(p & 0xFFFF) + r[x], 0), maxv), b = min(max((int)(p >> 16) + r[x + 1], 0), maxv);
-                *reinterpret_cast<uint32_t *>(d + x) = (uint32_t)a | (uint32_t)b << 16;
-            }
-        } else {
-            for (int x = 0; x < N; x++)
-                d[x] = (uint16_t)min(max((int)d[x] + r[x], 0), maxv);
-        }
-    } else if (dst && live && tu.dst_offset >= 0) {
+    if (dst && live && tu.dst_offset >= 0) {
         uint8_t *d = dst + tu.dst_offset + (ptrdiff_t)i * stride;
         const int16_t *r = mine + i * N;
+        if (N >= 8) {
+            int z[N >= 8 ? N : 8];
 #pragma unroll
-        for (int x = 0; x < N; x += 4) {
-            if (!(((uintptr_t)d) & 3)) {
-                const uint32_t p = *reinterpret_cast<const uint32_t *>(d + x);
-                const uint32_t o = pack4(clip_u8((int)(p & 0xFF) + r[x]), clip_u8((int)((p >> 8) & 0xFF) + r[x + 1]),
-                                         clip_u8((int)((p >> 16) & 0xFF) + r[x + 2]), clip_u8((int)(p >> 24) + r[x + 3]));
-                *reinterpret_cast<uint32_t *>(d + x) = o;
-            } else {
-                for (int e = 0; e < 4; e++)
-                    d[x + e] = (uint8_t)clip_u8((int)d[x + e] + r[x + e]);
-            }
+            for (int x = 0; x < N; x++)
+                z[x] = r[x];
+            hm_add_row<(N >= 8 ? N : 8)>(d, z, bd);
+        } else if (bd > 8) {
+            uint16_t *d16 = reinterpret_cast<uint16_t *>(d);
+            const int maxv = (1 << bd) - 1;
+            for (int x = 0; x < N; x++)
+                d16[x] = (uint16_t)min(max((int)d16[x] + r[x], 0), maxv);
+        } else if (!(((uintptr_t)d) & 3)) {
+            const uint32_t p = *reinterpret_cast<const uint32_t *>(d);
+            *reinterpret_cast<uint32_t *>(d) = pack4(clip_u8((int)(p & 0xFF) + r[0]), clip_u8((int)((p >> 8) & 0xFF) + r[1]),
+                                                     clip_u8((int)((p >> 16) & 0xFF) + r[2]), clip_u8((int)(p >> 24) + r[3]));
+        } else {
+            for (int e = 0; e < 4; e++)
+                d[e] = (uint8_t)clip_u8((int)d[e] + r[e]);
         }
     }
 }
@@ -271,48 +323,6 @@ __device__ __forceinline__ void hm_split(const int (&v)[16], hm_i4 &hi, hm_i4 &l
         const uint32_t p23 = ((uint32_t)v[4 * q + 2] & 0xFFFFu) | ((uint32_t)v[4 * q + 3] << 16);
         hi[q] = (int)__builtin_amdgcn_perm(p23, p01, 0x07050301u);
         lo[q] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
-    }
-}
-
-/* the residual row segment z[0..NS-1] added to NS picture samples at d (8-bit or 16-bit), as wide as d's alignment allows */
-template <int NS>
-__device__ __forceinline__ void hm_add_row(uint8_t *d8, const int (&z)[NS], int bd)
-{
-    if (bd > 8) {
-        const int maxv = (1 << bd) - 1;
-        uint16_t *d = reinterpret_cast<uint16_t *>(d8);
-        if (!(reinterpret_cast<uintptr_t>(d) & 15)) {
-#pragma unroll
-            for (int q = 0; q < NS / 8; q++) {
-                const uint4 p = reinterpret_cast<const uint4 *>(d)[q];
-                const uint32_t pw[4] = { p.x, p.y, p.z, p.w };
-                uint32_t o[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    o[k] = (uint32_t)min(max((int)(pw[k] & 0xFFFF) + z[8 * q + 2 * k], 0), maxv) |
-                           (uint32_t)min(max((int)(pw[k] >> 16) + z[8 * q + 2 * k + 1], 0), maxv) << 16;
-                reinterpret_cast<uint4 *>(d)[q] = make_uint4(o[0], o[1], o[2], o[3]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NS; k++)
-                d[k] = (uint16_t)min(max((int)d[k] + z[k], 0), maxv);
-        }
-    } else if (!(reinterpret_cast<uintptr_t>(d8) & 7)) {
-#pragma unroll
-        for (int q = 0; q < NS / 8; q++) {
-            const uint2 p = reinterpret_cast<const uint2 *>(d8)[q];
-            const int *zz = &z[8 * q];
-            const uint32_t o0 = pack4(clip_u8((int)(p.x & 0xFF) + zz[0]), clip_u8((int)((p.x >> 8) & 0xFF) + zz[1]),
-                                      clip_u8((int)((p.x >> 16) & 0xFF) + zz[2]), clip_u8((int)(p.x >> 24) + zz[3]));
-            const uint32_t o1 = pack4(clip_u8((int)(p.y & 0xFF) + zz[4]), clip_u8((int)((p.y >> 8) & 0xFF) + zz[5]),
-                                      clip_u8((int)((p.y >> 16) & 0xFF) + zz[6]), clip_u8((int)(p.y >> 24) + zz[7]));
-            reinterpret_cast<uint2 *>(d8)[q] = make_uint2(o0, o1);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NS; k++)
-            d8[k] = (uint8_t)clip_u8((int)d8[k] + z[k]);
     }
 }
 
@@ -617,8 +627,10 @@ int ffhip_launch_hevc_idct_bd(int bd, int kind, int log2_size, int16_t *coeffs, 
             LAUNCH_CHECK();
             return 0;
         }
-        const char *e16 = getenv("FFHIP_HEVC_IDCT16_VALU");
-        if (kind == FFHIP_HEVC_IDCT && log2_size == 4 && !(e16 && e16[0] == '1')) {
+        /* 16x16: with 16-byte staging the dot2 kernel (0.55 of HBM) beats the two-units-per-MFMA kernel (0.34, half of whose matrix
+         * work is discarded and whose columns move through LDS 2 bytes at a time); the latter stays as a measured variant */
+        const char *e16 = getenv("FFHIP_HEVC_IDCT16_MFMA");
+        if (kind == FFHIP_HEVC_IDCT && log2_size == 4 && e16 && e16[0] == '1') {
             const int r = hm_tab_init();
             if (r < 0)
                 return r;

@@ -36,6 +36,18 @@ def _coeffs(rng, n, kind):
 def test_hevc_idct_batch(lg, kind, with_dst):
     """a frame's worth of TUs of one size: every col_limit (incl. odd / out of range), coefficient blocks that are dense,
     sparse and saturating, units that skip the picture, a ragged last wave"""
+    _run_idct(lg, kind, with_dst)
+
+
+@pytest.mark.parametrize("with_dst", [True, False])
+@pytest.mark.parametrize("lg,env", [(4, "FFHIP_HEVC_IDCT16_MFMA"), (5, "FFHIP_HEVC_IDCT32_VALU")])
+def test_hevc_idct_other_kernel(lg, env, with_dst, monkeypatch):
+    """the kernels that are not the default for their size stay correct: 16x16 as two units per MFMA, 32x32 on the dot2 kernel"""
+    monkeypatch.setenv(env, "1")
+    _run_idct(lg, 0, with_dst)
+
+
+def _run_idct(lg, kind, with_dst):
     from ffmpeg_amd import hevc
     torch = _torch()
     if kind == hevc.DST_4X4 and lg != 2:
