@@ -50,6 +50,58 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
 {
     return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
 }
+
+/* the residual row segment z[0..NS-1] (NS = 4, 8, 16, 32) added to NS picture samples at d8 (bd 8: bytes; above: uint16_t, clipped to
+ * (1 << bd) - 1), as wide as d8's alignment allows: 16-byte accesses for 16-bit samples, 8-byte ones for bytes (one dword for NS = 4) */
+template <int NS>
+__device__ __forceinline__ void ffhip_add_row(uint8_t *d8, const int (&z)[NS], int bd)
+{
+    if (bd > 8) {
+        const int maxv = (1 << bd) - 1;
+        uint16_t *d = reinterpret_cast<uint16_t *>(d8);
+        auto two = [&](uint32_t p, int a, int b) {
+            return (uint32_t)min(max((int)(p & 0xFFFF) + a, 0), maxv) | (uint32_t)min(max((int)(p >> 16) + b, 0), maxv) << 16;
+        };
+        if (NS >= 8 && !(reinterpret_cast<uintptr_t>(d) & 15)) {
+#pragma unroll
+            for (int q = 0; q < NS / 8; q++) {
+                const uint4 p = reinterpret_cast<const uint4 *>(d)[q];
+                reinterpret_cast<uint4 *>(d)[q] = make_uint4(two(p.x, z[8 * q], z[8 * q + 1]), two(p.y, z[8 * q + 2], z[8 * q + 3]),
+                                                             two(p.z, z[8 * q + 4], z[8 * q + 5]), two(p.w, z[8 * q + 6], z[8 * q + 7]));
+            }
+        } else if (!(reinterpret_cast<uintptr_t>(d) & 7)) {
+#pragma unroll
+            for (int q = 0; q < NS / 4; q++) {
+                const uint2 p = reinterpret_cast<const uint2 *>(d)[q];
+                reinterpret_cast<uint2 *>(d)[q] = make_uint2(two(p.x, z[4 * q], z[4 * q + 1]), two(p.y, z[4 * q + 2], z[4 * q + 3]));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; k++)
+                d[k] = (uint16_t)min(max((int)d[k] + z[k], 0), maxv);
+        }
+        return;
+    }
+    auto four = [&](uint32_t p, const int *zz) {
+        return pack4(clip_u8((int)(p & 0xFF) + zz[0]), clip_u8((int)((p >> 8) & 0xFF) + zz[1]), clip_u8((int)((p >> 16) & 0xFF) + zz[2]),
+                     clip_u8((int)(p >> 24) + zz[3]));
+    };
+    if (NS >= 8 && !(reinterpret_cast<uintptr_t>(d8) & 7)) {
+#pragma unroll
+        for (int q = 0; q < NS / 8; q++) {
+            const uint2 p = reinterpret_cast<const uint2 *>(d8)[q];
+            reinterpret_cast<uint2 *>(d8)[q] = make_uint2(four(p.x, &z[8 * q]), four(p.y, &z[8 * q + 4]));
+        }
+    } else if (!(reinterpret_cast<uintptr_t>(d8) & 3)) {
+#pragma unroll
+        for (int q = 0; q < NS / 4; q++)
+            reinterpret_cast<uint32_t *>(d8)[q] = four(reinterpret_cast<const uint32_t *>(d8)[q], &z[4 * q]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+            d8[k] = (uint8_t)clip_u8((int)d8[k] + z[k]);
+    }
+}
 #endif
 
 /* one lazily created scratch arena per process for the host-pointer (signature-exact) faces; every user holds

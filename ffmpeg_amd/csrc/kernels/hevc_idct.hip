@@ -120,48 +120,6 @@ __device__ __forceinline__ void hevc_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-/* the residual row segment z[0..NS-1] added to NS picture samples at d (8-bit or 16-bit), as wide as d's alignment allows */
-template <int NS>
-__device__ __forceinline__ void hm_add_row(uint8_t *d8, const int (&z)[NS], int bd)
-{
-    if (bd > 8) {
-        const int maxv = (1 << bd) - 1;
-        uint16_t *d = reinterpret_cast<uint16_t *>(d8);
-        if (!(reinterpret_cast<uintptr_t>(d) & 15)) {
-#pragma unroll
-            for (int q = 0; q < NS / 8; q++) {
-                const uint4 p = reinterpret_cast<const uint4 *>(d)[q];
-                const uint32_t pw[4] = { p.x, p.y, p.z, p.w };
-                uint32_t o[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    o[k] = (uint32_t)min(max((int)(pw[k] & 0xFFFF) + z[8 * q + 2 * k], 0), maxv) |
-                           (uint32_t)min(max((int)(pw[k] >> 16) + z[8 * q + 2 * k + 1], 0), maxv) << 16;
-                reinterpret_cast<uint4 *>(d)[q] = make_uint4(o[0], o[1], o[2], o[3]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NS; k++)
-                d[k] = (uint16_t)min(max((int)d[k] + z[k], 0), maxv);
-        }
-    } else if (!(reinterpret_cast<uintptr_t>(d8) & 7)) {
-#pragma unroll
-        for (int q = 0; q < NS / 8; q++) {
-            const uint2 p = reinterpret_cast<const uint2 *>(d8)[q];
-            const int *zz = &z[8 * q];
-            const uint32_t o0 = pack4(clip_u8((int)(p.x & 0xFF) + zz[0]), clip_u8((int)((p.x >> 8) & 0xFF) + zz[1]),
-                                      clip_u8((int)((p.x >> 16) & 0xFF) + zz[2]), clip_u8((int)(p.x >> 24) + zz[3]));
-            const uint32_t o1 = pack4(clip_u8((int)(p.y & 0xFF) + zz[4]), clip_u8((int)((p.y >> 8) & 0xFF) + zz[5]),
-                                      clip_u8((int)((p.y >> 16) & 0xFF) + zz[6]), clip_u8((int)(p.y >> 24) + zz[7]));
-            reinterpret_cast<uint2 *>(d8)[q] = make_uint2(o0, o1);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NS; k++)
-            d8[k] = (uint8_t)clip_u8((int)d8[k] + z[k]);
-    }
-}
-
 /* bd: the depth the template was instantiated for in the reference (hevc/dsp.c:133-196): it sets the second-pass shift 20 - bd, the
  * DC shift 14 - bd, dequant's 15 - bd - log2 and the pixel type / clip of add_residual (uint16_t above 8 bits, stride in bytes) */
 template <int LOG2>
@@ -262,27 +220,12 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
     }
     (void)cg;
     if (dst && live && tu.dst_offset >= 0) {
-        uint8_t *d = dst + tu.dst_offset + (ptrdiff_t)i * stride;
         const int16_t *r = mine + i * N;
-        if (N >= 8) {
-            int z[N >= 8 ? N : 8];
+        int z[N];
 #pragma unroll
-            for (int x = 0; x < N; x++)
-                z[x] = r[x];
-            hm_add_row<(N >= 8 ? N : 8)>(d, z, bd);
-        } else if (bd > 8) {
-            uint16_t *d16 = reinterpret_cast<uint16_t *>(d);
-            const int maxv = (1 << bd) - 1;
-            for (int x = 0; x < N; x++)
-                d16[x] = (uint16_t)min(max((int)d16[x] + r[x], 0), maxv);
-        } else if (!(((uintptr_t)d) & 3)) {
-            const uint32_t p = *reinterpret_cast<const uint32_t *>(d);
-            *reinterpret_cast<uint32_t *>(d) = pack4(clip_u8((int)(p & 0xFF) + r[0]), clip_u8((int)((p >> 8) & 0xFF) + r[1]),
-                                                     clip_u8((int)((p >> 16) & 0xFF) + r[2]), clip_u8((int)(p >> 24) + r[3]));
-        } else {
-            for (int e = 0; e < 4; e++)
-                d[e] = (uint8_t)clip_u8((int)d[e] + r[e]);
-        }
+        for (int x = 0; x < N; x++)
+            z[x] = r[x];
+        ffhip_add_row<N>(dst + tu.dst_offset + (ptrdiff_t)i * stride, z, bd);
     }
 }
 
@@ -420,7 +363,7 @@ __global__ __launch_bounds__(256) void k_hevc_idct32_mfma(int16_t *coeffs, uint8
         z[2 * k] = (int)(int16_t)(rw[k] & 0xFFFF);
         z[2 * k + 1] = (int)(int16_t)(rw[k] >> 16);
     }
-    hm_add_row<16>(dst + tu.dst_offset + (ptrdiff_t)rr * stride + 16 * rh * (bd > 8 ? 2 : 1), z, bd);
+    ffhip_add_row<16>(dst + tu.dst_offset + (ptrdiff_t)rr * stride + 16 * rh * (bd > 8 ? 2 : 1), z, bd);
 }
 
 /*
@@ -534,7 +477,7 @@ __global__ __launch_bounds__(256) void k_hevc_idct16_mfma(int16_t *coeffs, uint8
         z[2 * k] = (int)(int16_t)(rw[k] & 0xFFFF);
         z[2 * k + 1] = (int)(int16_t)(rw[k] >> 16);
     }
-    hm_add_row<8>(dst + rtu.dst_offset + (ptrdiff_t)rr * stride + 8 * rh * (bd > 8 ? 2 : 1), z, bd);
+    ffhip_add_row<8>(dst + rtu.dst_offset + (ptrdiff_t)rr * stride + 8 * rh * (bd > 8 ? 2 : 1), z, bd);
 }
 
 static HevcMfmaTab *g_hm_tab16;

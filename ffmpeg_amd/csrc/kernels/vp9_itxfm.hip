@@ -62,12 +62,20 @@ __global__ __launch_bounds__(256) void k_vp9_itxfm(void *coeffs_, uint8_t *dst, 
     const int u = u0 + ul;
     const bool live = u < n;
     const FFHipVp9TU tu = tus[live ? u : u0];
-    /* ---- stage the wave's units ---- */
-    constexpr int DW = N * N * (int)sizeof(COEF) / 4;
-    for (int t = lane; t < UPW * DW; t += 64) {
-        const int b = t / DW, w = t % DW;
-        if (u0 + b < n)
-            reinterpret_cast<uint32_t *>(blk)[t] = reinterpret_cast<const uint32_t *>(coeffs + tus[u0 + b].coeff_offset)[w];
+    /* ---- stage the wave's units: 16 bytes per lane and step where the block is 16-byte aligned, else as dwords ---- */
+    constexpr int DW = N * N * (int)sizeof(COEF) / 4, Q4 = DW / 4;
+    for (int t = lane; t < UPW * Q4; t += 64) {
+        const int b = t / Q4, w = t % Q4;
+        if (u0 + b < n) {
+            const COEF *g = coeffs + tus[u0 + b].coeff_offset;
+            if (!(reinterpret_cast<uintptr_t>(g) & 15)) {
+                reinterpret_cast<uint4 *>(blk)[t] = reinterpret_cast<const uint4 *>(g)[w];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    reinterpret_cast<uint32_t *>(blk)[4 * t + k] = reinterpret_cast<const uint32_t *>(g)[4 * w + k];
+            }
+        }
     }
     vp_wave_sync();
     COEF *mine = blk + ul * N * N;
@@ -118,40 +126,31 @@ __global__ __launch_bounds__(256) void k_vp9_itxfm(void *coeffs_, uint8_t *dst, 
     /* ---- picture += (residual + round) >> bits, row i of my unit ---- */
     if (live) {
         const COEF *r = mine + i * N;
-        auto res = [&](int v) { return BITS ? (int)((uint32_t)v + (1u << (BITS ? BITS - 1 : 0))) >> BITS : v; };
-        if constexpr (HBD) {
-            uint16_t *d = reinterpret_cast<uint16_t *>(dst + tu.dst_offset + (ptrdiff_t)i * stride);
-            const int maxv = (1 << bd) - 1;
+        int z[N];
 #pragma unroll
-            for (int c = 0; c < N; c++)
-                d[c] = (uint16_t)min(max((int)d[c] + res((int)r[c]), 0), maxv);
-        } else {
-            uint8_t *d = dst + tu.dst_offset + (ptrdiff_t)i * stride;
-#pragma unroll
-            for (int c = 0; c < N; c += 4) {
-                if (!(((uintptr_t)d) & 3)) {
-                    const uint32_t p = *reinterpret_cast<const uint32_t *>(d + c);
-                    const uint32_t q = pack4(clip_u8((int)(p & 0xFF) + res(r[c])), clip_u8((int)((p >> 8) & 0xFF) + res(r[c + 1])),
-                                             clip_u8((int)((p >> 16) & 0xFF) + res(r[c + 2])), clip_u8((int)(p >> 24) + res(r[c + 3])));
-                    *reinterpret_cast<uint32_t *>(d + c) = q;
-                } else {
-                    for (int e = 0; e < 4; e++)
-                        d[c + e] = (uint8_t)clip_u8((int)d[c + e] + res(r[c + e]));
-                }
-            }
-        }
+        for (int c = 0; c < N; c++)
+            z[c] = BITS ? (int)((uint32_t)(int)r[c] + (1u << (BITS ? BITS - 1 : 0))) >> BITS : (int)r[c];
+        ffhip_add_row<N>(dst + tu.dst_offset + (ptrdiff_t)i * stride, z, HBD ? bd : 8);
     }
     /* ---- the block is consumed: zeroed (dc-only: block[0] alone, as the reference leaves the rest untouched) ---- */
-    for (int t = lane; t < UPW * DW; t += 64) {
-        const int b = t / DW, w = t % DW;
+    for (int t = lane; t < UPW * Q4; t += 64) {
+        const int b = t / Q4, w = t % Q4;
         if (u0 + b < n) {
             const FFHipVp9TU tb = tus[u0 + b];
-            uint32_t *cw = reinterpret_cast<uint32_t *>(coeffs + tb.coeff_offset);
+            COEF *g = coeffs + tb.coeff_offset;
+            uint32_t *cw = reinterpret_cast<uint32_t *>(g);
             const bool dcb = !WHT && tb.dc_only && (LOG2 == 5 || tb.txtp == 0);
-            if (!dcb)
-                cw[w] = 0;
-            else if (w == 0)
+            if (!dcb) {
+                if (!(reinterpret_cast<uintptr_t>(g) & 15)) {
+                    reinterpret_cast<uint4 *>(g)[w] = make_uint4(0, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        cw[4 * w + k] = 0;
+                }
+            } else if (w == 0) {
                 cw[0] = HBD ? 0u : cw[0] & 0xFFFF0000u;
+            }
         }
     }
 }
