@@ -7,13 +7,29 @@
  *       avg: (dst + v + 1) >> 1; only samples with a non-zero weight are read (three cases, as the reference)
  *   weight_h264_pixels{16,8,4,2}_8_c, biweight_  libavcodec/h264dsp_template.c:30-100
  *
- * GPU design: 16 lanes per block, one lane per row (h <= 16), rows of <= 16 bytes handled with byte accesses —
- * these are the reference's per-call operands, one record per call; throughput comes from the batch size.
+ * GPU design: 16 lanes per block, one lane per row (h <= 16) — these are the reference's per-call operands, one record per call;
+ * throughput comes from the batch size.  Chroma MC moves its rows as dwords (below); weight / biweight still byte by byte.
  * Algorithmic traffic 2 B per sample (chroma MC), 2-3 B per sample (weight / biweight).
  */
 #include "common.h"
 #include "h264_kernels.h"
 
+/* bytes p[0 .. nb-1] (nb <= 9, any alignment) as three dwords in stream order: only the aligned dwords that hold one of those
+ * bytes are read (a block at the picture's edge reads nothing the reference does not read, rounded to its dwords) */
+__device__ __forceinline__ void cm_row(const uint8_t *p, int nb, uint32_t (&w)[3])
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3), last = (sh + (uint32_t)nb - 1) >> 2; /* index of the last dword needed: 0..2 */
+    const uint32_t d0 = q[0], d1 = last >= 1 ? q[1] : 0, d2 = last >= 2 ? q[2] : 0;
+    w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    w[2] = d2 >> (8 * sh);
+}
+
+/* 16 lanes per block, one lane per row: a row's (and the next row's) w + 1 source bytes arrive as aligned dwords, a sample is one
+ * v_perm (s[k], s[k+1], t[k], t[k+1]) and one v_dot4_u32_u8 against (A, B, C, D), the row leaves as one or two dwords when dst
+ * is aligned.  (Round 1 read and wrote every byte by itself: 26 memory instructions per lane for an 8-wide row, now 8.) */
 __global__ __launch_bounds__(256) void k_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
                                                         const FFHipChromaBlock *blocks, int n)
 {
@@ -24,20 +40,43 @@ __global__ __launch_bounds__(256) void k_h264_chroma_mc(uint8_t *dst, const uint
     if (row >= blk.h)
         return;
     const int w = 8 >> blk.w_idx, x = blk.x & 7, y = blk.y & 7;
-    const int A = (8 - x) * (8 - y), B = x * (8 - y), C = (8 - x) * y, D = x * y;
+    const uint32_t A = (8 - x) * (8 - y), B = x * (8 - y), C = (8 - x) * y, D = x * y;
     const uint8_t *s = src + blk.src_offset + (ptrdiff_t)row * stride;
     uint8_t *d = dst + blk.dst_offset + (ptrdiff_t)row * stride;
-    const ptrdiff_t step = C ? stride : 1;
-    for (int k = 0; k < w; k++) {
-        int v;
-        if (D)
-            v = A * s[k] + B * s[k + 1] + C * s[stride + k] + D * s[stride + k + 1];
-        else if (B + C)
-            v = A * s[k] + (B + C) * s[step + k];
-        else
-            v = A * s[k];
-        v = (v + 32) >> 6;
-        d[k] = (uint8_t)(blk.avg ? (d[k] + v + 1) >> 1 : v);
+    /* the reference's three cases read only samples with a non-zero weight: the right neighbour if x, the row below if y */
+    uint32_t sw[3], tw[3] = { 0, 0, 0 };
+    cm_row(s, w + (x ? 1 : 0), sw);
+    if (y)
+        cm_row(s + stride, w + (x ? 1 : 0), tw);
+    const uint32_t coef = A | B << 8 | C << 16 | D << 24;
+    uint32_t out[2] = { 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < w) {
+            const uint32_t s4 = __builtin_amdgcn_alignbyte(sw[(k >> 2) + 1], sw[k >> 2], k & 3);
+            const uint32_t t4 = __builtin_amdgcn_alignbyte(tw[(k >> 2) + 1], tw[k >> 2], k & 3);
+            const uint32_t q = __builtin_amdgcn_perm(t4, s4, 0x05040100u); /* s[k], s[k+1], t[k], t[k+1] */
+            const uint32_t v = (__builtin_amdgcn_udot4(q, coef, 32u, false)) >> 6; /* <= 255: the weights sum to 64 */
+            out[k >> 2] |= v << (8 * (k & 3));
+        }
+    }
+    if (!(reinterpret_cast<uintptr_t>(d) & 3) && w >= 4) {
+        uint32_t *dw = reinterpret_cast<uint32_t *>(d);
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            if (4 * q < w) {
+                uint32_t o = out[q];
+                if (blk.avg) {
+                    const uint32_t p = dw[q];
+                    o = (p | o) - (((p ^ o) & 0xFEFEFEFEu) >> 1); /* four (a + b + 1) >> 1 at once (libavcodec/rnd_avg.h) */
+                }
+                dw[q] = o;
+            }
+    } else {
+        for (int k = 0; k < w; k++) {
+            const uint32_t v = (out[k >> 2] >> (8 * (k & 3))) & 0xFF;
+            d[k] = (uint8_t)(blk.avg ? (d[k] + v + 1) >> 1 : v);
+        }
     }
 }
 
