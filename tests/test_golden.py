@@ -333,3 +333,95 @@ def test_sws_uops_golden():
         g("free")(C.byref(h))
         for i, (a, b) in enumerate(zip(got, dst)):
             assert np.array_equal(a, b), (name, size, "plane %d: %d bytes differ" % (i, (a != b).sum()))
+
+
+# ---- round 2's additions (tests/golden/round2.npz, written by tools/make_golden.py round2 from the reference built in place) ----
+def test_round2_mdct_pfa_golden():
+    """ff_tx_mdct_pfa_{3,5,7,9}xM: the oracle on the stored inputs == the stored reference outputs, bit for bit"""
+    O = ffi.oracle()
+    d = load("round2")
+    for key in d["mdct_keys"]:
+        key = str(key)
+        _, inv, scale = key.split("_")
+        len_ = int(key.split("_")[0][4:])
+        assert O.ffo_mdct_pfa_factor(len_) in (3, 5, 7, 9)
+        s = O.ffo_mdct_create(int(inv), len_, float(scale))
+        for t in range(d[key + "_in"].shape[0]):
+            out = np.zeros(len_, np.float32)
+            O.ffo_mdct_run(s, ptr(out, f32p), ptr(np.ascontiguousarray(d[key + "_in"][t]), f32p), 4)
+            assert np.array_equal(out.view(np.uint32), d[key + "_out"][t].view(np.uint32)), key
+        O.ffo_mdct_free(s)
+
+
+def test_round2_vp9_loopfilter_sb_golden():
+    O = ffi.oracle()
+    d = load("round2")
+    lim, mblim = np.ascontiguousarray(d["lf_lim"]), np.ascontiguousarray(d["lf_mblim"])
+    changed = 0
+    for n in range(int(d["lf_n"])):
+        bd, row, col = (int(v) for v in d["lf%d_par" % n])
+        pl = [d["lf%d_in%d" % (n, k)].copy() for k in range(3)]
+        level, mask = np.ascontiguousarray(d["lf%d_level" % n]), np.ascontiguousarray(d["lf%d_mask" % n])
+        O.ffo_vp9_loopfilter_sb(bd, 1, 1, ptr(level, u8p), ptr(mask, u8p), row, col,
+                                *(C.cast(p.ctypes.data + k * p.strides[0] + k * p.itemsize, u8p) for p, k in zip(pl, (64, 32, 32))),
+                                pl[0].strides[0], pl[1].strides[0], ptr(lim, u8p), ptr(mblim, u8p))
+        for k in range(3):
+            assert np.array_equal(pl[k], d["lf%d_out%d" % (n, k)]), (n, k)
+            changed += int((pl[k] != d["lf%d_in%d" % (n, k)]).sum())
+    assert changed > 1000
+
+
+def test_round2_aac_tools_golden():
+    """mid/side + intensity stereo, apply_ltp, update_ltp, imdct_and_windowing_960 against the reference's stored outputs"""
+    O = ffi.oracle()
+    d = load("round2")
+    u16p, i8p_ = C.POINTER(C.c_uint16), C.POINTER(C.c_int8)
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    for k in range(2):
+        ng, max_sfb, ms_present = (int(v) for v in d["st%d_par" % k])
+        g = {name: np.ascontiguousarray(d["st%d_%s" % (k, name)]) for name in ("group_len", "ms_mask", "band_type0", "band_type1", "sf1", "swb")}
+        a0, a1 = d["st%d_in0" % k].copy(), d["st%d_in1" % k].copy()
+        O.ffo_aac_apply_mid_side_stereo(ptr(a0, f32p), ptr(a1, f32p), ng, ptr(g["group_len"], u8p), max_sfb, ptr(g["ms_mask"], u8p),
+                                        ptr(g["band_type0"], i32p), ptr(g["band_type1"], i32p), ptr(g["swb"], u16p))
+        O.ffo_aac_apply_intensity_stereo(ptr(a0, f32p), ptr(a1, f32p), ng, ptr(g["group_len"], u8p), max_sfb, ms_present, ptr(g["ms_mask"], u8p),
+                                         ptr(g["band_type1"], i32p), ptr(g["sf1"], f32p), ptr(g["swb"], u16p))
+        assert np.array_equal(bits(a0), bits(d["st%d_out0" % k])) and np.array_equal(bits(a1), bits(d["st%d_out1" % k])), k
+    win = [np.ascontiguousarray(d["win%d" % k]) for k in range(4)]
+    wp = (f32p * 4)(*[ptr(w, f32p) for w in win])
+    # apply_ltp
+    from test_oracle_vs_ref import aac_tns_filters
+    lag, max_sfb, num_swb, tmb = (int(v) for v in d["ltp_par"])
+    t = {name: np.ascontiguousarray(d["ltp_tns_" + name]) for name in ("n_filt", "length", "direction", "order", "coef")}
+    t.update(num_windows=1, num_swb=num_swb, swb=np.ascontiguousarray(d["ltp_swb"]), tns_max_bands=tmb, max_sfb=max_sfb)
+    rec = aac_tns_filters(O, t)
+    m = O.ffo_mdct_create(0, 1024, np.float32(-32786.0 * 2 + 36))
+    co, pf = d["ltp_in"].copy(), np.zeros(1024, np.float32)
+    O.ffo_aac_apply_ltp(m, wp, ptr(co, f32p), ptr(np.ascontiguousarray(d["ltp_state"]), f32p), lag, float(d["ltp_coef"]),
+                        ptr(np.ascontiguousarray(d["ltp_used"]), i8p_), ptr(np.ascontiguousarray(d["ltp_seq"]), i32p),
+                        ptr(np.ascontiguousarray(d["ltp_kb"]), i32p), max_sfb, ptr(t["swb"], u16p), rec.ctypes.data if len(rec) else None, len(rec),
+                        ptr(pf, f32p))
+    O.ffo_mdct_free(m)
+    assert np.array_equal(bits(pf), bits(d["ltp_pred"])) and np.array_equal(bits(co), bits(d["ltp_out"]))
+    assert not np.array_equal(bits(co), bits(d["ltp_in"]))
+    # update_ltp
+    for k in range(3):
+        st = d["ul%d_in" % k].copy()
+        seq0, kb0 = (int(v) for v in d["ul%d_par" % k])
+        O.ffo_aac_update_ltp(wp, ptr(st, f32p), ptr(np.ascontiguousarray(d["ul%d_buf" % k]), f32p), ptr(np.ascontiguousarray(d["ul%d_saved" % k]), f32p),
+                             ptr(np.ascontiguousarray(d["ul%d_output" % k]), f32p), seq0, kb0)
+        assert np.array_equal(bits(st), bits(d["ul%d_out" % k])), k
+    # imdct_and_windowing_960
+    w960 = [np.ascontiguousarray(d["w960_%d" % k]) for k in range(4)]
+    wp960 = (f32p * 4)(*[ptr(w, f32p) for w in w960])
+    ml, ms = O.ffo_mdct_create(1, 960, np.float32((1.0 / 960) / 32768.0)), O.ffo_mdct_create(1, 120, np.float32((1.0 / 120) / 32768.0))
+    saved = d["a960_saved_in"].copy()
+    prev = (0, 0)
+    for f in range(len(d["a960_seq"])):
+        s2 = np.array([d["a960_seq"][f], prev[0]], np.int32); k2 = np.array([d["a960_kb"][f], prev[1]], np.int32)
+        out = np.zeros(960, np.float32)
+        O.ffo_aac_imdct_and_windowing_len(960, 128, ml, ms, wp960, ptr(np.ascontiguousarray(d["a960_coeffs"][f]), f32p), ptr(s2, i32p),
+                                          ptr(k2, i32p), ptr(saved, f32p), ptr(out, f32p))
+        assert np.array_equal(bits(out), bits(d["a960_out"][f])), f
+        prev = (int(d["a960_seq"][f]), int(d["a960_kb"][f]))
+    assert np.array_equal(bits(saved), bits(d["a960_saved_out"]))
+    O.ffo_mdct_free(ml); O.ffo_mdct_free(ms)

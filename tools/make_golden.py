@@ -494,12 +494,118 @@ def sws_uops():
     np.savez_compressed(os.path.join(OUT, "sws_uops.npz"), **d)
 
 
+def round2():
+    """round 2's additions, one file: the prime-factor MDCT lengths other than 15xM, ff_vp9_loopfilter_sb on superblocks, the AAC
+    stereo tools / long-term prediction / 960-sample windowing — inputs and the REAL reference's outputs"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import aac_gen as A
+    import vp9_lf_gen as G
+    from test_oracle_vs_ref import aac_tns_case
+    u16p, i8p_ = C.POINTER(C.c_uint16), C.POINTER(C.c_int8)
+    d = {}
+    # ---- ff_tx_mdct_pfa_{3,5,7,9}xM
+    rng = np.random.default_rng(2001)
+    keys = []
+    for len_ in (96, 1536, 640, 112, 1152):
+        for inv, scale in ((0, 1.0), (1, 1.0 / len_)):
+            x = rng.uniform(-1, 1, (2, len_ if inv else 2 * len_)).astype(np.float32)
+            rc = R.ffref_tx_create(1, inv, len_, scale, 0)
+            out = np.zeros((2, len_), np.float32)
+            for t in range(2):
+                R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 4)
+            R.ffref_tx_free(rc)
+            key = "mdct%d_%d_%r" % (len_, inv, scale)
+            keys.append(key)
+            d[key + "_in"], d[key + "_out"] = x, out
+    d["mdct_keys"] = np.array(keys)
+    # ---- ff_vp9_loopfilter_sb: three superblocks per depth (first / later row and column), stream-like masks
+    rng = np.random.default_rng(2002)
+    lim, mblim = G.filter_lut(3)
+    d["lf_lim"], d["lf_mblim"] = lim, mblim
+    n = 0
+    for bd in (8, 10):
+        for row, col in ((0, 0), (8, 8), (0, 16)):
+            f = G.structured(rng, row // 8, col // 8, 23, 24)
+            dt = np.uint8 if bd == 8 else np.uint16
+            pl = []
+            for sz in (192, 96, 96):
+                base = np.cumsum(rng.integers(-2, 3, (sz, sz + 4)), axis=1) + 128
+                pl.append(np.clip((base << (bd - 8)) + rng.integers(0, (1 << (bd - 8)) + 1, base.shape), 0, (1 << bd) - 1).astype(dt))
+            before = [p.copy() for p in pl]
+            level, mask = np.ascontiguousarray(f["level"]), np.ascontiguousarray(f["mask"])
+            R.ffref_vp9_loopfilter_sb(bd, 1, 1, ptr(level, u8p), ptr(mask, u8p), row, col,
+                                      *(C.cast(p.ctypes.data + k * p.strides[0] + k * p.itemsize, u8p) for p, k in zip(pl, (64, 32, 32))),
+                                      pl[0].strides[0], pl[1].strides[0], ptr(lim, u8p), ptr(mblim, u8p))
+            d["lf%d_par" % n] = np.array([bd, row, col], np.int32)
+            d["lf%d_level" % n], d["lf%d_mask" % n] = level, mask
+            for k in range(3):
+                d["lf%d_in%d" % (n, k)], d["lf%d_out%d" % (n, k)] = before[k], pl[k]
+            n += 1
+    d["lf_n"] = np.array(n)
+    # ---- AAC: mid/side + intensity (a long and a short pair), apply_ltp, update_ltp, imdct_and_windowing_960
+    rng = np.random.default_rng(2003)
+    for k, short in enumerate((0, 1)):
+        c = A.cpe(rng, short)
+        a0, a1 = A.spectrum(rng), A.spectrum(rng)
+        for name in ("group_len", "ms_mask", "band_type0", "band_type1", "sf1", "swb"):
+            d["st%d_%s" % (k, name)] = c[name]
+        d["st%d_par" % k] = np.array([c["num_window_groups"], c["max_sfb"], c["ms_present"]], np.int32)
+        d["st%d_in0" % k], d["st%d_in1" % k] = a0.copy(), a1.copy()
+        R.ffref_aac_apply_mid_side_stereo(ptr(a0, f32p), ptr(a1, f32p), c["num_window_groups"], ptr(c["group_len"], u8p), c["max_sfb"],
+                                          ptr(c["ms_mask"], u8p), ptr(c["band_type0"], i32p), ptr(c["band_type1"], i32p), ptr(c["swb"], u16p))
+        R.ffref_aac_apply_intensity_stereo(ptr(a0, f32p), ptr(a1, f32p), c["num_window_groups"], ptr(c["group_len"], u8p), c["max_sfb"],
+                                           c["ms_present"], ptr(c["ms_mask"], u8p), ptr(c["band_type1"], i32p), ptr(c["sf1"], f32p),
+                                           ptr(c["swb"], u16p))
+        d["st%d_out0" % k], d["st%d_out1" % k] = a0, a1
+    win = [np.ctypeslib.as_array(R.ffref_aac_window(k), (sz,)).copy() for k, sz in ((0, 1024), (1, 128), (2, 1024), (3, 128))]
+    for k in range(4):
+        d["win%d" % k] = win[k]
+    l = A.ltp(rng, A.LONG_START)
+    t = aac_tns_case(rng, 0)
+    t["swb"], t["num_swb"], t["max_sfb"] = l["swb"], l["num_swb"], l["max_sfb"]
+    co = A.spectrum(rng)
+    d["ltp_in"], d["ltp_state"], d["ltp_used"], d["ltp_swb"] = co.copy(), l["ltp_state"], l["used"], l["swb"]
+    d["ltp_par"] = np.array([l["lag"], l["max_sfb"], l["num_swb"], t["tns_max_bands"]], np.int32)
+    d["ltp_coef"], d["ltp_seq"], d["ltp_kb"] = np.float32(l["coef"]), l["seq"], l["kb"]
+    for name in ("n_filt", "length", "direction", "order", "coef"):
+        d["ltp_tns_" + name] = t[name]
+    pf = np.zeros(1024, np.float32)
+    assert R.ffref_aac_apply_ltp(ptr(co, f32p), ptr(l["ltp_state"], f32p), l["lag"], l["coef"], ptr(l["used"], i8p_), ptr(l["seq"], i32p),
+                                 ptr(l["kb"], i32p), l["max_sfb"], l["num_swb"], t["tns_max_bands"], ptr(l["swb"], u16p), 1, ptr(t["n_filt"], i32p),
+                                 ptr(t["length"], i32p), ptr(t["direction"], i32p), ptr(t["order"], i32p), ptr(t["coef"], f32p), ptr(pf, f32p)) == 0
+    d["ltp_out"], d["ltp_pred"] = co, pf
+    for k, (seq0, kb0) in enumerate(((0, 0), (1, 1), (2, 0))):
+        buf, saved, out = A.spectrum(rng), A.spectrum(rng)[:512].copy(), A.spectrum(rng)
+        st = (rng.standard_normal(3072) * 100).astype(np.float32)
+        d["ul%d_in" % k], d["ul%d_buf" % k], d["ul%d_saved" % k], d["ul%d_output" % k] = st.copy(), buf, saved, out
+        d["ul%d_par" % k] = np.array([seq0, kb0], np.int32)
+        assert R.ffref_aac_update_ltp(ptr(st, f32p), ptr(buf, f32p), ptr(saved, f32p), ptr(out, f32p), seq0, kb0) == 0
+        d["ul%d_out" % k] = st
+    w960 = [np.ctypeslib.as_array(R.ffref_aac_window_len(960, k), (sz,)).copy() for k, sz in ((0, 960), (1, 120), (2, 960), (3, 120))]
+    for k in range(4):
+        d["w960_%d" % k] = w960[k]
+    seq = np.array([0, 1, 2, 2, 3, 0, 1, 2, 3, 0], np.int32)
+    kb = np.array([0, 1, 1, 0, 0, 1, 0, 0, 1, 1], np.int32)
+    coeffs = np.round(rng.standard_normal((len(seq), 1024)) * 2000.0 / (1 + np.arange(1024) / 64.0)).astype(np.float32)
+    saved = (rng.standard_normal(480) * 0.05).astype(np.float32)
+    d["a960_seq"], d["a960_kb"], d["a960_coeffs"], d["a960_saved_in"] = seq, kb, coeffs, saved.copy()
+    out = np.zeros((len(seq), 960), np.float32)
+    prev = (0, 0)
+    for f in range(len(seq)):
+        s2, k2 = np.array([seq[f], prev[0]], np.int32), np.array([kb[f], prev[1]], np.int32)
+        assert R.ffref_aac_imdct_and_windowing_len(960, ptr(np.ascontiguousarray(coeffs[f]), f32p), ptr(s2, i32p), ptr(k2, i32p), ptr(saved, f32p),
+                                                   ptr(out[f], f32p)) == 0
+        prev = (int(seq[f]), int(kb[f]))
+    d["a960_out"], d["a960_saved_out"] = out, saved
+    np.savez_compressed(os.path.join(OUT, "round2.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
