@@ -206,10 +206,10 @@ def extras(torch, dev):
     out["h264_idct8_add"] = {"Gblocks/s": round(nb / (ms * 1e-3) / 1e9, 3), "GB/s": round(gbs, 1),
                              "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "blocks": nb, "ms": round(ms, 4)}
     del plane, coefs, coefs0, offs
-    # HEVC 32x32 and 8x8 inverse transform + add_residual over 4K luma planes (coefficients read + residual written in
+    # HEVC 32x32 (matrix cores), 16x16 and 8x8 inverse transform + add_residual over 4K luma planes (coefficients read + residual written in
     # place + picture read + written: 6 B per sample)
     from ffmpeg_amd import hevc
-    for lg, planes in ((5, 16), (3, 8)):
+    for lg, planes in ((5, 16), (4, 16), (3, 8)):
         nsz = 1 << lg
         bw, bh = 3840 // nsz, 2160 // nsz
         ntu = planes * bw * bh
@@ -471,7 +471,94 @@ def extras(torch, dev):
     out["dct3_1024"] = {"Mtransforms/s": round(nt / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                         "transforms": nt, "ms": round(ms, 4)}
     f.close()
+    out.update(round2_legs(torch, dev, ev))
     out.update(sws_ops_leg(torch, dev))
+    return out
+
+
+def round2_legs(torch, dev, ev):
+    """rows added in round 2: the forward DCT-II, a 3xM prime-factor MDCT (768-sample AAC frames), VP9's 32x32 inverse
+    transform, the VP9 loop filter of a 4K picture in decoder order"""
+    from ffmpeg_amd import tx, vp9
+    out = {}
+    nt = 65536
+    for key, typ, inv, ln, n_in, n_out in (("dct2_1024", tx.FLOAT_DCT, 0, 1024, 1024, 1024), ("mdct1536_pfa3_fwd", tx.FLOAT_MDCT, 0, 1536, 3072, 1536)):
+        f = tx.TxContext(typ, inv, ln, 1.0)
+        tin = torch.rand((nt, n_in), dtype=torch.float32, device=dev)
+        tout = torch.empty((nt, n_out), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            f.batch(tout, tin)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(10):
+            f.batch(tout, tin)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        gbs = nt * (n_in + n_out) * 4 / (ms * 1e-3) / 1e9
+        out[key] = {"Mtransforms/s": round(nt / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "transforms": nt, "ms": round(ms, 4)}
+        f.close()
+        del tin, tout
+    # VP9 itxfm_add 32x32 (DCT_DCT), every block of 8 4K luma planes: 6 B per sample
+    planes, nsz = 8, 32
+    bw, bh = 3840 // nsz, 2160 // nsz
+    ntu = planes * bw * bh
+    tus = np.zeros(ntu, vp9.TU_DTYPE)
+    idx = np.arange(ntu)
+    pl, rem = idx // (bw * bh), idx % (bw * bh)
+    tus["coeff_offset"] = idx * nsz * nsz
+    tus["dst_offset"] = pl * 3840 * 2160 + (rem // bw) * nsz * 3840 + (rem % bw) * nsz
+    d_t = torch.from_numpy(tus.view(np.uint8).reshape(ntu, 12).copy()).to(dev)
+    c0 = torch.randint(-512, 512, (ntu, nsz * nsz), dtype=torch.int16, device=dev)
+    pic = torch.randint(0, 256, (planes * 2160, 3840), dtype=torch.uint8, device=dev)
+    cc = c0.clone()
+    vp9.itxfm_add_batch(3, cc, pic, 3840, d_t, ntu)
+    tot = 0.0
+    for _ in range(5):
+        cc.copy_(c0)
+        e0, e1 = ev(), ev()
+        e0.record()
+        vp9.itxfm_add_batch(3, cc, pic, 3840, d_t, ntu)
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    ms = tot / 5
+    gbs = ntu * nsz * nsz * 6 / (ms * 1e-3) / 1e9
+    out["vp9_itxfm32_add"] = {"Mblocks/s": round(ntu / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                              "blocks": ntu, "ms": round(ms, 4)}
+    del cc, c0, pic, d_t
+    # the VP9 loop filter of a 4K 4:2:0 picture in the decoder's (superblock) order: one launch, a 2-D wavefront — latency, not bytes
+    sbc, sbr = 60, 34
+    rng = np.random.default_rng(9)
+    tabs = np.zeros((sbr * sbc, 320), np.uint32)
+    # every 8-sample luma segment on the 8x8 grid filtered 8 wide at level 32, every second chroma one (a dense, regular picture)
+    ent = np.uint32(0x80000000 | 1 << 24 | (32 >> 4) << 16 | 6 << 8 | (2 * (32 + 2) + 6))
+    y = tabs[:, :256].reshape(-1, 2, 16, 8)
+    y[:, :, 0::2, :] = ent
+    uv = tabs[:, 256:].reshape(-1, 2, 8, 4)
+    uv[:, :, 0::2, :] = ent
+    t3 = tabs.reshape(sbr, sbc, 320)
+    t3[:, 0, 0:8] = 0            # no column edge at the picture's left border (luma position 0 / chroma position 0 of column edges)
+    t3[:, 0, 256:260] = 0
+    t3[0, :, 128:136] = 0        # nor a row edge at its top
+    t3[0, :, 288:292] = 0
+    d_tabs = torch.from_numpy(tabs.view(np.int32)).to(dev)
+    yy = torch.from_numpy(np.clip(np.cumsum(rng.integers(-2, 3, (64 * sbr, 64 * sbc)), axis=1) + 128, 0, 255).astype(np.uint8)).to(dev)
+    uu = yy[::2, ::2].contiguous()
+    vv = uu.clone()
+    for _ in range(2):
+        vp9.loopfilter_frame(yy, uu, vv, 64 * sbc, 32 * sbc, 8 * sbc, 8 * sbr, d_tabs)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        vp9.loopfilter_frame(yy, uu, vv, 64 * sbc, 32 * sbc, 8 * sbc, 8 * sbr, d_tabs)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    out["vp9_loopfilter_frame_4k"] = {"ms_per_picture_one_stream": round(ms, 4), "pictures_per_s": round(1e3 / ms, 1),
+                                      "Mpixels/s": round(64 * sbc * 64 * sbr / (ms * 1e-3) / 1e6, 1),
+                                      "note": "decoder order (superblock wavefront, luma and chroma chains side by side), every 8x8-grid edge 8 wide"}
     return out
 
 
