@@ -685,8 +685,8 @@ def strong_leg(torch, dist, dev, ctx, S, rank, world, n_total, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # a step is < 1 ms: 200 steady-state steps, not an 18 ms glimpse
+    ap.add_argument("--warmup", type=int, default=50)  # ~50 ms: the clocks have settled (20 / 3 measured 3-4 % slower)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
