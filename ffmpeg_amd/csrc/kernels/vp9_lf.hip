@@ -211,34 +211,14 @@ __device__ __forceinline__ void vp9_lf_sb_row(uint8_t *p0, uint8_t *p1, ptrdiff_
     for (int col = 0; col < sb_cols; col++) {
         const int w = min(N, (CHROMA ? 4 : 8) * cols - N * col);
         uint8_t *sb[2] = { prow[0] + (ptrdiff_t)col * N * PS, prow[1] + (ptrdiff_t)col * N * PS };
-        /* ---- the row above has finished superblock col + 1 ---- */
-        if (row > 0) {
-            const int want = min(col + 2, sb_cols);
-            int spins = 0;
-            while (known < want) {
-                known = __hip_atomic_load(&progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (known >= want)
-                    break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
-                    if (lane == 0)
-                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    return;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        /* ---- tile <- picture: the prefetched N x N, the 8 columns to the left (right of the first superblock), the 8 rows above
-         *      (below the first superblock row; the corner is never read); everything else of the tile is never read ---- */
+        /* ---- tile <- picture: the prefetched N x N and the 8 columns to the left (right of the first superblock); the column
+         *      edges need no more ---- */
         {
-            uint32_t vl[NP][Left::K], vt[NP][Top::K];
+            uint32_t vl[NP][Left::K];
 #pragma unroll
-            for (int q = 0; q < NP; q++) {
+            for (int q = 0; q < NP; q++)
                 if (col)
                     Left::issue(vl[q], sb[q] - 8 * PS, stride, h, D8, lane);
-                if (row)
-                    Top::issue(vt[q], sb[q] - 8 * stride, stride, 8, w / SPD, lane);
-            }
 #pragma unroll
             for (int k = 0; k < TK; k++)
                 if (lane + 64 * k < TW)
@@ -248,8 +228,6 @@ __device__ __forceinline__ void vp9_lf_sb_row(uint8_t *p0, uint8_t *p1, ptrdiff_
                 In::commit(nin[q], t32[q] + 8 * PD + D8, PD, h, w / SPD, lane);
                 if (col)
                     Left::commit(vl[q], t32[q] + 8 * PD, PD, h, D8, lane);
-                if (row)
-                    Top::commit(vt[q], t32[q] + D8, PD, 8, w / SPD, lane);
             }
         }
         wave_sync();
@@ -271,6 +249,34 @@ __device__ __forceinline__ void vp9_lf_sb_row(uint8_t *p0, uint8_t *p1, ptrdiff_
             const uint32_t e = tab[p * NSEG + (line >> 3)];
             if (e >> 31)
                 run(tile[pl] + (line + 8) * P + 8, 1, p, e);
+        }
+        /* ---- only the row edges read (and rewrite) the upper neighbour's last rows: the wait for the row above — it must have
+         *      finished superblock col + 1, whose column edges reach into those rows — sits behind the column pass, which it thus
+         *      overlaps; then the 8 rows above (the corner is never read) ---- */
+        if (row > 0) {
+            const int want = min(col + 2, sb_cols);
+            int spins = 0;
+            while (known < want) {
+                known = __hip_atomic_load(&progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (known >= want)
+                    break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                    if (lane == 0)
+                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (row) {
+            uint32_t vt[NP][Top::K];
+#pragma unroll
+            for (int q = 0; q < NP; q++)
+                Top::issue(vt[q], sb[q] - 8 * stride, stride, 8, w / SPD, lane);
+#pragma unroll
+            for (int q = 0; q < NP; q++)
+                Top::commit(vt[q], t32[q] + D8, PD, 8, w / SPD, lane);
         }
         wave_sync();
         /* ---- row edges: lane = sample column ---- */
