@@ -524,35 +524,6 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
             *reinterpret_cast<uint32_t *>(cur + lown) = mine;
         if (!last)
             fetch(mx + 1);
-        /* ---- context rows: the row above must have finished macroblock mx + 1 ---- */
-        if (my > 0) {
-            /* LDS progress counts finished steps (the ring slot's last dword arrives a step late); the memory progress counts
-             * macroblocks complete in memory */
-            const int want = (fault & 8) ? 0 : from_lds ? min(mx + 2, mb_w) : mx + 1;
-            int spins = 0;
-            while (known < want) {
-                known = from_lds ? __hip_atomic_load(&lprog[w - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                                 : __hip_atomic_load(&gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (known >= want)
-                    break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
-                    if (lane == 0)
-                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    return;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (in_ring) {
-                uint32_t v;
-                if (from_lds)
-                    v = ring[w - 1][mx % DB_R][lane];
-                else /* written write-through by the band above: device-scope (L1-bypassing) loads */
-                    v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(mb + (ptrdiff_t)(lane / NDW - CTX) * stride + 4 * ps),
-                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *reinterpret_cast<uint32_t *>(cur + (lane / NDW) * TPP + 4 * ps) = v;
-            }
-        }
         wave_lds_sync();
         /* ---- vertical edges, left to right: lane = row; samples -4 .. MB-1 of the row ---- */
         if (lane < MB && !(fault & 4)) {
@@ -585,6 +556,36 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
                     *reinterpret_cast<uint32_t *>(trow + 4 * d - 4) = v;
                 else
                     *reinterpret_cast<uint32_t *>(tprev) = v;
+            }
+        }
+        /* ---- context rows: the row above must have finished macroblock mx + 1.  Only the horizontal edges read (and rewrite)
+         *      them, so the wait sits behind the vertical pass, which it overlaps ---- */
+        if (my > 0) {
+            /* LDS progress counts finished steps (the ring slot's last dword arrives a step late); the memory progress counts
+             * macroblocks complete in memory */
+            const int want = (fault & 8) ? 0 : from_lds ? min(mx + 2, mb_w) : mx + 1;
+            int spins = 0;
+            while (known < want) {
+                known = from_lds ? __hip_atomic_load(&lprog[w - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                 : __hip_atomic_load(&gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (known >= want)
+                    break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                    if (lane == 0)
+                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (in_ring) {
+                uint32_t v;
+                if (from_lds)
+                    v = ring[w - 1][mx % DB_R][lane];
+                else /* written write-through by the band above: device-scope (L1-bypassing) loads */
+                    v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(mb + (ptrdiff_t)(lane / NDW - CTX) * stride + 4 * ps),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *reinterpret_cast<uint32_t *>(cur + (lane / NDW) * TPP + 4 * ps) = v;
             }
         }
         wave_lds_sync();
