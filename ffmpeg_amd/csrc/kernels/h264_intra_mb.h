@@ -28,8 +28,10 @@
 
 #if defined(__HIPCC__)
 #define IMB_FN __host__ __device__ __forceinline__
+#define IMB_MEM __host__ __device__ __forceinline__
 #else
 #define IMB_FN static inline
+#define IMB_MEM inline
 #endif
 
 /* ---- prediction rules over the edge line e[]: left column bottom-up, corner, row above, top-right ---- */
@@ -43,90 +45,113 @@ IMB_FN unsigned hp_need(int mode)
     return (unsigned)(0x0211a777a312ull >> (4 * mode)) & 15u;
 }
 
-template <int N>
-IMB_FN int hp_dir_sample(int mode, const int *e, int x, int y, int dc)
+/* the edge line as a callable e(k) (an array in LDS, or the tile read in place) */
+struct HpArr {
+    const int *p;
+    IMB_MEM int operator()(int k) const { return p[k]; }
+};
+
+template <int N, class E>
+IMB_FN int hp_dir_sample_e(int mode, const E &e, int x, int y, int dc)
 {
-    const int *T = e + N + 1;
+    auto T = [&](int k) { return e(N + 1 + k); };
     switch (mode) {
-    case 0: return T[x];
-    case 1: return e[N - 1 - y];
+    case 0: return T(x);
+    case 1: return e(N - 1 - y);
     case 3: {
         const int i = x + y;
-        return i < 2 * N - 2 ? hp_a3(T[i], T[i + 1], T[i + 2]) : (T[2 * N - 2] + 3 * T[2 * N - 1] + 2) >> 2;
+        return i < 2 * N - 2 ? hp_a3(T(i), T(i + 1), T(i + 2)) : (T(2 * N - 2) + 3 * T(2 * N - 1) + 2) >> 2;
     }
     case 4: {
         const int i = N - 1 - y + x;
-        return hp_a3(e[i], e[i + 1], e[i + 2]);
+        return hp_a3(e(i), e(i + 1), e(i + 2));
     }
     case 5: {
         const int d = 2 * x - y, h = d >> 1;
         if (d < 0)
-            return hp_a3(e[N + d], e[N + d + 1], e[N + d + 2]);
-        return (d & 1) ? hp_a3(e[N + h], e[N + h + 1], e[N + h + 2]) : hp_a2(e[N + h], e[N + h + 1]);
+            return hp_a3(e(N + d), e(N + d + 1), e(N + d + 2));
+        return (d & 1) ? hp_a3(e(N + h), e(N + h + 1), e(N + h + 2)) : hp_a2(e(N + h), e(N + h + 1));
     }
     case 6: {
         const int d = 2 * y - x, h = d >> 1;
         if (d < 0)
-            return hp_a3(e[N - d - 2], e[N - d - 1], e[N - d]);
-        return (d & 1) ? hp_a3(e[N - h], e[N - h - 1], e[N - h - 2]) : hp_a2(e[N - h], e[N - h - 1]);
+            return hp_a3(e(N - d - 2), e(N - d - 1), e(N - d));
+        return (d & 1) ? hp_a3(e(N - h), e(N - h - 1), e(N - h - 2)) : hp_a2(e(N - h), e(N - h - 1));
     }
     case 7: {
         const int i = (y >> 1) + x;
-        return (y & 1) ? hp_a3(T[i], T[i + 1], T[i + 2]) : hp_a2(T[i], T[i + 1]);
+        return (y & 1) ? hp_a3(T(i), T(i + 1), T(i + 2)) : hp_a2(T(i), T(i + 1));
     }
     case 8: {
         const int i = 2 * y + x, j = N - 1 - (i >> 1);
         if (i >= 2 * N - 2)
-            return e[0];
+            return e(0);
         if (i == 2 * N - 3)
-            return (e[1] + 3 * e[0] + 2) >> 2;
-        return (i & 1) ? hp_a3(e[j], e[j - 1], e[j - 2]) : hp_a2(e[j], e[j - 1]);
+            return (e(1) + 3 * e(0) + 2) >> 2;
+        return (i & 1) ? hp_a3(e(j), e(j - 1), e(j - 2)) : hp_a2(e(j), e(j - 1));
     }
     default: return dc;
     }
 }
 
-/* the DC of modes 2 (both sides), 9 (LEFT_DC), 10 (TOP_DC); 128 otherwise */
 template <int N>
-IMB_FN int hp_dir_dc(int mode, const int *e)
+IMB_FN int hp_dir_sample(int mode, const int *e, int x, int y, int dc)
+{
+    return hp_dir_sample_e<N>(mode, HpArr{ e }, x, y, dc);
+}
+
+/* the DC of modes 2 (both sides), 9 (LEFT_DC), 10 (TOP_DC); 128 otherwise */
+template <int N, class E>
+IMB_FN int hp_dir_dc_e(int mode, const E &e)
 {
     if (mode != 2 && mode != 9 && mode != 10)
         return 128;
     int sl = 0, st = 0;
     for (int i = 0; i < N; i++) {
-        sl += e[i];
-        st += e[N + 1 + i];
+        sl += mode != 10 ? e(i) : 0;
+        st += mode != 9 ? e(N + 1 + i) : 0;
     }
     return mode == 2 ? (sl + st + N) >> (N == 8 ? 4 : 3) : ((mode == 9 ? sl : st) + N / 2) >> (N == 8 ? 3 : 2);
 }
 
+template <int N>
+IMB_FN int hp_dir_dc(int mode, const int *e)
+{
+    return hp_dir_dc_e<N>(mode, HpArr{ e });
+}
+
 /* PREDICT_8x8_LOAD_LEFT / _TOP / _TOPRIGHT / _TOPLEFT (h264pred_template.c:822-856): entry j of the low-pass filtered line from
- * the raw line w[0..24]; entries the mode does not read are 0 */
-IMB_FN int hp_filter8(const int *w, int j, unsigned need, bool tl, bool tr)
+ * the raw line w(0..24); entries the mode does not read are 0 */
+template <class W>
+IMB_FN int hp_filter8_e(const W &w, int j, unsigned need, bool tl, bool tr)
 {
     if (j < 8) {
         if (!(need & 1))
             return 0;
-        return j == 7 ? hp_a3(tl ? w[8] : w[7], w[7], w[6]) : j == 0 ? (w[1] + 3 * w[0] + 2) >> 2 : hp_a3(w[j + 1], w[j], w[j - 1]);
+        return j == 7 ? hp_a3(tl ? w(8) : w(7), w(7), w(6)) : j == 0 ? (w(1) + 3 * w(0) + 2) >> 2 : hp_a3(w(j + 1), w(j), w(j - 1));
     }
     if (j == 8)
-        return (need & 4) ? hp_a3(w[7], w[8], w[9]) : 0;
+        return (need & 4) ? hp_a3(w(7), w(8), w(9)) : 0;
     if (j < 17) {
         if (!(need & 2))
             return 0;
-        return j == 9 ? hp_a3(tl ? w[8] : w[9], w[9], w[10]) : j == 16 ? hp_a3(tr ? w[17] : w[16], w[16], w[15]) : hp_a3(w[j - 1], w[j], w[j + 1]);
+        return j == 9 ? hp_a3(tl ? w(8) : w(9), w(9), w(10)) : j == 16 ? hp_a3(tr ? w(17) : w(16), w(16), w(15)) : hp_a3(w(j - 1), w(j), w(j + 1));
     }
     if (!(need & 8))
         return 0;
-    return !tr ? w[16] : j == 24 ? (w[23] + 3 * w[24] + 2) >> 2 : hp_a3(w[j - 1], w[j], w[j + 1]);
+    return !tr ? w(16) : j == 24 ? (w(23) + 3 * w(24) + 2) >> 2 : hp_a3(w(j - 1), w(j), w(j + 1));
+}
+
+IMB_FN int hp_filter8(const int *w, int j, unsigned need, bool tl, bool tr)
+{
+    return hp_filter8_e(HpArr{ w }, j, need, tl, tr);
 }
 
 /* ---- the tile ---- */
 struct ImbTile {
     uint8_t y[17 * 32];    /* luma:   sample (r, c), r = -1..15, c = -4..27, at [(r + 1) * 32 + c + 4] */
     uint8_t c[2][9 * 16];  /* chroma: sample (r, c), r = -1..7,  c = -4..11, at [(r + 1) * 16 + c + 4] */
-    int e[28], ef[28];     /* a block's edge line, raw and low-pass filtered (pred8x8l) */
-    int t8[64];            /* first pass of an 8x8 inverse transform */
+    int t8[4][64];         /* first pass of the four 8x8 inverse transforms */
     int dcq[16];           /* luma_dc_dequant_idct's results by block */
 };
 
@@ -276,7 +301,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
         return;
     }
     /* ---- chroma: pred8x8 on both planes, then chroma_dc_dequant_idct + idct_add8 when cbp & 0x30; lane = 4 samples of a row.
-     *      Intra16x16 also dequantises its 16 luma DCs here (lanes 32..47) ---- */
+     *      Intra16x16 also dequantises its 16 luma DCs here (lanes 32..47), the 8x8 transform runs its first pass (lanes 32..63) ---- */
     x.run([&](int lane) {
         if (lane < 32) {
             const int p = lane >> 4, yy = (lane >> 1) & 7, x0 = 4 * (lane & 1);
@@ -315,6 +340,24 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
                 else if (dconly)
                     v = imb_clip_u8(v + ((dc + 32) >> 6));
                 T.c[p][imb_ci(yy, x0 + j)] = (uint8_t)v;
+            }
+        } else if (R.type == FFHIP_H264_INTRA_8x8) {
+            /* first pass of the four 8x8 inverse transforms (they depend on the coefficients alone): lane 32 + 8 q + j = transform j
+             * of block 4 q, working on block[j + 8 k], results stored as int16 */
+            const int q = (lane - 32) >> 3, j = lane & 7, nnz = R.nnz[4 * q];
+            const int16_t *b = nnz ? imb_block(R, coefs, 4 * q) : nullptr;
+            if (b && !(nnz == 1 && b[0])) {
+                int in[8];
+                uint32_t out[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    in[k] = b[j + 8 * k];
+                if (j == 0)
+                    in[0] = (int16_t)(in[0] + 32);
+                imb_idct8_1d(in, out);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    T.t8[q][j + 8 * k] = (int16_t)out[k];
             }
         } else if (lane < 48 && R.type == FFHIP_H264_INTRA_16x16 && (R.flags & FFHIP_H264_INTRA_LUMA_DC)) {
             /* luma_dc_dequant_idct (h264idct_template.c:259-293): lane 32 + o computes output o of the 4x4 Hadamard */
@@ -357,44 +400,46 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
     }
 
     if (R.type == FFHIP_H264_INTRA_4x4) {
-        for (int i = 0; i < 16; i++) {
-            const int bx = imb_bx(i), by = imb_by(i), mode = R.pred4[i];
-            /* the block's edge line; top-right: the samples themselves or, when the block there is not decoded yet / outside,
-             * the last sample of the row above four times (hl_decode_mb_predict_luma, h264_mb.c:672-689) */
-            const bool tr_avail = (R.topright_avail << i) & 0x8000;
+        /* A 4x4 block reads its left, upper-left, upper and — where the decoding order has it — upper-right neighbours, so the blocks
+         * on an anti-diagonal x + 2 y = t of the 4 x 4 grid are independent: ten steps of one or two blocks instead of sixteen
+         * (results cannot differ: each block sees exactly the samples it sees in block order).  A step is ONE phase: a lane reads
+         * the edge samples its rule needs straight from the tile (they lie outside the blocks written in this step) and adds its
+         * own sample of the residual. */
+        for (int t = 0; t < 10; t++) {
             x.run([&](int lane) {
-                if (lane < 13) {
-                    int v;
-                    if (lane < 4)
-                        v = T.y[imb_yi(by + 3 - lane, bx - 1)];
-                    else if (lane < 9)
-                        v = T.y[imb_yi(by - 1, bx + lane - 5)];
+                if (lane >= 32)
+                    return;
+                const int y0 = t <= 3 ? 0 : (t - 2) >> 1, y4 = y0 + (lane >> 4), x4 = t - 2 * y4;
+                if (y4 > 3 || x4 < 0 || x4 > 3)
+                    return;
+                const int i = (x4 & 1) | (y4 & 1) << 1 | (x4 >> 1) << 2 | (y4 >> 1) << 3;
+                const int bx = 4 * x4, by = 4 * y4, mode = R.pred4[i];
+                /* top-right: the samples themselves or, when the block there is not decoded yet / outside, the last sample of the
+                 * row above four times (hl_decode_mb_predict_luma, h264_mb.c:672-689) */
+                const bool tr_avail = (R.topright_avail << i) & 0x8000;
+                auto e = [&](int k) {
+                    const int r = k < 4 ? by + 3 - k : by - 1, c = k < 4 ? bx - 1 : (k < 9 || tr_avail) ? bx + k - 5 : bx + 3;
+                    return (int)T.y[imb_yi(r, c)];
+                };
+                const int xx = lane & 3, yy = (lane >> 2) & 3;
+                int v = hp_dir_sample_e<4>(mode, e, xx, yy, hp_dir_dc_e<4>(mode, e));
+                const int nnz = R.nnz[i];
+                if (nnz) {
+                    const int16_t *b = imb_block(R, coefs, i);
+                    const int dc = b ? b[0] : 0;
+                    if (nnz == 1 && dc)
+                        v = imb_clip_u8(v + ((dc + 32) >> 6));
                     else
-                        v = T.y[imb_yi(by - 1, tr_avail ? bx + lane - 5 : bx + 3)];
-                    T.e[lane] = v;
+                        v = imb_clip_u8(v + imb_idct4_at(b, dc, xx, yy));
                 }
-            });
-            x.run([&](int lane) {
-                if (lane < 16) {
-                    const int xx = lane & 3, yy = lane >> 2;
-                    int v = hp_dir_sample<4>(mode, T.e, xx, yy, hp_dir_dc<4>(mode, T.e));
-                    const int nnz = R.nnz[i];
-                    if (nnz) {
-                        const int16_t *b = imb_block(R, coefs, i);
-                        const int dc = b ? b[0] : 0;
-                        if (nnz == 1 && dc)
-                            v = imb_clip_u8(v + ((dc + 32) >> 6));
-                        else
-                            v = imb_clip_u8(v + imb_idct4_at(b, dc, xx, yy));
-                    }
-                    T.y[imb_yi(by + yy, bx + xx)] = (uint8_t)v;
-                }
+                T.y[imb_yi(by + yy, bx + xx)] = (uint8_t)v;
             });
         }
         return;
     }
 
-    /* Intra4x4 with the 8x8 transform: pred8x8l over the filtered edge line, idct8_add / idct8_dc_add */
+    /* Intra4x4 with the 8x8 transform: pred8x8l over the low-pass filtered edge line (evaluated where it is read, from the raw
+     * samples in the tile), idct8_add's second pass / idct8_dc_add: one phase per block */
     for (int i = 0; i < 16; i += 4) {
         const int bx = imb_bx(i), by = imb_by(i), mode = R.pred4[i], nnz = R.nnz[i];
         const bool tl = (R.topleft_avail << i) & 0x8000, tr = (R.topright_avail << i) & 0x4000;
@@ -403,43 +448,17 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
         const int dc = b ? b[0] : 0;
         const bool dconly = nnz == 1 && dc, full = nnz && !dconly;
         x.run([&](int lane) {
-            if (lane < 25) {
-                int v;
-                if (lane < 8)
-                    v = T.y[imb_yi(by + 7 - lane, bx - 1)];
-                else
-                    v = T.y[imb_yi(by - 1, bx + lane - 9)];
-                T.e[lane] = v;
-            } else if (lane >= 32 && lane < 40 && full) {
-                /* first pass of the inverse transform: transform j works on block[j + 8 k], results stored as int16 */
-                const int j = lane - 32;
-                int in[8];
-                uint32_t out[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    in[k] = b ? b[j + 8 * k] : 0;
-                if (j == 0)
-                    in[0] = (int16_t)(in[0] + 32);
-                imb_idct8_1d(in, out);
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    T.t8[j + 8 * k] = (int16_t)out[k];
-            }
-        });
-        x.run([&](int lane) {
-            if (lane < 25)
-                T.ef[lane] = hp_filter8(T.e, lane, need, tl, tr);
-        });
-        x.run([&](int lane) {
+            auto w = [&](int k) { return (int)T.y[k < 8 ? imb_yi(by + 7 - k, bx - 1) : imb_yi(by - 1, bx + k - 9)]; };
+            auto ef = [&](int k) { return hp_filter8_e(w, k, need, tl, tr); };
             const int xx = lane & 7, yy = lane >> 3;
-            int v = hp_dir_sample<8>(mode, T.ef, xx, yy, hp_dir_dc<8>(mode, T.ef));
+            int v = hp_dir_sample_e<8>(mode, ef, xx, yy, hp_dir_dc_e<8>(mode, ef));
             if (full) {
                 /* second pass: transform xx works on block[8 xx + k], output yy goes to dst[xx + yy * stride] */
                 int in[8];
                 uint32_t out[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++)
-                    in[k] = T.t8[8 * xx + k];
+                    in[k] = T.t8[i >> 2][8 * xx + k];
                 imb_idct8_1d(in, out);
                 uint32_t o = out[0];
 #pragma unroll
