@@ -610,25 +610,38 @@ __device__ __forceinline__ int hv_abs(int v) { return v < 0 ? -v : v; }
 /* PIX = uint8_t (bd 8) / uint16_t: beta and tc arrive in 8-bit units and are scaled as the reference's templates scale them
  * (beta <<= BIT_DEPTH - 8, tc = _tc[j] << (BIT_DEPTH - 8): hevc/dsp_template.c:845,862,907); stride and offsets in bytes */
 template <typename PIX>
-__global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, int bd)
+__device__ __forceinline__ void hevc_lf_lines(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, int e, int lane_, int bd)
 {
+    constexpr int PS = (int)sizeof(PIX);
     const int maxv = (1 << bd) - 1;
     auto clipp = [&](int v) { return min(max(v, 0), maxv); };
-    const int e = (blockIdx.x * 256 + threadIdx.x) >> 3;
-    const int line = threadIdx.x & 7, j = line >> 2, d = line & 3;
+    const int line = lane_ & 7, j = line >> 2;
     const bool live = e < n;
     const FFHipHevcEdge ed = edges[live ? e : 0];
     const bool vertical = ed.kind & 1, chroma = ed.kind & 2;
     const ptrdiff_t st = stride / (ptrdiff_t)sizeof(PIX), xs = vertical ? 1 : st, ys = vertical ? st : 1;
     PIX *pix = reinterpret_cast<PIX *>(base + ed.offset) + (ptrdiff_t)line * ys;
     const int tc = ed.tc[j] << (bd - 8), no_p = ed.no_p[j], no_q = ed.no_q[j], beta = ed.beta << (bd - 8);
-    int p3 = 0, p2 = 0, p1 = 0, p0 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    if (live) {
-        p1 = pix[-2 * xs]; p0 = pix[-xs]; q0 = pix[0]; q1 = pix[xs];
+    /* a vertical edge's line is 8 contiguous samples p3 .. q3: two dwords (two 8-byte words at 16 bits) when p3 is so aligned */
+    const bool wide = live && vertical && !chroma && !(reinterpret_cast<uintptr_t>(pix - 4) & (PS == 1 ? 3 : 7));
+    int v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; /* p3 p2 p1 p0 q0 q1 q2 q3 */
+    if (wide) {
+        if constexpr (PS == 1) {
+            const uint32_t a = reinterpret_cast<const uint32_t *>(pix - 4)[0], c = reinterpret_cast<const uint32_t *>(pix - 4)[1];
+            v[0] = a & 255; v[1] = (a >> 8) & 255; v[2] = (a >> 16) & 255; v[3] = a >> 24;
+            v[4] = c & 255; v[5] = (c >> 8) & 255; v[6] = (c >> 16) & 255; v[7] = c >> 24;
+        } else {
+            const uint2 a = reinterpret_cast<const uint2 *>(pix - 4)[0], c = reinterpret_cast<const uint2 *>(pix - 4)[1];
+            v[0] = a.x & 0xFFFF; v[1] = a.x >> 16; v[2] = a.y & 0xFFFF; v[3] = a.y >> 16;
+            v[4] = c.x & 0xFFFF; v[5] = c.x >> 16; v[6] = c.y & 0xFFFF; v[7] = c.y >> 16;
+        }
+    } else if (live) {
+        v[2] = pix[-2 * xs]; v[3] = pix[-xs]; v[4] = pix[0]; v[5] = pix[xs];
         if (!chroma) {
-            p3 = pix[-4 * xs]; p2 = pix[-3 * xs]; q2 = pix[2 * xs]; q3 = pix[3 * xs];
+            v[0] = pix[-4 * xs]; v[1] = pix[-3 * xs]; v[6] = pix[2 * xs]; v[7] = pix[3 * xs];
         }
     }
+    const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
     if (chroma) {
         if (live && tc > 0) {
             const int delta = clip3((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
@@ -640,27 +653,29 @@ __global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff
     /* decisions of my group from its lines 0 and 3 (all 64 lanes take part in the shuffles) */
     const int dp = hv_abs(p2 - 2 * p1 + p0), dq = hv_abs(q2 - 2 * q1 + q0);
     const int flat = hv_abs(p3 - p0) + hv_abs(q3 - q0), step = hv_abs(p0 - q0);
-    const int l0 = (threadIdx.x & 63) & ~3, l3 = l0 + 3;
+    const int l0 = (lane_ & 63) & ~3, l3 = l0 + 3;
     const int dp0 = __shfl(dp, l0, 64), dp3 = __shfl(dp, l3, 64), dq0 = __shfl(dq, l0, 64), dq3 = __shfl(dq, l3, 64);
     const int flat0 = __shfl(flat, l0, 64), flat3 = __shfl(flat, l3, 64), step0 = __shfl(step, l0, 64), step3 = __shfl(step, l3, 64);
-    (void)d;
     if (!live)
         return;
     const int d0 = dp0 + dq0, d3 = dp3 + dq3;
     if (d0 + d3 >= beta)
         return;
+    unsigned ch = 0; /* bit k: v[k] changed */
     const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
     if (flat0 < beta_3 && step0 < tc25 && flat3 < beta_3 && step3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
         const int t = tc << 1;
         if (!no_p) {
-            pix[-xs]     = (PIX)(p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -t, t));
-            pix[-2 * xs] = (PIX)(p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -t, t));
-            pix[-3 * xs] = (PIX)(p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -t, t));
+            v[3] = p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -t, t);
+            v[2] = p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -t, t);
+            v[1] = p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -t, t);
+            ch |= 0x0E;
         }
         if (!no_q) {
-            pix[0]      = (PIX)(q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -t, t));
-            pix[xs]     = (PIX)(q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -t, t));
-            pix[2 * xs] = (PIX)(q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -t, t));
+            v[4] = q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -t, t);
+            v[5] = q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -t, t);
+            v[6] = q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -t, t);
+            ch |= 0x70;
         }
     } else {
         const int side = (beta + (beta >> 1)) >> 3;
@@ -668,14 +683,159 @@ __global__ __launch_bounds__(256) void k_hevc_loop_filter(uint8_t *base, ptrdiff
         int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
         if (hv_abs(delta) < 10 * tc) {
             delta = clip3(delta, -tc, tc);
-            if (!no_p) pix[-xs] = (PIX)clipp(p0 + delta);
-            if (!no_q) pix[0] = (PIX)clipp(q0 - delta);
-            if (!no_p && nd_p > 1)
-                pix[-2 * xs] = (PIX)clipp(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2));
-            if (!no_q && nd_q > 1)
-                pix[xs] = (PIX)clipp(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2));
+            if (!no_p) { v[3] = clipp(p0 + delta); ch |= 0x08; }
+            if (!no_q) { v[4] = clipp(q0 - delta); ch |= 0x10; }
+            if (!no_p && nd_p > 1) { v[2] = clipp(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2)); ch |= 0x04; }
+            if (!no_q && nd_q > 1) { v[5] = clipp(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2)); ch |= 0x20; }
         }
     }
+    if (!ch)
+        return;
+    if (wide) {
+        if constexpr (PS == 1) {
+            if (ch & 0x0F)
+                reinterpret_cast<uint32_t *>(pix - 4)[0] = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
+            if (ch & 0xF0)
+                reinterpret_cast<uint32_t *>(pix - 4)[1] = (uint32_t)v[4] | (uint32_t)v[5] << 8 | (uint32_t)v[6] << 16 | (uint32_t)v[7] << 24;
+        } else {
+            if (ch & 0x0F)
+                reinterpret_cast<uint2 *>(pix - 4)[0] = make_uint2((uint32_t)v[0] | (uint32_t)v[1] << 16, (uint32_t)v[2] | (uint32_t)v[3] << 16);
+            if (ch & 0xF0)
+                reinterpret_cast<uint2 *>(pix - 4)[1] = make_uint2((uint32_t)v[4] | (uint32_t)v[5] << 16, (uint32_t)v[6] | (uint32_t)v[7] << 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 1; k < 7; k++)
+            if (ch >> k & 1)
+                pix[(k - 4) * xs] = (PIX)v[k];
+    }
+}
+
+/*
+ * k_hevc_loop_filter_h — HORIZONTAL edges (the filter runs down a column, a segment's 8 lines lie side by side in a row) with a lane
+ * per 4-line group: the group's columns are one dword (8 bytes at 16 bits) of each row, so a wave moves 32 segments with dword
+ * accesses instead of 8 segments byte by byte, and a group decides from its own lines 0 and 3 without a shuffle.  The sample-per-
+ * lane kernel above stays for vertical edges and unaligned planes.  One launch serves a batch: each wave looks at its 32 records
+ * and takes this path only when all of them are horizontal (a picture's batch is all vertical, then all horizontal).
+ */
+template <typename PIX>
+__device__ __forceinline__ void hevc_lf_hgroup(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge &ed, int j, int bd)
+{
+    constexpr int PS = (int)sizeof(PIX);
+    using ROW = typename std::conditional<PS == 1, uint32_t, uint2>::type;
+    const bool chroma = ed.kind & 2;
+    const int maxv = (1 << bd) - 1;
+    auto clipp = [&](int v) { return min(max(v, 0), maxv); };
+    const int tc = ed.tc[j] << (bd - 8), no_p = ed.no_p[j], no_q = ed.no_q[j], beta = ed.beta << (bd - 8);
+    uint8_t *pix = base + ed.offset + 4 * j * PS; /* the group's first column on row q0 */
+    auto ld = [&](int r, int (&v)[4]) {
+        const ROW w = *reinterpret_cast<const ROW *>(pix + (ptrdiff_t)r * stride);
+        if constexpr (PS == 1) {
+            v[0] = w & 255; v[1] = (w >> 8) & 255; v[2] = (w >> 16) & 255; v[3] = w >> 24;
+        } else {
+            v[0] = w.x & 0xFFFF; v[1] = w.x >> 16; v[2] = w.y & 0xFFFF; v[3] = w.y >> 16;
+        }
+    };
+    auto st = [&](int r, const int (&v)[4]) {
+        ROW w;
+        if constexpr (PS == 1)
+            w = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
+        else
+            w = make_uint2((uint32_t)v[0] | (uint32_t)v[1] << 16, (uint32_t)v[2] | (uint32_t)v[3] << 16);
+        *reinterpret_cast<ROW *>(pix + (ptrdiff_t)r * stride) = w;
+    };
+    int p1[4], p0[4], q0[4], q1[4];
+    ld(-2, p1); ld(-1, p0); ld(0, q0); ld(1, q1);
+    if (chroma) {
+        if (tc <= 0)
+            return;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int delta = clip3((((q0[c] - p0[c]) * 4) + p1[c] - q1[c] + 4) >> 3, -tc, tc);
+            if (!no_p) p0[c] = clipp(p0[c] + delta);
+            if (!no_q) q0[c] = clipp(q0[c] - delta);
+        }
+        if (!no_p) st(-1, p0);
+        if (!no_q) st(0, q0);
+        return;
+    }
+    int p3[4], p2[4], q2[4], q3[4];
+    ld(-4, p3); ld(-3, p2); ld(2, q2); ld(3, q3);
+    auto dpf = [&](int c) { return hv_abs(p2[c] - 2 * p1[c] + p0[c]); };
+    auto dqf = [&](int c) { return hv_abs(q2[c] - 2 * q1[c] + q0[c]); };
+    const int dp0 = dpf(0), dp3 = dpf(3), dq0 = dqf(0), dq3 = dqf(3);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta)
+        return;
+    const int flat0 = hv_abs(p3[0] - p0[0]) + hv_abs(q3[0] - q0[0]), flat3 = hv_abs(p3[3] - p0[3]) + hv_abs(q3[3] - q0[3]);
+    const int step0 = hv_abs(p0[0] - q0[0]), step3 = hv_abs(p0[3] - q0[3]);
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    if (flat0 < beta_3 && step0 < tc25 && flat3 < beta_3 && step3 < tc25 && (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+        const int t = tc << 1;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int P3 = p3[c], P2 = p2[c], P1 = p1[c], P0 = p0[c], Q0 = q0[c], Q1 = q1[c], Q2 = q2[c], Q3 = q3[c];
+            if (!no_p) {
+                p0[c] = P0 + clip3(((P2 + 2 * P1 + 2 * P0 + 2 * Q0 + Q1 + 4) >> 3) - P0, -t, t);
+                p1[c] = P1 + clip3(((P2 + P1 + P0 + Q0 + 2) >> 2) - P1, -t, t);
+                p2[c] = P2 + clip3(((2 * P3 + 3 * P2 + P1 + P0 + Q0 + 4) >> 3) - P2, -t, t);
+            }
+            if (!no_q) {
+                q0[c] = Q0 + clip3(((P1 + 2 * P0 + 2 * Q0 + 2 * Q1 + Q2 + 4) >> 3) - Q0, -t, t);
+                q1[c] = Q1 + clip3(((P0 + Q0 + Q1 + Q2 + 2) >> 2) - Q1, -t, t);
+                q2[c] = Q2 + clip3(((2 * Q3 + 3 * Q2 + Q1 + Q0 + P0 + 4) >> 3) - Q2, -t, t);
+            }
+        }
+        if (!no_p) { st(-1, p0); st(-2, p1); st(-3, p2); }
+        if (!no_q) { st(0, q0); st(1, q1); st(2, q2); }
+    } else {
+        const int side = (beta + (beta >> 1)) >> 3;
+        const int nd_p = dp0 + dp3 < side ? 2 : 1, nd_q = dq0 + dq3 < side ? 2 : 1, tc_2 = tc >> 1;
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int P2 = p2[c], P1 = p1[c], P0 = p0[c], Q0 = q0[c], Q1 = q1[c], Q2 = q2[c];
+            int delta = (9 * (Q0 - P0) - 3 * (Q1 - P1) + 8) >> 4;
+            if (hv_abs(delta) < 10 * tc) {
+                any = true;
+                delta = clip3(delta, -tc, tc);
+                if (!no_p) p0[c] = clipp(P0 + delta);
+                if (!no_q) q0[c] = clipp(Q0 - delta);
+                if (!no_p && nd_p > 1)
+                    p1[c] = clipp(P1 + clip3((((P2 + P0 + 1) >> 1) - P1 + delta) >> 1, -tc_2, tc_2));
+                if (!no_q && nd_q > 1)
+                    q1[c] = clipp(Q1 + clip3((((Q2 + Q0 + 1) >> 1) - Q1 - delta) >> 1, -tc_2, tc_2));
+            }
+        }
+        if (any) {
+            if (!no_p) { st(-1, p0); if (nd_p > 1) st(-2, p1); }
+            if (!no_q) { st(0, q0); if (nd_q > 1) st(1, q1); }
+        }
+    }
+}
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void k_hevc_loop_filter_w(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, int bd)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)), lane = threadIdx.x & 63;
+    const int e0 = wave * 32;
+    if (e0 >= n)
+        return;
+    /* horizontal everywhere in my 32 records (and rows that take dword / 8-byte accesses)? */
+    const int e = e0 + (lane >> 1);
+    const bool live = e < n;
+    FFHipHevcEdge ed = {};
+    if (live)
+        ed = edges[e];
+    const bool ok = !live || (!(ed.kind & 1) && !((reinterpret_cast<uintptr_t>(base) + (size_t)ed.offset) & (sizeof(PIX) == 1 ? 3 : 7)));
+    if (__builtin_amdgcn_read_exec() == __ballot(ok) && !((size_t)stride & (sizeof(PIX) == 1 ? 3 : 7))) {
+        if (live)
+            hevc_lf_hgroup<PIX>(base, stride, ed, lane & 1, bd);
+        return;
+    }
+    /* otherwise: the sample-per-lane rules, 8 records at a time */
+    for (int r = 0; r < 4; r++)
+        hevc_lf_lines<PIX>(base, stride, edges, n, e0 + 8 * r + (lane >> 3), lane, bd);
 }
 
 int ffhip_launch_hevc_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipHevcEdge *edges, int n, hipStream_t stream)
@@ -688,9 +848,9 @@ int ffhip_launch_hevc_loop_filter_bd(int bd, uint8_t *base, ptrdiff_t stride, co
     if (n <= 0)
         return 0;
     if (bd == 8)
-        hipLaunchKernelGGL(k_hevc_loop_filter<uint8_t>, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n, 8);
+        hipLaunchKernelGGL(k_hevc_loop_filter_w<uint8_t>, dim3(cdiv(n, 128)), dim3(256), 0, stream, base, stride, edges, n, 8);
     else if ((bd == 10 || bd == 12) && !(((uintptr_t)base | (size_t)stride) & 1))
-        hipLaunchKernelGGL(k_hevc_loop_filter<uint16_t>, dim3(cdiv(n, 32)), dim3(256), 0, stream, base, stride, edges, n, bd);
+        hipLaunchKernelGGL(k_hevc_loop_filter_w<uint16_t>, dim3(cdiv(n, 128)), dim3(256), 0, stream, base, stride, edges, n, bd);
     else {
         ffhip_set_error("ffhip_hevc_loop_filter: bit depth %d (8, 10, 12) / 16-bit planes must be 2-byte aligned", bd);
         return FFHIP_EINVAL;
