@@ -75,6 +75,40 @@ class AacImdct:
                                                                     None if stream is None else C.c_void_p(stream)), "ffhip_aac_update_ltp_batch_dev")
 
 
+class AacLd:
+    """AACDecDSP.imdct_and_windowing_ld (eld=False: windows = (ff_sine_512, ff_sine_128)) / _eld (eld=True: windows =
+    (ff_aac_eld_window_512 or _480,), frame_len 512 / 480) on device-resident frames"""
+
+    def __init__(self, windows, eld=False, frame_len=512, scale=None):
+        w = [np.ascontiguousarray(x, np.float32) for x in windows]
+        scale = (1.0 / frame_len) / 32768.0 if scale is None else scale
+        self.frame_len, self.eld = frame_len, eld
+        self._c = _lib.vp()
+        _lib.check(_lib.lib().ffhip_aac_ld_create(C.byref(self._c), int(eld), frame_len, w[0].ctypes.data, None if eld else w[1].ctypes.data, scale),
+                   "ffhip_aac_ld_create")
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c and _lib is not None:
+            _lib.lib().ffhip_aac_ld_free(C.byref(self._c))
+        self._c = None
+
+    __del__ = close
+
+    def batch(self, coeffs, out, saved, kb_prev=None, stream=None):
+        """coeffs / out: float32 cuda [nframes, nch, 1024]; saved: [nch, 256] (LD) / [nch, 3 * frame_len] (ELD); kb_prev (LD): host
+        uint8 [nframes, nch]"""
+        import torch
+        nframes, nch = coeffs.shape[0], coeffs.shape[1]
+        kp = None
+        if not self.eld:
+            kb = np.ascontiguousarray(kb_prev, np.uint8).reshape(nframes * nch)
+            kp = kb.ctypes.data
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        return _lib.check(_lib.lib().ffhip_aac_ld_batch_dev(self._c, coeffs.data_ptr(), out.data_ptr(), saved.data_ptr(), kp, nch, nframes, stream),
+                          "ffhip_aac_ld_batch_dev")
+
+
 #: FFHipAacBandOp / FFHipAacLtp (include/ffhip.h)
 BAND_OP_DTYPE = np.dtype([("frame0", np.int32), ("frame1", np.int32), ("start", np.int16), ("len", np.int16), ("scale", np.float32),
                           ("kind", np.uint8), ("pad", np.uint8, 3)])

@@ -735,3 +735,209 @@ extern "C" int ffhip_aac_update_ltp_batch_dev(FFHipAacImdct *c, float *ltp_state
     LAUNCH_CHECK();
     return 0;
 }
+
+
+/* ---- AAC-LD / AAC-ELD: AACDecDSP.imdct_and_windowing_ld / _eld (aacdec_dsp_template.c:516-602), float ------------------------------
+ * One transform size per stream and no window sequences.  As with the 1024-sample member, what a frame leaves behind depends on
+ * that frame's inverse MDCT alone (LD: its upper half; ELD: the whole of it, kept for three frames), so a run of frames is an MDCT
+ * batch and one windowing pass over all frames; frames before the run come from the caller's `saved`. */
+struct FFHipAacLd {
+    FFHipTXContext *tx = nullptr;
+    int eld = 0, n = 512;
+    float *win = nullptr;     /* LD: sine_512 then sine_128; ELD: the 3.75 n window */
+    float *work = nullptr;    /* buf [frames][n], ELD: + shuffled coefficients [frames][n], + new saved [nch][3 n] */
+    uint8_t *info = nullptr;  /* LD: use_kb_window[1] per frame */
+    size_t work_floats = 0, info_bytes = 0;
+    std::mutex mu;
+};
+
+extern "C" void ffhip_aac_ld_free(FFHipAacLd **pc)
+{
+    if (!pc || !*pc)
+        return;
+    FFHipAacLd *c = *pc;
+    ffhip_tx_uninit(&c->tx);
+    if (c->win) (void)hipFree(c->win);
+    if (c->work) (void)hipFree(c->work);
+    if (c->info) (void)hipFree(c->info);
+    delete c;
+    *pc = nullptr;
+}
+
+extern "C" int ffhip_aac_ld_create(FFHipAacLd **pc, int eld, int frame_len, const float *w0, const float *w1, float scale)
+{
+    if (!pc || !w0 || (!eld && !w1))
+        return FFHIP_EINVAL;
+    *pc = nullptr;
+    if (!(frame_len == 512 || (eld && frame_len == 480))) {
+        ffhip_set_error("ffhip_aac_ld_create: frame length %d (LD: 512; ELD: 512, 480)", frame_len);
+        return FFHIP_EINVAL;
+    }
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    FFHipAacLd *c = new (std::nothrow) FFHipAacLd();
+    if (!c)
+        return FFHIP_ENOMEM;
+    c->eld = !!eld;
+    c->n = frame_len;
+    int r = ffhip_tx_init(&c->tx, nullptr, FFHIP_TX_FLOAT_MDCT, 1, frame_len, &scale, 0);
+    const size_t nw = eld ? (size_t)frame_len * 15 / 4 : 512 + 128;
+    std::vector<float> w(nw);
+    if (eld) {
+        memcpy(w.data(), w0, nw * sizeof(float));
+    } else {
+        memcpy(w.data(), w0, 512 * sizeof(float));
+        memcpy(w.data() + 512, w1, 128 * sizeof(float));
+    }
+    if (r >= 0 && (hipMalloc(&c->win, nw * sizeof(float)) != hipSuccess ||
+                   hipMemcpy(c->win, w.data(), nw * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)) {
+        ffhip_set_error("ffhip_aac_ld_create: window upload failed");
+        r = FFHIP_ENOMEM;
+    }
+    if (r < 0) {
+        ffhip_aac_ld_free(&c);
+        return r;
+    }
+    *pc = c;
+    return 0;
+}
+
+/* LD: one thread = 4 samples of a frame's 512 */
+__global__ __launch_bounds__(128) void k_aac_ld_out(const float *buf, const uint8_t *kbp, const float *win, const float *saved, int nch, float *out)
+{
+    const int f = blockIdx.x, o = 4 * threadIdx.x;
+    const float *b = buf + (size_t)f * 512;
+    const float *sv = f < nch ? saved + (size_t)f * 256 : buf + (size_t)(f - nch) * 512 + 256;
+    float4 v;
+    if (!kbp[f])
+        v = aac_wov4(sv, b, win, 256, o);
+    else if (o < 192)
+        v = aac_ld4(sv + o);
+    else if (o < 320)
+        v = aac_wov4(sv + 192, b, win + 512, 64, o - 192); /* the low-overlap window: sine_128 across the middle */
+    else
+        v = aac_ld4(b + o - 256);
+    *reinterpret_cast<float4 *>(out + (size_t)f * 1024 + o) = v;
+}
+
+/* ELD: the coefficient shuffle in front of the transform is new[k] = (k even ? -1 : +1) * old[n - 1 - k] (the reference's four
+ * in-place swaps, aacdec_dsp_template.c:561-565, written out per element) */
+__global__ __launch_bounds__(512) void k_aac_eld_shuffle(const float *coeffs, float *shuf, int n)
+{
+    const int f = blockIdx.x, k = threadIdx.x;
+    if (k >= n)
+        return;
+    const float v = coeffs[(size_t)f * 1024 + n - 1 - k];
+    shuf[(size_t)f * n + k] = (k & 1) ? v : -v;
+}
+
+/* history sample j of the frame `back` frames before frame f of its channel (back = 0: this frame), signs as the reference leaves
+ * them in buf (-, +, -, +, ...): from the batch's transforms, or from the caller's saved (newest first) before the batch */
+__device__ __forceinline__ float eld_hist(const float *buf, const float *saved, int n, int nch, int f, int back, int j)
+{
+    const int t = f / nch, ch = f - t * nch;
+    if (t - back >= 0) {
+        const float v = buf[(size_t)(f - back * nch) * n + j];
+        return (j & 1) ? v : -v;
+    }
+    return saved[(size_t)ch * 3 * n + (size_t)(back - t - 1) * n + j];
+}
+
+__global__ __launch_bounds__(512) void k_aac_eld_out(const float *buf, const float *saved, const float *w, int n, int nch, float *out)
+{
+    const int f = blockIdx.x, o = threadIdx.x;
+    if (o >= n)
+        return;
+    const int n2 = n >> 1, n4 = n >> 2;
+    auto B = [&](int j) { return eld_hist(buf, saved, n, nch, f, 0, j); };
+    auto S = [&](int idx) { return eld_hist(buf, saved, n, nch, f, 1 + idx / n, idx % n); }; /* the reference's saved[idx] */
+    float v;
+    if (o < n4) {
+        const int i = o + n4;
+        v = B(n2 - 1 - i) * w[i - n4] + S(i + n2) * w[i + n - n4] + -S(n + n2 - 1 - i) * w[i + 2 * n - n4] + -S(2 * n + n2 + i) * w[i + 3 * n - n4];
+    } else if (o < n4 + n2) {
+        const int i = o - n4;
+        v = B(i) * w[i + n2 - n4] + -S(n - 1 - i) * w[i + n2 + n - n4] + -S(n + i) * w[i + n2 + 2 * n - n4] + S(2 * n + n - 1 - i) * w[i + n2 + 3 * n - n4];
+    } else {
+        const int i = o - n2 - n4;
+        v = B(i + n2) * w[i + n - n4] + -S(n2 - 1 - i) * w[i + 2 * n - n4] + -S(n + n2 + i) * w[i + 3 * n - n4];
+    }
+    out[(size_t)f * 1024 + o] = v;
+}
+
+/* the history the batch leaves behind: slot k (newest first) = the frame k + 1 before the end */
+__global__ __launch_bounds__(512) void k_aac_eld_save(const float *buf, const float *saved, int n, int nch, int nframes, float *nsaved)
+{
+    const int ch = blockIdx.x, k = blockIdx.y, j = threadIdx.x;
+    if (j >= n)
+        return;
+    /* as seen from a (virtual) frame at time nframes: back = k + 1 */
+    nsaved[(size_t)ch * 3 * n + (size_t)k * n + j] = eld_hist(buf, saved, n, nch, nframes * nch + ch, k + 1, j);
+}
+
+extern "C" int ffhip_aac_ld_batch_dev(FFHipAacLd *c, const float *coeffs, float *out, float *saved, const uint8_t *kb_prev, int nch, int nframes,
+                                      void *stream)
+{
+    if (!c || !coeffs || !out || !saved || nch <= 0 || nframes < 0 || (!c->eld && !kb_prev))
+        return FFHIP_EINVAL;
+    const size_t nf = (size_t)nch * nframes;
+    if (!nf)
+        return 0;
+    if (((uintptr_t)coeffs | (uintptr_t)out | (uintptr_t)saved) & 15) {
+        ffhip_set_error("ffhip_aac_ld: coeffs, out and saved must be 16-byte aligned");
+        return FFHIP_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipStream_t st = (hipStream_t)stream;
+    const int n = c->n;
+    const size_t need = nf * n * (c->eld ? 2 : 1) + (c->eld ? (size_t)nch * 3 * n : 0);
+    if (need > c->work_floats) {
+        if (c->work) {
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(c->work);
+        }
+        c->work = nullptr;
+        c->work_floats = 0;
+        if (hipMalloc(&c->work, need * sizeof(float)) != hipSuccess) {
+            ffhip_set_error("ffhip_aac_ld: %zu bytes of work space not available", need * sizeof(float));
+            return FFHIP_ENOMEM;
+        }
+        c->work_floats = need;
+    }
+    float *buf = c->work;
+    if (!c->eld) {
+        if (nf > c->info_bytes) {
+            if (c->info) {
+                (void)hipStreamSynchronize(st);
+                (void)hipFree(c->info);
+            }
+            c->info = nullptr;
+            c->info_bytes = 0;
+            if (hipMalloc(&c->info, nf) != hipSuccess)
+                return FFHIP_ENOMEM;
+            c->info_bytes = nf;
+        }
+        if (hipMemcpyAsync(c->info, kb_prev, nf, hipMemcpyHostToDevice, st) != hipSuccess)
+            return FFHIP_EINVAL;
+        const int r = ffhip_tx_batch_dev(c->tx, buf, 2048, coeffs, 4096, sizeof(float), (int)nf, stream);
+        if (r < 0)
+            return r;
+        hipLaunchKernelGGL(k_aac_ld_out, dim3((unsigned)nf), dim3(128), 0, st, buf, c->info, c->win, saved, nch, out);
+        LAUNCH_CHECK();
+        if (hipMemcpy2DAsync(saved, 256 * sizeof(float), buf + (nf - nch) * 512 + 256, 512 * sizeof(float), 256 * sizeof(float), (size_t)nch,
+                             hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return FFHIP_EINVAL;
+        return 0;
+    }
+    float *shuf = buf + nf * n, *nsaved = shuf + nf * n;
+    hipLaunchKernelGGL(k_aac_eld_shuffle, dim3((unsigned)nf), dim3(512), 0, st, coeffs, shuf, n);
+    const int r = ffhip_tx_batch_dev(c->tx, buf, (size_t)n * 4, shuf, (size_t)n * 4, sizeof(float), (int)nf, stream);
+    if (r < 0)
+        return r;
+    hipLaunchKernelGGL(k_aac_eld_out, dim3((unsigned)nf), dim3(512), 0, st, buf, saved, c->win, n, nch, out);
+    hipLaunchKernelGGL(k_aac_eld_save, dim3(nch, 3), dim3(512), 0, st, buf, saved, n, nch, nframes, nsaved);
+    LAUNCH_CHECK();
+    if (hipMemcpyAsync(saved, nsaved, (size_t)nch * 3 * n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return FFHIP_EINVAL;
+    return 0;
+}

@@ -564,6 +564,19 @@ int ffhip_aac_tns_filters(FFHipAacTnsFilter *out, int frame, const int n_filt[8]
  *  filters of a frame cover disjoint ranges, so all of them run concurrently. */
 int ffhip_aac_apply_tns_batch_dev(float *coeffs, const FFHipAacTnsFilter *filters, int nfilters, int decode, void *stream);
 
+/** AAC-LD and AAC-ELD: AACDecDSP.imdct_and_windowing_ld / _eld (aacdec_dsp_template.c:516-602), float.  eld == 0: 512-sample frames,
+ *  w0 = ff_sine_512, w1 = ff_sine_128, scale = mdct512's ((1.0 / 512) / 32768, aacdec.c:1282).  eld != 0: frame_len 512 or 480, w0 =
+ *  ff_aac_eld_window_512 / _480 (1920 / 1800 floats, libavcodec/aactab.h:61-63), w1 unused, scale that of mdct512 / mdct480.
+ *  Batch: nframes consecutive frames of nch channels, frame-major, device pointers: coeffs / out rows of 1024 floats (the first
+ *  frame_len used; the reference's ELD member shuffles sce->coeffs in place — this one leaves them alone), saved [nch][256] (LD) or
+ *  [nch][3 * frame_len] (ELD: the three previous frames, newest first) in and out; kb_prev (LD only, HOST array [nframes][nch]) =
+ *  ics->use_kb_window[1] of each frame, which selects the low-overlap window.  Asynchronous on `stream`. */
+typedef struct FFHipAacLd FFHipAacLd;
+int  ffhip_aac_ld_create(FFHipAacLd **c, int eld, int frame_len, const float *w0, const float *w1, float scale);
+void ffhip_aac_ld_free(FFHipAacLd **c);
+int  ffhip_aac_ld_batch_dev(FFHipAacLd *c, const float *coeffs, float *out, float *saved, const uint8_t *kb_prev, int nch, int nframes,
+                            void *stream);
+
 /** AACDecDSP.apply_mid_side_stereo / apply_intensity_stereo (aacdec_dsp_template.c:83-160), float, and the band-wise add that ends
  *  apply_ltp (:276-280): one record per range of coefficients.  The host walks (window groups, scalefactor bands, band types, the
  *  M/S mask — the fields decode_cpe / decode_ics leave in ChannelElement / IndividualChannelStream) produce the records; the ranges

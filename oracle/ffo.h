@@ -223,6 +223,9 @@ void ffo_aac_update_ltp(const float *const windows[4], float *ltp_state, const f
 void ffo_aac_sine_window(float *w, int n);
 void ffo_aac_kbd_window(float *w, float alpha, int n);
 /* windows[]: sine_1024, sine_128, kbd_long_1024, kbd_short_128; seq / kb = { this frame, previous frame }; saved[512] in / out */
+void ffo_aac_imdct_and_windowing_ld(const FfoTx *mdct512, const float *sine_512, const float *sine_128, const float *coeffs, int kb_prev,
+                                    float *saved, float *out);
+void ffo_aac_imdct_and_windowing_eld(int n, const FfoTx *mdct, const float *window, const float *coeffs, float *saved, float *out);
 void ffo_aac_imdct_and_windowing_len(int L, int in_short_stride, const FfoTx *mdct_long, const FfoTx *mdct_short, const float *const windows[4],
                                      const float *coeffs, const int seq[2], const int kb[2], float *saved, float *out);
 void ffo_aac_imdct_and_windowing(const FfoTx *mdct1024, const FfoTx *mdct128, const float *const windows[4], const float *coeffs,

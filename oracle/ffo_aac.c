@@ -282,3 +282,51 @@ void ffo_aac_update_ltp(const float *const windows[4], float *ltp_state, const f
     memcpy(ltp_state + 1024, output, 1024 * sizeof(float));
     memcpy(ltp_state + 2048, saved_ltp, 1024 * sizeof(float));
 }
+
+/* AACDecDSP.imdct_and_windowing_ld (aacdec_dsp_template.c:516-541): one 512-point inverse MDCT per frame, the overlap under
+ * sine_512 or — when the PREVIOUS frame asked for it — the low-overlap window (sine_128 in the middle); saved holds 256, out 512 */
+void ffo_aac_imdct_and_windowing_ld(const FfoTx *mdct512, const float *sine_512, const float *sine_128, const float *coeffs, int kb_prev,
+                                    float *saved, float *out)
+{
+    float buf[512];
+    ffo_mdct_run(mdct512, buf, coeffs, sizeof(float));
+    if (kb_prev) {
+        memcpy(out, saved, 192 * sizeof(float));
+        window_overlap(out + 192, saved + 192, buf, sine_128, 64);
+        memcpy(out + 320, buf + 64, 192 * sizeof(float));
+    } else {
+        window_overlap(out, saved, buf, sine_512, 256);
+    }
+    memcpy(saved, buf + 256, 256 * sizeof(float));
+}
+
+/* AACDecDSP.imdct_and_windowing_eld (aacdec_dsp_template.c:543-602), n = 512 or 480: the coefficient shuffle that maps the ELD
+ * filterbank onto a conventional inverse MDCT, sign flips, four-term window sums over the history of three frames (saved[3 n],
+ * newest first); window = ff_aac_eld_window_512 / _480.  The reference shuffles sce->coeffs in place; this takes a copy. */
+void ffo_aac_imdct_and_windowing_eld(int n, const FfoTx *mdct, const float *window, const float *coeffs, float *saved, float *out)
+{
+    const int n2 = n >> 1, n4 = n >> 2;
+    float in[512], buf[512];
+    memcpy(in, coeffs, n * sizeof(float));
+    for (int i = 0; i < n2; i += 2) {
+        float t = in[i];
+        in[i] = -in[n - 1 - i];
+        in[n - 1 - i] = t;
+        t = -in[i + 1];
+        in[i + 1] = in[n - 2 - i];
+        in[n - 2 - i] = t;
+    }
+    ffo_mdct_run(mdct, buf, in, sizeof(float));
+    for (int i = 0; i < n; i += 2)
+        buf[i] = -buf[i];
+    for (int i = n4; i < n2; i++)
+        out[i - n4] = buf[n2 - 1 - i] * window[i - n4] + saved[i + n2] * window[i + n - n4] + -saved[n + n2 - 1 - i] * window[i + 2 * n - n4] +
+                      -saved[2 * n + n2 + i] * window[i + 3 * n - n4];
+    for (int i = 0; i < n2; i++)
+        out[n4 + i] = buf[i] * window[i + n2 - n4] + -saved[n - 1 - i] * window[i + n2 + n - n4] + -saved[n + i] * window[i + n2 + 2 * n - n4] +
+                      saved[2 * n + n - 1 - i] * window[i + n2 + 3 * n - n4];
+    for (int i = 0; i < n4; i++)
+        out[n2 + n4 + i] = buf[i + n2] * window[i + n - n4] + -saved[n2 - 1 - i] * window[i + 2 * n - n4] + -saved[n + n2 + i] * window[i + 3 * n - n4];
+    memmove(saved + n, saved, 2 * n * sizeof(float));
+    memcpy(saved, buf, n * sizeof(float));
+}

@@ -267,3 +267,55 @@ int ffref_aac_imdct_and_windowing_len(int L, const float *coeffs, const int seq[
     memcpy(saved, sce->saved, (L / 2) * sizeof(float));
     return 0;
 }
+
+/* ---- AAC-LD / AAC-ELD: AACDecDSP.imdct_and_windowing_ld / _eld ---- */
+/* which: 0 ff_sine_512, 1 ff_sine_128, 2 ff_aac_eld_window_512, 3 ff_aac_eld_window_480 */
+const float *ffref_aac_ld_table(int which)
+{
+    if (!aac())
+        return NULL;
+    return which == 0 ? ff_sine_512 : which == 1 ? ff_sine_128 : which == 2 ? ff_aac_eld_window_512 : ff_aac_eld_window_480;
+}
+
+static int ld_tx(AACDecContext *ac)
+{
+    if (!ac->mdct512) {
+        float s480 = (1.0 / 480) / 32768.0f, s512 = (1.0 / 512) / 32768.0f;
+        if (av_tx_init(&ac->mdct480, &ac->mdct480_fn, AV_TX_FLOAT_MDCT, 1, 480, &s480, 0) < 0 ||
+            av_tx_init(&ac->mdct512, &ac->mdct512_fn, AV_TX_FLOAT_MDCT, 1, 512, &s512, 0) < 0)
+            return -1;
+    }
+    return 0;
+}
+
+int ffref_aac_imdct_and_windowing_ld(const float *coeffs, int kb_prev, float *saved, float *out)
+{
+    AACDecContext *ac = aac();
+    SingleChannelElement *sce = &cpe_scratch()->ch[0];
+    if (!ac || ld_tx(ac) < 0)
+        return -1;
+    sce->ics.use_kb_window[1] = kb_prev;
+    memcpy(sce->coeffs, coeffs, 1024 * sizeof(float));
+    memcpy(sce->saved, saved, 256 * sizeof(float));
+    sce->output = sce->ret_buf;
+    ac->dsp.imdct_and_windowing_ld(ac, sce);
+    memcpy(out, sce->output, 512 * sizeof(float));
+    memcpy(saved, sce->saved, 256 * sizeof(float));
+    return 0;
+}
+
+int ffref_aac_imdct_and_windowing_eld(int n, const float *coeffs, float *saved, float *out)
+{
+    AACDecContext *ac = aac();
+    SingleChannelElement *sce = &cpe_scratch()->ch[0];
+    if (!ac || ld_tx(ac) < 0 || (n != 512 && n != 480))
+        return -1;
+    ac->oc[1].m4ac.frame_length_short = n == 480;
+    memcpy(sce->coeffs, coeffs, 1024 * sizeof(float));
+    memcpy(sce->saved, saved, 3 * n * sizeof(float));
+    sce->output = sce->ret_buf;
+    ac->dsp.imdct_and_windowing_eld(ac, sce);
+    memcpy(out, sce->output, n * sizeof(float));
+    memcpy(saved, sce->saved, 3 * n * sizeof(float));
+    return 0;
+}

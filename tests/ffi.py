@@ -118,6 +118,10 @@ def oracle():
         L.ffo_aac_imdct_and_windowing.restype = None
         L.ffo_aac_imdct_and_windowing_len.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(f32p), f32p, i32p, i32p, f32p, f32p]
         L.ffo_aac_imdct_and_windowing_len.restype = None
+        L.ffo_aac_imdct_and_windowing_ld.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_int, f32p, f32p]
+        L.ffo_aac_imdct_and_windowing_ld.restype = None
+        L.ffo_aac_imdct_and_windowing_eld.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p]
+        L.ffo_aac_imdct_and_windowing_eld.restype = None
         L.ffo_aac_tns_filters.argtypes = [C.c_void_p, i32p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
         L.ffo_aac_tns_filters.restype = C.c_int
         L.ffo_aac_tns_run.argtypes = [f32p, C.c_void_p, C.c_int]
@@ -316,6 +320,13 @@ def ref():
         L.ffref_aac_imdct_and_windowing.restype = C.c_int
         L.ffref_aac_apply_tns.argtypes = [f32p, i32p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int]
         L.ffref_aac_apply_tns.restype = C.c_int
+        if hasattr(L, "ffref_aac_imdct_and_windowing_ld"):
+            L.ffref_aac_ld_table.argtypes = [C.c_int]
+            L.ffref_aac_ld_table.restype = f32p
+            L.ffref_aac_imdct_and_windowing_ld.argtypes = [f32p, C.c_int, f32p, f32p]
+            L.ffref_aac_imdct_and_windowing_ld.restype = C.c_int
+            L.ffref_aac_imdct_and_windowing_eld.argtypes = [C.c_int, f32p, f32p, f32p]
+            L.ffref_aac_imdct_and_windowing_eld.restype = C.c_int
         if hasattr(L, "ffref_aac_imdct_and_windowing_len"):
             L.ffref_aac_window_len.argtypes = [C.c_int, C.c_int]
             L.ffref_aac_window_len.restype = f32p

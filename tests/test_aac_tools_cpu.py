@@ -187,3 +187,34 @@ def test_imdct_and_windowing_960_768(L):
         assert np.array_equal(bits(sa), bits(sb)), (f, seq, prev)
         prev = (seq, kb)
     O.ffo_mdct_free(ml); O.ffo_mdct_free(ms)
+
+
+def test_imdct_and_windowing_ld_eld():
+    """AACDecDSP.imdct_and_windowing_ld / _eld (AAC-LD, AAC-ELD at 512 and 480 samples, aacdec_dsp_template.c:516-602): the oracle
+    against the members over runs of frames (the ELD history is three frames deep), the decoder's own tables"""
+    R, O = _ref(), ffi.oracle()
+    if not hasattr(R, "ffref_aac_imdct_and_windowing_ld"):
+        pytest.skip("oracle/_ref predates the LD / ELD shim")
+    rng = np.random.default_rng(3160)
+    tabs = [np.ctypeslib.as_array(R.ffref_aac_ld_table(k), (n,)).copy() for k, n in ((0, 512), (1, 128), (2, 1920), (3, 1800))]
+    m512, m480 = O.ffo_mdct_create(1, 512, np.float32((1.0 / 512) / 32768.0)), O.ffo_mdct_create(1, 480, np.float32((1.0 / 480) / 32768.0))
+    sa = (rng.standard_normal(256) * .1).astype(np.float32)
+    sb = sa.copy()
+    for f in range(60):
+        co = A.spectrum(rng) * np.float32(100)
+        kbp = int(rng.integers(0, 2))
+        oa, ob = np.zeros(512, np.float32), np.zeros(512, np.float32)
+        assert R.ffref_aac_imdct_and_windowing_ld(ptr(co, f32p), kbp, ptr(sa, f32p), ptr(oa, f32p)) == 0
+        O.ffo_aac_imdct_and_windowing_ld(m512, ptr(tabs[0], f32p), ptr(tabs[1], f32p), ptr(co, f32p), kbp, ptr(sb, f32p), ptr(ob, f32p))
+        assert np.array_equal(bits(oa), bits(ob)) and np.array_equal(bits(sa), bits(sb)), f
+    for n, m, w in ((512, m512, tabs[2]), (480, m480, tabs[3])):
+        sa = (rng.standard_normal(3 * n) * .1).astype(np.float32)
+        sb = sa.copy()
+        for f in range(40):
+            co = A.spectrum(rng) * np.float32(100)
+            oa, ob = np.zeros(n, np.float32), np.zeros(n, np.float32)
+            assert R.ffref_aac_imdct_and_windowing_eld(n, ptr(co, f32p), ptr(sa, f32p), ptr(oa, f32p)) == 0
+            O.ffo_aac_imdct_and_windowing_eld(n, m, ptr(w, f32p), ptr(co, f32p), ptr(sb, f32p), ptr(ob, f32p))
+            assert np.array_equal(bits(oa), bits(ob)), (n, f)
+            assert np.array_equal(bits(sa), bits(sb)), (n, f)
+    O.ffo_mdct_free(m512); O.ffo_mdct_free(m480)

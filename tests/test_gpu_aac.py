@@ -184,3 +184,53 @@ def test_aac_imdct_and_windowing_960_768(L, nch, nframes):
         prev = (int(seq[f, 0]), int(kb[f, 0]))
     O.ffo_mdct_free(ml); O.ffo_mdct_free(ms)
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["ld", "eld512", "eld480"])
+@pytest.mark.parametrize("nch,nframes", [(1, 1), (2, 2), (3, 90)])
+def test_aac_ld_eld_batch(kind, nch, nframes):
+    """AACDecDSP.imdct_and_windowing_ld / _eld on device-resident frames against the oracle (pinned to the reference's members in
+    tests/test_aac_tools_cpu.py) frame after frame, a second call continuing from the state the first one left — the ELD history
+    is three frames deep, so runs shorter than that mix the caller's history with the batch's own"""
+    from ffmpeg_amd import aac
+    from ffi import ptr, f32p
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(2760 + nch + nframes)
+    eld = kind != "ld"
+    n = 480 if kind == "eld480" else 512
+    if eld:
+        win = [np.sin(np.linspace(0.01, 3.0, n * 15 // 4)).astype(np.float32) * np.float32(0.9)]      # any table: the caller hands it over
+        depth = 3 * n
+    else:
+        win = [np.zeros(512, np.float32), np.zeros(128, np.float32)]
+        O.ffo_aac_sine_window(ptr(win[0], f32p), 512); O.ffo_aac_sine_window(ptr(win[1], f32p), 128)
+        depth = 256
+    m = O.ffo_mdct_create(1, n, np.float32((1.0 / n) / 32768.0))
+    ctx = aac.AacLd(win, eld=eld, frame_len=n)
+    total = nframes + 5
+    coeffs = (rng.standard_normal((total, nch, 1024)) * 3000.0).astype(np.float32)
+    kbp = rng.integers(0, 2, (total, nch)).astype(np.uint8)
+    saved0 = (rng.standard_normal((nch, depth)) * 0.1).astype(np.float32)
+    want = np.zeros((total, nch, 1024), np.float32)
+    wsaved = saved0.copy()
+    for c in range(nch):
+        for f in range(total):
+            co = np.ascontiguousarray(coeffs[f, c])
+            if eld:
+                O.ffo_aac_imdct_and_windowing_eld(n, m, ptr(win[0], f32p), ptr(co, f32p), ptr(wsaved[c], f32p), ptr(want[f, c], f32p))
+            else:
+                O.ffo_aac_imdct_and_windowing_ld(m, ptr(win[0], f32p), ptr(win[1], f32p), ptr(co, f32p), int(kbp[f, c]), ptr(wsaved[c], f32p),
+                                                 ptr(want[f, c], f32p))
+    d_co = torch.from_numpy(coeffs).cuda()
+    d_out = torch.zeros((total, nch, 1024), dtype=torch.float32, device="cuda:0")
+    d_saved = torch.from_numpy(saved0.copy()).cuda()
+    ctx.batch(d_co[:nframes], d_out[:nframes], d_saved, None if eld else kbp[:nframes])
+    ctx.batch(d_co[nframes:], d_out[nframes:], d_saved, None if eld else kbp[nframes:])
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frames differing: %s" % np.argwhere((got != want).any(axis=2))[:5]
+    assert np.array_equal(d_saved.cpu().numpy().view(np.uint32), wsaved.view(np.uint32))
+    assert np.array_equal(d_co.cpu().numpy(), coeffs)
+    O.ffo_mdct_free(m)
+    ctx.close()
