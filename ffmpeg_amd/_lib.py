@@ -151,6 +151,9 @@ def lib():
         "ffhip_hevc_sao_restore_batch_dev_hbd": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_hevc_mc_w_batch_dev_hbd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, vp, C.c_ssize_t, vp, vp, C.c_int, vp]),
         "ffhip_aac_imdct_create_len": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float]),
+        "ffhip_aac_coupling_bands": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
+        "ffhip_aac_prediction_record": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]),
+        "ffhip_aac_apply_prediction_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
         "ffhip_aac_ld_create": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_float]),
         "ffhip_aac_ld_free": (None, [vp]),
         "ffhip_aac_ld_batch_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),

@@ -113,7 +113,9 @@ class AacLd:
 BAND_OP_DTYPE = np.dtype([("frame0", np.int32), ("frame1", np.int32), ("start", np.int16), ("len", np.int16), ("scale", np.float32),
                           ("kind", np.uint8), ("pad", np.uint8, 3)])
 LTP_DTYPE = np.dtype([("state", np.int32), ("lag", np.int16), ("seq0", np.uint8), ("kb", np.uint8), ("coef", np.float32), ("pad", np.int32)])
-BAND_MS, BAND_INTENSITY, BAND_ADD = 0, 1, 2
+BAND_MS, BAND_INTENSITY, BAND_ADD, BAND_FMAC = 0, 1, 2, 3
+PREDICTION_DTYPE = np.dtype([("channel", np.int32), ("frame", np.int32), ("kmax", np.int16), ("flags", np.uint8), ("reset_group", np.uint8),
+                             ("enable", np.uint32, 21), ("pad", np.uint32)])
 
 
 def _p(a, dt):
@@ -145,6 +147,30 @@ def ltp_bands(frame, pred_frame, max_sfb, used, swb_offset):
     keep = [_p(used, np.int8), _p(swb_offset, np.uint16)]
     n = _lib.check(_lib.lib().ffhip_aac_ltp_bands(rec.ctypes.data, frame, pred_frame, max_sfb, keep[0][1], keep[1][1]), "ffhip_aac_ltp_bands")
     return rec[:n]
+
+
+def coupling_bands(dest_frame, src_frame, num_window_groups, group_len, max_sfb, band_type, gain, swb_offset):
+    """apply_dependent_coupling's walk (FMAC records)"""
+    rec = np.zeros(128, BAND_OP_DTYPE)
+    keep = [_p(group_len, np.uint8), _p(band_type, np.int32), _p(gain, np.float32), _p(swb_offset, np.uint16)]
+    n = _lib.check(_lib.lib().ffhip_aac_coupling_bands(rec.ctypes.data, dest_frame, src_frame, num_window_groups, keep[0][1], max_sfb, keep[1][1],
+                                                       keep[2][1], keep[3][1]), "ffhip_aac_coupling_bands")
+    return rec[:n]
+
+
+def prediction_record(channel, frame, is_long, initialized, predictor_present, prediction_used, pred_sfb_max, swb_offset, reset_group):
+    rec = np.zeros(1, PREDICTION_DTYPE)
+    keep = [_p(prediction_used, np.uint8), _p(swb_offset, np.uint16)]
+    _lib.check(_lib.lib().ffhip_aac_prediction_record(rec.ctypes.data, channel, frame, int(is_long), int(initialized), int(predictor_present),
+                                                      keep[0][1], pred_sfb_max, keep[1][1], reset_group), "ffhip_aac_prediction_record")
+    return rec
+
+
+def apply_prediction_batch(predictor_state, coeffs, recs, n, stream=None):
+    """predictor_state: float32 cuda [channels, 672, 8]; coeffs: float32 cuda [frames, 1024]; recs: uint8 cuda [n, 100]"""
+    return _lib.check(_lib.lib().ffhip_aac_apply_prediction_batch_dev(predictor_state.data_ptr(), coeffs.data_ptr(), recs.data_ptr(), n,
+                                                                      None if stream is None else C.c_void_p(stream)),
+                      "ffhip_aac_apply_prediction_batch_dev")
 
 
 def band_ops_batch(a, b, ops, n, stream=None):

@@ -574,6 +574,8 @@ __global__ __launch_bounds__(256) void k_aac_band_ops(float *a, float *b, const 
             pb[i] = x - y;
         } else if (op.kind == FFHIP_AAC_BAND_INTENSITY) {
             pb[i] = x * op.scale;
+        } else if (op.kind == FFHIP_AAC_BAND_FMAC) {
+            pa[i] = x + op.scale * y; /* product, then sum: two roundings, as the C reference's dest += gain * src */
         } else {
             pa[i] = x + y;
         }
@@ -939,5 +941,119 @@ extern "C" int ffhip_aac_ld_batch_dev(FFHipAacLd *c, const float *coeffs, float 
     LAUNCH_CHECK();
     if (hipMemcpyAsync(saved, nsaved, (size_t)nch * 3 * n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return FFHIP_EINVAL;
+    return 0;
+}
+
+
+/* AACDecDSP.apply_dependent_coupling's walk (aacdec_float_coupling.h:42-71): one FMAC record per coupled band and window (<= 128);
+ * gain = cce->coup.gain[index] (120 floats), band_type = cce->ch[0].band_type (ZERO_BT = 0 bands are skipped) */
+extern "C" int ffhip_aac_coupling_bands(FFHipAacBandOp *out, int dest_frame, int src_frame, int num_window_groups, const uint8_t *group_len,
+                                        int max_sfb, const int *band_type, const float *gain, const uint16_t *swb_offset)
+{
+    if (!out || !group_len || !band_type || !gain || !swb_offset || !aac_groups_ok(num_window_groups, group_len, max_sfb, "ffhip_aac_coupling_bands") ||
+        num_window_groups * max_sfb > 120)
+        return FFHIP_EINVAL;
+    int n = 0, window0 = 0, idx = 0;
+    for (int g = 0; g < num_window_groups; g++) {
+        for (int i = 0; i < max_sfb; i++, idx++)
+            if (band_type[idx] != 0)
+                for (int w = 0; w < group_len[g]; w++)
+                    out[n++] = band_op(FFHIP_AAC_BAND_FMAC, dest_frame, src_frame, (window0 + w) * 128 + swb_offset[i], swb_offset[i + 1] - swb_offset[i],
+                                       gain[idx]);
+        window0 += group_len[g];
+    }
+    return n;
+}
+
+/* ---- AACDecDSP.apply_prediction (AAC Main; aacdec_dsp_template.c:636-664, predict(): aacdec_float_prediction.h:35-85) -------------- */
+static_assert(sizeof(FFHipAacPrediction) == 100, "FFHipAacPrediction is a 100-byte record");
+
+extern "C" int ffhip_aac_prediction_record(FFHipAacPrediction *out, int channel, int frame, int is_long, int initialized, int predictor_present,
+                                           const uint8_t *prediction_used, int pred_sfb_max, const uint16_t *swb_offset, int reset_group)
+{
+    if (!out || !prediction_used || !swb_offset || pred_sfb_max < 0 || pred_sfb_max > 41 || reset_group < 0 || reset_group > 30 ||
+        swb_offset[pred_sfb_max] > 672) {
+        ffhip_set_error("ffhip_aac_prediction_record: pred_sfb_max %d / reset group %d out of range", pred_sfb_max, reset_group);
+        return FFHIP_EINVAL;
+    }
+    memset(out, 0, sizeof(*out));
+    out->channel = channel;
+    out->frame = frame;
+    out->kmax = (int16_t)swb_offset[pred_sfb_max];
+    out->flags = (uint8_t)((is_long ? FFHIP_AAC_PRED_LONG : 0) | (initialized ? 0 : FFHIP_AAC_PRED_RESET_FIRST));
+    out->reset_group = (uint8_t)reset_group;
+    if (predictor_present)
+        for (int sfb = 0; sfb < pred_sfb_max; sfb++)
+            if (prediction_used[sfb])
+                for (int k = swb_offset[sfb]; k < swb_offset[sfb + 1]; k++)
+                    out->enable[k >> 5] |= 1u << (k & 31);
+    return 0;
+}
+
+__device__ __forceinline__ float pr_round(float f) { return __uint_as_float((__float_as_uint(f) + 0x00008000u) & 0xFFFF0000u); }
+__device__ __forceinline__ float pr_even(float f)
+{
+    const uint32_t i = __float_as_uint(f);
+    return __uint_as_float((i + 0x00007FFFu + (i & 1u)) & 0xFFFF0000u); /* the reference's `tmp.i & 0x00010000U >> 16` is tmp.i & 1 */
+}
+__device__ __forceinline__ float pr_trunc(float f) { return __uint_as_float(__float_as_uint(f) & 0xFFFF0000u); }
+
+/* one thread per predictor: every coefficient below kmax has its own backward-adaptive state, nothing crosses coefficients */
+__global__ __launch_bounds__(704) void k_aac_prediction(float *state, float *coeffs, const FFHipAacPrediction *recs)
+{
+    const FFHipAacPrediction &R = recs[blockIdx.x];
+    const int k = threadIdx.x;
+    if (k >= 672)
+        return;
+    float4 *sp = reinterpret_cast<float4 *>(state + ((size_t)R.channel * 672 + k) * 8);
+    float4 A = sp[0];                       /* cor0 cor1 var0 var1 */
+    float2 B = *reinterpret_cast<float2 *>(sp + 1); /* r0 r1 */
+    auto reset = [&] { A = make_float4(0.0f, 0.0f, 1.0f, 1.0f); B = make_float2(0.0f, 0.0f); };
+    if (R.flags & FFHIP_AAC_PRED_RESET_FIRST)
+        reset();
+    if (!(R.flags & FFHIP_AAC_PRED_LONG)) {
+        reset();
+    } else {
+        if (k < R.kmax) {
+            const float a = 0.953125f, alpha = 0.90625f;
+            float *c = coeffs + (size_t)R.frame * 1024 + k;
+            const float r0 = B.x, r1 = B.y, cor0 = A.x, cor1 = A.y, var0 = A.z, var1 = A.w;
+            const float k1 = var0 > 1 ? cor0 * pr_even(a / var0) : 0;
+            const float k2 = var1 > 1 ? cor1 * pr_even(a / var1) : 0;
+            const float pv = pr_round(k1 * r0 + k2 * r1);
+            float e0 = *c;
+            if (R.enable[k >> 5] >> (k & 31) & 1u) {
+                e0 = e0 + pv;
+                *c = e0;
+            }
+            const float e1 = e0 - k1 * r0;
+            A.y = pr_trunc(alpha * cor1 + r1 * e1);
+            A.w = pr_trunc(alpha * var1 + 0.5f * (r1 * r1 + e1 * e1));
+            A.x = pr_trunc(alpha * cor0 + r0 * e0);
+            A.z = pr_trunc(alpha * var0 + 0.5f * (r0 * r0 + e0 * e0));
+            B.y = pr_trunc(a * (r0 - k1 * e0));
+            B.x = pr_trunc(a * e0);
+        }
+        if (R.reset_group && k % 30 == R.reset_group - 1)
+            reset();
+    }
+    sp[0] = A;
+    *reinterpret_cast<float2 *>(sp + 1) = B;
+}
+
+extern "C" int ffhip_aac_apply_prediction_batch_dev(float *predictor_state, float *coeffs, const FFHipAacPrediction *recs, int n, void *stream)
+{
+    if (!predictor_state || !coeffs || !recs || n < 0)
+        return FFHIP_EINVAL;
+    if ((uintptr_t)predictor_state & 15) {
+        ffhip_set_error("ffhip_aac_apply_prediction: predictor_state must be 16-byte aligned");
+        return FFHIP_EINVAL;
+    }
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    if (!n)
+        return 0;
+    hipLaunchKernelGGL(k_aac_prediction, dim3(n), dim3(704), 0, (hipStream_t)stream, predictor_state, coeffs, recs);
+    LAUNCH_CHECK();
     return 0;
 }

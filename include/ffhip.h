@@ -564,6 +564,26 @@ int ffhip_aac_tns_filters(FFHipAacTnsFilter *out, int frame, const int n_filt[8]
  *  filters of a frame cover disjoint ranges, so all of them run concurrently. */
 int ffhip_aac_apply_tns_batch_dev(float *coeffs, const FFHipAacTnsFilter *filters, int nfilters, int decode, void *stream);
 
+/** AACDecDSP.apply_prediction (AAC Main's backward-adaptive predictors; aacdec_dsp_template.c:636-664, aacdec_float_prediction.h):
+ *  one record per channel-frame, one thread per predictor.  predictor_state: device array [channels][672] of PredictorState (8 floats:
+ *  cor0 cor1 var0 var1 r0 r1 k1 x_est, libavcodec/aac_defines.h:130-139), carried from frame to frame by the caller — so a batch is
+ *  one frame of many channels.  The host helper folds predictor_present / prediction_used[] / ff_aac_pred_sfb_max[] / swb_offset into
+ *  the per-coefficient enable bits. */
+enum { FFHIP_AAC_PRED_LONG = 1,          /* window_sequence[0] != EIGHT_SHORT_SEQUENCE (else: all predictors are reset) */
+       FFHIP_AAC_PRED_RESET_FIRST = 2 }; /* ics.predictor_initialized was 0 */
+typedef struct FFHipAacPrediction {
+    int32_t  channel;      /* predictor_state + channel * 672 * 8 */
+    int32_t  frame;        /* coeffs + frame * 1024 */
+    int16_t  kmax;         /* swb_offset[pred_sfb_max]: predictors 0 .. kmax - 1 run */
+    uint8_t  flags;
+    uint8_t  reset_group;  /* ics.predictor_reset_group (0: none) */
+    uint32_t enable[21];   /* bit k: coeffs[k] += prediction */
+    uint32_t pad;          /* sizeof == 100 */
+} FFHipAacPrediction;
+int ffhip_aac_prediction_record(FFHipAacPrediction *out, int channel, int frame, int is_long, int initialized, int predictor_present,
+                                const uint8_t *prediction_used, int pred_sfb_max, const uint16_t *swb_offset, int reset_group);
+int ffhip_aac_apply_prediction_batch_dev(float *predictor_state, float *coeffs, const FFHipAacPrediction *recs, int n, void *stream);
+
 /** AAC-LD and AAC-ELD: AACDecDSP.imdct_and_windowing_ld / _eld (aacdec_dsp_template.c:516-602), float.  eld == 0: 512-sample frames,
  *  w0 = ff_sine_512, w1 = ff_sine_128, scale = mdct512's ((1.0 / 512) / 32768, aacdec.c:1282).  eld != 0: frame_len 512 or 480, w0 =
  *  ff_aac_eld_window_512 / _480 (1920 / 1800 floats, libavcodec/aactab.h:61-63), w1 unused, scale that of mdct512 / mdct480.
@@ -584,7 +604,8 @@ int  ffhip_aac_ld_batch_dev(FFHipAacLd *c, const float *coeffs, float *out, floa
  *  records — and any number of pairs — run in one launch. */
 enum { FFHIP_AAC_BAND_MS = 0,         /* butterflies_float: a, b = a + b, a - b          (libavutil/float_dsp.c:112-122) */
        FFHIP_AAC_BAND_INTENSITY = 1,  /* vector_fmul_scalar: b = a * scale               (libavutil/float_dsp.c:45-51)   */
-       FFHIP_AAC_BAND_ADD = 2 };      /* a += b                                          (apply_ltp's last loop)         */
+       FFHIP_AAC_BAND_ADD = 2,        /* a += b                                          (apply_ltp's last loop)         */
+       FFHIP_AAC_BAND_FMAC = 3 };     /* a += scale * b   (product rounded, then the sum) (channel coupling)              */
 typedef struct FFHipAacBandOp {
     int32_t frame0;     /* a = base_a + frame0 * 1024 + start */
     int32_t frame1;     /* b = base_b + frame1 * 1024 + start */
@@ -607,6 +628,12 @@ int ffhip_aac_ltp_bands(FFHipAacBandOp *out, int frame, int pred_frame, int max_
 /** The records of a batch on device arrays a / b of channel-frames (1024 floats each; the same array for the stereo tools,
  *  coeffs / predFreq for the LTP add); ops is a device array. */
 int ffhip_aac_band_ops_batch_dev(float *a, float *b, const FFHipAacBandOp *ops, int n, void *stream);
+/** AACDecDSP.apply_dependent_coupling (aacdec_float_coupling.h:42-71): the walk over the coupling channel's bands as FMAC records
+ *  (dest_frame / src_frame index the same device array of channel-frames; run with ffhip_aac_band_ops_batch_dev(coeffs, coeffs, ..)).
+ *  apply_independent_coupling (:78-88) is ONE such record over the output samples: { dest, src, 0, len, gain, FFHIP_AAC_BAND_FMAC }. */
+int ffhip_aac_coupling_bands(FFHipAacBandOp *out, int dest_frame, int src_frame, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                             const int *band_type, const float *gain, const uint16_t *swb_offset);
+
 
 /** AACDecDSP.apply_ltp (aacdec_dsp_template.c:252-282) as its three steps: (1) ffhip_aac_ltp_predict_batch_dev — the delayed state
  *  times ltp->coef, windowing_and_mdct_ltp (:225-247) and the forward 1024-point MDCT (created by ffhip_aac_ltp_init with the scale

@@ -223,6 +223,11 @@ void ffo_aac_update_ltp(const float *const windows[4], float *ltp_state, const f
 void ffo_aac_sine_window(float *w, int n);
 void ffo_aac_kbd_window(float *w, float alpha, int n);
 /* windows[]: sine_1024, sine_128, kbd_long_1024, kbd_short_128; seq / kb = { this frame, previous frame }; saved[512] in / out */
+void ffo_aac_apply_prediction(float *ps, float *coef, int is_long, int *initialized, int predictor_present, const uint8_t *prediction_used,
+                              int pred_sfb_max, const uint16_t *swb_offset, int reset_group);
+void ffo_aac_apply_dependent_coupling(float *dest, const float *src, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                                      const int *band_type, const float *gain, const uint16_t *swb_offset);
+void ffo_aac_apply_independent_coupling(float *dest, const float *src, float gain, int len);
 void ffo_aac_imdct_and_windowing_ld(const FfoTx *mdct512, const float *sine_512, const float *sine_128, const float *coeffs, int kb_prev,
                                     float *saved, float *out);
 void ffo_aac_imdct_and_windowing_eld(int n, const FfoTx *mdct, const float *window, const float *coeffs, float *saved, float *out);

@@ -330,3 +330,81 @@ void ffo_aac_imdct_and_windowing_eld(int n, const FfoTx *mdct, const float *wind
     memmove(saved + n, saved, 2 * n * sizeof(float));
     memcpy(saved, buf, n * sizeof(float));
 }
+
+/* AACDecDSP.apply_prediction, float (AAC Main; aacdec_dsp_template.c:636-664 with predict(), aacdec_float_prediction.h:35-85).
+ * ps: 672 PredictorState records of 8 floats (cor0, cor1, var0, var1, r0, r1, k1, x_est: aac_defines.h:130-139) */
+static float f16_round(float pf) { uint32_t i; memcpy(&i, &pf, 4); i = (i + 0x00008000U) & 0xFFFF0000U; memcpy(&pf, &i, 4); return pf; }
+static float f16_even(float pf)
+{
+    uint32_t i;
+    memcpy(&i, &pf, 4);
+    i = (i + 0x00007FFFU + (i & (0x00010000U >> 16))) & 0xFFFF0000U; /* the reference's precedence: i & 1 */
+    memcpy(&pf, &i, 4);
+    return pf;
+}
+static float f16_trunc(float pf) { uint32_t i; memcpy(&i, &pf, 4); i &= 0xFFFF0000U; memcpy(&pf, &i, 4); return pf; }
+
+static void pred_reset(float *ps)
+{
+    ps[0] = ps[1] = 0.0f;
+    ps[2] = ps[3] = 1.0f;
+    ps[4] = ps[5] = 0.0f;
+}
+
+void ffo_aac_apply_prediction(float *ps, float *coef, int is_long, int *initialized, int predictor_present, const uint8_t *prediction_used,
+                              int pred_sfb_max, const uint16_t *swb_offset, int reset_group)
+{
+    if (!*initialized) {
+        for (int i = 0; i < 672; i++)
+            pred_reset(ps + 8 * i);
+        *initialized = 1;
+    }
+    if (!is_long) {
+        for (int i = 0; i < 672; i++)
+            pred_reset(ps + 8 * i);
+        return;
+    }
+    const float a = 0.953125f, alpha = 0.90625f;
+    for (int sfb = 0; sfb < pred_sfb_max; sfb++)
+        for (int k = swb_offset[sfb]; k < swb_offset[sfb + 1]; k++) {
+            float *p = ps + 8 * k;
+            const float r0 = p[4], r1 = p[5], cor0 = p[0], cor1 = p[1], var0 = p[2], var1 = p[3];
+            const float k1 = var0 > 1 ? cor0 * f16_even(a / var0) : 0;
+            const float k2 = var1 > 1 ? cor1 * f16_even(a / var1) : 0;
+            const float pv = f16_round(k1 * r0 + k2 * r1);
+            if (predictor_present && prediction_used[sfb])
+                coef[k] += pv;
+            const float e0 = coef[k], e1 = e0 - k1 * r0;
+            p[1] = f16_trunc(alpha * cor1 + r1 * e1);
+            p[3] = f16_trunc(alpha * var1 + 0.5f * (r1 * r1 + e1 * e1));
+            p[0] = f16_trunc(alpha * cor0 + r0 * e0);
+            p[2] = f16_trunc(alpha * var0 + 0.5f * (r0 * r0 + e0 * e0));
+            p[5] = f16_trunc(a * (r0 - k1 * e0));
+            p[4] = f16_trunc(a * e0);
+        }
+    if (reset_group)
+        for (int i = reset_group - 1; i < 672; i += 30)
+            pred_reset(ps + 8 * i);
+}
+
+/* AACDecDSP.apply_dependent_coupling (aacdec_float_coupling.h:42-71; band_type 0 = ZERO_BT) and apply_independent_coupling (:78-88) */
+void ffo_aac_apply_dependent_coupling(float *dest, const float *src, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                                      const int *band_type, const float *gain, const uint16_t *swb_offset)
+{
+    int idx = 0;
+    for (int g = 0; g < num_window_groups; g++) {
+        for (int i = 0; i < max_sfb; i++, idx++)
+            if (band_type[idx] != 0)
+                for (int w = 0; w < group_len[g]; w++)
+                    for (int k = swb_offset[i]; k < swb_offset[i + 1]; k++)
+                        dest[w * 128 + k] += gain[idx] * src[w * 128 + k];
+        dest += group_len[g] * 128;
+        src += group_len[g] * 128;
+    }
+}
+
+void ffo_aac_apply_independent_coupling(float *dest, const float *src, float gain, int len)
+{
+    for (int i = 0; i < len; i++)
+        dest[i] += src[i] * gain;
+}

@@ -319,3 +319,75 @@ int ffref_aac_imdct_and_windowing_eld(int n, const float *coeffs, float *saved, 
     memcpy(saved, sce->saved, 3 * n * sizeof(float));
     return 0;
 }
+
+/* ---- AAC Main prediction and channel coupling: AACDecDSP.apply_prediction / apply_dependent_coupling / apply_independent_coupling ---- */
+/* sampling_index: pred_sfb_max = ff_aac_pred_sfb_max[sampling_index] is matched by the caller choosing the index */
+int ffref_aac_apply_prediction(float *ps, float *coef, int is_long, int *initialized, int predictor_present, const uint8_t *prediction_used,
+                               int sampling_index, const uint16_t *swb_offset, int reset_group)
+{
+    AACDecContext *ac = aac();
+    SingleChannelElement *sce = &cpe_scratch()->ch[0];
+    static float *st; /* MAX_PREDICTORS PredictorState records of 8 floats (libavcodec/aac_defines.h:130-139; the type itself needs USE_FIXED) */
+    if (!ac)
+        return -1;
+    if (!st)
+        st = av_mallocz(MAX_PREDICTORS * 8 * sizeof(float));
+    memcpy(st, ps, MAX_PREDICTORS * 8 * sizeof(float));
+    sce->predictor_state = (struct PredictorState *)st;
+    ac->oc[1].m4ac.sampling_index = sampling_index;
+    sce->ics.window_sequence[0] = is_long ? ONLY_LONG_SEQUENCE : EIGHT_SHORT_SEQUENCE;
+    sce->ics.predictor_initialized = *initialized;
+    sce->ics.predictor_present = predictor_present;
+    sce->ics.predictor_reset_group = reset_group;
+    memcpy(sce->ics.prediction_used, prediction_used, 41);
+    sce->ics.swb_offset = swb_offset;
+    memcpy(sce->coeffs, coef, 1024 * sizeof(float));
+    ac->dsp.apply_prediction(ac, sce);
+    memcpy(coef, sce->coeffs, 1024 * sizeof(float));
+    memcpy(ps, st, MAX_PREDICTORS * 8 * sizeof(float));
+    *initialized = sce->ics.predictor_initialized;
+    return ff_aac_pred_sfb_max[sampling_index];
+}
+
+int ffref_aac_apply_dependent_coupling(float *dest, const float *src, int num_window_groups, const uint8_t *group_len, int max_sfb,
+                                       const int *band_type, const float *gain, const uint16_t *swb_offset)
+{
+    AACDecContext *ac = aac();
+    static ChannelElement *cce;
+    SingleChannelElement *target = &cpe_scratch()->ch[0];
+    if (!ac)
+        return -1;
+    if (!cce)
+        cce = av_mallocz(sizeof(*cce));
+    ac->oc[1].m4ac.object_type = AOT_AAC_MAIN;
+    ics_groups(&cce->ch[0].ics, num_window_groups, group_len, max_sfb, swb_offset);
+    for (int i = 0; i < 128; i++)
+        cce->ch[0].band_type[i] = band_type[i];
+    memcpy(cce->coup.gain[3], gain, 120 * sizeof(float));
+    memcpy(cce->ch[0].coeffs, src, 1024 * sizeof(float));
+    memcpy(target->coeffs, dest, 1024 * sizeof(float));
+    ac->dsp.apply_dependent_coupling(ac, target, cce, 3);
+    memcpy(dest, target->coeffs, 1024 * sizeof(float));
+    return 0;
+}
+
+int ffref_aac_apply_independent_coupling(float *dest, const float *src, float gain, int len)
+{
+    AACDecContext *ac = aac();
+    static ChannelElement *cce;
+    SingleChannelElement *target = &cpe_scratch()->ch[0];
+    if (!ac || (len != 1024 && len != 2048))
+        return -1;
+    if (!cce)
+        cce = av_mallocz(sizeof(*cce));
+    ac->oc[1].m4ac.sbr = len == 2048;
+    cce->coup.gain[5][0] = gain;
+    cce->ch[0].output = cce->ch[0].ret_buf;
+    target->output = target->ret_buf;
+    memcpy(cce->ch[0].output, src, len * sizeof(float));
+    memcpy(target->output, dest, len * sizeof(float));
+    ac->dsp.apply_independent_coupling(ac, target, cce, 5);
+    memcpy(dest, target->output, len * sizeof(float));
+    ac->oc[1].m4ac.sbr = 0;
+    return 0;
+}

@@ -118,6 +118,12 @@ def oracle():
         L.ffo_aac_imdct_and_windowing.restype = None
         L.ffo_aac_imdct_and_windowing_len.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(f32p), f32p, i32p, i32p, f32p, f32p]
         L.ffo_aac_imdct_and_windowing_len.restype = None
+        L.ffo_aac_apply_prediction.argtypes = [f32p, f32p, C.c_int, i32p, C.c_int, u8p, C.c_int, C.POINTER(C.c_uint16), C.c_int]
+        L.ffo_aac_apply_prediction.restype = None
+        L.ffo_aac_apply_dependent_coupling.argtypes = [f32p, f32p, C.c_int, u8p, C.c_int, i32p, f32p, C.POINTER(C.c_uint16)]
+        L.ffo_aac_apply_dependent_coupling.restype = None
+        L.ffo_aac_apply_independent_coupling.argtypes = [f32p, f32p, C.c_float, C.c_int]
+        L.ffo_aac_apply_independent_coupling.restype = None
         L.ffo_aac_imdct_and_windowing_ld.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_int, f32p, f32p]
         L.ffo_aac_imdct_and_windowing_ld.restype = None
         L.ffo_aac_imdct_and_windowing_eld.argtypes = [C.c_int, C.c_void_p, f32p, f32p, f32p, f32p]
@@ -320,6 +326,13 @@ def ref():
         L.ffref_aac_imdct_and_windowing.restype = C.c_int
         L.ffref_aac_apply_tns.argtypes = [f32p, i32p, i32p, i32p, i32p, f32p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int]
         L.ffref_aac_apply_tns.restype = C.c_int
+        if hasattr(L, "ffref_aac_apply_prediction"):
+            L.ffref_aac_apply_prediction.argtypes = [f32p, f32p, C.c_int, i32p, C.c_int, u8p, C.c_int, C.POINTER(C.c_uint16), C.c_int]
+            L.ffref_aac_apply_prediction.restype = C.c_int
+            L.ffref_aac_apply_dependent_coupling.argtypes = [f32p, f32p, C.c_int, u8p, C.c_int, i32p, f32p, C.POINTER(C.c_uint16)]
+            L.ffref_aac_apply_dependent_coupling.restype = C.c_int
+            L.ffref_aac_apply_independent_coupling.argtypes = [f32p, f32p, C.c_float, C.c_int]
+            L.ffref_aac_apply_independent_coupling.restype = C.c_int
         if hasattr(L, "ffref_aac_imdct_and_windowing_ld"):
             L.ffref_aac_ld_table.argtypes = [C.c_int]
             L.ffref_aac_ld_table.restype = f32p

@@ -218,3 +218,54 @@ def test_imdct_and_windowing_ld_eld():
             assert np.array_equal(bits(oa), bits(ob)), (n, f)
             assert np.array_equal(bits(sa), bits(sb)), (n, f)
     O.ffo_mdct_free(m512); O.ffo_mdct_free(m480)
+
+
+def test_apply_prediction_and_coupling():
+    """AAC Main's backward-adaptive predictors over runs of frames (state carried, resets by group, short windows resetting all,
+    the never-initialised first frame) and the two channel-coupling members: oracle == reference, bit for bit"""
+    R, O = _ref(), ffi.oracle()
+    if not hasattr(R, "ffref_aac_apply_prediction"):
+        pytest.skip("oracle/_ref predates the prediction shim")
+    rng = np.random.default_rng(3170)
+    sa = (rng.standard_normal(672 * 8)).astype(np.float32)          # garbage: the first frame must reset it
+    sb = sa.copy()
+    ia, ib = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    sampling_index = 4                                               # 44.1 kHz: pred_sfb_max 40
+    added = 0
+    base = (rng.standard_normal(1024) * 300).astype(np.float32)          # a tonal signal: the predictors lock on (var > 1)
+    for f in range(80):
+        is_long = int(f % 11 != 7)
+        present = int(rng.integers(0, 3) > 0)
+        used = rng.integers(0, 2, 41).astype(np.uint8)
+        reset_group = int(rng.integers(0, 31)) if rng.integers(0, 4) == 0 else 0
+        ca = (base * (1 + .05 * rng.standard_normal(1024))).astype(np.float32)
+        cb = ca.copy()
+        c0 = ca.copy()
+        pmax = R.ffref_aac_apply_prediction(ptr(sa, f32p), ptr(ca, f32p), is_long, ptr(ia, i32p), present, ptr(used, u8p), sampling_index,
+                                            ptr(A.SWB_1024, u16p), reset_group)
+        assert pmax == 40
+        O.ffo_aac_apply_prediction(ptr(sb, f32p), ptr(cb, f32p), is_long, ptr(ib, i32p), present, ptr(used, u8p), pmax, ptr(A.SWB_1024, u16p), reset_group)
+        assert np.array_equal(bits(ca), bits(cb)), f
+        s6a, s6b = sa.reshape(672, 8)[:, :6], sb.reshape(672, 8)[:, :6]
+        assert np.array_equal(bits(s6a), bits(s6b)), f
+        added += int((bits(ca) != bits(c0)).sum())
+    assert added > 5000
+    for short in (0, 1):
+        for rep in range(30):
+            c = A.ics(rng, short)
+            bt = np.zeros(128, np.int32)
+            bt[:c["num_window_groups"] * c["max_sfb"]] = rng.integers(0, 3, c["num_window_groups"] * c["max_sfb"])
+            gain = (2.0 ** (rng.integers(-20, 20, 120) / 8.0)).astype(np.float32)
+            src = A.spectrum(rng)
+            da = A.spectrum(rng)
+            db = da.copy()
+            args = (c["num_window_groups"], ptr(c["group_len"], u8p), c["max_sfb"], ptr(bt, i32p), ptr(gain, f32p), ptr(c["swb"], u16p))
+            assert R.ffref_aac_apply_dependent_coupling(ptr(da, f32p), ptr(src, f32p), *args) == 0
+            O.ffo_aac_apply_dependent_coupling(ptr(db, f32p), ptr(src, f32p), *args)
+            assert np.array_equal(bits(da), bits(db))
+    for ln in (1024, 2048):
+        src, da = (rng.standard_normal(2048) * 100).astype(np.float32), (rng.standard_normal(2048) * 100).astype(np.float32)
+        db = da.copy()
+        assert R.ffref_aac_apply_independent_coupling(ptr(da, f32p), ptr(src, f32p), 0.7071, ln) == 0
+        O.ffo_aac_apply_independent_coupling(ptr(db, f32p), ptr(src, f32p), 0.7071, ln)
+        assert np.array_equal(bits(da), bits(db))

@@ -148,3 +148,90 @@ def test_aac_ltp_rejects():
     with pytest.raises(RuntimeError, match="follows"):
         ctx.update_ltp(z, z, 1)
     ctx.close()
+
+
+@pytest.mark.parametrize("nch", [1, 7, 64])
+def test_aac_apply_prediction_chain(nch):
+    """AAC Main's predictors on the device: runs of frames of several channels, the state carried in device memory, against the
+    oracle (pinned to the reference's member on the CPU) — group resets, short-window resets, uninitialised first frames"""
+    import torch
+    from ffmpeg_amd import aac
+    O = ffi.oracle()
+    rng = np.random.default_rng(3300 + nch)
+    state = rng.standard_normal((nch, 672, 8)).astype(np.float32)                 # garbage until a channel's first frame
+    d_state = torch.from_numpy(state.copy()).cuda()
+    init = np.zeros(nch, np.int32)
+    base = (rng.standard_normal((nch, 1024)) * 300).astype(np.float32)           # a tonal signal: the predictors lock on
+    changed = 0
+    for f in range(12):
+        coeffs = (base * (1 + .05 * rng.standard_normal((nch, 1024)))).astype(np.float32)
+        want = coeffs.copy()
+        recs = []
+        for c in range(nch):
+            if f > 0 and rng.random() < .2:
+                continue                                                            # a channel with no element in this frame
+            is_long = int(rng.random() < .85)
+            present = int(rng.random() < .7)
+            used = rng.integers(0, 2, 41).astype(np.uint8)
+            reset_group = int(rng.integers(1, 31)) if rng.random() < .3 else 0
+            recs.append(aac.prediction_record(c, c, is_long, int(init[c]), present, used, 40, A.SWB_1024, reset_group))
+            ini = np.array([init[c]], np.int32)
+            st = np.ascontiguousarray(state[c]).reshape(-1)
+            O.ffo_aac_apply_prediction(ptr(st, f32p), ptr(want[c], f32p), is_long, ptr(ini, i32p), present, ptr(used, u8p), 40,
+                                       ptr(A.SWB_1024, u16p), reset_group)
+            state[c] = st.reshape(672, 8)
+            init[c] = ini[0]
+        if not recs:
+            continue
+        rec = np.concatenate(recs)
+        d_co = torch.from_numpy(coeffs.copy()).cuda()
+        aac.apply_prediction_batch(d_state, d_co, _dev(torch, rec, 100), len(rec))
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(d_co.cpu().numpy()), bits(want)), f
+        changed += int((bits(want) != bits(coeffs)).sum())
+        got = d_state.cpu().numpy()
+        touched = np.array([int(r["channel"][0]) for r in recs])
+        assert np.array_equal(bits(got[touched][:, :, :6]), bits(state[touched][:, :, :6])), f
+    assert changed > 100 * nch
+
+
+def test_aac_coupling_batch():
+    import torch
+    from ffmpeg_amd import aac
+    O = ffi.oracle()
+    rng = np.random.default_rng(3310)
+    nf = 200
+    fr = np.stack([A.spectrum(rng) for _ in range(2 * nf)])
+    want = fr.copy()
+    recs = []
+    for p in range(nf):
+        c = A.ics(rng, p % 3 == 0)
+        n = c["num_window_groups"] * c["max_sfb"]
+        if n > 120:
+            c["max_sfb"] = 120 // c["num_window_groups"]
+            n = c["num_window_groups"] * c["max_sfb"]
+        bt = np.zeros(128, np.int32)
+        bt[:n] = rng.integers(0, 3, n)
+        gain = (2.0 ** (rng.integers(-20, 20, 120) / 8.0)).astype(np.float32)
+        O.ffo_aac_apply_dependent_coupling(ptr(want[2 * p], f32p), ptr(want[2 * p + 1], f32p), c["num_window_groups"], ptr(c["group_len"], u8p),
+                                           c["max_sfb"], ptr(bt, i32p), ptr(gain, f32p), ptr(c["swb"], u16p))
+        recs.append(aac.coupling_bands(2 * p, 2 * p + 1, c["num_window_groups"], c["group_len"], c["max_sfb"], bt, gain, c["swb"]))
+    rec = np.concatenate(recs)
+    d = torch.from_numpy(fr.copy()).cuda()
+    aac.band_ops_batch(d, d, _dev(torch, rec, 20), len(rec))
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(d.cpu().numpy()), bits(want))
+    assert (bits(want) != bits(fr)).sum() > 10000
+    # apply_independent_coupling: one FMAC record over the output samples of a frame (2048 with SBR)
+    a, b = (rng.standard_normal((2, 2048)) * 100).astype(np.float32)
+    w = a.copy()
+    O.ffo_aac_apply_independent_coupling(ptr(w, f32p), ptr(b, f32p), 0.7071, 2048)
+    one = np.zeros(1, aac.BAND_OP_DTYPE)
+    one[0] = (0, 1, 0, 2048, 0.7071, aac.BAND_FMAC, (0, 0, 0))
+    d2 = torch.from_numpy(np.stack([a[:1024], b[:1024]]).copy()).cuda()       # rows of 1024: dest = rows 0.., src = rows 1..: use a flat pair
+    flat = torch.from_numpy(np.concatenate([a, b]).copy()).cuda()
+    one[0]["frame1"] = 2                                                        # src starts 2 * 1024 floats in
+    aac.band_ops_batch(flat, flat, _dev(torch, one, 20), 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(flat.cpu().numpy()[:2048]), bits(w))
+    del d2
