@@ -126,10 +126,10 @@ def extras(torch, dev):
     ctx = S.SwsContext(w, h, 0, w, h, 2, 4)
     src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(0, w, h)]
     dst = [torch.empty((n, h, 3 * w), dtype=torch.uint8, device=dev)]
-    for _ in range(2):
+    for _ in range(10):
         ctx.scale_batch(src, dst)
     e0, e1 = ev(), ev()
-    reps = 10
+    reps = 50
     e0.record()
     for _ in range(reps):
         ctx.scale_batch(src, dst)
