@@ -66,3 +66,30 @@ for name, filt in (("8-tap (3 sets mixed)", lambda k: rng.integers(0, 3, k)), ("
     ms = e0.elapsed_time(e1) / 5
     print(json.dumps({"case": "vp9 mc put %s, every 16x16 block of %d 4K planes, mixed (mx, my)" % (name, planes), "blocks": n, "ms": round(ms, 4),
                       "Gpixel/s": round(planes * W * H / ms / 1e6, 1), "hbm_frac": round(2 * planes * W * H / ms / 1e6 / 8000, 4)}), flush=True)
+
+def timed(fn, reps=5):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+# ---- loop filters, function level: every 8x8-grid edge of the planes as 8-sample records, 8 wide; column edges, then row edges ----
+EDGE_DT = np.dtype([("offset", np.int32), ("wd_idx", np.uint8), ("dir", np.uint8), ("E", np.uint8), ("I", np.uint8), ("H", np.uint8), ("pad", np.uint8, 3)])
+pic = torch.from_numpy(np.clip(np.cumsum(np.random.default_rng(3).integers(-2, 3, (planes * H, W)), axis=1) + 128, 0, 255).astype(np.uint8)).to(dev)
+for d, name in ((0, "column"), (1, "row")):
+    ys, xs = (np.arange(0, planes * H, 8), np.arange(8, W, 8)) if d == 0 else (np.arange(8, planes * H, 8), np.arange(0, W, 8))
+    if d:
+        ys = ys[ys % H != 0]
+    yy, xx = np.meshgrid(ys, xs, indexing="ij")
+    ed = np.zeros(yy.size, EDGE_DT)
+    ed["offset"] = (yy * W + xx).reshape(-1)
+    ed["wd_idx"], ed["dir"], ed["E"], ed["I"], ed["H"] = 1, d, 60, 20, 2
+    dev_ed = torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).to(dev)
+    ms = timed(lambda: vp9.loop_filter_batch(pic, W, dev_ed, ed.size))
+    print(json.dumps({"case": "vp9 loop_filter_8 (8 wide), every 8x8-grid %s edge of %d 4K planes" % (name, planes), "segments": int(ed.size),
+                      "ms": round(ms, 4), "Gpixel/s": round(planes * W * H / ms / 1e6, 1)}), flush=True)
