@@ -126,7 +126,23 @@ __global__ __launch_bounds__(256) void k_h264_loop_filter(uint8_t *base, ptrdiff
         return;
     const ptrdiff_t xs = vert_edge ? 1 : stride, ys = vert_edge ? stride : 1;
     const int tc0 = intra ? 0 : ed.tc0[chroma ? d >> 1 : d >> 2];
-    lf_apply(base + ed.offset + d * ys, xs, (chroma ? 1 : 0) + (intra ? 2 : 0), ed.alpha, ed.beta, tc0);
+    uint8_t *pix = base + ed.offset + d * ys;
+    const int cls = (chroma ? 1 : 0) + (intra ? 2 : 0);
+    if (vert_edge && !(reinterpret_cast<uintptr_t>(pix) & 3)) {
+        /* a vertical edge's line is 8 contiguous bytes p3 .. q3: two dwords in, the dwords that changed out (the sample-wise
+         * form below costs up to 8 byte loads and 6 byte stores per lane) */
+        uint32_t *w = reinterpret_cast<uint32_t *>(pix - 4);
+        const uint32_t a = w[0], b = w[1];
+        LfLine v = { (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), (int)(a >> 24),
+                     (int)(b & 255), (int)((b >> 8) & 255), (int)((b >> 16) & 255), (int)(b >> 24) };
+        const int m = lf_line(v, cls, ed.alpha, ed.beta, tc0);
+        if (m & 7)
+            w[0] = (uint32_t)v.p3 | (uint32_t)v.p2 << 8 | (uint32_t)v.p1 << 16 | (uint32_t)v.p0 << 24;
+        if (m & 56)
+            w[1] = (uint32_t)v.q0 | (uint32_t)v.q1 << 8 | (uint32_t)v.q2 << 16 | (uint32_t)v.q3 << 24;
+        return;
+    }
+    lf_apply(pix, xs, cls, ed.alpha, ed.beta, tc0);
 }
 
 int ffhip_launch_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n, hipStream_t stream)
