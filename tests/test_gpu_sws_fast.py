@@ -424,6 +424,11 @@ WIDE_CASES = [
     ("yuv420p", 640, 360, "yuv420p", 160, 90 + 2, ffi.SWS_AREA),       # 4x area: 4..5 taps at stride 4
     ("nv12", 384, 216, "nv12", 512, 108, ffi.SWS_BICUBIC),           # up horizontally, down vertically
     ("yuv420p", 202, 120, "yuv420p", 104, 60, ffi.SWS_BICUBIC),      # odd chroma width (planar)
+    # exact 2:1 across several column blocks
+    ("yuv420p", 2560, 96, "yuv420p", 1280, 48, ffi.SWS_BICUBIC),     # planes + a planar U/V pair
+    ("nv21", 2560, 96, "nv21", 1280, 48, ffi.SWS_BICUBIC),           # interleaved pair, swapped
+    ("nv12", 2560, 96, "yuv420p", 1280, 40, ffi.SWS_BICUBIC),        # interleaved in, planar out, another vertical ratio
+    ("yuv420p", 2576, 96, "nv12", 1288, 48, ffi.SWS_BICUBIC),        # ragged last block
 ]
 
 
