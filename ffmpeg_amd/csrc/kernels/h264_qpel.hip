@@ -183,44 +183,61 @@ __device__ __forceinline__ uint32_t qp_round5(qp_s2 lo, qp_s2 hi)
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x06040200);
 }
 
-__global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
-                                                     const FFHipQpelBlock *blocks, int n)
+/* What one block needs from its record, wave-uniform. */
+struct QpBlk {
+    int size, mc, soff, doff, ndw, rows;
+    uint32_t sh;
+    bool avg;
+    const uint8_t *sa;
+};
+__device__ __forceinline__ QpBlk qp_blk(const FFHipQpelBlock *blocks, int b, const uint8_t *src, ptrdiff_t stride)
 {
-    __shared__ uint32_t lds[4][21 * 8 + 21 * 8];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= n)
-        return;
-    uint32_t *raw = lds[wave];             /* [row][8] aligned source dwords, row 0 = y-2 */
-    uint32_t *hb = lds[wave] + 21 * 8;     /* [row][8] int16 pairs: unclipped horizontal sums of the block's columns */
     const FFHipQpelBlock blk = blocks[b];
-    const int size = 16 >> __builtin_amdgcn_readfirstlane((int)blk.size_idx);
-    const int mc = __builtin_amdgcn_readfirstlane((int)blk.mcxy) & 15;
-    const bool avg = __builtin_amdgcn_readfirstlane((int)blk.avg) != 0;
-    const int soff = __builtin_amdgcn_readfirstlane(blk.src_offset), doff = __builtin_amdgcn_readfirstlane(blk.dst_offset);
-    const int per_row = size >> 2, rows = size + 5;
+    QpBlk q;
+    q.size = 16 >> __builtin_amdgcn_readfirstlane((int)blk.size_idx);
+    q.mc = __builtin_amdgcn_readfirstlane((int)blk.mcxy) & 15;
+    q.avg = __builtin_amdgcn_readfirstlane((int)blk.avg) != 0;
+    q.soff = __builtin_amdgcn_readfirstlane(blk.src_offset);
+    q.doff = __builtin_amdgcn_readfirstlane(blk.dst_offset);
+    q.rows = q.size + 5;
+    const uint8_t *s0 = src + q.soff - 2 - 2 * stride;
+    q.sh = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 3); /* same for every row: stride % 4 == 0 */
+    q.sa = s0 - q.sh;
+    q.ndw = (int)((q.sh + q.size + 5 + 3) >> 2);                     /* <= 7 */
+    return q;
+}
+/* the footprint: rows y-2 .. y+size+2, the aligned dwords that hold bytes x-2 .. x+size+2; three dwords per lane at most */
+__device__ __forceinline__ void qp_fetch(const QpBlk &q, ptrdiff_t stride, int lane, uint32_t f[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int t = lane + 64 * i, r = t >> 3, j = t & 7;
+        f[i] = (r < q.rows && j < q.ndw) ? *reinterpret_cast<const uint32_t *>(q.sa + (ptrdiff_t)r * stride + 4 * j) : 0;
+    }
+}
+
+__device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t f[3], uint32_t *raw, uint32_t *hb, uint8_t *dst, ptrdiff_t stride, int lane)
+{
+    const int size = q.size, mc = q.mc, rows = q.rows;
+    const uint32_t sh = q.sh;
+    const bool avg = q.avg;
+    const int per_row = size >> 2;
     const int mx = mc & 3, my = mc >> 2;
     const bool useJ = (mx == 2 && my != 0) || (my == 2 && mx != 0);
     const bool useV = (mx != 2 && my != 0) || (mc == 8);
     const bool useH = (my != 2 && mx != 0) || (mc == 2);
     const bool vcol1 = mx == 3, hrow1 = my == 3;
 
-    /* ---- 1. footprint -> LDS: rows y-2 .. y+size+2, the aligned dwords that hold bytes x-2 .. x+size+2 ---- */
-    const uint8_t *s0 = src + soff - 2 - 2 * stride;
-    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 3); /* same for every row: stride % 4 == 0 */
-    const uint8_t *sa = s0 - sh;
-    const int ndw = (int)((sh + size + 5 + 3) >> 2);                     /* <= 7 */
-    for (int t = lane; t < rows * 8; t += 64) {
-        const int r = t >> 3, j = t & 7;
-        if (j < ndw)
-            raw[t] = *reinterpret_cast<const uint32_t *>(sa + (ptrdiff_t)r * stride + 4 * j);
-    }
+    /* ---- 1. footprint -> LDS ---- */
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (lane + 64 * i < rows * 8)
+            raw[lane + 64 * i] = f[i];
     __builtin_amdgcn_wave_barrier();
     auto stream = [&](int row, int xg) { /* 12 bytes from byte x-2+4*xg of a footprint row */
-        const uint32_t *q = raw + row * 8 + xg;
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-        const uint32_t d3 = sh == 3 ? q[3] : 0;
+        const uint32_t *p = raw + row * 8 + xg;
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        const uint32_t d3 = sh == 3 ? p[3] : 0;
         Row12 r;
         r.w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
         r.w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
@@ -241,76 +258,105 @@ __global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t
 
     /* ---- 3. my four samples ---- */
     const int y = lane / per_row, xg = lane - y * per_row;
-    if (y >= size)
+    if (y < size) {
+        uint8_t *d = dst + q.doff + (ptrdiff_t)y * stride + 4 * xg;
+        uint32_t pj = 0, ph = 0, pv = 0, pf = 0;
+        if (useJ) {
+            uint2 h[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                h[k] = *reinterpret_cast<const uint2 *>(hb + (y + k) * 8 + 2 * xg);
+            int v[4];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                auto col = [&](int k) { return __builtin_bit_cast(qp_s2, half ? h[k].y : h[k].x); };
+                const qp_s2 s23 = col(2) + col(3), s14 = col(1) + col(4), s05 = col(0) + col(5); /* |.| <= 21420: int16 */
+                v[2 * half]     = (int)s23.x * 20 - (int)s14.x * 5 + (int)s05.x;
+                v[2 * half + 1] = (int)s23.y * 20 - (int)s14.y * 5 + (int)s05.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                pj |= (uint32_t)clip_u8((v[i] + 512) >> 10) << (8 * i);
+            if (useH) {
+                const uint2 hr = h[hrow1 ? 3 : 2];
+                ph = qp_round5(__builtin_bit_cast(qp_s2, hr.x), __builtin_bit_cast(qp_s2, hr.y));
+            }
+        } else if (useH) {
+            qp_s2 lo, hi;
+            qp_hraw4(stream(y + (hrow1 ? 3 : 2), xg), lo, hi);
+            ph = qp_round5(lo, hi);
+        }
+        if (useV) {
+            /* the column under sample i: stream byte 2 + i (3 + i for the right-hand neighbour) of rows y-2 .. y+3 */
+            const uint32_t o = sh + 2 + (vcol1 ? 1 : 0);
+            qp_s2 c01[6], c23[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const uint32_t *p = raw + (y + k) * 8 + xg + (o >> 2);
+                const uint32_t w = __builtin_amdgcn_alignbyte(p[1], p[0], o & 3);
+                c01[k] = qp_pair(0, w, 0x0c010c00);
+                c23[k] = qp_pair(0, w, 0x0c030c02);
+            }
+            pv = qp_round5(qp_tap6(c01[0], c01[1], c01[2], c01[3], c01[4], c01[5]), qp_tap6(c23[0], c23[1], c23[2], c23[3], c23[4], c23[5]));
+        }
+        {
+            const uint32_t o = sh + (mc == 3 ? 3 : 2);
+            const uint32_t *p = raw + (y + (mc == 12 ? 3 : 2)) * 8 + xg + (o >> 2);
+            pf = __builtin_amdgcn_alignbyte(p[1], p[0], o & 3);
+        }
+        uint32_t out;
+        switch (mc) {
+        case 0:  out = pf; break;
+        case 1: case 3:  out = rnd_avg4(pf, ph); break;
+        case 2:  out = ph; break;
+        case 4: case 12: out = rnd_avg4(pf, pv); break;
+        case 5: case 7: case 13: case 15: out = rnd_avg4(ph, pv); break;
+        case 6: case 14: out = rnd_avg4(ph, pj); break;
+        case 8:  out = pv; break;
+        case 9: case 11: out = rnd_avg4(pv, pj); break;
+        default: out = pj; break; /* 10 */
+        }
+        if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
+            uint32_t *dw = reinterpret_cast<uint32_t *>(d);
+            if (avg)
+                out = rnd_avg4(*dw, out);
+            *dw = out;
+        } else {
+            for (int i = 0; i < 4; i++) {
+                const uint32_t v = (out >> (8 * i)) & 0xFF;
+                d[i] = (uint8_t)(avg ? (d[i] + v + 1) >> 1 : v);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier(); /* the next block of this wave reuses the planes */
+}
+
+/* NB consecutive blocks per wave: their records, then all their footprints, are in flight before the first is computed, so a
+ * wave keeps NB x 3 loads outstanding instead of 3 and pays the record -> footprint -> store latency chain once per NB blocks. */
+template <int NB>
+__global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
+                                                     const FFHipQpelBlock *blocks, int n)
+{
+    __shared__ uint32_t lds[4][21 * 8 + 21 * 8];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int b0 = (blockIdx.x * 4 + wave) * NB;
+    if (b0 >= n)
         return;
-    uint8_t *d = dst + doff + (ptrdiff_t)y * stride + 4 * xg;
-    uint32_t pj = 0, ph = 0, pv = 0, pf = 0;
-    if (useJ) {
-        uint2 h[6];
+    uint32_t *raw = lds[wave];             /* [row][8] aligned source dwords, row 0 = y-2 */
+    uint32_t *hb = lds[wave] + 21 * 8;     /* [row][8] int16 pairs: unclipped horizontal sums of the block's columns */
+    QpBlk q[NB];
+    uint32_t f[NB][3];
 #pragma unroll
-        for (int k = 0; k < 6; k++)
-            h[k] = *reinterpret_cast<const uint2 *>(hb + (y + k) * 8 + 2 * xg);
-        int v[4];
+    for (int k = 0; k < NB; k++)
+        q[k] = qp_blk(blocks, min(b0 + k, n - 1), src, stride);
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            auto col = [&](int k) { return __builtin_bit_cast(qp_s2, half ? h[k].y : h[k].x); };
-            const qp_s2 s23 = col(2) + col(3), s14 = col(1) + col(4), s05 = col(0) + col(5); /* |.| <= 21420: int16 */
-            v[2 * half]     = (int)s23.x * 20 - (int)s14.x * 5 + (int)s05.x;
-            v[2 * half + 1] = (int)s23.y * 20 - (int)s14.y * 5 + (int)s05.y;
-        }
+    for (int k = 0; k < NB; k++)
+        qp_fetch(q[k], stride, lane, f[k]);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            pj |= (uint32_t)clip_u8((v[i] + 512) >> 10) << (8 * i);
-        if (useH) {
-            const uint2 hr = h[hrow1 ? 3 : 2];
-            ph = qp_round5(__builtin_bit_cast(qp_s2, hr.x), __builtin_bit_cast(qp_s2, hr.y));
-        }
-    } else if (useH) {
-        qp_s2 lo, hi;
-        qp_hraw4(stream(y + (hrow1 ? 3 : 2), xg), lo, hi);
-        ph = qp_round5(lo, hi);
-    }
-    if (useV) {
-        /* the column under sample i: stream byte 2 + i (3 + i for the right-hand neighbour) of rows y-2 .. y+3 */
-        const uint32_t o = sh + 2 + (vcol1 ? 1 : 0);
-        qp_s2 c01[6], c23[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const uint32_t *q = raw + (y + k) * 8 + xg + (o >> 2);
-            const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3);
-            c01[k] = qp_pair(0, w, 0x0c010c00);
-            c23[k] = qp_pair(0, w, 0x0c030c02);
-        }
-        pv = qp_round5(qp_tap6(c01[0], c01[1], c01[2], c01[3], c01[4], c01[5]), qp_tap6(c23[0], c23[1], c23[2], c23[3], c23[4], c23[5]));
-    }
-    {
-        const uint32_t o = sh + (mc == 3 ? 3 : 2);
-        const uint32_t *q = raw + (y + (mc == 12 ? 3 : 2)) * 8 + xg + (o >> 2);
-        pf = __builtin_amdgcn_alignbyte(q[1], q[0], o & 3);
-    }
-    uint32_t out;
-    switch (mc) {
-    case 0:  out = pf; break;
-    case 1: case 3:  out = rnd_avg4(pf, ph); break;
-    case 2:  out = ph; break;
-    case 4: case 12: out = rnd_avg4(pf, pv); break;
-    case 5: case 7: case 13: case 15: out = rnd_avg4(ph, pv); break;
-    case 6: case 14: out = rnd_avg4(ph, pj); break;
-    case 8:  out = pv; break;
-    case 9: case 11: out = rnd_avg4(pv, pj); break;
-    default: out = pj; break; /* 10 */
-    }
-    if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
-        uint32_t *dw = reinterpret_cast<uint32_t *>(d);
-        if (avg)
-            out = rnd_avg4(*dw, out);
-        *dw = out;
-    } else {
-        for (int i = 0; i < 4; i++) {
-            const uint32_t v = (out >> (8 * i)) & 0xFF;
-            d[i] = (uint8_t)(avg ? (d[i] + v + 1) >> 1 : v);
-        }
-    }
+    for (int k = 0; k < NB; k++)
+        if (b0 + k < n)
+            qp_block(q[k], f[k], raw, hb, dst, stride, lane);
 }
 
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
@@ -319,8 +365,16 @@ int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, c
     if (n <= 0)
         return 0;
     const char *eo = getenv("FFHIP_QPEL_OLD"); /* measured variant: the register-only kernel */
-    if (!(stride & 3) && !(eo && eo[0] == '1'))
-        hipLaunchKernelGGL(k_h264_qpel_l, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+    const char *en = getenv("FFHIP_QPEL_NB");  /* measured variant: blocks per wave */
+    const int nb = en ? atoi(en) : 4;
+    if (!(stride & 3) && !(eo && eo[0] == '1')) {
+        if (nb >= 4 && n >= 4 * 4096)
+            hipLaunchKernelGGL(k_h264_qpel_l<4>, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+        else if (nb >= 2 && n >= 2 * 4096)
+            hipLaunchKernelGGL(k_h264_qpel_l<2>, dim3(cdiv(n, 8)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+        else
+            hipLaunchKernelGGL(k_h264_qpel_l<1>, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+    }
     else
         hipLaunchKernelGGL(k_h264_qpel, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
     LAUNCH_CHECK();

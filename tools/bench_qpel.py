@@ -38,9 +38,11 @@ def blocks(mc):
     return torch.from_numpy(b.view(np.uint8).reshape(len(b), 12)).to(dev), len(b)
 
 
-for old in ("0", "1"):
+QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"     # the default kernel, mixed positions and plain copies only (PMC runs)
+for old, nb in ((("0", "4"),) if QUICK else (("0", "4"), ("0", "2"), ("0", "1"), ("1", "1"))):
     os.environ["FFHIP_QPEL_OLD"] = old
-    for mc in (-1, 0, 2, 8, 10, 5, 9):
+    os.environ["FFHIP_QPEL_NB"] = nb
+    for mc in ((-1, 0) if QUICK else (-1, 0, 2, 8, 10, 5, 9)):
         d_bl, n = blocks(mc)
         for _ in range(2):
             h264.qpel_batch(dst, ref, stride, d_bl, n)
@@ -52,5 +54,5 @@ for old in ("0", "1"):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         px = n * 256
-        print(json.dumps({"kernel": "regs" if old == "1" else "lds", "mcxy": "mixed" if mc < 0 else mc, "blocks": n, "ms": round(ms, 4),
+        print(json.dumps({"kernel": "regs" if old == "1" else "lds x%s" % nb, "mcxy": "mixed" if mc < 0 else mc, "blocks": n, "ms": round(ms, 4),
                           "Gpixel/s": round(px / ms / 1e6, 1), "hbm_frac": round(2 * px / ms / 1e6 / 8000, 4)}), flush=True)
