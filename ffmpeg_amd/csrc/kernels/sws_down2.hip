@@ -1,0 +1,317 @@
+/*
+ * sws_down2.hip — the fused H+V scaler for EXACT 2:1 down-scaling with banks of up to 8 taps in both directions (bicubic /
+ * bilinear 4K -> 1080p), planes and byte-interleaved U/V pairs (NV12 / NV21) in and out.
+ *
+ * Arithmetic: hScale8To15_c (libswscale/swscale.c:128-142), nv12ToUV_c (input.c:936), yuv2planeX_8_c / yuv2nv12cX_c
+ * (output.c:468-529) — int32 sums, >> 7 and min(., 32767) for the horizontal pass, the 64 << 12 seed, >> 19 and the clip
+ * to 8 bits for the vertical one.  Same results as sws_lwalk.hip / sws_scale.hip, bit for bit (tests/test_gpu_sws_fast.py).
+ *
+ * What exact 2:1 buys over the wide walker (sws_lwalk.hip: a source row's window goes through 9.8 KB of LDS per wave, which
+ * holds the CU at a few waves):
+ *  - Window positions are REGULAR: output x reads source samples 2x - 3 .. 2x + 4 (initFilter, libswscale/utils.c:519-561,
+ *    folds the taps that fall outside the row onto the first / last sample: the regular bank over an edge-REPLICATED row, with
+ *    its own coefficients in the columns next to either edge — ffhip_down2_virtual_bank re-expresses every bank row that way,
+ *    tap by tap, else this kernel is not used).  4 adjacent outputs read 14 adjacent bytes; the SEVEN (s[2m+1], s[2m+2]) int16
+ *    pairs of those bytes serve all sixteen v_dot2_i32_i16 of the row.  No position table, no LDS.
+ *  - The vertical schedule is STATIC and pair-aligned: output row y reads filtered rows 2y-3 .. 2y+4 = the row pairs
+ *    T(y-1) .. T(y+2), T(t) = (row 2t-1, row 2t); a step filters two new source rows, packs them into ONE new pair and keeps a
+ *    ring of four: 4 dots per sample, coefficient pairs in SGPRs (one s_load_dwordx16 per four steps).
+ * Per 4 output samples: 2 x 27 (horizontal, plane; 30 for a U/V pair) + 4 (pack) + 16 + 4 (vertical) VALU instructions = about 20
+ * per sample — a fifth of the chip's issue rate at the HBM roof of the 5 bytes a sample moves.
+ *
+ * Geometry: a wave owns 64 lanes x 4 output bytes of a strip of output rows and walks down the source rows, four rows in
+ * flight.  A lane reads the 16 (pair: 24) source bytes at 8g - 4 (8g - 8) of every source row and writes the dword at 4g.
+ */
+#include <stdlib.h>
+#include <vector>
+
+#include "common.h"
+#include "sws_kernels.h"
+
+typedef short dn_s2 __attribute__((ext_vector_type(2)));
+typedef uint32_t dn_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t dn_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t dn_u16 __attribute__((ext_vector_type(16)));
+typedef dn_u4 __attribute__((aligned(4))) dn_u4a;
+typedef dn_u2 __attribute__((aligned(4))) dn_u2a;
+typedef const uint8_t __attribute__((address_space(1))) *dn_gcp;
+typedef uint8_t __attribute__((address_space(1))) *dn_gp;
+typedef const dn_u4a __attribute__((address_space(1))) *dn_gc4;
+typedef const dn_u2a __attribute__((address_space(1))) *dn_gc2;
+typedef uint32_t __attribute__((address_space(1))) *dn_g1;
+typedef const dn_u16 __attribute__((address_space(4))) *dn_cc16; /* constant address space: scalar loads */
+
+__device__ __forceinline__ int dn_dot(uint32_t p, uint32_t c, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(dn_s2, p), __builtin_bit_cast(dn_s2, c), acc, false);
+}
+
+template <int PAIR>
+__device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gbase, int strip, int lane)
+{
+    constexpr int NQ = PAIR ? 6 : 4, NCF = PAIR ? 8 : 16;
+    const int graw = gbase + lane;
+    const bool act = graw < J.ngroups;
+    const int g = min(graw, J.ngroups - 1);
+    const bool lb = g == 0, rb = g == J.ngroups - 1;
+    const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
+    /* the first / last lane of a row loads its span inside the row and rebuilds the replicated bytes */
+    const uint32_t soff = (uint32_t)(lb ? 0 : 8 * g - (PAIR ? 8 : 4) - (rb ? (PAIR ? 8 : 4) : 0));
+    const uint32_t doff = 4u * (uint32_t)g;
+
+    uint32_t cf[NCF];
+    {
+        const dn_u4 *p = reinterpret_cast<const dn_u4 *>(J.hfv) + (size_t)g * (NCF / 4);
+#pragma unroll
+        for (int i = 0; i < NCF / 4; i++) {
+            const dn_u4 v = p[i];
+            cf[4 * i] = v.x; cf[4 * i + 1] = v.y; cf[4 * i + 2] = v.z; cf[4 * i + 3] = v.w;
+        }
+    }
+    const uint32_t par = PAIR ? (J.swap ? 0x00010001u : 0u) : 0u;
+    const uint32_t selA = 0x0c040c02u + par, selB = 0x0c050c03u - par; /* pair: channel samples 2 bytes apart */
+
+    const int S = J.steps_per_strip;                 /* a multiple of 4 */
+    const int a = strip * S, b = min(a + S, J.dstH); /* this strip's output rows */
+    const uint8_t *sbase = J.src + (size_t)frame * J.sfp;
+    uint8_t *dr = J.dst + (size_t)frame * J.dfp + (ptrdiff_t)a * J.dstride;
+    const ptrdiff_t sstride = J.sstride, dstride = J.dstride;
+    const int srcH = J.srcH;
+    int pr = 2 * a - 3;                              /* next source row to fetch (unclamped) */
+    const uint8_t *pf = sbase + (ptrdiff_t)min(max(pr, 0), srcH - 1) * sstride;
+    asm("" : "+s"(pf), "+s"(dr));
+
+    struct Raw { uint32_t q[NQ]; };
+    auto load_next = [&](Raw &o) {
+        uint32_t off = soff;
+        asm volatile("" : "+v"(off)); /* keeps `uniform base + zext(lane offset)` next to the access: saddr addressing */
+        const dn_u4 w = *(dn_gc4)((dn_gcp)pf + off);
+        o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w;
+        if (PAIR) {
+            const dn_u2 e = *(dn_gc2)((dn_gcp)pf + off + 16);
+            o.q[4] = e.x; o.q[5] = e.y;
+        }
+        pr++;
+        pf += (pr >= 1 && pr <= srcH - 1) ? sstride : 0; /* rows above / below the plane replicate the edge row */
+        asm("" : "+s"(pf));
+    };
+
+    /* horizontal pass of one source row: this lane's 4 samples, >> 7 */
+    auto hpass = [&](const Raw &w, int (&h)[4]) {
+        uint32_t v[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; i++)
+            v[i] = w.q[i];
+        if (border) {
+            if (PAIR) {
+                const uint32_t f0 = __builtin_amdgcn_perm(w.q[0], w.q[0], 0x01000100u), f5 = __builtin_amdgcn_perm(w.q[5], w.q[5], 0x03020302u);
+                v[0] = lb ? f0 : rb ? w.q[2] : w.q[0];
+                v[1] = lb ? f0 : rb ? w.q[3] : w.q[1];
+                v[2] = lb ? w.q[0] : rb ? w.q[4] : w.q[2];
+                v[3] = lb ? w.q[1] : rb ? w.q[5] : w.q[3];
+                v[4] = lb ? w.q[2] : rb ? f5 : w.q[4];
+                v[5] = lb ? w.q[3] : rb ? f5 : w.q[5];
+            } else {
+                const uint32_t f0 = __builtin_amdgcn_perm(w.q[0], w.q[0], 0x00000000u), f3 = __builtin_amdgcn_perm(w.q[3], w.q[3], 0x03030303u);
+                v[0] = lb ? f0 : rb ? w.q[1] : w.q[0];
+                v[1] = lb ? w.q[0] : rb ? w.q[2] : w.q[1];
+                v[2] = lb ? w.q[1] : rb ? w.q[3] : w.q[2];
+                v[3] = lb ? w.q[2] : rb ? f3 : w.q[3];
+            }
+        }
+        if (PAIR) {
+            uint32_t A[5], B[5];
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+                A[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selA);
+                B[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selB);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                int sa = 0, sb = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    sa = dn_dot(A[i + k], cf[4 * i + k], sa);
+                    sb = dn_dot(B[i + k], cf[4 * i + k], sb);
+                }
+                h[2 * i] = sa >> 7;
+                h[2 * i + 1] = sb >> 7;
+            }
+        } else {
+            uint32_t P[7];
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                P[2 * m] = __builtin_amdgcn_perm(v[m + 1], v[m], 0x0c020c01u);
+                P[2 * m + 1] = __builtin_amdgcn_perm(v[m + 1], v[m], 0x0c040c03u);
+            }
+            P[6] = __builtin_amdgcn_perm(v[3], v[3], 0x0c020c01u);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int s = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    s = dn_dot(P[i + k], cf[4 * i + k], s);
+                h[i] = s >> 7;
+            }
+        }
+    };
+    /* two source rows -> one row pair (int16-saturated: equals min(., 32767) + truncation because no sum of the bank can fall
+     * below -32768, host-checked) */
+    auto hpair = [&](const Raw &w0, const Raw &w1, uint32_t (&T)[4]) {
+        int h0[4], h1[4];
+        hpass(w0, h0);
+        hpass(w1, h1);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            T[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(h0[i], h1[i]));
+    };
+
+    Raw buf[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        load_next(buf[k]);
+    /* rows 2a-3 .. 2a+2: the pairs T(a-1), T(a), T(a+1) -> slots 3, 0, 1 (a % 4 == 0) */
+    uint32_t ring[4][4];
+    hpair(buf[0], buf[1], ring[3]);
+    load_next(buf[0]); load_next(buf[1]);
+    hpair(buf[2], buf[3], ring[0]);
+    load_next(buf[2]); load_next(buf[3]);
+    hpair(buf[0], buf[1], ring[1]);
+    load_next(buf[0]); load_next(buf[1]);
+
+    int kround = 64 << 12;
+    asm volatile("" : "+v"(kround));
+    const uint32_t *vt = J.vfv;
+    for (int y = a; y < b; y += 4) {
+        const dn_u16 c16 = *(dn_cc16)(vt + 4 * y);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (y + k < b) { /* uniform */
+                Raw &w0 = buf[(2 * k + 2) & 3], &w1 = buf[(2 * k + 3) & 3];
+                hpair(w0, w1, ring[(k + 2) & 3]);
+                load_next(w0); load_next(w1);
+                const uint32_t c0 = c16[4 * k], c1 = c16[4 * k + 1], c2 = c16[4 * k + 2], c3 = c16[4 * k + 3];
+                int t[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    t[i] = dn_dot(ring[(k + 3) & 3][i], c0, kround);
+                    t[i] = dn_dot(ring[k][i], c1, t[i]);
+                    t[i] = dn_dot(ring[(k + 1) & 3][i], c2, t[i]);
+                    t[i] = dn_dot(ring[(k + 2) & 3][i], c3, t[i]);
+                }
+                uint32_t out;
+                /* clip_u8(t >> 19), four bytes in sample order; the wait states cover a dot result read by the next instruction */
+                asm("s_nop 2\n\t"
+                    "v_ashr_pk_u8_i32 %0, %1, %2, 19\n\t"
+                    "v_ashr_pk_u8_i32 %0, %3, %4, 19 op_sel:[0,0,0,1]"
+                    : "=&v"(out) : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+                uint32_t off = doff;
+                asm volatile("" : "+v"(off));
+                if (act)
+                    *(dn_g1)((dn_gp)dr + off) = out;
+                dr += dstride;
+                asm("" : "+s"(dr));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sws_down2(FFHipDn2Args A)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    uint32_t blk = blockIdx.x;
+    if (A.xcd) {
+        /* workgroup b runs on XCD b % 8 (observed, not promised: speed only): every XCD gets one contiguous eighth of the units,
+         * so that the waves sharing source lines (adjacent column blocks, the halo rows of adjacent strips) meet in one L2 */
+        const uint32_t nb = gridDim.x, x = blk & 7u, sl = blk >> 3, q = nb >> 3, r = nb & 7u;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sl;
+    }
+    const uint32_t gw = blk * 4u + (uint32_t)wave;
+    if (gw >= (uint32_t)A.units_per_frame * (uint32_t)A.nframes)
+        return;
+    const int frame = (int)(gw / (uint32_t)A.units_per_frame);
+    const int u = (int)(gw - (uint32_t)frame * (uint32_t)A.units_per_frame);
+    int j = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
+    const FFHipDn2Job &J = A.job[j];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.pair)
+        dn2_unit<1>(J, frame, cb * 64, strip, lane);
+    else
+        dn2_unit<0>(J, frame, cb * 64, strip, lane);
+}
+
+/* ================================================================================================== */
+/* host side */
+
+/*
+ * Re-express a bank of an exact 2:1 down-scale (at most 8 taps) as coefficients on the REGULAR windows of the edge-replicated
+ * row: output x reads samples clamp(2x - 3 + k), k = 0..7.  Every non-zero tap of the bank row must sit on one of those
+ * samples; taps the reference folded onto the edge sample land on one of the replicas.  Output: n_dst x 4 dwords,
+ * (c0, c1) .. (c6, c7) as int16 pairs.  Returns 0 when the bank is not of this shape.
+ */
+int ffhip_down2_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, std::vector<uint32_t> *out)
+{
+    if (n_src != 2 * n_dst || fsize < 1 || fsize > 16)
+        return 0;
+    out->assign((size_t)n_dst * 4, 0);
+    for (int x = 0; x < n_dst; x++) {
+        const int s0 = 2 * x - 3;
+        int16_t v[8] = { 0 };
+        bool used[8] = { false };
+        for (int i = 0; i < fsize; i++) {
+            const int16_t c = filter[(size_t)x * fsize + i];
+            if (!c)
+                continue;
+            const int p = pos[x] + i;
+            if (p < 0 || p >= n_src)
+                return 0;
+            int k = 0;
+            for (; k < 8; k++) {
+                int q = s0 + k;
+                q = q < 0 ? 0 : q >= n_src ? n_src - 1 : q;
+                if (q == p && !used[k])
+                    break;
+            }
+            if (k == 8)
+                return 0;
+            used[k] = true;
+            v[k] = c;
+        }
+        for (int k = 0; k < 4; k++)
+            (*out)[4 * (size_t)x + k] = (uint16_t)v[2 * k] | ((uint32_t)(uint16_t)v[2 * k + 1] << 16);
+    }
+    return 1;
+}
+
+/* strips of about `want` output rows (a multiple of 4: the row loop is unrolled four times), evened out over the plane */
+void ffhip_down2_plan_job(FFHipDn2Job *j, int want)
+{
+    const int n = cdiv(j->dstH, want);
+    j->steps_per_strip = cdiv(cdiv(j->dstH, n), 4) * 4;
+    j->nstrips = cdiv(j->dstH, j->steps_per_strip);
+    j->ncb = cdiv(j->ngroups, 64);
+}
+
+int ffhip_launch_down2(FFHipDn2Args &A, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    int u = 0;
+    for (int i = 0; i < A.njobs; i++) {
+        A.job[i].unit_begin = u;
+        u += A.job[i].ncb * A.job[i].nstrips;
+    }
+    A.units_per_frame = u;
+    const long long waves = (long long)u * A.nframes;
+    if (waves >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
+        return FFHIP_EINVAL;
+    }
+    hipLaunchKernelGGL(k_sws_down2, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    LAUNCH_CHECK();
+    return 0;
+}

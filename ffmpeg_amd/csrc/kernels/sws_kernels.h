@@ -115,6 +115,32 @@ void ffhip_up2_plan_job(FFHipUp2Job *j, int lanes_per_frame, int want_steps);
 int  ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream);
 
 /*
+ * Exact-2:1 fast path (sws_down2.hip): banks of up to 8 taps re-expressed on the regular windows 2x - 3 .. 2x + 4 of the
+ * edge-replicated rows.  A job is one plane (4 output columns per lane) or one byte-interleaved U/V pair (2 + 2 per lane).
+ */
+struct FFHipDn2Job {
+    const uint8_t *src; uint8_t *dst;   /* pair: the interleaved plane (the lower of the two channel pointers) */
+    ptrdiff_t sstride, dstride;
+    size_t sfp, dfp;
+    int pair, swap;                     /* swap: the channel at the EVEN destination bytes sits at the ODD source bytes */
+    int srcH, dstH;                     /* source rows; output rows = srcH / 2 */
+    int ngroups;                        /* 4-byte destination groups per row: plane dstW / 4, pair dstW / 2 (>= 3) */
+    const uint32_t *hfv;                /* device: virtual horizontal bank, dstW x 4 dwords */
+    const uint32_t *vfv;                /* device: virtual vertical bank, (dstH + 8) x 4 dwords, 64-byte aligned */
+    int ncb, nstrips, steps_per_strip, unit_begin;
+};
+struct FFHipDn2Args {
+    FFHipDn2Job job[3];
+    int njobs, units_per_frame, nframes;
+    int xcd;                            /* XCD-contiguous unit order */
+};
+#ifdef __cplusplus
+int  ffhip_down2_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, std::vector<uint32_t> *out);
+#endif
+void ffhip_down2_plan_job(FFHipDn2Job *j, int want_rows);
+int  ffhip_launch_down2(FFHipDn2Args &A, hipStream_t stream);
+
+/*
  * MFMA-horizontal variant of the fast path (k_sws_mfma in sws_colwalk.hip): a job is one plane or one
  * byte-interleaved U/V pair (NV12/NV21 in and out).
  */

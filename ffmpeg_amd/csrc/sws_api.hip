@@ -47,6 +47,10 @@ struct FFHipSwsContext {
     int up2_ok = 0;
     void *up2_dev = nullptr;
     const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
+    /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
+    int dn2_ok = 0;
+    void *dn2_dev = nullptr;
+    const uint32_t *dn2_h[2] = { nullptr, nullptr }, *dn2_v[2] = { nullptr, nullptr };
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
     int mf_ok = 0, mf_chr_pair = 0, mf_ntiles[2] = { 0, 0 };
     void *mf_dev = nullptr;
@@ -408,6 +412,39 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 c->lw_ok = ok;
             }
         }
+        /* exact 2:1 in both directions, chroma laid out alike on both sides, no horizontal sum leaves int16: the
+         * static-schedule kernel (sws_down2.hip) */
+        if (ffhip_cw_bank_nowrap(c->f[0].data(), c->d[0].size, c->d[0].n) && ffhip_cw_bank_nowrap(c->f[1].data(), c->d[1].size, c->d[1].n) &&
+            l.srcW == 2 * l.dstW && l.srcH == 2 * l.dstH && ch.srcW == 2 * ch.dstW && ch.srcH == 2 * ch.dstH &&
+            fmt_nv(t->srcFormat) == fmt_nv(t->dstFormat) && !(l.dstW & 3) && l.dstW >= 12 &&
+            (fmt_nv(t->srcFormat) ? !(ch.dstW & 1) && ch.dstW >= 6 : !(ch.dstW & 3) && ch.dstW >= 12)) {
+            std::vector<uint32_t> vb[4];
+            const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
+            bool ok = true;
+            for (int i = 0; i < 4 && ok; i++)
+                ok = ffhip_down2_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], &vb[i]) != 0;
+            if (ok) {
+                for (int i = 2; i < 4; i++)
+                    vb[i].resize((size_t)(c->d[i].n + 8) * 4, 0); /* the row loop reads four rows of coefficients at a time */
+                size_t uo[4], ut = 0;
+                for (int i = 0; i < 4; i++) {
+                    uo[i] = ut;
+                    ut += (vb[i].size() * 4 + 255) & ~(size_t)255;
+                }
+                if (hipMalloc(&c->dn2_dev, ut) == hipSuccess) {
+                    uint8_t *b = static_cast<uint8_t *>(c->dn2_dev);
+                    for (int i = 0; i < 4 && ok; i++)
+                        ok = hipMemcpy(b + uo[i], vb[i].data(), vb[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+                    if (ok) {
+                        c->dn2_h[0] = reinterpret_cast<const uint32_t *>(b + uo[0]);
+                        c->dn2_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
+                        c->dn2_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
+                        c->dn2_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
+                        c->dn2_ok = 1;
+                    }
+                }
+            }
+        }
         /* MFMA variant: same banks; chroma either byte-interleaved on both sides or planar on both sides */
         const bool nv_in = fmt_nv(t->srcFormat), nv_out = fmt_nv(t->dstFormat);
         if (c->cw_opt && nv_in == nv_out) {
@@ -469,7 +506,7 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -496,6 +533,15 @@ extern "C" int ffhip_sws_up2_virtual_bank_host(const int16_t *filter, const int3
     return 1;
 }
 
+extern "C" int ffhip_sws_down2_virtual_bank_host(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, uint32_t *out)
+{
+    std::vector<uint32_t> v;
+    if (!filter || !pos || !out || !ffhip_down2_virtual_bank(filter, pos, fsize, n_dst, n_src, &v))
+        return 0;
+    memcpy(out, v.data(), v.size() * 4);
+    return 1;
+}
+
 extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
 {
     if (!c)
@@ -506,6 +552,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->mf_dev);
     if (c->up2_dev)
         (void)hipFree(c->up2_dev);
+    if (c->dn2_dev)
+        (void)hipFree(c->dn2_dev);
     if (c->dev_ntables)
         (void)hipFree(c->dev_ntables);
     if (c->dev_wtables)
@@ -761,6 +809,44 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             }
             return ffhip_launch_colwalk(A, lg, depth, stream);
         }
+    }
+    uintptr_t al2 = (uintptr_t)l.src[0] | (size_t)l.src_stride[0] | l.src_fp[0] | (uintptr_t)l.dst[0] | (size_t)l.dst_stride[0] | l.dst_fp[0];
+    for (int i = 0; i < 2; i++) {
+        al2 |= (size_t)ch.src_stride[i] | ch.src_fp[i] | (size_t)ch.dst_stride[i] | ch.dst_fp[i];
+        al2 |= ch.src_step == 2 ? (uintptr_t)(ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1]) : (uintptr_t)ch.src[i];
+        al2 |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
+    }
+    const char *e2 = getenv("FFHIP_SWS_DOWN2");
+    bool neg = false;
+    for (int i = 0; i < 2; i++)
+        neg = neg || l.src_stride[i] < 0 || l.dst_stride[i] < 0 || ch.src_stride[i] < 0 || ch.dst_stride[i] < 0;
+    if (!(al2 & 3) && c->dn2_ok && !neg && !(e2 && e2[0] == '0') && !(ev && ev[0] == '0')) {
+        /* exact 2:1: static schedule, regular windows, no LDS (sws_down2.hip).  FFHIP_SWS_DOWN2=0 takes the wide walker. */
+        FFHipDn2Args D;
+        memset(&D, 0, sizeof(D));
+        D.nframes = nframes;
+        const char *ex = getenv("FFHIP_DN2_XCD"), *es = getenv("FFHIP_DN2_STRIP");
+        D.xcd = !(ex && ex[0] == '0');
+        auto dnjob = [&](const FFHipScalePlaneArgs &p, int which, const uint8_t *src, ptrdiff_t ss, size_t sf, uint8_t *dst,
+                         ptrdiff_t dsr, size_t df, int pair, int swap) {
+            FFHipDn2Job &j = D.job[D.njobs++];
+            j.src = src; j.dst = dst; j.sstride = ss; j.dstride = dsr; j.sfp = sf; j.dfp = df;
+            j.pair = pair; j.swap = swap;
+            j.srcH = p.srcH; j.dstH = p.dstH;
+            j.ngroups = pair ? p.dstW / 2 : p.dstW / 4;
+            j.hfv = c->dn2_h[which]; j.vfv = c->dn2_v[which];
+            ffhip_down2_plan_job(&j, es && atoi(es) > 0 ? atoi(es) : 32); /* measured: 28..36 rows per strip */
+        };
+        dnjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
+        if (ch.src_step == 2) {
+            const bool ssw = ch.src[1] < ch.src[0], dsw = ch.dst[1] < ch.dst[0];
+            dnjob(ch, 1, ssw ? ch.src[1] : ch.src[0], ch.src_stride[0], ch.src_fp[0], dsw ? ch.dst[1] : ch.dst[0],
+                  ch.dst_stride[0], ch.dst_fp[0], 1, ssw != dsw);
+        } else {
+            for (int k = 0; k < 2; k++)
+                dnjob(ch, 1, ch.src[k], ch.src_stride[k], ch.src_fp[k], ch.dst[k], ch.dst_stride[k], ch.dst_fp[k], 0, 0);
+        }
+        return ffhip_launch_down2(D, stream);
     }
     /* wide banks: the LDS-backed walker (FFHIP_SWS_WIDE=0 forces the LDS-tiled kernel) */
     const char *ew = getenv("FFHIP_SWS_WIDE");

@@ -112,6 +112,11 @@ class SwsContext:
         """True when the static-schedule exact-2x kernel (k_sws_up2) serves the banks."""
         return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 8)
 
+    @property
+    def down2_path(self):
+        """True when the static-schedule exact-2:1 kernel (k_sws_down2) serves the banks."""
+        return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 16)
+
     def close(self):
         if getattr(self, "_c", None) and _lib is not None:
             _lib.lib().ffhip_sws_freeContext(self._c)

@@ -143,6 +143,10 @@ int              ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t 
  *  int16 pairs.  Returns 1, or 0 when some tap of the bank does not sit on its regular window (the kernel is then not
  *  used).  Exposed for the CPU test-suite. */
 int              ffhip_sws_up2_virtual_bank_host(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, uint32_t *out);
+/** The same for the exact-2:1 kernel (sws_down2.hip): a bank of `fsize` <= 16 taps of a 2:1 down-scale (n_src == 2 n_dst) as
+ *  eight coefficients per output on the regular window 2x - 3 .. 2x + 4 of the edge-replicated row.  out: n_dst x 4 dwords,
+ *  (c0, c1) .. (c6, c7).  Returns 1, or 0 when some tap does not sit on its regular window. */
+int              ffhip_sws_down2_virtual_bank_host(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, uint32_t *out);
 
 /** Host-table generation alone (no device needed): our initFilter().  `which`: 0 hLum 1 hChr 2 vLum
  *  3 vChr.  Returns filter size or <0; pointers stay valid until ffhip_sws_tables_free().  Used by

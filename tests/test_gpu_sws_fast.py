@@ -50,8 +50,11 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     from ffmpeg_amd import swscale as S
     torch = _torch()
     rng = np.random.default_rng(seed)
-    for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD"):
+    for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD",
+              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP"):
         monkeypatch.delenv(k, raising=False)
+    if need != "down2":
+        monkeypatch.setenv("FFHIP_SWS_DOWN2", "0")  # test_down2* covers sws_down2.hip
     if need != "up2":
         monkeypatch.setenv("FFHIP_SWS_UP2", "0")   # these tests are about the general kernels; test_up2* covers sws_up2.hip
     for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
@@ -79,6 +82,8 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
         assert ctx.up2_path, "case does not reach the exact-2x kernel"
     elif need == "wide":
         assert ctx.wide_path, "case does not reach the wide-bank walker"
+    elif need == "down2":
+        assert ctx.down2_path, "case does not reach the exact-2:1 kernel"
     elif need == "fast":
         assert ctx.fast_path, "case does not reach the column walker"
     if (env or {}).get("FFHIP_SWS_MFMA") == "1" and need_mfma:
@@ -446,3 +451,44 @@ def test_wide_path_on_narrow_banks(case, monkeypatch):
 
 def test_wide_path_full_size(monkeypatch):
     _run("nv12", 3840, 2160, "nv12", 1920, 1080, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=80, need="wide")
+
+
+# ---------------------------------------------------------------------------------------------
+# exact 2:1 down-scaling on the static-schedule kernel (sws_down2.hip)
+DOWN2_CASES = [
+    ("nv12", 384, 216, "nv12", 192, 108, ffi.SWS_BICUBIC),           # 8 x 8 taps, one column block, two strips
+    ("nv21", 384, 216, "nv21", 192, 108, ffi.SWS_BICUBIC),
+    ("nv12", 384, 216, "nv21", 192, 108, ffi.SWS_BICUBIC),           # the channels change places
+    ("nv21", 384, 216, "nv12", 192, 108, ffi.SWS_BICUBIC),
+    ("yuv420p", 384, 216, "yuv420p", 192, 108, ffi.SWS_BICUBIC),     # three single-plane jobs
+    ("nv12", 384, 216, "nv12", 192, 108, ffi.SWS_BILINEAR),          # 4 taps inside the 8-sample windows
+    ("nv12", 48, 16, "nv12", 24, 8, ffi.SWS_BICUBIC),                # the smallest: 6 / 3 groups, both edge lanes adjacent
+    ("yuv420p", 48, 48, "yuv420p", 24, 24, ffi.SWS_BICUBIC),         # chroma 12 wide: 3 groups
+    ("nv12", 2096, 1416, "nv12", 1048, 708, ffi.SWS_BICUBIC),        # several column blocks and strips, ragged last block
+    ("yuv420p", 2576, 96, "yuv420p", 1288, 48, ffi.SWS_BICUBIC),     # ragged last block, planar
+    ("nv12", 512, 492, "nv12", 256, 246, ffi.SWS_BICUBIC),           # dstH % 4 != 0: the last step group is cut
+    ("nv12", 1032, 16, "nv12", 516, 8, ffi.SWS_BICUBIC),             # chroma: as many source rows as taps, every window touches an edge
+    ("nv12", 520, 500, "nv12", 260, 250, ffi.SWS_BICUBIC),           # chroma 130 wide: a width the wide walker does not take
+    ("nv12", 1032, 8, "nv12", 516, 4, ffi.SWS_BICUBIC),              # fewer chroma rows than taps
+]
+
+
+@pytest.mark.parametrize("env", [{}, {"FFHIP_DN2_XCD": "0"}, {"FFHIP_DN2_STRIP": "8"}],
+                         ids=lambda e: ",".join("%s=%s" % (k[6:], v) for k, v in e.items()) or "default")
+@pytest.mark.parametrize("case", DOWN2_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_down2(case, env, monkeypatch):
+    _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="down2")
+
+
+def test_down2_full_size(monkeypatch):
+    _run("nv12", 3840, 2160, "nv12", 1920, 1080, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=81, need="down2")
+
+
+def test_down2_not_taken(monkeypatch):
+    """shapes the kernel does not serve: interleaved -> planar, a width off the 4-column grid, another ratio"""
+    from ffmpeg_amd import swscale as S
+    for sf, sw, sh, df, dw, dh in (("nv12", 384, 216, "yuv420p", 192, 108), ("nv12", 388, 216, "nv12", 194, 108),
+                                   ("nv12", 384, 216, "nv12", 192, 72)):
+        ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], ffi.SWS_BICUBIC)
+        assert not ctx.down2_path
+        ctx.close()
