@@ -46,6 +46,100 @@ __device__ __forceinline__ int dn_dot(uint32_t p, uint32_t c, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(dn_s2, p), __builtin_bit_cast(dn_s2, c), acc, false);
 }
 
+
+/*
+ * The dots of a row are hand-scheduled asm blocks (as in sws_up2.hip): VOP3P v_dot2_i32_i16 with an inline 0 / the seed as the
+ * first addend (the compiler's v_dot2c form costs a v_mov per chain), four chains interleaved so that every DOT result is read
+ * by a non-DOT instruction >= 3 instructions after it was written (the gfx950 DOT hazard), and every value that leaves a block
+ * is the result of a plain VALU instruction.
+ */
+/* plane: d[i] = (sum_k P[i + k] . cf[4 i + k]) >> 7 */
+__device__ __forceinline__ void dn_h4_plane(int (&d)[4], const uint32_t (&P)[7], const uint32_t (&cf)[16])
+{
+    asm("v_dot2_i32_i16 %0, %4, %11, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %15, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %19, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %23, 0\n\t"
+        "v_dot2_i32_i16 %0, %5, %12, %0\n\t"
+        "v_dot2_i32_i16 %1, %6, %16, %1\n\t"
+        "v_dot2_i32_i16 %2, %7, %20, %2\n\t"
+        "v_dot2_i32_i16 %3, %8, %24, %3\n\t"
+        "v_dot2_i32_i16 %0, %6, %13, %0\n\t"
+        "v_dot2_i32_i16 %1, %7, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %8, %21, %2\n\t"
+        "v_dot2_i32_i16 %3, %9, %25, %3\n\t"
+        "v_dot2_i32_i16 %0, %7, %14, %0\n\t"
+        "v_dot2_i32_i16 %1, %8, %18, %1\n\t"
+        "v_dot2_i32_i16 %2, %9, %22, %2\n\t"
+        "v_dot2_i32_i16 %3, %10, %26, %3\n\t"
+        "v_ashrrev_i32 %0, 7, %0\n\t"
+        "v_ashrrev_i32 %1, 7, %1\n\t"
+        "v_ashrrev_i32 %2, 7, %2\n\t"
+        "v_ashrrev_i32 %3, 7, %3"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(P[5]), "v"(P[6]),
+          "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]), "v"(cf[6]), "v"(cf[7]),
+          "v"(cf[8]), "v"(cf[9]), "v"(cf[10]), "v"(cf[11]), "v"(cf[12]), "v"(cf[13]), "v"(cf[14]), "v"(cf[15]));
+}
+/* pair: d[0] = A[0..3] . cf[0..3], d[1] = B[0..3] . cf[0..3], d[2] = A[1..4] . cf[4..7], d[3] = B[1..4] . cf[4..7], each >> 7 */
+__device__ __forceinline__ void dn_h4_pair(int (&d)[4], const uint32_t (&A)[5], const uint32_t (&B)[5], const uint32_t (&cf)[8])
+{
+    asm("v_dot2_i32_i16 %0, %4, %14, 0\n\t"
+        "v_dot2_i32_i16 %1, %9, %14, 0\n\t"
+        "v_dot2_i32_i16 %2, %5, %18, 0\n\t"
+        "v_dot2_i32_i16 %3, %10, %18, 0\n\t"
+        "v_dot2_i32_i16 %0, %5, %15, %0\n\t"
+        "v_dot2_i32_i16 %1, %10, %15, %1\n\t"
+        "v_dot2_i32_i16 %2, %6, %19, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "v_dot2_i32_i16 %0, %6, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %11, %16, %1\n\t"
+        "v_dot2_i32_i16 %2, %7, %20, %2\n\t"
+        "v_dot2_i32_i16 %3, %12, %20, %3\n\t"
+        "v_dot2_i32_i16 %0, %7, %17, %0\n\t"
+        "v_dot2_i32_i16 %1, %12, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %8, %21, %2\n\t"
+        "v_dot2_i32_i16 %3, %13, %21, %3\n\t"
+        "v_ashrrev_i32 %0, 7, %0\n\t"
+        "v_ashrrev_i32 %1, 7, %1\n\t"
+        "v_ashrrev_i32 %2, 7, %2\n\t"
+        "v_ashrrev_i32 %3, 7, %3"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]),
+          "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]), "v"(cf[6]), "v"(cf[7]));
+}
+/* one output row of 4 samples: t[i] = kround + sum_k R_k[i] . c_k, bytes clip_u8(t[i] >> 19) packed in sample order */
+__device__ __forceinline__ uint32_t dn_v4(const uint32_t (&R0)[4], const uint32_t (&R1)[4], const uint32_t (&R2)[4], const uint32_t (&R3)[4],
+                                          uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int kround)
+{
+    uint32_t out;
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %1, %5, %21, %25\n\t"
+        "v_dot2_i32_i16 %2, %6, %21, %25\n\t"
+        "v_dot2_i32_i16 %3, %7, %21, %25\n\t"
+        "v_dot2_i32_i16 %4, %8, %21, %25\n\t"
+        "v_dot2_i32_i16 %1, %9, %22, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %22, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %22, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %22, %4\n\t"
+        "v_dot2_i32_i16 %1, %13, %23, %1\n\t"
+        "v_dot2_i32_i16 %2, %14, %23, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %23, %3\n\t"
+        "v_dot2_i32_i16 %4, %16, %23, %4\n\t"
+        "v_dot2_i32_i16 %1, %17, %24, %1\n\t"
+        "v_dot2_i32_i16 %2, %18, %24, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %24, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %24, %4\n\t"
+        "v_ashr_pk_u8_i32 %0, %1, %2, 19\n\t"
+        "s_nop 1\n\t"
+        "v_ashr_pk_u8_i32 %0, %3, %4, 19 op_sel:[0,0,0,1]"
+        : "=&v"(out), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(R0[0]), "v"(R0[1]), "v"(R0[2]), "v"(R0[3]), "v"(R1[0]), "v"(R1[1]), "v"(R1[2]), "v"(R1[3]),
+          "v"(R2[0]), "v"(R2[1]), "v"(R2[2]), "v"(R2[3]), "v"(R3[0]), "v"(R3[1]), "v"(R3[2]), "v"(R3[3]),
+          "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(kround));
+    return out;
+}
+
 template <int PAIR>
 __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gbase, int strip, int lane)
 {
@@ -119,24 +213,14 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
                 v[3] = lb ? w.q[2] : rb ? f3 : w.q[3];
             }
         }
-        if (PAIR) {
+        if constexpr (PAIR != 0) {
             uint32_t A[5], B[5];
 #pragma unroll
             for (int m = 0; m < 5; m++) {
                 A[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selA);
                 B[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selB);
             }
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                int sa = 0, sb = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    sa = dn_dot(A[i + k], cf[4 * i + k], sa);
-                    sb = dn_dot(B[i + k], cf[4 * i + k], sb);
-                }
-                h[2 * i] = sa >> 7;
-                h[2 * i + 1] = sb >> 7;
-            }
+            dn_h4_pair(h, A, B, cf);
         } else {
             uint32_t P[7];
 #pragma unroll
@@ -145,14 +229,7 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
                 P[2 * m + 1] = __builtin_amdgcn_perm(v[m + 1], v[m], 0x0c040c03u);
             }
             P[6] = __builtin_amdgcn_perm(v[3], v[3], 0x0c020c01u);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int s = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    s = dn_dot(P[i + k], cf[4 * i + k], s);
-                h[i] = s >> 7;
-            }
+            dn_h4_plane(h, P, cf);
         }
     };
     /* two source rows -> one row pair (int16-saturated: equals min(., 32767) + truncation because no sum of the bank can fall
@@ -191,20 +268,7 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
                 hpair(w0, w1, ring[(k + 2) & 3]);
                 load_next(w0); load_next(w1);
                 const uint32_t c0 = c16[4 * k], c1 = c16[4 * k + 1], c2 = c16[4 * k + 2], c3 = c16[4 * k + 3];
-                int t[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    t[i] = dn_dot(ring[(k + 3) & 3][i], c0, kround);
-                    t[i] = dn_dot(ring[k][i], c1, t[i]);
-                    t[i] = dn_dot(ring[(k + 1) & 3][i], c2, t[i]);
-                    t[i] = dn_dot(ring[(k + 2) & 3][i], c3, t[i]);
-                }
-                uint32_t out;
-                /* clip_u8(t >> 19), four bytes in sample order; the wait states cover a dot result read by the next instruction */
-                asm("s_nop 2\n\t"
-                    "v_ashr_pk_u8_i32 %0, %1, %2, 19\n\t"
-                    "v_ashr_pk_u8_i32 %0, %3, %4, 19 op_sel:[0,0,0,1]"
-                    : "=&v"(out) : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+                const uint32_t out = dn_v4(ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround);
                 uint32_t off = doff;
                 asm volatile("" : "+v"(off));
                 if (act)
