@@ -179,7 +179,7 @@ def extras(torch, dev):
     out["sws_host_pointer_end_to_end"] = {"Mpixels/s": round(DST_W * DST_H / t / 1e6, 1), "ms_per_frame": round(t * 1e3, 3),
                                           "note": "ffhip_sws_scale on pageable host memory, one frame per call: H2D + kernel + D2H"}
     hc.close()
-    # down-scaling (8 x 8-tap banks: the LDS-backed wide walker) and scaled packed-RGB output (column walker + yuv2rgb)
+    # down-scaling (8 x 8-tap banks at exact 2:1: k_sws_down2) and scaled packed-RGB output (column walker + yuv2rgb)
     sws_case("sws_nv12_4k_to_1080p_bicubic", 23, 3840, 2160, 23, 1920, 1080, 64)
     sws_case("sws_yuv420p_1080p_to_rgb24_4k_bicubic", 0, 1920, 1080, 2, 3840, 2160, 32)
     # H.264 8x8 IDCT + add over 32 4K luma planes (129,600 blocks each, 384 B/block)
