@@ -41,6 +41,7 @@ struct TxDev {
     int nblocks2;
     int max_cnt, ahead;        /* largest butterfly list of a level; 1: fetch lists/twiddles one level ahead (FFHIP_TX_AHEAD) */
     int cos_off[16], sched_off[16], sched_cnt[16];
+    int half;                  /* forward RDFT: 1 real-to-real, 2 real-to-imaginary output */
 };
 
 /* 2 * F * 2^k MDCT lengths, F = 3, 5, 7, 9, 15 (ff_tx_mdct_pfa_<F>xM): per-transform geometry and the extra tables of the
@@ -56,6 +57,7 @@ struct TxPfa {
 
 struct FFHipTXContext {
     int type, inv, len;
+    int half = 0;            /* AV_TX_REAL_TO_REAL / _IMAGINARY (1 / 2) */
     int full = 0;            /* AV_TX_FULL_IMDCT: the inverse writes 2 * len outputs (half transform in the middle, mirrored) */
     float scale;
     TxDev d;
@@ -625,7 +627,44 @@ __global__ __launch_bounds__(1024) void k_rdft(TxDev d, const uint8_t *blob, int
         }
         tx_wave_sync();
         tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
-        if (!INV) {
+        if (!INV && d.half) {
+            /* ff_tx_rdft_r2r / _r2i (tx_template.c:1718-1830, the len % 4 == 0 codelets): only the real / only the imaginary parts
+             * of the bins, len/2 + 1 resp. len/2 floats.  The reference works in place over the FFT's output and reads every value
+             * before it overwrites it, so this is the same function of the FFT output; bin len/4 enters the loop AFTER its two
+             * scalings, tcos[len/4] is tsin[0] and tsin[len/4] the zero behind the table, and r2i's out[len/2 - 1] is the FFT's own
+             * data[len/2 - 1].im (the copy loop reads a slot the loop never wrote). */
+            float *o = reinterpret_cast<float *>(out2);
+            const float2 d4 = z[TX_PAD(len4)];
+            const float2 s4 = make_float2(f2 * d4.x, f3 * d4.y);
+            for (int i = lane; i <= len4; i += 64) {
+                if (i == 0) {
+                    if (d.half == 1) {
+                        const float2 v = z[TX_PAD(0)];
+                        o[0] = f0 * (v.x + v.y);
+                        o[len2] = f1 * (v.x - v.y);
+                    } else {
+                        o[len2 - 1] = z[TX_PAD(len2 - 1)].y;
+                    }
+                } else {
+                    const float2 sf = i == len4 ? s4 : z[TX_PAD(i)], sl = i == len4 ? s4 : z[TX_PAD(len2 - i)];
+                    const float t1 = f6 * (sf.y + sl.y), t2 = f7 * (sf.x - sl.x);
+                    const float c = tcos[i], sn = tsin[i];
+                    if (d.half == 1) {
+                        const float t0 = f4 * (sf.x + sl.x);
+                        const float t3 = t1 * c - t2 * sn;
+                        o[i] = t0 + t3;
+                        if (i < len4)
+                            o[len2 - i] = t0 - t3;
+                    } else {
+                        const float t0 = f5 * (sf.y - sl.y);
+                        const float t3 = t1 * sn + t2 * c;
+                        o[i - 1] = t3 - t0;
+                        if (i < len4)
+                            o[len2 - 1 - i] = t0 + t3;
+                    }
+                }
+            }
+        } else if (!INV) {
             for (int i = lane; i <= len4; i += 64) {
                 if (i == 0) {
                     const float2 v = z[TX_PAD(0)];
@@ -1286,9 +1325,14 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     if (dct && inv)
         len *= 2; /* ff_tx_dct_init (tx_template.c:1844-1848): the inverse is initialised with half its length ... */
     const float rscale = dct && inv ? *scale * 0.5f : *scale; /* ... and its RDFT with half the scale */
-    if (rdft && !dct && (flags & (FFHIP_TX_REAL_TO_REAL | FFHIP_TX_REAL_TO_IMAGINARY))) {
-        ffhip_set_error("ffhip_tx_init: the half-complex RDFT variants (AV_TX_REAL_TO_REAL / _IMAGINARY) are not on the hip path");
-        return FFHIP_ENOSYS;
+    int half = 0;
+    if (type == FFHIP_TX_FLOAT_RDFT && (flags & (FFHIP_TX_REAL_TO_REAL | FFHIP_TX_REAL_TO_IMAGINARY))) {
+        /* ff_tx_rdft_r2r / _r2i (tx_template.c:1718-1830) are FF_TX_FORWARD_ONLY */
+        if (inv) {
+            ffhip_set_error("ffhip_tx_init: AV_TX_REAL_TO_REAL / _IMAGINARY are forward-only");
+            return FFHIP_EINVAL;
+        }
+        half = flags & FFHIP_TX_REAL_TO_REAL ? 1 : 2;
     }
     if (rdft && (len < 8 || len > 4096 || (len & (len - 1)))) {
         ffhip_set_error("ffhip_tx_init: %s len %d not a power of two in 8..4096", dct ? "DCT" : "RDFT", len);
@@ -1323,6 +1367,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         return FFHIP_ENOMEM;
     c->type = type; c->inv = !!inv; c->len = rdft ? 2 * len : len; c->scale = *scale;
     c->full = type == FFHIP_TX_FLOAT_MDCT && inv && (flags & FFHIP_TX_FULL_IMDCT);
+    c->half = half;
     if (pfa) {
         const int r = tx_init_pfa(c, *scale, pfa_f);
         if (r < 0) {
@@ -1347,7 +1392,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         map[p] = i;
     }
     /* exp table (ff_tx_mdct_gen_exp) */
-    std::vector<float2> ex(dct ? 4 + n / 2 + 3 * n / 2 : rdft ? 4 + n / 2 : fft ? 2 : n); /* an FFT has no twiddle table of its own: keep its LDS blob small */
+    std::vector<float2> ex(dct ? 4 + n / 2 + 3 * n / 2 : rdft ? 4 + n / 2 + 1 : fft ? 2 : n); /* RDFT: one zero behind tsin[], which r2r / r2i read at i = len/4 */ /* an FFT has no twiddle table of its own: keep its LDS blob small */
     if (rdft) {
         /* ff_tx_rdft_init (tx_template.c:1601-1655): fact[8], tcos[len/4], tsin[len/4], doubles stored as floats */
         const int rl = 2 * n, len4 = rl / 4;
@@ -1358,7 +1403,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
         tab[2] = (float)m;
         tab[3] = (float)-m;
         tab[4] = (float)((0.5 - 0.0) * m);
-        tab[5] = (float)((0.0 - 0.5) * m);
+        tab[5] = half == 1 ? 1 / rscale : (float)((0.0 - 0.5) * m); /* r2r: 1 / s->scale_f */
         tab[6] = (float)((0.5 - c->inv) * m);
         tab[7] = (float)(-(0.5 - c->inv) * m);
         for (int i = 0; i < len4; i++) {
@@ -1392,6 +1437,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     TxDev &d = c->d;
     memset(&d, 0, sizeof(d));
     d.n = n; d.lg = lg;
+    d.half = c->half;
     for (int l = 2; l <= lg; l++) {
         const int m = 1 << l;
         const double freq = 2 * M_PI / m;
@@ -1735,8 +1781,9 @@ static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
     const bool fft = s->type == FFHIP_TX_FLOAT_FFT || rdft || dct; /* contiguous on both sides */
     /* RDFT: len reals <-> len/2 + 1 complex bins; DCT: len reals <-> len reals (the reference's scribbles into its input and
      * behind the forward output, tx.h:100-102, are not reproduced) */
+    /* half-complex RDFT: len/2 + 1 real resp. len/2 imaginary parts */
     const size_t in_elems = dct ? (size_t)len : rdft ? (size_t)(s->inv ? len + 2 : len) : fft ? (size_t)2 * len : s->inv ? (size_t)len : (size_t)2 * len;
-    const size_t out_elems = dct ? (size_t)len : rdft ? (size_t)(s->inv ? len : len + 2) : fft || s->full ? (size_t)2 * len : (size_t)len;
+    const size_t out_elems = s->half ? (size_t)(len / 2 + (s->half == 1)) : dct ? (size_t)len : rdft ? (size_t)(s->inv ? len : len + 2) : fft || s->full ? (size_t)2 * len : (size_t)len;
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     /* the strided side is packed on the host so that the device sees contiguous data */
     std::vector<float> hin(in_elems), hout(out_elems);

@@ -1142,8 +1142,10 @@ typedef struct FFHipTXContext FFHipTXContext;
                                    inverse is initialised with half the number of samples it transforms */
 #define FFHIP_TX_FULL_IMDCT        (1ULL << 2)   /* == AV_TX_FULL_IMDCT: an inverse MDCT writes 2 * len outputs (ff_tx_mdct_inv_full,
                                                   * libavutil/tx_template.c:1391-1408); batches: 8-byte aligned rows of 2 * len floats */
-#define FFHIP_TX_REAL_TO_REAL      (1ULL << 3)   /* == AV_TX_REAL_TO_REAL: not on the hip path (ENOSYS)      */
-#define FFHIP_TX_REAL_TO_IMAGINARY (1ULL << 4)   /* == AV_TX_REAL_TO_IMAGINARY: not on the hip path (ENOSYS) */
+#define FFHIP_TX_REAL_TO_REAL      (1ULL << 3)   /* == AV_TX_REAL_TO_REAL: a forward RDFT writes the len/2 + 1 real parts only (ff_tx_rdft_r2r,
+                                                  * libavutil/tx_template.c:1718-1827)                                                  */
+#define FFHIP_TX_REAL_TO_IMAGINARY (1ULL << 4)   /* == AV_TX_REAL_TO_IMAGINARY: ... the len/2 imaginary parts only (ff_tx_rdft_r2i, :1829); the last one
+                                                  * is, as in the reference, the underlying FFT's own value.  Both forward-only (EINVAL otherwise) */
 /** av_tx_fn (libavutil/tx.h:151) with an opaque context of ours in place of AVTXContext. */
 typedef void (*ffhip_tx_fn)(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
 /**

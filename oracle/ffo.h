@@ -187,6 +187,8 @@ void   ffo_imdct_full_run(const FfoTx *s, float *out, const float *in); /* AV_TX
 void   ffo_fft_run(int inv, int len, float *out, const float *in);
 /* AV_TX_FLOAT_RDFT, power-of-two: inv == 0: in = len reals, out = len/2 + 1 complex; inv == 1: the other way round */
 void   ffo_rdft_run(int inv, int len, float scale, float *out, const float *in);
+/* mode 1: AV_TX_REAL_TO_REAL (len/2 + 1 floats out), 2: AV_TX_REAL_TO_IMAGINARY (len/2 floats out); forward, len a power of two >= 8 */
+void   ffo_rdft_half_run(int mode, int len, float scale, float *out, const float *in);
 /* AV_TX_FLOAT_DCT: DCT-II (inv 0) / DCT-III (inv 1) of n real samples, n a power of two (tx_template.c:1832-2002) */
 void   ffo_dct_run(int inv, int n, float scale, float *out, const float *in);
 /* double-precision cosine-sum definition (ff_tx_mdct_naive_fwd/_inv, tx_template.c:1144-1193) */

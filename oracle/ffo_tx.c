@@ -693,6 +693,72 @@ void ffo_rdft_run(int inv, int len, float scale, float *out, const float *in)
 }
 
 /*
+ * AV_TX_FLOAT_RDFT with AV_TX_REAL_TO_REAL (mode 1) / AV_TX_REAL_TO_IMAGINARY (mode 2), len % 4 == 0, power of two:
+ * ff_tx_rdft_r2r / ff_tx_rdft_r2i (libavutil/tx_template.c:1718-1830; forward only).  len reals -> the real parts of bins
+ * 0 .. len/2 (len/2 + 1 floats) resp. len/2 floats of imaginary parts.  The reference runs in place over the FFT's output,
+ * one float array aliasing the complex one; it is restated the same way (the buffer is the FFT output, `o` aliases it), so
+ * the table quirks come out by themselves: bin len/4 enters the loop after its two scalings, tcos[len/4] is tsin[0],
+ * tsin[len/4] is the zero of the reference's over-sized, zeroed table, and r2i's last output is the FFT's own
+ * data[len/2 - 1].im, which the copy loop picks up from a slot the main loop never writes.
+ */
+void ffo_rdft_half_run(int mode, int len, float scale, float *out, const float *in)
+{
+    const int len2 = len >> 1, len4 = len >> 2;
+    const double f = 2 * M_PI / len, m = (double)scale;
+    float fact[8];
+    float *tcos = calloc(2 * len4 + 1, sizeof(float)), *tsin = tcos + len4;
+    cpx *data = malloc(sizeof(cpx) * (len2 + 1));
+    float *o = (float *)data;
+    float tmp_dc;
+    fact[0] = (float)(1.0 * m);
+    fact[1] = (float)(1.0 * m);
+    fact[2] = (float)m;
+    fact[3] = (float)-m;
+    fact[4] = (float)((0.5 - 0.0) * m);
+    fact[5] = mode == 1 ? 1 / scale : (float)((0.0 - 0.5) * m);
+    fact[6] = (float)((0.5 - 0) * m);
+    fact[7] = (float)(-(0.5 - 0) * m);
+    for (int i = 0; i < len4; i++) {
+        tcos[i] = (float)cos(i * f);
+        tsin[i] = (float)(cos(((len - i * 4) / 4.0) * f) * -1);
+    }
+    ffo_fft_run(0, len2, (float *)data, in);
+    tmp_dc = data[0].re;
+    data[0].re = tmp_dc + data[0].im;
+    tmp_dc = tmp_dc - data[0].im;
+    data[0].re = fact[0] * data[0].re;
+    tmp_dc = fact[1] * tmp_dc;
+    data[len4].re = fact[2] * data[len4].re;
+    data[len4].im = fact[3] * data[len4].im;
+    for (int i = 1; i <= len4; i++) {
+        float t[4];
+        const cpx sf = data[i], sl = data[len2 - i];
+        if (mode == 1)
+            t[0] = fact[4] * (sf.re + sl.re);
+        else
+            t[0] = fact[5] * (sf.im - sl.im);
+        t[1] = fact[6] * (sf.im + sl.im);
+        t[2] = fact[7] * (sf.re - sl.re);
+        if (mode == 1) {
+            t[3] = t[1] * tcos[i] - t[2] * tsin[i];
+            o[i] = t[0] + t[3];
+            o[len - i] = t[0] - t[3];
+        } else {
+            t[3] = t[1] * tsin[i] + t[2] * tcos[i];
+            o[i - 1] = t[3] - t[0];
+            o[len - i - 1] = t[0] + t[3];
+        }
+    }
+    for (int i = 1; i < len4 + (mode == 2); i++)
+        o[len2 - i] = o[len - i];
+    if (mode == 1)
+        o[len2] = tmp_dc;
+    memcpy(out, o, sizeof(float) * (len2 + (mode == 1)));
+    free(data);
+    free(tcos);
+}
+
+/*
  * AV_TX_FLOAT_DCT, power-of-two: ff_tx_dctII (forward) / ff_tx_dctIII (inverse) on top of the RDFT
  * (libavutil/tx_template.c:1832-2002).  n is the number of real samples (av_tx_init is handed n for the forward and n / 2 for
  * the inverse transform, ff_tx_dct_init doubles it); the RDFT runs with scale resp. scale / 2.  Tables in double, stored as

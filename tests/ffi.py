@@ -110,6 +110,8 @@ def oracle():
         L.ffo_rdft_run.restype = None
         L.ffo_dct_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
         L.ffo_dct_run.restype = None
+        L.ffo_rdft_half_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
+        L.ffo_rdft_half_run.restype = None
         L.ffo_aac_sine_window.argtypes = [f32p, C.c_int]
         L.ffo_aac_sine_window.restype = None
         L.ffo_aac_kbd_window.argtypes = [f32p, C.c_float, C.c_int]

@@ -286,6 +286,40 @@ def test_rdft_batch(len_, inv, scale):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["r2r", "r2i"])
+@pytest.mark.parametrize("len_,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
+def test_rdft_half_batch(len_, mode, scale):
+    """AV_TX_FLOAT_RDFT with AV_TX_REAL_TO_REAL / AV_TX_REAL_TO_IMAGINARY: len reals -> len/2 + 1 real resp. len/2 imaginary parts
+    (ff_tx_rdft_r2r / _r2i); bit-identical, nothing written behind them, host face too; forward-only like the reference"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    rng = np.random.default_rng(len_ * 2 + mode)
+    nt = 3000 if len_ == 1024 else 41
+    n_out = len_ // 2 + (mode == 1)
+    flag = tx.REAL_TO_REAL if mode == 1 else tx.REAL_TO_IMAGINARY
+    x = (rng.standard_normal((nt, len_)) * 10.0 ** rng.integers(-3, 4, (nt, 1))).astype(np.float32)
+    x[1] = 0
+    want = np.zeros((nt, len_ // 2 + 1), np.float32)
+    O = ffi.oracle()
+    for t in range(nt):
+        O.ffo_rdft_half_run(mode, len_, scale, ptr(want[t], f32p), ptr(x[t], f32p))
+    want = np.ascontiguousarray(want[:, :n_out])
+    ctx = tx.TxContext(tx.FLOAT_RDFT, 0, len_, scale, flags=flag)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((nt, len_ // 2 + 4), dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out[:, :n_out], d_in)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(np.ascontiguousarray(got[:, :n_out]).view(np.uint32), want.view(np.uint32)), "max |diff| %g" % np.abs(got[:, :n_out] - want).max()
+    assert not got[:, n_out:].any()
+    one = np.zeros(n_out, np.float32)
+    ctx.fn(one, x[3].copy(), 4)
+    assert np.array_equal(one.view(np.uint32), want[3].view(np.uint32))
+    ctx.close()
+    with pytest.raises(Exception):
+        tx.TxContext(tx.FLOAT_RDFT, 1, len_, scale, flags=flag)
+
+
 @pytest.mark.parametrize("inv", [0, 1])
 @pytest.mark.parametrize("n,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
 def test_dct_batch(n, inv, scale):

@@ -1053,6 +1053,27 @@ def test_dct_float(n, inv):
         R.ffref_tx_free(rc)
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["r2r", "r2i"])
+@pytest.mark.parametrize("len_", [8, 16, 64, 512, 1024, 4096])
+def test_rdft_half_float(len_, mode):
+    """AV_TX_FLOAT_RDFT with AV_TX_REAL_TO_REAL / AV_TX_REAL_TO_IMAGINARY (ff_tx_rdft_r2r / _r2i, forward only): len/2 + 1 real
+    resp. len/2 imaginary parts, bit-identical — including r2i's last value, which the reference leaves as the FFT produced it"""
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(7 * len_ + mode)
+    nout = len_ // 2 + (mode == 1)
+    for scale in (1.0, 1.0 / len_, -0.37):
+        rc = R.ffref_tx_create(6, 0, len_, scale, 1 << (2 + mode))   # AV_TX_REAL_TO_REAL = 1 << 3, _IMAGINARY = 1 << 4 (tx.h:184-185)
+        assert rc
+        assert not R.ffref_tx_create(6, 1, len_, scale, 1 << (2 + mode))   # FF_TX_FORWARD_ONLY
+        for rep in range(3):
+            x = (rng.standard_normal(len_) * 10.0 ** float(rng.integers(-3, 4))).astype(np.float32)
+            a, b = np.zeros(len_ + 2, np.float32), np.zeros(len_ + 2, np.float32)   # the reference's FFT lands in dst first
+            R.ffref_tx_run(rc, ptr(a, f32p), ptr(x.copy(), f32p), 4)
+            O.ffo_rdft_half_run(mode, len_, scale, ptr(b, f32p), ptr(x, f32p))
+            assert np.array_equal(a[:nout].view(np.uint32), b[:nout].view(np.uint32)), (scale, rep)
+        R.ffref_tx_free(rc)
+
+
 def test_dct_vs_definition():
     """the float DCT-II against the double-precision cosine sum it implements (av_tx's scaling: X[k] = 2 sum x[j] cos(pi (2j + 1)
     k / 2n)), and the DCT-III as its inverse up to a constant factor"""
