@@ -466,23 +466,43 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
         uint8_t *target = s == ST_TMP ? p->tmp[0] : dst[0];
         if (s_qpel[s].n)
             r = ffhip_launch_h264_qpel(target, ref[0], stride[0], (const FFHipQpelBlock *)(db + s_qpel[s].off), s_qpel[s].n, stream);
-        for (int c = 0; c < 2 && r >= 0; c++) {
-            uint8_t *ct = s == ST_TMP ? p->tmp[1 + c] : dst[1 + c];
-            if (s_cmc[c][s].n)
-                r = ffhip_launch_h264_chroma_mc(ct, ref[1 + c], stride[1 + c], (const FFHipChromaBlock *)(db + s_cmc[c][s].off), s_cmc[c][s].n,
-                                                stream);
+        if (r >= 0) { /* Cb and Cr of the stage: one launch */
+            FFHipPlaneMulti M;
+            M.nseg = 0;
+            for (int c = 0; c < 2; c++)
+                if (s_cmc[c][s].n) {
+                    FFHipPlaneSeg &g = M.seg[M.nseg++];
+                    g.dst = s == ST_TMP ? p->tmp[1 + c] : dst[1 + c]; g.src = ref[1 + c]; g.blocks = db + s_cmc[c][s].off;
+                    g.stride = stride[1 + c]; g.n = (int)s_cmc[c][s].n; g.first = 0;
+                }
+            r = ffhip_launch_h264_chroma_mc_multi(M, stream);
         }
     }
-    for (int pl = 0; pl < 3 && r >= 0; pl++)
-        if (s_wt[pl].n)
-            r = ffhip_launch_h264_weight(dst[pl], p->tmp[pl] ? p->tmp[pl] : dst[pl], stride[pl], (const FFHipWeightBlock *)(db + s_wt[pl].off),
-                                         s_wt[pl].n, stream);
+    if (r >= 0) { /* explicit weights of the three planes: one launch */
+        FFHipPlaneMulti M;
+        M.nseg = 0;
+        for (int pl = 0; pl < 3; pl++)
+            if (s_wt[pl].n) {
+                FFHipPlaneSeg &g = M.seg[M.nseg++];
+                g.dst = dst[pl]; g.src = p->tmp[pl] ? p->tmp[pl] : dst[pl]; g.blocks = db + s_wt[pl].off;
+                g.stride = stride[pl]; g.n = (int)s_wt[pl].n; g.first = 0;
+            }
+        r = ffhip_launch_h264_weight_multi(M, stream);
+    }
     /* ---- residual ---- */
-    for (int pl = 0; pl < 3 && r >= 0; pl++)
-        for (int k = 0; k < 4 && r >= 0; k++)
-            if (s_ioff[pl][k].n)
-                r = ffhip_launch_h264_idct_add(k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off),
-                                               (int16_t *)(db + s_icoef[pl][k].off), s_ioff[pl][k].n, stream);
+    if (r >= 0) {
+        /* one launch for the three planes' four kinds: no block is named twice, so the lists are independent */
+        FFHipIdctMulti M;
+        M.nseg = 0;
+        for (int pl = 0; pl < 3; pl++)
+            for (int k = 0; k < 4; k++)
+                if (s_ioff[pl][k].n) {
+                    FFHipIdctSeg &g = M.seg[M.nseg++];
+                    g.dst = dst[pl]; g.offs = (const int32_t *)(db + s_ioff[pl][k].off); g.coef = (int16_t *)(db + s_icoef[pl][k].off);
+                    g.stride = stride[pl]; g.n = (int)s_ioff[pl][k].n; g.kind = k; g.first = 0;
+                }
+        r = ffhip_launch_h264_idct_multi(M, stream);
+    }
     /* ---- intra macroblocks: every inter macroblock is complete now; one wavefront over the three planes ---- */
     if (r >= 0 && !p->intra.empty())
         r = ffhip_launch_h264_intra_frame(dst[0], dst[1], dst[2], stride[0], stride[1], p->mb_w, p->mb_h,

@@ -30,10 +30,10 @@ __device__ __forceinline__ void cm_row(const uint8_t *p, int nb, uint32_t (&w)[3
 /* 16 lanes per block, one lane per row: a row's (and the next row's) w + 1 source bytes arrive as aligned dwords, a sample is one
  * v_perm (s[k], s[k+1], t[k], t[k+1]) and one v_dot4_u32_u8 against (A, B, C, D), the row leaves as one or two dwords when dst
  * is aligned.  (Round 1 read and wrote every byte by itself: 26 memory instructions per lane for an 8-wide row, now 8.) */
-__global__ __launch_bounds__(256) void k_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
-                                                        const FFHipChromaBlock *blocks, int n)
+/* workgroup `wg` of a list: 16 blocks, a thread per row */
+__device__ __forceinline__ void chroma_mc_group(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n, int wg)
 {
-    const int b = (blockIdx.x * 256 + threadIdx.x) >> 4, row = threadIdx.x & 15;
+    const int b = (wg * 256 + (int)threadIdx.x) >> 4, row = threadIdx.x & 15;
     if (b >= n)
         return;
     const FFHipChromaBlock blk = blocks[b];
@@ -80,6 +80,48 @@ __global__ __launch_bounds__(256) void k_h264_chroma_mc(uint8_t *dst, const uint
     }
 }
 
+__global__ __launch_bounds__(256) void k_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
+                                                        const FFHipChromaBlock *blocks, int n)
+{
+    chroma_mc_group(dst, src, stride, blocks, n, (int)blockIdx.x);
+}
+
+/* the lists of several planes in one launch (the picture layer: Cb and Cr of a stage) */
+__global__ __launch_bounds__(256) void k_h264_chroma_mc_multi(FFHipPlaneMulti M)
+{
+    int si = 0;
+    for (int i = 1; i < M.nseg; i++)
+        if ((int)blockIdx.x >= M.seg[i].first)
+            si = i;
+    const FFHipPlaneSeg &S = M.seg[si];
+    chroma_mc_group(S.dst, S.src, S.stride, static_cast<const FFHipChromaBlock *>(S.blocks), S.n, (int)blockIdx.x - S.first);
+}
+
+static int plane_multi_pack(FFHipPlaneMulti &M)
+{
+    int wg = 0, k = 0;
+    for (int i = 0; i < M.nseg; i++) {
+        if (M.seg[i].n <= 0)
+            continue;
+        M.seg[k] = M.seg[i];
+        M.seg[k].first = wg;
+        wg += cdiv(M.seg[k].n, 16);
+        k++;
+    }
+    M.nseg = k;
+    return wg;
+}
+
+int ffhip_launch_h264_chroma_mc_multi(FFHipPlaneMulti &M, hipStream_t stream)
+{
+    const int wg = plane_multi_pack(M);
+    if (!wg)
+        return 0;
+    hipLaunchKernelGGL(k_h264_chroma_mc_multi, dim3(wg), dim3(256), 0, stream, M);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int ffhip_launch_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
                                 hipStream_t stream)
 {
@@ -90,10 +132,9 @@ int ffhip_launch_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stri
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_h264_weight(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
-                                                     const FFHipWeightBlock *blocks, int n)
+__device__ __forceinline__ void weight_group(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n, int wg)
 {
-    const int b = (blockIdx.x * 256 + threadIdx.x) >> 4, row = threadIdx.x & 15;
+    const int b = (wg * 256 + (int)threadIdx.x) >> 4, row = threadIdx.x & 15;
     if (b >= n)
         return;
     const FFHipWeightBlock blk = blocks[b];
@@ -113,6 +154,32 @@ __global__ __launch_bounds__(256) void k_h264_weight(uint8_t *dst, const uint8_t
         for (int k = 0; k < w; k++)
             d[k] = (uint8_t)min(max((s[k] * blk.weights + d[k] * blk.weightd + off) >> (ld + 1), 0), 255);
     }
+}
+
+__global__ __launch_bounds__(256) void k_h264_weight(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
+                                                     const FFHipWeightBlock *blocks, int n)
+{
+    weight_group(dst, src, stride, blocks, n, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_h264_weight_multi(FFHipPlaneMulti M)
+{
+    int si = 0;
+    for (int i = 1; i < M.nseg; i++)
+        if ((int)blockIdx.x >= M.seg[i].first)
+            si = i;
+    const FFHipPlaneSeg &S = M.seg[si];
+    weight_group(S.dst, S.src, S.stride, static_cast<const FFHipWeightBlock *>(S.blocks), S.n, (int)blockIdx.x - S.first);
+}
+
+int ffhip_launch_h264_weight_multi(FFHipPlaneMulti &M, hipStream_t stream)
+{
+    const int wg = plane_multi_pack(M);
+    if (!wg)
+        return 0;
+    hipLaunchKernelGGL(k_h264_weight_multi, dim3(wg), dim3(256), 0, stream, M);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int ffhip_launch_h264_weight(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,

@@ -114,12 +114,11 @@ __device__ __forceinline__ void idct8_add_regs(const uint32_t rows[8][4], uint8_
 
 #define REC8 144 /* padded LDS record of one 8x8 block: 128 B + 16 B => conflict-free ds_read_b128 */
 
-__global__ __launch_bounds__(NT) void k_h264_idct8_add(uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
-                                                       int16_t *blocks, int n, int dst_vec)
+/* one workgroup's NT blocks, b0 = the first one's index; lds: NT * REC8 bytes */
+__device__ __forceinline__ void idct8_add_group(uint8_t *lds, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset, int16_t *blocks,
+                                                int n, int dst_vec, long long b0)
 {
-    __shared__ __align__(16) uint8_t lds[NT * REC8];
     const int tid = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * NT;
     const int nb = (int)min((long long)NT, (long long)n - b0);
     uint4 *gsrc = reinterpret_cast<uint4 *>(blocks + b0 * 64);
     /* coalesced copy in: 8 x 16-B pieces per block */
@@ -142,6 +141,13 @@ __global__ __launch_bounds__(NT) void k_h264_idct8_add(uint8_t *dst_base, ptrdif
     uint8_t *dst = dst_base + dst_offset[b0 + tid];
     const bool vec = dst_vec && !((uintptr_t)dst & 7);
     idct8_add_regs(r2, dst, stride, vec);
+}
+
+__global__ __launch_bounds__(NT) void k_h264_idct8_add(uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
+                                                       int16_t *blocks, int n, int dst_vec)
+{
+    __shared__ __align__(16) uint8_t lds[NT * REC8];
+    idct8_add_group(lds, dst_base, stride, dst_offset, blocks, n, dst_vec, (long long)blockIdx.x * NT);
 }
 
 /* 4x4: direct 2 x 16-B loads per thread */
@@ -282,6 +288,67 @@ int ffhip_launch_h264_idct_add(int kind, uint8_t *dst_base, ptrdiff_t stride, co
     default:
         return FFHIP_EINVAL;
     }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/*
+ * Several block lists in ONE launch (the picture layer's residual stage: up to three planes x four kinds; a launch costs the
+ * host more than these small kernels cost the GPU): workgroup b serves the segment whose range of workgroups holds b.  The
+ * lists never name the same destination block twice (each block has one kind), so the segments are independent.
+ */
+__global__ __launch_bounds__(NT) void k_h264_idct_multi(FFHipIdctMulti M)
+{
+    __shared__ __align__(16) uint8_t lds[NT * REC8];
+    int si = 0;
+    for (int i = 1; i < M.nseg; i++)
+        if ((int)blockIdx.x >= M.seg[i].first)
+            si = i;
+    const FFHipIdctSeg &S = M.seg[si];
+    const long long b0 = (long long)((int)blockIdx.x - S.first) * NT, i = b0 + threadIdx.x;
+    const ptrdiff_t stride = S.stride;
+    if (S.kind == FFHIP_H264_IDCT8) {
+        idct8_add_group(lds, S.dst, stride, S.offs, S.coef, S.n, !(((uintptr_t)S.dst | (size_t)stride) & 7), b0);
+        return;
+    }
+    if (i >= S.n)
+        return;
+    uint8_t *dst = S.dst + S.offs[i];
+    if (S.kind == FFHIP_H264_IDCT4) {
+        uint4 *g = reinterpret_cast<uint4 *>(S.coef + i * 16);
+        const uint4 c0 = g[0], c1 = g[1];
+        g[0] = make_uint4(0, 0, 0, 0);
+        g[1] = make_uint4(0, 0, 0, 0);
+        idct4_add_regs(c0, c1, dst, stride, !(((uintptr_t)S.dst | (size_t)stride | (uintptr_t)dst) & 3));
+    } else {
+        const int N = S.kind == FFHIP_H264_IDCT8_DC ? 8 : 4;
+        int16_t *b = S.coef + i * (N * N);
+        const int dc = (b[0] + 32) >> 6;
+        b[0] = 0;
+        if (N == 8)
+            dc_add_regs<8>(dc, dst, stride);
+        else
+            dc_add_regs<4>(dc, dst, stride);
+    }
+}
+
+int ffhip_launch_h264_idct_multi(FFHipIdctMulti &M, hipStream_t stream)
+{
+    int wg = 0, k = 0;
+    for (int i = 0; i < M.nseg; i++) {
+        if (M.seg[i].n <= 0)
+            continue;
+        if (M.seg[i].kind < FFHIP_H264_IDCT4 || M.seg[i].kind > FFHIP_H264_IDCT8_DC)
+            return FFHIP_EINVAL;
+        M.seg[k] = M.seg[i];
+        M.seg[k].first = wg;
+        wg += cdiv(M.seg[k].n, NT);
+        k++;
+    }
+    M.nseg = k;
+    if (!k)
+        return 0;
+    hipLaunchKernelGGL(k_h264_idct_multi, dim3(wg), dim3(NT), 0, stream, M);
     LAUNCH_CHECK();
     return 0;
 }

@@ -6,6 +6,15 @@
 #include <stdint.h>
 #include "ffhip.h"
 
+/* the block lists of up to three planes in one launch (chroma MC, weighted prediction); empty segments are dropped */
+struct FFHipPlaneSeg { uint8_t *dst; const uint8_t *src; const void *blocks; int stride, n, first; };
+struct FFHipPlaneMulti { FFHipPlaneSeg seg[3]; int nseg; };
+int ffhip_launch_h264_chroma_mc_multi(FFHipPlaneMulti &M, hipStream_t stream);
+int ffhip_launch_h264_weight_multi(FFHipPlaneMulti &M, hipStream_t stream);
+/* several idct_add lists in one launch (kinds FFHIP_H264_IDCT4 .. FFHIP_H264_IDCT8_DC); empty segments are dropped */
+struct FFHipIdctSeg { uint8_t *dst; const int32_t *offs; int16_t *coef; int stride, n, kind, first; };
+struct FFHipIdctMulti { FFHipIdctSeg seg[12]; int nseg; };
+int ffhip_launch_h264_idct_multi(FFHipIdctMulti &M, hipStream_t stream);
 int ffhip_launch_h264_idct_add(int kind, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
                                int16_t *blocks, int n, hipStream_t stream);
 int ffhip_launch_h264_idct_add_mb(int which, uint8_t *dst_base, ptrdiff_t stride, const int32_t *mb_offset,
