@@ -559,7 +559,62 @@ def round2_legs(torch, dev, ev):
     out["vp9_loopfilter_frame_4k"] = {"ms_per_picture_one_stream": round(ms, 4), "pictures_per_s": round(1e3 / ms, 1),
                                       "Mpixels/s": round(64 * sbc * 64 * sbr / (ms * 1e-3) / 1e6, 1),
                                       "note": "decoder order (superblock wavefront, luma and chroma chains side by side), every 8x8-grid edge 8 wide"}
+    out.update(h264_picture_leg(torch, dev, ev))
     return out
+
+
+def h264_picture_leg(torch, dev, ev):
+    """the picture layer: synthetic 1080p P-pictures (tools/h264_synth.py) through ffhip_h264_picture_flush — MC,
+    residual add and the in-loop filter in decoder order.  A lone picture is a chain of latency-bound kernels; 16 pictures in flight,
+    each on its own stream and host thread, fill the hardware queues (GPU_MAX_HW_QUEUES, see main())."""
+    import threading
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from h264_synth import record_p_picture
+    from ffmpeg_amd import h264
+    mb_w, mb_h, P, npic = 120, 68, 32, 16
+    W, H = mb_w * 16, mb_h * 16
+    sy, sc = W + 2 * P, W // 2 + P
+    rng = np.random.default_rng(5)
+    shp = ((H + 2 * P, sy), (H // 2 + P, sc), (H // 2 + P, sc))
+    refs = [torch.randint(0, 256, s_, dtype=torch.uint8, device=dev) for s_ in shp]
+    pics, dsts, streams = [], [], []
+    for _ in range(npic):
+        p = h264.Picture(mb_w, mb_h)
+        record_p_picture(p, h264, mb_w, mb_h, sy, sc, P, rng)
+        pics.append(p)
+        dsts.append([torch.zeros(s_, dtype=torch.uint8, device=dev) for s_ in shp])
+        streams.append(torch.cuda.Stream(device=dev))
+    res = {}
+    for n in (1, npic):
+        for rep in range(2):                                  # the first round warms the pools up
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for s_ in streams[:n]:
+                s_.wait_event(e0)
+            rounds = 4
+
+            def work(i):
+                for _ in range(rounds):
+                    pics[i].flush(dsts[i], [sy, sc, sc], refs, stream=streams[i].cuda_stream)
+            th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            cur = torch.cuda.current_stream()
+            for s_ in streams[:n]:
+                cur.wait_stream(s_)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / rounds
+        res[n] = ms
+    for p in pics:
+        p.close()
+    return {"h264_picture_pipeline_1080p": {"ms_per_picture_alone": round(res[1], 3), "ms_per_picture_16_in_flight": round(res[npic] / npic, 3),
+                                           "pictures_per_s_16_in_flight": round(1e3 * npic / res[npic], 1),
+                                           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                                           "note": "P-pictures: qpel + chroma MC, idct_add on ~half of the blocks, deblocking in decoder order; one stream and host thread per picture"}}
 
 
 def sws_ops_leg(torch, dev):
@@ -693,6 +748,11 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the RCCL scatter/convert/gather leg at N>1")
     args = ap.parse_args()
 
+    # one rank, many streams (the picture-layer leg of the extras): the HIP runtime folds all streams of a process onto
+    # GPU_MAX_HW_QUEUES hardware queues, 4 by default; 16 is the measured optimum there.  Read at runtime
+    # initialisation, hence before torch is imported; the timed headline runs on one stream and does not depend on it.
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
     from ffmpeg_amd import swscale as S, _lib

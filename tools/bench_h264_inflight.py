@@ -18,10 +18,10 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 from ffmpeg_amd import h264  # noqa: E402
-from test_gpu_h264_picture import QPEL_DT, CHROMA_DT, EDGE_DT  # noqa: E402
+from h264_synth import record_p_picture  # noqa: E402
 
 dev = torch.device("cuda", 0)
 mb_w, mb_h, P = 120, 68, 32
@@ -38,40 +38,7 @@ def planes(zero):
 
 
 def record(pic):
-    pic.begin()
-    q, c = np.zeros(1, QPEL_DT), np.zeros(1, CHROMA_DT)
-    ed8, ed4 = np.zeros(8, EDGE_DT), np.zeros(4, EDGE_DT)
-    for e in (ed8, ed4):
-        e["alpha"], e["beta"] = 40, 9
-        e["tc0"] = 1
-    ed4["kind"] = 2
-    blk8, blk4 = np.zeros(64, np.int16), np.zeros(16, np.int16)
-    for my in range(mb_h):
-        for mx in range(mb_w):
-            x, y = mx * 16, my * 16
-            dy, dx = (int(v) for v in rng.integers(-16, 17, 2))
-            q[0] = (y * sy + x, (P + y + dy) * sy + P + x + dx, int(rng.integers(0, 16)), 0, 0, 0)
-            pic.mc_luma(h264.MC_PUT, q)
-            for pl in (1, 2):
-                c[0] = ((y // 2) * sc + x // 2, (P // 2 + y // 2 + dy // 2) * sc + P // 2 + x // 2 + dx // 2, 0, 8, int(rng.integers(0, 8)),
-                        int(rng.integers(0, 8)), 0, (0, 0, 0))
-                pic.mc_chroma(pl, h264.MC_PUT, c)
-            for by in (0, 8):
-                for bx in (0, 8):
-                    if rng.random() < .5:
-                        blk8[:] = 0
-                        blk8[:6] = rng.integers(-80, 81, 6)
-                        pic.idct_add(0, 1, (y + by) * sy + x + bx, blk8)
-            for pl in (1, 2):
-                for by in (0, 4):
-                    for bx in (0, 4):
-                        if rng.random() < .3:
-                            blk4[:] = 0
-                            blk4[:3] = rng.integers(-80, 81, 3)
-                            pic.idct_add(pl, 0, (y // 2 + by) * sc + x // 2 + bx, blk4)
-            pic.deblock_mb(0, mx, my, ed8)
-            pic.deblock_mb(1, mx, my, ed4)
-            pic.deblock_mb(2, mx, my, ed4)
+    record_p_picture(pic, h264, mb_w, mb_h, sy, sc, P, rng)
 
 
 refs = planes(False)
