@@ -191,15 +191,29 @@ __device__ __forceinline__ uint32_t me_satd8_cols(const uint4 *va, const uint4 *
     return acc;
 }
 
-template <int KIND, int MB, bool SHARE = false, int QUAD = 0>
-__global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int height, ptrdiff_t stride,
-                                               size_t frame_pitch, int R, int16_t *mv_out, uint32_t *cost_out)
+/* a wave's LDS operations execute in order and the waves of a workgroup share nothing: no barrier */
+__device__ __forceinline__ void me_wave_sync()
 {
-    extern __shared__ __align__(16) uint8_t lds[];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* WPB independent waves (macroblocks bx .. bx + WPB - 1 of a row) per workgroup: a CU holds only about 16 workgroups whatever
+ * their size, so one-wave workgroups leave half of its 32 wave slots empty (measured: 4.5 waves per SIMD) */
+template <int KIND, int MB, bool SHARE = false, int QUAD = 0, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void k_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int height, ptrdiff_t stride,
+                                                     size_t frame_pitch, int R, int16_t *mv_out, uint32_t *cost_out, int lds_per_wave)
+{
+    extern __shared__ __align__(16) uint8_t lds_all[];
     constexpr int LOG2 = MB == 16 ? 4 : 3;
     const int bw = width >> LOG2, bh = height >> LOG2;
-    const int bx = blockIdx.x, by = blockIdx.y, f = blockIdx.z;
-    const int lane = threadIdx.x;
+    const int wave = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int bx = blockIdx.x * WPB + wave, by = blockIdx.y, f = blockIdx.z;
+    if (WPB > 1 && bx >= bw)
+        return;
+    uint8_t *lds = lds_all + wave * lds_per_wave;
+    const int lane = threadIdx.x & 63;
     const int x_mb = bx << LOG2, y_mb = by << LOG2;
     const int lim_x = (bw - 1) << LOG2, lim_y = (bh - 1) << LOG2;
     const int x0 = max(x_mb - R, 0), y0 = max(y_mb - R, 0);
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t
             }
         }
     }
-    __syncthreads();
+    me_wave_sync();
     /* SATD with SHARED column transforms: the vertical Hadamard of a window column segment (8 rows) serves the 8
      * candidates that contain it, so it is computed once per macroblock into LDS — va: the current block's columns
      * per 8-row band, vb[r][c]: window column c, rows r..r+7 */
@@ -254,13 +268,68 @@ __global__ __launch_bounds__(64) void k_me_esa(const uint8_t *cur, const uint8_t
             const int r = i / wcols, c = i - r * wcols;
             vb[i] = me_hadamard_col(win + r * pitch + c, pitch);
         }
-        __syncthreads();
+        me_wave_sync();
     }
 
     uint32_t best = 0xFFFFFFFFu, best_ci = 0xFFFFFFFFu, cost0 = 0;
     const int ci0 = (y_mb - y0) * ncx + (x_mb - x0);
     int l0 = ci0 & 63; /* the lane that meets the zero-MV candidate */
-    if (QUAD) {
+    if (QUAD == 3) {
+        /* SAD 16x16, four VERTICALLY adjacent candidates per lane (one column position cx, rows cy0 .. cy0 + 3): the 19 window
+         * rows they cover are fetched once each — five aligned dwords, funnel-shifted by the lane's byte phase — and every row
+         * meets up to four rows of the current block, which sits in scalar registers: 256 v_sad_u8 (full rate) + 76
+         * v_alignbyte + 38 LDS reads per four candidates, against 64 + 64 + 32 per candidate in the one-candidate form and the
+         * slow-issuing v_qsad_pk_u16_u8 of the horizontal quad form. */
+        uint32_t cb[16][4];
+#pragma unroll
+        for (int y = 0; y < 16; y++) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(cblk + 16 * y);
+            cb[y][0] = __builtin_amdgcn_readfirstlane(c.x);
+            cb[y][1] = __builtin_amdgcn_readfirstlane(c.y);
+            cb[y][2] = __builtin_amdgcn_readfirstlane(c.z);
+            cb[y][3] = __builtin_amdgcn_readfirstlane(c.w);
+        }
+        const int ngy = (ncy + 3) >> 2;
+        {
+            const int cy_z = ci0 / ncx, cx_z = ci0 - cy_z * ncx;
+            l0 = ((cy_z >> 2) * ncx + cx_z) & 63;
+        }
+        for (int g = lane; g < ncx * ngy; g += 64) {
+            const int gy = g / ncx, cx = g - gy * ncx, cy0 = 4 * gy;
+            const uint32_t sh = (uint32_t)cx & 3u;
+            const uint8_t *col = win + (cx & ~3);
+            uint32_t cost[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int r = 0; r < 19; r++) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(col + min(cy0 + r, wrows - 1) * pitch);
+                const uint4 d = *reinterpret_cast<const uint4 *>(q);
+                const uint32_t e = q[4];
+                const uint32_t w[4] = { __builtin_amdgcn_alignbyte(d.y, d.x, sh), __builtin_amdgcn_alignbyte(d.z, d.y, sh),
+                                        __builtin_amdgcn_alignbyte(d.w, d.z, sh), __builtin_amdgcn_alignbyte(e, d.w, sh) };
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int y = r - k;
+                    if (y >= 0 && y < 16) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            cost[k] = __builtin_amdgcn_sad_u8(cb[y][j], w[j], cost[k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ci = (cy0 + k) * ncx + cx;
+                if (cy0 + k < ncy) {
+                    if (ci == ci0)
+                        cost0 = cost[k];
+                    if (cost[k] < best) {
+                        best = cost[k];
+                        best_ci = (uint32_t)ci;
+                    }
+                }
+            }
+        }
+    } else if (QUAD) {
         /* SAD 16x16, four horizontally adjacent candidates per lane: their rows are the same five ALIGNED window dwords
          * at byte offsets 0..3, the current block sits in scalar registers (it is the same for every lane) — the
          * one-candidate-per-lane form spent more on unaligned LDS fetches than on differences */
@@ -400,30 +469,48 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
         return FFHIP_EINVAL;
     }
     const dim3 grid(bw, bh, nframes), block(64);
-#define ESA(K, M) hipLaunchKernelGGL((k_me_esa<K, M>), grid, block, lds, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out)
+    /* SAD: four macroblocks (waves) per workgroup, FFHIP_ME_WPB=1 for the one-wave form */
+    const char *ew = getenv("FFHIP_ME_WPB");
+    const int lpw = (int)((lds + 15) & ~(size_t)15);
+    const bool w4 = !(ew && ew[0] == '1') && (size_t)lpw * 4 <= 64 * 1024; /* large search ranges: one wave, one window */
+    const dim3 grid4(cdiv(bw, 4), bh, nframes), block4(256);
+#define ESA(K, M) hipLaunchKernelGGL((k_me_esa<K, M>), grid, block, lds, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out, 0)
+#define ESA4(K, M, Q) hipLaunchKernelGGL((k_me_esa<K, M, false, Q, 4>), grid4, block4, (size_t)lpw * 4, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out, lpw)
     if (cost_kind == FFHIP_ME_SAD) {
         /* measured (4K, 8 frame pairs): R = 7: one candidate per lane 448 M, quad + v_qsad_pk_u16_u8 480 M, quad + v_sad_u8 433 M
          * MB-searches/s; R = 16: 122 / 116 / 114 M.  v_qsad_pk_u16_u8 issues at about 1/14 rate on gfx950, which eats what
          * the four-fold saving in LDS reads buys; the quad form is the default only while the candidates fit one pass.
-         * FFHIP_ME_SAD_QUAD = 0 / 1 / 2 forces a form. */
+         * FFHIP_ME_SAD_QUAD = 0 / 1 / 2 / 3 forces a form.  Round 2 measured two more hypotheses (tools/run_esa.py): four VERTICALLY
+         * adjacent candidates per lane sharing their window rows (form 3: a quarter of the LDS reads and alignbytes, v_sad_u8 only):
+         * 418 M at R = 7, 100 M at R = 16 — slower than both; and four macroblock waves per workgroup instead of one (a CU's workgroup
+         * slots): + 2..6 %, kept.  Every form sits at 60 % VALU issue with the rest in LDS round trips per candidate row. */
         const char *eq = getenv("FFHIP_ME_SAD_QUAD");
         const bool one_pass = ((2 * R + 1 + 3) / 4) * (2 * R + 1) <= 64;
-        if (mb_size == 16 && !eq && !one_pass)
-            ESA(FFHIP_ME_SAD, 16);
-        else if (mb_size == 16 && eq && eq[0] == '2')
+        if (mb_size == 16 && eq && eq[0] == '3') {
+            if (w4) ESA4(FFHIP_ME_SAD, 16, 3);
+            else hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SAD, 16, false, 3>), grid, block, lds, stream, cur, ref, width, height, stride,
+                                    frame_pitch, R, mv_out, cost_out, 0);
+        } else if (mb_size == 16 && !eq && !one_pass) {
+            if (w4) ESA4(FFHIP_ME_SAD, 16, 0); else ESA(FFHIP_ME_SAD, 16);
+        } else if (mb_size == 16 && eq && eq[0] == '2') {
             hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SAD, 16, false, 2>), grid, block, lds, stream, cur, ref, width, height, stride,
-                               frame_pitch, R, mv_out, cost_out);
-        else if (mb_size == 16 && !(eq && eq[0] == '0'))
-            hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SAD, 16, false, 1>), grid, block, lds, stream, cur, ref, width, height, stride,
-                               frame_pitch, R, mv_out, cost_out);
-        else if (mb_size == 16) ESA(FFHIP_ME_SAD, 16); else ESA(FFHIP_ME_SAD, 8);
+                               frame_pitch, R, mv_out, cost_out, 0);
+        } else if (mb_size == 16 && !(eq && eq[0] == '0')) {
+            if (w4) ESA4(FFHIP_ME_SAD, 16, 1);
+            else hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SAD, 16, false, 1>), grid, block, lds, stream, cur, ref, width, height, stride,
+                                    frame_pitch, R, mv_out, cost_out, 0);
+        } else if (mb_size == 16) {
+            if (w4) ESA4(FFHIP_ME_SAD, 16, 0); else ESA(FFHIP_ME_SAD, 16);
+        } else {
+            if (w4) ESA4(FFHIP_ME_SAD, 8, 0); else ESA(FFHIP_ME_SAD, 8);
+        }
     } else {
         /* shared column transforms when their LDS plane fits (R <= 24 at 16x16); FFHIP_ME_SATD_SHARE=0: per-candidate */
         const char *es = getenv("FFHIP_ME_SATD_SHARE");
         const size_t vsz = ((size_t)(mb_size / 8) * mb_size + (size_t)(2 * R + mb_size - 7) * (2 * R + mb_size)) * 16;
         const size_t lds_s = ((lds + 15) & ~(size_t)15) + vsz;
         if (lds_s <= 64 * 1024 && !(es && es[0] == '0')) {
-#define ESAS(M) hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SATD, M, true, 0>), grid, block, lds_s, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out)
+#define ESAS(M) hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SATD, M, true, 0>), grid, block, lds_s, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out, cost_out, 0)
             if (mb_size == 16) ESAS(16); else ESAS(8);
 #undef ESAS
         } else {
@@ -431,6 +518,7 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
         }
     }
 #undef ESA
+#undef ESA4
     LAUNCH_CHECK();
     return 0;
 }
