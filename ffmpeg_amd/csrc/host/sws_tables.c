@@ -349,8 +349,12 @@ struct FFHipSwsHostTables {
 
 static int is_yuv(int fmt)
 {
-    return fmt == FFHIP_PIX_FMT_YUV420P || fmt == FFHIP_PIX_FMT_NV12 || fmt == FFHIP_PIX_FMT_NV21;
+    return fmt == FFHIP_PIX_FMT_YUV420P || fmt == FFHIP_PIX_FMT_NV12 || fmt == FFHIP_PIX_FMT_NV21 || fmt == FFHIP_PIX_FMT_YUV422P ||
+           fmt == FFHIP_PIX_FMT_YUV444P;
 }
+/* av_pix_fmt_get_chroma_sub_sample() of the YUV formats on this path (libswscale/utils.c:1265-1266) */
+static int chroma_hsub(int fmt) { return fmt == FFHIP_PIX_FMT_YUV444P ? 0 : 1; }
+static int chroma_vsub(int fmt) { return fmt == FFHIP_PIX_FMT_YUV444P || fmt == FFHIP_PIX_FMT_YUV422P ? 0 : 1; }
 static int is_rgb(int fmt)
 {
     return fmt == FFHIP_PIX_FMT_RGB24 || fmt == FFHIP_PIX_FMT_BGR24 || (fmt >= FFHIP_PIX_FMT_ARGB && fmt <= FFHIP_PIX_FMT_BGRA);
@@ -388,15 +392,21 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
 
     /* RGB output without SWS_FULL_CHR_H_INT keeps chroma at half horizontal resolution
      * (utils.c:1359-1360) and full vertical resolution */
-    chrDstHSub = 1;
-    chrDstVSub = is_rgb(dstFormat) ? 0 : 1;
+    chrDstHSub = is_rgb(dstFormat) ? 1 : chroma_hsub(dstFormat);
+    chrDstVSub = is_rgb(dstFormat) ? 0 : chroma_vsub(dstFormat);
+    if (is_rgb(dstFormat) && (chroma_hsub(srcFormat) != 1 || chroma_vsub(srcFormat) != 1)) {
+        /* utils.c:1375-1390 re-derives the source's chroma subsampling for packed targets: only the 4:2:0 sources are taken */
+        ffhip_set_error("ffhip_sws: 4:2:2 / 4:4:4 sources to packed RGB are not on the hip path");
+        free(h);
+        return NULL;
+    }
     if (is_rgb(dstFormat) && (dstW & 1)) {
         ffhip_set_error("ffhip_sws: odd RGB width forces SWS_FULL_CHR_H_INT in the reference; not on this path");
         free(h);
         return NULL;
     }
-    chrSrcW = ceil_rshift(srcW, 1);
-    chrSrcH = ceil_rshift(srcH, 1);
+    chrSrcW = ceil_rshift(srcW, chroma_hsub(srcFormat));
+    chrSrcH = ceil_rshift(srcH, chroma_vsub(srcFormat));
     chrDstW = ceil_rshift(dstW, chrDstHSub);
     chrDstH = ceil_rshift(dstH, chrDstVSub);
 

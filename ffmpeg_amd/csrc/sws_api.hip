@@ -68,7 +68,13 @@ static bool em_forced()
     const char *em = getenv("FFHIP_SWS_MFMA");
     return em && em[0] == '1';
 }
-static bool fmt_yuv(int f) { return f == FFHIP_PIX_FMT_YUV420P || f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
+static bool fmt_yuv(int f)
+{
+    return f == FFHIP_PIX_FMT_YUV420P || f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21 || f == FFHIP_PIX_FMT_YUV422P || f == FFHIP_PIX_FMT_YUV444P;
+}
+/* chroma subsampling of the YUV formats on this path (av_pix_fmt_get_chroma_sub_sample) */
+static int fmt_hsub(int f) { return f == FFHIP_PIX_FMT_YUV444P ? 0 : 1; }
+static int fmt_vsub(int f) { return f == FFHIP_PIX_FMT_YUV444P || f == FFHIP_PIX_FMT_YUV422P ? 0 : 1; }
 static bool fmt_nv(int f) { return f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
 /* packed layout number of an RGB target (the kernels' `layout` / `bgr` argument): 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
 static int rgb_layout(int f)
@@ -263,6 +269,10 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         ffhip_set_error("ffhip_sws: odd RGB width is not on the hip path");
         return nullptr;
     }
+    if (fmt_rgb(t->dstFormat) && (fmt_hsub(t->srcFormat) != 1 || fmt_vsub(t->srcFormat) != 1)) {
+        ffhip_set_error("ffhip_sws: 4:2:2 / 4:4:4 sources to packed RGB are not on the hip path");
+        return nullptr;
+    }
     if (!ffhip_have_device()) {
         ffhip_set_error("ffhip_sws: no HIP device (FFHIP_ENOSYS) - keep the C function pointers");
         return nullptr;
@@ -271,8 +281,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
     if (!c)
         return nullptr;
     c->t = *t;
-    c->chrSrcW = (t->srcW + 1) >> 1;
-    c->chrSrcH = (t->srcH + 1) >> 1;
+    c->chrSrcW = -((-t->srcW) >> fmt_hsub(t->srcFormat));
+    c->chrSrcH = -((-t->srcH) >> fmt_vsub(t->srcFormat));
     c->unscaled_yuv2rgb = t->srcW == t->dstW && t->srcH == t->dstH && t->srcFormat == FFHIP_PIX_FMT_YUV420P &&
                           fmt_rgb(t->dstFormat) && !(t->flags & FFHIP_SWS_ACCURATE_RND) && !(t->dstH & 1);
     if (make_k(*t, &c->k) < 0) {
@@ -908,9 +918,12 @@ struct PlaneDesc { int wbytes, rows; };
 
 static int plane_list(int fmt, int w, int h, PlaneDesc out[3])
 {
-    const int cw = (w + 1) >> 1, chh = (h + 1) >> 1;
-    if (fmt == FFHIP_PIX_FMT_YUV420P) { out[0] = { w, h }; out[1] = { cw, chh }; out[2] = { cw, chh }; return 3; }
-    if (fmt_nv(fmt)) { out[0] = { w, h }; out[1] = { 2 * cw, chh }; return 2; }
+    if (fmt_yuv(fmt)) {
+        const int cw = -((-w) >> fmt_hsub(fmt)), chh = -((-h) >> fmt_vsub(fmt));
+        if (fmt_nv(fmt)) { out[0] = { w, h }; out[1] = { 2 * cw, chh }; return 2; }
+        out[0] = { w, h }; out[1] = { cw, chh }; out[2] = { cw, chh };
+        return 3;
+    }
     out[0] = { (rgb_layout(fmt) < 2 ? 3 : 4) * w, h };
     return 1;
 }
@@ -991,8 +1004,9 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
     size_t fp[4] = { 0, 0, 0, 0 };
     for (int i = 0; i < ns; i++) {
         /* a slice brings luma rows [y, y + h) and chroma rows [y >> 1, (y + h + 1) >> 1) (swscale.c:280-283) */
-        const int row0 = !sliced ? 0 : i ? srcSliceY >> 1 : srcSliceY;
-        const int rows = !sliced ? sp[i].rows : i ? ((srcSliceY + srcSliceH + 1) >> 1) - (srcSliceY >> 1) : srcSliceH;
+        const int vs = fmt_vsub(c->t.srcFormat);
+        const int row0 = !sliced ? 0 : i ? srcSliceY >> vs : srcSliceY;
+        const int rows = !sliced ? sp[i].rows : i ? (-((-(srcSliceY + srcSliceH)) >> vs)) - (srcSliceY >> vs) : srcSliceH;
         HIP_TRY(copy2d(base + off_s[i] + (size_t)row0 * pitch_s[i], pitch_s[i], src[i], srcStride[i], sp[i].wbytes, rows,
                        hipMemcpyHostToDevice));
         dsrc[i] = base + off_s[i];

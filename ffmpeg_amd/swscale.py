@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-PIX_FMT = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
+PIX_FMT = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
 SWS_BILINEAR, SWS_BICUBIC, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 2, 4, 0x10, 0x20, 0x40
 SWS_GAUSS, SWS_SINC, SWS_LANCZOS = 0x80, 0x100, 0x200
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
@@ -21,8 +21,9 @@ SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
 
 def plane_shapes(fmt, w, h):
     """[(rows, bytes_per_row)] of the planes of one frame."""
-    cw, ch = (w + 1) // 2, (h + 1) // 2
-    if fmt == PIX_FMT["yuv420p"]:
+    hs, vs = (0, 0) if fmt == PIX_FMT["yuv444p"] else (1, 0) if fmt == PIX_FMT["yuv422p"] else (1, 1)
+    cw, ch = -((-w) >> hs), -((-h) >> vs)
+    if fmt in (PIX_FMT["yuv420p"], PIX_FMT["yuv422p"], PIX_FMT["yuv444p"]):
         return [(h, w), (ch, cw), (ch, cw)]
     if fmt in (PIX_FMT["nv12"], PIX_FMT["nv21"]):
         return [(h, w), (ch, 2 * cw)]

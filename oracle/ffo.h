@@ -15,6 +15,8 @@
 /* AVPixelFormat values (libavutil/pixfmt.h) */
 #define FFO_PIX_FMT_YUV420P 0
 #define FFO_PIX_FMT_RGB24   2
+#define FFO_PIX_FMT_YUV422P 4
+#define FFO_PIX_FMT_YUV444P 5
 #define FFO_PIX_FMT_BGR24   3
 #define FFO_PIX_FMT_NV12    23
 #define FFO_PIX_FMT_ARGB    25

@@ -243,7 +243,9 @@ int ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], cons
 {
     static const uint8_t d64[8] = { 64, 64, 64, 64, 64, 64, 64, 64 };
     const int srcW = t->srcW, srcH = t->srcH, dstW = t->dstW, dstH = t->dstH;
-    const int chrSrcW = (srcW + 1) >> 1, chrSrcH = (srcH + 1) >> 1;
+    /* av_pix_fmt_get_chroma_sub_sample(): 4:4:4 has none, 4:2:2 only horizontally (libswscale/utils.c:1265,1393-1394) */
+    const int hs = t->srcFormat == FFO_PIX_FMT_YUV444P ? 0 : 1, vs = t->srcFormat == FFO_PIX_FMT_YUV444P || t->srcFormat == FFO_PIX_FMT_YUV422P ? 0 : 1;
+    const int chrSrcW = -((-srcW) >> hs), chrSrcH = -((-srcH) >> vs);
     const int chrDstW = t->hChr.n, chrDstH = t->vChr.n;
     const int lpitch = dstW + 8, cpitch = chrDstW + 8;
     int16_t *hl = malloc(sizeof(int16_t) * (size_t)lpitch * srcH);

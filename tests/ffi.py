@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libffref.so")
 
-PIX = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
+PIX = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
 RGB_LAYOUT = {2: 0, 3: 1, 25: 2, 26: 3, 27: 4, 28: 5}   # AVPixelFormat -> the oracle's packed layout number
 SWS_BICUBIC, SWS_BILINEAR, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 4, 2, 0x10, 0x20, 0x40
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
@@ -463,8 +463,9 @@ def alloc_frame(fmt, w, h, rng=None, pad=0):
         if rng is not None:
             a[:] = rng.integers(0, 256, a.shape, dtype=np.uint8)
         return a
-    cw, ch = (w + 1) // 2, (h + 1) // 2
-    if fmt == PIX["yuv420p"]:
+    hs, vs = (0, 0) if fmt == PIX["yuv444p"] else (1, 0) if fmt == PIX["yuv422p"] else (1, 1)
+    cw, ch = -((-w) >> hs), -((-h) >> vs)
+    if fmt in (PIX["yuv420p"], PIX["yuv422p"], PIX["yuv444p"]):
         return [mk(h, w), mk(ch, cw), mk(ch, cw)]
     if fmt in (PIX["nv12"], PIX["nv21"]):
         return [mk(h, w), mk(ch, 2 * cw)]

@@ -108,6 +108,14 @@ SCALE_CASES = [
     ("yuv420p", 352, 288, "argb", 120, 90, ffi.SWS_BICUBIC, 0),
     ("nv21", 176, 144, "abgr", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
     ("yuv420p", 1920, 1080, "rgb24", 1920, 1080, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
+    # 4:2:2 / 4:4:4 planar: the same kernels on other chroma plane sizes
+    ("yuv422p", 128, 72, "yuv422p", 200, 130, ffi.SWS_BICUBIC, 3),
+    ("yuv444p", 101, 77, "yuv420p", 333, 191, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 128, 72, "yuv444p", 200, 100, ffi.SWS_BILINEAR, 0),
+    ("yuv422p", 161, 90, "nv12", 100, 62, ffi.SWS_BICUBIC, 0),
+    ("nv21", 96, 64, "yuv422p", 200, 130, ffi.SWS_BICUBIC, 0),
+    ("yuv422p", 128, 72, "yuv444p", 128, 72, ffi.SWS_BICUBIC, 0),     # same size: only the chroma planes are scaled
+    ("yuv444p", 1920, 1080, "yuv444p", 1280, 720, ffi.SWS_BICUBIC, 0),
 ]
 
 
@@ -147,13 +155,14 @@ def test_scaled(case):
             cuts = [0, 4, 4 + 2 * ((sh - 4) // 4), sh]
             rets = []
             for y0, y1 in zip(cuts[:-1], cuts[1:]):
-                sl = [src[0][y0:]] + [a[y0 // 2:] for a in src[1:]]
+                vs = 0 if sf in ("yuv422p", "yuv444p") else 1
+                sl = [src[0][y0:]] + [a[y0 >> vs:] for a in src[1:]]
                 rets.append(ctx.scale(sl, hd, y0, y1 - y0))
             assert rets == [0, 0, dh]
             for a, b in zip(hd, want):
                 assert np.array_equal(a, b)
             with pytest.raises(RuntimeError, match="out of order"):
-                ctx.scale([src[0][8:]] + [a[4:] for a in src[1:]], hd, 8, 2)
+                ctx.scale([src[0][8:]] + [a[8 >> vs:] for a in src[1:]], hd, 8, 2)
     ctx.close()
 
 

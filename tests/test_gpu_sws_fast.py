@@ -123,6 +123,8 @@ CASES = [
     ("yuv420p", 240, 136, "yuv420p", 320, 180, ffi.SWS_BICUBIC),     # 1.33x
     ("yuv420p", 202, 120, "nv12", 456, 270, ffi.SWS_BICUBIC),        # 2.26x, srcW % 4 != 0, odd chroma width
     ("nv21", 90, 50, "yuv420p", 200, 110, ffi.SWS_BILINEAR),         # padded banks at a fractional ratio
+    ("yuv422p", 128, 72, "yuv422p", 256, 160, ffi.SWS_BICUBIC),      # 4:2:2 / 4:4:4: other chroma plane sizes, same kernels
+    ("yuv444p", 128, 72, "yuv420p", 272, 144, ffi.SWS_BICUBIC),
 ]
 
 
@@ -155,6 +157,8 @@ UP2_CASES = [
     ("nv12", 192, 108, "nv12", 384, 216, ffi.SWS_POINT),             # 1-tap banks
     ("yuv420p", 136, 72, "yuv420p", 272, 144, ffi.SWS_BICUBLIN),     # bicubic luma, bilinear chroma
     ("nv12", 520, 90, "nv12", 1040, 180, ffi.SWS_BICUBIC),           # 130 luma groups: 2.03 waves per row
+    ("yuv422p", 128, 72, "yuv422p", 256, 144, ffi.SWS_BICUBIC),      # 4:2:2: chroma planes 64 x 72 -> 128 x 144
+    ("yuv444p", 128, 72, "yuv444p", 256, 144, ffi.SWS_BICUBIC),      # 4:4:4: three planes of the luma's size
 ]
 UP2_VARIANTS = [
     {},
@@ -429,6 +433,7 @@ WIDE_CASES = [
     ("yuv420p", 640, 360, "yuv420p", 160, 90 + 2, ffi.SWS_AREA),       # 4x area: 4..5 taps at stride 4
     ("nv12", 384, 216, "nv12", 512, 108, ffi.SWS_BICUBIC),           # up horizontally, down vertically
     ("yuv420p", 202, 120, "yuv420p", 104, 60, ffi.SWS_BICUBIC),      # odd chroma width (planar)
+    ("yuv422p", 480, 270, "yuv444p", 320, 180, ffi.SWS_BICUBIC),     # 4:2:2 -> 4:4:4: chroma up horizontally, down vertically
     # exact 2:1 across several column blocks
     ("yuv420p", 2560, 96, "yuv420p", 1280, 48, ffi.SWS_BICUBIC),     # planes + a planar U/V pair
     ("nv21", 2560, 96, "nv21", 1280, 48, ffi.SWS_BICUBIC),           # interleaved pair, swapped
@@ -470,6 +475,8 @@ DOWN2_CASES = [
     ("nv12", 1032, 16, "nv12", 516, 8, ffi.SWS_BICUBIC),             # chroma: as many source rows as taps, every window touches an edge
     ("nv12", 520, 500, "nv12", 260, 250, ffi.SWS_BICUBIC),           # chroma 130 wide: a width the wide walker does not take
     ("nv12", 1032, 8, "nv12", 516, 4, ffi.SWS_BICUBIC),              # fewer chroma rows than taps
+    ("yuv422p", 384, 216, "yuv422p", 192, 108, ffi.SWS_BICUBIC),     # 4:2:2 / 4:4:4 planes
+    ("yuv444p", 384, 216, "yuv444p", 192, 108, ffi.SWS_BICUBIC),
 ]
 
 

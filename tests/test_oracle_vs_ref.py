@@ -79,7 +79,35 @@ SCALE_CASES = [
     ("yuv420p", 176, 144, "argb", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND | ffi.SWS_BITEXACT),
     ("nv21", 176, 144, "abgr", 120, 200, ffi.SWS_BICUBIC),
     ("nv12", 192, 108, "nv12", 384, 216, 0x200),
+    # 4:2:2 / 4:4:4 planar (chroma subsampled horizontally only / not at all), to themselves and across subsamplings
+    ("yuv422p", 128, 72, "yuv422p", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv444p", 128, 72, "yuv444p", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv422p", 192, 108, "yuv422p", 96, 54, ffi.SWS_BICUBIC),
+    ("yuv444p", 192, 108, "yuv444p", 96, 54, ffi.SWS_BICUBIC),
+    ("yuv444p", 101, 77, "yuv420p", 333, 191, ffi.SWS_BICUBIC),
+    ("yuv420p", 128, 72, "yuv444p", 200, 100, ffi.SWS_BILINEAR),
+    ("yuv422p", 161, 90, "nv12", 100, 62, ffi.SWS_BICUBIC),
+    ("nv21", 96, 64, "yuv422p", 200, 130, ffi.SWS_BICUBIC),
+    ("yuv422p", 128, 72, "yuv444p", 128, 72, ffi.SWS_BICUBIC),
+    ("yuv444p", 128, 72, "yuv420p", 128, 72, ffi.SWS_BICUBIC),
 ]
+
+
+@pytest.mark.parametrize("case", [c for c in SCALE_CASES if "yuv422p" in c or "yuv444p" in c], ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_host_tables_422_444(case):
+    """our initFilter() restatement on the 4:2:2 / 4:4:4 formats: chroma plane sizes and banks equal the reference's"""
+    from ffmpeg_amd import swscale as S
+    sf, sw, sh, df, dw, dh, flags = case
+    R = ffi.ref()
+    ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, PIX[df], flags, 1)
+    assert ctx and not R.ffref_sws_is_unscaled(ctx)
+    banks = ffi.ref_tables(ctx)
+    R.ffref_sws_free(ctx)
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    for name in ("hLum", "hChr", "vLum", "vChr"):
+        f, p, fs, n = ht.bank(name)
+        rf, rp, rfs, rn = banks[name]
+        assert (fs, n) == (rfs, rn) and np.array_equal(p, rp) and np.array_equal(f, rf), name
 
 
 @pytest.mark.parametrize("case", SCALE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
