@@ -31,7 +31,9 @@ def sws():
              ("yuv420p", 48, 32, "rgb24", 96, 64, 4), ("yuv420p", 48, 32, "bgr24", 48, 32, 4 | 0x40000 | 0x80000),
              # appended later (the earlier cases keep their seeded inputs): 32-bit packed targets
              ("yuv420p", 64, 16, "bgra", 64, 16, 4), ("yuv420p", 62, 8, "argb", 62, 8, 4),
-             ("nv12", 48, 32, "rgba", 96, 64, 4), ("yuv420p", 48, 32, "abgr", 48, 32, 4 | 0x40000 | 0x80000)]
+             ("nv12", 48, 32, "rgba", 96, 64, 4), ("yuv420p", 48, 32, "abgr", 48, 32, 4 | 0x40000 | 0x80000),
+             # round 2: 4:2:2 / 4:4:4 planar on either side
+             ("yuv422p", 64, 40, "yuv422p", 160, 88, 4), ("yuv444p", 48, 32, "yuv420p", 96, 64, 4), ("nv12", 64, 48, "yuv444p", 40, 30, 4)]
     for i, (sf, sw, sh, df, dw, dh, fl) in enumerate(cases):
         src = ffi.alloc_frame(PIX[sf], sw, sh, rng)
         ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, PIX[df], fl, 1)
