@@ -317,6 +317,13 @@ def test_fft_golden():
                 out = np.zeros(n, np.float32)
                 O.ffo_dct_run(inv, n, 1.0, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p))
                 assert np.array_equal(out.view(np.uint32), want[t].view(np.uint32)), ("dct", n, inv)
+    for len_ in (16, 1024):
+        for mode in (1, 2):
+            x, want = d["rdfth%d_%d_in" % (len_, mode)], d["rdfth%d_%d_out" % (len_, mode)]
+            for t in range(x.shape[0]):
+                out = np.zeros(len_ // 2 + 1, np.float32)
+                O.ffo_rdft_half_run(mode, len_, 1.0, ptr(out, f32p), ptr(np.ascontiguousarray(x[t]), f32p))
+                assert np.array_equal(out[:want.shape[1]].view(np.uint32), want[t].view(np.uint32)), ("rdft half", len_, mode)
 
 
 def test_sws_uops_golden():

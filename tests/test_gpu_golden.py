@@ -303,6 +303,20 @@ def test_rdft_golden_gpu():
             ctx.close()
 
 
+def test_rdft_half_golden_gpu():
+    from ffmpeg_amd import tx
+    torch = _torch()
+    d = G.load("fft")
+    for len_ in (16, 1024):
+        for mode in (1, 2):
+            x, want = d["rdfth%d_%d_in" % (len_, mode)], d["rdfth%d_%d_out" % (len_, mode)]
+            ctx = tx.TxContext(tx.FLOAT_RDFT, 0, len_, 1.0, flags=tx.REAL_TO_REAL if mode == 1 else tx.REAL_TO_IMAGINARY)
+            out = torch.zeros((want.shape[0], len_ // 2 + 2), dtype=torch.float32, device="cuda:0")
+            ctx.batch(out[:, :want.shape[1]], torch.from_numpy(np.ascontiguousarray(x)).cuda())
+            assert np.array_equal(np.ascontiguousarray(out.cpu().numpy()[:, :want.shape[1]]).view(np.uint32), want.view(np.uint32)), (len_, mode)
+            ctx.close()
+
+
 def test_dct_golden_gpu():
     from ffmpeg_amd import tx
     torch = _torch()

@@ -229,6 +229,19 @@ def fft():
                 R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 4)
             R.ffref_tx_free(rc)
             d["dct%d_%d_in" % (n, inv)], d["dct%d_%d_out" % (n, inv)] = x[:, :n].copy(), out[:, :n].copy()
+    # the half-complex forward RDFTs (flags AV_TX_REAL_TO_REAL = 1 << 3 / AV_TX_REAL_TO_IMAGINARY = 1 << 4): len / 2 + 1 real parts resp.
+    # len / 2 imaginary parts; the reference's FFT lands in dst first, hence the wide buffer
+    rng = np.random.default_rng(1011)
+    for len_ in (16, 1024):
+        for mode in (1, 2):
+            x = rng.uniform(-1, 1, (3, len_)).astype(np.float32)
+            rc = R.ffref_tx_create(6, 0, len_, 1.0, 1 << (2 + mode))
+            nout = len_ // 2 + (mode == 1)
+            out = np.zeros((3, len_ + 2), np.float32)
+            for t in range(3):
+                R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 4)
+            R.ffref_tx_free(rc)
+            d["rdfth%d_%d_in" % (len_, mode)], d["rdfth%d_%d_out" % (len_, mode)] = x, out[:, :nout].copy()
     np.savez_compressed(os.path.join(OUT, "fft.npz"), **d)
 
 
