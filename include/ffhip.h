@@ -64,7 +64,8 @@ int         ffhip_stream_synchronize(void *stream);
 #define FFHIP_PIX_FMT_YUV420P 0
 #define FFHIP_PIX_FMT_RGB24   2
 #define FFHIP_PIX_FMT_BGR24   3
-#define FFHIP_PIX_FMT_YUV422P 4    /* planar 4:2:2 and 4:4:4, 8 bits (== AV_PIX_FMT_YUV422P / _YUV444P): YUV targets only */
+#define FFHIP_PIX_FMT_YUV422P 4    /* planar 4:2:2 and 4:4:4, 8 bits (== AV_PIX_FMT_YUV422P / _YUV444P): sources and targets of the scaler;
+                                    * as sources they go to YUV targets only (packed RGB takes the 4:2:0 sources) */
 #define FFHIP_PIX_FMT_YUV444P 5
 #define FFHIP_PIX_FMT_NV12    23
 #define FFHIP_PIX_FMT_NV21    24
