@@ -371,6 +371,20 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     int lum_scaler = scaler_of(flags, 0), chr_scaler = scaler_of(flags, 1);
     int r;
 
+    /* full-range twins on both sides: no range conversion, the base formats' scaler (handle_jpeg(), utils.c:1019-1050) */
+    {
+        const int sj = srcFormat >= FFHIP_PIX_FMT_YUVJ420P && srcFormat <= FFHIP_PIX_FMT_YUVJ444P;
+        const int dj = dstFormat >= FFHIP_PIX_FMT_YUVJ420P && dstFormat <= FFHIP_PIX_FMT_YUVJ444P;
+        static const int base[3] = { FFHIP_PIX_FMT_YUV420P, FFHIP_PIX_FMT_YUV422P, FFHIP_PIX_FMT_YUV444P };
+        if (sj != dj) {
+            ffhip_set_error("ffhip_sws: a full-range (J) format on one side only needs a range conversion; not on the hip path");
+            return NULL;
+        }
+        if (sj) {
+            srcFormat = base[srcFormat - FFHIP_PIX_FMT_YUVJ420P];
+            dstFormat = base[dstFormat - FFHIP_PIX_FMT_YUVJ420P];
+        }
+    }
     if (flags & FFHIP_SWS_FAST_BILINEAR) {
         /* the C path of SWS_FAST_BILINEAR runs ff_hyscale_fast_c, a different horizontal scaler
          * (libswscale/hscale_fast_bilinear.c) that is not part of this hot path */

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-PIX_FMT = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
+PIX_FMT = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "yuvj420p": 12, "yuvj422p": 13, "yuvj444p": 14, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
 SWS_BILINEAR, SWS_BICUBIC, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 2, 4, 0x10, 0x20, 0x40
 SWS_GAUSS, SWS_SINC, SWS_LANCZOS = 0x80, 0x100, 0x200
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
@@ -21,6 +21,7 @@ SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
 
 def plane_shapes(fmt, w, h):
     """[(rows, bytes_per_row)] of the planes of one frame."""
+    fmt = {12: 0, 13: 4, 14: 5}.get(fmt, fmt)          # the full-range twins share their base formats' layout
     hs, vs = (0, 0) if fmt == PIX_FMT["yuv444p"] else (1, 0) if fmt == PIX_FMT["yuv422p"] else (1, 1)
     cw, ch = -((-w) >> hs), -((-h) >> vs)
     if fmt in (PIX_FMT["yuv420p"], PIX_FMT["yuv422p"], PIX_FMT["yuv444p"]):

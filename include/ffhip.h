@@ -67,6 +67,11 @@ int         ffhip_stream_synchronize(void *stream);
 #define FFHIP_PIX_FMT_YUV422P 4    /* planar 4:2:2 and 4:4:4, 8 bits (== AV_PIX_FMT_YUV422P / _YUV444P): sources and targets of the scaler;
                                     * as sources they go to YUV targets only (packed RGB takes the 4:2:0 sources) */
 #define FFHIP_PIX_FMT_YUV444P 5
+#define FFHIP_PIX_FMT_YUVJ420P 12  /* the full-range "J" twins (== AV_PIX_FMT_YUVJ420P / 422P / 444P): taken when BOTH sides are J formats —
+                                    * equal ranges need no range conversion, the conversion is the base formats' (handle_jpeg(),
+                                    * libswscale/utils.c:1019-1050); a J format on one side only, or J to packed RGB, is not on the hip path */
+#define FFHIP_PIX_FMT_YUVJ422P 13
+#define FFHIP_PIX_FMT_YUVJ444P 14
 #define FFHIP_PIX_FMT_NV12    23
 #define FFHIP_PIX_FMT_NV21    24
 #define FFHIP_PIX_FMT_ARGB    25   /* packed 8:8:8:8; alpha = 255 (the sources on this path carry none) */

@@ -166,6 +166,32 @@ def test_scaled(case):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,base", [("yuvj420p", "yuv420p"), ("yuvj444p", "yuv444p")])
+def test_full_range_twins(name, base):
+    """yuvjXXXp on both sides runs as the base formats (no range conversion between equal ranges)"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    sw, sh, dw, dh = 96, 54, 192, 108
+    rng = np.random.default_rng(12)
+    src = ffi.alloc_frame(PIX[base], sw, sh, rng)
+    ht = S.HostTables(sw, sh, PIX[base], dw, dh, PIX[base], ffi.SWS_BICUBIC)
+    t = ffi.make_otables(sw, sh, PIX[base], dw, dh, PIX[base], ffi.SWS_BICUBIC, ht.banks(), ht.coeffs())
+    want = ffi.alloc_frame(PIX[base], dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(want)
+    assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+    ctx = S.SwsContext(sw, sh, S.PIX_FMT[name], dw, dh, S.PIX_FMT[name], ffi.SWS_BICUBIC)
+    dsrc = _upload(src, n=2)
+    ddst = [torch.zeros((2,) + a.shape, dtype=torch.uint8, device="cuda:0") for a in want]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    for p, a in enumerate(want):
+        assert np.array_equal(ddst[p][1].cpu().numpy(), a)
+    ctx.close()
+    with pytest.raises(ValueError):
+        S.SwsContext(sw, sh, S.PIX_FMT[name], dw, dh, PIX[base], ffi.SWS_BICUBIC)
+
+
 def test_from_tables_dropin():
     """drop-in construction: the banks are handed over (as FFmpeg would), not generated by us"""
     from ffmpeg_amd import swscale as S, _lib

@@ -110,6 +110,37 @@ def test_host_tables_422_444(case):
         assert (fs, n) == (rfs, rn) and np.array_equal(p, rp) and np.array_equal(f, rf), name
 
 
+@pytest.mark.parametrize("base,j", [(0, 12), (4, 13), (5, 14)], ids=["yuvj420p", "yuvj422p", "yuvj444p"])
+def test_full_range_twins_are_their_base_formats(base, j):
+    """yuvjXXXp on BOTH sides: equal ranges, no range conversion — the reference's frames and banks equal the base formats'
+    (handle_jpeg, libswscale/utils.c:1019-1050), and our host tables take the pair as the base pair; one J side alone is refused"""
+    from ffmpeg_amd import swscale as S
+    R = ffi.ref()
+    rng = np.random.default_rng(j)
+    sw, sh, dw, dh = 64, 40, 160, 88
+    src = ffi.alloc_frame(base, sw, sh, rng)
+    outs = []
+    for fmt in (base, j):
+        ctx = R.ffref_sws_create(sw, sh, fmt, dw, dh, fmt, ffi.SWS_BICUBIC, 1)
+        assert ctx
+        dst = ffi.alloc_frame(base, dw, dh)
+        sp, ss = ffi.planes(src)
+        dp, ds = ffi.planes(dst)
+        assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, dp, ds) == dh
+        outs.append((dst, ffi.ref_tables(ctx)))
+        R.ffref_sws_free(ctx)
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    ht = S.HostTables(sw, sh, j, dw, dh, j, ffi.SWS_BICUBIC)
+    assert (ht.t.srcFormat, ht.t.dstFormat) == (base, base)
+    for name in ("hLum", "hChr", "vLum", "vChr"):
+        f, p, fs, n = ht.bank(name)
+        rf, rp, rfs, rn = outs[1][1][name]
+        assert (fs, n) == (rfs, rn) and np.array_equal(p, rp) and np.array_equal(f, rf), name
+    with pytest.raises(ValueError, match="one side only"):
+        S.HostTables(sw, sh, j, dw, dh, base, ffi.SWS_BICUBIC)
+
+
 @pytest.mark.parametrize("case", SCALE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
 def test_scaled_frame(case):
     sf, sw, sh, df, dw, dh, flags = case
