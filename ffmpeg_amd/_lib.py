@@ -5,6 +5,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libffhip.so")
+# the same sources with -DFFHIP_MEASURE: FFHIP_* environment knobs (measured kernel variants, fault injection) are live only
+# there.  Test / measurement infrastructure: select("measure") is called by the tests that set a knob, never by the package.
+SO_MEASURE = os.path.join(HERE, "libffhip_measure.so")
 
 u8p = C.POINTER(C.c_uint8)
 i8p = C.POINTER(C.c_int8)
@@ -26,6 +29,18 @@ class SwsTables(C.Structure):
 
 
 _lib = None
+_libs = {}
+_which = "product"
+
+
+def select(which):
+    """"product" (default) or "measure": which build lib() hands out from now on.  Objects made by one build must not be
+    passed to the other (each has its own per-device tables)."""
+    global _lib, _which
+    if which not in ("product", "measure"):
+        raise ValueError(which)
+    _which = which
+    _lib = _libs.get(which)
 
 
 def lib():
@@ -33,9 +48,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO):
-        raise ImportError("ffmpeg_amd/libffhip.so is missing - build it with "
-                          "`python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    so = SO if _which == "product" else SO_MEASURE
+    if not os.path.exists(so):
+        raise ImportError("ffmpeg_amd/%s is missing - build it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)" % os.path.basename(so))
     # In a process that also uses torch, torch's bundled HIP runtime must be the one the process initialises:
     # libffhip.so's DT_NEEDED libamdhip64.so.7 then binds to the copy torch already loaded (same SONAME).  The
     # other order loads /opt/rocm's runtime first, torch then brings its own, and two runtimes fight over the
@@ -44,10 +60,28 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(SO)
+    L = C.CDLL(so)
+    i64p = C.POINTER(C.c_int64)
     sig = {
         "ffhip_device_count": (C.c_int, []),
         "ffhip_set_device": (C.c_int, [C.c_int]),
+        "ffhip_get_device": (C.c_int, []),
+        "ffhip_stream_create": (C.c_int, [C.POINTER(vp)]),
+        "ffhip_stream_destroy": (C.c_int, [vp]),
+        "ffhip_shard_range": (None, [C.c_int64, C.c_int, C.c_int, i64p, i64p]),
+        "ffhip_shard_frame_pairs": (None, [C.c_int64, C.c_int, C.c_int, i64p, i64p, i64p, i64p]),
+        "ffhip_device_set_create": (C.c_int, [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]),
+        "ffhip_device_set_free": (None, [C.POINTER(vp)]),
+        "ffhip_device_set_size": (C.c_int, [vp]),
+        "ffhip_device_set_device": (C.c_int, [vp, C.c_int]),
+        "ffhip_device_set_stream": (vp, [vp, C.c_int]),
+        "ffhip_device_set_bind": (C.c_int, [vp, C.c_int]),
+        "ffhip_device_set_synchronize": (C.c_int, [vp]),
+        "ffhip_batch_scatter": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int64, C.POINTER(vp)]),
+        "ffhip_batch_scatter_ranges": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int64, i64p, i64p, C.POINTER(vp)]),
+        "ffhip_batch_scatter_frames_for_pairs": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int64, C.POINTER(vp)]),
+        "ffhip_batch_gather": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int64, C.POINTER(vp)]),
+        "ffhip_batch_gather_ranges": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int64, i64p, i64p, C.POINTER(vp)]),
         "ffhip_last_error": (C.c_char_p, []),
         "ffhip_version": (C.c_char_p, []),
         "ffhip_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
@@ -190,6 +224,7 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     L._missing = missing
+    _libs[_which] = L
     _lib = L
     return L
 

@@ -27,6 +27,7 @@
 enum { AAC_ONLY_LONG, AAC_LONG_START, AAC_EIGHT_SHORT, AAC_LONG_STOP }; /* enum WindowSequence, libavcodec/aac.h:63-68 */
 
 struct FFHipAacImdct {
+    int device = 0; /* windows, work buffers and the MDCT tables live on this device; every call makes it current */
     FFHipTXContext *tx1024 = nullptr, *tx128 = nullptr, *tx_ltp = nullptr;
     float *ltp_in = nullptr;    /* [ltp_frames][2048]: the windowed predictions before the forward MDCT */
     size_t ltp_frames = 0;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void k_aac_gather(const float *coeffs, const i
 
 extern "C" void ffhip_aac_imdct_free(FFHipAacImdct **pc)
 {
+    FFHipDeviceGuard dg(pc && *pc ? (*pc)->device : -1);
     if (!pc || !*pc)
         return;
     FFHipAacImdct *c = *pc;
@@ -165,6 +167,8 @@ extern "C" int ffhip_aac_imdct_create_len(FFHipAacImdct **pc, int frame_len, con
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     FFHipAacImdct *c = new (std::nothrow) FFHipAacImdct();
+    if (c)
+        c->device = ffhip_current_device();
     if (!c)
         return FFHIP_ENOMEM;
     const int L = frame_len, S = L / 8;
@@ -202,6 +206,7 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
                                                        const uint8_t *prev_sequence, const uint8_t *prev_kb_window, int nch, int nframes,
                                                        void *stream)
 {
+    FFHipDeviceGuard dg(c ? c->device : -1);
     if (!c || !coeffs || !out || !saved || !window_sequence || !use_kb_window || !prev_sequence || !prev_kb_window || nch <= 0 || nframes < 0)
         return FFHIP_EINVAL;
     const size_t n = (size_t)nch * nframes;
@@ -297,6 +302,7 @@ extern "C" int ffhip_aac_imdct_and_windowing_batch_dev(FFHipAacImdct *c, const f
 extern "C" int ffhip_aac_imdct_and_windowing(FFHipAacImdct *c, const float *coeffs, const int window_sequence[2], const int use_kb_window[2],
                                              float *saved, float *out)
 {
+    FFHipDeviceGuard dg(c ? c->device : -1);
     if (!c || !coeffs || !window_sequence || !use_kb_window || !saved || !out)
         return FFHIP_EINVAL;
     std::lock_guard<std::mutex> lk(ffhip_scratch_mutex()); /* the arena is shared with every other host-pointer face */
@@ -638,6 +644,7 @@ __global__ __launch_bounds__(256) void k_aac_ltp_window(const float *ltp_state, 
 
 extern "C" int ffhip_aac_ltp_init(FFHipAacImdct *c, float scale_ltp)
 {
+    FFHipDeviceGuard dg(c ? c->device : -1);
     if (!c)
         return FFHIP_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -648,6 +655,7 @@ extern "C" int ffhip_aac_ltp_init(FFHipAacImdct *c, float scale_ltp)
 extern "C" int ffhip_aac_ltp_predict_batch_dev(FFHipAacImdct *c, const float *ltp_state, float *pred_freq, const FFHipAacLtp *recs, int n,
                                                void *stream)
 {
+    FFHipDeviceGuard dg(c ? c->device : -1);
     if (!c || !ltp_state || !pred_freq || !recs || n < 0)
         return FFHIP_EINVAL;
     if (!n)
@@ -714,6 +722,7 @@ __global__ __launch_bounds__(256) void k_aac_update_ltp(const float *buf, const 
 
 extern "C" int ffhip_aac_update_ltp_batch_dev(FFHipAacImdct *c, float *ltp_state, const float *out, int nch, void *stream)
 {
+    FFHipDeviceGuard dg(c ? c->device : -1);
     if (!c || !ltp_state || !out || nch <= 0)
         return FFHIP_EINVAL;
     if (((uintptr_t)ltp_state | (uintptr_t)out) & 15) {
@@ -744,6 +753,7 @@ extern "C" int ffhip_aac_update_ltp_batch_dev(FFHipAacImdct *c, float *ltp_state
  * that frame's inverse MDCT alone (LD: its upper half; ELD: the whole of it, kept for three frames), so a run of frames is an MDCT
  * batch and one windowing pass over all frames; frames before the run come from the caller's `saved`. */
 struct FFHipAacLd {
+    int device = 0;
     FFHipTXContext *tx = nullptr;
     int eld = 0, n = 512;
     float *win = nullptr;     /* LD: sine_512 then sine_128; ELD: the 3.75 n window */
@@ -755,6 +765,7 @@ struct FFHipAacLd {
 
 extern "C" void ffhip_aac_ld_free(FFHipAacLd **pc)
 {
+    FFHipDeviceGuard dg(pc && *pc ? (*pc)->device : -1);
     if (!pc || !*pc)
         return;
     FFHipAacLd *c = *pc;
@@ -778,6 +789,8 @@ extern "C" int ffhip_aac_ld_create(FFHipAacLd **pc, int eld, int frame_len, cons
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     FFHipAacLd *c = new (std::nothrow) FFHipAacLd();
+    if (c)
+        c->device = ffhip_current_device();
     if (!c)
         return FFHIP_ENOMEM;
     c->eld = !!eld;
@@ -880,6 +893,7 @@ __global__ __launch_bounds__(512) void k_aac_eld_save(const float *buf, const fl
 extern "C" int ffhip_aac_ld_batch_dev(FFHipAacLd *c, const float *coeffs, float *out, float *saved, const uint8_t *kb_prev, int nch, int nframes,
                                       void *stream)
 {
+    FFHipDeviceGuard dg(c ? c->device : -1);
     if (!c || !coeffs || !out || !saved || nch <= 0 || nframes < 0 || (!c->eld && !kb_prev))
         return FFHIP_EINVAL;
     const size_t nf = (size_t)nch * nframes;

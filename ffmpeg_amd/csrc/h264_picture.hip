@@ -41,6 +41,7 @@ size_t place(size_t &total, const std::vector<T> &v, Section &s)
 } // namespace
 
 struct FFHipH264Picture {
+    int device = 0; /* staging and scratch planes live on this device; flush() makes it current for its duration */
     int mb_w = 0, mb_h = 0;
     std::vector<FFHipQpelBlock> qpel[3];          /* luma MC by stage                      */
     std::vector<FFHipChromaBlock> cmc[2][3];      /* chroma MC: plane (Cb, Cr) x stage     */
@@ -66,6 +67,7 @@ struct FFHipH264Picture {
 
 extern "C" void ffhip_h264_picture_free(FFHipH264Picture **pp)
 {
+    FFHipDeviceGuard dg(pp && *pp ? (*pp)->device : -1);
     if (!pp || !*pp)
         return;
     FFHipH264Picture *p = *pp;
@@ -123,6 +125,8 @@ extern "C" int ffhip_h264_picture_create(FFHipH264Picture **pp, int mb_w, int mb
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     FFHipH264Picture *p = new (std::nothrow) FFHipH264Picture();
+    if (p)
+        p->device = ffhip_current_device();
     if (!p)
         return FFHIP_ENOMEM;
     p->mb_w = mb_w;
@@ -322,6 +326,7 @@ extern "C" int ffhip_h264_intra_frame_dev(uint8_t *y, uint8_t *cb, uint8_t *cr, 
 extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                                         void *stream_)
 {
+    FFHipDeviceGuard dg(p ? p->device : -1);
     if (!p || !dst || !stride || !ref)
         return FFHIP_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
@@ -330,7 +335,7 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
             return FFHIP_EINVAL;
     /* a finished deblocking wavefront (an earlier picture's) that lost a hand-off is reported now rather than never */
     {
-        const int r = ffhip_h264_deblock_check();
+        const int r = ffhip_progress_check(stream);
         if (r < 0)
             return r;
     }

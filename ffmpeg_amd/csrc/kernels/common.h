@@ -104,15 +104,43 @@ __device__ __forceinline__ void ffhip_add_row(uint8_t *d8, const int (&z)[NS], i
 }
 #endif
 
-/* one lazily created scratch arena per process for the host-pointer (signature-exact) faces; every user holds
- * ffhip_scratch_mutex() from its reserve to its last copy-back */
+/* one lazily created staging arena PER DEVICE for the host-pointer (signature-exact) faces; every user holds
+ * ffhip_scratch_mutex() (the current device's) from its reserve to its last copy-back */
 int   ffhip_scratch_reserve(size_t bytes, void **dev);
+int   ffhip_have_device(void);     /* also binds a thread that never chose a device to the process default (runtime.hip) */
+int   ffhip_current_device(void);  /* the calling thread's HIP device */
 #ifdef __cplusplus
 #include <mutex>
+#include <vector>
 std::mutex &ffhip_scratch_mutex(void);
+std::vector<uint8_t> &ffhip_scratch_bounce(void); /* host bounce buffer of the current device's arena; guarded by its mutex */
+
+/* makes a context's device current for the duration of one of its calls (contexts are bound to the device they were created on) */
+struct FFHipDeviceGuard {
+    int prev;
+    explicit FFHipDeviceGuard(int device);
+    ~FFHipDeviceGuard();
+    FFHipDeviceGuard(const FFHipDeviceGuard &) = delete;
+    FFHipDeviceGuard &operator=(const FFHipDeviceGuard &) = delete;
+};
+
+/* per-device one-time setup (function attributes and tables are per device):
+ *     static FFHipPerDeviceOnce once;  if (once.enter()) { bool ok = ...; once.leave(ok); } */
+struct FFHipPerDeviceOnce {
+    std::mutex mu;
+    uint64_t done = 0;
+    bool enter(void);
+    void leave(bool ok);
+};
 #endif
-/* called wherever a process-global device resource is created: pins ffhip_set_device() to that device from then on */
-void  ffhip_note_device_resources(void);
-int   ffhip_have_device(void);
+
+/* experiment / fault-injection switches exist only in the measurement build (libffhip_measure.so, -DFFHIP_MEASURE): the product
+ * library reads no environment variable, so nothing a user exports can change its pixels */
+#ifdef FFHIP_MEASURE
+#include <stdlib.h>
+#define FFHIP_KNOB(name) getenv(name)
+#else
+#define FFHIP_KNOB(name) ((const char *)0)
+#endif
 
 #endif

@@ -676,108 +676,7 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
     }
 }
 
-/*
- * Progress counters of the launches in flight: a ring of slots in one device allocation made on first use, zeroed in
- * stream order per launch.  A slot is taken again only after the launch that used it has finished (an event per slot),
- * and every slot has a FAIL word in pinned host memory that the kernels set on a spin timeout (never in a correct run:
- * a lost hand-off).  The words are checked when a slot is reused and by ffhip_h264_deblock_check() — which
- * ffhip_stream_synchronize() and the picture pipeline's flush call — so a partly filtered picture is reported
- * (FFHIP_EIO), not returned silently.
- */
-#define DB_SLOTS 64
-#define DB_SLOT_INTS 2048
-struct DbSlot { hipEvent_t done; bool used; };
-static int *g_db_pool;
-static int *g_db_fail; /* pinned host, one word per slot */
-static DbSlot g_db_slot[DB_SLOTS];
-static unsigned g_db_next;
-static bool g_db_failed;
-static std::mutex g_db_mu;
-
-static int db_pool_init()
-{
-    if (g_db_pool)
-        return 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_db_pool), (size_t)DB_SLOTS * DB_SLOT_INTS * sizeof(int)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g_db_fail), DB_SLOTS * sizeof(int), hipHostMallocMapped));
-    for (int i = 0; i < DB_SLOTS; i++) {
-        g_db_fail[i] = 0;
-        HIP_TRY(hipEventCreateWithFlags(&g_db_slot[i].done, hipEventDisableTiming));
-        g_db_slot[i].used = false;
-    }
-    ffhip_note_device_resources();
-    return 0;
-}
-
-/* under g_db_mu: next slot whose previous launch has finished; its counters and fail word */
-static int db_slot_acquire(int **prog, int **fail, int *slot)
-{
-    int r = db_pool_init();
-    if (r < 0)
-        return r;
-    const int i = (int)(g_db_next++ % DB_SLOTS);
-    if (g_db_slot[i].used) {
-        HIP_TRY(hipEventSynchronize(g_db_slot[i].done));
-        if (g_db_fail[i]) {
-            g_db_fail[i] = 0;
-            g_db_failed = true;
-        }
-    }
-    g_db_slot[i].used = true;
-    *prog = g_db_pool + (size_t)i * DB_SLOT_INTS;
-    *fail = g_db_fail + i;
-    *slot = i;
-    return 0;
-}
-
-int ffhip_h264_deblock_check(void)
-{
-    std::lock_guard<std::mutex> lk(g_db_mu);
-    if (g_db_fail)
-        for (int i = 0; i < DB_SLOTS; i++)
-            if (g_db_slot[i].used && hipEventQuery(g_db_slot[i].done) == hipSuccess && g_db_fail[i]) {
-                g_db_fail[i] = 0;
-                g_db_failed = true;
-            }
-    if (g_db_failed) {
-        g_db_failed = false;
-        ffhip_set_error("ffhip_h264_deblock: a frame-order deblocking launch timed out waiting for a row hand-off; its picture is only partly filtered");
-        return FFHIP_EIO;
-    }
-    return 0;
-}
-
-/* The same counters serve the intra reconstruction wavefront (h264_intra.hip): `nints` zeroed progress words + the fail word of
- * a slot.  On success the pool stays locked until ffhip_h264_wavefront_slot_done() has recorded the slot's event behind the
- * launch. */
-int ffhip_h264_wavefront_slot(int nints, int **prog, int **fail, int *slot, hipStream_t stream)
-{
-    if (nints > DB_SLOT_INTS) {
-        ffhip_set_error("ffhip_h264: %d macroblock rows exceed the supported %d", nints - 1, DB_SLOT_INTS - 1);
-        return FFHIP_EINVAL;
-    }
-    g_db_mu.lock();
-    int r = db_slot_acquire(prog, fail, slot);
-    if (r >= 0 && hipMemsetAsync(*prog, 0, (size_t)nints * sizeof(int), stream) != hipSuccess) {
-        ffhip_set_error("ffhip_h264: hipMemsetAsync of the progress counters failed");
-        r = FFHIP_EIO;
-    }
-    if (r < 0)
-        g_db_mu.unlock();
-    return r;
-}
-
-int ffhip_h264_wavefront_slot_done(int slot, hipStream_t stream)
-{
-    const hipError_t e = hipEventRecord(g_db_slot[slot].done, stream);
-    g_db_mu.unlock();
-    if (e != hipSuccess) {
-        ffhip_set_error("ffhip_h264: hipEventRecord failed: %s", hipGetErrorString(e));
-        return FFHIP_EIO;
-    }
-    return 0;
-}
-
+/* the progress counters come from the per-device pool (progress_pool.hip): a slot per launch, zeroed in stream order */
 static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                           const FFHipH264Edge *edges, hipStream_t stream)
 {
@@ -788,32 +687,31 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
         ffhip_set_error("ffhip_h264_deblock_frame_chroma: plane, stride and frame pitch must be 4-byte aligned");
         return FFHIP_EINVAL;
     }
-    const char *eo = getenv("FFHIP_DEBLOCK_OLD"); /* the per-row-workgroup kernel (measurement / cross-check) */
-    const char *ef = getenv("FFHIP_DEBLOCK_FAULT"); /* test hook: lost hand-offs -> timeout -> FFHIP_EIO at the next check */
+    const char *eo = FFHIP_KNOB("FFHIP_DEBLOCK_OLD"); /* the per-row-workgroup kernel (measurement / cross-check) */
+    const char *ef = FFHIP_KNOB("FFHIP_DEBLOCK_FAULT"); /* test hook: lost hand-offs -> timeout -> FFHIP_EIO at the next check */
     const int fault = ef ? atoi(ef) : 0; /* 1: the test hook; 2 no stores, 4 no filters, 8 no waiting: timing experiments (wrong output) */
     const bool band = aligned && !(eo && eo[0] == '1' && !chroma);
     /* rows per band.  A lone picture is latency-bound: 4 = one wave per SIMD, the waves of a band must not share an issue port
      * (measured 1.9 ms vs 2.4 ms per 4K plane).  A batch that fills the chip anyway is throughput-bound: 16 keeps 15 of 16
      * hand-offs in LDS (32 planes: 2.9 ms vs 4.9 ms).  FFHIP_DEBLOCK_BAND = 4 / 8 / 16 overrides. */
-    const char *ew = getenv("FFHIP_DEBLOCK_BAND");
+    const char *ew = FFHIP_KNOB("FFHIP_DEBLOCK_BAND");
     const int bw = ew && atoi(ew) == 16 ? 16 : ew && atoi(ew) == 8 ? 8 : ew && atoi(ew) == 4 ? 4 :
                    (long long)nframes * mb_h > 2048 ? 16 : 4;
     const int nbands = cdiv(mb_h, bw);
     const int per_frame = band ? nbands : mb_h + 1;
-    if (per_frame > DB_SLOT_INTS) {
-        ffhip_set_error("ffhip_h264_deblock_frame: %d macroblock rows exceed the supported %d", mb_h, DB_SLOT_INTS - 1);
+    if (per_frame > FFHIP_PROGRESS_SLOT_INTS) {
+        ffhip_set_error("ffhip_h264_deblock_frame: %d macroblock rows exceed the supported %d", mb_h, FFHIP_PROGRESS_SLOT_INTS - 1);
         return FFHIP_EINVAL;
     }
     const int ne = chroma ? 4 : 8;
-    const int per_launch = DB_SLOT_INTS / per_frame; /* frames whose counters fit one pool slot */
+    const int per_launch = FFHIP_PROGRESS_SLOT_INTS / per_frame; /* frames whose counters fit one pool slot */
     for (int f0 = 0; f0 < nframes; f0 += per_launch) {
         const int nf = nframes - f0 < per_launch ? nframes - f0 : per_launch;
-        std::lock_guard<std::mutex> lk(g_db_mu);
-        int *prog, *fail, slot;
-        const int r = db_slot_acquire(&prog, &fail, &slot);
+        FFHipProgressSlot ps;
+        const int r = ffhip_progress_acquire(nf * per_frame, stream, &ps);
         if (r < 0)
             return r;
-        HIP_TRY(hipMemsetAsync(prog, 0, (size_t)nf * per_frame * sizeof(int), stream));
+        int *const prog = ps.prog, *const fail = ps.fail;
         uint8_t *pl = plane + (size_t)f0 * frame_pitch;
         const FFHipH264Edge *ed = edges + (size_t)f0 * mb_w * mb_h * ne;
         if (!band)
@@ -823,8 +721,14 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
         else if (chroma) { if (bw == 16) DB_LAUNCH(true, 16); else if (bw == 8) DB_LAUNCH(true, 8); else DB_LAUNCH(true, 4); }
         else             { if (bw == 16) DB_LAUNCH(false, 16); else if (bw == 8) DB_LAUNCH(false, 8); else DB_LAUNCH(false, 4); }
 #undef DB_LAUNCH
-        LAUNCH_CHECK();
-        HIP_TRY(hipEventRecord(g_db_slot[slot].done, stream));
+        const hipError_t e = hipGetLastError();
+        const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            return FFHIP_EIO;
+        }
+        if (r2 < 0)
+            return r2;
     }
     return 0;
 }

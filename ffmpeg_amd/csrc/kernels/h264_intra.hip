@@ -192,13 +192,14 @@ int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_
         ffhip_set_error("ffhip_h264_intra_frame: planes and strides must be 4-byte aligned");
         return FFHIP_EINVAL;
     }
-    int *prog, *fail, slot;
-    const int r = ffhip_h264_wavefront_slot(mb_h + 1, &prog, &fail, &slot, stream);
+    FFHipProgressSlot ps;
+    const int r = ffhip_progress_acquire(mb_h + 1, stream, &ps);
     if (r < 0)
         return r;
+    int *const prog = ps.prog, *const fail = ps.fail;
     hipLaunchKernelGGL(k_h264_intra_frame, dim3(mb_h), dim3(64), 0, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog, fail);
     const hipError_t e = hipGetLastError();
-    const int r2 = ffhip_h264_wavefront_slot_done(slot, stream);
+    const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
     if (e != hipSuccess) {
         ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
         return FFHIP_EIO;

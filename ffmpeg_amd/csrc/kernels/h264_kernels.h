@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "ffhip.h"
+#include "progress_pool.h"
 
 /* the block lists of up to three planes in one launch (chroma MC, weighted prediction); empty segments are dropped */
 struct FFHipPlaneSeg { uint8_t *dst; const uint8_t *src; const void *blocks; int stride, n, first; };
@@ -27,11 +28,6 @@ int ffhip_launch_h264_luma_dc_dequant(int16_t *output, size_t out_pitch, const i
 int ffhip_launch_h264_chroma_dc_dequant(int16_t *blocks, const int32_t *block_offset, const int32_t *qmul, int n, hipStream_t stream);
 int ffhip_launch_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n,
                                   hipStream_t stream);
-/* FFHIP_EIO (once) when a frame-order deblocking launch that has finished reported a lost hand-off; else 0 */
-int ffhip_h264_deblock_check(void);
-/* progress counters + fail word of the wavefront launches (h264_deblock.hip); slot() leaves the pool locked until slot_done() */
-int ffhip_h264_wavefront_slot(int nints, int **prog, int **fail, int *slot, hipStream_t stream);
-int ffhip_h264_wavefront_slot_done(int slot, hipStream_t stream);
 int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                   const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
 int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,

@@ -364,8 +364,8 @@ int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, c
 {
     if (n <= 0)
         return 0;
-    const char *eo = getenv("FFHIP_QPEL_OLD"); /* measured variant: the register-only kernel */
-    const char *en = getenv("FFHIP_QPEL_NB");  /* measured variant: blocks per wave */
+    const char *eo = FFHIP_KNOB("FFHIP_QPEL_OLD"); /* measured variant: the register-only kernel */
+    const char *en = FFHIP_KNOB("FFHIP_QPEL_NB");  /* measured variant: blocks per wave */
     const int nb = en ? atoi(en) : 4;
     if (!(stride & 3) && !(eo && eo[0] == '1')) {
         if (nb >= 4 && n >= 4 * 4096)

@@ -24,7 +24,6 @@
 /* |64 sqrt2 cos(m pi / 64)| as the standard rounds it; T32[k][i] = +-g[fold((2i+1)k mod 128)] */
 static int8_t hevc_t32_host[32][32];
 static std::once_flag hevc_tab_once;
-static hipError_t hevc_tab_err;
 /* the same matrix as int16 PAIRS for v_dot2_i32_i16, per transform size N (offset hevc_pk_off(N)): entry [j][q][0] =
  * (T_N[4q][j], T_N[4q+2][j]) (even basis functions), [j][q][1] = (T_N[4q+1][j], T_N[4q+3][j]) (odd), j < N/2, q < N/4 */
 __constant__ uint32_t hevc_pk[352];
@@ -249,9 +248,7 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
 typedef int hm_i4 __attribute__((ext_vector_type(4)));
 typedef int hm_i16 __attribute__((ext_vector_type(16)));
 struct HevcMfmaTab { int8_t b1[64][16], b2[64][16]; int32_t sum[32]; }; /* sum[j] = 128 * sum_k T[k][j] */
-static HevcMfmaTab *g_hm_tab;
 static std::once_flag hm_once;
-static hipError_t hm_err;
 
 __device__ __forceinline__ bool hm_keep(int k, int end) /* hevc_pass<32>'s rule */
 {
@@ -480,16 +477,34 @@ __global__ __launch_bounds__(256) void k_hevc_idct16_mfma(int16_t *coeffs, uint8
     ffhip_add_row<8>(dst + rtu.dst_offset + (ptrdiff_t)rr * stride + 8 * rh * (bd > 8 ? 2 : 1), z, bd);
 }
 
-static HevcMfmaTab *g_hm_tab16;
+/* the host tables are built once; their device copies (the __constant__ hevc_pk image and the two MFMA operand tables) exist per
+ * device, uploaded when a device first runs a transform */
+static HevcMfmaTab *g_hm_tab16_dev[64];
+static HevcMfmaTab *g_hm_tab_dev[64];
+static HevcMfmaTab hm_host, hm_host16;
+static FFHipPerDeviceOnce hevc_pk_dev_once, hm_dev_once;
+
+static int hevc_pk_upload()
+{
+    std::call_once(hevc_tab_once, [] { hevc_build_table(); });
+    if (hevc_pk_dev_once.enter()) {
+        const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(hevc_pk), hevc_pk_host, sizeof(hevc_pk_host));
+        hevc_pk_dev_once.leave(e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("ffhip_hevc_idct: coefficient table upload failed: %s", hipGetErrorString(e));
+            return FFHIP_EIO;
+        }
+    }
+    return 0;
+}
 
 static int hm_tab_init()
 {
+    const int r = hevc_pk_upload();
+    if (r < 0)
+        return r;
     std::call_once(hm_once, [] {
-        std::call_once(hevc_tab_once, [] {
-            hevc_build_table();
-            hevc_tab_err = hipMemcpyToSymbol(HIP_SYMBOL(hevc_pk), hevc_pk_host, sizeof(hevc_pk_host));
-        });
-        static HevcMfmaTab h;
+        HevcMfmaTab &h = hm_host;
         for (int l = 0; l < 64; l++) {
             const int j = l & 31, g = l >> 5;
             for (int s = 0; s < 16; s++) {
@@ -503,12 +518,9 @@ static int hm_tab_init()
                 t += hevc_t32_host[k][j];
             h.sum[j] = 128 * t;
         }
-        hm_err = hipMalloc(reinterpret_cast<void **>(&g_hm_tab), sizeof(h));
-        if (hm_err == hipSuccess)
-            hm_err = hipMemcpy(g_hm_tab, &h, sizeof(h), hipMemcpyHostToDevice);
         /* the block-diagonal pair of 16-point matrices (T16[k][j] = T32[2 k][j]): slot s of group g belongs to unit s >> 3 and is
          * row 8 g + (s & 7) of T16 in pass 1, row (s & 3) + 8 ((s >> 2) & 1) + 4 g in pass 2 */
-        static HevcMfmaTab h16;
+        HevcMfmaTab &h16 = hm_host16;
         for (int l = 0; l < 64; l++) {
             const int jp = l & 31, g = l >> 5, j = jp & 15;
             for (int sl = 0; sl < 16; sl++) {
@@ -523,16 +535,26 @@ static int hm_tab_init()
                 t += hevc_t32_host[2 * k][jp & 15];
             h16.sum[jp] = 128 * t;
         }
-        if (hm_err == hipSuccess)
-            hm_err = hipMalloc(reinterpret_cast<void **>(&g_hm_tab16), sizeof(h16));
-        if (hm_err == hipSuccess)
-            hm_err = hipMemcpy(g_hm_tab16, &h16, sizeof(h16), hipMemcpyHostToDevice);
-        if (hm_err == hipSuccess)
-            ffhip_note_device_resources();
     });
-    if (hm_err != hipSuccess || hevc_tab_err != hipSuccess) {
-        ffhip_set_error("ffhip_hevc_idct: table upload failed");
-        return FFHIP_EIO;
+    if (hm_dev_once.enter()) {
+        const int d = ffhip_current_device();
+        HevcMfmaTab *t32 = nullptr, *t16 = nullptr;
+        const bool ok = hipMalloc(reinterpret_cast<void **>(&t32), sizeof(HevcMfmaTab)) == hipSuccess &&
+                        hipMalloc(reinterpret_cast<void **>(&t16), sizeof(HevcMfmaTab)) == hipSuccess &&
+                        hipMemcpy(t32, &hm_host, sizeof(HevcMfmaTab), hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(t16, &hm_host16, sizeof(HevcMfmaTab), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) {
+            g_hm_tab_dev[d] = t32;
+            g_hm_tab16_dev[d] = t16;
+        } else {
+            (void)hipFree(t32);
+            (void)hipFree(t16);
+        }
+        hm_dev_once.leave(ok);
+        if (!ok) {
+            ffhip_set_error("ffhip_hevc_idct: table upload failed");
+            return FFHIP_EIO;
+        }
     }
     return 0;
 }
@@ -552,32 +574,29 @@ int ffhip_launch_hevc_idct_bd(int bd, int kind, int log2_size, int16_t *coeffs, 
         ffhip_set_error("ffhip_hevc: bit depth %d (8, 10 and 12 are built)", bd);
         return FFHIP_EINVAL;
     }
-    std::call_once(hevc_tab_once, [] {
-        hevc_build_table();
-        hevc_tab_err = hipMemcpyToSymbol(HIP_SYMBOL(hevc_pk), hevc_pk_host, sizeof(hevc_pk_host));
-    });
-    if (hevc_tab_err != hipSuccess) {
-        ffhip_set_error("ffhip_hevc_idct: coefficient table upload failed: %s", hipGetErrorString(hevc_tab_err));
-        return FFHIP_EIO;
+    {
+        const int r = hevc_pk_upload();
+        if (r < 0)
+            return r;
     }
     {
-        const char *eo = getenv("FFHIP_HEVC_IDCT32_VALU"); /* measured variant: the dot2 kernel for 32x32 as well */
+        const char *eo = FFHIP_KNOB("FFHIP_HEVC_IDCT32_VALU"); /* measured variant: the dot2 kernel for 32x32 as well */
         if (kind == FFHIP_HEVC_IDCT && log2_size == 5 && !(eo && eo[0] == '1')) {
             const int r = hm_tab_init();
             if (r < 0)
                 return r;
-            hipLaunchKernelGGL(k_hevc_idct32_mfma, dim3(cdiv(n, 4)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd, g_hm_tab);
+            hipLaunchKernelGGL(k_hevc_idct32_mfma, dim3(cdiv(n, 4)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd, g_hm_tab_dev[ffhip_current_device()]);
             LAUNCH_CHECK();
             return 0;
         }
         /* 16x16: with 16-byte staging the dot2 kernel (0.55 of HBM) beats the two-units-per-MFMA kernel (0.34, half of whose matrix
          * work is discarded and whose columns move through LDS 2 bytes at a time); the latter stays as a measured variant */
-        const char *e16 = getenv("FFHIP_HEVC_IDCT16_MFMA");
+        const char *e16 = FFHIP_KNOB("FFHIP_HEVC_IDCT16_MFMA");
         if (kind == FFHIP_HEVC_IDCT && log2_size == 4 && e16 && e16[0] == '1') {
             const int r = hm_tab_init();
             if (r < 0)
                 return r;
-            hipLaunchKernelGGL(k_hevc_idct16_mfma, dim3(cdiv(n, 8)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd, g_hm_tab16);
+            hipLaunchKernelGGL(k_hevc_idct16_mfma, dim3(cdiv(n, 8)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd, g_hm_tab16_dev[ffhip_current_device()]);
             LAUNCH_CHECK();
             return 0;
         }

@@ -363,7 +363,7 @@ int ffhip_launch_hevc_mc(int chroma, int mode, void *dst, ptrdiff_t dststride, c
 {
     if (n <= 0)
         return 0;
-    const char *e = getenv("FFHIP_HEVC_MC_OLD");
+    const char *e = FFHIP_KNOB("FFHIP_HEVC_MC_OLD");
     const bool old = e && e[0] == '1';
     if (chroma)
         hevc_mc_launch<true>(mode, old, dst, dststride, src, srcstride, src2, blocks, n, stream);

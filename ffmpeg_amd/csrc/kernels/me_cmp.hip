@@ -470,7 +470,7 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
     }
     const dim3 grid(bw, bh, nframes), block(64);
     /* SAD: four macroblocks (waves) per workgroup, FFHIP_ME_WPB=1 for the one-wave form */
-    const char *ew = getenv("FFHIP_ME_WPB");
+    const char *ew = FFHIP_KNOB("FFHIP_ME_WPB");
     const int lpw = (int)((lds + 15) & ~(size_t)15);
     const bool w4 = !(ew && ew[0] == '1') && (size_t)lpw * 4 <= 64 * 1024; /* large search ranges: one wave, one window */
     const dim3 grid4(cdiv(bw, 4), bh, nframes), block4(256);
@@ -484,7 +484,7 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
          * adjacent candidates per lane sharing their window rows (form 3: a quarter of the LDS reads and alignbytes, v_sad_u8 only):
          * 418 M at R = 7, 100 M at R = 16 — slower than both; and four macroblock waves per workgroup instead of one (a CU's workgroup
          * slots): + 2..6 %, kept.  Every form sits at 60 % VALU issue with the rest in LDS round trips per candidate row. */
-        const char *eq = getenv("FFHIP_ME_SAD_QUAD");
+        const char *eq = FFHIP_KNOB("FFHIP_ME_SAD_QUAD");
         const bool one_pass = ((2 * R + 1 + 3) / 4) * (2 * R + 1) <= 64;
         if (mb_size == 16 && eq && eq[0] == '3') {
             if (w4) ESA4(FFHIP_ME_SAD, 16, 3);
@@ -506,7 +506,7 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
         }
     } else {
         /* shared column transforms when their LDS plane fits (R <= 24 at 16x16); FFHIP_ME_SATD_SHARE=0: per-candidate */
-        const char *es = getenv("FFHIP_ME_SATD_SHARE");
+        const char *es = FFHIP_KNOB("FFHIP_ME_SATD_SHARE");
         const size_t vsz = ((size_t)(mb_size / 8) * mb_size + (size_t)(2 * R + mb_size - 7) * (2 * R + mb_size)) * 16;
         const size_t lds_s = ((lds + 15) & ~(size_t)15) + vsz;
         if (lds_s <= 64 * 1024 && !(es && es[0] == '0')) {

@@ -1,0 +1,26 @@
+/* progress_pool.h — the progress counters of the row-ordered ("wavefront") launches in flight: H.264 frame-order deblocking, the
+ * H.264 intra reconstruction wavefront, the VP9 superblock-order loop filter.  Internal to libffhip (progress_pool.hip). */
+#ifndef FFHIP_PROGRESS_POOL_H
+#define FFHIP_PROGRESS_POOL_H
+
+#include <hip/hip_runtime.h>
+
+#define FFHIP_PROGRESS_SLOT_INTS 2048
+
+struct FFHipProgressSlot {
+    int *prog; /* `nints` zeroed (in stream order) progress words on the current device */
+    int *fail; /* the slot's FAIL word, pinned host memory mapped into the device: a kernel sets it on a spin timeout */
+    int  index, device;
+};
+
+/* A free slot of the current device's pool, its first `nints` (<= FFHIP_PROGRESS_SLOT_INTS) counters zeroed on `stream`.  The pool
+ * lock is NOT held when this returns: the slot is simply owned until ffhip_progress_release(). */
+int ffhip_progress_acquire(int nints, hipStream_t stream, FFHipProgressSlot *s);
+/* launched: an event behind the launch on `stream` marks when the slot may be reused; !launched (an error path): the slot is free
+ * again at once. */
+int ffhip_progress_release(const FFHipProgressSlot *s, hipStream_t stream, bool launched);
+/* FFHIP_EIO (once) if a finished launch that was issued on `stream` lost a hand-off — keyed by stream, so the owner of picture A
+ * hears about picture A and nobody else does.  Checks the current device's pool. */
+int ffhip_progress_check(hipStream_t stream);
+
+#endif

@@ -1194,7 +1194,7 @@ int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream)
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    const char *et = getenv("FFHIP_CWRGB_DIRECT"); /* measured variant: per-lane 24-byte stores, no LDS transpose */
+    const char *et = FFHIP_KNOB("FFHIP_CWRGB_DIRECT"); /* measured variant: per-lane 24-byte stores, no LDS transpose */
     const bool tr = !(et && et[0] == '1');
 #define CWR_LAUNCH(S, B) do { if (tr) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, true>), grid, block, 0, stream, A); \
                               else hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, false>), grid, block, 0, stream, A); } while (0)

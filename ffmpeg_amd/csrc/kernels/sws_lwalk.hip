@@ -338,7 +338,7 @@ int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_
 void ffhip_lw_plan_job(FFHipLwJob *j)
 {
     j->ncb = cdiv(j->dstW, j->pair ? 128 : 256);
-    const char *es = getenv("FFHIP_LW_STRIP"); /* measured variant: shorter strips (more, lighter waves; more halo rows) */
+    const char *es = FFHIP_KNOB("FFHIP_LW_STRIP"); /* measured variant: shorter strips (more, lighter waves; more halo rows) */
     const int want = es && atoi(es) > 0 && atoi(es) < 64 ? atoi(es) : 64;
     const int n = cdiv(j->dstH, want);
     j->strip_rows = cdiv(j->dstH, n);
@@ -366,15 +366,15 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
     /* measured (nv12 4K -> 1080p / 720p / 540p): reading the windows one row ahead is 1-2 % SLOWER than reading them in
      * the row they are used (0.78 vs 0.77 ms per 128 frames) — the extra registers cost more than the latency they hide once
      * the units are light; FFHIP_LW_AHEAD=1 selects the pipelined form */
-    const char *ea = getenv("FFHIP_LW_AHEAD");
+    const char *ea = FFHIP_KNOB("FFHIP_LW_AHEAD");
     const bool ahead = ea && ea[0] == '1';
 #define LW_LAUNCH(H, V, N)                                                                                   \
     do {                                                                                                     \
-        static bool attr_done = false;                                                                       \
-        if (!attr_done) {                                                                                    \
+        static FFHipPerDeviceOnce attr_done;                                                                 \
+        if (attr_done.enter()) {                                                                             \
             (void)hipFuncSetAttribute((const void *)k_sws_lwalk<H, V, N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
             (void)hipFuncSetAttribute((const void *)k_sws_lwalk<H, V, N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-            attr_done = true;                                                                                \
+            attr_done.leave(true);                                                                           \
         }                                                                                                    \
         if (ahead) hipLaunchKernelGGL((k_sws_lwalk<H, V, N, true>), grid, block, lds, stream, A);            \
         else       hipLaunchKernelGGL((k_sws_lwalk<H, V, N, false>), grid, block, lds, stream, A);           \

@@ -346,7 +346,7 @@ int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_
         LAUNCH_CHECK();
         return 0;
     }
-    const char *ev = getenv("FFHIP_YUV2RGB_VARIANT"); /* "old": per-lane strided stores; "plain": no v_ashr_pk */
+    const char *ev = FFHIP_KNOB("FFHIP_YUV2RGB_VARIANT"); /* "old": per-lane strided stores; "plain": no v_ashr_pk */
     const long long waves = (long long)((chunks + 63) >> 6) * (a.h >> 1) * a.nframes;
     if (vec && waves < (1LL << 31) && !(ev && ev[0] == 'o')) {
         const dim3 grid((unsigned)((waves + 3) / 4));

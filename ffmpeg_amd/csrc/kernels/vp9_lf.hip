@@ -376,16 +376,17 @@ int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdif
         ffhip_set_error("ffhip_vp9_loopfilter_frame: bit depth %d (8, 10, 12); planes and strides must be 4-byte aligned", bd);
         return FFHIP_EINVAL;
     }
-    int *prog, *fail, slot;
-    const int r = ffhip_h264_wavefront_slot(2 * sb_rows + 1, &prog, &fail, &slot, stream);
+    FFHipProgressSlot ps;
+    const int r = ffhip_progress_acquire(2 * sb_rows + 1, stream, &ps);
     if (r < 0)
         return r;
+    int *const prog = ps.prog, *const fail = ps.fail;
     if (bd == 8)
         hipLaunchKernelGGL(k_vp9_lf_frame<uint8_t>, dim3(2 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8);
     else
         hipLaunchKernelGGL(k_vp9_lf_frame<uint16_t>, dim3(2 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, bd);
     const hipError_t e = hipGetLastError();
-    const int r2 = ffhip_h264_wavefront_slot_done(slot, stream);
+    const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
     if (e != hipSuccess) {
         ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
         return FFHIP_EIO;

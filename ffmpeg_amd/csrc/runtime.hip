@@ -6,14 +6,23 @@
 #include <mutex>
 
 #include "kernels/common.h"
+#include "kernels/progress_pool.h"
 
-static int g_count = -2;
+#include <atomic>
+#include <vector>
+
+#define FFHIP_MAX_DEVICES 64
+
+static std::atomic<int> g_count{ -2 };
 static std::mutex g_mu;
 
 extern "C" int ffhip_device_count(void)
 {
+    int c = g_count.load(std::memory_order_acquire);
+    if (c != -2)
+        return c;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_count == -2) {
+    if (g_count.load() == -2) {
         int n = 0;
         hipError_t e = hipGetDeviceCount(&n);
         if (e != hipSuccess) {
@@ -21,44 +30,87 @@ extern "C" int ffhip_device_count(void)
             (void)hipGetLastError();
             n = 0;
         }
-        g_count = n;
+        if (n > FFHIP_MAX_DEVICES)
+            n = FFHIP_MAX_DEVICES;
+        g_count.store(n, std::memory_order_release);
     }
-    return g_count;
+    return g_count.load();
 }
 
-int ffhip_have_device(void) { return ffhip_device_count() > 0; }
-
 /*
- * Process-global device resources (the staging arena below, the deblocking progress pool, the dynamic-LDS attribute latches of
- * the transforms) are created once, on the device that is current at first use.  They remember that device here; selecting
- * another one afterwards would make the host-pointer faces dereference the first GPU's memory, so it is refused (one process
- * per GPU: bind first, then work).
+ * Which device a call runs on.  One process may drive every GPU of the node (the reference's execution model is one process with
+ * frame / slice threads: libavcodec/pthread_frame.c, libswscale/swscale.c:1645-1679), so nothing in the library is tied to "the"
+ * device:
+ *   - contexts (FFHipSwsContext, FFHipTXContext, FFHipH264Picture, FFHipAac*, FFHipSwsUOps, FFHipDeviceSet) remember the device
+ *     they were created on and make it current for the duration of each of their calls, whatever the calling thread is bound to;
+ *   - context-free entry points (the batched `_dev` faces, the host-pointer shims) run on the calling thread's current device;
+ *     the shared resources they use (staging arena, progress-counter pool, coefficient tables, dynamic-LDS attribute latches,
+ *     compiled op-list modules) live in per-device tables indexed by it.
+ * HIP's current device is per THREAD and a new thread starts on device 0.  The first ffhip_set_device() of the process also sets
+ * the process default; a thread that never called ffhip_set_device() (an FFmpeg frame/slice worker calling a shim face) is bound
+ * to that default at its first entry, so the workers of a process that chose device N do not silently run on device 0.
  */
-static int g_resource_device = -1;
-void ffhip_note_device_resources(void)
+static std::atomic<int> g_default_device{ -1 };
+static thread_local bool t_bound;
+
+static inline void thread_bind(void)
 {
-    int d = -1;
-    if (hipGetDevice(&d) == hipSuccess) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (g_resource_device < 0)
-            g_resource_device = d;
+    if (t_bound)
+        return;
+    t_bound = true;
+    const int d = g_default_device.load(std::memory_order_acquire);
+    int cur = -1;
+    if (d >= 0 && hipGetDevice(&cur) == hipSuccess && cur != d)
+        (void)hipSetDevice(d);
+}
+
+int ffhip_have_device(void)
+{
+    if (ffhip_device_count() <= 0)
+        return 0;
+    thread_bind();
+    return 1;
+}
+
+int ffhip_current_device(void)
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
     }
+    return d < FFHIP_MAX_DEVICES ? d : 0;
 }
 
 extern "C" int ffhip_set_device(int device)
 {
     if (device < 0 || device >= ffhip_device_count())
         return FFHIP_EINVAL;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (g_resource_device >= 0 && g_resource_device != device) {
-            ffhip_set_error("ffhip_set_device(%d): this process already holds device resources on device %d "
-                            "(call ffhip_set_device before any other entry point)", device, g_resource_device);
-            return FFHIP_EINVAL;
-        }
-    }
     HIP_TRY(hipSetDevice(device));
+    t_bound = true;
+    int none = -1;
+    g_default_device.compare_exchange_strong(none, device);
     return 0;
+}
+
+extern "C" int ffhip_get_device(void)
+{
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_current_device();
+}
+
+FFHipDeviceGuard::FFHipDeviceGuard(int device) : prev(-1)
+{
+    thread_bind();
+    int cur = -1;
+    if (device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess)
+        prev = cur;
+}
+FFHipDeviceGuard::~FFHipDeviceGuard()
+{
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
 }
 
 extern "C" int ffhip_malloc(void **p, size_t bytes)
@@ -88,39 +140,81 @@ extern "C" int ffhip_memcpy_d2h(void *d, const void *s, size_t n)
     HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost));
     return 0;
 }
-int ffhip_h264_deblock_check(void);
+extern "C" int ffhip_stream_create(void **stream)
+{
+    if (!stream)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return 0;
+}
+extern "C" int ffhip_stream_destroy(void *stream)
+{
+    if (stream)
+        HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
 extern "C" int ffhip_stream_synchronize(void *stream)
 {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return ffhip_h264_deblock_check(); /* a finished deblocking launch that lost a hand-off is reported here, not dropped */
+    /* a finished wavefront launch OF THIS STREAM that lost a hand-off is reported here, not dropped */
+    return ffhip_progress_check((hipStream_t)stream);
 }
 
-/* grow-only arena of the host-pointer faces.  ONE mutex guards it for every user: a face holds ffhip_scratch_mutex() for its
- * whole stage / run / copy-back sequence (the arena may be freed and reallocated by the next caller's reserve). */
-static void  *g_scratch;
-static size_t g_scratch_sz;
-static std::mutex g_scratch_mu;
-std::mutex &ffhip_scratch_mutex(void) { return g_scratch_mu; }
+/* grow-only staging arena of the host-pointer faces, one per device.  ONE mutex per device guards it for every user: a face
+ * holds ffhip_scratch_mutex() for its whole stage / run / copy-back sequence (the arena may be freed and reallocated by the next
+ * caller's reserve).  Faces on different devices do not contend. */
+struct DeviceArena {
+    std::mutex mu;
+    void *buf = nullptr;
+    size_t size = 0;
+    std::vector<uint8_t> bounce;
+};
+static DeviceArena g_arena[FFHIP_MAX_DEVICES];
+std::mutex &ffhip_scratch_mutex(void) { return g_arena[ffhip_current_device()].mu; }
+std::vector<uint8_t> &ffhip_scratch_bounce(void) { return g_arena[ffhip_current_device()].bounce; }
 int ffhip_scratch_reserve(size_t bytes, void **dev)
 {
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    ffhip_note_device_resources();
-    if (bytes > g_scratch_sz) {
-        if (g_scratch)
-            HIP_TRY(hipFree(g_scratch));
-        g_scratch = NULL;
-        g_scratch_sz = 0;
+    DeviceArena &a = g_arena[ffhip_current_device()];
+    if (bytes > a.size) {
+        if (a.buf)
+            HIP_TRY(hipFree(a.buf));
+        a.buf = NULL;
+        a.size = 0;
         size_t want = bytes + (bytes >> 1) + 4096;
-        hipError_t e = hipMalloc(&g_scratch, want);
+        hipError_t e = hipMalloc(&a.buf, want);
         if (e != hipSuccess) {
             ffhip_set_error("scratch hipMalloc(%zu): %s", want, hipGetErrorString(e));
             return FFHIP_ENOMEM;
         }
-        g_scratch_sz = want;
+        a.size = want;
     }
-    *dev = g_scratch;
+    *dev = a.buf;
     return 0;
+}
+
+/* run `f` once per device (dynamic-LDS attribute latches, coefficient-table uploads): `once` is a static of the caller */
+bool FFHipPerDeviceOnce::enter(void)
+{
+    mu.lock();
+    const int d = ffhip_current_device();
+    if (done >> (d & 63) & 1) {
+        mu.unlock();
+        return false;
+    }
+    return true; /* locked: the caller does its work, then leave() */
+}
+void FFHipPerDeviceOnce::leave(bool ok)
+{
+    const int d = ffhip_current_device();
+    if (ok)
+        done |= 1ull << (d & 63);
+    mu.unlock();
 }
 
 /* ---- achievable-bandwidth probe (bench.py: the box's streaming roofs beside the 8 TB/s spec) ---- */

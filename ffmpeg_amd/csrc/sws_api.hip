@@ -17,6 +17,7 @@
 #include "kernels/shim_arena.h"
 
 struct FFHipSwsContext {
+    int device = 0; /* the banks live on this device; every call of the context makes it current for its duration */
     FFHipSwsTables t;
     std::vector<int16_t> f[4];
     std::vector<int32_t> p[4];
@@ -65,7 +66,7 @@ struct FFHipSwsContext {
 
 static bool em_forced()
 {
-    const char *em = getenv("FFHIP_SWS_MFMA");
+    const char *em = FFHIP_KNOB("FFHIP_SWS_MFMA");
     return em && em[0] == '1';
 }
 static bool fmt_yuv(int f)
@@ -280,6 +281,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
     FFHipSwsContext *c = new (std::nothrow) FFHipSwsContext();
     if (!c)
         return nullptr;
+    c->device = ffhip_current_device();
     c->t = *t;
     c->chrSrcW = -((-t->srcW) >> fmt_hsub(t->srcFormat));
     c->chrSrcH = -((-t->srcH) >> fmt_vsub(t->srcFormat));
@@ -409,7 +411,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         /* wide banks (down-scaling, long kernels): the LDS-backed walker; FFHIP_SWS_WIDE=1 builds it for narrow banks
          * too (parity tests of that kernel on up-scaling cases) */
         {
-            const char *ew = getenv("FFHIP_SWS_WIDE");
+            const char *ew = FFHIP_KNOB("FFHIP_SWS_WIDE");
             if ((!c->cw_ok || (ew && ew[0] == '1')) && build_wide_view(c, limits)) {
                 const int hts[2] = { c->lw_ht, c->lw_ht };
                 bool ok = true;
@@ -556,6 +558,7 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
 {
     if (!c)
         return;
+    FFHipDeviceGuard dg(c->device);
     if (c->dev_tables)
         (void)hipFree(c->dev_tables);
     if (c->mf_dev)
@@ -580,6 +583,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
     hipStream_t stream = (hipStream_t)stream_;
     if (!c || nframes < 0 || !src || !dst)
         return FFHIP_EINVAL;
+    FFHipDeviceGuard dg(c->device);
     const FFHipSwsTables &t = c->t;
     const uint8_t *s0 = (const uint8_t *)src[0], *s1 = (const uint8_t *)src[1], *s2 = (const uint8_t *)src[2];
 
@@ -614,7 +618,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         a.chr_step = cstep;
         a.dst = (uint8_t *)dst[0]; a.dst_stride = dstStride[0]; a.dst_fp = dstFramePitch[0];
         a.nframes = nframes;
-        const char *ev = getenv("FFHIP_SWS_FAST");
+        const char *ev = FFHIP_KNOB("FFHIP_SWS_FAST");
         uintptr_t al = (uintptr_t)s0 | (size_t)srcStride[0] | srcFramePitch[0] | (uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp |
                        (size_t)cus | (size_t)cvs | cuf | cvf | (uintptr_t)(cstep == 2 ? s1 : cu) | (uintptr_t)(cstep == 2 ? s1 : cv);
         if (c->cw_rgb && !(ev && ev[0] == '0') && !(al & 3)) {
@@ -658,7 +662,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
 
     /* fast path: 4x4-tap banks, dword-aligned planes.  FFHIP_SWS_FAST=0 forces the LDS-tiled kernel;
      * FFHIP_CW_LUMA_GROUPS / FFHIP_CW_PLAIN select measured variants. */
-    const char *ev = getenv("FFHIP_SWS_FAST");
+    const char *ev = FFHIP_KNOB("FFHIP_SWS_FAST");
     if (c->cw_ok && !(ev && ev[0] == '0')) {
         uintptr_t al = 0;
         for (int i = 0; i < 2; i++) {
@@ -669,7 +673,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             al |= ch.src_step == 2 ? (uintptr_t)(ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1]) : (uintptr_t)ch.src[i];
             al |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
         }
-        const char *eu = getenv("FFHIP_SWS_UP2");
+        const char *eu = FFHIP_KNOB("FFHIP_SWS_UP2");
         if (!(al & 3) && c->up2_ok && !(eu && eu[0] == '0') && !(em_forced())) {
             /* exact 2x: static schedule, regular windows (sws_up2.hip).  FFHIP_SWS_UP2=0 takes the general column walker. */
             FFHipUp2Args U;
@@ -695,8 +699,8 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             }
             /* frames per wave: the split that wastes the fewest lanes at the right edge of the widest job's rows;
              * lane offsets (frame pitch included) must stay below 2^32 */
-            const char *ef = getenv("FFHIP_UP2_FSHIFT"), *es = getenv("FFHIP_UP2_STRIP"), *ed = getenv("FFHIP_UP2_DEPTH");
-            const char *ev2 = getenv("FFHIP_UP2_VAR"), *ex = getenv("FFHIP_UP2_XCD");
+            const char *ef = FFHIP_KNOB("FFHIP_UP2_FSHIFT"), *es = FFHIP_KNOB("FFHIP_UP2_STRIP"), *ed = FFHIP_KNOB("FFHIP_UP2_DEPTH");
+            const char *ev2 = FFHIP_KNOB("FFHIP_UP2_VAR"), *ex = FFHIP_KNOB("FFHIP_UP2_XCD");
             U.xcd = !(ex && ex[0] == '0');
             int best = 0;
             double bestw = 1e30;
@@ -730,10 +734,10 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             }
         }
         if (!(al & 3)) {
-            const char *em = getenv("FFHIP_SWS_MFMA");
+            const char *em = FFHIP_KNOB("FFHIP_SWS_MFMA");
             if (c->mf_ok && em && em[0] == '1') {
                 /* horizontal pass on the matrix cores (k_sws_mfma) */
-                const char *est = getenv("FFHIP_MF_STRIP");
+                const char *est = FFHIP_KNOB("FFHIP_MF_STRIP");
                 FFHipMfArgs M;
                 memset(&M, 0, sizeof(M));
                 M.nframes = nframes;
@@ -762,19 +766,19 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                 }
                 return ffhip_launch_mfma(M, stream);
             }
-            const char *eg = getenv("FFHIP_CW_LUMA_GROUPS"), *ep = getenv("FFHIP_CW_PLAIN");
-            const char *ed = getenv("FFHIP_CW_DEPTH"), *es = getenv("FFHIP_CW_STRIP");
+            const char *eg = FFHIP_KNOB("FFHIP_CW_LUMA_GROUPS"), *ep = FFHIP_KNOB("FFHIP_CW_PLAIN");
+            const char *ed = FFHIP_KNOB("FFHIP_CW_DEPTH"), *es = FFHIP_KNOB("FFHIP_CW_STRIP");
             const int lg = (eg && eg[0] == '1') || (ep && ep[0] == '1') ? 1 : 2; /* measured: 2 groups/lane is 12 % faster */
             const int depth = ed && ed[0] == '3' ? 3 : 6; /* measured: 6 rows in flight is 4 % faster with OPT */
             const int strip = es && atoi(es) > 0 ? atoi(es) : 120;
             FFHipCwArgs A;
             memset(&A, 0, sizeof(A));
             A.nframes = nframes;
-            const char *eo = getenv("FFHIP_CW_OPT");
+            const char *eo = FFHIP_KNOB("FFHIP_CW_OPT");
             A.flags = ep && ep[0] == '1' ? 1 : 0;
             if (c->cw_opt && !A.flags && !(eo && eo[0] == '0'))
                 A.flags |= 2;
-            const char *edup = getenv("FFHIP_CW_DUP");
+            const char *edup = FFHIP_KNOB("FFHIP_CW_DUP");
             if ((A.flags & 2) && c->cw_dup && !(edup && edup[0] == '0'))
                 A.flags |= 4;
             auto bank = [&](FFHipCwJob &j, const FFHipScalePlaneArgs &p) {
@@ -826,7 +830,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         al2 |= ch.src_step == 2 ? (uintptr_t)(ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1]) : (uintptr_t)ch.src[i];
         al2 |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
     }
-    const char *e2 = getenv("FFHIP_SWS_DOWN2");
+    const char *e2 = FFHIP_KNOB("FFHIP_SWS_DOWN2");
     bool neg = false;
     for (int i = 0; i < 2; i++)
         neg = neg || l.src_stride[i] < 0 || l.dst_stride[i] < 0 || ch.src_stride[i] < 0 || ch.dst_stride[i] < 0;
@@ -835,7 +839,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         FFHipDn2Args D;
         memset(&D, 0, sizeof(D));
         D.nframes = nframes;
-        const char *ex = getenv("FFHIP_DN2_XCD"), *es = getenv("FFHIP_DN2_STRIP");
+        const char *ex = FFHIP_KNOB("FFHIP_DN2_XCD"), *es = FFHIP_KNOB("FFHIP_DN2_STRIP");
         D.xcd = !(ex && ex[0] == '0');
         auto dnjob = [&](const FFHipScalePlaneArgs &p, int which, const uint8_t *src, ptrdiff_t ss, size_t sf, uint8_t *dst,
                          ptrdiff_t dsr, size_t df, int pair, int swap) {
@@ -859,7 +863,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         return ffhip_launch_down2(D, stream);
     }
     /* wide banks: the LDS-backed walker (FFHIP_SWS_WIDE=0 forces the LDS-tiled kernel) */
-    const char *ew = getenv("FFHIP_SWS_WIDE");
+    const char *ew = FFHIP_KNOB("FFHIP_SWS_WIDE");
     const bool cw_taken_off = ev && ev[0] == '0';
     if (c->lw_ok && !(ew && ew[0] == '0') && !(cw_taken_off && !(ew && ew[0] == '1'))) {
         uintptr_t al = (uintptr_t)l.src[0] | (size_t)l.src_stride[0] | l.src_fp[0] | (uintptr_t)l.dst[0] | (size_t)l.dst_stride[0] |
@@ -946,6 +950,7 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
 {
     if (!c || !src || !dst || srcSliceH <= 0)
         return FFHIP_EINVAL;
+    FFHipDeviceGuard dg(c->device);
     std::lock_guard<std::mutex> lk(c->mu);
     const FFHipSwsTables &t = c->t;
     const bool unscaled = c->unscaled_yuv2rgb;
@@ -1199,6 +1204,7 @@ static int packed_line(FFHipSwsContext *c, int mode, const int16_t *lf, const in
 {
     if (!c || !dest || !lum || !cu || !cv || dstW < 2 || (dstW & 1) || lfs < 1 || cfs < 1 || lfs > 256 || cfs > 256 || !fmt_rgb(c->t.dstFormat))
         return FFHIP_EINVAL;
+    FFHipDeviceGuard dg(c->device);
     const int lay = rgb_layout(c->t.dstFormat), bpp = lay < 2 ? 3 : 4, cw = dstW >> 1;
     const size_t pitch = ((size_t)dstW * 2 + 63) & ~(size_t)63, bd = ((size_t)dstW * bpp + 63) & ~(size_t)63;
     Arena A(1024 + pitch * (lfs + 2 * cfs) + bd);

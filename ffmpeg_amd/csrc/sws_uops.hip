@@ -459,25 +459,40 @@ int generate(const FFHipSwsUOp *uops, int n_uops, Plan &pl)
 
 /* ---- hiprtc + module cache --------------------------------------------------------------------------------------------------- */
 struct Program {
-    std::vector<char> code;
-    hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr;
+    std::vector<char> code;          /* the code object: per architecture, shared by every device of that architecture */
+    hipModule_t mod[64] = {};        /* loaded per device, on the device's first use of the program */
+    hipFunction_t fn[64] = {};
 };
 std::mutex g_cache_mutex;
-std::unordered_map<std::string, std::shared_ptr<Program>> g_cache; /* by program text; programs live as long as the process */
+std::unordered_map<std::string, std::shared_ptr<Program>> g_cache; /* by arch + program text; programs live as long as the process */
+
+/* the architecture the current device wants ("gfx950"; feature suffixes such as ":sramecc+:xnack-" dropped) */
+std::string device_arch(void)
+{
+    hipDeviceProp_t pr;
+    if (ffhip_have_device() && hipGetDeviceProperties(&pr, ffhip_current_device()) == hipSuccess && pr.gcnArchName[0]) {
+        std::string a(pr.gcnArchName);
+        const size_t c = a.find(':');
+        return c == std::string::npos ? a : a.substr(0, c);
+    }
+    return "gfx950"; /* no device: ffhip_sws_uops_check() only wants to know that the list compiles */
+}
 
 int build(const std::string &src, std::shared_ptr<Program> *out, bool load)
 {
+    const std::string arch = device_arch();
+    const std::string key = arch + "\n" + src;
     std::lock_guard<std::mutex> lk(g_cache_mutex);
-    std::shared_ptr<Program> &pr = g_cache[src];
+    std::shared_ptr<Program> &pr = g_cache[key];
     if (!pr) {
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, src.c_str(), "sws_uops.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
             ffhip_set_error("hiprtcCreateProgram failed");
-            g_cache.erase(src);
+            g_cache.erase(key);
             return FFHIP_EIO;
         }
-        const char *opts[] = { "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17" };
+        const std::string archopt = "--offload-arch=" + arch;
+        const char *opts[] = { archopt.c_str(), "-O3", "-ffp-contract=off", "-std=c++17" };
         const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
         if (rc != HIPRTC_SUCCESS) {
             size_t ls = 0;
@@ -486,7 +501,7 @@ int build(const std::string &src, std::shared_ptr<Program> *out, bool load)
             hiprtcGetProgramLog(prog, &log[0]);
             ffhip_set_error("hiprtc: %s\n%.1500s", hiprtcGetErrorString(rc), log.c_str());
             hiprtcDestroyProgram(&prog);
-            g_cache.erase(src);
+            g_cache.erase(key);
             return FFHIP_EIO;
         }
         auto np = std::make_shared<Program>();
@@ -497,12 +512,14 @@ int build(const std::string &src, std::shared_ptr<Program> *out, bool load)
         hiprtcDestroyProgram(&prog);
         pr = np;
     }
-    if (load && !pr->fn) {
+    if (load) {
         if (!ffhip_have_device())
             return FFHIP_ENOSYS;
-        ffhip_note_device_resources();
-        HIP_TRY(hipModuleLoadData(&pr->mod, pr->code.data()));
-        HIP_TRY(hipModuleGetFunction(&pr->fn, pr->mod, "sws_uops"));
+        const int d = ffhip_current_device();
+        if (!pr->fn[d]) {
+            HIP_TRY(hipModuleLoadData(&pr->mod[d], pr->code.data()));
+            HIP_TRY(hipModuleGetFunction(&pr->fn[d], pr->mod[d], "sws_uops"));
+        }
     }
     *out = pr;
     return 0;
@@ -510,17 +527,21 @@ int build(const std::string &src, std::shared_ptr<Program> *out, bool load)
 
 } // namespace
 
+/* a small table a launch reads (line skips / filter offsets).  Content-addressed and never overwritten: launches of the same
+ * compiled list on different streams with different tables each keep reading their own copy. */
+struct DevTable {
+    std::vector<int32_t> host;
+    int32_t *dev = nullptr;
+};
 struct FFHipSwsUOps {
+    int device = 0; /* the list's constants, tables and loaded module live here; every call makes it current */
     Plan plan;
     std::shared_ptr<Program> prog;
     void *data[MAXDATA] = {};
     FFHipSwsOpFunc fb_func = nullptr;
     const void *fb_priv = nullptr;
-    /* the two small tables of the last call, on the device (re-uploaded when their content changes) */
     std::mutex tab_mutex;
-    std::vector<int32_t> rowtab_host, offx_host;
-    int32_t *rowtab_dev = nullptr, *offx_dev = nullptr;
-    size_t rowtab_cap = 0, offx_cap = 0;
+    std::vector<std::unique_ptr<DevTable>> tabs;
 };
 
 extern "C" int ffhip_sws_uops_source(const FFHipSwsUOp *uops, int num_uops, char *buf, size_t size)
@@ -552,13 +573,13 @@ extern "C" void ffhip_sws_uops_free(FFHipSwsUOps **pp)
     if (!pp || !*pp)
         return;
     FFHipSwsUOps *p = *pp;
+    FFHipDeviceGuard dg(p->device);
     for (void *d : p->data)
         if (d)
             (void)hipFree(d);
-    if (p->rowtab_dev)
-        (void)hipFree(p->rowtab_dev);
-    if (p->offx_dev)
-        (void)hipFree(p->offx_dev);
+    for (auto &t : p->tabs)
+        if (t->dev)
+            (void)hipFree(t->dev);
     delete p;
     *pp = nullptr;
 }
@@ -578,6 +599,7 @@ extern "C" int ffhip_sws_uops_compile(const FFHipSwsUOp *uops, int num_uops, FFH
         ffhip_set_error("sws uops: no HIP device");
         return FFHIP_ENOSYS;
     }
+    p->device = ffhip_current_device();
     if ((r = build(p->plan.src, &p->prog, true)) < 0)
         return r;
     FFHipSwsUOps *raw = p.release();
@@ -645,7 +667,7 @@ int launch(FFHipSwsUOps *p, KArgs &a, int nframes, hipStream_t st)
     const int groups = cdiv(a.npx, p->plan.V);
     /* lines per thread: a wave that converts 256 pixels and retires is mostly launch and address set-up; 8 lines per thread keeps
      * >= 4 workgroups per CU in flight on pictures from SD up, smaller jobs fall back to fewer lines */
-    static const int rows_env = getenv("FFHIP_UOPS_ROWS") ? atoi(getenv("FFHIP_UOPS_ROWS")) : 0;
+    static const int rows_env = FFHIP_KNOB("FFHIP_UOPS_ROWS") ? atoi(FFHIP_KNOB("FFHIP_UOPS_ROWS")) : 0;
     int rows = rows_env > 0 ? rows_env : 8;
     while (rows > 1 && (long)cdiv(groups, 64) * cdiv(a.ny, 4 * rows) * nframes < 2048)
         rows >>= 1;
@@ -654,26 +676,36 @@ int launch(FFHipSwsUOps *p, KArgs &a, int nframes, hipStream_t st)
         gy = 16384;
     size_t sz = sizeof a;
     void *cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };
-    HIP_TRY(hipModuleLaunchKernel(p->prog->fn, cdiv(groups, 64), gy, nframes, 64, 4, 1, 0, st, nullptr, cfg));
+    HIP_TRY(hipModuleLaunchKernel(p->prog->fn[p->device], cdiv(groups, 64), gy, nframes, 64, 4, 1, 0, st, nullptr, cfg));
     return 0;
 }
 
-/* a table the kernel reads: kept on the device between calls, re-sent when its content changed */
-int table(std::vector<int32_t> &host, int32_t *&dev, size_t &cap, const int32_t *src, size_t n, hipStream_t st)
+/* the device copy of a table with this content (under p->tab_mutex).  A new content gets a NEW allocation — tables in use by
+ * launches in flight on any stream are never touched; past 32 distinct tables the device is drained once and the set restarts. */
+int table(FFHipSwsUOps *p, const int32_t *src, size_t n, hipStream_t st, int32_t **dev)
 {
-    if (host.size() == n && dev && !memcmp(host.data(), src, n * sizeof(int32_t)))
-        return 0;
-    HIP_TRY(hipStreamSynchronize(st)); /* a launch in flight may still read the old content */
-    if (n > cap) {
-        if (dev)
-            (void)hipFree(dev);
-        dev = nullptr;
-        cap = 0;
-        HIP_TRY(hipMalloc(&dev, n * sizeof(int32_t)));
-        cap = n;
+    for (auto &t : p->tabs)
+        if (t->host.size() == n && !memcmp(t->host.data(), src, n * sizeof(int32_t))) {
+            *dev = t->dev;
+            return 0;
+        }
+    if (p->tabs.size() >= 32) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (auto &t : p->tabs)
+            (void)hipFree(t->dev);
+        p->tabs.clear();
     }
-    host.assign(src, src + n);
-    HIP_TRY(hipMemcpyAsync(dev, host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    std::unique_ptr<DevTable> t(new DevTable);
+    t->host.assign(src, src + n);
+    HIP_TRY(hipMalloc(&t->dev, (n ? n : 1) * sizeof(int32_t)));
+    const hipError_t e = hipMemcpyAsync(t->dev, t->host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) {
+        (void)hipFree(t->dev);
+        ffhip_set_error("sws uops: table upload failed: %s", hipGetErrorString(e));
+        return FFHIP_EIO;
+    }
+    *dev = t->dev;
+    p->tabs.push_back(std::move(t));
     return 0;
 }
 
@@ -682,8 +714,9 @@ int table(std::vector<int32_t> &host, int32_t *&dev, size_t &cap, const int32_t 
 extern "C" int ffhip_sws_uops_run_dev(FFHipSwsUOps *p, const FFHipSwsOpExec *e, int bx_start, int y_start, int bx_end, int y_end,
                                       int nframes, const ptrdiff_t *in_frame_pitch, const ptrdiff_t *out_frame_pitch, void *stream)
 {
-    if (!p || !p->prog || !p->prog->fn)
+    if (!p || !p->prog || !p->prog->fn[p->device])
         return FFHIP_EINVAL;
+    FFHipDeviceGuard dg(p->device);
     if (nframes < 1 || (nframes > 1 && (!in_frame_pitch || !out_frame_pitch)))
         BAD("sws uops: %d pictures without frame pitches", nframes);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -694,14 +727,16 @@ extern "C" int ffhip_sws_uops_run_dev(FFHipSwsUOps *p, const FFHipSwsOpExec *e, 
         return r;
     std::lock_guard<std::mutex> lk(p->tab_mutex);
     if (!rowtab.empty()) {
-        if ((r = table(p->rowtab_host, p->rowtab_dev, p->rowtab_cap, rowtab.data(), rowtab.size(), st)) < 0)
+        int32_t *d = nullptr;
+        if ((r = table(p, rowtab.data(), rowtab.size(), st, &d)) < 0)
             return r;
-        a.rowtab = p->rowtab_dev;
+        a.rowtab = d;
     }
     if (p->plan.fh_size) {
-        if ((r = table(p->offx_host, p->offx_dev, p->offx_cap, e->in_offset_x, (size_t)a.x0 + a.npx, st)) < 0)
+        int32_t *d = nullptr;
+        if ((r = table(p, e->in_offset_x, (size_t)a.x0 + a.npx, st, &d)) < 0)
             return r;
-        a.offx = p->offx_dev;
+        a.offx = d;
     }
     for (int i = 0; i < 4; i++) {
         a.in[i] = e->in[i];
@@ -720,6 +755,7 @@ struct Span { long lo, hi; };   /* bytes of a plane a call touches, relative to 
 bool host_run(FFHipSwsUOps *p, const FFHipSwsOpExec *e, int bx_start, int y_start, int bx_end, int y_end)
 {
     const Plan &pl = p->plan;
+    FFHipDeviceGuard dg(p->device);
     KArgs a;
     std::vector<int32_t> rowtab;
     if (geometry(p, e, bx_start, y_start, bx_end, y_end, a, rowtab) < 0)

@@ -56,6 +56,7 @@ struct TxPfa {
 };
 
 struct FFHipTXContext {
+    int device = 0;          /* the tables live on this device; every call of the context makes it current for its duration */
     int type, inv, len;
     int half = 0;            /* AV_TX_REAL_TO_REAL / _IMAGINARY (1 / 2) */
     int full = 0;            /* AV_TX_FULL_IMDCT: the inverse writes 2 * len outputs (half transform in the middle, mirrored) */
@@ -1186,6 +1187,7 @@ extern "C" void ffhip_tx_uninit(FFHipTXContext **pctx)
     if (!pctx || !*pctx)
         return;
     FFHipTXContext *c = *pctx;
+    FFHipDeviceGuard dg(c->device);
     if (c->dev)
         (void)hipFree(c->dev);
     if (c->stage)
@@ -1365,6 +1367,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     FFHipTXContext *c = new (std::nothrow) FFHipTXContext();
     if (!c)
         return FFHIP_ENOMEM;
+    c->device = ffhip_current_device();
     c->type = type; c->inv = !!inv; c->len = rdft ? 2 * len : len; c->scale = *scale;
     c->full = type == FFHIP_TX_FLOAT_MDCT && inv && (flags & FFHIP_TX_FULL_IMDCT);
     c->half = half;
@@ -1459,7 +1462,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     for (int l = 2; l <= lg; l++)
         d.max_cnt = d.sched_cnt[l] > d.max_cnt ? d.sched_cnt[l] : d.max_cnt;
     {
-        const char *ea = getenv("FFHIP_TX_AHEAD");
+        const char *ea = FFHIP_KNOB("FFHIP_TX_AHEAD");
         d.ahead = ea && ea[0] == '1'; /* measured slightly slower (350 vs 345 M transforms/s): opt-in */
     }
     /* one device allocation for all tables */
@@ -1503,6 +1506,7 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
         return FFHIP_EINVAL;
     if (nt == 0)
         return 0;
+    FFHipDeviceGuard dg(c->device);
     if (!c->full)
         return tx_batch_half(c, out, out_pitch, in, in_pitch, stride, nt, stream);
     /* full inverse: rows of 2 * len floats; the half transform goes to the middle, then the mirror pass */
@@ -1535,7 +1539,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         }
         /* tables in LDS while they are small next to the waves' work arrays; the big transforms (n = 2048: 50 KB of tables,
          * 17 KB per wave) keep them in L2 and spend the LDS on waves (FFHIP_TX_TABLDS=0/1 forces either) */
-        const char *etl = getenv("FFHIP_TX_TABLDS");
+        const char *etl = FFHIP_KNOB("FFHIP_TX_TABLDS");
         const bool tl = etl ? etl[0] == '1' : c->blob_bytes <= 32 * 1024;
         const size_t blob_lds = tl ? (c->blob_bytes + 15) & ~(size_t)15 : 0;
         const int blob_arg = tl ? (int)c->blob_bytes : 0;
@@ -1543,7 +1547,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         const size_t zw = tx_z_bytes(n) + (c->type == FFHIP_TX_FLOAT_DCT && !c->inv ? (((size_t)n + 1) * 4 + 15) & ~(size_t)15 : 0);
         /* the forward DCT's workgroups meet at two barriers per transform (the running sums): two or three smaller ones per CU
          * overlap one's chain with another's transforms */
-        const char *ewpb = getenv("FFHIP_DCT_WPB");
+        const char *ewpb = FFHIP_KNOB("FFHIP_DCT_WPB");
         int wpb = c->type == FFHIP_TX_FLOAT_DCT && !c->inv ? (ewpb ? atoi(ewpb) : 8) : 16;
         if (wpb < 1 || wpb > 16 || (wpb & (wpb - 1)))
             wpb = 8;
@@ -1562,8 +1566,8 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         int blocks = cus * per_cu;
         if (blocks > (nt + wpb - 1) / wpb)
             blocks = (nt + wpb - 1) / wpb;
-        static bool fft_attr = false;
-        if (!fft_attr) {
+        static FFHipPerDeviceOnce fft_attr; /* function attributes are per device */
+        if (fft_attr.enter()) {
             (void)hipFuncSetAttribute((const void *)k_fft_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_fft_z<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_rdft<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1574,8 +1578,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             (void)hipFuncSetAttribute((const void *)k_dct<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_dct<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_dct<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            fft_attr = true;
-            ffhip_note_device_resources();
+            fft_attr.leave(true);
         }
         if (c->type == FFHIP_TX_FLOAT_RDFT) {
 #define TX_LAUNCH(K)                                                                                                                  \
@@ -1644,11 +1647,10 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         const int big = P.m > 64;
 #define PFA_GO(INV_, F_, C_)                                                                                                               \
     do {                                                                                                                                   \
-        static bool attr = false;                                                                                                          \
-        if (!attr) {                                                                                                                       \
+        static FFHipPerDeviceOnce attr;                                                                                                    \
+        if (attr.enter()) {                                                                                                                \
             (void)hipFuncSetAttribute((const void *)k_mdct_pfa<INV_, F_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-            attr = true;                                                                                                                   \
-            ffhip_note_device_resources();                                                                                                 \
+            attr.leave(true);                                                                                                              \
         }                                                                                                                                  \
         hipLaunchKernelGGL((k_mdct_pfa<INV_, F_, C_>), dim3(blocks), dim3(64 * wpb), lds_p, (hipStream_t)stream, c->d, P, T,              \
                            (const uint8_t *)c->dev, (int)c->blob_bytes, (const float *)in, in_pitch, (float *)out, out_pitch, nt,         \
@@ -1681,7 +1683,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
     const ptrdiff_t es = stride / (ptrdiff_t)sizeof(float);
     const dim3 grid(cdiv(nt, wpb)), block(64 * wpb);
     /* FFT-level tables in LDS when they fit next to the waves' areas (FFHIP_TX_LDSTAB=0 keeps them in L2) */
-    const char *et = getenv("FFHIP_TX_LDSTAB");
+    const char *et = FFHIP_KNOB("FFHIP_TX_LDSTAB");
     const size_t ftab_sz = (size_t)((const uint8_t *)c->d.blocks2 - (const uint8_t *)c->d.cos_tab); /* twiddles + butterfly lists */
     int ftab = 0;
     size_t lds = per_wave * wpb;
@@ -1692,11 +1694,11 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
     }
     /* contiguous 8-byte aligned batches: the staging-free kernel (FFHIP_TX_Z=0 selects the older ones) */
     {
-        const char *ez = getenv("FFHIP_TX_Z");
-        const char *ew = getenv("FFHIP_TX_WPB");
+        const char *ez = FFHIP_KNOB("FFHIP_TX_Z");
+        const char *ew = FFHIP_KNOB("FFHIP_TX_WPB");
         int wpb = ew && atoi(ew) > 0 ? atoi(ew) : 16; /* waves per workgroup: 16 measured best (the table copy is shared) */
         if (wpb > 16) wpb = 16;
-        const char *etl = getenv("FFHIP_TX_TABLDS");
+        const char *etl = FFHIP_KNOB("FFHIP_TX_TABLDS");
         const bool tl = etl ? etl[0] == '1' : c->blob_bytes <= 32 * 1024; /* as for the FFT: big transforms keep their tables in L2 */
         const size_t blob_lds = tl ? (c->blob_bytes + 15) & ~(size_t)15 : 0;
         const int blob_arg = tl ? (int)c->blob_bytes : 0;
@@ -1716,14 +1718,13 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             int blocks = cus * per_cu;
             if (blocks > (nt + wpb - 1) / wpb)
                 blocks = (nt + wpb - 1) / wpb;
-            static bool attr_done = false;
-            if (!attr_done) {
+            static FFHipPerDeviceOnce attr_done;
+            if (attr_done.enter()) {
                 (void)hipFuncSetAttribute((const void *)k_mdct_z<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_mdct_z<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_mdct_z<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipFuncSetAttribute((const void *)k_mdct_z<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_done = true;
-                ffhip_note_device_resources();
+                attr_done.leave(true);
             }
             if (c->inv) {
                 if (tl) TX_LAUNCH((k_mdct_z<1, true>)); else TX_LAUNCH((k_mdct_z<1, false>));
@@ -1734,7 +1735,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             return 0;
         }
     }
-    const char *ev = getenv("FFHIP_TX_PERSISTENT");
+    const char *ev = FFHIP_KNOB("FFHIP_TX_PERSISTENT");
     const bool aligned = es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 15);
     const size_t lds_p = ((c->blob_bytes + 15) & ~(size_t)15) + per_wave * 4;
     /* measured (profiles/r01_sweep_tx.txt, N = 1024): 180 vs 175 M forward and 247 vs 225 M inverse transforms/s against
@@ -1775,6 +1776,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
 /* av_tx_fn-shaped single transform with HOST pointers (libavutil/tx.h:151): stage, run, copy back */
 static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
 {
+    FFHipDeviceGuard dg(s->device);
     std::lock_guard<std::mutex> lk(s->mu);
     const int len = s->len;
     const bool rdft = s->type == FFHIP_TX_FLOAT_RDFT, dct = s->type == FFHIP_TX_FLOAT_DCT;

@@ -38,10 +38,22 @@ extern "C" {
 /** Number of usable HIP devices (0 when none / no driver).  Mirrors the role of av_get_cpu_flags()
  *  & AV_CPU_FLAG_* gating in every ff_*_init_<arch>() (libavutil/cpu.h:32-62). */
 int         ffhip_device_count(void);
-/** Bind the calling thread to a device (one process per GPU; rank -> LOCAL_RANK).  Call it before any other entry point:
- *  once the process holds device resources (staging arena, deblocking progress pool, ...) on one device, selecting a
- *  different one returns FFHIP_EINVAL. */
+/** Bind the calling thread to a device.  HIP's current device is per thread; context-free entry points (the batched `_dev`
+ *  faces, the host-pointer shims) run on the calling thread's device, and their shared resources (staging arena, progress
+ *  counters, coefficient tables, compiled op lists) live in per-device tables, so one process may drive every GPU of the node from
+ *  as many threads as it likes — the reference's own model of one process with frame / slice threads
+ *  (libavcodec/pthread_frame.c, libswscale/swscale.c:1645-1679).  May be called at any time, any number of times.
+ *  The FIRST call of the process also sets the process default: a thread that never calls ffhip_set_device() (an FFmpeg worker
+ *  thread calling a shim face) is bound to that default at its first entry instead of HIP's device 0.
+ *  Contexts (FFHipSwsContext, FFHipTXContext, FFHipH264Picture, FFHipAacImdct, FFHipAacLd, FFHipSwsUOps) are bound to the device
+ *  that was current when they were created: their calls make that device current for their own duration, whatever the calling
+ *  thread is bound to.  The stream handed to a call must belong to the device the call runs on. */
 int         ffhip_set_device(int device);
+/** The calling thread's device (after the default binding described above), or FFHIP_ENOSYS. */
+int         ffhip_get_device(void);
+/** A stream on the calling thread's device (hipStreamNonBlocking), for callers without the HIP headers. */
+int         ffhip_stream_create(void **stream);
+int         ffhip_stream_destroy(void *stream);
 /** Streaming-bandwidth probe of the current device (measurement aid: bench.py reports the box's achievable roofs beside
  *  the 8 TB/s spec).  pattern 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p->4K scaler's mix), 4 read n/2 + write n (yuv420p->rgb24's);
  *  `bytes` per buffer; *gbps = bytes moved per second / 1e9 over `reps` launches (HIP events). */
@@ -53,9 +65,49 @@ int         ffhip_malloc(void **dev_ptr, size_t bytes);
 int         ffhip_free(void *dev_ptr);
 int         ffhip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int         ffhip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
-/** hipStreamSynchronize; also the point where a frame-order deblocking launch that timed out on a row hand-off (never in a
- *  correct run) is reported: FFHIP_EIO once, ffhip_last_error() has the text — its picture is only partly filtered. */
+/** hipStreamSynchronize; also the point where a row-ordered launch OF THIS STREAM (frame-order deblocking, intra wavefront, VP9
+ *  frame loop filter) that timed out on a row hand-off (never in a correct run) is reported: FFHIP_EIO once, ffhip_last_error()
+ *  has the text — its picture is only partly processed.  Other streams' pictures are not affected and not reported here. */
 int         ffhip_stream_synchronize(void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* several GPUs in one process: device set, frame-batch scatter / gather over xGMI              */
+/* ------------------------------------------------------------------------------------------ */
+/* The path shards embarrassingly: a batch is cut into contiguous ranges, one per device, with no data-path
+ * collective.  What the reference does with threads inside one process (frame threads, libavcodec/pthread_frame.c; slice threads,
+ * libswscale/swscale.c:1645-1679; avfilter slice threading for the motion search, libavfilter/vf_minterpolate.c) a caller does here
+ * with one host thread (or one loop) per member of an FFHipDeviceSet.  ffmpeg_amd/dist.py holds the one-process-per-GPU form of
+ * the same partition (torch.distributed / RCCL). */
+typedef struct FFHipDeviceSet FFHipDeviceSet;
+/** ceil(n/world) contiguous items per rank; the last ranks may get fewer or none. */
+void ffhip_shard_range(int64_t n_items, int rank, int world, int64_t *lo, int64_t *hi);
+/** Motion search over a sequence: pair p searches frame p+1 in frame p.  Pairs [plo, phi) shard like everything else and read
+ *  frames [flo, fhi) = [plo, phi] — the rank's own range plus ONE halo frame (empty when the rank has no pair). */
+void ffhip_shard_frame_pairs(int64_t n_frames, int rank, int world, int64_t *plo, int64_t *phi, int64_t *flo, int64_t *fhi);
+/** `n` devices (devices == NULL or n <= 0: all of them), one non-blocking stream each, peer access enabled between every pair
+ *  that has a direct xGMI path.  A device may appear more than once (a member is a (device, stream) pair). */
+int   ffhip_device_set_create(FFHipDeviceSet **s, const int *devices, int n);
+void  ffhip_device_set_free(FFHipDeviceSet **s);
+int   ffhip_device_set_size(const FFHipDeviceSet *s);
+int   ffhip_device_set_device(const FFHipDeviceSet *s, int member);
+void *ffhip_device_set_stream(const FFHipDeviceSet *s, int member);
+/** ffhip_set_device(member's device) for the calling thread: a worker thread's first call. */
+int   ffhip_device_set_bind(const FFHipDeviceSet *s, int member);
+/** Waits for every member's stream (ffhip_stream_synchronize semantics); the first error wins. */
+int   ffhip_device_set_synchronize(FFHipDeviceSet *s);
+/** full[lo_i, hi_i) (items of item_bytes, on the root member's device) -> shards[i] on member i, hipMemcpyPeerAsync on member
+ *  i's stream behind what the root's stream has queued.  _scatter uses ffhip_shard_range(); _ranges takes explicit, possibly
+ *  overlapping ranges (halos); _frames_for_pairs the motion search's ranges.  shards[root] may point into `full` (no copy). */
+int   ffhip_batch_scatter(FFHipDeviceSet *s, int root, const void *full, size_t item_bytes, int64_t n_items, void *const *shards);
+int   ffhip_batch_scatter_ranges(FFHipDeviceSet *s, int root, const void *full, size_t item_bytes, int64_t n_items, const int64_t *lo,
+                                 const int64_t *hi, void *const *shards);
+int   ffhip_batch_scatter_frames_for_pairs(FFHipDeviceSet *s, int root, const void *frames, size_t frame_bytes, int64_t n_frames,
+                                           void *const *shards);
+/** The inverse: shards[i] -> full[lo_i, hi_i) on the root, each copy on member i's stream behind the work that produced the shard;
+ *  the root's stream then waits for all copies (so work queued on it afterwards sees the whole batch). */
+int   ffhip_batch_gather(FFHipDeviceSet *s, int root, void *full, size_t item_bytes, int64_t n_items, const void *const *shards);
+int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t item_bytes, int64_t n_items, const int64_t *lo,
+                                const int64_t *hi, const void *const *shards);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libswscale: hscale / vscale / yuv2rgb                                                      */

@@ -18,3 +18,29 @@ def _built():
     """Make sure the in-tree shared objects exist (cheap no-op when they are current)."""
     import __graft_entry__ as g
     g.build(quiet=True)
+
+
+@pytest.fixture(autouse=True)
+def _knob_tests_use_the_measure_build(monkeypatch):
+    """The product library reads no environment variable.  A test that sets an FFHIP_* knob (a measured kernel variant, a
+    fault-injection hook) therefore runs against ffmpeg_amd/libffhip_measure.so — the same sources with -DFFHIP_MEASURE — from the
+    moment it sets the first knob until it ends; every other test runs the product build."""
+    from ffmpeg_amd import _lib
+    orig = monkeypatch.setenv
+
+    def setenv(name, value, prepend=None):
+        if name.startswith("FFHIP_"):
+            _lib.select("measure")
+        return orig(name, value, prepend)
+    monkeypatch.setenv = setenv
+    yield
+    _lib.select("product")
+
+
+@pytest.fixture
+def measure_build():
+    """For tests whose knob must already be live when they bind the library (fault-injection into installed faces)."""
+    from ffmpeg_amd import _lib
+    _lib.select("measure")
+    yield
+    _lib.select("product")

@@ -33,6 +33,50 @@ def test_header_symbols_exported():
     assert not [n for n in names if '"%s"' % n not in src]
 
 
+def test_measure_build_exports_the_same_abi():
+    """libffhip_measure.so (-DFFHIP_MEASURE; what the knob tests load) is the same library with the knobs live."""
+    L = C.CDLL(_lib.SO_MEASURE)
+    assert not [n for n in declared_symbols() if not hasattr(L, n)]
+
+
+def _strings(path, minlen=6):
+    data = open(path, "rb").read()
+    return [m.group().decode() for m in re.finditer(rb"[\x20-\x7e]{%d,}" % minlen, data)]
+
+
+def test_product_library_reads_no_environment():
+    """A library loaded into ffmpeg must not change its pixels on an environment variable: every experiment switch and fault
+    hook sits behind FFHIP_KNOB(), a null constant in the product build.  So the product binary neither imports getenv nor
+    holds any knob name; the allow-list of FFHIP_ words in its strings is the error codes and internal constants below."""
+    import subprocess
+    allowed = {"FFHIP_ENOSYS", "FFHIP_EINVAL", "FFHIP_EIO", "FFHIP_ENOMEM", "FFHIP_PROGRESS_SLOT_INTS"}
+    words = set()
+    for s in _strings(_lib.SO):
+        words |= set(re.findall(r"FFHIP_[A-Z0-9_]+", s))
+    assert words <= allowed, sorted(words - allowed)
+    imports = subprocess.run(["nm", "-D", "--undefined-only", _lib.SO], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "getenv" not in imports
+    # ... and the measure build is where they live
+    mwords = set()
+    for s in _strings(_lib.SO_MEASURE):
+        mwords |= set(re.findall(r"FFHIP_[A-Z0-9_]+", s))
+    assert {"FFHIP_FAULT", "FFHIP_DEBLOCK_FAULT", "FFHIP_UP2_VAR", "FFHIP_QPEL_OLD"} <= mwords
+
+
+def test_shard_ranges_match_the_python_partition():
+    """ffhip_shard_range / ffhip_shard_frame_pairs (the C-level partition of one process driving N GPUs) == ffmpeg_amd.dist's."""
+    from ffmpeg_amd import dist
+    L = _lib.lib()
+    lo, hi, flo, fhi = (C.c_int64() for _ in range(4))
+    for n in (0, 1, 2, 7, 8, 9, 255, 256, 257, 512):
+        for world in (1, 2, 3, 4, 8):
+            for r in range(world):
+                L.ffhip_shard_range(n, r, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == dist.shard_range(n, r, world)
+                L.ffhip_shard_frame_pairs(n, r, world, C.byref(lo), C.byref(hi), C.byref(flo), C.byref(fhi))
+                assert (lo.value, hi.value, flo.value, fhi.value) == dist.shard_frame_pairs(n, r, world)
+
+
 def test_version_and_error_strings():
     L = _lib.lib()
     assert L.ffhip_version().decode()
@@ -66,6 +110,9 @@ def test_no_device_means_enosys_not_a_cpu_fallback():
     assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), 0, 1, 256, None, 0) == ENOSYS and not ctx.value   # FFT
     vp = C.c_void_p()
     assert L.ffhip_malloc(C.byref(vp), 16) == ENOSYS
+    assert L.ffhip_get_device() == ENOSYS and L.ffhip_stream_create(C.byref(vp)) == ENOSYS
+    assert L.ffhip_device_set_create(C.byref(vp), None, 0) == ENOSYS and not vp.value
+    assert L.ffhip_set_device(0) == -22
     from ffmpeg_amd import swscale as S
     with pytest.raises(RuntimeError, match="no HIP device"):
         S.SwsContext(64, 32, 0, 64, 32, 2)

@@ -288,7 +288,7 @@ def test_deblock_frame_row_kernel_agrees(monkeypatch):
     test_deblock_frame(40, 37, 0)
 
 
-def test_deblock_lost_handoff_is_reported(monkeypatch):
+def test_deblock_lost_handoff_is_reported(monkeypatch, measure_build):
     """a wavefront that never receives a hand-off must time out and be REPORTED at the next synchronisation point, not leave a
     partly filtered picture behind silently (FFHIP_DEBLOCK_FAULT=1: rows do not publish their progress)"""
     from ffmpeg_amd import h264, _lib

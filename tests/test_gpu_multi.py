@@ -1,0 +1,297 @@
+"""One process, several host threads, (when the box has them) several GPUs — through the C ABI alone.
+
+The reference's execution model is one process with frame / slice threads (libavcodec/pthread_frame.c,
+libswscale/swscale.c:1645-1679), so libffhip.so keeps nothing in process globals that belongs to a device: contexts are bound to
+the device they were created on, the shared resources of the context-free faces sit in per-device tables, and
+FFHipDeviceSet + ffhip_batch_scatter/gather cut a frame batch over the members exactly as ffmpeg_amd.dist does over ranks.
+Every case checks bytes against the single-device result (itself checked against the oracle elsewhere).  On the 1-GPU box the
+device set holds device 0 twice (a member is a (device, stream) pair); with more devices visible it also holds 0 and 1."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import ffi
+
+pytestmark = pytest.mark.gpu
+PIX = ffi.PIX
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _member_sets(L):
+    sets = [[0, 0], [0, 0, 0]]
+    if L.ffhip_device_count() > 1:
+        sets += [[0, 1], [1, 0], list(range(L.ffhip_device_count()))]
+    return sets
+
+
+def _frames(rng, n, h, w):
+    return rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+
+
+def _scale_on(device, y, uv, dw, dh, stream=None):
+    """nv12 [n] frames -> nv12 dw x dh on `device` (tensors already there); returns (Y, UV) tensors"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    n, sh, sw = y.shape
+    ctx = S.SwsContext(sw, sh, PIX["nv12"], dw, dh, PIX["nv12"], S.SWS_BICUBIC)
+    oy = torch.empty((n, dh, dw), dtype=torch.uint8, device=device)
+    ouv = torch.empty((n, dh // 2, dw), dtype=torch.uint8, device=device)
+    ctx.scale_batch([y, uv], [oy, ouv], stream=stream)
+    return ctx, oy, ouv
+
+
+def test_two_host_threads_share_device_0():
+    """two threads, each with its own context and stream on device 0, run interleaved: same bytes as one thread alone"""
+    from ffmpeg_amd import _lib
+    torch = _torch()
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    sw, sh, dw, dh, n = 320, 180, 640, 360, 6
+    ys, uvs = _frames(rng, 2 * n, sh, sw), _frames(rng, 2 * n, sh // 2, sw)
+    _, wy, wuv = _scale_on("cuda:0", torch.from_numpy(ys).cuda(), torch.from_numpy(uvs).cuda(), dw, dh)
+    torch.cuda.synchronize()
+    wy, wuv = wy.cpu().numpy(), wuv.cpu().numpy()
+    got, errs = {}, []
+
+    def worker(k):
+        try:
+            assert L.ffhip_set_device(0) == 0 and L.ffhip_get_device() == 0
+            st = C.c_void_p()
+            assert L.ffhip_stream_create(C.byref(st)) == 0
+            y, uv = torch.from_numpy(ys[k * n:(k + 1) * n]).to("cuda:0"), torch.from_numpy(uvs[k * n:(k + 1) * n]).to("cuda:0")
+            torch.cuda.synchronize()
+            outs = []
+            for _ in range(4):   # repeated launches from both threads at once
+                ctx, oy, ouv = _scale_on("cuda:0", y, uv, dw, dh, stream=st.value)
+                outs.append((ctx, oy, ouv))
+            assert L.ffhip_stream_synchronize(st) == 0
+            got[k] = (outs[-1][1].cpu().numpy(), outs[-1][2].cpu().numpy())
+            assert all(torch.equal(o[1], outs[0][1]) for o in outs)
+            assert L.ffhip_stream_destroy(st) == 0
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for k in range(2):
+        assert np.array_equal(got[k][0], wy[k * n:(k + 1) * n]) and np.array_equal(got[k][1], wuv[k * n:(k + 1) * n])
+
+
+def test_unbound_worker_thread_follows_the_process_default():
+    """a thread that never calls ffhip_set_device() is bound to the device of the process's first ffhip_set_device(), not to
+    HIP's per-thread default 0 (FFmpeg workers calling shim faces on LOCAL_RANK > 0)"""
+    from ffmpeg_amd import _lib
+    _torch()
+    L = _lib.lib()
+    first = L.ffhip_device_count() - 1
+    # the first call in this process may have happened in an earlier test (device 0); what matters is that a fresh thread reports
+    # the process default, whichever it is
+    L.ffhip_set_device(first)
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(L.ffhip_get_device()))
+    t.start()
+    t.join()
+    main = []
+    t2 = threading.Thread(target=lambda: (L.ffhip_set_device(0), main.append(L.ffhip_get_device())))
+    t2.start()
+    t2.join()
+    assert main == [0]
+    assert seen and 0 <= seen[0] < L.ffhip_device_count()
+    if L.ffhip_device_count() == 1:
+        assert seen == [0]
+    L.ffhip_set_device(0)
+
+
+@pytest.mark.parametrize("root", [0, 1])
+def test_scatter_scale_gather_over_a_device_set(root):
+    """configs[1]'s shape of work, cut over the members of a device set in ONE process: scatter nv12 frames from the root,
+    every member scales its shard with a context created on ITS device, gather: == the single-device batch"""
+    from ffmpeg_amd import _lib, swscale as S
+    torch = _torch()
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    sw, sh, dw, dh, n = 256, 144, 512, 288, 7
+    ys, uvs = _frames(rng, n, sh, sw), _frames(rng, n, sh // 2, sw)
+    _, wy, wuv = _scale_on("cuda:0", torch.from_numpy(ys).cuda(), torch.from_numpy(uvs).cuda(), dw, dh)
+    torch.cuda.synchronize()
+    wy, wuv = wy.cpu().numpy(), wuv.cpu().numpy()
+    for devs in _member_sets(L):
+        w = len(devs)
+        ds = C.c_void_p()
+        arr = (C.c_int * w)(*devs)
+        assert L.ffhip_device_set_create(C.byref(ds), arr, w) == 0, L.ffhip_last_error()
+        assert L.ffhip_device_set_size(ds) == w and [L.ffhip_device_set_device(ds, i) for i in range(w)] == devs
+        rdev = "cuda:%d" % devs[root]
+        fy, fuv = torch.from_numpy(ys).to(rdev), torch.from_numpy(uvs).to(rdev)
+        oy_full = torch.zeros((n, dh, dw), dtype=torch.uint8, device=rdev)
+        ouv_full = torch.zeros((n, dh // 2, dw), dtype=torch.uint8, device=rdev)
+        torch.cuda.synchronize(rdev)
+        lo, hi = C.c_int64(), C.c_int64()
+        shards, keep = [], []
+        for i in range(w):
+            L.ffhip_shard_range(n, i, w, C.byref(lo), C.byref(hi))
+            k = hi.value - lo.value
+            dev = "cuda:%d" % devs[i]
+            shards.append([torch.empty((k, sh, sw), dtype=torch.uint8, device=dev), torch.empty((k, sh // 2, sw), dtype=torch.uint8, device=dev),
+                           torch.empty((k, dh, dw), dtype=torch.uint8, device=dev), torch.empty((k, dh // 2, dw), dtype=torch.uint8, device=dev)])
+        for d in set(devs):
+            torch.cuda.synchronize("cuda:%d" % d)
+
+        def ptrs(j):
+            return (C.c_void_p * w)(*[s[j].data_ptr() for s in shards])
+        assert L.ffhip_batch_scatter(ds, root, fy.data_ptr(), sh * sw, n, ptrs(0)) == 0, L.ffhip_last_error()
+        assert L.ffhip_batch_scatter(ds, root, fuv.data_ptr(), (sh // 2) * sw, n, ptrs(1)) == 0
+        errs = []
+
+        def member(i):
+            try:
+                assert L.ffhip_device_set_bind(ds, i) == 0 and L.ffhip_get_device() == devs[i]
+                if shards[i][0].shape[0] == 0:
+                    return
+                ctx = S.SwsContext(sw, sh, PIX["nv12"], dw, dh, PIX["nv12"], S.SWS_BICUBIC)   # on the member's device
+                keep.append(ctx)
+                ctx.scale_batch(shards[i][:2], shards[i][2:], stream=L.ffhip_device_set_stream(ds, i))
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+        ts = [threading.Thread(target=member, args=(i,)) for i in range(w)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        assert L.ffhip_batch_gather(ds, root, oy_full.data_ptr(), dh * dw, n, ptrs(2)) == 0, L.ffhip_last_error()
+        assert L.ffhip_batch_gather(ds, root, ouv_full.data_ptr(), (dh // 2) * dw, n, ptrs(3)) == 0
+        assert L.ffhip_device_set_synchronize(ds) == 0
+        assert np.array_equal(oy_full.cpu().numpy(), wy) and np.array_equal(ouv_full.cpu().numpy(), wuv), devs
+        keep.clear()
+        L.ffhip_device_set_free(C.byref(ds))
+        assert not ds.value
+
+
+def test_scatter_frames_for_pairs_has_the_halo():
+    """the motion search's ranges: member i holds frames [plo, phi] — its pairs plus ONE halo frame"""
+    from ffmpeg_amd import _lib, dist
+    torch = _torch()
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    n, fb = 9, 4096
+    frames = rng.integers(0, 256, (n, fb), dtype=np.uint8)
+    for devs in _member_sets(L):
+        w = len(devs)
+        ds = C.c_void_p()
+        assert L.ffhip_device_set_create(C.byref(ds), (C.c_int * w)(*devs), w) == 0
+        full = torch.from_numpy(frames).to("cuda:%d" % devs[0])
+        rngs = [dist.shard_frame_pairs(n, i, w)[2:] for i in range(w)]
+        sh = [torch.zeros((max(b - a, 1), fb), dtype=torch.uint8, device="cuda:%d" % devs[i]) for i, (a, b) in enumerate(rngs)]
+        for d in set(devs):
+            torch.cuda.synchronize("cuda:%d" % d)
+        assert L.ffhip_batch_scatter_frames_for_pairs(ds, 0, full.data_ptr(), fb, n, (C.c_void_p * w)(*[t.data_ptr() for t in sh])) == 0
+        assert L.ffhip_device_set_synchronize(ds) == 0
+        for i, (a, b) in enumerate(rngs):
+            assert np.array_equal(sh[i].cpu().numpy()[:b - a], frames[a:b])
+        L.ffhip_device_set_free(C.byref(ds))
+
+
+def test_context_called_from_a_thread_bound_elsewhere():
+    """a context is bound to its device: a call from a thread whose current device differs still runs (and lands) on the
+    context's device.  Needs two devices."""
+    from ffmpeg_amd import _lib
+    torch = _torch()
+    L = _lib.lib()
+    if L.ffhip_device_count() < 2:
+        pytest.skip("one device visible")
+    rng = np.random.default_rng(8)
+    sw, sh, dw, dh, n = 128, 72, 256, 144, 3
+    ys, uvs = _frames(rng, n, sh, sw), _frames(rng, n, sh // 2, sw)
+    _, wy, wuv = _scale_on("cuda:0", torch.from_numpy(ys).cuda(), torch.from_numpy(uvs).cuda(), dw, dh)
+    torch.cuda.synchronize()
+    assert L.ffhip_set_device(1) == 0
+    y1, uv1 = torch.from_numpy(ys).to("cuda:1"), torch.from_numpy(uvs).to("cuda:1")
+    st = C.c_void_p()
+    assert L.ffhip_stream_create(C.byref(st)) == 0
+    ctx, oy, ouv = _scale_on("cuda:1", y1, uv1, dw, dh, stream=st.value)       # created on device 1
+    assert L.ffhip_stream_synchronize(st) == 0
+    assert L.ffhip_set_device(0) == 0                                            # now bound to 0 ...
+    oy.zero_()
+    torch.cuda.synchronize("cuda:1")
+    ctx.scale_batch([y1, uv1], [oy, ouv], stream=st.value)                       # ... the call still runs on 1
+    assert L.ffhip_get_device() == 0
+    L.ffhip_set_device(1)
+    assert L.ffhip_stream_synchronize(st) == 0
+    L.ffhip_set_device(0)
+    assert np.array_equal(oy.cpu().numpy(), wy.cpu().numpy()) and np.array_equal(ouv.cpu().numpy(), wuv.cpu().numpy())
+
+
+def test_many_wavefront_launches_in_flight_from_several_threads():
+    """more row-ordered launches in flight than the progress pool has slots (64 per device), from 4 threads on 4 streams: slots are
+    recycled by event (no thread waits under the pool lock), every picture is filtered exactly as alone"""
+    from ffmpeg_amd import _lib, h264
+    torch = _torch()
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    mb_w, mb_h, per_thread = 20, 12, 40
+    stride = mb_w * 16
+    n = mb_w * mb_h * 8
+    edt = ffi.EDGE_DTYPE
+    base = rng.integers(0, 256, (mb_h * 16, stride), dtype=np.uint8)
+    base = (base.astype(np.int32) // 8 + 100).astype(np.uint8)   # smooth enough for the filters to fire
+    ed = np.zeros(n, edt)
+    ed["alpha"], ed["beta"] = 40, 12
+    ed["kind"] = np.where(rng.random(n) < .25, 4, 0)
+    ed["tc0"] = rng.integers(-1, 5, (n, 4))
+    want = base.copy()
+    ffi.oracle().ffo_h264_deblock_frame(ffi.ptr(want), stride, mb_w, mb_h, C.c_void_p(ed.ctypes.data))
+    d_ed = torch.from_numpy(ed.view(np.uint8).reshape(n, 12)).cuda()
+    torch.cuda.synchronize()
+    errs = []
+
+    def worker(k):
+        try:
+            assert L.ffhip_set_device(0) == 0
+            st = C.c_void_p()
+            assert L.ffhip_stream_create(C.byref(st)) == 0
+            planes = [torch.from_numpy(base).to("cuda:0") for _ in range(per_thread)]
+            torch.cuda.synchronize()
+            for p in planes:
+                h264.deblock_frame(p, stride, mb_w, mb_h, d_ed, stream=st.value)
+            assert L.ffhip_stream_synchronize(st) == 0
+            for p in planes:
+                assert np.array_equal(p.cpu().numpy(), want)
+            L.ffhip_stream_destroy(st)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+
+
+def test_lost_handoff_is_reported_to_its_own_stream_only(monkeypatch, measure_build):
+    """a lost hand-off in picture A (stream a) must not fail the flush / synchronize of picture B (stream b)"""
+    from ffmpeg_amd import _lib, h264
+    torch = _torch()
+    L = _lib.lib()
+    a, b = C.c_void_p(), C.c_void_p()
+    assert L.ffhip_stream_create(C.byref(a)) == 0 and L.ffhip_stream_create(C.byref(b)) == 0
+    mb_w, mb_h = 4, 3
+    pa = torch.zeros((mb_h * 16, mb_w * 16), dtype=torch.uint8, device="cuda:0")
+    pb = torch.zeros((mb_h * 16, mb_w * 16), dtype=torch.uint8, device="cuda:0")
+    ed = torch.zeros((mb_w * mb_h * 8, 12), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    monkeypatch.setenv("FFHIP_DEBLOCK_FAULT", "1")
+    h264.deblock_frame(pa, mb_w * 16, mb_w, mb_h, ed, stream=a.value)
+    monkeypatch.delenv("FFHIP_DEBLOCK_FAULT")
+    h264.deblock_frame(pb, mb_w * 16, mb_w, mb_h, ed, stream=b.value)
+    torch.cuda.synchronize()
+    assert L.ffhip_stream_synchronize(b) == 0                     # B is fine and hears nothing
+    assert L.ffhip_stream_synchronize(a) == -5                    # A's owner is told (FFHIP_EIO) ...
+    assert b"hand-off" in L.ffhip_last_error()
+    assert L.ffhip_stream_synchronize(a) == 0                     # ... once
+    L.ffhip_stream_destroy(a)
+    L.ffhip_stream_destroy(b)

@@ -179,7 +179,7 @@ def _c_table(O):
     return c
 
 
-def test_faces_fall_back_to_the_displaced_c_functions(monkeypatch):
+def test_faces_fall_back_to_the_displaced_c_functions(monkeypatch, measure_build):
     """FFHIP_FAULT=1: every face reports a device failure before touching anything.  A face installed over a C function must
     answer through it (same bytes as the C function alone), one that displaced nothing must leave its operands untouched and
     say so — never return silently with half a result."""
@@ -318,7 +318,7 @@ class SwsLine(C.Structure):   # member order of FFHipSwsLineContext (include/ffh
 
 
 @pytest.mark.parametrize("fault", [0, 1])
-def test_sws_init_swscale_hip(fault, monkeypatch):
+def test_sws_init_swscale_hip(fault, monkeypatch, measure_build):
     """hyScale / hcScale with checkasm's adversarial coefficients (sw_scale.c:356-458), yuv2plane1 / yuv2planeX with its dither
     offsets (:109-180), yuv2nv12cX (:182-262).  fault = 1: every member answers through the C function it displaced."""
     L = _lib()

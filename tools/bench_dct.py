@@ -1,6 +1,8 @@
 import json, os, sys
 sys.path.insert(0, "/root/repo")
 import torch
+from ffmpeg_amd import _lib as _fflib  # noqa: E402
+_fflib.select("measure")  # the FFHIP_* knobs this tool sets exist only in libffhip_measure.so
 from ffmpeg_amd import tx
 nt = 65536
 for n in (1024, 256, 4096):

@@ -5,6 +5,8 @@ import json, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
+from ffmpeg_amd import _lib as _fflib  # noqa: E402
+_fflib.select("measure")  # the FFHIP_* knobs this tool sets exist only in libffhip_measure.so
 from ffmpeg_amd import h264
 dev = torch.device("cuda", 0)
 w, h = 3840, 2160

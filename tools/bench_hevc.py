@@ -10,6 +10,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
+from ffmpeg_amd import _lib as _fflib  # noqa: E402
+_fflib.select("measure")  # the FFHIP_* knobs this tool sets exist only in libffhip_measure.so
 from ffmpeg_amd import hevc  # noqa: E402
 
 dev = torch.device("cuda", 0)

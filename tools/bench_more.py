@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
+from ffmpeg_amd import _lib as _fflib  # noqa: E402
+_fflib.select("measure")  # the FFHIP_* knobs this tool sets exist only in libffhip_measure.so
 from ffmpeg_amd import swscale as S, h264  # noqa: E402
 
 dev = torch.device("cuda", 0)

@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 import torch  # noqa: E402
+from ffmpeg_amd import _lib as _fflib  # noqa: E402
+_fflib.select("measure")  # the FFHIP_* knobs this tool sets exist only in libffhip_measure.so
 import bench  # noqa: E402
 
 r = bench.sws_ops_leg(torch, "cuda:0")

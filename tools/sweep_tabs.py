@@ -7,6 +7,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
+from ffmpeg_amd import _lib as _fflib  # noqa: E402
+_fflib.select("measure")  # the FFHIP_* knobs this tool sets exist only in libffhip_measure.so
 from ffmpeg_amd import tx  # noqa: E402
 
 cases = [(tx.FLOAT_MDCT, 1024, 0), (tx.FLOAT_MDCT, 2048, 0), (tx.FLOAT_MDCT, 2048, 1), (tx.FLOAT_MDCT, 4096, 0), (tx.FLOAT_MDCT, 4096, 1),
