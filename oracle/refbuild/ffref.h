@@ -48,6 +48,8 @@ void ffref_h264_chroma_dc_dequant_idct(int16_t *block, int qmul);
 void ffref_h264_add_pixels_clear(int n, uint8_t *dst, int16_t *block, ptrdiff_t stride);
 /* CPU-baseline runners: a batch split statically over pthreads (disjoint blocks / independent frames) */
 int  ffref_h264_idct_batch(int which, uint8_t *dst, ptrdiff_t stride, const int32_t *off, int16_t *blk, int n, int threads);
+int  ffref_h264_idct_batch_timed(int which, uint8_t *dst, ptrdiff_t stride, const int32_t *off, int16_t *blk, int n, int threads,
+                                 double min_seconds, double *seconds, int *passes);
 int  ffref_sws_scale_frames_mt(void *const *ctxs, const uint8_t *const *const *srcs, const int *ss, uint8_t *const *const *dsts,
                                const int *ds, int srcH, int threads, int reps);
 /* which: 0 idct_add16 1 idct8_add4 2 idct_add16intra */

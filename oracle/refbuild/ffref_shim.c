@@ -202,6 +202,82 @@ int ffref_h264_idct_batch(int which, uint8_t *dst, ptrdiff_t stride, const int32
     return started;
 }
 
+/* The same split with PERSISTENT threads and a clock inside: one untimed warm-up pass (page faults, caches, thread start), then
+ * whole passes until `min_seconds` have gone by.  Every pass runs the reference's function over every block again (after the
+ * first pass the coefficient blocks are the zeros the function itself leaves behind: same instructions, same stores).
+ * *seconds = wall time of the timed passes, *passes = how many; returns the number of worker threads. */
+#include <time.h>
+typedef struct { IdctJob job; pthread_barrier_t *bar; volatile int *stop; } IdctLoop;
+static void *idct_loop_worker(void *p)
+{
+    IdctLoop *l = p;
+    for (;;) {
+        pthread_barrier_wait(l->bar);
+        if (*l->stop)
+            break;
+        idct_worker(&l->job);
+        pthread_barrier_wait(l->bar);
+    }
+    return NULL;
+}
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+int ffref_h264_idct_batch_timed(int which, uint8_t *dst, ptrdiff_t stride, const int32_t *off, int16_t *blk, int n, int threads,
+                                double min_seconds, double *seconds, int *passes)
+{
+    dsp_init();
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    static pthread_t th[1024];
+    static IdctLoop loop[1024];
+    const int per = (n + threads - 1) / threads;
+    int want = 0;
+    for (int t = 0; t < threads; t++)
+        if (t * per < n)
+            want++;
+    pthread_barrier_t bar;
+    volatile int stop = 0;
+    if (pthread_barrier_init(&bar, NULL, want + 1))
+        return -1;
+    int started = 0;
+    for (int t = 0; t < want; t++) {
+        int lo = t * per, hi = lo + per > n ? n : lo + per;
+        loop[t] = (IdctLoop){ { which, dst, stride, off, blk, lo, hi }, &bar, &stop };
+        if (pthread_create(&th[t], NULL, idct_loop_worker, &loop[t]))
+            break;
+        started++;
+    }
+    if (started != want) { /* cannot release a barrier sized for more threads: give up loudly */
+        stop = 1;
+        for (int t = 0; t < started; t++)
+            pthread_cancel(th[t]);
+        return -1;
+    }
+    pthread_barrier_wait(&bar); /* warm-up pass */
+    pthread_barrier_wait(&bar);
+    int np = 0;
+    const double t0 = now_s();
+    double t1;
+    do {
+        pthread_barrier_wait(&bar);
+        pthread_barrier_wait(&bar);
+        np++;
+        t1 = now_s();
+    } while (t1 - t0 < min_seconds && np < 100000);
+    stop = 1;
+    pthread_barrier_wait(&bar);
+    for (int t = 0; t < started; t++)
+        pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&bar);
+    *seconds = t1 - t0;
+    *passes = np;
+    return started;
+}
+
 typedef struct { void *ctx; const uint8_t *const *src; const int *ss; uint8_t *const *dst; const int *ds; int h, reps; } SwsJob;
 static void *sws_worker(void *p)
 {

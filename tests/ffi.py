@@ -259,6 +259,9 @@ def ref():
                                       C.POINTER(u8p), C.POINTER(C.c_int)]
         if hasattr(L, "ffref_h264_idct_batch"):
             L.ffref_h264_idct_batch.argtypes = [C.c_int, u8p, C.c_ssize_t, i32p, i16p, C.c_int, C.c_int]
+        if hasattr(L, "ffref_h264_idct_batch_timed"):
+            L.ffref_h264_idct_batch_timed.argtypes = [C.c_int, u8p, C.c_ssize_t, i32p, i16p, C.c_int, C.c_int, C.c_double,
+                                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]
             L.ffref_sws_scale_frames_mt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                                     C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
         if hasattr(L, "ffref_sws_yuv2packedX"):

@@ -282,14 +282,15 @@ def test_hevc_sao_host_faces():
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("old", ["0", "1"])
+@pytest.mark.parametrize("old", ["default", "0", "1"])
 @pytest.mark.parametrize("uni", [0, 1])
 @pytest.mark.parametrize("chroma", [0, 1])
 def test_hevc_mc_batch(chroma, uni, old, monkeypatch):
     """prediction blocks of all 10 widths x fractional positions in one batch (tests/checkasm/hevc_pel.c shapes); both kernels"""
     from ffmpeg_amd import hevc
     torch = _torch()
-    monkeypatch.setenv("FFHIP_HEVC_MC_OLD", old)
+    if old != "default":   # a knob selects libffhip_measure.so (conftest.py); "default" is the product library
+        monkeypatch.setenv("FFHIP_HEVC_MC_OLD", old)
     rng = np.random.default_rng(60 + 2 * chroma + uni)
     W, H, P = 512, 1024, 16
     ss = W + 2 * P + 3
@@ -360,14 +361,15 @@ def _weights(rng, rep):
     return d, (1 << d) + int(rng.integers(-128, 128)), (1 << d) + int(rng.integers(-128, 128)), int(rng.integers(-256, 255))
 
 
-@pytest.mark.parametrize("old", ["0", "1"])
+@pytest.mark.parametrize("old", ["default", "0", "1"])
 @pytest.mark.parametrize("mode", [2, 3, 4])
 @pytest.mark.parametrize("chroma", [0, 1])
 def test_hevc_mc_weighted_batch(chroma, mode, old, monkeypatch):
     """put_hevc_{qpel,epel}_{uni_w,bi,bi_w}: all 10 widths x fractional positions x weights in one batch; both kernels"""
     from ffmpeg_amd import hevc
     torch = _torch()
-    monkeypatch.setenv("FFHIP_HEVC_MC_OLD", old)
+    if old != "default":   # a knob selects libffhip_measure.so (conftest.py); "default" is the product library
+        monkeypatch.setenv("FFHIP_HEVC_MC_OLD", old)
     rng = np.random.default_rng(160 + 8 * chroma + mode)
     W, H, P = 512, 1024, 16
     ss = W + 2 * P + 3

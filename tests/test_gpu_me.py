@@ -64,12 +64,13 @@ def _shifted_pair(rng, w, h, stride, R, flat=False):
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("w,h,pad,mb,R", [(64, 48, 0, 16, 7), (176, 144, 16, 16, 7), (176, 144, 0, 8, 7), (96, 80, 3, 16, 16),
                                           (40, 40, 0, 8, 3), (72, 56, 0, 16, 0)])
-@pytest.mark.parametrize("share", ["1", "0", "3"], ids=["shared", "per-candidate", "column"])
+@pytest.mark.parametrize("share", ["default", "1", "0", "3"], ids=["product", "shared", "per-candidate", "column"])
 def test_esa_frames(kind, w, h, pad, mb, R, share, monkeypatch):
     from ffmpeg_amd import me
     torch = _torch()
-    monkeypatch.setenv("FFHIP_ME_SATD_SHARE", "0" if share == "0" else "1")   # SATD: column transforms shared through LDS / per candidate
-    monkeypatch.setenv("FFHIP_ME_SAD_QUAD", share)     # SAD 16x16: four candidates per lane (side by side) / one / four in a column
+    if share != "default":   # "default": no knob -> the product library; the variants run libffhip_measure.so (conftest.py)
+        monkeypatch.setenv("FFHIP_ME_SATD_SHARE", "0" if share == "0" else "1")   # SATD: column transforms shared through LDS / per candidate
+        monkeypatch.setenv("FFHIP_ME_SAD_QUAD", share)     # SAD 16x16: four candidates per lane (side by side) / one / four in a column
     rng = np.random.default_rng(w + h + mb + R + kind)
     stride = w + pad
     nf = 3

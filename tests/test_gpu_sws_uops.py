@@ -176,7 +176,7 @@ def test_large_pictures_against_the_oracle():
     assert np.array_equal(outs[0], outs[1]) and outs[0].any()
 
 
-def test_void_face_falls_back(monkeypatch):
+def test_void_face_falls_back(monkeypatch, measure_build):
     """FFHIP_FAULT=1: the SwsOpFunc face cannot reach the device and runs the function it was given as fallback (the caller's
     backend_c compilation of the same list in the FFmpeg-side stub; here the oracle's)"""
     L, g = _lib()

@@ -43,7 +43,7 @@ def _check(got, want):
         (got.view(np.uint32) != want.view(np.uint32)).sum(), got.size, np.abs(got - want).max())
 
 
-@pytest.mark.parametrize("persistent", ["z", "z-noahead", "1", "0", "0-l2tab", "1-noahead"])
+@pytest.mark.parametrize("persistent", ["default", "z", "z-noahead", "1", "0", "0-l2tab", "1-noahead"])
 @pytest.mark.parametrize("inv", [0, 1])
 @pytest.mark.parametrize("len_,scale", [(16, 1.0), (64, 1.0 / 64), (256, -1.0), (1024, 1.0), (1024, 32768.0), (1024, 1.0 / 1024),
                                         (2048, 1.0 / 2048), (4096, 1.0)])
@@ -52,11 +52,12 @@ def test_mdct_batch(inv, len_, scale, persistent, monkeypatch):
     the one-shot kernel is the general path"""
     from ffmpeg_amd import tx
     torch = _torch()
-    monkeypatch.setenv("FFHIP_TX_Z", "1" if persistent[0] == "z" else "0")   # z: the staging-free kernel (default)
-    monkeypatch.setenv("FFHIP_TX_PERSISTENT", "1" if persistent[0] == "z" else persistent[0])
-    monkeypatch.setenv("FFHIP_TX_LDSTAB", "0" if persistent.endswith("l2tab") else "1")
-    monkeypatch.setenv("FFHIP_TX_AHEAD", "0" if persistent.endswith("noahead") else "1")
-    monkeypatch.setenv("FFHIP_TX_WPB", "4" if persistent == "z-noahead" else "16")
+    if persistent != "default":   # "default": no knob set -> the product library (the others run libffhip_measure.so, conftest.py)
+        monkeypatch.setenv("FFHIP_TX_Z", "1" if persistent[0] == "z" else "0")   # z: the staging-free kernel (default)
+        monkeypatch.setenv("FFHIP_TX_PERSISTENT", "1" if persistent[0] == "z" else persistent[0])
+        monkeypatch.setenv("FFHIP_TX_LDSTAB", "0" if persistent.endswith("l2tab") else "1")
+        monkeypatch.setenv("FFHIP_TX_AHEAD", "0" if persistent.endswith("noahead") else "1")
+        monkeypatch.setenv("FFHIP_TX_WPB", "4" if persistent == "z-noahead" else "16")
     rng = np.random.default_rng(len_ + inv)
     nt = 37 if len_ != 1024 else 5000      # more transforms than resident waves: the persistent loop wraps
     n_in = len_ if inv else 2 * len_
