@@ -115,7 +115,7 @@ def cpu_baseline(budget_s=5.0):
             if got > 0 and secs.value > 0:
                 legs[key] = {"value": round(n * passes.value / secs.value / 1e9, 5), "unit": "Gblocks/s", "cores": got,
                              "sample": "%d passes over %d 8x8 blocks (ff_h264_idct8_add_8_c, %d 4K luma planes) in %.2f s after a warm-up "
-                                       "pass, %d persistent thread(s)" % (passes.value, n, planes, secs.value, got)}
+                                       "pass, %d persistent thread(s) on thread-local (NUMA-local) copies of their share" % (passes.value, n, planes, secs.value, got)}
             del pic, off, blk
     best = max((legs[k] for k in legs if k.startswith("sws_")), key=lambda l: l["value"])
     return {"value": best["value"], "unit": "Mpixels/s", "cores": best["cores"], "kind": "reference",

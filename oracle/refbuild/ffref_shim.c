@@ -211,6 +211,30 @@ typedef struct { IdctJob job; pthread_barrier_t *bar; volatile int *stop; } Idct
 static void *idct_loop_worker(void *p)
 {
     IdctLoop *l = p;
+    /* NUMA: the caller's arrays were first touched by ONE thread (one memory node); a worker of a 2-socket box would stream its
+     * share over the socket link.  Each worker therefore times its share on thread-local copies it has first-touched itself —
+     * its coefficient blocks and the picture rows they land in — which is the placement a frame-threaded decoder gets. */
+    IdctJob *j = &l->job;
+    const int step = j->which == 1 || j->which == 3 ? 64 : 16, side = j->which == 1 || j->which == 3 ? 8 : 4;
+    const size_t nblk = (size_t)(j->hi - j->lo) * step;
+    int32_t omin = INT32_MAX, omax = 0;
+    for (int i = j->lo; i < j->hi; i++) {
+        if (j->off[i] < omin) omin = j->off[i];
+        if (j->off[i] > omax) omax = j->off[i];
+    }
+    const size_t npic = (size_t)(omax - omin) + (size_t)side * j->stride;
+    int16_t *lb = malloc(nblk * sizeof(int16_t));
+    uint8_t *lp = malloc(npic);
+    int32_t *lo = malloc((size_t)(j->hi - j->lo) * sizeof(int32_t));
+    if (lb && lp && lo) {
+        memcpy(lb, j->blk + (size_t)j->lo * step, nblk * sizeof(int16_t));
+        memcpy(lp, j->dst + omin, npic);
+        for (int i = j->lo; i < j->hi; i++)
+            lo[i - j->lo] = j->off[i] - omin;
+        j->blk = lb - (size_t)j->lo * step;
+        j->dst = lp;
+        j->off = lo - j->lo;
+    }
     for (;;) {
         pthread_barrier_wait(l->bar);
         if (*l->stop)
@@ -218,6 +242,9 @@ static void *idct_loop_worker(void *p)
         idct_worker(&l->job);
         pthread_barrier_wait(l->bar);
     }
+    free(lb);
+    free(lp);
+    free(lo);
     return NULL;
 }
 static double now_s(void)
