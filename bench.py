@@ -423,7 +423,9 @@ def extras(torch, dev):
     ed = np.zeros(mbw * mbh * 8, dtype=np.dtype([("o", np.int32), ("k", np.uint8), ("a", np.uint8), ("b", np.uint8),
                                                      ("p", np.uint8), ("tc", np.int8, 4)]))
     ed["a"], ed["b"] = 40, 9
-    ed["k"] = np.where(rng.random(ed.size) < .25, 4, 0)
+    kk = np.zeros((mbw * mbh, 2, 4), np.uint8)   # bS = 4 exists on the MACROBLOCK edges (edge 0) of intra macroblocks only: a quarter of them
+    kk[rng.random(mbw * mbh) < .25, :, 0] = 4
+    ed["k"] = kk.ravel()
     ed["tc"] = rng.integers(0, 4, (ed.size, 4))
     ded = torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).to(dev)
     h264.deblock_frame(planes[0], w, mbw, mbh, ded)

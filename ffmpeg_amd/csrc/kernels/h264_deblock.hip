@@ -357,11 +357,11 @@ __device__ __forceinline__ int db_sad(int a, int b)
  * (h264dsp_template.c:104-330): `if (tc0) p1 += clip(..., -tc0, tc0)` is the unconditional form because the clip range is empty
  * when tc0 == 0. */
 template <bool CHROMA>
-__device__ __forceinline__ void db_normal(int (&v)[8], int alpha, int beta, int tc0)
+__device__ __forceinline__ void db_normal(int (&v)[8], int alpha, int beta, int tc0, int en = 1)
 {
     const int p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6];
     /* `&`, not `&&`: no short-circuit control flow — the lanes of an edge take every path anyway */
-    int c = (int)(db_sad(p0, q0) < alpha) & (int)(db_sad(p1, p0) < beta) & (int)(db_sad(q1, q0) < beta);
+    int c = en & (int)(db_sad(p0, q0) < alpha) & (int)(db_sad(p1, p0) < beta) & (int)(db_sad(q1, q0) < beta);
     if (CHROMA) {
         c &= (int)(tc0 > 0);
         const int delta = clip3((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc0, tc0);
@@ -382,11 +382,11 @@ __device__ __forceinline__ void db_normal(int (&v)[8], int alpha, int beta, int 
 }
 
 template <bool CHROMA>
-__device__ __forceinline__ void db_intra(int (&v)[8], int alpha, int beta)
+__device__ __forceinline__ void db_intra(int (&v)[8], int alpha, int beta, int en = 1)
 {
     const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
     const int d0 = db_sad(p0, q0);
-    const int c = (int)(d0 < alpha) & (int)(db_sad(p1, p0) < beta) & (int)(db_sad(q1, q0) < beta);
+    const int c = en & (int)(d0 < alpha) & (int)(db_sad(p1, p0) < beta) & (int)(db_sad(q1, q0) < beta);
     const int wp0 = (2 * p1 + p0 + q1 + 2) >> 2, wq0 = (2 * q1 + q0 + p1 + 2) >> 2; /* the weak forms */
     if (CHROMA) {
         v[3] = c ? wp0 : p0;
@@ -396,12 +396,18 @@ __device__ __forceinline__ void db_intra(int (&v)[8], int alpha, int beta)
     const int strong = d0 < ((alpha >> 2) + 2);
     const int sp = c & strong & (int)(db_sad(p2, p0) < beta), sq = c & strong & (int)(db_sad(q2, q0) < beta);
     const int s4 = p0 + q0;
-    v[3] = sp ? (p2 + 2 * p1 + 2 * s4 + q1 + 4) >> 3 : c ? wp0 : p0;
-    v[2] = sp ? (p2 + p1 + s4 + 2) >> 2 : p1;
-    v[1] = sp ? (2 * p3 + 3 * p2 + p1 + s4 + 4) >> 3 : p2;
-    v[4] = sq ? (p1 + 2 * s4 + 2 * q1 + q2 + 4) >> 3 : c ? wq0 : q0;
-    v[5] = sq ? (s4 + q1 + q2 + 2) >> 2 : q1;
-    v[6] = sq ? (2 * q3 + 3 * q2 + q1 + s4 + 4) >> 3 : q2;
+    /* every candidate value is computed first and made opaque: with the arithmetic visible behind the selects the compiler sinks it
+     * into divergent branches (exec-mask bookkeeping around three-instruction blocks) instead of emitting v_cndmask */
+    int sp0 = (p2 + 2 * p1 + 2 * s4 + q1 + 4) >> 3, sp1 = (p2 + p1 + s4 + 2) >> 2, sp2 = (2 * p3 + 3 * p2 + p1 + s4 + 4) >> 3;
+    int sq0 = (p1 + 2 * s4 + 2 * q1 + q2 + 4) >> 3, sq1 = (s4 + q1 + q2 + 2) >> 2, sq2 = (2 * q3 + 3 * q2 + q1 + s4 + 4) >> 3;
+    int w0 = c ? wp0 : p0, w1 = c ? wq0 : q0;
+    asm("" : "+v"(sp0), "+v"(sp1), "+v"(sp2), "+v"(sq0), "+v"(sq1), "+v"(sq2), "+v"(w0), "+v"(w1));
+    v[3] = sp ? sp0 : w0;
+    v[2] = sp ? sp1 : p1;
+    v[1] = sp ? sp2 : p2;
+    v[4] = sq ? sq0 : w1;
+    v[5] = sq ? sq1 : q1;
+    v[6] = sq ? sq2 : q2;
 }
 
 typedef uint32_t db_u4 __attribute__((ext_vector_type(4)));
@@ -676,6 +682,253 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
     }
 }
 
+/*
+ * k_h264_deblock_skew — the decoder-order wavefront with the data movement built first (round 3).
+ *
+ * The band kernel above spends a wave (16-20 useful lanes) per macroblock row and moves the picture as per-lane dwords; its
+ * load/store skeleton alone streamed at 7 % of HBM (profiles/r02_deblock_parts.txt).  Here ONE wave owns Q = 4 consecutive
+ * macroblock rows (8 for a chroma plane) and walks them SKEWED: lanes 16 q .. 16 q + 15 are row q of the band, and at wave step
+ * s row q filters macroblock x = s - 2 q — exactly the lag the order demands (macroblock (x, y) needs (x + 1, y - 1) finished,
+ * libavcodec/h264_loopfilter.c:716 with the raster walk of h264_slice.c's loop_filter()).  So
+ *   - all 64 lanes filter in every pass (lane = row of its macroblock for the vertical edges, lane = column for the horizontal);
+ *   - three of four row hand-offs are free: the rows of a band share one LDS strip (Q x 16 rows + 4 context rows, a ring of 8
+ *     macroblock slots wide, 144-byte pitch + 16 bytes of skew per row group: the row passes' 16-byte accesses and the column
+ *     passes' byte accesses both spread over the banks), a row's top context simply IS the bottom of the row group above;
+ *   - the picture moves as 16-byte rows: a lane loads its macroblock row a step ahead (one global_load_dwordx4 per lane and
+ *     step) and stores, a step behind, the row of the PREVIOUS macroblock's columns shifted up by four rows — the 16 x 16 region
+ *     (x - 1, rows 16 y - 4 .. 16 y + 11) is exactly what macroblock (x, y) has just made final: every picture byte is
+ *     written once, as part of a 16-byte row, by the row group that gives it its final value;
+ *   - only a band's last row talks to the next band through memory: its bottom four rows go out as write-through dwords, the
+ *     counter follows a step later (the stores are a whole step old and acknowledged by then: no round trip waits on the
+ *     critical path), and the consumer reads them with device-scope loads — the band kernel's protocol, once per Q rows.
+ * A picture's bands sit on ONE XCD (block L -> XCD L & 7: picture f on XCD f & 7), so the hand-off traffic of a picture stays in
+ * one L2 and eight pictures run side by side on the eight XCDs.
+ * Needs 16-byte (chroma: 8-byte) aligned planes / strides / pitches and 16-byte aligned edge records; anything else takes the
+ * band kernel (4-byte aligned) or the row kernel.
+ */
+/* One sample line across one edge for the skewed-rows kernel, every lane of the wave on its own macroblock: NO per-lane control
+ * flow (the four row groups filter different macroblocks: a divergent branch per edge cost more exec-mask bookkeeping than the
+ * filter).  The normal filter is always computed and selected by `en`; the intra filter runs behind ONE wave-uniform branch, taken
+ * only when some lane's edge is a bS = 4 edge. */
+template <bool CHROMA>
+__device__ __forceinline__ void db_edge(int (&v)[8], uint32_t rec, uint32_t tcw, int tcsh, bool skip)
+{
+    const int alpha = (rec >> 8) & 255, beta = (rec >> 16) & 255;
+    const bool en = alpha != 0 && beta != 0 && !skip;
+    const bool intra = (rec & 255) >= 4;
+    if (__builtin_amdgcn_ballot_w64(en && !intra)) /* bS = 0 edges (alpha 0) are common inside macroblocks: skipped wave-uniformly */
+        db_normal<CHROMA>(v, alpha, beta, (int)(int8_t)(tcw >> tcsh), (int)(en && !intra)); /* its own select: disabled lanes keep v */
+    if (__builtin_amdgcn_ballot_w64(en && intra))
+        db_intra<CHROMA>(v, alpha, beta, (int)(en && intra));
+}
+
+template <bool CHROMA>
+__global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
+                                                         const FFHipH264Edge *edges, int *gprog, int nbands, int bwaves, int nframes,
+                                                         int *fail, int fault)
+{
+    constexpr int MB = CHROMA ? 8 : 16;          /* samples per macroblock side = lanes per row group */
+    constexpr int NDW = MB / 4;                  /* dwords per macroblock row = edges per direction */
+    constexpr int NE = 2 * NDW;                  /* edge records per macroblock */
+    constexpr int Q = 64 / MB;                   /* macroblock rows per wave */
+    constexpr int SL = 8;                        /* ring slots (macroblocks) per row */
+    constexpr int PITCH = SL * MB + 16;          /* 144 / 80 bytes: 36 / 20 dwords, 16 (8) rows spread over all banks */
+    constexpr int ROWS = Q * MB + 4;             /* the band's rows + 4 context rows of the band above */
+    /* a workgroup is 1 .. 4 independent waves (the hardware spreads the waves of a workgroup over the SIMDs of its CU); each has
+     * its own strip and edge table in the dynamic LDS */
+    constexpr int TILE_BYTES = (ROWS * PITCH + (Q + 1) * 16 + 15) & ~15, ETAB_BYTES = Q * (3 * NE + 4) * 4;
+    extern __shared__ __align__(16) uint8_t db_lds[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    uint8_t *const tile = db_lds + wv * (TILE_BYTES + ETAB_BYTES);
+    uint32_t (*const etab)[3 * NE + 4] = reinterpret_cast<uint32_t (*)[3 * NE + 4]>(tile + TILE_BYTES);
+
+    /* block -> (picture, first band): the bands of a picture on one XCD.  A picture gets `bwaves` waves; wave j takes bands j,
+     * j + bwaves, ...: a band is busy for mb_w + 2 Q - 1 steps of a picture that takes mb_w + (2 Q + 2) nbands, so with one wave per
+     * band the SIMDs of a full batch idle more than half of the time — fewer, longer-lived waves per picture leave the rest of
+     * the chip to the other pictures.  (Band b's predecessor belongs to a wave dispatched no later: no wave waits on the unborn.) */
+    const int L = blockIdx.x, xcd = L & 7, idx = (L >> 3) * wpb + wv; /* bwaves is a multiple of the waves per workgroup */
+    const int f = xcd + 8 * (idx / bwaves), band0 = idx % bwaves;
+    if (f >= nframes)
+        return;
+    plane += (size_t)f * frame_pitch;
+    edges += (size_t)f * mb_w * mb_h * NE;
+    gprog += (size_t)f * nbands;
+
+    const int lane = threadIdx.x & 63, q = lane / MB, l = lane % MB;
+    for (int band = band0; band < nbands; band += bwaves) {
+    const int y = band * Q + q;
+    const bool row_ok = y < mb_h;
+    const int qb = min(Q - 1, mb_h - 1 - band * Q);      /* the band's last row inside the picture (wave-uniform) */
+    const bool next_band = band + 1 < nbands;
+    const int tcsh = 8 * (CHROMA ? l >> 1 : l >> 2);     /* this line's tc0 byte of an edge record (row l / column l) */
+    /* LDS: local row r' = picture row - (band's first row) + 4; rows of group q carry skew (q + 1) * 16, the 4 context rows 0 */
+    uint8_t *const ownrow = tile + (MB * q + l + 4) * PITCH + (q + 1) * 16;       /* V pass: this lane's macroblock row */
+    uint8_t *const strow = tile + (MB * q + l) * PITCH + (q + (l >= 4 ? 1 : 0)) * 16; /* store pass: the row four above it */
+    const uint8_t *const grow = plane + ((ptrdiff_t)y * MB + l) * stride;          /* picture row of ownrow */
+    uint8_t *const gst = plane + ((ptrdiff_t)y * MB + l - 4) * stride;             /* picture row of strow */
+    const bool st_ok = row_ok && (y > 0 || l >= 4);
+    /* bottom rows of the band's last row: 4 rows x NDW dwords = MB lanes (row group qb) */
+    const int br = MB - 4 + l / NDW, bd = l % NDW;
+    uint8_t *const botl = tile + (MB * qb + br + 4) * PITCH + (qb + 1) * 16 + 4 * bd;
+    uint8_t *const botg = plane + ((ptrdiff_t)(band * Q + qb) * MB + br) * stride + 4 * bd;
+    /* top context of the band (rows -4 .. -1 of its first row): the same MB lanes of row group 0 */
+    const int cr = l / NDW, cd = l % NDW;
+    uint8_t *const ctxl = tile + cr * PITCH + 4 * cd;
+    const uint8_t *const ctxg = plane + ((ptrdiff_t)band * Q * MB - 4 + cr) * stride + 4 * cd;
+    const uint32_t *const erow = reinterpret_cast<const uint32_t *>(edges + (size_t)(row_ok ? y : 0) * mb_w * NE);
+
+    typedef uint32_t rowv __attribute__((ext_vector_type(CHROMA ? 2 : 4)));
+    rowv own = {};
+    db_u4 eown = { 0, 0, 0, 0 };
+    auto fetch = [&](int xn) { /* macroblock xn's row l and (lanes l < 3 NDW / 2) 16 bytes of its edge records */
+        if (row_ok && xn >= 0 && xn < mb_w) {
+            own = *reinterpret_cast<const rowv *>(grow + xn * MB);
+            if (l < 3 * NE / 4)
+                eown = *reinterpret_cast<const db_u4 *>(erow + (size_t)xn * 3 * NE + 4 * l);
+        }
+    };
+    int known = 0;
+    bool have_top = false;
+    uint32_t topv = 0;
+    auto load_top = [&](int x0) {
+        return __hip_atomic_load(reinterpret_cast<const uint32_t *>(ctxg + x0 * MB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    fetch(0 - 2 * q);
+    const int nsteps = mb_w + 1 + 2 * (Q - 1);
+    for (int s = 0; s < nsteps; s++) {
+        const int x = s - 2 * q;
+        const bool act = row_ok && x >= 0 && x < mb_w;
+        /* ---- everything issued a step ago is complete: the loads of this step's macroblocks and the stores of the previous
+         *      step's results.  The band's bottom rows of macroblocks < xb - 2 are therefore in memory: publish ---- */
+        __builtin_amdgcn_s_waitcnt(0);
+        const int xb = s - 2 * qb; /* the stores issued a step ago (at xb - 1) held the columns of macroblock xb - 3, or the row's end */
+        if (next_band && xb >= 3 && xb <= mb_w + 1 && !(fault & 1)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_store(&gprog[band], xb > mb_w ? mb_w : xb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (act) {
+            *reinterpret_cast<rowv *>(ownrow + (x & (SL - 1)) * MB) = own;
+            if (l < 3 * NE / 4)
+                *reinterpret_cast<db_u4 *>(&etab[q][4 * l]) = eown;
+        }
+        fetch(x + 1);
+        /* ---- picture stores of the previous step's results: macroblock x - 1 was filtered a step ago, which made the columns of
+         *      macroblock x - 2 final (rows shifted up by four); behind the row's last macroblock its own columns are final too ---- */
+        if (!(fault & 2) && x >= 1 && x <= mb_w) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int m = t ? x - 1 : x - 2;
+                if (m < 0 || (t && x != mb_w))
+                    continue;
+                if (st_ok)
+                    *reinterpret_cast<rowv *>(gst + m * MB) = *reinterpret_cast<const rowv *>(strow + (m & (SL - 1)) * MB);
+                if (row_ok && q == qb) { /* ... and the bottom four rows of the band's last row */
+                    const uint32_t v = *reinterpret_cast<const uint32_t *>(botl + (m & (SL - 1)) * MB);
+                    uint32_t *g = reinterpret_cast<uint32_t *>(botg + m * MB);
+                    if (next_band)
+                        __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* write-through: read by the next band */
+                    else
+                        *g = v;
+                }
+            }
+        }
+        wave_lds_sync();
+        /* ---- vertical edges, left to right: lane = row; samples -4 .. MB-1 of the row ---- */
+        if (act && !(fault & 4)) {
+            uint8_t *pl = ownrow + ((x - 1) & (SL - 1)) * MB + MB - 4, *pm = ownrow + (x & (SL - 1)) * MB;
+            int v0[MB + 4];
+            {
+                const uint32_t lw = *reinterpret_cast<const uint32_t *>(pl);
+                const rowv mw = *reinterpret_cast<const rowv *>(pm);
+                v0[0] = lw & 255; v0[1] = (lw >> 8) & 255; v0[2] = (lw >> 16) & 255; v0[3] = lw >> 24;
+#pragma unroll
+                for (int d = 0; d < NDW; d++) {
+                    const uint32_t w = mw[d];
+                    v0[4 + 4 * d] = w & 255; v0[5 + 4 * d] = (w >> 8) & 255; v0[6 + 4 * d] = (w >> 16) & 255; v0[7 + 4 * d] = w >> 24;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NDW; k++) {
+                int v[8] = { v0[4 * k], v0[4 * k + 1], v0[4 * k + 2], v0[4 * k + 3], v0[4 * k + 4], v0[4 * k + 5], v0[4 * k + 6], v0[4 * k + 7] };
+                db_edge<CHROMA>(v, etab[q][3 * k + 1], etab[q][3 * k + 2], tcsh, k == 0 && x == 0);
+#pragma unroll
+                for (int i = 1; i < 7; i++)
+                    v0[4 * k + i] = v[i];
+            }
+            *reinterpret_cast<uint32_t *>(pl) = (uint32_t)v0[0] | ((uint32_t)v0[1] << 8) | ((uint32_t)v0[2] << 16) | ((uint32_t)v0[3] << 24);
+            rowv mw;
+#pragma unroll
+            for (int d = 0; d < NDW; d++)
+                mw[d] = (uint32_t)v0[4 + 4 * d] | ((uint32_t)v0[5 + 4 * d] << 8) | ((uint32_t)v0[6 + 4 * d] << 16) | ((uint32_t)v0[7 + 4 * d] << 24);
+            *reinterpret_cast<rowv *>(pm) = mw;
+        }
+        /* ---- the band's top context: the band above must have its bottom rows of macroblock s in memory (count >= s + 1).  Only
+         *      the horizontal edges of row group 0 read (and rewrite) them, so the wait sits behind the vertical pass ---- */
+        if (band > 0 && s < mb_w) {
+            if (!have_top) {
+                const int want = (fault & 8) ? 0 : s + 1;
+                int spins = 0;
+                while (known < want) {
+                    known = __hip_atomic_load(&gprog[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (known >= want)
+                        break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                        if (lane == 0)
+                            __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        return;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (lane < MB)
+                    topv = load_top(s);
+            }
+            if (lane < MB)
+                *reinterpret_cast<uint32_t *>(ctxl + (s & (SL - 1)) * MB) = topv;
+        }
+        wave_lds_sync();
+        /* the next macroblock's context, if the band above has already published it: its latency hides behind the H pass */
+        have_top = false;
+        if (band > 0 && s + 1 < mb_w && known >= s + 2) {
+            if (lane < MB)
+                topv = load_top(s + 1);
+            have_top = true;
+        }
+        /* ---- horizontal edges, top to bottom: lane = column; yv[i] = row i - 4 of the macroblock ---- */
+        if (act && !(fault & 4)) {
+            uint8_t *tcol = tile + MB * q * PITCH + q * 16 + (x & (SL - 1)) * MB + l;   /* row -4 of group q (skew of group q - 1) */
+            int yv[MB + 4];
+#pragma unroll
+            for (int r = 0; r < MB + 4; r++)
+                yv[r] = (CHROMA && r < 2) ? 0 : tcol[r * PITCH + (r >= 4 ? 16 : 0)];
+#pragma unroll
+            for (int k = 0; k < NDW; k++) {
+                int v[8] = { yv[4 * k], yv[4 * k + 1], yv[4 * k + 2], yv[4 * k + 3], yv[4 * k + 4], yv[4 * k + 5], yv[4 * k + 6], yv[4 * k + 7] };
+                db_edge<CHROMA>(v, etab[q][3 * (NDW + k) + 1], etab[q][3 * (NDW + k) + 2], tcsh, k == 0 && y == 0);
+#pragma unroll
+                for (int i = 1; i < 7; i++)
+                    yv[4 * k + i] = v[i];
+            }
+            /* rows a horizontal filter can have changed: luma p2 .. q2 of every edge, chroma p0 / q0 */
+#pragma unroll
+            for (int r = 1; r < MB + 3; r++)
+                if (!CHROMA || (r & 3) == 3 || (r & 3) == 0)
+                    tcol[r * PITCH + (r >= 4 ? 16 : 0)] = (uint8_t)yv[r];
+        }
+        wave_lds_sync();
+    }
+    /* the last step's stores (the flush of the band's last row) are out: publish the whole row */
+    if (next_band && !(fault & 1)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0)
+            __hip_atomic_store(&gprog[band], mb_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wave_lds_sync();
+    } /* bands of this wave */
+}
+
 /* the progress counters come from the per-device pool (progress_pool.hip): a slot per launch, zeroed in stream order */
 static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                           const FFHipH264Edge *edges, hipStream_t stream)
@@ -687,18 +940,22 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
         ffhip_set_error("ffhip_h264_deblock_frame_chroma: plane, stride and frame pitch must be 4-byte aligned");
         return FFHIP_EINVAL;
     }
-    const char *eo = FFHIP_KNOB("FFHIP_DEBLOCK_OLD"); /* the per-row-workgroup kernel (measurement / cross-check) */
+    const char *eo = FFHIP_KNOB("FFHIP_DEBLOCK_OLD"); /* 1: the per-row-workgroup kernel, 2: the band kernel (measurement / cross-check) */
     const char *ef = FFHIP_KNOB("FFHIP_DEBLOCK_FAULT"); /* test hook: lost hand-offs -> timeout -> FFHIP_EIO at the next check */
     const int fault = ef ? atoi(ef) : 0; /* 1: the test hook; 2 no stores, 4 no filters, 8 no waiting: timing experiments (wrong output) */
-    const bool band = aligned && !(eo && eo[0] == '1' && !chroma);
-    /* rows per band.  A lone picture is latency-bound: 4 = one wave per SIMD, the waves of a band must not share an issue port
-     * (measured 1.9 ms vs 2.4 ms per 4K plane).  A batch that fills the chip anyway is throughput-bound: 16 keeps 15 of 16
-     * hand-offs in LDS (32 planes: 2.9 ms vs 4.9 ms).  FFHIP_DEBLOCK_BAND = 4 / 8 / 16 overrides. */
+    const int old = eo ? atoi(eo) : 0;
+    /* the skewed-rows kernel moves 16-byte (chroma: 8-byte) rows and reads the edge records as 16-byte vectors */
+    const size_t amask = chroma ? 7 : 15;
+    const bool skew = !old && !(((uintptr_t)plane | (size_t)stride | frame_pitch) & amask) && !((uintptr_t)edges & 15);
+    const bool band = !skew && aligned && !(old == 1 && !chroma);
+    /* band kernel, rows per band.  A lone picture is latency-bound: 4 = one wave per SIMD, the waves of a band must not share an
+     * issue port.  A batch that fills the chip anyway is throughput-bound: 16 keeps 15 of 16 hand-offs in LDS.
+     * FFHIP_DEBLOCK_BAND = 4 / 8 / 16 overrides. */
     const char *ew = FFHIP_KNOB("FFHIP_DEBLOCK_BAND");
-    const int bw = ew && atoi(ew) == 16 ? 16 : ew && atoi(ew) == 8 ? 8 : ew && atoi(ew) == 4 ? 4 :
+    const int bw = skew ? (chroma ? 8 : 4) : ew && atoi(ew) == 16 ? 16 : ew && atoi(ew) == 8 ? 8 : ew && atoi(ew) == 4 ? 4 :
                    (long long)nframes * mb_h > 2048 ? 16 : 4;
     const int nbands = cdiv(mb_h, bw);
-    const int per_frame = band ? nbands : mb_h + 1;
+    const int per_frame = (band || skew) ? nbands : mb_h + 1;
     if (per_frame > FFHIP_PROGRESS_SLOT_INTS) {
         ffhip_set_error("ffhip_h264_deblock_frame: %d macroblock rows exceed the supported %d", mb_h, FFHIP_PROGRESS_SLOT_INTS - 1);
         return FFHIP_EINVAL;
@@ -714,7 +971,24 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
         int *const prog = ps.prog, *const fail = ps.fail;
         uint8_t *pl = plane + (size_t)f0 * frame_pitch;
         const FFHipH264Edge *ed = edges + (size_t)f0 * mb_w * mb_h * ne;
-        if (!band)
+        if (skew) {
+            /* waves per picture: one per band while the chip has SIMDs to spare (a lone picture is latency-bound), else what an
+             * XCD's 128 SIMDs leave each of its pictures, but never fewer than a quarter of the bands (the wavefront's width) */
+            const char *eb = FFHIP_KNOB("FFHIP_DEBLOCK_WAVES"), *ewp = FFHIP_KNOB("FFHIP_DEBLOCK_WPB");
+            const int wpb = ewp && atoi(ewp) >= 1 && atoi(ewp) <= 4 ? atoi(ewp) : 1; /* measured: 1, 2 and 4 waves per workgroup are within 5 % (profiles/r03_deblock_wpb_experiment.txt) */
+            const int per_xcd = cdiv(nf, 8);
+            int bwaves = eb && atoi(eb) > 0 ? atoi(eb) : 128 / per_xcd;
+            if (bwaves < cdiv(nbands, 4)) bwaves = cdiv(nbands, 4);
+            if (bwaves > nbands) bwaves = nbands;
+            bwaves = cdiv(bwaves, wpb) * wpb; /* whole workgroups (waves beyond the last band retire at once) */
+            const dim3 g(8 * (bwaves / wpb) * per_xcd), t(64 * wpb);
+            const int mbs = chroma ? 8 : 16, qq = 64 / mbs, nee = chroma ? 4 : 8;
+            const unsigned lds = (unsigned)wpb * (((unsigned)((qq * mbs + 4) * (8 * mbs + 16) + (qq + 1) * 16 + 15) & ~15u) + (unsigned)qq * (3 * nee + 4) * 4);
+            if (chroma)
+                hipLaunchKernelGGL(k_h264_deblock_skew<true>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault);
+            else
+                hipLaunchKernelGGL(k_h264_deblock_skew<false>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault);
+        } else if (!band)
             hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h, nf), dim3(64), 0, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, fail);
 #define DB_LAUNCH(CH, W) hipLaunchKernelGGL((k_h264_deblock_band<CH, W>), dim3(nbands, nf), dim3(64 * W), 0, stream, pl, frame_pitch, stride, \
                                             mb_w, mb_h, ed, prog, nbands, fail, fault)

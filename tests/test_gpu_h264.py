@@ -144,10 +144,13 @@ def test_loop_filter_batch(kind):
     assert np.array_equal(d_plane.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("mb_w,mb_h,pad", [(1, 1, 0), (5, 3, 16), (7, 4, 3), (45, 30, 0), (240, 135, 0)])
+@pytest.mark.parametrize("mb_w,mb_h,pad", [(1, 1, 0), (5, 3, 16), (7, 4, 3), (45, 30, 0), (240, 135, 0), (2, 9, 0), (3, 5, 32), (1, 13, 0),
+                                           (9, 8, 4), (120, 68, 0), (17, 6, 16)])
 def test_deblock_frame(mb_w, mb_h, pad):
-    """frame order (wavefront) == serial order, bit for bit; 240x135 MBs = one 4K luma plane; pad 3: a stride that is not
-    a multiple of 4 takes the byte path with full release/acquire hand-offs"""
+    """frame order (wavefront) == serial order, bit for bit; 240x135 MBs = one 4K luma plane.  pad 0 / 16 / 32: 16-byte aligned
+    rows take the skewed-rows kernel (4 macroblock rows per wave; mb_h around and across multiples of 4: partial last bands,
+    one-macroblock-wide pictures), pad 4 the band kernel (dword rows), pad 3 (a stride that is not a multiple of 4) the byte path
+    with full release/acquire hand-offs"""
     from ffmpeg_amd import h264
     torch = _torch()
     rng = np.random.default_rng(mb_w * 100 + mb_h)
@@ -283,9 +286,11 @@ def test_idct_add8_dc_dequant_add_pixels_batches():
         assert np.array_equal(dp_.cpu().numpy(), wp) and not dr.cpu().numpy().any()
 
 
-def test_deblock_frame_row_kernel_agrees(monkeypatch):
-    """FFHIP_DEBLOCK_OLD=1: the one-workgroup-per-row kernel (the byte path of unaligned strides) on an aligned picture"""
-    monkeypatch.setenv("FFHIP_DEBLOCK_OLD", "1")
+@pytest.mark.parametrize("old", ["1", "2"], ids=["row-kernel", "band-kernel"])
+def test_deblock_frame_row_kernel_agrees(old, monkeypatch):
+    """FFHIP_DEBLOCK_OLD=1: the one-workgroup-per-row kernel (the byte path of unaligned strides), =2: the band kernel (dword rows),
+    both on a 16-byte aligned picture that the skewed-rows kernel would otherwise take"""
+    monkeypatch.setenv("FFHIP_DEBLOCK_OLD", old)
     test_deblock_frame(40, 37, 0)
 
 
@@ -296,7 +301,7 @@ def test_deblock_lost_handoff_is_reported(monkeypatch, measure_build):
     torch = _torch()
     L = _lib.lib()
     assert L.ffhip_stream_synchronize(None) == 0
-    mb_w, mb_h = 4, 3
+    mb_w, mb_h = 4, 9          # three bands of the skewed-rows kernel: two hand-offs through memory
     plane = torch.zeros((mb_h * 16, mb_w * 16), dtype=torch.uint8, device="cuda:0")
     ed = torch.zeros((mb_w * mb_h * 8, 12), dtype=torch.uint8, device="cuda:0")
     monkeypatch.setenv("FFHIP_DEBLOCK_FAULT", "1")
@@ -332,7 +337,8 @@ def test_deblock_frames_batch():
     assert np.array_equal(d.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("mb_w,mb_h,nf,pad", [(1, 1, 1, 0), (5, 1, 1, 4), (1, 7, 2, 0), (40, 25, 3, 8), (240, 135, 2, 0)])
+@pytest.mark.parametrize("mb_w,mb_h,nf,pad", [(1, 1, 1, 0), (5, 1, 1, 4), (1, 7, 2, 0), (40, 25, 3, 8), (240, 135, 2, 0), (3, 9, 9, 0), (2, 17, 1, 8),
+                                              (120, 68, 2, 0), (7, 8, 17, 16), (6, 16, 1, 4)])
 def test_deblock_frame_chroma(mb_w, mb_h, nf, pad):
     """one 4:2:0 chroma plane per frame in decoder order (wavefront) == the serial order, bit for bit; 240x135 MBs = the chroma
     plane of a 4K picture; several pictures per launch"""

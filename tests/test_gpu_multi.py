@@ -279,7 +279,7 @@ def test_lost_handoff_is_reported_to_its_own_stream_only(monkeypatch, measure_bu
     L = _lib.lib()
     a, b = C.c_void_p(), C.c_void_p()
     assert L.ffhip_stream_create(C.byref(a)) == 0 and L.ffhip_stream_create(C.byref(b)) == 0
-    mb_w, mb_h = 4, 3
+    mb_w, mb_h = 4, 9          # three bands: hand-offs through memory exist
     pa = torch.zeros((mb_h * 16, mb_w * 16), dtype=torch.uint8, device="cuda:0")
     pb = torch.zeros((mb_h * 16, mb_w * 16), dtype=torch.uint8, device="cuda:0")
     ed = torch.zeros((mb_w * mb_h * 8, 12), dtype=torch.uint8, device="cuda:0")

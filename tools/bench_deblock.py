@@ -18,7 +18,17 @@ rng = np.random.default_rng(3)
 ed = np.zeros(mbw * mbh * 8, dtype=np.dtype([("o", np.int32), ("k", np.uint8), ("a", np.uint8), ("b", np.uint8), ("p", np.uint8),
                                                  ("tc", np.int8, 4)]))
 ed["a"], ed["b"] = 40, 9
-ed["k"] = np.where(rng.random(ed.size) < .25, 4, 0)
+# bS = 4 (the strong filter) exists on macroblock EDGES of intra macroblocks only (edge 0 of either direction,
+# h264_loopfilter.c check_mv / filter_mb_dir); DB_INTRA = share of macroblocks that are intra (default 0.25), DB_INTRA_ANY=1 puts
+# the strong filter on a quarter of ALL edges instead (what the tests do: a stream cannot, the kernel must cope anyway)
+intra = float(os.environ.get("DB_INTRA", "0.25"))
+if os.environ.get("DB_INTRA_ANY") == "1":
+    ed["k"] = np.where(rng.random(ed.size) < .25, 4, 0)
+else:
+    mb_intra = rng.random(mbw * mbh) < intra
+    k = np.zeros((mbw * mbh, 2, 4), np.uint8)
+    k[mb_intra, :, 0] = 4
+    ed["k"] = k.ravel()
 ed["tc"] = rng.integers(0, 4, (ed.size, 4))
 ded = torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).to(dev)
 for nf in (1, 2, 4, 8, 16, 32, 64):
@@ -37,7 +47,9 @@ for nf in (1, 2, 4, 8, 16, 32, 64):
 cw, ch = w // 2, h // 2
 edc = np.zeros(mbw * mbh * 4, dtype=ed.dtype)
 edc["a"], edc["b"] = 40, 9
-edc["k"] = np.where(rng.random(edc.size) < .25, 6, 2)
+kc = np.full((mbw * mbh, 2, 2), 2, np.uint8)
+kc[rng.random(mbw * mbh) < intra, :, 0] = 6
+edc["k"] = kc.ravel()
 edc["tc"] = rng.integers(0, 4, (edc.size, 4))
 dedc = torch.from_numpy(edc.view(np.uint8).reshape(-1, 12)).to(dev)
 for nf in (1, 8, 32, 64):
