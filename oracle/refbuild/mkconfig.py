@@ -71,6 +71,9 @@ def scan(path, seen, toks, roots):
 def main():
     ref, out = sys.argv[1], sys.argv[2]
     srcs = sys.argv[3:]
+    # a second configuration from the same recipe (the checkasm build switches a few more components on): space-separated tokens
+    ONES.update(os.environ.get("MKCONFIG_ONES", "").split())
+    ONES.difference_update(os.environ.get("MKCONFIG_ZEROS", "").split())
     toks, seen = set(), set()
     for s in srcs:
         scan(s, seen, toks, [ref])
