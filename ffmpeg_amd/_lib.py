@@ -212,6 +212,13 @@ def lib():
         "ff_float_dsp_init_hip": (C.c_int, [vp]),
         "ff_h264dsp_init_hip": (C.c_int, [vp, C.c_int, C.c_int]),
         "ff_h264qpel_init_hip": (C.c_int, [vp, C.c_int]),
+        "ffhip_h264_idct_add_batch_dev_hbd": (C.c_int, [C.c_int, C.c_int, vp, C.c_ssize_t, vp, vp, C.c_int, vp]),
+        "ffhip_h264_idct_mb_batch_dev_hbd": (C.c_int, [C.c_int, C.c_int, vp, vp, C.c_ssize_t, vp, vp, vp, vp, C.c_int, vp]),
+        "ffhip_h264_dc_dequant_batch_dev_hbd": (C.c_int, [C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, vp, C.c_int, vp]),
+        "ffhip_h264_loop_filter_batch_dev_hbd": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ffhip_h264_qpel_batch_dev_hbd": (C.c_int, [C.c_int, vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ffhip_h264_chroma_mc_batch_dev_hbd": (C.c_int, [C.c_int, vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ffhip_h264_weight_batch_dev_hbd": (C.c_int, [C.c_int, vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ff_me_cmp_init_hip": (C.c_int, [vp]),
     }
     missing = []

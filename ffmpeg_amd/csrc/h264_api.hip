@@ -389,3 +389,68 @@ extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const 
         return FFHIP_ENOSYS;
     return ffhip_launch_fdsp(op, dst, dst_pitch, src0, pitch0, src1, pitch1, src2, pitch2, mul, len, nvec, (hipStream_t)stream);
 }
+
+/* ---- any bit depth, MBAFF and 4:2:2 members (kernels/h264_hbd.hip) ---------------------------------------------------------- */
+extern "C" int ffhip_h264_idct_add_batch_dev_hbd(int bit_depth, int kind, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset,
+                                                 int16_t *blocks, int n, void *stream)
+{
+    if (!dst_base || !dst_offset || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_idct_add_bd(bit_depth, kind, dst_base, stride, dst_offset, blocks, n, (hipStream_t)stream);
+}
+extern "C" int ffhip_h264_idct_mb_batch_dev_hbd(int bit_depth, int which, uint8_t *dst_base, uint8_t *dst2, ptrdiff_t stride,
+                                                const int32_t *mb_offset, const int32_t *blockoffset, int16_t *blocks, const uint8_t *nnzc,
+                                                int nmb, void *stream)
+{
+    if (!dst_base || (which >= 3 && !dst2) || !mb_offset || !blockoffset || !blocks || !nnzc || nmb < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_idct_mb_bd(bit_depth, which, dst_base, dst2, stride, mb_offset, blockoffset, blocks, nnzc, nmb, (hipStream_t)stream);
+}
+extern "C" int ffhip_h264_dc_dequant_batch_dev_hbd(int bit_depth, int which, int16_t *output, size_t out_pitch, const int16_t *input,
+                                                   size_t in_pitch, const int32_t *block_offset, const int32_t *qmul, int n, void *stream)
+{
+    if (!output || !qmul || n < 0 || (which == 0 && !input) || (which != 0 && !block_offset))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_dc_dequant_bd(bit_depth, which, output, out_pitch, input, in_pitch, block_offset, qmul, n, (hipStream_t)stream);
+}
+extern "C" int ffhip_h264_loop_filter_batch_dev_hbd(int bit_depth, uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n, void *stream)
+{
+    if (!base || !edges || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_loop_filter_bd(bit_depth, base, stride, edges, n, (hipStream_t)stream);
+}
+extern "C" int ffhip_h264_qpel_batch_dev_hbd(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
+                                             void *stream)
+{
+    if (!dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_qpel_bd(bit_depth, dst, src, stride, blocks, n, (hipStream_t)stream);
+}
+extern "C" int ffhip_h264_chroma_mc_batch_dev_hbd(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks,
+                                                  int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_chroma_mc_bd(bit_depth, dst, src, stride, blocks, n, (hipStream_t)stream);
+}
+extern "C" int ffhip_h264_weight_batch_dev_hbd(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks,
+                                               int n, void *stream)
+{
+    if (!dst || !blocks || n < 0)
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_weight_bd(bit_depth, dst, src ? src : dst, stride, blocks, n, (hipStream_t)stream);
+}

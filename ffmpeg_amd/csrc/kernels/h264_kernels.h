@@ -28,6 +28,26 @@ int ffhip_launch_h264_luma_dc_dequant(int16_t *output, size_t out_pitch, const i
 int ffhip_launch_h264_chroma_dc_dequant(int16_t *blocks, const int32_t *block_offset, const int32_t *qmul, int n, hipStream_t stream);
 int ffhip_launch_h264_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n,
                                   hipStream_t stream);
+/* any bit depth + the MBAFF / 4:2:2 members (h264_hbd.hip) */
+int ffhip_launch_h264_idct_add_bd(int bd, int kind, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset, int16_t *blocks, int n,
+                                  hipStream_t stream);
+int ffhip_launch_h264_idct_mb_bd(int bd, int which, uint8_t *dst_base, uint8_t *dst2, ptrdiff_t stride, const int32_t *mb_offset,
+                                 const int32_t *blockoffset, int16_t *blocks, const uint8_t *nnzc, int nmb, hipStream_t stream);
+int ffhip_launch_h264_dc_dequant_bd(int bd, int which, int16_t *output, size_t out_pitch, const int16_t *input, size_t in_pitch,
+                                    const int32_t *block_offset, const int32_t *qmul, int n, hipStream_t stream);
+/* alpha_beta: NULL (the records' bytes) or n x { alpha, beta } ints overriding them */
+int ffhip_launch_h264_loop_filter_bd(int bd, uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n, hipStream_t stream,
+                                     const int32_t *alpha_beta = nullptr);
+int ffhip_launch_h264_qpel_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n, hipStream_t stream);
+int ffhip_launch_h264_chroma_mc_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
+                                   hipStream_t stream);
+int ffhip_launch_h264_weight_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
+                                hipStream_t stream);
+/* host faces of those (shims_h264_hbd.hip) */
+int ffhip_h264dsp_fill_generic(FFHipH264DSPContext *c, FFHipH264DSPContext *o, int bit_depth, int chroma_format_idc);
+int ffhip_h264qpel_init_generic(FFHipH264QpelContext *c, int bit_depth);
+int ffhip_h264chroma_init_generic(FFHipH264ChromaContext *c, int bit_depth);
+int ffhip_h264weight_init_generic(FFHipH264WeightContext *c, int bit_depth);
 int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                   const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
 int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,

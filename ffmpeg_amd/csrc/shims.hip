@@ -33,42 +33,7 @@
 
 extern "C" long ffhip_shim_fallbacks(void) { return g_fallbacks.load(); }
 
-#define DP 64 /* device row pitch of a staged rectangle */
-
-/* a rectangle rows r0..r1 x columns c0..c1 around host pointer p (row step = stride, may be negative) */
-struct Rect {
-    uint8_t *host;
-    ptrdiff_t stride;
-    int r0, r1, c0, c1;
-    uint8_t *dev; /* device address corresponding to `host` */
-};
-
-static size_t rect_bytes(const Rect &r) { return (size_t)(r.r1 - r.r0 + 1) * DP + 2 * DP; }
-
-static bool rect_up(Rect &r, uint8_t *buf)
-{
-    r.dev = buf + DP - (ptrdiff_t)r.r0 * DP - r.c0; /* row r0 col c0 lands at buf + DP */
-    const int w = r.c1 - r.c0 + 1, h = r.r1 - r.r0 + 1;
-    if (r.stride >= w) /* one 2-D copy; bottom-up pictures (negative strides) go row by row */
-        return hipMemcpy2D(r.dev + (ptrdiff_t)r.r0 * DP + r.c0, DP, r.host + r.r0 * r.stride + r.c0, r.stride, w, h, hipMemcpyHostToDevice) ==
-               hipSuccess;
-    for (int y = r.r0; y <= r.r1; y++)
-        if (hipMemcpy(r.dev + (ptrdiff_t)y * DP + r.c0, r.host + y * r.stride + r.c0, w, hipMemcpyHostToDevice) != hipSuccess)
-            return false;
-    return true;
-}
-
-/* commit rows r0..r1 x columns c0..c1 of a staged rectangle from the bounce buffer (after Arena::down()) */
-static void rect_commit(const Arena &A, const Rect &r, int r0, int r1, int c0, int c1)
-{
-    for (int y = r0; y <= r1; y++)
-        memcpy(r.host + y * r.stride + c0, A.host(r.dev + (ptrdiff_t)y * DP + c0), c1 - c0 + 1);
-}
-static void commit2d(const Arena &A, void *dst, ptrdiff_t dstride, const void *dev, ptrdiff_t dpitch, size_t wbytes, int rows)
-{
-    for (int y = 0; y < rows; y++)
-        memcpy(static_cast<uint8_t *>(dst) + y * dstride, A.host(static_cast<const uint8_t *>(dev) + y * dpitch), wbytes);
-}
+#include "kernels/shim_rect.h"
 
 /* ---- h264dsp: single blocks ---------------------------------------------------------------------- */
 static bool idct_single(int kind, uint8_t *dst, int16_t *block, ptrdiff_t stride)
@@ -252,13 +217,19 @@ static void s_h_lf_chroma_i(uint8_t *p, ptrdiff_t s, int a, int b) { if (!lf_sin
 
 extern "C" int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int chroma_format_idc)
 {
-    if (!c)
+    if (!c || chroma_format_idc < 0 || chroma_format_idc > 3)
         return FFHIP_EINVAL;
-    if (bit_depth != 8 || chroma_format_idc > 1)
-        return FFHIP_EINVAL; /* other depths / 4:2:2 keep the C pointers (h264dsp.c:70-150 selects per depth and chroma format) */
+    if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14)
+        return FFHIP_EINVAL; /* h264dsp.c:135-147: the depths H.264 defines */
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     FFHipH264DSPContext o = *c;
+    if (bit_depth > 8) { /* every member from the depth-generic faces (shims_h264_hbd.hip) */
+        const int r = ffhip_h264dsp_fill_generic(c, &o, bit_depth, chroma_format_idc == 2 ? 2 : 1);
+        if (r >= 0)
+            *c = o;
+        return r;
+    }
     o.v_loop_filter_luma = s_v_lf_luma;                 o.h_loop_filter_luma = s_h_lf_luma;
     o.v_loop_filter_luma_intra = s_v_lf_luma_i;         o.h_loop_filter_luma_intra = s_h_lf_luma_i;
     o.v_loop_filter_chroma = s_v_lf_chroma;             o.h_loop_filter_chroma = s_h_lf_chroma;
@@ -269,6 +240,10 @@ extern "C" int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int ch
     o.idct_add16intra = s_idct_add16intra;              o.idct_add8 = s_idct_add8;
     o.luma_dc_dequant_idct = s_luma_dc_dequant;         o.chroma_dc_dequant_idct = s_chroma_dc_dequant;
     o.add_pixels4_clear = s_add_pixels4;                o.add_pixels8_clear = s_add_pixels8;
+    /* the MBAFF members, and for 4:2:2 the chroma forms the reference switches, come from the depth-generic faces at 8 bits */
+    const int r = ffhip_h264dsp_fill_generic(c, &o, 8, chroma_format_idc == 2 ? 2 : 1);
+    if (r < 0)
+        return r;
     fb_snapshot(g_fb_h264, *c, o);
     *c = o;
     return 0;
@@ -322,10 +297,12 @@ QPEL_16(avg, 1, 16, 0) QPEL_16(avg, 1, 8, 1) QPEL_16(avg, 1, 4, 2)
 
 extern "C" int ff_h264qpel_init_hip(FFHipH264QpelContext *c, int bit_depth)
 {
-    if (!c || bit_depth != 8)
-        return FFHIP_EINVAL;
+    if (!c || (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14))
+        return FFHIP_EINVAL; /* h264qpel.c:87-103: the depths H.264 defines */
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
+    if (bit_depth > 8)
+        return ffhip_h264qpel_init_generic(c, bit_depth); /* 16-bit samples: shims_h264_hbd.hip */
     /* table index = X + 4*Y, [0] 16x16 [1] 8x8 [2] 4x4 (h264qpel.c:55-70) */
     static const ffhip_qpel_mc_func put[3][16] = { QPEL_ROW(put, 16), QPEL_ROW(put, 8), QPEL_ROW(put, 4) };
     static const ffhip_qpel_mc_func avg[3][16] = { QPEL_ROW(avg, 16), QPEL_ROW(avg, 8), QPEL_ROW(avg, 4) };
@@ -370,10 +347,12 @@ CHROMA_FN(put, 0, 0) CHROMA_FN(put, 0, 1) CHROMA_FN(put, 0, 2) CHROMA_FN(avg, 1,
 
 extern "C" int ff_h264chroma_init_hip(FFHipH264ChromaContext *c, int bit_depth)
 {
-    if (!c || bit_depth != 8)
+    if (!c || bit_depth < 8 || bit_depth > 16)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
+    if (bit_depth > 8) /* h264chroma.c:40-52: ONE 16-bit instantiation serves every depth above 8 (bilinear: nothing depends on the depth) */
+        return ffhip_h264chroma_init_generic(c, 10);
     FFHipH264ChromaContext o = *c;
     o.put_h264_chroma_pixels_tab[0] = s_put_chroma0; o.put_h264_chroma_pixels_tab[1] = s_put_chroma1;
     o.put_h264_chroma_pixels_tab[2] = s_put_chroma2;
@@ -420,10 +399,12 @@ WEIGHT_FN(0) WEIGHT_FN(1) WEIGHT_FN(2) WEIGHT_FN(3)
 
 extern "C" int ff_h264dsp_weight_init_hip(FFHipH264WeightContext *c, int bit_depth)
 {
-    if (!c || bit_depth != 8)
+    if (!c || (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14))
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
+    if (bit_depth > 8)
+        return ffhip_h264weight_init_generic(c, bit_depth);
     FFHipH264WeightContext o = *c;
     o.weight_pixels_tab[0] = s_weight0; o.weight_pixels_tab[1] = s_weight1; o.weight_pixels_tab[2] = s_weight2;
     o.weight_pixels_tab[3] = s_weight3;

@@ -291,7 +291,7 @@ int ffhip_sws_yuv2packedX(FFHipSwsContext *c, const int16_t *lumFilter, const in
 /**
  * H264DSPContext subset (libavcodec/h264dsp.h:42-117), same member names and signatures, HOST
  * pointers.  ff_h264dsp_init_hip() below fills it the way ff_h264dsp_init_<arch>() would
- * (libavcodec/h264dsp.c:155-169).  8-bit only; other depths keep the C pointers.
+ * (libavcodec/h264dsp.c:155-169).
  */
 typedef struct FFHipH264DSPContext {
     void (*v_loop_filter_luma)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
@@ -318,13 +318,22 @@ typedef struct FFHipH264DSPContext {
     void (*chroma_dc_dequant_idct)(int16_t *block, int qmul);                        /* h264dsp.h:104 (4:2:0) */
     void (*add_pixels8_clear)(uint8_t *dst, int16_t *block, ptrdiff_t stride);      /* h264dsp.h:107 */
     void (*add_pixels4_clear)(uint8_t *dst, int16_t *block, ptrdiff_t stride);      /* h264dsp.h:108 */
+    /* the MBAFF forms of the vertical-edge filters (h264dsp.h:50-51,57-58,63-65,70-71): half as many lines per tc0 entry */
+    void (*h_loop_filter_luma_mbaff)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
+    void (*h_loop_filter_luma_mbaff_intra)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta);
+    void (*h_loop_filter_chroma_mbaff)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
+    void (*h_loop_filter_chroma_mbaff_intra)(uint8_t *pix, ptrdiff_t stride, int alpha, int beta);
 } FFHipH264DSPContext;
 /**
  * Fills every member, the way ff_h264dsp_init_<arch>() does at the end of ff_h264dsp_init() (libavcodec/h264dsp.c:155-169):
  * *c arrives holding the C functions (or NULL members) — the hip faces REMEMBER them, and a call that cannot run on the device
  * (a HIP error, an argument outside the staged range, or FFHIP_FAULT=1 in the environment: the test hook) is answered by the
  * displaced C function instead of returning with dst untouched; ffhip_shim_fallbacks() counts such calls.  The same holds for
- * every ff_*_init_hip() below.  Returns 0, or FFHIP_ENOSYS / FFHIP_EINVAL leaving *c untouched.  4:2:0 / 8-bit only.
+ * every ff_*_init_hip() below.  Returns 0, or FFHIP_ENOSYS / FFHIP_EINVAL leaving *c untouched.
+ * bit_depth 8 / 9 / 10 / 12 / 14 (every depth the reference instantiates, h264dsp.c:135-147: above 8 bits samples are uint16_t and
+ * coefficients int32_t, the depth is baked into the installed functions) and chroma_format_idc 0..2: for 4:2:2 the members the
+ * reference switches are the 4:2:2 ones (h_loop_filter_chroma422[_intra / _mbaff], idct_add8_422, chroma422_dc_dequant_idct,
+ * h264dsp.c:74-78,98-101,121-132).  4:4:4 (chroma_format_idc 3) uses the 4:2:0 table in the reference too.
  */
 int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int chroma_format_idc);
 /** Calls a host-pointer face answered through the displaced C pointer so far (and, when there was none to call, left undone:
@@ -416,6 +425,28 @@ int ffhip_h264_deblock_frames_dev(uint8_t *luma, size_t frame_pitch, int nframes
 int ffhip_h264_deblock_frames_chroma_dev(uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                                          const FFHipH264Edge *edges, void *stream);
 
+/**
+ * The batched faces above at ANY depth the reference instantiates (bit_depth 8 / 9 / 10 / 12 / 14), plus the members that exist
+ * only here: MBAFF and 4:2:2.  Above 8 bits samples are uint16_t and coefficients int32_t (libavcodec/bit_depth_template.c);
+ * strides and offsets stay in BYTES, coefficient pitches in coefficients.  Bit-exact restatement of the reference's templates
+ * (h264idct_template.c, h264addpx_template.c, h264dsp_template.c, h264qpel_template.c, h264chroma_template.c) with the depth as a
+ * kernel argument; the 8-bit kernels above remain the fast path of 8-bit 4:2:0 streams.
+ *   idct_add:     kinds FFHIP_H264_IDCT4 .. ADD_PIXELS8_CLEAR, n x (16 | 64) coefficients
+ *   idct_mb:      which 0 idct_add16, 1 idct8_add4, 2 idct_add16intra (one plane: dst2 unused), 3 idct_add8 (4:2:0: Cb = dst_base,
+ *                 Cr = dst2, 768 coefficients and a 15 x 8 cache per macroblock), 4 idct_add8_422
+ *   dc_dequant:   which 0 luma_dc_dequant_idct (input + m*in_pitch -> the DC positions of output + m*out_pitch), 1 chroma_dc_dequant_idct,
+ *                 2 chroma422_dc_dequant_idct (in place on output + block_offset[m])
+ *   loop_filter:  FFHipH264Edge.pad = lines per tc0 entry (0: the plain member: luma 4, chroma 2; MBAFF: luma 2, chroma 1;
+ *                 4:2:2 h_loop_filter_chroma422: 4, its MBAFF form 2); alpha / beta at the 8-bit scale, as the decoder's tables hold them
+ */
+int ffhip_h264_idct_add_batch_dev_hbd(int bit_depth, int kind, uint8_t *dst_base, ptrdiff_t stride, const int32_t *dst_offset, int16_t *blocks,
+                                      int n, void *stream);
+int ffhip_h264_idct_mb_batch_dev_hbd(int bit_depth, int which, uint8_t *dst_base, uint8_t *dst2, ptrdiff_t stride, const int32_t *mb_offset,
+                                     const int32_t *blockoffset, int16_t *blocks, const uint8_t *nnzc, int nmb, void *stream);
+int ffhip_h264_dc_dequant_batch_dev_hbd(int bit_depth, int which, int16_t *output, size_t out_pitch, const int16_t *input, size_t in_pitch,
+                                        const int32_t *block_offset, const int32_t *qmul, int n, void *stream);
+int ffhip_h264_loop_filter_batch_dev_hbd(int bit_depth, uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: h264qpel                                                                       */
 /* ------------------------------------------------------------------------------------------ */
@@ -485,6 +516,14 @@ typedef struct FFHipWeightBlock {
 } FFHipWeightBlock;
 int ffhip_h264_weight_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
                                 void *stream);
+/** qpel / chroma MC / weighted prediction at bit_depth 8 / 9 / 10 / 12 / 14 (16-bit samples above 8; offsets and stride in bytes):
+ *  h264qpel.c:87-103, h264chroma.c:38-52, h264dsp.c:102-109 at the depth. */
+int ffhip_h264_qpel_batch_dev_hbd(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
+                                  void *stream);
+int ffhip_h264_chroma_mc_batch_dev_hbd(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
+                                       void *stream);
+int ffhip_h264_weight_batch_dev_hbd(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
+                                    void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: caller-side batching for the H.264 macroblock loop           */

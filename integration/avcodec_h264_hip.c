@@ -31,7 +31,8 @@ void ff_h264_pred_init_c(H264PredContext *h, int codec_id, const int bit_depth, 
 #define H264DSP_MEMBERS(X) X(v_loop_filter_luma) X(h_loop_filter_luma) X(v_loop_filter_luma_intra) X(h_loop_filter_luma_intra) \
     X(v_loop_filter_chroma) X(h_loop_filter_chroma) X(v_loop_filter_chroma_intra) X(h_loop_filter_chroma_intra) \
     X(idct_add) X(idct8_add) X(idct_dc_add) X(idct8_dc_add) X(idct_add16) X(idct8_add4) X(idct_add16intra) X(idct_add8) \
-    X(luma_dc_dequant_idct) X(chroma_dc_dequant_idct) X(add_pixels8_clear) X(add_pixels4_clear)
+    X(luma_dc_dequant_idct) X(chroma_dc_dequant_idct) X(add_pixels8_clear) X(add_pixels4_clear) \
+    X(h_loop_filter_luma_mbaff) X(h_loop_filter_luma_mbaff_intra) X(h_loop_filter_chroma_mbaff) X(h_loop_filter_chroma_mbaff_intra)
 
 static av_cold void h264dsp_init_hip(H264DSPContext *c, const int bit_depth, const int chroma_format_idc)
 {

@@ -85,6 +85,21 @@ void ffo_h264_chroma_mc(int avg, int w, uint8_t *dst, const uint8_t *src, ptrdif
 void ffo_h264_weight(int w, uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset);
 void ffo_h264_biweight(int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
                        int weights, int offset);
+
+/* ---- the same tables at ANY bit depth (8 / 9 / 10 / 12 / 14) and the 4:2:2 / MBAFF members: ffo_h264_hbd.c.  Above 8 bits samples
+ *      are uint16_t, coefficients int32_t; strides stay in bytes.  kind of ffo_h264_idct_bd = FFHIP_H264_IDCT4 .. ADD_PIXELS8_CLEAR ---- */
+void ffo_h264_idct_bd(int bd, int kind, uint8_t *dst, int16_t *block, ptrdiff_t stride);
+void ffo_h264_idct_mb_bd(int bd, int which, uint8_t *dst, const int *bo, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc);
+void ffo_h264_idct_add8_bd(int bd, int is422, uint8_t **dest, const int *bo, int16_t *block, ptrdiff_t stride, const uint8_t *nnzc);
+void ffo_h264_luma_dc_dequant_bd(int bd, int16_t *output, int16_t *input, int qmul);
+void ffo_h264_chroma_dc_dequant_bd(int bd, int is422, int16_t *block, int qmul);
+/* kind: bit 0 = h_ (vertical edge), bit 1 = chroma, bit 2 = intra; inner = lines per tc0 entry (luma 4, MBAFF 2; chroma 2, MBAFF 1, 4:2:2 4, 4:2:2 MBAFF 2) */
+void ffo_h264_loop_filter_bd(int bd, int kind, int inner, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0);
+void ffo_h264_qpel_bd(int bd, int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
+void ffo_h264_chroma_mc_bd(int bd, int avg, int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y);
+void ffo_h264_weight_bd(int bd, int w, uint8_t *block, ptrdiff_t stride, int height, int log2_denom, int weight, int offset);
+void ffo_h264_biweight_bd(int bd, int w, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd,
+                          int weights, int offset);
 /* ---- AVFloatDSPContext vector operations (ffo_fdsp.c): op numbering = FFHIP_FDSP_* of include/ffhip.h ---- */
 #define FFO_FDSP_FMUL          0   /* dst = src0 * src1                                   */
 #define FFO_FDSP_FMAC_SCALAR   1   /* dst += src0 * mul                                   */

@@ -61,6 +61,10 @@ void ffref_h264_idct_add8(uint8_t **dst, const int *blockoffset, int16_t *block,
 void ffref_h264_loop_filter(int which, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
 /* avg: 0 put 1 avg; size_idx: 0 16x16 1 8x8 2 4x4; mcxy = x + 4*y */
 void ffref_h264_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
+/* re-initialises the h264dsp / h264qpel / h264chroma tables the calls above use at 8 / 9 / 10 / 12 / 14 bits */
+void ffref_h264_set_bit_depth(int bit_depth);
+void ffref_h264_loop_filter_variant(int kind, int variant, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0);
+void ffref_h264_chroma_dc_dequant_idct_422(int16_t *block, int qmul);
 /* H264ChromaContext.{put,avg}_h264_chroma_pixels_tab[idx]: idx 0 = 8 wide, 1 = 4, 2 = 2; x,y in 1/8 pel */
 void ffref_h264_chroma(int avg, int idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y);
 /* H264DSPContext.weight_h264_pixels_tab[idx] / biweight_h264_pixels_tab[idx]: idx 0 = 16 wide, 1 = 8, 2 = 4, 3 = 2 */

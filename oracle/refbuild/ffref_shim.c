@@ -390,6 +390,33 @@ void ffref_h264_biweight(int idx, uint8_t *dst, uint8_t *src, ptrdiff_t stride, 
     dsp_init();
     h264.biweight_pixels_tab[idx](dst, src, stride, height, log2_denom, weightd, weights, offset);
 }
+/* the depth the ffref_h264_* calls run at: the three H.264 tables are re-initialised the way the decoder does per SPS
+ * (ff_h264dsp_init(&h->h264dsp, sps->bit_depth_luma, sps->chroma_format_idc) & co, libavcodec/h264_slice.c); pixels are uint16_t and
+ * coefficients int32_t above 8 bits.  bit_depth 8 / 9 / 10 / 12 / 14 are the depths the reference instantiates (h264dsp.c:135-147) */
+void ffref_h264_set_bit_depth(int bit_depth)
+{
+    dsp_init();
+    ff_h264dsp_init(&h264, bit_depth, 1);
+    ff_h264dsp_init(&h264_422, bit_depth, 2);
+    ff_h264qpel_init(&qpel, bit_depth);
+    ff_h264chroma_init(&chroma, bit_depth);
+}
+/* the members ffref_h264_loop_filter() does not reach: kind as there (bit 0 h_, bit 1 chroma, bit 2 intra), variant 1 = MBAFF
+ * (h_ only), 2 = 4:2:2 (h_ chroma only), 3 = 4:2:2 MBAFF */
+void ffref_h264_loop_filter_variant(int kind, int variant, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0)
+{
+    dsp_init();
+    const H264DSPContext *c = variant >= 2 ? &h264_422 : &h264;
+    const int mbaff = variant & 1;
+    switch (kind) {
+    case 1: (mbaff ? c->h_loop_filter_luma_mbaff : c->h_loop_filter_luma)(pix, stride, alpha, beta, tc0); break;
+    case 3: (mbaff ? c->h_loop_filter_chroma_mbaff : c->h_loop_filter_chroma)(pix, stride, alpha, beta, tc0); break;
+    case 5: (mbaff ? c->h_loop_filter_luma_mbaff_intra : c->h_loop_filter_luma_intra)(pix, stride, alpha, beta); break;
+    case 7: (mbaff ? c->h_loop_filter_chroma_mbaff_intra : c->h_loop_filter_chroma_intra)(pix, stride, alpha, beta); break;
+    default: ffref_h264_loop_filter(kind, pix, stride, alpha, beta, tc0); break;
+    }
+}
+void ffref_h264_chroma_dc_dequant_idct_422(int16_t *block, int qmul) { dsp_init(); h264_422.chroma_dc_dequant_idct(block, qmul); }
 void ffref_fdsp(int op, float *dst, const float *src0, const float *src1, const float *src2, float mul, int len)
 {
     static AVFloatDSPContext *f;

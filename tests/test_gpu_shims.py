@@ -27,7 +27,9 @@ class H264DSP(C.Structure):   # member order of FFHipH264DSPContext (include/ffh
                 ("v_loop_filter_chroma_intra", LFI), ("h_loop_filter_chroma_intra", LFI), ("idct_add", IDCT),
                 ("idct8_add", IDCT), ("idct_dc_add", IDCT), ("idct8_dc_add", IDCT), ("idct_add16", IDCTM),
                 ("idct8_add4", IDCTM), ("idct_add16intra", IDCTM), ("idct_add8", IDCT8P), ("luma_dc_dequant_idct", LUMADC),
-                ("chroma_dc_dequant_idct", CHROMADC), ("add_pixels8_clear", IDCT), ("add_pixels4_clear", IDCT)]
+                ("chroma_dc_dequant_idct", CHROMADC), ("add_pixels8_clear", IDCT), ("add_pixels4_clear", IDCT),
+                ("h_loop_filter_luma_mbaff", LF), ("h_loop_filter_luma_mbaff_intra", LFI), ("h_loop_filter_chroma_mbaff", LF),
+                ("h_loop_filter_chroma_mbaff_intra", LFI)]
 
 
 class H264Qpel(C.Structure):
@@ -62,7 +64,7 @@ def test_h264dsp_init_hip():
     L = _lib()
     O = ffi.oracle()
     c = H264DSP()
-    assert L.ff_h264dsp_init_hip(C.byref(c), 10, 1) < 0          # only 8-bit is on the hip path
+    assert L.ff_h264dsp_init_hip(C.byref(c), 11, 1) < 0          # 8 / 9 / 10 / 12 / 14 are the depths H.264 defines (h264dsp.c:135-147)
     assert L.ff_h264dsp_init_hip(C.byref(c), 8, 1) == 0
     rng = np.random.default_rng(1)
     stride = 48
@@ -162,7 +164,8 @@ def test_h264dsp_dc_dequant_add8_add_pixels():
     L = _lib()
     c = H264DSP()
     assert L.ff_h264dsp_init_hip(C.byref(c), 8, 1) == 0
-    assert L.ff_h264dsp_init_hip(C.byref(H264DSP()), 8, 2) < 0   # 4:2:2 keeps the C pointers (idct_add8_422, chroma422_dc)
+    assert L.ff_h264dsp_init_hip(C.byref(H264DSP()), 8, 2) == 0  # 4:2:2: the chroma members come from the depth-generic faces
+    assert L.ff_h264dsp_init_hip(C.byref(H264DSP()), 8, 4) < 0
     before = L.ffhip_shim_fallbacks()
     _h264_new_members(c, ffi.oracle(), np.random.default_rng(21), _eq)
     assert L.ffhip_shim_fallbacks() == before                  # everything ran on the device
