@@ -16,6 +16,9 @@ void ffhip_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)))
 int  ffhip_host_init_filter(int16_t **out_filter, int32_t **out_pos, int xInc, int srcW, int dstW, int one,
                             int scaler, int flags);
 void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange);
+/* the YUV formats above 8 bits: sample depth, layout (0 planar, samples in the low bits; 1 semi-planar, samples in the high bits),
+ * chroma subsampling shifts.  Returns 0 for any other format (outputs untouched). */
+int  ffhip_pixfmt_hbd(int fmt, int *depth, int *layout, int *hsub, int *vsub);
 
 #ifdef __cplusplus
 }

@@ -347,14 +347,58 @@ struct FFHipSwsHostTables {
     int unscaled_yuv2rgb;
 };
 
+/* av_pix_fmt_desc_get() of the deeper YUV formats on this path: comp[0].depth, planar / semi-planar, log2_chroma_w / _h */
+int ffhip_pixfmt_hbd(int fmt, int *depth, int *layout, int *hsub, int *vsub)
+{
+    int d, l = 0, hs = 1, vs = 1;
+    switch (fmt) {
+    case FFHIP_PIX_FMT_YUV420P9LE:  d = 9; break;
+    case FFHIP_PIX_FMT_YUV420P10LE: d = 10; break;
+    case FFHIP_PIX_FMT_YUV420P12LE: d = 12; break;
+    case FFHIP_PIX_FMT_YUV420P14LE: d = 14; break;
+    case FFHIP_PIX_FMT_YUV420P16LE: d = 16; break;
+    case FFHIP_PIX_FMT_YUV422P9LE:  d = 9; vs = 0; break;
+    case FFHIP_PIX_FMT_YUV422P10LE: d = 10; vs = 0; break;
+    case FFHIP_PIX_FMT_YUV422P12LE: d = 12; vs = 0; break;
+    case FFHIP_PIX_FMT_YUV422P14LE: d = 14; vs = 0; break;
+    case FFHIP_PIX_FMT_YUV422P16LE: d = 16; vs = 0; break;
+    case FFHIP_PIX_FMT_YUV444P9LE:  d = 9; hs = vs = 0; break;
+    case FFHIP_PIX_FMT_YUV444P10LE: d = 10; hs = vs = 0; break;
+    case FFHIP_PIX_FMT_YUV444P12LE: d = 12; hs = vs = 0; break;
+    case FFHIP_PIX_FMT_YUV444P14LE: d = 14; hs = vs = 0; break;
+    case FFHIP_PIX_FMT_YUV444P16LE: d = 16; hs = vs = 0; break;
+    case FFHIP_PIX_FMT_P010LE: d = 10; l = 1; break;
+    case FFHIP_PIX_FMT_P012LE: d = 12; l = 1; break;
+    case FFHIP_PIX_FMT_P016LE: d = 16; l = 1; break;
+    default: return 0;
+    }
+    if (depth) *depth = d;
+    if (layout) *layout = l;
+    if (hsub) *hsub = hs;
+    if (vsub) *vsub = vs;
+    return 1;
+}
+
 static int is_yuv(int fmt)
 {
     return fmt == FFHIP_PIX_FMT_YUV420P || fmt == FFHIP_PIX_FMT_NV12 || fmt == FFHIP_PIX_FMT_NV21 || fmt == FFHIP_PIX_FMT_YUV422P ||
-           fmt == FFHIP_PIX_FMT_YUV444P;
+           fmt == FFHIP_PIX_FMT_YUV444P || ffhip_pixfmt_hbd(fmt, NULL, NULL, NULL, NULL);
 }
 /* av_pix_fmt_get_chroma_sub_sample() of the YUV formats on this path (libswscale/utils.c:1265-1266) */
-static int chroma_hsub(int fmt) { return fmt == FFHIP_PIX_FMT_YUV444P ? 0 : 1; }
-static int chroma_vsub(int fmt) { return fmt == FFHIP_PIX_FMT_YUV444P || fmt == FFHIP_PIX_FMT_YUV422P ? 0 : 1; }
+static int chroma_hsub(int fmt)
+{
+    int hs;
+    if (ffhip_pixfmt_hbd(fmt, NULL, NULL, &hs, NULL))
+        return hs;
+    return fmt == FFHIP_PIX_FMT_YUV444P ? 0 : 1;
+}
+static int chroma_vsub(int fmt)
+{
+    int vs;
+    if (ffhip_pixfmt_hbd(fmt, NULL, NULL, NULL, &vs))
+        return vs;
+    return fmt == FFHIP_PIX_FMT_YUV444P || fmt == FFHIP_PIX_FMT_YUV422P ? 0 : 1;
+}
 static int is_rgb(int fmt)
 {
     return fmt == FFHIP_PIX_FMT_RGB24 || fmt == FFHIP_PIX_FMT_BGR24 || (fmt >= FFHIP_PIX_FMT_ARGB && fmt <= FFHIP_PIX_FMT_BGRA);
@@ -396,6 +440,18 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         ffhip_set_error("ffhip_sws: unsupported conversion %d -> %d (%dx%d -> %dx%d)", srcFormat, dstFormat,
                         srcW, srcH, dstW, dstH);
         return NULL;
+    }
+    if (ffhip_pixfmt_hbd(srcFormat, NULL, NULL, NULL, NULL) || ffhip_pixfmt_hbd(dstFormat, NULL, NULL, NULL, NULL)) {
+        if (is_rgb(dstFormat)) {
+            ffhip_set_error("ffhip_sws: sources above 8 bits to packed RGB are not on the hip path");
+            return NULL;
+        }
+        if (srcW == dstW && srcH == dstH) {
+            /* equal sizes take the reference's special converters (planarCopyWrapper, planarToP01xWrapper, ...: swscale_unscaled.c):
+             * shifts and dithers of their own, not the scaler's arithmetic */
+            ffhip_set_error("ffhip_sws: equal-size conversions above 8 bits are not on the hip path (the scaler is)");
+            return NULL;
+        }
     }
     h = calloc(1, sizeof(*h));
     if (!h)

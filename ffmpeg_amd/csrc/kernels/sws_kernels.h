@@ -227,6 +227,24 @@ int  ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32
 void ffhip_lw_plan_job(FFHipLwJob *j);
 int  ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream);
 
+/* the scaler above 8 bits (sws_scale16.hip): one record per output plane (an interleaved UV plane is two records, one per channel) */
+struct FFHipScale16Plane {
+    const uint8_t *src;      /* source plane of this channel */
+    uint8_t *dst;
+    ptrdiff_t src_stride, dst_stride;
+    size_t src_fp, dst_fp;   /* frame pitches */
+    int sdepth, sstep, schan, smsb;   /* source samples: depth, sample step (2: interleaved pair), channel inside the pair, samples in the high bits */
+    int ddepth, dstep, dchan, dmsb;
+    int dstW, dstH;
+    int dither, dither_off;  /* 8-bit target fed from a deeper source: ff_dither_8x8_128[y & 7][(x + dither_off) & 7] */
+    FFHipDevFilter h, v;
+};
+struct FFHipScale16Args {
+    FFHipScale16Plane pl[3];
+    int nplanes, max_rows;
+};
+int ffhip_launch_scale16(const FFHipScale16Args &a, int nframes, hipStream_t stream);
+
 /* per-line parity faces */
 int ffhip_launch_hscale8to15(int16_t *dst, int dstW, ptrdiff_t dstPitch, const uint8_t *src, ptrdiff_t srcPitch,
                              int nlines, const int16_t *filter, const int32_t *pos, int fs, hipStream_t stream);

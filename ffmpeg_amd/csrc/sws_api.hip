@@ -18,6 +18,7 @@
 
 struct FFHipSwsContext {
     int device = 0; /* the banks live on this device; every call of the context makes it current for its duration */
+    int hbd = 0;    /* a side above 8 bits: the 16-bit scaler (sws_scale16.hip) serves the context, none of the 8-bit fast paths apply */
     FFHipSwsTables t;
     std::vector<int16_t> f[4];
     std::vector<int32_t> p[4];
@@ -69,13 +70,23 @@ static bool em_forced()
     const char *em = FFHIP_KNOB("FFHIP_SWS_MFMA");
     return em && em[0] == '1';
 }
+static bool fmt_hbd(int f) { return ffhip_pixfmt_hbd(f, nullptr, nullptr, nullptr, nullptr) != 0; }
 static bool fmt_yuv(int f)
 {
-    return f == FFHIP_PIX_FMT_YUV420P || f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21 || f == FFHIP_PIX_FMT_YUV422P || f == FFHIP_PIX_FMT_YUV444P;
+    return f == FFHIP_PIX_FMT_YUV420P || f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21 || f == FFHIP_PIX_FMT_YUV422P || f == FFHIP_PIX_FMT_YUV444P ||
+           fmt_hbd(f);
 }
 /* chroma subsampling of the YUV formats on this path (av_pix_fmt_get_chroma_sub_sample) */
-static int fmt_hsub(int f) { return f == FFHIP_PIX_FMT_YUV444P ? 0 : 1; }
-static int fmt_vsub(int f) { return f == FFHIP_PIX_FMT_YUV444P || f == FFHIP_PIX_FMT_YUV422P ? 0 : 1; }
+static int fmt_hsub(int f)
+{
+    int hs;
+    return ffhip_pixfmt_hbd(f, nullptr, nullptr, &hs, nullptr) ? hs : f == FFHIP_PIX_FMT_YUV444P ? 0 : 1;
+}
+static int fmt_vsub(int f)
+{
+    int vs;
+    return ffhip_pixfmt_hbd(f, nullptr, nullptr, nullptr, &vs) ? vs : f == FFHIP_PIX_FMT_YUV444P || f == FFHIP_PIX_FMT_YUV422P ? 0 : 1;
+}
 static bool fmt_nv(int f) { return f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; }
 /* packed layout number of an RGB target (the kernels' `layout` / `bgr` argument): 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
 static int rgb_layout(int f)
@@ -331,6 +342,23 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
     if (c->unscaled_yuv2rgb)
         return c;
 
+    if (fmt_hbd(t->srcFormat) || fmt_hbd(t->dstFormat)) {
+        /* above 8 bits on either side: the 16-bit scaler takes the banks as they are */
+        if (fmt_rgb(t->dstFormat) || (t->srcW == t->dstW && t->srcH == t->dstH) || t->srcFormat == FFHIP_PIX_FMT_NV21 ||
+            t->dstFormat == FFHIP_PIX_FMT_NV21) {
+            ffhip_set_error("ffhip_sws: above 8 bits the hip path scales between the YUV formats only (no packed RGB, no equal-size conversion, no NV21 mix)");
+            ffhip_sws_freeContext(c);
+            return nullptr;
+        }
+        if (c->d[1].n != -((-t->dstW) >> fmt_hsub(t->dstFormat)) || c->d[3].n != -((-t->dstH) >> fmt_vsub(t->dstFormat)) ||
+            c->d[0].n != t->dstW || c->d[2].n != t->dstH) {
+            ffhip_set_error("ffhip_sws: the banks do not match the target's plane sizes");
+            ffhip_sws_freeContext(c);
+            return nullptr;
+        }
+        c->hbd = 1;
+        return c;
+    }
     int r = 0;
     if (fmt_rgb(t->dstFormat)) {
         FFHipScaleRgbArgs &a = c->rgb;
@@ -576,6 +604,41 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
     delete c;
 }
 
+/* a context with a side above 8 bits: luma, then the two chroma channels (planes of their own or the halves of an interleaved pair) */
+static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
+                   void *const dst[4], const int dstStride[4], const size_t dstFramePitch[4], hipStream_t stream)
+{
+    const FFHipSwsTables &t = c->t;
+    int sd = 8, sl = fmt_nv(t.srcFormat) ? 2 : 0, dd = 8, dl = fmt_nv(t.dstFormat) ? 2 : 0;
+    (void)ffhip_pixfmt_hbd(t.srcFormat, &sd, &sl, nullptr, nullptr);
+    (void)ffhip_pixfmt_hbd(t.dstFormat, &dd, &dl, nullptr, nullptr);
+    const int ssz = sd > 8 ? 2 : 1, dsz = dd > 8 ? 2 : 1;
+    for (int pl = 0; pl < (sl ? 2 : 3); pl++)
+        if (!src[pl] || (srcStride[pl] % ssz) || (srcFramePitch[pl] % ssz) || ((uintptr_t)src[pl] % ssz))
+            return FFHIP_EINVAL;
+    for (int pl = 0; pl < (dl ? 2 : 3); pl++)
+        if (!dst[pl] || (dstStride[pl] % dsz) || (dstFramePitch[pl] % dsz) || ((uintptr_t)dst[pl] % dsz))
+            return FFHIP_EINVAL;
+    FFHipScale16Args a;
+    memset(&a, 0, sizeof(a));
+    a.nplanes = 3;
+    for (int pl = 0; pl < 3; pl++) {
+        FFHipScale16Plane &p = a.pl[pl];
+        const int sp = pl == 0 ? 0 : sl ? 1 : pl, dp = pl == 0 ? 0 : dl ? 1 : pl;   /* plane index on either side */
+        p.src = static_cast<const uint8_t *>(src[sp]);
+        p.dst = static_cast<uint8_t *>(dst[dp]);
+        p.src_stride = srcStride[sp]; p.dst_stride = dstStride[dp];
+        p.src_fp = srcFramePitch[sp]; p.dst_fp = dstFramePitch[dp];
+        p.sdepth = sd; p.smsb = sl == 1; p.sstep = pl && sl ? 2 : 1; p.schan = pl && sl ? pl - 1 : 0;
+        p.ddepth = dd; p.dmsb = dl == 1; p.dstep = pl && dl ? 2 : 1; p.dchan = pl && dl ? pl - 1 : 0;
+        p.h = c->d[pl ? 1 : 0]; p.v = c->d[pl ? 3 : 2];
+        p.dstW = p.h.n; p.dstH = p.v.n;
+        p.dither = dd == 8 && sd > 8;       /* swscale.c:291: should_dither = isNBPS(src) || is16BPS(src) */
+        p.dither_off = pl == 2 ? 3 : 0;     /* vscale.c: the V plane reads the dither row three entries on; yuv2nv12cX_c: (i + 3) & 7 */
+    }
+    return ffhip_launch_scale16(a, nframes, stream);
+}
+
 extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4],
                                          const int srcStride[4], const size_t srcFramePitch[4], void *const dst[4],
                                          const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
@@ -586,6 +649,8 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
     FFHipDeviceGuard dg(c->device);
     const FFHipSwsTables &t = c->t;
     const uint8_t *s0 = (const uint8_t *)src[0], *s1 = (const uint8_t *)src[1], *s2 = (const uint8_t *)src[2];
+    if (c->hbd)
+        return scale16(c, nframes, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream);
 
     if (c->unscaled_yuv2rgb) {
         FFHipYuv2RgbArgs a;
@@ -924,8 +989,10 @@ static int plane_list(int fmt, int w, int h, PlaneDesc out[3])
 {
     if (fmt_yuv(fmt)) {
         const int cw = -((-w) >> fmt_hsub(fmt)), chh = -((-h) >> fmt_vsub(fmt));
-        if (fmt_nv(fmt)) { out[0] = { w, h }; out[1] = { 2 * cw, chh }; return 2; }
-        out[0] = { w, h }; out[1] = { cw, chh }; out[2] = { cw, chh };
+        int depth = 8, layout = 0;
+        const int bs = ffhip_pixfmt_hbd(fmt, &depth, &layout, nullptr, nullptr) ? 2 : 1; /* bytes per sample */
+        if (fmt_nv(fmt) || layout == 1) { out[0] = { bs * w, h }; out[1] = { bs * 2 * cw, chh }; return 2; }
+        out[0] = { bs * w, h }; out[1] = { bs * cw, chh }; out[2] = { bs * cw, chh };
         return 3;
     }
     out[0] = { (rgb_layout(fmt) < 2 ? 3 : 4) * w, h };

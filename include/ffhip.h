@@ -124,6 +124,30 @@ int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t 
                                     * libswscale/utils.c:1019-1050); a J format on one side only, or J to packed RGB, is not on the hip path */
 #define FFHIP_PIX_FMT_YUVJ422P 13
 #define FFHIP_PIX_FMT_YUVJ444P 14
+/* Above 8 bits (== AV_PIX_FMT_*; little-endian): planar yuv4xxp at 9 / 10 / 12 / 14 / 16 bits with the samples in the low bits, and
+ * the semi-planar P010 / P012 / P016 with the samples in the HIGH bits.  Sources and targets of SCALED contexts on the legacy path
+ * (hScale16To15_c / hScale16To19_c / hScale8To19_c, yuv2plane1 / yuv2planeX at the target depth, the P01x readers and writers:
+ * libswscale/swscale.c:69-160, output.c:150-360, input.c p010LEToY_c / p010LEToUV_c), freely mixed with the 8-bit YUV formats above
+ * (an 8-bit target fed from a deeper source is dithered with ff_dither_8x8_128, as swscale does: swscale.c:291,519-522).  Equal-size
+ * conversions take the reference's special converters (swscale_unscaled.c) and are not on the hip path; nor are packed RGB targets. */
+#define FFHIP_PIX_FMT_YUV420P16LE 45
+#define FFHIP_PIX_FMT_YUV422P16LE 47
+#define FFHIP_PIX_FMT_YUV444P16LE 49
+#define FFHIP_PIX_FMT_YUV420P9LE  60
+#define FFHIP_PIX_FMT_YUV420P10LE 62
+#define FFHIP_PIX_FMT_YUV422P10LE 64
+#define FFHIP_PIX_FMT_YUV444P9LE  66
+#define FFHIP_PIX_FMT_YUV444P10LE 68
+#define FFHIP_PIX_FMT_YUV422P9LE  70
+#define FFHIP_PIX_FMT_YUV420P12LE 123
+#define FFHIP_PIX_FMT_YUV420P14LE 125
+#define FFHIP_PIX_FMT_YUV422P12LE 127
+#define FFHIP_PIX_FMT_YUV422P14LE 129
+#define FFHIP_PIX_FMT_YUV444P12LE 131
+#define FFHIP_PIX_FMT_YUV444P14LE 133
+#define FFHIP_PIX_FMT_P010LE      158
+#define FFHIP_PIX_FMT_P016LE      169
+#define FFHIP_PIX_FMT_P012LE      209
 #define FFHIP_PIX_FMT_NV12    23
 #define FFHIP_PIX_FMT_NV21    24
 #define FFHIP_PIX_FMT_ARGB    25   /* packed 8:8:8:8; alpha = 255 (the sources on this path carry none) */

@@ -63,6 +63,11 @@ void ffo_yuv2rgb_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *c
                    int uvalpha, int layout);
 int  ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], const int srcStride[3],
                          uint8_t *const dst[3], const int dstStride[3]);
+/* the same above 8 bits (ffo_sws_hbd.c): a format is (depth, layout): layout 0 planar LE samples in the low bits (8-bit planar when
+ * depth == 8), 1 semi-planar with the samples in the high bits (p010le / p012le / p016le), 2 semi-planar 8-bit (nv12).  Scaled
+ * contexts only; planes as the format has them (planar Y, U, V; semi-planar Y, UV). */
+int  ffo_sws_scale_frame_hbd(const FfoSwsTables *t, int sdepth, int slayout, int ddepth, int dlayout, const uint8_t *const src[3],
+                             const int srcStride[3], uint8_t *const dst[3], const int dstStride[3]);
 
 /* ---- h264dsp / h264qpel (ffo_h264.c), 8-bit ---- */
 void ffo_h264_idct_add(uint8_t *dst, int16_t *block, ptrdiff_t stride);

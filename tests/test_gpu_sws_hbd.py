@@ -1,0 +1,83 @@
+"""GPU parity of the scaler above 8 bits (k_sws_scale16 through ffhip_sws_scale_batch_dev and the host-pointer ffhip_sws_scale): ==
+the oracle (oracle/ffo_sws_hbd.c, pinned to the reference's sws_scale() on the real pixel formats by
+tests/test_oracle_vs_ref_sws_hbd.py), bit for bit, on every format pair / scaler / ratio of that test, several frames per launch,
+plus a 1080p -> 4K p010 frame."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+from ffi import u8p
+from test_oracle_vs_ref_sws_hbd import CASES, FMT, make_frame, planes_of, oracle_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _oracle_frame(t, sname, dname, src, dw, dh, pad):
+    O = ffi.oracle()
+    O.ffo_sws_scale_frame_hbd.argtypes = [C.POINTER(ffi.OSwsTables), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(C.c_int),
+                                          C.POINTER(u8p), C.POINTER(C.c_int)]
+    want = make_frame(dname, dw, dh, None, pad=pad)
+    sp, ss = planes_of(src)
+    wp, ws = planes_of(want)
+    assert O.ffo_sws_scale_frame_hbd(C.byref(t), FMT[sname][1], FMT[sname][2], FMT[dname][1], FMT[dname][2], sp, ss, wp, ws) == 0
+    return want
+
+
+def _run(case, nframes=3, pad=8):
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    sname, sw, sh, dname, dw, dh, flags = case
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    ht, t = oracle_tables(sname, sw, sh, dname, dw, dh, flags)
+    frames = [make_frame(sname, sw, sh, rng, pad=pad) for _ in range(nframes)]
+    wants = [_oracle_frame(t, sname, dname, f, dw, dh, pad) for f in frames]
+    ctx = S.SwsContext(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags)
+    nsp, ndp = len(frames[0]), len(wants[0])
+    src = [torch.from_numpy(np.stack([f[i] for f in frames]).view(np.uint8)).cuda() for i in range(nsp)]
+    dst = [torch.zeros((nframes,) + tuple(wants[0][i].view(np.uint8).shape), dtype=torch.uint8, device="cuda") for i in range(ndp)]
+    ctx.scale_batch(src, dst)
+    torch.cuda.synchronize()
+    for i in range(ndp):
+        got = dst[i].cpu().numpy()
+        for f in range(nframes):
+            w = wants[f][i].view(np.uint8)
+            vis = (wants[f][i].shape[1] - pad) * wants[f][i].itemsize       # the padding columns are not the scaler's to write
+            assert np.array_equal(got[f][:, :vis], w[:, :vis]), "frame %d plane %d: %d bytes differ" % (f, i, (got[f][:, :vis] != w[:, :vis]).sum())
+            assert not got[f][:, vis:].any()
+    # the host-pointer face (sws_scale() shape) on the first frame
+    out = make_frame(dname, dw, dh, None, pad=pad)
+    ctx.scale([p.view(np.uint8) for p in frames[0]], [p.view(np.uint8) for p in out])
+    for i in range(ndp):
+        vis = out[i].shape[1] - pad
+        assert np.array_equal(out[i][:, :vis], wants[0][i][:, :vis]), i
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_scale_above_8_bits(case):
+    _run(case)
+
+
+def test_p010_1080p_to_4k():
+    _run(("p010le", 1920, 1080, "p010le", 3840, 2160, ffi.SWS_BICUBIC), nframes=1, pad=0)
+
+
+def test_yuv420p10_1080p_to_4k_and_back():
+    _run(("yuv420p10le", 1920, 1080, "yuv420p10le", 3840, 2160, ffi.SWS_BICUBIC), nframes=1, pad=0)
+    _run(("yuv420p10le", 3840, 2160, "yuv420p", 1920, 1080, ffi.SWS_BICUBIC), nframes=1, pad=0)
+
+
+def test_what_is_not_on_the_path_is_refused():
+    from ffmpeg_amd import swscale as S
+    _torch()
+    for args in ((64, 36, 62, 64, 36, 158), (64, 36, 62, 128, 72, 2)):    # equal-size p010 conversion; 10-bit to rgb24
+        with pytest.raises(ValueError):
+            S.SwsContext(*args)
