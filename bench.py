@@ -222,6 +222,10 @@ def extras(torch, dev):
     sws_case("sws_yuv420p_1080p_to_rgb24_4k_bicubic", 0, 1920, 1080, 2, 3840, 2160, 32)
     # 4:4:4 planar through the exact-2x kernel: three planes of the luma's size (AV_PIX_FMT_YUV444P = 5)
     sws_case("sws_yuv444p_1080p_to_4k_bicubic", 5, 1920, 1080, 5, 3840, 2160, 32)
+    # above 8 bits: p010 / yuv420p10 1080p -> 4K through the 16-bit scaler (3.75 B per output pixel; random 16-bit words are valid samples
+    # for the arithmetic: the planar reader takes the word as it is, the P010 reader its high 10 bits)
+    sws_case("sws_p010_1080p_to_4k_bicubic", 158, 1920, 1080, 158, 3840, 2160, 16)
+    sws_case("sws_yuv420p10_1080p_to_4k_bicubic", 62, 1920, 1080, 62, 3840, 2160, 16)
     # H.264 8x8 IDCT + add over 32 4K luma planes (129,600 blocks each, 384 B/block)
     planes, stride = 32, 3840
     nb = planes * 129600

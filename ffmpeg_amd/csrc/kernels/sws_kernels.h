@@ -242,6 +242,8 @@ struct FFHipScale16Plane {
 struct FFHipScale16Args {
     FFHipScale16Plane pl[3];
     int nplanes, max_rows;
+    int sw_pitch; /* samples per staged source row in LDS (>= the widest 64-column reach, even) */
+    int staged;   /* every 64-column run of every plane's horizontal bank reaches <= 320 source columns: footprints through LDS */
 };
 int ffhip_launch_scale16(const FFHipScale16Args &a, int nframes, hipStream_t stream);
 

@@ -19,8 +19,9 @@
 #include "sws_kernels.h"
 
 #define S16_TW 64
-#define S16_TH 16
-#define S16_MAXROWS 160 /* source rows a tile may reach: (TH - 1) * step + taps; larger reaches run in row chunks of the tile */
+#define S16_TH 32
+#define S16_MAXROWS 96  /* source rows of one chunk of a tile: (rows - 1) * step + taps; larger reaches run in several chunks */
+#define S16_SW 320      /* source columns the staged form holds per row: 64 windows at up to ~4.5 : 1 */
 
 __constant__ uint8_t s16_dither[8][8] = { /* ff_dither_8x8_128, libswscale/swscale.c:42-52 */
     { 36, 68, 60, 92, 34, 66, 58, 90 },  { 100, 4, 124, 28, 98, 2, 122, 26 }, { 52, 84, 44, 76, 50, 82, 42, 74 },
@@ -38,22 +39,48 @@ __device__ __forceinline__ int s16_src(const uint8_t *row, const FFHipScale16Pla
 
 __device__ __forceinline__ int s16_clipu(int v, int bits) { return min(max(v, 0), (1 << bits) - 1); }
 
+/* STAGED: the tile's source footprint goes through LDS first (coalesced loads, samples normalised to their values once: the P01x
+ * shift, the 8-bit widening, the de-interleave), the horizontal pass then reads LDS; a lane keeps its column's coefficients in
+ * registers and runs down the rows.  !STAGED: horizontal windows wider than the LDS tile (steep down-scaling): taps from global memory. */
+/* the vertical sum over the bank's taps: unrolled when the tap count is a template argument */
+#define S16_VSUM(STMT)                                           \
+    do {                                                         \
+        if (VFS) {                                               \
+            _Pragma("unroll") for (int j = 0; j < VFS; j++) { STMT; } \
+        } else {                                                 \
+            for (int j = 0; j < vfs; j++) { STMT; }              \
+        }                                                        \
+    } while (0)
+
+template <bool STAGED, int HFS, int VFS> /* HFS / VFS: the banks' tap counts when they are 4 / 8 (unrolled), 0 = any */
 __global__ __launch_bounds__(256) void k_sws_scale16(FFHipScale16Args a)
 {
-    extern __shared__ int32_t hs[]; /* [rows][S16_TW] */
+    extern __shared__ int32_t hs[]; /* [max_rows][S16_TW] int32, then (STAGED) [max_rows][S16_SW] uint16 */
     const FFHipScale16Plane p = a.pl[blockIdx.z % a.nplanes];
     const int f = blockIdx.z / a.nplanes;
     const int x0 = blockIdx.x * S16_TW, y0 = blockIdx.y * S16_TH;
     if (x0 >= p.dstW || y0 >= p.dstH)
         return;
+    uint16_t *const srcT = reinterpret_cast<uint16_t *>(hs + a.max_rows * S16_TW);
+    const int SWP = a.sw_pitch; /* LDS pitch of a staged source row, in samples */
     const int tw = min(S16_TW, p.dstW - x0), th = min(S16_TH, p.dstH - y0);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lx = tid & (S16_TW - 1), lg = tid / S16_TW; /* column of the tile, row group 0..3 */
     const uint8_t *src = p.src + (size_t)f * p.src_fp;
     uint8_t *dst = p.dst + (size_t)f * p.dst_fp;
     const int wide = p.ddepth == 16;
     const int sh = p.sdepth == 8 ? (wide ? 3 : 7) : (wide ? p.sdepth - 5 : p.sdepth - 1);
     const int lim = wide ? (1 << 19) - 1 : (1 << 15) - 1;
-    const int hfs = p.h.size, vfs = p.v.size;
+    const int hfs = HFS ? HFS : p.h.size, vfs = VFS ? VFS : p.v.size;
+    const int c0 = p.h.pos[x0], sw = p.h.pos[x0 + tw - 1] + hfs - c0; /* source columns the tile's windows reach (positions ascend) */
+    /* this lane's window and coefficients (up to 16 taps in registers; longer banks read theirs from memory) */
+    const bool colv = lx < tw;
+    const int sp = colv ? p.h.pos[x0 + lx] - c0 : 0;
+    const int16_t *hf = p.h.filter + (size_t)(x0 + (colv ? lx : 0)) * hfs;
+    constexpr int HC = HFS ? HFS : 16;
+    int hc[HC];
+#pragma unroll
+    for (int j = 0; j < HC; j++)
+        hc[j] = j < hfs ? (int)hf[j] : 0;
     /* output rows in chunks whose source reach fits the LDS rows */
     for (int yc = 0; yc < th;) {
         const int r0 = p.v.pos[y0 + yc];
@@ -61,65 +88,80 @@ __global__ __launch_bounds__(256) void k_sws_scale16(FFHipScale16Args a)
         while (yn < th && p.v.pos[y0 + yn] + vfs - r0 <= a.max_rows)
             yn++;
         const int nrows = p.v.pos[y0 + yn - 1] + vfs - r0;
-        /* stage 1 */
-        for (int it = tid; it < nrows * S16_TW; it += 256) {
-            const int r = it / S16_TW, x = it % S16_TW;
-            if (x < tw) {
-                const uint8_t *row = src + (ptrdiff_t)(r0 + r) * p.src_stride;
-                const int sp = p.h.pos[x0 + x];
-                const int16_t *hf = p.h.filter + (size_t)(x0 + x) * hfs;
+        if (STAGED) {
+            /* stage 0: rows r0 .. r0 + nrows, columns c0 .. c0 + sw as sample values */
+            for (int it = tid; it < nrows * sw; it += 256) {
+                const int r = it / sw, c = it - r * sw;
+                srcT[r * SWP + c] = (uint16_t)s16_src(src + (ptrdiff_t)(r0 + r) * p.src_stride, p, c0 + c);
+            }
+            __syncthreads();
+        }
+        /* stage 1: a lane per column, rows lg, lg + 4, ... */
+        if (colv)
+            for (int r = lg; r < nrows; r += 256 / S16_TW) {
                 unsigned acc = 0;
-                for (int j = 0; j < hfs; j++)
-                    acc += (unsigned)(s16_src(row, p, sp + j) * (int)hf[j]);
-                hs[r * S16_TW + x] = min((int)acc >> sh, lim);
+                if (STAGED) {
+                    const uint16_t *w = srcT + r * SWP + sp;
+                    if (HFS) {
+#pragma unroll
+                        for (int j = 0; j < HC; j++)
+                            acc += (unsigned)((int)w[j] * hc[j]);
+                    } else if (hfs <= 16) {
+#pragma unroll
+                        for (int j = 0; j < HC; j++)
+                            if (j < hfs)
+                                acc += (unsigned)((int)w[j] * hc[j]);
+                    } else
+                        for (int j = 0; j < hfs; j++)
+                            acc += (unsigned)((int)w[j] * (int)hf[j]);
+                } else {
+                    const uint8_t *row = src + (ptrdiff_t)(r0 + r) * p.src_stride;
+                    for (int j = 0; j < hfs; j++)
+                        acc += (unsigned)(s16_src(row, p, c0 + sp + j) * (int)hf[j]);
+                }
+                hs[r * S16_TW + lx] = min((int)acc >> sh, lim);
             }
-        }
         __syncthreads();
-        /* stage 2 */
-        for (int it = tid; it < (yn - yc) * S16_TW; it += 256) {
-            const int yy = yc + it / S16_TW, x = it % S16_TW;
-            if (x >= tw)
-                continue;
-            const int y = y0 + yy;
-            const int32_t *col = hs + (p.v.pos[y] - r0) * S16_TW + x;
-            const int16_t *vf = p.v.filter + (size_t)y * vfs;
-            int out;
-            if (p.ddepth == 8) {
-                const int dz = p.dither ? s16_dither[y & 7][((x0 + x) + p.dither_off) & 7] : 64;
-                if (vfs == 1)
-                    out = s16_clipu((col[0] + dz) >> 7, 8);
-                else {
-                    unsigned acc = (unsigned)dz << 12;
-                    for (int j = 0; j < vfs; j++)
-                        acc += (unsigned)(col[j * S16_TW] * (int)vf[j]);
-                    out = s16_clipu((int)acc >> 19, 8);
+        /* stage 2: a lane per column, output rows yc + lg, + 4, ... */
+        if (colv)
+            for (int yy = yc + lg; yy < yn; yy += 256 / S16_TW) {
+                const int y = y0 + yy, x = lx;
+                const int32_t *col = hs + (p.v.pos[y] - r0) * S16_TW + x;
+                const int16_t *vf = p.v.filter + (size_t)y * vfs;
+                int out;
+                if (p.ddepth == 8) {
+                    const int dz = p.dither ? s16_dither[y & 7][((x0 + x) + p.dither_off) & 7] : 64;
+                    if (vfs == 1)
+                        out = s16_clipu((col[0] + dz) >> 7, 8);
+                    else {
+                        unsigned acc = (unsigned)dz << 12;
+                        S16_VSUM(acc += (unsigned)(col[j * S16_TW] * (int)vf[j]));
+                        out = s16_clipu((int)acc >> 19, 8);
+                    }
+                    dst[(ptrdiff_t)y * p.dst_stride + (size_t)(x0 + x) * p.dstep + p.dchan] = (uint8_t)out;
+                    continue;
                 }
-                dst[(ptrdiff_t)y * p.dst_stride + (size_t)(x0 + x) * p.dstep + p.dchan] = (uint8_t)out;
-                continue;
-            }
-            if (wide) {
-                if (vfs == 1)
-                    out = s16_clipu((col[0] + 4) >> 3, 16);
-                else {
-                    unsigned acc = (1u << 14) - 0x40000000u;
-                    for (int j = 0; j < vfs; j++)
-                        acc += (unsigned)col[j * S16_TW] * (unsigned)(int)vf[j];
-                    out = 0x8000 + min(max((int)acc >> 15, -32768), 32767);
+                if (wide) {
+                    if (vfs == 1)
+                        out = s16_clipu((col[0] + 4) >> 3, 16);
+                    else {
+                        unsigned acc = (1u << 14) - 0x40000000u;
+                        S16_VSUM(acc += (unsigned)col[j * S16_TW] * (unsigned)(int)vf[j]);
+                        out = 0x8000 + min(max((int)acc >> 15, -32768), 32767);
+                    }
+                } else if (vfs == 1) {
+                    const int shift = 15 - p.ddepth;
+                    out = s16_clipu((col[0] + (1 << (shift - 1))) >> shift, p.ddepth);
+                } else {
+                    const int shift = 27 - p.ddepth;
+                    unsigned acc = 1u << (shift - 1);
+                    S16_VSUM(acc += (unsigned)(col[j * S16_TW] * (int)vf[j]));
+                    out = s16_clipu((int)acc >> shift, p.ddepth);
                 }
-            } else if (vfs == 1) {
-                const int shift = 15 - p.ddepth;
-                out = s16_clipu((col[0] + (1 << (shift - 1))) >> shift, p.ddepth);
-            } else {
-                const int shift = 27 - p.ddepth;
-                unsigned acc = 1u << (shift - 1);
-                for (int j = 0; j < vfs; j++)
-                    acc += (unsigned)(col[j * S16_TW] * (int)vf[j]);
-                out = s16_clipu((int)acc >> shift, p.ddepth);
+                if (p.dmsb)
+                    out <<= 16 - p.ddepth;
+                reinterpret_cast<uint16_t *>(dst + (ptrdiff_t)y * p.dst_stride)[(size_t)(x0 + x) * p.dstep + p.dchan] = (uint16_t)out;
             }
-            if (p.dmsb)
-                out <<= 16 - p.ddepth;
-            reinterpret_cast<uint16_t *>(dst + (ptrdiff_t)y * p.dst_stride)[(size_t)(x0 + x) * p.dstep + p.dchan] = (uint16_t)out;
-        }
         __syncthreads();
         yc = yn;
     }
@@ -140,14 +182,38 @@ int ffhip_launch_scale16(const FFHipScale16Args &a0, int nframes, hipStream_t st
         ffhip_set_error("ffhip_sws: a vertical bank of %d taps exceeds the %d rows a tile holds", need, S16_MAXROWS);
         return FFHIP_EINVAL;
     }
-    a.max_rows = S16_MAXROWS;
+    /* LDS as the context needs it (a.max_rows, a.sw_pitch from the banks): the exact-2x case holds 20 rows of 64 + 36 samples, ~7 KB
+     * a workgroup — many workgroups per CU — where the general bound would be 86 KB and one */
+    if (a.max_rows < need) a.max_rows = need;
+    if (a.max_rows > S16_MAXROWS) a.max_rows = S16_MAXROWS;
+    if (a.sw_pitch < 8 || a.sw_pitch > S16_SW) a.sw_pitch = S16_SW;
     const dim3 g(cdiv(maxw, S16_TW), cdiv(maxh, S16_TH), (unsigned)(a.nplanes * nframes));
-    static FFHipPerDeviceOnce attr;
-    if (attr.enter()) {
-        (void)hipFuncSetAttribute((const void *)k_sws_scale16, hipFuncAttributeMaxDynamicSharedMemorySize, S16_MAXROWS * S16_TW * 4);
-        attr.leave(true);
+    const size_t lds_plain = (size_t)a.max_rows * S16_TW * 4, lds_staged = lds_plain + (size_t)a.max_rows * a.sw_pitch * 2;
+    /* every plane of a launch shares the kernel: the unrolled forms need all planes' banks at that size */
+    int hfs = a.pl[0].h.size, vfs = a.pl[0].v.size;
+    for (int i = 1; i < a.nplanes; i++) {
+        if (a.pl[i].h.size != hfs) hfs = 0;
+        if (a.pl[i].v.size != vfs) vfs = 0;
     }
-    hipLaunchKernelGGL(k_sws_scale16, g, dim3(256), S16_MAXROWS * S16_TW * 4, stream, a);
+    const int H = hfs == 4 || hfs == 8 ? hfs : 0, V = vfs == 4 ? 4 : 0;
+    const size_t lds = a.staged ? lds_staged : lds_plain;
+#define S16_GO(ST, HH, VV)                                                                                                                   \
+    do {                                                                                                                                     \
+        static FFHipPerDeviceOnce attr;                                                                                                      \
+        if (attr.enter()) {                                                                                                                  \
+            (void)hipFuncSetAttribute((const void *)k_sws_scale16<ST, HH, VV>, hipFuncAttributeMaxDynamicSharedMemorySize,                   \
+                                      S16_MAXROWS * S16_TW * 4 + S16_MAXROWS * S16_SW * 2);                                                  \
+            attr.leave(true);                                                                                                                \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL((k_sws_scale16<ST, HH, VV>), g, dim3(256), lds, stream, a);                                                       \
+    } while (0)
+    if (!a.staged) S16_GO(false, 0, 0);
+    else if (H == 4 && V == 4) S16_GO(true, 4, 4);
+    else if (H == 8 && V == 4) S16_GO(true, 8, 4);
+    else if (H == 4) S16_GO(true, 4, 0);
+    else if (H == 8) S16_GO(true, 8, 0);
+    else S16_GO(true, 0, 0);
+#undef S16_GO
     LAUNCH_CHECK();
     return 0;
 }

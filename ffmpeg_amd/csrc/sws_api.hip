@@ -18,6 +18,7 @@
 
 struct FFHipSwsContext {
     int device = 0; /* the banks live on this device; every call of the context makes it current for its duration */
+    int hbd_sw = 320, hbd_rows = 96; /* LDS shape the banks need: samples per staged source row, source rows per 32-row tile */
     int hbd = 0;    /* a side above 8 bits: the 16-bit scaler (sws_scale16.hip) serves the context, none of the 8-bit fast paths apply */
     FFHipSwsTables t;
     std::vector<int16_t> f[4];
@@ -356,7 +357,32 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             ffhip_sws_freeContext(c);
             return nullptr;
         }
-        c->hbd = 1;
+        /* does every 64-column run of both horizontal banks reach at most 320 source columns (the staged kernel's LDS row)? */
+        c->hbd = 2;
+        c->hbd_sw = 8;
+        c->hbd_rows = 1;
+        for (int b = 0; b < 2; b++) {
+            const std::vector<int32_t> &pos = c->p[b];
+            const int fs = c->d[b].size, n = c->d[b].n;
+            for (int x0 = 0; x0 < n; x0 += 64) {
+                const int x1 = (x0 + 63 < n ? x0 + 63 : n - 1);
+                int lo = pos[x0], hi = pos[x0];
+                for (int x = x0; x <= x1; x++) { lo = pos[x] < lo ? pos[x] : lo; hi = pos[x] > hi ? pos[x] : hi; }
+                if (hi + fs - lo > 320 || lo != pos[x0])
+                    c->hbd = 1; /* not staged */
+                else if (hi + fs - lo > c->hbd_sw)
+                    c->hbd_sw = hi + fs - lo;
+            }
+            /* source rows a 32-row tile of the vertical bank reaches (capped: taller reaches run in chunks) */
+            const std::vector<int32_t> &vp = c->p[2 + b];
+            const int vfs = c->d[2 + b].size, vn = c->d[2 + b].n;
+            for (int y0 = 0; y0 < vn; y0 += 32) {
+                const int y1 = (y0 + 31 < vn ? y0 + 31 : vn - 1);
+                if (vp[y1] + vfs - vp[y0] > c->hbd_rows)
+                    c->hbd_rows = vp[y1] + vfs - vp[y0];
+            }
+        }
+        c->hbd_sw = (c->hbd_sw + 3) & ~1;
         return c;
     }
     int r = 0;
@@ -636,6 +662,9 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
         p.dither = dd == 8 && sd > 8;       /* swscale.c:291: should_dither = isNBPS(src) || is16BPS(src) */
         p.dither_off = pl == 2 ? 3 : 0;     /* vscale.c: the V plane reads the dither row three entries on; yuv2nv12cX_c: (i + 3) & 7 */
     }
+    a.staged = c->hbd == 2;
+    a.sw_pitch = c->hbd_sw;
+    a.max_rows = c->hbd_rows;
     return ffhip_launch_scale16(a, nframes, stream);
 }
 

@@ -19,9 +19,19 @@ SWS_GAUSS, SWS_SINC, SWS_LANCZOS = 0x80, 0x100, 0x200
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
 
 
+# AVPixelFormat -> (semi-planar, hsub, vsub) of the formats above 8 bits the scaler takes
+HBD_FMT = {45: (0, 1, 1), 47: (0, 1, 0), 49: (0, 0, 0), 60: (0, 1, 1), 62: (0, 1, 1), 64: (0, 1, 0), 66: (0, 0, 0), 68: (0, 0, 0), 70: (0, 1, 0),
+           123: (0, 1, 1), 125: (0, 1, 1), 127: (0, 1, 0), 129: (0, 1, 0), 131: (0, 0, 0), 133: (0, 0, 0), 158: (1, 1, 1), 169: (1, 1, 1),
+           209: (1, 1, 1)}
+
+
 def plane_shapes(fmt, w, h):
     """[(rows, bytes_per_row)] of the planes of one frame."""
     fmt = {12: 0, 13: 4, 14: 5}.get(fmt, fmt)          # the full-range twins share their base formats' layout
+    if fmt in HBD_FMT:                                    # above 8 bits: two bytes per sample (include/ffhip.h FFHIP_PIX_FMT_*LE)
+        semi, hs, vs = HBD_FMT[fmt]
+        cw, ch = -((-w) >> hs), -((-h) >> vs)
+        return [(h, 2 * w), (ch, 4 * cw)] if semi else [(h, 2 * w), (ch, 2 * cw), (ch, 2 * cw)]
     hs, vs = (0, 0) if fmt == PIX_FMT["yuv444p"] else (1, 0) if fmt == PIX_FMT["yuv422p"] else (1, 1)
     cw, ch = -((-w) >> hs), -((-h) >> vs)
     if fmt in (PIX_FMT["yuv420p"], PIX_FMT["yuv422p"], PIX_FMT["yuv444p"]):
