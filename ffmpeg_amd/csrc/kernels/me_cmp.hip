@@ -98,6 +98,43 @@ __device__ __forceinline__ int satd_block(PA a, ptrdiff_t sa, PB b, ptrdiff_t sb
     return s;
 }
 
+/* the half-pel SADs (pix_abs{16,8}_{x2,y2,xy2}_c, me_cmp.c:184-370: blk2 averaged with its right / lower / both neighbours), the sum
+ * of squared differences (sse{16,8}_c, :53-104) and the noise-preserving variant (nsse{16,8}_c, :387-440, weight 8: the value the
+ * reference uses without an encoder context) */
+template <typename PA, typename PB>
+__device__ __forceinline__ int cmp_other(int kind, PA a, PB b, ptrdiff_t s, int w, int h)
+{
+    int r = 0;
+    if (kind == FFHIP_ME_NSSE) {
+        int score2 = 0;
+        for (int y = 0; y < h; y++) {
+            for (int x = 0; x < w; x++) {
+                const int d = (int)a[y * s + x] - (int)b[y * s + x];
+                r += d * d;
+            }
+            if (y + 1 < h)
+                for (int x = 0; x < w - 1; x++)
+                    score2 += abs((int)a[y * s + x] - (int)a[(y + 1) * s + x] - (int)a[y * s + x + 1] + (int)a[(y + 1) * s + x + 1]) -
+                              abs((int)b[y * s + x] - (int)b[(y + 1) * s + x] - (int)b[y * s + x + 1] + (int)b[(y + 1) * s + x + 1]);
+        }
+        return r + abs(score2) * 8;
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int p = a[y * s + x], q0 = b[y * s + x];
+            if (kind == FFHIP_ME_SSE) {
+                r += (p - q0) * (p - q0);
+                continue;
+            }
+            int q;
+            if (kind == FFHIP_ME_SAD_X2) q = (q0 + (int)b[y * s + x + 1] + 1) >> 1;
+            else if (kind == FFHIP_ME_SAD_Y2) q = (q0 + (int)b[(y + 1) * s + x] + 1) >> 1;
+            else q = (q0 + (int)b[y * s + x + 1] + (int)b[(y + 1) * s + x] + (int)b[(y + 1) * s + x + 1] + 2) >> 2;
+            r += abs(p - q);
+        }
+    return r;
+}
+
 /* ---- function-level batch: one thread per comparison -------------------------------------------- */
 __global__ __launch_bounds__(64) void k_me_cmp(int kind, int width, int h, const uint8_t *blk1, const int32_t *off1,
                                                const uint8_t *blk2, const int32_t *off2, ptrdiff_t stride, int32_t *out, int n)
@@ -106,7 +143,8 @@ __global__ __launch_bounds__(64) void k_me_cmp(int kind, int width, int h, const
     if (i >= n)
         return;
     const uint8_t *a = blk1 + off1[i], *b = blk2 + off2[i];
-    out[i] = kind == FFHIP_ME_SAD ? sad_bytes(a, stride, b, stride, width, h) : satd_block(a, stride, b, stride, width, h);
+    out[i] = kind == FFHIP_ME_SAD ? sad_bytes(a, stride, b, stride, width, h) : kind == FFHIP_ME_SATD ? satd_block(a, stride, b, stride, width, h)
+                                                                               : cmp_other(kind, a, b, stride, width, h);
 }
 
 int ffhip_launch_me_cmp(int kind, int width, int h, const uint8_t *blk1, const int32_t *off1, const uint8_t *blk2,

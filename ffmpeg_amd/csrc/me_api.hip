@@ -9,7 +9,7 @@ extern "C" int ffhip_me_cmp_batch_dev(int kind, int width, int h, const uint8_t 
                                       void *stream)
 {
     if (!blk1 || !blk2 || !off1 || !off2 || !out || n < 0 || (width != 16 && width != 8) || h <= 0 ||
-        (kind != FFHIP_ME_SAD && kind != FFHIP_ME_SATD))
+        kind < FFHIP_ME_SAD || kind > FFHIP_ME_NSSE)
         return FFHIP_EINVAL;
     if (kind == FFHIP_ME_SATD && h != 8 && h != 16) /* hadamard8_diff16_c handles h 8|16 only (me_cmp.c:933-950) */
         return FFHIP_EINVAL;

@@ -764,8 +764,10 @@ static bool cmp_single(int kind, int width, const uint8_t *blk1, const uint8_t *
         *result = 0;
         return true;
     }
+    /* what the C function of the slot reads: the half-pel forms one more column / row of blk2; sse and nsse stay inside the blocks */
+    const int bx = kind == FFHIP_ME_SAD_X2 || kind == FFHIP_ME_SAD_XY2, by = kind == FFHIP_ME_SAD_Y2 || kind == FFHIP_ME_SAD_XY2;
     Rect a = { const_cast<uint8_t *>(blk1), stride, 0, rows - 1, 0, width - 1, nullptr };
-    Rect b = { const_cast<uint8_t *>(blk2), stride, 0, rows - 1, 0, width - 1, nullptr };
+    Rect b = { const_cast<uint8_t *>(blk2), stride, 0, rows - 1 + by, 0, width - 1 + bx, nullptr };
     Arena A(rect_bytes(a) + rect_bytes(b) + 64);
     if (!A.ok)
         return false;
@@ -799,6 +801,28 @@ CMP_SHIM(s_pixabs16, FFHIP_ME_SAD, 16, pix_abs[0][0])
 CMP_SHIM(s_pixabs8, FFHIP_ME_SAD, 8, pix_abs[1][0])
 CMP_SHIM(s_satd16, FFHIP_ME_SATD, 16, hadamard8_diff[0])
 CMP_SHIM(s_satd8, FFHIP_ME_SATD, 8, hadamard8_diff[1])
+CMP_SHIM(s_pixabs16_x2, FFHIP_ME_SAD_X2, 16, pix_abs_hpel[0][0])
+CMP_SHIM(s_pixabs16_y2, FFHIP_ME_SAD_Y2, 16, pix_abs_hpel[0][1])
+CMP_SHIM(s_pixabs16_xy2, FFHIP_ME_SAD_XY2, 16, pix_abs_hpel[0][2])
+CMP_SHIM(s_pixabs8_x2, FFHIP_ME_SAD_X2, 8, pix_abs_hpel[1][0])
+CMP_SHIM(s_pixabs8_y2, FFHIP_ME_SAD_Y2, 8, pix_abs_hpel[1][1])
+CMP_SHIM(s_pixabs8_xy2, FFHIP_ME_SAD_XY2, 8, pix_abs_hpel[1][2])
+CMP_SHIM(s_sse16, FFHIP_ME_SSE, 16, sse[0])
+CMP_SHIM(s_sse8, FFHIP_ME_SSE, 8, sse[1])
+/* nsse: the second term's weight comes from the encoder context when there is one (me_cmp.c:404-407): those calls are the C function's */
+#define NSSE_SHIM(name, width, member)                                                                        \
+    static int name(void *c, const uint8_t *a, const uint8_t *b, ptrdiff_t s, int h)                          \
+    {                                                                                                         \
+        int r = 0;                                                                                            \
+        if (!c && cmp_single(FFHIP_ME_NSSE, width, a, b, s, h, &r))                                           \
+            return r;                                                                                         \
+        const bool have_ = g_fb_me.member != nullptr;                                                         \
+        if (!c || !have_)                                                                                     \
+            shim_note(#member, have_);                                                                        \
+        return have_ ? g_fb_me.member(c, a, b, s, h) : 0;                                                     \
+    }
+NSSE_SHIM(s_nsse16, 16, nsse[0])
+NSSE_SHIM(s_nsse8, 8, nsse[1])
 
 extern "C" int ff_me_cmp_init_hip(FFHipMECmpContext *c)
 {
@@ -810,6 +834,10 @@ extern "C" int ff_me_cmp_init_hip(FFHipMECmpContext *c)
     o.sad[0] = s_sad16;              o.sad[1] = s_sad8;
     o.pix_abs[0][0] = s_pixabs16;    o.pix_abs[1][0] = s_pixabs8;    /* ff_me_cmp_init: me_cmp.c:989-1000 */
     o.hadamard8_diff[0] = s_satd16;  o.hadamard8_diff[1] = s_satd8;
+    o.pix_abs_hpel[0][0] = s_pixabs16_x2; o.pix_abs_hpel[0][1] = s_pixabs16_y2; o.pix_abs_hpel[0][2] = s_pixabs16_xy2;
+    o.pix_abs_hpel[1][0] = s_pixabs8_x2;  o.pix_abs_hpel[1][1] = s_pixabs8_y2;  o.pix_abs_hpel[1][2] = s_pixabs8_xy2;
+    o.sse[0] = s_sse16;              o.sse[1] = s_sse8;
+    o.nsse[0] = s_nsse16;            o.nsse[1] = s_nsse8;
     fb_snapshot(g_fb_me, *c, o);
     *c = o;
     return 0;

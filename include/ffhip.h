@@ -1231,11 +1231,22 @@ typedef struct FFHipMECmpContext {
     ffhip_me_cmp_func sad[2];             /* [0] 16 wide = pix_abs16_c, [1] 8 wide = pix_abs8_c */
     ffhip_me_cmp_func hadamard8_diff[2];  /* [0] hadamard8_diff16_c, [1] hadamard8_diff8x8_c     */
     ffhip_me_cmp_func pix_abs[2][1];      /* [w][0] full-pel                                     */
+    /* what a motion search uses beside them (me_cmp.c:961-1012): the half-pel SADs pix_abs[w][1..3] = _x2 / _y2 / _xy2 (blk2 read
+     * one column / row / both further), sse[0..1] and nsse[0..1] ([0] 16 wide, [1] 8 wide).  nsse weighs its second term with the
+     * encoder's nsse_weight when the context argument is non-NULL: such calls go to the displaced C function, NULL means 8 */
+    ffhip_me_cmp_func pix_abs_hpel[2][3];
+    ffhip_me_cmp_func sse[2];
+    ffhip_me_cmp_func nsse[2];
 } FFHipMECmpContext;
 int ff_me_cmp_init_hip(FFHipMECmpContext *c);
 
 #define FFHIP_ME_SAD   0
 #define FFHIP_ME_SATD  1
+#define FFHIP_ME_SAD_X2  2   /* pix_abs*_x2_c: blk2 averaged with its right neighbour (w + 1 columns read) */
+#define FFHIP_ME_SAD_Y2  3   /* pix_abs*_y2_c: ... with the row below (h + 1 rows read)                  */
+#define FFHIP_ME_SAD_XY2 4   /* pix_abs*_xy2_c: ... with all three                                       */
+#define FFHIP_ME_SSE     5   /* sse16_c / sse8_c                                                          */
+#define FFHIP_ME_NSSE    6   /* nsse16_c / nsse8_c with the context-free weight 8                         */
 /** n independent comparisons: out[i] = cmp(blk1 + off1[i], blk2 + off2[i], stride, h). width 16|8. */
 int ffhip_me_cmp_batch_dev(int kind, int width, int h, const uint8_t *blk1, const int32_t *off1,
                            const uint8_t *blk2, const int32_t *off2, ptrdiff_t stride, int32_t *out, int n,

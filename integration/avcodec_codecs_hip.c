@@ -32,6 +32,10 @@ av_cold void ff_me_cmp_init(MECmpContext *c, AVCodecContext *avctx)
         h.sad[i]            = (ffhip_me_cmp_func)c->sad[i];
         h.hadamard8_diff[i] = (ffhip_me_cmp_func)c->hadamard8_diff[i];
         h.pix_abs[i][0]     = (ffhip_me_cmp_func)c->pix_abs[i][0];
+        for (int k = 0; k < 3; k++)
+            h.pix_abs_hpel[i][k] = (ffhip_me_cmp_func)c->pix_abs[i][k + 1];
+        h.sse[i]            = (ffhip_me_cmp_func)c->sse[i];
+        h.nsse[i]           = (ffhip_me_cmp_func)c->nsse[i];
     }
     if (ff_me_cmp_init_hip(&h) < 0)
         return;
@@ -39,6 +43,10 @@ av_cold void ff_me_cmp_init(MECmpContext *c, AVCodecContext *avctx)
         c->sad[i]            = (me_cmp_func)h.sad[i];
         c->hadamard8_diff[i] = (me_cmp_func)h.hadamard8_diff[i];
         c->pix_abs[i][0]     = (me_cmp_func)h.pix_abs[i][0];
+        for (int k = 0; k < 3; k++)
+            c->pix_abs[i][k + 1] = (me_cmp_func)h.pix_abs_hpel[i][k];
+        c->sse[i]            = (me_cmp_func)h.sse[i];
+        c->nsse[i]           = (me_cmp_func)h.nsse[i];
     }
 }
 

@@ -193,6 +193,8 @@ void ffo_h264_deblock_frame_chroma(uint8_t *plane, ptrdiff_t stride, int mb_w, i
 int      ffo_sad(int width, const uint8_t *a, const uint8_t *b, ptrdiff_t stride, int h);
 int      ffo_hadamard8_diff8x8(const uint8_t *dst, const uint8_t *src, ptrdiff_t stride);
 int      ffo_hadamard8_diff16(const uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h);
+/* kind 2 pix_abs_x2, 3 _y2, 4 _xy2, 5 sse, 6 nsse (context-free weight 8): me_cmp.c:53-104,184-440 */
+int ffo_me_cmp_other(int kind, int width, const uint8_t *a, const uint8_t *b, ptrdiff_t stride, int h);
 uint64_t ffo_me_search_esa(const uint8_t *cur, const uint8_t *ref, int linesize, int width, int height, int mb_size,
                            int search_param, int cost_kind, int x_mb, int y_mb, int *mv);
 void     ffo_me_esa_frame(const uint8_t *cur, const uint8_t *ref, int linesize, int width, int height, int mb_size,

@@ -122,3 +122,37 @@ void ffo_me_esa_frame(const uint8_t *cur, const uint8_t *ref, int linesize, int 
             cost_out[by * bw + bx] = (uint32_t)c;
         }
 }
+
+/* the half-pel SADs, SSE and NSSE: pix_abs{16,8}_{x2,y2,xy2}_c (libavcodec/me_cmp.c:184-370), sse{16,8}_c (:53-104), nsse{16,8}_c
+ * (:387-440, the context-free weight 8).  kind = FFHIP_ME_SAD_X2 (2) .. FFHIP_ME_NSSE (6) */
+int ffo_me_cmp_other(int kind, int width, const uint8_t *a, const uint8_t *b, ptrdiff_t stride, int h)
+{
+    int r = 0;
+    if (kind == 6) {
+        int score2 = 0;
+        for (int y = 0; y < h; y++) {
+            for (int x = 0; x < width; x++)
+                r += (a[x] - b[x]) * (a[x] - b[x]);
+            if (y + 1 < h)
+                for (int x = 0; x < width - 1; x++) {
+                    int da = a[x] - a[x + stride] - a[x + 1] + a[x + stride + 1];
+                    int db = b[x] - b[x + stride] - b[x + 1] + b[x + stride + 1];
+                    score2 += (da < 0 ? -da : da) - (db < 0 ? -db : db);
+                }
+            a += stride;
+            b += stride;
+        }
+        return r + (score2 < 0 ? -score2 : score2) * 8;
+    }
+    for (int y = 0; y < h; y++, a += stride, b += stride)
+        for (int x = 0; x < width; x++) {
+            int q = b[x], d;
+            if (kind == 5) { r += (a[x] - q) * (a[x] - q); continue; }
+            if (kind == 2) q = (b[x] + b[x + 1] + 1) >> 1;
+            else if (kind == 3) q = (b[x] + b[x + stride] + 1) >> 1;
+            else q = (b[x] + b[x + 1] + b[x + stride] + b[x + stride + 1] + 2) >> 2;
+            d = a[x] - q;
+            r += d < 0 ? -d : d;
+        }
+    return r;
+}

@@ -592,6 +592,10 @@ int ffref_me_cmp(int kind, int idx, const uint8_t *blk1, const uint8_t *blk2, pt
     case 0: return mecmp.sad[idx](NULL, blk1, blk2, stride, h);
     case 1: return mecmp.hadamard8_diff[idx](NULL, blk1, blk2, stride, h);
     case 2: return mecmp.sse[idx](NULL, blk1, blk2, stride, h);
+    case 3: return mecmp.pix_abs[idx][1](NULL, blk1, blk2, stride, h); /* _x2 */
+    case 4: return mecmp.pix_abs[idx][2](NULL, blk1, blk2, stride, h); /* _y2 */
+    case 5: return mecmp.pix_abs[idx][3](NULL, blk1, blk2, stride, h); /* _xy2 */
+    case 6: return mecmp.nsse[idx](NULL, blk1, blk2, stride, h);       /* no encoder context: weight 8 */
     }
     return -1;
 }

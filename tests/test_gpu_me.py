@@ -48,6 +48,32 @@ def test_me_cmp_batch(kind, width):
         assert np.array_equal(out.cpu().numpy(), want), "h=%d" % h
 
 
+@pytest.mark.parametrize("width", [16, 8])
+@pytest.mark.parametrize("kind", [2, 3, 4, 5, 6], ids=["x2", "y2", "xy2", "sse", "nsse"])
+def test_me_cmp_halfpel_sse_nsse_batch(kind, width):
+    """pix_abs*_x2 / _y2 / _xy2, sse, nsse (me_cmp.c:53-104,184-440) over many positions: == the oracle (pinned to the reference)"""
+    torch = _torch()
+    from ffmpeg_amd import _lib
+    L, O = _lib.lib(), ffi.oracle()
+    O.ffo_me_cmp_other.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]
+    rng = np.random.default_rng(kind * 3 + width)
+    W = 80
+    a = rng.integers(0, 256, (W, W), dtype=np.uint8)
+    b = rng.integers(0, 256, (W, W), dtype=np.uint8)
+    b[:40] = np.clip(a[:40].astype(int) + rng.integers(-6, 7, (40, W)), 0, 255)
+    n = 400
+    for h in (4, 8, 16):
+        o1 = (rng.integers(0, W - 18, n) * W + rng.integers(0, W - 18, n)).astype(np.int32)
+        o2 = (rng.integers(0, W - 18, n) * W + rng.integers(0, W - 18, n)).astype(np.int32)
+        want = np.array([O.ffo_me_cmp_other(kind, width, C.cast(a.ctypes.data + int(o1[i]), u8p), C.cast(b.ctypes.data + int(o2[i]), u8p), W, h)
+                         for i in range(n)], np.int32)
+        out = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        da, db, d1, d2 = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(o1).cuda(), torch.from_numpy(o2).cuda()
+        assert L.ffhip_me_cmp_batch_dev(kind, width, h, da.data_ptr(), d1.data_ptr(), db.data_ptr(), d2.data_ptr(), W, out.data_ptr(), n, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want), (kind, width, h)
+
+
 def _shifted_pair(rng, w, h, stride, R, flat=False):
     big = rng.integers(0, 256, (h + 64, w + 64), dtype=np.uint8)
     if flat:

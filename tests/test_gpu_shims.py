@@ -50,7 +50,8 @@ class H264Weight(C.Structure):
 
 
 class MECmp(C.Structure):
-    _fields_ = [("sad", CMP * 2), ("hadamard8_diff", CMP * 2), ("pix_abs", (CMP * 1) * 2)]
+    _fields_ = [("sad", CMP * 2), ("hadamard8_diff", CMP * 2), ("pix_abs", (CMP * 1) * 2), ("pix_abs_hpel", (CMP * 3) * 2), ("sse", CMP * 2),
+                ("nsse", CMP * 2)]
 
 
 def _lib():

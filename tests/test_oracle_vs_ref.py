@@ -970,6 +970,12 @@ def test_me_cmp():
             assert R.ffref_me_cmp(0, 1, pa, pb, 64, h) == O.ffo_sad(8, pa, pb, 64, h)
             assert R.ffref_me_cmp(1, 0, pa, pb, 64, h) == O.ffo_hadamard8_diff16(pa, pb, 64, h)
         assert R.ffref_me_cmp(1, 1, pa, pb, 64, 8) == O.ffo_hadamard8_diff8x8(pa, pb, 64)
+        # the half-pel SADs, SSE and NSSE (ffref kinds 3 / 4 / 5 = pix_abs[w][1..3], 2 = sse, 6 = nsse; oracle kinds FFHIP_ME_*)
+        O.ffo_me_cmp_other.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int]
+        for h in (4, 8, 16):
+            for idx, w in ((0, 16), (1, 8)):
+                for rk, ok in ((3, 2), (4, 3), (5, 4), (2, 5), (6, 6)):
+                    assert R.ffref_me_cmp(rk, idx, pa, pb, 64, h) == O.ffo_me_cmp_other(ok, w, pa, pb, 64, h), (rk, w, h)
 
 
 @pytest.mark.parametrize("R_", [3, 7])
