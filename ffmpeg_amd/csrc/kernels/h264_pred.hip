@@ -1,5 +1,5 @@
 /*
- * h264_pred.hip — H.264 intra prediction, 8 bits, 4:2:0, batched and in place: H264PredContext
+ * h264_pred.hip — H.264 intra prediction, 4:2:0, 8 bits and (templates on the sample type) 9 / 10 / 12 / 14, batched and in place: H264PredContext
  * (libavcodec/h264pred.h:92-116; bodies libavcodec/h264pred_template.c, table libavcodec/h264pred.c:448-538).
  *
  * A block's neighbours are staged once into LDS as its "edge line" e[] = the left column bottom-up, the corner, the row above
@@ -13,6 +13,8 @@
  * The lossless _add members (h264pred_template.c:1104-1330) integrate the residual along the prediction direction in wrapping
  * 8-bit arithmetic: one thread per column (VERT) or row (HOR), which also clears the coefficients it consumed.
  */
+#include <type_traits>
+
 #include "common.h"
 #include "h264_intra_mb.h"
 #include "h264_kernels.h"
@@ -22,6 +24,16 @@ static_assert(sizeof(FFHipH264Pred) == 12, "FFHipH264Pred is a 12-byte record");
 /* hp_a2 / hp_a3 / hp_need / hp_dir_sample: the per-sample rules over the edge line, shared with the picture pipeline's intra
  * reconstruction (h264_intra_mb.h) */
 
+__device__ __forceinline__ void hp_store4(uint16_t *d, const int *v) /* 16-bit samples: two dwords when aligned */
+{
+    if (!(reinterpret_cast<uintptr_t>(d) & 7)) {
+        *reinterpret_cast<uint2 *>(d) = make_uint2((uint32_t)v[0] | (uint32_t)v[1] << 16, (uint32_t)v[2] | (uint32_t)v[3] << 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            d[j] = (uint16_t)v[j];
+    }
+}
 __device__ __forceinline__ void hp_store4(uint8_t *d, const int *v)
 {
     if (!(reinterpret_cast<uintptr_t>(d) & 3)) {
@@ -34,9 +46,10 @@ __device__ __forceinline__ void hp_store4(uint8_t *d, const int *v)
 }
 
 /* pred4x4 (L8 = false, N = 4) and pred8x8l (L8 = true, N = 8) */
-template <bool L8>
-__global__ __launch_bounds__(256) void k_h264_pred_dir(uint8_t *plane, ptrdiff_t stride, const FFHipH264Pred *blocks, int n)
+template <bool L8, typename P>
+__global__ __launch_bounds__(256) void k_h264_pred_dir(uint8_t *plane, ptrdiff_t stride_b, const FFHipH264Pred *blocks, int n, int bd)
 {
+    const ptrdiff_t stride = stride_b / (ptrdiff_t)sizeof(P); /* offsets and strides arrive in bytes, samples are P */
     constexpr int N = L8 ? 8 : 4, ITEMS = N * N / 4, RPB = 256 / ITEMS, LINE = 3 * N + 1, QW = N / 4;
     __shared__ int raw[RPB][LINE + 1];
     __shared__ int flt[L8 ? RPB : 1][LINE + 1];
@@ -48,7 +61,7 @@ __global__ __launch_bounds__(256) void k_h264_pred_dir(uint8_t *plane, ptrdiff_t
     const int mode = k.mode;
     const unsigned need = valid ? hp_need(mode) : 0u;
     const bool tl = k.flags & FFHIP_H264_PRED_TOPLEFT, tr = k.flags & FFHIP_H264_PRED_TOPRIGHT;
-    uint8_t *src = plane + k.offset;
+    P *src = reinterpret_cast<P *>(plane + k.offset);
     for (int j = it; j < LINE; j += ITEMS) {
         int v = 0;
         if (j < N) {
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(256) void k_h264_pred_dir(uint8_t *plane, ptrdiff_t
             if (tr && ((need & 8) || (j == 2 * N + 1 && (need & 2))))
                 v = src[j - N - 1 - stride];
         } else if (need & 8) {
-            v = (k.flags & FFHIP_H264_PRED_TR_SPLAT) ? src[3 - stride] : plane[k.aux + (j - 2 * N - 1)];
+            v = (k.flags & FFHIP_H264_PRED_TR_SPLAT) ? src[3 - stride] : reinterpret_cast<const P *>(plane + k.aux)[j - 2 * N - 1];
         }
         raw[r][j] = v;
     }
@@ -94,7 +107,7 @@ __global__ __launch_bounds__(256) void k_h264_pred_dir(uint8_t *plane, ptrdiff_t
     }
     if (!valid)
         return;
-    int dc = 128;
+    int dc = 1 << (bd - 1); /* DC_128_PRED at the depth */
     if (mode == 2 || mode == 9 || mode == 10) {
         int sl = 0, st = 0;
 #pragma unroll
@@ -113,12 +126,14 @@ __global__ __launch_bounds__(256) void k_h264_pred_dir(uint8_t *plane, ptrdiff_t
 }
 
 /* pred8x8 (chroma, N = 8: DC per 4x4 quadrant, the "mad cow" edge variants) and pred16x16 (N = 16) */
-template <int N>
-__global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t stride, const FFHipH264Pred *blocks, int n)
+template <int N, typename P>
+__global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t stride_b, const FFHipH264Pred *blocks, int n, int bd)
 {
+    const ptrdiff_t stride = stride_b / (ptrdiff_t)sizeof(P);
+    const int mid = 1 << (bd - 1), maxv = (1 << bd) - 1;
     constexpr int ITEMS = N * N / 4, RPB = 256 / ITEMS, QW = N / 4, H2 = N / 2;
     __shared__ int L[RPB][N], T[RPB][N + 1]; /* T[0] is the corner */
-    __shared__ int P[RPB][4];
+    __shared__ int PP[RPB][4];
     const int r = threadIdx.x / ITEMS, it = threadIdx.x % ITEMS, b = blockIdx.x * RPB + r;
     const bool valid = b < n;
     FFHipH264Pred k = {};
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t
     const bool use_t = valid && (mode == 0 || mode == 2 || mode == 3 || mode == 5 || mode == 7 || mode == 8);
     const bool use_l = valid && (mode == 0 || mode == 1 || mode == 3 || mode == 4 || mode >= 7);
     const int lrows = mode == 7 ? 4 : N; /* L0T: pred4x4_dc on the first quadrant reads four rows of the left column */
-    uint8_t *src = plane + k.offset;
+    P *src = reinterpret_cast<P *>(plane + k.offset);
     if (it < N) {
         L[r][it] = use_l && it < lrows ? src[(ptrdiff_t)it * stride - 1] : 0;
         T[r][it + 1] = use_t ? src[it - stride] : 0;
@@ -148,9 +163,9 @@ __global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t
             }
             H = N == 16 ? (5 * H + 32) >> 6 : (17 * H + 16) >> 5;
             V = N == 16 ? (5 * V + 32) >> 6 : (17 * V + 16) >> 5;
-            P[r][0] = 16 * (l[N - 1] + t[N - 1] + 1) - (H2 - 1) * (V + H);
-            P[r][1] = H;
-            P[r][2] = V;
+            PP[r][0] = 16 * (l[N - 1] + t[N - 1] + 1) - (H2 - 1) * (V + H);
+            PP[r][1] = H;
+            PP[r][2] = V;
         } else if (N == 16) {
             int sl = 0, st = 0;
 #pragma unroll
@@ -158,11 +173,11 @@ __global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t
                 sl += l[i];
                 st += t[i];
             }
-            P[r][0] = mode == 0 ? (sl + st + 16) >> 5 : mode == 4 ? (sl + 8) >> 4 : mode == 5 ? (st + 8) >> 4 : 128;
+            PP[r][0] = mode == 0 ? (sl + st + 16) >> 5 : mode == 4 ? (sl + 8) >> 4 : mode == 5 ? (st + 8) >> 4 : mid;
         } else {
             const int t0 = t[0] + t[1] + t[2] + t[3], t1 = t[4] + t[5] + t[6] + t[7];
             const int l0 = l[0] + l[1] + l[2] + l[3], l1 = l[4] + l[5] + l[6] + l[7];
-            int q0 = 128, q1 = 128, q2 = 128, q3 = 128;
+            int q0 = mid, q1 = mid, q2 = mid, q3 = mid;
             switch (mode) {
             case 0: q0 = (t0 + l0 + 4) >> 3; q1 = (t1 + 2) >> 2; q2 = (l1 + 2) >> 2; q3 = (t1 + l1 + 4) >> 3; break;
             case 4: q0 = q1 = (l0 + 2) >> 2; q2 = q3 = (l1 + 2) >> 2; break;
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t
             case 10: q2 = q3 = (l1 + 2) >> 2; break;
             default: break;
             }
-            P[r][0] = q0; P[r][1] = q1; P[r][2] = q2; P[r][3] = q3;
+            PP[r][0] = q0; PP[r][1] = q1; PP[r][2] = q2; PP[r][3] = q3;
         }
     }
     __syncthreads();
@@ -189,26 +204,28 @@ __global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t
         else if (mode == 2)
             v[j] = T[r][x + 1];
         else if (mode == 3)
-            v[j] = clip_u8((P[r][0] + y * P[r][2] + x * P[r][1]) >> 5);
+            v[j] = min(max((PP[r][0] + y * PP[r][2] + x * PP[r][1]) >> 5, 0), maxv);
         else
-            v[j] = N == 16 ? P[r][0] : P[r][2 * (y >> 2) + (x >> 2)];
+            v[j] = N == 16 ? PP[r][0] : PP[r][2 * (y >> 2) + (x >> 2)];
     }
     hp_store4(src + (ptrdiff_t)y * stride + x0, v);
 }
 
 /* pred4x4_add / pred8x8l_add / pred8x8l_filter_add: thread i owns column i (mode 0, VERT_PRED) or row i (mode 1, HOR_PRED) */
-template <int N, bool FILTER>
-__global__ __launch_bounds__(256) void k_h264_pred_add(uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n)
+template <int N, bool FILTER, typename P>
+__global__ __launch_bounds__(256) void k_h264_pred_add(uint8_t *plane, ptrdiff_t stride_b, int16_t *coeffs, const FFHipH264Pred *blocks, int n)
 {
+    typedef typename std::conditional<sizeof(P) == 2, int32_t, int16_t>::type CF; /* dctcoef: int32_t above 8 bits */
+    const ptrdiff_t stride = stride_b / (ptrdiff_t)sizeof(P);
     const int gid = blockIdx.x * 256 + threadIdx.x, b = gid / N, i = gid % N;
     if (b >= n)
         return;
     const FFHipH264Pred k = blocks[b];
-    uint8_t *pix = plane + k.offset;
-    int16_t *blk = coeffs + k.aux;
+    P *pix = reinterpret_cast<P *>(plane + k.offset);
+    CF *blk = reinterpret_cast<CF *>(coeffs) + k.aux; /* aux counts coefficients */
     const bool vert = k.mode == 0;
     const ptrdiff_t along = vert ? stride : 1, across = vert ? 1 : stride; /* steps along / across the prediction direction */
-    const uint8_t *edge = pix - along;                                        /* the border sample in front of line 0 */
+    const P *edge = pix - along;                                              /* the border sample in front of line 0 */
     unsigned v;
     if (FILTER) {
         const bool tl = k.flags & FFHIP_H264_PRED_TOPLEFT, tr = k.flags & FFHIP_H264_PRED_TOPRIGHT;
@@ -225,32 +242,53 @@ __global__ __launch_bounds__(256) void k_h264_pred_add(uint8_t *plane, ptrdiff_t
     const int cal = vert ? N : 1, cac = vert ? 1 : N; /* the same two steps in the coefficient block */
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        v = (v + (unsigned)blk[j * cal + i * cac]) & 255u;
-        pix[j * along + i * across] = (uint8_t)v;
+        v = (v + (unsigned)blk[j * cal + i * cac]) & (sizeof(P) == 2 ? 0xFFFFu : 255u); /* the sample type's wrap-around */
+        pix[j * along + i * across] = (P)v;
         blk[j * cal + i * cac] = 0;
     }
 }
 
-int ffhip_launch_h264_pred(int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n, hipStream_t stream)
+int ffhip_launch_h264_pred_bd(int bd, int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n,
+                              hipStream_t stream)
 {
     if (n <= 0)
         return 0;
+    if (bd != 8 && bd != 9 && bd != 10 && bd != 12 && bd != 14) {
+        ffhip_set_error("ffhip_h264_pred: bit depth %d (8, 9, 10, 12 and 14 are the depths H.264 defines)", bd);
+        return FFHIP_EINVAL;
+    }
+    if (bd > 8 && (stride & 1))
+        return FFHIP_EINVAL;
     const dim3 block(256);
+#define PRED_GO(K, G, ...)                                                                                                   \
+    do {                                                                                                                    \
+        if (bd > 8) hipLaunchKernelGGL((K<__VA_ARGS__, uint16_t>), dim3(G), block, 0, stream, plane, stride, blocks, n, bd); \
+        else        hipLaunchKernelGGL((K<__VA_ARGS__, uint8_t>), dim3(G), block, 0, stream, plane, stride, blocks, n, bd);  \
+    } while (0)
+#define PRED_ADD(G, ...)                                                                                                            \
+    do {                                                                                                                            \
+        if (bd > 8) hipLaunchKernelGGL((k_h264_pred_add<__VA_ARGS__, uint16_t>), dim3(G), block, 0, stream, plane, stride, coeffs, blocks, n); \
+        else        hipLaunchKernelGGL((k_h264_pred_add<__VA_ARGS__, uint8_t>), dim3(G), block, 0, stream, plane, stride, coeffs, blocks, n);  \
+    } while (0)
     switch (kind) {
-    case FFHIP_H264_PRED4x4:   hipLaunchKernelGGL(k_h264_pred_dir<false>, dim3(cdiv(n, 64)), block, 0, stream, plane, stride, blocks, n); break;
-    case FFHIP_H264_PRED8x8L:  hipLaunchKernelGGL(k_h264_pred_dir<true>, dim3(cdiv(n, 16)), block, 0, stream, plane, stride, blocks, n); break;
-    case FFHIP_H264_PRED8x8:   hipLaunchKernelGGL(k_h264_pred_blk<8>, dim3(cdiv(n, 16)), block, 0, stream, plane, stride, blocks, n); break;
-    case FFHIP_H264_PRED16x16: hipLaunchKernelGGL(k_h264_pred_blk<16>, dim3(cdiv(n, 4)), block, 0, stream, plane, stride, blocks, n); break;
-    case FFHIP_H264_PRED4x4_ADD:
-        hipLaunchKernelGGL((k_h264_pred_add<4, false>), dim3(cdiv(n, 64)), block, 0, stream, plane, stride, coeffs, blocks, n); break;
-    case FFHIP_H264_PRED8x8L_ADD:
-        hipLaunchKernelGGL((k_h264_pred_add<8, false>), dim3(cdiv(n, 32)), block, 0, stream, plane, stride, coeffs, blocks, n); break;
-    case FFHIP_H264_PRED8x8L_FILTER_ADD:
-        hipLaunchKernelGGL((k_h264_pred_add<8, true>), dim3(cdiv(n, 32)), block, 0, stream, plane, stride, coeffs, blocks, n); break;
+    case FFHIP_H264_PRED4x4:   PRED_GO(k_h264_pred_dir, cdiv(n, 64), false); break;
+    case FFHIP_H264_PRED8x8L:  PRED_GO(k_h264_pred_dir, cdiv(n, 16), true); break;
+    case FFHIP_H264_PRED8x8:   PRED_GO(k_h264_pred_blk, cdiv(n, 16), 8); break;
+    case FFHIP_H264_PRED16x16: PRED_GO(k_h264_pred_blk, cdiv(n, 4), 16); break;
+    case FFHIP_H264_PRED4x4_ADD:         PRED_ADD(cdiv(n, 64), 4, false); break;
+    case FFHIP_H264_PRED8x8L_ADD:        PRED_ADD(cdiv(n, 32), 8, false); break;
+    case FFHIP_H264_PRED8x8L_FILTER_ADD: PRED_ADD(cdiv(n, 32), 8, true); break;
     default:
         ffhip_set_error("ffhip_h264_pred: kind %d outside 0..6", kind);
         return FFHIP_EINVAL;
     }
+#undef PRED_GO
+#undef PRED_ADD
     LAUNCH_CHECK();
     return 0;
+}
+
+int ffhip_launch_h264_pred(int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n, hipStream_t stream)
+{
+    return ffhip_launch_h264_pred_bd(8, kind, plane, stride, coeffs, blocks, n, stream);
 }

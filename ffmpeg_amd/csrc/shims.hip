@@ -1131,29 +1131,31 @@ extern "C" int ff_vp9dsp_scaled_mc_init_hip(FFHipVP9ScaledMcContext *c, int bpp)
 /* ---- h264pred host faces: the picture patch is staged from exactly the neighbours the C member reads ---- */
 /* need: bit0 left column, bit1 row above, bit2 corner, bit3 top-right (4x4: topright[0..3]; 8x8l: T9..15 if has_topright) */
 #define HP_P 64 /* pitch of the staged patch; the block sits at row 1, column 16 */
-static bool h264_pred_host(int kind, int mode, int n, unsigned need, int lrows, uint8_t *src, ptrdiff_t stride, const uint8_t *topright,
+/* bd: the depth the face was installed for (samples of 2 bytes and int32 coefficients above 8) */
+static bool h264_pred_host(int bd, int kind, int mode, int n, unsigned need, int lrows, uint8_t *src, ptrdiff_t stride, const uint8_t *topright,
                            int has_tl, int has_tr, int16_t *block)
 {
+    const int px = bd > 8 ? 2 : 1;
     uint8_t st[17 * HP_P] = { 0 };
     uint8_t *o = st + HP_P + 16;
     if (need & 1)
         for (int y = 0; y < lrows; y++)
-            o[y * HP_P - 1] = src[y * stride - 1];
+            memcpy(o + y * HP_P - px, src + y * stride - px, px);
     if (need & 2) {
-        memcpy(o - HP_P, src - stride, n);
+        memcpy(o - HP_P, src - stride, n * px);
         if (kind == FFHIP_H264_PRED8x8L || kind == FFHIP_H264_PRED8x8L_FILTER_ADD) {
             if (has_tr)
-                o[8 - HP_P] = src[8 - stride];
+                memcpy(o + 8 * px - HP_P, src + 8 * px - stride, px);
             if (has_tr && (need & 8))
-                memcpy(o - HP_P + 9, src - stride + 9, 7);
+                memcpy(o - HP_P + 9 * px, src - stride + 9 * px, 7 * px);
         }
     }
     if (need & 4)
-        o[-HP_P - 1] = src[-stride - 1];
+        memcpy(o - HP_P - px, src - stride - px, px);
     if (kind == FFHIP_H264_PRED4x4 && (need & 8))
-        memcpy(o - HP_P + 32, topright, 4); /* wherever the caller's pointer leads, the record addresses the staged copy */
-    const int ncoef = block ? n * n : 0;
-    Arena A(64 + sizeof(st) + 128 + 64);
+        memcpy(o - HP_P + 32, topright, 4 * px); /* wherever the caller's pointer leads, the record addresses the staged copy */
+    const int ncoef = block ? n * n * px : 0; /* in int16 units: int32 coefficients above 8 bits */
+    Arena A(64 + sizeof(st) + 256 + 64);
     if (!A.ok)
         return false;
     uint8_t *buf = A.buf, *dp = buf + 64;
@@ -1167,14 +1169,16 @@ static bool h264_pred_host(int kind, int mode, int n, unsigned need, int lrows, 
         return false;
     if (ncoef && hipMemcpy(dc, block, ncoef * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess)
         return false;
-    if (ffhip_launch_h264_pred(kind, dp, HP_P, dc, (const FFHipH264Pred *)buf, 1, 0) < 0 || !A.down())
+    if (ffhip_launch_h264_pred_bd(bd, kind, dp, HP_P, dc, (const FFHipH264Pred *)buf, 1, 0) < 0 || !A.down())
         return false;
-    commit2d(A, src, stride, dp + HP_P + 16, HP_P, n, n);
+    commit2d(A, src, stride, dp + HP_P + 16, HP_P, (size_t)n * px, n);
     if (ncoef)
         memcpy(block, A.host(dc), ncoef * sizeof(int16_t)); /* cleared by the kernel */
     return true;
 }
-static FFHipH264PredContext g_fb_pred;
+template <int BD> struct PredFb { static FFHipH264PredContext t; };
+template <int BD> FFHipH264PredContext PredFb<BD>::t;
+#define g_fb_pred PredFb<BD>::t
 static constexpr unsigned hp_need4(int mode) { return (unsigned)(0x0211a777a312ull >> (4 * mode)) & 15u; } /* as kernels/h264_pred.hip */
 /* pred8x8 / pred16x16: 0 DC 1 HOR 2 VERT 3 PLANE 4 LEFT_DC 5 TOP_DC 6 DC_128 7 L0T 8 0LT 9 L00 10 0L0 */
 static constexpr unsigned hp_need_blk(int mode)
@@ -1182,79 +1186,95 @@ static constexpr unsigned hp_need_blk(int mode)
     return (mode == 0 || mode == 1 || mode == 3 || mode == 4 || mode >= 7 ? 1u : 0u) |
            (mode == 0 || mode == 2 || mode == 3 || mode == 5 || mode == 7 || mode == 8 ? 2u : 0u) | (mode == 3 ? 4u : 0u);
 }
-template <int MODE>
+template <int BD, int MODE>
 static void s_pred4x4(uint8_t *src, const uint8_t *topright, ptrdiff_t stride)
 {
-    if (!h264_pred_host(FFHIP_H264_PRED4x4, MODE, 4, hp_need4(MODE), 4, src, stride, topright, 0, 0, nullptr))
+    if (!h264_pred_host(BD, FFHIP_H264_PRED4x4, MODE, 4, hp_need4(MODE), 4, src, stride, topright, 0, 0, nullptr))
         SHIM_FB(g_fb_pred, pred4x4[MODE], src, topright, stride);
 }
-template <int MODE>
+template <int BD, int MODE>
 static void s_pred8x8l(uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride)
 {
     constexpr unsigned need = hp_need4(MODE);
     /* the corner is also read by the edge filter when has_topleft (PREDICT_8x8_LOAD_LEFT / _TOP) */
-    if (!h264_pred_host(FFHIP_H264_PRED8x8L, MODE, 8, need | ((has_topleft && (need & 3)) ? 4u : 0u), 8, src, stride, nullptr, has_topleft,
+    if (!h264_pred_host(BD, FFHIP_H264_PRED8x8L, MODE, 8, need | ((has_topleft && (need & 3)) ? 4u : 0u), 8, src, stride, nullptr, has_topleft,
                         has_topright, nullptr))
         SHIM_FB(g_fb_pred, pred8x8l[MODE], src, has_topleft, has_topright, stride);
 }
-template <int MODE>
+template <int BD, int MODE>
 static void s_pred8x8(uint8_t *src, ptrdiff_t stride)
 {
-    if (!h264_pred_host(FFHIP_H264_PRED8x8, MODE, 8, hp_need_blk(MODE), MODE == 7 ? 4 : 8, src, stride, nullptr, 0, 0, nullptr))
+    if (!h264_pred_host(BD, FFHIP_H264_PRED8x8, MODE, 8, hp_need_blk(MODE), MODE == 7 ? 4 : 8, src, stride, nullptr, 0, 0, nullptr))
         SHIM_FB(g_fb_pred, pred8x8[MODE], src, stride);
 }
-template <int MODE>
+template <int BD, int MODE>
 static void s_pred16x16(uint8_t *src, ptrdiff_t stride)
 {
-    if (!h264_pred_host(FFHIP_H264_PRED16x16, MODE, 16, hp_need_blk(MODE), 16, src, stride, nullptr, 0, 0, nullptr))
+    if (!h264_pred_host(BD, FFHIP_H264_PRED16x16, MODE, 16, hp_need_blk(MODE), 16, src, stride, nullptr, 0, 0, nullptr))
         SHIM_FB(g_fb_pred, pred16x16[MODE], src, stride);
 }
-template <int KIND, int N, int MODE>
+template <int BD, int KIND, int N, int MODE>
 static void s_pred_add(uint8_t *pix, int16_t *block, ptrdiff_t stride)
 {
-    if (!h264_pred_host(KIND, MODE, N, MODE == 0 ? 2u : 1u, N, pix, stride, nullptr, 0, 0, block)) {
+    if (!h264_pred_host(BD, KIND, MODE, N, MODE == 0 ? 2u : 1u, N, pix, stride, nullptr, 0, 0, block)) {
         if (KIND == FFHIP_H264_PRED4x4_ADD) SHIM_FB(g_fb_pred, pred4x4_add[MODE], pix, block, stride);
         else                                SHIM_FB(g_fb_pred, pred8x8l_add[MODE], pix, block, stride);
     }
 }
-template <int MODE>
+template <int BD, int MODE>
 static void s_pred8x8l_filter_add(uint8_t *pix, int16_t *block, int has_topleft, int has_topright, ptrdiff_t stride)
 {
-    if (!h264_pred_host(FFHIP_H264_PRED8x8L_FILTER_ADD, MODE, 8, (MODE == 0 ? 2u : 1u) | (has_topleft ? 4u : 0u), 8, pix, stride, nullptr,
+    if (!h264_pred_host(BD, FFHIP_H264_PRED8x8L_FILTER_ADD, MODE, 8, (MODE == 0 ? 2u : 1u) | (has_topleft ? 4u : 0u), 8, pix, stride, nullptr,
                         has_topleft, MODE == 0 ? has_topright : 0, block))
         SHIM_FB(g_fb_pred, pred8x8l_filter_add[MODE], pix, block, has_topleft, has_topright, stride);
 }
 /* pred8x8_add / pred16x16_add walk block_offset[] in the C order, each 4x4 seeing what the previous ones wrote
  * (h264pred_template.c:1262-1330) */
-template <int NB, int MODE8x8>
+template <int BD, int NB, int MODE8x8>
 static void s_pred_mb_add(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
 {
     for (int i = 0; i < NB; i++)
-        s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, MODE8x8 == 2 ? 0 : 1>(pix + block_offset[i], block + i * 16, stride);
+        s_pred_add<BD, FFHIP_H264_PRED4x4_ADD, 4, MODE8x8 == 2 ? 0 : 1>(pix + block_offset[i], block + i * 16 * (BD > 8 ? 2 : 1), stride);
+}
+
+#undef g_fb_pred
+template <int BD>
+static int h264_pred_fill(FFHipH264PredContext *h)
+{
+    FFHipH264PredContext o = *h;
+#define HP(M) o.pred4x4[M] = s_pred4x4<BD, M>; o.pred8x8l[M] = s_pred8x8l<BD, M>;
+    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10) HP(11)
+#undef HP
+#define HP(M) o.pred8x8[M] = s_pred8x8<BD, M>;
+    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10)
+#undef HP
+#define HP(M) o.pred16x16[M] = s_pred16x16<BD, M>;
+    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6)
+#undef HP
+    o.pred4x4_add[0] = s_pred_add<BD, FFHIP_H264_PRED4x4_ADD, 4, 0>;   o.pred4x4_add[1] = s_pred_add<BD, FFHIP_H264_PRED4x4_ADD, 4, 1>;
+    o.pred8x8l_add[0] = s_pred_add<BD, FFHIP_H264_PRED8x8L_ADD, 8, 0>; o.pred8x8l_add[1] = s_pred_add<BD, FFHIP_H264_PRED8x8L_ADD, 8, 1>;
+    o.pred8x8l_filter_add[0] = s_pred8x8l_filter_add<BD, 0>;           o.pred8x8l_filter_add[1] = s_pred8x8l_filter_add<BD, 1>;
+    o.pred8x8_add[2] = s_pred_mb_add<BD, 4, 2>;    o.pred8x8_add[1] = s_pred_mb_add<BD, 4, 1>;
+    o.pred16x16_add[2] = s_pred_mb_add<BD, 16, 2>; o.pred16x16_add[1] = s_pred_mb_add<BD, 16, 1>;
+    fb_snapshot(PredFb<BD>::t, *h, o);
+    *h = o;
+    return 0;
 }
 
 extern "C" int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc)
 {
-    if (!h || codec_id != FFHIP_CODEC_ID_H264 || bit_depth != 8 || chroma_format_idc > 1)
+    /* AV_CODEC_ID_H264 at the depths it defines, 4:2:0 (4:2:2 switches pred8x8 to the 8 x 16 forms, h264pred.c:560-585: those keep C) */
+    if (!h || codec_id != FFHIP_CODEC_ID_H264 || chroma_format_idc > 1)
+        return FFHIP_EINVAL;
+    if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    FFHipH264PredContext o = *h;
-#define HP(M) o.pred4x4[M] = s_pred4x4<M>; o.pred8x8l[M] = s_pred8x8l<M>;
-    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10) HP(11)
-#undef HP
-#define HP(M) o.pred8x8[M] = s_pred8x8<M>;
-    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10)
-#undef HP
-#define HP(M) o.pred16x16[M] = s_pred16x16<M>;
-    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6)
-#undef HP
-    o.pred4x4_add[0] = s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, 0>;   o.pred4x4_add[1] = s_pred_add<FFHIP_H264_PRED4x4_ADD, 4, 1>;
-    o.pred8x8l_add[0] = s_pred_add<FFHIP_H264_PRED8x8L_ADD, 8, 0>; o.pred8x8l_add[1] = s_pred_add<FFHIP_H264_PRED8x8L_ADD, 8, 1>;
-    o.pred8x8l_filter_add[0] = s_pred8x8l_filter_add<0>;           o.pred8x8l_filter_add[1] = s_pred8x8l_filter_add<1>;
-    o.pred8x8_add[2] = s_pred_mb_add<4, 2>;    o.pred8x8_add[1] = s_pred_mb_add<4, 1>;
-    o.pred16x16_add[2] = s_pred_mb_add<16, 2>; o.pred16x16_add[1] = s_pred_mb_add<16, 1>;
-    fb_snapshot(g_fb_pred, *h, o);
-    *h = o;
-    return 0;
+    switch (bit_depth) {
+    case 8:  return h264_pred_fill<8>(h);
+    case 9:  return h264_pred_fill<9>(h);
+    case 10: return h264_pred_fill<10>(h);
+    case 12: return h264_pred_fill<12>(h);
+    default: return h264_pred_fill<14>(h);
+    }
 }

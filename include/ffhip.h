@@ -803,7 +803,9 @@ typedef struct FFHipH264PredContext {
 } FFHipH264PredContext;
 #define FFHIP_CODEC_ID_H264 27 /* AV_CODEC_ID_H264 (libavcodec/codec_id.h:77) */
 /** ff_h264_pred_init_<arch>(H264PredContext *, codec_id, bit_depth, chroma_format_idc) shape (libavcodec/h264pred.h:120-127).
- *  FFHIP_EINVAL for what this library does not replace (other codecs' variants, > 8 bits, 4:2:2): those keep the C pointers. */
+ *  bit_depth 8 / 9 / 10 / 12 / 14 (16-bit samples and int32 coefficients of the _add members above 8; the depth is baked into the
+ *  installed functions).  FFHIP_EINVAL for what this library does not replace (other codecs' variants, 4:2:2's 8 x 16 chroma
+ *  forms): those keep the C pointers. */
 int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc);
 
 #define FFHIP_H264_PRED4x4             0  /* pred4x4[mode]                                 */

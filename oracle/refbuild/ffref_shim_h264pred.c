@@ -13,17 +13,25 @@
 
 static void pure_c(void) { av_force_cpu_flags(0); av_log_set_level(AV_LOG_ERROR); }
 
-/* ---- h264pred: H264PredContext of the H.264 codec, 8 bits, 4:2:0 ---- */
+/* ---- h264pred: H264PredContext of the H.264 codec, 4:2:0, at the depth ffref_h264_pred_set_bit_depth() chose (8 to start with) ---- */
+static H264PredContext pred_ctx;
+static int pred_ready;
 static H264PredContext *h264pred(void)
 {
-    static H264PredContext h;
-    static int ready;
     pure_c();
-    if (!ready) {
-        ff_h264_pred_init(&h, AV_CODEC_ID_H264, 8, 1);
-        ready = 1;
+    if (!pred_ready) {
+        ff_h264_pred_init(&pred_ctx, AV_CODEC_ID_H264, 8, 1);
+        pred_ready = 1;
     }
-    return &h;
+    return &pred_ctx;
+}
+/* 8 / 9 / 10 / 12 / 14: the instantiations of h264pred_template.c (libavcodec/h264pred.c:448-538 per depth); samples are uint16_t and
+ * the _add members' coefficients int32_t above 8 bits */
+void ffref_h264_pred_set_bit_depth(int bit_depth)
+{
+    pure_c();
+    ff_h264_pred_init(&pred_ctx, AV_CODEC_ID_H264, bit_depth, 1);
+    pred_ready = 1;
 }
 void ffref_h264_pred4x4(int mode, uint8_t *src, const uint8_t *topright, ptrdiff_t stride) { h264pred()->pred4x4[mode](src, topright, stride); }
 void ffref_h264_pred8x8l(int mode, uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride)

@@ -139,10 +139,72 @@ def test_h264_pred_host_faces():
 
 
 def test_h264_pred_init_rejects():
-    """what this library does not replace keeps the C pointers: other codecs' variants, > 8 bits, 4:2:2"""
+    """what this library does not replace keeps the C pointers: other codecs' variants, depths H.264 does not define, 4:2:2"""
     from ffmpeg_amd import h264, _lib
     _torch()
     hctx = h264.H264PredContext()
     L = _lib.lib()
-    for args in ((h264.CODEC_ID_H264, 10, 1), (h264.CODEC_ID_H264, 8, 2), (139, 8, 1)):
+    for args in ((h264.CODEC_ID_H264, 11, 1), (h264.CODEC_ID_H264, 8, 2), (h264.CODEC_ID_H264, 10, 2), (139, 8, 1)):
         assert L.ff_h264_pred_init_hip(C.byref(hctx), *args) < 0
+
+
+@pytest.mark.skipif(not ffi.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("depth", [9, 10, 12, 14])
+def test_h264_pred_above_8_bits_matches_the_reference(depth):
+    """the host faces ff_h264_pred_init_hip() installs at 9 / 10 / 12 / 14 bits == the reference's own instantiations of
+    h264pred_template.c at that depth (libavcodec/h264pred.c:448-538; oracle/_ref), every mode of every table, 16-bit samples"""
+    from ffmpeg_amd import h264
+    _torch()
+    R = ffi.ref()
+    R.ffref_h264_pred_set_bit_depth.argtypes = [C.c_int]
+    R.ffref_h264_pred_set_bit_depth(depth)
+    try:
+        hc = h264.pred_init(bit_depth=depth)
+        rng = np.random.default_rng(70 + depth)
+        W = 48
+        stride = W * 2
+
+        def patch(extreme):
+            a = rng.integers(0, 1 << depth, (40, W)).astype(np.uint16)
+            if extreme:
+                a[::3] = rng.choice(np.array([0, (1 << depth) - 1], np.uint16), a[::3].shape)
+            return a
+
+        def at(a, r, c):
+            return C.c_void_p(a.ctypes.data + (r * W + c) * 2)
+        for rep in range(3):
+            for mode in range(12):
+                p0 = patch(rep == 1)
+                a, b = p0.copy(), p0.copy()
+                tr = rng.integers(0, 1 << depth, 8).astype(np.uint16)
+                R.ffref_h264_pred4x4(mode, C.cast(at(a, 8, 16), ffi.u8p), C.cast(tr.ctypes.data, ffi.u8p), stride)
+                hc.pred4x4[mode](at(b, 8, 16), C.c_void_p(tr.ctypes.data), stride)
+                assert np.array_equal(a, b), ("pred4x4", mode)
+                for tl in (0, 1):
+                    for trf in (0, 1):
+                        a, b = p0.copy(), p0.copy()
+                        R.ffref_h264_pred8x8l(mode, C.cast(at(a, 8, 16), ffi.u8p), tl, trf, stride)
+                        hc.pred8x8l[mode](at(b, 8, 16), tl, trf, stride)
+                        assert np.array_equal(a, b), ("pred8x8l", mode, tl, trf)
+            for mode in range(11):
+                p0 = patch(rep == 1)
+                a, b = p0.copy(), p0.copy()
+                R.ffref_h264_pred8x8(mode, C.cast(at(a, 8, 16), ffi.u8p), stride)
+                hc.pred8x8[mode](at(b, 8, 16), stride)
+                assert np.array_equal(a, b), ("pred8x8", mode)
+            for mode in range(7):
+                p0 = patch(rep == 1)
+                a, b = p0.copy(), p0.copy()
+                R.ffref_h264_pred16x16(mode, C.cast(at(a, 8, 16), ffi.u8p), stride)
+                hc.pred16x16[mode](at(b, 8, 16), stride)
+                assert np.array_equal(a, b), ("pred16x16", mode)
+            for mode in (0, 1):                                  # the lossless _add members: int32 coefficients
+                for n, rf, hf in ((4, R.ffref_h264_pred4x4_add, hc.pred4x4_add), (8, R.ffref_h264_pred8x8l_add, hc.pred8x8l_add)):
+                    p0 = patch(rep == 1)
+                    co = rng.integers(-(1 << depth), 1 << depth, n * n).astype(np.int32)
+                    a, b, ca, cb = p0.copy(), p0.copy(), co.copy(), co.copy()
+                    rf(mode, C.cast(at(a, 8, 16), ffi.u8p), C.cast(ca.ctypes.data, ffi.i16p), stride)
+                    hf[mode](at(b, 8, 16), C.c_void_p(cb.ctypes.data), stride)
+                    assert np.array_equal(a, b) and np.array_equal(ca, cb), ("add", n, mode)
+    finally:
+        R.ffref_h264_pred_set_bit_depth(8)
