@@ -140,6 +140,22 @@ extern "C" int ffhip_memcpy_d2h(void *d, const void *s, size_t n)
     HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost));
     return 0;
 }
+/* pitched copies for frame planes (what an hwcontext's transfer_data_to / _from needs): asynchronous on `stream`; the host side
+ * must stay valid until the stream is synchronised (pageable host memory is staged by the runtime) */
+extern "C" int ffhip_memcpy2d_h2d_async(void *d, size_t dpitch, const void *s, size_t spitch, size_t width_bytes, size_t rows, void *stream)
+{
+    if (!d || !s || dpitch < width_bytes || spitch < width_bytes)
+        return FFHIP_EINVAL;
+    HIP_TRY(hipMemcpy2DAsync(d, dpitch, s, spitch, width_bytes, rows, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int ffhip_memcpy2d_d2h_async(void *d, size_t dpitch, const void *s, size_t spitch, size_t width_bytes, size_t rows, void *stream)
+{
+    if (!d || !s || dpitch < width_bytes || spitch < width_bytes)
+        return FFHIP_EINVAL;
+    HIP_TRY(hipMemcpy2DAsync(d, dpitch, s, spitch, width_bytes, rows, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
 extern "C" int ffhip_stream_create(void **stream)
 {
     if (!stream)

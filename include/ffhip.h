@@ -65,6 +65,9 @@ int         ffhip_malloc(void **dev_ptr, size_t bytes);
 int         ffhip_free(void *dev_ptr);
 int         ffhip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int         ffhip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
+/** Pitched plane copies, asynchronous on `stream` (the transfer_data_to / _from of an AVHWFramesContext: integration/avutil_hwcontext_hip.c). */
+int         ffhip_memcpy2d_h2d_async(void *dev_dst, size_t dpitch, const void *host_src, size_t spitch, size_t width_bytes, size_t rows, void *stream);
+int         ffhip_memcpy2d_d2h_async(void *host_dst, size_t dpitch, const void *dev_src, size_t spitch, size_t width_bytes, size_t rows, void *stream);
 /** hipStreamSynchronize; also the point where a row-ordered launch OF THIS STREAM (frame-order deblocking, intra wavefront, VP9
  *  frame loop filter) that timed out on a row hand-off (never in a correct run) is reported: FFHIP_EIO once, ffhip_last_error()
  *  has the text — its picture is only partly processed.  Other streams' pictures are not affected and not reported here. */

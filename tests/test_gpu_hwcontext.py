@@ -1,0 +1,44 @@
+"""The `hip` AVHWDeviceType (integration/avutil_hwcontext_hip.c) through the reference's own generic hwcontext entry points.
+
+oracle/_ref/hwcontext_hip_test (built by oracle/refbuild `make hwcontext` from the reference's libavutil / libswscale objects, its
+hwcontext.c compiled unchanged with the hip type in hw_table[]) creates the device, a frame pool in HBM, uploads a host frame, hands
+AVFrame.data[] / linesize[] of the device frames to ffhip_sws_scale_batch_dev, downloads, and compares with the reference's sws_scale.
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "hwcontext_hip_test")
+
+CASES = [
+    ("640", "360", "1280", "720", "yuv420p", "yuv420p"),
+    ("1920", "1080", "3840", "2160", "yuv420p", "yuv420p"),      # the headline shape, frames resident between upload and download
+    ("1920", "1080", "1280", "720", "nv12", "yuv420p"),
+    ("1280", "720", "1280", "720", "yuv420p", "rgb24"),
+    ("642", "358", "1000", "562", "yuv420p", "bgr24"),
+    ("1920", "1080", "3840", "2160", "p010le", "p010le"),
+    ("960", "540", "1920", "1080", "yuv420p10le", "yuv420p"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(c))
+def test_hwcontext_hip_frames_scaled_in_hbm(case):
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/hwcontext_hip_test not built (needs /root/reference at build time)")
+    r = subprocess.run([EXE, *case], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS hwcontext hip" in r.stdout
+
+
+def test_hwcontext_hip_without_a_device_reports_it():
+    """No device: the program says so and exits 77 (the type is still compiled into hw_table[])."""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/hwcontext_hip_test not built")
+    import ffmpeg_amd._lib as L
+    if L.lib().ffhip_device_count() > 0:
+        pytest.skip("a device is present")
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 77 and "SKIP" in r.stdout
