@@ -49,6 +49,7 @@ struct TxDev {
 struct TxPfa {
     int n1, m, G;              /* complex points per transform (F m), sub-transform size, transforms per wave (G * m = 64; 1 for m >= 64) */
     int F;                     /* the small factor */
+    int fft;                   /* 1: ff_tx_fft_pfa (n1 complex in, n1 complex out, no twiddles) rather than the MDCT around it */
     int magic_q;               /* ceil(2^24 / (n1 / 2)): e / (n1 / 2) == (e * magic) >> 24 for e * n1 / 2 < 2^24 */
     const int *in_map;         /* n1: ((i * F + j) -> k >> 1, the point sub-transform i takes as its j-th input */
     const int *out_map;        /* n1: CRT output map                                                     */
@@ -171,28 +172,41 @@ __device__ __forceinline__ void tx_fft_levels_ahead(float2 *z, const TxDev &d, c
     }
 }
 
-/* in-place split-radix FFT of z[0..n) held in LDS, one wave */
+/* a transform's team: one wave (n <= 2048: the work array is a wave's own, wave-local synchronisation) or, WG, the whole
+ * workgroup on one transform (n = 4096..16384: the work array is the workgroup's LDS, barriers between the levels) */
+template <bool WG>
+__device__ __forceinline__ void tx_team_sync()
+{
+    if (WG)
+        __syncthreads();
+    else
+        tx_wave_sync();
+}
+
+/* in-place split-radix FFT of z[0..n) held in LDS, one team; `lane` is the thread's index in the team */
+template <bool WG = false>
 __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, const float *cos_tab, const uint32_t *sched,
                                            const uint16_t *blocks2, int lane)
 {
-    for (int b = lane; b < d.nblocks2; b += 64) {
+    const int TS = WG ? (int)blockDim.x : 64;
+    for (int b = lane; b < d.nblocks2; b += TS) {
         const int o = blocks2[b];
         const float2 x = z[o], y = z[o + 1];
         z[o] = make_float2(x.x + y.x, x.y + y.y);
         z[o + 1] = make_float2(x.x - y.x, x.y - y.y);
     }
-    if (d.max_cnt <= 128 && d.ahead) {
+    if (!WG && d.max_cnt <= 128 && d.ahead) {
         tx_fft_levels_ahead<2>(z, d, cos_tab, sched, lane);
         tx_wave_sync();
         return;
     }
     for (int l = 2; l <= d.lg; l++) {
-        tx_wave_sync();
+        tx_team_sync<WG>();
         const int q = 1 << (l - 2);
         const int o1 = TX_PAD(q), o2 = TX_PAD(2 * q), o3 = TX_PAD(3 * q);
         const float *tab = cos_tab + d.cos_off[l];
         const uint32_t *sc = sched + d.sched_off[l];
-        for (int b = lane; b < d.sched_cnt[l]; b += 64) {
+        for (int b = lane; b < d.sched_cnt[l]; b += TS) {
             const uint32_t e = sc[b];
             const int a0 = e & 0xFFFF, k = e >> 16;
             float2 v0 = z[a0], v1 = z[a0 + o1], v2 = z[a0 + o2], v3 = z[a0 + o3];
@@ -200,7 +214,7 @@ __device__ __forceinline__ void tx_fft_lds(float2 *z, const TxDev &d, const floa
             z[a0] = v0; z[a0 + o1] = v1; z[a0 + o2] = v2; z[a0 + o3] = v3;
         }
     }
-    tx_wave_sync();
+    tx_team_sync<WG>();
 }
 
 /*
@@ -444,13 +458,15 @@ __global__ __launch_bounds__(256) void k_mdct_l(TxDev d, const uint8_t *blob, in
  * Tables (map, exp, twiddles, butterfly lists) are copied to LDS once per workgroup; waves loop over transforms.
  * Same float operations in the same order as k_mdct.
  */
-template <int INV, bool TL>
+template <int INV, bool TL, bool WG = false>
 __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch,
                                                  float *out, size_t out_pitch, int nt, int waves_total)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
+    /* WG: the workgroup is one team on one transform at a time (`wave` 0, `lane` the thread index, stride the workgroup) */
+    const int wave = WG ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = WG ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const int TS = WG ? (int)blockDim.x : 64;
     /* TL: the context's tables are copied to LDS once per workgroup (blob_bytes > 0); otherwise they stay in global memory
      * (L2-resident) and blob_bytes is 0: large transforms, where the copy would cost the workgroup most of its waves */
     if (TL) {
@@ -469,12 +485,12 @@ __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, i
     const int n = d.n, q = n >> 1;
     float2 *z = reinterpret_cast<float2 *>(lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(n));
 
-    for (int t = blockIdx.x * (blockDim.x >> 6) + wave; t < nt; t += waves_total) {
+    for (int t = WG ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6)) + wave; t < nt; t += WG ? (int)gridDim.x : waves_total) {
         const float2 *in2 = reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
         float2 *out2 = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
         if (!INV) {
             /* ff_tx_mdct_fwd's fold (tx_template.c:1285-1296), elements i (k = 2i < n) and n-1-i (k >= n) together */
-            for (int i = lane; i < q; i += 64) {
+            for (int i = lane; i < q; i += TS) {
                 const float2 p1 = in2[q + i];          /* x[n+2i],   x[n+2i+1]   */
                 const float2 p2 = in2[q - 1 - i];      /* x[n-2-2i], x[n-1-2i]   */
                 const float2 p3 = in2[3 * q + i];      /* x[3n+2i],  x[3n+2i+1]  */
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, i
             }
         } else {
             /* ff_tx_mdct_inv's pre-twiddle (tx_template.c:1321-1328) in input order, elements j and n-1-j together */
-            for (int j = lane; j < q; j += 64) {
+            for (int j = lane; j < q; j += TS) {
                 const float2 f = in2[j];               /* x[2j],      x[2j+1]     */
                 const float2 g = in2[n - 1 - j];       /* x[2n-2-2j], x[2n-1-2j]  */
                 const int j1 = n - 1 - j;
@@ -497,9 +513,9 @@ __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, i
                 z[l_map[j1]] = make_float2(f.y * e1.x - g.x * e1.y, f.y * e1.y + g.x * e1.x);
             }
         }
-        tx_wave_sync();
-        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
-        for (int i = lane; i < q; i += 64) {
+        tx_team_sync<WG>();
+        tx_fft_lds<WG>(z, d, l_cos, l_sched, l_b2, lane);
+        for (int i = lane; i < q; i += TS) {
             const int i0 = q + i, i1 = q - i - 1;
             const float2 e0 = l_exp[i0], e1 = l_exp[i1];
             if (!INV) {
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, i
                 out2[i0] = make_float2(c, b);
             }
         }
-        tx_wave_sync();
+        tx_team_sync<WG>();
     }
 }
 
@@ -526,13 +542,14 @@ __global__ __launch_bounds__(1024) void k_mdct_z(TxDev d, const uint8_t *blob, i
  * permutation into the padded LDS work array, transformed there by the same flattened split-radix network as the MDCT,
  * and written out in order.  Forward and inverse differ by the permutation only.  16 B moved per complex sample.
  */
-template <bool TL>
+template <bool TL, bool WG = false>
 __global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch,
                                                 float *out, size_t out_pitch, int nt, int waves_total)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
+    const int wave = WG ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* WG: as in k_mdct_z */
+    const int lane = WG ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const int TS = WG ? (int)blockDim.x : 64;
     /* TL: the context's tables are copied to LDS once per workgroup (blob_bytes > 0); otherwise they stay in global memory
      * (L2-resident) and blob_bytes is 0: large transforms, where the copy would cost the workgroup most of its waves */
     if (TL) {
@@ -549,16 +566,16 @@ __global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, in
     const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
     const int n = d.n;
     float2 *z = reinterpret_cast<float2 *>(lds_raw + ((blob_bytes + 15) & ~15) + wave * tx_z_bytes(n));
-    for (int t = blockIdx.x * (blockDim.x >> 6) + wave; t < nt; t += waves_total) {
+    for (int t = WG ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6)) + wave; t < nt; t += WG ? (int)gridDim.x : waves_total) {
         const float2 *in2 = reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
         float2 *out2 = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
-        for (int j = lane; j < n; j += 64)
+        for (int j = lane; j < n; j += TS)
             z[l_map[j]] = in2[j];
-        tx_wave_sync();
-        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
-        for (int i = lane; i < n; i += 64)
+        tx_team_sync<WG>();
+        tx_fft_lds<WG>(z, d, l_cos, l_sched, l_b2, lane);
+        for (int i = lane; i < n; i += TS)
             out2[i] = z[TX_PAD(i)];
-        tx_wave_sync();
+        tx_team_sync<WG>();
     }
 }
 
@@ -1027,7 +1044,8 @@ __device__ __forceinline__ void tx_fft_small(const TxTab53 &T, const float2 (&f)
     }
 }
 
-/* C: sub-transforms per lane (1 while m <= 64; 4 covers m = 128 and 256 with G = 1) */
+/* C: sub-transforms per lane (1 while m <= 64; 2 covers m = 128, 4 m = 256, with G = 1).  INV 0 / 1: the forward / inverse MDCT;
+ * 2: the prime-factor FFT alone (ff_tx_fft_pfa, either direction: the maps carry it) */
 template <int INV, int F, int C>
 __global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, const uint8_t *blob, int blob_bytes, const float *in,
                                                    size_t in_pitch, float *out, size_t out_pitch, int nt, int waves_total)
@@ -1058,7 +1076,15 @@ __global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, 
         const int ng = min(G, nt - t0);
         /* 1. fold / pre-twiddle in INPUT order (the value of point k depends on k alone: exp[k >> 1] and the samples around it),
          *    points i and n1-1-i together as in k_mdct_z: coalesced 8-byte loads, every input byte loaded once */
-        for (int e = lane; e < ng * q; e += 64) {
+        if (INV == 2) { /* ff_tx_fft_pfa: the points are the input itself */
+            for (int r = 0; r < ng; r++) {
+                const float2 *in2 = reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)(t0 + r) * in_pitch);
+                float2 *w = z + r * n1;
+                for (int i = lane; i < n1; i += 64)
+                    w[i] = in2[i];
+            }
+        }
+        for (int e = lane; INV != 2 && e < ng * q; e += 64) {
             const int r = (int)(((uint32_t)e * (uint32_t)P.magic_q) >> 24), i = e - r * q, j = n1 - 1 - i;
             const float2 *in2 = reinterpret_cast<const float2 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)(t0 + r) * in_pitch);
             const float2 e0 = l_exp[i], e1 = l_exp[j];
@@ -1106,8 +1132,15 @@ __global__ __launch_bounds__(1024) void k_mdct_pfa(TxDev d, TxPfa P, TxTab53 T, 
         tx_wave_sync();
         /* 3. the F G sub-transforms */
         tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
-        /* 4. post-twiddle */
-        for (int e = lane; e < ng * q; e += 64) {
+        /* 4. post-twiddle (the FFT: the CRT output map alone, tx_template.c:1078-1079) */
+        if (INV == 2) {
+            for (int r = 0; r < ng; r++) {
+                float2 *out2 = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)(t0 + r) * out_pitch);
+                for (int i = lane; i < n1; i += 64)
+                    out2[i] = z[TX_PAD(r * n1 + l_out[i])];
+            }
+        }
+        for (int e = lane; INV != 2 && e < ng * q; e += 64) {
             const int r = (int)(((uint32_t)e * (uint32_t)P.magic_q) >> 24), i = e - r * q;
             const int i0 = q + i, i1 = q - i - 1;
             const float2 z0 = z[TX_PAD(r * n1 + l_out[i0])], z1 = z[TX_PAD(r * n1 + l_out[i1])];
@@ -1209,9 +1242,9 @@ static int mulinv(int n, int m)
 
 /* tables of the 15xM prime-factor MDCT (ff_tx_mdct_pfa_init, libavutil/tx_template.c:1425-1469; ff_tx_gen_compound_mapping with
  * opts == NULL, libavutil/tx.c:75-121; TX_EMBED_INPUT_PFA_MAP, tx_priv.h:275-284; ff_tx_mdct_gen_exp, tx_template.c:2107-2134) */
-static int tx_init_pfa(FFHipTXContext *c, float scale_f, int F)
+static int tx_init_pfa(FFHipTXContext *c, float scale_f, int F, bool is_fft)
 {
-    const int n1 = c->len >> 1, m = n1 / F, G = m < 64 ? 64 / m : 1, inv = c->inv;
+    const int n1 = is_fft ? c->len : c->len >> 1, m = n1 / F, G = m < 64 ? 64 / m : 1, inv = c->inv;
     int lg = 0;
     while ((1 << lg) < m)
         lg++;
@@ -1224,13 +1257,41 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f, int F)
             in_map[j * F + i] = (i * m + j * F) % n1;
             out_map[(i * m * m_inv + j * F * n_inv) % n1] = i * m + j;
         }
-    if (inv)
+    if (is_fft) {
+        /* ff_tx_fft_pfa_init (tx_template.c:1032-1045): the compound map is generated for the forward direction and flattened
+         * through the F-point codelet's own input map, which carries the direction: identity / reversed ACs for 3, 5, 7, 9
+         * (ff_tx_gen_default_map, tx.c:525-542), the 3 x 5 map for 15 (ff_tx_gen_pfa_input_map, tx.c:44-72: for the inverse it is
+         * the scatter form with its ACs reversed) */
+        int fm[15];
+        fm[0] = 0;
+        for (int i = 1; i < F; i++)
+            fm[i] = inv ? F - i : i;
+        if (F == 15) {
+            for (int a = 0; a < 5; a++)
+                for (int b = 0; b < 3; b++) {
+                    if (inv)
+                        fm[(a * 3 + b * 5) % 15] = a * 3 + b;
+                    else
+                        fm[a * 3 + b] = (a * 3 + b * 5) % 15;
+                }
+            if (inv)
+                for (int w = 1; w <= 7; w++)
+                    std::swap(fm[w], fm[15 - w]);
+        }
+        for (int k = 0; k < n1; k += F) {
+            int t[15];
+            memcpy(t, &in_map[k], sizeof(int) * F);
+            for (int i = 0; i < F; i++)
+                in_map[k + i] = t[fm[i]];
+        }
+    }
+    if (inv && !is_fft)
         for (int i = 0; i < m; i++) {
             int *p = &in_map[i * F + 1];
             for (int j = 0; j < (F - 1) >> 1; j++)
                 std::swap(p[j], p[F - j - 2]);
         }
-    if (F == 15) /* the 15-point transform is itself 3 x 5: its input map is embedded (TX_EMBED_INPUT_PFA_MAP) */
+    if (F == 15 && !is_fft) /* the 15-point transform is itself 3 x 5: its input map is embedded (TX_EMBED_INPUT_PFA_MAP) */
         for (int k = 0; k < n1; k += 15) {
             int t[15];
             memcpy(t, &in_map[k], sizeof(t));
@@ -1240,8 +1301,8 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f, int F)
         }
     /* the natural-order table only: the reference's permuted copy for the inverse pre-twiddle is exp[map[i]], i.e. the
      * twiddle of input point k is exp[k >> 1] in both directions */
-    std::vector<float2> ex(n1);
-    {
+    std::vector<float2> ex(is_fft ? 2 : n1); /* an FFT has no twiddle table of its own */
+    if (!is_fft) {
         const double sc = scale_f;
         const double theta = (sc < 0 ? n1 : 0) + 1.0 / 8.0, rt = sqrt(fabs(sc));
         for (int i = 0; i < n1; i++) {
@@ -1298,6 +1359,7 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f, int F)
     TxPfa &P = c->pfa;
     P.n1 = n1; P.m = m; P.G = G; P.F = F;
     P.magic_q = (int)(((1u << 24) + (uint32_t)(n1 / 2) - 1) / (uint32_t)(n1 / 2));
+    P.fft = is_fft;
     P.in_map = (const int *)(base + o_in);
     P.out_map = (const int *)(base + o_out);
     P.sub_map = (const int *)(base + o_sub);
@@ -1355,11 +1417,24 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
             if (len % f2 == 0 && m >= 4 && m <= (factors[i] == 15 ? 64 : 256) && !(m & (m - 1)))
                 pfa_f = factors[i];
         }
+    } else if (type == FFHIP_TX_FLOAT_FFT) {
+        /* F * 2^k complex points, F = 15, 9, 7, 5, 3: av_tx_init's ff_tx_fft_pfa over fft<F>_ns and the 2^k-point split-radix
+         * codelet (libavutil/tx_template.c:948-1101; the odd part of len is the first factor ff_tx_decompose_length offers, so the
+         * tree is the same one).  120 / 240 / 480 / 960 / 1920: the CELT / AAC-960 frame sizes as plain FFTs */
+        static const int factors[5] = { 15, 9, 7, 5, 3 };
+        for (int i = 0; i < 5 && !pfa_f; i++) {
+            const int m = len / factors[i];
+            if (len % factors[i] == 0 && m >= 4 && m <= (factors[i] == 15 ? 128 : 256) && !(m & (m - 1)))
+                pfa_f = factors[i];
+        }
     }
     const bool pfa = pfa_f != 0;
-    if (!pfa && (fft ? (len < 4 || len > 2048 || (len & (len - 1))) : (len < 16 || len > 4096 || (len & (len - 1))))) {
-        ffhip_set_error("ffhip_tx_init: len %d is neither a power of two in %s nor 2 * {3, 5, 7, 9} * 2^k (k = 2..8) nor 2 * 15 * 2^k (k = 2..6)", len,
-                        fft ? "4..2048" : "16..4096");
+    /* powers of two: one wave per transform up to 2048 complex points, the whole workgroup on one transform above that (FFT
+     * 4096..16384, MDCT 8192..32768); the RDFT / DCT kernels are wave-sized */
+    const int fft_max = type == FFHIP_TX_FLOAT_FFT ? 16384 : 2048;
+    if (!pfa && (fft ? (len < 4 || len > fft_max || (len & (len - 1))) : (len < 16 || len > 32768 || (len & (len - 1))))) {
+        ffhip_set_error("ffhip_tx_init: len %d is neither a power of two in %s nor %s{3, 5, 7, 9} * 2^k (k = 2..8) nor %s15 * 2^k (k = 2..%d)", len,
+                        fft ? (fft_max > 2048 ? "4..16384" : "4..2048") : "16..32768", fft ? "" : "2 * ", fft ? "" : "2 * ", fft ? 7 : 6);
         return FFHIP_EINVAL;
     }
     if (!ffhip_have_device())
@@ -1372,7 +1447,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     c->full = type == FFHIP_TX_FLOAT_MDCT && inv && (flags & FFHIP_TX_FULL_IMDCT);
     c->half = half;
     if (pfa) {
-        const int r = tx_init_pfa(c, *scale, pfa_f);
+        const int r = tx_init_pfa(c, *scale, pfa_f, type == FFHIP_TX_FLOAT_FFT);
         if (r < 0) {
             ffhip_tx_uninit(&c);
             return r;
@@ -1530,7 +1605,44 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
                          void *stream)
 {
     const int n = c->d.n;
-    if (c->type == FFHIP_TX_FLOAT_FFT || c->type == FFHIP_TX_FLOAT_RDFT || c->type == FFHIP_TX_FLOAT_DCT) {
+    if (!c->pfa.n1 && n > 2048) {
+        /* 4096..16384 complex points: the work array (33..132 KiB padded) is the workgroup's, the whole workgroup runs each level
+         * (k_fft_z / k_mdct_z with WG); tables stay in L2 */
+        if ((c->type != FFHIP_TX_FLOAT_FFT && stride != (ptrdiff_t)sizeof(float)) || (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7)) {
+            ffhip_set_error("ffhip_tx: transforms above 2048 complex points need contiguous, 8-byte aligned rows");
+            return FFHIP_EINVAL;
+        }
+        const size_t lds_z = tx_z_bytes(n);
+        const int threads = n >= 8192 ? 1024 : 512;
+        int cus = 256, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        int per_cu = (int)((160 * 1024) / (((lds_z + 1279) / 1280) * 1280));
+        if (per_cu * (threads / 64) > 32) per_cu = 32 / (threads / 64);
+        if (per_cu < 1) per_cu = 1;
+        const int blocks = nt < cus * per_cu ? nt : cus * per_cu;
+        static FFHipPerDeviceOnce wg_attr;
+        if (wg_attr.enter()) {
+            (void)hipFuncSetAttribute((const void *)k_fft_z<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_mdct_z<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_mdct_z<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            wg_attr.leave(true);
+        }
+#define TX_LAUNCH_WG(K)                                                                                                               \
+    hipLaunchKernelGGL((K), dim3(blocks), dim3(threads), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev, 0,               \
+                       (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks)
+        if (c->type == FFHIP_TX_FLOAT_FFT)
+            TX_LAUNCH_WG((k_fft_z<false, true>));
+        else if (c->inv)
+            TX_LAUNCH_WG((k_mdct_z<1, false, true>));
+        else
+            TX_LAUNCH_WG((k_mdct_z<0, false, true>));
+#undef TX_LAUNCH_WG
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (!c->pfa.n1 && (c->type == FFHIP_TX_FLOAT_FFT || c->type == FFHIP_TX_FLOAT_RDFT || c->type == FFHIP_TX_FLOAT_DCT)) {
         /* complex in, complex out, contiguous (av_tx's FFT ignores `stride`); 8-byte aligned rows.  RDFT: len reals on one
          * side, len/2 + 1 complex bins on the other */
         if (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7) {
@@ -1607,7 +1719,7 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
     }
     if (c->pfa.n1) {
         const TxPfa &P = c->pfa;
-        if (stride != (ptrdiff_t)sizeof(float) || (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7)) {
+        if ((!P.fft && stride != (ptrdiff_t)sizeof(float)) || (((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7)) {
             ffhip_set_error("ffhip_tx: the prime-factor lengths need contiguous, 8-byte aligned rows");
             return FFHIP_EINVAL;
         }
@@ -1658,15 +1770,20 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
     } while (0)
 #define PFA_F(F_)                                                                                                                          \
     do {                                                                                                                                   \
-        if (c->inv) { if (big) PFA_GO(1, F_, 4); else PFA_GO(1, F_, 1); }                                                                  \
-        else        { if (big) PFA_GO(0, F_, 4); else PFA_GO(0, F_, 1); }                                                                  \
+        if (P.fft)       { if (big) PFA_GO(2, F_, 4); else PFA_GO(2, F_, 1); }                                                             \
+        else if (c->inv) { if (big) PFA_GO(1, F_, 4); else PFA_GO(1, F_, 1); }                                                             \
+        else             { if (big) PFA_GO(0, F_, 4); else PFA_GO(0, F_, 1); }                                                             \
     } while (0)
         switch (P.F) {
         case 3:  PFA_F(3); break;
         case 5:  PFA_F(5); break;
         case 7:  PFA_F(7); break;
         case 9:  PFA_F(9); break;
-        default: if (c->inv) PFA_GO(1, 15, 1); else PFA_GO(0, 15, 1); break;
+        default:
+            if (P.fft) { if (big) PFA_GO(2, 15, 2); else PFA_GO(2, 15, 1); }
+            else if (c->inv) PFA_GO(1, 15, 1);
+            else PFA_GO(0, 15, 1);
+            break;
         }
 #undef PFA_F
 #undef PFA_GO

@@ -1289,10 +1289,12 @@ typedef struct FFHipTXContext FFHipTXContext;
 typedef void (*ffhip_tx_fn)(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
 /**
  * Same argument meaning as av_tx_init() (libavutil/tx.h:169-172, libavutil/tx.c:903): type, inv,
- * len (MDCT: number of output coefficients of the forward transform, power of two 16..4096 or one of the prime-factor
+ * len (MDCT: number of output coefficients of the forward transform, power of two 16..32768 (above 4096: contiguous 8-byte aligned
+ * rows, one workgroup per transform) or one of the prime-factor
  * lengths 2 * 15 * 2^k, k = 2..6 = 120 / 240 / 480 / 960 / 1920 (CELT, AAC-960) and 2 * F * 2^k, F = 3 / 5 / 7 / 9, k = 2..8 (96- and
  * 768-sample AAC frames, Siren's 320, ...): ff_tx_mdct_pfa_<F>xM, libavutil/tx_template.c:1425-1600 — their batches must be
- * contiguous 8-byte aligned rows); FFT: number of complex samples, power of two 4..2048; RDFT: number of real samples,
+ * contiguous 8-byte aligned rows); FFT: number of complex samples, power of two 4..16384 or F * 2^k for F = 3 / 5 / 7 / 9 (k = 2..8) and
+ * 15 (k = 2..7: 60 .. 1920) — ff_tx_fft_pfa over fft<F>_ns, libavutil/tx_template.c:948-1101; RDFT: number of real samples,
  * power of two 8..4096 — forward (r2c) reads len floats and writes len/2 + 1 complex bins, inverse (c2r) the other way round,
  * ff_tx_rdft_r2c / _c2r, libavutil/tx_template.c:1601-1716), *scale (FFT: ignored, may be NULL).  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
  * (libavutil/tx_priv.h:199-237).  *fn receives the single-transform host-pointer shim.

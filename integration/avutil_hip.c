@@ -83,8 +83,14 @@ static void hip_tx(AVTXContext *s, void *out, void *in, ptrdiff_t stride) /* av_
         .factors = { F0, F1 }, .nb_factors = NF, .min_len = MIN, .max_len = MAX, .init = hip_tx_init, .uninit = hip_tx_uninit, \
         .cpu_flags = AV_CPU_FLAG_HIP, .prio = FF_TX_PRIO_MAX, /* "custom implementations/ASICs", tx_priv.h:168 */               \
     }
-HIP_CODELET(ff_tx_fft_float_hip_def,       AV_TX_FLOAT_FFT,  0, 2, 0, 1, 4, 2048);
-HIP_CODELET(ff_tx_mdct_float_hip_def,      AV_TX_FLOAT_MDCT, 0, 2, 0, 1, 16, 4096);
+HIP_CODELET(ff_tx_fft_float_hip_def,       AV_TX_FLOAT_FFT,  0, 2, 0, 1, 4, 16384);
+HIP_CODELET(ff_tx_mdct_float_hip_def,      AV_TX_FLOAT_MDCT, 0, 2, 0, 1, 16, 32768);
+/* the prime-factor FFT lengths F x 2^k (ff_tx_fft_pfa over fft<F>_ns, tx_template.c:948-1101): 120 / 240 / 480 / 960 / 1920 ... */
+HIP_CODELET(ff_tx_fft_pfa_15_float_hip_def, AV_TX_FLOAT_FFT, 0, 15, 2, 2, 60, 1920);
+HIP_CODELET(ff_tx_fft_pfa_3_float_hip_def,  AV_TX_FLOAT_FFT, 0, 3, 2, 2, 12, 768);
+HIP_CODELET(ff_tx_fft_pfa_5_float_hip_def,  AV_TX_FLOAT_FFT, 0, 5, 2, 2, 20, 1280);
+HIP_CODELET(ff_tx_fft_pfa_7_float_hip_def,  AV_TX_FLOAT_FFT, 0, 7, 2, 2, 28, 1792);
+HIP_CODELET(ff_tx_fft_pfa_9_float_hip_def,  AV_TX_FLOAT_FFT, 0, 9, 2, 2, 36, 2304);
 /* the prime-factor MDCT lengths F x 2^k (ff_tx_mdct_pfa_<F>xM, tx_template.c:1425-1600): CELT 120..960, AAC-960 / -768, ... */
 HIP_CODELET(ff_tx_mdct_pfa_15_float_hip_def, AV_TX_FLOAT_MDCT, 0, 15, 2, 2, 120, 1920);
 HIP_CODELET(ff_tx_mdct_pfa_3_float_hip_def,  AV_TX_FLOAT_MDCT, 0, 3, 2, 2, 24, 1536);
@@ -96,7 +102,8 @@ HIP_CODELET(ff_tx_dctII_float_hip_def,     AV_TX_FLOAT_DCT,  FF_TX_FORWARD_ONLY,
 HIP_CODELET(ff_tx_dctIII_float_hip_def,    AV_TX_FLOAT_DCT,  FF_TX_INVERSE_ONLY, 2, TX_FACTOR_ANY, 2, 8, 4096);
 
 const FFTXCodelet * const ff_tx_codelet_list_float_hip[] = {
-    &ff_tx_fft_float_hip_def, &ff_tx_mdct_float_hip_def, &ff_tx_mdct_pfa_15_float_hip_def, &ff_tx_mdct_pfa_3_float_hip_def,
+    &ff_tx_fft_float_hip_def, &ff_tx_fft_pfa_15_float_hip_def, &ff_tx_fft_pfa_3_float_hip_def, &ff_tx_fft_pfa_5_float_hip_def,
+    &ff_tx_fft_pfa_7_float_hip_def, &ff_tx_fft_pfa_9_float_hip_def, &ff_tx_mdct_float_hip_def, &ff_tx_mdct_pfa_15_float_hip_def, &ff_tx_mdct_pfa_3_float_hip_def,
     &ff_tx_mdct_pfa_5_float_hip_def, &ff_tx_mdct_pfa_7_float_hip_def, &ff_tx_mdct_pfa_9_float_hip_def, &ff_tx_rdft_float_hip_def,
     &ff_tx_dctII_float_hip_def, &ff_tx_dctIII_float_hip_def, NULL,
 };

@@ -208,7 +208,8 @@ void   ffo_mdct_run(const FfoTx *s, float *out, const float *in, ptrdiff_t strid
 void   ffo_mdct_free(FfoTx *s);
 /* AV_TX_FLOAT_FFT, power-of-two len: complex (re, im) floats in and out */
 void   ffo_imdct_full_run(const FfoTx *s, float *out, const float *in); /* AV_TX_FULL_IMDCT: 2 * len outputs */
-void   ffo_fft_run(int inv, int len, float *out, const float *in);
+void   ffo_fft_run(int inv, int len, float *out, const float *in);       /* ... or F * 2^k, F = 3 / 5 / 7 / 9 / 15 (ff_tx_fft_pfa) */
+int    ffo_fft_pfa_factor(int len);                                      /* the F of such a length, 0 for none */
 /* AV_TX_FLOAT_RDFT, power-of-two: inv == 0: in = len reals, out = len/2 + 1 complex; inv == 1: the other way round */
 void   ffo_rdft_run(int inv, int len, float scale, float *out, const float *in);
 /* mode 1: AV_TX_REAL_TO_REAL (len/2 + 1 floats out), 2: AV_TX_REAL_TO_IMAGINARY (len/2 floats out); forward, len a power of two >= 8 */

@@ -605,8 +605,76 @@ static void pfa_run(const FfoTx *s, float *out, const float *in, ptrdiff_t strid
  * "no shuffle" split-radix network the MDCT uses; the inverse differs by the permutation only.  Complex interleaved
  * (re, im) floats in and out, len of each; unnormalised.
  */
+/*
+ * AV_TX_FLOAT_FFT, len = F * 2^k with F = 15 / 9 / 7 / 5 / 3: ff_tx_fft_pfa over fft<F>_ns and the 2^k-point split-radix codelet
+ * (libavutil/tx_template.c:948-1080; the tree av_tx_init builds for these lengths, e.g. 960 = fft15_ns x fft64_ns).  The compound
+ * map is generated for the forward direction (ff_tx_gen_compound_mapping(s, opts, 0, n, m), :1032) and its input half flattened
+ * through the F-point codelet's own map (:1041-1045), which carries the direction: ff_tx_gen_default_map (tx.c:525-542) for
+ * 3 / 5 / 7 / 9, ff_tx_gen_pfa_input_map(3, 5) (tx.c:44-72) for 15.
+ */
+int ffo_fft_pfa_factor(int len)
+{
+    static const int f[5] = { 15, 9, 7, 5, 3 };
+    for (int i = 0; i < 5; i++) {
+        const int m = len / f[i];
+        if (len % f[i] == 0 && m >= 4 && !(m & (m - 1)))
+            return f[i];
+    }
+    return 0;
+}
+
+static void fft_pfa_run(int inv, int len, int F, float *out, const float *in)
+{
+    FfoTx *s = pfa_create(inv, 2 * len, F, 1.0f); /* the MDCT of twice the length shares the tables (cos, tab53 / 7 / 9, sub_map, out_map) */
+    const int m = len / F;
+    int *in_map = malloc(sizeof(int) * len), fm[15];
+    const int *out_map = s->map + len;
+    const cpx *src = (const cpx *)in;
+    cpx *dst = (cpx *)out, *tmp = malloc(sizeof(cpx) * len), f[15];
+    int lg = 0;
+    while ((1 << lg) < m)
+        lg++;
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < F; i++)
+            in_map[j * F + i] = (i * m + j * F) % len;
+    fm[0] = 0;
+    for (int i = 1; i < F; i++)
+        fm[i] = inv ? F - i : i;
+    if (F == 15) {
+        for (int a = 0; a < 5; a++)
+            for (int b = 0; b < 3; b++) {
+                if (inv)
+                    fm[(a * 3 + b * 5) % 15] = a * 3 + b;
+                else
+                    fm[a * 3 + b] = (a * 3 + b * 5) % 15;
+            }
+        if (inv)
+            for (int w = 1; w <= 7; w++) {
+                const int t = fm[w];
+                fm[w] = fm[15 - w];
+                fm[15 - w] = t;
+            }
+    }
+    for (int i = 0; i < m; i++) {
+        for (int j = 0; j < F; j++)
+            f[j] = src[in_map[i * F + fm[j]]];
+        fft_small(s, tmp + s->sub_map[i], f, m);
+    }
+    for (int i = 0; i < F; i++)
+        sr_fft(s, tmp + m * i, m, lg);
+    for (int i = 0; i < len; i++)
+        dst[i] = tmp[out_map[i]];
+    free(tmp);
+    free(in_map);
+    ffo_mdct_free(s);
+}
+
 void ffo_fft_run(int inv, int len, float *out, const float *in)
 {
+    if (ffo_fft_pfa_factor(len)) {
+        fft_pfa_run(inv, len, ffo_fft_pfa_factor(len), out, in);
+        return;
+    }
     struct FfoTx s;
     memset(&s, 0, sizeof(s));
     int lg = 0;

@@ -228,6 +228,8 @@ def oracle():
         L.ffo_me_esa_frame.restype = None
         L.ffo_mdct_create.argtypes = [C.c_int, C.c_int, C.c_float]
         L.ffo_mdct_create.restype = C.c_void_p
+        L.ffo_fft_pfa_factor.argtypes = [C.c_int]
+        L.ffo_fft_pfa_factor.restype = C.c_int
         L.ffo_mdct_pfa_factor.argtypes = [C.c_int]
         L.ffo_mdct_pfa_factor.restype = C.c_int
         L.ffo_mdct_run.argtypes = [C.c_void_p, f32p, f32p, C.c_ssize_t]

@@ -152,13 +152,16 @@ def test_mdct_aac_batch_property():
 
 
 @pytest.mark.parametrize("inv", [0, 1])
-@pytest.mark.parametrize("len_", [4, 8, 32, 256, 1024, 2048])
+@pytest.mark.parametrize("len_", [4, 8, 32, 256, 1024, 2048, 4096, 8192, 16384] + [f * m for f in (3, 5, 7, 9) for m in (4, 32, 64, 128, 256)] +
+                         [15 * m for m in (4, 8, 16, 32, 64, 128)])
 def test_fft_batch(len_, inv):
-    """AV_TX_FLOAT_FFT, power-of-two: bit-identical to the oracle (= the reference); the host-pointer face too"""
+    """AV_TX_FLOAT_FFT: bit-identical to the oracle (= the reference); the host-pointer face too.  Powers of two up to 2048 run one
+    wave per transform, 4096..16384 one workgroup per transform (more transforms than resident workgroups: nt 700 at 4096);
+    F * 2^k (120 / 960 / 1920 ...) the prime-factor kernel"""
     from ffmpeg_amd import tx
     torch = _torch()
     rng = np.random.default_rng(len_ * 2 + inv)
-    nt = 3000 if len_ == 1024 else 41
+    nt = 3000 if len_ in (1024, 960) else 700 if len_ == 4096 else 300 if len_ == 16384 else 41
     x = (rng.standard_normal((nt, 2 * len_)) * 10.0 ** rng.integers(-3, 4, (nt, 1))).astype(np.float32)
     x[1] = 0
     want = np.zeros_like(x)
@@ -235,6 +238,44 @@ def test_mdct_pfa_3579_batch(f, m, nt, inv):
     ctx.fn(o1, inp[nt - 1])
     _check(o1[None], want[nt - 1:nt])
     ctx.close()
+
+
+@pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("len_,scale,nt", [(8192, 1.0, 600), (16384, 1.0 / 16384, 37), (32768, -1.0, 300)])
+def test_mdct_big_batch(inv, len_, scale, nt):
+    """MDCT 8192..32768 (4096..16384 complex points): one workgroup per transform, the work array in its LDS; bit-identical"""
+    from ffmpeg_amd import tx
+    torch = _torch()
+    rng = np.random.default_rng(len_ + inv)
+    n_in = len_ if inv else 2 * len_
+    inp = (rng.random((nt, n_in), dtype=np.float32) * 2 - 1).astype(np.float32)
+    inp[1] = 0
+    want = _oracle(inv, len_, scale, inp[:9])
+    ctx = tx.TxContext(tx.FLOAT_MDCT, inv, len_, scale)
+    d_in = torch.from_numpy(inp).cuda()
+    d_out = torch.zeros((nt, len_ + 6), dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out[:, :len_], d_in)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    _check(np.ascontiguousarray(got[:9, :len_]), want)
+    assert not got[:, len_:].any()
+    # the rest of the batch: rows beyond the workgroups' first pass equal a second run of the same rows at the front of a batch
+    d_out2 = torch.zeros((9, len_), dtype=torch.float32, device="cuda:0")
+    ctx.batch(d_out2, d_in[nt - 9:].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(d_out2, d_out[nt - 9:, :len_])
+    _check(d_out2[-1:].cpu().numpy(), _oracle(inv, len_, scale, inp[nt - 1:]))
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ctx.batch(torch.zeros((2, 2 * len_), dtype=torch.float32, device="cuda:0"), d_in[:2], stride=8)
+    ctx.close()
+
+
+def test_fft_unsupported_lengths():
+    from ffmpeg_amd import tx
+    _torch()
+    for len_ in (15 * 256, 3 * 512, 11 * 16, 3 * 2, 45 * 4, 32768, 2):
+        with pytest.raises(RuntimeError):
+            tx.TxContext(tx.FLOAT_FFT, 0, len_, 1.0)
 
 
 def test_mdct_pfa_unsupported_lengths():

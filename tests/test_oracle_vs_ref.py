@@ -995,7 +995,7 @@ def test_me_search_esa(R_):
             assert c1 == c2 and np.array_equal(m1, m2)
 
 
-@pytest.mark.parametrize("len_", [16, 64, 256, 1024, 2048, 120, 240, 480, 960, 1920])
+@pytest.mark.parametrize("len_", [16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 120, 240, 480, 960, 1920])
 @pytest.mark.parametrize("inv", [0, 1])
 def test_mdct_float(len_, inv):
     """The restated split-radix recursion (and, for 2 * 15 * 2^k, the 15xM prime-factor codelet: Opus / AAC-960 sizes) reproduces
@@ -1042,9 +1042,12 @@ def test_mdct_float_pfa_3579(len_, inv):
 
 
 @pytest.mark.parametrize("inv", [0, 1])
-@pytest.mark.parametrize("len_", [4, 8, 16, 64, 256, 1024, 2048, 4096])
+@pytest.mark.parametrize("len_", [4, 8, 16, 64, 256, 1024, 2048, 4096, 8192, 16384] +
+                         [f * m for f in (3, 5, 7, 9) for m in (4, 16, 64, 128, 256)] + [15 * m for m in (4, 8, 16, 32, 64, 128)])
 def test_fft_float(len_, inv):
-    """AV_TX_FLOAT_FFT power-of-two, both directions: bit-identical (tests/checkasm/av_tx.c compares to 5e-4 only)"""
+    """AV_TX_FLOAT_FFT, both directions: bit-identical (tests/checkasm/av_tx.c compares to 5e-4 only).  Powers of two (the split-radix
+    codelets) and F * 2^k, F = 3 / 5 / 7 / 9 / 15: the ff_tx_fft_pfa tree av_tx_init builds for them (120 / 960 / 1920 = fft15_ns x
+    fft8 / 64 / 128_ns)"""
     R, O = ffi.ref(), ffi.oracle()
     rc = R.ffref_tx_create(0, inv, len_, 1.0, 0)
     assert rc
