@@ -342,6 +342,25 @@ def extras(torch, dev):
                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "transforms": nt, "ms": round(ms, 4)}
         f.close()
         del tin, tout
+    # the av_tx tails: complex FFTs of 960 (fft15 x fft64, the prime-factor kernel) and 16384 points (one workgroup per transform): 16 B per point
+    for ln, nt, key in ((960, 32768, "fft960_pfa"), (16384, 4096, "fft16384")):
+        f = tx.TxContext(tx.FLOAT_FFT, 0, ln, 1.0)
+        tin = torch.rand((nt, 2 * ln), dtype=torch.float32, device=dev)
+        tout = torch.empty((nt, 2 * ln), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            f.batch(tout, tin)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(5):
+            f.batch(tout, tin)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        gbs = nt * ln * 16 / (ms * 1e-3) / 1e9
+        out[key] = {"Mtransforms/s": round(nt / (ms * 1e-3) / 1e6, 3), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "transforms": nt, "ms": round(ms, 4)}
+        f.close()
+        del tin, tout
     # exhaustive SAD search, 16x16 blocks, R = 7, 8 pairs of 3840x2160 luma planes (BASELINE configs[4] shape)
     nf, w, h = 8, 3840, 2160
     cur = torch.randint(0, 256, (nf, h, w), dtype=torch.uint8, device=dev)

@@ -89,6 +89,7 @@ def lib():
         "ffhip_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
         "ffhip_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
         "ffhip_stream_synchronize": (C.c_int, [vp]),
+        "ffhip_pointer_device": (C.c_int, [vp]),
         "ffhip_memcpy2d_h2d_async": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]),
         "ffhip_memcpy2d_d2h_async": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]),
         "ffhip_sws_getContext": (vp, [C.c_int] * 7),

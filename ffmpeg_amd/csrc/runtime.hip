@@ -140,6 +140,18 @@ extern "C" int ffhip_memcpy_d2h(void *d, const void *s, size_t n)
     HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost));
     return 0;
 }
+/* which device an address lives on: the ordinal for device memory, FFHIP_EINVAL for host (or unknown) memory.  What a caller that is
+ * handed pointers by a framework (an SwsPass of hardware frames) checks before it launches on them */
+extern "C" int ffhip_pointer_device(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return FFHIP_EINVAL;
+    }
+    return a.type == hipMemoryTypeDevice ? a.device : FFHIP_EINVAL;
+}
+
 /* pitched copies for frame planes (what an hwcontext's transfer_data_to / _from needs): asynchronous on `stream`; the host side
  * must stay valid until the stream is synchronised (pageable host memory is staged by the runtime) */
 extern "C" int ffhip_memcpy2d_h2d_async(void *d, size_t dpitch, const void *s, size_t spitch, size_t width_bytes, size_t rows, void *stream)

@@ -65,6 +65,8 @@ int         ffhip_malloc(void **dev_ptr, size_t bytes);
 int         ffhip_free(void *dev_ptr);
 int         ffhip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
 int         ffhip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
+/** The device ordinal `p` lives on, or FFHIP_EINVAL for host / unknown memory. */
+int         ffhip_pointer_device(const void *p);
 /** Pitched plane copies, asynchronous on `stream` (the transfer_data_to / _from of an AVHWFramesContext: integration/avutil_hwcontext_hip.c). */
 int         ffhip_memcpy2d_h2d_async(void *dev_dst, size_t dpitch, const void *host_src, size_t spitch, size_t width_bytes, size_t rows, void *stream);
 int         ffhip_memcpy2d_d2h_async(void *host_dst, size_t dpitch, const void *dev_src, size_t spitch, size_t width_bytes, size_t rows, void *stream);

@@ -49,9 +49,117 @@ static AVFrame *host_frame(enum AVPixelFormat fmt, int w, int h)
     return av_frame_get_buffer(f, 0) < 0 ? NULL : f;
 }
 
+long ffhip_integration_hw_launches(void);
+long ffhip_integration_hw_refused(void);
+
+static void fill_frame(AVFrame *f, enum AVPixelFormat fmt, int w, int h, AVLFG *lfg)
+{
+    const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(fmt);
+    const int np = av_pix_fmt_count_planes(fmt);
+    for (int p = 0; p < np; p++) {
+        const int rows = (p == 1 || p == 2) ? AV_CEIL_RSHIFT(h, d->log2_chroma_h) : h;
+        const int bw = av_image_get_linesize(fmt, w, p);
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < bw; x++)
+                f->data[p][y * f->linesize[p] + x] = av_lfg_get(lfg) >> 24;
+        if (d->comp[0].depth > 8 && !(d->flags & AV_PIX_FMT_FLAG_FLOAT))
+            for (int y = 0; y < rows; y++)
+                for (int x = 0; x < bw / 2; x++) {
+                    uint16_t *s = (uint16_t *)(f->data[p] + y * f->linesize[p]) + x;
+                    *s = (*s & ((1 << d->comp[0].depth) - 1)) << d->comp[0].shift;
+                }
+    }
+}
+
+static int rows_differ(const AVFrame *a, const AVFrame *b, enum AVPixelFormat fmt, int w, int h)
+{
+    const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(fmt);
+    int bad = 0;
+    for (int p = 0; p < av_pix_fmt_count_planes(fmt); p++) {
+        const int rows = (p == 1 || p == 2) ? AV_CEIL_RSHIFT(h, d->log2_chroma_h) : h;
+        const int bw = av_image_get_linesize(fmt, w, p);
+        for (int y = 0; y < rows; y++)
+            bad += !!memcmp(a->data[p] + y * a->linesize[p], b->data[p] + y * b->linesize[p], bw);
+    }
+    return bad;
+}
+
+/*
+ * `graph` mode: sws_scale_frame() of the reference's new API on two frames of the hip device — ff_fmt_from_frame sees the hardware
+ * format (format.c:351-357), the graph offers its op lists to the backend whose hw_format matches (ops_dispatch.c:113-117: the
+ * hip_hw backend of integration/swscale_hw_hip.c), op_pass_run calls it with the device pointers — against the same call on host
+ * frames with the C backend.  usage: hwcontext_hip_test graph srcfmt dstfmt w h [dw dh]
+ */
+static int graph_main(int argc, char **argv)
+{
+    const enum AVPixelFormat sf = av_get_pix_fmt(argv[2]), df = av_get_pix_fmt(argv[3]);
+    const int sw = atoi(argv[4]), sh = atoi(argv[5]), dw = argc > 7 ? atoi(argv[6]) : sw, dh = argc > 7 ? atoi(argv[7]) : sh;
+    AVBufferRef *dev = NULL, *sfc, *dfc;
+    AVFrame *hs, *hd, *href, *ds = av_frame_alloc(), *dd = av_frame_alloc();
+    SwsContext *g = sws_alloc_context(), *r = sws_alloc_context();
+    AVLFG lfg;
+    long before;
+    int ret, bad;
+    if (sf == AV_PIX_FMT_NONE || df == AV_PIX_FMT_NONE)
+        return 2;
+    if (ffhip_device_count() <= 0) {
+        printf("SKIP no HIP device\n");
+        return 77;
+    }
+    CHECK(av_hwdevice_ctx_create(&dev, FFHIP_HWDEVICE_TYPE, "0", NULL, 0));
+    sfc = frames_ctx(dev, sf, sw, sh);
+    dfc = frames_ctx(dev, df, dw, dh);
+    if (!sfc || !dfc) {
+        fprintf(stderr, "FAIL frames context\n");
+        return 1;
+    }
+    hs = host_frame(sf, sw, sh);
+    hd = host_frame(df, dw, dh);
+    href = host_frame(df, dw, dh);
+    av_lfg_init(&lfg, 0x5eed + sw);
+    fill_frame(hs, sf, sw, sh, &lfg);
+    CHECK(av_hwframe_get_buffer(sfc, ds, 0));
+    CHECK(av_hwframe_get_buffer(dfc, dd, 0));
+    CHECK(av_hwframe_transfer_data(ds, hs, 0));
+    g->flags = r->flags = SWS_BICUBIC | SWS_BITEXACT | SWS_ACCURATE_RND;
+    g->threads = r->threads = 1;
+    g->backends = SWS_BACKEND_C | 1 << 6; /* SWS_BACKEND_HIP; _C carries the format tests (the patch adds the new bit to
+                                           * SWS_BACKEND_UNSTABLE, format.c:602-609) and is never offered hardware frames */
+    r->backends = SWS_BACKEND_C;
+    before = ffhip_integration_hw_launches();
+    if ((ret = sws_scale_frame(g, dd, ds)) < 0) {
+        fprintf(stderr, "FAIL sws_scale_frame on hip frames: %d (%s)\n", ret, ffhip_last_error());
+        return 1;
+    }
+    if (ffhip_integration_hw_refused()) {
+        printf("REFUSED multi-pass conversion (host-memory intermediate): %s -> %s\n", argv[2], argv[3]);
+        return 3;
+    }
+    if (ffhip_integration_hw_launches() == before) {
+        fprintf(stderr, "FAIL the hip_hw backend did not run\n");
+        return 1;
+    }
+    CHECK(av_hwframe_transfer_data(hd, dd, 0));
+    if ((ret = sws_scale_frame(r, href, hs)) < 0) {
+        fprintf(stderr, "FAIL reference sws_scale_frame: %d\n", ret);
+        return 1;
+    }
+    if ((bad = rows_differ(hd, href, df, dw, dh))) {
+        fprintf(stderr, "FAIL %d rows differ from backend_c\n", bad);
+        return 1;
+    }
+    printf("PASS sws_scale_frame on hip frames: %s %dx%d -> %s %dx%d in HBM (%ld launches), bit-exact with backend_c\n", argv[2], sw, sh, argv[3], dw, dh,
+           ffhip_integration_hw_launches() - before);
+    sws_free_context(&g);
+    sws_free_context(&r);
+    av_frame_free(&hs); av_frame_free(&hd); av_frame_free(&href); av_frame_free(&ds); av_frame_free(&dd);
+    av_buffer_unref(&sfc); av_buffer_unref(&dfc); av_buffer_unref(&dev);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    const int sw = argc > 4 ? atoi(argv[1]) : 640, sh = argc > 4 ? atoi(argv[2]) : 360;
+    const int sw = argc > 4 && strcmp(argv[1], "graph") ? atoi(argv[1]) : 640, sh = argc > 4 ? atoi(argv[2]) : 360;
     const int dw = argc > 4 ? atoi(argv[3]) : 1280, dh = argc > 4 ? atoi(argv[4]) : 720;
     const enum AVPixelFormat sf = argc > 6 ? av_get_pix_fmt(argv[5]) : AV_PIX_FMT_YUV420P, df = argc > 6 ? av_get_pix_fmt(argv[6]) : AV_PIX_FMT_YUV420P;
     const int flags = SWS_BICUBIC | SWS_BITEXACT | SWS_ACCURATE_RND;
@@ -68,6 +176,8 @@ int main(int argc, char **argv)
     size_t zero[4] = { 0 };
     int bad = 0, nplanes;
 
+    if (argc > 5 && !strcmp(argv[1], "graph"))
+        return graph_main(argc, argv);
     if (sf == AV_PIX_FMT_NONE || df == AV_PIX_FMT_NONE) {
         fprintf(stderr, "unknown pixel format\n");
         return 2;

@@ -33,6 +33,36 @@ def test_hwcontext_hip_frames_scaled_in_hbm(case):
     assert "PASS hwcontext hip" in r.stdout
 
 
+GRAPH_OK = [("rgb24", "bgr24", "640", "360"), ("rgba", "rgb24", "641", "359"), ("yuv444p", "rgb24", "640", "360"), ("rgb24", "yuv444p", "640", "360"),
+            ("yuv444p10le", "yuv444p", "640", "360"), ("yuv444p", "yuv444p16le", "640", "360"), ("bgr0", "rgb24", "1920", "1080"),
+            ("yuv444p", "yuv444p", "640", "360", "1280", "360"), ("yuv444p", "yuv444p", "640", "360", "640", "720")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GRAPH_OK, ids=lambda c: "-".join(c))
+def test_sws_scale_frame_on_hip_frames(case):
+    """sws_scale_frame() of the reference's new API on two frames of the hip device: its graph offers the op list to the backend whose
+    hw_format matches (integration/swscale_hw_hip.c), op_pass_run hands it AVFrame.data[] = device pointers, the conversion runs in
+    HBM; the downloaded result equals the same call on host frames with backend_c.  Format conversions and one-dimensional scaling
+    are single passes."""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/hwcontext_hip_test not built")
+    r = subprocess.run([EXE, "graph", *case], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS sws_scale_frame on hip frames" in r.stdout and "bit-exact with backend_c" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sws_scale_frame_multi_pass_is_refused_not_faulted():
+    """Two-dimensional scaling is two passes with an intermediate frame the reference's graph allocates in host memory for every
+    device type but Vulkan (graph.c:130-175): the hip backend refuses the pass (exit 3, logged) instead of launching on a host
+    pointer."""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/hwcontext_hip_test not built")
+    r = subprocess.run([EXE, "graph", "yuv444p", "yuv444p", "640", "360", "960", "540"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and "REFUSED" in r.stdout, r.stdout + r.stderr
+
+
 def test_hwcontext_hip_without_a_device_reports_it():
     """No device: the program says so and exits 77 (the type is still compiled into hw_table[])."""
     if not os.path.exists(EXE):
