@@ -216,12 +216,16 @@ __device__ __forceinline__ void qp_fetch(const QpBlk &q, ptrdiff_t stride, int l
     }
 }
 
-__device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t f[3], uint32_t *raw, uint32_t *hb, uint8_t *dst, ptrdiff_t stride, int lane)
+/* raw: the footprint as aligned dwords, row r at raw + r * rp (rp = 8: the wave's own plane, filled here from f; rp = QW_WP: a view
+ * into the workgroup's window, f == nullptr).  ob != nullptr: the lane's four output samples go to ob[lane] instead of memory
+ * (16x16 blocks; the caller stores four blocks' rows together). */
+__device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t *f, uint32_t *raw, const int rp, uint32_t *hb, uint8_t *dst, ptrdiff_t stride,
+                                         int lane, uint32_t *ob = nullptr)
 {
     const int size = q.size, mc = q.mc, rows = q.rows;
     const uint32_t sh = q.sh;
     const bool avg = q.avg;
-    const int per_row = size >> 2;
+    const int per_row = size >> 2, lgp = size == 16 ? 2 : size == 8 ? 1 : 0; /* 4-sample groups per row, and their log2 */
     const int mx = mc & 3, my = mc >> 2;
     const bool useJ = (mx == 2 && my != 0) || (my == 2 && mx != 0);
     const bool useV = (mx != 2 && my != 0) || (mc == 8);
@@ -229,13 +233,15 @@ __device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t f[3], ui
     const bool vcol1 = mx == 3, hrow1 = my == 3;
 
     /* ---- 1. footprint -> LDS ---- */
+    if (f) {
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-        if (lane + 64 * i < rows * 8)
-            raw[lane + 64 * i] = f[i];
-    __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < 3; i++)
+            if (lane + 64 * i < rows * 8)
+                raw[lane + 64 * i] = f[i];
+        __builtin_amdgcn_wave_barrier();
+    }
     auto stream = [&](int row, int xg) { /* 12 bytes from byte x-2+4*xg of a footprint row */
-        const uint32_t *p = raw + row * 8 + xg;
+        const uint32_t *p = raw + row * rp + xg;
         const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
         const uint32_t d3 = sh == 3 ? p[3] : 0;
         Row12 r;
@@ -248,7 +254,7 @@ __device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t f[3], ui
     /* ---- 2. horizontal sums of every footprint row, once ---- */
     if (useJ) {
         for (int t = lane; t < rows * per_row; t += 64) {
-            const int r = t / per_row, xg = t - r * per_row;
+            const int r = t >> lgp, xg = t & (per_row - 1);
             qp_s2 lo, hi;
             qp_hraw4(stream(r, xg), lo, hi);
             *reinterpret_cast<uint2 *>(hb + r * 8 + 2 * xg) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
@@ -257,7 +263,7 @@ __device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t f[3], ui
     }
 
     /* ---- 3. my four samples ---- */
-    const int y = lane / per_row, xg = lane - y * per_row;
+    const int y = lane >> lgp, xg = lane & (per_row - 1);
     if (y < size) {
         uint8_t *d = dst + q.doff + (ptrdiff_t)y * stride + 4 * xg;
         uint32_t pj = 0, ph = 0, pv = 0, pf = 0;
@@ -292,7 +298,7 @@ __device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t f[3], ui
             qp_s2 c01[6], c23[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                const uint32_t *p = raw + (y + k) * 8 + xg + (o >> 2);
+                const uint32_t *p = raw + (y + k) * rp + xg + (o >> 2);
                 const uint32_t w = __builtin_amdgcn_alignbyte(p[1], p[0], o & 3);
                 c01[k] = qp_pair(0, w, 0x0c010c00);
                 c23[k] = qp_pair(0, w, 0x0c030c02);
@@ -301,7 +307,7 @@ __device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t f[3], ui
         }
         {
             const uint32_t o = sh + (mc == 3 ? 3 : 2);
-            const uint32_t *p = raw + (y + (mc == 12 ? 3 : 2)) * 8 + xg + (o >> 2);
+            const uint32_t *p = raw + (y + (mc == 12 ? 3 : 2)) * rp + xg + (o >> 2);
             pf = __builtin_amdgcn_alignbyte(p[1], p[0], o & 3);
         }
         uint32_t out;
@@ -316,7 +322,9 @@ __device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t f[3], ui
         case 9: case 11: out = rnd_avg4(pv, pj); break;
         default: out = pj; break; /* 10 */
         }
-        if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
+        if (ob) {
+            ob[lane] = out;
+        } else if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
             uint32_t *dw = reinterpret_cast<uint32_t *>(d);
             if (avg)
                 out = rnd_avg4(*dw, out);
@@ -356,7 +364,75 @@ __global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t
 #pragma unroll
     for (int k = 0; k < NB; k++)
         if (b0 + k < n)
-            qp_block(q[k], f[k], raw, hb, dst, stride, lane);
+            qp_block(q[k], f[k], raw, 8, hb, dst, stride, lane);
+}
+
+/* ================================================================================================== */
+/*
+ * k_h264_qpel_t — k_h264_qpel_l<4> with the memory side rebuilt around what tools/ubench/tilecopy measures: at 16x16 blocks the
+ * memory pipeline is bound by the NUMBER of row segments a wave requests, not their bytes (the 32-plane copy skeleton: 0.28 ms with
+ * the footprint as three dword loads per lane and 16 B destination rows, 0.20 ms with the two changes below, 0.15 ms for plain
+ * 64-byte rows).  stride % 16 == 0.
+ *   - the footprint arrives as ONE 16-byte load per lane: lane (row, chunk) fetches an ALIGNED 16-byte chunk (2 or 3 per row cover
+ *     the size + 5 bytes; an aligned chunk that holds a needed byte never leaves that byte's page, so nothing beyond the documented
+ *     footprint can fault), 21 rows x 3 chunks = 63 lanes;
+ *   - the wave's four blocks are computed into an LDS tile and leave as one 16-byte store per lane, lane (row, block): x-adjacent
+ *     16x16 blocks — consecutive macroblocks — make 64-byte rows, 4 requests per block instead of 16.
+ * The arithmetic is qp_block's, unchanged.  (A workgroup-wide window shared by 16 blocks was measured too: fewer requests still,
+ * but the load -> barrier -> compute -> store chain of a 28 KB workgroup left it slower, 0.47 vs 0.35 ms on the mixed case.)
+ */
+typedef uint32_t qp_u4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_h264_qpel_t(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n)
+{
+    __shared__ __align__(16) uint32_t rawp[4][21 * 12];
+    __shared__ uint32_t hbp[4][21 * 8];
+    __shared__ __align__(16) uint32_t obp[4][4 * 64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int b0 = (blockIdx.x * 4 + wave) * 4;
+    if (b0 >= n)
+        return;
+    uint32_t *raw = rawp[wave], *hb = hbp[wave], *ob = obp[wave];
+    const int fr = (lane * 171) >> 9, fc = lane - 3 * fr; /* footprint row and 16-byte chunk of this lane: lane / 3, lane % 3 */
+    QpBlk q[4];
+    qp_u4 f[4];
+    uint32_t sh16[4];
+    bool tile = true; /* all four 16x16 with dword-aligned destinations: their rows leave together */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        q[k] = qp_blk(blocks, min(b0 + k, n - 1), src, stride);
+        tile = tile && q[k].size == 16 && b0 + k < n && !((reinterpret_cast<uintptr_t>(dst) + (uintptr_t)(intptr_t)q[k].doff) & 3);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint8_t *s0 = src + q[k].soff - 2 - 2 * stride;
+        sh16[k] = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 15);
+        const int nch = (int)(sh16[k] + q[k].size + 5 + 15) >> 4;
+        f[k] = (fr < q[k].rows && fc < nch) ? *reinterpret_cast<const qp_u4 *>(s0 - sh16[k] + (ptrdiff_t)fr * stride + 16 * fc) : (qp_u4){ 0, 0, 0, 0 };
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (b0 + k >= n)
+            break;
+        if (lane < 63)
+            *reinterpret_cast<qp_u4 *>(raw + fr * 12 + 4 * fc) = f[k];
+        __builtin_amdgcn_wave_barrier();
+        q[k].sh = sh16[k] & 3;
+        qp_block(q[k], nullptr, raw + (sh16[k] >> 2), 12, hb, dst, stride, lane, tile ? ob + 64 * k : nullptr);
+    }
+    if (tile) {
+        const int y = lane >> 2, c = lane & 3;
+        qp_u4 o = *reinterpret_cast<const qp_u4 *>(ob + 64 * c + 4 * y);
+        const int doff = c == 0 ? q[0].doff : c == 1 ? q[1].doff : c == 2 ? q[2].doff : q[3].doff;
+        const bool avg = c == 0 ? q[0].avg : c == 1 ? q[1].avg : c == 2 ? q[2].avg : q[3].avg;
+        qp_u4 *dp = reinterpret_cast<qp_u4 *>(dst + doff + (ptrdiff_t)y * stride);
+        if (avg) {
+            const qp_u4 old = *dp;
+            o.x = rnd_avg4(old.x, o.x); o.y = rnd_avg4(old.y, o.y); o.z = rnd_avg4(old.z, o.z); o.w = rnd_avg4(old.w, o.w);
+        }
+        *dp = o;
+    }
 }
 
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
@@ -367,7 +443,10 @@ int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, c
     const char *eo = FFHIP_KNOB("FFHIP_QPEL_OLD"); /* measured variant: the register-only kernel */
     const char *en = FFHIP_KNOB("FFHIP_QPEL_NB");  /* measured variant: blocks per wave */
     const int nb = en ? atoi(en) : 4;
-    if (!(stride & 3) && !(eo && eo[0] == '1')) {
+    const char *ew = FFHIP_KNOB("FFHIP_QPEL_W");   /* measured variant: 0 = k_h264_qpel_l (dword footprint loads, a store per block row) */
+    if (!(stride & 15) && n >= 1024 && !(eo && eo[0] == '1') && !(ew && ew[0] == '0')) {
+        hipLaunchKernelGGL(k_h264_qpel_t, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+    } else if (!(stride & 3) && !(eo && eo[0] == '1')) {
         if (nb >= 4 && n >= 4 * 4096)
             hipLaunchKernelGGL(k_h264_qpel_l<4>, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n);
         else if (nb >= 2 && n >= 2 * 4096)

@@ -179,17 +179,22 @@ QPEL_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy",
                     ("avg", np.uint8), ("pad", np.uint8)])
 
 
-@pytest.mark.parametrize("old", ["default", "0", "1"], ids=["product", "lds", "regs"])
-@pytest.mark.parametrize("w,h,pad", [(64, 48, 0), (3840, 2160, 0), (208, 96, 5), (208, 96, 12)])
-def test_qpel_batch(w, h, pad, old, monkeypatch):
-    """put/avg x 16 mcXY x 3 sizes mixed in one batch; unaligned reference positions; both kernels (the LDS-sharing
-    one needs stride % 4 == 0, pad 5 falls back to the register-only kernel)"""
+@pytest.mark.parametrize("old", ["default", "0", "1", "w0"], ids=["product", "lds", "regs", "nowindow"])
+@pytest.mark.parametrize("w,h,pad,mvr", [(64, 48, 0, 24), (3840, 2160, 0, 24), (208, 96, 5, 24), (208, 96, 12, 24), (1280, 720, 0, 6), (1264, 720, 4, 14),
+                                         (1920, 1088, 0, 100)])
+def test_qpel_batch(w, h, pad, mvr, old, monkeypatch):
+    """put/avg x 16 mcXY x 3 sizes mixed in one batch; unaligned reference positions; every kernel: the workgroup-window one (1024
+    blocks and up; motion within +-6 / +-14 keeps the 16 blocks of a workgroup inside one window, +-24 mixes window and per-block
+    workgroups, +-100 leaves almost none; 1264 wide = 79 macroblocks per row: workgroups that straddle a row's end), the LDS-sharing
+    one (stride % 4 == 0), the register-only one (pad 5)"""
     from ffmpeg_amd import h264
     torch = _torch()
-    if old != "default":   # a knob selects libffhip_measure.so (conftest.py); "default" is the product library
+    if old == "w0":
+        monkeypatch.setenv("FFHIP_QPEL_W", "0")
+    elif old != "default":   # a knob selects libffhip_measure.so (conftest.py); "default" is the product library
         monkeypatch.setenv("FFHIP_QPEL_OLD", old)
     rng = np.random.default_rng(w + pad)
-    P = 32                                                  # reference padding so that MVs may point outside the picture
+    P = 32 if mvr <= 24 else 128                            # reference padding so that MVs may point outside the picture
     stride = w + 2 * P + pad
     ref = rng.integers(0, 256, (h + 2 * P, stride), dtype=np.uint8)
     dst = rng.integers(0, 256, (h + 2 * P, stride), dtype=np.uint8)
@@ -200,7 +205,7 @@ def test_qpel_batch(w, h, pad, old, monkeypatch):
             n = 16 >> size_idx
             for sy in range(0, 16, n):
                 for sx in range(0, 16, n):
-                    dy, dx = rng.integers(-24, 25, 2)
+                    dy, dx = rng.integers(-mvr, mvr + 1, 2)
                     y, x = P + my * 16 + sy, P + mx * 16 + sx
                     blocks.append((y * stride + x, (y + dy) * stride + x + dx, rng.integers(0, 16), size_idx,
                                    rng.integers(0, 2), 0))

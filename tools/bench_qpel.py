@@ -16,7 +16,7 @@ from ffmpeg_amd import h264  # noqa: E402
 dev = torch.device("cuda", 0)
 DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy", np.uint8), ("size_idx", np.uint8), ("avg", np.uint8),
                ("pad", np.uint8)])
-W, H, P, planes = 3840, 2160, 32, 8
+W, H, P, planes = 3840, 2160, 32, int(os.environ.get("PLANES", "8"))
 stride = W + 2 * P
 rows = H + 2 * P
 rng = np.random.default_rng(5)
@@ -41,10 +41,11 @@ def blocks(mc):
 
 
 QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"     # the default kernel, mixed positions and plain copies only (PMC runs)
-for old, nb in ((("0", "4"),) if QUICK else (("0", "4"), ("0", "2"), ("0", "1"), ("1", "1"))):
+ALL = len(sys.argv) > 1 and sys.argv[1] == "all"         # the default kernel, every position (PLANES=32 for the batch the verdict asks about)
+for old, nb in ((("0", "4"),) if QUICK or ALL else (("0", "4"), ("0", "2"), ("0", "1"), ("1", "1"))):
     os.environ["FFHIP_QPEL_OLD"] = old
     os.environ["FFHIP_QPEL_NB"] = nb
-    for mc in ((-1, 0) if QUICK else (-1, 0, 2, 8, 10, 5, 9)):
+    for mc in ((-1, 0) if QUICK else (-1,) + tuple(range(16)) if ALL else (-1, 0, 2, 8, 10, 5, 9)):
         d_bl, n = blocks(mc)
         for _ in range(2):
             h264.qpel_batch(dst, ref, stride, d_bl, n)
