@@ -493,6 +493,153 @@ __global__ __launch_bounds__(64 * WPB) void k_me_esa(const uint8_t *cur, const u
     }
 }
 
+/*
+ * k_me_esa_g — SAD, 16x16 macroblocks: the search of NMB = 8 horizontally adjacent macroblocks by one workgroup.
+ *
+ * What the one-wave-per-macroblock forms above pay per candidate beside its 64 v_sad_u8 — the window's LDS reads, the funnel
+ * shifts that bring a byte phase into place, the staging, the wave reduction — is shared here along every axis that offers it:
+ *   - one reference window, (16 + 2R) rows x (8 * 16 + 2R) columns, is staged once for the eight macroblocks (their windows
+ *     overlap by 2R columns out of 16 + 2R);
+ *   - a lane takes a 4 x 4 GROUP of candidates of one macroblock: four byte phases of the same aligned dwords times four vertical
+ *     offsets.  The 19 window rows under the group are read once each (five dwords, two LDS instructions), shifted once into the
+ *     phases 1..3 (twelve v_alignbyte), and every shifted dword meets the (up to four) rows of the current block it lies under:
+ *     1024 v_sad_u8 + 228 v_alignbyte + 38 LDS reads per 16 candidates, against 1024 + 768 + 512 in the one-candidate form;
+ *   - the current block's rows come from LDS as they are needed (one broadcast read per window row, four rows live at a time), so
+ *     the lanes of a wave may belong to different macroblocks and a wave is full whatever R is: R = 7 has 16 groups per
+ *     macroblock, 128 per workgroup;
+ *   - the winner is ONE 32-bit key per candidate, cost << 12 | index, index 0 for the zero motion vector and raster index + 1 for
+ *     the others: its minimum is the reference's "first minimum in raster order wins, the zero vector wins ties"
+ *     (libavfilter/motion_estimation.c:79-100); a v_or3 masks candidates outside the picture, ds_min_u32 merges the lanes.
+ * R <= 30 (the index must fit 12 bits; a 16x16 SAD fits 16).
+ */
+#define ESA_G_NMB 8
+__global__ __launch_bounds__(256) void k_me_esa_g(const uint8_t *cur, const uint8_t *ref, int width, int height, ptrdiff_t stride, size_t frame_pitch,
+                                                  int R, int16_t *mv_out, uint32_t *cost_out, int pitch)
+{
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    const int bw = width >> 4, bh = height >> 4;
+    const int bx0 = blockIdx.x * ESA_G_NMB, by = blockIdx.y, f = blockIdx.z;
+    const int nmb = min(ESA_G_NMB, bw - bx0);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lim_x = (bw - 1) << 4, lim_y = (bh - 1) << 4;
+    const int y_mb = by << 4, y0 = max(y_mb - R, 0), y1 = min(y_mb + R, lim_y), ncy = y1 - y0 + 1, wrows = ncy + 15;
+    const int xf = bx0 << 4, wx0 = max(xf - R, 0), wx1 = min(xf + ((nmb - 1) << 4) + R, lim_x) + 15; /* window columns wx0 .. wx1 */
+    uint32_t *keys = reinterpret_cast<uint32_t *>(lds_all);          /* [NMB] */
+    uint8_t *cblk = lds_all + 64;                                    /* [NMB][16][16] */
+    uint8_t *win = cblk + ESA_G_NMB * 256;                           /* [wrows][pitch] */
+    const uint8_t *cf = cur + (size_t)f * frame_pitch, *rf = ref + (size_t)f * frame_pitch;
+    if (tid < ESA_G_NMB)
+        keys[tid] = 0xFFFFFFFFu;
+    /* staging: 16-byte loads at byte-exact addresses (rows on a 16-chunk grid: no division); the chunk that would cross the right
+     * picture edge goes bytewise.  `pitch` is a multiple of 16. */
+    {
+        const int n16 = (wx1 - wx0 + 1 + 15) >> 4;              /* <= 12: R <= 30 */
+        const int ncur = nmb * 16, tot = ncur + (wrows << 4);
+        for (int i = tid; i < tot; i += T) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < ncur) {   /* the current blocks: row r of macroblock m */
+                const int m = i >> 4, r = i & 15;
+                __builtin_memcpy(&v, cf + (ptrdiff_t)(y_mb + r) * stride + xf + 16 * m, 16);
+                *reinterpret_cast<uint4 *>(cblk + 16 * i) = v;
+            } else {
+                const int r = (i - ncur) >> 4, j = (i - ncur) & 15, xb = wx0 + 16 * j;
+                if (j < n16) {
+                    const uint8_t *p = rf + (ptrdiff_t)(y0 + r) * stride + xb;
+                    if (xb + 16 <= width) {
+                        __builtin_memcpy(&v, p, 16);
+                    } else {
+                        uint32_t w[4] = { 0, 0, 0, 0 };
+                        for (int b = 0; b < 16 && xb + b < width; b++)
+                            w[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
+                        v = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    *reinterpret_cast<uint4 *>(win + r * pitch + 16 * j) = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    /* groups per macroblock: columns are grouped on the window's dword grid, so a macroblock whose first candidate column is
+     * not a multiple of four from the window's start (left picture edge only) has its candidates begin inside the first group */
+    const int ngx = (2 * R + 1 + (wx0 == 0 ? (-R & 3) : 0) + 3) >> 2, ngy = (2 * R + 1 + 3) >> 2, G = ngx * ngy;
+    for (int it = tid; it < nmb * G; it += T) {
+        const int m = it / G, g = it - m * G, gy = g / ngx, gx = g - gy * ngx;
+        const int x_mb = xf + (m << 4), x0 = max(x_mb - R, 0), x1 = min(x_mb + R, lim_x), ncx = x1 - x0 + 1;
+        const int xo = x0 - wx0, off = xo & 3, cy0 = 4 * gy;
+        const uint8_t *cbm = cblk + m * 256;
+        uint32_t cb[4][4]; /* the four rows of the current block a window row lies under: row y lives in cb[y & 3] */
+        const uint8_t *col = win + (xo - off) + 4 * gx;
+        uint32_t cost[4][4]; /* [vertical offset][byte phase] */
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                cost[k][j] = 0;
+#pragma unroll
+        for (int r = 0; r < 19; r++) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(col + min(cy0 + r, wrows - 1) * pitch);
+            const uint4 d = *reinterpret_cast<const uint4 *>(q);
+            const uint32_t e = q[4];
+            const uint32_t w0[5] = { d.x, d.y, d.z, d.w, e };
+            if (r < 16) { /* a broadcast read: every lane of the macroblock asks for the same 16 bytes */
+                const uint4 c = *reinterpret_cast<const uint4 *>(cbm + 16 * r);
+                cb[r & 3][0] = c.x; cb[r & 3][1] = c.y; cb[r & 3][2] = c.z; cb[r & 3][3] = c.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    w[i] = j ? __builtin_amdgcn_alignbyte(w0[i + 1], w0[i], j) : w0[i];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int y = r - k;
+                    if (y >= 0 && y < 16) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            cost[k][j] = __builtin_amdgcn_sad_u8(cb[y & 3][i], w[i], cost[k][j]);
+                    }
+                }
+            }
+        }
+        /* keys: candidate (cx, cy) = (4 gx + j - off, cy0 + k), valid inside [0, ncx) x [0, ncy) */
+        const int zx = x_mb - x0, zy = y_mb - y0; /* the zero vector's candidate */
+        uint32_t best = 0xFFFFFFFFu;
+        uint32_t mx[4], my[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            mx[j] = (uint32_t)(4 * gx + j - off) < (uint32_t)ncx ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            my[k] = cy0 + k < ncy ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int cy = cy0 + k;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int cx = 4 * gx + j - off;
+                const uint32_t idx = (cx == zx && cy == zy) ? 0u : (uint32_t)(cy * ncx + cx + 1);
+                best = min(best, ((cost[k][j] << 12) + idx) | mx[j] | my[k]);
+            }
+        }
+        atomicMin(&keys[m], best);
+    }
+    __syncthreads();
+    if (tid < nmb) {
+        const uint32_t key = keys[tid], idx = key & 0xFFF;
+        const int x_mb = xf + (tid << 4), x0 = max(x_mb - R, 0), x1 = min(x_mb + R, lim_x), ncx = x1 - x0 + 1;
+        int mvx = x_mb, mvy = y_mb;
+        if (idx) {
+            mvx = x0 + (int)((idx - 1) % (uint32_t)ncx);
+            mvy = y0 + (int)((idx - 1) / (uint32_t)ncx);
+        }
+        const size_t b = ((size_t)f * bh + by) * bw + bx0 + tid;
+        mv_out[2 * b] = (int16_t)mvx;
+        mv_out[2 * b + 1] = (int16_t)mvy;
+        cost_out[b] = key >> 12;
+    }
+}
+
 int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int height, ptrdiff_t stride, size_t frame_pitch,
                         int nframes, int mb_size, int R, int cost_kind, int16_t *mv_out, uint32_t *cost_out, hipStream_t stream)
 {
@@ -524,7 +671,17 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
          * slots): + 2..6 %, kept.  Every form sits at 60 % VALU issue with the rest in LDS round trips per candidate row. */
         const char *eq = FFHIP_KNOB("FFHIP_ME_SAD_QUAD");
         const bool one_pass = ((2 * R + 1 + 3) / 4) * (2 * R + 1) <= 64;
-        if (mb_size == 16 && eq && eq[0] == '3') {
+        if (mb_size == 16 && !eq && R <= 30) {
+            /* round 3: eight macroblocks per workgroup, 4 x 4 candidate groups per lane (k_me_esa_g) */
+            /* rows of whole 16-byte chunks + the fifth dword of the last group; an odd number of chunks, so that the four rows a
+             * wave's groups start on (4 apart) fall on different banks */
+            const int gpitch = (((ESA_G_NMB * 16 + 2 * R + 8 + 15) >> 4) | 1) << 4;
+            const size_t glds = 64 + ESA_G_NMB * 256 + (size_t)(2 * R + 16) * gpitch;
+            const int ng = ((2 * R + 1 + 3 + 3) / 4) * ((2 * R + 1 + 3) / 4) * ESA_G_NMB;
+            const int threads = ng >= 256 ? 256 : (ng + 63) & ~63;
+            hipLaunchKernelGGL(k_me_esa_g, dim3(cdiv(bw, ESA_G_NMB), bh, nframes), dim3(threads), glds, stream, cur, ref, width, height, stride,
+                               frame_pitch, R, mv_out, cost_out, gpitch);
+        } else if (mb_size == 16 && eq && eq[0] == '3') {
             if (w4) ESA4(FFHIP_ME_SAD, 16, 3);
             else hipLaunchKernelGGL((k_me_esa<FFHIP_ME_SAD, 16, false, 3>), grid, block, lds, stream, cur, ref, width, height, stride,
                                     frame_pitch, R, mv_out, cost_out, 0);
