@@ -207,7 +207,8 @@ int ffref_h264_idct_batch(int which, uint8_t *dst, ptrdiff_t stride, const int32
  * first pass the coefficient blocks are the zeros the function itself leaves behind: same instructions, same stores).
  * *seconds = wall time of the timed passes, *passes = how many; returns the number of worker threads. */
 #include <time.h>
-typedef struct { IdctJob job; pthread_barrier_t *bar; volatile int *stop; } IdctLoop;
+typedef struct { IdctJob job; pthread_barrier_t *bar; volatile int *stop; double t_end; long passes; double t_done; } IdctLoop;
+static double now_s(void);
 static void *idct_loop_worker(void *p)
 {
     IdctLoop *l = p;
@@ -235,13 +236,18 @@ static void *idct_loop_worker(void *p)
         j->dst = lp;
         j->off = lo - j->lo;
     }
-    for (;;) {
-        pthread_barrier_wait(l->bar);
-        if (*l->stop)
-            break;
+    /* one barrier-bracketed warm-up pass, then free-running passes until the deadline: a barrier per pass costs a 256-thread box
+     * milliseconds of futex traffic per round, an order more than the 1.2 ms a thread's share of one pass takes */
+    pthread_barrier_wait(l->bar);
+    idct_worker(&l->job);
+    pthread_barrier_wait(l->bar);
+    pthread_barrier_wait(l->bar); /* the caller has set t_end */
+    do {
         idct_worker(&l->job);
-        pthread_barrier_wait(l->bar);
-    }
+        l->passes++;
+        l->t_done = now_s();
+    } while (l->t_done < l->t_end);
+    pthread_barrier_wait(l->bar);
     free(lb);
     free(lp);
     free(lo);
@@ -268,6 +274,7 @@ int ffref_h264_idct_batch_timed(int which, uint8_t *dst, ptrdiff_t stride, const
             want++;
     pthread_barrier_t bar;
     volatile int stop = 0;
+    (void)stop;
     if (pthread_barrier_init(&bar, NULL, want + 1))
         return -1;
     int started = 0;
@@ -286,21 +293,25 @@ int ffref_h264_idct_batch_timed(int which, uint8_t *dst, ptrdiff_t stride, const
     }
     pthread_barrier_wait(&bar); /* warm-up pass */
     pthread_barrier_wait(&bar);
-    int np = 0;
     const double t0 = now_s();
-    double t1;
-    do {
-        pthread_barrier_wait(&bar);
-        pthread_barrier_wait(&bar);
-        np++;
-        t1 = now_s();
-    } while (t1 - t0 < min_seconds && np < 100000);
-    stop = 1;
+    for (int t = 0; t < started; t++) {
+        loop[t].t_end = t0 + min_seconds;
+        loop[t].passes = 0;
+    }
     pthread_barrier_wait(&bar);
+    pthread_barrier_wait(&bar);
+    /* threads finish their last pass at different times: the rate is blocks done / the time the slowest needed */
+    double t1 = t0, blocks = 0;
+    for (int t = 0; t < started; t++) {
+        if (loop[t].t_done > t1)
+            t1 = loop[t].t_done;
+        blocks += (double)loop[t].passes * (loop[t].job.hi - loop[t].job.lo);
+    }
+    const int np = (int)(blocks / n + 0.5);
     for (int t = 0; t < started; t++)
         pthread_join(th[t], NULL);
     pthread_barrier_destroy(&bar);
-    *seconds = t1 - t0;
+    *seconds = (t1 - t0) * ((double)np * n / (blocks > 0 ? blocks : 1)); /* the time np whole passes take at the measured rate */
     *passes = np;
     return started;
 }
