@@ -25,7 +25,9 @@ class SwsTables(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("srcW", "srcH", "srcFormat", "dstW", "dstH", "dstFormat", "flags")] + \
                [(k, SwsFilter) for k in ("hLum", "hChr", "vLum", "vChr")] + \
                [(k, C.c_int64) for k in ("yuv2rgb_cy", "yuv2rgb_oy", "yuv2rgb_crv", "yuv2rgb_cbu", "yuv2rgb_cgu",
-                                         "yuv2rgb_cgv")] + [("yuv2rgb_yoffs", C.c_int)]
+                                         "yuv2rgb_cgv")] + [("yuv2rgb_yoffs", C.c_int)] + \
+               [("src_range", C.c_int), ("dst_range", C.c_int), ("lumConvertRange_coeff", C.c_uint32), ("chrConvertRange_coeff", C.c_uint32),
+                ("lumConvertRange_offset", C.c_int64), ("chrConvertRange_offset", C.c_int64)]
 
 
 _lib = None
@@ -115,6 +117,7 @@ def lib():
         "ffhip_sws_tables_create": (vp, [C.c_int] * 7),
         "ffhip_sws_tables_get": (C.c_int, [vp, C.POINTER(SwsTables)]),
         "ffhip_sws_tables_is_unscaled_yuv2rgb": (C.c_int, [vp]),
+        "ffhip_sws_tables_set_ranges": (C.c_int, [vp, C.c_int, C.c_int]),
         "ffhip_sws_tables_free": (None, [vp]),
         "ffhip_sws_scale": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(u8p),
                                       C.POINTER(C.c_int)]),

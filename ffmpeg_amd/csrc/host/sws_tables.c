@@ -406,6 +406,30 @@ static int is_rgb(int fmt)
 
 static int ceil_rshift(int a, int b) { return -((-a) >> b); }
 
+/* solve dst = ((src << src_shift) * coeff + offset) >> (mult_shift + src_shift) for the end points of the two ranges
+ * (solve_range_convert / init_range_convert_constants, libswscale/swscale.c:568-624).  dst_depth = c->dstBpc (8 for 8-bit targets). */
+static void range_solve(unsigned src_min, unsigned src_max, unsigned dst_min, unsigned dst_max, int src_shift, int mult_shift,
+                        uint32_t *coeff, int64_t *offset)
+{
+    const unsigned sr = (uint16_t)(src_max - src_min), dr = (uint16_t)(dst_max - dst_min);
+    const int total = mult_shift + src_shift;
+    const uint64_t q = ((uint64_t)dr << total) / sr;
+    *coeff = (uint32_t)((q + ((uint64_t)1 << src_shift) - 1) >> src_shift); /* AV_CEIL_RSHIFT */
+    *offset = ((int64_t)dst_max << total) - ((int64_t)src_max << src_shift) * *coeff + (1U << (mult_shift - 1));
+}
+void ffhip_sws_range_constants(int src_range, int dst_depth, uint32_t *lum_coeff, int64_t *lum_offset, uint32_t *chr_coeff, int64_t *chr_offset)
+{
+    const int bd = dst_depth > 16 ? 16 : dst_depth, src_bits = bd <= 14 ? 15 : 19, src_shift = src_bits - bd, mult_shift = bd <= 14 ? 14 : 18;
+    const unsigned mpeg_min = 16U << (bd - 8), mpeg_max_lum = 235U << (bd - 8), mpeg_max_chr = 240U << (bd - 8), jpeg_max = (1U << bd) - 1;
+    if (src_range) {
+        range_solve(0, jpeg_max, mpeg_min, mpeg_max_lum, src_shift, mult_shift, lum_coeff, lum_offset);
+        range_solve(0, jpeg_max, mpeg_min, mpeg_max_chr, src_shift, mult_shift, chr_coeff, chr_offset);
+    } else {
+        range_solve(mpeg_min, mpeg_max_lum, 0, jpeg_max, src_shift, mult_shift, lum_coeff, lum_offset);
+        range_solve(mpeg_min, mpeg_max_chr, 0, jpeg_max, src_shift, mult_shift, chr_coeff, chr_offset);
+    }
+}
+
 FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, int dstW, int dstH,
                                             int dstFormat, int flags)
 {
@@ -413,20 +437,24 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     int chrSrcW, chrSrcH, chrDstW, chrDstH, chrDstHSub, chrDstVSub;
     int64_t lumXInc, lumYInc, chrXInc, chrYInc;
     int lum_scaler = scaler_of(flags, 0), chr_scaler = scaler_of(flags, 1);
-    int r;
+    int r, src_range = 0, dst_range = 0;
 
     /* full-range twins on both sides: no range conversion, the base formats' scaler (handle_jpeg(), utils.c:1019-1050) */
     {
         const int sj = srcFormat >= FFHIP_PIX_FMT_YUVJ420P && srcFormat <= FFHIP_PIX_FMT_YUVJ444P;
         const int dj = dstFormat >= FFHIP_PIX_FMT_YUVJ420P && dstFormat <= FFHIP_PIX_FMT_YUVJ444P;
         static const int base[3] = { FFHIP_PIX_FMT_YUV420P, FFHIP_PIX_FMT_YUV422P, FFHIP_PIX_FMT_YUV444P };
-        if (sj != dj) {
-            ffhip_set_error("ffhip_sws: a full-range (J) format on one side only needs a range conversion; not on the hip path");
-            return NULL;
-        }
-        if (sj) {
+        /* a J format is its base format with the range flag set (handle_jpeg(), utils.c:773-800, :1903-1904) */
+        src_range = sj;
+        dst_range = dj;
+        if (sj)
             srcFormat = base[srcFormat - FFHIP_PIX_FMT_YUVJ420P];
+        if (dj)
             dstFormat = base[dstFormat - FFHIP_PIX_FMT_YUVJ420P];
+        if (sj != dj && is_rgb(dstFormat)) {
+            /* the reference folds the source's range into the yuv2rgb tables (ff_yuv2rgb_c_init_tables' fullRange branch) */
+            ffhip_set_error("ffhip_sws: full-range YUV to packed RGB is not on the hip path");
+            return NULL;
         }
     }
     if (flags & FFHIP_SWS_FAST_BILINEAR) {
@@ -446,12 +474,8 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
             ffhip_set_error("ffhip_sws: sources above 8 bits to packed RGB are not on the hip path");
             return NULL;
         }
-        if (srcW == dstW && srcH == dstH) {
-            /* equal sizes take the reference's special converters (planarCopyWrapper, planarToP01xWrapper, ...: swscale_unscaled.c):
-             * shifts and dithers of their own, not the scaler's arithmetic */
-            ffhip_set_error("ffhip_sws: equal-size conversions above 8 bits are not on the hip path (the scaler is)");
-            return NULL;
-        }
+        /* (equal sizes without a range change take the reference's special converters — planarCopyWrapper, planarToP01xWrapper, ...:
+         * swscale_unscaled.c — not the scaler's arithmetic: ffhip_sws_from_tables() refuses those, once the ranges are known) */
     }
     h = calloc(1, sizeof(*h));
     if (!h)
@@ -459,6 +483,14 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     h->t.srcW = srcW; h->t.srcH = srcH; h->t.srcFormat = srcFormat;
     h->t.dstW = dstW; h->t.dstH = dstH; h->t.dstFormat = dstFormat;
     h->t.flags = flags;
+    h->t.src_range = src_range;
+    h->t.dst_range = dst_range;
+    if (src_range != dst_range) {
+        int ddepth = 8;
+        ffhip_pixfmt_hbd(dstFormat, &ddepth, NULL, NULL, NULL);
+        ffhip_sws_range_constants(src_range, ddepth, &h->t.lumConvertRange_coeff, &h->t.lumConvertRange_offset,
+                                  &h->t.chrConvertRange_coeff, &h->t.chrConvertRange_offset);
+    }
 
     /* RGB output without SWS_FULL_CHR_H_INT keeps chroma at half horizontal resolution
      * (utils.c:1359-1360) and full vertical resolution */
@@ -521,6 +553,28 @@ int ffhip_sws_tables_get(const FFHipSwsHostTables *t, FFHipSwsTables *out)
 }
 
 int ffhip_sws_tables_is_unscaled_yuv2rgb(const FFHipSwsHostTables *t) { return t ? t->unscaled_yuv2rgb : 0; }
+
+/* the srcRange / dstRange arguments of sws_setColorspaceDetails() (libswscale/utils.c:848-1000) for a YUV target: 0 limited, 1 full */
+int ffhip_sws_tables_set_ranges(FFHipSwsHostTables *t, int src_range, int dst_range)
+{
+    int ddepth = 8;
+    if (!t || (src_range | dst_range) & ~1)
+        return FFHIP_EINVAL;
+    if (src_range != dst_range && is_rgb(t->t.dstFormat)) {
+        ffhip_set_error("ffhip_sws: full-range YUV to packed RGB is not on the hip path");
+        return FFHIP_ENOSYS;
+    }
+    t->t.src_range = src_range;
+    t->t.dst_range = dst_range;
+    t->t.lumConvertRange_coeff = t->t.chrConvertRange_coeff = 0;
+    t->t.lumConvertRange_offset = t->t.chrConvertRange_offset = 0;
+    if (src_range != dst_range) {
+        ffhip_pixfmt_hbd(t->t.dstFormat, &ddepth, NULL, NULL, NULL);
+        ffhip_sws_range_constants(src_range, ddepth, &t->t.lumConvertRange_coeff, &t->t.lumConvertRange_offset,
+                                  &t->t.chrConvertRange_coeff, &t->t.chrConvertRange_offset);
+    }
+    return 0;
+}
 
 void ffhip_sws_tables_free(FFHipSwsHostTables *t)
 {

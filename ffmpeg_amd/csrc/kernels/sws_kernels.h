@@ -52,6 +52,9 @@ struct FFHipScalePlaneArgs {
     int tw, th;                 /* output tile */
     int max_cols, max_rows;     /* source footprint of the widest / tallest tile */
     int tiles_x, tiles_y;
+    /* range conversion of the horizontal intermediates (lum / chrRangeTo / FromJpeg_c, swscale.c:160-207): v = (v * rc_coeff +
+     * rc_offset) >> 14, clipped to 2^15 - 1 when rc_clip (ToJpeg); rc_coeff == 0: none */
+    int rc_coeff, rc_offset, rc_clip;
 };
 int ffhip_launch_scale_yuv(const FFHipScalePlaneArgs &lum, const FFHipScalePlaneArgs &chr, hipStream_t stream);
 /* picks tw/th/max_* for a bank pair from HOST copies of the position tables */
@@ -238,6 +241,11 @@ struct FFHipScale16Plane {
     int dstW, dstH;
     int dither, dither_off;  /* 8-bit target fed from a deeper source: ff_dither_8x8_128[y & 7][(x + dither_off) & 7] */
     FFHipDevFilter h, v;
+    /* range conversion of the horizontal intermediates: 15-bit ones as in FFHipScalePlaneArgs, 19-bit ones (targets above 14 bits)
+     * with 64-bit products and >> 18 (lumRangeToJpeg16_c & co, swscale.c:209-255); rc_coeff == 0: none */
+    uint32_t rc_coeff;
+    int rc_clip;
+    int64_t rc_offset;
 };
 struct FFHipScale16Args {
     FFHipScale16Plane pl[3];

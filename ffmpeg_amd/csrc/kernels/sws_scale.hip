@@ -97,9 +97,19 @@ __device__ __forceinline__ void tile_load(uint8_t *srcT, int spitch, int max_row
 
 /* stage 2: horizontal pass over the LDS footprint; thread = one output column pair, all rows.
  * `tw_full` is the nominal tile width (thread mapping), `tw` the valid width of this tile. */
+/* the reference's range conversion on a 15-bit horizontal sum, int16 in and out as its line buffers are (swscale.c:160-207) */
+__device__ __forceinline__ int range15(int v, int coeff, int offset, int clip)
+{
+    if (!coeff)
+        return v;
+    v = ((int)(int16_t)v * coeff + offset) >> 14;
+    return clip ? min(v, 32767) : v;
+}
+
 template <int C, int HFS>
 __device__ __forceinline__ void tile_hscale(const uint8_t *srcT, int spitch, int16_t *hs, int hpitch, int max_rows,
-                                            int nrows, const FFHipDevFilter &h, int x0, int tw_full, int tw, int c0a)
+                                            int nrows, const FFHipDevFilter &h, int x0, int tw_full, int tw, int c0a,
+                                            int rc_coeff = 0, int rc_offset = 0, int rc_clip = 0)
 {
     const int tid = threadIdx.x;
     const int hfs = HFS ? HFS : h.size;
@@ -134,8 +144,8 @@ __device__ __forceinline__ void tile_hscale(const uint8_t *srcT, int spitch, int
                          (int)((wa >> 16) & 0xFF) * ka[2] + (int)(wa >> 24) * ka[3];
                 int vb = (int)(wb & 0xFF) * kb[0] + (int)((wb >> 8) & 0xFF) * kb[1] +
                          (int)((wb >> 16) & 0xFF) * kb[2] + (int)(wb >> 24) * kb[3];
-                va = min(va >> 7, 32767);
-                vb = min(vb >> 7, 32767);
+                va = range15(min(va >> 7, 32767), rc_coeff, rc_offset, rc_clip);
+                vb = range15(min(vb >> 7, 32767), rc_coeff, rc_offset, rc_clip);
                 *reinterpret_cast<uint32_t *>(hs + (c * max_rows + r) * hpitch + xa) =
                     ((uint32_t)va & 0xFFFF) | ((uint32_t)vb << 16);
             }
@@ -148,8 +158,8 @@ __device__ __forceinline__ void tile_hscale(const uint8_t *srcT, int spitch, int
                     va += (int)row[pa + j] * fa[j];
                     vb += (int)row[pb + j] * fb[j];
                 }
-                va = min(va >> 7, 32767);
-                vb = min(vb >> 7, 32767);
+                va = range15(min(va >> 7, 32767), rc_coeff, rc_offset, rc_clip);
+                vb = range15(min(vb >> 7, 32767), rc_coeff, rc_offset, rc_clip);
                 *reinterpret_cast<uint32_t *>(hs + (c * max_rows + r) * hpitch + xa) =
                     ((uint32_t)va & 0xFFFF) | ((uint32_t)vb << 16);
             }
@@ -181,7 +191,7 @@ __device__ __forceinline__ void scale_plane_body(const FFHipScalePlaneArgs &a, u
     g.step = a.src_step; g.srcW = a.srcW;
     tile_load<C>(srcT, spitch, a.max_rows, g, f, r0, nrows, c0a, c1, src_vec);
     __syncthreads();
-    tile_hscale<C, HFS>(srcT, spitch, hs, hpitch, a.max_rows, nrows, a.h, x0, a.tw, tw, c0a);
+    tile_hscale<C, HFS>(srcT, spitch, hs, hpitch, a.max_rows, nrows, a.h, x0, a.tw, tw, c0a, a.rc_coeff, a.rc_offset, a.rc_clip);
     __syncthreads();
 
     /* ---------------- stage 3: vertical pass, LDS int16 -> HBM u8 ---------------- */

@@ -119,7 +119,20 @@ __global__ __launch_bounds__(256) void k_sws_scale16(FFHipScale16Args a)
                     for (int j = 0; j < hfs; j++)
                         acc += (unsigned)(s16_src(row, p, c0 + sp + j) * (int)hf[j]);
                 }
-                hs[r * S16_TW + lx] = min((int)acc >> sh, lim);
+                int hv = min((int)acc >> sh, lim);
+                if (p.rc_coeff) {
+                    /* lum / chrRangeTo / FromJpeg[16]_c (swscale.c:160-255): 15-bit intermediates live in int16 line buffers and use
+                     * 32-bit products, 19-bit ones in int32 with 64-bit products */
+                    if (lim == (1 << 15) - 1) {
+                        hv = ((int)(int16_t)hv * (int)(uint16_t)p.rc_coeff + (int)p.rc_offset) >> 14;
+                        hv = (int)(int16_t)(p.rc_clip ? min(hv, lim) : hv);
+                    } else {
+                        hv = (int)(((int64_t)hv * p.rc_coeff + p.rc_offset) >> 18);
+                        if (p.rc_clip)
+                            hv = min(hv, lim);
+                    }
+                }
+                hs[r * S16_TW + lx] = hv;
             }
         __syncthreads();
         /* stage 2: a lane per column, output rows yc + lg, + 4, ... */

@@ -286,6 +286,11 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         ffhip_set_error("ffhip_sws: 4:2:2 / 4:4:4 sources to packed RGB are not on the hip path");
         return nullptr;
     }
+    if (t->src_range != t->dst_range && fmt_rgb(t->dstFormat)) {
+        /* the reference folds the source's range into the yuv2rgb tables (ff_yuv2rgb_c_init_tables' fullRange branch) */
+        ffhip_set_error("ffhip_sws: full-range YUV to packed RGB is not on the hip path");
+        return nullptr;
+    }
     if (!ffhip_have_device()) {
         ffhip_set_error("ffhip_sws: no HIP device (FFHIP_ENOSYS) - keep the C function pointers");
         return nullptr;
@@ -345,7 +350,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
 
     if (fmt_hbd(t->srcFormat) || fmt_hbd(t->dstFormat)) {
         /* above 8 bits on either side: the 16-bit scaler takes the banks as they are */
-        if (fmt_rgb(t->dstFormat) || (t->srcW == t->dstW && t->srcH == t->dstH) || t->srcFormat == FFHIP_PIX_FMT_NV21 ||
+        if (fmt_rgb(t->dstFormat) || (t->srcW == t->dstW && t->srcH == t->dstH && t->src_range == t->dst_range) || t->srcFormat == FFHIP_PIX_FMT_NV21 ||
             t->dstFormat == FFHIP_PIX_FMT_NV21) {
             ffhip_set_error("ffhip_sws: above 8 bits the hip path scales between the YUV formats only (no packed RGB, no equal-size conversion, no NV21 mix)");
             ffhip_sws_freeContext(c);
@@ -415,9 +420,24 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         l.h = c->d[0]; l.v = c->d[2];
         ch.srcW = c->chrSrcW; ch.srcH = c->chrSrcH; ch.dstW = c->d[1].n; ch.dstH = c->d[3].n;
         ch.h = c->d[1]; ch.v = c->d[3];
+        const bool rc = t->src_range != t->dst_range;
+        if (rc) {
+            /* lum / chrRangeToJpeg_c, ...FromJpeg_c (swscale.c:160-207): 16-bit coefficient, 32-bit offset at 15-bit intermediates */
+            l.rc_coeff = (int)(uint16_t)t->lumConvertRange_coeff; l.rc_offset = (int)t->lumConvertRange_offset; l.rc_clip = !t->src_range;
+            ch.rc_coeff = (int)(uint16_t)t->chrConvertRange_coeff; ch.rc_offset = (int)t->chrConvertRange_offset; ch.rc_clip = !t->src_range;
+        }
         r = ffhip_plan_scale_plane(&l, 1, c->p[0].data(), c->p[2].data());
         if (!r)
             r = ffhip_plan_scale_plane(&ch, 2, c->p[1].data(), c->p[3].data());
+        if (rc) {
+            /* the static-schedule and walker kernels carry no range stage: the general tiled kernel serves these contexts */
+            if (r) {
+                ffhip_set_error("ffhip_sws: bank sizes outside the tiled kernel's range");
+                ffhip_sws_freeContext(c);
+                return nullptr;
+            }
+            return c;
+        }
         const int limits[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
         {
             const bool ok = build_fast_view(c, limits, false);
@@ -661,6 +681,11 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
         p.dstW = p.h.n; p.dstH = p.v.n;
         p.dither = dd == 8 && sd > 8;       /* swscale.c:291: should_dither = isNBPS(src) || is16BPS(src) */
         p.dither_off = pl == 2 ? 3 : 0;     /* vscale.c: the V plane reads the dither row three entries on; yuv2nv12cX_c: (i + 3) & 7 */
+        if (t.src_range != t.dst_range) {
+            p.rc_coeff = pl ? t.chrConvertRange_coeff : t.lumConvertRange_coeff;
+            p.rc_offset = pl ? t.chrConvertRange_offset : t.lumConvertRange_offset;
+            p.rc_clip = !t.src_range;
+        }
     }
     a.staged = c->hbd == 2;
     a.sw_pitch = c->hbd_sw;

@@ -61,11 +61,13 @@ def alloc_batch(fmt, w, h, n, device, align=256, fill=None):
 class HostTables:
     """ffhip_sws_tables_*: filter banks / coefficients without touching a device (host logic)."""
 
-    def __init__(self, srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags):
+    def __init__(self, srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags, ranges=None):
         L = _lib.lib()
         self._h = L.ffhip_sws_tables_create(srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags)
         if not self._h:
             raise ValueError(L.ffhip_last_error().decode())
+        if ranges is not None:   # sws_setColorspaceDetails()'s srcRange / dstRange
+            _lib.check(L.ffhip_sws_tables_set_ranges(self._h, int(ranges[0]), int(ranges[1])), "ffhip_sws_tables_set_ranges")
         self.t = _lib.SwsTables()
         _lib.check(L.ffhip_sws_tables_get(self._h, C.byref(self.t)))
         self.unscaled_yuv2rgb = bool(L.ffhip_sws_tables_is_unscaled_yuv2rgb(self._h))

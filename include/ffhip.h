@@ -197,6 +197,13 @@ typedef struct FFHipSwsTables {
      * (libswscale/yuv2rgb.c:717-800): cy, oy, crv', cbu', cgu', cgv' and the ramp offset yoffs. */
     int64_t yuv2rgb_cy, yuv2rgb_oy, yuv2rgb_crv, yuv2rgb_cbu, yuv2rgb_cgu, yuv2rgb_cgv;
     int     yuv2rgb_yoffs;
+    /* Range conversion between YUV formats (round 3): c->opts.src_range / dst_range (0 limited, 1 full) and, when they differ,
+     * the constants of c->lumConvertRange / chrConvertRange (ff_sws_init_range_convert + init_range_convert_constants,
+     * libswscale/swscale.c:591-660), which the scaler applies to its horizontal intermediates: lumRangeToJpeg_c & co
+     * (swscale.c:160-255).  Packed RGB targets take the range through the yuv2rgb coefficients instead (not these fields). */
+    int      src_range, dst_range;
+    uint32_t lumConvertRange_coeff, chrConvertRange_coeff;
+    int64_t  lumConvertRange_offset, chrConvertRange_offset;
 } FFHipSwsTables;
 
 typedef struct FFHipSwsContext FFHipSwsContext;
@@ -247,6 +254,11 @@ int  ffhip_sws_tables_get(const FFHipSwsHostTables *t, FFHipSwsTables *out);
 /** 1 when the (src,dst,flags) triple takes the reference's table-driven unscaled converter
  *  `yuv2rgb_c_24_rgb` (rule at libswscale/swscale_unscaled.c:2425-2431), 0 for ff_swscale(). */
 int  ffhip_sws_tables_is_unscaled_yuv2rgb(const FFHipSwsHostTables *t);
+/** The srcRange / dstRange arguments of sws_setColorspaceDetails() (libswscale/utils.c:848-1000) for YUV targets: 0 limited
+ *  (MPEG), 1 full (JPEG).  When they differ the tables carry the constants of c->lumConvertRange / chrConvertRange and the
+ *  scaler applies them to its horizontal intermediates (swscale.c:160-255); a J format on one side of
+ *  ffhip_sws_tables_create() sets the same.  Call before ffhip_sws_tables_get(). */
+int  ffhip_sws_tables_set_ranges(FFHipSwsHostTables *t, int src_range, int dst_range);
 void ffhip_sws_tables_free(FFHipSwsHostTables *t);
 
 /**

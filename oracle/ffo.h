@@ -43,7 +43,14 @@ typedef struct FfoSwsTables {
     int srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags;
     FfoSwsFilter hLum, hChr, vLum, vChr;
     FfoYuv2RgbCoeffs k;
+    /* range conversion between YUV formats: c->opts.src_range / dst_range and the constants of c->lum / chrConvertRange
+     * (init_range_convert_constants, libswscale/swscale.c:591-624); all zero: none */
+    int src_range, dst_range;
+    uint32_t lum_rc_coeff, chr_rc_coeff;
+    int64_t lum_rc_offset, chr_rc_offset;
 } FfoSwsTables;
+/* init_range_convert_constants() for a source of range src_range (1 = full) going to the other one at a target of dst_depth bits */
+void ffo_sws_range_constants(int src_range, int dst_depth, uint32_t *lum_coeff, int64_t *lum_offset, uint32_t *chr_coeff, int64_t *chr_offset);
 
 void ffo_yuv2rgb_luts_init(FfoYuv2RgbLuts *l, const FfoYuv2RgbCoeffs *k);
 int  ffo_yuv420p_to_rgb24(const FfoYuv2RgbLuts *l, int width, const uint8_t *const src[3], const int srcStride[3],

@@ -238,6 +238,41 @@ static int rgb_layout(int fmt)
 }
 static int is_rgb(int fmt) { return rgb_layout(fmt) >= 0; }
 
+/* solve_range_convert / init_range_convert_constants (libswscale/swscale.c:568-624) */
+static void range_solve(unsigned src_min, unsigned src_max, unsigned dst_min, unsigned dst_max, int src_shift, int mult_shift,
+                        uint32_t *coeff, int64_t *offset)
+{
+    const unsigned src_range = (uint16_t)(src_max - src_min), dst_range = (uint16_t)(dst_max - dst_min);
+    const int total_shift = mult_shift + src_shift;
+    const uint64_t q = ((uint64_t)dst_range << total_shift) / src_range;
+    *coeff = (uint32_t)-((-(int64_t)q) >> src_shift); /* AV_CEIL_RSHIFT */
+    *offset = ((int64_t)dst_max << total_shift) - ((int64_t)src_max << src_shift) * *coeff + (1U << (mult_shift - 1));
+}
+void ffo_sws_range_constants(int src_range, int dst_depth, uint32_t *lum_coeff, int64_t *lum_offset, uint32_t *chr_coeff, int64_t *chr_offset)
+{
+    const int bit_depth = dst_depth > 16 ? 16 : dst_depth;
+    const int src_bits = bit_depth <= 14 ? 15 : 19, src_shift = src_bits - bit_depth, mult_shift = bit_depth <= 14 ? 14 : 18;
+    const unsigned mpeg_min = 16U << (bit_depth - 8), mpeg_max_lum = 235U << (bit_depth - 8), mpeg_max_chr = 240U << (bit_depth - 8);
+    const unsigned jpeg_max = (1U << bit_depth) - 1;
+    if (src_range) {
+        range_solve(0, jpeg_max, mpeg_min, mpeg_max_lum, src_shift, mult_shift, lum_coeff, lum_offset);
+        range_solve(0, jpeg_max, mpeg_min, mpeg_max_chr, src_shift, mult_shift, chr_coeff, chr_offset);
+    } else {
+        range_solve(mpeg_min, mpeg_max_lum, 0, jpeg_max, src_shift, mult_shift, lum_coeff, lum_offset);
+        range_solve(mpeg_min, mpeg_max_chr, 0, jpeg_max, src_shift, mult_shift, chr_coeff, chr_offset);
+    }
+}
+/* lumRangeToJpeg_c / lumRangeFromJpeg_c and the chroma pair on one int16 line (swscale.c:160-207) */
+static void range15_line(int16_t *dst, int width, uint32_t coeff_, int64_t offset_, int to_jpeg)
+{
+    const uint16_t coeff = (uint16_t)coeff_;
+    const int32_t offset = (int32_t)offset_;
+    for (int i = 0; i < width; i++) {
+        const int v = (dst[i] * coeff + offset) >> 14;
+        dst[i] = (int16_t)(to_jpeg && v > (1 << 15) - 1 ? (1 << 15) - 1 : v);
+    }
+}
+
 int ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], const int srcStride[3],
                         uint8_t *const dst[3], const int dstStride[3])
 {
@@ -279,6 +314,15 @@ int ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], cons
         }
         ffo_hscale8to15(hu + (size_t)y * cpitch, chrDstW, pu, t->hChr.filter, t->hChr.pos, t->hChr.size);
         ffo_hscale8to15(hv + (size_t)y * cpitch, chrDstW, pv, t->hChr.filter, t->hChr.pos, t->hChr.size);
+    }
+    /* c->lumConvertRange / chrConvertRange on every horizontal line (ff_swscale via lum_convert / chr_convert, hscale.c) */
+    if (t->src_range != t->dst_range && !is_rgb(t->dstFormat)) {
+        for (int y = 0; y < srcH; y++)
+            range15_line(hl + (size_t)y * lpitch, dstW, t->lum_rc_coeff, t->lum_rc_offset, !t->src_range);
+        for (int y = 0; y < chrSrcH; y++) {
+            range15_line(hu + (size_t)y * cpitch, chrDstW, t->chr_rc_coeff, t->chr_rc_offset, !t->src_range);
+            range15_line(hv + (size_t)y * cpitch, chrDstW, t->chr_rc_coeff, t->chr_rc_offset, !t->src_range);
+        }
     }
 
     if (is_rgb(t->dstFormat)) {

@@ -59,6 +59,22 @@ static void hscale(int32_t *dst, int dstW, const uint8_t *row, int depth, int la
     }
 }
 
+/* c->lumConvertRange / chrConvertRange on one horizontal line: the 15-bit forms work on int16 lines with a 16-bit coefficient and a
+ * 32-bit offset (lumRangeToJpeg_c ..., swscale.c:160-207), the 19-bit ones on int32 lines with 64-bit products
+ * (lumRangeToJpeg16_c ..., :209-255) */
+static void range_line(int32_t *dst, int width, uint32_t coeff, int64_t offset, int to_jpeg, int wide)
+{
+    for (int i = 0; i < width; i++) {
+        if (!wide) {
+            const int v = ((int16_t)dst[i] * (int)(uint16_t)coeff + (int32_t)offset) >> 14;
+            dst[i] = (int16_t)(to_jpeg && v > (1 << 15) - 1 ? (1 << 15) - 1 : v);
+        } else {
+            const int v = (int)(((int64_t)dst[i] * coeff + offset) >> 18);
+            dst[i] = to_jpeg && v > (1 << 19) - 1 ? (1 << 19) - 1 : v;
+        }
+    }
+}
+
 /* one output sample from its vertical taps */
 static inline int vout(const int32_t *const *rows, const int16_t *vf, int vfs, int x, int ddepth, int wide, int dither)
 {
@@ -131,6 +147,14 @@ int ffo_sws_scale_frame_hbd(const FfoSwsTables *t, int sdepth, int slayout, int 
         const uint8_t *ru = src[1] + (ptrdiff_t)y * srcStride[1], *rv = semi ? ru : src[2] + (ptrdiff_t)y * srcStride[2];
         hscale(hu + y * cp, chrDstW, ru, sdepth, slayout, semi ? 0 : -1, t->hChr.filter, t->hChr.pos, t->hChr.size, wide);
         hscale(hv + y * cp, chrDstW, rv, sdepth, slayout, semi ? 1 : -1, t->hChr.filter, t->hChr.pos, t->hChr.size, wide);
+    }
+    if (t->src_range != t->dst_range) {
+        for (int y = 0; y < srcH; y++)
+            range_line(hl + y * lp, dstW, t->lum_rc_coeff, t->lum_rc_offset, !t->src_range, wide);
+        for (int y = 0; y < csh; y++) {
+            range_line(hu + y * cp, chrDstW, t->chr_rc_coeff, t->chr_rc_offset, !t->src_range, wide);
+            range_line(hv + y * cp, chrDstW, t->chr_rc_coeff, t->chr_rc_offset, !t->src_range, wide);
+        }
     }
     for (int y = 0; y < dstH; y++) {
         for (int j = 0; j < t->vLum.size; j++)

@@ -15,6 +15,7 @@
 
 /* ---- libswscale ---- */
 void *ffref_sws_create(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt, int flags, int threads);
+void *ffref_sws_create_ranges(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt, int flags, int threads, int src_range, int dst_range);
 void  ffref_sws_free(void *ctx);
 int   ffref_sws_scale(void *ctx, const uint8_t *const src[], const int srcStride[], int y, int h,
                       uint8_t *const dst[], const int dstStride[]);

@@ -45,6 +45,29 @@ void *ffref_sws_create(int srcW, int srcH, int srcFmt, int dstW, int dstH, int d
     }
     return sws;
 }
+/* the same with c->opts.src_range / dst_range given (1 = full range): what sws_setColorspaceDetails() or a J format sets */
+void *ffref_sws_create_ranges(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt, int flags, int threads, int src_range, int dst_range)
+{
+    pure_c();
+    SwsContext *sws = sws_alloc_context();
+    if (!sws)
+        return NULL;
+    av_opt_set_int(sws, "srcw", srcW, 0);
+    av_opt_set_int(sws, "srch", srcH, 0);
+    av_opt_set_int(sws, "src_format", srcFmt, 0);
+    av_opt_set_int(sws, "dstw", dstW, 0);
+    av_opt_set_int(sws, "dsth", dstH, 0);
+    av_opt_set_int(sws, "dst_format", dstFmt, 0);
+    av_opt_set_int(sws, "sws_flags", flags, 0);
+    av_opt_set_int(sws, "threads", threads, 0);
+    av_opt_set_int(sws, "src_range", src_range, 0);
+    av_opt_set_int(sws, "dst_range", dst_range, 0);
+    if (sws_init_context(sws, NULL, NULL) < 0) {
+        sws_freeContext(sws);
+        return NULL;
+    }
+    return sws;
+}
 void ffref_sws_free(void *ctx) { sws_freeContext(ctx); }
 int ffref_sws_scale(void *ctx, const uint8_t *const src[], const int srcStride[], int y, int h,
                     uint8_t *const dst[], const int dstStride[])

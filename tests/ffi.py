@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libffref.so")
 
-PIX = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
+PIX = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "yuvj420p": 12, "yuvj422p": 13, "yuvj444p": 14, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
 RGB_LAYOUT = {2: 0, 3: 1, 25: 2, 26: 3, 27: 4, 28: 5}   # AVPixelFormat -> the oracle's packed layout number
 SWS_BICUBIC, SWS_BILINEAR, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 4, 2, 0x10, 0x20, 0x40
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
@@ -39,7 +39,9 @@ class OYuv2RgbCoeffs(C.Structure):
 
 class OSwsTables(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("srcW", "srcH", "srcFormat", "dstW", "dstH", "dstFormat", "flags")] + \
-               [(k, OSwsFilter) for k in ("hLum", "hChr", "vLum", "vChr")] + [("k", OYuv2RgbCoeffs)]
+               [(k, OSwsFilter) for k in ("hLum", "hChr", "vLum", "vChr")] + [("k", OYuv2RgbCoeffs)] + \
+               [("src_range", C.c_int), ("dst_range", C.c_int), ("lum_rc_coeff", C.c_uint32), ("chr_rc_coeff", C.c_uint32),
+                ("lum_rc_offset", C.c_int64), ("chr_rc_offset", C.c_int64)]
 
 
 class OLuts(C.Structure):
@@ -80,6 +82,8 @@ def oracle():
         L.ffo_yuv2rgb_1.argtypes = [C.POINTER(OLuts), i16p, pp, pp, u8p, C.c_int, C.c_int, C.c_int]
         for f in (L.ffo_yuv2rgb_X, L.ffo_yuv2rgb_2, L.ffo_yuv2rgb_1):
             f.restype = None
+        L.ffo_sws_range_constants.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
+        L.ffo_sws_range_constants.restype = None
         L.ffo_sws_scale_frame.argtypes = [C.POINTER(OSwsTables), C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(u8p),
                                           C.POINTER(C.c_int)]
         for n in ("ffo_h264_idct_add", "ffo_h264_idct8_add", "ffo_h264_idct_dc_add", "ffo_h264_idct8_dc_add"):
@@ -255,6 +259,8 @@ def ref():
         L = C.CDLL(REF_SO)
         L.ffref_sws_create.argtypes = [C.c_int] * 8
         L.ffref_sws_create.restype = C.c_void_p
+        L.ffref_sws_create_ranges.argtypes = [C.c_int] * 10
+        L.ffref_sws_create_ranges.restype = C.c_void_p
         L.ffref_sws_free.argtypes = [C.c_void_p]
         L.ffref_sws_free.restype = None
         L.ffref_sws_scale.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int,
@@ -445,9 +451,15 @@ def ref_tables(ctx):
 DEFAULT_COEFFS = dict(cy=76309, oy=16 << 16, crv=89830, cbu=113537, cgu=-22049, cgv=-45756, yoffs=838)
 
 
-def make_otables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, banks, coeffs=DEFAULT_COEFFS):
-    """banks: dict name -> (filter int16[], pos int32[], size, n).  Keeps numpy refs alive on the struct."""
+def make_otables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, banks, coeffs=DEFAULT_COEFFS, ranges=None, dst_depth=8):
+    """banks: dict name -> (filter int16[], pos int32[], size, n).  Keeps numpy refs alive on the struct.
+    ranges = (src_range, dst_range): the oracle derives the conversion constants itself (ffo_sws_range_constants)."""
     t = OSwsTables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags)
+    if ranges is not None and ranges[0] != ranges[1]:
+        t.src_range, t.dst_range = ranges
+        lc, cc, lo, co = C.c_uint32(), C.c_uint32(), C.c_int64(), C.c_int64()
+        oracle().ffo_sws_range_constants(ranges[0], dst_depth, C.byref(lc), C.byref(lo), C.byref(cc), C.byref(co))
+        t.lum_rc_coeff, t.chr_rc_coeff, t.lum_rc_offset, t.chr_rc_offset = lc.value, cc.value, lo.value, co.value
     keep = []
     for name in ("hLum", "hChr", "vLum", "vChr"):
         f, p, fs, n = banks[name]

@@ -188,8 +188,9 @@ def test_full_range_twins(name, base):
     for p, a in enumerate(want):
         assert np.array_equal(ddst[p][1].cpu().numpy(), a)
     ctx.close()
-    with pytest.raises(ValueError):
-        S.SwsContext(sw, sh, S.PIX_FMT[name], dw, dh, PIX[base], ffi.SWS_BICUBIC)
+    # a J format on one side only is a range conversion (test_range_conversion below); packed RGB targets refuse it
+    with pytest.raises(ValueError, match="full-range"):
+        S.SwsContext(sw, sh, S.PIX_FMT[name], dw, dh, PIX["rgb24"], ffi.SWS_BICUBIC)
 
 
 def test_from_tables_dropin():
@@ -256,3 +257,55 @@ def test_vscale_line_face(fs):
         _lib.check(L.ffhip_sws_yuv2planeX8_dev(d_f.data_ptr(), fs, d_l.data_ptr(), lines.strides[0], d_o.data_ptr(), dstW,
                                                d_d.data_ptr(), off, torch.cuda.current_stream().cuda_stream))
         assert np.array_equal(d_o.cpu().numpy(), want)
+
+
+RANGE_CASES = [("yuvj420p", 64, 40, "yuv420p", 160, 88, ffi.SWS_BICUBIC), ("yuv420p", 64, 40, "yuvj420p", 160, 88, ffi.SWS_BICUBIC),
+               ("yuvj420p", 96, 54, "yuv420p", 96, 54, ffi.SWS_BICUBIC), ("yuv420p", 96, 54, "yuvj420p", 96, 54, ffi.SWS_BILINEAR),
+               ("yuvj444p", 64, 40, "yuv422p", 48, 30, ffi.SWS_BICUBIC), ("yuv422p", 80, 40, "yuvj420p", 120, 90, ffi.SWS_BILINEAR),
+               ("yuvj420p", 64, 40, "nv12", 128, 80, ffi.SWS_BICUBIC), ("nv12", 64, 40, "yuvj420p", 100, 60, ffi.SWS_BICUBIC),
+               ("yuvj420p", 200, 120, "yuv420p", 50, 30, ffi.SWS_BICUBIC), ("yuvj420p", 1920, 1080, "yuv420p", 3840, 2160, ffi.SWS_BICUBIC),
+               ("yuv420p", 1920, 1080, "yuvj420p", 1280, 720, ffi.SWS_BICUBIC)]
+
+
+@pytest.mark.parametrize("case", RANGE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_range_conversion(case):
+    """a full-range (J) format on one side: lum / chrRangeToJpeg_c, ...FromJpeg_c on the horizontal intermediates (libswscale/
+    swscale.c:160-207) — HIP == oracle (pinned to the reference by tests/test_oracle_vs_ref.py::test_range_conversion), extreme samples
+    included; these contexts run on the general tiled kernel (the static-schedule kernels carry no range stage)"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    sf, sw, sh, df, dw, dh, flags = case
+    base = {"yuvj420p": "yuv420p", "yuvj422p": "yuv422p", "yuvj444p": "yuv444p"}
+    bs, bd = base.get(sf, sf), base.get(df, df)
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    src = ffi.alloc_frame(PIX[bs], sw, sh, rng, pad=0)
+    for pl in src:
+        pl[::5, : pl.shape[1] // 2] = 255
+        pl[3::7, pl.shape[1] // 3:] = 0
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    ranges = (int(sf in base), int(df in base))
+    assert (ht.t.src_range, ht.t.dst_range) == ranges
+    t = ffi.make_otables(sw, sh, PIX[bs], dw, dh, PIX[bd], flags, ht.banks(), ht.coeffs(), ranges=ranges)
+    want = ffi.alloc_frame(PIX[bd], dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(want)
+    assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+    ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    assert ctx.fast_path is False and not ctx.up2_path
+    n = 2
+    dsrc = _upload(src, n=n)
+    ddst = [torch.zeros((n,) + a.shape, dtype=torch.uint8, device="cuda:0") for a in want]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        for p, a in enumerate(want):
+            got = ddst[p][f].cpu().numpy()
+            assert np.array_equal(got, a), "frame %d plane %d: %d mismatches" % (f, p, (got != a).sum())
+    # ... and differs from the same conversion without the range change (the stage is not a no-op)
+    ctx2 = S.SwsContext(sw, sh, PIX[bs], dw, dh, PIX[bd], flags)
+    d2 = [torch.zeros_like(x) for x in ddst]
+    ctx2.scale_batch(dsrc, d2)
+    torch.cuda.synchronize()
+    assert not torch.equal(d2[0], ddst[0])
+    with pytest.raises(ValueError, match="full-range"):
+        S.SwsContext(sw, sh, PIX["yuvj420p"], dw & ~1, dh, PIX["rgb24"], flags)

@@ -9,7 +9,7 @@ import pytest
 
 import ffi
 from ffi import u8p
-from test_oracle_vs_ref_sws_hbd import CASES, FMT, make_frame, planes_of, oracle_tables
+from test_oracle_vs_ref_sws_hbd import CASES, FMT, RANGE_CASES, make_frame, planes_of, oracle_tables
 
 pytestmark = pytest.mark.gpu
 
@@ -31,15 +31,21 @@ def _oracle_frame(t, sname, dname, src, dw, dh, pad):
     return want
 
 
-def _run(case, nframes=3, pad=8):
+def _run(case, nframes=3, pad=8, ranges=None):
     from ffmpeg_amd import swscale as S
     torch = _torch()
     sname, sw, sh, dname, dw, dh, flags = case
     rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
-    ht, t = oracle_tables(sname, sw, sh, dname, dw, dh, flags)
+    if ranges is None:
+        ht, t = oracle_tables(sname, sw, sh, dname, dw, dh, flags)
+    else:   # sws_setColorspaceDetails()'s srcRange / dstRange: the tables carry them, the context is built from the tables
+        ht = S.HostTables(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags, ranges=ranges)
+        t = ffi.make_otables(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags, ht.banks(), ht.coeffs(), ranges=ranges, dst_depth=FMT[dname][1])
+        assert (ht.t.lumConvertRange_coeff, ht.t.lumConvertRange_offset, ht.t.chrConvertRange_coeff, ht.t.chrConvertRange_offset) == \
+               (t.lum_rc_coeff, t.lum_rc_offset, t.chr_rc_coeff, t.chr_rc_offset)
     frames = [make_frame(sname, sw, sh, rng, pad=pad) for _ in range(nframes)]
     wants = [_oracle_frame(t, sname, dname, f, dw, dh, pad) for f in frames]
-    ctx = S.SwsContext(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags)
+    ctx = S.SwsContext(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags, tables=ht.t if ranges is not None else None)
     nsp, ndp = len(frames[0]), len(wants[0])
     src = [torch.from_numpy(np.stack([f[i] for f in frames]).view(np.uint8)).cuda() for i in range(nsp)]
     dst = [torch.zeros((nframes,) + tuple(wants[0][i].view(np.uint8).shape), dtype=torch.uint8, device="cuda") for i in range(ndp)]
@@ -64,6 +70,12 @@ def _run(case, nframes=3, pad=8):
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
 def test_scale_above_8_bits(case):
     _run(case)
+
+
+@pytest.mark.parametrize("case", RANGE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x_%d%d" % c)
+def test_range_conversion_above_8_bits(case):
+    """lumRangeToJpeg_c ... / the ...16_c forms (19-bit intermediates, 64-bit products) inside k_sws_scale16"""
+    _run(case[:7], ranges=case[7:])
 
 
 def test_p010_1080p_to_4k():

@@ -137,8 +137,55 @@ def test_full_range_twins_are_their_base_formats(base, j):
         f, p, fs, n = ht.bank(name)
         rf, rp, rfs, rn = outs[1][1][name]
         assert (fs, n) == (rfs, rn) and np.array_equal(p, rp) and np.array_equal(f, rf), name
-    with pytest.raises(ValueError, match="one side only"):
-        S.HostTables(sw, sh, j, dw, dh, base, ffi.SWS_BICUBIC)
+    # a J format on one side only: a range conversion between YUV formats (round 3), refused for packed RGB targets
+    ht = S.HostTables(sw, sh, j, dw, dh, base, ffi.SWS_BICUBIC)
+    assert (ht.t.srcFormat, ht.t.dstFormat, ht.t.src_range, ht.t.dst_range) == (base, base, 1, 0)
+    with pytest.raises(ValueError, match="full-range"):
+        S.HostTables(sw, sh, j, dw, dh, PIX["rgb24"], ffi.SWS_BICUBIC)
+
+
+RANGE_CASES = [("yuvj420p", 64, 40, "yuv420p", 160, 88, ffi.SWS_BICUBIC), ("yuv420p", 64, 40, "yuvj420p", 160, 88, ffi.SWS_BICUBIC),
+               ("yuvj420p", 96, 54, "yuv420p", 96, 54, ffi.SWS_BICUBIC),      # equal sizes: the scaler with one-tap banks, not a copy
+               ("yuv420p", 96, 54, "yuvj420p", 96, 54, ffi.SWS_BILINEAR),
+               ("yuvj444p", 64, 40, "yuv422p", 48, 30, ffi.SWS_BICUBIC), ("yuv422p", 80, 40, "yuvj420p", 120, 90, ffi.SWS_BILINEAR),
+               ("yuvj420p", 64, 40, "nv12", 128, 80, ffi.SWS_BICUBIC), ("nv12", 64, 40, "yuvj420p", 100, 60, ffi.SWS_BICUBIC),
+               ("yuvj420p", 200, 120, "yuv420p", 50, 30, ffi.SWS_BICUBIC)]
+
+
+@pytest.mark.parametrize("case", RANGE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_range_conversion(case):
+    """lumRangeToJpeg_c / lumRangeFromJpeg_c / chrRange*_c between the horizontal and the vertical pass (libswscale/swscale.c:160-207,
+    591-660): oracle == reference on extreme samples (the ToJpeg clip, the int16 wrap of FromJpeg) as well as noise; the constants
+    libffhip's host side derives == the reference's"""
+    from ffmpeg_amd import swscale as S
+    sf, sw, sh, df, dw, dh, flags = case
+    base = {"yuvj420p": "yuv420p", "yuvj422p": "yuv422p", "yuvj444p": "yuv444p"}
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    bs, bd = base.get(sf, sf), base.get(df, df)
+    src = ffi.alloc_frame(PIX[bs], sw, sh, rng, pad=3)
+    for pl in src:
+        pl[::5, : pl.shape[1] // 2] = 255
+        pl[3::7, pl.shape[1] // 3:] = 0
+    ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, PIX[df], flags, 1)
+    assert ctx and not R.ffref_sws_is_unscaled(ctx)
+    want = ffi.alloc_frame(PIX[bd], dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(want)
+    assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, dp, ds) == dh
+    banks = ffi.ref_tables(ctx)
+    R.ffref_sws_free(ctx)
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    ranges = (int(sf in base), int(df in base))
+    assert (ht.t.src_range, ht.t.dst_range) == ranges
+    t = ffi.make_otables(sw, sh, PIX[bs], dw, dh, PIX[bd], flags, banks, ranges=ranges)
+    assert (ht.t.lumConvertRange_coeff, ht.t.lumConvertRange_offset, ht.t.chrConvertRange_coeff, ht.t.chrConvertRange_offset) == \
+           (t.lum_rc_coeff, t.lum_rc_offset, t.chr_rc_coeff, t.chr_rc_offset)
+    got = ffi.alloc_frame(PIX[bd], dw, dh)
+    gp, gs = ffi.planes(got)
+    assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b), "plane %d: %d samples differ" % (i, (a != b).sum())
 
 
 @pytest.mark.parametrize("case", SCALE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)

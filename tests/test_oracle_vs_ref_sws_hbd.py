@@ -107,3 +107,37 @@ def test_scaler_above_8_bits(case):
     assert O.ffo_sws_scale_frame_hbd(C.byref(t), sd, sl, dd, dl, sp, ss, gp, gs) == 0
     for i, (a, b) in enumerate(zip(want, got)):
         assert np.array_equal(a, b), "plane %d: %d of %d samples differ (max %d)" % (i, (a != b).sum(), a.size, np.abs(a.astype(int) - b.astype(int)).max())
+
+
+RANGE_CASES = [("yuv420p10le", 64, 36, "yuv420p10le", 128, 72, ffi.SWS_BICUBIC, 1, 0), ("yuv420p10le", 64, 36, "yuv420p10le", 128, 72, ffi.SWS_BICUBIC, 0, 1),
+               ("p010le", 96, 54, "p010le", 96, 54, ffi.SWS_BICUBIC, 0, 1),          # equal sizes with a range change: the scaler, not a copy
+               ("yuv420p16le", 64, 36, "yuv420p16le", 96, 54, ffi.SWS_BICUBIC, 1, 0),  # 19-bit intermediates: lumRangeFromJpeg16_c
+               ("yuv420p16le", 64, 36, "p016le", 96, 54, ffi.SWS_BILINEAR, 0, 1),
+               ("yuv420p", 64, 36, "yuv420p10le", 96, 54, ffi.SWS_BICUBIC, 1, 0), ("yuv420p12le", 96, 54, "yuv420p", 64, 36, ffi.SWS_BICUBIC, 0, 1)]
+
+
+@pytest.mark.parametrize("case", RANGE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x_%d%d" % c)
+def test_range_conversion_above_8_bits(case):
+    """c->lumConvertRange / chrConvertRange at 9..16 bits (lumRangeToJpeg_c ... for targets up to 14 bits, the ...16_c forms with 64-bit
+    products above; libswscale/swscale.c:160-255, 591-660), ranges set the way sws_setColorspaceDetails() sets them"""
+    sname, sw, sh, dname, dw, dh, flags, sr, dr = case
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    src = make_frame(sname, sw, sh, rng, pad=6)
+    want, got = make_frame(dname, dw, dh, None, pad=4), make_frame(dname, dw, dh, None, pad=4)
+    ctx = R.ffref_sws_create_ranges(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags, 1, sr, dr)
+    assert ctx and not R.ffref_sws_is_unscaled(ctx)
+    sp, ss = planes_of(src)
+    wp, ws = planes_of(want)
+    assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, wp, ws) == dh
+    banks = ffi.ref_tables(ctx)
+    R.ffref_sws_free(ctx)
+    _, sd, sl, _, _ = FMT[sname]
+    _, dd, dl, _, _ = FMT[dname]
+    t = ffi.make_otables(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags, banks, ranges=(sr, dr), dst_depth=dd)
+    O.ffo_sws_scale_frame_hbd.argtypes = [C.POINTER(ffi.OSwsTables), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(C.c_int),
+                                          C.POINTER(u8p), C.POINTER(C.c_int)]
+    gp, gs = planes_of(got)
+    assert O.ffo_sws_scale_frame_hbd(C.byref(t), sd, sl, dd, dl, sp, ss, gp, gs) == 0
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert np.array_equal(a, b), "plane %d: %d of %d samples differ (max %d)" % (i, (a != b).sum(), a.size, np.abs(a.astype(int) - b.astype(int)).max())
