@@ -104,6 +104,9 @@ struct FFHipUp2Job {
     const uint32_t *vfv;                /* device: virtual vertical bank, row y at dwords 2 (y + 1): (2 srcH + 18) x 2 dwords, 16-byte aligned */
     int nfull, upj;                     /* full 64-lane column blocks per row; units per (pack of frames, strip) */
     int nstrips, steps_per_strip, unit_begin;
+    /* samples above 8 bits (k_sws_up2<., ., 1>; 0: bytes): depths 9..14 of the little-endian uint16 samples on either side, and
+     * whether they sit in the high bits (P010 / P012).  Groups are then 16 destination bytes. */
+    int hb_sdepth, hb_ddepth, hb_smsb, hb_dmsb;
 };
 struct FFHipUp2Args {
     FFHipUp2Job job[3];

@@ -34,6 +34,7 @@
  * instruction (measured with the arithmetic taken out: 256-byte pieces cost 7 % of the bandwidth).
  */
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -48,15 +49,42 @@ typedef const uint8_t __attribute__((address_space(1))) *up_gcp;
 typedef uint8_t __attribute__((address_space(1))) *up_gp;
 typedef const up_u3a __attribute__((address_space(1))) *up_gc3;
 typedef up_u2 __attribute__((address_space(1))) *up_g2;
+typedef up_u4 __attribute__((aligned(4))) up_u4a;
+typedef up_u2 __attribute__((aligned(4))) up_u2a;
+typedef const up_u4a __attribute__((address_space(1))) *up_gc4;
+typedef const up_u2a __attribute__((address_space(1))) *up_gc2;
+typedef up_u4a __attribute__((address_space(1))) *up_g4;
 typedef const up_u8 __attribute__((address_space(4))) *up_cc8; /* constant address space: scalar loads */
 
 struct UpRaw { uint32_t q[3]; };
+struct UpRawH { uint32_t q[6]; }; /* 16-bit samples: 8 of a plane (4 dwords) or 6 (u, v) columns of an interleaved pair (6 dwords) */
 
 /*
  * Four horizontal samples: d[i] = (pa[i] . ca[i] + pb[i] . cb[i]) >> 7.  The two DOT chains per sample are interleaved
  * four wide; each result is shifted three instructions after its last DOT wrote it, and leaves the block as the
  * result of a plain VALU instruction.
  */
+/* the same for samples above 8 bits: >> (depth - 1) (hScale16To15_c, libswscale/swscale.c:99-126), the shift in an SGPR */
+__device__ __forceinline__ void up_h4s(int (&d)[4], uint32_t pa0, uint32_t pa1, uint32_t pa2, uint32_t pa3, uint32_t pb0,
+                                       uint32_t pb1, uint32_t pb2, uint32_t pb3, const uint32_t *cf, int sh)
+{
+    asm("v_dot2_i32_i16 %0, %4, %12, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %13, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %14, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %15, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %18, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "v_ashrrev_i32 %0, %20, %0\n\t"
+        "v_ashrrev_i32 %1, %20, %1\n\t"
+        "v_ashrrev_i32 %2, %20, %2\n\t"
+        "v_ashrrev_i32 %3, %20, %3"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3), "v"(pb0), "v"(pb1), "v"(pb2), "v"(pb3),
+          "v"(cf[0]), "v"(cf[2]), "v"(cf[4]), "v"(cf[6]), "v"(cf[1]), "v"(cf[3]), "v"(cf[5]), "v"(cf[7]), "s"(sh));
+}
+
 __device__ __forceinline__ void up_h4(int (&d)[4], uint32_t pa0, uint32_t pa1, uint32_t pa2, uint32_t pa3, uint32_t pb0,
                                       uint32_t pb1, uint32_t pb2, uint32_t pb3, const uint32_t *cf)
 {
@@ -113,12 +141,67 @@ __device__ __forceinline__ void up_v8(uint32_t &w0, uint32_t &w1, const uint32_t
 }
 
 /*
+ * The same row for targets above 8 bits (yuv2planeX_10_c_template, libswscale/output.c:341-360): t[i] >> (27 - depth), clipped to
+ * depth bits, two samples per dword: v_cvt_pk_i16_i32 saturates to int16 (depth <= 14: the clip range lies inside), v_pk_max_i16 / v_pk_min_i16
+ * clip the pair to 0 .. 2^depth - 1.
+ */
+__device__ __forceinline__ void up_v8h(uint32_t (&w)[4], const uint32_t (&pa)[8], const uint32_t (&pb)[8], uint32_t f01, uint32_t f23,
+                                       int kround, int sh, uint32_t maxpk)
+{
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_dot2_i32_i16 %4, %12, %28, %30\n\t"
+        "v_dot2_i32_i16 %5, %13, %28, %30\n\t"
+        "v_dot2_i32_i16 %6, %14, %28, %30\n\t"
+        "v_dot2_i32_i16 %7, %15, %28, %30\n\t"
+        "v_dot2_i32_i16 %8, %16, %28, %30\n\t"
+        "v_dot2_i32_i16 %9, %17, %28, %30\n\t"
+        "v_dot2_i32_i16 %10, %18, %28, %30\n\t"
+        "v_dot2_i32_i16 %11, %19, %28, %30\n\t"
+        "v_dot2_i32_i16 %4, %20, %29, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %29, %5\n\t"
+        "v_dot2_i32_i16 %6, %22, %29, %6\n\t"
+        "v_dot2_i32_i16 %7, %23, %29, %7\n\t"
+        "v_dot2_i32_i16 %8, %24, %29, %8\n\t"
+        "v_dot2_i32_i16 %9, %25, %29, %9\n\t"
+        "v_dot2_i32_i16 %10, %26, %29, %10\n\t"
+        "v_dot2_i32_i16 %11, %27, %29, %11\n\t"
+        "v_ashrrev_i32 %4, %31, %4\n\t"
+        "v_ashrrev_i32 %5, %31, %5\n\t"
+        "v_ashrrev_i32 %6, %31, %6\n\t"
+        "v_ashrrev_i32 %7, %31, %7\n\t"
+        "v_ashrrev_i32 %8, %31, %8\n\t"
+        "v_ashrrev_i32 %9, %31, %9\n\t"
+        "v_ashrrev_i32 %10, %31, %10\n\t"
+        "v_ashrrev_i32 %11, %31, %11\n\t"
+        "v_cvt_pk_i16_i32 %0, %4, %5\n\t"
+        "v_cvt_pk_i16_i32 %1, %6, %7\n\t"
+        "v_cvt_pk_i16_i32 %2, %8, %9\n\t"
+        "v_cvt_pk_i16_i32 %3, %10, %11\n\t"
+        "v_pk_max_i16 %0, %0, 0\n\t"
+        "v_pk_max_i16 %1, %1, 0\n\t"
+        "v_pk_max_i16 %2, %2, 0\n\t"
+        "v_pk_max_i16 %3, %3, 0\n\t"
+        "v_pk_min_i16 %0, %0, %32\n\t"
+        "v_pk_min_i16 %1, %1, %32\n\t"
+        "v_pk_min_i16 %2, %2, %32\n\t"
+        "v_pk_min_i16 %3, %3, %32"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6),
+          "=&v"(t7)
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7]),
+          "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]), "v"(pb[6]), "v"(pb[7]),
+          "s"(f01), "s"(f23), "v"(kround), "v"(sh), "v"(maxpk));
+}
+
+/*
  * One unit = one wave.  PAIR 0: a plane, 8 output columns per lane.  PAIR 1: a byte-interleaved U/V pair, 4 + 4 output
  * samples per lane.  Either way a lane reads the 12 source bytes at 4g - 4 of every source row and writes the 8
  * destination bytes at 8g of two destination rows per source row (g = the lane's group in the row).
  * D = source rows in flight (3 or 6); the ring of vertical pairs has 3 slots, so D | 6 keeps every index static.
+ * HB: samples above 8 bits (little-endian uint16, 9..14 bits, P01x's in the high bits): the same walk with 16 source bytes (plane:
+ * 8 samples from 4g - 2) or 24 (pair: 6 (u, v) columns from 2g - 2) per lane and row, 16 destination bytes per lane and row; the
+ * seven (s[k], s[k+1]) pairs of a plane are its dwords and three v_alignbyte, a pair's come from v_perm as at 8 bits.
  */
-template <int PAIR, int D, int VAR>
+template <int PAIR, int D, int VAR, int HB = 0>
 __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int fshift, int gbase, int strip, int lane, int nframes)
 {
     /* measurement-only variants (wrong output; tools/sweep_sws.py): 16 never stores, 32 re-reads one source row (48 = both: the
@@ -134,8 +217,14 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
     const bool lb = g == 0, rb = g == J.ngroups - 1;
     const bool border = gbase == 0 || gbase + lpf >= J.ngroups; /* wave-uniform */
 
-    const uint32_t soff = (uint32_t)fs * (uint32_t)J.sfp + (uint32_t)(lb ? 0 : rb ? 4 * g - 8 : 4 * g - 4);
-    const uint32_t doff = (uint32_t)fs * (uint32_t)J.dfp + 8u * (uint32_t)g;
+    const uint32_t soff = (uint32_t)fs * (uint32_t)J.sfp +
+                          (uint32_t)(!HB ? (lb ? 0 : rb ? 4 * g - 8 : 4 * g - 4)
+                                     : PAIR ? (lb ? 0 : rb ? 8 * g - 16 : 8 * g - 8) : (lb ? 0 : rb ? 8 * g - 8 : 8 * g - 4));
+    const uint32_t doff = (uint32_t)fs * (uint32_t)J.dfp + (HB ? 16u : 8u) * (uint32_t)g;
+    /* above 8 bits: horizontal shift depth - 1, vertical shift 27 - depth with its rounding seed, the clip, P01x's alignment */
+    const int hsh = HB ? J.hb_sdepth - 1 : 7, vsh = HB ? 27 - J.hb_ddepth : 19;
+    const uint32_t maxpk = HB ? ((1u << J.hb_ddepth) - 1) * 0x00010001u : 0;
+    const int smsb = HB ? (J.hb_smsb ? 16 - J.hb_sdepth : 0) : 0, dmsb = HB ? (J.hb_dmsb ? 16 - J.hb_ddepth : 0) : 0;
 
     /* ---- horizontal coefficients of this lane's columns (virtual bank: regular windows of the replicated row) ---- */
     constexpr int NCF = PAIR ? 8 : 16;
@@ -167,11 +256,21 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
     uint8_t *dr = dbase + (ptrdiff_t)(2 * a - 3) * dstride;      /* row 2a-3 (row -1 of the first strip is never stored) */
     asm("" : "+s"(pf), "+s"(dr));
 
-    auto load_next = [&](UpRaw &o) {
+    typedef typename std::conditional<HB != 0, UpRawH, UpRaw>::type Raw;
+    auto load_next = [&](Raw &o) {
         uint32_t off = soff;
         asm volatile("" : "+v"(off)); /* keeps `uniform base + zext(lane offset)` next to the access: saddr addressing */
-        const up_u3 w = *(up_gc3)((up_gcp)pf + off);
-        o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z;
+        if (HB) {
+            const up_u4 w = *(up_gc4)((up_gcp)pf + off);
+            o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w;
+            if (PAIR) {
+                const up_u2 x = *(up_gc2)((up_gcp)pf + off + 16);
+                o.q[4] = x.x; o.q[5] = x.y;
+            }
+        } else {
+            const up_u3 w = *(up_gc3)((up_gcp)pf + off);
+            o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z;
+        }
         pr++;
         if (!DBG_ROW0)
             pf += (pr >= 1 && pr <= srcH - 1) ? sstride : 0; /* rows above / below the plane replicate the edge row */
@@ -183,12 +282,75 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
 #pragma unroll
     for (int i = 0; i < 8; i++)
         hprev[i] = 0;
-    int kround = 64 << 12;
+    int kround = HB ? 1 << (vsh - 1) : 64 << 12;
     asm volatile("" : "+v"(kround));
 
     /* horizontal pass of one source row: 8 samples, appended to the ring as (h[r-1], h[r]) pairs (int16-saturated:
      * equals min(., 32767) + truncation because no sum of the bank can fall below -32768, host-checked) */
-    auto hpass = [&](const UpRaw &w, uint32_t (&Pnew)[8]) {
+    auto hpass = [&](const Raw &w, uint32_t (&Pnew)[8]) {
+        int h[8];
+        if (HB) {
+            uint32_t v[6];
+            constexpr int NQ = PAIR ? 6 : 4;
+#pragma unroll
+            for (int i = 0; i < NQ; i++)
+                v[i] = w.q[i];
+            if (border) {
+                /* edge replication: the first / last lane of a row loaded its span one (plane) or two (pair) dwords further inside */
+                if (PAIR) {
+                    const uint32_t q0 = w.q[0], q1 = w.q[1], q2 = w.q[2], q3 = w.q[3], q4 = w.q[4], q5 = w.q[5];
+                    v[0] = lb ? q0 : rb ? q2 : q0; v[1] = lb ? q0 : rb ? q3 : q1; v[2] = lb ? q0 : rb ? q4 : q2;
+                    v[3] = lb ? q1 : rb ? q5 : q3; v[4] = lb ? q2 : rb ? q5 : q4; v[5] = lb ? q3 : rb ? q5 : q5;
+                } else {
+                    const uint32_t q0 = w.q[0], q1 = w.q[1], q2 = w.q[2], q3 = w.q[3];
+                    const uint32_t f0 = __builtin_amdgcn_perm(q0, q0, 0x01000100u), f3 = __builtin_amdgcn_perm(q3, q3, 0x03020302u);
+                    v[0] = lb ? f0 : rb ? q1 : q0; v[1] = lb ? q0 : rb ? q2 : q1;
+                    v[2] = lb ? q1 : rb ? q3 : q2; v[3] = lb ? q2 : rb ? f3 : q3;
+                }
+            }
+            if (smsb) { /* P01x: the samples sit in the high bits */
+                typedef unsigned short up_h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int i = 0; i < NQ; i++)
+                    v[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(up_h2, v[i]) >> (unsigned short)smsb);
+            }
+            if (PAIR) {
+                /* columns c0..c5 = (u, v) dwords; pair k of a channel = (c_k, c_k+1) halves */
+                uint32_t a[5], b[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    a[k] = __builtin_amdgcn_perm(v[k + 1], v[k], 0x05040100u);
+                    b[k] = __builtin_amdgcn_perm(v[k + 1], v[k], 0x07060302u);
+                }
+                int ha[4], hb[4];
+                up_h4s(ha, a[0], a[1], a[1], a[2], a[2], a[3], a[3], a[4], cf, hsh);
+                up_h4s(hb, b[0], b[1], b[1], b[2], b[2], b[3], b[3], b[4], cf, hsh);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    h[2 * i] = ha[i];
+                    h[2 * i + 1] = hb[i];
+                }
+            } else {
+                /* samples s0..s7 = the four dwords; the odd pairs are one funnel shift each */
+                const uint32_t p0 = v[0], p2 = v[1], p4 = v[2], p6 = v[3];
+                const uint32_t p1 = __builtin_amdgcn_alignbyte(v[1], v[0], 2), p3 = __builtin_amdgcn_alignbyte(v[2], v[1], 2);
+                const uint32_t p5 = __builtin_amdgcn_alignbyte(v[3], v[2], 2);
+                int hl[4], hh[4];
+                up_h4s(hl, p0, p1, p1, p2, p2, p3, p3, p4, cf, hsh);
+                up_h4s(hh, p2, p3, p3, p4, p4, p5, p5, p6, cf + 8, hsh);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    h[i] = hl[i];
+                    h[4 + i] = hh[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                Pnew[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[i], h[i]));
+                hprev[i] = h[i];
+            }
+            return;
+        }
         uint32_t v0 = w.q[0], v1 = w.q[1], v2 = w.q[2];
         if (border) {
             /* edge replication: the first / last lane of a row loaded its span one dword further inside */
@@ -197,7 +359,6 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
             v1 = lb ? w.q[0] : rb ? w.q[2] : w.q[1];
             v2 = lb ? w.q[1] : rb ? f2 : w.q[2];
         }
-        int h[8];
         if (PAIR) {
             /* channel samples u0..u5 at bytes 0,2,..,10 (or 1,3,..,11); pair k = (u_k, u_k+1) */
             const uint32_t a0 = __builtin_amdgcn_perm(v1, v0, sA0), a1 = __builtin_amdgcn_perm(v1, v0, sA1);
@@ -237,7 +398,7 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
         }
     };
 
-    UpRaw buf[D];
+    Raw buf[D];
 #pragma unroll
     for (int k = 0; k < D; k++)
         load_next(buf[k]);
@@ -258,8 +419,43 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
             c8[q] = *(up_cc8)(vt + 4 * (r + 2 * q) - 4);
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            UpRaw &w = buf[(k + 3) % D];
+            Raw &w = buf[(k + 3) % D];
             if (r + k < b) { /* uniform */
+                if (HB) {
+                    hpass(w, ring[k % 3]);
+                    const up_u8 cc = c8[k >> 1];
+                    const uint32_t fb01 = k & 1 ? cc.s4 : cc.s0, fb23 = k & 1 ? cc.s5 : cc.s1;
+                    const uint32_t fa01 = k & 1 ? cc.s6 : cc.s2, fa23 = k & 1 ? cc.s7 : cc.s3;
+                    const int y = 2 * (r + k) - 3;
+                    typedef unsigned short up_h2 __attribute__((ext_vector_type(2)));
+                    uint32_t o0[4], o1[4];
+                    up_v8h(o0, ring[(k + 1) % 3], ring[k % 3], fb01, fb23, kround, vsh, maxpk);
+                    uint32_t off = doff;
+                    asm volatile("" : "+v"(off));
+                    if (dmsb) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            o0[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(up_h2, o0[i]) << (unsigned short)dmsb);
+                    }
+                    if (act && y >= 0) {
+                        up_u4 st; st.x = o0[0]; st.y = o0[1]; st.z = o0[2]; st.w = o0[3];
+                        *(up_g4)((up_gp)dr + off) = st;
+                    }
+                    up_v8h(o1, ring[(k + 1) % 3], ring[k % 3], fa01, fa23, kround, vsh, maxpk);
+                    if (dmsb) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            o1[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(up_h2, o1[i]) << (unsigned short)dmsb);
+                    }
+                    if (act && y + 1 < dstH) {
+                        up_u4 st; st.x = o1[0]; st.y = o1[1]; st.z = o1[2]; st.w = o1[3];
+                        *(up_g4)((up_gp)(dr + dstride) + off) = st;
+                    }
+                    dr += 2 * dstride;
+                    asm("" : "+s"(dr));
+                    load_next(w);
+                    continue;
+                }
                 if (!DBG_COPY)
                     hpass(w, ring[k % 3]);
                 const up_u8 cc = c8[k >> 1];
@@ -289,7 +485,7 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
     }
 }
 
-template <int D, int VAR> /* VAR: 0 the product; 16 / 48 / 64 measurement only (see up2_unit) */
+template <int D, int VAR, int HB = 0> /* VAR: 0 the product; 16 / 48 / 64 measurement only (see up2_unit); HB: samples above 8 bits */
 __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -328,9 +524,9 @@ __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
         gbase = J.nfull * 64 + (idx - nf) * (64 >> fsh);
     }
     if (J.pair)
-        up2_unit<1, D, VAR>(J, frame0, fsh, gbase, strip, lane, A.nframes);
+        up2_unit<1, D, VAR, HB>(J, frame0, fsh, gbase, strip, lane, A.nframes);
     else
-        up2_unit<0, D, VAR>(J, frame0, fsh, gbase, strip, lane, A.nframes);
+        up2_unit<0, D, VAR, HB>(J, frame0, fsh, gbase, strip, lane, A.nframes);
 }
 
 /* ================================================================================================== */
@@ -410,6 +606,14 @@ int ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream)
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (A.job[0].hb_sdepth) { /* samples above 8 bits: the product variant only */
+        if (depth == 3)
+            hipLaunchKernelGGL((k_sws_up2<3, 0, 1>), grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL((k_sws_up2<6, 0, 1>), grid, block, 0, stream, A);
+        LAUNCH_CHECK();
+        return 0;
+    }
 #define UP2_LAUNCH(DD, VV) hipLaunchKernelGGL((k_sws_up2<DD, VV>), grid, block, 0, stream, A)
 #define UP2_CASE(VV) case VV: if (depth == 3) UP2_LAUNCH(3, VV); else UP2_LAUNCH(6, VV); break
     switch (var) {

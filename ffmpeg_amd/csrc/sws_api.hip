@@ -272,6 +272,56 @@ static bool build_wide_view(FFHipSwsContext *c, const int limits[4])
     return true;
 }
 
+/* exact 2x: the 4-tap views (c->nf / c->np) as virtual banks on the regular windows of the edge-replicated rows, on the device;
+ * sets c->up2_ok when every bank row is of that shape (sws_up2.hip) */
+static void up2_build(FFHipSwsContext *c, const int nsrc[4])
+{
+    std::vector<uint32_t> vb[4];
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; i++)
+        ok = ffhip_up2_virtual_bank(c->nf[i].data(), c->np[i].data(), c->d[i].n, nsrc[i], &vb[i]) != 0;
+    if (!ok)
+        return;
+    /* vertical banks: one leading row (y = -1) and 17 trailing ones of zeros (the row loop reads ahead) */
+    for (int i = 2; i < 4; i++) {
+        std::vector<uint32_t> pv((size_t)(c->d[i].n + 18) * 2, 0);
+        memcpy(pv.data() + 2, vb[i].data(), vb[i].size() * 4);
+        vb[i].swap(pv);
+    }
+    size_t uo[4], ut = 0;
+    for (int i = 0; i < 4; i++) {
+        uo[i] = ut;
+        ut += (vb[i].size() * 4 + 255) & ~(size_t)255;
+    }
+    if (hipMalloc(&c->up2_dev, ut) != hipSuccess)
+        return;
+    uint8_t *b = static_cast<uint8_t *>(c->up2_dev);
+    for (int i = 0; i < 4 && ok; i++)
+        ok = hipMemcpy(b + uo[i], vb[i].data(), vb[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        c->up2_h[0] = reinterpret_cast<const uint32_t *>(b + uo[0]);
+        c->up2_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
+        c->up2_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
+        c->up2_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
+        c->up2_ok = 1;
+    }
+}
+
+/* no horizontal sum of a 4-tap bank falls below -32768 after >> (depth - 1) on samples of `depth` bits: int16 saturation then
+ * equals the reference's min(., 32767) + truncation (ffhip_cw_bank_nowrap is this at 8 bits) */
+static bool bank_nowrap_depth(const int16_t *f, int n, int depth)
+{
+    for (int x = 0; x < n; x++) {
+        long long neg = 0;
+        for (int j = 0; j < 4; j++)
+            if (f[(size_t)x * 4 + j] < 0)
+                neg += f[(size_t)x * 4 + j];
+        if (((1LL << depth) - 1) * neg < -32768LL * (1LL << (depth - 1)))
+            return false;
+    }
+    return true;
+}
+
 extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
 {
     if (!t || !fmt_yuv(t->srcFormat) || !(fmt_yuv(t->dstFormat) || fmt_rgb(t->dstFormat))) {
@@ -388,6 +438,21 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             }
         }
         c->hbd_sw = (c->hbd_sw + 3) & ~1;
+        /* exact 2x between formats of 9..14 bits laid out alike (planar <-> planar, P01x <-> P01x), no range change: the
+         * static-schedule kernel's 16-bit twin (k_sws_up2<., ., 1>) */
+        {
+            int sd = 8, sl = 0, dd = 8, dl = 0;
+            (void)ffhip_pixfmt_hbd(t->srcFormat, &sd, &sl, nullptr, nullptr);
+            (void)ffhip_pixfmt_hbd(t->dstFormat, &dd, &dl, nullptr, nullptr);
+            const int cw = c->chrSrcW, chh = c->chrSrcH;
+            const int limits[4] = { t->srcW, cw, t->srcH, chh };
+            if (sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl == dl && sl != 2 && t->src_range == t->dst_range &&
+                t->dstW == 2 * t->srcW && t->dstH == 2 * t->srcH && c->d[1].n == 2 * cw && c->d[3].n == 2 * chh &&
+                !(t->srcW & 3) && t->srcW >= 8 && (sl ? !(cw & 1) && cw >= 4 : !(cw & 3) && cw >= 8) &&
+                build_fast_view(c, limits, false) && bank_nowrap_depth(c->nf[0].data(), c->d[0].n, sd) &&
+                bank_nowrap_depth(c->nf[1].data(), c->d[1].n, sd))
+                up2_build(c, limits);
+        }
         return c;
     }
     int r = 0;
@@ -451,36 +516,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         if (c->cw_opt && l.dstW == 2 * l.srcW && l.dstH == 2 * l.srcH && ch.dstW == 2 * ch.srcW && ch.dstH == 2 * ch.srcH &&
             fmt_nv(t->srcFormat) == fmt_nv(t->dstFormat) && !(l.srcW & 3) && l.srcW >= 8 &&
             (fmt_nv(t->srcFormat) ? !(ch.srcW & 1) && ch.srcW >= 4 : !(ch.srcW & 3) && ch.srcW >= 8)) {
-            std::vector<uint32_t> vb[4];
             const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
-            bool ok = true;
-            for (int i = 0; i < 4 && ok; i++)
-                ok = ffhip_up2_virtual_bank(c->nf[i].data(), c->np[i].data(), c->d[i].n, nsrc[i], &vb[i]) != 0;
-            if (ok) {
-                /* vertical banks: one leading row (y = -1) and 17 trailing ones of zeros (the row loop reads ahead) */
-                for (int i = 2; i < 4; i++) {
-                    std::vector<uint32_t> pv((size_t)(c->d[i].n + 18) * 2, 0);
-                    memcpy(pv.data() + 2, vb[i].data(), vb[i].size() * 4);
-                    vb[i].swap(pv);
-                }
-                size_t uo[4], ut = 0;
-                for (int i = 0; i < 4; i++) {
-                    uo[i] = ut;
-                    ut += (vb[i].size() * 4 + 255) & ~(size_t)255;
-                }
-                if (hipMalloc(&c->up2_dev, ut) == hipSuccess) {
-                    uint8_t *b = static_cast<uint8_t *>(c->up2_dev);
-                    for (int i = 0; i < 4 && ok; i++)
-                        ok = hipMemcpy(b + uo[i], vb[i].data(), vb[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-                    if (ok) {
-                        c->up2_h[0] = reinterpret_cast<const uint32_t *>(b + uo[0]);
-                        c->up2_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
-                        c->up2_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
-                        c->up2_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
-                        c->up2_ok = 1;
-                    }
-                }
-            }
+            up2_build(c, nsrc);
         }
         /* wide banks (down-scaling, long kernels): the LDS-backed walker; FFHIP_SWS_WIDE=1 builds it for narrow banks
          * too (parity tests of that kernel on up-scaling cases) */
@@ -665,6 +702,64 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
     for (int pl = 0; pl < (dl ? 2 : 3); pl++)
         if (!dst[pl] || (dstStride[pl] % dsz) || (dstFramePitch[pl] % dsz) || ((uintptr_t)dst[pl] % dsz))
             return FFHIP_EINVAL;
+    {
+        uintptr_t al = 0;
+        bool neg = false;
+        for (int pl = 0; pl < (sl ? 2 : 3); pl++) {
+            al |= (uintptr_t)src[pl] | (uintptr_t)srcStride[pl] | srcFramePitch[pl] | (uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl];
+            neg = neg || srcStride[pl] < 0 || dstStride[pl] < 0;
+        }
+        const char *eu = FFHIP_KNOB("FFHIP_SWS_UP2");
+        if (c->up2_ok && !(al & 3) && !neg && !(eu && eu[0] == '0')) {
+            /* exact 2x above 8 bits: the static-schedule kernel (FFHIP_SWS_UP2=0: the tiled k_sws_scale16) */
+            FFHipUp2Args U;
+            memset(&U, 0, sizeof(U));
+            U.nframes = nframes;
+            U.xcd = 1;
+            const int cw = c->chrSrcW, chh = c->chrSrcH;
+            auto upjob = [&](int which, int plane, int w, int h, int pair) {
+                FFHipUp2Job &j = U.job[U.njobs++];
+                j.src = static_cast<const uint8_t *>(src[plane]); j.dst = static_cast<uint8_t *>(dst[plane]);
+                j.sstride = srcStride[plane]; j.dstride = dstStride[plane]; j.sfp = srcFramePitch[plane]; j.dfp = dstFramePitch[plane];
+                j.pair = pair; j.swap = 0;
+                j.srcW = w; j.srcH = h;
+                j.ngroups = pair ? w / 2 : w / 4;
+                j.hfv = c->up2_h[which]; j.vfv = c->up2_v[which];
+                j.hb_sdepth = sd; j.hb_ddepth = dd; j.hb_smsb = sl == 1; j.hb_dmsb = dl == 1;
+            };
+            upjob(0, 0, t.srcW, t.srcH, 0);
+            if (sl) {
+                upjob(1, 1, cw, chh, 1);
+            } else {
+                upjob(1, 1, cw, chh, 0);
+                upjob(1, 2, cw, chh, 0);
+            }
+            /* frames per wave: as at 8 bits, the split that wastes the fewest lanes at the right edge of the rows */
+            int best = 0;
+            double bestw = 1e30;
+            for (int fsft = 0; fsft <= 2; fsft++) {
+                const int lpf = 64 >> fsft;
+                bool fits = !(nframes < (1 << fsft) && fsft);
+                double w = 0;
+                for (int i = 0; i < U.njobs; i++) {
+                    const FFHipUp2Job &j = U.job[i];
+                    const unsigned long long span_s = (unsigned long long)((1 << fsft) - 1) * j.sfp + (unsigned long long)j.srcH * (size_t)j.sstride;
+                    const unsigned long long span_d = (unsigned long long)((1 << fsft) - 1) * j.dfp + 2ull * j.srcH * (size_t)j.dstride;
+                    if (span_s >= (1ull << 31) || span_d >= (1ull << 31))
+                        fits = false;
+                    const int nfull = fsft ? j.ngroups / 64 : 0;
+                    w += ((double)nfull + (double)cdiv(j.ngroups - nfull * 64, lpf) / (1 << fsft)) * j.srcH;
+                }
+                if (fits && w < bestw - 1e-9) { bestw = w; best = fsft; }
+            }
+            if (bestw < 1e29) {
+                U.fshift = best;
+                for (int i = 0; i < U.njobs; i++)
+                    ffhip_up2_plan_job(&U.job[i], 64 >> U.fshift, 60);
+                return ffhip_launch_up2(U, 3, 0, stream);
+            }
+        }
+    }
     FFHipScale16Args a;
     memset(&a, 0, sizeof(a));
     a.nplanes = 3;

@@ -72,6 +72,37 @@ def test_scale_above_8_bits(case):
     _run(case)
 
 
+# exact 2x between formats of 9..14 bits laid out alike: the static-schedule kernel's 16-bit twin (k_sws_up2<., ., 1>); "tiled" runs the
+# same cases on k_sws_scale16 (FFHIP_SWS_UP2=0, the measure build)
+UP2_CASES = [
+    ("yuv420p10le", 64, 36, "yuv420p10le", 128, 72, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 72, 40, "yuv420p10le", 144, 80, ffi.SWS_BILINEAR),
+    ("p010le", 72, 40, "p010le", 144, 80, ffi.SWS_BICUBIC),              # (u, v) columns: the pair path, samples in the high bits
+    ("p012le", 64, 36, "p012le", 128, 72, ffi.SWS_POINT),
+    ("yuv420p10le", 1000, 62, "yuv420p10le", 2000, 124, ffi.SWS_BICUBIC),  # 250 groups per row: ragged-end blocks shared by frames
+    ("p010le", 520, 70, "p010le", 1040, 140, ffi.SWS_BICUBIC),
+    ("yuv422p10le", 64, 36, "yuv422p10le", 128, 72, ffi.SWS_BICUBIC),
+    ("yuv444p10le", 64, 36, "yuv444p10le", 128, 72, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 64, 36, "yuv420p12le", 128, 72, ffi.SWS_BICUBIC),      # depths differ: >> (src depth - 1) across, >> (27 - dst depth) down
+    ("yuv420p14le", 64, 36, "yuv420p9le", 128, 72, ffi.SWS_BICUBIC),
+    ("yuv420p12le", 64, 36, "yuv420p12le", 128, 72, ffi.SWS_AREA),
+]
+
+
+@pytest.mark.parametrize("variant", ["product", "tiled"])
+@pytest.mark.parametrize("case", UP2_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_exact_2x_above_8_bits(case, variant, monkeypatch):
+    from ffmpeg_amd import swscale as S
+    if variant == "tiled":
+        monkeypatch.setenv("FFHIP_SWS_UP2", "0")
+    else:
+        _torch()
+        ctx = S.SwsContext(case[1], case[2], FMT[case[0]][0], case[4], case[5], FMT[case[3]][0], case[6])
+        assert ctx.up2_path, "the exact-2x kernel should serve this context"
+        ctx.close()
+    _run(case, nframes=5)
+
+
 @pytest.mark.parametrize("case", RANGE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x_%d%d" % c)
 def test_range_conversion_above_8_bits(case):
     """lumRangeToJpeg_c ... / the ...16_c forms (19-bit intermediates, 64-bit products) inside k_sws_scale16"""
