@@ -189,6 +189,10 @@ def extras(torch, dev):
     def sws_case(key, sf, sw, sh, df, dw, dh, n):
         c = S.SwsContext(sw, sh, sf, dw, dh, df, 4)
         s_ = [torch.randint(0, 256, (n, r, cc), dtype=torch.uint8, device=dev) for r, cc in S.plane_shapes(sf, sw, sh)]
+        if sf in (62, 158):   # 10-bit samples: valid ones (planar: the low 10 bits of the word, P010: the high 10)
+            for t_ in s_:
+                w16 = t_.view(torch.int16)
+                w16.bitwise_and_(0x03FF if sf == 62 else -64)
         d_ = [torch.empty((n, r, cc), dtype=torch.uint8, device=dev) for r, cc in S.plane_shapes(df, dw, dh)]
         for _ in range(2):
             c.scale_batch(s_, d_)
@@ -222,10 +226,11 @@ def extras(torch, dev):
     sws_case("sws_yuv420p_1080p_to_rgb24_4k_bicubic", 0, 1920, 1080, 2, 3840, 2160, 32)
     # 4:4:4 planar through the exact-2x kernel: three planes of the luma's size (AV_PIX_FMT_YUV444P = 5)
     sws_case("sws_yuv444p_1080p_to_4k_bicubic", 5, 1920, 1080, 5, 3840, 2160, 32)
-    # above 8 bits: p010 / yuv420p10 1080p -> 4K through the 16-bit scaler (3.75 B per output pixel; random 16-bit words are valid samples
-    # for the arithmetic: the planar reader takes the word as it is, the P010 reader its high 10 bits)
-    sws_case("sws_p010_1080p_to_4k_bicubic", 158, 1920, 1080, 158, 3840, 2160, 16)
-    sws_case("sws_yuv420p10_1080p_to_4k_bicubic", 62, 1920, 1080, 62, 3840, 2160, 16)
+    # above 8 bits: p010 / yuv420p10 1080p -> 4K (3.75 B per output pixel) through the exact-2x kernel's 16-bit twin, and a ratio that
+    # takes the tiled 16-bit scaler (k_sws_scale16)
+    sws_case("sws_p010_1080p_to_4k_bicubic", 158, 1920, 1080, 158, 3840, 2160, 64)
+    sws_case("sws_yuv420p10_1080p_to_4k_bicubic", 62, 1920, 1080, 62, 3840, 2160, 64)
+    sws_case("sws_p010_4k_to_1080p_bicubic", 158, 3840, 2160, 158, 1920, 1080, 16)
     # H.264 8x8 IDCT + add over 32 4K luma planes (129,600 blocks each, 384 B/block)
     planes, stride = 32, 3840
     nb = planes * 129600
