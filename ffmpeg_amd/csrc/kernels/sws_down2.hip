@@ -108,6 +108,61 @@ __device__ __forceinline__ void dn_h4_pair(int (&d)[4], const uint32_t (&A)[5], 
         : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]),
           "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]), "v"(cf[6]), "v"(cf[7]));
 }
+/* the same two blocks with the shift in an SGPR: samples above 8 bits shift by depth - 1 (hScale16To15_c, swscale.c:99-126) */
+__device__ __forceinline__ void dn_h4_plane_s(int (&d)[4], const uint32_t (&P)[7], const uint32_t (&cf)[16], int sh)
+{
+    asm("v_dot2_i32_i16 %0, %4, %11, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %15, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %19, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %23, 0\n\t"
+        "v_dot2_i32_i16 %0, %5, %12, %0\n\t"
+        "v_dot2_i32_i16 %1, %6, %16, %1\n\t"
+        "v_dot2_i32_i16 %2, %7, %20, %2\n\t"
+        "v_dot2_i32_i16 %3, %8, %24, %3\n\t"
+        "v_dot2_i32_i16 %0, %6, %13, %0\n\t"
+        "v_dot2_i32_i16 %1, %7, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %8, %21, %2\n\t"
+        "v_dot2_i32_i16 %3, %9, %25, %3\n\t"
+        "v_dot2_i32_i16 %0, %7, %14, %0\n\t"
+        "v_dot2_i32_i16 %1, %8, %18, %1\n\t"
+        "v_dot2_i32_i16 %2, %9, %22, %2\n\t"
+        "v_dot2_i32_i16 %3, %10, %26, %3\n\t"
+        "v_ashrrev_i32 %0, %27, %0\n\t"
+        "v_ashrrev_i32 %1, %27, %1\n\t"
+        "v_ashrrev_i32 %2, %27, %2\n\t"
+        "v_ashrrev_i32 %3, %27, %3"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(P[5]), "v"(P[6]),
+          "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]), "v"(cf[6]), "v"(cf[7]),
+          "v"(cf[8]), "v"(cf[9]), "v"(cf[10]), "v"(cf[11]), "v"(cf[12]), "v"(cf[13]), "v"(cf[14]), "v"(cf[15]), "s"(sh));
+}
+/* pair: d[0] = A[0..3] . cf[0..3], d[1] = B[0..3] . cf[0..3], d[2] = A[1..4] . cf[4..7], d[3] = B[1..4] . cf[4..7], each >> 7 */
+__device__ __forceinline__ void dn_h4_pair_s(int (&d)[4], const uint32_t (&A)[5], const uint32_t (&B)[5], const uint32_t (&cf)[8], int sh)
+{
+    asm("v_dot2_i32_i16 %0, %4, %14, 0\n\t"
+        "v_dot2_i32_i16 %1, %9, %14, 0\n\t"
+        "v_dot2_i32_i16 %2, %5, %18, 0\n\t"
+        "v_dot2_i32_i16 %3, %10, %18, 0\n\t"
+        "v_dot2_i32_i16 %0, %5, %15, %0\n\t"
+        "v_dot2_i32_i16 %1, %10, %15, %1\n\t"
+        "v_dot2_i32_i16 %2, %6, %19, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "v_dot2_i32_i16 %0, %6, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %11, %16, %1\n\t"
+        "v_dot2_i32_i16 %2, %7, %20, %2\n\t"
+        "v_dot2_i32_i16 %3, %12, %20, %3\n\t"
+        "v_dot2_i32_i16 %0, %7, %17, %0\n\t"
+        "v_dot2_i32_i16 %1, %12, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %8, %21, %2\n\t"
+        "v_dot2_i32_i16 %3, %13, %21, %3\n\t"
+        "v_ashrrev_i32 %0, %22, %0\n\t"
+        "v_ashrrev_i32 %1, %22, %1\n\t"
+        "v_ashrrev_i32 %2, %22, %2\n\t"
+        "v_ashrrev_i32 %3, %22, %3"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]),
+          "v"(cf[0]), "v"(cf[1]), "v"(cf[2]), "v"(cf[3]), "v"(cf[4]), "v"(cf[5]), "v"(cf[6]), "v"(cf[7]), "s"(sh));
+}
 /* one output row of 4 samples: t[i] = kround + sum_k R_k[i] . c_k, bytes clip_u8(t[i] >> 19) packed in sample order */
 __device__ __forceinline__ uint32_t dn_v4(const uint32_t (&R0)[4], const uint32_t (&R1)[4], const uint32_t (&R2)[4], const uint32_t (&R3)[4],
                                           uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int kround)
@@ -140,18 +195,62 @@ __device__ __forceinline__ uint32_t dn_v4(const uint32_t (&R0)[4], const uint32_
     return out;
 }
 
-template <int PAIR>
+/* the same row above 8 bits (yuv2planeX_10_c_template, output.c:341-360): t[i] >> (27 - depth) clipped to depth bits, two dwords */
+__device__ __forceinline__ void dn_v4h(uint32_t &o0, uint32_t &o1, const uint32_t (&R0)[4], const uint32_t (&R1)[4], const uint32_t (&R2)[4],
+                                       const uint32_t (&R3)[4], uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int kround, int sh, uint32_t maxpk)
+{
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %2, %6, %22, %26\n\t"
+        "v_dot2_i32_i16 %3, %7, %22, %26\n\t"
+        "v_dot2_i32_i16 %4, %8, %22, %26\n\t"
+        "v_dot2_i32_i16 %5, %9, %22, %26\n\t"
+        "v_dot2_i32_i16 %2, %10, %23, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %23, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %23, %4\n\t"
+        "v_dot2_i32_i16 %5, %13, %23, %5\n\t"
+        "v_dot2_i32_i16 %2, %14, %24, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %24, %3\n\t"
+        "v_dot2_i32_i16 %4, %16, %24, %4\n\t"
+        "v_dot2_i32_i16 %5, %17, %24, %5\n\t"
+        "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
+        "v_ashrrev_i32 %2, %27, %2\n\t"
+        "v_ashrrev_i32 %3, %27, %3\n\t"
+        "v_ashrrev_i32 %4, %27, %4\n\t"
+        "v_ashrrev_i32 %5, %27, %5\n\t"
+        "v_cvt_pk_i16_i32 %0, %2, %3\n\t"
+        "v_cvt_pk_i16_i32 %1, %4, %5\n\t"
+        "v_pk_max_i16 %0, %0, 0\n\t"
+        "v_pk_max_i16 %1, %1, 0\n\t"
+        "v_pk_min_i16 %0, %0, %28\n\t"
+        "v_pk_min_i16 %1, %1, %28"
+        : "=&v"(o0), "=&v"(o1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(R0[0]), "v"(R0[1]), "v"(R0[2]), "v"(R0[3]), "v"(R1[0]), "v"(R1[1]), "v"(R1[2]), "v"(R1[3]),
+          "v"(R2[0]), "v"(R2[1]), "v"(R2[2]), "v"(R2[3]), "v"(R3[0]), "v"(R3[1]), "v"(R3[2]), "v"(R3[3]),
+          "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(kround), "v"(sh), "v"(maxpk));
+}
+
+/* HB: samples above 8 bits (little-endian uint16, 9..14 bits, P01x's in the high bits).  A lane then reads 32 source bytes per row
+ * (plane: the 16 samples from 8g - 4, whose seven (s[2m+1], s[2m+2]) pairs are one v_alignbyte each) or 40 (pair: the ten (u, v)
+ * columns from 4g - 3, pairs by v_perm as at 8 bits) and writes 8 destination bytes per row. */
+template <int PAIR, int HB = 0>
 __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gbase, int strip, int lane)
 {
-    constexpr int NQ = PAIR ? 6 : 4, NCF = PAIR ? 8 : 16;
+    constexpr int NQ = HB ? (PAIR ? 10 : 8) : (PAIR ? 6 : 4), NCF = PAIR ? 8 : 16;
     const int graw = gbase + lane;
     const bool act = graw < J.ngroups;
     const int g = min(graw, J.ngroups - 1);
     const bool lb = g == 0, rb = g == J.ngroups - 1;
     const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
     /* the first / last lane of a row loads its span inside the row and rebuilds the replicated bytes */
-    const uint32_t soff = (uint32_t)(lb ? 0 : 8 * g - (PAIR ? 8 : 4) - (rb ? (PAIR ? 8 : 4) : 0));
-    const uint32_t doff = 4u * (uint32_t)g;
+    const uint32_t soff = HB ? (uint32_t)(lb ? 0 : 16 * g - (PAIR ? 12 : 8) - (rb ? (PAIR ? 12 : 8) : 0))
+                             : (uint32_t)(lb ? 0 : 8 * g - (PAIR ? 8 : 4) - (rb ? (PAIR ? 8 : 4) : 0));
+    const uint32_t doff = (HB ? 8u : 4u) * (uint32_t)g;
+    const int hsh = HB ? J.hb_sdepth - 1 : 7, vsh = HB ? 27 - J.hb_ddepth : 19;
+    const uint32_t maxpk = HB ? ((1u << J.hb_ddepth) - 1) * 0x00010001u : 0;
+    const int smsb = HB ? (J.hb_smsb ? 16 - J.hb_sdepth : 0) : 0, dmsb = HB ? (J.hb_dmsb ? 16 - J.hb_ddepth : 0) : 0;
 
     uint32_t cf[NCF];
     {
@@ -181,7 +280,14 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
         asm volatile("" : "+v"(off)); /* keeps `uniform base + zext(lane offset)` next to the access: saddr addressing */
         const dn_u4 w = *(dn_gc4)((dn_gcp)pf + off);
         o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w;
-        if (PAIR) {
+        if (HB) {
+            const dn_u4 x = *(dn_gc4)((dn_gcp)pf + off + 16);
+            o.q[4] = x.x; o.q[5] = x.y; o.q[6] = x.z; o.q[7] = x.w;
+            if (PAIR) {
+                const dn_u2 e = *(dn_gc2)((dn_gcp)pf + off + 32);
+                o.q[8 % NQ] = e.x; o.q[9 % NQ] = e.y;
+            }
+        } else if (PAIR) {
             const dn_u2 e = *(dn_gc2)((dn_gcp)pf + off + 16);
             o.q[4] = e.x; o.q[5] = e.y;
         }
@@ -196,6 +302,44 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
 #pragma unroll
         for (int i = 0; i < NQ; i++)
             v[i] = w.q[i];
+        if (HB) {
+            typedef unsigned short dn_h2 __attribute__((ext_vector_type(2)));
+            if (border) {
+                /* the first / last lane of a row loaded its span two (plane) or three (pair) dwords further inside */
+                constexpr int SHIFT = PAIR ? 3 : 2;
+                const uint32_t f0 = PAIR ? w.q[0] : __builtin_amdgcn_perm(w.q[0], w.q[0], 0x01000100u);
+                const uint32_t fl = PAIR ? w.q[NQ - 1] : __builtin_amdgcn_perm(w.q[NQ - 1], w.q[NQ - 1], 0x03020302u);
+#pragma unroll
+                for (int i = 0; i < NQ; i++) {
+                    const uint32_t vl = i < SHIFT ? f0 : w.q[(i - SHIFT + NQ) % NQ];
+                    const uint32_t vr = i + SHIFT < NQ ? w.q[(i + SHIFT) % NQ] : fl;
+                    v[i] = lb ? vl : rb ? vr : w.q[i];
+                }
+            }
+            if (smsb) {
+#pragma unroll
+                for (int i = 0; i < NQ; i++)
+                    v[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(dn_h2, v[i]) >> (unsigned short)smsb);
+            }
+            if constexpr (PAIR != 0) {
+                /* columns c0..c9 from 4g - 3: pair m of a channel = (c[2m], c[2m+1]) halves = columns 4g - 3 + 2m, + 1 */
+                uint32_t A[5], B[5];
+#pragma unroll
+                for (int m = 0; m < 5; m++) {
+                    A[m] = __builtin_amdgcn_perm(v[(2 * m + 1) % NQ], v[(2 * m) % NQ], 0x05040100u);
+                    B[m] = __builtin_amdgcn_perm(v[(2 * m + 1) % NQ], v[(2 * m) % NQ], 0x07060302u);
+                }
+                dn_h4_pair_s(h, A, B, cf, hsh);
+            } else {
+                /* dwords (s0,s1) .. (s14,s15) from 8g - 4: pair m = (s[2m+1], s[2m+2]) */
+                uint32_t P[7];
+#pragma unroll
+                for (int m = 0; m < 7; m++)
+                    P[m] = __builtin_amdgcn_alignbyte(v[(m + 1) % NQ], v[m % NQ], 2);
+                dn_h4_plane_s(h, P, cf, hsh);
+            }
+            return;
+        }
         if (border) {
             if (PAIR) {
                 const uint32_t f0 = __builtin_amdgcn_perm(w.q[0], w.q[0], 0x01000100u), f5 = __builtin_amdgcn_perm(w.q[5], w.q[5], 0x03020302u);
@@ -256,7 +400,7 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
     hpair(buf[0], buf[1], ring[1]);
     load_next(buf[0]); load_next(buf[1]);
 
-    int kround = 64 << 12;
+    int kround = HB ? 1 << (vsh - 1) : 64 << 12;
     asm volatile("" : "+v"(kround));
     const uint32_t *vt = J.vfv;
     for (int y = a; y < b; y += 4) {
@@ -268,11 +412,27 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
                 hpair(w0, w1, ring[(k + 2) & 3]);
                 load_next(w0); load_next(w1);
                 const uint32_t c0 = c16[4 * k], c1 = c16[4 * k + 1], c2 = c16[4 * k + 2], c3 = c16[4 * k + 3];
-                const uint32_t out = dn_v4(ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround);
                 uint32_t off = doff;
-                asm volatile("" : "+v"(off));
-                if (act)
-                    *(dn_g1)((dn_gp)dr + off) = out;
+                if (HB) {
+                    typedef unsigned short dn_h2 __attribute__((ext_vector_type(2)));
+                    typedef dn_u2 __attribute__((address_space(1))) *dn_g2;
+                    uint32_t o0, o1;
+                    dn_v4h(o0, o1, ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround, vsh, maxpk);
+                    if (dmsb) {
+                        o0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(dn_h2, o0) << (unsigned short)dmsb);
+                        o1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(dn_h2, o1) << (unsigned short)dmsb);
+                    }
+                    asm volatile("" : "+v"(off));
+                    if (act) {
+                        dn_u2 st; st.x = o0; st.y = o1;
+                        *(dn_g2)((dn_gp)dr + off) = st;
+                    }
+                } else {
+                    const uint32_t out = dn_v4(ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround);
+                    asm volatile("" : "+v"(off));
+                    if (act)
+                        *(dn_g1)((dn_gp)dr + off) = out;
+                }
                 dr += dstride;
                 asm("" : "+s"(dr));
             }
@@ -280,6 +440,7 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
     }
 }
 
+template <int HB>
 __global__ __launch_bounds__(256) void k_sws_down2(FFHipDn2Args A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -303,9 +464,9 @@ __global__ __launch_bounds__(256) void k_sws_down2(FFHipDn2Args A)
     const int local = u - J.unit_begin;
     const int strip = local / J.ncb, cb = local - strip * J.ncb;
     if (J.pair)
-        dn2_unit<1>(J, frame, cb * 64, strip, lane);
+        dn2_unit<1, HB>(J, frame, cb * 64, strip, lane);
     else
-        dn2_unit<0>(J, frame, cb * 64, strip, lane);
+        dn2_unit<0, HB>(J, frame, cb * 64, strip, lane);
 }
 
 /* ================================================================================================== */
@@ -375,7 +536,10 @@ int ffhip_launch_down2(FFHipDn2Args &A, hipStream_t stream)
         ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
         return FFHIP_EINVAL;
     }
-    hipLaunchKernelGGL(k_sws_down2, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    if (A.job[0].hb_sdepth)
+        hipLaunchKernelGGL(k_sws_down2<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    else
+        hipLaunchKernelGGL(k_sws_down2<0>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
     LAUNCH_CHECK();
     return 0;
 }

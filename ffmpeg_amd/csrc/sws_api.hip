@@ -307,15 +307,46 @@ static void up2_build(FFHipSwsContext *c, const int nsrc[4])
     }
 }
 
+/* exact 2:1: the banks (up to 8 taps) as virtual banks on the windows 2x - 3 .. 2x + 4 of the edge-replicated rows, on the device;
+ * sets c->dn2_ok when every bank row is of that shape (sws_down2.hip) */
+static void dn2_build(FFHipSwsContext *c, const int nsrc[4])
+{
+    std::vector<uint32_t> vb[4];
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; i++)
+        ok = ffhip_down2_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], &vb[i]) != 0;
+    if (!ok)
+        return;
+    for (int i = 2; i < 4; i++)
+        vb[i].resize((size_t)(c->d[i].n + 8) * 4, 0); /* the row loop reads four rows of coefficients at a time */
+    size_t uo[4], ut = 0;
+    for (int i = 0; i < 4; i++) {
+        uo[i] = ut;
+        ut += (vb[i].size() * 4 + 255) & ~(size_t)255;
+    }
+    if (hipMalloc(&c->dn2_dev, ut) != hipSuccess)
+        return;
+    uint8_t *b = static_cast<uint8_t *>(c->dn2_dev);
+    for (int i = 0; i < 4 && ok; i++)
+        ok = hipMemcpy(b + uo[i], vb[i].data(), vb[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        c->dn2_h[0] = reinterpret_cast<const uint32_t *>(b + uo[0]);
+        c->dn2_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
+        c->dn2_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
+        c->dn2_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
+        c->dn2_ok = 1;
+    }
+}
+
 /* no horizontal sum of a 4-tap bank falls below -32768 after >> (depth - 1) on samples of `depth` bits: int16 saturation then
  * equals the reference's min(., 32767) + truncation (ffhip_cw_bank_nowrap is this at 8 bits) */
-static bool bank_nowrap_depth(const int16_t *f, int n, int depth)
+static bool bank_nowrap_depth(const int16_t *f, int n, int depth, int size = 4)
 {
     for (int x = 0; x < n; x++) {
         long long neg = 0;
-        for (int j = 0; j < 4; j++)
-            if (f[(size_t)x * 4 + j] < 0)
-                neg += f[(size_t)x * 4 + j];
+        for (int j = 0; j < size; j++)
+            if (f[(size_t)x * size + j] < 0)
+                neg += f[(size_t)x * size + j];
         if (((1LL << depth) - 1) * neg < -32768LL * (1LL << (depth - 1)))
             return false;
     }
@@ -452,6 +483,13 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 build_fast_view(c, limits, false) && bank_nowrap_depth(c->nf[0].data(), c->d[0].n, sd) &&
                 bank_nowrap_depth(c->nf[1].data(), c->d[1].n, sd))
                 up2_build(c, limits);
+            /* ... and exact 2:1 (k_sws_down2<1>), banks of up to 8 taps */
+            const int cdw = c->d[1].n, cdh = c->d[3].n;
+            if (sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl == dl && sl != 2 && t->src_range == t->dst_range &&
+                t->srcW == 2 * t->dstW && t->srcH == 2 * t->dstH && cw == 2 * cdw && chh == 2 * cdh &&
+                !(t->dstW & 3) && t->dstW >= 12 && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
+                bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
+                dn2_build(c, limits);
         }
         return c;
     }
@@ -541,32 +579,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             l.srcW == 2 * l.dstW && l.srcH == 2 * l.dstH && ch.srcW == 2 * ch.dstW && ch.srcH == 2 * ch.dstH &&
             fmt_nv(t->srcFormat) == fmt_nv(t->dstFormat) && !(l.dstW & 3) && l.dstW >= 12 &&
             (fmt_nv(t->srcFormat) ? !(ch.dstW & 1) && ch.dstW >= 6 : !(ch.dstW & 3) && ch.dstW >= 12)) {
-            std::vector<uint32_t> vb[4];
             const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
-            bool ok = true;
-            for (int i = 0; i < 4 && ok; i++)
-                ok = ffhip_down2_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], &vb[i]) != 0;
-            if (ok) {
-                for (int i = 2; i < 4; i++)
-                    vb[i].resize((size_t)(c->d[i].n + 8) * 4, 0); /* the row loop reads four rows of coefficients at a time */
-                size_t uo[4], ut = 0;
-                for (int i = 0; i < 4; i++) {
-                    uo[i] = ut;
-                    ut += (vb[i].size() * 4 + 255) & ~(size_t)255;
-                }
-                if (hipMalloc(&c->dn2_dev, ut) == hipSuccess) {
-                    uint8_t *b = static_cast<uint8_t *>(c->dn2_dev);
-                    for (int i = 0; i < 4 && ok; i++)
-                        ok = hipMemcpy(b + uo[i], vb[i].data(), vb[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-                    if (ok) {
-                        c->dn2_h[0] = reinterpret_cast<const uint32_t *>(b + uo[0]);
-                        c->dn2_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
-                        c->dn2_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
-                        c->dn2_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
-                        c->dn2_ok = 1;
-                    }
-                }
-            }
+            dn2_build(c, nsrc);
         }
         /* MFMA variant: same banks; chroma either byte-interleaved on both sides or planar on both sides */
         const bool nv_in = fmt_nv(t->srcFormat), nv_out = fmt_nv(t->dstFormat);
@@ -758,6 +772,33 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                     ffhip_up2_plan_job(&U.job[i], 64 >> U.fshift, 60);
                 return ffhip_launch_up2(U, 3, 0, stream);
             }
+        }
+        const char *e2 = FFHIP_KNOB("FFHIP_SWS_DOWN2");
+        if (c->dn2_ok && !(al & 3) && !neg && !(e2 && e2[0] == '0')) {
+            /* exact 2:1 above 8 bits: the static-schedule kernel (FFHIP_SWS_DOWN2=0: the tiled k_sws_scale16) */
+            FFHipDn2Args D;
+            memset(&D, 0, sizeof(D));
+            D.nframes = nframes;
+            D.xcd = 1;
+            auto dnjob = [&](int which, int plane, int dw_, int sh_, int dh_, int pair) {
+                FFHipDn2Job &j = D.job[D.njobs++];
+                j.src = static_cast<const uint8_t *>(src[plane]); j.dst = static_cast<uint8_t *>(dst[plane]);
+                j.sstride = srcStride[plane]; j.dstride = dstStride[plane]; j.sfp = srcFramePitch[plane]; j.dfp = dstFramePitch[plane];
+                j.pair = pair; j.swap = 0;
+                j.srcH = sh_; j.dstH = dh_;
+                j.ngroups = pair ? dw_ / 2 : dw_ / 4;
+                j.hfv = c->dn2_h[which]; j.vfv = c->dn2_v[which];
+                j.hb_sdepth = sd; j.hb_ddepth = dd; j.hb_smsb = sl == 1; j.hb_dmsb = dl == 1;
+                ffhip_down2_plan_job(&j, 32);
+            };
+            dnjob(0, 0, t.dstW, t.srcH, t.dstH, 0);
+            if (sl) {
+                dnjob(1, 1, c->d[1].n, c->chrSrcH, c->d[3].n, 1);
+            } else {
+                dnjob(1, 1, c->d[1].n, c->chrSrcH, c->d[3].n, 0);
+                dnjob(1, 2, c->d[1].n, c->chrSrcH, c->d[3].n, 0);
+            }
+            return ffhip_launch_down2(D, stream);
         }
     }
     FFHipScale16Args a;

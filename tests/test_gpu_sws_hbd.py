@@ -109,6 +109,36 @@ def test_range_conversion_above_8_bits(case):
     _run(case[:7], ranges=case[7:])
 
 
+DOWN2_CASES = [
+    ("yuv420p10le", 96, 48, "yuv420p10le", 48, 24, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 112, 64, "yuv420p10le", 56, 32, ffi.SWS_BILINEAR),
+    ("p010le", 96, 48, "p010le", 48, 24, ffi.SWS_BICUBIC),                 # (u, v) columns: the pair path, samples in the high bits
+    ("p012le", 96, 48, "p012le", 48, 24, ffi.SWS_AREA),
+    ("yuv420p10le", 2000, 124, "yuv420p10le", 1000, 62, ffi.SWS_BICUBIC),  # 250 groups per row: a ragged last block
+    ("p010le", 1040, 140, "p010le", 520, 70, ffi.SWS_BICUBIC),
+    ("yuv422p10le", 96, 48, "yuv422p10le", 48, 24, ffi.SWS_BICUBIC),
+    ("yuv444p10le", 96, 48, "yuv444p10le", 48, 24, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 96, 48, "yuv420p12le", 48, 24, ffi.SWS_BICUBIC),
+    ("yuv420p14le", 96, 48, "yuv420p9le", 48, 24, ffi.SWS_BICUBIC),
+]
+
+
+@pytest.mark.parametrize("variant", ["product", "tiled"])
+@pytest.mark.parametrize("case", DOWN2_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_exact_2to1_above_8_bits(case, variant, monkeypatch):
+    """exact 2:1 between formats of 9..14 bits laid out alike: the static-schedule kernel's 16-bit twin (k_sws_down2<1>); "tiled" runs
+    the same cases on k_sws_scale16 (FFHIP_SWS_DOWN2=0, the measure build)"""
+    from ffmpeg_amd import swscale as S
+    if variant == "tiled":
+        monkeypatch.setenv("FFHIP_SWS_DOWN2", "0")
+    else:
+        _torch()
+        ctx = S.SwsContext(case[1], case[2], FMT[case[0]][0], case[4], case[5], FMT[case[3]][0], case[6])
+        assert ctx.down2_path, "the exact-2:1 kernel should serve this context"
+        ctx.close()
+    _run(case, nframes=5)
+
+
 def test_p010_1080p_to_4k():
     _run(("p010le", 1920, 1080, "p010le", 3840, 2160, ffi.SWS_BICUBIC), nframes=1, pad=0)
 
