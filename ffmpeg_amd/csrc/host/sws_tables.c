@@ -451,11 +451,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
             srcFormat = base[srcFormat - FFHIP_PIX_FMT_YUVJ420P];
         if (dj)
             dstFormat = base[dstFormat - FFHIP_PIX_FMT_YUVJ420P];
-        if (sj != dj && is_rgb(dstFormat)) {
-            /* the reference folds the source's range into the yuv2rgb tables (ff_yuv2rgb_c_init_tables' fullRange branch) */
-            ffhip_set_error("ffhip_sws: full-range YUV to packed RGB is not on the hip path");
-            return NULL;
-        }
+        /* packed RGB targets: the source's range goes into the yuv2rgb tables (ff_yuv2rgb_c_init_tables' fullRange branch) */
     }
     if (flags & FFHIP_SWS_FAST_BILINEAR) {
         /* the C path of SWS_FAST_BILINEAR runs ff_hyscale_fast_c, a different horizontal scaler
@@ -485,7 +481,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     h->t.flags = flags;
     h->t.src_range = src_range;
     h->t.dst_range = dst_range;
-    if (src_range != dst_range) {
+    if (src_range != dst_range && !is_rgb(dstFormat)) {
         int ddepth = 8;
         ffhip_pixfmt_hbd(dstFormat, &ddepth, NULL, NULL, NULL);
         ffhip_sws_range_constants(src_range, ddepth, &h->t.lumConvertRange_coeff, &h->t.lumConvertRange_offset,
@@ -540,7 +536,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         out[k]->size = r;
         out[k]->n = bank[k].d;
     }
-    ffhip_host_yuv2rgb_coeffs(&h->t, 0);
+    ffhip_host_yuv2rgb_coeffs(&h->t, is_rgb(dstFormat) ? src_range : 0);
     return h;
 }
 
@@ -560,15 +556,13 @@ int ffhip_sws_tables_set_ranges(FFHipSwsHostTables *t, int src_range, int dst_ra
     int ddepth = 8;
     if (!t || (src_range | dst_range) & ~1)
         return FFHIP_EINVAL;
-    if (src_range != dst_range && is_rgb(t->t.dstFormat)) {
-        ffhip_set_error("ffhip_sws: full-range YUV to packed RGB is not on the hip path");
-        return FFHIP_ENOSYS;
-    }
+    if (is_rgb(t->t.dstFormat)) /* the coefficients carry the source's range (sws_setColorspaceDetails -> ff_yuv2rgb_c_init_tables) */
+        ffhip_host_yuv2rgb_coeffs(&t->t, src_range);
     t->t.src_range = src_range;
     t->t.dst_range = dst_range;
     t->t.lumConvertRange_coeff = t->t.chrConvertRange_coeff = 0;
     t->t.lumConvertRange_offset = t->t.chrConvertRange_offset = 0;
-    if (src_range != dst_range) {
+    if (src_range != dst_range && !is_rgb(t->t.dstFormat)) {
         ffhip_pixfmt_hbd(t->t.dstFormat, &ddepth, NULL, NULL, NULL);
         ffhip_sws_range_constants(src_range, ddepth, &t->t.lumConvertRange_coeff, &t->t.lumConvertRange_offset,
                                   &t->t.chrConvertRange_coeff, &t->t.chrConvertRange_offset);

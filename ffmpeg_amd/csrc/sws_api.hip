@@ -367,11 +367,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         ffhip_set_error("ffhip_sws: 4:2:2 / 4:4:4 sources to packed RGB are not on the hip path");
         return nullptr;
     }
-    if (t->src_range != t->dst_range && fmt_rgb(t->dstFormat)) {
-        /* the reference folds the source's range into the yuv2rgb tables (ff_yuv2rgb_c_init_tables' fullRange branch) */
-        ffhip_set_error("ffhip_sws: full-range YUV to packed RGB is not on the hip path");
-        return nullptr;
-    }
+    /* (a packed RGB target takes the source's range through the yuv2rgb coefficients the caller hands over: ff_yuv2rgb_c_init_tables'
+     * fullRange branch, libswscale/yuv2rgb.c:760-768; the range fields then play no part) */
     if (!ffhip_have_device()) {
         ffhip_set_error("ffhip_sws: no HIP device (FFHIP_ENOSYS) - keep the C function pointers");
         return nullptr;

@@ -188,9 +188,7 @@ def test_full_range_twins(name, base):
     for p, a in enumerate(want):
         assert np.array_equal(ddst[p][1].cpu().numpy(), a)
     ctx.close()
-    # a J format on one side only is a range conversion (test_range_conversion below); packed RGB targets refuse it
-    with pytest.raises(ValueError, match="full-range"):
-        S.SwsContext(sw, sh, S.PIX_FMT[name], dw, dh, PIX["rgb24"], ffi.SWS_BICUBIC)
+    # a J format on one side only is a range conversion (test_range_conversion below; packed RGB targets: test_full_range_yuv_to_rgb)
 
 
 def test_from_tables_dropin():
@@ -307,5 +305,48 @@ def test_range_conversion(case):
     ctx2.scale_batch(dsrc, d2)
     torch.cuda.synchronize()
     assert not torch.equal(d2[0], ddst[0])
-    with pytest.raises(ValueError, match="full-range"):
-        S.SwsContext(sw, sh, PIX["yuvj420p"], dw & ~1, dh, PIX["rgb24"], flags)
+
+
+@pytest.mark.parametrize("dst", ["rgb24", "bgra"])
+@pytest.mark.parametrize("sw,sh,dw,dh,flags", [(64, 16, 64, 16, ffi.SWS_BICUBIC), (1920, 1080, 1920, 1080, ffi.SWS_BICUBIC), (64, 40, 160, 88, ffi.SWS_BICUBIC),
+                                               (96, 54, 48, 28, ffi.SWS_BILINEAR), (176, 144, 352, 288, ffi.SWS_BICUBIC),
+                                               (64, 40, 64, 40, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND)])
+def test_full_range_yuv_to_rgb(dst, sw, sh, dw, dh, flags):
+    """yuvj420p -> packed RGB: the full-range yuv2rgb coefficients (ff_yuv2rgb_c_init_tables' fullRange branch) in the unscaled kernel
+    and in the scaled RGB kernels; HIP == oracle (pinned to the reference by tests/test_oracle_vs_ref.py::test_full_range_yuv_to_rgb)"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    rng = np.random.default_rng(sw + dw + len(dst))
+    src = ffi.alloc_frame(PIX["yuv420p"], sw, sh, rng, pad=0)
+    for pl in src:
+        pl[::5, : pl.shape[1] // 2] = 255
+        pl[3::7, pl.shape[1] // 3:] = 0
+    ht = S.HostTables(sw, sh, PIX["yuvj420p"], dw, dh, PIX[dst], flags)
+    co = ht.coeffs()
+    want = ffi.alloc_frame(PIX[dst], dw, dh)
+    sp, ss = ffi.planes(src)
+    O = ffi.oracle()
+    if ht.unscaled_yuv2rgb:
+        luts = ffi.OLuts()
+        k = ffi.OYuv2RgbCoeffs(*[co[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+        O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
+        O.ffo_yuv420p_to_rgb24(C.byref(luts), sw, sp, ss, 0, sh, ptr(want[0]), want[0].strides[0], ffi.RGB_LAYOUT[PIX[dst]])
+    else:
+        t = ffi.make_otables(sw, sh, PIX["yuv420p"], dw, dh, PIX[dst], flags, ht.banks(), co)
+        dp, ds = ffi.planes(want)
+        assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+    ctx = S.SwsContext(sw, sh, PIX["yuvj420p"], dw, dh, PIX[dst], flags)
+    n = 2
+    dsrc = _upload(src, n=n)
+    ddst = [torch.zeros((n,) + want[0].shape, dtype=torch.uint8, device="cuda:0")]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        got = ddst[0][f].cpu().numpy()
+        assert np.array_equal(got, want[0]), "frame %d: %d mismatches" % (f, (got != want[0]).sum())
+    # ... and differs from the limited-range conversion of the same bytes
+    ctx2 = S.SwsContext(sw, sh, PIX["yuv420p"], dw, dh, PIX[dst], flags)
+    d2 = [torch.zeros_like(ddst[0])]
+    ctx2.scale_batch(dsrc, d2)
+    torch.cuda.synchronize()
+    assert not torch.equal(d2[0], ddst[0])

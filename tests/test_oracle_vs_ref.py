@@ -140,8 +140,41 @@ def test_full_range_twins_are_their_base_formats(base, j):
     # a J format on one side only: a range conversion between YUV formats (round 3), refused for packed RGB targets
     ht = S.HostTables(sw, sh, j, dw, dh, base, ffi.SWS_BICUBIC)
     assert (ht.t.srcFormat, ht.t.dstFormat, ht.t.src_range, ht.t.dst_range) == (base, base, 1, 0)
-    with pytest.raises(ValueError, match="full-range"):
-        S.HostTables(sw, sh, j, dw, dh, PIX["rgb24"], ffi.SWS_BICUBIC)
+
+
+@pytest.mark.parametrize("dst", ["rgb24", "bgra"])
+@pytest.mark.parametrize("sw,sh,dw,dh,flags", [(64, 16, 64, 16, ffi.SWS_BICUBIC), (1078, 6, 1078, 6, ffi.SWS_BICUBIC), (64, 40, 160, 88, ffi.SWS_BICUBIC),
+                                               (96, 54, 48, 28, ffi.SWS_BILINEAR), (64, 40, 64, 40, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND)])
+def test_full_range_yuv_to_rgb(dst, sw, sh, dw, dh, flags):
+    """yuvj420p -> packed RGB: the source's range goes into the yuv2rgb tables (ff_yuv2rgb_c_init_tables' fullRange branch,
+    libswscale/yuv2rgb.c:749-768), not into a range stage: the oracle with the coefficients libffhip's host side derives for a
+    full-range source == the reference, on the unscaled table path and through the scaler"""
+    from ffmpeg_amd import swscale as S
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(sw + dw + len(dst))
+    src = ffi.alloc_frame(PIX["yuv420p"], sw, sh, rng, pad=3)
+    for pl in src:
+        pl[::5, : pl.shape[1] // 2] = 255
+        pl[3::7, pl.shape[1] // 3:] = 0
+    want, banks = _ref_convert(PIX["yuvj420p"], sw, sh, PIX[dst], dw, dh, flags, src)
+    ht = S.HostTables(sw, sh, PIX["yuvj420p"], dw, dh, PIX[dst], flags)
+    co = ht.coeffs()
+    assert co != ffi.DEFAULT_COEFFS and ht.t.src_range == 1
+    sp, ss = ffi.planes(src)
+    if banks is None:   # the unscaled table converter
+        assert ht.unscaled_yuv2rgb
+        luts = ffi.OLuts()
+        k = ffi.OYuv2RgbCoeffs(*[co[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+        O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
+        got = np.zeros_like(want[0])
+        O.ffo_yuv420p_to_rgb24(C.byref(luts), sw, sp, ss, 0, sh, ptr(got), got.strides[0], ffi.RGB_LAYOUT[PIX[dst]])
+        assert np.array_equal(got, want[0])
+    else:
+        t = ffi.make_otables(sw, sh, PIX["yuv420p"], dw, dh, PIX[dst], flags, banks, co)
+        got = ffi.alloc_frame(PIX[dst], dw, dh)
+        gp, gs = ffi.planes(got)
+        assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh
+        assert np.array_equal(got[0], want[0])
 
 
 RANGE_CASES = [("yuvj420p", 64, 40, "yuv420p", 160, 88, ffi.SWS_BICUBIC), ("yuv420p", 64, 40, "yuvj420p", 160, 88, ffi.SWS_BICUBIC),
