@@ -492,9 +492,12 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
      * (utils.c:1359-1360) and full vertical resolution */
     chrDstHSub = is_rgb(dstFormat) ? 1 : chroma_hsub(dstFormat);
     chrDstVSub = is_rgb(dstFormat) ? 0 : chroma_vsub(dstFormat);
-    if (is_rgb(dstFormat) && (chroma_hsub(srcFormat) != 1 || chroma_vsub(srcFormat) != 1)) {
-        /* utils.c:1375-1390 re-derives the source's chroma subsampling for packed targets: only the 4:2:0 sources are taken */
-        ffhip_set_error("ffhip_sws: 4:2:2 / 4:4:4 sources to packed RGB are not on the hip path");
+    /* 4:2:2 sources to packed RGB: the chroma banks run from the source's own chroma plane size to dstW / 2 x dstH (chrSrcHSubSample
+     * stays the format's for YUV sources: the "drop every other pixel" of utils.c:1368-1392 is for RGB sources).  4:4:4 sources make
+     * the reference switch SWS_FULL_CHR_H_INT on ("input having non subsampled chroma", utils.c:1276-1285): the yuv2rgb_full_* writers,
+     * another arithmetic (coefficients instead of the tables, error-diffusion dither) that is not on this path */
+    if (is_rgb(dstFormat) && chroma_hsub(srcFormat) == 0 && chroma_vsub(srcFormat) == 0) {
+        ffhip_set_error("ffhip_sws: 4:4:4 sources to packed RGB take the reference's full-chroma writers; not on the hip path");
         free(h);
         return NULL;
     }

@@ -363,8 +363,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         ffhip_set_error("ffhip_sws: odd RGB width is not on the hip path");
         return nullptr;
     }
-    if (fmt_rgb(t->dstFormat) && (fmt_hsub(t->srcFormat) != 1 || fmt_vsub(t->srcFormat) != 1)) {
-        ffhip_set_error("ffhip_sws: 4:2:2 / 4:4:4 sources to packed RGB are not on the hip path");
+    if (fmt_rgb(t->dstFormat) && fmt_hsub(t->srcFormat) == 0 && fmt_vsub(t->srcFormat) == 0) {
+        ffhip_set_error("ffhip_sws: 4:4:4 sources to packed RGB take the reference's full-chroma writers; not on the hip path");
         return nullptr;
     }
     /* (a packed RGB target takes the source's range through the yuv2rgb coefficients the caller hands over: ff_yuv2rgb_c_init_tables'

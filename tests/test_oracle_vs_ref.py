@@ -1382,3 +1382,35 @@ def test_mdct_vs_naive(inv):
     (O.ffo_mdct_naive_inv if inv else O.ffo_mdct_naive_fwd)(n, 1.0, nv.ctypes.data_as(C.POINTER(C.c_double)), ptr(x, f32p))
     O.ffo_mdct_free(oc)
     assert np.abs(out - nv).max() <= 2.0 ** -18 * np.abs(nv).max() * 4
+
+
+@pytest.mark.parametrize("dst", ["rgb24", "bgra"])
+@pytest.mark.parametrize("sf,sw,sh,dw,dh,flags", [("yuv422p", 64, 16, 64, 16, ffi.SWS_BICUBIC), ("yuv422p", 1078, 6, 1078, 6, ffi.SWS_BICUBIC),
+                                                  ("yuv422p", 64, 40, 160, 88, ffi.SWS_BICUBIC), ("yuv422p", 96, 54, 48, 28, ffi.SWS_BILINEAR),
+                                                  ("yuv422p", 96, 54, 120, 54, ffi.SWS_BICUBIC),
+                                                  ("yuv422p", 64, 40, 64, 40, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND)])
+def test_422_to_packed_rgb(dst, sf, sw, sh, dw, dh, flags):
+    """4:2:2 planar sources to packed RGB: the chroma banks run from the source's own chroma plane to dstW / 2 x dstH
+    (libswscale/utils.c:1359-1397); equal sizes included — yuv422p has a table converter of its own in the reference
+    (YUV422FUNC, yuv2rgb.c:238-281: every line its own chroma row), whose bytes are what the scaler's one-tap path gives.
+    (4:4:4 sources switch the reference to its full-chroma writers, utils.c:1276-1285: refused by the hip path.)"""
+    from ffmpeg_amd import swscale as S
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(sw + dw + len(dst) + len(sf))
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=3)
+    R_ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, PIX[dst], flags, 1)
+    assert R_ctx
+    want = ffi.alloc_frame(PIX[dst], dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(want)
+    assert R.ffref_sws_scale(R_ctx, sp, ss, 0, sh, dp, ds) == dh
+    R.ffref_sws_free(R_ctx)
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags)
+    assert not ht.unscaled_yuv2rgb
+    t = ffi.make_otables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags, ht.banks(), ht.coeffs())
+    got = ffi.alloc_frame(PIX[dst], dw, dh)
+    gp, gs = ffi.planes(got)
+    assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh
+    assert np.array_equal(got[0], want[0]), "%d bytes differ" % (got[0] != want[0]).sum()
+    with pytest.raises(ValueError, match="4:4:4"):
+        S.HostTables(sw, sh, PIX["yuv444p"], dw, dh, PIX[dst], flags)
