@@ -118,8 +118,19 @@ def cpu_baseline(budget_s=5.0):
                                        "pass, %d persistent thread(s) on thread-local (NUMA-local) copies of their share" % (passes.value, n, planes, secs.value, got)}
             del pic, off, blk
     best = max((legs[k] for k in legs if k.startswith("sws_")), key=lambda l: l["value"])
-    return {"value": best["value"], "unit": "Mpixels/s", "cores": best["cores"], "kind": "reference",
-            "sample": best["sample"] + " of %d host cores, pure C (no SIMD asm: nasm absent)" % cores, "host_cores": cores, "legs": legs}
+    out = {"value": best["value"], "unit": "Mpixels/s", "cores": best["cores"], "kind": "reference",
+           "sample": best["sample"] + " of %d host cores, pure C (no SIMD asm: nasm absent)" % cores, "host_cores": cores, "legs": legs}
+    # what the box lets this process use: a container's CPU quota / cpuset bounds every sustained all-cores leg (a 9 ms burst is not throttled,
+    # 1.5 s are: round 2's one-shot idct leg read 4x the sustained rate on such a box)
+    try:
+        out["sched_affinity_cores"] = len(os.sched_getaffinity(0))
+        for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            if os.path.exists(f):
+                out["cgroup_cpu_limit"] = open(f).read().strip()
+                break
+    except OSError:
+        pass
+    return out
 
 
 def measure_traffic(kname, frames):
