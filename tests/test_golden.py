@@ -432,3 +432,107 @@ def test_round2_aac_tools_golden():
         prev = (int(d["a960_seq"][f]), int(d["a960_kb"][f]))
     assert np.array_equal(bits(saved), bits(d["a960_saved_out"]))
     O.ffo_mdct_free(ml); O.ffo_mdct_free(ms)
+
+
+# ---- round 3 ------------------------------------------------------------------------------------------------------------------
+HBD_FMT = {"yuv420p9le": (60, 9, 0), "yuv420p10le": (62, 10, 0), "yuv420p12le": (123, 12, 0), "yuv420p14le": (125, 14, 0),
+           "yuv420p16le": (45, 16, 0), "p010le": (158, 10, 1), "p012le": (209, 12, 1), "p016le": (169, 16, 1)}
+
+
+def _planes(arrs):
+    p = (u8p * 4)()
+    s = (C.c_int * 4)()
+    for i, a in enumerate(arrs):
+        p[i] = C.cast(a.ctypes.data, u8p)
+        s[i] = a.strides[0]
+    return p, s
+
+
+def test_round3_sws_golden():
+    """the scaler above 8 bits, range conversion, full-range and 4:2:2 sources to packed RGB: the oracle on the stored frames, with
+    the banks / constants / coefficients libffhip's host side derives (no device needed), == the stored reference outputs"""
+    from ffmpeg_amd import swscale as S
+    O = ffi.oracle()
+    O.ffo_sws_scale_frame_hbd.argtypes = [C.POINTER(ffi.OSwsTables), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(C.c_int),
+                                          C.POINTER(u8p), C.POINTER(C.c_int)]
+    d = load("round3")
+    base = {"yuvj420p": "yuv420p"}
+    for k, case in enumerate(d["sws_cases"]):
+        sn, sw, sh, dn, dw, dh, flags, sr, dr = str(case).split()
+        sw, sh, dw, dh, flags, sr, dr = (int(v) for v in (sw, sh, dw, dh, flags, sr, dr))
+        src = [np.ascontiguousarray(d["sws%d_src%d" % (k, i)]) for i in range(3) if "sws%d_src%d" % (k, i) in d]
+        want = [d["sws%d_out%d" % (k, i)] for i in range(3) if "sws%d_out%d" % (k, i) in d]
+        got = [np.zeros_like(a) for a in want]
+        sfmt = HBD_FMT[sn][0] if sn in HBD_FMT else ffi.PIX[sn]
+        dfmt = HBD_FMT[dn][0] if dn in HBD_FMT else ffi.PIX[dn]
+        hb = sn in HBD_FMT or dn in HBD_FMT
+        ht = S.HostTables(sw, sh, sfmt, dw, dh, dfmt, flags, ranges=(sr, dr) if hb and sr != dr else None)
+        sp, ss = _planes(src)
+        gp, gs = _planes(got)
+        if hb:
+            sd, sl = HBD_FMT[sn][1:] if sn in HBD_FMT else (8, 0)
+            dd, dl = HBD_FMT[dn][1:] if dn in HBD_FMT else (8, 0)
+            t = ffi.make_otables(sw, sh, sfmt, dw, dh, dfmt, flags, ht.banks(), ht.coeffs(), ranges=(sr, dr), dst_depth=dd)
+            assert O.ffo_sws_scale_frame_hbd(C.byref(t), sd, sl, dd, dl, sp, ss, gp, gs) == 0, case
+        else:
+            rgb = dn in ("rgb24", "bgra")
+            t = ffi.make_otables(sw, sh, ffi.PIX[base.get(sn, sn)], dw, dh, ffi.PIX[base.get(dn, dn)], flags, ht.banks(), ht.coeffs(),
+                                 ranges=None if rgb else (sr, dr))
+            if ht.unscaled_yuv2rgb:
+                co = ht.coeffs()
+                luts = ffi.OLuts()
+                kk = ffi.OYuv2RgbCoeffs(*[co[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+                O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(kk))
+                O.ffo_yuv420p_to_rgb24(C.byref(luts), sw, sp, ss, 0, sh, ptr(got[0]), got[0].strides[0], ffi.RGB_LAYOUT[ffi.PIX[dn]])
+            else:
+                assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh, case
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), (str(case), int((a != b).sum()))
+
+
+def test_round3_fft_golden():
+    """ff_tx_fft_pfa (120 / 960 / 96 / 1280) and FFT-4096: the oracle on the stored inputs == the stored reference outputs, bit for bit"""
+    O = ffi.oracle()
+    d = load("round3")
+    for key in d["fft_keys"]:
+        key = str(key)
+        len_, inv = int(key[3:].split("_")[0]), int(key.split("_")[1])
+        for t in range(d[key + "_in"].shape[0]):
+            out = np.zeros(2 * len_, np.float32)
+            O.ffo_fft_run(inv, len_, ptr(out, f32p), ptr(np.ascontiguousarray(d[key + "_in"][t]), f32p))
+            assert np.array_equal(out.view(np.uint32), d[key + "_out"][t].view(np.uint32)), key
+
+
+def test_round3_h264_hbd_golden():
+    """h264dsp / qpel / chroma / weight at 10 and 12 bits: the oracle's *_bd functions on the stored inputs == the stored outputs"""
+    O = ffi.oracle()
+    O.ffo_h264_idct_bd.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_ssize_t]
+    O.ffo_h264_loop_filter_bd.argtypes = [C.c_int, C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.POINTER(C.c_int8)]
+    O.ffo_h264_qpel_bd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t]
+    O.ffo_h264_chroma_mc_bd.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+    O.ffo_h264_biweight_bd.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    d = load("round3")
+
+    def pat(a, row, col):
+        return C.cast(a.ctypes.data + (row * a.shape[1] + col) * a.itemsize, u8p)
+    for bd in (10, 12):
+        for kind in (0, 1):
+            c = np.ascontiguousarray(d["h%d_idct%d_c" % (bd, kind)])
+            pic = np.ascontiguousarray(d["h%d_idct%d_in" % (bd, kind)])
+            O.ffo_h264_idct_bd(bd, kind, pat(pic, 2, 5), C.cast(c.ctypes.data, i16p), pic.strides[0])
+            assert np.array_equal(pic, d["h%d_idct%d_out" % (bd, kind)]) and not c.any(), (bd, kind)
+        tc = np.array([0, 1, 3, -1], np.int8)
+        for kind, inner in ((0, 4), (5, 4), (2, 2), (7, 2)):
+            pic = np.ascontiguousarray(d["h%d_lf%d_in" % (bd, kind)])
+            O.ffo_h264_loop_filter_bd(bd, kind, inner, pat(pic, 12, 12), pic.strides[0], 40, 9, tc.ctypes.data_as(C.POINTER(C.c_int8)))
+            assert np.array_equal(pic, d["h%d_lf%d_out" % (bd, kind)]), (bd, kind)
+        src = np.ascontiguousarray(d["h%d_mc_src" % bd])
+        pic = np.ascontiguousarray(d["h%d_qpel_in" % bd])
+        O.ffo_h264_qpel_bd(bd, 1, 0, 10, pat(pic, 6, 8), pat(src, 6, 8), pic.strides[0])
+        assert np.array_equal(pic, d["h%d_qpel_out" % bd]), bd
+        pic = np.ascontiguousarray(d["h%d_chroma_in" % bd])
+        O.ffo_h264_chroma_mc_bd(bd, 0, 8, pat(pic, 2, 4), pat(src, 2, 4), pic.strides[0], 8, 3, 5)
+        assert np.array_equal(pic, d["h%d_chroma_out" % bd]), bd
+        pic = np.ascontiguousarray(d["h%d_bw_in" % bd])
+        O.ffo_h264_biweight_bd(bd, 16, pat(pic, 1, 4), pat(src, 1, 4), pic.strides[0], 16, 5, 37, -21, 9)
+        assert np.array_equal(pic, d["h%d_bw_out" % bd]), bd

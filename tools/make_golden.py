@@ -615,12 +615,106 @@ def round2():
     np.savez_compressed(os.path.join(OUT, "round2.npz"), **d)
 
 
+def round3():
+    """round 3's additions, one file: the scaler above 8 bits, range conversion, full-range and 4:2:2 sources to packed RGB, the
+    prime-factor FFT and FFTs beyond one wave, the h264 tables at 10 / 12 bits — inputs and the REAL reference's outputs"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_oracle_vs_ref_sws_hbd as H
+    import test_oracle_vs_ref_h264_hbd as B
+    d = {}
+    # ---- sws: (src name, w, h, dst name, w, h, flags, src_range, dst_range); 8-bit names from ffi.PIX, deeper ones from H.FMT
+    rng = np.random.default_rng(3001)
+    cases = [("p010le", 64, 36, "p010le", 128, 72, 4, 0, 0), ("yuv420p10le", 128, 72, "yuv420p", 64, 36, 4, 0, 0),
+             ("yuv420p16le", 64, 36, "yuv420p16le", 96, 54, 4, 0, 0), ("yuv420p10le", 96, 48, "yuv420p10le", 48, 24, 2, 0, 0),
+             ("yuv420p10le", 64, 36, "yuv420p10le", 96, 54, 4, 1, 0), ("yuv420p16le", 64, 36, "p016le", 96, 54, 2, 0, 1),
+             ("yuvj420p", 64, 40, "yuv420p", 160, 88, 4, 1, 0), ("yuv420p", 96, 54, "yuvj420p", 96, 54, 2, 0, 1),
+             ("yuvj420p", 64, 40, "rgb24", 160, 88, 4, 1, 1), ("yuvj420p", 64, 16, "bgra", 64, 16, 4, 1, 1),
+             ("yuv422p", 64, 40, "rgb24", 160, 88, 4, 0, 0), ("yuv422p", 64, 16, "rgb24", 64, 16, 4, 0, 0)]
+    names = []
+    for k, (sn, sw, sh, dn, dw, dh, flags, sr, dr) in enumerate(cases):
+        hb = sn in H.FMT and H.FMT[sn][1] > 8 or dn in H.FMT and H.FMT[dn][1] > 8
+        sfmt = H.FMT[sn][0] if sn in H.FMT else ffi.PIX[sn]
+        dfmt = H.FMT[dn][0] if dn in H.FMT else ffi.PIX[dn]
+        base = {"yuvj420p": "yuv420p"}
+        if hb:
+            src = H.make_frame(sn, sw, sh, rng, pad=2)
+            want = H.make_frame(dn, dw, dh, None, pad=0)
+            sp, ss = H.planes_of(src)
+            wp, ws = H.planes_of(want)
+            ctx = R.ffref_sws_create_ranges(sw, sh, sfmt, dw, dh, dfmt, flags, 1, sr, dr)
+        else:
+            src = ffi.alloc_frame(ffi.PIX[base.get(sn, sn)], sw, sh, rng, pad=2)
+            for pl in src:
+                pl[::5, : pl.shape[1] // 2] = 255
+                pl[3::7, pl.shape[1] // 3:] = 0
+            want = ffi.alloc_frame(ffi.PIX[base.get(dn, dn)], dw, dh)
+            sp, ss = ffi.planes(src)
+            wp, ws = ffi.planes(want)
+            ctx = R.ffref_sws_create(sw, sh, sfmt, dw, dh, dfmt, flags, 1)
+        assert ctx and R.ffref_sws_scale(ctx, sp, ss, 0, sh, wp, ws) == dh
+        R.ffref_sws_free(ctx)
+        names.append("%s %d %d %s %d %d %d %d %d" % (sn, sw, sh, dn, dw, dh, flags, sr, dr))
+        for i, a in enumerate(src):
+            d["sws%d_src%d" % (k, i)] = a
+        for i, a in enumerate(want):
+            d["sws%d_out%d" % (k, i)] = a
+    d["sws_cases"] = np.array(names)
+    # ---- av_tx: ff_tx_fft_pfa lengths, both directions, and the first length beyond one wave
+    rng = np.random.default_rng(3002)
+    keys = []
+    for len_, inv in ((120, 0), (120, 1), (960, 0), (960, 1), (96, 1), (1280, 0), (4096, 0)):
+        x = (rng.standard_normal((2, 2 * len_)) * 10.0 ** rng.integers(-2, 3, (2, 1))).astype(np.float32)
+        rc = R.ffref_tx_create(0, inv, len_, 1.0, 0)
+        out = np.zeros((2, 2 * len_), np.float32)
+        for t in range(2):
+            R.ffref_tx_run(rc, ptr(out[t], f32p), ptr(x[t].copy(), f32p), 8)
+        R.ffref_tx_free(rc)
+        key = "fft%d_%d" % (len_, inv)
+        keys.append(key)
+        d[key + "_in"], d[key + "_out"] = x, out
+    d["fft_keys"] = np.array(keys)
+    # ---- h264 at 10 and 12 bits: idct 4x4 / 8x8, one luma and one chroma loop filter, a J-position qpel, chroma MC, (bi)weight
+    O = ffi.oracle()
+    B._sigs(R, O)
+    R.ffref_h264_set_bit_depth.argtypes = [C.c_int]
+    rng = np.random.default_rng(3003)
+    for bd in (10, 12):
+        R.ffref_h264_set_bit_depth(bd)
+        for kind in (0, 1):
+            n = 8 if kind else 4
+            c = B.coefs(rng, n * n, bd)
+            pic = B.pixels(rng, (n + 4, 40), bd, True)
+            d["h%d_idct%d_c" % (bd, kind)], d["h%d_idct%d_in" % (bd, kind)] = c.copy(), pic.copy()
+            R.ffref_h264_idct(kind, B.at(pic, 2, 5), B.bptr(c), pic.strides[0])
+            d["h%d_idct%d_out" % (bd, kind)] = pic
+        for kind, inner in ((0, 4), (5, 4), (2, 2), (7, 2)):
+            pic = np.clip(300 + rng.integers(-12 << (bd - 8), (12 << (bd - 8)) + 1, (40, 40)), 0, (1 << bd) - 1).astype(np.uint16)
+            tc = np.array([0, 1, 3, -1], np.int8)
+            d["h%d_lf%d_in" % (bd, kind)] = pic.copy()
+            R.ffref_h264_loop_filter_variant(kind, 0, B.at(pic, 12, 12), pic.strides[0], 40, 9, tc.ctypes.data_as(C.POINTER(C.c_int8)))
+            d["h%d_lf%d_out" % (bd, kind)] = pic
+        src, pic = B.pixels(rng, (32, 40), bd, True), B.pixels(rng, (32, 40), bd)
+        d["h%d_mc_src" % bd], d["h%d_qpel_in" % bd] = src, pic.copy()
+        R.ffref_h264_qpel(1, 0, 10, B.at(pic, 6, 8), B.at(src, 6, 8), pic.strides[0])
+        d["h%d_qpel_out" % bd] = pic
+        pic = B.pixels(rng, (32, 40), bd)
+        d["h%d_chroma_in" % bd] = pic.copy()
+        R.ffref_h264_chroma(0, 0, B.at(pic, 2, 4), B.at(src, 2, 4), pic.strides[0], 8, 3, 5)
+        d["h%d_chroma_out" % bd] = pic
+        pic = B.pixels(rng, (32, 40), bd, True)
+        d["h%d_bw_in" % bd] = pic.copy()
+        R.ffref_h264_biweight(0, B.at(pic, 1, 4), B.at(src, 1, 4), pic.strides[0], 16, 5, 37, -21, 9)
+        d["h%d_bw_out" % bd] = pic
+    R.ffref_h264_set_bit_depth(8)
+    np.savez_compressed(os.path.join(OUT, "round3.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
