@@ -211,6 +211,119 @@ __global__ __launch_bounds__(256) void k_h264_pred_blk(uint8_t *plane, ptrdiff_t
     hp_store4(src + (ptrdiff_t)y * stride + x0, v);
 }
 
+/*
+ * pred8x8[] at chroma_format_idc 2 (4:2:2): the 8 wide x 16 tall forms (h264pred_template.c:477-530 vertical / horizontal / 128,
+ * :567-571 left_dc = two 8x8 left_dc, :599-620 top_dc, :650-698 dc = eight 4x4 DCs, :700-745 the "mad cow" edge variants, :781-817
+ * plane with its own V weighting; installed by ff_h264_pred_init() h264pred.c:478-512).  32 items (16 rows x two groups of 4) per
+ * block, 8 blocks per workgroup.  Same modes as pred8x8: 0 DC 1 HOR 2 VERT 3 PLANE 4 LEFT_DC 5 TOP_DC 6 DC_128 7 L0T 8 0LT 9 L00
+ * 10 0L0.
+ */
+template <typename P>
+__global__ __launch_bounds__(256) void k_h264_pred_8x16(uint8_t *plane, ptrdiff_t stride_b, const FFHipH264Pred *blocks, int n, int bd)
+{
+    const ptrdiff_t stride = stride_b / (ptrdiff_t)sizeof(P);
+    const int mid = 1 << (bd - 1), maxv = (1 << bd) - 1;
+    __shared__ int L[8][16], T[8][9]; /* T[0] is the corner */
+    __shared__ int PP[8][8];
+    const int r = threadIdx.x >> 5, it = threadIdx.x & 31, b = blockIdx.x * 8 + r;
+    const bool valid = b < n;
+    FFHipH264Pred k = {};
+    if (valid)
+        k = blocks[b];
+    const int mode = k.mode;
+    const bool use_t = valid && (mode == 0 || mode == 2 || mode == 3 || mode == 5 || mode == 7 || mode == 8);
+    const bool use_l = valid && (mode == 0 || mode == 1 || mode == 3 || mode == 4 || mode >= 7);
+    const int lrows = mode == 7 ? 4 : 16; /* L0T: pred4x4_dc on the first 4x4 reads four rows of the left column */
+    P *src = reinterpret_cast<P *>(plane + k.offset);
+    if (it < 16)
+        L[r][it] = use_l && it < lrows ? src[(ptrdiff_t)it * stride - 1] : 0;
+    else if (it < 24)
+        T[r][it - 15] = use_t ? src[(it - 16) - stride] : 0;
+    else if (it == 24)
+        T[r][0] = valid && mode == 3 ? src[-stride - 1] : 0;
+    __syncthreads();
+    if (it == 0 && valid) {
+        const int *l = L[r], *t = T[r] + 1;
+        if (mode == 3) {
+            /* H over the top row as for 8x8, V over the 16 left rows: k (l[7 + k] - l[7 - k]), k = 1..8, l[-1] = the corner */
+            int H = 0, V = 0;
+#pragma unroll
+            for (int i = 1; i <= 4; i++)
+                H += i * (t[3 + i] - t[3 - i]);
+#pragma unroll
+            for (int i = 1; i <= 8; i++)
+                V += i * (l[7 + i] - (i == 8 ? t[-1] : l[7 - i]));
+            H = (17 * H + 16) >> 5;
+            V = (5 * V + 32) >> 6;
+            PP[r][0] = 16 * (l[15] + t[7] + 1) - 7 * V - 3 * H;
+            PP[r][1] = H;
+            PP[r][2] = V;
+        } else {
+            const int t0 = t[0] + t[1] + t[2] + t[3], t1 = t[4] + t[5] + t[6] + t[7];
+            int lq[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                lq[g] = l[4 * g] + l[4 * g + 1] + l[4 * g + 2] + l[4 * g + 3];
+            int q[8]; /* [2 * row group + column half] */
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                q[i] = mid;
+            auto left_dc = [&]() { /* pred8x16_left_dc: each 4-row group's own left sum, both halves */
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    q[2 * g] = q[2 * g + 1] = (lq[g] + 2) >> 2;
+            };
+            auto top_dc = [&]() {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    q[2 * g] = (t0 + 2) >> 2;
+                    q[2 * g + 1] = (t1 + 2) >> 2;
+                }
+            };
+            auto full_dc = [&]() { /* pred8x16_dc */
+                q[0] = (lq[0] + t0 + 4) >> 3;
+                q[1] = (t1 + 2) >> 2;
+#pragma unroll
+                for (int g = 1; g < 4; g++) {
+                    q[2 * g] = (lq[g] + 2) >> 2;
+                    q[2 * g + 1] = (t1 + lq[g] + 4) >> 3;
+                }
+            };
+            switch (mode) {
+            case 0: full_dc(); break;
+            case 4: left_dc(); break;
+            case 5: top_dc(); break;
+            case 7: top_dc(); q[0] = (t0 + lq[0] + 4) >> 3; break;   /* top_dc, then pred4x4_dc on the first 4x4 */
+            case 8: full_dc(); q[0] = (t0 + 2) >> 2; break;          /* dc, then pred4x4_top_dc on the first 4x4 */
+            case 9: left_dc(); q[2] = q[3] = mid; break;             /* left_dc, then 128 on rows 4..7 */
+            case 10: left_dc(); q[0] = q[1] = mid; break;            /* left_dc, then 128 on rows 0..3 */
+            default: break;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                PP[r][i] = q[i];
+        }
+    }
+    __syncthreads();
+    if (!valid)
+        return;
+    const int y = it >> 1, x0 = 4 * (it & 1);
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + j;
+        if (mode == 1)
+            v[j] = L[r][y];
+        else if (mode == 2)
+            v[j] = T[r][x + 1];
+        else if (mode == 3)
+            v[j] = min(max((PP[r][0] + y * PP[r][2] + x * PP[r][1]) >> 5, 0), maxv);
+        else
+            v[j] = PP[r][2 * (y >> 2) + (x >> 2)];
+    }
+    hp_store4(src + (ptrdiff_t)y * stride + x0, v);
+}
+
 /* pred4x4_add / pred8x8l_add / pred8x8l_filter_add: thread i owns column i (mode 0, VERT_PRED) or row i (mode 1, HOR_PRED) */
 template <int N, bool FILTER, typename P>
 __global__ __launch_bounds__(256) void k_h264_pred_add(uint8_t *plane, ptrdiff_t stride_b, int16_t *coeffs, const FFHipH264Pred *blocks, int n)
@@ -275,11 +388,15 @@ int ffhip_launch_h264_pred_bd(int bd, int kind, uint8_t *plane, ptrdiff_t stride
     case FFHIP_H264_PRED8x8L:  PRED_GO(k_h264_pred_dir, cdiv(n, 16), true); break;
     case FFHIP_H264_PRED8x8:   PRED_GO(k_h264_pred_blk, cdiv(n, 16), 8); break;
     case FFHIP_H264_PRED16x16: PRED_GO(k_h264_pred_blk, cdiv(n, 4), 16); break;
+    case FFHIP_H264_PRED8x16:
+        if (bd > 8) hipLaunchKernelGGL((k_h264_pred_8x16<uint16_t>), dim3(cdiv(n, 8)), block, 0, stream, plane, stride, blocks, n, bd);
+        else        hipLaunchKernelGGL((k_h264_pred_8x16<uint8_t>), dim3(cdiv(n, 8)), block, 0, stream, plane, stride, blocks, n, bd);
+        break;
     case FFHIP_H264_PRED4x4_ADD:         PRED_ADD(cdiv(n, 64), 4, false); break;
     case FFHIP_H264_PRED8x8L_ADD:        PRED_ADD(cdiv(n, 32), 8, false); break;
     case FFHIP_H264_PRED8x8L_FILTER_ADD: PRED_ADD(cdiv(n, 32), 8, true); break;
     default:
-        ffhip_set_error("ffhip_h264_pred: kind %d outside 0..6", kind);
+        ffhip_set_error("ffhip_h264_pred: kind %d outside 0..7", kind);
         return FFHIP_EINVAL;
     }
 #undef PRED_GO

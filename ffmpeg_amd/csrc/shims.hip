@@ -1133,8 +1133,10 @@ extern "C" int ff_vp9dsp_scaled_mc_init_hip(FFHipVP9ScaledMcContext *c, int bpp)
 #define HP_P 64 /* pitch of the staged patch; the block sits at row 1, column 16 */
 /* bd: the depth the face was installed for (samples of 2 bytes and int32 coefficients above 8) */
 static bool h264_pred_host(int bd, int kind, int mode, int n, unsigned need, int lrows, uint8_t *src, ptrdiff_t stride, const uint8_t *topright,
-                           int has_tl, int has_tr, int16_t *block)
+                           int has_tl, int has_tr, int16_t *block, int nh = 0)
 {
+    if (!nh)
+        nh = n; /* rows of the block (8 x 16: n = 8 columns, nh = 16) */
     const int px = bd > 8 ? 2 : 1;
     uint8_t st[17 * HP_P] = { 0 };
     uint8_t *o = st + HP_P + 16;
@@ -1171,13 +1173,15 @@ static bool h264_pred_host(int bd, int kind, int mode, int n, unsigned need, int
         return false;
     if (ffhip_launch_h264_pred_bd(bd, kind, dp, HP_P, dc, (const FFHipH264Pred *)buf, 1, 0) < 0 || !A.down())
         return false;
-    commit2d(A, src, stride, dp + HP_P + 16, HP_P, (size_t)n * px, n);
+    commit2d(A, src, stride, dp + HP_P + 16, HP_P, (size_t)n * px, nh);
     if (ncoef)
         memcpy(block, A.host(dc), ncoef * sizeof(int16_t)); /* cleared by the kernel */
     return true;
 }
-template <int BD> struct PredFb { static FFHipH264PredContext t; };
-template <int BD> FFHipH264PredContext PredFb<BD>::t;
+/* the C functions our faces displaced, per depth; F = 1: the 4:2:2 forms of pred8x8[] / pred8x8_add[] (a 4:2:0 and a 4:2:2 context of
+ * one depth hold different C functions there) */
+template <int BD, int F = 0> struct PredFb { static FFHipH264PredContext t; };
+template <int BD, int F> FFHipH264PredContext PredFb<BD, F>::t;
 #define g_fb_pred PredFb<BD>::t
 static constexpr unsigned hp_need4(int mode) { return (unsigned)(0x0211a777a312ull >> (4 * mode)) & 15u; } /* as kernels/h264_pred.hip */
 /* pred8x8 / pred16x16: 0 DC 1 HOR 2 VERT 3 PLANE 4 LEFT_DC 5 TOP_DC 6 DC_128 7 L0T 8 0LT 9 L00 10 0L0 */
@@ -1206,6 +1210,12 @@ static void s_pred8x8(uint8_t *src, ptrdiff_t stride)
 {
     if (!h264_pred_host(BD, FFHIP_H264_PRED8x8, MODE, 8, hp_need_blk(MODE), MODE == 7 ? 4 : 8, src, stride, nullptr, 0, 0, nullptr))
         SHIM_FB(g_fb_pred, pred8x8[MODE], src, stride);
+}
+template <int BD, int MODE> /* pred8x8[MODE] at chroma_format_idc >= 2 */
+static void s_pred8x16(uint8_t *src, ptrdiff_t stride)
+{
+    if (!h264_pred_host(BD, FFHIP_H264_PRED8x16, MODE, 8, hp_need_blk(MODE), MODE == 7 ? 4 : 16, src, stride, nullptr, 0, 0, nullptr, 16))
+        SHIM_FB((PredFb<BD, 1>::t), pred8x8[MODE], src, stride);
 }
 template <int BD, int MODE>
 static void s_pred16x16(uint8_t *src, ptrdiff_t stride)
@@ -1237,44 +1247,71 @@ static void s_pred_mb_add(uint8_t *pix, const int *block_offset, int16_t *block,
         s_pred_add<BD, FFHIP_H264_PRED4x4_ADD, 4, MODE8x8 == 2 ? 0 : 1>(pix + block_offset[i], block + i * 16 * (BD > 8 ? 2 : 1), stride);
 }
 
+/* pred8x16_vertical_add / _horizontal_add (h264pred_template.c:1302-1330): blocks 0..3 at block_offset[0..3], 4..7 at [8..11] */
+template <int BD, int MODE8x8>
+static void s_pred_8x16_add(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
+{
+    for (int i = 0; i < 8; i++)
+        s_pred_add<BD, FFHIP_H264_PRED4x4_ADD, 4, MODE8x8 == 2 ? 0 : 1>(pix + block_offset[i < 4 ? i : i + 4], block + i * 16 * (BD > 8 ? 2 : 1), stride);
+}
+
 #undef g_fb_pred
 template <int BD>
-static int h264_pred_fill(FFHipH264PredContext *h)
+static int h264_pred_fill(FFHipH264PredContext *h, int chroma_format_idc)
 {
     FFHipH264PredContext o = *h;
 #define HP(M) o.pred4x4[M] = s_pred4x4<BD, M>; o.pred8x8l[M] = s_pred8x8l<BD, M>;
     HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10) HP(11)
 #undef HP
+    if (chroma_format_idc <= 1) {
 #define HP(M) o.pred8x8[M] = s_pred8x8<BD, M>;
-    HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10)
+        HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10)
 #undef HP
+    } else {
+#define HP(M) o.pred8x8[M] = s_pred8x16<BD, M>;
+        HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10)
+#undef HP
+    }
 #define HP(M) o.pred16x16[M] = s_pred16x16<BD, M>;
     HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6)
 #undef HP
     o.pred4x4_add[0] = s_pred_add<BD, FFHIP_H264_PRED4x4_ADD, 4, 0>;   o.pred4x4_add[1] = s_pred_add<BD, FFHIP_H264_PRED4x4_ADD, 4, 1>;
     o.pred8x8l_add[0] = s_pred_add<BD, FFHIP_H264_PRED8x8L_ADD, 8, 0>; o.pred8x8l_add[1] = s_pred_add<BD, FFHIP_H264_PRED8x8L_ADD, 8, 1>;
     o.pred8x8l_filter_add[0] = s_pred8x8l_filter_add<BD, 0>;           o.pred8x8l_filter_add[1] = s_pred8x8l_filter_add<BD, 1>;
-    o.pred8x8_add[2] = s_pred_mb_add<BD, 4, 2>;    o.pred8x8_add[1] = s_pred_mb_add<BD, 4, 1>;
+    if (chroma_format_idc <= 1) {
+        o.pred8x8_add[2] = s_pred_mb_add<BD, 4, 2>;    o.pred8x8_add[1] = s_pred_mb_add<BD, 4, 1>;
+    } else {
+        o.pred8x8_add[2] = s_pred_8x16_add<BD, 2>;     o.pred8x8_add[1] = s_pred_8x16_add<BD, 1>;
+    }
     o.pred16x16_add[2] = s_pred_mb_add<BD, 16, 2>; o.pred16x16_add[1] = s_pred_mb_add<BD, 16, 1>;
-    fb_snapshot(PredFb<BD>::t, *h, o);
+    if (chroma_format_idc <= 1) {
+        fb_snapshot(PredFb<BD>::t, *h, o);
+    } else {
+        /* the 8 x 16 members' C functions go to the 4:2:2 table, everything else to the shared one */
+        FFHipH264PredContext rest = *h;
+        memcpy(rest.pred8x8, o.pred8x8, sizeof(rest.pred8x8));
+        memcpy(rest.pred8x8_add, o.pred8x8_add, sizeof(rest.pred8x8_add));
+        fb_snapshot(PredFb<BD>::t, rest, o);
+        fb_snapshot(PredFb<BD, 1>::t, *h, o);
+    }
     *h = o;
     return 0;
 }
 
 extern "C" int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc)
 {
-    /* AV_CODEC_ID_H264 at the depths it defines, 4:2:0 (4:2:2 switches pred8x8 to the 8 x 16 forms, h264pred.c:560-585: those keep C) */
-    if (!h || codec_id != FFHIP_CODEC_ID_H264 || chroma_format_idc > 1)
+    /* AV_CODEC_ID_H264 at the depths it defines; chroma_format_idc >= 2 switches pred8x8 to the 8 x 16 forms (h264pred.c:478-535) */
+    if (!h || codec_id != FFHIP_CODEC_ID_H264 || chroma_format_idc < 0 || chroma_format_idc > 3)
         return FFHIP_EINVAL;
     if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     switch (bit_depth) {
-    case 8:  return h264_pred_fill<8>(h);
-    case 9:  return h264_pred_fill<9>(h);
-    case 10: return h264_pred_fill<10>(h);
-    case 12: return h264_pred_fill<12>(h);
-    default: return h264_pred_fill<14>(h);
+    case 8:  return h264_pred_fill<8>(h, chroma_format_idc);
+    case 9:  return h264_pred_fill<9>(h, chroma_format_idc);
+    case 10: return h264_pred_fill<10>(h, chroma_format_idc);
+    case 12: return h264_pred_fill<12>(h, chroma_format_idc);
+    default: return h264_pred_fill<14>(h, chroma_format_idc);
     }
 }

@@ -147,7 +147,7 @@ class Picture:
 
 
 # ---- H264PredContext (include/ffhip.h; libavcodec/h264pred.h:92-116) ----
-PRED4x4, PRED8x8L, PRED8x8, PRED16x16, PRED4x4_ADD, PRED8x8L_ADD, PRED8x8L_FILTER_ADD = range(7)
+PRED4x4, PRED8x8L, PRED8x8, PRED16x16, PRED4x4_ADD, PRED8x8L_ADD, PRED8x8L_FILTER_ADD, PRED8x16 = range(8)
 PRED_TOPLEFT, PRED_TOPRIGHT, PRED_TR_SPLAT = 1, 2, 4
 CODEC_ID_H264 = 27
 #: FFHipH264Pred

@@ -821,8 +821,9 @@ typedef struct FFHipH264PredContext {
 #define FFHIP_CODEC_ID_H264 27 /* AV_CODEC_ID_H264 (libavcodec/codec_id.h:77) */
 /** ff_h264_pred_init_<arch>(H264PredContext *, codec_id, bit_depth, chroma_format_idc) shape (libavcodec/h264pred.h:120-127).
  *  bit_depth 8 / 9 / 10 / 12 / 14 (16-bit samples and int32 coefficients of the _add members above 8; the depth is baked into the
- *  installed functions).  FFHIP_EINVAL for what this library does not replace (other codecs' variants, 4:2:2's 8 x 16 chroma
- *  forms): those keep the C pointers. */
+ *  installed functions).  chroma_format_idc 0..3: from 2 on pred8x8[] / pred8x8_add[] are the 8 wide x 16 tall forms, as
+ *  ff_h264_pred_init() installs them (h264pred.c:478-535).  FFHIP_EINVAL for what this library does not replace (other codecs'
+ *  variants): those keep the C pointers. */
 int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc);
 
 #define FFHIP_H264_PRED4x4             0  /* pred4x4[mode]                                 */
@@ -832,6 +833,7 @@ int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, 
 #define FFHIP_H264_PRED4x4_ADD         4  /* pred4x4_add[mode]: mode 0 VERT_PRED, 1 HOR_PRED */
 #define FFHIP_H264_PRED8x8L_ADD        5  /* pred8x8l_add[mode]                            */
 #define FFHIP_H264_PRED8x8L_FILTER_ADD 6  /* pred8x8l_filter_add[mode]                     */
+#define FFHIP_H264_PRED8x16            7  /* pred8x8[mode] at chroma_format_idc 2 (4:2:2): the 8 wide x 16 tall forms */
 #define FFHIP_H264_PRED_TOPLEFT   1  /* flags: pred8x8l's has_topleft                                                       */
 #define FFHIP_H264_PRED_TOPRIGHT  2  /* flags: pred8x8l's has_topright                                                      */
 #define FFHIP_H264_PRED_TR_SPLAT  4  /* flags: pred4x4's topright is src[3 - stride] four times (the decoder's substitute when the

@@ -232,10 +232,12 @@ void ffo_h264_pred4x4(int mode, uint8_t *src, const uint8_t *topright, ptrdiff_t
 void ffo_h264_pred8x8l(int mode, uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride);
 void ffo_h264_pred8x8(int mode, uint8_t *src, ptrdiff_t stride);
 void ffo_h264_pred16x16(int mode, uint8_t *src, ptrdiff_t stride);
+void ffo_h264_pred8x16(int mode, uint8_t *src, ptrdiff_t stride);   /* pred8x8[] at chroma_format_idc 2 */
 void ffo_h264_pred4x4_add(int mode, uint8_t *pix, int16_t *block, ptrdiff_t stride);
 void ffo_h264_pred8x8l_add(int mode, uint8_t *pix, int16_t *block, ptrdiff_t stride);
 void ffo_h264_pred8x8l_filter_add(int mode, uint8_t *pix, int16_t *block, int has_topleft, int has_topright, ptrdiff_t stride);
 void ffo_h264_pred8x8_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
+void ffo_h264_pred8x16_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
 void ffo_h264_pred16x16_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
 
 /* one TNS filter of a channel-frame: `size` coefficients from `start` (index into the frame's 1024) stepping by `inc` */

@@ -208,6 +208,76 @@ void ffo_h264_pred8x8(int mode, uint8_t *src, ptrdiff_t stride)
             src[y * stride + x] = mode == 1 ? left[y] : mode == 2 ? top[x] : (uint8_t)q[2 * (y >> 2) + (x >> 2)];
 }
 
+/* H264PredContext.pred8x8[mode] at chroma_format_idc 2 (h264pred.c:478-512): the 8 wide x 16 tall forms of 4:2:2 chroma
+ * (h264pred_template.c:477-817).  One DC per 4x4 cell, o[2 * cell_row + cell_col]; the sums are the same four-sample groups:
+ * t0 / t1 over the top row's halves, l[r] over rows 4r..4r+3 of the left column. */
+void ffo_h264_pred8x16(int mode, uint8_t *src, ptrdiff_t stride)
+{
+    if (mode == 3) {                                                 /* pred8x16_plane (:781-817) */
+        int H = 0, V = 0;
+        for (int k = 1; k <= 4; k++)
+            H += k * (src[3 + k - stride] - src[3 - k - stride]);
+        for (int k = 1; k <= 8; k++)
+            V += k * (src[(7 + k) * stride - 1] - src[(7 - k) * stride - 1]);
+        H = (17 * H + 16) >> 5;
+        V = (5 * V + 32) >> 6;
+        const int a = 16 * (src[15 * stride - 1] + src[7 - stride] + 1) - 7 * V - 3 * H;
+        for (int y = 0; y < 16; y++)
+            for (int x = 0; x < 8; x++)
+                src[y * stride + x] = (uint8_t)clip8((a + y * V + x * H) >> 5);
+        return;
+    }
+    int o[8], t0 = 0, t1 = 0, l[4] = { 0, 0, 0, 0 };
+    for (int i = 0; i < 8; i++)
+        o[i] = 128;
+    const int use_t = mode == 0 || mode == 2 || mode == 5 || mode == 7 || mode == 8;
+    const int use_l = mode == 0 || mode == 1 || mode == 4 || mode >= 7;
+    if (use_t)
+        for (int i = 0; i < 4; i++) {
+            t0 += src[i - stride];
+            t1 += src[4 + i - stride];
+        }
+    if (use_l)
+        for (int r = 0; r < 4; r++)
+            for (int i = 0; i < 4; i++)
+                if (mode != 7 || r == 0)
+                    l[r] += src[(4 * r + i) * stride - 1];
+    switch (mode) {
+    case 0: case 8:                                                  /* pred8x16_dc (:650-695); 8 = _0lt: cell 0 from the top alone */
+        o[0] = mode == 0 ? (t0 + l[0] + 4) >> 3 : (t0 + 2) >> 2;
+        o[1] = (t1 + 2) >> 2;
+        for (int r = 1; r < 4; r++) {
+            o[2 * r] = (l[r] + 2) >> 2;
+            o[2 * r + 1] = (t1 + l[r] + 4) >> 3;
+        }
+        break;
+    case 4: case 9: case 10:                                         /* left_dc (:567-571); 9 = _l00: cells of rows 4..7 are 128;
+                                                                        10 = _0l0: cells of rows 0..3 are 128 (:725-749) */
+        for (int r = 0; r < 4; r++)
+            if (!(mode == 9 && r == 1) && !(mode == 10 && r == 0))
+                o[2 * r] = o[2 * r + 1] = (l[r] + 2) >> 2;
+        break;
+    case 5: case 7:                                                  /* top_dc (:599-603); 7 = _l0t: cell 0 is pred4x4_dc */
+        for (int r = 0; r < 4; r++) {
+            o[2 * r] = (t0 + 2) >> 2;
+            o[2 * r + 1] = (t1 + 2) >> 2;
+        }
+        if (mode == 7)
+            o[0] = (t0 + l[0] + 4) >> 3;
+        break;
+    default: break;                                                  /* 6: 128 everywhere */
+    }
+    uint8_t top[8], left[16];
+    if (mode == 2)
+        memcpy(top, src - stride, 8);
+    if (mode == 1)
+        for (int y = 0; y < 16; y++)
+            left[y] = src[y * stride - 1];
+    for (int y = 0; y < 16; y++)
+        for (int x = 0; x < 8; x++)
+            src[y * stride + x] = mode == 1 ? left[y] : mode == 2 ? top[x] : (uint8_t)o[2 * (y >> 2) + (x >> 2)];
+}
+
 /* H264PredContext.pred16x16[mode] (h264pred.h:98; h264pred_template.c:332-461) */
 void ffo_h264_pred16x16(int mode, uint8_t *src, ptrdiff_t stride)
 {
@@ -270,6 +340,12 @@ void ffo_h264_pred8x8_add(int mode, uint8_t *pix, const int *block_offset, int16
 {
     for (int i = 0; i < 4; i++)
         plain_add(mode == 2 ? 0 : 1, pix + block_offset[i], block + i * 16, stride, 4);
+}
+/* pred8x8_add[] at chroma_format_idc 2 (h264pred_template.c:1302-1330): blocks 0..3 at block_offset[0..3], 4..7 at [8..11] */
+void ffo_h264_pred8x16_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
+{
+    for (int i = 0; i < 8; i++)
+        plain_add(mode == 2 ? 0 : 1, pix + block_offset[i < 4 ? i : i + 4], block + i * 16, stride, 4);
 }
 void ffo_h264_pred16x16_add(int mode, uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride)
 {

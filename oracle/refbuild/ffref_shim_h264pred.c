@@ -33,6 +33,13 @@ void ffref_h264_pred_set_bit_depth(int bit_depth)
     ff_h264_pred_init(&pred_ctx, AV_CODEC_ID_H264, bit_depth, 1);
     pred_ready = 1;
 }
+/* the same with chroma_format_idc given: from 2 on pred8x8[] / pred8x8_add[] are the 8 x 16 forms (h264pred.c:478-535) */
+void ffref_h264_pred_set_format(int bit_depth, int chroma_format_idc)
+{
+    pure_c();
+    ff_h264_pred_init(&pred_ctx, AV_CODEC_ID_H264, bit_depth, chroma_format_idc);
+    pred_ready = 1;
+}
 void ffref_h264_pred4x4(int mode, uint8_t *src, const uint8_t *topright, ptrdiff_t stride) { h264pred()->pred4x4[mode](src, topright, stride); }
 void ffref_h264_pred8x8l(int mode, uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride)
 {

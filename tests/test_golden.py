@@ -257,6 +257,27 @@ def test_h264_pred_golden():
     h264_pred_golden_check(apply, load("h264pred"))
 
 
+def h264_pred422_golden_check(apply, d):
+    """kind 7 (pred8x8[] at 4:2:2, 8 bits): the blocks against the reference's stored outputs; nothing else may change"""
+    recs = d["k7_rec"]
+    pic = apply(7, d["pic"].copy(), recs, None)
+    mask = np.ones(pic.shape, bool)
+    for i, (x, y, *_) in enumerate(recs.tolist()):
+        assert np.array_equal(pic[y:y + 16, x:x + 8], d["k7_out"][i]), (i, recs[i])
+        mask[y:y + 16, x:x + 8] = False
+    assert np.array_equal(pic[mask], d["pic"][mask])
+
+
+def test_h264_pred422_golden():
+    from test_oracle_vs_ref import h264_pred_apply
+    O = ffi.oracle()
+
+    def apply(kind, pic, recs, coeffs):
+        h264_pred_apply(O, "ffo", kind, pic, recs, coeffs)
+        return pic
+    h264_pred422_golden_check(apply, load("h264pred422"))
+
+
 def aac_golden_windows(d):
     return [np.ascontiguousarray(d[k]) for k in ("sine_1024", "sine_128", "kbd_long_1024", "kbd_short_128")]
 

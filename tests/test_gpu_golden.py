@@ -335,3 +335,18 @@ def test_h264_pred_golden_gpu():
     """H264PredContext batch kinds against the reference's stored outputs (tests/golden/h264pred.npz)"""
     from test_gpu_h264_pred import hip_pred_apply
     G.h264_pred_golden_check(hip_pred_apply, G.load("h264pred"))
+
+
+def test_h264_pred422_golden_gpu():
+    """pred8x8[] at chroma_format_idc 2 against the reference's stored outputs (tests/golden/h264pred422.npz): the batch face at 8
+    bits, the host faces of ff_h264_pred_init_hip(h, H264, 10, 2) at 10"""
+    import ctypes as C
+    from ffmpeg_amd import h264
+    from test_gpu_h264_pred import hip_pred_apply
+    d = G.load("h264pred422")
+    G.h264_pred422_golden_check(hip_pred_apply, d)
+    hc = h264.pred_init(bit_depth=10, chroma_format_idc=2)
+    p = np.ascontiguousarray(d["p10_in"])
+    for mode in range(11):
+        hc.pred8x8[mode](C.c_void_p(p[mode].ctypes.data + (8 * 48 + 16) * 2), 96)
+    assert np.array_equal(p, d["p10_out"])

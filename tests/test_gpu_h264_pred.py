@@ -7,7 +7,7 @@ import pytest
 
 import ffi
 from ffi import ptr, u8p, i16p, i32p
-from test_oracle_vs_ref import H264_PRED_KINDS, h264_pred_grid, h264_pred_apply, h264_pred_plane
+from test_oracle_vs_ref import H264_PRED_KINDS, h264_pred_kind, h264_pred_grid, h264_pred_apply, h264_pred_plane
 
 pytestmark = pytest.mark.gpu
 
@@ -37,12 +37,12 @@ def hip_pred_apply(kind, pic, recs, coeffs):
     return d_pic.cpu().numpy()
 
 
-@pytest.mark.parametrize("kind", range(7))
+@pytest.mark.parametrize("kind", range(8))
 def test_h264_pred_batch(kind):
     """a picture's worth of independent blocks: every mode and flag combination, random / saturated / smooth content, picture
     widths on and off the dword grid"""
     O = ffi.oracle()
-    n = H264_PRED_KINDS[kind][0]
+    n = h264_pred_kind(kind)[0]
     for width, height, content in ((1283, 360, 0), (1280, 352, 1), (642, 200, 2)):
         rng = np.random.default_rng(2650 + 10 * kind + content)
         if content == 0:
@@ -53,7 +53,7 @@ def test_h264_pred_batch(kind):
             pic = np.clip(np.add.outer(np.arange(height) * 2, np.arange(width) * -1) + 200 + rng.integers(-5, 6, (height, width)), 0, 255).astype(np.uint8)
         recs = h264_pred_grid(rng, kind, height, width)
         coeffs = wc = None
-        if kind >= 4:
+        if 4 <= kind < 7:
             coeffs = rng.integers(-300, 301, (len(recs) + 1) * n * n).astype(np.int16)
             coeffs[:n * n] = rng.choice(np.array([-32768, 32767], np.int16), n * n)
             wc = coeffs.copy()
@@ -62,7 +62,7 @@ def test_h264_pred_batch(kind):
         got = hip_pred_apply(kind, pic.copy(), recs, coeffs)
         assert (want != pic).sum() > 500
         assert np.array_equal(got, want), "%d mismatches, first %s" % ((got != want).sum(), np.argwhere(got != want)[:3])
-        if kind >= 4:
+        if 4 <= kind < 7:
             assert np.array_equal(coeffs, wc) and coeffs[-n * n:].any()      # consumed blocks cleared, the spare one untouched
 
 
@@ -144,8 +144,83 @@ def test_h264_pred_init_rejects():
     _torch()
     hctx = h264.H264PredContext()
     L = _lib.lib()
-    for args in ((h264.CODEC_ID_H264, 11, 1), (h264.CODEC_ID_H264, 8, 2), (h264.CODEC_ID_H264, 10, 2), (139, 8, 1)):
+    for args in ((h264.CODEC_ID_H264, 11, 1), (h264.CODEC_ID_H264, 8, 4), (h264.CODEC_ID_H264, 10, -1), (139, 8, 1)):
         assert L.ff_h264_pred_init_hip(C.byref(hctx), *args) < 0
+
+
+@pytest.mark.skipif(not ffi.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("depth", [8, 9, 10, 12, 14])
+def test_h264_pred_422_matches_the_reference(depth):
+    """chroma_format_idc 2 (4:2:2): pred8x8[] are the 8 wide x 16 tall forms (h264pred.c:478-512, h264pred_template.c:477-817) and
+    pred8x8_add[] walk eight 4x4 blocks (:1302-1330) — the host faces ff_h264_pred_init_hip(..., 2) installs and the batch face
+    (kind FFHIP_H264_PRED8x16) == the reference's own context initialised the same way, every mode, every depth"""
+    from ffmpeg_amd import h264, _lib
+    torch = _torch()
+    R = ffi.ref()
+    R.ffref_h264_pred_set_format.argtypes = [C.c_int, C.c_int]
+    R.ffref_h264_pred_set_format(depth, 2)
+    try:
+        hc = h264.pred_init(bit_depth=depth, chroma_format_idc=2)
+        rng = np.random.default_rng(170 + depth)
+        W, px = 48, 2 if depth > 8 else 1
+        dt = np.uint16 if depth > 8 else np.uint8
+        stride = W * px
+
+        def patch(extreme):
+            a = rng.integers(0, 1 << depth, (40, W)).astype(dt)
+            if extreme:
+                a[::3] = rng.choice(np.array([0, (1 << depth) - 1], dt), a[::3].shape)
+            return a
+
+        def at(a, r, c):
+            return C.c_void_p(a.ctypes.data + (r * W + c) * px)
+        for rep in range(4):
+            for mode in range(11):
+                p0 = patch(rep == 1)
+                a, b = p0.copy(), p0.copy()
+                R.ffref_h264_pred8x8(mode, C.cast(at(a, 8, 16), ffi.u8p), stride)
+                hc.pred8x8[mode](at(b, 8, 16), stride)
+                assert np.array_equal(a, b), ("pred8x16", mode, rep)
+                assert (a[8:24, 16:24] != p0[8:24, 16:24]).any() or mode == 6 or rep == 1, "an 8 x 16 block is written"
+            bo = np.zeros(16, np.int32)     # block_offset[]: 4x4 blocks of the 8 x 16 chroma block, scan order; 4..7 unused
+            for i in range(4):
+                bo[i] = ((i >> 1) * 4 * W + (i & 1) * 4) * px
+                bo[8 + i] = ((2 + (i >> 1)) * 4 * W + (i & 1) * 4) * px
+            for mode in (1, 2):             # HOR_PRED8x8 / VERT_PRED8x8: the lossless members
+                p0 = patch(rep == 1)
+                co = rng.integers(-(1 << depth), 1 << depth, 8 * 16).astype(np.int32 if depth > 8 else np.int16)
+                a, b, ca, cb = p0.copy(), p0.copy(), co.copy(), co.copy()
+                R.ffref_h264_pred8x8_add(mode, C.cast(at(a, 8, 16), ffi.u8p), bo.ctypes.data_as(C.POINTER(C.c_int)), C.cast(ca.ctypes.data, ffi.i16p), stride)
+                hc.pred8x8_add[mode](at(b, 8, 16), C.c_void_p(bo.ctypes.data), C.c_void_p(cb.ctypes.data), stride)
+                assert np.array_equal(a, b) and np.array_equal(ca, cb), ("pred8x16_add", mode)
+        if depth != 8:
+            return
+        # the batch face (8-bit): many blocks of mixed modes in one launch
+        nb = 300
+        plane = patch(False)
+        plane = np.tile(plane, (12, 10))[: 24 * 17, : 24 * 18].copy()
+        PW = plane.shape[1]
+        want = plane.copy()
+        recs = np.zeros(nb, dtype=np.dtype([("offset", "<i4"), ("aux", "<i4"), ("mode", "u1"), ("flags", "u1"), ("pad", "u1", (2,))]))
+        k = 0
+        for by in range(17):
+            for bx in range(18):
+                if k >= nb:
+                    break
+                mode = int(rng.integers(0, 11))
+                r0, c0 = by * 24 + 4, bx * 24 + 8
+                recs[k] = ((r0 * PW + c0) * px, 0, mode, 0, (0, 0))
+                R.ffref_h264_pred8x8(mode, C.cast(C.c_void_p(want.ctypes.data + (r0 * PW + c0) * px), ffi.u8p), PW * px)
+                k += 1
+        d_plane = torch.from_numpy(plane.view(np.uint8).reshape(plane.shape[0], -1)).cuda()
+        d_recs = torch.from_numpy(recs.view(np.uint8).reshape(nb, 12)).cuda()
+        L = _lib.lib()
+        assert L.ffhip_h264_pred_batch_dev(7, d_plane.data_ptr(), PW * px, None, d_recs.data_ptr(), nb, None) == 0
+        torch.cuda.synchronize()
+        got = d_plane.cpu().numpy().view(dt).reshape(plane.shape)
+        assert np.array_equal(got, want), "%d samples differ" % (got != want).sum()
+    finally:
+        R.ffref_h264_pred_set_format(8, 1)
 
 
 @pytest.mark.skipif(not ffi.have_ref(), reason="oracle/_ref not built")

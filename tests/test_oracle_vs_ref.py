@@ -896,9 +896,54 @@ def test_h264_pred_add():
                 assert np.array_equal(a, b) and np.array_equal(ca, cb), (name, mode, rep)
 
 
+def test_h264_pred_422():
+    """chroma_format_idc 2: pred8x8[] / pred8x8_add[] are the 8 wide x 16 tall forms (h264pred.c:478-512, :534-535;
+    h264pred_template.c:477-817, :1302-1330) - the restatement's ffo_h264_pred8x16 / _add == the reference's context
+    initialised for 4:2:2, every mode"""
+    R, O = ffi.ref(), ffi.oracle()
+    R.ffref_h264_pred_set_format.argtypes = [C.c_int, C.c_int]
+    O.ffo_h264_pred8x16.argtypes = [C.c_int, u8p, C.c_ssize_t]
+    O.ffo_h264_pred8x16_add.argtypes = [C.c_int, u8p, i32p, i16p, C.c_ssize_t]
+    rng = np.random.default_rng(2642)
+    at = lambda x: C.cast(x.ctypes.data + 16 * 48 + 16, u8p)
+    R.ffref_h264_pred_set_format(8, 2)
+    try:
+        for mode in range(11):
+            for rep in range(16):
+                a = h264_pred_plane(rng, rep); b = a.copy(); p0 = a.copy()
+                R.ffref_h264_pred8x8(mode, at(a), 48)
+                O.ffo_h264_pred8x16(mode, at(b), 48)
+                assert np.array_equal(a, b), (mode, rep)
+                keep = np.ones((48, 48), bool); keep[16:32, 16:24] = False
+                assert np.array_equal(a[keep], p0[keep]), "nothing but the 8 x 16 block is written"
+        offs = np.zeros(16, np.int32)
+        for i in range(4):
+            offs[i] = 4 * (i & 1) + 4 * (i >> 1) * 48
+            offs[8 + i] = 4 * (i & 1) + 4 * (2 + (i >> 1)) * 48
+        for rep in range(24):
+            lim = 300 if rep % 3 else 32767
+            for mode in (2, 1):
+                a = h264_pred_plane(rng, rep); b = a.copy()
+                ca = rng.integers(-lim, lim + 1, 8 * 16).astype(np.int16); cb = ca.copy()
+                R.ffref_h264_pred8x8_add(mode, at(a), ptr(offs, i32p), ptr(ca, i16p), 48)
+                O.ffo_h264_pred8x16_add(mode, at(b), ptr(offs, i32p), ptr(cb, i16p), 48)
+                assert np.array_equal(a, b) and np.array_equal(ca, cb), (mode, rep)
+    finally:
+        R.ffref_h264_pred_set_format(8, 1)
+
+
 #: the batch kinds of include/ffhip.h FFHIP_H264_PRED*: (block size, number of modes, member name)
 H264_PRED_KINDS = ((4, 12, "pred4x4"), (8, 12, "pred8x8l"), (8, 11, "pred8x8"), (16, 7, "pred16x16"),
                    (4, 2, "pred4x4_add"), (8, 2, "pred8x8l_add"), (8, 2, "pred8x8l_filter_add"))
+#: FFHIP_H264_PRED8x16 (kind 7): pred8x8[] at chroma_format_idc 2 - 8 wide, 16 tall; kept out of the tuple above, which the
+#: committed h264pred.npz enumerates
+H264_PRED_KIND_422 = (8, 11, "pred8x16")
+
+
+def h264_pred_kind(kind):
+    """(width, height, number of modes, member name) of a batch kind"""
+    n, nmodes, name = H264_PRED_KINDS[kind] if kind < 7 else H264_PRED_KIND_422
+    return n, 16 if kind == 7 else n, nmodes, name
 
 
 def h264_pred_grid(rng, kind, height, width, count=None):
@@ -906,10 +951,10 @@ def h264_pred_grid(rng, kind, height, width, count=None):
     neighbours are another block's output: rows of (x, y, mode, flags, aux).  flags / aux as FFHipH264Pred: pred8x8l's
     has_topleft (1) / has_topright (2); pred4x4's topright either at aux (bytes into the plane, stride = width) or replicated
     (flag 4); the _add kinds' aux = coefficient index."""
-    n, nmodes, _ = H264_PRED_KINDS[kind]
+    n, nh, nmodes, _ = h264_pred_kind(kind)
     recs = []
     i = 0
-    for y in range(n, height - n + 1, 2 * n):
+    for y in range(n, height - nh + 1, nh + n):
         for x in range(n, width - 2 * n + 1, 3 * n):
             mode = i % nmodes
             flags, aux = 0, 0
@@ -934,8 +979,10 @@ def h264_pred_grid(rng, kind, height, width, count=None):
 
 def h264_pred_apply(L, pref, kind, pic, recs, coeffs=None):
     """run the reference or the oracle over the records, in place on pic (and coeffs)"""
-    n, _, name = H264_PRED_KINDS[kind]
+    n, _, _, name = h264_pred_kind(kind)
     width = pic.shape[1]
+    if kind == 7 and pref == "ffref":       # the reference's pred8x8[] after ffref_h264_pred_set_format(8, 2)
+        name = "pred8x8"
     fn = getattr(L, "%s_h264_%s" % (pref, name))
     for x, y, mode, flags, aux in recs.tolist():
         at = C.cast(pic.ctypes.data + y * width + x, u8p)
@@ -944,7 +991,7 @@ def h264_pred_apply(L, pref, kind, pic, recs, coeffs=None):
             fn(mode, at, ptr(tr), width)
         elif kind == 1:
             fn(mode, at, flags & 1, (flags >> 1) & 1, width)
-        elif kind in (2, 3):
+        elif kind in (2, 3, 7):
             fn(mode, at, width)
         else:
             blk = C.cast(coeffs.ctypes.data + 2 * aux, i16p)

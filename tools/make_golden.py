@@ -709,12 +709,44 @@ def round3():
     np.savez_compressed(os.path.join(OUT, "round3.npz"), **d)
 
 
+def h264pred422():
+    """pred8x8[] at chroma_format_idc 2 (the 8 wide x 16 tall forms): at 8 bits a grid of independent blocks of one 136x200
+    picture, every mode three times or more (batch kind 7); at 10 bits one 40x48 patch per mode with the block at (8, 16)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_vs_ref import h264_pred_grid, h264_pred_apply
+    R.ffref_h264_pred_set_format.argtypes = [C.c_int, C.c_int]
+    rng = np.random.default_rng(31)
+    pic = rng.integers(0, 256, (136, 200), dtype=np.uint8)
+    pic[:, 100:] = np.clip(np.add.outer(np.arange(136) * 3, np.arange(100) * -2) + 120 + rng.integers(-4, 5, (136, 100)), 0, 255)
+    pic[64:, :60] = rng.choice(np.array([0, 255], np.uint8), (72, 60))
+    d = {"pic": pic}
+    R.ffref_h264_pred_set_format(8, 2)
+    recs = h264_pred_grid(rng, 7, 136, 200)
+    out = pic.copy()
+    h264_pred_apply(R, "ffref", 7, out, recs)
+    d["k7_rec"] = recs
+    d["k7_out"] = np.stack([out[y:y + 16, x:x + 8] for x, y, *_ in recs.tolist()])
+    mask = np.ones(pic.shape, bool)
+    for x, y, *_ in recs.tolist():
+        mask[y:y + 16, x:x + 8] = False
+    assert np.array_equal(out[mask], pic[mask]) and len(recs) >= 33
+    R.ffref_h264_pred_set_format(10, 2)
+    p10 = rng.integers(0, 1024, (11, 40, 48)).astype(np.uint16)
+    p10[3] = np.clip(np.add.outer(np.arange(40) * 30, np.arange(48) * -17) + 500 + rng.integers(-9, 10, (40, 48)), 0, 1023)   # the plane mode on a slope
+    d["p10_in"] = p10.copy()
+    for mode in range(11):
+        R.ffref_h264_pred8x8(mode, C.cast(p10[mode].ctypes.data + (8 * 48 + 16) * 2, u8p), 96)
+    d["p10_out"] = p10
+    R.ffref_h264_pred_set_format(8, 1)
+    np.savez_compressed(os.path.join(OUT, "h264pred422.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
