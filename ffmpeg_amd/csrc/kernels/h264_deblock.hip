@@ -706,22 +706,114 @@ __global__ __launch_bounds__(64 * DB_W) void k_h264_deblock_band(uint8_t *plane,
  * Needs 16-byte (chroma: 8-byte) aligned planes / strides / pitches and 16-byte aligned edge records; anything else takes the
  * band kernel (4-byte aligned) or the row kernel.
  */
-/* One sample line across one edge for the skewed-rows kernel, every lane of the wave on its own macroblock: NO per-lane control
- * flow (the four row groups filter different macroblocks: a divergent branch per edge cost more exec-mask bookkeeping than the
- * filter).  The normal filter is always computed and selected by `en`; the intra filter runs behind ONE wave-uniform branch, taken
- * only when some lane's edge is a bS = 4 edge. */
+/* ---- the skewed-rows kernel's edge filter ----------------------------------------------------------
+ * A wave that is alone on its SIMD issues ONE instruction every four cycles, scalar or vector, and a step of the wavefront is eight
+ * DEPENDENT edges: the filter is written for the fewest instructions, not for the fewest operations.
+ *   - every comparison of h264dsp_template.c:104-330 is a sign: |a - b| < t  <=>  v_sad_u32(a, b, -t) < 0, and a conjunction is the
+ *     sign of a maximum (v_max3_i32) — no compare / s_and chains, no exec-mask control flow;
+ *   - alpha == 0 or beta == 0 (a bS = 0 edge) disables itself: |a - b| - 0 is never negative;
+ *   - clips are v_med3_i32 (lanes whose range is empty, tc0 < 0, are deselected anyway);
+ *   - the bS = 4 filter runs behind one wave-uniform branch and overrides the lanes it owns from the ORIGINAL samples.
+ * v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 of one line; rec = {bS, alpha, beta, -} bytes, tcw = the edge's four tc0 bytes. */
+__device__ __forceinline__ int db_sad3(int a, int b, int c)
+{
+    int d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int db_med3(int a, int lo, int hi)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(lo), "v"(hi));
+    return d;
+}
+__device__ __forceinline__ int db_clip255(int a)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(d) : "v"(a), "s"(255));
+    return d;
+}
+__device__ __forceinline__ int db_max3(int a, int b, int c)
+{
+    int d;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 template <bool CHROMA>
 __device__ __forceinline__ void db_edge(int (&v)[8], uint32_t rec, uint32_t tcw, int tcsh, bool skip)
 {
-    const int alpha = (rec >> 8) & 255, beta = (rec >> 16) & 255;
-    const bool en = alpha != 0 && beta != 0 && !skip;
-    const bool intra = (rec & 255) >= 4;
-    if (__builtin_amdgcn_ballot_w64(en && !intra)) /* bS = 0 edges (alpha 0) are common inside macroblocks: skipped wave-uniformly */
-        db_normal<CHROMA>(v, alpha, beta, (int)(int8_t)(tcw >> tcsh), (int)(en && !intra)); /* its own select: disabled lanes keep v */
-    if (__builtin_amdgcn_ballot_w64(en && intra))
-        db_intra<CHROMA>(v, alpha, beta, (int)(en && intra));
+    const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
+    const int alpha = (rec >> 8) & 255, negb = -(int)((rec >> 16) & 255);
+    const int nega = skip ? 0 : -alpha;                       /* a picture edge: never filtered */
+    const int tc0 = __builtin_amdgcn_sbfe(tcw, tcsh, 8);
+    const bool is4 = (rec & 255) >= 4;
+    /* m < 0: |p0 - q0| < alpha && |p1 - p0| < beta && |q1 - q0| < beta */
+    const int m = db_max3(db_sad3(p0, q0, nega), db_sad3(p1, p0, negb), db_sad3(q1, q0, negb));
+    const int mn = max(m, CHROMA ? -tc0 : ~tc0);              /* ... && tc0 > 0 (chroma) / tc0 >= 0 (luma): the bS < 4 filter's lanes */
+    {   /* the bS < 4 filter, every lane (four macroblocks of different rows share an instruction: they are rarely all bS = 0, and a
+         * wave-uniform skip costs register copies on both paths) */
+        const int x4 = ((q0 - p0) << 2) + (p1 - q1) + 4;
+        if (CHROMA) {
+            const int delta = (mn >> 31) & db_med3(x4 >> 3, -tc0, tc0);
+            v[3] = db_clip255(p0 + delta);
+            v[4] = db_clip255(q0 - delta);
+        } else {
+            const int dap = db_sad3(p2, p0, negb), daq = db_sad3(q2, q0, negb);     /* < 0: |p2 - p0| < beta */
+            const int avg = (p0 + q0 + 1) >> 1, ntc0 = -tc0;
+            const int dp = db_med3(((p2 + avg) >> 1) - p1, ntc0, tc0), dq = db_med3(((q2 + avg) >> 1) - q1, ntc0, tc0);
+            const int tc = tc0 + (int)((uint32_t)dap >> 31) + (int)((uint32_t)daq >> 31);
+            const int delta = (mn >> 31) & db_med3(x4 >> 3, -tc, tc);
+            v[2] = p1 + (dp & (max(mn, dap) >> 31));
+            v[5] = q1 + (dq & (max(mn, daq) >> 31));
+            v[3] = db_clip255(p0 + delta);
+            v[4] = db_clip255(q0 - delta);
+        }
+    }
+    const int mi = is4 ? m : 0;                               /* < 0: a bS = 4 line that passes the alpha / beta test */
+    if (__builtin_amdgcn_ballot_w64(mi < 0)) {
+        const int wp0 = (2 * p1 + p0 + q1 + 2) >> 2, wq0 = (2 * q1 + q0 + p1 + 2) >> 2;   /* the weak forms */
+        if (CHROMA) {
+            v[3] = mi < 0 ? wp0 : v[3];
+            v[4] = mi < 0 ? wq0 : v[4];
+        } else {
+            const int ds = db_sad3(p0, q0, -((alpha >> 2) + 2));                        /* < 0: the strong filter */
+            const int msp = db_max3(mi, ds, db_sad3(p2, p0, negb)), msq = db_max3(mi, ds, db_sad3(q2, q0, negb));
+            const int s4 = p0 + q0, ep = p1 + s4, eq = q1 + s4;
+            int sp0 = (2 * ep + p2 + q1 + 4) >> 3, sp1 = (p2 + ep + 2) >> 2, sp2 = (2 * (p3 + p2) + p2 + ep + 4) >> 3;
+            int sq0 = (2 * eq + q2 + p1 + 4) >> 3, sq1 = (q2 + eq + 2) >> 2, sq2 = (2 * (q3 + q2) + q2 + eq + 4) >> 3;
+            int w0 = mi < 0 ? wp0 : v[3], w1 = mi < 0 ? wq0 : v[4], w2 = mi < 0 ? p1 : v[2], w3 = mi < 0 ? q1 : v[5];
+            /* every candidate first, opaque: with the arithmetic visible behind the selects the compiler sinks it into divergent
+             * branches (exec-mask bookkeeping around three-instruction blocks) instead of emitting v_cndmask */
+            asm("" : "+v"(sp0), "+v"(sp1), "+v"(sp2), "+v"(sq0), "+v"(sq1), "+v"(sq2), "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+            v[3] = msp < 0 ? sp0 : w0;
+            v[2] = msp < 0 ? sp1 : w2;
+            v[1] = msp < 0 ? sp2 : p2;
+            v[4] = msq < 0 ? sq0 : w1;
+            v[5] = msq < 0 ? sq1 : w3;
+            v[6] = msq < 0 ? sq2 : q2;
+        }
+    }
 }
 
+#ifndef DB_SKEW
+#define DB_SKEW 1
+#endif
+/* spin on an LDS counter of another wave of the workgroup; false (and the launch's fail flag) after 2^22 polls — never in a correct run */
+__device__ __forceinline__ bool db_wait_lds(const int *ctr, int want, int *fail)
+{
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) {
+            if ((threadIdx.x & 63) == 0)
+                __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
 template <bool CHROMA>
 __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
                                                          const FFHipH264Edge *edges, int *gprog, int nbands, int bwaves, int nframes,
@@ -732,22 +824,30 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
     constexpr int NE = 2 * NDW;                  /* edge records per macroblock */
     constexpr int Q = 64 / MB;                   /* macroblock rows per wave */
     constexpr int SL = 8;                        /* ring slots (macroblocks) per row */
+    constexpr int SK = DB_SKEW;                  /* macroblocks a row group trails the one above */
     constexpr int PITCH = SL * MB + 16;          /* 144 / 80 bytes: 36 / 20 dwords, 16 (8) rows spread over all banks */
-    constexpr int ROWS = Q * MB + 4;             /* the band's rows + 4 context rows of the band above */
-    /* a workgroup is 1 .. 4 independent waves (the hardware spreads the waves of a workgroup over the SIMDs of its CU); each has
-     * its own strip and edge table in the dynamic LDS */
-    constexpr int TILE_BYTES = (ROWS * PITCH + (Q + 1) * 16 + 15) & ~15, ETAB_BYTES = Q * (3 * NE + 4) * 4;
+    /* A workgroup is W = 1 .. 4 waves on the SIMDs of one CU working on W CONSECUTIVE bands ("super-band") in ONE LDS strip: wave w's
+     * top context is the bottom of wave w - 1's last row group, in place, exactly as between the row groups of a wave — the
+     * hand-off between the waves of a workgroup is an LDS counter (a few hundred ns), only the workgroup's first / last wave talk
+     * through memory (a write-through store, its acknowledgement, a counter, a poll and a load: several microseconds and six
+     * steps of lag per hand-off, which is what a lone picture's time was made of). */
+    constexpr int ETAB_BYTES = Q * (3 * NE + 4) * 4;
     extern __shared__ __align__(16) uint8_t db_lds[];
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    uint8_t *const tile = db_lds + wv * (TILE_BYTES + ETAB_BYTES);
-    uint32_t (*const etab)[3 * NE + 4] = reinterpret_cast<uint32_t (*)[3 * NE + 4]>(tile + TILE_BYTES);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), W = (int)(blockDim.x >> 6);
+    const int strip_bytes = ((4 + W * Q * MB) * PITCH + (W * Q + 1) * 16 + 15) & ~15;
+    uint8_t *const tile = db_lds + wv * Q * (MB * PITCH + 16);   /* this wave's rows: local row r, group q -> r * PITCH + (q + 1) * 16 */
+    uint32_t (*const etab)[3 * NE + 4] = reinterpret_cast<uint32_t (*)[3 * NE + 4]>(db_lds + strip_bytes + wv * ETAB_BYTES);
+    /* vdone[w] / hdone[w]: steps of wave w whose vertical pass / whole step are complete, counted over all of its super-bands */
+    int *const vdone = reinterpret_cast<int *>(db_lds + strip_bytes + W * ETAB_BYTES), *const hdone = vdone + W;
+    if (threadIdx.x < 2 * (unsigned)W)
+        vdone[threadIdx.x] = 0;
+    __syncthreads();
 
-    /* block -> (picture, first band): the bands of a picture on one XCD.  A picture gets `bwaves` waves; wave j takes bands j,
-     * j + bwaves, ...: a band is busy for mb_w + 2 Q - 1 steps of a picture that takes mb_w + (2 Q + 2) nbands, so with one wave per
-     * band the SIMDs of a full batch idle more than half of the time — fewer, longer-lived waves per picture leave the rest of
-     * the chip to the other pictures.  (Band b's predecessor belongs to a wave dispatched no later: no wave waits on the unborn.) */
-    const int L = blockIdx.x, xcd = L & 7, idx = (L >> 3) * wpb + wv; /* bwaves is a multiple of the waves per workgroup */
-    const int f = xcd + 8 * (idx / bwaves), band0 = idx % bwaves;
+    /* block -> (picture, first super-band): the bands of a picture on one XCD.  A picture gets bwaves / W workgroups; workgroup j
+     * takes super-bands j, j + bwaves / W, ...  (Super-band b's predecessor belongs to a workgroup dispatched no later, or to an
+     * earlier pass of the same one: no wave waits on the unborn.) */
+    const int L = blockIdx.x, xcd = L & 7, nwg = bwaves / W; /* bwaves is a multiple of the waves per workgroup */
+    const int f = xcd + 8 * ((L >> 3) / nwg), sb0 = (L >> 3) % nwg;
     if (f >= nframes)
         return;
     plane += (size_t)f * frame_pitch;
@@ -755,7 +855,12 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
     gprog += (size_t)f * nbands;
 
     const int lane = threadIdx.x & 63, q = lane / MB, l = lane % MB;
-    for (int band = band0; band < nbands; band += bwaves) {
+    const int nsteps = mb_w + 2 + SK * (Q - 1); /* a row runs two steps past its last macroblock: the columns of x - 2 leave at step x */
+    int base = 0;                                /* this wave's step count before the current super-band */
+    for (int sb = sb0; sb * W < nbands; sb += nwg, base += nsteps) {
+    const int band = sb * W + wv;
+    if (band < nbands) {
+    const bool from_mem = wv == 0 && band > 0, from_lds = wv > 0;
     const int y = band * Q + q;
     const bool row_ok = y < mb_h;
     const int qb = min(Q - 1, mb_h - 1 - band * Q);      /* the band's last row inside the picture (wave-uniform) */
@@ -766,7 +871,8 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
     uint8_t *const strow = tile + (MB * q + l) * PITCH + (q + (l >= 4 ? 1 : 0)) * 16; /* store pass: the row four above it */
     const uint8_t *const grow = plane + ((ptrdiff_t)y * MB + l) * stride;          /* picture row of ownrow */
     uint8_t *const gst = plane + ((ptrdiff_t)y * MB + l - 4) * stride;             /* picture row of strow */
-    const bool st_ok = row_ok && (y > 0 || l >= 4);
+    const bool to_mem = next_band && wv == W - 1, to_lds = next_band && wv < W - 1;
+    const bool st_ok = row_ok && (y > 0 || l >= 4), bot_ok = row_ok && q == qb && !to_lds; /* the wave below stores them with its rows */
     /* bottom rows of the band's last row: 4 rows x NDW dwords = MB lanes (row group qb) */
     const int br = MB - 4 + l / NDW, bd = l % NDW;
     uint8_t *const botl = tile + (MB * qb + br + 4) * PITCH + (qb + 1) * 16 + 4 * bd;
@@ -793,68 +899,69 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
     auto load_top = [&](int x0) {
         return __hip_atomic_load(reinterpret_cast<const uint32_t *>(ctxg + x0 * MB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    fetch(0 - 2 * q);
-    const int nsteps = mb_w + 1 + 2 * (Q - 1);
+    fetch(0 - SK * q);
     for (int s = 0; s < nsteps; s++) {
-        const int x = s - 2 * q;
+        const int x = s - SK * q;
         const bool act = row_ok && x >= 0 && x < mb_w;
         /* ---- everything issued a step ago is complete: the loads of this step's macroblocks and the stores of the previous
          *      step's results.  The band's bottom rows of macroblocks < xb - 2 are therefore in memory: publish ---- */
         __builtin_amdgcn_s_waitcnt(0);
-        const int xb = s - 2 * qb; /* the stores issued a step ago (at xb - 1) held the columns of macroblock xb - 3, or the row's end */
-        if (next_band && xb >= 3 && xb <= mb_w + 1 && !(fault & 1)) {
+        const int xb = s - SK * qb; /* the stores issued a step ago (at xb - 1) held the columns of macroblock xb - 3 */
+        if (to_mem && xb >= 3 && xb <= mb_w + 2 && !(fault & 1)) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0)
-                __hip_atomic_store(&gprog[band], xb > mb_w ? mb_w : xb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&gprog[band], xb - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (act) {
-            *reinterpret_cast<rowv *>(ownrow + (x & (SL - 1)) * MB) = own;
-            if (l < 3 * NE / 4)
-                *reinterpret_cast<db_u4 *>(&etab[q][4 * l]) = eown;
+        /* ---- the edge records of this step's macroblocks: staged by the lanes that loaded them, read back (broadcast) by every
+         *      lane of the row group; LDS operations of one wave execute in order, nothing to wait for in between ---- */
+        if (act && l < 3 * NE / 4)
+            *reinterpret_cast<db_u4 *>(&etab[q][4 * l]) = eown;
+        const rowv cur = own;                        /* this step's macroblock row: straight from the registers it was loaded into */
+        wave_lds_sync();
+        uint32_t erec[NE], etcw[NE];
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            erec[k] = etab[q][3 * k + 1];
+            etcw[k] = etab[q][3 * k + 2];
         }
+        uint8_t *const pl = ownrow + ((x - 1) & (SL - 1)) * MB + MB - 4, *const pm = ownrow + (x & (SL - 1)) * MB;
+        const uint32_t lw = *reinterpret_cast<const uint32_t *>(pl);   /* the left macroblock's last four samples of this row */
         fetch(x + 1);
         /* ---- picture stores of the previous step's results: macroblock x - 1 was filtered a step ago, which made the columns of
          *      macroblock x - 2 final (rows shifted up by four); behind the row's last macroblock its own columns are final too ---- */
-        if (!(fault & 2) && x >= 1 && x <= mb_w) {
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int m = t ? x - 1 : x - 2;
-                if (m < 0 || (t && x != mb_w))
-                    continue;
+        {
+            const int m = x - 2;
+            if (!(fault & 2) && m >= 0 && m < mb_w) {
                 if (st_ok)
                     *reinterpret_cast<rowv *>(gst + m * MB) = *reinterpret_cast<const rowv *>(strow + (m & (SL - 1)) * MB);
-                if (row_ok && q == qb) { /* ... and the bottom four rows of the band's last row */
-                    const uint32_t v = *reinterpret_cast<const uint32_t *>(botl + (m & (SL - 1)) * MB);
-                    uint32_t *g = reinterpret_cast<uint32_t *>(botg + m * MB);
-                    if (next_band)
-                        __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* write-through: read by the next band */
-                    else
-                        *g = v;
-                }
+                if (bot_ok) /* ... and the bottom four rows of the band's last row: write-through, the next band reads them */
+                    __hip_atomic_store(reinterpret_cast<uint32_t *>(botg + m * MB), *reinterpret_cast<const uint32_t *>(botl + (m & (SL - 1)) * MB),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         wave_lds_sync();
-        /* ---- vertical edges, left to right: lane = row; samples -4 .. MB-1 of the row ---- */
-        if (act && !(fault & 4)) {
-            uint8_t *pl = ownrow + ((x - 1) & (SL - 1)) * MB + MB - 4, *pm = ownrow + (x & (SL - 1)) * MB;
+        /* ---- the ring is SL macroblocks long: the last row group is about to overwrite the column of macroblock x - SL, whose bottom
+         *      rows the wave below reads until its step x - SL + 2 (two steps behind its top edge: the store pass) ---- */
+        if (to_lds && !(fault & 8) && !db_wait_lds(&hdone[wv + 1], base + s - SK * qb - SL + 3, fail))
+            return;
+        /* ---- vertical edges, left to right: lane = row; samples -4 .. MB-1 of the row, in registers throughout ---- */
+        if (act) {
             int v0[MB + 4];
-            {
-                const uint32_t lw = *reinterpret_cast<const uint32_t *>(pl);
-                const rowv mw = *reinterpret_cast<const rowv *>(pm);
-                v0[0] = lw & 255; v0[1] = (lw >> 8) & 255; v0[2] = (lw >> 16) & 255; v0[3] = lw >> 24;
+            v0[0] = lw & 255; v0[1] = (lw >> 8) & 255; v0[2] = (lw >> 16) & 255; v0[3] = lw >> 24;
 #pragma unroll
-                for (int d = 0; d < NDW; d++) {
-                    const uint32_t w = mw[d];
-                    v0[4 + 4 * d] = w & 255; v0[5 + 4 * d] = (w >> 8) & 255; v0[6 + 4 * d] = (w >> 16) & 255; v0[7 + 4 * d] = w >> 24;
-                }
+            for (int d = 0; d < NDW; d++) {
+                const uint32_t w = cur[d];
+                v0[4 + 4 * d] = w & 255; v0[5 + 4 * d] = (w >> 8) & 255; v0[6 + 4 * d] = (w >> 16) & 255; v0[7 + 4 * d] = w >> 24;
             }
+            if (!(fault & 4)) {
 #pragma unroll
-            for (int k = 0; k < NDW; k++) {
-                int v[8] = { v0[4 * k], v0[4 * k + 1], v0[4 * k + 2], v0[4 * k + 3], v0[4 * k + 4], v0[4 * k + 5], v0[4 * k + 6], v0[4 * k + 7] };
-                db_edge<CHROMA>(v, etab[q][3 * k + 1], etab[q][3 * k + 2], tcsh, k == 0 && x == 0);
+                for (int k = 0; k < NDW; k++) {
+                    int v[8] = { v0[4 * k], v0[4 * k + 1], v0[4 * k + 2], v0[4 * k + 3], v0[4 * k + 4], v0[4 * k + 5], v0[4 * k + 6], v0[4 * k + 7] };
+                    db_edge<CHROMA>(v, erec[k], etcw[k], tcsh, k == 0 && x == 0);
 #pragma unroll
-                for (int i = 1; i < 7; i++)
-                    v0[4 * k + i] = v[i];
+                    for (int i = 1; i < 7; i++)
+                        v0[4 * k + i] = v[i];
+                }
             }
             *reinterpret_cast<uint32_t *>(pl) = (uint32_t)v0[0] | ((uint32_t)v0[1] << 8) | ((uint32_t)v0[2] << 16) | ((uint32_t)v0[3] << 24);
             rowv mw;
@@ -863,9 +970,18 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
                 mw[d] = (uint32_t)v0[4 + 4 * d] | ((uint32_t)v0[5 + 4 * d] << 8) | ((uint32_t)v0[6 + 4 * d] << 16) | ((uint32_t)v0[7 + 4 * d] << 24);
             *reinterpret_cast<rowv *>(pm) = mw;
         }
-        /* ---- the band's top context: the band above must have its bottom rows of macroblock s in memory (count >= s + 1).  Only
+        if (to_lds) { /* this step's vertical pass is in LDS (one wave's LDS operations execute in order: the counter follows the rows) */
+            wave_lds_sync();
+            if (lane == 0 && !(fault & 1)) /* fault & 1: the test hook — no hand-off is published, the waiting wave must time out and report */
+                __hip_atomic_store(&vdone[wv], base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        /* ---- the band's top context.  From the wave above, in place: its last row group must have filtered the left edge of
+         *      macroblock s + 1 (its step s + 1 + SK (Q - 1)) ---- */
+        if (from_lds && s < mb_w && !(fault & 8) && !db_wait_lds(&vdone[wv - 1], base + s + 2 + SK * (Q - 1), fail))
+            return;
+        /* ---- from the workgroup above, through memory: it must have its bottom rows of macroblock s in memory (count >= s + 1).  Only
          *      the horizontal edges of row group 0 read (and rewrite) them, so the wait sits behind the vertical pass ---- */
-        if (band > 0 && s < mb_w) {
+        if (from_mem && s < mb_w) {
             if (!have_top) {
                 const int want = (fault & 8) ? 0 : s + 1;
                 int spins = 0;
@@ -890,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
         wave_lds_sync();
         /* the next macroblock's context, if the band above has already published it: its latency hides behind the H pass */
         have_top = false;
-        if (band > 0 && s + 1 < mb_w && known >= s + 2) {
+        if (from_mem && s + 1 < mb_w && known >= s + 2) {
             if (lane < MB)
                 topv = load_top(s + 1);
             have_top = true;
@@ -905,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
 #pragma unroll
             for (int k = 0; k < NDW; k++) {
                 int v[8] = { yv[4 * k], yv[4 * k + 1], yv[4 * k + 2], yv[4 * k + 3], yv[4 * k + 4], yv[4 * k + 5], yv[4 * k + 6], yv[4 * k + 7] };
-                db_edge<CHROMA>(v, etab[q][3 * (NDW + k) + 1], etab[q][3 * (NDW + k) + 2], tcsh, k == 0 && y == 0);
+                db_edge<CHROMA>(v, erec[NDW + k], etcw[NDW + k], tcsh, k == 0 && y == 0);
 #pragma unroll
                 for (int i = 1; i < 7; i++)
                     yv[4 * k + i] = v[i];
@@ -917,16 +1033,20 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
                     tcol[r * PITCH + (r >= 4 ? 16 : 0)] = (uint8_t)yv[r];
         }
         wave_lds_sync();
+        if (from_lds && lane == 0)
+            __hip_atomic_store(&hdone[wv], base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     /* the last step's stores (the flush of the band's last row) are out: publish the whole row */
-    if (next_band && !(fault & 1)) {
+    if (to_mem && !(fault & 1)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0)
             __hip_atomic_store(&gprog[band], mb_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     wave_lds_sync();
-    } /* bands of this wave */
+    } /* band < nbands */
+    __syncthreads(); /* the strip is reused: every wave is through with this super-band */
+    } /* super-bands of this workgroup */
 }
 
 /* the progress counters come from the per-device pool (progress_pool.hip): a slot per launch, zeroed in stream order */
@@ -975,15 +1095,16 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
             /* waves per picture: one per band while the chip has SIMDs to spare (a lone picture is latency-bound), else what an
              * XCD's 128 SIMDs leave each of its pictures, but never fewer than a quarter of the bands (the wavefront's width) */
             const char *eb = FFHIP_KNOB("FFHIP_DEBLOCK_WAVES"), *ewp = FFHIP_KNOB("FFHIP_DEBLOCK_WPB");
-            const int wpb = ewp && atoi(ewp) >= 1 && atoi(ewp) <= 4 ? atoi(ewp) : 1; /* measured: 1, 2 and 4 waves per workgroup are within 5 % (profiles/r03_deblock_wpb_experiment.txt) */
+            const int wpb = ewp && atoi(ewp) >= 1 && atoi(ewp) <= 4 ? atoi(ewp) : 4; /* cooperating waves per workgroup (bands per super-band) */
             const int per_xcd = cdiv(nf, 8);
             int bwaves = eb && atoi(eb) > 0 ? atoi(eb) : 128 / per_xcd;
             if (bwaves < cdiv(nbands, 4)) bwaves = cdiv(nbands, 4);
             if (bwaves > nbands) bwaves = nbands;
-            bwaves = cdiv(bwaves, wpb) * wpb; /* whole workgroups (waves beyond the last band retire at once) */
+            bwaves = cdiv(bwaves, wpb) * wpb; /* whole workgroups (waves beyond the last band idle) */
             const dim3 g(8 * (bwaves / wpb) * per_xcd), t(64 * wpb);
             const int mbs = chroma ? 8 : 16, qq = 64 / mbs, nee = chroma ? 4 : 8;
-            const unsigned lds = (unsigned)wpb * (((unsigned)((qq * mbs + 4) * (8 * mbs + 16) + (qq + 1) * 16 + 15) & ~15u) + (unsigned)qq * (3 * nee + 4) * 4);
+            const unsigned lds = (((unsigned)((4 + wpb * qq * mbs) * (8 * mbs + 16) + (wpb * qq + 1) * 16 + 15)) & ~15u) +
+                                 (unsigned)wpb * (unsigned)qq * (3 * nee + 4) * 4 + 2u * wpb * 4;
             if (chroma)
                 hipLaunchKernelGGL(k_h264_deblock_skew<true>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault);
             else

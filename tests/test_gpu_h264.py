@@ -299,6 +299,18 @@ def test_deblock_frame_row_kernel_agrees(old, monkeypatch):
     test_deblock_frame(40, 37, 0)
 
 
+@pytest.mark.parametrize("wpb,waves", [("1", "0"), ("2", "0"), ("4", "4"), ("4", "8"), ("3", "3"), ("1", "2")])
+def test_deblock_frame_workgroup_shapes(wpb, waves, monkeypatch, measure_build):
+    """the skewed-rows kernel with 1 .. 4 cooperating waves per workgroup (hand-offs through LDS inside a workgroup, through memory
+    between workgroups) and with fewer workgroups than super-bands (a workgroup walks several, its strip reused) == serial order;
+    luma and chroma"""
+    monkeypatch.setenv("FFHIP_DEBLOCK_WPB", wpb)
+    monkeypatch.setenv("FFHIP_DEBLOCK_WAVES", waves)
+    test_deblock_frame(45, 30, 0)
+    test_deblock_frame(9, 70, 16)
+    test_deblock_frame_chroma(30, 35, 3, 0)
+
+
 def test_deblock_lost_handoff_is_reported(monkeypatch, measure_build):
     """a wavefront that never receives a hand-off must time out and be REPORTED at the next synchronisation point, not leave a
     partly filtered picture behind silently (FFHIP_DEBLOCK_FAULT=1: rows do not publish their progress)"""
@@ -306,7 +318,7 @@ def test_deblock_lost_handoff_is_reported(monkeypatch, measure_build):
     torch = _torch()
     L = _lib.lib()
     assert L.ffhip_stream_synchronize(None) == 0
-    mb_w, mb_h = 4, 9          # three bands of the skewed-rows kernel: two hand-offs through memory
+    mb_w, mb_h = 4, 36         # nine bands of the skewed-rows kernel = three workgroups: hand-offs through LDS inside, through memory between
     plane = torch.zeros((mb_h * 16, mb_w * 16), dtype=torch.uint8, device="cuda:0")
     ed = torch.zeros((mb_w * mb_h * 8, 12), dtype=torch.uint8, device="cuda:0")
     monkeypatch.setenv("FFHIP_DEBLOCK_FAULT", "1")
