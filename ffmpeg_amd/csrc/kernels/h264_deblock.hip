@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <atomic>
 #include "h264_kernels.h"
 
 struct LfLine { int p3, p2, p1, p0, q0, q1, q2, q3; };
@@ -817,7 +818,7 @@ __device__ __forceinline__ bool db_wait_lds(const int *ctr, int want, int *fail)
 template <bool CHROMA>
 __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
                                                          const FFHipH264Edge *edges, int *gprog, int nbands, int bwaves, int nframes,
-                                                         int *fail, int fault)
+                                                         int *fail, int fault, int xrot)
 {
     constexpr int MB = CHROMA ? 8 : 16;          /* samples per macroblock side = lanes per row group */
     constexpr int NDW = MB / 4;                  /* dwords per macroblock row = edges per direction */
@@ -846,7 +847,9 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
     /* block -> (picture, first super-band): the bands of a picture on one XCD.  A picture gets bwaves / W workgroups; workgroup j
      * takes super-bands j, j + bwaves / W, ...  (Super-band b's predecessor belongs to a workgroup dispatched no later, or to an
      * earlier pass of the same one: no wave waits on the unborn.) */
-    const int L = blockIdx.x, xcd = L & 7, nwg = bwaves / W; /* bwaves is a multiple of the waves per workgroup */
+    /* xrot: the launcher's running count — a lone picture per launch (the picture pipeline: one launch per plane, many pictures in
+     * flight on their own streams) would otherwise always land on XCD 0 */
+    const int L = blockIdx.x, xcd = (L - xrot) & 7, nwg = bwaves / W; /* bwaves is a multiple of the waves per workgroup */
     const int f = xcd + 8 * ((L >> 3) / nwg), sb0 = (L >> 3) % nwg;
     if (f >= nframes)
         return;
@@ -1105,10 +1108,12 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
             const int mbs = chroma ? 8 : 16, qq = 64 / mbs, nee = chroma ? 4 : 8;
             const unsigned lds = (((unsigned)((4 + wpb * qq * mbs) * (8 * mbs + 16) + (wpb * qq + 1) * 16 + 15)) & ~15u) +
                                  (unsigned)wpb * (unsigned)qq * (3 * nee + 4) * 4 + 2u * wpb * 4;
+            static std::atomic<unsigned> launches{0};
+            const int xrot = nf < 8 ? (int)(launches.fetch_add((unsigned)nf, std::memory_order_relaxed) & 7) : 0; /* where the batch's first picture goes */
             if (chroma)
-                hipLaunchKernelGGL(k_h264_deblock_skew<true>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault);
+                hipLaunchKernelGGL(k_h264_deblock_skew<true>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault, xrot);
             else
-                hipLaunchKernelGGL(k_h264_deblock_skew<false>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault);
+                hipLaunchKernelGGL(k_h264_deblock_skew<false>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault, xrot);
         } else if (!band)
             hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h, nf), dim3(64), 0, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, fail);
 #define DB_LAUNCH(CH, W) hipLaunchKernelGGL((k_h264_deblock_band<CH, W>), dim3(nbands, nf), dim3(64 * W), 0, stream, pl, frame_pitch, stride, \

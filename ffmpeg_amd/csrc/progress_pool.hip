@@ -66,10 +66,11 @@ static int pool_init(Pool &p)
 /* hipErrorNotReady must not linger as the thread's "last error": the launch paths read hipGetLastError() right after */
 static bool event_done(hipEvent_t ev)
 {
-    if (hipEventQuery(ev) == hipSuccess)
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess)
         return true;
     (void)hipGetLastError();
-    return false;
+    return e != hipErrorNotReady; /* an event the runtime no longer answers for (its stream was destroyed): that launch is over */
 }
 
 /* under p.mu: an in-flight slot whose launch has finished becomes free; its FAIL word moves to the failed-stream list */
@@ -113,9 +114,12 @@ int ffhip_progress_acquire(int nints, hipStream_t stream, FFHipProgressSlot *s)
                 w = (int)((p.next + k) % SLOTS);
         hipEvent_t ev = w >= 0 ? p.slot[w].done : nullptr;
         lk.unlock();
-        if (ev)
-            HIP_TRY(hipEventSynchronize(ev));
-        else
+        if (ev) {
+            if (hipEventSynchronize(ev) != hipSuccess) { /* seen for events of destroyed streams: fall back to polling (event_done) */
+                (void)hipGetLastError();
+                std::this_thread::yield();
+            }
+        } else
             std::this_thread::yield(); /* all 64 slots owned by threads between acquire and release: they are about to record */
         lk.lock();
     }

@@ -41,7 +41,7 @@ for old, bw, flt in () if os.environ.get("DB_SKIP_PARTS") == "1" else (("0", "0"
 # waves per picture (FFHIP_DEBLOCK_WAVES; 0 = the launcher's choice)
 os.environ["FFHIP_DEBLOCK_FAULT"] = "0"
 os.environ["FFHIP_DEBLOCK_OLD"] = "0"
-for waves, pad in (("0", "1"), ("34", "1"), ("34", "2"), ("34", "4"), ("17", "1"), ("68", "1")):
+for waves, pad in (("0", "4"), ("0", "1"), ("0", "2"), ("0", "3"), ("20", "4"), ("36", "4")):
     os.environ["FFHIP_DEBLOCK_WAVES"] = waves
     os.environ["FFHIP_DEBLOCK_WPB"] = pad
     for nf in (1, 32, 64, 128):
