@@ -73,3 +73,34 @@ def test_vp9_loopfilter_frame_rejects():
         vp9.loopfilter_frame(y, y, y, 64, 32, 8, 8, t, bit_depth=9)
     with pytest.raises(Exception):
         vp9.loopfilter_frame(y[1:], y, y, 64, 32, 8, 8, t)          # misaligned plane
+
+
+@pytest.mark.parametrize("knobs", [{"FFHIP_VP9_LF_WPB": "1"}, {"FFHIP_VP9_LF_WPB": "2"}, {"FFHIP_VP9_LF_WPB": "3"}, {"FFHIP_VP9_LF_OLD": "1"}],
+                         ids=["1-row-workgroups", "2-row-workgroups", "3-row-workgroups", "row-kernel"])
+def test_vp9_loopfilter_frame_workgroup_shapes(knobs, monkeypatch, measure_build):
+    """1 .. 3 superblock rows per workgroup (hand-offs through LDS inside a workgroup, through memory between workgroups) and the
+    one-wave-per-row kernel of round 2 == the serial order, 8 and 10 bits"""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    test_vp9_loopfilter_frame(9, 5, "structured", 8)
+    test_vp9_loopfilter_frame(2, 40, "bits2", 8)
+    test_vp9_loopfilter_frame(7, 6, "bits1", 10)
+
+
+def test_vp9_loopfilter_frame_lost_handoff_is_reported(monkeypatch, measure_build):
+    """a wave that never receives a hand-off (FFHIP_VP9_LF_FAULT=1: nothing is published, neither the LDS counters of a workgroup nor
+    the counters in memory) times out and the launch is REPORTED at the next synchronisation point"""
+    import torch
+    from ffmpeg_amd import vp9, _lib
+    L = _lib.lib()
+    assert L.ffhip_stream_synchronize(None) == 0
+    sbc, sbr = 2, 9
+    y = torch.zeros(64 * sbr * 64 * sbc, dtype=torch.uint8, device="cuda")
+    u = torch.zeros(32 * sbr * 32 * sbc, dtype=torch.uint8, device="cuda")
+    t = torch.zeros(sbr * sbc * 320, dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("FFHIP_VP9_LF_FAULT", "1")
+    vp9.loopfilter_frame(y, u, u.clone(), 64 * sbc, 32 * sbc, 8 * sbc, 8 * sbr, t)
+    monkeypatch.delenv("FFHIP_VP9_LF_FAULT")
+    assert L.ffhip_stream_synchronize(None) == -5                       # FFHIP_EIO
+    assert L.ffhip_stream_synchronize(None) == 0                       # reported once
+    test_vp9_loopfilter_frame(9, 5, "structured", 8)                      # and the pool keeps working

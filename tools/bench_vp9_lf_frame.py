@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
+from ffmpeg_amd import _lib  # noqa: E402
+if os.environ.get("FFHIP_MEASURE_LIB") == "1":
+    _lib.select("measure")  # the FFHIP_VP9_LF_* knobs exist only there
 from ffmpeg_amd import vp9  # noqa: E402
 import vp9_lf_gen as G  # noqa: E402
 
