@@ -379,6 +379,22 @@ extern "C" int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t
     return ffhip_launch_vp9_lf_frame(bit_depth, y, u, v, stride_y, stride_uv, cols, rows, tables, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_vp9_loopfilter_frame_ss_dev(int bit_depth, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y,
+                                                 ptrdiff_t stride_uv, int cols, int rows, const FFHipVp9LfSb *tables, void *stream)
+{
+    if (ss_h == 1 && ss_v == 1)
+        return ffhip_vp9_loopfilter_frame_dev(bit_depth, y, u, v, stride_y, stride_uv, cols, rows, tables, stream);
+    if (!hevc_bd_ok(bit_depth) || !y || !u || !v || !tables || cols < 0 || rows < 0 || rows > 8 * 1364)
+        return FFHIP_EINVAL;
+    if (ss_h || ss_v) { /* 4:4:0 / 4:2:2 (VP9 profiles 1 / 3, rare): not built */
+        ffhip_set_error("ffhip_vp9_loopfilter_frame_ss_dev: chroma sub-sampling %d x %d (4:2:0 and 4:4:4 are built)", ss_h, ss_v);
+        return FFHIP_ENOSYS;
+    }
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_lf_frame(bit_depth, y, u, v, stride_y, stride_uv, cols, rows, tables, (hipStream_t)stream, 1);
+}
+
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */
 extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1,
                                     size_t pitch1, const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream)

@@ -725,11 +725,18 @@ __device__ __forceinline__ void vp9_lf_sb_rows(vl_lds_u8 *lds, int W, uint8_t *p
 /* blocks 0 .. nwg-1: luma (the long chain first), nwg .. 2 nwg-1: chroma; W superblock rows per block */
 template <typename PIX>
 __global__ __launch_bounds__(256) void k_vp9_lf_frame_wg(uint8_t *py, uint8_t *pu, uint8_t *pv, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
-                                                        const FFHipVp9LfSb *tabs, int *progress, int *fail, int bd, int fault)
+                                                        const FFHipVp9LfSb *tabs, int *progress, int *fail, int bd, int fault, int planes444)
 {
     extern __shared__ __align__(16) uint8_t vl_lds[];
     const int W = (int)(blockDim.x >> 6);
     const int sb_rows = (rows + 7) >> 3, nwg = (sb_rows + W - 1) / W;
+    if (planes444) { /* 4:4:4: the chroma planes are filtered exactly as luma, with luma's masks and levels (vp9lpf.c:185-201: uv_masks =
+                      * lflvl->mask[ss_h | ss_v], filter_plane_cols / _rows with ss 0): three luma chains */
+        const int pl = (int)blockIdx.x / nwg, b = (int)blockIdx.x - pl * nwg;
+        uint8_t *p = pl == 0 ? py : pl == 1 ? pu : pv;
+        vp9_lf_sb_rows<PIX, false>((vl_lds_u8 *)vl_lds, W, p, p, pl ? suv : sy, cols, rows, b * W, sb_rows, tabs, progress + pl * sb_rows, fail, bd, fault);
+        return;
+    }
     if ((int)blockIdx.x < nwg)
         vp9_lf_sb_rows<PIX, false>((vl_lds_u8 *)vl_lds, W, py, py, sy, cols, rows, blockIdx.x * W, sb_rows, tabs, progress, fail, bd, fault);
     else
@@ -749,7 +756,7 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
 }
 
 int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
-                              const FFHipVp9LfSb *tabs, hipStream_t stream)
+                              const FFHipVp9LfSb *tabs, hipStream_t stream, int planes444)
 {
     const int sb_rows = (rows + 7) >> 3;
     if (cols <= 0 || rows <= 0)
@@ -759,14 +766,14 @@ int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdif
         return FFHIP_EINVAL;
     }
     FFHipProgressSlot ps;
-    const int r = ffhip_progress_acquire(2 * sb_rows + 1, stream, &ps);
+    const int r = ffhip_progress_acquire((planes444 ? 3 : 2) * sb_rows + 1, stream, &ps);
     if (r < 0)
         return r;
     int *const prog = ps.prog, *const fail = ps.fail;
     const char *eo = FFHIP_KNOB("FFHIP_VP9_LF_OLD"); /* 1: one wave per superblock row, every hand-off through memory (cross-check) */
     const char *ew = FFHIP_KNOB("FFHIP_VP9_LF_WPB"), *ef = FFHIP_KNOB("FFHIP_VP9_LF_FAULT");
     const int fault = ef ? atoi(ef) : 0; /* 1: the test hook (no hand-off is published); 8: no waiting (timing experiment, wrong output) */
-    if (eo && atoi(eo) == 1) {
+    if (eo && atoi(eo) == 1 && !planes444) {
         if (bd == 8)
             hipLaunchKernelGGL(k_vp9_lf_frame<uint8_t>, dim3(2 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8);
         else
@@ -779,9 +786,9 @@ int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdif
         const unsigned luma = (2u * (8 + W * 64) * (76 * ps_ / 4) + W * 256u + 2u * W) * 4u, chroma = (4u * (8 + W * 32) * (44 * ps_ / 4) + W * 64u + 2u * W) * 4u;
         const unsigned lds = ((luma > chroma ? luma : chroma) + 15u) & ~15u;
         if (bd == 8)
-            hipLaunchKernelGGL(k_vp9_lf_frame_wg<uint8_t>, dim3(2 * nwg), dim3(64 * W), lds, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8, fault);
+            hipLaunchKernelGGL(k_vp9_lf_frame_wg<uint8_t>, dim3((planes444 ? 3 : 2) * nwg), dim3(64 * W), lds, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8, fault, planes444);
         else
-            hipLaunchKernelGGL(k_vp9_lf_frame_wg<uint16_t>, dim3(2 * nwg), dim3(64 * W), lds, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, bd, fault);
+            hipLaunchKernelGGL(k_vp9_lf_frame_wg<uint16_t>, dim3((planes444 ? 3 : 2) * nwg), dim3(64 * W), lds, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, bd, fault, planes444);
     }
     const hipError_t e = hipGetLastError();
     const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);

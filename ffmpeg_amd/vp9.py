@@ -94,9 +94,14 @@ def lf_sb_tables(filters, sb_cols, sb_rows, lim_lut, mblim_lut):
     return out
 
 
-def loopfilter_frame(y, u, v, stride_y, stride_uv, cols, rows, tables, stream=None, bit_depth=8):
+def loopfilter_frame(y, u, v, stride_y, stride_uv, cols, rows, tables, stream=None, bit_depth=8, ss=(1, 1)):
     """ff_vp9_loopfilter_sb over a picture of cols x rows 8x8 blocks in the decoder's order, one launch: y / u / v device tensors,
-    strides in bytes, tables = device uint32 [sb_rows * sb_cols, 320] from lf_sb_tables (sb_* = (* + 7) >> 3)"""
+    strides in bytes, tables = device uint32 [sb_rows * sb_cols, 320] from lf_sb_tables (sb_* = (* + 7) >> 3); ss = (ss_h, ss_v):
+    (1, 1) 4:2:0, (0, 0) 4:4:4 (all planes by the luma tables)"""
+    if tuple(ss) != (1, 1):
+        return _lib.check(_lib.lib().ffhip_vp9_loopfilter_frame_ss_dev(bit_depth, ss[0], ss[1], y.data_ptr(), u.data_ptr(), v.data_ptr(), stride_y,
+                                                                       stride_uv, cols, rows, tables.data_ptr(), _st(stream)),
+                          "ffhip_vp9_loopfilter_frame_ss_dev")
     return _lib.check(_lib.lib().ffhip_vp9_loopfilter_frame_dev(bit_depth, y.data_ptr(), u.data_ptr(), v.data_ptr(), stride_y, stride_uv, cols,
                                                                 rows, tables.data_ptr(), _st(stream)), "ffhip_vp9_loopfilter_frame_dev")
 

@@ -1221,6 +1221,12 @@ int ffhip_vp9_lf_sb_tables(FFHipVp9LfSb *out, const FFHipVp9Filter *lflvl, int r
  *  lost hand-off is reported by ffhip_stream_synchronize. */
 int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y, ptrdiff_t stride_uv, int cols,
                                    int rows, const FFHipVp9LfSb *tables, void *stream);
+/** The same with the picture's chroma sub-sampling (VP9Context.ss_h / .ss_v).  1, 1: the call above.  0, 0 (4:4:4, profiles 1 / 3): the
+ *  chroma planes are filtered exactly as luma — ff_vp9_loopfilter_sb passes luma's masks (uv_masks = lflvl->mask[ss_h | ss_v]) and
+ *  levels with ss 0 (vp9lpf.c:185-201) — so all three planes use tables[].y and three luma chains run side by side; tables[].uv is not
+ *  read.  4:4:0 / 4:2:2: FFHIP_ENOSYS. */
+int ffhip_vp9_loopfilter_frame_ss_dev(int bit_depth, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y,
+                                      ptrdiff_t stride_uv, int cols, int rows, const FFHipVp9LfSb *tables, void *stream);
 
 /**
  * vp9dsp above 8 bits (profiles 2 / 3): the batch faces above at the bpp ff_vp9dsp_init(dsp, bpp, bitexact) instantiates its template

@@ -104,3 +104,48 @@ def test_vp9_loopfilter_frame_lost_handoff_is_reported(monkeypatch, measure_buil
     assert L.ffhip_stream_synchronize(None) == -5                       # FFHIP_EIO
     assert L.ffhip_stream_synchronize(None) == 0                       # reported once
     test_vp9_loopfilter_frame(9, 5, "structured", 8)                      # and the pool keeps working
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("sbc,sbr,kind", [(9, 5, "structured"), (7, 6, "bits1"), (1, 1, "structured"), (2, 13, "bits2")])
+def test_vp9_loopfilter_frame_444(sbc, sbr, kind, bd):
+    """4:4:4 (ss_h = ss_v = 0): ff_vp9_loopfilter_sb filters the chroma planes with luma's masks and levels (vp9lpf.c:185-201) — the
+    frame call with ss = (0, 0) == the oracle's ffo_vp9_loopfilter_sb(ss_h 0, ss_v 0) superblock by superblock, all three planes"""
+    import torch
+    from ffmpeg_amd import vp9, _lib
+    rng = np.random.default_rng(2000 * sbc + 10 * sbr + bd + len(kind))
+    lim, mblim = G.filter_lut(int(rng.integers(0, 8)))
+    cols, rows = 8 * sbc, 8 * sbr
+    if kind == "structured":
+        cols, rows = cols - int(rng.integers(0, 8)), rows - int(rng.integers(0, 8))
+    planes = [_plane(rng, 64 * sbr, 64 * sbc, 12 if k == 0 else 4, bd) for k in range(3)]
+    before = [p.copy() for p in planes]
+    filt = np.zeros(sbr * sbc, G.FILTER_DT)
+    O = ffi.oracle()
+    for r in range(sbr):
+        for c in range(sbc):
+            f = G.structured(rng, r, c, cols, rows) if kind == "structured" else G.random_bits(rng, int(kind[-1]))
+            filt[r * sbc + c] = f
+            level, mask = np.ascontiguousarray(f["level"]), np.ascontiguousarray(f["mask"])
+            at = [p.ctypes.data + r * 64 * p.strides[0] + c * 64 * p.itemsize for p in planes]
+            O.ffo_vp9_loopfilter_sb(bd, 0, 0, ptr(level, u8p), ptr(mask, u8p), 8 * r, 8 * c, *(C.cast(a, u8p) for a in at),
+                                    planes[0].strides[0], planes[1].strides[0], ptr(lim, u8p), ptr(mblim, u8p))
+    tabs = vp9.lf_sb_tables(filt.view(np.uint8).reshape(sbr * sbc, 192), sbc, sbr, lim, mblim)
+    dev = [torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).cuda() for b in before]
+    d_tabs = torch.from_numpy(tabs.view(np.int32)).cuda()
+    vp9.loopfilter_frame(dev[0], dev[1], dev[2], before[0].strides[0], before[1].strides[0], cols, rows, d_tabs, bit_depth=bd, ss=(0, 0))
+    torch.cuda.synchronize()
+    assert _lib.lib().ffhip_stream_synchronize(None) == 0
+    changed = 0
+    for k, (d, want, b) in enumerate(zip(dev, planes, before)):
+        got = d.cpu().numpy().view(want.dtype).reshape(want.shape)
+        h, w = 8 * rows, 8 * cols
+        bad = np.argwhere(got[:h, :w] != want[:h, :w])
+        assert bad.size == 0, (k, bad[:5], len(bad))
+        outside = got != b
+        outside[:h, :w] = False
+        assert not outside.any()
+        changed += int((want != b).sum())
+    assert changed > (30 * sbc * sbr if sbc * sbr > 8 else -1)
+    with pytest.raises(Exception):
+        vp9.loopfilter_frame(dev[0], dev[1], dev[2], before[0].strides[0], before[1].strides[0], cols, rows, d_tabs, bit_depth=bd, ss=(1, 0))
