@@ -103,13 +103,15 @@ static void lf_rows(uint32_t *tab, int nseg, int row, int ss_h, int ss_v, const 
 int ffhip_vp9_lf_sb_tables(FFHipVp9LfSb *out, const FFHipVp9Filter *lflvl, int row, int col, int ss_h, int ss_v, const uint8_t *lim_lut,
                            const uint8_t *mblim_lut)
 {
-    if (!out || !lflvl || !lim_lut || !mblim_lut || ss_h != 1 || ss_v != 1) {
-        ffhip_set_error("ffhip_vp9_lf_sb_tables: null argument, or a chroma format other than 4:2:0");
+    if (!out || !lflvl || !lim_lut || !mblim_lut || ss_h != ss_v || ss_h < 0 || ss_h > 1) {
+        ffhip_set_error("ffhip_vp9_lf_sb_tables: null argument, or a chroma format other than 4:2:0 / 4:4:4");
         return FFHIP_EINVAL;
     }
     memset(out, 0, sizeof(*out));
     lf_cols(&out->y[0][0][0], 8, col, 0, 0, lflvl->level, lflvl->mask[0][0], lim_lut, mblim_lut);
     lf_rows(&out->y[1][0][0], 8, row, 0, 0, lflvl->level, lflvl->mask[0][1], lim_lut, mblim_lut);
+    if (!ss_h)
+        return 0; /* 4:4:4: the chroma planes take the luma tables (ffhip_vp9_loopfilter_frame_ss_dev); uv stays empty */
     lf_cols(&out->uv[0][0][0], 4, col, ss_h, ss_v, lflvl->level, lflvl->mask[1][0], lim_lut, mblim_lut);
     lf_rows(&out->uv[1][0][0], 4, row, ss_h, ss_v, lflvl->level, lflvl->mask[1][1], lim_lut, mblim_lut);
     /* a 16-wide chroma filter on the superblock's last 4-sample position would reach 4 samples into the next superblock: mask_edges

@@ -1211,7 +1211,8 @@ typedef struct FFHipVp9LfSb {            /* entry: bit 31 valid, 24..25 width (0
     uint32_t uv[2][8][4];                /* the same for both chroma planes (32 x 32 samples) */
 } FFHipVp9LfSb;
 /** Host side: the tables of the superblock at (row, col) — in 8-sample units, as the reference passes them (superblock (r, c): row =
- *  8 r, col = 8 c; only "is it the first" matters) — from its VP9Filter and the frame's filter_lut (vp9.c:683-697). */
+ *  8 r, col = 8 c; only "is it the first" matters) — from its VP9Filter and the frame's filter_lut (vp9.c:683-697).  ss_h = ss_v = 1
+ *  (4:2:0) or 0 (4:4:4: y only, the chroma planes are filtered by the luma tables); anything else FFHIP_EINVAL. */
 int ffhip_vp9_lf_sb_tables(FFHipVp9LfSb *out, const FFHipVp9Filter *lflvl, int row, int col, int ss_h, int ss_v, const uint8_t *lim_lut,
                            const uint8_t *mblim_lut);
 /** One picture of cols x rows 8x8 blocks (VP9Context.cols / .rows: (width + 7) >> 3, (height + 7) >> 3), i.e. (cols + 7) >> 3 by
