@@ -91,6 +91,19 @@ extern "C" int ffhip_h264_deblock_frames_chroma_dev(uint8_t *plane, size_t frame
     return ffhip_launch_h264_deblock_frames_chroma(plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_h264_deblock_frames_dev_hbd(int bit_depth, int chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w,
+                                                 int mb_h, const FFHipH264Edge *edges, void *stream)
+{
+    if (!plane || !edges || mb_w <= 0 || mb_h <= 0 || nframes < 0 || (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    if (bit_depth == 8)
+        return chroma ? ffhip_launch_h264_deblock_frames_chroma(plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, (hipStream_t)stream)
+                      : ffhip_launch_h264_deblock_frames(plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, (hipStream_t)stream);
+    return ffhip_launch_h264_deblock_frames_bd(bit_depth, chroma, plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, (hipStream_t)stream);
+}
+
 extern "C" int ffhip_h264_deblock_frames_dev(uint8_t *luma, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                                              const FFHipH264Edge *edges, void *stream)
 {

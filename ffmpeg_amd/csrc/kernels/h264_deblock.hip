@@ -741,13 +741,16 @@ __device__ __forceinline__ int db_max3(int a, int b, int c)
     return d;
 }
 
+/* sh = bit depth - 8: alpha, beta and tc0 arrive in 8-bit units and are scaled as h264dsp_template.c:104-330 scales them (alpha, beta
+ * << sh; luma tc0 * (1 << sh); chroma ((tc0 - 1) << sh) + 1); maxv = 2^depth - 1 */
 template <bool CHROMA>
-__device__ __forceinline__ void db_edge(int (&v)[8], uint32_t rec, uint32_t tcw, int tcsh, bool skip)
+__device__ __forceinline__ void db_edge(int (&v)[8], uint32_t rec, uint32_t tcw, int tcsh, bool skip, int sh = 0, int maxv = 255)
 {
     const int p3 = v[0], p2 = v[1], p1 = v[2], p0 = v[3], q0 = v[4], q1 = v[5], q2 = v[6], q3 = v[7];
-    const int alpha = (rec >> 8) & 255, negb = -(int)((rec >> 16) & 255);
+    const int alpha = (int)((rec >> 8) & 255) << sh, negb = -((int)((rec >> 16) & 255) << sh);
     const int nega = skip ? 0 : -alpha;                       /* a picture edge: never filtered */
-    const int tc0 = __builtin_amdgcn_sbfe(tcw, tcsh, 8);
+    const int tc8 = __builtin_amdgcn_sbfe(tcw, tcsh, 8);
+    const int tc0 = CHROMA ? (tc8 - 1) * (1 << sh) + 1 : tc8 * (1 << sh);
     const bool is4 = (rec & 255) >= 4;
     /* m < 0: |p0 - q0| < alpha && |p1 - p0| < beta && |q1 - q0| < beta */
     const int m = db_max3(db_sad3(p0, q0, nega), db_sad3(p1, p0, negb), db_sad3(q1, q0, negb));
@@ -757,8 +760,8 @@ __device__ __forceinline__ void db_edge(int (&v)[8], uint32_t rec, uint32_t tcw,
         const int x4 = ((q0 - p0) << 2) + (p1 - q1) + 4;
         if (CHROMA) {
             const int delta = (mn >> 31) & db_med3(x4 >> 3, -tc0, tc0);
-            v[3] = db_clip255(p0 + delta);
-            v[4] = db_clip255(q0 - delta);
+            v[3] = db_med3(p0 + delta, 0, maxv);
+            v[4] = db_med3(q0 - delta, 0, maxv);
         } else {
             const int dap = db_sad3(p2, p0, negb), daq = db_sad3(q2, q0, negb);     /* < 0: |p2 - p0| < beta */
             const int avg = (p0 + q0 + 1) >> 1, ntc0 = -tc0;
@@ -767,8 +770,8 @@ __device__ __forceinline__ void db_edge(int (&v)[8], uint32_t rec, uint32_t tcw,
             const int delta = (mn >> 31) & db_med3(x4 >> 3, -tc, tc);
             v[2] = p1 + (dp & (max(mn, dap) >> 31));
             v[5] = q1 + (dq & (max(mn, daq) >> 31));
-            v[3] = db_clip255(p0 + delta);
-            v[4] = db_clip255(q0 - delta);
+            v[3] = db_med3(p0 + delta, 0, maxv);
+            v[4] = db_med3(q0 - delta, 0, maxv);
         }
     }
     const int mi = is4 ? m : 0;                               /* < 0: a bS = 4 line that passes the alpha / beta test */
@@ -815,18 +818,20 @@ __device__ __forceinline__ bool db_wait_lds(const int *ctr, int want, int *fail)
     asm volatile("" ::: "memory");
     return true;
 }
-template <bool CHROMA>
+template <bool CHROMA, typename PIX = uint8_t>
 __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
                                                          const FFHipH264Edge *edges, int *gprog, int nbands, int bwaves, int nframes,
-                                                         int *fail, int fault, int xrot)
+                                                         int *fail, int fault, int xrot, int bd)
 {
     constexpr int MB = CHROMA ? 8 : 16;          /* samples per macroblock side = lanes per row group */
+    constexpr int PS = (int)sizeof(PIX), MBB = MB * PS; /* bytes per sample (uint16_t above 8 bits), per macroblock row */
+    const int sh = PS == 1 ? 0 : bd - 8, maxv = PS == 1 ? 255 : (1 << bd) - 1;
     constexpr int NDW = MB / 4;                  /* dwords per macroblock row = edges per direction */
     constexpr int NE = 2 * NDW;                  /* edge records per macroblock */
     constexpr int Q = 64 / MB;                   /* macroblock rows per wave */
     constexpr int SL = 8;                        /* ring slots (macroblocks) per row */
     constexpr int SK = DB_SKEW;                  /* macroblocks a row group trails the one above */
-    constexpr int PITCH = SL * MB + 16;          /* 144 / 80 bytes: 36 / 20 dwords, 16 (8) rows spread over all banks */
+    constexpr int PITCH = SL * MBB + 16;         /* 8 bits: 144 / 80 bytes = 36 / 20 dwords, 16 (8) rows spread over all banks */
     /* A workgroup is W = 1 .. 4 waves on the SIMDs of one CU working on W CONSECUTIVE bands ("super-band") in ONE LDS strip: wave w's
      * top context is the bottom of wave w - 1's last row group, in place, exactly as between the row groups of a wave — the
      * hand-off between the waves of a workgroup is an LDS counter (a few hundred ns), only the workgroup's first / last wave talk
@@ -876,31 +881,36 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
     uint8_t *const gst = plane + ((ptrdiff_t)y * MB + l - 4) * stride;             /* picture row of strow */
     const bool to_mem = next_band && wv == W - 1, to_lds = next_band && wv < W - 1;
     const bool st_ok = row_ok && (y > 0 || l >= 4), bot_ok = row_ok && q == qb && !to_lds; /* the wave below stores them with its rows */
-    /* bottom rows of the band's last row: 4 rows x NDW dwords = MB lanes (row group qb) */
-    const int br = MB - 4 + l / NDW, bd = l % NDW;
-    uint8_t *const botl = tile + (MB * qb + br + 4) * PITCH + (qb + 1) * 16 + 4 * bd;
-    uint8_t *const botg = plane + ((ptrdiff_t)(band * Q + qb) * MB + br) * stride + 4 * bd;
+    /* bottom rows of the band's last row: 4 rows x NDW groups of 4 samples = MB lanes (row group qb) */
+    const int br = MB - 4 + l / NDW, bq = l % NDW;
+    uint8_t *const botl = tile + (MB * qb + br + 4) * PITCH + (qb + 1) * 16 + 4 * PS * bq;
+    uint8_t *const botg = plane + ((ptrdiff_t)(band * Q + qb) * MB + br) * stride + 4 * PS * bq;
     /* top context of the band (rows -4 .. -1 of its first row): the same MB lanes of row group 0 */
     const int cr = l / NDW, cd = l % NDW;
-    uint8_t *const ctxl = tile + cr * PITCH + 4 * cd;
-    const uint8_t *const ctxg = plane + ((ptrdiff_t)band * Q * MB - 4 + cr) * stride + 4 * cd;
+    uint8_t *const ctxl = tile + cr * PITCH + 4 * PS * cd;
+    const uint8_t *const ctxg = plane + ((ptrdiff_t)band * Q * MB - 4 + cr) * stride + 4 * PS * cd;
     const uint32_t *const erow = reinterpret_cast<const uint32_t *>(edges + (size_t)(row_ok ? y : 0) * mb_w * NE);
 
-    typedef uint32_t rowv __attribute__((ext_vector_type(CHROMA ? 2 : 4)));
+    typedef uint32_t rowv_n __attribute__((ext_vector_type(MBB / 4)));
+    typedef rowv_n __attribute__((aligned(MBB < 16 ? MBB : 16))) rowv; /* a row of 16-bit luma is two 16-byte pieces */
+    typedef uint32_t quadv_n __attribute__((ext_vector_type(PS)));          /* four samples */
+    typedef quadv_n __attribute__((aligned(4))) quadv;
     rowv own = {};
     db_u4 eown = { 0, 0, 0, 0 };
     auto fetch = [&](int xn) { /* macroblock xn's row l and (lanes l < 3 NDW / 2) 16 bytes of its edge records */
         if (row_ok && xn >= 0 && xn < mb_w) {
-            own = *reinterpret_cast<const rowv *>(grow + xn * MB);
+            own = *reinterpret_cast<const rowv *>(grow + xn * MBB);
             if (l < 3 * NE / 4)
                 eown = *reinterpret_cast<const db_u4 *>(erow + (size_t)xn * 3 * NE + 4 * l);
         }
     };
     int known = 0;
     bool have_top = false;
-    uint32_t topv = 0;
+    uint32_t topv[PS] = {};
     auto load_top = [&](int x0) {
-        return __hip_atomic_load(reinterpret_cast<const uint32_t *>(ctxg + x0 * MB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < PS; i++)
+            topv[i] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(ctxg + x0 * MBB) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     fetch(0 - SK * q);
     for (int s = 0; s < nsteps; s++) {
@@ -927,8 +937,8 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
             erec[k] = etab[q][3 * k + 1];
             etcw[k] = etab[q][3 * k + 2];
         }
-        uint8_t *const pl = ownrow + ((x - 1) & (SL - 1)) * MB + MB - 4, *const pm = ownrow + (x & (SL - 1)) * MB;
-        const uint32_t lw = *reinterpret_cast<const uint32_t *>(pl);   /* the left macroblock's last four samples of this row */
+        uint8_t *const pl = ownrow + ((x - 1) & (SL - 1)) * MBB + MBB - 4 * PS, *const pm = ownrow + (x & (SL - 1)) * MBB;
+        const quadv lw = *reinterpret_cast<const quadv *>(pl);   /* the left macroblock's last four samples of this row */
         fetch(x + 1);
         /* ---- picture stores of the previous step's results: macroblock x - 1 was filtered a step ago, which made the columns of
          *      macroblock x - 2 final (rows shifted up by four); behind the row's last macroblock its own columns are final too ---- */
@@ -936,10 +946,12 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
             const int m = x - 2;
             if (!(fault & 2) && m >= 0 && m < mb_w) {
                 if (st_ok)
-                    *reinterpret_cast<rowv *>(gst + m * MB) = *reinterpret_cast<const rowv *>(strow + (m & (SL - 1)) * MB);
+                    *reinterpret_cast<rowv *>(gst + m * MBB) = *reinterpret_cast<const rowv *>(strow + (m & (SL - 1)) * MBB);
                 if (bot_ok) /* ... and the bottom four rows of the band's last row: write-through, the next band reads them */
-                    __hip_atomic_store(reinterpret_cast<uint32_t *>(botg + m * MB), *reinterpret_cast<const uint32_t *>(botl + (m & (SL - 1)) * MB),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < PS; i++)
+                        __hip_atomic_store(reinterpret_cast<uint32_t *>(botg + m * MBB) + i, reinterpret_cast<const uint32_t *>(botl + (m & (SL - 1)) * MBB)[i],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         wave_lds_sync();
@@ -950,27 +962,32 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
         /* ---- vertical edges, left to right: lane = row; samples -4 .. MB-1 of the row, in registers throughout ---- */
         if (act) {
             int v0[MB + 4];
-            v0[0] = lw & 255; v0[1] = (lw >> 8) & 255; v0[2] = (lw >> 16) & 255; v0[3] = lw >> 24;
+            constexpr uint32_t SM = PS == 1 ? 0xFFu : 0xFFFFu; /* sample i of a run of dwords: dword i PS / 4, bit 8 (i PS % 4) */
 #pragma unroll
-            for (int d = 0; d < NDW; d++) {
-                const uint32_t w = cur[d];
-                v0[4 + 4 * d] = w & 255; v0[5 + 4 * d] = (w >> 8) & 255; v0[6 + 4 * d] = (w >> 16) & 255; v0[7 + 4 * d] = w >> 24;
-            }
+            for (int i = 0; i < 4; i++)
+                v0[i] = (int)((lw[(i * PS) >> 2] >> (8 * ((i * PS) & 3))) & SM);
+#pragma unroll
+            for (int i = 0; i < MB; i++)
+                v0[4 + i] = (int)((cur[(i * PS) >> 2] >> (8 * ((i * PS) & 3))) & SM);
             if (!(fault & 4)) {
 #pragma unroll
                 for (int k = 0; k < NDW; k++) {
                     int v[8] = { v0[4 * k], v0[4 * k + 1], v0[4 * k + 2], v0[4 * k + 3], v0[4 * k + 4], v0[4 * k + 5], v0[4 * k + 6], v0[4 * k + 7] };
-                    db_edge<CHROMA>(v, erec[k], etcw[k], tcsh, k == 0 && x == 0);
+                    db_edge<CHROMA>(v, erec[k], etcw[k], tcsh, k == 0 && x == 0, sh, maxv);
 #pragma unroll
                     for (int i = 1; i < 7; i++)
                         v0[4 * k + i] = v[i];
                 }
             }
-            *reinterpret_cast<uint32_t *>(pl) = (uint32_t)v0[0] | ((uint32_t)v0[1] << 8) | ((uint32_t)v0[2] << 16) | ((uint32_t)v0[3] << 24);
-            rowv mw;
+            quadv lo = {};
 #pragma unroll
-            for (int d = 0; d < NDW; d++)
-                mw[d] = (uint32_t)v0[4 + 4 * d] | ((uint32_t)v0[5 + 4 * d] << 8) | ((uint32_t)v0[6 + 4 * d] << 16) | ((uint32_t)v0[7 + 4 * d] << 24);
+            for (int i = 0; i < 4; i++)
+                lo[(i * PS) >> 2] |= (uint32_t)v0[i] << (8 * ((i * PS) & 3));
+            *reinterpret_cast<quadv *>(pl) = lo;
+            rowv mw = {};
+#pragma unroll
+            for (int i = 0; i < MB; i++)
+                mw[(i * PS) >> 2] |= (uint32_t)v0[4 + i] << (8 * ((i * PS) & 3));
             *reinterpret_cast<rowv *>(pm) = mw;
         }
         if (to_lds) { /* this step's vertical pass is in LDS (one wave's LDS operations execute in order: the counter follows the rows) */
@@ -1001,30 +1018,33 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (lane < MB)
-                    topv = load_top(s);
+                    load_top(s);
             }
-            if (lane < MB)
-                *reinterpret_cast<uint32_t *>(ctxl + (s & (SL - 1)) * MB) = topv;
+            if (lane < MB) {
+#pragma unroll
+                for (int i = 0; i < PS; i++)
+                    reinterpret_cast<uint32_t *>(ctxl + (s & (SL - 1)) * MBB)[i] = topv[i];
+            }
         }
         wave_lds_sync();
         /* the next macroblock's context, if the band above has already published it: its latency hides behind the H pass */
         have_top = false;
         if (from_mem && s + 1 < mb_w && known >= s + 2) {
             if (lane < MB)
-                topv = load_top(s + 1);
+                load_top(s + 1);
             have_top = true;
         }
         /* ---- horizontal edges, top to bottom: lane = column; yv[i] = row i - 4 of the macroblock ---- */
         if (act && !(fault & 4)) {
-            uint8_t *tcol = tile + MB * q * PITCH + q * 16 + (x & (SL - 1)) * MB + l;   /* row -4 of group q (skew of group q - 1) */
+            uint8_t *tcol = tile + MB * q * PITCH + q * 16 + (x & (SL - 1)) * MBB + l * PS;   /* row -4 of group q (skew of group q - 1) */
             int yv[MB + 4];
 #pragma unroll
             for (int r = 0; r < MB + 4; r++)
-                yv[r] = (CHROMA && r < 2) ? 0 : tcol[r * PITCH + (r >= 4 ? 16 : 0)];
+                yv[r] = (CHROMA && r < 2) ? 0 : (int)*reinterpret_cast<const PIX *>(tcol + r * PITCH + (r >= 4 ? 16 : 0));
 #pragma unroll
             for (int k = 0; k < NDW; k++) {
                 int v[8] = { yv[4 * k], yv[4 * k + 1], yv[4 * k + 2], yv[4 * k + 3], yv[4 * k + 4], yv[4 * k + 5], yv[4 * k + 6], yv[4 * k + 7] };
-                db_edge<CHROMA>(v, erec[NDW + k], etcw[NDW + k], tcsh, k == 0 && y == 0);
+                db_edge<CHROMA>(v, erec[NDW + k], etcw[NDW + k], tcsh, k == 0 && y == 0, sh, maxv);
 #pragma unroll
                 for (int i = 1; i < 7; i++)
                     yv[4 * k + i] = v[i];
@@ -1033,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
 #pragma unroll
             for (int r = 1; r < MB + 3; r++)
                 if (!CHROMA || (r & 3) == 3 || (r & 3) == 0)
-                    tcol[r * PITCH + (r >= 4 ? 16 : 0)] = (uint8_t)yv[r];
+                    *reinterpret_cast<PIX *>(tcol + r * PITCH + (r >= 4 ? 16 : 0)) = (PIX)yv[r];
         }
         wave_lds_sync();
         if (from_lds && lane == 0)
@@ -1054,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
 
 /* the progress counters come from the per-device pool (progress_pool.hip): a slot per launch, zeroed in stream order */
 static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
-                          const FFHipH264Edge *edges, hipStream_t stream)
+                          const FFHipH264Edge *edges, hipStream_t stream, int bd = 8)
 {
     if (mb_w <= 0 || mb_h <= 0 || nframes <= 0)
         return 0;
@@ -1068,8 +1088,12 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
     const int fault = ef ? atoi(ef) : 0; /* 1: the test hook; 2 no stores, 4 no filters, 8 no waiting: timing experiments (wrong output) */
     const int old = eo ? atoi(eo) : 0;
     /* the skewed-rows kernel moves 16-byte (chroma: 8-byte) rows and reads the edge records as 16-byte vectors */
-    const size_t amask = chroma ? 7 : 15;
-    const bool skew = !old && !(((uintptr_t)plane | (size_t)stride | frame_pitch) & amask) && !((uintptr_t)edges & 15);
+    const size_t amask = chroma && bd == 8 ? 7 : 15;
+    const bool skew = (!old || bd > 8) && !(((uintptr_t)plane | (size_t)stride | frame_pitch) & amask) && !((uintptr_t)edges & 15);
+    if (bd > 8 && !skew) { /* the 4-byte aligned and byte paths below are 8-bit kernels */
+        ffhip_set_error("ffhip_h264_deblock_frame (bit depth %d): plane, stride, frame pitch and edge records must be 16-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
     const bool band = !skew && aligned && !(old == 1 && !chroma);
     /* band kernel, rows per band.  A lone picture is latency-bound: 4 = one wave per SIMD, the waves of a band must not share an
      * issue port.  A batch that fills the chip anyway is throughput-bound: 16 keeps 15 of 16 hand-offs in LDS.
@@ -1098,22 +1122,25 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
             /* waves per picture: one per band while the chip has SIMDs to spare (a lone picture is latency-bound), else what an
              * XCD's 128 SIMDs leave each of its pictures, but never fewer than a quarter of the bands (the wavefront's width) */
             const char *eb = FFHIP_KNOB("FFHIP_DEBLOCK_WAVES"), *ewp = FFHIP_KNOB("FFHIP_DEBLOCK_WPB");
-            const int wpb = ewp && atoi(ewp) >= 1 && atoi(ewp) <= 4 ? atoi(ewp) : 4; /* cooperating waves per workgroup (bands per super-band) */
+            int wpb = ewp && atoi(ewp) >= 1 && atoi(ewp) <= 4 ? atoi(ewp) : 4; /* cooperating waves per workgroup (bands per super-band) */
+            if (bd > 8 && !chroma && wpb > 3)
+                wpb = 3; /* 16-bit luma: a strip row is 272 bytes, 3 waves' strip is what 64 KB of LDS hold */
             const int per_xcd = cdiv(nf, 8);
             int bwaves = eb && atoi(eb) > 0 ? atoi(eb) : 128 / per_xcd;
             if (bwaves < cdiv(nbands, 4)) bwaves = cdiv(nbands, 4);
             if (bwaves > nbands) bwaves = nbands;
             bwaves = cdiv(bwaves, wpb) * wpb; /* whole workgroups (waves beyond the last band idle) */
             const dim3 g(8 * (bwaves / wpb) * per_xcd), t(64 * wpb);
-            const int mbs = chroma ? 8 : 16, qq = 64 / mbs, nee = chroma ? 4 : 8;
-            const unsigned lds = (((unsigned)((4 + wpb * qq * mbs) * (8 * mbs + 16) + (wpb * qq + 1) * 16 + 15)) & ~15u) +
+            const int mbs = chroma ? 8 : 16, qq = 64 / mbs, nee = chroma ? 4 : 8, psz = bd > 8 ? 2 : 1;
+            const unsigned lds = (((unsigned)((4 + wpb * qq * mbs) * (8 * mbs * psz + 16) + (wpb * qq + 1) * 16 + 15)) & ~15u) +
                                  (unsigned)wpb * (unsigned)qq * (3 * nee + 4) * 4 + 2u * wpb * 4;
             static std::atomic<unsigned> launches{0};
             const int xrot = nf < 8 ? (int)(launches.fetch_add((unsigned)nf, std::memory_order_relaxed) & 7) : 0; /* where the batch's first picture goes */
-            if (chroma)
-                hipLaunchKernelGGL(k_h264_deblock_skew<true>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault, xrot);
-            else
-                hipLaunchKernelGGL(k_h264_deblock_skew<false>, g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, nf, fail, fault, xrot);
+#define DBS_LAUNCH(CH, T) hipLaunchKernelGGL((k_h264_deblock_skew<CH, T>), g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, \
+                                             nf, fail, fault, xrot, bd)
+            if (bd > 8) { if (chroma) DBS_LAUNCH(true, uint16_t); else DBS_LAUNCH(false, uint16_t); }
+            else        { if (chroma) DBS_LAUNCH(true, uint8_t); else DBS_LAUNCH(false, uint8_t); }
+#undef DBS_LAUNCH
         } else if (!band)
             hipLaunchKernelGGL(k_h264_deblock_frame, dim3(mb_h, nf), dim3(64), 0, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, fail);
 #define DB_LAUNCH(CH, W) hipLaunchKernelGGL((k_h264_deblock_band<CH, W>), dim3(nbands, nf), dim3(64 * W), 0, stream, pl, frame_pitch, stride, \
@@ -1149,4 +1176,11 @@ int ffhip_launch_h264_deblock_frames_chroma(uint8_t *plane, size_t frame_pitch, 
                                             const FFHipH264Edge *edges, hipStream_t stream)
 {
     return deblock_frames(true, plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream);
+}
+
+/* 9 .. 14 bits: uint16_t samples (stride and frame pitch in bytes), the skewed-rows kernel only */
+int ffhip_launch_h264_deblock_frames_bd(int bd, int chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                                        const FFHipH264Edge *edges, hipStream_t stream)
+{
+    return deblock_frames(chroma != 0, plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream, bd);
 }

@@ -43,6 +43,8 @@ int ffhip_launch_h264_chroma_mc_bd(int bd, uint8_t *dst, const uint8_t *src, ptr
                                    hipStream_t stream);
 int ffhip_launch_h264_weight_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
                                 hipStream_t stream);
+int ffhip_launch_h264_deblock_frames_bd(int bd, int chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
+                                        const FFHipH264Edge *edges, hipStream_t stream);
 int ffhip_launch_h264_pred_bd(int bd, int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n,
                               hipStream_t stream);
 /* host faces of those (shims_h264_hbd.hip) */

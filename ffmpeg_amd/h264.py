@@ -76,6 +76,14 @@ def deblock_frames(luma, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream
                       "ffhip_h264_deblock_frames_dev")
 
 
+def deblock_frames_hbd(bit_depth, plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, chroma=False, stream=None):
+    """frame-order deblocking at 8 / 9 / 10 / 12 / 14 bits (uint16 samples above 8; stride and frame pitch in bytes); chroma: one
+    4:2:0 chroma plane per frame"""
+    return _lib.check(_lib.lib().ffhip_h264_deblock_frames_dev_hbd(bit_depth, 1 if chroma else 0, plane.data_ptr(), frame_pitch, nframes, stride,
+                                                                   mb_w, mb_h, edges.data_ptr(), _stream(stream)),
+                      "ffhip_h264_deblock_frames_dev_hbd")
+
+
 def qpel_batch(dst, src, stride, blocks, n, stream=None):
     return _lib.check(_lib.lib().ffhip_h264_qpel_batch_dev(dst.data_ptr(), src.data_ptr(), stride, blocks.data_ptr(),
                                                            n, _stream(stream)), "ffhip_h264_qpel_batch_dev")

@@ -467,6 +467,16 @@ int ffhip_h264_deblock_frames_chroma_dev(uint8_t *plane, size_t frame_pitch, int
                                          const FFHipH264Edge *edges, void *stream);
 
 /**
+ * Both of the above at the depths H264DSPContext is instantiated for (libavcodec/h264dsp.c:135-147; bit_depth 8, 9, 10, 12 or 14): above
+ * 8 bits the samples are uint16_t (stride and frame_pitch stay in BYTES), alpha / beta / tc0 of the edge records stay in the 8-bit
+ * units the decoder passes and are scaled inside as h264dsp_template.c:104-330 scales them (alpha, beta << (depth - 8); luma tc0 *
+ * (1 << (depth - 8)); chroma ((tc0 - 1) << (depth - 8)) + 1).  chroma != 0: one 4:2:0 chroma plane per frame.  Above 8 bits plane,
+ * stride, frame_pitch and edges must be 16-byte aligned (the byte / dword paths are 8-bit kernels): FFHIP_EINVAL otherwise.
+ */
+int ffhip_h264_deblock_frames_dev_hbd(int bit_depth, int chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w,
+                                      int mb_h, const FFHipH264Edge *edges, void *stream);
+
+/**
  * The batched faces above at ANY depth the reference instantiates (bit_depth 8 / 9 / 10 / 12 / 14), plus the members that exist
  * only here: MBAFF and 4:2:2.  Above 8 bits samples are uint16_t and coefficients int32_t (libavcodec/bit_depth_template.c);
  * strides and offsets stay in BYTES, coefficient pitches in coefficients.  Bit-exact restatement of the reference's templates

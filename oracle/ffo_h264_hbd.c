@@ -363,3 +363,28 @@ void ffo_h264_biweight_bd(int bd, int w, uint8_t *dst, const uint8_t *src, ptrdi
         for (int x = 0; x < w; x++)
             wr(dst, bd, y * s + x, clip_px((rd(src, bd, y * s + x) * weights + rd(dst, bd, y * s + x) * weightd + offset) >> (log2_denom + 1), bd));
 }
+
+/* Frame order at depth bd: ffo_h264_deblock_frame / _chroma (ffo_h264.c) with the depth's filters — the macroblocks in raster order,
+ * each its vertical edges left to right, then its horizontal ones top to bottom (h264_loopfilter.c:716 ff_h264_filter_mb, the raster
+ * walk of h264_slice.c loop_filter()).  Samples uint16_t above 8 bits, stride in bytes; the records as the 8-bit functions take them. */
+void ffo_h264_deblock_frame_bd(int bd, int chroma, uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges)
+{
+    const int n = chroma ? 8 : 16, ne = chroma ? 2 : 4, ps = bd > 8 ? 2 : 1;
+    for (int my = 0; my < mb_h; my++)
+        for (int mx = 0; mx < mb_w; mx++) {
+            const FfoH264Edge *e = edges + (size_t)(my * mb_w + mx) * 2 * ne;
+            uint8_t *mb = plane + (ptrdiff_t)my * n * stride + (ptrdiff_t)mx * n * ps;
+            for (int dir = 0; dir < 2; dir++)
+                for (int k = 0; k < ne; k++) {
+                    const FfoH264Edge *ed = e + dir * ne + k;
+                    uint8_t *pix = dir ? mb + (ptrdiff_t)4 * k * stride : mb + 4 * k * ps;
+                    if (!ed->alpha || !ed->beta)
+                        continue;
+                    if (k == 0 && (dir ? my == 0 : mx == 0))
+                        continue;
+                    const int intra = ed->kind >= 4;
+                    /* dir 0: a vertical edge -> the h_ filter (bit 0); chroma: bit 1; bS 4: bit 2; lines per tc0 entry: luma 4, chroma 2 */
+                    ffo_h264_loop_filter_bd(bd, (dir ? 0 : 1) + (chroma ? 2 : 0) + (intra ? 4 : 0), chroma ? 2 : 4, pix, stride, ed->alpha, ed->beta, ed->tc0);
+                }
+        }
+}

@@ -239,3 +239,58 @@ def test_depths_the_standard_does_not_define_are_refused():
     for bd in (7, 11, 13, 16):
         assert L.ffhip_h264_idct_add_batch_dev_hbd(bd, 0, p, 64, p, p, 1, None) == -22
         assert L.ffhip_h264_qpel_batch_dev_hbd(bd, p, p, 64, p, 1, None) == -22
+
+
+@pytest.mark.parametrize("chroma", [False, True], ids=["luma", "chroma"])
+@pytest.mark.parametrize("depth", [9, 10, 12, 14])
+@pytest.mark.parametrize("mb_w,mb_h,nf,pad", [(1, 1, 1, 0), (5, 3, 1, 16), (45, 30, 2, 0), (2, 41, 1, 32), (120, 68, 1, 0), (7, 9, 9, 16)])
+def test_deblock_frames_hbd(mb_w, mb_h, nf, pad, depth, chroma):
+    """frame-order (decoder-order wavefront) deblocking at 9 .. 14 bits == the serial order with the depth's filters
+    (h264dsp_template.c:104-330 at BIT_DEPTH > 8: alpha, beta and tc0 scaled inside), luma and one 4:2:0 chroma plane, several
+    pictures per launch, hand-offs through LDS inside a workgroup and through memory between workgroups"""
+    import torch
+    from ffmpeg_amd import h264
+    from test_gpu_h264 import EDGE_DT, LADDER
+    assert torch.cuda.is_available()
+    O = ffi.oracle()
+    O.ffo_h264_deblock_frame_bd.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(mb_w * 100 + mb_h + depth + (7 if chroma else 0))
+    n_s = 8 if chroma else 16
+    h, w = mb_h * n_s, mb_w * n_s
+    stride = (w + pad // 2) * 2                      # bytes; 16-byte aligned
+    base = rng.integers(0, 1 << depth, (nf, h // 8 + 1, w // 8 + 1)).astype(np.int64)
+    planes = np.zeros((nf, h, stride // 2), np.uint16)
+    for f in range(nf):
+        p = np.kron(base[f], np.ones((8, 8), np.int64))[:h, :w] + rng.integers(-6 << (depth - 8), (6 << (depth - 8)) + 1, (h, w))
+        planes[f, :, :w] = np.clip(p, 0, (1 << depth) - 1)
+    ne = 4 if chroma else 8
+    n = mb_w * mb_h * ne
+    ed = np.zeros(nf * n, EDGE_DT)
+    lad = np.array(LADDER)
+    sel = rng.integers(0, len(LADDER), nf * n)
+    ed["alpha"], ed["beta"] = lad[sel, 0], lad[sel, 1]
+    ed["kind"] = np.where(rng.random(nf * n) < .25, 6 if chroma else 4, 2 if chroma else 0)
+    ed["tc0"] = rng.integers(-1, 5, (nf * n, 4))
+    ed["alpha"][rng.random(nf * n) < .15] = 0        # skipped edges
+    want = planes.copy()
+    for f in range(nf):
+        O.ffo_h264_deblock_frame_bd(depth, int(chroma), C.cast(want[f].ctypes.data, u8p), stride, mb_w, mb_h, C.c_void_p(ed[f * n:].ctypes.data))
+    d = torch.from_numpy(planes.view(np.uint8).reshape(nf, h, stride)).cuda()
+    h264.deblock_frames_hbd(depth, d, h * stride, nf, stride, mb_w, mb_h, torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).cuda(), chroma=chroma)
+    torch.cuda.synchronize()
+    from ffmpeg_amd import _lib
+    assert _lib.lib().ffhip_stream_synchronize(None) == 0
+    got = d.cpu().numpy().view(np.uint16).reshape(planes.shape)
+    assert (want != planes).sum() > (10 if mb_w > 1 else 0)
+    assert np.array_equal(got, want), "%d mismatches, first %s" % ((got != want).sum(), np.argwhere(got != want)[:4])
+
+
+def test_deblock_frames_hbd_rejects():
+    import torch
+    from ffmpeg_amd import h264
+    d = torch.zeros((16, 40), dtype=torch.uint8, device="cuda:0")
+    ed = torch.zeros((8, 12), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(RuntimeError):
+        h264.deblock_frames_hbd(11, d, 0, 1, 32, 1, 1, ed)          # not a depth of H264DSPContext
+    with pytest.raises(RuntimeError, match="aligned"):
+        h264.deblock_frames_hbd(10, d, 0, 1, 40, 1, 1, ed)          # stride not 16-byte aligned

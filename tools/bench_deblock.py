@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/bench_deblock.py — frame-order luma deblocking of 4K planes: per-frame time vs frames per launch."""
+"""tools/bench_deblock.py — frame-order luma deblocking of 4K planes: per-frame time vs frames per launch.  DB_DEPTH=10 (9 / 12 / 14):
+the same at that depth (uint16 samples) through ffhip_h264_deblock_frames_dev_hbd."""
 import json
 import os
 import sys
@@ -31,6 +32,20 @@ else:
     ed["k"] = k.ravel()
 ed["tc"] = rng.integers(0, 4, (ed.size, 4))
 ded = torch.from_numpy(ed.view(np.uint8).reshape(-1, 12)).to(dev)
+depth = int(os.environ.get("DB_DEPTH", "8"))
+if depth > 8:
+    for nf in (1, 8, 32):
+        batch = (torch.randint(100, 140, (nf, h, w), dtype=torch.int32, device=dev) << (depth - 8)).to(torch.int16)
+        dd = ded.repeat(nf, 1)
+        for rep in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            h264.deblock_frames_hbd(depth, batch, 2 * w * h, nf, 2 * w, mbw, mbh, dd)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        print(json.dumps({"depth": depth, "frames_per_launch": nf, "ms": round(ms, 3), "ms_per_frame": round(ms / nf, 4), "Gpixel/s": round(nf * w * h / ms / 1e6, 2)}), flush=True)
+    sys.exit(0)
 for nf in (1, 2, 4, 8, 16, 32, 64):
     batch = torch.randint(100, 140, (nf, h, w), dtype=torch.uint8, device=dev)
     dd = ded.repeat(nf, 1)
