@@ -492,6 +492,21 @@ def extras(torch, dev):
     out["h264_deblock_frame_4k"] = {"Mpixels/s": round(w * h / (per[32] * 1e-3) / 1e6, 1), "ms_per_frame_one_stream": round(ms, 4),
                                     "ms_per_frame_batch_of_8": round(per[8], 4), "ms_per_frame_batch_of_32": round(per[32], 4),
                                     "note": "decoder order (2-D wavefront inside a frame); a batch runs its frames side by side"}
+    # the same at 10 bits (uint16 samples, ffhip_h264_deblock_frames_dev_hbd): a lone plane and 32 in one launch
+    per10 = {}
+    for nfb in (1, 32):
+        batch = (torch.randint(100, 140, (nfb, h, w), dtype=torch.int32, device=dev) << 2).to(torch.int16)
+        dedn = ded.repeat(nfb, 1)
+        h264.deblock_frames_hbd(10, batch, 2 * w * h, nfb, 2 * w, mbw, mbh, dedn)
+        e0, e1 = ev(), ev()
+        e0.record()
+        h264.deblock_frames_hbd(10, batch, 2 * w * h, nfb, 2 * w, mbw, mbh, dedn)
+        e1.record()
+        torch.cuda.synchronize()
+        per10[nfb] = e0.elapsed_time(e1) / nfb
+        del batch, dedn
+    out["h264_deblock_frame_4k_10bit"] = {"Mpixels/s": round(w * h / (per10[32] * 1e-3) / 1e6, 1), "ms_per_frame_alone": round(per10[1], 4),
+                                          "ms_per_frame_batch_of_32": round(per10[32], 4)}
     del planes, ded
     # 15xM prime-factor MDCT, the CELT / AAC-960 frame size: inverse, len 960 (7,680 B moved per transform)
     nt, ln = 65536, 960

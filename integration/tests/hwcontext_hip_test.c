@@ -51,6 +51,7 @@ static AVFrame *host_frame(enum AVPixelFormat fmt, int w, int h)
 
 long ffhip_integration_hw_launches(void);
 long ffhip_integration_hw_refused(void);
+long ffhip_integration_device_intermediates(void);
 
 static void fill_frame(AVFrame *f, enum AVPixelFormat fmt, int w, int h, AVLFG *lfg)
 {
@@ -132,7 +133,7 @@ static int graph_main(int argc, char **argv)
         return 1;
     }
     if (ffhip_integration_hw_refused()) {
-        printf("REFUSED multi-pass conversion (host-memory intermediate): %s -> %s\n", argv[2], argv[3]);
+        printf("REFUSED a pass on a host pointer: %s -> %s\n", argv[2], argv[3]);
         return 3;
     }
     if (ffhip_integration_hw_launches() == before) {
@@ -148,8 +149,8 @@ static int graph_main(int argc, char **argv)
         fprintf(stderr, "FAIL %d rows differ from backend_c\n", bad);
         return 1;
     }
-    printf("PASS sws_scale_frame on hip frames: %s %dx%d -> %s %dx%d in HBM (%ld launches), bit-exact with backend_c\n", argv[2], sw, sh, argv[3], dw, dh,
-           ffhip_integration_hw_launches() - before);
+    printf("PASS sws_scale_frame on hip frames: %s %dx%d -> %s %dx%d in HBM (%ld launches, %ld intermediate planes in device memory), bit-exact with backend_c\n",
+           argv[2], sw, sh, argv[3], dw, dh, ffhip_integration_hw_launches() - before, ffhip_integration_device_intermediates());
     sws_free_context(&g);
     sws_free_context(&r);
     av_frame_free(&hs); av_frame_free(&hd); av_frame_free(&href); av_frame_free(&ds); av_frame_free(&dd);

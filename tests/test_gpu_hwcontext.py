@@ -36,6 +36,9 @@ def test_hwcontext_hip_frames_scaled_in_hbm(case):
 GRAPH_OK = [("rgb24", "bgr24", "640", "360"), ("rgba", "rgb24", "641", "359"), ("yuv444p", "rgb24", "640", "360"), ("rgb24", "yuv444p", "640", "360"),
             ("yuv444p10le", "yuv444p", "640", "360"), ("yuv444p", "yuv444p16le", "640", "360"), ("bgr0", "rgb24", "1920", "1080"),
             ("yuv444p", "yuv444p", "640", "360", "1280", "360"), ("yuv444p", "yuv444p", "640", "360", "640", "720")]
+#: two-dimensional scaling: two passes, the intermediate frame in device memory (integration/swscale_graph_hip.c)
+GRAPH_2D = [("yuv444p", "yuv444p", "640", "360", "960", "540"), ("yuv444p", "yuv444p", "1920", "1080", "1280", "720"), ("rgb24", "rgb24", "640", "360", "1280", "720"),
+            ("yuv444p", "rgb24", "640", "360", "800", "450"), ("yuv444p10le", "yuv444p10le", "640", "360", "1280", "720"), ("rgba", "bgr24", "641", "359", "320", "200")]
 
 
 @pytest.mark.gpu
@@ -53,14 +56,17 @@ def test_sws_scale_frame_on_hip_frames(case):
 
 
 @pytest.mark.gpu
-def test_sws_scale_frame_multi_pass_is_refused_not_faulted():
-    """Two-dimensional scaling is two passes with an intermediate frame the reference's graph allocates in host memory for every
-    device type but Vulkan (graph.c:130-175): the hip backend refuses the pass (exit 3, logged) instead of launching on a host
-    pointer."""
+@pytest.mark.parametrize("case", GRAPH_2D, ids=lambda c: "-".join(c))
+def test_sws_scale_frame_two_passes_on_hip_frames(case):
+    """Two-dimensional scaling is two passes with an intermediate frame pass_alloc_output() allocates (graph.c:130-175) — in host memory
+    for every device type but Vulkan; integration/swscale_graph_hip.c gives graphs between two hip frames a device-memory intermediate
+    (the branch pass_alloc_output_hw() is for Vulkan), so both passes run in HBM: == the same call on host frames with backend_c"""
     if not os.path.exists(EXE):
         pytest.skip("oracle/_ref/hwcontext_hip_test not built")
-    r = subprocess.run([EXE, "graph", "yuv444p", "yuv444p", "640", "360", "960", "540"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 3 and "REFUSED" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([EXE, "graph", *case], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS sws_scale_frame on hip frames" in r.stdout and "bit-exact with backend_c" in r.stdout
+    assert " 0 intermediate planes" not in r.stdout, r.stdout
 
 
 def test_hwcontext_hip_without_a_device_reports_it():
