@@ -10,4 +10,23 @@
 #include "libavutil/hwcontext.h"
 #include "avutil_hwcontext_hip.h"
 #define AV_HWDEVICE_TYPE_VULKAN FFHIP_HWDEVICE_TYPE
+/* ... and sws_scale_frame() itself notes, for the duration of the call, that it runs between two frames of the hip device: the graph
+ * it builds on this thread (integration/swscale_graph_hip.c) then routes the legacy scaler's passes to the device */
+#define sws_scale_frame ffhip_ref_sws_scale_frame
 #include "libswscale/swscale.c"
+#undef sws_scale_frame
+#undef AV_HWDEVICE_TYPE_VULKAN
+
+_Thread_local int ffhip_integration_hip_frames;
+
+int sws_scale_frame(SwsContext *sws, AVFrame *dst, const AVFrame *src);
+int sws_scale_frame(SwsContext *sws, AVFrame *dst, const AVFrame *src)
+{
+    const int prev = ffhip_integration_hip_frames;
+    int ret;
+    ffhip_integration_hip_frames = src && dst && src->hw_frames_ctx && dst->hw_frames_ctx && src->format == FFHIP_HW_PIX_FMT &&
+                                   dst->format == FFHIP_HW_PIX_FMT;
+    ret = ffhip_ref_sws_scale_frame(sws, dst, src);
+    ffhip_integration_hip_frames = prev;
+    return ret;
+}

@@ -52,6 +52,8 @@ static AVFrame *host_frame(enum AVPixelFormat fmt, int w, int h)
 long ffhip_integration_hw_launches(void);
 long ffhip_integration_hw_refused(void);
 long ffhip_integration_device_intermediates(void);
+long ffhip_integration_legacy_launches(void);
+long ffhip_integration_legacy_refused(void);
 
 static void fill_frame(AVFrame *f, enum AVPixelFormat fmt, int w, int h, AVLFG *lfg)
 {
@@ -122,21 +124,26 @@ static int graph_main(int argc, char **argv)
     CHECK(av_hwframe_get_buffer(sfc, ds, 0));
     CHECK(av_hwframe_get_buffer(dfc, dd, 0));
     CHECK(av_hwframe_transfer_data(ds, hs, 0));
-    g->flags = r->flags = SWS_BICUBIC | SWS_BITEXACT | SWS_ACCURATE_RND;
+    /* SWS_UNSTABLE: the op lists first (graph.c:727-754), the legacy scaler for what they do not take (subsampled formats) */
+    g->flags = r->flags = SWS_BICUBIC | SWS_BITEXACT | SWS_ACCURATE_RND | SWS_UNSTABLE;
     g->threads = r->threads = 1;
-    g->backends = SWS_BACKEND_C | 1 << 6; /* SWS_BACKEND_HIP; _C carries the format tests (the patch adds the new bit to
-                                           * SWS_BACKEND_UNSTABLE, format.c:602-609) and is never offered hardware frames */
-    r->backends = SWS_BACKEND_C;
-    before = ffhip_integration_hw_launches();
+    g->backends = SWS_BACKEND_LEGACY | SWS_BACKEND_C | 1 << 6; /* SWS_BACKEND_HIP; _C carries the format tests (the patch adds the new
+                                           * bit to SWS_BACKEND_UNSTABLE, format.c:602-609) and is never offered hardware frames */
+    r->backends = SWS_BACKEND_LEGACY | SWS_BACKEND_C;
+    before = ffhip_integration_hw_launches() + ffhip_integration_legacy_launches();
     if ((ret = sws_scale_frame(g, dd, ds)) < 0) {
         fprintf(stderr, "FAIL sws_scale_frame on hip frames: %d (%s)\n", ret, ffhip_last_error());
         return 1;
+    }
+    if (ffhip_integration_legacy_refused()) {
+        printf("REFUSED by libffhip's scaler: %s -> %s\n", argv[2], argv[3]);
+        return 3;
     }
     if (ffhip_integration_hw_refused()) {
         printf("REFUSED a pass on a host pointer: %s -> %s\n", argv[2], argv[3]);
         return 3;
     }
-    if (ffhip_integration_hw_launches() == before) {
+    if (ffhip_integration_hw_launches() + ffhip_integration_legacy_launches() == before) {
         fprintf(stderr, "FAIL the hip_hw backend did not run\n");
         return 1;
     }
@@ -149,8 +156,8 @@ static int graph_main(int argc, char **argv)
         fprintf(stderr, "FAIL %d rows differ from backend_c\n", bad);
         return 1;
     }
-    printf("PASS sws_scale_frame on hip frames: %s %dx%d -> %s %dx%d in HBM (%ld launches, %ld intermediate planes in device memory), bit-exact with backend_c\n",
-           argv[2], sw, sh, argv[3], dw, dh, ffhip_integration_hw_launches() - before, ffhip_integration_device_intermediates());
+    printf("PASS sws_scale_frame on hip frames: %s %dx%d -> %s %dx%d in HBM (%ld op-list launches, %ld legacy-scaler passes, %ld intermediate planes in device memory), bit-exact with backend_c\n",
+           argv[2], sw, sh, argv[3], dw, dh, ffhip_integration_hw_launches(), ffhip_integration_legacy_launches(), ffhip_integration_device_intermediates());
     sws_free_context(&g);
     sws_free_context(&r);
     av_frame_free(&hs); av_frame_free(&hd); av_frame_free(&href); av_frame_free(&ds); av_frame_free(&dd);

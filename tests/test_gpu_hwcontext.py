@@ -55,6 +55,36 @@ def test_sws_scale_frame_on_hip_frames(case):
     assert "PASS sws_scale_frame on hip frames" in r.stdout and "bit-exact with backend_c" in r.stdout
 
 
+#: subsampled formats: no op backend is offered those (format.c:560-600); the graph falls back to the legacy scaler, whose passes on hip
+#: frames run libffhip's scaler on the device pointers (integration/swscale_graph_hip.c)
+GRAPH_LEGACY = [("yuv420p", "yuv420p", "640", "360", "1280", "720"), ("nv12", "nv12", "1920", "1080", "3840", "2160"), ("nv12", "yuv420p", "640", "360", "320", "180"),
+                ("yuv420p", "rgb24", "640", "360", "1280", "720"), ("p010le", "p010le", "640", "360", "1280", "720"), ("yuv420p10le", "yuv420p10le", "1280", "720", "640", "360"),
+                ("nv12", "yuv420p", "640", "360"), ("yuv422p", "yuv420p", "640", "360", "800", "600"), ("yuv420p", "bgra", "642", "358", "1000", "500")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GRAPH_LEGACY, ids=lambda c: "-".join(c))
+def test_sws_scale_frame_subsampled_formats_on_hip_frames(case):
+    """sws_scale_frame() between two hip frames of subsampled formats — among them BASELINE's headline conversion, nv12 1080p -> 4K
+    bicubic: the reference's graph builds a legacy-scaler pass (add_legacy_sws_pass, graph.c:560-660) and its ff_swscale() call arrives
+    with device pointers at libffhip's scaler; == the same call on host frames (the reference's own ff_swscale), bit for bit"""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/hwcontext_hip_test not built")
+    r = subprocess.run([EXE, "graph", *case], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS sws_scale_frame on hip frames" in r.stdout and "bit-exact with backend_c" in r.stdout and " 1 legacy-scaler passes" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sws_scale_frame_refuses_what_libffhip_does_not_take():
+    """a conversion of hip frames the legacy device scaler does not take (gray8 here) is refused — logged, the test program exits 3 —
+    not run on device pointers by the reference's C code"""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/hwcontext_hip_test not built")
+    r = subprocess.run([EXE, "graph", "yuv420p", "yuv411p", "640", "360", "320", "180"], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (1, 3), r.stdout + r.stderr      # 1: the frames context refuses the format, 3: the scaler does
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", GRAPH_2D, ids=lambda c: "-".join(c))
 def test_sws_scale_frame_two_passes_on_hip_frames(case):
