@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "libavutil/frame.h"
 #include "libavutil/hwcontext.h"
@@ -158,6 +159,20 @@ static int graph_main(int argc, char **argv)
     }
     printf("PASS sws_scale_frame on hip frames: %s %dx%d -> %s %dx%d in HBM (%ld op-list launches, %ld legacy-scaler passes, %ld intermediate planes in device memory), bit-exact with backend_c\n",
            argv[2], sw, sh, argv[3], dw, dh, ffhip_integration_hw_launches(), ffhip_integration_legacy_launches(), ffhip_integration_device_intermediates());
+    if (getenv("HWTEST_REPEAT")) { /* the API-level rate: n sws_scale_frame() calls on the same two device frames, one launch each */
+        const int n = atoi(getenv("HWTEST_REPEAT"));
+        struct timespec t0, t1;
+        ffhip_stream_synchronize(NULL);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int i = 0; i < n; i++)
+            if (sws_scale_frame(g, dd, ds) < 0)
+                return 1;
+        ffhip_stream_synchronize(NULL);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double sec = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+        printf("RATE %d sws_scale_frame calls on hip frames: %.1f us per frame, %.1f frames/s, %.1f Mpixel/s out\n", n, 1e6 * sec / n, n / sec,
+               1e-6 * n / sec * dw * dh);
+    }
     sws_free_context(&g);
     sws_free_context(&r);
     av_frame_free(&hs); av_frame_free(&hd); av_frame_free(&href); av_frame_free(&ds); av_frame_free(&dd);
