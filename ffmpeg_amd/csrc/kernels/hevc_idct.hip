@@ -218,13 +218,23 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
         }
     }
     (void)cg;
-    if (dst && live && tu.dst_offset >= 0) {
-        const int16_t *r = mine + i * N;
-        int z[N];
+    if (dst) {
+        /* picture += residual, one row per lane.  Rows are handed out ROW-major over the wave's units (lane = row * UPW + unit): the
+         * units of a wave are usually neighbours in the picture, so consecutive lanes then touch consecutive pieces of one picture row
+         * (unit-major, lanes 0 .. N-1 walk down the N rows of one block: N short pieces of N different lines per N lanes) */
+        const int ul2 = UPW > 1 ? lane % UPW : 0, i2 = UPW > 1 ? lane / UPW : lane;
+        const int u2 = u0 + ul2;
+        if (u2 < n) {
+            const int32_t doff = UPW > 1 ? tus[u2].dst_offset : tu.dst_offset;
+            if (doff >= 0) {
+                const int16_t *r = blk + ul2 * N * N + i2 * N;
+                int z[N];
 #pragma unroll
-        for (int x = 0; x < N; x++)
-            z[x] = r[x];
-        ffhip_add_row<N>(dst + tu.dst_offset + (ptrdiff_t)i * stride, z, bd);
+                for (int x = 0; x < N; x++)
+                    z[x] = r[x];
+                ffhip_add_row<N>(dst + doff + (ptrdiff_t)i2 * stride, z, bd);
+            }
+        }
     }
 }
 
