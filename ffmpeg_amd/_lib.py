@@ -27,7 +27,8 @@ class SwsTables(C.Structure):
                [(k, C.c_int64) for k in ("yuv2rgb_cy", "yuv2rgb_oy", "yuv2rgb_crv", "yuv2rgb_cbu", "yuv2rgb_cgu",
                                          "yuv2rgb_cgv")] + [("yuv2rgb_yoffs", C.c_int)] + \
                [("src_range", C.c_int), ("dst_range", C.c_int), ("lumConvertRange_coeff", C.c_uint32), ("chrConvertRange_coeff", C.c_uint32),
-                ("lumConvertRange_offset", C.c_int64), ("chrConvertRange_offset", C.c_int64)]
+                ("lumConvertRange_offset", C.c_int64), ("chrConvertRange_offset", C.c_int64),
+                ("full_chr_h_int", C.c_int), ("yuv2rgb_full", C.c_int * 6)]
 
 
 _lib = None

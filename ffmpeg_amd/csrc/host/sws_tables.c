@@ -316,6 +316,13 @@ nomem:
 /* ITU-R BT.601 row of ff_yuv2rgb_coeffs[] == SWS_CS_DEFAULT (libswscale/yuv2rgb.c:47-59) */
 static const int32_t cs_default[4] = { 104597, 132201, 25675, 53279 };
 
+/* roundToInt16() (yuv2rgb.c:705-716) followed by the (int16_t) cast of its callers */
+static int round_to_int16(int64_t f)
+{
+    const int r = (int)((f + (1 << 15)) >> 16);
+    return r < -0x7FFF ? (int16_t)0x8000 : r > 0x7FFF ? 0x7FFF : r;
+}
+
 /* ff_yuv2rgb_c_init_tables() for bpp 24, limited-range source, neutral brightness/contrast/saturation */
 void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange)
 {
@@ -338,6 +345,13 @@ void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange)
     t->yuv2rgb_cgu = ((cgu * (1 << 16)) + 0x8000) / cy;
     t->yuv2rgb_cgv = ((cgv * (1 << 16)) + 0x8000) / cy;
     t->yuv2rgb_yoffs = (fullRange ? 384 : 326) + 512; /* + YUVRGB_TABLE_LUMA_HEADROOM */
+    /* the full-chroma writers' int16 coefficients (yuv2rgb.c:786-791), from the values BEFORE the division by cy */
+    t->yuv2rgb_full[0] = round_to_int16(cy * (1 << 13));
+    t->yuv2rgb_full[1] = round_to_int16(oy * (1 << 9));
+    t->yuv2rgb_full[2] = round_to_int16(crv * (1 << 13));
+    t->yuv2rgb_full[3] = round_to_int16(cgv * (1 << 13));
+    t->yuv2rgb_full[4] = round_to_int16(cgu * (1 << 13));
+    t->yuv2rgb_full[5] = round_to_int16(cbu * (1 << 13));
 }
 
 struct FFHipSwsHostTables {
@@ -434,7 +448,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
                                             int dstFormat, int flags)
 {
     FFHipSwsHostTables *h;
-    int chrSrcW, chrSrcH, chrDstW, chrDstH, chrDstHSub, chrDstVSub;
+    int chrSrcW, chrSrcH, chrDstW, chrDstH, chrDstHSub, chrDstVSub, full_chr;
     int64_t lumXInc, lumYInc, chrXInc, chrYInc;
     int lum_scaler = scaler_of(flags, 0), chr_scaler = scaler_of(flags, 1);
     int r, src_range = 0, dst_range = 0;
@@ -490,22 +504,18 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
 
     /* RGB output without SWS_FULL_CHR_H_INT keeps chroma at half horizontal resolution
      * (utils.c:1359-1360) and full vertical resolution */
-    chrDstHSub = is_rgb(dstFormat) ? 1 : chroma_hsub(dstFormat);
+    /* SWS_FULL_CHR_H_INT (utils.c:1270-1290): asked for, or forced on a packed RGB target by an odd width or by a source without chroma
+     * sub-sampling (unless SWS_FAST_BILINEAR) — chroma then keeps full horizontal resolution and the yuv2rgb_full_* writers run */
+    full_chr = is_rgb(dstFormat) && ((flags & FFHIP_SWS_FULL_CHR_H_INT) || (dstW & 1) ||
+                                     (chroma_hsub(srcFormat) == 0 && chroma_vsub(srcFormat) == 0 && !(flags & FFHIP_SWS_FAST_BILINEAR)));
+    h->t.full_chr_h_int = full_chr;
+    if (full_chr)
+        h->t.flags |= FFHIP_SWS_FULL_CHR_H_INT;
+    /* RGB output without SWS_FULL_CHR_H_INT keeps chroma at half horizontal resolution (utils.c:1359-1360); full vertical resolution
+     * either way.  4:2:2 sources: the chroma banks run from the source's own chroma plane size (chrSrcHSubSample stays the format's for
+     * YUV sources: the "drop every other pixel" of utils.c:1368-1392 is for RGB sources) */
+    chrDstHSub = is_rgb(dstFormat) ? (full_chr ? 0 : 1) : chroma_hsub(dstFormat);
     chrDstVSub = is_rgb(dstFormat) ? 0 : chroma_vsub(dstFormat);
-    /* 4:2:2 sources to packed RGB: the chroma banks run from the source's own chroma plane size to dstW / 2 x dstH (chrSrcHSubSample
-     * stays the format's for YUV sources: the "drop every other pixel" of utils.c:1368-1392 is for RGB sources).  4:4:4 sources make
-     * the reference switch SWS_FULL_CHR_H_INT on ("input having non subsampled chroma", utils.c:1276-1285): the yuv2rgb_full_* writers,
-     * another arithmetic (coefficients instead of the tables, error-diffusion dither) that is not on this path */
-    if (is_rgb(dstFormat) && chroma_hsub(srcFormat) == 0 && chroma_vsub(srcFormat) == 0) {
-        ffhip_set_error("ffhip_sws: 4:4:4 sources to packed RGB take the reference's full-chroma writers; not on the hip path");
-        free(h);
-        return NULL;
-    }
-    if (is_rgb(dstFormat) && (dstW & 1)) {
-        ffhip_set_error("ffhip_sws: odd RGB width forces SWS_FULL_CHR_H_INT in the reference; not on this path");
-        free(h);
-        return NULL;
-    }
     chrSrcW = ceil_rshift(srcW, chroma_hsub(srcFormat));
     chrSrcH = ceil_rshift(srcH, chroma_vsub(srcFormat));
     chrDstW = ceil_rshift(dstW, chrDstHSub);

@@ -187,6 +187,8 @@ struct FFHipScaleRgbArgs {
     int tiles_x, tiles_y;
     int bgr;
     FFHipYuv2RgbK k;
+    int full;           /* SWS_FULL_CHR_H_INT: hc has dstW entries, the yuv2rgb_full_* writers with fk[] (FFHipSwsTables.yuv2rgb_full) */
+    int fk[6];
 };
 int ffhip_launch_scale_rgb(const FFHipScaleRgbArgs &a, hipStream_t stream);
 int ffhip_plan_scale_rgb(FFHipScaleRgbArgs *a, const int32_t *hl, const int32_t *hc, const int32_t *vl,

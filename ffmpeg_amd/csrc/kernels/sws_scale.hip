@@ -394,14 +394,15 @@ int ffhip_launch_scale_yuv(const FFHipScalePlaneArgs &lum, const FFHipScalePlane
  * utils.c:1359-1360) and full vertical resolution; U,V are clamped to [0,255] exactly as the
  * tables' headroom does (fill_table, yuv2rgb.c:688-690), Y is not.
  */
-template <int HFS>
+template <int HFS, bool FULL = false>
 __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitch_l, int spitch_c, int off_sc, int off_hl,
                                                   int off_hc, int flags)
 {
     extern __shared__ __align__(16) uint8_t lds[];
     const int x0 = blockIdx.x * a.tw, y0 = blockIdx.y * a.th, f = blockIdx.z;
     const int tw = min(a.tw, a.dstW - x0), th = min(a.th, a.dstH - y0);
-    const int twc_full = a.tw >> 1, xc0 = x0 >> 1, twc = (tw + 1) >> 1;
+    /* FULL (SWS_FULL_CHR_H_INT): a chroma sample per pixel */
+    const int twc_full = FULL ? a.tw : a.tw >> 1, xc0 = FULL ? x0 : x0 >> 1, twc = FULL ? tw : (tw + 1) >> 1;
     const int tid = threadIdx.x;
     const int lfs = a.vl.size, cfs = a.vc.size;
 
@@ -429,8 +430,75 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
     const int xq = 4 * q;
     if (xq >= tw)
         return;
-    const int npx = min(4, tw - xq) & ~1; /* RGB widths are even on this path */
+    const int npx = FULL ? min(4, tw - xq) : min(4, tw - xq) & ~1; /* without full chroma RGB widths are even */
     const FFHipYuv2RgbK k = a.k;
+    if (FULL) {
+        /* yuv2rgb_full_{1,2,X}_c_template + yuv2rgb_write_full (libswscale/output.c:1998-2310): packed_vscale()'s dispatch as below,
+         * Y / U / V in the writers' scale (the vertical sum >> 10), R = Y' + V v2r ... in 32-bit wrapping arithmetic, clipped to 30
+         * bits, >> 22 */
+        const int lay = a.bgr, bp = lay < 2 ? 3 : 4;
+        for (int y = rsub; y < th; y += nsub) {
+            const int lr = a.vl.pos[y0 + y] - r0_l, cr = a.vc.pos[y0 + y] - r0_c;
+            const uint16_t *lf = reinterpret_cast<const uint16_t *>(a.vl.filter) + (size_t)(y0 + y) * lfs;
+            const uint16_t *cf = reinterpret_cast<const uint16_t *>(a.vc.filter) + (size_t)(y0 + y) * cfs;
+            const int16_t *lcol = hs_l + lr * a.tw + xq;
+            const int16_t *ucol = hs_c + (0 * a.max_rows_c + cr) * twc_full + xq;
+            const int16_t *vcol = hs_c + (1 * a.max_rows_c + cr) * twc_full + xq;
+            const bool chr_bilin = cfs == 2 && (int)cf[0] + (int)cf[1] == 4096 && cf[1] <= 4096u;
+            const bool lum_bilin = lfs == 2 && (int)lf[0] + (int)lf[1] == 4096 && lf[1] <= 4096u;
+            uint8_t px[16];
+            for (int i = 0; i < npx; i++) {
+                int Y, U, V;
+                if (lfs == 1 && (cfs == 1 || chr_bilin)) {
+                    Y = lcol[i] * 4;
+                    if (cfs == 1 || cf[1] == 0) {
+                        U = (ucol[i] - (128 << 7)) * 4;
+                        V = (vcol[i] - (128 << 7)) * 4;
+                    } else {
+                        const int al = cf[1], al1 = 4096 - al;
+                        U = (ucol[i] * al1 + ucol[i + twc_full] * al - (128 << 19)) >> 10;
+                        V = (vcol[i] * al1 + vcol[i + twc_full] * al - (128 << 19)) >> 10;
+                    }
+                } else if (lum_bilin && chr_bilin) {
+                    const int ya = lf[1], ya1 = 4096 - ya, ua = cf[1], ua1 = 4096 - ua;
+                    Y = (lcol[i] * ya1 + lcol[i + a.tw] * ya) >> 10;
+                    U = (ucol[i] * ua1 + ucol[i + twc_full] * ua - (128 << 19)) >> 10;
+                    V = (vcol[i] * ua1 + vcol[i + twc_full] * ua - (128 << 19)) >> 10;
+                } else {
+                    uint32_t ay = 1u << 9, au = (1u << 9) - (128u << 19), av = (1u << 9) - (128u << 19);
+                    for (int j = 0; j < lfs; j++)
+                        ay += (uint32_t)((int)lcol[i + j * a.tw] * (int)(int16_t)lf[j]);
+                    for (int j = 0; j < cfs; j++) {
+                        const int c = (int16_t)cf[j];
+                        au += (uint32_t)((int)ucol[i + j * twc_full] * c);
+                        av += (uint32_t)((int)vcol[i + j * twc_full] * c);
+                    }
+                    Y = (int32_t)ay >> 10; U = (int32_t)au >> 10; V = (int32_t)av >> 10;
+                }
+                const uint32_t yy = (uint32_t)(Y - a.fk[1]) * (uint32_t)a.fk[0] + (1u << 21);
+                int R = (int)(yy + (uint32_t)V * (uint32_t)a.fk[2]);
+                int G = (int)(yy + (uint32_t)V * (uint32_t)a.fk[3] + (uint32_t)U * (uint32_t)a.fk[4]);
+                int B = (int)(yy + (uint32_t)U * (uint32_t)a.fk[5]);
+                R = min(max(R, 0), (1 << 30) - 1);      /* av_clip_uintp2(., 30), a no-op when the top two bits are clear */
+                G = min(max(G, 0), (1 << 30) - 1);
+                B = min(max(B, 0), (1 << 30) - 1);
+                const uint8_t r = (uint8_t)(R >> 22), g = (uint8_t)(G >> 22), b = (uint8_t)(B >> 22);
+                uint8_t *q = px + bp * i;
+                switch (lay) {
+                case 0: q[0] = r; q[1] = g; q[2] = b; break;
+                case 1: q[0] = b; q[1] = g; q[2] = r; break;
+                case 2: q[0] = 255; q[1] = r; q[2] = g; q[3] = b; break;
+                case 3: q[0] = r; q[1] = g; q[2] = b; q[3] = 255; break;
+                case 4: q[0] = 255; q[1] = b; q[2] = g; q[3] = r; break;
+                default: q[0] = b; q[1] = g; q[2] = r; q[3] = 255; break;
+                }
+            }
+            uint8_t *d = a.dst + (size_t)f * a.dst_fp + (ptrdiff_t)(y0 + y) * a.dst_stride + bp * (x0 + xq);
+            for (int i = 0; i < bp * npx; i++)
+                d[i] = px[i];
+        }
+        return;
+    }
     for (int y = rsub; y < th; y += nsub) {
         const int lr = a.vl.pos[y0 + y] - r0_l, cr = a.vc.pos[y0 + y] - r0_c;
         const uint16_t *lf = reinterpret_cast<const uint16_t *>(a.vl.filter) + (size_t)(y0 + y) * lfs;
@@ -538,7 +606,7 @@ static size_t rgb_lds(const FFHipScaleRgbArgs &a, int *spl, int *spc, int *osc, 
     s = (s + 15) & ~(size_t)15; *ohl = (int)s;
     s += (size_t)a.max_rows_l * a.tw * 2;
     s = (s + 15) & ~(size_t)15; *ohc = (int)s;
-    s += (size_t)2 * a.max_rows_c * (a.tw >> 1) * 2;
+    s += (size_t)2 * a.max_rows_c * (a.full ? a.tw : a.tw >> 1) * 2;
     return s + 16;
 }
 
@@ -555,7 +623,7 @@ int ffhip_plan_scale_rgb(FFHipScaleRgbArgs *a, const int32_t *hl, const int32_t 
             for (int x0 = 0; x0 < a->dstW; x0 += tw) {
                 int xe = x0 + tw < a->dstW ? x0 + tw : a->dstW;
                 int n = hl[xe - 1] + a->hl.size - (hl[x0] & ~3);
-                int ce = (xe + 1) >> 1, c0 = x0 >> 1;
+                int ce = a->full ? xe : (xe + 1) >> 1, c0 = a->full ? x0 : x0 >> 1;
                 int m = hc[ce - 1] + a->hc.size - (hc[c0] & ~3);
                 if (n > mcl) mcl = n;
                 if (m > mcc) mcc = m;
@@ -598,7 +666,12 @@ int ffhip_launch_scale_rgb(const FFHipScaleRgbArgs &a, hipStream_t stream)
     if (!(((uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp) & 3))
         flags |= 4;
     const dim3 grid(a.tiles_x, a.tiles_y, a.nframes), block(NT);
-    if (a.hl.size == 4 && a.hc.size == 4)
+    if (a.full) {
+        if (a.hl.size == 4 && a.hc.size == 4)
+            hipLaunchKernelGGL((k_scale_rgb<4, true>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags);
+        else
+            hipLaunchKernelGGL((k_scale_rgb<0, true>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags);
+    } else if (a.hl.size == 4 && a.hc.size == 4)
         hipLaunchKernelGGL((k_scale_rgb<4>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags);
     else
         hipLaunchKernelGGL((k_scale_rgb<0>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags);

@@ -359,12 +359,16 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         ffhip_set_error("ffhip_sws: unsupported format pair");
         return nullptr;
     }
-    if (fmt_rgb(t->dstFormat) && (t->dstW & 1)) {
-        ffhip_set_error("ffhip_sws: odd RGB width is not on the hip path");
+    /* an odd RGB width and a 4:4:4 source force SWS_FULL_CHR_H_INT in the reference (utils.c:1270-1290): the tables must say so */
+    if (fmt_rgb(t->dstFormat) && !t->full_chr_h_int &&
+        ((t->dstW & 1) || (fmt_hsub(t->srcFormat) == 0 && fmt_vsub(t->srcFormat) == 0 && !(t->flags & FFHIP_SWS_FAST_BILINEAR)))) {
+        ffhip_set_error("ffhip_sws: an odd RGB width / a 4:4:4 source to packed RGB runs with SWS_FULL_CHR_H_INT in the reference: "
+                        "FFHipSwsTables.full_chr_h_int and .yuv2rgb_full must be set");
         return nullptr;
     }
-    if (fmt_rgb(t->dstFormat) && fmt_hsub(t->srcFormat) == 0 && fmt_vsub(t->srcFormat) == 0) {
-        ffhip_set_error("ffhip_sws: 4:4:4 sources to packed RGB take the reference's full-chroma writers; not on the hip path");
+    if (t->full_chr_h_int && t->srcW == t->dstW && t->srcH == t->dstH && t->srcFormat == FFHIP_PIX_FMT_YUV420P && fmt_rgb(t->dstFormat) &&
+        !(t->flags & FFHIP_SWS_ACCURATE_RND) && !(t->dstH & 1) && (t->dstW & 1)) {
+        ffhip_set_error("ffhip_sws: equal-size yuv420p to an odd-width packed RGB target is the table converter's tail case; not on the hip path");
         return nullptr;
     }
     /* (a packed RGB target takes the source's range through the yuv2rgb coefficients the caller hands over: ff_yuv2rgb_c_init_tables'
@@ -499,7 +503,10 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         a.hl = c->d[0]; a.hc = c->d[1]; a.vl = c->d[2]; a.vc = c->d[3];
         a.bgr = rgb_layout(t->dstFormat);
         a.k = c->k;
-        if (a.vc.n != t->dstH || a.hc.n != (t->dstW + 1) / 2) {
+        a.full = t->full_chr_h_int != 0; /* SWS_FULL_CHR_H_INT: a chroma sample per pixel, the yuv2rgb_full_* writers */
+        for (int i = 0; i < 6; i++)
+            a.fk[i] = t->yuv2rgb_full[i];
+        if (a.vc.n != t->dstH || a.hc.n != (a.full ? t->dstW : (t->dstW + 1) / 2)) {
             ffhip_set_error("ffhip_sws: chroma banks do not match a packed-RGB target (need chrDstH == dstH)");
             ffhip_sws_freeContext(c);
             return nullptr;
@@ -507,7 +514,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         r = ffhip_plan_scale_rgb(&a, c->p[0].data(), c->p[1].data(), c->p[2].data(), c->p[3].data());
         /* column walker with RGB output: 4-tap vertical banks (yuv2rgb_X), <= 4-tap horizontal banks, no int16 wrap */
         const int limits[4] = { a.srcW, a.chrSrcW, a.srcH, a.chrSrcH };
-        if (!r && !(t->dstW & 7) && build_fast_view(c, limits, true))
+        if (!r && !a.full && !(t->dstW & 7) && build_fast_view(c, limits, true))
             c->cw_rgb = ffhip_cw_bank_ok(c->np[0].data(), 4, c->d[0].n, a.srcW, c->np[2].data(), 4, c->d[2].n, a.srcH) &&
                         ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, a.chrSrcW, c->np[3].data(), 4, c->d[3].n, a.chrSrcH) &&
                         c->d[1].n * 2 == t->dstW && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&

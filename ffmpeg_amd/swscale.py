@@ -85,6 +85,10 @@ class HostTables:
         return dict(cy=t.yuv2rgb_cy, oy=t.yuv2rgb_oy, crv=t.yuv2rgb_crv, cbu=t.yuv2rgb_cbu, cgu=t.yuv2rgb_cgu,
                     cgv=t.yuv2rgb_cgv, yoffs=t.yuv2rgb_yoffs)
 
+    def full(self):
+        """the six coefficients of the full-chroma RGB writers when SWS_FULL_CHR_H_INT is in effect for this conversion, else None"""
+        return [int(v) for v in self.t.yuv2rgb_full] if self.t.full_chr_h_int else None
+
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.lib().ffhip_sws_tables_free(self._h)

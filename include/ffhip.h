@@ -122,7 +122,7 @@ int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t 
 #define FFHIP_PIX_FMT_RGB24   2
 #define FFHIP_PIX_FMT_BGR24   3
 #define FFHIP_PIX_FMT_YUV422P 4    /* planar 4:2:2 and 4:4:4, 8 bits (== AV_PIX_FMT_YUV422P / _YUV444P): sources and targets of the scaler;
-                                    * as sources they go to YUV targets only (packed RGB takes the 4:2:0 sources) */
+                                    * to packed RGB 4:4:4 sources run with SWS_FULL_CHR_H_INT, as in the reference (utils.c:1276-1285) */
 #define FFHIP_PIX_FMT_YUV444P 5
 #define FFHIP_PIX_FMT_YUVJ420P 12  /* the full-range "J" twins (== AV_PIX_FMT_YUVJ420P / 422P / 444P): taken when BOTH sides are J formats —
                                     * equal ranges need no range conversion, the conversion is the base formats' (handle_jpeg(),
@@ -160,6 +160,7 @@ int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t 
 #define FFHIP_PIX_FMT_ABGR    27
 #define FFHIP_PIX_FMT_BGRA    28
 /* Flags: numeric values are SwsFlags' (libswscale/swscale.h:130-153). */
+#define FFHIP_SWS_FULL_CHR_H_INT 0x2000 /* full chroma interpolation for packed RGB targets (swscale.h:147) */
 #define FFHIP_SWS_FAST_BILINEAR 0x1
 #define FFHIP_SWS_BILINEAR      0x2
 #define FFHIP_SWS_BICUBIC       0x4
@@ -204,6 +205,11 @@ typedef struct FFHipSwsTables {
     int      src_range, dst_range;
     uint32_t lumConvertRange_coeff, chrConvertRange_coeff;
     int64_t  lumConvertRange_offset, chrConvertRange_offset;
+    /* SWS_FULL_CHR_H_INT on a packed RGB target — asked for, or forced by an odd width or a 4:4:4 source (libswscale/utils.c:1270-1290):
+     * hChr has dstW entries and the yuv2rgb_full_{1,2,X} writers run (output.c:1998-2310) with c->yuv2rgb_{y_coeff, y_offset,
+     * v2r_coeff, v2g_coeff, u2g_coeff, u2b_coeff} (yuv2rgb.c:786-791), in this order */
+    int      full_chr_h_int;
+    int      yuv2rgb_full[6];
 } FFHipSwsTables;
 
 typedef struct FFHipSwsContext FFHipSwsContext;

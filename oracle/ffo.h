@@ -48,6 +48,11 @@ typedef struct FfoSwsTables {
     int src_range, dst_range;
     uint32_t lum_rc_coeff, chr_rc_coeff;
     int64_t lum_rc_offset, chr_rc_offset;
+    /* SWS_FULL_CHR_H_INT on a packed RGB target (utils.c:1270-1290: asked for, or forced by an odd width or a 4:4:4 source): chroma at
+     * full horizontal resolution (hChr.n == dstW) and the yuv2rgb_full_{1,2,X} writers (output.c:1998-2310), whose six int16
+     * coefficients are c->yuv2rgb_{y_coeff, y_offset, v2r_coeff, v2g_coeff, u2g_coeff, u2b_coeff} (yuv2rgb.c:786-791) */
+    int full_chr;
+    int full_coef[6];
 } FfoSwsTables;
 /* init_range_convert_constants() for a source of range src_range (1 = full) going to the other one at a target of dst_depth bits */
 void ffo_sws_range_constants(int src_range, int dst_depth, uint32_t *lum_coeff, int64_t *lum_offset, uint32_t *chr_coeff, int64_t *chr_offset);

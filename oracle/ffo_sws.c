@@ -200,6 +200,62 @@ static void rgb24_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *
 }
 
 /* the three packed-output members, one line (yuv2packedX / yuv2packed2 / yuv2packed1 of a packed-RGB context) */
+/* yuv2rgb_write_full (libswscale/output.c:1998-2051) for the 24- and 32-bit layouts: Y, U, V in the writers' 10-bit-shifted scale */
+static void put_rgb_full(uint8_t *d, const int *k, int Y, int U, int V, int bgr)
+{
+    uint32_t y = (uint32_t)(Y - k[1]) * (uint32_t)k[0] + (1U << 21);
+    int R = (int)(y + (uint32_t)V * (uint32_t)k[2]);
+    int G = (int)(y + (uint32_t)V * (uint32_t)k[3] + (uint32_t)U * (uint32_t)k[4]);
+    int B = (int)(y + (uint32_t)U * (uint32_t)k[5]);
+    if ((R | G | B) & 0xC0000000) { /* av_clip_uintp2(., 30) */
+        R = R & ~((1 << 30) - 1) ? (~R >> 31) & ((1 << 30) - 1) : R;
+        G = G & ~((1 << 30) - 1) ? (~G >> 31) & ((1 << 30) - 1) : G;
+        B = B & ~((1 << 30) - 1) ? (~B >> 31) & ((1 << 30) - 1) : B;
+    }
+    const uint8_t r = (uint8_t)(R >> 22), g = (uint8_t)(G >> 22), b = (uint8_t)(B >> 22);
+    switch (bgr) {
+    case 0: d[0] = r; d[1] = g; d[2] = b; break;
+    case 1: d[0] = b; d[1] = g; d[2] = r; break;
+    case 2: d[0] = 255; d[1] = r; d[2] = g; d[3] = b; break;
+    case 3: d[0] = r; d[1] = g; d[2] = b; d[3] = 255; break;
+    case 4: d[0] = 255; d[1] = b; d[2] = g; d[3] = r; break;
+    default: d[0] = b; d[1] = g; d[2] = r; d[3] = 255; break;
+    }
+}
+/* one line of yuv2rgb_full_X / _2 / _1 (output.c:2160-2310): a chroma sample per pixel; mode 0: X, 1: the two-row blend (yalpha,
+ * uvalpha), 2: one luma row (uvalpha 0: one chroma row, else the blend) */
+static void rgb_full_line(const int *k, int mode, const int16_t *lf, const int16_t *const *lum, int lfs, const int16_t *cf,
+                          const int16_t *const *cu, const int16_t *const *cv, int cfs, int yalpha, int uvalpha, uint8_t *dest, int dstW, int bgr)
+{
+    for (int i = 0; i < dstW; i++) {
+        int Y, U, V;
+        if (mode == 0) {
+            uint32_t y = 1 << 9, u = (1 << 9) - (128 << 19), v = (1 << 9) - (128 << 19);
+            for (int j = 0; j < lfs; j++)
+                y += (uint32_t)(lum[j][i] * (int)lf[j]);
+            for (int j = 0; j < cfs; j++) {
+                u += (uint32_t)(cu[j][i] * (int)cf[j]);
+                v += (uint32_t)(cv[j][i] * (int)cf[j]);
+            }
+            Y = (int32_t)y >> 10; U = (int32_t)u >> 10; V = (int32_t)v >> 10;
+        } else if (mode == 1) {
+            Y = (lum[0][i] * (4096 - yalpha) + lum[1][i] * yalpha) >> 10;
+            U = (cu[0][i] * (4096 - uvalpha) + cu[1][i] * uvalpha - (128 << 19)) >> 10;
+            V = (cv[0][i] * (4096 - uvalpha) + cv[1][i] * uvalpha - (128 << 19)) >> 10;
+        } else {
+            Y = lum[0][i] * 4;
+            if (!uvalpha) {
+                U = (cu[0][i] - (128 << 7)) * 4;
+                V = (cv[0][i] - (128 << 7)) * 4;
+            } else {
+                U = (cu[0][i] * (4096 - uvalpha) + cu[1][i] * uvalpha - (128 << 19)) >> 10;
+                V = (cv[0][i] * (4096 - uvalpha) + cv[1][i] * uvalpha - (128 << 19)) >> 10;
+            }
+        }
+        put_rgb_full(dest + px_bytes(bgr) * i, k, Y, U, V, bgr);
+    }
+}
+
 void ffo_yuv2rgb_X(const FfoYuv2RgbLuts *l, const int16_t *lf, const int16_t *const *lum, int lfs, const int16_t *cf,
                    const int16_t *const *cu, const int16_t *const *cv, int cfs, uint8_t *dest, int dstW, int layout)
 {
@@ -344,7 +400,16 @@ int ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], cons
                 ur[j] = hu + (size_t)(t->vChr.pos[y] + j) * cpitch;
                 vr[j] = hv + (size_t)(t->vChr.pos[y] + j) * cpitch;
             }
-            if (lfs == 1 && cfs == 1) {
+            if (t->full_chr) { /* the same dispatch of packed_vscale() (vscale.c:126-170) over the full-chroma writers */
+                if (lfs == 1 && cfs == 1)
+                    rgb_full_line(t->full_coef, 2, NULL, lr, 1, NULL, ur, vr, 1, 0, 0, d, dstW, bgr);
+                else if (lfs == 1 && cfs == 2 && cf[1] + cf[0] == 4096 && cf[1] <= 4096U)
+                    rgb_full_line(t->full_coef, 2, NULL, lr, 1, NULL, ur, vr, 2, 0, cf[1], d, dstW, bgr);
+                else if (lfs == 2 && cfs == 2 && lf[1] + lf[0] == 4096 && lf[1] <= 4096U && cf[1] + cf[0] == 4096 && cf[1] <= 4096U)
+                    rgb_full_line(t->full_coef, 1, NULL, lr, 2, NULL, ur, vr, 2, lf[1], cf[1], d, dstW, bgr);
+                else
+                    rgb_full_line(t->full_coef, 0, (const int16_t *)lf, lr, lfs, (const int16_t *)cf, ur, vr, cfs, 0, 0, d, dstW, bgr);
+            } else if (lfs == 1 && cfs == 1) {
                 rgb24_1(luts, lr[0], ur, vr, d, dstW, 0, bgr);
             } else if (lfs == 1 && cfs == 2 && cf[1] + cf[0] == 4096 && cf[1] <= 4096U) {
                 rgb24_1(luts, lr[0], ur, vr, d, dstW, cf[1], bgr);

@@ -23,6 +23,8 @@ int   ffref_sws_scale(void *ctx, const uint8_t *const src[], const int srcStride
 int   ffref_sws_filter(void *ctx, int which, const int16_t **filter, const int32_t **pos, int *n);
 /* 1 when the context installed a convert_unscaled special converter */
 int   ffref_sws_is_unscaled(void *ctx);
+int   ffref_sws_flags(void *ctx);
+void  ffref_sws_full_coeffs(void *ctx, int out[6]);
 /* the four (already divided) yuv2rgb table coefficients + y terms the context derived */
 void  ffref_sws_yuv2rgb_tables(void *ctx, const uint8_t **rV, const int **gU, const int **gV, const uint8_t **bU);
 int   ffref_pix_fmt(const char *name);

@@ -93,6 +93,15 @@ int ffref_sws_filter(void *ctx, int which, const int16_t **filter, const int32_t
     return -1;
 }
 int ffref_sws_is_unscaled(void *ctx) { return inner(ctx)->convert_unscaled != NULL; }
+/* the flags the context ended up with (SWS_FULL_CHR_H_INT may have been forced, utils.c:1270-1290) and the six coefficients of the
+ * full-chroma writers (yuv2rgb.c:786-791) */
+int ffref_sws_flags(void *ctx) { return (int)((SwsContext *)ctx)->flags; }
+void ffref_sws_full_coeffs(void *ctx, int out[6])
+{
+    SwsInternal *c = inner(ctx);
+    out[0] = c->yuv2rgb_y_coeff;   out[1] = c->yuv2rgb_y_offset;  out[2] = c->yuv2rgb_v2r_coeff;
+    out[3] = c->yuv2rgb_v2g_coeff; out[4] = c->yuv2rgb_u2g_coeff; out[5] = c->yuv2rgb_u2b_coeff;
+}
 void ffref_sws_yuv2rgb_tables(void *ctx, const uint8_t **rV, const int **gU, const int **gV, const uint8_t **bU)
 {
     SwsInternal *c = inner(ctx);

@@ -41,7 +41,7 @@ class OSwsTables(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("srcW", "srcH", "srcFormat", "dstW", "dstH", "dstFormat", "flags")] + \
                [(k, OSwsFilter) for k in ("hLum", "hChr", "vLum", "vChr")] + [("k", OYuv2RgbCoeffs)] + \
                [("src_range", C.c_int), ("dst_range", C.c_int), ("lum_rc_coeff", C.c_uint32), ("chr_rc_coeff", C.c_uint32),
-                ("lum_rc_offset", C.c_int64), ("chr_rc_offset", C.c_int64)]
+                ("lum_rc_offset", C.c_int64), ("chr_rc_offset", C.c_int64), ("full_chr", C.c_int), ("full_coef", C.c_int * 6)]
 
 
 class OLuts(C.Structure):
@@ -281,6 +281,8 @@ def ref():
                 f.restype = None
         L.ffref_sws_filter.argtypes = [C.c_void_p, C.c_int, C.POINTER(i16p), C.POINTER(i32p), C.POINTER(C.c_int)]
         L.ffref_sws_is_unscaled.argtypes = [C.c_void_p]
+        L.ffref_sws_flags.argtypes = [C.c_void_p]
+        L.ffref_sws_full_coeffs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ffref_sws_hyscale.argtypes = [C.c_void_p, i16p, C.c_int, u8p, i16p, i32p, C.c_int]
         L.ffref_sws_hyscale.restype = None
         L.ffref_sws_yuv2planeX.argtypes = [C.c_void_p, i16p, C.c_int, C.POINTER(i16p), u8p, C.c_int, u8p, C.c_int]
@@ -451,10 +453,13 @@ def ref_tables(ctx):
 DEFAULT_COEFFS = dict(cy=76309, oy=16 << 16, crv=89830, cbu=113537, cgu=-22049, cgv=-45756, yoffs=838)
 
 
-def make_otables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, banks, coeffs=DEFAULT_COEFFS, ranges=None, dst_depth=8):
+def make_otables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, banks, coeffs=DEFAULT_COEFFS, ranges=None, dst_depth=8, full=None):
     """banks: dict name -> (filter int16[], pos int32[], size, n).  Keeps numpy refs alive on the struct.
     ranges = (src_range, dst_range): the oracle derives the conversion constants itself (ffo_sws_range_constants)."""
     t = OSwsTables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags)
+    if full is not None:     # the six coefficients of the full-chroma RGB writers
+        t.full_chr = 1
+        t.full_coef = (C.c_int * 6)(*[int(v) for v in full])
     if ranges is not None and ranges[0] != ranges[1]:
         t.src_range, t.dst_range = ranges
         lc, cc, lo, co = C.c_uint32(), C.c_uint32(), C.c_int64(), C.c_int64()

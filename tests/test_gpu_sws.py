@@ -123,6 +123,20 @@ SCALE_CASES = [
     ("yuv422p", 352, 288, "argb", 120, 90, ffi.SWS_BILINEAR, 3),
     ("yuv422p", 1920, 1080, "rgb24", 1920, 1080, ffi.SWS_BICUBIC, 0),
     ("yuv422p", 960, 540, "bgr24", 1920, 1080, ffi.SWS_BICUBIC, 0),
+    # SWS_FULL_CHR_H_INT (0x2000) on packed RGB targets: asked for, or forced by a 4:4:4 source or an odd width (utils.c:1270-1290):
+    # a chroma sample per pixel and the yuv2rgb_full_{1,2,X} writers (output.c:1998-2310)
+    ("yuv444p", 64, 36, "rgb24", 128, 72, ffi.SWS_BICUBIC, 0),
+    ("yuv444p", 97, 53, "bgr24", 60, 41, ffi.SWS_BICUBIC, 3),
+    ("yuv444p", 40, 30, "rgba", 40, 30, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
+    ("yuv420p", 64, 36, "rgb24", 128, 72, ffi.SWS_BICUBIC | 0x2000, 0),
+    ("yuv420p", 66, 38, "bgra", 131, 73, ffi.SWS_BICUBIC, 0),
+    ("yuv422p", 64, 36, "rgb24", 96, 54, ffi.SWS_BILINEAR | 0x2000, 0),
+    ("nv12", 64, 36, "argb", 127, 71, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
+    ("yuv444p", 48, 32, "rgb24", 48, 64, ffi.SWS_BILINEAR, 0),
+    ("yuv420p", 80, 60, "bgr24", 160, 60, ffi.SWS_POINT | 0x2000, 0),
+    ("yuv444p", 1920, 1080, "rgb24", 1280, 720, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 960, 540, "rgb24", 1920, 1080, ffi.SWS_BICUBIC | 0x2000 | ffi.SWS_ACCURATE_RND, 0),
+    ("yuv420p", 64, 36, "abgr", 64, 36, ffi.SWS_BICUBIC | 0x2000 | ffi.SWS_ACCURATE_RND, 0),
 ]
 
 
@@ -135,7 +149,7 @@ def test_scaled(case):
     src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=pad)
     ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
     assert not ht.unscaled_yuv2rgb
-    t = ffi.make_otables(sw, sh, PIX[sf], dw, dh, PIX[df], flags, ht.banks(), ht.coeffs())
+    t = ffi.make_otables(sw, sh, PIX[sf], dw, dh, PIX[df], flags, ht.banks(), ht.coeffs(), full=ht.full())
     want = ffi.alloc_frame(PIX[df], dw, dh)
     sp, ss = ffi.planes(src)
     dp, ds = ffi.planes(want)

@@ -1440,7 +1440,7 @@ def test_422_to_packed_rgb(dst, sf, sw, sh, dw, dh, flags):
     """4:2:2 planar sources to packed RGB: the chroma banks run from the source's own chroma plane to dstW / 2 x dstH
     (libswscale/utils.c:1359-1397); equal sizes included — yuv422p has a table converter of its own in the reference
     (YUV422FUNC, yuv2rgb.c:238-281: every line its own chroma row), whose bytes are what the scaler's one-tap path gives.
-    (4:4:4 sources switch the reference to its full-chroma writers, utils.c:1276-1285: refused by the hip path.)"""
+    (4:4:4 sources switch the reference to its full-chroma writers, utils.c:1276-1285: test_full_chroma_rgb.)"""
     from ffmpeg_amd import swscale as S
     R, O = ffi.ref(), ffi.oracle()
     rng = np.random.default_rng(sw + dw + len(dst) + len(sf))
@@ -1459,5 +1459,41 @@ def test_422_to_packed_rgb(dst, sf, sw, sh, dw, dh, flags):
     gp, gs = ffi.planes(got)
     assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh
     assert np.array_equal(got[0], want[0]), "%d bytes differ" % (got[0] != want[0]).sum()
-    with pytest.raises(ValueError, match="4:4:4"):
-        S.HostTables(sw, sh, PIX["yuv444p"], dw, dh, PIX[dst], flags)
+    assert S.HostTables(sw, sh, PIX["yuv444p"], dw, dh, PIX[dst], flags).full() is not None   # 4:4:4: the full-chroma writers (test_full_chroma_rgb)
+
+
+FULL_CHR_CASES = [("rgb24", "yuv444p", 64, 36, 128, 72, 4), ("bgr24", "yuv444p", 97, 53, 60, 41, 4), ("rgba", "yuv444p", 40, 30, 40, 30, 4 | 0x40000),
+                  ("rgb24", "yuv420p", 64, 36, 128, 72, 4 | 0x2000), ("bgra", "yuv420p", 66, 38, 131, 73, 4), ("rgb24", "yuv422p", 64, 36, 96, 54, 2 | 0x2000),
+                  ("argb", "nv12", 64, 36, 127, 71, 4 | 0x40000), ("rgb24", "yuv444p", 48, 32, 48, 64, 2), ("bgr24", "yuv420p", 80, 60, 160, 60, 0x10 | 0x2000),
+                  ("rgb24", "yuv444p", 128, 64, 32, 16, 4 | 0x40000), ("abgr", "yuv420p", 64, 36, 64, 36, 4 | 0x2000 | 0x40000)]
+
+
+@pytest.mark.parametrize("dst,sf,sw,sh,dw,dh,flags", FULL_CHR_CASES)
+def test_full_chroma_rgb(dst, sf, sw, sh, dw, dh, flags):
+    """SWS_FULL_CHR_H_INT on packed RGB targets — asked for (0x2000), or forced by an odd width or a 4:4:4 source (utils.c:1270-1290):
+    chroma keeps full horizontal resolution and the yuv2rgb_full_{1,2,X} writers run (output.c:1998-2310).  Our banks and the six
+    coefficients (host restatement) + the oracle's writers == the reference's frame; the coefficients and the effective flag == the
+    reference context's own"""
+    from ffmpeg_amd import swscale as S
+    R, O = ffi.ref(), ffi.oracle()
+    rng = np.random.default_rng(sw + dw + len(dst) + len(sf) + flags)
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=3)
+    R_ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, PIX[dst], flags, 1)
+    assert R_ctx
+    assert R.ffref_sws_flags(R_ctx) & 0x2000, "the reference runs this case with full chroma"
+    rk = (C.c_int * 6)()
+    R.ffref_sws_full_coeffs(R_ctx, rk)
+    want = ffi.alloc_frame(PIX[dst], dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(want)
+    assert R.ffref_sws_scale(R_ctx, sp, ss, 0, sh, dp, ds) == dh
+    R.ffref_sws_free(R_ctx)
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags)
+    assert ht.full() == list(rk) and ht.t.flags & 0x2000 and ht.t.hChr.n == dw
+    if ht.unscaled_yuv2rgb:     # the table converter of equal-size yuv420p -> RGB without ACCURATE_RND ignores the flag (swscale_unscaled.c:2425-2431)
+        return
+    t = ffi.make_otables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags, ht.banks(), ht.coeffs(), full=ht.full())
+    got = ffi.alloc_frame(PIX[dst], dw, dh)
+    gp, gs = ffi.planes(got)
+    assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh
+    assert np.array_equal(got[0], want[0]), "%d bytes differ" % (got[0] != want[0]).sum()
