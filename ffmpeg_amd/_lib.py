@@ -28,7 +28,7 @@ class SwsTables(C.Structure):
                                          "yuv2rgb_cgv")] + [("yuv2rgb_yoffs", C.c_int)] + \
                [("src_range", C.c_int), ("dst_range", C.c_int), ("lumConvertRange_coeff", C.c_uint32), ("chrConvertRange_coeff", C.c_uint32),
                 ("lumConvertRange_offset", C.c_int64), ("chrConvertRange_offset", C.c_int64),
-                ("full_chr_h_int", C.c_int), ("yuv2rgb_full", C.c_int * 6)]
+                ("full_chr_h_int", C.c_int), ("yuv2rgb_full", C.c_int * 6), ("dst_alpha_fill", C.c_int)]
 
 
 _lib = None

@@ -451,7 +451,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     int chrSrcW, chrSrcH, chrDstW, chrDstH, chrDstHSub, chrDstVSub, full_chr;
     int64_t lumXInc, lumYInc, chrXInc, chrYInc;
     int lum_scaler = scaler_of(flags, 0), chr_scaler = scaler_of(flags, 1);
-    int r, src_range = 0, dst_range = 0;
+    int r, src_range = 0, dst_range = 0, alpha_fill = 0;
 
     /* full-range twins on both sides: no range conversion, the base formats' scaler (handle_jpeg(), utils.c:1019-1050) */
     {
@@ -466,6 +466,22 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         if (dj)
             dstFormat = base[dstFormat - FFHIP_PIX_FMT_YUVJ420P];
         /* packed RGB targets: the source's range goes into the yuv2rgb tables (ff_yuv2rgb_c_init_tables' fullRange branch) */
+    }
+    /* an alpha plane on one side only: ignored as a source (needAlpha = isALPHA(src) && isALPHA(dst), utils.c:1398), filled with 255 as
+     * a target (ff_swscale's fillPlane, swscale.c:536-553) */
+    {
+        static const int base[3] = { FFHIP_PIX_FMT_YUV420P, FFHIP_PIX_FMT_YUV422P, FFHIP_PIX_FMT_YUV444P };
+        const int sa = srcFormat == FFHIP_PIX_FMT_YUVA420P ? 1 : srcFormat == FFHIP_PIX_FMT_YUVA422P ? 2 : srcFormat == FFHIP_PIX_FMT_YUVA444P ? 3 : 0;
+        const int da = dstFormat == FFHIP_PIX_FMT_YUVA420P ? 1 : dstFormat == FFHIP_PIX_FMT_YUVA422P ? 2 : dstFormat == FFHIP_PIX_FMT_YUVA444P ? 3 : 0;
+        if (sa && (da || dstFormat == FFHIP_PIX_FMT_ARGB || dstFormat == FFHIP_PIX_FMT_RGBA || dstFormat == FFHIP_PIX_FMT_ABGR || dstFormat == FFHIP_PIX_FMT_BGRA)) {
+            ffhip_set_error("ffhip_sws: alpha on both sides (a scaled alpha plane) is not on the hip path");
+            return NULL;
+        }
+        if (sa)
+            srcFormat = base[sa - 1];
+        if (da)
+            dstFormat = base[da - 1];
+        alpha_fill = da != 0;
     }
     if (flags & FFHIP_SWS_FAST_BILINEAR) {
         /* the C path of SWS_FAST_BILINEAR runs ff_hyscale_fast_c, a different horizontal scaler
@@ -493,6 +509,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     h->t.srcW = srcW; h->t.srcH = srcH; h->t.srcFormat = srcFormat;
     h->t.dstW = dstW; h->t.dstH = dstH; h->t.dstFormat = dstFormat;
     h->t.flags = flags;
+    h->t.dst_alpha_fill = alpha_fill;
     h->t.src_range = src_range;
     h->t.dst_range = dst_range;
     if (src_range != dst_range && !is_rgb(dstFormat)) {

@@ -833,9 +833,30 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
     return ffhip_launch_scale16(a, nframes, stream);
 }
 
+static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
+                           void *const dst[4], const int dstStride[4], const size_t dstFramePitch[4], void *stream_);
+
 extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4],
                                          const int srcStride[4], const size_t srcFramePitch[4], void *const dst[4],
                                          const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
+{
+    const int r = scale_batch_dev(c, nframes, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream_);
+    if (r < 0 || !c->t.dst_alpha_fill)
+        return r;
+    /* a target with an alpha plane the source does not drive: opaque (ff_swscale's fillPlane, libswscale/swscale.c:536-553) */
+    if (!dst[3]) {
+        ffhip_set_error("ffhip_sws_scale_batch_dev: the target format has an alpha plane: dst[3] is NULL");
+        return FFHIP_EINVAL;
+    }
+    FFHipDeviceGuard dg(c->device);
+    for (int f = 0; f < nframes; f++)
+        HIP_TRY(hipMemset2DAsync((uint8_t *)dst[3] + (size_t)f * dstFramePitch[3], (size_t)dstStride[3], 255, (size_t)c->t.dstW, (size_t)c->t.dstH,
+                                 (hipStream_t)stream_));
+    return r;
+}
+
+static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
+                           void *const dst[4], const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!c || nframes < 0 || !src || !dst)
@@ -1299,7 +1320,7 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
         a.wvalid = t.dstW & ~1; a.h = srcSliceH; a.dst_y0 = 0; a.nframes = 1; a.k = c->k;
         r = ffhip_launch_yuv420p_rgb24(a, rgb_layout(t.dstFormat), 0);
     } else {
-        r = ffhip_sws_scale_batch_dev(c, 1, dsrc, pitch_s, fp, ddst, pitch_d, fp, 0);
+        r = scale_batch_dev(c, 1, dsrc, pitch_s, fp, ddst, pitch_d, fp, 0);
     }
     if (r < 0)
         return r;
@@ -1308,6 +1329,9 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
         uint8_t *hd = dst[i] + (unscaled ? (ptrdiff_t)srcSliceY * dstStride[i] : 0);
         HIP_TRY(copy2d(hd, dstStride[i], base + off_d[i], pitch_d[i], dp[i].wbytes, dp[i].rows, hipMemcpyDeviceToHost));
     }
+    if (t.dst_alpha_fill && dst[3]) /* the alpha plane of a target whose source has none: opaque (swscale.c:536-553) */
+        for (int y = 0; y < t.dstH; y++)
+            memset(dst[3] + (ptrdiff_t)y * dstStride[3], 255, (size_t)t.dstW);
     return unscaled ? srcSliceH : t.dstH;
 }
 

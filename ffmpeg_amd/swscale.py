@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-PIX_FMT = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "yuvj420p": 12, "yuvj422p": 13, "yuvj444p": 14, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
+PIX_FMT = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "yuva420p": 33, "yuva422p": 78, "yuva444p": 79, "yuvj420p": 12, "yuvj422p": 13, "yuvj444p": 14, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
 SWS_BILINEAR, SWS_BICUBIC, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 2, 4, 0x10, 0x20, 0x40
 SWS_GAUSS, SWS_SINC, SWS_LANCZOS = 0x80, 0x100, 0x200
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
@@ -23,6 +23,7 @@ SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
 HBD_FMT = {45: (0, 1, 1), 47: (0, 1, 0), 49: (0, 0, 0), 60: (0, 1, 1), 62: (0, 1, 1), 64: (0, 1, 0), 66: (0, 0, 0), 68: (0, 0, 0), 70: (0, 1, 0),
            123: (0, 1, 1), 125: (0, 1, 1), 127: (0, 1, 0), 129: (0, 1, 0), 131: (0, 0, 0), 133: (0, 0, 0), 158: (1, 1, 1), 169: (1, 1, 1),
            209: (1, 1, 1)}
+YUVA_FMT = {33: 0, 78: 4, 79: 5}   # yuva420p / 422p / 444p -> the base formats (libavutil/pixfmt.h)
 
 
 def plane_shapes(fmt, w, h):
@@ -32,6 +33,8 @@ def plane_shapes(fmt, w, h):
         semi, hs, vs = HBD_FMT[fmt]
         cw, ch = -((-w) >> hs), -((-h) >> vs)
         return [(h, 2 * w), (ch, 4 * cw)] if semi else [(h, 2 * w), (ch, 2 * cw), (ch, 2 * cw)]
+    if fmt in YUVA_FMT:                                   # the base format's planes plus a full-size alpha plane
+        return plane_shapes(YUVA_FMT[fmt], w, h) + [(h, w)]
     hs, vs = (0, 0) if fmt == PIX_FMT["yuv444p"] else (1, 0) if fmt == PIX_FMT["yuv422p"] else (1, 1)
     cw, ch = -((-w) >> hs), -((-h) >> vs)
     if fmt in (PIX_FMT["yuv420p"], PIX_FMT["yuv422p"], PIX_FMT["yuv444p"]):

@@ -124,6 +124,12 @@ int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t 
 #define FFHIP_PIX_FMT_YUV422P 4    /* planar 4:2:2 and 4:4:4, 8 bits (== AV_PIX_FMT_YUV422P / _YUV444P): sources and targets of the scaler;
                                     * to packed RGB 4:4:4 sources run with SWS_FULL_CHR_H_INT, as in the reference (utils.c:1276-1285) */
 #define FFHIP_PIX_FMT_YUV444P 5
+#define FFHIP_PIX_FMT_YUVA420P 33  /* planar YUV with an alpha plane, 8 bits (== AV_PIX_FMT_YUVA420P / _YUVA422P / _YUVA444P).  As sources their
+                                    * alpha plane is not read when the target has none (c->needAlpha = 0, utils.c:1398); as targets of sources
+                                    * without alpha the plane dst[3] is filled with 255, as ff_swscale() fills it (swscale.c:536-553).  Alpha on
+                                    * both sides (a scaled alpha plane) is not on this path */
+#define FFHIP_PIX_FMT_YUVA422P 78
+#define FFHIP_PIX_FMT_YUVA444P 79
 #define FFHIP_PIX_FMT_YUVJ420P 12  /* the full-range "J" twins (== AV_PIX_FMT_YUVJ420P / 422P / 444P): taken when BOTH sides are J formats —
                                     * equal ranges need no range conversion, the conversion is the base formats' (handle_jpeg(),
                                     * libswscale/utils.c:1019-1050); a J format on one side only, or J to packed RGB, is not on the hip path */
@@ -210,6 +216,9 @@ typedef struct FFHipSwsTables {
      * v2r_coeff, v2g_coeff, u2g_coeff, u2b_coeff} (yuv2rgb.c:786-791), in this order */
     int      full_chr_h_int;
     int      yuv2rgb_full[6];
+    /* the target has an alpha plane the source does not drive: dst[3] is filled with 255 (fillPlane, swscale.c:536-553).
+     * srcFormat / dstFormat above are then the formats without the alpha plane */
+    int      dst_alpha_fill;
 } FFHipSwsTables;
 
 typedef struct FFHipSwsContext FFHipSwsContext;

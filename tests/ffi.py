@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libffref.so")
 
-PIX = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "yuvj420p": 12, "yuvj422p": 13, "yuvj444p": 14, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
+PIX = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "yuva420p": 33, "yuva422p": 78, "yuva444p": 79, "yuvj420p": 12, "yuvj422p": 13, "yuvj444p": 14, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
 RGB_LAYOUT = {2: 0, 3: 1, 25: 2, 26: 3, 27: 4, 28: 5}   # AVPixelFormat -> the oracle's packed layout number
 SWS_BICUBIC, SWS_BILINEAR, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 4, 2, 0x10, 0x20, 0x40
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
@@ -477,6 +477,8 @@ def make_otables(srcW, srcH, srcFmt, dstW, dstH, dstFmt, flags, banks, coeffs=DE
     t._keep = keep
     return t
 
+YUVA_BASE = {33: 0, 78: 4, 79: 5}   # yuva420p / 422p / 444p -> the base formats (libavutil/pixfmt.h)
+
 
 def alloc_frame(fmt, w, h, rng=None, pad=0):
     """Allocate the planes of one frame (strides = width + pad). Random content when rng is given."""
@@ -485,6 +487,8 @@ def alloc_frame(fmt, w, h, rng=None, pad=0):
         if rng is not None:
             a[:] = rng.integers(0, 256, a.shape, dtype=np.uint8)
         return a
+    if fmt in YUVA_BASE:
+        return alloc_frame(YUVA_BASE[fmt], w, h, rng, pad) + [mk(h, w)]
     hs, vs = (0, 0) if fmt == PIX["yuv444p"] else (1, 0) if fmt == PIX["yuv422p"] else (1, 1)
     cw, ch = -((-w) >> hs), -((-h) >> vs)
     if fmt in (PIX["yuv420p"], PIX["yuv422p"], PIX["yuv444p"]):

@@ -1497,3 +1497,43 @@ def test_full_chroma_rgb(dst, sf, sw, sh, dw, dh, flags):
     gp, gs = ffi.planes(got)
     assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh
     assert np.array_equal(got[0], want[0]), "%d bytes differ" % (got[0] != want[0]).sum()
+
+
+ALPHA_CASES = [("yuv420p", "yuva420p", 64, 36, 128, 72, 4), ("yuv422p", "yuva444p", 65, 37, 40, 30, 2), ("nv12", "yuva422p", 64, 36, 96, 54, 4 | 0x40000),
+               ("yuva420p", "yuv420p", 64, 36, 128, 72, 4), ("yuva444p", "rgb24", 64, 36, 100, 50, 4), ("yuva422p", "nv12", 66, 38, 33, 19, 2),
+               ("yuva420p", "bgr24", 64, 36, 64, 36, 4), ("yuv420p", "yuva420p", 64, 36, 64, 36, 4), ("yuva444p", "yuv420p", 48, 32, 48, 32, 4)]
+
+
+@pytest.mark.parametrize("sf,dst,sw,sh,dw,dh,flags", ALPHA_CASES)
+def test_alpha_on_one_side(sf, dst, sw, sh, dw, dh, flags):
+    """An alpha plane on one side only.  As a source it is not read (needAlpha = isALPHA(src) && isALPHA(dst), utils.c:1398); as a target it
+    is filled with 255 (ff_swscale, swscale.c:536-553; planarCopyWrapper's fillPlane for the equal-size copy, swscale_unscaled.c:2150-2160).
+    So the reference's frame == its frame for the base formats, plus an opaque plane — which is what the host tables restate
+    (`dst_alpha_fill`, both formats mapped to their base)."""
+    from ffmpeg_amd import swscale as S
+    R = ffi.ref()
+    base = {"yuva420p": "yuv420p", "yuva422p": "yuv422p", "yuva444p": "yuv444p"}
+    rng = np.random.default_rng(sw + dw + len(dst) + len(sf) + flags)
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=3)
+    out = []
+    for a, b in ((sf, dst), (base.get(sf, sf), base.get(dst, dst))):
+        ctx = R.ffref_sws_create(sw, sh, PIX[a], dw, dh, PIX[b], flags, 1)
+        assert ctx
+        want = ffi.alloc_frame(PIX[b], dw, dh)
+        for p in want:
+            p[:] = 7
+        sp, ss = ffi.planes(src)
+        dp, ds = ffi.planes(want)
+        assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, dp, ds) == dh
+        R.ffref_sws_free(ctx)
+        out.append(want)
+    n = len(out[1])
+    for p, q in zip(out[0][:n], out[1]):
+        assert np.array_equal(p, q)
+    if dst in base:
+        assert len(out[0]) == 4 and (out[0][3] == 255).all()
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags)
+    assert ht.t.dst_alpha_fill == (dst in base) and ht.t.srcFormat == PIX[base.get(sf, sf)] and ht.t.dstFormat == PIX[base.get(dst, dst)]
+    for a, b in (("yuva420p", "yuva444p"), ("yuva420p", "rgba")):
+        with pytest.raises(ValueError):
+            S.HostTables(sw, sh, PIX[a], dw, dh, PIX[b], flags)
