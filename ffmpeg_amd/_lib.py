@@ -137,6 +137,7 @@ def lib():
         "ffhip_h264_loop_filter_batch_dev": (C.c_int, [vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_h264_deblock_frame_dev": (C.c_int, [vp, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_picture_create": (C.c_int, [vp, C.c_int, C.c_int]),
+        "ffhip_h264_picture_create_hbd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "ffhip_h264_picture_free": (None, [vp]),
         "ffhip_h264_picture_begin": (None, [vp]),
         "ffhip_h264_picture_mc_luma": (C.c_int, [vp, C.c_int, vp]),

@@ -43,6 +43,7 @@ size_t place(size_t &total, const std::vector<T> &v, Section &s)
 struct FFHipH264Picture {
     int device = 0; /* staging and scratch planes live on this device; flush() makes it current for its duration */
     int mb_w = 0, mb_h = 0;
+    int bd = 8;     /* sample depth: above 8 the planes hold uint16_t, coefficient blocks int32_t (dctcoef, bit_depth_template.c:39-50) */
     std::vector<FFHipQpelBlock> qpel[3];          /* luma MC by stage                      */
     std::vector<FFHipChromaBlock> cmc[2][3];      /* chroma MC: plane (Cb, Cr) x stage     */
     std::vector<FFHipWeightBlock> wt[3];          /* weight / biweight per plane           */
@@ -119,9 +120,18 @@ extern "C" void ffhip_h264_picture_begin(FFHipH264Picture *p)
 
 extern "C" int ffhip_h264_picture_create(FFHipH264Picture **pp, int mb_w, int mb_h)
 {
+    return ffhip_h264_picture_create_hbd(pp, mb_w, mb_h, 8);
+}
+
+extern "C" int ffhip_h264_picture_create_hbd(FFHipH264Picture **pp, int mb_w, int mb_h, int bit_depth)
+{
     if (!pp || mb_w <= 0 || mb_h <= 0)
         return FFHIP_EINVAL;
     *pp = nullptr;
+    if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14) {
+        ffhip_set_error("ffhip_h264_picture_create_hbd: bit depth %d (8, 9, 10, 12 and 14 are the depths H.264 defines)", bit_depth);
+        return FFHIP_EINVAL;
+    }
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     FFHipH264Picture *p = new (std::nothrow) FFHipH264Picture();
@@ -131,6 +141,7 @@ extern "C" int ffhip_h264_picture_create(FFHipH264Picture **pp, int mb_w, int mb
         return FFHIP_ENOMEM;
     p->mb_w = mb_w;
     p->mb_h = mb_h;
+    p->bd = bit_depth;
     const size_t nmb = (size_t)mb_w * mb_h;
     p->edges[0].assign(nmb * 8, FFHipH264Edge());
     p->edges[1].assign(nmb * 4, FFHipH264Edge());
@@ -179,14 +190,16 @@ extern "C" int ffhip_h264_picture_idct_add(FFHipH264Picture *p, int plane, int k
 {
     if (!p || !block || plane < 0 || plane > 2 || kind < FFHIP_H264_IDCT4 || kind > FFHIP_H264_IDCT8_DC)
         return FFHIP_EINVAL;
-    const int ncoef = (kind == FFHIP_H264_IDCT8 || kind == FFHIP_H264_IDCT8_DC) ? 64 : 16;
+    /* int16 units: above 8 bits a coefficient is an int32 (dctcoef), the caller's `block` is the decoder's sl->mb as it stands */
+    const int wide = p->bd > 8 ? 2 : 1;
+    const int ncoef = ((kind == FFHIP_H264_IDCT8 || kind == FFHIP_H264_IDCT8_DC) ? 64 : 16) * wide;
     p->idct_off[plane][kind].push_back(dst_offset);
     std::vector<int16_t> &c = p->idct_coef[plane][kind];
     c.insert(c.end(), block, block + ncoef);
     /* the side effect of the dsp function the decoder relies on: coefficients are consumed (h264idct_template.c:66,142,
      * and block[0] = 0 for the dc forms) */
     if (kind == FFHIP_H264_IDCT4_DC || kind == FFHIP_H264_IDCT8_DC)
-        block[0] = 0;
+        block[0] = block[wide - 1] = 0;
     else
         memset(block, 0, sizeof(int16_t) * ncoef);
     return 0;
@@ -300,6 +313,10 @@ extern "C" int ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264I
 {
     if (!p || !d || d->mb_x < 0 || d->mb_x >= p->mb_w || d->mb_y < 0 || d->mb_y >= p->mb_h)
         return FFHIP_EINVAL;
+    if (p->bd > 8) {
+        ffhip_set_error("ffhip_h264_picture_intra_mb: the intra reconstruction wavefront is built for 8-bit samples only (this picture: %d)", p->bd);
+        return FFHIP_ENOSYS;
+    }
     FFHipH264IntraMB R = *d;
     std::vector<int16_t> &c = p->intra_coef;
     if (c.size() > (size_t)INT32_MAX - 1024)
@@ -466,6 +483,50 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
     }
 
     int r = 0;
+    if (p->bd > 8) {
+        /* the same stages on the kernels templated on the sample type (kernels/h264_hbd.hip): one launch per list */
+        const int bd = p->bd;
+        for (int pl = 0; pl < 3; pl++)
+            if ((stride[pl] & 1) || ((uintptr_t)dst[pl] & 1) || ((uintptr_t)ref[pl] & 1)) {
+                ffhip_set_error("ffhip_h264_picture_flush: plane %d of a %d-bit picture is not 2-byte aligned", pl, bd);
+                return FFHIP_EINVAL;
+            }
+        for (int s = 0; s < 3 && r >= 0; s++) {
+            if (s_qpel[s].n)
+                r = ffhip_launch_h264_qpel_bd(bd, s == ST_TMP ? p->tmp[0] : dst[0], ref[0], stride[0], (const FFHipQpelBlock *)(db + s_qpel[s].off),
+                                              s_qpel[s].n, stream);
+            for (int c = 0; c < 2 && r >= 0; c++)
+                if (s_cmc[c][s].n)
+                    r = ffhip_launch_h264_chroma_mc_bd(bd, s == ST_TMP ? p->tmp[1 + c] : dst[1 + c], ref[1 + c], stride[1 + c],
+                                                       (const FFHipChromaBlock *)(db + s_cmc[c][s].off), s_cmc[c][s].n, stream);
+        }
+        for (int pl = 0; pl < 3 && r >= 0; pl++)
+            if (s_wt[pl].n)
+                r = ffhip_launch_h264_weight_bd(bd, dst[pl], p->tmp[pl] ? p->tmp[pl] : dst[pl], stride[pl], (const FFHipWeightBlock *)(db + s_wt[pl].off),
+                                                s_wt[pl].n, stream);
+        for (int pl = 0; pl < 3 && r >= 0; pl++)
+            for (int k = 0; k < 4 && r >= 0; k++)
+                if (s_ioff[pl][k].n)
+                    r = ffhip_launch_h264_idct_add_bd(bd, k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off),
+                                                      (int16_t *)(db + s_icoef[pl][k].off), s_ioff[pl][k].n, stream);
+        if (r < 0)
+            return r;
+        const bool chroma = p->any_edge[1] || p->any_edge[2];
+        if (chroma) {
+            HIP_TRY(hipEventRecord(p->fork, stream));
+            HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
+            for (int pl = 1; pl < 3 && r >= 0; pl++)
+                if (p->any_edge[pl])
+                    r = ffhip_launch_h264_deblock_frames_bd(bd, 1, dst[pl], 0, 1, stride[pl], p->mb_w, p->mb_h, (const FFHipH264Edge *)(db + s_edge[pl].off),
+                                                            p->aux);
+            HIP_TRY(hipEventRecord(p->join, p->aux));
+        }
+        if (r >= 0 && p->any_edge[0])
+            r = ffhip_launch_h264_deblock_frames_bd(bd, 0, dst[0], 0, 1, stride[0], p->mb_w, p->mb_h, (const FFHipH264Edge *)(db + s_edge[0].off), stream);
+        if (chroma)
+            HIP_TRY(hipStreamWaitEvent(stream, p->join, 0));
+        return r < 0 ? r : 0;
+    }
     /* ---- prediction ---- */
     for (int s = 0; s < 3 && r >= 0; s++) {
         uint8_t *target = s == ST_TMP ? p->tmp[0] : dst[0];

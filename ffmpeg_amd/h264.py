@@ -108,9 +108,9 @@ class Picture:
     """ctypes mirror of FFHipH264Picture: record a picture's per-block dsp calls on the host, flush them as a handful of
     launches (include/ffhip.h).  Records are numpy structured scalars / arrays of the batch faces' dtypes."""
 
-    def __init__(self, mb_w, mb_h):
+    def __init__(self, mb_w, mb_h, bit_depth=8):
         self._p = _lib.vp()
-        _lib.check(_lib.lib().ffhip_h264_picture_create(C.byref(self._p), mb_w, mb_h), "ffhip_h264_picture_create")
+        _lib.check(_lib.lib().ffhip_h264_picture_create_hbd(C.byref(self._p), mb_w, mb_h, bit_depth), "ffhip_h264_picture_create_hbd")
 
     def close(self):
         if getattr(self, "_p", None) is not None and self._p and _lib is not None:   # _lib is gone during interpreter shutdown

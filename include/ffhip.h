@@ -609,6 +609,12 @@ typedef struct FFHipH264Picture FFHipH264Picture;
 #define FFHIP_H264_MC_TMP 1   /* put into the bi-prediction scratch plane (sl->bipred_scratchpad)  */
 #define FFHIP_H264_MC_AVG 2   /* avg onto the picture: the second list of an unweighted bi-prediction */
 int  ffhip_h264_picture_create(FFHipH264Picture **p, int mb_w, int mb_h);
+/** The same object for a High 10 / High 4:2:0 picture of bit_depth 9 / 10 / 12 / 14 (8: == ffhip_h264_picture_create): planes hold
+ *  uint16_t samples, offsets and strides stay in BYTES (as the decoder's linesize / block_offset << pixel_shift), the blocks handed to
+ *  idct_add() hold int32_t coefficients (dctcoef, libavcodec/bit_depth_template.c:39-50; sl->mb as the decoder keeps it), edge records
+ *  keep alpha / beta / tc0 at the 8-bit scale (the kernels scale them as h264dsp_template.c:108-110 does).  The inter stages and the
+ *  decoder-order deblocking run; intra macroblocks are refused at record time (FFHIP_ENOSYS: the reconstruction wavefront is 8-bit). */
+int  ffhip_h264_picture_create_hbd(FFHipH264Picture **p, int mb_w, int mb_h, int bit_depth);
 void ffhip_h264_picture_free(FFHipH264Picture **p);
 void ffhip_h264_picture_begin(FFHipH264Picture *p);
 /** mc_dir_part(): qpix_op[luma_xy] and chroma_op (h264_mb.c:206-300); blk->avg is set from `stage`. */

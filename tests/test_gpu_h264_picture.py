@@ -190,3 +190,96 @@ def test_picture_pipeline(mb_w, mb_h, pictures, p_intra):
             assert (want[pl] != dst0[pl]).sum() > 1000
             assert np.array_equal(got, want[pl]), "picture %d plane %d: %d mismatches" % (it, pl, (got != want[pl]).sum())
     pic.close()
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,pictures", [(10, 6, 4, 2), (10, 40, 22, 1), (9, 7, 5, 1), (12, 11, 7, 1), (14, 6, 4, 1)])
+def test_picture_pipeline_hbd(depth, mb_w, mb_h, pictures):
+    """The inter stages and the decoder-order deblocking of a High 10-class picture (uint16_t samples, int32 coefficients, offsets and
+    strides in bytes): flush() == the oracle's depth-templated dsp functions called one by one in decoder order (oracle/ffo_h264_hbd.c,
+    pinned to the reference's h264dsp / h264qpel / h264chroma instantiations at 9 / 10 / 12 / 14 bits).  Intra macroblocks are refused."""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    O = ffi.oracle()
+    i16p = C.POINTER(C.c_int16)
+    O.ffo_h264_idct_bd.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_ssize_t]
+    O.ffo_h264_qpel_bd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t]
+    O.ffo_h264_chroma_mc_bd.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+    O.ffo_h264_weight_bd.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int]
+    O.ffo_h264_biweight_bd.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    O.ffo_h264_deblock_frame_bd.argtypes = [C.c_int, C.c_int, u8p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(mb_w * 31 + mb_h + depth)
+    P = 32
+    W, H = mb_w * 16, mb_h * 16
+    sy, sc = W + 2 * P, W // 2 + P                            # in samples; the records count bytes
+    strides = [2 * sy, 2 * sc, 2 * sc]
+    top = 1 << depth
+    refs = [rng.integers(0, top, (2 * (H + 2 * P), sy), dtype=np.uint16), rng.integers(0, top, (2 * (H // 2 + P), sc), dtype=np.uint16),
+            rng.integers(0, top, (2 * (H // 2 + P), sc), dtype=np.uint16)]
+    dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
+    d_refs = [dev(r) for r in refs]
+    pic = h264.Picture(mb_w, mb_h, bit_depth=depth)
+    with pytest.raises(RuntimeError, match="8-bit"):
+        d = G.make_intra_mb(rng, 0, 0, mb_w, mb_h)
+        pic.intra_mb(G.to_record(d), d["nnzc"], d["mb"].copy(), d["luma_dc"], d["pcm"])
+    for it in range(pictures):
+        dst0 = [rng.integers(0, top, (H, sy), dtype=np.uint16), rng.integers(0, top, (H // 2, sc), dtype=np.uint16),
+                rng.integers(0, top, (H // 2, sc), dtype=np.uint16)]
+        want = [a.copy() for a in dst0]
+        tmp = [np.zeros_like(a) for a in dst0]
+        edges = [np.zeros(mb_w * mb_h * (8 if pl == 0 else 4), EDGE_DT) for pl in range(3)]
+        pic.begin()
+        for my in range(mb_h):
+            for mx in range(mb_w):
+                for call in _make_mb(rng, mx, my, W, H, P, sy, sc, 0.0):
+                    if call[0] == "mc":
+                        _, pl, stage, rec = call
+                        rec = rec.copy()
+                        rec["dst_offset"] *= 2
+                        rec["src_offset"] *= 2
+                        tgt = tmp[pl] if stage == h264.MC_TMP else want[pl]
+                        r = rec[0]
+                        if pl == 0:
+                            pic.mc_luma(stage, rec)
+                            O.ffo_h264_qpel_bd(depth, int(stage == h264.MC_AVG), int(r["size_idx"]), int(r["mcxy"]), _at(tgt, r["dst_offset"]),
+                                               _at(refs[0], r["src_offset"]), strides[0])
+                        else:
+                            pic.mc_chroma(pl, stage, rec)
+                            O.ffo_h264_chroma_mc_bd(depth, int(stage == h264.MC_AVG), int(r["h"]), _at(tgt, r["dst_offset"]), _at(refs[pl], r["src_offset"]),
+                                                    strides[pl], int(r["h"]), int(r["x"]), int(r["y"]))
+                    elif call[0] == "w":
+                        _, pl, rec = call
+                        rec = rec.copy()
+                        rec["dst_offset"] *= 2
+                        rec["src_offset"] *= 2
+                        pic.weight(pl, rec)
+                        r = rec[0]
+                        wpx = [16, 8, 4, 2][int(r["w_idx"])]
+                        if r["bi"]:
+                            O.ffo_h264_biweight_bd(depth, wpx, _at(want[pl], r["dst_offset"]), _at(tmp[pl], r["src_offset"]), strides[pl], int(r["height"]),
+                                                   int(r["log2_denom"]), int(r["weightd"]), int(r["weights"]), int(r["offset"]))
+                        else:
+                            O.ffo_h264_weight_bd(depth, wpx, _at(want[pl], r["dst_offset"]), strides[pl], int(r["height"]), int(r["log2_denom"]),
+                                                 int(r["weightd"]), int(r["offset"]))
+                    elif call[0] == "idct":
+                        _, pl, kind, off, blk = call
+                        blk = blk.astype(np.int32) << (depth - 8)            # dctcoef above 8 bits; residuals grow with the depth
+                        host = blk.copy()
+                        pic.idct_add(pl, kind, 2 * off, host)
+                        assert host[0] == 0 and (kind >= 2 or not host.any())
+                        ob = blk.copy()
+                        O.ffo_h264_idct_bd(depth, kind, _at(want[pl], 2 * off), C.cast(ob.ctypes.data, i16p), strides[pl])
+                    else:
+                        _, pl, ed = call
+                        pic.deblock_mb(pl, mx, my, ed)
+                        ne = len(ed)
+                        edges[pl][(my * mb_w + mx) * ne:(my * mb_w + mx + 1) * ne] = ed
+        for pl in range(3):
+            O.ffo_h264_deblock_frame_bd(depth, int(pl > 0), ptr(want[pl]), strides[pl], mb_w, mb_h, C.c_void_p(edges[pl].ctypes.data))
+        d_dst = [dev(a) for a in dst0]
+        pic.flush(d_dst, strides, d_refs)
+        torch.cuda.synchronize()
+        for pl in range(3):
+            got = d_dst[pl].cpu().numpy().view(np.uint16)
+            assert (want[pl] != dst0[pl]).sum() > 1000 and want[pl].max() < top
+            assert np.array_equal(got, want[pl]), "picture %d plane %d: %d mismatches" % (it, pl, (got != want[pl]).sum())
+    pic.close()
