@@ -219,19 +219,24 @@ extern "C" int ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int
 static int scan8_luma(int i) { return 4 + (i & 1) + ((i >> 2) & 1) * 2 + (1 + ((i >> 1) & 1) + ((i >> 3) & 1) * 2) * 8; }
 static int scan8_chroma(int pl, int k) { return 4 + (k & 1) + (5 * pl + 1 + (k >> 1)) * 8; }
 
-extern "C" int ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_t *mb, const int16_t *mb_luma_dc, const uint8_t *pcm,
-                                     int16_t *coefs, int32_t *ncoefs, int32_t cap)
+/* CF = dctcoef of the depth (int16_t at 8 bits, int32_t above); runs, R.coef, *ncoefs and cap count int16 entries at every depth */
+template <typename CF>
+static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_t *mb_, const int16_t *mb_luma_dc_, const uint8_t *pcm, int16_t *coefs,
+                      int32_t *ncoefs, int32_t cap)
 {
+    constexpr int W = (int)(sizeof(CF) / sizeof(int16_t));
     if (!rec || !coefs || !ncoefs || rec->type > FFHIP_H264_INTRA_PCM || *ncoefs < 0)
         return FFHIP_EINVAL;
     FFHipH264IntraMB &R = *rec;
+    CF *mb = reinterpret_cast<CF *>(mb_);
+    const CF *mb_luma_dc = reinterpret_cast<const CF *>(mb_luma_dc_);
     R.flags = 0;
     memset(R.pad, 0, sizeof(R.pad));
     memset(R.nnz, 0, sizeof(R.nnz));
     memset(R.luma_dc, 0, sizeof(R.luma_dc));
     R.blocks = 0;
     int32_t n = (*ncoefs + 7) & ~7; /* runs start on 16 bytes */
-    if ((int64_t)n + 384 > cap)
+    if ((int64_t)n + (384 + 16) * W > cap)
         return FFHIP_ENOMEM;
     for (int32_t i = *ncoefs; i < n; i++)
         coefs[i] = 0;
@@ -239,22 +244,49 @@ extern "C" int ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *nnzc,
     if (R.type == FFHIP_H264_INTRA_PCM) {
         if (!pcm)
             return FFHIP_EINVAL;
-        memcpy(coefs + n, pcm, 384);
-        *ncoefs = n + 192;
+        if (W == 1) {
+            memcpy(coefs + n, pcm, 384);
+        } else {
+            /* get_bits(&gb, bit_depth) 384 times over sl->intra_pcm_ptr (h264_mb_template.c:100-131): MSB-first fields */
+            uint16_t *out = reinterpret_cast<uint16_t *>(coefs + n);
+            uint32_t acc = 0;
+            int have = 0;
+            for (int k = 0; k < 384; k++) {
+                while (have < bd) {
+                    acc = (acc << 8) | *pcm++;
+                    have += 8;
+                }
+                have -= bd;
+                out[k] = (uint16_t)((acc >> have) & ((1u << bd) - 1u));
+            }
+        }
+        *ncoefs = n + 192 * W;
         return 0;
     }
     if (!nnzc || !mb)
         return FFHIP_EINVAL;
     /* a block travels when the dsp function hl_decode_mb() would call on it reads it; the caller's copy is consumed the way that
      * function consumes it: zeroed by idct_add / idct8_add (h264idct_template.c:66,142), [0] = 0 by the dc forms (:150,166) */
-    auto take = [&](int16_t *b, int cnt, bool full) {
-        memcpy(coefs + n, b, sizeof(int16_t) * cnt);
-        n += cnt;
+    auto take = [&](CF *b, int cnt, bool full) {
+        memcpy(coefs + n, b, sizeof(CF) * cnt);
+        n += cnt * W;
         if (full)
-            memset(b, 0, sizeof(int16_t) * cnt);
+            memset(b, 0, sizeof(CF) * cnt);
         else
             b[0] = 0;
     };
+    if (R.type == FFHIP_H264_INTRA_16x16 && nnzc[0]) {
+        /* scan8[LUMA_DC_BLOCK_INDEX]: luma_dc_dequant_idct writes the 16 DC positions of sl->mb (h264_mb.c:707-711) */
+        if (!mb_luma_dc)
+            return FFHIP_EINVAL;
+        R.flags |= FFHIP_H264_INTRA_LUMA_DC;
+        if (W == 1) {
+            memcpy(R.luma_dc, mb_luma_dc, sizeof(R.luma_dc));
+        } else { /* dctcoef does not fit the record's int16 field: the sixteen DCs lead the run (h264_intra_mb.h imb_block) */
+            memcpy(coefs + n, mb_luma_dc, sizeof(CF) * 16);
+            n += 16 * W;
+        }
+    }
     if (R.type == FFHIP_H264_INTRA_4x4) {
         for (int i = 0; i < 16; i++) {
             const int nnz = nnzc[scan8_luma(i)];
@@ -274,12 +306,6 @@ extern "C" int ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *nnzc,
             }
         }
     } else {
-        if (nnzc[0]) { /* scan8[LUMA_DC_BLOCK_INDEX]: luma_dc_dequant_idct writes the 16 DC positions of sl->mb (h264_mb.c:707-711) */
-            if (!mb_luma_dc)
-                return FFHIP_EINVAL;
-            R.flags |= FFHIP_H264_INTRA_LUMA_DC;
-            memcpy(R.luma_dc, mb_luma_dc, sizeof(R.luma_dc));
-        }
         for (int i = 0; i < 16; i++) { /* idct_add16intra (h264idct_template.c:191-200) */
             const int nnz = nnzc[scan8_luma(i)];
             R.nnz[i] = (uint8_t)nnz;
@@ -294,7 +320,7 @@ extern "C" int ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *nnzc,
             if (nnzc[40 * pl]) /* scan8[CHROMA_DC_BLOCK_INDEX + pl - 1] */
                 R.flags |= (uint8_t)(FFHIP_H264_INTRA_CB_DC << (pl - 1));
             for (int k = 0; k < 4; k++) {
-                int16_t *b = mb + 256 * pl + 16 * k;
+                CF *b = mb + 256 * pl + 16 * k;
                 const int nnz = nnzc[scan8_chroma(pl, k)];
                 R.nnz[16 + 4 * (pl - 1) + k] = (uint8_t)nnz;
                 if (nnz || b[0]) {
@@ -308,22 +334,34 @@ extern "C" int ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *nnzc,
     return 0;
 }
 
+extern "C" int ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_t *mb, const int16_t *mb_luma_dc, const uint8_t *pcm,
+                                     int16_t *coefs, int32_t *ncoefs, int32_t cap)
+{
+    return intra_pack<int16_t>(8, rec, nnzc, mb, mb_luma_dc, pcm, coefs, ncoefs, cap);
+}
+
+extern "C" int ffhip_h264_intra_pack_hbd(int bit_depth, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_t *mb, const int16_t *mb_luma_dc,
+                                         const uint8_t *pcm, int16_t *coefs, int32_t *ncoefs, int32_t cap)
+{
+    if (bit_depth == 8)
+        return intra_pack<int16_t>(8, rec, nnzc, mb, mb_luma_dc, pcm, coefs, ncoefs, cap);
+    if (bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14)
+        return FFHIP_EINVAL;
+    return intra_pack<int32_t>(bit_depth, rec, nnzc, mb, mb_luma_dc, pcm, coefs, ncoefs, cap);
+}
+
 extern "C" int ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264IntraMB *d, const uint8_t *nnzc, int16_t *mb,
                                            const int16_t *mb_luma_dc, const uint8_t *pcm)
 {
     if (!p || !d || d->mb_x < 0 || d->mb_x >= p->mb_w || d->mb_y < 0 || d->mb_y >= p->mb_h)
         return FFHIP_EINVAL;
-    if (p->bd > 8) {
-        ffhip_set_error("ffhip_h264_picture_intra_mb: the intra reconstruction wavefront is built for 8-bit samples only (this picture: %d)", p->bd);
-        return FFHIP_ENOSYS;
-    }
     FFHipH264IntraMB R = *d;
     std::vector<int16_t> &c = p->intra_coef;
-    if (c.size() > (size_t)INT32_MAX - 1024)
+    if (c.size() > (size_t)INT32_MAX - 2048)
         return FFHIP_EINVAL;
     int32_t n = (int32_t)c.size();
-    c.resize((size_t)n + 400);
-    const int r = ffhip_h264_intra_pack(&R, nnzc, mb, mb_luma_dc, pcm, c.data(), &n, (int32_t)c.size());
+    c.resize((size_t)n + 816);
+    const int r = ffhip_h264_intra_pack_hbd(p->bd, &R, nnzc, mb, mb_luma_dc, pcm, c.data(), &n, (int32_t)c.size());
     c.resize((size_t)n);
     if (r < 0)
         return r;
@@ -337,6 +375,14 @@ extern "C" int ffhip_h264_intra_frame_dev(uint8_t *y, uint8_t *cb, uint8_t *cr, 
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     return ffhip_launch_h264_intra_frame(y, cb, cr, stride_y, stride_c, mb_w, mb_h, recs, row_start, coefs, (hipStream_t)stream);
+}
+
+extern "C" int ffhip_h264_intra_frame_dev_hbd(int bit_depth, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t stride_y, ptrdiff_t stride_c, int mb_w,
+                                              int mb_h, const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, void *stream)
+{
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_intra_frame_bd(bit_depth, y, cb, cr, stride_y, stride_c, mb_w, mb_h, recs, row_start, coefs, (hipStream_t)stream);
 }
 
 /* ---- flush ------------------------------------------------------------------------------------------ */
@@ -509,6 +555,10 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
                 if (s_ioff[pl][k].n)
                     r = ffhip_launch_h264_idct_add_bd(bd, k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off),
                                                       (int16_t *)(db + s_icoef[pl][k].off), s_ioff[pl][k].n, stream);
+        if (r >= 0 && !p->intra.empty())
+            r = ffhip_launch_h264_intra_frame_bd(bd, dst[0], dst[1], dst[2], stride[0], stride[1], p->mb_w, p->mb_h,
+                                                 (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
+                                                 (const int16_t *)(db + s_intracoef.off), stream);
         if (r < 0)
             return r;
         const bool chroma = p->any_edge[1] || p->any_edge[2];

@@ -42,27 +42,38 @@ struct ImbWave {
     }
 };
 
-__device__ __forceinline__ uint32_t ld_dev(const uint8_t *p)
+/* four samples: a dword at 8 bits, two above */
+template <typename PIX> struct ImbQuad { typedef uint32_t T; };
+template <> struct ImbQuad<uint16_t> { typedef uint64_t T; };
+template <typename Q>
+__device__ __forceinline__ Q ld_dev(const uint8_t *p)
 {
-    return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(reinterpret_cast<const Q *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_dev(uint8_t *p, uint32_t v)
+template <typename Q>
+__device__ __forceinline__ void st_dev(uint8_t *p, Q v)
 {
-    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<Q *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 } // namespace
 
 /* dword positions inside FFHipH264IntraMB the prefetch reads out of the lanes that hold them */
-static_assert(offsetof(FFHipH264IntraMB, type) == 4 && offsetof(FFHipH264IntraMB, coef) == 68 && offsetof(FFHipH264IntraMB, blocks) == 72,
+static_assert(offsetof(FFHipH264IntraMB, type) == 4 && offsetof(FFHipH264IntraMB, flags) == 40 && offsetof(FFHipH264IntraMB, coef) == 68 &&
+                  offsetof(FFHipH264IntraMB, blocks) == 72,
               "record layout");
 #define IMB_REC_DW ((int)(sizeof(FFHipH264IntraMB) / 4))
-#define IMB_RUN_MAX 384 /* int16: 16 x 16 luma + 8 x 16 chroma (a PCM macroblock: 192) */
 
+/* PIX = uint8_t: strides / plane pointers in bytes, runs of int16 coefficients (at most 16 x 16 luma + 8 x 16 chroma = 384 int16 = 3 dwords
+ * per lane).  PIX = uint16_t (9..14 bits): int32 coefficients, the sixteen luma DCs ahead of them: (16 + 384) int32 = 7 dwords per lane. */
+template <typename PIX>
 __global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                                          const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs,
-                                                         int *progress, int *fail)
+                                                         int *progress, int *fail, int maxv)
 {
-    __shared__ __align__(16) ImbTile T;
+    typedef typename ImbQuad<PIX>::T Q;
+    typedef typename ImbCoef<PIX>::T CF;
+    constexpr int PS = (int)sizeof(PIX), NDW = PS == 1 ? 3 : 7, IMB_RUN_MAX = NDW * 128 /* int16 */;
+    __shared__ __align__(16) ImbTileT<PIX> T;
     /* the macroblock being reconstructed and the next one: its record and coefficient run are fetched while this one is
      * worked on — read from global memory inside the block loop they were 16 dependent round trips per macroblock (measured:
      * 17.6 us per macroblock of an I-picture) */
@@ -79,20 +90,21 @@ __global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *p
     auto fetch_rec = [&](int idx) { /* dword `lane` of record idx */
         return lane < IMB_REC_DW && idx < kend ? reinterpret_cast<const uint32_t *>(recs + idx)[lane] : 0u;
     };
-    uint32_t cw[3];
+    uint32_t cw[NDW];
     auto fetch_run = [&](uint32_t rec_dw) { /* the run of the record whose dwords the lanes hold: 3 dwords per lane */
         const uint32_t type = __builtin_amdgcn_readlane(rec_dw, 1) & 0xFFu, blocks = __builtin_amdgcn_readlane(rec_dw, 18);
-        const int at = (int)__builtin_amdgcn_readlane(rec_dw, 17), ndw = imb_run_len((int)type, blocks) >> 1;
+        const int flags = (int)(__builtin_amdgcn_readlane(rec_dw, 10) & 0xFFu);
+        const int at = (int)__builtin_amdgcn_readlane(rec_dw, 17), ndw = imb_run_len((int)type, blocks, PS, flags) >> 1;
         const uint32_t *g = reinterpret_cast<const uint32_t *>(coefs + at);
 #pragma unroll
-        for (int j = 0; j < 3; j++)
+        for (int j = 0; j < NDW; j++)
             cw[j] = lane + 64 * j < ndw ? g[lane + 64 * j] : 0u;
     };
     auto park = [&](int slot, uint32_t rec_dw) {
         if (lane < IMB_REC_DW)
             reinterpret_cast<uint32_t *>(&Rb[slot])[lane] = rec_dw;
 #pragma unroll
-        for (int j = 0; j < 3; j++)
+        for (int j = 0; j < NDW; j++)
             reinterpret_cast<uint32_t *>(Cb[slot])[lane + 64 * j] = cw[j];
     };
     {
@@ -125,47 +137,47 @@ __global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *p
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* the neighbour loads are issued after the counter was seen */
         }
         /* ---- neighbours into the tile, one dword per lane; what lies outside the picture reads as 0 ---- */
-        uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16;
-        uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 };
+        uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16 * PS;
+        uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8 * PS, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 * PS };
         const bool has_l = mx > 0, has_t = my > 0, has_r = mx + 1 < mb_w;
-        uint32_t nb = 0;
+        Q nb = 0;
         if (lane < 8) { /* the row above: columns -4 .. 27 */
             const int c = 4 * lane - 4;
             if (has_t && (c >= 0 || has_l) && (c < 16 || has_r))
-                nb = ld_dev(ymb - sy + c);
+                nb = ld_dev<Q>(ymb - sy + c * PS);
         } else if (lane < 24) { /* the column to the left */
             if (has_l)
-                nb = ld_dev(ymb + (ptrdiff_t)(lane - 8) * sy - 4);
+                nb = ld_dev<Q>(ymb + (ptrdiff_t)(lane - 8) * sy - 4 * PS);
         } else if (lane < 30) {
             const int p = (lane - 24) / 3, c = 4 * ((lane - 24) % 3) - 4;
             if (has_t && (c >= 0 || has_l))
-                nb = ld_dev(cmb[p] - sc + c);
+                nb = ld_dev<Q>(cmb[p] - sc + c * PS);
         } else if (lane < 46) {
             if (has_l)
-                nb = ld_dev(cmb[(lane - 30) >> 3] + (ptrdiff_t)((lane - 30) & 7) * sc - 4);
+                nb = ld_dev<Q>(cmb[(lane - 30) >> 3] + (ptrdiff_t)((lane - 30) & 7) * sc - 4 * PS);
         }
         /* the next macroblock's coefficients leave now and land while this one is reconstructed */
         if (k + 1 < kend)
             fetch_run(nrec);
         if (lane < 8) {
-            *reinterpret_cast<uint32_t *>(&T.y[imb_yi(-1, 4 * lane - 4)]) = nb;
+            *reinterpret_cast<Q *>(&T.y[imb_yi(-1, 4 * lane - 4)]) = nb;
         } else if (lane < 24) { /* + zeros right of the macroblock (a top-right block that does not exist) */
             const int r = lane - 8;
-            *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, -4)]) = nb;
-            *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, 16)]) = 0u;
-            *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, 20)]) = 0u;
+            *reinterpret_cast<Q *>(&T.y[imb_yi(r, -4)]) = nb;
+            *reinterpret_cast<Q *>(&T.y[imb_yi(r, 16)]) = 0u;
+            *reinterpret_cast<Q *>(&T.y[imb_yi(r, 20)]) = 0u;
         } else if (lane < 30) {
-            *reinterpret_cast<uint32_t *>(&T.c[(lane - 24) / 3][imb_ci(-1, 4 * ((lane - 24) % 3) - 4)]) = nb;
+            *reinterpret_cast<Q *>(&T.c[(lane - 24) / 3][imb_ci(-1, 4 * ((lane - 24) % 3) - 4)]) = nb;
         } else if (lane < 46) {
-            *reinterpret_cast<uint32_t *>(&T.c[(lane - 30) >> 3][imb_ci((lane - 30) & 7, -4)]) = nb;
+            *reinterpret_cast<Q *>(&T.c[(lane - 30) >> 3][imb_ci((lane - 30) & 7, -4)]) = nb;
         }
         imb_wave_sync();
-        imb_reconstruct(X, T, R, Cb[cur]);
-        /* ---- the macroblock leaves the tile: 64 + 32 dwords, write-through ---- */
-        st_dev(ymb + (ptrdiff_t)(lane >> 2) * sy + 4 * (lane & 3), *reinterpret_cast<const uint32_t *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]));
+        imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(Cb[cur]), maxv);
+        /* ---- the macroblock leaves the tile: 64 + 32 quads of samples, write-through ---- */
+        st_dev<Q>(ymb + (ptrdiff_t)(lane >> 2) * sy + 4 * (lane & 3) * PS, *reinterpret_cast<const Q *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]));
         if (lane < 32) {
             const int p = lane >> 4, r = (lane >> 1) & 7, c = 4 * (lane & 1);
-            st_dev(cmb[p] + (ptrdiff_t)r * sc + c, *reinterpret_cast<const uint32_t *>(&T.c[p][imb_ci(r, c)]));
+            st_dev<Q>(cmb[p] + (ptrdiff_t)r * sc + c * PS, *reinterpret_cast<const Q *>(&T.c[p][imb_ci(r, c)]));
         }
         const int next = k + 1 < kend ? (int)(__builtin_amdgcn_readlane(nrec, 0) & 0xFFFFu) : mb_w; /* the next record's mb_x */
         if (k + 1 < kend)
@@ -182,14 +194,25 @@ __global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *p
 int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                   const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream)
 {
+    return ffhip_launch_h264_intra_frame_bd(8, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, stream);
+}
+
+int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                     const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream)
+{
     if (mb_w <= 0 || mb_h <= 0)
         return 0;
+    if (bd != 8 && bd != 9 && bd != 10 && bd != 12 && bd != 14) {
+        ffhip_set_error("ffhip_h264_intra_frame: bit depth %d (8, 9, 10, 12 and 14 are the depths H.264 defines)", bd);
+        return FFHIP_EINVAL;
+    }
+    const unsigned amask = bd > 8 ? 7u : 3u; /* four samples per access */
     if (!y || !cb || !cr || !recs || !row_start || !coefs) {
         ffhip_set_error("ffhip_h264_intra_frame: null argument");
         return FFHIP_EINVAL;
     }
-    if (((uintptr_t)y | (uintptr_t)cb | (uintptr_t)cr | (size_t)sy | (size_t)sc) & 3) {
-        ffhip_set_error("ffhip_h264_intra_frame: planes and strides must be 4-byte aligned");
+    if (((uintptr_t)y | (uintptr_t)cb | (uintptr_t)cr | (size_t)sy | (size_t)sc) & amask) {
+        ffhip_set_error("ffhip_h264_intra_frame: planes and strides must be %u-byte aligned", amask + 1);
         return FFHIP_EINVAL;
     }
     FFHipProgressSlot ps;
@@ -197,7 +220,12 @@ int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_
     if (r < 0)
         return r;
     int *const prog = ps.prog, *const fail = ps.fail;
-    hipLaunchKernelGGL(k_h264_intra_frame, dim3(mb_h), dim3(64), 0, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog, fail);
+    if (bd > 8)
+        hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(mb_h), dim3(64), 0, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog, fail,
+                           (1 << bd) - 1);
+    else
+        hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(mb_h), dim3(64), 0, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog, fail,
+                           255);
     const hipError_t e = hipGetLastError();
     const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
     if (e != hipSuccess) {

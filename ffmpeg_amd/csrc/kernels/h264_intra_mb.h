@@ -1,5 +1,7 @@
 /*
- * h264_intra_mb.h — reconstruction of ONE intra macroblock (8 bits, 4:2:0, frame macroblock, no transform bypass): what
+ * h264_intra_mb.h — reconstruction of ONE intra macroblock (4:2:0, frame macroblock, no transform bypass; templated on the sample
+ * type: uint8_t with int16_t coefficients, uint16_t at 9..14 bits with int32_t coefficients — pixel / dctcoef of
+ * libavcodec/bit_depth_template.c:39-50): what
  * hl_decode_mb() does between the two xchg_mb_border() calls and after them (libavcodec/h264_mb_template.c:151-262,
  * hl_decode_mb_predict_luma / hl_decode_mb_idct_luma libavcodec/h264_mb.c:612-760):
  *
@@ -102,10 +104,10 @@ IMB_FN int hp_dir_sample(int mode, const int *e, int x, int y, int dc)
 
 /* the DC of modes 2 (both sides), 9 (LEFT_DC), 10 (TOP_DC); 128 otherwise */
 template <int N, class E>
-IMB_FN int hp_dir_dc_e(int mode, const E &e)
+IMB_FN int hp_dir_dc_e(int mode, const E &e, int mid = 128 /* 1 << (bit_depth - 1) */)
 {
     if (mode != 2 && mode != 9 && mode != 10)
-        return 128;
+        return mid;
     int sl = 0, st = 0;
     for (int i = 0; i < N; i++) {
         sl += mode != 10 ? e(i) : 0;
@@ -148,12 +150,17 @@ IMB_FN int hp_filter8(const int *w, int j, unsigned need, bool tl, bool tr)
 }
 
 /* ---- the tile ---- */
-struct ImbTile {
-    uint8_t y[17 * 32];    /* luma:   sample (r, c), r = -1..15, c = -4..27, at [(r + 1) * 32 + c + 4] */
-    uint8_t c[2][9 * 16];  /* chroma: sample (r, c), r = -1..7,  c = -4..11, at [(r + 1) * 16 + c + 4] */
+template <typename PIX> struct ImbCoef { typedef int16_t T; };
+template <> struct ImbCoef<uint16_t> { typedef int32_t T; };
+
+template <typename PIX>
+struct ImbTileT {
+    PIX y[17 * 32];        /* luma:   sample (r, c), r = -1..15, c = -4..27, at [(r + 1) * 32 + c + 4] */
+    PIX c[2][9 * 16];      /* chroma: sample (r, c), r = -1..7,  c = -4..11, at [(r + 1) * 16 + c + 4] */
     int t8[4][64];         /* first pass of the four 8x8 inverse transforms */
     int dcq[16];           /* luma_dc_dequant_idct's results by block */
 };
+typedef ImbTileT<uint8_t> ImbTile;
 
 IMB_FN int imb_yi(int r, int c) { return (r + 1) * 32 + c + 4; }
 IMB_FN int imb_ci(int r, int c) { return (r + 1) * 16 + c + 4; }
@@ -165,6 +172,14 @@ IMB_FN int imb_clip_u8(int v)
 #endif
     return r;
 }
+/* av_clip_pixel at the tile's depth: maxv = (1 << bit_depth) - 1 */
+template <typename PIX>
+IMB_FN int imb_clip(int v, int maxv)
+{
+    if (sizeof(PIX) == 1)
+        return imb_clip_u8(v);
+    return v < 0 ? 0 : v > maxv ? maxv : v;
+}
 IMB_FN int imb_popc(uint32_t v) { return __builtin_popcount(v); }
 
 /* position of 4x4 block i inside the macroblock (h->block_offset[i], h264_slice.c init_scan_tables / block_offset) */
@@ -172,20 +187,27 @@ IMB_FN int imb_bx(int i) { return 4 * ((i & 1) + ((i >> 2) & 1) * 2); }
 IMB_FN int imb_by(int i) { return 4 * (((i >> 1) & 1) + ((i >> 3) & 1) * 2); }
 
 /* coefficients of luma block i (0..15; 8x8 transform: i = 0, 4, 8, 12, 64 coefficients) / chroma block 16 + k (Cb), 20 + k (Cr)
- * in the macroblock's packed run (run = the picture's coefficient array + R.coef, or a copy of the run); nullptr when the block was all zero and not stored */
-IMB_FN const int16_t *imb_block(const FFHipH264IntraMB &R, const int16_t *run, int bit)
+ * in the macroblock's packed run (run = the picture's coefficient array + R.coef, or a copy of the run); nullptr when the block was
+ * all zero and not stored.  Above 8 bits a run that carries FFHIP_H264_INTRA_LUMA_DC starts with the sixteen int32 luma DCs
+ * (sl->mb_luma_dc as dctcoef; the record's int16 luma_dc[] cannot hold them). */
+template <typename CF>
+IMB_FN const CF *imb_block(const FFHipH264IntraMB &R, const CF *run, int bit)
 {
     if (!((R.blocks >> bit) & 1u))
         return nullptr;
     const int lsz = R.type == FFHIP_H264_INTRA_8x8 ? 64 : 16;
     const uint32_t below = R.blocks & ((1u << bit) - 1u);
-    return run + imb_popc(below & 0xFFFFu) * lsz + imb_popc(below >> 16) * 16;
+    const int lead = sizeof(CF) == 4 && (R.flags & FFHIP_H264_INTRA_LUMA_DC) ? 16 : 0;
+    return run + lead + imb_popc(below & 0xFFFFu) * lsz + imb_popc(below >> 16) * 16;
 }
 
-/* int16 entries of a macroblock's run */
-IMB_FN int imb_run_len(int type, uint32_t blocks)
+/* int16 entries of a macroblock's run; psz = sizeof(sample) */
+IMB_FN int imb_run_len(int type, uint32_t blocks, int psz = 1, int flags = 0)
 {
-    return type == FFHIP_H264_INTRA_PCM ? 192 : imb_popc(blocks & 0xFFFFu) * (type == FFHIP_H264_INTRA_8x8 ? 64 : 16) + imb_popc(blocks >> 16) * 16;
+    if (type == FFHIP_H264_INTRA_PCM)
+        return 192 * psz;
+    const int n = imb_popc(blocks & 0xFFFFu) * (type == FFHIP_H264_INTRA_8x8 ? 64 : 16) + imb_popc(blocks >> 16) * 16;
+    return psz == 1 ? n : 2 * (n + ((flags & FFHIP_H264_INTRA_LUMA_DC) ? 16 : 0));
 }
 
 /* output k of the 4-point butterfly of ff_h264_idct_add (h264idct_template.c:39-64): modulo 2^32, arithmetic shifts */
@@ -197,13 +219,14 @@ IMB_FN int imb_bfly4(int k, int s0, int s1, int s2, int s3)
 }
 
 /* what ff_h264_idct_add adds to sample (x, y) of its block; b[0] is passed separately (Intra16x16 puts the dequantised DC there) */
-IMB_FN int imb_idct4_at(const int16_t *b, int b0, int x, int y)
+template <typename CF>
+IMB_FN int imb_idct4_at(const CF *b, int b0, int x, int y)
 {
     int r[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int s0 = j == 0 ? (int16_t)(b0 + 32) : (b ? b[j] : 0);
-        r[j] = (int16_t)imb_bfly4(x, s0, b ? b[j + 4] : 0, b ? b[j + 8] : 0, b ? b[j + 12] : 0); /* the first pass stores int16 */
+        const int s0 = j == 0 ? (CF)(b0 + 32) : (b ? b[j] : 0);
+        r[j] = (CF)imb_bfly4(x, s0, b ? b[j + 4] : 0, b ? b[j + 8] : 0, b ? b[j + 12] : 0); /* the first pass stores dctcoef */
     }
     return imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
 }
@@ -232,9 +255,10 @@ IMB_FN void imb_idct8_1d(const int in[8], uint32_t out[8])
 
 /* pred8x8 (N = 8, with the one-sided "mad cow" DC variants) / pred16x16 (N = 16) sample (x, y); t / l index the tile's row above
  * and left column through TOP(i) / LEFT(i), i = -1 the corner (h264pred_template.c:389-820; modes h264pred.h:67-82) */
-template <int N, class Top, class Left>
-IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT)
+template <int N, typename PIX = uint8_t, class Top, class Left>
+IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT, int maxv = 255)
 {
+    const int mid = (maxv + 1) >> 1;
     constexpr int H2 = N / 2;
     if (mode == 1)
         return LEFT(y);
@@ -249,7 +273,7 @@ IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT)
         H = N == 16 ? (5 * H + 32) >> 6 : (17 * H + 16) >> 5;
         V = N == 16 ? (5 * V + 32) >> 6 : (17 * V + 16) >> 5;
         const int a = 16 * (LEFT(N - 1) + TOP(N - 1) + 1) - (H2 - 1) * (V + H);
-        return imb_clip_u8((a + y * V + x * H) >> 5);
+        return imb_clip<PIX>((a + y * V + x * H) >> 5, maxv);
     }
     if (N == 16) {
         int sl = 0, st = 0;
@@ -257,7 +281,7 @@ IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT)
             sl += (mode == 0 || mode == 4) ? LEFT(i) : 0;
             st += (mode == 0 || mode == 5) ? TOP(i) : 0;
         }
-        return mode == 0 ? (sl + st + 16) >> 5 : mode == 4 ? (sl + 8) >> 4 : mode == 5 ? (st + 8) >> 4 : 128;
+        return mode == 0 ? (sl + st + 16) >> 5 : mode == 4 ? (sl + 8) >> 4 : mode == 5 ? (st + 8) >> 4 : mid;
     }
     const bool ut = mode == 0 || mode == 5 || mode == 7 || mode == 8, ul = mode == 0 || mode == 4 || mode >= 7;
     int t0 = 0, t1 = 0, l0 = 0, l1 = 0;
@@ -267,7 +291,7 @@ IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT)
         l0 += ul ? LEFT(i) : 0;
         l1 += (ul && mode != 7) ? LEFT(4 + i) : 0;
     }
-    int q0 = 128, q1 = 128, q2 = 128, q3 = 128;
+    int q0 = mid, q1 = mid, q2 = mid, q3 = mid;
     switch (mode) {
     case 0: q0 = (t0 + l0 + 4) >> 3; q1 = (t1 + 2) >> 2; q2 = (l1 + 2) >> 2; q3 = (t1 + l1 + 4) >> 3; break;
     case 4: q0 = q1 = (l0 + 2) >> 2; q2 = q3 = (l1 + 2) >> 2; break;
@@ -285,12 +309,16 @@ IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT)
  * The macroblock, phase by phase.  X.run(body) runs body(lane) for the 64 lanes and synchronises the tile.
  * T holds the neighbours (unavailable ones as 0) on entry and the reconstructed macroblock on return.
  */
-template <class X>
-IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const int16_t *coefs /* the macroblock's run */)
+template <typename PIX, class X>
+IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, const typename ImbCoef<PIX>::T *coefs /* the macroblock's run */,
+                            int maxv = 255 /* (1 << bit_depth) - 1 */)
 {
+    typedef typename ImbCoef<PIX>::T CF;
+    const int mid = (maxv + 1) >> 1;
     if (R.type == FFHIP_H264_INTRA_PCM) {
-        /* the samples as they stand in the bitstream: 256 luma, 64 Cb, 64 Cr bytes (h264_mb_template.c:137-150) */
-        const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coefs);
+        /* the samples as they stand in the bitstream: 256 luma, 64 Cb, 64 Cr (h264_mb_template.c:98-150; above 8 bits the host side
+         * has unpacked the bit_depth-bit fields into uint16_t) */
+        const PIX *pcm = reinterpret_cast<const PIX *>(coefs);
         x.run([&](int lane) {
             for (int j = 0; j < 4; j++)
                 T.y[imb_yi(lane >> 2, 4 * (lane & 3) + j)] = pcm[16 * (lane >> 2) + 4 * (lane & 3) + j];
@@ -305,13 +333,13 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
     x.run([&](int lane) {
         if (lane < 32) {
             const int p = lane >> 4, yy = (lane >> 1) & 7, x0 = 4 * (lane & 1);
-            const uint8_t *tc = T.c[p];
+            const PIX *tc = T.c[p];
             auto TOP = [&](int i) { return (int)tc[imb_ci(-1, i)]; };
             auto LEFT = [&](int i) { return (int)tc[imb_ci(i, -1)]; };
             const int k = (yy >> 2) * 2 + (x0 >> 2); /* chroma block 16 + k / 32 + k */
             int dc = 0;
             bool full = false, dconly = false;
-            const int16_t *b = nullptr;
+            const CF *b = nullptr;
             if (R.cbp & 0x30) {
                 b = imb_block(R, coefs, 16 + 4 * p + k);
                 dc = b ? b[0] : 0;
@@ -320,7 +348,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
                     int d4[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const int16_t *bq = imb_block(R, coefs, 16 + 4 * p + q);
+                        const CF *bq = imb_block(R, coefs, 16 + 4 * p + q);
                         d4[q] = bq ? bq[0] : 0;
                     }
                     const uint32_t qm = (uint32_t)R.qmul[1 + p];
@@ -328,24 +356,24 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
                     const uint32_t e = a - bb;
                     a = a + bb; bb = c - d; c = c + d;
                     const uint32_t v = k == 0 ? a + c : k == 1 ? e + bb : k == 2 ? a - c : e - bb;
-                    dc = (int16_t)((int)(v * qm) >> 7);
+                    dc = (CF)((int)(v * qm) >> 7);
                 }
                 full = R.nnz[16 + 4 * p + k] != 0;
                 dconly = !full && dc != 0;
             }
             for (int j = 0; j < 4; j++) {
-                int v = imb_pred_blk<8>(R.chroma_pred, x0 + j, yy, TOP, LEFT);
+                int v = imb_pred_blk<8, PIX>(R.chroma_pred, x0 + j, yy, TOP, LEFT, maxv);
                 if (full)
-                    v = imb_clip_u8(v + imb_idct4_at(b, dc, j, yy & 3));
+                    v = imb_clip<PIX>(v + imb_idct4_at(b, dc, j, yy & 3), maxv);
                 else if (dconly)
-                    v = imb_clip_u8(v + ((dc + 32) >> 6));
-                T.c[p][imb_ci(yy, x0 + j)] = (uint8_t)v;
+                    v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
+                T.c[p][imb_ci(yy, x0 + j)] = (PIX)v;
             }
         } else if (R.type == FFHIP_H264_INTRA_8x8) {
             /* first pass of the four 8x8 inverse transforms (they depend on the coefficients alone): lane 32 + 8 q + j = transform j
              * of block 4 q, working on block[j + 8 k], results stored as int16 */
             const int q = (lane - 32) >> 3, j = lane & 7, nnz = R.nnz[4 * q];
-            const int16_t *b = nnz ? imb_block(R, coefs, 4 * q) : nullptr;
+            const CF *b = nnz ? imb_block(R, coefs, 4 * q) : nullptr;
             if (b && !(nnz == 1 && b[0])) {
                 int in[8];
                 uint32_t out[8];
@@ -353,11 +381,11 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
                 for (int k = 0; k < 8; k++)
                     in[k] = b[j + 8 * k];
                 if (j == 0)
-                    in[0] = (int16_t)(in[0] + 32);
+                    in[0] = (CF)(in[0] + 32);
                 imb_idct8_1d(in, out);
 #pragma unroll
                 for (int k = 0; k < 8; k++)
-                    T.t8[q][j + 8 * k] = (int16_t)out[k];
+                    T.t8[q][j + 8 * k] = (CF)out[k];
             }
         } else if (lane < 48 && R.type == FFHIP_H264_INTRA_16x16 && (R.flags & FFHIP_H264_INTRA_LUMA_DC)) {
             /* luma_dc_dequant_idct (h264idct_template.c:259-293): lane 32 + o computes output o of the 4x4 Hadamard */
@@ -365,7 +393,9 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
             int t[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int a = R.luma_dc[4 * r], b = R.luma_dc[4 * r + 1], c = R.luma_dc[4 * r + 2], d = R.luma_dc[4 * r + 3];
+                /* above 8 bits the sixteen DCs lead the run (imb_block) */
+                const int a = sizeof(CF) == 4 ? (int)coefs[4 * r] : R.luma_dc[4 * r], b = sizeof(CF) == 4 ? (int)coefs[4 * r + 1] : R.luma_dc[4 * r + 1];
+                const int c = sizeof(CF) == 4 ? (int)coefs[4 * r + 2] : R.luma_dc[4 * r + 2], d = sizeof(CF) == 4 ? (int)coefs[4 * r + 3] : R.luma_dc[4 * r + 3];
                 const int z0 = a + b, z1 = a - b, z2 = c - d, z3 = c + d;
                 t[r] = i == 0 ? z0 + z3 : i == 1 ? z0 - z3 : i == 2 ? z1 - z2 : z1 + z2;
             }
@@ -374,7 +404,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
             const uint32_t v = w == 0 ? z0 + z3 : w == 1 ? z1 + z2 : w == 2 ? z1 - z2 : z0 - z3;
             /* output[16 * {0, 1, 4, 5}[w] + x_offset[i]], x_offset = {0, 32, 128, 160}: as a block number */
             const int blk = (w == 0 ? 0 : w == 1 ? 1 : w == 2 ? 4 : 5) + (i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 8 : 10);
-            T.dcq[blk] = (int16_t)((int)(v * (uint32_t)R.qmul[0] + 128) >> 8);
+            T.dcq[blk] = (CF)((int)(v * (uint32_t)R.qmul[0] + 128) >> 8);
         }
     });
 
@@ -384,16 +414,16 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
             const int i = lane >> 2, yy = imb_by(i) + (lane & 3), x0 = imb_bx(i);
             auto TOP = [&](int k) { return (int)T.y[imb_yi(-1, k)]; };
             auto LEFT = [&](int k) { return (int)T.y[imb_yi(k, -1)]; };
-            const int16_t *b = imb_block(R, coefs, i);
+            const CF *b = imb_block(R, coefs, i);
             const int dc = (R.flags & FFHIP_H264_INTRA_LUMA_DC) ? T.dcq[i] : (b ? b[0] : 0);
             const bool full = R.nnz[i] != 0, dconly = !full && dc != 0;
             for (int j = 0; j < 4; j++) {
-                int v = imb_pred_blk<16>(R.pred16, x0 + j, yy, TOP, LEFT);
+                int v = imb_pred_blk<16, PIX>(R.pred16, x0 + j, yy, TOP, LEFT, maxv);
                 if (full)
-                    v = imb_clip_u8(v + imb_idct4_at(b, dc, j, lane & 3));
+                    v = imb_clip<PIX>(v + imb_idct4_at(b, dc, j, lane & 3), maxv);
                 else if (dconly)
-                    v = imb_clip_u8(v + ((dc + 32) >> 6));
-                T.y[imb_yi(yy, x0 + j)] = (uint8_t)v;
+                    v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
+                T.y[imb_yi(yy, x0 + j)] = (PIX)v;
             }
         });
         return;
@@ -422,17 +452,17 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
                     return (int)T.y[imb_yi(r, c)];
                 };
                 const int xx = lane & 3, yy = (lane >> 2) & 3;
-                int v = hp_dir_sample_e<4>(mode, e, xx, yy, hp_dir_dc_e<4>(mode, e));
+                int v = hp_dir_sample_e<4>(mode, e, xx, yy, hp_dir_dc_e<4>(mode, e, mid));
                 const int nnz = R.nnz[i];
                 if (nnz) {
-                    const int16_t *b = imb_block(R, coefs, i);
+                    const CF *b = imb_block(R, coefs, i);
                     const int dc = b ? b[0] : 0;
                     if (nnz == 1 && dc)
-                        v = imb_clip_u8(v + ((dc + 32) >> 6));
+                        v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
                     else
-                        v = imb_clip_u8(v + imb_idct4_at(b, dc, xx, yy));
+                        v = imb_clip<PIX>(v + imb_idct4_at(b, dc, xx, yy), maxv);
                 }
-                T.y[imb_yi(by + yy, bx + xx)] = (uint8_t)v;
+                T.y[imb_yi(by + yy, bx + xx)] = (PIX)v;
             });
         }
         return;
@@ -444,14 +474,14 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
         const int bx = imb_bx(i), by = imb_by(i), mode = R.pred4[i], nnz = R.nnz[i];
         const bool tl = (R.topleft_avail << i) & 0x8000, tr = (R.topright_avail << i) & 0x4000;
         const unsigned need = hp_need(mode);
-        const int16_t *b = nnz ? imb_block(R, coefs, i) : nullptr;
+        const CF *b = nnz ? imb_block(R, coefs, i) : nullptr;
         const int dc = b ? b[0] : 0;
         const bool dconly = nnz == 1 && dc, full = nnz && !dconly;
         x.run([&](int lane) {
             auto w = [&](int k) { return (int)T.y[k < 8 ? imb_yi(by + 7 - k, bx - 1) : imb_yi(by - 1, bx + k - 9)]; };
             auto ef = [&](int k) { return hp_filter8_e(w, k, need, tl, tr); };
             const int xx = lane & 7, yy = lane >> 3;
-            int v = hp_dir_sample_e<8>(mode, ef, xx, yy, hp_dir_dc_e<8>(mode, ef));
+            int v = hp_dir_sample_e<8>(mode, ef, xx, yy, hp_dir_dc_e<8>(mode, ef, mid));
             if (full) {
                 /* second pass: transform xx works on block[8 xx + k], output yy goes to dst[xx + yy * stride] */
                 int in[8];
@@ -464,11 +494,11 @@ IMB_FN void imb_reconstruct(X &x, ImbTile &T, const FFHipH264IntraMB &R, const i
 #pragma unroll
                 for (int k = 1; k < 8; k++)
                     o = yy == k ? out[k] : o;
-                v = imb_clip_u8(v + ((int)o >> 6));
+                v = imb_clip<PIX>(v + ((int)o >> 6), maxv);
             } else if (dconly) {
-                v = imb_clip_u8(v + ((dc + 32) >> 6));
+                v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
             }
-            T.y[imb_yi(by + yy, bx + xx)] = (uint8_t)v;
+            T.y[imb_yi(by + yy, bx + xx)] = (PIX)v;
         });
     }
 }

@@ -612,8 +612,8 @@ int  ffhip_h264_picture_create(FFHipH264Picture **p, int mb_w, int mb_h);
 /** The same object for a High 10 / High 4:2:0 picture of bit_depth 9 / 10 / 12 / 14 (8: == ffhip_h264_picture_create): planes hold
  *  uint16_t samples, offsets and strides stay in BYTES (as the decoder's linesize / block_offset << pixel_shift), the blocks handed to
  *  idct_add() hold int32_t coefficients (dctcoef, libavcodec/bit_depth_template.c:39-50; sl->mb as the decoder keeps it), edge records
- *  keep alpha / beta / tc0 at the 8-bit scale (the kernels scale them as h264dsp_template.c:108-110 does).  The inter stages and the
- *  decoder-order deblocking run; intra macroblocks are refused at record time (FFHIP_ENOSYS: the reconstruction wavefront is 8-bit). */
+ *  keep alpha / beta / tc0 at the 8-bit scale (the kernels scale them as h264dsp_template.c:108-110 does), intra macroblocks hand
+ *  over sl->mb / sl->mb_luma_dc / sl->intra_pcm_ptr as ffhip_h264_intra_pack_hbd() describes.  Planes and strides 8-byte aligned. */
 int  ffhip_h264_picture_create_hbd(FFHipH264Picture **p, int mb_w, int mb_h, int bit_depth);
 void ffhip_h264_picture_free(FFHipH264Picture **p);
 void ffhip_h264_picture_begin(FFHipH264Picture *p);
@@ -675,11 +675,23 @@ int  ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264IntraMB *mb
  *  391 of them), advancing *ncoefs.  FFHIP_ENOMEM when the run does not fit. */
 int  ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *non_zero_count_cache, int16_t *mb, const int16_t *mb_luma_dc,
                            const uint8_t *pcm, int16_t *coefs, int32_t *ncoefs, int32_t cap);
+/** The same at bit_depth 9 / 10 / 12 / 14 (8: == ffhip_h264_intra_pack; what ffhip_h264_picture_intra_mb() runs on a picture made by
+ *  ffhip_h264_picture_create_hbd()): mb and mb_luma_dc are the decoder's arrays AS THEY STAND at that depth — 3 x 256 and 16 int32
+ *  (dctcoef, libavcodec/bit_depth_template.c:39-50) behind the int16_t pointers sl->mb / sl->mb_luma_dc are declared with; pcm is
+ *  sl->intra_pcm_ptr, 384 bit_depth-bit fields (h264_mb_template.c:100-131), unpacked here into uint16_t samples.  coefs, *ncoefs, cap
+ *  and rec->coef keep counting int16 entries (a run is at most 807 of them); an Intra16x16 macroblock's sixteen luma DCs lead its run
+ *  (rec->luma_dc stays zero: it cannot hold them). */
+int  ffhip_h264_intra_pack_hbd(int bit_depth, FFHipH264IntraMB *rec, const uint8_t *non_zero_count_cache, int16_t *mb,
+                               const int16_t *mb_luma_dc, const uint8_t *pcm, int16_t *coefs, int32_t *ncoefs, int32_t cap);
 /** The intra reconstruction wavefront alone, on records already in device memory (what flush() launches): recs sorted by
  *  (mb_y, mb_x), row_start[mb_h + 1] indexes them by macroblock row, coefs is the packed coefficient array.  Planes and strides
  *  4-byte aligned.  Asynchronous on `stream`; a lost hand-off is reported by the next flush / ffhip_stream_synchronize. */
 int  ffhip_h264_intra_frame_dev(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t stride_y, ptrdiff_t stride_c, int mb_w, int mb_h,
                                 const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, void *stream);
+/** The same on uint16_t samples at bit_depth 9 / 10 / 12 / 14 (records and runs as ffhip_h264_intra_pack_hbd() leaves them; strides in
+ *  bytes; planes and strides 8-byte aligned). */
+int  ffhip_h264_intra_frame_dev_hbd(int bit_depth, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t stride_y, ptrdiff_t stride_c, int mb_w,
+                                    int mb_h, const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, void *stream);
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
 int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                               void *stream);

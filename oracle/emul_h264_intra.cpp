@@ -22,9 +22,12 @@ struct EmulWave {
 };
 } // namespace
 
-extern "C" int ffemul_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
-                                       const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs)
+template <typename PIX>
+static int intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraMB *recs,
+                       const int32_t *row_start, const int16_t *coefs, int maxv)
 {
+    typedef typename ImbCoef<PIX>::T CF;
+    constexpr int PS = (int)sizeof(PIX), QB = 4 * PS; /* the kernel moves four samples per lane */
     EmulWave X;
     for (int my = 0; my < mb_h; my++)
         for (int k = row_start[my]; k < row_start[my + 1]; k++) {
@@ -32,43 +35,58 @@ extern "C" int ffemul_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, 
             const int mx = R.mb_x;
             if (R.mb_y != my || mx < 0 || mx >= mb_w || (k > row_start[my] && recs[k - 1].mb_x >= mx))
                 return -1;
-            ImbTile T;
+            ImbTileT<PIX> T;
             memset(&T, 0xA5, sizeof(T)); /* whatever the phases do not write first must not matter */
-            uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16;
-            uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 };
+            uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16 * PS;
+            uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8 * PS, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 * PS };
             const bool has_l = mx > 0, has_t = my > 0, has_r = mx + 1 < mb_w;
-            /* the kernel's tile fill, dword by dword */
+            /* the kernel's tile fill, quad by quad */
             for (int lane = 0; lane < 46; lane++) {
-                uint32_t v = 0;
+                uint64_t v = 0;
                 if (lane < 8) {
                     const int c = 4 * lane - 4;
                     if (has_t && (c >= 0 || has_l) && (c < 16 || has_r))
-                        memcpy(&v, ymb - sy + c, 4);
-                    memcpy(&T.y[imb_yi(-1, c)], &v, 4);
+                        memcpy(&v, ymb - sy + c * PS, QB);
+                    memcpy(&T.y[imb_yi(-1, c)], &v, QB);
                 } else if (lane < 24) {
                     const int r = lane - 8;
                     if (has_l)
-                        memcpy(&v, ymb + (ptrdiff_t)r * sy - 4, 4);
-                    memcpy(&T.y[imb_yi(r, -4)], &v, 4);
-                    memset(&T.y[imb_yi(r, 16)], 0, 8);
+                        memcpy(&v, ymb + (ptrdiff_t)r * sy - 4 * PS, QB);
+                    memcpy(&T.y[imb_yi(r, -4)], &v, QB);
+                    memset(&T.y[imb_yi(r, 16)], 0, 2 * QB);
                 } else if (lane < 30) {
                     const int p = (lane - 24) / 3, c = 4 * ((lane - 24) % 3) - 4;
                     if (has_t && (c >= 0 || has_l))
-                        memcpy(&v, cmb[p] - sc + c, 4);
-                    memcpy(&T.c[p][imb_ci(-1, c)], &v, 4);
+                        memcpy(&v, cmb[p] - sc + c * PS, QB);
+                    memcpy(&T.c[p][imb_ci(-1, c)], &v, QB);
                 } else {
                     const int p = (lane - 30) >> 3, r = (lane - 30) & 7;
                     if (has_l)
-                        memcpy(&v, cmb[p] + (ptrdiff_t)r * sc - 4, 4);
-                    memcpy(&T.c[p][imb_ci(r, -4)], &v, 4);
+                        memcpy(&v, cmb[p] + (ptrdiff_t)r * sc - 4 * PS, QB);
+                    memcpy(&T.c[p][imb_ci(r, -4)], &v, QB);
                 }
             }
-            imb_reconstruct(X, T, R, coefs + R.coef);
+            imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(coefs + R.coef), maxv);
             for (int r = 0; r < 16; r++)
-                memcpy(ymb + (ptrdiff_t)r * sy, &T.y[imb_yi(r, 0)], 16);
+                memcpy(ymb + (ptrdiff_t)r * sy, &T.y[imb_yi(r, 0)], 16 * PS);
             for (int p = 0; p < 2; p++)
                 for (int r = 0; r < 8; r++)
-                    memcpy(cmb[p] + (ptrdiff_t)r * sc, &T.c[p][imb_ci(r, 0)], 8);
+                    memcpy(cmb[p] + (ptrdiff_t)r * sc, &T.c[p][imb_ci(r, 0)], 8 * PS);
         }
     return 0;
+}
+
+extern "C" int ffemul_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                       const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs)
+{
+    return intra_frame<uint8_t>(py, pcb, pcr, sy, sc, mb_w, mb_h, recs, row_start, coefs, 255);
+}
+
+/* bit_depth 9 / 10 / 12 / 14: uint16_t samples, strides in bytes, runs of int32 coefficients */
+extern "C" int ffemul_h264_intra_frame_bd(int bd, uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                          const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs)
+{
+    if (bd == 8)
+        return intra_frame<uint8_t>(py, pcb, pcr, sy, sc, mb_w, mb_h, recs, row_start, coefs, 255);
+    return intra_frame<uint16_t>(py, pcb, pcr, sy, sc, mb_w, mb_h, recs, row_start, coefs, (1 << bd) - 1);
 }

@@ -26,32 +26,35 @@ def bxy(i):
     return 4 * ((i & 1) + ((i >> 2) & 1) * 2), 4 * (((i >> 1) & 1) + ((i >> 3) & 1) * 2)
 
 
-def _coefs(rng, n, big):
-    lim = 32767 if big else 300
-    return rng.integers(-lim, lim + 1, n).astype(np.int16)
+def _coefs(rng, n, big, depth=8):
+    lim = (32767 if big else 300) << (depth - 8)           # residuals grow with the depth; dctcoef is int32 above 8 bits
+    return rng.integers(-lim, lim + 1, n).astype(np.int16 if depth == 8 else np.int32)
 
 
-def _block(rng, mb, at, n, allow_dc_only=True):
+def _block(rng, mb, at, n, allow_dc_only=True, depth=8):
     """fills mb[at:at+n] and returns the block's non-zero count as the entropy decoder would have counted it"""
     r = rng.random()
     big = rng.random() < .05
     if r < .4:
         return 0
     if r < .6 and allow_dc_only:
-        mb[at] = _coefs(rng, 1, big)[0] or 7
+        mb[at] = _coefs(rng, 1, big, depth)[0] or 7
         return 1
     if r < .7:
-        mb[at + int(rng.integers(1, n))] = _coefs(rng, 1, big)[0] or -3
+        mb[at + int(rng.integers(1, n))] = _coefs(rng, 1, big, depth)[0] or -3
         return 1
-    v = _coefs(rng, n, big) * (rng.random(n) < .4)
+    v = _coefs(rng, n, big, depth) * (rng.random(n) < .4)
     if np.count_nonzero(v) < 2:
         v[1], v[n - 1] = 5, -9
     mb[at:at + n] = v
     return int(np.count_nonzero(v))
 
 
-def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None):
-    """one intra macroblock's decoder state as a dict"""
+def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8):
+    """one intra macroblock's decoder state as a dict; above 8 bits sl->mb / sl->mb_luma_dc hold int32 (dctcoef) and the I_PCM payload is
+    the 384 depth-bit fields as they stand in the bitstream (h264_mb_template.c:100-131)"""
+    cdt = np.int16 if depth == 8 else np.int32
+    sh = depth - 8
     top, left = my > 0, mx > 0
     tl, tr = top and left, top and mx + 1 < mb_w
     topleft, topright = 0xFFFF, 0xEEEA
@@ -67,9 +70,9 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None):
         mtype = int(rng.choice([I16, I4, I8, PCM], p=[.3, .35, .3, .05]))
     d = dict(mb_x=mx, mb_y=my, type=mtype, pred16=0, chroma_pred=0, cbp=0, topleft=topleft, topright=topright,
              pred4=np.zeros(16, np.uint8), qmul=rng.integers(16, 6000, 3).astype(np.int32), nnzc=np.zeros(15 * 8, np.uint8),
-             mb=np.zeros(768, np.int16), luma_dc=np.zeros(16, np.int16), pcm=None)
+             mb=np.zeros(768, cdt), luma_dc=np.zeros(16, cdt), pcm=None, depth=depth)
     if mtype == PCM:
-        d["pcm"] = rng.integers(0, 256, 384, dtype=np.uint8)
+        d["pcm"] = rng.integers(0, 256, 48 * depth, dtype=np.uint8)
         return d
 
     def blk_mode(i_top, i_left):           # a 16x16 / chroma mode after ff_h264_check_intra_pred_mode
@@ -100,22 +103,22 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None):
     mb, nnzc = d["mb"], d["nnzc"]
     if mtype == I4:
         for i in range(16):
-            nnzc[SCAN8[i]] = _block(rng, mb, 16 * i, 16)
+            nnzc[SCAN8[i]] = _block(rng, mb, 16 * i, 16, depth=depth)
     elif mtype == I8:
         for i in range(0, 16, 4):
-            n = _block(rng, mb, 16 * i, 64)
+            n = _block(rng, mb, 16 * i, 64, depth=depth)
             for k in range(4):                           # decode_luma_residual spreads an 8x8 block's count over its four entries
                 nnzc[SCAN8[i + k]] = n
     else:
         if rng.random() < .7:
             nnzc[0] = 1                                   # scan8[LUMA_DC_BLOCK_INDEX]
-            d["luma_dc"][:] = rng.integers(-2000, 2001, 16) * (rng.random(16) < .6)
+            d["luma_dc"][:] = (rng.integers(-2000, 2001, 16) << sh) * (rng.random(16) < .6)
         for i in range(16):
-            n = _block(rng, mb, 16 * i, 16, allow_dc_only=False)
+            n = _block(rng, mb, 16 * i, 16, allow_dc_only=False, depth=depth)
             if n:
                 mb[16 * i] = 0                            # the DC travels in mb_luma_dc
             if n == 0 and not nnzc[0] and rng.random() < .3:
-                mb[16 * i] = rng.integers(-500, 501) or 11   # idct_add16intra's `else if (block[i * 16])`
+                mb[16 * i] = (int(rng.integers(-500, 501)) << sh) or 11   # idct_add16intra's `else if (block[i * 16])`
             nnzc[SCAN8[i]] = int(np.count_nonzero(mb[16 * i:16 * i + 16])) if n else 0
     cc = int(rng.integers(0, 3))                         # coded_block_pattern's chroma part: 0 none, 1 DC, 2 DC + AC
     d["cbp"] = (cc << 4) | int(rng.integers(0, 16))
@@ -125,11 +128,11 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None):
                 nnzc[40 * pl] = 1                         # scan8[CHROMA_DC_BLOCK_INDEX + pl - 1]
                 for k in range(4):
                     if rng.random() < .7:
-                        mb[256 * pl + 16 * k] = rng.integers(-1500, 1501)
+                        mb[256 * pl + 16 * k] = int(rng.integers(-1500, 1501)) << sh
             if cc == 2:
                 for k in range(4):
                     dc = mb[256 * pl + 16 * k]
-                    n = _block(rng, mb, 256 * pl + 16 * k, 16, allow_dc_only=False)
+                    n = _block(rng, mb, 256 * pl + 16 * k, 16, allow_dc_only=False, depth=depth)
                     mb[256 * pl + 16 * k] = dc
                     nnzc[scan8_chroma(pl, k)] = n
     return d
@@ -161,4 +164,23 @@ def oracle_decode(O, d, planes, strides, mb=None, fn="ffo_h264_hl_decode_intra_m
                    d["type"], d["pred16"], d["chroma_pred"], _p(d["pred4"], C.c_uint8), d["topleft"], d["topright"],
                    _p(d["nnzc"], C.c_uint8), d["cbp"], _p(mb, C.c_int16), _p(dc, C.c_int16), _p(d["qmul"], C.c_int),
                    _p(d["pcm"], C.c_uint8))
+    return mb
+
+
+def ref_decode(R, d, planes, strides, mb_w):
+    """the reference's own ff_h264_hl_decode_mb() for this macroblock at d["depth"] (oracle/refbuild/ffref_shim_h264mb.c) on planes
+    (numpy uint8 / uint16, modified in place; strides in BYTES); returns the consumed sl->mb"""
+    depth = d["depth"]
+    ps = 2 if depth > 8 else 1
+    mx, my = d["mb_x"], d["mb_y"]
+    mb, dc = d["mb"].copy(), d["luma_dc"].copy()
+    at = [planes[0].ctypes.data + my * 16 * strides[0] + mx * 16 * ps, planes[1].ctypes.data + my * 8 * strides[1] + mx * 8 * ps,
+          planes[2].ctypes.data + my * 8 * strides[2] + mx * 8 * ps]
+    u8 = C.POINTER(C.c_uint8)
+    f = R.ffref_h264_hl_decode_intra_mb_bd
+    f.argtypes = [C.c_int, u8, u8, u8] + [C.c_int] * 8 + [u8, C.c_uint, C.c_uint, u8, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), u8]
+    f.restype = C.c_int
+    f(depth, C.cast(at[0], u8), C.cast(at[1], u8), C.cast(at[2], u8), strides[0], strides[1], mx, my, mb_w, d["type"], d["pred16"], d["chroma_pred"],
+      _p(d["pred4"], C.c_uint8), d["topleft"], d["topright"], _p(d["nnzc"], C.c_uint8), d["cbp"], mb.ctypes.data, dc.ctypes.data,
+      _p(d["qmul"], C.c_int32), _p(d["pcm"], C.c_uint8))
     return mb

@@ -34,12 +34,12 @@ def _at(a, off):
     return C.cast(a.ctypes.data + int(off), u8p)
 
 
-def _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra=0.0):
+def _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra=0.0, depth=8):
     """the dsp calls of one macroblock as plain data: ("mc", plane, stage, record), ("w", plane, record), ("idct", plane, kind,
     offset, block), ("edges", plane, records); an intra macroblock is ("intra", decoder state) + its edges"""
     calls = []
     if rng.random() < p_intra:
-        calls.append(("intra", G.make_intra_mb(rng, mx, my, W // 16, H // 16)))
+        calls.append(("intra", G.make_intra_mb(rng, mx, my, W // 16, H // 16, depth=depth)))
         for pl in (0, 1, 2):
             ne = 8 if pl == 0 else 4
             ed = np.zeros(ne, EDGE_DT)
@@ -192,11 +192,16 @@ def test_picture_pipeline(mb_w, mb_h, pictures, p_intra):
     pic.close()
 
 
-@pytest.mark.parametrize("depth,mb_w,mb_h,pictures", [(10, 6, 4, 2), (10, 40, 22, 1), (9, 7, 5, 1), (12, 11, 7, 1), (14, 6, 4, 1)])
-def test_picture_pipeline_hbd(depth, mb_w, mb_h, pictures):
-    """The inter stages and the decoder-order deblocking of a High 10-class picture (uint16_t samples, int32 coefficients, offsets and
-    strides in bytes): flush() == the oracle's depth-templated dsp functions called one by one in decoder order (oracle/ffo_h264_hbd.c,
-    pinned to the reference's h264dsp / h264qpel / h264chroma instantiations at 9 / 10 / 12 / 14 bits).  Intra macroblocks are refused."""
+@pytest.mark.parametrize("depth,mb_w,mb_h,pictures,p_intra", [(10, 6, 4, 2, 0.0), (10, 40, 22, 1, 0.0), (9, 7, 5, 1, 0.0), (12, 11, 7, 1, 0.0),
+                                                               (14, 6, 4, 1, 0.0), (10, 6, 4, 3, .3), (10, 40, 22, 1, .15), (10, 11, 7, 2, 1.0),
+                                                               (9, 6, 4, 1, 1.0), (12, 9, 5, 1, .5), (14, 6, 5, 1, 1.0), (10, 120, 68, 1, 1.0)])
+def test_picture_pipeline_hbd(depth, mb_w, mb_h, pictures, p_intra):
+    """A High 10-class picture (uint16_t samples, int32 coefficients, offsets and strides in bytes): flush() == the same dsp calls made
+    one by one in decoder order — the inter stages and the deblocking by the oracle's depth-templated functions (oracle/ffo_h264_hbd.c,
+    pinned to the reference's h264dsp / h264qpel / h264chroma instantiations at 9 / 10 / 12 / 14 bits), intra macroblocks by the
+    reference's own ff_h264_hl_decode_mb() at that depth (oracle/_ref, ffref_shim_h264mb.c: hl_decode_mb_simple_16 / _complex)."""
+    if p_intra and not ffi.have_ref():
+        pytest.skip("oracle/_ref not built")
     from ffmpeg_amd import h264
     torch = _torch()
     O = ffi.oracle()
@@ -211,6 +216,7 @@ def test_picture_pipeline_hbd(depth, mb_w, mb_h, pictures):
     P = 32
     W, H = mb_w * 16, mb_h * 16
     sy, sc = W + 2 * P, W // 2 + P                            # in samples; the records count bytes
+    sc += -sc % 4                                             # the intra wavefront moves four samples (8 bytes) per access
     strides = [2 * sy, 2 * sc, 2 * sc]
     top = 1 << depth
     refs = [rng.integers(0, top, (2 * (H + 2 * P), sy), dtype=np.uint16), rng.integers(0, top, (2 * (H // 2 + P), sc), dtype=np.uint16),
@@ -218,9 +224,6 @@ def test_picture_pipeline_hbd(depth, mb_w, mb_h, pictures):
     dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
     d_refs = [dev(r) for r in refs]
     pic = h264.Picture(mb_w, mb_h, bit_depth=depth)
-    with pytest.raises(RuntimeError, match="8-bit"):
-        d = G.make_intra_mb(rng, 0, 0, mb_w, mb_h)
-        pic.intra_mb(G.to_record(d), d["nnzc"], d["mb"].copy(), d["luma_dc"], d["pcm"])
     for it in range(pictures):
         dst0 = [rng.integers(0, top, (H, sy), dtype=np.uint16), rng.integers(0, top, (H // 2, sc), dtype=np.uint16),
                 rng.integers(0, top, (H // 2, sc), dtype=np.uint16)]
@@ -230,8 +233,14 @@ def test_picture_pipeline_hbd(depth, mb_w, mb_h, pictures):
         pic.begin()
         for my in range(mb_h):
             for mx in range(mb_w):
-                for call in _make_mb(rng, mx, my, W, H, P, sy, sc, 0.0):
-                    if call[0] == "mc":
+                for call in _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra, depth):
+                    if call[0] == "intra":
+                        d = call[1]
+                        mb_r = G.ref_decode(ffi.ref(), d, want, strides, mb_w)
+                        mb_p = d["mb"].copy()
+                        pic.intra_mb(G.to_record(d), d["nnzc"], mb_p, d["luma_dc"], d["pcm"])
+                        assert d["type"] == G.PCM or np.array_equal(mb_p, mb_r)       # sl->mb consumed as the dsp functions do
+                    elif call[0] == "mc":
                         _, pl, stage, rec = call
                         rec = rec.copy()
                         rec["dst_offset"] *= 2

@@ -128,3 +128,57 @@ def test_intra_pack_rejects_bad_arguments():
     big = np.zeros(1024, np.int16)
     assert L.ffhip_h264_intra_pack(C.c_void_p(rec.ctypes.data), G._p(d["nnzc"], C.c_uint8), G._p(mb, C.c_int16), None, None,
                                    G._p(big, C.c_int16), C.byref(n), C.c_int32(big.size)) == _lib.EINVAL
+
+
+@pytest.mark.skipif(not os.path.exists(ffi.REF_SO), reason="oracle/_ref not built")
+@pytest.mark.parametrize("depth,mb_w,mb_h,frac", [(10, 1, 1, 1.0), (10, 8, 6, 1.0), (9, 5, 4, 1.0), (12, 9, 5, .4), (14, 6, 4, 1.0), (10, 20, 12, 1.0)])
+def test_kernel_logic_emulated_on_cpu_equals_reference_above_8_bits(depth, mb_w, mb_h, frac):
+    """uint16_t samples, int32 coefficients (High 10 and the other depths H.264 defines): the product's host side (ffhip_h264_intra_pack_hbd:
+    which blocks travel, the luma DCs ahead of the run, I_PCM fields unpacked, the caller's sl->mb consumed) + the kernel's
+    per-macroblock logic executed lane by lane on the CPU == the reference's own ff_h264_hl_decode_mb() at that depth (compiled in
+    place, hl_decode_mb_simple_16 / _complex), whole pictures in decoder order."""
+    if not os.path.exists(EMUL_SO):
+        pytest.skip("oracle/libffemul.so not built")
+    from ffmpeg_amd import _lib
+    L, E, R = _lib.lib(), C.CDLL(EMUL_SO), ffi.ref()
+    L.ffhip_h264_intra_pack_hbd.restype = C.c_int
+    rng = np.random.default_rng(depth * 1000 + mb_w * 100 + mb_h)
+    u8 = C.POINTER(C.c_uint8)
+    for it in range(4 if mb_w * mb_h < 100 else 2):
+        pad = int(rng.choice([0, 4, 12]))
+        sy, sc = mb_w * 16 + pad, mb_w * 8 + pad
+        planes = [rng.integers(0, 1 << depth, (mb_h * 16, sy), dtype=np.uint16), rng.integers(0, 1 << depth, (mb_h * 8, sc), dtype=np.uint16),
+                  rng.integers(0, 1 << depth, (mb_h * 8, sc), dtype=np.uint16)]
+        st = [2 * sy, 2 * sc, 2 * sc]
+        want = [p.copy() for p in planes]
+        recs, coefs, ncoef = [], np.zeros(mb_w * mb_h * 816 + 64, np.int16), 0
+        rows = np.zeros(mb_h + 1, np.int32)
+        for my in range(mb_h):
+            for mx in range(mb_w):
+                if rng.random() >= frac:
+                    continue
+                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=depth)
+                mb_r = G.ref_decode(R, d, want, st, mb_w)
+                rec, mb_p = G.to_record(d), d["mb"].copy()
+                n = C.c_int32(ncoef)
+                assert L.ffhip_h264_intra_pack_hbd(depth, rec.ctypes.data, d["nnzc"].ctypes.data, mb_p.ctypes.data, d["luma_dc"].ctypes.data,
+                                                   G._p(d["pcm"], C.c_uint8), G._p(coefs, C.c_int16), C.byref(n), C.c_int32(coefs.size)) == 0
+                ncoef = n.value
+                if d["type"] != G.PCM:
+                    assert np.array_equal(mb_p, mb_r), "host side consumed sl->mb differently from the dsp functions at (%d, %d)" % (mx, my)
+                recs.append(rec)
+                rows[my + 1] += 1
+        rows = np.cumsum(rows).astype(np.int32)
+        recs = np.concatenate(recs) if recs else np.zeros(0, G.INTRA_DT)
+        got = [p.copy() for p in planes]
+        r = E.ffemul_h264_intra_frame_bd(depth, C.cast(got[0].ctypes.data, u8), C.cast(got[1].ctypes.data, u8), C.cast(got[2].ctypes.data, u8),
+                                         C.c_ssize_t(st[0]), C.c_ssize_t(st[1]), mb_w, mb_h, C.c_void_p(recs.ctypes.data), G._p(rows, C.c_int32),
+                                         G._p(coefs, C.c_int16))
+        assert r == 0
+        for pl in range(3):
+            bad = np.argwhere(got[pl] != want[pl])
+            assert not len(bad), "picture %d plane %d: %d mismatches, first at row %d column %d (%d intra macroblocks)" % (
+                it, pl, len(bad), bad[0][0], bad[0][1], len(recs))
+            assert want[pl].max() < (1 << depth)
+        if len(recs):
+            assert (want[0] != planes[0]).any()

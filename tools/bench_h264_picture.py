@@ -23,11 +23,21 @@ mb_w, mb_h, P = 240, 135, 32
 W, H = mb_w * 16, mb_h * 16
 sy, sc = W + 2 * P, W // 2 + P
 rng = np.random.default_rng(4)
-refs = [torch.randint(0, 256, (H + 2 * P, sy), dtype=torch.uint8, device=dev), torch.randint(0, 256, (H // 2 + P, sc), dtype=torch.uint8, device=dev),
-        torch.randint(0, 256, (H // 2 + P, sc), dtype=torch.uint8, device=dev)]
-dst = [torch.zeros((H, sy), dtype=torch.uint8, device=dev), torch.zeros((H // 2, sc), dtype=torch.uint8, device=dev),
-       torch.zeros((H // 2, sc), dtype=torch.uint8, device=dev)]
-pic = h264.Picture(mb_w, mb_h)
+DEPTH = int(os.environ.get("BENCH_DEPTH", "8"))   # 9 / 10 / 12 / 14: uint16_t samples, int32 coefficients, byte offsets and strides
+PS = 2 if DEPTH > 8 else 1
+CDT = np.int32 if DEPTH > 8 else np.int16
+
+
+def plane(rows, cols, rand):
+    if PS == 1:
+        return torch.randint(0, 256, (rows, cols), dtype=torch.uint8, device=dev) if rand else torch.zeros((rows, cols), dtype=torch.uint8, device=dev)
+    a = torch.randint(0, 1 << DEPTH, (rows, cols), dtype=torch.int16, device=dev) if rand else torch.zeros((rows, cols), dtype=torch.int16, device=dev)
+    return a.view(torch.uint8)
+
+
+refs = [plane(H + 2 * P, sy, 1), plane(H // 2 + P, sc, 1), plane(H // 2 + P, sc, 1)]
+dst = [plane(H, sy, 0), plane(H // 2, sc, 0), plane(H // 2, sc, 0)]
+pic = h264.Picture(mb_w, mb_h, bit_depth=DEPTH)
 
 
 def record():
@@ -39,15 +49,15 @@ def record():
         e["alpha"], e["beta"] = 40, 9
         e["tc0"] = 1
     ed4["kind"] = 2
-    blk8, blk4 = np.zeros(64, np.int16), np.zeros(16, np.int16)
+    blk8, blk4 = np.zeros(64, CDT), np.zeros(16, CDT)
     for my in range(mb_h):
         for mx in range(mb_w):
             x, y = mx * 16, my * 16
             dy, dx = (int(v) for v in rng.integers(-16, 17, 2))
-            q[0] = (y * sy + x, (P + y + dy) * sy + P + x + dx, int(rng.integers(0, 16)), 0, 0, 0)
+            q[0] = (PS * (y * sy + x), PS * ((P + y + dy) * sy + P + x + dx), int(rng.integers(0, 16)), 0, 0, 0)
             pic.mc_luma(h264.MC_PUT, q)
             for pl in (1, 2):
-                c[0] = ((y // 2) * sc + x // 2, (P // 2 + y // 2 + dy // 2) * sc + P // 2 + x // 2 + dx // 2, 0, 8, int(rng.integers(0, 8)),
+                c[0] = (PS * ((y // 2) * sc + x // 2), PS * ((P // 2 + y // 2 + dy // 2) * sc + P // 2 + x // 2 + dx // 2), 0, 8, int(rng.integers(0, 8)),
                         int(rng.integers(0, 8)), 0, (0, 0, 0))
                 pic.mc_chroma(pl, h264.MC_PUT, c)
             n["mc"] += 3
@@ -56,7 +66,7 @@ def record():
                     if rng.random() < .5:
                         blk8[:] = 0
                         blk8[:6] = rng.integers(-80, 81, 6)
-                        pic.idct_add(0, 1, (y + by) * sy + x + bx, blk8)
+                        pic.idct_add(0, 1, PS * ((y + by) * sy + x + bx), blk8)
                         n["idct"] += 1
             for pl in (1, 2):
                 for by in (0, 4):
@@ -64,7 +74,7 @@ def record():
                         if rng.random() < .3:
                             blk4[:] = 0
                             blk4[:3] = rng.integers(-80, 81, 3)
-                            pic.idct_add(pl, 0, (y // 2 + by) * sc + x // 2 + bx, blk4)
+                            pic.idct_add(pl, 0, PS * ((y // 2 + by) * sc + x // 2 + bx), blk4)
                             n["idct"] += 1
             pic.deblock_mb(0, mx, my, ed8)
             pic.deblock_mb(1, mx, my, ed4)
@@ -84,7 +94,7 @@ def record_intra(frac):
     for my in range(mb_h):
         for mx in range(mb_w):
             if rng.random() < frac:
-                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h)
+                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=DEPTH)
                 pic.intra_mb(G.to_record(d), d["nnzc"], d["mb"], d["luma_dc"], d["pcm"])
                 n += 1
             pic.deblock_mb(0, mx, my, ed8)
@@ -105,13 +115,13 @@ def timed(reps=10):
     return e0.elapsed_time(e1) / reps
 
 
-strides = [sy, sc, sc]
+strides = [PS * sy, PS * sc, PS * sc]
 if "--intra" in sys.argv:
     for frac in (1.0, .1):
         n = record_intra(frac)
         ms = timed()
-        print(json.dumps({"case": "h264 4K picture, %d%% intra macroblocks (Intra16x16 / 4x4 / 8x8 mixed, residuals): reconstruction "
-                                  "wavefront + frame-order deblock through ffhip_h264_picture_flush" % round(100 * frac),
+        print(json.dumps({"case": "h264 4K picture at %d bits, %d%% intra macroblocks (Intra16x16 / 4x4 / 8x8 mixed, residuals): reconstruction "
+                                  "wavefront + frame-order deblock through ffhip_h264_picture_flush" % (DEPTH, round(100 * frac)),
                           "intra_macroblocks": n, "ms_per_picture_gpu": round(ms, 3), "pictures_per_s": round(1e3 / ms, 1)}), flush=True)
     sys.exit(0)
 
@@ -130,7 +140,7 @@ e1.record()
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / reps * 1e3
 ms = e0.elapsed_time(e1) / reps
-print(json.dumps({"case": "h264 4K P-picture through ffhip_h264_picture_flush (MC + IDCT + frame-order deblock, Y/Cb/Cr)",
+print(json.dumps({"case": "h264 4K P-picture at %d bits through ffhip_h264_picture_flush (MC + IDCT + frame-order deblock, Y/Cb/Cr)" % DEPTH,
                   "macroblocks": mb_w * mb_h, "mc_calls": counts["mc"], "idct_calls": counts["idct"], "ms_per_picture_gpu": round(ms, 3),
                   "ms_per_picture_wall": round(wall, 3), "pictures_per_s": round(1e3 / ms, 1),
                   "python_recording_s": round(t_rec, 2)}), flush=True)
