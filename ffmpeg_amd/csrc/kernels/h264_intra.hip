@@ -17,6 +17,7 @@
  * (s_waitcnt 0) before the row's counter moves, and the counter's value is awaited before the neighbour loads are issued.
  */
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "h264_intra_mb.h"
@@ -55,6 +56,25 @@ __device__ __forceinline__ void st_dev(uint8_t *p, Q v)
 {
     __hip_atomic_store(reinterpret_cast<Q *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+/* the top neighbours of macroblock (mx, my) out of memory, as the lanes hold them: luma columns -4 .. 27 in lanes 0..7, Cb / Cr columns
+ * -4 .. 7 in lanes 24..29; what lies outside the picture reads as 0 */
+template <typename Q, int PS>
+__device__ __forceinline__ Q imb_top_from_mem(const uint8_t *py, const uint8_t *pcb, const uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int my,
+                                              int mx, int lane)
+{
+    const bool has_l = mx > 0, has_r = mx + 1 < mb_w;
+    Q v = 0;
+    if (lane < 8) {
+        const int c = 4 * lane - 4;
+        if ((c >= 0 || has_l) && (c < 16 || has_r))
+            v = ld_dev<Q>(py + ((ptrdiff_t)my * 16 - 1) * sy + (mx * 16 + c) * PS);
+    } else if (lane >= 24 && lane < 30) {
+        const int p = (lane - 24) / 3, c = 4 * ((lane - 24) % 3) - 4;
+        if (c >= 0 || has_l)
+            v = ld_dev<Q>((p ? pcr : pcb) + ((ptrdiff_t)my * 8 - 1) * sc + (mx * 8 + c) * PS);
+    }
+    return v;
+}
 } // namespace
 
 /* dword positions inside FFHipH264IntraMB the prefetch reads out of the lanes that hold them */
@@ -64,34 +84,75 @@ static_assert(offsetof(FFHipH264IntraMB, type) == 4 && offsetof(FFHipH264IntraMB
 #define IMB_REC_DW ((int)(sizeof(FFHipH264IntraMB) / 4))
 
 /* PIX = uint8_t: strides / plane pointers in bytes, runs of int16 coefficients (at most 16 x 16 luma + 8 x 16 chroma = 384 int16 = 3 dwords
- * per lane).  PIX = uint16_t (9..14 bits): int32 coefficients, the sixteen luma DCs ahead of them: (16 + 384) int32 = 7 dwords per lane. */
+ * per lane).  PIX = uint16_t (9..14 bits): int32 coefficients, the sixteen luma DCs ahead of them: (16 + 384) int32 = 7 dwords per lane.
+ *
+ * Round 3: W = blockDim.x / 64 consecutive macroblock rows per workgroup (the recipe of k_h264_deblock_skew).  Inside the workgroup
+ * a row hands its macroblocks' BOTTOM LINES to the row below through an LDS line buffer (`lines`: one luma line and two chroma lines of
+ * the picture's width per row boundary) and an LDS counter — no store acknowledgement, no poll, no load round trip; the line is
+ * pre-filled with what memory holds (the inter macroblocks of a P-picture are complete before this launch) unless the whole row is
+ * intra.  A macroblock whose left neighbour was the previous record of the row takes its left column from its own tile.  Only the
+ * rows at a workgroup boundary use memory: the producer publishes a macroblock one step LATE (at the top of the next step, when the
+ * write-through stores issued a whole step earlier have long been acknowledged), the consumer reads the counter and the next record's
+ * top neighbours one step AHEAD — both stay off the step's critical path, at the price of a few macroblocks of lag per boundary. */
 template <typename PIX>
-__global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
-                                                         const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs,
-                                                         int *progress, int *fail, int maxv)
+__global__ __launch_bounds__(256) void k_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                                          const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs,
+                                                          int *progress, int *fail, int maxv)
 {
     typedef typename ImbQuad<PIX>::T Q;
     typedef typename ImbCoef<PIX>::T CF;
-    constexpr int PS = (int)sizeof(PIX), NDW = PS == 1 ? 3 : 7, IMB_RUN_MAX = NDW * 128 /* int16 */;
-    __shared__ __align__(16) ImbTileT<PIX> T;
+    constexpr int PS = (int)sizeof(PIX), NDW = PS == 1 ? 3 : 7, IMB_RUN_MAX = NDW * 128 /* int16 */, WMAX = 4;
+    __shared__ __align__(16) ImbTileT<PIX> Ts[WMAX];
     /* the macroblock being reconstructed and the next one: its record and coefficient run are fetched while this one is
      * worked on — read from global memory inside the block loop they were 16 dependent round trips per macroblock (measured:
      * 17.6 us per macroblock of an I-picture) */
-    __shared__ __align__(16) FFHipH264IntraMB Rb[2];
-    __shared__ __align__(16) int16_t Cb[2][IMB_RUN_MAX];
-    const int my = blockIdx.x, lane = threadIdx.x;
+    __shared__ __align__(16) FFHipH264IntraMB Rbs[WMAX][2];
+    __shared__ __align__(16) int16_t Cbs[WMAX][2][IMB_RUN_MAX];
+    __shared__ int ldone[WMAX];
+    extern __shared__ __align__(16) uint8_t imb_lines[];
+    const int W = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int my = (int)blockIdx.x * W + wv;
+    ImbTileT<PIX> &T = Ts[wv];
+    FFHipH264IntraMB(&Rb)[2] = Rbs[wv];
+    int16_t(&Cb)[2][IMB_RUN_MAX] = Cbs[wv];
+    /* a row boundary inside the workgroup: 4 mb_w luma quads, then 2 mb_w quads of Cb and of Cr */
+    const int lyq = mb_w * 4, lcq = mb_w * 2, line_q = lyq + 2 * lcq;
+    Q *const mine = reinterpret_cast<Q *>(imb_lines) + (size_t)wv * line_q;
+    const Q *const above = reinterpret_cast<const Q *>(imb_lines) + (size_t)(wv > 0 ? wv - 1 : 0) * line_q;
+    const bool to_lds = wv + 1 < W && my + 1 < mb_h, from_lds = wv > 0, to_mem = !to_lds && my + 1 < mb_h, from_mem = wv == 0 && my > 0;
+    if (lane == 0)
+        __hip_atomic_store(&ldone[wv], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    if (my >= mb_h)
+        return;
     int k = row_start[my];
     const int kend = row_start[my + 1];
     /* nothing of this row is pending left of its first intra macroblock */
-    if (lane == 0)
-        __hip_atomic_store(&progress[my], k < kend ? (int)recs[k].mb_x : mb_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int first = k < kend ? (int)recs[k].mb_x : mb_w;
+    if (to_mem && lane == 0)
+        __hip_atomic_store(&progress[my], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (to_lds) {
+        if (kend - k < mb_w) { /* some macroblocks are inter: their bottom lines are in memory already */
+            const uint8_t *ry = py + ((ptrdiff_t)my * 16 + 15) * sy;
+            for (int q = lane; q < lyq; q += 64)
+                mine[q] = *reinterpret_cast<const Q *>(ry + (size_t)q * 4 * PS);
+            for (int p = 0; p < 2; p++) {
+                const uint8_t *rc = (p ? pcr : pcb) + ((ptrdiff_t)my * 8 + 7) * sc;
+                for (int q = lane; q < lcq; q += 64)
+                    mine[lyq + p * lcq + q] = *reinterpret_cast<const Q *>(rc + (size_t)q * 4 * PS);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+            __hip_atomic_store(&ldone[wv], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     if (k >= kend)
         return;
-    auto fetch_rec = [&](int idx) { /* dword `lane` of record idx */
+    auto fetch_rec = [&](int idx) __attribute__((always_inline)) { /* dword `lane` of record idx */
         return lane < IMB_REC_DW && idx < kend ? reinterpret_cast<const uint32_t *>(recs + idx)[lane] : 0u;
     };
     uint32_t cw[NDW];
-    auto fetch_run = [&](uint32_t rec_dw) { /* the run of the record whose dwords the lanes hold: 3 dwords per lane */
+    auto fetch_run = [&](uint32_t rec_dw) __attribute__((always_inline)) { /* the run of the record whose dwords the lanes hold: NDW dwords per lane */
         const uint32_t type = __builtin_amdgcn_readlane(rec_dw, 1) & 0xFFu, blocks = __builtin_amdgcn_readlane(rec_dw, 18);
         const int flags = (int)(__builtin_amdgcn_readlane(rec_dw, 10) & 0xFFu);
         const int at = (int)__builtin_amdgcn_readlane(rec_dw, 17), ndw = imb_run_len((int)type, blocks, PS, flags) >> 1;
@@ -100,35 +161,62 @@ __global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *p
         for (int j = 0; j < NDW; j++)
             cw[j] = lane + 64 * j < ndw ? g[lane + 64 * j] : 0u;
     };
-    auto park = [&](int slot, uint32_t rec_dw) {
+    auto park = [&](int slot, uint32_t rec_dw) __attribute__((always_inline)) {
         if (lane < IMB_REC_DW)
             reinterpret_cast<uint32_t *>(&Rb[slot])[lane] = rec_dw;
 #pragma unroll
         for (int j = 0; j < NDW; j++)
             reinterpret_cast<uint32_t *>(Cb[slot])[lane + 64 * j] = cw[j];
     };
+    auto top_from_mem = [&](int mx) __attribute__((always_inline)) -> Q { return imb_top_from_mem<Q, PS>(py, pcb, pcr, sy, sc, mb_w, my, mx, lane); };
     {
         const uint32_t r0 = fetch_rec(k);
         fetch_run(r0);
         park(0, r0);
     }
     imb_wave_sync();
-    int known = 0; /* last value seen of progress[my - 1] */
+    int known = 0;       /* last value seen of the counter of the row above */
+    int ahead = 0;       /* from_mem: that counter, read a step ahead (lane 0) */
+    int prev_mx = -2;    /* the macroblock this wave reconstructed last: its right columns are still in the tile */
+    Q pf = 0;            /* from_mem: the next record's top neighbours, read a step ahead */
+    bool have_pf = false;
     ImbWave X{ lane };
     for (int cur = 0; k < kend; k++, cur ^= 1) {
         const FFHipH264IntraMB &R = Rb[cur];
-        const uint32_t nrec = fetch_rec(k + 1);
         const int mx = R.mb_x;
+        if (to_mem) {
+            /* the previous macroblock's write-through stores left a whole step ago: acknowledged, the counter moves */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            if (lane == 0)
+                __hip_atomic_store(&progress[my], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t nrec = fetch_rec(k + 1);
         /* ---- the row above has finished macroblock mx + 1 ---- */
-        if (my > 0) {
-            const int want = min(mx + 2, mb_w);
+        const int want = min(mx + 2, mb_w);
+        if (from_lds) {
+            int spins = 0;
+            while (known < want) {
+                known = __hip_atomic_load(&ldone[wv - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (known >= want)
+                    break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                    if (lane == 0)
+                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else if (from_mem && !have_pf) {
+            known = max(known, __builtin_amdgcn_readfirstlane(ahead));
             int spins = 0;
             while (known < want) {
                 known = __hip_atomic_load(&progress[my - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (known >= want)
                     break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 24)) { /* never in a correct run; do not hang the device */
+                if (++spins > (1 << 24)) {
                     if (lane == 0)
                         __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     return;
@@ -136,24 +224,33 @@ __global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *p
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* the neighbour loads are issued after the counter was seen */
         }
-        /* ---- neighbours into the tile, one dword per lane; what lies outside the picture reads as 0 ---- */
+        /* ---- neighbours into the tile, one quad per lane; what lies outside the picture reads as 0 ---- */
         uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16 * PS;
         uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8 * PS, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 * PS };
-        const bool has_l = mx > 0, has_t = my > 0, has_r = mx + 1 < mb_w;
+        const bool has_l = mx > 0, has_r = mx + 1 < mb_w, left_here = prev_mx == mx - 1;
         Q nb = 0;
-        if (lane < 8) { /* the row above: columns -4 .. 27 */
-            const int c = 4 * lane - 4;
-            if (has_t && (c >= 0 || has_l) && (c < 16 || has_r))
-                nb = ld_dev<Q>(ymb - sy + c * PS);
-        } else if (lane < 24) { /* the column to the left */
-            if (has_l)
+        if (from_lds) {
+            if (lane < 8) { /* the row above: columns -4 .. 27 */
+                const int c = 4 * lane - 4;
+                if ((c >= 0 || has_l) && (c < 16 || has_r))
+                    nb = above[mx * 4 + lane - 1];
+            } else if (lane >= 24 && lane < 30) {
+                const int p = (lane - 24) / 3, q = (lane - 24) % 3 - 1;
+                if (q >= 0 || has_l)
+                    nb = above[lyq + p * lcq + mx * 2 + q];
+            }
+        } else if (from_mem) {
+            nb = have_pf ? pf : top_from_mem(mx);
+        }
+        if (lane >= 8 && lane < 24) { /* the column to the left */
+            if (left_here)
+                nb = *reinterpret_cast<const Q *>(&T.y[imb_yi(lane - 8, 12)]);
+            else if (has_l)
                 nb = ld_dev<Q>(ymb + (ptrdiff_t)(lane - 8) * sy - 4 * PS);
-        } else if (lane < 30) {
-            const int p = (lane - 24) / 3, c = 4 * ((lane - 24) % 3) - 4;
-            if (has_t && (c >= 0 || has_l))
-                nb = ld_dev<Q>(cmb[p] - sc + c * PS);
-        } else if (lane < 46) {
-            if (has_l)
+        } else if (lane >= 30 && lane < 46) {
+            if (left_here)
+                nb = *reinterpret_cast<const Q *>(&T.c[(lane - 30) >> 3][imb_ci((lane - 30) & 7, 4)]);
+            else if (has_l)
                 nb = ld_dev<Q>(cmb[(lane - 30) >> 3] + (ptrdiff_t)((lane - 30) & 7) * sc - 4 * PS);
         }
         /* the next macroblock's coefficients leave now and land while this one is reconstructed */
@@ -172,22 +269,54 @@ __global__ __launch_bounds__(64) void k_h264_intra_frame(uint8_t *py, uint8_t *p
             *reinterpret_cast<Q *>(&T.c[(lane - 30) >> 3][imb_ci((lane - 30) & 7, -4)]) = nb;
         }
         imb_wave_sync();
-        imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(Cb[cur]), maxv);
-        /* ---- the macroblock leaves the tile: 64 + 32 quads of samples, write-through ---- */
-        st_dev<Q>(ymb + (ptrdiff_t)(lane >> 2) * sy + 4 * (lane & 3) * PS, *reinterpret_cast<const Q *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]));
-        if (lane < 32) {
-            const int p = lane >> 4, r = (lane >> 1) & 7, c = 4 * (lane & 1);
-            st_dev<Q>(cmb[p] + (ptrdiff_t)r * sc + c * PS, *reinterpret_cast<const Q *>(&T.c[p][imb_ci(r, c)]));
-        }
         const int next = k + 1 < kend ? (int)(__builtin_amdgcn_readlane(nrec, 0) & 0xFFFFu) : mb_w; /* the next record's mb_x */
+        have_pf = false;
+        if (from_mem && k + 1 < kend) { /* a step ahead: the counter, and the next record's top neighbours when they are known to be there */
+            if (known >= min(next + 2, mb_w)) {
+                pf = top_from_mem(next);
+                have_pf = true;
+            } else if (lane == 0) { /* consumed at the top of the next step, not here */
+                ahead = __hip_atomic_load(&progress[my - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(Cb[cur]), maxv);
+        /* ---- the macroblock leaves the tile: 64 + 32 quads of samples; write-through where another workgroup reads them ---- */
+        {
+            uint8_t *dy = ymb + (ptrdiff_t)(lane >> 2) * sy + 4 * (lane & 3) * PS;
+            const Q vy = *reinterpret_cast<const Q *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]);
+            if (to_mem)
+                st_dev<Q>(dy, vy);
+            else
+                *reinterpret_cast<Q *>(dy) = vy;
+            if (to_lds && (lane >> 2) == 15)
+                mine[mx * 4 + (lane & 3)] = vy;
+            if (lane < 32) {
+                const int p = lane >> 4, r = (lane >> 1) & 7, c = 4 * (lane & 1);
+                uint8_t *dc = cmb[p] + (ptrdiff_t)r * sc + c * PS;
+                const Q vc = *reinterpret_cast<const Q *>(&T.c[p][imb_ci(r, c)]);
+                if (to_mem)
+                    st_dev<Q>(dc, vc);
+                else
+                    *reinterpret_cast<Q *>(dc) = vc;
+                if (to_lds && r == 7)
+                    mine[lyq + p * lcq + mx * 2 + (lane & 1)] = vc;
+            }
+        }
         if (k + 1 < kend)
             park(cur ^ 1, nrec);
-        /* acknowledged before the counter moves */
+        if (to_lds) { /* LDS operations of a wave execute in order: the line is in place when the counter moves */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_store(&ldone[wv], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        prev_mx = mx;
+        imb_wave_sync(); /* the other record / run and the tile are rewritten by the next step */
+    }
+    if (to_mem) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0)
-            __hip_atomic_store(&progress[my], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        imb_wave_sync(); /* the other record / run and the tile are rewritten by the next step */
+            __hip_atomic_store(&progress[my], mb_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -215,17 +344,32 @@ int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *c
         ffhip_set_error("ffhip_h264_intra_frame: planes and strides must be %u-byte aligned", amask + 1);
         return FFHIP_EINVAL;
     }
+    /* rows per workgroup: as many (up to 4) as the line buffers between them fit beside the static per-row tiles in 64 KB of LDS */
+    const int ps_ = bd > 8 ? 2 : 1;
+    const size_t fixed = bd > 8 ? sizeof(ImbTileT<uint16_t>) * 4 + sizeof(FFHipH264IntraMB) * 8 + 4 * 2 * 7 * 256 + 64
+                                : sizeof(ImbTileT<uint8_t>) * 4 + sizeof(FFHipH264IntraMB) * 8 + 4 * 2 * 3 * 256 + 64;
+    const size_t line = (size_t)mb_w * 32 * ps_;
+    int W = 4;
+#ifdef FFHIP_MEASURE
+    if (const char *e = getenv("FFHIP_INTRA_WPB"))
+        W = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4;
+#endif
+    while (W > 1 && fixed + (size_t)(W - 1) * line > 64 * 1024)
+        W--;
+    W = W < mb_h ? W : mb_h;
+    const size_t lds = (size_t)(W - 1) * line;
+    const int nwg = (mb_h + W - 1) / W;
     FFHipProgressSlot ps;
     const int r = ffhip_progress_acquire(mb_h + 1, stream, &ps);
     if (r < 0)
         return r;
     int *const prog = ps.prog, *const fail = ps.fail;
     if (bd > 8)
-        hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(mb_h), dim3(64), 0, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog, fail,
-                           (1 << bd) - 1);
+        hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(nwg), dim3(64 * W), lds, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog,
+                           fail, (1 << bd) - 1);
     else
-        hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(mb_h), dim3(64), 0, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog, fail,
-                           255);
+        hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(nwg), dim3(64 * W), lds, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog,
+                           fail, 255);
     const hipError_t e = hipGetLastError();
     const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
     if (e != hipSuccess) {

@@ -305,6 +305,79 @@ IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT, int maxv = 2
     return (y >> 2) ? ((x >> 2) ? q3 : q2) : ((x >> 2) ? q1 : q0);
 }
 
+/* The same rules, split for a lane that produces the four samples (x0 .. x0 + 3, y): everything the rule reads is read ONCE, before
+ * the lane writes (the compiler cannot hoist tile reads over tile writes itself: imb_pred_blk per sample re-read the whole edge — 64
+ * byte reads for a DC, 64 for a plane — four times). */
+struct ImbPred {
+    int left, top[4], dc, a, H, V;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IMB_UNIFORM(v) __builtin_amdgcn_readfirstlane(v) /* the same in every lane: keep it in a scalar register, branch without masks */
+#else
+#define IMB_UNIFORM(v) (v)
+#endif
+
+template <int N, class Top, class Left>
+IMB_FN ImbPred imb_pred_row(int mode, int x0, int y, Top TOP, Left LEFT, int mid)
+{
+    constexpr int H2 = N / 2;
+    ImbPred P;
+    P.left = P.dc = P.a = P.H = P.V = 0;
+    P.top[0] = P.top[1] = P.top[2] = P.top[3] = 0;
+    if (mode == 1) {
+        P.left = LEFT(y);
+    } else if (mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            P.top[j] = TOP(x0 + j);
+    } else if (mode == 3) {
+        int H = 0, V = 0;
+        for (int i = 1; i <= H2; i++) {
+            H += i * (TOP(H2 - 1 + i) - TOP(H2 - 1 - i));
+            V += i * (LEFT(H2 - 1 + i) - (i == H2 ? TOP(-1) : LEFT(H2 - 1 - i)));
+        }
+        P.H = N == 16 ? (5 * H + 32) >> 6 : (17 * H + 16) >> 5;
+        P.V = N == 16 ? (5 * V + 32) >> 6 : (17 * V + 16) >> 5;
+        P.a = 16 * (LEFT(N - 1) + TOP(N - 1) + 1) - (H2 - 1) * (P.V + P.H);
+    } else if (N == 16) {
+        int sl = 0, st = 0;
+        for (int i = 0; i < 16; i++) {
+            sl += (mode == 0 || mode == 4) ? LEFT(i) : 0;
+            st += (mode == 0 || mode == 5) ? TOP(i) : 0;
+        }
+        P.dc = mode == 0 ? (sl + st + 16) >> 5 : mode == 4 ? (sl + 8) >> 4 : mode == 5 ? (st + 8) >> 4 : mid;
+    } else {
+        const bool ut = mode == 0 || mode == 5 || mode == 7 || mode == 8, ul = mode == 0 || mode == 4 || mode >= 7;
+        int t0 = 0, t1 = 0, l0 = 0, l1 = 0;
+        for (int i = 0; i < 4; i++) {
+            t0 += ut ? TOP(i) : 0;
+            t1 += ut ? TOP(4 + i) : 0;
+            l0 += ul ? LEFT(i) : 0;
+            l1 += (ul && mode != 7) ? LEFT(4 + i) : 0;
+        }
+        int q0 = mid, q1 = mid, q2 = mid, q3 = mid;
+        switch (mode) {
+        case 0: q0 = (t0 + l0 + 4) >> 3; q1 = (t1 + 2) >> 2; q2 = (l1 + 2) >> 2; q3 = (t1 + l1 + 4) >> 3; break;
+        case 4: q0 = q1 = (l0 + 2) >> 2; q2 = q3 = (l1 + 2) >> 2; break;
+        case 5: q0 = q2 = (t0 + 2) >> 2; q1 = q3 = (t1 + 2) >> 2; break;
+        case 7: q0 = (t0 + l0 + 4) >> 3; q2 = (t0 + 2) >> 2; q1 = q3 = (t1 + 2) >> 2; break;
+        case 8: q0 = (t0 + 2) >> 2; q1 = (t1 + 2) >> 2; q2 = (l1 + 2) >> 2; q3 = (t1 + l1 + 4) >> 3; break;
+        case 9: q0 = q1 = (l0 + 2) >> 2; break;
+        case 10: q2 = q3 = (l1 + 2) >> 2; break;
+        default: break;
+        }
+        P.dc = (y >> 2) ? ((x0 >> 2) ? q3 : q2) : ((x0 >> 2) ? q1 : q0);
+    }
+    return P;
+}
+
+template <typename PIX>
+IMB_FN int imb_pred_px(int mode, const ImbPred &P, int j, int x, int y, int maxv)
+{
+    return mode == 1 ? P.left : mode == 2 ? P.top[j] : mode == 3 ? imb_clip<PIX>((P.a + y * P.V + x * P.H) >> 5, maxv) : P.dc;
+}
+
 /*
  * The macroblock, phase by phase.  X.run(body) runs body(lane) for the 64 lanes and synchronises the tile.
  * T holds the neighbours (unavailable ones as 0) on entry and the reconstructed macroblock on return.
@@ -361,8 +434,10 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
                 full = R.nnz[16 + 4 * p + k] != 0;
                 dconly = !full && dc != 0;
             }
+            const int cmode = IMB_UNIFORM((int)R.chroma_pred);
+            const ImbPred P = imb_pred_row<8>(cmode, x0, yy, TOP, LEFT, mid);
             for (int j = 0; j < 4; j++) {
-                int v = imb_pred_blk<8, PIX>(R.chroma_pred, x0 + j, yy, TOP, LEFT, maxv);
+                int v = imb_pred_px<PIX>(cmode, P, j, x0 + j, yy, maxv);
                 if (full)
                     v = imb_clip<PIX>(v + imb_idct4_at(b, dc, j, yy & 3), maxv);
                 else if (dconly)
@@ -417,8 +492,10 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             const CF *b = imb_block(R, coefs, i);
             const int dc = (R.flags & FFHIP_H264_INTRA_LUMA_DC) ? T.dcq[i] : (b ? b[0] : 0);
             const bool full = R.nnz[i] != 0, dconly = !full && dc != 0;
+            const int lmode = IMB_UNIFORM((int)R.pred16);
+            const ImbPred P = imb_pred_row<16>(lmode, x0, yy, TOP, LEFT, mid);
             for (int j = 0; j < 4; j++) {
-                int v = imb_pred_blk<16, PIX>(R.pred16, x0 + j, yy, TOP, LEFT, maxv);
+                int v = imb_pred_px<PIX>(lmode, P, j, x0 + j, yy, maxv);
                 if (full)
                     v = imb_clip<PIX>(v + imb_idct4_at(b, dc, j, lane & 3), maxv);
                 else if (dconly)

@@ -19,7 +19,10 @@ import h264_intra_gen as G  # noqa: E402
 from test_gpu_h264_picture import QPEL_DT, CHROMA_DT, EDGE_DT  # noqa: E402
 
 dev = torch.device("cuda", 0)
-mb_w, mb_h, P = 240, 135, 32
+mb_w, mb_h = (int(v) for v in os.environ.get("BENCH_MB", "240x135").split("x"))   # 4K unless told otherwise
+P = 32
+MTYPE = int(os.environ["BENCH_MTYPE"]) if "BENCH_MTYPE" in os.environ else None   # 0 Intra16x16, 1 4x4, 2 8x8, 3 I_PCM; default mixed
+NODEBLOCK = os.environ.get("BENCH_NODEBLOCK") == "1"   # the reconstruction wavefront alone
 W, H = mb_w * 16, mb_h * 16
 sy, sc = W + 2 * P, W // 2 + P
 rng = np.random.default_rng(4)
@@ -94,9 +97,11 @@ def record_intra(frac):
     for my in range(mb_h):
         for mx in range(mb_w):
             if rng.random() < frac:
-                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=DEPTH)
+                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=MTYPE, depth=DEPTH)
                 pic.intra_mb(G.to_record(d), d["nnzc"], d["mb"], d["luma_dc"], d["pcm"])
                 n += 1
+            if NODEBLOCK:
+                continue
             pic.deblock_mb(0, mx, my, ed8)
             pic.deblock_mb(1, mx, my, ed4)
             pic.deblock_mb(2, mx, my, ed4)
