@@ -305,6 +305,77 @@ IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT, int maxv = 2
     return (y >> 2) ? ((x >> 2) ? q3 : q2) : ((x >> 2) ? q1 : q0);
 }
 
+/* ---- pred4x4 as a table: every directional rule is (w0 e[i0] + w1 e[i1] + w2 e[i2] + 2) >> 2 with weights (1, 2, 1), (2, 2, 0) or
+ * (4, 0, 0) — hp_a3, hp_a2, a copy — over the edge line.  imb_p4_entry() is hp_dir_sample_e<4> solved for (i0, i1, i2, kind): bits 0-3,
+ * 4-7, 8-11 the three indices, bits 12-13 the kind (0 a3, 1 a2, 2 copy).  A lane of the Intra4x4 phases always produces the same
+ * sample (x, y) of its block, so it keeps its nine entries in five registers (ImbP4, built once per kernel) and a phase costs a
+ * select + three edge reads instead of a nine-way switch evaluated under divergence (two blocks, two modes per phase). */
+IMB_FN uint32_t imb_p4_a3(int a, int b, int c) { return (uint32_t)(a | b << 4 | c << 8); }
+IMB_FN uint32_t imb_p4_a2(int a, int b) { return (uint32_t)(a | b << 4 | b << 8 | 1 << 12); }
+IMB_FN uint32_t imb_p4_cp(int a) { return (uint32_t)(a | a << 4 | a << 8 | 2 << 12); }
+IMB_FN uint32_t imb_p4_entry(int mode, int x, int y)
+{
+    switch (mode) {
+    case 0: return imb_p4_cp(5 + x);
+    case 1: return imb_p4_cp(3 - y);
+    case 3: {
+        const int i = x + y;
+        return i < 6 ? imb_p4_a3(5 + i, 6 + i, 7 + i) : imb_p4_a3(11, 12, 12);
+    }
+    case 4: {
+        const int i = 3 - y + x;
+        return imb_p4_a3(i, i + 1, i + 2);
+    }
+    case 5: {
+        const int d = 2 * x - y, h = d >> 1;
+        return d < 0 ? imb_p4_a3(4 + d, 5 + d, 6 + d) : (d & 1) ? imb_p4_a3(4 + h, 5 + h, 6 + h) : imb_p4_a2(4 + h, 5 + h);
+    }
+    case 6: {
+        const int d = 2 * y - x, h = d >> 1;
+        return d < 0 ? imb_p4_a3(2 - d, 3 - d, 4 - d) : (d & 1) ? imb_p4_a3(4 - h, 3 - h, 2 - h) : imb_p4_a2(4 - h, 3 - h);
+    }
+    case 7: {
+        const int i = (y >> 1) + x;
+        return (y & 1) ? imb_p4_a3(5 + i, 6 + i, 7 + i) : imb_p4_a2(5 + i, 6 + i);
+    }
+    case 8: {
+        const int i = 2 * y + x, j = 3 - (i >> 1);
+        return i >= 6 ? imb_p4_cp(0) : i == 5 ? imb_p4_a3(1, 0, 0) : (i & 1) ? imb_p4_a3(j, j - 1, j - 2) : imb_p4_a2(j, j - 1);
+    }
+    default: return 0; /* the DC modes: not a table rule */
+    }
+}
+
+struct ImbP4 {
+    uint32_t w[5]; /* entry of mode m in bits 16 (m & 1) .. of w[m >> 1] */
+};
+
+IMB_FN ImbP4 imb_p4_build(int lane)
+{
+    ImbP4 L;
+    const int x = lane & 3, y = (lane >> 2) & 3;
+#pragma unroll
+    for (int m = 0; m < 10; m += 2)
+        L.w[m >> 1] = imb_p4_entry(m, x, y) | (m + 1 < 9 ? imb_p4_entry(m + 1, x, y) << 16 : 0u);
+    return L;
+}
+
+IMB_FN uint32_t imb_p4_code(const ImbP4 &L, int lane, int mode)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int h = mode >> 1;
+    uint32_t w = L.w[0];
+    w = h == 1 ? L.w[1] : w;
+    w = h == 2 ? L.w[2] : w;
+    w = h == 3 ? L.w[3] : w;
+    w = h == 4 ? L.w[4] : w;
+    return (w >> (16 * (mode & 1))) & 0x3FFFu;
+#else
+    (void)L;
+    return imb_p4_entry(mode, lane & 3, (lane >> 2) & 3);
+#endif
+}
+
 /* The same rules, split for a lane that produces the four samples (x0 .. x0 + 3, y): everything the rule reads is read ONCE, before
  * the lane writes (the compiler cannot hoist tile reads over tile writes itself: imb_pred_blk per sample re-read the whole edge — 64
  * byte reads for a DC, 64 for a plane — four times). */
@@ -384,7 +455,7 @@ IMB_FN int imb_pred_px(int mode, const ImbPred &P, int j, int x, int y, int maxv
  */
 template <typename PIX, class X>
 IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, const typename ImbCoef<PIX>::T *coefs /* the macroblock's run */,
-                            int maxv = 255 /* (1 << bit_depth) - 1 */)
+                            int maxv = 255 /* (1 << bit_depth) - 1 */, const ImbP4 &P4 = ImbP4() /* imb_p4_build(lane) */)
 {
     typedef typename ImbCoef<PIX>::T CF;
     const int mid = (maxv + 1) >> 1;
@@ -512,6 +583,30 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
          * (results cannot differ: each block sees exactly the samples it sees in block order).  A step is ONE phase: a lane reads
          * the edge samples its rule needs straight from the tile (they lie outside the blocks written in this step) and adds its
          * own sample of the residual. */
+        /* The residuals do not depend on the prediction: all sixteen blocks' in ONE phase ahead of the ten steps, lane = column x of
+         * block i (four first-pass butterflies serve the column's four samples: 8 butterflies per lane instead of 5 per sample inside a
+         * step), parked in t8 (unused by this macroblock type) as res[16 i + 4 y + x]. */
+        x.run([&](int lane) {
+            const int i = lane >> 2, xx = lane & 3, nnz = R.nnz[i];
+            if (!nnz)
+                return;
+            int *res = &T.t8[0][0] + 16 * i;
+            const CF *b = imb_block(R, coefs, i); /* travels whenever nnz != 0 */
+            const int dc = b[0];
+            if (nnz == 1 && dc) {
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    res[4 * y + xx] = (dc + 32) >> 6;
+                return;
+            }
+            int r[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                r[j] = (CF)imb_bfly4(xx, j == 0 ? (CF)(dc + 32) : b[j], b[j + 4], b[j + 8], b[j + 12]);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                res[4 * y + xx] = imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
+        });
         for (int t = 0; t < 10; t++) {
             x.run([&](int lane) {
                 if (lane >= 32)
@@ -529,16 +624,17 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
                     return (int)T.y[imb_yi(r, c)];
                 };
                 const int xx = lane & 3, yy = (lane >> 2) & 3;
-                int v = hp_dir_sample_e<4>(mode, e, xx, yy, hp_dir_dc_e<4>(mode, e, mid));
-                const int nnz = R.nnz[i];
-                if (nnz) {
-                    const CF *b = imb_block(R, coefs, i);
-                    const int dc = b ? b[0] : 0;
-                    if (nnz == 1 && dc)
-                        v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
-                    else
-                        v = imb_clip<PIX>(v + imb_idct4_at(b, dc, xx, yy), maxv);
+                int v;
+                if (mode == 2 || mode >= 9) {
+                    v = hp_dir_dc_e<4>(mode, e, mid);
+                } else {
+                    const uint32_t code = imb_p4_code(P4, lane, mode);
+                    const int a = e((int)(code & 15u)), b = e((int)((code >> 4) & 15u)), c = e((int)((code >> 8) & 15u));
+                    const int kind = (int)(code >> 12);
+                    v = kind == 0 ? (a + 2 * b + c + 2) >> 2 : kind == 1 ? (a + b + 1) >> 1 : a;
                 }
+                if (R.nnz[i])
+                    v = imb_clip<PIX>(v + (&T.t8[0][0])[16 * i + 4 * yy + xx], maxv);
                 T.y[imb_yi(by + yy, bx + xx)] = (PIX)v;
             });
         }
