@@ -231,6 +231,19 @@ IMB_FN int imb_idct4_at(const CF *b, int b0, int x, int y)
     return imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
 }
 
+/* the same for the four samples (x, 0..3) of a column: the four first-pass butterflies serve all of them */
+template <typename CF>
+IMB_FN void imb_idct4_col(const CF *b, int b0, int x, int out[4])
+{
+    int r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        r[j] = (CF)imb_bfly4(x, j == 0 ? (CF)(b0 + 32) : (b ? b[j] : 0), b ? b[j + 4] : 0, b ? b[j + 8] : 0, b ? b[j + 12] : 0);
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+        out[y] = imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
+}
+
 /* one 8-point pass of ff_h264_idct8_add (h264idct_template.c:69-143) */
 IMB_FN void imb_idct8_1d(const int in[8], uint32_t out[8])
 {
@@ -380,7 +393,7 @@ IMB_FN uint32_t imb_p4_code(const ImbP4 &L, int lane, int mode)
  * the lane writes (the compiler cannot hoist tile reads over tile writes itself: imb_pred_blk per sample re-read the whole edge — 64
  * byte reads for a DC, 64 for a plane — four times). */
 struct ImbPred {
-    int left, top[4], dc, a, H, V;
+    int s[4], dc, a, H, V; /* s[j]: sample j's value under the horizontal / vertical rules */
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -389,19 +402,30 @@ struct ImbPred {
 #define IMB_UNIFORM(v) (v)
 #endif
 
-template <int N, class Top, class Left>
-IMB_FN ImbPred imb_pred_row(int mode, int x0, int y, Top TOP, Left LEFT, int mid)
+/* the four samples are (x0 + j, y) of a row, or with COL (x0, y + j) of a column (y a multiple of 4) */
+template <int N, bool COL, class Top, class Left>
+IMB_FN ImbPred imb_pred_quad(int mode, int x0, int y, Top TOP, Left LEFT, int mid)
 {
     constexpr int H2 = N / 2;
     ImbPred P;
-    P.left = P.dc = P.a = P.H = P.V = 0;
-    P.top[0] = P.top[1] = P.top[2] = P.top[3] = 0;
+    P.dc = P.a = P.H = P.V = 0;
+    P.s[0] = P.s[1] = P.s[2] = P.s[3] = 0;
     if (mode == 1) {
-        P.left = LEFT(y);
-    } else if (mode == 2) {
+        if (COL) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            P.top[j] = TOP(x0 + j);
+            for (int j = 0; j < 4; j++)
+                P.s[j] = LEFT(y + j);
+        } else {
+            P.s[0] = P.s[1] = P.s[2] = P.s[3] = LEFT(y);
+        }
+    } else if (mode == 2) {
+        if (COL) {
+            P.s[0] = P.s[1] = P.s[2] = P.s[3] = TOP(x0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                P.s[j] = TOP(x0 + j);
+        }
     } else if (mode == 3) {
         int H = 0, V = 0;
         for (int i = 1; i <= H2; i++) {
@@ -446,7 +470,7 @@ IMB_FN ImbPred imb_pred_row(int mode, int x0, int y, Top TOP, Left LEFT, int mid
 template <typename PIX>
 IMB_FN int imb_pred_px(int mode, const ImbPred &P, int j, int x, int y, int maxv)
 {
-    return mode == 1 ? P.left : mode == 2 ? P.top[j] : mode == 3 ? imb_clip<PIX>((P.a + y * P.V + x * P.H) >> 5, maxv) : P.dc;
+    return (mode == 1 || mode == 2) ? P.s[j] : mode == 3 ? imb_clip<PIX>((P.a + y * P.V + x * P.H) >> 5, maxv) : P.dc;
 }
 
 /*
@@ -476,11 +500,11 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
      *      Intra16x16 also dequantises its 16 luma DCs here (lanes 32..47), the 8x8 transform runs its first pass (lanes 32..63) ---- */
     x.run([&](int lane) {
         if (lane < 32) {
-            const int p = lane >> 4, yy = (lane >> 1) & 7, x0 = 4 * (lane & 1);
+            /* lane = column (lane & 3) of chroma block k = (lane >> 2) & 3 of plane p: everything is read before the column is written */
+            const int p = lane >> 4, k = (lane >> 2) & 3, xc = 4 * (k & 1) + (lane & 3), y0 = 4 * (k >> 1);
             const PIX *tc = T.c[p];
             auto TOP = [&](int i) { return (int)tc[imb_ci(-1, i)]; };
             auto LEFT = [&](int i) { return (int)tc[imb_ci(i, -1)]; };
-            const int k = (yy >> 2) * 2 + (x0 >> 2); /* chroma block 16 + k / 32 + k */
             int dc = 0;
             bool full = false, dconly = false;
             const CF *b = nullptr;
@@ -506,14 +530,18 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
                 dconly = !full && dc != 0;
             }
             const int cmode = IMB_UNIFORM((int)R.chroma_pred);
-            const ImbPred P = imb_pred_row<8>(cmode, x0, yy, TOP, LEFT, mid);
+            const ImbPred P = imb_pred_quad<8, true>(cmode, xc, y0, TOP, LEFT, mid);
+            int res[4] = { 0, 0, 0, 0 };
+            if (full)
+                imb_idct4_col(b, dc, lane & 3, res);
+            else if (dconly)
+                res[0] = res[1] = res[2] = res[3] = (dc + 32) >> 6;
+#pragma unroll
             for (int j = 0; j < 4; j++) {
-                int v = imb_pred_px<PIX>(cmode, P, j, x0 + j, yy, maxv);
-                if (full)
-                    v = imb_clip<PIX>(v + imb_idct4_at(b, dc, j, yy & 3), maxv);
-                else if (dconly)
-                    v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
-                T.c[p][imb_ci(yy, x0 + j)] = (PIX)v;
+                int v = imb_pred_px<PIX>(cmode, P, j, xc, y0 + j, maxv);
+                if (full || dconly)
+                    v = imb_clip<PIX>(v + res[j], maxv);
+                T.c[p][imb_ci(y0 + j, xc)] = (PIX)v;
             }
         } else if (R.type == FFHIP_H264_INTRA_8x8) {
             /* first pass of the four 8x8 inverse transforms (they depend on the coefficients alone): lane 32 + 8 q + j = transform j
@@ -555,23 +583,27 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
     });
 
     if (R.type == FFHIP_H264_INTRA_16x16) {
-        /* pred16x16 + idct_add16intra (h264idct_template.c:191-200): lane = row (lane & 3) of block (lane >> 2) */
+        /* pred16x16 + idct_add16intra (h264idct_template.c:191-200): lane = column (lane & 3) of block (lane >> 2) */
         x.run([&](int lane) {
-            const int i = lane >> 2, yy = imb_by(i) + (lane & 3), x0 = imb_bx(i);
+            const int i = lane >> 2, y0 = imb_by(i), xc = imb_bx(i) + (lane & 3);
             auto TOP = [&](int k) { return (int)T.y[imb_yi(-1, k)]; };
             auto LEFT = [&](int k) { return (int)T.y[imb_yi(k, -1)]; };
             const CF *b = imb_block(R, coefs, i);
             const int dc = (R.flags & FFHIP_H264_INTRA_LUMA_DC) ? T.dcq[i] : (b ? b[0] : 0);
             const bool full = R.nnz[i] != 0, dconly = !full && dc != 0;
             const int lmode = IMB_UNIFORM((int)R.pred16);
-            const ImbPred P = imb_pred_row<16>(lmode, x0, yy, TOP, LEFT, mid);
+            const ImbPred P = imb_pred_quad<16, true>(lmode, xc, y0, TOP, LEFT, mid);
+            int res[4] = { 0, 0, 0, 0 };
+            if (full)
+                imb_idct4_col(b, dc, lane & 3, res);
+            else if (dconly)
+                res[0] = res[1] = res[2] = res[3] = (dc + 32) >> 6;
+#pragma unroll
             for (int j = 0; j < 4; j++) {
-                int v = imb_pred_px<PIX>(lmode, P, j, x0 + j, yy, maxv);
-                if (full)
-                    v = imb_clip<PIX>(v + imb_idct4_at(b, dc, j, lane & 3), maxv);
-                else if (dconly)
-                    v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
-                T.y[imb_yi(yy, x0 + j)] = (PIX)v;
+                int v = imb_pred_px<PIX>(lmode, P, j, xc, y0 + j, maxv);
+                if (full || dconly)
+                    v = imb_clip<PIX>(v + res[j], maxv);
+                T.y[imb_yi(y0 + j, xc)] = (PIX)v;
             }
         });
         return;
@@ -643,6 +675,25 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
 
     /* Intra4x4 with the 8x8 transform: pred8x8l over the low-pass filtered edge line (evaluated where it is read, from the raw
      * samples in the tile), idct8_add's second pass / idct8_dc_add: one phase per block */
+    /* the second pass of the four transforms, in place, once (a block's step then adds t8[8 x + y]; inside the step every sample's lane
+     * ran the whole 8-point pass of its column to keep one output) */
+    x.run([&](int lane) {
+        if (lane >= 32)
+            return;
+        const int q = lane >> 3, xx = lane & 7, nnz = R.nnz[4 * q];
+        const CF *b = nnz ? imb_block(R, coefs, 4 * q) : nullptr;
+        if (!b || (nnz == 1 && b[0]))
+            return;
+        int in[8];
+        uint32_t out[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            in[k] = T.t8[q][8 * xx + k];
+        imb_idct8_1d(in, out);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            T.t8[q][8 * xx + k] = (int)out[k] >> 6;
+    });
     for (int i = 0; i < 16; i += 4) {
         const int bx = imb_bx(i), by = imb_by(i), mode = R.pred4[i], nnz = R.nnz[i];
         const bool tl = (R.topleft_avail << i) & 0x8000, tr = (R.topright_avail << i) & 0x4000;
@@ -656,18 +707,8 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             const int xx = lane & 7, yy = lane >> 3;
             int v = hp_dir_sample_e<8>(mode, ef, xx, yy, hp_dir_dc_e<8>(mode, ef, mid));
             if (full) {
-                /* second pass: transform xx works on block[8 xx + k], output yy goes to dst[xx + yy * stride] */
-                int in[8];
-                uint32_t out[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    in[k] = T.t8[i >> 2][8 * xx + k];
-                imb_idct8_1d(in, out);
-                uint32_t o = out[0];
-#pragma unroll
-                for (int k = 1; k < 8; k++)
-                    o = yy == k ? out[k] : o;
-                v = imb_clip<PIX>(v + ((int)o >> 6), maxv);
+                /* transform xx worked on block[8 xx + k], output yy goes to dst[xx + yy * stride] */
+                v = imb_clip<PIX>(v + T.t8[i >> 2][8 * xx + yy], maxv);
             } else if (dconly) {
                 v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
             }
