@@ -690,6 +690,47 @@ def round2_legs(torch, dev, ev):
     return out
 
 
+def h264_intra_picture_leg(torch, dev, ev, h264):
+    """a 1080p I-picture (every macroblock intra: Intra16x16 / 4x4 / 8x8-transform / I_PCM mixed with residuals, the decoder-side
+    state from tests/h264_intra_gen.py — an input generator, not the oracle) through ffhip_h264_picture_flush: the reconstruction
+    wavefront (kernels/h264_intra.hip) + the decoder-order deblocking with bS = 3 / 4 edges."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import h264_intra_gen as G
+    EDGE_DT = np.dtype([("offset", np.int32), ("kind", np.uint8), ("alpha", np.uint8), ("beta", np.uint8), ("pad", np.uint8), ("tc0", np.int8, 4)])
+    mb_w, mb_h = 120, 68
+    rng = np.random.default_rng(6)
+    sy, sc = mb_w * 16, mb_w * 8
+    dst = [torch.zeros((mb_h * 16, sy), dtype=torch.uint8, device=dev), torch.zeros((mb_h * 8, sc), dtype=torch.uint8, device=dev),
+           torch.zeros((mb_h * 8, sc), dtype=torch.uint8, device=dev)]
+    pic = h264.Picture(mb_w, mb_h)
+    pic.begin()
+    ed8, ed4 = np.zeros(8, EDGE_DT), np.zeros(4, EDGE_DT)
+    for e in (ed8, ed4):
+        e["alpha"], e["beta"], e["kind"] = 40, 9, 4
+    ed4["kind"] = 6
+    for my in range(mb_h):
+        for mx in range(mb_w):
+            d = G.make_intra_mb(rng, mx, my, mb_w, mb_h)
+            pic.intra_mb(G.to_record(d), d["nnzc"], d["mb"], d["luma_dc"], d["pcm"])
+            for pl, ed in ((0, ed8), (1, ed4), (2, ed4)):
+                pic.deblock_mb(pl, mx, my, ed)
+    pic.flush(dst, [sy, sc, sc], dst)
+    torch.cuda.synchronize()
+    reps = 10
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(reps):
+        pic.flush(dst, [sy, sc, sc], dst)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    pic.close()
+    return {"h264_intra_picture_1080p": {"ms_per_picture": round(ms, 3), "pictures_per_s": round(1e3 / ms, 1), "intra_macroblocks": mb_w * mb_h,
+                                         "us_per_wavefront_step": round(1e3 * ms / (mb_w + 2 * mb_h), 2),
+                                         "note": "a dependency chain of mb_w + 2 mb_h macroblock steps (intra prediction reads the left / upper / upper-right "
+                                                 "neighbours' reconstructed samples): latency-bound by construction, one wave per macroblock row"}}
+
+
 def h264_picture_leg(torch, dev, ev):
     """the picture layer: synthetic 1080p P-pictures (tools/h264_synth.py) through ffhip_h264_picture_flush — MC,
     residual add and the in-loop filter in decoder order.  A lone picture is a chain of latency-bound kernels; 16 pictures in flight,
@@ -738,7 +779,8 @@ def h264_picture_leg(torch, dev, ev):
         res[n] = ms
     for p in pics:
         p.close()
-    return {"h264_picture_pipeline_1080p": {"ms_per_picture_alone": round(res[1], 3), "ms_per_picture_16_in_flight": round(res[npic] / npic, 3),
+    intra = h264_intra_picture_leg(torch, dev, ev, h264)
+    return {**intra, "h264_picture_pipeline_1080p": {"ms_per_picture_alone": round(res[1], 3), "ms_per_picture_16_in_flight": round(res[npic] / npic, 3),
                                            "pictures_per_s_16_in_flight": round(1e3 * npic / res[npic], 1),
                                            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                                            "note": "P-pictures: qpel + chroma MC, idct_add on ~half of the blocks, deblocking in decoder order; one stream and host thread per picture"}}

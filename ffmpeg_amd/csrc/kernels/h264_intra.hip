@@ -181,7 +181,6 @@ __global__ __launch_bounds__(256) void k_h264_intra_frame(uint8_t *py, uint8_t *
     Q pf = 0;            /* from_mem: the next record's top neighbours, read a step ahead */
     bool have_pf = false;
     ImbWave X{ lane };
-    const ImbP4 P4 = imb_p4_build(lane); /* this lane's pred4x4 rules, one entry per mode */
     for (int cur = 0; k < kend; k++, cur ^= 1) {
         const FFHipH264IntraMB &R = Rb[cur];
         const int mx = R.mb_x;
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(256) void k_h264_intra_frame(uint8_t *py, uint8_t *
                 ahead = __hip_atomic_load(&progress[my - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(Cb[cur]), maxv, P4);
+        imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(Cb[cur]), maxv);
         /* ---- the macroblock leaves the tile: 64 + 32 quads of samples; write-through where another workgroup reads them ---- */
         {
             uint8_t *dy = ymb + (ptrdiff_t)(lane >> 2) * sy + 4 * (lane & 3) * PS;

@@ -159,6 +159,7 @@ struct ImbTileT {
     PIX c[2][9 * 16];      /* chroma: sample (r, c), r = -1..7,  c = -4..11, at [(r + 1) * 16 + c + 4] */
     int t8[4][64];         /* first pass of the four 8x8 inverse transforms */
     int dcq[16];           /* luma_dc_dequant_idct's results by block */
+    int edge[32];          /* pred8x8l: the block's low-pass filtered edge line (25 entries) */
 };
 typedef ImbTileT<uint8_t> ImbTile;
 
@@ -320,9 +321,9 @@ IMB_FN int imb_pred_blk(int mode, int x, int y, Top TOP, Left LEFT, int maxv = 2
 
 /* ---- pred4x4 as a table: every directional rule is (w0 e[i0] + w1 e[i1] + w2 e[i2] + 2) >> 2 with weights (1, 2, 1), (2, 2, 0) or
  * (4, 0, 0) — hp_a3, hp_a2, a copy — over the edge line.  imb_p4_entry() is hp_dir_sample_e<4> solved for (i0, i1, i2, kind): bits 0-3,
- * 4-7, 8-11 the three indices, bits 12-13 the kind (0 a3, 1 a2, 2 copy).  A lane of the Intra4x4 phases always produces the same
- * sample (x, y) of its block, so it keeps its nine entries in five registers (ImbP4, built once per kernel) and a phase costs a
- * select + three edge reads instead of a nine-way switch evaluated under divergence (two blocks, two modes per phase). */
+ * 4-7, 8-11 the three indices, bits 12-13 the kind (0 a3, 1 a2, 2 copy): the switch yields three indices, the edge reads and the
+ * arithmetic are common to all modes (two blocks with two modes share a step).  (Keeping a lane's nine entries in five registers
+ * instead was no faster and cost registers the prefetches need.) */
 IMB_FN uint32_t imb_p4_a3(int a, int b, int c) { return (uint32_t)(a | b << 4 | c << 8); }
 IMB_FN uint32_t imb_p4_a2(int a, int b) { return (uint32_t)(a | b << 4 | b << 8 | 1 << 12); }
 IMB_FN uint32_t imb_p4_cp(int a) { return (uint32_t)(a | a << 4 | a << 8 | 2 << 12); }
@@ -359,36 +360,6 @@ IMB_FN uint32_t imb_p4_entry(int mode, int x, int y)
     }
 }
 
-struct ImbP4 {
-    uint32_t w[5]; /* entry of mode m in bits 16 (m & 1) .. of w[m >> 1] */
-};
-
-IMB_FN ImbP4 imb_p4_build(int lane)
-{
-    ImbP4 L;
-    const int x = lane & 3, y = (lane >> 2) & 3;
-#pragma unroll
-    for (int m = 0; m < 10; m += 2)
-        L.w[m >> 1] = imb_p4_entry(m, x, y) | (m + 1 < 9 ? imb_p4_entry(m + 1, x, y) << 16 : 0u);
-    return L;
-}
-
-IMB_FN uint32_t imb_p4_code(const ImbP4 &L, int lane, int mode)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int h = mode >> 1;
-    uint32_t w = L.w[0];
-    w = h == 1 ? L.w[1] : w;
-    w = h == 2 ? L.w[2] : w;
-    w = h == 3 ? L.w[3] : w;
-    w = h == 4 ? L.w[4] : w;
-    return (w >> (16 * (mode & 1))) & 0x3FFFu;
-#else
-    (void)L;
-    return imb_p4_entry(mode, lane & 3, (lane >> 2) & 3);
-#endif
-}
-
 /* The same rules, split for a lane that produces the four samples (x0 .. x0 + 3, y): everything the rule reads is read ONCE, before
  * the lane writes (the compiler cannot hoist tile reads over tile writes itself: imb_pred_blk per sample re-read the whole edge — 64
  * byte reads for a DC, 64 for a plane — four times). */
@@ -396,6 +367,17 @@ struct ImbPred {
     int s[4], dc, a, H, V; /* s[j]: sample j's value under the horizontal / vertical rules */
 };
 
+/* a phase body is inlined into its one call site whatever the size of the caller: a body left as a call takes its captures by
+ * address, i.e. through scratch memory */
+#define IMB_INL __attribute__((always_inline))
+#if defined(__HIP_DEVICE_COMPILE__)
+/* per-lane state carried from one phase to the next: a register on the device, a slot per lane in the emulation */
+#define IMB_STATE(name) uint32_t name = 0
+#define IMB_AT(name, lane) name
+#else
+#define IMB_STATE(name) uint32_t name[64]
+#define IMB_AT(name, lane) name[lane]
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define IMB_UNIFORM(v) __builtin_amdgcn_readfirstlane(v) /* the same in every lane: keep it in a scalar register, branch without masks */
 #else
@@ -479,7 +461,7 @@ IMB_FN int imb_pred_px(int mode, const ImbPred &P, int j, int x, int y, int maxv
  */
 template <typename PIX, class X>
 IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, const typename ImbCoef<PIX>::T *coefs /* the macroblock's run */,
-                            int maxv = 255 /* (1 << bit_depth) - 1 */, const ImbP4 &P4 = ImbP4() /* imb_p4_build(lane) */)
+                            int maxv = 255 /* (1 << bit_depth) - 1 */)
 {
     typedef typename ImbCoef<PIX>::T CF;
     const int mid = (maxv + 1) >> 1;
@@ -487,7 +469,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
         /* the samples as they stand in the bitstream: 256 luma, 64 Cb, 64 Cr (h264_mb_template.c:98-150; above 8 bits the host side
          * has unpacked the bit_depth-bit fields into uint16_t) */
         const PIX *pcm = reinterpret_cast<const PIX *>(coefs);
-        x.run([&](int lane) {
+        x.run([&](int lane) IMB_INL {
             for (int j = 0; j < 4; j++)
                 T.y[imb_yi(lane >> 2, 4 * (lane & 3) + j)] = pcm[16 * (lane >> 2) + 4 * (lane & 3) + j];
             if (lane < 32)
@@ -498,7 +480,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
     }
     /* ---- chroma: pred8x8 on both planes, then chroma_dc_dequant_idct + idct_add8 when cbp & 0x30; lane = 4 samples of a row.
      *      Intra16x16 also dequantises its 16 luma DCs here (lanes 32..47), the 8x8 transform runs its first pass (lanes 32..63) ---- */
-    x.run([&](int lane) {
+    x.run([&](int lane) IMB_INL {
         if (lane < 32) {
             /* lane = column (lane & 3) of chroma block k = (lane >> 2) & 3 of plane p: everything is read before the column is written */
             const int p = lane >> 4, k = (lane >> 2) & 3, xc = 4 * (k & 1) + (lane & 3), y0 = 4 * (k >> 1);
@@ -584,7 +566,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
 
     if (R.type == FFHIP_H264_INTRA_16x16) {
         /* pred16x16 + idct_add16intra (h264idct_template.c:191-200): lane = column (lane & 3) of block (lane >> 2) */
-        x.run([&](int lane) {
+        x.run([&](int lane) IMB_INL {
             const int i = lane >> 2, y0 = imb_by(i), xc = imb_bx(i) + (lane & 3);
             auto TOP = [&](int k) { return (int)T.y[imb_yi(-1, k)]; };
             auto LEFT = [&](int k) { return (int)T.y[imb_yi(k, -1)]; };
@@ -618,7 +600,30 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
         /* The residuals do not depend on the prediction: all sixteen blocks' in ONE phase ahead of the ten steps, lane = column x of
          * block i (four first-pass butterflies serve the column's four samples: 8 butterflies per lane instead of 5 per sample inside a
          * step), parked in t8 (unused by this macroblock type) as res[16 i + 4 y + x]. */
-        x.run([&](int lane) {
+        /* ... and a lane of the steps collects what its ten steps need from the record — mode, "has a residual", "top-right is
+         * there" — one byte per step in three registers: the record lives in LDS and a fence ends every step, so read in place it was a
+         * dependent round trip at the head of each step.  (The host emulation runs the lanes one after another: a slot per lane.) */
+        IMB_STATE(inf0);
+        IMB_STATE(inf1);
+        IMB_STATE(inf2);
+        x.run([&](int lane) IMB_INL {
+            uint32_t m0 = 0, m1 = 0, m2 = 0;
+            if (lane < 32) {
+#pragma unroll
+                for (int t = 0; t < 10; t++) {
+                    const int y0 = t <= 3 ? 0 : (t - 2) >> 1, y4 = y0 + (lane >> 4), x4 = t - 2 * y4;
+                    const bool on = y4 <= 3 && x4 >= 0 && x4 <= 3;
+                    const int bi = on ? (x4 & 1) | (y4 & 1) << 1 | (x4 >> 1) << 2 | (y4 >> 1) << 3 : 0;
+                    const uint32_t v = (uint32_t)R.pred4[bi] | (R.nnz[bi] ? 16u : 0u) | (((R.topright_avail << bi) & 0x8000) ? 32u : 0u) | 64u;
+                    const uint32_t sh = (on ? v : 0u) << (8 * (t & 3));
+                    m0 |= t < 4 ? sh : 0u;
+                    m1 |= t >= 4 && t < 8 ? sh : 0u;
+                    m2 |= t >= 8 ? sh : 0u;
+                }
+            }
+            IMB_AT(inf0, lane) = m0;
+            IMB_AT(inf1, lane) = m1;
+            IMB_AT(inf2, lane) = m2;
             const int i = lane >> 2, xx = lane & 3, nnz = R.nnz[i];
             if (!nnz)
                 return;
@@ -640,17 +645,19 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
                 res[4 * y + xx] = imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
         });
         for (int t = 0; t < 10; t++) {
-            x.run([&](int lane) {
+            x.run([&](int lane) IMB_INL {
                 if (lane >= 32)
                     return;
-                const int y0 = t <= 3 ? 0 : (t - 2) >> 1, y4 = y0 + (lane >> 4), x4 = t - 2 * y4;
-                if (y4 > 3 || x4 < 0 || x4 > 3)
+                const uint32_t i0 = IMB_AT(inf0, lane), i1 = IMB_AT(inf1, lane), i2 = IMB_AT(inf2, lane); /* values, then the choice */
+                const uint32_t info = ((t < 4 ? i0 : t < 8 ? i1 : i2) >> (8 * (t & 3))) & 0xFFu;
+                if (!(info & 64u))
                     return;
+                const int y0 = t <= 3 ? 0 : (t - 2) >> 1, y4 = y0 + (lane >> 4), x4 = t - 2 * y4;
                 const int i = (x4 & 1) | (y4 & 1) << 1 | (x4 >> 1) << 2 | (y4 >> 1) << 3;
-                const int bx = 4 * x4, by = 4 * y4, mode = R.pred4[i];
+                const int bx = 4 * x4, by = 4 * y4, mode = (int)(info & 15u);
                 /* top-right: the samples themselves or, when the block there is not decoded yet / outside, the last sample of the
                  * row above four times (hl_decode_mb_predict_luma, h264_mb.c:672-689) */
-                const bool tr_avail = (R.topright_avail << i) & 0x8000;
+                const bool tr_avail = (info & 32u) != 0;
                 auto e = [&](int k) {
                     const int r = k < 4 ? by + 3 - k : by - 1, c = k < 4 ? bx - 1 : (k < 9 || tr_avail) ? bx + k - 5 : bx + 3;
                     return (int)T.y[imb_yi(r, c)];
@@ -659,13 +666,13 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
                 int v;
                 if (mode == 2 || mode >= 9) {
                     v = hp_dir_dc_e<4>(mode, e, mid);
-                } else {
-                    const uint32_t code = imb_p4_code(P4, lane, mode);
+                } else { /* every directional rule is (w0 e[i0] + w1 e[i1] + w2 e[i2] + 2) >> 2: imb_p4_entry() */
+                    const uint32_t code = imb_p4_entry(mode, xx, yy);
                     const int a = e((int)(code & 15u)), b = e((int)((code >> 4) & 15u)), c = e((int)((code >> 8) & 15u));
                     const int kind = (int)(code >> 12);
                     v = kind == 0 ? (a + 2 * b + c + 2) >> 2 : kind == 1 ? (a + b + 1) >> 1 : a;
                 }
-                if (R.nnz[i])
+                if (info & 16u)
                     v = imb_clip<PIX>(v + (&T.t8[0][0])[16 * i + 4 * yy + xx], maxv);
                 T.y[imb_yi(by + yy, bx + xx)] = (PIX)v;
             });
@@ -677,7 +684,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
      * samples in the tile), idct8_add's second pass / idct8_dc_add: one phase per block */
     /* the second pass of the four transforms, in place, once (a block's step then adds t8[8 x + y]; inside the step every sample's lane
      * ran the whole 8-point pass of its column to keep one output) */
-    x.run([&](int lane) {
+    x.run([&](int lane) IMB_INL {
         if (lane >= 32)
             return;
         const int q = lane >> 3, xx = lane & 7, nnz = R.nnz[4 * q];
@@ -701,9 +708,16 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
         const CF *b = nnz ? imb_block(R, coefs, i) : nullptr;
         const int dc = b ? b[0] : 0;
         const bool dconly = nnz == 1 && dc, full = nnz && !dconly;
-        x.run([&](int lane) {
+        /* the filtered line once per block (25 lanes), then the rule reads it: evaluated where it was read, a DC cost every lane 16
+         * filtered entries of three raw reads each */
+        x.run([&](int lane) IMB_INL {
+            if (lane >= 25)
+                return;
             auto w = [&](int k) { return (int)T.y[k < 8 ? imb_yi(by + 7 - k, bx - 1) : imb_yi(by - 1, bx + k - 9)]; };
-            auto ef = [&](int k) { return hp_filter8_e(w, k, need, tl, tr); };
+            T.edge[lane] = hp_filter8_e(w, lane, need, tl, tr);
+        });
+        x.run([&](int lane) IMB_INL {
+            auto ef = [&](int k) { return T.edge[k]; };
             const int xx = lane & 7, yy = lane >> 3;
             int v = hp_dir_sample_e<8>(mode, ef, xx, yy, hp_dir_dc_e<8>(mode, ef, mid));
             if (full) {
