@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
-from ffmpeg_amd import h264  # noqa: E402
+from ffmpeg_amd import _lib, h264  # noqa: E402
+if os.environ.get("FFHIP_MEASURE_LIB") == "1":   # the -DFFHIP_MEASURE build: FFHIP_INTRA_WPB and the other knobs are live there
+    _lib.select("measure")
 import h264_intra_gen as G  # noqa: E402
 from test_gpu_h264_picture import QPEL_DT, CHROMA_DT, EDGE_DT  # noqa: E402
 
