@@ -292,3 +292,18 @@ def test_picture_pipeline_hbd(depth, mb_w, mb_h, pictures, p_intra):
             assert (want[pl] != dst0[pl]).sum() > 1000 and want[pl].max() < top
             assert np.array_equal(got, want[pl]), "picture %d plane %d: %d mismatches" % (it, pl, (got != want[pl]).sum())
     pic.close()
+
+
+@pytest.mark.parametrize("wpb", [1, 2, 3])
+@pytest.mark.parametrize("depth", [8, 10])
+def test_intra_wavefront_workgroup_shapes(wpb, depth, monkeypatch, measure_build):
+    """1 / 2 / 3 macroblock rows per workgroup (the product picks the largest of 1..4 whose line buffers fit 64 KB of LDS beside the
+    tiles: 3 for a 4K picture above 8 bits, 2 at 8K): the memory hand-off alone, and the mixes of LDS and memory boundaries, give the
+    same pictures — mixed and all-intra ones, and rows of a P-picture that have no intra macroblock at all."""
+    monkeypatch.setenv("FFHIP_INTRA_WPB", str(wpb))
+    if depth == 8:
+        test_picture_pipeline(11, 7, 1, 1.0)
+        test_picture_pipeline(13, 9, 1, .12)
+    else:
+        test_picture_pipeline_hbd(depth, 11, 7, 1, 1.0)
+        test_picture_pipeline_hbd(depth, 13, 9, 1, .12)
