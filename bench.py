@@ -414,7 +414,7 @@ def extras(torch, dev):
         rng = np.random.default_rng(3)
         my, mx = np.meshgrid(np.arange(h // 16), np.arange(w // 16), indexing="ij")
         blk = np.zeros(nf * my.size, dtype=np.dtype([("d", np.int32), ("s", np.int32), ("mc", np.uint8), ("sz", np.uint8),
-                                                         ("avg", np.uint8), ("pad", np.uint8)]))
+                                                         ("avg", np.uint8), ("flags", np.uint8), ("sx", np.int16), ("sy", np.int16)]))
         for fi in range(nf):
             base = fi * (h + 2 * P) * stride
             d = base + (P + my.ravel() * 16) * stride + P + mx.ravel() * 16
@@ -423,7 +423,7 @@ def extras(torch, dev):
             blk["d"][sl] = d
             blk["s"][sl] = d + dy * stride + dx
             blk["mc"][sl] = rng.integers(0, 16, my.size)
-        dblk = torch.from_numpy(blk.view(np.uint8).reshape(-1, 12)).to(dev)
+        dblk = torch.from_numpy(blk.view(np.uint8).reshape(-1, 16)).to(dev)
         h264.qpel_batch(dstp, refp, stride, dblk, blk.size)
         e0, e1 = ev(), ev()
         e0.record()

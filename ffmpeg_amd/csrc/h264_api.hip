@@ -124,6 +124,56 @@ extern "C" int ffhip_h264_qpel_batch_dev(uint8_t *dst, const uint8_t *src, ptrdi
     return ffhip_launch_h264_qpel(dst, src, stride, blocks, n, (hipStream_t)stream);
 }
 
+/* the FFHIP_MC_EMU forms: the reference pictures' dimensions in samples of the plane (h264_mb.c:229-247, 297-317) */
+static int pic_dims_ok(const char *who, int pic_w, int pic_h)
+{
+    if (pic_w <= 0 || pic_h <= 0 || pic_w > 32767 || pic_h > 32767) {
+        ffhip_set_error("%s: picture dimensions %d x %d", who, pic_w, pic_h);
+        return 0;
+    }
+    return 1;
+}
+
+extern "C" int ffhip_h264_qpel_batch_dev_pic(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h,
+                                             const FFHipQpelBlock *blocks, int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0 || !pic_dims_ok("ffhip_h264_qpel_batch_dev_pic", pic_w, pic_h))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_qpel(dst, src, stride, blocks, n, (hipStream_t)stream, pic_w, pic_h);
+}
+
+extern "C" int ffhip_h264_chroma_mc_batch_dev_pic(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h,
+                                                  const FFHipChromaBlock *blocks, int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0 || !pic_dims_ok("ffhip_h264_chroma_mc_batch_dev_pic", pic_w, pic_h))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_chroma_mc(dst, src, stride, blocks, n, (hipStream_t)stream, pic_w, pic_h);
+}
+
+extern "C" int ffhip_h264_qpel_batch_dev_hbd_pic(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h,
+                                                 const FFHipQpelBlock *blocks, int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0 || !pic_dims_ok("ffhip_h264_qpel_batch_dev_hbd_pic", pic_w, pic_h))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_qpel_bd(bit_depth, dst, src, stride, blocks, n, (hipStream_t)stream, pic_w, pic_h);
+}
+
+extern "C" int ffhip_h264_chroma_mc_batch_dev_hbd_pic(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h,
+                                                      const FFHipChromaBlock *blocks, int n, void *stream)
+{
+    if (!dst || !src || !blocks || n < 0 || !pic_dims_ok("ffhip_h264_chroma_mc_batch_dev_hbd_pic", pic_w, pic_h))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_chroma_mc_bd(bit_depth, dst, src, stride, blocks, n, (hipStream_t)stream, pic_w, pic_h);
+}
+
 extern "C" int ffhip_h264_chroma_mc_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks,
                                               int n, void *stream)
 {

@@ -205,6 +205,51 @@ extern "C" int ffhip_h264_picture_idct_add(FFHipH264Picture *p, int plane, int k
     return 0;
 }
 
+/* scan8[] (libavcodec/h264_parse.h:40-57): luma block i, chroma block k of plane pl (1 Cb, 2 Cr), and the three DC entries */
+static int scan8_luma(int i) { return 4 + (i & 1) + ((i >> 2) & 1) * 2 + (1 + ((i >> 1) & 1) + ((i >> 3) & 1) * 2) * 8; }
+static int scan8_chroma(int pl, int k) { return 4 + (k & 1) + (5 * pl + 1 + (k >> 1)) * 8; }
+
+/* The macroblock-level members hl_decode_mb() calls for an inter macroblock's residual (h264_mb.c:780-797, h264_mb_template.c:254-257),
+ * expanded into the per-block records exactly as the dsp functions dispatch them (h264idct_template.c:176-228): which 0 idct_add16,
+ * 1 idct8_add4 (plane 0..2, one destination), 3 idct_add8 (dst_offset[0] Cb, [1] Cr; block = sl->mb, blocks 16..19 and 32..35).
+ * block_offset is the decoder's h->block_offset (bytes), nnzc the pointer the member gets.  Consumes `block` as the functions do. */
+extern "C" int ffhip_h264_picture_idct_mb(FFHipH264Picture *p, int which, int plane, const int32_t dst_offset[2], const int *block_offset,
+                                          int16_t *block, const uint8_t *nnzc)
+{
+    if (!p || !dst_offset || !block_offset || !block || !nnzc || plane < 0 || plane > 2)
+        return FFHIP_EINVAL;
+    const int wide = p->bd > 8 ? 2 : 1; /* int16 per coefficient: block + i*16*sizeof(pixel) in the reference */
+    auto coef0 = [&](int i) { return wide == 2 ? reinterpret_cast<const int32_t *>(block)[i * 16] : (int32_t)block[i * 16]; };
+    int r = 0;
+    if (which == 0) {
+        for (int i = 0; i < 16 && r >= 0; i++) {
+            const int nnz = nnzc[scan8_luma(i)];
+            if (nnz)
+                r = ffhip_h264_picture_idct_add(p, plane, nnz == 1 && coef0(i) ? FFHIP_H264_IDCT4_DC : FFHIP_H264_IDCT4, dst_offset[0] + block_offset[i],
+                                                block + i * 16 * wide);
+        }
+    } else if (which == 1) {
+        for (int i = 0; i < 16 && r >= 0; i += 4) {
+            const int nnz = nnzc[scan8_luma(i)];
+            if (nnz)
+                r = ffhip_h264_picture_idct_add(p, plane, nnz == 1 && coef0(i) ? FFHIP_H264_IDCT8_DC : FFHIP_H264_IDCT8, dst_offset[0] + block_offset[i],
+                                                block + i * 16 * wide);
+        }
+    } else if (which == 3) {
+        for (int j = 1; j < 3 && r >= 0; j++)
+            for (int i = j * 16; i < j * 16 + 4 && r >= 0; i++) {
+                if (nnzc[scan8_chroma(j, i - j * 16)])
+                    r = ffhip_h264_picture_idct_add(p, j, FFHIP_H264_IDCT4, dst_offset[j - 1] + block_offset[i], block + i * 16 * wide);
+                else if (coef0(i))
+                    r = ffhip_h264_picture_idct_add(p, j, FFHIP_H264_IDCT4_DC, dst_offset[j - 1] + block_offset[i], block + i * 16 * wide);
+            }
+    } else {
+        ffhip_set_error("ffhip_h264_picture_idct_mb: which = %d (0 idct_add16, 1 idct8_add4, 3 idct_add8)", which);
+        return FFHIP_EINVAL;
+    }
+    return r;
+}
+
 extern "C" int ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int mb_y, const FFHipH264Edge *e)
 {
     if (!p || !e || plane < 0 || plane > 2 || mb_x < 0 || mb_x >= p->mb_w || mb_y < 0 || mb_y >= p->mb_h)
@@ -214,10 +259,6 @@ extern "C" int ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int
     p->any_edge[plane] = true;
     return 0;
 }
-
-/* scan8[] (libavcodec/h264_parse.h:40-57): luma block i, chroma block k of plane pl (1 Cb, 2 Cr), and the three DC entries */
-static int scan8_luma(int i) { return 4 + (i & 1) + ((i >> 2) & 1) * 2 + (1 + ((i >> 1) & 1) + ((i >> 3) & 1) * 2) * 8; }
-static int scan8_chroma(int pl, int k) { return 4 + (k & 1) + (5 * pl + 1 + (k >> 1)) * 8; }
 
 /* CF = dctcoef of the depth (int16_t at 8 bits, int32_t above); runs, R.coef, *ncoefs and cap count int16 entries at every depth */
 template <typename CF>
@@ -540,11 +581,12 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
         for (int s = 0; s < 3 && r >= 0; s++) {
             if (s_qpel[s].n)
                 r = ffhip_launch_h264_qpel_bd(bd, s == ST_TMP ? p->tmp[0] : dst[0], ref[0], stride[0], (const FFHipQpelBlock *)(db + s_qpel[s].off),
-                                              s_qpel[s].n, stream);
+                                              s_qpel[s].n, stream, 16 * p->mb_w, 16 * p->mb_h);
             for (int c = 0; c < 2 && r >= 0; c++)
                 if (s_cmc[c][s].n)
                     r = ffhip_launch_h264_chroma_mc_bd(bd, s == ST_TMP ? p->tmp[1 + c] : dst[1 + c], ref[1 + c], stride[1 + c],
-                                                       (const FFHipChromaBlock *)(db + s_cmc[c][s].off), s_cmc[c][s].n, stream);
+                                                       (const FFHipChromaBlock *)(db + s_cmc[c][s].off), s_cmc[c][s].n, stream, 8 * p->mb_w,
+                                                       8 * p->mb_h);
         }
         for (int pl = 0; pl < 3 && r >= 0; pl++)
             if (s_wt[pl].n)
@@ -581,10 +623,13 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
     for (int s = 0; s < 3 && r >= 0; s++) {
         uint8_t *target = s == ST_TMP ? p->tmp[0] : dst[0];
         if (s_qpel[s].n)
-            r = ffhip_launch_h264_qpel(target, ref[0], stride[0], (const FFHipQpelBlock *)(db + s_qpel[s].off), s_qpel[s].n, stream);
+            r = ffhip_launch_h264_qpel(target, ref[0], stride[0], (const FFHipQpelBlock *)(db + s_qpel[s].off), s_qpel[s].n, stream, 16 * p->mb_w,
+                                       16 * p->mb_h);
         if (r >= 0) { /* Cb and Cr of the stage: one launch */
             FFHipPlaneMulti M;
             M.nseg = 0;
+            M.pic_w = 8 * p->mb_w; /* records flagged FFHIP_MC_EMU clamp to the reference pictures' chroma planes (4:2:0) */
+            M.pic_h = 8 * p->mb_h;
             for (int c = 0; c < 2; c++)
                 if (s_cmc[c][s].n) {
                     FFHipPlaneSeg &g = M.seg[M.nseg++];

@@ -27,11 +27,24 @@ __device__ __forceinline__ void cm_row(const uint8_t *p, int nb, uint32_t (&w)[3
     w[2] = d2 >> (8 * sh);
 }
 
+/* FFHIP_MC_EMU (include/ffhip.h; h264_mb.c:297-317 -> videodsp_template.c:24-100): the same stream from clamped coordinates of the
+ * reference picture's plane whose (0, 0) is org */
+__device__ __forceinline__ void cm_row_emu(const uint8_t *org, ptrdiff_t stride, int x, int y, int nb, int pw, int ph, uint32_t (&w)[3])
+{
+    const uint8_t *row = org + (ptrdiff_t)min(max(y, 0), ph - 1) * stride;
+    w[0] = w[1] = w[2] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        if (i < nb)
+            w[i >> 2] |= (uint32_t)row[min(max(x + i, 0), pw - 1)] << (8 * (i & 3));
+}
+
 /* 16 lanes per block, one lane per row: a row's (and the next row's) w + 1 source bytes arrive as aligned dwords, a sample is one
  * v_perm (s[k], s[k+1], t[k], t[k+1]) and one v_dot4_u32_u8 against (A, B, C, D), the row leaves as one or two dwords when dst
  * is aligned.  (Round 1 read and wrote every byte by itself: 26 memory instructions per lane for an 8-wide row, now 8.) */
 /* workgroup `wg` of a list: 16 blocks, a thread per row */
-__device__ __forceinline__ void chroma_mc_group(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n, int wg)
+__device__ __forceinline__ void chroma_mc_group(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n, int wg,
+                                                int pic_w, int pic_h)
 {
     const int b = (wg * 256 + (int)threadIdx.x) >> 4, row = threadIdx.x & 15;
     if (b >= n)
@@ -45,9 +58,16 @@ __device__ __forceinline__ void chroma_mc_group(uint8_t *dst, const uint8_t *src
     uint8_t *d = dst + blk.dst_offset + (ptrdiff_t)row * stride;
     /* the reference's three cases read only samples with a non-zero weight: the right neighbour if x, the row below if y */
     uint32_t sw[3], tw[3] = { 0, 0, 0 };
-    cm_row(s, w + (x ? 1 : 0), sw);
-    if (y)
-        cm_row(s + stride, w + (x ? 1 : 0), tw);
+    if (pic_w > 0 && (blk.flags & FFHIP_MC_EMU)) {
+        const uint8_t *org = src + blk.src_offset;
+        cm_row_emu(org, stride, blk.src_x, blk.src_y + row, w + (x ? 1 : 0), pic_w, pic_h, sw);
+        if (y)
+            cm_row_emu(org, stride, blk.src_x, blk.src_y + row + 1, w + (x ? 1 : 0), pic_w, pic_h, tw);
+    } else {
+        cm_row(s, w + (x ? 1 : 0), sw);
+        if (y)
+            cm_row(s + stride, w + (x ? 1 : 0), tw);
+    }
     const uint32_t coef = A | B << 8 | C << 16 | D << 24;
     uint32_t out[2] = { 0, 0 };
 #pragma unroll
@@ -81,9 +101,9 @@ __device__ __forceinline__ void chroma_mc_group(uint8_t *dst, const uint8_t *src
 }
 
 __global__ __launch_bounds__(256) void k_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
-                                                        const FFHipChromaBlock *blocks, int n)
+                                                        const FFHipChromaBlock *blocks, int n, int pic_w, int pic_h)
 {
-    chroma_mc_group(dst, src, stride, blocks, n, (int)blockIdx.x);
+    chroma_mc_group(dst, src, stride, blocks, n, (int)blockIdx.x, pic_w, pic_h);
 }
 
 /* the lists of several planes in one launch (the picture layer: Cb and Cr of a stage) */
@@ -94,7 +114,7 @@ __global__ __launch_bounds__(256) void k_h264_chroma_mc_multi(FFHipPlaneMulti M)
         if ((int)blockIdx.x >= M.seg[i].first)
             si = i;
     const FFHipPlaneSeg &S = M.seg[si];
-    chroma_mc_group(S.dst, S.src, S.stride, static_cast<const FFHipChromaBlock *>(S.blocks), S.n, (int)blockIdx.x - S.first);
+    chroma_mc_group(S.dst, S.src, S.stride, static_cast<const FFHipChromaBlock *>(S.blocks), S.n, (int)blockIdx.x - S.first, M.pic_w, M.pic_h);
 }
 
 static int plane_multi_pack(FFHipPlaneMulti &M)
@@ -123,11 +143,11 @@ int ffhip_launch_h264_chroma_mc_multi(FFHipPlaneMulti &M, hipStream_t stream)
 }
 
 int ffhip_launch_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
-                                hipStream_t stream)
+                                hipStream_t stream, int pic_w, int pic_h)
 {
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(k_h264_chroma_mc, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+    hipLaunchKernelGGL(k_h264_chroma_mc, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
     LAUNCH_CHECK();
     return 0;
 }

@@ -337,14 +337,28 @@ __global__ __launch_bounds__(256) void k_h264_loop_filter_hbd(uint8_t *base, ptr
 
 /* ---- luma qpel: a lane per output sample (16 lanes per row of a 16-wide block) --------------------------------------------- */
 __device__ __forceinline__ int hbd_tap6(int a, int b, int c, int d, int e, int f) { return (c + d) * 20 - (b + e) * 5 + (a + f); }
+
+/* The reference samples around one output sample: at(dx, dy).  A record flagged FFHIP_MC_EMU (include/ffhip.h; h264_mb.c:229-247,
+ * 297-317 -> videodsp_template.c:24-100) reads them at clamped coordinates of the reference picture whose (0, 0) is `p`. */
 template <typename P>
-__device__ __forceinline__ int hbd_h(const P *p) { return hbd_tap6(p[-2], p[-1], p[0], p[1], p[2], p[3]); }
-template <typename P>
-__device__ __forceinline__ int hbd_v(const P *p, ptrdiff_t s) { return hbd_tap6(p[-2 * s], p[-s], p[0], p[s], p[2 * s], p[3 * s]); }
+struct HbdSrc {
+    const P *p;      /* plain: the sample under the output sample; emu: the picture's (0, 0) */
+    ptrdiff_t s;     /* row pitch in samples */
+    int x, y, pw, ph;
+    bool emu;
+    __device__ __forceinline__ int at(int dx, int dy) const
+    {
+        if (emu)
+            return (int)p[(ptrdiff_t)min(max(y + dy, 0), ph - 1) * s + min(max(x + dx, 0), pw - 1)];
+        return (int)p[dy * s + dx];
+    }
+    __device__ __forceinline__ int h(int dx, int dy) const { return hbd_tap6(at(dx - 2, dy), at(dx - 1, dy), at(dx, dy), at(dx + 1, dy), at(dx + 2, dy), at(dx + 3, dy)); }
+    __device__ __forceinline__ int v(int dx, int dy) const { return hbd_tap6(at(dx, dy - 2), at(dx, dy - 1), at(dx, dy), at(dx, dy + 1), at(dx, dy + 2), at(dx, dy + 3)); }
+};
 
 template <typename P>
 __global__ __launch_bounds__(256) void k_h264_qpel_hbd(uint8_t *dst_base, const uint8_t *src_base, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
-                                                      int bd)
+                                                      int bd, int pic_w, int pic_h)
 {
     const int b = blockIdx.x, t = threadIdx.x; /* one workgroup per block, 256 lanes = 16 x 16 samples */
     if (b >= n)
@@ -354,11 +368,15 @@ __global__ __launch_bounds__(256) void k_h264_qpel_hbd(uint8_t *dst_base, const 
     if (x >= sz || y >= sz)
         return;
     const ptrdiff_t s = stride / (ptrdiff_t)sizeof(P);
-    const P *src = reinterpret_cast<const P *>(src_base + bl.src_offset) + y * s + x;
+    HbdSrc<P> S;
+    S.s = s; S.pw = pic_w; S.ph = pic_h;
+    S.emu = pic_w > 0 && (bl.flags & FFHIP_MC_EMU);
+    S.x = bl.src_x + x; S.y = bl.src_y + y;
+    S.p = reinterpret_cast<const P *>(src_base + bl.src_offset) + (S.emu ? 0 : y * s + x);
     P *dst = reinterpret_cast<P *>(dst_base + bl.dst_offset) + y * s + x;
     const int maxv = (1 << bd) - 1, mc = bl.mcxy & 15, mx = mc & 3, my = mc >> 2;
-#define QH(p) hclip((hbd_h<P>(p) + 16) >> 5, maxv)
-#define QV(p) hclip((hbd_v<P>(p, s) + 16) >> 5, maxv)
+#define QH(dx, dy) hclip((S.h(dx, dy) + 16) >> 5, maxv)
+#define QV(dx, dy) hclip((S.v(dx, dy) + 16) >> 5, maxv)
 #define QA(a, b) (((a) + (b) + 1) >> 1)
     int hv = 0;
     if (mx == 2 || my == 2) {
@@ -366,28 +384,28 @@ __global__ __launch_bounds__(256) void k_h264_qpel_hbd(uint8_t *dst_base, const 
             int tt[6];
 #pragma unroll
             for (int k = 0; k < 6; k++)
-                tt[k] = hbd_h<P>(src + (k - 2) * s);
+                tt[k] = S.h(0, k - 2);
             hv = hclip((hbd_tap6(tt[0], tt[1], tt[2], tt[3], tt[4], tt[5]) + 512) >> 10, maxv);
         }
     }
     int v;
     switch (mc) {
-    case 0:  v = src[0]; break;
-    case 1:  v = QA((int)src[0], QH(src)); break;
-    case 2:  v = QH(src); break;
-    case 3:  v = QA((int)src[1], QH(src)); break;
-    case 4:  v = QA((int)src[0], QV(src)); break;
-    case 8:  v = QV(src); break;
-    case 12: v = QA((int)src[s], QV(src)); break;
-    case 5:  v = QA(QH(src), QV(src)); break;
-    case 7:  v = QA(QH(src), QV(src + 1)); break;
-    case 13: v = QA(QH(src + s), QV(src)); break;
-    case 15: v = QA(QH(src + s), QV(src + 1)); break;
+    case 0:  v = S.at(0, 0); break;
+    case 1:  v = QA(S.at(0, 0), QH(0, 0)); break;
+    case 2:  v = QH(0, 0); break;
+    case 3:  v = QA(S.at(1, 0), QH(0, 0)); break;
+    case 4:  v = QA(S.at(0, 0), QV(0, 0)); break;
+    case 8:  v = QV(0, 0); break;
+    case 12: v = QA(S.at(0, 1), QV(0, 0)); break;
+    case 5:  v = QA(QH(0, 0), QV(0, 0)); break;
+    case 7:  v = QA(QH(0, 0), QV(1, 0)); break;
+    case 13: v = QA(QH(0, 1), QV(0, 0)); break;
+    case 15: v = QA(QH(0, 1), QV(1, 0)); break;
     case 10: v = hv; break;
-    case 6:  v = QA(QH(src), hv); break;
-    case 14: v = QA(QH(src + s), hv); break;
-    case 9:  v = QA(QV(src), hv); break;
-    default: v = QA(QV(src + 1), hv); break;
+    case 6:  v = QA(QH(0, 0), hv); break;
+    case 14: v = QA(QH(0, 1), hv); break;
+    case 9:  v = QA(QV(0, 0), hv); break;
+    default: v = QA(QV(1, 0), hv); break;
     }
     dst[0] = (P)(bl.avg ? QA((int)dst[0], v) : v);
 #undef QH
@@ -397,7 +415,7 @@ __global__ __launch_bounds__(256) void k_h264_qpel_hbd(uint8_t *dst_base, const 
 /* ---- chroma MC and explicit weighting: a lane per output sample ---------------------------------------------------------------- */
 template <typename P>
 __global__ __launch_bounds__(128) void k_h264_chroma_mc_hbd(uint8_t *dst_base, const uint8_t *src_base, ptrdiff_t stride, const FFHipChromaBlock *blocks,
-                                                           int n)
+                                                           int n, int pic_w, int pic_h)
 {
     const int b = blockIdx.x, t = threadIdx.x; /* up to 8 wide x 16 rows */
     if (b >= n)
@@ -407,13 +425,17 @@ __global__ __launch_bounds__(128) void k_h264_chroma_mc_hbd(uint8_t *dst_base, c
     if (x >= w || y >= bl.h)
         return;
     const ptrdiff_t s = stride / (ptrdiff_t)sizeof(P);
-    const P *src = reinterpret_cast<const P *>(src_base + bl.src_offset) + y * s + x;
+    HbdSrc<P> S;
+    S.s = s; S.pw = pic_w; S.ph = pic_h;
+    S.emu = pic_w > 0 && (bl.flags & FFHIP_MC_EMU);
+    S.x = bl.src_x + x; S.y = bl.src_y + y;
+    S.p = reinterpret_cast<const P *>(src_base + bl.src_offset) + (S.emu ? 0 : y * s + x);
     P *dst = reinterpret_cast<P *>(dst_base + bl.dst_offset) + y * s + x;
     const int fx = bl.x, fy = bl.y, A = (8 - fx) * (8 - fy), B = fx * (8 - fy), Cc = (8 - fx) * fy, D = fx * fy;
-    int v = A * (int)src[0];
-    if (B) v += B * (int)src[1];        /* the template never reads a neighbour whose weight is zero */
-    if (Cc) v += Cc * (int)src[s];
-    if (D) v += D * (int)src[s + 1];
+    int v = A * S.at(0, 0);
+    if (B) v += B * S.at(1, 0);        /* the template never reads a neighbour whose weight is zero */
+    if (Cc) v += Cc * S.at(0, 1);
+    if (D) v += D * S.at(1, 1);
     v = (v + 32) >> 6;
     dst[0] = (P)(bl.avg ? ((int)dst[0] + v + 1) >> 1 : v);
 }
@@ -528,29 +550,30 @@ int ffhip_launch_h264_loop_filter_bd(int bd, uint8_t *base, ptrdiff_t stride, co
     return 0;
 }
 
-int ffhip_launch_h264_qpel_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n, hipStream_t stream)
+int ffhip_launch_h264_qpel_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n, hipStream_t stream,
+                              int pic_w, int pic_h)
 {
     if (n <= 0)
         return 0;
     HBD_CHECK(bd);
     if (bd > 8)
-        hipLaunchKernelGGL(k_h264_qpel_hbd<uint16_t>, dim3(n), dim3(256), 0, stream, dst, src, stride, blocks, n, bd);
+        hipLaunchKernelGGL(k_h264_qpel_hbd<uint16_t>, dim3(n), dim3(256), 0, stream, dst, src, stride, blocks, n, bd, pic_w, pic_h);
     else
-        hipLaunchKernelGGL(k_h264_qpel_hbd<uint8_t>, dim3(n), dim3(256), 0, stream, dst, src, stride, blocks, n, bd);
+        hipLaunchKernelGGL(k_h264_qpel_hbd<uint8_t>, dim3(n), dim3(256), 0, stream, dst, src, stride, blocks, n, bd, pic_w, pic_h);
     LAUNCH_CHECK();
     return 0;
 }
 
 int ffhip_launch_h264_chroma_mc_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
-                                   hipStream_t stream)
+                                   hipStream_t stream, int pic_w, int pic_h)
 {
     if (n <= 0)
         return 0;
     HBD_CHECK(bd);
     if (bd > 8)
-        hipLaunchKernelGGL(k_h264_chroma_mc_hbd<uint16_t>, dim3(n), dim3(128), 0, stream, dst, src, stride, blocks, n);
+        hipLaunchKernelGGL(k_h264_chroma_mc_hbd<uint16_t>, dim3(n), dim3(128), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
     else
-        hipLaunchKernelGGL(k_h264_chroma_mc_hbd<uint8_t>, dim3(n), dim3(128), 0, stream, dst, src, stride, blocks, n);
+        hipLaunchKernelGGL(k_h264_chroma_mc_hbd<uint8_t>, dim3(n), dim3(128), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
     LAUNCH_CHECK();
     return 0;
 }

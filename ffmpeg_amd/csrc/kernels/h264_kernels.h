@@ -9,7 +9,7 @@
 
 /* the block lists of up to three planes in one launch (chroma MC, weighted prediction); empty segments are dropped */
 struct FFHipPlaneSeg { uint8_t *dst; const uint8_t *src; const void *blocks; int stride, n, first; };
-struct FFHipPlaneMulti { FFHipPlaneSeg seg[3]; int nseg; };
+struct FFHipPlaneMulti { FFHipPlaneSeg seg[3]; int nseg; int pic_w = 0, pic_h = 0; /* chroma MC: FFHIP_MC_EMU clamps to these */ };
 int ffhip_launch_h264_chroma_mc_multi(FFHipPlaneMulti &M, hipStream_t stream);
 int ffhip_launch_h264_weight_multi(FFHipPlaneMulti &M, hipStream_t stream);
 /* several idct_add lists in one launch (kinds FFHIP_H264_IDCT4 .. FFHIP_H264_IDCT8_DC); empty segments are dropped */
@@ -38,9 +38,11 @@ int ffhip_launch_h264_dc_dequant_bd(int bd, int which, int16_t *output, size_t o
 /* alpha_beta: NULL (the records' bytes) or n x { alpha, beta } ints overriding them */
 int ffhip_launch_h264_loop_filter_bd(int bd, uint8_t *base, ptrdiff_t stride, const FFHipH264Edge *edges, int n, hipStream_t stream,
                                      const int32_t *alpha_beta = nullptr);
-int ffhip_launch_h264_qpel_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n, hipStream_t stream);
+/* pic_w / pic_h (samples of the plane; 0: no record is read as FFHIP_MC_EMU) */
+int ffhip_launch_h264_qpel_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n, hipStream_t stream,
+                              int pic_w = 0, int pic_h = 0);
 int ffhip_launch_h264_chroma_mc_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
-                                   hipStream_t stream);
+                                   hipStream_t stream, int pic_w = 0, int pic_h = 0);
 int ffhip_launch_h264_weight_bd(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
                                 hipStream_t stream);
 int ffhip_launch_h264_deblock_frames_bd(int bd, int chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
@@ -63,9 +65,9 @@ int ffhip_launch_h264_deblock_frames_chroma(uint8_t *plane, size_t frame_pitch, 
 int ffhip_launch_h264_deblock_frames(uint8_t *luma, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
                                      const FFHipH264Edge *edges, hipStream_t stream);
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
-                           hipStream_t stream);
+                           hipStream_t stream, int pic_w = 0, int pic_h = 0);
 int ffhip_launch_h264_chroma_mc(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
-                                hipStream_t stream);
+                                hipStream_t stream, int pic_w = 0, int pic_h = 0);
 int ffhip_launch_h264_weight(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
                              hipStream_t stream);
 int ffhip_launch_h264_pred(int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n, hipStream_t stream);

@@ -41,6 +41,27 @@ __device__ __forceinline__ Row12 load_row12(const uint8_t *p)
     return r;
 }
 
+/* FFHIP_MC_EMU (include/ffhip.h; h264_mb.c:229-247 -> videodsp_template.c:24-100): footprint sample (x, y) of the reference picture
+ * whose (0, 0) is org, read at clamped coordinates — what emulated_edge_mc() leaves in the decoder's edge buffer.  Byte loads: such
+ * blocks are the picture's rim, and nothing outside the picture is touched. */
+__device__ __forceinline__ uint32_t qp_emu_dword(const uint8_t *org, ptrdiff_t stride, int x, int y, int pw, int ph)
+{
+    const uint8_t *row = org + (ptrdiff_t)min(max(y, 0), ph - 1) * stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        v |= (uint32_t)row[min(max(x + i, 0), pw - 1)] << (8 * i);
+    return v;
+}
+__device__ __forceinline__ Row12 load_row12_emu(const uint8_t *org, ptrdiff_t stride, int x, int y, int pw, int ph)
+{
+    Row12 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        r.w[i] = qp_emu_dword(org, stride, x + 4 * i, y, pw, ph);
+    return r;
+}
+
 __device__ __forceinline__ int rbyte(const Row12 &r, int i) { return (int)((r.w[i >> 2] >> (8 * (i & 3))) & 0xFF); }
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return (c + d) * 20 - (b + e) * 5 + (a + f); }
 /* unclipped horizontal sum at sample i (0..4) of the lane; stream byte 0 is x-2 */
@@ -51,7 +72,7 @@ __device__ __forceinline__ int hraw(const Row12 &r, int i)
 __device__ __forceinline__ uint32_t rnd_avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) & 0xFEFEFEFEu) >> 1); }
 
 __global__ __launch_bounds__(256) void k_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
-                                                   const FFHipQpelBlock *blocks, int n)
+                                                   const FFHipQpelBlock *blocks, int n, int pic_w, int pic_h)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -77,7 +98,13 @@ __global__ __launch_bounds__(256) void k_h264_qpel(uint8_t *dst, const uint8_t *
     const bool vcol1 = mx == 3, hrow1 = my == 3;
 
     Row12 r[6]; /* rows y-2 .. y+3 */
-    if (useV || useJ) {
+    if (pic_w > 0 && (__builtin_amdgcn_readfirstlane((int)blk.flags) & FFHIP_MC_EMU)) {
+        const uint8_t *org = src + __builtin_amdgcn_readfirstlane(blk.src_offset);
+        const int ex = __builtin_amdgcn_readfirstlane((int)blk.src_x) + 4 * xg - 2, ey = __builtin_amdgcn_readfirstlane((int)blk.src_y) + y;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            r[k] = load_row12_emu(org, stride, ex, ey + k - 2, pic_w, pic_h);
+    } else if (useV || useJ) {
 #pragma unroll
         for (int k = 0; k < 6; k++)
             r[k] = load_row12(s + (ptrdiff_t)(k - 2) * stride);
@@ -189,8 +216,10 @@ struct QpBlk {
     uint32_t sh;
     bool avg;
     const uint8_t *sa;
+    bool emu;    /* FFHIP_MC_EMU: soff is the reference picture's origin, (sx, sy) the block's position in it */
+    int sx, sy;
 };
-__device__ __forceinline__ QpBlk qp_blk(const FFHipQpelBlock *blocks, int b, const uint8_t *src, ptrdiff_t stride)
+__device__ __forceinline__ QpBlk qp_blk(const FFHipQpelBlock *blocks, int b, const uint8_t *src, ptrdiff_t stride, int pic_w)
 {
     const FFHipQpelBlock blk = blocks[b];
     QpBlk q;
@@ -204,11 +233,26 @@ __device__ __forceinline__ QpBlk qp_blk(const FFHipQpelBlock *blocks, int b, con
     q.sh = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 3); /* same for every row: stride % 4 == 0 */
     q.sa = s0 - q.sh;
     q.ndw = (int)((q.sh + q.size + 5 + 3) >> 2);                     /* <= 7 */
+    q.emu = pic_w > 0 && (__builtin_amdgcn_readfirstlane((int)blk.flags) & FFHIP_MC_EMU);
+    q.sx = __builtin_amdgcn_readfirstlane((int)blk.src_x);
+    q.sy = __builtin_amdgcn_readfirstlane((int)blk.src_y);
+    if (q.emu) { /* the footprint is assembled byte by byte from its first sample: no shift */
+        q.sh = 0;
+        q.ndw = (q.size + 5 + 3) >> 2;
+    }
     return q;
 }
 /* the footprint: rows y-2 .. y+size+2, the aligned dwords that hold bytes x-2 .. x+size+2; three dwords per lane at most */
-__device__ __forceinline__ void qp_fetch(const QpBlk &q, ptrdiff_t stride, int lane, uint32_t f[3])
+__device__ __forceinline__ void qp_fetch(const QpBlk &q, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h, int lane, uint32_t f[3])
 {
+    if (q.emu) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int t = lane + 64 * i, r = t >> 3, j = t & 7;
+            f[i] = (r < q.rows && j < q.ndw) ? qp_emu_dword(src + q.soff, stride, q.sx - 2 + 4 * j, q.sy - 2 + r, pic_w, pic_h) : 0;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const int t = lane + 64 * i, r = t >> 3, j = t & 7;
@@ -343,7 +387,7 @@ __device__ __forceinline__ void qp_block(const QpBlk &q, const uint32_t *f, uint
  * wave keeps NB x 3 loads outstanding instead of 3 and pays the record -> footprint -> store latency chain once per NB blocks. */
 template <int NB>
 __global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
-                                                     const FFHipQpelBlock *blocks, int n)
+                                                     const FFHipQpelBlock *blocks, int n, int pic_w, int pic_h)
 {
     __shared__ uint32_t lds[4][21 * 8 + 21 * 8];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -357,10 +401,10 @@ __global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t
     uint32_t f[NB][3];
 #pragma unroll
     for (int k = 0; k < NB; k++)
-        q[k] = qp_blk(blocks, min(b0 + k, n - 1), src, stride);
+        q[k] = qp_blk(blocks, min(b0 + k, n - 1), src, stride, pic_w);
 #pragma unroll
     for (int k = 0; k < NB; k++)
-        qp_fetch(q[k], stride, lane, f[k]);
+        qp_fetch(q[k], src, stride, pic_w, pic_h, lane, f[k]);
 #pragma unroll
     for (int k = 0; k < NB; k++)
         if (b0 + k < n)
@@ -383,7 +427,8 @@ __global__ __launch_bounds__(256) void k_h264_qpel_l(uint8_t *dst, const uint8_t
  */
 typedef uint32_t qp_u4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_h264_qpel_t(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n)
+__global__ __launch_bounds__(256) void k_h264_qpel_t(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
+                                                     int pic_w, int pic_h)
 {
     __shared__ __align__(16) uint32_t rawp[4][21 * 12];
     __shared__ uint32_t hbp[4][21 * 8];
@@ -401,11 +446,26 @@ __global__ __launch_bounds__(256) void k_h264_qpel_t(uint8_t *dst, const uint8_t
     bool tile = true; /* all four 16x16 with dword-aligned destinations: their rows leave together */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        q[k] = qp_blk(blocks, min(b0 + k, n - 1), src, stride);
+        q[k] = qp_blk(blocks, min(b0 + k, n - 1), src, stride, pic_w);
         tile = tile && q[k].size == 16 && b0 + k < n && !((reinterpret_cast<uintptr_t>(dst) + (uintptr_t)(intptr_t)q[k].doff) & 3);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+        if (q[k].emu) { /* the rim of the picture: the chunk is assembled from clamped byte loads, first footprint byte at chunk 0 byte 0 */
+            sh16[k] = 0;
+            f[k] = (qp_u4){ 0, 0, 0, 0 };
+            if (fr < q[k].rows && fc < 2) {
+                const uint8_t *org = src + q[k].soff;
+                const int ex = q[k].sx - 2 + 16 * fc, ey = q[k].sy - 2 + fr;
+                f[k].x = qp_emu_dword(org, stride, ex, ey, pic_w, pic_h);
+                f[k].y = qp_emu_dword(org, stride, ex + 4, ey, pic_w, pic_h);
+                if (fc == 0) {
+                    f[k].z = qp_emu_dword(org, stride, ex + 8, ey, pic_w, pic_h);
+                    f[k].w = qp_emu_dword(org, stride, ex + 12, ey, pic_w, pic_h);
+                }
+            }
+            continue;
+        }
         const uint8_t *s0 = src + q[k].soff - 2 - 2 * stride;
         sh16[k] = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 15);
         const int nch = (int)(sh16[k] + q[k].size + 5 + 15) >> 4;
@@ -436,7 +496,7 @@ __global__ __launch_bounds__(256) void k_h264_qpel_t(uint8_t *dst, const uint8_t
 }
 
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
-                           hipStream_t stream)
+                           hipStream_t stream, int pic_w, int pic_h)
 {
     if (n <= 0)
         return 0;
@@ -445,17 +505,17 @@ int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, c
     const int nb = en ? atoi(en) : 4;
     const char *ew = FFHIP_KNOB("FFHIP_QPEL_W");   /* measured variant: 0 = k_h264_qpel_l (dword footprint loads, a store per block row) */
     if (!(stride & 15) && n >= 1024 && !(eo && eo[0] == '1') && !(ew && ew[0] == '0')) {
-        hipLaunchKernelGGL(k_h264_qpel_t, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+        hipLaunchKernelGGL(k_h264_qpel_t, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
     } else if (!(stride & 3) && !(eo && eo[0] == '1')) {
         if (nb >= 4 && n >= 4 * 4096)
-            hipLaunchKernelGGL(k_h264_qpel_l<4>, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+            hipLaunchKernelGGL(k_h264_qpel_l<4>, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
         else if (nb >= 2 && n >= 2 * 4096)
-            hipLaunchKernelGGL(k_h264_qpel_l<2>, dim3(cdiv(n, 8)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+            hipLaunchKernelGGL(k_h264_qpel_l<2>, dim3(cdiv(n, 8)), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
         else
-            hipLaunchKernelGGL(k_h264_qpel_l<1>, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+            hipLaunchKernelGGL(k_h264_qpel_l<1>, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
     }
     else
-        hipLaunchKernelGGL(k_h264_qpel, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n);
+        hipLaunchKernelGGL(k_h264_qpel, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
     LAUNCH_CHECK();
     return 0;
 }

@@ -84,13 +84,20 @@ def deblock_frames_hbd(bit_depth, plane, frame_pitch, nframes, stride, mb_w, mb_
                       "ffhip_h264_deblock_frames_dev_hbd")
 
 
-def qpel_batch(dst, src, stride, blocks, n, stream=None):
+def qpel_batch(dst, src, stride, blocks, n, stream=None, pic=None):
+    """blocks: uint8 [n, 16] FFHipQpelBlock records; pic = (pic_w, pic_h): the _pic form, which honours FFHIP_MC_EMU records"""
+    if pic is not None:
+        return _lib.check(_lib.lib().ffhip_h264_qpel_batch_dev_pic(dst.data_ptr(), src.data_ptr(), stride, pic[0], pic[1], blocks.data_ptr(),
+                                                                   n, _stream(stream)), "ffhip_h264_qpel_batch_dev_pic")
     return _lib.check(_lib.lib().ffhip_h264_qpel_batch_dev(dst.data_ptr(), src.data_ptr(), stride, blocks.data_ptr(),
                                                            n, _stream(stream)), "ffhip_h264_qpel_batch_dev")
 
 
-def chroma_mc_batch(dst, src, stride, blocks, n, stream=None):
-    """blocks: uint8 [n, 16] FFHipChromaBlock records"""
+def chroma_mc_batch(dst, src, stride, blocks, n, stream=None, pic=None):
+    """blocks: uint8 [n, 20] FFHipChromaBlock records; pic = (pic_w, pic_h) of the chroma plane: the _pic form (FFHIP_MC_EMU)"""
+    if pic is not None:
+        return _lib.check(_lib.lib().ffhip_h264_chroma_mc_batch_dev_pic(dst.data_ptr(), src.data_ptr(), stride, pic[0], pic[1], blocks.data_ptr(),
+                                                                        n, _stream(stream)), "ffhip_h264_chroma_mc_batch_dev_pic")
     return _lib.check(_lib.lib().ffhip_h264_chroma_mc_batch_dev(dst.data_ptr(), src.data_ptr(), stride, blocks.data_ptr(), n,
                                                                 _stream(stream)), "ffhip_h264_chroma_mc_batch_dev")
 
@@ -102,6 +109,16 @@ def weight_batch(dst, src, stride, blocks, n, stream=None):
 
 
 MC_PUT, MC_TMP, MC_AVG = 0, 1, 2
+MC_EMU = 1   # FFHIP_MC_EMU: the record's footprint is read at clamped coordinates of the reference picture (include/ffhip.h)
+#: FFHipQpelBlock / FFHipChromaBlock / FFHipWeightBlock / FFHipH264Edge (include/ffhip.h)
+QPEL_DTYPE = np.dtype([("dst_offset", "<i4"), ("src_offset", "<i4"), ("mcxy", "u1"), ("size_idx", "u1"), ("avg", "u1"), ("flags", "u1"),
+                       ("src_x", "<i2"), ("src_y", "<i2")])
+CHROMA_DTYPE = np.dtype([("dst_offset", "<i4"), ("src_offset", "<i4"), ("w_idx", "u1"), ("h", "u1"), ("x", "u1"), ("y", "u1"), ("avg", "u1"),
+                         ("flags", "u1"), ("src_x", "<i2"), ("src_y", "<i2"), ("pad", "<i2")])
+WEIGHT_DTYPE = np.dtype([("dst_offset", "<i4"), ("src_offset", "<i4"), ("w_idx", "u1"), ("height", "u1"), ("log2_denom", "u1"), ("bi", "u1"),
+                         ("weightd", "<i2"), ("weights", "<i2"), ("offset", "<i2"), ("pad", "<i2")])
+EDGE_DTYPE = np.dtype([("offset", "<i4"), ("kind", "u1"), ("alpha", "u1"), ("beta", "u1"), ("pad", "u1"), ("tc0", "i1", (4,))])
+assert QPEL_DTYPE.itemsize == 16 and CHROMA_DTYPE.itemsize == 20 and WEIGHT_DTYPE.itemsize == 20 and EDGE_DTYPE.itemsize == 12
 
 
 class Picture:

@@ -524,19 +524,35 @@ typedef struct FFHipH264QpelContext {
 } FFHipH264QpelContext;
 int ff_h264qpel_init_hip(FFHipH264QpelContext *c, int bit_depth);
 
-/** One motion-compensated block of the batch face (what mc_dir_part() passes, h264_mb.c:206-250). */
+/** One motion-compensated block of the batch face (what mc_dir_part() passes, h264_mb.c:206-250).
+ *
+ *  Edge emulation (round 4).  The reference allocates no border around a picture: when the 6-tap footprint of a block leaves the
+ *  reference picture, mc_dir_part() copies it through h->vdsp.emulated_edge_mc() (libavcodec/videodsp_template.c:24-100: samples
+ *  outside the picture repeat the nearest one inside) and filters from that copy (h264_mb.c:229-247 luma, :297-317 chroma).  A record
+ *  says the same with FFHIP_MC_EMU in `flags`: src_offset then addresses sample (0, 0) of the reference PICTURE (pic->data[plane] -
+ *  ref base), (src_x, src_y) is the integer-sample position of the block's origin in that picture — any value, also far outside —
+ *  and the kernel reads footprint sample (x, y) at row clamp(y, 0, pic_h - 1), column clamp(x, 0, pic_w - 1): emulated_edge_mc's
+ *  result, sample for sample (its whole-block-outside cases included, :37-56), for the 21 x 21 window the decoder copies as for any
+ *  other.  pic_w / pic_h are those of the plane (luma: 16 * mb_width, 16 * mb_height; 4:2:0 chroma: half), handed to the *_pic
+ *  entry points (the picture object knows them).  A record without the flag is read unclamped, as before. */
+#define FFHIP_MC_EMU 1
 typedef struct FFHipQpelBlock {
     int32_t dst_offset;  /* into dst plane                                            */
-    int32_t src_offset;  /* into ref plane: integer-pel position of the block origin  */
+    int32_t src_offset;  /* into ref plane: integer-pel position of the block origin; FFHIP_MC_EMU: of the reference picture's (0, 0) */
     uint8_t mcxy;        /* luma_xy = (mx&3) + ((my&3)<<2)                            */
     uint8_t size_idx;    /* 0: 16x16, 1: 8x8, 2: 4x4                                   */
     uint8_t avg;         /* 0 put, 1 avg                                              */
-    uint8_t pad;
-} FFHipQpelBlock;
+    uint8_t flags;       /* FFHIP_MC_EMU                                              */
+    int16_t src_x, src_y;/* FFHIP_MC_EMU: block origin in the reference picture, integer samples (else unused, 0) */
+} FFHipQpelBlock;        /* sizeof == 16 */
 /** n blocks, one stride for src & dst (as qpel_mc_func); dst blocks must not overlap. src must be
- *  readable 2 px left/up and 3 px right/down of each block. */
+ *  readable 2 px left/up and 3 px right/down of each block (records flagged FFHIP_MC_EMU are not honoured here: use the _pic form). */
 int ffhip_h264_qpel_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride,
                               const FFHipQpelBlock *blocks, int n, void *stream);
+/** The same with the reference pictures' dimensions (samples of this plane): records flagged FFHIP_MC_EMU read their footprint
+ *  through clamped coordinates, and only samples inside a reference picture are ever touched for them. */
+int ffhip_h264_qpel_batch_dev_pic(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h,
+                                  const FFHipQpelBlock *blocks, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: h264chroma + explicit weighted prediction (the first "next" row) */
@@ -551,16 +567,22 @@ typedef struct FFHipH264ChromaContext {
 /** Fills entries 0..2 (entry 3, the 1-wide VP9 helper, is left untouched).  8-bit only. */
 int ff_h264chroma_init_hip(FFHipH264ChromaContext *c, int bit_depth);
 
-/** One chroma MC call of the batch face (what mc_dir_part() passes to chroma_op, h264_mb.c:270-300). */
+/** One chroma MC call of the batch face (what mc_dir_part() passes to chroma_op, h264_mb.c:270-300).  FFHIP_MC_EMU as for
+ *  FFHipQpelBlock: the (w + 1) x (h + 1) samples are read at clamped coordinates of the reference picture's chroma plane
+ *  (emulated_edge_mc(…, 9, 8 * chroma_idc + 1, mx >> 3, my >> ysh, pic_width >> 1, pic_height >> 1), h264_mb.c:297-317). */
 typedef struct FFHipChromaBlock {
     int32_t dst_offset, src_offset;
     uint8_t w_idx;       /* 0: 8 wide, 1: 4, 2: 2 */
     uint8_t h;           /* rows, <= 16            */
     uint8_t x, y;        /* eighth-pel fractions   */
-    uint8_t avg, pad[3];
-} FFHipChromaBlock;
+    uint8_t avg, flags;  /* flags: FFHIP_MC_EMU    */
+    int16_t src_x, src_y;/* FFHIP_MC_EMU: block origin in the reference picture's plane, integer samples */
+    int16_t pad;
+} FFHipChromaBlock;      /* sizeof == 20 */
 int ffhip_h264_chroma_mc_batch_dev(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n,
                                    void *stream);
+int ffhip_h264_chroma_mc_batch_dev_pic(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h,
+                                       const FFHipChromaBlock *blocks, int n, void *stream);
 
 /** h264_weight_func / h264_biweight_func (libavcodec/h264dsp.h:31-37) and the two tables of H264DSPContext
  *  (:44-45): index 0 = 16 wide, 1 = 8, 2 = 4, 3 = 2 (libavcodec/h264dsp.c:100-107). */
@@ -590,6 +612,11 @@ int ffhip_h264_chroma_mc_batch_dev_hbd(int bit_depth, uint8_t *dst, const uint8_
                                        void *stream);
 int ffhip_h264_weight_batch_dev_hbd(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipWeightBlock *blocks, int n,
                                     void *stream);
+/** ... and their FFHIP_MC_EMU forms: pic_w / pic_h in samples of the plane. */
+int ffhip_h264_qpel_batch_dev_hbd_pic(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h,
+                                      const FFHipQpelBlock *blocks, int n, void *stream);
+int ffhip_h264_chroma_mc_batch_dev_hbd_pic(int bit_depth, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int pic_w, int pic_h,
+                                           const FFHipChromaBlock *blocks, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: caller-side batching for the H.264 macroblock loop           */
@@ -625,6 +652,13 @@ int  ffhip_h264_picture_weight(FFHipH264Picture *p, int plane, const FFHipWeight
 /** idct_add / idct8_add / idct_dc_add / idct8_dc_add: the 16 / 64 coefficients are copied and the caller's block is consumed
  *  exactly as the dsp function does (zeroed; dc forms: block[0] = 0). */
 int  ffhip_h264_picture_idct_add(FFHipH264Picture *p, int plane, int kind, int32_t dst_offset, int16_t *block);
+/** The macroblock-level residual members of an INTER macroblock as hl_decode_mb() calls them (libavcodec/h264_mb.c:780-797,
+ *  h264_mb_template.c:254-257): which 0 = idct_add16, 1 = idct8_add4 (plane's dst_offset[0]), 3 = idct_add8 (4:2:0; dst_offset[0] Cb,
+ *  [1] Cr, `plane` ignored; block = sl->mb).  Expanded on the host into idct_add records the way the dsp functions dispatch
+ *  (h264idct_template.c:176-228: nnz == 1 with a DC -> the dc form, …); block_offset is h->block_offset (bytes), nnzc the pointer the
+ *  member is handed (sl->non_zero_count_cache); `block` is consumed as those functions consume it. */
+int  ffhip_h264_picture_idct_mb(FFHipH264Picture *p, int which, int plane, const int32_t dst_offset[2], const int *block_offset, int16_t *block,
+                                const uint8_t *nnzc);
 /** ff_h264_filter_mb(): the macroblock's edge records, 8 for luma ((dir * 4 + e)), 4 for a chroma plane ((dir * 2 + e)). */
 int  ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int mb_y, const FFHipH264Edge *edges);
 /**

@@ -1,0 +1,395 @@
+/*
+ * integration/avcodec_h264_picture_hip.c — libavcodec/hip/h264_picture.c of the FFmpeg-side patch: the H.264 macroblock loop
+ * recorded into a libffhip picture object.
+ *
+ * How.  hl_decode_mb() (libavcodec/h264_mb_template.c:41-270) and ff_h264_filter_mb() (libavcodec/h264_loopfilter.c:716) reach the
+ * pixels only through function pointers: h->h264qpel / h->h264chroma / h->h264dsp / h->vdsp.  The `hip` arch therefore does not
+ * restate hl_motion() / mc_part() / mc_dir_part() / filter_mb_dir(): it installs members that RECORD their operands, and the
+ * decoder's own code runs unchanged on top of them — which partition calls which table entry with which motion vector, reference,
+ * weight, bS, alpha, beta and tc0 is decided by the reference's code, not by a copy of it.  What a member gets:
+ *
+ *   qpel_mc_func(dst, src, stride)                   -> FFHipQpelBlock   (table index = size, mcXY)
+ *   h264_chroma_mc_func(dst, src, stride, h, x, y)   -> FFHipChromaBlock
+ *   weight / biweight(dst[, src], stride, h, ...)    -> FFHipWeightBlock
+ *   idct_add16 / idct8_add4 / idct_add8(dst, block_offset, block, stride, nnzc) -> ffhip_h264_picture_idct_mb()
+ *   vdsp.emulated_edge_mc(buf, src, ..., src_x, src_y, w, h)  -> remembered; the qpel / chroma call that then reads `buf`
+ *                                                       (sl->edge_emu_buffer) becomes a record flagged FFHIP_MC_EMU that carries
+ *                                                       the block's position in the reference picture: no border, no copy
+ *   h264_{v,h}_loop_filter_{luma,chroma}[_intra](pix, stride, alpha, beta[, tc0]) -> the macroblock's FFHipH264Edge records
+ *
+ * Addresses are never dereferenced here: the current picture and the references are hip frames, h->cur_pic.f->data[] and
+ * H264Ref.data[] hold DEVICE addresses, and a member turns them into offsets from the plane bases.  A prediction put into
+ * sl->bipred_scratchpad (mc_part_weighted(), h264_mb.c:407-419) is held back until the biweight call that follows names the block it
+ * belongs to: the picture object keeps a picture-sized scratch plane per plane and addresses it with the destination's offset.
+ *
+ * Intra macroblocks predict from reconstructed neighbours and cannot be a list of independent calls: they go to libffhip as ONE
+ * record each (ffhip_h264_picture_intra_mb(), the reconstruction wavefront), built from the H264SliceContext fields hl_decode_mb()
+ * would read.  4:2:0, frame macroblocks, CAVLC / CABAC alike (entropy decoding stays on the CPU and fills sl-> as ever).
+ */
+#include <string.h>
+
+#include "libavutil/attributes.h"
+#include "libavutil/common.h"
+#include "libavcodec/h264dec.h"
+#include "libavcodec/h264_ps.h"
+#include "libavcodec/mpegutils.h"
+
+#include "avcodec_h264_picture_hip.h"
+
+static _Thread_local FFHipH264Recorder *cur_rec;   /* function pointers carry no user data: the recorder of the running call */
+
+#define REC FFHipH264Recorder *r = cur_rec
+#define FAIL(e) do { if (r->error >= 0) r->error = (e); return; } while (0)
+
+/* which plane of the current picture / of the scratchpad an address lies in: 0..2, 16 + plane for the scratchpad, -1 neither */
+static int classify_dst(const FFHipH264Recorder *r, const uint8_t *p)
+{
+    for (int pl = 0; pl < 3; pl++)
+        if (p >= r->cur[pl] && p < r->cur[pl] + (size_t)r->rows[pl] * r->linesize[pl])
+            return pl;
+    if (p >= r->scratch && p < r->scratch + r->scratch_size) {
+        /* tmp_cb = scratch, tmp_cr = scratch + (8 << pixel_shift), tmp_y = scratch + 16 * mb_uvlinesize (h264_mb.c:388-390) */
+        const size_t o = (size_t)(p - r->scratch);
+        if (o >= (size_t)16 * r->linesize[1])
+            return 16;
+        return (o % (size_t)r->linesize[1]) >= ((size_t)8 << r->pixel_shift) ? 18 : 17;
+    }
+    return -1;
+}
+
+/* src of a qpel / chroma call -> (src_offset, flags, src_x, src_y) */
+static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int32_t *off, uint8_t *flags, int16_t *sx, int16_t *sy)
+{
+    if (r->emu.valid && src >= r->emu_buf && src < r->emu_buf + r->emu_size) {
+        /* the block sits at (col, row) of the window emulated_edge_mc() was asked to copy; the window's first sample is
+         * (emu.src_x, emu.src_y) of the reference picture, and emu.src the address that sample would have */
+        const size_t o = (size_t)(src - r->emu_buf);
+        const int row = (int)(o / (size_t)r->emu.linesize), col = (int)(o % (size_t)r->emu.linesize) >> r->pixel_shift;
+        const uint8_t *origin = r->emu.src - ((ptrdiff_t)r->emu.src_y * r->emu.linesize + ((ptrdiff_t)r->emu.src_x << r->pixel_shift));
+        *off   = (int32_t)(origin - r->ref_base[pl]);
+        *flags = FFHIP_MC_EMU;
+        *sx    = (int16_t)(r->emu.src_x + col);
+        *sy    = (int16_t)(r->emu.src_y + row);
+        return 0;
+    }
+    *off = (int32_t)(src - r->ref_base[pl]);
+    *flags = 0;
+    *sx = *sy = 0;
+    return 0;
+}
+
+static void rec_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_t *src, ptrdiff_t stride)
+{
+    REC;
+    FFHipQpelBlock q = { 0 };
+    int where = classify_dst(r, dst), pl = where & 15, rc;
+    if (where < 0 || pl != 0 || stride != r->linesize[0])
+        FAIL(FFHIP_EINVAL);   /* 4:4:4 (chroma through the luma tables) and field macroblocks (doubled stride) stay on the C path */
+    locate_src(r, 0, src, &q.src_offset, &q.flags, &q.src_x, &q.src_y);
+    q.mcxy = (uint8_t)mcxy;
+    q.size_idx = (uint8_t)size_idx;
+    if (where >= 16) {
+        if (r->npend >= 8)
+            FAIL(FFHIP_EINVAL);
+        r->pend[r->npend].plane = 0;
+        r->pend[r->npend].tmp = dst;
+        r->pend[r->npend].q = q;
+        r->npend++;
+        return;
+    }
+    q.dst_offset = (int32_t)(dst - r->cur[0]);
+    rc = ffhip_h264_picture_mc_luma(r->pic, avg ? FFHIP_H264_MC_AVG : FFHIP_H264_MC_PUT, &q);
+    if (rc < 0)
+        FAIL(rc);
+}
+
+static void rec_chroma(int avg, int w_idx, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int h, int x, int y)
+{
+    REC;
+    FFHipChromaBlock c = { 0 };
+    int where = classify_dst(r, dst), pl = where & 15, rc;
+    if (where < 0 || pl < 1 || stride != r->linesize[pl])
+        FAIL(FFHIP_EINVAL);
+    locate_src(r, pl, src, &c.src_offset, &c.flags, &c.src_x, &c.src_y);
+    c.w_idx = (uint8_t)w_idx;
+    c.h = (uint8_t)h;
+    c.x = (uint8_t)x;
+    c.y = (uint8_t)y;
+    if (where >= 16) {
+        if (r->npend >= 8)
+            FAIL(FFHIP_EINVAL);
+        r->pend[r->npend].plane = pl;
+        r->pend[r->npend].tmp = dst;
+        r->pend[r->npend].c = c;
+        r->npend++;
+        return;
+    }
+    c.dst_offset = (int32_t)(dst - r->cur[pl]);
+    rc = ffhip_h264_picture_mc_chroma(r->pic, pl, avg ? FFHIP_H264_MC_AVG : FFHIP_H264_MC_PUT, &c);
+    if (rc < 0)
+        FAIL(rc);
+}
+
+static void rec_weight(int w_idx, int bi, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, int height, int log2_denom, int weightd, int weights,
+                       int offset)
+{
+    REC;
+    FFHipWeightBlock w = { 0 };
+    int pl = classify_dst(r, dst), rc;
+    if (pl < 0 || pl > 2 || stride != r->linesize[pl])
+        FAIL(FFHIP_EINVAL);
+    w.dst_offset = w.src_offset = (int32_t)(dst - r->cur[pl]);
+    w.w_idx = (uint8_t)w_idx;
+    w.height = (uint8_t)height;
+    w.log2_denom = (uint8_t)log2_denom;
+    w.bi = (uint8_t)bi;
+    w.weightd = (int16_t)weightd;
+    w.weights = (int16_t)weights;
+    w.offset = (int16_t)offset;
+    if (bi) {
+        /* the predictions waiting in the scratchpad belong here: same row pitch, so an address difference is an offset difference */
+        int k = 0;
+        for (int i = 0; i < r->npend; i++) {
+            struct FFHipH264Pending *p = &r->pend[i];
+            if (p->plane != pl) {
+                r->pend[k++] = *p;
+                continue;
+            }
+            if (pl == 0) {
+                p->q.dst_offset = w.dst_offset + (int32_t)(p->tmp - src);
+                rc = ffhip_h264_picture_mc_luma(r->pic, FFHIP_H264_MC_TMP, &p->q);
+            } else {
+                p->c.dst_offset = w.dst_offset + (int32_t)(p->tmp - src);
+                rc = ffhip_h264_picture_mc_chroma(r->pic, pl, FFHIP_H264_MC_TMP, &p->c);
+            }
+            if (rc < 0)
+                FAIL(rc);
+        }
+        r->npend = k;
+    }
+    rc = ffhip_h264_picture_weight(r->pic, pl, &w);
+    if (rc < 0)
+        FAIL(rc);
+}
+
+/* ---- the table members ------------------------------------------------------------------------------------------------------- */
+#define QP1(op, avg, sz, si, mc) static void op##_qpel##sz##_mc##mc(uint8_t *d, const uint8_t *s, ptrdiff_t st) { rec_qpel(avg, si, mc, d, s, st); }
+#define QP16(op, avg, sz, si) QP1(op, avg, sz, si, 0) QP1(op, avg, sz, si, 1) QP1(op, avg, sz, si, 2) QP1(op, avg, sz, si, 3) \
+    QP1(op, avg, sz, si, 4) QP1(op, avg, sz, si, 5) QP1(op, avg, sz, si, 6) QP1(op, avg, sz, si, 7) QP1(op, avg, sz, si, 8) QP1(op, avg, sz, si, 9) \
+    QP1(op, avg, sz, si, 10) QP1(op, avg, sz, si, 11) QP1(op, avg, sz, si, 12) QP1(op, avg, sz, si, 13) QP1(op, avg, sz, si, 14) QP1(op, avg, sz, si, 15)
+QP16(put, 0, 16, 0) QP16(put, 0, 8, 1) QP16(put, 0, 4, 2) QP16(avg, 1, 16, 0) QP16(avg, 1, 8, 1) QP16(avg, 1, 4, 2)
+#define QT(op, sz) { op##_qpel##sz##_mc0, op##_qpel##sz##_mc1, op##_qpel##sz##_mc2, op##_qpel##sz##_mc3, op##_qpel##sz##_mc4, op##_qpel##sz##_mc5, \
+    op##_qpel##sz##_mc6, op##_qpel##sz##_mc7, op##_qpel##sz##_mc8, op##_qpel##sz##_mc9, op##_qpel##sz##_mc10, op##_qpel##sz##_mc11, \
+    op##_qpel##sz##_mc12, op##_qpel##sz##_mc13, op##_qpel##sz##_mc14, op##_qpel##sz##_mc15 }
+static const qpel_mc_func rec_put_qpel[3][16] = { QT(put, 16), QT(put, 8), QT(put, 4) };
+static const qpel_mc_func rec_avg_qpel[3][16] = { QT(avg, 16), QT(avg, 8), QT(avg, 4) };
+
+#define CH(op, avg, w, wi) static void op##_chroma##w(uint8_t *d, const uint8_t *s, ptrdiff_t st, int h, int x, int y) { rec_chroma(avg, wi, d, s, st, h, x, y); }
+CH(put, 0, 8, 0) CH(put, 0, 4, 1) CH(put, 0, 2, 2) CH(avg, 1, 8, 0) CH(avg, 1, 4, 1) CH(avg, 1, 2, 2)
+
+#define WT(w, wi) \
+    static void weight##w(uint8_t *b, ptrdiff_t st, int h, int ld, int wt, int of) { rec_weight(wi, 0, b, b, st, h, ld, wt, 0, of); } \
+    static void biweight##w(uint8_t *d, uint8_t *s, ptrdiff_t st, int h, int ld, int wd, int ws, int of) { rec_weight(wi, 1, d, s, st, h, ld, wd, ws, of); }
+WT(16, 0) WT(8, 1) WT(4, 2) WT(2, 3)
+
+/* idct_add16 / idct8_add4 / idct_add8: libffhip expands them (h264idct_template.c:168-228) and consumes sl->mb as they do */
+static void rec_idct_mb(int which, uint8_t *const dst[2], const int *block_offset, int16_t *block, ptrdiff_t stride, const uint8_t nnzc[15 * 8])
+{
+    REC;
+    int32_t off[2] = { 0, 0 };
+    int pl = classify_dst(r, dst[0]), rc;
+    if (pl < 0 || pl > 2 || stride != r->linesize[pl])
+        FAIL(FFHIP_EINVAL);
+    off[0] = (int32_t)(dst[0] - r->cur[pl]);
+    if (which == 3) {
+        if (pl != 1 || classify_dst(r, dst[1]) != 2)
+            FAIL(FFHIP_EINVAL);
+        off[1] = (int32_t)(dst[1] - r->cur[2]);
+    }
+    rc = ffhip_h264_picture_idct_mb(r->pic, which, pl, off, block_offset, block, nnzc);
+    if (rc < 0)
+        FAIL(rc);
+}
+static void rec_idct_add16(uint8_t *dst, const int *bo, int16_t *block, ptrdiff_t stride, const uint8_t nnzc[5 * 8])
+{
+    uint8_t *d[2] = { dst, NULL };
+    rec_idct_mb(0, d, bo, block, stride, nnzc);
+}
+static void rec_idct8_add4(uint8_t *dst, const int *bo, int16_t *block, ptrdiff_t stride, const uint8_t nnzc[5 * 8])
+{
+    uint8_t *d[2] = { dst, NULL };
+    rec_idct_mb(1, d, bo, block, stride, nnzc);
+}
+static void rec_idct_add8(uint8_t **dest, const int *bo, int16_t *block, ptrdiff_t stride, const uint8_t nnzc[15 * 8])
+{
+    rec_idct_mb(3, dest, bo, block, stride, nnzc);
+}
+
+static void rec_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize, ptrdiff_t src_linesize, int block_w, int block_h,
+                                 int src_x, int src_y, int w, int h)
+{
+    REC;
+    (void)block_w; (void)block_h; (void)w; (void)h; /* the window and the picture's size: the kernels clamp per sample instead */
+    if (buf != r->emu_buf || buf_linesize != src_linesize)
+        FAIL(FFHIP_EINVAL);
+    r->emu.src = src;
+    r->emu.linesize = src_linesize;
+    r->emu.src_x = src_x;
+    r->emu.src_y = src_y;
+    r->emu.valid = 1;
+}
+static void rec_prefetch(const uint8_t *buf, ptrdiff_t stride, int h) { (void)buf; (void)stride; (void)h; }
+
+/* ---- ff_h264_filter_mb(): the loop-filter members collect the macroblock's edges ------------------------------------------------ */
+static _Thread_local struct {
+    FFHipH264Edge e[3][8];
+    int any[3], mb_x, mb_y;
+} cur_edges;
+
+static void rec_edge(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0)
+{
+    REC;
+    const int chroma = (kind & 2) != 0, dir = !(kind & 1); /* FFHIP_H264_LF_V_* filter across a horizontal edge: dir 1 */
+    int pl = classify_dst(r, pix), x, y, e;
+    ptrdiff_t o;
+    FFHipH264Edge *E;
+    if (pl < 0 || pl > 2 || (pl != 0) != chroma || stride != r->linesize[pl])
+        FAIL(FFHIP_EINVAL);
+    o = pix - r->cur[pl];
+    y = (int)(o / stride);
+    x = (int)(o % stride) >> r->pixel_shift;
+    if (!chroma) {
+        if ((x >> 4) != cur_edges.mb_x || (y >> 4) != cur_edges.mb_y)
+            FAIL(FFHIP_EINVAL);
+        e = dir ? (y & 15) >> 2 : (x & 15) >> 2;
+    } else {
+        if ((x >> 3) != cur_edges.mb_x || (y >> 3) != cur_edges.mb_y)
+            FAIL(FFHIP_EINVAL);
+        e = dir ? (y & 7) >> 2 : (x & 7) >> 2;
+    }
+    E = &cur_edges.e[pl][dir * (chroma ? 2 : 4) + e];
+    E->offset = (int32_t)o;
+    E->kind = (uint8_t)kind;
+    E->alpha = (uint8_t)alpha;
+    E->beta = (uint8_t)beta;
+    if (tc0)
+        memcpy(E->tc0, tc0, 4);
+    cur_edges.any[pl] = 1;
+}
+#define LF(name, kind) static void rec_##name(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0) { rec_edge(kind, pix, stride, alpha, beta, tc0); }
+#define LFI(name, kind) static void rec_##name(uint8_t *pix, ptrdiff_t stride, int alpha, int beta) { rec_edge(kind, pix, stride, alpha, beta, NULL); }
+LF(v_loop_filter_luma, FFHIP_H264_LF_V_LUMA) LF(h_loop_filter_luma, FFHIP_H264_LF_H_LUMA)
+LF(v_loop_filter_chroma, FFHIP_H264_LF_V_CHROMA) LF(h_loop_filter_chroma, FFHIP_H264_LF_H_CHROMA)
+LFI(v_loop_filter_luma_intra, FFHIP_H264_LF_V_LUMA_INTRA) LFI(h_loop_filter_luma_intra, FFHIP_H264_LF_H_LUMA_INTRA)
+LFI(v_loop_filter_chroma_intra, FFHIP_H264_LF_V_CHROMA_INTRA) LFI(h_loop_filter_chroma_intra, FFHIP_H264_LF_H_CHROMA_INTRA)
+
+av_cold void ff_h264_hip_recorder_install(H264Context *h)
+{
+    for (int s = 0; s < 3; s++)
+        for (int i = 0; i < 16; i++) {
+            h->h264qpel.put_h264_qpel_pixels_tab[s][i] = rec_put_qpel[s][i];
+            h->h264qpel.avg_h264_qpel_pixels_tab[s][i] = rec_avg_qpel[s][i];
+        }
+    h->h264chroma.put_h264_chroma_pixels_tab[0] = put_chroma8;
+    h->h264chroma.put_h264_chroma_pixels_tab[1] = put_chroma4;
+    h->h264chroma.put_h264_chroma_pixels_tab[2] = put_chroma2;
+    h->h264chroma.avg_h264_chroma_pixels_tab[0] = avg_chroma8;
+    h->h264chroma.avg_h264_chroma_pixels_tab[1] = avg_chroma4;
+    h->h264chroma.avg_h264_chroma_pixels_tab[2] = avg_chroma2;
+    h->h264dsp.weight_pixels_tab[0] = weight16;     h->h264dsp.biweight_pixels_tab[0] = biweight16;
+    h->h264dsp.weight_pixels_tab[1] = weight8;      h->h264dsp.biweight_pixels_tab[1] = biweight8;
+    h->h264dsp.weight_pixels_tab[2] = weight4;      h->h264dsp.biweight_pixels_tab[2] = biweight4;
+    h->h264dsp.weight_pixels_tab[3] = weight2;      h->h264dsp.biweight_pixels_tab[3] = biweight2;
+    h->h264dsp.idct_add16  = rec_idct_add16;
+    h->h264dsp.idct8_add4  = rec_idct8_add4;
+    h->h264dsp.idct_add8   = rec_idct_add8;
+    h->h264dsp.v_loop_filter_luma         = rec_v_loop_filter_luma;
+    h->h264dsp.h_loop_filter_luma         = rec_h_loop_filter_luma;
+    h->h264dsp.v_loop_filter_luma_intra   = rec_v_loop_filter_luma_intra;
+    h->h264dsp.h_loop_filter_luma_intra   = rec_h_loop_filter_luma_intra;
+    h->h264dsp.v_loop_filter_chroma       = rec_v_loop_filter_chroma;
+    h->h264dsp.h_loop_filter_chroma       = rec_h_loop_filter_chroma;
+    h->h264dsp.v_loop_filter_chroma_intra = rec_v_loop_filter_chroma_intra;
+    h->h264dsp.h_loop_filter_chroma_intra = rec_h_loop_filter_chroma_intra;
+    h->vdsp.emulated_edge_mc = rec_emulated_edge_mc;
+    h->vdsp.prefetch = rec_prefetch;
+}
+
+void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, const H264Context *h, const H264SliceContext *sl,
+                                const uint8_t *const ref_base[3])
+{
+    memset(r, 0, sizeof(*r));
+    r->pic = pic;
+    r->pixel_shift = h->pixel_shift;
+    for (int pl = 0; pl < 3; pl++) {
+        r->cur[pl] = h->cur_pic.f->data[pl];
+        r->ref_base[pl] = ref_base[pl];
+        r->linesize[pl] = pl ? sl->uvlinesize : sl->linesize;
+        r->rows[pl] = h->mb_height * (pl ? 8 : 16);
+    }
+    r->scratch = sl->bipred_scratchpad;
+    r->scratch_size = (size_t)16 * sl->uvlinesize + (size_t)16 * sl->linesize; /* tmp_y starts 16 chroma rows in and is 16 luma rows tall */
+    r->emu_buf = sl->edge_emu_buffer;
+    r->emu_size = (size_t)21 * sl->linesize + ((size_t)21 << h->pixel_shift);
+}
+
+int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceContext *sl)
+{
+    const int mb_type = h->cur_pic.mb_type[sl->mb_xy];
+    if (r->error < 0)
+        return r->error;
+    if (MB_FIELD(sl) || FRAME_MBAFF(h) || CHROMA444(h) || CHROMA422(h) || !h->ps.sps->chroma_format_idc ||
+        (sl->qscale == 0 && h->ps.sps->transform_bypass))
+        return r->error = FFHIP_ENOSYS;   /* such a picture stays on the C path as a whole */
+    if (IS_INTRA(mb_type)) {
+        FFHipH264IntraMB m = { 0 };
+        const int intra_qmul = 0;
+        m.mb_x = (int16_t)sl->mb_x;
+        m.mb_y = (int16_t)sl->mb_y;
+        m.type = IS_INTRA_PCM(mb_type) ? FFHIP_H264_INTRA_PCM : IS_INTRA16x16(mb_type) ? FFHIP_H264_INTRA_16x16
+               : IS_8x8DCT(mb_type) ? FFHIP_H264_INTRA_8x8 : FFHIP_H264_INTRA_4x4;
+        m.pred16 = (uint8_t)sl->intra16x16_pred_mode;
+        m.chroma_pred = (uint8_t)sl->chroma_pred_mode;
+        m.cbp = (uint8_t)(sl->cbp & 0x3f);
+        m.topleft_avail = (uint16_t)sl->topleft_samples_available;
+        m.topright_avail = (uint16_t)sl->topright_samples_available;
+        for (int i = 0; i < 16; i++)
+            m.pred4[i] = (uint8_t)sl->intra4x4_pred_mode_cache[scan8[i]];
+        /* luma_dc_dequant_idct's and chroma_dc_dequant_idct's qmul (h264_mb.c:707-711, h264_mb_template.c:246-253) */
+        m.qmul[0] = h->ps.pps->dequant4_coeff[intra_qmul][sl->qscale][0];
+        m.qmul[1] = h->ps.pps->dequant4_coeff[1][sl->chroma_qp[0]][0];
+        m.qmul[2] = h->ps.pps->dequant4_coeff[2][sl->chroma_qp[1]][0];
+        h->list_counts[sl->mb_xy] = sl->list_count;   /* hl_decode_mb()'s one side effect outside the pixels (h264_mb_template.c:61) */
+        r->error = FFMIN(0, ffhip_h264_picture_intra_mb(r->pic, &m, sl->non_zero_count_cache, sl->mb, sl->mb_luma_dc[0], sl->intra_pcm_ptr));
+        return r->error;
+    }
+    cur_rec = r;
+    r->emu.valid = 0;
+    r->npend = 0;
+    ff_h264_hl_decode_mb(h, sl);
+    cur_rec = NULL;
+    if (r->error >= 0 && r->npend)
+        r->error = FFHIP_EINVAL;   /* a prediction went to the scratchpad and no biweight claimed it */
+    return r->error;
+}
+
+int ff_h264_hip_filter_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceContext *sl, int mb_x, int mb_y)
+{
+    if (r->error < 0)
+        return r->error;
+    memset(&cur_edges, 0, sizeof(cur_edges));
+    cur_edges.mb_x = mb_x;
+    cur_edges.mb_y = mb_y;
+    cur_rec = r;
+    {
+        uint8_t *y  = (uint8_t *)r->cur[0] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[0]) * 16;
+        uint8_t *cb = (uint8_t *)r->cur[1] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[1]) * 8;
+        uint8_t *cr = (uint8_t *)r->cur[2] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[2]) * 8;
+        ff_h264_filter_mb(h, sl, mb_x, mb_y, y, cb, cr, (unsigned)r->linesize[0], (unsigned)r->linesize[1]);
+    }
+    cur_rec = NULL;
+    for (int pl = 0; pl < 3 && r->error >= 0; pl++)
+        if (cur_edges.any[pl])
+            r->error = FFMIN(0, ffhip_h264_picture_deblock_mb(r->pic, pl, mb_x, mb_y, cur_edges.e[pl]));
+    return r->error;
+}

@@ -1,0 +1,62 @@
+/*
+ * integration/avcodec_h264_picture_hip.h — libavcodec/hip/h264_picture.h of the FFmpeg-side patch: the macroblock loop of the H.264
+ * decoder recorded into a libffhip picture object (include/ffhip.h, FFHipH264Picture) instead of executed block by block.
+ */
+#ifndef FFHIP_INTEGRATION_H264_PICTURE_HIP_H
+#define FFHIP_INTEGRATION_H264_PICTURE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "libavcodec/h264dec.h"
+
+#include "ffhip.h"
+
+/* One recorder per slice thread (the decoder's H264SliceContext owns the buffers it watches). */
+typedef struct FFHipH264Recorder {
+    FFHipH264Picture *pic;
+    int pixel_shift;
+    int error;                      /* first libffhip error (< 0), sticky until begin() */
+    /* the picture being decoded: h->cur_pic.f->data[] as the DEVICE addresses of the hip frame, and the base every reference
+     * picture's data[] is counted from (the decoded-picture-buffer allocation: what ffhip_h264_picture_flush() gets as ref[]) */
+    const uint8_t *cur[3];
+    const uint8_t *ref_base[3];
+    ptrdiff_t linesize[3];
+    int rows[3];
+    const uint8_t *scratch;         /* sl->bipred_scratchpad and its size: never dereferenced, only recognised */
+    size_t scratch_size;
+    const uint8_t *emu_buf;         /* sl->edge_emu_buffer, likewise */
+    size_t emu_size;
+    /* the last h->vdsp.emulated_edge_mc() call: the next qpel / chroma call that reads sl->edge_emu_buffer stands for it */
+    struct {
+        const uint8_t *src;
+        ptrdiff_t linesize;
+        int src_x, src_y, valid;
+    } emu;
+    /* predictions put into sl->bipred_scratchpad wait here for the biweight call that names their destination */
+    struct FFHipH264Pending {
+        int plane;
+        const uint8_t *tmp;
+        FFHipQpelBlock q;
+        FFHipChromaBlock c;
+    } pend[8];
+    int npend;
+} FFHipH264Recorder;
+
+/* Replaces, in h, the dsp members hl_decode_mb() calls for inter macroblocks (h264qpel, h264chroma, weight / biweight, idct_add16 /
+ * idct8_add4 / idct_add8, vdsp.emulated_edge_mc, vdsp.prefetch) and the loop-filter members ff_h264_filter_mb() calls with recording
+ * ones; chroma_dc_dequant_idct and everything else stay what ff_h264dsp_init() left.  Call once after the decoder's own init. */
+void ff_h264_hip_recorder_install(H264Context *h);
+
+/* A new picture: `pic` was made for h->mb_width x h->mb_height at the stream's bit depth and has had begin() called. */
+void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, const H264Context *h, const H264SliceContext *sl,
+                                const uint8_t *const ref_base[3]);
+
+/* ff_h264_hl_decode_mb(h, sl) with the dsp calls recorded into r->pic (intra macroblocks: one FFHipH264IntraMB record).  Returns 0 or
+ * the first libffhip error. */
+int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceContext *sl);
+
+/* ff_h264_filter_mb(h, sl, mb_x, mb_y, …) with the loop-filter calls recorded as the macroblock's edge records. */
+int ff_h264_hip_filter_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceContext *sl, int mb_x, int mb_y);
+
+#endif

@@ -57,7 +57,9 @@ class OEdge(C.Structure):
 EDGE_DTYPE = np.dtype([("offset", "<i4"), ("kind", "u1"), ("alpha", "u1"), ("beta", "u1"), ("pad", "u1"),
                        ("tc0", "i1", (4,))])
 QPEL_DTYPE = np.dtype([("dst_offset", "<i4"), ("src_offset", "<i4"), ("mcxy", "u1"), ("size_idx", "u1"),
-                       ("avg", "u1"), ("pad", "u1")])
+                       ("avg", "u1"), ("flags", "u1"), ("src_x", "<i2"), ("src_y", "<i2")])     # FFHipQpelBlock, 16 bytes
+CHROMA_DTYPE = np.dtype([("dst_offset", "<i4"), ("src_offset", "<i4"), ("w_idx", "u1"), ("h", "u1"), ("x", "u1"), ("y", "u1"), ("avg", "u1"),
+                         ("flags", "u1"), ("src_x", "<i2"), ("src_y", "<i2"), ("pad", "<i2")])  # FFHipChromaBlock, 20 bytes
 
 _oracle = None
 _ref = None

@@ -82,11 +82,11 @@ def test_h264_golden_gpu():
     par = d["qpel_par"]
     dsts = torch.from_numpy(np.tile(d["qpel_dst"], (len(par), 1))).cuda()          # one 32-row copy per call
     blk = np.zeros(len(par), np.dtype([("d", np.int32), ("s", np.int32), ("mc", np.uint8), ("sz", np.uint8), ("avg", np.uint8),
-                                       ("pad", np.uint8)]))
+                                       ("flags", np.uint8), ("sx", np.int16), ("sy", np.int16)]))
     # src and dst live in different tensors: the batch face takes one stride and two bases
     for i, (avg, size_idx, mc) in enumerate(par):
-        blk[i] = (i * 32 * 64 + 6 * 64 + 8, 6 * 64 + 8, mc, size_idx, avg, 0)
-    h264.qpel_batch(dsts, src, 64, torch.from_numpy(blk.view(np.uint8).reshape(-1, 12)).cuda(), len(par))
+        blk[i] = (i * 32 * 64 + 6 * 64 + 8, 6 * 64 + 8, mc, size_idx, avg, 0, 0, 0)
+    h264.qpel_batch(dsts, src, 64, torch.from_numpy(blk.view(np.uint8).reshape(-1, 16)).cuda(), len(par))
     got = dsts.cpu().numpy().reshape(len(par), 32, 64)
     for i in range(len(par)):
         assert np.array_equal(got[i, 6:22, 8:24], d["qpel_out"][i]), tuple(par[i])

@@ -175,8 +175,8 @@ def test_deblock_frame(mb_w, mb_h, pad):
     assert np.array_equal(got, want), "%d mismatches" % (got != want).sum()
 
 
-QPEL_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy", np.uint8), ("size_idx", np.uint8),
-                    ("avg", np.uint8), ("pad", np.uint8)])
+QPEL_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy", np.uint8), ("size_idx", np.uint8), ("avg", np.uint8),
+                    ("flags", np.uint8), ("src_x", np.int16), ("src_y", np.int16)])
 
 
 @pytest.mark.parametrize("old", ["default", "0", "1", "w0"], ids=["product", "lds", "regs", "nowindow"])
@@ -208,7 +208,7 @@ def test_qpel_batch(w, h, pad, mvr, old, monkeypatch):
                     dy, dx = rng.integers(-mvr, mvr + 1, 2)
                     y, x = P + my * 16 + sy, P + mx * 16 + sx
                     blocks.append((y * stride + x, (y + dy) * stride + x + dx, rng.integers(0, 16), size_idx,
-                                   rng.integers(0, 2), 0))
+                                   rng.integers(0, 2), 0, 0, 0))
     bl = np.array(blocks, QPEL_DT)
     n = len(bl)
     want = dst.copy()
@@ -219,7 +219,7 @@ def test_qpel_batch(w, h, pad, mvr, old, monkeypatch):
         O.ffo_h264_qpel(int(b["avg"]), int(b["size_idx"]), int(b["mcxy"]), C.cast(want.ctypes.data + int(b["dst_offset"]), u8p),
                         C.cast(ref.ctypes.data + int(b["src_offset"]), u8p), stride)
     d_dst, d_ref = torch.from_numpy(dst).cuda(), torch.from_numpy(ref).cuda()
-    d_bl = torch.from_numpy(bl.view(np.uint8).reshape(n, 12)).cuda()
+    d_bl = torch.from_numpy(bl.view(np.uint8).reshape(n, 16)).cuda()
     h264.qpel_batch(d_dst, d_ref, stride, d_bl, n)
     torch.cuda.synchronize()
     got = d_dst.cpu().numpy()
@@ -396,7 +396,7 @@ def test_deblock_frame_chroma_rejects_unaligned():
 # chroma 1/8-pel MC and explicit weighted prediction
 # ---------------------------------------------------------------------------------------------
 CHROMA_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("h", np.uint8), ("x", np.uint8),
-                      ("y", np.uint8), ("avg", np.uint8), ("pad", np.uint8, 3)])
+                      ("y", np.uint8), ("avg", np.uint8), ("flags", np.uint8), ("src_x", np.int16), ("src_y", np.int16), ("pad", np.int16)])
 WEIGHT_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("height", np.uint8),
                       ("log2_denom", np.uint8), ("bi", np.uint8), ("weightd", np.int16), ("weights", np.int16),
                       ("offset", np.int16), ("pad", np.int16)])
@@ -407,7 +407,7 @@ def test_chroma_mc_batch(w, h, pad):
     """every 8x8 chroma block of a plane: mixed widths 8/4/2, heights, all (x,y) fractions, put/avg"""
     from ffmpeg_amd import h264
     torch = _torch()
-    assert CHROMA_DT.itemsize == 16
+    assert CHROMA_DT.itemsize == 20
     rng = np.random.default_rng(w + pad)
     P = 16
     stride = w + 2 * P + pad
@@ -427,7 +427,7 @@ def test_chroma_mc_batch(w, h, pad):
                                    rng.integers(0, 2), 0))
     bl = np.zeros(len(blocks), CHROMA_DT)
     for i, b in enumerate(blocks):
-        bl[i] = b[:7] + ([0, 0, 0],)
+        bl[i] = b[:7] + (0, 0, 0, 0)
     n = len(bl)
     chk = np.arange(n) if n <= 30000 else rng.choice(n, 30000, replace=False)
     want = dst.copy()
@@ -436,7 +436,7 @@ def test_chroma_mc_batch(w, h, pad):
         ffi.oracle().ffo_h264_chroma_mc(int(b["avg"]), 8 >> int(b["w_idx"]), C.cast(want.ctypes.data + int(b["dst_offset"]), u8p),
                                         C.cast(ref.ctypes.data + int(b["src_offset"]), u8p), stride, int(b["h"]), int(b["x"]), int(b["y"]))
     d_dst, d_ref = torch.from_numpy(dst).cuda(), torch.from_numpy(ref).cuda()
-    h264.chroma_mc_batch(d_dst, d_ref, stride, torch.from_numpy(bl.view(np.uint8).reshape(n, 16)).cuda(), n)
+    h264.chroma_mc_batch(d_dst, d_ref, stride, torch.from_numpy(bl.view(np.uint8).reshape(n, 20)).cuda(), n)
     torch.cuda.synchronize()
     got = d_dst.cpu().numpy()
     if n <= 30000:
@@ -475,5 +475,100 @@ def test_weight_batch():
                                          int(b["offset"]))
     d_dst, d_src = torch.from_numpy(dst).cuda(), torch.from_numpy(src).cuda()
     h264.weight_batch(d_dst, d_src, stride, torch.from_numpy(bl.view(np.uint8).reshape(-1, 20)).cuda(), bl.size)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_dst.cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# FFHIP_MC_EMU: blocks whose footprint leaves an UNPADDED reference picture (h264_mb.c:229-247, 297-317)
+# ---------------------------------------------------------------------------------------------
+def _emu(depth=8):
+    R = ffi.ref()
+    R.ffref_emulated_edge_mc.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t] + [C.c_int] * 6
+    R.ffref_emulated_edge_mc.restype = None
+    return lambda buf, src_addr, stride, bw, bh, x, y, w, h: R.ffref_emulated_edge_mc(depth, buf.ctypes.data, src_addr, stride, stride, bw, bh, x, y, w, h)
+
+
+@pytest.mark.parametrize("kern", ["default", "0", "1"], ids=["product", "lds", "regs"])
+@pytest.mark.parametrize("w,h,pad,n", [(64, 48, 0, 600), (64, 48, 5, 600), (208, 96, 0, 6000), (1920, 1088, 0, 40000)])
+def test_qpel_edge_emulation(w, h, pad, n, kern, monkeypatch):
+    """n blocks of every size / position / op at random places around and far outside a w x h reference picture that has NO border:
+    records flagged FFHIP_MC_EMU == the reference's emulated_edge_mc() (videodsp_template.c:24, compiled in place) into a 21 x 21
+    buffer, then the qpel function on that buffer — what mc_dir_part() does; unflagged interior blocks ride in the same batch"""
+    if not ffi.have_ref():
+        pytest.skip("oracle/_ref not built")
+    from ffmpeg_amd import h264
+    torch = _torch()
+    if kern != "default":
+        monkeypatch.setenv("FFHIP_QPEL_OLD", kern)
+    rng = np.random.default_rng(w + pad + n)
+    stride = max(w + 16, 1024) + pad                          # one stride for both operands; 64 destination blocks per row
+    two = 2                                                   # two reference pictures in the allocation, back to back: no border
+    ref = rng.integers(0, 256, (two * h, stride), dtype=np.uint8)
+    dst = rng.integers(0, 256, (16 * ((n + 63) // 64), stride), dtype=np.uint8)
+    emu = _emu()
+    bl = np.zeros(n, QPEL_DT)
+    want = dst.copy()
+    O = ffi.oracle()
+    buf = np.zeros((21, stride), np.uint8)
+    for i in range(n):
+        size_idx = int(rng.integers(0, 3))
+        far = rng.random() < .3
+        x = int(rng.integers(-4000, 4000)) if far else int(rng.integers(-40, w + 24))
+        y = int(rng.integers(-4000, 4000)) if far else int(rng.integers(-40, h + 24))
+        pic = int(rng.integers(0, two))
+        mc, avg = int(rng.integers(0, 16)), int(rng.integers(0, 2))
+        do = (i // 64) * 16 * stride + (i % 64) * 16
+        inside = x >= 2 and y >= 2 and x + 16 + 3 <= w and y + 16 + 3 <= h
+        org = pic * h * stride
+        if inside and rng.random() < .5:
+            bl[i] = (do, org + y * stride + x, mc, size_idx, avg, 0, 0, 0)
+            src_at = ref.ctypes.data + org + y * stride + x
+        else:
+            bl[i] = (do, org, mc, size_idx, avg, h264.MC_EMU, x, y)
+            emu(buf, ref.ctypes.data + org + (y - 2) * stride + (x - 2), stride, 21, 21, x - 2, y - 2, w, h)
+            src_at = buf.ctypes.data + 2 * stride + 2
+        O.ffo_h264_qpel(avg, size_idx, mc, C.cast(want.ctypes.data + do, u8p), C.cast(src_at, u8p), stride)
+    d_dst, d_ref = torch.from_numpy(dst).cuda(), torch.from_numpy(ref).cuda()
+    d_bl = torch.from_numpy(bl.view(np.uint8).reshape(n, 16)).cuda()
+    h264.qpel_batch(d_dst, d_ref, stride, d_bl, n, pic=(w, h))
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    bad = got != want
+    assert not bad.any(), "%d mismatches, first block %d" % (bad.sum(), (np.argwhere(bad)[0][0] // 16) * 64 + np.argwhere(bad)[0][1] // 16)
+
+
+@pytest.mark.parametrize("w,h,n", [(32, 24, 500), (104, 48, 4000), (960, 544, 20000)])
+def test_chroma_mc_edge_emulation(w, h, n):
+    """chroma blocks around and far outside an unpadded w x h chroma plane: FFHIP_MC_EMU == emulated_edge_mc(buf, src, …, 9, 9, x, y, w, h)
+    then the chroma function on the buffer (h264_mb.c:297-317)"""
+    if not ffi.have_ref():
+        pytest.skip("oracle/_ref not built")
+    from ffmpeg_amd import h264
+    torch = _torch()
+    rng = np.random.default_rng(w + n)
+    stride = max(w + 8, 64 * 8)
+    ref = rng.integers(0, 256, (2 * h, stride), dtype=np.uint8)
+    dst = rng.integers(0, 256, (16 * ((n + 63) // 64), stride), dtype=np.uint8)
+    emu = _emu()
+    bl = np.zeros(n, CHROMA_DT)
+    want = dst.copy()
+    O = ffi.oracle()
+    buf = np.zeros((17, stride), np.uint8)
+    for i in range(n):
+        w_idx = int(rng.integers(0, 3))
+        bh = int(rng.choice([2, 4, 8, 16] if w_idx == 0 else [2, 4, 8]))
+        far = rng.random() < .3
+        x = int(rng.integers(-3000, 3000)) if far else int(rng.integers(-20, w + 12))
+        y = int(rng.integers(-3000, 3000)) if far else int(rng.integers(-20, h + 12))
+        pic = int(rng.integers(0, 2))
+        fx, fy, avg = int(rng.integers(0, 8)), int(rng.integers(0, 8)), int(rng.integers(0, 2))
+        do = (i // 64) * 16 * stride + (i % 64) * 8
+        org = pic * h * stride
+        bl[i] = (do, org, w_idx, bh, fx, fy, avg, h264.MC_EMU, x, y, 0)
+        emu(buf, ref.ctypes.data + org + y * stride + x, stride, 9, 17, x, y, w, h)
+        O.ffo_h264_chroma_mc(avg, 8 >> w_idx, C.cast(want.ctypes.data + do, u8p), C.cast(buf.ctypes.data, u8p), stride, bh, fx, fy)
+    d_dst, d_ref = torch.from_numpy(dst).cuda(), torch.from_numpy(ref).cuda()
+    h264.chroma_mc_batch(d_dst, d_ref, stride, torch.from_numpy(bl.view(np.uint8).reshape(n, 20)).cuda(), n, pic=(w, h))
     torch.cuda.synchronize()
     assert np.array_equal(d_dst.cpu().numpy(), want)

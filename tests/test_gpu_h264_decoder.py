@@ -1,0 +1,120 @@
+"""The H.264 picture layer driven by the REFERENCE'S OWN macroblock loop (VERDICT r3 missing #1 / #2).
+
+One persistent reference decoder object per library (oracle/refbuild/ffref_shim_h264mb.c): the same decoder state — inter and intra
+macroblocks, motion vectors that point far outside the UNPADDED reference pictures, explicit / implicit weights, residuals — is
+handed to ff_h264_hl_decode_mb() (libavcodec/h264_mb.c:800) twice:
+
+  * libffref.so: the reference's C dsp functions on host planes, emulated_edge_mc() and all -> the expected picture;
+  * libffref_hip.so: the recording members of integration/avcodec_h264_picture_hip.c on device addresses -> an FFHipH264Picture,
+    flushed on the GPU.
+
+The test generator decides nothing about dsp calls: partition -> table entry, edge emulation, scratchpad use, weights, residual
+dispatch are the reference's code in both runs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ffi
+import h264_intra_gen as G
+import h264_inter_gen as I
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _libs():
+    if not ffi.have_ref() or not I.have_ref_hip():
+        pytest.skip("oracle/_ref not built")
+    from ffmpeg_amd import _lib
+    _lib.lib()                                   # libffhip.so first: libffref_hip.so binds to the instance the package uses
+    return ffi.ref(), C.CDLL(I.REF_HIP_SO)
+
+
+def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=1, bipred=True):
+    from ffmpeg_amd import h264
+    torch = _torch()
+    R, RH = _libs()
+    rng = np.random.default_rng(seed)
+    px = 2 if depth > 8 else 1
+    dt = np.uint16 if depth > 8 else np.uint8
+    top = 1 << depth
+    W, H = mb_w * 16, mb_h * 16
+    sy = W + int(rng.integers(0, 3)) * 16                   # row pitches in samples: the picture has NO border, only row padding
+    sc = W // 2 + 16
+    ls, uvls = sy * px, sc * px
+    strides = [ls, uvls, uvls]
+    # the decoded-picture buffer: nref reference pictures per plane in one allocation, exactly H (H / 2) rows each
+    refs = [rng.integers(0, top, (nref * H, sy), dtype=dt), rng.integers(0, top, (nref * H // 2, sc), dtype=dt),
+            rng.integers(0, top, (nref * H // 2, sc), dtype=dt)]
+    dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
+    d_refs = [dev(r) for r in refs]
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls, uvls, 0)
+    gpu = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, ls, uvls, 1)
+    rows = [H, H // 2, H // 2]
+    for lst in (0, 1):
+        for i in range(nref):
+            j = i if lst == 0 else nref - 1 - i           # the two lists order the same pictures differently
+            cpu.set_ref(lst, i, [refs[pl].ctypes.data + j * rows[pl] * strides[pl] for pl in range(3)])
+            gpu.set_ref(lst, i, [d_refs[pl].data_ptr() + j * rows[pl] * strides[pl] for pl in range(3)])
+    pic = h264.Picture(mb_w, mb_h, bit_depth=depth)
+    RH.ffrefhip_h264dec_record_begin.argtypes = [C.c_void_p] * 5
+    RH.ffrefhip_h264dec_record_begin.restype = None
+    n_emu = 0
+    for it in range(pictures):
+        pw = I.make_pwt(rng, weights, depth, nref)
+        cpu.set_pwt(pw)
+        gpu.set_pwt(pw)
+        dst0 = [rng.integers(0, top, (H, sy), dtype=dt), rng.integers(0, top, (H // 2, sc), dtype=dt), rng.integers(0, top, (H // 2, sc), dtype=dt)]
+        want = [a.copy() for a in dst0]
+        d_dst = [dev(a) for a in dst0]
+        cpu.set_cur([a.ctypes.data for a in want])
+        gpu.set_cur([t.data_ptr() for t in d_dst])
+        pic.begin()
+        RH.ffrefhip_h264dec_record_begin(gpu.d, pic._p, *[t.data_ptr() for t in d_refs])
+        for my in range(mb_h):
+            for mx in range(mb_w):
+                if rng.random() < p_intra:
+                    d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=depth)
+                    a, b = cpu.decode_intra(d), gpu.decode_intra(d)
+                    assert d["type"] == G.PCM or np.array_equal(a, b)        # sl->mb consumed alike
+                else:
+                    m = I.make_inter_mb(rng, cpu.bits, mx, my, nref, mvr, depth=depth, bipred=bipred)
+                    a, b = cpu.decode_inter(m), gpu.decode_inter(m)
+                    assert np.array_equal(a, b)
+        pic.flush(d_dst, strides, d_refs)
+        torch.cuda.synchronize()
+        for pl in range(3):
+            got = d_dst[pl].cpu().numpy().view(dt)
+            assert (want[pl] != dst0[pl]).sum() > 100 and want[pl].max() < top
+            bad = got != want[pl]
+            assert not bad.any(), "picture %d plane %d: %d mismatches, first at %s" % (it, pl, bad.sum(), np.argwhere(bad)[0])
+    pic.close()
+    cpu.close()
+    gpu.close()
+
+
+@pytest.mark.parametrize("mb_w,mb_h,nref,mvr,p_intra,weights", [
+    (6, 4, 2, 40, 0.0, 0),             # small motion: mostly inside, the rim emulated
+    (6, 4, 2, 600, 0.0, 0),            # vectors up to 150 samples: most blocks leave the 96 x 64 picture, many entirely
+    (11, 7, 3, 4000, 0.0, 1),          # +-1000 samples, explicit weights
+    (11, 7, 3, 300, 0.0, 2),           # implicit weights
+    (40, 22, 4, 200, 0.0, 0),          # enough blocks for the workgroup-window kernel
+    (40, 22, 2, 120, .15, 1),          # intra macroblocks predicting from inter neighbours
+    (9, 5, 1, 64, .3, 2),
+    (120, 68, 4, 256, .05, 1),         # a 1080p P/B picture
+])
+def test_decoder_driven_picture(mb_w, mb_h, nref, mvr, p_intra, weights):
+    _run_picture(8, mb_w, mb_h, nref, mvr, p_intra, weights, seed=mb_w * 131 + mb_h * 7 + mvr + weights)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,nref,mvr,p_intra,weights", [
+    (10, 6, 4, 2, 600, 0.0, 0), (10, 11, 7, 3, 4000, 0.0, 1), (10, 40, 22, 3, 200, .1, 2), (9, 7, 5, 2, 300, .2, 1), (12, 9, 5, 2, 500, 0.0, 2),
+    (14, 6, 5, 2, 400, .2, 1)])
+def test_decoder_driven_picture_hbd(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
+    _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed=depth * 1000 + mb_w * 31 + mvr)

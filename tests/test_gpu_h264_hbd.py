@@ -195,7 +195,7 @@ def test_mc_and_weight_batch_hbd(depth):
     torch.cuda.synchronize()
     assert np.array_equal(back(dd, dst0), want)
     # chroma MC
-    cdt = np.dtype([("dst_offset", "<i4"), ("src_offset", "<i4"), ("w_idx", "u1"), ("h", "u1"), ("x", "u1"), ("y", "u1"), ("avg", "u1"), ("pad", "u1", (3,))])
+    cdt = ffi.CHROMA_DTYPE
     cb = np.zeros(n, cdt)
     for i in range(n):
         o = ((P + (i // bx) * 16) * W + P + (i % bx) * 16) * px

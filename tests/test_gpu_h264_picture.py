@@ -13,9 +13,9 @@ from ffi import ptr, u8p
 pytestmark = pytest.mark.gpu
 
 QPEL_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy", np.uint8), ("size_idx", np.uint8), ("avg", np.uint8),
-                    ("pad", np.uint8)])
+                    ("flags", np.uint8), ("src_x", np.int16), ("src_y", np.int16)])
 CHROMA_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("h", np.uint8), ("x", np.uint8),
-                      ("y", np.uint8), ("avg", np.uint8), ("pad", np.uint8, 3)])
+                      ("y", np.uint8), ("avg", np.uint8), ("flags", np.uint8), ("src_x", np.int16), ("src_y", np.int16), ("pad", np.int16)])
 WEIGHT_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("height", np.uint8),
                       ("log2_denom", np.uint8), ("bi", np.uint8), ("weightd", np.int16), ("weights", np.int16), ("offset", np.int16),
                       ("pad", np.int16)])
@@ -64,13 +64,13 @@ def _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra=0.0, depth=8):
                 dy, dx = (int(v) for v in rng.integers(-20, 21, 2))
                 fx, fy = (int(v) for v in rng.integers(0, 4, 2))
                 q = np.zeros(1, QPEL_DT)
-                q[0] = (do, (refi * (H + 2 * P) + P + y + dy) * sy + P + x + dx, fx + 4 * fy, size_idx, 0, 0)
+                q[0] = (do, (refi * (H + 2 * P) + P + y + dy) * sy + P + x + dx, fx + 4 * fy, size_idx, 0, 0, 0, 0)
                 calls.append(("mc", 0, stage, q))
                 cw = size // 2
                 for pl in (1, 2):
                     c = np.zeros(1, CHROMA_DT)
                     c[0] = (cdo, (refi * (H // 2 + P) + P // 2 + y // 2 + dy // 2) * sc + P // 2 + x // 2 + dx // 2, 0 if cw == 8 else 1, cw,
-                            int(rng.integers(0, 8)), int(rng.integers(0, 8)), 0, (0, 0, 0))
+                            int(rng.integers(0, 8)), int(rng.integers(0, 8)), 0, 0, 0, 0, 0)
                     calls.append(("mc", pl, stage, c))
             if mode.endswith("_w"):
                 den, of = int(rng.integers(0, 8)), int(rng.integers(-20, 21))

@@ -59,11 +59,11 @@ def record():
         for mx in range(mb_w):
             x, y = mx * 16, my * 16
             dy, dx = (int(v) for v in rng.integers(-16, 17, 2))
-            q[0] = (PS * (y * sy + x), PS * ((P + y + dy) * sy + P + x + dx), int(rng.integers(0, 16)), 0, 0, 0)
+            q[0] = (PS * (y * sy + x), PS * ((P + y + dy) * sy + P + x + dx), int(rng.integers(0, 16)), 0, 0, 0, 0, 0)
             pic.mc_luma(h264.MC_PUT, q)
             for pl in (1, 2):
                 c[0] = (PS * ((y // 2) * sc + x // 2), PS * ((P // 2 + y // 2 + dy // 2) * sc + P // 2 + x // 2 + dx // 2), 0, 8, int(rng.integers(0, 8)),
-                        int(rng.integers(0, 8)), 0, (0, 0, 0))
+                        int(rng.integers(0, 8)), 0, 0, 0, 0, 0)
                 pic.mc_chroma(pl, h264.MC_PUT, c)
             n["mc"] += 3
             for by in (0, 8):

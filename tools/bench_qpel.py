@@ -15,7 +15,7 @@ from ffmpeg_amd import h264  # noqa: E402
 
 dev = torch.device("cuda", 0)
 DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy", np.uint8), ("size_idx", np.uint8), ("avg", np.uint8),
-               ("pad", np.uint8)])
+               ("flags", np.uint8), ("src_x", np.int16), ("src_y", np.int16)])
 W, H, P, planes = 3840, 2160, 32, int(os.environ.get("PLANES", "8"))
 stride = W + 2 * P
 rows = H + 2 * P
@@ -37,7 +37,7 @@ def blocks(mc):
         b["mcxy"] = rng.integers(0, 16, my.size) if mc < 0 else mc
         out.append(b)
     b = np.concatenate(out)
-    return torch.from_numpy(b.view(np.uint8).reshape(len(b), 12)).to(dev), len(b)
+    return torch.from_numpy(b.view(np.uint8).reshape(len(b), 16)).to(dev), len(b)
 
 
 QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"     # the default kernel, mixed positions and plain copies only (PMC runs)

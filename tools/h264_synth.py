@@ -4,9 +4,9 @@
 import numpy as np
 
 QPEL_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("mcxy", np.uint8), ("size_idx", np.uint8), ("avg", np.uint8),
-                    ("pad", np.uint8)])                                          # FFHipQpelBlock
+                    ("flags", np.uint8), ("src_x", np.int16), ("src_y", np.int16)])                                          # FFHipQpelBlock
 CHROMA_DT = np.dtype([("dst_offset", np.int32), ("src_offset", np.int32), ("w_idx", np.uint8), ("h", np.uint8), ("x", np.uint8),
-                      ("y", np.uint8), ("avg", np.uint8), ("pad", np.uint8, 3)])  # FFHipChromaBlock
+                      ("y", np.uint8), ("avg", np.uint8), ("flags", np.uint8), ("src_x", np.int16), ("src_y", np.int16), ("pad", np.int16)])  # FFHipChromaBlock
 EDGE_DT = np.dtype([("offset", np.int32), ("kind", np.uint8), ("alpha", np.uint8), ("beta", np.uint8), ("pad", np.uint8),
                     ("tc0", np.int8, 4)])                                         # FFHipH264Edge
 
@@ -25,11 +25,11 @@ def record_p_picture(pic, h264, mb_w, mb_h, sy, sc, P, rng):
         for mx in range(mb_w):
             x, y = mx * 16, my * 16
             dy, dx = (int(v) for v in rng.integers(-16, 17, 2))
-            q[0] = (y * sy + x, (P + y + dy) * sy + P + x + dx, int(rng.integers(0, 16)), 0, 0, 0)
+            q[0] = (y * sy + x, (P + y + dy) * sy + P + x + dx, int(rng.integers(0, 16)), 0, 0, 0, 0, 0)
             pic.mc_luma(h264.MC_PUT, q)
             for pl in (1, 2):
                 c[0] = ((y // 2) * sc + x // 2, (P // 2 + y // 2 + dy // 2) * sc + P // 2 + x // 2 + dx // 2, 0, 8, int(rng.integers(0, 8)),
-                        int(rng.integers(0, 8)), 0, (0, 0, 0))
+                        int(rng.integers(0, 8)), 0, 0, 0, 0, 0)
                 pic.mc_chroma(pl, h264.MC_PUT, c)
             for by in (0, 8):
                 for bx in (0, 8):
