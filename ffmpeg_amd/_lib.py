@@ -155,6 +155,11 @@ def lib():
         "ffhip_h264_deblock_frames_dev": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_deblock_frames_dev_hbd": (C.c_int, [C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_qpel_batch_dev": (C.c_int, [vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
+        "ffhip_h264_qpel_batch_dev_pic": (C.c_int, [vp, vp, C.c_ssize_t, C.c_int, C.c_int, vp, C.c_int, vp]),
+        "ffhip_h264_chroma_mc_batch_dev_pic": (C.c_int, [vp, vp, C.c_ssize_t, C.c_int, C.c_int, vp, C.c_int, vp]),
+        "ffhip_h264_qpel_batch_dev_hbd_pic": (C.c_int, [C.c_int, vp, vp, C.c_ssize_t, C.c_int, C.c_int, vp, C.c_int, vp]),
+        "ffhip_h264_chroma_mc_batch_dev_hbd_pic": (C.c_int, [C.c_int, vp, vp, C.c_ssize_t, C.c_int, C.c_int, vp, C.c_int, vp]),
+        "ffhip_h264_picture_idct_mb": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp]),
         "ffhip_me_cmp_batch_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_me_esa_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_size_t, C.c_int, C.c_int,
                                              C.c_int, C.c_int, vp, vp, vp]),

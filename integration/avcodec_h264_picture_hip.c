@@ -57,8 +57,12 @@ static int classify_dst(const FFHipH264Recorder *r, const uint8_t *p)
     return -1;
 }
 
-/* src of a qpel / chroma call -> (src_offset, flags, src_x, src_y) */
-static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int32_t *off, uint8_t *flags, int16_t *sx, int16_t *sy)
+/* src of a qpel / chroma call -> (src_offset, flags, src_x, src_y).  Luma (need > 0): the batch kernels fetch a block's whole
+ * (size + 5)^2 footprint whatever the quarter-sample position, while mc_dir_part() asks for emulation only where the position's own
+ * taps leave the picture (`if (mx & 7) extra_width -= 3`, h264_mb.c:229-236) — an integer-position block may sit flush against the
+ * picture's edge unemulated.  Such a block is recorded as FFHIP_MC_EMU as well: the clamped fetch returns the same samples inside
+ * the picture, and the ones outside carry no weight at that position. */
+static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int need, int32_t *off, uint8_t *flags, int16_t *sx, int16_t *sy)
 {
     if (r->emu.valid && src >= r->emu_buf && src < r->emu_buf + r->emu_size) {
         /* the block sits at (col, row) of the window emulated_edge_mc() was asked to copy; the window's first sample is
@@ -75,6 +79,33 @@ static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int32_t 
     *off = (int32_t)(src - r->ref_base[pl]);
     *flags = 0;
     *sx = *sy = 0;
+    if (need > 0) {
+        /* which reference picture is it?  the one looked at last, nearly always */
+        const ptrdiff_t ls = r->linesize[0], span = (ptrdiff_t)r->rows[0] * ls;
+        const uint8_t *origin = r->last_ref;
+        if (!origin || src < origin || src >= origin + span) {
+            origin = NULL;
+            for (int l = 0; l < (int)r->sl->list_count && !origin; l++)
+                for (int i = 0; i < (int)r->sl->ref_count[l] && !origin; i++) {
+                    const uint8_t *d = r->sl->ref_list[l][i].data[0];
+                    if (d && src >= d && src < d + span)
+                        origin = d;
+                }
+            if (!origin)
+                return FFHIP_EINVAL;
+            r->last_ref = origin;
+        }
+        {
+            const ptrdiff_t o = src - origin;
+            const int y = (int)(o / ls), x = (int)(o % ls) >> r->pixel_shift;
+            if (x < 2 || y < 2 || x + need + 3 > r->pic_w || y + need + 3 > r->rows[0]) {
+                *off   = (int32_t)(origin - r->ref_base[0]);
+                *flags = FFHIP_MC_EMU;
+                *sx    = (int16_t)x;
+                *sy    = (int16_t)y;
+            }
+        }
+    }
     return 0;
 }
 
@@ -85,7 +116,9 @@ static void rec_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_
     int where = classify_dst(r, dst), pl = where & 15, rc;
     if (where < 0 || pl != 0 || stride != r->linesize[0])
         FAIL(FFHIP_EINVAL);   /* 4:4:4 (chroma through the luma tables) and field macroblocks (doubled stride) stay on the C path */
-    locate_src(r, 0, src, &q.src_offset, &q.flags, &q.src_x, &q.src_y);
+    rc = locate_src(r, 0, src, 16 >> size_idx, &q.src_offset, &q.flags, &q.src_x, &q.src_y);
+    if (rc < 0)
+        FAIL(rc);
     q.mcxy = (uint8_t)mcxy;
     q.size_idx = (uint8_t)size_idx;
     if (where >= 16) {
@@ -110,7 +143,7 @@ static void rec_chroma(int avg, int w_idx, uint8_t *dst, const uint8_t *src, ptr
     int where = classify_dst(r, dst), pl = where & 15, rc;
     if (where < 0 || pl < 1 || stride != r->linesize[pl])
         FAIL(FFHIP_EINVAL);
-    locate_src(r, pl, src, &c.src_offset, &c.flags, &c.src_x, &c.src_y);
+    locate_src(r, pl, src, 0, &c.src_offset, &c.flags, &c.src_x, &c.src_y);
     c.w_idx = (uint8_t)w_idx;
     c.h = (uint8_t)h;
     c.x = (uint8_t)x;
@@ -321,6 +354,7 @@ void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, con
     memset(r, 0, sizeof(*r));
     r->pic = pic;
     r->pixel_shift = h->pixel_shift;
+    r->pic_w = 16 * h->mb_width;
     for (int pl = 0; pl < 3; pl++) {
         r->cur[pl] = h->cur_pic.f->data[pl];
         r->ref_base[pl] = ref_base[pl];
@@ -364,6 +398,7 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
         return r->error;
     }
     cur_rec = r;
+    r->sl = sl;
     r->emu.valid = 0;
     r->npend = 0;
     ff_h264_hl_decode_mb(h, sl);

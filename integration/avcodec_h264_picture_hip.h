@@ -23,6 +23,9 @@ typedef struct FFHipH264Recorder {
     const uint8_t *ref_base[3];
     ptrdiff_t linesize[3];
     int rows[3];
+    int pic_w;                      /* luma samples per row */
+    const H264SliceContext *sl;     /* the slice context of the running hl_decode_mb() call (its reference lists) */
+    const uint8_t *last_ref;        /* data[0] of the reference picture the last luma block read */
     const uint8_t *scratch;         /* sl->bipred_scratchpad and its size: never dereferenced, only recognised */
     size_t scratch_size;
     const uint8_t *emu_buf;         /* sl->edge_emu_buffer, likewise */

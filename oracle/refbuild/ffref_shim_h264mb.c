@@ -310,6 +310,8 @@ void FN(h264dec_set_ref)(FFRefH264Dec *d, int list, int idx, uint8_t *y, uint8_t
     r->linesize[0] = d->sl->linesize;
     r->linesize[1] = r->linesize[2] = d->sl->uvlinesize;
     r->reference = PICT_FRAME;
+    if (d->sl->ref_count[list] < (unsigned)idx + 1)
+        d->sl->ref_count[list] = idx + 1;
 }
 
 /* sl->pwt as pred_weight_table() / implicit_weight_table() leave it (h264_parse.c:30-118, h264_slice.c:700-760): use_weight 0 none,
