@@ -495,6 +495,309 @@ __global__ __launch_bounds__(256) void k_h264_qpel_t(uint8_t *dst, const uint8_t
     }
 }
 
+/* ================================================================================================== */
+/*
+ * k_h264_qpel_m — the 6-tap filters on the MATRIX CORES (round 4; north_star: "MFMA only if the … product genuinely becomes a dense
+ * contraction").  Round 3's PMC on k_h264_qpel_t: 315 VALU + 517 SALU wave-instructions per 16x16 block, issue-bound (VALU 53 % busy,
+ * issue stalls 44 %) — the arithmetic, not the memory, caps block MC at 0.21 of HBM.  A 6-tap pass over a block IS a small dense
+ * product: 21 footprint bytes against a banded 21 x 16 coefficient matrix whose entries (1, -5, 20) fit int8 unsplit.
+ *
+ *   stage 1  C1[row][col] = sum_k raw'[row][k] * Th[k][col]      v_mfma_i32_16x16x32_i8, A = 8 footprint bytes per lane straight from
+ *            an unaligned global_load_dwordx2 (lane = row m, byte group g: bytes 8g .. 8g+7 of footprint row m), B = Th, a per-lane
+ *            constant.  raw' = raw ^ 0x80 (signed), the missing 128 * sum(coefficients) rides in as the accumulator's initial value,
+ *            so C1 is the exact unclipped horizontal sum.  B = a shifted identity instead gives the raw samples in the same layout.
+ *            The 21 footprint rows are two row blocks (0..15, 16..20).
+ *   stage 2  C2[y][col] = sum_r Tv[y][r] * X[r][col]             the same instruction with A = Tv (constant) and B = X, the bytes of
+ *            what stage 1 left: a lane's eight C1 values ARE eight consecutive K entries of its column once K is numbered to match
+ *            (k' = 8g + r <-> row 4g + r of block A, 8g + 4 + r <-> row 16 + 4g + r), so no lane exchanges anything.  X = raw
+ *            samples -> V; X = the sums' low and high bytes (two products, (hi << 8) + lo) -> the centre position J; X = the clipped
+ *            horizontal samples against a row-selection matrix -> H on the output rows.
+ *   then     clip and pack with v_cvt_pk_i16_i32 / v_pk_ashrrev_i16 / v_sat_pk_u8_i16, average planes with the packed rnd_avg32
+ *            identity, turn the lane's 4-row column strip into a 4-sample row with two quad-DPP + v_perm steps, average with the
+ *            full-sample plane (an unaligned dword load in that layout) and store through the four-block LDS tile as before.
+ *
+ * ~60 VALU + 3..7 MFMA (a pipe of their own) per block instead of 315 VALU; no workgroup barrier.
+ * Bit-exact: every product and sum is an exact int32.  Workgroups are numbered so that each XCD gets one contiguous eighth of the
+ * batch (neighbouring blocks share most of their footprints: one L2 instead of eight).
+ */
+typedef int qm_i4 __attribute__((ext_vector_type(4)));
+typedef long qm_l1 __attribute__((aligned(1)));
+typedef uint32_t qm_u1 __attribute__((aligned(1)));
+
+struct QmTab { unsigned long long th[64], id2[64], id3[64], tv[64], sel2[64], sel3[64]; };
+constexpr int qm_c6(int t) { return (t == 0 || t == 5) ? 1 : (t == 1 || t == 4) ? -5 : (t == 2 || t == 3) ? 20 : 0; }
+constexpr QmTab qm_make()
+{
+    QmTab t{};
+    for (int l = 0; l < 64; l++) {
+        const int g = l >> 4, n = l & 15;
+        unsigned long long th = 0, id2 = 0, id3 = 0, tv = 0, s2 = 0, s3 = 0;
+        for (int j = 0; j < 8; j++) {
+            const int k = 8 * g + j;                                    /* stage 1: footprint byte k, output column n */
+            const int rho = j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4);   /* stage 2: K slot 8g + j holds footprint row rho; output row n */
+            th  |= (unsigned long long)(unsigned char)(signed char)qm_c6(k - n) << (8 * j);
+            id2 |= (unsigned long long)(k == n + 2) << (8 * j);
+            id3 |= (unsigned long long)(k == n + 3) << (8 * j);
+            tv  |= (unsigned long long)(unsigned char)(signed char)qm_c6(rho - n) << (8 * j);
+            s2  |= (unsigned long long)(rho == n + 2) << (8 * j);
+            s3  |= (unsigned long long)(rho == n + 3) << (8 * j);
+        }
+        t.th[l] = th; t.id2[l] = id2; t.id3[l] = id3; t.tv[l] = tv; t.sel2[l] = s2; t.sel3[l] = s3;
+    }
+    return t;
+}
+__device__ const QmTab qm_tab = qm_make();
+
+__device__ __forceinline__ uint32_t qm_sat_pk_u8(uint32_t pk) /* two int16 -> two uint8, saturating, in the low half */
+{
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(pk));
+    return r;
+}
+/* four int32 (each within int16 after the shift) -> clip_u8(v >> SH) x 4, byte r = value r */
+template <int SH>
+__device__ __forceinline__ uint32_t qm_pack4(int a, int b, int c, int d, int bias)
+{
+    qp_s2 lo = __builtin_amdgcn_cvt_pk_i16(a, b), hi = __builtin_amdgcn_cvt_pk_i16(c, d);
+    if (bias) {
+        const qp_s2 kb = { (short)bias, (short)bias };
+        lo += kb;
+        hi += kb;
+    }
+    if (SH) {
+        lo = lo >> (short)SH;
+        hi = hi >> (short)SH;
+    }
+    return __builtin_amdgcn_perm(qm_sat_pk_u8(__builtin_bit_cast(uint32_t, hi)), qm_sat_pk_u8(__builtin_bit_cast(uint32_t, lo)), 0x05040100u);
+}
+__device__ __forceinline__ long qm_long(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
+__device__ __forceinline__ qm_i4 qm_splat(int v) { return (qm_i4){ v, v, v, v }; }
+
+struct QmBlk { int size, mc, soff, doff, sx, sy; bool avg, emu; };
+
+/* which planes a quarter-sample position combines, as bit masks over mcXY (libavcodec/h264qpel_template.c:313-459) */
+struct QmFlags { bool useJ, useV, useH, wantF, row3, col3; };
+__device__ __forceinline__ QmFlags qm_flags(int mc)
+{
+    /* bit mc of each constant; the table:   mc  0 1 2 3 | 4 5 6 7 | 8 9 10 11 | 12 13 14 15
+     *   J (centre)                               . . . . | . . J . | . J J  J  | .  .  J  .
+     *   V (vertical half)                        . . . . | V V . V | V V .  V  | V  V  .  V
+     *   H (horizontal half)                      . H H H | . H H H | . . .  .  | .  H  H  H
+     *   F (full sample)                          F F . F | F . . . | . . .  .  | F  .  .  .      */
+    QmFlags f;
+    f.useJ  = (0x4E40u >> mc) & 1;
+    f.useV  = (0xBBB0u >> mc) & 1;
+    f.useH  = (0xE0EEu >> mc) & 1;
+    f.wantF = (0x101Bu >> mc) & 1;
+    f.row3  = (mc >> 2) == 3;   /* H one row down / F one row down (mc 12) */
+    f.col3  = (mc & 3) == 3;    /* V one column right / F one column right (mc 3) */
+    return f;
+}
+
+/* One block.  TWO: 16 x 16 (two footprint row blocks).  fa / fb: this lane's 8 bytes of footprint rows m and 16 + m; ff: the
+ * full-sample dword of the lane's row-layout position.  Returns the lane's four output samples in the row layout. */
+template <bool TWO>
+__device__ __forceinline__ uint32_t qm_block(int mc, long fa, long fb, uint32_t ff, int lane, long cTh, long cTv, uint32_t selT1, uint32_t selT2)
+{
+    const QmFlags F = qm_flags(mc);
+    const long K80 = (long)0x8080808080808080ull;
+    const long a0 = fa ^ K80, a1 = fb ^ K80;
+    uint32_t pj = 0, ph = 0, pv = 0;
+    if (F.useJ || F.useH) {
+        /* exact horizontal sums of the footprint rows: sum(coefficients) = 32, so +128 * 32 undoes the ^0x80 */
+        const qm_i4 h0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a0, cTh, qm_splat(4096), 0, 0, 0);
+        qm_i4 h1 = qm_splat(0);
+        if (TWO)
+            h1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, cTh, qm_splat(4096), 0, 0, 0);
+        if (F.useJ) {
+            /* |sum| <= 10710: a low byte (made signed by ^0x80, +128 * 32 in the accumulator) and a signed high byte */
+            const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)h0.y, (uint32_t)h0.x, 0x05010400u), p1 = __builtin_amdgcn_perm((uint32_t)h0.w, (uint32_t)h0.z, 0x05010400u);
+            const uint32_t p2 = __builtin_amdgcn_perm((uint32_t)h1.y, (uint32_t)h1.x, 0x05010400u), p3 = __builtin_amdgcn_perm((uint32_t)h1.w, (uint32_t)h1.z, 0x05010400u);
+            const long blo = qm_long(__builtin_amdgcn_perm(p1, p0, 0x05040100u), __builtin_amdgcn_perm(p3, p2, 0x05040100u)) ^ K80;
+            const long bhi = qm_long(__builtin_amdgcn_perm(p1, p0, 0x07060302u), __builtin_amdgcn_perm(p3, p2, 0x07060302u));
+            const qm_i4 chi = __builtin_amdgcn_mfma_i32_16x16x32_i8(cTv, bhi, qm_splat(0), 0, 0, 0);
+            const qm_i4 clo = __builtin_amdgcn_mfma_i32_16x16x32_i8(cTv, blo, qm_splat(4096 + 512), 0, 0, 0);
+            pj = qm_pack4<0>(((chi.x << 8) + clo.x) >> 10, ((chi.y << 8) + clo.y) >> 10, ((chi.z << 8) + clo.z) >> 10, ((chi.w << 8) + clo.w) >> 10, 0);
+        }
+        if (F.useH) {
+            /* clip((sum + 16) >> 5) of every footprint row, then the rows y + 2 (y + 3 for the positions below) by a 0/1 matrix */
+            const long bh = qm_long(qm_pack4<5>(h0.x, h0.y, h0.z, h0.w, 16), qm_pack4<5>(h1.x, h1.y, h1.z, h1.w, 16)) ^ K80;
+            const qm_i4 hh = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(F.row3 ? qm_tab.sel3[lane] : qm_tab.sel2[lane]), bh, qm_splat(128), 0, 0, 0);
+            ph = (uint32_t)hh.x | (uint32_t)hh.y << 8 | (uint32_t)hh.z << 16 | (uint32_t)hh.w << 24;
+        }
+    }
+    if (F.useV) {
+        /* the raw samples of column x (x + 1 for the positions to the right) in the stage-2 layout, then the vertical 6 taps */
+        const long cId = (long)(F.col3 ? qm_tab.id3[lane] : qm_tab.id2[lane]);
+        const qm_i4 r0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a0, cId, qm_splat(128), 0, 0, 0);
+        qm_i4 r1 = qm_splat(0);
+        if (TWO)
+            r1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(a1, cId, qm_splat(128), 0, 0, 0);
+        const uint32_t x0 = __builtin_amdgcn_perm((uint32_t)r0.y, (uint32_t)r0.x, 0x0c0c0400u), x1 = __builtin_amdgcn_perm((uint32_t)r0.w, (uint32_t)r0.z, 0x0c0c0400u);
+        const uint32_t x2 = __builtin_amdgcn_perm((uint32_t)r1.y, (uint32_t)r1.x, 0x0c0c0400u), x3 = __builtin_amdgcn_perm((uint32_t)r1.w, (uint32_t)r1.z, 0x0c0c0400u);
+        const long bv = qm_long(__builtin_amdgcn_perm(x1, x0, 0x05040100u), __builtin_amdgcn_perm(x3, x2, 0x05040100u)) ^ K80;
+        const qm_i4 vv = __builtin_amdgcn_mfma_i32_16x16x32_i8(cTv, bv, qm_splat(4096 + 16), 0, 0, 0);
+        pv = qm_pack4<5>(vv.x, vv.y, vv.z, vv.w, 0);
+    }
+    /* a position averages the first and the last of the planes it has (one plane: with itself), still 4-row column strips */
+    uint32_t c = rnd_avg4(F.useH ? ph : F.useV ? pv : pj, F.useJ ? pj : F.useV ? pv : ph);
+    /* 4 x 4 byte transposition inside each lane quad: lane 4q + j gets row 4g + j, columns 4q .. 4q + 3 */
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)c, 0xB1, 0xf, 0xf, true);     /* quad_perm [1,0,3,2] */
+    const uint32_t c1 = __builtin_amdgcn_perm(t1, c, selT1);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)c1, 0x4E, 0xf, 0xf, true);    /* quad_perm [2,3,0,1] */
+    c = __builtin_amdgcn_perm(t2, c1, selT2);
+    return mc == 0 ? ff : F.wantF ? rnd_avg4(ff, c) : c;
+}
+
+/* The memory side is k_h264_qpel_t's, which tools/ubench/tilecopy found to be the cheapest way to move 16 x 16 tiles (the cost follows
+ * the number of row segments a wave requests): ONE aligned 16-byte load per lane brings a block's footprint (21 rows x 3 chunks), it
+ * rests in a wave-private LDS plane, and the four blocks of a wave leave as 64-byte rows.  (A first version fed the matrix cores
+ * straight from unaligned 8-byte global loads — no LDS at all — and was slower: three load instructions per block and byte-misaligned
+ * requests cost more in the texture addresser than the LDS round trip saves.)  The lanes then pick their MFMA operands out of LDS:
+ * lane (g, m) the 8 bytes 8g .. 8g + 7 of footprint rows m and 16 + m (three dwords and two funnel shifts each). */
+/* one group of four consecutive blocks of a wave: records and footprint chunks */
+/* (plain arrays of scalars: an array of record structs is not taken apart by the compiler and lands in scratch memory) */
+struct QmRec { int size[4], mc[4], doff[4]; bool avg[4]; };
+#define QM_GROUP(G) QmRec G##_q; qp_u4 G##_f[4]; uint32_t G##_sh16[4]; bool G##_tile = false; int G##_b0 = 0
+#define QM_ARGS(G) G##_q.size, G##_q.mc, G##_q.doff, G##_q.avg, G##_f, G##_sh16, G##_tile, G##_b0
+__device__ __forceinline__ void qm_load(int (&Gsize)[4], int (&Gmc)[4], int (&Gdoff)[4], bool (&Gavg)[4], qp_u4 (&Gf)[4], uint32_t (&Gsh16)[4], bool &Gtile,
+                                        int &Gb0, int b0, uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
+                                        int pic_w, int pic_h, int fr, int fc)
+{
+    Gb0 = b0;
+    Gtile = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const QpBlk q = qp_blk(blocks, min(b0 + k, n - 1), src, stride, pic_w);
+        Gsize[k] = q.size; Gmc[k] = q.mc; Gdoff[k] = q.doff; Gavg[k] = q.avg;
+        Gtile = Gtile && q.size == 16 && b0 + k < n && !((reinterpret_cast<uintptr_t>(dst) + (uintptr_t)(intptr_t)q.doff) & 3);
+        if (q.emu) { /* the rim of the picture: the chunk is assembled from clamped byte loads, first footprint byte at chunk 0 byte 0 */
+            Gsh16[k] = 0;
+            Gf[k] = (qp_u4){ 0, 0, 0, 0 };
+            if (fr < q.rows && fc < 2) {
+                const uint8_t *org = src + q.soff;
+                const int ex = q.sx - 2 + 16 * fc, ey = q.sy - 2 + fr;
+                Gf[k].x = qp_emu_dword(org, stride, ex, ey, pic_w, pic_h);
+                Gf[k].y = qp_emu_dword(org, stride, ex + 4, ey, pic_w, pic_h);
+                if (fc == 0) {
+                    Gf[k].z = qp_emu_dword(org, stride, ex + 8, ey, pic_w, pic_h);
+                    Gf[k].w = qp_emu_dword(org, stride, ex + 12, ey, pic_w, pic_h);
+                }
+            }
+            continue;
+        }
+        const uint8_t *s0 = src + q.soff - 2 - 2 * stride;
+        Gsh16[k] = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 15);
+        const int nch = (int)(Gsh16[k] + q.size + 5 + 15) >> 4;
+        Gf[k] = (fr < q.rows && fc < nch) ? *reinterpret_cast<const qp_u4 *>(s0 - Gsh16[k] + (ptrdiff_t)fr * stride + 16 * fc) : (qp_u4){ 0, 0, 0, 0 };
+    }
+}
+
+__device__ __forceinline__ void qm_compute(const int (&Gsize)[4], const int (&Gmc)[4], const int (&Gdoff)[4], const bool (&Gavg)[4], const qp_u4 (&Gf)[4],
+                                           const uint32_t (&Gsh16)[4], const bool &Gtile, const int &Gb0, uint8_t *dst, ptrdiff_t stride, int n, uint32_t *raw, uint32_t *ob, int lane, int fr, int fc,
+                                           long cTh, long cTv, uint32_t selT1, uint32_t selT2)
+{
+    const int g = lane >> 4, m = lane & 15;
+    const int ry = 4 * g + (lane & 3), rxg = (lane >> 2) & 3; /* the row and 4-sample group this lane owns after the transposition */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (Gb0 + k < n) {
+        if (lane < 63)
+            *reinterpret_cast<qp_u4 *>(raw + fr * 12 + 4 * fc) = Gf[k];
+        __builtin_amdgcn_wave_barrier();
+        const int size = Gsize[k], mc = Gmc[k], last = size + 4;
+        const QmFlags F = qm_flags(mc);
+        const uint32_t sh = Gsh16[k] & 3;
+        const uint32_t *r0p = raw + (Gsh16[k] >> 2);   /* the dword that holds footprint byte 0 of row 0 */
+        long fa = 0, fb = 0;
+        uint32_t ff = 0;
+        if (mc) {
+            const uint32_t *pa = r0p + min(m, last) * 12 + 2 * g;
+            const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2];
+            fa = qm_long(__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh));
+            if (size == 16) {
+                const uint32_t *pb = r0p + min(16 + m, 20) * 12 + 2 * g;
+                const uint32_t b0_ = pb[0], b1_ = pb[1], b2_ = pb[2];
+                fb = qm_long(__builtin_amdgcn_alignbyte(b1_, b0_, sh), __builtin_amdgcn_alignbyte(b2_, b1_, sh));
+            }
+        }
+        if (F.wantF) {
+            const uint32_t o = sh + 2 + (mc == 3);
+            const uint32_t *pf = r0p + (min(ry, size - 1) + 2 + (mc == 12)) * 12 + rxg + (o >> 2);
+            ff = __builtin_amdgcn_alignbyte(pf[1], pf[0], o & 3);
+        }
+        uint32_t out = size == 16 ? qm_block<true>(mc, fa, fb, ff, lane, cTh, cTv, selT1, selT2) : qm_block<false>(mc, fa, fb, ff, lane, cTh, cTv, selT1, selT2);
+        if (Gtile) {
+            ob[64 * k + 4 * ry + rxg] = out;
+        } else if (ry < size && 4 * rxg < size) {
+            uint8_t *d = dst + Gdoff[k] + (ptrdiff_t)ry * stride + 4 * rxg;
+            if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
+                uint32_t *dw = reinterpret_cast<uint32_t *>(d);
+                if (Gavg[k])
+                    out = rnd_avg4(*dw, out);
+                *dw = out;
+            } else {
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t v = (out >> (8 * i)) & 0xFF;
+                    d[i] = (uint8_t)(Gavg[k] ? (d[i] + v + 1) >> 1 : v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier(); /* the next block overwrites the plane */
+        }
+    }
+    if (Gtile) {
+        const int y = lane >> 2, c = lane & 3;
+        qp_u4 o = *reinterpret_cast<const qp_u4 *>(ob + 64 * c + 4 * y);
+        const int doff = c == 0 ? Gdoff[0] : c == 1 ? Gdoff[1] : c == 2 ? Gdoff[2] : Gdoff[3];
+        const bool avg = c == 0 ? Gavg[0] : c == 1 ? Gavg[1] : c == 2 ? Gavg[2] : Gavg[3];
+        qp_u4 *dp = reinterpret_cast<qp_u4 *>(dst + doff + (ptrdiff_t)y * stride);
+        if (avg) {
+            const qp_u4 old = *dp;
+            o.x = rnd_avg4(old.x, o.x); o.y = rnd_avg4(old.y, o.y); o.z = rnd_avg4(old.z, o.z); o.w = rnd_avg4(old.w, o.w);
+        }
+        *dp = o;
+        __builtin_amdgcn_wave_barrier(); /* the next group refills the tile */
+    }
+}
+
+/* NG groups of four blocks per wave, the next group's records and footprints in flight while this one is computed */
+template <int NG>
+__global__ __launch_bounds__(256) void k_h264_qpel_m(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
+                                                     int pic_w, int pic_h, int per_xcd)
+{
+    __shared__ __align__(16) uint32_t rawp[4][22 * 12];
+    __shared__ __align__(16) uint32_t obp[4][4 * 64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    /* workgroup L runs on XCD L % 8 (observed, not promised: speed only): XCD x takes the workgroups x * per_xcd .. of the batch, so
+     * that the blocks whose footprints overlap meet in one L2 (PMC: 12 x fewer bytes fetched past the L2s) */
+    const int wg = per_xcd ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int b0 = (wg * 4 + wave) * 4 * NG;
+    if (b0 >= n)
+        return;
+    uint32_t *raw = rawp[wave], *ob = obp[wave];
+    const long cTh = (long)qm_tab.th[lane], cTv = (long)qm_tab.tv[lane];
+    const uint32_t selT1 = (lane & 1) ? 0x03070105u : 0x06020400u, selT2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+    const int fr = (lane * 171) >> 9, fc = lane - 3 * fr; /* footprint row and 16-byte chunk of this lane: lane / 3, lane % 3 */
+    QM_GROUP(A);
+    QM_GROUP(B);
+    qm_load(QM_ARGS(A), b0, dst, src, stride, blocks, n, pic_w, pic_h, fr, fc);
+#pragma unroll
+    for (int gi = 0; gi < NG; gi += 2) {
+        if (gi + 1 < NG && b0 + 4 * (gi + 1) < n)
+            qm_load(QM_ARGS(B), b0 + 4 * (gi + 1), dst, src, stride, blocks, n, pic_w, pic_h, fr, fc);
+        qm_compute(QM_ARGS(A), dst, stride, n, raw, ob, lane, fr, fc, cTh, cTv, selT1, selT2);
+        if (gi + 1 >= NG || b0 + 4 * (gi + 1) >= n)
+            break;
+        if (gi + 2 < NG && b0 + 4 * (gi + 2) < n)
+            qm_load(QM_ARGS(A), b0 + 4 * (gi + 2), dst, src, stride, blocks, n, pic_w, pic_h, fr, fc);
+        qm_compute(QM_ARGS(B), dst, stride, n, raw, ob, lane, fr, fc, cTh, cTv, selT1, selT2);
+        if (gi + 2 >= NG || b0 + 4 * (gi + 2) >= n)
+            break;
+    }
+}
+
 int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
                            hipStream_t stream, int pic_w, int pic_h)
 {
@@ -504,7 +807,20 @@ int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, c
     const char *en = FFHIP_KNOB("FFHIP_QPEL_NB");  /* measured variant: blocks per wave */
     const int nb = en ? atoi(en) : 4;
     const char *ew = FFHIP_KNOB("FFHIP_QPEL_W");   /* measured variant: 0 = k_h264_qpel_l (dword footprint loads, a store per block row) */
-    if (!(stride & 15) && n >= 1024 && !(eo && eo[0] == '1') && !(ew && ew[0] == '0')) {
+    const char *em = FFHIP_KNOB("FFHIP_QPEL_M");   /* measured variant: 0 = round 3's kernels (VALU filters) */
+    if (!(stride & 15) && !(em && em[0] == '0') && !(eo && eo[0] == '1') && !(ew && ew[0] == '0')) {
+        /* the matrix-core kernel: aligned 16-byte chunk loads, so the stride must keep a row's alignment */
+        const char *ex = FFHIP_KNOB("FFHIP_QPEL_XCD"); /* measured variant: 0 = workgroups in launch order */
+        const char *eg = FFHIP_KNOB("FFHIP_QPEL_NG"); /* measured variant: groups of four blocks per wave (1, 2, 4) */
+        const int ng = eg ? atoi(eg) : 1 /* measured: 2 and 4 are slower (0.34 / 0.47 ms against 0.31 at 32 planes) */, remap = !(ex && ex[0] == '0');
+        const int per_xcd = cdiv(cdiv(n, 16 * ng), 8);
+        if (ng == 4)
+            hipLaunchKernelGGL(k_h264_qpel_m<4>, dim3(8 * per_xcd), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h, remap ? per_xcd : 0);
+        else if (ng == 2)
+            hipLaunchKernelGGL(k_h264_qpel_m<2>, dim3(8 * per_xcd), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h, remap ? per_xcd : 0);
+        else
+            hipLaunchKernelGGL(k_h264_qpel_m<1>, dim3(8 * per_xcd), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h, remap ? per_xcd : 0);
+    } else if (!(stride & 15) && n >= 1024 && !(eo && eo[0] == '1') && !(ew && ew[0] == '0')) {
         hipLaunchKernelGGL(k_h264_qpel_t, dim3(cdiv(n, 16)), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h);
     } else if (!(stride & 3) && !(eo && eo[0] == '1')) {
         if (nb >= 4 && n >= 4 * 4096)

@@ -95,10 +95,10 @@ def test_h264_golden_gpu():
     cpar = d["chroma_par"]
     cd = torch.from_numpy(np.tile(d["chroma_dst"], (len(cpar), 1))).cuda()
     cb = np.zeros(len(cpar), np.dtype([("d", np.int32), ("s", np.int32), ("w", np.uint8), ("h", np.uint8), ("x", np.uint8),
-                                       ("y", np.uint8), ("avg", np.uint8), ("pad", np.uint8, 3)]))
+                                       ("y", np.uint8), ("avg", np.uint8), ("flags", np.uint8), ("sx", np.int16), ("sy", np.int16), ("pad", np.int16)]))
     for i, (avg, idx, x, y) in enumerate(cpar):
-        cb[i] = (i * 24 * 32 + 2 * 32 + 8, 2 * 32 + 8, idx, 8, x, y, avg, [0, 0, 0])
-    h264.chroma_mc_batch(cd, csrc, 32, torch.from_numpy(cb.view(np.uint8).reshape(-1, 16)).cuda(), len(cpar))
+        cb[i] = (i * 24 * 32 + 2 * 32 + 8, 2 * 32 + 8, idx, 8, x, y, avg, 0, 0, 0, 0)
+    h264.chroma_mc_batch(cd, csrc, 32, torch.from_numpy(cb.view(np.uint8).reshape(-1, 20)).cuda(), len(cpar))
     got = cd.cpu().numpy().reshape(len(cpar), 24, 32)
     for i in range(len(cpar)):
         assert np.array_equal(got[i, 2:10, 8:16], d["chroma_out"][i]), tuple(cpar[i])

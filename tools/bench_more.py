@@ -80,11 +80,11 @@ ref = torch.randint(0, 256, (h + 2 * P, stride), dtype=torch.uint8, device=dev)
 dst = torch.zeros_like(ref)
 by, bx = np.meshgrid(np.arange(h // 8), np.arange(w // 8), indexing="ij")
 cb = np.zeros(by.size, np.dtype([("d", np.int32), ("s", np.int32), ("w", np.uint8), ("h", np.uint8), ("x", np.uint8), ("y", np.uint8),
-                                 ("avg", np.uint8), ("pad", np.uint8, 3)]))
+                                 ("avg", np.uint8), ("flags", np.uint8), ("sx", np.int16), ("sy", np.int16), ("pad", np.int16)]))
 cb["d"] = (P + by.ravel() * 8) * stride + P + bx.ravel() * 8
 cb["s"] = cb["d"] + rng.integers(-8, 9, by.size) * stride + rng.integers(-8, 9, by.size)
 cb["h"], cb["x"], cb["y"] = 8, rng.integers(0, 8, by.size), rng.integers(0, 8, by.size)
-dcb = torch.from_numpy(cb.view(np.uint8).reshape(-1, 16)).to(dev)
+dcb = torch.from_numpy(cb.view(np.uint8).reshape(-1, 20)).to(dev)
 ms = timed(lambda: h264.chroma_mc_batch(dst, ref, stride, dcb, cb.size))
 print(json.dumps({"case": "h264 chroma mc8, every 8x8 block of a 1920x1080 plane", "blocks": int(cb.size), "ms": round(ms, 4),
                   "Mpix/s": round(cb.size * 64 / ms / 1e3, 1)}), flush=True)
