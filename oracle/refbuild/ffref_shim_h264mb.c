@@ -235,7 +235,7 @@ FFRefH264Dec *FN(h264dec_open)(int bit_depth, int mb_w, int mb_h, int linesize, 
         d->pps->dequant4_coeff[k] = d->pps->dequant4_buffer[k];
     for (int k = 0; k < 2; k++)               /* chroma_qp_table: the identity is enough for the loop filter's index arithmetic */
         for (int q = 0; q < QP_MAX_NUM + 1; q++)
-            d->pps->chroma_qp_table[k][q] = (uint8_t)q;
+            d->pps->chroma_qp_table[k][q] = (uint8_t)FFMIN(q + 2 * k, QP_MAX_NUM);
     h->ps.sps = d->sps;
     h->ps.pps = d->pps;
     h->avctx = d->avctx;               /* active_thread_type = 0: hl_motion() does not wait for reference rows */
@@ -411,6 +411,54 @@ int FN(h264dec_decode_intra)(FFRefH264Dec *d, int mb_x, int mb_y, int type, int 
     r = run_hl_decode_mb(d);
     memcpy(mb, sl->mb, (sizeof(int16_t) << ps) * 3 * 256);
     return r;
+}
+
+/* ff_h264_filter_mb() (libavcodec/h264_loopfilter.c:716) on one macroblock, in raster order over a picture: the state is what
+ * fill_filter_caches() (h264_slice.c:2313) leaves for it.  ints = { mb_type, left_type (0: no left neighbour to filter against), top_type,
+ * qscale of this / the left / the top macroblock, cbp, list_count, slice_alpha_c0_offset, slice_beta_offset, chroma_qp[0], chroma_qp[1],
+ * pps->cabac }; mv_cache [2][40][2] int16, caches = ref_cache [2][40] int8 followed by non_zero_count_cache [15 * 8] uint8 — the
+ * macroblock's own entries AND the neighbours' (the cache's border row and column).  C build: filters the picture given to set_cur()
+ * in place.  hip build: records the macroblock's edges. */
+int FN(h264dec_filter_mb)(FFRefH264Dec *d, int mb_x, int mb_y, const int *ints, const int16_t *mv_cache, const uint8_t *caches)
+{
+    H264Context *h = d->h;
+    H264SliceContext *sl = d->sl;
+    const int mb_xy = mb_x + mb_y * h->mb_stride, top_xy = mb_xy - h->mb_stride, ps = h->pixel_shift;
+    sl->mb_x = mb_x;
+    sl->mb_y = mb_y;
+    sl->mb_xy = mb_xy;
+    h->cur_pic.mb_type[mb_xy] = ints[0];
+    sl->left_type[LTOP] = sl->left_type[LBOT] = ints[1];
+    sl->top_type = ints[2];
+    sl->left_mb_xy[LTOP] = sl->left_mb_xy[LBOT] = mb_xy - 1;
+    sl->top_mb_xy = top_xy;
+    h->cur_pic.qscale_table[mb_xy] = (int8_t)ints[3];
+    if (mb_x > 0) {
+        h->cur_pic.mb_type[mb_xy - 1] = ints[1];
+        h->cur_pic.qscale_table[mb_xy - 1] = (int8_t)ints[4];
+    }
+    if (mb_y > 0) {
+        h->cur_pic.mb_type[top_xy] = ints[2];
+        h->cur_pic.qscale_table[top_xy] = (int8_t)ints[5];
+    }
+    sl->cbp = ints[6];
+    sl->list_count = ints[7];
+    sl->slice_alpha_c0_offset = ints[8];
+    sl->slice_beta_offset = ints[9];
+    sl->chroma_qp[0] = ints[10];
+    sl->chroma_qp[1] = ints[11];
+    d->pps->cabac = ints[12];
+    memcpy(sl->mv_cache, mv_cache, sizeof(sl->mv_cache));
+    memcpy(sl->ref_cache, caches, sizeof(sl->ref_cache));
+    memcpy(sl->non_zero_count_cache, caches + sizeof(sl->ref_cache), 15 * 8);
+#ifdef FFREF_WITH_HIP
+    if (d->record)
+        return ff_h264_hip_filter_mb(&d->rec, h, sl, mb_x, mb_y);
+#endif
+    ff_h264_filter_mb(h, sl, mb_x, mb_y, d->f->data[0] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->linesize) * 16,
+                      d->f->data[1] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * 8,
+                      d->f->data[2] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * 8, sl->linesize, sl->uvlinesize);
+    return 0;
 }
 
 #ifndef FFREF_WITH_HIP

@@ -206,3 +206,46 @@ def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=
                         nnzc[G.scan8_chroma(pl, k)] = n
     m["mb_type"] = int(mb_type)
     return m
+
+
+def make_filter_picture(rng, B, mb_w, mb_h, depth=8, p_intra=.2):
+    """per-macroblock state for ff_h264_filter_mb() as fill_filter_caches() (h264_slice.c:2313) leaves it: types and quantizers are
+    consistent across the picture (a macroblock's left / top type IS its neighbour's), the motion / reference / non-zero-count caches
+    are drawn per macroblock (the function reads only the current macroblock's caches, border entries included)."""
+    T16, T16x8, T8x16, T8x8, P0L0, P1L0, P0L1, P1L1, DCT8, I4, I16 = B[:11]
+    qpo = 6 * (depth - 8)
+    types = np.zeros((mb_h, mb_w), np.int64)
+    qps = rng.integers(12 + qpo, 52 + qpo, (mb_h, mb_w))
+    for y in range(mb_h):
+        for x in range(mb_w):
+            if rng.random() < p_intra:
+                t = int(rng.choice([I4, I16, I4 | DCT8]))
+            else:
+                t = int(rng.choice([T16, T16x8, T8x16, T8x8])) | P0L0 | (P0L1 if rng.random() < .4 else 0)
+                if t & (T16x8 | T8x16 | T8x8):
+                    t |= P1L0
+                if rng.random() < .3:
+                    t |= DCT8
+            types[y, x] = t
+    alpha_off, beta_off = int(rng.integers(-6, 7)) * 2, int(rng.integers(-6, 7)) * 2
+    cabac = int(rng.integers(0, 2))
+    out = []
+    for y in range(mb_h):
+        for x in range(mb_w):
+            qp = int(qps[y, x])
+            ints = np.array([types[y, x], types[y, x - 1] if x else 0, types[y - 1, x] if y else 0, qp, int(qps[y, x - 1]) if x else 0,
+                             int(qps[y - 1, x]) if y else 0, int(rng.integers(0, 16)) | (int(rng.integers(0, 3)) << 4), int(rng.integers(1, 3)),
+                             alpha_off, beta_off, qp, min(qp + 2, 87), cabac], np.int32)
+            base = rng.integers(-8, 9, 2)
+            mv = np.tile(base, (2, 40, 1)).astype(np.int16)
+            noisy = rng.random((2, 40)) < .3
+            mv[noisy] += rng.integers(-6, 7, (int(noisy.sum()), 2)).astype(np.int16)
+            ref = rng.integers(0, 2, (2, 40)).astype(np.int8)
+            if rng.random() < .5:
+                ref[:] = ref[0, 0]
+            if ints[7] == 1:
+                ref[1] = -1
+            nnz = (rng.integers(1, 4, 120) * (rng.random(120) < .35)).astype(np.uint8)
+            caches = np.concatenate([ref.view(np.uint8).ravel(), nnz])
+            out.append(dict(mb_x=x, mb_y=y, ints=ints, mv_cache=mv, caches=caches))
+    return out

@@ -118,3 +118,50 @@ def test_decoder_driven_picture(mb_w, mb_h, nref, mvr, p_intra, weights):
     (14, 6, 5, 2, 400, .2, 1)])
 def test_decoder_driven_picture_hbd(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
     _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed=depth * 1000 + mb_w * 31 + mvr)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,p_intra", [(8, 6, 4, .2), (8, 11, 7, 0.0), (8, 40, 22, .15), (8, 9, 5, 1.0), (8, 120, 68, .1), (10, 6, 4, .2),
+                                                      (10, 40, 22, .1), (12, 9, 5, .3)])
+def test_decoder_driven_deblocking(depth, mb_w, mb_h, p_intra):
+    """the in-loop filter of a picture decided by the reference's own ff_h264_filter_mb() (libavcodec/h264_loopfilter.c:716: bS from
+    types / motion / coefficients, the qp averages, alpha / beta / tc0): on the host it filters macroblock by macroblock in raster order
+    with the C members; in record mode the same calls land as the macroblocks' edge records and the frame-order kernel filters the
+    picture on the GPU."""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    R, RH = _libs()
+    rng = np.random.default_rng(depth * 100 + mb_w + mb_h)
+    px = 2 if depth > 8 else 1
+    dt = np.uint16 if depth > 8 else np.uint8
+    W, H = mb_w * 16, mb_h * 16
+    sy, sc = W + 32, W // 2 + 16
+    ls, uvls = sy * px, sc * px
+    strides = [ls, uvls, uvls]
+    mid, amp = 1 << (depth - 1), 20 << (depth - 8)            # smooth-ish content so that the filters' thresholds pass often
+    dst0 = [(mid + rng.integers(-amp, amp + 1, (H, sy))).astype(dt), (mid + rng.integers(-amp, amp + 1, (H // 2, sc))).astype(dt),
+            (mid + rng.integers(-amp, amp + 1, (H // 2, sc))).astype(dt)]
+    want = [a.copy() for a in dst0]
+    dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
+    d_dst = [dev(a) for a in dst0]
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls, uvls, 0)
+    gpu = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, ls, uvls, 1)
+    cpu.set_cur([a.ctypes.data for a in want])
+    gpu.set_cur([t.data_ptr() for t in d_dst])
+    pic = h264.Picture(mb_w, mb_h, bit_depth=depth)
+    pic.begin()
+    RH.ffrefhip_h264dec_record_begin.argtypes = [C.c_void_p] * 5
+    RH.ffrefhip_h264dec_record_begin.restype = None
+    RH.ffrefhip_h264dec_record_begin(gpu.d, pic._p, *[t.data_ptr() for t in d_dst])
+    for st in I.make_filter_picture(rng, cpu.bits, mb_w, mb_h, depth, p_intra):
+        cpu.filter_mb(st["mb_x"], st["mb_y"], st)
+        gpu.filter_mb(st["mb_x"], st["mb_y"], st)
+    pic.flush(d_dst, strides, d_dst)
+    torch.cuda.synchronize()
+    for pl in range(3):
+        got = d_dst[pl].cpu().numpy().view(dt)
+        assert (want[pl] != dst0[pl]).sum() > 50
+        bad = got != want[pl]
+        assert not bad.any(), "plane %d: %d mismatches, first at %s" % (pl, bad.sum(), np.argwhere(bad)[0])
+    pic.close()
+    cpu.close()
+    gpu.close()
