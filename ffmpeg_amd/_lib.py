@@ -70,6 +70,9 @@ def lib():
         "ffhip_set_device": (C.c_int, [C.c_int]),
         "ffhip_get_device": (C.c_int, []),
         "ffhip_stream_create": (C.c_int, [C.POINTER(vp)]),
+        "ffhip_stream_order": (C.c_int, [vp, vp]),
+        "ffhip_device_push": (C.c_int, [C.c_int, vp]),
+        "ffhip_device_pop": (None, [C.c_int]),
         "ffhip_stream_destroy": (C.c_int, [vp]),
         "ffhip_shard_range": (None, [C.c_int64, C.c_int, C.c_int, i64p, i64p]),
         "ffhip_shard_frame_pairs": (None, [C.c_int64, C.c_int, C.c_int, i64p, i64p, i64p, i64p]),

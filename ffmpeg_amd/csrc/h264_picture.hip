@@ -439,10 +439,19 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
             return FFHIP_EINVAL;
     /* a finished deblocking wavefront (an earlier picture's) that lost a hand-off is reported now rather than never */
     {
+        /* (the chroma planes' wavefront runs on the picture's second stream but files its failures under the caller's) */
         const int r = ffhip_progress_check(stream);
         if (r < 0)
             return r;
     }
+    /* everything a later stage would refuse is refused before anything is queued: the stages modify dst in place */
+    if (p->bd > 8)
+        for (int pl = 0; pl < 3; pl++)
+            if (p->any_edge[pl] && ((stride[pl] & 15) || ((uintptr_t)dst[pl] & 15))) {
+                ffhip_set_error("ffhip_h264_picture_flush: plane %d of a %d-bit picture with deblocking records must be 16-byte aligned "
+                                "(plane and stride)", pl, p->bd);
+                return FFHIP_EINVAL;
+            }
 
     /* layout of the one staging buffer */
     size_t total = 0;
@@ -607,10 +616,12 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
         if (chroma) {
             HIP_TRY(hipEventRecord(p->fork, stream));
             HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
+            ffhip_progress_report_to(stream, true); /* a hand-off lost on the second stream is the caller's stream's to hear about */
             for (int pl = 1; pl < 3 && r >= 0; pl++)
                 if (p->any_edge[pl])
                     r = ffhip_launch_h264_deblock_frames_bd(bd, 1, dst[pl], 0, 1, stride[pl], p->mb_w, p->mb_h, (const FFHipH264Edge *)(db + s_edge[pl].off),
                                                             p->aux);
+            ffhip_progress_report_to(nullptr, false);
             HIP_TRY(hipEventRecord(p->join, p->aux));
         }
         if (r >= 0 && p->any_edge[0])
@@ -679,6 +690,7 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
         HIP_TRY(hipEventRecord(p->fork, stream));
         HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
         const ptrdiff_t gap = dst[2] - dst[1];
+        ffhip_progress_report_to(stream, true); /* a hand-off lost on the second stream is the caller's stream's to hear about */
         if (p->any_edge[1] && p->any_edge[2] && stride[1] == stride[2] && gap > 0 && !(gap & 3) &&
             s_edge[2].off == s_edge[1].off + p->edges[1].size() * sizeof(FFHipH264Edge)) {
             r = ffhip_launch_h264_deblock_frames_chroma(dst[1], (size_t)gap, 2, stride[1], p->mb_w, p->mb_h,
@@ -689,6 +701,7 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
                     r = ffhip_launch_h264_deblock_frames_chroma(dst[pl], 0, 1, stride[pl], p->mb_w, p->mb_h,
                                                                 (const FFHipH264Edge *)(db + s_edge[pl].off), p->aux);
         }
+        ffhip_progress_report_to(nullptr, false);
         HIP_TRY(hipEventRecord(p->join, p->aux));
     }
     if (r >= 0 && p->any_edge[0])

@@ -22,5 +22,8 @@ int ffhip_progress_release(const FFHipProgressSlot *s, hipStream_t stream, bool 
 /* FFHIP_EIO (once) if a finished launch that was issued on `stream` lost a hand-off — keyed by stream, so the owner of picture A
  * hears about picture A and nobody else does.  Checks the current device's pool. */
 int ffhip_progress_check(hipStream_t stream);
+/* on: launches the calling thread queues from now on file a lost hand-off under `stream` whatever stream they run on (the picture
+ * layer's chroma wavefront runs on a private second stream; its caller only ever asks about its own); off: back to the launch's. */
+void ffhip_progress_report_to(hipStream_t stream, bool on);
 
 #endif

@@ -83,6 +83,15 @@ static void retire(Pool &p, int i)
     p.slot[i].state = S_FREE;
 }
 
+/* a launch queued on a helper stream on behalf of a caller's stream files its failure under the caller's */
+static thread_local bool t_report_set;
+static thread_local hipStream_t t_report;
+void ffhip_progress_report_to(hipStream_t stream, bool on)
+{
+    t_report_set = on;
+    t_report = stream;
+}
+
 int ffhip_progress_acquire(int nints, hipStream_t stream, FFHipProgressSlot *s)
 {
     if (nints < 0 || nints > FFHIP_PROGRESS_SLOT_INTS) {
@@ -125,7 +134,7 @@ int ffhip_progress_acquire(int nints, hipStream_t stream, FFHipProgressSlot *s)
     }
     p.next = (unsigned)got + 1;
     p.slot[got].state = S_OWNED;
-    p.slot[got].stream = stream;
+    p.slot[got].stream = t_report_set ? t_report : stream;
     lk.unlock();
     s->prog = p.counters + (size_t)got * FFHIP_PROGRESS_SLOT_INTS;
     s->fail = p.fail + got;
@@ -156,6 +165,13 @@ int ffhip_progress_release(const FFHipProgressSlot *s, hipStream_t stream, bool 
         ffhip_set_error("ffhip: hipEventRecord failed: %s", hipGetErrorString(e));
         return FFHIP_EIO;
     }
+    /* nothing was launched, but acquire()'s hipMemsetAsync may still be queued on `stream`: a slot handed to another stream now
+     * could have its live counters zeroed by it.  The slot stays in flight until the stream has passed this point. */
+    if (hipEventRecord(sl.done, stream) == hipSuccess) {
+        sl.state = S_FLIGHT;
+        return 0;
+    }
+    (void)hipStreamSynchronize(stream);
     sl.state = S_FREE;
     return 0;
 }

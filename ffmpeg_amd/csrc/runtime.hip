@@ -57,10 +57,12 @@ static inline void thread_bind(void)
 {
     if (t_bound)
         return;
-    t_bound = true;
     const int d = g_default_device.load(std::memory_order_acquire);
+    if (d < 0)
+        return; /* no process default yet: a worker that enters first must still pick up the one a later ffhip_set_device() makes */
+    t_bound = true;
     int cur = -1;
-    if (d >= 0 && hipGetDevice(&cur) == hipSuccess && cur != d)
+    if (hipGetDevice(&cur) == hipSuccess && cur != d)
         (void)hipSetDevice(d);
 }
 
@@ -90,6 +92,50 @@ extern "C" int ffhip_set_device(int device)
     t_bound = true;
     int none = -1;
     g_default_device.compare_exchange_strong(none, device);
+    return 0;
+}
+
+/* ffhip_set_device() for the duration of a callback that must not re-bind the calling thread (buffer-pool callbacks run on whatever
+ * thread drops the last reference): *prev receives what ffhip_device_pop() restores */
+extern "C" int ffhip_device_push(int device, int *prev)
+{
+    if (!prev || device < 0 || device >= ffhip_device_count())
+        return FFHIP_EINVAL;
+    thread_bind();
+    int cur = -1;
+    *prev = -1;
+    if (hipGetDevice(&cur) != hipSuccess)
+        return FFHIP_ENOSYS;
+    if (cur != device) {
+        HIP_TRY(hipSetDevice(device));
+        *prev = cur;
+    }
+    return 0;
+}
+extern "C" void ffhip_device_pop(int prev)
+{
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+}
+
+/* everything queued on `first` so far happens before anything queued on `then` from now on (either may be NULL: the legacy default
+ * stream, which a hipStreamNonBlocking stream is NOT ordered against by itself) */
+extern "C" int ffhip_stream_order(void *first, void *then)
+{
+    if (first == then)
+        return 0;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(e, (hipStream_t)first);
+    if (r == hipSuccess)
+        r = hipStreamWaitEvent((hipStream_t)then, e, 0);
+    (void)hipEventDestroy(e); /* deferred by the runtime until the event has completed */
+    if (r != hipSuccess) {
+        ffhip_set_error("ffhip_stream_order: %s", hipGetErrorString(r));
+        return FFHIP_EIO;
+    }
     return 0;
 }
 

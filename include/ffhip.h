@@ -51,9 +51,16 @@ int         ffhip_device_count(void);
 int         ffhip_set_device(int device);
 /** The calling thread's device (after the default binding described above), or FFHIP_ENOSYS. */
 int         ffhip_get_device(void);
+/** ffhip_set_device() for the duration of a callback that must leave the calling thread bound as it found it (AVBuffer pool
+ *  callbacks run on whichever thread drops the last reference): push makes `device` current and stores in *prev what pop restores. */
+int         ffhip_device_push(int device, int *prev);
+void        ffhip_device_pop(int prev);
 /** A stream on the calling thread's device (hipStreamNonBlocking), for callers without the HIP headers. */
 int         ffhip_stream_create(void **stream);
 int         ffhip_stream_destroy(void *stream);
+/** Everything queued on `first` so far happens before anything queued on `then` from now on (an event recorded on one, waited for on
+ *  the other).  Either may be NULL, the legacy default stream — which a non-blocking stream is not ordered against by itself. */
+int         ffhip_stream_order(void *first, void *then);
 /** Streaming-bandwidth probe of the current device (measurement aid: bench.py reports the box's achievable roofs beside
  *  the 8 TB/s spec).  pattern 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p->4K scaler's mix), 4 read n/2 + write n (yuv420p->rgb24's);
  *  `bytes` per buffer; *gbps = bytes moved per second / 1e9 over `reps` launches (HIP events). */

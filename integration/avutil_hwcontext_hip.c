@@ -61,8 +61,11 @@ static void hip_buffer_free(void *opaque, uint8_t *data)
 {
     AVHWFramesContext *ctx = opaque;
     AVHIPDeviceContext *hw = ctx->device_ctx->hwctx;
-    if (ffhip_set_device(hw->device) >= 0)
+    int prev;
+    if (ffhip_device_push(hw->device, &prev) >= 0) { /* the thread that drops the last reference stays bound as it was */
         ffhip_free(data);
+        ffhip_device_pop(prev);
+    }
 }
 
 static AVBufferRef *hip_pool_alloc(void *opaque, size_t size)
@@ -71,7 +74,12 @@ static AVBufferRef *hip_pool_alloc(void *opaque, size_t size)
     AVHIPDeviceContext *hw = ctx->device_ctx->hwctx;
     AVBufferRef *ret = NULL;
     void *data = NULL;
-    if (ffhip_set_device(hw->device) < 0 || ffhip_malloc(&data, size) < 0)
+    int prev, r;
+    if (ffhip_device_push(hw->device, &prev) < 0)
+        return NULL;
+    r = ffhip_malloc(&data, size);
+    ffhip_device_pop(prev);
+    if (r < 0)
         return NULL;
     ret = av_buffer_create(data, size, hip_buffer_free, ctx, 0);
     if (!ret)
@@ -134,24 +142,38 @@ static int hip_transfer(AVHWFramesContext *ctx, AVFrame *dst, const AVFrame *src
     HIPFramesContext *priv = ctx->hwctx;
     AVHIPDeviceContext *hw = ctx->device_ctx->hwctx;
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(ctx->sw_format);
-    int r;
-    if ((r = ffhip_set_device(hw->device)) < 0)
+    int r, prev;
+    if ((r = ffhip_device_push(hw->device, &prev)) < 0)
         return hip_err(r);
+    /* The consumers of hip frames that take no stream (the swscale backend's SwsOpFunc, swscale_hw_hip.c; the graph's legacy pass,
+     * swscale_graph_hip.c) launch on the legacy default stream, and hw->stream is a non-blocking one: the two are unordered unless
+     * said otherwise.  A transfer therefore starts behind everything the default stream has queued (a download reads what a
+     * conversion wrote) and, when it does not wait itself, the default stream continues behind it (a conversion reads an upload). */
+    if ((r = ffhip_stream_order(NULL, hw->stream)) < 0) {
+        ffhip_device_pop(prev);
+        return hip_err(r);
+    }
     for (int i = 0; i < FF_ARRAY_ELEMS(src->data) && src->data[i]; i++) {
         const int h = src->height >> ((i == 0 || i == 3) ? 0 : priv->shift_height);
         const int bw = av_image_get_linesize(ctx->sw_format, src->width, i); /* bytes of a row of this plane */
-        if (bw < 0)
+        if (bw < 0) {
+            ffhip_device_pop(prev);
             return bw;
+        }
         r = to_device ? ffhip_memcpy2d_h2d_async(dst->data[i], dst->linesize[i], src->data[i], src->linesize[i], bw, h, hw->stream)
                       : ffhip_memcpy2d_d2h_async(dst->data[i], dst->linesize[i], src->data[i], src->linesize[i], bw, h, hw->stream);
-        if (r < 0)
+        if (r < 0) {
+            ffhip_device_pop(prev);
             return hip_err(r);
+        }
     }
     (void)desc;
     if (!to_device || !hw->async_upload) /* a download must have landed before the caller reads it */
-        if ((r = ffhip_stream_synchronize(hw->stream)) < 0)
-            return hip_err(r);
-    return 0;
+        r = ffhip_stream_synchronize(hw->stream);
+    else
+        r = ffhip_stream_order(hw->stream, NULL);
+    ffhip_device_pop(prev);
+    return r < 0 ? hip_err(r) : 0;
 }
 static int hip_transfer_data_to(AVHWFramesContext *ctx, AVFrame *dst, const AVFrame *src) { return hip_transfer(ctx, dst, src, 1); }
 static int hip_transfer_data_from(AVHWFramesContext *ctx, AVFrame *dst, const AVFrame *src) { return hip_transfer(ctx, dst, src, 0); }

@@ -8,8 +8,11 @@
  * below hands them to ffhip_sws_uops_run_dev: the conversion runs in HBM, nothing crosses PCIe.  over_read / over_write are 0 and
  * block_size is what ffhip_sws_uops_block_size says, so the dispatcher never takes its memcpy tail path on the device pointers.
  *
- * The same micro-op lowering as the software-frame backend (flags 0: backend_c's own lowering, bit-exact with it).  Launches go to
- * the null stream: the device context's stream is a blocking stream, so av_hwframe_transfer_data() on it is ordered behind them.
+ * The same micro-op lowering as the software-frame backend (flags 0: backend_c's own lowering, bit-exact with it).  SwsOpFunc carries
+ * no stream, so launches go to the legacy default stream; the device context's transfer stream is a NON-blocking one
+ * (ffhip_stream_create) and therefore not ordered against it by itself — avutil_hwcontext_hip.c's hip_transfer() says the order with
+ * events on both sides (ffhip_stream_order: a transfer starts behind what the default stream has queued; after an upload that does
+ * not wait, the default stream continues behind it).
  *
  * This build's list of backends is { hip (hw), c }: the software-frame `hip` backend (oracle/refbuild/ffref_shim_ops.c in this
  * repository's tests) sits between them in the real patch.
