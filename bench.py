@@ -41,6 +41,39 @@ HBM_PEAK_GBS = 8000.0                                             # MI355X_MICRO
 HBM_GUIDE_ACHIEVABLE_GBS = 6290.0                                 # same guide: 6.29 TB/s measured (float4 copy, 79 %)
 
 
+def usable_cores():
+    """what this process may actually run on at once: min(scheduler affinity, the container's CPU quota) — `cores` of every CPU leg is
+    capped by it (a 256-thread leg under a 16-CPU cgroup quota is a 16-core measurement)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per) + .5)))
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + .5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(budget_s=5.0):
     """Bounded samples of the same work on the host cores (checker infrastructure, timed only)."""
     import ffi
@@ -81,7 +114,40 @@ def cpu_baseline(budget_s=5.0):
         return {"value": round(n * px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": threads,
                 "sample": "%d frames %s in %.1f s, %d thread(s)" % (n, what, dt, threads)}
 
-    legs = {"sws_1_thread": run_sws(1, 2.0), "sws_slice_threads": run_sws(min(cores, 64), 3.0)}
+    usable = usable_cores()
+
+    def run_sws_frame(threads, budget):
+        """sws_scale_frame() on refcounted frames: the entry through which a threaded context reaches ff_sws_slice_worker on every
+        slice thread (libswscale/swscale.c:1405-1420, 1645-1679); sws_scale() on such a context runs slice_ctx[0] alone (:1626-1643)"""
+        R.ffref_frame_alloc.restype = C.c_void_p
+        R.ffref_frame_alloc.argtypes = [C.c_int] * 3
+        R.ffref_frame_plane.restype = C.c_void_p
+        R.ffref_frame_plane.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        R.ffref_sws_scale_frame.argtypes = [C.c_void_p] * 3
+        R.ffref_frame_free.argtypes = [C.c_void_p]
+        fs, fd = R.ffref_frame_alloc(SRC_W, SRC_H, NV12), R.ffref_frame_alloc(DST_W, DST_H, NV12)
+        for i, rows in ((0, SRC_H), (1, SRC_H // 2)):
+            ls = C.c_int()
+            pl = np.ctypeslib.as_array(C.cast(R.ffref_frame_plane(fs, i, C.byref(ls)), C.POINTER(C.c_uint8)), shape=(rows, ls.value))
+            pl[:] = rng.integers(0, 256, pl.shape, dtype=np.uint8)
+        ctx = R.ffref_sws_create(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, 4, threads)
+        R.ffref_sws_scale_frame(ctx, fd, fs)                         # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            R.ffref_sws_scale_frame(ctx, fd, fs)
+            n += 1
+            dt = time.perf_counter() - t0
+            if (dt > budget and n >= 3) or n >= 2000:
+                break
+        R.ffref_sws_free(ctx)
+        R.ffref_frame_free(fs)
+        R.ffref_frame_free(fd)
+        return {"value": round(n * px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": min(threads, usable), "threads": threads,
+                "sample": "%d frames %s in %.1f s, sws_scale_frame on a context with %d slice thread(s)" % (n, what, dt, threads)}
+
+    legs = {"sws_1_thread": run_sws(1, 2.0)}
+    if hasattr(R, "ffref_sws_scale_frame"):
+        legs["sws_slice_threads"] = run_sws_frame(max(2, min(usable, 64)), 3.0)
     # frame-parallel: one single-threaded context and one frame per thread (a batch of independent frames on all cores)
     if hasattr(R, "ffref_sws_scale_frames_mt"):
         nt = min(cores, 256)
@@ -97,7 +163,7 @@ def cpu_baseline(budget_s=5.0):
         dt = time.perf_counter() - t0
         for c in ctxs:
             R.ffref_sws_free(c)
-        legs["sws_frame_parallel"] = {"value": round(nt * reps * px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": nt,
+        legs["sws_frame_parallel"] = {"value": round(nt * reps * px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": min(nt, usable), "threads": nt,
                                       "sample": "%d frames %s in %.1f s, %d single-threaded contexts side by side" % (nt * reps, what, dt, nt)}
         del dsts, dps
     # h264 idct8_add over 4K luma planes (129,600 blocks each): 1 thread, then a static split over all cores.  Persistent threads,
@@ -113,13 +179,14 @@ def cpu_baseline(budget_s=5.0):
             got = R.ffref_h264_idct_batch_timed(1, ffi.ptr(pic), 3840, ffi.ptr(off, ffi.i32p), ffi.ptr(blk, ffi.i16p), n, th, 1.5,
                                                 C.byref(secs), C.byref(passes))
             if got > 0 and secs.value > 0:
-                legs[key] = {"value": round(n * passes.value / secs.value / 1e9, 5), "unit": "Gblocks/s", "cores": got,
+                legs[key] = {"value": round(n * passes.value / secs.value / 1e9, 5), "unit": "Gblocks/s", "cores": min(got, usable), "threads": got,
                              "sample": "%d passes over %d 8x8 blocks (ff_h264_idct8_add_8_c, %d 4K luma planes) in %.2f s after a warm-up "
                                        "pass, %d persistent thread(s) on thread-local (NUMA-local) copies of their share" % (passes.value, n, planes, secs.value, got)}
             del pic, off, blk
     best = max((legs[k] for k in legs if k.startswith("sws_")), key=lambda l: l["value"])
     out = {"value": best["value"], "unit": "Mpixels/s", "cores": best["cores"], "kind": "reference",
-           "sample": best["sample"] + " of %d host cores, pure C (no SIMD asm: nasm absent)" % cores, "host_cores": cores, "legs": legs}
+           "sample": best["sample"] + "; %d usable of %d host cores (%s), pure C (no SIMD asm: nasm absent)" % (usable, cores, cpu_model()),
+           "host_cores": cores, "usable_cores": usable, "cpu_model": cpu_model(), "legs": legs}
     # what the box lets this process use: a container's CPU quota / cpuset bounds every sustained all-cores leg (a 9 ms burst is not throttled,
     # 1.5 s are: round 2's one-shot idct leg read 4x the sustained rate on such a box)
     try:

@@ -688,3 +688,30 @@ void ffref_tx_free(void *ctx)
     }
 }
 
+
+/* ---- sws_scale_frame() on refcounted frames: the entry through which a context made with threads > 1 actually threads ---------------
+ * (sws_scale() on such a context runs slice_ctx[0] alone, libswscale/swscale.c:1626-1643; sws_scale_frame -> sws_frame_start /
+ * sws_send_slice / sws_receive_slice reaches ff_sws_slice_worker on every slice thread, :1405-1420, :1645-1679).  bench.py's
+ * slice-threaded CPU leg and tests/test_oracle_vs_ref.py use it. */
+void *ffref_frame_alloc(int w, int h, int fmt)
+{
+    AVFrame *f = av_frame_alloc();
+    if (!f)
+        return NULL;
+    f->width = w;
+    f->height = h;
+    f->format = fmt;
+    if (av_frame_get_buffer(f, 64) < 0) {
+        av_frame_free(&f);
+        return NULL;
+    }
+    return f;
+}
+void ffref_frame_free(void *f) { AVFrame *p = f; av_frame_free(&p); }
+uint8_t *ffref_frame_plane(void *f, int i, int *linesize)
+{
+    AVFrame *p = f;
+    *linesize = p->linesize[i];
+    return p->data[i];
+}
+int ffref_sws_scale_frame(void *ctx, void *dst, void *src) { return sws_scale_frame(ctx, dst, src); }

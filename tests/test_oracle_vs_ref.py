@@ -1537,3 +1537,39 @@ def test_alpha_on_one_side(sf, dst, sw, sh, dw, dh, flags):
     for a, b in (("yuva420p", "yuva444p"), ("yuva420p", "rgba")):
         with pytest.raises(ValueError):
             S.HostTables(sw, sh, PIX[a], dw, dh, PIX[b], flags)
+
+
+def test_sws_scale_frame_slice_threads_equal_one_thread():
+    """the CPU baseline's slice-threaded leg (bench.py) goes through sws_scale_frame(), the entry that reaches ff_sws_slice_worker on
+    every slice thread (libswscale/swscale.c:1405-1420, 1645-1679): its output is the single-threaded one bit for bit"""
+    R = ffi.ref()
+    if not hasattr(R, "ffref_sws_scale_frame"):
+        pytest.skip("oracle/_ref predates ffref_sws_scale_frame")
+    R.ffref_frame_alloc.restype = C.c_void_p
+    R.ffref_frame_alloc.argtypes = [C.c_int] * 3
+    R.ffref_frame_plane.restype = C.c_void_p
+    R.ffref_frame_plane.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    R.ffref_sws_scale_frame.argtypes = [C.c_void_p] * 3
+    R.ffref_frame_free.argtypes = [C.c_void_p]
+    NV12, sw, sh, dw, dh = 23, 320, 180, 640, 360
+
+    def plane(f, i, rows):
+        ls = C.c_int()
+        p = R.ffref_frame_plane(f, i, C.byref(ls))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(rows, ls.value))
+    rng = np.random.default_rng(9)
+    src = R.ffref_frame_alloc(sw, sh, NV12)
+    for i, rows in ((0, sh), (1, sh // 2)):
+        pl = plane(src, i, rows)
+        pl[:] = rng.integers(0, 256, pl.shape, dtype=np.uint8)
+    outs = []
+    for threads in (1, 4):
+        ctx = R.ffref_sws_create(sw, sh, NV12, dw, dh, NV12, ffi.SWS_BICUBIC, threads)
+        dst = R.ffref_frame_alloc(dw, dh, NV12)
+        assert R.ffref_sws_scale_frame(ctx, dst, src) >= 0
+        outs.append([plane(dst, 0, dh)[:, :dw].copy(), plane(dst, 1, dh // 2)[:, :dw].copy()])
+        R.ffref_sws_free(ctx)
+        R.ffref_frame_free(dst)
+    R.ffref_frame_free(src)
+    assert outs[0][0].std() > 10
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
