@@ -24,6 +24,7 @@ struct FFHipYuv2RgbArgs {
     int h;                           /* rows of this slice (even) */
     int dst_y0;                      /* srcSliceY: first destination row */
     int nframes;
+    int flat;                        /* set by the launcher: chunks numbered through the frame's row pairs (k_yuv420p_rgb24_t) */
     FFHipYuv2RgbK k;
 };
 /* packed layout: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (32-bit: alpha = 255) */
