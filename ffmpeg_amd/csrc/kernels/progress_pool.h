@@ -5,7 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
-#define FFHIP_PROGRESS_SLOT_INTS 2048
+#define FFHIP_PROGRESS_SLOT_INTS 8192 /* 2048 until round 4: 64 4K luma planes (34 bands each) then split into launches of 60 + 4 pictures, and the 4 paid a whole latency chain (2.26 ms against 0.96 ms for 32 planes) */
 
 struct FFHipProgressSlot {
     int *prog; /* `nints` zeroed (in stream order) progress words on the current device */

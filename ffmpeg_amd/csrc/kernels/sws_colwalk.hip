@@ -542,10 +542,24 @@ __device__ __forceinline__ void cw_wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool SIL, int LAY, int D, bool TR> /* LAY: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (alpha = 255) */
+/* LUT (round 4): the chroma part of the closed form — 23 VALU instructions per chroma sample and output row, a third of the kernel — is
+ * a function of one byte per term: r(V), b(U), g = gu(U) + gv(V) (the products distribute over the sum exactly in wrapping int32
+ * arithmetic).  The workgroup builds the four 256-entry tables in 4 KB of LDS once (one entry per thread) and a sample costs two
+ * 8-byte LDS reads and an add. */
+template <bool SIL, int LAY, int D, bool TR, bool LUT = true> /* LAY: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (alpha = 255) */
 __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
 {
     __shared__ uint32_t tiles[4][384];
+    __shared__ uint2 lutU[LUT ? 256 : 1], lutV[LUT ? 256 : 1]; /* { b(U), gu(U) }, { r(V), gv(V) } */
+    if (LUT) {
+        const int t = (int)threadIdx.x;
+        const FFHipYuv2RgbK Kt = A.k;
+        lutU[t] = make_uint2((uint32_t)(__mul24(Kt.off_b + (__mul24(t, Kt.cbu) >> 16), Kt.cy) + Kt.kb),
+                             (uint32_t)(__mul24(Kt.off_g + (__mul24(t, Kt.cgu) >> 16), Kt.cy) + Kt.kb));
+        lutV[t] = make_uint2((uint32_t)(__mul24(Kt.off_r + (__mul24(t, Kt.crv) >> 16), Kt.cy) + Kt.kb),
+                             (uint32_t)__mul24(__mul24(t, Kt.cgv) >> 16, Kt.cy));
+        __syncthreads();
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
@@ -692,10 +706,17 @@ __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
             for (int mm = 0; mm < 2; mm++) {
                 const int m = 2 * h + mm;
                 const int Uc = min(max(Uv[m] >> 19, 0), 255), Vc = min(max(Vv[m] >> 19, 0), 255);
-                const int br = __mul24(K.off_r + (__mul24(Vc, K.crv) >> 16), K.cy) + K.kb;
-                const int bb = __mul24(K.off_b + (__mul24(Uc, K.cbu) >> 16), K.cy) + K.kb;
-                const int bg = __mul24(K.off_g + (__mul24(Uc, K.cgu) >> 16) +
-                                                            (__mul24(Vc, K.cgv) >> 16), K.cy) + K.kb;
+                int br, bb, bg;
+                if (LUT) {
+                    const uint2 tu = lutU[Uc], tv = lutV[Vc];
+                    br = (int)tv.x;
+                    bb = (int)tu.x;
+                    bg = (int)(tu.y + tv.y);
+                } else {
+                    br = __mul24(K.off_r + (__mul24(Vc, K.crv) >> 16), K.cy) + K.kb;
+                    bb = __mul24(K.off_b + (__mul24(Uc, K.cbu) >> 16), K.cy) + K.kb;
+                    bg = __mul24(K.off_g + (__mul24(Uc, K.cgu) >> 16) + (__mul24(Vc, K.cgv) >> 16), K.cy) + K.kb;
+                }
                 const int c0 = BGR ? bb : br, c2 = BGR ? br : bb;
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
@@ -1196,7 +1217,10 @@ int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream)
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     const char *et = FFHIP_KNOB("FFHIP_CWRGB_DIRECT"); /* measured variant: per-lane 24-byte stores, no LDS transpose */
     const bool tr = !(et && et[0] == '1');
-#define CWR_LAUNCH(S, B) do { if (tr) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, true>), grid, block, 0, stream, A); \
+    const char *el = FFHIP_KNOB("FFHIP_CWRGB_LUT"); /* measured variant: 0 = the closed form in VALU instructions */
+    const bool lut = !(el && el[0] == '0');
+#define CWR_LAUNCH(S, B) do { if (!lut) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, true, false>), grid, block, 0, stream, A); \
+                              else if (tr) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, true>), grid, block, 0, stream, A); \
                               else hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, false>), grid, block, 0, stream, A); } while (0)
 #define CWR_LAUNCH32(S, B) hipLaunchKernelGGL((k_sws_colwalk_rgb<S, B, 3, false>), grid, block, 0, stream, A)
     if (A.sil) {
