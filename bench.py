@@ -302,6 +302,8 @@ def extras(torch, dev):
     # down-scaling (8 x 8-tap banks at exact 2:1: k_sws_down2) and scaled packed-RGB output (column walker + yuv2rgb)
     sws_case("sws_nv12_4k_to_1080p_bicubic", 23, 3840, 2160, 23, 1920, 1080, 64)
     sws_case("sws_yuv420p_1080p_to_rgb24_4k_bicubic", 0, 1920, 1080, 2, 3840, 2160, 32)
+    # a J (full-range) source: range conversion between the passes of the exact-2x kernel (round 4; AV_PIX_FMT_YUVJ420P = 12)
+    sws_case("sws_yuvj420p_1080p_to_yuv420p_4k_bicubic", 12, 1920, 1080, 0, 3840, 2160, 64)
     # 4:4:4 planar through the exact-2x kernel: three planes of the luma's size (AV_PIX_FMT_YUV444P = 5)
     sws_case("sws_yuv444p_1080p_to_4k_bicubic", 5, 1920, 1080, 5, 3840, 2160, 32)
     # above 8 bits: p010 / yuv420p10 1080p -> 4K (3.75 B per output pixel) through the exact-2x kernel's 16-bit twin, and a ratio that

@@ -108,6 +108,9 @@ struct FFHipUp2Job {
     /* samples above 8 bits (k_sws_up2<., ., 1>; 0: bytes): depths 9..14 of the little-endian uint16 samples on either side, and
      * whether they sit in the high bits (P010 / P012).  Groups are then 16 destination bytes. */
     int hb_sdepth, hb_ddepth, hb_smsb, hb_dmsb;
+    /* range conversion on the 15-bit horizontal samples (lum / chrRangeToJpeg_c, ...FromJpeg_c, libswscale/swscale.c:160-207):
+     * h = (h * rc_coeff + rc_offset) >> 14, clipped to 32767 (k_sws_up2<., ., 0, 1>; rc_coeff 0: none) */
+    int rc_coeff, rc_offset;
 };
 struct FFHipUp2Args {
     FFHipUp2Job job[3];

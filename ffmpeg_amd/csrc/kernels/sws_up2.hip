@@ -201,7 +201,7 @@ __device__ __forceinline__ void up_v8h(uint32_t (&w)[4], const uint32_t (&pa)[8]
  * 8 samples from 4g - 2) or 24 (pair: 6 (u, v) columns from 2g - 2) per lane and row, 16 destination bytes per lane and row; the
  * seven (s[k], s[k+1]) pairs of a plane are its dwords and three v_alignbyte, a pair's come from v_perm as at 8 bits.
  */
-template <int PAIR, int D, int VAR, int HB = 0>
+template <int PAIR, int D, int VAR, int HB = 0, int RC = 0>
 __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int fshift, int gbase, int strip, int lane, int nframes)
 {
     /* measurement-only variants (wrong output; tools/sweep_sws.py): 16 never stores, 32 re-reads one source row (48 = both: the
@@ -391,6 +391,15 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
                 h[4 + i] = hh[i];
             }
         }
+        if (RC) {
+            /* the reference converts the range of its int16 line buffer: min(h, 32767) is what that buffer holds, the product fits
+             * 32 bits, and the pack below saturates at 32767 as ...ToJpeg's FFMIN does (the other direction never gets there; no
+             * result falls below -32768: host-checked) */
+            const int rcc = J.rc_coeff, rco = J.rc_offset;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                h[i] = (__mul24(min(h[i], 32767), rcc) + rco) >> 14; /* 16 x 17 bits: v_mad_i32_i24, full rate */
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             Pnew[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[i], h[i]));
@@ -485,7 +494,7 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
     }
 }
 
-template <int D, int VAR, int HB = 0> /* VAR: 0 the product; 16 / 48 / 64 measurement only (see up2_unit); HB: samples above 8 bits */
+template <int D, int VAR, int HB = 0, int RC = 0> /* VAR: 0 the product; 16 / 48 / 64 measurement only (see up2_unit); HB: samples above 8 bits; RC: range conversion */
 __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -524,9 +533,9 @@ __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
         gbase = J.nfull * 64 + (idx - nf) * (64 >> fsh);
     }
     if (J.pair)
-        up2_unit<1, D, VAR, HB>(J, frame0, fsh, gbase, strip, lane, A.nframes);
+        up2_unit<1, D, VAR, HB, RC>(J, frame0, fsh, gbase, strip, lane, A.nframes);
     else
-        up2_unit<0, D, VAR, HB>(J, frame0, fsh, gbase, strip, lane, A.nframes);
+        up2_unit<0, D, VAR, HB, RC>(J, frame0, fsh, gbase, strip, lane, A.nframes);
 }
 
 /* ================================================================================================== */
@@ -611,6 +620,14 @@ int ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream)
             hipLaunchKernelGGL((k_sws_up2<3, 0, 1>), grid, block, 0, stream, A);
         else
             hipLaunchKernelGGL((k_sws_up2<6, 0, 1>), grid, block, 0, stream, A);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (A.job[0].rc_coeff) { /* range conversion between the passes: the product variant only */
+        if (depth == 3)
+            hipLaunchKernelGGL((k_sws_up2<3, 0, 0, 1>), grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL((k_sws_up2<6, 0, 0, 1>), grid, block, 0, stream, A);
         LAUNCH_CHECK();
         return 0;
     }

@@ -48,6 +48,7 @@ struct FFHipSwsContext {
     FFHipDevFilter dw[4];
     /* exact-2x fast path (sws_up2.hip): virtual banks (regular windows of the edge-replicated rows) on the device */
     int up2_ok = 0;
+    int up2_rc = 0; /* a range-converting context: the exact-2x kernel with the range stage is its only fast kernel */
     void *up2_dev = nullptr;
     const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
     /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
@@ -537,11 +538,39 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         if (!r)
             r = ffhip_plan_scale_plane(&ch, 2, c->p[1].data(), c->p[3].data());
         if (rc) {
-            /* the static-schedule and walker kernels carry no range stage: the general tiled kernel serves these contexts */
+            /* of the fast kernels only the exact-2x one carries the range stage (round 4: k_sws_up2<., ., 0, 1>); everything else
+             * about such a context is the general tiled kernel's */
             if (r) {
                 ffhip_set_error("ffhip_sws: bank sizes outside the tiled kernel's range");
                 ffhip_sws_freeContext(c);
                 return nullptr;
+            }
+            const int lim[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
+            auto rc_floor_ok = [&](const std::vector<int16_t> &f, int n, int coeff, int offset) {
+                /* the lowest horizontal sample a bank row can produce, through the conversion: the int16 pack saturates where the
+                 * reference's store wraps, so nothing may fall below -32768 */
+                for (int x = 0; x < n; x++) {
+                    int neg = 0;
+                    for (int j = 0; j < 4; j++)
+                        if (f[(size_t)x * 4 + j] < 0)
+                            neg += f[(size_t)x * 4 + j];
+                    const long long hmin = (255LL * neg) >> 7;
+                    if (((hmin * coeff + offset) >> 14) < -32768)
+                        return false;
+                }
+                return true;
+            };
+            if (l.dstW == 2 * l.srcW && l.dstH == 2 * l.srcH && ch.dstW == 2 * ch.srcW && ch.dstH == 2 * ch.srcH &&
+                fmt_nv(t->srcFormat) == fmt_nv(t->dstFormat) && !(l.srcW & 3) && l.srcW >= 8 &&
+                (fmt_nv(t->srcFormat) ? !(ch.srcW & 1) && ch.srcW >= 4 : !(ch.srcW & 3) && ch.srcW >= 8) && build_fast_view(c, lim, false) &&
+                ffhip_cw_bank_ok(c->np[0].data(), 4, c->d[0].n, l.srcW, c->np[2].data(), 4, c->d[2].n, l.srcH) &&
+                ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, ch.srcW, c->np[3].data(), 4, c->d[3].n, ch.srcH) &&
+                ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) && ffhip_cw_bank_nowrap(c->nf[1].data(), 4, c->d[1].n) &&
+                rc_floor_ok(c->nf[0], c->d[0].n, l.rc_coeff, l.rc_offset) && rc_floor_ok(c->nf[1], c->d[1].n, ch.rc_coeff, ch.rc_offset)) {
+                const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
+                up2_build(c, nsrc);
+                c->cw_ok = c->up2_ok; /* the dispatcher's gate; c->up2_rc keeps every other fast kernel out */
+                c->up2_rc = c->up2_ok;
             }
             return c;
         }
@@ -967,6 +996,7 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 j.srcW = p.srcW; j.srcH = p.srcH;
                 j.ngroups = pair ? p.srcW / 2 : p.srcW / 4;
                 j.hfv = c->up2_h[which]; j.vfv = c->up2_v[which];
+                j.rc_coeff = p.rc_coeff; j.rc_offset = p.rc_offset;
             };
             upjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
             if (ch.src_step == 2) {
@@ -1013,7 +1043,7 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 return ffhip_launch_up2(U, ed && ed[0] == '6' ? 6 : 3, ev2 ? atoi(ev2) : 0, stream);
             }
         }
-        if (!(al & 3)) {
+        if (!(al & 3) && !c->up2_rc) {
             const char *em = FFHIP_KNOB("FFHIP_SWS_MFMA");
             if (c->mf_ok && em && em[0] == '1') {
                 /* horizontal pass on the matrix cores (k_sws_mfma) */

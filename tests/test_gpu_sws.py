@@ -283,14 +283,16 @@ RANGE_CASES = [("yuvj420p", 64, 40, "yuv420p", 160, 88, ffi.SWS_BICUBIC), ("yuv4
                ("yuvj444p", 64, 40, "yuv422p", 48, 30, ffi.SWS_BICUBIC), ("yuv422p", 80, 40, "yuvj420p", 120, 90, ffi.SWS_BILINEAR),
                ("yuvj420p", 64, 40, "nv12", 128, 80, ffi.SWS_BICUBIC), ("nv12", 64, 40, "yuvj420p", 100, 60, ffi.SWS_BICUBIC),
                ("yuvj420p", 200, 120, "yuv420p", 50, 30, ffi.SWS_BICUBIC), ("yuvj420p", 1920, 1080, "yuv420p", 3840, 2160, ffi.SWS_BICUBIC),
-               ("yuv420p", 1920, 1080, "yuvj420p", 1280, 720, ffi.SWS_BICUBIC)]
+               ("yuv420p", 1920, 1080, "yuvj420p", 1280, 720, ffi.SWS_BICUBIC), ("yuv420p", 320, 180, "yuvj420p", 640, 360, ffi.SWS_BICUBIC),
+               ("yuvj420p", 176, 144, "yuv420p", 352, 288, ffi.SWS_BILINEAR), ("yuv444p", 64, 40, "yuvj444p", 128, 80, ffi.SWS_BICUBIC)]
 
 
 @pytest.mark.parametrize("case", RANGE_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
 def test_range_conversion(case):
     """a full-range (J) format on one side: lum / chrRangeToJpeg_c, ...FromJpeg_c on the horizontal intermediates (libswscale/
     swscale.c:160-207) — HIP == oracle (pinned to the reference by tests/test_oracle_vs_ref.py::test_range_conversion), extreme samples
-    included; these contexts run on the general tiled kernel (the static-schedule kernels carry no range stage)"""
+    included; these contexts run on the general tiled kernel, except exact 2x between like layouts: the static-schedule kernel with
+    the range stage between its passes (k_sws_up2<., ., 0, 1>, round 4)"""
     from ffmpeg_amd import swscale as S
     torch = _torch()
     sf, sw, sh, df, dw, dh, flags = case
@@ -310,7 +312,8 @@ def test_range_conversion(case):
     dp, ds = ffi.planes(want)
     assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
     ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
-    assert ctx.fast_path is False and not ctx.up2_path
+    up2 = dw == 2 * sw and dh == 2 * sh and (bs == "nv12") == (bd == "nv12") and not (sw & 7) and sw >= 16
+    assert bool(ctx.up2_path) == up2, (ctx.fast_path, ctx.up2_path)
     n = 2
     dsrc = _upload(src, n=n)
     ddst = [torch.zeros((n,) + a.shape, dtype=torch.uint8, device="cuda:0") for a in want]
