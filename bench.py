@@ -771,18 +771,22 @@ def h264_intra_picture_leg(torch, dev, ev, h264):
     sy, sc = mb_w * 16, mb_w * 8
     dst = [torch.zeros((mb_h * 16, sy), dtype=torch.uint8, device=dev), torch.zeros((mb_h * 8, sc), dtype=torch.uint8, device=dev),
            torch.zeros((mb_h * 8, sc), dtype=torch.uint8, device=dev)]
-    pic = h264.Picture(mb_w, mb_h)
-    pic.begin()
     ed8, ed4 = np.zeros(8, EDGE_DT), np.zeros(4, EDGE_DT)
     for e in (ed8, ed4):
         e["alpha"], e["beta"], e["kind"] = 40, 9, 4
     ed4["kind"] = 6
-    for my in range(mb_h):
-        for mx in range(mb_w):
-            d = G.make_intra_mb(rng, mx, my, mb_w, mb_h)
-            pic.intra_mb(G.to_record(d), d["nnzc"], d["mb"], d["luma_dc"], d["pcm"])
+    states = [(mx, my, G.make_intra_mb(rng, mx, my, mb_w, mb_h)) for my in range(mb_h) for mx in range(mb_w)]
+    states = [(mx, my, d, G.to_record(d)) for mx, my, d in states]
+
+    def record():
+        pic = h264.Picture(mb_w, mb_h)
+        pic.begin()
+        for mx, my, d, rec in states:
+            pic.intra_mb(rec, d["nnzc"], d["mb"].copy(), d["luma_dc"], d["pcm"])      # the record call consumes sl->mb as the decoder's dsp calls do
             for pl, ed in ((0, ed8), (1, ed4), (2, ed4)):
                 pic.deblock_mb(pl, mx, my, ed)
+        return pic
+    pic = record()
     pic.flush(dst, [sy, sc, sc], dst)
     torch.cuda.synchronize()
     reps = 10
@@ -793,11 +797,45 @@ def h264_intra_picture_leg(torch, dev, ev, h264):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    pic.close()
+    # I-pictures IN FLIGHT (round 4): a lone wavefront is a latency chain that leaves the chip idle; a decoder with frame threads (or
+    # several streams) has several pictures reconstructing at once.  NP pictures, each its own object, stream and host thread.
+    import threading
+    NP = 16
+    pics = [pic] + [record() for _ in range(NP - 1)]
+    dsts = [dst] + [[torch.zeros_like(t) for t in dst] for _ in range(NP - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NP)]
+    flight = None
+    for rep in range(2):
+        torch.cuda.synchronize()
+        f0, f1 = ev(), ev()
+        f0.record()
+        for s_ in streams:
+            s_.wait_event(f0)
+        rounds = 4
+
+        def work(i):
+            for _ in range(rounds):
+                pics[i].flush(dsts[i], [sy, sc, sc], dsts[i], stream=streams[i].cuda_stream)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(NP)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        cur = torch.cuda.current_stream()
+        for s_ in streams:
+            cur.wait_stream(s_)
+        f1.record()
+        torch.cuda.synchronize()
+        flight = f0.elapsed_time(f1) / rounds
+    for p_ in pics:
+        p_.close()
     return {"h264_intra_picture_1080p": {"ms_per_picture": round(ms, 3), "pictures_per_s": round(1e3 / ms, 1), "intra_macroblocks": mb_w * mb_h,
                                          "us_per_wavefront_step": round(1e3 * ms / (mb_w + 2 * mb_h), 2),
+                                         "ms_per_picture_%d_in_flight" % NP: round(flight / NP, 3),
+                                         "pictures_per_s_%d_in_flight" % NP: round(1e3 * NP / flight, 1),
                                          "note": "a dependency chain of mb_w + 2 mb_h macroblock steps (intra prediction reads the left / upper / upper-right "
-                                                 "neighbours' reconstructed samples): latency-bound by construction, one wave per macroblock row"}}
+                                                 "neighbours' reconstructed samples): latency-bound by construction, one wave per macroblock row; in flight: "
+                                                 "one object, stream and host thread per picture"}}
 
 
 def h264_picture_leg(torch, dev, ev):
