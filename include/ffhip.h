@@ -1386,6 +1386,12 @@ typedef struct FFHipTXContext FFHipTXContext;
 #define FFHIP_TX_FLOAT_RDFT 6   /* == AV_TX_FLOAT_RDFT (r2c forward, c2r inverse; libavutil/tx.h:70-90) */
 #define FFHIP_TX_FLOAT_DCT  9   /* == AV_TX_FLOAT_DCT: DCT-II forward, DCT-III inverse (libavutil/tx.h:95-104), power of two 8..4096; as with av_tx_init the
                                    inverse is initialised with half the number of samples it transforms */
+/* Refused — ffhip_tx_init() returns FFHIP_ENOSYS and the caller keeps the C / SIMD codelets (the reference's convention for an arch
+ * that does not offer a transform: its codelet list simply has no entry, libavutil/tx.c:593-650):
+ *   AV_TX_DOUBLE_* (2, 3, 7, 10, 13, 16) and AV_TX_INT32_* (4, 5, 8, 11, 14, 17): libavutil/tx_double.c / tx_int32.c — float only here;
+ *   AV_TX_FLOAT_DCT_I (12) and AV_TX_FLOAT_DST_I (15) (libavutil/tx.h:116,128; tx_template.c:2056-2105): the reference runs them as an
+ *   RDFT over 2 (len - 1) resp. 2 (len + 1) reals, an odd-length — partly naive — FFT for the lengths codecs use, not a power-of-two
+ *   network; no batch user on the path (docs/EXPERIMENTS.md: the reference's own `Transform tree` for them). */
 #define FFHIP_TX_FULL_IMDCT        (1ULL << 2)   /* == AV_TX_FULL_IMDCT: an inverse MDCT writes 2 * len outputs (ff_tx_mdct_inv_full,
                                                   * libavutil/tx_template.c:1391-1408); batches: 8-byte aligned rows of 2 * len floats */
 #define FFHIP_TX_REAL_TO_REAL      (1ULL << 3)   /* == AV_TX_REAL_TO_REAL: a forward RDFT writes the len/2 + 1 real parts only (ff_tx_rdft_r2r,
