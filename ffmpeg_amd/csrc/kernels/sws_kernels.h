@@ -240,6 +240,32 @@ int  ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32
 void ffhip_lw_plan_job(FFHipLwJob *j);
 int  ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream);
 
+/*
+ * The column walker above 8 bits (sws_walk16.hip): banks padded to ht, vt in {4, 8} taps.  A job is one plane (nch 1) or the two
+ * chroma channels together (nch 2: an interleaved (u, v) plane on the source and / or the target side; a planar side has the two
+ * planes in src[] / dst[]).  Samples are little-endian uint16 of 9..14 bits, in the high bits for P01x.
+ */
+struct FFHipW16Job {
+    const uint8_t *src[2]; uint8_t *dst[2];
+    ptrdiff_t sstride[2], dstride[2];
+    size_t sfp[2], dfp[2];
+    int nch, sstep, dstep;                    /* sample step inside a row: 1 planar, 2 interleaved */
+    int srcH, dstW, dstH;                     /* in samples of one channel */
+    const int16_t *hf; const int32_t *hp;     /* device: dstW x ht taps, positions in samples of the channel */
+    const int16_t *vf; const int32_t *vp;     /* device: dstH x vt taps */
+    int ncb, nstrips, strip_rows, unit_begin;
+};
+struct FFHipW16Args {
+    FFHipW16Job job[3];
+    int njobs, units_per_frame, nframes, ht, vt;
+    int sdepth, ddepth, smsb, dmsb;
+};
+#ifdef __cplusplus
+bool ffhip_w16_pad_bank(const int16_t *filter, const int32_t *pos, int size, int n, int nsrc, int T, std::vector<int16_t> *of, std::vector<int32_t> *op);
+#endif
+void ffhip_w16_plan_job(FFHipW16Job *j, int strip_target);
+int  ffhip_launch_walk16(FFHipW16Args &A, hipStream_t stream);
+
 /* the scaler above 8 bits (sws_scale16.hip): one record per output plane (an interleaved UV plane is two records, one per channel) */
 struct FFHipScale16Plane {
     const uint8_t *src;      /* source plane of this channel */

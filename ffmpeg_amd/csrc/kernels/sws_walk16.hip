@@ -1,0 +1,346 @@
+/*
+ * sws_walk16.hip — the column walker for samples above 8 bits (round 4): the fused H+V scaler for 9..14-bit YUV formats (planar
+ * yuv4xxpNN, P010 / P012 with their samples in the high bits) at ANY ratio whose banks have at most 8 taps in either direction —
+ * 720p -> 1080p, 1080p -> 1440p, 4K -> 1440p, ...  Exact 2x / 2:1 keep their static-schedule kernels (sws_up2.hip / sws_down2.hip);
+ * before this kernel everything else above 8 bits ran on the LDS-tiled k_sws_scale16 (0.05 - 0.08 of HBM).
+ *
+ * Arithmetic (the reference's, bit for bit):
+ *   hScale16To15_c        libswscale/swscale.c:99-126    val = sum src[pos + j] * filter[j];  dst = FFMIN(val >> (depth - 1), 32767)
+ *   yuv2planeX_10_c       libswscale/output.c:341-360    val = (1 << (26 - bits)) + sum line[j][i] * filter[j];  av_clip_uintp2(val >> (27 - bits), bits)
+ *   yuv2p01xlX / cX       libswscale/output.c:478-529    the same, stored << (16 - bits)
+ * int32 sums mod 2^32 (v_dot2_i32_i16 without clamp), samples read as int16 (<= 14 bits: positive).
+ *
+ * Design — the 8-bit walker's (sws_colwalk.hip), re-cut for two-byte samples:
+ *   - one WAVE owns 64 lanes x 4 output columns of a strip of output rows and walks down the source rows; the 15-bit intermediate
+ *     never leaves registers: per column a ring of VT - 1 vertically adjacent int16 PAIRS (h[r-1], h[r]) — an output row whose
+ *     window ends at r is VT / 2 v_dot2 per sample on the pairs that end at r, r-2, ...; the ring index is static (the row loop is
+ *     unrolled VT - 1 times);
+ *   - the horizontal windows need NO unpacking: a lane loads the HT samples of each of its columns with one (2-byte aligned) global
+ *     load of 2 HT bytes, and consecutive samples in a dword ARE the (s[k], s[k+1]) operand of v_dot2_i32_i16.  An interleaved
+ *     (u, v) plane (P010) loads HT dwords per column and splits the channels with v_perm_b32.  Neighbouring columns' windows
+ *     overlap: the loads are L1 / L2 hits, HBM sees every source row once per strip (+ VT - 1 halo rows);
+ *   - banks are padded on the host to HT in {4, 8} and VT in {4, 8} taps (zero taps, positions pulled inside the plane at the far
+ *     edge); a strip has at most 64 output rows, lane l keeps row l's vertical position and coefficient pairs and a row's
+ *     descriptors are v_readlane away;
+ *   - the next source row's samples are in flight while this one is filtered.
+ * Algorithmic bytes: source in + destination out, 2 bytes per sample.
+ */
+#include <vector>
+
+#include "common.h"
+#include "sws_kernels.h"
+
+typedef short w16_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short w16_h2 __attribute__((ext_vector_type(2)));
+typedef uint32_t w16_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t w16_u4 __attribute__((ext_vector_type(4)));
+typedef w16_u2 __attribute__((aligned(2))) w16_u2a;
+typedef w16_u4 __attribute__((aligned(2))) w16_u4a;
+typedef w16_u2 __attribute__((aligned(4))) w16_u2d;
+typedef w16_u4 __attribute__((aligned(4))) w16_u4d;
+
+__device__ __forceinline__ int w16_dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(w16_s2, a), __builtin_bit_cast(w16_s2, b), c, false);
+}
+
+/* NCH channels (1: a plane, 4 output columns per lane; 2: the two chroma channels of an interleaved source and / or target, 2 output
+ * columns of each per lane — the same four samples and the same register budget either way) */
+template <int HT, int VT, int NCH>
+__device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Args &A, int f, int strip, int cb, int lane)
+{
+    constexpr int R = VT - 1;          /* ring slots: pairs that end at rows r, r-1, ..., r-(VT-2) */
+    constexpr int HP = HT / 2, VP = VT / 2;
+    constexpr int NC = NCH == 2 ? 2 : 4;
+    const int X0 = (cb * 64 + lane) * NC;
+    const int y0 = strip * J.strip_rows, y1 = min(y0 + J.strip_rows, J.dstH);
+    const int hsh = A.sdepth - 1, vsh = 27 - A.ddepth;
+    const int smsb = A.smsb ? 16 - A.sdepth : 0, dmsb = A.dmsb ? 16 - A.ddepth : 0;
+    const int maxv = (1 << A.ddepth) - 1;
+    const bool sil = J.sstep == 2, dil = J.dstep == 2;
+
+    /* ---- horizontal descriptors of this lane's columns ---- */
+    uint32_t soff[NC];         /* byte offset of the window's first sample in a source row (planar: of the even sample at or below it) */
+    uint32_t sodd[NC];         /* planar: 2 when the window starts at an odd sample (the funnel shift), else 0 */
+    uint32_t cf[NC][HP];
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        const int xi = min(X0 + i, J.dstW - 1);
+        const uint32_t hp = (uint32_t)J.hp[xi];
+        soff[i] = sil ? hp * 4u : (hp & ~1u) * 2u;
+        sodd[i] = sil ? 0u : (hp & 1u) * 2u;
+#pragma unroll
+        for (int m = 0; m < HP; m++)
+            cf[i][m] = reinterpret_cast<const uint32_t *>(J.hf)[(size_t)xi * HP + m];
+    }
+    const uint8_t *const sb0 = J.src[0] + (size_t)f * J.sfp[0], *const sb1 = NCH == 2 ? J.src[1] + (size_t)f * J.sfp[1] : sb0;
+    uint8_t *const db0 = J.dst[0] + (size_t)f * J.dfp[0], *const db1 = NCH == 2 ? J.dst[1] + (size_t)f * J.dfp[1] : db0;
+
+    /* the sample PAIRS of one source row, per channel and column: pr[ch][i][m] = (s[2m], s[2m + 1]) of the window */
+    struct Row { uint32_t pr[NCH][NC][HP]; };
+    auto load_row = [&](Row &o, int row) {
+        const int rr = min(row, J.srcH - 1);
+        if (NCH == 2 && sil) {
+            /* HT (u, v) dwords per column, split into the two channels' pairs */
+            const uint8_t *p = sb0 + (ptrdiff_t)rr * J.sstride[0];
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                uint32_t q[HT];
+                const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + soff[i]);
+                q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+                if (HT == 8) {
+                    const w16_u4 w = *reinterpret_cast<const w16_u4d *>(p + soff[i] + 16);
+                    q[4 % HT] = w.x; q[5 % HT] = w.y; q[6 % HT] = w.z; q[7 % HT] = w.w;
+                }
+#pragma unroll
+                for (int m = 0; m < HP; m++) {
+                    o.pr[0][i][m] = __builtin_amdgcn_perm(q[2 * m + 1], q[2 * m], 0x05040100u);
+                    o.pr[NCH - 1][i][m] = __builtin_amdgcn_perm(q[2 * m + 1], q[2 * m], 0x07060302u);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            /* a planar row: the window starts at an even or an odd sample.  ALIGNED dwords from the even sample below it (a
+             * 2-byte-aligned 8-byte load is split by the texture addresser: PMC 46 % issue stalls), the last one only when the
+             * window's last sample lies in it, and a funnel shift by the lane's 0 or 2 bytes */
+            const uint8_t *p = (ch ? sb1 : sb0) + (ptrdiff_t)rr * J.sstride[ch];
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                uint32_t q[HP + 1];
+                if (HT == 4) {
+                    const w16_u2 v = *reinterpret_cast<const w16_u2d *>(p + soff[i]);
+                    q[0] = v.x; q[1] = v.y;
+                } else {
+                    const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + soff[i]);
+                    q[0] = v.x; q[1] = v.y; q[2 % (HP + 1)] = v.z; q[3 % (HP + 1)] = v.w;
+                }
+                q[HP] = 0;
+                if (sodd[i])
+                    q[HP] = *reinterpret_cast<const uint32_t *>(p + soff[i] + 4 * HP);
+#pragma unroll
+                for (int m = 0; m < HP; m++)
+                    o.pr[ch][i][m] = __builtin_amdgcn_alignbyte(q[m + 1], q[m], sodd[i]);
+            }
+        }
+    };
+
+    uint32_t ring[R][NCH][NC];
+    int hprev[NCH][NC];
+#pragma unroll
+    for (int s = 0; s < R; s++)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+            for (int i = 0; i < NC; i++)
+                ring[s][ch][i] = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+            hprev[ch][i] = 0;
+
+    auto hpass = [&](const Row &w, uint32_t (&Pnew)[NCH][NC]) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                int acc = 0;
+#pragma unroll
+                for (int m = 0; m < HP; m++) {
+                    uint32_t s = w.pr[ch][i][m];
+                    if (smsb)
+                        s = __builtin_bit_cast(uint32_t, __builtin_bit_cast(w16_h2, s) >> (unsigned short)smsb);
+                    acc = w16_dot2(s, cf[i][m], acc);
+                }
+                const int h = acc >> hsh;
+                /* saturating pack == FFMIN(., 32767) + truncation: no bank row can produce a sum below -32768 (host-checked) */
+                Pnew[ch][i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[ch][i], h));
+                hprev[ch][i] = h;
+            }
+    };
+
+    /* ---- the walk ---- */
+    /* the strip's vertical descriptors (<= 64 output rows): lane l holds row y0 + l's window position and coefficient pairs, a row's
+     * are then one v_readlane each instead of a chain of dependent scalar loads per output row */
+    int vpl;
+    uint32_t vcl[VP];
+    {
+        const int y = min(y0 + lane, J.dstH - 1);
+        vpl = J.vp[y];
+#pragma unroll
+        for (int m = 0; m < VP; m++)
+            vcl[m] = reinterpret_cast<const uint32_t *>(J.vf)[(size_t)y * VP + m];
+    }
+    int yy = y0;
+    int need = __builtin_amdgcn_readlane(vpl, 0) + VT - 1;
+    const int rlast = __builtin_amdgcn_readlane(vpl, y1 - 1 - y0) + VT - 1;
+    int r = need - (VT - 1);
+    Row cur, nxt;
+    load_row(cur, r);
+    const int kround = 1 << (vsh - 1);
+    while (r <= rlast) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int rr = r + k;
+            if (rr <= rlast) { /* uniform */
+                load_row(nxt, rr + 1);
+                hpass(cur, ring[k]);
+                while (yy < y1 && need <= rr) {
+                    /* the row's VT coefficients as VT / 2 pairs: wave-uniform, scalar loads */
+                    uint32_t vc[VP];
+#pragma unroll
+                    for (int m = 0; m < VP; m++)
+                        vc[m] = (uint32_t)__builtin_amdgcn_readlane((int)vcl[m], yy - y0);
+                    uint32_t o[NCH][NC / 2];
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ch++) {
+                        int t[NC];
+#pragma unroll
+                        for (int i = 0; i < NC; i++) {
+                            int acc = kround;
+                            /* pair m covers rows need - VT + 1 + 2m, + 2m + 1: it ends at rr - (VT - 2 - 2m) -> slot (k - (VT - 2 - 2m)) mod R */
+#pragma unroll
+                            for (int m = 0; m < VP; m++)
+                                acc = w16_dot2(ring[((k - (VT - 2 - 2 * m)) % R + R) % R][ch][i], vc[m], acc);
+                            t[i] = min(max(acc >> vsh, 0), maxv) << dmsb;
+                        }
+#pragma unroll
+                        for (int i = 0; i < NC / 2; i++)
+                            o[ch][i] = (uint32_t)t[2 * i] | ((uint32_t)t[2 * i + 1] << 16);
+                    }
+                    if (X0 < J.dstW) {
+                        if (NCH == 2 && dil) {
+                            /* (u0, v0) (u1, v1): 8 bytes */
+                            uint8_t *d = db0 + (ptrdiff_t)yy * J.dstride[0] + (size_t)X0 * 4;
+                            const uint32_t uv0 = __builtin_amdgcn_perm(o[NCH - 1][0], o[0][0], 0x05040100u);
+                            const uint32_t uv1 = __builtin_amdgcn_perm(o[NCH - 1][0], o[0][0], 0x07060302u);
+                            if (X0 + 2 <= J.dstW) {
+                                w16_u2 s;
+                                s.x = uv0; s.y = uv1;
+                                *reinterpret_cast<w16_u2d *>(d) = s;
+                            } else {
+                                *reinterpret_cast<uint32_t *>(d) = uv0;
+                            }
+                        } else if (NCH == 2) {
+                            /* two samples of each channel into its own plane */
+                            uint8_t *du = db0 + (ptrdiff_t)yy * J.dstride[0] + (size_t)X0 * 2, *dv = db1 + (ptrdiff_t)yy * J.dstride[1] + (size_t)X0 * 2;
+                            if (X0 + 2 <= J.dstW) {
+                                *reinterpret_cast<uint32_t *>(du) = o[0][0];
+                                *reinterpret_cast<uint32_t *>(dv) = o[NCH - 1][0];
+                            } else {
+                                *reinterpret_cast<uint16_t *>(du) = (uint16_t)o[0][0];
+                                *reinterpret_cast<uint16_t *>(dv) = (uint16_t)o[NCH - 1][0];
+                            }
+                        } else {
+                            uint8_t *d = db0 + (ptrdiff_t)yy * J.dstride[0] + (size_t)X0 * 2;
+                            if (X0 + 4 <= J.dstW) {
+                                w16_u2 s;
+                                s.x = o[0][0]; s.y = o[0][NC / 2 - 1];
+                                *reinterpret_cast<w16_u2a *>(d) = s;
+                            } else { /* the ragged last group of a row (no array indexed by a loop counter: that would live in scratch memory) */
+                                reinterpret_cast<uint16_t *>(d)[0] = (uint16_t)o[0][0];
+                                if (X0 + 1 < J.dstW) reinterpret_cast<uint16_t *>(d)[1] = (uint16_t)(o[0][0] >> 16);
+                                if (X0 + 2 < J.dstW) reinterpret_cast<uint16_t *>(d)[2] = (uint16_t)o[0][NC / 2 - 1];
+                            }
+                        }
+                    }
+                    yy++;
+                    if (yy < y1)
+                        need = __builtin_amdgcn_readlane(vpl, yy - y0) + VT - 1;
+                }
+                cur = nxt;
+            }
+        }
+        r += R;
+    }
+}
+
+template <int HT, int VT>
+__global__ __launch_bounds__(256) void k_sws_walk16(FFHipW16Args A)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
+    if (gw >= (uint32_t)A.units_per_frame * (uint32_t)A.nframes)
+        return;
+    const int f = (int)(gw / (uint32_t)A.units_per_frame);
+    const int u = (int)(gw - (uint32_t)f * (uint32_t)A.units_per_frame);
+    int j = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
+    const FFHipW16Job &J = A.job[j];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.nch == 2) /* (both forms keep four samples per lane: the same register budget) */
+        w16_unit<HT, VT, 2>(J, A, f, strip, cb, lane);
+    else
+        w16_unit<HT, VT, 1>(J, A, f, strip, cb, lane);
+}
+
+/* ================================================================================================== */
+/* host side */
+
+/* A bank of `size` taps as one of `T` taps (size <= T): zero taps appended, the window pulled back inside the plane at the far
+ * edge (pos + T <= nsrc).  Returns false when the plane is narrower than T samples. */
+bool ffhip_w16_pad_bank(const int16_t *filter, const int32_t *pos, int size, int n, int nsrc, int T, std::vector<int16_t> *of, std::vector<int32_t> *op)
+{
+    if (size > T || nsrc < T)
+        return false;
+    of->assign((size_t)n * T, 0);
+    op->assign((size_t)n, 0);
+    for (int x = 0; x < n; x++) {
+        int p = pos[x];
+        if (p < 0)
+            return false;
+        int np = p + T <= nsrc ? p : nsrc - T;
+        const int sh = p - np;
+        for (int j = 0; j < size; j++) {
+            const int16_t c = filter[(size_t)x * size + j];
+            if (!c)
+                continue;
+            if (sh + j >= T || p + j >= nsrc)
+                return false;
+            (*of)[(size_t)x * T + sh + j] = c;
+        }
+        (*op)[x] = np;
+    }
+    return true;
+}
+
+void ffhip_w16_plan_job(FFHipW16Job *j, int strip_target)
+{
+    j->ncb = cdiv(j->dstW, j->nch == 2 ? 128 : 256); /* 64 lanes x 4 columns of a plane / 2 columns of both channels */
+    const int n = cdiv(j->dstH, strip_target > 0 ? strip_target : 1);
+    j->strip_rows = cdiv(j->dstH, n);
+    j->nstrips = cdiv(j->dstH, j->strip_rows);
+}
+
+int ffhip_launch_walk16(FFHipW16Args &A, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    int u = 0;
+    for (int i = 0; i < A.njobs; i++) {
+        A.job[i].unit_begin = u;
+        u += A.job[i].ncb * A.job[i].nstrips;
+    }
+    A.units_per_frame = u;
+    const long long waves = (long long)u * A.nframes;
+    if (waves >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
+        return FFHIP_EINVAL;
+    }
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (A.ht == 4 && A.vt == 4)
+        hipLaunchKernelGGL((k_sws_walk16<4, 4>), grid, block, 0, stream, A);
+    else if (A.ht == 8 && A.vt == 4)
+        hipLaunchKernelGGL((k_sws_walk16<8, 4>), grid, block, 0, stream, A);
+    else if (A.ht == 4 && A.vt == 8)
+        hipLaunchKernelGGL((k_sws_walk16<4, 8>), grid, block, 0, stream, A);
+    else
+        hipLaunchKernelGGL((k_sws_walk16<8, 8>), grid, block, 0, stream, A);
+    LAUNCH_CHECK();
+    return 0;
+}

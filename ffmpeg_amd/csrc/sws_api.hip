@@ -47,6 +47,11 @@ struct FFHipSwsContext {
     void *dev_wtables = nullptr;
     FFHipDevFilter dw[4];
     /* exact-2x fast path (sws_up2.hip): virtual banks (regular windows of the edge-replicated rows) on the device */
+    /* the column walker above 8 bits (sws_walk16.hip): banks padded to w16_ht x w16_vt taps on the device */
+    int w16_ok = 0, w16_ht = 0, w16_vt = 0;
+    void *w16_dev = nullptr;
+    const int16_t *w16_f[4] = { nullptr, nullptr, nullptr, nullptr };
+    const int32_t *w16_p[4] = { nullptr, nullptr, nullptr, nullptr };
     int up2_ok = 0;
     int up2_rc = 0; /* a range-converting context: the exact-2x kernel with the range stage is its only fast kernel */
     void *up2_dev = nullptr;
@@ -492,6 +497,39 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 !(t->dstW & 3) && t->dstW >= 12 && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
                 dn2_build(c, limits);
+            /* every other ratio between 9..14-bit formats whose banks have at most 8 taps: the 16-bit column walker (sws_walk16.hip);
+             * no range change (it carries no range stage), no 8-bit side */
+            if (!c->up2_ok && !c->dn2_ok && sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl != 2 && dl != 2 && t->src_range == t->dst_range &&
+                c->d[0].size <= 8 && c->d[1].size <= 8 && c->d[2].size <= 8 && c->d[3].size <= 8 &&
+                bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size)) {
+                const int ht = c->d[0].size <= 4 && c->d[1].size <= 4 ? 4 : 8, vt = c->d[2].size <= 4 && c->d[3].size <= 4 ? 4 : 8;
+                const int T[4] = { ht, ht, vt, vt };
+                std::vector<int16_t> pf[4];
+                std::vector<int32_t> pp[4];
+                bool ok = true;
+                for (int i = 0; i < 4 && ok; i++)
+                    ok = ffhip_w16_pad_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, limits[i], T[i], &pf[i], &pp[i]);
+                size_t off[8], tot = 0;
+                for (int i = 0; i < 4; i++) {
+                    off[2 * i] = tot;     tot += (pf[i].size() * 2 + 255) & ~(size_t)255;
+                    off[2 * i + 1] = tot; tot += (pp[i].size() * 4 + 255) & ~(size_t)255;
+                }
+                if (ok && hipMalloc(&c->w16_dev, tot) == hipSuccess) {
+                    uint8_t *b = static_cast<uint8_t *>(c->w16_dev);
+                    for (int i = 0; i < 4 && ok; i++)
+                        ok = hipMemcpy(b + off[2 * i], pf[i].data(), pf[i].size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+                             hipMemcpy(b + off[2 * i + 1], pp[i].data(), pp[i].size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+                    if (ok) {
+                        for (int i = 0; i < 4; i++) {
+                            c->w16_f[i] = reinterpret_cast<const int16_t *>(b + off[2 * i]);
+                            c->w16_p[i] = reinterpret_cast<const int32_t *>(b + off[2 * i + 1]);
+                        }
+                        c->w16_ht = ht;
+                        c->w16_vt = vt;
+                        c->w16_ok = 1;
+                    }
+                }
+            }
         }
         return c;
     }
@@ -676,7 +714,7 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -723,6 +761,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->mf_dev);
     if (c->up2_dev)
         (void)hipFree(c->up2_dev);
+    if (c->w16_dev)
+        (void)hipFree(c->w16_dev);
     if (c->dn2_dev)
         (void)hipFree(c->dn2_dev);
     if (c->dev_ntables)
@@ -832,6 +872,51 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 dnjob(1, 2, c->d[1].n, c->chrSrcH, c->d[3].n, 0);
             }
             return ffhip_launch_down2(D, stream);
+        }
+    }
+    {
+        const char *ew = FFHIP_KNOB("FFHIP_SWS_WALK16"); /* measured variant: 0 = the tiled k_sws_scale16 */
+        uintptr_t al = 0;
+        bool neg = false;
+        for (int pl = 0; pl < (sl ? 2 : 3); pl++) {
+            al |= (uintptr_t)src[pl] | (uintptr_t)srcStride[pl] | srcFramePitch[pl];
+            neg = neg || srcStride[pl] < 0;
+        }
+        for (int pl = 0; pl < (dl ? 2 : 3); pl++) {
+            al |= (uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl];
+            neg = neg || dstStride[pl] < 0;
+        }
+        if (c->w16_ok && !(al & 3) && !neg && !(ew && ew[0] == '0')) {
+            FFHipW16Args W;
+            memset(&W, 0, sizeof(W));
+            W.nframes = nframes;
+            W.ht = c->w16_ht; W.vt = c->w16_vt;
+            W.sdepth = sd; W.ddepth = dd; W.smsb = sl == 1; W.dmsb = dl == 1;
+            auto job = [&](int which, int nch, int splane0, int dplane0) {
+                FFHipW16Job &j = W.job[W.njobs++];
+                j.nch = nch;
+                j.sstep = which && sl ? 2 : 1; j.dstep = which && dl ? 2 : 1;
+                for (int k = 0; k < nch; k++) {
+                    /* an interleaved side: both channels live in plane 1, the second two bytes on; a planar side: planes 1 and 2 */
+                    const int sp = which && sl ? 1 : splane0 + k, dp = which && dl ? 1 : dplane0 + k;
+                    j.src[k] = static_cast<const uint8_t *>(src[sp]) + (which && sl ? 2 * k : 0);
+                    j.dst[k] = static_cast<uint8_t *>(dst[dp]) + (which && dl ? 2 * k : 0);
+                    j.sstride[k] = srcStride[sp]; j.dstride[k] = dstStride[dp];
+                    j.sfp[k] = srcFramePitch[sp]; j.dfp[k] = dstFramePitch[dp];
+                }
+                j.srcH = which ? c->chrSrcH : t.srcH;
+                j.dstW = c->d[which].n; j.dstH = c->d[2 + which].n;
+                j.hf = c->w16_f[which]; j.hp = c->w16_p[which]; j.vf = c->w16_f[2 + which]; j.vp = c->w16_p[2 + which];
+                ffhip_w16_plan_job(&j, 64);
+            };
+            job(0, 1, 0, 0);
+            if (sl || dl) {
+                job(1, 2, 1, 1);
+            } else {
+                job(1, 1, 1, 1);
+                job(1, 1, 2, 2);
+            }
+            return ffhip_launch_walk16(W, stream);
         }
     }
     FFHipScale16Args a;

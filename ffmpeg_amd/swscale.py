@@ -129,6 +129,16 @@ class SwsContext:
         return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 4)
 
     @property
+    def paths(self):
+        """the bit set of ffhip_sws_fast_path: 1 column walker, 2 mfma, 4 wide walker, 8 exact 2x, 16 exact 2:1, 32 16-bit walker"""
+        return int(_lib.lib().ffhip_sws_fast_path(self._c))
+
+    @property
+    def walk16_path(self):
+        """True when the 16-bit column walker (k_sws_walk16) serves the banks."""
+        return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 32)
+
+    @property
     def up2_path(self):
         """True when the static-schedule exact-2x kernel (k_sws_up2) serves the banks."""
         return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 8)

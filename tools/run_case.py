@@ -12,6 +12,8 @@ from ffmpeg_amd import swscale as S  # noqa: E402
 
 a = sys.argv[1:]
 sf, sw, sh, df, dw, dh = a[0], int(a[1]), int(a[2]), a[3], int(a[4]), int(a[5])
+S.PIX_FMT.setdefault("p010", 158)        # AV_PIX_FMT_P010LE / YUV420P10LE (include/ffhip.h FFHIP_PIX_FMT_*)
+S.PIX_FMT.setdefault("yuv420p10", 62)
 flags = int(a[6], 0) if len(a) > 6 else S.SWS_BICUBIC
 n = int(a[7]) if len(a) > 7 else 32
 reps = int(a[8]) if len(a) > 8 else 5
@@ -20,6 +22,10 @@ ctx = S.SwsContext(sw, sh, S.PIX_FMT[sf], dw, dh, S.PIX_FMT[df], flags)
 g = torch.Generator(device=dev).manual_seed(1)
 src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev, generator=g) for r, c in S.plane_shapes(S.PIX_FMT[sf], sw, sh)]
 dst = [torch.zeros((n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(S.PIX_FMT[df], dw, dh)]
+for name, planes in ((sf, src),):
+    if name in ("p010", "yuv420p10"):    # valid 10-bit samples: the low 10 bits of the word (planar) or the high 10 (P010)
+        for t_ in planes:
+            t_.view(torch.int16).bitwise_and_(0x03FF if name == "yuv420p10" else -64)
 ctx.scale_batch(src, dst)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,5 +36,5 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 byt = n * (S.frame_bytes(S.PIX_FMT[sf], sw, sh) + S.frame_bytes(S.PIX_FMT[df], dw, dh))
-print(json.dumps({"case": " ".join(a[:6]), "fast_path": ctx.fast_path, "frames": n, "ms": round(ms, 4),
+print(json.dumps({"case": " ".join(a[:6]), "fast_path": ctx.fast_path, "paths": ctx.paths, "frames": n, "ms": round(ms, 4),
                   "Mpix/s": round(n * dw * dh / ms / 1e3, 1), "GB/s": round(byt / ms / 1e6, 1), "hbm_frac": round(byt / ms / 8e9, 4)}))
