@@ -44,6 +44,74 @@ __device__ __forceinline__ int w16_dot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(w16_s2, a), __builtin_bit_cast(w16_s2, b), c, false);
 }
 
+/*
+ * Hand-scheduled dot products, as in the 8-bit walkers: hipcc selects the accumulate-in-place VOP2 form v_dot2c_i32_i16 for the builtin,
+ * which costs a v_mov per chain to seed the accumulator; the VOP3P form takes the seed as a third source.  Hazards inside an asm
+ * block are ours (gfx950: a DOT result may feed the same opcode as src2 at once, any other VALU only after 3 wait states): four
+ * chains are interleaved and a block ends in s_nop 2.  Operands are int16 pairs; a*[c] / b*[c] belong to chain c.
+ */
+/* d[c] = a0[c] . b0[c] + a1[c] . b1[c] */
+__device__ __forceinline__ void w16_dots_first(int (&d)[4], const uint32_t (&a0)[4], const uint32_t (&a1)[4], const uint32_t (&b0)[4], const uint32_t (&b1)[4])
+{
+    asm("v_dot2_i32_i16 %0, %4, %12, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %13, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %14, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %15, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %18, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
+          "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]));
+}
+/* d[c] += a0[c] . b0[c] + a1[c] . b1[c] */
+__device__ __forceinline__ void w16_dots_more(int (&d)[4], const uint32_t (&a0)[4], const uint32_t (&a1)[4], const uint32_t (&b0)[4], const uint32_t (&b1)[4])
+{
+    asm("v_dot2_i32_i16 %0, %4, %12, %0\n\t"
+        "v_dot2_i32_i16 %1, %5, %13, %1\n\t"
+        "v_dot2_i32_i16 %2, %6, %14, %2\n\t"
+        "v_dot2_i32_i16 %3, %7, %15, %3\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %18, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "s_nop 2"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+        : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
+          "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]));
+}
+/* the vertical form: wave-uniform coefficient pairs (one SGPR operand per instruction); FIRST: d[c] = seed + ..., else d[c] += ... */
+template <bool FIRST>
+__device__ __forceinline__ void w16_vdots(int (&d)[4], const uint32_t (&a0)[4], const uint32_t (&a1)[4], uint32_t f0, uint32_t f1, int seed)
+{
+    if (FIRST)
+        asm("v_dot2_i32_i16 %0, %4, %12, %14\n\t"
+            "v_dot2_i32_i16 %1, %5, %12, %14\n\t"
+            "v_dot2_i32_i16 %2, %6, %12, %14\n\t"
+            "v_dot2_i32_i16 %3, %7, %12, %14\n\t"
+            "v_dot2_i32_i16 %0, %8, %13, %0\n\t"
+            "v_dot2_i32_i16 %1, %9, %13, %1\n\t"
+            "v_dot2_i32_i16 %2, %10, %13, %2\n\t"
+            "v_dot2_i32_i16 %3, %11, %13, %3\n\t"
+            "s_nop 2"
+            : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+            : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "s"(f0), "s"(f1), "v"(seed));
+    else
+        asm("v_dot2_i32_i16 %0, %4, %12, %0\n\t"
+            "v_dot2_i32_i16 %1, %5, %12, %1\n\t"
+            "v_dot2_i32_i16 %2, %6, %12, %2\n\t"
+            "v_dot2_i32_i16 %3, %7, %12, %3\n\t"
+            "v_dot2_i32_i16 %0, %8, %13, %0\n\t"
+            "v_dot2_i32_i16 %1, %9, %13, %1\n\t"
+            "v_dot2_i32_i16 %2, %10, %13, %2\n\t"
+            "v_dot2_i32_i16 %3, %11, %13, %3\n\t"
+            "s_nop 2"
+            : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+            : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "s"(f0), "s"(f1));
+}
+
 /* NCH channels (1: a plane, 4 output columns per lane; 2: the two chroma channels of an interleaved source and / or target, 2 output
  * columns of each per lane — the same four samples and the same register budget either way) */
 template <int HT, int VT, int NCH>
@@ -141,24 +209,35 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
         for (int i = 0; i < NC; i++)
             hprev[ch][i] = 0;
 
+    /* the four chains of a lane, c = ch * NC + i, operands gathered pair by pair */
+    uint32_t cfc[HP][4];
+#pragma unroll
+    for (int m = 0; m < HP; m++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            cfc[m][c] = cf[c % NC][m];
     auto hpass = [&](const Row &w, uint32_t (&Pnew)[NCH][NC]) {
+        uint32_t sp[HP][4];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++)
+        for (int m = 0; m < HP; m++)
 #pragma unroll
-            for (int i = 0; i < NC; i++) {
-                int acc = 0;
-#pragma unroll
-                for (int m = 0; m < HP; m++) {
-                    uint32_t s = w.pr[ch][i][m];
-                    if (smsb)
-                        s = __builtin_bit_cast(uint32_t, __builtin_bit_cast(w16_h2, s) >> (unsigned short)smsb);
-                    acc = w16_dot2(s, cf[i][m], acc);
-                }
-                const int h = acc >> hsh;
-                /* saturating pack == FFMIN(., 32767) + truncation: no bank row can produce a sum below -32768 (host-checked) */
-                Pnew[ch][i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[ch][i], h));
-                hprev[ch][i] = h;
+            for (int c = 0; c < 4; c++) {
+                uint32_t s = w.pr[c / NC][c % NC][m];
+                if (smsb)
+                    s = __builtin_bit_cast(uint32_t, __builtin_bit_cast(w16_h2, s) >> (unsigned short)smsb);
+                sp[m][c] = s;
             }
+        int acc[4];
+        w16_dots_first(acc, sp[0], sp[1], cfc[0], cfc[1]);
+        if (HP == 4)
+            w16_dots_more(acc, sp[2 % HP], sp[3 % HP], cfc[2 % HP], cfc[3 % HP]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int h = acc[c] >> hsh;
+            /* saturating pack == FFMIN(., 32767) + truncation: no bank row can produce a sum below -32768 (host-checked) */
+            Pnew[c / NC][c % NC] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c / NC][c % NC], h));
+            hprev[c / NC][c % NC] = h;
+        }
     };
 
     /* ---- the walk ---- */
@@ -194,21 +273,30 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                     for (int m = 0; m < VP; m++)
                         vc[m] = (uint32_t)__builtin_amdgcn_readlane((int)vcl[m], yy - y0);
                     uint32_t o[NCH][NC / 2];
+                    {
+                        /* pair m covers rows need - VT + 1 + 2m, + 2m + 1: it ends at rr - (VT - 2 - 2m) -> slot (k - (VT - 2 - 2m)) mod R */
+                        uint32_t pp[VP][4];
 #pragma unroll
-                    for (int ch = 0; ch < NCH; ch++) {
-                        int t[NC];
+                        for (int m = 0; m < VP; m++)
 #pragma unroll
-                        for (int i = 0; i < NC; i++) {
-                            int acc = kround;
-                            /* pair m covers rows need - VT + 1 + 2m, + 2m + 1: it ends at rr - (VT - 2 - 2m) -> slot (k - (VT - 2 - 2m)) mod R */
+                            for (int c = 0; c < 4; c++)
+                                pp[m][c] = ring[((k - (VT - 2 - 2 * m)) % R + R) % R][c / NC][c % NC];
+                        int t[4];
+                        w16_vdots<true>(t, pp[0], pp[1], vc[0], vc[1], kround);
+                        if (VP == 4)
+                            w16_vdots<false>(t, pp[2 % VP], pp[3 % VP], vc[2 % VP], vc[3 % VP], 0);
+                        /* >> (27 - bits), then the clip to 0 .. 2^bits - 1 on int16 pairs (v_cvt_pk_i16_i32 saturates to int16: the
+                         * clip range lies inside) and P01x's alignment */
 #pragma unroll
-                            for (int m = 0; m < VP; m++)
-                                acc = w16_dot2(ring[((k - (VT - 2 - 2 * m)) % R + R) % R][ch][i], vc[m], acc);
-                            t[i] = min(max(acc >> vsh, 0), maxv) << dmsb;
+                        for (int c = 0; c < 4; c += 2) {
+                            w16_s2 pk = __builtin_amdgcn_cvt_pk_i16(t[c] >> vsh, t[c + 1] >> vsh);
+                            const w16_s2 zero = { 0, 0 }, top = { (short)maxv, (short)maxv };
+                            pk = __builtin_elementwise_min(__builtin_elementwise_max(pk, zero), top);
+                            uint32_t v = __builtin_bit_cast(uint32_t, pk);
+                            if (dmsb)
+                                v = __builtin_bit_cast(uint32_t, __builtin_bit_cast(w16_h2, v) << (unsigned short)dmsb);
+                            o[c / NC][(c % NC) / 2] = v;
                         }
-#pragma unroll
-                        for (int i = 0; i < NC / 2; i++)
-                            o[ch][i] = (uint32_t)t[2 * i] | ((uint32_t)t[2 * i + 1] << 16);
                     }
                     if (X0 < J.dstW) {
                         if (NCH == 2 && dil) {
