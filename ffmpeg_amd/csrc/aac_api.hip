@@ -174,9 +174,9 @@ extern "C" int ffhip_aac_imdct_create_len(FFHipAacImdct **pc, int frame_len, con
     const int L = frame_len, S = L / 8;
     c->L = L;
     c->in_short = L == 768 ? 96 : 128; /* imdct_and_windowing_768 reads in + i * 96, the other two in + i * 128 */
-    int r = ffhip_tx_init(&c->tx1024, nullptr, FFHIP_TX_FLOAT_MDCT, 1, L, &scale_long, 0);
+    int r = ffhip_tx_init(&c->tx1024, nullptr, FFHIP_TX_FLOAT_MDCT, 1, L, &scale_long, FFHIP_TX_BITEXACT);
     if (r >= 0)
-        r = ffhip_tx_init(&c->tx128, nullptr, FFHIP_TX_FLOAT_MDCT, 1, S, &scale_short, 0);
+        r = ffhip_tx_init(&c->tx128, nullptr, FFHIP_TX_FLOAT_MDCT, 1, S, &scale_short, FFHIP_TX_BITEXACT);
     std::vector<float> w(4 * 1024, 0.0f);
     memcpy(&w[0], sine_long, L * sizeof(float));
     memcpy(&w[1024], sine_short, S * sizeof(float));
@@ -649,7 +649,7 @@ extern "C" int ffhip_aac_ltp_init(FFHipAacImdct *c, float scale_ltp)
         return FFHIP_EINVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     ffhip_tx_uninit(&c->tx_ltp);
-    return ffhip_tx_init(&c->tx_ltp, nullptr, FFHIP_TX_FLOAT_MDCT, 0, 1024, &scale_ltp, 0);
+    return ffhip_tx_init(&c->tx_ltp, nullptr, FFHIP_TX_FLOAT_MDCT, 0, 1024, &scale_ltp, FFHIP_TX_BITEXACT);
 }
 
 extern "C" int ffhip_aac_ltp_predict_batch_dev(FFHipAacImdct *c, const float *ltp_state, float *pred_freq, const FFHipAacLtp *recs, int n,
@@ -795,7 +795,7 @@ extern "C" int ffhip_aac_ld_create(FFHipAacLd **pc, int eld, int frame_len, cons
         return FFHIP_ENOMEM;
     c->eld = !!eld;
     c->n = frame_len;
-    int r = ffhip_tx_init(&c->tx, nullptr, FFHIP_TX_FLOAT_MDCT, 1, frame_len, &scale, 0);
+    int r = ffhip_tx_init(&c->tx, nullptr, FFHIP_TX_FLOAT_MDCT, 1, frame_len, &scale, FFHIP_TX_BITEXACT);
     const size_t nw = eld ? (size_t)frame_len * 15 / 4 : 512 + 128;
     std::vector<float> w(nw);
     if (eld) {

@@ -1,0 +1,18 @@
+/* tx_kernels.h — launchers of kernels/tx_radix.hip (the register-resident FFT / MDCT of 256 .. 1024 complex points) */
+#ifndef FFHIP_TX_KERNELS_H
+#define FFHIP_TX_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+/* n complex points are served by the radix kernels */
+bool ffhip_tx_radix_ok(int n);
+
+/* wtab: n entries exp(-2 pi i k / n) on the device.  Rows 8-byte aligned and contiguous. */
+int ffhip_launch_fft_r(int n, int inv, const float2 *wtab, const float *in, size_t in_pitch, float *out, size_t out_pitch, int nt,
+                       hipStream_t stream);
+/* exptab: the context's ff_tx_mdct_gen_exp table (n entries, natural order, scale folded in) */
+int ffhip_launch_mdct_r(int n, int inv, const float2 *wtab, const float2 *exptab, const float *in, size_t in_pitch, float *out,
+                        size_t out_pitch, int nt, hipStream_t stream);
+
+#endif

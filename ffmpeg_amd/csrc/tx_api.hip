@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "kernels/common.h"
+#include "kernels/tx_kernels.h"
 
 struct TxDev {
     int n, lg;                 /* complex FFT size (= len/2) and its log2                         */
@@ -66,6 +67,7 @@ struct FFHipTXContext {
     TxPfa pfa = {};
     void *dev = nullptr;
     size_t blob_bytes = 0;   /* size of the table blob at `dev` (multiple of 16) */
+    float2 *wtab = nullptr;  /* exp(-2 pi i k / n), k < n: the register-resident kernels' twiddles (kernels/tx_radix.hip), or null */
     /* host-pointer shim staging */
     void *stage = nullptr;
     size_t stage_sz = 0;
@@ -1223,6 +1225,8 @@ extern "C" void ffhip_tx_uninit(FFHipTXContext **pctx)
     FFHipDeviceGuard dg(c->device);
     if (c->dev)
         (void)hipFree(c->dev);
+    if (c->wtab)
+        (void)hipFree(c->wtab);
     if (c->stage)
         (void)hipFree(c->stage);
     delete c;
@@ -1565,6 +1569,19 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     d.cos_tab = (const float *)(base + off_cos);
     d.sched = (const uint32_t *)(base + off_sched);
     d.blocks2 = (const uint16_t *)(base + off_b2);
+    if (!(flags & FFHIP_TX_BITEXACT) && (type == FFHIP_TX_FLOAT_FFT || type == FFHIP_TX_FLOAT_MDCT) && ffhip_tx_radix_ok(n)) {
+        std::vector<float2> w(n);
+        for (int k = 0; k < n; k++) {
+            const double a = 2 * M_PI * k / n;
+            w[k] = make_float2((float)cos(a), (float)-sin(a));
+        }
+        if (hipMalloc(&c->wtab, n * sizeof(float2)) != hipSuccess ||
+            hipMemcpy(c->wtab, w.data(), n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+            ffhip_set_error("ffhip_tx_init: table upload failed");
+            ffhip_tx_uninit(&c);
+            return FFHIP_ENOMEM;
+        }
+    }
     *pctx = c;
     if (fn)
         *fn = tx_single;
@@ -1713,6 +1730,11 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
             LAUNCH_CHECK();
             return 0;
         }
+        {
+            const char *er = FFHIP_KNOB("FFHIP_TX_RADIX");
+            if (c->wtab && !(er && er[0] == '0'))
+                return ffhip_launch_fft_r(n, c->inv, c->wtab, (const float *)in, in_pitch, (float *)out, out_pitch, nt, (hipStream_t)stream);
+        }
         if (tl) TX_LAUNCH((k_fft_z<true>)); else TX_LAUNCH((k_fft_z<false>));
         LAUNCH_CHECK();
         return 0;
@@ -1823,6 +1845,12 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         while (wpb > 1 && lds_z > 150 * 1024) {
             wpb >>= 1;
             lds_z = blob_lds + tx_z_bytes(n) * wpb;
+        }
+        if (es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7) && c->wtab) {
+            const char *er = FFHIP_KNOB("FFHIP_TX_RADIX");
+            if (!(er && er[0] == '0'))
+                return ffhip_launch_mdct_r(n, c->inv, c->wtab, c->d.exp, (const float *)in, in_pitch, (float *)out, out_pitch, nt,
+                                           (hipStream_t)stream);
         }
         if (es == 1 && !(((uintptr_t)in | in_pitch | (uintptr_t)out | out_pitch) & 7) && lds_z <= 150 * 1024 && !(ez && ez[0] == '0')) {
             int cus = 256, dev = 0;

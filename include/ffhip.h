@@ -1398,6 +1398,14 @@ typedef struct FFHipTXContext FFHipTXContext;
                                                   * libavutil/tx_template.c:1718-1827)                                                  */
 #define FFHIP_TX_REAL_TO_IMAGINARY (1ULL << 4)   /* == AV_TX_REAL_TO_IMAGINARY: ... the len/2 imaginary parts only (ff_tx_rdft_r2i, :1829); the last one
                                                   * is, as in the reference, the underlying FFT's own value.  Both forward-only (EINVAL otherwise) */
+#define FFHIP_TX_BITEXACT          (1ULL << 62)  /* libffhip's own (no AV_TX_ counterpart; av_tx_init() rejects unknown bits, so the wrapper never
+                                                  * forwards it): float FFT / MDCT contexts of 256, 512 and 1024 complex points run, by
+                                                  * default, a radix-16 / -8 / -4 factorisation held in registers (kernels/tx_radix.hip) whose
+                                                  * results agree with the C codelets within 2^-18 of a transform's largest output — the
+                                                  * position FFmpeg's own SIMD codelets are in (tests/checkasm/av_tx.c compares with an
+                                                  * epsilon).  With this flag the context runs the split-radix network in the C reference's
+                                                  * operation order instead: bit-identical to ff_tx_*_float_c, at about half the rate.  Every
+                                                  * other length and type is bit-identical either way. */
 /** av_tx_fn (libavutil/tx.h:151) with an opaque context of ours in place of AVTXContext. */
 typedef void (*ffhip_tx_fn)(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
 /**

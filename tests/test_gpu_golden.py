@@ -145,7 +145,7 @@ def test_tx_golden_gpu():
         _, inv, scale = key.split("_")
         len_ = int(key.split("_")[0][4:])
         x, want = d[key + "_in"], d[key + "_out"]
-        ctx = tx.TxContext(tx.FLOAT_MDCT, int(inv), len_, float(scale))
+        ctx = tx.TxContext(tx.FLOAT_MDCT, int(inv), len_, float(scale), flags=tx.BITEXACT)
         out = torch.zeros((x.shape[0], len_), dtype=torch.float32, device="cuda:0")
         ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
         got = out.cpu().numpy()
@@ -282,7 +282,7 @@ def test_fft_golden_gpu():
     for len_ in (8, 256, 1024):
         for inv in (0, 1):
             x, want = d["fft%d_%d_in" % (len_, inv)], d["fft%d_%d_out" % (len_, inv)]
-            ctx = tx.TxContext(tx.FLOAT_FFT, inv, len_, 1.0)
+            ctx = tx.TxContext(tx.FLOAT_FFT, inv, len_, 1.0, flags=tx.BITEXACT)
             out = torch.zeros((x.shape[0], 2 * len_), dtype=torch.float32, device="cuda:0")
             ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
             assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (len_, inv)
