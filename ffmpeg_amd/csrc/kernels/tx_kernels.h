@@ -7,6 +7,8 @@
 
 /* n complex points are served by the radix kernels */
 bool ffhip_tx_radix_ok(int n);
+/* ... the FFT alone also at 2048 .. 16384 (a team of n / 16 threads per transform) */
+bool ffhip_tx_radix_fft_ok(int n);
 
 /* wtab: n entries exp(-2 pi i k / n) on the device.  Rows 8-byte aligned and contiguous. */
 int ffhip_launch_fft_r(int n, int inv, const float2 *wtab, const float *in, size_t in_pitch, float *out, size_t out_pitch, int nt,

@@ -173,16 +173,12 @@ __device__ __forceinline__ void fr_pass(c32 (&v)[(1 << LG) / 64], const c32 (&w)
         } else {
             const int j = lane + 64 * b;
             const int base = (j / NS) * (NS * R) + (j & (NS - 1));
-            if constexpr ((NS * R) % 32 == 0) { /* the padding of base + k Ns is the padding of base plus a constant */
-                c32 *zb = z + FR_PAD(base);
+            /* the padding of base + k Ns is the padding of base plus a constant: base is a multiple of Ns R plus less than Ns, and
+             * either 32 divides Ns R or Ns R divides 32 (the butterfly's outputs stay inside one 32-element row) */
+            c32 *zb = z + FR_PAD(base);
 #pragma unroll
-                for (int k = 0; k < R; k++)
-                    zb[k * NS + ((k * NS) >> 5)] = a[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < R; k++)
-                    z[FR_PAD(base + k * NS)] = a[k];
-            }
+            for (int k = 0; k < R; k++)
+                zb[k * NS + ((NS * R) % 32 == 0 ? (k * NS) >> 5 : 0)] = a[k];
         }
     }
     if (!LAST) {
@@ -213,6 +209,141 @@ __device__ __forceinline__ void fr_core(c32 (&v)[(1 << LG) / 64], const FrTw<LG>
 
 constexpr int FR_WAVES = 4;
 __host__ __device__ constexpr size_t fr_z_bytes(int n) { return ((size_t)FR_PAD(n) * 8 + 15) & ~(size_t)15; }
+
+
+/* ---- 2048 .. 16384 points: a TEAM of T = N / 16 threads (two waves .. the whole 1024-thread workgroup) per transform, 16 points per
+ * thread, the work array in the workgroup's LDS with barriers between the passes (16384 = 16 x 16 x 16 x 4: three trips).  The
+ * inter-pass twiddles cannot stay in registers at 1024 threads (128 VGPRs each); a butterfly loads W^1, W^2, W^4, W^8 of its
+ * (j % Ns) from the table and forms the other eleven by one to three multiplications (error <= 3 ulp of a twiddle). ---- */
+template <int T>
+__device__ __forceinline__ void frw_sync()
+{
+    if (T > 64)
+        __syncthreads();
+    else
+        fr_sync();
+}
+
+template <int N, int T, int INV, int R, int NS, bool FIRST, bool LAST>
+__device__ __forceinline__ void frw_pass(c32 (&v)[N / T], const c32 *wtab, c32 *z, int tid)
+{
+    constexpr int P = N / T, B = P / R;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        c32 a[R];
+#pragma unroll
+        for (int t = 0; t < R; t++)
+            a[t] = v[b + B * t];
+        const int j = tid + T * b;
+        if (!FIRST) {
+            const int k1 = (j & (NS - 1)) * (N / (NS * R));
+            auto ld = [&](int k) {
+                c32 x = wtab[k];
+                if (INV)
+                    x.y = -x.y;
+                return x;
+            };
+            c32 w[R];
+            w[1] = ld(k1);
+            w[2] = ld(2 * k1);
+            w[3] = cmul(w[1], w[2]);
+            if constexpr (R > 4) {
+                w[4] = ld(4 * k1);
+#pragma unroll
+                for (int t = 5; t < 8; t++)
+                    w[t] = cmul(w[4], w[t - 4]);
+            }
+            if constexpr (R > 8) {
+                w[8] = ld(8 * k1);
+#pragma unroll
+                for (int t = 9; t < 16; t++)
+                    w[t] = cmul(w[8], w[t - 8]);
+            }
+#pragma unroll
+            for (int t = 1; t < R; t++)
+                a[t] = cmul(a[t], w[t]);
+        }
+        dft<INV, R>(a);
+        if (LAST) {
+#pragma unroll
+            for (int k = 0; k < R; k++)
+                v[b + B * k] = a[k];
+        } else {
+            const int base = (j / NS) * (NS * R) + (j & (NS - 1));
+            c32 *zb = z + FR_PAD(base);
+#pragma unroll
+            for (int k = 0; k < R; k++)
+                zb[k * NS + ((NS * R) % 32 == 0 ? (k * NS) >> 5 : 0)] = a[k]; /* as in fr_pass */
+        }
+    }
+    if (!LAST) {
+        frw_sync<T>();
+        const c32 *zl = z + FR_PAD(tid);
+#pragma unroll
+        for (int s = 0; s < P; s++)
+            v[s] = zl[(T + T / 32) * s]; /* FR_PAD(tid + T s) */
+        frw_sync<T>();
+    }
+}
+
+template <int LG> struct FrwPlan;
+template <> struct FrwPlan<11> { static constexpr int NP = 3; static constexpr int R[4] = { 16, 16, 8, 1 }; };
+template <> struct FrwPlan<12> { static constexpr int NP = 3; static constexpr int R[4] = { 16, 16, 16, 1 }; };
+template <> struct FrwPlan<13> { static constexpr int NP = 4; static constexpr int R[4] = { 16, 16, 8, 4 }; };
+template <> struct FrwPlan<14> { static constexpr int NP = 4; static constexpr int R[4] = { 16, 16, 16, 4 }; };
+
+template <int LG, int INV>
+__global__ __launch_bounds__((1 << LG) / 16) void k_fft_rw(const c32 *wtab, const float *in, size_t in_pitch, float *out, size_t out_pitch, int nt)
+{
+    constexpr int N = 1 << LG, T = N / 16, P = 16;
+    using PL = FrwPlan<LG>;
+    constexpr int R0 = PL::R[0], R1 = PL::R[1], R2 = PL::R[2], R3 = PL::R[3];
+    extern __shared__ __align__(16) uint8_t lds_dyn[];
+    c32 *z = reinterpret_cast<c32 *>(lds_dyn);
+    const int tid = threadIdx.x;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const c32 *in2 = reinterpret_cast<const c32 *>(reinterpret_cast<const uint8_t *>(in) + (size_t)t * in_pitch);
+        c32 *out2 = reinterpret_cast<c32 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
+        c32 v[P];
+#pragma unroll
+        for (int s = 0; s < P; s++)
+            v[s] = in2[tid + T * s];
+        frw_pass<N, T, INV, R0, 1, true, false>(v, wtab, z, tid);
+        frw_pass<N, T, INV, R1, R0, false, false>(v, wtab, z, tid);
+        if constexpr (PL::NP == 3) {
+            frw_pass<N, T, INV, R2, R0 * R1, false, true>(v, wtab, z, tid);
+        } else {
+            frw_pass<N, T, INV, R2, R0 * R1, false, false>(v, wtab, z, tid);
+            frw_pass<N, T, INV, R3, R0 * R1 * R2, false, true>(v, wtab, z, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < P; s++)
+            out2[tid + T * s] = v[s];
+    }
+}
+
+template <int LG, int INV>
+int frw_go(const c32 *wtab, const float *in, size_t in_pitch, float *out, size_t out_pitch, int nt, hipStream_t stream)
+{
+    constexpr int N = 1 << LG, T = N / 16;
+    const size_t lds = fr_z_bytes(N);
+    static FFHipPerDeviceOnce attr;
+    if (attr.enter()) {
+        (void)hipFuncSetAttribute((const void *)k_fft_rw<LG, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr.leave(true);
+    }
+    int cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    int per_cu = (int)((160 * 1024) / (((lds + 1279) / 1280) * 1280));
+    if (per_cu * (T / 64) > 32) per_cu = 32 / (T / 64);
+    if (per_cu < 1) per_cu = 1;
+    const int blocks = nt < cus * per_cu ? nt : cus * per_cu;
+    hipLaunchKernelGGL((k_fft_rw<LG, INV>), dim3(blocks), dim3(T), lds, stream, wtab, in, in_pitch, out, out_pitch, nt);
+    LAUNCH_CHECK();
+    return 0;
+}
 
 template <int LG, int INV>
 __global__ __launch_bounds__(64 * FR_WAVES) void k_fft_r(const c32 *wtab, const float *in, size_t in_pitch, float *out, size_t out_pitch,
@@ -330,6 +461,11 @@ bool ffhip_tx_radix_ok(int n)
     return n == 256 || n == 512 || n == 1024;
 }
 
+bool ffhip_tx_radix_fft_ok(int n)
+{
+    return ffhip_tx_radix_ok(n) || n == 2048 || n == 4096 || n == 8192 || n == 16384;
+}
+
 int ffhip_launch_fft_r(int n, int inv, const float2 *wtab, const float *in, size_t in_pitch, float *out, size_t out_pitch, int nt,
                        hipStream_t stream)
 {
@@ -341,6 +477,10 @@ int ffhip_launch_fft_r(int n, int inv, const float2 *wtab, const float *in, size
     case 256:  if (inv) FR_GO(8, 1); else FR_GO(8, 0); break;
     case 512:  if (inv) FR_GO(9, 1); else FR_GO(9, 0); break;
     case 1024: if (inv) FR_GO(10, 1); else FR_GO(10, 0); break;
+    case 2048:  return inv ? frw_go<11, 1>(wtab, in, in_pitch, out, out_pitch, nt, stream) : frw_go<11, 0>(wtab, in, in_pitch, out, out_pitch, nt, stream);
+    case 4096:  return inv ? frw_go<12, 1>(wtab, in, in_pitch, out, out_pitch, nt, stream) : frw_go<12, 0>(wtab, in, in_pitch, out, out_pitch, nt, stream);
+    case 8192:  return inv ? frw_go<13, 1>(wtab, in, in_pitch, out, out_pitch, nt, stream) : frw_go<13, 0>(wtab, in, in_pitch, out, out_pitch, nt, stream);
+    case 16384: return inv ? frw_go<14, 1>(wtab, in, in_pitch, out, out_pitch, nt, stream) : frw_go<14, 0>(wtab, in, in_pitch, out, out_pitch, nt, stream);
     default: return FFHIP_EINVAL;
     }
 #undef FR_GO

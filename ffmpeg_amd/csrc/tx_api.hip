@@ -1569,7 +1569,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     d.cos_tab = (const float *)(base + off_cos);
     d.sched = (const uint32_t *)(base + off_sched);
     d.blocks2 = (const uint16_t *)(base + off_b2);
-    if (!(flags & FFHIP_TX_BITEXACT) && (type == FFHIP_TX_FLOAT_FFT || type == FFHIP_TX_FLOAT_MDCT) && ffhip_tx_radix_ok(n)) {
+    if (!(flags & FFHIP_TX_BITEXACT) && ((type == FFHIP_TX_FLOAT_MDCT && ffhip_tx_radix_ok(n)) || (type == FFHIP_TX_FLOAT_FFT && ffhip_tx_radix_fft_ok(n)))) {
         std::vector<float2> w(n);
         for (int k = 0; k < n; k++) {
             const double a = 2 * M_PI * k / n;
@@ -1649,6 +1649,11 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
 #define TX_LAUNCH_WG(K)                                                                                                               \
     hipLaunchKernelGGL((K), dim3(blocks), dim3(threads), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev, 0,               \
                        (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks)
+        {
+            const char *er = FFHIP_KNOB("FFHIP_TX_RADIX");
+            if (c->type == FFHIP_TX_FLOAT_FFT && c->wtab && !(er && er[0] == '0'))
+                return ffhip_launch_fft_r(n, c->inv, c->wtab, (const float *)in, in_pitch, (float *)out, out_pitch, nt, (hipStream_t)stream);
+        }
         if (c->type == FFHIP_TX_FLOAT_FFT)
             TX_LAUNCH_WG((k_fft_z<false, true>));
         else if (c->inv)

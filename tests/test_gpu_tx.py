@@ -40,7 +40,7 @@ def _oracle(inv, len_, scale, inp, stride_elems=1):
 def _radix(type_, len_):
     """the context runs kernels/tx_radix.hip unless FFHIP_TX_BITEXACT is set"""
     from ffmpeg_amd import tx
-    return (type_ == tx.FLOAT_FFT and len_ in (256, 512, 1024)) or (type_ == tx.FLOAT_MDCT and len_ in (512, 1024, 2048))
+    return (type_ == tx.FLOAT_FFT and len_ in (256, 512, 1024, 2048, 4096, 8192, 16384)) or (type_ == tx.FLOAT_MDCT and len_ in (512, 1024, 2048))
 
 
 def _check(got, want, exact=True):
@@ -196,15 +196,17 @@ def test_fft_batch(len_, inv):
 
 
 @pytest.mark.parametrize("inv", [0, 1])
-@pytest.mark.parametrize("len_", [256, 512, 1024])
+@pytest.mark.parametrize("len_", [256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_fft_batch_radix(len_, inv):
-    """AV_TX_FLOAT_FFT as a caller gets it at 256 / 512 / 1024 points: kernels/tx_radix.hip (16 x 16 x 4 in registers) against the
+    """AV_TX_FLOAT_FFT as a caller gets it at 256 .. 16384 points: kernels/tx_radix.hip (16 x 16 x 4 in registers; from 2048 points a
+    team of n / 16 threads, 16 x 16 x 16 x 4 through the workgroup's LDS) against the
     oracle within the stated tolerance, 2^-18 of each transform's largest output, over magnitudes 1e-3 .. 1e3 — and against the
     reference's own checkasm bound (tests/checkasm/av_tx.c: EPS 5e-4 on inputs in [-1, 1], relative to the output scale)"""
     from ffmpeg_amd import tx
     torch = _torch()
     rng = np.random.default_rng(len_ * 2 + inv + 7)
-    nt = 20011   # more transforms than resident waves (16384): the wave loop wraps, the last round is ragged
+    # more transforms than resident waves (16384) / teams (2304 at 2048 points .. 256 at 16384): the loop wraps, the last round is ragged
+    nt = 20011 if len_ <= 1024 else 2500 if len_ == 2048 else 700 if len_ == 4096 else 300
     x = (rng.standard_normal((nt, 2 * len_)) * 10.0 ** rng.integers(-3, 4, (nt, 1))).astype(np.float32)
     x[1] = 0
     x[2] = 0
