@@ -31,6 +31,7 @@
 
 #include "kernels/common.h"
 #include "kernels/tx_kernels.h"
+#include "kernels/tx_radix_core.h"
 
 struct TxDev {
     int n, lg;                 /* complex FFT size (= len/2) and its log2                         */
@@ -588,9 +589,11 @@ __global__ __launch_bounds__(1024) void k_fft_z(TxDev d, const uint8_t *blob, in
  * are produced together from the work array straight into global memory; c2r runs the same pass on the way in.  d.exp
  * holds the reference's table as floats: fact[8], tcos[len/4], tsin[len/4].
  */
-template <int INV, bool TL>
+/* RLG = 8 / 9 / 10: the len/2-point FFT runs the register-resident radix core (kernels/tx_radix_core.h; the work array in natural
+ * order, results within the float tolerance); 0: the reference-order split-radix network (bit-identical) */
+template <int INV, bool TL, int RLG = 0>
 __global__ __launch_bounds__(1024) void k_rdft(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch, float *out,
-                                               size_t out_pitch, int nt, int waves_total)
+                                               size_t out_pitch, int nt, int waves_total, const float2 *wtab)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -610,6 +613,10 @@ __global__ __launch_bounds__(1024) void k_rdft(TxDev d, const uint8_t *blob, int
     const float *l_cos = reinterpret_cast<const float *>(tbase + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
     const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
     const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    auto zi = [&](int j) { return RLG ? TX_PAD(j) : l_map[j]; };
+    FrTw<RLG ? RLG : 8> rtw;
+    if (RLG)
+        fr_load_all_tw<RLG ? RLG : 8, INV>(rtw, wtab, lane);
     const int len2 = d.n, len4 = len2 >> 1;
     const float *tcos = fact + 8, *tsin = tcos + len4;
     const float f0 = fact[0], f1 = fact[1], f2 = fact[2], f3 = fact[3], f4 = fact[4], f5 = fact[5], f6 = fact[6], f7 = fact[7];
@@ -628,25 +635,28 @@ __global__ __launch_bounds__(1024) void k_rdft(TxDev d, const uint8_t *blob, int
         float2 *out2 = reinterpret_cast<float2 *>(reinterpret_cast<uint8_t *>(out) + (size_t)t * out_pitch);
         if (!INV) {
             for (int j = lane; j < len2; j += 64)
-                z[l_map[j]] = in2[j];
+                z[zi(j)] = in2[j];
         } else {
             for (int i = lane; i <= len4; i += 64) {
                 if (i == 0) {
                     const float re = in2[0].x, im = in2[len2].x; /* data[0].im = data[len2].re */
-                    z[l_map[0]] = make_float2(f0 * (re + im), f1 * (re - im));
+                    z[zi(0)] = make_float2(f0 * (re + im), f1 * (re - im));
                 } else if (i == len4) {
                     const float2 v = in2[len4];
-                    z[l_map[len4]] = make_float2(f2 * v.x, f3 * v.y);
+                    z[zi(len4)] = make_float2(f2 * v.x, f3 * v.y);
                 } else {
                     float2 oa, ob;
                     pair(i, in2[i], in2[len2 - i], oa, ob);
-                    z[l_map[i]] = oa;
-                    z[l_map[len2 - i]] = ob;
+                    z[zi(i)] = oa;
+                    z[zi(len2 - i)] = ob;
                 }
             }
         }
         tx_wave_sync();
-        tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
+        if constexpr (RLG != 0)
+            fr_fft_lds<RLG, INV>(z, rtw, lane);
+        else
+            tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
         if (!INV && d.half) {
             /* ff_tx_rdft_r2r / _r2i (tx_template.c:1718-1830, the len % 4 == 0 codelets): only the real / only the imaginary parts
              * of the bins, len/2 + 1 resp. len/2 floats.  The reference works in place over the FFT's output and reads every value
@@ -733,9 +743,11 @@ __global__ __launch_bounds__(1024) void k_rdft(TxDev d, const uint8_t *blob, int
  * d.exp holds fact[8], tcos[N/4], tsin[N/4] (the RDFT's) followed by the DCT's exp[N + N/2].  acc: N/2 + 1 floats per wave
  * behind the work array (DCT-II only).
  */
-template <int INV, bool TL>
+/* RLG = 8 / 9 / 10: the len/2-point FFT runs the register-resident radix core (kernels/tx_radix_core.h; the work array in natural
+ * order, results within the float tolerance); 0: the reference-order split-radix network (bit-identical) */
+template <int INV, bool TL, int RLG = 0>
 __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int blob_bytes, const float *in, size_t in_pitch, float *out,
-                                              size_t out_pitch, int nt, int waves_total)
+                                              size_t out_pitch, int nt, int waves_total, const float2 *wtab)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -753,6 +765,10 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
     const float *l_cos = reinterpret_cast<const float *>(tbase + (reinterpret_cast<const uint8_t *>(d.cos_tab) - blob));
     const uint32_t *l_sched = reinterpret_cast<const uint32_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.sched) - blob));
     const uint16_t *l_b2 = reinterpret_cast<const uint16_t *>(tbase + (reinterpret_cast<const uint8_t *>(d.blocks2) - blob));
+    auto zi = [&](int j) { return RLG ? TX_PAD(j) : l_map[j]; };
+    FrTw<RLG ? RLG : 8> rtw;
+    if (RLG)
+        fr_load_all_tw<RLG ? RLG : 8, INV>(rtw, wtab, lane);
     const int len2 = d.n, len4 = len2 >> 1, N = 2 * len2;
     const float *tcos = fact + 8, *tsin = tcos + len4, *dexp = tsin + len4;
     const float f0 = fact[0], f1 = fact[1], f2 = fact[2], f3 = fact[3], f4 = fact[4], f5 = fact[5], f6 = fact[6], f7 = fact[7];
@@ -787,8 +803,8 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
                 const float s0 = dexp[N + 2 * c], s1 = dexp[N + 2 * c + 1];
                 const float p1 = (a.x + b.y) * 0.5f, p2 = (a.x - b.y) * s0;
                 const float q1 = (a.y + b.x) * 0.5f, q2 = (a.y - b.x) * s1;
-                z[l_map[c]] = make_float2(p1 + p2, q1 + q2);
-                z[l_map[len2 - 1 - c]] = make_float2(q1 - q2, p1 - p2);
+                z[zi(c)] = make_float2(p1 + p2, q1 + q2);
+                z[zi(len2 - 1 - c)] = make_float2(q1 - q2, p1 - p2);
             }
         } else if (INV) {
             /* bin k of the sequence ff_tx_dctIII hands the c2r transform */
@@ -801,20 +817,24 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
             for (int i = lane; i <= len4; i += 64) {
                 if (i == 0) {
                     const float re = x[0], im = 2 * x[N - 1];
-                    z[l_map[0]] = make_float2(f0 * (re + im), f1 * (re - im));
+                    z[zi(0)] = make_float2(f0 * (re + im), f1 * (re - im));
                 } else if (i == len4) {
                     const float2 v = bin(len4);
-                    z[l_map[len4]] = make_float2(f2 * v.x, f3 * v.y);
+                    z[zi(len4)] = make_float2(f2 * v.x, f3 * v.y);
                 } else {
                     float2 oa, ob;
                     pair(i, bin(i), bin(len2 - i), oa, ob);
-                    z[l_map[i]] = oa;
-                    z[l_map[len2 - i]] = ob;
+                    z[zi(i)] = oa;
+                    z[zi(len2 - i)] = ob;
                 }
             }
         }
         tx_wave_sync();
-        if (INV || active)
+        if (RLG && !active)
+            continue; /* (no barriers with the radix core: the running sums are a wave's own scan) */
+        if constexpr (RLG != 0)
+            fr_fft_lds<RLG, INV>(z, rtw, lane);
+        else if (INV || active)
             tx_fft_lds(z, d, l_cos, l_sched, l_b2, lane);
         if (!INV) {
           if (active) {
@@ -845,6 +865,34 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
              * workgroup's first wave walks the chain of wave w's transform, the W chains cost the instruction slots of one
              * (round 1 had every wave walk its own with one live lane: 138 M transforms/s at N = 1024 against 342 M/s for the
              * DCT-III, which has no such chain).  Eight terms per trip through registers. */
+            if constexpr (RLG != 0) {
+                /* the same sums as a suffix scan of the wave's own terms: lane l owns acc[l C .. l C + C - 1], adds up its chunk from the
+                 * top, and takes the sum of the chunks above it (and of acc[len2]) from a shuffle scan.  A different order of float
+                 * additions than the reference's chain: within the tolerance, not bit-identical. */
+                tx_wave_sync();
+                constexpr int C = (1 << RLG) / 64;
+                float sfx[C];
+#pragma unroll
+                for (int i = 0; i < C; i++)
+                    sfx[i] = acc[lane * C + i];
+#pragma unroll
+                for (int i = C - 2; i >= 0; i--)
+                    sfx[i] += sfx[i + 1];
+                float incl = sfx[0];
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const float o = __shfl_down(incl, dd);
+                    if (lane + dd < 64)
+                        incl += o;
+                }
+                float above = __shfl_down(incl, 1);
+                above = (lane == 63 ? 0.0f : above) + acc[len2];
+                tx_wave_sync();
+#pragma unroll
+                for (int i = 0; i < C; i++)
+                    acc[lane * C + i] = sfx[i] + above;
+                tx_wave_sync();
+            } else {
             __syncthreads();
             if (wave == 0 && lane < W && t0 + lane < nt) {
                 float *a = reinterpret_cast<float *>(lds_raw + ((blob_bytes + 15) & ~15) + lane * per_wave + tx_z_bytes(len2));
@@ -877,6 +925,7 @@ __global__ __launch_bounds__(1024) void k_dct(TxDev d, const uint8_t *blob, int 
                 }
             }
             __syncthreads();
+            }
             if (!active)
                 continue;
             float2 *y2 = reinterpret_cast<float2 *>(y);
@@ -1569,7 +1618,7 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     d.cos_tab = (const float *)(base + off_cos);
     d.sched = (const uint32_t *)(base + off_sched);
     d.blocks2 = (const uint16_t *)(base + off_b2);
-    if (!(flags & FFHIP_TX_BITEXACT) && ((type == FFHIP_TX_FLOAT_MDCT && ffhip_tx_radix_ok(n)) || (type == FFHIP_TX_FLOAT_FFT && ffhip_tx_radix_fft_ok(n)))) {
+    if (!(flags & FFHIP_TX_BITEXACT) && (type == FFHIP_TX_FLOAT_FFT ? ffhip_tx_radix_fft_ok(n) : ffhip_tx_radix_ok(n))) {
         std::vector<float2> w(n);
         for (int k = 0; k < n; k++) {
             const double a = 2 * M_PI * k / n;
@@ -1700,38 +1749,73 @@ static int tx_batch_half(FFHipTXContext *c, void *out, size_t out_pitch, const v
         int blocks = cus * per_cu;
         if (blocks > (nt + wpb - 1) / wpb)
             blocks = (nt + wpb - 1) / wpb;
+        int rlg = 0;
+        {
+            const char *er = FFHIP_KNOB("FFHIP_TX_RADIX");
+            if (c->wtab && !(er && er[0] == '0') && ffhip_tx_radix_ok(n))
+                rlg = c->d.lg;
+        }
         static FFHipPerDeviceOnce fft_attr; /* function attributes are per device */
         if (fft_attr.enter()) {
             (void)hipFuncSetAttribute((const void *)k_fft_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)k_fft_z<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_rdft<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_rdft<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_rdft<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_rdft<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_dct<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_dct<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_dct<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)k_dct<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<0, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_rdft<1, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<0, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)k_dct<1, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             fft_attr.leave(true);
         }
         if (c->type == FFHIP_TX_FLOAT_RDFT) {
 #define TX_LAUNCH(K)                                                                                                                  \
     hipLaunchKernelGGL((K), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev, blob_arg,       \
                        (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb)
-            if (c->inv) {
-                if (tl) TX_LAUNCH((k_rdft<1, true>)); else TX_LAUNCH((k_rdft<1, false>));
-            } else {
-                if (tl) TX_LAUNCH((k_rdft<0, true>)); else TX_LAUNCH((k_rdft<0, false>));
-            }
+            /* (the split-radix kernels take the pointer too and ignore it) */
+#define TX_LAUNCH_R(K)                                                                                                                \
+    hipLaunchKernelGGL((K), dim3(blocks), dim3(64 * wpb), lds_z, (hipStream_t)stream, c->d, (const uint8_t *)c->dev, blob_arg,       \
+                       (const float *)in, in_pitch, (float *)out, out_pitch, nt, blocks * wpb, (const float2 *)c->wtab)
+#define TX_LAUNCH_RLG(KN, INV_)                                                                                                       \
+    do {                                                                                                                              \
+        switch (rlg) {                                                                                                                \
+        case 8:  if (tl) TX_LAUNCH_R((KN<INV_, true, 8>)); else TX_LAUNCH_R((KN<INV_, false, 8>)); break;                            \
+        case 9:  if (tl) TX_LAUNCH_R((KN<INV_, true, 9>)); else TX_LAUNCH_R((KN<INV_, false, 9>)); break;                            \
+        case 10: if (tl) TX_LAUNCH_R((KN<INV_, true, 10>)); else TX_LAUNCH_R((KN<INV_, false, 10>)); break;                          \
+        default: if (tl) TX_LAUNCH_R((KN<INV_, true, 0>)); else TX_LAUNCH_R((KN<INV_, false, 0>)); break;                            \
+        }                                                                                                                             \
+    } while (0)
+            if (c->inv) TX_LAUNCH_RLG(k_rdft, 1); else TX_LAUNCH_RLG(k_rdft, 0);
             LAUNCH_CHECK();
             return 0;
         }
         if (c->type == FFHIP_TX_FLOAT_DCT) {
-            if (c->inv) {
-                if (tl) TX_LAUNCH((k_dct<1, true>)); else TX_LAUNCH((k_dct<1, false>));
-            } else {
-                if (tl) TX_LAUNCH((k_dct<0, true>)); else TX_LAUNCH((k_dct<0, false>));
-            }
+            if (c->inv) TX_LAUNCH_RLG(k_dct, 1); else TX_LAUNCH_RLG(k_dct, 0);
             LAUNCH_CHECK();
             return 0;
         }

@@ -296,7 +296,7 @@ def test_rdft_golden_gpu():
     for len_ in (16, 1024):
         for inv in (0, 1):
             x, want = d["rdft%d_%d_in" % (len_, inv)], d["rdft%d_%d_out" % (len_, inv)]
-            ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, 1.0)
+            ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, 1.0, flags=tx.BITEXACT)
             out = torch.zeros(want.shape, dtype=torch.float32, device="cuda:0")
             ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
             assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (len_, inv)
@@ -310,7 +310,7 @@ def test_rdft_half_golden_gpu():
     for len_ in (16, 1024):
         for mode in (1, 2):
             x, want = d["rdfth%d_%d_in" % (len_, mode)], d["rdfth%d_%d_out" % (len_, mode)]
-            ctx = tx.TxContext(tx.FLOAT_RDFT, 0, len_, 1.0, flags=tx.REAL_TO_REAL if mode == 1 else tx.REAL_TO_IMAGINARY)
+            ctx = tx.TxContext(tx.FLOAT_RDFT, 0, len_, 1.0, flags=(tx.REAL_TO_REAL if mode == 1 else tx.REAL_TO_IMAGINARY) | tx.BITEXACT)
             out = torch.zeros((want.shape[0], len_ // 2 + 2), dtype=torch.float32, device="cuda:0")
             ctx.batch(out[:, :want.shape[1]], torch.from_numpy(np.ascontiguousarray(x)).cuda())
             assert np.array_equal(np.ascontiguousarray(out.cpu().numpy()[:, :want.shape[1]]).view(np.uint32), want.view(np.uint32)), (len_, mode)
@@ -324,7 +324,7 @@ def test_dct_golden_gpu():
     for n in (16, 1024):
         for inv in (0, 1):
             x, want = d["dct%d_%d_in" % (n, inv)], d["dct%d_%d_out" % (n, inv)]
-            ctx = tx.TxContext(tx.FLOAT_DCT, inv, n >> inv, 1.0)
+            ctx = tx.TxContext(tx.FLOAT_DCT, inv, n >> inv, 1.0, flags=tx.BITEXACT)
             out = torch.zeros(want.shape, dtype=torch.float32, device="cuda:0")
             ctx.batch(out, torch.from_numpy(np.ascontiguousarray(x)).cuda())
             assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (n, inv)

@@ -43,6 +43,46 @@ def _radix(type_, len_):
     return (type_ == tx.FLOAT_FFT and len_ in (256, 512, 1024, 2048, 4096, 8192, 16384)) or (type_ == tx.FLOAT_MDCT and len_ in (512, 1024, 2048))
 
 
+def _radix_real(len_):
+    """RDFT / DCT contexts over len reals run the radix core (len / 2 complex points) unless FFHIP_TX_BITEXACT is set"""
+    return len_ in (512, 1024, 2048)
+
+
+def _cmp(got, want, exact, what="", rel=2.0 ** -17):
+    """bit-identical, or (the radix core under an RDFT) within 2^-17 of each transform's largest output — the pass that separates
+    the bins adds and subtracts pairs of FFT outputs, so the bound is one bit wider than the FFT's own 2^-18"""
+    if exact:
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(want).view(np.uint32)), \
+            "%s max |diff| %g" % (what, np.abs(got - want).max())
+    else:
+        got, want = np.atleast_2d(got), np.atleast_2d(want)
+        tol = rel * np.abs(want).max(axis=1)
+        err = np.abs(got - want).max(axis=1)
+        assert (err <= tol).all(), "%s transform %d: %g > %g" % (what, int(np.argmax(err - tol)), err.max(), tol[np.argmax(err - tol)])
+
+
+def _cmp_dct(got, want, x, inv):
+    """The DCT's last pass scales differences of FFT outputs by up to 0.5 / sin(pi / 2N) ~ N / pi (ff_tx_dct_init's exp table,
+    tx_template.c:1856-1870), so two correct float implementations differ by far more than 2^-18 of the largest output at the ends
+    of a row — the reference differs from the exact transform by as much (DCT-III, N = 2048: 2^-14 of the largest output).
+    Stated bound: against the exact transform (float64, scipy; its scale fitted to the reference) our error, normalised by each
+    transform's largest output, is the reference's own — batch mean within 1.5 x, batch worst within 3 x (measured: 0.97-1.06 x
+    and 0.6-1.3 x over 400 transforms)."""
+    import scipy.fft
+    got, want, x = np.atleast_2d(got).astype(np.float64), np.atleast_2d(want).astype(np.float64), np.atleast_2d(x).astype(np.float64)
+    ex = scipy.fft.dct(x, type=3 if inv else 2, axis=1)
+    nz = np.abs(ex).max(axis=1) > 0
+    assert (got[~nz] == 0).all()
+    got, want, ex = got[nz], want[nz], ex[nz]
+    f = (want * ex).sum() / (ex * ex).sum()
+    top = np.abs(want).max(axis=1)
+    e_ref = np.abs(want - f * ex).max(axis=1) / top
+    e_got = np.abs(got - f * ex).max(axis=1) / top
+    assert e_ref.max() <= 2.0 ** -10, "the float64 transform does not model the reference: %g" % e_ref.max()
+    assert e_got.mean() <= 1.5 * e_ref.mean() + 2.0 ** -22, (e_got.mean(), e_ref.mean())
+    assert e_got.max() <= 3 * e_ref.max() + 2.0 ** -20, (e_got.max(), e_ref.max())
+
+
 def _check(got, want, exact=True):
     for t in range(want.shape[0]):
         tol = 2.0 ** -18 * np.abs(want[t]).max()
@@ -353,10 +393,12 @@ def test_mdct_pfa15_rejects_strided_rows():
     ctx.close()
 
 
+@pytest.mark.parametrize("bitexact", [True, False], ids=["bitexact", "default"])
 @pytest.mark.parametrize("inv", [0, 1])
-@pytest.mark.parametrize("len_,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
-def test_rdft_batch(len_, inv, scale):
-    """AV_TX_FLOAT_RDFT, power-of-two: r2c forward (len reals -> len/2 + 1 bins), c2r inverse; bit-identical, host face too"""
+@pytest.mark.parametrize("len_,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (512, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
+def test_rdft_batch(len_, inv, scale, bitexact):
+    """AV_TX_FLOAT_RDFT, power-of-two: r2c forward (len reals -> len/2 + 1 bins), c2r inverse; bit-identical (a default context of
+    512 / 1024 / 2048 reals: the radix core, within the tolerance), host face too"""
     from ffmpeg_amd import tx
     torch = _torch()
     rng = np.random.default_rng(len_ * 2 + inv)
@@ -370,23 +412,25 @@ def test_rdft_batch(len_, inv, scale):
     O = ffi.oracle()
     for t in range(nt):
         O.ffo_rdft_run(inv, len_, scale, ptr(want[t], f32p), ptr(x[t], f32p))
-    ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, scale)
+    ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, scale, flags=tx.BITEXACT if bitexact else 0)
+    exact = bitexact or not _radix_real(len_)
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.zeros((nt, n_out + 2), dtype=torch.float32, device="cuda:0")
     ctx.batch(d_out[:, :n_out], d_in)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy()
-    assert np.array_equal(np.ascontiguousarray(got[:, :n_out]).view(np.uint32), want.view(np.uint32)), "max |diff| %g" % np.abs(got[:, :n_out] - want).max()
+    _cmp(got[:, :n_out], want, exact)
     assert not got[:, n_out:].any()
     one = np.zeros(n_out, np.float32)
     ctx.fn(one, x[3].copy(), 4)
-    assert np.array_equal(one.view(np.uint32), want[3].view(np.uint32))
+    _cmp(one, want[3], exact)
     ctx.close()
 
 
+@pytest.mark.parametrize("bitexact", [True, False], ids=["bitexact", "default"])
 @pytest.mark.parametrize("mode", [1, 2], ids=["r2r", "r2i"])
-@pytest.mark.parametrize("len_,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
-def test_rdft_half_batch(len_, mode, scale):
+@pytest.mark.parametrize("len_,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (512, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
+def test_rdft_half_batch(len_, mode, scale, bitexact):
     """AV_TX_FLOAT_RDFT with AV_TX_REAL_TO_REAL / AV_TX_REAL_TO_IMAGINARY: len reals -> len/2 + 1 real resp. len/2 imaginary parts
     (ff_tx_rdft_r2r / _r2i); bit-identical, nothing written behind them, host face too; forward-only like the reference"""
     from ffmpeg_amd import tx
@@ -402,49 +446,67 @@ def test_rdft_half_batch(len_, mode, scale):
     for t in range(nt):
         O.ffo_rdft_half_run(mode, len_, scale, ptr(want[t], f32p), ptr(x[t], f32p))
     want = np.ascontiguousarray(want[:, :n_out])
-    ctx = tx.TxContext(tx.FLOAT_RDFT, 0, len_, scale, flags=flag)
+    ctx = tx.TxContext(tx.FLOAT_RDFT, 0, len_, scale, flags=flag | (tx.BITEXACT if bitexact else 0))
+    exact = bitexact or not _radix_real(len_)
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.zeros((nt, len_ // 2 + 4), dtype=torch.float32, device="cuda:0")
     ctx.batch(d_out[:, :n_out], d_in)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy()
-    assert np.array_equal(np.ascontiguousarray(got[:, :n_out]).view(np.uint32), want.view(np.uint32)), "max |diff| %g" % np.abs(got[:, :n_out] - want).max()
+    if mode == 2 and not exact:
+        # r2i's last output is the underlying FFT's own data[len/2 - 1].im (the reference's copy loop reads a slot its loop never
+        # wrote): an unscaled FFT value among scaled ones, so its bound is the FFT's — 2^-18 of what an FFT output can reach
+        assert (np.abs(got[:, n_out - 1] - want[:, n_out - 1]) <= 2.0 ** -18 * np.abs(x).sum(axis=1)).all()
+        got[:, n_out - 1] = want[:, n_out - 1]
+    _cmp(got[:, :n_out], want, exact)
     assert not got[:, n_out:].any()
     one = np.zeros(n_out, np.float32)
     ctx.fn(one, x[3].copy(), 4)
-    assert np.array_equal(one.view(np.uint32), want[3].view(np.uint32))
+    if exact:
+        _cmp(one, want[3], True)
+    else:
+        assert np.array_equal(one, d_out[3, :n_out].cpu().numpy())   # the host-pointer face runs the same kernel
     ctx.close()
     with pytest.raises(Exception):
         tx.TxContext(tx.FLOAT_RDFT, 1, len_, scale, flags=flag)
 
 
+@pytest.mark.parametrize("bitexact", [True, False], ids=["bitexact", "default"])
 @pytest.mark.parametrize("inv", [0, 1])
-@pytest.mark.parametrize("n,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
-def test_dct_batch(n, inv, scale):
+@pytest.mark.parametrize("n,scale", [(8, 1.0), (16, 0.25), (64, 1.0), (512, 1.0), (1024, 1.0 / 1024), (2048, -0.37), (4096, 1.0)])
+def test_dct_batch(n, inv, scale, bitexact):
     """AV_TX_FLOAT_DCT, power-of-two: DCT-II forward / DCT-III inverse of n reals (the inverse initialised with n / 2, as av_tx_init
     is); bit-identical - the forward transform's odd outputs are a running sum whose order the kernel keeps - host face too"""
     from ffmpeg_amd import tx
     torch = _torch()
     rng = np.random.default_rng(n * 2 + inv + 7)
-    nt = 3000 if n == 1024 else 41
+    nt = 3000 if n == 1024 else 400 if _radix_real(n) and not bitexact else 41
     x = (rng.standard_normal((nt, n)) * 10.0 ** rng.integers(-3, 4, (nt, 1))).astype(np.float32)
     x[1] = 0
     want = np.zeros((nt, n), np.float32)
     O = ffi.oracle()
     for t in range(nt):
         O.ffo_dct_run(inv, n, scale, ptr(want[t], f32p), ptr(x[t], f32p))
-    ctx = tx.TxContext(tx.FLOAT_DCT, inv, n >> inv, scale)
+    # default contexts of 512 / 1024 / 2048 reals: the radix core, and the forward transform's running sum as a scan - tolerance
+    ctx = tx.TxContext(tx.FLOAT_DCT, inv, n >> inv, scale, flags=tx.BITEXACT if bitexact else 0)
+    exact = bitexact or not _radix_real(n)
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.zeros((nt, n + 2), dtype=torch.float32, device="cuda:0")
     ctx.batch(d_out[:, :n], d_in)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy()
-    assert np.array_equal(np.ascontiguousarray(got[:, :n]).view(np.uint32), want.view(np.uint32)), "max |diff| %g" % np.abs(got[:, :n] - want).max()
+    if exact:
+        _cmp(got[:, :n], want, True)
+    else:
+        _cmp_dct(got[:, :n], want, x, inv)
     assert not got[:, n:].any()
     assert np.array_equal(d_in.cpu().numpy(), x)          # the batch face leaves its input alone
     one = np.zeros(n, np.float32)
     ctx.fn(one, x[3].copy(), 4)
-    assert np.array_equal(one.view(np.uint32), want[3].view(np.uint32))
+    if exact:
+        _cmp(one, want[3], True)
+    else:
+        assert np.array_equal(one, got[3, :n])            # the host-pointer face runs the same kernel
     ctx.close()
 
 
@@ -506,7 +568,7 @@ def test_table_placement(typ, len_, inv, tabs, monkeypatch):
         want = np.zeros_like(x)
         for t in range(nt):
             O.ffo_dct_run(inv, len_, 1.0, ptr(want[t], f32p), ptr(x[t], f32p))
-        ctx = tx.TxContext(tx.FLOAT_DCT, inv, len_ >> inv, 1.0)
+        ctx = tx.TxContext(tx.FLOAT_DCT, inv, len_ >> inv, 1.0, flags=tx.BITEXACT)
     else:
         x = rng.standard_normal((nt, len_ + 2 if inv else len_)).astype(np.float32)
         if inv:
@@ -514,7 +576,7 @@ def test_table_placement(typ, len_, inv, tabs, monkeypatch):
         want = np.zeros((nt, len_ if inv else len_ + 2), np.float32)
         for t in range(nt):
             O.ffo_rdft_run(inv, len_, 1.0, ptr(want[t], f32p), ptr(x[t], f32p))
-        ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, 1.0)
+        ctx = tx.TxContext(tx.FLOAT_RDFT, inv, len_, 1.0, flags=tx.BITEXACT)
     d_out = torch.zeros(want.shape, dtype=torch.float32, device="cuda:0")
     ctx.batch(d_out, torch.from_numpy(x).cuda())
     torch.cuda.synchronize()
