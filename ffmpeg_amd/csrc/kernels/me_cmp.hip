@@ -190,8 +190,12 @@ __device__ __forceinline__ uint4 me_hadamard_col(P p, int stride)
 /*
  * sum |H8 (a - b) H8^T| of one 8x8 block from the VERTICAL Hadamard columns of a and of b (me_hadamard_col): the
  * transform is separable and exact in integers, so H(a) - H(b) = H(a - b) and the order of the two passes is free.
- * The horizontal pass runs across the 8 columns on packed int16 pairs (|coefficient| <= 255 * 64 < 2^15); its last
- * stage and the absolute sum use |p + q| + |p - q| = 2 max(|p|, |q|).  Returns HALF the sum.
+ * The horizontal pass runs across the 8 columns on packed int16 pairs (|coefficient| <= 255 * 64 < 2^15).  Column 0 enters every
+ * output with a plus sign (the Hadamard matrix's first column), so 0x8000 added to its four dwords (by the caller: va[0] arrives
+ * with its halves' top bits flipped) leaves every
+ * output biased by 0x8000 (mod 2^16, no wrap: 16448 .. 49088), and v_sad_u16 against the bias is the absolute sum of two
+ * coefficients in one instruction (round 4; before: |p + q| + |p - q| = 2 max(|p|, |q|) through negate / max / max / dot, six
+ * instructions per four coefficients where this takes four).
  */
 __device__ __forceinline__ uint32_t me_satd8_cols(const uint4 *va, const uint4 *vb, uint32_t acc)
 {
@@ -215,16 +219,13 @@ __device__ __forceinline__ uint32_t me_satd8_cols(const uint4 *va, const uint4 *
                     d[i][m] = p + q;
                     d[i + span][m] = p - q;
                 }
-    const me_s2 zero = { 0, 0 };
-    const me_u2 ones = { 1, 1 };
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const me_s2 p = d[i][m], q = d[i + 4][m];
-            const me_s2 ap = __builtin_elementwise_max(p, zero - p), aq = __builtin_elementwise_max(q, zero - q);
-            const me_s2 mx = __builtin_elementwise_max(ap, aq);
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(me_u2, mx), ones, acc, false);
+            const me_s2 p = d[i][m], q = d[i + 4][m]; /* p carries the bias, q does not */
+            acc = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, p + q), 0x80008000u, acc);
+            acc = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, p - q), 0x80008000u, acc);
         }
     return acc;
 }
@@ -300,8 +301,13 @@ __global__ __launch_bounds__(64 * WPB) void k_me_esa(const uint8_t *cur, const u
     uint4 *vb = va + (MB / 8) * MB;
     const int vrows = wrows - 7;
     if (SHARE) {
-        for (int i = lane; i < (MB / 8) * MB; i += 64)
-            va[i] = me_hadamard_col(cblk + (i / MB) * 8 * MB + (i % MB), MB);
+        for (int i = lane; i < (MB / 8) * MB; i += 64) {
+            uint4 h = me_hadamard_col(cblk + (i / MB) * 8 * MB + (i % MB), MB);
+            if (!(i & 7)) { /* column 0 of an 8x8 block carries me_satd8_cols' bias */
+                h.x ^= 0x80008000u; h.y ^= 0x80008000u; h.z ^= 0x80008000u; h.w ^= 0x80008000u;
+            }
+            va[i] = h;
+        }
         for (int i = lane; i < vrows * wcols; i += 64) {
             const int r = i / wcols, c = i - r * wcols;
             vb[i] = me_hadamard_col(win + r * pitch + c, pitch);
@@ -451,13 +457,12 @@ __global__ __launch_bounds__(64 * WPB) void k_me_esa(const uint8_t *cur, const u
                 cost = (uint32_t)sad_bytes(cblk, MB, cand, pitch, MB, MB);
             }
         } else if (SHARE) {
-            uint32_t half = 0;
+            cost = 0;
 #pragma unroll
             for (int sy = 0; sy < MB / 8; sy++)
 #pragma unroll
                 for (int sx = 0; sx < MB / 8; sx++)
-                    half = me_satd8_cols(va + sy * MB + 8 * sx, vb + (cy + 8 * sy) * wcols + cx + 8 * sx, half);
-            cost = 2 * half;
+                    cost = me_satd8_cols(va + sy * MB + 8 * sx, vb + (cy + 8 * sy) * wcols + cx + 8 * sx, cost);
         } else {
             cost = (uint32_t)satd_block(cblk, MB, cand, pitch, MB, MB);
         }
