@@ -244,7 +244,17 @@ extern "C" int ff_h264dsp_init_hip(FFHipH264DSPContext *c, int bit_depth, int ch
     const int r = ffhip_h264dsp_fill_generic(c, &o, 8, chroma_format_idc == 2 ? 2 : 1);
     if (r < 0)
         return r;
-    fb_snapshot(g_fb_h264, *c, o);
+    if (chroma_format_idc == 2) {
+        /* the six members the reference picks by chroma format carry depth-generic 4:2:2 faces here, which keep their displaced C
+         * functions in a table of their own (shims_h264_hbd.hip): g_fb_h264's slots stay the 4:2:0 faces' */
+        FFHipH264DSPContext in = *c, ours = o;
+        ours.h_loop_filter_chroma = in.h_loop_filter_chroma;               ours.h_loop_filter_chroma_intra = in.h_loop_filter_chroma_intra;
+        ours.h_loop_filter_chroma_mbaff = in.h_loop_filter_chroma_mbaff;   ours.h_loop_filter_chroma_mbaff_intra = in.h_loop_filter_chroma_mbaff_intra;
+        ours.idct_add8 = in.idct_add8;                                     ours.chroma_dc_dequant_idct = in.chroma_dc_dequant_idct;
+        fb_snapshot(g_fb_h264, in, ours);
+    } else {
+        fb_snapshot(g_fb_h264, *c, o);
+    }
     *c = o;
     return 0;
 }

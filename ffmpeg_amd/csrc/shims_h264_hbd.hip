@@ -17,13 +17,18 @@
 
 namespace {
 
+/* The C functions an init displaced, per bit depth — and, for the six members ff_h264dsp_init() picks by chroma_format_idc
+ * (h264dsp.c:113-132: the horizontal chroma filters, idct_add8, chroma_dc_dequant_idct), per chroma format: a 4:2:0 and a 4:2:2 decoder
+ * of one depth in one process each fall back to their own C function (round 4; one table per depth before). */
 template <int BD> struct Fb {
     static FFHipH264DSPContext dsp;
+    static FFHipH264DSPContext dsp422;
     static FFHipH264QpelContext qpel;
     static FFHipH264ChromaContext chroma;
     static FFHipH264WeightContext weight;
 };
 template <int BD> FFHipH264DSPContext Fb<BD>::dsp;
+template <int BD> FFHipH264DSPContext Fb<BD>::dsp422;
 template <int BD> FFHipH264QpelContext Fb<BD>::qpel;
 template <int BD> FFHipH264ChromaContext Fb<BD>::chroma;
 template <int BD> FFHipH264WeightContext Fb<BD>::weight;
@@ -267,23 +272,27 @@ template <int BD> struct F {
     static void idct_add8(uint8_t **d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[15 * 8])
     { if (!idct_mb<BD>(3, d, bo, b, s, n)) SHIM_FB(B::dsp, idct_add8, d, bo, b, s, n); }
     static void idct_add8_422(uint8_t **d, const int *bo, int16_t *b, ptrdiff_t s, const uint8_t n[15 * 8])
-    { if (!idct_mb<BD>(4, d, bo, b, s, n)) SHIM_FB(B::dsp, idct_add8, d, bo, b, s, n); }
+    { if (!idct_mb<BD>(4, d, bo, b, s, n)) SHIM_FB(B::dsp422, idct_add8, d, bo, b, s, n); }
     static void luma_dc_dequant_idct(int16_t *o, int16_t *i, int q) { if (!dc_dequant<BD>(0, o, i, q)) SHIM_FB(B::dsp, luma_dc_dequant_idct, o, i, q); }
     static void chroma_dc_dequant_idct(int16_t *b, int q) { if (!dc_dequant<BD>(1, b, nullptr, q)) SHIM_FB(B::dsp, chroma_dc_dequant_idct, b, q); }
-    static void chroma422_dc_dequant_idct(int16_t *b, int q) { if (!dc_dequant<BD>(2, b, nullptr, q)) SHIM_FB(B::dsp, chroma_dc_dequant_idct, b, q); }
-#define LF(name, member, kind, inner) static void name(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) \
-    { if (!lf_single<BD>(kind, inner, p, s, a, b, t)) SHIM_FB(B::dsp, member, p, s, a, b, t); }
-#define LFI(name, member, kind, inner) static void name(uint8_t *p, ptrdiff_t s, int a, int b) \
-    { if (!lf_single<BD>(kind, inner, p, s, a, b, nullptr)) SHIM_FB(B::dsp, member, p, s, a, b); }
+    static void chroma422_dc_dequant_idct(int16_t *b, int q) { if (!dc_dequant<BD>(2, b, nullptr, q)) SHIM_FB(B::dsp422, chroma_dc_dequant_idct, b, q); }
+#define LFT(name, member, kind, inner, tab) static void name(uint8_t *p, ptrdiff_t s, int a, int b, int8_t *t) \
+    { if (!lf_single<BD>(kind, inner, p, s, a, b, t)) SHIM_FB(B::tab, member, p, s, a, b, t); }
+#define LFIT(name, member, kind, inner, tab) static void name(uint8_t *p, ptrdiff_t s, int a, int b) \
+    { if (!lf_single<BD>(kind, inner, p, s, a, b, nullptr)) SHIM_FB(B::tab, member, p, s, a, b); }
+#define LF(name, member, kind, inner) LFT(name, member, kind, inner, dsp)
+#define LFI(name, member, kind, inner) LFIT(name, member, kind, inner, dsp)
     LF(v_luma, v_loop_filter_luma, 0, 4) LF(h_luma, h_loop_filter_luma, 1, 4) LF(h_luma_mbaff, h_loop_filter_luma_mbaff, 1, 2)
     LF(v_chroma, v_loop_filter_chroma, 2, 2) LF(h_chroma, h_loop_filter_chroma, 3, 2) LF(h_chroma_mbaff, h_loop_filter_chroma_mbaff, 3, 1)
-    LF(h_chroma422, h_loop_filter_chroma, 3, 4) LF(h_chroma422_mbaff, h_loop_filter_chroma_mbaff, 3, 2)
+    LFT(h_chroma422, h_loop_filter_chroma, 3, 4, dsp422) LFT(h_chroma422_mbaff, h_loop_filter_chroma_mbaff, 3, 2, dsp422)
     LFI(v_luma_i, v_loop_filter_luma_intra, 4, 4) LFI(h_luma_i, h_loop_filter_luma_intra, 5, 4) LFI(h_luma_mbaff_i, h_loop_filter_luma_mbaff_intra, 5, 2)
     LFI(v_chroma_i, v_loop_filter_chroma_intra, 6, 2) LFI(h_chroma_i, h_loop_filter_chroma_intra, 7, 2)
-    LFI(h_chroma_mbaff_i, h_loop_filter_chroma_mbaff_intra, 7, 1) LFI(h_chroma422_i, h_loop_filter_chroma_intra, 7, 4)
-    LFI(h_chroma422_mbaff_i, h_loop_filter_chroma_mbaff_intra, 7, 2)
+    LFI(h_chroma_mbaff_i, h_loop_filter_chroma_mbaff_intra, 7, 1) LFIT(h_chroma422_i, h_loop_filter_chroma_intra, 7, 4, dsp422)
+    LFIT(h_chroma422_mbaff_i, h_loop_filter_chroma_mbaff_intra, 7, 2, dsp422)
 #undef LF
 #undef LFI
+#undef LFT
+#undef LFIT
     template <int AVG, int IDX, int MC> static void qpel(uint8_t *d, const uint8_t *s, ptrdiff_t st)
     {
         if (!qpel_single<BD>(AVG, IDX, MC, d, s, st)) {
@@ -348,7 +357,18 @@ template <int BD>
 int init_dsp(FFHipH264DSPContext *c, FFHipH264DSPContext &o, int cfi, bool all)
 {
     fill_dsp<BD>(o, cfi, all);
-    fb_snapshot(Fb<BD>::dsp, *c, o);
+    if (cfi <= 1) {
+        fb_snapshot(Fb<BD>::dsp, *c, o);
+    } else {
+        /* the six members picked by the chroma format go to the 4:2:2 table, the others (the same C functions either way) to the
+         * depth's common one: equal words are skipped by fb_snapshot */
+        FFHipH264DSPContext in = *c, ours = o;
+        fb_snapshot(Fb<BD>::dsp422, in, ours);
+        ours.h_loop_filter_chroma = in.h_loop_filter_chroma;               ours.h_loop_filter_chroma_intra = in.h_loop_filter_chroma_intra;
+        ours.h_loop_filter_chroma_mbaff = in.h_loop_filter_chroma_mbaff;   ours.h_loop_filter_chroma_mbaff_intra = in.h_loop_filter_chroma_mbaff_intra;
+        ours.idct_add8 = in.idct_add8;                                     ours.chroma_dc_dequant_idct = in.chroma_dc_dequant_idct;
+        fb_snapshot(Fb<BD>::dsp, in, ours);
+    }
     return 0;
 }
 

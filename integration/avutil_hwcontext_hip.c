@@ -7,11 +7,11 @@
  * pitched copies on the device context's stream.  A consumer — the hip swscale backend, a hip decoder — takes AVFrame.data[] /
  * linesize[] as the device pointers and strides of ffhip_sws_scale_batch_dev() & co, and the frames never cross PCIe in between.
  *
- * The shape follows the HWContextType of libavutil/hwcontext_internal.h:32-100.  In the real patch the type gets its own enum values
- * (AV_HWDEVICE_TYPE_HIP, AV_PIX_FMT_HIP, a "hip" row in hw_type_names[] and in hw_table[], libavutil/hwcontext.c:32-100).  This build
- * compiles the reference's hwcontext.c UNCHANGED (avutil_hwcontext_table_hip.c): it borrows the CUDA slot of hw_table[] — the one
- * slot whose frame layout (device pointers in data[]) is the same — so FFHIP_HWDEVICE_TYPE / FFHIP_HW_PIX_FMT below are that slot's
- * values, and every generic entry point (av_hwdevice_ctx_create, av_hwframe_ctx_init, av_hwframe_get_buffer,
+ * The shape follows the HWContextType of libavutil/hwcontext_internal.h:32-100.  The type has enum values of its own
+ * (AV_HWDEVICE_TYPE_HIP, AV_PIX_FMT_HIP: avutil_hwcontext_hip.h) and its rows in hw_table[] / hw_type_names[]
+ * (libavutil/hwcontext.c:32-100) and av_pix_fmt_descriptors[] (libavutil/pixdesc.c) — added by wrappers that compile the reference
+ * files UNCHANGED, where they lie (avutil_hwcontext_table_hip.c, avutil_pixdesc_hip.c): every generic entry point
+ * (av_hwdevice_find_type_by_name("hip"), av_hwdevice_ctx_create, av_hwframe_ctx_init, av_hwframe_get_buffer,
  * av_hwframe_transfer_data) dispatches into this file.
  */
 #include <string.h>

@@ -7,10 +7,16 @@
 #include "libavutil/hwcontext.h"
 #include "libavutil/pixfmt.h"
 
-/* the real patch adds AV_HWDEVICE_TYPE_HIP / AV_PIX_FMT_HIP; this build borrows the CUDA slot of the unmodified hwcontext.c
- * (see avutil_hwcontext_hip.c and avutil_hwcontext_table_hip.c) */
-#define FFHIP_HWDEVICE_TYPE AV_HWDEVICE_TYPE_CUDA
-#define FFHIP_HW_PIX_FMT    AV_PIX_FMT_CUDA
+/* The patch appends one enumerator to each public enum: AV_HWDEVICE_TYPE_HIP after AV_HWDEVICE_TYPE_OHCODEC (libavutil/hwcontext.h:43)
+ * and AV_PIX_FMT_HIP before AV_PIX_FMT_NB (libavutil/pixfmt.h:508).  The reference headers are compiled as they lie, so here the
+ * two are the same VALUES spelled as constants: the first free device type and the first free pixel format.  The files that size or
+ * initialise a table by these enums get the extra row from a wrapper that compiles the reference file where it lies:
+ * hw_type_names[] / hw_table[] in avutil_hwcontext_table_hip.c, av_pix_fmt_descriptors[] in avutil_pixdesc_hip.c. */
+enum { FFHIP_PIX_FMT_NB_REF = AV_PIX_FMT_NB, FFHIP_HWDEVICE_TYPE_NB_REF = AV_HWDEVICE_TYPE_OHCODEC + 1 };
+#define AV_HWDEVICE_TYPE_HIP ((enum AVHWDeviceType)FFHIP_HWDEVICE_TYPE_NB_REF)
+#define AV_PIX_FMT_HIP       ((enum AVPixelFormat)FFHIP_PIX_FMT_NB_REF)
+#define FFHIP_HWDEVICE_TYPE  AV_HWDEVICE_TYPE_HIP   /* (the names the integration files were written with) */
+#define FFHIP_HW_PIX_FMT     AV_PIX_FMT_HIP
 
 typedef struct AVHIPDeviceContext {
     int   device;        /* HIP device ordinal: contexts of libffhip created while it is current are bound to it */

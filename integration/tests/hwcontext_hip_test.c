@@ -205,12 +205,29 @@ int main(int argc, char **argv)
         fprintf(stderr, "unknown pixel format\n");
         return 2;
     }
+    /* (no device needed for the tables) */
+    if (av_hwdevice_find_type_by_name("hip") != AV_HWDEVICE_TYPE_HIP || !av_hwdevice_get_type_name(AV_HWDEVICE_TYPE_HIP) ||
+        strcmp(av_hwdevice_get_type_name(AV_HWDEVICE_TYPE_HIP), "hip") || av_hwdevice_find_type_by_name("cuda") != AV_HWDEVICE_TYPE_CUDA ||
+        av_hwdevice_find_type_by_name("ohcodec") != AV_HWDEVICE_TYPE_OHCODEC) {
+        fprintf(stderr, "FAIL hw_type_names[]\n");
+        return 1;
+    }
+    {
+        const AVPixFmtDescriptor *pd = av_pix_fmt_desc_get(AV_PIX_FMT_HIP), *pc = av_pix_fmt_desc_get(AV_PIX_FMT_CUDA);
+        if (!pd || !(pd->flags & AV_PIX_FMT_FLAG_HWACCEL) || strcmp(pd->name, "hip") || av_get_pix_fmt("hip") != AV_PIX_FMT_HIP ||
+            !pc || strcmp(pc->name, "cuda") || av_get_pix_fmt("cuda") != AV_PIX_FMT_CUDA || av_pix_fmt_desc_get_id(pd) != AV_PIX_FMT_HIP ||
+            strcmp(av_get_pix_fmt_name(AV_PIX_FMT_HIP), "hip")) {
+            fprintf(stderr, "FAIL av_pix_fmt_descriptors[]\n");
+            return 1;
+        }
+    }
+    printf("hip rows of hw_type_names[] / av_pix_fmt_descriptors[]: OK (type %d, format %d)\n", (int)AV_HWDEVICE_TYPE_HIP, (int)AV_PIX_FMT_HIP);
     if (ffhip_device_count() <= 0) {
         printf("SKIP no HIP device\n");
         return 77;
     }
-    /* the type is found by name and by enum through the unmodified hwcontext.c */
-    if (av_hwdevice_iterate_types(AV_HWDEVICE_TYPE_NONE) != FFHIP_HWDEVICE_TYPE) {
+    /* the type is found by name and by enum through the unmodified hwcontext.c, with enum values of its own */
+    if (av_hwdevice_iterate_types(AV_HWDEVICE_TYPE_NONE) != AV_HWDEVICE_TYPE_HIP || AV_HWDEVICE_TYPE_HIP == AV_HWDEVICE_TYPE_CUDA) {
         fprintf(stderr, "FAIL the hip type is not in hw_table[]\n");
         return 1;
     }

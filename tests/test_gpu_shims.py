@@ -230,6 +230,33 @@ def test_faces_fall_back_to_the_displaced_c_functions(monkeypatch, measure_build
     _h264_new_members(c, O, rng, _eq)                           # and the device results are the C results anyway
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("order", ["420-first", "422-first"])
+def test_fallbacks_are_kept_per_chroma_format(depth, order, monkeypatch, measure_build):
+    """ff_h264dsp_init() picks six members by chroma_format_idc (h264dsp.c:113-132).  A 4:2:0 and a 4:2:2 table of one bit depth
+    initialised in one process — either order — each answer, under FFHIP_FAULT=1, through the C function THEY displaced (round 3
+    kept one fallback table per depth: the later init's function answered for both)."""
+    L = _lib()
+    CDC = dict(H264DSP._fields_)["chroma_dc_dequant_idct"]
+    HLF = dict(H264DSP._fields_)["h_loop_filter_chroma_intra"]
+    seen = []
+    keep = {}
+    tabs = {}
+    for cf in ((1, 2) if order == "420-first" else (2, 1)):
+        c = H264DSP()
+        keep[cf] = (CDC(lambda b, q, cf=cf: seen.append(("dc", cf))), HLF(lambda p, s, a, b, cf=cf: seen.append(("lf", cf))))
+        c.chroma_dc_dequant_idct, c.h_loop_filter_chroma_intra = keep[cf]
+        assert L.ff_h264dsp_init_hip(C.byref(c), depth, cf) == 0
+        tabs[cf] = c
+    monkeypatch.setenv("FFHIP_FAULT", "1")
+    blk = np.zeros(64, np.int16 if depth == 8 else np.int32)
+    pix = np.zeros((32, 64), np.uint8)
+    for cf in (1, 2, 1):
+        tabs[cf].chroma_dc_dequant_idct(C.cast(blk.ctypes.data, i16p), 16)
+        tabs[cf].h_loop_filter_chroma_intra(C.cast(pix.ctypes.data + 8 * 64 + 16, u8p), 64, 20, 20)
+    assert seen == [("dc", 1), ("lf", 1), ("dc", 2), ("lf", 2), ("dc", 1), ("lf", 1)], seen
+
+
 def test_h264qpel_init_hip():
     """tests/checkasm/h264qpel.c:51-82: put/avg x sizes x 16 positions, src and dst buffers compared"""
     L = _lib()
