@@ -111,6 +111,8 @@ def lib():
         "ffhip_sws_uops_block_size": (C.c_int, [vp]),
         "ffhip_sws_uops_source": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_size_t]),
         "ffhip_sws_uops_check": (C.c_int, [vp, C.c_int]),
+        "ffhip_sws_uops_cache_stats": (None, [C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+        "ffhip_sws_uops_set_cache_dir": (C.c_int, [C.c_char_p]),
         "ffhip_sws_uops_set_fallback": (None, [vp, vp, vp]),
         "ffhip_sws_uops_func": (None, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "ffhip_sws_uops_run_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),

@@ -18,7 +18,10 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -478,13 +481,95 @@ std::string device_arch(void)
     return "gfx950"; /* no device: ffhip_sws_uops_check() only wants to know that the list compiles */
 }
 
+/*
+ * The on-disk cache of code objects (round 4): a new op list costs a ~25 ms hiprtc compile once per MACHINE, not once per process.
+ * Directory: what the application passed to ffhip_sws_uops_set_cache_dir() (off until it does: the library itself reads no
+ * environment variable; the FFmpeg-side backend picks $XDG_CACHE_HOME/ffhip or $HOME/.cache/ffhip, integration/swscale_hw_hip.c).
+ * A file is named by a 128-bit FNV-1a hash of its key — this file's format tag, the hiprtc version, the architecture and the
+ * program text — and carries the whole key in front of the code object, so a hash collision or a file of another compiler version
+ * reads as a miss; files are written to a temporary name and renamed, so a concurrent reader sees a whole file or none.
+ */
+std::string g_disk_dir; /* guarded by g_cache_mutex; empty = off (the default: the library reads no environment variable) */
+
+std::string disk_key(const std::string &arch, const std::string &src)
+{
+    int maj = 0, min = 0;
+    (void)hiprtcVersion(&maj, &min);
+    char head[96];
+    snprintf(head, sizeof(head), "ffhip-uops-1 hiprtc %d.%d %s\n", maj, min, arch.c_str());
+    return head + src;
+}
+
+std::string disk_path(const std::string &dir, const std::string &key)
+{
+    uint64_t h[2] = { 0xcbf29ce484222325ull, 0x84222325cbf29ce4ull };
+    for (unsigned char c : key) {
+        h[0] = (h[0] ^ c) * 0x100000001b3ull;
+        h[1] = (h[1] ^ (c + 0x9e)) * 0x100000001b3ull + (h[0] >> 29);
+    }
+    char name[64];
+    snprintf(name, sizeof(name), "/%016llx%016llx.hsaco", (unsigned long long)h[0], (unsigned long long)h[1]);
+    return dir + name;
+}
+
+bool disk_load(const std::string &path, const std::string &key, std::vector<char> *code)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f)
+        return false;
+    bool ok = false;
+    uint64_t klen = 0, clen = 0;
+    if (fread(&klen, 8, 1, f) == 1 && fread(&clen, 8, 1, f) == 1 && klen == key.size() && clen > 0 && clen < (1u << 28)) {
+        std::string k(klen, '\0');
+        code->resize(clen);
+        ok = fread(&k[0], 1, klen, f) == klen && k == key && fread(code->data(), 1, clen, f) == clen && fgetc(f) == EOF;
+    }
+    fclose(f);
+    if (!ok)
+        code->clear();
+    return ok;
+}
+
+void disk_store(const std::string &dir, const std::string &path, const std::string &key, const std::vector<char> &code)
+{
+    /* mkdir -p of the last two components (…/.cache may not exist yet); failures just leave the cache cold */
+    const size_t cut = dir.rfind('/');
+    if (cut != std::string::npos && cut > 0)
+        (void)mkdir(dir.substr(0, cut).c_str(), 0700);
+    (void)mkdir(dir.c_str(), 0700);
+    char tmp[32];
+    snprintf(tmp, sizeof(tmp), ".tmp%ld", (long)getpid());
+    const std::string t = path + tmp;
+    FILE *f = fopen(t.c_str(), "wb");
+    if (!f)
+        return;
+    const uint64_t klen = key.size(), clen = code.size();
+    const bool ok = fwrite(&klen, 8, 1, f) == 1 && fwrite(&clen, 8, 1, f) == 1 && fwrite(key.data(), 1, klen, f) == klen &&
+                    fwrite(code.data(), 1, clen, f) == clen;
+    if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0)
+        (void)remove(t.c_str());
+}
+
+std::atomic<long> g_compiles{0}, g_disk_hits{0};
+
 int build(const std::string &src, std::shared_ptr<Program> *out, bool load)
 {
     const std::string arch = device_arch();
     const std::string key = arch + "\n" + src;
     std::lock_guard<std::mutex> lk(g_cache_mutex);
     std::shared_ptr<Program> &pr = g_cache[key];
+    const std::string ddir = pr ? std::string() : g_disk_dir;
+    const std::string dkey = ddir.empty() ? std::string() : disk_key(arch, src);
+    const std::string dpath = ddir.empty() ? std::string() : disk_path(ddir, dkey);
+    if (!pr && !ddir.empty()) {
+        auto np = std::make_shared<Program>();
+        if (disk_load(dpath, dkey, &np->code)) {
+            g_disk_hits++;
+            pr = np;
+        }
+    }
     if (!pr) {
+        g_compiles++;
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, src.c_str(), "sws_uops.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
             ffhip_set_error("hiprtcCreateProgram failed");
@@ -511,6 +596,8 @@ int build(const std::string &src, std::shared_ptr<Program> *out, bool load)
         hiprtcGetCode(prog, np->code.data());
         hiprtcDestroyProgram(&prog);
         pr = np;
+        if (!ddir.empty())
+            disk_store(ddir, dpath, dkey, np->code);
     }
     if (load) {
         if (!ffhip_have_device())
@@ -566,6 +653,21 @@ extern "C" int ffhip_sws_uops_check(const FFHipSwsUOp *uops, int num_uops)
         return r;
     std::shared_ptr<Program> pr;
     return build(pl.src, &pr, false);
+}
+
+extern "C" int ffhip_sws_uops_set_cache_dir(const char *dir)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    g_disk_dir = dir ? dir : "";
+    return 0;
+}
+
+extern "C" void ffhip_sws_uops_cache_stats(long *compiles, long *disk_hits)
+{
+    if (compiles)
+        *compiles = g_compiles.load();
+    if (disk_hits)
+        *disk_hits = g_disk_hits.load();
 }
 
 extern "C" void ffhip_sws_uops_free(FFHipSwsUOps **pp)

@@ -1536,6 +1536,15 @@ int  ffhip_sws_uops_block_size(const FFHipSwsUOps *p);
 int  ffhip_sws_uops_source(const FFHipSwsUOp *uops, int num_uops, char *buf, size_t size);
 /** Generates and compiles the program without loading it (no device needed): 0, FFHIP_ENOTSUP, FFHIP_EINVAL or FFHIP_EIO. */
 int  ffhip_sws_uops_check(const FFHipSwsUOp *uops, int num_uops);
+/** Compiled programs are kept per process (by program text) and — once the application names a directory — across processes as
+ *  code objects on disk, so that the ~25 ms hiprtc compile of a new op list is paid once per machine.  NULL or "" turns the disk
+ *  cache off, which is the default: the library reads no environment variable; the FFmpeg-side backend chooses
+ *  $XDG_CACHE_HOME/ffhip or $HOME/.cache/ffhip (integration/swscale_hw_hip.c).  The directory (and its parent) is created on the first
+ *  store.  A file carries its whole key (hiprtc version, architecture, program text): a stale, damaged or foreign file is a miss and
+ *  is rewritten; files appear by rename, so concurrent processes are safe.  Process-wide; returns 0. */
+int  ffhip_sws_uops_set_cache_dir(const char *dir);
+/** hiprtc compiles and disk hits of this process so far (either pointer may be NULL). */
+void ffhip_sws_uops_cache_stats(long *compiles, long *disk_hits);
 /** What the void face below runs when the device fails under it (the same list compiled by the caller's C backend). */
 void ffhip_sws_uops_set_fallback(FFHipSwsUOps *p, FFHipSwsOpFunc func, const void *priv);
 /** SwsCompiledOp.func for software frames: HOST pointers in `exec`, priv = the FFHipSwsUOps.  Stages exactly the bytes the

@@ -25,6 +25,11 @@
 #include "libswscale/ops_internal.h"
 #include "libswscale/uops.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "libavutil/thread.h"
+
 #include "ffhip.h"
 #include "avutil_hwcontext_hip.h"
 
@@ -59,9 +64,26 @@ static void hip_hw_free(void *priv)
     ffhip_sws_uops_free(&u);
 }
 
+/* Where compiled op lists are kept between processes (ffhip_sws_uops_set_cache_dir): the user's cache directory, as the Vulkan
+ * pipeline cache and the shader caches of the drivers do.  libffhip itself reads no environment variable; this is the FFmpeg side. */
+static AVOnce hip_uops_cache_once = AV_ONCE_INIT;
+static void hip_uops_cache_dir(void)
+{
+    const char *x = getenv("XDG_CACHE_HOME"), *h = getenv("HOME");
+    char dir[1024];
+    if (x && x[0])
+        snprintf(dir, sizeof(dir), "%s/ffhip", x);
+    else if (h && h[0])
+        snprintf(dir, sizeof(dir), "%s/.cache/ffhip", h);
+    else
+        return;
+    ffhip_sws_uops_set_cache_dir(dir);
+}
+
 static int compile_uops_hip_hw(SwsContext *ctx, const SwsUOpList *uops, SwsCompiledOp *out)
 {
     FFHipSwsUOps *u = NULL;
+    ff_thread_once(&hip_uops_cache_once, hip_uops_cache_dir);
     const int ret = ffhip_sws_uops_compile((const FFHipSwsUOp *)uops->ops, uops->num_ops, &u);
     if (ret < 0)
         return ret == FFHIP_ENOTSUP ? AVERROR(ENOTSUP) : ret == FFHIP_ENOSYS ? AVERROR(ENOSYS) : AVERROR(EINVAL);

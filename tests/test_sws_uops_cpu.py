@@ -2,12 +2,15 @@
 instance on checkasm's shapes (tests/checkasm/sw_ops.c) and as the backend of the reference's own graph — and the generator of
 libffhip checked without a GPU (every program it writes for those lists compiles with hiprtc)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 import ffi
 import swsops as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.skipif(not ffi.have_ref(), reason="oracle/_ref/libffref.so not built")
 
@@ -175,3 +178,53 @@ def test_generated_programs_compile():
     if lut:
         lst = (S.UOp * 3)(S._mk(S.U32, S.READ_PLANAR), lut[0], S._mk(S.U32, S.WRITE_PLANAR))
         assert L.ffhip_sws_uops_check(lst, 3) == -95
+
+
+def test_code_objects_are_cached_on_disk(tmp_path):
+    """The on-disk cache of compiled op lists (include/ffhip.h, ffhip_sws_uops_cache_stats): a second PROCESS finds the code objects
+    the first one compiled (ffhip_sws_uops_set_cache_dir), a damaged file is a miss that is rewritten, no directory = every list compiled."""
+    import subprocess
+    import sys
+    prog = r"""
+import ctypes as C, sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import ffi, swsops as S
+from ffmpeg_amd import _lib
+L = _lib.lib()
+R = S.declare_ref(ffi.ref())
+L.ffhip_sws_uops_check.argtypes = [C.POINTER(S.UOp), C.c_int]
+if sys.argv[1]:
+    assert L.ffhip_sws_uops_set_cache_dir(sys.argv[1].encode()) == 0
+rng = np.random.default_rng(5)
+n = 0
+for name, u in S.instances(R):
+    if u.uop in (S.LINEAR, S.PERMUTE) or n >= 6:
+        continue
+    case = S.case_of(rng, name, u, None)[0]
+    assert L.ffhip_sws_uops_check(case.uops, len(case.uops)) == 0
+    n += 1
+a, b = C.c_long(), C.c_long()
+L.ffhip_sws_uops_cache_stats(C.byref(a), C.byref(b))
+print("STATS", n, a.value, b.value)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+    def run(cache):
+        r = subprocess.run([sys.executable, "-c", prog, cache], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return [int(x) for x in [ln for ln in r.stdout.splitlines() if ln.startswith("STATS")][0].split()[1:]]
+    d = str(tmp_path / "cache" / "ffhip")
+    n, comp, hits = run(d)
+    assert n == 6 and comp == 6 and hits == 0
+    files = sorted(os.listdir(d))
+    assert len(files) == 6 and all(f.endswith(".hsaco") for f in files)
+    assert run(d) == [6, 0, 6]                                   # another process: nothing compiled
+    with open(os.path.join(d, files[0]), "r+b") as f:            # a truncated file is a miss ...
+        f.truncate(100)
+    with open(os.path.join(d, files[1]), "r+b") as f:            # ... and so is one whose key was tampered with
+        f.seek(20)
+        f.write(b"X")
+    assert run(d) == [6, 2, 4]
+    assert run(d) == [6, 0, 6]                                   # ... rewritten whole
+    assert run("") == [6, 6, 0]                                  # off
+    assert sorted(os.listdir(d)) == files
