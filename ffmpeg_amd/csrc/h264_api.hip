@@ -248,7 +248,7 @@ extern "C" int ffhip_vp9_intra_pred_batch_dev(int tx, uint8_t *dst, ptrdiff_t st
 extern "C" int ffhip_h264_pred_batch_dev(int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n,
                                          void *stream)
 {
-    if (!plane || !blocks || n < 0 || kind < 0 || kind > FFHIP_H264_PRED8x16 ||
+    if (!plane || !blocks || n < 0 || kind < 0 || kind > FFHIP_H264_PRED_CODEC ||
         (kind >= FFHIP_H264_PRED4x4_ADD && kind <= FFHIP_H264_PRED8x8L_FILTER_ADD && !coeffs))
         return FFHIP_EINVAL;
     if (!ffhip_have_device())

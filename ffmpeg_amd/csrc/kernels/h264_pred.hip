@@ -361,6 +361,122 @@ __global__ __launch_bounds__(256) void k_h264_pred_add(uint8_t *plane, ptrdiff_t
     }
 }
 
+
+/*
+ * The forms ff_h264_pred_init() installs for the OTHER codecs that share H264PredContext (libavcodec/h264pred.c:540-578, bodies
+ * :57-432; 8 bits): SVQ3, RV40, VP7 / VP8.  `mode` is a FFHIP_H264_PREDV_* code (include/ffhip.h) that also says the block size.
+ * One thread per sample; a thread reads the handful of neighbours its sample's rule names straight from the plane (tails of the
+ * table: no staging).  t(i) = the row above (i >= 4 of a 4x4 block: topright[i - 4]), l(i) = the left column (i >= 4: the rows
+ * below the block, RV40's "down-left" edge; the _NODOWN forms repeat l3), lt = the corner.
+ */
+__global__ __launch_bounds__(256) void k_h264_pred_codec(uint8_t *plane, ptrdiff_t stride, const FFHipH264Pred *blocks, int n)
+{
+    const int b = blockIdx.x;
+    if (b >= n)
+        return;
+    const FFHipH264Pred k = blocks[b];
+    const int mode = k.mode;
+    const int N = mode < 16 ? 4 : mode < 32 ? 8 : 16;
+    const int tid = threadIdx.x;
+    if (tid >= N * N)
+        return;
+    const int x = tid % N, y = tid / N;
+    uint8_t *src = plane + k.offset;
+    const uint8_t *tr = plane + k.aux;
+    auto t = [&](int i) -> int { return N == 4 && i >= 4 ? tr[i - 4] : src[i - stride]; };
+    auto lraw = [&](int i) -> int { return src[(ptrdiff_t)i * stride - 1]; };
+    const bool nodown = mode == FFHIP_H264_PREDV_DL_RV40_NODOWN || mode == FFHIP_H264_PREDV_VL_RV40_NODOWN || mode == FFHIP_H264_PREDV_HU_RV40_NODOWN;
+    auto l = [&](int i) -> int { return lraw(nodown && i > 3 ? 3 : i); };
+    auto clip = [](int v) -> int { return v < 0 ? 0 : v > 255 ? 255 : v; };
+    int v = 0;
+    switch (mode) {
+    case FFHIP_H264_PREDV_127_DC: case FFHIP_H264_PREDV8_127_DC: case FFHIP_H264_PREDV16_127_DC: v = 127; break;
+    case FFHIP_H264_PREDV_129_DC: case FFHIP_H264_PREDV8_129_DC: case FFHIP_H264_PREDV16_129_DC: v = 129; break;
+    case FFHIP_H264_PREDV_VERT_VP8: /* pred4x4_vertical_vp8_c: the row above, smoothed */
+        v = ((x ? t(x - 1) : (int)src[-1 - stride]) + 2 * t(x) + t(x + 1) + 2) >> 2;
+        break;
+    case FFHIP_H264_PREDV_HOR_VP8:  /* pred4x4_horizontal_vp8_c */
+        v = ((y ? lraw(y - 1) : (int)src[-1 - stride]) + 2 * lraw(y) + lraw(y < 3 ? y + 1 : 3) + 2) >> 2;
+        break;
+    case FFHIP_H264_PREDV_DL_SVQ3: { /* pred4x4_down_left_svq3_c */
+        const int i = min(x + y + 1, 3);
+        v = (lraw(i) + t(i)) >> 1;
+        break;
+    }
+    case FFHIP_H264_PREDV_DL_RV40: case FFHIP_H264_PREDV_DL_RV40_NODOWN: { /* pred4x4_down_left_rv40{,_nodown}_c */
+        const int d = x + y;
+        v = d < 6 ? (t(d) + t(d + 2) + 2 * t(d + 1) + 2 + l(d) + l(d + 2) + 2 * l(d + 1) + 2) >> 3 : (t(6) + t(7) + 1 + l(6) + l(7) + 1) >> 2;
+        break;
+    }
+    case FFHIP_H264_PREDV_VL_RV40: case FFHIP_H264_PREDV_VL_RV40_NODOWN: /* pred4x4_vertical_left_rv40 (l4 = l3 without the down-left edge) */
+        if (!(y & 1)) {
+            const int q = x + (y >> 1);
+            v = x == 0 && y == 0 ? (2 * t(0) + 2 * t(1) + l(1) + 2 * l(2) + l(3) + 4) >> 3 : (t(q) + t(q + 1) + 1) >> 1;
+        } else {
+            const int q = x + (y >> 1);
+            v = x == 0 && y == 1 ? (t(0) + 2 * t(1) + t(2) + l(2) + 2 * l(3) + l(4) + 4) >> 3 : (t(q) + 2 * t(q + 1) + t(q + 2) + 2) >> 2;
+        }
+        break;
+    case FFHIP_H264_PREDV_VL_VP8: { /* pred4x4_vertical_left_vp8_c: H.264's but for the last column's lower half */
+        const int q = x + (y >> 1);
+        if (x == 3 && y >= 2)
+            v = (t(y + 2) + 2 * t(y + 3) + t(y + 4) + 2) >> 2;
+        else
+            v = (y & 1) ? (t(q) + 2 * t(q + 1) + t(q + 2) + 2) >> 2 : (t(q) + t(q + 1) + 1) >> 1;
+        break;
+    }
+    case FFHIP_H264_PREDV_HU_RV40: case FFHIP_H264_PREDV_HU_RV40_NODOWN: { /* pred4x4_horizontal_up_rv40{,_nodown}_c */
+        const int z = x + 2 * y;
+        switch (z) {
+        case 0: v = (t(1) + 2 * t(2) + t(3) + 2 * l(0) + 2 * l(1) + 4) >> 3; break;
+        case 1: v = (t(2) + 2 * t(3) + t(4) + l(0) + 2 * l(1) + l(2) + 4) >> 3; break;
+        case 2: v = (t(3) + 2 * t(4) + t(5) + 2 * l(1) + 2 * l(2) + 4) >> 3; break;
+        case 3: v = (t(4) + 2 * t(5) + t(6) + l(1) + 2 * l(2) + l(3) + 4) >> 3; break;
+        case 4: v = (t(5) + 2 * t(6) + t(7) + 2 * l(2) + 2 * l(3) + 4) >> 3; break;
+        case 5: v = (t(6) + 3 * t(7) + l(2) + 3 * l(3) + 4) >> 3; break;
+        case 6: v = (t(6) + t(7) + l(3) + l(4) + 2) >> 2; break;
+        case 7: v = (l(3) + 2 * l(4) + l(5) + 2) >> 2; break;
+        case 8: v = (l(4) + l(5) + 1) >> 1; break;
+        default: v = (l(4) + 2 * l(5) + l(6) + 2) >> 2; break;
+        }
+        break;
+    }
+    case FFHIP_H264_PREDV_TM_VP8: case FFHIP_H264_PREDV8_TM_VP8: case FFHIP_H264_PREDV16_TM_VP8: /* pred{4x4,8x8,16x16}_tm_vp8_c */
+        v = clip(lraw(y) + t(x) - (int)src[-1 - stride]);
+        break;
+    case FFHIP_H264_PREDV8_DC_RV40: case FFHIP_H264_PREDV8_LEFT_DC_RV40: case FFHIP_H264_PREDV8_TOP_DC_RV40: { /* pred8x8_*dc_rv40_c */
+        int sl = 0, st = 0;
+        for (int i = 0; i < 8; i++) {
+            if (mode != FFHIP_H264_PREDV8_TOP_DC_RV40) sl += lraw(i);
+            if (mode != FFHIP_H264_PREDV8_LEFT_DC_RV40) st += t(i);
+        }
+        v = mode == FFHIP_H264_PREDV8_DC_RV40 ? (sl + st + 8) >> 4 : (sl + st + 4) >> 3;
+        break;
+    }
+    default: { /* FFHIP_H264_PREDV16_PLANE_SVQ3 / _RV40: pred16x16_plane_compat_8_c (h264pred_template.c:410-456) */
+        int H = 0, V = 0;
+        for (int q = 1; q <= 8; q++) {
+            H += q * (t(7 + q) - (q == 8 ? (int)src[-1 - stride] : t(7 - q)));
+            V += q * (lraw(7 + q) - (q == 8 ? (int)src[-1 - stride] : lraw(7 - q)));
+        }
+        if (mode == FFHIP_H264_PREDV16_PLANE_SVQ3) {
+            const int h2 = (5 * (H / 4)) / 16, v2 = (5 * (V / 4)) / 16;
+            H = v2; V = h2; /* "required for 100% accuracy": the two are swapped */
+        } else {
+            H = (H + (H >> 2)) >> 4;
+            V = (V + (V >> 2)) >> 4;
+        }
+        const int a = 16 * (lraw(15) + t(15) + 1) - 7 * (V + H);
+        v = clip((a + y * V + x * H) >> 5);
+        break;
+    }
+    }
+    /* every sample is computed before any is stored: the block's own samples are nobody's neighbours, but a 4x4 block's topright
+     * pointer may lead anywhere */
+    __syncthreads();
+    src[(ptrdiff_t)y * stride + x] = (uint8_t)v;
+}
+
 int ffhip_launch_h264_pred_bd(int bd, int kind, uint8_t *plane, ptrdiff_t stride, int16_t *coeffs, const FFHipH264Pred *blocks, int n,
                               hipStream_t stream)
 {
@@ -395,8 +511,15 @@ int ffhip_launch_h264_pred_bd(int bd, int kind, uint8_t *plane, ptrdiff_t stride
     case FFHIP_H264_PRED4x4_ADD:         PRED_ADD(cdiv(n, 64), 4, false); break;
     case FFHIP_H264_PRED8x8L_ADD:        PRED_ADD(cdiv(n, 32), 8, false); break;
     case FFHIP_H264_PRED8x8L_FILTER_ADD: PRED_ADD(cdiv(n, 32), 8, true); break;
+    case FFHIP_H264_PRED_CODEC:
+        if (bd != 8) {
+            ffhip_set_error("ffhip_h264_pred: the other codecs' forms exist at 8 bits only (libavcodec/h264pred.c:540)");
+            return FFHIP_EINVAL;
+        }
+        hipLaunchKernelGGL(k_h264_pred_codec, dim3(n), block, 0, stream, plane, stride, blocks, n);
+        break;
     default:
-        ffhip_set_error("ffhip_h264_pred: kind %d outside 0..7", kind);
+        ffhip_set_error("ffhip_h264_pred: kind %d outside 0..8", kind);
         return FFHIP_EINVAL;
     }
 #undef PRED_GO

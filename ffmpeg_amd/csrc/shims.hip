@@ -1164,7 +1164,8 @@ static bool h264_pred_host(int bd, int kind, int mode, int n, unsigned need, int
     }
     if (need & 4)
         memcpy(o - HP_P - px, src - stride - px, px);
-    if (kind == FFHIP_H264_PRED4x4 && (need & 8))
+    const bool k4 = kind == FFHIP_H264_PRED4x4 || (kind == FFHIP_H264_PRED_CODEC && n == 4); /* the 4x4 kinds take a topright pointer */
+    if (k4 && (need & 8))
         memcpy(o - HP_P + 32, topright, 4 * px); /* wherever the caller's pointer leads, the record addresses the staged copy */
     const int ncoef = block ? n * n * px : 0; /* in int16 units: int32 coefficients above 8 bits */
     Arena A(64 + sizeof(st) + 256 + 64);
@@ -1174,7 +1175,7 @@ static bool h264_pred_host(int bd, int kind, int mode, int n, unsigned need, int
     int16_t *dc = (int16_t *)(dp + sizeof(st));
     FFHipH264Pred k = {};
     k.offset = HP_P + 16;
-    k.aux = kind == FFHIP_H264_PRED4x4 ? 16 + 32 : 0; /* where topright[] was staged: row 0 of the patch */
+    k.aux = k4 ? 16 + 32 : 0; /* where topright[] was staged: row 0 of the patch */
     k.mode = (uint8_t)mode;
     k.flags = (uint8_t)((has_tl ? FFHIP_H264_PRED_TOPLEFT : 0) | (has_tr ? FFHIP_H264_PRED_TOPRIGHT : 0));
     if (hipMemcpy(buf, &k, sizeof(k), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dp, st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess)
@@ -1266,10 +1267,10 @@ static void s_pred_8x16_add(uint8_t *pix, const int *block_offset, int16_t *bloc
 }
 
 #undef g_fb_pred
+/* the faces of the H.264 table at the depth */
 template <int BD>
-static int h264_pred_fill(FFHipH264PredContext *h, int chroma_format_idc)
+static void h264_pred_faces(FFHipH264PredContext &o, int chroma_format_idc)
 {
-    FFHipH264PredContext o = *h;
 #define HP(M) o.pred4x4[M] = s_pred4x4<BD, M>; o.pred8x8l[M] = s_pred8x8l<BD, M>;
     HP(0) HP(1) HP(2) HP(3) HP(4) HP(5) HP(6) HP(7) HP(8) HP(9) HP(10) HP(11)
 #undef HP
@@ -1294,6 +1295,13 @@ static int h264_pred_fill(FFHipH264PredContext *h, int chroma_format_idc)
         o.pred8x8_add[2] = s_pred_8x16_add<BD, 2>;     o.pred8x8_add[1] = s_pred_8x16_add<BD, 1>;
     }
     o.pred16x16_add[2] = s_pred_mb_add<BD, 16, 2>; o.pred16x16_add[1] = s_pred_mb_add<BD, 16, 1>;
+}
+
+template <int BD>
+static int h264_pred_fill(FFHipH264PredContext *h, int chroma_format_idc)
+{
+    FFHipH264PredContext o = *h;
+    h264_pred_faces<BD>(o, chroma_format_idc);
     if (chroma_format_idc <= 1) {
         fb_snapshot(PredFb<BD>::t, *h, o);
     } else {
@@ -1308,10 +1316,113 @@ static int h264_pred_fill(FFHipH264PredContext *h, int chroma_format_idc)
     return 0;
 }
 
+
+/* ---- the other codecs that share H264PredContext (h264pred.c:540-578; 8 bits, 4:2:0): SVQ3, RV40, VP7, VP8 ---- */
+/* the C functions their own forms displaced: one table per codec (CI 0 SVQ3, 1 RV40, 2 VP7, 3 VP8); the members a codec shares with
+ * H.264 answer through the 8-bit table PredFb<8>::t like every other 8-bit context's */
+template <int CI> struct PredFbCodec { static FFHipH264PredContext t; };
+template <int CI> FFHipH264PredContext PredFbCodec<CI>::t;
+/* need: bit0 left (LROWS rows), bit1 row above, bit2 corner, bit3 topright[0..3] */
+template <int CI, int IDX, int V, unsigned NEED, int LROWS>
+static void s_predv4(uint8_t *src, const uint8_t *topright, ptrdiff_t stride)
+{
+    if (!h264_pred_host(8, FFHIP_H264_PRED_CODEC, V, 4, NEED, LROWS, src, stride, topright, 0, 0, nullptr))
+        SHIM_FB(PredFbCodec<CI>::t, pred4x4[IDX], src, topright, stride);
+}
+/* an H.264 form in a slot of the codec's own (VP7 / VP8: the plain vertical / horizontal at VERT_VP8_PRED / HOR_VP8_PRED) */
+template <int CI, int IDX, int MODE>
+static void s_predv4_plain(uint8_t *src, const uint8_t *topright, ptrdiff_t stride)
+{
+    if (!h264_pred_host(8, FFHIP_H264_PRED4x4, MODE, 4, hp_need4(MODE), 4, src, stride, topright, 0, 0, nullptr))
+        SHIM_FB(PredFbCodec<CI>::t, pred4x4[IDX], src, topright, stride);
+}
+template <int CI, int IDX, int V, unsigned NEED>
+static void s_predv8(uint8_t *src, ptrdiff_t stride)
+{
+    if (!h264_pred_host(8, FFHIP_H264_PRED_CODEC, V, 8, NEED, 8, src, stride, nullptr, 0, 0, nullptr))
+        SHIM_FB(PredFbCodec<CI>::t, pred8x8[IDX], src, stride);
+}
+template <int CI, int IDX, int V, unsigned NEED>
+static void s_predv16(uint8_t *src, ptrdiff_t stride)
+{
+    if (!h264_pred_host(8, FFHIP_H264_PRED_CODEC, V, 16, NEED, 16, src, stride, nullptr, 0, 0, nullptr))
+        SHIM_FB(PredFbCodec<CI>::t, pred16x16[IDX], src, stride);
+}
+
+template <int CI>
+static int h264_pred_fill_codec(FFHipH264PredContext *h)
+{
+    const FFHipH264PredContext in = *h;
+    FFHipH264PredContext o = in;
+    h264_pred_faces<8>(o, 1);
+    FFHipH264PredContext shared = o; /* what the codec takes from the H.264 table */
+    if (CI == 0) { /* SVQ3 */
+        o.pred4x4[3] = s_predv4<CI, 3, FFHIP_H264_PREDV_DL_SVQ3, 3u, 4>;
+        o.pred16x16[3] = s_predv16<CI, 3, FFHIP_H264_PREDV16_PLANE_SVQ3, 7u>;
+    } else if (CI == 1) { /* RV40 */
+        o.pred4x4[3] = s_predv4<CI, 3, FFHIP_H264_PREDV_DL_RV40, 11u, 8>;
+        o.pred4x4[7] = s_predv4<CI, 7, FFHIP_H264_PREDV_VL_RV40, 11u, 8>;
+        o.pred4x4[8] = s_predv4<CI, 8, FFHIP_H264_PREDV_HU_RV40, 11u, 8>;
+        o.pred4x4[12] = s_predv4<CI, 12, FFHIP_H264_PREDV_DL_RV40_NODOWN, 11u, 4>;
+        o.pred4x4[13] = s_predv4<CI, 13, FFHIP_H264_PREDV_HU_RV40_NODOWN, 11u, 4>;
+        o.pred4x4[14] = s_predv4<CI, 14, FFHIP_H264_PREDV_VL_RV40_NODOWN, 11u, 4>;
+        o.pred16x16[3] = s_predv16<CI, 3, FFHIP_H264_PREDV16_PLANE_RV40, 7u>;
+    } else { /* VP7 / VP8 */
+        o.pred4x4[0] = s_predv4<CI, 0, FFHIP_H264_PREDV_VERT_VP8, 14u, 4>;
+        o.pred4x4[1] = s_predv4<CI, 1, FFHIP_H264_PREDV_HOR_VP8, 5u, 4>;
+        o.pred4x4[7] = s_predv4<CI, 7, FFHIP_H264_PREDV_VL_VP8, 10u, 4>;
+        o.pred4x4[9] = s_predv4<CI, 9, FFHIP_H264_PREDV_TM_VP8, 7u, 4>;
+        o.pred4x4[10] = s_predv4_plain<CI, 10, 0>;  /* VERT_VP8_PRED: the plain vertical / horizontal forms (h264pred.c:563,566) */
+        o.pred4x4[14] = s_predv4_plain<CI, 14, 1>;  /* HOR_VP8_PRED */
+        o.pred4x4[12] = s_predv4<CI, 12, FFHIP_H264_PREDV_127_DC, 0u, 4>;
+        o.pred4x4[13] = s_predv4<CI, 13, FFHIP_H264_PREDV_129_DC, 0u, 4>;
+        o.pred8x8[3] = s_predv8<CI, 3, FFHIP_H264_PREDV8_TM_VP8, 7u>;
+        o.pred8x8[7] = s_predv8<CI, 7, FFHIP_H264_PREDV8_127_DC, 0u>;
+        o.pred8x8[8] = s_predv8<CI, 8, FFHIP_H264_PREDV8_129_DC, 0u>;
+        o.pred16x16[3] = s_predv16<CI, 3, FFHIP_H264_PREDV16_TM_VP8, 7u>;
+        o.pred16x16[7] = s_predv16<CI, 7, FFHIP_H264_PREDV16_127_DC, 0u>;
+        o.pred16x16[8] = s_predv16<CI, 8, FFHIP_H264_PREDV16_129_DC, 0u>;
+        if (CI == 3)
+            o.pred4x4[11] = in.pred4x4[11]; /* VP8: DC_128_PRED is not set (h264pred.c:466) */
+    }
+    if (CI >= 1) { /* RV40 / VP7 / VP8: the rv40 DCs, and no "mad cow" forms (h264pred.c:489-513) */
+        o.pred8x8[0] = s_predv8<CI, 0, FFHIP_H264_PREDV8_DC_RV40, 3u>;
+        o.pred8x8[4] = s_predv8<CI, 4, FFHIP_H264_PREDV8_LEFT_DC_RV40, 1u>;
+        o.pred8x8[5] = s_predv8<CI, 5, FFHIP_H264_PREDV8_TOP_DC_RV40, 2u>;
+        for (int m = 7; m <= 10; m++)
+            if (!(CI >= 2 && m <= 8))
+                o.pred8x8[m] = in.pred8x8[m];
+    }
+    /* the displaced C functions: a member whose face is the H.264 table's goes to that table, the codec's own forms to the codec's */
+    FFHipH264PredContext in_shared = in, in_own = in;
+    void **po = reinterpret_cast<void **>(&o), **ps = reinterpret_cast<void **>(&shared);
+    void **pis = reinterpret_cast<void **>(&in_shared), **pio = reinterpret_cast<void **>(&in_own);
+    for (size_t i = 0; i < sizeof(o) / sizeof(void *); i++) {
+        if (po[i] == ps[i])
+            pio[i] = po[i]; /* shared face: nothing for the codec's table */
+        else
+            pis[i] = po[i]; /* own form (or left alone): nothing for the shared table */
+    }
+    fb_snapshot(PredFb<8>::t, in_shared, o);
+    fb_snapshot(PredFbCodec<CI>::t, in_own, o);
+    *h = o;
+    return 0;
+}
+
 extern "C" int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc)
 {
     /* AV_CODEC_ID_H264 at the depths it defines; chroma_format_idc >= 2 switches pred8x8 to the 8 x 16 forms (h264pred.c:478-535) */
-    if (!h || codec_id != FFHIP_CODEC_ID_H264 || chroma_format_idc < 0 || chroma_format_idc > 3)
+    if (!h || chroma_format_idc < 0 || chroma_format_idc > 3)
+        return FFHIP_EINVAL;
+    if (codec_id == FFHIP_CODEC_ID_SVQ3 || codec_id == FFHIP_CODEC_ID_RV40 || codec_id == FFHIP_CODEC_ID_VP7 || codec_id == FFHIP_CODEC_ID_VP8) {
+        if (bit_depth != 8 || chroma_format_idc > 1)
+            return FFHIP_EINVAL; /* these codecs are 8 bits, 4:2:0 */
+        if (!ffhip_have_device())
+            return FFHIP_ENOSYS;
+        return codec_id == FFHIP_CODEC_ID_SVQ3 ? h264_pred_fill_codec<0>(h) : codec_id == FFHIP_CODEC_ID_RV40 ? h264_pred_fill_codec<1>(h)
+             : codec_id == FFHIP_CODEC_ID_VP7 ? h264_pred_fill_codec<2>(h) : h264_pred_fill_codec<3>(h);
+    }
+    if (codec_id != FFHIP_CODEC_ID_H264)
         return FFHIP_EINVAL;
     if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14)
         return FFHIP_EINVAL;

@@ -902,12 +902,18 @@ typedef struct FFHipH264PredContext {
     void (*pred8x8_add[3])(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
     void (*pred16x16_add[3])(uint8_t *pix, const int *block_offset, int16_t *block, ptrdiff_t stride);
 } FFHipH264PredContext;
-#define FFHIP_CODEC_ID_H264 27 /* AV_CODEC_ID_H264 (libavcodec/codec_id.h:77) */
+#define FFHIP_CODEC_ID_H264 27  /* AV_CODEC_ID_H264 (libavcodec/codec_id.h:77) */
+#define FFHIP_CODEC_ID_SVQ3 23  /* AV_CODEC_ID_SVQ3, _RV40, _VP8, _VP7 (libavcodec/codec_id.h): the codecs whose decoders share H264PredContext, with their */
+#define FFHIP_CODEC_ID_RV40 69  /* own forms of some members at 8 bits (libavcodec/h264pred.c:540-578)                                                    */
+#define FFHIP_CODEC_ID_VP8  139
+#define FFHIP_CODEC_ID_VP7  178
 /** ff_h264_pred_init_<arch>(H264PredContext *, codec_id, bit_depth, chroma_format_idc) shape (libavcodec/h264pred.h:120-127).
  *  bit_depth 8 / 9 / 10 / 12 / 14 (16-bit samples and int32 coefficients of the _add members above 8; the depth is baked into the
  *  installed functions).  chroma_format_idc 0..3: from 2 on pred8x8[] / pred8x8_add[] are the 8 wide x 16 tall forms, as
- *  ff_h264_pred_init() installs them (h264pred.c:478-535).  FFHIP_EINVAL for what this library does not replace (other codecs'
- *  variants): those keep the C pointers. */
+ *  ff_h264_pred_init() installs them (h264pred.c:478-535).  codec_id: FFHIP_CODEC_ID_H264, or — 8 bits, chroma_format_idc <= 1 — SVQ3 /
+ *  RV40 / VP7 / VP8: the table as ff_h264_pred_init() leaves it for that codec (their own forms of pred4x4[] / pred8x8[] / pred16x16[]
+ *  members, h264pred.c:540-578; members the reference does not set for the codec — RV40 / VP7 / VP8: pred8x8[]'s four "mad cow" DC
+ *  slots, VP8: pred4x4[DC_128_PRED] — are left as they were).  FFHIP_EINVAL for any other codec_id. */
 int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, int chroma_format_idc);
 
 #define FFHIP_H264_PRED4x4             0  /* pred4x4[mode]                                 */
@@ -918,6 +924,36 @@ int ff_h264_pred_init_hip(FFHipH264PredContext *h, int codec_id, int bit_depth, 
 #define FFHIP_H264_PRED8x8L_ADD        5  /* pred8x8l_add[mode]                            */
 #define FFHIP_H264_PRED8x8L_FILTER_ADD 6  /* pred8x8l_filter_add[mode]                     */
 #define FFHIP_H264_PRED8x16            7  /* pred8x8[mode] at chroma_format_idc 2 (4:2:2): the 8 wide x 16 tall forms */
+#define FFHIP_H264_PRED_CODEC          8  /* the forms ff_h264_pred_init() installs for SVQ3 / RV40 / VP7 / VP8 (8 bits): mode = a
+                                           * FFHIP_H264_PREDV_* code below, which also says the block size */
+/* 4x4 (aux = bytes into the plane of topright[0..3], as for PRED4x4; the RV40 forms without _NODOWN also read the four rows below the
+ * block in the left column: LOAD_DOWN_LEFT_EDGE, h264pred.c:141-190) */
+#define FFHIP_H264_PREDV_127_DC          0   /* pred4x4_127_dc_c               VP7 / VP8 pred4x4[DC_127_PRED]            */
+#define FFHIP_H264_PREDV_129_DC          1   /* pred4x4_129_dc_c                         pred4x4[DC_129_PRED]            */
+#define FFHIP_H264_PREDV_VERT_VP8        2   /* pred4x4_vertical_vp8_c                   pred4x4[VERT_PRED]              */
+#define FFHIP_H264_PREDV_HOR_VP8         3   /* pred4x4_horizontal_vp8_c                 pred4x4[HOR_PRED]               */
+#define FFHIP_H264_PREDV_DL_SVQ3         4   /* pred4x4_down_left_svq3_c       SVQ3      pred4x4[DIAG_DOWN_LEFT_PRED]    */
+#define FFHIP_H264_PREDV_DL_RV40         5   /* pred4x4_down_left_rv40_c       RV40      pred4x4[DIAG_DOWN_LEFT_PRED]    */
+#define FFHIP_H264_PREDV_DL_RV40_NODOWN  6   /* ..._nodown_c                             pred4x4[DIAG_DOWN_LEFT_PRED_RV40_NODOWN] */
+#define FFHIP_H264_PREDV_VL_RV40         7   /* pred4x4_vertical_left_rv40_c             pred4x4[VERT_LEFT_PRED]         */
+#define FFHIP_H264_PREDV_VL_RV40_NODOWN  8   /* ..._nodown_c                             pred4x4[VERT_LEFT_PRED_RV40_NODOWN] */
+#define FFHIP_H264_PREDV_VL_VP8          9   /* pred4x4_vertical_left_vp8_c    VP7 / VP8 pred4x4[VERT_LEFT_PRED]         */
+#define FFHIP_H264_PREDV_HU_RV40         10  /* pred4x4_horizontal_up_rv40_c   RV40      pred4x4[HOR_UP_PRED]            */
+#define FFHIP_H264_PREDV_HU_RV40_NODOWN  11  /* ..._nodown_c                             pred4x4[HOR_UP_PRED_RV40_NODOWN] */
+#define FFHIP_H264_PREDV_TM_VP8          12  /* pred4x4_tm_vp8_c               VP7 / VP8 pred4x4[TM_VP8_PRED]            */
+/* 8x8 (chroma) */
+#define FFHIP_H264_PREDV8_DC_RV40        16  /* pred8x8_dc_rv40_c       RV40 / VP7 / VP8 pred8x8[DC_PRED8x8]             */
+#define FFHIP_H264_PREDV8_LEFT_DC_RV40   17  /* pred8x8_left_dc_rv40_c                   pred8x8[LEFT_DC_PRED8x8]        */
+#define FFHIP_H264_PREDV8_TOP_DC_RV40    18  /* pred8x8_top_dc_rv40_c                    pred8x8[TOP_DC_PRED8x8]         */
+#define FFHIP_H264_PREDV8_TM_VP8         19  /* pred8x8_tm_vp8_c               VP7 / VP8 pred8x8[PLANE_PRED8x8]          */
+#define FFHIP_H264_PREDV8_127_DC         20  /* pred8x8_127_dc_8_c                       pred8x8[DC_127_PRED8x8]         */
+#define FFHIP_H264_PREDV8_129_DC         21  /* pred8x8_129_dc_8_c                       pred8x8[DC_129_PRED8x8]         */
+/* 16x16 */
+#define FFHIP_H264_PREDV16_PLANE_SVQ3    32  /* pred16x16_plane_svq3_c         SVQ3      pred16x16[PLANE_PRED8x8]        */
+#define FFHIP_H264_PREDV16_PLANE_RV40    33  /* pred16x16_plane_rv40_c         RV40      pred16x16[PLANE_PRED8x8]        */
+#define FFHIP_H264_PREDV16_TM_VP8        34  /* pred16x16_tm_vp8_c             VP7 / VP8 pred16x16[PLANE_PRED8x8]        */
+#define FFHIP_H264_PREDV16_127_DC        35  /* pred16x16_127_dc_8_c                     pred16x16[DC_127_PRED8x8]       */
+#define FFHIP_H264_PREDV16_129_DC        36  /* pred16x16_129_dc_8_c                     pred16x16[DC_129_PRED8x8]       */
 #define FFHIP_H264_PRED_TOPLEFT   1  /* flags: pred8x8l's has_topleft                                                       */
 #define FFHIP_H264_PRED_TOPRIGHT  2  /* flags: pred8x8l's has_topright                                                      */
 #define FFHIP_H264_PRED_TR_SPLAT  4  /* flags: pred4x4's topright is src[3 - stride] four times (the decoder's substitute when the

@@ -9,6 +9,7 @@
 #include "libavutil/cpu.h"
 #include "libavutil/log.h"
 #include "libavcodec/codec_id.h"
+#include <string.h>
 #include "libavcodec/h264pred.h"
 
 static void pure_c(void) { av_force_cpu_flags(0); av_log_set_level(AV_LOG_ERROR); }
@@ -39,6 +40,20 @@ void ffref_h264_pred_set_format(int bit_depth, int chroma_format_idc)
     pure_c();
     ff_h264_pred_init(&pred_ctx, AV_CODEC_ID_H264, bit_depth, chroma_format_idc);
     pred_ready = 1;
+}
+/* the table of another codec that shares H264PredContext (AV_CODEC_ID_SVQ3 / _RV40 / _VP7 / _VP8: h264pred.c:540-578), 8 bits, 4:2:0;
+ * members the reference leaves unset for the codec are NULL (the context is cleared first): ffref_h264_pred_has() tells */
+void ffref_h264_pred_set_codec(int codec_id)
+{
+    pure_c();
+    memset(&pred_ctx, 0, sizeof(pred_ctx));
+    ff_h264_pred_init(&pred_ctx, codec_id, 8, 1);
+    pred_ready = 1;
+}
+int ffref_h264_pred_has(int table, int mode)
+{
+    const H264PredContext *c = h264pred();
+    return table == 0 ? c->pred4x4[mode] != NULL : table == 2 ? c->pred8x8[mode] != NULL : table == 3 ? c->pred16x16[mode] != NULL : c->pred8x8l[mode] != NULL;
 }
 void ffref_h264_pred4x4(int mode, uint8_t *src, const uint8_t *topright, ptrdiff_t stride) { h264pred()->pred4x4[mode](src, topright, stride); }
 void ffref_h264_pred8x8l(int mode, uint8_t *src, int has_topleft, int has_topright, ptrdiff_t stride)

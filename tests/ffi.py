@@ -373,6 +373,8 @@ def ref():
             L.ffref_aac_apply_ltp.restype = C.c_int
             L.ffref_aac_update_ltp.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int]
             L.ffref_aac_update_ltp.restype = C.c_int
+        L.ffref_h264_pred_set_codec.argtypes = [C.c_int]
+        L.ffref_h264_pred_has.argtypes = [C.c_int, C.c_int]
         L.ffref_h264_pred4x4.argtypes = [C.c_int, u8p, u8p, C.c_ssize_t]
         L.ffref_h264_pred8x8l.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_ssize_t]
         L.ffref_h264_pred8x8.argtypes = [C.c_int, u8p, C.c_ssize_t]

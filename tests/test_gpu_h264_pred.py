@@ -144,8 +144,83 @@ def test_h264_pred_init_rejects():
     _torch()
     hctx = h264.H264PredContext()
     L = _lib.lib()
-    for args in ((h264.CODEC_ID_H264, 11, 1), (h264.CODEC_ID_H264, 8, 4), (h264.CODEC_ID_H264, 10, -1), (139, 8, 1)):
+    # (1: AV_CODEC_ID_MPEG1VIDEO has no H264PredContext; 139 / 69: VP8 and RV40 exist at 8 bits, 4:2:0 only)
+    for args in ((h264.CODEC_ID_H264, 11, 1), (h264.CODEC_ID_H264, 8, 4), (h264.CODEC_ID_H264, 10, -1), (1, 8, 1), (139, 10, 1), (69, 8, 2)):
         assert L.ff_h264_pred_init_hip(C.byref(hctx), *args) < 0
+
+
+CODECS = {"svq3": 23, "rv40": 69, "vp7": 178, "vp8": 139}   # AV_CODEC_ID_* (libavcodec/codec_id.h)
+
+
+@pytest.mark.skipif(not ffi.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("codec", sorted(CODECS))
+def test_h264_pred_other_codecs_match_the_reference(codec):
+    """ff_h264_pred_init(h, AV_CODEC_ID_SVQ3 / _RV40 / _VP7 / _VP8, 8, 1) (h264pred.c:540-578): the table ff_h264_pred_init_hip()
+    leaves for the codec has a face exactly where the reference's has a function (started from a cleared table on both sides), and
+    every face == the reference's member on random, saturated and smooth neighbourhoods — the codecs' own forms (down-left / vertical-
+    left / horizontal-up with RV40's down-left edge and without, SVQ3's and RV40's planes, VP8's smoothed vertical / horizontal,
+    TrueMotion, the 127 / 129 DCs, RV40's chroma DCs) and the members they share with H.264"""
+    from ffmpeg_amd import h264
+    _torch()
+    R = ffi.ref()
+    R.ffref_h264_pred_set_codec(CODECS[codec])
+    try:
+        h = h264.pred_init(CODECS[codec], 8, 1)
+        rng = np.random.default_rng(CODECS[codec])
+        at = lambda a: a.ctypes.data + 16 * 48 + 16
+        checked = 0
+        for table, name, nmodes in ((0, "pred4x4", 15), (1, "pred8x8l", 12), (2, "pred8x8", 11), (3, "pred16x16", 9)):
+            for mode in range(nmodes):
+                has = bool(R.ffref_h264_pred_has(table, mode))
+                assert bool(getattr(h, name)[mode]) == has, (codec, name, mode, has)
+                if not has:
+                    continue
+                for rep in range(4):
+                    a = h264_pred_plane(rng, rep + mode)
+                    if rep == 3:
+                        a[:] = rng.choice(np.array([0, 255], np.uint8), a.shape)
+                    b = a.copy()
+                    tr = rng.integers(0, 256, 4, dtype=np.uint8)
+                    if table == 0:
+                        h.pred4x4[mode](at(a), tr.ctypes.data, 48)
+                        R.ffref_h264_pred4x4(mode, C.cast(at(b), u8p), ptr(tr), 48)
+                    elif table == 1:
+                        tl, trf = (1 if mode in (4, 5, 6) else int(rng.integers(0, 2))), int(rng.integers(0, 2))
+                        h.pred8x8l[mode](at(a), tl, trf, 48)
+                        R.ffref_h264_pred8x8l(mode, C.cast(at(b), u8p), tl, trf, 48)
+                    else:
+                        getattr(h, name)[mode](at(a), 48)
+                        getattr(R, "ffref_h264_" + name)(mode, C.cast(at(b), u8p), 48)
+                    assert np.array_equal(a, b), (codec, name, mode, rep, np.argwhere(a != b)[:4])
+                    checked += 1
+        assert checked >= 4 * 40
+    finally:
+        R.ffref_h264_pred_set_bit_depth(8)   # the shim's context is shared: back to H.264
+
+
+def test_h264_pred_codec_forms_batch():
+    """kind FFHIP_H264_PRED_CODEC of the batch face: many independent blocks of the codecs' own forms in one launch == the host faces'
+    results block by block (which test_h264_pred_other_codecs_match_the_reference pins to the reference)"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    rng = np.random.default_rng(77)
+    width, height = 640, 192
+    pic = rng.integers(0, 256, (height, width), dtype=np.uint8)
+    recs = []
+    for by in range(1, height // 32 - 1):
+        for bx in range(1, width // 32 - 1):
+            v = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36]))
+            x, y = 32 * bx + 8, 32 * by + 8
+            recs.append((x, y, v, 0, (y - 1) * width + x + 4))
+    recs = np.array(recs, np.int64)
+    got = hip_pred_apply(8, pic.copy(), recs, None)
+    want = pic.copy()
+    for x, y, v, _, aux in recs:      # one block at a time through the same face
+        one = hip_pred_apply(8, want.copy(), np.array([(x, y, v, 0, aux)], np.int64), None)
+        n = 4 if v < 16 else 8 if v < 32 else 16
+        want[y:y + n, x:x + n] = one[y:y + n, x:x + n]
+        assert np.array_equal(one[:y], want[:y]) and np.array_equal(one[y + n:], want[y + n:])   # nothing outside the block
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.skipif(not ffi.have_ref(), reason="oracle/_ref not built")
