@@ -371,24 +371,26 @@ def extras(torch, dev):
         out["hevc_idct%d_add" % nsz] = {"Mblocks/s": round(ntu / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1),
                                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "blocks": ntu, "ms": round(ms, 4)}
         del cc, c0, pic, d_t
-    # complex FFT-1024 forward, 65,536 transforms: 16,384 B per transform
+    # complex FFT-1024 forward, 65,536 transforms: 16,384 B per transform.  The default context (the register-resident radix kernel,
+    # within the float tolerance of the C codelets) and the FFHIP_TX_BITEXACT one (the split-radix network in the reference's order)
     from ffmpeg_amd import tx as _tx
-    fctx = _tx.TxContext(_tx.FLOAT_FFT, 0, 1024, 1.0)
     fin = torch.rand((65536, 2048), dtype=torch.float32, device=dev)
     fout = torch.empty((65536, 2048), dtype=torch.float32, device=dev)
-    for _ in range(2):
-        fctx.batch(fout, fin)
-    e0, e1 = ev(), ev()
-    e0.record()
-    for _ in range(10):
-        fctx.batch(fout, fin)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    gbs = 65536 * 16384 / (ms * 1e-3) / 1e9
-    out["fft1024_fwd"] = {"Mtransforms/s": round(65536 / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                          "transforms": 65536, "ms": round(ms, 4)}
-    fctx.close()
+    for key, flags in (("fft1024_fwd", 0), ("fft1024_fwd_bitexact", _tx.BITEXACT)):
+        fctx = _tx.TxContext(_tx.FLOAT_FFT, 0, 1024, 1.0, flags=flags)
+        for _ in range(2):
+            fctx.batch(fout, fin)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(10):
+            fctx.batch(fout, fin)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        gbs = 65536 * 16384 / (ms * 1e-3) / 1e9
+        out[key] = {"Mtransforms/s": round(65536 / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "transforms": 65536, "ms": round(ms, 4)}
+        fctx.close()
     del fin, fout
     # vector_fmul_window (the windowing + overlap-add after an IMDCT): 65,536 frames of len 1024 (16,384 B moved each)
     from ffmpeg_amd import fdsp
