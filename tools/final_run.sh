@@ -1,0 +1,11 @@
+#!/bin/bash
+# tools/final_run.sh — the round's closing pass on the GPU box: the whole -m gpu suite (log kept), smoke, bench.py (JSON line kept), the
+# reference's checkasm for the hip flag in one pass, and the rocprofv3 kernel stats of the bench command.  Everything lands in gpurun_out/.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+mkdir -p gpurun_out
+STEP_TIMEOUT=${SUITE_TIMEOUT:-1500} PY_TAIL=30 bash tools/gpu_pytest.sh gpu_suite tests -q
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; echo "bench rc=$?"; tail -c 600 gpurun_out/bench_final.json
+CK_TAIL=6 timeout 1200 bash tools/run_checkasm.sh > gpurun_out/checkasm.log 2>&1; echo "checkasm rc=$?"
+STEP_TIMEOUT=600 bash tools/gpu.sh "prof final_bench bench.py --no-pmc --steps 20 --warmup 5" | tail -12
