@@ -121,7 +121,11 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     constexpr int HP = HT / 2, VP = VT / 2;
     constexpr int NC = NCH == 2 ? 2 : 4;
     const int X0 = (cb * 64 + lane) * NC;
-    const int y0 = strip * J.strip_rows, y1 = min(y0 + J.strip_rows, J.dstH);
+    /* the job's fields the loops use, read ONCE: the job is picked by a run-time index out of the kernel arguments, and the compiler
+     * re-read J.dstW / J.dstride[] from memory (s_load + s_waitcnt) for every output row */
+    const int dstW = J.dstW, dstH = J.dstH, srcH = J.srcH;
+    const ptrdiff_t ss0 = J.sstride[0], ss1 = J.sstride[NCH - 1], ds0 = J.dstride[0], ds1 = J.dstride[NCH - 1];
+    const int y0 = strip * J.strip_rows, y1 = min(y0 + J.strip_rows, dstH);
     const int hsh = A.sdepth - 1, vsh = 27 - A.ddepth;
     const int smsb = A.smsb ? 16 - A.sdepth : 0, dmsb = A.dmsb ? 16 - A.ddepth : 0;
     const int maxv = (1 << A.ddepth) - 1;
@@ -133,7 +137,7 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     uint32_t cf[NC][HP];
 #pragma unroll
     for (int i = 0; i < NC; i++) {
-        const int xi = min(X0 + i, J.dstW - 1);
+        const int xi = min(X0 + i, dstW - 1);
         const uint32_t hp = (uint32_t)J.hp[xi];
         soff[i] = sil ? hp * 4u : (hp & ~1u) * 2u;
         sodd[i] = sil ? 0u : (hp & 1u) * 2u;
@@ -147,17 +151,18 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     /* the sample PAIRS of one source row, per channel and column: pr[ch][i][m] = (s[2m], s[2m + 1]) of the window */
     struct Row { uint32_t pr[NCH][NC][HP]; };
     auto load_row = [&](Row &o, int row) {
-        const int rr = min(row, J.srcH - 1);
+        const int rr = min(row, srcH - 1);
         if (NCH == 2 && sil) {
             /* HT (u, v) dwords per column, split into the two channels' pairs */
-            const uint8_t *p = sb0 + (ptrdiff_t)rr * J.sstride[0];
+            const uint8_t *p = sb0 + (ptrdiff_t)rr * ss0;
 #pragma unroll
             for (int i = 0; i < NC; i++) {
                 uint32_t q[HT];
-                const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + soff[i]);
+                const uint32_t so = soff[i];
+                const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + so);
                 q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
                 if (HT == 8) {
-                    const w16_u4 w = *reinterpret_cast<const w16_u4d *>(p + soff[i] + 16);
+                    const w16_u4 w = *reinterpret_cast<const w16_u4d *>(p + so + 16);
                     q[4 % HT] = w.x; q[5 % HT] = w.y; q[6 % HT] = w.z; q[7 % HT] = w.w;
                 }
 #pragma unroll
@@ -173,20 +178,22 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
             /* a planar row: the window starts at an even or an odd sample.  ALIGNED dwords from the even sample below it (a
              * 2-byte-aligned 8-byte load is split by the texture addresser: PMC 46 % issue stalls), the last one only when the
              * window's last sample lies in it, and a funnel shift by the lane's 0 or 2 bytes */
-            const uint8_t *p = (ch ? sb1 : sb0) + (ptrdiff_t)rr * J.sstride[ch];
+            const uint8_t *p = (ch ? sb1 : sb0) + (ptrdiff_t)rr * (ch ? ss1 : ss0);
 #pragma unroll
             for (int i = 0; i < NC; i++) {
                 uint32_t q[HP + 1];
+                const uint32_t so = soff[i]; /* (forcing the scalar-base form of global_load here — an opaque copy of the offset per
+                                              * load — measured 4-8 % slower than the hoisted 64-bit lane addresses) */
                 if (HT == 4) {
-                    const w16_u2 v = *reinterpret_cast<const w16_u2d *>(p + soff[i]);
+                    const w16_u2 v = *reinterpret_cast<const w16_u2d *>(p + so);
                     q[0] = v.x; q[1] = v.y;
                 } else {
-                    const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + soff[i]);
+                    const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + so);
                     q[0] = v.x; q[1] = v.y; q[2 % (HP + 1)] = v.z; q[3 % (HP + 1)] = v.w;
                 }
                 q[HP] = 0;
                 if (sodd[i])
-                    q[HP] = *reinterpret_cast<const uint32_t *>(p + soff[i] + 4 * HP);
+                    q[HP] = *reinterpret_cast<const uint32_t *>(p + so + 4 * HP);
 #pragma unroll
                 for (int m = 0; m < HP; m++)
                     o.pr[ch][i][m] = __builtin_amdgcn_alignbyte(q[m + 1], q[m], sodd[i]);
@@ -222,10 +229,9 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
         for (int m = 0; m < HP; m++)
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                uint32_t s = w.pr[c / NC][c % NC][m];
-                if (smsb)
-                    s = __builtin_bit_cast(uint32_t, __builtin_bit_cast(w16_h2, s) >> (unsigned short)smsb);
-                sp[m][c] = s;
+                /* P01x keeps its samples in the high bits: one packed shift (by 0 for the other layouts — a select on top of it cost
+                 * as much again) */
+                sp[m][c] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(w16_h2, w.pr[c / NC][c % NC][m]) >> (unsigned short)smsb);
             }
         int acc[4];
         w16_dots_first(acc, sp[0], sp[1], cfc[0], cfc[1]);
@@ -246,13 +252,17 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     int vpl;
     uint32_t vcl[VP];
     {
-        const int y = min(y0 + lane, J.dstH - 1);
+        const int y = min(y0 + lane, dstH - 1);
         vpl = J.vp[y];
 #pragma unroll
         for (int m = 0; m < VP; m++)
             vcl[m] = reinterpret_cast<const uint32_t *>(J.vf)[(size_t)y * VP + m];
     }
     int yy = y0;
+    /* where this lane's samples of output row yy go: advanced by the stride per row (a 64-bit multiply-add per row before) */
+    uint8_t *dq0 = db0 + (ptrdiff_t)y0 * ds0 + (size_t)X0 * (NCH == 2 && dil ? 4 : 2);
+    uint8_t *dq1 = db1 + (ptrdiff_t)y0 * ds1 + (size_t)X0 * 2;
+    const bool in_w = X0 < dstW, whole = X0 + (NCH == 2 ? 2 : 4) <= dstW;
     int need = __builtin_amdgcn_readlane(vpl, 0) + VT - 1;
     const int rlast = __builtin_amdgcn_readlane(vpl, y1 - 1 - y0) + VT - 1;
     int r = need - (VT - 1);
@@ -298,13 +308,13 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                             o[c / NC][(c % NC) / 2] = v;
                         }
                     }
-                    if (X0 < J.dstW) {
+                    if (in_w) {
                         if (NCH == 2 && dil) {
                             /* (u0, v0) (u1, v1): 8 bytes */
-                            uint8_t *d = db0 + (ptrdiff_t)yy * J.dstride[0] + (size_t)X0 * 4;
+                            uint8_t *d = dq0;
                             const uint32_t uv0 = __builtin_amdgcn_perm(o[NCH - 1][0], o[0][0], 0x05040100u);
                             const uint32_t uv1 = __builtin_amdgcn_perm(o[NCH - 1][0], o[0][0], 0x07060302u);
-                            if (X0 + 2 <= J.dstW) {
+                            if (whole) {
                                 w16_u2 s;
                                 s.x = uv0; s.y = uv1;
                                 *reinterpret_cast<w16_u2d *>(d) = s;
@@ -313,8 +323,8 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                             }
                         } else if (NCH == 2) {
                             /* two samples of each channel into its own plane */
-                            uint8_t *du = db0 + (ptrdiff_t)yy * J.dstride[0] + (size_t)X0 * 2, *dv = db1 + (ptrdiff_t)yy * J.dstride[1] + (size_t)X0 * 2;
-                            if (X0 + 2 <= J.dstW) {
+                            uint8_t *du = dq0, *dv = dq1;
+                            if (whole) {
                                 *reinterpret_cast<uint32_t *>(du) = o[0][0];
                                 *reinterpret_cast<uint32_t *>(dv) = o[NCH - 1][0];
                             } else {
@@ -322,19 +332,21 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                                 *reinterpret_cast<uint16_t *>(dv) = (uint16_t)o[NCH - 1][0];
                             }
                         } else {
-                            uint8_t *d = db0 + (ptrdiff_t)yy * J.dstride[0] + (size_t)X0 * 2;
-                            if (X0 + 4 <= J.dstW) {
+                            uint8_t *d = dq0;
+                            if (whole) {
                                 w16_u2 s;
                                 s.x = o[0][0]; s.y = o[0][NC / 2 - 1];
                                 *reinterpret_cast<w16_u2a *>(d) = s;
                             } else { /* the ragged last group of a row (no array indexed by a loop counter: that would live in scratch memory) */
                                 reinterpret_cast<uint16_t *>(d)[0] = (uint16_t)o[0][0];
-                                if (X0 + 1 < J.dstW) reinterpret_cast<uint16_t *>(d)[1] = (uint16_t)(o[0][0] >> 16);
-                                if (X0 + 2 < J.dstW) reinterpret_cast<uint16_t *>(d)[2] = (uint16_t)o[0][NC / 2 - 1];
+                                if (X0 + 1 < dstW) reinterpret_cast<uint16_t *>(d)[1] = (uint16_t)(o[0][0] >> 16);
+                                if (X0 + 2 < dstW) reinterpret_cast<uint16_t *>(d)[2] = (uint16_t)o[0][NC / 2 - 1];
                             }
                         }
                     }
                     yy++;
+                    dq0 += ds0;
+                    dq1 += ds1;
                     if (yy < y1)
                         need = __builtin_amdgcn_readlane(vpl, yy - y0) + VT - 1;
                 }

@@ -892,6 +892,25 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
             W.nframes = nframes;
             W.ht = c->w16_ht; W.vt = c->w16_vt;
             W.sdepth = sd; W.ddepth = dd; W.smsb = sl == 1; W.dmsb = dl == 1;
+            /* rows per strip: 64 when the batch fills the chip several times over; a strip re-filters VT - 1 source rows, but a
+             * wave is one dependent chain of rows, and a launch of fewer waves than the chip holds (32 frames of 720p -> 1080p: 6,656
+             * against 7,168 slots) runs at the speed of one chain: halve until there are 1.5 slots' worth (measured, 720p -> 1080p:
+             * 64 rows 0.263, 32 rows 0.308, 16 rows 0.298 of HBM; the larger pictures are best at 64) */
+            int strip = 64;
+            {
+                const char *es = FFHIP_KNOB("FFHIP_W16_STRIP"); /* measured variant */
+                auto waves = [&](int st) {
+                    const long long lum = (long long)cdiv(c->d[0].n, 256) * cdiv(c->d[2].n, st);
+                    const long long chr = (sl || dl) ? (long long)cdiv(c->d[1].n, 128) * cdiv(c->d[3].n, st)
+                                                     : 2LL * cdiv(c->d[1].n, 256) * cdiv(c->d[3].n, st);
+                    return (lum + chr) * nframes;
+                };
+                if (es && atoi(es) > 0)
+                    strip = atoi(es) > 64 ? 64 : atoi(es);
+                else
+                    while (strip > 16 && waves(strip) < 3 * 7168 / 2)
+                        strip >>= 1;
+            }
             auto job = [&](int which, int nch, int splane0, int dplane0) {
                 FFHipW16Job &j = W.job[W.njobs++];
                 j.nch = nch;
@@ -907,7 +926,7 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 j.srcH = which ? c->chrSrcH : t.srcH;
                 j.dstW = c->d[which].n; j.dstH = c->d[2 + which].n;
                 j.hf = c->w16_f[which]; j.hp = c->w16_p[which]; j.vf = c->w16_f[2 + which]; j.vp = c->w16_p[2 + which];
-                ffhip_w16_plan_job(&j, 64);
+                ffhip_w16_plan_job(&j, strip);
             };
             job(0, 1, 0, 0);
             if (sl || dl) {
