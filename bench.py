@@ -835,13 +835,55 @@ def h264_intra_picture_leg(torch, dev, ev, h264):
         flight = f0.elapsed_time(f1) / rounds
     for p_ in pics:
         p_.close()
+    # N pictures' wavefronts in ONE launch (round 4, ffhip_h264_intra_frames_dev): the reconstruction alone (no deblocking), the same
+    # records for every picture of the batch, each picture its own planes
+    import ctypes as C
+    from ffmpeg_amd import _lib
+    L = _lib.lib()
+
+    class IntraPic(C.Structure):
+        _fields_ = [("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p), ("recs", C.c_void_p), ("row_start", C.c_void_p), ("coefs", C.c_void_p)]
+    L.ffhip_h264_intra_pack.restype = C.c_int
+    coefs, ncoef, recs = np.zeros(mb_w * mb_h * 400, np.int16), 0, []
+    for mx, my, d, rec in states:
+        rec = rec.copy()
+        mbc = d["mb"].copy()
+        nn = C.c_int32(ncoef)
+        assert L.ffhip_h264_intra_pack(rec.ctypes.data, d["nnzc"].ctypes.data, mbc.ctypes.data, d["luma_dc"].ctypes.data,
+                                       G._p(d["pcm"], C.c_uint8), G._p(coefs, C.c_int16), C.byref(nn), C.c_int32(coefs.size)) == 0
+        ncoef = nn.value
+        recs.append(rec)
+    rows = np.arange(mb_h + 1, dtype=np.int32) * mb_w
+    d_rec = torch.from_numpy(np.concatenate(recs).view(np.uint8).reshape(-1, 108).copy()).to(dev)
+    d_rows, d_coef = torch.from_numpy(rows).to(dev), torch.from_numpy(coefs[:ncoef].copy()).to(dev)
+    batch = {}
+    for npl in (1, 16, 32, 64):
+        planes = [[torch.zeros_like(t) for t in dst] for _ in range(npl)]
+        arr = (IntraPic * npl)(*[IntraPic(pp[0].data_ptr(), pp[1].data_ptr(), pp[2].data_ptr(), d_rec.data_ptr(), d_rows.data_ptr(), d_coef.data_ptr())
+                                 for pp in planes])
+        st_ = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            _lib.check(L.ffhip_h264_intra_frames_dev(8, npl, C.cast(arr, C.c_void_p), sy, sc, mb_w, mb_h, C.c_void_p(st_)), "ffhip_h264_intra_frames_dev")
+        b0, b1 = ev(), ev()
+        b0.record()
+        for _ in range(4):
+            _lib.check(L.ffhip_h264_intra_frames_dev(8, npl, C.cast(arr, C.c_void_p), sy, sc, mb_w, mb_h, C.c_void_p(st_)), "ffhip_h264_intra_frames_dev")
+        b1.record()
+        torch.cuda.synchronize()
+        batch[npl] = b0.elapsed_time(b1) / 4
+        del planes
     return {"h264_intra_picture_1080p": {"ms_per_picture": round(ms, 3), "pictures_per_s": round(1e3 / ms, 1), "intra_macroblocks": mb_w * mb_h,
+                                         "wavefront_alone_ms": round(batch[1], 3),
+                                         "wavefront_ms_per_launch_of_16_32_64_pictures": [round(batch[16], 3), round(batch[32], 3), round(batch[64], 3)],
+                                         "wavefront_pictures_per_s_32_per_launch": round(32e3 / batch[32], 1),
+                                         "wavefront_pictures_per_s_64_in_two_launches": round(64e3 / batch[64], 1),
                                          "us_per_wavefront_step": round(1e3 * ms / (mb_w + 2 * mb_h), 2),
                                          "ms_per_picture_%d_in_flight" % NP: round(flight / NP, 3),
                                          "pictures_per_s_%d_in_flight" % NP: round(1e3 * NP / flight, 1),
                                          "note": "a dependency chain of mb_w + 2 mb_h macroblock steps (intra prediction reads the left / upper / upper-right "
                                                  "neighbours' reconstructed samples): latency-bound by construction, one wave per macroblock row; in flight: "
-                                                 "one object, stream and host thread per picture"}}
+                                                 "one object, stream and host thread per picture; per launch: ffhip_h264_intra_frames_dev, the "
+                                                 "reconstruction wavefronts of N pictures side by side (no deblocking)"}}
 
 
 def h264_picture_leg(torch, dev, ev):

@@ -156,6 +156,7 @@ def lib():
         "ffhip_h264_intra_pack_hbd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int32]),
         "ffhip_h264_intra_frame_dev": (C.c_int, [vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp, vp, vp]),
         "ffhip_h264_intra_frame_dev_hbd": (C.c_int, [C.c_int, vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp, vp, vp]),
+        "ffhip_h264_intra_frames_dev": (C.c_int, [C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp]),
         "ffhip_h264_deblock_frames_chroma_dev": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_deblock_frames_dev": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_h264_deblock_frames_dev_hbd": (C.c_int, [C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),

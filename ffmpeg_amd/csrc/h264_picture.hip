@@ -426,6 +426,16 @@ extern "C" int ffhip_h264_intra_frame_dev_hbd(int bit_depth, uint8_t *y, uint8_t
     return ffhip_launch_h264_intra_frame_bd(bit_depth, y, cb, cr, stride_y, stride_c, mb_w, mb_h, recs, row_start, coefs, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_h264_intra_frames_dev(int bit_depth, int npics, const FFHipH264IntraPic *pics, ptrdiff_t stride_y, ptrdiff_t stride_c,
+                                           int mb_w, int mb_h, void *stream)
+{
+    if (npics < 0 || (npics && !pics))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_intra_frames_bd(bit_depth, npics, pics, stride_y, stride_c, mb_w, mb_h, (hipStream_t)stream);
+}
+
 /* ---- flush ------------------------------------------------------------------------------------------ */
 extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                                         void *stream_)

@@ -94,11 +94,22 @@ static_assert(offsetof(FFHipH264IntraMB, type) == 4 && offsetof(FFHipH264IntraMB
  * rows at a workgroup boundary use memory: the producer publishes a macroblock one step LATE (at the top of the next step, when the
  * write-through stores issued a whole step earlier have long been acknowledged), the consumer reads the counter and the next record's
  * top neighbours one step AHEAD — both stay off the step's critical path, at the price of a few macroblocks of lag per boundary. */
+/* Round 4: a launch carries up to FFHIP_INTRA_PICS pictures of one geometry (blockIdx.y: the picture; each its own planes, records
+ * and progress counters) — the wavefront of ONE 1080p picture keeps 68 waves busy on a chip that holds 8,192, and its latency
+ * (mb_w + 2 mb_h dependent steps) does not shrink; what a decoder with N pictures in hand (frame threads, an all-intra stream) wants is
+ * N wavefronts side by side in one launch.  Workgroups are dispatched x-fastest, so a row's upper neighbour of the same picture is
+ * always dispatched before it, whatever the other pictures do. */
+/* (two workgroups per CU where it costs no spill: 8 bits fits 256 VGPRs; above, the kernel keeps its 286) */
 template <typename PIX>
-__global__ __launch_bounds__(256) void k_h264_intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
-                                                          const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs,
-                                                          int *progress, int *fail, int maxv)
+__global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_frame(FFHipIntraPics S, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h, int *progress_all,
+                                                          int *fail, int maxv)
 {
+    /* (read once: the set is indexed at run time, and fields used in place would be re-read from the kernel arguments in the loops) */
+    uint8_t *const py = S.pic[blockIdx.y].y, *const pcb = S.pic[blockIdx.y].cb, *const pcr = S.pic[blockIdx.y].cr;
+    const FFHipH264IntraMB *const recs = S.pic[blockIdx.y].recs;
+    const int32_t *const row_start = S.pic[blockIdx.y].row_start;
+    const int16_t *const coefs = S.pic[blockIdx.y].coefs;
+    int *const progress = progress_all + (size_t)blockIdx.y * (size_t)(mb_h + 1);
     typedef typename ImbQuad<PIX>::T Q;
     typedef typename ImbCoef<PIX>::T CF;
     constexpr int PS = (int)sizeof(PIX), NDW = PS == 1 ? 3 : 7, IMB_RUN_MAX = NDW * 128 /* int16 */, WMAX = 4;
@@ -329,20 +340,34 @@ int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_
 int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                      const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream)
 {
-    if (mb_w <= 0 || mb_h <= 0)
+    FFHipIntraPic one = { y, cb, cr, recs, row_start, coefs };
+    return ffhip_launch_h264_intra_frames_bd(bd, 1, &one, sy, sc, mb_w, mb_h, stream);
+}
+
+int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pics, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                      hipStream_t stream)
+{
+    if (mb_w <= 0 || mb_h <= 0 || npics <= 0)
         return 0;
     if (bd != 8 && bd != 9 && bd != 10 && bd != 12 && bd != 14) {
         ffhip_set_error("ffhip_h264_intra_frame: bit depth %d (8, 9, 10, 12 and 14 are the depths H.264 defines)", bd);
         return FFHIP_EINVAL;
     }
     const unsigned amask = bd > 8 ? 7u : 3u; /* four samples per access */
-    if (!y || !cb || !cr || !recs || !row_start || !coefs) {
+    if (!pics) {
         ffhip_set_error("ffhip_h264_intra_frame: null argument");
         return FFHIP_EINVAL;
     }
-    if (((uintptr_t)y | (uintptr_t)cb | (uintptr_t)cr | (size_t)sy | (size_t)sc) & amask) {
-        ffhip_set_error("ffhip_h264_intra_frame: planes and strides must be %u-byte aligned", amask + 1);
-        return FFHIP_EINVAL;
+    for (int i = 0; i < npics; i++) {
+        const FFHipIntraPic &P = pics[i];
+        if (!P.y || !P.cb || !P.cr || !P.recs || !P.row_start || !P.coefs) {
+            ffhip_set_error("ffhip_h264_intra_frame: null argument (picture %d)", i);
+            return FFHIP_EINVAL;
+        }
+        if (((uintptr_t)P.y | (uintptr_t)P.cb | (uintptr_t)P.cr | (size_t)sy | (size_t)sc) & amask) {
+            ffhip_set_error("ffhip_h264_intra_frame: planes and strides must be %u-byte aligned", amask + 1);
+            return FFHIP_EINVAL;
+        }
     }
     /* rows per workgroup: as many (up to 4) as the line buffers between them fit beside the static per-row tiles in 64 KB of LDS */
     const int ps_ = bd > 8 ? 2 : 1;
@@ -359,22 +384,35 @@ int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *c
     W = W < mb_h ? W : mb_h;
     const size_t lds = (size_t)(W - 1) * line;
     const int nwg = (mb_h + W - 1) / W;
-    FFHipProgressSlot ps;
-    const int r = ffhip_progress_acquire(mb_h + 1, stream, &ps);
-    if (r < 0)
-        return r;
-    int *const prog = ps.prog, *const fail = ps.fail;
-    if (bd > 8)
-        hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(nwg), dim3(64 * W), lds, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog,
-                           fail, (1 << bd) - 1);
-    else
-        hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(nwg), dim3(64 * W), lds, stream, y, cb, cr, sy, sc, mb_w, mb_h, recs, row_start, coefs, prog,
-                           fail, 255);
-    const hipError_t e = hipGetLastError();
-    const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
-    if (e != hipSuccess) {
-        ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
-        return FFHIP_EIO;
+    if (mb_h + 1 > FFHIP_PROGRESS_SLOT_INTS) {
+        ffhip_set_error("ffhip_h264_intra_frame: %d macroblock rows exceed the progress pool", mb_h);
+        return FFHIP_EINVAL;
     }
-    return r2;
+    int per = FFHIP_PROGRESS_SLOT_INTS / (mb_h + 1);
+    per = per > FFHIP_INTRA_PICS ? FFHIP_INTRA_PICS : per;
+    for (int p0 = 0; p0 < npics; p0 += per) {
+        const int n = npics - p0 < per ? npics - p0 : per;
+        FFHipIntraPics S;
+        S.n = n;
+        for (int i = 0; i < FFHIP_INTRA_PICS; i++)
+            S.pic[i] = pics[p0 + (i < n ? i : 0)];
+        FFHipProgressSlot ps;
+        const int r = ffhip_progress_acquire((mb_h + 1) * n, stream, &ps);
+        if (r < 0)
+            return r;
+        int *const prog = ps.prog, *const fail = ps.fail;
+        if (bd > 8)
+            hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, (1 << bd) - 1);
+        else
+            hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, 255);
+        const hipError_t e = hipGetLastError();
+        const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            return FFHIP_EIO;
+        }
+        if (r2 < 0)
+            return r2;
+    }
+    return 0;
 }

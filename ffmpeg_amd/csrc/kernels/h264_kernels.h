@@ -54,6 +54,12 @@ int ffhip_h264dsp_fill_generic(FFHipH264DSPContext *c, FFHipH264DSPContext *o, i
 int ffhip_h264qpel_init_generic(FFHipH264QpelContext *c, int bit_depth);
 int ffhip_h264chroma_init_generic(FFHipH264ChromaContext *c, int bit_depth);
 int ffhip_h264weight_init_generic(FFHipH264WeightContext *c, int bit_depth);
+/* up to FFHIP_INTRA_PICS pictures of one geometry in one launch of the intra wavefront (== FFHipH264IntraPic of include/ffhip.h) */
+#define FFHIP_INTRA_PICS 32
+typedef FFHipH264IntraPic FFHipIntraPic;
+struct FFHipIntraPics { int n; int pad; FFHipIntraPic pic[FFHIP_INTRA_PICS]; };
+int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pics, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                      hipStream_t stream);
 int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                   const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
 int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,

@@ -733,6 +733,19 @@ int  ffhip_h264_intra_frame_dev(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t 
  *  bytes; planes and strides 8-byte aligned). */
 int  ffhip_h264_intra_frame_dev_hbd(int bit_depth, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t stride_y, ptrdiff_t stride_c, int mb_w,
                                     int mb_h, const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, void *stream);
+/** N pictures' wavefronts in ONE launch (round 4): pictures of one geometry and depth, each with its own planes, sorted records, row
+ *  starts and coefficient runs (all device pointers, as for the call above).  A wavefront's latency is its dependency chain (mb_w +
+ *  2 mb_h macroblock steps: 2.6 ms for a 1080p I-picture) and one picture occupies 68 of the chip's 8,192 wave slots — a decoder that
+ *  holds several pictures (frame threads, an all-intra stream) gets them reconstructed side by side for the latency of one.  Launches
+ *  of 32 pictures; asynchronous on `stream`. */
+typedef struct FFHipH264IntraPic {
+    uint8_t *y, *cb, *cr;
+    const FFHipH264IntraMB *recs;
+    const int32_t *row_start;
+    const int16_t *coefs;
+} FFHipH264IntraPic;
+int  ffhip_h264_intra_frames_dev(int bit_depth, int npics, const FFHipH264IntraPic *pics /* host array */, ptrdiff_t stride_y,
+                                 ptrdiff_t stride_c, int mb_w, int mb_h, void *stream);
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
 int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                               void *stream);
