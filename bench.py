@@ -833,6 +833,18 @@ def h264_intra_picture_leg(torch, dev, ev, h264):
         f1.record()
         torch.cuda.synchronize()
         flight = f0.elapsed_time(f1) / rounds
+    # ... and the same NP I-pictures flushed together (ffhip_h264_pictures_flush): one launch of NP wavefronts, then the in-loop filter of
+    # all planes side by side
+    flush_batch = None
+    for rep in range(2):
+        torch.cuda.synchronize()
+        g0, g1 = ev(), ev()
+        g0.record()
+        for _ in range(4):
+            h264.pictures_flush(pics, dsts, [sy, sc, sc], dsts)
+        g1.record()
+        torch.cuda.synchronize()
+        flush_batch = g0.elapsed_time(g1) / 4
     for p_ in pics:
         p_.close()
     # N pictures' wavefronts in ONE launch (round 4, ffhip_h264_intra_frames_dev): the reconstruction alone (no deblocking), the same
@@ -873,6 +885,8 @@ def h264_intra_picture_leg(torch, dev, ev, h264):
         batch[npl] = b0.elapsed_time(b1) / 4
         del planes
     return {"h264_intra_picture_1080p": {"ms_per_picture": round(ms, 3), "pictures_per_s": round(1e3 / ms, 1), "intra_macroblocks": mb_w * mb_h,
+                                         "ms_per_batched_flush_of_%d" % NP: round(flush_batch, 3),
+                                         "pictures_per_s_batched_flush_of_%d" % NP: round(1e3 * NP / flush_batch, 1),
                                          "wavefront_alone_ms": round(batch[1], 3),
                                          "wavefront_ms_per_launch_of_16_32_64_pictures": [round(batch[16], 3), round(batch[32], 3), round(batch[64], 3)],
                                          "wavefront_pictures_per_s_32_per_launch": round(32e3 / batch[32], 1),
@@ -932,11 +946,24 @@ def h264_picture_leg(torch, dev, ev):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / rounds
         res[n] = ms
+    # the same pictures flushed TOGETHER (round 4, ffhip_h264_pictures_flush): each picture's prediction and residual launches, then the
+    # in-loop filter of all their planes in one launch per plane kind; one host thread, one stream
+    for rep in range(2):
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(4):
+            h264.pictures_flush(pics, dsts, [sy, sc, sc], [refs] * npic)
+        e1.record()
+        torch.cuda.synchronize()
+        res["batch"] = e0.elapsed_time(e1) / 4
     for p in pics:
         p.close()
     intra = h264_intra_picture_leg(torch, dev, ev, h264)
     return {**intra, "h264_picture_pipeline_1080p": {"ms_per_picture_alone": round(res[1], 3), "ms_per_picture_16_in_flight": round(res[npic] / npic, 3),
                                            "pictures_per_s_16_in_flight": round(1e3 * npic / res[npic], 1),
+                                           "ms_per_batched_flush_of_16": round(res["batch"], 3),
+                                           "pictures_per_s_batched_flush_of_16": round(1e3 * npic / res["batch"], 1),
                                            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                                            "note": "P-pictures: qpel + chroma MC, idct_add on ~half of the blocks, deblocking in decoder order; one stream and host thread per picture"}}
 

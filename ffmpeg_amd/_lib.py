@@ -151,6 +151,7 @@ def lib():
         "ffhip_h264_picture_idct_add": (C.c_int, [vp, C.c_int, C.c_int, C.c_int32, vp]),
         "ffhip_h264_picture_deblock_mb": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
         "ffhip_h264_picture_flush": (C.c_int, [vp, vp, vp, vp, vp]),
+        "ffhip_h264_pictures_flush": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
         "ffhip_h264_picture_intra_mb": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "ffhip_h264_intra_pack": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int32]),
         "ffhip_h264_intra_pack_hbd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int32]),

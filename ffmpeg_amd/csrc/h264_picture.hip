@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <new>
 #include <string.h>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels/common.h"
@@ -437,8 +439,14 @@ extern "C" int ffhip_h264_intra_frames_dev(int bit_depth, int npics, const FFHip
 }
 
 /* ---- flush ------------------------------------------------------------------------------------------ */
-extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
-                                        void *stream_)
+/* what a batched flush (ffhip_h264_pictures_flush) takes over from a picture after its prediction and residual stages */
+struct FlushBack {
+    bool intra = false;
+    FFHipH264IntraPic ip = {};
+    const FFHipH264Edge *edges[3] = { nullptr, nullptr, nullptr };
+};
+
+static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3], void *stream_, FlushBack *defer)
 {
     FFHipDeviceGuard dg(p ? p->device : -1);
     if (!p || !dst || !stride || !ref)
@@ -616,6 +624,17 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
                 if (s_ioff[pl][k].n)
                     r = ffhip_launch_h264_idct_add_bd(bd, k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off),
                                                       (int16_t *)(db + s_icoef[pl][k].off), s_ioff[pl][k].n, stream);
+        if (defer) {
+            if (!p->intra.empty()) {
+                defer->intra = true;
+                defer->ip = FFHipH264IntraPic{ dst[0], dst[1], dst[2], (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
+                                               (const int16_t *)(db + s_intracoef.off) };
+            }
+            for (int pl = 0; pl < 3; pl++)
+                if (p->any_edge[pl])
+                    defer->edges[pl] = (const FFHipH264Edge *)(db + s_edge[pl].off);
+            return r < 0 ? r : 0;
+        }
         if (r >= 0 && !p->intra.empty())
             r = ffhip_launch_h264_intra_frame_bd(bd, dst[0], dst[1], dst[2], stride[0], stride[1], p->mb_w, p->mb_h,
                                                  (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
@@ -685,6 +704,17 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
                 }
         r = ffhip_launch_h264_idct_multi(M, stream);
     }
+    if (defer) {
+        if (!p->intra.empty()) {
+            defer->intra = true;
+            defer->ip = FFHipH264IntraPic{ dst[0], dst[1], dst[2], (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
+                                           (const int16_t *)(db + s_intracoef.off) };
+        }
+        for (int pl = 0; pl < 3; pl++)
+            if (p->any_edge[pl])
+                defer->edges[pl] = (const FFHipH264Edge *)(db + s_edge[pl].off);
+        return r < 0 ? r : 0;
+    }
     /* ---- intra macroblocks: every inter macroblock is complete now; one wavefront over the three planes ---- */
     if (r >= 0 && !p->intra.empty())
         r = ffhip_launch_h264_intra_frame(dst[0], dst[1], dst[2], stride[0], stride[1], p->mb_w, p->mb_h,
@@ -718,5 +748,109 @@ extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[
         r = ffhip_launch_h264_deblock_frame(dst[0], stride[0], p->mb_w, p->mb_h, (const FFHipH264Edge *)(db + s_edge[0].off), stream);
     if (chroma)
         HIP_TRY(hipStreamWaitEvent(stream, p->join, 0));
+    return r < 0 ? r : 0;
+}
+
+extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
+                                        void *stream)
+{
+    return flush_impl(p, dst, stride, ref, stream, nullptr);
+}
+
+/* Several pictures together: every picture's own staging copy, prediction and residual launches (throughput kernels), then what is a
+ * latency chain per picture — the intra reconstruction wavefront and the in-loop filter — ONCE for all of them, side by side. */
+extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, uint8_t *const *dst, const int stride[3], const uint8_t *const *ref,
+                                         void *stream_)
+{
+    if (n < 0 || (n && (!pics || !dst || !stride || !ref)))
+        return FFHIP_EINVAL;
+    if (n == 0)
+        return 0;
+    for (int i = 0; i < n; i++)
+        if (!pics[i] || pics[i]->mb_w != pics[0]->mb_w || pics[i]->mb_h != pics[0]->mb_h || pics[i]->bd != pics[0]->bd ||
+            pics[i]->device != pics[0]->device) {
+            ffhip_set_error("ffhip_h264_pictures_flush: the pictures of a batch share geometry, depth and device");
+            return FFHIP_EINVAL;
+        }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (pics[i] == pics[j]) {
+                ffhip_set_error("ffhip_h264_pictures_flush: picture object %d appears twice", i);
+                return FFHIP_EINVAL;
+            }
+    if (n == 1)
+        return flush_impl(pics[0], dst, stride, ref, stream_, nullptr);
+    FFHipH264Picture *const p0 = pics[0];
+    FFHipDeviceGuard dg(p0->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int bd = p0->bd, mb_w = p0->mb_w, mb_h = p0->mb_h;
+    std::vector<FlushBack> B((size_t)n);
+    {
+        /* the front half of a flush is host work — sorting a picture's intra records, copying megabytes of records and coefficients
+         * into its pinned buffer — before a handful of launches: up to eight pictures are prepared at a time by threads of this call
+         * (launch order between the pictures is free; the stages that follow wait for all of them) */
+        const int nthr = n < 8 ? n : 8;
+        std::vector<int> rc((size_t)nthr, 0);
+        std::vector<std::string> errs((size_t)nthr);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; t++)
+            th.emplace_back([&, t]() {
+                for (int i = t; i < n; i += nthr) {
+                    const int r = flush_impl(pics[i], dst + 3 * i, stride, ref + 3 * i, stream_, &B[(size_t)i]);
+                    if (r < 0) {
+                        rc[(size_t)t] = r;
+                        errs[(size_t)t] = ffhip_last_error(); /* (the error text is per thread) */
+                        return;
+                    }
+                }
+            });
+        for (std::thread &t : th)
+            t.join();
+        for (int t = 0; t < nthr; t++)
+            if (rc[(size_t)t] < 0) {
+                ffhip_set_error("%s", errs[(size_t)t].c_str());
+                return rc[(size_t)t]; /* (the other pictures have had their prediction and residual stages queued) */
+            }
+    }
+    std::vector<FFHipH264IntraPic> ip;
+    for (int i = 0; i < n; i++)
+        if (B[i].intra)
+            ip.push_back(B[i].ip);
+    int r = 0;
+    if (!ip.empty())
+        r = ffhip_launch_h264_intra_frames_bd(bd, (int)ip.size(), ip.data(), stride[0], stride[1], mb_w, mb_h, stream);
+    if (r < 0)
+        return r;
+    /* the in-loop filter: all chroma planes (Cb and Cr of every picture: up to 2 n "pictures") on the first object's second stream
+     * beside all luma planes on the caller's */
+    std::vector<uint8_t *> pl_c, pl_y;
+    std::vector<const FFHipH264Edge *> ed_c, ed_y;
+    for (int i = 0; i < n; i++) {
+        for (int pl = 1; pl < 3; pl++)
+            if (B[i].edges[pl]) {
+                pl_c.push_back(dst[3 * i + pl]);
+                ed_c.push_back(B[i].edges[pl]);
+            }
+        if (B[i].edges[0]) {
+            pl_y.push_back(dst[3 * i]);
+            ed_y.push_back(B[i].edges[0]);
+        }
+    }
+    if (!pl_c.empty() && stride[1] != stride[2]) {
+        ffhip_set_error("ffhip_h264_pictures_flush: Cb and Cr share a stride");
+        return FFHIP_EINVAL;
+    }
+    if (!pl_c.empty()) {
+        HIP_TRY(hipEventRecord(p0->fork, stream));
+        HIP_TRY(hipStreamWaitEvent(p0->aux, p0->fork, 0));
+        ffhip_progress_report_to(stream, true);
+        r = ffhip_launch_h264_deblock_pictures_bd(bd, 1, pl_c.data(), ed_c.data(), (int)pl_c.size(), stride[1], mb_w, mb_h, p0->aux);
+        ffhip_progress_report_to(nullptr, false);
+        HIP_TRY(hipEventRecord(p0->join, p0->aux));
+    }
+    if (r >= 0 && !pl_y.empty())
+        r = ffhip_launch_h264_deblock_pictures_bd(bd, 0, pl_y.data(), ed_y.data(), (int)pl_y.size(), stride[0], mb_w, mb_h, stream);
+    if (!pl_c.empty())
+        HIP_TRY(hipStreamWaitEvent(stream, p0->join, 0));
     return r < 0 ? r : 0;
 }

@@ -20,6 +20,8 @@
 #include <mutex>
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "common.h"
 #include <atomic>
 #include "h264_kernels.h"
@@ -818,10 +820,13 @@ __device__ __forceinline__ bool db_wait_lds(const int *ctr, int want, int *fail)
     asm volatile("" ::: "memory");
     return true;
 }
+/* the pictures of a launch that do not sit at a constant pitch (round 4: the picture objects of a batched flush, each with its own
+ * planes and its own edge records): picture f's plane and records by table */
+struct FFHipDbPtrs { uint8_t *plane[FFHIP_DB_PTRS]; const FFHipH264Edge *edges[FFHIP_DB_PTRS]; };
 template <bool CHROMA, typename PIX = uint8_t>
 __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_t frame_pitch, ptrdiff_t stride, int mb_w, int mb_h,
                                                          const FFHipH264Edge *edges, int *gprog, int nbands, int bwaves, int nframes,
-                                                         int *fail, int fault, int xrot, int bd)
+                                                         int *fail, int fault, int xrot, int bd, FFHipDbPtrs PT, int use_ptrs)
 {
     constexpr int MB = CHROMA ? 8 : 16;          /* samples per macroblock side = lanes per row group */
     constexpr int PS = (int)sizeof(PIX), MBB = MB * PS; /* bytes per sample (uint16_t above 8 bits), per macroblock row */
@@ -858,8 +863,13 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
     const int f = xcd + 8 * ((L >> 3) / nwg), sb0 = (L >> 3) % nwg;
     if (f >= nframes)
         return;
-    plane += (size_t)f * frame_pitch;
-    edges += (size_t)f * mb_w * mb_h * NE;
+    if (use_ptrs) { /* (read once, here: the table is indexed at run time) */
+        plane = PT.plane[f];
+        edges = PT.edges[f];
+    } else {
+        plane += (size_t)f * frame_pitch;
+        edges += (size_t)f * mb_w * mb_h * NE;
+    }
     gprog += (size_t)f * nbands;
 
     const int lane = threadIdx.x & 63, q = lane / MB, l = lane % MB;
@@ -1074,10 +1084,23 @@ __global__ __launch_bounds__(256) void k_h264_deblock_skew(uint8_t *plane, size_
 
 /* the progress counters come from the per-device pool (progress_pool.hip): a slot per launch, zeroed in stream order */
 static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,
-                          const FFHipH264Edge *edges, hipStream_t stream, int bd = 8)
+                          const FFHipH264Edge *edges, hipStream_t stream, int bd = 8, uint8_t *const *planes = nullptr,
+                          const FFHipH264Edge *const *edge_tabs = nullptr)
 {
     if (mb_w <= 0 || mb_h <= 0 || nframes <= 0)
         return 0;
+    if (planes) { /* picture f's plane and edge records by table: the skewed-rows kernel only; the checks below see the OR of all */
+        uintptr_t al = 0, ale = 0;
+        for (int f = 0; f < nframes; f++) {
+            if (!planes[f] || !edge_tabs || !edge_tabs[f])
+                return FFHIP_EINVAL;
+            al |= (uintptr_t)planes[f];
+            ale |= (uintptr_t)edge_tabs[f];
+        }
+        plane = reinterpret_cast<uint8_t *>(al);
+        edges = reinterpret_cast<const FFHipH264Edge *>(ale);
+        frame_pitch = 0;
+    }
     const bool aligned = !(((uintptr_t)plane | (size_t)stride | frame_pitch) & 3);
     if (chroma && !aligned) {
         ffhip_set_error("ffhip_h264_deblock_frame_chroma: plane, stride and frame pitch must be 4-byte aligned");
@@ -1108,7 +1131,13 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
         return FFHIP_EINVAL;
     }
     const int ne = chroma ? 4 : 8;
-    const int per_launch = FFHIP_PROGRESS_SLOT_INTS / per_frame; /* frames whose counters fit one pool slot */
+    if (planes && !skew) {
+        ffhip_set_error("ffhip_h264_deblock: a batch of separate pictures needs 16-byte aligned planes, strides and edge records");
+        return FFHIP_EINVAL;
+    }
+    int per_launch = FFHIP_PROGRESS_SLOT_INTS / per_frame; /* frames whose counters fit one pool slot */
+    if (planes && per_launch > FFHIP_DB_PTRS)
+        per_launch = FFHIP_DB_PTRS;
     for (int f0 = 0; f0 < nframes; f0 += per_launch) {
         const int nf = nframes - f0 < per_launch ? nframes - f0 : per_launch;
         FFHipProgressSlot ps;
@@ -1116,8 +1145,15 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
         if (r < 0)
             return r;
         int *const prog = ps.prog, *const fail = ps.fail;
-        uint8_t *pl = plane + (size_t)f0 * frame_pitch;
-        const FFHipH264Edge *ed = edges + (size_t)f0 * mb_w * mb_h * ne;
+        uint8_t *pl = planes ? nullptr : plane + (size_t)f0 * frame_pitch;
+        const FFHipH264Edge *ed = planes ? nullptr : edges + (size_t)f0 * mb_w * mb_h * ne;
+        FFHipDbPtrs PT;
+        memset(&PT, 0, sizeof(PT));
+        if (planes)
+            for (int f = 0; f < nf; f++) {
+                PT.plane[f] = planes[f0 + f];
+                PT.edges[f] = edge_tabs[f0 + f];
+            }
         if (skew) {
             /* waves per picture: one per band while the chip has SIMDs to spare (a lone picture is latency-bound), else what an
              * XCD's 128 SIMDs leave each of its pictures, but never fewer than a quarter of the bands (the wavefront's width) */
@@ -1137,7 +1173,7 @@ static int deblock_frames(bool chroma, uint8_t *plane, size_t frame_pitch, int n
             static std::atomic<unsigned> launches{0};
             const int xrot = nf < 8 ? (int)(launches.fetch_add((unsigned)nf, std::memory_order_relaxed) & 7) : 0; /* where the batch's first picture goes */
 #define DBS_LAUNCH(CH, T) hipLaunchKernelGGL((k_h264_deblock_skew<CH, T>), g, t, lds, stream, pl, frame_pitch, stride, mb_w, mb_h, ed, prog, nbands, bwaves, \
-                                             nf, fail, fault, xrot, bd)
+                                             nf, fail, fault, xrot, bd, PT, planes ? 1 : 0)
             if (bd > 8) { if (chroma) DBS_LAUNCH(true, uint16_t); else DBS_LAUNCH(false, uint16_t); }
             else        { if (chroma) DBS_LAUNCH(true, uint8_t); else DBS_LAUNCH(false, uint8_t); }
 #undef DBS_LAUNCH
@@ -1176,6 +1212,13 @@ int ffhip_launch_h264_deblock_frames_chroma(uint8_t *plane, size_t frame_pitch, 
                                             const FFHipH264Edge *edges, hipStream_t stream)
 {
     return deblock_frames(true, plane, frame_pitch, nframes, stride, mb_w, mb_h, edges, stream);
+}
+
+/* nframes pictures that do not sit at a constant pitch: planes[f] and its edge records edges[f] (host arrays of device pointers) */
+int ffhip_launch_h264_deblock_pictures_bd(int bd, int chroma, uint8_t *const *planes, const FFHipH264Edge *const *edges, int nframes, ptrdiff_t stride,
+                                          int mb_w, int mb_h, hipStream_t stream)
+{
+    return deblock_frames(chroma != 0, nullptr, 0, nframes, stride, mb_w, mb_h, nullptr, stream, bd, planes, edges);
 }
 
 /* 9 .. 14 bits: uint16_t samples (stride and frame pitch in bytes), the skewed-rows kernel only */

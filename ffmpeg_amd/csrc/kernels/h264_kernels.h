@@ -64,6 +64,9 @@ int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_
                                   const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
 int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                      const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
+#define FFHIP_DB_PTRS 32
+int ffhip_launch_h264_deblock_pictures_bd(int bd, int chroma, uint8_t *const *planes, const FFHipH264Edge *const *edges, int nframes, ptrdiff_t stride,
+                                          int mb_w, int mb_h, hipStream_t stream);
 int ffhip_launch_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges,
                                     hipStream_t stream);
 int ffhip_launch_h264_deblock_frames_chroma(uint8_t *plane, size_t frame_pitch, int nframes, ptrdiff_t stride, int mb_w, int mb_h,

@@ -171,6 +171,16 @@ class Picture:
         return _lib.check(_lib.lib().ffhip_h264_picture_flush(self._p, dp, st, rp, _stream(stream)), "ffhip_h264_picture_flush")
 
 
+def pictures_flush(pics, dsts, strides, refs, stream=None):
+    """ffhip_h264_pictures_flush: Picture objects flushed together; dsts / refs: per picture three uint8 cuda tensors"""
+    n = len(pics)
+    pp = (C.c_void_p * n)(*[p._p for p in pics])
+    dp = (C.c_void_p * (3 * n))(*[t.data_ptr() for d in dsts for t in d])
+    rp = (C.c_void_p * (3 * n))(*[t.data_ptr() for r in refs for t in r])
+    st = (C.c_int * 3)(*strides)
+    return _lib.check(_lib.lib().ffhip_h264_pictures_flush(pp, n, dp, st, rp, _stream(stream)), "ffhip_h264_pictures_flush")
+
+
 # ---- H264PredContext (include/ffhip.h; libavcodec/h264pred.h:92-116) ----
 PRED4x4, PRED8x8L, PRED8x8, PRED16x16, PRED4x4_ADD, PRED8x8L_ADD, PRED8x8L_FILTER_ADD, PRED8x16 = range(8)
 PRED_TOPLEFT, PRED_TOPRIGHT, PRED_TR_SPLAT = 1, 2, 4

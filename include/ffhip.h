@@ -749,6 +749,13 @@ int  ffhip_h264_intra_frames_dev(int bit_depth, int npics, const FFHipH264IntraP
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
 int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                               void *stream);
+/** n picture objects (one geometry, depth and device; the pictures a decoder's frame threads hold at once) flushed TOGETHER (round 4):
+ *  dst[3 i + pl] / ref[3 i + pl] are picture i's planes and reference bases, stride[] is shared.  Every picture's staging copy,
+ *  prediction and residual launches are its own; the two stages that are a latency chain per picture — the intra reconstruction
+ *  wavefront and the in-loop filter — run ONCE for all pictures, side by side (launches of up to 32 pictures; planes and strides
+ *  16-byte aligned when any picture carries deblocking records).  The result per picture is flush()'s.  Asynchronous on `stream`. */
+int  ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, uint8_t *const *dst, const int stride[3], const uint8_t *const *ref,
+                               void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: AACDecDSP.imdct_and_windowing — float decoder, 1024-sample frames */

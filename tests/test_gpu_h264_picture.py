@@ -111,6 +111,67 @@ def _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra=0.0, depth=8):
     return calls
 
 
+def _record_one(pic, rng, O, h264, mb_w, mb_h, P, refs, strides, p_intra):
+    """one picture recorded into `pic` (begin() .. the last deblock_mb) and decoded by the oracle: returns (dst0, want)"""
+    W, H = mb_w * 16, mb_h * 16
+    sy, sc = strides[0], strides[1]
+    dst0 = [rng.integers(0, 256, (H, sy), dtype=np.uint8), rng.integers(0, 256, (H // 2, sc), dtype=np.uint8),
+            rng.integers(0, 256, (H // 2, sc), dtype=np.uint8)]
+    want = [a.copy() for a in dst0]
+    tmp = [np.zeros_like(a) for a in dst0]                # the oracle's bi-prediction scratch
+    edges = [np.zeros(mb_w * mb_h * (8 if pl == 0 else 4), EDGE_DT) for pl in range(3)]
+    pic.begin()
+    for my in range(mb_h):
+        for mx in range(mb_w):
+            for call in _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra):
+                if call[0] == "intra":
+                    # hl_decode_mb() on the oracle's picture now (decoder order); the record runs in flush()'s wavefront
+                    d = call[1]
+                    mb_o = G.oracle_decode(O, d, want, strides)
+                    mb_p = d["mb"].copy()
+                    pic.intra_mb(G.to_record(d), d["nnzc"], mb_p, d["luma_dc"], d["pcm"])
+                    assert d["type"] == G.PCM or np.array_equal(mb_p, mb_o)       # sl->mb consumed as the dsp functions do
+                elif call[0] == "mc":
+                    _, pl, stage, rec = call
+                    tgt = tmp[pl] if stage == h264.MC_TMP else want[pl]
+                    r = rec[0]
+                    if pl == 0:
+                        pic.mc_luma(stage, rec)
+                        O.ffo_h264_qpel(int(stage == h264.MC_AVG), int(r["size_idx"]), int(r["mcxy"]), _at(tgt, r["dst_offset"]),
+                                        _at(refs[0], r["src_offset"]), sy)
+                    else:
+                        pic.mc_chroma(pl, stage, rec)
+                        O.ffo_h264_chroma_mc(int(stage == h264.MC_AVG), int(r["h"]), _at(tgt, r["dst_offset"]), _at(refs[pl], r["src_offset"]),
+                                             sc, int(r["h"]), int(r["x"]), int(r["y"]))
+                elif call[0] == "w":
+                    _, pl, rec = call
+                    pic.weight(pl, rec)
+                    r = rec[0]
+                    wpx = [16, 8, 4, 2][int(r["w_idx"])]
+                    if r["bi"]:
+                        O.ffo_h264_biweight(wpx, _at(want[pl], r["dst_offset"]), _at(tmp[pl], r["src_offset"]), strides[pl], int(r["height"]),
+                                            int(r["log2_denom"]), int(r["weightd"]), int(r["weights"]), int(r["offset"]))
+                    else:
+                        O.ffo_h264_weight(wpx, _at(want[pl], r["dst_offset"]), strides[pl], int(r["height"]), int(r["log2_denom"]),
+                                          int(r["weightd"]), int(r["offset"]))
+                elif call[0] == "idct":
+                    _, pl, kind, off, blk = call
+                    host = blk.copy()
+                    pic.idct_add(pl, kind, off, host)
+                    assert host[0] == 0 and (kind >= 2 or not host.any())       # consumed as the dsp function does
+                    ob = blk.copy()
+                    getattr(O, IDCT_FN[kind])(_at(want[pl], off), ob.ctypes.data_as(C.POINTER(C.c_int16)), strides[pl])
+                else:
+                    _, pl, ed = call
+                    pic.deblock_mb(pl, mx, my, ed)
+                    ne = len(ed)
+                    edges[pl][(my * mb_w + mx) * ne:(my * mb_w + mx + 1) * ne] = ed
+    O.ffo_h264_deblock_frame(ptr(want[0]), sy, mb_w, mb_h, C.c_void_p(edges[0].ctypes.data))
+    for pl in (1, 2):
+        O.ffo_h264_deblock_frame_chroma(ptr(want[pl]), sc, mb_w, mb_h, C.c_void_p(edges[pl].ctypes.data))
+    return dst0, want
+
+
 @pytest.mark.parametrize("mb_w,mb_h,pictures,p_intra", [(6, 4, 3, 0.0), (40, 22, 1, 0.0), (6, 4, 4, .3), (40, 22, 1, .15), (11, 7, 2, 1.0),
                                                          (120, 68, 1, 1.0)])
 def test_picture_pipeline(mb_w, mb_h, pictures, p_intra):
@@ -128,60 +189,7 @@ def test_picture_pipeline(mb_w, mb_h, pictures, p_intra):
     d_refs = [torch.from_numpy(r).cuda() for r in refs]
     pic = h264.Picture(mb_w, mb_h)
     for it in range(pictures):
-        dst0 = [rng.integers(0, 256, (H, sy), dtype=np.uint8), rng.integers(0, 256, (H // 2, sc), dtype=np.uint8),
-                rng.integers(0, 256, (H // 2, sc), dtype=np.uint8)]
-        want = [a.copy() for a in dst0]
-        tmp = [np.zeros_like(a) for a in dst0]                # the oracle's bi-prediction scratch
-        edges = [np.zeros(mb_w * mb_h * (8 if pl == 0 else 4), EDGE_DT) for pl in range(3)]
-        pic.begin()
-        for my in range(mb_h):
-            for mx in range(mb_w):
-                for call in _make_mb(rng, mx, my, W, H, P, sy, sc, p_intra):
-                    if call[0] == "intra":
-                        # hl_decode_mb() on the oracle's picture now (decoder order); the record runs in flush()'s wavefront
-                        d = call[1]
-                        mb_o = G.oracle_decode(O, d, want, strides)
-                        mb_p = d["mb"].copy()
-                        pic.intra_mb(G.to_record(d), d["nnzc"], mb_p, d["luma_dc"], d["pcm"])
-                        assert d["type"] == G.PCM or np.array_equal(mb_p, mb_o)       # sl->mb consumed as the dsp functions do
-                    elif call[0] == "mc":
-                        _, pl, stage, rec = call
-                        tgt = tmp[pl] if stage == h264.MC_TMP else want[pl]
-                        r = rec[0]
-                        if pl == 0:
-                            pic.mc_luma(stage, rec)
-                            O.ffo_h264_qpel(int(stage == h264.MC_AVG), int(r["size_idx"]), int(r["mcxy"]), _at(tgt, r["dst_offset"]),
-                                            _at(refs[0], r["src_offset"]), sy)
-                        else:
-                            pic.mc_chroma(pl, stage, rec)
-                            O.ffo_h264_chroma_mc(int(stage == h264.MC_AVG), int(r["h"]), _at(tgt, r["dst_offset"]), _at(refs[pl], r["src_offset"]),
-                                                 sc, int(r["h"]), int(r["x"]), int(r["y"]))
-                    elif call[0] == "w":
-                        _, pl, rec = call
-                        pic.weight(pl, rec)
-                        r = rec[0]
-                        wpx = [16, 8, 4, 2][int(r["w_idx"])]
-                        if r["bi"]:
-                            O.ffo_h264_biweight(wpx, _at(want[pl], r["dst_offset"]), _at(tmp[pl], r["src_offset"]), strides[pl], int(r["height"]),
-                                                int(r["log2_denom"]), int(r["weightd"]), int(r["weights"]), int(r["offset"]))
-                        else:
-                            O.ffo_h264_weight(wpx, _at(want[pl], r["dst_offset"]), strides[pl], int(r["height"]), int(r["log2_denom"]),
-                                              int(r["weightd"]), int(r["offset"]))
-                    elif call[0] == "idct":
-                        _, pl, kind, off, blk = call
-                        host = blk.copy()
-                        pic.idct_add(pl, kind, off, host)
-                        assert host[0] == 0 and (kind >= 2 or not host.any())       # consumed as the dsp function does
-                        ob = blk.copy()
-                        getattr(O, IDCT_FN[kind])(_at(want[pl], off), ob.ctypes.data_as(C.POINTER(C.c_int16)), strides[pl])
-                    else:
-                        _, pl, ed = call
-                        pic.deblock_mb(pl, mx, my, ed)
-                        ne = len(ed)
-                        edges[pl][(my * mb_w + mx) * ne:(my * mb_w + mx + 1) * ne] = ed
-        O.ffo_h264_deblock_frame(ptr(want[0]), sy, mb_w, mb_h, C.c_void_p(edges[0].ctypes.data))
-        for pl in (1, 2):
-            O.ffo_h264_deblock_frame_chroma(ptr(want[pl]), sc, mb_w, mb_h, C.c_void_p(edges[pl].ctypes.data))
+        dst0, want = _record_one(pic, rng, O, h264, mb_w, mb_h, P, refs, strides, p_intra)
         d_dst = [torch.from_numpy(a.copy()).cuda() for a in dst0]
         pic.flush(d_dst, strides, d_refs)
         torch.cuda.synchronize()
@@ -190,6 +198,49 @@ def test_picture_pipeline(mb_w, mb_h, pictures, p_intra):
             assert (want[pl] != dst0[pl]).sum() > 1000
             assert np.array_equal(got, want[pl]), "picture %d plane %d: %d mismatches" % (it, pl, (got != want[pl]).sum())
     pic.close()
+
+
+@pytest.mark.parametrize("mb_w,mb_h,pictures,p_intra", [(6, 4, 5, 0.3), (20, 11, 3, 0.15), (11, 7, 35, 1.0), (12, 6, 4, 0.0)])
+def test_pictures_flush_batch(mb_w, mb_h, pictures, p_intra):
+    """ffhip_h264_pictures_flush (round 4): several picture objects flushed together — each picture's own prediction and residual
+    launches, then ONE launch of all their intra wavefronts and the in-loop filter of all their planes side by side (pictures that
+    do not sit at a constant pitch: plane and edge-record tables) — must leave every picture exactly as its own flush() does, i.e.
+    as the oracle decodes it.  35 pictures: two launches; a picture without intra macroblocks and one without inter ones in a batch"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(mb_w * 17 + mb_h + pictures)
+    P = 32
+    W, H = mb_w * 16, mb_h * 16
+    sy, sc = W + 2 * P, W // 2 + P
+    strides = [sy, sc, sc]
+    refs = [rng.integers(0, 256, (2 * (H + 2 * P), sy), dtype=np.uint8), rng.integers(0, 256, (2 * (H // 2 + P), sc), dtype=np.uint8),
+            rng.integers(0, 256, (2 * (H // 2 + P), sc), dtype=np.uint8)]
+    d_refs = [torch.from_numpy(r).cuda() for r in refs]
+    pics, wants, dsts, d0s = [], [], [], []
+    for it in range(pictures):
+        pic = h264.Picture(mb_w, mb_h)
+        pi = p_intra if it != 1 else (0.0 if p_intra < 1.0 else 1.0)      # picture 1 of a mixed batch has no intra macroblock
+        dst0, want = _record_one(pic, rng, O, h264, mb_w, mb_h, P, refs, strides, pi)
+        pics.append(pic)
+        wants.append(want)
+        d0s.append(dst0)
+        dsts.append([torch.from_numpy(a.copy()).cuda() for a in dst0])
+    h264.pictures_flush(pics, dsts, strides, [d_refs] * pictures)
+    torch.cuda.synchronize()
+    for it in range(pictures):
+        for pl in range(3):
+            got = dsts[it][pl].cpu().numpy()
+            assert np.array_equal(got, wants[it][pl]), "picture %d plane %d: %d mismatches" % (it, pl, (got != wants[it][pl]).sum())
+    # the objects are reusable after a batch: the next picture of each, flushed alone
+    dst0, want = _record_one(pics[0], rng, O, h264, mb_w, mb_h, P, refs, strides, p_intra)
+    d_dst = [torch.from_numpy(a.copy()).cuda() for a in dst0]
+    pics[0].flush(d_dst, strides, d_refs)
+    torch.cuda.synchronize()
+    for pl in range(3):
+        assert np.array_equal(d_dst[pl].cpu().numpy(), want[pl])
+    for p_ in pics:
+        p_.close()
 
 
 @pytest.mark.parametrize("depth,mb_w,mb_h,pictures,p_intra", [(10, 6, 4, 2, 0.0), (10, 40, 22, 1, 0.0), (9, 7, 5, 1, 0.0), (12, 11, 7, 1, 0.0),
