@@ -758,7 +758,23 @@ def round2_legs(torch, dev, ev):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
+    # N pictures per launch (round 4, ffhip_vp9_loopfilter_frames_dev): each picture its own planes, the same tables
+    lfb = {}
+    for npl in (8, 16, 32):
+        pics = [(yy.clone(), uu.clone(), vv.clone(), d_tabs) for _ in range(npl)]
+        for _ in range(2):
+            vp9.loopfilter_frames(pics, 64 * sbc, 32 * sbc, 8 * sbc, 8 * sbr)
+        b0, b1 = ev(), ev()
+        b0.record()
+        for _ in range(3):
+            vp9.loopfilter_frames(pics, 64 * sbc, 32 * sbc, 8 * sbc, 8 * sbr)
+        b1.record()
+        torch.cuda.synchronize()
+        lfb[npl] = b0.elapsed_time(b1) / 3
+        del pics
     out["vp9_loopfilter_frame_4k"] = {"ms_per_picture_one_stream": round(ms, 4), "pictures_per_s": round(1e3 / ms, 1),
+                                      "ms_per_launch_of_8_16_32_pictures": [round(lfb[8], 3), round(lfb[16], 3), round(lfb[32], 3)],
+                                      "pictures_per_s_32_per_launch": round(32e3 / lfb[32], 1),
                                       "Mpixels/s": round(64 * sbc * 64 * sbr / (ms * 1e-3) / 1e6, 1),
                                       "note": "decoder order (superblock wavefront, luma and chroma chains side by side), every 8x8-grid edge 8 wide"}
     out.update(h264_picture_leg(torch, dev, ev))

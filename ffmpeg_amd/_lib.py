@@ -225,6 +225,7 @@ def lib():
         "ffhip_vp9_lf_sb_tables": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
         "ffhip_vp9_loopfilter_frame_dev": (C.c_int, [C.c_int, vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_vp9_loopfilter_frame_ss_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
+        "ffhip_vp9_loopfilter_frames_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp]),
         "ffhip_vp9_itxfm_add_batch_dev_hbd": (C.c_int, [C.c_int, C.c_int, vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_vp9_mc_batch_dev_hbd": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_vp9_scaled_mc_batch_dev_hbd": (C.c_int, [C.c_int, vp, C.c_ssize_t, vp, C.c_ssize_t, vp, C.c_int, vp]),

@@ -458,6 +458,20 @@ extern "C" int ffhip_vp9_loopfilter_frame_ss_dev(int bit_depth, int ss_h, int ss
     return ffhip_launch_vp9_lf_frame(bit_depth, y, u, v, stride_y, stride_uv, cols, rows, tables, (hipStream_t)stream, 1);
 }
 
+extern "C" int ffhip_vp9_loopfilter_frames_dev(int bit_depth, int ss_h, int ss_v, int npics, const FFHipVp9LfPic *pics, ptrdiff_t stride_y,
+                                               ptrdiff_t stride_uv, int cols, int rows, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || npics < 0 || (npics && !pics) || cols < 0 || rows < 0 || rows > 8 * 1364)
+        return FFHIP_EINVAL;
+    if (ss_h != ss_v) { /* 4:4:0 / 4:2:2 (VP9 profiles 1 / 3, rare): not built */
+        ffhip_set_error("ffhip_vp9_loopfilter_frames_dev: chroma sub-sampling %d x %d (4:2:0 and 4:4:4 are built)", ss_h, ss_v);
+        return FFHIP_ENOSYS;
+    }
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_lf_frames(bit_depth, npics, pics, stride_y, stride_uv, cols, rows, (hipStream_t)stream, ss_h ? 0 : 1);
+}
+
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */
 extern "C" int ffhip_fdsp_batch_dev(int op, float *dst, size_t dst_pitch, const float *src0, size_t pitch0, const float *src1,
                                     size_t pitch1, const float *src2, size_t pitch2, float mul, int len, int nvec, void *stream)

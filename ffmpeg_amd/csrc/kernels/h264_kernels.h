@@ -99,6 +99,11 @@ int ffhip_launch_vp9_smc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, 
 int ffhip_launch_vp9_intra(int tx, uint8_t *dst, ptrdiff_t stride, const uint8_t *edges, const FFHipVp9Intra *blocks, int n, hipStream_t stream);
 int ffhip_launch_vp9_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipVp9Edge *edges, int n, hipStream_t stream);
 /* the vp9dsp kernels at bit depth 8 / 10 / 12 (uint16_t samples and int32 coefficients above 8; strides and offsets in bytes) */
+/* up to FFHIP_VP9_LF_PICS pictures of one geometry per launch of the superblock-order loop filter (== FFHipVp9LfPic of include/ffhip.h) */
+#define FFHIP_VP9_LF_PICS 32
+struct FFHipVp9LfPics { int n; int pad; FFHipVp9LfPic pic[FFHIP_VP9_LF_PICS]; };
+int ffhip_launch_vp9_lf_frames(int bd, int npics, const FFHipVp9LfPic *pics, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows, hipStream_t stream,
+                               int planes444 = 0);
 int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
                               const FFHipVp9LfSb *tabs, hipStream_t stream, int planes444 = 0);
 int ffhip_launch_vp9_itxfm_bd(int bd, int tx, void *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipVp9TU *tus, int n, hipStream_t stream);

@@ -723,13 +723,20 @@ __device__ __forceinline__ void vp9_lf_sb_rows(vl_lds_u8 *lds, int W, uint8_t *p
 }
 
 /* blocks 0 .. nwg-1: luma (the long chain first), nwg .. 2 nwg-1: chroma; W superblock rows per block */
+/* round 4: blockIdx.y = the picture of a batch (one geometry; each picture its own planes, tables and progress counters): a picture's
+ * filter is a dependency chain through it that occupies 34 superblock rows' worth of waves — the pictures a decoder's frame threads
+ * hold are filtered side by side for the latency of one */
 template <typename PIX>
-__global__ __launch_bounds__(256) void k_vp9_lf_frame_wg(uint8_t *py, uint8_t *pu, uint8_t *pv, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
-                                                        const FFHipVp9LfSb *tabs, int *progress, int *fail, int bd, int fault, int planes444)
+__global__ __launch_bounds__(256) void k_vp9_lf_frame_wg(FFHipVp9LfPics S, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows, int *progress_all,
+                                                        int *fail, int bd, int fault, int planes444)
 {
     extern __shared__ __align__(16) uint8_t vl_lds[];
     const int W = (int)(blockDim.x >> 6);
     const int sb_rows = (rows + 7) >> 3, nwg = (sb_rows + W - 1) / W;
+    /* (read once: the set is indexed at run time) */
+    uint8_t *const py = S.pic[blockIdx.y].y, *const pu = S.pic[blockIdx.y].u, *const pv = S.pic[blockIdx.y].v;
+    const FFHipVp9LfSb *const tabs = S.pic[blockIdx.y].tables;
+    int *const progress = progress_all + (size_t)blockIdx.y * (size_t)((planes444 ? 3 : 2) * sb_rows);
     if (planes444) { /* 4:4:4: the chroma planes are filtered exactly as luma, with luma's masks and levels (vp9lpf.c:185-201: uv_masks =
                       * lflvl->mask[ss_h | ss_v], filter_plane_cols / _rows with ss 0): three luma chains */
         const int pl = (int)blockIdx.x / nwg, b = (int)blockIdx.x - pl * nwg;
@@ -758,43 +765,72 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame(uint8_t *py, uint8_t *pu, u
 int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
                               const FFHipVp9LfSb *tabs, hipStream_t stream, int planes444)
 {
+    FFHipVp9LfPic one = { y, u, v, tabs };
+    return ffhip_launch_vp9_lf_frames(bd, 1, &one, sy, suv, cols, rows, stream, planes444);
+}
+
+int ffhip_launch_vp9_lf_frames(int bd, int npics, const FFHipVp9LfPic *pics, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows, hipStream_t stream,
+                               int planes444)
+{
     const int sb_rows = (rows + 7) >> 3;
-    if (cols <= 0 || rows <= 0)
+    if (cols <= 0 || rows <= 0 || npics <= 0)
         return 0;
-    if ((bd != 8 && bd != 10 && bd != 12) || (((uintptr_t)y | (uintptr_t)u | (uintptr_t)v | (size_t)sy | (size_t)suv) & 3)) {
+    uintptr_t al = (size_t)sy | (size_t)suv;
+    for (int i = 0; i < npics; i++) {
+        if (!pics[i].y || !pics[i].u || !pics[i].v || !pics[i].tables)
+            return FFHIP_EINVAL;
+        al |= (uintptr_t)pics[i].y | (uintptr_t)pics[i].u | (uintptr_t)pics[i].v;
+    }
+    if ((bd != 8 && bd != 10 && bd != 12) || (al & 3)) {
         ffhip_set_error("ffhip_vp9_loopfilter_frame: bit depth %d (8, 10, 12); planes and strides must be 4-byte aligned", bd);
         return FFHIP_EINVAL;
     }
-    FFHipProgressSlot ps;
-    const int r = ffhip_progress_acquire((planes444 ? 3 : 2) * sb_rows + 1, stream, &ps);
-    if (r < 0)
-        return r;
-    int *const prog = ps.prog, *const fail = ps.fail;
+    const int per_pic = (planes444 ? 3 : 2) * sb_rows;
+    if (per_pic + 1 > FFHIP_PROGRESS_SLOT_INTS)
+        return FFHIP_EINVAL;
     const char *eo = FFHIP_KNOB("FFHIP_VP9_LF_OLD"); /* 1: one wave per superblock row, every hand-off through memory (cross-check) */
     const char *ew = FFHIP_KNOB("FFHIP_VP9_LF_WPB"), *ef = FFHIP_KNOB("FFHIP_VP9_LF_FAULT");
     const int fault = ef ? atoi(ef) : 0; /* 1: the test hook (no hand-off is published); 8: no waiting (timing experiment, wrong output) */
-    if (eo && atoi(eo) == 1 && !planes444) {
-        if (bd == 8)
-            hipLaunchKernelGGL(k_vp9_lf_frame<uint8_t>, dim3(2 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8);
-        else
-            hipLaunchKernelGGL(k_vp9_lf_frame<uint16_t>, dim3(2 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, bd);
-    } else {
-        /* superblock rows per workgroup: what 64 KB of LDS hold (two stacks of 8 + 64 W rows, 76 samples wide) */
-        const int wmax = bd == 8 ? 4 : 2;
-        const int W = ew && atoi(ew) >= 1 && atoi(ew) <= wmax ? atoi(ew) : wmax;
-        const int ps_ = bd == 8 ? 1 : 2, nwg = (sb_rows + W - 1) / W;
-        const unsigned luma = (2u * (8 + W * 64) * (76 * ps_ / 4) + W * 256u + 2u * W) * 4u, chroma = (4u * (8 + W * 32) * (44 * ps_ / 4) + W * 64u + 2u * W) * 4u;
-        const unsigned lds = ((luma > chroma ? luma : chroma) + 15u) & ~15u;
-        if (bd == 8)
-            hipLaunchKernelGGL(k_vp9_lf_frame_wg<uint8_t>, dim3((planes444 ? 3 : 2) * nwg), dim3(64 * W), lds, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, 8, fault, planes444);
-        else
-            hipLaunchKernelGGL(k_vp9_lf_frame_wg<uint16_t>, dim3((planes444 ? 3 : 2) * nwg), dim3(64 * W), lds, stream, y, u, v, sy, suv, cols, rows, tabs, prog, fail, bd, fault, planes444);
+    const bool old = eo && atoi(eo) == 1 && !planes444;
+    int per = old ? 1 : (FFHIP_PROGRESS_SLOT_INTS - 1) / per_pic;
+    per = per > FFHIP_VP9_LF_PICS ? FFHIP_VP9_LF_PICS : per;
+    for (int p0 = 0; p0 < npics; p0 += per) {
+        const int n = npics - p0 < per ? npics - p0 : per;
+        FFHipProgressSlot ps;
+        const int r = ffhip_progress_acquire(n * per_pic + 1, stream, &ps);
+        if (r < 0)
+            return r;
+        int *const prog = ps.prog, *const fail = ps.fail;
+        if (old) {
+            const FFHipVp9LfPic &P = pics[p0];
+            if (bd == 8)
+                hipLaunchKernelGGL(k_vp9_lf_frame<uint8_t>, dim3(2 * sb_rows), dim3(64), 0, stream, P.y, P.u, P.v, sy, suv, cols, rows, P.tables, prog, fail, 8);
+            else
+                hipLaunchKernelGGL(k_vp9_lf_frame<uint16_t>, dim3(2 * sb_rows), dim3(64), 0, stream, P.y, P.u, P.v, sy, suv, cols, rows, P.tables, prog, fail, bd);
+        } else {
+            FFHipVp9LfPics S;
+            S.n = n;
+            for (int i = 0; i < FFHIP_VP9_LF_PICS; i++)
+                S.pic[i] = pics[p0 + (i < n ? i : 0)];
+            /* superblock rows per workgroup: what 64 KB of LDS hold (two stacks of 8 + 64 W rows, 76 samples wide) */
+            const int wmax = bd == 8 ? 4 : 2;
+            const int W = ew && atoi(ew) >= 1 && atoi(ew) <= wmax ? atoi(ew) : wmax;
+            const int ps_ = bd == 8 ? 1 : 2, nwg = (sb_rows + W - 1) / W;
+            const unsigned luma = (2u * (8 + W * 64) * (76 * ps_ / 4) + W * 256u + 2u * W) * 4u, chroma = (4u * (8 + W * 32) * (44 * ps_ / 4) + W * 64u + 2u * W) * 4u;
+            const unsigned lds = ((luma > chroma ? luma : chroma) + 15u) & ~15u;
+            if (bd == 8)
+                hipLaunchKernelGGL(k_vp9_lf_frame_wg<uint8_t>, dim3((planes444 ? 3 : 2) * nwg, n), dim3(64 * W), lds, stream, S, sy, suv, cols, rows, prog, fail, 8, fault, planes444);
+            else
+                hipLaunchKernelGGL(k_vp9_lf_frame_wg<uint16_t>, dim3((planes444 ? 3 : 2) * nwg, n), dim3(64 * W), lds, stream, S, sy, suv, cols, rows, prog, fail, bd, fault, planes444);
+        }
+        const hipError_t e = hipGetLastError();
+        const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            return FFHIP_EIO;
+        }
+        if (r2 < 0)
+            return r2;
     }
-    const hipError_t e = hipGetLastError();
-    const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
-    if (e != hipSuccess) {
-        ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
-        return FFHIP_EIO;
-    }
-    return r2;
+    return 0;
 }

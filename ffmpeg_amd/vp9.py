@@ -106,6 +106,17 @@ def loopfilter_frame(y, u, v, stride_y, stride_uv, cols, rows, tables, stream=No
                                                                 rows, tables.data_ptr(), _st(stream)), "ffhip_vp9_loopfilter_frame_dev")
 
 
+class LfPic(C.Structure):   # FFHipVp9LfPic (include/ffhip.h)
+    _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("tables", C.c_void_p)]
+
+
+def loopfilter_frames(pics, stride_y, stride_uv, cols, rows, stream=None, bit_depth=8, ss=(1, 1)):
+    """ffhip_vp9_loopfilter_frames_dev: pics = [(y, u, v, tables)] device tensors of pictures that share the geometry; one launch"""
+    arr = (LfPic * len(pics))(*[LfPic(y.data_ptr(), u.data_ptr(), v.data_ptr(), t.data_ptr()) for y, u, v, t in pics])
+    return _lib.check(_lib.lib().ffhip_vp9_loopfilter_frames_dev(bit_depth, ss[0], ss[1], len(pics), C.cast(arr, C.c_void_p), stride_y, stride_uv, cols,
+                                                                 rows, _st(stream)), "ffhip_vp9_loopfilter_frames_dev")
+
+
 _LF = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int)
 
 

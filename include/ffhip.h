@@ -1368,6 +1368,15 @@ int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_
  *  read.  4:4:0 / 4:2:2: FFHIP_ENOSYS. */
 int ffhip_vp9_loopfilter_frame_ss_dev(int bit_depth, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y,
                                       ptrdiff_t stride_uv, int cols, int rows, const FFHipVp9LfSb *tables, void *stream);
+/** N pictures of one geometry in ONE launch (round 4; what a decoder's frame threads hold at once): each picture its own planes and
+ *  tables (device pointers), strides shared.  A picture's filter is a dependency chain through it (0.9 ms for a 4K picture on a chip it
+ *  cannot fill); the pictures of a batch are filtered side by side.  ss_h / ss_v as above.  `pics` is a host array. */
+typedef struct FFHipVp9LfPic {
+    uint8_t *y, *u, *v;
+    const FFHipVp9LfSb *tables;
+} FFHipVp9LfPic;
+int ffhip_vp9_loopfilter_frames_dev(int bit_depth, int ss_h, int ss_v, int npics, const FFHipVp9LfPic *pics, ptrdiff_t stride_y,
+                                    ptrdiff_t stride_uv, int cols, int rows, void *stream);
 
 /**
  * vp9dsp above 8 bits (profiles 2 / 3): the batch faces above at the bpp ff_vp9dsp_init(dsp, bpp, bitexact) instantiates its template

@@ -149,3 +149,45 @@ def test_vp9_loopfilter_frame_444(sbc, sbr, kind, bd):
     assert changed > (30 * sbc * sbr if sbc * sbr > 8 else -1)
     with pytest.raises(Exception):
         vp9.loopfilter_frame(dev[0], dev[1], dev[2], before[0].strides[0], before[1].strides[0], cols, rows, d_tabs, bit_depth=bd, ss=(1, 0))
+
+
+@pytest.mark.parametrize("bd,ss,sbc,sbr,npics", [(8, (1, 1), 9, 5, 6), (10, (1, 1), 7, 6, 3), (8, (0, 0), 5, 4, 4), (8, (1, 1), 3, 2, 70), (8, (1, 1), 30, 17, 2)])
+def test_vp9_loopfilter_frames_batch(bd, ss, sbc, sbr, npics):
+    """ffhip_vp9_loopfilter_frames_dev (round 4): the pictures of a batch — each its own planes and tables — come out exactly as from
+    launches of their own (which the tests above pin to the oracle superblock by superblock); 70 pictures: three launches"""
+    import torch
+    from ffmpeg_amd import vp9, _lib
+    rng = np.random.default_rng(7000 + 100 * sbc + sbr + npics + bd)
+    lim, mblim = G.filter_lut(int(rng.integers(0, 8)))
+    cols, rows = 8 * sbc - int(rng.integers(0, 8)), 8 * sbr - int(rng.integers(0, 8))
+    sub = 1 if ss == (1, 1) else 0
+    batch, single, keep = [], [], []
+    sy = suv = None
+    for i in range(npics):
+        planes = [_plane(rng, 64 * sbr, 64 * sbc, 12, bd), _plane(rng, (64 >> sub) * sbr, (64 >> sub) * sbc, 12 if not sub else 4, bd),
+                  _plane(rng, (64 >> sub) * sbr, (64 >> sub) * sbc, 12 if not sub else 4, bd)]
+        sy, suv = planes[0].strides[0], planes[1].strides[0]
+        filt = np.zeros(sbr * sbc, G.FILTER_DT)
+        for r in range(sbr):
+            for c in range(sbc):
+                filt[r * sbc + c] = G.structured(rng, r, c, cols, rows)
+        tabs = vp9.lf_sb_tables(filt.view(np.uint8).reshape(sbr * sbc, 192), sbc, sbr, lim, mblim)   # (4:4:4 reads the luma tables only)
+        d_tabs = torch.from_numpy(tabs.view(np.int32)).cuda()
+        a = [torch.from_numpy(p.view(np.uint8).reshape(-1).copy()).cuda() for p in planes]
+        b = [t.clone() for t in a]
+        batch.append((a[0], a[1], a[2], d_tabs))
+        single.append(b)
+        keep.append((planes, d_tabs))
+    vp9.loopfilter_frames(batch, sy, suv, cols, rows, bit_depth=bd, ss=ss)
+    for i in range(npics):
+        b = single[i]
+        vp9.loopfilter_frame(b[0], b[1], b[2], sy, suv, cols, rows, keep[i][1], bit_depth=bd, ss=ss)
+    torch.cuda.synchronize()
+    assert _lib.lib().ffhip_stream_synchronize(None) == 0
+    changed = 0
+    for i in range(npics):
+        for k in range(3):
+            x, y = batch[i][k].cpu().numpy(), single[i][k].cpu().numpy()
+            assert np.array_equal(x, y), (i, k)
+            changed += int((x != keep[i][0][k].view(np.uint8).reshape(-1)).sum())
+    assert changed > 1000

@@ -56,3 +56,16 @@ ms = e0.elapsed_time(e1) / N
 print(json.dumps({"case": "vp9 loop filter, 4K picture (3840x2176, 4:2:0, %d bits) in superblock order, one launch" % bd, "superblocks": sbc * sbr,
                   "filtered_8_sample_segments": entries, "ms_per_picture_gpu": round(ms, 3), "pictures_per_s": round(1e3 / ms, 1),
                   "us_per_superblock_step": round(1e3 * ms / (sbc + 2 * sbr), 2)}))
+# the same picture N times in ONE launch (ffhip_vp9_loopfilter_frames_dev): each copy its own planes
+for npl in (8, 16, 32):
+    pics = [(y.clone(), u.clone(), v.clone(), d_tabs) for _ in range(npl)]
+    for _ in range(2):
+        vp9.loopfilter_frames(pics, sy, suv, 8 * sbc, 8 * sbr, bit_depth=bd)
+    e0.record()
+    for _ in range(4):
+        vp9.loopfilter_frames(pics, sy, suv, 8 * sbc, 8 * sbr, bit_depth=bd)
+    e1.record()
+    torch.cuda.synchronize()
+    msb = e0.elapsed_time(e1) / 4
+    print(json.dumps({"pictures_per_launch": npl, "ms_per_launch": round(msb, 3), "pictures_per_s": round(npl * 1e3 / msb, 1)}))
+    del pics
