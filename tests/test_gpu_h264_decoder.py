@@ -36,7 +36,7 @@ def _libs():
     return ffi.ref(), C.CDLL(I.REF_HIP_SO)
 
 
-def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=1, bipred=True):
+def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=1, bipred=True, batch=False):
     from ffmpeg_amd import h264
     torch = _torch()
     R, RH = _libs()
@@ -66,7 +66,10 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=
     RH.ffrefhip_h264dec_record_begin.argtypes = [C.c_void_p] * 5
     RH.ffrefhip_h264dec_record_begin.restype = None
     n_emu = 0
+    held = []                                    # batch: (object, device planes, the reference's planes, the planes before) per picture
     for it in range(pictures):
+        if batch and it:
+            pic = h264.Picture(mb_w, mb_h, bit_depth=depth)       # frame threads: every picture in hand has its own object
         pw = I.make_pwt(rng, weights, depth, nref)
         cpu.set_pwt(pw)
         gpu.set_pwt(pw)
@@ -87,6 +90,9 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=
                     m = I.make_inter_mb(rng, cpu.bits, mx, my, nref, mvr, depth=depth, bipred=bipred)
                     a, b = cpu.decode_inter(m), gpu.decode_inter(m)
                     assert np.array_equal(a, b)
+        if batch:
+            held.append((pic, d_dst, want, dst0))
+            continue
         pic.flush(d_dst, strides, d_refs)
         torch.cuda.synchronize()
         for pl in range(3):
@@ -94,6 +100,18 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=
             assert (want[pl] != dst0[pl]).sum() > 100 and want[pl].max() < top
             bad = got != want[pl]
             assert not bad.any(), "picture %d plane %d: %d mismatches, first at %s" % (it, pl, bad.sum(), np.argwhere(bad)[0])
+    if batch:
+        # ffhip_h264_pictures_flush: the held pictures together (one launch of all their intra wavefronts)
+        h264.pictures_flush([h[0] for h in held], [h[1] for h in held], strides, [d_refs] * len(held))
+        torch.cuda.synchronize()
+        for it, (p_, d_dst, want, dst0) in enumerate(held):
+            for pl in range(3):
+                got = d_dst[pl].cpu().numpy().view(dt)
+                bad = got != want[pl]
+                assert not bad.any(), "picture %d plane %d: %d mismatches, first at %s" % (it, pl, bad.sum(), np.argwhere(bad)[0])
+            if it:
+                p_.close()
+        pic = held[0][0]
     pic.close()
     cpu.close()
     gpu.close()
@@ -165,3 +183,10 @@ def test_decoder_driven_deblocking(depth, mb_w, mb_h, p_intra):
     pic.close()
     cpu.close()
     gpu.close()
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,pictures,p_intra", [(8, 12, 7, 5, 0.25), (10, 8, 5, 3, 0.4), (8, 20, 11, 34, 0.15)])
+def test_decoder_driven_pictures_flushed_together(depth, mb_w, mb_h, pictures, p_intra):
+    """frame threads: several pictures recorded by the reference's own macroblock loop into their own objects, then ONE
+    ffhip_h264_pictures_flush — every picture == the reference's decode (34 pictures: the intra wavefronts take two launches)"""
+    _run_picture(depth, mb_w, mb_h, 2, 300, p_intra, 1, 9100 + pictures, pictures=pictures, batch=True)
