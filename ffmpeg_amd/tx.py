@@ -12,7 +12,7 @@ from . import _lib
 
 FLOAT_FFT, FLOAT_MDCT, FLOAT_RDFT, FLOAT_DCT = 0, 1, 6, 9
 FULL_IMDCT, REAL_TO_REAL, REAL_TO_IMAGINARY = 1 << 2, 1 << 3, 1 << 4
-BITEXACT = 1 << 62   # FFHIP_TX_BITEXACT: the C reference's operation order (include/ffhip.h)
+BITEXACT = 1 << 32   # FFHIP_TX_BITEXACT: the C reference's operation order (include/ffhip.h)
 _TXFN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t)
 
 

@@ -1463,8 +1463,9 @@ typedef struct FFHipTXContext FFHipTXContext;
                                                   * libavutil/tx_template.c:1718-1827)                                                  */
 #define FFHIP_TX_REAL_TO_IMAGINARY (1ULL << 4)   /* == AV_TX_REAL_TO_IMAGINARY: ... the len/2 imaginary parts only (ff_tx_rdft_r2i, :1829); the last one
                                                   * is, as in the reference, the underlying FFT's own value.  Both forward-only (EINVAL otherwise) */
-#define FFHIP_TX_BITEXACT          (1ULL << 62)  /* libffhip's own (no AV_TX_ counterpart; av_tx_init() rejects unknown bits, so the wrapper never
-                                                  * forwards it): float FFT / MDCT contexts of 256, 512 and 1024 complex points run, by
+#define FFHIP_TX_BITEXACT          (1ULL << 32)  /* libffhip's own: a bit neither AVTXFlags (bits 0..4, libavutil/tx.h:134-166) nor the
+                                                  * codelet-private FF_TX_* flags (bits 58..63, tx_priv.h:154-159) use; av_tx_init() rejects
+                                                  * unknown bits, so the wrapper never forwards it: float FFT (256 … 16384 points) and MDCT / RDFT / DCT contexts on 256, 512 and 1024 complex points run, by
                                                   * default, a radix-16 / -8 / -4 factorisation held in registers (kernels/tx_radix.hip) whose
                                                   * results agree with the C codelets within 2^-18 of a transform's largest output — the
                                                   * position FFmpeg's own SIMD codelets are in (tests/checkasm/av_tx.c compares with an
