@@ -793,17 +793,24 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
         std::vector<int> rc((size_t)nthr, 0);
         std::vector<std::string> errs((size_t)nthr);
         std::vector<std::thread> th;
-        for (int t = 0; t < nthr; t++)
-            th.emplace_back([&, t]() {
-                for (int i = t; i < n; i += nthr) {
-                    const int r = flush_impl(pics[i], dst + 3 * i, stride, ref + 3 * i, stream_, &B[(size_t)i]);
-                    if (r < 0) {
-                        rc[(size_t)t] = r;
-                        errs[(size_t)t] = ffhip_last_error(); /* (the error text is per thread) */
-                        return;
-                    }
+        auto work = [&](int t) {
+            for (int i = t; i < n; i += nthr) {
+                const int r = flush_impl(pics[i], dst + 3 * i, stride, ref + 3 * i, stream_, &B[(size_t)i]);
+                if (r < 0) {
+                    rc[(size_t)t] = r;
+                    errs[(size_t)t] = ffhip_last_error(); /* (the error text is per thread) */
+                    return;
                 }
-            });
+            }
+        };
+        int started = 0;
+        try {
+            for (; started < nthr - 1; started++)
+                th.emplace_back(work, started);
+        } catch (...) { /* no more threads to be had: this one takes the shares that found none */
+        }
+        for (int t = started; t < nthr; t++)
+            work(t);
         for (std::thread &t : th)
             t.join();
         for (int t = 0; t < nthr; t++)
