@@ -780,6 +780,19 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
             }
     if (n == 1)
         return flush_impl(pics[0], dst, stride, ref, stream_, nullptr);
+    /* what the shared in-loop filter launches would refuse is refused before anything is queued (the stages modify dst in place): they
+     * address the pictures by table, which only the skewed-rows kernel takes — 16-byte aligned planes and strides (8 for 8-bit chroma) */
+    for (int i = 0; i < n; i++)
+        for (int pl = 0; pl < 3; pl++) {
+            if (!pics[i]->any_edge[pl])
+                continue;
+            const uintptr_t amask = pl && pics[0]->bd == 8 ? 7 : 15;
+            if (!dst[3 * i + pl] || (((uintptr_t)dst[3 * i + pl] | (uintptr_t)stride[pl]) & amask) || (pl == 2 && stride[1] != stride[2])) {
+                ffhip_set_error("ffhip_h264_pictures_flush: plane %d of picture %d carries deblocking records: plane and stride must be %d-byte "
+                                "aligned (Cb and Cr share a stride)", pl, i, (int)amask + 1);
+                return FFHIP_EINVAL;
+            }
+        }
     FFHipH264Picture *const p0 = pics[0];
     FFHipDeviceGuard dg(p0->device);
     hipStream_t stream = (hipStream_t)stream_;

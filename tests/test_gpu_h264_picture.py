@@ -239,6 +239,15 @@ def test_pictures_flush_batch(mb_w, mb_h, pictures, p_intra):
     torch.cuda.synchronize()
     for pl in range(3):
         assert np.array_equal(d_dst[pl].cpu().numpy(), want[pl])
+    # planes the shared filter launches cannot take are refused BEFORE anything is queued: nothing of any picture is touched
+    off = [torch.from_numpy(np.zeros(d0s[0][0].size + 16, np.uint8)).cuda()[4:4 + d0s[0][0].size].view(d0s[0][0].shape[0], -1)] + dsts[1][1:]
+    before = [[t.clone() for t in d] for d in (dsts[0], off)]
+    with pytest.raises(RuntimeError):
+        h264.pictures_flush(pics[:2], [dsts[0], off], strides, [d_refs] * 2)
+    torch.cuda.synchronize()
+    for d, b in zip((dsts[0], off), before):
+        for t, u in zip(d, b):
+            assert torch.equal(t, u)
     for p_ in pics:
         p_.close()
 
