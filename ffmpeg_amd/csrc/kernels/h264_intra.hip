@@ -60,11 +60,12 @@ __device__ __forceinline__ void st_dev(uint8_t *p, Q v)
  * -4 .. 7 in lanes 24..29; what lies outside the picture reads as 0 */
 template <typename Q, int PS>
 __device__ __forceinline__ Q imb_top_from_mem(const uint8_t *py, const uint8_t *pcb, const uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int my,
-                                              int mx, int lane)
+                                              int mx, int lane, int parts)
 {
     const bool has_l = mx > 0, has_r = mx + 1 < mb_w;
     Q v = 0;
-    if (lane < 8) {
+    if (lane < 8 ? !(parts & 1) : !(parts & 2)) {
+    } else if (lane < 8) {
         const int c = 4 * lane - 4;
         if ((c >= 0 || has_l) && (c < 16 || has_r))
             v = ld_dev<Q>(py + ((ptrdiff_t)my * 16 - 1) * sy + (mx * 16 + c) * PS);
@@ -101,7 +102,7 @@ static_assert(offsetof(FFHipH264IntraMB, type) == 4 && offsetof(FFHipH264IntraMB
  * always dispatched before it, whatever the other pictures do. */
 /* (two workgroups per CU where it costs no spill: 8 bits fits 256 VGPRs; above, the kernel keeps its 286) */
 template <typename PIX>
-__global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_frame(FFHipIntraPics S, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h, int *progress_all,
+__global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h, int *progress_all,
                                                           int *fail, int maxv)
 {
     /* (read once: the set is indexed at run time, and fields used in place would be re-read from the kernel arguments in the loops) */
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_fr
     const FFHipH264IntraMB *const recs = S.pic[blockIdx.y].recs;
     const int32_t *const row_start = S.pic[blockIdx.y].row_start;
     const int16_t *const coefs = S.pic[blockIdx.y].coefs;
-    int *const progress = progress_all + (size_t)blockIdx.y * (size_t)(mb_h + 1);
     typedef typename ImbQuad<PIX>::T Q;
     typedef typename ImbCoef<PIX>::T CF;
     constexpr int PS = (int)sizeof(PIX), NDW = PS == 1 ? 3 : 7, IMB_RUN_MAX = NDW * 128 /* int16 */, WMAX = 4;
@@ -120,9 +120,17 @@ __global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_fr
     __shared__ __align__(16) FFHipH264IntraMB Rbs[WMAX][2];
     __shared__ __align__(16) int16_t Cbs[WMAX][2][IMB_RUN_MAX];
     __shared__ int ldone[WMAX];
+    __shared__ uint32_t p4tab[IMB_TABS]; /* imb_tab(): the prediction rules as tables */
     extern __shared__ __align__(16) uint8_t imb_lines[];
     const int W = (int)(blockDim.x >> 6), wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    const int my = (int)blockIdx.x * W + wv;
+    /* twice the workgroups a picture's rows need: the second set reconstructs the chroma planes, a wavefront of its own (intra
+     * prediction never crosses planes) with its own counters — a step of the luma chain is a quarter shorter without them */
+    const int nwg = (mb_h + W - 1) / W;
+    const bool split = (int)gridDim.x > nwg, second = (int)blockIdx.x >= nwg;
+    const int parts = split ? (second ? 2 : 1) : 3;
+    const bool do_y = parts & 1, do_c = parts & 2;
+    const int my = ((int)blockIdx.x - (second ? nwg : 0)) * W + wv;
+    int *const progress = progress_all + ((size_t)blockIdx.y * (split ? 2 : 1) + (second ? 1 : 0)) * (size_t)(mb_h + 1);
     ImbTileT<PIX> &T = Ts[wv];
     FFHipH264IntraMB(&Rb)[2] = Rbs[wv];
     int16_t(&Cb)[2][IMB_RUN_MAX] = Cbs[wv];
@@ -133,6 +141,10 @@ __global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_fr
     const bool to_lds = wv + 1 < W && my + 1 < mb_h, from_lds = wv > 0, to_mem = !to_lds && my + 1 < mb_h, from_mem = wv == 0 && my > 0;
     if (lane == 0)
         __hip_atomic_store(&ldone[wv], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int i = (int)threadIdx.x; i < IMB_TABS; i += (int)blockDim.x)
+        p4tab[i] = imb_tab(i);
+    if (lane < 16)
+        T.zero[lane] = 0;
     __syncthreads();
     if (my >= mb_h)
         return;
@@ -145,9 +157,9 @@ __global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_fr
     if (to_lds) {
         if (kend - k < mb_w) { /* some macroblocks are inter: their bottom lines are in memory already */
             const uint8_t *ry = py + ((ptrdiff_t)my * 16 + 15) * sy;
-            for (int q = lane; q < lyq; q += 64)
+            for (int q = lane; q < lyq && do_y; q += 64)
                 mine[q] = *reinterpret_cast<const Q *>(ry + (size_t)q * 4 * PS);
-            for (int p = 0; p < 2; p++) {
+            for (int p = 0; p < 2 && do_c; p++) {
                 const uint8_t *rc = (p ? pcr : pcb) + ((ptrdiff_t)my * 8 + 7) * sc;
                 for (int q = lane; q < lcq; q += 64)
                     mine[lyq + p * lcq + q] = *reinterpret_cast<const Q *>(rc + (size_t)q * 4 * PS);
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_fr
         for (int j = 0; j < NDW; j++)
             reinterpret_cast<uint32_t *>(Cb[slot])[lane + 64 * j] = cw[j];
     };
-    auto top_from_mem = [&](int mx) __attribute__((always_inline)) -> Q { return imb_top_from_mem<Q, PS>(py, pcb, pcr, sy, sc, mb_w, my, mx, lane); };
+    auto top_from_mem = [&](int mx) __attribute__((always_inline)) -> Q { return imb_top_from_mem<Q, PS>(py, pcb, pcr, sy, sc, mb_w, my, mx, lane, parts); };
     {
         const uint32_t r0 = fetch_rec(k);
         fetch_run(r0);
@@ -243,9 +255,9 @@ __global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_fr
         if (from_lds) {
             if (lane < 8) { /* the row above: columns -4 .. 27 */
                 const int c = 4 * lane - 4;
-                if ((c >= 0 || has_l) && (c < 16 || has_r))
+                if ((c >= 0 || has_l) && (c < 16 || has_r) && do_y)
                     nb = above[mx * 4 + lane - 1];
-            } else if (lane >= 24 && lane < 30) {
+            } else if (lane >= 24 && lane < 30 && do_c) {
                 const int p = (lane - 24) / 3, q = (lane - 24) % 3 - 1;
                 if (q >= 0 || has_l)
                     nb = above[lyq + p * lcq + mx * 2 + q];
@@ -254,11 +266,13 @@ __global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_fr
             nb = have_pf ? pf : top_from_mem(mx);
         }
         if (lane >= 8 && lane < 24) { /* the column to the left */
-            if (left_here)
+            if (!do_y)
+                ;
+            else if (left_here)
                 nb = *reinterpret_cast<const Q *>(&T.y[imb_yi(lane - 8, 12)]);
             else if (has_l)
                 nb = ld_dev<Q>(ymb + (ptrdiff_t)(lane - 8) * sy - 4 * PS);
-        } else if (lane >= 30 && lane < 46) {
+        } else if (lane >= 30 && lane < 46 && do_c) {
             if (left_here)
                 nb = *reinterpret_cast<const Q *>(&T.c[(lane - 30) >> 3][imb_ci((lane - 30) & 7, 4)]);
             else if (has_l)
@@ -290,18 +304,20 @@ __global__ __launch_bounds__(256, sizeof(PIX) == 1 ? 2 : 1) void k_h264_intra_fr
                 ahead = __hip_atomic_load(&progress[my - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(Cb[cur]), maxv);
+        imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(Cb[cur]), p4tab, maxv, parts);
         /* ---- the macroblock leaves the tile: 64 + 32 quads of samples; write-through where another workgroup reads them ---- */
         {
             uint8_t *dy = ymb + (ptrdiff_t)(lane >> 2) * sy + 4 * (lane & 3) * PS;
             const Q vy = *reinterpret_cast<const Q *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]);
-            if (to_mem)
+            if (!do_y)
+                ;
+            else if (to_mem)
                 st_dev<Q>(dy, vy);
             else
                 *reinterpret_cast<Q *>(dy) = vy;
-            if (to_lds && (lane >> 2) == 15)
+            if (to_lds && (lane >> 2) == 15 && do_y)
                 mine[mx * 4 + (lane & 3)] = vy;
-            if (lane < 32) {
+            if (lane < 32 && do_c) {
                 const int p = lane >> 4, r = (lane >> 1) & 7, c = 4 * (lane & 1);
                 uint8_t *dc = cmb[p] + (ptrdiff_t)r * sc + c * PS;
                 const Q vc = *reinterpret_cast<const Q *>(&T.c[p][imb_ci(r, c)]);
@@ -371,8 +387,8 @@ int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pi
     }
     /* rows per workgroup: as many (up to 4) as the line buffers between them fit beside the static per-row tiles in 64 KB of LDS */
     const int ps_ = bd > 8 ? 2 : 1;
-    const size_t fixed = bd > 8 ? sizeof(ImbTileT<uint16_t>) * 4 + sizeof(FFHipH264IntraMB) * 8 + 4 * 2 * 7 * 256 + 64
-                                : sizeof(ImbTileT<uint8_t>) * 4 + sizeof(FFHipH264IntraMB) * 8 + 4 * 2 * 3 * 256 + 64;
+    const size_t fixed = bd > 8 ? sizeof(ImbTileT<uint16_t>) * 4 + sizeof(FFHipH264IntraMB) * 8 + 4 * 2 * 7 * 256 + 64 + IMB_TABS * 4
+                                : sizeof(ImbTileT<uint8_t>) * 4 + sizeof(FFHipH264IntraMB) * 8 + 4 * 2 * 3 * 256 + 64 + IMB_TABS * 4;
     const size_t line = (size_t)mb_w * 32 * ps_;
     int W = 4;
 #ifdef FFHIP_MEASURE
@@ -388,7 +404,16 @@ int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pi
         ffhip_set_error("ffhip_h264_intra_frame: %d macroblock rows exceed the progress pool", mb_h);
         return FFHIP_EINVAL;
     }
-    int per = FFHIP_PROGRESS_SLOT_INTS / (mb_h + 1);
+    /* the chroma planes as a wavefront of their own while the pictures of a launch leave the chip room for twice the workgroups
+     * (two per CU by registers) */
+    bool split = (size_t)npics * nwg * 2 <= 512;
+#ifdef FFHIP_MEASURE
+    if (const char *e = getenv("FFHIP_INTRA_SPLIT"))
+        split = atoi(e) != 0;
+#endif
+    if ((mb_h + 1) * 2 > FFHIP_PROGRESS_SLOT_INTS)
+        split = false;
+    int per = FFHIP_PROGRESS_SLOT_INTS / ((mb_h + 1) * (split ? 2 : 1));
     per = per > FFHIP_INTRA_PICS ? FFHIP_INTRA_PICS : per;
     for (int p0 = 0; p0 < npics; p0 += per) {
         const int n = npics - p0 < per ? npics - p0 : per;
@@ -397,14 +422,14 @@ int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pi
         for (int i = 0; i < FFHIP_INTRA_PICS; i++)
             S.pic[i] = pics[p0 + (i < n ? i : 0)];
         FFHipProgressSlot ps;
-        const int r = ffhip_progress_acquire((mb_h + 1) * n, stream, &ps);
+        const int r = ffhip_progress_acquire((mb_h + 1) * (split ? 2 : 1) * n, stream, &ps);
         if (r < 0)
             return r;
         int *const prog = ps.prog, *const fail = ps.fail;
         if (bd > 8)
-            hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, (1 << bd) - 1);
+            hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(split ? 2 * nwg : nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, (1 << bd) - 1);
         else
-            hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, 255);
+            hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(split ? 2 * nwg : nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, 255);
         const hipError_t e = hipGetLastError();
         const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
         if (e != hipSuccess) {

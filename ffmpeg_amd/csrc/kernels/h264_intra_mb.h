@@ -160,6 +160,7 @@ struct ImbTileT {
     int t8[4][64];         /* first pass of the four 8x8 inverse transforms */
     int dcq[16];           /* luma_dc_dequant_idct's results by block */
     int edge[32];          /* pred8x8l: the block's low-pass filtered edge line (25 entries) */
+    typename ImbCoef<PIX>::T zero[16]; /* sixteen zero coefficients: the block of a lane whose block was not stored (set once per tile) */
 };
 typedef ImbTileT<uint8_t> ImbTile;
 
@@ -202,6 +203,23 @@ IMB_FN const CF *imb_block(const FFHipH264IntraMB &R, const CF *run, int bit)
     return run + lead + imb_popc(below & 0xFFFFu) * lsz + imb_popc(below >> 16) * 16;
 }
 
+/* the record's fields every lane reads alike: on the device the record lives in LDS and a field read in place is a vector value —
+ * a branch on it is compiled as a masked region, its popcounts as vector code.  Taken once per macroblock into scalar registers. */
+struct ImbHead {
+    int type, cbp, flags;
+    uint32_t blocks;
+};
+template <typename CF>
+IMB_FN const CF *imb_block(const ImbHead &H, const CF *run, int bit)
+{
+    if (!((H.blocks >> bit) & 1u))
+        return nullptr;
+    const int lsz = H.type == FFHIP_H264_INTRA_8x8 ? 64 : 16;
+    const uint32_t below = H.blocks & ((1u << bit) - 1u);
+    const int lead = sizeof(CF) == 4 && (H.flags & FFHIP_H264_INTRA_LUMA_DC) ? 16 : 0;
+    return run + lead + imb_popc(below & 0xFFFFu) * lsz + imb_popc(below >> 16) * 16;
+}
+
 /* int16 entries of a macroblock's run; psz = sizeof(sample) */
 IMB_FN int imb_run_len(int type, uint32_t blocks, int psz = 1, int flags = 0)
 {
@@ -240,6 +258,24 @@ IMB_FN void imb_idct4_col(const CF *b, int b0, int x, int out[4])
 #pragma unroll
     for (int j = 0; j < 4; j++)
         r[j] = (CF)imb_bfly4(x, j == 0 ? (CF)(b0 + 32) : (b ? b[j] : 0), b ? b[j + 4] : 0, b ? b[j + 8] : 0, b ? b[j + 12] : 0);
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+        out[y] = imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
+}
+
+/* The residual of column x of a 4x4 block for EVERY lane in one straight line: b = the block's coefficients, or the tile's zero block
+ * when it has none / only its DC counts — ff_h264_idct_add on (dc, 0, 0, ...) adds (dc + 32) >> 6 everywhere, which is
+ * ff_h264_idct_dc_add (h264idct_template.c:145-160), and on all zeros adds nothing.  The one difference between the two functions is
+ * kept: idct_add stores block[0] + 32 back as dctcoef before it is read, idct_dc_add computes in int. */
+template <typename CF>
+IMB_FN void imb_resid4_col(const CF *b, int dc, bool dconly, int x, int out[4])
+{
+    int r[4];
+    r[0] = imb_bfly4(x, dconly ? dc + 32 : (int)(CF)(dc + 32), b[4], b[8], b[12]);
+    r[0] = dconly ? r[0] : (int)(CF)r[0];
+#pragma unroll
+    for (int j = 1; j < 4; j++)
+        r[j] = (CF)imb_bfly4(x, b[j], b[j + 4], b[j + 8], b[j + 12]);
 #pragma unroll
     for (int y = 0; y < 4; y++)
         out[y] = imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
@@ -360,6 +396,103 @@ IMB_FN uint32_t imb_p4_entry(int mode, int x, int y)
     }
 }
 
+/* ... and solved once more, for the TILE: entry [(tr * 12 + mode) * 16 + 4 y + x] holds where sample (x, y) of a block finds its three
+ * edge samples — offsets from the block's first sample in the tile (pitch 32), + 33, a byte each — and the kind in bits 24-25; tr: the
+ * block's top-right neighbour exists (else e[9..12] = e[8], h264_mb.c:672-689).  The DC family (kind 3) carries what its one formula
+ * (left + top + round) >> shift takes: bit 26 the left column, 27 the row above, 28 shift 3 (else 2), 29 the mid value (DC_128).
+ * The kernel keeps the table in LDS: a step of the Intra4x4 wavefront is then the same straight line of code in every lane — read
+ * three samples + the two sums, evaluate the four forms, select — where a switch over the lane's mode was nine masked branches. */
+#define IMB_P4_ON  0x80000000u   /* the lane has a sample in this step */
+#define IMB_P4_RES 0x40000000u   /* its block has a residual */
+#define IMB_P4_TAB (2 * 12 * 16)
+IMB_FN uint32_t imb_p4_tab(int idx)
+{
+    const int pos = idx & 15, mode = (idx >> 4) % 12, tr = (idx >> 4) / 12;
+    if (mode == 2 || mode >= 9) {
+        const uint32_t p = mode == 2 ? 7u : mode == 9 ? 1u : mode == 10 ? 2u : 8u;
+        return 3u << 24 | p << 26 | 33u | 33u << 8 | 33u << 16;
+    }
+    const uint32_t code = imb_p4_entry(mode, pos & 3, pos >> 2);
+    uint32_t v = (code >> 12) << 24;
+    for (int j = 0; j < 3; j++) {
+        const int k = (int)((code >> (4 * j)) & 15u);
+        const int rel = k < 4 ? (3 - k) * 32 - 1 : k == 4 ? -33 : -32 + ((k < 9 || tr) ? k - 5 : 3);
+        v |= (uint32_t)(rel + 33) << (8 * j);
+    }
+    return v;
+}
+
+/* pred8x8l the same way, in two tables.  imb_p8_edge_tab: entry [(tl * 2 + tr) * 32 + j] = where entry j of the low-pass filtered line
+ * (hp_filter8_e; every entry is (w[lo] + 2 w[j'] + w[hi] + 2) >> 2 over the raw line, the ends and the corners of an absent neighbour
+ * repeat a sample) finds its three raw samples: offsets from the block's first sample in the tile, + 33, nine bits each.  Entries the
+ * block's mode does not read are computed all the same (their samples lie inside the tile; nothing reads the result).
+ * imb_p8_tab: entry [mode * 64 + 8 y + x], mode 0..8 without DC = hp_dir_sample_e<8> solved for three indices into the filtered line
+ * (five bits each) and the kind in bits 15-16. */
+#define IMB_P8_EDGE_TAB (4 * 32)
+#define IMB_P8_TAB (9 * 64)
+IMB_FN uint32_t imb_p8_edge_tab(int idx)
+{
+    const int j = idx & 31, tr = (idx >> 5) & 1, tl = (idx >> 6) & 1;
+    if (j > 24)
+        return 33u | 33u << 9 | 33u << 18;
+    int k[3] = { j ? j - 1 : 0, j, j < 24 ? j + 1 : 24 };
+    if (j == 7 && !tl)
+        k[2] = 7;
+    if (j == 9 && !tl)
+        k[0] = 9;
+    if (j == 16 && !tr)
+        k[2] = 16;
+    if (j >= 17 && !tr)
+        k[0] = k[1] = k[2] = 16;
+    uint32_t v = 0;
+    for (int q = 0; q < 3; q++)
+        v |= (uint32_t)((k[q] < 8 ? (7 - k[q]) * 32 - 1 : k[q] - 41) + 33) << (9 * q);
+    return v;
+}
+IMB_FN uint32_t imb_p8_a3(int a, int b, int c) { return (uint32_t)(a | b << 5 | c << 10); }
+IMB_FN uint32_t imb_p8_a2(int a, int b) { return (uint32_t)(a | b << 5 | b << 10 | 1 << 15); }
+IMB_FN uint32_t imb_p8_cp(int a) { return (uint32_t)(a | a << 5 | a << 10 | 2 << 15); }
+IMB_FN uint32_t imb_p8_tab(int idx)
+{
+    const int mode = idx >> 6, x = idx & 7, y = (idx >> 3) & 7;
+    constexpr int N = 8;
+    switch (mode) {
+    case 0: return imb_p8_cp(N + 1 + x);
+    case 1: return imb_p8_cp(N - 1 - y);
+    case 3: {
+        const int i = x + y;
+        return i < 2 * N - 2 ? imb_p8_a3(N + 1 + i, N + 2 + i, N + 3 + i) : imb_p8_a3(3 * N - 1, 3 * N, 3 * N);
+    }
+    case 4: {
+        const int i = N - 1 - y + x;
+        return imb_p8_a3(i, i + 1, i + 2);
+    }
+    case 5: {
+        const int d = 2 * x - y, h = d >> 1;
+        return d < 0 ? imb_p8_a3(N + d, N + d + 1, N + d + 2) : (d & 1) ? imb_p8_a3(N + h, N + h + 1, N + h + 2) : imb_p8_a2(N + h, N + h + 1);
+    }
+    case 6: {
+        const int d = 2 * y - x, h = d >> 1;
+        return d < 0 ? imb_p8_a3(N - d - 2, N - d - 1, N - d) : (d & 1) ? imb_p8_a3(N - h, N - h - 1, N - h - 2) : imb_p8_a2(N - h, N - h - 1);
+    }
+    case 7: {
+        const int i = (y >> 1) + x;
+        return (y & 1) ? imb_p8_a3(N + 1 + i, N + 2 + i, N + 3 + i) : imb_p8_a2(N + 1 + i, N + 2 + i);
+    }
+    case 8: {
+        const int i = 2 * y + x, j = N - 1 - (i >> 1);
+        return i >= 2 * N - 2 ? imb_p8_cp(0) : i == 2 * N - 3 ? imb_p8_a3(1, 0, 0) : (i & 1) ? imb_p8_a3(j, j - 1, j - 2) : imb_p8_a2(j, j - 1);
+    }
+    default: return 0; /* DC (mode 2): not a table rule */
+    }
+}
+/* the three tables, one after the other, as the kernel keeps them in LDS */
+#define IMB_TABS (IMB_P4_TAB + IMB_P8_EDGE_TAB + IMB_P8_TAB)
+IMB_FN uint32_t imb_tab(int idx)
+{
+    return idx < IMB_P4_TAB ? imb_p4_tab(idx) : idx < IMB_P4_TAB + IMB_P8_EDGE_TAB ? imb_p8_edge_tab(idx - IMB_P4_TAB) : imb_p8_tab(idx - IMB_P4_TAB - IMB_P8_EDGE_TAB);
+}
+
 /* The same rules, split for a lane that produces the four samples (x0 .. x0 + 3, y): everything the rule reads is read ONCE, before
  * the lane writes (the compiler cannot hoist tile reads over tile writes itself: imb_pred_blk per sample re-read the whole edge — 64
  * byte reads for a DC, 64 for a plane — four times). */
@@ -374,9 +507,20 @@ struct ImbPred {
 /* per-lane state carried from one phase to the next: a register on the device, a slot per lane in the emulation */
 #define IMB_STATE(name) uint32_t name = 0
 #define IMB_AT(name, lane) name
+#define IMB_STATE_N(name, n) uint32_t name[n]
+#define IMB_AT_N(name, k, lane) name[k]
 #else
 #define IMB_STATE(name) uint32_t name[64]
 #define IMB_AT(name, lane) name[lane]
+#define IMB_STATE_N(name, n) uint32_t name[n][64]
+#define IMB_AT_N(name, k, lane) name[k][lane]
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+/* a value read ahead of the selects that use it stays read ahead: the compiler otherwise sinks a tile read into the one arm that uses
+ * it, which turns the select back into a masked branch with a second round trip inside */
+#define IMB_PIN(v) asm volatile("" : "+v"(v))
+#else
+#define IMB_PIN(v) (void)(v)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define IMB_UNIFORM(v) __builtin_amdgcn_readfirstlane(v) /* the same in every lane: keep it in a scalar register, branch without masks */
@@ -458,21 +602,26 @@ IMB_FN int imb_pred_px(int mode, const ImbPred &P, int j, int x, int y, int maxv
 /*
  * The macroblock, phase by phase.  X.run(body) runs body(lane) for the 64 lanes and synchronises the tile.
  * T holds the neighbours (unavailable ones as 0) on entry and the reconstructed macroblock on return.
+ * Luma and chroma share nothing but the record: `parts` selects the planes a caller wants (the kernel runs a picture's chroma as a
+ * wavefront of its own beside the luma one when it has the room: a macroblock step of the luma chain is a quarter shorter without it).
  */
 template <typename PIX, class X>
 IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, const typename ImbCoef<PIX>::T *coefs /* the macroblock's run */,
-                            int maxv = 255 /* (1 << bit_depth) - 1 */)
+                            const uint32_t *p4tab /* imb_tab(0 .. IMB_TABS - 1) */, int maxv = 255 /* (1 << bit_depth) - 1 */,
+                            int parts = 3 /* 1: the luma samples, 2: the two chroma planes; the same in every lane */)
 {
     typedef typename ImbCoef<PIX>::T CF;
     const int mid = (maxv + 1) >> 1;
-    if (R.type == FFHIP_H264_INTRA_PCM) {
+    const ImbHead H = { IMB_UNIFORM((int)R.type), IMB_UNIFORM((int)R.cbp), IMB_UNIFORM((int)R.flags), (uint32_t)IMB_UNIFORM((int)R.blocks) };
+    if (H.type == FFHIP_H264_INTRA_PCM) {
         /* the samples as they stand in the bitstream: 256 luma, 64 Cb, 64 Cr (h264_mb_template.c:98-150; above 8 bits the host side
          * has unpacked the bit_depth-bit fields into uint16_t) */
         const PIX *pcm = reinterpret_cast<const PIX *>(coefs);
         x.run([&](int lane) IMB_INL {
-            for (int j = 0; j < 4; j++)
-                T.y[imb_yi(lane >> 2, 4 * (lane & 3) + j)] = pcm[16 * (lane >> 2) + 4 * (lane & 3) + j];
-            if (lane < 32)
+            if (parts & 1)
+                for (int j = 0; j < 4; j++)
+                    T.y[imb_yi(lane >> 2, 4 * (lane & 3) + j)] = pcm[16 * (lane >> 2) + 4 * (lane & 3) + j];
+            if (lane < 32 && (parts & 2))
                 for (int j = 0; j < 4; j++)
                     T.c[lane >> 4][imb_ci((lane >> 1) & 7, 4 * (lane & 1) + j)] = pcm[256 + 64 * (lane >> 4) + 4 * (lane & 15) + j];
         });
@@ -482,54 +631,57 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
      *      Intra16x16 also dequantises its 16 luma DCs here (lanes 32..47), the 8x8 transform runs its first pass (lanes 32..63) ---- */
     x.run([&](int lane) IMB_INL {
         if (lane < 32) {
+            if (!(parts & 2))
+                return;
             /* lane = column (lane & 3) of chroma block k = (lane >> 2) & 3 of plane p: everything is read before the column is written */
             const int p = lane >> 4, k = (lane >> 2) & 3, xc = 4 * (k & 1) + (lane & 3), y0 = 4 * (k >> 1);
             const PIX *tc = T.c[p];
             auto TOP = [&](int i) { return (int)tc[imb_ci(-1, i)]; };
             auto LEFT = [&](int i) { return (int)tc[imb_ci(i, -1)]; };
+            /* the residual in one straight line for every lane (imb_resid4_col): a lane whose block is not in the run works on the
+             * tile's zero block — masked branches per case cost more than the arithmetic they skip */
             int dc = 0;
-            bool full = false, dconly = false;
-            const CF *b = nullptr;
-            if (R.cbp & 0x30) {
-                b = imb_block(R, coefs, 16 + 4 * p + k);
-                dc = b ? b[0] : 0;
-                if (R.flags & (FFHIP_H264_INTRA_CB_DC << p)) {
-                    /* chroma_dc_dequant_idct (h264idct_template.c:323-345) on the four DCs of the plane */
-                    int d4[4];
+            bool dconly = false;
+            const CF *b = T.zero;
+            if (H.cbp & 0x30) {
+                /* the plane's blocks follow the luma blocks in the run (imb_block, with the luma part counted once in scalar registers) */
+                const uint32_t cb = H.blocks >> 16;
+                const CF *c0 = coefs + (sizeof(CF) == 4 && (H.flags & FFHIP_H264_INTRA_LUMA_DC) ? 16 : 0) +
+                               imb_popc(H.blocks & 0xFFFFu) * (H.type == FFHIP_H264_INTRA_8x8 ? 64 : 16);
+                /* chroma_dc_dequant_idct (h264idct_template.c:323-345) on the four DCs of the plane; taken when the plane has a DC block */
+                int d4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const CF *bq = imb_block(R, coefs, 16 + 4 * p + q);
-                        d4[q] = bq ? bq[0] : 0;
-                    }
-                    const uint32_t qm = (uint32_t)R.qmul[1 + p];
-                    uint32_t a = (uint32_t)d4[0], bb = (uint32_t)d4[1], c = (uint32_t)d4[2], d = (uint32_t)d4[3];
-                    const uint32_t e = a - bb;
-                    a = a + bb; bb = c - d; c = c + d;
-                    const uint32_t v = k == 0 ? a + c : k == 1 ? e + bb : k == 2 ? a - c : e - bb;
-                    dc = (CF)((int)(v * qm) >> 7);
+                for (int q = 0; q < 4; q++) {
+                    const int bit = 4 * p + q;
+                    const CF *bq = ((cb >> bit) & 1u) ? c0 + 16 * imb_popc(cb & ((1u << bit) - 1u)) : T.zero;
+                    d4[q] = bq[0];
                 }
-                full = R.nnz[16 + 4 * p + k] != 0;
+                const uint32_t qm = (uint32_t)R.qmul[1 + p];
+                uint32_t a = (uint32_t)d4[0], bb = (uint32_t)d4[1], c = (uint32_t)d4[2], d = (uint32_t)d4[3];
+                const uint32_t e = a - bb;
+                a = a + bb; bb = c - d; c = c + d;
+                const uint32_t v = k == 0 ? a + c : k == 1 ? e + bb : k == 2 ? a - c : e - bb;
+                const int own = k == 0 ? d4[0] : k == 1 ? d4[1] : k == 2 ? d4[2] : d4[3];
+                dc = ((H.flags >> p) & FFHIP_H264_INTRA_CB_DC) ? (int)(CF)((int)(v * qm) >> 7) : own;
+                const int bit = 4 * p + k;
+                const bool full = R.nnz[16 + bit] != 0 && ((cb >> bit) & 1u);
+                b = full ? c0 + 16 * imb_popc(cb & ((1u << bit) - 1u)) : T.zero;
                 dconly = !full && dc != 0;
             }
             const int cmode = IMB_UNIFORM((int)R.chroma_pred);
             const ImbPred P = imb_pred_quad<8, true>(cmode, xc, y0, TOP, LEFT, mid);
-            int res[4] = { 0, 0, 0, 0 };
-            if (full)
-                imb_idct4_col(b, dc, lane & 3, res);
-            else if (dconly)
-                res[0] = res[1] = res[2] = res[3] = (dc + 32) >> 6;
+            int res[4];
+            imb_resid4_col(b, dc, dconly, lane & 3, res);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int v = imb_pred_px<PIX>(cmode, P, j, xc, y0 + j, maxv);
-                if (full || dconly)
-                    v = imb_clip<PIX>(v + res[j], maxv);
-                T.c[p][imb_ci(y0 + j, xc)] = (PIX)v;
-            }
-        } else if (R.type == FFHIP_H264_INTRA_8x8) {
+            for (int j = 0; j < 4; j++)
+                T.c[p][imb_ci(y0 + j, xc)] = (PIX)imb_clip<PIX>(imb_pred_px<PIX>(cmode, P, j, xc, y0 + j, maxv) + res[j], maxv);
+        } else if (!(parts & 1)) {
+            return;
+        } else if (H.type == FFHIP_H264_INTRA_8x8) {
             /* first pass of the four 8x8 inverse transforms (they depend on the coefficients alone): lane 32 + 8 q + j = transform j
              * of block 4 q, working on block[j + 8 k], results stored as int16 */
             const int q = (lane - 32) >> 3, j = lane & 7, nnz = R.nnz[4 * q];
-            const CF *b = nnz ? imb_block(R, coefs, 4 * q) : nullptr;
+            const CF *b = nnz ? imb_block(H, coefs, 4 * q) : nullptr;
             if (b && !(nnz == 1 && b[0])) {
                 int in[8];
                 uint32_t out[8];
@@ -543,7 +695,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
                 for (int k = 0; k < 8; k++)
                     T.t8[q][j + 8 * k] = (CF)out[k];
             }
-        } else if (lane < 48 && R.type == FFHIP_H264_INTRA_16x16 && (R.flags & FFHIP_H264_INTRA_LUMA_DC)) {
+        } else if (lane < 48 && H.type == FFHIP_H264_INTRA_16x16 && (H.flags & FFHIP_H264_INTRA_LUMA_DC)) {
             /* luma_dc_dequant_idct (h264idct_template.c:259-293): lane 32 + o computes output o of the 4x4 Hadamard */
             const int o = lane - 32, i = o & 3, w = o >> 2; /* second-pass column i, output w of { z0+z3, z1+z2, z1-z2, z0-z3 } */
             int t[4];
@@ -560,38 +712,34 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             const uint32_t v = w == 0 ? z0 + z3 : w == 1 ? z1 + z2 : w == 2 ? z1 - z2 : z0 - z3;
             /* output[16 * {0, 1, 4, 5}[w] + x_offset[i]], x_offset = {0, 32, 128, 160}: as a block number */
             const int blk = (w == 0 ? 0 : w == 1 ? 1 : w == 2 ? 4 : 5) + (i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 8 : 10);
-            T.dcq[blk] = (CF)((int)(v * (uint32_t)R.qmul[0] + 128) >> 8);
+            T.dcq[blk] = (CF)((int)(v * (uint32_t)IMB_UNIFORM(R.qmul[0]) + 128) >> 8);
         }
     });
 
-    if (R.type == FFHIP_H264_INTRA_16x16) {
+    if (!(parts & 1))
+        return;
+    if (H.type == FFHIP_H264_INTRA_16x16) {
         /* pred16x16 + idct_add16intra (h264idct_template.c:191-200): lane = column (lane & 3) of block (lane >> 2) */
         x.run([&](int lane) IMB_INL {
             const int i = lane >> 2, y0 = imb_by(i), xc = imb_bx(i) + (lane & 3);
             auto TOP = [&](int k) { return (int)T.y[imb_yi(-1, k)]; };
             auto LEFT = [&](int k) { return (int)T.y[imb_yi(k, -1)]; };
-            const CF *b = imb_block(R, coefs, i);
-            const int dc = (R.flags & FFHIP_H264_INTRA_LUMA_DC) ? T.dcq[i] : (b ? b[0] : 0);
+            const CF *bp = imb_block(H, coefs, i);
+            const CF *bs = bp ? bp : T.zero;
+            const int dc = (H.flags & FFHIP_H264_INTRA_LUMA_DC) ? T.dcq[i] : (int)bs[0];
             const bool full = R.nnz[i] != 0, dconly = !full && dc != 0;
             const int lmode = IMB_UNIFORM((int)R.pred16);
             const ImbPred P = imb_pred_quad<16, true>(lmode, xc, y0, TOP, LEFT, mid);
-            int res[4] = { 0, 0, 0, 0 };
-            if (full)
-                imb_idct4_col(b, dc, lane & 3, res);
-            else if (dconly)
-                res[0] = res[1] = res[2] = res[3] = (dc + 32) >> 6;
+            int res[4];
+            imb_resid4_col(full ? bs : T.zero, dc, dconly, lane & 3, res);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int v = imb_pred_px<PIX>(lmode, P, j, xc, y0 + j, maxv);
-                if (full || dconly)
-                    v = imb_clip<PIX>(v + res[j], maxv);
-                T.y[imb_yi(y0 + j, xc)] = (PIX)v;
-            }
+            for (int j = 0; j < 4; j++)
+                T.y[imb_yi(y0 + j, xc)] = (PIX)imb_clip<PIX>(imb_pred_px<PIX>(lmode, P, j, xc, y0 + j, maxv) + res[j], maxv);
         });
         return;
     }
 
-    if (R.type == FFHIP_H264_INTRA_4x4) {
+    if (H.type == FFHIP_H264_INTRA_4x4) {
         /* A 4x4 block reads its left, upper-left, upper and — where the decoding order has it — upper-right neighbours, so the blocks
          * on an anti-diagonal x + 2 y = t of the 4 x 4 grid are independent: ten steps of one or two blocks instead of sixteen
          * (results cannot differ: each block sees exactly the samples it sees in block order).  A step is ONE phase: a lane reads
@@ -600,81 +748,60 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
         /* The residuals do not depend on the prediction: all sixteen blocks' in ONE phase ahead of the ten steps, lane = column x of
          * block i (four first-pass butterflies serve the column's four samples: 8 butterflies per lane instead of 5 per sample inside a
          * step), parked in t8 (unused by this macroblock type) as res[16 i + 4 y + x]. */
-        /* ... and a lane of the steps collects what its ten steps need from the record — mode, "has a residual", "top-right is
-         * there" — one byte per step in three registers: the record lives in LDS and a fence ends every step, so read in place it was a
-         * dependent round trip at the head of each step.  (The host emulation runs the lanes one after another: a slot per lane.) */
-        IMB_STATE(inf0);
-        IMB_STATE(inf1);
-        IMB_STATE(inf2);
+        /* ... and a lane of the steps collects what its ten steps need: the table entry of its sample under the block's mode
+         * (imb_p4_tab) with "has a residual" — a register per step: the record lives in LDS and a fence ends every step, so read in
+         * place it was a dependent round trip at the head of each step, and the mode a masked branch per rule (measured, round 4:
+         * 1,630 cycles per step, of which the tile's round trip is a tenth).  (The host emulation runs the lanes one after another:
+         * a slot per lane.) */
+        IMB_STATE_N(inf, 10);
         x.run([&](int lane) IMB_INL {
-            uint32_t m0 = 0, m1 = 0, m2 = 0;
-            if (lane < 32) {
 #pragma unroll
-                for (int t = 0; t < 10; t++) {
-                    const int y0 = t <= 3 ? 0 : (t - 2) >> 1, y4 = y0 + (lane >> 4), x4 = t - 2 * y4;
-                    const bool on = y4 <= 3 && x4 >= 0 && x4 <= 3;
-                    const int bi = on ? (x4 & 1) | (y4 & 1) << 1 | (x4 >> 1) << 2 | (y4 >> 1) << 3 : 0;
-                    const uint32_t v = (uint32_t)R.pred4[bi] | (R.nnz[bi] ? 16u : 0u) | (((R.topright_avail << bi) & 0x8000) ? 32u : 0u) | 64u;
-                    const uint32_t sh = (on ? v : 0u) << (8 * (t & 3));
-                    m0 |= t < 4 ? sh : 0u;
-                    m1 |= t >= 4 && t < 8 ? sh : 0u;
-                    m2 |= t >= 8 ? sh : 0u;
-                }
+            for (int t = 0; t < 10; t++) {
+                const int y0 = t <= 3 ? 0 : (t - 2) >> 1, y4 = y0 + ((lane >> 4) & 1), x4 = t - 2 * y4;
+                const bool on = lane < 32 && y4 <= 3 && x4 >= 0 && x4 <= 3;
+                const int bi = on ? (x4 & 1) | (y4 & 1) << 1 | (x4 >> 1) << 2 | (y4 >> 1) << 3 : 0;
+                const int mode = R.pred4[bi] < 11 ? R.pred4[bi] : 11, tr = ((R.topright_avail << bi) & 0x8000) ? 12 : 0;
+                const uint32_t e = p4tab[(tr + mode) * 16 + (lane & 15)] | (R.nnz[bi] ? IMB_P4_RES : 0u) | IMB_P4_ON;
+                IMB_AT_N(inf, t, lane) = on ? e : 0u;
             }
-            IMB_AT(inf0, lane) = m0;
-            IMB_AT(inf1, lane) = m1;
-            IMB_AT(inf2, lane) = m2;
             const int i = lane >> 2, xx = lane & 3, nnz = R.nnz[i];
-            if (!nnz)
-                return;
             int *res = &T.t8[0][0] + 16 * i;
-            const CF *b = imb_block(R, coefs, i); /* travels whenever nnz != 0 */
-            const int dc = b[0];
-            if (nnz == 1 && dc) {
-#pragma unroll
-                for (int y = 0; y < 4; y++)
-                    res[4 * y + xx] = (dc + 32) >> 6;
-                return;
-            }
-            int r[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                r[j] = (CF)imb_bfly4(xx, j == 0 ? (CF)(dc + 32) : b[j], b[j + 4], b[j + 8], b[j + 12]);
+            const CF *bp = imb_block(H, coefs, i); /* travels whenever nnz != 0 */
+            const CF *bs = nnz && bp ? bp : T.zero;
+            const int dc = bs[0];
+            const bool dconly = nnz == 1 && dc;
+            int out[4];
+            imb_resid4_col(dconly ? T.zero : bs, dc, dconly, xx, out);
 #pragma unroll
             for (int y = 0; y < 4; y++)
-                res[4 * y + xx] = imb_bfly4(y, r[0], r[1], r[2], r[3]) >> 6;
+                res[4 * y + xx] = out[y];
         });
+#pragma unroll
         for (int t = 0; t < 10; t++) {
             x.run([&](int lane) IMB_INL {
-                if (lane >= 32)
+                const uint32_t ent = IMB_AT_N(inf, t, lane);
+                if (!(ent & IMB_P4_ON))
                     return;
-                const uint32_t i0 = IMB_AT(inf0, lane), i1 = IMB_AT(inf1, lane), i2 = IMB_AT(inf2, lane); /* values, then the choice */
-                const uint32_t info = ((t < 4 ? i0 : t < 8 ? i1 : i2) >> (8 * (t & 3))) & 0xFFu;
-                if (!(info & 64u))
-                    return;
-                const int y0 = t <= 3 ? 0 : (t - 2) >> 1, y4 = y0 + (lane >> 4), x4 = t - 2 * y4;
+                const int y0 = t <= 3 ? 0 : (t - 2) >> 1, y4 = y0 + ((lane >> 4) & 1), x4 = t - 2 * y4;
                 const int i = (x4 & 1) | (y4 & 1) << 1 | (x4 >> 1) << 2 | (y4 >> 1) << 3;
-                const int bx = 4 * x4, by = 4 * y4, mode = (int)(info & 15u);
-                /* top-right: the samples themselves or, when the block there is not decoded yet / outside, the last sample of the
-                 * row above four times (hl_decode_mb_predict_luma, h264_mb.c:672-689) */
-                const bool tr_avail = (info & 32u) != 0;
-                auto e = [&](int k) {
-                    const int r = k < 4 ? by + 3 - k : by - 1, c = k < 4 ? bx - 1 : (k < 9 || tr_avail) ? bx + k - 5 : bx + 3;
-                    return (int)T.y[imb_yi(r, c)];
-                };
                 const int xx = lane & 3, yy = (lane >> 2) & 3;
-                int v;
-                if (mode == 2 || mode >= 9) {
-                    v = hp_dir_dc_e<4>(mode, e, mid);
-                } else { /* every directional rule is (w0 e[i0] + w1 e[i1] + w2 e[i2] + 2) >> 2: imb_p4_entry() */
-                    const uint32_t code = imb_p4_entry(mode, xx, yy);
-                    const int a = e((int)(code & 15u)), b = e((int)((code >> 4) & 15u)), c = e((int)((code >> 8) & 15u));
-                    const int kind = (int)(code >> 12);
-                    v = kind == 0 ? (a + 2 * b + c + 2) >> 2 : kind == 1 ? (a + b + 1) >> 1 : a;
-                }
-                if (info & 16u)
-                    v = imb_clip<PIX>(v + (&T.t8[0][0])[16 * i + 4 * yy + xx], maxv);
-                T.y[imb_yi(by + yy, bx + xx)] = (PIX)v;
+                PIX *o = &T.y[imb_yi(4 * y4, 4 * x4)];
+                /* everything any form reads, unconditionally: one round trip to the tile */
+                int a = o[(int)(ent & 255u) - 33], b = o[(int)((ent >> 8) & 255u) - 33], c = o[(int)((ent >> 16) & 255u) - 33];
+                const int sl = (int)o[-1] + (int)o[31] + (int)o[63] + (int)o[95], st = (int)o[-32] + (int)o[-31] + (int)o[-30] + (int)o[-29];
+                int res = (&T.t8[0][0])[16 * i + 4 * yy + xx];
+                IMB_PIN(a);
+                IMB_PIN(b);
+                IMB_PIN(c);
+                IMB_PIN(res);
+                const uint32_t kind = (ent >> 24) & 3u;
+                const int dir = kind == 0 ? (a + 2 * b + c + 2) >> 2 : kind == 1 ? (a + b + 1) >> 1 : a;
+                const int sh = (ent >> 28) & 1u ? 3 : 2;
+                const int dcv = (((ent >> 26) & 1u ? sl : 0) + ((ent >> 27) & 1u ? st : 0) + ((ent >> 29) & 1u ? 4 * mid : 1 << (sh - 1))) >> sh;
+                int v = kind == 3 ? dcv : dir;
+                const int vr = imb_clip<PIX>(v + res, maxv);
+                v = (ent & IMB_P4_RES) ? vr : v;
+                o[32 * yy + xx] = (PIX)v;
             });
         }
         return;
@@ -688,7 +815,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
         if (lane >= 32)
             return;
         const int q = lane >> 3, xx = lane & 7, nnz = R.nnz[4 * q];
-        const CF *b = nnz ? imb_block(R, coefs, 4 * q) : nullptr;
+        const CF *b = nnz ? imb_block(H, coefs, 4 * q) : nullptr;
         if (!b || (nnz == 1 && b[0]))
             return;
         int in[8];
@@ -702,24 +829,33 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             T.t8[q][8 * xx + k] = (int)out[k] >> 6;
     });
     for (int i = 0; i < 16; i += 4) {
-        const int bx = imb_bx(i), by = imb_by(i), mode = R.pred4[i], nnz = R.nnz[i];
-        const bool tl = (R.topleft_avail << i) & 0x8000, tr = (R.topright_avail << i) & 0x4000;
-        const unsigned need = hp_need(mode);
-        const CF *b = nnz ? imb_block(R, coefs, i) : nullptr;
-        const int dc = b ? b[0] : 0;
+        const int bx = imb_bx(i), by = imb_by(i), mode = IMB_UNIFORM((int)R.pred4[i]), nnz = IMB_UNIFORM((int)R.nnz[i]);
+        const bool tl = (IMB_UNIFORM((int)R.topleft_avail) << i) & 0x8000, tr = (IMB_UNIFORM((int)R.topright_avail) << i) & 0x4000;
+        const CF *b = nnz ? imb_block(H, coefs, i) : nullptr;
+        const int dc = b ? IMB_UNIFORM((int)b[0]) : 0;
         const bool dconly = nnz == 1 && dc, full = nnz && !dconly;
         /* the filtered line once per block (25 lanes), then the rule reads it: evaluated where it was read, a DC cost every lane 16
          * filtered entries of three raw reads each */
         x.run([&](int lane) IMB_INL {
             if (lane >= 25)
                 return;
-            auto w = [&](int k) { return (int)T.y[k < 8 ? imb_yi(by + 7 - k, bx - 1) : imb_yi(by - 1, bx + k - 9)]; };
-            T.edge[lane] = hp_filter8_e(w, lane, need, tl, tr);
+            const uint32_t ent = p4tab[IMB_P4_TAB + (tl ? 64 : 0) + (tr ? 32 : 0) + lane];
+            const PIX *o = &T.y[imb_yi(by, bx)];
+            const int a = o[(int)(ent & 511u) - 33], bq = o[(int)((ent >> 9) & 511u) - 33], c = o[(int)((ent >> 18) & 511u) - 33];
+            T.edge[lane] = (a + 2 * bq + c + 2) >> 2;
         });
         x.run([&](int lane) IMB_INL {
             auto ef = [&](int k) { return T.edge[k]; };
             const int xx = lane & 7, yy = lane >> 3;
-            int v = hp_dir_sample_e<8>(mode, ef, xx, yy, hp_dir_dc_e<8>(mode, ef, mid));
+            int v;
+            if (mode == 2 || mode >= 9) {
+                v = hp_dir_dc_e<8>(mode, ef, mid);
+            } else {
+                const uint32_t ent = p4tab[IMB_P4_TAB + IMB_P8_EDGE_TAB + 64 * mode + lane];
+                const int a = T.edge[ent & 31u], bq = T.edge[(ent >> 5) & 31u], c = T.edge[(ent >> 10) & 31u];
+                const uint32_t kind = ent >> 15;
+                v = kind == 0 ? (a + 2 * bq + c + 2) >> 2 : kind == 1 ? (a + bq + 1) >> 1 : a;
+            }
             if (full) {
                 /* transform xx worked on block[8 xx + k], output yy goes to dst[xx + yy * stride] */
                 v = imb_clip<PIX>(v + T.t8[i >> 2][8 * xx + yy], maxv);

@@ -22,6 +22,9 @@ struct EmulWave {
 };
 } // namespace
 
+static int g_split; /* the kernel's two-wavefront form: the whole picture's luma, then the whole picture's chroma */
+extern "C" void ffemul_h264_intra_set_split(int on) { g_split = on; }
+
 template <typename PIX>
 static int intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraMB *recs,
                        const int32_t *row_start, const int16_t *coefs, int maxv)
@@ -29,7 +32,11 @@ static int intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, pt
     typedef typename ImbCoef<PIX>::T CF;
     constexpr int PS = (int)sizeof(PIX), QB = 4 * PS; /* the kernel moves four samples per lane */
     EmulWave X;
-    for (int my = 0; my < mb_h; my++)
+    static uint32_t p4tab[IMB_TABS]; /* the kernel's copy lives in LDS */
+    for (int i = 0; i < IMB_TABS; i++)
+        p4tab[i] = imb_tab(i);
+    for (int pass = 0; pass < (g_split ? 2 : 1); pass++)
+    for (int my = 0, parts = g_split ? 1 + pass : 3; my < mb_h; my++)
         for (int k = row_start[my]; k < row_start[my + 1]; k++) {
             const FFHipH264IntraMB &R = recs[k];
             const int mx = R.mb_x;
@@ -37,6 +44,7 @@ static int intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, pt
                 return -1;
             ImbTileT<PIX> T;
             memset(&T, 0xA5, sizeof(T)); /* whatever the phases do not write first must not matter */
+            memset(T.zero, 0, sizeof(T.zero)); /* (the kernel: once per wave) */
             uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16 * PS;
             uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8 * PS, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 * PS };
             const bool has_l = mx > 0, has_t = my > 0, has_r = mx + 1 < mb_w;
@@ -66,10 +74,10 @@ static int intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, pt
                     memcpy(&T.c[p][imb_ci(r, -4)], &v, QB);
                 }
             }
-            imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(coefs + R.coef), maxv);
-            for (int r = 0; r < 16; r++)
+            imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(coefs + R.coef), p4tab, maxv, parts);
+            for (int r = 0; r < 16 && (parts & 1); r++)
                 memcpy(ymb + (ptrdiff_t)r * sy, &T.y[imb_yi(r, 0)], 16 * PS);
-            for (int p = 0; p < 2; p++)
+            for (int p = 0; p < 2 && (parts & 2); p++)
                 for (int r = 0; r < 8; r++)
                     memcpy(cmb[p] + (ptrdiff_t)r * sc, &T.c[p][imb_ci(r, 0)], 8 * PS);
         }

@@ -64,12 +64,13 @@ def _pack(L, d, coefs, ncoef):
     return rec, mb, n.value
 
 
-def _decode_picture(rng, mb_w, mb_h, frac, pad):
+def _decode_picture(rng, mb_w, mb_h, frac, pad, split=0):
     """a picture's intra macroblocks through oracle (planes `want`) and through pack + emulation (planes `got`)"""
     from ffmpeg_amd import _lib
     L = _lib.lib()
     L.ffhip_h264_intra_pack.restype = C.c_int
     E = C.CDLL(EMUL_SO)
+    E.ffemul_h264_intra_set_split(split)  # the kernel's two wavefronts: all luma, then all chroma
     O = ffi.oracle()
     planes, st = _planes(rng, mb_w, mb_h, pad)
     want = [p.copy() for p in planes]
@@ -96,13 +97,14 @@ def _decode_picture(rng, mb_w, mb_h, frac, pad):
     return planes, want, got, len(recs)
 
 
-@pytest.mark.parametrize("mb_w,mb_h,frac,pad", [(1, 1, 1.0, 0), (2, 3, 1.0, 4), (8, 6, 1.0, 0), (9, 5, .35, 12), (20, 12, 1.0, 0)])
-def test_kernel_logic_emulated_on_cpu_equals_oracle(mb_w, mb_h, frac, pad):
+@pytest.mark.parametrize("mb_w,mb_h,frac,pad,split", [(1, 1, 1.0, 0, 0), (2, 3, 1.0, 4, 0), (8, 6, 1.0, 0, 0), (9, 5, .35, 12, 0), (20, 12, 1.0, 0, 0),
+                                                      (8, 6, 1.0, 0, 1), (9, 5, .35, 12, 1)])
+def test_kernel_logic_emulated_on_cpu_equals_oracle(mb_w, mb_h, frac, pad, split):
     if not os.path.exists(EMUL_SO):
         pytest.skip("oracle/libffemul.so not built")
     rng = np.random.default_rng(mb_w * 100 + mb_h)
     for it in range(6 if mb_w * mb_h < 100 else 2):
-        planes, want, got, n = _decode_picture(rng, mb_w, mb_h, frac, pad)
+        planes, want, got, n = _decode_picture(rng, mb_w, mb_h, frac, pad, split)
         for pl in range(3):
             bad = np.argwhere(got[pl] != want[pl])
             assert not len(bad), "picture %d plane %d: %d mismatches, first at row %d column %d (%d intra macroblocks)" % (
@@ -142,6 +144,7 @@ def test_kernel_logic_emulated_on_cpu_equals_reference_above_8_bits(depth, mb_w,
     from ffmpeg_amd import _lib
     L, E, R = _lib.lib(), C.CDLL(EMUL_SO), ffi.ref()
     L.ffhip_h264_intra_pack_hbd.restype = C.c_int
+    E.ffemul_h264_intra_set_split(int(depth == 9 or depth == 12))  # two of the cases in the kernel's two-wavefront form
     rng = np.random.default_rng(depth * 1000 + mb_w * 100 + mb_h)
     u8 = C.POINTER(C.c_uint8)
     for it in range(4 if mb_w * mb_h < 100 else 2):
