@@ -148,10 +148,10 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
     __syncthreads();
     if (my >= mb_h)
         return;
-    int k = row_start[my];
-    const int kend = row_start[my + 1];
+    int k = __builtin_amdgcn_readfirstlane(row_start[my]);
+    const int kend = __builtin_amdgcn_readfirstlane(row_start[my + 1]);
     /* nothing of this row is pending left of its first intra macroblock */
-    const int first = k < kend ? (int)recs[k].mb_x : mb_w;
+    const int first = __builtin_amdgcn_readfirstlane(k < kend ? (int)recs[k].mb_x : mb_w);
     if (to_mem && lane == 0)
         __hip_atomic_store(&progress[my], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (to_lds) {
@@ -171,8 +171,10 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
     }
     if (k >= kend)
         return;
-    auto fetch_rec = [&](int idx) __attribute__((always_inline)) { /* dword `lane` of record idx */
-        return lane < IMB_REC_DW && idx < kend ? reinterpret_cast<const uint32_t *>(recs + idx)[lane] : 0u;
+    /* dword `lane` of record idx; past the row's last record: of that one again, past the record's last dword: that one again (an
+     * unconditional load: a default value written under a mask makes the compiler wait for every outstanding memory operation first) */
+    auto fetch_rec = [&](int idx) __attribute__((always_inline)) {
+        return reinterpret_cast<const uint32_t *>(recs + (idx < kend ? idx : kend - 1))[lane < IMB_REC_DW ? lane : IMB_REC_DW - 1];
     };
     uint32_t cw[NDW];
     auto fetch_run = [&](uint32_t rec_dw) __attribute__((always_inline)) { /* the run of the record whose dwords the lanes hold: NDW dwords per lane */
@@ -201,12 +203,16 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
     int known = 0;       /* last value seen of the counter of the row above */
     int ahead = 0;       /* from_mem: that counter, read a step ahead (lane 0) */
     int prev_mx = -2;    /* the macroblock this wave reconstructed last: its right columns are still in the tile */
+    int mx = first;      /* this record's mb_x, out of the record prefetched a step earlier: a scalar (read from the parked record it is a
+                          * vector value, and the waits below loops under execution masks) */
     Q pf = 0;            /* from_mem: the next record's top neighbours, read a step ahead */
     bool have_pf = false;
+    /* the record after this one, fetched a whole step before it is looked at: its run's prefetch reads the run's place and size out of
+     * it in the middle of the step, and a record fetched at the top of the same step was an L2 round trip late there */
+    uint32_t nrec = fetch_rec(k + 1);
     ImbWave X{ lane };
     for (int cur = 0; k < kend; k++, cur ^= 1) {
         const FFHipH264IntraMB &R = Rb[cur];
-        const int mx = R.mb_x;
         if (to_mem) {
             /* the previous macroblock's write-through stores left a whole step ago: acknowledged, the counter moves */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -214,7 +220,6 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
             if (lane == 0)
                 __hip_atomic_store(&progress[my], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const uint32_t nrec = fetch_rec(k + 1);
         /* ---- the row above has finished macroblock mx + 1 ---- */
         const int want = min(mx + 2, mb_w);
         if (from_lds) {
@@ -249,7 +254,10 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
         }
         /* ---- neighbours into the tile, one quad per lane; what lies outside the picture reads as 0 ---- */
         uint8_t *ymb = py + (ptrdiff_t)my * 16 * sy + mx * 16 * PS;
-        uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 8 * sc + mx * 8 * PS, pcr + (ptrdiff_t)my * 8 * sc + mx * 8 * PS };
+        /* (Cr as an offset from Cb: a pointer picked per lane out of two loses its address space — flat instead of global accesses, and
+         * a flat access also counts as an LDS operation the next LDS wait stalls for) */
+        uint8_t *const cmb0 = pcb + (ptrdiff_t)my * 8 * sc + mx * 8 * PS;
+        const ptrdiff_t cr_off = pcr - pcb;
         const bool has_l = mx > 0, has_r = mx + 1 < mb_w, left_here = prev_mx == mx - 1;
         Q nb = 0;
         if (from_lds) {
@@ -276,11 +284,12 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
             if (left_here)
                 nb = *reinterpret_cast<const Q *>(&T.c[(lane - 30) >> 3][imb_ci((lane - 30) & 7, 4)]);
             else if (has_l)
-                nb = ld_dev<Q>(cmb[(lane - 30) >> 3] + (ptrdiff_t)((lane - 30) & 7) * sc - 4 * PS);
+                nb = ld_dev<Q>(cmb0 + (((lane - 30) >> 3) ? cr_off : 0) + (ptrdiff_t)((lane - 30) & 7) * sc - 4 * PS);
         }
-        /* the next macroblock's coefficients leave now and land while this one is reconstructed */
-        if (k + 1 < kend)
-            fetch_run(nrec);
+        /* the next macroblock's coefficients leave now and land while this one is reconstructed (after the row's last record: that
+         * record's again — every step issues and consumes the same loads, so nothing is left pending on a path of its own) */
+        fetch_run(nrec);
+        const uint32_t nrec2 = fetch_rec(k + 2);
         if (lane < 8) {
             *reinterpret_cast<Q *>(&T.y[imb_yi(-1, 4 * lane - 4)]) = nb;
         } else if (lane < 24) { /* + zeros right of the macroblock (a top-right block that does not exist) */
@@ -294,7 +303,10 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
             *reinterpret_cast<Q *>(&T.c[(lane - 30) >> 3][imb_ci((lane - 30) & 7, -4)]) = nb;
         }
         imb_wave_sync();
-        const int next = k + 1 < kend ? (int)(__builtin_amdgcn_readlane(nrec, 0) & 0xFFFFu) : mb_w; /* the next record's mb_x */
+        /* the next record's mb_x (read out of the lanes whether or not there is a next record: a load left pending on one path makes the
+         * compiler wait for ALL memory operations — the previous macroblock's stores included — at the top of the loop) */
+        const int next_x = (int)(__builtin_amdgcn_readlane(nrec, 0) & 0xFFFFu);
+        const int next = k + 1 < kend ? next_x : mb_w;
         have_pf = false;
         if (from_mem && k + 1 < kend) { /* a step ahead: the counter, and the next record's top neighbours when they are known to be there */
             if (known >= min(next + 2, mb_w)) {
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
                 mine[mx * 4 + (lane & 3)] = vy;
             if (lane < 32 && do_c) {
                 const int p = lane >> 4, r = (lane >> 1) & 7, c = 4 * (lane & 1);
-                uint8_t *dc = cmb[p] + (ptrdiff_t)r * sc + c * PS;
+                uint8_t *dc = cmb0 + (p ? cr_off : 0) + (ptrdiff_t)r * sc + c * PS;
                 const Q vc = *reinterpret_cast<const Q *>(&T.c[p][imb_ci(r, c)]);
                 if (to_mem)
                     st_dev<Q>(dc, vc);
@@ -329,14 +341,15 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
                     mine[lyq + p * lcq + mx * 2 + (lane & 1)] = vc;
             }
         }
-        if (k + 1 < kend)
-            park(cur ^ 1, nrec);
+        park(cur ^ 1, nrec);
         if (to_lds) { /* LDS operations of a wave execute in order: the line is in place when the counter moves */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0)
                 __hip_atomic_store(&ldone[wv], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         prev_mx = mx;
+        mx = next;
+        nrec = nrec2;
         imb_wave_sync(); /* the other record / run and the tile are rewritten by the next step */
     }
     if (to_mem) {
@@ -406,7 +419,7 @@ int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pi
     }
     /* the chroma planes as a wavefront of their own while the pictures of a launch leave the chip room for twice the workgroups
      * (two per CU by registers) */
-    bool split = (size_t)npics * nwg * 2 <= 512;
+    bool split = (size_t)npics * nwg * 2 <= 576;
 #ifdef FFHIP_MEASURE
     if (const char *e = getenv("FFHIP_INTRA_SPLIT"))
         split = atoi(e) != 0;
