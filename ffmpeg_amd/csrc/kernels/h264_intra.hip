@@ -207,9 +207,12 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
                           * vector value, and the waits below loops under execution masks) */
     Q pf = 0;            /* from_mem: the next record's top neighbours, read a step ahead */
     bool have_pf = false;
-    /* the record after this one, fetched a whole step before it is looked at: its run's prefetch reads the run's place and size out of
-     * it in the middle of the step, and a record fetched at the top of the same step was an L2 round trip late there */
+    /* Two records and one run ahead.  At the top of step k the record of macroblock k + 2 leaves; at the end of the step — after the
+     * reconstruction, BEFORE the macroblock's stores — the run of k + 1 (in registers since the end of step k - 1) is parked in LDS and
+     * the run of k + 2 leaves.  Nothing a step waits for is younger than a store: vector memory operations complete in order, and a
+     * record looked at in the middle of a step used to wait for the previous macroblock's stores to be acknowledged. */
     uint32_t nrec = fetch_rec(k + 1);
+    fetch_run(nrec);
     ImbWave X{ lane };
     for (int cur = 0; k < kend; k++, cur ^= 1) {
         const FFHipH264IntraMB &R = Rb[cur];
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
             if (lane == 0)
                 __hip_atomic_store(&progress[my], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        const uint32_t nrec2 = fetch_rec(k + 2);
         /* ---- the row above has finished macroblock mx + 1 ---- */
         const int want = min(mx + 2, mb_w);
         if (from_lds) {
@@ -286,10 +290,6 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
             else if (has_l)
                 nb = ld_dev<Q>(cmb0 + (((lane - 30) >> 3) ? cr_off : 0) + (ptrdiff_t)((lane - 30) & 7) * sc - 4 * PS);
         }
-        /* the next macroblock's coefficients leave now and land while this one is reconstructed (after the row's last record: that
-         * record's again — every step issues and consumes the same loads, so nothing is left pending on a path of its own) */
-        fetch_run(nrec);
-        const uint32_t nrec2 = fetch_rec(k + 2);
         if (lane < 8) {
             *reinterpret_cast<Q *>(&T.y[imb_yi(-1, 4 * lane - 4)]) = nb;
         } else if (lane < 24) { /* + zeros right of the macroblock (a top-right block that does not exist) */
@@ -317,6 +317,10 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
             }
         }
         imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(Cb[cur]), p4tab, maxv, parts);
+        /* the next macroblock's record and run into LDS, the run after it leaves (after the row's last record: that record's again —
+         * every step issues and consumes the same loads, so nothing is left pending on a path of its own) */
+        park(cur ^ 1, nrec);
+        fetch_run(nrec2);
         /* ---- the macroblock leaves the tile: 64 + 32 quads of samples; write-through where another workgroup reads them ---- */
         {
             uint8_t *dy = ymb + (ptrdiff_t)(lane >> 2) * sy + 4 * (lane & 3) * PS;
@@ -341,7 +345,6 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
                     mine[lyq + p * lcq + mx * 2 + (lane & 1)] = vc;
             }
         }
-        park(cur ^ 1, nrec);
         if (to_lds) { /* LDS operations of a wave execute in order: the line is in place when the counter moves */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0)
