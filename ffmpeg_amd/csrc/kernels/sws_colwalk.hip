@@ -1206,7 +1206,17 @@ int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream)
     if (A.nframes <= 0)
         return 0;
     A.ncb = cdiv(A.dstW, 512);
-    const int n = cdiv(A.dstH, 64);
+    /* output rows per strip (a wave owns 512 columns of one): 64 when the batch fills the chip twice over at the kernel's three
+     * waves per SIMD; shorter strips for smaller batches — a strip re-filters the rows above it, but ONE 4K frame in 64-row strips
+     * is 272 waves on 1,024 SIMDs (measured, yuv420p 1080p -> rgb24 4K: 1 frame 59 -> 31 us at 24 rows, 4 frames 76 -> 51 us;
+     * 32 frames are fastest at 64) */
+    int rows = 64;
+    static const int shorter[] = { 48, 32, 24 };
+    for (int i = 0; i < 3 && (long long)A.ncb * cdiv(A.dstH, rows) * A.nframes < 2 * 3072; i++)
+        rows = shorter[i];
+    if (const char *es = FFHIP_KNOB("FFHIP_CWRGB_STRIP")) /* measured variant */
+        rows = atoi(es) >= 8 && atoi(es) <= 64 ? atoi(es) : rows;
+    const int n = cdiv(A.dstH, rows);
     A.strip_rows = cdiv(A.dstH, n); /* <= 64 */
     A.nstrips = cdiv(A.dstH, A.strip_rows);
     const long long waves = (long long)A.ncb * A.nstrips * A.nframes;

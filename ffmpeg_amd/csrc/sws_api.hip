@@ -1141,8 +1141,20 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             for (int i = 0; i < U.njobs; i++)
                 neg = neg || U.job[i].sstride < 0 || U.job[i].dstride < 0;
             if (!neg) {
-                for (int i = 0; i < U.njobs; i++)
-                    ffhip_up2_plan_job(&U.job[i], 64 >> U.fshift, es && atoi(es) > 0 ? atoi(es) : 60);
+                /* source rows per strip: 60 when that is eight waves per SIMD or more; shorter strips for a small batch — a strip
+                 * re-reads the rows above it and pays a prologue, but ONE 1080p -> 4K frame in 60-row strips is 232 waves on 1,024
+                 * SIMDs (measured, nv12: 1 frame 27.7 -> 20.6 us, 4 frames 30.5 -> 23.8 us, 16 frames 63.5 -> 56.6 us, 64 frames
+                 * unchanged; what sws_scale_frame() on a filter graph's frames sees.  FFHIP_UP2_STRIP fixes it in the measure build) */
+                static const int wants[] = { 60, 36, 24, 12 };
+                for (int t = 0; t < 4; t++) {
+                    long long u = 0;
+                    for (int i = 0; i < U.njobs; i++) {
+                        ffhip_up2_plan_job(&U.job[i], 64 >> U.fshift, es && atoi(es) > 0 ? atoi(es) : wants[t]);
+                        u += (long long)U.job[i].upj * U.job[i].nstrips;
+                    }
+                    if ((es && atoi(es) > 0) || u * ((nframes + (1 << U.fshift) - 1) >> U.fshift) >= 8192)
+                        break;
+                }
                 /* FFHIP_UP2_VAR: 0 the product; 16 / 48 / 64 = measurement-only builds (no stores / arithmetic only / bytes only) */
                 return ffhip_launch_up2(U, ed && ed[0] == '6' ? 6 : 3, ev2 ? atoi(ev2) : 0, stream);
             }
@@ -1184,7 +1196,11 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             const char *ed = FFHIP_KNOB("FFHIP_CW_DEPTH"), *es = FFHIP_KNOB("FFHIP_CW_STRIP");
             const int lg = (eg && eg[0] == '1') || (ep && ep[0] == '1') ? 1 : 2; /* measured: 2 groups/lane is 12 % faster */
             const int depth = ed && ed[0] == '3' ? 3 : 6; /* measured: 6 rows in flight is 4 % faster with OPT */
-            const int strip = es && atoi(es) > 0 ? atoi(es) : 120;
+            /* output rows per strip: 120 when that is four waves per SIMD or more, shorter strips for a smaller batch (measured, yuv420p
+             * 720p -> 1080p: 1 frame 49 -> 19 us, 8 frames 50 -> 29 us at 24 rows, 32 frames 64 -> 57 us at 40: a lone frame in
+             * 120-row strips is 56 waves) */
+            static const int strips[] = { 120, 60, 40, 24 };
+            int gpl[3], strip = 120;
             FFHipCwArgs A;
             memset(&A, 0, sizeof(A));
             A.nframes = nframes;
@@ -1205,7 +1221,7 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             jl.kind = lg == 2 ? 1 : 0;
             jl.src[0] = l.src[0]; jl.sstride[0] = l.src_stride[0]; jl.sfp[0] = l.src_fp[0];
             jl.dst[0] = l.dst[0]; jl.dstride[0] = l.dst_stride[0]; jl.dfp[0] = l.dst_fp[0];
-            ffhip_cw_plan_job(&jl, lg, strip);
+            gpl[0] = lg;
             A.njobs = 1;
             if (ch.src_step == 1 && ch.dst_step == 1) {
                 for (int k = 0; k < 2; k++) {
@@ -1214,7 +1230,7 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                     j.kind = jl.kind;
                     j.src[0] = ch.src[k]; j.sstride[0] = ch.src_stride[k]; j.sfp[0] = ch.src_fp[k];
                     j.dst[0] = ch.dst[k]; j.dstride[0] = ch.dst_stride[k]; j.dfp[0] = ch.dst_fp[k];
-                    ffhip_cw_plan_job(&j, lg, strip);
+                    gpl[A.njobs - 1] = lg;
                 }
             } else {
                 FFHipCwJob &j = A.job[A.njobs++];
@@ -1233,7 +1249,17 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                     j.dst_swap = ch.dst[1] < ch.dst[0];
                     j.dst[0] = j.dst_swap ? ch.dst[1] : ch.dst[0];
                 }
-                ffhip_cw_plan_job(&j, 1, strip);
+                gpl[A.njobs - 1] = 1;
+            }
+            for (int t = 0; t < 4; t++) {
+                strip = es && atoi(es) > 0 ? atoi(es) : strips[t];
+                long long u = 0;
+                for (int i = 0; i < A.njobs; i++) {
+                    ffhip_cw_plan_job(&A.job[i], gpl[i], strip);
+                    u += (long long)A.job[i].ncb * A.job[i].nstrips;
+                }
+                if ((es && atoi(es) > 0) || u * nframes >= 4096)
+                    break;
             }
             return ffhip_launch_colwalk(A, lg, depth, stream);
         }

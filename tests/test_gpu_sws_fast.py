@@ -60,7 +60,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     if need != "up2" and dw == 2 * sw and dh == 2 * sh:
         monkeypatch.setenv("FFHIP_SWS_UP2", "0")   # these tests are about the general kernels; test_up2* covers sws_up2.hip
     for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
-              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_SWS_WIDE", "FFHIP_CW_DUP", "FFHIP_LW_STRIP", "FFHIP_LW_AHEAD"):
+              "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_CWRGB_STRIP", "FFHIP_SWS_WIDE", "FFHIP_CW_DUP", "FFHIP_LW_STRIP", "FFHIP_LW_AHEAD"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -390,7 +390,8 @@ RGB_CASES = [
 ]
 
 
-@pytest.mark.parametrize("env", [{}, {"FFHIP_CWRGB_DIRECT": "1"}, {"FFHIP_SWS_FAST": "0"}], ids=["default", "direct", "tiled"])
+@pytest.mark.parametrize("env", [{}, {"FFHIP_CWRGB_DIRECT": "1"}, {"FFHIP_SWS_FAST": "0"}, {"FFHIP_CWRGB_STRIP": "64"}, {"FFHIP_CWRGB_STRIP": "9"}],
+                         ids=["default", "direct", "tiled", "strip64", "strip9"])
 @pytest.mark.parametrize("case", RGB_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
 def test_fast_path_rgb(case, env, monkeypatch):
     _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF)

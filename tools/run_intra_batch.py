@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""tools/run_intra_batch.py [npics=32] [launches=4] — ffhip_h264_intra_frames_dev on npics all-intra 1080p pictures (the same records,
-each picture its own planes), for profiler passes and timing."""
+"""tools/run_intra_batch.py [npics=32] [launches=4] [mb_w=120 mb_h=68 [type]] — ffhip_h264_intra_frames_dev on npics all-intra pictures
+(1080p unless given; the same records, each picture its own planes), for profiler passes and timing.  type 0..3 = Intra16x16 / Intra4x4 /
+Intra4x4 with the 8x8 transform / I_PCM only (a picture of ONE macroblock row has no hand-off: the time per macroblock of the chain itself).
+FFHIP_BUILD=measure selects the build in which the FFHIP_* knobs are live."""
 import ctypes as C
 import json
 import os
@@ -17,7 +19,8 @@ import h264_intra_gen as G  # noqa: E402
 
 npics = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-mb_w, mb_h = 120, 68
+mb_w, mb_h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (120, 68)
+mtype = [G.I16, G.I4, G.I8, G.PCM][int(sys.argv[5])] if len(sys.argv) > 5 else None
 if os.environ.get("FFHIP_BUILD") == "measure":  # the build in which the FFHIP_* knobs are live
     _lib.select("measure")
 L = _lib.lib()
@@ -32,7 +35,7 @@ rng = np.random.default_rng(6)
 coefs, ncoef, recs = np.zeros(mb_w * mb_h * 400, np.int16), 0, []
 for my in range(mb_h):
     for mx in range(mb_w):
-        d = G.make_intra_mb(rng, mx, my, mb_w, mb_h)
+        d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, mtype)
         rec = G.to_record(d)
         mb = d["mb"].copy()
         n = C.c_int32(ncoef)
@@ -56,4 +59,5 @@ for _ in range(launches):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / launches
-print(json.dumps({"pictures_per_launch": npics, "ms_per_launch": round(ms, 3), "pictures_per_s": round(1e3 * npics / ms, 1)}))
+print(json.dumps({"pictures_per_launch": npics, "ms_per_launch": round(ms, 4), "pictures_per_s": round(1e3 * npics / ms, 1),
+                  "us_per_step": round(1e3 * ms / (mb_w + 2 * (mb_h - 1)), 3)}))
