@@ -261,6 +261,12 @@ def extras(torch, dev):
     out["yuv420p_rgb24_4k"] = {"Mpixels/s": round(n * w * h / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1),
                                "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "frames": n, "ms": round(ms, 4)}
     out["yuv420p_rgb24_4k"]["frac_of_guide_achievable_6290"] = round(gbs / HBM_GUIDE_ACHIEVABLE_GBS, 4)
+    # this box's streaming probe at the kernel's own mix (read n / 2, write n: 1.5 B read and 3 B written per pixel) — north_star's 0.70 of
+    # the 8 TB/s peak is 5.6 TB/s of a 1 : 2 mix; the probe says what a plain grid-stride copy of that mix reaches on the box of this run
+    g = C.c_double(0)
+    if _lib.lib().ffhip_membw_probe(4, 2 << 30, 10, C.byref(g)) == 0:
+        out["yuv420p_rgb24_4k"]["box_probe_read1_write2_GB/s"] = round(g.value, 1)
+        out["yuv420p_rgb24_4k"]["frac_of_box_probe_read1_write2"] = round(gbs / g.value, 4)
     ctx.close()
     del src, dst
 

@@ -46,15 +46,18 @@ struct FFHipH264Picture {
     int device = 0; /* staging and scratch planes live on this device; flush() makes it current for its duration */
     int mb_w = 0, mb_h = 0;
     int bd = 8;     /* sample depth: above 8 the planes hold uint16_t, coefficient blocks int32_t (dctcoef, bit_depth_template.c:39-50) */
-    std::vector<FFHipQpelBlock> qpel[3];          /* luma MC by stage                      */
+    int cfmt = 1;   /* sps->chroma_format_idc: 1 (4:2:0) or 3 (4:4:4: Cb and Cr are reconstructed by the LUMA members, hl_decode_mb_444) */
+    std::vector<FFHipQpelBlock> qpel[3][3];       /* luma-table MC: plane (4:2:0: plane 0 only) x stage */
     std::vector<FFHipChromaBlock> cmc[2][3];      /* chroma MC: plane (Cb, Cr) x stage     */
     std::vector<FFHipWeightBlock> wt[3];          /* weight / biweight per plane           */
     std::vector<int32_t> idct_off[3][4];          /* per plane x FFHIP_H264_IDCT* kind     */
     std::vector<int16_t> idct_coef[3][4];
-    std::vector<FFHipH264IntraMB> intra;          /* intra macroblocks in recording order   */
-    std::vector<int16_t> intra_coef;              /* their packed coefficient runs          */
-    std::vector<FFHipH264IntraMB> intra_sorted;   /* flush(): by (mb_y, mb_x)               */
-    std::vector<int32_t> intra_rows;              /* flush(): mb_h + 1 row starts           */
+    /* intra macroblocks in recording order and their packed coefficient runs.  4:2:0: [0] holds whole macroblocks; 4:4:4: [pl] holds
+     * plane pl's share of every intra macroblock as a luma-only record (the wavefront runs once per plane, side by side) */
+    std::vector<FFHipH264IntraMB> intra[3];
+    std::vector<int16_t> intra_coef[3];
+    std::vector<FFHipH264IntraMB> intra_sorted[3]; /* flush(): by (mb_y, mb_x)               */
+    std::vector<int32_t> intra_rows[3];            /* flush(): mb_h + 1 row starts           */
     std::vector<FFHipH264Edge> edges[3];          /* whole-picture edge arrays, zero = skip */
     bool any_edge[3] = { false, false, false };
     void *pinned = nullptr, *dev = nullptr;
@@ -66,6 +69,11 @@ struct FFHipH264Picture {
     /* the chroma planes' deblocking wavefront runs beside the luma one on a second stream, forked and joined with events */
     hipStream_t aux = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    /* geometry of plane pl in samples / rows, and the edge records a macroblock has in it */
+    int plane_w(int pl) const { return (pl && cfmt != 3 ? 8 : 16) * mb_w; }
+    int plane_h(int pl) const { return (pl && cfmt == 1 ? 8 : 16) * mb_h; }
+    int edges_per_mb(int pl) const { return pl && cfmt != 3 ? 4 : 8; }
+    int intra_sets() const { return cfmt == 3 ? 3 : 1; }
 };
 
 extern "C" void ffhip_h264_picture_free(FFHipH264Picture **pp)
@@ -102,13 +110,14 @@ extern "C" void ffhip_h264_picture_begin(FFHipH264Picture *p)
     if (!p)
         return;
     for (int s = 0; s < 3; s++) {
-        p->qpel[s].clear();
+        for (int pl = 0; pl < 3; pl++)
+            p->qpel[pl][s].clear();
         p->cmc[0][s].clear();
         p->cmc[1][s].clear();
     }
-    p->intra.clear();
-    p->intra_coef.clear();
     for (int pl = 0; pl < 3; pl++) {
+        p->intra[pl].clear();
+        p->intra_coef[pl].clear();
         p->wt[pl].clear();
         for (int k = 0; k < 4; k++) {
             p->idct_off[pl][k].clear();
@@ -127,9 +136,19 @@ extern "C" int ffhip_h264_picture_create(FFHipH264Picture **pp, int mb_w, int mb
 
 extern "C" int ffhip_h264_picture_create_hbd(FFHipH264Picture **pp, int mb_w, int mb_h, int bit_depth)
 {
+    return ffhip_h264_picture_create_fmt(pp, mb_w, mb_h, bit_depth, 1);
+}
+
+extern "C" int ffhip_h264_picture_create_fmt(FFHipH264Picture **pp, int mb_w, int mb_h, int bit_depth, int chroma_format_idc)
+{
     if (!pp || mb_w <= 0 || mb_h <= 0)
         return FFHIP_EINVAL;
     *pp = nullptr;
+    if (chroma_format_idc != 1 && chroma_format_idc != 3) {
+        /* 4:2:2 (hl_motion_422, the 8x16 chroma predictors and its chroma edge filters in frame order) and monochrome stay on the C path */
+        ffhip_set_error("ffhip_h264_picture_create_fmt: chroma_format_idc %d (1 = 4:2:0 and 3 = 4:4:4 are built)", chroma_format_idc);
+        return chroma_format_idc == 0 || chroma_format_idc == 2 ? FFHIP_ENOSYS : FFHIP_EINVAL;
+    }
     if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14) {
         ffhip_set_error("ffhip_h264_picture_create_hbd: bit depth %d (8, 9, 10, 12 and 14 are the depths H.264 defines)", bit_depth);
         return FFHIP_EINVAL;
@@ -144,10 +163,10 @@ extern "C" int ffhip_h264_picture_create_hbd(FFHipH264Picture **pp, int mb_w, in
     p->mb_w = mb_w;
     p->mb_h = mb_h;
     p->bd = bit_depth;
+    p->cfmt = chroma_format_idc;
     const size_t nmb = (size_t)mb_w * mb_h;
-    p->edges[0].assign(nmb * 8, FFHipH264Edge());
-    p->edges[1].assign(nmb * 4, FFHipH264Edge());
-    p->edges[2].assign(nmb * 4, FFHipH264Edge());
+    for (int pl = 0; pl < 3; pl++)
+        p->edges[pl].assign(nmb * (size_t)p->edges_per_mb(pl), FFHipH264Edge());
     if (hipEventCreateWithFlags(&p->copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess ||
@@ -162,11 +181,20 @@ extern "C" int ffhip_h264_picture_create_hbd(FFHipH264Picture **pp, int mb_w, in
 /* ---- recording: cheap appends on the host ----------------------------------------------------------- */
 extern "C" int ffhip_h264_picture_mc_luma(FFHipH264Picture *p, int stage, const FFHipQpelBlock *blk)
 {
-    if (!p || !blk || stage < 0 || stage > 2)
+    return ffhip_h264_picture_mc_luma_plane(p, 0, stage, blk);
+}
+
+extern "C" int ffhip_h264_picture_mc_luma_plane(FFHipH264Picture *p, int plane, int stage, const FFHipQpelBlock *blk)
+{
+    if (!p || !blk || plane < 0 || plane > 2 || stage < 0 || stage > 2)
         return FFHIP_EINVAL;
+    if (plane && p->cfmt != 3) {
+        ffhip_set_error("ffhip_h264_picture_mc_luma_plane: plane %d of a 4:2:0 picture takes chroma MC records", plane);
+        return FFHIP_EINVAL;
+    }
     FFHipQpelBlock b = *blk;
     b.avg = stage == ST_AVG;
-    p->qpel[stage].push_back(b);
+    p->qpel[plane][stage].push_back(b);
     return 0;
 }
 
@@ -174,6 +202,10 @@ extern "C" int ffhip_h264_picture_mc_chroma(FFHipH264Picture *p, int plane, int 
 {
     if (!p || !blk || plane < 1 || plane > 2 || stage < 0 || stage > 2)
         return FFHIP_EINVAL;
+    if (p->cfmt == 3) {
+        ffhip_set_error("ffhip_h264_picture_mc_chroma: the chroma planes of a 4:4:4 picture are predicted by the luma tables (mc_luma_plane)");
+        return FFHIP_EINVAL;
+    }
     FFHipChromaBlock b = *blk;
     b.avg = stage == ST_AVG;
     p->cmc[plane - 1][stage].push_back(b);
@@ -237,7 +269,7 @@ extern "C" int ffhip_h264_picture_idct_mb(FFHipH264Picture *p, int which, int pl
                 r = ffhip_h264_picture_idct_add(p, plane, nnz == 1 && coef0(i) ? FFHIP_H264_IDCT8_DC : FFHIP_H264_IDCT8, dst_offset[0] + block_offset[i],
                                                 block + i * 16 * wide);
         }
-    } else if (which == 3) {
+    } else if (which == 3 && p->cfmt == 1) {
         for (int j = 1; j < 3 && r >= 0; j++)
             for (int i = j * 16; i < j * 16 + 4 && r >= 0; i++) {
                 if (nnzc[scan8_chroma(j, i - j * 16)])
@@ -246,7 +278,7 @@ extern "C" int ffhip_h264_picture_idct_mb(FFHipH264Picture *p, int which, int pl
                     r = ffhip_h264_picture_idct_add(p, j, FFHIP_H264_IDCT4_DC, dst_offset[j - 1] + block_offset[i], block + i * 16 * wide);
             }
     } else {
-        ffhip_set_error("ffhip_h264_picture_idct_mb: which = %d (0 idct_add16, 1 idct8_add4, 3 idct_add8)", which);
+        ffhip_set_error("ffhip_h264_picture_idct_mb: which = %d (0 idct_add16, 1 idct8_add4, 3 idct_add8 of a 4:2:0 picture)", which);
         return FFHIP_EINVAL;
     }
     return r;
@@ -256,16 +288,18 @@ extern "C" int ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int
 {
     if (!p || !e || plane < 0 || plane > 2 || mb_x < 0 || mb_x >= p->mb_w || mb_y < 0 || mb_y >= p->mb_h)
         return FFHIP_EINVAL;
-    const int per = plane ? 4 : 8;
+    const int per = p->edges_per_mb(plane);
     memcpy(&p->edges[plane][((size_t)mb_y * p->mb_w + mb_x) * per], e, sizeof(FFHipH264Edge) * per);
     p->any_edge[plane] = true;
     return 0;
 }
 
 /* CF = dctcoef of the depth (int16_t at 8 bits, int32_t above); runs, R.coef, *ncoefs and cap count int16 entries at every depth */
+/* luma_only (a plane of a 4:4:4 macroblock): the record carries sixteen luma-type blocks and nothing else; an I_PCM run holds the plane's
+ * 256 samples (the run keeps its 4:2:0 length, the rest zero: the kernel's run fetch is sized by the macroblock type) */
 template <typename CF>
 static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_t *mb_, const int16_t *mb_luma_dc_, const uint8_t *pcm, int16_t *coefs,
-                      int32_t *ncoefs, int32_t cap)
+                      int32_t *ncoefs, int32_t cap, bool luma_only = false)
 {
     constexpr int W = (int)(sizeof(CF) / sizeof(int16_t));
     if (!rec || !coefs || !ncoefs || rec->type > FFHIP_H264_INTRA_PCM || *ncoefs < 0)
@@ -287,14 +321,17 @@ static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_
     if (R.type == FFHIP_H264_INTRA_PCM) {
         if (!pcm)
             return FFHIP_EINVAL;
+        const int nsamp = luma_only ? 256 : 384;
         if (W == 1) {
-            memcpy(coefs + n, pcm, 384);
+            memcpy(coefs + n, pcm, (size_t)nsamp);
+            memset(reinterpret_cast<uint8_t *>(coefs + n) + nsamp, 0, (size_t)(384 - nsamp));
         } else {
             /* get_bits(&gb, bit_depth) 384 times over sl->intra_pcm_ptr (h264_mb_template.c:100-131): MSB-first fields */
             uint16_t *out = reinterpret_cast<uint16_t *>(coefs + n);
             uint32_t acc = 0;
             int have = 0;
-            for (int k = 0; k < 384; k++) {
+            memset(out, 0, 384 * sizeof(uint16_t));
+            for (int k = 0; k < nsamp; k++) {
                 while (have < bd) {
                     acc = (acc << 8) | *pcm++;
                     have += 8;
@@ -358,6 +395,8 @@ static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_
             }
         }
     }
+    if (luma_only)
+        R.cbp &= 0x0f;
     if (R.cbp & 0x30) { /* chroma_dc_dequant_idct + idct_add8 (h264_mb_template.c:246-258, h264idct_template.c:216-228) */
         for (int pl = 1; pl < 3; pl++) {
             if (nnzc[40 * pl]) /* scan8[CHROMA_DC_BLOCK_INDEX + pl - 1] */
@@ -393,22 +432,49 @@ extern "C" int ffhip_h264_intra_pack_hbd(int bit_depth, FFHipH264IntraMB *rec, c
     return intra_pack<int32_t>(bit_depth, rec, nnzc, mb, mb_luma_dc, pcm, coefs, ncoefs, cap);
 }
 
+/* One plane of a 4:4:4 macroblock (hl_decode_mb_444: hl_decode_mb_predict_luma / hl_decode_mb_idct_luma with p = plane,
+ * h264_mb.c:614-800): the arguments are the plane's slices of the decoder's arrays — nnzc + 5 * 8 * p (scan8[i + 16 p] = scan8[i] + 40 p,
+ * the DC entry scan8[LUMA_DC_BLOCK_INDEX + p] = 40 p), sl->mb + 256 p, sl->mb_luma_dc[p], the plane's 256 I_PCM samples — and
+ * rec->qmul[0] = pps->dequant4_coeff[p][p ? chroma_qp[p - 1] : qscale][0]. */
+extern "C" int ffhip_h264_intra_pack_plane(int bit_depth, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_t *mb, const int16_t *mb_luma_dc,
+                                           const uint8_t *pcm, int16_t *coefs, int32_t *ncoefs, int32_t cap)
+{
+    if (bit_depth == 8)
+        return intra_pack<int16_t>(8, rec, nnzc, mb, mb_luma_dc, pcm, coefs, ncoefs, cap, true);
+    if (bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14)
+        return FFHIP_EINVAL;
+    return intra_pack<int32_t>(bit_depth, rec, nnzc, mb, mb_luma_dc, pcm, coefs, ncoefs, cap, true);
+}
+
 extern "C" int ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264IntraMB *d, const uint8_t *nnzc, int16_t *mb,
                                            const int16_t *mb_luma_dc, const uint8_t *pcm)
 {
     if (!p || !d || d->mb_x < 0 || d->mb_x >= p->mb_w || d->mb_y < 0 || d->mb_y >= p->mb_h)
         return FFHIP_EINVAL;
-    FFHipH264IntraMB R = *d;
-    std::vector<int16_t> &c = p->intra_coef;
-    if (c.size() > (size_t)INT32_MAX - 2048)
-        return FFHIP_EINVAL;
-    int32_t n = (int32_t)c.size();
-    c.resize((size_t)n + 816);
-    const int r = ffhip_h264_intra_pack_hbd(p->bd, &R, nnzc, mb, mb_luma_dc, pcm, c.data(), &n, (int32_t)c.size());
-    c.resize((size_t)n);
-    if (r < 0)
-        return r;
-    p->intra.push_back(R);
+    const int wide = p->bd > 8 ? 2 : 1; /* int16 entries per dctcoef */
+    for (int pl = 0; pl < p->intra_sets(); pl++) {
+        FFHipH264IntraMB R = *d;
+        std::vector<int16_t> &c = p->intra_coef[pl];
+        if (c.size() > (size_t)INT32_MAX - 2048)
+            return FFHIP_EINVAL;
+        int32_t n = (int32_t)c.size();
+        c.resize((size_t)n + 816);
+        int r;
+        if (p->cfmt == 3) {
+            /* the plane's share of the macroblock as a luma-only record: same prediction modes and availability in all three planes */
+            R.qmul[0] = d->qmul[pl];
+            const uint8_t *pcm_pl = pcm ? pcm + (p->bd > 8 ? 32 * p->bd * pl : 256 * pl) : nullptr; /* 256 bit_depth-bit fields per plane */
+            r = ffhip_h264_intra_pack_plane(p->bd, &R, nnzc ? nnzc + 40 * pl : nullptr, mb ? mb + 256 * pl * wide : nullptr,
+                                            mb_luma_dc ? mb_luma_dc + 32 * pl : nullptr /* int16_t mb_luma_dc[3][16 * 2], h264dec.h */, pcm_pl,
+                                            c.data(), &n, (int32_t)c.size());
+        } else {
+            r = ffhip_h264_intra_pack_hbd(p->bd, &R, nnzc, mb, mb_luma_dc, pcm, c.data(), &n, (int32_t)c.size());
+        }
+        c.resize((size_t)n);
+        if (r < 0)
+            return r;
+        p->intra[pl].push_back(R);
+    }
     return 0;
 }
 
@@ -438,13 +504,82 @@ extern "C" int ffhip_h264_intra_frames_dev(int bit_depth, int npics, const FFHip
     return ffhip_launch_h264_intra_frames_bd(bit_depth, npics, pics, stride_y, stride_c, mb_w, mb_h, (hipStream_t)stream);
 }
 
+extern "C" int ffhip_h264_intra_planes_dev(int bit_depth, int nplanes, const FFHipH264IntraPic *planes, ptrdiff_t stride, int mb_w, int mb_h,
+                                           void *stream)
+{
+    if (nplanes < 0 || (nplanes && !planes))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_h264_intra_frames_bd(bit_depth, nplanes, planes, stride, stride, mb_w, mb_h, (hipStream_t)stream, 1);
+}
+
 /* ---- flush ------------------------------------------------------------------------------------------ */
 /* what a batched flush (ffhip_h264_pictures_flush) takes over from a picture after its prediction and residual stages */
 struct FlushBack {
-    bool intra = false;
-    FFHipH264IntraPic ip = {};
+    int nintra = 0;                 /* wavefronts of this picture: 1 (4:2:0, all three planes), or one per plane that has records (4:4:4) */
+    FFHipH264IntraPic ip[3] = {};
     const FFHipH264Edge *edges[3] = { nullptr, nullptr, nullptr };
 };
+
+/* the picture's intra wavefront(s) and in-loop filter, from what the front half left in `B` */
+static int flush_tail(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const FlushBack &B, hipStream_t stream)
+{
+    const int bd = p->bd;
+    int r = 0;
+    /* ---- intra macroblocks: every inter macroblock is complete now; one wavefront over the three planes (4:4:4: one per plane, side by
+     * side in one launch) ---- */
+    if (B.nintra)
+        r = ffhip_launch_h264_intra_frames_bd(bd, B.nintra, B.ip, stride[0], stride[1], p->mb_w, p->mb_h, stream, p->cfmt == 3);
+    if (r < 0)
+        return r;
+    /* ---- in-loop filter, decoder order: the planes are independent, and a lone wavefront is a chain of dependent hand-offs that
+     * leaves the GPU mostly idle — the chroma planes run beside the luma plane on the second stream ---- */
+    const bool chroma = B.edges[1] || B.edges[2];
+    if (p->cfmt == 3) {
+        /* all three planes by the luma filter (filter_mb_edgev / edgeh on img_cb / img_cr, h264_loopfilter.c:601-703): one launch of
+         * three "pictures" when the skewed-rows kernel can address them by table, else plane by plane */
+        uint8_t *pl_[3];
+        const FFHipH264Edge *ed_[3];
+        int n = 0;
+        bool tab = stride[0] == stride[1] && stride[0] == stride[2] && !(stride[0] & 15);
+        for (int pl = 0; pl < 3; pl++)
+            if (B.edges[pl]) {
+                pl_[n] = dst[pl];
+                ed_[n++] = B.edges[pl];
+                tab = tab && !((uintptr_t)dst[pl] & 15);
+            }
+        if (n > 1 && tab)
+            return ffhip_launch_h264_deblock_pictures_bd(bd, 0, pl_, ed_, n, stride[0], p->mb_w, p->mb_h, stream);
+        n = 0;
+        for (int pl = 0; pl < 3 && r >= 0; pl++)
+            if (B.edges[pl])
+                r = ffhip_launch_h264_deblock_frames_bd(bd, 0, dst[pl], 0, 1, stride[pl], p->mb_w, p->mb_h, B.edges[pl], stream);
+        return r < 0 ? r : 0;
+    }
+    if (chroma) {
+        HIP_TRY(hipEventRecord(p->fork, stream));
+        HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
+        const ptrdiff_t gap = dst[2] - dst[1];
+        ffhip_progress_report_to(stream, true); /* a hand-off lost on the second stream is the caller's stream's to hear about */
+        /* (8 bits: Cb and Cr as ONE launch of two "pictures" when Cr follows Cb at a 4-byte aligned distance and both are filtered) */
+        if (bd == 8 && B.edges[1] && B.edges[2] && stride[1] == stride[2] && gap > 0 && !(gap & 3) &&
+            B.edges[2] == B.edges[1] + p->edges[1].size()) {
+            r = ffhip_launch_h264_deblock_frames_chroma(dst[1], (size_t)gap, 2, stride[1], p->mb_w, p->mb_h, B.edges[1], p->aux);
+        } else {
+            for (int pl = 1; pl < 3 && r >= 0; pl++)
+                if (B.edges[pl])
+                    r = ffhip_launch_h264_deblock_frames_bd(bd, 1, dst[pl], 0, 1, stride[pl], p->mb_w, p->mb_h, B.edges[pl], p->aux);
+        }
+        ffhip_progress_report_to(nullptr, false);
+        HIP_TRY(hipEventRecord(p->join, p->aux));
+    }
+    if (r >= 0 && B.edges[0])
+        r = ffhip_launch_h264_deblock_frames_bd(bd, 0, dst[0], 0, 1, stride[0], p->mb_w, p->mb_h, B.edges[0], stream);
+    if (chroma)
+        HIP_TRY(hipStreamWaitEvent(stream, p->join, 0));
+    return r < 0 ? r : 0;
+}
 
 static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3], void *stream_, FlushBack *defer)
 {
@@ -470,35 +605,55 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
                                 "(plane and stride)", pl, p->bd);
                 return FFHIP_EINVAL;
             }
+    if (p->bd > 8)
+        for (int pl = 0; pl < 3; pl++)
+            if ((stride[pl] & 1) || ((uintptr_t)dst[pl] & 1) || ((uintptr_t)ref[pl] & 1)) {
+                ffhip_set_error("ffhip_h264_picture_flush: plane %d of a %d-bit picture is not 2-byte aligned", pl, p->bd);
+                return FFHIP_EINVAL;
+            }
+    const int nsets = p->intra_sets();
+    if (p->cfmt == 3 && (!p->intra[0].empty() || !p->intra[1].empty() || !p->intra[2].empty())) {
+        /* the wavefront launch takes one luma stride for every "picture" of a launch: the three planes of a 4:4:4 picture share it (the
+         * decoder's linesize == uvlinesize there); four samples per access */
+        const unsigned amask = p->bd > 8 ? 7u : 3u;
+        if (stride[1] != stride[0] || stride[2] != stride[0] || (((uintptr_t)dst[0] | (uintptr_t)dst[1] | (uintptr_t)dst[2] | (unsigned)stride[0]) & amask)) {
+            ffhip_set_error("ffhip_h264_picture_flush: the planes of a 4:4:4 picture with intra macroblocks share one stride and are %u-byte aligned",
+                            amask + 1);
+            return FFHIP_EINVAL;
+        }
+    }
 
     /* layout of the one staging buffer */
     size_t total = 0;
-    Section s_qpel[3], s_cmc[2][3], s_wt[3], s_ioff[3][4], s_icoef[3][4], s_edge[3], s_intra, s_irows, s_intracoef;
-    if (!p->intra.empty()) {
+    Section s_qpel[3][3], s_cmc[2][3], s_wt[3], s_ioff[3][4], s_icoef[3][4], s_edge[3], s_intra[3], s_irows[3], s_intracoef[3];
+    for (int q = 0; q < nsets; q++) {
+        if (p->intra[q].empty())
+            continue;
         /* the wavefront walks a row's intra macroblocks left to right: by (mb_y, mb_x), one record per macroblock */
-        p->intra_sorted = p->intra;
-        std::stable_sort(p->intra_sorted.begin(), p->intra_sorted.end(), [](const FFHipH264IntraMB &a, const FFHipH264IntraMB &b) {
+        p->intra_sorted[q] = p->intra[q];
+        std::stable_sort(p->intra_sorted[q].begin(), p->intra_sorted[q].end(), [](const FFHipH264IntraMB &a, const FFHipH264IntraMB &b) {
             return a.mb_y != b.mb_y ? a.mb_y < b.mb_y : a.mb_x < b.mb_x;
         });
-        p->intra_rows.assign((size_t)p->mb_h + 1, 0);
-        for (size_t i = 0; i < p->intra_sorted.size(); i++) {
-            const FFHipH264IntraMB &a = p->intra_sorted[i];
-            if (i && a.mb_y == p->intra_sorted[i - 1].mb_y && a.mb_x == p->intra_sorted[i - 1].mb_x) {
+        p->intra_rows[q].assign((size_t)p->mb_h + 1, 0);
+        for (size_t i = 0; i < p->intra_sorted[q].size(); i++) {
+            const FFHipH264IntraMB &a = p->intra_sorted[q][i];
+            if (i && a.mb_y == p->intra_sorted[q][i - 1].mb_y && a.mb_x == p->intra_sorted[q][i - 1].mb_x) {
                 ffhip_set_error("ffhip_h264_picture_flush: macroblock (%d, %d) recorded twice as intra", a.mb_x, a.mb_y);
                 return FFHIP_EINVAL;
             }
-            p->intra_rows[(size_t)a.mb_y + 1]++;
+            p->intra_rows[q][(size_t)a.mb_y + 1]++;
         }
         for (int r = 0; r < p->mb_h; r++)
-            p->intra_rows[(size_t)r + 1] += p->intra_rows[r];
-        if (p->intra_coef.empty())
-            p->intra_coef.assign(8, 0); /* a picture of coefficient-free intra macroblocks still hands the kernel a base */
-        place(total, p->intra_sorted, s_intra);
-        place(total, p->intra_rows, s_irows);
-        place(total, p->intra_coef, s_intracoef);
+            p->intra_rows[q][(size_t)r + 1] += p->intra_rows[q][r];
+        if (p->intra_coef[q].empty())
+            p->intra_coef[q].assign(8, 0); /* a picture of coefficient-free intra macroblocks still hands the kernel a base */
+        place(total, p->intra_sorted[q], s_intra[q]);
+        place(total, p->intra_rows[q], s_irows[q]);
+        place(total, p->intra_coef[q], s_intracoef[q]);
     }
     for (int s = 0; s < 3; s++) {
-        place(total, p->qpel[s], s_qpel[s]);
+        for (int pl = 0; pl < 3; pl++)
+            place(total, p->qpel[pl][s], s_qpel[pl][s]);
         place(total, p->cmc[0][s], s_cmc[0][s]);
         place(total, p->cmc[1][s], s_cmc[1][s]);
     }
@@ -547,20 +702,21 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
         if (bytes)
             memcpy(hb + s.off, src, bytes);
     };
-    if (!p->intra.empty()) {
-        put(s_intra, p->intra_sorted.data(), p->intra_sorted.size() * sizeof(FFHipH264IntraMB));
-        put(s_irows, p->intra_rows.data(), p->intra_rows.size() * sizeof(int32_t));
-        put(s_intracoef, p->intra_coef.data(), p->intra_coef.size() * sizeof(int16_t));
-    }
+    for (int q = 0; q < nsets; q++)
+        if (!p->intra[q].empty()) {
+            put(s_intra[q], p->intra_sorted[q].data(), p->intra_sorted[q].size() * sizeof(FFHipH264IntraMB));
+            put(s_irows[q], p->intra_rows[q].data(), p->intra_rows[q].size() * sizeof(int32_t));
+            put(s_intracoef[q], p->intra_coef[q].data(), p->intra_coef[q].size() * sizeof(int16_t));
+        }
     bool need_tmp[3] = { false, false, false };
     for (int s = 0; s < 3; s++) {
-        put(s_qpel[s], p->qpel[s].data(), p->qpel[s].size() * sizeof(FFHipQpelBlock));
+        for (int pl = 0; pl < 3; pl++)
+            put(s_qpel[pl][s], p->qpel[pl][s].data(), p->qpel[pl][s].size() * sizeof(FFHipQpelBlock));
         for (int c = 0; c < 2; c++)
             put(s_cmc[c][s], p->cmc[c][s].data(), p->cmc[c][s].size() * sizeof(FFHipChromaBlock));
     }
-    need_tmp[0] = !p->qpel[ST_TMP].empty();
-    need_tmp[1] = !p->cmc[0][ST_TMP].empty();
-    need_tmp[2] = !p->cmc[1][ST_TMP].empty();
+    for (int pl = 0; pl < 3; pl++)
+        need_tmp[pl] = !p->qpel[pl][ST_TMP].empty() || (pl && !p->cmc[pl - 1][ST_TMP].empty());
     for (int pl = 0; pl < 3; pl++) {
         put(s_wt[pl], p->wt[pl].data(), p->wt[pl].size() * sizeof(FFHipWeightBlock));
         for (const FFHipWeightBlock &w : p->wt[pl])
@@ -576,7 +732,7 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
     for (int pl = 0; pl < 3; pl++) {
         if (!need_tmp[pl])
             continue;
-        const size_t rows = (size_t)p->mb_h * (pl ? 8 : 16), need = rows * (size_t)stride[pl] + 64;
+        const size_t rows = (size_t)p->plane_h(pl), need = rows * (size_t)stride[pl] + 64;
         if (need > p->tmp_sz[pl]) {
             HIP_TRY(hipStreamSynchronize(stream));
             if (p->tmp[pl])
@@ -596,24 +752,32 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
         p->copy_pending = true;
     }
 
+    FlushBack B;
+    for (int q = 0; q < nsets; q++)
+        if (!p->intra[q].empty()) {
+            /* 4:4:4: the plane as the "luma" of a luma-only wavefront (cb / cr are never touched there) */
+            uint8_t *const y = p->cfmt == 3 ? dst[q] : dst[0];
+            B.ip[B.nintra++] = FFHipH264IntraPic{ y, p->cfmt == 3 ? y : dst[1], p->cfmt == 3 ? y : dst[2], (const FFHipH264IntraMB *)(db + s_intra[q].off),
+                                                  (const int32_t *)(db + s_irows[q].off), (const int16_t *)(db + s_intracoef[q].off) };
+        }
+    for (int pl = 0; pl < 3; pl++)
+        if (p->any_edge[pl])
+            B.edges[pl] = (const FFHipH264Edge *)(db + s_edge[pl].off);
+
     int r = 0;
     if (p->bd > 8) {
         /* the same stages on the kernels templated on the sample type (kernels/h264_hbd.hip): one launch per list */
         const int bd = p->bd;
-        for (int pl = 0; pl < 3; pl++)
-            if ((stride[pl] & 1) || ((uintptr_t)dst[pl] & 1) || ((uintptr_t)ref[pl] & 1)) {
-                ffhip_set_error("ffhip_h264_picture_flush: plane %d of a %d-bit picture is not 2-byte aligned", pl, bd);
-                return FFHIP_EINVAL;
-            }
         for (int s = 0; s < 3 && r >= 0; s++) {
-            if (s_qpel[s].n)
-                r = ffhip_launch_h264_qpel_bd(bd, s == ST_TMP ? p->tmp[0] : dst[0], ref[0], stride[0], (const FFHipQpelBlock *)(db + s_qpel[s].off),
-                                              s_qpel[s].n, stream, 16 * p->mb_w, 16 * p->mb_h);
+            for (int pl = 0; pl < 3 && r >= 0; pl++)
+                if (s_qpel[pl][s].n)
+                    r = ffhip_launch_h264_qpel_bd(bd, s == ST_TMP ? p->tmp[pl] : dst[pl], ref[pl], stride[pl], (const FFHipQpelBlock *)(db + s_qpel[pl][s].off),
+                                                  s_qpel[pl][s].n, stream, p->plane_w(pl), p->plane_h(pl));
             for (int c = 0; c < 2 && r >= 0; c++)
                 if (s_cmc[c][s].n)
                     r = ffhip_launch_h264_chroma_mc_bd(bd, s == ST_TMP ? p->tmp[1 + c] : dst[1 + c], ref[1 + c], stride[1 + c],
-                                                       (const FFHipChromaBlock *)(db + s_cmc[c][s].off), s_cmc[c][s].n, stream, 8 * p->mb_w,
-                                                       8 * p->mb_h);
+                                                       (const FFHipChromaBlock *)(db + s_cmc[c][s].off), s_cmc[c][s].n, stream, p->plane_w(1),
+                                                       p->plane_h(1));
         }
         for (int pl = 0; pl < 3 && r >= 0; pl++)
             if (s_wt[pl].n)
@@ -624,131 +788,60 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
                 if (s_ioff[pl][k].n)
                     r = ffhip_launch_h264_idct_add_bd(bd, k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off),
                                                       (int16_t *)(db + s_icoef[pl][k].off), s_ioff[pl][k].n, stream);
-        if (defer) {
-            if (!p->intra.empty()) {
-                defer->intra = true;
-                defer->ip = FFHipH264IntraPic{ dst[0], dst[1], dst[2], (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
-                                               (const int16_t *)(db + s_intracoef.off) };
+    } else {
+        /* ---- prediction ---- */
+        for (int s = 0; s < 3 && r >= 0; s++) {
+            for (int pl = 0; pl < 3 && r >= 0; pl++)
+                if (s_qpel[pl][s].n)
+                    r = ffhip_launch_h264_qpel(s == ST_TMP ? p->tmp[pl] : dst[pl], ref[pl], stride[pl], (const FFHipQpelBlock *)(db + s_qpel[pl][s].off),
+                                               s_qpel[pl][s].n, stream, p->plane_w(pl), p->plane_h(pl));
+            if (r >= 0) { /* Cb and Cr of the stage: one launch */
+                FFHipPlaneMulti M;
+                M.nseg = 0;
+                M.pic_w = p->plane_w(1); /* records flagged FFHIP_MC_EMU clamp to the reference pictures' chroma planes */
+                M.pic_h = p->plane_h(1);
+                for (int c = 0; c < 2; c++)
+                    if (s_cmc[c][s].n) {
+                        FFHipPlaneSeg &g = M.seg[M.nseg++];
+                        g.dst = s == ST_TMP ? p->tmp[1 + c] : dst[1 + c]; g.src = ref[1 + c]; g.blocks = db + s_cmc[c][s].off;
+                        g.stride = stride[1 + c]; g.n = (int)s_cmc[c][s].n; g.first = 0;
+                    }
+                r = ffhip_launch_h264_chroma_mc_multi(M, stream);
             }
-            for (int pl = 0; pl < 3; pl++)
-                if (p->any_edge[pl])
-                    defer->edges[pl] = (const FFHipH264Edge *)(db + s_edge[pl].off);
-            return r < 0 ? r : 0;
         }
-        if (r >= 0 && !p->intra.empty())
-            r = ffhip_launch_h264_intra_frame_bd(bd, dst[0], dst[1], dst[2], stride[0], stride[1], p->mb_w, p->mb_h,
-                                                 (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
-                                                 (const int16_t *)(db + s_intracoef.off), stream);
-        if (r < 0)
-            return r;
-        const bool chroma = p->any_edge[1] || p->any_edge[2];
-        if (chroma) {
-            HIP_TRY(hipEventRecord(p->fork, stream));
-            HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
-            ffhip_progress_report_to(stream, true); /* a hand-off lost on the second stream is the caller's stream's to hear about */
-            for (int pl = 1; pl < 3 && r >= 0; pl++)
-                if (p->any_edge[pl])
-                    r = ffhip_launch_h264_deblock_frames_bd(bd, 1, dst[pl], 0, 1, stride[pl], p->mb_w, p->mb_h, (const FFHipH264Edge *)(db + s_edge[pl].off),
-                                                            p->aux);
-            ffhip_progress_report_to(nullptr, false);
-            HIP_TRY(hipEventRecord(p->join, p->aux));
-        }
-        if (r >= 0 && p->any_edge[0])
-            r = ffhip_launch_h264_deblock_frames_bd(bd, 0, dst[0], 0, 1, stride[0], p->mb_w, p->mb_h, (const FFHipH264Edge *)(db + s_edge[0].off), stream);
-        if (chroma)
-            HIP_TRY(hipStreamWaitEvent(stream, p->join, 0));
-        return r < 0 ? r : 0;
-    }
-    /* ---- prediction ---- */
-    for (int s = 0; s < 3 && r >= 0; s++) {
-        uint8_t *target = s == ST_TMP ? p->tmp[0] : dst[0];
-        if (s_qpel[s].n)
-            r = ffhip_launch_h264_qpel(target, ref[0], stride[0], (const FFHipQpelBlock *)(db + s_qpel[s].off), s_qpel[s].n, stream, 16 * p->mb_w,
-                                       16 * p->mb_h);
-        if (r >= 0) { /* Cb and Cr of the stage: one launch */
+        if (r >= 0) { /* explicit weights of the three planes: one launch */
             FFHipPlaneMulti M;
             M.nseg = 0;
-            M.pic_w = 8 * p->mb_w; /* records flagged FFHIP_MC_EMU clamp to the reference pictures' chroma planes (4:2:0) */
-            M.pic_h = 8 * p->mb_h;
-            for (int c = 0; c < 2; c++)
-                if (s_cmc[c][s].n) {
+            for (int pl = 0; pl < 3; pl++)
+                if (s_wt[pl].n) {
                     FFHipPlaneSeg &g = M.seg[M.nseg++];
-                    g.dst = s == ST_TMP ? p->tmp[1 + c] : dst[1 + c]; g.src = ref[1 + c]; g.blocks = db + s_cmc[c][s].off;
-                    g.stride = stride[1 + c]; g.n = (int)s_cmc[c][s].n; g.first = 0;
+                    g.dst = dst[pl]; g.src = p->tmp[pl] ? p->tmp[pl] : dst[pl]; g.blocks = db + s_wt[pl].off;
+                    g.stride = stride[pl]; g.n = (int)s_wt[pl].n; g.first = 0;
                 }
-            r = ffhip_launch_h264_chroma_mc_multi(M, stream);
+            r = ffhip_launch_h264_weight_multi(M, stream);
+        }
+        /* ---- residual ---- */
+        if (r >= 0) {
+            /* one launch for the three planes' four kinds: no block is named twice, so the lists are independent */
+            FFHipIdctMulti M;
+            M.nseg = 0;
+            for (int pl = 0; pl < 3; pl++)
+                for (int k = 0; k < 4; k++)
+                    if (s_ioff[pl][k].n) {
+                        FFHipIdctSeg &g = M.seg[M.nseg++];
+                        g.dst = dst[pl]; g.offs = (const int32_t *)(db + s_ioff[pl][k].off); g.coef = (int16_t *)(db + s_icoef[pl][k].off);
+                        g.stride = stride[pl]; g.n = (int)s_ioff[pl][k].n; g.kind = k; g.first = 0;
+                    }
+            r = ffhip_launch_h264_idct_multi(M, stream);
         }
     }
-    if (r >= 0) { /* explicit weights of the three planes: one launch */
-        FFHipPlaneMulti M;
-        M.nseg = 0;
-        for (int pl = 0; pl < 3; pl++)
-            if (s_wt[pl].n) {
-                FFHipPlaneSeg &g = M.seg[M.nseg++];
-                g.dst = dst[pl]; g.src = p->tmp[pl] ? p->tmp[pl] : dst[pl]; g.blocks = db + s_wt[pl].off;
-                g.stride = stride[pl]; g.n = (int)s_wt[pl].n; g.first = 0;
-            }
-        r = ffhip_launch_h264_weight_multi(M, stream);
-    }
-    /* ---- residual ---- */
-    if (r >= 0) {
-        /* one launch for the three planes' four kinds: no block is named twice, so the lists are independent */
-        FFHipIdctMulti M;
-        M.nseg = 0;
-        for (int pl = 0; pl < 3; pl++)
-            for (int k = 0; k < 4; k++)
-                if (s_ioff[pl][k].n) {
-                    FFHipIdctSeg &g = M.seg[M.nseg++];
-                    g.dst = dst[pl]; g.offs = (const int32_t *)(db + s_ioff[pl][k].off); g.coef = (int16_t *)(db + s_icoef[pl][k].off);
-                    g.stride = stride[pl]; g.n = (int)s_ioff[pl][k].n; g.kind = k; g.first = 0;
-                }
-        r = ffhip_launch_h264_idct_multi(M, stream);
-    }
-    if (defer) {
-        if (!p->intra.empty()) {
-            defer->intra = true;
-            defer->ip = FFHipH264IntraPic{ dst[0], dst[1], dst[2], (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
-                                           (const int16_t *)(db + s_intracoef.off) };
-        }
-        for (int pl = 0; pl < 3; pl++)
-            if (p->any_edge[pl])
-                defer->edges[pl] = (const FFHipH264Edge *)(db + s_edge[pl].off);
-        return r < 0 ? r : 0;
-    }
-    /* ---- intra macroblocks: every inter macroblock is complete now; one wavefront over the three planes ---- */
-    if (r >= 0 && !p->intra.empty())
-        r = ffhip_launch_h264_intra_frame(dst[0], dst[1], dst[2], stride[0], stride[1], p->mb_w, p->mb_h,
-                                          (const FFHipH264IntraMB *)(db + s_intra.off), (const int32_t *)(db + s_irows.off),
-                                          (const int16_t *)(db + s_intracoef.off), stream);
-    /* ---- in-loop filter, decoder order: the planes are independent, and a lone wavefront is a chain of dependent hand-offs
-     * that leaves the GPU mostly idle — the chroma planes run beside the luma plane on the second stream, and as ONE launch
-     * of two "pictures" when Cr follows Cb at a 4-byte aligned distance and both are filtered ---- */
     if (r < 0)
         return r;
-    const bool chroma = p->any_edge[1] || p->any_edge[2];
-    if (chroma) {
-        HIP_TRY(hipEventRecord(p->fork, stream));
-        HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
-        const ptrdiff_t gap = dst[2] - dst[1];
-        ffhip_progress_report_to(stream, true); /* a hand-off lost on the second stream is the caller's stream's to hear about */
-        if (p->any_edge[1] && p->any_edge[2] && stride[1] == stride[2] && gap > 0 && !(gap & 3) &&
-            s_edge[2].off == s_edge[1].off + p->edges[1].size() * sizeof(FFHipH264Edge)) {
-            r = ffhip_launch_h264_deblock_frames_chroma(dst[1], (size_t)gap, 2, stride[1], p->mb_w, p->mb_h,
-                                                        (const FFHipH264Edge *)(db + s_edge[1].off), p->aux);
-        } else {
-            for (int pl = 1; pl < 3 && r >= 0; pl++)
-                if (p->any_edge[pl])
-                    r = ffhip_launch_h264_deblock_frames_chroma(dst[pl], 0, 1, stride[pl], p->mb_w, p->mb_h,
-                                                                (const FFHipH264Edge *)(db + s_edge[pl].off), p->aux);
-        }
-        ffhip_progress_report_to(nullptr, false);
-        HIP_TRY(hipEventRecord(p->join, p->aux));
+    if (defer) {
+        *defer = B;
+        return 0;
     }
-    if (r >= 0 && p->any_edge[0])
-        r = ffhip_launch_h264_deblock_frame(dst[0], stride[0], p->mb_w, p->mb_h, (const FFHipH264Edge *)(db + s_edge[0].off), stream);
-    if (chroma)
-        HIP_TRY(hipStreamWaitEvent(stream, p->join, 0));
-    return r < 0 ? r : 0;
+    return flush_tail(p, dst, stride, B, stream);
 }
 
 extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
@@ -768,8 +861,8 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
         return 0;
     for (int i = 0; i < n; i++)
         if (!pics[i] || pics[i]->mb_w != pics[0]->mb_w || pics[i]->mb_h != pics[0]->mb_h || pics[i]->bd != pics[0]->bd ||
-            pics[i]->device != pics[0]->device) {
-            ffhip_set_error("ffhip_h264_pictures_flush: the pictures of a batch share geometry, depth and device");
+            pics[i]->cfmt != pics[0]->cfmt || pics[i]->device != pics[0]->device) {
+            ffhip_set_error("ffhip_h264_pictures_flush: the pictures of a batch share geometry, chroma format, depth and device");
             return FFHIP_EINVAL;
         }
     for (int i = 0; i < n; i++)
@@ -780,13 +873,17 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
             }
     if (n == 1)
         return flush_impl(pics[0], dst, stride, ref, stream_, nullptr);
+    if (pics[0]->cfmt == 3 && (stride[1] != stride[0] || stride[2] != stride[0])) {
+        ffhip_set_error("ffhip_h264_pictures_flush: the planes of 4:4:4 pictures share one stride");
+        return FFHIP_EINVAL;
+    }
     /* what the shared in-loop filter launches would refuse is refused before anything is queued (the stages modify dst in place): they
      * address the pictures by table, which only the skewed-rows kernel takes — 16-byte aligned planes and strides (8 for 8-bit chroma) */
     for (int i = 0; i < n; i++)
         for (int pl = 0; pl < 3; pl++) {
             if (!pics[i]->any_edge[pl])
                 continue;
-            const uintptr_t amask = pl && pics[0]->bd == 8 ? 7 : 15;
+            const uintptr_t amask = pl && pics[0]->bd == 8 && pics[0]->cfmt != 3 ? 7 : 15;
             if (!dst[3 * i + pl] || (((uintptr_t)dst[3 * i + pl] | (uintptr_t)stride[pl]) & amask) || (pl == 2 && stride[1] != stride[2])) {
                 ffhip_set_error("ffhip_h264_pictures_flush: plane %d of picture %d carries deblocking records: plane and stride must be %d-byte "
                                 "aligned (Cb and Cr share a stride)", pl, i, (int)amask + 1);
@@ -832,13 +929,14 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
                 return rc[(size_t)t]; /* (the other pictures have had their prediction and residual stages queued) */
             }
     }
+    const bool c444 = p0->cfmt == 3; /* every plane is a luma plane: wavefronts and filters alike */
     std::vector<FFHipH264IntraPic> ip;
     for (int i = 0; i < n; i++)
-        if (B[i].intra)
-            ip.push_back(B[i].ip);
+        for (int q = 0; q < B[i].nintra; q++)
+            ip.push_back(B[i].ip[q]);
     int r = 0;
     if (!ip.empty())
-        r = ffhip_launch_h264_intra_frames_bd(bd, (int)ip.size(), ip.data(), stride[0], stride[1], mb_w, mb_h, stream);
+        r = ffhip_launch_h264_intra_frames_bd(bd, (int)ip.size(), ip.data(), stride[0], stride[1], mb_w, mb_h, stream, c444);
     if (r < 0)
         return r;
     /* the in-loop filter: all chroma planes (Cb and Cr of every picture: up to 2 n "pictures") on the first object's second stream
@@ -848,8 +946,8 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
     for (int i = 0; i < n; i++) {
         for (int pl = 1; pl < 3; pl++)
             if (B[i].edges[pl]) {
-                pl_c.push_back(dst[3 * i + pl]);
-                ed_c.push_back(B[i].edges[pl]);
+                (c444 ? pl_y : pl_c).push_back(dst[3 * i + pl]);
+                (c444 ? ed_y : ed_c).push_back(B[i].edges[pl]);
             }
         if (B[i].edges[0]) {
             pl_y.push_back(dst[3 * i]);
@@ -860,6 +958,7 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
         ffhip_set_error("ffhip_h264_pictures_flush: Cb and Cr share a stride");
         return FFHIP_EINVAL;
     }
+
     if (!pl_c.empty()) {
         HIP_TRY(hipEventRecord(p0->fork, stream));
         HIP_TRY(hipStreamWaitEvent(p0->aux, p0->fork, 0));

@@ -103,7 +103,7 @@ static_assert(offsetof(FFHipH264IntraMB, type) == 4 && offsetof(FFHipH264IntraMB
 /* (two workgroups per CU where it costs no spill: 8 bits fits 256 VGPRs; above, the kernel keeps its 286) */
 template <typename PIX>
 __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h, int *progress_all,
-                                                          int *fail, int maxv)
+                                                          int *fail, int maxv, int luma_only)
 {
     /* (read once: the set is indexed at run time, and fields used in place would be re-read from the kernel arguments in the loops) */
     uint8_t *const py = S.pic[blockIdx.y].y, *const pcb = S.pic[blockIdx.y].cb, *const pcr = S.pic[blockIdx.y].cr;
@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256, 2) void k_h264_intra_frame(FFHipIntraPics S, p
     /* twice the workgroups a picture's rows need: the second set reconstructs the chroma planes, a wavefront of its own (intra
      * prediction never crosses planes) with its own counters — a step of the luma chain is a quarter shorter without them */
     const int nwg = (mb_h + W - 1) / W;
-    const bool split = (int)gridDim.x > nwg, second = (int)blockIdx.x >= nwg;
-    const int parts = split ? (second ? 2 : 1) : 3;
+    /* luma_only (4:4:4, hl_decode_mb_444: h264_mb_template.c:256): every "picture" of the launch is ONE plane of a picture, reconstructed
+     * by the luma rules from records that carry that plane's blocks; its cb / cr pointers are never used */
+    const bool split = !luma_only && (int)gridDim.x > nwg, second = split && (int)blockIdx.x >= nwg;
+    const int parts = luma_only ? 1 : split ? (second ? 2 : 1) : 3;
     const bool do_y = parts & 1, do_c = parts & 2;
     const int my = ((int)blockIdx.x - (second ? nwg : 0)) * W + wv;
     int *const progress = progress_all + ((size_t)blockIdx.y * (split ? 2 : 1) + (second ? 1 : 0)) * (size_t)(mb_h + 1);
@@ -377,7 +379,7 @@ int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *c
 }
 
 int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pics, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
-                                      hipStream_t stream)
+                                      hipStream_t stream, int luma_only)
 {
     if (mb_w <= 0 || mb_h <= 0 || npics <= 0)
         return 0;
@@ -422,10 +424,10 @@ int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pi
     }
     /* the chroma planes as a wavefront of their own while the pictures of a launch leave the chip room for twice the workgroups
      * (two per CU by registers) */
-    bool split = (size_t)npics * nwg * 2 <= 576;
+    bool split = !luma_only && (size_t)npics * nwg * 2 <= 576;
 #ifdef FFHIP_MEASURE
     if (const char *e = getenv("FFHIP_INTRA_SPLIT"))
-        split = atoi(e) != 0;
+        split = !luma_only && atoi(e) != 0;
 #endif
     if ((mb_h + 1) * 2 > FFHIP_PROGRESS_SLOT_INTS)
         split = false;
@@ -443,9 +445,9 @@ int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pi
             return r;
         int *const prog = ps.prog, *const fail = ps.fail;
         if (bd > 8)
-            hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(split ? 2 * nwg : nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, (1 << bd) - 1);
+            hipLaunchKernelGGL(k_h264_intra_frame<uint16_t>, dim3(split ? 2 * nwg : nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, (1 << bd) - 1, luma_only);
         else
-            hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(split ? 2 * nwg : nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, 255);
+            hipLaunchKernelGGL(k_h264_intra_frame<uint8_t>, dim3(split ? 2 * nwg : nwg, n), dim3(64 * W), lds, stream, S, sy, sc, mb_w, mb_h, prog, fail, 255, luma_only);
         const hipError_t e = hipGetLastError();
         const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
         if (e != hipSuccess) {

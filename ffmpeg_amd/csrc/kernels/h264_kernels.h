@@ -58,8 +58,9 @@ int ffhip_h264weight_init_generic(FFHipH264WeightContext *c, int bit_depth);
 #define FFHIP_INTRA_PICS 32
 typedef FFHipH264IntraPic FFHipIntraPic;
 struct FFHipIntraPics { int n; int pad; FFHipIntraPic pic[FFHIP_INTRA_PICS]; };
+/* luma_only: every entry is one plane of a 4:4:4 picture (y = the plane; cb / cr unused but non-null), its records that plane's */
 int ffhip_launch_h264_intra_frames_bd(int bd, int npics, const FFHipIntraPic *pics, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
-                                      hipStream_t stream);
+                                      hipStream_t stream, int luma_only = 0);
 int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                   const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
 int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,

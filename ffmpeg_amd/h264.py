@@ -125,9 +125,10 @@ class Picture:
     """ctypes mirror of FFHipH264Picture: record a picture's per-block dsp calls on the host, flush them as a handful of
     launches (include/ffhip.h).  Records are numpy structured scalars / arrays of the batch faces' dtypes."""
 
-    def __init__(self, mb_w, mb_h, bit_depth=8):
+    def __init__(self, mb_w, mb_h, bit_depth=8, chroma_format=1):
+        """chroma_format: sps->chroma_format_idc, 1 (4:2:0) or 3 (4:4:4: Cb / Cr through the luma members)"""
         self._p = _lib.vp()
-        _lib.check(_lib.lib().ffhip_h264_picture_create_hbd(C.byref(self._p), mb_w, mb_h, bit_depth), "ffhip_h264_picture_create_hbd")
+        _lib.check(_lib.lib().ffhip_h264_picture_create_fmt(C.byref(self._p), mb_w, mb_h, bit_depth, chroma_format), "ffhip_h264_picture_create_fmt")
 
     def close(self):
         if getattr(self, "_p", None) is not None and self._p and _lib is not None:   # _lib is gone during interpreter shutdown
@@ -141,6 +142,9 @@ class Picture:
 
     def mc_luma(self, stage, rec):
         return _lib.check(_lib.lib().ffhip_h264_picture_mc_luma(self._p, stage, rec.ctypes.data), "ffhip_h264_picture_mc_luma")
+
+    def mc_luma_plane(self, plane, stage, rec):
+        return _lib.check(_lib.lib().ffhip_h264_picture_mc_luma_plane(self._p, plane, stage, rec.ctypes.data), "ffhip_h264_picture_mc_luma_plane")
 
     def mc_chroma(self, plane, stage, rec):
         return _lib.check(_lib.lib().ffhip_h264_picture_mc_chroma(self._p, plane, stage, rec.ctypes.data), "ffhip_h264_picture_mc_chroma")

@@ -649,10 +649,31 @@ int  ffhip_h264_picture_create(FFHipH264Picture **p, int mb_w, int mb_h);
  *  keep alpha / beta / tc0 at the 8-bit scale (the kernels scale them as h264dsp_template.c:108-110 does), intra macroblocks hand
  *  over sl->mb / sl->mb_luma_dc / sl->intra_pcm_ptr as ffhip_h264_intra_pack_hbd() describes.  Planes and strides 8-byte aligned. */
 int  ffhip_h264_picture_create_hbd(FFHipH264Picture **p, int mb_w, int mb_h, int bit_depth);
+/** The same object for a picture of sps->chroma_format_idc 1 (4:2:0: == ffhip_h264_picture_create_hbd) or 3 (4:4:4, round 4), at any of the
+ *  depths.  A 4:4:4 picture is what hl_decode_mb_444() (libavcodec/h264_mb_template.c:256-362) makes of it: three planes of luma geometry,
+ *  all reconstructed by the LUMA members —
+ *    prediction: qpix_op[luma_xy] on dest_cb / dest_cr with the luma vector (mc_dir_part(), h264_mb.c:262-288), weights of the luma width
+ *                (mc_part_weighted(), :362-366): ffhip_h264_picture_mc_luma_plane() / ffhip_h264_picture_weight() with plane 1 / 2;
+ *                ffhip_h264_picture_mc_chroma() is refused;
+ *    residual:   idct_add16 / idct8_add4 per plane on sl->mb + 256 p with the cache rows of plane p (hl_decode_mb_idct_luma(..., p),
+ *                h264_mb.c:735-800): ffhip_h264_picture_idct_mb() which 0 / 1 with plane p; which 3 (idct_add8) is refused;
+ *    intra:      hl_decode_mb_predict_luma(..., p) for p = 0, 1, 2 with ONE set of prediction modes (h264_mb.c:614-733):
+ *                ffhip_h264_picture_intra_mb() takes the decoder's arrays as for 4:2:0 — mb_luma_dc = sl->mb_luma_dc[0], the [3][16 * 2]
+ *                int16 array as it stands (plane p's DCs 32 int16 further at every depth, libavcodec/h264dec.h), pcm = the 768 fields —
+ *                and splits the macroblock into three luma-only records; flush() runs the three planes' wavefronts side by side in one
+ *                launch;
+ *    deblocking: filter_mb_edgev / filter_mb_edgeh on img_cb / img_cr (h264_loopfilter.c:601-703): ffhip_h264_picture_deblock_mb() takes 8
+ *                luma-kind edge records for every plane.
+ *  The three planes share one stride when the picture carries intra macroblocks (the decoder's linesize == uvlinesize there).
+ *  chroma_format_idc 2 (hl_motion_422, the 8x16 chroma predictors, chroma422 edge filters in frame order) and 0: FFHIP_ENOSYS — such a
+ *  stream's pictures stay on the decoder's C path; the function tables above cover 4:2:2. */
+int  ffhip_h264_picture_create_fmt(FFHipH264Picture **p, int mb_w, int mb_h, int bit_depth, int chroma_format_idc);
 void ffhip_h264_picture_free(FFHipH264Picture **p);
 void ffhip_h264_picture_begin(FFHipH264Picture *p);
 /** mc_dir_part(): qpix_op[luma_xy] and chroma_op (h264_mb.c:206-300); blk->avg is set from `stage`. */
 int  ffhip_h264_picture_mc_luma(FFHipH264Picture *p, int stage, const FFHipQpelBlock *blk);
+/** ... on plane 0 (== mc_luma), or on Cb / Cr of a 4:4:4 picture (offsets into that plane and that plane of the references). */
+int  ffhip_h264_picture_mc_luma_plane(FFHipH264Picture *p, int plane, int stage, const FFHipQpelBlock *blk);
 int  ffhip_h264_picture_mc_chroma(FFHipH264Picture *p, int plane /* 1 Cb, 2 Cr */, int stage, const FFHipChromaBlock *blk);
 /** mc_part_weighted(): weight_op / biweight_op (h264_mb.c:340-420); a biweight's src_offset addresses the scratch plane. */
 int  ffhip_h264_picture_weight(FFHipH264Picture *p, int plane, const FFHipWeightBlock *blk);
@@ -666,7 +687,8 @@ int  ffhip_h264_picture_idct_add(FFHipH264Picture *p, int plane, int kind, int32
  *  member is handed (sl->non_zero_count_cache); `block` is consumed as those functions consume it. */
 int  ffhip_h264_picture_idct_mb(FFHipH264Picture *p, int which, int plane, const int32_t dst_offset[2], const int *block_offset, int16_t *block,
                                 const uint8_t *nnzc);
-/** ff_h264_filter_mb(): the macroblock's edge records, 8 for luma ((dir * 4 + e)), 4 for a chroma plane ((dir * 2 + e)). */
+/** ff_h264_filter_mb(): the macroblock's edge records, 8 for luma ((dir * 4 + e)), 4 for a chroma plane ((dir * 2 + e)); 4:4:4: 8 for
+ *  every plane, luma kinds. */
 int  ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int mb_y, const FFHipH264Edge *edges);
 /**
  * An INTRA macroblock: what hl_decode_mb() does for IS_INTRA(mb_type) (libavcodec/h264_mb_template.c:137-262 with
@@ -724,6 +746,13 @@ int  ffhip_h264_intra_pack(FFHipH264IntraMB *rec, const uint8_t *non_zero_count_
  *  (rec->luma_dc stays zero: it cannot hold them). */
 int  ffhip_h264_intra_pack_hbd(int bit_depth, FFHipH264IntraMB *rec, const uint8_t *non_zero_count_cache, int16_t *mb,
                                const int16_t *mb_luma_dc, const uint8_t *pcm, int16_t *coefs, int32_t *ncoefs, int32_t cap);
+/** One PLANE of a 4:4:4 macroblock as a luma-only record (what ffhip_h264_picture_intra_mb() does three times on a 4:4:4 picture): the
+ *  arguments are plane p's slices of the decoder's arrays — non_zero_count_cache + 5 * 8 * p (scan8[i + 16 p] == scan8[i] + 40 p, the DC
+ *  entry scan8[LUMA_DC_BLOCK_INDEX + p] == 40 p), sl->mb + 256 p dctcoef, sl->mb_luma_dc[p], the plane's 256 I_PCM fields — and
+ *  rec->qmul[0] = pps->dequant4_coeff[p][p ? sl->chroma_qp[p - 1] : sl->qscale][0] (hl_decode_mb_predict_luma, h264_mb.c:626,712).  The
+ *  record's chroma fields are cleared; an I_PCM run keeps its 4:2:0 length (the last third zero). */
+int  ffhip_h264_intra_pack_plane(int bit_depth, FFHipH264IntraMB *rec, const uint8_t *non_zero_count_cache, int16_t *mb, const int16_t *mb_luma_dc,
+                                 const uint8_t *pcm, int16_t *coefs, int32_t *ncoefs, int32_t cap);
 /** The intra reconstruction wavefront alone, on records already in device memory (what flush() launches): recs sorted by
  *  (mb_y, mb_x), row_start[mb_h + 1] indexes them by macroblock row, coefs is the packed coefficient array.  Planes and strides
  *  4-byte aligned.  Asynchronous on `stream`; a lost hand-off is reported by the next flush / ffhip_stream_synchronize. */
@@ -746,6 +775,10 @@ typedef struct FFHipH264IntraPic {
 } FFHipH264IntraPic;
 int  ffhip_h264_intra_frames_dev(int bit_depth, int npics, const FFHipH264IntraPic *pics /* host array */, ptrdiff_t stride_y,
                                  ptrdiff_t stride_c, int mb_w, int mb_h, void *stream);
+/** The same where every entry is ONE PLANE of a 4:4:4 picture: y = the plane, recs / row_start / coefs = that plane's luma-only records
+ *  (ffhip_h264_intra_pack_plane); cb / cr are not touched (pass y). */
+int  ffhip_h264_intra_planes_dev(int bit_depth, int nplanes, const FFHipH264IntraPic *planes /* host array */, ptrdiff_t stride, int mb_w, int mb_h,
+                                 void *stream);
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
 int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                               void *stream);

@@ -24,7 +24,8 @@
  *
  * Intra macroblocks predict from reconstructed neighbours and cannot be a list of independent calls: they go to libffhip as ONE
  * record each (ffhip_h264_picture_intra_mb(), the reconstruction wavefront), built from the H264SliceContext fields hl_decode_mb()
- * would read.  4:2:0, frame macroblocks, CAVLC / CABAC alike (entropy decoding stays on the CPU and fills sl-> as ever).
+ * would read.  4:2:0 and 4:4:4 (hl_decode_mb_444: the luma members on all three planes — the recorder only has to accept them there),
+ * frame macroblocks, CAVLC / CABAC alike (entropy decoding stays on the CPU and fills sl-> as ever).
  */
 #include <string.h>
 
@@ -48,11 +49,12 @@ static int classify_dst(const FFHipH264Recorder *r, const uint8_t *p)
         if (p >= r->cur[pl] && p < r->cur[pl] + (size_t)r->rows[pl] * r->linesize[pl])
             return pl;
     if (p >= r->scratch && p < r->scratch + r->scratch_size) {
-        /* tmp_cb = scratch, tmp_cr = scratch + (8 << pixel_shift), tmp_y = scratch + 16 * mb_uvlinesize (h264_mb.c:388-390) */
+        /* tmp_cb = scratch, tmp_cr = scratch + (8 << pixel_shift + (chroma_idc == 3)), tmp_y = scratch + 16 * mb_uvlinesize
+         * (h264_mb.c:388-390) */
         const size_t o = (size_t)(p - r->scratch);
         if (o >= (size_t)16 * r->linesize[1])
             return 16;
-        return (o % (size_t)r->linesize[1]) >= ((size_t)8 << r->pixel_shift) ? 18 : 17;
+        return (o % (size_t)r->linesize[1]) >= ((size_t)(r->cfmt == 3 ? 16 : 8) << r->pixel_shift) ? 18 : 17;
     }
     return -1;
 }
@@ -81,25 +83,25 @@ static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int need
     *sx = *sy = 0;
     if (need > 0) {
         /* which reference picture is it?  the one looked at last, nearly always */
-        const ptrdiff_t ls = r->linesize[0], span = (ptrdiff_t)r->rows[0] * ls;
-        const uint8_t *origin = r->last_ref;
+        const ptrdiff_t ls = r->linesize[pl], span = (ptrdiff_t)r->rows[pl] * ls;
+        const uint8_t *origin = r->last_ref[pl];
         if (!origin || src < origin || src >= origin + span) {
             origin = NULL;
             for (int l = 0; l < (int)r->sl->list_count && !origin; l++)
                 for (int i = 0; i < (int)r->sl->ref_count[l] && !origin; i++) {
-                    const uint8_t *d = r->sl->ref_list[l][i].data[0];
+                    const uint8_t *d = r->sl->ref_list[l][i].data[pl];
                     if (d && src >= d && src < d + span)
                         origin = d;
                 }
             if (!origin)
                 return FFHIP_EINVAL;
-            r->last_ref = origin;
+            r->last_ref[pl] = origin;
         }
         {
             const ptrdiff_t o = src - origin;
             const int y = (int)(o / ls), x = (int)(o % ls) >> r->pixel_shift;
-            if (x < 2 || y < 2 || x + need + 3 > r->pic_w || y + need + 3 > r->rows[0]) {
-                *off   = (int32_t)(origin - r->ref_base[0]);
+            if (x < 2 || y < 2 || x + need + 3 > r->pic_w[pl] || y + need + 3 > r->rows[pl]) {
+                *off   = (int32_t)(origin - r->ref_base[pl]);
                 *flags = FFHIP_MC_EMU;
                 *sx    = (int16_t)x;
                 *sy    = (int16_t)y;
@@ -114,9 +116,11 @@ static void rec_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_
     REC;
     FFHipQpelBlock q = { 0 };
     int where = classify_dst(r, dst), pl = where & 15, rc;
-    if (where < 0 || pl != 0 || stride != r->linesize[0])
-        FAIL(FFHIP_EINVAL);   /* 4:4:4 (chroma through the luma tables) and field macroblocks (doubled stride) stay on the C path */
-    rc = locate_src(r, 0, src, 16 >> size_idx, &q.src_offset, &q.flags, &q.src_x, &q.src_y);
+    /* the luma tables reach Cb / Cr in a 4:4:4 picture only (mc_dir_part(), h264_mb.c:262-288); field macroblocks (doubled stride) stay on
+     * the C path */
+    if (where < 0 || (pl != 0 && r->cfmt != 3) || stride != r->linesize[pl])
+        FAIL(FFHIP_EINVAL);
+    rc = locate_src(r, pl, src, 16 >> size_idx, &q.src_offset, &q.flags, &q.src_x, &q.src_y);
     if (rc < 0)
         FAIL(rc);
     q.mcxy = (uint8_t)mcxy;
@@ -124,14 +128,15 @@ static void rec_qpel(int avg, int size_idx, int mcxy, uint8_t *dst, const uint8_
     if (where >= 16) {
         if (r->npend >= 8)
             FAIL(FFHIP_EINVAL);
-        r->pend[r->npend].plane = 0;
+        r->pend[r->npend].plane = pl;
+        r->pend[r->npend].luma_tab = 1;
         r->pend[r->npend].tmp = dst;
         r->pend[r->npend].q = q;
         r->npend++;
         return;
     }
-    q.dst_offset = (int32_t)(dst - r->cur[0]);
-    rc = ffhip_h264_picture_mc_luma(r->pic, avg ? FFHIP_H264_MC_AVG : FFHIP_H264_MC_PUT, &q);
+    q.dst_offset = (int32_t)(dst - r->cur[pl]);
+    rc = ffhip_h264_picture_mc_luma_plane(r->pic, pl, avg ? FFHIP_H264_MC_AVG : FFHIP_H264_MC_PUT, &q);
     if (rc < 0)
         FAIL(rc);
 }
@@ -141,7 +146,7 @@ static void rec_chroma(int avg, int w_idx, uint8_t *dst, const uint8_t *src, ptr
     REC;
     FFHipChromaBlock c = { 0 };
     int where = classify_dst(r, dst), pl = where & 15, rc;
-    if (where < 0 || pl < 1 || stride != r->linesize[pl])
+    if (where < 0 || pl < 1 || r->cfmt == 3 || stride != r->linesize[pl])
         FAIL(FFHIP_EINVAL);
     locate_src(r, pl, src, 0, &c.src_offset, &c.flags, &c.src_x, &c.src_y);
     c.w_idx = (uint8_t)w_idx;
@@ -152,6 +157,7 @@ static void rec_chroma(int avg, int w_idx, uint8_t *dst, const uint8_t *src, ptr
         if (r->npend >= 8)
             FAIL(FFHIP_EINVAL);
         r->pend[r->npend].plane = pl;
+        r->pend[r->npend].luma_tab = 0;
         r->pend[r->npend].tmp = dst;
         r->pend[r->npend].c = c;
         r->npend++;
@@ -188,9 +194,9 @@ static void rec_weight(int w_idx, int bi, uint8_t *dst, const uint8_t *src, ptrd
                 r->pend[k++] = *p;
                 continue;
             }
-            if (pl == 0) {
+            if (p->luma_tab) {
                 p->q.dst_offset = w.dst_offset + (int32_t)(p->tmp - src);
-                rc = ffhip_h264_picture_mc_luma(r->pic, FFHIP_H264_MC_TMP, &p->q);
+                rc = ffhip_h264_picture_mc_luma_plane(r->pic, pl, FFHIP_H264_MC_TMP, &p->q);
             } else {
                 p->c.dst_offset = w.dst_offset + (int32_t)(p->tmp - src);
                 rc = ffhip_h264_picture_mc_chroma(r->pic, pl, FFHIP_H264_MC_TMP, &p->c);
@@ -286,7 +292,8 @@ static void rec_edge(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int be
     int pl = classify_dst(r, pix), x, y, e;
     ptrdiff_t o;
     FFHipH264Edge *E;
-    if (pl < 0 || pl > 2 || (pl != 0) != chroma || stride != r->linesize[pl])
+    /* 4:4:4: the luma members on every plane (filter_mb_edgev / edgeh on img_cb / img_cr, h264_loopfilter.c:601-703) */
+    if (pl < 0 || pl > 2 || (r->cfmt == 3 ? chroma : (pl != 0) != chroma) || stride != r->linesize[pl])
         FAIL(FFHIP_EINVAL);
     o = pix - r->cur[pl];
     y = (int)(o / stride);
@@ -354,12 +361,13 @@ void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, con
     memset(r, 0, sizeof(*r));
     r->pic = pic;
     r->pixel_shift = h->pixel_shift;
-    r->pic_w = 16 * h->mb_width;
+    r->cfmt = h->ps.sps->chroma_format_idc;
     for (int pl = 0; pl < 3; pl++) {
         r->cur[pl] = h->cur_pic.f->data[pl];
         r->ref_base[pl] = ref_base[pl];
         r->linesize[pl] = pl ? sl->uvlinesize : sl->linesize;
-        r->rows[pl] = h->mb_height * (pl ? 8 : 16);
+        r->pic_w[pl] = h->mb_width * (pl && r->cfmt != 3 ? 8 : 16);
+        r->rows[pl] = h->mb_height * (pl && r->cfmt == 1 ? 8 : 16);
     }
     r->scratch = sl->bipred_scratchpad;
     r->scratch_size = (size_t)16 * sl->uvlinesize + (size_t)16 * sl->linesize; /* tmp_y starts 16 chroma rows in and is 16 luma rows tall */
@@ -372,7 +380,7 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
     const int mb_type = h->cur_pic.mb_type[sl->mb_xy];
     if (r->error < 0)
         return r->error;
-    if (MB_FIELD(sl) || FRAME_MBAFF(h) || CHROMA444(h) || CHROMA422(h) || !h->ps.sps->chroma_format_idc ||
+    if (MB_FIELD(sl) || FRAME_MBAFF(h) || CHROMA422(h) || !h->ps.sps->chroma_format_idc ||
         (sl->qscale == 0 && h->ps.sps->transform_bypass))
         return r->error = FFHIP_ENOSYS;   /* such a picture stays on the C path as a whole */
     if (IS_INTRA(mb_type)) {
@@ -389,7 +397,9 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
         m.topright_avail = (uint16_t)sl->topright_samples_available;
         for (int i = 0; i < 16; i++)
             m.pred4[i] = (uint8_t)sl->intra4x4_pred_mode_cache[scan8[i]];
-        /* luma_dc_dequant_idct's and chroma_dc_dequant_idct's qmul (h264_mb.c:707-711, h264_mb_template.c:246-253) */
+        /* luma_dc_dequant_idct's and chroma_dc_dequant_idct's qmul (h264_mb.c:707-711, h264_mb_template.c:246-253); 4:4:4: the same
+         * three table entries are plane p's luma_dc_dequant_idct qmul, dequant4_coeff[p][p ? chroma_qp[p - 1] : qscale][0] (h264_mb.c:626,
+         * 712), and sl->mb / sl->mb_luma_dc / the cache hold the three planes one after the other (libffhip splits them) */
         m.qmul[0] = h->ps.pps->dequant4_coeff[intra_qmul][sl->qscale][0];
         m.qmul[1] = h->ps.pps->dequant4_coeff[1][sl->chroma_qp[0]][0];
         m.qmul[2] = h->ps.pps->dequant4_coeff[2][sl->chroma_qp[1]][0];
@@ -418,8 +428,9 @@ int ff_h264_hip_filter_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceC
     cur_rec = r;
     {
         uint8_t *y  = (uint8_t *)r->cur[0] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[0]) * 16;
-        uint8_t *cb = (uint8_t *)r->cur[1] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[1]) * 8;
-        uint8_t *cr = (uint8_t *)r->cur[2] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[2]) * 8;
+        const int cs = r->cfmt == 3 ? 16 : 8; /* the chroma planes' macroblock size */
+        uint8_t *cb = (uint8_t *)r->cur[1] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[1]) * cs;
+        uint8_t *cr = (uint8_t *)r->cur[2] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[2]) * cs;
         ff_h264_filter_mb(h, sl, mb_x, mb_y, y, cb, cr, (unsigned)r->linesize[0], (unsigned)r->linesize[1]);
     }
     cur_rec = NULL;

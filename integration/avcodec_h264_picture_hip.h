@@ -16,6 +16,7 @@
 typedef struct FFHipH264Recorder {
     FFHipH264Picture *pic;
     int pixel_shift;
+    int cfmt;                       /* sps->chroma_format_idc: 1, or 3 (Cb / Cr through the luma members, hl_decode_mb_444) */
     int error;                      /* first libffhip error (< 0), sticky until begin() */
     /* the picture being decoded: h->cur_pic.f->data[] as the DEVICE addresses of the hip frame, and the base every reference
      * picture's data[] is counted from (the decoded-picture-buffer allocation: what ffhip_h264_picture_flush() gets as ref[]) */
@@ -23,9 +24,9 @@ typedef struct FFHipH264Recorder {
     const uint8_t *ref_base[3];
     ptrdiff_t linesize[3];
     int rows[3];
-    int pic_w;                      /* luma samples per row */
+    int pic_w[3];                   /* samples per row of the plane */
     const H264SliceContext *sl;     /* the slice context of the running hl_decode_mb() call (its reference lists) */
-    const uint8_t *last_ref;        /* data[0] of the reference picture the last luma block read */
+    const uint8_t *last_ref[3];     /* data[pl] of the reference picture the last luma-table block of the plane read */
     const uint8_t *scratch;         /* sl->bipred_scratchpad and its size: never dereferenced, only recognised */
     size_t scratch_size;
     const uint8_t *emu_buf;         /* sl->edge_emu_buffer, likewise */
@@ -38,7 +39,7 @@ typedef struct FFHipH264Recorder {
     } emu;
     /* predictions put into sl->bipred_scratchpad wait here for the biweight call that names their destination */
     struct FFHipH264Pending {
-        int plane;
+        int plane, luma_tab;        /* luma_tab: a qpel record (q), else a chroma MC record (c) */
         const uint8_t *tmp;
         FFHipQpelBlock q;
         FFHipChromaBlock c;

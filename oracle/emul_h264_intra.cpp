@@ -22,7 +22,9 @@ struct EmulWave {
 };
 } // namespace
 
-static int g_split; /* the kernel's two-wavefront form: the whole picture's luma, then the whole picture's chroma */
+/* 1: the kernel's two-wavefront form: the whole picture's luma, then the whole picture's chroma; 2: the luma-only form (a plane of a
+ * 4:4:4 picture: py is that plane, the records its luma-only ones, pcb / pcr are not touched) */
+static int g_split;
 extern "C" void ffemul_h264_intra_set_split(int on) { g_split = on; }
 
 template <typename PIX>
@@ -35,7 +37,7 @@ static int intra_frame(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, pt
     static uint32_t p4tab[IMB_TABS]; /* the kernel's copy lives in LDS */
     for (int i = 0; i < IMB_TABS; i++)
         p4tab[i] = imb_tab(i);
-    for (int pass = 0; pass < (g_split ? 2 : 1); pass++)
+    for (int pass = 0; pass < (g_split == 1 ? 2 : 1); pass++)
     for (int my = 0, parts = g_split ? 1 + pass : 3; my < mb_h; my++)
         for (int k = row_start[my]; k < row_start[my + 1]; k++) {
             const FFHipH264IntraMB &R = recs[k];

@@ -160,7 +160,7 @@ typedef struct FFRefH264Dec {
     AVFrame *f;
     AVCodecContext *avctx;
     H264Picture *refpics;     /* parents of the H264Ref entries (await_references reads ->parent only under frame threading) */
-    int record, bit_depth, mb_w, mb_h;
+    int record, bit_depth, mb_w, mb_h, cfmt;
 #ifdef FFREF_WITH_HIP
     FFHipH264Recorder rec;
 #endif
@@ -200,8 +200,17 @@ void FN(h264dec_close)(FFRefH264Dec *d)
     av_free(d);
 }
 
+FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesize, int uvlinesize, int record, int chroma_format_idc);
+
 /* linesize / uvlinesize in bytes.  record != 0 only in the hip build. */
 FFRefH264Dec *FN(h264dec_open)(int bit_depth, int mb_w, int mb_h, int linesize, int uvlinesize, int record)
+{
+    return FN(h264dec_open_fmt)(bit_depth, mb_w, mb_h, linesize, uvlinesize, record, 1);
+}
+
+/* ... of sps->chroma_format_idc 1 (4:2:0) or 3 (4:4:4: ff_h264_hl_decode_mb() takes hl_decode_mb_444, h264_mb.c:807-811; the chroma
+ * planes have the luma geometry and uvlinesize == linesize as the decoder allocates them) */
+FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesize, int uvlinesize, int record, int chroma_format_idc)
 {
     const int ps = bit_depth > 8;
     FFRefH264Dec *d = av_mallocz(sizeof(*d));
@@ -211,8 +220,11 @@ FFRefH264Dec *FN(h264dec_open)(int bit_depth, int mb_w, int mb_h, int linesize, 
     if (record)
         return NULL;
 #endif
-    if (!d)
+    if (!d || (chroma_format_idc != 1 && chroma_format_idc != 3) || (chroma_format_idc == 3 && uvlinesize != linesize)) {
+        av_free(d);
         return NULL;
+    }
+    d->cfmt = chroma_format_idc;
     d->h = h = av_mallocz(sizeof(*h));
     d->sl = sl = av_mallocz(sizeof(*sl));
     d->sps = av_mallocz(sizeof(SPS));
@@ -226,9 +238,9 @@ FFRefH264Dec *FN(h264dec_open)(int bit_depth, int mb_w, int mb_h, int linesize, 
     d->bit_depth = bit_depth;
     d->mb_w = mb_w;
     d->mb_h = mb_h;
-    d->sps->chroma_format_idc = 1;
+    d->sps->chroma_format_idc = chroma_format_idc;
     d->sps->bit_depth_luma = d->sps->bit_depth_chroma = bit_depth;
-    d->sps->profile_idc = 100;
+    d->sps->profile_idc = chroma_format_idc == 3 ? 244 : 100;
     d->sps->mb_width = mb_w;
     d->sps->mb_height = mb_h;
     for (int k = 0; k < 6; k++)
@@ -240,16 +252,16 @@ FFRefH264Dec *FN(h264dec_open)(int bit_depth, int mb_w, int mb_h, int linesize, 
     h->ps.pps = d->pps;
     h->avctx = d->avctx;               /* active_thread_type = 0: hl_motion() does not wait for reference rows */
     h->pixel_shift = ps;
-    h->chroma_x_shift = h->chroma_y_shift = 1;
+    h->chroma_x_shift = h->chroma_y_shift = chroma_format_idc == 1;
     h->mb_width = mb_w;
     h->mb_height = mb_h;
     h->mb_stride = mb_w + 1;
     h->mb_num = mb_w * mb_h;
     h->picture_structure = PICT_FRAME;
-    ff_h264dsp_init(&h->h264dsp, bit_depth, 1);
+    ff_h264dsp_init(&h->h264dsp, bit_depth, chroma_format_idc);
     ff_h264qpel_init(&h->h264qpel, bit_depth);
     ff_h264chroma_init(&h->h264chroma, bit_depth);
-    ff_h264_pred_init(&h->hpc, AV_CODEC_ID_H264, bit_depth, 1);
+    ff_h264_pred_init(&h->hpc, AV_CODEC_ID_H264, bit_depth, chroma_format_idc);
     ff_videodsp_init(&h->vdsp, bit_depth);
 #ifdef FFREF_WITH_HIP
     if (record)
@@ -403,8 +415,9 @@ int FN(h264dec_decode_intra)(FFRefH264Dec *d, int mb_x, int mb_y, int type, int 
     sl->intra_pcm_ptr = intra_pcm_ptr;
     for (int i = 0; i < 16; i++)
         sl->intra4x4_pred_mode_cache[scan8[i]] = intra4x4_pred_mode[i];
-    if (mb_luma_dc)
-        memcpy(sl->mb_luma_dc[0], mb_luma_dc, (sizeof(int16_t) << ps) * 16);
+    if (mb_luma_dc) /* 4:4:4: 3 x 16 dctcoef, plane by plane, into sl->mb_luma_dc[0..2] (each 16 * 2 int16 whatever the depth) */
+        for (int p = 0; p < (d->cfmt == 3 ? 3 : 1); p++)
+            memcpy(sl->mb_luma_dc[p], (const uint8_t *)mb_luma_dc + (sizeof(int16_t) << ps) * 16 * p, (sizeof(int16_t) << ps) * 16);
     d->pps->dequant4_buffer[0][sl->qscale][0] = qmul[0];
     d->pps->dequant4_buffer[1][sl->chroma_qp[0]][0] = qmul[1];
     d->pps->dequant4_buffer[2][sl->chroma_qp[1]][0] = qmul[2];
@@ -456,8 +469,9 @@ int FN(h264dec_filter_mb)(FFRefH264Dec *d, int mb_x, int mb_y, const int *ints, 
         return ff_h264_hip_filter_mb(&d->rec, h, sl, mb_x, mb_y);
 #endif
     ff_h264_filter_mb(h, sl, mb_x, mb_y, d->f->data[0] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->linesize) * 16,
-                      d->f->data[1] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * 8,
-                      d->f->data[2] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * 8, sl->linesize, sl->uvlinesize);
+                      d->f->data[1] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * (d->cfmt == 3 ? 16 : 8),
+                      d->f->data[2] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * (d->cfmt == 3 ? 16 : 8), sl->linesize,
+                      sl->uvlinesize);
     return 0;
 }
 

