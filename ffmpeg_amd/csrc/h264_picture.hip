@@ -153,11 +153,12 @@ extern "C" int ffhip_h264_picture_create_fmt(FFHipH264Picture **pp, int mb_w, in
         ffhip_set_error("ffhip_h264_picture_create_hbd: bit depth %d (8, 9, 10, 12 and 14 are the depths H.264 defines)", bit_depth);
         return FFHIP_EINVAL;
     }
-    if (!ffhip_have_device())
-        return FFHIP_ENOSYS;
+    /* Recording is host work and needs no device (the decoder's macroblock loop can be exercised, and the lists inspected through
+     * ffhip_h264_picture_lists(), on any machine); an object made without one refuses flush() with FFHIP_ENOSYS. */
+    const bool have_dev = ffhip_have_device() != 0;
     FFHipH264Picture *p = new (std::nothrow) FFHipH264Picture();
     if (p)
-        p->device = ffhip_current_device();
+        p->device = have_dev ? ffhip_current_device() : -1;
     if (!p)
         return FFHIP_ENOMEM;
     p->mb_w = mb_w;
@@ -167,6 +168,10 @@ extern "C" int ffhip_h264_picture_create_fmt(FFHipH264Picture **pp, int mb_w, in
     const size_t nmb = (size_t)mb_w * mb_h;
     for (int pl = 0; pl < 3; pl++)
         p->edges[pl].assign(nmb * (size_t)p->edges_per_mb(pl), FFHipH264Edge());
+    if (!have_dev) {
+        *pp = p;
+        return 0;
+    }
     if (hipEventCreateWithFlags(&p->copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess ||
@@ -504,6 +509,41 @@ extern "C" int ffhip_h264_intra_frames_dev(int bit_depth, int npics, const FFHip
     return ffhip_launch_h264_intra_frames_bd(bit_depth, npics, pics, stride_y, stride_c, mb_w, mb_h, (hipStream_t)stream);
 }
 
+/* what has been recorded since begin(), as it stands: pointers into the object, valid until the next record call */
+extern "C" int ffhip_h264_picture_lists(const FFHipH264Picture *p, FFHipH264PictureLists *out)
+{
+    if (!p || !out)
+        return FFHIP_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->mb_w = p->mb_w;
+    out->mb_h = p->mb_h;
+    out->bit_depth = p->bd;
+    out->chroma_format_idc = p->cfmt;
+    for (int pl = 0; pl < 3; pl++) {
+        for (int s = 0; s < 3; s++) {
+            out->qpel[pl][s] = p->qpel[pl][s].data();
+            out->nqpel[pl][s] = (int)p->qpel[pl][s].size();
+            if (pl) {
+                out->cmc[pl - 1][s] = p->cmc[pl - 1][s].data();
+                out->ncmc[pl - 1][s] = (int)p->cmc[pl - 1][s].size();
+            }
+        }
+        out->wt[pl] = p->wt[pl].data();
+        out->nwt[pl] = (int)p->wt[pl].size();
+        for (int k = 0; k < 4; k++) {
+            out->idct_off[pl][k] = p->idct_off[pl][k].data();
+            out->idct_coef[pl][k] = p->idct_coef[pl][k].data();
+            out->nidct[pl][k] = (int)p->idct_off[pl][k].size();
+        }
+        out->intra[pl] = p->intra[pl].data();
+        out->nintra[pl] = (int)p->intra[pl].size();
+        out->intra_coef[pl] = p->intra_coef[pl].data();
+        out->nintra_coef[pl] = (int)p->intra_coef[pl].size();
+        out->edges[pl] = p->any_edge[pl] ? p->edges[pl].data() : nullptr;
+    }
+    return 0;
+}
+
 extern "C" int ffhip_h264_intra_planes_dev(int bit_depth, int nplanes, const FFHipH264IntraPic *planes, ptrdiff_t stride, int mb_w, int mb_h,
                                            void *stream)
 {
@@ -590,6 +630,10 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
     for (int pl = 0; pl < 3; pl++)
         if (!dst[pl] || !ref[pl] || stride[pl] <= 0)
             return FFHIP_EINVAL;
+    if (p->device < 0) {
+        ffhip_set_error("ffhip_h264_picture_flush: the picture object was made without a HIP device (records only)");
+        return FFHIP_ENOSYS;
+    }
     /* a finished deblocking wavefront (an earlier picture's) that lost a hand-off is reported now rather than never */
     {
         /* (the chroma planes' wavefront runs on the picture's second stream but files its failures under the caller's) */

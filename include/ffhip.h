@@ -779,6 +779,36 @@ int  ffhip_h264_intra_frames_dev(int bit_depth, int npics, const FFHipH264IntraP
  *  (ffhip_h264_intra_pack_plane); cb / cr are not touched (pass y). */
 int  ffhip_h264_intra_planes_dev(int bit_depth, int nplanes, const FFHipH264IntraPic *planes /* host array */, ptrdiff_t stride, int mb_w, int mb_h,
                                  void *stream);
+/** What has been recorded since begin(), as it stands: the lists flush() copies to the device, by the stage and plane it runs them in
+ *  (pointers into the object, valid until the next record call or begin(); a list with no entry may be NULL).  Recording needs no HIP
+ *  device — ffhip_h264_picture_create*() succeed without one and only flush() returns FFHIP_ENOSYS then — so a decoder's macroblock loop
+ *  over the recording members can be checked on any machine (tests/test_h264_picture_cpu.py runs the lists through the oracle's dsp
+ *  functions in flush()'s order and compares with the reference's own decode).
+ *    qpel[plane][stage]  luma-table MC (4:2:0: plane 0 only), stage FFHIP_H264_MC_PUT / _TMP / _AVG
+ *    cmc[plane - 1][stage]  chroma MC of Cb / Cr (4:2:0)
+ *    wt[plane]           weight / biweight calls (a biweight's src_offset addresses the plane's bi-prediction scratch)
+ *    idct_off / idct_coef[plane][kind]  residual blocks by FFHIP_H264_IDCT4 / IDCT8 / IDCT4_DC / IDCT8_DC: nidct offsets, 16 or 64 dctcoef each
+ *    intra[set] / intra_coef[set]  intra macroblock records in recording order and their packed runs (int16 units): set 0 = whole
+ *                        macroblocks (4:2:0), or one luma-only set per plane (4:4:4)
+ *    edges[plane]        mb_w * mb_h * (8 | 4) edge records (zero records = not filtered), NULL when the plane has none */
+typedef struct FFHipH264PictureLists {
+    int mb_w, mb_h, bit_depth, chroma_format_idc;
+    const FFHipQpelBlock *qpel[3][3];
+    int nqpel[3][3];
+    const FFHipChromaBlock *cmc[2][3];
+    int ncmc[2][3];
+    const FFHipWeightBlock *wt[3];
+    int nwt[3];
+    const int32_t *idct_off[3][4];
+    const int16_t *idct_coef[3][4];
+    int nidct[3][4];
+    const FFHipH264IntraMB *intra[3];
+    int nintra[3];
+    const int16_t *intra_coef[3];
+    int nintra_coef[3];
+    const FFHipH264Edge *edges[3];
+} FFHipH264PictureLists;
+int  ffhip_h264_picture_lists(const FFHipH264Picture *p, FFHipH264PictureLists *out);
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
 int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                               void *stream);

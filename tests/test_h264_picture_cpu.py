@@ -1,0 +1,186 @@
+"""The H.264 picture layer's HOST side, without a GPU.
+
+The same experiment as tests/test_gpu_h264_decoder.py — the reference's own ff_h264_hl_decode_mb() / ff_h264_filter_mb() driven twice over
+the same decoder state: once with the C dsp tables on host planes (the expected picture), once over the recording members of
+integration/avcodec_h264_picture_hip.c into an FFHipH264Picture — but the recorded lists (ffhip_h264_picture_lists) are then executed on the
+CPU by oracle/emul_h264_picture.cpp: flush()'s stage order, the oracle's dsp functions (pinned to the reference), the wavefront kernel's
+per-macroblock phases lane by lane for the intra records.  Recording needs no device, so this pins on any machine what the recorder and
+libffhip's host code decide: which member becomes which record on which plane, offsets, FFHIP_MC_EMU coordinates on unpadded references,
+the scratchpad's bookkeeping, weights, the residual dispatch, the intra packing, the edge tables — at 4:2:0 and 4:4:4, 8 bits and above."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ffi
+import h264_intra_gen as G
+import h264_inter_gen as I
+
+EMUL_SO = os.path.join(ffi.ROOT, "oracle", "libffemul.so")
+pytestmark = pytest.mark.skipif(not (ffi.have_ref() and I.have_ref_hip() and os.path.exists(EMUL_SO)), reason="oracle/_ref or libffemul.so not built")
+
+
+class Lists(C.Structure):                       # == FFHipH264PictureLists (include/ffhip.h)
+    _fields_ = [("mb_w", C.c_int), ("mb_h", C.c_int), ("bit_depth", C.c_int), ("chroma_format_idc", C.c_int),
+                ("qpel", (C.c_void_p * 3) * 3), ("nqpel", (C.c_int * 3) * 3), ("cmc", (C.c_void_p * 3) * 2), ("ncmc", (C.c_int * 3) * 2),
+                ("wt", C.c_void_p * 3), ("nwt", C.c_int * 3), ("idct_off", (C.c_void_p * 4) * 3), ("idct_coef", (C.c_void_p * 4) * 3),
+                ("nidct", (C.c_int * 4) * 3), ("intra", C.c_void_p * 3), ("nintra", C.c_int * 3), ("intra_coef", C.c_void_p * 3),
+                ("nintra_coef", C.c_int * 3), ("edges", C.c_void_p * 3)]
+
+
+def _env():
+    from ffmpeg_amd import _lib
+    L = _lib.lib()                              # libffhip.so first: libffref_hip.so binds to the instance the package uses
+    RH = C.CDLL(I.REF_HIP_SO)
+    E = C.CDLL(EMUL_SO)
+    E.ffemul_h264_picture_flush.argtypes = [C.c_void_p] * 4
+    RH.ffrefhip_h264dec_record_begin.argtypes = [C.c_void_p] * 5
+    RH.ffrefhip_h264dec_record_begin.restype = None
+    return _lib, L, ffi.ref(), RH, E
+
+
+class HostPicture:
+    """an FFHipH264Picture made where there may be no device: records only"""
+
+    def __init__(self, _lib, L, mb_w, mb_h, depth, cfmt):
+        self.L, self.p = L, _lib.vp()
+        assert L.ffhip_h264_picture_create_fmt(C.byref(self.p), mb_w, mb_h, depth, cfmt) == 0
+        L.ffhip_h264_picture_begin(self.p)
+
+    def lists(self):
+        ls = Lists()
+        assert self.L.ffhip_h264_picture_lists(self.p, C.byref(ls)) == 0
+        return ls
+
+    def close(self):
+        self.L.ffhip_h264_picture_free(C.byref(self.p))
+
+
+def _cpu_flush(E, ls, planes, strides, refs):
+    dp = (C.c_void_p * 3)(*[a.ctypes.data for a in planes])
+    rp = (C.c_void_p * 3)(*[a.ctypes.data for a in refs])
+    st = (C.c_int * 3)(*strides)
+    assert E.ffemul_h264_picture_flush(C.byref(ls), dp, st, rp) == 0
+
+
+def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed):
+    _lib, L, R, RH, E = _env()
+    rng = np.random.default_rng(seed)
+    px, dt, top = (2, np.uint16, 1 << depth) if depth > 8 else (1, np.uint8, 256)
+    W, H = mb_w * 16, mb_h * 16
+    sy = W + int(rng.integers(0, 3)) * 16                   # row pitches in samples: NO border around a picture, only row padding
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    ls_, uvls = sy * px, sc * px
+    strides = [ls_, uvls, uvls]
+    rows = [H, HC, HC]
+    refs = [rng.integers(0, top, (nref * rows[pl], strides[pl] // px), dtype=dt) for pl in range(3)]
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls_, uvls, 0, cfmt=cfmt)
+    rec = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, ls_, uvls, 1, cfmt=cfmt)
+    for lst in (0, 1):
+        for i in range(nref):
+            j = i if lst == 0 else nref - 1 - i
+            at = [refs[pl].ctypes.data + j * rows[pl] * strides[pl] for pl in range(3)]
+            cpu.set_ref(lst, i, at)
+            rec.set_ref(lst, i, at)
+    pw = I.make_pwt(rng, weights, depth, nref)
+    cpu.set_pwt(pw)
+    rec.set_pwt(pw)
+    dst0 = [rng.integers(0, top, (rows[pl], strides[pl] // px), dtype=dt) for pl in range(3)]
+    want, got = [a.copy() for a in dst0], [a.copy() for a in dst0]
+    cpu.set_cur([a.ctypes.data for a in want])
+    rec.set_cur([a.ctypes.data for a in got])               # record mode: addresses only, nothing is read or written through them
+    pic = HostPicture(_lib, L, mb_w, mb_h, depth, cfmt)
+    RH.ffrefhip_h264dec_record_begin(rec.d, pic.p, *[r.ctypes.data for r in refs])
+    for my in range(mb_h):
+        for mx in range(mb_w):
+            if rng.random() < p_intra:
+                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=depth, cfmt=cfmt)
+                a, b = cpu.decode_intra(d), rec.decode_intra(d)
+                assert d["type"] == G.PCM or np.array_equal(a, b)         # sl->mb consumed alike
+            else:
+                m = I.make_inter_mb(rng, cpu.bits, mx, my, nref, mvr, depth=depth, cfmt=cfmt)
+                assert np.array_equal(cpu.decode_inter(m), rec.decode_inter(m))
+    for pl in range(3):
+        assert np.array_equal(got[pl], dst0[pl])             # recording touched no sample
+    ls = pic.lists()
+    assert (ls.mb_w, ls.mb_h, ls.bit_depth, ls.chroma_format_idc) == (mb_w, mb_h, depth, cfmt)
+    if cfmt == 3:
+        assert not any(ls.ncmc[c][s] for c in range(2) for s in range(3))
+        assert p_intra >= 1 or all(ls.nqpel[pl][0] for pl in range(3))
+    else:
+        assert not any(ls.nqpel[pl][s] for pl in (1, 2) for s in range(3)) and not ls.nintra[1] and not ls.nintra[2]
+    _cpu_flush(E, ls, got, strides, refs)
+    for pl in range(3):
+        assert (want[pl] != dst0[pl]).sum() > 100 and want[pl].max() < top
+        bad = got[pl] != want[pl]
+        assert not bad.any(), "plane %d: %d mismatches, first at %s" % (pl, bad.sum(), np.argwhere(bad)[0])
+    pic.close()
+    cpu.close()
+    rec.close()
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,nref,mvr,p_intra,weights", [
+    (8, 6, 4, 2, 40, 0.0, 0), (8, 6, 4, 2, 600, 0.0, 0), (8, 11, 7, 3, 4000, 0.0, 1), (8, 11, 7, 3, 300, 0.0, 2), (8, 20, 11, 2, 120, .15, 1),
+    (8, 9, 5, 1, 64, 1.0, 0), (10, 7, 5, 2, 600, .2, 1), (12, 6, 4, 2, 400, .2, 2)])
+def test_recorded_picture_executed_on_cpu_equals_reference_420(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
+    _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, 1, seed=depth * 1000 + mb_w * 31 + mvr + weights)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,nref,mvr,p_intra,weights", [
+    (8, 6, 4, 2, 40, 0.0, 0), (8, 11, 7, 3, 2000, 0.0, 1), (8, 11, 7, 3, 300, 0.0, 2), (8, 9, 5, 1, 64, 1.0, 0), (8, 20, 11, 2, 120, .15, 1),
+    (10, 7, 5, 2, 600, .2, 1), (12, 6, 4, 2, 500, .3, 0), (14, 6, 4, 2, 400, .2, 2)])
+def test_recorded_picture_executed_on_cpu_equals_reference_444(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
+    """hl_decode_mb_444 (libavcodec/h264_mb_template.c:256-362) over the recording members: the luma tables on Cb / Cr, three luma-only
+    intra records per macroblock"""
+    _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, 3, seed=4440000 + depth * 1000 + mb_w * 31 + mvr + weights)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,p_intra,cfmt", [(8, 6, 4, .2, 1), (8, 20, 11, .15, 1), (10, 7, 5, .2, 1), (8, 6, 4, .2, 3), (8, 20, 11, .15, 3),
+                                                           (8, 9, 5, 1.0, 3), (10, 7, 5, .2, 3), (12, 6, 4, .3, 3)])
+def test_recorded_deblocking_executed_on_cpu_equals_reference(depth, mb_w, mb_h, p_intra, cfmt):
+    """ff_h264_filter_mb() (libavcodec/h264_loopfilter.c:716) over the recording loop-filter members -> the picture's edge tables ->
+    the oracle's frame-order filter == the reference's C filter, macroblock by macroblock in raster order; 4:4:4: the luma members on all
+    three planes (h264_loopfilter.c:601-703)"""
+    _lib, L, R, RH, E = _env()
+    rng = np.random.default_rng(depth * 100 + mb_w + mb_h + cfmt)
+    px, dt = (2, np.uint16) if depth > 8 else (1, np.uint8)
+    W, H = mb_w * 16, mb_h * 16
+    sy = W + 32
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    strides = [sy * px, sc * px, sc * px]
+    mid, amp = 1 << (depth - 1), 20 << (depth - 8)
+    dst0 = [(mid + rng.integers(-amp, amp + 1, (r, s))).astype(dt) for r, s in ((H, sy), (HC, sc), (HC, sc))]
+    want, got = [a.copy() for a in dst0], [a.copy() for a in dst0]
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, strides[0], strides[1], 0, cfmt=cfmt)
+    rec = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, strides[0], strides[1], 1, cfmt=cfmt)
+    cpu.set_cur([a.ctypes.data for a in want])
+    rec.set_cur([a.ctypes.data for a in got])
+    pic = HostPicture(_lib, L, mb_w, mb_h, depth, cfmt)
+    RH.ffrefhip_h264dec_record_begin(rec.d, pic.p, *[a.ctypes.data for a in got])
+    for st in I.make_filter_picture(rng, cpu.bits, mb_w, mb_h, depth, p_intra):
+        cpu.filter_mb(st["mb_x"], st["mb_y"], st)
+        rec.filter_mb(st["mb_x"], st["mb_y"], st)
+    ls = pic.lists()
+    assert all(ls.edges[pl] for pl in range(3))
+    _cpu_flush(E, ls, got, strides, got)
+    for pl in range(3):
+        assert (want[pl] != dst0[pl]).sum() > 50
+        bad = got[pl] != want[pl]
+        assert not bad.any(), "plane %d: %d mismatches, first at %s" % (pl, bad.sum(), np.argwhere(bad)[0])
+    pic.close()
+    cpu.close()
+    rec.close()
+
+
+def test_flush_without_a_device_is_refused_by_name():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    _lib, L, R, RH, E = _env()
+    pic = HostPicture(_lib, L, 4, 4, 8, 1)
+    a = np.zeros((64, 64), np.uint8)
+    dp = (C.c_void_p * 3)(a.ctypes.data, a.ctypes.data, a.ctypes.data)
+    st = (C.c_int * 3)(64, 64, 64)
+    assert L.ffhip_h264_picture_flush(pic.p, dp, st, dp, None) == _lib.ENOSYS
+    pic.close()
