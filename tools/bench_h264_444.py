@@ -71,7 +71,7 @@ if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     if not (ffi.have_ref() and I.have_ref_hip()):
         sys.exit("oracle/_ref not built")
-    for depth in (8, 10):
+    for depth in ((8, 10) if len(sys.argv) < 3 else (int(sys.argv[2]),)):
         for cfmt in (1, 3):
             for p_intra in (1.0, .05):
                 run(depth, cfmt, p_intra, reps)
