@@ -168,9 +168,11 @@ class Picture:
                           "ffhip_h264_picture_deblock_mb")
 
     def flush(self, dst, strides, ref, stream=None):
-        """dst / ref: three uint8 cuda tensors each (Y, Cb, Cr); strides: their row pitches in bytes"""
-        dp = (C.c_void_p * 3)(*[t.data_ptr() for t in dst])
-        rp = (C.c_void_p * 3)(*[t.data_ptr() for t in ref])
+        """dst / ref: three uint8 cuda tensors each (Y, Cb, Cr) — or device addresses as ints (a field: the frame plane's address + one
+        line for the bottom field, with twice the line size as stride); strides: the row pitches in bytes"""
+        ptr = lambda t: t if isinstance(t, int) else t.data_ptr()
+        dp = (C.c_void_p * 3)(*[ptr(t) for t in dst])
+        rp = (C.c_void_p * 3)(*[ptr(t) for t in ref])
         st = (C.c_int * 3)(*strides)
         return _lib.check(_lib.lib().ffhip_h264_picture_flush(self._p, dp, st, rp, _stream(stream)), "ffhip_h264_picture_flush")
 

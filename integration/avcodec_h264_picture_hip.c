@@ -25,7 +25,12 @@
  * Intra macroblocks predict from reconstructed neighbours and cannot be a list of independent calls: they go to libffhip as ONE
  * record each (ffhip_h264_picture_intra_mb(), the reconstruction wavefront), built from the H264SliceContext fields hl_decode_mb()
  * would read.  4:2:0 and 4:4:4 (hl_decode_mb_444: the luma members on all three planes — the recorder only has to accept them there),
- * frame macroblocks, CAVLC / CABAC alike (entropy decoding stays on the CPU and fills sl-> as ever).
+ * frame macroblocks — or the field macroblocks of a FIELD picture (PAFF): a field is every second line of the frame buffer, i.e. a
+ * picture of half the height at twice the line size, which is how hl_decode_mb() itself addresses it (mb_linesize = 2 * linesize,
+ * block_offset[48..], odd rows one line down: h264_mb_template.c:61-78) and how the references' fields arrive (pic_as_field(),
+ * h264_refs.c:39-48); the libffhip picture object is made for the field and never learns the difference.  MBAFF frames (frame and
+ * field macroblock pairs mixed in one picture) stay on the C path.  CAVLC / CABAC alike (entropy decoding stays on the CPU and fills
+ * sl-> as ever).
  */
 #include <string.h>
 
@@ -43,10 +48,16 @@ static _Thread_local FFHipH264Recorder *cur_rec;   /* function pointers carry no
 #define FAIL(e) do { if (r->error >= 0) r->error = (e); return; } while (0)
 
 /* which plane of the current picture / of the scratchpad an address lies in: 0..2, 16 + plane for the scratchpad, -1 neither */
+/* bytes from a plane's first sample to the end of its last row (a field's last row ends one frame line before rows * linesize would) */
+static size_t plane_span(const FFHipH264Recorder *r, int pl)
+{
+    return (size_t)(r->rows[pl] - 1) * r->linesize[pl] + ((size_t)r->pic_w[pl] << r->pixel_shift);
+}
+
 static int classify_dst(const FFHipH264Recorder *r, const uint8_t *p)
 {
     for (int pl = 0; pl < 3; pl++)
-        if (p >= r->cur[pl] && p < r->cur[pl] + (size_t)r->rows[pl] * r->linesize[pl])
+        if (p >= r->cur[pl] && p < r->cur[pl] + plane_span(r, pl))
             return pl;
     if (p >= r->scratch && p < r->scratch + r->scratch_size) {
         /* tmp_cb = scratch, tmp_cr = scratch + (8 << pixel_shift + (chroma_idc == 3)), tmp_y = scratch + 16 * mb_uvlinesize
@@ -83,14 +94,17 @@ static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int need
     *sx = *sy = 0;
     if (need > 0) {
         /* which reference picture is it?  the one looked at last, nearly always */
-        const ptrdiff_t ls = r->linesize[pl], span = (ptrdiff_t)r->rows[pl] * ls;
+        const ptrdiff_t ls = r->linesize[pl], span = (ptrdiff_t)plane_span(r, pl);
+        /* (the two fields of one frame interleave in memory: a sample belongs to the field in whose lines it lies — its column, taken at
+         * the field's line size, falls inside the picture's width) */
+        const ptrdiff_t wbytes = (ptrdiff_t)r->pic_w[pl] << r->pixel_shift;
         const uint8_t *origin = r->last_ref[pl];
-        if (!origin || src < origin || src >= origin + span) {
+        if (!origin || src < origin || src >= origin + span || (src - origin) % ls >= wbytes) {
             origin = NULL;
             for (int l = 0; l < (int)r->sl->list_count && !origin; l++)
                 for (int i = 0; i < (int)r->sl->ref_count[l] && !origin; i++) {
                     const uint8_t *d = r->sl->ref_list[l][i].data[pl];
-                    if (d && src >= d && src < d + span)
+                    if (d && src >= d && src < d + span && (src - d) % ls < wbytes)
                         origin = d;
                 }
             if (!origin)
@@ -362,17 +376,22 @@ void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, con
     r->pic = pic;
     r->pixel_shift = h->pixel_shift;
     r->cfmt = h->ps.sps->chroma_format_idc;
+    r->field = FIELD_PICTURE(h) && !FRAME_MBAFF(h);
     for (int pl = 0; pl < 3; pl++) {
-        r->cur[pl] = h->cur_pic.f->data[pl];
+        const ptrdiff_t ls = pl ? sl->uvlinesize : sl->linesize;
+        /* a field: the lines of its parity, from the frame's first (top) or second (bottom) line on */
+        r->cur[pl] = h->cur_pic.f->data[pl] + (r->field && h->picture_structure == PICT_BOTTOM_FIELD ? ls : 0);
         r->ref_base[pl] = ref_base[pl];
-        r->linesize[pl] = pl ? sl->uvlinesize : sl->linesize;
+        r->linesize[pl] = ls << r->field;
         r->pic_w[pl] = h->mb_width * (pl && r->cfmt != 3 ? 8 : 16);
-        r->rows[pl] = h->mb_height * (pl && r->cfmt == 1 ? 8 : 16);
+        r->rows[pl] = (h->mb_height >> r->field) * (pl && r->cfmt == 1 ? 8 : 16);
     }
     r->scratch = sl->bipred_scratchpad;
-    r->scratch_size = (size_t)16 * sl->uvlinesize + (size_t)16 * sl->linesize; /* tmp_y starts 16 chroma rows in and is 16 luma rows tall */
+    /* tmp_y starts 16 chroma rows in and is 16 luma rows tall; both buffers are walked at mb_linesize (alloc_scratch_buffers(),
+     * h264_slice.c:168-200, sizes them for field macroblocks) */
+    r->scratch_size = (size_t)16 * r->linesize[1] + (size_t)16 * r->linesize[0];
     r->emu_buf = sl->edge_emu_buffer;
-    r->emu_size = (size_t)21 * sl->linesize + ((size_t)21 << h->pixel_shift);
+    r->emu_size = (size_t)21 * r->linesize[0] + ((size_t)21 << h->pixel_shift);
 }
 
 int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceContext *sl)
@@ -380,14 +399,14 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
     const int mb_type = h->cur_pic.mb_type[sl->mb_xy];
     if (r->error < 0)
         return r->error;
-    if (MB_FIELD(sl) || FRAME_MBAFF(h) || CHROMA422(h) || !h->ps.sps->chroma_format_idc ||
+    if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field || CHROMA422(h) || !h->ps.sps->chroma_format_idc ||
         (sl->qscale == 0 && h->ps.sps->transform_bypass))
         return r->error = FFHIP_ENOSYS;   /* such a picture stays on the C path as a whole */
     if (IS_INTRA(mb_type)) {
         FFHipH264IntraMB m = { 0 };
         const int intra_qmul = 0;
         m.mb_x = (int16_t)sl->mb_x;
-        m.mb_y = (int16_t)sl->mb_y;
+        m.mb_y = (int16_t)(sl->mb_y >> r->field);   /* a field picture: rows of the field (mb_y = 2 * row + bottom, h264_slice.c:2676-2680) */
         m.type = IS_INTRA_PCM(mb_type) ? FFHIP_H264_INTRA_PCM : IS_INTRA16x16(mb_type) ? FFHIP_H264_INTRA_16x16
                : IS_8x8DCT(mb_type) ? FFHIP_H264_INTRA_8x8 : FFHIP_H264_INTRA_4x4;
         m.pred16 = (uint8_t)sl->intra16x16_pred_mode;
@@ -422,20 +441,24 @@ int ff_h264_hip_filter_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceC
 {
     if (r->error < 0)
         return r->error;
+    if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field)
+        return r->error = FFHIP_ENOSYS;
     memset(&cur_edges, 0, sizeof(cur_edges));
     cur_edges.mb_x = mb_x;
-    cur_edges.mb_y = mb_y;
+    cur_edges.mb_y = mb_y >> r->field;     /* the row inside the field: what loop_filter()'s `dest -= linesize * 15` amounts to */
     cur_rec = r;
     {
-        uint8_t *y  = (uint8_t *)r->cur[0] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[0]) * 16;
-        const int cs = r->cfmt == 3 ? 16 : 8; /* the chroma planes' macroblock size */
-        uint8_t *cb = (uint8_t *)r->cur[1] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[1]) * cs;
-        uint8_t *cr = (uint8_t *)r->cur[2] + (((ptrdiff_t)mb_x << h->pixel_shift) + (ptrdiff_t)mb_y * r->linesize[2]) * cs;
+        const int cs = r->cfmt == 3 ? 16 : 8, fy = mb_y >> r->field; /* the chroma planes' macroblock size; the macroblock's row in `pic` */
+        uint8_t *y  = (uint8_t *)r->cur[0] + ((ptrdiff_t)mb_x << h->pixel_shift) * 16 + (ptrdiff_t)fy * r->linesize[0] * 16;
+        uint8_t *cb = (uint8_t *)r->cur[1] + ((ptrdiff_t)mb_x << h->pixel_shift) * cs + (ptrdiff_t)fy * r->linesize[1] * cs;
+        uint8_t *cr = (uint8_t *)r->cur[2] + ((ptrdiff_t)mb_x << h->pixel_shift) * cs + (ptrdiff_t)fy * r->linesize[2] * cs;
+        sl->mb_linesize = r->linesize[0];      /* as loop_filter() leaves them (h264_slice.c:2480-2491) */
+        sl->mb_uvlinesize = r->linesize[1];
         ff_h264_filter_mb(h, sl, mb_x, mb_y, y, cb, cr, (unsigned)r->linesize[0], (unsigned)r->linesize[1]);
     }
     cur_rec = NULL;
     for (int pl = 0; pl < 3 && r->error >= 0; pl++)
         if (cur_edges.any[pl])
-            r->error = FFMIN(0, ffhip_h264_picture_deblock_mb(r->pic, pl, mb_x, mb_y, cur_edges.e[pl]));
+            r->error = FFMIN(0, ffhip_h264_picture_deblock_mb(r->pic, pl, mb_x, mb_y >> r->field, cur_edges.e[pl]));
     return r->error;
 }

@@ -17,6 +17,7 @@ typedef struct FFHipH264Recorder {
     FFHipH264Picture *pic;
     int pixel_shift;
     int cfmt;                       /* sps->chroma_format_idc: 1, or 3 (Cb / Cr through the luma members, hl_decode_mb_444) */
+    int field;                      /* a field picture (PAFF): `pic` is the FIELD — every second line of the frame buffer from cur[] on */
     int error;                      /* first libffhip error (< 0), sticky until begin() */
     /* the picture being decoded: h->cur_pic.f->data[] as the DEVICE addresses of the hip frame, and the base every reference
      * picture's data[] is counted from (the decoded-picture-buffer allocation: what ffhip_h264_picture_flush() gets as ref[]) */
@@ -52,7 +53,10 @@ typedef struct FFHipH264Recorder {
  * ones; chroma_dc_dequant_idct and everything else stay what ff_h264dsp_init() left.  Call once after the decoder's own init. */
 void ff_h264_hip_recorder_install(H264Context *h);
 
-/* A new picture: `pic` was made for h->mb_width x h->mb_height at the stream's bit depth and has had begin() called. */
+/* A new picture: `pic` was made for h->mb_width x h->mb_height at the stream's bit depth and has had begin() called.
+ * A FIELD picture (h->picture_structure != PICT_FRAME, no MBAFF): `pic` was made for h->mb_width x h->mb_height / 2 — the field is a picture
+ * of its own whose lines are every second line of the frame buffer: flush() gets data[pl] (+ one line for the bottom field) as dst[pl]
+ * and TWICE the frame's line sizes as strides; the references' fields are addressed the same way through ref_base[]. */
 void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, const H264Context *h, const H264SliceContext *sl,
                                 const uint8_t *const ref_base[3]);
 

@@ -170,7 +170,8 @@ typedef struct FFRefH264Dec {
 int FN(h264dec_mb_type_bits)(int which)
 {
     static const int v[] = { MB_TYPE_16x16, MB_TYPE_16x8, MB_TYPE_8x16, MB_TYPE_8x8, MB_TYPE_P0L0, MB_TYPE_P1L0, MB_TYPE_P0L1, MB_TYPE_P1L1,
-                             MB_TYPE_8x8DCT, MB_TYPE_INTRA4x4, MB_TYPE_INTRA16x16, MB_TYPE_INTRA_PCM, MB_TYPE_DIRECT2, MB_TYPE_SKIP };
+                             MB_TYPE_8x8DCT, MB_TYPE_INTRA4x4, MB_TYPE_INTRA16x16, MB_TYPE_INTRA_PCM, MB_TYPE_DIRECT2, MB_TYPE_SKIP,
+                             MB_TYPE_INTERLACED };
     return which >= 0 && which < (int)(sizeof(v) / sizeof(v[0])) ? v[which] : -1;
 }
 
@@ -272,6 +273,9 @@ FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesi
         const int x = 4 * ((i & 1) + ((i >> 2) & 1) * 2), yy = 4 * (((i >> 1) & 1) + ((i >> 3) & 1) * 2);
         h->block_offset[i] = (x << ps) + yy * linesize;
         h->block_offset[16 + i] = h->block_offset[32 + i] = (x << ps) + yy * uvlinesize;
+        /* ... and of a field macroblock: every second line (h264_slice.c init_dimensions / ff_h264_field_start) */
+        h->block_offset[48 + i] = (x << ps) + 2 * yy * linesize;
+        h->block_offset[48 + 16 + i] = h->block_offset[48 + 32 + i] = (x << ps) + 2 * yy * uvlinesize;
     }
     h->cur_pic.f = d->f;
     h->cur_pic.mb_type = av_calloc((size_t)h->mb_stride * (mb_h + 1) + 1, sizeof(uint32_t));
@@ -322,6 +326,33 @@ void FN(h264dec_set_ref)(FFRefH264Dec *d, int list, int idx, uint8_t *y, uint8_t
     r->linesize[0] = d->sl->linesize;
     r->linesize[1] = r->linesize[2] = d->sl->uvlinesize;
     r->reference = PICT_FRAME;
+    if (d->sl->ref_count[list] < (unsigned)idx + 1)
+        d->sl->ref_count[list] = idx + 1;
+}
+
+/* A FIELD picture (PAFF): picture_structure = PICT_TOP_FIELD (1) / PICT_BOTTOM_FIELD (2), PICT_FRAME (3) back to frames.  The decoder then
+ * runs every macroblock as a field macroblock (sl->mb_field_decoding_flag, MB_FIELD(sl)): hl_decode_mb() doubles the line sizes, takes
+ * block_offset[48..] and starts odd rows one line down (h264_mb_template.c:61-78); mb_y of the calls below is the decoder's own — 2 * the
+ * field's macroblock row + (bottom field) (h264_slice.c:2676-2680,2759-2761) — and h->mb_height stays the FRAME's (even). */
+void FN(h264dec_set_field)(FFRefH264Dec *d, int picture_structure)
+{
+    d->h->picture_structure = picture_structure;
+    d->sl->mb_field_decoding_flag = picture_structure != PICT_FRAME;
+    d->sl->is_complex = picture_structure != PICT_FRAME;   /* h264_cavlc.c / h264_cabac.c: FRAME_MBAFF || picture_structure != PICT_FRAME */
+}
+
+/* sl->ref_list[list][idx] as a FIELD of a frame whose planes are given (h264_refs.c pic_as_field(), :44-59): the bottom field starts one
+ * line down, line sizes double, reference = the parity */
+void FN(h264dec_set_ref_field)(FFRefH264Dec *d, int list, int idx, uint8_t *y, uint8_t *cb, uint8_t *cr, int parity)
+{
+    H264Ref *r = &d->sl->ref_list[list][idx];
+    const int bottom = parity == PICT_BOTTOM_FIELD;
+    r->data[0] = y + (bottom ? d->sl->linesize : 0);
+    r->data[1] = cb + (bottom ? d->sl->uvlinesize : 0);
+    r->data[2] = cr + (bottom ? d->sl->uvlinesize : 0);
+    r->linesize[0] = 2 * d->sl->linesize;
+    r->linesize[1] = r->linesize[2] = 2 * d->sl->uvlinesize;
+    r->reference = parity;
     if (d->sl->ref_count[list] < (unsigned)idx + 1)
         d->sl->ref_count[list] = idx + 1;
 }
@@ -436,7 +467,8 @@ int FN(h264dec_filter_mb)(FFRefH264Dec *d, int mb_x, int mb_y, const int *ints, 
 {
     H264Context *h = d->h;
     H264SliceContext *sl = d->sl;
-    const int mb_xy = mb_x + mb_y * h->mb_stride, top_xy = mb_xy - h->mb_stride, ps = h->pixel_shift;
+    const int fld = h->picture_structure != PICT_FRAME; /* a field picture: the row above is two rows up in the frame's numbering */
+    const int mb_xy = mb_x + mb_y * h->mb_stride, top_xy = mb_xy - (h->mb_stride << fld), ps = h->pixel_shift;
     sl->mb_x = mb_x;
     sl->mb_y = mb_y;
     sl->mb_xy = mb_xy;
@@ -450,7 +482,7 @@ int FN(h264dec_filter_mb)(FFRefH264Dec *d, int mb_x, int mb_y, const int *ints, 
         h->cur_pic.mb_type[mb_xy - 1] = ints[1];
         h->cur_pic.qscale_table[mb_xy - 1] = (int8_t)ints[4];
     }
-    if (mb_y > 0) {
+    if (mb_y > fld) {
         h->cur_pic.mb_type[top_xy] = ints[2];
         h->cur_pic.qscale_table[top_xy] = (int8_t)ints[5];
     }
@@ -468,10 +500,21 @@ int FN(h264dec_filter_mb)(FFRefH264Dec *d, int mb_x, int mb_y, const int *ints, 
     if (d->record)
         return ff_h264_hip_filter_mb(&d->rec, h, sl, mb_x, mb_y);
 #endif
-    ff_h264_filter_mb(h, sl, mb_x, mb_y, d->f->data[0] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->linesize) * 16,
-                      d->f->data[1] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * (d->cfmt == 3 ? 16 : 8),
-                      d->f->data[2] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * (d->cfmt == 3 ? 16 : 8), sl->linesize,
-                      sl->uvlinesize);
+    {
+        /* loop_filter() (h264_slice.c:2470-2491): a field macroblock on an odd row starts one line below the row pair's first */
+        const int cs = d->cfmt == 3 ? 16 : 8;
+        uint8_t *dy = d->f->data[0] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->linesize) * 16;
+        uint8_t *dcb = d->f->data[1] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * cs;
+        uint8_t *dcr = d->f->data[2] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * cs;
+        if (fld && (mb_y & 1)) {
+            dy -= (ptrdiff_t)sl->linesize * 15;
+            dcb -= (ptrdiff_t)sl->uvlinesize * (cs - 1);
+            dcr -= (ptrdiff_t)sl->uvlinesize * (cs - 1);
+        }
+        sl->mb_linesize = sl->linesize << fld;
+        sl->mb_uvlinesize = sl->uvlinesize << fld;
+        ff_h264_filter_mb(h, sl, mb_x, mb_y, dy, dcb, dcr, sl->linesize << fld, sl->uvlinesize << fld);
+    }
     return 0;
 }
 

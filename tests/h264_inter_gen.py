@@ -47,9 +47,13 @@ class Dec:
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if hasattr(lib, prefix + "h264dec_filter_mb"):
             f("h264dec_filter_mb").argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3
+        f("h264dec_set_field").argtypes = [C.c_void_p, C.c_int]
+        f("h264dec_set_field").restype = None
+        f("h264dec_set_ref_field").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        f("h264dec_set_ref_field").restype = None
         self.d = f("h264dec_open_fmt")(depth, mb_w, mb_h, linesize, uvlinesize, record, cfmt)
         assert self.d
-        self.bits = [f("h264dec_mb_type_bits")(i) for i in range(14)]
+        self.bits = [f("h264dec_mb_type_bits")(i) for i in range(15)]     # [14]: MB_TYPE_INTERLACED
 
     def fn(self, name):
         return getattr(self.L, self.p + name)
@@ -64,6 +68,14 @@ class Dec:
 
     def set_ref(self, lst, idx, ptrs):
         self.fn("h264dec_set_ref")(self.d, lst, idx, *ptrs)
+
+    def set_field(self, picture_structure):
+        """1 top field, 2 bottom field (PAFF: every macroblock a field macroblock, mb_y = 2 * row + bottom), 3 back to frames"""
+        self.fn("h264dec_set_field")(self.d, picture_structure)
+
+    def set_ref_field(self, lst, idx, ptrs, parity):
+        """the field of parity 1 (top) / 2 (bottom) of the frame whose planes are ptrs"""
+        self.fn("h264dec_set_ref_field")(self.d, lst, idx, *ptrs, parity)
 
     def set_pwt(self, w):
         self.fn("h264dec_set_pwt")(self.d, w["use_weight"], w["use_weight_chroma"], w["luma_denom"], w["chroma_denom"], w["luma"].ctypes.data,
@@ -115,7 +127,7 @@ def make_pwt(rng, kind, depth, nref):
     return w
 
 
-def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=True, cfmt=1):
+def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=True, cfmt=1, extra_type=0):
     """B: the header's MB_TYPE_* values (Dec.bits).  mvr: motion-vector range in quarter samples — any size, the references have no
     border.  cfmt 3 (4:4:4): the residual of every plane is luma-type (cbp & 15 and the transform size count for all three), no chroma
     DC / AC part.  Returns the macroblock's state as a dict."""
@@ -209,11 +221,11 @@ def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=
                         n = G._block(rng, mb, 256 * pl + 16 * k, 16, allow_dc_only=False, depth=depth)
                         mb[256 * pl + 16 * k] = dc
                         nnzc[G.scan8_chroma(pl, k)] = n
-    m["mb_type"] = int(mb_type)
+    m["mb_type"] = int(mb_type) | extra_type       # (MB_TYPE_INTERLACED on every macroblock of a field picture)
     return m
 
 
-def make_filter_picture(rng, B, mb_w, mb_h, depth=8, p_intra=.2):
+def make_filter_picture(rng, B, mb_w, mb_h, depth=8, p_intra=.2, extra_type=0):
     """per-macroblock state for ff_h264_filter_mb() as fill_filter_caches() (h264_slice.c:2313) leaves it: types and quantizers are
     consistent across the picture (a macroblock's left / top type IS its neighbour's), the motion / reference / non-zero-count caches
     are drawn per macroblock (the function reads only the current macroblock's caches, border entries included)."""
@@ -231,7 +243,7 @@ def make_filter_picture(rng, B, mb_w, mb_h, depth=8, p_intra=.2):
                     t |= P1L0
                 if rng.random() < .3:
                     t |= DCT8
-            types[y, x] = t
+            types[y, x] = t | extra_type
     alpha_off, beta_off = int(rng.integers(-6, 7)) * 2, int(rng.integers(-6, 7)) * 2
     cabac = int(rng.integers(0, 2))
     out = []

@@ -248,3 +248,90 @@ def test_picture_formats_refused_by_name():
     pic = h264.Picture(4, 4)
     assert L.ffhip_h264_picture_mc_luma_plane(pic._p, 1, 0, q.ctypes.data) == _lib.EINVAL  # ... and those of a 4:2:0 picture do not
     pic.close()
+
+
+# ---- field pictures (PAFF; VERDICT r3 missing #3: field macroblocks, libavcodec/h264_mb.c:229,289) ------------------------------------------
+def _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, cfmt, seed, deblock=False):
+    """a frame decoded as two field pictures by the reference's own macroblock loop (every macroblock a field macroblock, mb_y = 2 * row +
+    bottom; the references fields of frames): each field is ONE libffhip picture object of half the height whose planes are every second line
+    of the frame buffer — flush() gets the plane's address (+ one line for the bottom field) and twice the line size"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    R, RH = _libs()
+    rng = np.random.default_rng(seed)
+    px, dt, top = (2, np.uint16, 1 << depth) if depth > 8 else (1, np.uint8, 256)
+    mb_h = 2 * fmb_h
+    W, H = mb_w * 16, mb_h * 16
+    sy = W + int(rng.integers(0, 3)) * 16
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    strides = [sy * px, sc * px, sc * px]
+    rows = [H, HC, HC]
+    mid, amp = 1 << (depth - 1), 20 << (depth - 8)
+    if deblock:
+        dst0 = [(mid + rng.integers(-amp, amp + 1, (rows[pl], strides[pl] // px))).astype(dt) for pl in range(3)]
+    else:
+        dst0 = [rng.integers(0, top, (rows[pl], strides[pl] // px), dtype=dt) for pl in range(3)]
+    refs = [rng.integers(0, top, (nref * rows[pl], strides[pl] // px), dtype=dt) for pl in range(3)]
+    dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
+    want = [a.copy() for a in dst0]
+    d_dst, d_refs = [dev(a) for a in dst0], [dev(a) for a in refs]
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, strides[0], strides[1], 0, cfmt=cfmt)
+    gpu = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, strides[0], strides[1], 1, cfmt=cfmt)
+    cpu.set_cur([a.ctypes.data for a in want])
+    gpu.set_cur([t.data_ptr() for t in d_dst])
+    RH.ffrefhip_h264dec_record_begin.argtypes = [C.c_void_p] * 5
+    RH.ffrefhip_h264dec_record_begin.restype = None
+    INTERLACED = cpu.bits[14]
+    for ps in (1, 2):
+        bottom = int(ps == 2)
+        cpu.set_field(ps)
+        gpu.set_field(ps)
+        pw = I.make_pwt(rng, weights, depth, nref)
+        cpu.set_pwt(pw)
+        gpu.set_pwt(pw)
+        for lst in (0, 1):
+            for i in range(nref):
+                j, par = int(rng.integers(0, nref)), int(rng.integers(1, 3))
+                cpu.set_ref_field(lst, i, [refs[pl].ctypes.data + j * rows[pl] * strides[pl] for pl in range(3)], par)
+                gpu.set_ref_field(lst, i, [d_refs[pl].data_ptr() + j * rows[pl] * strides[pl] for pl in range(3)], par)
+        pic = h264.Picture(mb_w, fmb_h, bit_depth=depth, chroma_format=cfmt)
+        pic.begin()
+        base = d_dst if deblock else d_refs
+        RH.ffrefhip_h264dec_record_begin(gpu.d, pic._p, *[t.data_ptr() for t in base])
+        if deblock:
+            for st in I.make_filter_picture(rng, cpu.bits, mb_w, fmb_h, depth, p_intra, extra_type=INTERLACED):
+                cpu.filter_mb(st["mb_x"], 2 * st["mb_y"] + bottom, st)
+                gpu.filter_mb(st["mb_x"], 2 * st["mb_y"] + bottom, st)
+        else:
+            for fy in range(fmb_h):
+                for mx in range(mb_w):
+                    if rng.random() < p_intra:
+                        d = G.make_intra_mb(rng, mx, fy, mb_w, fmb_h, depth=depth, cfmt=cfmt)
+                        d["mb_y"] = 2 * fy + bottom
+                        a, b = cpu.decode_intra(d), gpu.decode_intra(d)
+                        assert d["type"] == G.PCM or np.array_equal(a, b)
+                    else:
+                        m = I.make_inter_mb(rng, cpu.bits, mx, 2 * fy + bottom, nref, mvr, depth=depth, cfmt=cfmt, extra_type=INTERLACED)
+                        assert np.array_equal(cpu.decode_inter(m), gpu.decode_inter(m))
+        pic.flush([d_dst[pl].data_ptr() + bottom * strides[pl] for pl in range(3)], [2 * s for s in strides], [t.data_ptr() for t in base])
+        torch.cuda.synchronize()
+        pic.close()
+    for pl in range(3):
+        got = d_dst[pl].cpu().numpy().view(dt)
+        assert (want[pl][0::2] != dst0[pl][0::2]).sum() > 40 and (want[pl][1::2] != dst0[pl][1::2]).sum() > 40
+        bad = got != want[pl]
+        assert not bad.any(), "plane %d: %d mismatches, first at %s" % (pl, bad.sum(), np.argwhere(bad)[0])
+    cpu.close()
+    gpu.close()
+
+
+@pytest.mark.parametrize("depth,mb_w,fmb_h,nref,mvr,p_intra,weights,cfmt", [
+    (8, 6, 3, 2, 40, 0.0, 0, 1), (8, 11, 4, 3, 2000, 0.0, 1, 1), (8, 11, 4, 3, 300, 0.0, 2, 1), (8, 9, 3, 1, 64, 1.0, 0, 1), (8, 40, 11, 2, 120, .15, 1, 1),
+    (8, 120, 34, 3, 256, .05, 2, 1), (10, 7, 3, 2, 600, .2, 1, 1), (12, 9, 4, 2, 500, .3, 0, 1), (8, 9, 4, 2, 300, .2, 2, 3), (10, 6, 3, 2, 500, .3, 1, 3)])
+def test_decoder_driven_field_pictures(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, cfmt):
+    _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, cfmt, seed=7770000 + depth * 1000 + mb_w * 31 + mvr + weights + cfmt)
+
+
+@pytest.mark.parametrize("depth,mb_w,fmb_h,p_intra,cfmt", [(8, 6, 3, .2, 1), (8, 40, 11, .15, 1), (8, 9, 3, 1.0, 1), (8, 120, 34, .1, 1), (10, 7, 3, .2, 1), (8, 9, 4, .2, 3)])
+def test_decoder_driven_field_deblocking(depth, mb_w, fmb_h, p_intra, cfmt):
+    _run_field_frame(depth, mb_w, fmb_h, 1, 0, p_intra, 0, cfmt, seed=7780000 + depth * 100 + mb_w + fmb_h + cfmt, deblock=True)

@@ -184,3 +184,99 @@ def test_flush_without_a_device_is_refused_by_name():
     st = (C.c_int * 3)(64, 64, 64)
     assert L.ffhip_h264_picture_flush(pic.p, dp, st, dp, None) == _lib.ENOSYS
     pic.close()
+
+
+# ---- field pictures (PAFF) -------------------------------------------------------------------------------------------------------------
+def _field_refs(rng, dec_list, refs, rows, strides, nref):
+    """both lists: fields of the nref reference FRAMES, either parity, in different orders (same- and opposite-parity prediction)"""
+    picks = [(int(rng.integers(0, nref)), int(rng.integers(1, 3))) for _ in range(2 * nref)]
+    for lst in (0, 1):
+        for i in range(nref):
+            j, par = picks[lst * nref + i]
+            for d, base in dec_list:
+                d.set_ref_field(lst, i, [base[pl] + j * rows[pl] * strides[pl] for pl in range(3)], par)
+
+
+def _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, cfmt, seed, deblock=False):
+    """a frame decoded as two FIELD pictures (top, then bottom): every macroblock a field macroblock of the decoder's own numbering
+    (mb_y = 2 * row + bottom), the references fields of frames (pic_as_field, h264_refs.c:39-48) — the recorder hands libffhip each field
+    as a picture of its own: every second line of the frame buffer, half the height, twice the line size"""
+    _lib, L, R, RH, E = _env()
+    rng = np.random.default_rng(seed)
+    px, dt, top = (2, np.uint16, 1 << depth) if depth > 8 else (1, np.uint8, 256)
+    mb_h = 2 * fmb_h                                        # the frame's macroblock rows
+    W, H = mb_w * 16, mb_h * 16
+    sy = W + int(rng.integers(0, 3)) * 16
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    strides = [sy * px, sc * px, sc * px]
+    rows = [H, HC, HC]
+    mid, amp = 1 << (depth - 1), 20 << (depth - 8)
+    if deblock:
+        dst0 = [(mid + rng.integers(-amp, amp + 1, (rows[pl], strides[pl] // px))).astype(dt) for pl in range(3)]
+    else:
+        dst0 = [rng.integers(0, top, (rows[pl], strides[pl] // px), dtype=dt) for pl in range(3)]
+    refs = [rng.integers(0, top, (nref * rows[pl], strides[pl] // px), dtype=dt) for pl in range(3)]
+    want, got = [a.copy() for a in dst0], [a.copy() for a in dst0]
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, strides[0], strides[1], 0, cfmt=cfmt)
+    rec = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, strides[0], strides[1], 1, cfmt=cfmt)
+    cpu.set_cur([a.ctypes.data for a in want])
+    rec.set_cur([a.ctypes.data for a in got])
+    INTERLACED = cpu.bits[14]
+    for ps in (1, 2):                                       # PICT_TOP_FIELD, PICT_BOTTOM_FIELD
+        bottom = ps == 2
+        cpu.set_field(ps)
+        rec.set_field(ps)
+        pw = I.make_pwt(rng, weights, depth, nref)
+        cpu.set_pwt(pw)
+        rec.set_pwt(pw)
+        _field_refs(rng, [(cpu, [r.ctypes.data for r in refs]), (rec, [r.ctypes.data for r in refs])], refs, rows, strides, nref)
+        pic = HostPicture(_lib, L, mb_w, fmb_h, depth, cfmt)
+        RH.ffrefhip_h264dec_record_begin(rec.d, pic.p, *[(got if deblock else refs)[pl].ctypes.data for pl in range(3)])
+        if deblock:
+            for st in I.make_filter_picture(rng, cpu.bits, mb_w, fmb_h, depth, p_intra, extra_type=INTERLACED):
+                cpu.filter_mb(st["mb_x"], 2 * st["mb_y"] + bottom, st)
+                rec.filter_mb(st["mb_x"], 2 * st["mb_y"] + bottom, st)
+        else:
+            for fy in range(fmb_h):
+                for mx in range(mb_w):
+                    if rng.random() < p_intra:
+                        d = G.make_intra_mb(rng, mx, fy, mb_w, fmb_h, depth=depth, cfmt=cfmt)
+                        d["mb_y"] = 2 * fy + bottom
+                        a, b = cpu.decode_intra(d), rec.decode_intra(d)
+                        assert d["type"] == G.PCM or np.array_equal(a, b)
+                    else:
+                        m = I.make_inter_mb(rng, cpu.bits, mx, 2 * fy + bottom, nref, mvr, depth=depth, cfmt=cfmt, extra_type=INTERLACED)
+                        assert np.array_equal(cpu.decode_inter(m), rec.decode_inter(m))
+        ls = pic.lists()
+        assert (ls.mb_w, ls.mb_h) == (mb_w, fmb_h)
+        # the field as a picture: the frame plane's address (+ one line for the bottom field), twice the line size
+        dp = (C.c_void_p * 3)(*[got[pl].ctypes.data + bottom * strides[pl] for pl in range(3)])
+        rp = (C.c_void_p * 3)(*[(got if deblock else refs)[pl].ctypes.data for pl in range(3)])
+        st2 = (C.c_int * 3)(*[2 * s for s in strides])
+        assert E.ffemul_h264_picture_flush(C.byref(ls), dp, st2, rp) == 0
+        pic.close()
+        for pl in range(3):                                  # the other field's lines: untouched so far / still what the first pass left
+            assert np.array_equal(got[pl][1 - bottom::2], want[pl][1 - bottom::2])
+    for pl in range(3):
+        assert (want[pl][0::2] != dst0[pl][0::2]).sum() > 40 and (want[pl][1::2] != dst0[pl][1::2]).sum() > 40
+        bad = got[pl] != want[pl]
+        assert not bad.any(), "plane %d: %d mismatches, first at %s" % (pl, bad.sum(), np.argwhere(bad)[0])
+    cpu.close()
+    rec.close()
+
+
+@pytest.mark.parametrize("depth,mb_w,fmb_h,nref,mvr,p_intra,weights,cfmt", [
+    (8, 6, 3, 2, 40, 0.0, 0, 1), (8, 11, 4, 3, 2000, 0.0, 1, 1), (8, 11, 4, 3, 300, 0.0, 2, 1), (8, 9, 3, 1, 64, 1.0, 0, 1), (8, 20, 6, 2, 120, .15, 1, 1),
+    (10, 7, 3, 2, 600, .2, 1, 1), (8, 9, 4, 2, 300, .2, 2, 3), (10, 6, 3, 2, 500, .3, 1, 3)])
+def test_recorded_field_pictures_executed_on_cpu_equal_reference(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, cfmt):
+    """PAFF: ff_h264_hl_decode_mb() on field macroblocks (mb_linesize = 2 * linesize, block_offset[48..], pic_height halved and the chroma
+    vector offset between fields of opposite parity in mc_dir_part(), h264_mb.c:229,289-293; the implicit weights' [mb_y & 1]) over the
+    recording members, each field flushed as a picture of its own"""
+    _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, cfmt, seed=7770000 + depth * 1000 + mb_w * 31 + mvr + weights + cfmt)
+
+
+@pytest.mark.parametrize("depth,mb_w,fmb_h,p_intra,cfmt", [(8, 6, 3, .2, 1), (8, 20, 6, .15, 1), (8, 9, 3, 1.0, 1), (10, 7, 3, .2, 1), (8, 9, 4, .2, 3)])
+def test_recorded_field_deblocking_executed_on_cpu_equals_reference(depth, mb_w, fmb_h, p_intra, cfmt):
+    """ff_h264_filter_mb() in field pictures (the row above is the field's own, bS 3 on horizontal intra edges: h264_loopfilter.c:550,
+    mvy_limit 2): each field's edge tables through the frame-order filter on that field's lines"""
+    _run_field_frame(depth, mb_w, fmb_h, 1, 0, p_intra, 0, cfmt, seed=7780000 + depth * 100 + mb_w + fmb_h + cfmt, deblock=True)
