@@ -473,15 +473,19 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         static const int base[3] = { FFHIP_PIX_FMT_YUV420P, FFHIP_PIX_FMT_YUV422P, FFHIP_PIX_FMT_YUV444P };
         const int sa = srcFormat == FFHIP_PIX_FMT_YUVA420P ? 1 : srcFormat == FFHIP_PIX_FMT_YUVA422P ? 2 : srcFormat == FFHIP_PIX_FMT_YUVA444P ? 3 : 0;
         const int da = dstFormat == FFHIP_PIX_FMT_YUVA420P ? 1 : dstFormat == FFHIP_PIX_FMT_YUVA422P ? 2 : dstFormat == FFHIP_PIX_FMT_YUVA444P ? 3 : 0;
-        if (sa && (da || dstFormat == FFHIP_PIX_FMT_ARGB || dstFormat == FFHIP_PIX_FMT_RGBA || dstFormat == FFHIP_PIX_FMT_ABGR || dstFormat == FFHIP_PIX_FMT_BGRA)) {
-            ffhip_set_error("ffhip_sws: alpha on both sides (a scaled alpha plane) is not on the hip path");
+        if (sa && (dstFormat == FFHIP_PIX_FMT_ARGB || dstFormat == FFHIP_PIX_FMT_RGBA || dstFormat == FFHIP_PIX_FMT_ABGR || dstFormat == FFHIP_PIX_FMT_BGRA)) {
+            /* the yuv2rgba writers with an alpha argument (output.c yuv2rgba32_X etc.) are not built */
+            ffhip_set_error("ffhip_sws: a source alpha plane into the alpha channel of packed RGB is not on the hip path");
             return NULL;
         }
         if (sa)
             srcFormat = base[sa - 1];
         if (da)
             dstFormat = base[da - 1];
-        alpha_fill = da != 0;
+        /* alpha on both sides of a planar conversion: the alpha plane goes through the LUMA scaler — lum_h_scale and lum_planar_vscale run
+         * hyScale / yuv2planeX on plane 3 with the luma banks and the luma dither (hscale.c:63-79, vscale.c:57-70), without the range
+         * stage (hscale.c:57-59 converts plane 0 only) */
+        alpha_fill = sa && da ? 2 : da != 0;
     }
     if (flags & FFHIP_SWS_FAST_BILINEAR) {
         /* the C path of SWS_FAST_BILINEAR runs ff_hyscale_fast_c, a different horizontal scaler
@@ -586,6 +590,11 @@ int ffhip_sws_tables_set_ranges(FFHipSwsHostTables *t, int src_range, int dst_ra
     int ddepth = 8;
     if (!t || (src_range | dst_range) & ~1)
         return FFHIP_EINVAL;
+    if (t->t.dst_alpha_fill == 2 && src_range != dst_range) {
+        /* the alpha plane runs as the luma of a second pass of the same context: that pass would convert its range, the reference does not */
+        ffhip_set_error("ffhip_sws_tables_set_ranges: a range conversion together with a scaled alpha plane is not on the hip path");
+        return FFHIP_ENOSYS;
+    }
     if (is_rgb(t->t.dstFormat)) /* the coefficients carry the source's range (sws_setColorspaceDetails -> ff_yuv2rgb_c_init_tables) */
         ffhip_host_yuv2rgb_coeffs(&t->t, src_range);
     t->t.src_range = src_range;

@@ -68,6 +68,8 @@ struct FFHipSwsContext {
     /* staging for the host-pointer face */
     void *stage = nullptr;
     size_t stage_sz = 0;
+    void *alpha_scratch = nullptr; /* chroma planes of the alpha pass (dst_alpha_fill == 2): written, never read */
+    size_t alpha_scratch_sz = 0;
     int slice_next = 0;   /* scaled contexts fed in slices: the next source line expected */
     std::mutex mu;
 };
@@ -771,6 +773,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->dev_wtables);
     if (c->stage)
         (void)hipFree(c->stage);
+    if (c->alpha_scratch)
+        (void)hipFree(c->alpha_scratch);
     delete c;
 }
 
@@ -969,19 +973,66 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
 static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
                            void *const dst[4], const int dstStride[4], const size_t dstFramePitch[4], void *stream_);
 
+struct PlaneDesc { int wbytes, rows; };
+
+static int plane_list(int fmt, int w, int h, PlaneDesc out[3])
+{
+    if (fmt_yuv(fmt)) {
+        const int cw = -((-w) >> fmt_hsub(fmt)), chh = -((-h) >> fmt_vsub(fmt));
+        int depth = 8, layout = 0;
+        const int bs = ffhip_pixfmt_hbd(fmt, &depth, &layout, nullptr, nullptr) ? 2 : 1; /* bytes per sample */
+        if (fmt_nv(fmt) || layout == 1) { out[0] = { bs * w, h }; out[1] = { bs * 2 * cw, chh }; return 2; }
+        out[0] = { bs * w, h }; out[1] = { bs * cw, chh }; out[2] = { bs * cw, chh };
+        return 3;
+    }
+    out[0] = { (rgb_layout(fmt) < 2 ? 3 : 4) * w, h };
+    return 1;
+}
+
+
 extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4],
                                          const int srcStride[4], const size_t srcFramePitch[4], void *const dst[4],
                                          const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
 {
+    if (c && c->t.dst_alpha_fill && (!dst || !dst[3] || (c->t.dst_alpha_fill == 2 && (!src || !src[3])))) {
+        ffhip_set_error("ffhip_sws_scale_batch_dev: the format has an alpha plane: plane 3 is NULL");
+        return FFHIP_EINVAL;
+    }
     const int r = scale_batch_dev(c, nframes, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream_);
     if (r < 0 || !c->t.dst_alpha_fill)
         return r;
-    /* a target with an alpha plane the source does not drive: opaque (ff_swscale's fillPlane, libswscale/swscale.c:536-553) */
-    if (!dst[3]) {
-        ffhip_set_error("ffhip_sws_scale_batch_dev: the target format has an alpha plane: dst[3] is NULL");
-        return FFHIP_EINVAL;
-    }
     FFHipDeviceGuard dg(c->device);
+    if (c->t.dst_alpha_fill == 2) {
+        /* alpha on both sides: the alpha plane is the luma of a second pass (lum_h_scale / lum_planar_vscale run the luma banks on plane
+         * 3, hscale.c:63-79, vscale.c:57-70); that pass's chroma planes land in a scratch buffer nobody reads */
+        PlaneDesc dp[3];
+        if (plane_list(c->t.dstFormat, c->t.dstW, c->t.dstH, dp) != 3) {
+            ffhip_set_error("ffhip_sws_scale_batch_dev: a scaled alpha plane belongs to a planar target");
+            return FFHIP_EINVAL;
+        }
+        const size_t pitch = ((size_t)dp[1].wbytes + 255) & ~(size_t)255, fp = pitch * (size_t)dp[1].rows, need = 2 * fp * (size_t)(nframes > 0 ? nframes : 1);
+        if (need > c->alpha_scratch_sz) {
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream_)); /* an earlier call's alpha pass may still be writing the old buffer */
+            if (c->alpha_scratch)
+                (void)hipFree(c->alpha_scratch);
+            c->alpha_scratch = nullptr;
+            c->alpha_scratch_sz = 0;
+            if (hipMalloc(&c->alpha_scratch, need) != hipSuccess) {
+                ffhip_set_error("ffhip_sws_scale_batch_dev: hipMalloc(%zu) for the alpha pass failed", need);
+                return FFHIP_ENOMEM;
+            }
+            c->alpha_scratch_sz = need;
+        }
+        uint8_t *const sc = (uint8_t *)c->alpha_scratch;
+        const void *s2[4] = { src[3], src[1], src[2], nullptr };
+        const int ss2[4] = { srcStride[3], srcStride[1], srcStride[2], 0 };
+        const size_t sf2[4] = { srcFramePitch[3], srcFramePitch[1], srcFramePitch[2], 0 };
+        void *d2[4] = { dst[3], sc, sc + fp * (size_t)(nframes > 0 ? nframes : 1), nullptr };
+        const int ds2[4] = { dstStride[3], (int)pitch, (int)pitch, 0 };
+        const size_t df2[4] = { dstFramePitch[3], fp, fp, 0 };
+        return scale_batch_dev(c, nframes, s2, ss2, sf2, d2, ds2, df2, stream_);
+    }
+    /* a target with an alpha plane the source does not drive: opaque (ff_swscale's fillPlane, libswscale/swscale.c:536-553) */
     for (int f = 0; f < nframes; f++)
         HIP_TRY(hipMemset2DAsync((uint8_t *)dst[3] + (size_t)f * dstFramePitch[3], (size_t)dstStride[3], 255, (size_t)c->t.dstW, (size_t)c->t.dstH,
                                  (hipStream_t)stream_));
@@ -1358,22 +1409,6 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
 }
 
 /* ---- host-pointer face ---------------------------------------------------------------------- */
-struct PlaneDesc { int wbytes, rows; };
-
-static int plane_list(int fmt, int w, int h, PlaneDesc out[3])
-{
-    if (fmt_yuv(fmt)) {
-        const int cw = -((-w) >> fmt_hsub(fmt)), chh = -((-h) >> fmt_vsub(fmt));
-        int depth = 8, layout = 0;
-        const int bs = ffhip_pixfmt_hbd(fmt, &depth, &layout, nullptr, nullptr) ? 2 : 1; /* bytes per sample */
-        if (fmt_nv(fmt) || layout == 1) { out[0] = { bs * w, h }; out[1] = { bs * 2 * cw, chh }; return 2; }
-        out[0] = { bs * w, h }; out[1] = { bs * cw, chh }; out[2] = { bs * cw, chh };
-        return 3;
-    }
-    out[0] = { (rgb_layout(fmt) < 2 ? 3 : 4) * w, h };
-    return 1;
-}
-
 static hipError_t copy2d(void *dst, ptrdiff_t dpitch, const void *src, ptrdiff_t spitch, size_t wbytes, int rows,
                          hipMemcpyKind kind)
 {
@@ -1387,6 +1422,9 @@ static hipError_t copy2d(void *dst, ptrdiff_t dpitch, const void *src, ptrdiff_t
     return hipSuccess;
 }
 
+static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY, int srcSliceH,
+                            uint8_t *const dst[], const int dstStride[]);
+
 extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                                int srcSliceH, uint8_t *const dst[], const int dstStride[])
 {
@@ -1394,6 +1432,36 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
         return FFHIP_EINVAL;
     FFHipDeviceGuard dg(c->device);
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->t.dst_alpha_fill != 2)
+        return sws_scale_locked(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    /* alpha on both sides: a second pass whose luma is the alpha plane (see ffhip_sws_scale_batch_dev); whole frames only — the slice
+     * collection holds one frame's source */
+    if (srcSliceY != 0 || srcSliceH != c->t.srcH) {
+        ffhip_set_error("ffhip_sws_scale: source slices together with a scaled alpha plane are not on the hip path");
+        return FFHIP_ENOSYS;
+    }
+    if (!src[3] || !dst[3]) {
+        ffhip_set_error("ffhip_sws_scale: the formats have an alpha plane: plane 3 is NULL");
+        return FFHIP_EINVAL;
+    }
+    const int r = sws_scale_locked(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    if (r < 0)
+        return r;
+    PlaneDesc dp[3];
+    if (plane_list(c->t.dstFormat, c->t.dstW, c->t.dstH, dp) != 3)
+        return FFHIP_EINVAL;
+    std::vector<uint8_t> scratch((size_t)dp[1].wbytes * (size_t)dp[1].rows * 2);
+    const uint8_t *const s2[4] = { src[3], src[1], src[2], nullptr };
+    const int ss2[4] = { srcStride[3], srcStride[1], srcStride[2], 0 };
+    uint8_t *const d2[4] = { dst[3], scratch.data(), scratch.data() + (size_t)dp[1].wbytes * (size_t)dp[1].rows, nullptr };
+    const int ds2[4] = { dstStride[3], dp[1].wbytes, dp[1].wbytes, 0 };
+    const int r2 = sws_scale_locked(c, s2, ss2, 0, srcSliceH, d2, ds2);
+    return r2 < 0 ? r2 : r;
+}
+
+static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY, int srcSliceH,
+                            uint8_t *const dst[], const int dstStride[])
+{
     const FFHipSwsTables &t = c->t;
     const bool unscaled = c->unscaled_yuv2rgb;
     /*
@@ -1489,7 +1557,7 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
         uint8_t *hd = dst[i] + (unscaled ? (ptrdiff_t)srcSliceY * dstStride[i] : 0);
         HIP_TRY(copy2d(hd, dstStride[i], base + off_d[i], pitch_d[i], dp[i].wbytes, dp[i].rows, hipMemcpyDeviceToHost));
     }
-    if (t.dst_alpha_fill && dst[3]) /* the alpha plane of a target whose source has none: opaque (swscale.c:536-553) */
+    if (t.dst_alpha_fill == 1 && dst[3]) /* the alpha plane of a target whose source has none: opaque (swscale.c:536-553) */
         for (int y = 0; y < t.dstH; y++)
             memset(dst[3] + (ptrdiff_t)y * dstStride[3], 255, (size_t)t.dstW);
     return unscaled ? srcSliceH : t.dstH;

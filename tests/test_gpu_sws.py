@@ -376,6 +376,58 @@ def test_full_range_yuv_to_rgb(dst, sw, sh, dw, dh, flags):
     assert not torch.equal(d2[0], ddst[0])
 
 
+ALPHA2_CASES = [("yuva420p", 64, 36, "yuva420p", 128, 72, ffi.SWS_BICUBIC, 0), ("yuva420p", 65, 37, "yuva444p", 40, 30, ffi.SWS_BILINEAR, 5),
+                ("yuva444p", 64, 36, "yuva422p", 96, 54, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0), ("yuva422p", 66, 38, "yuva420p", 33, 19, ffi.SWS_BILINEAR, 0),
+                ("yuva420p", 960, 540, "yuva420p", 1920, 1080, ffi.SWS_BICUBIC, 0), ("yuva420p", 1920, 1080, "yuva420p", 960, 540, ffi.SWS_BICUBIC, 0),
+                ("yuva420p", 640, 360, "yuva420p", 1000, 562, 0x200, 3)]        # SWS_LANCZOS: wide banks
+
+
+@pytest.mark.parametrize("case", ALPHA2_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x_p%d" % c)
+def test_alpha_on_both_sides(case):
+    """planar YUVA -> planar YUVA: the alpha plane is scaled by the luma banks (lum_h_scale / lum_planar_vscale on plane 3, hscale.c:63-79,
+    vscale.c:57-70; pinned to the reference in test_oracle_vs_ref.py::test_alpha_on_both_sides_is_the_luma_scaler): the oracle's luma of the
+    base conversion with A in Y's place, through every kernel family (exact 2x, exact 2:1, the column walkers, the tiled kernel), the batch
+    face and the host-pointer face"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    sf, sw, sh, df, dw, dh, flags, pad = case
+    base = {"yuva420p": "yuv420p", "yuva422p": "yuv422p", "yuva444p": "yuv444p"}
+    bs, bd = base[sf], base[df]
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=pad)
+    ht = S.HostTables(sw, sh, PIX[bs], dw, dh, PIX[bd], flags)
+    t = ffi.make_otables(sw, sh, PIX[bs], dw, dh, PIX[bd], flags, ht.banks(), ht.coeffs(), full=ht.full())
+    want = ffi.alloc_frame(PIX[bd], dw, dh)
+    sp, ss = ffi.planes(src[:3])
+    dp, ds = ffi.planes(want)
+    assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+    wa = ffi.alloc_frame(PIX[bd], dw, dh)
+    sp, ss = ffi.planes([src[3], src[1], src[2]])
+    dp, ds = ffi.planes(wa)
+    assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+    want.append(wa[0])
+    ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    n = 3
+    dsrc = _upload(src, n=n)
+    ddst = [torch.full((n,) + a.shape[:1] + (a.shape[1] + pad,), 9, dtype=torch.uint8, device="cuda:0") for a in want]
+    for _ in range(2):                      # the second call reuses the context's scratch planes
+        ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        for p, a in enumerate(want):
+            got = ddst[p][f].cpu().numpy()
+            assert np.array_equal(got[:, :a.shape[1]], a), "frame %d plane %d: %d mismatches" % (f, p, (got[:, :a.shape[1]] != a).sum())
+            assert (got[:, a.shape[1]:] == 9).all(), "plane %d: bytes beyond the row were written" % p
+    assert not (want[3] == 255).all()
+    with pytest.raises(RuntimeError, match="alpha"):
+        ctx.scale_batch(dsrc[:3], ddst)
+    hd = [np.zeros_like(a) for a in want]
+    assert ctx.scale(src, hd) == dh
+    for a, b in zip(hd, want):
+        assert np.array_equal(a, b)
+    ctx.close()
+
+
 ALPHA_CASES = [("yuv420p", 64, 36, "yuva420p", 128, 72, ffi.SWS_BICUBIC, 0), ("yuv422p", 65, 37, "yuva444p", 40, 30, ffi.SWS_BILINEAR, 5),
                ("nv12", 64, 36, "yuva422p", 96, 54, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0), ("yuva420p", 64, 36, "yuv420p", 128, 72, ffi.SWS_BICUBIC, 3),
                ("yuva444p", 64, 36, "rgb24", 100, 50, ffi.SWS_BICUBIC, 0), ("yuva422p", 66, 38, "nv12", 33, 19, ffi.SWS_BILINEAR, 0),
@@ -386,8 +438,8 @@ ALPHA_CASES = [("yuv420p", 64, 36, "yuva420p", 128, 72, ffi.SWS_BICUBIC, 0), ("y
 @pytest.mark.parametrize("case", ALPHA_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x_p%d" % c)
 def test_alpha_on_one_side(case):
     """yuva420p / 422p / 444p on one side: a source's alpha plane is not read, a target's is filled with 255 (swscale.c:536-553) and the
-    other planes are the base formats' (pinned to the reference in test_oracle_vs_ref.py::test_alpha_on_one_side).  Alpha on both sides
-    (a scaled alpha plane) is refused."""
+    other planes are the base formats' (pinned to the reference in test_oracle_vs_ref.py::test_alpha_on_one_side).  A source alpha plane
+    into packed RGBA is refused (planar alpha on both sides: test_alpha_on_both_sides)."""
     from ffmpeg_amd import swscale as S
     torch = _torch()
     sf, sw, sh, df, dw, dh, flags, pad = case

@@ -1534,9 +1534,47 @@ def test_alpha_on_one_side(sf, dst, sw, sh, dw, dh, flags):
         assert len(out[0]) == 4 and (out[0][3] == 255).all()
     ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags)
     assert ht.t.dst_alpha_fill == (dst in base) and ht.t.srcFormat == PIX[base.get(sf, sf)] and ht.t.dstFormat == PIX[base.get(dst, dst)]
-    for a, b in (("yuva420p", "yuva444p"), ("yuva420p", "rgba")):
-        with pytest.raises(ValueError):
-            S.HostTables(sw, sh, PIX[a], dw, dh, PIX[b], flags)
+    with pytest.raises(ValueError):        # a source alpha plane into the alpha channel of packed RGB: the yuv2rgba writers are not built
+        S.HostTables(sw, sh, PIX["yuva420p"], dw, dh, PIX["rgba"], flags)
+
+
+ALPHA2_CASES = [("yuva420p", "yuva420p", 64, 36, 128, 72, 4), ("yuva420p", "yuva444p", 65, 37, 40, 30, 2), ("yuva444p", "yuva422p", 64, 36, 96, 54, 4 | 0x40000),
+                ("yuva422p", "yuva420p", 66, 38, 33, 19, 2), ("yuva420p", "yuva420p", 96, 54, 48, 27, 4), ("yuva444p", "yuva420p", 48, 32, 100, 50, 0x200)]
+
+
+@pytest.mark.parametrize("sf,dst,sw,sh,dw,dh,flags", ALPHA2_CASES)
+def test_alpha_on_both_sides_is_the_luma_scaler(sf, dst, sw, sh, dw, dh, flags):
+    """Planar YUVA on both sides: the reference scales the alpha plane with the LUMA banks and the luma dither (lum_h_scale and
+    lum_planar_vscale on plane 3, hscale.c:63-79, vscale.c:57-70).  So its alpha plane == the LUMA plane it produces for the base formats
+    when the source's Y plane is replaced by A — which is what libffhip runs (dst_alpha_fill == 2: a second pass of the context) — and
+    its other planes are the base conversion's."""
+    from ffmpeg_amd import swscale as S
+    R = ffi.ref()
+    base = {"yuva420p": "yuv420p", "yuva422p": "yuv422p", "yuva444p": "yuv444p"}
+    rng = np.random.default_rng(sw + dw + len(dst) + len(sf) + flags)
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=3)
+    assert len(src) == 4
+
+    def run(a, b, planes):
+        ctx = R.ffref_sws_create(sw, sh, PIX[a], dw, dh, PIX[b], flags, 1)
+        assert ctx
+        want = ffi.alloc_frame(PIX[b], dw, dh)
+        for p in want:
+            p[:] = 7
+        sp, ss = ffi.planes(planes)
+        dp, ds = ffi.planes(want)
+        assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, dp, ds) == dh
+        R.ffref_sws_free(ctx)
+        return want
+    full = run(sf, dst, src)
+    plain = run(base[sf], base[dst], src[:3])
+    alpha_as_luma = run(base[sf], base[dst], [src[3], src[1], src[2]])
+    assert len(full) == 4
+    for p in range(3):
+        assert np.array_equal(full[p], plain[p])
+    assert np.array_equal(full[3], alpha_as_luma[0]) and not (full[3] == 255).all() and not np.array_equal(full[3], full[0])
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags)
+    assert ht.t.dst_alpha_fill == 2 and ht.t.srcFormat == PIX[base[sf]] and ht.t.dstFormat == PIX[base[dst]]
 
 
 def test_sws_scale_frame_slice_threads_equal_one_thread():
