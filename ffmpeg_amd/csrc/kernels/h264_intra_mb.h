@@ -866,4 +866,133 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
         });
     }
 }
+/* ================================================================================================================================
+ * 4:2:2 (round 4): the two 8 x 16 chroma planes of an intra macroblock — hl_decode_mb() at chroma_format_idc 2
+ * (libavcodec/h264_mb_template.c:151-262): pred8x8[chroma_pred_mode] is a pred8x16 function there (h264pred.c:480-512,
+ * h264pred_template.c:567-817), the residual is chroma422_dc_dequant_idct per plane (h264idct_template.c:295-321, qmul =
+ * dequant4_coeff[1 + p][chroma_qp[p] + 3][0]: h264_mb_template.c:230-245) + idct_add8_422 (:230-252: eight blocks per plane, the cache
+ * rows running on downwards).  The luma plane of such a macroblock is a luma-only record of the wavefront above; the chroma planes
+ * are a record and a wavefront of their own (k_h264_intra_c422: chroma prediction reads the left, upper-left and upper neighbours only).
+ * ONE phase: lane = column (lane & 3) of block (lane >> 2) & 7 of plane lane >> 5; prediction reads samples outside the macroblock only.
+ * ================================================================================================================================ */
+/* (the record: FFHipH264IntraC422 in include/ffhip.h) */
+
+template <typename PIX>
+struct ImbTileC422 {
+    PIX c[2][17 * 16];    /* sample (r, c), r = -1..15, c = -4..11, at [(r + 1) * 16 + c + 4] (imb_ci) */
+    typename ImbCoef<PIX>::T zero[16];
+};
+
+/* pred8x16 sample column (xc, y0 .. y0 + 3) of block k: modes as H264PredContext.pred8x8[] at chroma_format_idc 2 */
+template <typename PIX, class Top, class Left>
+IMB_FN void imb_pred8x16_col(int mode, int k, int xc, int y0, Top TOP, Left LEFT, int maxv, int out[4])
+{
+    const int mid = (maxv + 1) >> 1;
+    if (mode == 1) {
+        for (int j = 0; j < 4; j++)
+            out[j] = LEFT(y0 + j);
+        return;
+    }
+    if (mode == 2) {
+        out[0] = out[1] = out[2] = out[3] = TOP(xc);
+        return;
+    }
+    if (mode == 3) { /* pred8x16_plane (h264pred_template.c:781-817) */
+        int H = 0, V = 0;
+        for (int i = 1; i <= 4; i++)
+            H += i * (TOP(3 + i) - TOP(3 - i));
+        for (int i = 1; i <= 8; i++)
+            V += i * (LEFT(7 + i) - (i == 8 ? TOP(-1) : LEFT(7 - i)));
+        H = (17 * H + 16) >> 5;
+        V = (5 * V + 32) >> 6;
+        const int a = 16 * (LEFT(15) + TOP(7) + 1) - 7 * V - 3 * H;
+        for (int j = 0; j < 4; j++)
+            out[j] = imb_clip<PIX>((a + (y0 + j) * V + xc * H) >> 5, maxv);
+        return;
+    }
+    /* the DC family: one value per 4 x 4 cell (r = cell row 0..3, cx = cell column) */
+    const int r = k >> 1, cx = k & 1;
+    const bool use_t = mode == 0 || mode == 5 || mode == 7 || mode == 8, use_l = mode == 0 || mode == 4 || mode >= 7;
+    int t0 = 0, t1 = 0, l0 = 0, lr = 0;
+    for (int i = 0; i < 4; i++) {
+        t0 += use_t ? TOP(i) : 0;
+        t1 += use_t ? TOP(4 + i) : 0;
+        l0 += use_l ? LEFT(i) : 0;
+        lr += (use_l && mode != 7) ? LEFT(4 * r + i) : 0;
+    }
+    int v = mid;
+    switch (mode) {
+    case 0: case 8: /* pred8x16_dc (:650-695); 8 = mad_cow_dc_0lt: cell 0 from the top alone */
+        v = cx == 0 ? (r == 0 ? (mode == 0 ? (t0 + l0 + 4) >> 3 : (t0 + 2) >> 2) : (lr + 2) >> 2)
+                    : (r == 0 ? (t1 + 2) >> 2 : (t1 + lr + 4) >> 3);
+        break;
+    case 4: case 9: case 10: /* left_dc (:567-571); 9 = _l00: the cells of rows 4..7 stay mid; 10 = _0l0: those of rows 0..3 (:725-749) */
+        v = ((mode == 9 && r == 1) || (mode == 10 && r == 0)) ? mid : (lr + 2) >> 2;
+        break;
+    case 5: case 7: /* top_dc (:599-603); 7 = _l0t: cell 0 is pred4x4_dc */
+        v = cx == 0 ? (t0 + 2) >> 2 : (t1 + 2) >> 2;
+        if (mode == 7 && k == 0)
+            v = (t0 + l0 + 4) >> 3;
+        break;
+    default: break; /* 6: DC_128 */
+    }
+    out[0] = out[1] = out[2] = out[3] = v;
+}
+
+template <typename PIX, class X>
+IMB_FN void imb_c422_reconstruct(X &x, ImbTileC422<PIX> &T, const FFHipH264IntraC422 &R, const typename ImbCoef<PIX>::T *coefs, int maxv)
+{
+    typedef typename ImbCoef<PIX>::T CF;
+    if (R.type == FFHIP_H264_INTRA_PCM) {
+        /* 8 x 16 samples of Cb, then of Cr, as they stand in the bitstream (h264_mb_template.c:98-150 with block_h = 16) */
+        const PIX *pcm = reinterpret_cast<const PIX *>(coefs);
+        x.run([&](int lane) IMB_INL {
+            const int p = lane >> 5, r = (lane >> 1) & 15, c0 = 4 * (lane & 1);
+            for (int j = 0; j < 4; j++)
+                T.c[p][imb_ci(r, c0 + j)] = pcm[128 * p + 8 * r + c0 + j];
+        });
+        return;
+    }
+    x.run([&](int lane) IMB_INL {
+        const int p = lane >> 5, k = (lane >> 2) & 7, xx = lane & 3, xc = 4 * (k & 1) + xx, y0 = 4 * (k >> 1);
+        const PIX *tc = T.c[p];
+        auto TOP = [&](int i) { return (int)tc[imb_ci(-1, i)]; };
+        auto LEFT = [&](int i) { return (int)tc[imb_ci(i, -1)]; };
+        int pred[4];
+        imb_pred8x16_col<PIX>((int)R.chroma_pred, k, xc, y0, TOP, LEFT, maxv, pred);
+        int dc = 0;
+        bool dconly = false;
+        const CF *b = T.zero;
+        if (R.cbp & 0x30) {
+            const uint32_t trav = (uint32_t)R.blocks;
+            auto blk = [&](int bit) -> const CF * { return ((trav >> bit) & 1u) ? coefs + 16 * imb_popc(trav & ((1u << bit) - 1u)) : T.zero; };
+            int d[8];
+            for (int q = 0; q < 8; q++)
+                d[q] = blk(8 * p + q)[0];
+            const int own = d[k];
+            if ((R.flags >> p) & 1) {
+                /* chroma422_dc_dequant_idct: block q = row q >> 1, column q & 1 of the 4 x 2 DC array */
+                uint32_t t[8];
+                for (int i = 0; i < 4; i++) {
+                    t[2 * i] = (uint32_t)d[2 * i] + (uint32_t)d[2 * i + 1];
+                    t[2 * i + 1] = (uint32_t)d[2 * i] - (uint32_t)d[2 * i + 1];
+                }
+                const int i = k & 1, w = k >> 1;
+                const uint32_t z0 = t[i] + t[4 + i], z1 = t[i] - t[4 + i], z2 = t[2 + i] - t[6 + i], z3 = t[2 + i] + t[6 + i];
+                const uint32_t v = w == 0 ? z0 + z3 : w == 1 ? z1 + z2 : w == 2 ? z1 - z2 : z0 - z3;
+                dc = (int)(CF)((int)(v * (uint32_t)R.qmul[p] + 128u) >> 8);
+            } else {
+                dc = own;
+            }
+            const int bit = 8 * p + k;
+            const bool full = ((R.full >> bit) & 1) && ((trav >> bit) & 1u);
+            b = full ? blk(bit) : T.zero;
+            dconly = !full && dc != 0;
+        }
+        int res[4];
+        imb_resid4_col(b, dc, dconly, xx, res);
+        for (int j = 0; j < 4; j++)
+            T.c[p][imb_ci(y0 + j, xc)] = (PIX)imb_clip<PIX>(pred[j] + res[j], maxv);
+    });
+}
 #endif

@@ -730,6 +730,22 @@ typedef struct FFHipH264IntraMB {
                                  coefficients each), bit 16 + k Cb block k, bit 20 + k Cr block k                     */
     int16_t  luma_dc[16];     /* sl->mb_luma_dc[0] (Intra16x16)                                                      */
 } FFHipH264IntraMB;           /* sizeof == 108 */
+/** The chroma planes of an intra macroblock of a 4:2:2 picture, as ffhip_h264_picture_intra_mb() records them on a picture made with
+ *  chroma_format_idc 2 (its luma is a luma-only FFHipH264IntraMB): pred8x16 by chroma_pred_mode on both planes, chroma422_dc_dequant_idct
+ *  + idct_add8_422 when cbp & 0x30 (libavcodec/h264_mb_template.c:151-262, h264idct_template.c:230-252,295-321).  Exported through
+ *  ffhip_h264_picture_lists(). */
+typedef struct FFHipH264IntraC422 {
+    int16_t  mb_x, mb_y;
+    uint8_t  type;        /* FFHIP_H264_INTRA_PCM: the run holds 2 x 128 samples; anything else: prediction + residual */
+    uint8_t  chroma_pred; /* sl->chroma_pred_mode (after ff_h264_check_intra_pred_mode)                                */
+    uint8_t  cbp;         /* sl->cbp & 0x30                                                                            */
+    uint8_t  flags;       /* bit p: nnz[scan8[CHROMA_DC_BLOCK_INDEX + p]] — the plane's DC block is coded             */
+    int32_t  qmul[2];     /* pps->dequant4_coeff[1 + p][sl->chroma_qp[p] + 3][0]                                       */
+    uint16_t full;        /* bit 8 p + k: block k of plane p has a non-zero count (idct_add; else idct_dc_add if its DC != 0) */
+    uint16_t blocks;      /* bit 8 p + k: block k of plane p travels in the run (16 coefficients each, in bit order)   */
+    int32_t  coef;        /* the run's start in the packed coefficient array (int16 units)                             */
+    int32_t  pad[2];
+} FFHipH264IntraC422;     /* sizeof == 32 */
 /** Records one intra macroblock: *mb with the fields above `flags` set.  non_zero_count_cache: the decoder's 15 x 8 cache
  *  (scan8 indexing, libavcodec/h264_parse.h:40-57).  mb: sl->mb (3 x 256 int16; Cb at 256, Cr at 512), CONSUMED the way the dsp
  *  functions hl_decode_mb() calls consume it (blocks zeroed after idct_add, [0] after idct_dc_add).  mb_luma_dc: sl->mb_luma_dc[0]
@@ -793,7 +809,9 @@ int  ffhip_h264_intra_planes_dev(int bit_depth, int nplanes, const FFHipH264Intr
  *    idct_off / idct_coef[plane][kind]  residual blocks by FFHIP_H264_IDCT4 / IDCT8 / IDCT4_DC / IDCT8_DC: nidct offsets, 16 or 64 dctcoef each
  *    intra[set] / intra_coef[set]  intra macroblock records in recording order and their packed runs (int16 units): set 0 = whole
  *                        macroblocks (4:2:0), or one luma-only set per plane (4:4:4)
- *    edges[plane]        mb_w * mb_h * (8 | 4) edge records (zero records = not filtered), NULL when the plane has none */
+ *    edges[plane]        mb_w * mb_h * (8 | 4 | 6) edge records (zero records = not filtered), NULL when the plane has none; a 4:2:2
+ *                        chroma plane: 6 per macroblock — the vertical edges at x = 0, 4 (16 lines, tc0 per 4 lines), then the horizontal
+ *                        ones at y = 0, 4, 8, 12 */
 typedef struct FFHipH264PictureLists {
     int mb_w, mb_h, bit_depth, chroma_format_idc;
     const FFHipQpelBlock *qpel[3][3];
@@ -810,6 +828,11 @@ typedef struct FFHipH264PictureLists {
     const int16_t *intra_coef[3];
     int nintra_coef[3];
     const FFHipH264Edge *edges[3];
+    /* 4:2:2: the chroma planes of the intra macroblocks (their luma: intra[0], luma-only) and their packed runs (int16 units) */
+    const FFHipH264IntraC422 *intra_c422;
+    int nintra_c422;
+    const int16_t *intra_c422_coef;
+    int nintra_c422_coef;
 } FFHipH264PictureLists;
 int  ffhip_h264_picture_lists(const FFHipH264Picture *p, FFHipH264PictureLists *out);
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
