@@ -46,7 +46,7 @@ struct FFHipH264Picture {
     int device = 0; /* staging and scratch planes live on this device; flush() makes it current for its duration */
     int mb_w = 0, mb_h = 0;
     int bd = 8;     /* sample depth: above 8 the planes hold uint16_t, coefficient blocks int32_t (dctcoef, bit_depth_template.c:39-50) */
-    int cfmt = 1;   /* sps->chroma_format_idc: 1 (4:2:0) or 3 (4:4:4: Cb and Cr are reconstructed by the LUMA members, hl_decode_mb_444) */
+    int cfmt = 1;   /* sps->chroma_format_idc: 1 (4:2:0), 2 (4:2:2: 8 x 16 chroma) or 3 (4:4:4: Cb and Cr through the LUMA members, hl_decode_mb_444) */
     std::vector<FFHipQpelBlock> qpel[3][3];       /* luma-table MC: plane (4:2:0: plane 0 only) x stage */
     std::vector<FFHipChromaBlock> cmc[2][3];      /* chroma MC: plane (Cb, Cr) x stage     */
     std::vector<FFHipWeightBlock> wt[3];          /* weight / biweight per plane           */
@@ -58,6 +58,10 @@ struct FFHipH264Picture {
     std::vector<int16_t> intra_coef[3];
     std::vector<FFHipH264IntraMB> intra_sorted[3]; /* flush(): by (mb_y, mb_x)               */
     std::vector<int32_t> intra_rows[3];            /* flush(): mb_h + 1 row starts           */
+    /* 4:2:2: [0] above holds the macroblocks' luma as luma-only records, the chroma planes have records and a wavefront of their own */
+    std::vector<FFHipH264IntraC422> intra_c422, intra_c422_sorted;
+    std::vector<int16_t> intra_c422_coef;
+    std::vector<int32_t> intra_c422_rows;
     std::vector<FFHipH264Edge> edges[3];          /* whole-picture edge arrays, zero = skip */
     bool any_edge[3] = { false, false, false };
     void *pinned = nullptr, *dev = nullptr;
@@ -72,7 +76,7 @@ struct FFHipH264Picture {
     /* geometry of plane pl in samples / rows, and the edge records a macroblock has in it */
     int plane_w(int pl) const { return (pl && cfmt != 3 ? 8 : 16) * mb_w; }
     int plane_h(int pl) const { return (pl && cfmt == 1 ? 8 : 16) * mb_h; }
-    int edges_per_mb(int pl) const { return pl && cfmt != 3 ? 4 : 8; }
+    int edges_per_mb(int pl) const { return !pl || cfmt == 3 ? 8 : cfmt == 2 ? 6 : 4; } /* 4:2:2 chroma: x = 0, 4, then y = 0, 4, 8, 12 */
     int intra_sets() const { return cfmt == 3 ? 3 : 1; }
 };
 
@@ -115,6 +119,8 @@ extern "C" void ffhip_h264_picture_begin(FFHipH264Picture *p)
         p->cmc[0][s].clear();
         p->cmc[1][s].clear();
     }
+    p->intra_c422.clear();
+    p->intra_c422_coef.clear();
     for (int pl = 0; pl < 3; pl++) {
         p->intra[pl].clear();
         p->intra_coef[pl].clear();
@@ -144,10 +150,10 @@ extern "C" int ffhip_h264_picture_create_fmt(FFHipH264Picture **pp, int mb_w, in
     if (!pp || mb_w <= 0 || mb_h <= 0)
         return FFHIP_EINVAL;
     *pp = nullptr;
-    if (chroma_format_idc != 1 && chroma_format_idc != 3) {
-        /* 4:2:2 (hl_motion_422, the 8x16 chroma predictors and its chroma edge filters in frame order) and monochrome stay on the C path */
-        ffhip_set_error("ffhip_h264_picture_create_fmt: chroma_format_idc %d (1 = 4:2:0 and 3 = 4:4:4 are built)", chroma_format_idc);
-        return chroma_format_idc == 0 || chroma_format_idc == 2 ? FFHIP_ENOSYS : FFHIP_EINVAL;
+    if (chroma_format_idc < 1 || chroma_format_idc > 3) {
+        /* monochrome stays on the C path */
+        ffhip_set_error("ffhip_h264_picture_create_fmt: chroma_format_idc %d (1 = 4:2:0, 2 = 4:2:2 and 3 = 4:4:4 are built)", chroma_format_idc);
+        return chroma_format_idc == 0 ? FFHIP_ENOSYS : FFHIP_EINVAL;
     }
     if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14) {
         ffhip_set_error("ffhip_h264_picture_create_hbd: bit depth %d (8, 9, 10, 12 and 14 are the depths H.264 defines)", bit_depth);
@@ -274,6 +280,17 @@ extern "C" int ffhip_h264_picture_idct_mb(FFHipH264Picture *p, int which, int pl
                 r = ffhip_h264_picture_idct_add(p, plane, nnz == 1 && coef0(i) ? FFHIP_H264_IDCT8_DC : FFHIP_H264_IDCT8, dst_offset[0] + block_offset[i],
                                                 block + i * 16 * wide);
         }
+    } else if (which == 3 && p->cfmt == 2) {
+        /* ff_h264_idct_add8_422 (h264idct_template.c:230-252): eight blocks per plane — coefficients 16 j + k, cache entries and offsets
+         * 16 j + k for the upper four, 16 j + k + 4 for the lower four (scan8_chroma(j, k) runs on down the cache for k = 4..7) */
+        for (int j = 1; j < 3 && r >= 0; j++)
+            for (int k = 0; k < 8 && r >= 0; k++) {
+                const int i = j * 16 + k, at = k < 4 ? i : i + 4;
+                if (nnzc[scan8_chroma(j, k)])
+                    r = ffhip_h264_picture_idct_add(p, j, FFHIP_H264_IDCT4, dst_offset[j - 1] + block_offset[at], block + i * 16 * wide);
+                else if (coef0(i))
+                    r = ffhip_h264_picture_idct_add(p, j, FFHIP_H264_IDCT4_DC, dst_offset[j - 1] + block_offset[at], block + i * 16 * wide);
+            }
     } else if (which == 3 && p->cfmt == 1) {
         for (int j = 1; j < 3 && r >= 0; j++)
             for (int i = j * 16; i < j * 16 + 4 && r >= 0; i++) {
@@ -451,12 +468,105 @@ extern "C" int ffhip_h264_intra_pack_plane(int bit_depth, FFHipH264IntraMB *rec,
     return intra_pack<int32_t>(bit_depth, rec, nnzc, mb, mb_luma_dc, pcm, coefs, ncoefs, cap, true);
 }
 
+/* The chroma planes of an intra macroblock of a 4:2:2 picture: which of the 2 x 8 blocks travel, consumed as chroma422_dc_dequant_idct +
+ * idct_add8_422 leave them (h264idct_template.c:230-252: idct_add zeroes a block, idct_dc_add its DC; the DC positions the dequantiser
+ * wrote are among them).  qmul: pps->dequant4_coeff[1 + p][chroma_qp[p] + 3][0].  pcm: the 2 x 128 chroma fields (after the 256 luma ones). */
+template <typename CF>
+static int intra_pack_c422(int bd, FFHipH264IntraC422 *rec, const FFHipH264IntraMB *d, const uint8_t *nnzc, int16_t *mb_, const uint8_t *pcm,
+                           std::vector<int16_t> &coefs)
+{
+    constexpr int W = (int)(sizeof(CF) / sizeof(int16_t));
+    FFHipH264IntraC422 &R = *rec;
+    memset(&R, 0, sizeof(R));
+    R.mb_x = d->mb_x;
+    R.mb_y = d->mb_y;
+    R.type = d->type;
+    R.chroma_pred = d->chroma_pred;
+    R.cbp = d->cbp & 0x30;
+    R.qmul[0] = d->qmul[1];
+    R.qmul[1] = d->qmul[2];
+    while (coefs.size() & 7)
+        coefs.push_back(0); /* runs start on 16 bytes */
+    if (coefs.size() > (size_t)INT32_MAX - 4096)
+        return FFHIP_EINVAL;
+    R.coef = (int32_t)coefs.size();
+    if (R.type == FFHIP_H264_INTRA_PCM) {
+        if (!pcm)
+            return FFHIP_EINVAL;
+        const size_t at = coefs.size();
+        coefs.resize(at + 128 * W);
+        if (W == 1) {
+            memcpy(coefs.data() + at, pcm, 256);
+        } else {
+            uint16_t *out = reinterpret_cast<uint16_t *>(coefs.data() + at);
+            uint32_t acc = 0;
+            int have = 0;
+            for (int k = 0; k < 256; k++) { /* MSB-first bit_depth-bit fields (h264_mb_template.c:100-131) */
+                while (have < bd) {
+                    acc = (acc << 8) | *pcm++;
+                    have += 8;
+                }
+                have -= bd;
+                out[k] = (uint16_t)((acc >> have) & ((1u << bd) - 1u));
+            }
+        }
+        return 0;
+    }
+    if (!nnzc || !mb_)
+        return FFHIP_EINVAL;
+    CF *mb = reinterpret_cast<CF *>(mb_);
+    if (R.cbp & 0x30)
+        for (int pl = 1; pl < 3; pl++) {
+            if (nnzc[40 * pl]) /* scan8[CHROMA_DC_BLOCK_INDEX + pl - 1] */
+                R.flags |= (uint8_t)(1 << (pl - 1));
+            for (int k = 0; k < 8; k++) {
+                CF *b = mb + 256 * pl + 16 * k;
+                const int nnz = nnzc[scan8_chroma(pl, k)], bit = 8 * (pl - 1) + k;
+                if (nnz)
+                    R.full |= (uint16_t)(1u << bit);
+                if (nnz || b[0]) {
+                    R.blocks |= (uint16_t)(1u << bit);
+                    const size_t at = coefs.size();
+                    coefs.resize(at + 16 * W);
+                    memcpy(coefs.data() + at, b, sizeof(CF) * 16);
+                    if (nnz)
+                        memset(b, 0, sizeof(CF) * 16);
+                    else
+                        b[0] = 0;
+                }
+            }
+        }
+    return 0;
+}
+
 extern "C" int ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264IntraMB *d, const uint8_t *nnzc, int16_t *mb,
                                            const int16_t *mb_luma_dc, const uint8_t *pcm)
 {
     if (!p || !d || d->mb_x < 0 || d->mb_x >= p->mb_w || d->mb_y < 0 || d->mb_y >= p->mb_h)
         return FFHIP_EINVAL;
     const int wide = p->bd > 8 ? 2 : 1; /* int16 entries per dctcoef */
+    if (p->cfmt == 2) {
+        /* 4:2:2: the luma as a luma-only record of the wavefront, the two 8 x 16 chroma planes as a record of their own */
+        FFHipH264IntraMB R = *d;
+        std::vector<int16_t> &c = p->intra_coef[0];
+        if (c.size() > (size_t)INT32_MAX - 2048)
+            return FFHIP_EINVAL;
+        int32_t n = (int32_t)c.size();
+        c.resize((size_t)n + 816);
+        int r = ffhip_h264_intra_pack_plane(p->bd, &R, nnzc, mb, mb_luma_dc, pcm, c.data(), &n, (int32_t)c.size());
+        c.resize((size_t)n);
+        if (r < 0)
+            return r;
+        FFHipH264IntraC422 C;
+        const uint8_t *pcm_c = pcm ? pcm + (p->bd > 8 ? 32 * p->bd : 256) : nullptr; /* behind the 256 luma fields */
+        r = p->bd > 8 ? intra_pack_c422<int32_t>(p->bd, &C, d, nnzc, mb, pcm_c, p->intra_c422_coef)
+                      : intra_pack_c422<int16_t>(8, &C, d, nnzc, mb, pcm_c, p->intra_c422_coef);
+        if (r < 0)
+            return r;
+        p->intra[0].push_back(R);
+        p->intra_c422.push_back(C);
+        return 0;
+    }
     for (int pl = 0; pl < p->intra_sets(); pl++) {
         FFHipH264IntraMB R = *d;
         std::vector<int16_t> &c = p->intra_coef[pl];
@@ -541,6 +651,10 @@ extern "C" int ffhip_h264_picture_lists(const FFHipH264Picture *p, FFHipH264Pict
         out->nintra_coef[pl] = (int)p->intra_coef[pl].size();
         out->edges[pl] = p->any_edge[pl] ? p->edges[pl].data() : nullptr;
     }
+    out->intra_c422 = p->intra_c422.data();
+    out->nintra_c422 = (int)p->intra_c422.size();
+    out->intra_c422_coef = p->intra_c422_coef.data();
+    out->nintra_c422_coef = (int)p->intra_c422_coef.size();
     return 0;
 }
 
@@ -560,6 +674,10 @@ struct FlushBack {
     int nintra = 0;                 /* wavefronts of this picture: 1 (4:2:0, all three planes), or one per plane that has records (4:4:4) */
     FFHipH264IntraPic ip[3] = {};
     const FFHipH264Edge *edges[3] = { nullptr, nullptr, nullptr };
+    /* 4:2:2: the chroma planes' wavefront */
+    const FFHipH264IntraC422 *c422 = nullptr;
+    const int32_t *c422_rows = nullptr;
+    const int16_t *c422_coef = nullptr;
 };
 
 /* the picture's intra wavefront(s) and in-loop filter, from what the front half left in `B` */
@@ -570,12 +688,23 @@ static int flush_tail(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
     /* ---- intra macroblocks: every inter macroblock is complete now; one wavefront over the three planes (4:4:4: one per plane, side by
      * side in one launch) ---- */
     if (B.nintra)
-        r = ffhip_launch_h264_intra_frames_bd(bd, B.nintra, B.ip, stride[0], stride[1], p->mb_w, p->mb_h, stream, p->cfmt == 3);
+        r = ffhip_launch_h264_intra_frames_bd(bd, B.nintra, B.ip, stride[0], stride[1], p->mb_w, p->mb_h, stream, p->cfmt != 1);
+    if (r >= 0 && B.c422) /* 4:2:2: the luma above was luma-only; the 8 x 16 chroma planes are a wavefront of their own */
+        r = ffhip_launch_h264_intra_c422(bd, dst[1], dst[2], stride[1], p->mb_w, p->mb_h, B.c422, B.c422_rows, B.c422_coef, stream);
     if (r < 0)
         return r;
     /* ---- in-loop filter, decoder order: the planes are independent, and a lone wavefront is a chain of dependent hand-offs that
      * leaves the GPU mostly idle — the chroma planes run beside the luma plane on the second stream ---- */
     const bool chroma = B.edges[1] || B.edges[2];
+    if (p->cfmt == 2) {
+        /* 4:2:2: 8 x 16 chroma macroblocks with six edges each: a frame-order kernel of their own, on the caller's stream behind luma */
+        if (B.edges[0])
+            r = ffhip_launch_h264_deblock_frames_bd(bd, 0, dst[0], 0, 1, stride[0], p->mb_w, p->mb_h, B.edges[0], stream);
+        for (int pl = 1; pl < 3 && r >= 0; pl++)
+            if (B.edges[pl])
+                r = ffhip_launch_h264_deblock_c422(bd, dst[pl], stride[pl], p->mb_w, p->mb_h, B.edges[pl], stream);
+        return r < 0 ? r : 0;
+    }
     if (p->cfmt == 3) {
         /* all three planes by the luma filter (filter_mb_edgev / edgeh on img_cb / img_cr, h264_loopfilter.c:601-703): one launch of
          * three "pictures" when the skewed-rows kernel can address them by table, else plane by plane */
@@ -667,9 +796,31 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
         }
     }
 
+    if (!p->intra_c422.empty() && (stride[1] != stride[2] || (((uintptr_t)dst[1] | (uintptr_t)dst[2] | (unsigned)stride[1]) & (p->bd > 8 ? 7u : 3u)))) {
+        ffhip_set_error("ffhip_h264_picture_flush: the chroma planes of a 4:2:2 picture with intra macroblocks share one stride and are %d-byte "
+                        "aligned", p->bd > 8 ? 8 : 4);
+        return FFHIP_EINVAL;
+    }
     /* layout of the one staging buffer */
     size_t total = 0;
     Section s_qpel[3][3], s_cmc[2][3], s_wt[3], s_ioff[3][4], s_icoef[3][4], s_edge[3], s_intra[3], s_irows[3], s_intracoef[3];
+    Section s_c422, s_c422rows, s_c422coef;
+    if (!p->intra_c422.empty()) {
+        p->intra_c422_sorted = p->intra_c422;
+        std::stable_sort(p->intra_c422_sorted.begin(), p->intra_c422_sorted.end(), [](const FFHipH264IntraC422 &a, const FFHipH264IntraC422 &b) {
+            return a.mb_y != b.mb_y ? a.mb_y < b.mb_y : a.mb_x < b.mb_x;
+        });
+        p->intra_c422_rows.assign((size_t)p->mb_h + 1, 0);
+        for (const FFHipH264IntraC422 &a : p->intra_c422_sorted)
+            p->intra_c422_rows[(size_t)a.mb_y + 1]++; /* (a macroblock recorded twice is caught on its luma record below) */
+        for (int r = 0; r < p->mb_h; r++)
+            p->intra_c422_rows[(size_t)r + 1] += p->intra_c422_rows[r];
+        if (p->intra_c422_coef.empty())
+            p->intra_c422_coef.assign(8, 0);
+        place(total, p->intra_c422_sorted, s_c422);
+        place(total, p->intra_c422_rows, s_c422rows);
+        place(total, p->intra_c422_coef, s_c422coef);
+    }
     for (int q = 0; q < nsets; q++) {
         if (p->intra[q].empty())
             continue;
@@ -752,6 +903,11 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
             put(s_irows[q], p->intra_rows[q].data(), p->intra_rows[q].size() * sizeof(int32_t));
             put(s_intracoef[q], p->intra_coef[q].data(), p->intra_coef[q].size() * sizeof(int16_t));
         }
+    if (!p->intra_c422.empty()) {
+        put(s_c422, p->intra_c422_sorted.data(), p->intra_c422_sorted.size() * sizeof(FFHipH264IntraC422));
+        put(s_c422rows, p->intra_c422_rows.data(), p->intra_c422_rows.size() * sizeof(int32_t));
+        put(s_c422coef, p->intra_c422_coef.data(), p->intra_c422_coef.size() * sizeof(int16_t));
+    }
     bool need_tmp[3] = { false, false, false };
     for (int s = 0; s < 3; s++) {
         for (int pl = 0; pl < 3; pl++)
@@ -807,6 +963,11 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
     for (int pl = 0; pl < 3; pl++)
         if (p->any_edge[pl])
             B.edges[pl] = (const FFHipH264Edge *)(db + s_edge[pl].off);
+    if (!p->intra_c422.empty()) {
+        B.c422 = (const FFHipH264IntraC422 *)(db + s_c422.off);
+        B.c422_rows = (const int32_t *)(db + s_c422rows.off);
+        B.c422_coef = (const int16_t *)(db + s_c422coef.off);
+    }
 
     int r = 0;
     if (p->bd > 8) {
@@ -917,6 +1078,14 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
             }
     if (n == 1)
         return flush_impl(pics[0], dst, stride, ref, stream_, nullptr);
+    if (pics[0]->cfmt == 2) { /* 4:2:2: the chroma planes' two frame-order kernels take one picture per launch: the pictures one by one */
+        for (int i = 0; i < n; i++) {
+            const int r = flush_impl(pics[i], dst + 3 * i, stride, ref + 3 * i, stream_, nullptr);
+            if (r < 0)
+                return r;
+        }
+        return 0;
+    }
     if (pics[0]->cfmt == 3 && (stride[1] != stride[0] || stride[2] != stride[0])) {
         ffhip_set_error("ffhip_h264_pictures_flush: the planes of 4:4:4 pictures share one stride");
         return FFHIP_EINVAL;

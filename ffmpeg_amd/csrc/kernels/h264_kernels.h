@@ -65,6 +65,10 @@ int ffhip_launch_h264_intra_frame(uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_
                                   const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
 int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *cr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                      const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
+/* 4:2:2 (kernels/h264_c422.hip): the chroma planes' intra wavefront and their frame-order in-loop filter, one picture per launch */
+int ffhip_launch_h264_intra_c422(int bd, uint8_t *cb, uint8_t *cr, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraC422 *recs,
+                                 const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
+int ffhip_launch_h264_deblock_c422(int bd, uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges, hipStream_t stream);
 #define FFHIP_DB_PTRS 32
 int ffhip_launch_h264_deblock_pictures_bd(int bd, int chroma, uint8_t *const *planes, const FFHipH264Edge *const *edges, int nframes, ptrdiff_t stride,
                                           int mb_w, int mb_h, hipStream_t stream);

@@ -65,7 +65,7 @@ static int classify_dst(const FFHipH264Recorder *r, const uint8_t *p)
         const size_t o = (size_t)(p - r->scratch);
         if (o >= (size_t)16 * r->linesize[1])
             return 16;
-        return (o % (size_t)r->linesize[1]) >= ((size_t)(r->cfmt == 3 ? 16 : 8) << r->pixel_shift) ? 18 : 17;
+        return (o % (size_t)r->linesize[1]) >= ((size_t)(r->cfmt == 3 ? 16 : 8) << r->pixel_shift) ? 18 : 17; /* (4:2:2: 8 wide, 16 rows) */
     }
     return -1;
 }
@@ -316,12 +316,20 @@ static void rec_edge(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int be
         if ((x >> 4) != cur_edges.mb_x || (y >> 4) != cur_edges.mb_y)
             FAIL(FFHIP_EINVAL);
         e = dir ? (y & 15) >> 2 : (x & 15) >> 2;
+    } else if (r->cfmt == 2) {
+        /* 4:2:2: an 8 x 16 chroma macroblock — the vertical edges x = 0, 4 (h_loop_filter_chroma422, 16 lines), then the horizontal ones
+         * y = 0, 4, 8, 12 (filter_mb_dir(), h264_loopfilter.c:601-703 with chroma422): six records, [0..1] then [2..5] */
+        if ((x >> 3) != cur_edges.mb_x || (y >> 4) != cur_edges.mb_y)
+            FAIL(FFHIP_EINVAL);
+        E = &cur_edges.e[pl][dir ? 2 + ((y & 15) >> 2) : (x & 7) >> 2];
+        goto fill;
     } else {
         if ((x >> 3) != cur_edges.mb_x || (y >> 3) != cur_edges.mb_y)
             FAIL(FFHIP_EINVAL);
         e = dir ? (y & 7) >> 2 : (x & 7) >> 2;
     }
     E = &cur_edges.e[pl][dir * (chroma ? 2 : 4) + e];
+fill:
     E->offset = (int32_t)o;
     E->kind = (uint8_t)kind;
     E->alpha = (uint8_t)alpha;
@@ -384,7 +392,7 @@ void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, con
         r->ref_base[pl] = ref_base[pl];
         r->linesize[pl] = ls << r->field;
         r->pic_w[pl] = h->mb_width * (pl && r->cfmt != 3 ? 8 : 16);
-        r->rows[pl] = (h->mb_height >> r->field) * (pl && r->cfmt == 1 ? 8 : 16);
+        r->rows[pl] = (h->mb_height >> r->field) * (pl && r->cfmt == 1 ? 8 : 16);   /* (4:2:2: chroma 8 wide, 16 rows per macroblock) */
     }
     r->scratch = sl->bipred_scratchpad;
     /* tmp_y starts 16 chroma rows in and is 16 luma rows tall; both buffers are walked at mb_linesize (alloc_scratch_buffers(),
@@ -399,7 +407,7 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
     const int mb_type = h->cur_pic.mb_type[sl->mb_xy];
     if (r->error < 0)
         return r->error;
-    if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field || CHROMA422(h) || !h->ps.sps->chroma_format_idc ||
+    if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field || !h->ps.sps->chroma_format_idc ||
         (sl->qscale == 0 && h->ps.sps->transform_bypass))
         return r->error = FFHIP_ENOSYS;   /* such a picture stays on the C path as a whole */
     if (IS_INTRA(mb_type)) {
@@ -420,8 +428,9 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
          * three table entries are plane p's luma_dc_dequant_idct qmul, dequant4_coeff[p][p ? chroma_qp[p - 1] : qscale][0] (h264_mb.c:626,
          * 712), and sl->mb / sl->mb_luma_dc / the cache hold the three planes one after the other (libffhip splits them) */
         m.qmul[0] = h->ps.pps->dequant4_coeff[intra_qmul][sl->qscale][0];
-        m.qmul[1] = h->ps.pps->dequant4_coeff[1][sl->chroma_qp[0]][0];
-        m.qmul[2] = h->ps.pps->dequant4_coeff[2][sl->chroma_qp[1]][0];
+        /* (4:2:2: chroma422_dc_dequant_idct's quantiser sits three steps up, h264_mb_template.c:232-236) */
+        m.qmul[1] = h->ps.pps->dequant4_coeff[1][sl->chroma_qp[0] + (CHROMA422(h) ? 3 : 0)][0];
+        m.qmul[2] = h->ps.pps->dequant4_coeff[2][sl->chroma_qp[1] + (CHROMA422(h) ? 3 : 0)][0];
         h->list_counts[sl->mb_xy] = sl->list_count;   /* hl_decode_mb()'s one side effect outside the pixels (h264_mb_template.c:61) */
         r->error = FFMIN(0, ffhip_h264_picture_intra_mb(r->pic, &m, sl->non_zero_count_cache, sl->mb, sl->mb_luma_dc[0], sl->intra_pcm_ptr));
         return r->error;
@@ -448,10 +457,11 @@ int ff_h264_hip_filter_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceC
     cur_edges.mb_y = mb_y >> r->field;     /* the row inside the field: what loop_filter()'s `dest -= linesize * 15` amounts to */
     cur_rec = r;
     {
-        const int cs = r->cfmt == 3 ? 16 : 8, fy = mb_y >> r->field; /* the chroma planes' macroblock size; the macroblock's row in `pic` */
+        /* the chroma planes' macroblock width and height; the macroblock's row in `pic` */
+        const int cs = r->cfmt == 3 ? 16 : 8, ch = r->cfmt == 1 ? 8 : 16, fy = mb_y >> r->field;
         uint8_t *y  = (uint8_t *)r->cur[0] + ((ptrdiff_t)mb_x << h->pixel_shift) * 16 + (ptrdiff_t)fy * r->linesize[0] * 16;
-        uint8_t *cb = (uint8_t *)r->cur[1] + ((ptrdiff_t)mb_x << h->pixel_shift) * cs + (ptrdiff_t)fy * r->linesize[1] * cs;
-        uint8_t *cr = (uint8_t *)r->cur[2] + ((ptrdiff_t)mb_x << h->pixel_shift) * cs + (ptrdiff_t)fy * r->linesize[2] * cs;
+        uint8_t *cb = (uint8_t *)r->cur[1] + ((ptrdiff_t)mb_x << h->pixel_shift) * cs + (ptrdiff_t)fy * r->linesize[1] * ch;
+        uint8_t *cr = (uint8_t *)r->cur[2] + ((ptrdiff_t)mb_x << h->pixel_shift) * cs + (ptrdiff_t)fy * r->linesize[2] * ch;
         sl->mb_linesize = r->linesize[0];      /* as loop_filter() leaves them (h264_slice.c:2480-2491) */
         sl->mb_uvlinesize = r->linesize[1];
         ff_h264_filter_mb(h, sl, mb_x, mb_y, y, cb, cr, (unsigned)r->linesize[0], (unsigned)r->linesize[1]);

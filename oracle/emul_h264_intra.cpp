@@ -100,3 +100,53 @@ extern "C" int ffemul_h264_intra_frame_bd(int bd, uint8_t *py, uint8_t *pcb, uin
         return intra_frame<uint8_t>(py, pcb, pcr, sy, sc, mb_w, mb_h, recs, row_start, coefs, 255);
     return intra_frame<uint16_t>(py, pcb, pcr, sy, sc, mb_w, mb_h, recs, row_start, coefs, (1 << bd) - 1);
 }
+
+/* ---- 4:2:2: the chroma planes' wavefront (k_h264_intra_c422), macroblocks in raster order ---- */
+template <typename PIX>
+static int intra_c422_frame(uint8_t *pcb, uint8_t *pcr, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraC422 *recs, const int32_t *row_start,
+                            const int16_t *coefs, int maxv)
+{
+    typedef typename ImbCoef<PIX>::T CF;
+    constexpr int PS = (int)sizeof(PIX);
+    EmulWave X;
+    for (int my = 0; my < mb_h; my++)
+        for (int k = row_start[my]; k < row_start[my + 1]; k++) {
+            const FFHipH264IntraC422 &R = recs[k];
+            const int mx = R.mb_x;
+            if (R.mb_y != my || mx < 0 || mx >= mb_w || (k > row_start[my] && recs[k - 1].mb_x >= mx))
+                return -1;
+            ImbTileC422<PIX> T;
+            memset(&T, 0xA5, sizeof(T));
+            memset(T.zero, 0, sizeof(T.zero));
+            uint8_t *cmb[2] = { pcb + (ptrdiff_t)my * 16 * sc + mx * 8 * PS, pcr + (ptrdiff_t)my * 16 * sc + mx * 8 * PS };
+            const bool has_l = mx > 0, has_t = my > 0;
+            for (int p = 0; p < 2; p++) {
+                for (int c = -4; c < 8; c++) { /* the row above, corner included; what lies outside the picture reads as 0 */
+                    PIX v = 0;
+                    if (has_t && (c >= 0 || has_l))
+                        memcpy(&v, cmb[p] - sc + c * PS, PS);
+                    T.c[p][imb_ci(-1, c)] = v;
+                }
+                for (int r = 0; r < 16; r++)
+                    for (int c = -4; c < 0; c++) {
+                        PIX v = 0;
+                        if (has_l)
+                            memcpy(&v, cmb[p] + (ptrdiff_t)r * sc + c * PS, PS);
+                        T.c[p][imb_ci(r, c)] = v;
+                    }
+            }
+            imb_c422_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(coefs + R.coef), maxv);
+            for (int p = 0; p < 2; p++)
+                for (int r = 0; r < 16; r++)
+                    memcpy(cmb[p] + (ptrdiff_t)r * sc, &T.c[p][imb_ci(r, 0)], 8 * PS);
+        }
+    return 0;
+}
+
+extern "C" int ffemul_h264_intra_c422_frame_bd(int bd, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraC422 *recs,
+                                               const int32_t *row_start, const int16_t *coefs)
+{
+    if (bd == 8)
+        return intra_c422_frame<uint8_t>(pcb, pcr, sc, mb_w, mb_h, recs, row_start, coefs, 255);
+    return intra_c422_frame<uint16_t>(pcb, pcr, sc, mb_w, mb_h, recs, row_start, coefs, (1 << bd) - 1);
+}

@@ -25,6 +25,8 @@ extern "C" {
 void ffemul_h264_intra_set_split(int on);
 int ffemul_h264_intra_frame_bd(int bd, uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                const FFHipH264IntraMB *recs, const int32_t *row_start, const int16_t *coefs);
+int ffemul_h264_intra_c422_frame_bd(int bd, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraC422 *recs,
+                                    const int32_t *row_start, const int16_t *coefs);
 }
 
 static_assert(sizeof(FfoH264Edge) == sizeof(FFHipH264Edge), "one edge record layout");
@@ -50,11 +52,11 @@ const uint8_t *emu_window(std::vector<uint8_t> &tmp, const uint8_t *pic00, ptrdi
  * executor does not know how to run. */
 extern "C" int ffemul_h264_picture_flush(const FFHipH264PictureLists *L, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3])
 {
-    const int bd = L->bit_depth, px = bd > 8 ? 2 : 1, wide = px, c444 = L->chroma_format_idc == 3;
-    if (L->chroma_format_idc != 1 && !c444)
+    const int bd = L->bit_depth, px = bd > 8 ? 2 : 1, wide = px, c444 = L->chroma_format_idc == 3, c422 = L->chroma_format_idc == 2;
+    if (L->chroma_format_idc < 1 || L->chroma_format_idc > 3)
         return -1;
     const int pw[3] = { 16 * L->mb_w, (c444 ? 16 : 8) * L->mb_w, (c444 ? 16 : 8) * L->mb_w };
-    const int ph[3] = { 16 * L->mb_h, (c444 ? 16 : 8) * L->mb_h, (c444 ? 16 : 8) * L->mb_h };
+    const int ph[3] = { 16 * L->mb_h, (c444 || c422 ? 16 : 8) * L->mb_h, (c444 || c422 ? 16 : 8) * L->mb_h };
     std::vector<uint8_t> scratch[3], win;
     for (int pl = 0; pl < 3; pl++)
         scratch[pl].assign((size_t)ph[pl] * (size_t)stride[pl] + 64, 0xCD);
@@ -121,7 +123,7 @@ extern "C" int ffemul_h264_picture_flush(const FFHipH264PictureLists *L, uint8_t
         std::vector<int16_t> coefs(L->intra_coef[q], L->intra_coef[q] + L->nintra_coef[q]);
         coefs.resize(coefs.size() + 1024, 0); /* the kernel's run fetch is sized by the macroblock type, not by the run */
         int r;
-        if (c444) {
+        if (c444 || c422) { /* luma-only records: 4:4:4 every plane, 4:2:2 the luma plane */
             ffemul_h264_intra_set_split(2);
             r = ffemul_h264_intra_frame_bd(bd, dst[q], dst[q], dst[q], stride[q], stride[q], L->mb_w, L->mb_h, recs.data(), rows.data(), coefs.data());
             ffemul_h264_intra_set_split(0);
@@ -131,9 +133,27 @@ extern "C" int ffemul_h264_picture_flush(const FFHipH264PictureLists *L, uint8_t
         if (r)
             return -1;
     }
+    if (L->nintra_c422) { /* 4:2:2: the chroma planes' records through k_h264_intra_c422's phase body */
+        std::vector<FFHipH264IntraC422> recs(L->intra_c422, L->intra_c422 + L->nintra_c422);
+        std::stable_sort(recs.begin(), recs.end(), [](const FFHipH264IntraC422 &a, const FFHipH264IntraC422 &b) {
+            return a.mb_y != b.mb_y ? a.mb_y < b.mb_y : a.mb_x < b.mb_x;
+        });
+        std::vector<int32_t> rows((size_t)L->mb_h + 1, 0);
+        for (const FFHipH264IntraC422 &r : recs)
+            rows[(size_t)r.mb_y + 1]++;
+        for (int r = 0; r < L->mb_h; r++)
+            rows[(size_t)r + 1] += rows[r];
+        if (!c422 || stride[1] != stride[2] ||
+            ffemul_h264_intra_c422_frame_bd(bd, dst[1], dst[2], stride[1], L->mb_w, L->mb_h, recs.data(), rows.data(), L->intra_c422_coef))
+            return -1;
+    }
     /* ---- in-loop filter, decoder order ---- */
     for (int pl = 0; pl < 3; pl++)
-        if (L->edges[pl])
-            ffo_h264_deblock_frame_bd(bd, pl && !c444, dst[pl], stride[pl], L->mb_w, L->mb_h, reinterpret_cast<const FfoH264Edge *>(L->edges[pl]));
+        if (L->edges[pl]) {
+            if (pl && c422)
+                ffo_h264_deblock_frame_c422_bd(bd, dst[pl], stride[pl], L->mb_w, L->mb_h, reinterpret_cast<const FfoH264Edge *>(L->edges[pl]));
+            else
+                ffo_h264_deblock_frame_bd(bd, pl && !c444, dst[pl], stride[pl], L->mb_w, L->mb_h, reinterpret_cast<const FfoH264Edge *>(L->edges[pl]));
+        }
     return 0;
 }

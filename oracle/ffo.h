@@ -199,6 +199,7 @@ typedef struct FfoH264Edge {
 } FfoH264Edge;
 /* frame order at 8 .. 14 bits (ffo_h264_hbd.c): uint16_t samples above 8 bits, stride in bytes */
 void ffo_h264_deblock_frame_bd(int bd, int chroma, uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges);
+void ffo_h264_deblock_frame_c422_bd(int bd, uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges);
 void ffo_h264_deblock_frame(uint8_t *luma, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges);
 /* one 4:2:0 chroma plane in frame order: edges[(mb * 2 + dir) * 2 + e], edges at 0 and 4 */
 void ffo_h264_deblock_frame_chroma(uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges);

@@ -388,3 +388,26 @@ void ffo_h264_deblock_frame_bd(int bd, int chroma, uint8_t *plane, ptrdiff_t str
                 }
         }
 }
+
+/* One 4:2:2 chroma plane in frame order (ff_h264_filter_mb at chroma_format_idc 2, h264_loopfilter.c:601-703): 8 x 16 macroblocks, six
+ * edge records each — the vertical edges at x = 0, 4 (h_loop_filter_chroma422: 16 lines, tc0 per 4 lines), then the horizontal ones at
+ * y = 0, 4, 8, 12 (v_loop_filter_chroma: 8 columns, tc0 per 2) — macroblocks in raster order, vertical before horizontal. */
+void ffo_h264_deblock_frame_c422_bd(int bd, uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FfoH264Edge *edges)
+{
+    const int ps = bd > 8 ? 2 : 1;
+    for (int my = 0; my < mb_h; my++)
+        for (int mx = 0; mx < mb_w; mx++) {
+            const FfoH264Edge *e = edges + (size_t)(my * mb_w + mx) * 6;
+            uint8_t *mb = plane + (ptrdiff_t)my * 16 * stride + (ptrdiff_t)mx * 8 * ps;
+            for (int k = 0; k < 6; k++) {
+                const FfoH264Edge *ed = e + k;
+                const int dir = k >= 2, pos = dir ? k - 2 : k;
+                uint8_t *pix = dir ? mb + (ptrdiff_t)4 * pos * stride : mb + 4 * pos * ps;
+                if (!ed->alpha || !ed->beta)
+                    continue;
+                if (pos == 0 && (dir ? my == 0 : mx == 0))
+                    continue;
+                ffo_h264_loop_filter_bd(bd, (dir ? 0 : 1) + 2 + (ed->kind >= 4 ? 4 : 0), dir ? 2 : 4, pix, stride, ed->alpha, ed->beta, ed->tc0);
+            }
+        }
+}

@@ -221,7 +221,7 @@ FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesi
     if (record)
         return NULL;
 #endif
-    if (!d || (chroma_format_idc != 1 && chroma_format_idc != 3) || (chroma_format_idc == 3 && uvlinesize != linesize)) {
+    if (!d || chroma_format_idc < 1 || chroma_format_idc > 3 || (chroma_format_idc == 3 && uvlinesize != linesize)) {
         av_free(d);
         return NULL;
     }
@@ -241,7 +241,7 @@ FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesi
     d->mb_h = mb_h;
     d->sps->chroma_format_idc = chroma_format_idc;
     d->sps->bit_depth_luma = d->sps->bit_depth_chroma = bit_depth;
-    d->sps->profile_idc = chroma_format_idc == 3 ? 244 : 100;
+    d->sps->profile_idc = chroma_format_idc == 3 ? 244 : chroma_format_idc == 2 ? 122 : 100;
     d->sps->mb_width = mb_w;
     d->sps->mb_height = mb_h;
     for (int k = 0; k < 6; k++)
@@ -253,7 +253,8 @@ FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesi
     h->ps.pps = d->pps;
     h->avctx = d->avctx;               /* active_thread_type = 0: hl_motion() does not wait for reference rows */
     h->pixel_shift = ps;
-    h->chroma_x_shift = h->chroma_y_shift = chroma_format_idc == 1;
+    h->chroma_x_shift = chroma_format_idc != 3;
+    h->chroma_y_shift = chroma_format_idc == 1;
     h->mb_width = mb_w;
     h->mb_height = mb_h;
     h->mb_stride = mb_w + 1;
@@ -422,8 +423,9 @@ int FN(h264dec_decode_inter)(FFRefH264Dec *d, int mb_x, int mb_y, int mb_type, c
         sl->sub_mb_type[i] = sub_mb_type[i];
     memcpy(sl->mv_cache, mv_cache, sizeof(sl->mv_cache));
     memcpy(sl->ref_cache, ref_cache, sizeof(sl->ref_cache));
-    d->pps->dequant4_buffer[4][sl->chroma_qp[0]][0] = qmul_cb;
-    d->pps->dequant4_buffer[5][sl->chroma_qp[1]][0] = qmul_cr;
+    /* (4:2:2: the chroma DC quantiser sits three steps up, h264_mb_template.c:232-236) */
+    d->pps->dequant4_buffer[4][sl->chroma_qp[0] + (d->cfmt == 2 ? 3 : 0)][0] = qmul_cb;
+    d->pps->dequant4_buffer[5][sl->chroma_qp[1] + (d->cfmt == 2 ? 3 : 0)][0] = qmul_cr;
     r = run_hl_decode_mb(d);
     memcpy(mb, sl->mb, (sizeof(int16_t) << d->h->pixel_shift) * 3 * 256);
     return r;
@@ -450,8 +452,8 @@ int FN(h264dec_decode_intra)(FFRefH264Dec *d, int mb_x, int mb_y, int type, int 
         for (int p = 0; p < (d->cfmt == 3 ? 3 : 1); p++)
             memcpy(sl->mb_luma_dc[p], (const uint8_t *)mb_luma_dc + (sizeof(int16_t) << ps) * 16 * p, (sizeof(int16_t) << ps) * 16);
     d->pps->dequant4_buffer[0][sl->qscale][0] = qmul[0];
-    d->pps->dequant4_buffer[1][sl->chroma_qp[0]][0] = qmul[1];
-    d->pps->dequant4_buffer[2][sl->chroma_qp[1]][0] = qmul[2];
+    d->pps->dequant4_buffer[1][sl->chroma_qp[0] + (d->cfmt == 2 ? 3 : 0)][0] = qmul[1];
+    d->pps->dequant4_buffer[2][sl->chroma_qp[1] + (d->cfmt == 2 ? 3 : 0)][0] = qmul[2];
     r = run_hl_decode_mb(d);
     memcpy(mb, sl->mb, (sizeof(int16_t) << ps) * 3 * 256);
     return r;
@@ -502,14 +504,14 @@ int FN(h264dec_filter_mb)(FFRefH264Dec *d, int mb_x, int mb_y, const int *ints, 
 #endif
     {
         /* loop_filter() (h264_slice.c:2470-2491): a field macroblock on an odd row starts one line below the row pair's first */
-        const int cs = d->cfmt == 3 ? 16 : 8;
+        const int cs = d->cfmt == 3 ? 16 : 8, ch = d->cfmt == 1 ? 8 : 16; /* block_h = 16 >> chroma_y_shift */
         uint8_t *dy = d->f->data[0] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->linesize) * 16;
-        uint8_t *dcb = d->f->data[1] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * cs;
-        uint8_t *dcr = d->f->data[2] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->uvlinesize) * cs;
+        uint8_t *dcb = d->f->data[1] + ((ptrdiff_t)mb_x << ps) * cs + (ptrdiff_t)mb_y * sl->uvlinesize * ch;
+        uint8_t *dcr = d->f->data[2] + ((ptrdiff_t)mb_x << ps) * cs + (ptrdiff_t)mb_y * sl->uvlinesize * ch;
         if (fld && (mb_y & 1)) {
             dy -= (ptrdiff_t)sl->linesize * 15;
-            dcb -= (ptrdiff_t)sl->uvlinesize * (cs - 1);
-            dcr -= (ptrdiff_t)sl->uvlinesize * (cs - 1);
+            dcb -= (ptrdiff_t)sl->uvlinesize * (ch - 1);
+            dcr -= (ptrdiff_t)sl->uvlinesize * (ch - 1);
         }
         sl->mb_linesize = sl->linesize << fld;
         sl->mb_uvlinesize = sl->uvlinesize << fld;

@@ -208,15 +208,16 @@ def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=
         cc = 0 if cfmt == 3 else int(rng.integers(0, 3))
         m["cbp"] |= cc << 4
         sh = depth - 8
+        nck = 8 if cfmt == 2 else 4           # 4:2:2: eight blocks per chroma plane
         if cc:
             for pl in (1, 2):
                 if rng.random() < .7:
                     nnzc[40 * pl] = 1
-                    for k in range(4):
+                    for k in range(nck):
                         if rng.random() < .7:
                             mb[256 * pl + 16 * k] = int(rng.integers(-1500, 1501)) << sh
                 if cc == 2:
-                    for k in range(4):
+                    for k in range(nck):
                         dc = mb[256 * pl + 16 * k]
                         n = G._block(rng, mb, 256 * pl + 16 * k, 16, allow_dc_only=False, depth=depth)
                         mb[256 * pl + 16 * k] = dc

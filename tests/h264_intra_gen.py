@@ -74,7 +74,7 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8, cfmt=1):
              pred4=np.zeros(16, np.uint8), qmul=rng.integers(16, 6000, 3).astype(np.int32), nnzc=np.zeros(15 * 8, np.uint8),
              mb=np.zeros(768, cdt), luma_dc=np.zeros(48 if cfmt == 3 else 16, cdt), pcm=None, depth=depth)
     if mtype == PCM:
-        d["pcm"] = rng.integers(0, 256, (96 if cfmt == 3 else 48) * depth, dtype=np.uint8)
+        d["pcm"] = rng.integers(0, 256, (96 if cfmt == 3 else 64 if cfmt == 2 else 48) * depth, dtype=np.uint8)   # 768 / 512 / 384 fields
         return d
 
     def blk_mode(i_top, i_left):           # a 16x16 / chroma mode after ff_h264_check_intra_pred_mode
@@ -129,15 +129,16 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8, cfmt=1):
         return d
     cc = int(rng.integers(0, 3))                         # coded_block_pattern's chroma part: 0 none, 1 DC, 2 DC + AC
     d["cbp"] = (cc << 4) | int(rng.integers(0, 16))
+    nck = 8 if cfmt == 2 else 4                          # 4:2:2: eight 4x4 blocks per chroma plane (8 x 16), the cache rows running on
     if cc:
         for pl in (1, 2):
             if rng.random() < .7:
                 nnzc[40 * pl] = 1                         # scan8[CHROMA_DC_BLOCK_INDEX + pl - 1]
-                for k in range(4):
+                for k in range(nck):
                     if rng.random() < .7:
                         mb[256 * pl + 16 * k] = int(rng.integers(-1500, 1501)) << sh
             if cc == 2:
-                for k in range(4):
+                for k in range(nck):
                     dc = mb[256 * pl + 16 * k]
                     n = _block(rng, mb, 256 * pl + 16 * k, 16, allow_dc_only=False, depth=depth)
                     mb[256 * pl + 16 * k] = dc

@@ -47,7 +47,7 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=
     W, H = mb_w * 16, mb_h * 16
     sy = W + int(rng.integers(0, 3)) * 16                   # row pitches in samples: the picture has NO border, only row padding
     sc = sy if cfmt == 3 else W // 2 + 16                   # 4:4:4: three planes of the luma geometry, uvlinesize == linesize
-    HC = H if cfmt == 3 else H // 2
+    HC = H if cfmt >= 2 else H // 2                         # 4:2:2: chroma half as wide, as tall
     ls, uvls = sy * px, sc * px
     strides = [ls, uvls, uvls]
     # the decoded-picture buffer: nref reference pictures per plane in one allocation, exactly H (H / 2) rows each
@@ -158,7 +158,7 @@ def _run_deblocking(depth, mb_w, mb_h, p_intra, cfmt, pad=32):
     dt = np.uint16 if depth > 8 else np.uint8
     W, H = mb_w * 16, mb_h * 16
     sy = W + pad
-    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H if cfmt == 2 else H // 2)
     ls, uvls = sy * px, sc * px
     strides = [ls, uvls, uvls]
     mid, amp = 1 << (depth - 1), 20 << (depth - 8)            # smooth-ish content so that the filters' thresholds pass often
@@ -234,9 +234,8 @@ def test_picture_formats_refused_by_name():
     from ffmpeg_amd import _lib, h264
     _torch()
     L = _lib.lib()
-    for cf in (0, 2):
-        p = _lib.vp()
-        assert L.ffhip_h264_picture_create_fmt(C.byref(p), 4, 4, 8, cf) == _lib.ENOSYS and not p
+    p = _lib.vp()
+    assert L.ffhip_h264_picture_create_fmt(C.byref(p), 4, 4, 8, 0) == _lib.ENOSYS and not p      # monochrome stays on the C path
     p = _lib.vp()
     assert L.ffhip_h264_picture_create_fmt(C.byref(p), 4, 4, 8, 5) == _lib.EINVAL and not p
     pic = h264.Picture(4, 4, chroma_format=3)
@@ -263,7 +262,7 @@ def _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, cfmt, seed
     mb_h = 2 * fmb_h
     W, H = mb_w * 16, mb_h * 16
     sy = W + int(rng.integers(0, 3)) * 16
-    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H if cfmt == 2 else H // 2)
     strides = [sy * px, sc * px, sc * px]
     rows = [H, HC, HC]
     mid, amp = 1 << (depth - 1), 20 << (depth - 8)
@@ -335,3 +334,30 @@ def test_decoder_driven_field_pictures(depth, mb_w, fmb_h, nref, mvr, p_intra, w
 @pytest.mark.parametrize("depth,mb_w,fmb_h,p_intra,cfmt", [(8, 6, 3, .2, 1), (8, 40, 11, .15, 1), (8, 9, 3, 1.0, 1), (8, 120, 34, .1, 1), (10, 7, 3, .2, 1), (8, 9, 4, .2, 3)])
 def test_decoder_driven_field_deblocking(depth, mb_w, fmb_h, p_intra, cfmt):
     _run_field_frame(depth, mb_w, fmb_h, 1, 0, p_intra, 0, cfmt, seed=7780000 + depth * 100 + mb_w + fmb_h + cfmt, deblock=True)
+
+
+# ---- 4:2:2 (VERDICT r3 missing #3: hl_motion_422, libavcodec/h264_mb_template.c:172) -------------------------------------------------------
+@pytest.mark.parametrize("depth,mb_w,mb_h,nref,mvr,p_intra,weights", [
+    (8, 6, 4, 2, 40, 0.0, 0), (8, 11, 7, 3, 2000, 0.0, 1), (8, 11, 7, 3, 300, 0.0, 2), (8, 9, 5, 1, 64, 1.0, 0), (8, 40, 22, 2, 120, .15, 1),
+    (8, 120, 68, 3, 256, .05, 2), (8, 120, 68, 1, 64, 1.0, 0), (10, 7, 5, 2, 600, .2, 1), (10, 40, 22, 3, 200, .1, 2), (12, 9, 5, 2, 500, 1.0, 0),
+    (14, 6, 5, 2, 400, .2, 1)])
+def test_decoder_driven_picture_422(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
+    """a 4:2:2 picture recorded by the reference's own macroblock loop == its C decode: chroma MC of the luma height, idct_add8_422, the luma
+    plane through the luma-only wavefront and the 8 x 16 chroma planes through k_h264_intra_c422 (pred8x16, chroma422_dc_dequant_idct)"""
+    _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed=4220000 + depth * 1000 + mb_w * 31 + mvr + weights, cfmt=2)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,p_intra,pad", [(8, 6, 4, .2, 32), (8, 40, 22, .15, 32), (8, 9, 5, 1.0, 4), (8, 120, 68, .1, 0), (10, 11, 7, .2, 32),
+                                                          (12, 9, 5, .3, 16)])
+def test_decoder_driven_deblocking_422(depth, mb_w, mb_h, p_intra, pad):
+    """the chroma planes of a 4:2:2 picture through k_h264_deblock_c422: six edges per 8 x 16 macroblock in decoder order"""
+    _run_deblocking(depth, mb_w, mb_h, p_intra, 2, pad=pad)
+
+
+@pytest.mark.parametrize("depth,mb_w,fmb_h,nref,mvr,p_intra,weights", [(8, 9, 4, 2, 300, .2, 2), (10, 6, 3, 2, 500, .3, 1), (8, 120, 34, 2, 200, .1, 1)])
+def test_decoder_driven_field_pictures_422(depth, mb_w, fmb_h, nref, mvr, p_intra, weights):
+    _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, 2, seed=7772000 + depth * 1000 + mb_w * 31 + mvr + weights)
+
+
+def test_decoder_driven_pictures_422_flushed_together():
+    _run_picture(8, 12, 7, 2, 300, 0.3, 1, 4229100, pictures=3, batch=True, cfmt=2)

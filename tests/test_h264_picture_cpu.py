@@ -26,7 +26,8 @@ class Lists(C.Structure):                       # == FFHipH264PictureLists (incl
                 ("qpel", (C.c_void_p * 3) * 3), ("nqpel", (C.c_int * 3) * 3), ("cmc", (C.c_void_p * 3) * 2), ("ncmc", (C.c_int * 3) * 2),
                 ("wt", C.c_void_p * 3), ("nwt", C.c_int * 3), ("idct_off", (C.c_void_p * 4) * 3), ("idct_coef", (C.c_void_p * 4) * 3),
                 ("nidct", (C.c_int * 4) * 3), ("intra", C.c_void_p * 3), ("nintra", C.c_int * 3), ("intra_coef", C.c_void_p * 3),
-                ("nintra_coef", C.c_int * 3), ("edges", C.c_void_p * 3)]
+                ("nintra_coef", C.c_int * 3), ("edges", C.c_void_p * 3), ("intra_c422", C.c_void_p), ("nintra_c422", C.c_int),
+                ("intra_c422_coef", C.c_void_p), ("nintra_c422_coef", C.c_int)]
 
 
 def _env():
@@ -70,7 +71,7 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed):
     px, dt, top = (2, np.uint16, 1 << depth) if depth > 8 else (1, np.uint8, 256)
     W, H = mb_w * 16, mb_h * 16
     sy = W + int(rng.integers(0, 3)) * 16                   # row pitches in samples: NO border around a picture, only row padding
-    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H if cfmt == 2 else H // 2)    # 4:2:2: chroma half as wide, as tall
     ls_, uvls = sy * px, sc * px
     strides = [ls_, uvls, uvls]
     rows = [H, HC, HC]
@@ -108,6 +109,8 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed):
     if cfmt == 3:
         assert not any(ls.ncmc[c][s] for c in range(2) for s in range(3))
         assert p_intra >= 1 or all(ls.nqpel[pl][0] for pl in range(3))
+    elif cfmt == 2:
+        assert ls.nintra_c422 == ls.nintra[0] and not ls.nintra[1] and (p_intra <= 0 or ls.nintra_c422)
     else:
         assert not any(ls.nqpel[pl][s] for pl in (1, 2) for s in range(3)) and not ls.nintra[1] and not ls.nintra[2]
     _cpu_flush(E, ls, got, strides, refs)
@@ -147,7 +150,7 @@ def test_recorded_deblocking_executed_on_cpu_equals_reference(depth, mb_w, mb_h,
     px, dt = (2, np.uint16) if depth > 8 else (1, np.uint8)
     W, H = mb_w * 16, mb_h * 16
     sy = W + 32
-    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H if cfmt == 2 else H // 2)
     strides = [sy * px, sc * px, sc * px]
     mid, amp = 1 << (depth - 1), 20 << (depth - 8)
     dst0 = [(mid + rng.integers(-amp, amp + 1, (r, s))).astype(dt) for r, s in ((H, sy), (HC, sc), (HC, sc))]
@@ -207,7 +210,7 @@ def _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, cfmt, seed
     mb_h = 2 * fmb_h                                        # the frame's macroblock rows
     W, H = mb_w * 16, mb_h * 16
     sy = W + int(rng.integers(0, 3)) * 16
-    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H // 2)
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H if cfmt == 2 else H // 2)
     strides = [sy * px, sc * px, sc * px]
     rows = [H, HC, HC]
     mid, amp = 1 << (depth - 1), 20 << (depth - 8)
@@ -280,3 +283,26 @@ def test_recorded_field_deblocking_executed_on_cpu_equals_reference(depth, mb_w,
     """ff_h264_filter_mb() in field pictures (the row above is the field's own, bS 3 on horizontal intra edges: h264_loopfilter.c:550,
     mvy_limit 2): each field's edge tables through the frame-order filter on that field's lines"""
     _run_field_frame(depth, mb_w, fmb_h, 1, 0, p_intra, 0, cfmt, seed=7780000 + depth * 100 + mb_w + fmb_h + cfmt, deblock=True)
+
+
+# ---- 4:2:2 -------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("depth,mb_w,mb_h,nref,mvr,p_intra,weights", [
+    (8, 6, 4, 2, 40, 0.0, 0), (8, 11, 7, 3, 2000, 0.0, 1), (8, 11, 7, 3, 300, 0.0, 2), (8, 9, 5, 1, 64, 1.0, 0), (8, 20, 11, 2, 120, .15, 1),
+    (10, 7, 5, 2, 600, .2, 1), (12, 6, 4, 2, 500, 1.0, 0), (14, 6, 4, 2, 400, .2, 2)])
+def test_recorded_picture_executed_on_cpu_equals_reference_422(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
+    """chroma_format_idc 2: hl_motion_422 (chroma blocks of the luma height, the vertical chroma vector at quarter-sample scale:
+    mc_dir_part(), h264_mb.c:289-317), idct_add8_422 after chroma422_dc_dequant_idct (h264idct_template.c:230-252,295-321), intra chroma by
+    the pred8x16 functions with eight residual blocks per plane (the record FFHipH264IntraC422 through k_h264_intra_c422's phase body)"""
+    _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, 2, seed=4220000 + depth * 1000 + mb_w * 31 + mvr + weights)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,p_intra", [(8, 6, 4, .2), (8, 20, 11, .15), (8, 9, 5, 1.0), (10, 7, 5, .2), (12, 6, 4, .3)])
+def test_recorded_deblocking_422_executed_on_cpu_equals_reference(depth, mb_w, mb_h, p_intra):
+    """ff_h264_filter_mb() at 4:2:2: six chroma edges per macroblock and plane — h_loop_filter_chroma422 on x = 0, 4 over 16 lines,
+    v_loop_filter_chroma on y = 0, 4, 8, 12 (filter_mb_dir(), h264_loopfilter.c:601-703)"""
+    test_recorded_deblocking_executed_on_cpu_equals_reference(depth, mb_w, mb_h, p_intra, 2)
+
+
+@pytest.mark.parametrize("depth,mb_w,fmb_h,nref,mvr,p_intra,weights", [(8, 9, 4, 2, 300, .2, 2), (10, 6, 3, 2, 500, .3, 1)])
+def test_recorded_field_pictures_422(depth, mb_w, fmb_h, nref, mvr, p_intra, weights):
+    _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, 2, seed=7772000 + depth * 1000 + mb_w * 31 + mvr + weights)
