@@ -687,10 +687,20 @@ static int flush_tail(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
     int r = 0;
     /* ---- intra macroblocks: every inter macroblock is complete now; one wavefront over the three planes (4:4:4: one per plane, side by
      * side in one launch) ---- */
-    if (B.nintra)
+    if (B.c422) {
+        /* 4:2:2: the luma wavefront below is luma-only; the 8 x 16 chroma planes are a wavefront of their own, beside it on the picture's
+         * second stream (prediction never crosses planes) */
+        HIP_TRY(hipEventRecord(p->fork, stream));
+        HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
+        ffhip_progress_report_to(stream, true); /* a hand-off lost on the second stream is the caller's stream's to hear about */
+        r = ffhip_launch_h264_intra_c422(bd, dst[1], dst[2], stride[1], p->mb_w, p->mb_h, B.c422, B.c422_rows, B.c422_coef, p->aux);
+        ffhip_progress_report_to(nullptr, false);
+        HIP_TRY(hipEventRecord(p->join, p->aux));
+    }
+    if (r >= 0 && B.nintra)
         r = ffhip_launch_h264_intra_frames_bd(bd, B.nintra, B.ip, stride[0], stride[1], p->mb_w, p->mb_h, stream, p->cfmt != 1);
-    if (r >= 0 && B.c422) /* 4:2:2: the luma above was luma-only; the 8 x 16 chroma planes are a wavefront of their own */
-        r = ffhip_launch_h264_intra_c422(bd, dst[1], dst[2], stride[1], p->mb_w, p->mb_h, B.c422, B.c422_rows, B.c422_coef, stream);
+    if (B.c422)
+        HIP_TRY(hipStreamWaitEvent(stream, p->join, 0));
     if (r < 0)
         return r;
     /* ---- in-loop filter, decoder order: the planes are independent, and a lone wavefront is a chain of dependent hand-offs that

@@ -652,8 +652,17 @@ int  ffhip_h264_picture_create(FFHipH264Picture **p, int mb_w, int mb_h);
  *  keep alpha / beta / tc0 at the 8-bit scale (the kernels scale them as h264dsp_template.c:108-110 does), intra macroblocks hand
  *  over sl->mb / sl->mb_luma_dc / sl->intra_pcm_ptr as ffhip_h264_intra_pack_hbd() describes.  Planes and strides 8-byte aligned. */
 int  ffhip_h264_picture_create_hbd(FFHipH264Picture **p, int mb_w, int mb_h, int bit_depth);
-/** The same object for a picture of sps->chroma_format_idc 1 (4:2:0: == ffhip_h264_picture_create_hbd) or 3 (4:4:4, round 4), at any of the
- *  depths.  A 4:4:4 picture is what hl_decode_mb_444() (libavcodec/h264_mb_template.c:256-362) makes of it: three planes of luma geometry,
+/** The same object for a picture of sps->chroma_format_idc 1 (4:2:0: == ffhip_h264_picture_create_hbd), 2 (4:2:2) or 3 (4:4:4) (round 4),
+ *  at any of the depths.
+ *  A 4:2:2 picture (hl_decode_mb() with block_h = 16, hl_motion_422: h264_mb_template.c:41-262,172) keeps the 4:2:0 record calls with 8 x 16
+ *  chroma: ffhip_h264_picture_mc_chroma() blocks of up to 16 rows (the decoder's `height`, y fraction (my << 1) & 7: h264_mb.c:289-317), the
+ *  8-wide weights over 16 rows, ffhip_h264_picture_idct_mb() which 3 = ff_h264_idct_add8_422 (eight blocks per plane after the decoder's own
+ *  chroma422_dc_dequant_idct), SIX edge records per macroblock and chroma plane (the vertical edges x = 0, 4 — h_loop_filter_chroma422, 16
+ *  lines, tc0 per 4 — then the horizontal ones y = 0, 4, 8, 12); ffhip_h264_picture_intra_mb() is the same call (qmul[1], qmul[2] =
+ *  dequant4_coeff[1 + p][chroma_qp[p] + 3][0]; 512 I_PCM fields) and becomes a luma-only record plus an FFHipH264IntraC422.  flush() runs the
+ *  luma plane through the luma kernels and the chroma planes' two dependency chains through plain kernels of their own (one picture per
+ *  launch; ffhip_h264_pictures_flush() takes such pictures one by one); Cb and Cr share a stride when the picture has intra macroblocks.
+ *  A 4:4:4 picture is what hl_decode_mb_444() (libavcodec/h264_mb_template.c:256-362) makes of it: three planes of luma geometry,
  *  all reconstructed by the LUMA members —
  *    prediction: qpix_op[luma_xy] on dest_cb / dest_cr with the luma vector (mc_dir_part(), h264_mb.c:262-288), weights of the luma width
  *                (mc_part_weighted(), :362-366): ffhip_h264_picture_mc_luma_plane() / ffhip_h264_picture_weight() with plane 1 / 2;
@@ -668,8 +677,7 @@ int  ffhip_h264_picture_create_hbd(FFHipH264Picture **p, int mb_w, int mb_h, int
  *    deblocking: filter_mb_edgev / filter_mb_edgeh on img_cb / img_cr (h264_loopfilter.c:601-703): ffhip_h264_picture_deblock_mb() takes 8
  *                luma-kind edge records for every plane.
  *  The three planes share one stride when the picture carries intra macroblocks (the decoder's linesize == uvlinesize there).
- *  chroma_format_idc 2 (hl_motion_422, the 8x16 chroma predictors, chroma422 edge filters in frame order) and 0: FFHIP_ENOSYS — such a
- *  stream's pictures stay on the decoder's C path; the function tables above cover 4:2:2. */
+ *  chroma_format_idc 0 (monochrome): FFHIP_ENOSYS — such a stream's pictures stay on the decoder's C path. */
 int  ffhip_h264_picture_create_fmt(FFHipH264Picture **p, int mb_w, int mb_h, int bit_depth, int chroma_format_idc);
 void ffhip_h264_picture_free(FFHipH264Picture **p);
 void ffhip_h264_picture_begin(FFHipH264Picture *p);

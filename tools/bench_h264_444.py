@@ -25,7 +25,7 @@ def run(depth, cfmt, p_intra, reps, mb_w=120, mb_h=68, nref=2):
     px, dt, top = (2, np.uint16, 1 << depth) if depth > 8 else (1, np.uint8, 256)
     W, H = mb_w * 16, mb_h * 16
     sy = W
-    sc, HC = (sy, H) if cfmt == 3 else (W // 2, H // 2)
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2, H if cfmt == 2 else H // 2)
     strides = [sy * px, sc * px, sc * px]
     dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
     d_refs = [dev(rng.integers(0, top, (nref * r, s), dtype=dt)) for r, s in ((H, sy), (HC, sc), (HC, sc))]
@@ -61,7 +61,7 @@ def run(depth, cfmt, p_intra, reps, mb_w=120, mb_h=68, nref=2):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print("%2d bits %s %s 1080p: flush %.3f ms = %.0f pictures/s (recording with the test generator: %.1f s)" % (
-        depth, "4:4:4" if cfmt == 3 else "4:2:0", "I-picture" if p_intra >= 1 else "P/B-picture (%.0f %% intra)" % (100 * p_intra), ms, 1e3 / ms,
+        depth, {1: "4:2:0", 2: "4:2:2", 3: "4:4:4"}[cfmt], "I-picture" if p_intra >= 1 else "P/B-picture (%.0f %% intra)" % (100 * p_intra), ms, 1e3 / ms,
         rec_s), flush=True)
     pic.close()
     gpu.close()
@@ -72,6 +72,6 @@ if __name__ == "__main__":
     if not (ffi.have_ref() and I.have_ref_hip()):
         sys.exit("oracle/_ref not built")
     for depth in ((8, 10) if len(sys.argv) < 3 else (int(sys.argv[2]),)):
-        for cfmt in (1, 3):
+        for cfmt in (1, 2, 3):
             for p_intra in (1.0, .05):
                 run(depth, cfmt, p_intra, reps)
