@@ -922,6 +922,44 @@ def h264_intra_picture_leg(torch, dev, ev, h264):
                                                  "reconstruction wavefronts of N pictures side by side (no deblocking)"}}
 
 
+def h264_intra_formats_leg(torch, dev, ev, h264):
+    """a 1080p I-picture at the other chroma formats of the picture layer (round 4): 4:2:2 — the luma wavefront beside the 8 x 16 chroma
+    planes' own (kernels/h264_c422.hip) — and 4:4:4 — three luma-only wavefronts side by side (hl_decode_mb_444) —, reconstruction only."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import h264_intra_gen as G
+    mb_w, mb_h = 120, 68
+    out = {}
+    for cfmt, name in ((2, "422"), (3, "444")):
+        rng = np.random.default_rng(60 + cfmt)
+        sy = mb_w * 16
+        sc, hc = (sy, mb_h * 16) if cfmt == 3 else (mb_w * 8, mb_h * 16)
+        dst = [torch.zeros((mb_h * 16, sy), dtype=torch.uint8, device=dev), torch.zeros((hc, sc), dtype=torch.uint8, device=dev),
+               torch.zeros((hc, sc), dtype=torch.uint8, device=dev)]
+        pic = h264.Picture(mb_w, mb_h, chroma_format=cfmt)
+        pic.begin()
+        for my in range(mb_h):
+            for mx in range(mb_w):
+                d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, cfmt=cfmt)
+                dc = np.zeros(96, np.int16)                # sl->mb_luma_dc as the decoder holds it: [3][16 * 2] int16
+                for p_ in range(len(d["luma_dc"]) // 16):
+                    dc[32 * p_:32 * p_ + 16] = d["luma_dc"][16 * p_:16 * p_ + 16]
+                pic.intra_mb(G.to_record(d), d["nnzc"], d["mb"].copy(), dc, d["pcm"])
+        for _ in range(2):
+            pic.flush(dst, [sy, sc, sc], dst)
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(10):
+            pic.flush(dst, [sy, sc, sc], dst)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        out["h264_intra_picture_1080p_" + name] = {"ms_per_picture": round(ms, 3), "pictures_per_s": round(1e3 / ms, 1),
+                                                   "note": "reconstruction wavefronts only (no deblocking records)"}
+        pic.close()
+    return out
+
+
 def h264_picture_leg(torch, dev, ev):
     """the picture layer: synthetic 1080p P-pictures (tools/h264_synth.py) through ffhip_h264_picture_flush — MC,
     residual add and the in-loop filter in decoder order.  A lone picture is a chain of latency-bound kernels; 16 pictures in flight,
@@ -982,6 +1020,10 @@ def h264_picture_leg(torch, dev, ev):
     for p in pics:
         p.close()
     intra = h264_intra_picture_leg(torch, dev, ev, h264)
+    try:
+        intra = {**intra, **h264_intra_formats_leg(torch, dev, ev, h264)}
+    except Exception as e:  # an extras leg must not cost the bench line
+        intra = {**intra, "h264_intra_picture_formats": {"error": repr(e)[:200]}}
     return {**intra, "h264_picture_pipeline_1080p": {"ms_per_picture_alone": round(res[1], 3), "ms_per_picture_16_in_flight": round(res[npic] / npic, 3),
                                            "pictures_per_s_16_in_flight": round(1e3 * npic / res[npic], 1),
                                            "ms_per_batched_flush_of_16": round(res["batch"], 3),
