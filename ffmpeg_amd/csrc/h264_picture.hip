@@ -707,12 +707,28 @@ static int flush_tail(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
      * leaves the GPU mostly idle — the chroma planes run beside the luma plane on the second stream ---- */
     const bool chroma = B.edges[1] || B.edges[2];
     if (p->cfmt == 2) {
-        /* 4:2:2: 8 x 16 chroma macroblocks with six edges each: a frame-order kernel of their own, on the caller's stream behind luma */
-        if (B.edges[0])
+        /* 4:2:2: 8 x 16 chroma macroblocks with six edges each: a frame-order kernel of their own (both planes in one launch when they
+         * share a stride), beside the luma plane's on the second stream */
+        if (chroma) {
+            HIP_TRY(hipEventRecord(p->fork, stream));
+            HIP_TRY(hipStreamWaitEvent(p->aux, p->fork, 0));
+            ffhip_progress_report_to(stream, true);
+            if (B.edges[1] && B.edges[2] && stride[1] == stride[2]) {
+                uint8_t *const pl_[2] = { dst[1], dst[2] };
+                const FFHipH264Edge *const ed_[2] = { B.edges[1], B.edges[2] };
+                r = ffhip_launch_h264_deblock_c422_planes(bd, 2, pl_, ed_, stride[1], p->mb_w, p->mb_h, p->aux);
+            } else {
+                for (int pl = 1; pl < 3 && r >= 0; pl++)
+                    if (B.edges[pl])
+                        r = ffhip_launch_h264_deblock_c422(bd, dst[pl], stride[pl], p->mb_w, p->mb_h, B.edges[pl], p->aux);
+            }
+            ffhip_progress_report_to(nullptr, false);
+            HIP_TRY(hipEventRecord(p->join, p->aux));
+        }
+        if (r >= 0 && B.edges[0])
             r = ffhip_launch_h264_deblock_frames_bd(bd, 0, dst[0], 0, 1, stride[0], p->mb_w, p->mb_h, B.edges[0], stream);
-        for (int pl = 1; pl < 3 && r >= 0; pl++)
-            if (B.edges[pl])
-                r = ffhip_launch_h264_deblock_c422(bd, dst[pl], stride[pl], p->mb_w, p->mb_h, B.edges[pl], stream);
+        if (chroma)
+            HIP_TRY(hipStreamWaitEvent(stream, p->join, 0));
         return r < 0 ? r : 0;
     }
     if (p->cfmt == 3) {
@@ -1088,14 +1104,6 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
             }
     if (n == 1)
         return flush_impl(pics[0], dst, stride, ref, stream_, nullptr);
-    if (pics[0]->cfmt == 2) { /* 4:2:2: the chroma planes' two frame-order kernels take one picture per launch: the pictures one by one */
-        for (int i = 0; i < n; i++) {
-            const int r = flush_impl(pics[i], dst + 3 * i, stride, ref + 3 * i, stream_, nullptr);
-            if (r < 0)
-                return r;
-        }
-        return 0;
-    }
     if (pics[0]->cfmt == 3 && (stride[1] != stride[0] || stride[2] != stride[0])) {
         ffhip_set_error("ffhip_h264_pictures_flush: the planes of 4:4:4 pictures share one stride");
         return FFHIP_EINVAL;
@@ -1153,13 +1161,32 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
             }
     }
     const bool c444 = p0->cfmt == 3; /* every plane is a luma plane: wavefronts and filters alike */
+    const bool c422 = p0->cfmt == 2; /* 8 x 16 chroma: the luma plane through the luma kernels, the chroma planes through kernels/h264_c422.hip */
     std::vector<FFHipH264IntraPic> ip;
-    for (int i = 0; i < n; i++)
+    std::vector<FFHipH264C422Pic> ic;
+    for (int i = 0; i < n; i++) {
         for (int q = 0; q < B[i].nintra; q++)
             ip.push_back(B[i].ip[q]);
+        if (B[i].c422)
+            ic.push_back(FFHipH264C422Pic{ dst[3 * i + 1], dst[3 * i + 2], B[i].c422, B[i].c422_rows, B[i].c422_coef });
+    }
     int r = 0;
-    if (!ip.empty())
-        r = ffhip_launch_h264_intra_frames_bd(bd, (int)ip.size(), ip.data(), stride[0], stride[1], mb_w, mb_h, stream, c444);
+    if (!ic.empty()) { /* the chroma planes' wavefronts of all pictures beside the luma ones, on the first object's second stream */
+        if (stride[1] != stride[2]) {
+            ffhip_set_error("ffhip_h264_pictures_flush: Cb and Cr share a stride");
+            return FFHIP_EINVAL;
+        }
+        HIP_TRY(hipEventRecord(p0->fork, stream));
+        HIP_TRY(hipStreamWaitEvent(p0->aux, p0->fork, 0));
+        ffhip_progress_report_to(stream, true);
+        r = ffhip_launch_h264_intra_c422_pics(bd, (int)ic.size(), ic.data(), stride[1], mb_w, mb_h, p0->aux);
+        ffhip_progress_report_to(nullptr, false);
+        HIP_TRY(hipEventRecord(p0->join, p0->aux));
+    }
+    if (r >= 0 && !ip.empty())
+        r = ffhip_launch_h264_intra_frames_bd(bd, (int)ip.size(), ip.data(), stride[0], stride[1], mb_w, mb_h, stream, c444 || c422);
+    if (!ic.empty())
+        HIP_TRY(hipStreamWaitEvent(stream, p0->join, 0));
     if (r < 0)
         return r;
     /* the in-loop filter: all chroma planes (Cb and Cr of every picture: up to 2 n "pictures") on the first object's second stream
@@ -1186,7 +1213,8 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
         HIP_TRY(hipEventRecord(p0->fork, stream));
         HIP_TRY(hipStreamWaitEvent(p0->aux, p0->fork, 0));
         ffhip_progress_report_to(stream, true);
-        r = ffhip_launch_h264_deblock_pictures_bd(bd, 1, pl_c.data(), ed_c.data(), (int)pl_c.size(), stride[1], mb_w, mb_h, p0->aux);
+        r = c422 ? ffhip_launch_h264_deblock_c422_planes(bd, (int)pl_c.size(), pl_c.data(), ed_c.data(), stride[1], mb_w, mb_h, p0->aux)
+                 : ffhip_launch_h264_deblock_pictures_bd(bd, 1, pl_c.data(), ed_c.data(), (int)pl_c.size(), stride[1], mb_w, mb_h, p0->aux);
         ffhip_progress_report_to(nullptr, false);
         HIP_TRY(hipEventRecord(p0->join, p0->aux));
     }

@@ -15,7 +15,7 @@
  *
  * Both are the plain form of their 4:2:0 counterparts — one wave per macroblock row, a counter per row in the progress pool, everything that
  * crosses rows moved with device-scope loads and stores behind agent-scope fences — without those kernels' batching, LDS hand-offs and
- * prefetches: 4:2:2 is the contribution format, correctness first.  One picture per launch.
+ * prefetches: 4:2:2 is the contribution format, correctness first.  A launch takes the pictures (chroma planes) of a batch side by side.
  */
 #include <stddef.h>
 
@@ -79,10 +79,18 @@ __device__ __forceinline__ void c4_publish(int *counter, int value, int lane)
 }
 } // namespace
 
+/* up to FFHIP_C422_PICS pictures of one geometry per launch (blockIdx.y = the picture: its planes, records and its slice of the counters) */
+struct FFHipC422IntraSet { FFHipH264C422Pic pic[FFHIP_C422_PICS]; };
+struct FFHipC422PlaneSet { uint8_t *plane[2 * FFHIP_C422_PICS]; const FFHipH264Edge *edges[2 * FFHIP_C422_PICS]; };
+
 template <typename PIX>
-__global__ __launch_bounds__(64) void k_h264_intra_c422(uint8_t *pcb, uint8_t *pcr, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraC422 *recs,
-                                                        const int32_t *row_start, const int16_t *coefs, int *progress, int *fail, int maxv)
+__global__ __launch_bounds__(64) void k_h264_intra_c422(FFHipC422IntraSet S, ptrdiff_t sc, int mb_w, int mb_h, int *progress, int *fail, int maxv)
 {
+    uint8_t *const pcb = S.pic[blockIdx.y].cb, *const pcr = S.pic[blockIdx.y].cr;
+    const FFHipH264IntraC422 *const recs = S.pic[blockIdx.y].recs;
+    const int32_t *const row_start = S.pic[blockIdx.y].row_start;
+    const int16_t *const coefs = S.pic[blockIdx.y].coefs;
+    progress += (size_t)blockIdx.y * (size_t)mb_h;
     typedef typename C4Quad<PIX>::T Q;
     typedef typename ImbCoef<PIX>::T CF;
     constexpr int PS = (int)sizeof(PIX);
@@ -161,9 +169,11 @@ __device__ __forceinline__ void c4_edge(PIX *pix, int xs, bool intra, int alpha,
 }
 
 template <typename PIX>
-__global__ __launch_bounds__(64) void k_h264_deblock_c422(uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges, int *progress,
-                                                          int *fail, int bd)
+__global__ __launch_bounds__(64) void k_h264_deblock_c422(FFHipC422PlaneSet S, ptrdiff_t stride, int mb_w, int mb_h, int *progress, int *fail, int bd)
 {
+    uint8_t *const plane = S.plane[blockIdx.y];
+    const FFHipH264Edge *const edges = S.edges[blockIdx.y];
+    progress += (size_t)blockIdx.y * (size_t)mb_h;
     typedef typename C4Quad<PIX>::T Q;
     constexpr int PS = (int)sizeof(PIX);
     /* tile[r + 2][c + 4]: rows -2 .. 15, columns -4 .. 7 of the macroblock */
@@ -231,63 +241,108 @@ __global__ __launch_bounds__(64) void k_h264_deblock_c422(uint8_t *plane, ptrdif
 
 static bool c422_bd_ok(int bd) { return bd == 8 || bd == 9 || bd == 10 || bd == 12 || bd == 14; }
 
-int ffhip_launch_h264_intra_c422(int bd, uint8_t *cb, uint8_t *cr, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraC422 *recs,
-                                 const int32_t *row_start, const int16_t *coefs, hipStream_t stream)
+int ffhip_launch_h264_intra_c422_pics(int bd, int npics, const FFHipH264C422Pic *pics, ptrdiff_t sc, int mb_w, int mb_h, hipStream_t stream)
 {
-    if (mb_w <= 0 || mb_h <= 0)
+    if (mb_w <= 0 || mb_h <= 0 || npics <= 0)
         return 0;
     const unsigned amask = bd > 8 ? 7u : 3u;
-    if (!c422_bd_ok(bd) || !cb || !cr || !recs || !row_start || !coefs || (((uintptr_t)cb | (uintptr_t)cr | (size_t)sc) & amask)) {
+    if (!c422_bd_ok(bd) || !pics || ((size_t)sc & amask)) {
         ffhip_set_error("ffhip_h264_intra_c422: bad argument (depths 8 / 9 / 10 / 12 / 14; planes and stride %u-byte aligned)", amask + 1);
         return FFHIP_EINVAL;
     }
+    for (int i = 0; i < npics; i++)
+        if (!pics[i].cb || !pics[i].cr || !pics[i].recs || !pics[i].row_start || !pics[i].coefs || (((uintptr_t)pics[i].cb | (uintptr_t)pics[i].cr) & amask)) {
+            ffhip_set_error("ffhip_h264_intra_c422: null or misaligned argument (picture %d)", i);
+            return FFHIP_EINVAL;
+        }
     if (mb_h > FFHIP_PROGRESS_SLOT_INTS) {
         ffhip_set_error("ffhip_h264_intra_c422: %d macroblock rows exceed the progress pool", mb_h);
         return FFHIP_EINVAL;
     }
-    FFHipProgressSlot ps;
-    const int r = ffhip_progress_acquire(mb_h, stream, &ps);
-    if (r < 0)
-        return r;
-    if (bd > 8)
-        hipLaunchKernelGGL(k_h264_intra_c422<uint16_t>, dim3(mb_h), dim3(64), 0, stream, cb, cr, sc, mb_w, mb_h, recs, row_start, coefs, ps.prog, ps.fail, (1 << bd) - 1);
-    else
-        hipLaunchKernelGGL(k_h264_intra_c422<uint8_t>, dim3(mb_h), dim3(64), 0, stream, cb, cr, sc, mb_w, mb_h, recs, row_start, coefs, ps.prog, ps.fail, 255);
-    const hipError_t e = hipGetLastError();
-    const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
-    if (e != hipSuccess) {
-        ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
-        return FFHIP_EIO;
+    int per = FFHIP_PROGRESS_SLOT_INTS / mb_h;
+    per = per > FFHIP_C422_PICS ? FFHIP_C422_PICS : per;
+    for (int p0 = 0; p0 < npics; p0 += per) {
+        const int n = npics - p0 < per ? npics - p0 : per;
+        FFHipC422IntraSet S;
+        for (int i = 0; i < FFHIP_C422_PICS; i++)
+            S.pic[i] = pics[p0 + (i < n ? i : 0)];
+        FFHipProgressSlot ps;
+        const int r = ffhip_progress_acquire(mb_h * n, stream, &ps);
+        if (r < 0)
+            return r;
+        if (bd > 8)
+            hipLaunchKernelGGL(k_h264_intra_c422<uint16_t>, dim3(mb_h, n), dim3(64), 0, stream, S, sc, mb_w, mb_h, ps.prog, ps.fail, (1 << bd) - 1);
+        else
+            hipLaunchKernelGGL(k_h264_intra_c422<uint8_t>, dim3(mb_h, n), dim3(64), 0, stream, S, sc, mb_w, mb_h, ps.prog, ps.fail, 255);
+        const hipError_t e = hipGetLastError();
+        const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            return FFHIP_EIO;
+        }
+        if (r2 < 0)
+            return r2;
     }
-    return r2 < 0 ? r2 : 0;
+    return 0;
 }
 
-int ffhip_launch_h264_deblock_c422(int bd, uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges, hipStream_t stream)
+int ffhip_launch_h264_intra_c422(int bd, uint8_t *cb, uint8_t *cr, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraC422 *recs,
+                                 const int32_t *row_start, const int16_t *coefs, hipStream_t stream)
 {
-    if (mb_w <= 0 || mb_h <= 0)
+    const FFHipH264C422Pic one = { cb, cr, recs, row_start, coefs };
+    return ffhip_launch_h264_intra_c422_pics(bd, 1, &one, sc, mb_w, mb_h, stream);
+}
+
+/* nplanes chroma planes of one geometry and stride (Cb and Cr of one picture, or of the pictures of a batch), each with its edge records */
+int ffhip_launch_h264_deblock_c422_planes(int bd, int nplanes, uint8_t *const *planes, const FFHipH264Edge *const *edges, ptrdiff_t stride, int mb_w,
+                                          int mb_h, hipStream_t stream)
+{
+    if (mb_w <= 0 || mb_h <= 0 || nplanes <= 0)
         return 0;
     const unsigned amask = bd > 8 ? 7u : 3u;
-    if (!c422_bd_ok(bd) || !plane || !edges || (((uintptr_t)plane | (size_t)stride) & amask) || ((uintptr_t)edges & 3)) {
-        ffhip_set_error("ffhip_h264_deblock_c422: bad argument (depths 8 / 9 / 10 / 12 / 14; plane and stride %u-byte aligned)", amask + 1);
+    if (!c422_bd_ok(bd) || !planes || !edges || ((size_t)stride & amask)) {
+        ffhip_set_error("ffhip_h264_deblock_c422: bad argument (depths 8 / 9 / 10 / 12 / 14; planes and stride %u-byte aligned)", amask + 1);
         return FFHIP_EINVAL;
     }
+    for (int i = 0; i < nplanes; i++)
+        if (!planes[i] || !edges[i] || ((uintptr_t)planes[i] & amask) || ((uintptr_t)edges[i] & 3)) {
+            ffhip_set_error("ffhip_h264_deblock_c422: null or misaligned argument (plane %d)", i);
+            return FFHIP_EINVAL;
+        }
     if (mb_h > FFHIP_PROGRESS_SLOT_INTS) {
         ffhip_set_error("ffhip_h264_deblock_c422: %d macroblock rows exceed the progress pool", mb_h);
         return FFHIP_EINVAL;
     }
-    FFHipProgressSlot ps;
-    const int r = ffhip_progress_acquire(mb_h, stream, &ps);
-    if (r < 0)
-        return r;
-    if (bd > 8)
-        hipLaunchKernelGGL(k_h264_deblock_c422<uint16_t>, dim3(mb_h), dim3(64), 0, stream, plane, stride, mb_w, mb_h, edges, ps.prog, ps.fail, bd);
-    else
-        hipLaunchKernelGGL(k_h264_deblock_c422<uint8_t>, dim3(mb_h), dim3(64), 0, stream, plane, stride, mb_w, mb_h, edges, ps.prog, ps.fail, bd);
-    const hipError_t e = hipGetLastError();
-    const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
-    if (e != hipSuccess) {
-        ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
-        return FFHIP_EIO;
+    int per = FFHIP_PROGRESS_SLOT_INTS / mb_h;
+    per = per > 2 * FFHIP_C422_PICS ? 2 * FFHIP_C422_PICS : per;
+    for (int p0 = 0; p0 < nplanes; p0 += per) {
+        const int n = nplanes - p0 < per ? nplanes - p0 : per;
+        FFHipC422PlaneSet S;
+        for (int i = 0; i < 2 * FFHIP_C422_PICS; i++) {
+            S.plane[i] = planes[p0 + (i < n ? i : 0)];
+            S.edges[i] = edges[p0 + (i < n ? i : 0)];
+        }
+        FFHipProgressSlot ps;
+        const int r = ffhip_progress_acquire(mb_h * n, stream, &ps);
+        if (r < 0)
+            return r;
+        if (bd > 8)
+            hipLaunchKernelGGL(k_h264_deblock_c422<uint16_t>, dim3(mb_h, n), dim3(64), 0, stream, S, stride, mb_w, mb_h, ps.prog, ps.fail, bd);
+        else
+            hipLaunchKernelGGL(k_h264_deblock_c422<uint8_t>, dim3(mb_h, n), dim3(64), 0, stream, S, stride, mb_w, mb_h, ps.prog, ps.fail, bd);
+        const hipError_t e = hipGetLastError();
+        const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            return FFHIP_EIO;
+        }
+        if (r2 < 0)
+            return r2;
     }
-    return r2 < 0 ? r2 : 0;
+    return 0;
+}
+
+int ffhip_launch_h264_deblock_c422(int bd, uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges, hipStream_t stream)
+{
+    return ffhip_launch_h264_deblock_c422_planes(bd, 1, &plane, &edges, stride, mb_w, mb_h, stream);
 }

@@ -69,6 +69,12 @@ int ffhip_launch_h264_intra_frame_bd(int bd, uint8_t *y, uint8_t *cb, uint8_t *c
 int ffhip_launch_h264_intra_c422(int bd, uint8_t *cb, uint8_t *cr, ptrdiff_t sc, int mb_w, int mb_h, const FFHipH264IntraC422 *recs,
                                  const int32_t *row_start, const int16_t *coefs, hipStream_t stream);
 int ffhip_launch_h264_deblock_c422(int bd, uint8_t *plane, ptrdiff_t stride, int mb_w, int mb_h, const FFHipH264Edge *edges, hipStream_t stream);
+/* ... of several pictures of one geometry side by side (blockIdx.y = the picture / the plane) */
+#define FFHIP_C422_PICS 32
+struct FFHipH264C422Pic { uint8_t *cb, *cr; const FFHipH264IntraC422 *recs; const int32_t *row_start; const int16_t *coefs; };
+int ffhip_launch_h264_intra_c422_pics(int bd, int npics, const FFHipH264C422Pic *pics, ptrdiff_t sc, int mb_w, int mb_h, hipStream_t stream);
+int ffhip_launch_h264_deblock_c422_planes(int bd, int nplanes, uint8_t *const *planes, const FFHipH264Edge *const *edges, ptrdiff_t stride, int mb_w,
+                                          int mb_h, hipStream_t stream);
 #define FFHIP_DB_PTRS 32
 int ffhip_launch_h264_deblock_pictures_bd(int bd, int chroma, uint8_t *const *planes, const FFHipH264Edge *const *edges, int nframes, ptrdiff_t stride,
                                           int mb_w, int mb_h, hipStream_t stream);

@@ -359,5 +359,55 @@ def test_decoder_driven_field_pictures_422(depth, mb_w, fmb_h, nref, mvr, p_intr
     _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, 2, seed=7772000 + depth * 1000 + mb_w * 31 + mvr + weights)
 
 
-def test_decoder_driven_pictures_422_flushed_together():
-    _run_picture(8, 12, 7, 2, 300, 0.3, 1, 4229100, pictures=3, batch=True, cfmt=2)
+@pytest.mark.parametrize("depth,mb_w,mb_h,pictures,p_intra", [(8, 12, 7, 3, 0.3), (10, 8, 5, 3, 0.4), (8, 10, 6, 35, 1.0)])
+def test_decoder_driven_pictures_422_flushed_together(depth, mb_w, mb_h, pictures, p_intra):
+    """4:2:2 pictures in one ffhip_h264_pictures_flush: the luma-only wavefronts of all pictures in one launch, their chroma planes'
+    wavefronts beside them in another (35 pictures: two launches each)"""
+    _run_picture(depth, mb_w, mb_h, 2, 300, p_intra, 1, 4229100 + pictures, pictures=pictures, batch=True, cfmt=2)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,cfmt,npic", [(8, 12, 7, 2, 3), (10, 8, 5, 2, 2), (8, 9, 6, 3, 3), (8, 10, 6, 2, 20)])
+def test_decoder_driven_deblocking_flushed_together(depth, mb_w, mb_h, cfmt, npic):
+    """the in-loop filter of several 4:2:2 / 4:4:4 pictures in one ffhip_h264_pictures_flush: all luma planes in one launch, the 8 x 16 chroma
+    planes of all pictures in another (k_h264_deblock_c422, blockIdx.y = the plane; 20 pictures: 40 chroma planes) — every picture == the
+    reference's ff_h264_filter_mb() on it"""
+    from ffmpeg_amd import h264
+    torch = _torch()
+    R, RH = _libs()
+    rng = np.random.default_rng(depth * 100 + mb_w + mb_h + cfmt + npic)
+    px, dt = (2, np.uint16) if depth > 8 else (1, np.uint8)
+    W, H = mb_w * 16, mb_h * 16
+    sy = W + 32
+    sc, HC = (sy, H) if cfmt == 3 else (W // 2 + 16, H)
+    strides = [sy * px, sc * px, sc * px]
+    mid, amp = 1 << (depth - 1), 20 << (depth - 8)
+    dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
+    cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, strides[0], strides[1], 0, cfmt=cfmt)
+    gpu = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, strides[0], strides[1], 1, cfmt=cfmt)
+    RH.ffrefhip_h264dec_record_begin.argtypes = [C.c_void_p] * 5
+    RH.ffrefhip_h264dec_record_begin.restype = None
+    held = []
+    for it in range(npic):
+        dst0 = [(mid + rng.integers(-amp, amp + 1, (r, s))).astype(dt) for r, s in ((H, sy), (HC, sc), (HC, sc))]
+        want = [a.copy() for a in dst0]
+        d_dst = [dev(a) for a in dst0]
+        cpu.set_cur([a.ctypes.data for a in want])
+        gpu.set_cur([t.data_ptr() for t in d_dst])
+        pic = h264.Picture(mb_w, mb_h, bit_depth=depth, chroma_format=cfmt)
+        pic.begin()
+        RH.ffrefhip_h264dec_record_begin(gpu.d, pic._p, *[t.data_ptr() for t in d_dst])
+        for st in I.make_filter_picture(rng, cpu.bits, mb_w, mb_h, depth, .2):
+            cpu.filter_mb(st["mb_x"], st["mb_y"], st)
+            gpu.filter_mb(st["mb_x"], st["mb_y"], st)
+        held.append((pic, d_dst, want, dst0))
+    h264.pictures_flush([h[0] for h in held], [h[1] for h in held], strides, [h[1] for h in held])
+    torch.cuda.synchronize()
+    for it, (pic, d_dst, want, dst0) in enumerate(held):
+        for pl in range(3):
+            got = d_dst[pl].cpu().numpy().view(dt)
+            assert (want[pl] != dst0[pl]).sum() > 50
+            bad = got != want[pl]
+            assert not bad.any(), "picture %d plane %d: %d mismatches, first at %s" % (it, pl, bad.sum(), np.argwhere(bad)[0])
+        pic.close()
+    cpu.close()
+    gpu.close()
