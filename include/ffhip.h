@@ -660,8 +660,9 @@ int  ffhip_h264_picture_create_hbd(FFHipH264Picture **p, int mb_w, int mb_h, int
  *  chroma422_dc_dequant_idct), SIX edge records per macroblock and chroma plane (the vertical edges x = 0, 4 — h_loop_filter_chroma422, 16
  *  lines, tc0 per 4 — then the horizontal ones y = 0, 4, 8, 12); ffhip_h264_picture_intra_mb() is the same call (qmul[1], qmul[2] =
  *  dequant4_coeff[1 + p][chroma_qp[p] + 3][0]; 512 I_PCM fields) and becomes a luma-only record plus an FFHipH264IntraC422.  flush() runs the
- *  luma plane through the luma kernels and the chroma planes' two dependency chains through plain kernels of their own (one picture per
- *  launch; ffhip_h264_pictures_flush() takes such pictures one by one); Cb and Cr share a stride when the picture has intra macroblocks.
+ *  luma plane through the luma kernels and the chroma planes' two dependency chains through plain kernels of their own, beside the luma
+ *  ones on the object's second stream (ffhip_h264_pictures_flush(): the chroma planes of all pictures side by side in one launch); Cb and Cr
+ *  share a stride when the picture has intra macroblocks.
  *  A 4:4:4 picture is what hl_decode_mb_444() (libavcodec/h264_mb_template.c:256-362) makes of it: three planes of luma geometry,
  *  all reconstructed by the LUMA members —
  *    prediction: qpix_op[luma_xy] on dest_cb / dest_cr with the luma vector (mc_dir_part(), h264_mb.c:262-288), weights of the luma width
