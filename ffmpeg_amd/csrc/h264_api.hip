@@ -449,13 +449,25 @@ extern "C" int ffhip_vp9_loopfilter_frame_ss_dev(int bit_depth, int ss_h, int ss
         return ffhip_vp9_loopfilter_frame_dev(bit_depth, y, u, v, stride_y, stride_uv, cols, rows, tables, stream);
     if (!hevc_bd_ok(bit_depth) || !y || !u || !v || !tables || cols < 0 || rows < 0 || rows > 8 * 1364)
         return FFHIP_EINVAL;
-    if (ss_h || ss_v) { /* 4:4:0 / 4:2:2 (VP9 profiles 1 / 3, rare): not built */
-        ffhip_set_error("ffhip_vp9_loopfilter_frame_ss_dev: chroma sub-sampling %d x %d (4:2:0 and 4:4:4 are built)", ss_h, ss_v);
-        return FFHIP_ENOSYS;
+    if (ss_h || ss_v) { /* 4:4:0 / 4:2:2: rectangular chroma superblocks take tables of their own */
+        ffhip_set_error("ffhip_vp9_loopfilter_frame_ss_dev: chroma sub-sampling %d x %d needs the chroma tables (ffhip_vp9_loopfilter_frame_ssc_dev)", ss_h, ss_v);
+        return FFHIP_EINVAL;
     }
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     return ffhip_launch_vp9_lf_frame(bit_depth, y, u, v, stride_y, stride_uv, cols, rows, tables, (hipStream_t)stream, 1);
+}
+
+extern "C" int ffhip_vp9_loopfilter_frame_ssc_dev(int bit_depth, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y,
+                                                  ptrdiff_t stride_uv, int cols, int rows, const FFHipVp9LfSb *tables, const FFHipVp9LfSbC *ctables,
+                                                  void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || !y || !u || !v || !tables || !ctables || cols < 0 || rows < 0 || rows > 8 * 1364 || ss_h == ss_v ||
+        ((ss_h | ss_v) & ~1))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_lf_frame_ssc(bit_depth, ss_h, ss_v, y, u, v, stride_y, stride_uv, cols, rows, tables, ctables, (hipStream_t)stream);
 }
 
 extern "C" int ffhip_vp9_loopfilter_frames_dev(int bit_depth, int ss_h, int ss_v, int npics, const FFHipVp9LfPic *pics, ptrdiff_t stride_y,

@@ -103,15 +103,16 @@ static void lf_rows(uint32_t *tab, int nseg, int row, int ss_h, int ss_v, const 
 int ffhip_vp9_lf_sb_tables(FFHipVp9LfSb *out, const FFHipVp9Filter *lflvl, int row, int col, int ss_h, int ss_v, const uint8_t *lim_lut,
                            const uint8_t *mblim_lut)
 {
-    if (!out || !lflvl || !lim_lut || !mblim_lut || ss_h != ss_v || ss_h < 0 || ss_h > 1) {
-        ffhip_set_error("ffhip_vp9_lf_sb_tables: null argument, or a chroma format other than 4:2:0 / 4:4:4");
+    if (!out || !lflvl || !lim_lut || !mblim_lut || ((ss_h | ss_v) & ~1)) {
+        ffhip_set_error("ffhip_vp9_lf_sb_tables: null argument, or a sub-sampling shift other than 0 / 1");
         return FFHIP_EINVAL;
     }
     memset(out, 0, sizeof(*out));
     lf_cols(&out->y[0][0][0], 8, col, 0, 0, lflvl->level, lflvl->mask[0][0], lim_lut, mblim_lut);
     lf_rows(&out->y[1][0][0], 8, row, 0, 0, lflvl->level, lflvl->mask[0][1], lim_lut, mblim_lut);
-    if (!ss_h)
-        return 0; /* 4:4:4: the chroma planes take the luma tables (ffhip_vp9_loopfilter_frame_ss_dev); uv stays empty */
+    if (!ss_h || !ss_v)
+        return 0; /* 4:4:4: the chroma planes take the luma tables (ffhip_vp9_loopfilter_frame_ss_dev); 4:2:2 / 4:4:0: tables of their own
+                   * (ffhip_vp9_lf_sb_ctables); uv stays empty */
     lf_cols(&out->uv[0][0][0], 4, col, ss_h, ss_v, lflvl->level, lflvl->mask[1][0], lim_lut, mblim_lut);
     lf_rows(&out->uv[1][0][0], 4, row, ss_h, ss_v, lflvl->level, lflvl->mask[1][1], lim_lut, mblim_lut);
     /* a 16-wide chroma filter on the superblock's last 4-sample position would reach 4 samples into the next superblock: mask_edges
@@ -124,4 +125,31 @@ int ffhip_vp9_lf_sb_tables(FFHipVp9LfSb *out, const FFHipVp9Filter *lflvl, int r
                 return FFHIP_EINVAL;
             }
     return 0;
+}
+
+/* The chroma planes of a 4:2:2 (ss_h 1, ss_v 0) or 4:4:0 (0, 1) superblock: filter_plane_cols / _rows with the two shifts apart
+ * (vp9lpf.c:185-201, uv_masks = lflvl->mask[ss_h | ss_v] = mask[1]) — lf_cols / lf_rows above already follow the reference's branches for
+ * either shift; only the tile is rectangular: column edges [position][segment] = 8 x 8 (4:2:2) / 16 x 4 (4:4:0), row edges 16 x 4 / 8 x 8. */
+int ffhip_vp9_lf_sb_ctables(FFHipVp9LfSbC *out, const FFHipVp9Filter *lflvl, int row, int col, int ss_h, int ss_v, const uint8_t *lim_lut,
+                            const uint8_t *mblim_lut)
+{
+    if (!out || !lflvl || !lim_lut || !mblim_lut || ((ss_h | ss_v) & ~1) || ss_h == ss_v) {
+        ffhip_set_error("ffhip_vp9_lf_sb_ctables: null argument, or a chroma format other than 4:2:2 (1, 0) / 4:4:0 (0, 1)");
+        return FFHIP_EINVAL;
+    }
+    const int npc = ss_h ? 8 : 16, nsc = ss_v ? 4 : 8, npr = ss_v ? 8 : 16, nsr = ss_h ? 4 : 8;
+    memset(out, 0, sizeof(*out));
+    lf_cols(out->t, nsc, col, ss_h, ss_v, lflvl->level, lflvl->mask[1][0], lim_lut, mblim_lut);
+    lf_rows(out->t + npc * nsc, nsr, row, ss_h, ss_v, lflvl->level, lflvl->mask[1][1], lim_lut, mblim_lut);
+    /* a 16-wide filter on a tile's last 4-sample position would reach into the next superblock (never asked for: vp9block.c:1215-1228) */
+    for (int sg = 0; sg < nsc; sg++)
+        if ((out->t[(npc - 1) * nsc + sg] >> 31) && ((out->t[(npc - 1) * nsc + sg] >> 24) & 3) == 2)
+            goto wide;
+    for (int sg = 0; sg < nsr; sg++)
+        if ((out->t[npc * nsc + (npr - 1) * nsr + sg] >> 31) && ((out->t[npc * nsc + (npr - 1) * nsr + sg] >> 24) & 3) == 2)
+            goto wide;
+    return 0;
+wide:
+    ffhip_set_error("ffhip_vp9_lf_sb_ctables: a 16-wide chroma filter 4 samples before the superblock's end (no stream produces it)");
+    return FFHIP_EINVAL;
 }

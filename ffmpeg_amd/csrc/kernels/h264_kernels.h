@@ -115,6 +115,9 @@ int ffhip_launch_vp9_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipVp9
 struct FFHipVp9LfPics { int n; int pad; FFHipVp9LfPic pic[FFHIP_VP9_LF_PICS]; };
 int ffhip_launch_vp9_lf_frames(int bd, int npics, const FFHipVp9LfPic *pics, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows, hipStream_t stream,
                                int planes444 = 0);
+/* 4:2:2 / 4:4:0: luma by `tabs`' y part, the rectangular chroma superblocks by `ctabs` */
+int ffhip_launch_vp9_lf_frame_ssc(int bd, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
+                                  const FFHipVp9LfSb *tabs, const FFHipVp9LfSbC *ctabs, hipStream_t stream);
 int ffhip_launch_vp9_lf_frame(int bd, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
                               const FFHipVp9LfSb *tabs, hipStream_t stream, int planes444 = 0);
 int ffhip_launch_vp9_itxfm_bd(int bd, int tx, void *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipVp9TU *tus, int n, hipStream_t stream);

@@ -361,6 +361,166 @@ __device__ __forceinline__ void vp9_lf_sb_row(uint8_t *p0, uint8_t *p1, ptrdiff_
     }
 }
 
+/* ================================================================================================== */
+/*
+ * 4:2:2 / 4:4:0 (VP9 profiles 1 / 3 with ss_h != ss_v; round 4): a chroma superblock is 32 x 64 resp. 64 x 32 samples, filter_plane_cols /
+ * _rows run with the two shifts apart (libavcodec/vp9lpf.c:27-178,185-201) — vp9_lf_sb_row's walk on a rectangular tile, one plane per
+ * wave (the row pass of a 64-wide tile needs all 64 lanes): the luma plane keeps vp9_lf_sb_row<., false>, U and V are waves of their own
+ * with counters of their own.  Tables: FFHipVp9LfSbC (host/vp9_lf_tables.c ffhip_vp9_lf_sb_ctables).
+ */
+template <typename PIX, int NW, int NH>
+__device__ __forceinline__ void vp9_lf_plane_row(uint8_t *p0, ptrdiff_t stride, int cols, int rows, int row, const FFHipVp9LfSbC *tabs, int *progress,
+                                                 int *fail, int bd)
+{
+    constexpr int PS = (int)sizeof(PIX), SPD = 4 / PS;
+    constexpr int P = NW + 12;                                       /* tile row pitch in samples */
+    constexpr int NPC = NW / 4, NSC = NH / 8, NPR = NH / 4, NSR = NW / 8, TW = NPC * NSC + NPR * NSR; /* column / row edge positions, segments */
+    constexpr int TK = (TW + 63) / 64, DN = NW / SPD, D8 = 8 / SPD, PD = P / SPD;
+    constexpr int UW = 64 / NW, UH = 64 / NH;                         /* 8x8 luma blocks per chroma sample step: samples = (8 / U) per block */
+    static_assert(TW == 128 && sizeof(FFHipVp9LfSbC) == 4 * TW, "one table per superblock");
+    __shared__ __align__(16) PIX tile[(NH + 8) * P];                  /* rows -8..NH-1, columns -8..NW-1: sample (r, c) at [(r + 8) * P + c + 8] */
+    __shared__ uint32_t tab[TW];
+    using In = Vp9LfRegion<DN, NH, false>;
+    using Left = Vp9LfRegion<D8, NH, true>;
+    using Top = Vp9LfRegion<DN, 8, true>;
+    using Top7 = Vp9LfRegion<DN, 7, true>;
+    const int lane = threadIdx.x;
+    const int sh = bd - 8, F = 1 << sh, fmax = (1 << (bd - 1)) - 1, maxv = (1 << bd) - 1;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const int sb_cols = (cols + 7) >> 3;
+    const int h = min(NH, (8 / UH) * rows - NH * row);               /* the picture may end inside the last superblocks */
+    uint8_t *const prow = p0 + (ptrdiff_t)row * NH * stride;
+    uint32_t *const t32 = reinterpret_cast<uint32_t *>(tile);
+    int known = 0;
+    for (int col = 0; col < sb_cols; col++) {
+        const int w = min(NW, (8 / UW) * cols - NW * col);
+        uint8_t *const sb = prow + (ptrdiff_t)col * NW * PS;
+        {
+            uint32_t vin[In::K], vl[Left::K];
+            In::issue(vin, sb, stride, h, w / SPD, lane);
+            if (col)
+                Left::issue(vl, sb - 8 * PS, stride, h, D8, lane);
+            const uint32_t *g = tabs[(size_t)row * sb_cols + col].t;
+#pragma unroll
+            for (int k = 0; k < TK; k++)
+                if (lane + 64 * k < TW)
+                    tab[lane + 64 * k] = g[lane + 64 * k];
+            In::commit(vin, t32 + 8 * PD + D8, PD, h, w / SPD, lane);
+            if (col)
+                Left::commit(vl, t32 + 8 * PD, PD, h, D8, lane);
+        }
+        wave_sync();
+        auto run = [&](PIX *line0, int step, int pos, uint32_t e) {
+            const int wd = ((e >> 24) & 3) == 0 ? 4 : ((e >> 24) & 3) == 1 ? 8 : 16;
+            PIX *pix = line0 + 4 * pos * step;
+            int px[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                px[k] = (wd >= 16 || (k >= 4 && k < 12)) ? (int)pix[(k - 8) * step] : 0;
+            vp9_lf_line(px, wd, (int)(e & 0xFF) << sh, (int)((e >> 8) & 0xFF) << sh, (int)((e >> 16) & 0xFF) << sh, F, fmax, maxv,
+                        [&](int k, int v) { pix[(k - 8) * step] = (PIX)v; });
+        };
+        /* ---- column edges: lane = sample row ---- */
+        if (lane < NH)
+            for (int p = 0; p < NPC; p++) {
+                const uint32_t e = tab[p * NSC + (lane >> 3)];
+                if (e >> 31)
+                    run(tile + (lane + 8) * P + 8, 1, p, e);
+            }
+        /* ---- the row above has finished superblock col + 1; then its last 8 rows ---- */
+        if (row > 0) {
+            const int want = min(col + 2, sb_cols);
+            int spins = 0;
+            while (known < want) {
+                known = __hip_atomic_load(&progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (known >= want)
+                    break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 24)) {
+                    if (lane == 0)
+                        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint32_t vt[Top::K];
+            Top::issue(vt, sb - 8 * stride, stride, 8, w / SPD, lane);
+            Top::commit(vt, t32 + D8, PD, 8, w / SPD, lane);
+        }
+        wave_sync();
+        /* ---- row edges: lane = sample column ---- */
+        if (lane < NW)
+            for (int p = 0; p < NPR; p++) {
+                const uint32_t e = tab[NPC * NSC + p * NSR + (lane >> 3)];
+                if (e >> 31)
+                    run(tile + 8 * P + lane + 8, P, p, e);
+            }
+        wave_sync();
+        In::store(t32 + 8 * PD + D8, PD, sb, stride, h, w / SPD, lane);
+        if (col)
+            Left::store(t32 + 8 * PD, PD, sb - 8 * PS, stride, h, D8, lane);
+        if (row)
+            Top7::store(t32 + PD + D8, PD, sb - 7 * stride, stride, 7, w / SPD, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0)
+            __hip_atomic_store(&progress[row], col + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wave_sync();
+    }
+}
+
+/* blocks 0 .. sb_rows - 1: luma rows, then the U rows, then the V rows; ss422: 32 x 64 chroma superblocks (ss_h 1, ss_v 0), else 64 x 32 */
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_vp9_lf_frame_ssc(uint8_t *py, uint8_t *pu, uint8_t *pv, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
+                                                         const FFHipVp9LfSb *tabs, const FFHipVp9LfSbC *ctabs, int *progress, int *fail, int bd, int ss422)
+{
+    const int sb_rows = (rows + 7) >> 3, b = (int)blockIdx.x;
+    if (b < sb_rows) {
+        vp9_lf_sb_row<PIX, false>(py, py, sy, cols, rows, b, tabs, progress, fail, bd);
+        return;
+    }
+    const int pl = (b - sb_rows) / sb_rows, r = (b - sb_rows) % sb_rows;
+    uint8_t *const p = pl ? pv : pu;
+    if (ss422)
+        vp9_lf_plane_row<PIX, 32, 64>(p, suv, cols, rows, r, ctabs, progress + (1 + pl) * sb_rows, fail, bd);
+    else
+        vp9_lf_plane_row<PIX, 64, 32>(p, suv, cols, rows, r, ctabs, progress + (1 + pl) * sb_rows, fail, bd);
+}
+
+int ffhip_launch_vp9_lf_frame_ssc(int bd, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
+                                  const FFHipVp9LfSb *tabs, const FFHipVp9LfSbC *ctabs, hipStream_t stream)
+{
+    const int sb_rows = (rows + 7) >> 3;
+    if (cols <= 0 || rows <= 0)
+        return 0;
+    if ((bd != 8 && bd != 10 && bd != 12) || !y || !u || !v || !tabs || !ctabs || ss_h == ss_v || (ss_h | ss_v) & ~1 ||
+        (((uintptr_t)y | (uintptr_t)u | (uintptr_t)v | (size_t)sy | (size_t)suv) & 3)) {
+        ffhip_set_error("ffhip_vp9_loopfilter_frame_ssc: bit depth %d (8, 10, 12), sub-sampling 1 x 0 or 0 x 1; planes and strides 4-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
+    if (3 * sb_rows + 1 > FFHIP_PROGRESS_SLOT_INTS)
+        return FFHIP_EINVAL;
+    FFHipProgressSlot ps;
+    const int r = ffhip_progress_acquire(3 * sb_rows + 1, stream, &ps);
+    if (r < 0)
+        return r;
+    if (bd == 8)
+        hipLaunchKernelGGL(k_vp9_lf_frame_ssc<uint8_t>, dim3(3 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, ctabs, ps.prog, ps.fail, 8, ss_h);
+    else
+        hipLaunchKernelGGL(k_vp9_lf_frame_ssc<uint16_t>, dim3(3 * sb_rows), dim3(64), 0, stream, y, u, v, sy, suv, cols, rows, tabs, ctabs, ps.prog, ps.fail, bd, ss_h);
+    const hipError_t e = hipGetLastError();
+    const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+    if (e != hipSuccess) {
+        ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+        return FFHIP_EIO;
+    }
+    return r2 < 0 ? r2 : 0;
+}
+
 /* ---- the frame kernel's line filter: the same arithmetic as vp9_lf_line (vp9dsp_template.c:1777-1930) without per-lane control
  * flow.  A lane is a line of its own 8-line segment with its own width and limits, so a divergent `if` per test made the wave walk
  * every path behind exec-mask bookkeeping (530 VALU + 560 SALU + 107 branches per call site).  Here every test is a sign —

@@ -177,3 +177,26 @@ def smc_init(bpp=8):
     c = VP9ScaledMcContext()
     _lib.check(_lib.lib().ff_vp9dsp_scaled_mc_init_hip(C.byref(c), bpp), "ff_vp9dsp_scaled_mc_init_hip")
     return c
+
+
+def lf_sb_tables_ss(filters, sb_cols, sb_rows, lim_lut, mblim_lut, ss):
+    """4:2:2 (ss = (1, 0)) / 4:4:0 ((0, 1)): (tables uint32 [n, 320] with the luma part filled, ctables uint32 [n, 128]) of the picture's
+    superblocks (ffhip_vp9_lf_sb_tables + ffhip_vp9_lf_sb_ctables)"""
+    L = _lib.lib()
+    n = sb_cols * sb_rows
+    out, cout = np.zeros((n, 320), np.uint32), np.zeros((n, 128), np.uint32)
+    for r in range(sb_rows):
+        for c in range(sb_cols):
+            k = r * sb_cols + c
+            _lib.check(L.ffhip_vp9_lf_sb_tables(out[k].ctypes.data, filters[k].ctypes.data, 8 * r, 8 * c, ss[0], ss[1], lim_lut.ctypes.data,
+                                                mblim_lut.ctypes.data), "ffhip_vp9_lf_sb_tables")
+            _lib.check(L.ffhip_vp9_lf_sb_ctables(cout[k].ctypes.data, filters[k].ctypes.data, 8 * r, 8 * c, ss[0], ss[1], lim_lut.ctypes.data,
+                                                 mblim_lut.ctypes.data), "ffhip_vp9_lf_sb_ctables")
+    return out, cout
+
+
+def loopfilter_frame_ssc(y, u, v, stride_y, stride_uv, cols, rows, tables, ctables, ss, stream=None, bit_depth=8):
+    """ffhip_vp9_loopfilter_frame_ssc_dev: a 4:2:2 / 4:4:0 picture (rectangular chroma superblocks)"""
+    return _lib.check(_lib.lib().ffhip_vp9_loopfilter_frame_ssc_dev(bit_depth, ss[0], ss[1], y.data_ptr(), u.data_ptr(), v.data_ptr(), stride_y,
+                                                                    stride_uv, cols, rows, tables.data_ptr(), ctables.data_ptr(), _st(stream)),
+                      "ffhip_vp9_loopfilter_frame_ssc_dev")

@@ -1448,9 +1448,19 @@ typedef struct FFHipVp9LfSb {            /* entry: bit 31 valid, 24..25 width (0
     uint32_t y[2][16][8];                /* [0 column edges / 1 row edges][position: 4 p samples along the filter axis][segment of 8 lines] */
     uint32_t uv[2][8][4];                /* the same for both chroma planes (32 x 32 samples) */
 } FFHipVp9LfSb;
+/** The chroma planes' table of one superblock where the two sub-sampling shifts differ — 4:2:2 (ss_h 1, ss_v 0: 32 x 64 chroma samples) and
+ *  4:4:0 (ss_h 0, ss_v 1: 64 x 32): entries as in FFHipVp9LfSb; first the column edges [position][segment of 8 lines] (4:2:2: 8 x 8, 4:4:0:
+ *  16 x 4), then the row edges [position][segment of 8 columns] (4:2:2: 16 x 4, 4:4:0: 8 x 8) — 128 words either way.  Both chroma planes
+ *  share it (filter_plane_cols / _rows with uv_masks = lflvl->mask[1], libavcodec/vp9lpf.c:185-201). */
+typedef struct FFHipVp9LfSbC {
+    uint32_t t[128];
+} FFHipVp9LfSbC;
+int ffhip_vp9_lf_sb_ctables(FFHipVp9LfSbC *out, const FFHipVp9Filter *lflvl, int row, int col, int ss_h, int ss_v, const uint8_t *lim_lut,
+                            const uint8_t *mblim_lut);
 /** Host side: the tables of the superblock at (row, col) — in 8-sample units, as the reference passes them (superblock (r, c): row =
  *  8 r, col = 8 c; only "is it the first" matters) — from its VP9Filter and the frame's filter_lut (vp9.c:683-697).  ss_h = ss_v = 1
- *  (4:2:0) or 0 (4:4:4: y only, the chroma planes are filtered by the luma tables); anything else FFHIP_EINVAL. */
+ *  (4:2:0) or 0 (4:4:4: y only, the chroma planes are filtered by the luma tables); 1, 0 / 0, 1 (4:2:2 / 4:4:0): y only as well, the chroma
+ *  planes take ffhip_vp9_lf_sb_ctables(). */
 int ffhip_vp9_lf_sb_tables(FFHipVp9LfSb *out, const FFHipVp9Filter *lflvl, int row, int col, int ss_h, int ss_v, const uint8_t *lim_lut,
                            const uint8_t *mblim_lut);
 /** One picture of cols x rows 8x8 blocks (VP9Context.cols / .rows: (width + 7) >> 3, (height + 7) >> 3), i.e. (cols + 7) >> 3 by
@@ -1463,9 +1473,15 @@ int ffhip_vp9_loopfilter_frame_dev(int bit_depth, uint8_t *y, uint8_t *u, uint8_
 /** The same with the picture's chroma sub-sampling (VP9Context.ss_h / .ss_v).  1, 1: the call above.  0, 0 (4:4:4, profiles 1 / 3): the
  *  chroma planes are filtered exactly as luma — ff_vp9_loopfilter_sb passes luma's masks (uv_masks = lflvl->mask[ss_h | ss_v]) and
  *  levels with ss 0 (vp9lpf.c:185-201) — so all three planes use tables[].y and three luma chains run side by side; tables[].uv is not
- *  read.  4:4:0 / 4:2:2: FFHIP_ENOSYS. */
+ *  read.  4:4:0 / 4:2:2: FFHIP_EINVAL here (they need the chroma tables: ffhip_vp9_loopfilter_frame_ssc_dev). */
 int ffhip_vp9_loopfilter_frame_ss_dev(int bit_depth, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y,
                                       ptrdiff_t stride_uv, int cols, int rows, const FFHipVp9LfSb *tables, void *stream);
+/** 4:2:2 (ss_h 1, ss_v 0) and 4:4:0 (0, 1) — VP9 profiles 1 / 3 with rectangular chroma superblocks (round 4): luma by tables[].y, both
+ *  chroma planes by ctables[] (one per superblock, raster order, device memory).  A plain kernel (one wave per superblock row and plane);
+ *  one picture per launch. */
+int ffhip_vp9_loopfilter_frame_ssc_dev(int bit_depth, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t stride_y,
+                                       ptrdiff_t stride_uv, int cols, int rows, const FFHipVp9LfSb *tables, const FFHipVp9LfSbC *ctables,
+                                       void *stream);
 /** N pictures of one geometry in ONE launch (round 4; what a decoder's frame threads hold at once): each picture its own planes and
  *  tables (device pointers), strides shared.  A picture's filter is a dependency chain through it (0.9 ms for a 4K picture on a chip it
  *  cannot fill); the pictures of a batch are filtered side by side.  ss_h / ss_v as above.  `pics` is a host array. */

@@ -191,3 +191,61 @@ def test_vp9_loopfilter_frames_batch(bd, ss, sbc, sbr, npics):
             assert np.array_equal(x, y), (i, k)
             changed += int((x != keep[i][0][k].view(np.uint8).reshape(-1)).sum())
     assert changed > 1000
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("ss", [(1, 0), (0, 1)], ids=["422", "440"])
+@pytest.mark.parametrize("sbc,sbr,kind", [(9, 5, "structured"), (7, 6, "bits1"), (1, 1, "structured"), (2, 13, "bits0"), (30, 17, "structured")])
+def test_vp9_loopfilter_frame_422_440(sbc, sbr, kind, ss, bd):
+    """VP9 4:2:2 (ss_h 1, ss_v 0) and 4:4:0 (0, 1): rectangular chroma superblocks (ffhip_vp9_loopfilter_frame_ssc_dev, tables from
+    ffhip_vp9_lf_sb_tables + ffhip_vp9_lf_sb_ctables) == the oracle's ffo_vp9_loopfilter_sb superblock by superblock (pinned to the
+    reference's ff_vp9_loopfilter_sb at these shifts in tests/test_vp9_lf_sb_cpu.py)"""
+    import torch
+    from ffmpeg_amd import vp9, _lib
+    ss_h, ss_v = ss
+    rng = np.random.default_rng(1000 * sbc + 10 * sbr + bd + len(kind) + 7 * ss_h)
+    lim, mblim = G.filter_lut(int(rng.integers(0, 8)))
+    cols, rows = 8 * sbc, 8 * sbr
+    if kind == "structured":
+        cols, rows = cols - int(rng.integers(0, 8)), rows - int(rng.integers(0, 8))
+    cw, chh = 64 >> ss_h, 64 >> ss_v
+    planes = [_plane(rng, 64 * sbr, 64 * sbc, 12, bd), _plane(rng, chh * sbr, cw * sbc, 4, bd), _plane(rng, chh * sbr, cw * sbc, 4, bd)]
+    before = [p.copy() for p in planes]
+    filt = np.zeros(sbr * sbc, G.FILTER_DT)
+    O = ffi.oracle()
+    L = _lib.lib()
+    for r in range(sbr):
+        for c in range(sbc):
+            for _ in range(50):                   # arbitrary bits may ask for a 16-wide chroma filter at a tile's last position: drawn again
+                f = G.structured(rng, r, c, cols, rows, ss_h, ss_v) if kind == "structured" else G.random_bits(rng, int(kind[-1]))
+                probe = np.zeros(128, np.uint32)
+                if L.ffhip_vp9_lf_sb_ctables(probe.ctypes.data, np.ascontiguousarray(f).ctypes.data, 8 * r, 8 * c, ss_h, ss_v, lim.ctypes.data,
+                                             mblim.ctypes.data) == 0:
+                    break
+            else:
+                pytest.fail("no acceptable filter drawn")
+            filt[r * sbc + c] = f
+            level, mask = np.ascontiguousarray(f["level"]), np.ascontiguousarray(f["mask"])
+            at = [planes[0].ctypes.data + r * 64 * planes[0].strides[0] + c * 64 * planes[0].itemsize] + \
+                 [p.ctypes.data + r * chh * p.strides[0] + c * cw * p.itemsize for p in planes[1:]]
+            O.ffo_vp9_loopfilter_sb(bd, ss_h, ss_v, ptr(level, u8p), ptr(mask, u8p), 8 * r, 8 * c, *(C.cast(a, u8p) for a in at),
+                                    planes[0].strides[0], planes[1].strides[0], ptr(lim, u8p), ptr(mblim, u8p))
+    tabs, ctabs = vp9.lf_sb_tables_ss(filt.view(np.uint8).reshape(sbr * sbc, 192), sbc, sbr, lim, mblim, ss)
+    dev = [torch.from_numpy(b.view(np.uint8).reshape(-1).copy()).cuda() for b in before]
+    d_tabs, d_ctabs = torch.from_numpy(tabs.view(np.int32)).cuda(), torch.from_numpy(ctabs.view(np.int32)).cuda()
+    vp9.loopfilter_frame_ssc(dev[0], dev[1], dev[2], before[0].strides[0], before[1].strides[0], cols, rows, d_tabs, d_ctabs, ss, bit_depth=bd)
+    torch.cuda.synchronize()
+    assert L.ffhip_stream_synchronize(None) == 0
+    changed = 0
+    for k, (d, want, b) in enumerate(zip(dev, planes, before)):
+        got = d.cpu().numpy().view(want.dtype).reshape(want.shape)
+        h, w = (8 * rows, 8 * cols) if k == 0 else ((8 >> ss_v) * rows, (8 >> ss_h) * cols)
+        bad = np.argwhere(got[:h, :w] != want[:h, :w])
+        assert bad.size == 0, (k, bad[:5], len(bad))
+        outside = got != b
+        outside[:h, :w] = False
+        assert not outside.any()
+        changed += int((want[1:] != b[1:]).sum()) if k else 0
+    assert changed > (20 * sbc * sbr if sbc * sbr > 8 else -1)
+    with pytest.raises(Exception):               # the 4:2:0 / 4:4:4 entry points refuse these formats by name
+        vp9.loopfilter_frame(dev[0], dev[1], dev[2], before[0].strides[0], before[1].strides[0], cols, rows, d_tabs, bit_depth=bd, ss=ss)

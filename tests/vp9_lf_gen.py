@@ -165,3 +165,23 @@ def run_tables(O, tab, bd, planes, strides, ss_h=1, ss_v=1):
                     st = strides[0 if pl == 0 else 1]
                     at = planes[pl] + ((8 * sg * st + 4 * p * ps) if d == 0 else (4 * p * st + 8 * sg * ps))
                     O.ffo_vp9_loop_filter_bd(bd, wd, d, C.cast(at, u8), st, e & 0xFF, (e >> 8) & 0xFF, (e >> 16) & 0xFF)
+
+
+def run_ctables(O, ctab, bd, planes_uv, stride, ss_h, ss_v):
+    """executes one superblock's FFHipVp9LfSbC (4:2:2 / 4:4:0) the way k_vp9_lf_frame_ssc does, on both chroma planes: all column edges
+    position by position, then all row edges"""
+    import ctypes as C
+    u8 = C.POINTER(C.c_uint8)
+    ps = 2 if bd > 8 else 1
+    t = np.asarray(ctab, np.uint32).reshape(128)
+    npc, nsc, npr, nsr = (8 if ss_h else 16), (4 if ss_v else 8), (8 if ss_v else 16), (4 if ss_h else 8)
+    for base_at in planes_uv:
+        for d, (npos, nseg, off) in enumerate(((npc, nsc, 0), (npr, nsr, npc * nsc))):
+            for p in range(npos):
+                for sg in range(nseg):
+                    e = int(t[off + p * nseg + sg])
+                    if not e >> 31:
+                        continue
+                    wd = (4, 8, 16)[(e >> 24) & 3]
+                    at = base_at + ((8 * sg * stride + 4 * p * ps) if d == 0 else (4 * p * stride + 8 * sg * ps))
+                    O.ffo_vp9_loop_filter_bd(bd, wd, d, C.cast(at, u8), stride, e & 0xFF, (e >> 8) & 0xFF, (e >> 16) & 0xFF)
