@@ -475,8 +475,8 @@ extern "C" int ffhip_vp9_loopfilter_frames_dev(int bit_depth, int ss_h, int ss_v
 {
     if (!hevc_bd_ok(bit_depth) || npics < 0 || (npics && !pics) || cols < 0 || rows < 0 || rows > 8 * 1364)
         return FFHIP_EINVAL;
-    if (ss_h != ss_v) { /* 4:4:0 / 4:2:2 (VP9 profiles 1 / 3, rare): not built */
-        ffhip_set_error("ffhip_vp9_loopfilter_frames_dev: chroma sub-sampling %d x %d (4:2:0 and 4:4:4 are built)", ss_h, ss_v);
+    if (ss_h != ss_v) { /* 4:4:0 / 4:2:2: the plain kernel of those formats takes one picture per launch (ffhip_vp9_loopfilter_frame_ssc_dev) */
+        ffhip_set_error("ffhip_vp9_loopfilter_frames_dev: chroma sub-sampling %d x %d is not batched: ffhip_vp9_loopfilter_frame_ssc_dev per picture", ss_h, ss_v);
         return FFHIP_ENOSYS;
     }
     if (!ffhip_have_device())

@@ -637,7 +637,8 @@ int ffhip_h264_chroma_mc_batch_dev_hbd_pic(int bit_depth, uint8_t *dst, const ui
  * h264_mb.c:206-420,612-800) and ff_h264_filter_mb() computes (h264_loopfilter.c:716); flush() runs, per plane,
  *     MC put -> picture | MC put -> bi-prediction scratch | MC avg -> picture | weight / biweight | IDCT + add |
  *     intra macroblocks (reconstruction wavefront, all three planes) | deblock (decoder order)
- * 4:2:0, 8 bits.  All planes of the picture, of the references and the scratch share one stride per plane (qpel_mc_func has one).
+ * ffhip_h264_picture_create(): 4:2:0, 8 bits; the other depths and chroma formats: ffhip_h264_picture_create_hbd / _fmt below.  All planes
+ * of the picture, of the references and the scratch share one stride per plane (qpel_mc_func has one).
  * ref[pl] is the base the blocks' src_offset counts from — typically the decoded-picture-buffer allocation, so that one base
  * reaches every reference picture.  One object serves one stream; begin() starts the next picture (flush() does not clear).
  */
@@ -710,7 +711,8 @@ int  ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int
  * WAVEFRONT (one wave per macroblock row; an intra macroblock starts when the row above has finished the macroblock up and to the
  * right) after the inter macroblocks' prediction and residual stages and before deblocking — the order of the reference's
  * data flow, whose in-loop filter runs behind reconstruction on samples intra prediction never sees (xchg_mb_border,
- * h264_mb.c:528-597).  Fields are the decoder's H264SliceContext state of the macroblock.  8 bits, 4:2:0, frame macroblocks;
+ * h264_mb.c:528-597).  Fields are the decoder's H264SliceContext state of the macroblock.  Frame macroblocks, or the field macroblocks of
+ * a field picture whose object was made for the field (mb_y = the row inside the field); 4:2:2 / 4:4:4: ffhip_h264_picture_create_fmt();
  * the lossless transform bypass (qscale 0 with sps->transform_bypass) is not taken: keep such a picture on the C path.
  */
 #define FFHIP_H264_INTRA_16x16 0   /* IS_INTRA16x16(mb_type)                                                         */

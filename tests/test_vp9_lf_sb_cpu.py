@@ -95,7 +95,11 @@ def test_tables_reject():
     f = np.zeros(192, np.uint8)
     lim, mblim = G.filter_lut(0)
     assert L.ffhip_vp9_lf_sb_tables(tab.ctypes.data, f.ctypes.data, 0, 0, 0, 0, lim.ctypes.data, mblim.ctypes.data) == 0  # 4:4:4: the luma tables
-    assert L.ffhip_vp9_lf_sb_tables(tab.ctypes.data, f.ctypes.data, 0, 0, 1, 0, lim.ctypes.data, mblim.ctypes.data) < 0   # 4:2:2 / 4:4:0: not built
+    assert L.ffhip_vp9_lf_sb_tables(tab.ctypes.data, f.ctypes.data, 0, 0, 1, 0, lim.ctypes.data, mblim.ctypes.data) == 0  # 4:2:2 / 4:4:0: the luma part
+    assert L.ffhip_vp9_lf_sb_tables(tab.ctypes.data, f.ctypes.data, 0, 0, 2, 0, lim.ctypes.data, mblim.ctypes.data) < 0
+    ctab = np.zeros(128, np.uint32)
+    assert L.ffhip_vp9_lf_sb_ctables(ctab.ctypes.data, f.ctypes.data, 0, 0, 1, 0, lim.ctypes.data, mblim.ctypes.data) == 0
+    assert L.ffhip_vp9_lf_sb_ctables(ctab.ctypes.data, f.ctypes.data, 0, 0, 1, 1, lim.ctypes.data, mblim.ctypes.data) < 0  # 4:2:0 / 4:4:4: the other tables
     assert L.ffhip_vp9_lf_sb_tables(None, f.ctypes.data, 0, 0, 1, 1, lim.ctypes.data, mblim.ctypes.data) < 0
     g = np.zeros((), G.FILTER_DT)
     g["mask"][1, 0, 0, 0] = 0x80                               # 16-wide chroma column edge at the superblock's last position
