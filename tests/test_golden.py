@@ -557,3 +557,59 @@ def test_round3_h264_hbd_golden():
         pic = np.ascontiguousarray(d["h%d_bw_in" % bd])
         O.ffo_h264_biweight_bd(bd, 16, pat(pic, 1, 4), pat(src, 1, 4), pic.strides[0], 16, 5, 37, -21, 9)
         assert np.array_equal(pic, d["h%d_bw_out" % bd]), bd
+
+
+def test_round4_alpha_both_sides_golden():
+    """planar YUVA -> planar YUVA: the reference's four planes == the oracle's base conversion, and the oracle's luma of the same conversion
+    with A in Y's place for the alpha plane (lum_h_scale / lum_planar_vscale on plane 3) — what libffhip's second pass computes"""
+    from ffmpeg_amd import swscale as S
+    d = load("round4")
+    base = {33: 0, 78: 4, 79: 5}                        # yuva420p / 422p / 444p -> yuv420p / 422p / 444p
+    for k in range(int(d["a_n"])):
+        sf, sw, sh, df, dw, dh, flags = (int(v) for v in d["a%d_meta" % k])
+        src = [np.ascontiguousarray(d["a%d_src%d" % (k, p)]) for p in range(4)]
+        ht = S.HostTables(sw, sh, sf, dw, dh, df, flags)
+        assert ht.t.dst_alpha_fill == 2 and ht.t.srcFormat == base[sf] and ht.t.dstFormat == base[df]
+        t = ffi.make_otables(sw, sh, base[sf], dw, dh, base[df], flags, ht.banks(), ht.coeffs(), full=ht.full())
+        for planes, wanted in ((src[:3], (0, 1, 2)), ([src[3], src[1], src[2]], (3,))):
+            out = ffi.alloc_frame(base[df], dw, dh)
+            sp, ss = ffi.planes(planes)
+            dp, ds = ffi.planes(out)
+            assert ffi.oracle().ffo_sws_scale_frame(C.byref(t), sp, ss, dp, ds) == dh
+            for j, p in enumerate(wanted):
+                assert np.array_equal(out[j if p < 3 else 0], d["a%d_dst%d" % (k, p)]), (k, p)
+
+
+def test_round4_vp9_loopfilter_422_440_golden():
+    """the superblock filter with the two sub-sampling shifts apart: oracle == the reference's output, and the product's tables
+    (ffhip_vp9_lf_sb_tables' luma part + ffhip_vp9_lf_sb_ctables) executed in kernel order leave the same samples"""
+    import vp9_lf_gen as VG
+    from ffmpeg_amd import _lib
+    L = _lib.lib()
+    O = ffi.oracle()
+    d = load("round4")
+    lim, mblim = np.ascontiguousarray(d["lf_lim"]), np.ascontiguousarray(d["lf_mblim"])
+    changed = 0
+    for n in range(int(d["lf_n"])):
+        bd, ss_h, ss_v, row, col = (int(v) for v in d["lf%d_par" % n])
+        cw, chh = 64 >> ss_h, 64 >> ss_v
+        pos = ((64, 64), (chh, cw), (chh, cw))
+        level, mask = np.ascontiguousarray(d["lf%d_level" % n]), np.ascontiguousarray(d["lf%d_mask" % n])
+        a = [d["lf%d_in%d" % (n, k)].copy() for k in range(3)]
+        b = [p.copy() for p in a]
+        addr = lambda pl: [p.ctypes.data + r * p.strides[0] + c * p.itemsize for p, (r, c) in zip(pl, pos)]
+        O.ffo_vp9_loopfilter_sb(bd, ss_h, ss_v, ptr(level, u8p), ptr(mask, u8p), row, col, *(C.cast(x, u8p) for x in addr(a)), a[0].strides[0],
+                                a[1].strides[0], ptr(lim, u8p), ptr(mblim, u8p))
+        f = np.zeros((), VG.FILTER_DT)
+        f["level"], f["mask"] = level, mask
+        fb = np.frombuffer(f.tobytes(), np.uint8).copy()
+        tab, ctab = np.zeros(320, np.uint32), np.zeros(128, np.uint32)
+        assert L.ffhip_vp9_lf_sb_tables(tab.ctypes.data, fb.ctypes.data, row, col, ss_h, ss_v, lim.ctypes.data, mblim.ctypes.data) == 0
+        assert L.ffhip_vp9_lf_sb_ctables(ctab.ctypes.data, fb.ctypes.data, row, col, ss_h, ss_v, lim.ctypes.data, mblim.ctypes.data) == 0
+        VG.run_tables(O, tab, bd, addr(b), [b[0].strides[0], b[1].strides[0]])
+        VG.run_ctables(O, ctab, bd, addr(b)[1:], b[1].strides[0], ss_h, ss_v)
+        for k in range(3):
+            assert np.array_equal(a[k], d["lf%d_out%d" % (n, k)]), (n, k)
+            assert np.array_equal(b[k], d["lf%d_out%d" % (n, k)]), (n, k, "tables")
+            changed += int((a[k] != d["lf%d_in%d" % (n, k)]).sum())
+    assert changed > 500

@@ -350,3 +350,55 @@ def test_h264_pred422_golden_gpu():
     for mode in range(11):
         hc.pred8x8[mode](C.c_void_p(p[mode].ctypes.data + (8 * 48 + 16) * 2), 96)
     assert np.array_equal(p, d["p10_out"])
+
+
+def test_round4_alpha_both_sides_golden_gpu():
+    """planar YUVA -> planar YUVA through libffhip == the reference's four planes (tests/golden/round4.npz)"""
+    import torch
+    from ffmpeg_amd import swscale as S
+    d = load("round4")
+    for k in range(int(d["a_n"])):
+        sf, sw, sh, df, dw, dh, flags = (int(v) for v in d["a%d_meta" % k])
+        src = [np.ascontiguousarray(d["a%d_src%d" % (k, p)]) for p in range(4)]
+        want = [d["a%d_dst%d" % (k, p)] for p in range(4)]
+        ctx = S.SwsContext(sw, sh, sf, dw, dh, df, flags)
+        dsrc = [torch.from_numpy(a).cuda()[None].contiguous() for a in src]
+        ddst = [torch.zeros((1,) + a.shape, dtype=torch.uint8, device="cuda") for a in want]
+        ctx.scale_batch(dsrc, ddst)
+        torch.cuda.synchronize()
+        for p in range(4):
+            got = ddst[p][0].cpu().numpy()
+            w = want[p].shape[1]
+            assert np.array_equal(got[:, :w], want[p]), (k, p, int((got[:, :w] != want[p]).sum()))
+        ctx.close()
+
+
+def test_round4_vp9_loopfilter_422_440_golden_gpu():
+    """a picture of one superblock at 4:2:2 / 4:4:0 through ffhip_vp9_loopfilter_frame_ssc_dev == the reference's ff_vp9_loopfilter_sb
+    (the fixture's first-row, first-column cases)"""
+    import torch
+    import vp9_lf_gen as VG
+    from ffmpeg_amd import vp9
+    d = load("round4")
+    lim, mblim = np.ascontiguousarray(d["lf_lim"]), np.ascontiguousarray(d["lf_mblim"])
+    ran = 0
+    for n in range(int(d["lf_n"])):
+        bd, ss_h, ss_v, row, col = (int(v) for v in d["lf%d_par" % n])
+        if row or col:
+            continue
+        cw, chh = 64 >> ss_h, 64 >> ss_v
+        pos = ((64, 64), (chh, cw), (chh, cw))
+        f = np.zeros(1, VG.FILTER_DT)
+        f["level"][0], f["mask"][0] = d["lf%d_level" % n], d["lf%d_mask" % n]
+        tabs, ctabs = vp9.lf_sb_tables_ss(f.view(np.uint8).reshape(1, 192), 1, 1, lim, mblim, (ss_h, ss_v))
+        ins = [np.ascontiguousarray(d["lf%d_in%d" % (n, k)]) for k in range(3)]
+        dev = [torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda() for a in ins]
+        at = [t[r * a.strides[0] + c * a.itemsize:] for t, a, (r, c) in zip(dev, ins, pos)]
+        vp9.loopfilter_frame_ssc(at[0], at[1], at[2], ins[0].strides[0], ins[1].strides[0], 8, 8, torch.from_numpy(tabs.view(np.int32)).cuda(),
+                                 torch.from_numpy(ctabs.view(np.int32)).cuda(), (ss_h, ss_v), bit_depth=bd)
+        torch.cuda.synchronize()
+        for k in range(3):
+            got = dev[k].cpu().numpy().view(ins[k].dtype).reshape(ins[k].shape)
+            assert np.array_equal(got, d["lf%d_out%d" % (n, k)]), (n, k)
+        ran += 1
+    assert ran == 4

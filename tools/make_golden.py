@@ -709,6 +709,53 @@ def round3():
     np.savez_compressed(os.path.join(OUT, "round3.npz"), **d)
 
 
+def round4():
+    """round 4's additions whose oracle side is a restatement: a scaled alpha plane (planar YUVA on both sides) and the VP9 superblock loop
+    filter with the two sub-sampling shifts apart (4:2:2, 4:4:0) — inputs and the REAL reference's outputs"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import vp9_lf_gen as G
+    d = {}
+    rng = np.random.default_rng(4001)
+    cases = [("yuva420p", 64, 36, "yuva420p", 128, 72, 4), ("yuva444p", 48, 32, "yuva420p", 100, 50, 2), ("yuva422p", 66, 38, "yuva420p", 33, 19, 2)]
+    for k, (sn, sw, sh, dn, dw, dh, flags) in enumerate(cases):
+        src = ffi.alloc_frame(ffi.PIX[sn], sw, sh, rng, pad=3)
+        ctx = R.ffref_sws_create(sw, sh, ffi.PIX[sn], dw, dh, ffi.PIX[dn], flags, 1)
+        assert ctx
+        out = ffi.alloc_frame(ffi.PIX[dn], dw, dh)
+        sp, ss = ffi.planes(src)
+        dp, ds = ffi.planes(out)
+        assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, dp, ds) == dh
+        R.ffref_sws_free(ctx)
+        d["a%d_meta" % k] = np.array([ffi.PIX[sn], sw, sh, ffi.PIX[dn], dw, dh, flags], np.int32)
+        for p in range(4):
+            d["a%d_src%d" % (k, p)], d["a%d_dst%d" % (k, p)] = src[p], out[p]
+    d["a_n"] = np.int32(len(cases))
+    lim, mblim = G.filter_lut(3)
+    d["lf_lim"], d["lf_mblim"] = lim, mblim
+    n = 0
+    for bd in (8, 10):
+        for ss_h, ss_v in ((1, 0), (0, 1)):
+            for row, col in ((0, 0), (8, 8)):
+                dt = np.uint8 if bd == 8 else np.uint16
+                cw, chh = 64 >> ss_h, 64 >> ss_v
+                f = G.structured(rng, row // 8, col // 8, 23, 22, ss_h, ss_v)
+                mk = lambda h, w: np.clip(np.cumsum(rng.integers(-2, 3, (h, w + 7)), axis=1) * (1 << (bd - 8)) + (1 << (bd - 1)), 0, (1 << bd) - 1).astype(dt)
+                pl = [mk(192, 192), mk(3 * chh, 3 * cw), mk(3 * chh, 3 * cw)]
+                d["lf%d_par" % n] = np.array([bd, ss_h, ss_v, row, col], np.int32)
+                d["lf%d_level" % n], d["lf%d_mask" % n] = np.ascontiguousarray(f["level"]), np.ascontiguousarray(f["mask"])
+                for k in range(3):
+                    d["lf%d_in%d" % (n, k)] = pl[k].copy()
+                pos = ((64, 64), (chh, cw), (chh, cw))
+                R.ffref_vp9_loopfilter_sb(bd, ss_h, ss_v, ptr(d["lf%d_level" % n], u8p), ptr(d["lf%d_mask" % n], u8p), row, col,
+                                          *(C.cast(p.ctypes.data + r * p.strides[0] + c * p.itemsize, u8p) for p, (r, c) in zip(pl, pos)),
+                                          pl[0].strides[0], pl[1].strides[0], ptr(lim, u8p), ptr(mblim, u8p))
+                for k in range(3):
+                    d["lf%d_out%d" % (n, k)] = pl[k]
+                n += 1
+    d["lf_n"] = np.int32(n)
+    np.savez_compressed(os.path.join(OUT, "round4.npz"), **d)
+
+
 def h264pred422():
     """pred8x8[] at chroma_format_idc 2 (the 8 wide x 16 tall forms): at 8 bits a grid of independent blocks of one 136x200
     picture, every mode three times or more (batch kind 7); at 10 bits one 40x48 patch per mode with the block at (8, 16)"""
@@ -747,6 +794,6 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422(); round4()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
