@@ -356,7 +356,7 @@ def test_round4_alpha_both_sides_golden_gpu():
     """planar YUVA -> planar YUVA through libffhip == the reference's four planes (tests/golden/round4.npz)"""
     import torch
     from ffmpeg_amd import swscale as S
-    d = load("round4")
+    d = G.load("round4")
     for k in range(int(d["a_n"])):
         sf, sw, sh, df, dw, dh, flags = (int(v) for v in d["a%d_meta" % k])
         src = [np.ascontiguousarray(d["a%d_src%d" % (k, p)]) for p in range(4)]
@@ -379,7 +379,7 @@ def test_round4_vp9_loopfilter_422_440_golden_gpu():
     import torch
     import vp9_lf_gen as VG
     from ffmpeg_amd import vp9
-    d = load("round4")
+    d = G.load("round4")
     lim, mblim = np.ascontiguousarray(d["lf_lim"]), np.ascontiguousarray(d["lf_mblim"])
     ran = 0
     for n in range(int(d["lf_n"])):
