@@ -379,6 +379,14 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         ffhip_set_error("ffhip_sws: equal-size yuv420p to an odd-width packed RGB target is the table converter's tail case; not on the hip path");
         return nullptr;
     }
+    /* alpha: 1 = dst[3] filled with 255, 2 = src[3] scaled into dst[3] by the luma banks (a second pass of the context): a planar 8-bit
+     * target, and no range conversion (the reference converts plane 0 only, hscale.c:57-59; the second pass would convert its luma) */
+    if (t->dst_alpha_fill < 0 || t->dst_alpha_fill > 2 ||
+        (t->dst_alpha_fill == 2 && (fmt_rgb(t->dstFormat) || fmt_nv(t->dstFormat) || ffhip_pixfmt_hbd(t->srcFormat, nullptr, nullptr, nullptr, nullptr) ||
+                                    ffhip_pixfmt_hbd(t->dstFormat, nullptr, nullptr, nullptr, nullptr) || t->src_range != t->dst_range))) {
+        ffhip_set_error("ffhip_sws: a scaled alpha plane (dst_alpha_fill 2) goes with a planar 8-bit target and equal ranges");
+        return nullptr;
+    }
     /* (a packed RGB target takes the source's range through the yuv2rgb coefficients the caller hands over: ff_yuv2rgb_c_init_tables'
      * fullRange branch, libswscale/yuv2rgb.c:760-768; the range fields then play no part) */
     if (!ffhip_have_device()) {
