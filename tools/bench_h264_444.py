@@ -1,6 +1,6 @@
 """Times the H.264 picture layer on 4:4:4 pictures (hl_decode_mb_444 recorded by the reference's own macroblock loop, see
 tests/test_gpu_h264_decoder.py): a 1080p I-picture (three luma-only wavefronts side by side) and a P/B picture, 8 and 10 bits, beside the
-4:2:0 picture of the same size.  Usage: python tools/bench_h264_444.py [reps]"""
+4:2:0 picture of the same size.  Usage: python tools/bench_h264_444.py [reps [depth [4k]]]"""
 import ctypes as C
 import os
 import sys
@@ -60,8 +60,8 @@ def run(depth, cfmt, p_intra, reps, mb_w=120, mb_h=68, nref=2):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print("%2d bits %s %s 1080p: flush %.3f ms = %.0f pictures/s (recording with the test generator: %.1f s)" % (
-        depth, {1: "4:2:0", 2: "4:2:2", 3: "4:4:4"}[cfmt], "I-picture" if p_intra >= 1 else "P/B-picture (%.0f %% intra)" % (100 * p_intra), ms, 1e3 / ms,
+    print("%2d bits %s %s %dx%d: flush %.3f ms = %.0f pictures/s (recording with the test generator: %.1f s)" % (
+        depth, {1: "4:2:0", 2: "4:2:2", 3: "4:4:4"}[cfmt], "I-picture" if p_intra >= 1 else "P/B-picture (%.0f %% intra)" % (100 * p_intra), 16 * mb_w, 16 * mb_h, ms, 1e3 / ms,
         rec_s), flush=True)
     pic.close()
     gpu.close()
@@ -74,4 +74,7 @@ if __name__ == "__main__":
     for depth in ((8, 10) if len(sys.argv) < 3 else (int(sys.argv[2]),)):
         for cfmt in (1, 2, 3):
             for p_intra in (1.0, .05):
-                run(depth, cfmt, p_intra, reps)
+                if len(sys.argv) > 3 and sys.argv[3] == "4k":
+                    run(depth, cfmt, p_intra, reps, mb_w=240, mb_h=135)
+                else:
+                    run(depth, cfmt, p_intra, reps)
