@@ -72,7 +72,7 @@ if __name__ == "__main__":
     if not (ffi.have_ref() and I.have_ref_hip()):
         sys.exit("oracle/_ref not built")
     for depth in ((8, 10) if len(sys.argv) < 3 else (int(sys.argv[2]),)):
-        for cfmt in (1, 2, 3):
+        for cfmt in ((1, 2, 3) if len(sys.argv) < 5 else (int(sys.argv[4]),)):
             for p_intra in (1.0, .05):
                 if len(sys.argv) > 3 and sys.argv[3] == "4k":
                     run(depth, cfmt, p_intra, reps, mb_w=240, mb_h=135)
