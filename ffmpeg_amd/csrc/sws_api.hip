@@ -68,8 +68,9 @@ struct FFHipSwsContext {
     /* staging for the host-pointer face */
     void *stage = nullptr;
     size_t stage_sz = 0;
-    void *alpha_scratch = nullptr; /* chroma planes of the alpha pass (dst_alpha_fill == 2): written, never read */
+    void *alpha_scratch = nullptr; /* chroma planes of the alpha pass (dst_alpha_fill == 2) where a planner cannot leave them out */
     size_t alpha_scratch_sz = 0;
+    bool luma_pass = false;        /* the alpha pass is running: the planners enumerate the luma job only */
     int slice_next = 0;   /* scaled contexts fed in slices: the next source line expected */
     std::mutex mu;
 };
@@ -1038,7 +1039,10 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         void *d2[4] = { dst[3], sc, sc + fp * (size_t)(nframes > 0 ? nframes : 1), nullptr };
         const int ds2[4] = { dstStride[3], (int)pitch, (int)pitch, 0 };
         const size_t df2[4] = { dstFramePitch[3], fp, fp, 0 };
-        return scale_batch_dev(c, nframes, s2, ss2, sf2, d2, ds2, df2, stream_);
+        c->luma_pass = true; /* (a context serves one call at a time: the planners leave the chroma jobs out) */
+        const int r2 = scale_batch_dev(c, nframes, s2, ss2, sf2, d2, ds2, df2, stream_);
+        c->luma_pass = false;
+        return r2;
     }
     /* a target with an alpha plane the source does not drive: opaque (ff_swscale's fillPlane, libswscale/swscale.c:536-553) */
     for (int f = 0; f < nframes; f++)
@@ -1162,7 +1166,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 j.rc_coeff = p.rc_coeff; j.rc_offset = p.rc_offset;
             };
             upjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
-            if (ch.src_step == 2) {
+            if (c->luma_pass) {
+            } else if (ch.src_step == 2) {
                 const bool ssw = ch.src[1] < ch.src[0], dsw = ch.dst[1] < ch.dst[0];
                 upjob(ch, 1, ssw ? ch.src[1] : ch.src[0], ch.src_stride[0], ch.src_fp[0], dsw ? ch.dst[1] : ch.dst[0],
                       ch.dst_stride[0], ch.dst_fp[0], 1, ssw != dsw);
@@ -1241,7 +1246,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                     j.nstrips = cdiv(p.dstH, j.strip_rows);
                 };
                 mfjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
-                if (c->mf_chr_pair) {
+                if (c->luma_pass) {
+                } else if (c->mf_chr_pair) {
                     const uint8_t *sp = ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1];
                     uint8_t *dp = ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1];
                     mfjob(ch, 1, sp, ch.src_stride[0], ch.src_fp[0], dp, ch.dst_stride[0], ch.dst_fp[0], 1, ch.dst[1] < ch.dst[0]);
@@ -1282,7 +1288,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             jl.dst[0] = l.dst[0]; jl.dstride[0] = l.dst_stride[0]; jl.dfp[0] = l.dst_fp[0];
             gpl[0] = lg;
             A.njobs = 1;
-            if (ch.src_step == 1 && ch.dst_step == 1) {
+            if (c->luma_pass) {
+            } else if (ch.src_step == 1 && ch.dst_step == 1) {
                 for (int k = 0; k < 2; k++) {
                     FFHipCwJob &j = A.job[A.njobs++];
                     bank(j, ch);
@@ -1351,7 +1358,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             ffhip_down2_plan_job(&j, es && atoi(es) > 0 ? atoi(es) : 32); /* measured: 28..36 rows per strip */
         };
         dnjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
-        if (ch.src_step == 2) {
+        if (c->luma_pass) {
+        } else if (ch.src_step == 2) {
             const bool ssw = ch.src[1] < ch.src[0], dsw = ch.dst[1] < ch.dst[0];
             dnjob(ch, 1, ssw ? ch.src[1] : ch.src[0], ch.src_stride[0], ch.src_fp[0], dsw ? ch.dst[1] : ch.dst[0],
                   ch.dst_stride[0], ch.dst_fp[0], 1, ssw != dsw);
@@ -1382,7 +1390,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 ffhip_lw_plan_job(&j);
             };
             /* the heavier units (a U/V pair is twice a plane) are enumerated first: they start first */
-            if (ch.src_step == 1 && ch.dst_step == 1) {
+            if (c->luma_pass) {
+            } else if (ch.src_step == 1 && ch.dst_step == 1) {
                 for (int k = 0; k < 2; k++) {
                     FFHipLwJob &j = W.job[W.njobs++];
                     j.src[0] = ch.src[k]; j.sstride[0] = ch.src_stride[k]; j.sfp[0] = ch.src_fp[k];
@@ -1413,6 +1422,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             return ffhip_launch_lwalk(W, stream);
         }
     }
+    if (c->luma_pass)
+        ch.tiles_y = 0; /* the tiled kernel's grid is the luma tiles followed by the chroma tiles: none of the latter */
     return ffhip_launch_scale_yuv(l, ch, stream);
 }
 
@@ -1463,7 +1474,9 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
     const int ss2[4] = { srcStride[3], srcStride[1], srcStride[2], 0 };
     uint8_t *const d2[4] = { dst[3], scratch.data(), scratch.data() + (size_t)dp[1].wbytes * (size_t)dp[1].rows, nullptr };
     const int ds2[4] = { dstStride[3], dp[1].wbytes, dp[1].wbytes, 0 };
+    c->luma_pass = true;
     const int r2 = sws_scale_locked(c, s2, ss2, 0, srcSliceH, d2, ds2);
+    c->luma_pass = false;
     return r2 < 0 ? r2 : r;
 }
 
