@@ -225,8 +225,8 @@ typedef struct FFHipSwsTables {
     int      yuv2rgb_full[6];
     /* 1: the target has an alpha plane the source does not drive: dst[3] is filled with 255 (fillPlane, swscale.c:536-553).
      * 2: both sides are planar YUVA: the alpha plane is scaled by the LUMA banks (lum_h_scale / lum_planar_vscale on plane 3,
-     *    hscale.c:63-79, vscale.c:57-70) — src[3] -> dst[3] as the luma of a second pass of the context (its chroma lands in a scratch
-     *    buffer of the context); not together with a range conversion (the reference converts plane 0 only).
+     *    hscale.c:63-79, vscale.c:57-70) — src[3] -> dst[3] as the luma of a second pass of the context in which the planners enumerate
+     *    the luma job only; not together with a range conversion (the reference converts plane 0 only).
      * srcFormat / dstFormat above are then the formats without the alpha plane */
     int      dst_alpha_fill;
 } FFHipSwsTables;
