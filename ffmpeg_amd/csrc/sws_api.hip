@@ -68,8 +68,6 @@ struct FFHipSwsContext {
     /* staging for the host-pointer face */
     void *stage = nullptr;
     size_t stage_sz = 0;
-    void *alpha_scratch = nullptr; /* chroma planes of the alpha pass (dst_alpha_fill == 2) where a planner cannot leave them out */
-    size_t alpha_scratch_sz = 0;
     bool luma_pass = false;        /* the alpha pass is running: the planners enumerate the luma job only */
     int slice_next = 0;   /* scaled contexts fed in slices: the next source line expected */
     std::mutex mu;
@@ -782,8 +780,6 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->dev_wtables);
     if (c->stage)
         (void)hipFree(c->stage);
-    if (c->alpha_scratch)
-        (void)hipFree(c->alpha_scratch);
     delete c;
 }
 
@@ -1013,32 +1009,18 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
     FFHipDeviceGuard dg(c->device);
     if (c->t.dst_alpha_fill == 2) {
         /* alpha on both sides: the alpha plane is the luma of a second pass (lum_h_scale / lum_planar_vscale run the luma banks on plane
-         * 3, hscale.c:63-79, vscale.c:57-70); that pass's chroma planes land in a scratch buffer nobody reads */
-        PlaneDesc dp[3];
-        if (plane_list(c->t.dstFormat, c->t.dstW, c->t.dstH, dp) != 3) {
+         * 3, hscale.c:63-79, vscale.c:57-70) in which the planners enumerate the luma job only; the chroma slots keep the picture's own
+         * planes (were a planner to scale them again it would write the bytes they already hold) */
+        if (fmt_rgb(c->t.dstFormat) || fmt_nv(c->t.dstFormat)) {
             ffhip_set_error("ffhip_sws_scale_batch_dev: a scaled alpha plane belongs to a planar target");
             return FFHIP_EINVAL;
         }
-        const size_t pitch = ((size_t)dp[1].wbytes + 255) & ~(size_t)255, fp = pitch * (size_t)dp[1].rows, need = 2 * fp * (size_t)(nframes > 0 ? nframes : 1);
-        if (need > c->alpha_scratch_sz) {
-            HIP_TRY(hipStreamSynchronize((hipStream_t)stream_)); /* an earlier call's alpha pass may still be writing the old buffer */
-            if (c->alpha_scratch)
-                (void)hipFree(c->alpha_scratch);
-            c->alpha_scratch = nullptr;
-            c->alpha_scratch_sz = 0;
-            if (hipMalloc(&c->alpha_scratch, need) != hipSuccess) {
-                ffhip_set_error("ffhip_sws_scale_batch_dev: hipMalloc(%zu) for the alpha pass failed", need);
-                return FFHIP_ENOMEM;
-            }
-            c->alpha_scratch_sz = need;
-        }
-        uint8_t *const sc = (uint8_t *)c->alpha_scratch;
         const void *s2[4] = { src[3], src[1], src[2], nullptr };
         const int ss2[4] = { srcStride[3], srcStride[1], srcStride[2], 0 };
         const size_t sf2[4] = { srcFramePitch[3], srcFramePitch[1], srcFramePitch[2], 0 };
-        void *d2[4] = { dst[3], sc, sc + fp * (size_t)(nframes > 0 ? nframes : 1), nullptr };
-        const int ds2[4] = { dstStride[3], (int)pitch, (int)pitch, 0 };
-        const size_t df2[4] = { dstFramePitch[3], fp, fp, 0 };
+        void *d2[4] = { dst[3], dst[1], dst[2], nullptr };
+        const int ds2[4] = { dstStride[3], dstStride[1], dstStride[2], 0 };
+        const size_t df2[4] = { dstFramePitch[3], dstFramePitch[1], dstFramePitch[2], 0 };
         c->luma_pass = true; /* (a context serves one call at a time: the planners leave the chroma jobs out) */
         const int r2 = scale_batch_dev(c, nframes, s2, ss2, sf2, d2, ds2, df2, stream_);
         c->luma_pass = false;
