@@ -150,11 +150,15 @@ extern "C" int ffhip_h264_picture_create_fmt(FFHipH264Picture **pp, int mb_w, in
     if (!pp || mb_w <= 0 || mb_h <= 0)
         return FFHIP_EINVAL;
     *pp = nullptr;
-    if (chroma_format_idc < 1 || chroma_format_idc > 3) {
-        /* monochrome stays on the C path */
-        ffhip_set_error("ffhip_h264_picture_create_fmt: chroma_format_idc %d (1 = 4:2:0, 2 = 4:2:2 and 3 = 4:4:4 are built)", chroma_format_idc);
-        return chroma_format_idc == 0 ? FFHIP_ENOSYS : FFHIP_EINVAL;
+    if (chroma_format_idc < 0 || chroma_format_idc > 3) {
+        ffhip_set_error("ffhip_h264_picture_create_fmt: chroma_format_idc %d (0 .. 3)", chroma_format_idc);
+        return FFHIP_EINVAL;
     }
+    /* monochrome: the decoder reconstructs it as a 4:2:0 picture whose chroma planes come out mid-grey through the ordinary members
+     * (DC_128 chroma prediction, chroma MC from mid-grey references, no chroma residual, no chroma edges: h264_mb_template.c:112-148,
+     * h264_cavlc.c decode_chroma, h264_loopfilter.c:726) — the same object */
+    if (chroma_format_idc == 0)
+        chroma_format_idc = 1;
     if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14) {
         ffhip_set_error("ffhip_h264_picture_create_hbd: bit depth %d (8, 9, 10, 12 and 14 are the depths H.264 defines)", bit_depth);
         return FFHIP_EINVAL;

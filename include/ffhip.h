@@ -679,7 +679,9 @@ int  ffhip_h264_picture_create_hbd(FFHipH264Picture **p, int mb_w, int mb_h, int
  *    deblocking: filter_mb_edgev / filter_mb_edgeh on img_cb / img_cr (h264_loopfilter.c:601-703): ffhip_h264_picture_deblock_mb() takes 8
  *                luma-kind edge records for every plane.
  *  The three planes share one stride when the picture carries intra macroblocks (the decoder's linesize == uvlinesize there).
- *  chroma_format_idc 0 (monochrome): FFHIP_ENOSYS — such a stream's pictures stay on the decoder's C path. */
+ *  chroma_format_idc 0 (monochrome) makes the 4:2:0 object: the decoder reconstructs such a picture as 4:2:0 with mid-grey chroma through the
+ *  ordinary members (h264_mb_template.c:112-148); an I_PCM macroblock's record carries mid-grey chroma fields (the FFmpeg-side recorder
+ *  appends them). */
 int  ffhip_h264_picture_create_fmt(FFHipH264Picture **p, int mb_w, int mb_h, int bit_depth, int chroma_format_idc);
 void ffhip_h264_picture_free(FFHipH264Picture **p);
 void ffhip_h264_picture_begin(FFHipH264Picture *p);

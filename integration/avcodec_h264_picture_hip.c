@@ -383,7 +383,7 @@ void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, con
     memset(r, 0, sizeof(*r));
     r->pic = pic;
     r->pixel_shift = h->pixel_shift;
-    r->cfmt = h->ps.sps->chroma_format_idc;
+    r->cfmt = h->ps.sps->chroma_format_idc ? h->ps.sps->chroma_format_idc : 1; /* monochrome is decoded as 4:2:0 with mid-grey chroma */
     r->field = FIELD_PICTURE(h) && !FRAME_MBAFF(h);
     for (int pl = 0; pl < 3; pl++) {
         const ptrdiff_t ls = pl ? sl->uvlinesize : sl->linesize;
@@ -407,8 +407,7 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
     const int mb_type = h->cur_pic.mb_type[sl->mb_xy];
     if (r->error < 0)
         return r->error;
-    if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field || !h->ps.sps->chroma_format_idc ||
-        (sl->qscale == 0 && h->ps.sps->transform_bypass))
+    if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field || (sl->qscale == 0 && h->ps.sps->transform_bypass))
         return r->error = FFHIP_ENOSYS;   /* such a picture stays on the C path as a whole */
     if (IS_INTRA(mb_type)) {
         FFHipH264IntraMB m = { 0 };
@@ -432,6 +431,29 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
         m.qmul[1] = h->ps.pps->dequant4_coeff[1][sl->chroma_qp[0] + (CHROMA422(h) ? 3 : 0)][0];
         m.qmul[2] = h->ps.pps->dequant4_coeff[2][sl->chroma_qp[1] + (CHROMA422(h) ? 3 : 0)][0];
         h->list_counts[sl->mb_xy] = sl->list_count;   /* hl_decode_mb()'s one side effect outside the pixels (h264_mb_template.c:61) */
+        if (IS_INTRA_PCM(mb_type) && !h->ps.sps->chroma_format_idc) {
+            /* monochrome I_PCM: 256 luma fields in the bitstream, the chroma planes are set to mid-grey (h264_mb_template.c:112-119,
+             * 137-142): the record's 384 fields = the luma fields + 128 fields of 1 << (bit_depth - 1), MSB-first as the bitstream has them */
+            uint8_t pcm[384 * 2];
+            const int bd = h->ps.sps->bit_depth_luma, lbytes = 32 * bd;
+            memcpy(pcm, sl->intra_pcm_ptr, lbytes);
+            if (bd == 8) {
+                memset(pcm + 256, 128, 128);
+            } else {
+                uint32_t acc = 0;
+                int have = 0, at = lbytes;
+                for (int k = 0; k < 128; k++) {
+                    acc = (acc << bd) | (1u << (bd - 1));
+                    have += bd;
+                    while (have >= 8) {
+                        have -= 8;
+                        pcm[at++] = (uint8_t)(acc >> have);
+                    }
+                }
+            }
+            r->error = FFMIN(0, ffhip_h264_picture_intra_mb(r->pic, &m, sl->non_zero_count_cache, sl->mb, sl->mb_luma_dc[0], pcm));
+            return r->error;
+        }
         r->error = FFMIN(0, ffhip_h264_picture_intra_mb(r->pic, &m, sl->non_zero_count_cache, sl->mb, sl->mb_luma_dc[0], sl->intra_pcm_ptr));
         return r->error;
     }

@@ -221,7 +221,7 @@ FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesi
     if (record)
         return NULL;
 #endif
-    if (!d || chroma_format_idc < 1 || chroma_format_idc > 3 || (chroma_format_idc == 3 && uvlinesize != linesize)) {
+    if (!d || chroma_format_idc < 0 || chroma_format_idc > 3 || (chroma_format_idc == 3 && uvlinesize != linesize)) {
         av_free(d);
         return NULL;
     }
@@ -241,7 +241,7 @@ FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesi
     d->mb_h = mb_h;
     d->sps->chroma_format_idc = chroma_format_idc;
     d->sps->bit_depth_luma = d->sps->bit_depth_chroma = bit_depth;
-    d->sps->profile_idc = chroma_format_idc == 3 ? 244 : chroma_format_idc == 2 ? 122 : 100;
+    d->sps->profile_idc = chroma_format_idc == 3 ? 244 : chroma_format_idc == 2 ? 122 : 100;   /* (High covers monochrome) */
     d->sps->mb_width = mb_w;
     d->sps->mb_height = mb_h;
     for (int k = 0; k < 6; k++)
@@ -254,7 +254,7 @@ FFRefH264Dec *FN(h264dec_open_fmt)(int bit_depth, int mb_w, int mb_h, int linesi
     h->avctx = d->avctx;               /* active_thread_type = 0: hl_motion() does not wait for reference rows */
     h->pixel_shift = ps;
     h->chroma_x_shift = chroma_format_idc != 3;
-    h->chroma_y_shift = chroma_format_idc == 1;
+    h->chroma_y_shift = chroma_format_idc <= 1;   /* (monochrome is decoded into 4:2:0 frames) */
     h->mb_width = mb_w;
     h->mb_height = mb_h;
     h->mb_stride = mb_w + 1;
@@ -504,7 +504,7 @@ int FN(h264dec_filter_mb)(FFRefH264Dec *d, int mb_x, int mb_y, const int *ints, 
 #endif
     {
         /* loop_filter() (h264_slice.c:2470-2491): a field macroblock on an odd row starts one line below the row pair's first */
-        const int cs = d->cfmt == 3 ? 16 : 8, ch = d->cfmt == 1 ? 8 : 16; /* block_h = 16 >> chroma_y_shift */
+        const int cs = d->cfmt == 3 ? 16 : 8, ch = d->cfmt <= 1 ? 8 : 16; /* block_h = 16 >> chroma_y_shift */
         uint8_t *dy = d->f->data[0] + (((ptrdiff_t)mb_x << ps) + (ptrdiff_t)mb_y * sl->linesize) * 16;
         uint8_t *dcb = d->f->data[1] + ((ptrdiff_t)mb_x << ps) * cs + (ptrdiff_t)mb_y * sl->uvlinesize * ch;
         uint8_t *dcr = d->f->data[2] + ((ptrdiff_t)mb_x << ps) * cs + (ptrdiff_t)mb_y * sl->uvlinesize * ch;

@@ -205,7 +205,7 @@ def make_inter_mb(rng, B, mb_x, mb_y, nref, mvr, depth=8, bipred=True, residual=
                     for i in range(16):
                         if m["cbp"] & (1 << (i >> 2)):
                             nnzc[c + SCAN8[i]] = G._block(rng, mb, o + 16 * i, 16, depth=depth)
-        cc = 0 if cfmt == 3 else int(rng.integers(0, 3))
+        cc = 0 if cfmt in (0, 3) else int(rng.integers(0, 3))   # monochrome: no chroma residual
         m["cbp"] |= cc << 4
         sh = depth - 8
         nck = 8 if cfmt == 2 else 4           # 4:2:2: eight blocks per chroma plane

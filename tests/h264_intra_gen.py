@@ -74,7 +74,7 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8, cfmt=1):
              pred4=np.zeros(16, np.uint8), qmul=rng.integers(16, 6000, 3).astype(np.int32), nnzc=np.zeros(15 * 8, np.uint8),
              mb=np.zeros(768, cdt), luma_dc=np.zeros(48 if cfmt == 3 else 16, cdt), pcm=None, depth=depth)
     if mtype == PCM:
-        d["pcm"] = rng.integers(0, 256, (96 if cfmt == 3 else 64 if cfmt == 2 else 48) * depth, dtype=np.uint8)   # 768 / 512 / 384 fields
+        d["pcm"] = rng.integers(0, 256, (96 if cfmt == 3 else 64 if cfmt == 2 else 32 if cfmt == 0 else 48) * depth, dtype=np.uint8)   # 768 / 512 / 256 / 384 fields
         return d
 
     def blk_mode(i_top, i_left):           # a 16x16 / chroma mode after ff_h264_check_intra_pred_mode
@@ -87,6 +87,8 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8, cfmt=1):
     d["chroma_pred"] = blk_mode(top, left)
     if top and left and rng.random() < .15:
         d["chroma_pred"] = int(rng.integers(7, 11))   # the one-sided DC variants (MBAFF + constrained intra): any macroblock with neighbours
+    if cfmt == 0:
+        d["chroma_pred"] = 6                          # monochrome: decode_chroma is off, chroma_pred_mode = DC_128_PRED8x8 (h264_cavlc.c)
     step = 4 if mtype == I8 else 1
     for i in range(0, 16, step):
         x, y = bxy(i)
@@ -128,6 +130,8 @@ def make_intra_mb(rng, mx, my, mb_w, mb_h, mtype=None, depth=8, cfmt=1):
         d["cbp"] = int(rng.integers(0, 16))
         return d
     cc = int(rng.integers(0, 3))                         # coded_block_pattern's chroma part: 0 none, 1 DC, 2 DC + AC
+    if cfmt == 0:
+        cc = 0                                            # monochrome: no chroma residual
     d["cbp"] = (cc << 4) | int(rng.integers(0, 16))
     nck = 8 if cfmt == 2 else 4                          # 4:2:2: eight 4x4 blocks per chroma plane (8 x 16), the cache rows running on
     if cc:

@@ -53,6 +53,8 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=
     # the decoded-picture buffer: nref reference pictures per plane in one allocation, exactly H (H / 2) rows each
     refs = [rng.integers(0, top, (nref * H, sy), dtype=dt), rng.integers(0, top, (nref * HC, sc), dtype=dt),
             rng.integers(0, top, (nref * HC, sc), dtype=dt)]
+    if cfmt == 0:                                           # monochrome: the decoder's frames hold mid-grey chroma
+        refs[1][:], refs[2][:] = top >> 1, top >> 1
     dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(a.shape[0], -1).copy()).cuda()
     d_refs = [dev(r) for r in refs]
     cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls, uvls, 0, cfmt=cfmt)
@@ -235,7 +237,8 @@ def test_picture_formats_refused_by_name():
     _torch()
     L = _lib.lib()
     p = _lib.vp()
-    assert L.ffhip_h264_picture_create_fmt(C.byref(p), 4, 4, 8, 0) == _lib.ENOSYS and not p      # monochrome stays on the C path
+    assert L.ffhip_h264_picture_create_fmt(C.byref(p), 4, 4, 8, 0) == 0 and p                    # monochrome: the 4:2:0 object
+    L.ffhip_h264_picture_free(C.byref(p))
     p = _lib.vp()
     assert L.ffhip_h264_picture_create_fmt(C.byref(p), 4, 4, 8, 5) == _lib.EINVAL and not p
     pic = h264.Picture(4, 4, chroma_format=3)
@@ -411,3 +414,9 @@ def test_decoder_driven_deblocking_flushed_together(depth, mb_w, mb_h, cfmt, npi
         pic.close()
     cpu.close()
     gpu.close()
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,nref,mvr,p_intra,weights", [(8, 11, 7, 3, 600, .2, 2), (8, 9, 5, 1, 64, 1.0, 0), (8, 40, 22, 2, 120, .15, 1), (10, 7, 5, 2, 300, .3, 1)])
+def test_decoder_driven_picture_monochrome(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
+    """chroma_format_idc 0 through the 4:2:0 object: mid-grey chroma planes by the ordinary members, I_PCM with the recorder's mid-grey fields"""
+    _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed=4000000 + depth * 1000 + mb_w * 31 + mvr + weights, cfmt=0)

@@ -76,6 +76,8 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed):
     strides = [ls_, uvls, uvls]
     rows = [H, HC, HC]
     refs = [rng.integers(0, top, (nref * rows[pl], strides[pl] // px), dtype=dt) for pl in range(3)]
+    if cfmt == 0:                                            # monochrome: the decoder's frames hold mid-grey chroma
+        refs[1][:], refs[2][:] = top >> 1, top >> 1
     cpu = I.Dec(R, "ffref_", depth, mb_w, mb_h, ls_, uvls, 0, cfmt=cfmt)
     rec = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, ls_, uvls, 1, cfmt=cfmt)
     for lst in (0, 1):
@@ -105,7 +107,7 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed):
     for pl in range(3):
         assert np.array_equal(got[pl], dst0[pl])             # recording touched no sample
     ls = pic.lists()
-    assert (ls.mb_w, ls.mb_h, ls.bit_depth, ls.chroma_format_idc) == (mb_w, mb_h, depth, cfmt)
+    assert (ls.mb_w, ls.mb_h, ls.bit_depth, ls.chroma_format_idc) == (mb_w, mb_h, depth, cfmt or 1)       # monochrome: the 4:2:0 object
     if cfmt == 3:
         assert not any(ls.ncmc[c][s] for c in range(2) for s in range(3))
         assert p_intra >= 1 or all(ls.nqpel[pl][0] for pl in range(3))
@@ -306,3 +308,11 @@ def test_recorded_deblocking_422_executed_on_cpu_equals_reference(depth, mb_w, m
 @pytest.mark.parametrize("depth,mb_w,fmb_h,nref,mvr,p_intra,weights", [(8, 9, 4, 2, 300, .2, 2), (10, 6, 3, 2, 500, .3, 1)])
 def test_recorded_field_pictures_422(depth, mb_w, fmb_h, nref, mvr, p_intra, weights):
     _run_field_frame(depth, mb_w, fmb_h, nref, mvr, p_intra, weights, 2, seed=7772000 + depth * 1000 + mb_w * 31 + mvr + weights)
+
+
+@pytest.mark.parametrize("depth,mb_w,mb_h,nref,mvr,p_intra,weights", [(8, 6, 4, 2, 40, 0.0, 0), (8, 11, 7, 3, 600, .2, 2), (8, 9, 5, 1, 64, 1.0, 0), (10, 7, 5, 2, 300, .3, 1)])
+def test_recorded_monochrome_picture_executed_on_cpu_equals_reference(depth, mb_w, mb_h, nref, mvr, p_intra, weights):
+    """chroma_format_idc 0: the reference reconstructs a monochrome picture as 4:2:0 with mid-grey chroma through the ordinary members
+    (DC_128 chroma prediction, chroma MC from mid-grey references, no chroma residual; I_PCM sets the chroma samples to 1 << (bit_depth - 1):
+    h264_mb_template.c:112-148) — the same picture object, the recorder appending the mid-grey I_PCM fields"""
+    _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, 0, seed=4000000 + depth * 1000 + mb_w * 31 + mvr + weights)
