@@ -316,3 +316,41 @@ def test_recorded_monochrome_picture_executed_on_cpu_equals_reference(depth, mb_
     (DC_128 chroma prediction, chroma MC from mid-grey references, no chroma residual; I_PCM sets the chroma samples to 1 << (bit_depth - 1):
     h264_mb_template.c:112-148) — the same picture object, the recorder appending the mid-grey I_PCM fields"""
     _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, 0, seed=4000000 + depth * 1000 + mb_w * 31 + mvr + weights)
+
+
+def test_recorder_refuses_what_stays_on_the_c_path_and_stays_refused():
+    """ff_h264_hip_hl_decode_mb() / ff_h264_hip_filter_mb(): a field macroblock in a picture whose recording began as a frame (what an
+    MBAFF pair brings: MB_FIELD(sl) != the recorder's field flag) answers FFHIP_ENOSYS, and the error sticks — the picture stays on the C path as a
+    whole, later macroblocks are not recorded into a half-described picture"""
+    _lib, L, R, RH, E = _env()
+    rng = np.random.default_rng(77)
+    mb_w, mb_h, depth = 4, 3, 8
+    W, H = mb_w * 16, mb_h * 16
+    strides, rows = [W, W // 2 + 16, W // 2 + 16], [H, H // 2, H // 2]
+    refs = [rng.integers(0, 256, (rows[pl], strides[pl]), dtype=np.uint8) for pl in range(3)]
+    got = [np.zeros((rows[pl], strides[pl]), np.uint8) for pl in range(3)]
+    rec = I.Dec(RH, "ffrefhip_", depth, mb_w, mb_h, strides[0], strides[1], 1)
+    for lst in (0, 1):
+        rec.set_ref(lst, 0, [r.ctypes.data for r in refs])
+    rec.set_pwt(I.make_pwt(rng, 0, depth, 1))
+    rec.set_cur([a.ctypes.data for a in got])
+    pic = HostPicture(_lib, L, mb_w, mb_h, depth, 1)
+    RH.ffrefhip_h264dec_record_begin(rec.d, pic.p, *[r.ctypes.data for r in refs])
+    call = rec.fn("h264dec_decode_inter")
+    def run(m):
+        mb = m["mb"].copy()
+        return call(rec.d, m["mb_x"], m["mb_y"], m["mb_type"], m["sub_mb_type"].ctypes.data, m["mv_cache"].ctypes.data, m["ref_cache"].ctypes.data,
+                    m["cbp"], m["nnzc"].ctypes.data, mb.ctypes.data, m["qmul_cb"], m["qmul_cr"])
+    assert run(I.make_inter_mb(rng, rec.bits, 0, 0, 1, 40)) == 0
+    before = pic.lists()
+    n0 = sum(before.nqpel[0][s] for s in range(3))
+    assert n0 > 0
+    rec.set_field(1)                                              # field macroblocks from here on (sl->mb_field_decoding_flag), as in an MBAFF pair
+    assert run(I.make_inter_mb(rng, rec.bits, 1, 0, 1, 40, extra_type=rec.bits[14])) == _lib.ENOSYS
+    rec.set_field(3)
+    assert run(I.make_inter_mb(rng, rec.bits, 2, 0, 1, 40)) == _lib.ENOSYS                                 # ... and nothing after it
+    assert sum(pic.lists().nqpel[0][s] for s in range(3)) == n0
+    for a in got:
+        assert not a.any()
+    pic.close()
+    rec.close()
