@@ -100,6 +100,8 @@ def lib():
         "ffhip_memcpy2d_d2h_async": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]),
         "ffhip_sws_getContext": (vp, [C.c_int] * 7),
         "ffhip_sws_from_tables": (vp, [C.POINTER(SwsTables)]),
+        "ffhip_sws_yuv2rgb_coeffs": (C.c_int, [C.POINTER(SwsTables), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ffhip_sws_set_yuv2rgb": (C.c_int, [vp, C.POINTER(SwsTables)]),
         "ffhip_sws_freeContext": (None, [vp]),
         "ffhip_sws_fast_path": (C.c_int, [vp]),
         "ff_sws_init_swscale_hip": (C.c_int, [vp, C.c_int, C.c_int]),

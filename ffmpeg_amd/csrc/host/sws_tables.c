@@ -323,11 +323,16 @@ static int round_to_int16(int64_t f)
     return r < -0x7FFF ? (int16_t)0x8000 : r > 0x7FFF ? 0x7FFF : r;
 }
 
-/* ff_yuv2rgb_c_init_tables() for bpp 24, limited-range source, neutral brightness/contrast/saturation */
-void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange)
+/* ff_yuv2rgb_c_init_tables() (libswscale/yuv2rgb.c:750-797) for any matrix row, range and brightness / contrast / saturation: the
+ * coefficient arithmetic of that function, line by line, without the LUT fill (the kernels evaluate the ramp in closed form).
+ * inv_table = c->srcColorspaceTable (sws_getCoefficients()), the other arguments as sws_setColorspaceDetails() stores them
+ * (utils.c:848-905: c->brightness, c->contrast, c->saturation, sws->src_range). */
+int ffhip_sws_yuv2rgb_coeffs(FFHipSwsTables *t, const int inv_table[4], int fullRange, int brightness, int contrast, int saturation)
 {
-    int64_t crv = cs_default[0], cbu = cs_default[1], cgu = -cs_default[2], cgv = -cs_default[3];
-    int64_t cy = 1 << 16, oy = 0;
+    int64_t crv, cbu, cgu, cgv, cy = 1 << 16, oy = 0, d;
+    if (!t || !inv_table)
+        return FFHIP_EINVAL;
+    crv = inv_table[0]; cbu = inv_table[1]; cgu = -(int64_t)inv_table[2]; cgv = -(int64_t)inv_table[3];
     if (!fullRange) {
         cy = (cy * 255) / 219;
         oy = 16 << 16;
@@ -337,14 +342,12 @@ void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange)
         cgu = (cgu * 224) / 255;
         cgv = (cgv * 224) / 255;
     }
-    /* contrast = saturation = 1<<16, brightness = 0: the >>16 / >>32 products are identities */
-    t->yuv2rgb_cy  = cy;
-    t->yuv2rgb_oy  = oy;
-    t->yuv2rgb_crv = ((crv * (1 << 16)) + 0x8000) / cy;
-    t->yuv2rgb_cbu = ((cbu * (1 << 16)) + 0x8000) / cy;
-    t->yuv2rgb_cgu = ((cgu * (1 << 16)) + 0x8000) / cy;
-    t->yuv2rgb_cgv = ((cgv * (1 << 16)) + 0x8000) / cy;
-    t->yuv2rgb_yoffs = (fullRange ? 384 : 326) + 512; /* + YUVRGB_TABLE_LUMA_HEADROOM */
+    cy  = (cy  * contrast)              >> 16;
+    crv = (crv * contrast * saturation) >> 32;
+    cbu = (cbu * contrast * saturation) >> 32;
+    cgu = (cgu * contrast * saturation) >> 32;
+    cgv = (cgv * contrast * saturation) >> 32;
+    oy -= 256LL * brightness;
     /* the full-chroma writers' int16 coefficients (yuv2rgb.c:786-791), from the values BEFORE the division by cy */
     t->yuv2rgb_full[0] = round_to_int16(cy * (1 << 13));
     t->yuv2rgb_full[1] = round_to_int16(oy * (1 << 9));
@@ -352,6 +355,21 @@ void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange)
     t->yuv2rgb_full[3] = round_to_int16(cgv * (1 << 13));
     t->yuv2rgb_full[4] = round_to_int16(cgu * (1 << 13));
     t->yuv2rgb_full[5] = round_to_int16(cbu * (1 << 13));
+    d = cy > 1 ? cy : 1; /* FFMAX(cy, 1), yuv2rgb.c:794-797 */
+    t->yuv2rgb_cy  = cy;
+    t->yuv2rgb_oy  = oy;
+    t->yuv2rgb_crv = ((crv * (1 << 16)) + 0x8000) / d;
+    t->yuv2rgb_cbu = ((cbu * (1 << 16)) + 0x8000) / d;
+    t->yuv2rgb_cgu = ((cgu * (1 << 16)) + 0x8000) / d;
+    t->yuv2rgb_cgv = ((cgv * (1 << 16)) + 0x8000) / d;
+    t->yuv2rgb_yoffs = (fullRange ? 384 : 326) + 512; /* + YUVRGB_TABLE_LUMA_HEADROOM */
+    return 0;
+}
+
+/* ... for the default matrix (SWS_CS_DEFAULT) and neutral brightness / contrast / saturation: what sws_getContext() starts from */
+void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange)
+{
+    ffhip_sws_yuv2rgb_coeffs(t, cs_default, fullRange, 0, 1 << 16, 1 << 16);
 }
 
 struct FFHipSwsHostTables {
@@ -451,7 +469,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     int chrSrcW, chrSrcH, chrDstW, chrDstH, chrDstHSub, chrDstVSub, full_chr;
     int64_t lumXInc, lumYInc, chrXInc, chrYInc;
     int lum_scaler = scaler_of(flags, 0), chr_scaler = scaler_of(flags, 1);
-    int r, src_range = 0, dst_range = 0, alpha_fill = 0;
+    int r, src_range = 0, dst_range = 0, alpha_fill = 0, rgb_alpha = 0, rgbt;
 
     /* full-range twins on both sides: no range conversion, the base formats' scaler (handle_jpeg(), utils.c:1019-1050) */
     {
@@ -474,9 +492,14 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         const int sa = srcFormat == FFHIP_PIX_FMT_YUVA420P ? 1 : srcFormat == FFHIP_PIX_FMT_YUVA422P ? 2 : srcFormat == FFHIP_PIX_FMT_YUVA444P ? 3 : 0;
         const int da = dstFormat == FFHIP_PIX_FMT_YUVA420P ? 1 : dstFormat == FFHIP_PIX_FMT_YUVA422P ? 2 : dstFormat == FFHIP_PIX_FMT_YUVA444P ? 3 : 0;
         if (sa && (dstFormat == FFHIP_PIX_FMT_ARGB || dstFormat == FFHIP_PIX_FMT_RGBA || dstFormat == FFHIP_PIX_FMT_ABGR || dstFormat == FFHIP_PIX_FMT_BGRA)) {
-            /* the yuv2rgba writers with an alpha argument (output.c yuv2rgba32_X etc.) are not built */
-            ffhip_set_error("ffhip_sws: a source alpha plane into the alpha channel of packed RGB is not on the hip path");
-            return NULL;
+            /* equal sizes: the table converter's yuva2rgba_c / yuva2argb_c (yuv2rgb.c:524-529, 640-648) carry the alpha plane into the
+             * alpha byte; the scaler's yuv2rgba writers with an alpha argument (output.c yuv2rgba32_X etc.) are not built */
+            if (!(sa == 1 && srcW == dstW && srcH == dstH && !(flags & FFHIP_SWS_ACCURATE_RND) && !(dstH & 1) && !(dstW & 1))) {
+                ffhip_set_error("ffhip_sws: a source alpha plane into the alpha channel of packed RGB is on the hip path for the equal-size "
+                                "yuva420p converter only");
+                return NULL;
+            }
+            rgb_alpha = 1;
         }
         if (sa)
             srcFormat = base[sa - 1];
@@ -485,7 +508,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         /* alpha on both sides of a planar conversion: the alpha plane goes through the LUMA scaler — lum_h_scale and lum_planar_vscale run
          * hyScale / yuv2planeX on plane 3 with the luma banks and the luma dither (hscale.c:63-79, vscale.c:57-70), without the range
          * stage (hscale.c:57-59 converts plane 0 only) */
-        alpha_fill = sa && da ? 2 : da != 0;
+        alpha_fill = (sa && da) || rgb_alpha ? 2 : da != 0;
     }
     if (flags & FFHIP_SWS_FAST_BILINEAR) {
         /* the C path of SWS_FAST_BILINEAR runs ff_hyscale_fast_c, a different horizontal scaler
@@ -493,14 +516,21 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         ffhip_set_error("ffhip_sws: SWS_FAST_BILINEAR is not on the hip path");
         return NULL;
     }
-    if (!is_yuv(srcFormat) || (!is_yuv(dstFormat) && !is_rgb(dstFormat)) || srcW < 2 || srcH < 2 || dstW < 2 ||
+    /* the planar RGB target of the equal-size table converter (yuv420p_gbrp_c / yuv422p_gbrp_c, yuv2rgb.c:533, 553) */
+    if (dstFormat == FFHIP_PIX_FMT_GBRP && !(srcW == dstW && srcH == dstH && (srcFormat == FFHIP_PIX_FMT_YUV420P || srcFormat == FFHIP_PIX_FMT_YUV422P) &&
+                                             !(flags & FFHIP_SWS_ACCURATE_RND) && !(dstH & 1) && !(dstW & 1))) {
+        ffhip_set_error("ffhip_sws: gbrp is a target of the equal-size yuv420p / yuv422p converter only");
+        return NULL;
+    }
+    rgbt = is_rgb(dstFormat) || dstFormat == FFHIP_PIX_FMT_GBRP;
+    if (!is_yuv(srcFormat) || (!is_yuv(dstFormat) && !rgbt) || srcW < 2 || srcH < 2 || dstW < 2 ||
         dstH < 2) {
         ffhip_set_error("ffhip_sws: unsupported conversion %d -> %d (%dx%d -> %dx%d)", srcFormat, dstFormat,
                         srcW, srcH, dstW, dstH);
         return NULL;
     }
     if (ffhip_pixfmt_hbd(srcFormat, NULL, NULL, NULL, NULL) || ffhip_pixfmt_hbd(dstFormat, NULL, NULL, NULL, NULL)) {
-        if (is_rgb(dstFormat)) {
+        if (rgbt) {
             ffhip_set_error("ffhip_sws: sources above 8 bits to packed RGB are not on the hip path");
             return NULL;
         }
@@ -516,7 +546,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     h->t.dst_alpha_fill = alpha_fill;
     h->t.src_range = src_range;
     h->t.dst_range = dst_range;
-    if (src_range != dst_range && !is_rgb(dstFormat)) {
+    if (src_range != dst_range && !rgbt) {
         int ddepth = 8;
         ffhip_pixfmt_hbd(dstFormat, &ddepth, NULL, NULL, NULL);
         ffhip_sws_range_constants(src_range, ddepth, &h->t.lumConvertRange_coeff, &h->t.lumConvertRange_offset,
@@ -527,7 +557,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
      * (utils.c:1359-1360) and full vertical resolution */
     /* SWS_FULL_CHR_H_INT (utils.c:1270-1290): asked for, or forced on a packed RGB target by an odd width or by a source without chroma
      * sub-sampling (unless SWS_FAST_BILINEAR) — chroma then keeps full horizontal resolution and the yuv2rgb_full_* writers run */
-    full_chr = is_rgb(dstFormat) && ((flags & FFHIP_SWS_FULL_CHR_H_INT) || (dstW & 1) ||
+    full_chr = rgbt && ((flags & FFHIP_SWS_FULL_CHR_H_INT) || (dstW & 1) ||
                                      (chroma_hsub(srcFormat) == 0 && chroma_vsub(srcFormat) == 0 && !(flags & FFHIP_SWS_FAST_BILINEAR)));
     h->t.full_chr_h_int = full_chr;
     if (full_chr)
@@ -535,14 +565,14 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
     /* RGB output without SWS_FULL_CHR_H_INT keeps chroma at half horizontal resolution (utils.c:1359-1360); full vertical resolution
      * either way.  4:2:2 sources: the chroma banks run from the source's own chroma plane size (chrSrcHSubSample stays the format's for
      * YUV sources: the "drop every other pixel" of utils.c:1368-1392 is for RGB sources) */
-    chrDstHSub = is_rgb(dstFormat) ? (full_chr ? 0 : 1) : chroma_hsub(dstFormat);
-    chrDstVSub = is_rgb(dstFormat) ? 0 : chroma_vsub(dstFormat);
+    chrDstHSub = rgbt ? (full_chr ? 0 : 1) : chroma_hsub(dstFormat);
+    chrDstVSub = rgbt ? 0 : chroma_vsub(dstFormat);
     chrSrcW = ceil_rshift(srcW, chroma_hsub(srcFormat));
     chrSrcH = ceil_rshift(srcH, chroma_vsub(srcFormat));
     chrDstW = ceil_rshift(dstW, chrDstHSub);
     chrDstH = ceil_rshift(dstH, chrDstVSub);
 
-    h->unscaled_yuv2rgb = srcW == dstW && srcH == dstH && srcFormat == FFHIP_PIX_FMT_YUV420P && is_rgb(dstFormat) &&
+    h->unscaled_yuv2rgb = srcW == dstW && srcH == dstH && (srcFormat == FFHIP_PIX_FMT_YUV420P || srcFormat == FFHIP_PIX_FMT_YUV422P) && rgbt &&
                           !(flags & FFHIP_SWS_ACCURATE_RND) && !(dstH & 1);
 
     lumXInc = (((int64_t)srcW << 16) + (dstW >> 1)) / dstW;
@@ -570,7 +600,7 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         out[k]->size = r;
         out[k]->n = bank[k].d;
     }
-    ffhip_host_yuv2rgb_coeffs(&h->t, is_rgb(dstFormat) ? src_range : 0);
+    ffhip_host_yuv2rgb_coeffs(&h->t, rgbt ? src_range : 0);
     return h;
 }
 
@@ -595,7 +625,7 @@ int ffhip_sws_tables_set_ranges(FFHipSwsHostTables *t, int src_range, int dst_ra
         ffhip_set_error("ffhip_sws_tables_set_ranges: a range conversion together with a scaled alpha plane is not on the hip path");
         return FFHIP_ENOSYS;
     }
-    if (is_rgb(t->t.dstFormat)) /* the coefficients carry the source's range (sws_setColorspaceDetails -> ff_yuv2rgb_c_init_tables) */
+    if (is_rgb(t->t.dstFormat) || t->t.dstFormat == FFHIP_PIX_FMT_GBRP) /* the coefficients carry the source's range (sws_setColorspaceDetails -> ff_yuv2rgb_c_init_tables) */
         ffhip_host_yuv2rgb_coeffs(&t->t, src_range);
     t->t.src_range = src_range;
     t->t.dst_range = dst_range;

@@ -26,8 +26,16 @@ struct FFHipYuv2RgbArgs {
     int nframes;
     int flat;                        /* set by the launcher: chunks numbered through the frame's row pairs (k_yuv420p_rgb24_t) */
     FFHipYuv2RgbK k;
+    /* the converter's other forms (yuv2rgb.c:238-320, 540-553: YUV422FUNC, yuva2rgba_c / yuva2argb_c, yuv420p_gbrp_c) */
+    int c422 = 0;                    /* 4:2:2 source: luma row 2k + 1 takes chroma row 2k + 1 (u_stride / v_stride are the planes' own) */
+    const uint8_t *alpha = nullptr;  /* the source's alpha plane drives the alpha byte of a 32-bit target (else 255) */
+    ptrdiff_t alpha_stride = 0;
+    size_t alpha_fp = 0;
+    uint8_t *dst1 = nullptr, *dst2 = nullptr; /* layout 6 (gbrp): dst = G, dst1 = B, dst2 = R planes */
+    ptrdiff_t dst1_stride = 0, dst2_stride = 0;
+    size_t dst1_fp = 0, dst2_fp = 0;
 };
-/* packed layout: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (32-bit: alpha = 255) */
+/* packed layout: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (32-bit: alpha = 255 unless a.alpha), 6 planar gbrp */
 int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_t stream);
 
 /* one separable bank resident in HBM */

@@ -347,8 +347,151 @@ __global__ __launch_bounds__(256) void k_yuv420p_rgb32(FFHipYuv2RgbArgs a)
     }
 }
 
+/*
+ * The converter's remaining forms in one plain kernel: 4:2:2 sources (YUV422FUNC, yuv2rgb.c:238-320: the second luma row of a pair
+ * takes the chroma row of its own), a source alpha plane into the alpha byte of a 32-bit target (yuva2rgba_c / yuva2argb_c,
+ * yuv2rgb.c:524-529, PUTRGBA :88-93), and the planar target (yuv420p_gbrp_c / yuv422p_gbrp_c, PUTGBRP :127-135).  One lane = 4 pixels
+ * x 2 rows, as k_yuv420p_rgb32: a dword of each luma (and alpha) row and two bytes of each chroma row in; 12 / 16 / 3 x 4 bytes per
+ * row out, dword or 16-byte stores when VEC (aligned planes), bytes otherwise.
+ */
+template <int LAYOUT, bool VEC>
+__global__ __launch_bounds__(256) void k_yuv2rgb_forms(FFHipYuv2RgbArgs a)
+{
+    const int chunks = (a.wvalid + 3) >> 2;
+    const int rowpairs = a.h >> 1;
+    const long long total = (long long)chunks * rowpairs * a.nframes;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total)
+        return;
+    const int chunk = (int)(id % chunks);
+    const int rp = (int)((id / chunks) % rowpairs);
+    const int f = (int)(id / ((long long)chunks * rowpairs));
+    const int x0 = chunk << 2;
+    const int npx = min(4, a.wvalid - x0);
+    const FFHipYuv2RgbK k = a.k;
+    constexpr int BPP = LAYOUT < 2 ? 3 : LAYOUT < 6 ? 4 : 1;
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+        const int y = 2 * rp + row;
+        const int crow = a.c422 ? y : rp;
+        const uint8_t *py = a.y + (size_t)f * a.y_fp + (ptrdiff_t)y * a.y_stride + x0;
+        const uint8_t *pu = a.u + (size_t)f * a.u_fp + (ptrdiff_t)crow * a.u_stride + (x0 >> 1);
+        const uint8_t *pv = a.v + (size_t)f * a.v_fp + (ptrdiff_t)crow * a.v_stride + (x0 >> 1);
+        const uint8_t *pa = a.alpha ? a.alpha + (size_t)f * a.alpha_fp + (ptrdiff_t)y * a.alpha_stride + x0 : nullptr;
+        uint8_t *d = a.dst + (size_t)f * a.dst_fp + (ptrdiff_t)(y + a.dst_y0) * a.dst_stride + BPP * x0;
+        uint32_t yw = 0, uw = 0, vw = 0, aw = 0xFFFFFFFFu;
+        if (VEC && npx == 4) {
+            yw = *reinterpret_cast<const uint32_t *>(py);
+            uw = *reinterpret_cast<const uint16_t *>(pu);
+            vw = *reinterpret_cast<const uint16_t *>(pv);
+            if (pa)
+                aw = *reinterpret_cast<const uint32_t *>(pa);
+        } else {
+            for (int p = 0; p < npx; p++) {
+                yw |= (uint32_t)py[p] << (8 * p);
+                if (pa)
+                    aw = (aw & ~(0xFFu << (8 * p))) | ((uint32_t)pa[p] << (8 * p));
+            }
+            for (int m = 0; m < (npx >> 1); m++) {
+                uw |= (uint32_t)pu[m] << (8 * m);
+                vw |= (uint32_t)pv[m] << (8 * m);
+            }
+        }
+        uint8_t R[4], G[4], B[4];
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const Bases b = chroma_bases(k, (int)((uw >> (8 * m)) & 0xFF), (int)((vw >> (8 * m)) & 0xFF));
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int p = 2 * m + e;
+                const int c = (int)((yw >> (8 * p)) & 0xFF) * k.cy;
+                R[p] = (uint8_t)clip_u8((b.r + c) >> 16); G[p] = (uint8_t)clip_u8((b.g + c) >> 16); B[p] = (uint8_t)clip_u8((b.b + c) >> 16);
+            }
+        }
+        if (LAYOUT == 6) {
+            uint8_t *d1 = a.dst1 + (size_t)f * a.dst1_fp + (ptrdiff_t)(y + a.dst_y0) * a.dst1_stride + x0;
+            uint8_t *d2 = a.dst2 + (size_t)f * a.dst2_fp + (ptrdiff_t)(y + a.dst_y0) * a.dst2_stride + x0;
+            if (VEC && npx == 4) {
+                *reinterpret_cast<uint32_t *>(d)  = G[0] | (G[1] << 8) | (G[2] << 16) | ((uint32_t)G[3] << 24);
+                *reinterpret_cast<uint32_t *>(d1) = B[0] | (B[1] << 8) | (B[2] << 16) | ((uint32_t)B[3] << 24);
+                *reinterpret_cast<uint32_t *>(d2) = R[0] | (R[1] << 8) | (R[2] << 16) | ((uint32_t)R[3] << 24);
+            } else {
+                for (int p = 0; p < npx; p++) { d[p] = G[p]; d1[p] = B[p]; d2[p] = R[p]; }
+            }
+        } else if (LAYOUT >= 2) {
+            uint32_t o[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t A = (aw >> (8 * p)) & 0xFF;
+                o[p] = LAYOUT == 2 ? A | (R[p] << 8) | (G[p] << 16) | ((uint32_t)B[p] << 24)
+                     : LAYOUT == 3 ? R[p] | (G[p] << 8) | (B[p] << 16) | (A << 24)
+                     : LAYOUT == 4 ? A | (B[p] << 8) | (G[p] << 16) | ((uint32_t)R[p] << 24)
+                                   : B[p] | (G[p] << 8) | (R[p] << 16) | (A << 24);
+            }
+            if (VEC && npx == 4) {
+                *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+                for (int p = 0; p < npx; p++)
+                    for (int j = 0; j < 4; j++)
+                        d[4 * p + j] = (uint8_t)(o[p] >> (8 * j));
+            }
+        } else {
+            uint8_t o[12];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                o[3 * p] = LAYOUT == 1 ? B[p] : R[p]; o[3 * p + 1] = G[p]; o[3 * p + 2] = LAYOUT == 1 ? R[p] : B[p];
+            }
+            if (VEC && npx == 4) {
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    reinterpret_cast<uint32_t *>(d)[j] = o[4 * j] | (o[4 * j + 1] << 8) | (o[4 * j + 2] << 16) | ((uint32_t)o[4 * j + 3] << 24);
+            } else {
+                for (int j = 0; j < 3 * npx; j++)
+                    d[j] = o[j];
+            }
+        }
+    }
+}
+
+static int launch_forms(const FFHipYuv2RgbArgs &a, int layout, hipStream_t stream)
+{
+    const long long total4 = (long long)((a.wvalid + 3) >> 2) * (a.h >> 1) * a.nframes;
+    if (total4 <= 0)
+        return 0;
+    if (total4 >= (1LL << 31) * 256) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch");
+        return FFHIP_EINVAL;
+    }
+    bool vec = !(((uintptr_t)a.y | (size_t)a.y_stride | a.y_fp | (uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp) & 3) &&
+               !(((uintptr_t)a.u | (uintptr_t)a.v | (size_t)a.u_stride | (size_t)a.v_stride | a.u_fp | a.v_fp) & 1);
+    if (a.alpha)
+        vec = vec && !(((uintptr_t)a.alpha | (size_t)a.alpha_stride | a.alpha_fp) & 3);
+    if (layout >= 2 && layout < 6)
+        vec = vec && !(((uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp) & 15);
+    if (layout == 6)
+        vec = vec && !(((uintptr_t)a.dst1 | (uintptr_t)a.dst2 | (size_t)a.dst1_stride | (size_t)a.dst2_stride | a.dst1_fp | a.dst2_fp) & 3);
+    const dim3 grid((unsigned)((total4 + 255) / 256)), block(256);
+#define LF(LY) do { if (vec) hipLaunchKernelGGL((k_yuv2rgb_forms<LY, true>), grid, block, 0, stream, a); \
+                    else hipLaunchKernelGGL((k_yuv2rgb_forms<LY, false>), grid, block, 0, stream, a); } while (0)
+    switch (layout) {
+    case 0: LF(0); break;
+    case 1: LF(1); break;
+    case 2: LF(2); break;
+    case 3: LF(3); break;
+    case 4: LF(4); break;
+    case 5: LF(5); break;
+    case 6: LF(6); break;
+    default: return FFHIP_EINVAL;
+    }
+#undef LF
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_t stream)
 {
+    if (a.c422 || a.alpha || layout == 6)
+        return launch_forms(a, layout, stream);
     const int bgr = layout == 1;
     const int chunks = (a.wvalid + 15) >> 4;
     const long long total = (long long)chunks * (a.h >> 1) * a.nframes;

@@ -110,6 +110,14 @@ static int rgb_layout(int f)
     return -1;
 }
 static bool fmt_rgb(int f) { return rgb_layout(f) >= 0; }
+/* planar gbrp: a target of the equal-size table converter only (yuv420p_gbrp_c, yuv2rgb.c:533); the launcher's layout 6 */
+static bool fmt_gbrp(int f) { return f == FFHIP_PIX_FMT_GBRP; }
+/* the reference's table-driven converter takes the conversion (swscale_unscaled.c:2425-2431; yuva420p arrives as yuv420p + dst_alpha_fill) */
+static bool unscaled_rule(const FFHipSwsTables *t)
+{
+    return t->srcW == t->dstW && t->srcH == t->dstH && (t->srcFormat == FFHIP_PIX_FMT_YUV420P || t->srcFormat == FFHIP_PIX_FMT_YUV422P) &&
+           (fmt_rgb(t->dstFormat) || fmt_gbrp(t->dstFormat)) && !(t->flags & FFHIP_SWS_ACCURATE_RND) && !(t->dstH & 1);
+}
 
 static int make_k(const FFHipSwsTables &t, FFHipYuv2RgbK *k)
 {
@@ -362,7 +370,7 @@ static bool bank_nowrap_depth(const int16_t *f, int n, int depth, int size = 4)
 
 extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
 {
-    if (!t || !fmt_yuv(t->srcFormat) || !(fmt_yuv(t->dstFormat) || fmt_rgb(t->dstFormat))) {
+    if (!t || !fmt_yuv(t->srcFormat) || !(fmt_yuv(t->dstFormat) || fmt_rgb(t->dstFormat) || (fmt_gbrp(t->dstFormat) && unscaled_rule(t) && !(t->dstW & 1)))) {
         ffhip_set_error("ffhip_sws: unsupported format pair");
         return nullptr;
     }
@@ -373,17 +381,18 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                         "FFHipSwsTables.full_chr_h_int and .yuv2rgb_full must be set");
         return nullptr;
     }
-    if (t->full_chr_h_int && t->srcW == t->dstW && t->srcH == t->dstH && t->srcFormat == FFHIP_PIX_FMT_YUV420P && fmt_rgb(t->dstFormat) &&
-        !(t->flags & FFHIP_SWS_ACCURATE_RND) && !(t->dstH & 1) && (t->dstW & 1)) {
-        ffhip_set_error("ffhip_sws: equal-size yuv420p to an odd-width packed RGB target is the table converter's tail case; not on the hip path");
+    if (unscaled_rule(t) && (t->dstW & 1)) {
+        ffhip_set_error("ffhip_sws: equal-size yuv420p / yuv422p to an odd-width RGB target is the table converter's tail case; not on the hip path");
         return nullptr;
     }
     /* alpha: 1 = dst[3] filled with 255, 2 = src[3] scaled into dst[3] by the luma banks (a second pass of the context): a planar 8-bit
      * target, and no range conversion (the reference converts plane 0 only, hscale.c:57-59; the second pass would convert its luma) */
     if (t->dst_alpha_fill < 0 || t->dst_alpha_fill > 2 ||
-        (t->dst_alpha_fill == 2 && (fmt_rgb(t->dstFormat) || fmt_nv(t->dstFormat) || ffhip_pixfmt_hbd(t->srcFormat, nullptr, nullptr, nullptr, nullptr) ||
+        (t->dst_alpha_fill == 2 && unscaled_rule(t) && !(rgb_layout(t->dstFormat) >= 2 && rgb_layout(t->dstFormat) <= 5 && t->srcFormat == FFHIP_PIX_FMT_YUV420P)) ||
+        (t->dst_alpha_fill == 2 && !unscaled_rule(t) && (fmt_rgb(t->dstFormat) || fmt_nv(t->dstFormat) || ffhip_pixfmt_hbd(t->srcFormat, nullptr, nullptr, nullptr, nullptr) ||
                                     ffhip_pixfmt_hbd(t->dstFormat, nullptr, nullptr, nullptr, nullptr) || t->src_range != t->dst_range))) {
-        ffhip_set_error("ffhip_sws: a scaled alpha plane (dst_alpha_fill 2) goes with a planar 8-bit target and equal ranges");
+        ffhip_set_error("ffhip_sws: a source alpha plane (dst_alpha_fill 2) goes with a planar 8-bit target and equal ranges, or with the equal-size "
+                        "yuva420p -> 32-bit RGB converter");
         return nullptr;
     }
     /* (a packed RGB target takes the source's range through the yuv2rgb coefficients the caller hands over: ff_yuv2rgb_c_init_tables'
@@ -399,8 +408,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
     c->t = *t;
     c->chrSrcW = -((-t->srcW) >> fmt_hsub(t->srcFormat));
     c->chrSrcH = -((-t->srcH) >> fmt_vsub(t->srcFormat));
-    c->unscaled_yuv2rgb = t->srcW == t->dstW && t->srcH == t->dstH && t->srcFormat == FFHIP_PIX_FMT_YUV420P &&
-                          fmt_rgb(t->dstFormat) && !(t->flags & FFHIP_SWS_ACCURATE_RND) && !(t->dstH & 1);
+    c->unscaled_yuv2rgb = unscaled_rule(t);
     if (make_k(*t, &c->k) < 0) {
         delete c;
         return nullptr;
@@ -410,6 +418,22 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
     const FFHipSwsFilter *in[4] = { &t->hLum, &t->hChr, &t->vLum, &t->vChr };
     FFHipSwsFilter *own[4] = { &c->t.hLum, &c->t.hChr, &c->t.vLum, &c->t.vChr };
     size_t off[4][2], total = 0;
+    /* the reference builds no banks for a context that got a special converter (ff_sws_init_single_context() returns before
+     * initFilter(), libswscale/utils.c:1625-1637): the table converter takes none, the context keeps one-tap identities */
+    std::vector<int16_t> idf[4];
+    std::vector<int32_t> idp[4];
+    FFHipSwsFilter idb[4];
+    if (c->unscaled_yuv2rgb && (!t->hLum.filter || !t->hChr.filter || !t->vLum.filter || !t->vChr.filter)) {
+        const int n[4] = { t->dstW, (t->dstW + 1) >> 1, t->dstH, (t->dstH + 1) >> 1 };
+        for (int i = 0; i < 4; i++) {
+            idf[i].assign((size_t)n[i], (int16_t)(i < 2 ? 1 << 14 : 1 << 12));
+            idp[i].resize((size_t)n[i]);
+            for (int x = 0; x < n[i]; x++)
+                idp[i][x] = x;
+            idb[i].filter = idf[i].data(); idb[i].pos = idp[i].data(); idb[i].size = 1; idb[i].n = n[i];
+            in[i] = &idb[i];
+        }
+    }
     for (int i = 0; i < 4; i++) {
         if (!in[i]->filter || !in[i]->pos || in[i]->size <= 0 || in[i]->n <= 0) {
             ffhip_set_error("ffhip_sws: filter bank %d missing", i);
@@ -721,6 +745,30 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
     return c;
 }
 
+/* sws_setColorspaceDetails() on a live context (libswscale/utils.c:848-1000 ends in ff_yuv2rgb_c_init_tables() for RGB targets): the
+ * coefficient fields of `t` replace the context's, the banks and formats stay */
+extern "C" int ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t)
+{
+    if (!c || !t)
+        return FFHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    FFHipSwsTables n = c->t;
+    n.yuv2rgb_cy = t->yuv2rgb_cy; n.yuv2rgb_oy = t->yuv2rgb_oy; n.yuv2rgb_crv = t->yuv2rgb_crv; n.yuv2rgb_cbu = t->yuv2rgb_cbu;
+    n.yuv2rgb_cgu = t->yuv2rgb_cgu; n.yuv2rgb_cgv = t->yuv2rgb_cgv; n.yuv2rgb_yoffs = t->yuv2rgb_yoffs;
+    for (int i = 0; i < 6; i++)
+        n.yuv2rgb_full[i] = t->yuv2rgb_full[i];
+    FFHipYuv2RgbK k;
+    const int r = make_k(n, &k);
+    if (r < 0)
+        return r;
+    c->t = n;
+    c->k = k;
+    c->rgb.k = k;
+    for (int i = 0; i < 6; i++)
+        c->rgb.fk[i] = n.yuv2rgb_full[i];
+    return 0;
+}
+
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
     return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) : 0;
@@ -990,6 +1038,10 @@ static int plane_list(int fmt, int w, int h, PlaneDesc out[3])
         out[0] = { bs * w, h }; out[1] = { bs * cw, chh }; out[2] = { bs * cw, chh };
         return 3;
     }
+    if (fmt_gbrp(fmt)) {
+        out[0] = out[1] = out[2] = { w, h };
+        return 3;
+    }
     out[0] = { (rgb_layout(fmt) < 2 ? 3 : 4) * w, h };
     return 1;
 }
@@ -999,10 +1051,17 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                                          const int srcStride[4], const size_t srcFramePitch[4], void *const dst[4],
                                          const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
 {
+    if (c && c->unscaled_yuv2rgb) /* one launch; a source alpha plane (src[3]) is read by it */
+        return scale_batch_dev(c, nframes, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream_);
     if (c && c->t.dst_alpha_fill && (!dst || !dst[3] || (c->t.dst_alpha_fill == 2 && (!src || !src[3])))) {
         ffhip_set_error("ffhip_sws_scale_batch_dev: the format has an alpha plane: plane 3 is NULL");
         return FFHIP_EINVAL;
     }
+    /* the alpha pass flips the context's planner state (luma_pass): a context with a scaled alpha plane serves one call at a time,
+     * both passes under the lock the host face holds too */
+    std::unique_lock<std::mutex> lk;
+    if (c && c->t.dst_alpha_fill == 2)
+        lk = std::unique_lock<std::mutex>(c->mu);
     const int r = scale_batch_dev(c, nframes, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream_);
     if (r < 0 || !c->t.dst_alpha_fill)
         return r;
@@ -1033,6 +1092,36 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
     return r;
 }
 
+/* the table converter on `rows` lines (a whole frame, or a 2-line aligned slice) of device planes: one launch */
+static int unscaled_launch(FFHipSwsContext *c, int nframes, int rows, const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
+                           void *const dst[4], const int dstStride[4], const size_t dstFramePitch[4], hipStream_t stream)
+{
+    const FFHipSwsTables &t = c->t;
+    FFHipYuv2RgbArgs a;
+    a.y = (const uint8_t *)src[0]; a.u = (const uint8_t *)src[1]; a.v = (const uint8_t *)src[2]; a.dst = (uint8_t *)dst[0];
+    a.y_stride = srcStride[0]; a.u_stride = srcStride[1]; a.v_stride = srcStride[2]; a.dst_stride = dstStride[0];
+    a.y_fp = srcFramePitch[0]; a.u_fp = srcFramePitch[1]; a.v_fp = srcFramePitch[2]; a.dst_fp = dstFramePitch[0];
+    a.wvalid = t.dstW & ~1; a.h = rows; a.dst_y0 = 0; a.nframes = nframes; a.flat = 0; a.k = c->k;
+    a.c422 = t.srcFormat == FFHIP_PIX_FMT_YUV422P;
+    if (!a.y || !a.u || !a.v || !a.dst)
+        return FFHIP_EINVAL;
+    if (t.dst_alpha_fill == 2) {
+        if (!src[3]) {
+            ffhip_set_error("ffhip_sws: the source's alpha plane (plane 3) is NULL");
+            return FFHIP_EINVAL;
+        }
+        a.alpha = (const uint8_t *)src[3]; a.alpha_stride = srcStride[3]; a.alpha_fp = srcFramePitch[3];
+    }
+    if (fmt_gbrp(t.dstFormat)) {
+        if (!dst[1] || !dst[2])
+            return FFHIP_EINVAL;
+        a.dst1 = (uint8_t *)dst[1]; a.dst1_stride = dstStride[1]; a.dst1_fp = dstFramePitch[1];
+        a.dst2 = (uint8_t *)dst[2]; a.dst2_stride = dstStride[2]; a.dst2_fp = dstFramePitch[2];
+        return ffhip_launch_yuv420p_rgb24(a, 6, stream);
+    }
+    return ffhip_launch_yuv420p_rgb24(a, rgb_layout(t.dstFormat), stream);
+}
+
 static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
                            void *const dst[4], const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
 {
@@ -1045,14 +1134,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
     if (c->hbd)
         return scale16(c, nframes, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream);
 
-    if (c->unscaled_yuv2rgb) {
-        FFHipYuv2RgbArgs a;
-        a.y = s0; a.u = s1; a.v = s2; a.dst = (uint8_t *)dst[0];
-        a.y_stride = srcStride[0]; a.u_stride = srcStride[1]; a.v_stride = srcStride[2]; a.dst_stride = dstStride[0];
-        a.y_fp = srcFramePitch[0]; a.u_fp = srcFramePitch[1]; a.v_fp = srcFramePitch[2]; a.dst_fp = dstFramePitch[0];
-        a.wvalid = t.dstW & ~1; a.h = t.srcH; a.dst_y0 = 0; a.nframes = nframes; a.k = c->k;
-        return ffhip_launch_yuv420p_rgb24(a, rgb_layout(t.dstFormat), stream);
-    }
+    if (c->unscaled_yuv2rgb)
+        return unscaled_launch(c, nframes, t.srcH, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream);
 
     /* chroma source description */
     const uint8_t *cu, *cv;
@@ -1433,7 +1516,7 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
         return FFHIP_EINVAL;
     FFHipDeviceGuard dg(c->device);
     std::lock_guard<std::mutex> lk(c->mu);
-    if (c->t.dst_alpha_fill != 2)
+    if (c->t.dst_alpha_fill != 2 || c->unscaled_yuv2rgb)
         return sws_scale_locked(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
     /* alpha on both sides: a second pass whose luma is the alpha plane (see ffhip_sws_scale_batch_dev); whole frames only — the slice
      * collection holds one frame's source */
@@ -1490,10 +1573,17 @@ static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], cons
         return FFHIP_EINVAL;
     }
     const int srcRows = unscaled ? srcSliceH : t.srcH;
-    PlaneDesc sp[3], dp[3];
-    const int ns = plane_list(t.srcFormat, t.srcW, srcRows, sp);
+    PlaneDesc sp[4], dp[3];
+    int ns = plane_list(t.srcFormat, t.srcW, srcRows, sp);
     const int nd = plane_list(t.dstFormat, t.dstW, unscaled ? srcSliceH : t.dstH, dp);
-    size_t off_s[3], off_d[3], total = 0;
+    if (unscaled && t.dst_alpha_fill == 2) { /* the source's alpha plane rides along as a fourth plane of the luma's size */
+        if (!src[3]) {
+            ffhip_set_error("ffhip_sws_scale: the source's alpha plane (plane 3) is NULL");
+            return FFHIP_EINVAL;
+        }
+        sp[ns++] = sp[0];
+    }
+    size_t off_s[4], off_d[3], total = 0;
     int pitch_s[4] = { 0, 0, 0, 0 }, pitch_d[4] = { 0, 0, 0, 0 };
     for (int i = 0; i < ns; i++) {
         pitch_s[i] = (sp[i].wbytes + 255) & ~255;
@@ -1543,13 +1633,7 @@ static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], cons
                        dp[0].wbytes, dp[0].rows, hipMemcpyHostToDevice));
     int r;
     if (unscaled) {
-        FFHipYuv2RgbArgs a;
-        a.y = (const uint8_t *)dsrc[0]; a.u = (const uint8_t *)dsrc[1]; a.v = (const uint8_t *)dsrc[2];
-        a.dst = (uint8_t *)ddst[0];
-        a.y_stride = pitch_s[0]; a.u_stride = pitch_s[1]; a.v_stride = pitch_s[2]; a.dst_stride = pitch_d[0];
-        a.y_fp = a.u_fp = a.v_fp = a.dst_fp = 0;
-        a.wvalid = t.dstW & ~1; a.h = srcSliceH; a.dst_y0 = 0; a.nframes = 1; a.k = c->k;
-        r = ffhip_launch_yuv420p_rgb24(a, rgb_layout(t.dstFormat), 0);
+        r = unscaled_launch(c, 1, srcSliceH, dsrc, pitch_s, fp, ddst, pitch_d, fp, 0);
     } else {
         r = scale_batch_dev(c, 1, dsrc, pitch_s, fp, ddst, pitch_d, fp, 0);
     }

@@ -134,7 +134,7 @@ int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t 
 #define FFHIP_PIX_FMT_YUVA420P 33  /* planar YUV with an alpha plane, 8 bits (== AV_PIX_FMT_YUVA420P / _YUVA422P / _YUVA444P).  As sources their
                                     * alpha plane is not read when the target has none (c->needAlpha = 0, utils.c:1398); as targets of sources
                                     * without alpha the plane dst[3] is filled with 255, as ff_swscale() fills it (swscale.c:536-553).  Alpha on
-                                    * both sides (a scaled alpha plane) is not on this path */
+                                    * both sides: the alpha plane is scaled by the luma banks (FFHipSwsTables.dst_alpha_fill == 2) */
 #define FFHIP_PIX_FMT_YUVA422P 78
 #define FFHIP_PIX_FMT_YUVA444P 79
 #define FFHIP_PIX_FMT_YUVJ420P 12  /* the full-range "J" twins (== AV_PIX_FMT_YUVJ420P / 422P / 444P): taken when BOTH sides are J formats —
@@ -172,6 +172,13 @@ int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t 
 #define FFHIP_PIX_FMT_RGBA    26
 #define FFHIP_PIX_FMT_ABGR    27
 #define FFHIP_PIX_FMT_BGRA    28
+#define FFHIP_PIX_FMT_GBRP    71   /* planar G, B, R (== AV_PIX_FMT_GBRP): a target of the equal-size table converter only (yuv420p_gbrp_c /
+                                    * yuv422p_gbrp_c, libswscale/yuv2rgb.c:533,553) */
+/* The equal-size table converter (ff_yuv2rgb_get_func_ptr(), libswscale/yuv2rgb.c:562-676; chosen at swscale_unscaled.c:2425-2431 when
+ * the sizes are equal, SWS_ACCURATE_RND is off and the height is even) takes yuv420p, yuv422p (each luma row with the chroma row of its
+ * own, YUV422FUNC) and yuva420p sources; the alpha plane of the latter drives the alpha byte of the four 32-bit targets (yuva2rgba_c /
+ * yuva2argb_c) and is not read for the others.  Targets: rgb24, bgr24, argb, rgba, abgr, bgra, gbrp; even widths (an odd width is the C
+ * converter's tail case and stays there). */
 /* Flags: numeric values are SwsFlags' (libswscale/swscale.h:130-153). */
 #define FFHIP_SWS_FULL_CHR_H_INT 0x2000 /* full chroma interpolation for packed RGB targets (swscale.h:147) */
 #define FFHIP_SWS_FAST_BILINEAR 0x1
@@ -227,6 +234,7 @@ typedef struct FFHipSwsTables {
      * 2: both sides are planar YUVA: the alpha plane is scaled by the LUMA banks (lum_h_scale / lum_planar_vscale on plane 3,
      *    hscale.c:63-79, vscale.c:57-70) — src[3] -> dst[3] as the luma of a second pass of the context in which the planners enumerate
      *    the luma job only; not together with a range conversion (the reference converts plane 0 only).
+     *    With the equal-size table converter to a 32-bit packed RGB target: src[3] drives the alpha byte (yuva2rgba_c / yuva2argb_c).
      * srcFormat / dstFormat above are then the formats without the alpha plane */
     int      dst_alpha_fill;
 } FFHipSwsTables;
@@ -239,8 +247,18 @@ typedef struct FFHipSwsContext FFHipSwsContext;
  *  Returns NULL (and sets ffhip_last_error) for an unsupported conversion or when no device. */
 FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcFormat,
                                       int dstW, int dstH, int dstFormat, int flags);
-/** Drop-in construction from FFmpeg's own tables (no filter generation on our side). */
+/** Drop-in construction from FFmpeg's own tables (no filter generation on our side).  A context the reference gave a special
+ *  converter has no banks (ff_sws_init_single_context() returns before initFilter(), libswscale/utils.c:1625-1637): for the
+ *  equal-size yuv420p -> packed RGB table converter (swscale_unscaled.c:2425-2431) the four banks may be left NULL. */
 FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t);
+/** The yuv2rgb fields of the tables (yuv2rgb_cy .. yuv2rgb_yoffs, yuv2rgb_full[]) as ff_yuv2rgb_c_init_tables() derives them
+ *  (libswscale/yuv2rgb.c:750-797) from what the context stores: inv_table = c->srcColorspaceTable, fullRange = sws->src_range,
+ *  c->brightness / c->contrast / c->saturation (sws_setColorspaceDetails(), utils.c:848-905).  No device needed.  0 or FFHIP_EINVAL. */
+int              ffhip_sws_yuv2rgb_coeffs(FFHipSwsTables *t, const int inv_table[4], int fullRange, int brightness, int contrast,
+                                          int saturation);
+/** sws_setColorspaceDetails() after the context was made (utils.c:990-996 re-runs ff_yuv2rgb_c_init_tables()): the yuv2rgb fields of
+ *  `t` replace the context's; every other field of `t` is ignored.  0, FFHIP_EINVAL (coefficients outside the closed form's range). */
+int              ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t);
 void             ffhip_sws_freeContext(FFHipSwsContext *c);
 /** 1 when the context's banks run on the register-resident column-walking kernel (4-tap x 4-tap banks
  *  whose 4-column groups read one 8-byte source span; sws_colwalk.hip), 0 when they take the general

@@ -60,6 +60,9 @@ void ffo_sws_range_constants(int src_range, int dst_depth, uint32_t *lum_coeff, 
 void ffo_yuv2rgb_luts_init(FfoYuv2RgbLuts *l, const FfoYuv2RgbCoeffs *k);
 int  ffo_yuv420p_to_rgb24(const FfoYuv2RgbLuts *l, int width, const uint8_t *const src[3], const int srcStride[3],
                           int srcSliceY, int srcSliceH, uint8_t *dst, int dstStride, int bgr);
+/* the converter's 4:2:2 / source-alpha / planar-gbrp forms (layout 6: dst = {G, B, R} planes) */
+int  ffo_yuv2rgb_unscaled(const FfoYuv2RgbLuts *l, int width, const uint8_t *const src[4], const int srcStride[4], int srcSliceY,
+                          int srcSliceH, uint8_t *const dst[3], const int dstStride[3], int layout, int c422, int alpha);
 void ffo_hscale8to15(int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *pos, int fs);
 void ffo_yuv2planeX8(const int16_t *filter, int fs, const int16_t *const *src, uint8_t *dest, int dstW,
                      const uint8_t *dither, int offset);

@@ -95,6 +95,43 @@ int ffo_yuv420p_to_rgb24(const FfoYuv2RgbLuts *l, int width, const uint8_t *cons
     return srcSliceH;
 }
 
+/*
+ * The table converter's other forms (ff_yuv2rgb_get_func_ptr(), libswscale/yuv2rgb.c:562-676):
+ *   c422   YUV422FUNC (yuv2rgb.c:238-320): pu_2 = pu_1 + srcStride[1] — luma row y + 1 takes chroma row y + 1, rows are indexed by y
+ *          (YUV2RGBFUNC :154-155: src[1] + (y >> !yuv422) * srcStride[1])
+ *   alpha  yuva2rgba_c / yuva2argb_c (:524-529; PUTRGBA :88-93): the 32-bit pixel is r[Y] + g[Y] + b[Y] + (pa[i] << abase) with tables
+ *          built WITHOUT the 255 (needAlpha, :943-966) — i.e. the alpha byte is the source's sample; src[3] / srcStride[3]
+ *   layout 6: yuv420p_gbrp_c / yuv422p_gbrp_c (:533, 553; PUTGBRP :127-135): dst[0] = G, dst[1] = B, dst[2] = R planes
+ * Same width rule as above (8 / 4 / 2-pixel groups: an odd trailing column is never written).
+ */
+int ffo_yuv2rgb_unscaled(const FfoYuv2RgbLuts *l, int width, const uint8_t *const src[4], const int srcStride[4], int srcSliceY,
+                         int srcSliceH, uint8_t *const dst[3], const int dstStride[3], int layout, int c422, int alpha)
+{
+    const int npairs = (width >> 3) * 4 + ((width & 4) ? 2 : 0) + ((width & 2) ? 1 : 0);
+    const int bp = layout == 6 ? 1 : px_bytes(layout);
+    for (int y = 0; y < srcSliceH; y++) {
+        const int crow = c422 ? y : y >> 1;
+        const uint8_t *py = src[0] + (ptrdiff_t)y * srcStride[0];
+        const uint8_t *pu = src[1] + (ptrdiff_t)crow * srcStride[1];
+        const uint8_t *pv = src[2] + (ptrdiff_t)crow * srcStride[2];
+        const uint8_t *pa = alpha ? src[3] + (ptrdiff_t)y * srcStride[3] : NULL;
+        uint8_t *d = dst[0] + (ptrdiff_t)(y + srcSliceY) * dstStride[0];
+        for (int x = 0; x < 2 * npairs; x++) {
+            const int U = pu[x >> 1], V = pv[x >> 1], Y = py[x];
+            if (layout == 6) {
+                d[x] = l->ramp[l->gU[U + HEADROOM] + l->gV[V + HEADROOM] + Y];
+                dst[1][(ptrdiff_t)(y + srcSliceY) * dstStride[1] + x] = l->ramp[l->bU[U + HEADROOM] + Y];
+                dst[2][(ptrdiff_t)(y + srcSliceY) * dstStride[2] + x] = l->ramp[l->rV[V + HEADROOM] + Y];
+                continue;
+            }
+            put_rgb(d + bp * x, l, Y, U, V, layout);
+            if (pa && layout >= 2)
+                d[bp * x + (layout == 2 || layout == 4 ? 0 : 3)] = pa[x];
+        }
+    }
+    return srcSliceH;
+}
+
 /* hScale8To15_c: libswscale/swscale.c:128-142 */
 void ffo_hscale8to15(int16_t *dst, int dstW, const uint8_t *src, const int16_t *filter, const int32_t *pos, int fs)
 {

@@ -17,6 +17,8 @@
 void *ffref_sws_create(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt, int flags, int threads);
 void *ffref_sws_create_ranges(int srcW, int srcH, int srcFmt, int dstW, int dstH, int dstFmt, int flags, int threads, int src_range, int dst_range);
 void  ffref_sws_free(void *ctx);
+int   ffref_sws_set_colorspace(void *ctx, int cs, int src_range, int brightness, int contrast, int saturation);
+void  ffref_sws_coefficients(int cs, int out[4]);
 int   ffref_sws_scale(void *ctx, const uint8_t *const src[], const int srcStride[], int y, int h,
                       uint8_t *const dst[], const int dstStride[]);
 /* which: 0 hLum 1 hChr 2 vLum 3 vChr.  Returns filter size; *n = number of output samples */

@@ -69,6 +69,14 @@ void *ffref_sws_create_ranges(int srcW, int srcH, int srcFmt, int dstW, int dstH
     return sws;
 }
 void ffref_sws_free(void *ctx) { sws_freeContext(ctx); }
+/* sws_setColorspaceDetails() on the live context: matrix row `cs` (SWS_CS_*) for the source, the default row for the target */
+int ffref_sws_set_colorspace(void *ctx, int cs, int src_range, int brightness, int contrast, int saturation)
+{
+    return sws_setColorspaceDetails(ctx, sws_getCoefficients(cs), src_range, sws_getCoefficients(SWS_CS_DEFAULT), 0, brightness, contrast,
+                                    saturation);
+}
+/* the four ints of sws_getCoefficients(cs) (libswscale/yuv2rgb.c:47-66): what c->srcColorspaceTable holds */
+void ffref_sws_coefficients(int cs, int out[4]) { memcpy(out, sws_getCoefficients(cs), 4 * sizeof(int)); }
 int ffref_sws_scale(void *ctx, const uint8_t *const src[], const int srcStride[], int y, int h,
                     uint8_t *const dst[], const int dstStride[])
 {

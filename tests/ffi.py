@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libffref.so")
 
-PIX = {"yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "yuva420p": 33, "yuva422p": 78, "yuva444p": 79, "yuvj420p": 12, "yuvj422p": 13, "yuvj444p": 14, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
-RGB_LAYOUT = {2: 0, 3: 1, 25: 2, 26: 3, 27: 4, 28: 5}   # AVPixelFormat -> the oracle's packed layout number
+PIX = {"gbrp": 71, "yuv420p": 0, "yuv422p": 4, "yuv444p": 5, "yuva420p": 33, "yuva422p": 78, "yuva444p": 79, "yuvj420p": 12, "yuvj422p": 13, "yuvj444p": 14, "rgb24": 2, "bgr24": 3, "nv12": 23, "nv21": 24, "argb": 25, "rgba": 26, "abgr": 27, "bgra": 28}
+RGB_LAYOUT = {2: 0, 3: 1, 25: 2, 26: 3, 27: 4, 28: 5, 71: 6}   # AVPixelFormat -> the oracle's packed layout number
 SWS_BICUBIC, SWS_BILINEAR, SWS_POINT, SWS_AREA, SWS_BICUBLIN = 4, 2, 0x10, 0x20, 0x40
 SWS_ACCURATE_RND, SWS_BITEXACT = 0x40000, 0x80000
 
@@ -74,6 +74,8 @@ def oracle():
         L.ffo_yuv2rgb_luts_init.argtypes = [C.POINTER(OLuts), C.POINTER(OYuv2RgbCoeffs)]
         L.ffo_yuv420p_to_rgb24.argtypes = [C.POINTER(OLuts), C.c_int, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int,
                                            C.c_int, u8p, C.c_int, C.c_int]
+        L.ffo_yuv2rgb_unscaled.argtypes = [C.POINTER(OLuts), C.c_int, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                           C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
         L.ffo_hscale8to15.argtypes = [i16p, C.c_int, u8p, i16p, i32p, C.c_int]
         L.ffo_yuv2planeX8.argtypes = [i16p, C.c_int, C.POINTER(i16p), u8p, C.c_int, u8p, C.c_int]
         L.ffo_yuv2plane1_8.argtypes = [i16p, u8p, C.c_int, u8p, C.c_int]
@@ -265,6 +267,9 @@ def ref():
         L.ffref_sws_create_ranges.restype = C.c_void_p
         L.ffref_sws_free.argtypes = [C.c_void_p]
         L.ffref_sws_free.restype = None
+        L.ffref_sws_set_colorspace.argtypes = [C.c_void_p] + [C.c_int] * 5
+        L.ffref_sws_coefficients.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.ffref_sws_coefficients.restype = None
         L.ffref_sws_scale.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                       C.POINTER(u8p), C.POINTER(C.c_int)]
         if hasattr(L, "ffref_h264_idct_batch"):
@@ -499,4 +504,6 @@ def alloc_frame(fmt, w, h, rng=None, pad=0):
         return [mk(h, w), mk(ch, cw), mk(ch, cw)]
     if fmt in (PIX["nv12"], PIX["nv21"]):
         return [mk(h, w), mk(ch, 2 * cw)]
+    if fmt == PIX["gbrp"]:
+        return [mk(h, w), mk(h, w), mk(h, w)]
     return [mk(h, (3 if fmt in (PIX["rgb24"], PIX["bgr24"]) else 4) * w)]

@@ -15,7 +15,7 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "checkasm_hip")
 
 # the tables libffhip replaces (include/ffhip.h) and the checkasm test that covers each
 TESTS = ["h264dsp", "h264qpel", "h264chroma", "h264pred", "motion", "hevc_add_res", "hevc_idct", "hevc_deblock", "hevc_dequant",
-         "hevc_pel", "hevc_sao", "vp9dsp", "float_dsp", "av_tx", "sw_scale", "sw_ops"]
+         "hevc_pel", "hevc_sao", "vp9dsp", "float_dsp", "av_tx", "sw_scale", "sw_ops", "sw_yuv2rgb"]
 
 
 def run(test, seed=1):
@@ -35,3 +35,18 @@ def test_reference_checkasm_passes_for_the_hip_flag(test):
     m = re.search(r"all (\d+) tests passed", out)
     assert m and int(m.group(1)) > 0, tail
     assert "HIP:" in out or "hip" in out.lower(), tail
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/checkasm_hip not built (needs /root/reference at build time)")
+def test_sw_yuv2rgb_rows_of_the_frame_level_hook():
+    """tests/checkasm/sw_yuv2rgb.c:179-180 checks c->convert_unscaled, the pointer integration/swscale_unscaled_hip.c installs
+    (libswscale/swscale_unscaled.c:2698-2704): the harness must report checked functions for the yuv420p, yuv422p and yuva420p
+    sources — 7 targets x 4 widths each — not "no tests to perform" (its comparison allows +-3; byte equality is
+    tests/test_gpu_sws_hook.py)"""
+    rc, out = run("sw_yuv2rgb")
+    assert rc == 0, out[-2000:]
+    assert "no tests to perform" not in out, out[-2000:]
+    m = re.search(r"all (\d+) tests passed", out)
+    assert m and int(m.group(1)) >= 3 * 7 * 4, out[-2000:]
+    for name in ("yuv420p", "yuv422p", "yuva420p"):
+        assert re.search(r"sw_yuv2rgb\.%s\s.*OK" % name, out) or re.search(r"%s\b.*\[OK\]" % name, out), out[-2000:]

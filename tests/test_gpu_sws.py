@@ -67,6 +67,74 @@ def test_unscaled_yuv420p_rgb24(w, h, pad, dst):
     ctx.close()
 
 
+FORM_CASES = [(sf, df) for sf in ("yuv422p", "yuva420p") for df in ("rgb24", "bgr24", "argb", "rgba", "abgr", "bgra", "gbrp")] + [("yuv420p", "gbrp")]
+
+
+@pytest.mark.parametrize("w,h,pad,n", [(64, 16, 0, 1), (1920, 1080, 0, 2), (354, 10, 3, 3), (30, 4, 1, 1), (2, 2, 0, 1)])
+@pytest.mark.parametrize("sf,df", FORM_CASES)
+def test_unscaled_converter_forms(sf, df, w, h, pad, n):
+    """the table converter's 4:2:2 sources (each luma row with the chroma row of its own), yuva420p (the alpha plane into the alpha byte
+    of the 32-bit targets, unread otherwise) and the planar gbrp target (yuv2rgb.c:238-320, 524-553) — batch face, host face, slices"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    O = ffi.oracle()
+    rng = np.random.default_rng(w + h + len(sf) + 3 * len(df))
+    src = ffi.alloc_frame(PIX[sf], w, h, rng, pad=pad)
+    luts = ffi.OLuts()
+    k = ffi.OYuv2RgbCoeffs(*[ffi.DEFAULT_COEFFS[c] for c in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
+    O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(k))
+    want = ffi.alloc_frame(PIX[df], w, h)
+    alpha = sf == "yuva420p" and df in ("argb", "rgba", "abgr", "bgra")
+    sp, ss = ffi.planes(src)
+    O.ffo_yuv2rgb_unscaled(C.byref(luts), w, sp, ss, 0, h, ffi.planes(want)[0], ffi.planes(want)[1], ffi.RGB_LAYOUT[PIX[df]],
+                           int(sf == "yuv422p"), int(alpha))
+    ctx = S.SwsContext(w, h, PIX[sf], w, h, PIX[df], S.SWS_BICUBIC)
+    dsrc = _upload(src if alpha or sf != "yuva420p" else src[:3], n=n)
+    ddst = [torch.zeros((n, a.shape[0], a.shape[1] + pad), dtype=torch.uint8, device="cuda:0") for a in want]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        for p, a in enumerate(want):
+            assert np.array_equal(ddst[p][f, :, :a.shape[1]].cpu().numpy(), a), (f, p)
+    # the SwsFunc face on host pointers: the frame, then 2-line aligned slices
+    hd = [np.zeros((a.shape[0], a.shape[1] + pad), np.uint8) for a in want]
+    assert ctx.scale(src, hd) == h
+    for p, a in enumerate(want):
+        assert np.array_equal(hd[p][:, :a.shape[1]], a)
+    if h >= 8:
+        hd2 = [np.zeros_like(a) for a in hd]
+        vs = 0 if sf == "yuv422p" else 1
+        for y0, hh in ((0, 2), (2, 4), (6, h - 6)):
+            sl = [src[0][y0:], src[1][y0 >> vs:], src[2][y0 >> vs:]] + ([src[3][y0:]] if len(src) > 3 else [])
+            assert ctx.scale(sl, hd2, y0, hh) == hh
+        for p, a in enumerate(want):
+            assert np.array_equal(hd2[p][:, :a.shape[1]], a)
+    ctx.close()
+
+
+def test_unscaled_colorspace_set_on_a_live_context():
+    """sws_setColorspaceDetails() after the init (libswscale/utils.c:848-1000): ffhip_sws_yuv2rgb_coeffs + ffhip_sws_set_yuv2rgb"""
+    from ffmpeg_amd import swscale as S, _lib
+    torch = _torch()
+    L = _lib.lib()
+    w, h = 640, 360
+    rng = np.random.default_rng(9)
+    src = ffi.alloc_frame(PIX["yuv420p"], w, h, rng)
+    ctx = S.SwsContext(w, h, PIX["yuv420p"], w, h, PIX["rgb24"], S.SWS_BICUBIC)
+    ddst = [torch.zeros((1, h, 3 * w), dtype=torch.uint8, device="cuda:0")]
+    bt709 = (C.c_int * 4)(117504, 138453, 13954, 34903)   # ff_yuv2rgb_coeffs[SWS_CS_ITU709], libswscale/yuv2rgb.c:47-66
+    for inv, full, b, c, s in ((bt709, 1, 0, 1 << 16, 1 << 16), (bt709, 0, 3 << 11, (1 << 16) + 5000, (1 << 16) - 9000)):
+        t = _lib.SwsTables()
+        _lib.check(L.ffhip_sws_yuv2rgb_coeffs(C.byref(t), inv, full, b, c, s))
+        _lib.check(L.ffhip_sws_set_yuv2rgb(ctx._c, C.byref(t)))
+        coeffs = dict(cy=t.yuv2rgb_cy, oy=t.yuv2rgb_oy, crv=t.yuv2rgb_crv, cbu=t.yuv2rgb_cbu, cgu=t.yuv2rgb_cgu, cgv=t.yuv2rgb_cgv,
+                      yoffs=t.yuv2rgb_yoffs)
+        want = _oracle_unscaled(src, w, h, 0, coeffs)
+        ctx.scale_batch(_upload(src), ddst)
+        assert np.array_equal(ddst[0][0].cpu().numpy(), want)
+    ctx.close()
+
+
 def test_unscaled_exhaustive_uv():
     """all 65536 (U,V) pairs against a moving Y ramp"""
     from ffmpeg_amd import swscale as S

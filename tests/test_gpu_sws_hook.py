@@ -1,0 +1,30 @@
+"""The frame-level SwsFunc hook of the FFmpeg-side patch (integration/swscale_unscaled_hip.c) as a caller of libswscale's public API
+meets it: oracle/_ref/sws_unscaled_hip_test is the reference's libavutil + libswscale (compiled where they lie) with the `hip` arch's
+hooks behind their inits, linked with libffhip.so.  It runs sws_getContext() / sws_scale() / sws_setColorspaceDetails() /
+sws_freeContext() on host frames with cpu flags 0 and with AV_CPU_FLAG_HIP forced and compares the pictures byte for byte (guard bytes
+included): yuv420p / yuv422p / yuva420p to rgb24, bgr24, argb, rgba, abgr, bgra, gbrp; whole frames (BASELINE configs[0]: yuv420p ->
+rgb24 1920x1080 first), slices, bottom-up pictures, a colour matrix / range / brightness / contrast / saturation set after the init;
+and two pairs the hook must leave with the C converter.  The reference's own harness on the same pointer: test_gpu_checkasm.py
+(sw_yuv2rgb)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "sws_unscaled_hip_test")
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/sws_unscaled_hip_test not built (needs /root/reference at build time)")
+def test_sws_scale_on_host_frames_goes_through_the_hip_swsfunc():
+    r = subprocess.run([EXE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, cwd="/tmp")
+    tail = "\n".join(r.stdout.splitlines()[-40:])
+    assert r.returncode == 0, tail
+    lines = r.stdout.splitlines()
+    assert lines[0].startswith("OK  ") and "yuv420p -> rgb24 1920x1080" in lines[0] and "hip SwsFunc == C" in lines[0], lines[0]
+    m = re.search(r"(\d+) cases, 0 failed", r.stdout)
+    assert m and int(m.group(1)) >= 50, tail
+    assert sum("left to C" in l for l in lines) == 2, tail
+    assert not [l for l in lines if l.startswith("FAIL")], tail
