@@ -185,11 +185,11 @@ SCALE_CASES = [
     ("yuv422p", 128, 72, "yuv444p", 128, 72, ffi.SWS_BICUBIC, 0),     # same size: only the chroma planes are scaled
     ("yuv444p", 1920, 1080, "yuv444p", 1280, 720, ffi.SWS_BICUBIC, 0),
     # 4:2:2 sources to packed RGB (round 3): chroma banks from the source's own chroma plane; equal sizes = one-tap banks
-    ("yuv422p", 64, 16, "rgb24", 64, 16, ffi.SWS_BICUBIC, 0),
+    ("yuv422p", 64, 16, "rgb24", 64, 16, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),   # (without ACCURATE_RND: the table converter, test_unscaled_converter_forms)
     ("yuv422p", 176, 144, "rgb24", 352, 288, ffi.SWS_BICUBIC, 0),
     ("yuv422p", 176, 144, "bgra", 176, 144, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
     ("yuv422p", 352, 288, "argb", 120, 90, ffi.SWS_BILINEAR, 3),
-    ("yuv422p", 1920, 1080, "rgb24", 1920, 1080, ffi.SWS_BICUBIC, 0),
+    ("yuv422p", 1920, 1080, "rgb24", 1920, 1080, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0),
     ("yuv422p", 960, 540, "bgr24", 1920, 1080, ffi.SWS_BICUBIC, 0),
     # SWS_FULL_CHR_H_INT (0x2000) on packed RGB targets: asked for, or forced by a 4:4:4 source or an odd width (utils.c:1270-1290):
     # a chroma sample per pixel and the yuv2rgb_full_{1,2,X} writers (output.c:1998-2310)
