@@ -1,0 +1,346 @@
+/*
+ * ffref_shim_h264dec.c — ours, TEST INFRASTRUCTURE ONLY.  The reference's WHOLE H.264 decoder (h264dec.c, h264_slice.c, h264_cavlc.c,
+ * h264_cabac.c, h264_ps.c, h264_refs.c, h264_picture.c, h264_direct.c, h264_mvpred.h, h2645_parse.c ... compiled where they lie by
+ * oracle/refbuild/Makefile, target `h264dec`) driven through libavcodec's public API — avcodec_open2() / avcodec_send_packet() /
+ * avcodec_receive_frame() — on access units a test-side bitstream writer made (tests/h264_bitstream.py), in two modes:
+ *
+ *   plain   the decoder as it is: the C dsp tables reconstruct and filter every macroblock in place;
+ *   record  the FFmpeg-side patch of integration/avcodec_h264_picture_hip.c at its two call sites in h264_slice.c:
+ *             decode_slice():  ff_h264_hl_decode_mb(h, sl)            (h264_slice.c:2632, 2648, 2703, 2713)  -> ff_h264_hip_hl_decode_mb()
+ *             loop_filter():   ff_h264_filter_mb_fast() / ff_h264_filter_mb()  (h264_slice.c:2499-2505)       -> ff_h264_hip_filter_mb()
+ *           h264_slice.c is compiled unchanged with the three callee names re-pointed at the hooks below (-D...: the Makefile), which
+ *           is what `if (h->hip_recorder) ... else ...` at those lines amounts to.  Everything before the calls — slice headers,
+ *           CAVLC, h264_mvpred.h, fill_decode_caches(), fill_filter_caches(), reference lists, the picture buffer — is the decoder's
+ *           own, untouched; so is ff_h264_hl_decode_mb() / ff_h264_filter_mb() themselves, which the recorder runs over its recording
+ *           dsp members.  A picture (a frame, or one field) becomes one libffhip picture object; when the decoder moves on to the
+ *           next picture (or is drained) the finished one is handed to the `flush` callback of the test, which executes its lists on
+ *           the picture buffer — oracle/emul_h264_picture.cpp on the host arena (CPU tier), ffhip_h264_picture_flush() on a device
+ *           mirror of the arena (GPU tier) — before any later picture's motion compensation can refer to it.
+ *
+ * Frames come from ONE arena (get_buffer2 below): the recorder turns addresses into offsets from a single base, which is what a
+ * decoded-picture buffer living in one hip allocation gives the real patch.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "libavcodec/avcodec.h"
+#include "libavcodec/codec_internal.h"
+#include "libavcodec/h264dec.h"
+#include "libavcodec/h264_ps.h"
+#include "libavutil/buffer.h"
+#include "libavutil/frame.h"
+#include "libavutil/imgutils.h"
+#include "libavutil/mem.h"
+#include "libavutil/pixdesc.h"
+
+#include "ffhip.h"
+#include "avcodec_h264_picture_hip.h"
+
+#define MAX_OUT 64
+
+/* dst_off[pl]: the picture's planes as byte offsets into the arena (a bottom field: one line down); stride[pl]: the picture's line sizes
+ * (a field: twice the frame's).  Returns 0 or < 0. */
+typedef int (*ffref_h264_flush_fn)(void *opaque, void *pic, const int64_t dst_off[3], const int stride[3], int mb_w, int mb_h, int field);
+
+typedef struct FFRefH264Stream {
+    AVCodecContext *avctx;
+    AVPacket *pkt;
+    int record;
+    uint8_t *arena;
+    size_t arena_size, arena_used;
+    ffref_h264_flush_fn flush;
+    void *flush_opaque;
+    /* the picture being recorded */
+    FFHipH264Recorder rec;
+    FFHipH264Picture *pic;
+    const H264Picture *cur_ptr;
+    int cur_structure, cur_field, cur_mb_w, cur_mb_h;
+    int64_t cur_off[3];
+    int cur_stride[3];
+    /* output */
+    AVFrame *out[MAX_OUT];
+    int nout;
+    /* counters */
+    long pictures, mbs_hl, mbs_filter, refused, errors, decode_errors;
+    int first_error;
+} FFRefH264Stream;
+
+extern const FFCodec ff_h264_decoder;
+
+static void arena_noop_free(void *opaque, uint8_t *data) { (void)opaque; (void)data; }
+
+/* AVCodecContext.get_buffer2: planes cut from the arena, every frame of a stream with the same line sizes, no border (the decoder
+ * emulates edges: h264_mb.c:229-260) */
+static int arena_get_buffer(AVCodecContext *avctx, AVFrame *f, int flags)
+{
+    FFRefH264Stream *s = avctx->opaque;
+    const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(f->format);
+    const int ps = d->comp[0].depth > 8;
+    (void)flags;
+    for (int pl = 0; pl < 3; pl++) {
+        const int w = pl ? AV_CEIL_RSHIFT(FFALIGN(f->width, 16), d->log2_chroma_w) : FFALIGN(f->width, 16);
+        const int h = pl ? AV_CEIL_RSHIFT(FFALIGN(f->height, 32), d->log2_chroma_h) : FFALIGN(f->height, 32);
+        const int ls = FFALIGN((w << ps) + 32, 64);
+        const size_t sz = (size_t)ls * h + 256;
+        if (s->arena_used + sz > s->arena_size)
+            return AVERROR(ENOMEM);
+        f->data[pl] = s->arena + s->arena_used;
+        f->linesize[pl] = ls;
+        f->buf[pl] = av_buffer_create(f->data[pl], sz, arena_noop_free, NULL, 0);
+        if (!f->buf[pl])
+            return AVERROR(ENOMEM);
+        s->arena_used += FFALIGN(sz, 256);
+    }
+    f->extended_data = f->data;
+    return 0;
+}
+
+static int flush_current(FFRefH264Stream *s)
+{
+    int r = 0;
+    if (!s->pic)
+        return 0;
+    if (s->rec.error < 0) {
+        r = s->rec.error;
+    } else if (s->flush) {
+        r = s->flush(s->flush_opaque, s->pic, s->cur_off, s->cur_stride, s->cur_mb_w, s->cur_mb_h, s->cur_field);
+    }
+    if (r < 0) {
+        s->errors++;
+        if (!s->first_error)
+            s->first_error = r;
+    }
+    ffhip_h264_picture_free(&s->pic);
+    s->pic = NULL;
+    s->cur_ptr = NULL;
+    return r;
+}
+
+/* the decoder has started on a picture the recorder has not seen: the finished one is executed, a picture object is made for the new one */
+static int begin_picture(FFRefH264Stream *s, const H264Context *h, H264SliceContext *sl)
+{
+    const SPS *sps = h->ps.sps;
+    const int field = FIELD_PICTURE(h) && !FRAME_MBAFF(h);
+    const uint8_t *base[3] = { s->arena, s->arena, s->arena };
+    int r;
+    flush_current(s);
+    r = ffhip_h264_picture_create_fmt(&s->pic, h->mb_width, h->mb_height >> field, sps->bit_depth_luma, sps->chroma_format_idc ? sps->chroma_format_idc : 1);
+    if (r < 0 || !s->pic) {
+        s->errors++;
+        if (!s->first_error)
+            s->first_error = r < 0 ? r : FFHIP_ENOMEM;
+        s->pic = NULL;
+        return -1;
+    }
+    ffhip_h264_picture_begin(s->pic);
+    /* the dsp tables may have been made anew for this picture's format (h264_slice.c init_dimensions / h264_init_ps) */
+    ff_h264_hip_recorder_install((H264Context *)h);
+    ff_h264_hip_recorder_begin(&s->rec, s->pic, h, sl, base);
+    s->cur_ptr = h->cur_pic_ptr;
+    s->cur_structure = h->picture_structure;
+    s->cur_field = field;
+    s->cur_mb_w = h->mb_width;
+    s->cur_mb_h = h->mb_height >> field;
+    for (int pl = 0; pl < 3; pl++) {
+        s->cur_off[pl] = s->rec.cur[pl] - s->arena;
+        s->cur_stride[pl] = (int)s->rec.linesize[pl];
+    }
+    s->pictures++;
+    return 0;
+}
+
+static FFRefH264Stream *session_of(const H264Context *h)
+{
+    FFRefH264Stream *s = h->avctx->opaque;
+    return s && s->record ? s : NULL;
+}
+
+static int ready(FFRefH264Stream *s, const H264Context *h, H264SliceContext *sl)
+{
+    if (s->cur_ptr != h->cur_pic_ptr || s->cur_structure != h->picture_structure || !s->pic)
+        if (begin_picture(s, h, sl) < 0)
+            return 0;
+    /* a later slice of the picture: its own reference lists / scratch buffers are the slice context's, which begin() bound once; the
+     * recorder reads them through r->sl per macroblock */
+    return 1;
+}
+
+static void note(FFRefH264Stream *s, int r)
+{
+    if (r < 0) {
+        if (r == FFHIP_ENOSYS)
+            s->refused++;
+        s->errors++;
+        if (!s->first_error)
+            s->first_error = r;
+    }
+}
+
+/* ---- the three names h264_slice.c calls (see the Makefile's -D for that file) ---- */
+void ffref_hook_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
+{
+    FFRefH264Stream *s = session_of(h);
+    if (!s) {
+        ff_h264_hl_decode_mb(h, sl);
+        return;
+    }
+    if (!ready(s, h, sl))
+        return;
+    s->mbs_hl++;
+    note(s, ff_h264_hip_hl_decode_mb(&s->rec, h, sl));
+}
+
+void ffref_hook_filter_mb_fast(const H264Context *h, H264SliceContext *sl, int mb_x, int mb_y, uint8_t *img_y, uint8_t *img_cb, uint8_t *img_cr,
+                               unsigned int linesize, unsigned int uvlinesize)
+{
+    FFRefH264Stream *s = session_of(h);
+    if (!s) {
+        ff_h264_filter_mb_fast(h, sl, mb_x, mb_y, img_y, img_cb, img_cr, linesize, uvlinesize);
+        return;
+    }
+    if (!ready(s, h, sl))
+        return;
+    s->mbs_filter++;
+    note(s, ff_h264_hip_filter_mb(&s->rec, h, sl, mb_x, mb_y));
+}
+
+void ffref_hook_filter_mb(const H264Context *h, H264SliceContext *sl, int mb_x, int mb_y, uint8_t *img_y, uint8_t *img_cb, uint8_t *img_cr,
+                          unsigned int linesize, unsigned int uvlinesize)
+{
+    FFRefH264Stream *s = session_of(h);
+    if (!s) {
+        ff_h264_filter_mb(h, sl, mb_x, mb_y, img_y, img_cb, img_cr, linesize, uvlinesize);
+        return;
+    }
+    if (!ready(s, h, sl))
+        return;
+    s->mbs_filter++;
+    note(s, ff_h264_hip_filter_mb(&s->rec, h, sl, mb_x, mb_y));
+}
+
+/* ---- the driver ---- */
+FFRefH264Stream *ffref_h264stream_open(int record, size_t arena_bytes)
+{
+    FFRefH264Stream *s = av_mallocz(sizeof(*s));
+    if (!s)
+        return NULL;
+    s->record = record;
+    s->arena_size = arena_bytes;
+    s->arena = av_malloc(arena_bytes);
+    s->pkt = av_packet_alloc();
+    s->avctx = avcodec_alloc_context3(&ff_h264_decoder.p);
+    if (!s->arena || !s->pkt || !s->avctx)
+        return NULL;
+    memset(s->arena, 0x55, arena_bytes);
+    s->avctx->opaque = s;
+    s->avctx->get_buffer2 = arena_get_buffer;
+    s->avctx->thread_count = 1;
+    s->avctx->flags |= AV_CODEC_FLAG_OUTPUT_CORRUPT;
+    s->avctx->err_recognition = AV_EF_EXPLODE | AV_EF_CRCCHECK | AV_EF_BITSTREAM;
+    if (avcodec_open2(s->avctx, &ff_h264_decoder.p, NULL) < 0)
+        return NULL;
+    return s;
+}
+
+void ffref_h264stream_set_flush(FFRefH264Stream *s, ffref_h264_flush_fn fn, void *opaque)
+{
+    s->flush = fn;
+    s->flush_opaque = opaque;
+}
+
+static int drain_frames(FFRefH264Stream *s)
+{
+    for (;;) {
+        AVFrame *f = av_frame_alloc();
+        int r = avcodec_receive_frame(s->avctx, f);
+        if (r < 0) {
+            av_frame_free(&f);
+            return r == AVERROR(EAGAIN) || r == AVERROR_EOF ? 0 : r;
+        }
+        if (f->decode_error_flags || (f->flags & AV_FRAME_FLAG_CORRUPT))
+            s->decode_errors++;
+        if (s->nout < MAX_OUT)
+            s->out[s->nout++] = f;
+        else
+            av_frame_free(&f);
+    }
+}
+
+/* one access unit (Annex B bytes); size 0: end of stream — the decoder is drained and the last picture executed.  0 or an AVERROR. */
+int ffref_h264stream_decode(FFRefH264Stream *s, const uint8_t *au, int size)
+{
+    int r;
+    if (size > 0) {
+        if (av_new_packet(s->pkt, size) < 0)
+            return AVERROR(ENOMEM);
+        memcpy(s->pkt->data, au, size);
+        r = avcodec_send_packet(s->avctx, s->pkt);
+        av_packet_unref(s->pkt);
+    } else {
+        r = avcodec_send_packet(s->avctx, NULL);
+    }
+    if (r < 0) {
+        s->decode_errors++;
+        return r;
+    }
+    r = drain_frames(s);
+    if (size <= 0 && s->record)
+        flush_current(s);
+    return r;
+}
+
+int ffref_h264stream_nframes(const FFRefH264Stream *s) { return s->nout; }
+
+/* output frame i (output order): plane offsets into the arena, line sizes, size in samples, bit depth */
+int ffref_h264stream_frame(const FFRefH264Stream *s, int i, int64_t off[3], int linesize[3], int *w, int *h, int *bit_depth)
+{
+    const AVFrame *f;
+    if (i < 0 || i >= s->nout)
+        return -1;
+    f = s->out[i];
+    for (int pl = 0; pl < 3; pl++) {
+        off[pl] = f->data[pl] - s->arena;
+        linesize[pl] = f->linesize[pl];
+    }
+    *w = f->width;
+    *h = f->height;
+    *bit_depth = av_pix_fmt_desc_get(f->format)->comp[0].depth;
+    return 0;
+}
+
+uint8_t *ffref_h264stream_arena(const FFRefH264Stream *s, size_t *used)
+{
+    if (used)
+        *used = s->arena_used;
+    return s->arena;
+}
+
+/* counters: 0 pictures recorded, 1 hl_decode_mb calls recorded, 2 filter calls recorded, 3 refused (FFHIP_ENOSYS), 4 recorder / flush
+ * errors, 5 the first such error, 6 frames the decoder flagged as damaged */
+long ffref_h264stream_stat(const FFRefH264Stream *s, int what)
+{
+    switch (what) {
+    case 0: return s->pictures;
+    case 1: return s->mbs_hl;
+    case 2: return s->mbs_filter;
+    case 3: return s->refused;
+    case 4: return s->errors;
+    case 5: return s->first_error;
+    case 6: return s->decode_errors;
+    }
+    return -1;
+}
+
+void ffref_h264stream_close(FFRefH264Stream *s)
+{
+    if (!s)
+        return;
+    if (s->pic)
+        ffhip_h264_picture_free(&s->pic);
+    for (int i = 0; i < s->nout; i++)
+        av_frame_free(&s->out[i]);
+    avcodec_free_context(&s->avctx);
+    av_packet_free(&s->pkt);
+    av_free(s->arena);
+    av_free(s);
+}

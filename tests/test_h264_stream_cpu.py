@@ -1,0 +1,61 @@
+"""The reference's WHOLE H.264 decoder with the `hip` recorder at its two call sites, on the CPU tier.
+
+tests/h264_bitstream.py writes multi-picture CAVLC streams (syntax elements only: I_PCM, Intra16x16, Intra4x4, P_L0_16x16 / 16x8 / 8x16,
+P_8x8 with every sub-type, P_Skip, motion vector differences that carry blocks far outside the picture, residual blocks with escapes, several
+slices per picture, disable_deblocking_filter_idc 0 / 1 / 2, field pictures).  oracle/_ref/libffref_h264dec.so — h264dec.c,
+h264_slice.c, h264_cavlc.c, h264_mvpred.h, h264_refs.c, h264_picture.c ... compiled where they lie — decodes each stream twice through
+avcodec_send_packet() / avcodec_receive_frame():
+  plain:   the decoder as it is;
+  record:  decode_slice()'s ff_h264_hl_decode_mb() and loop_filter()'s ff_h264_filter_mb_fast() / ff_h264_filter_mb() replaced by
+           ff_h264_hip_hl_decode_mb() / ff_h264_hip_filter_mb() (integration/avcodec_h264_picture_hip.c); a finished picture's lists are
+           executed on the decoder's own picture buffer by oracle/emul_h264_picture.cpp before the next picture refers to it.
+The per-macroblock state (mv_cache, ref_cache, non_zero_count_cache, neighbour types, qp tables, reference lists) is derived by the
+decoder from the bitstream — not written by a test.  Every output frame must be identical, sample for sample."""
+import numpy as np
+import pytest
+
+import h264_stream_driver as D
+
+pytestmark = pytest.mark.skipif(not D.have(), reason="oracle/_ref/libffref_h264dec.so or oracle/libffemul.so not built")
+
+
+def _both(aus):
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and st0["pictures"] == 0 and len(plain) > 0
+    rec, st1, counts = D.decode(aus, make_flush=lambda base, size: D.cpu_flush(base))
+    return plain, rec, st1, counts
+
+
+def _check(aus, wstats, min_pictures):
+    plain, rec, st, counts = _both(aus)
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0, st
+    assert st["pictures"] == min_pictures and counts["pictures"] == min_pictures, (st, counts)
+    assert st["mbs_hl"] > 0 and st["mbs_filter"] > 0 and counts["inter_blocks"] > 0 and counts["intra_mbs"] > 0
+    assert len(plain) == len(rec)
+    for i, (a, b) in enumerate(zip(plain, rec)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+    # the pictures are not trivial: the streams move
+    assert any(not np.array_equal(plain[0][0], f[0]) for f in plain[1:])
+    return st, counts
+
+
+@pytest.mark.parametrize("bit_depth", [8, 10])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_i_and_p_pictures(bit_depth, seed):
+    aus, ws = D.stream_ip(bit_depth, seed)
+    st, counts = _check(aus, ws, 5)
+    assert ws["pcm"] and ws["i16"] and ws["i4"] and ws["p16"] and ws["p168"] and ws["p88"] and ws["skip"] and ws["escapes"]
+
+
+@pytest.mark.parametrize("bit_depth", [8, 10])
+@pytest.mark.parametrize("seed", [4, 5])
+def test_several_slices_and_deblocking_modes(bit_depth, seed):
+    aus, ws = D.stream_slices(bit_depth, seed)
+    _check(aus, ws, 5)
+
+
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_field_pictures(bit_depth):
+    aus, ws = D.stream_fields(bit_depth, 6)
+    _check(aus, ws, 6)
