@@ -1,0 +1,88 @@
+"""GPU tier of tests/test_h264_stream_cpu.py: the reference's WHOLE H.264 decoder (oracle/_ref/libffref_h264dec.so) decodes the streams of
+tests/h264_bitstream.py with the `hip` recorder at its two call sites, and every finished picture is executed by
+ffhip_h264_picture_flush() on a DEVICE mirror of the decoder's picture arena — the decoded-picture buffer lives in HBM, later pictures'
+motion compensation reads what earlier flushes wrote there, nothing comes back to the host before the end of the stream.  The
+downloaded pictures must equal the plain decode of the same stream, sample for sample: I / P pictures with one to three references,
+several slices per picture, disable_deblocking_filter_idc 0 / 1 / 2, field pictures (PAFF); 8 and 10 bits."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import h264_stream_driver as D
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not D.have(), reason="oracle/_ref/libffref_h264dec.so not built")]
+
+
+def _gpu_flush_factory():
+    import torch
+    from ffmpeg_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    L = _lib.lib()
+    state = {}
+
+    def make(arena_base, arena_bytes):
+        dev = torch.full((arena_bytes,), 0x55, dtype=torch.uint8, device="cuda:0")
+        state["dev"] = dev
+        counts = {"pictures": 0}
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def flush(opaque, pic, dst_off, stride, mb_w, mb_h, field):
+            d = dev.data_ptr()
+            dp = (C.c_void_p * 3)(*[d + dst_off[i] for i in range(3)])
+            rp = (C.c_void_p * 3)(d, d, d)
+            st = (C.c_int * 3)(stride[0], stride[1], stride[2])
+            counts["pictures"] += 1
+            r = L.ffhip_h264_picture_flush(pic, dp, st, rp, stream)
+            torch.cuda.synchronize()           # the decoder frees the picture object when this returns
+            return r
+        return flush, counts
+
+    def read_back(arena_base, used):
+        host = state["dev"][:used].cpu().numpy()
+        C.memmove(arena_base, host.ctypes.data, used)
+    return make, read_back
+
+
+def _check(aus, npictures):
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) > 0
+    make, read_back = _gpu_flush_factory()
+    got, st, counts = D.decode(aus, make_flush=make, read_back=read_back)
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0, st
+    assert st["pictures"] == npictures == counts["pictures"] and st["mbs_hl"] > 0 and st["mbs_filter"] > 0, (st, counts)
+    assert len(plain) == len(got)
+    for i, (a, b) in enumerate(zip(plain, got)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+
+
+@pytest.mark.parametrize("bit_depth", [8, 10])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_i_and_p_pictures(bit_depth, seed):
+    aus, ws = D.stream_ip(bit_depth, seed)
+    _check(aus, 5)
+
+
+@pytest.mark.parametrize("bit_depth", [8, 10])
+@pytest.mark.parametrize("seed", [4, 5])
+def test_several_slices_and_deblocking_modes(bit_depth, seed):
+    aus, ws = D.stream_slices(bit_depth, seed)
+    _check(aus, 5)
+
+
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_field_pictures(bit_depth):
+    aus, ws = D.stream_fields(bit_depth, 6)
+    _check(aus, 6)
+
+
+def test_a_larger_picture():
+    """CIF-sized pictures: 22 x 18 macroblocks, six pictures, three slices"""
+    import h264_bitstream as B
+    p = B.Params(mb_w=22, mb_h=18, seed=11)
+    w = B.StreamWriter(p)
+    pics = [{"type": "I", "slices": [0, 150], "deblock": [(0, 0, 0), (0, 1, 1)]}]
+    for k in range(1, 6):
+        pics.append({"type": "P", "slices": [0, 100 + 7 * k, 300], "deblock": [(0, 0, 0), (2, -1, 1), (0, 2, -2)], "num_ref": min(k, 3)})
+    _check(w.stream(pics), 6)

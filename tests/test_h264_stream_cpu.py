@@ -59,3 +59,14 @@ def test_several_slices_and_deblocking_modes(bit_depth, seed):
 def test_field_pictures(bit_depth):
     aus, ws = D.stream_fields(bit_depth, 6)
     _check(aus, ws, 6)
+
+
+def test_a_larger_picture():
+    """CIF-sized pictures: 22 x 18 macroblocks, six pictures, three slices"""
+    import h264_bitstream as B
+    p = B.Params(mb_w=22, mb_h=18, seed=11)
+    w = B.StreamWriter(p)
+    pics = [{"type": "I", "slices": [0, 150], "deblock": [(0, 0, 0), (0, 1, 1)]}]
+    for k in range(1, 6):
+        pics.append({"type": "P", "slices": [0, 100 + 7 * k, 300], "deblock": [(0, 0, 0), (2, -1, 1), (0, 2, -2)], "num_ref": min(k, 3)})
+    _check(w.stream(pics), w.stats, 6)
