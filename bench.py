@@ -262,7 +262,8 @@ def extras(torch, dev):
                                "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "frames": n, "ms": round(ms, 4)}
     out["yuv420p_rgb24_4k"]["frac_of_guide_achievable_6290"] = round(gbs / HBM_GUIDE_ACHIEVABLE_GBS, 4)
     # this box's streaming probe at the kernel's own mix (read n / 2, write n: 1.5 B read and 3 B written per pixel) — north_star's 0.70 of
-    # the 8 TB/s peak is 5.6 TB/s of a 1 : 2 mix; the probe says what a plain grid-stride copy of that mix reaches on the box of this run
+    # the 8 TB/s peak is 5.6 TB/s of a 1 : 2 mix; the probe is the best of 24 ways to issue that traffic with no arithmetic at all
+    # (ffhip_membw_probe pattern 4): what the box of this run gives the mix
     g = C.c_double(0)
     if _lib.lib().ffhip_membw_probe(4, 2 << 30, 10, C.byref(g)) == 0:
         out["yuv420p_rgb24_4k"]["box_probe_read1_write2_GB/s"] = round(g.value, 1)
@@ -1388,13 +1389,15 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
 
-    # streaming PROBES of this box (simple grid-stride kernels: read / write / copy / the scaler's 1:4 mix).  They say how this box
-    # compares with others of the pool; they are not roofs — a tuned kernel can beat them — so the achievable yardstick is the
-    # larger of the guide's measured 6.29 TB/s and the best probe, and no fraction of it can exceed 1 by construction of a probe
+    # streaming PROBES of this box: per traffic mix the BEST of a 24-variant sweep of plain streaming kernels (1 / 2 / 8 16-byte accesses in
+    # flight per lane, plain or non-temporal, two grid sizes, grid-stride or XCD-adjacent private slices; ffhip_membw_probe, round 5 —
+    # tools/ubench/membw2.hip is the long form, profiles/r05_membw2.txt its 146 variants on one box), and the runtime's own
+    # hipMemcpyDtoDAsync.  They say what this box gives a kernel with no arithmetic at that mix; the achievable yardstick stays the larger
+    # of the guide's measured 6.29 TB/s and the best probe
     probes, yard = None, HBM_GUIDE_ACHIEVABLE_GBS
     if rank == 0:
         probes = {}
-        for pat, name in ((2, "copy"), (1, "write"), (3, "read1_write4"), (0, "read")):
+        for pat, name in ((2, "copy"), (1, "write"), (3, "read1_write4"), (4, "read1_write2"), (0, "read"), (5, "hipMemcpyDtoDAsync")):
             g = C.c_double(0)
             if _lib.lib().ffhip_membw_probe(pat, 2 << 30, 10, C.byref(g)) == 0:
                 probes[name] = round(g.value, 1)

@@ -291,50 +291,95 @@ void FFHipPerDeviceOnce::leave(bool ok)
     mu.unlock();
 }
 
-/* ---- achievable-bandwidth probe (bench.py: the box's streaming roofs beside the 8 TB/s spec) ---- */
+/* ---- achievable-bandwidth probe (bench.py: the box's streaming roofs beside the 8 TB/s spec) ----
+ * A streaming kernel's rate on these parts depends on how its accesses are issued as much as on the mix (tools/ubench/membw2.hip,
+ * profiles/r05_membw2.txt: 4.0 .. 6.1 TB/s of pure writes, 4.7 .. 5.9 TB/s of copy across 146 variants on one box).  So the probe is a
+ * SWEEP, and its answer the best variant: U = 1, 2 or 8 accesses of 16 bytes in flight per lane before the first dependent store, plain
+ * or non-temporal stores, non-temporal loads, 256 x 4 or 256 x 16 workgroups, grid-stride chunks or one private contiguous slice per
+ * workgroup with the slices of an XCD's workgroups (blockIdx % 8) adjacent; pattern 5 is the runtime's own hipMemcpyDtoDAsync.
+ * A wave-instruction touches 1 KiB, a workgroup's 4 KiB, consecutive instructions consecutive memory: what a row-streaming kernel does. */
 typedef uint32_t bw_u4 __attribute__((ext_vector_type(4)));
-template <int MODE> /* 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p -> 4K scaler's mix), 4 read n/2 + write n (yuv420p -> rgb24's) */
-__global__ __launch_bounds__(256) void k_membw(const bw_u4 *__restrict__ src, bw_u4 *__restrict__ dst, size_t n16, uint32_t *sink)
+/* RD : WR = 1 : K in units of 16 bytes (K = 1 with RD = 0: write-only, WR = 0: read-only) */
+template <int K, int U, int NT, int RD, int WR, int PAT>
+__global__ __launch_bounds__(256) void k_membw(const bw_u4 *__restrict__ src, bw_u4 *__restrict__ dst, size_t n_rd, uint32_t *sink)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
     bw_u4 acc = { 0, 0, 0, 0 };
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        bw_u4 v = { (uint32_t)i, 1, 2, 3 };
-        if (MODE == 0 || MODE == 2)
-            v = src[i];
-        if (MODE == 3 && (i & 3) == 0)
-            v = src[i >> 2];
-        if (MODE == 4 && (i & 1) == 0)
-            v = src[i >> 1];
-        if (MODE == 0)
-            acc += v;
-        else
-            dst[i] = v;
+    const size_t per_block = n_rd / gridDim.x / (256 * U) * (256 * U);
+    const size_t bid = PAT ? (size_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const size_t first = PAT ? bid * per_block : (size_t)blockIdx.x * 256 * U;
+    const size_t last = PAT ? first + per_block : n_rd;
+    const size_t step = PAT ? (size_t)256 * U : (size_t)gridDim.x * 256 * U;
+    for (size_t base = first; base + 256 * U <= last; base += step) {
+        bw_u4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (RD)
+                v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+            else
+                v[u] = bw_u4{ (uint32_t)i, 1, 2, 3 };
+        }
+        if (WR) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const size_t o = (base + (size_t)u * 256) * K + (size_t)k * 256 + threadIdx.x;
+                    bw_u4 w = v[u];
+                    w.x += k;
+                    if (NT)
+                        __builtin_nontemporal_store(w, dst + o);
+                    else
+                        dst[o] = w;
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                acc += v[u];
+        }
     }
-    if (MODE == 0 && acc.x + acc.y + acc.z + acc.w == 0x12345)
+    if (!WR && acc.x + acc.y + acc.z + acc.w == 0x12345)
         sink[0] = 1;
+}
+
+template <int K, int RD, int WR>
+static void membw_launch(int variant, const bw_u4 *a, bw_u4 *b, size_t n_rd, uint32_t *sink)
+{
+    /* variant: bits 0-1 U index (1, 2, 8), bit 2 non-temporal, bit 3 256 x 16 workgroups (else 256 x 4), bit 4 private slices */
+    const dim3 g(variant & 8 ? 4096 : 1024), t(256);
+    const int u = variant & 3, nt = (variant >> 2) & 1, pat = (variant >> 4) & 1;
+#define MB(U_, NT_, PAT_) hipLaunchKernelGGL((k_membw<K, U_, NT_, RD, WR, PAT_>), g, t, 0, 0, a, b, n_rd, sink)
+#define MBU(NT_, PAT_) do { if (u == 0) MB(1, NT_, PAT_); else if (u == 1) MB(2, NT_, PAT_); else MB(8, NT_, PAT_); } while (0)
+    if (nt) { if (pat) MBU(1, 1); else MBU(1, 0); }
+    else    { if (pat) MBU(0, 1); else MBU(0, 0); }
+#undef MBU
+#undef MB
 }
 
 extern "C" int ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gbps)
 {
-    if (pattern < 0 || pattern > 4 || bytes < (1u << 20) || reps < 1 || !gbps)
+    if (pattern < 0 || pattern > 5 || bytes < (1u << 20) || reps < 1 || !gbps)
         return FFHIP_EINVAL;
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
-    bytes &= ~(size_t)63;
+    bytes &= ~(size_t)((1u << 20) - 1);
     bw_u4 *a = nullptr, *b = nullptr;
     uint32_t *sink = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int r = FFHIP_ENOMEM;
-    float ms = 0;
-    auto launch = [&]() {
-        const dim3 g(2048), t(256);
+    double best = 0;
+    /* `bytes` is the larger (written, or read for pattern 0) side */
+    const int K = pattern == 3 ? 4 : pattern == 4 ? 2 : 1;
+    const size_t n_rd = bytes / 16 / K;
+    const double moved = pattern == 2 || pattern == 5 ? 2.0 * bytes : pattern == 3 ? 1.25 * bytes : pattern == 4 ? 1.5 * bytes : (double)bytes;
+    auto launch = [&](int v) {
         switch (pattern) {
-        case 0: hipLaunchKernelGGL((k_membw<0>), g, t, 0, 0, a, b, bytes / 16, sink); break;
-        case 1: hipLaunchKernelGGL((k_membw<1>), g, t, 0, 0, a, b, bytes / 16, sink); break;
-        case 2: hipLaunchKernelGGL((k_membw<2>), g, t, 0, 0, a, b, bytes / 16, sink); break;
-        case 3: hipLaunchKernelGGL((k_membw<3>), g, t, 0, 0, a, b, bytes / 16, sink); break;
-        default: hipLaunchKernelGGL((k_membw<4>), g, t, 0, 0, a, b, bytes / 16, sink); break;
+        case 0: membw_launch<1, 1, 0>(v, a, b, n_rd, sink); break;
+        case 1: membw_launch<1, 0, 1>(v, a, b, n_rd, sink); break;
+        case 2: membw_launch<1, 1, 1>(v, a, b, n_rd, sink); break;
+        case 3: membw_launch<4, 1, 1>(v, a, b, n_rd, sink); break;
+        case 4: membw_launch<2, 1, 1>(v, a, b, n_rd, sink); break;
+        default: (void)hipMemcpyDtoDAsync(b, a, bytes, 0); break;
         }
     };
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess)
@@ -343,19 +388,24 @@ extern "C" int ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gb
     if (hipMemset(a, 1, bytes) != hipSuccess || hipMemset(b, 2, bytes) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
         hipEventCreate(&e1) != hipSuccess)
         goto done;
-    for (int i = 0; i < 2; i++)
-        launch();
-    if (hipEventRecord(e0, 0) != hipSuccess)
-        goto done;
-    for (int i = 0; i < reps; i++)
-        launch();
-    if (hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess ||
-        hipGetLastError() != hipSuccess)
-        goto done;
-    {
-        const double moved = pattern == 2 ? 2.0 * bytes : pattern == 3 ? 1.25 * bytes : pattern == 4 ? 1.5 * bytes : (double)bytes;
-        *gbps = moved * reps / (ms * 1e-3) / 1e9;
+    for (int v = 0; v < (pattern == 5 ? 1 : 32); v++) {
+        float ms = 0;
+        if ((v & 3) == 3)
+            continue;
+        for (int i = 0; i < 2; i++)
+            launch(v);
+        if (hipEventRecord(e0, 0) != hipSuccess)
+            goto done;
+        for (int i = 0; i < reps; i++)
+            launch(v);
+        if (hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess ||
+            hipGetLastError() != hipSuccess)
+            goto done;
+        const double g = moved * reps / (ms * 1e-3) / 1e9;
+        if (g > best)
+            best = g;
     }
+    *gbps = best;
     r = 0;
 done:
     if (r < 0)

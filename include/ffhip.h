@@ -62,8 +62,11 @@ int         ffhip_stream_destroy(void *stream);
  *  the other).  Either may be NULL, the legacy default stream — which a non-blocking stream is not ordered against by itself. */
 int         ffhip_stream_order(void *first, void *then);
 /** Streaming-bandwidth probe of the current device (measurement aid: bench.py reports the box's achievable roofs beside
- *  the 8 TB/s spec).  pattern 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p->4K scaler's mix), 4 read n/2 + write n (yuv420p->rgb24's);
- *  `bytes` per buffer; *gbps = bytes moved per second / 1e9 over `reps` launches (HIP events). */
+ *  the 8 TB/s spec).  pattern 0 read, 1 write, 2 copy, 3 read n/4 + write n (the 1080p->4K scaler's mix), 4 read n/2 + write n
+ *  (yuv420p->rgb24's), 5 the runtime's hipMemcpyDtoDAsync.  Patterns 0-4 are a SWEEP of 24 ways to issue the same traffic (1 / 2 / 8
+ *  16-byte accesses in flight per lane, plain or non-temporal, 256 x 4 or 256 x 16 workgroups, grid-stride or private XCD-adjacent
+ *  slices) and answer with the best one.  `bytes` = the larger side's buffer; *gbps = bytes moved per second / 1e9 over `reps`
+ *  launches of that variant (HIP events). */
 int         ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gbps);
 const char *ffhip_last_error(void);
 const char *ffhip_version(void);
