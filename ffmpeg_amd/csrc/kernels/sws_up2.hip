@@ -207,6 +207,7 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
     /* measurement-only variants (wrong output; tools/sweep_sws.py): 16 never stores, 32 re-reads one source row (48 = both: the
      * arithmetic alone), 64 moves the bytes without arithmetic (the memory pattern alone) */
     constexpr bool DBG_NOST = VAR & 16, DBG_ROW0 = VAR & 32, DBG_COPY = VAR & 64;
+    constexpr bool NTS = VAR & 1; /* measured variant: non-temporal stores */
     const int lpf = 64 >> fshift;                 /* lanes per frame */
     const int fsub = lane >> (6 - fshift);
     const int gl = lane & (lpf - 1);
@@ -478,13 +479,15 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
                 asm volatile("" : "+v"(off));
                 if (act && y >= 0 && (!DBG_NOST || (w0 == 0x12345678u && w1 == 0x9abcdef0u))) {
                     up_u2 s; s.x = w0; s.y = w1;
-                    *(up_g2)((up_gp)dr + off) = s;
+                    if (NTS) __builtin_nontemporal_store(s, (up_g2)((up_gp)dr + off));
+                    else *(up_g2)((up_gp)dr + off) = s;
                 }
                 if (!DBG_COPY)
                     up_v8(a0, a1, ring[(k + 1) % 3], ring[k % 3], fa01, fa23, kround);
                 if (act && y + 1 < dstH && (!DBG_NOST || (a0 == 0x12345678u && a1 == 0x9abcdef0u))) {
                     up_u2 s; s.x = a0; s.y = a1;
-                    *(up_g2)((up_gp)(dr + dstride) + off) = s;
+                    if (NTS) __builtin_nontemporal_store(s, (up_g2)((up_gp)(dr + dstride) + off));
+                    else *(up_g2)((up_gp)(dr + dstride) + off) = s;
                 }
                 dr += 2 * dstride;
                 asm("" : "+s"(dr));
@@ -635,6 +638,7 @@ int ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream)
 #define UP2_CASE(VV) case VV: if (depth == 3) UP2_LAUNCH(3, VV); else UP2_LAUNCH(6, VV); break
     switch (var) {
     UP2_CASE(0);
+    UP2_CASE(1); /* non-temporal stores */
     UP2_CASE(16); UP2_CASE(48); UP2_CASE(64); /* measurement only */
     default:
         ffhip_set_error("ffhip_sws: exact-2x kernel variant %d is not built", var);

@@ -16,6 +16,7 @@
  * Pixels written per row: width & ~1 (the reference's 8/4/2-pixel loop never writes an odd tail).
  */
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "sws_kernels.h"
@@ -143,7 +144,7 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool BGR, bool PLAIN>
+template <bool BGR, bool PLAIN, bool NTS = true, bool XCD = false, bool NTL = false>
 __global__ __launch_bounds__(256) void k_yuv420p_rgb24_t(FFHipYuv2RgbArgs a)
 {
     __shared__ uint4 tile[4][192];
@@ -152,7 +153,9 @@ __global__ __launch_bounds__(256) void k_yuv420p_rgb24_t(FFHipYuv2RgbArgs a)
     const int chunks = (a.wvalid + 15) >> 4;
     const int wpr = (chunks + 63) >> 6; /* waves per row pair */
     const int rowpairs = a.h >> 1;
-    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave; /* < 2^31, checked by the launcher */
+    /* XCD (measured variant): workgroup b runs on XCD b % 8 — number the workgroups so that each XCD converts one contiguous eighth */
+    const uint32_t bidx = XCD ? (blockIdx.x & 7u) * ((gridDim.x + 7u) >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t gw = bidx * 4u + (uint32_t)wave; /* < 2^31, checked by the launcher */
     /* FLAT (width % 16 == 0, at least 64 chunks per row): the 16-pixel chunks of a frame's row pairs are numbered straight through and
      * a wave takes 64 consecutive ones, across the end of a row pair if need be — at 3840 columns (240 chunks = 3.75 waves) one wave in
      * four would otherwise run three quarters empty.  A wave then touches at most two row pairs: rp0 and rp0 + 1. */
@@ -198,10 +201,21 @@ __global__ __launch_bounds__(256) void k_yuv420p_rgb24_t(FFHipYuv2RgbArgs a)
 
     uint32_t o0[12], o1[12];
     if (full) {
-        const uint4 y0v = *reinterpret_cast<const uint4 *>(py0 + (uint32_t)x0);
-        const uint4 y1v = *reinterpret_cast<const uint4 *>(py1 + (uint32_t)x0);
-        const uint2 uv = *reinterpret_cast<const uint2 *>(pu + (uint32_t)(x0 >> 1));
-        const uint2 vv = *reinterpret_cast<const uint2 *>(pv + (uint32_t)(x0 >> 1));
+        typedef uint32_t ld_u4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t ld_u2 __attribute__((ext_vector_type(2)));
+        ld_u4 y0v, y1v;
+        ld_u2 uv, vv;
+        if (NTL) {
+            y0v = __builtin_nontemporal_load(reinterpret_cast<const ld_u4 *>(py0 + (uint32_t)x0));
+            y1v = __builtin_nontemporal_load(reinterpret_cast<const ld_u4 *>(py1 + (uint32_t)x0));
+            uv = __builtin_nontemporal_load(reinterpret_cast<const ld_u2 *>(pu + (uint32_t)(x0 >> 1)));
+            vv = __builtin_nontemporal_load(reinterpret_cast<const ld_u2 *>(pv + (uint32_t)(x0 >> 1)));
+        } else {
+            y0v = *reinterpret_cast<const ld_u4 *>(py0 + (uint32_t)x0);
+            y1v = *reinterpret_cast<const ld_u4 *>(py1 + (uint32_t)x0);
+            uv = *reinterpret_cast<const ld_u2 *>(pu + (uint32_t)(x0 >> 1));
+            vv = *reinterpret_cast<const ld_u2 *>(pv + (uint32_t)(x0 >> 1));
+        }
         const uint32_t yw0[4] = { y0v.x, y0v.y, y0v.z, y0v.w };
         const uint32_t yw1[4] = { y1v.x, y1v.y, y1v.z, y1v.w };
         const uint32_t uw[2] = { uv.x, uv.y }, vw[2] = { vv.x, vv.y };
@@ -247,9 +261,11 @@ __global__ __launch_bounds__(256) void k_yuv420p_rgb24_t(FFHipYuv2RgbArgs a)
                 if (flat) {
                     /* piece p is third (p % 3) of chunk c0 + p / 3, which lies in row pair rp0 or rp0 + 1 */
                     const int pc = (p * 171) >> 9, cc = c0 + pc, rr = rp0 + (cc >= bnd);
-                    *reinterpret_cast<uint4 *>(dframe + (ptrdiff_t)(2 * rr + row) * a.dst_stride + 48u * (uint32_t)(cc - rr * chunks) + 16u * (uint32_t)(p - 3 * pc)) = my[p];
+                    *reinterpret_cast<uint4 *>(dframe + (ptrdiff_t)(2 * rr + row) * a.dst_stride + 48u * (uint32_t)(cc - rr * chunks) + 16u * (uint32_t)(p - 3 * pc)) = my[p];   /* (measured variant: plain stores) */
                 } else {
-                    *reinterpret_cast<uint4 *>(drow + 16u * (uint32_t)p) = my[p];
+                    if (NTS) { typedef uint32_t nt_u4 __attribute__((ext_vector_type(4))); const uint4 t = my[p];
+                               __builtin_nontemporal_store(nt_u4{ t.x, t.y, t.z, t.w }, reinterpret_cast<nt_u4 *>(drow + 16u * (uint32_t)p)); }
+                    else *reinterpret_cast<uint4 *>(drow + 16u * (uint32_t)p) = my[p];
                 }
             }
         }
@@ -296,7 +312,7 @@ __device__ __forceinline__ void put_px32(uint8_t *d, const Bases &b, int ycy)
     else                  { d[0] = (uint8_t)bl; d[1] = (uint8_t)g; d[2] = (uint8_t)r; d[3] = 255; }
 }
 
-template <int LAYOUT, bool VEC>
+template <int LAYOUT, bool VEC, bool NTS = true>
 __global__ __launch_bounds__(256) void k_yuv420p_rgb32(FFHipYuv2RgbArgs a)
 {
     /* one lane = 4 pixels x 2 rows: a dword of each luma row, two bytes of U and of V in, one aligned 16-byte store per
@@ -333,8 +349,14 @@ __global__ __launch_bounds__(256) void k_yuv420p_rgb32(FFHipYuv2RgbArgs a)
                 o1[p] = px32<LAYOUT>(b.r + c1, b.g + c1, b.b + c1);
             }
         }
-        *reinterpret_cast<uint4 *>(d0) = make_uint4(o0[0], o0[1], o0[2], o0[3]);
-        *reinterpret_cast<uint4 *>(d1) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+        if (NTS) { /* non-temporal: the destination is written once and not read back (3-6 % on the 24-bit kernel, profiles/r05_rgb24_variants.txt) */
+            typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(nt_u4{ o0[0], o0[1], o0[2], o0[3] }, reinterpret_cast<nt_u4 *>(d0));
+            __builtin_nontemporal_store(nt_u4{ o1[0], o1[1], o1[2], o1[3] }, reinterpret_cast<nt_u4 *>(d1));
+        } else {
+            *reinterpret_cast<uint4 *>(d0) = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+            *reinterpret_cast<uint4 *>(d1) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+        }
     } else {
         const int npairs = (min(4, a.wvalid - x0)) >> 1;
         for (int m = 0; m < npairs; m++) {
@@ -509,7 +531,10 @@ int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_
             ffhip_set_error("ffhip_sws: batch too large for one launch");
             return FFHIP_EINVAL;
         }
-#define L32(LY) do { if (vec) hipLaunchKernelGGL((k_yuv420p_rgb32<LY, true>), grid, block, 0, stream, a); \
+        const char *ev32 = FFHIP_KNOB("FFHIP_YUV2RGB_VARIANT"); /* 's': plain stores (measured variant) */
+        const bool pst32 = ev32 && strchr(ev32, 's');
+#define L32(LY) do { if (vec && pst32) hipLaunchKernelGGL((k_yuv420p_rgb32<LY, true, false>), grid, block, 0, stream, a); \
+                     else if (vec) hipLaunchKernelGGL((k_yuv420p_rgb32<LY, true>), grid, block, 0, stream, a); \
                      else hipLaunchKernelGGL((k_yuv420p_rgb32<LY, false>), grid, block, 0, stream, a); } while (0)
         switch (layout) {
         case 2: L32(2); break;
@@ -532,6 +557,17 @@ int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_
         const bool plain = ev && ev[0] == 'p';
         FFHipYuv2RgbArgs af = a;
         af.flat = flat;
+        /* measured variants (rgb24 only): 's' plain stores (the kernel up to round 4: 3-6 % slower than the non-temporal ones, profiles/
+         * r05_rgb24_variants.txt), 'x' XCD-contiguous numbering, 'l' non-temporal loads as well */
+        const bool pst = ev && strchr(ev, 's'), xcd = ev && strchr(ev, 'x'), ntl = ev && strchr(ev, 'l');
+        if (pst || xcd || ntl) {
+            if (pst && xcd) hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, false, true>), grid, block, 0, stream, af);
+            else if (pst)   hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, false, false>), grid, block, 0, stream, af);
+            else if (ntl)   hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, true, false, true>), grid, block, 0, stream, af);
+            else            hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, true, true>), grid, block, 0, stream, af);
+            LAUNCH_CHECK();
+            return 0;
+        }
         if (bgr) {
             if (plain) hipLaunchKernelGGL((k_yuv420p_rgb24_t<true, true>), grid, block, 0, stream, af);
             else       hipLaunchKernelGGL((k_yuv420p_rgb24_t<true, false>), grid, block, 0, stream, af);

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""tools/bench_up2_variants.py — the headline launch (nv12 1080p -> 4K bicubic, 256 frames) with the product kernel and the measure build's
+FFHIP_UP2_VAR=1 (non-temporal stores), three alternating passes, 20 warm-up + 100 timed launches each."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ffmpeg_amd import _lib
+_lib.select("measure")
+from ffmpeg_amd import swscale as S
+
+dev = torch.device("cuda:0")
+n = 256
+ctx = S.SwsContext(1920, 1080, 23, 3840, 2160, 23, 4)
+src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(23, 1920, 1080)]
+dst = [torch.empty((n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(23, 3840, 2160)]
+ref = None
+for p in range(3):
+    for var in ("", "1"):
+        if var:
+            os.environ["FFHIP_UP2_VAR"] = var
+        else:
+            os.environ.pop("FFHIP_UP2_VAR", None)
+        for _ in range(20):
+            ctx.scale_batch(src, dst)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(100):
+            ctx.scale_batch(src, dst)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 100
+        cs = int(dst[0][:2].to(torch.int64).sum().item()) + int(dst[1][:2].to(torch.int64).sum().item())
+        if ref is None:
+            ref = cs
+        print(json.dumps({"pass": p, "variant": var or "product", "ms": round(ms, 4), "hbm_frac": round(n * 15552000 / (ms * 1e-3) / 8e12, 4),
+                          "same_pixels": cs == ref}))

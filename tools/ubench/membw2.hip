@@ -3,7 +3,7 @@
 // measures 6.29 TB/s for a float4 copy).  Variants: U accesses of 16 B in flight per lane before the first dependent store (1, 2, 4, 8),
 // plain / non-temporal stores, non-temporal loads, grids of 256 x {4, 8, 16} blocks of 256 threads, and the runtime's own hipMemcpyDtoDAsync.
 // Mixes: copy (1 : 1), read-only, write-only, 1 : 2 (yuv420p -> rgb24: 1.5 B read, 3 B written per pixel), 1 : 4 (nv12 1080p -> 4K).
-// Build: hipcc --offload-arch=gfx950 -O3 -o membw2 membw2.hip     Run: ./membw2 [GiB]    One JSON line per variant.
+// Build: hipcc --offload-arch=gfx950 -O3 -o membw2 membw2.hip     Run: ./membw2 [GiB [reps [passes]]]    One JSON line per variant.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_mix(const u4 *__restrict__ src, u4 *__r
 }
 
 static hipEvent_t e0, e1;
+static int g_reps = 10, g_pass = 0;
 template <int K, int U, int NTS, int NTL, int RD, int WR, int PAT = 0>
 static void run(const char *mix, const u4 *s, u4 *d, size_t n_rd, int bpc, uint32_t *sink)
 {
@@ -65,14 +66,14 @@ static void run(const char *mix, const u4 *s, u4 *d, size_t n_rd, int bpc, uint3
     const double moved = (double)n_rd * 16 * ((RD ? 1 : 0) + (WR ? K : 0));
     for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_mix<K, U, NTS, NTL, RD, WR, PAT>), dim3(blocks), dim3(256), 0, 0, s, d, n_rd, sink);
     hipEventRecord(e0);
-    const int reps = 10;
+    const int reps = g_reps;
     for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_mix<K, U, NTS, NTL, RD, WR, PAT>), dim3(blocks), dim3(256), 0, 0, s, d, n_rd, sink);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
-    printf("{\"mix\": \"%s\", \"in_flight_16B\": %d, \"nt_store\": %d, \"nt_load\": %d, \"blocks_per_cu\": %d, \"pattern\": %d, \"ms\": %.4f, \"GB/s\": %.1f}\n", mix, U, NTS, NTL, bpc,
+    printf("{\"pass\": %d, \"mix\": \"%s\", \"in_flight_16B\": %d, \"nt_store\": %d, \"nt_load\": %d, \"blocks_per_cu\": %d, \"pattern\": %d, \"ms\": %.4f, \"GB/s\": %.1f}\n", g_pass, mix, U, NTS, NTL, bpc,
            PAT, ms, moved / ms / 1e6);
     fflush(stdout);
 }
@@ -101,11 +102,15 @@ int main(int argc, char **argv)
     hipMemset(d, 2, bytes);
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t n = bytes / 16;
-    SWEEP(1, 1, 1, "copy 1:1", n);
-    SWEEP(1, 1, 0, "read", n);
-    SWEEP(1, 0, 1, "write", n);
-    SWEEP(2, 1, 1, "read1 write2", n / 2);
-    SWEEP(4, 1, 1, "read1 write4", n / 4);
+    const int passes = argc > 3 ? atoi(argv[3]) : 1;
+    if (argc > 2) g_reps = atoi(argv[2]);
+    for (g_pass = 0; g_pass < passes; g_pass++) {
+        SWEEP(1, 1, 1, "copy 1:1", n);
+        SWEEP(1, 1, 0, "read", n);
+        SWEEP(1, 0, 1, "write", n);
+        SWEEP(2, 1, 1, "read1 write2", n / 2);
+        SWEEP(4, 1, 1, "read1 write4", n / 4);
+    }
     // the runtime's copy
     for (int i = 0; i < 3; i++) hipMemcpyDtoDAsync(d, s, bytes, 0);
     hipEventRecord(e0);
