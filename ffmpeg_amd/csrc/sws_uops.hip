@@ -16,8 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -488,6 +490,9 @@ std::string device_arch(void)
  * A file is named by a 128-bit FNV-1a hash of its key — this file's format tag, the hiprtc version, the architecture and the
  * program text — and carries the whole key in front of the code object, so a hash collision or a file of another compiler version
  * reads as a miss; files are written to a temporary name and renamed, so a concurrent reader sees a whole file or none.
+ * Trust (round 5): the directory must be a real directory owned by the effective user and closed to group / others (else the cache
+ * stays off), files are opened O_NOFOLLOW and must be the user's own regular files, temporaries come from mkstemp(), and the header
+ * carries a hash of the code object that is verified before the code is handed to the runtime.
  */
 std::string g_disk_dir; /* guarded by g_cache_mutex; empty = off (the default: the library reads no environment variable) */
 
@@ -496,7 +501,7 @@ std::string disk_key(const std::string &arch, const std::string &src)
     int maj = 0, min = 0;
     (void)hiprtcVersion(&maj, &min);
     char head[96];
-    snprintf(head, sizeof(head), "ffhip-uops-1 hiprtc %d.%d %s\n", maj, min, arch.c_str());
+    snprintf(head, sizeof(head), "ffhip-uops-2 hiprtc %d.%d %s\n", maj, min, arch.c_str());
     return head + src;
 }
 
@@ -512,17 +517,51 @@ std::string disk_path(const std::string &dir, const std::string &key)
     return dir + name;
 }
 
-bool disk_load(const std::string &path, const std::string &key, std::vector<char> *code)
+/* 64-bit FNV-1a of the code object: stored in the file's header, verified on load (a truncated, bit-rotten or tampered-with file
+ * reads as a miss — the code then comes from hiprtc as if the cache were cold) */
+uint64_t disk_sum(const char *p, size_t n)
 {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f)
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++)
+        h = (h ^ (unsigned char)p[i]) * 0x100000001b3ull;
+    return h;
+}
+
+/* The directory is trusted only when it is OURS: a real directory (no symlink in the last component), owned by the effective user, not
+ * writable by group or others.  Anything else — a shared /tmp-style location, a directory someone else made first — leaves the cache
+ * off: code objects loaded from it run with the process's access to all of its device memory. */
+bool disk_dir_trusted(const std::string &dir)
+{
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode))
         return false;
+    return st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH));
+}
+
+bool disk_load(const std::string &dir, const std::string &path, const std::string &key, std::vector<char> *code)
+{
+    if (!disk_dir_trusted(dir))
+        return false;
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0)
+        return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid()) {
+        close(fd);
+        return false;
+    }
+    FILE *f = fdopen(fd, "rb");
+    if (!f) {
+        close(fd);
+        return false;
+    }
     bool ok = false;
-    uint64_t klen = 0, clen = 0;
-    if (fread(&klen, 8, 1, f) == 1 && fread(&clen, 8, 1, f) == 1 && klen == key.size() && clen > 0 && clen < (1u << 28)) {
+    uint64_t klen = 0, clen = 0, sum = 0;
+    if (fread(&klen, 8, 1, f) == 1 && fread(&clen, 8, 1, f) == 1 && fread(&sum, 8, 1, f) == 1 && klen == key.size() && clen > 0 && clen < (1u << 28)) {
         std::string k(klen, '\0');
         code->resize(clen);
-        ok = fread(&k[0], 1, klen, f) == klen && k == key && fread(code->data(), 1, clen, f) == clen && fgetc(f) == EOF;
+        ok = fread(&k[0], 1, klen, f) == klen && k == key && fread(code->data(), 1, clen, f) == clen && fgetc(f) == EOF &&
+             disk_sum(code->data(), clen) == sum;
     }
     fclose(f);
     if (!ok)
@@ -532,20 +571,28 @@ bool disk_load(const std::string &path, const std::string &key, std::vector<char
 
 void disk_store(const std::string &dir, const std::string &path, const std::string &key, const std::vector<char> &code)
 {
-    /* mkdir -p of the last two components (…/.cache may not exist yet); failures just leave the cache cold */
+    /* mkdir -p of the last two components (…/.cache may not exist yet); failures just leave the cache cold.  mkdir(0700) does nothing
+     * to a directory that exists already: whether it is ours is checked afterwards */
     const size_t cut = dir.rfind('/');
     if (cut != std::string::npos && cut > 0)
         (void)mkdir(dir.substr(0, cut).c_str(), 0700);
     (void)mkdir(dir.c_str(), 0700);
-    char tmp[32];
-    snprintf(tmp, sizeof(tmp), ".tmp%ld", (long)getpid());
-    const std::string t = path + tmp;
-    FILE *f = fopen(t.c_str(), "wb");
-    if (!f)
+    if (!disk_dir_trusted(dir))
         return;
-    const uint64_t klen = key.size(), clen = code.size();
-    const bool ok = fwrite(&klen, 8, 1, f) == 1 && fwrite(&clen, 8, 1, f) == 1 && fwrite(key.data(), 1, klen, f) == klen &&
-                    fwrite(code.data(), 1, clen, f) == clen;
+    /* a fresh, exclusively created temporary file in that directory (no predictable name, no symlink followed), then rename */
+    std::string t = dir + "/.ffhip-XXXXXX";
+    const int fd = mkstemp(&t[0]);
+    if (fd < 0)
+        return;
+    FILE *f = fdopen(fd, "wb");
+    if (!f) {
+        close(fd);
+        (void)remove(t.c_str());
+        return;
+    }
+    const uint64_t klen = key.size(), clen = code.size(), sum = disk_sum(code.data(), code.size());
+    const bool ok = fwrite(&klen, 8, 1, f) == 1 && fwrite(&clen, 8, 1, f) == 1 && fwrite(&sum, 8, 1, f) == 1 &&
+                    fwrite(key.data(), 1, klen, f) == klen && fwrite(code.data(), 1, clen, f) == clen;
     if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0)
         (void)remove(t.c_str());
 }
@@ -563,7 +610,7 @@ int build(const std::string &src, std::shared_ptr<Program> *out, bool load)
     const std::string dpath = ddir.empty() ? std::string() : disk_path(ddir, dkey);
     if (!pr && !ddir.empty()) {
         auto np = std::make_shared<Program>();
-        if (disk_load(dpath, dkey, &np->code)) {
+        if (disk_load(ddir, dpath, dkey, &np->code)) {
             g_disk_hits++;
             pr = np;
         }

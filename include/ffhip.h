@@ -1746,7 +1746,10 @@ int  ffhip_sws_uops_check(const FFHipSwsUOp *uops, int num_uops);
  *  cache off, which is the default: the library reads no environment variable; the FFmpeg-side backend chooses
  *  $XDG_CACHE_HOME/ffhip or $HOME/.cache/ffhip (integration/swscale_hw_hip.c).  The directory (and its parent) is created on the first
  *  store.  A file carries its whole key (hiprtc version, architecture, program text): a stale, damaged or foreign file is a miss and
- *  is rewritten; files appear by rename, so concurrent processes are safe.  Process-wide; returns 0. */
+ *  is rewritten; files appear by rename, so concurrent processes are safe.  The directory is used only while it is a real directory
+ *  (lstat: no symlink) OWNED BY THE EFFECTIVE USER and not writable by group or others — code objects loaded from it run with the
+ *  process's access to its device memory — else the cache silently stays off; files are opened O_NOFOLLOW, must be the user's own
+ *  regular files, carry a hash of the code object that is verified on load, and are written through mkstemp().  Process-wide; returns 0. */
 int  ffhip_sws_uops_set_cache_dir(const char *dir);
 /** hiprtc compiles and disk hits of this process so far (either pointer may be NULL). */
 void ffhip_sws_uops_cache_stats(long *compiles, long *disk_hits);

@@ -75,6 +75,19 @@ static int classify_dst(const FFHipH264Recorder *r, const uint8_t *p)
  * taps leave the picture (`if (mx & 7) extra_width -= 3`, h264_mb.c:229-236) — an integer-position block may sit flush against the
  * picture's edge unemulated.  Such a block is recorded as FFHIP_MC_EMU as well: the clamped fetch returns the same samples inside
  * the picture, and the ones outside carry no weight at that position. */
+/* The records address the references by a 32-bit offset from ONE base per plane (ffhip.h: FFHipQpelBlock.src_offset; flush()'s ref[]): the
+ * current picture and every reference it uses must lie within 2 GiB of that base — one decoded-picture-buffer allocation (or a pool
+ * carved from one), which is how integration/avutil_hwcontext_hip.c's frame pool is meant to be set up for a decoder.  A reference
+ * outside that reach (separate far-apart allocations, a DPB beyond 2 GiB) is REFUSED here, not wrapped: the picture then fails with
+ * FFHIP_EINVAL at its first such block instead of reading a wild device address. */
+static int fits32(ptrdiff_t d, int32_t *out)
+{
+    if (d < INT32_MIN || d > INT32_MAX)
+        return 0;
+    *out = (int32_t)d;
+    return 1;
+}
+
 static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int need, int32_t *off, uint8_t *flags, int16_t *sx, int16_t *sy)
 {
     if (r->emu.valid && src >= r->emu_buf && src < r->emu_buf + r->emu_size) {
@@ -83,13 +96,17 @@ static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int need
         const size_t o = (size_t)(src - r->emu_buf);
         const int row = (int)(o / (size_t)r->emu.linesize), col = (int)(o % (size_t)r->emu.linesize) >> r->pixel_shift;
         const uint8_t *origin = r->emu.src - ((ptrdiff_t)r->emu.src_y * r->emu.linesize + ((ptrdiff_t)r->emu.src_x << r->pixel_shift));
-        *off   = (int32_t)(origin - r->ref_base[pl]);
+        /* (the block's own coordinates travel as int16: motion vectors are bounded well inside that, h264_mvpred.h / level limits) */
+        if (!fits32(origin - r->ref_base[pl], off) || r->emu.src_x + col < INT16_MIN || r->emu.src_x + col > INT16_MAX ||
+            r->emu.src_y + row < INT16_MIN || r->emu.src_y + row > INT16_MAX)
+            return FFHIP_EINVAL;
         *flags = FFHIP_MC_EMU;
         *sx    = (int16_t)(r->emu.src_x + col);
         *sy    = (int16_t)(r->emu.src_y + row);
         return 0;
     }
-    *off = (int32_t)(src - r->ref_base[pl]);
+    if (!fits32(src - r->ref_base[pl], off))
+        return FFHIP_EINVAL;
     *flags = 0;
     *sx = *sy = 0;
     if (need > 0) {
@@ -115,7 +132,8 @@ static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int need
             const ptrdiff_t o = src - origin;
             const int y = (int)(o / ls), x = (int)(o % ls) >> r->pixel_shift;
             if (x < 2 || y < 2 || x + need + 3 > r->pic_w[pl] || y + need + 3 > r->rows[pl]) {
-                *off   = (int32_t)(origin - r->ref_base[pl]);
+                if (!fits32(origin - r->ref_base[pl], off))
+                    return FFHIP_EINVAL;
                 *flags = FFHIP_MC_EMU;
                 *sx    = (int16_t)x;
                 *sy    = (int16_t)y;
@@ -162,7 +180,9 @@ static void rec_chroma(int avg, int w_idx, uint8_t *dst, const uint8_t *src, ptr
     int where = classify_dst(r, dst), pl = where & 15, rc;
     if (where < 0 || pl < 1 || r->cfmt == 3 || stride != r->linesize[pl])
         FAIL(FFHIP_EINVAL);
-    locate_src(r, pl, src, 0, &c.src_offset, &c.flags, &c.src_x, &c.src_y);
+    rc = locate_src(r, pl, src, 0, &c.src_offset, &c.flags, &c.src_x, &c.src_y);
+    if (rc < 0)
+        FAIL(rc);
     c.w_idx = (uint8_t)w_idx;
     c.h = (uint8_t)h;
     c.x = (uint8_t)x;
@@ -377,6 +397,14 @@ av_cold void ff_h264_hip_recorder_install(H264Context *h)
     h->vdsp.prefetch = rec_prefetch;
 }
 
+/* What keeps a whole picture on the C path, known before its first macroblock (MBAFF frames; lossless streams, where a
+ * qpprime_y_zero_transform_bypass macroblock may turn up at any macroblock): a caller asks this BEFORE it begins to record — once
+ * macroblocks have been recorded their coefficients are consumed and the pixels exist only as records, there is no way back. */
+int ff_h264_hip_picture_supported(const H264Context *h)
+{
+    return !FRAME_MBAFF(h) && !h->ps.sps->transform_bypass;
+}
+
 void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, const H264Context *h, const H264SliceContext *sl,
                                 const uint8_t *const ref_base[3])
 {
@@ -393,6 +421,11 @@ void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, con
         r->linesize[pl] = ls << r->field;
         r->pic_w[pl] = h->mb_width * (pl && r->cfmt != 3 ? 8 : 16);
         r->rows[pl] = (h->mb_height >> r->field) * (pl && r->cfmt == 1 ? 8 : 16);   /* (4:2:2: chroma 8 wide, 16 rows per macroblock) */
+    }
+    for (int pl = 0; pl < 3 && r->error >= 0; pl++) { /* the current picture itself must be within reach of the base (see fits32()) */
+        int32_t o;
+        if (!fits32(r->cur[pl] - r->ref_base[pl], &o) || !fits32(r->cur[pl] + plane_span(r, pl) - r->ref_base[pl], &o))
+            r->error = FFHIP_EINVAL;
     }
     r->scratch = sl->bipred_scratchpad;
     /* tmp_y starts 16 chroma rows in and is 16 luma rows tall; both buffers are walked at mb_linesize (alloc_scratch_buffers(),

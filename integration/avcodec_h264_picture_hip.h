@@ -16,11 +16,13 @@
 typedef struct FFHipH264Recorder {
     FFHipH264Picture *pic;
     int pixel_shift;
-    int cfmt;                       /* sps->chroma_format_idc: 1, or 3 (Cb / Cr through the luma members, hl_decode_mb_444) */
+    int cfmt;                       /* sps->chroma_format_idc: 1 (also for monochrome: mid-grey chroma), 2 or 3 (Cb / Cr through the luma members) */
     int field;                      /* a field picture (PAFF): `pic` is the FIELD — every second line of the frame buffer from cur[] on */
     int error;                      /* first libffhip error (< 0), sticky until begin() */
     /* the picture being decoded: h->cur_pic.f->data[] as the DEVICE addresses of the hip frame, and the base every reference
-     * picture's data[] is counted from (the decoded-picture-buffer allocation: what ffhip_h264_picture_flush() gets as ref[]) */
+     * picture's data[] is counted from (the decoded-picture-buffer allocation: what ffhip_h264_picture_flush() gets as ref[]).
+     * ONE allocation: the records hold 32-bit offsets from ref_base[] — the current picture and all its references must lie within
+     * 2 GiB of it; a picture or a reference outside that reach is refused (FFHIP_EINVAL), never wrapped */
     const uint8_t *cur[3];
     const uint8_t *ref_base[3];
     ptrdiff_t linesize[3];
@@ -52,6 +54,11 @@ typedef struct FFHipH264Recorder {
  * idct8_add4 / idct_add8, vdsp.emulated_edge_mc, vdsp.prefetch) and the loop-filter members ff_h264_filter_mb() calls with recording
  * ones; chroma_dc_dequant_idct and everything else stay what ff_h264dsp_init() left.  Call once after the decoder's own init. */
 void ff_h264_hip_recorder_install(H264Context *h);
+
+/* 1 when the picture the decoder is about to decode can be recorded as a whole: no MBAFF, no lossless (transform-bypass) stream.  Ask
+ * before ff_h264_hip_recorder_begin(): a refusal in the middle of a picture cannot be undone (the per-macroblock calls still return
+ * FFHIP_ENOSYS for such macroblocks, as a guard). */
+int ff_h264_hip_picture_supported(const H264Context *h);
 
 /* A new picture: `pic` was made for h->mb_width x h->mb_height at the stream's bit depth and has had begin() called.
  * A FIELD picture (h->picture_structure != PICT_FRAME, no MBAFF): `pic` was made for h->mb_width x h->mb_height / 2 — the field is a picture

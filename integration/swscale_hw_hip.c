@@ -1,3 +1,4 @@
+#define _GNU_SOURCE /* secure_getenv */
 /*
  * integration/swscale_hw_hip.c — libswscale/hip/ops_hw.c of the FFmpeg-side patch: the `hip` SwsOpBackend for HARDWARE frames.
  *
@@ -69,7 +70,10 @@ static void hip_hw_free(void *priv)
 static AVOnce hip_uops_cache_once = AV_ONCE_INIT;
 static void hip_uops_cache_dir(void)
 {
-    const char *x = getenv("XDG_CACHE_HOME"), *h = getenv("HOME");
+    /* secure_getenv: a set-uid / set-gid or otherwise privileged process does not take the location of executable code from its
+     * caller's environment; libffhip additionally refuses a directory that is not the effective user's own and closed to others
+     * (ffhip_sws_uops_set_cache_dir) */
+    const char *x = secure_getenv("XDG_CACHE_HOME"), *h = secure_getenv("HOME");
     char dir[1024];
     if (x && x[0])
         snprintf(dir, sizeof(dir), "%s/ffhip", x);

@@ -63,6 +63,7 @@ typedef struct FFRefH264Stream {
     /* counters */
     long pictures, mbs_hl, mbs_filter, refused, errors, decode_errors;
     int first_error;
+    int64_t base_shift;            /* test knob: the base the recorder counts offsets from lies this many bytes BELOW the arena */
 } FFRefH264Stream;
 
 extern const FFCodec ff_h264_decoder;
@@ -95,6 +96,8 @@ static int arena_get_buffer(AVCodecContext *avctx, AVFrame *f, int flags)
     return 0;
 }
 
+static void note(FFRefH264Stream *s, int r);
+
 static int flush_current(FFRefH264Stream *s)
 {
     int r = 0;
@@ -121,7 +124,7 @@ static int begin_picture(FFRefH264Stream *s, const H264Context *h, H264SliceCont
 {
     const SPS *sps = h->ps.sps;
     const int field = FIELD_PICTURE(h) && !FRAME_MBAFF(h);
-    const uint8_t *base[3] = { s->arena, s->arena, s->arena };
+    const uint8_t *base[3] = { s->arena - s->base_shift, s->arena - s->base_shift, s->arena - s->base_shift };
     int r;
     flush_current(s);
     r = ffhip_h264_picture_create_fmt(&s->pic, h->mb_width, h->mb_height >> field, sps->bit_depth_luma, sps->chroma_format_idc ? sps->chroma_format_idc : 1);
@@ -136,6 +139,7 @@ static int begin_picture(FFRefH264Stream *s, const H264Context *h, H264SliceCont
     /* the dsp tables may have been made anew for this picture's format (h264_slice.c init_dimensions / h264_init_ps) */
     ff_h264_hip_recorder_install((H264Context *)h);
     ff_h264_hip_recorder_begin(&s->rec, s->pic, h, sl, base);
+    note(s, s->rec.error);
     s->cur_ptr = h->cur_pic_ptr;
     s->cur_structure = h->picture_structure;
     s->cur_field = field;
@@ -241,6 +245,10 @@ FFRefH264Stream *ffref_h264stream_open(int record, size_t arena_bytes)
         return NULL;
     return s;
 }
+
+/* the decoded-picture buffer "allocated" far from the base the records count from: offsets beyond 32 bits must be refused by the
+ * recorder (FFHIP_EINVAL), never wrapped */
+void ffref_h264stream_set_base_shift(FFRefH264Stream *s, int64_t shift) { s->base_shift = shift; }
 
 void ffref_h264stream_set_flush(FFRefH264Stream *s, ffref_h264_flush_fn fn, void *opaque)
 {

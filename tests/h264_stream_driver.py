@@ -38,6 +38,8 @@ def dec():
                                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ffref_h264stream_arena.restype = C.c_void_p
         L.ffref_h264stream_arena.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.ffref_h264stream_set_base_shift.argtypes = [C.c_void_p, C.c_int64]
+        L.ffref_h264stream_set_base_shift.restype = None
         L.ffref_h264stream_close.argtypes = [C.c_void_p]
         L.ffref_h264stream_close.restype = None
         _dec = L
@@ -77,7 +79,7 @@ def cpu_flush(arena_base):
     return flush, counts
 
 
-def decode(aus, make_flush=None, arena_bytes=48 << 20, read_back=None):
+def decode(aus, make_flush=None, arena_bytes=48 << 20, read_back=None, base_shift=0):
     """Decodes the access units; make_flush(arena_base, arena_bytes) -> (flush callable, counters) switches the recorder on.  read_back(
     arena_base, used): called after the drain and before the frames are copied out (the GPU tier downloads its device mirror there).
     Returns (frames, stats, counters): frames = per output frame three numpy planes (copies)."""
@@ -87,6 +89,8 @@ def decode(aus, make_flush=None, arena_bytes=48 << 20, read_back=None):
     keep, counts = None, None
     try:
         base = L.ffref_h264stream_arena(s, None)
+        if base_shift:
+            L.ffref_h264stream_set_base_shift(s, base_shift)
         if make_flush is not None:
             fn, counts = make_flush(base, arena_bytes)
             keep = FLUSH_FN(fn)

@@ -70,3 +70,19 @@ def test_a_larger_picture():
     for k in range(1, 6):
         pics.append({"type": "P", "slices": [0, 100 + 7 * k, 300], "deblock": [(0, 0, 0), (2, -1, 1), (0, 2, -2)], "num_ref": min(k, 3)})
     _check(w.stream(pics), w.stats, 6)
+
+
+def test_a_picture_buffer_out_of_reach_of_the_base_is_refused():
+    """The records hold 32-bit offsets from one base (flush()'s ref[]): a decoded-picture buffer 3 GiB away from it must make the recorder
+    fail the picture (FFHIP_EINVAL, sticky) — not wrap the offsets (integration/avcodec_h264_picture_hip.c fits32())."""
+    aus, ws = D.stream_ip(8, 1, n=2)
+    calls = []
+
+    def make(base, size):
+        def flush(*a):
+            calls.append(a)
+            return 0
+        return flush, {}
+    frames, st, _ = D.decode(aus, make_flush=make, base_shift=3 << 30)
+    assert st["errors"] > 0 and st["first_error"] == -22 and st["pictures"] == 2
+    assert not calls, "a picture whose recorder failed must not be flushed"

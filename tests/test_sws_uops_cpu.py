@@ -228,3 +228,27 @@ print("STATS", n, a.value, b.value)
     assert run(d) == [6, 0, 6]                                   # ... rewritten whole
     assert run("") == [6, 6, 0]                                  # off
     assert sorted(os.listdir(d)) == files
+    # trust (round 5): a flipped bit in the CODE (the key intact) fails the header's hash -> a miss, recompiled and rewritten
+    with open(os.path.join(d, files[2]), "r+b") as f:
+        f.seek(-7, os.SEEK_END)
+        b = f.read(1)
+        f.seek(-7, os.SEEK_END)
+        f.write(bytes([b[0] ^ 0x40]))
+    assert run(d) == [6, 1, 5]
+    assert run(d) == [6, 0, 6]
+    # a directory others may write to is not used at all: nothing is loaded from it, nothing stored into it
+    os.chmod(d, 0o777)
+    assert run(d) == [6, 6, 0]
+    os.chmod(d, 0o700)
+    assert run(d) == [6, 0, 6]
+    # a symlink where the directory should be is not followed; a symlink where a code object should be is not opened
+    link = str(tmp_path / "cache" / "link")
+    os.symlink(d, link)
+    assert run(link) == [6, 6, 0]
+    victim = tmp_path / "victim"
+    victim.write_bytes(b"precious")
+    os.remove(os.path.join(d, files[3]))
+    os.symlink(str(victim), os.path.join(d, files[3]))
+    assert run(d) == [6, 1, 5]                                   # compiled; the planted link was replaced by rename, not written through
+    assert victim.read_bytes() == b"precious" and not os.path.islink(os.path.join(d, files[3]))
+    assert not [f for f in os.listdir(d) if not f.endswith(".hsaco")]   # no temporary left behind

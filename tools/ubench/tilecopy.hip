@@ -121,6 +121,62 @@ __global__ __launch_bounds__(256) void k_tile_w(uint8_t *dst, const uint8_t *src
     }
 }
 
+// P7: the staged strip (round 5).  A workgroup takes 16 x-adjacent tiles of one macroblock row; the union of their displaced footprints
+// (rows y0 - R - 2 .. y0 + 15 + R + 3, columns x0 - R - 2 .. x0 + 255 + R + 3) is staged ONCE into LDS with coalesced 16-byte row loads
+// (a wave-instruction covers whole rows of the strip: the "plain rows" shape), then every wave serves its four tiles from LDS and stores
+// them as P6 does.  R = the largest displacement (16 here: tile_off's).  P8: the same with a strip of 8 tiles per workgroup of 128 threads.
+template <int R, int NTW>
+__global__ __launch_bounds__(NTW * 16) void k_tile_s(uint8_t *dst, const uint8_t *src, int ntiles)
+{
+    constexpr int ROWS_S = 16 + 2 * R + 5, WB = NTW * 16 + 2 * R + 5, CH = (WB + 15 + 15) / 16, PITCH = CH * 4 + 1; /* dwords; +1: bank spread */
+    __shared__ uint32_t lds[ROWS_S * PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t0 = blockIdx.x * NTW;
+    if (t0 >= ntiles) return;
+    int dx0, dy0;
+    const size_t o0 = tile_off(t0, &dx0, &dy0);   /* the strip's first tile: same macroblock row for all NTW (MBW % NTW == 0) */
+    const uint8_t *s0 = src + o0 - (ptrdiff_t)(R + 2) * STRIDE - (R + 2);
+    const uint32_t sh0 = (uint32_t)((uintptr_t)s0 & 15);
+    const uint8_t *sa = s0 - sh0;
+    for (int u = threadIdx.x; u < ROWS_S * CH; u += NTW * 16) {
+        const int r = u / CH, c = u - r * CH;
+        const u4 v = *(const u4 *)(sa + (size_t)r * STRIDE + 16 * c);
+        uint32_t *q = lds + r * PITCH + 4 * c;
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    }
+    __syncthreads();
+    const int y = lane >> 2, c = lane & 3, t = t0 + 4 * wave + c;
+    int dx, dy;
+    const size_t oc = tile_off(t < ntiles ? t : ntiles - 1, &dx, &dy);
+    /* byte position of (row y, column 0) of tile t's displaced source inside the staged strip */
+    const uint32_t bx = sh0 + (R + 2) + 16 * (4 * wave + c) + dx, by = (R + 2) + dy + y;
+    const uint32_t *p = lds + by * PITCH + (bx >> 2);
+    u4 out;
+    out.x = __builtin_amdgcn_alignbyte(p[1], p[0], bx & 3);
+    out.y = __builtin_amdgcn_alignbyte(p[2], p[1], bx & 3);
+    out.z = __builtin_amdgcn_alignbyte(p[3], p[2], bx & 3);
+    out.w = __builtin_amdgcn_alignbyte(p[4], p[3], bx & 3);
+    if (t < ntiles)
+        *(u4 *)(dst + oc + (size_t)y * STRIDE) = out;
+}
+
+template <int R, int NTW>
+static void run_s(const char *name, uint8_t *d, const uint8_t *s, int ntiles)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int blocks = (ntiles + NTW - 1) / NTW, reps = 10;
+    for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_tile_s<R, NTW>), dim3(blocks), dim3(NTW * 16), 0, 0, d, s, ntiles);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_tile_s<R, NTW>), dim3(blocks), dim3(NTW * 16), 0, 0, d, s, ntiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("{\"pattern\": \"%s\", \"tiles\": %d, \"ms\": %.4f, \"GB/s\": %.1f}\n", name, ntiles, ms, 512.0 * ntiles / ms / 1e6);
+}
+
 template <int P>
 static void run(const char *name, uint8_t *d, const uint8_t *s, int ntiles)
 {
@@ -160,5 +216,9 @@ int main(int argc, char **argv)
     run<4>("P4 P3 through LDS", b, a, ntiles);
     run<5>("P5 footprint as one 16 B load per lane (21 rows x 32 B), LDS, P0 stores", b, a, ntiles);
     run<6>("P6 P5 loads x 4 tiles, LDS, one 16 B store per lane (16 rows x 64 B)", b, a, ntiles);
+    run_s<16, 16>("P7 staged strip of 16 tiles (53 rows x 304 B coalesced into LDS), tiles served from LDS, P6 stores", b, a, ntiles);
+    run_s<16, 8>("P8 staged strip of 8 tiles, 128 threads", b, a, ntiles);
+    run_s<24, 16>("P7 staged for displacements up to 24 (69 rows x 320 B; the data still moves by +-16)", b, a, ntiles);
+    run<6>("P6 again", b, a, ntiles);
     return 0;
 }
