@@ -27,6 +27,10 @@
 #include "libavcodec/codec_internal.h"
 #include "libavcodec/h264dec.h"
 #include "libavcodec/h264_ps.h"
+#include "libavcodec/h264chroma.h"
+#include "libavcodec/h264dsp.h"
+#include "libavcodec/h264qpel.h"
+#include "libavcodec/videodsp.h"
 #include "libavutil/buffer.h"
 #include "libavutil/frame.h"
 #include "libavutil/imgutils.h"
@@ -55,6 +59,9 @@ typedef struct FFRefH264Stream {
     FFHipH264Picture *pic;
     const H264Picture *cur_ptr;
     int cur_structure, cur_field, cur_mb_w, cur_mb_h;
+    int cur_plain;                 /* the current picture stays on the C path as a whole (ff_h264_hip_picture_supported() said no) */
+    int recording_tables;          /* h's dsp tables hold the recording members */
+    long plain_pictures;
     int64_t cur_off[3];
     int cur_stride[3];
     /* output */
@@ -101,8 +108,10 @@ static void note(FFRefH264Stream *s, int r);
 static int flush_current(FFRefH264Stream *s)
 {
     int r = 0;
-    if (!s->pic)
+    if (!s->pic) {
+        s->cur_plain = 0;
         return 0;
+    }
     if (s->rec.error < 0) {
         r = s->rec.error;
     } else if (s->flush) {
@@ -127,6 +136,25 @@ static int begin_picture(FFRefH264Stream *s, const H264Context *h, H264SliceCont
     const uint8_t *base[3] = { s->arena - s->base_shift, s->arena - s->base_shift, s->arena - s->base_shift };
     int r;
     flush_current(s);
+    s->cur_plain = 0;
+    if (!ff_h264_hip_picture_supported(h)) {
+        /* an MBAFF frame (or a lossless stream): decided BEFORE a macroblock of the picture is recorded; the whole picture runs through
+         * the reference's own functions on the C tables (made again as h264_slice.c:1022-1028 makes them), in place, on the same
+         * picture buffer the recorded pictures' flushes write to */
+        H264Context *hw = (H264Context *)h;
+        if (s->recording_tables) {
+            ff_h264dsp_init(&hw->h264dsp, sps->bit_depth_luma, sps->chroma_format_idc);
+            ff_h264chroma_init(&hw->h264chroma, sps->bit_depth_chroma);
+            ff_h264qpel_init(&hw->h264qpel, sps->bit_depth_luma);
+            ff_videodsp_init(&hw->vdsp, sps->bit_depth_luma);
+            s->recording_tables = 0;
+        }
+        s->cur_plain = 1;
+        s->cur_ptr = h->cur_pic_ptr;
+        s->cur_structure = h->picture_structure;
+        s->plain_pictures++;
+        return 0;
+    }
     r = ffhip_h264_picture_create_fmt(&s->pic, h->mb_width, h->mb_height >> field, sps->bit_depth_luma, sps->chroma_format_idc ? sps->chroma_format_idc : 1);
     if (r < 0 || !s->pic) {
         s->errors++;
@@ -138,6 +166,7 @@ static int begin_picture(FFRefH264Stream *s, const H264Context *h, H264SliceCont
     ffhip_h264_picture_begin(s->pic);
     /* the dsp tables may have been made anew for this picture's format (h264_slice.c init_dimensions / h264_init_ps) */
     ff_h264_hip_recorder_install((H264Context *)h);
+    s->recording_tables = 1;
     ff_h264_hip_recorder_begin(&s->rec, s->pic, h, sl, base);
     note(s, s->rec.error);
     s->cur_ptr = h->cur_pic_ptr;
@@ -159,11 +188,14 @@ static FFRefH264Stream *session_of(const H264Context *h)
     return s && s->record ? s : NULL;
 }
 
+/* 1: record the macroblock; 0: nothing to do (an error was noted); -1: this picture runs on the C path */
 static int ready(FFRefH264Stream *s, const H264Context *h, H264SliceContext *sl)
 {
-    if (s->cur_ptr != h->cur_pic_ptr || s->cur_structure != h->picture_structure || !s->pic)
+    if (s->cur_ptr != h->cur_pic_ptr || s->cur_structure != h->picture_structure || (!s->pic && !s->cur_plain))
         if (begin_picture(s, h, sl) < 0)
             return 0;
+    if (s->cur_plain)
+        return -1;
     /* a later slice of the picture: its own reference lists / scratch buffers are the slice context's, which begin() bound once; the
      * recorder reads them through r->sl per macroblock */
     return 1;
@@ -188,8 +220,10 @@ void ffref_hook_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
         ff_h264_hl_decode_mb(h, sl);
         return;
     }
-    if (!ready(s, h, sl))
-        return;
+    switch (ready(s, h, sl)) {
+    case 0: return;
+    case -1: ff_h264_hl_decode_mb(h, sl); return;
+    }
     s->mbs_hl++;
     note(s, ff_h264_hip_hl_decode_mb(&s->rec, h, sl));
 }
@@ -202,8 +236,10 @@ void ffref_hook_filter_mb_fast(const H264Context *h, H264SliceContext *sl, int m
         ff_h264_filter_mb_fast(h, sl, mb_x, mb_y, img_y, img_cb, img_cr, linesize, uvlinesize);
         return;
     }
-    if (!ready(s, h, sl))
-        return;
+    switch (ready(s, h, sl)) {
+    case 0: return;
+    case -1: ff_h264_filter_mb_fast(h, sl, mb_x, mb_y, img_y, img_cb, img_cr, linesize, uvlinesize); return;
+    }
     s->mbs_filter++;
     note(s, ff_h264_hip_filter_mb(&s->rec, h, sl, mb_x, mb_y));
 }
@@ -216,8 +252,10 @@ void ffref_hook_filter_mb(const H264Context *h, H264SliceContext *sl, int mb_x, 
         ff_h264_filter_mb(h, sl, mb_x, mb_y, img_y, img_cb, img_cr, linesize, uvlinesize);
         return;
     }
-    if (!ready(s, h, sl))
-        return;
+    switch (ready(s, h, sl)) {
+    case 0: return;
+    case -1: ff_h264_filter_mb(h, sl, mb_x, mb_y, img_y, img_cb, img_cr, linesize, uvlinesize); return;
+    }
     s->mbs_filter++;
     note(s, ff_h264_hip_filter_mb(&s->rec, h, sl, mb_x, mb_y));
 }
@@ -324,7 +362,7 @@ uint8_t *ffref_h264stream_arena(const FFRefH264Stream *s, size_t *used)
 }
 
 /* counters: 0 pictures recorded, 1 hl_decode_mb calls recorded, 2 filter calls recorded, 3 refused (FFHIP_ENOSYS), 4 recorder / flush
- * errors, 5 the first such error, 6 frames the decoder flagged as damaged */
+ * errors, 5 the first such error, 6 frames the decoder flagged as damaged, 7 pictures left on the C path as a whole */
 long ffref_h264stream_stat(const FFRefH264Stream *s, int what)
 {
     switch (what) {
@@ -335,6 +373,7 @@ long ffref_h264stream_stat(const FFRefH264Stream *s, int what)
     case 4: return s->errors;
     case 5: return s->first_error;
     case 6: return s->decode_errors;
+    case 7: return s->plain_pictures;
     }
     return -1;
 }

@@ -100,7 +100,7 @@ def decode(aus, make_flush=None, arena_bytes=48 << 20, read_back=None, base_shif
             assert r == 0, "avcodec_send_packet / receive_frame: %d" % r
         assert L.ffref_h264stream_decode(s, None, 0) == 0
         stats = {k: L.ffref_h264stream_stat(s, i) for i, k in enumerate(("pictures", "mbs_hl", "mbs_filter", "refused", "errors",
-                                                                        "first_error", "damaged"))}
+                                                                        "first_error", "damaged", "plain_pictures"))}
         if read_back is not None:
             used = C.c_size_t()
             L.ffref_h264stream_arena(s, C.byref(used))
@@ -160,4 +160,18 @@ def stream_fields(bit_depth=8, seed=3, mb_w=6, mb_h=6, n=3):
         pics.append({"type": "I" if k == 0 else "P", "slices": [0], "deblock": [(0, 0, 0)], "field": "top", "num_ref": min(max(2 * k, 1), 4)})
         pics.append({"type": "P", "slices": [0, 5], "deblock": [(0, 1, 1), (2, -1, 0)], "field": "bottom", "second_field": True,
                      "num_ref": min(2 * k + 1, 4)})
+    return w.stream(pics), w.stats
+
+
+def stream_mbaff_and_fields(seed=7, mb_w=6, mb_h=6):
+    """mb_adaptive_frame_field_flag = 1: frames are MBAFF frames (frame and field macroblock pairs mixed), field pictures are plain
+    fields.  I (MBAFF frame), P field pair, P (MBAFF frame), P field pair."""
+    p = B.Params(mb_w=mb_w, mb_h=mb_h, frame_mbs_only=0, mbaff=1, seed=seed)
+    w = B.StreamWriter(p)
+    pics = [{"type": "I", "slices": [0], "deblock": [(0, 0, 0)]},
+            {"type": "P", "slices": [0], "deblock": [(0, 1, 0)], "field": "top", "num_ref": 2},
+            {"type": "P", "slices": [0, 7], "deblock": [(0, 0, 0), (2, 1, -1)], "field": "bottom", "second_field": True, "num_ref": 3},
+            {"type": "P", "slices": [0, 12], "deblock": [(0, 1, 1), (0, 0, 0)], "num_ref": 2},
+            {"type": "P", "slices": [0], "deblock": [(0, -1, 2)], "field": "top", "num_ref": 4},
+            {"type": "P", "slices": [0], "deblock": [(0, 0, 0)], "field": "bottom", "second_field": True, "num_ref": 4}]
     return w.stream(pics), w.stats

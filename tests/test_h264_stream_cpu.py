@@ -86,3 +86,20 @@ def test_a_picture_buffer_out_of_reach_of_the_base_is_refused():
     frames, st, _ = D.decode(aus, make_flush=make, base_shift=3 << 30)
     assert st["errors"] > 0 and st["first_error"] == -22 and st["pictures"] == 2
     assert not calls, "a picture whose recorder failed must not be flushed"
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_mbaff_frames_stay_on_the_c_path_as_whole_pictures(seed):
+    """MBAFF frames are what the picture layer does not take: ff_h264_hip_picture_supported() says so BEFORE the picture's first
+    macroblock, and the whole picture runs through the reference's functions on the C tables — in a stream whose other pictures (plain
+    field pictures here, predicting from the MBAFF frames and predicted from by them) are recorded.  The writer emits
+    mb_field_decoding_flag per macroblock pair (frame and field pairs mixed, skipped top macroblocks included)."""
+    aus, ws = D.stream_mbaff_and_fields(seed)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == 4
+    rec, st, counts = D.decode(aus, make_flush=lambda base, size: D.cpu_flush(base))
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0, st
+    assert st["plain_pictures"] == 2 and st["pictures"] == 4 == counts["pictures"], (st, counts)
+    for i, (a, b) in enumerate(zip(plain, rec)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
