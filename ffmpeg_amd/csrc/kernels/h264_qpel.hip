@@ -761,6 +761,114 @@ __device__ __forceinline__ void qm_compute(const int (&Gsize)[4], const int (&Gm
     }
 }
 
+/* The operands of one block out of a raw plane: the lane's eight footprint bytes of rows m and 16 + m, and its full-sample dword */
+struct QmOps { long fa, fb; uint32_t ff; };
+__device__ __forceinline__ QmOps qm_operands(const uint32_t *raw, int size, int mc, uint32_t sh16, int g, int m, int ry, int rxg)
+{
+    QmOps o = { 0, 0, 0 };
+    const int last = size + 4;
+    const QmFlags F = qm_flags(mc);
+    const uint32_t sh = sh16 & 3;
+    const uint32_t *r0p = raw + (sh16 >> 2);   /* the dword that holds footprint byte 0 of row 0 */
+    if (mc) {
+        const uint32_t *pa = r0p + min(m, last) * 12 + 2 * g;
+        const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2];
+        o.fa = qm_long(__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh));
+        if (size == 16) {
+            const uint32_t *pb = r0p + min(16 + m, 20) * 12 + 2 * g;
+            const uint32_t b0_ = pb[0], b1_ = pb[1], b2_ = pb[2];
+            o.fb = qm_long(__builtin_amdgcn_alignbyte(b1_, b0_, sh), __builtin_amdgcn_alignbyte(b2_, b1_, sh));
+        }
+    }
+    if (F.wantF) {
+        const uint32_t q = sh + 2 + (mc == 3);
+        const uint32_t *pf = r0p + (min(ry, size - 1) + 2 + (mc == 12)) * 12 + rxg + (q >> 2);
+        o.ff = __builtin_amdgcn_alignbyte(pf[1], pf[0], q & 3);
+    }
+    return o;
+}
+
+/* qm_compute with the LDS round trip of block k + 1 (footprint chunk out, operands back) issued BEFORE the matrix-core chain of block k:
+ * two raw planes per wave, alternating.  One block per wave is a dependent chain — records, footprint, LDS, MFMA, transpose, LDS, store
+ * (R4.1) — and this takes the LDS leg out of it. */
+__device__ __forceinline__ void qm_compute_p(const int (&Gsize)[4], const int (&Gmc)[4], const int (&Gdoff)[4], const bool (&Gavg)[4], const qp_u4 (&Gf)[4],
+                                             const uint32_t (&Gsh16)[4], const bool &Gtile, const int &Gb0, uint8_t *dst, ptrdiff_t stride, int n, uint32_t *raw0, uint32_t *raw1,
+                                             uint32_t *ob, int lane, int fr, int fc, long cTh, long cTv, uint32_t selT1, uint32_t selT2)
+{
+    const int g = lane >> 4, m = lane & 15;
+    const int ry = 4 * g + (lane & 3), rxg = (lane >> 2) & 3;
+    if (lane < 63)
+        *reinterpret_cast<qp_u4 *>(raw0 + fr * 12 + 4 * fc) = Gf[0];
+    __builtin_amdgcn_wave_barrier();
+    QmOps cur = qm_operands(raw0, Gsize[0], Gmc[0], Gsh16[0], g, m, ry, rxg), nxt = cur;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (Gb0 + k < n) {
+            if (k < 3 && Gb0 + k + 1 < n) {
+                uint32_t *rn = (k & 1) ? raw0 : raw1;
+                if (lane < 63)
+                    *reinterpret_cast<qp_u4 *>(rn + fr * 12 + 4 * fc) = Gf[k + 1];
+                __builtin_amdgcn_wave_barrier();
+                nxt = qm_operands(rn, Gsize[k + 1], Gmc[k + 1], Gsh16[k + 1], g, m, ry, rxg);
+            }
+            const int size = Gsize[k], mc = Gmc[k];
+            uint32_t out = size == 16 ? qm_block<true>(mc, cur.fa, cur.fb, cur.ff, lane, cTh, cTv, selT1, selT2)
+                                      : qm_block<false>(mc, cur.fa, cur.fb, cur.ff, lane, cTh, cTv, selT1, selT2);
+            if (Gtile) {
+                ob[64 * k + 4 * ry + rxg] = out;
+            } else if (ry < size && 4 * rxg < size) {
+                uint8_t *d = dst + Gdoff[k] + (ptrdiff_t)ry * stride + 4 * rxg;
+                if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
+                    uint32_t *dw = reinterpret_cast<uint32_t *>(d);
+                    if (Gavg[k])
+                        out = rnd_avg4(*dw, out);
+                    *dw = out;
+                } else {
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t v = (out >> (8 * i)) & 0xFF;
+                        d[i] = (uint8_t)(Gavg[k] ? (d[i] + v + 1) >> 1 : v);
+                    }
+                }
+            }
+            cur = nxt;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (Gtile) {
+        const int y = lane >> 2, c = lane & 3;
+        qp_u4 o = *reinterpret_cast<const qp_u4 *>(ob + 64 * c + 4 * y);
+        const int doff = c == 0 ? Gdoff[0] : c == 1 ? Gdoff[1] : c == 2 ? Gdoff[2] : Gdoff[3];
+        const bool avg = c == 0 ? Gavg[0] : c == 1 ? Gavg[1] : c == 2 ? Gavg[2] : Gavg[3];
+        qp_u4 *dp = reinterpret_cast<qp_u4 *>(dst + doff + (ptrdiff_t)y * stride);
+        if (avg) {
+            const qp_u4 old = *dp;
+            o.x = rnd_avg4(old.x, o.x); o.y = rnd_avg4(old.y, o.y); o.z = rnd_avg4(old.z, o.z); o.w = rnd_avg4(old.w, o.w);
+        }
+        *dp = o;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* the product's geometry (one group of four blocks per wave) with qm_compute_p */
+__global__ __launch_bounds__(256) void k_h264_qpel_mp(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
+                                                      int pic_w, int pic_h, int per_xcd)
+{
+    __shared__ __align__(16) uint32_t rawp[4][2][22 * 12];
+    __shared__ __align__(16) uint32_t obp[4][4 * 64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int wg = per_xcd ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int b0 = (wg * 4 + wave) * 4;
+    if (b0 >= n)
+        return;
+    const long cTh = (long)qm_tab.th[lane], cTv = (long)qm_tab.tv[lane];
+    const uint32_t selT1 = (lane & 1) ? 0x03070105u : 0x06020400u, selT2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+    const int fr = (lane * 171) >> 9, fc = lane - 3 * fr;
+    QM_GROUP(A);
+    qm_load(QM_ARGS(A), b0, dst, src, stride, blocks, n, pic_w, pic_h, fr, fc);
+    qm_compute_p(QM_ARGS(A), dst, stride, n, rawp[wave][0], rawp[wave][1], obp[wave], lane, fr, fc, cTh, cTv, selT1, selT2);
+}
+
 /* NG groups of four blocks per wave, the next group's records and footprints in flight while this one is computed */
 template <int NG>
 __global__ __launch_bounds__(256) void k_h264_qpel_m(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipQpelBlock *blocks, int n,
@@ -814,7 +922,10 @@ int ffhip_launch_h264_qpel(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, c
         const char *eg = FFHIP_KNOB("FFHIP_QPEL_NG"); /* measured variant: groups of four blocks per wave (1, 2, 4) */
         const int ng = eg ? atoi(eg) : 1 /* measured: 2 and 4 are slower (0.34 / 0.47 ms against 0.31 at 32 planes) */, remap = !(ex && ex[0] == '0');
         const int per_xcd = cdiv(cdiv(n, 16 * ng), 8);
-        if (ng == 4)
+        const char *ep = FFHIP_KNOB("FFHIP_QPEL_PIPE"); /* measured variant: 1 = the LDS leg of block k + 1 ahead of block k's MFMA chain */
+        if (ep && ep[0] == '1')
+            hipLaunchKernelGGL(k_h264_qpel_mp, dim3(8 * per_xcd), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h, remap ? per_xcd : 0);
+        else if (ng == 4)
             hipLaunchKernelGGL(k_h264_qpel_m<4>, dim3(8 * per_xcd), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h, remap ? per_xcd : 0);
         else if (ng == 2)
             hipLaunchKernelGGL(k_h264_qpel_m<2>, dim3(8 * per_xcd), dim3(256), 0, stream, dst, src, stride, blocks, n, pic_w, pic_h, remap ? per_xcd : 0);
