@@ -492,11 +492,14 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         const int sa = srcFormat == FFHIP_PIX_FMT_YUVA420P ? 1 : srcFormat == FFHIP_PIX_FMT_YUVA422P ? 2 : srcFormat == FFHIP_PIX_FMT_YUVA444P ? 3 : 0;
         const int da = dstFormat == FFHIP_PIX_FMT_YUVA420P ? 1 : dstFormat == FFHIP_PIX_FMT_YUVA422P ? 2 : dstFormat == FFHIP_PIX_FMT_YUVA444P ? 3 : 0;
         if (sa && (dstFormat == FFHIP_PIX_FMT_ARGB || dstFormat == FFHIP_PIX_FMT_RGBA || dstFormat == FFHIP_PIX_FMT_ABGR || dstFormat == FFHIP_PIX_FMT_BGRA)) {
-            /* equal sizes: the table converter's yuva2rgba_c / yuva2argb_c (yuv2rgb.c:524-529, 640-648) carry the alpha plane into the
-             * alpha byte; the scaler's yuv2rgba writers with an alpha argument (output.c yuv2rgba32_X etc.) are not built */
-            if (!(sa == 1 && srcW == dstW && srcH == dstH && !(flags & FFHIP_SWS_ACCURATE_RND) && !(dstH & 1) && !(dstW & 1))) {
-                ffhip_set_error("ffhip_sws: a source alpha plane into the alpha channel of packed RGB is on the hip path for the equal-size "
-                                "yuva420p converter only");
+            /* the source's alpha plane drives the alpha byte (needAlpha, utils.c:1398): through the table converter's yuva2rgba_c /
+             * yuva2argb_c at equal sizes (yuva420p only: yuv2rgb.c:524-529, 640-648), through the scaler's yuv2rgba32_{1,2,X} / _full
+             * writers otherwise (output.c:1789-1939, 2160-2310; round 5) */
+            const int eq = srcW == dstW && srcH == dstH && !(flags & FFHIP_SWS_ACCURATE_RND) && !(dstH & 1);
+            if (eq && (sa != 1 || (dstW & 1))) {
+                /* equal sizes without ACCURATE_RND are the reference's special converters: yuva422p / yuva444p and odd widths have
+                 * none on the hip path */
+                ffhip_set_error("ffhip_sws: equal-size yuva422p / yuva444p (or an odd width) to 32-bit RGB is not on the hip path");
                 return NULL;
             }
             rgb_alpha = 1;

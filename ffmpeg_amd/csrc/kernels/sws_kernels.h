@@ -201,6 +201,12 @@ struct FFHipScaleRgbArgs {
     FFHipYuv2RgbK k;
     int full;           /* SWS_FULL_CHR_H_INT: hc has dstW entries, the yuv2rgb_full_* writers with fk[] (FFHipSwsTables.yuv2rgb_full) */
     int fk[6];
+    /* a source alpha plane into the alpha byte of a 32-bit target (yuv2rgba32_{1,2,X}_c / the _full twins, libswscale/output.c:
+     * 1789-1939, 2160-2310): the plane is scaled by the LUMA banks beside Y (lum_h_scale / the writers' alpSrc lines) */
+    int has_alpha = 0;          /* set before ffhip_plan_scale_rgb(): the tiles make room for the alpha plane */
+    const uint8_t *alpha = nullptr;
+    ptrdiff_t alpha_stride = 0;
+    size_t alpha_fp = 0;
 };
 int ffhip_launch_scale_rgb(const FFHipScaleRgbArgs &a, hipStream_t stream);
 int ffhip_plan_scale_rgb(FFHipScaleRgbArgs *a, const int32_t *hl, const int32_t *hc, const int32_t *vl,

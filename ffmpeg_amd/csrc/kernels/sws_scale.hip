@@ -396,7 +396,7 @@ int ffhip_launch_scale_yuv(const FFHipScalePlaneArgs &lum, const FFHipScalePlane
  */
 template <int HFS, bool FULL = false>
 __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitch_l, int spitch_c, int off_sc, int off_hl,
-                                                  int off_hc, int flags)
+                                                  int off_hc, int flags, int off_sa = 0, int off_ha = 0)
 {
     extern __shared__ __align__(16) uint8_t lds[];
     const int x0 = blockIdx.x * a.tw, y0 = blockIdx.y * a.th, f = blockIdx.z;
@@ -420,9 +420,20 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
     gc.fp[0] = a.src_fp[1]; gc.fp[1] = a.src_fp[2]; gc.step = a.chr_step; gc.srcW = a.chrSrcW;
     tile_load<1>(src_l, spitch_l, a.max_rows_l, gl, f, r0_l, r1_l - r0_l, c0a_l, c1_l, flags & 1);
     tile_load<2>(src_c, spitch_c, a.max_rows_c, gc, f, r0_c, r1_c - r0_c, c0a_c, c1_c, flags & 2);
+    /* the alpha plane: a second plane of the luma's geometry through the luma banks */
+    uint8_t *src_a = lds + off_sa;
+    int16_t *hs_a = reinterpret_cast<int16_t *>(lds + off_ha);
+    if (a.alpha) {
+        SrcGroup ga;
+        ga.src[0] = ga.src[1] = a.alpha; ga.stride[0] = ga.stride[1] = a.alpha_stride;
+        ga.fp[0] = ga.fp[1] = a.alpha_fp; ga.step = 1; ga.srcW = a.srcW;
+        tile_load<1>(src_a, spitch_l, a.max_rows_l, ga, f, r0_l, r1_l - r0_l, c0a_l, c1_l, flags & 8);
+    }
     __syncthreads();
     tile_hscale<1, HFS>(src_l, spitch_l, hs_l, a.tw, a.max_rows_l, r1_l - r0_l, a.hl, x0, a.tw, tw, c0a_l);
     tile_hscale<2, HFS>(src_c, spitch_c, hs_c, twc_full, a.max_rows_c, r1_c - r0_c, a.hc, xc0, twc_full, twc, c0a_c);
+    if (a.alpha)
+        tile_hscale<1, HFS>(src_a, spitch_l, hs_a, a.tw, a.max_rows_l, r1_l - r0_l, a.hl, x0, a.tw, tw, c0a_l);
     __syncthreads();
 
     const int quarterw = a.tw >> 2;
@@ -446,9 +457,26 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
             const int16_t *vcol = hs_c + (1 * a.max_rows_c + cr) * twc_full + xq;
             const bool chr_bilin = cfs == 2 && (int)cf[0] + (int)cf[1] == 4096 && cf[1] <= 4096u;
             const bool lum_bilin = lfs == 2 && (int)lf[0] + (int)lf[1] == 4096 && lf[1] <= 4096u;
+            const int16_t *acol = hs_a + lr * a.tw + xq;
             uint8_t px[16];
             for (int i = 0; i < npx; i++) {
-                int Y, U, V;
+                int Y, U, V, A = 255;
+                if (a.alpha) {
+                    /* yuv2rgb_full_{1,2,X}_c_template's alpha (output.c:2193-2200, 2241-2245, 2278-2282, 2298-2302): the luma's case */
+                    if (lfs == 1 && (cfs == 1 || chr_bilin)) {
+                        A = (acol[i] + 64) >> 7;
+                    } else if (lum_bilin && chr_bilin) {
+                        A = (acol[i] * (4096 - (int)lf[1]) + acol[i + a.tw] * (int)lf[1] + (1 << 18)) >> 19;
+                    } else {
+                        uint32_t aa = 1u << 18;
+                        for (int j = 0; j < lfs; j++)
+                            aa += (uint32_t)((int)acol[i + j * a.tw] * (int)(int16_t)lf[j]);
+                        A = (int32_t)aa >> 19;
+                    }
+                    if (A & 0x100)
+                        A = clip_u8(A);
+                    A &= 0xFF;
+                }
                 if (lfs == 1 && (cfs == 1 || chr_bilin)) {
                     Y = lcol[i] * 4;
                     if (cfs == 1 || cf[1] == 0) {
@@ -487,10 +515,10 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
                 switch (lay) {
                 case 0: q[0] = r; q[1] = g; q[2] = b; break;
                 case 1: q[0] = b; q[1] = g; q[2] = r; break;
-                case 2: q[0] = 255; q[1] = r; q[2] = g; q[3] = b; break;
-                case 3: q[0] = r; q[1] = g; q[2] = b; q[3] = 255; break;
-                case 4: q[0] = 255; q[1] = b; q[2] = g; q[3] = r; break;
-                default: q[0] = b; q[1] = g; q[2] = r; q[3] = 255; break;
+                case 2: q[0] = (uint8_t)A; q[1] = r; q[2] = g; q[3] = b; break;
+                case 3: q[0] = r; q[1] = g; q[2] = b; q[3] = (uint8_t)A; break;
+                case 4: q[0] = (uint8_t)A; q[1] = b; q[2] = g; q[3] = r; break;
+                default: q[0] = b; q[1] = g; q[2] = r; q[3] = (uint8_t)A; break;
                 }
             }
             uint8_t *d = a.dst + (size_t)f * a.dst_fp + (ptrdiff_t)(y0 + y) * a.dst_stride + bp * (x0 + xq);
@@ -557,6 +585,33 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
             for (int i = 0; i < 4; i++) Y[i] = (int32_t)ay[i] >> 19;
             for (int i = 0; i < 2; i++) { U[i] = (int32_t)au[i] >> 19; V[i] = (int32_t)av[i] >> 19; }
         }
+        /* the alpha byte: 255, or the source's alpha plane through the writer's own case (yuv2rgb_{1,2,X}_c_template with hasAlpha,
+         * output.c:1823-1835, 1875-1880, 1911-1916, 1939-1944: three different roundings, and X clips a PAIR when either value needs it) */
+        int A[4] = { 255, 255, 255, 255 };
+        if (a.alpha) {
+            const int16_t *acol = hs_a + lr * a.tw + xq;
+            if (lfs == 1 && (cfs == 1 || chr_bilin)) {
+                const bool uv0 = cfs == 1 || cf[1] == 0;
+                for (int i = 0; i < 4; i++)
+                    A[i] = clip_u8(uv0 ? (acol[i] * 255 + 16384) >> 15 : (acol[i] + 64) >> 7);
+            } else if (lum_bilin && chr_bilin) {
+                const int ya = lf[1], ya1 = 4096 - ya;
+                for (int i = 0; i < 4; i++)
+                    A[i] = clip_u8((acol[i] * ya1 + acol[i + a.tw] * ya) >> 19);
+            } else {
+                for (int i = 0; i < 4; i++) {
+                    uint32_t aa = 1u << 18;
+                    for (int j = 0; j < lfs; j++)
+                        aa += (uint32_t)((int)acol[i + j * a.tw] * (int)(int16_t)lf[j]);
+                    A[i] = (int32_t)aa >> 19;
+                }
+                for (int m = 0; m < 2; m++)
+                    if ((A[2 * m] | A[2 * m + 1]) & 0x100) {
+                        A[2 * m] = clip_u8(A[2 * m]);
+                        A[2 * m + 1] = clip_u8(A[2 * m + 1]);
+                    }
+            }
+        }
         uint8_t px[16];
         const int lay = a.bgr; /* 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
         const int bp = lay < 2 ? 3 : 4;
@@ -571,13 +626,14 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
                 const int yc = Y[2 * m + e] * k.cy;
                 const int r = clip_u8((br + yc) >> 16), g = clip_u8((bg + yc) >> 16), b = clip_u8((bb + yc) >> 16);
                 uint8_t *q = px + bp * (2 * m + e);
+                const uint8_t al = (uint8_t)A[2 * m + e];
                 switch (lay) {
                 case 0: q[0] = r; q[1] = g; q[2] = b; break;
                 case 1: q[0] = b; q[1] = g; q[2] = r; break;
-                case 2: q[0] = 255; q[1] = r; q[2] = g; q[3] = b; break;
-                case 3: q[0] = r; q[1] = g; q[2] = b; q[3] = 255; break;
-                case 4: q[0] = 255; q[1] = b; q[2] = g; q[3] = r; break;
-                default: q[0] = b; q[1] = g; q[2] = r; q[3] = 255; break;
+                case 2: q[0] = al; q[1] = r; q[2] = g; q[3] = b; break;
+                case 3: q[0] = r; q[1] = g; q[2] = b; q[3] = al; break;
+                case 4: q[0] = al; q[1] = b; q[2] = g; q[3] = r; break;
+                default: q[0] = b; q[1] = g; q[2] = r; q[3] = al; break;
                 }
             }
         }
@@ -596,7 +652,7 @@ __global__ __launch_bounds__(NT) void k_scale_rgb(FFHipScaleRgbArgs a, int spitc
     }
 }
 
-static size_t rgb_lds(const FFHipScaleRgbArgs &a, int *spl, int *spc, int *osc, int *ohl, int *ohc)
+static size_t rgb_lds(const FFHipScaleRgbArgs &a, int *spl, int *spc, int *osc, int *ohl, int *ohc, int *osa = nullptr, int *oha = nullptr)
 {
     *spl = ((a.max_cols_l + 6) & ~3) + 8;
     *spc = ((a.max_cols_c + 6) & ~3) + 8;
@@ -607,6 +663,14 @@ static size_t rgb_lds(const FFHipScaleRgbArgs &a, int *spl, int *spc, int *osc, 
     s += (size_t)a.max_rows_l * a.tw * 2;
     s = (s + 15) & ~(size_t)15; *ohc = (int)s;
     s += (size_t)2 * a.max_rows_c * (a.full ? a.tw : a.tw >> 1) * 2;
+    if (a.has_alpha) { /* the alpha plane's source tile and horizontal samples: the luma's sizes once more */
+        s = (s + 15) & ~(size_t)15;
+        if (osa) *osa = (int)s;
+        s += (size_t)a.max_rows_l * *spl;
+        s = (s + 15) & ~(size_t)15;
+        if (oha) *oha = (int)s;
+        s += (size_t)a.max_rows_l * a.tw * 2;
+    }
     return s + 16;
 }
 
@@ -650,8 +714,10 @@ int ffhip_launch_scale_rgb(const FFHipScaleRgbArgs &a, hipStream_t stream)
 {
     if (a.nframes <= 0)
         return 0;
-    int spl, spc, osc, ohl, ohc, flags = 0;
-    const size_t lds = rgb_lds(a, &spl, &spc, &osc, &ohl, &ohc);
+    int spl, spc, osc, ohl, ohc, osa = 0, oha = 0, flags = 0;
+    const size_t lds = rgb_lds(a, &spl, &spc, &osc, &ohl, &ohc, &osa, &oha);
+    if (a.alpha && !(((uintptr_t)a.alpha | (size_t)a.alpha_stride | a.alpha_fp) & 3))
+        flags |= 8;
     if (!(((uintptr_t)a.src[0] | (size_t)a.src_stride[0] | a.src_fp[0]) & 3))
         flags |= 1;
     if (a.chr_step == 1) {
@@ -668,13 +734,13 @@ int ffhip_launch_scale_rgb(const FFHipScaleRgbArgs &a, hipStream_t stream)
     const dim3 grid(a.tiles_x, a.tiles_y, a.nframes), block(NT);
     if (a.full) {
         if (a.hl.size == 4 && a.hc.size == 4)
-            hipLaunchKernelGGL((k_scale_rgb<4, true>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags);
+            hipLaunchKernelGGL((k_scale_rgb<4, true>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags, osa, oha);
         else
-            hipLaunchKernelGGL((k_scale_rgb<0, true>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags);
+            hipLaunchKernelGGL((k_scale_rgb<0, true>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags, osa, oha);
     } else if (a.hl.size == 4 && a.hc.size == 4)
-        hipLaunchKernelGGL((k_scale_rgb<4>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags);
+        hipLaunchKernelGGL((k_scale_rgb<4>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags, osa, oha);
     else
-        hipLaunchKernelGGL((k_scale_rgb<0>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags);
+        hipLaunchKernelGGL((k_scale_rgb<0>), grid, block, lds, stream, a, spl, spc, osc, ohl, ohc, flags, osa, oha);
     LAUNCH_CHECK();
     return 0;
 }

@@ -389,10 +389,11 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
      * target, and no range conversion (the reference converts plane 0 only, hscale.c:57-59; the second pass would convert its luma) */
     if (t->dst_alpha_fill < 0 || t->dst_alpha_fill > 2 ||
         (t->dst_alpha_fill == 2 && unscaled_rule(t) && !(rgb_layout(t->dstFormat) >= 2 && rgb_layout(t->dstFormat) <= 5 && t->srcFormat == FFHIP_PIX_FMT_YUV420P)) ||
-        (t->dst_alpha_fill == 2 && !unscaled_rule(t) && (fmt_rgb(t->dstFormat) || fmt_nv(t->dstFormat) || ffhip_pixfmt_hbd(t->srcFormat, nullptr, nullptr, nullptr, nullptr) ||
+        (t->dst_alpha_fill == 2 && !unscaled_rule(t) && fmt_rgb(t->dstFormat) && (rgb_layout(t->dstFormat) < 2 || fmt_nv(t->srcFormat) || fmt_hbd(t->srcFormat))) ||
+        (t->dst_alpha_fill == 2 && !unscaled_rule(t) && !fmt_rgb(t->dstFormat) && (fmt_nv(t->dstFormat) || ffhip_pixfmt_hbd(t->srcFormat, nullptr, nullptr, nullptr, nullptr) ||
                                     ffhip_pixfmt_hbd(t->dstFormat, nullptr, nullptr, nullptr, nullptr) || t->src_range != t->dst_range))) {
-        ffhip_set_error("ffhip_sws: a source alpha plane (dst_alpha_fill 2) goes with a planar 8-bit target and equal ranges, or with the equal-size "
-                        "yuva420p -> 32-bit RGB converter");
+        ffhip_set_error("ffhip_sws: a source alpha plane (dst_alpha_fill 2) goes with a planar 8-bit target and equal ranges, or with a 32-bit "
+                        "packed RGB target of an 8-bit planar source");
         return nullptr;
     }
     /* (a packed RGB target takes the source's range through the yuv2rgb coefficients the caller hands over: ff_yuv2rgb_c_init_tables'
@@ -578,6 +579,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         a.full = t->full_chr_h_int != 0; /* SWS_FULL_CHR_H_INT: a chroma sample per pixel, the yuv2rgb_full_* writers */
         for (int i = 0; i < 6; i++)
             a.fk[i] = t->yuv2rgb_full[i];
+        a.has_alpha = t->dst_alpha_fill == 2; /* the source's alpha plane into the alpha byte: the general kernel (the walker has no alpha lane) */
         if (a.vc.n != t->dstH || a.hc.n != (a.full ? t->dstW : (t->dstW + 1) / 2)) {
             ffhip_set_error("ffhip_sws: chroma banks do not match a packed-RGB target (need chrDstH == dstH)");
             ffhip_sws_freeContext(c);
@@ -586,7 +588,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         r = ffhip_plan_scale_rgb(&a, c->p[0].data(), c->p[1].data(), c->p[2].data(), c->p[3].data());
         /* column walker with RGB output: 4-tap vertical banks (yuv2rgb_X), <= 4-tap horizontal banks, no int16 wrap */
         const int limits[4] = { a.srcW, a.chrSrcW, a.srcH, a.chrSrcH };
-        if (!r && !a.full && !(t->dstW & 7) && build_fast_view(c, limits, true))
+        if (!r && !a.full && !a.has_alpha && !(t->dstW & 7) && build_fast_view(c, limits, true))
             c->cw_rgb = ffhip_cw_bank_ok(c->np[0].data(), 4, c->d[0].n, a.srcW, c->np[2].data(), 4, c->d[2].n, a.srcH) &&
                         ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, a.chrSrcW, c->np[3].data(), 4, c->d[3].n, a.chrSrcH) &&
                         c->d[1].n * 2 == t->dstW && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&
@@ -1051,7 +1053,7 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                                          const int srcStride[4], const size_t srcFramePitch[4], void *const dst[4],
                                          const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
 {
-    if (c && c->unscaled_yuv2rgb) /* one launch; a source alpha plane (src[3]) is read by it */
+    if (c && (c->unscaled_yuv2rgb || (c->t.dst_alpha_fill == 2 && fmt_rgb(c->t.dstFormat)))) /* one launch; a source alpha plane (src[3]) is read by it */
         return scale_batch_dev(c, nframes, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream_);
     if (c && c->t.dst_alpha_fill && (!dst || !dst[3] || (c->t.dst_alpha_fill == 2 && (!src || !src[3])))) {
         ffhip_set_error("ffhip_sws_scale_batch_dev: the format has an alpha plane: plane 3 is NULL");
@@ -1159,6 +1161,13 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
         a.chr_step = cstep;
         a.dst = (uint8_t *)dst[0]; a.dst_stride = dstStride[0]; a.dst_fp = dstFramePitch[0];
         a.nframes = nframes;
+        if (a.has_alpha) {
+            if (!src[3]) {
+                ffhip_set_error("ffhip_sws_scale_batch_dev: the source's alpha plane (plane 3) is NULL");
+                return FFHIP_EINVAL;
+            }
+            a.alpha = (const uint8_t *)src[3]; a.alpha_stride = srcStride[3]; a.alpha_fp = srcFramePitch[3];
+        }
         const char *ev = FFHIP_KNOB("FFHIP_SWS_FAST");
         uintptr_t al = (uintptr_t)s0 | (size_t)srcStride[0] | srcFramePitch[0] | (uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp |
                        (size_t)cus | (size_t)cvs | cuf | cvf | (uintptr_t)(cstep == 2 ? s1 : cu) | (uintptr_t)(cstep == 2 ? s1 : cv);
@@ -1516,7 +1525,7 @@ extern "C" int ffhip_sws_scale(FFHipSwsContext *c, const uint8_t *const src[], c
         return FFHIP_EINVAL;
     FFHipDeviceGuard dg(c->device);
     std::lock_guard<std::mutex> lk(c->mu);
-    if (c->t.dst_alpha_fill != 2 || c->unscaled_yuv2rgb)
+    if (c->t.dst_alpha_fill != 2 || c->unscaled_yuv2rgb || fmt_rgb(c->t.dstFormat))
         return sws_scale_locked(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
     /* alpha on both sides: a second pass whose luma is the alpha plane (see ffhip_sws_scale_batch_dev); whole frames only — the slice
      * collection holds one frame's source */
@@ -1576,7 +1585,7 @@ static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], cons
     PlaneDesc sp[4], dp[3];
     int ns = plane_list(t.srcFormat, t.srcW, srcRows, sp);
     const int nd = plane_list(t.dstFormat, t.dstW, unscaled ? srcSliceH : t.dstH, dp);
-    if (unscaled && t.dst_alpha_fill == 2) { /* the source's alpha plane rides along as a fourth plane of the luma's size */
+    if ((unscaled || fmt_rgb(t.dstFormat)) && t.dst_alpha_fill == 2) { /* the source's alpha plane rides along as a fourth plane of the luma's size */
         if (!src[3]) {
             ffhip_set_error("ffhip_sws_scale: the source's alpha plane (plane 3) is NULL");
             return FFHIP_EINVAL;
@@ -1613,8 +1622,9 @@ static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], cons
     for (int i = 0; i < ns; i++) {
         /* a slice brings luma rows [y, y + h) and chroma rows [y >> 1, (y + h + 1) >> 1) (swscale.c:280-283) */
         const int vs = fmt_vsub(c->t.srcFormat);
-        const int row0 = !sliced ? 0 : i ? srcSliceY >> vs : srcSliceY;
-        const int rows = !sliced ? sp[i].rows : i ? (-((-(srcSliceY + srcSliceH)) >> vs)) - (srcSliceY >> vs) : srcSliceH;
+        const bool cpl = i == 1 || i == 2; /* (plane 3, when there is one, is the alpha plane: the luma's geometry) */
+        const int row0 = !sliced ? 0 : cpl ? srcSliceY >> vs : srcSliceY;
+        const int rows = !sliced ? sp[i].rows : cpl ? (-((-(srcSliceY + srcSliceH)) >> vs)) - (srcSliceY >> vs) : srcSliceH;
         HIP_TRY(copy2d(base + off_s[i] + (size_t)row0 * pitch_s[i], pitch_s[i], src[i], srcStride[i], sp[i].wbytes, rows,
                        hipMemcpyHostToDevice));
         dsrc[i] = base + off_s[i];

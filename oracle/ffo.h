@@ -76,6 +76,8 @@ void ffo_yuv2rgb_2(const FfoYuv2RgbLuts *l, const int16_t *const lum[2], const i
                    int dstW, int yalpha, int uvalpha, int layout);
 void ffo_yuv2rgb_1(const FfoYuv2RgbLuts *l, const int16_t *lum, const int16_t *const cu[2], const int16_t *const cv[2], uint8_t *dest, int dstW,
                    int uvalpha, int layout);
+/* the alpha bytes of a 32-bit RGB picture from the source's alpha plane, after ffo_sws_scale_frame() (yuv2rgba32_{1,2,X}_c and the _full twins) */
+int  ffo_sws_rgba_alpha(const FfoSwsTables *t, const uint8_t *alpha, int alphaStride, uint8_t *dst, int dstStride);
 int  ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], const int srcStride[3],
                          uint8_t *const dst[3], const int dstStride[3]);
 /* the same above 8 bits (ffo_sws_hbd.c): a format is (depth, layout): layout 0 planar LE samples in the low bits (8-bit planar when

@@ -366,6 +366,81 @@ static void range15_line(int16_t *dst, int width, uint32_t coeff_, int64_t offse
     }
 }
 
+/*
+ * The alpha byte of a 32-bit packed RGB target whose SOURCE has an alpha plane (needAlpha, libswscale/utils.c:1398): the plane goes
+ * through the luma's horizontal bank (lum_h_scale on plane 3, hscale.c:63-79) and the packed writer forms A beside Y from the same
+ * lines with the luma's vertical coefficients — each of the writers in its own way (libswscale/output.c):
+ *   yuv2rgb_X     :1823-1835   (sum + (1 << 18)) >> 19, and the PAIR (A1, A2) clipped when (A1 | A2) & 0x100
+ *   yuv2rgb_2     :1875-1880   (a0 * (4096 - yalpha) + a1 * yalpha) >> 19, clipped
+ *   yuv2rgb_1     :1911-1916   uvalpha == 0: (a * 255 + 16384) >> 15;   :1939-1944  else (a + 64) >> 7; clipped
+ *   yuv2rgb_full_X :2193-2200  (sum + (1 << 18)) >> 19;  _2 :2241-2245  (... + (1 << 18)) >> 19;  _1 :2278-2302  (a + 64) >> 7;
+ *                              each clipped when A & 0x100
+ * Called after ffo_sws_scale_frame() has written the picture (alpha 255): overwrites the alpha bytes.  alpha: the source's plane 3.
+ */
+int ffo_sws_rgba_alpha(const FfoSwsTables *t, const uint8_t *alpha, int alphaStride, uint8_t *dst, int dstStride)
+{
+    const int srcH = t->srcH, dstW = t->dstW, dstH = t->dstH, lpitch = dstW + 8;
+    const int lay = rgb_layout(t->dstFormat), lfs = t->vLum.size, cfs = t->vChr.size;
+    const int abyte = lay == 2 || lay == 4 ? 0 : 3;
+    int16_t *ha;
+    if (lay < 2 || lay > 5)
+        return -1;
+    ha = malloc(sizeof(int16_t) * (size_t)lpitch * srcH);
+    if (!ha)
+        return -1;
+    for (int y = 0; y < srcH; y++)
+        ffo_hscale8to15(ha + (size_t)y * lpitch, dstW, alpha + (ptrdiff_t)y * alphaStride, t->hLum.filter, t->hLum.pos, t->hLum.size);
+    for (int y = 0; y < dstH; y++) {
+        const uint16_t *lf = (const uint16_t *)t->vLum.filter + (size_t)y * lfs;
+        const uint16_t *cf = (const uint16_t *)t->vChr.filter + (size_t)y * cfs;
+        const int16_t *a0 = ha + (size_t)t->vLum.pos[y] * lpitch;
+        uint8_t *d = dst + (ptrdiff_t)y * dstStride;
+        const int chr_bilin = cfs == 2 && cf[1] + cf[0] == 4096 && cf[1] <= 4096U;
+        const int lum_bilin = lfs == 2 && lf[1] + lf[0] == 4096 && lf[1] <= 4096U;
+        const int one = lfs == 1 && (cfs == 1 || chr_bilin), two = !one && lum_bilin && chr_bilin;
+        const int uvalpha = one && cfs == 2 ? cf[1] : 0;
+        const int npx = t->full_chr ? dstW : dstW & ~1;
+        for (int i = 0; i < npx; i++) {
+            int A;
+            if (one) {
+                A = t->full_chr || uvalpha ? (a0[i] + 64) >> 7 : (a0[i] * 255 + 16384) >> 15;
+            } else if (two) {
+                A = (a0[i] * (4096 - (int)lf[1]) + a0[i + lpitch] * (int)lf[1] + (t->full_chr ? 1 << 18 : 0)) >> 19;
+            } else {
+                uint32_t acc = 1 << 18;
+                for (int j = 0; j < lfs; j++)
+                    acc += (uint32_t)(a0[i + (size_t)j * lpitch] * (int)(int16_t)lf[j]);
+                A = (int32_t)acc >> 19;
+            }
+            if (t->full_chr) {
+                if (A & 0x100)
+                    A = clip_u8(A);
+            } else if (one || two) {
+                A = clip_u8(A);
+            } /* (the X writer decides for the PAIR: below) */
+            d[4 * i + abyte] = (uint8_t)A;
+            if (!t->full_chr && !one && !two && (i & 1)) {
+                /* recompute both of the pair unclipped, then clip both if either carries bit 8 */
+                int P[2];
+                for (int e = 0; e < 2; e++) {
+                    uint32_t acc = 1 << 18;
+                    for (int j = 0; j < lfs; j++)
+                        acc += (uint32_t)(a0[i - 1 + e + (size_t)j * lpitch] * (int)(int16_t)lf[j]);
+                    P[e] = (int32_t)acc >> 19;
+                }
+                if ((P[0] | P[1]) & 0x100) {
+                    P[0] = clip_u8(P[0]);
+                    P[1] = clip_u8(P[1]);
+                }
+                d[4 * (i - 1) + abyte] = (uint8_t)P[0];
+                d[4 * i + abyte] = (uint8_t)P[1];
+            }
+        }
+    }
+    free(ha);
+    return dstH;
+}
+
 int ffo_sws_scale_frame(const FfoSwsTables *t, const uint8_t *const src[3], const int srcStride[3],
                         uint8_t *const dst[3], const int dstStride[3])
 {

@@ -88,6 +88,7 @@ def oracle():
             f.restype = None
         L.ffo_sws_range_constants.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
         L.ffo_sws_range_constants.restype = None
+        L.ffo_sws_rgba_alpha.argtypes = [C.POINTER(OSwsTables), u8p, C.c_int, u8p, C.c_int]
         L.ffo_sws_scale_frame.argtypes = [C.POINTER(OSwsTables), C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(u8p),
                                           C.POINTER(C.c_int)]
         for n in ("ffo_h264_idct_add", "ffo_h264_idct8_add", "ffo_h264_idct_dc_add", "ffo_h264_idct8_dc_add"):

@@ -112,6 +112,47 @@ def test_unscaled_converter_forms(sf, df, w, h, pad, n):
     ctx.close()
 
 
+def _rgba_cases():
+    import test_sws_unscaled_forms_cpu as F
+    return F.RGBA_ALPHA_CASES
+
+
+@pytest.mark.parametrize("sf,sw,sh,df,dw,dh,flags", _rgba_cases())
+def test_scaled_source_alpha_into_packed_rgba(sf, sw, sh, df, dw, dh, flags):
+    """a YUVA source scaled to the four 32-bit RGB orders: the source's alpha plane goes through the luma banks into the alpha byte
+    (yuv2rgba32_{1,2,X}_c and the _full twins; the oracle's form is pinned to the reference in tests/test_sws_unscaled_forms_cpu.py) —
+    batch face (3 frames), host face, source slices"""
+    import test_sws_unscaled_forms_cpu as F
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    rng = np.random.default_rng(sw + dw + len(df) + flags % 97)
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=2)
+    src[3][:4] = 255
+    src[3][4:8] = 0
+    want, _ = F.rgba_alpha_oracle(sf, sw, sh, df, dw, dh, flags, src)
+    ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    n = 3
+    dsrc = _upload(src, n=n)
+    ddst = [torch.zeros((n, dh, 4 * dw + 8), dtype=torch.uint8, device="cuda:0")]
+    ctx.scale_batch(dsrc, ddst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        got = ddst[0][f, :, :4 * dw].cpu().numpy()
+        assert np.array_equal(got, want[0]), "frame %d: %d bytes differ" % (f, (got != want[0]).sum())
+    hd = [np.zeros_like(want[0])]
+    assert ctx.scale(src, hd) == dh
+    assert np.array_equal(hd[0], want[0])
+    if sh >= 12:
+        hd = [np.zeros_like(want[0])]
+        vs = 0 if sf in ("yuva422p", "yuva444p") else 1
+        rets = []
+        for y0, y1 in ((0, 4), (4, 20), (20, sh)):
+            sl = [src[0][y0:], src[1][y0 >> vs:], src[2][y0 >> vs:], src[3][y0:]]
+            rets.append(ctx.scale(sl, hd, y0, y1 - y0))
+        assert rets == [0, 0, dh] and np.array_equal(hd[0], want[0])
+    ctx.close()
+
+
 def test_unscaled_colorspace_set_on_a_live_context():
     """sws_setColorspaceDetails() after the init (libswscale/utils.c:848-1000): ffhip_sws_yuv2rgb_coeffs + ffhip_sws_set_yuv2rgb"""
     from ffmpeg_amd import swscale as S, _lib

@@ -111,3 +111,52 @@ def test_sliced_calls_equal_the_frame():
         p, s = ffi.planes(sl)
         O.ffo_yuv2rgb_unscaled(C.byref(luts), w, p, s, y, sh, ffi.planes(parts)[0], ffi.planes(parts)[1], 5, 0, 1)
     assert np.array_equal(whole[0], parts[0])
+
+
+# (source, sw, sh, target, dw, dh, flags): bicubic -> yuv2rgb_X; an exact-2x bilinear has 2-tap 4096-sum rows -> yuv2rgb_2 on the rows where
+# both banks are; equal sizes + ACCURATE_RND -> yuv2rgb_1 rows; 0x2000 / 4:4:4 / odd widths -> the _full writers
+RGBA_ALPHA_CASES = [("yuva420p", 64, 36, "rgba", 128, 72, ffi.SWS_BICUBIC), ("yuva420p", 64, 36, "argb", 100, 50, ffi.SWS_BICUBIC),
+                    ("yuva420p", 96, 54, "bgra", 64, 36, ffi.SWS_BILINEAR), ("yuva420p", 64, 36, "abgr", 128, 72, ffi.SWS_BILINEAR),
+                    ("yuva420p", 64, 36, "rgba", 64, 36, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND),
+                    ("yuva420p", 64, 36, "bgra", 64, 72, ffi.SWS_POINT), ("yuva422p", 64, 36, "rgba", 96, 54, ffi.SWS_BICUBIC),
+                    ("yuva444p", 64, 36, "argb", 96, 54, ffi.SWS_BICUBIC), ("yuva420p", 64, 36, "rgba", 97, 55, ffi.SWS_BICUBIC),
+                    ("yuva420p", 64, 36, "bgra", 128, 72, ffi.SWS_BILINEAR | 0x2000), ("yuva444p", 64, 36, "abgr", 64, 36, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND),
+                    ("yuva420p", 64, 36, "rgba", 64, 72, ffi.SWS_POINT | 0x2000),
+                    ("yuva420p", 64, 36, "rgba", 64, 36, ffi.SWS_BILINEAR | ffi.SWS_ACCURATE_RND),          # yuv2rgb_1 with uvalpha != 0
+                    ("yuva420p", 64, 36, "argb", 64, 36, ffi.SWS_BILINEAR | ffi.SWS_ACCURATE_RND | 0x2000), # yuv2rgb_full_1
+                    ("yuva420p", 640, 360, "bgra", 1280, 720, ffi.SWS_BICUBIC)]
+
+
+def rgba_alpha_oracle(sf, sw, sh, df, dw, dh, flags, src):
+    """the oracle's frame with the source's alpha plane in the alpha byte; returns (picture, host tables)"""
+    from ffmpeg_amd import swscale as S
+    O = ffi.oracle()
+    ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
+    assert ht.t.dst_alpha_fill == 2 and not ht.unscaled_yuv2rgb
+    t = ffi.make_otables(sw, sh, ht.t.srcFormat, dw, dh, PIX[df], ht.t.flags, ht.banks(), ht.coeffs(), full=ht.full())
+    got = ffi.alloc_frame(PIX[df], dw, dh)
+    sp, ss = ffi.planes(src[:3])
+    gp, gs = ffi.planes(got)
+    assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh
+    assert O.ffo_sws_rgba_alpha(C.byref(t), ptr(src[3]), src[3].strides[0], ptr(got[0]), got[0].strides[0]) == dh
+    return got, ht
+
+
+@pytest.mark.parametrize("sf,sw,sh,df,dw,dh,flags", RGBA_ALPHA_CASES)
+def test_scaled_source_alpha_into_packed_rgba(sf, sw, sh, df, dw, dh, flags):
+    """yuv2rgba32_{1,2,X}_c and the _full twins (libswscale/output.c:1789-1939, 2160-2310): the oracle's picture + ffo_sws_rgba_alpha ==
+    the reference's sws_scale() of a YUVA source to the four 32-bit orders"""
+    R = ffi.ref()
+    rng = np.random.default_rng(sw + dw + len(df) + flags % 97)
+    src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=2)
+    src[3][:4] = 255   # saturated rows: where the bicubic overshoot makes the writers clip
+    src[3][4:8] = 0
+    ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, PIX[df], flags, 1)
+    assert ctx and not R.ffref_sws_is_unscaled(ctx)
+    want = ffi.alloc_frame(PIX[df], dw, dh)
+    sp, ss = ffi.planes(src)
+    dp, ds = ffi.planes(want)
+    assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, dp, ds) == dh
+    R.ffref_sws_free(ctx)
+    got, _ = rgba_alpha_oracle(sf, sw, sh, df, dw, dh, flags, src)
+    assert np.array_equal(got[0], want[0]), "%d bytes differ" % (got[0] != want[0]).sum()
