@@ -531,8 +531,8 @@ int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_
             ffhip_set_error("ffhip_sws: batch too large for one launch");
             return FFHIP_EINVAL;
         }
-        const char *ev32 = FFHIP_KNOB("FFHIP_YUV2RGB_VARIANT"); /* 's': plain stores (measured variant) */
-        const bool pst32 = ev32 && strchr(ev32, 's');
+        const char *ev32 = FFHIP_KNOB("FFHIP_YUV2RGB_VARIANT"); /* "st": plain stores (measured variant) */
+        const bool pst32 = ev32 && strstr(ev32, "st");
 #define L32(LY) do { if (vec && pst32) hipLaunchKernelGGL((k_yuv420p_rgb32<LY, true, false>), grid, block, 0, stream, a); \
                      else if (vec) hipLaunchKernelGGL((k_yuv420p_rgb32<LY, true>), grid, block, 0, stream, a); \
                      else hipLaunchKernelGGL((k_yuv420p_rgb32<LY, false>), grid, block, 0, stream, a); } while (0)
@@ -557,10 +557,10 @@ int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_
         const bool plain = ev && ev[0] == 'p';
         FFHipYuv2RgbArgs af = a;
         af.flat = flat;
-        /* measured variants (rgb24 only): 's' plain stores (the kernel up to round 4: 3-6 % slower than the non-temporal ones, profiles/
-         * r05_rgb24_variants.txt), 'x' XCD-contiguous numbering, 'l' non-temporal loads as well */
-        const bool pst = ev && strchr(ev, 's'), xcd = ev && strchr(ev, 'x'), ntl = ev && strchr(ev, 'l');
-        if (pst || xcd || ntl) {
+        /* measured variants (rgb24 only): "st" plain stores (the kernel up to round 4: 3-6 % slower than the non-temporal ones, profiles/
+         * r05_rgb24_variants.txt), "xcd" XCD-contiguous numbering, "ntl" non-temporal loads as well */
+        const bool pst = ev && strstr(ev, "st"), xcd = ev && strstr(ev, "xcd"), ntl = ev && strstr(ev, "ntl");
+        if (!bgr && (pst || xcd || ntl)) { /* words: "st", "xcd", "ntl", "st+xcd" (none of them inside "old" / "plain" / "flat") */
             if (pst && xcd) hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, false, true>), grid, block, 0, stream, af);
             else if (pst)   hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, false, false>), grid, block, 0, stream, af);
             else if (ntl)   hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, true, false, true>), grid, block, 0, stream, af);

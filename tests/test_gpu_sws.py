@@ -540,26 +540,19 @@ def test_alpha_on_both_sides(case):
 ALPHA_CASES = [("yuv420p", 64, 36, "yuva420p", 128, 72, ffi.SWS_BICUBIC, 0), ("yuv422p", 65, 37, "yuva444p", 40, 30, ffi.SWS_BILINEAR, 5),
                ("nv12", 64, 36, "yuva422p", 96, 54, ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND, 0), ("yuva420p", 64, 36, "yuv420p", 128, 72, ffi.SWS_BICUBIC, 3),
                ("yuva444p", 64, 36, "rgb24", 100, 50, ffi.SWS_BICUBIC, 0), ("yuva422p", 66, 38, "nv12", 33, 19, ffi.SWS_BILINEAR, 0),
-               ("yuv420p", 64, 36, "yuva420p", 64, 36, ffi.SWS_BICUBIC, 0), ("yuv420p", 960, 540, "yuva420p", 1920, 1080, ffi.SWS_BICUBIC, 0),
-               ("yuva420p", 960, 540, "bgra", 1920, 1080, ffi.SWS_BICUBIC, 0)]
+               ("yuv420p", 64, 36, "yuva420p", 64, 36, ffi.SWS_BICUBIC, 0), ("yuv420p", 960, 540, "yuva420p", 1920, 1080, ffi.SWS_BICUBIC, 0)]
 
 
 @pytest.mark.parametrize("case", ALPHA_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x_p%d" % c)
 def test_alpha_on_one_side(case):
     """yuva420p / 422p / 444p on one side: a source's alpha plane is not read, a target's is filled with 255 (swscale.c:536-553) and the
-    other planes are the base formats' (pinned to the reference in test_oracle_vs_ref.py::test_alpha_on_one_side).  A source alpha plane
-    into packed RGBA is refused (planar alpha on both sides: test_alpha_on_both_sides)."""
+    other planes are the base formats' (pinned to the reference in test_oracle_vs_ref.py::test_alpha_on_one_side).  (Alpha on both sides:
+    planar, test_alpha_on_both_sides; a source alpha plane into packed RGBA, test_scaled_source_alpha_into_packed_rgba.)"""
     from ffmpeg_amd import swscale as S
     torch = _torch()
     sf, sw, sh, df, dw, dh, flags, pad = case
     base = {"yuva420p": "yuv420p", "yuva422p": "yuv422p", "yuva444p": "yuv444p"}
     bs, bd = base.get(sf, sf), base.get(df, df)
-    if sf in base and df == "bgra":
-        with pytest.raises(ValueError):
-            S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
-        with pytest.raises((ValueError, RuntimeError), match="alpha"):
-            S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], flags)
-        return
     rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
     src = ffi.alloc_frame(PIX[sf], sw, sh, rng, pad=pad)
     ht = S.HostTables(sw, sh, PIX[bs], dw, dh, PIX[bd], flags)

@@ -1,5 +1,5 @@
 """tools/alloc_sensitivity_rgb24.py — yuv420p -> rgb24 4K x 64 on six different allocations inside ONE process: the product kernel against the
-XCD-contiguous workgroup numbering (FFHIP_YUV2RGB_VARIANT=x, measure build).  The numbering wins 5 % on some buffers and loses 5 % on others
+XCD-contiguous workgroup numbering (FFHIP_YUV2RGB_VARIANT=xcd, measure build).  The numbering wins 5 % on some buffers and loses 5 % on others
 (profiles/r05_rgb24_variants.txt); the product's row-pair order does not move.  Why the variant is not the product."""
 import json, os, sys
 sys.path.insert(0, os.getcwd())
@@ -17,7 +17,7 @@ for trial in range(6):
     dst = [torch.empty((n, h, 3 * w), dtype=torch.uint8, device=dev)]
     keep += src + dst
     res = {}
-    for var in ("", "x", "", "x"):
+    for var in ("", "xcd", "", "xcd"):
         if var: os.environ["FFHIP_YUV2RGB_VARIANT"] = var
         else: os.environ.pop("FFHIP_YUV2RGB_VARIANT", None)
         for _ in range(10): ctx.scale_batch(src, dst)
@@ -26,5 +26,5 @@ for trial in range(6):
         for _ in range(60): ctx.scale_batch(src, dst)
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 60
-        res.setdefault(var or "product", []).append(round(n * w * h * 4.5 / (ms * 1e-3) / 8e12, 4))
+        res.setdefault("x" if var else "product", []).append(round(n * w * h * 4.5 / (ms * 1e-3) / 8e12, 4))
     print(trial, hex(dst[0].data_ptr()), hex(src[0].data_ptr()), res)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/bench_rgb24_variants.py — yuv420p -> rgb24 4K, 64 frames: the product kernel and the measured variants of the measure build
-(FFHIP_YUV2RGB_VARIANT: s = plain stores (the kernel up to round 4), x = XCD-contiguous workgroup numbering, l = non-temporal loads too),
+(FFHIP_YUV2RGB_VARIANT: st = plain stores (the kernel up to round 4), xcd = XCD-contiguous workgroup numbering, ntl = non-temporal loads too),
 three alternating passes, 20 warm-up + 100 timed launches each."""
 import json
 import os
@@ -19,7 +19,7 @@ src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev) for r, c 
 dst = [torch.empty((n, h, 3 * w), dtype=torch.uint8, device=dev)]
 ref = None
 for p in range(3):
-    for var in ("", "s", "x", "l", "sx"):
+    for var in ("", "st", "xcd", "ntl", "st+xcd"):
         if var:
             os.environ["FFHIP_YUV2RGB_VARIANT"] = var
         else:
