@@ -504,7 +504,10 @@ def test_round3_sws_golden():
                 luts = ffi.OLuts()
                 kk = ffi.OYuv2RgbCoeffs(*[co[n] for n in ("cy", "oy", "crv", "cbu", "cgu", "cgv", "yoffs")])
                 O.ffo_yuv2rgb_luts_init(C.byref(luts), C.byref(kk))
-                O.ffo_yuv420p_to_rgb24(C.byref(luts), sw, sp, ss, 0, sh, ptr(got[0]), got[0].strides[0], ffi.RGB_LAYOUT[ffi.PIX[dn]])
+                if sn == "yuv422p":   # the table converter's 4:2:2 form (YUV422FUNC, yuv2rgb.c:238-320): a chroma row per luma row
+                    O.ffo_yuv2rgb_unscaled(C.byref(luts), sw, sp, ss, 0, sh, gp, gs, ffi.RGB_LAYOUT[ffi.PIX[dn]], 1, 0)
+                else:
+                    O.ffo_yuv420p_to_rgb24(C.byref(luts), sw, sp, ss, 0, sh, ptr(got[0]), got[0].strides[0], ffi.RGB_LAYOUT[ffi.PIX[dn]])
             else:
                 assert O.ffo_sws_scale_frame(C.byref(t), sp, ss, gp, gs) == dh, case
         for a, b in zip(got, want):

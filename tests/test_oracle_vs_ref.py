@@ -1453,7 +1453,9 @@ def test_422_to_packed_rgb(dst, sf, sw, sh, dw, dh, flags):
     assert R.ffref_sws_scale(R_ctx, sp, ss, 0, sh, dp, ds) == dh
     R.ffref_sws_free(R_ctx)
     ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags)
-    assert not ht.unscaled_yuv2rgb
+    # equal sizes without ACCURATE_RND: the host tables name the table converter now (round 5; its own 4:2:2 form is pinned in
+    # tests/test_sws_unscaled_forms_cpu.py) — the banks they carry still describe the scaler's one-tap path, whose bytes are the same
+    assert ht.unscaled_yuv2rgb == (sw == dw and sh == dh and not flags & ffi.SWS_ACCURATE_RND)
     t = ffi.make_otables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags, ht.banks(), ht.coeffs())
     got = ffi.alloc_frame(PIX[dst], dw, dh)
     gp, gs = ffi.planes(got)
@@ -1534,8 +1536,8 @@ def test_alpha_on_one_side(sf, dst, sw, sh, dw, dh, flags):
         assert len(out[0]) == 4 and (out[0][3] == 255).all()
     ht = S.HostTables(sw, sh, PIX[sf], dw, dh, PIX[dst], flags)
     assert ht.t.dst_alpha_fill == (dst in base) and ht.t.srcFormat == PIX[base.get(sf, sf)] and ht.t.dstFormat == PIX[base.get(dst, dst)]
-    with pytest.raises(ValueError):        # a source alpha plane into the alpha channel of packed RGB: the yuv2rgba writers are not built
-        S.HostTables(sw, sh, PIX["yuva420p"], dw, dh, PIX["rgba"], flags)
+    # (a source alpha plane into the alpha byte of packed RGB is alpha on BOTH sides: dst_alpha_fill 2, tests/test_sws_unscaled_forms_cpu.py)
+    assert S.HostTables(sw, sh, PIX["yuva420p"], 2 * sw, sh, PIX["rgba"], flags).t.dst_alpha_fill == 2
 
 
 ALPHA2_CASES = [("yuva420p", "yuva420p", 64, 36, 128, 72, 4), ("yuva420p", "yuva444p", 65, 37, 40, 30, 2), ("yuva444p", "yuva422p", 64, 36, 96, 54, 4 | 0x40000),
