@@ -231,6 +231,7 @@ def lib():
         "ffhip_aac_update_ltp_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
         "ffhip_vp9_lf_sb_tables": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
         "ffhip_vp9_lf_sb_ctables": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+        "ffhip_vp9_loopfilter_frames_ssc_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp]),
         "ffhip_vp9_loopfilter_frame_ssc_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp, vp]),
         "ffhip_vp9_loopfilter_frame_dev": (C.c_int, [C.c_int, vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),
         "ffhip_vp9_loopfilter_frame_ss_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, vp]),

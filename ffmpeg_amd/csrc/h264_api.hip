@@ -475,13 +475,23 @@ extern "C" int ffhip_vp9_loopfilter_frames_dev(int bit_depth, int ss_h, int ss_v
 {
     if (!hevc_bd_ok(bit_depth) || npics < 0 || (npics && !pics) || cols < 0 || rows < 0 || rows > 8 * 1364)
         return FFHIP_EINVAL;
-    if (ss_h != ss_v) { /* 4:4:0 / 4:2:2: the plain kernel of those formats takes one picture per launch (ffhip_vp9_loopfilter_frame_ssc_dev) */
-        ffhip_set_error("ffhip_vp9_loopfilter_frames_dev: chroma sub-sampling %d x %d is not batched: ffhip_vp9_loopfilter_frame_ssc_dev per picture", ss_h, ss_v);
-        return FFHIP_ENOSYS;
+    if (ss_h != ss_v) { /* 4:4:0 / 4:2:2 need the chroma tables of their rectangular superblocks: ffhip_vp9_loopfilter_frames_ssc_dev */
+        ffhip_set_error("ffhip_vp9_loopfilter_frames_dev: chroma sub-sampling %d x %d takes chroma tables: ffhip_vp9_loopfilter_frames_ssc_dev", ss_h, ss_v);
+        return FFHIP_EINVAL;
     }
     if (!ffhip_have_device())
         return FFHIP_ENOSYS;
     return ffhip_launch_vp9_lf_frames(bit_depth, npics, pics, stride_y, stride_uv, cols, rows, (hipStream_t)stream, ss_h ? 0 : 1);
+}
+
+extern "C" int ffhip_vp9_loopfilter_frames_ssc_dev(int bit_depth, int ss_h, int ss_v, int npics, const FFHipVp9LfPicC *pics, ptrdiff_t stride_y,
+                                                   ptrdiff_t stride_uv, int cols, int rows, void *stream)
+{
+    if (!hevc_bd_ok(bit_depth) || npics < 0 || (npics && !pics) || cols < 0 || rows < 0 || rows > 8 * 1364 || ss_h == ss_v || ((ss_h | ss_v) & ~1))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device())
+        return FFHIP_ENOSYS;
+    return ffhip_launch_vp9_lf_frames_ssc(bit_depth, ss_h, ss_v, npics, pics, stride_y, stride_uv, cols, rows, (hipStream_t)stream);
 }
 
 /* ---- AVFloatDSPContext vector operations ---------------------------------------- */

@@ -115,6 +115,10 @@ int ffhip_launch_vp9_loop_filter(uint8_t *base, ptrdiff_t stride, const FFHipVp9
 struct FFHipVp9LfPics { int n; int pad; FFHipVp9LfPic pic[FFHIP_VP9_LF_PICS]; };
 int ffhip_launch_vp9_lf_frames(int bd, int npics, const FFHipVp9LfPic *pics, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows, hipStream_t stream,
                                int planes444 = 0);
+/* ... with the chroma tables of the rectangular-superblock formats (== FFHipVp9LfPicC) */
+struct FFHipVp9LfPicsC { int n; int pad; FFHipVp9LfPicC pic[FFHIP_VP9_LF_PICS]; };
+int ffhip_launch_vp9_lf_frames_ssc(int bd, int ss_h, int ss_v, int npics, const FFHipVp9LfPicC *pics, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
+                                   hipStream_t stream);
 /* 4:2:2 / 4:4:0: luma by `tabs`' y part, the rectangular chroma superblocks by `ctabs` */
 int ffhip_launch_vp9_lf_frame_ssc(int bd, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
                                   const FFHipVp9LfSb *tabs, const FFHipVp9LfSbC *ctabs, hipStream_t stream);

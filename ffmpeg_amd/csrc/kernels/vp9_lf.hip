@@ -491,6 +491,75 @@ __global__ __launch_bounds__(64) void k_vp9_lf_frame_ssc(uint8_t *py, uint8_t *p
         vp9_lf_plane_row<PIX, 64, 32>(p, suv, cols, rows, r, ctabs, progress + (1 + pl) * sb_rows, fail, bd);
 }
 
+/* N pictures of one geometry side by side (round 5): blockIdx.y = the picture, each with its planes, tables and progress counters */
+template <typename PIX>
+__global__ __launch_bounds__(64) void k_vp9_lf_frames_ssc(FFHipVp9LfPicsC S, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows, int *progress_all, int *fail,
+                                                          int bd, int ss422)
+{
+    const int sb_rows = (rows + 7) >> 3, b = (int)blockIdx.x;
+    uint8_t *const py = S.pic[blockIdx.y].y, *const pu = S.pic[blockIdx.y].u, *const pv = S.pic[blockIdx.y].v;
+    const FFHipVp9LfSb *const tabs = S.pic[blockIdx.y].tables;
+    const FFHipVp9LfSbC *const ctabs = S.pic[blockIdx.y].ctables;
+    int *const progress = progress_all + (size_t)blockIdx.y * (size_t)(3 * sb_rows);
+    if (b < sb_rows) {
+        vp9_lf_sb_row<PIX, false>(py, py, sy, cols, rows, b, tabs, progress, fail, bd);
+        return;
+    }
+    const int pl = (b - sb_rows) / sb_rows, r = (b - sb_rows) % sb_rows;
+    uint8_t *const p = pl ? pv : pu;
+    if (ss422)
+        vp9_lf_plane_row<PIX, 32, 64>(p, suv, cols, rows, r, ctabs, progress + (1 + pl) * sb_rows, fail, bd);
+    else
+        vp9_lf_plane_row<PIX, 64, 32>(p, suv, cols, rows, r, ctabs, progress + (1 + pl) * sb_rows, fail, bd);
+}
+
+int ffhip_launch_vp9_lf_frames_ssc(int bd, int ss_h, int ss_v, int npics, const FFHipVp9LfPicC *pics, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
+                                   hipStream_t stream)
+{
+    const int sb_rows = (rows + 7) >> 3;
+    if (cols <= 0 || rows <= 0 || npics <= 0)
+        return 0;
+    uintptr_t al = (size_t)sy | (size_t)suv;
+    for (int i = 0; i < npics; i++) {
+        if (!pics[i].y || !pics[i].u || !pics[i].v || !pics[i].tables || !pics[i].ctables)
+            return FFHIP_EINVAL;
+        al |= (uintptr_t)pics[i].y | (uintptr_t)pics[i].u | (uintptr_t)pics[i].v;
+    }
+    if ((bd != 8 && bd != 10 && bd != 12) || ss_h == ss_v || ((ss_h | ss_v) & ~1) || (al & 3)) {
+        ffhip_set_error("ffhip_vp9_loopfilter_frames_ssc: bit depth %d (8, 10, 12), sub-sampling 1 x 0 or 0 x 1; planes and strides 4-byte aligned", bd);
+        return FFHIP_EINVAL;
+    }
+    const int per_pic = 3 * sb_rows;
+    if (per_pic + 1 > FFHIP_PROGRESS_SLOT_INTS)
+        return FFHIP_EINVAL;
+    int per = (FFHIP_PROGRESS_SLOT_INTS - 1) / per_pic;
+    per = per > FFHIP_VP9_LF_PICS ? FFHIP_VP9_LF_PICS : per;
+    for (int p0 = 0; p0 < npics; p0 += per) {
+        const int n = npics - p0 < per ? npics - p0 : per;
+        FFHipProgressSlot ps;
+        const int r = ffhip_progress_acquire(n * per_pic + 1, stream, &ps);
+        if (r < 0)
+            return r;
+        FFHipVp9LfPicsC S;
+        S.n = n;
+        for (int i = 0; i < FFHIP_VP9_LF_PICS; i++)
+            S.pic[i] = pics[p0 + (i < n ? i : 0)];
+        if (bd == 8)
+            hipLaunchKernelGGL(k_vp9_lf_frames_ssc<uint8_t>, dim3(3 * sb_rows, n), dim3(64), 0, stream, S, sy, suv, cols, rows, ps.prog, ps.fail, 8, ss_h);
+        else
+            hipLaunchKernelGGL(k_vp9_lf_frames_ssc<uint16_t>, dim3(3 * sb_rows, n), dim3(64), 0, stream, S, sy, suv, cols, rows, ps.prog, ps.fail, bd, ss_h);
+        const hipError_t e = hipGetLastError();
+        const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            return FFHIP_EIO;
+        }
+        if (r2 < 0)
+            return r2;
+    }
+    return 0;
+}
+
 int ffhip_launch_vp9_lf_frame_ssc(int bd, int ss_h, int ss_v, uint8_t *y, uint8_t *u, uint8_t *v, ptrdiff_t sy, ptrdiff_t suv, int cols, int rows,
                                   const FFHipVp9LfSb *tabs, const FFHipVp9LfSbC *ctabs, hipStream_t stream)
 {

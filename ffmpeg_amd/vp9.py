@@ -117,6 +117,17 @@ def loopfilter_frames(pics, stride_y, stride_uv, cols, rows, stream=None, bit_de
                                                                  rows, _st(stream)), "ffhip_vp9_loopfilter_frames_dev")
 
 
+class LfPicC(C.Structure):   # == FFHipVp9LfPicC
+    _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("tables", C.c_void_p), ("ctables", C.c_void_p)]
+
+
+def loopfilter_frames_ssc(pics, stride_y, stride_uv, cols, rows, ss, stream=None, bit_depth=8):
+    """ffhip_vp9_loopfilter_frames_ssc_dev: pics = [(y, u, v, tables, ctables)] of 4:2:2 / 4:4:0 pictures that share the geometry; one launch"""
+    arr = (LfPicC * len(pics))(*[LfPicC(y.data_ptr(), u.data_ptr(), v.data_ptr(), t.data_ptr(), c.data_ptr()) for y, u, v, t, c in pics])
+    return _lib.check(_lib.lib().ffhip_vp9_loopfilter_frames_ssc_dev(bit_depth, ss[0], ss[1], len(pics), C.cast(arr, C.c_void_p), stride_y, stride_uv,
+                                                                     cols, rows, _st(stream)), "ffhip_vp9_loopfilter_frames_ssc_dev")
+
+
 _LF = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int)
 
 

@@ -1509,13 +1509,23 @@ int ffhip_vp9_loopfilter_frame_ssc_dev(int bit_depth, int ss_h, int ss_v, uint8_
                                        void *stream);
 /** N pictures of one geometry in ONE launch (round 4; what a decoder's frame threads hold at once): each picture its own planes and
  *  tables (device pointers), strides shared.  A picture's filter is a dependency chain through it (0.9 ms for a 4K picture on a chip it
- *  cannot fill); the pictures of a batch are filtered side by side.  ss_h / ss_v as above.  `pics` is a host array. */
+ *  cannot fill); the pictures of a batch are filtered side by side.  ss_h == ss_v (4:2:0 / 4:4:4).  `pics` is a host array. */
 typedef struct FFHipVp9LfPic {
     uint8_t *y, *u, *v;
     const FFHipVp9LfSb *tables;
 } FFHipVp9LfPic;
 int ffhip_vp9_loopfilter_frames_dev(int bit_depth, int ss_h, int ss_v, int npics, const FFHipVp9LfPic *pics, ptrdiff_t stride_y,
                                     ptrdiff_t stride_uv, int cols, int rows, void *stream);
+/** The same for the formats with rectangular chroma superblocks — 4:2:2 (ss_h 1, ss_v 0) and 4:4:0 (0, 1) (round 5): every picture brings
+ *  its chroma tables as well (ffhip_vp9_lf_sb_ctables()); ffhip_vp9_loopfilter_frame_ssc_dev()'s plain kernel with the pictures of the batch
+ *  side by side (libavcodec/vp9lpf.c:27-203).  ffhip_vp9_loopfilter_frames_dev() answers FFHIP_EINVAL for these formats. */
+typedef struct FFHipVp9LfPicC {
+    uint8_t *y, *u, *v;
+    const FFHipVp9LfSb *tables;
+    const FFHipVp9LfSbC *ctables;
+} FFHipVp9LfPicC;
+int ffhip_vp9_loopfilter_frames_ssc_dev(int bit_depth, int ss_h, int ss_v, int npics, const FFHipVp9LfPicC *pics, ptrdiff_t stride_y,
+                                        ptrdiff_t stride_uv, int cols, int rows, void *stream);
 
 /**
  * vp9dsp above 8 bits (profiles 2 / 3): the batch faces above at the bpp ff_vp9dsp_init(dsp, bpp, bitexact) instantiates its template

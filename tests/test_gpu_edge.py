@@ -63,7 +63,8 @@ def test_unsupported_arguments_are_errors():
     assert L.ffhip_fdsp_batch_dev(fdsp.FMUL, f.data_ptr(), 0, f.data_ptr(), 0, None, 0, None, 0, 0.0, 16, 1, None) == EINVAL   # src1 missing
     assert L.ffhip_fdsp_batch_dev(17, f.data_ptr(), 0, f.data_ptr(), 0, f.data_ptr(), 0, None, 0, 0.0, 16, 1, None) == EINVAL
     assert not L.ffhip_sws_getContext(64, 32, 23, 128, 64, 8, 4)      # AV_PIX_FMT_GRAY8 target: not on the hip path
-    assert not L.ffhip_sws_getContext(64, 32, 33, 128, 64, 26, 4)     # yuva420p -> rgba: alpha on both sides (a scaled alpha plane) is not on the hip path
+    assert not L.ffhip_sws_getContext(64, 32, 78, 64, 32, 26, 4)      # yuva422p -> rgba at equal size: the reference's special converters have no 4:2:2-with-alpha form here
+    assert not L.ffhip_sws_getContext(64, 32, 0, 128, 64, 71, 4)      # gbrp is a target of the equal-size converter only
     assert b"ffhip" in L.ffhip_last_error()
 
 

@@ -249,3 +249,49 @@ def test_vp9_loopfilter_frame_422_440(sbc, sbr, kind, ss, bd):
     assert changed > (20 * sbc * sbr if sbc * sbr > 8 else -1)
     with pytest.raises(Exception):               # the 4:2:0 / 4:4:4 entry points refuse these formats by name
         vp9.loopfilter_frame(dev[0], dev[1], dev[2], before[0].strides[0], before[1].strides[0], cols, rows, d_tabs, bit_depth=bd, ss=ss)
+
+
+@pytest.mark.parametrize("bd,ss,sbc,sbr,npics", [(8, (1, 0), 9, 5, 5), (10, (0, 1), 7, 6, 3), (8, (0, 1), 3, 2, 40), (12, (1, 0), 12, 9, 2)])
+def test_vp9_loopfilter_frames_ssc_batch(bd, ss, sbc, sbr, npics):
+    """ffhip_vp9_loopfilter_frames_ssc_dev (round 5): N 4:2:2 / 4:4:0 pictures — each its own planes, luma tables and chroma tables — in one
+    launch come out exactly as from launches of their own (ffhip_vp9_loopfilter_frame_ssc_dev, pinned to the oracle superblock by superblock
+    above); 40 pictures: two launches.  ffhip_vp9_loopfilter_frames_dev refuses these formats by name."""
+    import torch
+    from ffmpeg_amd import vp9, _lib
+    ss_h, ss_v = ss
+    rng = np.random.default_rng(9000 + 100 * sbc + sbr + npics + bd)
+    lim, mblim = G.filter_lut(int(rng.integers(0, 8)))
+    cols, rows = 8 * sbc - int(rng.integers(0, 8)), 8 * sbr - int(rng.integers(0, 8))
+    cw, chh = 64 >> ss_h, 64 >> ss_v
+    L = _lib.lib()
+    batch, single, keep = [], [], []
+    sy = suv = None
+    for i in range(npics):
+        planes = [_plane(rng, 64 * sbr, 64 * sbc, 12, bd), _plane(rng, chh * sbr, cw * sbc, 4, bd), _plane(rng, chh * sbr, cw * sbc, 4, bd)]
+        sy, suv = planes[0].strides[0], planes[1].strides[0]
+        filt = np.zeros(sbr * sbc, G.FILTER_DT)
+        for r in range(sbr):
+            for c in range(sbc):
+                filt[r * sbc + c] = G.structured(rng, r, c, cols, rows, ss_h, ss_v)
+        tabs, ctabs = vp9.lf_sb_tables_ss(filt.view(np.uint8).reshape(sbr * sbc, 192), sbc, sbr, lim, mblim, ss)
+        d_tabs, d_ctabs = torch.from_numpy(tabs.view(np.int32)).cuda(), torch.from_numpy(ctabs.view(np.int32)).cuda()
+        a = [torch.from_numpy(p.view(np.uint8).reshape(-1).copy()).cuda() for p in planes]
+        b = [t.clone() for t in a]
+        batch.append((a[0], a[1], a[2], d_tabs, d_ctabs))
+        single.append(b)
+        keep.append((planes, d_tabs, d_ctabs))
+    vp9.loopfilter_frames_ssc(batch, sy, suv, cols, rows, ss, bit_depth=bd)
+    for i in range(npics):
+        b = single[i]
+        vp9.loopfilter_frame_ssc(b[0], b[1], b[2], sy, suv, cols, rows, keep[i][1], keep[i][2], ss, bit_depth=bd)
+    torch.cuda.synchronize()
+    assert L.ffhip_stream_synchronize(None) == 0
+    changed = 0
+    for i in range(npics):
+        for k in range(3):
+            x, y = batch[i][k].cpu().numpy(), single[i][k].cpu().numpy()
+            assert np.array_equal(x, y), (i, k)
+            changed += int((x != keep[i][0][k].view(np.uint8).reshape(-1)).sum())
+    assert changed > 1000
+    with pytest.raises(Exception, match="chroma tables"):
+        vp9.loopfilter_frames([t[:4] for t in batch[:1]], sy, suv, cols, rows, bit_depth=bd, ss=ss)
