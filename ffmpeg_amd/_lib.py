@@ -150,6 +150,7 @@ def lib():
         "ffhip_h264_intra_pack_plane": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int32]),
         "ffhip_h264_intra_planes_dev": (C.c_int, [C.c_int, C.c_int, vp, C.c_ssize_t, C.c_int, C.c_int, vp]),
         "ffhip_h264_picture_lists": (C.c_int, [vp, vp]),
+        "ffhip_h264_picture_status": (C.c_int, [vp]),
         "ffhip_h264_picture_free": (None, [vp]),
         "ffhip_h264_picture_begin": (None, [vp]),
         "ffhip_h264_picture_mc_luma": (C.c_int, [vp, C.c_int, vp]),

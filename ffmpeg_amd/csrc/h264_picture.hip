@@ -43,6 +43,7 @@ size_t place(size_t &total, const std::vector<T> &v, Section &s)
 } // namespace
 
 struct FFHipH264Picture {
+    int last_status = 0; /* what the picture's last flush came to: 0, or the FFHIP_E* that left its planes incomplete (ffhip_h264_picture_status) */
     int device = 0; /* staging and scratch planes live on this device; flush() makes it current for its duration */
     int mb_w = 0, mb_h = 0;
     int bd = 8;     /* sample depth: above 8 the planes hold uint16_t, coefficient blocks int32_t (dctcoef, bit_depth_template.c:39-50) */
@@ -1082,13 +1083,40 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
 extern "C" int ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                                         void *stream)
 {
-    return flush_impl(p, dst, stride, ref, stream, nullptr);
+    int r;
+    try { /* no C++ exception crosses the C boundary */
+        r = flush_impl(p, dst, stride, ref, stream, nullptr);
+    } catch (...) {
+        ffhip_set_error("ffhip_h264_picture_flush: out of host memory");
+        r = FFHIP_ENOMEM;
+    }
+    if (p)
+        p->last_status = r < 0 ? r : 0;
+    return r;
 }
 
 /* Several pictures together: every picture's own staging copy, prediction and residual launches (throughput kernels), then what is a
  * latency chain per picture — the intra reconstruction wavefront and the in-loop filter — ONCE for all of them, side by side. */
+static int pictures_flush(FFHipH264Picture *const *pics, int n, uint8_t *const *dst, const int stride[3], const uint8_t *const *ref, void *stream_);
+
+extern "C" int ffhip_h264_picture_status(const FFHipH264Picture *p) { return p ? p->last_status : FFHIP_EINVAL; }
+
 extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, uint8_t *const *dst, const int stride[3], const uint8_t *const *ref,
                                          void *stream_)
+{
+    /* no C++ exception crosses the C boundary: the host side of a flush allocates (vectors, strings) */
+    try {
+        return pictures_flush(pics, n, dst, stride, ref, stream_);
+    } catch (const std::bad_alloc &) {
+        ffhip_set_error("ffhip_h264_pictures_flush: out of host memory");
+        return FFHIP_ENOMEM;
+    } catch (...) {
+        ffhip_set_error("ffhip_h264_pictures_flush: unexpected failure on the host side");
+        return FFHIP_EIO;
+    }
+}
+
+static int pictures_flush(FFHipH264Picture *const *pics, int n, uint8_t *const *dst, const int stride[3], const uint8_t *const *ref, void *stream_)
 {
     if (n < 0 || (n && (!pics || !dst || !stride || !ref)))
         return FFHIP_EINVAL;
@@ -1106,8 +1134,10 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
                 ffhip_set_error("ffhip_h264_pictures_flush: picture object %d appears twice", i);
                 return FFHIP_EINVAL;
             }
+    for (int i = 0; i < n; i++)
+        pics[i]->last_status = 0;
     if (n == 1)
-        return flush_impl(pics[0], dst, stride, ref, stream_, nullptr);
+        return pics[0]->last_status = flush_impl(pics[0], dst, stride, ref, stream_, nullptr);
     if (pics[0]->cfmt == 3 && (stride[1] != stride[0] || stride[2] != stride[0])) {
         ffhip_set_error("ffhip_h264_pictures_flush: the planes of 4:4:4 pictures share one stride");
         return FFHIP_EINVAL;
@@ -1130,21 +1160,27 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
     hipStream_t stream = (hipStream_t)stream_;
     const int bd = p0->bd, mb_w = p0->mb_w, mb_h = p0->mb_h;
     std::vector<FlushBack> B((size_t)n);
+    int first_err = 0;
     {
         /* the front half of a flush is host work — sorting a picture's intra records, copying megabytes of records and coefficients
          * into its pinned buffer — before a handful of launches: up to eight pictures are prepared at a time by threads of this call
          * (launch order between the pictures is free; the stages that follow wait for all of them) */
-        const int nthr = n < 8 ? n : 8;
-        std::vector<int> rc((size_t)nthr, 0);
-        std::vector<std::string> errs((size_t)nthr);
+        /* (two pictures or fewer: on the caller's thread — starting a thread costs more than it hides there) */
+        const int nthr = n <= 2 ? 1 : n < 8 ? n : 8;
+        std::vector<std::string> errs((size_t)n);
         std::vector<std::thread> th;
         auto work = [&](int t) {
             for (int i = t; i < n; i += nthr) {
-                const int r = flush_impl(pics[i], dst + 3 * i, stride, ref + 3 * i, stream_, &B[(size_t)i]);
-                if (r < 0) {
-                    rc[(size_t)t] = r;
-                    errs[(size_t)t] = ffhip_last_error(); /* (the error text is per thread) */
-                    return;
+                int r;
+                try {
+                    r = flush_impl(pics[i], dst + 3 * i, stride, ref + 3 * i, stream_, &B[(size_t)i]);
+                } catch (...) {
+                    r = FFHIP_ENOMEM;
+                }
+                if (r < 0) { /* this picture is out; the others of the share go on (their tails run below) */
+                    pics[i]->last_status = r;
+                    errs[(size_t)i] = r == FFHIP_ENOMEM && !ffhip_last_error()[0] ? "out of host memory" : ffhip_last_error(); /* (the error text is per thread) */
+                    B[(size_t)i] = FlushBack();
                 }
             }
         };
@@ -1158,10 +1194,13 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
             work(t);
         for (std::thread &t : th)
             t.join();
-        for (int t = 0; t < nthr; t++)
-            if (rc[(size_t)t] < 0) {
-                ffhip_set_error("%s", errs[(size_t)t].c_str());
-                return rc[(size_t)t]; /* (the other pictures have had their prediction and residual stages queued) */
+        /* A picture whose front half failed is left out of what follows — its planes are incomplete and its status says why
+         * (ffhip_h264_picture_status) — while every other picture of the batch is finished: they have had their prediction and residual
+         * stages queued against their planes, and stopping here would leave those half reconstructed.  The call returns the first failure. */
+        for (int i = 0; i < n && !first_err; i++)
+            if (pics[i]->last_status < 0) {
+                first_err = pics[i]->last_status;
+                ffhip_set_error("ffhip_h264_pictures_flush: picture %d: %s", i, errs[(size_t)i].c_str());
             }
     }
     const bool c444 = p0->cfmt == 3; /* every plane is a luma plane: wavefronts and filters alike */
@@ -1226,5 +1265,11 @@ extern "C" int ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, u
         r = ffhip_launch_h264_deblock_pictures_bd(bd, 0, pl_y.data(), ed_y.data(), (int)pl_y.size(), stride[0], mb_w, mb_h, stream);
     if (!pl_c.empty())
         HIP_TRY(hipStreamWaitEvent(stream, p0->join, 0));
-    return r < 0 ? r : 0;
+    if (r < 0) { /* a shared stage failed: no picture of the batch is known to be complete */
+        for (int i = 0; i < n; i++)
+            if (!pics[i]->last_status)
+                pics[i]->last_status = r;
+        return r;
+    }
+    return first_err;
 }

@@ -754,8 +754,13 @@ __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
                 s0.x = w[0]; s0.y = w[1]; s0.z = w[2]; s0.w = w[3];
                 s1.x = w[4 % (LAY < 2 ? 6 : 8)]; s1.y = w[5 % (LAY < 2 ? 6 : 8)]; s1.z = w[6 % (LAY < 2 ? 6 : 8)]; s1.w = w[7 % (LAY < 2 ? 6 : 8)];
                 typedef cw_u4 __attribute__((address_space(1))) *cw_g4;
-                *(cw_g4)d = s0;
-                *(cw_g4)(d + 16) = s1;
+                if (A.nts) { /* written once, not read back: non-temporal (as sws_yuv2rgb.hip, round 5) */
+                    __builtin_nontemporal_store(s0, (cw_g4)d);
+                    __builtin_nontemporal_store(s1, (cw_g4)(d + 16));
+                } else {
+                    *(cw_g4)d = s0;
+                    *(cw_g4)(d + 16) = s1;
+                }
             }
             dr += dstride;
             asm("" : "+s"(dr));
@@ -775,8 +780,10 @@ __global__ __launch_bounds__(256) void k_sws_colwalk_rgb(FFHipCwRgbArgs A)
                 const uint2 v = *reinterpret_cast<const uint2 *>(tile + i * 128 + lane * 2);
                 cw_u2 s;
                 s.x = v.x; s.y = v.y;
-                if (i * 512 + lane * 8 < nbytes)
-                    *(cw_g2)(d + i * 512) = s;
+                if (i * 512 + lane * 8 < nbytes) {
+                    if (A.nts) __builtin_nontemporal_store(s, (cw_g2)(d + i * 512));
+                    else *(cw_g2)(d + i * 512) = s;
+                }
             }
             cw_wave_sync_lds();
         } else if (act) {

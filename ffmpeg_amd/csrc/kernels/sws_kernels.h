@@ -228,6 +228,7 @@ struct FFHipCwRgbArgs {
     int ncb, nstrips, strip_rows, nframes;
     int vround;                /* seed of the vertical sums: 1 << 18 (yuv2rgb_X, and _1 which equals it), 0 (yuv2rgb_2) */
     FFHipYuv2RgbK k;
+    int nts;                   /* non-temporal stores of the picture (round 5; measure build: FFHIP_CWRGB_NTS=0 turns them off) */
 };
 int ffhip_launch_colwalk_rgb(FFHipCwRgbArgs &A, hipStream_t stream);
 

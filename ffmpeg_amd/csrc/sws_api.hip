@@ -1183,6 +1183,7 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             R.hlf = c->dn[0].filter; R.hlp = c->dn[0].pos; R.hcf = c->dn[1].filter; R.hcp = c->dn[1].pos;
             R.vlf = c->dn[2].filter; R.vlp = c->dn[2].pos; R.vcf = c->dn[3].filter; R.vcp = c->dn[3].pos;
             R.nframes = nframes; R.k = c->k; R.vround = c->cw_vround;
+            { const char *en = FFHIP_KNOB("FFHIP_CWRGB_NTS"); R.nts = !(en && en[0] == '0'); }
             return ffhip_launch_colwalk_rgb(R, stream);
         }
         return ffhip_launch_scale_rgb(a, stream);

@@ -879,6 +879,13 @@ int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const 
  *  16-byte aligned when any picture carries deblocking records).  The result per picture is flush()'s.  Asynchronous on `stream`. */
 int  ffhip_h264_pictures_flush(FFHipH264Picture *const *pics, int n, uint8_t *const *dst, const int stride[3], const uint8_t *const *ref,
                                void *stream);
+/** What the picture's last flush came to: 0, or the FFHIP_E* that left ITS planes incomplete.  When one picture of a
+ *  ffhip_h264_pictures_flush() batch fails on the host side (staging memory, a malformed record) the others are still finished — their
+ *  prediction and residual stages were queued against their planes already — and the call returns the first failure: this says which
+ *  pictures it was.  A failure of a stage the pictures share marks every picture of the batch.
+ *  A picture object takes records from ONE thread at a time (the record calls are plain appends): a decoder with several slice threads
+ *  working on one picture gives each a recorder and serialises the calls into the shared object, or records slice by slice. */
+int  ffhip_h264_picture_status(const FFHipH264Picture *p);
 
 /* ------------------------------------------------------------------------------------------ */
 /* libavcodec: AACDecDSP.imdct_and_windowing — float decoder, 1024-sample frames */

@@ -228,6 +228,8 @@ def test_pictures_flush_batch(mb_w, mb_h, pictures, p_intra):
         dsts.append([torch.from_numpy(a.copy()).cuda() for a in dst0])
     h264.pictures_flush(pics, dsts, strides, [d_refs] * pictures)
     torch.cuda.synchronize()
+    from ffmpeg_amd import _lib
+    assert all(_lib.lib().ffhip_h264_picture_status(p_._p) == 0 for p_ in pics)   # every picture of the batch complete
     for it in range(pictures):
         for pl in range(3):
             got = dsts[it][pl].cpu().numpy()
