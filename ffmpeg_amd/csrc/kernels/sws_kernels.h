@@ -133,6 +133,31 @@ void ffhip_up2_plan_job(FFHipUp2Job *j, int lanes_per_frame, int want_steps);
 int  ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream);
 
 /*
+ * Exact-2x up-scaling of planar yuv420p into packed RGB (sws_up2rgb.hip): 4-tap banks on all four axes re-expressed on the regular
+ * windows of the edge-replicated rows — luma 2x both ways, chroma 2x horizontally and (chrDstH == dstH) 4x vertically.
+ */
+struct FFHipUp2RgbArgs {
+    const uint8_t *src[3];      /* Y, U, V planes */
+    uint8_t *dst;
+    ptrdiff_t sstride[3], dstride;
+    size_t sfp[3], dfp;
+    int srcW, srcH;             /* luma; the picture is 2 srcW x 2 srcH, chroma srcW / 2 x srcH / 2 */
+    int ngroups;                /* 8-pixel groups per output row: srcW / 4 (even: the chroma rows end on a dword) */
+    int nframes;
+    const uint32_t *hlv, *hcv;  /* device: virtual horizontal banks, luma 2 srcW x 2 dwords, chroma srcW x 2 dwords */
+    const uint32_t *vt;         /* device: row y at dwords 4 (y + 1): (luma c01, luma c23, chroma c01, chroma c23); rows -1 and >= dstH zero */
+    int ncb, nstrips, steps_per_strip;
+    int vround;                 /* seed of the vertical sums: 1 << 18 (yuv2rgb_X) */
+    int lay;                    /* 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
+    FFHipYuv2RgbK k;
+};
+#ifdef __cplusplus
+int  ffhip_upn_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, int ratio, std::vector<uint32_t> *out);
+#endif
+void ffhip_up2rgb_plan(FFHipUp2RgbArgs *a, int want_steps);
+int  ffhip_launch_up2rgb(FFHipUp2RgbArgs &A, int var, hipStream_t stream);
+
+/*
  * Exact-2:1 fast path (sws_down2.hip): banks of up to 8 taps re-expressed on the regular windows 2x - 3 .. 2x + 4 of the
  * edge-replicated rows.  A job is one plane (4 output columns per lane) or one byte-interleaved U/V pair (2 + 2 per lane).
  */

@@ -130,7 +130,8 @@ class SwsContext:
 
     @property
     def paths(self):
-        """the bit set of ffhip_sws_fast_path: 1 column walker, 2 mfma, 4 wide walker, 8 exact 2x, 16 exact 2:1, 32 16-bit walker"""
+        """the bit set of ffhip_sws_fast_path: 1 column walker, 2 mfma, 4 wide walker, 8 exact 2x, 16 exact 2:1, 32 16-bit walker,
+        64 exact 2x of planar 4:2:0 into packed RGB"""
         return int(_lib.lib().ffhip_sws_fast_path(self._c))
 
     @property
@@ -142,6 +143,11 @@ class SwsContext:
     def up2_path(self):
         """True when the static-schedule exact-2x kernel (k_sws_up2) serves the banks."""
         return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 8)
+
+    @property
+    def up2rgb_path(self):
+        """True when the static-schedule exact-2x kernel with the packed-RGB writer (k_sws_up2_rgb) serves the banks."""
+        return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 64)
 
     @property
     def down2_path(self):

@@ -267,7 +267,9 @@ void             ffhip_sws_freeContext(FFHipSwsContext *c);
  *  whose 4-column groups read one 8-byte source span; sws_colwalk.hip), 0 when they take the general
  *  LDS-tiled kernel; bit 1 set when the matrix-core variant (k_sws_mfma) is available too; bit 2 set when the
  *  banks (5..16 taps: down-scaling, long kernels) run on the LDS-backed wide-bank walker (sws_lwalk.hip); bit 3 set when
- *  the conversion is an exact 2x up-scale served by the static-schedule kernel (sws_up2.hip).
+ *  the conversion is an exact 2x up-scale served by the static-schedule kernel (sws_up2.hip); bit 4: an exact 2:1 down-scale
+ *  (sws_down2.hip); bit 5: the 16-bit column walker (sws_walk16.hip); bit 6: exact 2x of planar yuv420p into packed RGB, the
+ *  static-schedule kernel with the yuv2rgb_X writer fused (sws_up2rgb.hip).
  *  Diagnostic only: results are identical. */
 int              ffhip_sws_fast_path(const FFHipSwsContext *c);
 /** Host-side preparation of the matrix-core horizontal pass (no device needed): turns one 4-tap horizontal

@@ -51,7 +51,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     torch = _torch()
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD",
-              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP"):
+              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS"):
         monkeypatch.delenv(k, raising=False)
     # the general kernels at exact 2:1 / 1:2 sizes need the fast paths switched off: a knob, i.e. libffhip_measure.so (conftest.py);
     # every other size runs the product library
@@ -59,6 +59,8 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
         monkeypatch.setenv("FFHIP_SWS_DOWN2", "0")  # test_down2* covers sws_down2.hip
     if need != "up2" and dw == 2 * sw and dh == 2 * sh:
         monkeypatch.setenv("FFHIP_SWS_UP2", "0")   # these tests are about the general kernels; test_up2* covers sws_up2.hip
+    if need != "up2rgb" and dw == 2 * sw and dh == 2 * sh:
+        monkeypatch.setenv("FFHIP_SWS_UP2RGB", "0")  # ... and test_up2rgb* sws_up2rgb.hip
     for k in ("FFHIP_CW_LUMA_GROUPS", "FFHIP_CW_DEPTH", "FFHIP_CW_PLAIN", "FFHIP_CW_STRIP", "FFHIP_SWS_FAST", "FFHIP_CW_OPT",
               "FFHIP_SWS_MFMA", "FFHIP_MF_STRIP", "FFHIP_CWRGB_DIRECT", "FFHIP_CWRGB_STRIP", "FFHIP_SWS_WIDE", "FFHIP_CW_DUP", "FFHIP_LW_STRIP", "FFHIP_LW_AHEAD"):
         monkeypatch.delenv(k, raising=False)
@@ -86,6 +88,8 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
         assert ctx.wide_path, "case does not reach the wide-bank walker"
     elif need == "down2":
         assert ctx.down2_path, "case does not reach the exact-2:1 kernel"
+    elif need == "up2rgb":
+        assert ctx.up2rgb_path, "case does not reach the exact-2x kernel with the RGB writer"
     elif need == "fast":
         assert ctx.fast_path, "case does not reach the column walker"
     if (env or {}).get("FFHIP_SWS_MFMA") == "1" and need_mfma:
@@ -399,6 +403,44 @@ def test_fast_path_rgb(case, env, monkeypatch):
 
 def test_fast_path_rgb_full_size(monkeypatch):
     _run("yuv420p", 1920, 1080, "rgb24", 3840, 2160, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=79)
+
+
+# exact 2x of planar 4:2:0 into packed RGB: the static-schedule kernel with the writer fused (k_sws_up2_rgb, sws_up2rgb.hip):
+# yuv2rgb_X (bicubic: 4 x 4 taps) and yuv2rgb_2 (bilinear: no rounding term), every packed layout, one group per row .. several
+# column blocks with a ragged last one, one strip .. several (the strip length is a knob of the measure build), a single chroma window
+UP2RGB_CASES = [
+    ("yuv420p", 16, 8, "rgb24", 32, 16, ffi.SWS_BICUBIC),             # two groups: both lanes sit at a row end
+    ("yuv420p", 128, 72, "rgb24", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 128, 72, "bgr24", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 136, 70, "argb", 272, 140, ffi.SWS_BICUBIC),          # 34 groups, odd chroma height
+    ("yuv420p", 128, 72, "rgba", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 264, 50, "abgr", 528, 100, ffi.SWS_BICUBIC),          # a full wave + a lane pair
+    ("yuv420p", 128, 72, "bgra", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 1048, 600, "rgb24", 2096, 1416 - 216, ffi.SWS_BICUBIC),  # several column blocks and strips, ragged last block
+    ("yuv420p", 128, 72, "rgb24", 256, 144, ffi.SWS_BILINEAR),
+    ("yuv420p", 520, 130, "bgr24", 1040, 260, ffi.SWS_BILINEAR),
+    ("yuv420p", 128, 72, "rgba", 256, 144, ffi.SWS_BILINEAR),
+]
+
+
+@pytest.mark.parametrize("env", [{}, {"FFHIP_UP2RGB_STEPS": "6"}, {"FFHIP_UP2RGB_STEPS": "500"}, {"FFHIP_SWS_UP2RGB": "v1"}, {"FFHIP_SWS_UP2RGB": "v2"},
+                                 {"FFHIP_SWS_UP2RGB": "v3"}],
+                         ids=["default", "strip6", "one_strip", "plain_stores", "direct", "pieces8"])
+@pytest.mark.parametrize("case", UP2RGB_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_up2rgb(case, env, monkeypatch):
+    _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="up2rgb")
+
+
+def test_up2rgb_full_size(monkeypatch):
+    _run("yuv420p", 1920, 1080, "rgb24", 3840, 2160, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=81, need="up2rgb")
+
+
+def test_up2rgb_is_not_taken_where_it_does_not_apply():
+    from ffmpeg_amd import swscale as S
+    for sf, sw, sh, df, dw, dh in (("nv12", 128, 72, "rgb24", 256, 144), ("yuv420p", 132, 72, "rgb24", 264, 144),
+                                   ("yuv420p", 128, 72, "rgb24", 256, 216), ("yuv422p", 128, 72, "rgb24", 256, 144)):
+        ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], ffi.SWS_BICUBIC)
+        assert not ctx.up2rgb_path, (sf, sw, sh, df, dw, dh)
 
 
 @pytest.mark.parametrize("fmts", [("nv12", "rgb24"), ("yuv420p", "bgr24"), ("nv21", "rgb24")])
