@@ -133,18 +133,19 @@ void ffhip_up2_plan_job(FFHipUp2Job *j, int lanes_per_frame, int want_steps);
 int  ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream);
 
 /*
- * Exact-2x up-scaling of planar yuv420p into packed RGB (sws_up2rgb.hip): 4-tap banks on all four axes re-expressed on the regular
+ * Exact-2x up-scaling of 4:2:0 (planar yuv420p or NV12 / NV21) into packed RGB (sws_up2rgb.hip): 4-tap banks on all four axes re-expressed on the regular
  * windows of the edge-replicated rows — luma 2x both ways, chroma 2x horizontally and (chrDstH == dstH) 4x vertically.
  */
 struct FFHipUp2RgbArgs {
-    const uint8_t *src[3];      /* Y, U, V planes */
+    const uint8_t *src[3];      /* Y, U, V planes; sil: src[1] = the byte-interleaved chroma plane (NV12; swap: NV21) */
     uint8_t *dst;
     ptrdiff_t sstride[3], dstride;
     size_t sfp[3], dfp;
+    int sil, swap;
     int srcW, srcH;             /* luma; the picture is 2 srcW x 2 srcH, chroma srcW / 2 x srcH / 2 */
     int ngroups;                /* 8-pixel groups per output row: srcW / 4 (even: the chroma rows end on a dword) */
     int nframes;
-    const uint32_t *hlv, *hcv;  /* device: virtual horizontal banks, luma 2 srcW x 2 dwords, chroma srcW x 2 dwords */
+    const uint32_t *hco;        /* device: the horizontal virtual banks in 32 dwords (ffhip_up2rgb_hco) */
     const uint32_t *vt;         /* device: row y at dwords 4 (y + 1): (luma c01, luma c23, chroma c01, chroma c23); rows -1 and >= dstH zero */
     int ncb, nstrips, steps_per_strip;
     int vround;                 /* seed of the vertical sums: 1 << 18 (yuv2rgb_X) */
@@ -153,6 +154,7 @@ struct FFHipUp2RgbArgs {
 };
 #ifdef __cplusplus
 int  ffhip_upn_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, int ratio, std::vector<uint32_t> *out);
+int  ffhip_up2rgb_hco(const std::vector<uint32_t> &hl, const std::vector<uint32_t> &hc, uint32_t out[32]);
 #endif
 void ffhip_up2rgb_plan(FFHipUp2RgbArgs *a, int want_steps);
 int  ffhip_launch_up2rgb(FFHipUp2RgbArgs &A, int var, hipStream_t stream);

@@ -1,5 +1,5 @@
 /*
- * sws_up2rgb.hip — the fused scaler + packed-RGB writer for EXACT 2x up-scaling of planar yuv420p with 4-tap banks on all four
+ * sws_up2rgb.hip — the fused scaler + packed-RGB writer for EXACT 2x up-scaling of 4:2:0 (yuv420p, NV12, NV21) with 4-tap banks on all four
  * axes (bicubic / bilinear 1080p -> 4K rgb24): hScale8To15_c (libswscale/swscale.c:128-142) on Y, U and V, then
  * yuv2rgb_X_c_template / yuv2rgb_write (libswscale/output.c:1789-1840, 1663-1787) as yuv2packedX reaches them (vscale.c:126-170).
  * Same bytes as k_sws_colwalk_rgb / k_scale_rgb (tests/test_gpu_sws_fast.py), which stay the kernels of every other geometry.
@@ -47,27 +47,47 @@ typedef const ur_u2a __attribute__((address_space(1))) *ur_gc2;
 typedef ur_u2 __attribute__((address_space(1))) *ur_g2;
 typedef ur_u4 __attribute__((address_space(1))) *ur_g4;
 typedef const ur_u8 __attribute__((address_space(4))) *ur_cc8; /* constant address space: scalar loads */
+typedef const uint32_t __attribute__((address_space(4))) *ur_cc1;
 
-/* four horizontal samples: d[i] = (pa[i] . ca[i] + pb[i] . cb[i]) >> 7 (the block of sws_up2.hip: every DOT result is consumed
- * >= 3 instructions after it was written) */
+/* four horizontal samples of adjacent columns (even, odd, even, odd): d[i] = (pa[i] . c01 + pb[i] . c23) >> 7 with the coefficient pairs
+ * of the column's parity in SGPRs — away from the row's ends an exact-2x bank has two rows of coefficients, not one per column.  (The
+ * block of sws_up2.hip: every DOT result is consumed >= 3 instructions after it was written.) */
 __device__ __forceinline__ void ur_h4(int (&d)[4], uint32_t pa0, uint32_t pa1, uint32_t pa2, uint32_t pa3, uint32_t pb0,
-                                      uint32_t pb1, uint32_t pb2, uint32_t pb3, const uint32_t *cf)
+                                      uint32_t pb1, uint32_t pb2, uint32_t pb3, uint32_t e01, uint32_t e23, uint32_t o01, uint32_t o23)
 {
     asm("v_dot2_i32_i16 %0, %4, %12, 0\n\t"
-        "v_dot2_i32_i16 %1, %5, %13, 0\n\t"
-        "v_dot2_i32_i16 %2, %6, %14, 0\n\t"
-        "v_dot2_i32_i16 %3, %7, %15, 0\n\t"
-        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
-        "v_dot2_i32_i16 %1, %9, %17, %1\n\t"
-        "v_dot2_i32_i16 %2, %10, %18, %2\n\t"
-        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "v_dot2_i32_i16 %1, %5, %14, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %12, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %14, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %13, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %15, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %13, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %15, %3\n\t"
         "v_ashrrev_i32 %0, 7, %0\n\t"
         "v_ashrrev_i32 %1, 7, %1\n\t"
         "v_ashrrev_i32 %2, 7, %2\n\t"
         "v_ashrrev_i32 %3, 7, %3"
         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
-        : "v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3), "v"(pb0), "v"(pb1), "v"(pb2), "v"(pb3),
-          "v"(cf[0]), "v"(cf[2]), "v"(cf[4]), "v"(cf[6]), "v"(cf[1]), "v"(cf[3]), "v"(cf[5]), "v"(cf[7]));
+        : "v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3), "v"(pb0), "v"(pb1), "v"(pb2), "v"(pb3), "s"(e01), "s"(e23), "s"(o01), "s"(o23));
+}
+/* the three columns next to a row's end, whose coefficients the reference renormalised after folding the taps onto the edge sample
+ * (initFilter(), libswscale/utils.c:519-561): c = their six coefficient dwords (column i: c[2i], c[2i + 1]) */
+__device__ __forceinline__ void ur_h3(int (&d)[3], uint32_t pa0, uint32_t pa1, uint32_t pa2, uint32_t pb0, uint32_t pb1, uint32_t pb2,
+                                      const uint32_t (&c)[6])
+{
+    asm("v_dot2_i32_i16 %0, %3, %9, 0\n\t"
+        "v_dot2_i32_i16 %1, %4, %11, 0\n\t"
+        "v_dot2_i32_i16 %2, %5, %13, 0\n\t"
+        "s_nop 0\n\t"
+        "v_dot2_i32_i16 %0, %6, %10, %0\n\t"
+        "v_dot2_i32_i16 %1, %7, %12, %1\n\t"
+        "v_dot2_i32_i16 %2, %8, %14, %2\n\t"
+        "s_nop 1\n\t"
+        "v_ashrrev_i32 %0, 7, %0\n\t"
+        "v_ashrrev_i32 %1, 7, %1\n\t"
+        "v_ashrrev_i32 %2, 7, %2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2])
+        : "v"(pa0), "v"(pa1), "v"(pa2), "v"(pb0), "v"(pb1), "v"(pb2), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]));
 }
 
 /* the sixteen vertical dots of 8 sums t[i] = seed + pa[i] . f01 + pb[i] . f23 (the pairs are (row, row + 1) int16 halves; f in SGPRs).
@@ -155,9 +175,9 @@ struct UrRawL { uint32_t q[3]; };
 struct UrRawC { uint32_t u[2], v[2]; };
 
 /* LAY: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (alpha = 255).  ST: 0 direct stores, 1 / 2 through the LDS transposer in 8- /
- * 16-byte pieces.  NTS: non-temporal stores of the picture. */
-template <int LAY, int ST, bool NTS>
-__global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
+ * 16-byte pieces.  NTS: non-temporal stores of the picture.  SIL: the chroma plane is byte-interleaved (NV12; A.swap: NV21). */
+template <int LAY, int ST, bool NTS, bool SIL = false>
+__global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tiles[4][LAY < 2 ? 384 : 512];
     __shared__ uint2 lut[512]; /* [U] = { b(U), gu(U) }, [256 + V] = { r(V), gv(V) }: the chroma terms of the closed form, cy-scaled, rounding in */
@@ -187,24 +207,16 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
     const bool lb = g == 0, rb = g == G - 1;
     const bool border = cb == 0 || cb == A.ncb - 1; /* wave-uniform */
     const uint32_t soffY = (uint32_t)(lb ? 0 : rb ? 4 * g - 8 : 4 * g - 4);
-    const uint32_t soffC = (uint32_t)(lb ? 0 : rb ? 2 * G - 8 : (2 * g - 2) & ~3);
+    const uint32_t soffC = SIL ? soffY /* (u, v) pairs 2g - 2 .. 2g + 3: 12 bytes at 4g - 4, as the luma span */
+                               : (uint32_t)(lb ? 0 : rb ? 2 * G - 8 : (2 * g - 2) & ~3);
 
-    /* horizontal coefficients (virtual banks: regular windows of the replicated rows): 8 luma + 4 chroma columns, 2 dwords each */
-    uint32_t cfL[16], cfC[8];
-    {
-        const ur_u4 *p = reinterpret_cast<const ur_u4 *>(A.hlv) + (size_t)g * 4;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const ur_u4 v = p[i];
-            cfL[4 * i] = v.x; cfL[4 * i + 1] = v.y; cfL[4 * i + 2] = v.z; cfL[4 * i + 3] = v.w;
-        }
-        const ur_u4 *q = reinterpret_cast<const ur_u4 *>(A.hcv) + (size_t)g * 2;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const ur_u4 v = q[i];
-            cfC[4 * i] = v.x; cfC[4 * i + 1] = v.y; cfC[4 * i + 2] = v.z; cfC[4 * i + 3] = v.w;
-        }
-    }
+    /* horizontal coefficients (virtual banks: regular windows of the replicated rows), all wave-uniform: A.hco = luma (even c01, c23,
+     * odd c01, c23), chroma the same, then the six dwords of the three columns at the left / right end of a luma row and of a chroma
+     * row — read by scalar loads; the end sets only by the waves that hold a row's first / last lane */
+    const ur_cc1 hco = (ur_cc1)A.hco;
+    const uint32_t LE01 = hco[0], LE23 = hco[1], LO01 = hco[2], LO23 = hco[3];
+    const uint32_t CE01 = hco[4], CE23 = hco[5], CO01 = hco[6], CO23 = hco[7];
+    const bool first = cb == 0, last = cb == A.ncb - 1; /* wave-uniform */
     /* chroma byte selectors: sample j of the lane's six (2g - 2 + j, replicated at the row's ends) is byte o + j of its 8 bytes,
      * pair j = (sample j, sample j + 1) as int16s */
     uint32_t csel[5];
@@ -220,8 +232,8 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
     const int srcH = A.srcH, chrH = A.srcH >> 1, dstH = 2 * A.srcH;
     const uint8_t *sy = A.src[0] + (size_t)f * A.sfp[0];
     const uint8_t *su = A.src[1] + (size_t)f * A.sfp[1];
-    const uint8_t *sv = A.src[2] + (size_t)f * A.sfp[2];
-    const ptrdiff_t ystride = A.sstride[0], ustride = A.sstride[1], vstride = A.sstride[2], dstride = A.dstride;
+    const uint8_t *sv = SIL ? su : A.src[2] + (size_t)f * A.sfp[2];
+    const ptrdiff_t ystride = A.sstride[0], ustride = A.sstride[1], vstride = SIL ? A.sstride[1] : A.sstride[2], dstride = A.dstride;
 
     int pr = a - 3; /* next luma row to fetch (unclamped) */
     const uint8_t *pfy = sy + (ptrdiff_t)min(max(pr, 0), srcH - 1) * ystride;
@@ -243,13 +255,19 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
     auto load_chroma = [&](UrRawC &o) {
         uint32_t off = soffC;
         asm volatile("" : "+v"(off));
-        const ur_u2 wu = *(ur_gc2)((ur_gcp)pfu + off);
-        const ur_u2 wv = *(ur_gc2)((ur_gcp)pfv + off);
-        o.u[0] = wu.x; o.u[1] = wu.y; o.v[0] = wv.x; o.v[1] = wv.y;
+        if (SIL) {
+            const ur_u3 w = *(ur_gc3)((ur_gcp)pfu + off);
+            o.u[0] = w.x; o.u[1] = w.y; o.v[0] = w.z; o.v[1] = 0;
+        } else {
+            const ur_u2 wu = *(ur_gc2)((ur_gcp)pfu + off);
+            const ur_u2 wv = *(ur_gc2)((ur_gcp)pfv + off);
+            o.u[0] = wu.x; o.u[1] = wu.y; o.v[0] = wv.x; o.v[1] = wv.y;
+        }
         cr++;
         const bool adv = cr >= 1 && cr <= chrH - 1;
         pfu += adv ? ustride : 0;
-        pfv += adv ? vstride : 0;
+        if (!SIL)
+            pfv += adv ? vstride : 0;
         asm("" : "+s"(pfu), "+s"(pfv));
     };
 
@@ -278,8 +296,24 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
         const uint32_t p4 = __builtin_amdgcn_perm(v1, v0, 0x0c070c06u), p5 = __builtin_amdgcn_perm(v2, v1, 0x0c040c03u);
         const uint32_t p6 = __builtin_amdgcn_perm(v2, v1, 0x0c050c04u);
         int hl[4], hh[4];
-        ur_h4(hl, p0, p1, p1, p2, p2, p3, p3, p4, cfL);
-        ur_h4(hh, p2, p3, p3, p4, p4, p5, p5, p6, cfL + 8);
+        ur_h4(hl, p0, p1, p1, p2, p2, p3, p3, p4, LE01, LE23, LO01, LO23);
+        ur_h4(hh, p2, p3, p3, p4, p4, p5, p5, p6, LE01, LE23, LO01, LO23);
+        if (first) { /* columns 0..2 of the row: lane 0's */
+            const uint32_t c[6] = { hco[8], hco[9], hco[10], hco[11], hco[12], hco[13] };
+            int d[3];
+            ur_h3(d, p0, p1, p1, p2, p3, p3, c);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                hl[i] = lb ? d[i] : hl[i];
+        }
+        if (last) { /* the last three columns: columns 5..7 of the last lane */
+            const uint32_t c[6] = { hco[14], hco[15], hco[16], hco[17], hco[18], hco[19] };
+            int d[3];
+            ur_h3(d, p3, p3, p4, p5, p5, p6, c);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                hh[1 + i] = rb ? d[i] : hh[1 + i];
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             Pnew[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[i], hl[i]));
@@ -290,19 +324,52 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
     };
     /* the same for one chroma row: 4 U + 4 V samples */
     auto hpassC = [&](const UrRawC &w, uint32_t (&Pnew)[8]) {
+        uint32_t i0 = w.u[0], i1 = w.u[1], i2 = w.v[0]; /* SIL: the 12 bytes of six (u, v) pairs */
+        if (SIL && border) { /* the first / last lane of a row loaded its span one dword further inside: replicate the end pair */
+            const uint32_t f0 = __builtin_amdgcn_perm(i0, i0, 0x01000100u), f2 = __builtin_amdgcn_perm(i2, i2, 0x03020302u);
+            const uint32_t q0 = i0, q1 = i1, q2 = i2;
+            i0 = lb ? f0 : rb ? q1 : q0;
+            i1 = lb ? q0 : rb ? q2 : q1;
+            i2 = lb ? q1 : rb ? f2 : q2;
+        }
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
-            const uint32_t q0 = ch ? w.v[0] : w.u[0], q1 = ch ? w.v[1] : w.u[1];
-            uint32_t v0 = q0, v1 = q1;
-            if (border) { /* left: samples -2, -1 are sample 0; right: the lane loaded the row's last 8 bytes, samples 4, 5 are the last one */
-                v0 = lb ? __builtin_amdgcn_perm(q0, q0, 0x00000000u) : rb ? q1 : q0;
-                v1 = lb ? q0 : rb ? __builtin_amdgcn_perm(q1, q1, 0x03030303u) : q1;
+            uint32_t p0, p1, p2, p3, p4;
+            if (SIL) {
+                /* a channel's samples sit at every second byte: pair j = bytes (2j, 2j + 2), + 1 for the channel at the odd bytes */
+                const uint32_t odd = (ch != 0) != (A.swap != 0) ? 0x00010001u : 0u;
+                const uint32_t s0 = 0x0c020c00u + odd, s1 = 0x0c040c02u + odd, s2 = 0x0c060c04u + odd;
+                p0 = __builtin_amdgcn_perm(i1, i0, s0); p1 = __builtin_amdgcn_perm(i1, i0, s1); p2 = __builtin_amdgcn_perm(i1, i0, s2);
+                p3 = __builtin_amdgcn_perm(i2, i1, s1); p4 = __builtin_amdgcn_perm(i2, i1, s2);
+            } else {
+                const uint32_t q0 = ch ? w.v[0] : w.u[0], q1 = ch ? w.v[1] : w.u[1];
+                uint32_t v0 = q0, v1 = q1;
+                if (border) { /* left: samples -2, -1 are sample 0; right: the lane loaded the row's last 8 bytes, samples 4, 5 are the last one */
+                    v0 = lb ? __builtin_amdgcn_perm(q0, q0, 0x00000000u) : rb ? q1 : q0;
+                    v1 = lb ? q0 : rb ? __builtin_amdgcn_perm(q1, q1, 0x03030303u) : q1;
+                }
+                p0 = __builtin_amdgcn_perm(v1, v0, csel[0]); p1 = __builtin_amdgcn_perm(v1, v0, csel[1]);
+                p2 = __builtin_amdgcn_perm(v1, v0, csel[2]); p3 = __builtin_amdgcn_perm(v1, v0, csel[3]);
+                p4 = __builtin_amdgcn_perm(v1, v0, csel[4]);
             }
-            const uint32_t p0 = __builtin_amdgcn_perm(v1, v0, csel[0]), p1 = __builtin_amdgcn_perm(v1, v0, csel[1]);
-            const uint32_t p2 = __builtin_amdgcn_perm(v1, v0, csel[2]), p3 = __builtin_amdgcn_perm(v1, v0, csel[3]);
-            const uint32_t p4 = __builtin_amdgcn_perm(v1, v0, csel[4]);
             int h[4];
-            ur_h4(h, p0, p1, p1, p2, p2, p3, p3, p4, cfC);
+            ur_h4(h, p0, p1, p1, p2, p2, p3, p3, p4, CE01, CE23, CO01, CO23);
+            if (first) {
+                const uint32_t c[6] = { hco[20], hco[21], hco[22], hco[23], hco[24], hco[25] };
+                int d[3];
+                ur_h3(d, p0, p1, p1, p2, p3, p3, c);
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    h[i] = lb ? d[i] : h[i];
+            }
+            if (last) { /* columns 1..3 of the last lane */
+                const uint32_t c[6] = { hco[26], hco[27], hco[28], hco[29], hco[30], hco[31] };
+                int d[3];
+                ur_h3(d, p1, p1, p2, p3, p3, p4, c);
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    h[1 + i] = rb ? d[i] : h[1 + i];
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 Pnew[4 * ch + i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(cprev[4 * ch + i], h[i]));
@@ -313,11 +380,58 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
 
     const int cy = __builtin_amdgcn_readfirstlane(A.k.cy);
     uint32_t *tile = tiles[wave];
-    const uint32_t tcol = 1536u * (uint32_t)cb + 8u * (uint32_t)lane; /* transposed: this lane's bytes of each 512-byte run */
     const int nbytes = (LAY < 2 ? 3 : 4) * min(8 * G - cb * 512, 512); /* valid bytes of this wave's row segment (% 48 == 0: G is even) */
     const bool fullw = cb * 64 + 64 <= G;                              /* wave-uniform: every lane has a group */
     const uint32_t dcol = (LAY < 2 ? 24u : 32u) * (uint32_t)graw;
     const char *lutb = reinterpret_cast<const char *>(lut);
+
+    constexpr int NW = LAY < 2 ? 6 : 8; /* dwords of a lane's 8 pixels */
+    auto st16 = [&](ur_gp d, const ur_u4 &v) {
+        if (NTS) __builtin_nontemporal_store(v, (ur_g4)d);
+        else *(ur_g4)d = v;
+    };
+    auto st8 = [&](ur_gp d, const ur_u2 &v) {
+        if (NTS) __builtin_nontemporal_store(v, (ur_g2)d);
+        else *(ur_g2)d = v;
+    };
+    /* the wave's row segment through the tile: a lane writes its 24 / 32 bytes, reads the 16 at 16 * lane (and 1024 + 16 * lane; rgb24:
+     * the 8 at 1024 + 8 * lane) */
+    auto tile_write = [&](const uint32_t (&w)[NW]) {
+        uint32_t *t = tile + lane * NW;
+        if (LAY >= 2) {
+            *reinterpret_cast<uint4 *>(t) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4 *>(t + 4) = make_uint4(w[4 % NW], w[5 % NW], w[6 % NW], w[7 % NW]);
+        } else {
+            *reinterpret_cast<uint2 *>(t) = make_uint2(w[0], w[1]);
+            *reinterpret_cast<uint2 *>(t + 2) = make_uint2(w[2], w[3]);
+            *reinterpret_cast<uint2 *>(t + 4) = make_uint2(w[4], w[5]);
+        }
+    };
+    auto tile_read = [&](uint4 &q0, uint4 &q1, uint2 &q2) {
+        q0 = *reinterpret_cast<const uint4 *>(tile + lane * 4);
+        q1 = make_uint4(0, 0, 0, 0);
+        q2 = make_uint2(0, 0);
+        if (LAY >= 2)
+            q1 = *reinterpret_cast<const uint4 *>(tile + 256 + lane * 4);
+        else
+            q2 = *reinterpret_cast<const uint2 *>(tile + 256 + lane * 2);
+    };
+    auto put_pieces = [&](uint8_t *drow, const uint4 &q0, const uint4 &q1, const uint2 &q2) {
+        ur_gp d = (ur_gp)drow + (uint32_t)(NW * 256) * (uint32_t)cb;
+        ur_u4 v0, v1;
+        v0.x = q0.x; v0.y = q0.y; v0.z = q0.z; v0.w = q0.w;
+        v1.x = q1.x; v1.y = q1.y; v1.z = q1.z; v1.w = q1.w;
+        ur_u2 v2;
+        v2.x = q2.x; v2.y = q2.y;
+        if (fullw || lane * 16 < nbytes)
+            st16(d + 16u * (uint32_t)lane, v0);
+        if (LAY >= 2) {
+            if (fullw || 1024 + lane * 16 < nbytes)
+                st16(d + 1024 + 16u * (uint32_t)lane, v1);
+        } else if (fullw || 1024 + lane * 8 < nbytes) {
+            st8(d + 1024 + 8u * (uint32_t)lane, v2);
+        }
+    };
 
     /* one output row: La / Lb the luma pairs (rows s0, s0+1) (s0+2, s0+3), Ca / Cb the chroma ones; coefficient dwords in SGPRs */
     auto emit = [&](const uint32_t (&La)[8], const uint32_t (&Lb)[8], const uint32_t (&Ca)[8], const uint32_t (&Cb)[8], uint32_t lf01,
@@ -343,7 +457,6 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
             val[3 * p + 1] = ur_mad24(ysh[p], cy, c1[p >> 1]);
             val[3 * p + 2] = ur_mad24(ysh[p], cy, c2[p >> 1]);
         }
-        constexpr int NW = LAY < 2 ? 6 : 8; /* dwords of a lane's 8 pixels */
         uint32_t w[NW];
         if (LAY >= 2) {
             int alpha = 255 << 16;
@@ -358,14 +471,6 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
             for (int d = 0; d < 6; d++)
                 w[d] = ur_pk4(val[4 * d], val[4 * d + 1], val[4 * d + 2], val[4 * d + 3]);
         }
-        auto st16 = [&](ur_gp d, const ur_u4 &v) {
-            if (NTS) __builtin_nontemporal_store(v, (ur_g4)d);
-            else *(ur_g4)d = v;
-        };
-        auto st8 = [&](ur_gp d, const ur_u2 &v) {
-            if (NTS) __builtin_nontemporal_store(v, (ur_g2)d);
-            else *(ur_g2)d = v;
-        };
         if (ST == 0) {
             /* direct: a lane's 24 / 32 contiguous bytes, 8 / 16 per store instruction */
             if (act && store) {
@@ -387,54 +492,27 @@ __global__ __launch_bounds__(256) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
             }
             return;
         }
-        /* transpose through the wave's 1.5 / 2 KiB of LDS: a store instruction covers 512 (ST 1) or 1024 (ST 2) contiguous bytes of the
-         * row instead of 8 / 16 bytes in every 24 / 32 */
-        uint32_t *t = tile + lane * NW;
-        if (LAY >= 2) {
-            *reinterpret_cast<uint4 *>(t) = make_uint4(w[0], w[1], w[2], w[3]);
-            *reinterpret_cast<uint4 *>(t + 4) = make_uint4(w[4 % NW], w[5 % NW], w[6 % NW], w[7 % NW]);
-        } else {
-            *reinterpret_cast<uint2 *>(t) = make_uint2(w[0], w[1]);
-            *reinterpret_cast<uint2 *>(t + 2) = make_uint2(w[2], w[3]);
-            *reinterpret_cast<uint2 *>(t + 4) = make_uint2(w[4], w[5]);
-        }
+        /* transpose through the wave's 1.5 / 2 KiB of LDS: a store instruction covers 512 (ST 1) or 1024 (ST 2) contiguous bytes of
+         * the row instead of 8 / 16 bytes in every 24 / 32 */
+        tile_write(w);
         ur_wave_sync_lds();
-        if (LAY >= 2 || ST == 2) {
-            /* 16-byte pieces: rgb24 1024 + 512 bytes (the tail in 8-byte pieces), 32-bit 1024 + 1024 */
-            const uint4 q0 = *reinterpret_cast<const uint4 *>(tile + lane * 4);
-            uint4 q1 = make_uint4(0, 0, 0, 0);
-            uint2 q2 = make_uint2(0, 0);
-            if (LAY >= 2)
-                q1 = *reinterpret_cast<const uint4 *>(tile + 256 + lane * 4);
-            else
-                q2 = *reinterpret_cast<const uint2 *>(tile + 256 + lane * 2);
+        if (ST == 2) {
+            uint4 q0, q1;
+            uint2 q2;
+            tile_read(q0, q1, q2);
             ur_wave_sync_lds();
-            if (store) { /* uniform */
-                ur_gp d = (ur_gp)dr + (uint32_t)(NW * 256) * (uint32_t)cb;
-                ur_u4 v0, v1;
-                v0.x = q0.x; v0.y = q0.y; v0.z = q0.z; v0.w = q0.w;
-                v1.x = q1.x; v1.y = q1.y; v1.z = q1.z; v1.w = q1.w;
-                ur_u2 v2;
-                v2.x = q2.x; v2.y = q2.y;
-                if (fullw || lane * 16 < nbytes)
-                    st16(d + 16u * (uint32_t)lane, v0);
-                if (LAY >= 2) {
-                    if (fullw || 1024 + lane * 16 < nbytes)
-                        st16(d + 1024 + 16u * (uint32_t)lane, v1);
-                } else if (fullw || 1024 + lane * 8 < nbytes) {
-                    st8(d + 1024 + 8u * (uint32_t)lane, v2);
-                }
-            }
+            if (store) /* uniform */
+                put_pieces(dr, q0, q1, q2);
         } else {
-            uint2 q[3];
+            uint2 q[NW / 2];
 #pragma unroll
-            for (int i = 0; i < 3; i++)
+            for (int i = 0; i < NW / 2; i++)
                 q[i] = *reinterpret_cast<const uint2 *>(tile + i * 128 + lane * 2);
             ur_wave_sync_lds();
             if (store) {
-                ur_gp d = (ur_gp)dr + tcol;
+                ur_gp d = (ur_gp)dr + (uint32_t)(NW * 256) * (uint32_t)cb + 8u * (uint32_t)lane;
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
+                for (int i = 0; i < NW / 2; i++) {
                     ur_u2 v;
                     v.x = q[i].x; v.y = q[i].y;
                     if (fullw || i * 512 + lane * 8 < nbytes)
@@ -549,6 +627,35 @@ int ffhip_upn_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst,
     return 1;
 }
 
+/*
+ * The two horizontal virtual banks (luma 2 srcW columns, chroma srcW columns; 2 dwords per column) in the 32 dwords the kernel reads
+ * with scalar loads: away from the ends of a row an exact-2x bank repeats with period 2, so the even and the odd column's coefficients
+ * stand for all of them; the three columns at either end (the only ones whose windows reach a replicated sample) keep their own.
+ *   [0..3] luma even c01, c23, odd c01, c23   [4..7] chroma   [8..13] luma columns 0..2   [14..19] luma columns n-3..n-1
+ *   [20..25] chroma columns 0..2   [26..31] chroma columns n-3..n-1
+ * Returns 0 when a bank does not repeat (then the kernel is not used).
+ */
+int ffhip_up2rgb_hco(const std::vector<uint32_t> &hl, const std::vector<uint32_t> &hc, uint32_t out[32])
+{
+    const std::vector<uint32_t> *bank[2] = { &hl, &hc };
+    for (int b = 0; b < 2; b++) {
+        const std::vector<uint32_t> &v = *bank[b];
+        const int n = (int)(v.size() / 2);
+        if (n < 16 || (n & 1))
+            return 0;
+        for (int x = 3; x < n - 3; x++)
+            if (v[2 * (size_t)x] != v[2 * (size_t)(4 + (x & 1))] || v[2 * (size_t)x + 1] != v[2 * (size_t)(4 + (x & 1)) + 1])
+                return 0;
+        for (int i = 0; i < 4; i++)
+            out[4 * b + i] = v[8 + i]; /* columns 4 (even) and 5 (odd) */
+        for (int i = 0; i < 6; i++) {
+            out[8 + 12 * b + i] = v[i];
+            out[14 + 12 * b + i] = v[2 * (size_t)(n - 3) + i];
+        }
+    }
+    return 1;
+}
+
 /* strips of about `want` luma steps (a multiple of 6: the row loop is unrolled six times), evened out over the plane */
 void ffhip_up2rgb_plan(FFHipUp2RgbArgs *a, int want)
 {
@@ -571,8 +678,10 @@ int ffhip_launch_up2rgb(FFHipUp2RgbArgs &A, int var, hipStream_t stream)
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     /* var (measure build): 0 the product (LDS transposer in 16-byte pieces, non-temporal stores); 1 plain (temporal) stores; 2 direct
-     * stores (no transposer); 3 transposer in 8-byte pieces */
-#define UR_LAUNCH(L) do { if (var == 2) hipLaunchKernelGGL((k_sws_up2_rgb<L, 0, true>), grid, block, 0, stream, A); \
+     * stores (no transposer); 3 transposer in 8-byte pieces.  (Reading the tile back one row later, so that neither LDS side waits, was
+     * measured too: no faster — profiles/r05_up2rgb_c.txt, _d.txt — and is not kept.) */
+#define UR_LAUNCH(L) do { if (A.sil) hipLaunchKernelGGL((k_sws_up2_rgb<L, 2, true, true>), grid, block, 0, stream, A); \
+                          else if (var == 2) hipLaunchKernelGGL((k_sws_up2_rgb<L, 0, true>), grid, block, 0, stream, A); \
                           else if (var == 1) hipLaunchKernelGGL((k_sws_up2_rgb<L, 2, false>), grid, block, 0, stream, A); \
                           else if (var == 3) hipLaunchKernelGGL((k_sws_up2_rgb<L, 1, true>), grid, block, 0, stream, A); \
                           else hipLaunchKernelGGL((k_sws_up2_rgb<L, 2, true>), grid, block, 0, stream, A); } while (0)

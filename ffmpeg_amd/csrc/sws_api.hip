@@ -56,10 +56,10 @@ struct FFHipSwsContext {
     int up2_rc = 0; /* a range-converting context: the exact-2x kernel with the range stage is its only fast kernel */
     void *up2_dev = nullptr;
     const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
-    /* exact 2x of planar yuv420p into packed RGB (sws_up2rgb.hip): virtual banks of all four axes, the vertical ones merged row by row */
+    /* exact 2x of 4:2:0 (yuv420p, NV12, NV21) into packed RGB (sws_up2rgb.hip): virtual banks of all four axes, the vertical ones merged row by row */
     int u2r_ok = 0;
     void *u2r_dev = nullptr;
-    const uint32_t *u2r_hl = nullptr, *u2r_hc = nullptr, *u2r_vt = nullptr;
+    const uint32_t *u2r_hco = nullptr, *u2r_vt = nullptr;
     /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
     int dn2_ok = 0;
     void *dn2_dev = nullptr;
@@ -326,7 +326,7 @@ static void up2_build(FFHipSwsContext *c, const int nsrc[4])
     }
 }
 
-/* exact 2x of planar yuv420p into packed RGB: luma 2x both ways, chroma 2x horizontally and 4x vertically (a packed target has a
+/* exact 2x of 4:2:0 into packed RGB: luma 2x both ways, chroma 2x horizontally and 4x vertically (a packed target has a
  * chroma line per output line).  The 4-tap views as virtual banks on the regular windows of the edge-replicated rows; the two vertical
  * ones merged into one table of four dwords per output row (the kernel reads it with scalar loads), one zero row in front (y = -1) and
  * zero rows behind (the row loop reads one row pair past the picture).  Sets c->u2r_ok (sws_up2rgb.hip). */
@@ -343,22 +343,22 @@ static void up2rgb_build(FFHipSwsContext *c, int srcW, int srcH, int dstW, int d
         !ffhip_upn_virtual_bank(c->nf[2].data(), c->np[2].data(), dstH, srcH, 2, &vl) ||
         !ffhip_upn_virtual_bank(c->nf[3].data(), c->np[3].data(), dstH, chrH, 4, &vc))
         return;
+    uint32_t hco[32];
+    if (!ffhip_up2rgb_hco(hl, hc, hco))
+        return;
     std::vector<uint32_t> vt((size_t)(dstH + 6) * 4, 0);
     for (int y = 0; y < dstH; y++) {
         uint32_t *r = vt.data() + (size_t)(y + 1) * 4;
         r[0] = vl[2 * (size_t)y]; r[1] = vl[2 * (size_t)y + 1]; r[2] = vc[2 * (size_t)y]; r[3] = vc[2 * (size_t)y + 1];
     }
-    const size_t o1 = (hl.size() * 4 + 255) & ~(size_t)255, o2 = o1 + ((hc.size() * 4 + 255) & ~(size_t)255);
-    if (hipMalloc(&c->u2r_dev, o2 + vt.size() * 4) != hipSuccess)
+    if (hipMalloc(&c->u2r_dev, 256 + vt.size() * 4) != hipSuccess)
         return;
     uint8_t *b = static_cast<uint8_t *>(c->u2r_dev);
-    if (hipMemcpy(b, hl.data(), hl.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(b + o1, hc.data(), hc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(b + o2, vt.data(), vt.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(b, hco, sizeof(hco), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b + 256, vt.data(), vt.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
         return;
-    c->u2r_hl = reinterpret_cast<const uint32_t *>(b);
-    c->u2r_hc = reinterpret_cast<const uint32_t *>(b + o1);
-    c->u2r_vt = reinterpret_cast<const uint32_t *>(b + o2);
+    c->u2r_hco = reinterpret_cast<const uint32_t *>(b);
+    c->u2r_vt = reinterpret_cast<const uint32_t *>(b + 256);
     c->u2r_ok = 1;
 }
 
@@ -633,8 +633,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                         ffhip_cw_bank_ok(c->np[1].data(), 4, c->d[1].n, a.chrSrcW, c->np[3].data(), 4, c->d[3].n, a.chrSrcH) &&
                         c->d[1].n * 2 == t->dstW && ffhip_cw_bank_nowrap(c->nf[0].data(), 4, c->d[0].n) &&
                         ffhip_cw_bank_nowrap(c->nf[1].data(), 4, c->d[1].n);
-        /* ... and, for exact 2x of planar 4:2:0, the static-schedule kernel with the RGB writer (sws_up2rgb.hip) */
-        if (c->cw_rgb && t->srcFormat == FFHIP_PIX_FMT_YUV420P)
+        /* ... and, for exact 2x of 4:2:0 (planar or NV12 / NV21), the static-schedule kernel with the RGB writer (sws_up2rgb.hip) */
+        if (c->cw_rgb && (t->srcFormat == FFHIP_PIX_FMT_YUV420P || fmt_nv(t->srcFormat)))
             up2rgb_build(c, t->srcW, t->srcH, t->dstW, t->dstH);
     } else {
         FFHipScalePlaneArgs &l = c->lum, &ch = c->chr;
@@ -1217,16 +1217,17 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
         uintptr_t al = (uintptr_t)s0 | (size_t)srcStride[0] | srcFramePitch[0] | (uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp |
                        (size_t)cus | (size_t)cvs | cuf | cvf | (uintptr_t)(cstep == 2 ? s1 : cu) | (uintptr_t)(cstep == 2 ? s1 : cv);
         const char *eu2 = FFHIP_KNOB("FFHIP_SWS_UP2RGB"); /* measure build: 0 keeps the column walker, v<n> a measured variant */
-        if (c->u2r_ok && cstep == 1 && !(ev && ev[0] == '0') && !(eu2 && eu2[0] == '0') && !(al & 3)) {
-            /* exact 2x, planar 4:2:0: static schedule, regular windows, the RGB writer fused (sws_up2rgb.hip) */
+        if (c->u2r_ok && !(ev && ev[0] == '0') && !(eu2 && eu2[0] == '0') && !(al & 3)) {
+            /* exact 2x of 4:2:0: static schedule, regular windows, the RGB writer fused (sws_up2rgb.hip) */
             FFHipUp2RgbArgs U;
             memset(&U, 0, sizeof(U));
-            U.src[0] = s0; U.src[1] = cu; U.src[2] = cv;
+            U.src[0] = s0; U.src[1] = cstep == 2 ? s1 : cu; U.src[2] = cstep == 2 ? s1 : cv;
+            U.sil = cstep == 2; U.swap = t.srcFormat == FFHIP_PIX_FMT_NV21;
             U.sstride[0] = srcStride[0]; U.sstride[1] = cus; U.sstride[2] = cvs;
             U.sfp[0] = srcFramePitch[0]; U.sfp[1] = cuf; U.sfp[2] = cvf;
             U.dst = a.dst; U.dstride = a.dst_stride; U.dfp = a.dst_fp;
             U.srcW = a.srcW; U.srcH = a.srcH; U.ngroups = a.srcW / 4; U.nframes = nframes;
-            U.hlv = c->u2r_hl; U.hcv = c->u2r_hc; U.vt = c->u2r_vt;
+            U.hco = c->u2r_hco; U.vt = c->u2r_vt;
             U.vround = c->cw_vround; U.lay = a.bgr; U.k = c->k;
             const char *es = FFHIP_KNOB("FFHIP_UP2RGB_STEPS");
             ffhip_up2rgb_plan(&U, es && atoi(es) > 0 ? atoi(es) : 36);

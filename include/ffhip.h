@@ -268,7 +268,7 @@ void             ffhip_sws_freeContext(FFHipSwsContext *c);
  *  LDS-tiled kernel; bit 1 set when the matrix-core variant (k_sws_mfma) is available too; bit 2 set when the
  *  banks (5..16 taps: down-scaling, long kernels) run on the LDS-backed wide-bank walker (sws_lwalk.hip); bit 3 set when
  *  the conversion is an exact 2x up-scale served by the static-schedule kernel (sws_up2.hip); bit 4: an exact 2:1 down-scale
- *  (sws_down2.hip); bit 5: the 16-bit column walker (sws_walk16.hip); bit 6: exact 2x of planar yuv420p into packed RGB, the
+ *  (sws_down2.hip); bit 5: the 16-bit column walker (sws_walk16.hip); bit 6: exact 2x of 4:2:0 (yuv420p, NV12, NV21) into packed RGB, the
  *  static-schedule kernel with the yuv2rgb_X writer fused (sws_up2rgb.hip).
  *  Diagnostic only: results are identical. */
 int              ffhip_sws_fast_path(const FFHipSwsContext *c);

@@ -405,7 +405,7 @@ def test_fast_path_rgb_full_size(monkeypatch):
     _run("yuv420p", 1920, 1080, "rgb24", 3840, 2160, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=79)
 
 
-# exact 2x of planar 4:2:0 into packed RGB: the static-schedule kernel with the writer fused (k_sws_up2_rgb, sws_up2rgb.hip):
+# exact 2x of 4:2:0 (planar, NV12, NV21) into packed RGB: the static-schedule kernel with the writer fused (k_sws_up2_rgb, sws_up2rgb.hip):
 # yuv2rgb_X (bicubic: 4 x 4 taps) and yuv2rgb_2 (bilinear: no rounding term), every packed layout, one group per row .. several
 # column blocks with a ragged last one, one strip .. several (the strip length is a knob of the measure build), a single chroma window
 UP2RGB_CASES = [
@@ -420,12 +420,19 @@ UP2RGB_CASES = [
     ("yuv420p", 128, 72, "rgb24", 256, 144, ffi.SWS_BILINEAR),
     ("yuv420p", 520, 130, "bgr24", 1040, 260, ffi.SWS_BILINEAR),
     ("yuv420p", 128, 72, "rgba", 256, 144, ffi.SWS_BILINEAR),
+    # byte-interleaved chroma: a lane's six (u, v) pairs are the 12 bytes under its luma span
+    ("nv12", 16, 8, "bgr24", 32, 16, ffi.SWS_BICUBIC),
+    ("nv12", 192, 108, "rgb24", 384, 216, ffi.SWS_BICUBIC),
+    ("nv21", 192, 108, "bgr24", 384, 216, ffi.SWS_BICUBIC),
+    ("nv12", 264, 50, "bgra", 528, 100, ffi.SWS_BICUBIC),
+    ("nv21", 1048, 600, "argb", 2096, 1200, ffi.SWS_BICUBIC),
+    ("nv12", 520, 130, "rgb24", 1040, 260, ffi.SWS_BILINEAR),
 ]
 
 
 @pytest.mark.parametrize("env", [{}, {"FFHIP_UP2RGB_STEPS": "6"}, {"FFHIP_UP2RGB_STEPS": "500"}, {"FFHIP_SWS_UP2RGB": "v1"}, {"FFHIP_SWS_UP2RGB": "v2"},
-                                 {"FFHIP_SWS_UP2RGB": "v3"}],
-                         ids=["default", "strip6", "one_strip", "plain_stores", "direct", "pieces8"])
+                                 {"FFHIP_SWS_UP2RGB": "v3"}, {"FFHIP_SWS_UP2RGB": "v4"}],
+                         ids=["default", "strip6", "one_strip", "plain_stores", "direct", "pieces8", "readback_at_once"])
 @pytest.mark.parametrize("case", UP2RGB_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
 def test_up2rgb(case, env, monkeypatch):
     _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="up2rgb")
@@ -437,7 +444,7 @@ def test_up2rgb_full_size(monkeypatch):
 
 def test_up2rgb_is_not_taken_where_it_does_not_apply():
     from ffmpeg_amd import swscale as S
-    for sf, sw, sh, df, dw, dh in (("nv12", 128, 72, "rgb24", 256, 144), ("yuv420p", 132, 72, "rgb24", 264, 144),
+    for sf, sw, sh, df, dw, dh in (("yuv444p", 128, 72, "rgb24", 256, 144), ("yuv420p", 132, 72, "rgb24", 264, 144),
                                    ("yuv420p", 128, 72, "rgb24", 256, 216), ("yuv422p", 128, 72, "rgb24", 256, 144)):
         ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], ffi.SWS_BICUBIC)
         assert not ctx.up2rgb_path, (sf, sw, sh, df, dw, dh)

@@ -15,9 +15,9 @@ from ffmpeg_amd import swscale as S
 dev = torch.device("cuda:0")
 n = 32
 configs = [("walker", {"FFHIP_SWS_UP2RGB": "0"})] + \
-          [("up2rgb steps %s" % s, {"FFHIP_UP2RGB_STEPS": s}) for s in ("24", "30", "36", "48", "60", "90", "120", "270")] + \
+          [("up2rgb steps %s" % s, {"FFHIP_UP2RGB_STEPS": s}) for s in ("24", "36", "48", "60", "120")] + \
           [("up2rgb plain stores", {"FFHIP_SWS_UP2RGB": "v1"}), ("up2rgb direct stores", {"FFHIP_SWS_UP2RGB": "v2"}),
-           ("up2rgb transposer 8-byte pieces", {"FFHIP_SWS_UP2RGB": "v3"}),
+           ("up2rgb transposer 8-byte pieces", {"FFHIP_SWS_UP2RGB": "v3"}), ("up2rgb transposer read back at once", {"FFHIP_SWS_UP2RGB": "v4"}),
            ("up2rgb direct, steps 30", {"FFHIP_SWS_UP2RGB": "v2", "FFHIP_UP2RGB_STEPS": "30"}),
            ("up2rgb default", {})]
 for df, bpp in ((2, 3), (28, 4)):
