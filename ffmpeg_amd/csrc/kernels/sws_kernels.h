@@ -147,7 +147,8 @@ struct FFHipUp2RgbArgs {
     int nframes;
     const uint32_t *hco;        /* device: the horizontal virtual banks in 32 dwords (ffhip_up2rgb_hco) */
     const uint32_t *vt;         /* device: row y at dwords 4 (y + 1): (luma c01, luma c23, chroma c01, chroma c23); rows -1 and >= dstH zero */
-    int ncb, nstrips, steps_per_strip;
+    int nstrips, steps_per_strip;
+    int fpp, wpp, npacks;       /* frames per pack (1, 2, 4: their groups share the pack's waves lane by lane), waves per pack and strip, packs */
     int vround;                 /* seed of the vertical sums: 1 << 18 (yuv2rgb_X) */
     int lay;                    /* 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
     FFHipYuv2RgbK k;
@@ -156,7 +157,7 @@ struct FFHipUp2RgbArgs {
 int  ffhip_upn_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, int ratio, std::vector<uint32_t> *out);
 int  ffhip_up2rgb_hco(const std::vector<uint32_t> &hl, const std::vector<uint32_t> &hc, uint32_t out[32]);
 #endif
-void ffhip_up2rgb_plan(FFHipUp2RgbArgs *a, int want_steps);
+void ffhip_up2rgb_plan(FFHipUp2RgbArgs *a, int want_steps, int fpp_forced);
 int  ffhip_launch_up2rgb(FFHipUp2RgbArgs &A, int var, hipStream_t stream);
 
 /*

@@ -193,22 +193,34 @@ __global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
-    const uint32_t upf = (uint32_t)A.ncb * (uint32_t)A.nstrips;
-    if (gw >= upf * (uint32_t)A.nframes)
+    /* units: (pack of A.fpp frames, strip, lane block).  The lanes of a pack's blocks run through the groups of its frames one after
+     * the other — lane index L = 64 * block + lane is group L % G of the pack's frame L / G — so a row width that is not a multiple of
+     * 64 groups leaves no lane idle (3840 pixels = 480 groups: two frames fill 15 waves); a wave may hold the end of one frame's row
+     * and the start of the next one's */
+    const uint32_t upp = (uint32_t)A.wpp * (uint32_t)A.nstrips;
+    if (gw >= upp * (uint32_t)A.npacks)
         return;
-    const int f = (int)(gw / upf);
-    const int u = (int)(gw - (uint32_t)f * upf);
-    const int strip = u / A.ncb, cb = u - strip * A.ncb;
+    const int pack = (int)(gw / upp);
+    const int u = (int)(gw - (uint32_t)pack * upp);
+    const int strip = u / A.wpp, cb = u - strip * A.wpp;
 
     const int G = A.ngroups;
-    const int graw = cb * 64 + lane;
-    const bool act = graw < G;
-    const int g = min(graw, G - 1);
+    const int f0 = pack * A.fpp;                          /* the pack's first frame */
+    const int nf = min(A.fpp, A.nframes - f0);            /* its frames that exist */
+    const int Lraw = cb * 64 + lane;
+    const bool act = Lraw < nf * G;
+    const int L = min(Lraw, nf * G - 1);                  /* idle lanes shadow the last one */
+    const int fs = (L >= G) + (L >= 2 * G) + (L >= 3 * G); /* A.fpp <= 4 */
+    const int g = L - fs * G;
     const bool lb = g == 0, rb = g == G - 1;
-    const bool border = cb == 0 || cb == A.ncb - 1; /* wave-uniform */
-    const uint32_t soffY = (uint32_t)(lb ? 0 : rb ? 4 * g - 8 : 4 * g - 4);
-    const uint32_t soffC = SIL ? soffY /* (u, v) pairs 2g - 2 .. 2g + 3: 12 bytes at 4g - 4, as the luma span */
-                               : (uint32_t)(lb ? 0 : rb ? 2 * G - 8 : (2 * g - 2) & ~3);
+    const bool first = __builtin_amdgcn_ballot_w64(lb) != 0, last = __builtin_amdgcn_ballot_w64(rb) != 0; /* wave-uniform */
+    const bool border = first || last;
+    const uint32_t yoff = (uint32_t)(lb ? 0 : rb ? 4 * g - 8 : 4 * g - 4);
+    const uint32_t coff = SIL ? yoff /* (u, v) pairs 2g - 2 .. 2g + 3: 12 bytes at 4g - 4, as the luma span */
+                              : (uint32_t)(lb ? 0 : rb ? 2 * G - 8 : (2 * g - 2) & ~3);
+    const uint32_t soffY = (uint32_t)fs * (uint32_t)A.sfp[0] + yoff;
+    const uint32_t soffU = (uint32_t)fs * (uint32_t)A.sfp[1] + coff;
+    const uint32_t soffV = SIL ? soffU : (uint32_t)fs * (uint32_t)A.sfp[2] + coff;
 
     /* horizontal coefficients (virtual banks: regular windows of the replicated rows), all wave-uniform: A.hco = luma (even c01, c23,
      * odd c01, c23), chroma the same, then the six dwords of the three columns at the left / right end of a luma row and of a chroma
@@ -216,7 +228,6 @@ __global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
     const ur_cc1 hco = (ur_cc1)A.hco;
     const uint32_t LE01 = hco[0], LE23 = hco[1], LO01 = hco[2], LO23 = hco[3];
     const uint32_t CE01 = hco[4], CE23 = hco[5], CO01 = hco[6], CO23 = hco[7];
-    const bool first = cb == 0, last = cb == A.ncb - 1; /* wave-uniform */
     /* chroma byte selectors: sample j of the lane's six (2g - 2 + j, replicated at the row's ends) is byte o + j of its 8 bytes,
      * pair j = (sample j, sample j + 1) as int16s */
     uint32_t csel[5];
@@ -230,9 +241,9 @@ __global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
     const int S = A.steps_per_strip;
     const int a = 1 + strip * S, b = min(a + S, A.srcH + 2); /* luma step r emits rows 2r-3 and 2r-2 */
     const int srcH = A.srcH, chrH = A.srcH >> 1, dstH = 2 * A.srcH;
-    const uint8_t *sy = A.src[0] + (size_t)f * A.sfp[0];
-    const uint8_t *su = A.src[1] + (size_t)f * A.sfp[1];
-    const uint8_t *sv = SIL ? su : A.src[2] + (size_t)f * A.sfp[2];
+    const uint8_t *sy = A.src[0] + (size_t)f0 * A.sfp[0];
+    const uint8_t *su = A.src[1] + (size_t)f0 * A.sfp[1];
+    const uint8_t *sv = SIL ? su : A.src[2] + (size_t)f0 * A.sfp[2];
     const ptrdiff_t ystride = A.sstride[0], ustride = A.sstride[1], vstride = SIL ? A.sstride[1] : A.sstride[2], dstride = A.dstride;
 
     int pr = a - 3; /* next luma row to fetch (unclamped) */
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
     int cr = (a + 1) / 2 - 3; /* next chroma row to fetch (unclamped): the first step's group is c = (a + 1) / 2, its window c-3 .. c */
     const uint8_t *pfu = su + (ptrdiff_t)min(max(cr, 0), chrH - 1) * ustride;
     const uint8_t *pfv = sv + (ptrdiff_t)min(max(cr, 0), chrH - 1) * vstride;
-    uint8_t *dr = A.dst + (size_t)f * A.dfp + (ptrdiff_t)(2 * a - 3) * dstride; /* row 2a-3 (row -1 of the first strip is never stored) */
+    uint8_t *dr = A.dst + (size_t)f0 * A.dfp + (ptrdiff_t)(2 * a - 3) * dstride; /* row 2a-3 (row -1 of the first strip is never stored) */
     asm("" : "+s"(pfy), "+s"(pfu), "+s"(pfv), "+s"(dr));
 
     auto load_luma = [&](UrRawL &o) {
@@ -253,14 +264,14 @@ __global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
         asm("" : "+s"(pfy));
     };
     auto load_chroma = [&](UrRawC &o) {
-        uint32_t off = soffC;
-        asm volatile("" : "+v"(off));
+        uint32_t off = soffU, offv = soffV;
+        asm volatile("" : "+v"(off), "+v"(offv));
         if (SIL) {
             const ur_u3 w = *(ur_gc3)((ur_gcp)pfu + off);
             o.u[0] = w.x; o.u[1] = w.y; o.v[0] = w.z; o.v[1] = 0;
         } else {
             const ur_u2 wu = *(ur_gc2)((ur_gcp)pfu + off);
-            const ur_u2 wv = *(ur_gc2)((ur_gcp)pfv + off);
+            const ur_u2 wv = *(ur_gc2)((ur_gcp)pfv + offv);
             o.u[0] = wu.x; o.u[1] = wu.y; o.v[0] = wv.x; o.v[1] = wv.y;
         }
         cr++;
@@ -380,12 +391,26 @@ __global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
 
     const int cy = __builtin_amdgcn_readfirstlane(A.k.cy);
     uint32_t *tile = tiles[wave];
-    const int nbytes = (LAY < 2 ? 3 : 4) * min(8 * G - cb * 512, 512); /* valid bytes of this wave's row segment (% 48 == 0: G is even) */
-    const bool fullw = cb * 64 + 64 <= G;                              /* wave-uniform: every lane has a group */
-    const uint32_t dcol = (LAY < 2 ? 24u : 32u) * (uint32_t)graw;
-    const char *lutb = reinterpret_cast<const char *>(lut);
-
     constexpr int NW = LAY < 2 ? 6 : 8; /* dwords of a lane's 8 pixels */
+    const bool fullw = cb * 64 + 64 <= nf * G;                         /* wave-uniform: every lane has a group */
+    const uint32_t dcol = (uint32_t)fs * (uint32_t)A.dfp + 4u * NW * (uint32_t)g; /* this lane's pixels from the pack's row pointer */
+    const char *lutb = reinterpret_cast<const char *>(lut);
+    /* the transposer's pieces: the bytes at offset o of the wave's tile are lane o / (4 NW)'s — where they go from the pack's row
+     * pointer (that lane's frame and group; frames meet at multiples of 48 bytes: G is even), and whether that lane has a group */
+    constexpr int NP = ST == 2 ? 2 : NW / 2;
+    uint32_t poff[NP];
+    bool pok[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const uint32_t o = ST == 2 ? (i == 0 ? 16u * (uint32_t)lane : 1024u + (LAY >= 2 ? 16u : 8u) * (uint32_t)lane)
+                                   : 512u * (uint32_t)i + 8u * (uint32_t)lane;
+        const uint32_t ls = o / (4u * NW);
+        const int Ls = cb * 64 + (int)ls;
+        const int fl = (Ls >= G) + (Ls >= 2 * G) + (Ls >= 3 * G);
+        pok[i] = Ls < nf * G;
+        poff[i] = (uint32_t)fl * (uint32_t)A.dfp + 4u * NW * (uint32_t)(Ls - fl * G) + (o - 4u * NW * ls);
+    }
+
     auto st16 = [&](ur_gp d, const ur_u4 &v) {
         if (NTS) __builtin_nontemporal_store(v, (ur_g4)d);
         else *(ur_g4)d = v;
@@ -417,19 +442,19 @@ __global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
             q2 = *reinterpret_cast<const uint2 *>(tile + 256 + lane * 2);
     };
     auto put_pieces = [&](uint8_t *drow, const uint4 &q0, const uint4 &q1, const uint2 &q2) {
-        ur_gp d = (ur_gp)drow + (uint32_t)(NW * 256) * (uint32_t)cb;
+        ur_gp d = (ur_gp)drow;
         ur_u4 v0, v1;
         v0.x = q0.x; v0.y = q0.y; v0.z = q0.z; v0.w = q0.w;
         v1.x = q1.x; v1.y = q1.y; v1.z = q1.z; v1.w = q1.w;
         ur_u2 v2;
         v2.x = q2.x; v2.y = q2.y;
-        if (fullw || lane * 16 < nbytes)
-            st16(d + 16u * (uint32_t)lane, v0);
+        if (fullw || pok[0])
+            st16(d + poff[0], v0);
         if (LAY >= 2) {
-            if (fullw || 1024 + lane * 16 < nbytes)
-                st16(d + 1024 + 16u * (uint32_t)lane, v1);
-        } else if (fullw || 1024 + lane * 8 < nbytes) {
-            st8(d + 1024 + 8u * (uint32_t)lane, v2);
+            if (fullw || pok[1 % NP])
+                st16(d + poff[1 % NP], v1);
+        } else if (fullw || pok[1 % NP]) {
+            st8(d + poff[1 % NP], v2);
         }
     };
 
@@ -510,13 +535,13 @@ __global__ __launch_bounds__(256, 4) void k_sws_up2_rgb(FFHipUp2RgbArgs A)
                 q[i] = *reinterpret_cast<const uint2 *>(tile + i * 128 + lane * 2);
             ur_wave_sync_lds();
             if (store) {
-                ur_gp d = (ur_gp)dr + (uint32_t)(NW * 256) * (uint32_t)cb + 8u * (uint32_t)lane;
+                ur_gp d = (ur_gp)dr;
 #pragma unroll
                 for (int i = 0; i < NW / 2; i++) {
                     ur_u2 v;
                     v.x = q[i].x; v.y = q[i].y;
-                    if (fullw || i * 512 + lane * 8 < nbytes)
-                        st8(d + i * 512, v);
+                    if (fullw || pok[i % NP])
+                        st8(d + poff[i % NP], v);
                 }
             }
         }
@@ -656,22 +681,36 @@ int ffhip_up2rgb_hco(const std::vector<uint32_t> &hl, const std::vector<uint32_t
     return 1;
 }
 
-/* strips of about `want` luma steps (a multiple of 6: the row loop is unrolled six times), evened out over the plane */
-void ffhip_up2rgb_plan(FFHipUp2RgbArgs *a, int want)
+/* strips of about `want` luma steps (a multiple of 6: the row loop is unrolled six times), evened out over the plane; frames per pack:
+ * the 1, 2 or 4 (never more than the batch has) whose groups leave the fewest lanes of the pack's last wave idle */
+void ffhip_up2rgb_plan(FFHipUp2RgbArgs *a, int want, int fpp)
 {
     const int steps = a->srcH + 1;
     const int n = cdiv(steps, want);
     const int s = cdiv(cdiv(steps, n), 6) * 6;
     a->steps_per_strip = s;
     a->nstrips = cdiv(steps, s);
-    a->ncb = cdiv(a->ngroups, 64);
+    int best = 1;
+    long long best_idle = -1;
+    for (int p = 1; p <= 4 && p <= (a->nframes > 0 ? a->nframes : 1); p *= 2) {
+        const long long lanes = (long long)cdiv(p * a->ngroups, 64) * 64, idle = (lanes - (long long)p * a->ngroups) * 4 / p; /* per 4 frames */
+        if (best_idle < 0 || idle < best_idle) {
+            best_idle = idle;
+            best = p;
+        }
+    }
+    if (fpp == 1 || fpp == 2 || fpp == 4) /* measure build: forced */
+        best = fpp;
+    a->fpp = best;
+    a->wpp = cdiv(best * a->ngroups, 64);
+    a->npacks = cdiv(a->nframes > 0 ? a->nframes : 1, best);
 }
 
 int ffhip_launch_up2rgb(FFHipUp2RgbArgs &A, int var, hipStream_t stream)
 {
     if (A.nframes <= 0)
         return 0;
-    const long long waves = (long long)A.ncb * A.nstrips * A.nframes;
+    const long long waves = (long long)A.wpp * A.nstrips * A.npacks;
     if (waves >= (1LL << 31)) {
         ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
         return FFHIP_EINVAL;

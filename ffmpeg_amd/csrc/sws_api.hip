@@ -1230,7 +1230,11 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             U.hco = c->u2r_hco; U.vt = c->u2r_vt;
             U.vround = c->cw_vround; U.lay = a.bgr; U.k = c->k;
             const char *es = FFHIP_KNOB("FFHIP_UP2RGB_STEPS");
-            ffhip_up2rgb_plan(&U, es && atoi(es) > 0 ? atoi(es) : 36);
+            const char *ef = FFHIP_KNOB("FFHIP_UP2RGB_FPP"); /* measure build: frames per pack */
+            /* measured (profiles/r05_up2rgb_f.txt): 24-bit pixels — the kernel is bound by its instruction stream: frames share the ragged
+             * last lane block (no idle lanes), strips of 24 luma rows; 32-bit pixels — closer to the write path: one frame per pack
+             * (two frames' rows written side by side cost 8 %, more when the frame pitch aliases), strips of 36 */
+            ffhip_up2rgb_plan(&U, es && atoi(es) > 0 ? atoi(es) : U.lay < 2 ? 24 : 36, ef ? atoi(ef) : U.lay < 2 ? 0 : 1);
             return ffhip_launch_up2rgb(U, eu2 && eu2[0] == 'v' ? atoi(eu2 + 1) : 0, stream);
         }
         if (c->cw_rgb && !(ev && ev[0] == '0') && !(al & 3)) {

@@ -51,7 +51,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     torch = _torch()
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD",
-              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS"):
+              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS", "FFHIP_UP2RGB_FPP"):
         monkeypatch.delenv(k, raising=False)
     # the general kernels at exact 2:1 / 1:2 sizes need the fast paths switched off: a knob, i.e. libffhip_measure.so (conftest.py);
     # every other size runs the product library
@@ -431,8 +431,8 @@ UP2RGB_CASES = [
 
 
 @pytest.mark.parametrize("env", [{}, {"FFHIP_UP2RGB_STEPS": "6"}, {"FFHIP_UP2RGB_STEPS": "500"}, {"FFHIP_SWS_UP2RGB": "v1"}, {"FFHIP_SWS_UP2RGB": "v2"},
-                                 {"FFHIP_SWS_UP2RGB": "v3"}, {"FFHIP_SWS_UP2RGB": "v4"}],
-                         ids=["default", "strip6", "one_strip", "plain_stores", "direct", "pieces8", "readback_at_once"])
+                                 {"FFHIP_SWS_UP2RGB": "v3"}, {"FFHIP_UP2RGB_FPP": "1"}, {"FFHIP_UP2RGB_FPP": "4"}],
+                         ids=["default", "strip6", "one_strip", "plain_stores", "direct", "pieces8", "fpp1", "fpp4"])
 @pytest.mark.parametrize("case", UP2RGB_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
 def test_up2rgb(case, env, monkeypatch):
     _run(*case, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="up2rgb")

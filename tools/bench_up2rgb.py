@@ -15,19 +15,22 @@ from ffmpeg_amd import swscale as S
 dev = torch.device("cuda:0")
 n = 32
 configs = [("walker", {"FFHIP_SWS_UP2RGB": "0"})] + \
-          [("up2rgb steps %s" % s, {"FFHIP_UP2RGB_STEPS": s}) for s in ("24", "36", "48", "60", "120")] + \
+          [("up2rgb steps %s" % s, {"FFHIP_UP2RGB_STEPS": s}) for s in ("24", "36", "48")] + \
           [("up2rgb plain stores", {"FFHIP_SWS_UP2RGB": "v1"}), ("up2rgb direct stores", {"FFHIP_SWS_UP2RGB": "v2"}),
            ("up2rgb transposer 8-byte pieces", {"FFHIP_SWS_UP2RGB": "v3"}), ("up2rgb transposer read back at once", {"FFHIP_SWS_UP2RGB": "v4"}),
            ("up2rgb direct, steps 30", {"FFHIP_SWS_UP2RGB": "v2", "FFHIP_UP2RGB_STEPS": "30"}),
-           ("up2rgb default", {})]
+           ("up2rgb default", {}), ("up2rgb one frame per pack", {"FFHIP_UP2RGB_FPP": "1"}),
+           ("up2rgb one frame per pack, steps 24", {"FFHIP_UP2RGB_FPP": "1", "FFHIP_UP2RGB_STEPS": "24"}),
+           ("up2rgb two frames per pack, steps 24", {"FFHIP_UP2RGB_FPP": "2", "FFHIP_UP2RGB_STEPS": "24"})]
+pad = int(os.environ.get("UP2RGB_PAD_ROWS", "0"))   # extra rows between the frames of the destination batch (another frame pitch)
 for df, bpp in ((2, 3), (28, 4)):
     ctx = S.SwsContext(1920, 1080, 0, 3840, 2160, df, 4)
     src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(0, 1920, 1080)]
-    dst = [torch.empty((n, 2160, bpp * 3840), dtype=torch.uint8, device=dev)]
+    dst = [torch.empty((n, 2160 + pad, bpp * 3840), dtype=torch.uint8, device=dev)[:, :2160]]
     ref = None
     for p in range(2):
         for name, env in configs:
-            for k in ("FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS"):
+            for k in ("FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS", "FFHIP_UP2RGB_FPP"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             for _ in range(40):
