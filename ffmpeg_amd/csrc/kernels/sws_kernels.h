@@ -274,6 +274,8 @@ struct FFHipLwJob {
     const int16_t *hf; const int32_t *hp;       /* device: padded banks */
     const int16_t *vf; const int32_t *vp;
     int ncb, nstrips, strip_rows, unit_begin;
+    int y16;                                    /* plane jobs: the vertical sums >> 19 stored UNCLIPPED as int16 (dstride in bytes): the luma
+                                                 * of a packed-RGB target's first stage (sws_y16rgb.hip is the second) */
 };
 struct FFHipLwArgs {
     FFHipLwJob job[3];
@@ -282,6 +284,21 @@ struct FFHipLwArgs {
 int  ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH, int pair);
 void ffhip_lw_plan_job(FFHipLwJob *j);
 int  ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream);
+
+/*
+ * Second stage of a scaled packed-RGB target that has no fused kernel (sws_y16rgb.hip): the scaler's output at the target's own
+ * geometry — luma w x h as UNCLIPPED int16, chroma w / 2 x h (a chroma line per output line, half the columns: what yuv2packedX
+ * is handed) — through the yuv2rgb tables' closed form into one of the six packed layouts.
+ */
+struct FFHipY16RgbArgs {
+    const uint8_t *y, *u, *v;   /* y: int16 samples */
+    uint8_t *dst;
+    ptrdiff_t ystride, cstride, dstride;
+    size_t yfp, cfp, dfp;
+    int w, h, nframes, lay;     /* w % 8 == 0; lay: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
+    FFHipYuv2RgbK k;
+};
+int ffhip_launch_y16_rgb(const FFHipY16RgbArgs &a, hipStream_t stream);
 
 /*
  * The column walker above 8 bits (sws_walk16.hip): banks padded to ht, vt in {4, 8} taps.  A job is one plane (nch 1) or the two

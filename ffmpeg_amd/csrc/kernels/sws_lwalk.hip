@@ -66,6 +66,7 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     uint32_t *raw = lds;                                        /* [NG][RAWD]        */
     uint4 *ring = reinterpret_cast<uint4 *>(lds + 2 * RAWD);    /* [RING][64]        */
     const bool sil = NG == 2 && J.sil, dil = NG == 2 && J.dil;
+    const bool y16 = NG == 1 && J.y16;
     const int y0 = strip * J.strip_rows;
     const int y1 = min(y0 + J.strip_rows, J.dstH);
     const int ny = y1 - y0;
@@ -227,7 +228,15 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
                 v[2] = lw_dot2(P.z, fk[k], v[2]);
                 v[3] = lw_dot2(P.w, fk[k], v[3]);
             }
-            if (NG == 1) {
+            if (NG == 1 && y16) {
+                /* the luma of a packed-RGB target's first stage: the sums >> 19 as they are, int16 — yuv2rgb_X does not clip Y before
+                 * the tables (libswscale/output.c:1814-1835); no 4-tap-or-wider bank of weights summing to 4096 leaves int16 */
+                lw_u2 w2;
+                w2.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0] >> 19, v[1] >> 19));
+                w2.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2] >> 19, v[3] >> 19));
+                if (act)
+                    *(lw_g2)((lw_gptr)d0 + (uint32_t)(2 * X0)) = w2;
+            } else if (NG == 1) {
                 const uint32_t w1 = __builtin_amdgcn_perm(lw_pk_u8(v[2], v[3]), lw_pk_u8(v[0], v[1]), 0x05040100);
                 if (act)
                     *(lw_g1)((lw_gptr)d0 + (uint32_t)X0) = w1;

@@ -56,6 +56,10 @@ struct FFHipSwsContext {
     int up2_rc = 0; /* a range-converting context: the exact-2x kernel with the range stage is its only fast kernel */
     void *up2_dev = nullptr;
     const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
+    /* a scaled packed-RGB target in two stages (lw_ok on an RGB context; sws_lwalk.hip with an int16 luma plane, then sws_y16rgb.hip):
+     * the intermediate planes, grown on demand — a context is used by one caller at a time, as an SwsContext is */
+    void *rgb2_tmp = nullptr;
+    size_t rgb2_tmp_sz = 0;
     /* exact 2x of 4:2:0 (yuv420p, NV12, NV21) into packed RGB (sws_up2rgb.hip): virtual banks of all four axes, the vertical ones merged row by row */
     int u2r_ok = 0;
     void *u2r_dev = nullptr;
@@ -636,6 +640,20 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         /* ... and, for exact 2x of 4:2:0 (planar or NV12 / NV21), the static-schedule kernel with the RGB writer (sws_up2rgb.hip) */
         if (c->cw_rgb && (t->srcFormat == FFHIP_PIX_FMT_YUV420P || fmt_nv(t->srcFormat)))
             up2rgb_build(c, t->srcW, t->srcH, t->dstW, t->dstH);
+        /* ... and every ratio the walker does not take (banks above 4 taps: all down-scaling) whose vertical luma bank has 3 taps or more
+         * (the reference then runs yuv2rgb_X, seed 1 << 18: vscale.c:126-170) goes in TWO stages: the wide-bank walker on these very banks
+         * into the target's own geometry (luma as unclipped int16, a chroma line per output line), then the tables' closed form
+         * (sws_y16rgb.hip) — against the LDS-tiled k_scale_rgb at 0.05 of HBM */
+        if (!r && !c->cw_rgb && !a.full && !a.has_alpha && !(t->dstW & 7) && c->d[2].size >= 3 && build_wide_view(c, limits)) {
+            bool ok = true;
+            for (int k = 0; k < 2 && ok; k++)
+                ok = ffhip_lw_bank_ok(c->wp[k].data(), c->lw_ht, c->d[k].n, limits[k], c->wp[2 + k].data(), c->lw_vt, c->d[2 + k].n,
+                                      limits[2 + k], k == 1 && fmt_nv(t->srcFormat)) != 0 &&
+                     ffhip_cw_bank_nowrap(c->wf[k].data(), 4 * c->lw_ht, c->d[k].n);
+            if (fmt_nv(t->srcFormat) && (a.chrSrcW & 3))
+                ok = false;
+            c->lw_ok = ok;
+        }
     } else {
         FFHipScalePlaneArgs &l = c->lum, &ch = c->chr;
         memset(&l, 0, sizeof(l));
@@ -865,6 +883,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->up2_dev);
     if (c->u2r_dev)
         (void)hipFree(c->u2r_dev);
+    if (c->rgb2_tmp)
+        (void)hipFree(c->rgb2_tmp);
     if (c->w16_dev)
         (void)hipFree(c->w16_dev);
     if (c->dn2_dev)
@@ -1251,6 +1271,59 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             R.nframes = nframes; R.k = c->k; R.vround = c->cw_vround;
             { const char *en = FFHIP_KNOB("FFHIP_CWRGB_NTS"); R.nts = !(en && en[0] == '0'); }
             return ffhip_launch_colwalk_rgb(R, stream);
+        }
+        const char *e2 = FFHIP_KNOB("FFHIP_SWS_RGB2"); /* measure build: 0 keeps the LDS-tiled kernel */
+        if (c->lw_ok && !(ev && ev[0] == '0') && !(e2 && e2[0] == '0') && !(al & 3)) {
+            /* two stages (see the context's creation): planes of the target's geometry, pitches and frames 256-byte aligned */
+            const size_t ypitch = ((size_t)2 * a.dstW + 255) & ~(size_t)255, cpitch = ((size_t)(a.dstW / 2) + 255) & ~(size_t)255;
+            const size_t yfp = ypitch * (size_t)a.dstH, cfp = cpitch * (size_t)a.dstH, need = (yfp + 2 * cfp) * (size_t)nframes;
+            if (need > c->rgb2_tmp_sz) {
+                if (c->rgb2_tmp)
+                    HIP_TRY(hipFree(c->rgb2_tmp)); /* (waits for the launches that still use it) */
+                c->rgb2_tmp = nullptr;
+                c->rgb2_tmp_sz = 0;
+                HIP_TRY(hipMalloc(&c->rgb2_tmp, need));
+                c->rgb2_tmp_sz = need;
+            }
+            uint8_t *ty = static_cast<uint8_t *>(c->rgb2_tmp), *tu = ty + yfp * (size_t)nframes, *tv = tu + cfp * (size_t)nframes;
+            FFHipLwArgs W;
+            memset(&W, 0, sizeof(W));
+            W.nframes = nframes; W.ht = c->lw_ht; W.vt = c->lw_vt;
+            auto wbank = [&](FFHipLwJob &j, int srcW, int srcH, int dstW, int which) {
+                j.srcW = srcW; j.srcH = srcH; j.dstW = dstW; j.dstH = a.dstH;
+                j.hf = c->dw[which].filter; j.hp = c->dw[which].pos; j.vf = c->dw[2 + which].filter; j.vp = c->dw[2 + which].pos;
+                ffhip_lw_plan_job(&j);
+            };
+            if (cstep == 1) {
+                for (int k = 0; k < 2; k++) {
+                    FFHipLwJob &j = W.job[W.njobs++];
+                    j.src[0] = k ? cv : cu; j.sstride[0] = k ? cvs : cus; j.sfp[0] = k ? cvf : cuf;
+                    j.dst[0] = k ? tv : tu; j.dstride[0] = (ptrdiff_t)cpitch; j.dfp[0] = cfp;
+                    wbank(j, a.chrSrcW, a.chrSrcH, a.dstW / 2, 1);
+                }
+            } else {
+                FFHipLwJob &j = W.job[W.njobs++];
+                j.pair = 1; j.sil = 1; j.dil = 0;
+                j.src_swap = cv < cu;
+                j.src[0] = j.src[1] = s1; j.sstride[0] = j.sstride[1] = cus; j.sfp[0] = j.sfp[1] = cuf;
+                j.dst[0] = tu; j.dst[1] = tv; j.dstride[0] = j.dstride[1] = (ptrdiff_t)cpitch; j.dfp[0] = j.dfp[1] = cfp;
+                wbank(j, a.chrSrcW, a.chrSrcH, a.dstW / 2, 1);
+            }
+            FFHipLwJob &jl = W.job[W.njobs++];
+            jl.src[0] = s0; jl.sstride[0] = srcStride[0]; jl.sfp[0] = srcFramePitch[0];
+            jl.dst[0] = ty; jl.dstride[0] = (ptrdiff_t)ypitch; jl.dfp[0] = yfp;
+            jl.y16 = 1;
+            wbank(jl, a.srcW, a.srcH, a.dstW, 0);
+            int r2 = ffhip_launch_lwalk(W, stream);
+            if (r2 < 0)
+                return r2;
+            FFHipY16RgbArgs Y;
+            memset(&Y, 0, sizeof(Y));
+            Y.y = ty; Y.u = tu; Y.v = tv; Y.dst = a.dst;
+            Y.ystride = (ptrdiff_t)ypitch; Y.cstride = (ptrdiff_t)cpitch; Y.dstride = a.dst_stride;
+            Y.yfp = yfp; Y.cfp = cfp; Y.dfp = a.dst_fp;
+            Y.w = a.dstW; Y.h = a.dstH; Y.nframes = nframes; Y.lay = a.bgr; Y.k = c->k;
+            return ffhip_launch_y16_rgb(Y, stream);
         }
         return ffhip_launch_scale_rgb(a, stream);
     }

@@ -51,7 +51,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     torch = _torch()
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD",
-              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS", "FFHIP_UP2RGB_FPP"):
+              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS", "FFHIP_UP2RGB_FPP", "FFHIP_SWS_RGB2"):
         monkeypatch.delenv(k, raising=False)
     # the general kernels at exact 2:1 / 1:2 sizes need the fast paths switched off: a knob, i.e. libffhip_measure.so (conftest.py);
     # every other size runs the product library
@@ -448,6 +448,43 @@ def test_up2rgb_is_not_taken_where_it_does_not_apply():
                                    ("yuv420p", 128, 72, "rgb24", 256, 216), ("yuv422p", 128, 72, "rgb24", 256, 144)):
         ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], ffi.SWS_BICUBIC)
         assert not ctx.up2rgb_path, (sf, sw, sh, df, dw, dh)
+
+
+# down-scaling (and every other ratio whose banks the column walker does not take) INTO packed RGB: two stages — the wide-bank walker
+# on the context's own banks with the luma stored as unclipped int16 (FFHipLwJob.y16), then the tables' closed form (sws_y16rgb.hip).
+# Random bytes through a bicubic down-scale overshoot 0..255 all the time: the int16 plane is what keeps the two stages exact
+RGB2_CASES = [
+    ("nv12", 384, 216, "rgb24", 192, 104, ffi.SWS_BICUBIC),            # ~2:1, 8 x 8 taps, interleaved chroma in
+    ("nv21", 384, 216, "bgr24", 192, 104, ffi.SWS_BICUBIC),
+    ("yuv420p", 384, 216, "rgb24", 192, 104, ffi.SWS_BICUBIC),
+    ("yuv420p", 640, 360, "bgra", 216, 120, ffi.SWS_BICUBIC),          # ~3:1: 12 taps padded to 16
+    ("nv12", 640, 368, "argb", 160, 92, ffi.SWS_BICUBIC),              # 4:1: 16 x 16 taps
+    ("yuv420p", 480, 270, "rgba", 320, 180, ffi.SWS_BICUBIC),          # 1.5:1
+    ("nv12", 2096, 1416, "rgb24", 1048, 600, ffi.SWS_BICUBIC),         # several column blocks and strips, ragged last block
+    ("yuv422p", 384, 216, "abgr", 192, 104, ffi.SWS_BICUBIC),          # 4:2:2 source: chroma down vertically as well
+    ("yuv420p", 384, 216, "rgb24", 200, 216, ffi.SWS_BICUBIC),         # horizontal only — vertical luma bank of 1 tap: NOT this path
+    ("yuv420p", 640, 360, "rgb24", 160, 92, ffi.SWS_AREA),             # area: 4..5 taps
+    ("yuv420p", 384, 216, "rgb24", 192, 104, ffi.SWS_BILINEAR),        # bilinear down: 4 taps that do not fit the column walker's spans
+]
+
+
+@pytest.mark.parametrize("case", RGB2_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_rgb_two_stage(case, monkeypatch):
+    from ffmpeg_amd import swscale as S
+    sf, sw, sh, df, dw, dh, fl = case
+    ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], fl)
+    two = bool(ctx.paths & 4) and not ctx.fast_path
+    assert two == (dh != sh), "paths %d" % ctx.paths
+    ctx.close()
+    _run(*case, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="any")
+
+
+def test_rgb_two_stage_full_size(monkeypatch):
+    _run("nv12", 3840, 2160, "rgb24", 1920, 1080, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=83, need="any")
+
+
+def test_rgb_two_stage_switched_off_is_the_tiled_kernel(monkeypatch):
+    _run("nv12", 384, 216, "rgb24", 192, 104, ffi.SWS_BICUBIC, env={"FFHIP_SWS_RGB2": "0"}, monkeypatch=monkeypatch, seed=5, need="any")
 
 
 @pytest.mark.parametrize("fmts", [("nv12", "rgb24"), ("yuv420p", "bgr24"), ("nv21", "rgb24")])
