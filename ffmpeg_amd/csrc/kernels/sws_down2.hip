@@ -232,6 +232,40 @@ __device__ __forceinline__ void dn_v4h(uint32_t &o0, uint32_t &o1, const uint32_
           "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(kround), "v"(sh), "v"(maxpk));
 }
 
+/* the same row, 8-bit pipeline, NOT clipped: t[i] >> 19 as int16 pairs — the luma plane of a packed-RGB target's first stage
+ * (yuv2rgb_X reads the sums unclipped, libswscale/output.c:1814-1835; sws_y16rgb.hip is the second stage) */
+__device__ __forceinline__ void dn_v4y(uint32_t &o0, uint32_t &o1, const uint32_t (&R0)[4], const uint32_t (&R1)[4], const uint32_t (&R2)[4],
+                                       const uint32_t (&R3)[4], uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int kround)
+{
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %2, %6, %22, %26\n\t"
+        "v_dot2_i32_i16 %3, %7, %22, %26\n\t"
+        "v_dot2_i32_i16 %4, %8, %22, %26\n\t"
+        "v_dot2_i32_i16 %5, %9, %22, %26\n\t"
+        "v_dot2_i32_i16 %2, %10, %23, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %23, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %23, %4\n\t"
+        "v_dot2_i32_i16 %5, %13, %23, %5\n\t"
+        "v_dot2_i32_i16 %2, %14, %24, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %24, %3\n\t"
+        "v_dot2_i32_i16 %4, %16, %24, %4\n\t"
+        "v_dot2_i32_i16 %5, %17, %24, %5\n\t"
+        "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
+        "v_ashrrev_i32 %2, 19, %2\n\t"
+        "v_ashrrev_i32 %3, 19, %3\n\t"
+        "v_ashrrev_i32 %4, 19, %4\n\t"
+        "v_ashrrev_i32 %5, 19, %5\n\t"
+        "v_cvt_pk_i16_i32 %0, %2, %3\n\t"
+        "v_cvt_pk_i16_i32 %1, %4, %5"
+        : "=&v"(o0), "=&v"(o1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(R0[0]), "v"(R0[1]), "v"(R0[2]), "v"(R0[3]), "v"(R1[0]), "v"(R1[1]), "v"(R1[2]), "v"(R1[3]),
+          "v"(R2[0]), "v"(R2[1]), "v"(R2[2]), "v"(R2[3]), "v"(R3[0]), "v"(R3[1]), "v"(R3[2]), "v"(R3[3]),
+          "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(kround));
+}
+
 /* HB: samples above 8 bits (little-endian uint16, 9..14 bits, P01x's in the high bits).  A lane then reads 32 source bytes per row
  * (plane: the 16 samples from 8g - 4, whose seven (s[2m+1], s[2m+2]) pairs are one v_alignbyte each) or 40 (pair: the ten (u, v)
  * columns from 4g - 3, pairs by v_perm as at 8 bits) and writes 8 destination bytes per row. */
@@ -426,6 +460,16 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
                     if (act) {
                         dn_u2 st; st.x = o0; st.y = o1;
                         *(dn_g2)((dn_gp)dr + off) = st;
+                    }
+                } else if (!PAIR && J.y16) { /* uniform */
+                    typedef dn_u2 __attribute__((address_space(1))) *dn_g2y;
+                    uint32_t o0, o1;
+                    dn_v4y(o0, o1, ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround);
+                    off *= 2; /* four int16 per lane */
+                    asm volatile("" : "+v"(off));
+                    if (act) {
+                        dn_u2 st; st.x = o0; st.y = o1;
+                        *(dn_g2y)((dn_gp)dr + off) = st;
                     }
                 } else {
                     const uint32_t out = dn_v4(ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround);

@@ -175,6 +175,7 @@ struct FFHipDn2Job {
     const uint32_t *vfv;                /* device: virtual vertical bank, (dstH + 8) x 4 dwords, 64-byte aligned */
     int ncb, nstrips, steps_per_strip, unit_begin;
     int hb_sdepth, hb_ddepth, hb_smsb, hb_dmsb; /* samples above 8 bits (k_sws_down2<1>; 0: bytes), as in FFHipUp2Job; groups are 8 destination bytes */
+    int y16;                            /* 8-bit plane job: the vertical sums >> 19 stored UNCLIPPED as int16 (8 bytes per group): see FFHipLwJob.y16 */
 };
 struct FFHipDn2Args {
     FFHipDn2Job job[3];

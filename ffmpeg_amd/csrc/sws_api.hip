@@ -66,6 +66,7 @@ struct FFHipSwsContext {
     const uint32_t *u2r_hco = nullptr, *u2r_vt = nullptr;
     /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
     int dn2_ok = 0;
+    int dn2_luma = 0; /* an RGB context's luma banks alone (its first stage's luma job on k_sws_down2, the chroma on the wide walker) */
     void *dn2_dev = nullptr;
     const uint32_t *dn2_h[2] = { nullptr, nullptr }, *dn2_v[2] = { nullptr, nullptr };
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
@@ -397,6 +398,27 @@ static void dn2_build(FFHipSwsContext *c, const int nsrc[4])
     }
 }
 
+/* the luma banks alone at exact 2:1, for a packed-RGB target's first stage (its chroma goes 2:1 across but 1:1 or 2:1 down by the
+ * source's subsampling, and rides the wide-bank walker): sets c->dn2_luma */
+static void dn2_build_luma(FFHipSwsContext *c, int srcW, int srcH)
+{
+    std::vector<uint32_t> vb[2];
+    if (!ffhip_down2_virtual_bank(c->f[0].data(), c->p[0].data(), c->d[0].size, c->d[0].n, srcW, &vb[0]) ||
+        !ffhip_down2_virtual_bank(c->f[2].data(), c->p[2].data(), c->d[2].size, c->d[2].n, srcH, &vb[1]))
+        return;
+    vb[1].resize((size_t)(c->d[2].n + 8) * 4, 0); /* the row loop reads four rows of coefficients at a time */
+    const size_t o1 = (vb[0].size() * 4 + 255) & ~(size_t)255;
+    if (hipMalloc(&c->dn2_dev, o1 + vb[1].size() * 4) != hipSuccess)
+        return;
+    uint8_t *b = static_cast<uint8_t *>(c->dn2_dev);
+    if (hipMemcpy(b, vb[0].data(), vb[0].size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b + o1, vb[1].data(), vb[1].size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    c->dn2_h[0] = reinterpret_cast<const uint32_t *>(b);
+    c->dn2_v[0] = reinterpret_cast<const uint32_t *>(b + o1);
+    c->dn2_luma = 1;
+}
+
 /* no horizontal sum of a 4-tap bank falls below -32768 after >> (depth - 1) on samples of `depth` bits: int16 saturation then
  * equals the reference's min(., 32767) + truncation (ffhip_cw_bank_nowrap is this at 8 bits) */
 static bool bank_nowrap_depth(const int16_t *f, int n, int depth, int size = 4)
@@ -653,6 +675,10 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             if (fmt_nv(t->srcFormat) && (a.chrSrcW & 3))
                 ok = false;
             c->lw_ok = ok;
+            /* exact 2:1 (4K -> 1080p): the luma on the static-schedule kernel */
+            if (ok && t->srcW == 2 * t->dstW && t->srcH == 2 * t->dstH && !(t->dstW & 3) && t->dstW >= 12 &&
+                ffhip_cw_bank_nowrap(c->f[0].data(), c->d[0].size, c->d[0].n))
+                dn2_build_luma(c, t->srcW, t->srcH);
         }
     } else {
         FFHipScalePlaneArgs &l = c->lum, &ch = c->chr;
@@ -1309,12 +1335,29 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 j.dst[0] = tu; j.dst[1] = tv; j.dstride[0] = j.dstride[1] = (ptrdiff_t)cpitch; j.dfp[0] = j.dfp[1] = cfp;
                 wbank(j, a.chrSrcW, a.chrSrcH, a.dstW / 2, 1);
             }
-            FFHipLwJob &jl = W.job[W.njobs++];
-            jl.src[0] = s0; jl.sstride[0] = srcStride[0]; jl.sfp[0] = srcFramePitch[0];
-            jl.dst[0] = ty; jl.dstride[0] = (ptrdiff_t)ypitch; jl.dfp[0] = yfp;
-            jl.y16 = 1;
-            wbank(jl, a.srcW, a.srcH, a.dstW, 0);
-            int r2 = ffhip_launch_lwalk(W, stream);
+            const char *ed = FFHIP_KNOB("FFHIP_SWS_DOWN2");
+            int r2 = 0;
+            if (c->dn2_luma && srcStride[0] > 0 && !(ed && ed[0] == '0')) {
+                FFHipDn2Args D;
+                memset(&D, 0, sizeof(D));
+                D.nframes = nframes;
+                D.xcd = 1;
+                FFHipDn2Job &j = D.job[D.njobs++];
+                j.src = s0; j.dst = ty; j.sstride = srcStride[0]; j.dstride = (ptrdiff_t)ypitch; j.sfp = srcFramePitch[0]; j.dfp = yfp;
+                j.srcH = a.srcH; j.dstH = a.dstH; j.ngroups = a.dstW / 4;
+                j.hfv = c->dn2_h[0]; j.vfv = c->dn2_v[0];
+                j.y16 = 1;
+                ffhip_down2_plan_job(&j, 32);
+                r2 = ffhip_launch_down2(D, stream);
+            } else {
+                FFHipLwJob &jl = W.job[W.njobs++];
+                jl.src[0] = s0; jl.sstride[0] = srcStride[0]; jl.sfp[0] = srcFramePitch[0];
+                jl.dst[0] = ty; jl.dstride[0] = (ptrdiff_t)ypitch; jl.dfp[0] = yfp;
+                jl.y16 = 1;
+                wbank(jl, a.srcW, a.srcH, a.dstW, 0);
+            }
+            if (r2 >= 0)
+                r2 = ffhip_launch_lwalk(W, stream);
             if (r2 < 0)
                 return r2;
             FFHipY16RgbArgs Y;

@@ -465,6 +465,11 @@ RGB2_CASES = [
     ("yuv420p", 384, 216, "rgb24", 200, 216, ffi.SWS_BICUBIC),         # horizontal only — vertical luma bank of 1 tap: NOT this path
     ("yuv420p", 640, 360, "rgb24", 160, 92, ffi.SWS_AREA),             # area: 4..5 taps
     ("yuv420p", 384, 216, "rgb24", 192, 104, ffi.SWS_BILINEAR),        # bilinear down: 4 taps that do not fit the column walker's spans
+    # exact 2:1: the luma job on the static-schedule kernel (k_sws_down2 with int16 stores), the chroma on the wide walker
+    ("nv12", 384, 216, "rgb24", 192, 108, ffi.SWS_BICUBIC),
+    ("yuv420p", 2576, 96, "bgra", 1288, 48, ffi.SWS_BICUBIC),          # several column blocks, ragged last one
+    ("nv21", 384, 216, "abgr", 192, 108, ffi.SWS_BICUBIC),
+    ("yuv422p", 384, 216, "bgr24", 192, 108, ffi.SWS_BICUBIC),
 ]
 
 
@@ -476,15 +481,20 @@ def test_rgb_two_stage(case, monkeypatch):
     two = bool(ctx.paths & 4) and not ctx.fast_path
     assert two == (dh != sh), "paths %d" % ctx.paths
     ctx.close()
-    _run(*case, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="any")
+    # (FFHIP_SWS_DOWN2=1: _run() switches the exact-2:1 kernel off for the tests of the general kernels; these want it)
+    _run(*case, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="any")
 
 
 def test_rgb_two_stage_full_size(monkeypatch):
-    _run("nv12", 3840, 2160, "rgb24", 1920, 1080, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=83, need="any")
+    _run("nv12", 3840, 2160, "rgb24", 1920, 1080, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, n=2, seed=83, need="any")
 
 
 def test_rgb_two_stage_switched_off_is_the_tiled_kernel(monkeypatch):
     _run("nv12", 384, 216, "rgb24", 192, 104, ffi.SWS_BICUBIC, env={"FFHIP_SWS_RGB2": "0"}, monkeypatch=monkeypatch, seed=5, need="any")
+
+
+def test_rgb_two_stage_exact_half_with_the_luma_on_the_wide_walker(monkeypatch):
+    _run("nv12", 384, 216, "rgb24", 192, 108, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "0"}, monkeypatch=monkeypatch, seed=6, need="any")
 
 
 @pytest.mark.parametrize("fmts", [("nv12", "rgb24"), ("yuv420p", "bgr24"), ("nv21", "rgb24")])
