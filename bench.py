@@ -312,6 +312,9 @@ def extras(torch, dev):
     # down-scaling INTO packed RGB (round 5: two stages — the wide-bank walker with an int16 luma plane, then the tables' closed form;
     # was the LDS-tiled kernel at 0.05), and the exact-2x RGB writer at 32 bits per pixel
     sws_case("sws_nv12_4k_to_rgb24_1080p_bicubic", 23, 3840, 2160, 2, 1920, 1080, 32)
+    # NV12 into rgb24 at the source's size: what sws_scale() runs for a decoder's frame (no table converter for semi-planar sources: the
+    # scaler with one-tap luma and the 4-tap vertical chroma bank; round 5: k_sws_eq_rgb, was the column walker at 0.355)
+    sws_case("sws_nv12_1080p_to_rgb24_1080p_bicubic", 23, 1920, 1080, 2, 1920, 1080, 64)
     sws_case("sws_yuv420p_1080p_to_bgra_4k_bicubic", 0, 1920, 1080, 28, 3840, 2160, 32)
     # a J (full-range) source: range conversion between the passes of the exact-2x kernel (round 4; AV_PIX_FMT_YUVJ420P = 12)
     sws_case("sws_yuvj420p_1080p_to_yuv420p_4k_bicubic", 12, 1920, 1080, 0, 3840, 2160, 64)

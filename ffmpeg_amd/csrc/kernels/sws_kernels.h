@@ -287,6 +287,29 @@ void ffhip_lw_plan_job(FFHipLwJob *j);
 int  ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream);
 
 /*
+ * 4:2:0 (planar or NV12 / NV21) into packed RGB at the source's size through the scaler's arithmetic (sws_eqrgb.hip): one-tap luma
+ * and horizontal banks, the 4-tap vertical chroma bank of an exact 2x (a chroma line per output line).
+ */
+struct FFHipEqRgbArgs {
+    const uint8_t *src[3];      /* Y, U, V planes; sil: src[1] = the byte-interleaved chroma plane (NV12; swap: NV21) */
+    uint8_t *dst;
+    ptrdiff_t sstride[3], dstride;
+    size_t sfp[3], dfp;
+    int sil, swap;
+    int chrH;                   /* chroma rows; the picture has 2 chrH rows */
+    int ngroups;                /* 8-pixel groups per row: width / 8 */
+    int nframes;
+    const uint32_t *vt;         /* device: the virtual vertical chroma bank, row y at dwords 2 (y + 1): (c01, c23); rows -1 and >= dstH zero */
+    int nstrips, steps_per_strip;
+    int fpp, wpp, npacks;       /* frames per pack (1, 2, 4), waves per pack and strip, packs: as FFHipUp2RgbArgs */
+    int vround;                 /* seed of the vertical sums: 1 << 18 (yuv2rgb_X) */
+    int lay;                    /* 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
+    FFHipYuv2RgbK k;
+};
+void ffhip_eqrgb_plan(FFHipEqRgbArgs *a, int want_steps, int fpp_forced);
+int  ffhip_launch_eqrgb(FFHipEqRgbArgs &A, hipStream_t stream);
+
+/*
  * Second stage of a scaled packed-RGB target that has no fused kernel (sws_y16rgb.hip): the scaler's output at the target's own
  * geometry — luma w x h as UNCLIPPED int16, chroma w / 2 x h (a chroma line per output line, half the columns: what yuv2packedX
  * is handed) — through the yuv2rgb tables' closed form into one of the six packed layouts.

@@ -56,6 +56,9 @@ struct FFHipSwsContext {
     int up2_rc = 0; /* a range-converting context: the exact-2x kernel with the range stage is its only fast kernel */
     void *up2_dev = nullptr;
     const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
+    /* 4:2:0 into packed RGB at the source's size through the scaler (sws_eqrgb.hip): the virtual vertical chroma bank on the device */
+    int eqr_ok = 0;
+    void *eqr_dev = nullptr;
     /* a scaled packed-RGB target in two stages (lw_ok on an RGB context; sws_lwalk.hip with an int16 luma plane, then sws_y16rgb.hip):
      * the intermediate planes, grown on demand — a context is used by one caller at a time, as an SwsContext is */
     void *rgb2_tmp = nullptr;
@@ -367,6 +370,34 @@ static void up2rgb_build(FFHipSwsContext *c, int srcW, int srcH, int dstW, int d
     c->u2r_ok = 1;
 }
 
+/* 4:2:0 into packed RGB at the source's size: one-tap unit banks for the luma and across, the vertical chroma bank an exact 2x bank
+ * (its 4-tap view on the regular windows of the edge-replicated plane).  Sets c->eqr_ok (sws_eqrgb.hip). */
+static void eqrgb_build(FFHipSwsContext *c, int srcW, int srcH, int chrW, int chrH)
+{
+    if ((srcW & 7) || (srcH & 1) || chrH < 4 || 2 * chrH != srcH || 2 * chrW != srcW || c->cw_vround != 1 << 18)
+        return;
+    const int unit[3] = { 1 << 14, 1 << 14, 1 << 12 }, want_n[3] = { srcW, chrW, srcH };
+    for (int i = 0; i < 3; i++) {
+        if (c->d[i].size != 1 || c->d[i].n != want_n[i])
+            return;
+        for (int x = 0; x < c->d[i].n; x++)
+            if (c->f[i][x] != unit[i] || c->p[i][x] != x)
+                return;
+    }
+    if (c->d[3].n != srcH)
+        return;
+    std::vector<uint32_t> vc;
+    if (!ffhip_up2_virtual_bank(c->nf[3].data(), c->np[3].data(), srcH, chrH, &vc))
+        return;
+    std::vector<uint32_t> vt((size_t)(srcH + 6) * 2, 0);
+    memcpy(vt.data() + 2, vc.data(), vc.size() * 4);
+    if (hipMalloc(&c->eqr_dev, vt.size() * 4) != hipSuccess)
+        return;
+    if (hipMemcpy(c->eqr_dev, vt.data(), vt.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    c->eqr_ok = 1;
+}
+
 /* exact 2:1: the banks (up to 8 taps) as virtual banks on the windows 2x - 3 .. 2x + 4 of the edge-replicated rows, on the device;
  * sets c->dn2_ok when every bank row is of that shape (sws_down2.hip) */
 static void dn2_build(FFHipSwsContext *c, const int nsrc[4])
@@ -662,6 +693,9 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         /* ... and, for exact 2x of 4:2:0 (planar or NV12 / NV21), the static-schedule kernel with the RGB writer (sws_up2rgb.hip) */
         if (c->cw_rgb && (t->srcFormat == FFHIP_PIX_FMT_YUV420P || fmt_nv(t->srcFormat)))
             up2rgb_build(c, t->srcW, t->srcH, t->dstW, t->dstH);
+        /* ... and the same sources at the source's own size (what sws_scale() runs for NV12 -> rgb24: no table converter exists for it) */
+        if (c->cw_rgb && (t->srcFormat == FFHIP_PIX_FMT_YUV420P || fmt_nv(t->srcFormat)) && t->srcW == t->dstW && t->srcH == t->dstH)
+            eqrgb_build(c, t->srcW, t->srcH, a.chrSrcW, a.chrSrcH);
         /* ... and every ratio the walker does not take (banks above 4 taps: all down-scaling) whose vertical luma bank has 3 taps or more
          * (the reference then runs yuv2rgb_X, seed 1 << 18: vscale.c:126-170) goes in TWO stages: the wide-bank walker on these very banks
          * into the target's own geometry (luma as unclipped int16, a chroma line per output line), then the tables' closed form
@@ -860,7 +894,7 @@ extern "C" int ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -911,6 +945,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->u2r_dev);
     if (c->rgb2_tmp)
         (void)hipFree(c->rgb2_tmp);
+    if (c->eqr_dev)
+        (void)hipFree(c->eqr_dev);
     if (c->w16_dev)
         (void)hipFree(c->w16_dev);
     if (c->dn2_dev)
@@ -1262,6 +1298,23 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
         const char *ev = FFHIP_KNOB("FFHIP_SWS_FAST");
         uintptr_t al = (uintptr_t)s0 | (size_t)srcStride[0] | srcFramePitch[0] | (uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp |
                        (size_t)cus | (size_t)cvs | cuf | cvf | (uintptr_t)(cstep == 2 ? s1 : cu) | (uintptr_t)(cstep == 2 ? s1 : cv);
+        const char *eq = FFHIP_KNOB("FFHIP_SWS_EQRGB"); /* measure build: 0 keeps the column walker */
+        if (c->eqr_ok && !(ev && ev[0] == '0') && !(eq && eq[0] == '0') && !(al & 3)) {
+            /* the source's size: chroma lines interpolated by the exact-2x vertical bank, nothing else scaled (sws_eqrgb.hip) */
+            FFHipEqRgbArgs E;
+            memset(&E, 0, sizeof(E));
+            E.src[0] = s0; E.src[1] = cstep == 2 ? s1 : cu; E.src[2] = cstep == 2 ? s1 : cv;
+            E.sil = cstep == 2; E.swap = t.srcFormat == FFHIP_PIX_FMT_NV21;
+            E.sstride[0] = srcStride[0]; E.sstride[1] = cus; E.sstride[2] = cvs;
+            E.sfp[0] = srcFramePitch[0]; E.sfp[1] = cuf; E.sfp[2] = cvf;
+            E.dst = a.dst; E.dstride = a.dst_stride; E.dfp = a.dst_fp;
+            E.chrH = a.chrSrcH; E.ngroups = a.dstW / 8; E.nframes = nframes;
+            E.vt = static_cast<const uint32_t *>(c->eqr_dev);
+            E.vround = c->cw_vround; E.lay = a.bgr; E.k = c->k;
+            const char *es = FFHIP_KNOB("FFHIP_EQRGB_STEPS"), *ef = FFHIP_KNOB("FFHIP_EQRGB_FPP");
+            ffhip_eqrgb_plan(&E, es && atoi(es) > 0 ? atoi(es) : 30, ef ? atoi(ef) : E.lay < 2 ? 0 : 1);
+            return ffhip_launch_eqrgb(E, stream);
+        }
         const char *eu2 = FFHIP_KNOB("FFHIP_SWS_UP2RGB"); /* measure build: 0 keeps the column walker, v<n> a measured variant */
         if (c->u2r_ok && !(ev && ev[0] == '0') && !(eu2 && eu2[0] == '0') && !(al & 3)) {
             /* exact 2x of 4:2:0: static schedule, regular windows, the RGB writer fused (sws_up2rgb.hip) */

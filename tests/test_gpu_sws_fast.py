@@ -51,7 +51,8 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     torch = _torch()
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD",
-              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS", "FFHIP_UP2RGB_FPP", "FFHIP_SWS_RGB2"):
+              "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS", "FFHIP_UP2RGB_FPP", "FFHIP_SWS_RGB2", "FFHIP_SWS_EQRGB", "FFHIP_EQRGB_STEPS",
+              "FFHIP_EQRGB_FPP"):
         monkeypatch.delenv(k, raising=False)
     # the general kernels at exact 2:1 / 1:2 sizes need the fast paths switched off: a knob, i.e. libffhip_measure.so (conftest.py);
     # every other size runs the product library
@@ -448,6 +449,50 @@ def test_up2rgb_is_not_taken_where_it_does_not_apply():
                                    ("yuv420p", 128, 72, "rgb24", 256, 216), ("yuv422p", 128, 72, "rgb24", 256, 144)):
         ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], ffi.SWS_BICUBIC)
         assert not ctx.up2rgb_path, (sf, sw, sh, df, dw, dh)
+
+
+# 4:2:0 into packed RGB at the SOURCE'S SIZE through the scaler (sws_eqrgb.hip): what sws_scale() runs for NV12 -> rgb24 (no table
+# converter exists for semi-planar sources) and for yuv420p under SWS_ACCURATE_RND: one-tap luma, the chroma lines brought up to a line
+# per output line by the 4-tap vertical bank
+EQRGB_CASES = [
+    ("nv12", 64, 8, "rgb24"), ("nv12", 192, 108, "rgb24"), ("nv21", 192, 108, "bgr24"), ("nv12", 264, 50, "bgra"), ("nv21", 136, 70, "argb"),
+    ("nv12", 1048, 600, "rgba"), ("nv12", 1048, 600, "rgb24"), ("yuv420p", 192, 108, "rgb24"), ("yuv420p", 520, 130, "abgr"),
+    ("yuv420p", 1048, 600, "bgr24"),
+]
+
+
+@pytest.mark.parametrize("env", [{}, {"FFHIP_EQRGB_STEPS": "3"}, {"FFHIP_EQRGB_STEPS": "900"}, {"FFHIP_EQRGB_FPP": "1"}, {"FFHIP_EQRGB_FPP": "4"}],
+                         ids=["default", "strip3", "one_strip", "fpp1", "fpp4"])
+@pytest.mark.parametrize("case", EQRGB_CASES, ids=lambda c: "%s_%dx%d_%s" % c)
+def test_eqrgb(case, env, monkeypatch):
+    from ffmpeg_amd import swscale as S
+    sf, w, h, df = case
+    fl = ffi.SWS_BICUBIC | (ffi.SWS_ACCURATE_RND if sf == "yuv420p" else 0)   # (plain yuv420p gets the table converter: test_gpu_sws.py)
+    ctx = S.SwsContext(w, h, PIX[sf], w, h, PIX[df], fl)
+    assert ctx.paths & 128, "case does not reach the equal-size kernel (paths %d)" % ctx.paths
+    ctx.close()
+    _run(sf, w, h, df, w, h, fl, env=env, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="any")
+
+
+@pytest.mark.parametrize("flags", [ffi.SWS_BILINEAR, ffi.SWS_POINT, ffi.SWS_BICUBIC | ffi.SWS_BITEXACT], ids=["bilinear", "point", "bitexact"])
+def test_eqrgb_other_vertical_chroma_banks(flags, monkeypatch):
+    """2-tap (bilinear: the reference runs yuv2rgb_1 with the row's chroma weight, libswscale/vscale.c:140-160, output.c:1883-1939) and
+    1-tap vertical chroma banks, when they fit the regular windows: same kernel, or the column walker — either way the reference's bytes"""
+    _run("nv12", 192, 108, "rgb24", 192, 108, flags, monkeypatch=monkeypatch, seed=87, need="any")
+    _run("nv21", 264, 50, "bgra", 264, 50, flags, monkeypatch=monkeypatch, seed=88, need="any")
+
+
+def test_eqrgb_full_size_and_switched_off(monkeypatch):
+    _run("nv12", 1920, 1080, "rgb24", 1920, 1080, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=5, seed=85, need="any")
+    _run("nv12", 192, 108, "rgb24", 192, 108, ffi.SWS_BICUBIC, env={"FFHIP_SWS_EQRGB": "0"}, monkeypatch=monkeypatch, seed=86, need="fast")
+
+
+def test_eqrgb_is_not_taken_where_it_does_not_apply():
+    from ffmpeg_amd import swscale as S
+    for sf, w, h, df, fl in (("nv12", 196, 108, "rgb24", ffi.SWS_BICUBIC),
+                             ("yuv422p", 192, 108, "rgb24", ffi.SWS_BICUBIC | ffi.SWS_ACCURATE_RND)):
+        ctx = S.SwsContext(w, h, PIX[sf], w, h, PIX[df], fl)
+        assert not ctx.paths & 128, (sf, w, h, df, fl)
 
 
 # down-scaling (and every other ratio whose banks the column walker does not take) INTO packed RGB: two stages — the wide-bank walker
