@@ -325,6 +325,9 @@ def extras(torch, dev):
     sws_case("sws_p010_1080p_to_4k_bicubic", 158, 1920, 1080, 158, 3840, 2160, 64)
     sws_case("sws_yuv420p10_1080p_to_4k_bicubic", 62, 1920, 1080, 62, 3840, 2160, 64)
     sws_case("sws_p010_4k_to_1080p_bicubic", 158, 3840, 2160, 158, 1920, 1080, 16)
+    # a 10-bit decoder's frame for an 8-bit consumer (round 5: the 16-bit column walker with the dithered 8-bit output stage; was the tiled
+    # k_sws_scale16 at 0.05)
+    sws_case("sws_p010_4k_to_nv12_1080p_bicubic", 158, 3840, 2160, 23, 1920, 1080, 16)
     # ... and the ratios that are not exactly 2: the 16-bit column walker (round 4, sws_walk16.hip; was k_sws_scale16)
     sws_case("sws_p010_720p_to_1080p_bicubic", 158, 1280, 720, 158, 1920, 1080, 64)
     sws_case("sws_p010_4k_to_1440p_bicubic", 158, 3840, 2160, 158, 2560, 1440, 16)

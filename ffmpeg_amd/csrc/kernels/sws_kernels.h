@@ -338,6 +338,7 @@ struct FFHipW16Job {
     const int16_t *hf; const int32_t *hp;     /* device: dstW x ht taps, positions in samples of the channel */
     const int16_t *vf; const int32_t *vp;     /* device: dstH x vt taps */
     int ncb, nstrips, strip_rows, unit_begin;
+    int dither_off;                           /* ddepth 8, plane jobs: 3 for the V plane (its dither row is read three entries on), else 0 */
 };
 struct FFHipW16Args {
     FFHipW16Job job[3];

@@ -39,6 +39,20 @@ typedef w16_u4 __attribute__((aligned(2))) w16_u4a;
 typedef w16_u2 __attribute__((aligned(4))) w16_u2d;
 typedef w16_u4 __attribute__((aligned(4))) w16_u4d;
 
+/* ff_dither_8x8_128 (libswscale/swscale.c:42-52): the ordered dither of an 8-bit target fed from a deeper source (swscale.c:291,519-522) */
+__constant__ __attribute__((aligned(8))) uint8_t w16_dither[8][8] = {
+    {  36, 68,  60, 92,  34, 66,  58, 90, }, { 100,  4, 124, 28,  98,  2, 122, 26, }, {  52, 84,  44, 76,  50, 82,  42, 74, },
+    { 116, 20, 108, 12, 114, 18, 106, 10, }, {  32, 64,  56, 88,  38, 70,  62, 94, }, {  96,  0, 120, 24, 102,  6, 126, 30, },
+    {  48, 80,  40, 72,  54, 86,  46, 78, }, { 112, 16, 104,  8, 118, 22, 110, 14, },
+};
+/* clip_u8(a >> 19) | clip_u8(b >> 19) << 8 in the low half (the high half is not defined: common.h) */
+__device__ __forceinline__ uint32_t w16_pk_u8(int a, int b)
+{
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 19" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ int w16_dot2(uint32_t a, uint32_t b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(w16_s2, a), __builtin_bit_cast(w16_s2, b), c, false);
@@ -126,7 +140,8 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     const int dstW = J.dstW, dstH = J.dstH, srcH = J.srcH;
     const ptrdiff_t ss0 = J.sstride[0], ss1 = J.sstride[NCH - 1], ds0 = J.dstride[0], ds1 = J.dstride[NCH - 1];
     const int y0 = strip * J.strip_rows, y1 = min(y0 + J.strip_rows, dstH);
-    const int hsh = A.sdepth - 1, vsh = 27 - A.ddepth;
+    const bool d8 = A.ddepth == 8; /* an 8-bit target fed from the deeper source: yuv2planeX_8_c / yuv2nv12cX_c with the ordered dither */
+    const int hsh = A.sdepth - 1, vsh = d8 ? 19 : 27 - A.ddepth;
     const int smsb = A.smsb ? 16 - A.sdepth : 0, dmsb = A.dmsb ? 16 - A.ddepth : 0;
     const int maxv = (1 << A.ddepth) - 1;
     const bool sil = J.sstep == 2, dil = J.dstep == 2;
@@ -260,15 +275,25 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     }
     int yy = y0;
     /* where this lane's samples of output row yy go: advanced by the stride per row (a 64-bit multiply-add per row before) */
-    uint8_t *dq0 = db0 + (ptrdiff_t)y0 * ds0 + (size_t)X0 * (NCH == 2 && dil ? 4 : 2);
-    uint8_t *dq1 = db1 + (ptrdiff_t)y0 * ds1 + (size_t)X0 * 2;
+    uint8_t *dq0 = db0 + (ptrdiff_t)y0 * ds0 + (size_t)X0 * ((NCH == 2 && dil ? 4 : 2) >> (d8 ? 1 : 0));
+    uint8_t *dq1 = db1 + (ptrdiff_t)y0 * ds1 + (size_t)X0 * (d8 ? 1 : 2);
+    /* d8: column c's entry of the dither row — (x + offset) & 7 with offset 3 for the V channel / plane (yuv2nv12cX_c, output.c:503-529;
+     * vscale.c's chroma call): which dword of the row's eight bytes and how far in */
+    bool dhi[4];
+    int dsh[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int idx = (X0 + c % NC + (NCH == 2 ? (c / NC ? 3 : 0) : J.dither_off)) & 7;
+        dhi[c] = idx >= 4;
+        dsh[c] = 8 * (idx & 3);
+    }
     const bool in_w = X0 < dstW, whole = X0 + (NCH == 2 ? 2 : 4) <= dstW;
     int need = __builtin_amdgcn_readlane(vpl, 0) + VT - 1;
     const int rlast = __builtin_amdgcn_readlane(vpl, y1 - 1 - y0) + VT - 1;
     int r = need - (VT - 1);
     Row cur, nxt;
     load_row(cur, r);
-    const int kround = 1 << (vsh - 1);
+    const int kround = d8 ? 0 : 1 << (vsh - 1);
     while (r <= rlast) {
 #pragma unroll
         for (int k = 0; k < R; k++) {
@@ -295,6 +320,49 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                         w16_vdots<true>(t, pp[0], pp[1], vc[0], vc[1], kround);
                         if (VP == 4)
                             w16_vdots<false>(t, pp[2 % VP], pp[3 % VP], vc[2 % VP], vc[3 % VP], 0);
+                        if (d8) { /* uniform */
+                            /* seed dither << 12, >> 19, clip to 8 bits (yuv2planeX_8_c, output.c:468-486): four bytes per lane */
+                            const uint2 drow = *reinterpret_cast<const uint2 *>(w16_dither[yy & 7]);
+                            uint32_t b01, b23;
+                            {
+                                int z[4];
+#pragma unroll
+                                for (int c = 0; c < 4; c++)
+                                    z[c] = t[c] + (int)((((dhi[c] ? drow.y : drow.x) >> dsh[c]) & 255u) << 12);
+                                b01 = w16_pk_u8(z[0], z[1]);
+                                b23 = w16_pk_u8(z[2], z[3]);
+                            }
+                            if (in_w) {
+                                if (NCH == 2 && dil) {           /* (u0, u1) (v0, v1) -> bytes u0 v0 u1 v1 */
+                                    const uint32_t w = __builtin_amdgcn_perm(b23, b01, 0x05010400u);
+                                    if (whole) *reinterpret_cast<uint32_t *>(dq0) = w;
+                                    else *reinterpret_cast<uint16_t *>(dq0) = (uint16_t)w;
+                                } else if (NCH == 2) {           /* two samples of each channel into its own plane */
+                                    if (whole) {
+                                        *reinterpret_cast<uint16_t *>(dq0) = (uint16_t)b01;
+                                        *reinterpret_cast<uint16_t *>(dq1) = (uint16_t)b23;
+                                    } else {
+                                        dq0[0] = (uint8_t)b01;
+                                        dq1[0] = (uint8_t)b23;
+                                    }
+                                } else {
+                                    const uint32_t w = __builtin_amdgcn_perm(b23, b01, 0x05040100u);
+                                    if (whole) {
+                                        *reinterpret_cast<uint32_t *>(dq0) = w;
+                                    } else {
+                                        dq0[0] = (uint8_t)w;
+                                        if (X0 + 1 < dstW) dq0[1] = (uint8_t)(w >> 8);
+                                        if (X0 + 2 < dstW) dq0[2] = (uint8_t)(w >> 16);
+                                    }
+                                }
+                            }
+                            yy++;
+                            dq0 += ds0;
+                            dq1 += ds1;
+                            if (yy < y1)
+                                need = __builtin_amdgcn_readlane(vpl, yy - y0) + VT - 1;
+                            continue;
+                        }
                         /* >> (27 - bits), then the clip to 0 .. 2^bits - 1 on int16 pairs (v_cvt_pk_i16_i32 saturates to int16: the
                          * clip range lies inside) and P01x's alignment */
 #pragma unroll

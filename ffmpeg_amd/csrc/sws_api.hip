@@ -630,7 +630,10 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 dn2_build(c, limits);
             /* every other ratio between 9..14-bit formats whose banks have at most 8 taps: the 16-bit column walker (sws_walk16.hip);
              * no range change (it carries no range stage), no 8-bit side */
-            if (!c->up2_ok && !c->dn2_ok && sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl != 2 && dl != 2 && t->src_range == t->dst_range &&
+            /* (round 5: also an 8-bit planar / NV12 target fed from a 9..14-bit source — a 10-bit decoder's frames for an 8-bit consumer:
+             * the 16-bit horizontal pass, yuv2planeX_8_c / yuv2nv12cX_c with the ordered dither on the way out) */
+            const bool to8 = dd == 8 && (t->dstFormat == FFHIP_PIX_FMT_NV12 || !fmt_nv(t->dstFormat));
+            if (!c->up2_ok && !c->dn2_ok && sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14) || to8) && sl != 2 && dl != 2 && t->src_range == t->dst_range &&
                 c->d[0].size <= 8 && c->d[1].size <= 8 && c->d[2].size <= 8 && c->d[3].size <= 8 &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size)) {
                 const int ht = c->d[0].size <= 4 && c->d[1].size <= 4 ? 4 : 8, vt = c->d[2].size <= 4 && c->d[3].size <= 4 ? 4 : 8;
@@ -1101,11 +1104,12 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 FFHipW16Job &j = W.job[W.njobs++];
                 j.nch = nch;
                 j.sstep = which && sl ? 2 : 1; j.dstep = which && dl ? 2 : 1;
+                j.dither_off = dplane0 == 2 ? 3 : 0;
                 for (int k = 0; k < nch; k++) {
-                    /* an interleaved side: both channels live in plane 1, the second two bytes on; a planar side: planes 1 and 2 */
+                    /* an interleaved side: both channels live in plane 1, the second one sample on; a planar side: planes 1 and 2 */
                     const int sp = which && sl ? 1 : splane0 + k, dp = which && dl ? 1 : dplane0 + k;
                     j.src[k] = static_cast<const uint8_t *>(src[sp]) + (which && sl ? 2 * k : 0);
-                    j.dst[k] = static_cast<uint8_t *>(dst[dp]) + (which && dl ? 2 * k : 0);
+                    j.dst[k] = static_cast<uint8_t *>(dst[dp]) + (which && dl ? (dd == 8 ? 1 : 2) * k : 0);
                     j.sstride[k] = srcStride[sp]; j.dstride[k] = dstStride[dp];
                     j.sfp[k] = srcFramePitch[sp]; j.dfp[k] = dstFramePitch[dp];
                 }

@@ -139,6 +139,39 @@ def test_exact_2to1_above_8_bits(case, variant, monkeypatch):
     _run(case, nframes=5)
 
 
+# a 9..14-bit source into an 8-bit planar / NV12 target — a 10-bit decoder's frames for an 8-bit consumer — on the 16-bit column walker
+# (round 5: the 16-bit horizontal pass, yuv2planeX_8_c / yuv2nv12cX_c with the ordered dither on the way out; was k_sws_scale16 at 0.05
+# of HBM); "tiled" runs the same cases on k_sws_scale16 (FFHIP_SWS_WALK16=0, the measure build)
+TO8_CASES = [
+    ("p010le", 384, 216, "nv12", 192, 108, ffi.SWS_BICUBIC),          # 2:1, interleaved in and out
+    ("p010le", 384, 216, "yuv420p", 256, 144, ffi.SWS_BICUBIC),       # 1.5:1, interleaved in, planar out: the V plane's dither three entries on
+    ("yuv420p10le", 384, 216, "yuv420p", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 384, 216, "nv12", 192, 108, ffi.SWS_BICUBIC),     # planar in, interleaved out
+    ("yuv420p12le", 202, 120, "yuv420p", 302, 180, ffi.SWS_BICUBIC),  # up, ragged last groups
+    ("yuv422p10le", 384, 216, "yuv422p", 256, 144, ffi.SWS_BICUBIC),
+    ("yuv444p10le", 192, 108, "yuv444p", 288, 162, ffi.SWS_BILINEAR),
+    ("p010le", 1048, 600, "nv12", 700, 400, ffi.SWS_BICUBIC),         # several column blocks and strips
+]
+
+
+@pytest.mark.parametrize("variant", ["product", "tiled"])
+@pytest.mark.parametrize("case", TO8_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_deeper_source_into_8_bits(case, variant, monkeypatch):
+    from ffmpeg_amd import swscale as S
+    if variant == "tiled":
+        monkeypatch.setenv("FFHIP_SWS_WALK16", "0")
+    else:
+        sname, sw, sh, dname, dw, dh, flags = case
+        ctx = S.SwsContext(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags)
+        assert ctx.walk16_path, "case does not reach the 16-bit column walker"
+        ctx.close()
+    _run(case)
+
+
+def test_p010_4k_to_nv12_1080p():
+    _run(("p010le", 3840, 2160, "nv12", 1920, 1080, ffi.SWS_BICUBIC), nframes=2)
+
+
 def test_p010_1080p_to_4k():
     _run(("p010le", 1920, 1080, "p010le", 3840, 2160, ffi.SWS_BICUBIC), nframes=1, pad=0)
 
