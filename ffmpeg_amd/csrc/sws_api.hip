@@ -1302,8 +1302,11 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
         const char *ev = FFHIP_KNOB("FFHIP_SWS_FAST");
         uintptr_t al = (uintptr_t)s0 | (size_t)srcStride[0] | srcFramePitch[0] | (uintptr_t)a.dst | (size_t)a.dst_stride | a.dst_fp |
                        (size_t)cus | (size_t)cvs | cuf | cvf | (uintptr_t)(cstep == 2 ? s1 : cu) | (uintptr_t)(cstep == 2 ? s1 : cv);
+        /* (the round-5 kernels walk their rows with running pointers and were written for top-down pictures: a negative stride keeps the
+         * older kernels) */
+        const bool topdown = srcStride[0] > 0 && cus > 0 && cvs > 0 && a.dst_stride > 0;
         const char *eq = FFHIP_KNOB("FFHIP_SWS_EQRGB"); /* measure build: 0 keeps the column walker */
-        if (c->eqr_ok && !(ev && ev[0] == '0') && !(eq && eq[0] == '0') && !(al & 3)) {
+        if (c->eqr_ok && topdown && !(ev && ev[0] == '0') && !(eq && eq[0] == '0') && !(al & 3)) {
             /* the source's size: chroma lines interpolated by the exact-2x vertical bank, nothing else scaled (sws_eqrgb.hip) */
             FFHipEqRgbArgs E;
             memset(&E, 0, sizeof(E));
@@ -1320,7 +1323,7 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             return ffhip_launch_eqrgb(E, stream);
         }
         const char *eu2 = FFHIP_KNOB("FFHIP_SWS_UP2RGB"); /* measure build: 0 keeps the column walker, v<n> a measured variant */
-        if (c->u2r_ok && !(ev && ev[0] == '0') && !(eu2 && eu2[0] == '0') && !(al & 3)) {
+        if (c->u2r_ok && topdown && !(ev && ev[0] == '0') && !(eu2 && eu2[0] == '0') && !(al & 3)) {
             /* exact 2x of 4:2:0: static schedule, regular windows, the RGB writer fused (sws_up2rgb.hip) */
             FFHipUp2RgbArgs U;
             memset(&U, 0, sizeof(U));
@@ -1356,7 +1359,7 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             return ffhip_launch_colwalk_rgb(R, stream);
         }
         const char *e2 = FFHIP_KNOB("FFHIP_SWS_RGB2"); /* measure build: 0 keeps the LDS-tiled kernel */
-        if (c->lw_ok && !(ev && ev[0] == '0') && !(e2 && e2[0] == '0') && !(al & 3)) {
+        if (c->lw_ok && topdown && !(ev && ev[0] == '0') && !(e2 && e2[0] == '0') && !(al & 3)) {
             /* two stages (see the context's creation): planes of the target's geometry, pitches and frames 256-byte aligned */
             const size_t ypitch = ((size_t)2 * a.dstW + 255) & ~(size_t)255, cpitch = ((size_t)(a.dstW / 2) + 255) & ~(size_t)255;
             const size_t yfp = ypitch * (size_t)a.dstH, cfp = cpitch * (size_t)a.dstH, need = (yfp + 2 * cfp) * (size_t)nframes;
