@@ -319,7 +319,7 @@ struct FFHipY16RgbArgs {
     uint8_t *dst;
     ptrdiff_t ystride, cstride, dstride;
     size_t yfp, cfp, dfp;
-    int w, h, nframes, lay;     /* w % 8 == 0; lay: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
+    int w, h, nframes, lay;     /* w even (a chroma sample per pixel pair); lay: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
     FFHipYuv2RgbK k;
 };
 int ffhip_launch_y16_rgb(const FFHipY16RgbArgs &a, hipStream_t stream);

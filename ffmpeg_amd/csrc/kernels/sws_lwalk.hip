@@ -92,6 +92,8 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
         }
     }
     const bool act = X0 < J.dstW;
+    const int nval = J.dstW - X0;          /* this lane's valid columns (per channel) when it holds the row's ragged end */
+    const bool whole = nval >= CPL;
 
     /* ---- vertical descriptors of the strip's <= 64 rows ---- */
     int vpl;
@@ -228,26 +230,45 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
                 v[2] = lw_dot2(P.z, fk[k], v[2]);
                 v[3] = lw_dot2(P.w, fk[k], v[3]);
             }
+            typedef uint16_t __attribute__((address_space(1))) *lw_gh;
+            typedef uint8_t __attribute__((address_space(1))) *lw_gb;
             if (NG == 1 && y16) {
                 /* the luma of a packed-RGB target's first stage: the sums >> 19 as they are, int16 — yuv2rgb_X does not clip Y before
                  * the tables (libswscale/output.c:1814-1835); no 4-tap-or-wider bank of weights summing to 4096 leaves int16 */
                 lw_u2 w2;
                 w2.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0] >> 19, v[1] >> 19));
                 w2.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2] >> 19, v[3] >> 19));
-                if (act)
+                if (whole) {
                     *(lw_g2)((lw_gptr)d0 + (uint32_t)(2 * X0)) = w2;
+                } else if (act) { /* the ragged last group of a row (round 5: widths that are not multiples of 4) */
+                    lw_gh d = (lw_gh)((lw_gptr)d0 + (uint32_t)(2 * X0));
+                    d[0] = (uint16_t)w2.x;
+                    if (nval > 1) d[1] = (uint16_t)(w2.x >> 16);
+                    if (nval > 2) d[2] = (uint16_t)w2.y;
+                }
             } else if (NG == 1) {
                 const uint32_t w1 = __builtin_amdgcn_perm(lw_pk_u8(v[2], v[3]), lw_pk_u8(v[0], v[1]), 0x05040100);
-                if (act)
+                if (whole) {
                     *(lw_g1)((lw_gptr)d0 + (uint32_t)X0) = w1;
+                } else if (act) {
+                    lw_gb d = (lw_gb)((lw_gptr)d0 + (uint32_t)X0);
+                    d[0] = (uint8_t)w1;
+                    if (nval > 1) d[1] = (uint8_t)(w1 >> 8);
+                    if (nval > 2) d[2] = (uint8_t)(w1 >> 16);
+                }
             } else if (dil) {
                 /* v = U0 U1 V0 V1 -> bytes U0 V0 U1 V1 (V first for NV21) */
                 const uint32_t w1 = __builtin_amdgcn_perm(lw_pk_u8(v[1], v[3]), lw_pk_u8(v[0], v[2]), sel_uv);
-                if (act)
+                if (whole)
                     *(lw_g1)((lw_gptr)d0 + (uint32_t)(2 * X0)) = w1;
+                else if (act)
+                    *(lw_gh)((lw_gptr)d0 + (uint32_t)(2 * X0)) = (uint16_t)w1; /* one (u, v) pair */
+            } else if (whole) {
+                *(lw_gh)((lw_gptr)d0 + (uint32_t)X0) = (uint16_t)lw_pk_u8(v[0], v[1]);
+                *(lw_gh)((lw_gptr)d1 + (uint32_t)X0) = (uint16_t)lw_pk_u8(v[2], v[3]);
             } else if (act) {
-                *(uint16_t __attribute__((address_space(1))) *)((lw_gptr)d0 + (uint32_t)X0) = (uint16_t)lw_pk_u8(v[0], v[1]);
-                *(uint16_t __attribute__((address_space(1))) *)((lw_gptr)d1 + (uint32_t)X0) = (uint16_t)lw_pk_u8(v[2], v[3]);
+                *(lw_gb)((lw_gptr)d0 + (uint32_t)X0) = (uint8_t)lw_pk_u8(v[0], v[1]);
+                *(lw_gb)((lw_gptr)d1 + (uint32_t)X0) = (uint8_t)lw_pk_u8(v[2], v[3]);
             }
             d0 += dstride0;
             d1 += dstride1;
@@ -323,7 +344,7 @@ __global__ __launch_bounds__(64) void k_sws_lwalk(FFHipLwArgs A)
  */
 int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH, int pair)
 {
-    if ((ht != 2 && ht != 4) || (vt != 4 && vt != 8) || hn <= 0 || (hn & 3) || vn <= 0 || srcW < 4 * ht || srcW < 8 ||
+    if ((ht != 2 && ht != 4) || (vt != 4 && vt != 8) || hn <= 0 || vn <= 0 || srcW < 4 * ht || srcW < 8 ||
         srcH < 2 * vt)
         return 0;
     const int block = pair ? 128 : 256; /* output columns of one wave */

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_y16_rgb(FFHipY16RgbArgs A)
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int G = A.w >> 3, ncb = (G + 63) >> 6;
+    const int G = (A.w + 7) >> 3, ncb = (G + 63) >> 6; /* groups of 8 pixels; the last one may be ragged (its loads stay inside the planes' padded pitch) */
     const uint32_t upf = (uint32_t)ncb * (uint32_t)A.h;
     const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
     if (gw >= upf * (uint32_t)A.nframes)
@@ -131,15 +131,22 @@ __global__ __launch_bounds__(256) void k_y16_rgb(FFHipY16RgbArgs A)
     for (int i = 0; i < NW / 2; i++)
         *reinterpret_cast<uint2 *>(t + 2 * i) = make_uint2(w[2 * i], w[2 * i + 1]);
     yr_wave_sync_lds();
-    const int nbytes = 4 * NW * min(G - cb * 64, 64); /* valid bytes of the segment (a multiple of 8) */
+    const int nbytes = (NW / 2) * min(A.w - cb * 512, 512); /* valid bytes of the segment: 3 or 4 per pixel */
     yr_gp d = (yr_gp)pd + (uint32_t)(NW * 256) * (uint32_t)cb + 8u * (uint32_t)lane;
 #pragma unroll
     for (int i = 0; i < NW / 2; i++) {
         const uint2 q = *reinterpret_cast<const uint2 *>(tile + i * 128 + lane * 2);
         yr_u2 s;
         s.x = q.x; s.y = q.y;
-        if (i * 512 + lane * 8 < nbytes)
+        const int o = i * 512 + lane * 8;
+        if (o + 8 <= nbytes) {
             __builtin_nontemporal_store(s, (yr_g2)(d + i * 512));
+        } else if (o < nbytes) { /* the row ends inside this piece (a width that is not a multiple of 8): its bytes one by one */
+            typedef uint8_t __attribute__((address_space(1))) *yr_gb;
+            const uint64_t v = (uint64_t)q.x | (uint64_t)q.y << 32;
+            for (int k = 0; k < nbytes - o; k++)
+                ((yr_gb)(d + i * 512))[k] = (uint8_t)(v >> (8 * k));
+        }
     }
     (void)act;
 }
@@ -148,11 +155,11 @@ int ffhip_launch_y16_rgb(const FFHipY16RgbArgs &a, hipStream_t stream)
 {
     if (a.nframes <= 0 || a.h <= 0)
         return 0;
-    if (a.w <= 0 || (a.w & 7)) {
-        ffhip_set_error("ffhip_sws: the second stage of a scaled RGB target takes widths that are multiples of 8 (got %d)", a.w);
+    if (a.w <= 0 || (a.w & 1)) {
+        ffhip_set_error("ffhip_sws: the second stage of a scaled RGB target takes even widths (got %d)", a.w);
         return FFHIP_EINVAL;
     }
-    const long long waves = (long long)cdiv(a.w >> 3, 64) * a.h * a.nframes;
+    const long long waves = (long long)cdiv(cdiv(a.w, 8), 64) * a.h * a.nframes;
     if (waves >= (1LL << 31)) {
         ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
         return FFHIP_EINVAL;

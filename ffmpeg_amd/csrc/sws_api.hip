@@ -703,7 +703,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
          * (the reference then runs yuv2rgb_X, seed 1 << 18: vscale.c:126-170) goes in TWO stages: the wide-bank walker on these very banks
          * into the target's own geometry (luma as unclipped int16, a chroma line per output line), then the tables' closed form
          * (sws_y16rgb.hip) — against the LDS-tiled k_scale_rgb at 0.05 of HBM */
-        if (!r && !c->cw_rgb && !a.full && !a.has_alpha && !(t->dstW & 7) && c->d[2].size >= 3 && build_wide_view(c, limits)) {
+        if (!r && !c->cw_rgb && !a.full && !a.has_alpha && !(t->dstW & 1) && c->d[2].size >= 3 && build_wide_view(c, limits)) {
             bool ok = true;
             for (int k = 0; k < 2 && ok; k++)
                 ok = ffhip_lw_bank_ok(c->wp[k].data(), c->lw_ht, c->d[k].n, limits[k], c->wp[2 + k].data(), c->lw_vt, c->d[2 + k].n,

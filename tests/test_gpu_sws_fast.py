@@ -515,6 +515,12 @@ RGB2_CASES = [
     ("yuv420p", 2576, 96, "bgra", 1288, 48, ffi.SWS_BICUBIC),          # several column blocks, ragged last one
     ("nv21", 384, 216, "abgr", 192, 108, ffi.SWS_BICUBIC),
     ("yuv422p", 384, 216, "bgr24", 192, 108, ffi.SWS_BICUBIC),
+    # even widths that are not multiples of 8: the row's last group is ragged in both stages
+    ("nv12", 384, 216, "rgb24", 170, 96, ffi.SWS_BICUBIC),
+    ("yuv420p", 384, 216, "bgra", 172, 96, ffi.SWS_BICUBIC),
+    ("nv21", 384, 216, "bgr24", 174, 100, ffi.SWS_BICUBIC),
+    ("yuv420p", 1080, 480, "argb", 540, 240, ffi.SWS_BICUBIC),         # 2:1 with 540 = 8 * 67 + 4 columns: the luma on k_sws_down2
+    ("nv12", 1920, 1080, "rgb24", 854, 480, ffi.SWS_BICUBIC),
 ]
 
 
@@ -583,6 +589,13 @@ WIDE_CASES = [
     ("nv21", 2560, 96, "nv21", 1280, 48, ffi.SWS_BICUBIC),           # interleaved pair, swapped
     ("nv12", 2560, 96, "yuv420p", 1280, 40, ffi.SWS_BICUBIC),        # interleaved in, planar out, another vertical ratio
     ("yuv420p", 2576, 96, "nv12", 1288, 48, ffi.SWS_BICUBIC),        # ragged last block
+    # widths that are not multiples of 4 (854 x 480 from 1080p, ...): the last lane of a row stores its one to three columns one by one
+    ("nv12", 384, 216, "nv12", 170, 96, ffi.SWS_BICUBIC),             # chroma 85 wide: one (u, v) pair in the last lane
+    ("yuv420p", 384, 216, "yuv420p", 170, 96, ffi.SWS_BICUBIC),
+    ("nv12", 384, 216, "yuv420p", 171 + 3, 96, ffi.SWS_BICUBIC),      # 174: luma 2 left over, chroma 87
+    ("yuv420p", 384, 216, "nv21", 166, 90, ffi.SWS_BICUBIC),
+    ("yuv444p", 384, 216, "yuv444p", 173, 97, ffi.SWS_BICUBIC),       # odd in both directions
+    ("nv12", 1920, 1080, "nv12", 854, 480, ffi.SWS_BICUBIC),
 ]
 
 

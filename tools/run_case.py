@@ -20,8 +20,18 @@ reps = int(a[8]) if len(a) > 8 else 5
 dev = torch.device("cuda", 0)
 ctx = S.SwsContext(sw, sh, S.PIX_FMT[sf], dw, dh, S.PIX_FMT[df], flags)
 g = torch.Generator(device=dev).manual_seed(1)
-src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev, generator=g) for r, c in S.plane_shapes(S.PIX_FMT[sf], sw, sh)]
-dst = [torch.zeros((n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(S.PIX_FMT[df], dw, dh)]
+# line pitches rounded up to 64 bytes, as av_frame_get_buffer() lays frames out (the fast kernels want dword-aligned lines)
+def planes(fmt, w, h, fill):
+    out = []
+    for r, c in S.plane_shapes(S.PIX_FMT[fmt], w, h):
+        pitch = (c + 63) // 64 * 64
+        t_ = torch.randint(0, 256, (n, r, pitch), dtype=torch.uint8, device=dev, generator=g) if fill else torch.zeros((n, r, pitch), dtype=torch.uint8, device=dev)
+        out.append(t_[:, :, :c])
+    return out
+
+
+src = planes(sf, sw, sh, True)
+dst = planes(df, dw, dh, False)
 for name, planes in ((sf, src),):
     if name in ("p010", "yuv420p10"):    # valid 10-bit samples: the low 10 bits of the word (planar) or the high 10 (P010)
         for t_ in planes:
