@@ -1,5 +1,5 @@
 /*
- * sws_lwalk.hip — fused H+V scaler for WIDE banks (5..16 taps on either axis: every down-scaling ratio to 1/4,
+ * sws_lwalk.hip — fused H+V scaler for WIDE banks (5..32 taps on either axis: every down-scaling ratio to about 1/8,
  * and up-scaling with long kernels), planar and NV12/NV21 in and out.
  *
  * Same arithmetic as sws_scale.hip / sws_colwalk.hip (hScale8To15_c, libswscale/swscale.c:128-142; yuv2planeX_8_c /
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void k_sws_lwalk(FFHipLwArgs A)
  */
 int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH, int pair)
 {
-    if ((ht != 2 && ht != 4) || (vt != 4 && vt != 8) || hn <= 0 || vn <= 0 || srcW < 4 * ht || srcW < 8 ||
+    if ((ht != 2 && ht != 4 && ht != 8) || (vt != 4 && vt != 8 && vt != 16) || hn <= 0 || vn <= 0 || srcW < 4 * ht || srcW < 8 ||
         srcH < 2 * vt)
         return 0;
     const int block = pair ? 128 : 256; /* output columns of one wave */
@@ -361,24 +361,43 @@ int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_
     for (int y = 0; y < vn; y++)
         if (vpos[y] < 0 || vpos[y] + 2 * vt > srcH || (y && vpos[y] < vpos[y - 1]))
             return 0;
-    const int nl = ht == 2 ? 3 : 5;
+    const int nl = ht == 2 ? 3 : ht == 4 ? 5 : 9;
     return span <= (pair ? (nl + 1) / 2 : nl) * 256 ? nl : 0;
+}
+
+static void lw_plan(FFHipLwJob *j, int want)
+{
+    j->ncb = cdiv(j->dstW, j->pair ? 128 : 256);
+    const int n = cdiv(j->dstH, want);
+    j->strip_rows = cdiv(j->dstH, n);
+    j->nstrips = cdiv(j->dstH, j->strip_rows);
 }
 
 void ffhip_lw_plan_job(FFHipLwJob *j)
 {
-    j->ncb = cdiv(j->dstW, j->pair ? 128 : 256);
     const char *es = FFHIP_KNOB("FFHIP_LW_STRIP"); /* measured variant: shorter strips (more, lighter waves; more halo rows) */
-    const int want = es && atoi(es) > 0 && atoi(es) < 64 ? atoi(es) : 64;
-    const int n = cdiv(j->dstH, want);
-    j->strip_rows = cdiv(j->dstH, n);
-    j->nstrips = cdiv(j->dstH, j->strip_rows);
+    lw_plan(j, es && atoi(es) > 0 && atoi(es) < 64 ? atoi(es) : 64);
 }
 
 int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
 {
     if (A.nframes <= 0)
         return 0;
+    /* a wave is one dependent chain down its strip: a launch of fewer waves than the chip has SIMDs (a thumbnail, a network input, a
+     * lone frame) runs at the speed of one chain — strips of 32, 16 rows then, until there is a wave per SIMD (round 5; a strip
+     * re-filters 2 VT - 1 source rows, which is why the default stays 64) */
+    {
+        const char *es = FFHIP_KNOB("FFHIP_LW_STRIP");
+        for (int want = 64; !(es && atoi(es) > 0); want >>= 1) {
+            long long w = 0;
+            for (int i = 0; i < A.njobs; i++) {
+                lw_plan(&A.job[i], want);
+                w += (long long)A.job[i].ncb * A.job[i].nstrips;
+            }
+            if (w * A.nframes >= 1024 || want <= 16)
+                break;
+        }
+    }
     int u = 0;
     for (int i = 0; i < A.njobs; i++) {
         A.job[i].unit_begin = u;
@@ -390,7 +409,7 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
         ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
         return FFHIP_EINVAL;
     }
-    const int nl = A.ht == 2 ? 3 : 5;
+    const int nl = A.ht == 2 ? 3 : A.ht == 4 ? 5 : 9;
     const size_t lds = (size_t)4 * 2 * (nl * 64 + 8) + (size_t)2 * A.vt * 64 * 16;
     const dim3 grid((unsigned)waves), block(64);
     /* measured (nv12 4K -> 1080p / 720p / 540p): reading the windows one row ahead is 1-2 % SLOWER than reading them in
@@ -409,15 +428,32 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
         if (ahead) hipLaunchKernelGGL((k_sws_lwalk<H, V, N, true>), grid, block, lds, stream, A);            \
         else       hipLaunchKernelGGL((k_sws_lwalk<H, V, N, false>), grid, block, lds, stream, A);           \
     } while (0)
+    /* round 5: banks of up to 32 taps on either axis (ratios down to about 1/8: a 1080p frame into a 224 x 224 network input has 36 and
+     * 20 taps... 32 x 32 covers 1080p -> 240p) — the default form only */
+#define LW_LAUNCH1(H, V, N)                                                                                  \
+    do {                                                                                                     \
+        static FFHipPerDeviceOnce attr_done;                                                                 \
+        if (attr_done.enter()) {                                                                             \
+            (void)hipFuncSetAttribute((const void *)k_sws_lwalk<H, V, N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            attr_done.leave(true);                                                                           \
+        }                                                                                                    \
+        hipLaunchKernelGGL((k_sws_lwalk<H, V, N, false>), grid, block, lds, stream, A);                      \
+    } while (0)
     if (A.ht == 2 && A.vt == 4) LW_LAUNCH(2, 4, 3);
     else if (A.ht == 2 && A.vt == 8) LW_LAUNCH(2, 8, 3);
     else if (A.ht == 4 && A.vt == 4) LW_LAUNCH(4, 4, 5);
     else if (A.ht == 4 && A.vt == 8) LW_LAUNCH(4, 8, 5);
+    else if (A.ht == 2 && A.vt == 16) LW_LAUNCH1(2, 16, 3);
+    else if (A.ht == 4 && A.vt == 16) LW_LAUNCH1(4, 16, 5);
+    else if (A.ht == 8 && A.vt == 4) LW_LAUNCH1(8, 4, 9);
+    else if (A.ht == 8 && A.vt == 8) LW_LAUNCH1(8, 8, 9);
+    else if (A.ht == 8 && A.vt == 16) LW_LAUNCH1(8, 16, 9);
     else {
         ffhip_set_error("ffhip_sws: no wide-bank kernel for %d x %d taps", 4 * A.ht, 2 * A.vt);
         return FFHIP_EINVAL;
     }
 #undef LW_LAUNCH
+#undef LW_LAUNCH1
     LAUNCH_CHECK();
     return 0;
 }

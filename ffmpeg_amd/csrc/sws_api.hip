@@ -251,15 +251,16 @@ static bool build_fast_view(FFHipSwsContext *c, const int limits[4], bool packed
  * Wide view of the banks for sws_lwalk.hip: all four padded to a common 4*ht horizontal / 2*vt vertical taps, windows
  * shifted back inside the plane where the padding would leave it (the real taps then sit at the end of the window).
  */
-static bool build_wide_view(FFHipSwsContext *c, const int limits[4])
+static bool build_wide_view(FFHipSwsContext *c, const int limits[4], int min_ht = 0)
 {
-    int ht = 0, vt = 0;
+    int ht = min_ht, vt = 0;
     for (int i = 0; i < 4; i++) {
         const int fs = c->d[i].size;
-        if (fs > 16)
+        if (fs > 32)
             return false;
-        if (i < 2) ht = fs > 8 ? 4 : (ht > 2 ? ht : 2);
-        else       vt = fs > 8 ? 8 : (vt > 4 ? vt : 4);
+        const int cls = fs > 16 ? 4 : fs > 8 ? 2 : 1; /* 8, 16 or 32 taps */
+        if (i < 2) ht = 2 * cls > ht ? 2 * cls : ht;
+        else       vt = 4 * cls > vt ? 4 * cls : vt;
     }
     for (int i = 0; i < 4; i++) {
         const int P = i < 2 ? 4 * ht : 2 * vt, fs = c->d[i].size, n = c->d[i].n;
@@ -282,6 +283,10 @@ static bool build_wide_view(FFHipSwsContext *c, const int limits[4])
         off[i][0] = tot; tot += (c->wf[i].size() * 2 + 15) & ~(size_t)15;
         off[i][1] = tot; tot += (c->wp[i].size() * 4 + 15) & ~(size_t)15;
     }
+    if (c->dev_wtables) { /* a second try with wider padding */
+        (void)hipFree(c->dev_wtables);
+        c->dev_wtables = nullptr;
+    }
     if (hipMalloc(&c->dev_wtables, tot) != hipSuccess)
         return false;
     uint8_t *b = static_cast<uint8_t *>(c->dev_wtables);
@@ -297,6 +302,29 @@ static bool build_wide_view(FFHipSwsContext *c, const int limits[4])
     c->lw_ht = ht;
     c->lw_vt = vt;
     return true;
+}
+
+/* the wide view + the walker's own checks (ffhip_lw_bank_ok, no int16 wrap of a horizontal sum).  A wave's row buffer grows with the tap
+ * class (3, 5, 9 x 256 bytes for 8, 16, 32 taps): a bank of few taps at a steep ratio (bilinear at 1/7) gets the next class's padding
+ * when its 256 columns span more source than its own class holds. */
+static bool wide_setup(FFHipSwsContext *c, const int limits[4], bool chroma_pair)
+{
+    for (int min_ht = 0; min_ht <= 8; min_ht = min_ht ? 2 * min_ht : 4) {
+        if (!build_wide_view(c, limits, min_ht))
+            return false;
+        bool ok = true;
+        for (int k = 0; k < 2 && ok; k++)
+            ok = ffhip_lw_bank_ok(c->wp[k].data(), c->lw_ht, c->d[k].n, limits[k], c->wp[2 + k].data(), c->lw_vt, c->d[2 + k].n,
+                                  limits[2 + k], k == 1 && chroma_pair) != 0 &&
+                 ffhip_cw_bank_nowrap(c->wf[k].data(), 4 * c->lw_ht, c->d[k].n);
+        if (ok)
+            return true;
+        if (c->lw_ht >= 8)
+            break;
+        if (min_ht < c->lw_ht)
+            min_ht = c->lw_ht; /* (the next class up from the one the taps asked for) */
+    }
+    return false;
 }
 
 /* exact 2x: the 4-tap views (c->nf / c->np) as virtual banks on the regular windows of the edge-replicated rows, on the device;
@@ -703,12 +731,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
          * (the reference then runs yuv2rgb_X, seed 1 << 18: vscale.c:126-170) goes in TWO stages: the wide-bank walker on these very banks
          * into the target's own geometry (luma as unclipped int16, a chroma line per output line), then the tables' closed form
          * (sws_y16rgb.hip) — against the LDS-tiled k_scale_rgb at 0.05 of HBM */
-        if (!r && !c->cw_rgb && !a.full && !a.has_alpha && !(t->dstW & 1) && c->d[2].size >= 3 && build_wide_view(c, limits)) {
-            bool ok = true;
-            for (int k = 0; k < 2 && ok; k++)
-                ok = ffhip_lw_bank_ok(c->wp[k].data(), c->lw_ht, c->d[k].n, limits[k], c->wp[2 + k].data(), c->lw_vt, c->d[2 + k].n,
-                                      limits[2 + k], k == 1 && fmt_nv(t->srcFormat)) != 0 &&
-                     ffhip_cw_bank_nowrap(c->wf[k].data(), 4 * c->lw_ht, c->d[k].n);
+        if (!r && !c->cw_rgb && !a.full && !a.has_alpha && !(t->dstW & 1) && c->d[2].size >= 3) {
+            bool ok = wide_setup(c, limits, fmt_nv(t->srcFormat));
             if (fmt_nv(t->srcFormat) && (a.chrSrcW & 3))
                 ok = false;
             c->lw_ok = ok;
@@ -791,13 +815,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
          * too (parity tests of that kernel on up-scaling cases) */
         {
             const char *ew = FFHIP_KNOB("FFHIP_SWS_WIDE");
-            if ((!c->cw_ok || (ew && ew[0] == '1')) && build_wide_view(c, limits)) {
-                const int hts[2] = { c->lw_ht, c->lw_ht };
-                bool ok = true;
-                for (int k = 0; k < 2 && ok; k++)
-                    ok = ffhip_lw_bank_ok(c->wp[k].data(), hts[k], c->d[k].n, limits[k], c->wp[2 + k].data(), c->lw_vt, c->d[2 + k].n,
-                                          limits[2 + k], k == 1 && (fmt_nv(t->srcFormat) || fmt_nv(t->dstFormat))) != 0 &&
-                         ffhip_cw_bank_nowrap(c->wf[k].data(), 4 * c->lw_ht, c->d[k].n);
+            if (!c->cw_ok || (ew && ew[0] == '1')) {
+                bool ok = wide_setup(c, limits, fmt_nv(t->srcFormat) || fmt_nv(t->dstFormat));
                 if (fmt_nv(t->srcFormat) && (ch.srcW & 3))
                     ok = false;
                 c->lw_ok = ok;

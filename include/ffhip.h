@@ -266,7 +266,7 @@ void             ffhip_sws_freeContext(FFHipSwsContext *c);
 /** 1 when the context's banks run on the register-resident column-walking kernel (4-tap x 4-tap banks
  *  whose 4-column groups read one 8-byte source span; sws_colwalk.hip), 0 when they take the general
  *  LDS-tiled kernel; bit 1 set when the matrix-core variant (k_sws_mfma) is available too; bit 2 set when the
- *  banks (5..16 taps: down-scaling, long kernels) run on the LDS-backed wide-bank walker (sws_lwalk.hip); bit 3 set when
+ *  banks (5..32 taps: down-scaling, long kernels) run on the LDS-backed wide-bank walker (sws_lwalk.hip); bit 3 set when
  *  the conversion is an exact 2x up-scale served by the static-schedule kernel (sws_up2.hip); bit 4: an exact 2:1 down-scale
  *  (sws_down2.hip); bit 5: the 16-bit column walker (sws_walk16.hip); bit 6: exact 2x of 4:2:0 (yuv420p, NV12, NV21) into packed RGB, the
  *  static-schedule kernel with the yuv2rgb_X writer fused (sws_up2rgb.hip).

@@ -521,6 +521,9 @@ RGB2_CASES = [
     ("nv21", 384, 216, "bgr24", 174, 100, ffi.SWS_BICUBIC),
     ("yuv420p", 1080, 480, "argb", 540, 240, ffi.SWS_BICUBIC),         # 2:1 with 540 = 8 * 67 + 4 columns: the luma on k_sws_down2
     ("nv12", 1920, 1080, "rgb24", 854, 480, ffi.SWS_BICUBIC),
+    # 17..32-tap banks: a thumbnail, a network input
+    ("nv12", 768, 432, "rgb24", 128, 72, ffi.SWS_BICUBIC),
+    ("yuv420p", 1920, 1080, "bgr24", 320, 180, ffi.SWS_BICUBIC),
 ]
 
 
@@ -596,6 +599,13 @@ WIDE_CASES = [
     ("yuv420p", 384, 216, "nv21", 166, 90, ffi.SWS_BICUBIC),
     ("yuv444p", 384, 216, "yuv444p", 173, 97, ffi.SWS_BICUBIC),       # odd in both directions
     ("nv12", 1920, 1080, "nv12", 854, 480, ffi.SWS_BICUBIC),
+    # banks of 17..32 taps (round 5): ratios down to about 1/8
+    ("nv12", 768, 432, "nv12", 128, 72, ffi.SWS_BICUBIC),             # 6:1: 24 x 24 taps
+    ("yuv420p", 640, 360, "yuv420p", 96, 54, ffi.SWS_BICUBIC),        # 6.67:1: 27 taps, planar
+    ("nv12", 768, 216, "yuv420p", 128, 108, ffi.SWS_BICUBIC),         # 6:1 across, 2:1 down: 32 x 8 taps
+    ("yuv420p", 192, 432, "nv12", 96, 72, ffi.SWS_BICUBIC),           # 2:1 across, 6:1 down: 8 x 32 taps
+    ("nv12", 1920, 1080, "nv12", 426, 240, ffi.SWS_BICUBIC),          # 4.5:1, a ragged width
+    ("yuv420p", 1920, 1080, "yuv420p", 256, 144, ffi.SWS_BILINEAR),   # 7.5:1 bilinear: 16 taps
 ]
 
 
