@@ -174,11 +174,10 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
             for (int i = 0; i < NC; i++) {
                 uint32_t q[HT];
                 const uint32_t so = soff[i];
-                const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + so);
-                q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
-                if (HT == 8) {
-                    const w16_u4 w = *reinterpret_cast<const w16_u4d *>(p + so + 16);
-                    q[4 % HT] = w.x; q[5 % HT] = w.y; q[6 % HT] = w.z; q[7 % HT] = w.w;
+#pragma unroll
+                for (int k = 0; k < HT / 4; k++) { /* HT (u, v) dwords: 16 bytes at a time */
+                    const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + so + 16 * k);
+                    q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w;
                 }
 #pragma unroll
                 for (int m = 0; m < HP; m++) {
@@ -203,8 +202,11 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                     const w16_u2 v = *reinterpret_cast<const w16_u2d *>(p + so);
                     q[0] = v.x; q[1] = v.y;
                 } else {
-                    const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + so);
-                    q[0] = v.x; q[1] = v.y; q[2 % (HP + 1)] = v.z; q[3 % (HP + 1)] = v.w;
+#pragma unroll
+                    for (int k = 0; k < HP / 4; k++) { /* HP dwords: 16 bytes at a time (8 taps: one load, 16 taps: two) */
+                        const w16_u4 v = *reinterpret_cast<const w16_u4d *>(p + so + 16 * k);
+                        q[(4 * k) % (HP + 1)] = v.x; q[(4 * k + 1) % (HP + 1)] = v.y; q[(4 * k + 2) % (HP + 1)] = v.z; q[(4 * k + 3) % (HP + 1)] = v.w;
+                    }
                 }
                 q[HP] = 0;
                 if (sodd[i])
@@ -250,8 +252,9 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
             }
         int acc[4];
         w16_dots_first(acc, sp[0], sp[1], cfc[0], cfc[1]);
-        if (HP == 4)
-            w16_dots_more(acc, sp[2 % HP], sp[3 % HP], cfc[2 % HP], cfc[3 % HP]);
+#pragma unroll
+        for (int m = 2; m < HP; m += 2)
+            w16_dots_more(acc, sp[m % HP], sp[(m + 1) % HP], cfc[m % HP], cfc[(m + 1) % HP]);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int h = acc[c] >> hsh;
@@ -318,8 +321,9 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                                 pp[m][c] = ring[((k - (VT - 2 - 2 * m)) % R + R) % R][c / NC][c % NC];
                         int t[4];
                         w16_vdots<true>(t, pp[0], pp[1], vc[0], vc[1], kround);
-                        if (VP == 4)
-                            w16_vdots<false>(t, pp[2 % VP], pp[3 % VP], vc[2 % VP], vc[3 % VP], 0);
+#pragma unroll
+                        for (int m = 2; m < VP; m += 2)
+                            w16_vdots<false>(t, pp[m % VP], pp[(m + 1) % VP], vc[m % VP], vc[(m + 1) % VP], 0);
                         if (d8) { /* uniform */
                             /* seed dither << 12, >> 19, clip to 8 bits (yuv2planeX_8_c, output.c:468-486): four bytes per lane */
                             const uint2 drow = *reinterpret_cast<const uint2 *>(w16_dither[yy & 7]);
@@ -507,8 +511,19 @@ int ffhip_launch_walk16(FFHipW16Args &A, hipStream_t stream)
         hipLaunchKernelGGL((k_sws_walk16<8, 4>), grid, block, 0, stream, A);
     else if (A.ht == 4 && A.vt == 8)
         hipLaunchKernelGGL((k_sws_walk16<4, 8>), grid, block, 0, stream, A);
-    else
+    else if (A.ht == 8 && A.vt == 8)
         hipLaunchKernelGGL((k_sws_walk16<8, 8>), grid, block, 0, stream, A);
+    /* round 5: banks of 9..16 taps (ratios down to 1/4: a 4K HDR frame into 720p) */
+    else if (A.ht == 16 && A.vt == 16)
+        hipLaunchKernelGGL((k_sws_walk16<16, 16>), grid, block, 0, stream, A);
+    else if (A.ht == 16 && A.vt == 8)
+        hipLaunchKernelGGL((k_sws_walk16<16, 8>), grid, block, 0, stream, A);
+    else if (A.ht == 8 && A.vt == 16)
+        hipLaunchKernelGGL((k_sws_walk16<8, 16>), grid, block, 0, stream, A);
+    else {
+        ffhip_set_error("ffhip_sws: no 16-bit column walker for %d x %d taps", A.ht, A.vt);
+        return FFHIP_EINVAL;
+    }
     LAUNCH_CHECK();
     return 0;
 }

@@ -662,9 +662,12 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
              * the 16-bit horizontal pass, yuv2planeX_8_c / yuv2nv12cX_c with the ordered dither on the way out) */
             const bool to8 = dd == 8 && (t->dstFormat == FFHIP_PIX_FMT_NV12 || !fmt_nv(t->dstFormat));
             if (!c->up2_ok && !c->dn2_ok && sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14) || to8) && sl != 2 && dl != 2 && t->src_range == t->dst_range &&
-                c->d[0].size <= 8 && c->d[1].size <= 8 && c->d[2].size <= 8 && c->d[3].size <= 8 &&
+                c->d[0].size <= 16 && c->d[1].size <= 16 && c->d[2].size <= 16 && c->d[3].size <= 16 &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size)) {
-                const int ht = c->d[0].size <= 4 && c->d[1].size <= 4 ? 4 : 8, vt = c->d[2].size <= 4 && c->d[3].size <= 4 ? 4 : 8;
+                const int hmax = c->d[0].size > c->d[1].size ? c->d[0].size : c->d[1].size, vmax = c->d[2].size > c->d[3].size ? c->d[2].size : c->d[3].size;
+                int ht = hmax <= 4 ? 4 : hmax <= 8 ? 8 : 16, vt = vmax <= 4 ? 4 : vmax <= 8 ? 8 : 16;
+                if (ht == 16 && vt == 4) vt = 8;   /* (the instantiated pairs: 4x4 .. 8x8, 16x8, 8x16, 16x16) */
+                if (vt == 16 && ht == 4) ht = 8;
                 const int T[4] = { ht, ht, vt, vt };
                 std::vector<int16_t> pf[4];
                 std::vector<int32_t> pp[4];

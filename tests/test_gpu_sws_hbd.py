@@ -168,6 +168,27 @@ def test_deeper_source_into_8_bits(case, variant, monkeypatch):
     _run(case)
 
 
+# banks of 9..16 taps on the 16-bit column walker (round 5): ratios between 1/2 and 1/4 — a 4K HDR frame into 720p
+WIDE16_CASES = [
+    ("p010le", 576, 324, "p010le", 192, 108, ffi.SWS_BICUBIC),         # 3:1: 12 x 12 taps
+    ("yuv420p10le", 640, 360, "yuv420p10le", 160, 90, ffi.SWS_BICUBIC),  # 4:1: 16 x 16 taps
+    ("p010le", 576, 324, "nv12", 192, 108, ffi.SWS_BICUBIC),           # ... into 8 bits
+    ("yuv420p12le", 640, 180, "yuv420p12le", 160, 90, ffi.SWS_BICUBIC),  # 16 taps across, 8 down
+    ("yuv422p10le", 320, 360, "yuv422p10le", 160, 90, ffi.SWS_BICUBIC),  # 8 across, 16 down
+    ("p010le", 1152, 648, "yuv420p10le", 400, 226, ffi.SWS_BICUBIC),   # ragged, interleaved in, planar out
+]
+
+
+@pytest.mark.parametrize("case", WIDE16_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_wide_banks_above_8_bits(case):
+    from ffmpeg_amd import swscale as S
+    sname, sw, sh, dname, dw, dh, flags = case
+    ctx = S.SwsContext(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags)
+    assert ctx.walk16_path, "case does not reach the 16-bit column walker"
+    ctx.close()
+    _run(case)
+
+
 def test_p010_4k_to_nv12_1080p():
     _run(("p010le", 3840, 2160, "nv12", 1920, 1080, ffi.SWS_BICUBIC), nframes=2)
 
