@@ -63,6 +63,8 @@ struct FFHipSwsContext {
      * the intermediate planes, grown on demand — a context is used by one caller at a time, as an SwsContext is */
     void *rgb2_tmp = nullptr;
     size_t rgb2_tmp_sz = 0;
+    hipEvent_t rgb2_done = nullptr; /* the last launch that read the intermediate: the next use waits for it, whatever its stream */
+    std::mutex rgb2_mu;             /* (its own lock: the host face reaches this path holding `mu`) */
     /* exact 2x of 4:2:0 (yuv420p, NV12, NV21) into packed RGB (sws_up2rgb.hip): virtual banks of all four axes, the vertical ones merged row by row */
     int u2r_ok = 0;
     void *u2r_dev = nullptr;
@@ -970,6 +972,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->u2r_dev);
     if (c->rgb2_tmp)
         (void)hipFree(c->rgb2_tmp);
+    if (c->rgb2_done)
+        (void)hipEventDestroy(c->rgb2_done);
     if (c->eqr_dev)
         (void)hipFree(c->eqr_dev);
     if (c->w16_dev)
@@ -1341,7 +1345,9 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             E.vt = static_cast<const uint32_t *>(c->eqr_dev);
             E.vround = c->cw_vround; E.lay = a.bgr; E.k = c->k;
             const char *es = FFHIP_KNOB("FFHIP_EQRGB_STEPS"), *ef = FFHIP_KNOB("FFHIP_EQRGB_FPP");
-            ffhip_eqrgb_plan(&E, es && atoi(es) > 0 ? atoi(es) : 30, ef ? atoi(ef) : E.lay < 2 ? 0 : 1);
+            /* (frames that share a wave address their planes by 32-bit lane offsets from the pack's first frame: up to three frame pitches) */
+            const bool far = (E.sfp[0] | E.sfp[1] | E.sfp[2] | E.dfp) >= ((size_t)1 << 30);
+            ffhip_eqrgb_plan(&E, es && atoi(es) > 0 ? atoi(es) : 30, ef ? atoi(ef) : E.lay < 2 && !far ? 0 : 1);
             return ffhip_launch_eqrgb(E, stream);
         }
         const char *eu2 = FFHIP_KNOB("FFHIP_SWS_UP2RGB"); /* measure build: 0 keeps the column walker, v<n> a measured variant */
@@ -1362,7 +1368,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             /* measured (profiles/r05_up2rgb_f.txt): 24-bit pixels — the kernel is bound by its instruction stream: frames share the ragged
              * last lane block (no idle lanes), strips of 24 luma rows; 32-bit pixels — closer to the write path: one frame per pack
              * (two frames' rows written side by side cost 8 %, more when the frame pitch aliases), strips of 36 */
-            ffhip_up2rgb_plan(&U, es && atoi(es) > 0 ? atoi(es) : U.lay < 2 ? 24 : 36, ef ? atoi(ef) : U.lay < 2 ? 0 : 1);
+            const bool far = (U.sfp[0] | U.sfp[1] | U.sfp[2] | U.dfp) >= ((size_t)1 << 30); /* (32-bit lane offsets span up to three frame pitches) */
+            ffhip_up2rgb_plan(&U, es && atoi(es) > 0 ? atoi(es) : U.lay < 2 ? 24 : 36, ef ? atoi(ef) : U.lay < 2 && !far ? 0 : 1);
             return ffhip_launch_up2rgb(U, eu2 && eu2[0] == 'v' ? atoi(eu2 + 1) : 0, stream);
         }
         if (c->cw_rgb && !(ev && ev[0] == '0') && !(al & 3)) {
@@ -1385,6 +1392,12 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             /* two stages (see the context's creation): planes of the target's geometry, pitches and frames 256-byte aligned */
             const size_t ypitch = ((size_t)2 * a.dstW + 255) & ~(size_t)255, cpitch = ((size_t)(a.dstW / 2) + 255) & ~(size_t)255;
             const size_t yfp = ypitch * (size_t)a.dstH, cfp = cpitch * (size_t)a.dstH, need = (yfp + 2 * cfp) * (size_t)nframes;
+            /* the intermediate is the context's: calls are serialised here, and a call on another stream waits for the last reader */
+            std::lock_guard<std::mutex> lk(c->rgb2_mu);
+            if (!c->rgb2_done)
+                HIP_TRY(hipEventCreateWithFlags(&c->rgb2_done, hipEventDisableTiming));
+            else
+                HIP_TRY(hipStreamWaitEvent(stream, c->rgb2_done, 0));
             if (need > c->rgb2_tmp_sz) {
                 if (c->rgb2_tmp)
                     HIP_TRY(hipFree(c->rgb2_tmp)); /* (waits for the launches that still use it) */
@@ -1448,7 +1461,10 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             Y.ystride = (ptrdiff_t)ypitch; Y.cstride = (ptrdiff_t)cpitch; Y.dstride = a.dst_stride;
             Y.yfp = yfp; Y.cfp = cfp; Y.dfp = a.dst_fp;
             Y.w = a.dstW; Y.h = a.dstH; Y.nframes = nframes; Y.lay = a.bgr; Y.k = c->k;
-            return ffhip_launch_y16_rgb(Y, stream);
+            r2 = ffhip_launch_y16_rgb(Y, stream);
+            if (r2 >= 0)
+                HIP_TRY(hipEventRecord(c->rgb2_done, stream));
+            return r2;
         }
         return ffhip_launch_scale_rgb(a, stream);
     }
