@@ -91,6 +91,10 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
             cf[i][2 * k + 1] = v.y;
         }
     }
+    /* the 256-byte pieces of a source row this wave's windows reach (the row buffer is sized for the tap class's steepest ratio; at
+     * 1.5 : 1 a third of it would be fetched and staged for nothing: measured traffic 1.9x the algorithmic bytes) */
+    const int xlast = min(cb * 64 * CPL + 64 * CPL - 1, J.dstW - 1);
+    const int nlu = min(NLG, (__builtin_amdgcn_readfirstlane(J.hp[xlast]) + 4 * HT - segb + 255) >> 8);
     const bool act = X0 < J.dstW;
     const int nval = J.dstW - X0;          /* this lane's valid columns (per channel) when it holds the row's ragged end */
     const bool whole = nval >= CPL;
@@ -131,6 +135,8 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     auto load_next = [&](Row &o) {
 #pragma unroll
         for (int j = 0; j < NLG; j++) {
+            if (j >= nlu) /* uniform */
+                break;
             uint32_t off = goff[j];
             asm volatile("" : "+v"(off));
             if (sil) {
@@ -167,6 +173,8 @@ __device__ __forceinline__ void lw_unit(const FFHipLwJob &J, int f, int strip, i
     auto stage = [&](const Row &cur) {
 #pragma unroll
         for (int j = 0; j < NLG; j++) {
+            if (j >= nlu) /* uniform */
+                break;
             if (sil) {
                 raw[lane + 64 * j] = __builtin_amdgcn_perm(cur.q[1][j], cur.q[0][j], sel_u);
                 raw[RAWD + lane + 64 * j] = __builtin_amdgcn_perm(cur.q[1][j], cur.q[0][j], sel_v);
