@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64) void k_sws_lwalk(FFHipLwArgs A)
  */
 int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_t *vpos, int vt, int vn, int srcH, int pair)
 {
-    if ((ht != 2 && ht != 4 && ht != 8) || (vt != 4 && vt != 8 && vt != 16) || hn <= 0 || vn <= 0 || srcW < 4 * ht || srcW < 8 ||
+    if ((ht != 2 && ht != 4 && ht != 8 && ht != 16) || (vt != 4 && vt != 8 && vt != 16) || hn <= 0 || vn <= 0 || srcW < 4 * ht || srcW < 8 ||
         srcH < 2 * vt)
         return 0;
     const int block = pair ? 128 : 256; /* output columns of one wave */
@@ -369,7 +369,7 @@ int ffhip_lw_bank_ok(const int32_t *hpos, int ht, int hn, int srcW, const int32_
     for (int y = 0; y < vn; y++)
         if (vpos[y] < 0 || vpos[y] + 2 * vt > srcH || (y && vpos[y] < vpos[y - 1]))
             return 0;
-    const int nl = ht == 2 ? 3 : ht == 4 ? 5 : 9;
+    const int nl = ht == 2 ? 3 : ht == 4 ? 5 : ht == 8 ? 9 : 17;
     return span <= (pair ? (nl + 1) / 2 : nl) * 256 ? nl : 0;
 }
 
@@ -417,7 +417,7 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
         ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
         return FFHIP_EINVAL;
     }
-    const int nl = A.ht == 2 ? 3 : A.ht == 4 ? 5 : 9;
+    const int nl = A.ht == 2 ? 3 : A.ht == 4 ? 5 : A.ht == 8 ? 9 : 17;
     const size_t lds = (size_t)4 * 2 * (nl * 64 + 8) + (size_t)2 * A.vt * 64 * 16;
     const dim3 grid((unsigned)waves), block(64);
     /* measured (nv12 4K -> 1080p / 720p / 540p): reading the windows one row ahead is 1-2 % SLOWER than reading them in
@@ -456,6 +456,9 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
     else if (A.ht == 8 && A.vt == 4) LW_LAUNCH1(8, 4, 9);
     else if (A.ht == 8 && A.vt == 8) LW_LAUNCH1(8, 8, 9);
     else if (A.ht == 8 && A.vt == 16) LW_LAUNCH1(8, 16, 9);
+    /* 64 taps across (a 1080p frame into a 224-wide network input: 36), up to 32 down */
+    else if (A.ht == 16 && A.vt == 8) LW_LAUNCH1(16, 8, 17);
+    else if (A.ht == 16 && A.vt == 16) LW_LAUNCH1(16, 16, 17);
     else {
         ffhip_set_error("ffhip_sws: no wide-bank kernel for %d x %d taps", 4 * A.ht, 2 * A.vt);
         return FFHIP_EINVAL;

@@ -258,12 +258,14 @@ static bool build_wide_view(FFHipSwsContext *c, const int limits[4], int min_ht 
     int ht = min_ht, vt = 0;
     for (int i = 0; i < 4; i++) {
         const int fs = c->d[i].size;
-        if (fs > 32)
+        if (fs > (i < 2 ? 64 : 32))
             return false;
-        const int cls = fs > 16 ? 4 : fs > 8 ? 2 : 1; /* 8, 16 or 32 taps */
+        const int cls = fs > 32 ? 8 : fs > 16 ? 4 : fs > 8 ? 2 : 1; /* 8, 16, 32 or (across only) 64 taps */
         if (i < 2) ht = 2 * cls > ht ? 2 * cls : ht;
         else       vt = 4 * cls > vt ? 4 * cls : vt;
     }
+    if (ht == 16 && vt == 4)
+        vt = 8; /* (the instantiated pairs at 64 taps across: 16 and 32 taps down) */
     for (int i = 0; i < 4; i++) {
         const int P = i < 2 ? 4 * ht : 2 * vt, fs = c->d[i].size, n = c->d[i].n;
         if (limits[i] < P)
@@ -311,7 +313,7 @@ static bool build_wide_view(FFHipSwsContext *c, const int limits[4], int min_ht 
  * when its 256 columns span more source than its own class holds. */
 static bool wide_setup(FFHipSwsContext *c, const int limits[4], bool chroma_pair)
 {
-    for (int min_ht = 0; min_ht <= 8; min_ht = min_ht ? 2 * min_ht : 4) {
+    for (int min_ht = 0; min_ht <= 16; min_ht = min_ht ? 2 * min_ht : 4) {
         if (!build_wide_view(c, limits, min_ht))
             return false;
         bool ok = true;
@@ -321,7 +323,7 @@ static bool wide_setup(FFHipSwsContext *c, const int limits[4], bool chroma_pair
                  ffhip_cw_bank_nowrap(c->wf[k].data(), 4 * c->lw_ht, c->d[k].n);
         if (ok)
             return true;
-        if (c->lw_ht >= 8)
+        if (c->lw_ht >= 16)
             break;
         if (min_ht < c->lw_ht)
             min_ht = c->lw_ht; /* (the next class up from the one the taps asked for) */

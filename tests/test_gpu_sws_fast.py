@@ -524,6 +524,7 @@ RGB2_CASES = [
     # 17..32-tap banks: a thumbnail, a network input
     ("nv12", 768, 432, "rgb24", 128, 72, ffi.SWS_BICUBIC),
     ("yuv420p", 1920, 1080, "bgr24", 320, 180, ffi.SWS_BICUBIC),
+    ("nv12", 1920, 1080, "rgb24", 224, 224, ffi.SWS_BICUBIC),          # 36 taps across
 ]
 
 
@@ -606,6 +607,9 @@ WIDE_CASES = [
     ("yuv420p", 192, 432, "nv12", 96, 72, ffi.SWS_BICUBIC),           # 2:1 across, 6:1 down: 8 x 32 taps
     ("nv12", 1920, 1080, "nv12", 426, 240, ffi.SWS_BICUBIC),          # 4.5:1, a ragged width
     ("yuv420p", 1920, 1080, "yuv420p", 256, 144, ffi.SWS_BILINEAR),   # 7.5:1 bilinear: 16 taps
+    # 33..64 taps across (round 5): a 1080p frame into a 224-wide network input
+    ("nv12", 1920, 1080, "nv12", 224, 224, ffi.SWS_BICUBIC),          # 8.6:1 across (36 taps), 4.8:1 down (20)
+    ("yuv420p", 1536, 216, "yuv420p", 128, 72, ffi.SWS_BICUBIC),      # 12:1 across (48 taps), 3:1 down
 ]
 
 
