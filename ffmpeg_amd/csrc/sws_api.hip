@@ -950,6 +950,23 @@ extern "C" int ffhip_sws_up2_virtual_bank_host(const int16_t *filter, const int3
     return 1;
 }
 
+extern "C" int ffhip_sws_upn_virtual_bank_host(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, int ratio, uint32_t *out)
+{
+    std::vector<uint32_t> v;
+    if (!filter || !pos || !out || !ffhip_upn_virtual_bank(filter, pos, n_dst, n_src, ratio, &v))
+        return 0;
+    memcpy(out, v.data(), v.size() * 4);
+    return 1;
+}
+
+extern "C" int ffhip_sws_up2rgb_hco_host(const uint32_t *hl, int n_hl, const uint32_t *hc, int n_hc, uint32_t out[32])
+{
+    if (!hl || !hc || !out || n_hl <= 0 || n_hc <= 0)
+        return 0;
+    const std::vector<uint32_t> a(hl, hl + (size_t)n_hl * 2), b(hc, hc + (size_t)n_hc * 2);
+    return ffhip_up2rgb_hco(a, b, out);
+}
+
 extern "C" int ffhip_sws_down2_virtual_bank_host(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, uint32_t *out)
 {
     std::vector<uint32_t> v;

@@ -287,6 +287,14 @@ int              ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t 
  *  int16 pairs.  Returns 1, or 0 when some tap of the bank does not sit on its regular window (the kernel is then not
  *  used).  Exposed for the CPU test-suite. */
 int              ffhip_sws_up2_virtual_bank_host(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, uint32_t *out);
+/** The same at `ratio` 2 or 4 (round 5; sws_up2rgb.hip: a packed-RGB target has a chroma line per output line, so 4:2:0 chroma goes up
+ *  four times vertically — output y on the regular window start ((y + 2) >> 2) - 2).  ratio 2 == the call above. */
+int              ffhip_sws_upn_virtual_bank_host(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, int ratio, uint32_t *out);
+/** The two horizontal virtual banks of the exact-2x RGB kernel (luma: n_hl columns, chroma: n_hc; 2 dwords each, as the calls above
+ *  write them) folded into the 32 dwords the kernel reads with scalar loads: [0..3] luma even c01, c23, odd c01, c23; [4..7] chroma;
+ *  [8..13] / [14..19] the luma bank's first / last three columns; [20..25] / [26..31] the chroma bank's.  Returns 1, or 0 when a bank
+ *  does not repeat with period 2 between its ends (the kernel is then not used). */
+int              ffhip_sws_up2rgb_hco_host(const uint32_t *hl, int n_hl, const uint32_t *hc, int n_hc, uint32_t out[32]);
 /** The same for the exact-2:1 kernel (sws_down2.hip): a bank of `fsize` <= 16 taps of a 2:1 down-scale (n_src == 2 n_dst) as
  *  eight coefficients per output on the regular window 2x - 3 .. 2x + 4 of the edge-replicated row.  out: n_dst x 4 dwords,
  *  (c0, c1) .. (c6, c7).  Returns 1, or 0 when some tap does not sit on its regular window. */
