@@ -65,6 +65,8 @@ struct FFHipSwsContext {
     size_t rgb2_tmp_sz = 0;
     hipEvent_t rgb2_done = nullptr; /* the last launch that read the intermediate: the next use waits for it, whatever its stream */
     std::mutex rgb2_mu;             /* (its own lock: the host face reaches this path holding `mu`) */
+    hipStream_t rgb2_aux = nullptr; /* exact 2:1: the luma job (k_sws_down2) runs beside the chroma jobs (k_sws_lwalk), forked and joined with events */
+    hipEvent_t rgb2_fork = nullptr, rgb2_join = nullptr;
     /* exact 2x of 4:2:0 (yuv420p, NV12, NV21) into packed RGB (sws_up2rgb.hip): virtual banks of all four axes, the vertical ones merged row by row */
     int u2r_ok = 0;
     void *u2r_dev = nullptr;
@@ -993,6 +995,14 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->rgb2_tmp);
     if (c->rgb2_done)
         (void)hipEventDestroy(c->rgb2_done);
+    if (c->rgb2_aux) {
+        (void)hipStreamSynchronize(c->rgb2_aux);
+        (void)hipStreamDestroy(c->rgb2_aux);
+    }
+    if (c->rgb2_fork)
+        (void)hipEventDestroy(c->rgb2_fork);
+    if (c->rgb2_join)
+        (void)hipEventDestroy(c->rgb2_join);
     if (c->eqr_dev)
         (void)hipFree(c->eqr_dev);
     if (c->w16_dev)
@@ -1451,7 +1461,22 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             }
             const char *ed = FFHIP_KNOB("FFHIP_SWS_DOWN2");
             int r2 = 0;
+            bool joined = false;
             if (c->dn2_luma && srcStride[0] > 0 && !(ed && ed[0] == '0')) {
+                /* the two first-stage kernels do not depend on each other and neither fills the chip for long (the chroma walker waits on
+                 * LDS round trips, VALU 29 % busy): side by side on two streams (FFHIP_SWS_RGB2=s: one after the other) */
+                hipStream_t ls = stream;
+                if (!(e2 && e2[0] == 's')) {
+                    if (!c->rgb2_aux) {
+                        HIP_TRY(hipStreamCreateWithFlags(&c->rgb2_aux, hipStreamNonBlocking));
+                        HIP_TRY(hipEventCreateWithFlags(&c->rgb2_fork, hipEventDisableTiming));
+                        HIP_TRY(hipEventCreateWithFlags(&c->rgb2_join, hipEventDisableTiming));
+                    }
+                    HIP_TRY(hipEventRecord(c->rgb2_fork, stream));
+                    HIP_TRY(hipStreamWaitEvent(c->rgb2_aux, c->rgb2_fork, 0));
+                    ls = c->rgb2_aux;
+                    joined = true;
+                }
                 FFHipDn2Args D;
                 memset(&D, 0, sizeof(D));
                 D.nframes = nframes;
@@ -1462,7 +1487,9 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 j.hfv = c->dn2_h[0]; j.vfv = c->dn2_v[0];
                 j.y16 = 1;
                 ffhip_down2_plan_job(&j, 32);
-                r2 = ffhip_launch_down2(D, stream);
+                r2 = ffhip_launch_down2(D, ls);
+                if (joined)
+                    HIP_TRY(hipEventRecord(c->rgb2_join, ls));
             } else {
                 FFHipLwJob &jl = W.job[W.njobs++];
                 jl.src[0] = s0; jl.sstride[0] = srcStride[0]; jl.sfp[0] = srcFramePitch[0];
@@ -1472,6 +1499,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             }
             if (r2 >= 0)
                 r2 = ffhip_launch_lwalk(W, stream);
+            if (joined)
+                HIP_TRY(hipStreamWaitEvent(stream, c->rgb2_join, 0));
             if (r2 < 0)
                 return r2;
             FFHipY16RgbArgs Y;

@@ -548,6 +548,12 @@ def test_rgb_two_stage_switched_off_is_the_tiled_kernel(monkeypatch):
     _run("nv12", 384, 216, "rgb24", 192, 104, ffi.SWS_BICUBIC, env={"FFHIP_SWS_RGB2": "0"}, monkeypatch=monkeypatch, seed=5, need="any")
 
 
+def test_rgb_two_stage_exact_half_one_kernel_after_the_other(monkeypatch):
+    """(the product runs the luma kernel beside the chroma kernel on a second stream; FFHIP_SWS_RGB2=s queues them on one)"""
+    _run("nv12", 384, 216, "rgb24", 192, 108, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "1", "FFHIP_SWS_RGB2": "s"}, monkeypatch=monkeypatch, seed=7,
+         need="any")
+
+
 def test_rgb_two_stage_exact_half_with_the_luma_on_the_wide_walker(monkeypatch):
     _run("nv12", 384, 216, "rgb24", 192, 108, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "0"}, monkeypatch=monkeypatch, seed=6, need="any")
 
