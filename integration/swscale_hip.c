@@ -7,8 +7,8 @@
  * bit depth, not by pixel format (swscale.c:608-611: srcBpc 8 and dstBpc <= 14 -> hScale8To15_c; output.c:3261-3275: 8-bit targets
  * -> yuv2plane1_8_c / yuv2planeX_8_c, semi-planar ones also yuv2nv12cX_c), so the hook asks for the planar (resp. NV12) set and
  * takes the members whose C twin is the one in place.  tests/checkasm/sw_scale.c then runs against the hip arch unchanged.
- * The ops backend ("hip" in ff_sws_op_backends[]) is oracle/refbuild/ffref_shim_ops.c; the frame-level SwsFunc hook of
- * INTEGRATION.md §1 needs two new SwsInternal fields and is therefore prose only.
+ * The ops backend ("hip" in ff_sws_op_backends[]) is oracle/refbuild/ffref_shim_ops.c.  Round 5: the function also installs the
+ * frame-level SwsFunc of a SCALED context (ff_sws_hip_scaled_hook(), integration/swscale_unscaled_hip.c): this is where the banks are ready.
  */
 #include "libavutil/attributes.h"
 #include "libavutil/cpu.h"
@@ -19,6 +19,7 @@
 #include "hip_cpu.h"
 
 void ff_sws_init_scale_c(SwsInternal *c);
+void ff_sws_hip_scaled_hook(SwsInternal *c); /* integration/swscale_unscaled_hip.c: the frame-level SwsFunc of a scaled context */
 
 av_cold void ff_sws_init_scale(SwsInternal *c)
 {
@@ -33,6 +34,7 @@ av_cold void ff_sws_init_scale(SwsInternal *c)
     l.yuv2plane1 = c->yuv2plane1;
     l.yuv2planeX = c->yuv2planeX;
     l.yuv2nv12cX = (void *)c->yuv2nv12cX;
+    ff_sws_hip_scaled_hook(c);   /* the frame hook first: a context that gets it never runs the line members (checkasm calls them directly) */
     if (ff_sws_init_swscale_hip(&l, FFHIP_PIX_FMT_YUV420P, nv ? FFHIP_PIX_FMT_NV12 : FFHIP_PIX_FMT_YUV420P) < 0)
         return;
     if (c->srcBpc == 8 && c->dstBpc <= 14) {     /* one function serves luma and chroma, as hScale8To15_c does (swscale.c:608-611) */

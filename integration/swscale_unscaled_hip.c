@@ -37,7 +37,9 @@ void ff_get_unscaled_swscale_c(SwsInternal *c);
 
 typedef struct HipUnscaled {
     FFHipSwsContext *ctx;
-    SwsFunc          c_func;          /* the converter the reference chose: runs when libffhip refuses a call */
+    SwsFunc          c_func;          /* the converter the reference chose: runs when libffhip refuses a call (scaled contexts: ff_swscale) */
+    int              scaled;          /* a scaled context (ff_sws_hip_scaled_hook() below) ... */
+    int              graph;           /* ... made by the filter graph (not sws_init_context()): slices arrive in TARGET lines */
     int              cs[4], range, brightness, contrast, saturation; /* what ctx's coefficients were derived from */
     long             calls, fallbacks;
 } HipUnscaled;
@@ -149,6 +151,121 @@ static av_cold void ff_get_unscaled_swscale_hip(SwsInternal *c)
     c->hw_priv          = u;
     c->convert_unscaled = hip_convert_unscaled;
     c->dst_slice_align  = 2;            /* as the C converter asks (swscale_unscaled.c:2430) */
+}
+
+/*
+ * SCALED contexts (and the unscaled ones the reference has no special converter for: NV12 -> RGB goes through the scaler).
+ *
+ * scale_internal() calls c->convert_unscaled for ANY context that has one (libswscale/swscale.c:1163-1186) and ff_swscale() otherwise,
+ * and the filter graph's legacy pass does the same (graph.c:394-404, 497).  ff_sws_init_scale() is the last step of
+ * ff_sws_init_single_context() (utils.c:1797), when the four banks stand in c->{h,v}{Lum,Chr}Filter[Pos|Size]: the `hip` arch's
+ * ff_sws_init_scale() (integration/swscale_hip.c) ends with a call of the function below, which hands the context's OWN banks, range
+ * constants and colour details to libffhip (ffhip_sws_from_tables) and, when libffhip takes the conversion, installs a SwsFunc — so that
+ * sws_scale() / sws_scale_frame() on host frames run the fused kernels instead of ff_swscale()'s line loop.  Not installed for slice
+ * threading (threads != 1, or a slice context of a threaded parent: the reference then asks for TARGET slices of a scaled picture,
+ * swscale.c:1645-1679, graph.c:505-545), for cascaded / gamma contexts (they delegate), when hw_priv is taken, or for an error-diffusion
+ * dither.  libffhip collects source slices in order and scales when the frame is complete (ffhip_sws_scale); a call it refuses runs
+ * ff_swscale().
+ */
+static int hip_convert_scaled(SwsInternal *c, const uint8_t *const src[], const int srcStride[], int y, int h,
+                              uint8_t *const dst[], const int dstStride[])
+{
+    HipUnscaled *u = c->hw_priv;
+    int r = -1;
+    if (isAnyRGB(c->opts.dst_format) && !hip_colorspace_current(c, u)) {
+        FFHipSwsTables t;
+        memset(&t, 0, sizeof(t));
+        if (ffhip_sws_yuv2rgb_coeffs(&t, c->srcColorspaceTable, c->opts.src_range, c->brightness, c->contrast, c->saturation) < 0 ||
+            ffhip_sws_set_yuv2rgb(u->ctx, &t) < 0)
+            goto c_path;
+        hip_colorspace_note(c, u);
+    }
+    if (u->graph) {
+        /* run_legacy_unscaled() (graph.c:394-404): y, h are lines of the pass, i.e. of the TARGET, and the graph runs this pass in one
+         * slice (threads == 1 is a condition of the hook): the frame */
+        if (y != 0 || h != c->opts.dst_h)
+            goto c_path;
+        h = c->opts.src_h;
+    }
+    r = ffhip_sws_scale(u->ctx, src, srcStride, y, h, dst, dstStride);
+c_path:
+    __atomic_fetch_add(&u->calls, 1, __ATOMIC_RELAXED);
+    if (r >= 0)
+        return r;
+    __atomic_fetch_add(&u->fallbacks, 1, __ATOMIC_RELAXED);
+    return ff_swscale(c, src, srcStride, y, h, dst, dstStride, 0, c->opts.dst_h);
+}
+
+/* test instrumentation, as ff_sws_hip_unscaled_calls() */
+long ff_sws_hip_scaled_calls(const SwsInternal *c, long *fallbacks)
+{
+    const HipUnscaled *u = c->convert_unscaled == hip_convert_scaled ? c->hw_priv : NULL;
+    if (!u)
+        return -1;
+    if (fallbacks)
+        *fallbacks = u->fallbacks;
+    return u->calls;
+}
+
+static int hip_scaled_format(enum AVPixelFormat f, int target)
+{
+    switch (f) {
+    /* FFHIP_PIX_FMT_* == AV_PIX_FMT_* (include/ffhip.h) */
+    case AV_PIX_FMT_YUV420P: case AV_PIX_FMT_YUV422P: case AV_PIX_FMT_YUV444P: case AV_PIX_FMT_NV12: case AV_PIX_FMT_NV21:
+    case AV_PIX_FMT_YUV420P9LE: case AV_PIX_FMT_YUV420P10LE: case AV_PIX_FMT_YUV420P12LE: case AV_PIX_FMT_YUV420P14LE: case AV_PIX_FMT_YUV420P16LE:
+    case AV_PIX_FMT_YUV422P9LE: case AV_PIX_FMT_YUV422P10LE: case AV_PIX_FMT_YUV422P12LE: case AV_PIX_FMT_YUV422P14LE: case AV_PIX_FMT_YUV422P16LE:
+    case AV_PIX_FMT_YUV444P9LE: case AV_PIX_FMT_YUV444P10LE: case AV_PIX_FMT_YUV444P12LE: case AV_PIX_FMT_YUV444P14LE: case AV_PIX_FMT_YUV444P16LE:
+    case AV_PIX_FMT_P010LE: case AV_PIX_FMT_P012LE: case AV_PIX_FMT_P016LE:
+        return (int)f;
+    case AV_PIX_FMT_RGB24: case AV_PIX_FMT_BGR24: case AV_PIX_FMT_ARGB: case AV_PIX_FMT_RGBA: case AV_PIX_FMT_ABGR: case AV_PIX_FMT_BGRA:
+        return target ? (int)f : -1;
+    default:
+        return -1;
+    }
+}
+
+av_cold void ff_sws_hip_scaled_hook(SwsInternal *c)
+{
+    const enum AVPixelFormat src = c->opts.src_format, dst = c->opts.dst_format;
+    const int srcf = hip_scaled_format(src, 0), dstf = hip_scaled_format(dst, 1);
+    FFHipSwsTables t;
+    HipUnscaled *u;
+
+    if (!(av_get_cpu_flags() & AV_CPU_FLAG_HIP) || c->convert_unscaled || c->hw_priv || c->parent || c->nb_slice_ctx ||
+        c->opts.threads != 1 || c->cascaded_context[0] || c->opts.gamma_flag || srcf < 0 || dstf < 0 ||
+        (c->opts.dither != SWS_DITHER_AUTO && c->opts.dither != SWS_DITHER_BAYER) || c->srcXYZ || c->dstXYZ || c->src0Alpha || c->dst0Alpha)
+        return;
+    memset(&t, 0, sizeof(t));
+    t.srcW = c->opts.src_w; t.srcH = c->opts.src_h; t.srcFormat = srcf;
+    t.dstW = c->opts.dst_w; t.dstH = c->opts.dst_h; t.dstFormat = dstf;
+    t.flags = c->opts.flags;
+    t.hLum = (FFHipSwsFilter){ c->hLumFilter, c->hLumFilterPos, c->hLumFilterSize, c->opts.dst_w };
+    t.hChr = (FFHipSwsFilter){ c->hChrFilter, c->hChrFilterPos, c->hChrFilterSize, c->chrDstW };
+    t.vLum = (FFHipSwsFilter){ c->vLumFilter, c->vLumFilterPos, c->vLumFilterSize, c->opts.dst_h };
+    t.vChr = (FFHipSwsFilter){ c->vChrFilter, c->vChrFilterPos, c->vChrFilterSize, c->chrDstH };
+    if (!t.hLum.filter || !t.hChr.filter || !t.vLum.filter || !t.vChr.filter)
+        return;
+    /* range conversion between YUV formats: the constants ff_sws_init_range_convert() computed (swscale.c:568-660) */
+    t.src_range = c->opts.src_range; t.dst_range = c->opts.dst_range;
+    t.lumConvertRange_coeff  = c->lumConvertRange_coeff;  t.chrConvertRange_coeff  = c->chrConvertRange_coeff;
+    t.lumConvertRange_offset = c->lumConvertRange_offset; t.chrConvertRange_offset = c->chrConvertRange_offset;
+    /* (the coefficient fields are part of every table set — ffhip_sws_from_tables() checks them — and only RGB targets read them) */
+    if (ffhip_sws_yuv2rgb_coeffs(&t, c->srcColorspaceTable, c->opts.src_range, c->brightness, c->contrast, c->saturation) < 0)
+        return;
+    t.full_chr_h_int = isAnyRGB(dst) && (c->opts.flags & SWS_FULL_CHR_H_INT);
+    u = av_refstruct_alloc_ext(sizeof(*u), 0, NULL, hip_unscaled_free);
+    if (!u)
+        return;
+    u->ctx = ffhip_sws_from_tables(&t);
+    if (!u->ctx) {                      /* no device, or a conversion libffhip does not take: ff_swscale() stays */
+        av_refstruct_unref(&u);
+        return;
+    }
+    hip_colorspace_note(c, u);
+    u->scaled = 1;
+    u->graph  = !c->is_legacy_init;     /* sws_init_context() sets it before it gets here (utils.c:1892); the graph's contexts are not made by it */
+    c->hw_priv          = u;
+    c->convert_unscaled = hip_convert_scaled;
 }
 
 av_cold void ff_get_unscaled_swscale(SwsInternal *c)

@@ -28,3 +28,25 @@ def test_sws_scale_on_host_frames_goes_through_the_hip_swsfunc():
     assert m and int(m.group(1)) >= 50, tail
     assert sum("left to C" in l for l in lines) == 2, tail
     assert not [l for l in lines if l.startswith("FAIL")], tail
+
+
+EXE_SCALED = os.path.join(ROOT, "oracle", "_ref", "sws_scaled_hip_test")
+
+
+@pytest.mark.skipif(not os.path.exists(EXE_SCALED), reason="oracle/_ref/sws_scaled_hip_test not built (needs /root/reference at build time)")
+def test_sws_scale_of_scaled_contexts_goes_through_the_hip_swsfunc():
+    """round 5: SCALED contexts (and NV12 -> RGB at the source's size, for which the reference has no special converter) get a frame-level
+    SwsFunc at the end of ff_sws_init_scale() (ff_sws_hip_scaled_hook(), integration/swscale_unscaled_hip.c) with the context's own banks:
+    the reference's sws_scale() on host frames then runs libffhip's fused kernels — NV12 1080p -> rgb24, 1080p -> 4K (BASELINE configs[1]'s
+    conversion), 4K -> 1080p into RGB, ragged widths, thumbnails, 10-bit sources, source slices, bottom-up pictures, colour details set
+    after the init — and the pictures are the C scaler's byte for byte"""
+    r = subprocess.run([EXE_SCALED], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, cwd="/tmp")
+    tail = "\n".join(r.stdout.splitlines()[-45:])
+    assert r.returncode == 0, tail
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("OK  ", "FAIL"))]
+    assert not [l for l in lines if l.startswith("FAIL")], tail
+    assert lines[0].startswith("OK  ") and "nv12 1920x1080 -> rgb24 1920x1080" in lines[0] and "hip SwsFunc == ff_swscale" in lines[0], lines[0]
+    assert any("nv12 1920x1080 -> nv12 3840x2160" in l and l.startswith("OK  ") for l in lines), tail
+    m = re.search(r"(\d+) cases, 0 failed", r.stdout)
+    assert m and int(m.group(1)) >= 25, tail
+    assert sum("left to C" in l for l in lines) == 2, tail
