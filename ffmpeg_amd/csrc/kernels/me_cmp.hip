@@ -705,8 +705,13 @@ int ffhip_launch_me_esa(const uint8_t *cur, const uint8_t *ref, int width, int h
             if (w4) ESA4(FFHIP_ME_SAD, 8, 0); else ESA(FFHIP_ME_SAD, 8);
         }
     } else {
-        /* shared column transforms when their LDS plane fits (R <= 24 at 16x16); FFHIP_ME_SATD_SHARE=0: per-candidate */
+        /* round 5: the 2-D transform as a dense int8 product on the matrix cores (me_satd.hip); FFHIP_ME_SATD_SHARE set: the VALU forms —
+         * shared column transforms when their LDS plane fits (R <= 24 at 16x16), FFHIP_ME_SATD_SHARE=0: per-candidate */
         const char *es = FFHIP_KNOB("FFHIP_ME_SATD_SHARE");
+        if (!es && ffhip_launch_me_esa_satd_mx(cur, ref, width, height, stride, frame_pitch, nframes, mb_size, R, mv_out, cost_out, stream)) {
+            LAUNCH_CHECK();
+            return 0;
+        }
         const size_t vsz = ((size_t)(mb_size / 8) * mb_size + (size_t)(2 * R + mb_size - 7) * (2 * R + mb_size)) * 16;
         const size_t lds_s = ((lds + 15) & ~(size_t)15) + vsz;
         if (lds_s <= 64 * 1024 && !(es && es[0] == '0')) {

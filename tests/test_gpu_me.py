@@ -89,7 +89,8 @@ def _shifted_pair(rng, w, h, stride, R, flat=False):
 
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("w,h,pad,mb,R", [(64, 48, 0, 16, 7), (176, 144, 16, 16, 7), (176, 144, 0, 8, 7), (96, 80, 3, 16, 16),
-                                          (40, 40, 0, 8, 3), (72, 56, 0, 16, 0)])
+                                          (40, 40, 0, 8, 3), (72, 56, 0, 16, 0), (128, 96, 0, 16, 24), (160, 128, 5, 16, 32),
+                                          (64, 64, 0, 8, 20), (52, 36, 1, 16, 5)])
 @pytest.mark.parametrize("share", ["default", "1", "0", "3"], ids=["product", "shared", "per-candidate", "column"])
 def test_esa_frames(kind, w, h, pad, mb, R, share, monkeypatch):
     from ffmpeg_amd import me

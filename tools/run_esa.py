@@ -7,7 +7,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-from ffmpeg_amd import me  # noqa: E402
+from ffmpeg_amd import _lib, me  # noqa: E402
+
+if any(k.startswith("FFHIP_ME_") for k in os.environ):   # a knob: the measure build (the product library reads no environment)
+    _lib.select("measure")
 
 kind = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 7
