@@ -23,10 +23,16 @@
  * times, copy s shifted by s bytes (dword j of copy s = bytes s + 4j .. s + 4j + 3 of the row): a candidate at column cx reads copy
  * cx & 3 at dword cx >> 2 — the staging is 16 loads per lane, the search saves 16 v_alignbyte per 16 candidates.
  *
- * MFMA results have no interlock against the VALU on this part and the compiler pads only what it emits itself, so the 16 MFMAs and
- * their 64 v_sad_u32 of a tile are ONE asm block with a fixed register quartet v[112:127] for the products: MFMA k + 3 is issued
- * before the sums of MFMA k, four v_sad_u32 (16 cycles) sit between two MFMAs (a 4-pass instruction) so that one wave keeps both pipes
- * busy.
+ * MFMA results have no interlock against the VALU on this part and the compiler pads only what it emits itself, so the MFMAs and
+ * their v_sad_u32 are asm blocks (half a tile each: 8 + 32) with a fixed register quartet v[112:127] for the products: MFMA k + 3 is
+ * issued before the sums of MFMA k, four v_sad_u32 sit between two MFMAs.
+ *
+ * What bounds it (tools/ubench/mfma_i8_rate.hip, profiles/r05_mfma_i8_rate.txt; four waves per SIMD): the MFMA alone issues every
+ * 7.5 ns per SIMD, four v_sad_u32 alone take 8.8 ns, the two interleaved 12.6 ns — an MFMA costs the VALU port about two ordinary
+ * issue slots on top of its own pipe time.  A macroblock at R = 7 is 960 v_sad_u32 + 253 MFMAs + ~400 other instructions:
+ * 960 x 2.2 + 253 x 3.8 + 400 x 2.1 ns = 3.9 us per SIMD, measured 4.5.  One instruction per coefficient is the floor of this form
+ * (int8 products cannot scale a second coefficient into the upper half of an accumulator, so v_sad_u16 on pairs is out of reach).
+ * FFHIP_ME_SATD_PART = m / s (measure build) runs the loop with only its MFMAs / only its sums: 0.97 / 0.81 ms against 1.15 whole.
  */
 #include "common.h"
 #include "me_kernels.h"
@@ -98,16 +104,75 @@ __device__ __forceinline__ void ms_wave_sync()
     MS_SN_2(SC) MS_MF(MS_D2, "a2", "b3", "c14") MS_SN_3(SC) MS_MF(MS_D3, "a3", "b3", "c15")                                                  \
     FD(SD) MS_SN_1(SD) MS_SN_2(SD) MS_SN_3(SD)
 
-template <bool CHAIN> /* CHAIN: one candidate per lane and tile — a single sum, returned in s3 */
+/* a whole tile with one sum per B operand: the 8 x 8 macroblock form, whose four B operands are four different tiles */
 __device__ __forceinline__ void ms_tile16(const ms_i4 (&A)[4], const ms_i4 &b0, const ms_i4 &b1, const ms_i4 &b2, const ms_i4 &b3,
                                           const ms_i4 (&c)[16], uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3)
 {
     const int kb = MS_BIAS;
-    if (CHAIN)
-        asm volatile(MS_BODY("s3", "s3", "s3", "s3", MS_SN_0, MS_SN_0, MS_SN_0) : [s3] "=&v"(s3) : MS_INS : MS_CLOB);
+    asm volatile(MS_BODY("s0", "s1", "s2", "s3", MS_S1_0, MS_S1_0, MS_S1_0)
+                 : [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3) : MS_INS : MS_CLOB);
+}
+
+/*
+ * Half a tile — 8 MFMAs (two B operands), 32 sums — so that the LDS reads of the other half are in flight meanwhile: the loop below
+ * asks for blocks 2, 3 before the first half and for the next tile's blocks 0, 1 before the second.  FIRST: the sums start here.
+ * FOUR sums, one per result register of a quartet: a v_sad_u32 that waits for the one before it issues every ~12 cycles
+ * (tools/ubench/mfma_i8_rate.hip: 5.1 ns a piece from one wave), four chains issue back to back.
+ */
+#define MS_Q1(r0, r1, r2, r3)                                                                                                              \
+    "v_sad_u32 %[s0], v" r0 ", %[k], 0\n\tv_sad_u32 %[s1], v" r1 ", %[k], 0\n\t"                                                            \
+    "v_sad_u32 %[s2], v" r2 ", %[k], 0\n\tv_sad_u32 %[s3], v" r3 ", %[k], 0\n\t"
+#define MS_QN(r0, r1, r2, r3)                                                                                                              \
+    "v_sad_u32 %[s0], v" r0 ", %[k], %[s0]\n\tv_sad_u32 %[s1], v" r1 ", %[k], %[s1]\n\t"                                                    \
+    "v_sad_u32 %[s2], v" r2 ", %[k], %[s2]\n\tv_sad_u32 %[s3], v" r3 ", %[k], %[s3]\n\t"
+#define MS_Q1_0 MS_Q1("112", "113", "114", "115")
+#define MS_QN_0 MS_QN("112", "113", "114", "115")
+#define MS_QN_1 MS_QN("116", "117", "118", "119")
+#define MS_QN_2 MS_QN("120", "121", "122", "123")
+#define MS_QN_3 MS_QN("124", "125", "126", "127")
+#define MS_HBODY(F0)                                                                                                                       \
+    "s_nop 1\n\t"                                                                                                                          \
+    MS_MF(MS_D0, "a0", "b0", "c0") MS_MF(MS_D1, "a1", "b0", "c1") MS_MF(MS_D2, "a2", "b0", "c2") MS_MF(MS_D3, "a3", "b0", "c3")              \
+    F0 MS_MF(MS_D0, "a0", "b1", "c4") MS_QN_1 MS_MF(MS_D1, "a1", "b1", "c5")                                                                 \
+    MS_QN_2 MS_MF(MS_D2, "a2", "b1", "c6") MS_QN_3 MS_MF(MS_D3, "a3", "b1", "c7")                                                            \
+    MS_QN_0 MS_QN_1 MS_QN_2 MS_QN_3
+#ifdef FFHIP_MEASURE /* FFHIP_ME_SATD_PART = m / s: the loop with only its MFMAs / only its sums (wrong results: where the time goes) */
+#define MS_HBODY_M                                                                                                                         \
+    "s_nop 1\n\t"                                                                                                                          \
+    MS_MF(MS_D0, "a0", "b0", "c0") MS_MF(MS_D1, "a1", "b0", "c1") MS_MF(MS_D2, "a2", "b0", "c2") MS_MF(MS_D3, "a3", "b0", "c3")              \
+    MS_MF(MS_D0, "a0", "b1", "c4") MS_MF(MS_D1, "a1", "b1", "c5") MS_MF(MS_D2, "a2", "b1", "c6") MS_MF(MS_D3, "a3", "b1", "c7")              \
+    "s_nop 7\n\ts_nop 7\n\tv_mov_b32 %[s0], v112\n\tv_mov_b32 %[s1], v113\n\tv_mov_b32 %[s2], v114\n\tv_mov_b32 %[s3], v115\n\t"
+#define MS_HBODY_S(F0) F0 MS_QN_1 MS_QN_2 MS_QN_3 MS_QN_0 MS_QN_1 MS_QN_2 MS_QN_3
+#endif
+template <bool FIRST, int PART = 0>
+__device__ __forceinline__ void ms_half(const ms_i4 (&A)[4], const ms_i4 &b0, const ms_i4 &b1, const ms_i4 *c, uint32_t (&sum)[4])
+{
+    const int kb = MS_BIAS;
+#define MS_HINS                                                                                                                           \
+    [a0] "v"(A[0]), [a1] "v"(A[1]), [a2] "v"(A[2]), [a3] "v"(A[3]), [b0] "v"(b0), [b1] "v"(b1), [c0] "v"(c[0]), [c1] "v"(c[1]),               \
+        [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [k] "s"(kb)
+#define MS_HOUT1 [s0] "=&v"(sum[0]), [s1] "=&v"(sum[1]), [s2] "=&v"(sum[2]), [s3] "=&v"(sum[3])
+#define MS_HOUTN [s0] "+v"(sum[0]), [s1] "+v"(sum[1]), [s2] "+v"(sum[2]), [s3] "+v"(sum[3])
+#ifdef FFHIP_MEASURE
+    if (PART == 1) {
+        asm volatile(MS_HBODY_M : MS_HOUT1 : MS_HINS : MS_CLOB);
+        return;
+    }
+    if (PART == 2) {
+        if (FIRST)
+            asm volatile(MS_HBODY_S(MS_Q1_0) : MS_HOUT1 : MS_HINS : MS_CLOB);
+        else
+            asm volatile(MS_HBODY_S(MS_QN_0) : MS_HOUTN : MS_HINS : MS_CLOB);
+        return;
+    }
+#endif
+    if (FIRST)
+        asm volatile(MS_HBODY(MS_Q1_0) : MS_HOUT1 : MS_HINS : MS_CLOB);
     else
-        asm volatile(MS_BODY("s0", "s1", "s2", "s3", MS_S1_0, MS_S1_0, MS_S1_0)
-                     : [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3) : MS_INS : MS_CLOB);
+        asm volatile(MS_HBODY(MS_QN_0) : MS_HOUTN : MS_HINS : MS_CLOB);
+#undef MS_HINS
+#undef MS_HOUT1
+#undef MS_HOUTN
 }
 
 /* the lane's B operand of one 8 x 8 block: rows 2g, 2g + 1 (the caller's address is row 2g), two dwords each */
@@ -136,7 +201,7 @@ __device__ __forceinline__ uint32_t ms_mul24(uint32_t a, uint32_t b) /* b: unifo
  * The offsets are a table because the four lane groups of a tile would otherwise each derive the same (row, column, copy) from the
  * candidate's index — 12 instructions per tile where the table costs them once per 64 candidates.
  */
-template <int MB, int WPB, int PD>
+template <int MB, int WPB, int PD, int PART = 0>
 __global__ __launch_bounds__(64 * WPB) void k_me_esa_satd_mx(const uint8_t *cur, const uint8_t *ref, int width, int height, ptrdiff_t stride,
                                                             size_t frame_pitch, int R, int16_t *mv_out, uint32_t *cost_out, int pitchd_rt,
                                                             int cstride, int lds_per_wave)
@@ -152,7 +217,7 @@ __global__ __launch_bounds__(64 * WPB) void k_me_esa_satd_mx(const uint8_t *cur,
         return;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;
-    const int ncmax = ((2 * R + 1) * (2 * R + 1) + 63) & ~63; /* whole tiles, whole groups of four tiles */
+    const int ncmax = (((2 * R + 1) * (2 * R + 1) + 63) & ~63) + 16; /* whole tiles, whole groups of four tiles, a tile of padding (the loop reads one ahead) */
     uint32_t *cblk = reinterpret_cast<uint32_t *>(lds_all + (size_t)wave * lds_per_wave);
     uint32_t *offs = cblk + MB * MB / 4;
     uint32_t *cost = offs + ncmax;
@@ -168,40 +233,59 @@ __global__ __launch_bounds__(64 * WPB) void k_me_esa_satd_mx(const uint8_t *cur,
 
     /* idx / ncx by a multiplication: ncand * ncx < 2^20 for every R the launcher admits */
     const uint32_t magic = (uint32_t)__builtin_amdgcn_readfirstlane((int)((1u << 20) / (uint32_t)ncx + 1u));
-    /* staging: everything with bit 7 flipped (sample - 128 as int8) */
+    /* staging: everything with bit 7 flipped (sample - 128 as int8).  The loads of a pass (16 per lane) are all asked for before the
+     * first is used — a wave alone pays one memory latency per pass, not four — and the tables are computed under them. */
     {
-        constexpr int DPR = MB / 4;
-        for (int i = lane; i < MB * DPR; i += 64) {
-            const int r = i / DPR, j = i % DPR;
-            uint32_t v;
-            __builtin_memcpy(&v, cf + (ptrdiff_t)(y_mb + r) * stride + x_mb + 4 * j, 4);
-            cblk[i] = v ^ 0x80808080u;
-        }
-        for (int i = lane; i < 16 * ntiles; i += 64) {
-            const int idc = min(i, ncand - 1);
-            const int cy = (int)(ms_mul24((uint32_t)idc, magic) >> 20), cx = idc - (int)ms_mul24((uint32_t)cy, (uint32_t)ncx);
-            offs[i] = 4u * (ms_mul24((uint32_t)cx & 3, (uint32_t)cstride) + ms_mul24((uint32_t)cy, (uint32_t)pitchd) + ((uint32_t)cx >> 2));
-            cost[i] = 0;
-        }
         const int dwr = (wcols + 3) >> 2;
         int lg = 2;
         while ((1 << lg) < dwr)
             lg++;
         /* a dword that would cross the picture's right edge is fetched where the row ends and shifted down: the bytes past the edge
          * belong to no candidate, they only must not be read */
-        const int xlast = width - 4;
-        for (int i = lane; i < (wrows << lg); i += 64) {
-            const int r = i >> lg, j = i & ((1 << lg) - 1);
-            if (j < dwr) {
-                const uint8_t *row = rf + (ptrdiff_t)(y0 + r) * stride;
-                uint32_t *o = win + __mul24(r, pitchd) + j;
+        const int xlast = width - 4, total = wrows << lg;
+        constexpr int DPR = MB / 4;
+        uint32_t cv = 0; /* the current block: MB * MB / 4 <= 64 dwords, one per lane */
+        const uint32_t ustride = (uint32_t)stride; /* offsets inside a frame fit 32 bits (the launcher checks) */
+        for (int base = 0; base < total; base += 256) {
+            uint32_t v[4][4];
+            int sh[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = min(base + 64 * u + lane, total - 1);
+                const int r = i >> lg, j = min(i & ((1 << lg) - 1), dwr - 1);
+                const uint32_t rowoff = ms_mul24((uint32_t)(y0 + r), ustride);
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int xb = x0 + 4 * j + s, xl = min(xb, xlast);
-                    uint32_t v;
-                    __builtin_memcpy(&v, row + xl, 4);
-                    o[s * cstride] = (v >> ((8 * (xb - xl)) & 31)) ^ 0x80808080u;
+                    __builtin_memcpy(&v[u][s], rf + (rowoff + (uint32_t)xl), 4);
+                    sh[u][s] = (8 * (xb - xl)) & 31;
                 }
+            }
+            if (base == 0) {
+                const int ic = min(lane, MB * DPR - 1);
+                __builtin_memcpy(&cv, cf + (ms_mul24((uint32_t)(y_mb + ic / DPR), ustride) + (uint32_t)(x_mb + 4 * (ic % DPR))), 4);
+                for (int i = lane; i < 16 * ntiles + 16; i += 64) {
+                    const int idc = min(i, ncand - 1);
+                    const int cy = (int)(ms_mul24((uint32_t)idc, magic) >> 20), cx = idc - (int)ms_mul24((uint32_t)cy, (uint32_t)ncx);
+                    offs[i] = 4u * (ms_mul24((uint32_t)cx & 3, (uint32_t)cstride) + ms_mul24((uint32_t)cy, (uint32_t)pitchd) + ((uint32_t)cx >> 2));
+                    cost[i] = 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + 64 * u + lane;
+                const int r = i >> lg, j = i & ((1 << lg) - 1);
+                if (i < total && j < dwr) {
+                    uint32_t *o = win + __mul24(r, pitchd) + j;
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+                        o[s * cstride] = (v[u][s] >> sh[u][s]) ^ 0x80808080u;
+                }
+            }
+            if (base == 0) {
+                asm volatile("" : "+v"(cv)); /* used here, not before the loads above are on their way */
+                if (lane < MB * DPR)
+                    cblk[lane] = cv ^ 0x80808080u;
             }
         }
     }
@@ -234,13 +318,21 @@ __global__ __launch_bounds__(64 * WPB) void k_me_esa_satd_mx(const uint8_t *cur,
 #pragma unroll
         for (int i = 0; i < 16; i++)
             c[i] = init[i >> 2][i & 3];
-        for (int t = 0; t < ntiles; t++, po += 16, pc += 16) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(wg + *po);
+        /* software pipeline over half tiles (the offsets table has one tile of padding behind the last) */
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(wg + *po);
+        ms_i4 b0 = ms_rows(p, pitchd), b1 = ms_rows(p + 2, pitchd);
+        for (int t = 0; t < ntiles; t++, pc += 16) {
+            po += 16;
+            const uint32_t on = *po;
             const uint32_t *q = p + 8 * pitchd;
-            const ms_i4 b0 = ms_rows(p, pitchd), b1 = ms_rows(p + 2, pitchd), b2 = ms_rows(q, pitchd), b3 = ms_rows(q + 2, pitchd);
-            uint32_t s0, s1, s2, s3;
-            ms_tile16<true>(A, b0, b1, b2, b3, c, s0, s1, s2, s3);
-            __hip_atomic_fetch_add(pc, s3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const ms_i4 b2 = ms_rows(q, pitchd), b3 = ms_rows(q + 2, pitchd);
+            uint32_t sum[4];
+            ms_half<true, PART>(A, b0, b1, c, sum);
+            p = reinterpret_cast<const uint32_t *>(wg + on);
+            b0 = ms_rows(p, pitchd);
+            b1 = ms_rows(p + 2, pitchd);
+            ms_half<false, PART>(A, b2, b3, c + 8, sum);
+            __hip_atomic_fetch_add(pc, sum[0] + sum[1] + sum[2] + sum[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     } else {
         ms_i4 c[16];
@@ -253,7 +345,7 @@ __global__ __launch_bounds__(64 * WPB) void k_me_esa_satd_mx(const uint8_t *cur,
             for (int k = 0; k < 4; k++)
                 b[k] = ms_rows(reinterpret_cast<const uint32_t *>(wg + po[16 * k]), pitchd);
             uint32_t s[4];
-            ms_tile16<false>(A, b[0], b[1], b[2], b[3], c, s[0], s[1], s[2], s[3]);
+            ms_tile16(A, b[0], b[1], b[2], b[3], c, s[0], s[1], s[2], s[3]);
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 __hip_atomic_fetch_add(pc + 16 * k, s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -304,9 +396,11 @@ int ffhip_launch_me_esa_satd_mx(const uint8_t *cur, const uint8_t *ref, int widt
     const int nc = (2 * R + 1) * (2 * R + 1);
     if ((long long)nc * (2 * R + 1) >= (1 << 20))
         return 0;
+    if (stride <= 0 || stride >= (1 << 24) || height >= (1 << 24) || (long long)height * stride >= (1LL << 32))
+        return 0; /* the kernel addresses a frame with 32-bit offsets */
     const int pitchd = (((2 * R + mb_size + 3) >> 2) + 1) | 1;
     const int cstride = (2 * R + mb_size) * pitchd + 1;
-    const size_t ncmax = ((size_t)nc + 63) & ~(size_t)63;
+    const size_t ncmax = (((size_t)nc + 63) & ~(size_t)63) + 16;
     const size_t lpw = (((size_t)mb_size * mb_size / 4 + 2 * ncmax + 4 * (size_t)cstride) * 4 + 15) & ~(size_t)15;
     if (lpw > 64 * 1024)
         return 0;
@@ -315,6 +409,18 @@ int ffhip_launch_me_esa_satd_mx(const uint8_t *cur, const uint8_t *ref, int widt
 #define MSL(M, W, P) hipLaunchKernelGGL((k_me_esa_satd_mx<M, W, P>), grid, block, lpw * W, stream, cur, ref, width, height, stride, frame_pitch, R, \
                                         mv_out, cost_out, pitchd, cstride, (int)lpw)
     if (mb_size == 16) {
+#ifdef FFHIP_MEASURE
+        const char *ep = FFHIP_KNOB("FFHIP_ME_SATD_PART");
+        if (ep && wpb == 4 && pitchd == 9) {
+            if (ep[0] == 'm')
+                hipLaunchKernelGGL((k_me_esa_satd_mx<16, 4, 9, 1>), grid, block, lpw * 4, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out,
+                                   cost_out, pitchd, cstride, (int)lpw);
+            else
+                hipLaunchKernelGGL((k_me_esa_satd_mx<16, 4, 9, 2>), grid, block, lpw * 4, stream, cur, ref, width, height, stride, frame_pitch, R, mv_out,
+                                   cost_out, pitchd, cstride, (int)lpw);
+            return 1;
+        }
+#endif
         if (wpb == 4 && pitchd == 9) MSL(16, 4, 9); /* R = 7, vf_mestimate's default search_param */
         else if (wpb == 4) MSL(16, 4, 0);
         else MSL(16, 1, 0);
