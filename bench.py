@@ -492,10 +492,13 @@ def extras(torch, dev):
                      "abs_diff/s": float("%.4g" % ad), "sad_issue_roof_frac": round(ad / 1.434e14, 4),
                      "hbm_frac": round(nf * 2 * w * h / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frame_pairs": nf, "ms": round(ms, 4)}
         if kind == me.SATD:
-            # SATD is priced on its own roof too: VALU issue.  3,466 VALU wave-instructions per macroblock (profiles/r04_esa_satd_pmc.txt; r03: 3,970)
-            # against 1024 SIMDs x 0.6 wave-instructions / ns (a wave64 instruction occupies its SIMD for 4 cycles at 2.4 GHz)
-            out[name]["valu_issue_roof_frac"] = round(nmb * 3466 / (ms * 1e-3) / (1024 * 0.6e9), 4)
-            out[name]["note"] = "a candidate costs ~640 lane-operations (Hadamard butterflies + absolute sum) against 64 for SAD; PMC: VALU busy 84.5 %"
+            # SATD is priced on its own roof too: VALU issue.  Round 5 (me_satd.hip: the 2-D Hadamard as a dense int8 product on the matrix
+            # cores, one v_sad_u32 per coefficient): 1,673 VALU wave-instructions per macroblock incl. 253 MFMAs (profiles/r05_esa_satd_mx_pmc.txt;
+            # r04's packed-int16 butterflies: 3,466) against 1024 SIMDs x 0.6 wave-instructions / ns (a wave64 instruction occupies its SIMD
+            # for 4 cycles at 2.4 GHz; the part runs this kernel at ~1.8 GHz)
+            out[name]["valu_issue_roof_frac"] = round(nmb * 1673 / (ms * 1e-3) / (1024 * 0.6e9), 4)
+            out[name]["note"] = ("a candidate is 4 blocks x 64 coefficients: 16 MFMAs + 64 v_sad_u32 per 16 candidates and lane; PMC: VALU busy 82.7 % "
+                                 "at 1.77 GHz, an MFMA costs the VALU port two issue slots (profiles/r05_mfma_i8_rate.txt)")
     del cur, ref
     # H.264 luma qpel: every 16x16 macroblock of 8 4K planes, mixed mcXY, put (BASELINE configs[2]): 2 B / sample
     for nf, key in ((8, "h264_qpel16_mixed"), (32, "h264_qpel16_mixed_32_planes")):
