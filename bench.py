@@ -499,7 +499,25 @@ def extras(torch, dev):
             out[name]["valu_issue_roof_frac"] = round(nmb * 1673 / (ms * 1e-3) / (1024 * 0.6e9), 4)
             out[name]["note"] = ("a candidate is 4 blocks x 64 coefficients: 16 MFMAs + 64 v_sad_u32 per 16 candidates and lane; PMC: VALU busy 82.7 % "
                                  "at 1.77 GHz, an MFMA costs the VALU port two issue slots (profiles/r05_mfma_i8_rate.txt)")
+    # the SATD search once more on 32 pairs: the launch-size dependence of a kernel whose clock the part lowers (profiles/r05_esa_satd_mx_pmc.txt)
     del cur, ref
+    nf = 32
+    cur = torch.randint(0, 256, (nf, h, w), dtype=torch.uint8, device=dev)
+    ref = torch.roll(cur, shifts=(3, -2), dims=(1, 2)).contiguous()
+    mv = torch.empty((nf, (w // 16) * (h // 16) * 2), dtype=torch.int16, device=dev)
+    cost = torch.empty((nf, (w // 16) * (h // 16)), dtype=torch.int32, device=dev)
+    me.esa_batch(cur, ref, w, h, w, w * h, nf, 16, 7, me.SATD, mv, cost)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(3):
+        me.esa_batch(cur, ref, w, h, w, w * h, nf, 16, 7, me.SATD, mv, cost)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    nmb = nf * (w // 16) * (h // 16)
+    out["me_esa_satd_r7_32_pairs"] = {"MB-searches/s": round(nmb / (ms * 1e-3), 1), "candidates/s": round(nmb * 225 / (ms * 1e-3), 1),
+                                      "valu_issue_roof_frac": round(nmb * 1673 / (ms * 1e-3) / (1024 * 0.6e9), 4), "frame_pairs": nf, "ms": round(ms, 4)}
+    del cur, ref, mv, cost
     # H.264 luma qpel: every 16x16 macroblock of 8 4K planes, mixed mcXY, put (BASELINE configs[2]): 2 B / sample
     for nf, key in ((8, "h264_qpel16_mixed"), (32, "h264_qpel16_mixed_32_planes")):
         w, h, P = 3840, 2160, 32
