@@ -421,6 +421,40 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
             T[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(h0[i], h1[i]));
     };
 
+    if (!HB && J.v1) { /* uniform */
+        /* no vertical filter: the chroma planes of a packed-RGB target's first stage when the source has a chroma line per output line
+         * (4K 4:2:0 -> 1080p RGB).  The vertical bank is then one tap of 4096 on the row itself and yuv2rgb_X's (U * 4096 + (1 << 18)) >> 19
+         * (libswscale/output.c:1814-1835) is (U + 64) >> 7 on the horizontal sum: four rows in flight, a dword of four samples out per row
+         * (pair: u0 v0 u1 v1) */
+        pr = a;
+        pf = sbase + (ptrdiff_t)min(a, srcH - 1) * sstride;
+        asm("" : "+s"(pf));
+        Raw rb4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            load_next(rb4[k]);
+        for (int y = a; y < b; y += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (y + k < b) { /* uniform */
+                    int h[4];
+                    hpass(rb4[k], h);
+                    load_next(rb4[k]);
+                    uint32_t out, off = doff;
+                    asm("v_ashr_pk_u8_i32 %0, %1, %2, 7\n\t"
+                        "v_ashr_pk_u8_i32 %0, %3, %4, 7 op_sel:[0,0,0,1]"
+                        : "=&v"(out) : "v"(h[0] + 64), "v"(h[1] + 64), "v"(h[2] + 64), "v"(h[3] + 64));
+                    asm volatile("" : "+v"(off));
+                    if (act)
+                        *(dn_g1)((dn_gp)dr + off) = out;
+                    dr += dstride;
+                    asm("" : "+s"(dr));
+                }
+            }
+        }
+        return;
+    }
+
     Raw buf[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)

@@ -176,6 +176,7 @@ struct FFHipDn2Job {
     int ncb, nstrips, steps_per_strip, unit_begin;
     int hb_sdepth, hb_ddepth, hb_smsb, hb_dmsb; /* samples above 8 bits (k_sws_down2<1>; 0: bytes), as in FFHipUp2Job; groups are 8 destination bytes */
     int y16;                            /* 8-bit plane job: the vertical sums >> 19 stored UNCLIPPED as int16 (8 bytes per group): see FFHipLwJob.y16 */
+    int v1;                             /* 8-bit job without a vertical filter: dstH = srcH rows, each clip_u8((horizontal sum + 64) >> 7) (sws_down2.hip) */
 };
 struct FFHipDn2Args {
     FFHipDn2Job job[3];
@@ -320,6 +321,7 @@ struct FFHipY16RgbArgs {
     ptrdiff_t ystride, cstride, dstride;
     size_t yfp, cfp, dfp;
     int w, h, nframes, lay;     /* w even (a chroma sample per pixel pair); lay: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
+    int uvi;                    /* u: ONE plane of (u, v) byte pairs (v unused) */
     FFHipYuv2RgbK k;
 };
 int ffhip_launch_y16_rgb(const FFHipY16RgbArgs &a, hipStream_t stream);

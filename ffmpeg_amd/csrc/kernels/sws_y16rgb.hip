@@ -52,7 +52,8 @@ __device__ __forceinline__ void yr_wave_sync_lds()
 }
 
 /* LAY: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra (alpha = 255).  A wave = 64 lanes x 8 pixels of one row. */
-template <int LAY>
+/* UVI: the chroma samples arrive as ONE plane of (u, v) byte pairs (the exact-2:1 first stage writes them that way, sws_down2.hip) */
+template <int LAY, bool UVI = false>
 __global__ __launch_bounds__(256) void k_y16_rgb(FFHipY16RgbArgs A)
 {
     constexpr int NW = LAY < 2 ? 6 : 8; /* dwords of a lane's 8 pixels */
@@ -86,7 +87,16 @@ __global__ __launch_bounds__(256) void k_y16_rgb(FFHipY16RgbArgs A)
     const uint8_t *pv = A.v + (size_t)f * A.cfp + (ptrdiff_t)row * A.cstride;
     uint8_t *pd = A.dst + (size_t)f * A.dfp + (ptrdiff_t)row * A.dstride;
     const yr_u4 yq = *(yr_gc4)((yr_gcp)py + 16u * (uint32_t)g); /* 8 int16 samples */
-    const uint32_t uq = *(yr_gc1)((yr_gcp)pu + 4u * (uint32_t)g), vq = *(yr_gc1)((yr_gcp)pv + 4u * (uint32_t)g);
+    uint32_t uq, vq;
+    if (UVI) {
+        typedef const yr_u2 __attribute__((address_space(1))) *yr_gc2;
+        const yr_u2 p = *(yr_gc2)((yr_gcp)pu + 8u * (uint32_t)g); /* u0 v0 u1 v1 | u2 v2 u3 v3 */
+        uq = __builtin_amdgcn_perm(p.y, p.x, 0x06040200u);
+        vq = __builtin_amdgcn_perm(p.y, p.x, 0x07050301u);
+    } else {
+        uq = *(yr_gc1)((yr_gcp)pu + 4u * (uint32_t)g);
+        vq = *(yr_gc1)((yr_gcp)pv + 4u * (uint32_t)g);
+    }
 
     const char *lutb = reinterpret_cast<const char *>(lut);
     const int cy = __builtin_amdgcn_readfirstlane(A.k.cy);
@@ -165,17 +175,18 @@ int ffhip_launch_y16_rgb(const FFHipY16RgbArgs &a, hipStream_t stream)
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define YR_L(L)                                                                                   \
+    case L:                                                                                       \
+        if (a.uvi) hipLaunchKernelGGL((k_y16_rgb<L, true>), grid, block, 0, stream, a);           \
+        else hipLaunchKernelGGL((k_y16_rgb<L, false>), grid, block, 0, stream, a);                \
+        break;
     switch (a.lay) {
-    case 0: hipLaunchKernelGGL((k_y16_rgb<0>), grid, block, 0, stream, a); break;
-    case 1: hipLaunchKernelGGL((k_y16_rgb<1>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((k_y16_rgb<2>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((k_y16_rgb<3>), grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((k_y16_rgb<4>), grid, block, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL((k_y16_rgb<5>), grid, block, 0, stream, a); break;
+    YR_L(0) YR_L(1) YR_L(2) YR_L(3) YR_L(4) YR_L(5)
     default:
         ffhip_set_error("ffhip_sws: packed layout %d is not one of the RGB writer's", a.lay);
         return FFHIP_EINVAL;
     }
+#undef YR_L
     LAUNCH_CHECK();
     return 0;
 }

@@ -73,7 +73,7 @@ struct FFHipSwsContext {
     const uint32_t *u2r_hco = nullptr, *u2r_vt = nullptr;
     /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
     int dn2_ok = 0;
-    int dn2_luma = 0; /* an RGB context's luma banks alone (its first stage's luma job on k_sws_down2, the chroma on the wide walker) */
+    int dn2_luma = 0; /* an RGB context's luma banks alone (its first stage's luma job on k_sws_down2, the chroma on the wide walker); 2: the chroma planes there as well (no vertical filter: FFHipDn2Job.v1) */
     void *dn2_dev = nullptr;
     const uint32_t *dn2_h[2] = { nullptr, nullptr }, *dn2_v[2] = { nullptr, nullptr };
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
@@ -467,21 +467,32 @@ static void dn2_build(FFHipSwsContext *c, const int nsrc[4])
  * source's subsampling, and rides the wide-bank walker): sets c->dn2_luma */
 static void dn2_build_luma(FFHipSwsContext *c, int srcW, int srcH)
 {
-    std::vector<uint32_t> vb[2];
+    std::vector<uint32_t> vb[3];
     if (!ffhip_down2_virtual_bank(c->f[0].data(), c->p[0].data(), c->d[0].size, c->d[0].n, srcW, &vb[0]) ||
         !ffhip_down2_virtual_bank(c->f[2].data(), c->p[2].data(), c->d[2].size, c->d[2].n, srcH, &vb[1]))
         return;
     vb[1].resize((size_t)(c->d[2].n + 8) * 4, 0); /* the row loop reads four rows of coefficients at a time */
-    const size_t o1 = (vb[0].size() * 4 + 255) & ~(size_t)255;
-    if (hipMalloc(&c->dn2_dev, o1 + vb[1].size() * 4) != hipSuccess)
+    /* the chroma planes on the same kernel when they need no vertical filter — a chroma line per output line (4K 4:2:0 -> 1080p RGB),
+     * every row of the vertical bank one tap of 4096 on the line itself — and go 2:1 across (FFHipDn2Job.v1) */
+    bool chr = c->d[3].n == c->chrSrcH && c->d[1].n >= 6;
+    for (int y = 0; y < c->d[3].n && chr; y++)
+        for (int i = 0; i < c->d[3].size && chr; i++) {
+            const int16_t t = c->f[3][(size_t)y * c->d[3].size + i];
+            chr = t == (c->p[3][y] + i == y ? 4096 : 0);
+        }
+    chr = chr && ffhip_down2_virtual_bank(c->f[1].data(), c->p[1].data(), c->d[1].size, c->d[1].n, c->chrSrcW, &vb[2]) != 0;
+    const size_t o1 = (vb[0].size() * 4 + 255) & ~(size_t)255, o2 = o1 + ((vb[1].size() * 4 + 255) & ~(size_t)255);
+    if (hipMalloc(&c->dn2_dev, o2 + (chr ? vb[2].size() * 4 : 0)) != hipSuccess)
         return;
     uint8_t *b = static_cast<uint8_t *>(c->dn2_dev);
     if (hipMemcpy(b, vb[0].data(), vb[0].size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(b + o1, vb[1].data(), vb[1].size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(b + o1, vb[1].data(), vb[1].size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        (chr && hipMemcpy(b + o2, vb[2].data(), vb[2].size() * 4, hipMemcpyHostToDevice) != hipSuccess))
         return;
     c->dn2_h[0] = reinterpret_cast<const uint32_t *>(b);
     c->dn2_v[0] = reinterpret_cast<const uint32_t *>(b + o1);
-    c->dn2_luma = 1;
+    c->dn2_h[1] = chr ? reinterpret_cast<const uint32_t *>(b + o2) : nullptr;
+    c->dn2_luma = 1 + (chr ? 1 : 0);
 }
 
 /* no horizontal sum of a 4-tap bank falls below -32768 after >> (depth - 1) on samples of `depth` bits: int16 saturation then
@@ -1436,6 +1447,49 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 c->rgb2_tmp_sz = need;
             }
             uint8_t *ty = static_cast<uint8_t *>(c->rgb2_tmp), *tu = ty + yfp * (size_t)nframes, *tv = tu + cfp * (size_t)nframes;
+            const char *ed = FFHIP_KNOB("FFHIP_SWS_DOWN2");
+            const int chrW = a.dstW / 2;
+            if (c->dn2_luma == 2 && srcStride[0] > 0 && !(ed && (ed[0] == '0' || ed[0] == 'l')) && chrW % (cstep == 2 ? 2 : 4) == 0 &&
+                chrW / (cstep == 2 ? 2 : 4) >= 3 && cus > 0 && cvs > 0) {
+                /* exact 2:1 with a chroma line per output line: luma and chroma in ONE launch of the static-schedule kernel (the chroma
+                 * jobs without a vertical filter), an interleaved pair leaves as a plane of (u, v) bytes (FFHIP_SWS_DOWN2=l: luma only,
+                 * the chroma on the wide walker as before round 5's last step) */
+                FFHipDn2Args D;
+                memset(&D, 0, sizeof(D));
+                D.nframes = nframes;
+                D.xcd = 1;
+                {
+                    FFHipDn2Job &j = D.job[D.njobs++];
+                    j.src = s0; j.dst = ty; j.sstride = srcStride[0]; j.dstride = (ptrdiff_t)ypitch; j.sfp = srcFramePitch[0]; j.dfp = yfp;
+                    j.srcH = a.srcH; j.dstH = a.dstH; j.ngroups = a.dstW / 4;
+                    j.hfv = c->dn2_h[0]; j.vfv = c->dn2_v[0];
+                    j.y16 = 1;
+                    ffhip_down2_plan_job(&j, 32);
+                }
+                for (int k = 0; k < (cstep == 2 ? 1 : 2); k++) {
+                    FFHipDn2Job &j = D.job[D.njobs++];
+                    j.pair = cstep == 2; j.swap = cstep == 2 && cv < cu; j.v1 = 1;
+                    j.src = cstep == 2 ? s1 : k ? cv : cu; j.sstride = k ? cvs : cus; j.sfp = k ? cvf : cuf;
+                    j.dst = k ? tv : tu; j.dstride = (ptrdiff_t)(cstep == 2 ? 2 * cpitch : cpitch); j.dfp = cstep == 2 ? 2 * cfp : cfp;
+                    j.srcH = a.chrSrcH; j.dstH = a.dstH; j.ngroups = chrW / (cstep == 2 ? 2 : 4);
+                    j.hfv = c->dn2_h[1]; j.vfv = c->dn2_v[0];
+                    ffhip_down2_plan_job(&j, 32);
+                }
+                int r1 = ffhip_launch_down2(D, stream);
+                if (r1 < 0)
+                    return r1;
+                FFHipY16RgbArgs Y;
+                memset(&Y, 0, sizeof(Y));
+                Y.y = ty; Y.u = tu; Y.v = tv; Y.dst = a.dst;
+                Y.uvi = cstep == 2;
+                Y.ystride = (ptrdiff_t)ypitch; Y.cstride = (ptrdiff_t)(cstep == 2 ? 2 * cpitch : cpitch); Y.dstride = a.dst_stride;
+                Y.yfp = yfp; Y.cfp = cstep == 2 ? 2 * cfp : cfp; Y.dfp = a.dst_fp;
+                Y.w = a.dstW; Y.h = a.dstH; Y.nframes = nframes; Y.lay = a.bgr; Y.k = c->k;
+                r1 = ffhip_launch_y16_rgb(Y, stream);
+                if (r1 >= 0)
+                    HIP_TRY(hipEventRecord(c->rgb2_done, stream));
+                return r1;
+            }
             FFHipLwArgs W;
             memset(&W, 0, sizeof(W));
             W.nframes = nframes; W.ht = c->lw_ht; W.vt = c->lw_vt;
@@ -1459,7 +1513,6 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 j.dst[0] = tu; j.dst[1] = tv; j.dstride[0] = j.dstride[1] = (ptrdiff_t)cpitch; j.dfp[0] = j.dfp[1] = cfp;
                 wbank(j, a.chrSrcW, a.chrSrcH, a.dstW / 2, 1);
             }
-            const char *ed = FFHIP_KNOB("FFHIP_SWS_DOWN2");
             int r2 = 0;
             bool joined = false;
             if (c->dn2_luma && srcStride[0] > 0 && !(ed && ed[0] == '0')) {

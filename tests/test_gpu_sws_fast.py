@@ -540,6 +540,20 @@ def test_rgb_two_stage(case, monkeypatch):
     _run(*case, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="any")
 
 
+@pytest.mark.parametrize("case", [c for c in RGB2_CASES if c[1] == 2 * c[4] and c[2] == 2 * c[5]], ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_rgb_two_stage_exact_half_chroma_on_the_wide_walker(case, monkeypatch):
+    """exact 2:1 from a 4:2:0 source: the product runs luma AND chroma (no vertical filter: FFHipDn2Job.v1) in one k_sws_down2 launch;
+    FFHIP_SWS_DOWN2=l keeps the chroma on the wide walker beside the luma kernel (the form before) — both must give the reference's bytes"""
+    _run(*case, env={"FFHIP_SWS_DOWN2": "l"}, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFF, need="any")
+
+
+@pytest.mark.parametrize("sf,df,dw,dh", [("nv12", "rgb24", 200, 108), ("nv21", "bgra", 1288, 48), ("yuv420p", "bgr24", 1288, 48), ("yuv420p", "argb", 200, 108),
+                                         ("nv12", "abgr", 12, 8), ("yuv420p", "rgba", 24, 8)])
+def test_rgb_two_stage_exact_half_one_launch(sf, df, dw, dh, monkeypatch):
+    """the single-launch first stage at widths with ragged last lane blocks, the smallest widths it takes, every layout"""
+    _run(sf, 2 * dw, 2 * dh, df, dw, dh, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, seed=dw + dh, need="any")
+
+
 def test_rgb_two_stage_full_size(monkeypatch):
     _run("nv12", 3840, 2160, "rgb24", 1920, 1080, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, n=2, seed=83, need="any")
 
