@@ -326,6 +326,17 @@ struct FFHipY16RgbArgs {
 };
 int ffhip_launch_y16_rgb(const FFHipY16RgbArgs &a, hipStream_t stream);
 
+/* planar 4:4:4 into packed RGB at the source's size: yuv2rgb_full_1_c + yuv2rgb_write_full on one-tap banks (sws_full444.hip) */
+struct FFHipFull444Args {
+    const uint8_t *src[3];      /* Y, U, V planes */
+    uint8_t *dst;
+    ptrdiff_t sstride[3], dstride;
+    size_t sfp[3], dfp;
+    int w, h, nframes, lay;     /* w >= 8; lay: 0 rgb24, 1 bgr24, 2 argb, 3 rgba, 4 abgr, 5 bgra */
+    int fk[6];                  /* FFHipSwsTables.yuv2rgb_full: y_coeff, y_offset, v2r, v2g, u2g, u2b */
+};
+int ffhip_launch_full444(const FFHipFull444Args &a, hipStream_t stream);
+
 /*
  * The column walker above 8 bits (sws_walk16.hip): banks padded to ht, vt in {4, 8} taps.  A job is one plane (nch 1) or the two
  * chroma channels together (nch 2: an interleaved (u, v) plane on the source and / or the target side; a planar side has the two

@@ -73,6 +73,7 @@ struct FFHipSwsContext {
     const uint32_t *u2r_hco = nullptr, *u2r_vt = nullptr;
     /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
     int dn2_ok = 0;
+    int f444_ok = 0;  /* planar 4:4:4 into packed RGB at the source's size: four one-tap banks, the full-chroma writer (sws_full444.hip) */
     int dn2_luma = 0; /* an RGB context's luma banks alone (its first stage's luma job on k_sws_down2, the chroma on the wide walker); 2: the chroma planes there as well (no vertical filter: FFHipDn2Job.v1) */
     void *dn2_dev = nullptr;
     const uint32_t *dn2_h[2] = { nullptr, nullptr }, *dn2_v[2] = { nullptr, nullptr };
@@ -734,6 +735,17 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             return nullptr;
         }
         r = ffhip_plan_scale_rgb(&a, c->p[0].data(), c->p[1].data(), c->p[2].data(), c->p[3].data());
+        /* planar 4:4:4 at the source's size (what sws_scale() runs for yuv444p -> rgb24: full chroma forced, no table converter): every
+         * bank one tap on the sample itself -> the streaming kernel of sws_full444.hip */
+        if (!r && a.full && !a.has_alpha && t->srcFormat == FFHIP_PIX_FMT_YUV444P && t->srcW == t->dstW && t->srcH == t->dstH && t->dstW >= 8) {
+            bool id = true;
+            for (int b = 0; b < 4 && id; b++) {
+                id = c->d[b].size == 1 && c->d[b].n == (b < 2 ? t->dstW : t->dstH);
+                for (int x = 0; x < c->d[b].n && id; x++)
+                    id = c->p[b][x] == x && c->f[b][x] == (b < 2 ? 16384 : 4096);
+            }
+            c->f444_ok = id;
+        }
         /* column walker with RGB output: 4-tap vertical banks (yuv2rgb_X), <= 4-tap horizontal banks, no int16 wrap */
         const int limits[4] = { a.srcW, a.chrSrcW, a.srcH, a.chrSrcH };
         if (!r && !a.full && !a.has_alpha && !(t->dstW & 7) && build_fast_view(c, limits, true))
@@ -936,7 +948,7 @@ extern "C" int ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -1371,6 +1383,18 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
         /* (the round-5 kernels walk their rows with running pointers and were written for top-down pictures: a negative stride keeps the
          * older kernels) */
         const bool topdown = srcStride[0] > 0 && cus > 0 && cvs > 0 && a.dst_stride > 0;
+        if (c->f444_ok && topdown && !(ev && ev[0] == '0') && !(al & 3)) {
+            FFHipFull444Args F;
+            memset(&F, 0, sizeof(F));
+            F.src[0] = s0; F.src[1] = cu; F.src[2] = cv;
+            F.sstride[0] = srcStride[0]; F.sstride[1] = cus; F.sstride[2] = cvs;
+            F.sfp[0] = srcFramePitch[0]; F.sfp[1] = cuf; F.sfp[2] = cvf;
+            F.dst = a.dst; F.dstride = a.dst_stride; F.dfp = a.dst_fp;
+            F.w = a.dstW; F.h = a.dstH; F.nframes = nframes; F.lay = a.bgr;
+            for (int i = 0; i < 6; i++)
+                F.fk[i] = a.fk[i];
+            return ffhip_launch_full444(F, stream);
+        }
         const char *eq = FFHIP_KNOB("FFHIP_SWS_EQRGB"); /* measure build: 0 keeps the column walker */
         if (c->eqr_ok && topdown && !(ev && ev[0] == '0') && !(eq && eq[0] == '0') && !(al & 3)) {
             /* the source's size: chroma lines interpolated by the exact-2x vertical bank, nothing else scaled (sws_eqrgb.hip) */

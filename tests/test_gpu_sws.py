@@ -246,6 +246,15 @@ SCALE_CASES = [
     ("yuv444p", 1920, 1080, "rgb24", 1280, 720, ffi.SWS_BICUBIC, 0),
     ("yuv420p", 960, 540, "rgb24", 1920, 1080, ffi.SWS_BICUBIC | 0x2000 | ffi.SWS_ACCURATE_RND, 0),
     ("yuv420p", 64, 36, "abgr", 64, 36, ffi.SWS_BICUBIC | 0x2000 | ffi.SWS_ACCURATE_RND, 0),
+    # planar 4:4:4 at the source's size (round 5): four one-tap banks + yuv2rgb_full_1 -> the streaming kernel of sws_full444.hip, every
+    # layout, ragged row ends (77 + 3 bytes of padding: dword-aligned lines), several lane blocks, the smallest width it takes
+    ("yuv444p", 200, 30, "rgb24", 200, 30, ffi.SWS_BICUBIC, 0),
+    ("yuv444p", 1032, 16, "bgr24", 1032, 16, ffi.SWS_BILINEAR, 0),
+    ("yuv444p", 77, 20, "argb", 77, 20, ffi.SWS_BICUBIC, 3),
+    ("yuv444p", 520, 12, "abgr", 520, 12, ffi.SWS_POINT, 0),
+    ("yuv444p", 8, 8, "bgra", 8, 8, ffi.SWS_BICUBIC, 0),
+    ("yuv444p", 1920, 1080, "rgba", 1920, 1080, ffi.SWS_BICUBIC, 0),
+    ("yuv444p", 1921, 4, "rgb24", 1921, 4, ffi.SWS_BICUBIC, 3),
 ]
 
 
@@ -293,6 +302,17 @@ def test_scaled(case):
                 assert np.array_equal(a, b)
             with pytest.raises(RuntimeError, match="out of order"):
                 ctx.scale([src[0][8:]] + [a[8 >> vs:] for a in src[1:]], hd, 8, 2)
+    ctx.close()
+
+
+def test_444_equal_size_takes_the_streaming_kernel():
+    from ffmpeg_amd import swscale as S
+    for df in ("rgb24", "bgra"):
+        ctx = S.SwsContext(200, 30, PIX["yuv444p"], 200, 30, PIX[df], ffi.SWS_BICUBIC)
+        assert ctx.paths & 256, ctx.paths
+        ctx.close()
+    ctx = S.SwsContext(200, 30, PIX["yuv444p"], 100, 30, PIX["rgb24"], ffi.SWS_BICUBIC)   # scaled: the general full-chroma kernel
+    assert not ctx.paths & 256
     ctx.close()
 
 
