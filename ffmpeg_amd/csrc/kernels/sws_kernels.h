@@ -337,6 +337,22 @@ struct FFHipFull444Args {
 };
 int ffhip_launch_full444(const FFHipFull444Args &a, hipStream_t stream);
 
+/* 4:2:0 between its planar and semi-planar layouts at the same size (sws_copy420.hip): a job fills one destination plane */
+struct FFHipCopy420Job {
+    const uint8_t *src[2];      /* WEAVE: the planes of the even / odd destination bytes; else src[0] */
+    uint8_t *dst;
+    ptrdiff_t sstride[2], dstride;
+    size_t sfp[2], dfp;
+    int kind, k;                /* 0 copy, 1 pick channel k of (a, b) pairs, 2 weave two planes into pairs, 3 swap the bytes of every pair */
+    int wbytes, rows;           /* the destination row in bytes (>= 16; weave / swap: even) */
+    int ncb, unit_begin;
+};
+struct FFHipCopy420Args {
+    FFHipCopy420Job job[3];
+    int njobs, units_per_frame, nframes;
+};
+int ffhip_launch_copy420(FFHipCopy420Args &A, hipStream_t stream);
+
 /*
  * The column walker above 8 bits (sws_walk16.hip): banks padded to ht, vt in {4, 8} taps.  A job is one plane (nch 1) or the two
  * chroma channels together (nch 2: an interleaved (u, v) plane on the source and / or the target side; a planar side has the two

@@ -391,9 +391,10 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
 {
     if (A.nframes <= 0)
         return 0;
-    /* a wave is one dependent chain down its strip: a launch of fewer waves than the chip has SIMDs (a thumbnail, a network input, a
-     * lone frame) runs at the speed of one chain — strips of 32, 16 rows then, until there is a wave per SIMD (round 5; a strip
-     * re-filters 2 VT - 1 source rows, which is why the default stays 64) */
+    /* a wave is one dependent chain down its strip: a launch of fewer waves than the chip holds (a thumbnail, a network input, a
+     * lone frame, 16 frames of 720p) runs at the speed of its chains — strips of 32, 16 rows then, until the launch has the waves the
+     * chip can keep resident (four per SIMD at this kernel's LDS; measured, 1080p -> 720p nv12, 16 frames = 1,440 waves at 64 rows:
+     * 0.062 ms, at 32 rows 0.047; a strip re-filters 2 VT - 1 source rows, which is why large launches stay at 64) */
     {
         const char *es = FFHIP_KNOB("FFHIP_LW_STRIP");
         for (int want = 64; !(es && atoi(es) > 0); want >>= 1) {
@@ -402,7 +403,7 @@ int ffhip_launch_lwalk(FFHipLwArgs &A, hipStream_t stream)
                 lw_plan(&A.job[i], want);
                 w += (long long)A.job[i].ncb * A.job[i].nstrips;
             }
-            if (w * A.nframes >= 1024 || want <= 16)
+            if (w * A.nframes >= 4096 || want <= 16)
                 break;
         }
     }

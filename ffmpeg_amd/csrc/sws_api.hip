@@ -73,6 +73,7 @@ struct FFHipSwsContext {
     const uint32_t *u2r_hco = nullptr, *u2r_vt = nullptr;
     /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
     int dn2_ok = 0;
+    int c420_ok = 0;  /* 4:2:0 between planar and semi-planar layouts at the same size, no range change: a copy (sws_copy420.hip) */
     int f444_ok = 0;  /* planar 4:4:4 into packed RGB at the source's size: four one-tap banks, the full-chroma writer (sws_full444.hip) */
     int dn2_luma = 0; /* an RGB context's luma banks alone (its first stage's luma job on k_sws_down2, the chroma on the wide walker); 2: the chroma planes there as well (no vertical filter: FFHipDn2Job.v1) */
     void *dn2_dev = nullptr;
@@ -827,6 +828,19 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             }
             return c;
         }
+        /* 4:2:0 planar <-> semi-planar at the same size: every bank one tap on the sample itself, the result is the source's bytes laid
+         * out differently (sws_copy420.hip) */
+        {
+            auto is420 = [](int f) { return f == FFHIP_PIX_FMT_YUV420P || f == FFHIP_PIX_FMT_NV12 || f == FFHIP_PIX_FMT_NV21; };
+            bool id = !r && is420(t->srcFormat) && is420(t->dstFormat) && t->srcW == t->dstW && t->srcH == t->dstH && t->dst_alpha_fill != 2 &&
+                      t->dstW >= 16 && c->d[1].n >= 16;
+            for (int b = 0; b < 4 && id; b++) {
+                id = c->d[b].size == 1;
+                for (int x = 0; x < c->d[b].n && id; x++)
+                    id = c->p[b][x] == x && c->f[b][x] == (b < 2 ? 16384 : 4096);
+            }
+            c->c420_ok = id;
+        }
         const int limits[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
         {
             const bool ok = build_fast_view(c, limits, false);
@@ -948,7 +962,7 @@ extern "C" int ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -1619,6 +1633,47 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
     /* fast path: 4x4-tap banks, dword-aligned planes.  FFHIP_SWS_FAST=0 forces the LDS-tiled kernel;
      * FFHIP_CW_LUMA_GROUPS / FFHIP_CW_PLAIN select measured variants. */
     const char *ev = FFHIP_KNOB("FFHIP_SWS_FAST");
+    if (c->c420_ok && !(ev && ev[0] == '0') && srcStride[0] > 0 && cus > 0 && cvs > 0 && dstStride[0] > 0 && dstStride[1] > 0 &&
+        (fmt_nv(t.dstFormat) || dstStride[2] > 0)) {
+        FFHipCopy420Args K;
+        memset(&K, 0, sizeof(K));
+        K.nframes = nframes;
+        const int cw = c->d[1].n, chh = c->d[3].n;
+        {
+            FFHipCopy420Job &j = K.job[K.njobs++];
+            j.src[0] = s0; j.sstride[0] = srcStride[0]; j.sfp[0] = srcFramePitch[0];
+            j.dst = (uint8_t *)dst[0]; j.dstride = dstStride[0]; j.dfp = dstFramePitch[0];
+            j.kind = 0; j.wbytes = t.dstW; j.rows = t.dstH;
+        }
+        if (fmt_nv(t.dstFormat)) {
+            FFHipCopy420Job &j = K.job[K.njobs++];
+            j.dst = (uint8_t *)dst[1]; j.dstride = dstStride[1]; j.dfp = dstFramePitch[1];
+            j.wbytes = 2 * cw; j.rows = chh;
+            const bool dsw = t.dstFormat == FFHIP_PIX_FMT_NV21;
+            if (cstep == 2) { /* pairs in, pairs out: as they are, or each pair turned round */
+                j.src[0] = s1; j.sstride[0] = cus; j.sfp[0] = cuf;
+                j.kind = dsw == (t.srcFormat == FFHIP_PIX_FMT_NV21) ? 0 : 3;
+            } else {
+                j.kind = 2;
+                j.src[0] = dsw ? cv : cu; j.sstride[0] = dsw ? cvs : cus; j.sfp[0] = dsw ? cvf : cuf;
+                j.src[1] = dsw ? cu : cv; j.sstride[1] = dsw ? cus : cvs; j.sfp[1] = dsw ? cuf : cvf;
+            }
+        } else {
+            for (int k = 0; k < 2; k++) {
+                FFHipCopy420Job &j = K.job[K.njobs++];
+                j.dst = (uint8_t *)dst[1 + k]; j.dstride = dstStride[1 + k]; j.dfp = dstFramePitch[1 + k];
+                j.wbytes = cw; j.rows = chh;
+                if (cstep == 2) {
+                    j.src[0] = s1; j.sstride[0] = cus; j.sfp[0] = cuf;
+                    j.kind = 1; j.k = (t.srcFormat == FFHIP_PIX_FMT_NV21) ? !k : k;
+                } else {
+                    j.src[0] = k ? cv : cu; j.sstride[0] = k ? cvs : cus; j.sfp[0] = k ? cvf : cuf;
+                    j.kind = 0;
+                }
+            }
+        }
+        return ffhip_launch_copy420(K, stream);
+    }
     if (c->cw_ok && !(ev && ev[0] == '0')) {
         uintptr_t al = 0;
         for (int i = 0; i < 2; i++) {

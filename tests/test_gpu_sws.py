@@ -255,6 +255,19 @@ SCALE_CASES = [
     ("yuv444p", 8, 8, "bgra", 8, 8, ffi.SWS_BICUBIC, 0),
     ("yuv444p", 1920, 1080, "rgba", 1920, 1080, ffi.SWS_BICUBIC, 0),
     ("yuv444p", 1921, 4, "rgb24", 1921, 4, ffi.SWS_BICUBIC, 3),
+    # 4:2:0 between its planar and semi-planar layouts at the same size (round 5): one-tap banks -> the layout kernel of sws_copy420.hip;
+    # rows whose last 16 bytes overlap their neighbours', lines that are not dword-aligned, several lane blocks, the smallest sizes it takes
+    ("nv12", 64, 36, "yuv420p", 64, 36, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 64, 36, "nv12", 64, 36, ffi.SWS_BICUBIC, 0),
+    ("nv21", 50, 22, "yuv420p", 50, 22, ffi.SWS_BILINEAR, 3),
+    ("yuv420p", 50, 22, "nv21", 50, 22, ffi.SWS_POINT, 1),
+    ("nv12", 38, 10, "nv21", 38, 10, ffi.SWS_BICUBIC, 0),
+    ("nv21", 32, 8, "nv21", 32, 8, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 34, 6, "yuv420p", 34, 6, ffi.SWS_BICUBIC, 5),
+    ("nv12", 2100, 24, "yuv420p", 2100, 24, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 2100, 24, "nv12", 2100, 24, ffi.SWS_BICUBIC, 2),
+    ("nv12", 1920, 1080, "yuv420p", 1920, 1080, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 1920, 1080, "nv21", 1920, 1080, ffi.SWS_BICUBIC, 0),
 ]
 
 
@@ -302,6 +315,20 @@ def test_scaled(case):
                 assert np.array_equal(a, b)
             with pytest.raises(RuntimeError, match="out of order"):
                 ctx.scale([src[0][8:]] + [a[8 >> vs:] for a in src[1:]], hd, 8, 2)
+    ctx.close()
+
+
+def test_420_layouts_take_the_layout_kernel():
+    from ffmpeg_amd import swscale as S
+    for sf, df in (("nv12", "yuv420p"), ("yuv420p", "nv12"), ("nv21", "nv12")):
+        ctx = S.SwsContext(64, 36, PIX[sf], 64, 36, PIX[df], ffi.SWS_BICUBIC)
+        assert ctx.paths & 512, ctx.paths
+        ctx.close()
+    ctx = S.SwsContext(64, 36, PIX["nv12"], 64, 36, PIX["yuv422p"], ffi.SWS_BICUBIC)   # another subsampling: chroma is scaled
+    assert not ctx.paths & 512
+    ctx.close()
+    ctx = S.SwsContext(24, 16, PIX["nv12"], 24, 16, PIX["yuv420p"], ffi.SWS_BICUBIC)   # chroma rows of 12 bytes: the older kernels
+    assert not ctx.paths & 512
     ctx.close()
 
 
