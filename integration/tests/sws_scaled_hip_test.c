@@ -202,6 +202,9 @@ int main(int argc, char **argv)
     CASE("nv12", 1920, 1080, "bgra", 1920, 1080, SWS_BICUBIC, 0, 0, 1, 1);
     CASE("nv21", 1080, 1920, "rgb24", 1080, 1920, SWS_BICUBIC, 0, 0, 0, 1);
     CASE("yuv420p", 1280, 720, "rgb24", 1280, 720, SWS_BICUBIC | SWS_ACCURATE_RND, 0, 0, 2, 1);
+    /* 4:4:4 into RGB at the source's size: no table converter either, full chroma forced (sws_full444.hip) */
+    CASE("yuv444p", 1920, 1080, "rgb24", 1920, 1080, SWS_BICUBIC, 0, 0, 0, 1);
+    CASE("yuv444p", 1281, 720, "bgra", 1281, 720, SWS_BILINEAR, 0, 0, 1, 1);
     /* BASELINE configs[1]'s conversion, one frame */
     CASE("nv12", 1920, 1080, "nv12", 3840, 2160, SWS_BICUBIC, 0, 0, 0, 1);
     /* exact 2x into RGB, 4K -> 1080p into RGB (two stages), other ratios */
