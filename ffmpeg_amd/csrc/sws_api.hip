@@ -73,6 +73,7 @@ struct FFHipSwsContext {
     const uint32_t *u2r_hco = nullptr, *u2r_vt = nullptr;
     /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
     int dn2_ok = 0;
+    int mix_dn2 = 0;  /* luma one tap on the sample itself, chroma planes exactly 2:1 both ways (yuv444p -> yuv420p at the same size): copy + k_sws_down2 */
     int c420_ok = 0;  /* 4:2:0 between planar and semi-planar layouts at the same size, no range change: a copy (sws_copy420.hip) */
     int f444_ok = 0;  /* planar 4:4:4 into packed RGB at the source's size: four one-tap banks, the full-chroma writer (sws_full444.hip) */
     int dn2_luma = 0; /* an RGB context's luma banks alone (its first stage's luma job on k_sws_down2, the chroma on the wide walker); 2: the chroma planes there as well (no vertical filter: FFHipDn2Job.v1) */
@@ -482,7 +483,8 @@ static void dn2_build_luma(FFHipSwsContext *c, int srcW, int srcH)
             const int16_t t = c->f[3][(size_t)y * c->d[3].size + i];
             chr = t == (c->p[3][y] + i == y ? 4096 : 0);
         }
-    chr = chr && ffhip_down2_virtual_bank(c->f[1].data(), c->p[1].data(), c->d[1].size, c->d[1].n, c->chrSrcW, &vb[2]) != 0;
+    chr = chr && ffhip_cw_bank_nowrap(c->f[1].data(), c->d[1].size, c->d[1].n) &&
+          ffhip_down2_virtual_bank(c->f[1].data(), c->p[1].data(), c->d[1].size, c->d[1].n, c->chrSrcW, &vb[2]) != 0;
     const size_t o1 = (vb[0].size() * 4 + 255) & ~(size_t)255, o2 = o1 + ((vb[1].size() * 4 + 255) & ~(size_t)255);
     if (hipMalloc(&c->dn2_dev, o2 + (chr ? vb[2].size() * 4 : 0)) != hipSuccess)
         return;
@@ -841,6 +843,34 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             }
             c->c420_ok = id;
         }
+        /* planar 4:4:4 -> 4:2:0 at the same size (a capture's frames subsampled for an encoder): the luma plane is the source's (one-tap
+         * banks), the chroma planes go exactly 2:1 both ways — the layout kernel's copy job + the static-schedule kernel on two planes,
+         * against the wide walker computing all three with its 8-tap classes */
+        if (!r && !c->c420_ok && t->srcFormat == FFHIP_PIX_FMT_YUV444P && t->dstFormat == FFHIP_PIX_FMT_YUV420P && t->srcW == t->dstW &&
+            t->srcH == t->dstH && t->dst_alpha_fill != 2 && t->dstW >= 16 && !(c->d[1].n & 3) && c->d[1].n >= 12) {
+            bool id = true;
+            for (int b = 0; b < 4 && id; b += 2) {
+                id = c->d[b].size == 1;
+                for (int x = 0; x < c->d[b].n && id; x++)
+                    id = c->p[b][x] == x && c->f[b][x] == (b < 2 ? 16384 : 4096);
+            }
+            std::vector<uint32_t> vb[2];
+            if (id && ffhip_cw_bank_nowrap(c->f[1].data(), c->d[1].size, c->d[1].n) &&
+                ffhip_down2_virtual_bank(c->f[1].data(), c->p[1].data(), c->d[1].size, c->d[1].n, c->chrSrcW, &vb[0]) &&
+                ffhip_down2_virtual_bank(c->f[3].data(), c->p[3].data(), c->d[3].size, c->d[3].n, c->chrSrcH, &vb[1])) {
+                vb[1].resize((size_t)(c->d[3].n + 8) * 4, 0); /* the row loop reads four rows of coefficients at a time */
+                const size_t o1 = (vb[0].size() * 4 + 255) & ~(size_t)255;
+                if (hipMalloc(&c->dn2_dev, o1 + vb[1].size() * 4) == hipSuccess) {
+                    uint8_t *bb = static_cast<uint8_t *>(c->dn2_dev);
+                    if (hipMemcpy(bb, vb[0].data(), vb[0].size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(bb + o1, vb[1].data(), vb[1].size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+                        c->dn2_h[1] = reinterpret_cast<const uint32_t *>(bb);
+                        c->dn2_v[1] = reinterpret_cast<const uint32_t *>(bb + o1);
+                        c->mix_dn2 = 1;
+                    }
+                }
+            }
+        }
         const int limits[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
         {
             const bool ok = build_fast_view(c, limits, false);
@@ -962,7 +992,7 @@ extern "C" int ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) + (c->mix_dn2 ? 1024 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -1673,6 +1703,33 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             }
         }
         return ffhip_launch_copy420(K, stream);
+    }
+    if (c->mix_dn2 && !(ev && ev[0] == '0') && srcStride[0] > 0 && cus > 0 && cvs > 0 && dstStride[0] > 0 && dstStride[1] > 0 && dstStride[2] > 0 &&
+        !(((uintptr_t)cu | (uintptr_t)cv | (size_t)cus | (size_t)cvs | cuf | cvf | (uintptr_t)dst[1] | (uintptr_t)dst[2] | (size_t)dstStride[1] |
+           (size_t)dstStride[2] | dstFramePitch[1] | dstFramePitch[2]) & 3)) {
+        FFHipCopy420Args K;
+        memset(&K, 0, sizeof(K));
+        K.nframes = nframes;
+        FFHipCopy420Job &kj = K.job[K.njobs++];
+        kj.src[0] = s0; kj.sstride[0] = srcStride[0]; kj.sfp[0] = srcFramePitch[0];
+        kj.dst = (uint8_t *)dst[0]; kj.dstride = dstStride[0]; kj.dfp = dstFramePitch[0];
+        kj.kind = 0; kj.wbytes = t.dstW; kj.rows = t.dstH;
+        int r1 = ffhip_launch_copy420(K, stream);
+        if (r1 < 0)
+            return r1;
+        FFHipDn2Args D;
+        memset(&D, 0, sizeof(D));
+        D.nframes = nframes;
+        D.xcd = 1;
+        for (int k = 0; k < 2; k++) {
+            FFHipDn2Job &j = D.job[D.njobs++];
+            j.src = k ? cv : cu; j.sstride = k ? cvs : cus; j.sfp = k ? cvf : cuf;
+            j.dst = (uint8_t *)dst[1 + k]; j.dstride = dstStride[1 + k]; j.dfp = dstFramePitch[1 + k];
+            j.srcH = c->chrSrcH; j.dstH = c->d[3].n; j.ngroups = c->d[1].n / 4;
+            j.hfv = c->dn2_h[1]; j.vfv = c->dn2_v[1];
+            ffhip_down2_plan_job(&j, 32);
+        }
+        return ffhip_launch_down2(D, stream);
     }
     if (c->cw_ok && !(ev && ev[0] == '0')) {
         uintptr_t al = 0;

@@ -268,6 +268,12 @@ SCALE_CASES = [
     ("yuv420p", 2100, 24, "nv12", 2100, 24, ffi.SWS_BICUBIC, 2),
     ("nv12", 1920, 1080, "yuv420p", 1920, 1080, ffi.SWS_BICUBIC, 0),
     ("yuv420p", 1920, 1080, "nv21", 1920, 1080, ffi.SWS_BICUBIC, 0),
+    # planar 4:4:4 -> 4:2:0 at the same size: the luma copied, the chroma planes on the exact-2:1 kernel
+    ("yuv444p", 64, 36, "yuv420p", 64, 36, ffi.SWS_BICUBIC, 0),
+    ("yuv444p", 200, 50, "yuv420p", 200, 50, ffi.SWS_BILINEAR, 0),
+    ("yuv444p", 1048, 24, "yuv420p", 1048, 24, ffi.SWS_BICUBIC, 0),
+    ("yuv444p", 1920, 1080, "yuv420p", 1920, 1080, ffi.SWS_BICUBIC, 0),
+    ("yuv444p", 66, 38, "yuv420p", 66, 38, ffi.SWS_BICUBIC, 2),      # 33 chroma columns: not this path
 ]
 
 
