@@ -73,6 +73,7 @@ struct FFHipSwsContext {
     const uint32_t *u2r_hco = nullptr, *u2r_vt = nullptr;
     /* exact-2:1 fast path (sws_down2.hip): the same for banks of up to 8 taps on the windows 2x - 3 .. 2x + 4 */
     int dn2_ok = 0;
+    int mix_up2 = 0;  /* luma one tap on the sample itself, chroma planes exactly 2x both ways (yuv420p -> yuv444p at the same size): copy + k_sws_up2 */
     int mix_dn2 = 0;  /* luma one tap on the sample itself, chroma planes exactly 2:1 both ways (yuv444p -> yuv420p at the same size): copy + k_sws_down2 */
     int c420_ok = 0;  /* 4:2:0 between planar and semi-planar layouts at the same size, no range change: a copy (sws_copy420.hip) */
     int f444_ok = 0;  /* planar 4:4:4 into packed RGB at the source's size: four one-tap banks, the full-chroma writer (sws_full444.hip) */
@@ -338,16 +339,18 @@ static bool wide_setup(FFHipSwsContext *c, const int limits[4], bool chroma_pair
 
 /* exact 2x: the 4-tap views (c->nf / c->np) as virtual banks on the regular windows of the edge-replicated rows, on the device;
  * sets c->up2_ok when every bank row is of that shape (sws_up2.hip) */
-static void up2_build(FFHipSwsContext *c, const int nsrc[4])
+/* chroma_only: the chroma banks alone (the luma plane is the source's: FFHipSwsContext.mix_up2) */
+static void up2_build(FFHipSwsContext *c, const int nsrc[4], bool chroma_only = false)
 {
     std::vector<uint32_t> vb[4];
     bool ok = true;
     for (int i = 0; i < 4 && ok; i++)
-        ok = ffhip_up2_virtual_bank(c->nf[i].data(), c->np[i].data(), c->d[i].n, nsrc[i], &vb[i]) != 0;
+        if (!(chroma_only && !(i & 1)))
+            ok = ffhip_up2_virtual_bank(c->nf[i].data(), c->np[i].data(), c->d[i].n, nsrc[i], &vb[i]) != 0;
     if (!ok)
         return;
     /* vertical banks: one leading row (y = -1) and 17 trailing ones of zeros (the row loop reads ahead) */
-    for (int i = 2; i < 4; i++) {
+    for (int i = chroma_only ? 3 : 2; i < 4; i++) {
         std::vector<uint32_t> pv((size_t)(c->d[i].n + 18) * 2, 0);
         memcpy(pv.data() + 2, vb[i].data(), vb[i].size() * 4);
         vb[i].swap(pv);
@@ -367,7 +370,10 @@ static void up2_build(FFHipSwsContext *c, const int nsrc[4])
         c->up2_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
         c->up2_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
         c->up2_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
-        c->up2_ok = 1;
+        if (chroma_only)
+            c->mix_up2 = 1;
+        else
+            c->up2_ok = 1;
     }
 }
 
@@ -887,6 +893,21 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
             up2_build(c, nsrc);
         }
+        /* planar 4:2:0 -> 4:4:4 at the same size: the luma plane is the source's, the chroma planes go exactly 2x both ways */
+        if (c->cw_opt && !c->up2_ok && t->srcFormat == FFHIP_PIX_FMT_YUV420P && t->dstFormat == FFHIP_PIX_FMT_YUV444P && l.dstW == l.srcW &&
+            l.dstH == l.srcH && ch.dstW == 2 * ch.srcW && ch.dstH == 2 * ch.srcH && !(ch.srcW & 3) && ch.srcW >= 8 && l.dstW >= 16 &&
+            t->dst_alpha_fill != 2) {
+            bool id = true;
+            for (int b = 0; b < 4 && id; b += 2) {
+                id = c->d[b].size == 1;
+                for (int x = 0; x < c->d[b].n && id; x++)
+                    id = c->p[b][x] == x && c->f[b][x] == (b < 2 ? 16384 : 4096);
+            }
+            if (id) {
+                const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
+                up2_build(c, nsrc, true);
+            }
+        }
         /* wide banks (down-scaling, long kernels): the LDS-backed walker; FFHIP_SWS_WIDE=1 builds it for narrow banks
          * too (parity tests of that kernel on up-scaling cases) */
         {
@@ -992,7 +1013,7 @@ extern "C" int ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) + (c->mix_dn2 ? 1024 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) + (c->mix_dn2 ? 1024 : 0) + (c->mix_up2 ? 2048 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -1742,7 +1763,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             al |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
         }
         const char *eu = FFHIP_KNOB("FFHIP_SWS_UP2");
-        if (!(al & 3) && c->up2_ok && !(eu && eu[0] == '0') && !(em_forced())) {
+        if (!(al & 3) && (c->up2_ok || (c->mix_up2 && !c->luma_pass && l.src_stride[0] > 0 && l.dst_stride[0] > 0 && ch.src_stride[0] > 0 && ch.src_stride[1] > 0 &&
+                                            ch.dst_stride[0] > 0 && ch.dst_stride[1] > 0)) && !(eu && eu[0] == '0') && !(em_forced())) {
             /* exact 2x: static schedule, regular windows (sws_up2.hip).  FFHIP_SWS_UP2=0 takes the general column walker. */
             FFHipUp2Args U;
             memset(&U, 0, sizeof(U));
@@ -1757,7 +1779,20 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 j.hfv = c->up2_h[which]; j.vfv = c->up2_v[which];
                 j.rc_coeff = p.rc_coeff; j.rc_offset = p.rc_offset;
             };
-            upjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
+            if (c->mix_up2) {
+                FFHipCopy420Args K;
+                memset(&K, 0, sizeof(K));
+                K.nframes = nframes;
+                FFHipCopy420Job &kj = K.job[K.njobs++];
+                kj.src[0] = l.src[0]; kj.sstride[0] = l.src_stride[0]; kj.sfp[0] = l.src_fp[0];
+                kj.dst = l.dst[0]; kj.dstride = l.dst_stride[0]; kj.dfp = l.dst_fp[0];
+                kj.kind = 0; kj.wbytes = l.dstW; kj.rows = l.dstH;
+                const int r1 = ffhip_launch_copy420(K, stream);
+                if (r1 < 0)
+                    return r1;
+            } else {
+                upjob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
+            }
             if (c->luma_pass) {
             } else if (ch.src_step == 2) {
                 const bool ssw = ch.src[1] < ch.src[0], dsw = ch.dst[1] < ch.dst[0];

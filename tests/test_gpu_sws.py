@@ -274,6 +274,12 @@ SCALE_CASES = [
     ("yuv444p", 1048, 24, "yuv420p", 1048, 24, ffi.SWS_BICUBIC, 0),
     ("yuv444p", 1920, 1080, "yuv420p", 1920, 1080, ffi.SWS_BICUBIC, 0),
     ("yuv444p", 66, 38, "yuv420p", 66, 38, ffi.SWS_BICUBIC, 2),      # 33 chroma columns: not this path
+    # planar 4:2:0 -> 4:4:4 at the same size: the luma copied, the chroma planes on the exact-2x kernel
+    ("yuv420p", 64, 36, "yuv444p", 64, 36, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 200, 50, "yuv444p", 200, 50, ffi.SWS_BILINEAR, 0),
+    ("yuv420p", 1048, 24, "yuv444p", 1048, 24, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 1920, 1080, "yuv444p", 1920, 1080, ffi.SWS_BICUBIC, 0),
+    ("yuv420p", 68, 38, "yuv444p", 68, 38, ffi.SWS_POINT, 0),
 ]
 
 
