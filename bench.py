@@ -332,6 +332,13 @@ def extras(torch, dev):
     sws_case("sws_p010_720p_to_1080p_bicubic", 158, 1280, 720, 158, 1920, 1080, 64)
     sws_case("sws_p010_4k_to_1440p_bicubic", 158, 3840, 2160, 158, 2560, 1440, 16)
     sws_case("sws_yuv420p10_1080p_to_1440p_bicubic", 62, 1920, 1080, 62, 2560, 1440, 32)
+    # round 5's second survey: conversions at the source's size that sat on general kernels — planar 4:4:4 into RGB (no table converter:
+    # the full-chroma writer on one-tap banks, sws_full444.hip), 4:2:0 between its layouts (sws_copy420.hip), 4:4:4 -> 4:2:0 (the luma
+    # copied, the chroma on the exact-2:1 kernel) — and the commonest down-scale on the wide walker
+    sws_case("sws_yuv444p_1080p_to_rgb24_1080p", 5, 1920, 1080, 2, 1920, 1080, 64)
+    sws_case("sws_nv12_1080p_to_yuv420p_1080p", 23, 1920, 1080, 0, 1920, 1080, 64)
+    sws_case("sws_yuv444p_1080p_to_yuv420p_1080p", 5, 1920, 1080, 0, 1920, 1080, 64)
+    sws_case("sws_nv12_1080p_to_720p_bicubic", 23, 1920, 1080, 23, 1280, 720, 64)
     # H.264 8x8 IDCT + add over 32 4K luma planes (129,600 blocks each, 384 B/block)
     planes, stride = 32, 3840
     nb = planes * 129600
