@@ -518,6 +518,283 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
     }
 }
 
+/* the vertical sums of one output row, >> 19, NOT clipped, as four ints: the luma of a packed-RGB target (yuv2rgb_X reads it so) */
+__device__ __forceinline__ void dn_v4i(int (&t)[4], const uint32_t (&R0)[4], const uint32_t (&R1)[4], const uint32_t (&R2)[4], const uint32_t (&R3)[4],
+                                       uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int kround)
+{
+    asm("v_dot2_i32_i16 %0, %4, %20, %24\n\t"
+        "v_dot2_i32_i16 %1, %5, %20, %24\n\t"
+        "v_dot2_i32_i16 %2, %6, %20, %24\n\t"
+        "v_dot2_i32_i16 %3, %7, %20, %24\n\t"
+        "v_dot2_i32_i16 %0, %8, %21, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %21, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %21, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %21, %3\n\t"
+        "v_dot2_i32_i16 %0, %12, %22, %0\n\t"
+        "v_dot2_i32_i16 %1, %13, %22, %1\n\t"
+        "v_dot2_i32_i16 %2, %14, %22, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %22, %3\n\t"
+        "v_dot2_i32_i16 %0, %16, %23, %0\n\t"
+        "v_dot2_i32_i16 %1, %17, %23, %1\n\t"
+        "v_dot2_i32_i16 %2, %18, %23, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %23, %3\n\t"
+        "v_ashrrev_i32 %0, 19, %0\n\t"
+        "v_ashrrev_i32 %1, 19, %1\n\t"
+        "v_ashrrev_i32 %2, 19, %2\n\t"
+        "v_ashrrev_i32 %3, 19, %3"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+        : "v"(R0[0]), "v"(R0[1]), "v"(R0[2]), "v"(R0[3]), "v"(R1[0]), "v"(R1[1]), "v"(R1[2]), "v"(R1[3]),
+          "v"(R2[0]), "v"(R2[1]), "v"(R2[2]), "v"(R2[3]), "v"(R3[0]), "v"(R3[1]), "v"(R3[2]), "v"(R3[3]),
+          "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(kround));
+}
+__device__ __forceinline__ int dn_mad24(int a, int b, int c) /* b: uniform */
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+/* one dword of four bytes clip_u8(x >> 16) */
+__device__ __forceinline__ uint32_t dn_pk4_16(int a, int b, int c, int d)
+{
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16\n\t"
+        "v_ashr_pk_u8_i32 %0, %3, %4, 16 op_sel:[0,0,0,1]"
+        : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return r;
+}
+
+/*
+ * k_sws_down2_rgb — exact 2:1 from NV12 / NV21 into packed RGB, FUSED (round 5, the last step): the two-stage form (R5.7) moves 1.65x the
+ * algorithmic bytes and both of its kernels stream, so what is left is the intermediate itself.  A lane's four luma outputs and its two
+ * chroma pairs cover the SAME four pixels (a pair job's group is two chroma columns = four pixels), so one lane has all of a pixel quad:
+ * the luma walk of dn2_unit (static vertical schedule, ring of four row pairs), one chroma row per output row through the horizontal pass
+ * alone ((U + 64) >> 7: the vertical chroma bank is one tap), the tables' closed form with the chroma terms from an LDS table
+ * (sws_y16rgb.hip's), 12 or 16 bytes per lane and row — lanes side by side, a row segment of 768 / 1024 contiguous bytes per store
+ * instruction.
+ */
+template <int LAY>
+__device__ __forceinline__ void dn2rgb_unit(const FFHipDn2RgbArgs &J, int frame, int gbase, int strip, int lane, const uint2 *lut)
+{
+    constexpr int BPG = LAY < 2 ? 12 : 16; /* destination bytes per group of four pixels */
+    const int graw = gbase + lane;
+    const bool act = graw < J.ngroups;
+    const int g = min(graw, J.ngroups - 1);
+    const bool lb = g == 0, rb = g == J.ngroups - 1;
+    const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
+    const uint32_t soff = (uint32_t)(lb ? 0 : 8 * g - 4 - (rb ? 4 : 0));
+    const uint32_t coff = (uint32_t)(lb ? 0 : 8 * g - 8 - (rb ? 8 : 0));
+    uint32_t cf[16], cc[8];
+    {
+        const dn_u4 *p = reinterpret_cast<const dn_u4 *>(J.hfv_l) + (size_t)g * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const dn_u4 v = p[i];
+            cf[4 * i] = v.x; cf[4 * i + 1] = v.y; cf[4 * i + 2] = v.z; cf[4 * i + 3] = v.w;
+        }
+        const dn_u4 *q = reinterpret_cast<const dn_u4 *>(J.hfv_c) + (size_t)g * 2;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const dn_u4 v = q[i];
+            cc[4 * i] = v.x; cc[4 * i + 1] = v.y; cc[4 * i + 2] = v.z; cc[4 * i + 3] = v.w;
+        }
+    }
+    const uint32_t par = J.swap ? 0x00010001u : 0u;
+    const uint32_t selA = 0x0c040c02u + par, selB = 0x0c050c03u - par; /* channel samples 2 bytes apart */
+
+    const int S = J.steps_per_strip; /* a multiple of 4 */
+    const int a = strip * S, b = min(a + S, J.dstH);
+    const uint8_t *sbase = J.ysrc + (size_t)frame * J.ysfp;
+    const uint8_t *cbase = J.csrc + (size_t)frame * J.csfp;
+    uint8_t *dr = J.dst + (size_t)frame * J.dfp + (ptrdiff_t)a * J.dstride;
+    const ptrdiff_t sstride = J.ysstride, cstride = J.csstride, dstride = J.dstride;
+    const int srcH = J.srcH, chrH = J.chrH;
+    int pr = 2 * a - 3; /* next luma row to fetch (unclamped) */
+    const uint8_t *pf = sbase + (ptrdiff_t)min(max(pr, 0), srcH - 1) * sstride;
+    int cr = a;         /* next chroma row to fetch */
+    const uint8_t *pc = cbase + (ptrdiff_t)min(a, chrH - 1) * cstride;
+    asm("" : "+s"(pf), "+s"(pc), "+s"(dr));
+
+    struct Raw { uint32_t q[4]; };
+    struct RawC { uint32_t q[6]; };
+    auto load_next = [&](Raw &o) {
+        uint32_t off = soff;
+        asm volatile("" : "+v"(off));
+        const dn_u4 w = *(dn_gc4)((dn_gcp)pf + off);
+        o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w;
+        pr++;
+        pf += (pr >= 1 && pr <= srcH - 1) ? sstride : 0;
+        asm("" : "+s"(pf));
+    };
+    auto load_chroma = [&](RawC &o) {
+        uint32_t off = coff;
+        asm volatile("" : "+v"(off));
+        const dn_u4 w = *(dn_gc4)((dn_gcp)pc + off);
+        const dn_u2 e = *(dn_gc2)((dn_gcp)pc + off + 16);
+        o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w; o.q[4] = e.x; o.q[5] = e.y;
+        cr++;
+        pc += cr <= chrH - 1 ? cstride : 0;
+        asm("" : "+s"(pc));
+    };
+    auto hpass = [&](const Raw &w, int (&h)[4]) {
+        uint32_t v[4] = { w.q[0], w.q[1], w.q[2], w.q[3] };
+        if (border) {
+            const uint32_t f0 = __builtin_amdgcn_perm(w.q[0], w.q[0], 0x00000000u), f3 = __builtin_amdgcn_perm(w.q[3], w.q[3], 0x03030303u);
+            v[0] = lb ? f0 : rb ? w.q[1] : w.q[0];
+            v[1] = lb ? w.q[0] : rb ? w.q[2] : w.q[1];
+            v[2] = lb ? w.q[1] : rb ? w.q[3] : w.q[2];
+            v[3] = lb ? w.q[2] : rb ? f3 : w.q[3];
+        }
+        uint32_t P[7];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            P[2 * m] = __builtin_amdgcn_perm(v[m + 1], v[m], 0x0c020c01u);
+            P[2 * m + 1] = __builtin_amdgcn_perm(v[m + 1], v[m], 0x0c040c03u);
+        }
+        P[6] = __builtin_amdgcn_perm(v[3], v[3], 0x0c020c01u);
+        dn_h4_plane(h, P, cf);
+    };
+    auto hpass_c = [&](const RawC &w, int (&h)[4]) {
+        uint32_t v[6] = { w.q[0], w.q[1], w.q[2], w.q[3], w.q[4], w.q[5] };
+        if (border) {
+            const uint32_t f0 = __builtin_amdgcn_perm(w.q[0], w.q[0], 0x01000100u), f5 = __builtin_amdgcn_perm(w.q[5], w.q[5], 0x03020302u);
+            v[0] = lb ? f0 : rb ? w.q[2] : w.q[0];
+            v[1] = lb ? f0 : rb ? w.q[3] : w.q[1];
+            v[2] = lb ? w.q[0] : rb ? w.q[4] : w.q[2];
+            v[3] = lb ? w.q[1] : rb ? w.q[5] : w.q[3];
+            v[4] = lb ? w.q[2] : rb ? f5 : w.q[4];
+            v[5] = lb ? w.q[3] : rb ? f5 : w.q[5];
+        }
+        uint32_t A[5], B[5];
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            A[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selA);
+            B[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selB);
+        }
+        dn_h4_pair(h, A, B, cc);
+    };
+    auto hpair = [&](const Raw &w0, const Raw &w1, uint32_t (&T)[4]) {
+        int h0[4], h1[4];
+        hpass(w0, h0);
+        hpass(w1, h1);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            T[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(h0[i], h1[i]));
+    };
+
+    Raw buf[4];
+    RawC cbuf[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        load_next(buf[k]);
+    load_chroma(cbuf[0]);
+    load_chroma(cbuf[1]);
+    uint32_t ring[4][4];
+    hpair(buf[0], buf[1], ring[3]);
+    load_next(buf[0]); load_next(buf[1]);
+    hpair(buf[2], buf[3], ring[0]);
+    load_next(buf[2]); load_next(buf[3]);
+    hpair(buf[0], buf[1], ring[1]);
+    load_next(buf[0]); load_next(buf[1]);
+
+    int kround = 64 << 12;
+    asm volatile("" : "+v"(kround));
+    const int cy = __builtin_amdgcn_readfirstlane(J.k.cy);
+    const char *lutb = reinterpret_cast<const char *>(lut);
+    const uint32_t *vt = J.vfv;
+    const uint32_t doff = (uint32_t)BPG * (uint32_t)g;
+    for (int y = a; y < b; y += 4) {
+        const dn_u16 c16 = *(dn_cc16)(vt + 4 * y);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (y + k < b) { /* uniform */
+                Raw &w0 = buf[(2 * k + 2) & 3], &w1 = buf[(2 * k + 3) & 3];
+                hpair(w0, w1, ring[(k + 2) & 3]);
+                load_next(w0); load_next(w1);
+                int hc[4];
+                hpass_c(cbuf[k & 1], hc);
+                load_chroma(cbuf[k & 1]);
+                int Y[4];
+                dn_v4i(Y, ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c16[4 * k], c16[4 * k + 1], c16[4 * k + 2], c16[4 * k + 3], kround);
+                /* (u0, v0, u1, v1): clip_u8((h + 64) >> 7), the tables' index */
+                int c0[2], c1[2], c2[2];
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const int ui = min(max((hc[2 * m] + 64) >> 7, 0), 255), vi = min(max((hc[2 * m + 1] + 64) >> 7, 0), 255);
+                    const uint2 tu = *reinterpret_cast<const uint2 *>(lutb + (ui << 3));
+                    const uint2 tv = *reinterpret_cast<const uint2 *>(lutb + 2048 + (vi << 3));
+                    constexpr bool BGR = LAY == 1 || LAY == 4 || LAY == 5;
+                    c0[m] = (int)(BGR ? tu.x : tv.x);
+                    c1[m] = (int)(tu.y + tv.y);
+                    c2[m] = (int)(BGR ? tv.x : tu.x);
+                }
+                int val[12];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    val[3 * p] = dn_mad24(Y[p], cy, c0[p >> 1]);
+                    val[3 * p + 1] = dn_mad24(Y[p], cy, c1[p >> 1]);
+                    val[3 * p + 2] = dn_mad24(Y[p], cy, c2[p >> 1]);
+                }
+                uint32_t off = doff;
+                asm volatile("" : "+v"(off));
+                if (LAY >= 2) {
+                    int alpha = 255 << 16;
+                    asm("" : "+v"(alpha));
+                    dn_u4 o;
+                    uint32_t w[4];
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        w[p] = (LAY == 2 || LAY == 4) ? dn_pk4_16(alpha, val[3 * p], val[3 * p + 1], val[3 * p + 2])
+                                                      : dn_pk4_16(val[3 * p], val[3 * p + 1], val[3 * p + 2], alpha);
+                    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+                    if (act)
+                        __builtin_nontemporal_store(o, (dn_u4a __attribute__((address_space(1))) *)((dn_gp)dr + off));
+                } else {
+                    typedef uint32_t dn_u3 __attribute__((ext_vector_type(3)));
+                    typedef dn_u3 __attribute__((aligned(4))) dn_u3a;
+                    dn_u3 o;
+                    o.x = dn_pk4_16(val[0], val[1], val[2], val[3]);
+                    o.y = dn_pk4_16(val[4], val[5], val[6], val[7]);
+                    o.z = dn_pk4_16(val[8], val[9], val[10], val[11]);
+                    if (act)
+                        __builtin_nontemporal_store(o, (dn_u3a __attribute__((address_space(1))) *)((dn_gp)dr + off));
+                }
+                dr += dstride;
+                asm("" : "+s"(dr));
+            }
+        }
+    }
+}
+
+template <int LAY>
+__global__ __launch_bounds__(256) void k_sws_down2_rgb(FFHipDn2RgbArgs A)
+{
+    __shared__ uint2 lut[512]; /* [U] = { b(U), gu(U) }, [256 + V] = { r(V), gv(V) }: the chroma terms, cy-scaled, rounding in (sws_y16rgb.hip) */
+    {
+        const int t = (int)threadIdx.x;
+        const FFHipYuv2RgbK Kt = A.k;
+        lut[t] = make_uint2((uint32_t)(__mul24(Kt.off_b + (__mul24(t, Kt.cbu) >> 16), Kt.cy) + Kt.kb),
+                            (uint32_t)(__mul24(Kt.off_g + (__mul24(t, Kt.cgu) >> 16), Kt.cy) + Kt.kb));
+        lut[256 + t] = make_uint2((uint32_t)(__mul24(Kt.off_r + (__mul24(t, Kt.crv) >> 16), Kt.cy) + Kt.kb),
+                                  (uint32_t)__mul24(__mul24(t, Kt.cgv) >> 16, Kt.cy));
+        __syncthreads();
+    }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    uint32_t blk = blockIdx.x;
+    if (A.xcd) {
+        const uint32_t nb = gridDim.x, x = blk & 7u, sl = blk >> 3, q = nb >> 3, r = nb & 7u;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sl;
+    }
+    const uint32_t gw = blk * 4u + (uint32_t)wave;
+    const uint32_t upf = (uint32_t)A.ncb * (uint32_t)A.nstrips;
+    if (gw >= upf * (uint32_t)A.nframes)
+        return;
+    const int frame = (int)(gw / upf);
+    const int u = (int)(gw - (uint32_t)frame * upf);
+    const int strip = u / A.ncb, cb = u - strip * A.ncb;
+    dn2rgb_unit<LAY>(A, frame, cb * 64, strip, lane, lut);
+}
+
 template <int HB>
 __global__ __launch_bounds__(256) void k_sws_down2(FFHipDn2Args A)
 {
@@ -618,6 +895,39 @@ int ffhip_launch_down2(FFHipDn2Args &A, hipStream_t stream)
         hipLaunchKernelGGL(k_sws_down2<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
     else
         hipLaunchKernelGGL(k_sws_down2<0>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int ffhip_launch_down2_rgb(FFHipDn2RgbArgs &A, int want_rows, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    if (A.ngroups < 3 || A.dstH <= 0) {
+        ffhip_set_error("ffhip_sws: the fused exact-2:1 RGB kernel takes widths from 12 (got %d groups)", A.ngroups);
+        return FFHIP_EINVAL;
+    }
+    const int n = cdiv(A.dstH, want_rows);
+    A.steps_per_strip = cdiv(cdiv(A.dstH, n), 4) * 4;
+    A.nstrips = cdiv(A.dstH, A.steps_per_strip);
+    A.ncb = cdiv(A.ngroups, 64);
+    const long long waves = (long long)A.ncb * A.nstrips * A.nframes;
+    if (waves >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
+        return FFHIP_EINVAL;
+    }
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    switch (A.lay) {
+    case 0: hipLaunchKernelGGL((k_sws_down2_rgb<0>), grid, block, 0, stream, A); break;
+    case 1: hipLaunchKernelGGL((k_sws_down2_rgb<1>), grid, block, 0, stream, A); break;
+    case 2: hipLaunchKernelGGL((k_sws_down2_rgb<2>), grid, block, 0, stream, A); break;
+    case 3: hipLaunchKernelGGL((k_sws_down2_rgb<3>), grid, block, 0, stream, A); break;
+    case 4: hipLaunchKernelGGL((k_sws_down2_rgb<4>), grid, block, 0, stream, A); break;
+    case 5: hipLaunchKernelGGL((k_sws_down2_rgb<5>), grid, block, 0, stream, A); break;
+    default:
+        ffhip_set_error("ffhip_sws: packed layout %d is not one of the RGB writer's", A.lay);
+        return FFHIP_EINVAL;
+    }
     LAUNCH_CHECK();
     return 0;
 }

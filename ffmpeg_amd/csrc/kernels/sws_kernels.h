@@ -186,6 +186,21 @@ struct FFHipDn2Args {
 #ifdef __cplusplus
 int  ffhip_down2_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, std::vector<uint32_t> *out);
 #endif
+/* exact 2:1 from NV12 / NV21 into packed RGB, fused (k_sws_down2_rgb in sws_down2.hip) */
+struct FFHipDn2RgbArgs {
+    const uint8_t *ysrc, *csrc;         /* the luma plane; the interleaved chroma plane */
+    uint8_t *dst;
+    ptrdiff_t ysstride, csstride, dstride;
+    size_t ysfp, csfp, dfp;
+    int swap;                           /* NV21: v at the even bytes */
+    int srcH, chrH, dstH;               /* luma rows, chroma rows (= dstH), output rows (= srcH / 2) */
+    int ngroups;                        /* groups of four pixels per output row: dstW / 4 (>= 3) */
+    const uint32_t *hfv_l, *hfv_c;      /* device: virtual horizontal banks, dstW x 4 and (dstW / 2) x 4 dwords */
+    const uint32_t *vfv;                /* device: the luma's virtual vertical bank, (dstH + 8) x 4 dwords */
+    int ncb, nstrips, steps_per_strip, nframes, xcd, lay;
+    FFHipYuv2RgbK k;
+};
+int  ffhip_launch_down2_rgb(FFHipDn2RgbArgs &A, int want_rows, hipStream_t stream);
 void ffhip_down2_plan_job(FFHipDn2Job *j, int want_rows);
 int  ffhip_launch_down2(FFHipDn2Args &A, hipStream_t stream);
 

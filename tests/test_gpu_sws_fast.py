@@ -554,6 +554,14 @@ def test_rgb_two_stage_exact_half_one_launch(sf, df, dw, dh, monkeypatch):
     _run(sf, 2 * dw, 2 * dh, df, dw, dh, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, seed=dw + dh, need="any")
 
 
+@pytest.mark.parametrize("sf,df,dw,dh", [("nv12", "rgb24", 200, 108), ("nv21", "bgra", 1288, 48), ("nv12", "bgr24", 192, 108), ("nv21", "argb", 12, 8),
+                                         ("nv12", "abgr", 1032, 20), ("nv12", "rgba", 2048, 12)])
+def test_rgb_exact_half_two_stages_kept(sf, df, dw, dh, monkeypatch):
+    """from NV12 / NV21 the product runs the FUSED k_sws_down2_rgb; FFHIP_SWS_DOWN2=t keeps the two-stage form (one first-stage launch +
+    k_y16_rgb with interleaved chroma): both must give the reference's bytes"""
+    _run(sf, 2 * dw, 2 * dh, df, dw, dh, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "t"}, monkeypatch=monkeypatch, seed=dw + 3 * dh, need="any")
+
+
 def test_rgb_two_stage_full_size(monkeypatch):
     _run("nv12", 3840, 2160, "rgb24", 1920, 1080, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, n=2, seed=83, need="any")
 
