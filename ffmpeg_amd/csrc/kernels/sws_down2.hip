@@ -572,7 +572,7 @@ __device__ __forceinline__ uint32_t dn_pk4_16(int a, int b, int c, int d)
  * (sws_y16rgb.hip's), 12 or 16 bytes per lane and row — lanes side by side, a row segment of 768 / 1024 contiguous bytes per store
  * instruction.
  */
-template <int LAY>
+template <int LAY, bool PL> /* PL: planar chroma (yuv420p): csrc / csrc2 are the U and V planes, 12 bytes of each per lane and row */
 __device__ __forceinline__ void dn2rgb_unit(const FFHipDn2RgbArgs &J, int frame, int gbase, int strip, int lane, const uint2 *lut)
 {
     constexpr int BPG = LAY < 2 ? 12 : 16; /* destination bytes per group of four pixels */
@@ -582,7 +582,7 @@ __device__ __forceinline__ void dn2rgb_unit(const FFHipDn2RgbArgs &J, int frame,
     const bool lb = g == 0, rb = g == J.ngroups - 1;
     const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
     const uint32_t soff = (uint32_t)(lb ? 0 : 8 * g - 4 - (rb ? 4 : 0));
-    const uint32_t coff = (uint32_t)(lb ? 0 : 8 * g - 8 - (rb ? 8 : 0));
+    const uint32_t coff = PL ? (uint32_t)(lb ? 0 : 4 * g - 4 - (rb ? 4 : 0)) : (uint32_t)(lb ? 0 : 8 * g - 8 - (rb ? 8 : 0));
     uint32_t cf[16], cc[8];
     {
         const dn_u4 *p = reinterpret_cast<const dn_u4 *>(J.hfv_l) + (size_t)g * 4;
@@ -605,6 +605,7 @@ __device__ __forceinline__ void dn2rgb_unit(const FFHipDn2RgbArgs &J, int frame,
     const int a = strip * S, b = min(a + S, J.dstH);
     const uint8_t *sbase = J.ysrc + (size_t)frame * J.ysfp;
     const uint8_t *cbase = J.csrc + (size_t)frame * J.csfp;
+    const ptrdiff_t c2 = PL ? J.csrc2 - J.csrc : 0; /* the V plane from the U plane: same stride and frame pitch (the caller sees to it) */
     uint8_t *dr = J.dst + (size_t)frame * J.dfp + (ptrdiff_t)a * J.dstride;
     const ptrdiff_t sstride = J.ysstride, cstride = J.csstride, dstride = J.dstride;
     const int srcH = J.srcH, chrH = J.chrH;
@@ -628,9 +629,17 @@ __device__ __forceinline__ void dn2rgb_unit(const FFHipDn2RgbArgs &J, int frame,
     auto load_chroma = [&](RawC &o) {
         uint32_t off = coff;
         asm volatile("" : "+v"(off));
-        const dn_u4 w = *(dn_gc4)((dn_gcp)pc + off);
-        const dn_u2 e = *(dn_gc2)((dn_gcp)pc + off + 16);
-        o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w; o.q[4] = e.x; o.q[5] = e.y;
+        if (PL) {
+            typedef uint32_t dn_u3 __attribute__((ext_vector_type(3)));
+            typedef dn_u3 __attribute__((aligned(4))) dn_u3a;
+            typedef const dn_u3a __attribute__((address_space(1))) *dn_gc3;
+            const dn_u3 u = *(dn_gc3)((dn_gcp)pc + off), v = *(dn_gc3)((dn_gcp)(pc + c2) + off);
+            o.q[0] = u.x; o.q[1] = u.y; o.q[2] = u.z; o.q[3] = v.x; o.q[4] = v.y; o.q[5] = v.z;
+        } else {
+            const dn_u4 w = *(dn_gc4)((dn_gcp)pc + off);
+            const dn_u2 e = *(dn_gc2)((dn_gcp)pc + off + 16);
+            o.q[0] = w.x; o.q[1] = w.y; o.q[2] = w.z; o.q[3] = w.w; o.q[4] = e.x; o.q[5] = e.y;
+        }
         cr++;
         pc += cr <= chrH - 1 ? cstride : 0;
         asm("" : "+s"(pc));
@@ -654,21 +663,45 @@ __device__ __forceinline__ void dn2rgb_unit(const FFHipDn2RgbArgs &J, int frame,
         dn_h4_plane(h, P, cf);
     };
     auto hpass_c = [&](const RawC &w, int (&h)[4]) {
-        uint32_t v[6] = { w.q[0], w.q[1], w.q[2], w.q[3], w.q[4], w.q[5] };
-        if (border) {
-            const uint32_t f0 = __builtin_amdgcn_perm(w.q[0], w.q[0], 0x01000100u), f5 = __builtin_amdgcn_perm(w.q[5], w.q[5], 0x03020302u);
-            v[0] = lb ? f0 : rb ? w.q[2] : w.q[0];
-            v[1] = lb ? f0 : rb ? w.q[3] : w.q[1];
-            v[2] = lb ? w.q[0] : rb ? w.q[4] : w.q[2];
-            v[3] = lb ? w.q[1] : rb ? w.q[5] : w.q[3];
-            v[4] = lb ? w.q[2] : rb ? f5 : w.q[4];
-            v[5] = lb ? w.q[3] : rb ? f5 : w.q[5];
-        }
         uint32_t A[5], B[5];
+        if (PL) {
+            /* a plane's samples 4g - 4 .. 4g + 7 in three dwords: pair m = (s[2m + 1], s[2m + 2]), as the luma's */
+            uint32_t x[2][3] = { { w.q[0], w.q[1], w.q[2] }, { w.q[3], w.q[4], w.q[5] } };
+            if (border) {
 #pragma unroll
-        for (int m = 0; m < 5; m++) {
-            A[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selA);
-            B[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selB);
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t q0 = w.q[3 * c], q1 = w.q[3 * c + 1], q2 = w.q[3 * c + 2];
+                    const uint32_t f0 = __builtin_amdgcn_perm(q0, q0, 0x00000000u), f2 = __builtin_amdgcn_perm(q2, q2, 0x03030303u);
+                    x[c][0] = lb ? f0 : rb ? q1 : q0;
+                    x[c][1] = lb ? q0 : rb ? q2 : q1;
+                    x[c][2] = lb ? q1 : rb ? f2 : q2;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                uint32_t *P = c ? B : A;
+                P[0] = __builtin_amdgcn_perm(x[c][1], x[c][0], 0x0c020c01u);
+                P[1] = __builtin_amdgcn_perm(x[c][1], x[c][0], 0x0c040c03u);
+                P[2] = __builtin_amdgcn_perm(x[c][2], x[c][1], 0x0c020c01u);
+                P[3] = __builtin_amdgcn_perm(x[c][2], x[c][1], 0x0c040c03u);
+                P[4] = __builtin_amdgcn_perm(x[c][2], x[c][2], 0x0c020c01u);
+            }
+        } else {
+            uint32_t v[6] = { w.q[0], w.q[1], w.q[2], w.q[3], w.q[4], w.q[5] };
+            if (border) {
+                const uint32_t f0 = __builtin_amdgcn_perm(w.q[0], w.q[0], 0x01000100u), f5 = __builtin_amdgcn_perm(w.q[5], w.q[5], 0x03020302u);
+                v[0] = lb ? f0 : rb ? w.q[2] : w.q[0];
+                v[1] = lb ? f0 : rb ? w.q[3] : w.q[1];
+                v[2] = lb ? w.q[0] : rb ? w.q[4] : w.q[2];
+                v[3] = lb ? w.q[1] : rb ? w.q[5] : w.q[3];
+                v[4] = lb ? w.q[2] : rb ? f5 : w.q[4];
+                v[5] = lb ? w.q[3] : rb ? f5 : w.q[5];
+            }
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+                A[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selA);
+                B[m] = __builtin_amdgcn_perm(v[m + 1], v[m], selB);
+            }
         }
         dn_h4_pair(h, A, B, cc);
     };
@@ -765,7 +798,7 @@ __device__ __forceinline__ void dn2rgb_unit(const FFHipDn2RgbArgs &J, int frame,
     }
 }
 
-template <int LAY>
+template <int LAY, bool PL>
 __global__ __launch_bounds__(256) void k_sws_down2_rgb(FFHipDn2RgbArgs A)
 {
     __shared__ uint2 lut[512]; /* [U] = { b(U), gu(U) }, [256 + V] = { r(V), gv(V) }: the chroma terms, cy-scaled, rounding in (sws_y16rgb.hip) */
@@ -792,7 +825,7 @@ __global__ __launch_bounds__(256) void k_sws_down2_rgb(FFHipDn2RgbArgs A)
     const int frame = (int)(gw / upf);
     const int u = (int)(gw - (uint32_t)frame * upf);
     const int strip = u / A.ncb, cb = u - strip * A.ncb;
-    dn2rgb_unit<LAY>(A, frame, cb * 64, strip, lane, lut);
+    dn2rgb_unit<LAY, PL>(A, frame, cb * 64, strip, lane, lut);
 }
 
 template <int HB>
@@ -917,17 +950,18 @@ int ffhip_launch_down2_rgb(FFHipDn2RgbArgs &A, int want_rows, hipStream_t stream
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define DR_L(L)                                                                                        \
+    case L:                                                                                            \
+        if (A.csrc2) hipLaunchKernelGGL((k_sws_down2_rgb<L, true>), grid, block, 0, stream, A);        \
+        else hipLaunchKernelGGL((k_sws_down2_rgb<L, false>), grid, block, 0, stream, A);               \
+        break;
     switch (A.lay) {
-    case 0: hipLaunchKernelGGL((k_sws_down2_rgb<0>), grid, block, 0, stream, A); break;
-    case 1: hipLaunchKernelGGL((k_sws_down2_rgb<1>), grid, block, 0, stream, A); break;
-    case 2: hipLaunchKernelGGL((k_sws_down2_rgb<2>), grid, block, 0, stream, A); break;
-    case 3: hipLaunchKernelGGL((k_sws_down2_rgb<3>), grid, block, 0, stream, A); break;
-    case 4: hipLaunchKernelGGL((k_sws_down2_rgb<4>), grid, block, 0, stream, A); break;
-    case 5: hipLaunchKernelGGL((k_sws_down2_rgb<5>), grid, block, 0, stream, A); break;
+    DR_L(0) DR_L(1) DR_L(2) DR_L(3) DR_L(4) DR_L(5)
     default:
         ffhip_set_error("ffhip_sws: packed layout %d is not one of the RGB writer's", A.lay);
         return FFHIP_EINVAL;
     }
+#undef DR_L
     LAUNCH_CHECK();
     return 0;
 }

@@ -188,11 +188,12 @@ int  ffhip_down2_virtual_bank(const int16_t *filter, const int32_t *pos, int fsi
 #endif
 /* exact 2:1 from NV12 / NV21 into packed RGB, fused (k_sws_down2_rgb in sws_down2.hip) */
 struct FFHipDn2RgbArgs {
-    const uint8_t *ysrc, *csrc;         /* the luma plane; the interleaved chroma plane */
+    const uint8_t *ysrc, *csrc;         /* the luma plane; the interleaved chroma plane, or the U plane */
+    const uint8_t *csrc2;               /* planar chroma: the V plane (same stride and frame pitch as U's), else null */
     uint8_t *dst;
     ptrdiff_t ysstride, csstride, dstride;
     size_t ysfp, csfp, dfp;
-    int swap;                           /* NV21: v at the even bytes */
+    int swap;                           /* NV21: v at the even bytes (interleaved chroma only) */
     int srcH, chrH, dstH;               /* luma rows, chroma rows (= dstH), output rows (= srcH / 2) */
     int ngroups;                        /* groups of four pixels per output row: dstW / 4 (>= 3) */
     const uint32_t *hfv_l, *hfv_c;      /* device: virtual horizontal banks, dstW x 4 and (dstW / 2) x 4 dwords */

@@ -1538,14 +1538,14 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             uint8_t *ty = static_cast<uint8_t *>(c->rgb2_tmp), *tu = ty + yfp * (size_t)nframes, *tv = tu + cfp * (size_t)nframes;
             const char *ed = FFHIP_KNOB("FFHIP_SWS_DOWN2");
             const int chrW = a.dstW / 2;
-            if (c->dn2_luma == 2 && cstep == 2 && srcStride[0] > 0 && cus > 0 && !(ed && (ed[0] == '0' || ed[0] == 'l' || ed[0] == 't')) &&
-                !(a.dstW & 3) && a.dstW >= 12) {
-                /* ... and from an interleaved source the whole conversion in ONE kernel, no intermediate (k_sws_down2_rgb; FFHIP_SWS_DOWN2=t:
-                 * the two-stage form below) */
+            if (c->dn2_luma == 2 && (cstep == 2 || (cus == cvs && cuf == cvf)) && srcStride[0] > 0 && cus > 0 &&
+                !(ed && (ed[0] == '0' || ed[0] == 'l' || ed[0] == 't')) && !(a.dstW & 3) && a.dstW >= 12) {
+                /* ... and the whole conversion in ONE kernel, no intermediate (k_sws_down2_rgb; planar chroma: planes laid out alike;
+                 * FFHIP_SWS_DOWN2=t: the two-stage form below) */
                 FFHipDn2RgbArgs F;
                 memset(&F, 0, sizeof(F));
                 F.ysrc = s0; F.ysstride = srcStride[0]; F.ysfp = srcFramePitch[0];
-                F.csrc = s1; F.csstride = cus; F.csfp = cuf; F.swap = cv < cu;
+                F.csrc = cstep == 2 ? s1 : cu; F.csrc2 = cstep == 2 ? nullptr : cv; F.csstride = cus; F.csfp = cuf; F.swap = cstep == 2 && cv < cu;
                 F.dst = a.dst; F.dstride = a.dst_stride; F.dfp = a.dst_fp;
                 F.srcH = a.srcH; F.chrH = a.chrSrcH; F.dstH = a.dstH; F.ngroups = a.dstW / 4;
                 F.hfv_l = c->dn2_h[0]; F.hfv_c = c->dn2_h[1]; F.vfv = c->dn2_v[0];

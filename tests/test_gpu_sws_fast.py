@@ -554,10 +554,17 @@ def test_rgb_two_stage_exact_half_one_launch(sf, df, dw, dh, monkeypatch):
     _run(sf, 2 * dw, 2 * dh, df, dw, dh, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, seed=dw + dh, need="any")
 
 
+@pytest.mark.parametrize("sf,df,dw,dh", [("yuv420p", "rgb24", 200, 108), ("yuv420p", "bgra", 1288, 48), ("yuv420p", "abgr", 12, 8), ("yuv420p", "bgr24", 1032, 20),
+                                         ("yuv420p", "rgba", 260, 16), ("yuv420p", "argb", 2048, 12)])
+def test_rgb_exact_half_fused_planar(sf, df, dw, dh, monkeypatch):
+    """the fused kernel on planar chroma (12 bytes of each plane per lane and row): lane blocks' borders, ragged blocks, every layout"""
+    _run(sf, 2 * dw, 2 * dh, df, dw, dh, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "1"}, monkeypatch=monkeypatch, seed=dw + 5 * dh, need="any")
+
+
 @pytest.mark.parametrize("sf,df,dw,dh", [("nv12", "rgb24", 200, 108), ("nv21", "bgra", 1288, 48), ("nv12", "bgr24", 192, 108), ("nv21", "argb", 12, 8),
-                                         ("nv12", "abgr", 1032, 20), ("nv12", "rgba", 2048, 12)])
+                                         ("nv12", "abgr", 1032, 20), ("nv12", "rgba", 2048, 12), ("yuv420p", "rgb24", 200, 108), ("yuv420p", "bgra", 1288, 48)])
 def test_rgb_exact_half_two_stages_kept(sf, df, dw, dh, monkeypatch):
-    """from NV12 / NV21 the product runs the FUSED k_sws_down2_rgb; FFHIP_SWS_DOWN2=t keeps the two-stage form (one first-stage launch +
+    """the product runs the FUSED k_sws_down2_rgb; FFHIP_SWS_DOWN2=t keeps the two-stage form (one first-stage launch +
     k_y16_rgb with interleaved chroma): both must give the reference's bytes"""
     _run(sf, 2 * dw, 2 * dh, df, dw, dh, ffi.SWS_BICUBIC, env={"FFHIP_SWS_DOWN2": "t"}, monkeypatch=monkeypatch, seed=dw + 3 * dh, need="any")
 
