@@ -1518,6 +1518,23 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
         }
         const char *e2 = FFHIP_KNOB("FFHIP_SWS_RGB2"); /* measure build: 0 keeps the LDS-tiled kernel */
         if (c->lw_ok && topdown && !(ev && ev[0] == '0') && !(e2 && e2[0] == '0') && !(al & 3)) {
+            const char *ed = FFHIP_KNOB("FFHIP_SWS_DOWN2");
+            const int chrW = a.dstW / 2;
+            /* exact 2:1 from a 4:2:0 source: fused, no intermediate — before anything of the two-stage form (its lock, its buffer) is touched */
+            if (c->dn2_luma == 2 && (cstep == 2 || (cus == cvs && cuf == cvf)) && srcStride[0] > 0 && cus > 0 &&
+                !(ed && (ed[0] == '0' || ed[0] == 'l' || ed[0] == 't')) && !(a.dstW & 3) && a.dstW >= 12) {
+                /* ... and the whole conversion in ONE kernel, no intermediate (k_sws_down2_rgb; planar chroma: planes laid out alike;
+                 * FFHIP_SWS_DOWN2=t: the two-stage form below) */
+                FFHipDn2RgbArgs F;
+                memset(&F, 0, sizeof(F));
+                F.ysrc = s0; F.ysstride = srcStride[0]; F.ysfp = srcFramePitch[0];
+                F.csrc = cstep == 2 ? s1 : cu; F.csrc2 = cstep == 2 ? nullptr : cv; F.csstride = cus; F.csfp = cuf; F.swap = cstep == 2 && cv < cu;
+                F.dst = a.dst; F.dstride = a.dst_stride; F.dfp = a.dst_fp;
+                F.srcH = a.srcH; F.chrH = a.chrSrcH; F.dstH = a.dstH; F.ngroups = a.dstW / 4;
+                F.hfv_l = c->dn2_h[0]; F.hfv_c = c->dn2_h[1]; F.vfv = c->dn2_v[0];
+                F.nframes = nframes; F.xcd = 1; F.lay = a.bgr; F.k = c->k;
+                return ffhip_launch_down2_rgb(F, 32, stream);
+            }
             /* two stages (see the context's creation): planes of the target's geometry, pitches and frames 256-byte aligned */
             const size_t ypitch = ((size_t)2 * a.dstW + 255) & ~(size_t)255, cpitch = ((size_t)(a.dstW / 2) + 255) & ~(size_t)255;
             const size_t yfp = ypitch * (size_t)a.dstH, cfp = cpitch * (size_t)a.dstH, need = (yfp + 2 * cfp) * (size_t)nframes;
@@ -1536,22 +1553,6 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 c->rgb2_tmp_sz = need;
             }
             uint8_t *ty = static_cast<uint8_t *>(c->rgb2_tmp), *tu = ty + yfp * (size_t)nframes, *tv = tu + cfp * (size_t)nframes;
-            const char *ed = FFHIP_KNOB("FFHIP_SWS_DOWN2");
-            const int chrW = a.dstW / 2;
-            if (c->dn2_luma == 2 && (cstep == 2 || (cus == cvs && cuf == cvf)) && srcStride[0] > 0 && cus > 0 &&
-                !(ed && (ed[0] == '0' || ed[0] == 'l' || ed[0] == 't')) && !(a.dstW & 3) && a.dstW >= 12) {
-                /* ... and the whole conversion in ONE kernel, no intermediate (k_sws_down2_rgb; planar chroma: planes laid out alike;
-                 * FFHIP_SWS_DOWN2=t: the two-stage form below) */
-                FFHipDn2RgbArgs F;
-                memset(&F, 0, sizeof(F));
-                F.ysrc = s0; F.ysstride = srcStride[0]; F.ysfp = srcFramePitch[0];
-                F.csrc = cstep == 2 ? s1 : cu; F.csrc2 = cstep == 2 ? nullptr : cv; F.csstride = cus; F.csfp = cuf; F.swap = cstep == 2 && cv < cu;
-                F.dst = a.dst; F.dstride = a.dst_stride; F.dfp = a.dst_fp;
-                F.srcH = a.srcH; F.chrH = a.chrSrcH; F.dstH = a.dstH; F.ngroups = a.dstW / 4;
-                F.hfv_l = c->dn2_h[0]; F.hfv_c = c->dn2_h[1]; F.vfv = c->dn2_v[0];
-                F.nframes = nframes; F.xcd = 1; F.lay = a.bgr; F.k = c->k;
-                return ffhip_launch_down2_rgb(F, 32, stream);
-            }
             if (c->dn2_luma == 2 && srcStride[0] > 0 && !(ed && (ed[0] == '0' || ed[0] == 'l')) && chrW % (cstep == 2 ? 2 : 4) == 0 &&
                 chrW / (cstep == 2 ? 2 : 4) >= 3 && cus > 0 && cvs > 0) {
                 /* exact 2:1 with a chroma line per output line: luma and chroma in ONE launch of the static-schedule kernel (the chroma
