@@ -232,6 +232,45 @@ __device__ __forceinline__ void dn_v4h(uint32_t &o0, uint32_t &o1, const uint32_
           "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(kround), "v"(sh), "v"(maxpk));
 }
 
+/* ff_dither_8x8_128 (libswscale/output.c:70-79): the ordered dither of an 8-bit target fed from a deeper source */
+__constant__ __attribute__((aligned(8))) uint8_t dn_dither[8][8] = {
+    {  36, 68,  60, 92,  34, 66,  58, 90, }, { 100,  4, 124, 28,  98,  2, 122, 26, }, {  52, 84,  44, 76,  50, 82,  42, 74, },
+    { 116, 20, 108, 12, 114, 18, 106, 10, }, {  32, 64,  56, 88,  38, 70,  62, 94, }, {  96,  0, 120, 24, 102,  6, 126, 30, },
+    {  48, 80,  40, 72,  54, 86,  46, 78, }, { 112, 16, 104,  8, 118, 22, 110, 14, },
+};
+/* a row of an 8-bit target fed from a deeper source (yuv2planeX_8_c / yuv2nv12cX_c, output.c:468-529): every sample its own seed
+ * dither << 12, >> 19, clip to 8 bits, four bytes in sample order */
+__device__ __forceinline__ uint32_t dn_v4d(const uint32_t (&R0)[4], const uint32_t (&R1)[4], const uint32_t (&R2)[4], const uint32_t (&R3)[4],
+                                           uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const int (&sd)[4])
+{
+    uint32_t out;
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %1, %5, %21, %25\n\t"
+        "v_dot2_i32_i16 %2, %6, %21, %26\n\t"
+        "v_dot2_i32_i16 %3, %7, %21, %27\n\t"
+        "v_dot2_i32_i16 %4, %8, %21, %28\n\t"
+        "v_dot2_i32_i16 %1, %9, %22, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %22, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %22, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %22, %4\n\t"
+        "v_dot2_i32_i16 %1, %13, %23, %1\n\t"
+        "v_dot2_i32_i16 %2, %14, %23, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %23, %3\n\t"
+        "v_dot2_i32_i16 %4, %16, %23, %4\n\t"
+        "v_dot2_i32_i16 %1, %17, %24, %1\n\t"
+        "v_dot2_i32_i16 %2, %18, %24, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %24, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %24, %4\n\t"
+        "v_ashr_pk_u8_i32 %0, %1, %2, 19\n\t"
+        "s_nop 1\n\t"
+        "v_ashr_pk_u8_i32 %0, %3, %4, 19 op_sel:[0,0,0,1]"
+        : "=&v"(out), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(R0[0]), "v"(R0[1]), "v"(R0[2]), "v"(R0[3]), "v"(R1[0]), "v"(R1[1]), "v"(R1[2]), "v"(R1[3]),
+          "v"(R2[0]), "v"(R2[1]), "v"(R2[2]), "v"(R2[3]), "v"(R3[0]), "v"(R3[1]), "v"(R3[2]), "v"(R3[3]),
+          "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(sd[0]), "v"(sd[1]), "v"(sd[2]), "v"(sd[3]));
+    return out;
+}
+
 /* the same row, 8-bit pipeline, NOT clipped: t[i] >> 19 as int16 pairs — the luma plane of a packed-RGB target's first stage
  * (yuv2rgb_X reads the sums unclipped, libswscale/output.c:1814-1835; sws_y16rgb.hip is the second stage) */
 __device__ __forceinline__ void dn_v4y(uint32_t &o0, uint32_t &o1, const uint32_t (&R0)[4], const uint32_t (&R1)[4], const uint32_t (&R2)[4],
@@ -481,7 +520,22 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
                 load_next(w0); load_next(w1);
                 const uint32_t c0 = c16[4 * k], c1 = c16[4 * k + 1], c2 = c16[4 * k + 2], c3 = c16[4 * k + 3];
                 uint32_t off = doff;
-                if (HB) {
+                if (HB && J.hb_ddepth == 8) { /* uniform */
+                    /* an 8-bit target (round 5: a 10-bit decoder's 4K frames for a 1080p 8-bit consumer): the ordered dither's entry of
+                     * every sample — (x + offset) & 7 with offset 3 for the V channel / plane (yuv2nv12cX_c, vscale.c's chroma call) */
+                    const uint2 drow = *reinterpret_cast<const uint2 *>(dn_dither[(y + k) & 7]);
+                    int sdv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int idx = (PAIR ? 2 * g + (i >> 1) + ((i & 1) ? 3 : 0) : 4 * g + i + J.dither_off) & 7;
+                        sdv[i] = (int)((((idx >= 4 ? drow.y : drow.x) >> (8 * (idx & 3))) & 255u) << 12);
+                    }
+                    const uint32_t out = dn_v4d(ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, sdv);
+                    uint32_t off8 = 4u * (uint32_t)g;
+                    asm volatile("" : "+v"(off8));
+                    if (act)
+                        *(dn_g1)((dn_gp)dr + off8) = out;
+                } else if (HB) {
                     typedef unsigned short dn_h2 __attribute__((ext_vector_type(2)));
                     typedef dn_u2 __attribute__((address_space(1))) *dn_g2;
                     uint32_t o0, o1;

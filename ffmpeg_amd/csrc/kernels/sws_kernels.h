@@ -174,8 +174,10 @@ struct FFHipDn2Job {
     const uint32_t *hfv;                /* device: virtual horizontal bank, dstW x 4 dwords */
     const uint32_t *vfv;                /* device: virtual vertical bank, (dstH + 8) x 4 dwords, 64-byte aligned */
     int ncb, nstrips, steps_per_strip, unit_begin;
-    int hb_sdepth, hb_ddepth, hb_smsb, hb_dmsb; /* samples above 8 bits (k_sws_down2<1>; 0: bytes), as in FFHipUp2Job; groups are 8 destination bytes */
+    int hb_sdepth, hb_ddepth, hb_smsb, hb_dmsb; /* samples above 8 bits (k_sws_down2<1>; 0: bytes), as in FFHipUp2Job; groups are 8 destination bytes
+                                         * (hb_ddepth == 8: an 8-bit target with the ordered dither, 4 destination bytes) */
     int y16;                            /* 8-bit plane job: the vertical sums >> 19 stored UNCLIPPED as int16 (8 bytes per group): see FFHipLwJob.y16 */
+    int dither_off;                     /* hb_ddepth == 8, plane job: the dither column offset (3 for the V plane) */
     int v1;                             /* 8-bit job without a vertical filter: dstH = srcH rows, each clip_u8((horizontal sum + 64) >> 7) (sws_down2.hip) */
 };
 struct FFHipDn2Args {

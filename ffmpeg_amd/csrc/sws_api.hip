@@ -678,7 +678,9 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 up2_build(c, limits);
             /* ... and exact 2:1 (k_sws_down2<1>), banks of up to 8 taps */
             const int cdw = c->d[1].n, cdh = c->d[3].n;
-            if (sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl == dl && sl != 2 && t->src_range == t->dst_range &&
+            /* (round 5: also into an 8-bit target laid out alike — P01x -> NV12, planar -> planar — with the ordered dither on the way out) */
+            const bool dn8 = dd == 8 && (sl == 1 ? t->dstFormat == FFHIP_PIX_FMT_NV12 : !fmt_nv(t->dstFormat));
+            if (sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14 && sl == dl) || dn8) && sl != 2 && t->src_range == t->dst_range &&
                 t->srcW == 2 * t->dstW && t->srcH == 2 * t->dstH && cw == 2 * cdw && chh == 2 * cdh &&
                 !(t->dstW & 3) && t->dstW >= 12 && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
@@ -1193,7 +1195,8 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 j.srcH = sh_; j.dstH = dh_;
                 j.ngroups = pair ? dw_ / 2 : dw_ / 4;
                 j.hfv = c->dn2_h[which]; j.vfv = c->dn2_v[which];
-                j.hb_sdepth = sd; j.hb_ddepth = dd; j.hb_smsb = sl == 1; j.hb_dmsb = dl == 1;
+                j.hb_sdepth = sd; j.hb_ddepth = dd; j.hb_smsb = sl == 1; j.hb_dmsb = dd > 8 && dl == 1;
+                j.dither_off = plane == 2 ? 3 : 0;
                 ffhip_down2_plan_job(&j, 32);
             };
             dnjob(0, 0, t.dstW, t.srcH, t.dstH, 0);

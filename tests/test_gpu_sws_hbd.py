@@ -151,7 +151,23 @@ TO8_CASES = [
     ("yuv422p10le", 384, 216, "yuv422p", 256, 144, ffi.SWS_BICUBIC),
     ("yuv444p10le", 192, 108, "yuv444p", 288, 162, ffi.SWS_BILINEAR),
     ("p010le", 1048, 600, "nv12", 700, 400, ffi.SWS_BICUBIC),         # several column blocks and strips
+    # exact 2:1 into 8 bits, layouts alike: k_sws_down2<1> with the ordered dither on the way out
+    ("yuv420p10le", 384, 216, "yuv420p", 192, 108, ffi.SWS_BICUBIC),  # planar: the V plane's dither three entries on
+    ("p010le", 2576, 96, "nv12", 1288, 48, ffi.SWS_BICUBIC),          # several lane blocks, ragged last one
+    ("yuv420p12le", 2064, 40, "yuv420p", 1032, 20, ffi.SWS_BILINEAR),
+    ("yuv444p10le", 384, 216, "yuv444p", 192, 108, ffi.SWS_BICUBIC),
 ]
+
+
+def test_exact_half_into_8_bits_takes_the_static_kernel():
+    from ffmpeg_amd import swscale as S
+    for sname, dname in (("p010le", "nv12"), ("yuv420p10le", "yuv420p")):
+        ctx = S.SwsContext(384, 216, FMT[sname][0], 192, 108, FMT[dname][0], ffi.SWS_BICUBIC)
+        assert ctx.paths & 16, ctx.paths
+        ctx.close()
+    ctx = S.SwsContext(384, 216, FMT["yuv420p10le"][0], 192, 108, FMT["nv12"][0], ffi.SWS_BICUBIC)   # planar in, pairs out: the walker
+    assert ctx.walk16_path and not ctx.paths & 16
+    ctx.close()
 
 
 @pytest.mark.parametrize("variant", ["product", "tiled"])
@@ -163,7 +179,8 @@ def test_deeper_source_into_8_bits(case, variant, monkeypatch):
     else:
         sname, sw, sh, dname, dw, dh, flags = case
         ctx = S.SwsContext(sw, sh, FMT[sname][0], dw, dh, FMT[dname][0], flags)
-        assert ctx.walk16_path, "case does not reach the 16-bit column walker"
+        # (exact 2:1 between formats laid out alike runs the static-schedule kernel's 16-bit twin with the dithered 8-bit stage: bit 4)
+        assert ctx.walk16_path or ctx.paths & 16, "case reaches neither the 16-bit column walker nor the exact-2:1 kernel"
         ctx.close()
     _run(case)
 
