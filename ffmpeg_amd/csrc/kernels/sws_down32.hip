@@ -1,0 +1,290 @@
+/*
+ * sws_down32.hip — the fused H+V scaler for EXACT 3:2 down-scaling (1080p -> 720p, 4K -> 1440p, 1440p -> 960p ...) with banks of up to
+ * 6 taps in both directions (bicubic, bilinear, point), planes and byte-interleaved U/V pairs (NV12 / NV21) in and out (round 5).
+ *
+ * Arithmetic: hScale8To15_c (libswscale/swscale.c:128-142), nv12ToUV_c (input.c:936), yuv2planeX_8_c / yuv2nv12cX_c (output.c:468-529):
+ * int32 sums, >> 7 and min(., 32767) for the horizontal pass, the 64 << 12 seed, >> 19 and the clip to 8 bits for the vertical one.
+ * Same results as sws_lwalk.hip / sws_scale.hip, bit for bit (tests/test_gpu_sws_fast.py).
+ *
+ * The commonest down-scale that is not 2:1 ran on the wide walker (LDS row buffers and a vertical ring in LDS, dynamically indexed: 0.17 –
+ * 0.24 of HBM).  At exactly 3:2 everything is regular with period (3 in, 2 out):
+ *  - output x = 2k + j reads source samples 3k - 2 + j .. 3k + 3 + j (initFilter, libswscale/utils.c:519-561, folds the taps that fall
+ *    outside the row onto the edge sample: the regular bank over an edge-REPLICATED row with its own coefficients next to either edge —
+ *    ffhip_d32_virtual_bank re-expresses every bank row that way, tap by tap, else this kernel is not used).  A lane owns 8 outputs = 4
+ *    periods = 12 source samples: 20 source bytes at the dword-aligned offset 12g - 4, every window a FIXED byte position in them (static
+ *    v_perm_b32 selectors), three v_dot2_i32_i16 per output.  A U/V pair is the same 20 bytes: 4 columns x 2 channels per lane.
+ *  - the vertical schedule is static with period (3 source rows, 2 output rows): the pairs P(q) = (row q, row q + 1) of horizontally
+ *    filtered samples for EVERY q (an even output row starts on 3m - 2, an odd one on 3m - 1) sit in a ring of six in registers; after
+ *    source row r = 0 or 1 (mod 3) an output row is due and reads P(r - 5), P(r - 3), P(r - 1).  Six source rows per loop trip make
+ *    every ring index a constant.  The rows' coefficient pairs are wave-uniform (scalar loads).
+ * All arithmetic through compiler builtins (the compiler schedules around the DOT hazard); 8 bytes out per lane and row.
+ * (Hand-scheduled DOT blocks as in sws_down2.hip were 4 % faster and are not in: the round's GPU budget ended before they were exact.)
+ */
+#include "common.h"
+#include "sws_kernels.h"
+
+typedef short d3_s2 __attribute__((ext_vector_type(2)));
+typedef uint32_t d3_u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t d3_u4 __attribute__((ext_vector_type(4)));
+typedef d3_u4 __attribute__((aligned(4))) d3_u4a;
+typedef d3_u2 __attribute__((aligned(4))) d3_u2a;
+typedef const uint8_t __attribute__((address_space(1))) *d3_gcp;
+typedef uint8_t __attribute__((address_space(1))) *d3_gp;
+typedef const d3_u4a __attribute__((address_space(1))) *d3_gc4;
+typedef const uint32_t __attribute__((address_space(1))) *d3_gc1;
+typedef d3_u2a __attribute__((address_space(1))) *d3_g2;
+
+__device__ __forceinline__ int d3_dot(uint32_t p, uint32_t c, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(d3_s2, p), __builtin_bit_cast(d3_s2, c), acc, false);
+}
+/* clip_u8(a) | clip_u8(b) << 8 | clip_u8(c) << 16 | clip_u8(d) << 24 of values already shifted */
+__device__ __forceinline__ uint32_t d3_pk4(int a, int b, int c, int d)
+{
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 0\n\t"
+        "v_ashr_pk_u8_i32 %0, %3, %4, 0 op_sel:[0,0,0,1]"
+        : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return r;
+}
+
+/* the int16 pair (byte q, byte q + STEP) of the 20 bytes in w[0..4]: q and STEP are compile-time constants */
+template <int Q, int STEP>
+__device__ __forceinline__ uint32_t d3_pair(const uint32_t (&w)[5])
+{
+    constexpr int i = Q >> 2, r = Q & 3;
+    constexpr uint32_t sel = 0x0c000c00u | (uint32_t)(r + STEP) << 16 | (uint32_t)r;
+    return __builtin_amdgcn_perm(w[i + 1 > 4 ? 4 : i + 1], w[i], sel);
+}
+
+template <int PAIR>
+__device__ __forceinline__ void d32_unit(const FFHipD32Job &J, int frame, int gbase, int strip, int lane)
+{
+    const int graw = gbase + lane;
+    const bool act = graw < J.ngroups;
+    const int g = min(graw, J.ngroups - 1);
+    const bool lb = g == 0, rb = g == J.ngroups - 1;
+    const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
+    /* the first / last lane of a row loads its 20 bytes one dword further inside and rebuilds the replicated ones */
+    const uint32_t soff = (uint32_t)(lb ? 0 : 12 * g - 4 - (rb ? 4 : 0));
+    uint32_t cf[8][3];
+    {
+        /* plane: outputs 8g .. 8g + 7; pair: columns 4g .. 4g + 3, both channels of a column share its coefficients */
+        const uint32_t *p = J.hfv + (size_t)g * (PAIR ? 12 : 24);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                cf[j][k] = p[3 * (PAIR ? j >> 1 : j) + k];
+    }
+    const int a = strip * J.strip_rows, b = min(a + J.strip_rows, J.dstH); /* this strip's output rows; a is a multiple of 4 */
+    const uint8_t *sbase = J.src + (size_t)frame * J.sfp;
+    uint8_t *dbase = J.dst + (size_t)frame * J.dfp;
+    const ptrdiff_t sstride = J.sstride, dstride = J.dstride;
+    const int srcH = J.srcH;
+    const bool swap = PAIR && J.swap;
+
+    auto load_row = [&](int r, uint32_t (&w)[5]) {
+        const uint8_t *p = sbase + (ptrdiff_t)min(max(r, 0), srcH - 1) * sstride; /* rows above / below the plane replicate the edge row */
+        const d3_u4 v = *(d3_gc4)((d3_gcp)p + soff);
+        const uint32_t e = *(d3_gc1)((d3_gcp)p + soff + 16);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; w[4] = e;
+    };
+    /* the horizontal pass of one source row: this lane's 8 samples, >> 7 (sample order: plane x0..x7; pair u0 v0 u1 v1 u2 v2 u3 v3) */
+    auto hpass = [&](const uint32_t (&raw)[5], int (&h)[8]) {
+        uint32_t w[5] = { raw[0], raw[1], raw[2], raw[3], raw[4] };
+        if (border) {
+            const uint32_t f0 = PAIR ? __builtin_amdgcn_perm(raw[0], raw[0], 0x01000100u) : __builtin_amdgcn_perm(raw[0], raw[0], 0x00000000u);
+            const uint32_t f4 = PAIR ? __builtin_amdgcn_perm(raw[4], raw[4], 0x03020302u) : __builtin_amdgcn_perm(raw[4], raw[4], 0x03030303u);
+            w[0] = lb ? f0 : rb ? raw[1] : raw[0];
+            w[1] = lb ? raw[0] : rb ? raw[2] : raw[1];
+            w[2] = lb ? raw[1] : rb ? raw[3] : raw[2];
+            w[3] = lb ? raw[2] : rb ? raw[4] : raw[3];
+            w[4] = lb ? raw[3] : rb ? f4 : raw[4];
+        }
+        if (swap) { /* uniform: the channel wanted at the even destination bytes sits at the odd source bytes */
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+                w[i] = __builtin_amdgcn_perm(w[i], w[i], 0x02030001u);
+        }
+        /* window start of output j, in bytes from the loaded base (= sample 12g - 4, column 6g - 2):
+         *   plane: j -> 2 + 3 (j >> 1) + (j & 1);   pair: sample e = 2 col + ch -> 2 (3 (col >> 1) + (col & 1)) + ch
+         * (the windows overlap: the compiler folds the 24 pairs into the 15 / 18 distinct ones) */
+#define D3_OUT(j)                                                                                                                        \
+        {                                                                                                                                \
+            constexpr int S = PAIR ? 2 * (3 * (((j) >> 1) >> 1) + (((j) >> 1) & 1)) + ((j) & 1) : 2 + 3 * ((j) >> 1) + ((j) & 1);       \
+            constexpr int ST = PAIR ? 2 : 1; /* the next sample of the same channel */                                                  \
+            int acc = d3_dot(d3_pair<S, ST>(w), cf[j][0], 0);                                                                            \
+            acc = d3_dot(d3_pair<S + 2 * ST, ST>(w), cf[j][1], acc);                                                                     \
+            acc = d3_dot(d3_pair<S + 4 * ST, ST>(w), cf[j][2], acc);                                                                     \
+            h[j] = acc >> 7;                                                                                                             \
+        }
+        D3_OUT(0) D3_OUT(1) D3_OUT(2) D3_OUT(3) D3_OUT(4) D3_OUT(5) D3_OUT(6) D3_OUT(7)
+#undef D3_OUT
+    };
+
+    /* source rows in trips of six from rbase = 3 (a / 2) - 6 (a multiple of 6): the first trip only fills the ring */
+    const int rbase0 = 3 * (a >> 1) - 6;
+    uint32_t ring[6][8];
+    int hprev[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+        hprev[c] = 0;
+#pragma unroll
+    for (int s = 0; s < 6; s++)
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            ring[s][c] = 0;
+    uint32_t nxt[2][5];
+    load_row(rbase0 + 4, nxt[0]);
+    load_row(rbase0 + 5, nxt[1]);
+    const uint32_t *vt = J.vfv;
+    const uint32_t doff = 8u * (uint32_t)g;
+
+    for (int rbase = rbase0; ; rbase += 6) {
+        const bool first = rbase == rbase0; /* uniform */
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            if (first && u < 4) /* (rows before 3 (a / 2) - 2 feed no output of this strip) */
+                continue;
+            const int r = rbase + u;
+            uint32_t cur[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+                cur[i] = nxt[u & 1][i];
+            load_row(r + 2, nxt[u & 1]);
+            int h[8];
+            hpass(cur, h);
+            /* P(r - 1) = (row r - 1, row r): int16-saturated = min(., 32767) + truncation (no sum of an admitted bank falls below -32768) */
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                ring[(u + 5) % 6][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));
+                hprev[c] = h[c];
+            }
+            if (u % 3 != 2) {
+                /* r = 3 (m + 1): output row 2m;  r = 3m + 4: output row 2m + 1 */
+                const int y = u % 3 == 0 ? 2 * (r / 3) - 2 : 2 * ((r - 1) / 3) - 1;
+                if (y >= b)
+                    return;
+                if (y >= a) { /* uniform */
+                    const uint32_t c0 = vt[4 * y], c1 = vt[4 * y + 1], c2 = vt[4 * y + 2];
+                    int t[8];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        int acc = d3_dot(ring[(u + 1) % 6][c], c0, 64 << 12);
+                        acc = d3_dot(ring[(u + 3) % 6][c], c1, acc);
+                        acc = d3_dot(ring[(u + 5) % 6][c], c2, acc);
+                        t[c] = acc >> 19;
+                    }
+                    d3_u2 o;
+                    o.x = d3_pk4(t[0], t[1], t[2], t[3]);
+                    o.y = d3_pk4(t[4], t[5], t[6], t[7]);
+                    if (act)
+                        *(d3_g2)((d3_gp)(dbase + (ptrdiff_t)y * dstride) + doff) = o;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sws_down32(FFHipD32Args A)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
+    if (gw >= (uint32_t)A.units_per_frame * (uint32_t)A.nframes)
+        return;
+    const int frame = (int)(gw / (uint32_t)A.units_per_frame);
+    const int u = (int)(gw - (uint32_t)frame * (uint32_t)A.units_per_frame);
+    int j = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
+    const FFHipD32Job &J = A.job[j];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.pair)
+        d32_unit<1>(J, frame, cb * 64, strip, lane);
+    else
+        d32_unit<0>(J, frame, cb * 64, strip, lane);
+}
+
+/* ================================================================================================== */
+/* host side */
+
+/*
+ * Re-express a bank of an exact 3:2 down-scale (at most 6 taps) as coefficients on the REGULAR windows of the edge-replicated row:
+ * output x reads samples clamp(3 (x >> 1) - 2 + (x & 1) + k), k = 0..5.  Every non-zero tap of the bank row must sit on one of those
+ * samples; taps the reference folded onto the edge sample land on one of the replicas.  Output: n_dst x `pitch` dwords (pitch 3 or 4),
+ * (c0, c1) (c2, c3) (c4, c5) as int16 pairs.  Returns 0 when the bank is not of this shape.
+ */
+int ffhip_d32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pitch, std::vector<uint32_t> *out)
+{
+    if (2 * n_src != 3 * n_dst || fsize < 1 || fsize > 12 || (n_dst & 1) || pitch < 3)
+        return 0;
+    out->assign((size_t)n_dst * pitch, 0);
+    for (int x = 0; x < n_dst; x++) {
+        const int s0 = 3 * (x >> 1) - 2 + (x & 1);
+        int16_t v[6] = { 0 };
+        bool used[6] = { false };
+        for (int i = 0; i < fsize; i++) {
+            const int16_t c = filter[(size_t)x * fsize + i];
+            if (!c)
+                continue;
+            const int p = pos[x] + i;
+            if (p < 0 || p >= n_src)
+                return 0;
+            int k = 0;
+            for (; k < 6; k++) {
+                int q = s0 + k;
+                q = q < 0 ? 0 : q >= n_src ? n_src - 1 : q;
+                if (q == p && !used[k])
+                    break;
+            }
+            if (k == 6)
+                return 0;
+            used[k] = true;
+            v[k] = c;
+        }
+        for (int k = 0; k < 3; k++)
+            (*out)[(size_t)pitch * x + k] = (uint16_t)v[2 * k] | ((uint32_t)(uint16_t)v[2 * k + 1] << 16);
+    }
+    return 1;
+}
+
+int ffhip_launch_down32(FFHipD32Args &A, hipStream_t stream)
+{
+    if (A.nframes <= 0)
+        return 0;
+    /* strips of 32 output rows, shorter until the launch has the waves the chip keeps resident (a strip re-filters five source rows) */
+    for (int want = 32; ; want >>= 1) {
+        long long u = 0;
+        for (int i = 0; i < A.njobs; i++) {
+            FFHipD32Job &j = A.job[i];
+            if (j.ngroups < 3 || j.dstH <= 0 || (j.dstH & 1)) {
+                ffhip_set_error("ffhip_sws: the exact-3:2 kernel takes rows of three groups or more and an even number of output rows");
+                return FFHIP_EINVAL;
+            }
+            const int n = cdiv(j.dstH, want);
+            j.strip_rows = cdiv(cdiv(j.dstH, n), 4) * 4;
+            j.nstrips = cdiv(j.dstH, j.strip_rows);
+            j.ncb = cdiv(j.ngroups, 64);
+            u += (long long)j.ncb * j.nstrips;
+        }
+        if (u * A.nframes >= 4096 || want <= 8)
+            break;
+    }
+    int u = 0;
+    for (int i = 0; i < A.njobs; i++) {
+        A.job[i].unit_begin = u;
+        u += A.job[i].ncb * A.job[i].nstrips;
+    }
+    A.units_per_frame = u;
+    const long long waves = (long long)u * A.nframes;
+    if (waves >= (1LL << 31)) {
+        ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
+        return FFHIP_EINVAL;
+    }
+    hipLaunchKernelGGL(k_sws_down32, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -188,6 +188,29 @@ struct FFHipDn2Args {
 #ifdef __cplusplus
 int  ffhip_down2_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, std::vector<uint32_t> *out);
 #endif
+/*
+ * Exact 3:2 down-scaling (sws_down32.hip): a job is one plane or one byte-interleaved U/V pair (NV12 / NV21 in and out).
+ */
+struct FFHipD32Job {
+    const uint8_t *src; uint8_t *dst;   /* pair: the interleaved plane (the lower of the two channel pointers) */
+    ptrdiff_t sstride, dstride;
+    size_t sfp, dfp;
+    int pair, swap;                     /* swap: the channel at the EVEN destination bytes sits at the ODD source bytes */
+    int srcH, dstH;                     /* source rows; output rows = srcH * 2 / 3, even */
+    int ngroups;                        /* 8-byte destination groups per row: plane dstW / 8, pair dstW / 4 (>= 3) */
+    const uint32_t *hfv;                /* device: virtual horizontal bank, dstW x 3 dwords */
+    const uint32_t *vfv;                /* device: virtual vertical bank, dstH x 4 dwords */
+    int ncb, nstrips, strip_rows, unit_begin;
+};
+struct FFHipD32Args {
+    FFHipD32Job job[3];
+    int njobs, units_per_frame, nframes;
+};
+#ifdef __cplusplus
+int  ffhip_d32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pitch, std::vector<uint32_t> *out);
+#endif
+int  ffhip_launch_down32(FFHipD32Args &A, hipStream_t stream);
+
 /* exact 2:1 from NV12 / NV21 into packed RGB, fused (k_sws_down2_rgb in sws_down2.hip) */
 struct FFHipDn2RgbArgs {
     const uint8_t *ysrc, *csrc;         /* the luma plane; the interleaved chroma plane, or the U plane */

@@ -79,6 +79,9 @@ struct FFHipSwsContext {
     int f444_ok = 0;  /* planar 4:4:4 into packed RGB at the source's size: four one-tap banks, the full-chroma writer (sws_full444.hip) */
     int dn2_luma = 0; /* an RGB context's luma banks alone (its first stage's luma job on k_sws_down2, the chroma on the wide walker); 2: the chroma planes there as well (no vertical filter: FFHipDn2Job.v1) */
     void *dn2_dev = nullptr;
+    int d32_ok = 0;   /* exact 3:2 down in both directions: the static-schedule kernel of sws_down32.hip */
+    void *d32_dev = nullptr;
+    const uint32_t *d32_h[2] = { nullptr, nullptr }, *d32_v[2] = { nullptr, nullptr };
     const uint32_t *dn2_h[2] = { nullptr, nullptr }, *dn2_v[2] = { nullptr, nullptr };
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
     int mf_ok = 0, mf_chr_pair = 0, mf_ntiles[2] = { 0, 0 };
@@ -470,6 +473,32 @@ static void dn2_build(FFHipSwsContext *c, const int nsrc[4])
         c->dn2_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
         c->dn2_ok = 1;
     }
+}
+
+/* exact 3:2: the banks (up to 6 taps) as virtual banks on the windows 3 (x >> 1) - 2 + (x & 1) .. + 5 of the edge-replicated rows, on the
+ * device; sets c->d32_ok when every bank row is of that shape (sws_down32.hip) */
+static void d32_build(FFHipSwsContext *c, const int nsrc[4])
+{
+    std::vector<uint32_t> vb[4];
+    for (int i = 0; i < 4; i++)
+        if (!ffhip_d32_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], i < 2 ? 3 : 4, &vb[i]))
+            return;
+    size_t uo[4], ut = 0;
+    for (int i = 0; i < 4; i++) {
+        uo[i] = ut;
+        ut += (vb[i].size() * 4 + 255) & ~(size_t)255;
+    }
+    if (hipMalloc(&c->d32_dev, ut) != hipSuccess)
+        return;
+    uint8_t *b = static_cast<uint8_t *>(c->d32_dev);
+    for (int i = 0; i < 4; i++)
+        if (hipMemcpy(b + uo[i], vb[i].data(), vb[i].size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return;
+    c->d32_h[0] = reinterpret_cast<const uint32_t *>(b + uo[0]);
+    c->d32_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
+    c->d32_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
+    c->d32_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
+    c->d32_ok = 1;
 }
 
 /* the luma banks alone at exact 2:1, for a packed-RGB target's first stage (its chroma goes 2:1 across but 1:1 or 2:1 down by the
@@ -930,6 +959,14 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
             dn2_build(c, nsrc);
         }
+        /* exact 3:2 in both directions (1080p -> 720p, 4K -> 1440p), chroma laid out alike on both sides: sws_down32.hip */
+        if (ffhip_cw_bank_nowrap(c->f[0].data(), c->d[0].size, c->d[0].n) && ffhip_cw_bank_nowrap(c->f[1].data(), c->d[1].size, c->d[1].n) &&
+            2 * l.srcW == 3 * l.dstW && 2 * l.srcH == 3 * l.dstH && 2 * ch.srcW == 3 * ch.dstW && 2 * ch.srcH == 3 * ch.dstH &&
+            fmt_nv(t->srcFormat) == fmt_nv(t->dstFormat) && !(l.dstW & 7) && l.dstW >= 24 && !(l.dstH & 1) && !(ch.dstH & 1) &&
+            (fmt_nv(t->srcFormat) ? !(ch.dstW & 3) && ch.dstW >= 12 : !(ch.dstW & 7) && ch.dstW >= 24) && t->dst_alpha_fill != 2) {
+            const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
+            d32_build(c, nsrc);
+        }
         /* MFMA variant: same banks; chroma either byte-interleaved on both sides or planar on both sides */
         const bool nv_in = fmt_nv(t->srcFormat), nv_out = fmt_nv(t->dstFormat);
         if (c->cw_opt && nv_in == nv_out) {
@@ -1015,7 +1052,7 @@ extern "C" int ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) + (c->mix_dn2 ? 1024 : 0) + (c->mix_up2 ? 2048 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) + (c->mix_dn2 ? 1024 : 0) + (c->mix_up2 ? 2048 : 0) + (c->d32_ok ? 4096 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
@@ -1099,6 +1136,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->w16_dev);
     if (c->dn2_dev)
         (void)hipFree(c->dn2_dev);
+    if (c->d32_dev)
+        (void)hipFree(c->d32_dev);
     if (c->dev_ntables)
         (void)hipFree(c->dev_ntables);
     if (c->dev_wtables)
@@ -2013,6 +2052,32 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 dnjob(ch, 1, ch.src[k], ch.src_stride[k], ch.src_fp[k], ch.dst[k], ch.dst_stride[k], ch.dst_fp[k], 0, 0);
         }
         return ffhip_launch_down2(D, stream);
+    }
+    const char *e3 = FFHIP_KNOB("FFHIP_SWS_DOWN32"); /* measure build: 0 keeps the wide walker */
+    if (!(al2 & 3) && c->d32_ok && !neg && !c->luma_pass && !(e3 && e3[0] == '0') && !(ev && ev[0] == '0')) {
+        /* exact 3:2: static schedule with period (3 in, 2 out), no LDS (sws_down32.hip) */
+        FFHipD32Args D;
+        memset(&D, 0, sizeof(D));
+        D.nframes = nframes;
+        auto djob = [&](const FFHipScalePlaneArgs &p, int which, const uint8_t *src, ptrdiff_t ss, size_t sf, uint8_t *dst, ptrdiff_t dsr, size_t df,
+                        int pair, int swap) {
+            FFHipD32Job &j = D.job[D.njobs++];
+            j.src = src; j.dst = dst; j.sstride = ss; j.dstride = dsr; j.sfp = sf; j.dfp = df;
+            j.pair = pair; j.swap = swap;
+            j.srcH = p.srcH; j.dstH = p.dstH;
+            j.ngroups = pair ? p.dstW / 4 : p.dstW / 8;
+            j.hfv = c->d32_h[which]; j.vfv = c->d32_v[which];
+        };
+        djob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0, 0);
+        if (ch.src_step == 2) {
+            const bool ssw = ch.src[1] < ch.src[0], dsw = ch.dst[1] < ch.dst[0];
+            djob(ch, 1, ssw ? ch.src[1] : ch.src[0], ch.src_stride[0], ch.src_fp[0], dsw ? ch.dst[1] : ch.dst[0], ch.dst_stride[0], ch.dst_fp[0], 1,
+                 ssw != dsw);
+        } else {
+            for (int k = 0; k < 2; k++)
+                djob(ch, 1, ch.src[k], ch.src_stride[k], ch.src_fp[k], ch.dst[k], ch.dst_stride[k], ch.dst_fp[k], 0, 0);
+        }
+        return ffhip_launch_down32(D, stream);
     }
     /* wide banks: the LDS-backed walker (FFHIP_SWS_WIDE=0 forces the LDS-tiled kernel) */
     const char *ew = FFHIP_KNOB("FFHIP_SWS_WIDE");

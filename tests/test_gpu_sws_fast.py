@@ -52,12 +52,14 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD",
               "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS", "FFHIP_UP2RGB_FPP", "FFHIP_SWS_RGB2", "FFHIP_SWS_EQRGB", "FFHIP_EQRGB_STEPS",
-              "FFHIP_EQRGB_FPP"):
+              "FFHIP_EQRGB_FPP", "FFHIP_SWS_DOWN32"):
         monkeypatch.delenv(k, raising=False)
     # the general kernels at exact 2:1 / 1:2 sizes need the fast paths switched off: a knob, i.e. libffhip_measure.so (conftest.py);
     # every other size runs the product library
     if need != "down2" and sw == 2 * dw and sh == 2 * dh:
         monkeypatch.setenv("FFHIP_SWS_DOWN2", "0")  # test_down2* covers sws_down2.hip
+    if need != "down32" and 2 * sw == 3 * dw and 2 * sh == 3 * dh:
+        monkeypatch.setenv("FFHIP_SWS_DOWN32", "0")  # test_down32* covers sws_down32.hip
     if need != "up2" and dw == 2 * sw and dh == 2 * sh:
         monkeypatch.setenv("FFHIP_SWS_UP2", "0")   # these tests are about the general kernels; test_up2* covers sws_up2.hip
     if need != "up2rgb" and dw == 2 * sw and dh == 2 * sh:
@@ -91,6 +93,8 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
         assert ctx.down2_path, "case does not reach the exact-2:1 kernel"
     elif need == "up2rgb":
         assert ctx.up2rgb_path, "case does not reach the exact-2x kernel with the RGB writer"
+    elif need == "down32":
+        assert ctx.paths & 4096, "case does not reach the exact-3:2 kernel"
     elif need == "fast":
         assert ctx.fast_path, "case does not reach the column walker"
     if (env or {}).get("FFHIP_SWS_MFMA") == "1" and need_mfma:
@@ -662,6 +666,37 @@ def test_wide_path_on_narrow_banks(case, monkeypatch):
 
 def test_wide_path_full_size(monkeypatch):
     _run("nv12", 3840, 2160, "nv12", 1920, 1080, ffi.SWS_BICUBIC, monkeypatch=monkeypatch, n=2, seed=80, need="wide")
+
+
+# ---------------------------------------------------------------------------------------------
+# exact 3:2 down-scaling on the static-schedule kernel (sws_down32.hip, round 5)
+DOWN32_CASES = [
+    ("nv12", 384, 216, "nv12", 256, 144, ffi.SWS_BICUBIC),           # 6 x 6 taps, one column block
+    ("nv21", 384, 216, "nv21", 256, 144, ffi.SWS_BICUBIC),
+    ("nv12", 384, 216, "nv21", 256, 144, ffi.SWS_BICUBIC),           # the pair turned round on the way
+    ("yuv420p", 384, 216, "yuv420p", 256, 144, ffi.SWS_BICUBIC),     # three plane jobs
+    ("yuv420p", 1560, 96, "yuv420p", 1040, 64, ffi.SWS_BICUBIC),     # several lane blocks, ragged last one (130 / 65 groups)
+    ("nv12", 1560, 96, "nv12", 1040, 64, ffi.SWS_BICUBIC),
+    ("nv12", 384, 216, "nv12", 256, 144, ffi.SWS_BILINEAR),          # 4 taps inside the 6-tap window
+    ("yuv420p", 384, 216, "yuv420p", 256, 144, ffi.SWS_POINT),
+    ("yuv422p", 288, 108, "yuv422p", 192, 72, ffi.SWS_BICUBIC),      # a chroma row per luma row
+    ("yuv444p", 144, 54, "yuv444p", 96, 36, ffi.SWS_BICUBIC),        # the smallest rows it takes: three groups
+    ("nv12", 384, 222, "nv12", 256, 148, ffi.SWS_BICUBIC),           # strips that end inside a period
+    ("nv12", 1920, 1080, "nv12", 1280, 720, ffi.SWS_BICUBIC),
+]
+
+
+@pytest.mark.parametrize("case", DOWN32_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_down32(case, monkeypatch):
+    _run(*case, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="down32")
+
+
+def test_down32_is_not_taken_for_other_shapes():
+    from ffmpeg_amd import swscale as S
+    for sf, sw, sh, df, dw, dh in (("nv12", 384, 216, "yuv420p", 256, 144), ("nv12", 378, 216, "nv12", 252, 144), ("nv12", 384, 216, "nv12", 256, 108)):
+        ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], ffi.SWS_BICUBIC)   # layouts differ; 252 is not a multiple of 8; 2:1 down
+        assert not ctx.paths & 4096, (sf, sw, sh, df, dw, dh)
+        ctx.close()
 
 
 # ---------------------------------------------------------------------------------------------
