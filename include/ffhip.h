@@ -272,7 +272,8 @@ void             ffhip_sws_freeContext(FFHipSwsContext *c);
  *  static-schedule kernel with the yuv2rgb_X writer fused (sws_up2rgb.hip); bit 7: the same sources into packed RGB at the source's size
  *  (sws_eqrgb.hip); bit 8: planar 4:4:4 into packed RGB at the source's size, the full-chroma writer on one-tap banks (sws_full444.hip); bit 9: 4:2:0
  *  between its planar and semi-planar layouts at the same size (sws_copy420.hip); bits 10 / 11: yuv444p -> yuv420p / yuv420p -> yuv444p at
- *  the same size: the luma plane copied, the chroma planes on the exact-2:1 / exact-2x static-schedule kernels.
+ *  the same size: the luma plane copied, the chroma planes on the exact-2:1 / exact-2x static-schedule kernels; bit 12: an exact 3:2
+ *  down-scale (sws_down32.hip).
  *  Diagnostic only: results are identical. */
 int              ffhip_sws_fast_path(const FFHipSwsContext *c);
 /** Host-side preparation of the matrix-core horizontal pass (no device needed): turns one 4-tap horizontal
