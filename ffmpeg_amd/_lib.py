@@ -123,6 +123,7 @@ def lib():
         "ffhip_sws_upn_virtual_bank_host": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "ffhip_sws_up2rgb_hco_host": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
         "ffhip_sws_down2_virtual_bank_host": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "ffhip_sws_d32_virtual_bank_host": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
         "ffhip_sws_mfma_tiles_host": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]),
         "ffhip_sws_tables_create": (vp, [C.c_int] * 7),
         "ffhip_sws_tables_get": (C.c_int, [vp, C.POINTER(SwsTables)]),

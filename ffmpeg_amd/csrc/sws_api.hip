@@ -1105,6 +1105,15 @@ extern "C" int ffhip_sws_down2_virtual_bank_host(const int16_t *filter, const in
     return 1;
 }
 
+extern "C" int ffhip_sws_d32_virtual_bank_host(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, uint32_t *out)
+{
+    std::vector<uint32_t> v;
+    if (!filter || !pos || !out || !ffhip_d32_virtual_bank(filter, pos, fsize, n_dst, n_src, 3, &v))
+        return 0;
+    memcpy(out, v.data(), v.size() * 4);
+    return 1;
+}
+
 extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
 {
     if (!c)

@@ -303,6 +303,10 @@ int              ffhip_sws_up2rgb_hco_host(const uint32_t *hl, int n_hl, const u
  *  eight coefficients per output on the regular window 2x - 3 .. 2x + 4 of the edge-replicated row.  out: n_dst x 4 dwords,
  *  (c0, c1) .. (c6, c7).  Returns 1, or 0 when some tap does not sit on its regular window. */
 int              ffhip_sws_down2_virtual_bank_host(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, uint32_t *out);
+/** The same for the exact-3:2 kernel (sws_down32.hip): a bank of `fsize` <= 12 taps of a 3:2 down-scale (2 n_src == 3 n_dst, n_dst
+ *  even) as six coefficients per output on the regular window 3 (x >> 1) - 2 + (x & 1) .. + 5 of the edge-replicated row.  out: n_dst x 3
+ *  dwords, (c0, c1) (c2, c3) (c4, c5).  Returns 1, or 0 when some tap does not sit on its regular window. */
+int              ffhip_sws_d32_virtual_bank_host(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, uint32_t *out);
 
 /** Host-table generation alone (no device needed): our initFilter().  `which`: 0 hLum 1 hChr 2 vLum
  *  3 vChr.  Returns filter size or <0; pointers stay valid until ffhip_sws_tables_free().  Used by
