@@ -723,3 +723,234 @@ uint8_t *ffref_frame_plane(void *f, int i, int *linesize)
     return p->data[i];
 }
 int ffref_sws_scale_frame(void *ctx, void *dst, void *src) { return sws_scale_frame(ctx, dst, src); }
+
+/* ---- CPU-baseline legs for BASELINE's other configurations (bench.py cpu_baseline; TEST / MEASUREMENT INFRASTRUCTURE) ---------------
+ * One runner for all of them: persistent threads, every thread builds its OWN state (buffers first-touched on its own node, its own
+ * contexts), runs one untimed warm-up chunk, then free-running chunks until the deadline.  A chunk is a fixed amount of the reference's
+ * own work through the reference's own function pointers; rate = units done / the time the slowest thread needed.
+ *   leg 0  unscaled yuv420p -> rgb24 3840x2160 (sws_scale -> yuv2rgb_c_24_rgb, libswscale/yuv2rgb.c:530): chunk = 1 frame, unit = pixel
+ *   leg 1  put_h264_qpel_pixels_tab[0][mc] on every 16x16 macroblock of a 4K luma plane, mc and the +-24 displacement drawn per block
+ *          (libavcodec/h264qpel_template.c): chunk = one macroblock row (240 blocks), unit = pixel
+ *   leg 2 / 3  h264 v_ / h_loop_filter_luma on one edge per 16x16 tile of a 4K plane, alpha 40, beta 12, tc0 2 (h264dsp_template.c:104-163):
+ *          chunk = one tile row (240 edges), unit = edge
+ *   leg 4 / 5  av_tx AV_TX_FLOAT_MDCT len 1024 forward / inverse (libavutil/tx_template.c): chunk = 64 transforms, unit = transform
+ *   leg 6  ff_me_search_esa, 16x16, search_param 7, SAD (libavfilter/motion_estimation.c:78-95): chunk = one macroblock row of a 4K pair,
+ *          unit = macroblock search
+ *   leg 7  the same window walked with MECmpContext.hadamard8_diff[0] as the cost (libavcodec/me_cmp.c:514-562,933-950)
+ */
+typedef struct BenchState {
+    int leg, thread;
+    void *ctx;
+    uint8_t *a, *b;
+    float *fa, *fb;
+    int32_t *mc;
+    long cursor;
+} BenchState;
+typedef struct BenchLoop { BenchState st; pthread_barrier_t *bar; double t_end, t_done; long chunks; int ok; } BenchLoop;
+
+static uint32_t bench_rand(uint32_t *s) { *s = *s * 1664525u + 1013904223u; return *s >> 8; }
+static void bench_fill(uint8_t *p, size_t n, uint32_t seed, int lo, int span)
+{
+    for (size_t i = 0; i < n; i++)
+        p[i] = (uint8_t)(lo + bench_rand(&seed) % (uint32_t)span);
+}
+enum { BW = 3840, BH = 2160, BPAD = 32, BSTRIDE = BW + 2 * BPAD };
+
+static long bench_units(int leg)
+{
+    switch (leg) {
+    case 0: return (long)BW * BH;
+    case 1: return 240L * 256;
+    case 2: case 3: return 240;
+    case 4: case 5: return 64;
+    default: return 240;
+    }
+}
+static int bench_make(BenchState *s)
+{
+    const size_t plane = (size_t)BSTRIDE * (BH + 2 * BPAD);
+    uint32_t seed = 0x9e3779b9u * (uint32_t)(s->thread + 1) + (uint32_t)s->leg;
+    switch (s->leg) {
+    case 0:
+        s->ctx = sws_getContext(BW, BH, AV_PIX_FMT_YUV420P, BW, BH, AV_PIX_FMT_RGB24, SWS_BICUBIC, NULL, NULL, NULL);
+        s->a = av_malloc((size_t)BW * BH * 3 / 2);
+        s->b = av_malloc((size_t)BW * BH * 3);
+        if (!s->ctx || !s->a || !s->b) return 0;
+        bench_fill(s->a, (size_t)BW * BH * 3 / 2, seed, 0, 256);
+        memset(s->b, 0, (size_t)BW * BH * 3);
+        return 1;
+    case 1:
+        s->a = av_malloc(plane); s->b = av_malloc(plane);
+        s->mc = av_malloc(sizeof(int32_t) * 2 * 240 * 135);
+        if (!s->a || !s->b || !s->mc) return 0;
+        bench_fill(s->a, plane, seed, 0, 256);
+        memset(s->b, 0, plane);
+        for (int i = 0; i < 240 * 135; i++) {
+            const int dy = (int)(bench_rand(&seed) % 49) - 24, dx = (int)(bench_rand(&seed) % 49) - 24;
+            s->mc[2 * i] = dy * BSTRIDE + dx;
+            s->mc[2 * i + 1] = (int)(bench_rand(&seed) & 15);
+        }
+        return 1;
+    case 2: case 3:
+        s->a = av_malloc((size_t)BW * BH);
+        if (!s->a) return 0;
+        bench_fill(s->a, (size_t)BW * BH, seed, 96, 64);
+        return 1;
+    case 4: case 5: {
+        RefTx *t = ffref_tx_create(AV_TX_FLOAT_MDCT, s->leg == 5, 1024, 1.0f, 0);
+        s->ctx = t;
+        s->fa = av_malloc(sizeof(float) * 64 * 2048);
+        s->fb = av_malloc(sizeof(float) * 64 * 2048);
+        if (!t || !s->fa || !s->fb) return 0;
+        for (int i = 0; i < 64 * 2048; i++)
+            s->fa[i] = (float)(bench_rand(&seed) & 0xffff) * (1.0f / 65536.0f) - 0.5f;
+        return 1;
+    }
+    default:
+        s->a = av_malloc((size_t)BW * BH); s->b = av_malloc((size_t)BW * BH);
+        if (!s->a || !s->b) return 0;
+        bench_fill(s->a, (size_t)BW * BH, seed, 0, 256);
+        /* the reference frame = the current one moved by (3, -2), as the GPU leg's (torch.roll) */
+        for (int y = 0; y < BH; y++)
+            for (int x = 0; x < BW; x++)
+                s->b[(size_t)y * BW + x] = s->a[(size_t)((y - 3 + BH) % BH) * BW + (x + 2) % BW];
+        return 1;
+    }
+}
+static void bench_drop(BenchState *s)
+{
+    if (s->leg == 0 && s->ctx) sws_freeContext(s->ctx);
+    if ((s->leg == 4 || s->leg == 5) && s->ctx) ffref_tx_free(s->ctx);
+    av_free(s->a); av_free(s->b); av_free(s->fa); av_free(s->fb); av_free(s->mc);
+}
+static void bench_chunk(BenchState *s)
+{
+    switch (s->leg) {
+    case 0: {
+        const uint8_t *src[4] = { s->a, s->a + (size_t)BW * BH, s->a + (size_t)BW * BH * 5 / 4, NULL };
+        const int ss[4] = { BW, BW / 2, BW / 2, 0 };
+        uint8_t *dst[4] = { s->b, NULL, NULL, NULL };
+        const int ds[4] = { 3 * BW, 0, 0, 0 };
+        sws_scale(s->ctx, src, ss, 0, BH, dst, ds);
+        break;
+    }
+    case 1: {
+        const int row = (int)(s->cursor++ % 135);
+        for (int x = 0; x < 240; x++) {
+            const size_t o = (size_t)(BPAD + 16 * row) * BSTRIDE + BPAD + 16 * x;
+            const int32_t *m = s->mc + 2 * (row * 240 + x);
+            qpel.put_h264_qpel_pixels_tab[0][m[1]](s->b + o, s->a + o + m[0], BSTRIDE);
+        }
+        break;
+    }
+    case 2: case 3: {
+        const int row = (int)(s->cursor++ % 135);
+        int8_t tc0[4] = { 2, 2, 2, 2 };
+        for (int x = 0; x < 240; x++) {
+            uint8_t *p = s->a + (size_t)16 * row * BW + 16 * x;
+            if (s->leg == 2) h264.v_loop_filter_luma(p + 8 * BW, BW, 40, 12, tc0);
+            else             h264.h_loop_filter_luma(p + 8, BW, 40, 12, tc0);
+        }
+        break;
+    }
+    case 4: case 5: {
+        RefTx *t = s->ctx;
+        const int nin = s->leg == 4 ? 2048 : 1024;
+        for (int i = 0; i < 64; i++)
+            t->fn(t->s, s->fb + (size_t)i * 1024, s->fa + (size_t)i * nin, sizeof(float));
+        break;
+    }
+    default: {
+        const int row = (int)(s->cursor++ % 135);
+        for (int x = 0; x < 240; x++) {
+            int mv[2];
+            if (s->leg == 6) {
+                ffref_me_search_esa(s->a, s->b, BW, BW, BH, 16, 7, 16 * x, 16 * row, mv);
+            } else {
+                /* ff_me_search_esa's window and order (motion_estimation.c:78-95) with the Hadamard cost */
+                const int x_mb = 16 * x, y_mb = 16 * row, lim_x = BW - 16, lim_y = BH - 16;
+                const int x0 = x_mb - 7 > 0 ? x_mb - 7 : 0, y0 = y_mb - 7 > 0 ? y_mb - 7 : 0;
+                const int x1 = x_mb + 7 < lim_x ? x_mb + 7 : lim_x, y1 = y_mb + 7 < lim_y ? y_mb + 7 : lim_y;
+                const uint8_t *c = s->a + (size_t)y_mb * BW + x_mb;
+                int best = mecmp.hadamard8_diff[0](NULL, c, s->b + (size_t)y_mb * BW + x_mb, BW, 16);
+                const int best0 = best;
+                mv[0] = x_mb; mv[1] = y_mb;
+                for (int yy = y0; yy <= (best0 ? y1 : y0 - 1); yy++) /* a zero cost at the block's own position returns at once (:84); nothing later does */
+                    for (int xx = x0; xx <= x1; xx++) {
+                        const int v = mecmp.hadamard8_diff[0](NULL, c, s->b + (size_t)yy * BW + xx, BW, 16);
+                        if (v < best) { best = v; mv[0] = xx; mv[1] = yy; }
+                    }
+            }
+            s->cursor += mv[0] & 0; /* keeps the result live */
+        }
+        break;
+    }
+    }
+}
+static void *bench_worker(void *p)
+{
+    BenchLoop *l = p;
+    l->ok = bench_make(&l->st);
+    pthread_barrier_wait(l->bar);
+    if (l->ok) bench_chunk(&l->st);
+    pthread_barrier_wait(l->bar);
+    pthread_barrier_wait(l->bar); /* the caller has set t_end */
+    l->t_done = now_s();
+    if (l->ok)
+        do {
+            bench_chunk(&l->st);
+            l->chunks++;
+            l->t_done = now_s();
+        } while (l->t_done < l->t_end);
+    pthread_barrier_wait(l->bar);
+    bench_drop(&l->st);
+    return NULL;
+}
+/* returns the number of threads that ran (<= 0: failure); *units = work done in *seconds */
+int ffref_bench_leg(int leg, int threads, double min_seconds, double *units, double *seconds)
+{
+    dsp_init();
+    if (leg < 0 || leg > 7) return -1;
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    static pthread_t th[1024];
+    static BenchLoop loop[1024];
+    pthread_barrier_t bar;
+    if (pthread_barrier_init(&bar, NULL, threads + 1))
+        return -1;
+    int started = 0;
+    for (int t = 0; t < threads; t++) {
+        memset(&loop[t], 0, sizeof(loop[t]));
+        loop[t].st.leg = leg;
+        loop[t].st.thread = t;
+        loop[t].bar = &bar;
+        if (pthread_create(&th[t], NULL, bench_worker, &loop[t]))
+            break;
+        started++;
+    }
+    if (started != threads) {
+        for (int t = 0; t < started; t++)
+            pthread_cancel(th[t]);
+        return -1;
+    }
+    pthread_barrier_wait(&bar); /* states built */
+    pthread_barrier_wait(&bar); /* warm-up chunk done */
+    const double t0 = now_s();
+    for (int t = 0; t < started; t++)
+        loop[t].t_end = t0 + min_seconds;
+    pthread_barrier_wait(&bar);
+    pthread_barrier_wait(&bar);
+    double t1 = t0, chunks = 0;
+    int ran = 0;
+    for (int t = 0; t < started; t++) {
+        if (loop[t].t_done > t1) t1 = loop[t].t_done;
+        chunks += (double)loop[t].chunks;
+        ran += loop[t].ok;
+    }
+    for (int t = 0; t < started; t++)
+        pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&bar);
+    *units = chunks * (double)bench_units(leg);
+    *seconds = t1 - t0;
+    return ran;
+}
