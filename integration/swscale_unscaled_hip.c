@@ -42,7 +42,34 @@ typedef struct HipUnscaled {
     int              graph;           /* ... made by the filter graph (not sws_init_context()): slices arrive in TARGET lines */
     int              cs[4], range, brightness, contrast, saturation; /* what ctx's coefficients were derived from */
     long             calls, fallbacks;
+    /* where the frame in flight runs: libffhip converts when a frame's LAST source slice arrives, so a frame must stay with
+     * the side that took its first slice.  0: the next call starts a frame; 1: libffhip holds the earlier slices; 2: the C path has it */
+    int              frame_path, frame_lines;
 } HipUnscaled;
+
+/* One source slice of a frame: libffhip, or the C function for the WHOLE frame when libffhip refuses the frame's first slice.  A failure
+ * after libffhip has taken earlier slices cannot be replayed (the caller's earlier slice buffers are no longer ours to read): it is
+ * returned as an error instead of a frame whose upper part was never converted. */
+static int hip_slice(SwsInternal *c, HipUnscaled *u, int prepared, const uint8_t *const src[], const int srcStride[], int y, int h,
+                     uint8_t *const dst[], const int dstStride[], int *fell_back)
+{
+    const int first = u->frame_path == 0;
+    int r = -1;
+    if (first)
+        u->frame_path = prepared ? 1 : 2;
+    if (u->frame_path == 1) {
+        r = ffhip_sws_scale(u->ctx, src, srcStride, y, h, dst, dstStride);
+        if (r < 0 && first)
+            u->frame_path = 2;
+        else if (r < 0)
+            r = AVERROR_EXTERNAL;
+    }
+    *fell_back = u->frame_path == 2;
+    u->frame_lines += h;
+    if (u->frame_lines >= c->opts.src_h || r == AVERROR_EXTERNAL)
+        u->frame_lines = u->frame_path = 0;           /* the frame is complete (scale_internal() resets its sliceDir at the same point) */
+    return r;
+}
 
 static void hip_unscaled_free(AVRefStructOpaque opaque, void *obj)
 {
@@ -67,19 +94,21 @@ static int hip_convert_unscaled(SwsInternal *c, const uint8_t *const src[], cons
                                 uint8_t *const dst[], const int dstStride[])
 {
     HipUnscaled *u = c->hw_priv;
-    int r = -1;
+    int r, prepared = 1, fell_back = 0;
     if (!hip_colorspace_current(c, u)) {
         FFHipSwsTables t;
         memset(&t, 0, sizeof(t));
         if (ffhip_sws_yuv2rgb_coeffs(&t, c->srcColorspaceTable, c->opts.src_range, c->brightness, c->contrast, c->saturation) < 0 ||
             ffhip_sws_set_yuv2rgb(u->ctx, &t) < 0)
-            goto c_path;
-        hip_colorspace_note(c, u);
+            prepared = 0;
+        else
+            hip_colorspace_note(c, u);
     }
-    r = ffhip_sws_scale(u->ctx, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
-c_path:
+    /* (a TARGET slice of sws_receive_slice() reaches an unscaled converter with both pointer sets moved to the slice, swscale.c:1163-1179:
+     * for a conversion at the source's size that IS the source slice of the same lines) */
+    r = hip_slice(c, u, prepared, src, srcStride, srcSliceY, srcSliceH, dst, dstStride, &fell_back);
     __atomic_fetch_add(&u->calls, 1, __ATOMIC_RELAXED);
-    if (r >= 0)
+    if (!fell_back)
         return r;
     __atomic_fetch_add(&u->fallbacks, 1, __ATOMIC_RELAXED);
     return u->c_func(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
@@ -171,26 +200,48 @@ static int hip_convert_scaled(SwsInternal *c, const uint8_t *const src[], const 
                               uint8_t *const dst[], const int dstStride[])
 {
     HipUnscaled *u = c->hw_priv;
-    int r = -1;
+    int r, prepared = 1, fell_back = 0;
     if (isAnyRGB(c->opts.dst_format) && !hip_colorspace_current(c, u)) {
         FFHipSwsTables t;
         memset(&t, 0, sizeof(t));
         if (ffhip_sws_yuv2rgb_coeffs(&t, c->srcColorspaceTable, c->opts.src_range, c->brightness, c->contrast, c->saturation) < 0 ||
             ffhip_sws_set_yuv2rgb(u->ctx, &t) < 0)
-            goto c_path;
-        hip_colorspace_note(c, u);
+            prepared = 0;
+        else
+            hip_colorspace_note(c, u);
     }
     if (u->graph) {
         /* run_legacy_unscaled() (graph.c:394-404): y, h are lines of the pass, i.e. of the TARGET, and the graph runs this pass in one
          * slice (threads == 1 is a condition of the hook): the frame */
         if (y != 0 || h != c->opts.dst_h)
-            goto c_path;
-        h = c->opts.src_h;
+            prepared = 0;
+        else
+            h = c->opts.src_h;
+    } else if (c->frame_src && c->frame_src->data[0] && !(y == 0 && h == c->opts.src_h)) {
+        /* sws_receive_slice() on a legacy context asking for a TARGET slice: the frame API is in flight (sws_frame_start()
+         * holds the source in c->frame_src), and scale_internal() has treated this context as an unscaled one — y, h are the target slice,
+         * every source pointer was moved down by y (chroma: y >> chrSrcVSubSample) lines and every target pointer up to the frame's first
+         * line (swscale.c:1163-1179).  Undo both and let ff_swscale() produce the slice from the whole source, as it would have been
+         * called without a converter (swscale.c:1184-1186). */
+        const uint8_t *s2[4] = { src[0], src[1], src[2], src[3] };
+        uint8_t *d2[4] = { dst[0], dst[1], dst[2], dst[3] };
+        for (int i = 0; i < 4 && s2[i]; i++) {
+            if (i > 0 && usePal(c->opts.src_format))
+                break;
+            s2[i] -= (y >> ((i == 1 || i == 2) ? c->chrSrcVSubSample : 0)) * (ptrdiff_t)srcStride[i];
+        }
+        for (int i = 0; i < 4 && d2[i]; i++) {
+            if (i > 0 && usePal(c->opts.dst_format))
+                break;
+            d2[i] += (y >> ((i == 1 || i == 2) ? c->chrDstVSubSample : 0)) * (ptrdiff_t)dstStride[i];
+        }
+        __atomic_fetch_add(&u->calls, 1, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&u->fallbacks, 1, __ATOMIC_RELAXED);
+        return ff_swscale(c, s2, srcStride, 0, c->opts.src_h, d2, dstStride, y, h);
     }
-    r = ffhip_sws_scale(u->ctx, src, srcStride, y, h, dst, dstStride);
-c_path:
+    r = hip_slice(c, u, prepared, src, srcStride, y, h, dst, dstStride, &fell_back);
     __atomic_fetch_add(&u->calls, 1, __ATOMIC_RELAXED);
-    if (r >= 0)
+    if (!fell_back)
         return r;
     __atomic_fetch_add(&u->fallbacks, 1, __ATOMIC_RELAXED);
     return ff_swscale(c, src, srcStride, y, h, dst, dstStride, 0, c->opts.dst_h);
@@ -233,6 +284,9 @@ av_cold void ff_sws_hip_scaled_hook(SwsInternal *c)
 
     if (!(av_get_cpu_flags() & AV_CPU_FLAG_HIP) || c->convert_unscaled || c->hw_priv || c->parent || c->nb_slice_ctx ||
         c->opts.threads != 1 || c->cascaded_context[0] || c->opts.gamma_flag || srcf < 0 || dstf < 0 ||
+        /* SWS_FAST_BILINEAR: 8-bit sources then scale through ff_hyscale_fast_c / ff_hcscale_fast_c (swscale.c:679, hscale.c:54-77), not
+         * through the banks handed over below — ffhip_sws_tables_create() refuses the flag for the same reason */
+        (c->opts.flags & SWS_FAST_BILINEAR) || c->hyscale_fast || c->hcscale_fast ||
         (c->opts.dither != SWS_DITHER_AUTO && c->opts.dither != SWS_DITHER_BAYER) || c->srcXYZ || c->dstXYZ || c->src0Alpha || c->dst0Alpha)
         return;
     memset(&t, 0, sizeof(t));

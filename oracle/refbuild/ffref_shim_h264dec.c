@@ -69,6 +69,7 @@ typedef struct FFRefH264Stream {
     int nout;
     /* counters */
     long pictures, mbs_hl, mbs_filter, refused, errors, decode_errors;
+    long mbs_class[8];             /* recorded macroblocks by what the DECODER derived for them: see ffref_h264stream_stat() */
     int first_error;
     int64_t base_shift;            /* test knob: the base the recorder counts offsets from lies this many bytes BELOW the arena */
 } FFRefH264Stream;
@@ -225,6 +226,23 @@ void ffref_hook_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
     case -1: ff_h264_hl_decode_mb(h, sl); return;
     }
     s->mbs_hl++;
+    {
+        /* what kind of macroblock the decoder's own parsing and derivation (h264_cavlc.c, h264_direct.c, h264_slice.c implicit_weight_table /
+         * h264_parse.c pred_weight_table) made of it — the tests assert that the streams reach these paths */
+        const int mt = h->cur_pic.mb_type[sl->mb_xy];
+        if (!IS_INTRA(mt)) {
+            s->mbs_class[0] += (mt & (MB_TYPE_P0L0 | MB_TYPE_P1L0)) && (mt & (MB_TYPE_P0L1 | MB_TYPE_P1L1));   /* uses both lists */
+            s->mbs_class[1] += !!IS_DIRECT(mt) || (IS_8X8(mt) && (IS_DIRECT(sl->sub_mb_type[0]) || IS_DIRECT(sl->sub_mb_type[1]) ||
+                                                                  IS_DIRECT(sl->sub_mb_type[2]) || IS_DIRECT(sl->sub_mb_type[3])));
+            s->mbs_class[3] += sl->pwt.use_weight == 1;
+            s->mbs_class[4] += sl->pwt.use_weight == 2;
+            s->mbs_class[5] += sl->slice_type_nos == AV_PICTURE_TYPE_B;
+        } else {
+            s->mbs_class[6] += IS_8x8DCT(mt) && !IS_INTRA16x16(mt) && !IS_INTRA_PCM(mt);                         /* Intra8x8 */
+        }
+        s->mbs_class[2] += !!IS_8x8DCT(mt) && (sl->cbp & 15);
+        s->mbs_class[7] += !!MB_FIELD(sl);
+    }
     note(s, ff_h264_hip_hl_decode_mb(&s->rec, h, sl));
 }
 
@@ -374,6 +392,9 @@ long ffref_h264stream_stat(const FFRefH264Stream *s, int what)
     case 5: return s->first_error;
     case 6: return s->decode_errors;
     case 7: return s->plain_pictures;
+    /* 8.. recorded macroblocks: 8 bi-predicted, 9 direct (whole or a sub-macroblock), 10 8x8 transform with coded luma, 11 explicit weights,
+     * 12 implicit weights, 13 of B slices, 14 Intra8x8, 15 field macroblocks */
+    case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: return s->mbs_class[what - 8];
     }
     return -1;
 }

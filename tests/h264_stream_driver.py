@@ -100,7 +100,8 @@ def decode(aus, make_flush=None, arena_bytes=48 << 20, read_back=None, base_shif
             assert r == 0, "avcodec_send_packet / receive_frame: %d" % r
         assert L.ffref_h264stream_decode(s, None, 0) == 0
         stats = {k: L.ffref_h264stream_stat(s, i) for i, k in enumerate(("pictures", "mbs_hl", "mbs_filter", "refused", "errors",
-                                                                        "first_error", "damaged", "plain_pictures"))}
+                                                                        "first_error", "damaged", "plain_pictures", "mbs_bipred", "mbs_direct", "mbs_8x8dct", "mbs_weighted",
+                                                                        "mbs_implicit", "mbs_b", "mbs_intra8x8", "mbs_field"))}
         if read_back is not None:
             used = C.c_size_t()
             L.ffref_h264stream_arena(s, C.byref(used))
@@ -175,3 +176,90 @@ def stream_mbaff_and_fields(seed=7, mb_w=6, mb_h=6):
             {"type": "P", "slices": [0], "deblock": [(0, -1, 2)], "field": "top", "num_ref": 4},
             {"type": "P", "slices": [0], "deblock": [(0, 0, 0)], "field": "bottom", "second_field": True, "num_ref": 4}]
     return w.stream(pics), w.stats
+
+
+# ---- round 6: B pictures, weighted prediction, the 8x8 transform, 4:2:2 ---------------------------------------------------------------------
+def stream_b(bit_depth=8, seed=21, mb_w=6, mb_h=5, direct_spatial=1, weighted_bipred=0, weighted_pred=0, t8x8=0, chroma_format=1,
+             slices=1, nonref=False, gops=2):
+    """I P B B B | P B B B ...: pic_order_cnt_type 0, B pictures between their references in output order and decoded after them (a small
+    pyramid: the middle B is itself a reference of the outer two), every B macroblock type, direct_spatial_mv_pred_flag as given.
+    nonref: the outer B pictures of each group are non-reference pictures (nal_ref_idc 0)."""
+    p = B.Params(mb_w=mb_w, mb_h=mb_h, bit_depth=bit_depth, seed=seed, num_ref_frames=4, poc_type=0, reorder=3, t8x8=t8x8,
+                 weighted_pred=weighted_pred, weighted_bipred=weighted_bipred, chroma_format=chroma_format)
+    w = B.StreamWriter(p)
+    rng = np.random.default_rng(seed + 300)
+    n_mb = mb_w * mb_h
+
+    def sl():
+        if slices == 1:
+            return [0], [(0, int(rng.integers(-2, 3)), int(rng.integers(-2, 3)))]
+        cuts = sorted(int(v) for v in rng.choice(np.arange(3, n_mb - 3), size=slices - 1, replace=False))
+        return [0] + cuts, [((0, 2, 1)[i % 3], int(rng.integers(-2, 3)), int(rng.integers(-2, 3))) for i in range(slices)]
+    pics, nref = [], 0
+
+    def add(t, poc, ref=True, **kw):
+        nonlocal nref
+        s_, d_ = sl()
+        avail = max(1, min(nref, p.num_ref_frames))
+        d = {"type": t, "slices": s_, "deblock": d_, "poc": poc, "ref": ref, "num_ref": min(avail, kw.pop("n0", 3)),
+             "num_ref_l1": min(avail, kw.pop("n1", 2)), "direct_spatial": direct_spatial}
+        d.update(kw)
+        pics.append(d)
+        nref += bool(ref)
+    add("I", 0)
+    base = 0
+    for g in range(gops):
+        add("P", base + 16, n0=2)
+        add("B", base + 8)
+        add("B", base + 4, ref=not nonref)
+        add("B", base + 12, ref=not nonref)
+        base += 16
+    return w.stream(pics), w.stats
+
+
+def stream_p_features(bit_depth=8, seed=31, mb_w=6, mb_h=5, weighted_pred=0, t8x8=0, chroma_format=1, n=5, fields=False):
+    """I P P P P (pic_order_cnt_type 2) with PPS features switched on: weighted_pred_flag (a pred_weight_table per P slice),
+    transform_8x8_mode_flag (Intra8x8, transform_size_8x8_flag on inter macroblocks), chroma_format_idc 2"""
+    p = B.Params(mb_w=mb_w, mb_h=mb_h, bit_depth=bit_depth, seed=seed, weighted_pred=weighted_pred, t8x8=t8x8, chroma_format=chroma_format,
+                 frame_mbs_only=0 if fields else 1)
+    w = B.StreamWriter(p)
+    rng = np.random.default_rng(seed + 400)
+    pics = []
+    if fields:
+        for k in range(n):
+            pics.append({"type": "I" if k == 0 else "P", "slices": [0], "deblock": [(0, 0, 0)], "field": "top", "num_ref": min(max(2 * k, 1), 4)})
+            pics.append({"type": "P", "slices": [0, 5], "deblock": [(0, 1, 1), (2, -1, 0)], "field": "bottom", "second_field": True,
+                         "num_ref": min(2 * k + 1, 4)})
+        return w.stream(pics), w.stats
+    pics.append({"type": "I", "slices": [0], "deblock": [(0, 0, 0)]})
+    for k in range(1, n):
+        pics.append({"type": "P", "slices": [0, 11] if k % 2 else [0], "deblock": [(0, int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), (2, 0, 1)][:2 if k % 2 else 1],
+                     "num_ref": min(k, 3)})
+    return w.stream(pics), w.stats
+
+
+# name -> (generator, kwargs, pictures, statistics of the DECODER that must be non-zero in record mode, writer statistics that must be non-zero)
+ROUND6_CASES = {
+    "b_spatial_8": (stream_b, dict(bit_depth=8, seed=21, direct_spatial=1), 9, ("mbs_b", "mbs_bipred", "mbs_direct"), ("b_direct16", "b_16", "b_168", "b_88", "b_direct8", "b_skip")),
+    "b_spatial_10": (stream_b, dict(bit_depth=10, seed=22, direct_spatial=1), 9, ("mbs_b", "mbs_bipred", "mbs_direct"), ("b_direct16", "b_88", "b_skip")),
+    "b_temporal_8": (stream_b, dict(bit_depth=8, seed=23, direct_spatial=0), 9, ("mbs_b", "mbs_bipred", "mbs_direct"), ("b_direct16", "b_direct8", "b_skip")),
+    "b_temporal_10": (stream_b, dict(bit_depth=10, seed=24, direct_spatial=0, slices=2), 9, ("mbs_b", "mbs_bipred", "mbs_direct"), ("b_direct16", "b_direct8", "b_skip")),
+    "b_explicit_weights_8": (stream_b, dict(bit_depth=8, seed=25, weighted_bipred=1, weighted_pred=1), 9, ("mbs_b", "mbs_bipred", "mbs_weighted"), ("wp_slices",)),
+    "b_explicit_weights_10": (stream_b, dict(bit_depth=10, seed=26, weighted_bipred=1, weighted_pred=1, direct_spatial=0), 9, ("mbs_bipred", "mbs_weighted"), ("wp_slices",)),
+    "b_implicit_weights_8": (stream_b, dict(bit_depth=8, seed=27, weighted_bipred=2), 9, ("mbs_b", "mbs_bipred", "mbs_implicit"), ()),
+    "b_implicit_weights_10": (stream_b, dict(bit_depth=10, seed=28, weighted_bipred=2, direct_spatial=0), 9, ("mbs_bipred", "mbs_implicit"), ()),
+    "b_8x8_transform_8": (stream_b, dict(bit_depth=8, seed=29, t8x8=1), 9, ("mbs_b", "mbs_8x8dct", "mbs_intra8x8"), ("i8", "t8x8_inter")),
+    "b_8x8_transform_10": (stream_b, dict(bit_depth=10, seed=30, t8x8=1, direct_spatial=0), 9, ("mbs_b", "mbs_8x8dct", "mbs_intra8x8"), ("i8", "t8x8_inter")),
+    "b_nonref_three_slices": (stream_b, dict(bit_depth=8, seed=31, nonref=True, slices=3, gops=3), 13, ("mbs_b", "mbs_bipred"), ("b_88",)),
+    "p_weighted_8": (stream_p_features, dict(bit_depth=8, seed=32, weighted_pred=1), 5, ("mbs_weighted",), ("wp_slices",)),
+    "p_weighted_fields_10": (stream_p_features, dict(bit_depth=10, seed=33, weighted_pred=1, fields=True, n=3, mb_h=6), 6, ("mbs_weighted",), ("wp_slices",)),
+    "p_8x8_transform_8": (stream_p_features, dict(bit_depth=8, seed=34, t8x8=1), 5, ("mbs_8x8dct", "mbs_intra8x8"), ("i8", "t8x8_inter")),
+    "p_8x8_transform_10": (stream_p_features, dict(bit_depth=10, seed=35, t8x8=1), 5, ("mbs_8x8dct", "mbs_intra8x8"), ("i8", "t8x8_inter")),
+    "high422_p_8": (stream_p_features, dict(bit_depth=8, seed=36, chroma_format=2), 5, ("mbs_hl",), ("p88",)),
+    "high422_b_all_10": (stream_b, dict(bit_depth=10, seed=37, chroma_format=2, t8x8=1, weighted_bipred=1, weighted_pred=1), 9,
+                         ("mbs_b", "mbs_bipred", "mbs_direct", "mbs_8x8dct", "mbs_weighted", "mbs_intra8x8"), ("i8", "wp_slices")),
+    "high422_b_implicit_8": (stream_b, dict(bit_depth=8, seed=38, chroma_format=2, weighted_bipred=2, direct_spatial=0, t8x8=1), 9,
+                             ("mbs_b", "mbs_implicit", "mbs_8x8dct"), ("b_direct8",)),
+    "b_cif_all_8": (stream_b, dict(bit_depth=8, seed=39, mb_w=22, mb_h=18, t8x8=1, weighted_bipred=2, slices=3), 9,
+                    ("mbs_b", "mbs_bipred", "mbs_direct", "mbs_8x8dct", "mbs_implicit", "mbs_intra8x8"), ("b_direct16", "b_direct8", "b_skip")),
+}

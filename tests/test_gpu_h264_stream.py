@@ -86,3 +86,22 @@ def test_a_larger_picture():
     for k in range(1, 6):
         pics.append({"type": "P", "slices": [0, 100 + 7 * k, 300], "deblock": [(0, 0, 0), (2, -1, 1), (0, 2, -2)], "num_ref": min(k, 3)})
     _check(w.stream(pics), 6)
+
+
+@pytest.mark.parametrize("name", sorted(D.ROUND6_CASES))
+def test_b_weighted_8x8_transform_and_422_streams(name):
+    """Round 6 (see tests/test_h264_stream_cpu.py): B slices with spatial / temporal direct prediction, explicit and implicit weights, the 8x8
+    transform (Intra8x8 and inter), non-reference B pictures, High 4:2:2; the decoder derives the state, the device executes the lists."""
+    gen, kw, npic, dstats, wstats = D.ROUND6_CASES[name]
+    aus, ws = gen(**kw)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == (npic // 2 if kw.get("fields") else npic)
+    make, read_back = _gpu_flush_factory()
+    got, st, counts = D.decode(aus, make_flush=make, read_back=read_back)
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
+    assert st["pictures"] == npic == counts["pictures"], (st, counts)
+    for k in dstats:
+        assert st[k] > 0, (k, st)
+    for i, (a, b) in enumerate(zip(plain, got)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())

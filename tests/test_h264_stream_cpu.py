@@ -103,3 +103,29 @@ def test_mbaff_frames_stay_on_the_c_path_as_whole_pictures(seed):
     for i, (a, b) in enumerate(zip(plain, rec)):
         for pl in range(3):
             assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+
+
+@pytest.mark.parametrize("name", sorted(D.ROUND6_CASES))
+def test_b_weighted_8x8_transform_and_422_streams(name):
+    """Round 6: what the picture layer accepted with test-written macroblock state, now with the state the DECODER derives — B slices
+    (every B macroblock and sub-macroblock type, B_Skip / B_Direct with spatial and temporal direct prediction: h264_direct.c:208-729),
+    explicit weights from a pred_weight_table (h264_parse.c:30) and implicit ones (h264_slice.c:689), transform_size_8x8_flag on inter
+    macroblocks and Intra8x8 (h264_cavlc.c:634), non-reference B pictures decoded out of output order, High 4:2:2 — 8 and 10 bits.  The
+    decoder's own counters say that such macroblocks were recorded."""
+    gen, kw, npic, dstats, wstats = D.ROUND6_CASES[name]
+    aus, ws = gen(**kw)
+    for k in wstats:
+        assert ws[k] > 0, (k, ws)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == (npic // 2 if kw.get("fields") else npic)
+    rec, st, counts = D.decode(aus, make_flush=lambda base, size: D.cpu_flush(base))
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
+    assert st["pictures"] == npic == counts["pictures"], (st, counts)
+    for k in dstats:
+        assert st[k] > 0, (k, st)
+    assert len(rec) == len(plain)
+    for i, (a, b) in enumerate(zip(plain, rec)):
+        for pl in range(3):
+            assert a[pl].shape == b[pl].shape
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+    assert any(not np.array_equal(plain[0][0], f[0]) for f in plain[1:])
