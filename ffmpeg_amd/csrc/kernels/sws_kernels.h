@@ -119,6 +119,11 @@ struct FFHipUp2Job {
     /* range conversion on the 15-bit horizontal samples (lum / chrRangeToJpeg_c, ...FromJpeg_c, libswscale/swscale.c:160-207):
      * h = (h * rc_coeff + rc_offset) >> 14, clipped to 32767 (k_sws_up2<., ., 0, 1>; rc_coeff 0: none) */
     int rc_coeff, rc_offset;
+    /* round 6: the horizontal bank as scalars (k_sws_up2<..., SC = 1>): every column but the three next to either end of a row has the
+     * coefficients of its parity — hco[0..1] an even column's two dwords, [2..3] an odd one's, [4..9] columns 0, 1, 2, [10..15] the last
+     * three; hco_ok: the bank has that shape (ffhip_up2_hco) */
+    uint32_t hco[16];
+    int hco_ok;
 };
 struct FFHipUp2Args {
     FFHipUp2Job job[3];
@@ -128,6 +133,7 @@ struct FFHipUp2Args {
 #ifdef __cplusplus
 #include <vector>
 int  ffhip_up2_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst, int n_src, std::vector<uint32_t> *out);
+int  ffhip_up2_hco(const std::vector<uint32_t> &h, uint32_t out[16]);
 #endif
 void ffhip_up2_plan_job(FFHipUp2Job *j, int lanes_per_frame, int want_steps);
 int  ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream);

@@ -105,6 +105,34 @@ __device__ __forceinline__ void up_h4(int (&d)[4], uint32_t pa0, uint32_t pa1, u
           "v"(cf[0]), "v"(cf[2]), "v"(cf[4]), "v"(cf[6]), "v"(cf[1]), "v"(cf[3]), "v"(cf[5]), "v"(cf[7]));
 }
 
+/* the same four samples with the bank in SGPRs (round 6, SC): even columns (e0, e1), odd columns (o0, o1) — one scalar operand per DOT */
+__device__ __forceinline__ void up_h4c(int (&d)[4], uint32_t pa0, uint32_t pa1, uint32_t pa2, uint32_t pa3, uint32_t pb0,
+                                       uint32_t pb1, uint32_t pb2, uint32_t pb3, uint32_t e0, uint32_t e1, uint32_t o0, uint32_t o1)
+{
+    asm("v_dot2_i32_i16 %0, %4, %12, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %14, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %12, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %14, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %13, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %15, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %13, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %15, %3\n\t"
+        "v_ashrrev_i32 %0, 7, %0\n\t"
+        "v_ashrrev_i32 %1, 7, %1\n\t"
+        "v_ashrrev_i32 %2, 7, %2\n\t"
+        "v_ashrrev_i32 %3, 7, %3"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3), "v"(pb0), "v"(pb1), "v"(pb2), "v"(pb3), "s"(e0), "s"(e1), "s"(o0), "s"(o1));
+}
+/* one sample of a row's end columns (their own coefficients): the compiler's DOT, hazards and all */
+__device__ __forceinline__ int up_h1(uint32_t pa, uint32_t pb, uint32_t c0, uint32_t c1)
+{
+    typedef short up_s2 __attribute__((ext_vector_type(2)));
+    int r = __builtin_amdgcn_sdot2(__builtin_bit_cast(up_s2, pa), __builtin_bit_cast(up_s2, c0), 0, false);
+    r = __builtin_amdgcn_sdot2(__builtin_bit_cast(up_s2, pb), __builtin_bit_cast(up_s2, c1), r, false);
+    return r >> 7;
+}
+
 /*
  * One output row of 8 samples: t[i] = kround + pa[i] . f01 + pb[i] . f23, bytes clip_u8(t[i] >> 19) packed in sample order;
  * the upper halves of the two dwords are written by the op_sel form of v_ashr_pk_u8_i32 (it keeps the lower half: verified on
@@ -201,7 +229,7 @@ __device__ __forceinline__ void up_v8h(uint32_t (&w)[4], const uint32_t (&pa)[8]
  * 8 samples from 4g - 2) or 24 (pair: 6 (u, v) columns from 2g - 2) per lane and row, 16 destination bytes per lane and row; the
  * seven (s[k], s[k+1]) pairs of a plane are its dwords and three v_alignbyte, a pair's come from v_perm as at 8 bits.
  */
-template <int PAIR, int D, int VAR, int HB = 0, int RC = 0>
+template <int PAIR, int D, int VAR, int HB = 0, int RC = 0, int SC = 0>
 __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int fshift, int gbase, int strip, int lane, int nframes)
 {
     /* measurement-only variants (wrong output; tools/sweep_sws.py): 16 never stores, 32 re-reads one source row (48 = both: the
@@ -228,9 +256,11 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
     const int smsb = HB ? (J.hb_smsb ? 16 - J.hb_sdepth : 0) : 0, dmsb = HB ? (J.hb_dmsb ? 16 - J.hb_ddepth : 0) : 0;
 
     /* ---- horizontal coefficients of this lane's columns (virtual bank: regular windows of the replicated row) ---- */
-    constexpr int NCF = PAIR ? 8 : 16;
+    /* SC (round 6): the bank in SGPRs — an even and an odd column's dwords, and the three columns at either end of a row, which only the
+     * first / last lane of the row's first / last wave recompute: 16 VGPRs fewer (68 -> 52: eight waves per SIMD) */
+    constexpr int NCF = SC ? 4 : PAIR ? 8 : 16;
     uint32_t cf[NCF];
-    {
+    if (!SC) {
         const up_u4 *p = reinterpret_cast<const up_u4 *>(J.hfv) + (size_t)g * (NCF / 4);
 #pragma unroll
         for (int i = 0; i < NCF / 4; i++) {
@@ -238,6 +268,7 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
             cf[4 * i] = v.x; cf[4 * i + 1] = v.y; cf[4 * i + 2] = v.z; cf[4 * i + 3] = v.w;
         }
     }
+    const uint32_t cE0 = J.hco[0], cE1 = J.hco[1], cO0 = J.hco[2], cO1 = J.hco[3];
     /* byte selectors: (s[k], s[k+1]) as an int16 pair.  Plane: adjacent bytes, sample b_k = byte k + 2 of the span.
      * Pair: bytes 2k (+1 for the channel that sits at the odd bytes) and 2k + 2. */
     const uint32_t par = PAIR ? (J.swap ? 0x00010001u : 0u) : 0u;
@@ -370,8 +401,22 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
             const uint32_t b4 = __builtin_amdgcn_perm(v2, v1, sB2);
             int ha[4], hb[4];
             /* output column c of a channel: window offset o = (c >> 1) + (c & 1) -> pairs o and o + 2 */
-            up_h4(ha, a0, a1, a1, a2, a2, a3, a3, a4, cf);
-            up_h4(hb, b0, b1, b1, b2, b2, b3, b3, b4, cf);
+            if (SC) {
+                up_h4c(ha, a0, a1, a1, a2, a2, a3, a3, a4, cE0, cE1, cO0, cO1);
+                up_h4c(hb, b0, b1, b1, b2, b2, b3, b3, b4, cE0, cE1, cO0, cO1);
+                if (border) { /* wave-uniform: columns 0..2 of the row's first lane, the last three of its last lane */
+                    const uint32_t *L = J.hco + 4, *R = J.hco + 10;
+                    const int l0 = up_h1(a0, a2, L[0], L[1]), l1 = up_h1(a1, a3, L[2], L[3]), l2 = up_h1(a1, a3, L[4], L[5]);
+                    const int m0 = up_h1(b0, b2, L[0], L[1]), m1 = up_h1(b1, b3, L[2], L[3]), m2 = up_h1(b1, b3, L[4], L[5]);
+                    const int r1 = up_h1(a1, a3, R[0], R[1]), r2 = up_h1(a1, a3, R[2], R[3]), r3 = up_h1(a2, a4, R[4], R[5]);
+                    const int q1 = up_h1(b1, b3, R[0], R[1]), q2 = up_h1(b1, b3, R[2], R[3]), q3 = up_h1(b2, b4, R[4], R[5]);
+                    ha[0] = lb ? l0 : ha[0]; ha[1] = lb ? l1 : rb ? r1 : ha[1]; ha[2] = lb ? l2 : rb ? r2 : ha[2]; ha[3] = rb ? r3 : ha[3];
+                    hb[0] = lb ? m0 : hb[0]; hb[1] = lb ? m1 : rb ? q1 : hb[1]; hb[2] = lb ? m2 : rb ? q2 : hb[2]; hb[3] = rb ? q3 : hb[3];
+                }
+            } else {
+                up_h4(ha, a0, a1, a1, a2, a2, a3, a3, a4, cf);
+                up_h4(hb, b0, b1, b1, b2, b2, b3, b3, b4, cf);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 h[2 * i] = ha[i];
@@ -384,8 +429,20 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
             const uint32_t p4 = __builtin_amdgcn_perm(v1, v0, 0x0c070c06u), p5 = __builtin_amdgcn_perm(v2, v1, 0x0c040c03u);
             const uint32_t p6 = __builtin_amdgcn_perm(v2, v1, 0x0c050c04u);
             int hl[4], hh[4];
-            up_h4(hl, p0, p1, p1, p2, p2, p3, p3, p4, cf);
-            up_h4(hh, p2, p3, p3, p4, p4, p5, p5, p6, cf + 8);
+            if (SC) {
+                up_h4c(hl, p0, p1, p1, p2, p2, p3, p3, p4, cE0, cE1, cO0, cO1);
+                up_h4c(hh, p2, p3, p3, p4, p4, p5, p5, p6, cE0, cE1, cO0, cO1);
+                if (border) { /* wave-uniform: columns 0..2 of the row's first lane, 5..7 of its last lane */
+                    const uint32_t *L = J.hco + 4, *R = J.hco + 10;
+                    const int l0 = up_h1(p0, p2, L[0], L[1]), l1 = up_h1(p1, p3, L[2], L[3]), l2 = up_h1(p1, p3, L[4], L[5]);
+                    const int r5 = up_h1(p3, p5, R[0], R[1]), r6 = up_h1(p3, p5, R[2], R[3]), r7 = up_h1(p4, p6, R[4], R[5]);
+                    hl[0] = lb ? l0 : hl[0]; hl[1] = lb ? l1 : hl[1]; hl[2] = lb ? l2 : hl[2];
+                    hh[1] = rb ? r5 : hh[1]; hh[2] = rb ? r6 : hh[2]; hh[3] = rb ? r7 : hh[3];
+                }
+            } else {
+                up_h4(hl, p0, p1, p1, p2, p2, p3, p3, p4, cf);
+                up_h4(hh, p2, p3, p3, p4, p4, p5, p5, p6, cf + 8);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 h[i] = hl[i];
@@ -497,7 +554,7 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
     }
 }
 
-template <int D, int VAR, int HB = 0, int RC = 0> /* VAR: 0 the product; 16 / 48 / 64 measurement only (see up2_unit); HB: samples above 8 bits; RC: range conversion */
+template <int D, int VAR, int HB = 0, int RC = 0, int SC = 0> /* VAR: 0 the product; 16 / 48 / 64 measurement only (see up2_unit); HB: samples above 8 bits; RC: range conversion; SC: the horizontal bank in SGPRs */
 __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -536,9 +593,9 @@ __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
         gbase = J.nfull * 64 + (idx - nf) * (64 >> fsh);
     }
     if (J.pair)
-        up2_unit<1, D, VAR, HB, RC>(J, frame0, fsh, gbase, strip, lane, A.nframes);
+        up2_unit<1, D, VAR, HB, RC, SC>(J, frame0, fsh, gbase, strip, lane, A.nframes);
     else
-        up2_unit<0, D, VAR, HB, RC>(J, frame0, fsh, gbase, strip, lane, A.nframes);
+        up2_unit<0, D, VAR, HB, RC, SC>(J, frame0, fsh, gbase, strip, lane, A.nframes);
 }
 
 /* ================================================================================================== */
@@ -580,6 +637,25 @@ int ffhip_up2_virtual_bank(const int16_t *filter, const int32_t *pos, int n_dst,
         }
         (*out)[2 * (size_t)x] = (uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
         (*out)[2 * (size_t)x + 1] = (uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+    }
+    return 1;
+}
+
+/* the virtual horizontal bank as scalars: 1 when every column but the three next to either end carries the two dwords of its parity
+ * (out[0..3] = an even and an odd column, [4..9] columns 0..2, [10..15] the last three) */
+int ffhip_up2_hco(const std::vector<uint32_t> &v, uint32_t out[16])
+{
+    const int n = (int)(v.size() / 2);
+    if (n < 16 || (n & 1))
+        return 0;
+    for (int x = 3; x < n - 3; x++)
+        if (v[2 * (size_t)x] != v[2 * (size_t)(4 + (x & 1))] || v[2 * (size_t)x + 1] != v[2 * (size_t)(4 + (x & 1)) + 1])
+            return 0;
+    for (int i = 0; i < 4; i++)
+        out[i] = v[8 + i];
+    for (int i = 0; i < 6; i++) {
+        out[4 + i] = v[i];
+        out[10 + i] = v[2 * (size_t)(n - 3) + i];
     }
     return 1;
 }
@@ -634,6 +710,19 @@ int ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream)
         LAUNCH_CHECK();
         return 0;
     }
+    bool sc = true;
+    for (int i = 0; i < A.njobs; i++)
+        sc = sc && A.job[i].hco_ok;
+    if (sc && (var == 2 || var == 3)) { /* var 2: the bank in SGPRs; 3: with six rows in flight */
+        if (var == 2 && depth == 3)
+            hipLaunchKernelGGL((k_sws_up2<3, 0, 0, 0, 1>), grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL((k_sws_up2<6, 0, 0, 0, 1>), grid, block, 0, stream, A);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (var == 2 || var == 3)
+        var = 0;
 #define UP2_LAUNCH(DD, VV) hipLaunchKernelGGL((k_sws_up2<DD, VV>), grid, block, 0, stream, A)
 #define UP2_CASE(VV) case VV: if (depth == 3) UP2_LAUNCH(3, VV); else UP2_LAUNCH(6, VV); break
     switch (var) {

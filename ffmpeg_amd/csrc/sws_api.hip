@@ -56,6 +56,8 @@ struct FFHipSwsContext {
     int up2_rc = 0; /* a range-converting context: the exact-2x kernel with the range stage is its only fast kernel */
     void *up2_dev = nullptr;
     const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
+    uint32_t up2_hco[2][16] = {};      /* the horizontal banks as scalars (FFHipUp2Job.hco), when they have that shape */
+    int up2_hco_ok[2] = { 0, 0 };
     /* 4:2:0 into packed RGB at the source's size through the scaler (sws_eqrgb.hip): the virtual vertical chroma bank on the device */
     int eqr_ok = 0;
     void *eqr_dev = nullptr;
@@ -352,6 +354,8 @@ static void up2_build(FFHipSwsContext *c, const int nsrc[4], bool chroma_only = 
             ok = ffhip_up2_virtual_bank(c->nf[i].data(), c->np[i].data(), c->d[i].n, nsrc[i], &vb[i]) != 0;
     if (!ok)
         return;
+    for (int i = 0; i < 2; i++)
+        c->up2_hco_ok[i] = !(chroma_only && i == 0) && ffhip_up2_hco(vb[i], c->up2_hco[i]);
     /* vertical banks: one leading row (y = -1) and 17 trailing ones of zeros (the row loop reads ahead) */
     for (int i = chroma_only ? 3 : 2; i < 4; i++) {
         std::vector<uint32_t> pv((size_t)(c->d[i].n + 18) * 2, 0);
@@ -1844,6 +1848,8 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                 j.ngroups = pair ? p.srcW / 2 : p.srcW / 4;
                 j.hfv = c->up2_h[which]; j.vfv = c->up2_v[which];
                 j.rc_coeff = p.rc_coeff; j.rc_offset = p.rc_offset;
+                j.hco_ok = c->up2_hco_ok[which];
+                memcpy(j.hco, c->up2_hco[which], sizeof(j.hco));
             };
             if (c->mix_up2) {
                 FFHipCopy420Args K;
