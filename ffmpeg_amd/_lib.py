@@ -104,6 +104,7 @@ def lib():
         "ffhip_sws_set_yuv2rgb": (C.c_int, [vp, C.POINTER(SwsTables)]),
         "ffhip_sws_freeContext": (None, [vp]),
         "ffhip_sws_fast_path": (C.c_int, [vp]),
+        "ffhip_sws_tuned_numbering": (C.c_int, [vp]),
         "ff_sws_init_swscale_hip": (C.c_int, [vp, C.c_int, C.c_int]),
         "ffhip_sws_yuv2packed1": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
         "ffhip_sws_yuv2packed2": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),

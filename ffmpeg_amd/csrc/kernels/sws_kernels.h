@@ -25,6 +25,9 @@ struct FFHipYuv2RgbArgs {
     int dst_y0;                      /* srcSliceY: first destination row */
     int nframes;
     int flat;                        /* set by the launcher: chunks numbered through the frame's row pairs (k_yuv420p_rgb24_t) */
+    int xcd;                         /* workgroup numbering of k_yuv420p_rgb24_t: 0 plain; 1 an eighth of the launch per XCD (chosen per context by the
+                                      * launch tuner of sws_api.hip: which of the two is faster depends on the box, profiles/r06_arena_offset_sweep.txt);
+                                      * 1 + k (measure build): XCD-contiguous chunks of 2^k workgroups dealt round-robin */
     FFHipYuv2RgbK k;
     /* the converter's other forms (yuv2rgb.c:238-320, 540-553: YUV422FUNC, yuva2rgba_c / yuva2argb_c, yuv420p_gbrp_c) */
     int c422 = 0;                    /* 4:2:2 source: luma row 2k + 1 takes chroma row 2k + 1 (u_stride / v_stride are the planes' own) */

@@ -560,12 +560,20 @@ __global__ __launch_bounds__(256) void k_sws_up2(FFHipUp2Args A)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     uint32_t blk = blockIdx.x;
-    if (A.xcd) {
+    if (A.xcd == 1) {
         /* workgroup b runs on XCD b % 8 (observed, not promised: speed only).  Give every XCD one contiguous eighth of the
          * units, in order, so that the waves sharing source lines (adjacent column blocks, the 3 halo rows of adjacent
          * strips) meet in one L2. */
         const uint32_t nb = gridDim.x, x = blk & 7u, sl = blk >> 3, q = nb >> 3, r = nb & 7u;
         blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sl;
+    } else if (A.xcd > 1) {
+        /* measured variant (round 6): XCD-contiguous CHUNKS of 1 << (xcd - 1) workgroups dealt round-robin — every XCD still walks
+         * contiguous units, but the eight XCDs' fronts stay within eight chunks of each other instead of an eighth of the batch apart */
+        const uint32_t lg = (uint32_t)A.xcd - 1u, C = 1u << lg, nb = gridDim.x, full = nb & ~(8u * C - 1u);
+        if (blk < full) {
+            const uint32_t x = blk & 7u, sl = blk >> 3;
+            blk = (((sl >> lg) << 3) + x) * C + (sl & (C - 1u));
+        }
     }
     const uint32_t gw = blk * 4u + (uint32_t)wave;
     if (gw >= (uint32_t)A.units_per_pack * (uint32_t)A.npacks)
@@ -713,16 +721,18 @@ int ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream)
     bool sc = true;
     for (int i = 0; i < A.njobs; i++)
         sc = sc && A.job[i].hco_ok;
-    if (sc && (var == 2 || var == 3)) { /* var 2: the bank in SGPRs; 3: with six rows in flight */
-        if (var == 2 && depth == 3)
-            hipLaunchKernelGGL((k_sws_up2<3, 0, 0, 0, 1>), grid, block, 0, stream, A);
-        else
-            hipLaunchKernelGGL((k_sws_up2<6, 0, 0, 0, 1>), grid, block, 0, stream, A);
-        LAUNCH_CHECK();
-        return 0;
+    if (var == 2 || var == 3) { /* measured variants (round 6): the bank in SGPRs (2), with non-temporal stores as well (3); depth as asked */
+        if (!sc)
+            var &= 1;
+        else {
+            if (var == 2 && depth == 3) hipLaunchKernelGGL((k_sws_up2<3, 0, 0, 0, 1>), grid, block, 0, stream, A);
+            else if (var == 2)          hipLaunchKernelGGL((k_sws_up2<6, 0, 0, 0, 1>), grid, block, 0, stream, A);
+            else if (depth == 3)        hipLaunchKernelGGL((k_sws_up2<3, 1, 0, 0, 1>), grid, block, 0, stream, A);
+            else                        hipLaunchKernelGGL((k_sws_up2<6, 1, 0, 0, 1>), grid, block, 0, stream, A);
+            LAUNCH_CHECK();
+            return 0;
+        }
     }
-    if (var == 2 || var == 3)
-        var = 0;
 #define UP2_LAUNCH(DD, VV) hipLaunchKernelGGL((k_sws_up2<DD, VV>), grid, block, 0, stream, A)
 #define UP2_CASE(VV) case VV: if (depth == 3) UP2_LAUNCH(3, VV); else UP2_LAUNCH(6, VV); break
     switch (var) {

@@ -154,7 +154,18 @@ __global__ __launch_bounds__(256) void k_yuv420p_rgb24_t(FFHipYuv2RgbArgs a)
     const int wpr = (chunks + 63) >> 6; /* waves per row pair */
     const int rowpairs = a.h >> 1;
     /* XCD (measured variant): workgroup b runs on XCD b % 8 — number the workgroups so that each XCD converts one contiguous eighth */
-    const uint32_t bidx = XCD ? (blockIdx.x & 7u) * ((gridDim.x + 7u) >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    /* workgroup b runs on XCD b % 8 (observed, not promised: speed only).  a.xcd == 1: every XCD converts one contiguous eighth of the
+     * launch; > 1 (measured variant, round 6): XCD-contiguous chunks of 1 << (xcd - 1) workgroups dealt round-robin */
+    uint32_t bidx = blockIdx.x;
+    if (XCD || a.xcd == 1) {
+        bidx = (blockIdx.x & 7u) * ((gridDim.x + 7u) >> 3) + (blockIdx.x >> 3);
+    } else if (a.xcd > 1) {
+        const uint32_t lg = (uint32_t)a.xcd - 1u, C = 1u << lg, full = gridDim.x & ~(8u * C - 1u);
+        if (bidx < full) {
+            const uint32_t x = bidx & 7u, sl = bidx >> 3;
+            bidx = (((sl >> lg) << 3) + x) * C + (sl & (C - 1u));
+        }
+    }
     const uint32_t gw = bidx * 4u + (uint32_t)wave; /* < 2^31, checked by the launcher */
     /* FLAT (width % 16 == 0, at least 64 chunks per row): the 16-pixel chunks of a frame's row pairs are numbered straight through and
      * a wave takes 64 consecutive ones, across the end of a row pair if need be — at 3840 columns (240 chunks = 3.75 waves) one wave in
@@ -560,11 +571,15 @@ int ffhip_launch_yuv420p_rgb24(const FFHipYuv2RgbArgs &a, int layout, hipStream_
         /* measured variants (rgb24 only): "st" plain stores (the kernel up to round 4: 3-6 % slower than the non-temporal ones, profiles/
          * r05_rgb24_variants.txt), "xcd" XCD-contiguous numbering, "ntl" non-temporal loads as well */
         const bool pst = ev && strstr(ev, "st"), xcd = ev && strstr(ev, "xcd"), ntl = ev && strstr(ev, "ntl");
+        if (xcd)
+            af.xcd = 1 + atoi(strstr(ev, "xcd") + 3);          /* "xcd": an eighth per XCD; "xcd4": chunks of 16 workgroups */
+        else if (ev)
+            af.xcd = 0;                                        /* a named variant overrides the context's tuned numbering */
         if (!bgr && (pst || xcd || ntl)) { /* words: "st", "xcd", "ntl", "st+xcd" (none of them inside "old" / "plain" / "flat") */
-            if (pst && xcd) hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, false, true>), grid, block, 0, stream, af);
+            if (pst && xcd) hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, false>), grid, block, 0, stream, af);
             else if (pst)   hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, false, false>), grid, block, 0, stream, af);
             else if (ntl)   hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, true, false, true>), grid, block, 0, stream, af);
-            else            hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, true, true>), grid, block, 0, stream, af);
+            else            hipLaunchKernelGGL((k_yuv420p_rgb24_t<false, false, true>), grid, block, 0, stream, af);
             LAUNCH_CHECK();
             return 0;
         }

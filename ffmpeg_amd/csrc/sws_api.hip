@@ -56,6 +56,11 @@ struct FFHipSwsContext {
     int up2_rc = 0; /* a range-converting context: the exact-2x kernel with the range stage is its only fast kernel */
     void *up2_dev = nullptr;
     const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
+    /* launch tuner of the table converter (round 6): which workgroup numbering of k_yuv420p_rgb24_t is faster is a property of the BOX
+     * (profiles/r06_arena_offset_sweep.txt, r06_xcd_numbering_sweep.txt: eighth-per-XCD +1 .. +8 % on some, -4 % on others, whatever the
+     * addresses), so the first four large launches of a context run plain, eighth, eighth, plain between events and the rest take the winner */
+    hipEvent_t tune_ev[8] = {};
+    int tune_n = 0, tune_choice = -1;
     uint32_t up2_hco[2][16] = {};      /* the horizontal banks as scalars (FFHipUp2Job.hco), when they have that shape */
     int up2_hco_ok[2] = { 0, 0 };
     /* 4:2:0 into packed RGB at the source's size through the scaler (sws_eqrgb.hip): the virtual vertical chroma bank on the device */
@@ -1059,6 +1064,11 @@ extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
     return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) + (c->mix_dn2 ? 1024 : 0) + (c->mix_up2 ? 2048 : 0) + (c->d32_ok ? 4096 : 0) : 0;
 }
 
+extern "C" int ffhip_sws_tuned_numbering(const FFHipSwsContext *c)
+{
+    return c ? c->tune_choice : -1;
+}
+
 extern "C" int ffhip_sws_mfma_tiles_host(const int16_t *filter, const int32_t *pos, int n, int srcW, int pair, int src_swap,
                                          uint8_t *out, size_t out_size)
 {
@@ -1129,6 +1139,9 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->mf_dev);
     if (c->up2_dev)
         (void)hipFree(c->up2_dev);
+    for (int i = 0; i < 8; i++)
+        if (c->tune_ev[i])
+            (void)hipEventDestroy(c->tune_ev[i]);
     if (c->u2r_dev)
         (void)hipFree(c->u2r_dev);
     if (c->rgb2_tmp)
@@ -1423,6 +1436,45 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
     return r;
 }
 
+/* The numbering of a large launch of the table converter: 0 plain, 1 an eighth per XCD.  While undecided, launches 0..3 of the context run
+ * plain, eighth, eighth, plain (a drift of the clocks cancels) and *slot names the event pair to record around this one; once all four
+ * have finished the faster numbering is kept — the eighth only when it wins by 1.5 %.  No decision is forced: a query that finds an
+ * event pending leaves the default (plain) in place for this call.  Not while the stream is being captured into a graph. */
+static int tune_pick(FFHipSwsContext *c, hipStream_t stream, int *slot)
+{
+    *slot = -1;
+    if (c->tune_choice >= 0)
+        return c->tune_choice;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (c->tune_n < 4) {
+        if (!c->tune_ev[0])
+            for (int i = 0; i < 8; i++)
+                if (hipEventCreate(&c->tune_ev[i]) != hipSuccess) {
+                    (void)hipGetLastError();
+                    c->tune_choice = 0;
+                    return 0;
+                }
+        *slot = c->tune_n;
+        return c->tune_n == 1 || c->tune_n == 2;
+    }
+    float e[4];
+    for (int i = 0; i < 4; i++)
+        if (hipEventQuery(c->tune_ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&e[i], c->tune_ev[2 * i], c->tune_ev[2 * i + 1]) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+    c->tune_choice = e[1] + e[2] < 0.985f * (e[0] + e[3]);
+    for (int i = 0; i < 8; i++) {
+        (void)hipEventDestroy(c->tune_ev[i]);
+        c->tune_ev[i] = nullptr;
+    }
+    return c->tune_choice;
+}
+
 /* the table converter on `rows` lines (a whole frame, or a 2-line aligned slice) of device planes: one launch */
 static int unscaled_launch(FFHipSwsContext *c, int nframes, int rows, const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
                            void *const dst[4], const int dstStride[4], const size_t dstFramePitch[4], hipStream_t stream)
@@ -1432,7 +1484,7 @@ static int unscaled_launch(FFHipSwsContext *c, int nframes, int rows, const void
     a.y = (const uint8_t *)src[0]; a.u = (const uint8_t *)src[1]; a.v = (const uint8_t *)src[2]; a.dst = (uint8_t *)dst[0];
     a.y_stride = srcStride[0]; a.u_stride = srcStride[1]; a.v_stride = srcStride[2]; a.dst_stride = dstStride[0];
     a.y_fp = srcFramePitch[0]; a.u_fp = srcFramePitch[1]; a.v_fp = srcFramePitch[2]; a.dst_fp = dstFramePitch[0];
-    a.wvalid = t.dstW & ~1; a.h = rows; a.dst_y0 = 0; a.nframes = nframes; a.flat = 0; a.k = c->k;
+    a.wvalid = t.dstW & ~1; a.h = rows; a.dst_y0 = 0; a.nframes = nframes; a.flat = 0; a.xcd = 0; a.k = c->k;
     a.c422 = t.srcFormat == FFHIP_PIX_FMT_YUV422P;
     if (!a.y || !a.u || !a.v || !a.dst)
         return FFHIP_EINVAL;
@@ -1450,7 +1502,22 @@ static int unscaled_launch(FFHipSwsContext *c, int nframes, int rows, const void
         a.dst2 = (uint8_t *)dst[2]; a.dst2_stride = dstStride[2]; a.dst2_fp = dstFramePitch[2];
         return ffhip_launch_yuv420p_rgb24(a, 6, stream);
     }
-    return ffhip_launch_yuv420p_rgb24(a, rgb_layout(t.dstFormat), stream);
+    /* 24-bit targets from planar 4:2:0, launches of 64 MiB and more: the numbering this box prefers */
+    int slot = -1;
+    if (rgb_layout(t.dstFormat) < 2 && !a.c422 && !a.alpha && (long long)nframes * rows * t.dstW * 3 >= (64LL << 20))
+        a.xcd = tune_pick(c, stream, &slot);
+    if (slot >= 0 && hipEventRecord(c->tune_ev[2 * slot], stream) != hipSuccess) {
+        (void)hipGetLastError();
+        slot = -1;
+    }
+    const int r = ffhip_launch_yuv420p_rgb24(a, rgb_layout(t.dstFormat), stream);
+    if (slot >= 0) {
+        if (r >= 0 && hipEventRecord(c->tune_ev[2 * slot + 1], stream) == hipSuccess)
+            c->tune_n++;
+        else
+            (void)hipGetLastError();
+    }
+    return r;
 }
 
 static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const src[4], const int srcStride[4], const size_t srcFramePitch[4],
@@ -1878,7 +1945,7 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
              * lane offsets (frame pitch included) must stay below 2^32 */
             const char *ef = FFHIP_KNOB("FFHIP_UP2_FSHIFT"), *es = FFHIP_KNOB("FFHIP_UP2_STRIP"), *ed = FFHIP_KNOB("FFHIP_UP2_DEPTH");
             const char *ev2 = FFHIP_KNOB("FFHIP_UP2_VAR"), *ex = FFHIP_KNOB("FFHIP_UP2_XCD");
-            U.xcd = !(ex && ex[0] == '0');
+            U.xcd = ex ? atoi(ex) : 1;     /* measure build: 0 plain numbering, 1 an eighth per XCD (the product), 1 + k chunks of 2^k workgroups */
             int best = 0;
             double bestw = 1e30;
             for (int fsft = 0; fsft <= 2; fsft++) {

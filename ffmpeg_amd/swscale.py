@@ -147,6 +147,11 @@ class SwsContext:
         return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 8)
 
     @property
+    def tuned_numbering(self):
+        """-1 / 0 / 1: the workgroup numbering the launch tuner kept for large launches of the table converter (ffhip_sws_tuned_numbering)"""
+        return int(_lib.lib().ffhip_sws_tuned_numbering(self._c))
+
+    @property
     def up2rgb_path(self):
         """True when the static-schedule exact-2x kernel with the packed-RGB writer (k_sws_up2_rgb) serves the banks."""
         return bool(_lib.lib().ffhip_sws_fast_path(self._c) & 64)

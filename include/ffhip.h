@@ -276,6 +276,10 @@ void             ffhip_sws_freeContext(FFHipSwsContext *c);
  *  down-scale (sws_down32.hip).
  *  Diagnostic only: results are identical. */
 int              ffhip_sws_fast_path(const FFHipSwsContext *c);
+/** Diagnostic: the workgroup numbering the context's launch tuner settled on for large launches of the table converter
+ *  (yuv2rgb_c_24_rgb's replacement, libswscale/yuv2rgb.c:530) — -1 undecided (fewer than four large launches so far), 0 plain,
+ *  1 an eighth of the launch per XCD.  Which one is faster is a property of the box; results are identical. */
+int              ffhip_sws_tuned_numbering(const FFHipSwsContext *c);
 /** Host-side preparation of the matrix-core horizontal pass (no device needed): turns one 4-tap horizontal
  *  bank (hLumFilter/hLumFilterPos or the chroma pair's) into per-tile MFMA operand records of 2320 bytes —
  *  B_hi[64 lanes][16], B_lo[64][16] (coefficient = 256*hi + lo, zero outside the band), bias[64] = 128*sum(f),
