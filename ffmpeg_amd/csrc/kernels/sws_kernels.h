@@ -418,6 +418,9 @@ struct FFHipW16Job {
     const int16_t *vf; const int32_t *vp;     /* device: dstH x vt taps */
     int ncb, nstrips, strip_rows, unit_begin;
     int dither_off;                           /* ddepth 8, plane jobs: 3 for the V plane (its dither row is read three entries on), else 0 */
+    int srcW;                                 /* samples of one channel per source row */
+    int stage;                                /* round 6: the span of a wave's windows in a source row fits 1 KiB (and the positions ascend): the row
+                                               * segment is loaded ONCE per wave into LDS and the lanes' windows are read from there */
 };
 struct FFHipW16Args {
     FFHipW16Job job[3];
@@ -428,6 +431,9 @@ struct FFHipW16Args {
 bool ffhip_w16_pad_bank(const int16_t *filter, const int32_t *pos, int size, int n, int nsrc, int T, std::vector<int16_t> *of, std::vector<int32_t> *op);
 #endif
 void ffhip_w16_plan_job(FFHipW16Job *j, int strip_target);
+#ifdef __cplusplus
+int  ffhip_w16_span(const int32_t *pos, int n, int cols, int bytes_per_column, int taps);
+#endif
 int  ffhip_launch_walk16(FFHipW16Args &A, hipStream_t stream);
 
 /* the scaler above 8 bits (sws_scale16.hip): one record per output plane (an interleaved UV plane is two records, one per channel) */

@@ -128,8 +128,13 @@ __device__ __forceinline__ void w16_vdots(int (&d)[4], const uint32_t (&a0)[4], 
 
 /* NCH channels (1: a plane, 4 output columns per lane; 2: the two chroma channels of an interleaved source and / or target, 2 output
  * columns of each per lane — the same four samples and the same register budget either way) */
-template <int HT, int VT, int NCH>
-__device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Args &A, int f, int strip, int cb, int lane)
+#define W16_SEG 1056 /* bytes of one staged row segment: 64 lanes x 16 bytes + the dword a window may read past its last sample */
+
+/* STG (round 6): the source row segment under a wave's windows goes through LDS — one 16-byte global load per lane and row instead of
+ * four to eight overlapping 8..16-byte loads (r04_walk16_pmc.txt: 43 % of the wave cycles were issue stalls behind them); wl = this wave's
+ * 2 x W16_SEG bytes */
+template <int HT, int VT, int NCH, bool STG>
+__device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Args &A, int f, int strip, int cb, int lane, uint8_t *wl)
 {
     constexpr int R = VT - 1;          /* ring slots: pairs that end at rows r, r-1, ..., r-(VT-2) */
     constexpr int HP = HT / 2, VP = VT / 2;
@@ -218,6 +223,82 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
         }
     };
 
+    /* ---- STG: the wave's segment of a source row: global -> registers (one row ahead) -> LDS -> the lanes' windows ---- */
+    constexpr int NPL = NCH == 2 ? 2 : 1;      /* source planes a row comes from (an interleaved source: one) */
+    const int npl = NCH == 2 && !sil ? 2 : 1;
+    const uint32_t seg0 = STG ? (uint32_t)__builtin_amdgcn_readfirstlane((int)soff[0]) & ~15u : 0u; /* positions ascend: the first lane's first window starts the segment */
+    const uint32_t rowbytes = (uint32_t)J.srcW * (sil ? 4u : 2u);
+    w16_u4 stg[NPL];
+    auto stage_load = [&](int row) {
+        const int rr = min(row, srcH - 1);
+        const uint32_t o = seg0 + 16u * (uint32_t)lane;
+#pragma unroll
+        for (int p = 0; p < NPL; p++) {
+            if (p >= npl)
+                break;
+            const uint8_t *rp = (p ? sb1 : sb0) + (ptrdiff_t)rr * (p ? ss1 : ss0);
+            w16_u4 v = { 0, 0, 0, 0 };
+            if (o + 16u <= rowbytes) {
+                v = *reinterpret_cast<const w16_u4d *>(rp + o);
+            } else if (o < rowbytes) { /* the row's ragged end: nothing is read past its last sample */
+                uint32_t q[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (o + 4u * k + 4u <= rowbytes)
+                        q[k] = *reinterpret_cast<const uint32_t *>(rp + o + 4 * k);
+                    else if (o + 4u * k + 2u <= rowbytes)
+                        q[k] = *reinterpret_cast<const uint16_t *>(rp + o + 4 * k);
+                }
+                v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = q[3];
+            }
+            stg[p] = v;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPL; p++) {
+            if (p >= npl)
+                break;
+            *reinterpret_cast<w16_u4 *>(wl + p * W16_SEG + 16 * lane) = stg[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    /* the windows of the staged row, as load_row() leaves them */
+    auto lds_row = [&](Row &o) {
+        if (NCH == 2 && sil) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                uint32_t q[HT];
+                const uint8_t *p = wl + (soff[i] - seg0);
+#pragma unroll
+                for (int k = 0; k < HT; k++)
+                    q[k] = *reinterpret_cast<const uint32_t *>(p + 4 * k);
+#pragma unroll
+                for (int m = 0; m < HP; m++) {
+                    o.pr[0][i][m] = __builtin_amdgcn_perm(q[2 * m + 1], q[2 * m], 0x05040100u);
+                    o.pr[NCH - 1][i][m] = __builtin_amdgcn_perm(q[2 * m + 1], q[2 * m], 0x07060302u);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                uint32_t q[HP + 1];
+                const uint8_t *p = wl + ch * W16_SEG + (soff[i] - seg0);
+#pragma unroll
+                for (int k = 0; k <= HP; k++)
+                    q[k] = *reinterpret_cast<const uint32_t *>(p + 4 * k);
+#pragma unroll
+                for (int m = 0; m < HP; m++)
+                    o.pr[ch][i][m] = __builtin_amdgcn_alignbyte(q[m + 1], q[m], sodd[i]);
+            }
+        }
+    };
+
     uint32_t ring[R][NCH][NC];
     int hprev[NCH][NC];
 #pragma unroll
@@ -295,14 +376,27 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     const int rlast = __builtin_amdgcn_readlane(vpl, y1 - 1 - y0) + VT - 1;
     int r = need - (VT - 1);
     Row cur, nxt;
-    load_row(cur, r);
+    if (STG) {
+        stage_load(r);
+        stage_store();
+        lds_row(cur);
+        stage_load(r + 1);
+    } else {
+        load_row(cur, r);
+    }
     const int kround = d8 ? 0 : 1 << (vsh - 1);
     while (r <= rlast) {
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const int rr = r + k;
             if (rr <= rlast) { /* uniform */
-                load_row(nxt, rr + 1);
+                if (STG) {
+                    stage_store();      /* row rr + 1, in flight since the previous step (the LDS reads of row rr were issued before: in order) */
+                    stage_load(rr + 2);
+                    lds_row(nxt);
+                } else {
+                    load_row(nxt, rr + 1);
+                }
                 hpass(cur, ring[k]);
                 while (yy < y1 && need <= rr) {
                     /* the row's VT coefficients as VT / 2 pairs: wave-uniform, scalar loads */
@@ -429,9 +523,10 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     }
 }
 
-template <int HT, int VT>
+template <int HT, int VT, bool STG = false>
 __global__ __launch_bounds__(256) void k_sws_walk16(FFHipW16Args A)
 {
+    __shared__ __align__(16) uint8_t seg[STG ? 4 : 1][STG ? 2 * W16_SEG : 16];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
@@ -446,9 +541,9 @@ __global__ __launch_bounds__(256) void k_sws_walk16(FFHipW16Args A)
     const int local = u - J.unit_begin;
     const int strip = local / J.ncb, cb = local - strip * J.ncb;
     if (J.nch == 2) /* (both forms keep four samples per lane: the same register budget) */
-        w16_unit<HT, VT, 2>(J, A, f, strip, cb, lane);
+        w16_unit<HT, VT, 2, STG>(J, A, f, strip, cb, lane, seg[STG ? wave : 0]);
     else
-        w16_unit<HT, VT, 1>(J, A, f, strip, cb, lane);
+        w16_unit<HT, VT, 1, STG>(J, A, f, strip, cb, lane, seg[STG ? wave : 0]);
 }
 
 /* ================================================================================================== */
@@ -481,6 +576,25 @@ bool ffhip_w16_pad_bank(const int16_t *filter, const int32_t *pos, int size, int
     return true;
 }
 
+/* the widest span, in bytes from a 16-byte boundary, that the windows of `cols` adjacent columns cover in a source row (`bytes_per_column`:
+ * 2 planar, 4 an interleaved pair; planar windows start at the even sample at or below theirs and may read the dword after their last
+ * sample); 0 when the positions do not ascend */
+int ffhip_w16_span(const int32_t *pos, int n, int cols, int bytes_per_column, int taps)
+{
+    int mx = 0;
+    for (int x = 1; x < n; x++)
+        if (pos[x] < pos[x - 1])
+            return 0;
+    for (int b = 0; b < n; b += cols) {
+        const int first = pos[b], last = pos[(b + cols < n ? b + cols : n) - 1];
+        const int lo = ((bytes_per_column == 2 ? first & ~1 : first) * bytes_per_column) & ~15;
+        const int hi = bytes_per_column == 2 ? (last & ~1) * 2 + 2 * taps + 4 : (last + taps) * 4;
+        if (hi - lo > mx)
+            mx = hi - lo;
+    }
+    return mx;
+}
+
 void ffhip_w16_plan_job(FFHipW16Job *j, int strip_target)
 {
     j->ncb = cdiv(j->dstW, j->nch == 2 ? 128 : 256); /* 64 lanes x 4 columns of a plane / 2 columns of both channels */
@@ -505,6 +619,17 @@ int ffhip_launch_walk16(FFHipW16Args &A, hipStream_t stream)
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    bool stg = A.ht <= 8 && A.vt <= 8;
+    for (int i = 0; i < A.njobs; i++)
+        stg = stg && A.job[i].stage;
+    if (stg) { /* round 6: source row segments through LDS */
+        if (A.ht == 4 && A.vt == 4)      hipLaunchKernelGGL((k_sws_walk16<4, 4, true>), grid, block, 0, stream, A);
+        else if (A.ht == 8 && A.vt == 4) hipLaunchKernelGGL((k_sws_walk16<8, 4, true>), grid, block, 0, stream, A);
+        else if (A.ht == 4 && A.vt == 8) hipLaunchKernelGGL((k_sws_walk16<4, 8, true>), grid, block, 0, stream, A);
+        else                             hipLaunchKernelGGL((k_sws_walk16<8, 8, true>), grid, block, 0, stream, A);
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (A.ht == 4 && A.vt == 4)
         hipLaunchKernelGGL((k_sws_walk16<4, 4>), grid, block, 0, stream, A);
     else if (A.ht == 8 && A.vt == 4)

@@ -50,6 +50,7 @@ struct FFHipSwsContext {
     /* the column walker above 8 bits (sws_walk16.hip): banks padded to w16_ht x w16_vt taps on the device */
     int w16_ok = 0, w16_ht = 0, w16_vt = 0;
     void *w16_dev = nullptr;
+    int w16_span[2][3] = {};           /* [luma, chroma][a plane job (256 columns), a pair job on planes (128), a pair job on an interleaved plane] */
     const int16_t *w16_f[4] = { nullptr, nullptr, nullptr, nullptr };
     const int32_t *w16_p[4] = { nullptr, nullptr, nullptr, nullptr };
     int up2_ok = 0;
@@ -759,6 +760,11 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                         c->w16_ht = ht;
                         c->w16_vt = vt;
                         c->w16_ok = 1;
+                        for (int i = 0; i < 2; i++) {
+                            c->w16_span[i][0] = ffhip_w16_span(pp[i].data(), c->d[i].n, 256, 2, ht);
+                            c->w16_span[i][1] = ffhip_w16_span(pp[i].data(), c->d[i].n, 128, 2, ht);
+                            c->w16_span[i][2] = ffhip_w16_span(pp[i].data(), c->d[i].n, 128, 4, ht);
+                        }
                     }
                 }
             }
@@ -1327,6 +1333,16 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 j.srcH = which ? c->chrSrcH : t.srcH;
                 j.dstW = c->d[which].n; j.dstH = c->d[2 + which].n;
                 j.hf = c->w16_f[which]; j.hp = c->w16_p[which]; j.vf = c->w16_f[2 + which]; j.vp = c->w16_p[2 + which];
+                j.srcW = which ? c->chrSrcW : t.srcW;
+                {
+                    const char *eg = FFHIP_KNOB("FFHIP_W16_STAGE"); /* measure build: 0 keeps the per-lane global loads */
+                    const int sp = c->w16_span[which][nch == 1 ? 0 : j.sstep == 2 ? 2 : 1];
+                    /* staged when a wave's windows cover at most 512 bytes of a source row, i.e. when the picture grows: adjacent lanes'
+                     * windows then overlap several times over and the per-lane loads fetched every sample four to eight times (measured,
+                     * profiles/r06_walk16_lds.txt: p010 720p -> 1080p 0.270 -> 0.353, yuv420p10 1080p -> 1440p 0.329 -> 0.401 of HBM); wider
+                     * spans (down-scaling: 4K -> 1440p flat, 1080p -> 720p -4 %) keep the direct loads; FFHIP_W16_STAGE=1 stages up to 1 KiB */
+                    j.stage = sp > 0 && sp <= (eg && eg[0] == '1' ? 1024 : 512) && !(eg && eg[0] == '0');
+                }
                 ffhip_w16_plan_job(&j, strip);
             };
             job(0, 1, 0, 0);
