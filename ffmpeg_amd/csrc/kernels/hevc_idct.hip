@@ -240,120 +240,6 @@ __global__ __launch_bounds__(256) void k_hevc_idct(int kind, int16_t *coeffs, ui
 
 /* ================================================================================================== */
 /*
- * k_hevc_idct8_tb (round 6) — the 8x8 inverse transform + add_residual with ONE THREAD PER BLOCK, the shape of k_h264_idct8_add (0.69 of
- * HBM on the same traffic: 6 bytes per sample).  The lane-per-column kernel above moves every coefficient through LDS as a single int16
- * three times (8 ds_read_u16 + 8 ds_write_b16 per lane and pass) and ran at 0.50; here a workgroup copies its 256 blocks into LDS in
- * 16-byte pieces, a thread reads ITS block as eight ds_read_b128, runs both passes in registers, writes the residual back through LDS
- * (coalesced, in place: the reference leaves it in coeffs) and adds its eight rows to the picture with 8-byte (16-byte above 8 bits)
- * accesses — adjacent threads hold adjacent blocks, so a row instruction of a wave covers 512 contiguous picture bytes.
- * Arithmetic: idct_8x8 (libavcodec/hevc/dsp_template.c:150-240: TR_8 over TR_4, the odd inputs below `end` only, SCALE's
- * av_clip_int16((x + add) >> shift), shifts 7 and 20 - bit depth; limit2 shrinking by 4 after column 4) on the standard's matrix.
- */
-#define HV8_REC 144 /* LDS record of one block: 128 bytes + 16 => conflict-free ds_read_b128 / ds_write_b128 */
-
-__device__ __forceinline__ void hevc8_1d(const int (&s)[8], int end, int shift, int (&out)[8])
-{
-    const int add = 1 << (shift - 1);
-    /* TR_4 on s0, s2, s4, s6 (always whole) */
-    const int e0 = 64 * (s[0] + s[4]), e1 = 64 * (s[0] - s[4]);
-    const int o0 = __mul24(83, s[2]) + __mul24(36, s[6]), o1 = __mul24(36, s[2]) - __mul24(83, s[6]);
-    const int e[4] = { e0 + o0, e1 + o1, e1 - o1, e0 - o0 };
-    /* odd inputs j < end: rows 4, 12, 20, 28 of the 32x32 matrix, columns 0..3 */
-    const int s1 = s[1], s3 = end > 3 ? s[3] : 0, s5 = end > 5 ? s[5] : 0, s7 = end > 7 ? s[7] : 0;
-    const int o[4] = { __mul24(89, s1) + __mul24(75, s3) + __mul24(50, s5) + __mul24(18, s7),
-                       __mul24(75, s1) - __mul24(18, s3) - __mul24(89, s5) - __mul24(50, s7),
-                       __mul24(50, s1) - __mul24(89, s3) + __mul24(18, s5) + __mul24(75, s7),
-                       __mul24(18, s1) - __mul24(50, s3) + __mul24(75, s5) - __mul24(89, s7) };
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        out[i] = hevc_clip16((e[i] + o[i] + add) >> shift);
-        out[7 - i] = hevc_clip16((e[i] - o[i] + add) >> shift);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_hevc_idct8_tb(int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipHevcTU *tus, int n, int bd)
-{
-    __shared__ __align__(16) uint8_t lds[256 * HV8_REC];
-    const int tid = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * 256;
-    const int nb = (int)min(256LL, (long long)n - b0);
-    /* coalesced copy in: 8 x 16-byte pieces per block, each block from its own coeff_offset (as dwords where a block does not sit on a
-     * 16-byte boundary, like the kernel above) */
-    for (int it = tid; it < nb * 8; it += 256) {
-        const int16_t *g = coeffs + tus[b0 + (it >> 3)].coeff_offset;
-        uint4 v;
-        if (!(reinterpret_cast<uintptr_t>(g) & 15)) {
-            v = reinterpret_cast<const uint4 *>(g)[it & 7];
-        } else {
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(g) + 4 * (it & 7);
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-        *reinterpret_cast<uint4 *>(lds + (it >> 3) * HV8_REC + (it & 7) * 16) = v;
-    }
-    __syncthreads();
-    FFHipHevcTU tu = { 0, -1, 0 };
-    int res[8][8];
-    if (tid < nb) {
-        tu = tus[b0 + tid];
-        uint32_t r[8][4];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(lds + tid * HV8_REC + k * 16);
-            r[k][0] = v.x; r[k][1] = v.y; r[k][2] = v.z; r[k][3] = v.w;
-        }
-        const int limit = min((int)tu.col_limit, 8);
-        int limit2 = min((int)tu.col_limit + 4, 8);
-        int t[8][8]; /* t[k][i]: row k, column i after the column pass */
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int in[8], o[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t v = r[k][i >> 1];
-                in[k] = (i & 1) ? (int)(int16_t)(v >> 16) : (int)(int16_t)(v & 0xFFFF);
-            }
-            hevc8_1d(in, limit2, 7, o);
-            if (limit2 < 8 && i == 4)   /* `if (limit2 < H && i % 4 == 0 && !!i) limit2 -= 4` */
-                limit2 -= 4;
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                t[k][i] = o[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            hevc8_1d(t[k], limit, 20 - bd, res[k]);
-        /* the residual, back into the block's LDS record */
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint4 v;
-            v.x = (uint32_t)(uint16_t)res[k][0] | (uint32_t)(uint16_t)res[k][1] << 16;
-            v.y = (uint32_t)(uint16_t)res[k][2] | (uint32_t)(uint16_t)res[k][3] << 16;
-            v.z = (uint32_t)(uint16_t)res[k][4] | (uint32_t)(uint16_t)res[k][5] << 16;
-            v.w = (uint32_t)(uint16_t)res[k][6] | (uint32_t)(uint16_t)res[k][7] << 16;
-            *reinterpret_cast<uint4 *>(lds + tid * HV8_REC + k * 16) = v;
-        }
-    }
-    __syncthreads();
-    for (int it = tid; it < nb * 8; it += 256) {
-        int16_t *g = coeffs + tus[b0 + (it >> 3)].coeff_offset;
-        const uint4 v = *reinterpret_cast<const uint4 *>(lds + (it >> 3) * HV8_REC + (it & 7) * 16);
-        if (!(reinterpret_cast<uintptr_t>(g) & 15)) {
-            reinterpret_cast<uint4 *>(g)[it & 7] = v;
-        } else {
-            uint32_t *w = reinterpret_cast<uint32_t *>(g) + 4 * (it & 7);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        }
-    }
-    if (dst && tid < nb && tu.dst_offset >= 0) {
-        uint8_t *d = dst + tu.dst_offset;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            ffhip_add_row<8>(d + (ptrdiff_t)k * stride, res[k], bd);
-    }
-}
-
-/* ================================================================================================== */
-/*
  * k_hevc_idct32_mfma — the 32x32 inverse transform on the matrix cores (north_star: "MFMA only if the product genuinely becomes
  * a dense contraction" — this one is: a 32x32 int8 matrix, |T| <= 90, times a 32x32 int16 block, twice).
  * One wave per transform unit, v_mfma_i32_32x32x32_i8 (A: lane = row l & 31, 16 K-bytes of group l >> 5; B: lane = column; D: lane =
@@ -721,15 +607,6 @@ int ffhip_launch_hevc_idct_bd(int bd, int kind, int log2_size, int16_t *coeffs, 
             if (r < 0)
                 return r;
             hipLaunchKernelGGL(k_hevc_idct16_mfma, dim3(cdiv(n, 8)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd, g_hm_tab16_dev[ffhip_current_device()]);
-            LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    {
-        /* 8x8 IDCT: one thread per block (round 6); FFHIP_HEVC_IDCT8_TB=0 (measure build) keeps the lane-per-column kernel */
-        const char *e8 = FFHIP_KNOB("FFHIP_HEVC_IDCT8_TB");
-        if (kind == FFHIP_HEVC_IDCT && log2_size == 3 && !(e8 && e8[0] == '0')) {
-            hipLaunchKernelGGL(k_hevc_idct8_tb, dim3(cdiv(n, 256)), dim3(256), 0, stream, coeffs, dst, stride, tus, n, bd);
             LAUNCH_CHECK();
             return 0;
         }

@@ -17,11 +17,9 @@ from ffmpeg_amd import hevc  # noqa: E402
 
 dev = torch.device("cuda", 0)
 ev = lambda: torch.cuda.Event(enable_timing=True)
-for lg, planes, valu, bd in ((5, 16, "0", 8), (5, 16, "1", 8), (5, 16, "0", 10), (4, 16, "0", 8), (4, 16, "m", 8), (4, 16, "0", 10), (3, 8, "0", 8),
-                             (3, 8, "c", 8), (3, 8, "0", 10), (3, 8, "c", 10), (3, 8, "0", 8), (3, 8, "c", 8)):
+for lg, planes, valu, bd in ((5, 16, "0", 8), (5, 16, "1", 8), (5, 16, "0", 10), (4, 16, "0", 8), (4, 16, "m", 8), (4, 16, "0", 10), (3, 8, "0", 8)):
     os.environ["FFHIP_HEVC_IDCT32_VALU"] = valu
     os.environ["FFHIP_HEVC_IDCT16_MFMA"] = "1" if valu == "m" else "0"
-    os.environ["FFHIP_HEVC_IDCT8_TB"] = "0" if valu == "c" else "1"   # c: the lane-per-column kernel of rounds 1-5 (round 6: one thread per block)
     nsz, ps = 1 << lg, 2 if bd > 8 else 1
     bw, bh = 3840 // nsz, 2160 // nsz
     ntu = planes * bw * bh
@@ -47,7 +45,7 @@ for lg, planes, valu, bd in ((5, 16, "0", 8), (5, 16, "1", 8), (5, 16, "0", 10),
         tot += e0.elapsed_time(e1)
     ms = tot / 5
     gbs = ntu * nsz * nsz * (4 + 2 * ps) / (ms * 1e-3) / 1e9
-    print(json.dumps({"case": "hevc idct%d + add_residual, %d-bit%s" % (nsz, bd, " (dot2 kernel)" if valu == "1" else " (two units per MFMA)" if valu == "m" else " (lane per column)" if valu == "c" else ""),
+    print(json.dumps({"case": "hevc idct%d + add_residual, %d-bit%s" % (nsz, bd, " (dot2 kernel)" if valu == "1" else " (two units per MFMA)" if valu == "m" else ""),
                       "Mblocks/s": round(ntu / (ms * 1e-3) / 1e6, 1), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / 8000, 4), "blocks": ntu,
                       "ms": round(ms, 4)}), flush=True)
     del cc, c0, pic, d_t
