@@ -1483,7 +1483,7 @@ def main():
         torch.cuda.empty_cache()
         strong = strong_leg(torch, dist, dev, ctx, S, rank, world, n)
 
-    kname = "k_sws_up2<3, 0, 0, 0>" if ctx.up2_path else "k_sws_colwalk<1,6,false,true,true>" if ctx.fast_path else "k_sws_scale_yuv<4,4>"
+    kname = "k_sws_up2<6, 1, 0, 0, 1>" if ctx.up2_path else "k_sws_colwalk<1,6,false,true,true>" if ctx.fast_path else "k_sws_scale_yuv<4,4>"
     traffic, traffic_source = None, None
     if rank == 0 and world == 1 and not args.no_pmc:
         traffic, traffic_source = measure_traffic(kname, n)

@@ -2002,7 +2002,14 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                         break;
                 }
                 /* FFHIP_UP2_VAR: 0 the product; 16 / 48 / 64 = measurement-only builds (no stores / arithmetic only / bytes only) */
-                return ffhip_launch_up2(U, ed && ed[0] == '6' ? 6 : 3, ev2 ? atoi(ev2) : 0, stream);
+                /* round 6, the product: the horizontal bank in SGPRs, six source rows in flight, non-temporal stores (variant 3 at depth 6:
+                 * +0.4 .. +0.7 % over rounds 2-5's kernel on two boxes, profiles/r06_up2_variants.txt; each ingredient alone is within
+                 * +-0.5 %); FFHIP_UP2_VAR=0 FFHIP_UP2_DEPTH=3 (measure build) is that kernel.  Banks whose interior columns are not the two
+                 * phase rows (ffhip_up2_hco) fall back to it inside the launcher. */
+                bool scal = !U.job[0].rc_coeff;     /* (the range-converting twin keeps its own instantiation) */
+                for (int i = 0; i < U.njobs; i++)
+                    scal = scal && U.job[i].hco_ok;
+                return ffhip_launch_up2(U, ed ? (ed[0] == '6' ? 6 : 3) : scal ? 6 : 3, ev2 ? atoi(ev2) : scal ? 3 : 0, stream);
             }
         }
         if (!(al & 3) && !c->up2_rc) {
