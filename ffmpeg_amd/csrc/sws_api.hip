@@ -2246,6 +2246,12 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
 static hipError_t copy2d(void *dst, ptrdiff_t dpitch, const void *src, ptrdiff_t spitch, size_t wbytes, int rows,
                          hipMemcpyKind kind)
 {
+    /* rows that follow each other on both sides: ONE linear copy.  Round 6: the runtime moves pageable memory through a 2-D copy at about
+     * half the rate of a linear one (nv12 1080p -> 4K through ffhip_sws_scale: 0.75 -> 0.38 ms per frame, 41 GB/s over PCIe both ways,
+     * profiles/r06_host_face.txt), so the staging buffer keeps rows of a multiple of 64 bytes tight and a tight host plane is copied
+     * linearly.  (Registering the caller's buffers after a few sightings was measured too: no faster than this, and not kept.) */
+    if (dpitch == (ptrdiff_t)wbytes && spitch == (ptrdiff_t)wbytes)
+        return hipMemcpy(dst, src, wbytes * (size_t)rows, kind);
     if (dpitch >= (ptrdiff_t)wbytes && spitch >= (ptrdiff_t)wbytes)
         return hipMemcpy2D(dst, dpitch, src, spitch, wbytes, rows, kind);
     for (int r = 0; r < rows; r++) { /* negative (bottom-up) strides: swscale.c:1141-1158 */
@@ -2336,12 +2342,12 @@ static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], cons
     size_t off_s[4], off_d[3], total = 0;
     int pitch_s[4] = { 0, 0, 0, 0 }, pitch_d[4] = { 0, 0, 0, 0 };
     for (int i = 0; i < ns; i++) {
-        pitch_s[i] = (sp[i].wbytes + 255) & ~255;
+        pitch_s[i] = sp[i].wbytes % 64 ? (sp[i].wbytes + 255) & ~255 : sp[i].wbytes; /* (tight rows copy linearly from a tight host plane) */
         off_s[i] = total;
         total += (size_t)pitch_s[i] * sp[i].rows + 256;
     }
     for (int i = 0; i < nd; i++) {
-        pitch_d[i] = (dp[i].wbytes + 255) & ~255;
+        pitch_d[i] = dp[i].wbytes % 64 ? (dp[i].wbytes + 255) & ~255 : dp[i].wbytes;
         off_d[i] = total;
         total += (size_t)pitch_d[i] * dp[i].rows + 256;
     }

@@ -98,6 +98,29 @@ def test_unscaled_launch_tuner_keeps_the_bytes(dst):
     ctx.close()
 
 
+def test_host_frames_that_come_back_are_still_right():
+    """round 6: the host-pointer face copies tight planes linearly (copy2d(), sws_api.hip: twice the PCIe rate of the 2-D copy it used).
+    The bytes must be the oracle's on every call for the SAME host buffers handed over again and again, for buffers that are then freed
+    and replaced (other addresses or, as malloc likes to, the same), and for content that changes between calls in place."""
+    from ffmpeg_amd import swscale as S
+    w, h = 1920, 1080
+    ctx = S.SwsContext(w, h, PIX["yuv420p"], w, h, PIX["rgb24"], S.SWS_BICUBIC)
+    for round_ in range(3):
+        rng = np.random.default_rng(500 + round_)
+        src = ffi.alloc_frame(PIX["yuv420p"], w, h, rng)
+        hd = np.zeros((h, 3 * w), np.uint8)
+        for call in range(6):
+            if call == 4:                    # new content in the (by now registered) buffers
+                for pl in src:
+                    pl[:] = rng.integers(0, 256, pl.shape, dtype=np.uint8)
+            want = _oracle_unscaled(src, w, h, ffi.RGB_LAYOUT[PIX["rgb24"]])
+            hd[:] = 0
+            assert ctx.scale(src, [hd]) == h
+            assert np.array_equal(hd, want), "round %d call %d" % (round_, call)
+        del src, hd
+    ctx.close()
+
+
 FORM_CASES = [(sf, df) for sf in ("yuv422p", "yuva420p") for df in ("rgb24", "bgr24", "argb", "rgba", "abgr", "bgra", "gbrp")] + [("yuv420p", "gbrp")]
 
 
