@@ -91,6 +91,8 @@ def lib():
         "ffhip_last_error": (C.c_char_p, []),
         "ffhip_version": (C.c_char_p, []),
         "ffhip_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+        "ffhip_frames_alloc": (C.c_int, [C.POINTER(vp), C.c_size_t, C.c_size_t]),
+        "ffhip_frames_free": (C.c_int, [vp]),
         "ffhip_free": (C.c_int, [vp]),
         "ffhip_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
         "ffhip_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
@@ -280,3 +282,40 @@ def check(rc, what="ffhip call"):
     if rc is None or (isinstance(rc, int) and rc < 0):
         raise RuntimeError("%s failed (%s): %s" % (what, rc, lib().ffhip_last_error().decode()))
     return rc
+
+
+class FrameMemory:
+    """A range of ffhip_frames_alloc() (device memory whose virtual and physical addresses share a large alignment) that torch can view:
+    `.tensor(shape, offset)` gives uint8 tensors inside it through __cuda_array_interface__; the range lives as long as this object."""
+
+    def __init__(self, nbytes, chunk=0):
+        p = C.c_void_p()
+        check(lib().ffhip_frames_alloc(C.byref(p), nbytes, chunk), "ffhip_frames_alloc")
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def tensor(self, shape, offset=0):
+        import torch
+        n = 1
+        for s_ in shape:
+            n *= s_
+        assert offset + n <= self.nbytes
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (self.ptr + offset, False), "version": 3, "strides": None}
+        v._keep = self
+        t = torch.as_tensor(v, device="cuda")
+        t._ffhip_frames = self          # the tensor keeps the range alive
+        return t
+
+    def close(self):
+        if self.ptr:
+            lib().ffhip_frames_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -356,6 +356,111 @@ static void membw_launch(int variant, const bw_u4 *a, bw_u4 *b, size_t n_rd, uin
 #undef MB
 }
 
+/* ---- frame memory with page-table friendly alignment (include/ffhip.h: ffhip_frames_alloc) ------------------------------------ */
+namespace {
+struct FrameRange { void *va; size_t size, chunk; std::vector<hipMemGenericAllocationHandle_t> h; };
+std::mutex g_frames_mu;
+std::vector<FrameRange> g_frames;
+} // namespace
+
+extern "C" int ffhip_frames_alloc(void **ptr, size_t bytes, size_t chunk)
+{
+    if (!ptr || !bytes)
+        return FFHIP_EINVAL;
+    *ptr = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return FFHIP_ENOSYS;
+    }
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) {
+        (void)hipGetLastError();
+        ffhip_set_error("ffhip_frames_alloc: no virtual memory management on device %d", dev);
+        return FFHIP_ENOSYS;
+    }
+    if (!chunk)
+        chunk = (size_t)1 << 30;
+    if ((chunk & (chunk - 1)) || chunk < gran) {
+        ffhip_set_error("ffhip_frames_alloc: chunk %zu is not a power of two of at least the granularity %zu", chunk, gran);
+        return FFHIP_EINVAL;
+    }
+    FrameRange r;
+    r.chunk = chunk;
+    r.size = (bytes + chunk - 1) / chunk * chunk;
+    r.va = nullptr;
+    if (hipMemAddressReserve(&r.va, r.size, chunk, nullptr, 0) != hipSuccess || !r.va) {
+        (void)hipGetLastError();
+        ffhip_set_error("ffhip_frames_alloc: hipMemAddressReserve(%zu, alignment %zu) failed", r.size, chunk);
+        return FFHIP_ENOMEM;
+    }
+    bool ok = true;
+    for (size_t o = 0; o < r.size && ok; o += chunk) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
+            ok = false;
+            break;
+        }
+        r.h.push_back(h);
+        if (hipMemMap((uint8_t *)r.va + o, chunk, 0, h, 0) != hipSuccess)
+            ok = false;
+    }
+    if (ok) {
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = dev;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(r.va, r.size, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        for (size_t i = 0; i < r.h.size(); i++) {
+            (void)hipMemUnmap((uint8_t *)r.va + i * chunk, chunk);
+            (void)hipMemRelease(r.h[i]);
+        }
+        (void)hipMemAddressFree(r.va, r.size);
+        (void)hipGetLastError();
+        ffhip_set_error("ffhip_frames_alloc: mapping %zu bytes in chunks of %zu failed", r.size, chunk);
+        return FFHIP_ENOMEM;
+    }
+    *ptr = r.va;
+    std::lock_guard<std::mutex> lk(g_frames_mu);
+    g_frames.push_back(std::move(r));
+    return 0;
+}
+
+extern "C" int ffhip_frames_free(void *ptr)
+{
+    if (!ptr)
+        return 0;
+    FrameRange r;
+    {
+        std::lock_guard<std::mutex> lk(g_frames_mu);
+        size_t i = 0;
+        for (; i < g_frames.size(); i++)
+            if (g_frames[i].va == ptr)
+                break;
+        if (i == g_frames.size()) {
+            ffhip_set_error("ffhip_frames_free: %p is not a range of ffhip_frames_alloc", ptr);
+            return FFHIP_EINVAL;
+        }
+        r = std::move(g_frames[i]);
+        g_frames.erase(g_frames.begin() + (ptrdiff_t)i);
+    }
+    (void)hipDeviceSynchronize();
+    for (size_t i = 0; i < r.h.size(); i++) {
+        (void)hipMemUnmap((uint8_t *)r.va + i * r.chunk, r.chunk);
+        (void)hipMemRelease(r.h[i]);
+    }
+    (void)hipMemAddressFree(r.va, r.size);
+    (void)hipGetLastError();
+    return 0;
+}
+
 extern "C" int ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gbps)
 {
     if (pattern < 0 || pattern > 5 || bytes < (1u << 20) || reps < 1 || !gbps)

@@ -68,6 +68,20 @@ int         ffhip_stream_order(void *first, void *then);
  *  slices) and answer with the best one.  `bytes` = the larger side's buffer; *gbps = bytes moved per second / 1e9 over `reps`
  *  launches of that variant (HIP events). */
 int         ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gbps);
+/**
+ * Device memory for frame batches, laid out for the GPU's page tables (round 6).  What a streaming kernel over several gigabytes gets
+ * out of HBM depends on how large the fragments of its page-table entries are, and a fragment can only be as large as the alignment
+ * the allocation's virtual AND physical addresses share — which plain hipMalloc leaves to chance per allocation (measured: 0.57 … 0.66
+ * of HBM for the same launch of the bench kernel, process by process and allocation by allocation, profiles/r06_alloc_*.txt).
+ * ffhip_frames_alloc() reserves a virtual range aligned to `chunk` bytes (0: 1 GiB; a power of two, at least the device's
+ * allocation granularity) and backs it with physical allocations of `chunk` bytes each, mapped chunk by chunk, so that both sides are
+ * aligned alike.  *ptr: the range, usable by every kernel, copy and torch view of the current device; the tail of the last chunk is
+ * mapped too.  This is what the FFmpeg-side frame pool (integration/avutil_hwcontext_hip.c) allocates its batches with.
+ * Returns 0, FFHIP_EINVAL, FFHIP_ENOMEM or FFHIP_ENOSYS (no virtual memory management on this device / runtime).
+ */
+int         ffhip_frames_alloc(void **ptr, size_t bytes, size_t chunk);
+/** Unmaps and releases a range ffhip_frames_alloc() returned (NULL: nothing).  0 or FFHIP_EINVAL (not such a range). */
+int         ffhip_frames_free(void *ptr);
 const char *ffhip_last_error(void);
 const char *ffhip_version(void);
 /** Device memory helpers for callers that do not bring their own allocator. */

@@ -53,4 +53,5 @@ def test_sws_scale_of_scaled_contexts_goes_through_the_hip_swsfunc():
     # round 6: the frame API asking for TARGET slices of a scaled picture (slice -64 / -1 / -32 in the listing) gives the C
     # scaler's picture; SWS_FAST_BILINEAR contexts (flags 0x1) are left to ff_swscale() like the dithered 16-bit target and the gray source
     assert sum(" slice -" in l and l.startswith("OK  ") for l in lines) == 3, tail
-    assert sum("left to C" in l for l in lines) == 4 and sum("flags 0x1 " in l and "left to C" in l for l in lines) == 2, tail
+    # (counted over the whole output: the runtime's own stderr lines can land inside a line of the listing)
+    assert r.stdout.count("left to C") == 4 and sum("flags 0x1 " in l for l in lines) == 2, tail
