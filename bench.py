@@ -258,7 +258,24 @@ def measure_traffic(kname, frames):
         "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE (2 passes), 2*FETCH + WRITE"
 
 
-def rgb24_leg(torch, dev):
+def frame_batches(torch, dev, _lib, src_shapes, dst_shapes, torch_alloc=False):
+    """uint8 tensors of the given shapes: source batches in one range of ffhip_frames_alloc(), target batches in another (each plane batch on
+    a 2 MiB boundary), or plain torch tensors"""
+    if torch_alloc:
+        return ([torch.empty(s_, dtype=torch.uint8, device=dev) for s_ in src_shapes], [torch.empty(s_, dtype=torch.uint8, device=dev) for s_ in dst_shapes])
+    out = []
+    for shapes in (src_shapes, dst_shapes):
+        sizes = [int(np.prod(s_)) for s_ in shapes]
+        offs, at = [], 0
+        for z in sizes:
+            offs.append(at)
+            at += (z + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        mem = _lib.FrameMemory(at)
+        out.append([mem.tensor(s_, o) for s_, o in zip(shapes, offs)])
+    return out[0], out[1]
+
+
+def rgb24_leg(torch, dev, torch_alloc=False):
     """north_star's first target: unscaled yuv420p -> rgb24, 3840x2160, 64-frame batch resident in HBM (4.5 B/pixel), HIP events around
     50 launches after 10 untimed ones, and this box's streaming probe at the kernel's own 1 : 2 read : write mix."""
     from ffmpeg_amd import swscale as S, _lib
@@ -266,11 +283,12 @@ def rgb24_leg(torch, dev):
     ev = lambda: torch.cuda.Event(enable_timing=True)
     n, w, h = 64, 3840, 2160
     ctx = S.SwsContext(w, h, 0, w, h, 2, 4)
-    src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(0, w, h)]
-    dst = [torch.empty((n, h, 3 * w), dtype=torch.uint8, device=dev)]
-    for _ in range(10):
+    src, dst = frame_batches(torch, dev, _lib, [(n, r, c) for r, c in S.plane_shapes(0, w, h)], [(n, h, 3 * w)], torch_alloc)
+    for t in src:
+        t.random_(0, 256)
+    for _ in range(12):
         ctx.scale_batch(src, dst)
-    torch.cuda.synchronize()      # the warm-up has finished: the context's launch tuner (ffhip_sws_tuned_numbering) can read its four timed launches
+    torch.cuda.synchronize()      # the warm-up has finished: the context's launch tuner (ffhip_sws_tuned_numbering) can read its eight timed launches
     ctx.scale_batch(src, dst)
     e0, e1 = ev(), ev()
     reps = 50
@@ -1362,6 +1380,8 @@ def main():
                          "on a cold device otherwise); reported in config.settle_ms, 0 switches it off")
     ap.add_argument("--sustain-ms", type=int, default=1200,
                     help="after the timed steps: back-to-back launches for this long, reported as roofline.frac_sustained (0 = skip)")
+    ap.add_argument("--torch-alloc", action="store_true",
+                    help="frame batches from torch's allocator (one hipMalloc each) instead of libffhip's frame memory (ffhip_frames_alloc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="skip the RCCL scatter/convert/gather leg at N>1")
@@ -1404,9 +1424,13 @@ def main():
     ctx = S.SwsContext(SRC_W, SRC_H, NV12, DST_W, DST_H, NV12, S.SWS_BICUBIC)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0xF0F00002 + rank)                       # SURVEY.md §8d seed, one shard per rank
-    src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev, generator=gen)
-           for r, c in S.plane_shapes(NV12, SRC_W, SRC_H)]
-    dst = [torch.empty((n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(NV12, DST_W, DST_H)]
+    # the frame batches live in libffhip's frame memory (ffhip_frames_alloc, include/ffhip.h: physical chunks of 16 MiB in shuffled
+    # order); --torch-alloc takes torch's allocator instead (one hipMalloc per plane batch, whose
+    # physical layout decides between 0.58 and 0.65 for the same launch, profiles/r06_alloc_vmm_sweep_*.txt)
+    src, dst = frame_batches(torch, dev, _lib, [(n, r, c) for r, c in S.plane_shapes(NV12, SRC_W, SRC_H)],
+                             [(n, r, c) for r, c in S.plane_shapes(NV12, DST_W, DST_H)], args.torch_alloc)
+    for t in src:
+        t.random_(0, 256, generator=gen)
     stream = torch.cuda.current_stream()
 
     def barrier():
@@ -1542,13 +1566,14 @@ def main():
             "config": {"workload": "swscale bicubic nv12 1920x1080 -> nv12 3840x2160, %d-frame batch per GPU, "
                                    "frames resident in HBM (BASELINE.json configs[1])" % n,
                        "frames_per_gpu": n, "flags": "SWS_BICUBIC", "sharding": "frames/rank, no data-path collective",
-                       "settle_ms": args.settle_ms, "sustain_ms": args.sustain_ms},
+                       "settle_ms": args.settle_ms, "sustain_ms": args.sustain_ms,
+                       "frames_alloc": "torch (hipMalloc)" if args.torch_alloc else "ffhip_frames_alloc: 16 MiB physical chunks, shuffled"},
         }
         ex, cpu = None, None
         if world == 1:
             # north_star's first target, measured in every N = 1 run (with or without the extras)
             try:
-                rgb = rgb24_leg(torch, dev)
+                rgb = rgb24_leg(torch, dev, args.torch_alloc)
                 roof.update({"rgb24_4k_frac": rgb["hbm_frac"], "rgb24_4k_ms": rgb["ms"], "rgb24_4k_Mpix": rgb["Mpixels/s"], "rgb24_4k_frames": rgb["frames"],
                              "rgb24_4k_tuned_numbering": rgb["tuned_numbering"]})
                 if "frac_of_box_probe_read1_write2" in rgb:

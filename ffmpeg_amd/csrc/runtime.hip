@@ -384,7 +384,7 @@ extern "C" int ffhip_frames_alloc(void **ptr, size_t bytes, size_t chunk)
         return FFHIP_ENOSYS;
     }
     if (!chunk)
-        chunk = (size_t)1 << 30;
+        chunk = (size_t)16 << 20;
     if ((chunk & (chunk - 1)) || chunk < gran) {
         ffhip_set_error("ffhip_frames_alloc: chunk %zu is not a power of two of at least the granularity %zu", chunk, gran);
         return FFHIP_EINVAL;
@@ -399,14 +399,37 @@ extern "C" int ffhip_frames_alloc(void **ptr, size_t bytes, size_t chunk)
         return FFHIP_ENOMEM;
     }
     bool ok = true;
-    for (size_t o = 0; o < r.size && ok; o += chunk) {
+    const size_t nch = r.size / chunk;
+    /* the physical chunks come out of the allocator one after the other (on an empty device: physically consecutive); they are mapped
+     * into the range in a fixed pseudo-random ORDER, so that the address bits above the chunk size of neighbouring pieces of the range
+     * have nothing to do with each other (FFHIP_FRAMES_ORDER=0, measure build: in order) */
+    std::vector<size_t> slot(nch);
+    for (size_t i = 0; i < nch; i++)
+        slot[i] = i;
+    {
+        const char *eo = FFHIP_KNOB("FFHIP_FRAMES_ORDER");
+        if (!(eo && eo[0] == '0')) {
+            uint32_t st = 0x9E3779B9u;
+            for (size_t i = nch; i > 1; i--) {
+                st = st * 1664525u + 1013904223u;
+                const size_t j = (size_t)(((uint64_t)(st >> 8) * i) >> 24);
+                const size_t t = slot[i - 1];
+                slot[i - 1] = slot[j];
+                slot[j] = t;
+            }
+        }
+    }
+    r.h.assign(nch, hipMemGenericAllocationHandle_t());
+    size_t made = 0;
+    for (size_t i = 0; i < nch && ok; i++) {
         hipMemGenericAllocationHandle_t h;
         if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
             ok = false;
             break;
         }
-        r.h.push_back(h);
-        if (hipMemMap((uint8_t *)r.va + o, chunk, 0, h, 0) != hipSuccess)
+        r.h[slot[i]] = h;       /* r.h[k]: the handle mapped at chunk k of the range */
+        made++;
+        if (hipMemMap((uint8_t *)r.va + slot[i] * chunk, chunk, 0, h, 0) != hipSuccess)
             ok = false;
     }
     if (ok) {
@@ -418,9 +441,9 @@ extern "C" int ffhip_frames_alloc(void **ptr, size_t bytes, size_t chunk)
     }
     if (!ok) {
         (void)hipGetLastError();
-        for (size_t i = 0; i < r.h.size(); i++) {
-            (void)hipMemUnmap((uint8_t *)r.va + i * chunk, chunk);
-            (void)hipMemRelease(r.h[i]);
+        for (size_t i = 0; i < made; i++) {
+            (void)hipMemUnmap((uint8_t *)r.va + slot[i] * chunk, chunk);
+            (void)hipMemRelease(r.h[slot[i]]);
         }
         (void)hipMemAddressFree(r.va, r.size);
         (void)hipGetLastError();

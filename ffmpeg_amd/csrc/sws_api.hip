@@ -59,8 +59,8 @@ struct FFHipSwsContext {
     const uint32_t *up2_h[2] = { nullptr, nullptr }, *up2_v[2] = { nullptr, nullptr };
     /* launch tuner of the table converter (round 6): which workgroup numbering of k_yuv420p_rgb24_t is faster is a property of the BOX
      * (profiles/r06_arena_offset_sweep.txt, r06_xcd_numbering_sweep.txt: eighth-per-XCD +1 .. +8 % on some, -4 % on others, whatever the
-     * addresses), so the first four large launches of a context run plain, eighth, eighth, plain between events and the rest take the winner */
-    hipEvent_t tune_ev[8] = {};
+     * addresses), so the first eight large launches of a context alternate the two between events and the rest take the winner */
+    hipEvent_t tune_ev[16] = {};
     int tune_n = 0, tune_choice = -1;
     uint32_t up2_hco[2][16] = {};      /* the horizontal banks as scalars (FFHipUp2Job.hco), when they have that shape */
     int up2_hco_ok[2] = { 0, 0 };
@@ -1145,7 +1145,7 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->mf_dev);
     if (c->up2_dev)
         (void)hipFree(c->up2_dev);
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 16; i++)
         if (c->tune_ev[i])
             (void)hipEventDestroy(c->tune_ev[i]);
     if (c->u2r_dev)
@@ -1452,9 +1452,9 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
     return r;
 }
 
-/* The numbering of a large launch of the table converter: 0 plain, 1 an eighth per XCD.  While undecided, launches 0..3 of the context run
- * plain, eighth, eighth, plain (a drift of the clocks cancels) and *slot names the event pair to record around this one; once all four
- * have finished the faster numbering is kept — the eighth only when it wins by 1.5 %.  No decision is forced: a query that finds an
+/* The numbering of a large launch of the table converter: 0 plain, 1 an eighth per XCD.  While undecided, launches 0..7 of the context run
+ * plain, eighth, eighth, plain, plain, eighth, eighth, plain (a drift of the clocks cancels) and *slot names the event pair to record
+ * around this one; once all eight have finished the faster numbering is kept — the eighth only when it wins by 2 %.  No decision is forced: a query that finds an
  * event pending leaves the default (plain) in place for this call.  Not while the stream is being captured into a graph. */
 static int tune_pick(FFHipSwsContext *c, hipStream_t stream, int *slot)
 {
@@ -1466,25 +1466,28 @@ static int tune_pick(FFHipSwsContext *c, hipStream_t stream, int *slot)
         (void)hipGetLastError();
         return 0;
     }
-    if (c->tune_n < 4) {
+    if (c->tune_n < 8) {
         if (!c->tune_ev[0])
-            for (int i = 0; i < 8; i++)
+            for (int i = 0; i < 16; i++)
                 if (hipEventCreate(&c->tune_ev[i]) != hipSuccess) {
                     (void)hipGetLastError();
                     c->tune_choice = 0;
                     return 0;
                 }
         *slot = c->tune_n;
-        return c->tune_n == 1 || c->tune_n == 2;
+        return (c->tune_n + 1) >> 1 & 1;       /* plain, eighth, eighth, plain, plain, eighth, eighth, plain */
     }
-    float e[4];
-    for (int i = 0; i < 4; i++)
-        if (hipEventQuery(c->tune_ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&e[i], c->tune_ev[2 * i], c->tune_ev[2 * i + 1]) != hipSuccess) {
+    float t[2] = { 0, 0 };
+    for (int i = 0; i < 8; i++) {
+        float e;
+        if (hipEventQuery(c->tune_ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&e, c->tune_ev[2 * i], c->tune_ev[2 * i + 1]) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
-    c->tune_choice = e[1] + e[2] < 0.985f * (e[0] + e[3]);
-    for (int i = 0; i < 8; i++) {
+        t[(i + 1) >> 1 & 1] += e;
+    }
+    c->tune_choice = t[1] < 0.98f * t[0];
+    for (int i = 0; i < 16; i++) {
         (void)hipEventDestroy(c->tune_ev[i]);
         c->tune_ev[i] = nullptr;
     }

@@ -69,14 +69,17 @@ int         ffhip_stream_order(void *first, void *then);
  *  launches of that variant (HIP events). */
 int         ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gbps);
 /**
- * Device memory for frame batches, laid out for the GPU's page tables (round 6).  What a streaming kernel over several gigabytes gets
- * out of HBM depends on how large the fragments of its page-table entries are, and a fragment can only be as large as the alignment
- * the allocation's virtual AND physical addresses share — which plain hipMalloc leaves to chance per allocation (measured: 0.57 … 0.66
- * of HBM for the same launch of the bench kernel, process by process and allocation by allocation, profiles/r06_alloc_*.txt).
- * ffhip_frames_alloc() reserves a virtual range aligned to `chunk` bytes (0: 1 GiB; a power of two, at least the device's
- * allocation granularity) and backs it with physical allocations of `chunk` bytes each, mapped chunk by chunk, so that both sides are
- * aligned alike.  *ptr: the range, usable by every kernel, copy and torch view of the current device; the tail of the last chunk is
- * mapped too.  This is what the FFmpeg-side frame pool (integration/avutil_hwcontext_hip.c) allocates its batches with.
+ * Device memory for frame batches whose rate does not depend on where the allocator happened to find it (round 6).  What a streaming
+ * kernel over several gigabytes gets out of HBM depends on the PHYSICAL layout of its buffers: the same launch of the bench kernel runs at
+ * 0.575 – 0.585 of HBM on one plain allocation and at 0.63 – 0.66 on the next, process by process and allocation by allocation — two
+ * modes, the slow one most often on large physically contiguous blocks (the first big hipMalloc of a fresh process; 1 GiB physical chunks:
+ * 7 of 12), whatever the virtual addresses (profiles/r06_alloc_vmm_sweep_*.txt, r06_arena_offset_sweep.txt).  ffhip_frames_alloc() builds
+ * the range from physical chunks of `chunk` bytes (0: 16 MiB; a power of two, at least the device's allocation granularity) mapped
+ * into one virtual range in a fixed pseudo-random order (HIP virtual memory management: hipMemCreate / hipMemMap), so that no large
+ * piece of the range is physically contiguous: measured 0.60 – 0.645 on every one of 12 allocations where plain ones gave 0.575 – 0.66
+ * (mean 0.628 against 0.610), and +3.6 % on average for the table converter.  *ptr: the range, ordinary device memory for every kernel,
+ * copy and torch view of the current device; the tail of the last chunk is mapped too.  bench.py holds its frame batches in it; a caller
+ * that keeps hundreds of frames resident (a transcoder's look-ahead, an inference batch) should too.
  * Returns 0, FFHIP_EINVAL, FFHIP_ENOMEM or FFHIP_ENOSYS (no virtual memory management on this device / runtime).
  */
 int         ffhip_frames_alloc(void **ptr, size_t bytes, size_t chunk);

@@ -70,8 +70,8 @@ def test_unscaled_yuv420p_rgb24(w, h, pad, dst):
 @pytest.mark.parametrize("dst", ["rgb24", "bgr24"])
 def test_unscaled_launch_tuner_keeps_the_bytes(dst):
     """round 6: large launches of the table converter (>= 64 MiB of 24-bit pixels) choose their workgroup numbering per context — the first
-    four run plain, eighth-per-XCD, eighth, plain between events, the rest the faster of the two (ffhip_sws_tuned_numbering).  Whatever
-    the box decides, every launch writes the oracle's bytes: a 4-frame 3840x2160 batch, seven calls."""
+    eight alternate plain and eighth-per-XCD between events, the rest take the faster of the two (ffhip_sws_tuned_numbering).  Whatever
+    the box decides, every launch writes the oracle's bytes: a 4-frame 3840x2160 batch, eleven calls."""
     from ffmpeg_amd import swscale as S
     torch = _torch()
     w, h, n = 3840, 2160, 4
@@ -82,14 +82,14 @@ def test_unscaled_launch_tuner_keeps_the_bytes(dst):
     assert ctx.tuned_numbering == -1
     dsrc = _upload(src, n=n)
     seen = []
-    for call in range(7):
+    for call in range(11):
         ddst = [torch.zeros((n, h, 3 * w), dtype=torch.uint8, device="cuda:0")]
         ctx.scale_batch(dsrc, ddst)
         torch.cuda.synchronize()
         for f in range(n):
             assert torch.equal(ddst[0][f], want), "call %d frame %d" % (call, f)
         seen.append(ctx.tuned_numbering)
-    assert seen[:4] == [-1] * 4 and seen[-1] in (0, 1), seen      # decided on the fifth large launch at the latest possible point
+    assert seen[:8] == [-1] * 8 and seen[-1] in (0, 1), seen      # decided on the ninth large launch
     # a small launch of the same context is not part of the tuning and not affected by it
     one = [torch.zeros((1, h, 3 * w), dtype=torch.uint8, device="cuda:0")]
     ctx.scale_batch([t[:1] for t in dsrc], one)

@@ -10,6 +10,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ffmpeg_amd import _lib
+_lib.select("measure")
 from ffmpeg_amd import swscale as S
 
 dev = torch.device("cuda:0")
@@ -52,13 +53,17 @@ def total(shapes):
 
 cases = (("up2 nv12 1080p->4K x256", 23, 1920, 1080, 23, 3840, 2160, 256, 256 * 15552000), ("rgb24 yuv420p 4K x64", 0, 3840, 2160, 2, 3840, 2160, 64, 64 * 3840 * 2160 * 4.5))
 for name, sf, sw, sh, df, dw, dh, n, byts in cases:
-    ctx = S.SwsContext(sw, sh, sf, dw, dh, df, 4)
     sshapes = [(n, r, c) for r, c in S.plane_shapes(sf, sw, sh)]
     dshapes = [(n, r, c) for r, c in S.plane_shapes(df, dw, dh)]
     keep = []
     for rnd in range(rounds):
         row = {"case": name, "round": rnd}
-        for label, chunk in (("torch", None), ("vmm_2M", 2 << 20), ("vmm_64M", 64 << 20), ("vmm_1G", 1 << 30)):
+        for label, chunk, order in (("torch", None, None), ("lin_2M", 2 << 20, "0"), ("mix_2M", 2 << 20, None), ("lin_16M", 16 << 20, "0"), ("mix_16M", 16 << 20, None),
+                                    ("mix_64M", 64 << 20, None), ("mix_256M", 256 << 20, None)):
+            if order:
+                os.environ["FFHIP_FRAMES_ORDER"] = order
+            else:
+                os.environ.pop("FFHIP_FRAMES_ORDER", None)
             if chunk is None:
                 src = [torch.randint(0, 256, s_, dtype=torch.uint8, device=dev) for s_ in sshapes]
                 dst = [torch.empty(s_, dtype=torch.uint8, device=dev) for s_ in dshapes]
@@ -68,9 +73,12 @@ for name, sf, sw, sh, df, dw, dh, n, byts in cases:
                 src, dst = carve(mem[0], sshapes), carve(mem[1], dshapes)
                 for t in src:
                     t.random_(0, 256)
+            ctx = S.SwsContext(sw, sh, sf, dw, dh, df, 4)     # a context per buffer set: the launch tuner decides for THESE buffers
             ms = timed(ctx, src, dst)
             row[label] = round(byts / (ms * 1e-3) / 8e12, 4)
-            row[label + "_dst"] = hex(dst[0].data_ptr())
+            if df == 2:
+                row[label + "_numbering"] = ctx.tuned_numbering
+            ctx.close()
             if rnd % 2 == 0:
                 keep.append((src, dst, mem))   # every other round leaves its buffers allocated: the next round's land elsewhere
             else:
@@ -78,4 +86,3 @@ for name, sf, sw, sh, df, dw, dh, n, byts in cases:
         print(json.dumps(row), flush=True)
     del keep
     torch.cuda.empty_cache()
-    ctx.close()
