@@ -315,7 +315,7 @@ def rgb24_leg(torch, dev, torch_alloc=False):
     return out["yuv420p_rgb24_4k"]
 
 
-def extras(torch, dev):
+def extras(torch, dev, torch_alloc=False):
     """Secondary hot-path kernels, short runs (rank 0, N=1)."""
     from ffmpeg_amd import swscale as S, h264, _lib
     out = {}
@@ -323,12 +323,14 @@ def extras(torch, dev):
 
     def sws_case(key, sf, sw, sh, df, dw, dh, n):
         c = S.SwsContext(sw, sh, sf, dw, dh, df, 4)
-        s_ = [torch.randint(0, 256, (n, r, cc), dtype=torch.uint8, device=dev) for r, cc in S.plane_shapes(sf, sw, sh)]
+        # (frame batches in libffhip's frame memory, as the headline's: ffhip_frames_alloc)
+        s_, d_ = frame_batches(torch, dev, _lib, [(n, r, cc) for r, cc in S.plane_shapes(sf, sw, sh)], [(n, r, cc) for r, cc in S.plane_shapes(df, dw, dh)], torch_alloc)
+        for t_ in s_:
+            t_.random_(0, 256)
         if sf in (62, 158):   # 10-bit samples: valid ones (planar: the low 10 bits of the word, P010: the high 10)
             for t_ in s_:
                 w16 = t_.view(torch.int16)
                 w16.bitwise_and_(0x03FF if sf == 62 else -64)
-        d_ = [torch.empty((n, r, cc), dtype=torch.uint8, device=dev) for r, cc in S.plane_shapes(df, dw, dh)]
         for _ in range(2):
             c.scale_batch(s_, d_)
         a, b = ev(), ev()
@@ -1582,7 +1584,7 @@ def main():
                 rgb = {"error": repr(e)[:200]}
             if not args.no_extras:
                 try:
-                    ex = extras(torch, dev)
+                    ex = extras(torch, dev, args.torch_alloc)
                 except Exception as e:  # extras never invalidate the headline line
                     ex = {"error": repr(e)[:300]}
                 ex["yuv420p_rgb24_4k"] = rgb

@@ -506,7 +506,8 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
                     }
                     if (act && y >= 0) {
                         up_u4 st; st.x = o0[0]; st.y = o0[1]; st.z = o0[2]; st.w = o0[3];
-                        *(up_g4)((up_gp)dr + off) = st;
+                        if (NTS) __builtin_nontemporal_store(st, (up_g4)((up_gp)dr + off));
+                        else *(up_g4)((up_gp)dr + off) = st;
                     }
                     up_v8h(o1, ring[(k + 1) % 3], ring[k % 3], fa01, fa23, kround, vsh, maxpk);
                     if (dmsb) {
@@ -516,7 +517,8 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
                     }
                     if (act && y + 1 < dstH) {
                         up_u4 st; st.x = o1[0]; st.y = o1[1]; st.z = o1[2]; st.w = o1[3];
-                        *(up_g4)((up_gp)(dr + dstride) + off) = st;
+                        if (NTS) __builtin_nontemporal_store(st, (up_g4)((up_gp)(dr + dstride) + off));
+                        else *(up_g4)((up_gp)(dr + dstride) + off) = st;
                     }
                     dr += 2 * dstride;
                     asm("" : "+s"(dr));
@@ -702,19 +704,22 @@ int ffhip_launch_up2(FFHipUp2Args &A, int depth, int var, hipStream_t stream)
         return FFHIP_EINVAL;
     }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (A.job[0].hb_sdepth) { /* samples above 8 bits: the product variant only */
-        if (depth == 3)
-            hipLaunchKernelGGL((k_sws_up2<3, 0, 1>), grid, block, 0, stream, A);
-        else
-            hipLaunchKernelGGL((k_sws_up2<6, 0, 1>), grid, block, 0, stream, A);
+    if (A.job[0].hb_sdepth) { /* samples above 8 bits: plain or (var & 1) non-temporal stores */
+        if (depth == 3 && !(var & 1))      hipLaunchKernelGGL((k_sws_up2<3, 0, 1>), grid, block, 0, stream, A);
+        else if (depth == 3)               hipLaunchKernelGGL((k_sws_up2<3, 1, 1>), grid, block, 0, stream, A);
+        else if (!(var & 1))               hipLaunchKernelGGL((k_sws_up2<6, 0, 1>), grid, block, 0, stream, A);
+        else                               hipLaunchKernelGGL((k_sws_up2<6, 1, 1>), grid, block, 0, stream, A);
         LAUNCH_CHECK();
         return 0;
     }
-    if (A.job[0].rc_coeff) { /* range conversion between the passes: the product variant only */
-        if (depth == 3)
-            hipLaunchKernelGGL((k_sws_up2<3, 0, 0, 1>), grid, block, 0, stream, A);
-        else
-            hipLaunchKernelGGL((k_sws_up2<6, 0, 0, 1>), grid, block, 0, stream, A);
+    if (A.job[0].rc_coeff) { /* range conversion between the passes: rounds 4-5's form, or (var 3) the bank in SGPRs + non-temporal stores */
+        bool scr = var == 3;
+        for (int i = 0; i < A.njobs; i++)
+            scr = scr && A.job[i].hco_ok;
+        if (scr && depth == 3)             hipLaunchKernelGGL((k_sws_up2<3, 1, 0, 1, 1>), grid, block, 0, stream, A);
+        else if (scr)                      hipLaunchKernelGGL((k_sws_up2<6, 1, 0, 1, 1>), grid, block, 0, stream, A);
+        else if (depth == 3)               hipLaunchKernelGGL((k_sws_up2<3, 0, 0, 1>), grid, block, 0, stream, A);
+        else                               hipLaunchKernelGGL((k_sws_up2<6, 0, 0, 1>), grid, block, 0, stream, A);
         LAUNCH_CHECK();
         return 0;
     }

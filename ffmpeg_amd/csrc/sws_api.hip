@@ -1248,7 +1248,10 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 U.fshift = best;
                 for (int i = 0; i < U.njobs; i++)
                     ffhip_up2_plan_job(&U.job[i], 64 >> U.fshift, 60);
-                return ffhip_launch_up2(U, 3, 0, stream);
+                {
+                    const char *ed = FFHIP_KNOB("FFHIP_UP2_DEPTH"), *ev2 = FFHIP_KNOB("FFHIP_UP2_VAR"); /* measure build: rows in flight, 1 = non-temporal stores */
+                    return ffhip_launch_up2(U, ed && ed[0] == '6' ? 6 : 3, ev2 ? atoi(ev2) : 0, stream);
+                }
             }
         }
         const char *e2 = FFHIP_KNOB("FFHIP_SWS_DOWN2");
@@ -2009,10 +2012,12 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
                  * +0.4 .. +0.7 % over rounds 2-5's kernel on two boxes, profiles/r06_up2_variants.txt; each ingredient alone is within
                  * +-0.5 %); FFHIP_UP2_VAR=0 FFHIP_UP2_DEPTH=3 (measure build) is that kernel.  Banks whose interior columns are not the two
                  * phase rows (ffhip_up2_hco) fall back to it inside the launcher. */
-                bool scal = !U.job[0].rc_coeff;     /* (the range-converting twin keeps its own instantiation) */
+                /* (the range-converting twin: the SGPR bank and non-temporal stores at three rows in flight — yuvj420p -> yuv420p 1080p -> 4K
+                 * 0.550 -> 0.592 of HBM, six rows 0.585; profiles/r06_up2_twins.txt) */
+                bool scal = true;
                 for (int i = 0; i < U.njobs; i++)
                     scal = scal && U.job[i].hco_ok;
-                return ffhip_launch_up2(U, ed ? (ed[0] == '6' ? 6 : 3) : scal ? 6 : 3, ev2 ? atoi(ev2) : scal ? 3 : 0, stream);
+                return ffhip_launch_up2(U, ed ? (ed[0] == '6' ? 6 : 3) : scal && !U.job[0].rc_coeff ? 6 : 3, ev2 ? atoi(ev2) : scal ? 3 : 0, stream);
             }
         }
         if (!(al & 3) && !c->up2_rc) {
