@@ -166,6 +166,13 @@ def lib():
         "ffhip_h264_picture_deblock_mb": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
         "ffhip_h264_picture_flush": (C.c_int, [vp, vp, vp, vp, vp]),
         "ffhip_h264_pictures_flush": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+        "ffhip_h264_mbaff_create": (C.c_int, [vp, C.c_int, C.c_int]),
+        "ffhip_h264_mbaff_free": (None, [vp]),
+        "ffhip_h264_mbaff_begin": (None, [vp]),
+        "ffhip_h264_mbaff_intra_mb": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
+        "ffhip_h264_mbaff_filter_call": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+        "ffhip_h264_mbaff_lists": (C.c_int, [vp, vp]),
+        "ffhip_h264_mbaff_flush": (C.c_int, [vp, vp, vp, vp]),
         "ffhip_h264_picture_intra_mb": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "ffhip_h264_intra_pack": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int32]),
         "ffhip_h264_intra_pack_hbd": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int32]),

@@ -1,0 +1,498 @@
+/*
+ * h264_mbaff.hip — MBAFF frames in the H.264 picture layer (round 6): the two DEPENDENCY CHAINS of a frame whose
+ * macroblock pairs mix frame and field macroblocks (mb_adaptive_frame_field_flag; libavcodec/h264_mb_template.c:61-78,
+ * h264_loopfilter.c:494-560,716-760, h264_slice.c:2480-2505), 8 bits, 4:2:0.
+ *
+ * How an MBAFF frame is taken apart.  A field macroblock of a pair is the field-picture case per macroblock: its lines are every
+ * second line of the frame from the pair's first (top field macroblock) or second (bottom) line on, twice the line size apart — which is
+ * how hl_decode_mb() itself addresses it (mb_linesize = 2 * linesize, block_offset[48..], `dest_y -= linesize * 15` for the bottom
+ * macroblock: h264_mb_template.c:61-78) and how the references' fields arrive (ff_h264_fill_mbaff_ref_list, h264_refs.c: entries
+ * 16 + 2 i + parity with doubled line sizes).  So the INTER half of the picture needs no new kernel: the recorder
+ * (integration/avcodec_h264_picture_hip.c) keeps three ordinary picture objects over the same planes — one for the frame macroblocks
+ * (line size S), one per field parity (line size 2 S, half the rows, the bottom one starting a line further down) — and their
+ * prediction, weight and residual lists run through the kernels every picture runs through.
+ * What does not decompose are the two chains whose order crosses macroblocks:
+ *
+ *   intra reconstruction   k_h264_mbaff_intra: one wave per macroblock-PAIR row walks the row's intra macroblocks in decoding order (top,
+ *                          then bottom macroblock of a pair); a macroblock is reconstructed on the tile of h264_intra_mb.h — the SAME phase
+ *                          bodies as every other picture's (imb_reconstruct) — filled and written back at the macroblock's own line
+ *                          step: "the row above" of a field macroblock is the line two frame lines up, of a bottom frame macroblock the
+ *                          top macroblock's last line — memory adjacency at the macroblock's step is exactly the neighbour derivation of
+ *                          the standard's 6.4.12.2, and what hl_decode_mb()'s predictors read.  Pair (x, p) starts when row p - 1 has
+ *                          finished pair x + 1.
+ *   the in-loop filter     k_h264_mbaff_deblock: ff_h264_filter_mb()'s dsp calls of a macroblock — up to ten per luma macroblock in an
+ *                          MBAFF frame: the left edge in two halves with their own bS / qp (filter_mb_mbaff_edgev), the top edge of a frame
+ *                          macroblock under a field pair once per field at twice the line size, the _mbaff members that cover 8 lines —
+ *                          are RECORDED AS CALLS (pointer, line size, alpha, beta, tc0 in the order issued) and executed in that order, one
+ *                          wave per pair row, directly on the picture (dword accesses at device scope): pair x of row p after pair x + 1
+ *                          of row p - 1.  Which edge is filtered how is the reference's decision, call by call.
+ *
+ * Both are the plain form (h264_c422.hip's protocol: a counter per row in the progress pool, device-scope loads and stores behind
+ * agent fences); interlaced material is correctness first.  The CPU tier executes the same lists in oracle/emul_h264_mbaff.cpp.
+ */
+#include <stddef.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kernels/common.h"
+#include "kernels/h264_intra_mb.h"
+#include "kernels/h264_kernels.h"
+#include "kernels/h264_lf_line.h"
+#include "kernels/progress_pool.h"
+
+struct FFHipH264Mbaff {
+    int mb_w, mb_h;                              /* the frame's macroblocks; mb_h even */
+    int device;
+    std::vector<FFHipH264IntraMB> recs;          /* intra macroblocks in decoding order: pair rows, pairs left to right, top then bottom */
+    std::vector<uint32_t> geo;                   /* per record: mb_x | mb_y (frame row) << 12 | field << 24 */
+    std::vector<int16_t> coefs;                  /* their packed coefficient runs */
+    std::vector<int32_t> intra_row;              /* mb_h / 2 + 1 starts into recs */
+    std::vector<FFHipH264Edge> calls[3];         /* per plane: the loop-filter calls in the order issued (pad = flags: 1 doubled line size, 2 _mbaff member) */
+    std::vector<int32_t> pair_end[3];            /* per plane and pair (row-major): one past its last call */
+    int last_pair[3];                            /* the pair whose calls are being appended (calls must arrive pair by pair, in order) */
+    void *dev = nullptr;
+    size_t dev_sz = 0;
+    int last_status = 0;
+};
+
+extern "C" int ffhip_h264_mbaff_create(FFHipH264Mbaff **m, int mb_w, int mb_h)
+{
+    if (!m || mb_w <= 0 || mb_h <= 0 || (mb_h & 1) || mb_w > 4095 || mb_h > 4095)
+        return FFHIP_EINVAL;
+    if (mb_h / 2 > FFHIP_PROGRESS_SLOT_INTS / 3) {
+        ffhip_set_error("ffhip_h264_mbaff: %d macroblock pair rows exceed the progress pool", mb_h / 2);
+        return FFHIP_EINVAL;
+    }
+    FFHipH264Mbaff *p = new (std::nothrow) FFHipH264Mbaff();
+    if (!p)
+        return FFHIP_ENOMEM;
+    p->mb_w = mb_w;
+    p->mb_h = mb_h;
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        (void)hipGetLastError();
+        p->device = -1; /* recording needs no device; flush does */
+    }
+    *m = p;
+    return 0;
+}
+
+extern "C" void ffhip_h264_mbaff_free(FFHipH264Mbaff **m)
+{
+    if (!m || !*m)
+        return;
+    if ((*m)->dev)
+        (void)hipFree((*m)->dev);
+    delete *m;
+    *m = nullptr;
+}
+
+extern "C" void ffhip_h264_mbaff_begin(FFHipH264Mbaff *m)
+{
+    if (!m)
+        return;
+    m->recs.clear();
+    m->geo.clear();
+    m->coefs.clear();
+    for (int pl = 0; pl < 3; pl++) {
+        m->calls[pl].clear();
+        m->pair_end[pl].assign((size_t)m->mb_w * (m->mb_h / 2), 0);
+        m->last_pair[pl] = -1;
+    }
+    m->last_status = 0;
+}
+
+extern "C" int ffhip_h264_mbaff_intra_mb(FFHipH264Mbaff *m, const FFHipH264IntraMB *desc, int field, const uint8_t *non_zero_count_cache, int16_t *mb,
+                                         const int16_t *mb_luma_dc, const uint8_t *pcm)
+{
+    if (!m || !desc || !non_zero_count_cache || !mb)
+        return FFHIP_EINVAL;
+    if (desc->mb_x < 0 || desc->mb_x >= m->mb_w || desc->mb_y < 0 || desc->mb_y >= m->mb_h) {
+        ffhip_set_error("ffhip_h264_mbaff_intra_mb: macroblock (%d, %d) outside %d x %d", desc->mb_x, desc->mb_y, m->mb_w, m->mb_h);
+        return FFHIP_EINVAL;
+    }
+    /* decoding order: (pair row, mb_x, bottom) ascending */
+    if (!m->geo.empty()) {
+        const uint32_t g = m->geo.back();
+        const int px = (int)(g & 0xFFF), py = (int)((g >> 12) & 0xFFF);
+        const long prev = ((long)(py >> 1) * m->mb_w + px) * 2 + (py & 1), cur = ((long)(desc->mb_y >> 1) * m->mb_w + desc->mb_x) * 2 + (desc->mb_y & 1);
+        if (cur <= prev) {
+            ffhip_set_error("ffhip_h264_mbaff_intra_mb: macroblock (%d, %d) out of decoding order", desc->mb_x, desc->mb_y);
+            return FFHIP_EINVAL;
+        }
+    }
+    FFHipH264IntraMB r = *desc;
+    const size_t at = m->coefs.size();
+    m->coefs.resize(at + 400);
+    int32_t n = (int32_t)at;
+    const int rc = ffhip_h264_intra_pack(&r, non_zero_count_cache, mb, mb_luma_dc, pcm, m->coefs.data(), &n, (int32_t)m->coefs.size());
+    if (rc < 0) {
+        m->coefs.resize(at);
+        return rc;
+    }
+    m->coefs.resize((size_t)n);
+    m->recs.push_back(r);
+    m->geo.push_back((uint32_t)desc->mb_x | (uint32_t)desc->mb_y << 12 | (uint32_t)(field ? 1 : 0) << 24);
+    return 0;
+}
+
+extern "C" int ffhip_h264_mbaff_filter_call(FFHipH264Mbaff *m, int plane, int mb_x, int mb_y, const FFHipH264Edge *call)
+{
+    if (!m || !call || plane < 0 || plane > 2 || mb_x < 0 || mb_x >= m->mb_w || mb_y < 0 || mb_y >= m->mb_h)
+        return FFHIP_EINVAL;
+    const int pair = (mb_y >> 1) * m->mb_w + mb_x;
+    if (pair < m->last_pair[plane]) {
+        ffhip_set_error("ffhip_h264_mbaff_filter_call: pair (%d, %d) after pair %d: calls arrive in decoding order", mb_x, mb_y >> 1, m->last_pair[plane]);
+        return FFHIP_EINVAL;
+    }
+    if ((call->kind & ~7) || (call->pad & ~3) || (call->offset & 3)) {
+        ffhip_set_error("ffhip_h264_mbaff_filter_call: bad record (kind %d, flags %d, offset %d)", call->kind, call->pad, call->offset);
+        return FFHIP_EINVAL;
+    }
+    /* pairs without calls between the last one and this one end where the last one ended */
+    const int32_t here = (int32_t)m->calls[plane].size();
+    for (int q = m->last_pair[plane] + 1; q < pair; q++)
+        m->pair_end[plane][(size_t)q] = here;
+    m->calls[plane].push_back(*call);
+    m->pair_end[plane][(size_t)pair] = here + 1;
+    m->last_pair[plane] = pair;
+    return 0;
+}
+
+/* pair_end[] of the pairs behind the last one that had calls, intra_row[] */
+static void mbaff_finish(FFHipH264Mbaff *m)
+{
+    const int npairs = m->mb_w * (m->mb_h / 2);
+    for (int pl = 0; pl < 3; pl++) {
+        const int32_t n = (int32_t)m->calls[pl].size();
+        for (int q = m->last_pair[pl] + 1; q < npairs; q++)
+            m->pair_end[pl][(size_t)q] = n;
+        m->last_pair[pl] = npairs - 1;
+    }
+    m->intra_row.assign((size_t)m->mb_h / 2 + 1, 0);
+    size_t k = 0;
+    for (int p = 0; p <= m->mb_h / 2; p++) {
+        while (k < m->geo.size() && (int)((m->geo[k] >> 12) & 0xFFF) >> 1 < p)
+            k++;
+        m->intra_row[(size_t)p] = (int32_t)k;
+    }
+}
+
+extern "C" int ffhip_h264_mbaff_lists(FFHipH264Mbaff *m, FFHipH264MbaffLists *out)
+{
+    if (!m || !out)
+        return FFHIP_EINVAL;
+    mbaff_finish(m);
+    memset(out, 0, sizeof(*out));
+    out->mb_w = m->mb_w;
+    out->mb_h = m->mb_h;
+    out->recs = m->recs.data();
+    out->geo = m->geo.data();
+    out->coefs = m->coefs.data();
+    out->intra_row = m->intra_row.data();
+    out->nrecs = (int32_t)m->recs.size();
+    out->ncoefs = (int32_t)m->coefs.size();
+    for (int pl = 0; pl < 3; pl++) {
+        out->calls[pl] = m->calls[pl].data();
+        out->pair_end[pl] = m->pair_end[pl].data();
+        out->ncalls[pl] = (int32_t)m->calls[pl].size();
+    }
+    return 0;
+}
+
+/* ================================================================================================== */
+/* kernels */
+
+namespace {
+__device__ __forceinline__ void mb_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+struct MbWave {
+    int lane;
+    template <class F>
+    __device__ __forceinline__ void run(F body)
+    {
+        body(lane);
+        mb_wave_sync();
+    }
+};
+__device__ __forceinline__ uint32_t mb_ld(const uint8_t *p)
+{
+    return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mb_st(uint8_t *p, uint32_t v)
+{
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool mb_wait(const int *counter, int want, int *fail, int lane)
+{
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 24)) {
+            if (lane == 0)
+                __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+/* every store of the wave is out and visible (to its own later loads and to the other rows) */
+__device__ __forceinline__ void mb_drain()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void mb_publish(int *counter, int value, int lane)
+{
+    mb_drain();
+    if (lane == 0)
+        __hip_atomic_store(counter, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+} // namespace
+
+/* one wave per pair row; progress[p] = "every pair left of this one is reconstructed" */
+__global__ __launch_bounds__(64) void k_h264_mbaff_intra(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
+                                                         const FFHipH264IntraMB *recs, const uint32_t *geo, const int32_t *row_start,
+                                                         const int16_t *coefs, int *progress, int *fail)
+{
+    __shared__ __align__(16) ImbTileT<uint8_t> T;
+    __shared__ __align__(16) FFHipH264IntraMB R;
+    __shared__ uint32_t p4tab[IMB_TABS];
+    const int p = (int)blockIdx.x, lane = (int)threadIdx.x;
+    for (int i = lane; i < IMB_TABS; i += 64)
+        p4tab[i] = imb_tab(i);
+    if (lane < 16)
+        T.zero[lane] = 0;
+    mb_wave_sync();
+    int k = __builtin_amdgcn_readfirstlane(row_start[p]);
+    const int kend = __builtin_amdgcn_readfirstlane(row_start[p + 1]);
+    mb_publish(&progress[p], k < kend ? (int)(geo[k] & 0xFFF) : mb_w, lane);
+    MbWave X{ lane };
+    for (; k < kend; k++) {
+        if (lane < (int)(sizeof(FFHipH264IntraMB) / 4))
+            reinterpret_cast<uint32_t *>(&R)[lane] = reinterpret_cast<const uint32_t *>(recs + k)[lane];
+        const uint32_t g = geo[k];
+        const int mx = (int)(g & 0xFFF), my = (int)((g >> 12) & 0xFFF), field = (int)(g >> 24) & 1;
+        mb_wave_sync();
+        if (p > 0 && !mb_wait(&progress[p - 1], min(mx + 2, mb_w), fail, lane))
+            return;
+        /* the macroblock's first frame line and its line step: a field macroblock of pair p starts on the pair's line 0 / 1 */
+        const int step = field ? 2 : 1;
+        const int line0 = field ? 32 * p + (my & 1) : 16 * my;
+        const ptrdiff_t ysy = sy * step, csc = sc * step;
+        uint8_t *ymb = py + (ptrdiff_t)line0 * sy + mx * 16;
+        const int cline0 = field ? 16 * p + (my & 1) : 8 * my;
+        uint8_t *cmb[2] = { pcb + (ptrdiff_t)cline0 * sc + mx * 8, pcr + (ptrdiff_t)cline0 * sc + mx * 8 };
+        const bool has_l = mx > 0, has_t = line0 - step >= 0, has_r = mx + 1 < mb_w;
+        /* the tile's neighbours, a quad per lane (what lies outside the picture reads as 0): lanes 0..7 the luma row above over columns
+         * -4 .. 27, 8..23 the luma column to the left, 24..29 the chroma rows above (columns -4 .. 7), 30..45 the chroma columns to the left */
+        {
+            uint32_t v = 0;
+            if (lane < 8) {
+                const int c = 4 * lane - 4;
+                if (has_t && (c >= 0 || has_l) && (c < 16 || has_r))
+                    v = mb_ld(ymb - ysy + c);
+                *reinterpret_cast<uint32_t *>(&T.y[imb_yi(-1, c)]) = v;
+            } else if (lane < 24) {
+                const int r = lane - 8;
+                if (has_l)
+                    v = mb_ld(ymb + (ptrdiff_t)r * ysy - 4);
+                *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, -4)]) = v;
+                *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, 16)]) = 0;
+                *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, 20)]) = 0;
+            } else if (lane < 30) {
+                const int pl = (lane - 24) / 3, c = 4 * ((lane - 24) % 3) - 4;
+                if (has_t && (c >= 0 || has_l))
+                    v = mb_ld(cmb[pl] - csc + c);
+                *reinterpret_cast<uint32_t *>(&T.c[pl][imb_ci(-1, c)]) = v;
+            } else if (lane < 46) {
+                const int pl = (lane - 30) >> 3, r = (lane - 30) & 7;
+                if (has_l)
+                    v = mb_ld(cmb[pl] + (ptrdiff_t)r * csc - 4);
+                *reinterpret_cast<uint32_t *>(&T.c[pl][imb_ci(r, -4)]) = v;
+            }
+        }
+        mb_wave_sync();
+        imb_reconstruct<uint8_t>(X, T, R, coefs + R.coef, p4tab, 255, 3);
+        /* the macroblock back into the picture: 64 luma quads, 32 chroma quads */
+        mb_st(ymb + (ptrdiff_t)(lane >> 2) * ysy + 4 * (lane & 3), *reinterpret_cast<const uint32_t *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]));
+        if (lane < 32) {
+            const int pl = lane >> 4, r = (lane >> 1) & 7, c = 4 * (lane & 1);
+            mb_st(cmb[pl] + (ptrdiff_t)r * csc + c, *reinterpret_cast<const uint32_t *>(&T.c[pl][imb_ci(r, c)]));
+        }
+        /* the next record: the other macroblock of this pair (the pair is not finished), or a pair further right */
+        const int nx = k + 1 < kend ? (int)(geo[k + 1] & 0xFFF) : mb_w;
+        if (nx != mx)
+            mb_publish(&progress[p], nx, lane);
+        else
+            mb_drain();
+    }
+}
+
+/* One plane's recorded loop-filter calls, one wave per pair row.  chroma: the plane is Cb / Cr (8 x 8 macroblocks). */
+__global__ __launch_bounds__(64) void k_h264_mbaff_deblock(uint8_t *plane, ptrdiff_t stride, int mb_w, int npair_rows, const FFHipH264Edge *calls,
+                                                           const int32_t *pair_end, int *progress, int *fail)
+{
+    const int p = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (p >= npair_rows)
+        return;
+    int at = p > 0 ? pair_end[(size_t)p * mb_w - 1] : 0;
+    for (int x = 0; x < mb_w; x++) {
+        const int end = pair_end[(size_t)p * mb_w + x];
+        if (p > 0 && !mb_wait(&progress[p - 1], min(x + 2, mb_w), fail, lane))
+            return;
+        for (; at < end; at++) {
+            const FFHipH264Edge e = calls[at];
+            const int kind = e.kind & 7;
+            const bool chroma = kind & 2, intra = kind & 4, hfilt = kind & 1; /* h_ members filter across a VERTICAL edge: a line = a row */
+            const bool mbaff = e.pad & 2;
+            const ptrdiff_t st = (e.pad & 1) ? 2 * stride : stride;
+            const int cls = (chroma ? 1 : 0) + (intra ? 2 : 0);
+            uint8_t *pix = plane + e.offset;
+            if (hfilt) {
+                /* lines = rows: luma 16 (tc0 per 4), chroma 8 (per 2); the _mbaff members: half of each (h264dsp_template.c:127-133,262-272) */
+                const int nlines = (chroma ? 8 : 16) >> (mbaff ? 1 : 0), per = (chroma ? 2 : 4) >> (mbaff ? 1 : 0);
+                if (lane < nlines) {
+                    uint8_t *l = pix + (ptrdiff_t)lane * st - 4;
+                    const uint32_t a = mb_ld(l), b = mb_ld(l + 4);
+                    LfLine v = { (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), (int)(a >> 24),
+                                 (int)(b & 255), (int)((b >> 8) & 255), (int)((b >> 16) & 255), (int)(b >> 24) };
+                    const int m = lf_line(v, cls, e.alpha, e.beta, intra ? 0 : e.tc0[lane / per]);
+                    if (m & 7)
+                        mb_st(l, (uint32_t)v.p3 | (uint32_t)v.p2 << 8 | (uint32_t)v.p1 << 16 | (uint32_t)v.p0 << 24);
+                    if (m & 56)
+                        mb_st(l + 4, (uint32_t)v.q0 | (uint32_t)v.q1 << 8 | (uint32_t)v.q2 << 16 | (uint32_t)v.q3 << 24);
+                }
+            } else {
+                /* lines = columns: luma 16 (tc0 per 4), chroma 8 (per 2): a lane takes four adjacent columns, eight rows of dwords */
+                const int nq = chroma ? 2 : 4, per = chroma ? 2 : 4;
+                if (lane < nq) {
+                    uint32_t w[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) /* (rows -4 and -3 feed the strong luma filter only: never read above the plane) */
+                        w[r] = (ptrdiff_t)e.offset + (ptrdiff_t)(r - 4) * st >= 0 ? mb_ld(pix + (ptrdiff_t)(r - 4) * st + 4 * lane) : 0u;
+                    int changed = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        LfLine v;
+                        const int sh = 8 * c;
+                        v.p3 = (w[0] >> sh) & 255; v.p2 = (w[1] >> sh) & 255; v.p1 = (w[2] >> sh) & 255; v.p0 = (w[3] >> sh) & 255;
+                        v.q0 = (w[4] >> sh) & 255; v.q1 = (w[5] >> sh) & 255; v.q2 = (w[6] >> sh) & 255; v.q3 = (w[7] >> sh) & 255;
+                        const int m = lf_line(v, cls, e.alpha, e.beta, intra ? 0 : e.tc0[(4 * lane + c) / per]);
+                        changed |= m;
+                        const uint32_t keep = ~(255u << sh);
+                        if (m & 1)  w[1] = (w[1] & keep) | (uint32_t)v.p2 << sh;
+                        if (m & 2)  w[2] = (w[2] & keep) | (uint32_t)v.p1 << sh;
+                        if (m & 4)  w[3] = (w[3] & keep) | (uint32_t)v.p0 << sh;
+                        if (m & 8)  w[4] = (w[4] & keep) | (uint32_t)v.q0 << sh;
+                        if (m & 16) w[5] = (w[5] & keep) | (uint32_t)v.q1 << sh;
+                        if (m & 32) w[6] = (w[6] & keep) | (uint32_t)v.q2 << sh;
+                    }
+#pragma unroll
+                    for (int r = 1; r < 7; r++)
+                        if (changed & (1 << (r - 1)))
+                            mb_st(pix + (ptrdiff_t)(r - 4) * st + 4 * lane, w[r]);
+                }
+            }
+            mb_drain(); /* the next call of this wave reads what this one wrote, through other lanes */
+        }
+        mb_publish(&progress[p], x + 1, lane);
+    }
+}
+
+extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], const int stride[3], void *stream_)
+{
+    if (!m || !dst || !stride || !dst[0] || !dst[1] || !dst[2])
+        return FFHIP_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int pl = 0; pl < 3; pl++)
+        if (((uintptr_t)dst[pl] | (size_t)stride[pl]) & 3 || stride[pl] <= 0) {
+            ffhip_set_error("ffhip_h264_mbaff_flush: planes and line sizes must be 4-byte aligned and positive");
+            return FFHIP_EINVAL;
+        }
+    if (stride[1] != stride[2]) {
+        ffhip_set_error("ffhip_h264_mbaff_flush: Cb and Cr share a line size");
+        return FFHIP_EINVAL;
+    }
+    mbaff_finish(m);
+    const int prow = m->mb_h / 2, npairs = m->mb_w * prow;
+    /* one device blob: records, geo, coefs, intra_row, then per plane calls + pair_end */
+    size_t off[12], total = 0;
+    auto place = [&](int i, size_t bytes) { off[i] = total; total += (bytes + 255) & ~(size_t)255; };
+    place(0, m->recs.size() * sizeof(FFHipH264IntraMB));
+    place(1, m->geo.size() * 4);
+    place(2, m->coefs.size() * 2 + 1024); /* (the last run is read in whole dwords) */
+    place(3, m->intra_row.size() * 4);
+    for (int pl = 0; pl < 3; pl++) {
+        place(4 + 2 * pl, m->calls[pl].size() * sizeof(FFHipH264Edge));
+        place(5 + 2 * pl, (size_t)npairs * 4);
+    }
+    if (total > m->dev_sz) {
+        if (m->dev)
+            (void)hipFree(m->dev);
+        m->dev = nullptr;
+        m->dev_sz = 0;
+        if (hipMalloc(&m->dev, total) != hipSuccess) {
+            (void)hipGetLastError();
+            ffhip_set_error("ffhip_h264_mbaff_flush: hipMalloc(%zu) failed", total);
+            return FFHIP_ENOMEM;
+        }
+        m->dev_sz = total;
+    }
+    uint8_t *b = (uint8_t *)m->dev;
+    /* (blocking copies: the lists are small, and the host vectors may be cleared by the next begin() as soon as this call returns) */
+    auto up = [&](int i, const void *src, size_t bytes) -> bool { return !bytes || hipMemcpy(b + off[i], src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+    bool ok = up(0, m->recs.data(), m->recs.size() * sizeof(FFHipH264IntraMB)) && up(1, m->geo.data(), m->geo.size() * 4) &&
+              up(2, m->coefs.data(), m->coefs.size() * 2) && up(3, m->intra_row.data(), m->intra_row.size() * 4);
+    for (int pl = 0; pl < 3 && ok; pl++)
+        ok = up(4 + 2 * pl, m->calls[pl].data(), m->calls[pl].size() * sizeof(FFHipH264Edge)) && up(5 + 2 * pl, m->pair_end[pl].data(), (size_t)npairs * 4);
+    if (!ok) {
+        (void)hipGetLastError();
+        ffhip_set_error("ffhip_h264_mbaff_flush: uploading the lists failed");
+        return m->last_status = FFHIP_EIO;
+    }
+    int rc = 0;
+    if (!m->recs.empty()) {
+        FFHipProgressSlot ps;
+        rc = ffhip_progress_acquire(prow, stream, &ps);
+        if (rc < 0)
+            return m->last_status = rc;
+        hipLaunchKernelGGL(k_h264_mbaff_intra, dim3(prow), dim3(64), 0, stream, dst[0], dst[1], dst[2], (ptrdiff_t)stride[0], (ptrdiff_t)stride[1], m->mb_w,
+                           m->mb_h, reinterpret_cast<const FFHipH264IntraMB *>(b + off[0]), reinterpret_cast<const uint32_t *>(b + off[1]),
+                           reinterpret_cast<const int32_t *>(b + off[3]), reinterpret_cast<const int16_t *>(b + off[2]), ps.prog, ps.fail);
+        const hipError_t e = hipGetLastError();
+        const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            return m->last_status = FFHIP_EIO;
+        }
+        if (r2 < 0)
+            return m->last_status = r2;
+    }
+    for (int pl = 0; pl < 3; pl++) {
+        if (m->calls[pl].empty())
+            continue;
+        FFHipProgressSlot ps;
+        rc = ffhip_progress_acquire(prow, stream, &ps);
+        if (rc < 0)
+            return m->last_status = rc;
+        hipLaunchKernelGGL(k_h264_mbaff_deblock, dim3(prow), dim3(64), 0, stream, dst[pl], (ptrdiff_t)stride[pl], m->mb_w, prow,
+                           reinterpret_cast<const FFHipH264Edge *>(b + off[4 + 2 * pl]), reinterpret_cast<const int32_t *>(b + off[5 + 2 * pl]), ps.prog,
+                           ps.fail);
+        const hipError_t e = hipGetLastError();
+        const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
+        if (e != hipSuccess) {
+            ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+            return m->last_status = FFHIP_EIO;
+        }
+        if (r2 < 0)
+            return m->last_status = r2;
+    }
+    return m->last_status = 0;
+}

@@ -911,6 +911,53 @@ int  ffhip_h264_picture_lists(const FFHipH264Picture *p, FFHipH264PictureLists *
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
 int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                               void *stream);
+/* ---- MBAFF frames (round 6): mb_adaptive_frame_field_flag, 8 bits, 4:2:0 ------------------------------------------------------------
+ * A frame whose macroblock pairs mix frame and field macroblocks (libavcodec/h264_mb_template.c:61-78, h264_loopfilter.c:494-560,716-760)
+ * is recorded into FOUR objects over the same planes (integration/avcodec_h264_picture_hip.c does it):
+ *   - three ordinary FFHipH264Picture objects for the INTER macroblocks' prediction, weight and residual lists: the frame macroblocks
+ *     (mb_w x mb_h, the frame's line sizes), the top-field macroblocks and the bottom-field macroblocks (each mb_w x mb_h / 2 at TWICE the
+ *     line sizes, the bottom one's planes one frame line further down) — a field macroblock of a pair is the field-picture case, which is
+ *     how hl_decode_mb() addresses it; flush each with ffhip_h264_picture_flush() (they hold no intra macroblocks and no edges);
+ *   - one FFHipH264Mbaff for the two chains whose order crosses macroblocks: the intra macroblocks (decoding order: pair rows, pairs
+ *     left to right, top then bottom macroblock) and the in-loop filter's dsp calls, recorded call by call in the order
+ *     ff_h264_filter_mb() issues them.  ffhip_h264_mbaff_flush() runs the intra reconstruction, then the filter, and goes LAST.
+ */
+typedef struct FFHipH264Mbaff FFHipH264Mbaff;
+/** mb_w x mb_h: the frame's macroblocks (mb_h even).  FFHIP_EINVAL otherwise. */
+int  ffhip_h264_mbaff_create(FFHipH264Mbaff **m, int mb_w, int mb_h);
+void ffhip_h264_mbaff_free(FFHipH264Mbaff **m);
+void ffhip_h264_mbaff_begin(FFHipH264Mbaff *m);
+/** One intra macroblock, as ffhip_h264_picture_intra_mb(): desc->mb_x, desc->mb_y = the macroblock's position in the FRAME (mb_y odd: the
+ *  bottom macroblock of its pair); field != 0: a field macroblock (MB_FIELD(sl)) — its lines are every second frame line from the pair's
+ *  line (mb_y & 1) on.  Macroblocks must arrive in decoding order. */
+int  ffhip_h264_mbaff_intra_mb(FFHipH264Mbaff *m, const FFHipH264IntraMB *desc, int field, const uint8_t *non_zero_count_cache, int16_t *mb,
+                               const int16_t *mb_luma_dc, const uint8_t *pcm);
+/** One loop-filter dsp call of macroblock (mb_x, mb_y) on `plane` (0 luma, 1 Cb, 2 Cr), as the H264DSPContext member received it:
+ *  call->offset = pix - the plane's first sample (a multiple of 4), call->kind = FFHIP_H264_LF_* of the member, alpha, beta, tc0, and in
+ *  call->pad the flags below.  Calls arrive in the order ff_h264_filter_mb() issues them, macroblock by macroblock in decoding order. */
+#define FFHIP_H264_LF_CALL_FIELD 1 /* the member was called with twice the plane's line size (a field macroblock's lines)              */
+#define FFHIP_H264_LF_CALL_MBAFF 2 /* the _mbaff member: h264_h_loop_filter_luma_mbaff[_intra] (8 lines), _chroma_mbaff[_intra] (4 lines) */
+int  ffhip_h264_mbaff_filter_call(FFHipH264Mbaff *m, int plane, int mb_x, int mb_y, const FFHipH264Edge *call);
+/** What has been recorded since begin(), as flush() uploads it (host pointers, valid until the next record call): the CPU tier's list
+ *  executor (oracle/emul_h264_mbaff.cpp) runs these. */
+typedef struct FFHipH264MbaffLists {
+    int mb_w, mb_h;
+    const FFHipH264IntraMB *recs;   /* nrecs intra macroblocks in decoding order */
+    const uint32_t *geo;            /* per record: mb_x | mb_y << 12 | field << 24 */
+    const int16_t *coefs;           /* their packed runs (ncoefs int16) */
+    const int32_t *intra_row;       /* mb_h / 2 + 1 starts into recs, by pair row */
+    int32_t nrecs, ncoefs;
+    const FFHipH264Edge *calls[3];  /* per plane: the calls in order */
+    const int32_t *pair_end[3];     /* per plane and pair (row-major, mb_w x mb_h / 2): one past the pair's last call */
+    int32_t ncalls[3];
+} FFHipH264MbaffLists;
+int  ffhip_h264_mbaff_lists(FFHipH264Mbaff *m, FFHipH264MbaffLists *out);
+/** The intra reconstruction (one wave per pair row, the tile and phases of every other picture's intra macroblocks at the
+ *  macroblock's own line step), then the recorded filter calls in order (one wave per pair row and plane; pair x of row p after pair x + 1
+ *  of row p - 1).  dst[] / stride[]: the FRAME's planes and line sizes (4-byte aligned; Cb and Cr share a line size).  Call after the
+ *  three inter objects' flushes on the same stream.  Asynchronous on `stream` once the lists are uploaded. */
+int  ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], const int stride[3], void *stream);
+
 /** n picture objects (one geometry, depth and device; the pictures a decoder's frame threads hold at once) flushed TOGETHER (round 4):
  *  dst[3 i + pl] / ref[3 i + pl] are picture i's planes and reference bases, stride[] is shared.  Every picture's staging copy,
  *  prediction and residual launches are its own; the two stages that are a latency chain per picture — the intra reconstruction

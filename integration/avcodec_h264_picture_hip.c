@@ -28,9 +28,17 @@
  * frame macroblocks — or the field macroblocks of a FIELD picture (PAFF): a field is every second line of the frame buffer, i.e. a
  * picture of half the height at twice the line size, which is how hl_decode_mb() itself addresses it (mb_linesize = 2 * linesize,
  * block_offset[48..], odd rows one line down: h264_mb_template.c:61-78) and how the references' fields arrive (pic_as_field(),
- * h264_refs.c:39-48); the libffhip picture object is made for the field and never learns the difference.  MBAFF frames (frame and
- * field macroblock pairs mixed in one picture) stay on the C path.  CAVLC / CABAC alike (entropy decoding stays on the CPU and fills
- * sl-> as ever).
+ * h264_refs.c:39-48); the libffhip picture object is made for the field and never learns the difference.  CAVLC / CABAC alike (entropy
+ * decoding stays on the CPU and fills sl-> as ever).
+ *
+ * MBAFF frames (frame and field macroblock pairs mixed in one picture; round 6, 8 bits, 4:2:0).  A field macroblock of a pair IS the field
+ * case, per macroblock: hl_decode_mb() addresses it at twice the line size from the pair's first or second line (h264_mb_template.c:65-73)
+ * and reads its references through the field entries of the list (ref_list[l][16 + 2 i + parity], h264_refs.c h264_fill_mbaff_ref_list; the
+ * cache rewritten at h264_mb_template.c:74-91).  The recorder therefore keeps THREE picture objects over the same planes — the frame
+ * macroblocks, the top-field ones, the bottom-field ones — and switches between them per macroblock; nothing below the switch knows.  What
+ * does not split that way goes into a fourth object (FFHipH264Mbaff): the intra macroblocks (they read their neighbours at the macroblock's
+ * own line step) and the loop filter, whose dsp calls in an MBAFF frame (the left edge in two halves through the _mbaff members, a frame
+ * macroblock's top edge once per field at twice the line size: h264_loopfilter.c:494-560,728-830) are recorded as what they are: calls.
  */
 #include <string.h>
 
@@ -52,6 +60,24 @@ static _Thread_local FFHipH264Recorder *cur_rec;   /* function pointers carry no
 static size_t plane_span(const FFHipH264Recorder *r, int pl)
 {
     return (size_t)(r->rows[pl] - 1) * r->linesize[pl] + ((size_t)r->pic_w[pl] << r->pixel_shift);
+}
+
+/* MBAFF: the object the macroblock at hand is recorded into (0 the frame macroblocks, 1 / 2 the top- / bottom-field ones) */
+static void select_view(FFHipH264Recorder *r, int v)
+{
+    if (r->active == v)
+        return;
+    r->active = v;
+    r->pic = r->view[v].pic;
+    r->field = v > 0;
+    for (int pl = 0; pl < 3; pl++) {
+        r->cur[pl] = r->view[v].cur[pl];
+        r->linesize[pl] = r->view[v].linesize[pl];
+        r->rows[pl] = r->view[v].rows[pl];
+        r->last_ref[pl] = NULL;   /* (an origin found at one line size says nothing at the other) */
+    }
+    r->scratch_size = (size_t)16 * r->linesize[1] + (size_t)16 * r->linesize[0];
+    r->emu_size = (size_t)21 * r->linesize[0] + ((size_t)21 << r->pixel_shift);
 }
 
 static int classify_dst(const FFHipH264Recorder *r, const uint8_t *p)
@@ -117,13 +143,17 @@ static int locate_src(FFHipH264Recorder *r, int pl, const uint8_t *src, int need
         const ptrdiff_t wbytes = (ptrdiff_t)r->pic_w[pl] << r->pixel_shift;
         const uint8_t *origin = r->last_ref[pl];
         if (!origin || src < origin || src >= origin + span || (src - origin) % ls >= wbytes) {
+            /* a field macroblock of an MBAFF frame reads the list's field entries: 16 + 2 i + parity (h264_mb_template.c:74-91) */
+            const int first = r->mbaff && r->field ? 16 : 0;
             origin = NULL;
-            for (int l = 0; l < (int)r->sl->list_count && !origin; l++)
-                for (int i = 0; i < (int)r->sl->ref_count[l] && !origin; i++) {
-                    const uint8_t *d = r->sl->ref_list[l][i].data[pl];
+            for (int l = 0; l < (int)r->sl->list_count && !origin; l++) {
+                const int n = first ? FFMIN(2 * (int)r->sl->ref_count[l], 32) : (int)r->sl->ref_count[l];
+                for (int i = 0; i < n && !origin; i++) {
+                    const uint8_t *d = r->sl->ref_list[l][first + i].data[pl];
                     if (d && src >= d && src < d + span && (src - d) % ls < wbytes)
                         origin = d;
                 }
+            }
             if (!origin)
                 return FFHIP_EINVAL;
             r->last_ref[pl] = origin;
@@ -319,13 +349,34 @@ static _Thread_local struct {
     int any[3], mb_x, mb_y;
 } cur_edges;
 
-static void rec_edge(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0)
+static void rec_edge(int kind, uint8_t *pix, ptrdiff_t stride, int alpha, int beta, const int8_t *tc0, int mbaff_member)
 {
     REC;
     const int chroma = (kind & 2) != 0, dir = !(kind & 1); /* FFHIP_H264_LF_V_* filter across a horizontal edge: dir 1 */
     int pl = classify_dst(r, pix), x, y, e;
     ptrdiff_t o;
     FFHipH264Edge *E;
+    if (r->mbaff) {
+        /* an MBAFF frame: the call as it is — where, which member, at the frame's line size or twice it (a field macroblock's lines, or a
+         * frame macroblock's edge towards a field pair: h264_loopfilter.c:520-545,812-830) */
+        FFHipH264Edge c = { 0 };
+        int rc;
+        if (pl < 0 || pl > 2 || (pl != 0) != chroma || (stride != r->linesize[pl] && stride != 2 * r->linesize[pl]))
+            FAIL(FFHIP_EINVAL);
+        c.offset = (int32_t)(pix - r->cur[pl]);
+        c.kind = (uint8_t)kind;
+        c.alpha = (uint8_t)alpha;
+        c.beta = (uint8_t)beta;
+        c.pad = (uint8_t)((stride != r->linesize[pl] ? FFHIP_H264_LF_CALL_FIELD : 0) | (mbaff_member ? FFHIP_H264_LF_CALL_MBAFF : 0));
+        if (tc0)
+            memcpy(c.tc0, tc0, 4);
+        rc = ffhip_h264_mbaff_filter_call(r->chains, pl, cur_edges.mb_x, cur_edges.mb_y, &c);
+        if (rc < 0)
+            FAIL(rc);
+        return;
+    }
+    if (mbaff_member)
+        FAIL(FFHIP_EINVAL);
     /* 4:4:4: the luma members on every plane (filter_mb_edgev / edgeh on img_cb / img_cr, h264_loopfilter.c:601-703) */
     if (pl < 0 || pl > 2 || (r->cfmt == 3 ? chroma : (pl != 0) != chroma) || stride != r->linesize[pl])
         FAIL(FFHIP_EINVAL);
@@ -358,12 +409,17 @@ fill:
         memcpy(E->tc0, tc0, 4);
     cur_edges.any[pl] = 1;
 }
-#define LF(name, kind) static void rec_##name(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0) { rec_edge(kind, pix, stride, alpha, beta, tc0); }
-#define LFI(name, kind) static void rec_##name(uint8_t *pix, ptrdiff_t stride, int alpha, int beta) { rec_edge(kind, pix, stride, alpha, beta, NULL); }
+#define LF(name, kind) static void rec_##name(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0) { rec_edge(kind, pix, stride, alpha, beta, tc0, 0); }
+#define LFI(name, kind) static void rec_##name(uint8_t *pix, ptrdiff_t stride, int alpha, int beta) { rec_edge(kind, pix, stride, alpha, beta, NULL, 0); }
+#define LFM(name, kind) static void rec_##name(uint8_t *pix, ptrdiff_t stride, int alpha, int beta, int8_t *tc0) { rec_edge(kind, pix, stride, alpha, beta, tc0, 1); }
+#define LFMI(name, kind) static void rec_##name(uint8_t *pix, ptrdiff_t stride, int alpha, int beta) { rec_edge(kind, pix, stride, alpha, beta, NULL, 1); }
 LF(v_loop_filter_luma, FFHIP_H264_LF_V_LUMA) LF(h_loop_filter_luma, FFHIP_H264_LF_H_LUMA)
 LF(v_loop_filter_chroma, FFHIP_H264_LF_V_CHROMA) LF(h_loop_filter_chroma, FFHIP_H264_LF_H_CHROMA)
 LFI(v_loop_filter_luma_intra, FFHIP_H264_LF_V_LUMA_INTRA) LFI(h_loop_filter_luma_intra, FFHIP_H264_LF_H_LUMA_INTRA)
 LFI(v_loop_filter_chroma_intra, FFHIP_H264_LF_V_CHROMA_INTRA) LFI(h_loop_filter_chroma_intra, FFHIP_H264_LF_H_CHROMA_INTRA)
+/* the left edge of a macroblock whose left pair is of the other kind: half as many lines per call (h264dsp_template.c:127-133,262-272) */
+LFM(h_loop_filter_luma_mbaff, FFHIP_H264_LF_H_LUMA) LFMI(h_loop_filter_luma_mbaff_intra, FFHIP_H264_LF_H_LUMA_INTRA)
+LFM(h_loop_filter_chroma_mbaff, FFHIP_H264_LF_H_CHROMA) LFMI(h_loop_filter_chroma_mbaff_intra, FFHIP_H264_LF_H_CHROMA_INTRA)
 
 av_cold void ff_h264_hip_recorder_install(H264Context *h)
 {
@@ -393,16 +449,22 @@ av_cold void ff_h264_hip_recorder_install(H264Context *h)
     h->h264dsp.h_loop_filter_chroma       = rec_h_loop_filter_chroma;
     h->h264dsp.v_loop_filter_chroma_intra = rec_v_loop_filter_chroma_intra;
     h->h264dsp.h_loop_filter_chroma_intra = rec_h_loop_filter_chroma_intra;
+    h->h264dsp.h_loop_filter_luma_mbaff         = rec_h_loop_filter_luma_mbaff;
+    h->h264dsp.h_loop_filter_luma_mbaff_intra   = rec_h_loop_filter_luma_mbaff_intra;
+    h->h264dsp.h_loop_filter_chroma_mbaff       = rec_h_loop_filter_chroma_mbaff;
+    h->h264dsp.h_loop_filter_chroma_mbaff_intra = rec_h_loop_filter_chroma_mbaff_intra;
     h->vdsp.emulated_edge_mc = rec_emulated_edge_mc;
     h->vdsp.prefetch = rec_prefetch;
 }
 
-/* What keeps a whole picture on the C path, known before its first macroblock (MBAFF frames; lossless streams, where a
- * qpprime_y_zero_transform_bypass macroblock may turn up at any macroblock): a caller asks this BEFORE it begins to record — once
+/* What keeps a whole picture on the C path, known before its first macroblock (MBAFF frames above 8 bits or not 4:2:0; lossless streams,
+ * where a qpprime_y_zero_transform_bypass macroblock may turn up at any macroblock): a caller asks this BEFORE it begins to record — once
  * macroblocks have been recorded their coefficients are consumed and the pixels exist only as records, there is no way back. */
 int ff_h264_hip_picture_supported(const H264Context *h)
 {
-    return !FRAME_MBAFF(h) && !h->ps.sps->transform_bypass;
+    if (h->ps.sps->transform_bypass)
+        return 0;
+    return !FRAME_MBAFF(h) || (h->ps.sps->bit_depth_luma == 8 && h->ps.sps->chroma_format_idc == 1 && !(h->mb_height & 1));
 }
 
 void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, const H264Context *h, const H264SliceContext *sl,
@@ -435,18 +497,61 @@ void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, con
     r->emu_size = (size_t)21 * r->linesize[0] + ((size_t)21 << h->pixel_shift);
 }
 
+void ff_h264_hip_recorder_begin_mbaff(FFHipH264Recorder *r, FFHipH264Picture *frame_mbs, FFHipH264Picture *top_mbs, FFHipH264Picture *bottom_mbs,
+                                      FFHipH264Mbaff *chains, const H264Context *h, const H264SliceContext *sl, const uint8_t *const ref_base[3])
+{
+    FFHipH264Picture *const pics[3] = { frame_mbs, top_mbs, bottom_mbs };
+    memset(r, 0, sizeof(*r));
+    r->mbaff = 1;
+    r->chains = chains;
+    r->pixel_shift = 0;
+    r->cfmt = 1;
+    if (!ff_h264_hip_picture_supported(h) || !FRAME_MBAFF(h))
+        r->error = FFHIP_ENOSYS;
+    for (int v = 0; v < 3; v++) {
+        r->view[v].pic = pics[v];
+        for (int pl = 0; pl < 3; pl++) {
+            const ptrdiff_t ls = pl ? sl->uvlinesize : sl->linesize;
+            r->view[v].cur[pl] = h->cur_pic.f->data[pl] + (v == 2 ? ls : 0);
+            r->view[v].linesize[pl] = ls << (v > 0);
+            r->view[v].rows[pl] = (h->mb_height >> (v > 0)) * (pl ? 8 : 16);
+        }
+    }
+    for (int pl = 0; pl < 3; pl++) {
+        r->ref_base[pl] = ref_base[pl];
+        r->pic_w[pl] = h->mb_width * (pl ? 8 : 16);
+    }
+    r->scratch = sl->bipred_scratchpad;
+    r->emu_buf = sl->edge_emu_buffer;
+    r->active = -1;
+    select_view(r, 0);
+    for (int pl = 0; pl < 3 && r->error >= 0; pl++) { /* the frame's planes within reach of the base: so are its fields' */
+        int32_t o;
+        if (!fits32(r->cur[pl] - r->ref_base[pl], &o) || !fits32(r->cur[pl] + plane_span(r, pl) - r->ref_base[pl], &o))
+            r->error = FFHIP_EINVAL;
+    }
+}
+
 int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceContext *sl)
 {
     const int mb_type = h->cur_pic.mb_type[sl->mb_xy];
     if (r->error < 0)
         return r->error;
-    if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field || (sl->qscale == 0 && h->ps.sps->transform_bypass))
+    if (r->mbaff) {
+        if (!FRAME_MBAFF(h))
+            return r->error = FFHIP_EINVAL;
+        select_view(r, MB_FIELD(sl) ? 1 + (sl->mb_y & 1) : 0);
+    } else if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field) {
         return r->error = FFHIP_ENOSYS;   /* such a picture stays on the C path as a whole */
+    }
+    if (sl->qscale == 0 && h->ps.sps->transform_bypass)
+        return r->error = FFHIP_ENOSYS;
     if (IS_INTRA(mb_type)) {
         FFHipH264IntraMB m = { 0 };
         const int intra_qmul = 0;
         m.mb_x = (int16_t)sl->mb_x;
-        m.mb_y = (int16_t)(sl->mb_y >> r->field);   /* a field picture: rows of the field (mb_y = 2 * row + bottom, h264_slice.c:2676-2680) */
+        /* a field picture: rows of the field (mb_y = 2 * row + bottom, h264_slice.c:2676-2680); an MBAFF frame: the row in the frame */
+        m.mb_y = (int16_t)(r->mbaff ? sl->mb_y : sl->mb_y >> r->field);
         m.type = IS_INTRA_PCM(mb_type) ? FFHIP_H264_INTRA_PCM : IS_INTRA16x16(mb_type) ? FFHIP_H264_INTRA_16x16
                : IS_8x8DCT(mb_type) ? FFHIP_H264_INTRA_8x8 : FFHIP_H264_INTRA_4x4;
         m.pred16 = (uint8_t)sl->intra16x16_pred_mode;
@@ -487,7 +592,11 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
             r->error = FFMIN(0, ffhip_h264_picture_intra_mb(r->pic, &m, sl->non_zero_count_cache, sl->mb, sl->mb_luma_dc[0], pcm));
             return r->error;
         }
-        r->error = FFMIN(0, ffhip_h264_picture_intra_mb(r->pic, &m, sl->non_zero_count_cache, sl->mb, sl->mb_luma_dc[0], sl->intra_pcm_ptr));
+        if (r->mbaff)
+            r->error = FFMIN(0, ffhip_h264_mbaff_intra_mb(r->chains, &m, !!MB_FIELD(sl), sl->non_zero_count_cache, sl->mb, sl->mb_luma_dc[0],
+                                                          sl->intra_pcm_ptr));
+        else
+            r->error = FFMIN(0, ffhip_h264_picture_intra_mb(r->pic, &m, sl->non_zero_count_cache, sl->mb, sl->mb_luma_dc[0], sl->intra_pcm_ptr));
         return r->error;
     }
     cur_rec = r;
@@ -505,6 +614,28 @@ int ff_h264_hip_filter_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceC
 {
     if (r->error < 0)
         return r->error;
+    if (r->mbaff) {
+        /* loop_filter()'s addressing of the macroblock (h264_slice.c:2470-2491), on the frame's planes */
+        const int field = !!MB_FIELD(sl);
+        uint8_t *img[3];
+        if (!FRAME_MBAFF(h))
+            return r->error = FFHIP_EINVAL;
+        select_view(r, 0);
+        for (int pl = 0; pl < 3; pl++) {
+            const ptrdiff_t ls = r->linesize[pl];
+            const int bh = pl ? 8 : 16;
+            img[pl] = (uint8_t *)r->cur[pl] + (ptrdiff_t)mb_x * bh + (ptrdiff_t)mb_y * bh * ls - (field && (mb_y & 1) ? (bh - 1) * ls : 0);
+        }
+        memset(&cur_edges, 0, sizeof(cur_edges));
+        cur_edges.mb_x = mb_x;
+        cur_edges.mb_y = mb_y;
+        sl->mb_linesize = r->linesize[0] << field;
+        sl->mb_uvlinesize = r->linesize[1] << field;
+        cur_rec = r;
+        ff_h264_filter_mb(h, sl, mb_x, mb_y, img[0], img[1], img[2], (unsigned)sl->mb_linesize, (unsigned)sl->mb_uvlinesize);
+        cur_rec = NULL;
+        return r->error;
+    }
     if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field)
         return r->error = FFHIP_ENOSYS;
     memset(&cur_edges, 0, sizeof(cur_edges));

@@ -48,6 +48,19 @@ typedef struct FFHipH264Recorder {
         FFHipChromaBlock c;
     } pend[8];
     int npend;
+    /* an MBAFF frame (round 6; 8 bits, 4:2:0): FOUR objects over the same planes.  view[0] the frame macroblocks, view[1] / view[2] the top- /
+     * bottom-field macroblocks (half the rows at twice the line size; the bottom one a frame line further down) — the object a macroblock is
+     * recorded into is chosen per macroblock and copied into pic / cur / linesize / rows above, so everything that serves a frame or a
+     * field picture serves a macroblock of either kind; `chains` takes the intra macroblocks and the loop filter's calls */
+    int mbaff;
+    int active;                     /* the view pic / cur / linesize / rows currently stand for */
+    struct FFHipH264View {
+        FFHipH264Picture *pic;
+        const uint8_t *cur[3];
+        ptrdiff_t linesize[3];
+        int rows[3];
+    } view[3];
+    FFHipH264Mbaff *chains;
 } FFHipH264Recorder;
 
 /* Replaces, in h, the dsp members hl_decode_mb() calls for inter macroblocks (h264qpel, h264chroma, weight / biweight, idct_add16 /
@@ -55,7 +68,8 @@ typedef struct FFHipH264Recorder {
  * ones; chroma_dc_dequant_idct and everything else stay what ff_h264dsp_init() left.  Call once after the decoder's own init. */
 void ff_h264_hip_recorder_install(H264Context *h);
 
-/* 1 when the picture the decoder is about to decode can be recorded as a whole: no MBAFF, no lossless (transform-bypass) stream.  Ask
+/* 1 when the picture the decoder is about to decode can be recorded as a whole: no lossless (transform-bypass) stream; an MBAFF frame
+ * (FRAME_MBAFF(h): begin it with ff_h264_hip_recorder_begin_mbaff()) only at 8 bits, 4:2:0.  Ask
  * before ff_h264_hip_recorder_begin(): a refusal in the middle of a picture cannot be undone (the per-macroblock calls still return
  * FFHIP_ENOSYS for such macroblocks, as a guard). */
 int ff_h264_hip_picture_supported(const H264Context *h);
@@ -66,6 +80,14 @@ int ff_h264_hip_picture_supported(const H264Context *h);
  * and TWICE the frame's line sizes as strides; the references' fields are addressed the same way through ref_base[]. */
 void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, const H264Context *h, const H264SliceContext *sl,
                                 const uint8_t *const ref_base[3]);
+
+/* A new MBAFF frame (FRAME_MBAFF(h)): frame_mbs / top_mbs / bottom_mbs are picture objects made for h->mb_width x h->mb_height and (the two
+ * field ones) h->mb_width x h->mb_height / 2, `chains` a FFHipH264Mbaff made for h->mb_width x h->mb_height; all four have had begin() called.
+ * When the frame is complete: ffhip_h264_picture_flush() of the three — frame_mbs with data[] and the frame's line sizes, top_mbs with data[]
+ * and TWICE the line sizes, bottom_mbs with data[] + one line and twice the line sizes — then ffhip_h264_mbaff_flush(chains, data[], the
+ * frame's line sizes), on one stream. */
+void ff_h264_hip_recorder_begin_mbaff(FFHipH264Recorder *r, FFHipH264Picture *frame_mbs, FFHipH264Picture *top_mbs, FFHipH264Picture *bottom_mbs,
+                                      FFHipH264Mbaff *chains, const H264Context *h, const H264SliceContext *sl, const uint8_t *const ref_base[3]);
 
 /* ff_h264_hl_decode_mb(h, sl) with the dsp calls recorded into r->pic (intra macroblocks: one FFHipH264IntraMB record).  Returns 0 or
  * the first libffhip error. */

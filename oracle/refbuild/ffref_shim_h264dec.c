@@ -45,6 +45,10 @@
 /* dst_off[pl]: the picture's planes as byte offsets into the arena (a bottom field: one line down); stride[pl]: the picture's line sizes
  * (a field: twice the frame's).  Returns 0 or < 0. */
 typedef int (*ffref_h264_flush_fn)(void *opaque, void *pic, const int64_t dst_off[3], const int stride[3], int mb_w, int mb_h, int field);
+/* An MBAFF frame (round 6): `flush` above is called three times first — the frame macroblocks' object (field 2), the top- and the
+ * bottom-field macroblocks' objects (field 3: half the rows, twice the line sizes, the bottom one's planes a line down) — then this with the
+ * FFHipH264Mbaff object, the FRAME's planes and line sizes. */
+typedef int (*ffref_h264_flush_mbaff_fn)(void *opaque, void *chains, const int64_t dst_off[3], const int stride[3], int mb_w, int mb_h);
 
 typedef struct FFRefH264Stream {
     AVCodecContext *avctx;
@@ -54,6 +58,12 @@ typedef struct FFRefH264Stream {
     size_t arena_size, arena_used;
     ffref_h264_flush_fn flush;
     void *flush_opaque;
+    ffref_h264_flush_mbaff_fn flush_mbaff;
+    void *flush_mbaff_opaque;
+    /* an MBAFF frame being recorded: pic = the frame macroblocks' object, these the field macroblocks' objects and the chains */
+    FFHipH264Picture *fpic[2];
+    FFHipH264Mbaff *chains;
+    long mbaff_pictures;
     /* the picture being recorded */
     FFHipH264Recorder rec;
     FFHipH264Picture *pic;
@@ -115,6 +125,24 @@ static int flush_current(FFRefH264Stream *s)
     }
     if (s->rec.error < 0) {
         r = s->rec.error;
+    } else if (s->chains) {
+        /* an MBAFF frame: the three inter objects, then the chains (without a test callback for them the frame cannot be finished) */
+        if (s->flush && s->flush_mbaff) {
+            int64_t off[3];
+            int st[3];
+            r = s->flush(s->flush_opaque, s->pic, s->cur_off, s->cur_stride, s->cur_mb_w, s->cur_mb_h, 2);
+            for (int v = 0; v < 2 && r >= 0; v++) {
+                for (int pl = 0; pl < 3; pl++) {
+                    off[pl] = s->cur_off[pl] + (v ? s->cur_stride[pl] : 0);
+                    st[pl] = 2 * s->cur_stride[pl];
+                }
+                r = s->flush(s->flush_opaque, s->fpic[v], off, st, s->cur_mb_w, s->cur_mb_h / 2, 3);
+            }
+            if (r >= 0)
+                r = s->flush_mbaff(s->flush_mbaff_opaque, s->chains, s->cur_off, s->cur_stride, s->cur_mb_w, s->cur_mb_h);
+        } else if (s->flush) {
+            r = FFHIP_ENOSYS;
+        }
     } else if (s->flush) {
         r = s->flush(s->flush_opaque, s->pic, s->cur_off, s->cur_stride, s->cur_mb_w, s->cur_mb_h, s->cur_field);
     }
@@ -124,6 +152,9 @@ static int flush_current(FFRefH264Stream *s)
             s->first_error = r;
     }
     ffhip_h264_picture_free(&s->pic);
+    ffhip_h264_picture_free(&s->fpic[0]);
+    ffhip_h264_picture_free(&s->fpic[1]);
+    ffhip_h264_mbaff_free(&s->chains);
     s->pic = NULL;
     s->cur_ptr = NULL;
     return r;
@@ -157,6 +188,18 @@ static int begin_picture(FFRefH264Stream *s, const H264Context *h, H264SliceCont
         return 0;
     }
     r = ffhip_h264_picture_create_fmt(&s->pic, h->mb_width, h->mb_height >> field, sps->bit_depth_luma, sps->chroma_format_idc ? sps->chroma_format_idc : 1);
+    if (r >= 0 && FRAME_MBAFF(h)) {
+        for (int v = 0; v < 2 && r >= 0; v++)
+            r = ffhip_h264_picture_create_fmt(&s->fpic[v], h->mb_width, h->mb_height / 2, 8, 1);
+        if (r >= 0)
+            r = ffhip_h264_mbaff_create(&s->chains, h->mb_width, h->mb_height);
+        if (r < 0) {
+            ffhip_h264_picture_free(&s->pic);
+            ffhip_h264_picture_free(&s->fpic[0]);
+            ffhip_h264_picture_free(&s->fpic[1]);
+            ffhip_h264_mbaff_free(&s->chains);
+        }
+    }
     if (r < 0 || !s->pic) {
         s->errors++;
         if (!s->first_error)
@@ -168,7 +211,15 @@ static int begin_picture(FFRefH264Stream *s, const H264Context *h, H264SliceCont
     /* the dsp tables may have been made anew for this picture's format (h264_slice.c init_dimensions / h264_init_ps) */
     ff_h264_hip_recorder_install((H264Context *)h);
     s->recording_tables = 1;
-    ff_h264_hip_recorder_begin(&s->rec, s->pic, h, sl, base);
+    if (s->chains) {
+        ffhip_h264_picture_begin(s->fpic[0]);
+        ffhip_h264_picture_begin(s->fpic[1]);
+        ffhip_h264_mbaff_begin(s->chains);
+        ff_h264_hip_recorder_begin_mbaff(&s->rec, s->pic, s->fpic[0], s->fpic[1], s->chains, h, sl, base);
+        s->mbaff_pictures++;
+    } else {
+        ff_h264_hip_recorder_begin(&s->rec, s->pic, h, sl, base);
+    }
     note(s, s->rec.error);
     s->cur_ptr = h->cur_pic_ptr;
     s->cur_structure = h->picture_structure;
@@ -312,6 +363,12 @@ void ffref_h264stream_set_flush(FFRefH264Stream *s, ffref_h264_flush_fn fn, void
     s->flush_opaque = opaque;
 }
 
+void ffref_h264stream_set_flush_mbaff(FFRefH264Stream *s, ffref_h264_flush_mbaff_fn fn, void *opaque)
+{
+    s->flush_mbaff = fn;
+    s->flush_mbaff_opaque = opaque;
+}
+
 static int drain_frames(FFRefH264Stream *s)
 {
     for (;;) {
@@ -395,6 +452,7 @@ long ffref_h264stream_stat(const FFRefH264Stream *s, int what)
     /* 8.. recorded macroblocks: 8 bi-predicted, 9 direct (whole or a sub-macroblock), 10 8x8 transform with coded luma, 11 explicit weights,
      * 12 implicit weights, 13 of B slices, 14 Intra8x8, 15 field macroblocks */
     case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: return s->mbs_class[what - 8];
+    case 16: return s->mbaff_pictures;   /* MBAFF frames recorded (each counted once in 0 as well) */
     }
     return -1;
 }
@@ -405,6 +463,9 @@ void ffref_h264stream_close(FFRefH264Stream *s)
         return;
     if (s->pic)
         ffhip_h264_picture_free(&s->pic);
+    ffhip_h264_picture_free(&s->fpic[0]);
+    ffhip_h264_picture_free(&s->fpic[1]);
+    ffhip_h264_mbaff_free(&s->chains);
     for (int i = 0; i < s->nout; i++)
         av_frame_free(&s->out[i]);
     avcodec_free_context(&s->avctx);

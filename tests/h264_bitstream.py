@@ -354,12 +354,39 @@ class StreamWriter:
         return d
 
     # ---- macroblocks -----------------------------------------------------------------------------------------------------------------
-    def intra_mb(self, bw, pic, mx, my, sl, st, type_offset, allow_i4=True):
+    def mbaff_neighbours(self, pic, mx, my, sl, pair_field):
+        """(left, top, topleft) availability of a macroblock of an MBAFF frame (6.4.12.2): the neighbours are macroblocks of the left /
+        upper / upper-left PAIR — except for the bottom frame macroblock of a pair, whose upper neighbour is the pair's own top macroblock
+        and whose upper-left one lies in the left pair.  WHICH macroblock of the pair it is, is the decoder's business."""
+        p = my >> 1
+
+        def pair(x, q):
+            return 0 <= x < pic.mb_w and 0 <= q and pic.slice_of[2 * q, x] == sl
+        left = pair(mx - 1, p)
+        if (my & 1) and not pair_field:
+            return left, True, left
+        return left, pair(mx, p - 1), pair(mx - 1, p - 1)
+
+    def mbaff_i4_isolated(self, pic, mx, my):
+        """Intra4x4 / Intra8x8 in an MBAFF frame: the mode predictor takes the modes of neighbouring blocks in the left / upper pair or the
+        pair's other macroblock, chosen by the frame / field kinds of both pairs; a macroblock none of whose possible neighbours is I_NxN
+        sees DC whichever it is (8.3.1.1), and the writer needs no more."""
+        p = my >> 1
+        for x, q in ((mx - 1, p), (mx, p - 1), (mx, p)):
+            for b in (0, 1):
+                if 0 <= x < pic.mb_w and q >= 0 and (x, 2 * q + b) != (mx, my) and pic.kind[2 * q + b, x] == 1:
+                    return False
+        return True
+
+    def intra_mb(self, bw, pic, mx, my, sl, st, type_offset, allow_i4=True, neigh=None):
+        """neigh: (left, top, topleft) of a macroblock of an MBAFF frame (mbaff_neighbours()); an I_NxN macroblock there is isolated
+        (mbaff_i4_isolated()): every block outside it counts as DC where its macroblock is available"""
         r = self.rng
         left, top = self.avail(pic, mx - 1, my, sl), self.avail(pic, mx, my - 1, sl)
         topleft = self.avail(pic, mx - 1, my - 1, sl)
-        if self.small:   # MBAFF: the neighbour derivation is the decoder's business; DC prediction is legal wherever the macroblock sits
-            left = top = topleft = False
+        if neigh is not None:
+            left, top, topleft = neigh
+        self._neigh = neigh
         k = r.random()
         if k < 0.08 and not self.small:
             # I_PCM: pcm_alignment_zero_bit, 256 + 2 x 64 samples of bit_depth bits
@@ -418,6 +445,8 @@ class StreamWriter:
             # that is not Intra4x4 coded
             def mode_of(nbx, nby):
                 nmx, nmy = nbx // 4, nby // 4
+                if self._neigh is not None and (nmx, nmy) != (mx, my):
+                    return I4_DC if (left if nbx < 4 * mx else top) else None
                 if not self.avail(pic, nmx, nmy, sl) and (nmx, nmy) != (mx, my):
                     return None
                 if (nmx, nmy) != (mx, my) and pic.kind[nmy, nmx] != 1:
@@ -459,6 +488,8 @@ class StreamWriter:
 
             def mode_of(nbx, nby):
                 nmx, nmy = nbx // 4, nby // 4
+                if self._neigh is not None and (nmx, nmy) != (mx, my):
+                    return I4_DC if (left if nbx < 4 * mx else top) else None
                 if not self.avail(pic, nmx, nmy, sl) and (nmx, nmy) != (mx, my):
                     return None
                 if (nmx, nmy) != (mx, my) and pic.kind[nmy, nmx] != 1:
@@ -698,12 +729,15 @@ class StreamWriter:
                 pair_field = int(r.random() < 0.5)
                 bw.u(1, pair_field)
             prev_skipped = False
+            neigh = self.mbaff_neighbours(pic, mx, my, sl, pair_field) if mbaff else None
+            allow_i4 = self.mbaff_i4_isolated(pic, mx, my) if mbaff else True
             if ptype == "I":
-                self.intra_mb(bw, pic, mx, my, sl, st, 0, allow_i4=not mbaff)
+                self.intra_mb(bw, pic, mx, my, sl, st, 0, allow_i4=allow_i4, neigh=neigh)
             elif r.random() < (0.12 if ptype == "B" else 0.2):
-                self.intra_mb(bw, pic, mx, my, sl, st, 23 if ptype == "B" else 5, allow_i4=not mbaff)
+                self.intra_mb(bw, pic, mx, my, sl, st, 23 if ptype == "B" else 5, allow_i4=allow_i4, neigh=neigh)
             elif ptype == "B":
-                self.inter_mb_b(bw, pic, mx, my, sl, st, (num_ref, num_ref_l1))
+                # (a field macroblock pair of an MBAFF frame: twice the slice's reference counts, 7.4.5.1)
+                self.inter_mb_b(bw, pic, mx, my, sl, st, (num_ref * 2, num_ref_l1 * 2) if mbaff and pair_field else (num_ref, num_ref_l1))
             else:
                 self.inter_mb(bw, pic, mx, my, sl, st, num_ref * 2 if mbaff and pair_field else num_ref)
             i += 1

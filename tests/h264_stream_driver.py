@@ -13,6 +13,8 @@ import h264_bitstream as B
 DEC_SO = os.path.join(ffi.ROOT, "oracle", "_ref", "libffref_h264dec.so")
 EMUL_SO = os.path.join(ffi.ROOT, "oracle", "libffemul.so")
 FLUSH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int)
+# an MBAFF frame: FLUSH_FN three times (field = 2: the frame macroblocks' object, 3: a field parity's), then this with the FFHipH264Mbaff object
+FLUSH_MBAFF_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.c_int)
 _dec = None
 
 
@@ -30,6 +32,8 @@ def dec():
         L.ffref_h264stream_open.argtypes = [C.c_int, C.c_size_t]
         L.ffref_h264stream_set_flush.argtypes = [C.c_void_p, FLUSH_FN, C.c_void_p]
         L.ffref_h264stream_set_flush.restype = None
+        L.ffref_h264stream_set_flush_mbaff.argtypes = [C.c_void_p, FLUSH_MBAFF_FN, C.c_void_p]
+        L.ffref_h264stream_set_flush_mbaff.restype = None
         L.ffref_h264stream_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.ffref_h264stream_nframes.argtypes = [C.c_void_p]
         L.ffref_h264stream_stat.argtypes = [C.c_void_p, C.c_int]
@@ -55,6 +59,11 @@ class Lists(C.Structure):                       # == FFHipH264PictureLists (incl
                 ("intra_c422_coef", C.c_void_p), ("nintra_c422_coef", C.c_int)]
 
 
+class MbaffLists(C.Structure):                  # == FFHipH264MbaffLists (include/ffhip.h)
+    _fields_ = [("mb_w", C.c_int), ("mb_h", C.c_int), ("recs", C.c_void_p), ("geo", C.c_void_p), ("coefs", C.c_void_p), ("intra_row", C.c_void_p),
+                ("nrecs", C.c_int32), ("ncoefs", C.c_int32), ("calls", C.c_void_p * 3), ("pair_end", C.c_void_p * 3), ("ncalls", C.c_int32 * 3)]
+
+
 def cpu_flush(arena_base):
     """flush = the recorded lists executed on the host arena (at address arena_base) by the oracle's list executor; returns the callable and
     the counters it keeps"""
@@ -62,7 +71,10 @@ def cpu_flush(arena_base):
     L = _lib.lib()
     E = C.CDLL(EMUL_SO)
     E.ffemul_h264_picture_flush.argtypes = [C.c_void_p] * 4
-    counts = {"pictures": 0, "inter_blocks": 0, "intra_mbs": 0, "edge_planes": 0}
+    E.ffemul_h264_mbaff_flush.argtypes = [C.c_void_p] * 3
+    L.ffhip_h264_mbaff_lists.argtypes = [C.c_void_p, C.c_void_p]
+    counts = {"pictures": 0, "inter_blocks": 0, "intra_mbs": 0, "edge_planes": 0, "mbaff_frames": 0, "mbaff_intra_mbs": 0, "mbaff_field_intra_mbs": 0,
+              "mbaff_calls": 0, "mbaff_calls_field_stride": 0, "mbaff_calls_mbaff_member": 0, "mbaff_field_inter_blocks": 0}
 
     def flush(opaque, pic, dst_off, stride, mb_w, mb_h, field):
         ls = Lists()
@@ -71,11 +83,33 @@ def cpu_flush(arena_base):
         dp = (C.c_void_p * 3)(*[arena_base + dst_off[i] for i in range(3)])
         rp = (C.c_void_p * 3)(arena_base, arena_base, arena_base)
         st = (C.c_int * 3)(stride[0], stride[1], stride[2])
-        counts["pictures"] += 1
+        counts["pictures"] += not (field & 2)         # (an MBAFF frame counts once, in flush_mbaff)
         counts["inter_blocks"] += sum(ls.nqpel[0][k] for k in range(3))
+        counts["mbaff_field_inter_blocks"] += sum(ls.nqpel[0][k] for k in range(3)) if field == 3 else 0
         counts["intra_mbs"] += ls.nintra[0]
         counts["edge_planes"] += sum(1 for k in range(3) if ls.edges[k])
         return E.ffemul_h264_picture_flush(C.byref(ls), dp, st, rp)
+
+    def flush_mbaff(opaque, chains, dst_off, stride, mb_w, mb_h):
+        ml = MbaffLists()
+        if L.ffhip_h264_mbaff_lists(chains, C.byref(ml)) != 0:
+            return -1
+        dp = (C.c_void_p * 3)(*[arena_base + dst_off[i] for i in range(3)])
+        st = (C.c_int * 3)(stride[0], stride[1], stride[2])
+        counts["pictures"] += 1
+        counts["mbaff_frames"] += 1
+        counts["mbaff_intra_mbs"] += ml.nrecs
+        if ml.nrecs:
+            geo = np.ctypeslib.as_array((C.c_uint32 * ml.nrecs).from_address(ml.geo))
+            counts["mbaff_field_intra_mbs"] += int(((geo >> 24) & 1).sum())
+        for pl in range(3):
+            counts["mbaff_calls"] += ml.ncalls[pl]
+            if ml.ncalls[pl]:
+                raw = np.ctypeslib.as_array((C.c_uint8 * (12 * ml.ncalls[pl])).from_address(ml.calls[pl])).reshape(-1, 12)
+                counts["mbaff_calls_field_stride"] += int((raw[:, 7] & 1).sum())
+                counts["mbaff_calls_mbaff_member"] += int(((raw[:, 7] >> 1) & 1).sum())
+        return E.ffemul_h264_mbaff_flush(C.byref(ml), dp, st)
+    flush.mbaff = flush_mbaff
     return flush, counts
 
 
@@ -86,7 +120,7 @@ def decode(aus, make_flush=None, arena_bytes=48 << 20, read_back=None, base_shif
     L = dec()
     s = L.ffref_h264stream_open(int(make_flush is not None), arena_bytes)
     assert s
-    keep, counts = None, None
+    keep, keep_m, counts = None, None, None
     try:
         base = L.ffref_h264stream_arena(s, None)
         if base_shift:
@@ -95,13 +129,16 @@ def decode(aus, make_flush=None, arena_bytes=48 << 20, read_back=None, base_shif
             fn, counts = make_flush(base, arena_bytes)
             keep = FLUSH_FN(fn)
             L.ffref_h264stream_set_flush(s, keep, None)
+            if getattr(fn, "mbaff", None) is not None:
+                keep_m = FLUSH_MBAFF_FN(fn.mbaff)
+                L.ffref_h264stream_set_flush_mbaff(s, keep_m, None)
         for a in aus:
             r = L.ffref_h264stream_decode(s, a, len(a))
             assert r == 0, "avcodec_send_packet / receive_frame: %d" % r
         assert L.ffref_h264stream_decode(s, None, 0) == 0
         stats = {k: L.ffref_h264stream_stat(s, i) for i, k in enumerate(("pictures", "mbs_hl", "mbs_filter", "refused", "errors",
                                                                         "first_error", "damaged", "plain_pictures", "mbs_bipred", "mbs_direct", "mbs_8x8dct", "mbs_weighted",
-                                                                        "mbs_implicit", "mbs_b", "mbs_intra8x8", "mbs_field"))}
+                                                                        "mbs_implicit", "mbs_b", "mbs_intra8x8", "mbs_field", "mbaff_pictures"))}
         if read_back is not None:
             used = C.c_size_t()
             L.ffref_h264stream_arena(s, C.byref(used))
@@ -180,12 +217,13 @@ def stream_mbaff_and_fields(seed=7, mb_w=6, mb_h=6):
 
 # ---- round 6: B pictures, weighted prediction, the 8x8 transform, 4:2:2 ---------------------------------------------------------------------
 def stream_b(bit_depth=8, seed=21, mb_w=6, mb_h=5, direct_spatial=1, weighted_bipred=0, weighted_pred=0, t8x8=0, chroma_format=1,
-             slices=1, nonref=False, gops=2):
+             slices=1, nonref=False, gops=2, mbaff=0):
     """I P B B B | P B B B ...: pic_order_cnt_type 0, B pictures between their references in output order and decoded after them (a small
     pyramid: the middle B is itself a reference of the outer two), every B macroblock type, direct_spatial_mv_pred_flag as given.
     nonref: the outer B pictures of each group are non-reference pictures (nal_ref_idc 0)."""
     p = B.Params(mb_w=mb_w, mb_h=mb_h, bit_depth=bit_depth, seed=seed, num_ref_frames=4, poc_type=0, reorder=3, t8x8=t8x8,
-                 weighted_pred=weighted_pred, weighted_bipred=weighted_bipred, chroma_format=chroma_format)
+                 weighted_pred=weighted_pred, weighted_bipred=weighted_bipred, chroma_format=chroma_format, frame_mbs_only=0 if mbaff else 1,
+                 mbaff=mbaff)
     w = B.StreamWriter(p)
     rng = np.random.default_rng(seed + 300)
     n_mb = mb_w * mb_h
@@ -194,6 +232,8 @@ def stream_b(bit_depth=8, seed=21, mb_w=6, mb_h=5, direct_spatial=1, weighted_bi
         if slices == 1:
             return [0], [(0, int(rng.integers(-2, 3)), int(rng.integers(-2, 3)))]
         cuts = sorted(int(v) for v in rng.choice(np.arange(3, n_mb - 3), size=slices - 1, replace=False))
+        if mbaff:
+            cuts = sorted(set(c & ~1 for c in cuts))   # a slice of an MBAFF frame starts on a macroblock pair
         return [0] + cuts, [((0, 2, 1)[i % 3], int(rng.integers(-2, 3)), int(rng.integers(-2, 3))) for i in range(slices)]
     pics, nref = [], 0
 
@@ -237,6 +277,41 @@ def stream_p_features(bit_depth=8, seed=31, mb_w=6, mb_h=5, weighted_pred=0, t8x
                      "num_ref": min(k, 3)})
     return w.stream(pics), w.stats
 
+
+def stream_mbaff_p(seed=41, mb_w=6, mb_h=6, n=5, t8x8=0, weighted_pred=0):
+    """I P P P P, every picture an MBAFF frame: frame and field macroblock pairs mixed (mb_field_decoding_flag per pair), one to three slices
+    starting on macroblock pairs, disable_deblocking_filter_idc 0 / 1 / 2, Intra16x16 with every prediction mode its neighbours allow and
+    isolated I_NxN macroblocks, one to three reference frames (a field macroblock: twice as many reference fields)"""
+    p = B.Params(mb_w=mb_w, mb_h=mb_h, frame_mbs_only=0, mbaff=1, seed=seed, t8x8=t8x8, weighted_pred=weighted_pred)
+    w = B.StreamWriter(p)
+    rng = np.random.default_rng(seed + 500)
+    n_mb = mb_w * mb_h
+    pics = []
+    for k in range(n):
+        ns = 1 + (k % 3)
+        cuts = sorted(set(int(v) & ~1 for v in rng.choice(np.arange(4, n_mb - 4), size=ns - 1, replace=False)))
+        idcs = [(0, 2, 1), (0, 0, 2), (2, 1, 0)][k % 3]
+        pics.append({"type": "I" if k == 0 else "P", "slices": [0] + cuts,
+                     "deblock": [(idcs[i % 3], int(rng.integers(-2, 3)), int(rng.integers(-2, 3))) for i in range(len(cuts) + 1)],
+                     "num_ref": min(max(k, 1), 3)})
+    return w.stream(pics), w.stats
+
+
+# MBAFF frames (8 bits, 4:2:0): name -> (generator, kwargs, pictures, DECODER statistics that must be non-zero, counters of the list executor
+# that must be non-zero)
+MBAFF_CASES = {
+    "mbaff_p": (stream_mbaff_p, dict(seed=41), 5, ("mbs_field",), ("mbaff_field_intra_mbs", "mbaff_calls_field_stride", "mbaff_calls_mbaff_member",
+                                                                   "mbaff_field_inter_blocks")),
+    "mbaff_p_8x8_weighted": (stream_mbaff_p, dict(seed=42, t8x8=1, weighted_pred=1), 5, ("mbs_field", "mbs_8x8dct", "mbs_weighted"),
+                             ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
+    "mbaff_p_wide": (stream_mbaff_p, dict(seed=43, mb_w=11, mb_h=8, n=4), 4, ("mbs_field",), ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
+    "mbaff_b_spatial": (stream_b, dict(seed=44, mb_h=6, mbaff=1, direct_spatial=1), 9, ("mbs_field", "mbs_b", "mbs_bipred", "mbs_direct"),
+                        ("mbaff_calls_mbaff_member",)),
+    "mbaff_b_temporal_implicit": (stream_b, dict(seed=45, mb_h=6, mbaff=1, direct_spatial=0, weighted_bipred=2, slices=2), 9,
+                                  ("mbs_field", "mbs_b", "mbs_bipred", "mbs_direct", "mbs_implicit"), ("mbaff_calls_mbaff_member",)),
+    "mbaff_b_explicit_8x8": (stream_b, dict(seed=46, mb_h=6, mbaff=1, weighted_bipred=1, weighted_pred=1, t8x8=1), 9,
+                             ("mbs_field", "mbs_b", "mbs_weighted", "mbs_8x8dct"), ("mbaff_calls_mbaff_member",)),
+}
 
 # name -> (generator, kwargs, pictures, statistics of the DECODER that must be non-zero in record mode, writer statistics that must be non-zero)
 ROUND6_CASES = {

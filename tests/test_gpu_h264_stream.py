@@ -32,10 +32,21 @@ def _gpu_flush_factory():
             dp = (C.c_void_p * 3)(*[d + dst_off[i] for i in range(3)])
             rp = (C.c_void_p * 3)(d, d, d)
             st = (C.c_int * 3)(stride[0], stride[1], stride[2])
-            counts["pictures"] += 1
+            counts["pictures"] += not (field & 2)     # (an MBAFF frame's three inter objects: counted once, with its chains)
             r = L.ffhip_h264_picture_flush(pic, dp, st, rp, stream)
             torch.cuda.synchronize()           # the decoder frees the picture object when this returns
             return r
+
+        def flush_mbaff(opaque, chains, dst_off, stride, mb_w, mb_h):
+            d = dev.data_ptr()
+            dp = (C.c_void_p * 3)(*[d + dst_off[i] for i in range(3)])
+            st = (C.c_int * 3)(stride[0], stride[1], stride[2])
+            counts["pictures"] += 1
+            counts["mbaff_frames"] = counts.get("mbaff_frames", 0) + 1
+            r = L.ffhip_h264_mbaff_flush(chains, dp, st, stream)
+            torch.cuda.synchronize()
+            return r
+        flush.mbaff = flush_mbaff
         return flush, counts
 
     def read_back(arena_base, used):
@@ -86,6 +97,41 @@ def test_a_larger_picture():
     for k in range(1, 6):
         pics.append({"type": "P", "slices": [0, 100 + 7 * k, 300], "deblock": [(0, 0, 0), (2, -1, 1), (0, 2, -2)], "num_ref": min(k, 3)})
     _check(w.stream(pics), 6)
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_mbaff_frames_between_field_pictures(seed):
+    """MBAFF frames (round 6; 8 bits, 4:2:0) between plain field pictures: the frame's three inter objects through ffhip_h264_picture_flush(),
+    its intra macroblocks and loop-filter calls through ffhip_h264_mbaff_flush() (ffmpeg_amd/csrc/h264_mbaff.hip), all on the device mirror"""
+    aus, ws = D.stream_mbaff_and_fields(seed)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == 4
+    make, read_back = _gpu_flush_factory()
+    got, st, counts = D.decode(aus, make_flush=make, read_back=read_back)
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
+    assert st["pictures"] == 6 == counts["pictures"] and st["mbaff_pictures"] == 2 == counts["mbaff_frames"], (st, counts)
+    for i, (a, b) in enumerate(zip(plain, got)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+
+
+@pytest.mark.parametrize("name", sorted(D.MBAFF_CASES))
+def test_mbaff_streams(name):
+    """Streams of MBAFF frames (see tests/test_h264_stream_cpu.py): I / P / B, every intra mode the MBAFF neighbourhood allows, field
+    macroblocks on reference fields, direct prediction, weights, the 8x8 transform, all deblocking modes — executed on the device"""
+    gen, kw, npic, dstats, cstats = D.MBAFF_CASES[name]
+    aus, ws = gen(**kw)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == npic
+    make, read_back = _gpu_flush_factory()
+    got, st, counts = D.decode(aus, make_flush=make, read_back=read_back)
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
+    assert st["pictures"] == npic == counts["pictures"] == st["mbaff_pictures"] == counts["mbaff_frames"], (st, counts)
+    for k in dstats:
+        assert st[k] > 0, (k, st)
+    for i, (a, b) in enumerate(zip(plain, got)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
 
 
 @pytest.mark.parametrize("name", sorted(D.ROUND6_CASES))

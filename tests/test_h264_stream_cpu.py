@@ -89,17 +89,66 @@ def test_a_picture_buffer_out_of_reach_of_the_base_is_refused():
 
 
 @pytest.mark.parametrize("seed", [7, 8, 9])
-def test_mbaff_frames_stay_on_the_c_path_as_whole_pictures(seed):
-    """MBAFF frames are what the picture layer does not take: ff_h264_hip_picture_supported() says so BEFORE the picture's first
-    macroblock, and the whole picture runs through the reference's functions on the C tables — in a stream whose other pictures (plain
-    field pictures here, predicting from the MBAFF frames and predicted from by them) are recorded.  The writer emits
-    mb_field_decoding_flag per macroblock pair (frame and field pairs mixed, skipped top macroblocks included)."""
+def test_mbaff_frames_between_field_pictures(seed):
+    """mb_adaptive_frame_field_flag = 1 (round 6): the stream's frames are MBAFF frames — frame and field macroblock pairs mixed, the writer
+    emits mb_field_decoding_flag per pair (skipped top macroblocks included) — between plain field pictures that predict from them and are
+    predicted from by them.  An MBAFF frame is recorded into FOUR objects (integration/avcodec_h264_picture_hip.c: the frame macroblocks,
+    the top- and the bottom-field macroblocks, the chains) and nothing stays on the C path."""
     aus, ws = D.stream_mbaff_and_fields(seed)
     plain, st0, _ = D.decode(aus)
     assert st0["damaged"] == 0 and len(plain) == 4
     rec, st, counts = D.decode(aus, make_flush=lambda base, size: D.cpu_flush(base))
     assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0, st
-    assert st["plain_pictures"] == 2 and st["pictures"] == 4 == counts["pictures"], (st, counts)
+    assert st["plain_pictures"] == 0 and st["pictures"] == 6 == counts["pictures"] and st["mbaff_pictures"] == 2 == counts["mbaff_frames"], (st, counts)
+    assert counts["mbaff_field_intra_mbs"] > 0 and counts["mbaff_calls_mbaff_member"] > 0 and counts["mbaff_calls_field_stride"] > 0, counts
+    for i, (a, b) in enumerate(zip(plain, rec)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+
+
+@pytest.mark.parametrize("name", sorted(D.MBAFF_CASES))
+def test_mbaff_streams(name):
+    """Streams of MBAFF frames only (8 bits, 4:2:0): I / P / B slices starting on macroblock pairs, every Intra16x16 and chroma prediction mode
+    the MBAFF neighbour derivation (6.4.12.2) allows, isolated Intra4x4 / Intra8x8 macroblocks with every mode, field macroblocks predicting
+    from reference FIELDS (ref_list[l][16 + 2 i + parity]) in and beyond the picture, direct prediction (spatial, temporal), explicit and
+    implicit weights, the 8x8 transform, disable_deblocking_filter_idc 0 / 1 / 2.  The decoder derives every macroblock's state; the four
+    objects' lists executed on the CPU (oracle/emul_h264_picture.cpp for the three inter objects, oracle/emul_h264_mbaff.cpp for the
+    chains) must give the plain decode, sample for sample."""
+    gen, kw, npic, dstats, cstats = D.MBAFF_CASES[name]
+    aus, ws = gen(**kw)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == npic
+    assert ws["i16"] > 0 and ws["i4"] + ws["i8"] > 0, ws
+    rec, st, counts = D.decode(aus, make_flush=lambda base, size: D.cpu_flush(base))
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
+    assert st["pictures"] == npic == counts["pictures"] == st["mbaff_pictures"] == counts["mbaff_frames"], (st, counts)
+    for k in dstats:
+        assert st[k] > 0, (k, st)
+    for k in cstats:
+        assert counts[k] > 0, (k, counts)
+    assert len(rec) == len(plain)
+    for i, (a, b) in enumerate(zip(plain, rec)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+    assert any(not np.array_equal(plain[0][0], f[0]) for f in plain[1:])
+
+
+def test_an_mbaff_frame_above_8_bits_stays_on_the_c_path():
+    """ff_h264_hip_picture_supported(): MBAFF is taken at 8 bits, 4:2:0 only — a 10-bit MBAFF frame is refused BEFORE its first macroblock and
+    runs through the reference's functions on the C tables as a whole, between recorded pictures."""
+    import h264_bitstream as B
+    p = B.Params(mb_w=6, mb_h=6, bit_depth=10, frame_mbs_only=0, mbaff=1, seed=17)
+    w = B.StreamWriter(p)
+    pics = [{"type": "I", "slices": [0], "deblock": [(0, 0, 0)]},
+            {"type": "P", "slices": [0], "deblock": [(0, 1, 0)], "field": "top", "num_ref": 2},
+            {"type": "P", "slices": [0], "deblock": [(0, 0, 0)], "field": "bottom", "second_field": True, "num_ref": 3},
+            {"type": "P", "slices": [0, 12], "deblock": [(0, 1, 1), (0, 0, 0)], "num_ref": 2}]
+    aus = w.stream(pics)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == 3
+    rec, st, counts = D.decode(aus, make_flush=lambda base, size: D.cpu_flush(base))
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0, st
+    assert st["plain_pictures"] == 2 and st["pictures"] == 2 == counts["pictures"] and st["mbaff_pictures"] == 0, (st, counts)
     for i, (a, b) in enumerate(zip(plain, rec)):
         for pl in range(3):
             assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
