@@ -305,6 +305,7 @@ MBAFF_CASES = {
     "mbaff_p_8x8_weighted": (stream_mbaff_p, dict(seed=42, t8x8=1, weighted_pred=1), 5, ("mbs_field", "mbs_8x8dct", "mbs_weighted"),
                              ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
     "mbaff_p_wide": (stream_mbaff_p, dict(seed=43, mb_w=11, mb_h=8, n=4), 4, ("mbs_field",), ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
+    "mbaff_p_cif": (stream_mbaff_p, dict(seed=48, mb_w=22, mb_h=18, n=3, t8x8=1), 3, ("mbs_field", "mbs_8x8dct"), ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
     "mbaff_b_spatial": (stream_b, dict(seed=44, mb_h=6, mbaff=1, direct_spatial=1), 9, ("mbs_field", "mbs_b", "mbs_bipred", "mbs_direct"),
                         ("mbaff_calls_mbaff_member",)),
     "mbaff_b_temporal_implicit": (stream_b, dict(seed=45, mb_h=6, mbaff=1, direct_spatial=0, weighted_bipred=2, slices=2), 9,

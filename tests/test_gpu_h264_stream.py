@@ -134,6 +134,22 @@ def test_mbaff_streams(name):
             assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
 
 
+def test_mbaff_1080i():
+    """1920 x 1088 MBAFF frames (120 x 68 macroblocks: 34 macroblock-pair rows, i.e. 34 waves walking 120 pairs each behind one another in the
+    intra and in the filter kernel — the dependency protocol under real concurrency): I + P, ~25 000 macroblocks, half of them field
+    macroblocks, ~200 000 recorded filter calls"""
+    aus, ws = D.stream_mbaff_p(seed=47, mb_w=120, mb_h=68, n=2)
+    plain, st0, _ = D.decode(aus, arena_bytes=192 << 20)
+    assert st0["damaged"] == 0 and len(plain) == 2
+    make, read_back = _gpu_flush_factory()
+    got, st, counts = D.decode(aus, make_flush=make, read_back=read_back, arena_bytes=192 << 20)
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
+    assert st["pictures"] == 2 == counts["pictures"] == st["mbaff_pictures"] and st["mbs_field"] > 4000, (st, counts)
+    for i, (a, b) in enumerate(zip(plain, got)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+
+
 @pytest.mark.parametrize("name", sorted(D.ROUND6_CASES))
 def test_b_weighted_8x8_transform_and_422_streams(name):
     """Round 6 (see tests/test_h264_stream_cpu.py): B slices with spatial / temporal direct prediction, explicit and implicit weights, the 8x8
