@@ -24,8 +24,8 @@
  *                          MBAFF frame: the left edge in two halves with their own bS / qp (filter_mb_mbaff_edgev), the top edge of a frame
  *                          macroblock under a field pair once per field at twice the line size, the _mbaff members that cover 8 lines —
  *                          are RECORDED AS CALLS (pointer, line size, alpha, beta, tc0 in the order issued) and executed in that order, one
- *                          wave per pair row, directly on the picture (dword accesses at device scope): pair x of row p after pair x + 1
- *                          of row p - 1.  Which edge is filtered how is the reference's decision, call by call.
+ *                          wave per pair row and plane, on an LDS tile of the pair and what its calls reach around it: pair x of row p
+ *                          after pair x + 1 of row p - 1.  Which edge is filtered how is the reference's decision, call by call.
  *
  * Both are the plain form (h264_c422.hip's protocol: a counter per row in the progress pool, device-scope loads and stores behind
  * agent fences); interlaced material is correctness first.  The CPU tier executes the same lists in oracle/emul_h264_mbaff.cpp.
@@ -335,75 +335,187 @@ __global__ __launch_bounds__(64) void k_h264_mbaff_intra(uint8_t *py, uint8_t *p
     }
 }
 
-/* One plane's recorded loop-filter calls, one wave per pair row.  chroma: the plane is Cb / Cr (8 x 8 macroblocks). */
-__global__ __launch_bounds__(64) void k_h264_mbaff_deblock(uint8_t *plane, ptrdiff_t stride, int mb_w, int npair_rows, const FFHipH264Edge *calls,
-                                                           const int32_t *pair_end, int *progress, int *fail)
+/* The recorded loop-filter calls of all three planes: blockIdx.x = the pair row, blockIdx.y = the plane; one wave each.
+ *
+ * A pair's calls touch its own 32 lines (chroma 16), up to 8 lines (chroma 4) of the pair above — a frame macroblock's top edge under a
+ * field pair is filtered once per field at twice the line size, three samples deep each (h264_loopfilter.c:520-545) — and 4 columns of
+ * the pair to the left: 40 x 20 bytes.  The wave fetches that tile ONCE (dwords at device scope), runs the pair's calls on it in LDS in
+ * the order recorded — a call costs an LDS round trip, not a memory one — and writes back the dwords that changed.  flush() places every call
+ * in its pair's tile on the host (one division per call there, none here).  1920 x 1088, ~110 000 calls per frame: 9.3 ms with a memory
+ * round trip per call and a launch per plane, 3.7 ms on the tile, 1.9 ms with a lane per column in the v_ members and the calls placed by
+ * the host (profiles/r06_h264_mbaff_v0 / _v1 / r06_h264_mbaff_kernel_stats.csv).  No other wave
+ * touches the tile meanwhile: row p - 1 is at pair x + 2 or beyond (columns >= 16 x + 28), row p + 1 at pair x - 2 or before. */
+/* a call as the kernel takes it (12 bytes, made by flush() from the recorded FFHipH264Edge and the plane's line size): where in the pair's
+ * tile, which member, its thresholds */
+struct MbaffDevCall {
+    uint16_t toff;       /* byte offset of pix in the tile */
+    uint8_t kf;          /* bits 0..2 FFHIP_H264_LF_* kind, bit 3 twice the line size, bit 4 the _mbaff member */
+    uint8_t alpha, beta;
+    uint8_t pad[3];
+    int8_t tc0[4];
+};
+static_assert(sizeof(MbaffDevCall) == 12, "MbaffDevCall is three dwords");
+
+struct MbaffLfArgs {
+    uint8_t *plane[3];
+    ptrdiff_t stride[3];
+    const MbaffDevCall *calls[3];
+    const int32_t *pair_end[3];
+    int mb_w, prow;
+};
+
+/* the tile of a pair on a plane: W x H samples of the pair, AB lines above, 4 columns to the left */
+#define MBAFF_TILE(cpl, W, H, AB, TP) const int W = (cpl) ? 8 : 16, H = (cpl) ? 16 : 32, AB = (cpl) ? 4 : 8, TP = W + 4
+
+__global__ __launch_bounds__(64) void k_h264_mbaff_deblock(MbaffLfArgs A, int *progress_all, int *fail)
 {
-    const int p = (int)blockIdx.x, lane = (int)threadIdx.x;
-    if (p >= npair_rows)
+    __shared__ __align__(16) uint8_t tile[40 * 20];
+    __shared__ __align__(16) uint32_t C[64 * 3];
+    const int p = (int)blockIdx.x, pl = (int)blockIdx.y, lane = (int)threadIdx.x;
+    MBAFF_TILE(pl != 0, W, H, AB, TP);
+    const int TD = TP / 4, TL = H + AB, ND = TL * TD; /* dwords per tile line, lines, dwords */
+    uint8_t *const plane = A.plane[pl];
+    const ptrdiff_t stride = A.stride[pl];
+    const MbaffDevCall *const calls = A.calls[pl];
+    const int32_t *const pair_end = A.pair_end[pl];
+    const int mb_w = A.mb_w;
+    int *const progress = progress_all + pl * A.prow;
+    if (!calls) /* nothing recorded on this plane */
         return;
     int at = p > 0 ? pair_end[(size_t)p * mb_w - 1] : 0;
     for (int x = 0; x < mb_w; x++) {
         const int end = pair_end[(size_t)p * mb_w + x];
+        if (at >= end) { /* a pair without calls: nothing of it is pending */
+            if (lane == 0)
+                __hip_atomic_store(&progress[p], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        /* the pair's first calls are on their way while the row above is awaited */
+        int n = min(64, end - at);
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
+        if (lane < n) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(calls + at + lane);
+            c0 = src[0]; c1 = src[1]; c2 = src[2];
+        }
         if (p > 0 && !mb_wait(&progress[p - 1], min(x + 2, mb_w), fail, lane))
             return;
-        for (; at < end; at++) {
-            const FFHipH264Edge e = calls[at];
-            const int kind = e.kind & 7;
-            const bool chroma = kind & 2, intra = kind & 4, hfilt = kind & 1; /* h_ members filter across a VERTICAL edge: a line = a row */
-            const bool mbaff = e.pad & 2;
-            const ptrdiff_t st = (e.pad & 1) ? 2 * stride : stride;
-            const int cls = (chroma ? 1 : 0) + (intra ? 2 : 0);
-            uint8_t *pix = plane + e.offset;
-            if (hfilt) {
-                /* lines = rows: luma 16 (tc0 per 4), chroma 8 (per 2); the _mbaff members: half of each (h264dsp_template.c:127-133,262-272) */
-                const int nlines = (chroma ? 8 : 16) >> (mbaff ? 1 : 0), per = (chroma ? 2 : 4) >> (mbaff ? 1 : 0);
-                if (lane < nlines) {
-                    uint8_t *l = pix + (ptrdiff_t)lane * st - 4;
-                    const uint32_t a = mb_ld(l), b = mb_ld(l + 4);
-                    LfLine v = { (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), (int)(a >> 24),
-                                 (int)(b & 255), (int)((b >> 8) & 255), (int)((b >> 16) & 255), (int)(b >> 24) };
-                    const int m = lf_line(v, cls, e.alpha, e.beta, intra ? 0 : e.tc0[lane / per]);
-                    if (m & 7)
-                        mb_st(l, (uint32_t)v.p3 | (uint32_t)v.p2 << 8 | (uint32_t)v.p1 << 16 | (uint32_t)v.p0 << 24);
-                    if (m & 56)
-                        mb_st(l + 4, (uint32_t)v.q0 | (uint32_t)v.q1 << 8 | (uint32_t)v.q2 << 16 | (uint32_t)v.q3 << 24);
-                }
-            } else {
-                /* lines = columns: luma 16 (tc0 per 4), chroma 8 (per 2): a lane takes four adjacent columns, eight rows of dwords */
-                const int nq = chroma ? 2 : 4, per = chroma ? 2 : 4;
-                if (lane < nq) {
-                    uint32_t w[8];
+        const int line0 = H * p - AB, col0 = W * x - 4;
+        uint32_t orig[4];
+        bool have[4];
 #pragma unroll
-                    for (int r = 0; r < 8; r++) /* (rows -4 and -3 feed the strong luma filter only: never read above the plane) */
-                        w[r] = (ptrdiff_t)e.offset + (ptrdiff_t)(r - 4) * st >= 0 ? mb_ld(pix + (ptrdiff_t)(r - 4) * st + 4 * lane) : 0u;
-                    int changed = 0;
+        for (int k = 0; k < 4; k++) {
+            const int d = lane + 64 * k, tl = d / TD, tc = d - tl * TD;
+            have[k] = d < ND && line0 + tl >= 0 && col0 + 4 * tc >= 0;
+            orig[k] = 0;
+            if (have[k])
+                orig[k] = mb_ld(plane + (ptrdiff_t)(line0 + tl) * stride + col0 + 4 * tc);
+        }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        LfLine v;
-                        const int sh = 8 * c;
-                        v.p3 = (w[0] >> sh) & 255; v.p2 = (w[1] >> sh) & 255; v.p1 = (w[2] >> sh) & 255; v.p0 = (w[3] >> sh) & 255;
-                        v.q0 = (w[4] >> sh) & 255; v.q1 = (w[5] >> sh) & 255; v.q2 = (w[6] >> sh) & 255; v.q3 = (w[7] >> sh) & 255;
-                        const int m = lf_line(v, cls, e.alpha, e.beta, intra ? 0 : e.tc0[(4 * lane + c) / per]);
-                        changed |= m;
-                        const uint32_t keep = ~(255u << sh);
-                        if (m & 1)  w[1] = (w[1] & keep) | (uint32_t)v.p2 << sh;
-                        if (m & 2)  w[2] = (w[2] & keep) | (uint32_t)v.p1 << sh;
-                        if (m & 4)  w[3] = (w[3] & keep) | (uint32_t)v.p0 << sh;
-                        if (m & 8)  w[4] = (w[4] & keep) | (uint32_t)v.q0 << sh;
-                        if (m & 16) w[5] = (w[5] & keep) | (uint32_t)v.q1 << sh;
-                        if (m & 32) w[6] = (w[6] & keep) | (uint32_t)v.q2 << sh;
-                    }
-#pragma unroll
-                    for (int r = 1; r < 7; r++)
-                        if (changed & (1 << (r - 1)))
-                            mb_st(pix + (ptrdiff_t)(r - 4) * st + 4 * lane, w[r]);
-                }
+        for (int k = 0; k < 4; k++)
+            if (lane + 64 * k < ND)
+                reinterpret_cast<uint32_t *>(tile)[lane + 64 * k] = orig[k];
+        for (;;) {
+            if (lane < n) {
+                C[3 * lane] = c0; C[3 * lane + 1] = c1; C[3 * lane + 2] = c2;
             }
-            mb_drain(); /* the next call of this wave reads what this one wrote, through other lanes */
+            mb_wave_sync();
+            for (int i = 0; i < n; i++) {
+                const uint32_t w0 = C[3 * i], w1 = C[3 * i + 1];
+                const int toff = (int)(w0 & 0xFFFF), kf = (int)(w0 >> 16) & 255, alpha = (int)(w0 >> 24), beta = (int)(w1 & 255);
+                const bool chroma = kf & 2, intra = kf & 4, hfilt = kf & 1; /* h_ members filter across a VERTICAL edge: a line = a row */
+                const int half = (kf >> 4) & 1;                             /* the _mbaff members: half the lines, half as many per tc0 entry */
+                const int step = (kf & 8) ? 2 * TP : TP;                    /* tile bytes from a line of the call to the next */
+                const int cls = (chroma ? 1 : 0) + (intra ? 2 : 0);
+                const int8_t *tc0 = reinterpret_cast<const int8_t *>(&C[3 * i + 2]);
+                if (hfilt) {
+                    /* lines = rows: luma 16 (tc0 per 4), chroma 8 (per 2); _mbaff: 8 (per 2), 4 (per 1) (h264dsp_template.c:127-133,262-272) */
+                    const int nlines = (chroma ? 8 : 16) >> half, per = (chroma ? 2 : 4) >> half;
+                    if (lane < nlines) {
+                        uint8_t *l = tile + toff + lane * step - 4;
+                        const uint32_t a = *reinterpret_cast<const uint32_t *>(l), b = *reinterpret_cast<const uint32_t *>(l + 4);
+                        LfLine v = { (int)(a & 255), (int)((a >> 8) & 255), (int)((a >> 16) & 255), (int)(a >> 24),
+                                     (int)(b & 255), (int)((b >> 8) & 255), (int)((b >> 16) & 255), (int)(b >> 24) };
+                        const int m = lf_line(v, cls, alpha, beta, intra ? 0 : tc0[lane / per]);
+                        if (m & 7)
+                            *reinterpret_cast<uint32_t *>(l) = (uint32_t)v.p3 | (uint32_t)v.p2 << 8 | (uint32_t)v.p1 << 16 | (uint32_t)v.p0 << 24;
+                        if (m & 56)
+                            *reinterpret_cast<uint32_t *>(l + 4) = (uint32_t)v.q0 | (uint32_t)v.q1 << 8 | (uint32_t)v.q2 << 16 | (uint32_t)v.q3 << 24;
+                    }
+                } else {
+                    /* lines = columns, a lane each: luma 16 (tc0 per 4; rows -4 .. 3: the strong filter's p3 / q3), chroma 8 (per 2; rows -2 .. 1) */
+                    const int ncols = chroma ? 8 : 16, per = chroma ? 2 : 4;
+                    if (lane < ncols) {
+                        uint8_t *c = tile + toff + lane;
+                        LfLine v;
+                        v.p1 = c[-2 * step]; v.p0 = c[-step]; v.q0 = c[0]; v.q1 = c[step];
+                        v.p3 = v.p2 = v.q2 = v.q3 = 0;
+                        if (!chroma) {
+                            v.p3 = c[-4 * step]; v.p2 = c[-3 * step]; v.q2 = c[2 * step]; v.q3 = c[3 * step];
+                        }
+                        const int m = lf_line(v, cls, alpha, beta, intra ? 0 : tc0[lane / per]);
+                        if (m & 1)  c[-3 * step] = (uint8_t)v.p2;
+                        if (m & 2)  c[-2 * step] = (uint8_t)v.p1;
+                        if (m & 4)  c[-step] = (uint8_t)v.p0;
+                        if (m & 8)  c[0] = (uint8_t)v.q0;
+                        if (m & 16) c[step] = (uint8_t)v.q1;
+                        if (m & 32) c[2 * step] = (uint8_t)v.q2;
+                    }
+                }
+                mb_wave_sync(); /* the next call reads what this one wrote, through other lanes */
+            }
+            at += n;
+            if (at >= end)
+                break;
+            n = min(64, end - at);
+            if (lane < n) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(calls + at + lane);
+                c0 = src[0]; c1 = src[1]; c2 = src[2];
+            }
+        }
+        /* the dwords that changed, back into the picture */
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int d = lane + 64 * k, tl = d / TD, tc = d - tl * TD;
+            if (have[k]) {
+                const uint32_t cur = reinterpret_cast<const uint32_t *>(tile)[d];
+                if (cur != orig[k])
+                    mb_st(plane + (ptrdiff_t)(line0 + tl) * stride + col0 + 4 * tc, cur);
+            }
         }
         mb_publish(&progress[p], x + 1, lane);
     }
+}
+
+/* FFHipH264Edge -> MbaffDevCall for plane pl at line size `stride`: the call of pair (x, p) placed in that pair's tile.  false: the call
+ * reaches outside it (not a call ff_h264_filter_mb() issues for a macroblock of that pair). */
+static bool mbaff_place_call(const FFHipH264Edge &e, int pl, int stride, int x, int p, MbaffDevCall *out)
+{
+    MBAFF_TILE(pl != 0, W, H, AB, TP);
+    const int TL = H + AB;
+    const int kind = e.kind & 7, chroma = (kind & 2) != 0, hfilt = kind & 1, half = (e.pad & FFHIP_H264_LF_CALL_MBAFF) != 0;
+    const int stl = (e.pad & FFHIP_H264_LF_CALL_FIELD) ? 2 : 1;
+    if (e.offset < 0 || chroma != (pl != 0))
+        return false;
+    const int line = e.offset / stride, col = e.offset - line * stride;
+    const int tl = line - (H * p - AB), tc = col - (W * x - 4);
+    if (tc < 4 || (tc & 3))
+        return false;
+    if (hfilt) {
+        const int nlines = (chroma ? 8 : 16) >> half;
+        if (tl < 0 || tl + (nlines - 1) * stl >= TL || tc >= TP)
+            return false;
+    } else {
+        const int up = chroma ? 2 : 4, down = chroma ? 1 : 3, ncols = chroma ? 8 : 16;
+        if (half || tl - up * stl < 0 || tl + down * stl >= TL || tc + ncols > TP)
+            return false;
+    }
+    out->toff = (uint16_t)(tl * TP + tc);
+    out->kf = (uint8_t)(kind | (stl == 2 ? 8 : 0) | (half ? 16 : 0));
+    out->alpha = e.alpha;
+    out->beta = e.beta;
+    out->pad[0] = out->pad[1] = out->pad[2] = 0;
+    memcpy(out->tc0, e.tc0, 4);
+    return true;
 }
 
 extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], const int stride[3], void *stream_)
@@ -445,13 +557,26 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         }
         m->dev_sz = total;
     }
+    /* the calls as the kernel takes them: placed in their pair's tile at this line size */
+    std::vector<MbaffDevCall> dcalls[3];
+    for (int pl = 0; pl < 3; pl++) {
+        dcalls[pl].resize(m->calls[pl].size());
+        size_t at = 0;
+        for (int q = 0; q < npairs; q++)
+            for (; at < (size_t)m->pair_end[pl][(size_t)q]; at++)
+                if (!mbaff_place_call(m->calls[pl][at], pl, stride[pl], q % m->mb_w, q / m->mb_w, &dcalls[pl][at])) {
+                    ffhip_set_error("ffhip_h264_mbaff_flush: plane %d call %zu (offset %d, kind %d, flags %d) lies outside macroblock pair (%d, %d)", pl, at,
+                                    m->calls[pl][at].offset, m->calls[pl][at].kind, m->calls[pl][at].pad, q % m->mb_w, q / m->mb_w);
+                    return m->last_status = FFHIP_EINVAL;
+                }
+    }
     uint8_t *b = (uint8_t *)m->dev;
     /* (blocking copies: the lists are small, and the host vectors may be cleared by the next begin() as soon as this call returns) */
     auto up = [&](int i, const void *src, size_t bytes) -> bool { return !bytes || hipMemcpy(b + off[i], src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
     bool ok = up(0, m->recs.data(), m->recs.size() * sizeof(FFHipH264IntraMB)) && up(1, m->geo.data(), m->geo.size() * 4) &&
               up(2, m->coefs.data(), m->coefs.size() * 2) && up(3, m->intra_row.data(), m->intra_row.size() * 4);
     for (int pl = 0; pl < 3 && ok; pl++)
-        ok = up(4 + 2 * pl, m->calls[pl].data(), m->calls[pl].size() * sizeof(FFHipH264Edge)) && up(5 + 2 * pl, m->pair_end[pl].data(), (size_t)npairs * 4);
+        ok = up(4 + 2 * pl, dcalls[pl].data(), dcalls[pl].size() * sizeof(MbaffDevCall)) && up(5 + 2 * pl, m->pair_end[pl].data(), (size_t)npairs * 4);
     if (!ok) {
         (void)hipGetLastError();
         ffhip_set_error("ffhip_h264_mbaff_flush: uploading the lists failed");
@@ -475,16 +600,21 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         if (r2 < 0)
             return m->last_status = r2;
     }
-    for (int pl = 0; pl < 3; pl++) {
-        if (m->calls[pl].empty())
-            continue;
+    if (!m->calls[0].empty() || !m->calls[1].empty() || !m->calls[2].empty()) {
+        MbaffLfArgs A;
+        for (int pl = 0; pl < 3; pl++) {
+            A.plane[pl] = dst[pl];
+            A.stride[pl] = stride[pl];
+            A.calls[pl] = m->calls[pl].empty() ? nullptr : reinterpret_cast<const MbaffDevCall *>(b + off[4 + 2 * pl]);
+            A.pair_end[pl] = reinterpret_cast<const int32_t *>(b + off[5 + 2 * pl]);
+        }
+        A.mb_w = m->mb_w;
+        A.prow = prow;
         FFHipProgressSlot ps;
-        rc = ffhip_progress_acquire(prow, stream, &ps);
+        rc = ffhip_progress_acquire(3 * prow, stream, &ps);
         if (rc < 0)
             return m->last_status = rc;
-        hipLaunchKernelGGL(k_h264_mbaff_deblock, dim3(prow), dim3(64), 0, stream, dst[pl], (ptrdiff_t)stride[pl], m->mb_w, prow,
-                           reinterpret_cast<const FFHipH264Edge *>(b + off[4 + 2 * pl]), reinterpret_cast<const int32_t *>(b + off[5 + 2 * pl]), ps.prog,
-                           ps.fail);
+        hipLaunchKernelGGL(k_h264_mbaff_deblock, dim3(prow, 3), dim3(64), 0, stream, A, ps.prog, ps.fail);
         const hipError_t e = hipGetLastError();
         const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
         if (e != hipSuccess) {
