@@ -51,10 +51,20 @@ struct FFHipH264Mbaff {
     std::vector<FFHipH264Edge> calls[3];         /* per plane: the loop-filter calls in the order issued (pad = flags: 1 doubled line size, 2 _mbaff member) */
     std::vector<int32_t> pair_end[3];            /* per plane and pair (row-major): one past its last call */
     int last_pair[3];                            /* the pair whose calls are being appended (calls must arrive pair by pair, in order) */
-    void *dev = nullptr;
+    void *dev = nullptr;                         /* the lists as the last flush uploaded them */
     size_t dev_sz = 0;
+    hipEvent_t done = nullptr;                   /* behind the last flush's launches: `dev` is theirs until it has passed */
+    bool pending = false;
     int last_status = 0;
 };
+
+/* the launches of the last flush have read their lists: `dev` may be written (or freed) again */
+static void mbaff_settle(FFHipH264Mbaff *m)
+{
+    if (m->pending && m->done)
+        (void)hipEventSynchronize(m->done);
+    m->pending = false;
+}
 
 extern "C" int ffhip_h264_mbaff_create(FFHipH264Mbaff **m, int mb_w, int mb_h)
 {
@@ -81,8 +91,14 @@ extern "C" void ffhip_h264_mbaff_free(FFHipH264Mbaff **m)
 {
     if (!m || !*m)
         return;
-    if ((*m)->dev)
-        (void)hipFree((*m)->dev);
+    {
+        FFHipDeviceGuard dg((*m)->device);
+        mbaff_settle(*m);
+        if ((*m)->done)
+            (void)hipEventDestroy((*m)->done);
+        if ((*m)->dev)
+            (void)hipFree((*m)->dev);
+    }
     delete *m;
     *m = nullptr;
 }
@@ -532,31 +548,9 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         ffhip_set_error("ffhip_h264_mbaff_flush: Cb and Cr share a line size");
         return FFHIP_EINVAL;
     }
+    FFHipDeviceGuard dg(m->device);
     mbaff_finish(m);
     const int prow = m->mb_h / 2, npairs = m->mb_w * prow;
-    /* one device blob: records, geo, coefs, intra_row, then per plane calls + pair_end */
-    size_t off[12], total = 0;
-    auto place = [&](int i, size_t bytes) { off[i] = total; total += (bytes + 255) & ~(size_t)255; };
-    place(0, m->recs.size() * sizeof(FFHipH264IntraMB));
-    place(1, m->geo.size() * 4);
-    place(2, m->coefs.size() * 2 + 1024); /* (the last run is read in whole dwords) */
-    place(3, m->intra_row.size() * 4);
-    for (int pl = 0; pl < 3; pl++) {
-        place(4 + 2 * pl, m->calls[pl].size() * sizeof(FFHipH264Edge));
-        place(5 + 2 * pl, (size_t)npairs * 4);
-    }
-    if (total > m->dev_sz) {
-        if (m->dev)
-            (void)hipFree(m->dev);
-        m->dev = nullptr;
-        m->dev_sz = 0;
-        if (hipMalloc(&m->dev, total) != hipSuccess) {
-            (void)hipGetLastError();
-            ffhip_set_error("ffhip_h264_mbaff_flush: hipMalloc(%zu) failed", total);
-            return FFHIP_ENOMEM;
-        }
-        m->dev_sz = total;
-    }
     /* the calls as the kernel takes them: placed in their pair's tile at this line size */
     std::vector<MbaffDevCall> dcalls[3];
     for (int pl = 0; pl < 3; pl++) {
@@ -570,6 +564,37 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
                     return m->last_status = FFHIP_EINVAL;
                 }
     }
+    /* one device blob: records, geo, coefs, intra_row, then per plane calls + pair_end */
+    size_t off[12], total = 0;
+    auto place = [&](int i, size_t bytes) { off[i] = total; total += (bytes + 255) & ~(size_t)255; };
+    place(0, m->recs.size() * sizeof(FFHipH264IntraMB));
+    place(1, m->geo.size() * 4);
+    place(2, m->coefs.size() * 2 + 1024); /* (the last run is read in whole dwords) */
+    place(3, m->intra_row.size() * 4);
+    for (int pl = 0; pl < 3; pl++) {
+        place(4 + 2 * pl, m->calls[pl].size() * sizeof(FFHipH264Edge));
+        place(5 + 2 * pl, (size_t)npairs * 4);
+    }
+    if (total > m->dev_sz) {
+        mbaff_settle(m);
+        if (m->dev)
+            (void)hipFree(m->dev);
+        m->dev = nullptr;
+        m->dev_sz = 0;
+        if (hipMalloc(&m->dev, total) != hipSuccess) {
+            (void)hipGetLastError();
+            ffhip_set_error("ffhip_h264_mbaff_flush: hipMalloc(%zu) failed", total);
+            return FFHIP_ENOMEM;
+        }
+        m->dev_sz = total;
+    }
+    mbaff_settle(m); /* a flush still in flight reads the lists this one is about to overwrite */
+    if (!m->done && hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        m->done = nullptr;
+        ffhip_set_error("ffhip_h264_mbaff_flush: hipEventCreate failed");
+        return m->last_status = FFHIP_EIO;
+    }
     uint8_t *b = (uint8_t *)m->dev;
     /* (blocking copies: the lists are small, and the host vectors may be cleared by the next begin() as soon as this call returns) */
     auto up = [&](int i, const void *src, size_t bytes) -> bool { return !bytes || hipMemcpy(b + off[i], src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
@@ -582,12 +607,22 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         ffhip_set_error("ffhip_h264_mbaff_flush: uploading the lists failed");
         return m->last_status = FFHIP_EIO;
     }
+    /* whatever was launched reads `dev` until this event has passed */
+    auto leave = [&](int rc) {
+        if (hipEventRecord(m->done, stream) == hipSuccess) {
+            m->pending = true;
+        } else {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(stream);
+        }
+        return m->last_status = rc;
+    };
     int rc = 0;
     if (!m->recs.empty()) {
         FFHipProgressSlot ps;
         rc = ffhip_progress_acquire(prow, stream, &ps);
         if (rc < 0)
-            return m->last_status = rc;
+            return leave(rc);
         hipLaunchKernelGGL(k_h264_mbaff_intra, dim3(prow), dim3(64), 0, stream, dst[0], dst[1], dst[2], (ptrdiff_t)stride[0], (ptrdiff_t)stride[1], m->mb_w,
                            m->mb_h, reinterpret_cast<const FFHipH264IntraMB *>(b + off[0]), reinterpret_cast<const uint32_t *>(b + off[1]),
                            reinterpret_cast<const int32_t *>(b + off[3]), reinterpret_cast<const int16_t *>(b + off[2]), ps.prog, ps.fail);
@@ -595,10 +630,10 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
         if (e != hipSuccess) {
             ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
-            return m->last_status = FFHIP_EIO;
+            return leave(FFHIP_EIO);
         }
         if (r2 < 0)
-            return m->last_status = r2;
+            return leave(r2);
     }
     if (!m->calls[0].empty() || !m->calls[1].empty() || !m->calls[2].empty()) {
         MbaffLfArgs A;
@@ -613,16 +648,16 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         FFHipProgressSlot ps;
         rc = ffhip_progress_acquire(3 * prow, stream, &ps);
         if (rc < 0)
-            return m->last_status = rc;
+            return leave(rc);
         hipLaunchKernelGGL(k_h264_mbaff_deblock, dim3(prow, 3), dim3(64), 0, stream, A, ps.prog, ps.fail);
         const hipError_t e = hipGetLastError();
         const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
         if (e != hipSuccess) {
             ffhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
-            return m->last_status = FFHIP_EIO;
+            return leave(FFHIP_EIO);
         }
         if (r2 < 0)
-            return m->last_status = r2;
+            return leave(r2);
     }
-    return m->last_status = 0;
+    return leave(0);
 }
