@@ -16,3 +16,6 @@ cp gpurun_out/1_prof.log gpurun_out/headline_bench.log 2>/dev/null
 python tools/headline_check.py gpurun_out/headline_kernel_stats.csv gpurun_out/headline_bench.log | tee gpurun_out/headline_check.txt
 # the headline kernel's instruction mix and traffic (three PMC passes over six 256-frame launches)
 STEP_TIMEOUT=600 bash tools/gpu.sh "pmc up2 bench.py --pmc-child" | tail -16
+# MBAFF frames in the picture layer: a 1920 x 1088 stream through the whole decoder, the two chains timed and traced
+STEP_TIMEOUT=600 bash tools/gpu.sh "py tools/bench_h264_mbaff.py 4" "prof h264_mbaff tools/bench_h264_mbaff.py 4" | tail -8
+cp gpurun_out/1_py.log gpurun_out/h264_mbaff_bench.log 2>/dev/null
