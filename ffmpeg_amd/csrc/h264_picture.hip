@@ -51,8 +51,8 @@ struct FFHipH264Picture {
     std::vector<FFHipQpelBlock> qpel[3][3];       /* luma-table MC: plane (4:2:0: plane 0 only) x stage */
     std::vector<FFHipChromaBlock> cmc[2][3];      /* chroma MC: plane (Cb, Cr) x stage     */
     std::vector<FFHipWeightBlock> wt[3];          /* weight / biweight per plane           */
-    std::vector<int32_t> idct_off[3][4];          /* per plane x FFHIP_H264_IDCT* kind     */
-    std::vector<int16_t> idct_coef[3][4];
+    std::vector<int32_t> idct_off[3][6];          /* per plane x FFHIP_H264_IDCT* kind (4, 5: add_pixels4 / 8_clear, the lossless bypass) */
+    std::vector<int16_t> idct_coef[3][6];
     /* intra macroblocks in recording order and their packed coefficient runs.  4:2:0: [0] holds whole macroblocks; 4:4:4: [pl] holds
      * plane pl's share of every intra macroblock as a luma-only record (the wavefront runs once per plane, side by side) */
     std::vector<FFHipH264IntraMB> intra[3];
@@ -126,7 +126,7 @@ extern "C" void ffhip_h264_picture_begin(FFHipH264Picture *p)
         p->intra[pl].clear();
         p->intra_coef[pl].clear();
         p->wt[pl].clear();
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 6; k++) {
             p->idct_off[pl][k].clear();
             p->idct_coef[pl][k].clear();
         }
@@ -238,11 +238,11 @@ extern "C" int ffhip_h264_picture_weight(FFHipH264Picture *p, int plane, const F
 
 extern "C" int ffhip_h264_picture_idct_add(FFHipH264Picture *p, int plane, int kind, int32_t dst_offset, int16_t *block)
 {
-    if (!p || !block || plane < 0 || plane > 2 || kind < FFHIP_H264_IDCT4 || kind > FFHIP_H264_IDCT8_DC)
+    if (!p || !block || plane < 0 || plane > 2 || kind < FFHIP_H264_IDCT4 || kind > FFHIP_H264_ADD_PIXELS8_CLEAR)
         return FFHIP_EINVAL;
     /* int16 units: above 8 bits a coefficient is an int32 (dctcoef), the caller's `block` is the decoder's sl->mb as it stands */
     const int wide = p->bd > 8 ? 2 : 1;
-    const int ncoef = ((kind == FFHIP_H264_IDCT8 || kind == FFHIP_H264_IDCT8_DC) ? 64 : 16) * wide;
+    const int ncoef = ((kind == FFHIP_H264_IDCT8 || kind == FFHIP_H264_IDCT8_DC || kind == FFHIP_H264_ADD_PIXELS8_CLEAR) ? 64 : 16) * wide;
     p->idct_off[plane][kind].push_back(dst_offset);
     std::vector<int16_t> &c = p->idct_coef[plane][kind];
     c.insert(c.end(), block, block + ncoef);
@@ -334,7 +334,12 @@ static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_
     FFHipH264IntraMB &R = *rec;
     CF *mb = reinterpret_cast<CF *>(mb_);
     const CF *mb_luma_dc = reinterpret_cast<const CF *>(mb_luma_dc_);
-    R.flags = 0;
+    const bool bypass = R.flags & FFHIP_H264_INTRA_BYPASS, dpcm = bypass && (R.flags & FFHIP_H264_INTRA_DPCM);
+    if (bypass && W != 1) {
+        ffhip_set_error("ffhip_h264_intra_pack: the transform bypass is taken at 8 bits only");
+        return FFHIP_ENOSYS;
+    }
+    R.flags = bypass ? FFHIP_H264_INTRA_BYPASS : 0;
     memset(R.pad, 0, sizeof(R.pad));
     memset(R.nnz, 0, sizeof(R.nnz));
     memset(R.luma_dc, 0, sizeof(R.luma_dc));
@@ -372,6 +377,99 @@ static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_
     }
     if (!nnzc || !mb)
         return FFHIP_EINVAL;
+    if (bypass) {
+        /* hl_decode_mb() with transform_bypass (h264_mb.c:614-770, h264_mb_template.c:190-213): the blocks hold residual SAMPLES (row-major:
+         * the decoder reads them with the untransposed scans, h264_slice.c:770-777), added by add_pixels4 / 8_clear to the prediction, or —
+         * _DPCM, vertical / horizontal prediction — by the pred*_add forms, which add each residual to the sample before it along the
+         * direction: here the residuals of such a block become their running sums along the direction (modulo 2^16; the sample keeps its
+         * low 8 bits), after which they are residuals of the plain prediction.  A block that travels is marked nnz = 16: "add it whole". */
+        auto sum = [](CF a, CF b) { return (CF)(uint16_t)((uint32_t)(uint16_t)a + (uint32_t)(uint16_t)b); };
+        /* running sums over an n x n region made of 4x4 blocks (base[blk(x4, y4) * 16 + x + 4 y]) or one 8x8 block; vertical: down the columns */
+        auto chain = [&](CF *base, int n, bool vertical, auto blk_at) {
+            for (int a = 0; a < n; a++) {       /* the line across the direction */
+                CF run = 0;
+                for (int t = 0; t < n; t++) {   /* along the direction */
+                    const int x = vertical ? a : t, y = vertical ? t : a;
+                    CF *c = blk_at(base, x, y);
+                    run = sum(run, *c);
+                    *c = run;
+                }
+            }
+        };
+        auto any = [](const CF *b, int cnt) {
+            for (int i = 0; i < cnt; i++)
+                if (b[i])
+                    return true;
+            return false;
+        };
+        auto take_all = [&](CF *b, int cnt) {
+            memcpy(coefs + n, b, sizeof(CF) * cnt);
+            n += cnt * W;
+            memset(b, 0, sizeof(CF) * cnt);
+        };
+        auto in4 = [](CF *base, int x, int y) { /* luma 4x4 blocks in decoding order: block i at (imb_bx(i), imb_by(i)) */
+            const int i = ((x >> 2) & 1) | ((y >> 2) & 1) << 1 | (x >> 3) << 2 | (y >> 3) << 3;
+            return base + 16 * i + (x & 3) + 4 * (y & 3);
+        };
+        if (R.type == FFHIP_H264_INTRA_16x16) {
+            if (nnzc[0]) { /* the DC block's samples go to their blocks' first positions (dc_mapping, h264_mb.c:713-723) */
+                static const uint8_t dc_mapping[16] = { 0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15 };
+                if (!mb_luma_dc)
+                    return FFHIP_EINVAL;
+                for (int i = 0; i < 16; i++)
+                    mb[16 * dc_mapping[i]] = mb_luma_dc[i];
+            }
+            const bool ch = dpcm && (R.pred16 == 2 /* VERT_PRED8x8 */ || R.pred16 == 1 /* HOR_PRED8x8 */);
+            if (ch) /* pred16x16_{vertical,horizontal}_add: the sixteen blocks' pred4x4_*_add run into one another (h264pred_template.c:1305-1330) */
+                chain(mb, 16, R.pred16 == 2, in4);
+            for (int i = 0; i < 16; i++)
+                if (ch ? any(mb + 16 * i, 16) : (nnzc[scan8_luma(i)] || mb[16 * i])) {
+                    R.nnz[i] = 16;
+                    R.blocks |= 1u << i;
+                    take_all(mb + 16 * i, 16);
+                }
+        } else if (R.type == FFHIP_H264_INTRA_4x4) {
+            for (int i = 0; i < 16; i++) {
+                const bool ch = dpcm && R.pred4[i] <= 1; /* VERT_PRED 0, HOR_PRED 1: pred4x4_*_add, whatever the count says */
+                if (ch)
+                    chain(mb + 16 * i, 4, R.pred4[i] == 0, [](CF *b, int x, int y) { return b + x + 4 * y; });
+                if (ch ? any(mb + 16 * i, 16) : nnzc[scan8_luma(i)] != 0) {
+                    R.nnz[i] = 16;
+                    R.blocks |= 1u << i;
+                    take_all(mb + 16 * i, 16);
+                }
+            }
+        } else {
+            for (int i = 0; i < 16; i += 4) {
+                const bool ch = dpcm && R.pred4[i] <= 1; /* pred8x8l_*_filter_add: the filtered edge sample plus the running sum */
+                if (ch)
+                    chain(mb + 16 * i, 8, R.pred4[i] == 0, [](CF *b, int x, int y) { return b + x + 8 * y; });
+                if (ch ? any(mb + 16 * i, 64) : nnzc[scan8_luma(i)] != 0) {
+                    R.nnz[i] = 16;
+                    R.blocks |= 1u << i;
+                    take_all(mb + 16 * i, 64);
+                }
+            }
+        }
+        if (luma_only)
+            R.cbp &= 0x0f;
+        if (R.cbp & 0x30) { /* (h264_mb_template.c:193-213: no DC transform; pred8x8_*_add chains the plane's four blocks) */
+            const bool ch = dpcm && (R.chroma_pred == 2 || R.chroma_pred == 1);
+            for (int pl = 1; pl < 3; pl++) {
+                CF *base = mb + 256 * pl;
+                if (ch)
+                    chain(base, 8, R.chroma_pred == 2, [](CF *b, int x, int y) { return b + 16 * ((x >> 2) + 2 * (y >> 2)) + (x & 3) + 4 * (y & 3); });
+                for (int k = 0; k < 4; k++)
+                    if (ch ? any(base + 16 * k, 16) : (nnzc[scan8_chroma(pl, k)] || base[16 * k])) {
+                        R.nnz[16 + 4 * (pl - 1) + k] = 16;
+                        R.blocks |= 1u << (16 + 4 * (pl - 1) + k);
+                        take_all(base + 16 * k, 16);
+                    }
+            }
+        }
+        *ncoefs = n;
+        return 0;
+    }
     /* a block travels when the dsp function hl_decode_mb() would call on it reads it; the caller's copy is consumed the way that
      * function consumes it: zeroed by idct_add / idct8_add (h264idct_template.c:66,142), [0] = 0 by the dc forms (:150,166) */
     auto take = [&](CF *b, int cnt, bool full) {
@@ -550,6 +648,10 @@ extern "C" int ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264I
     if (!p || !d || d->mb_x < 0 || d->mb_x >= p->mb_w || d->mb_y < 0 || d->mb_y >= p->mb_h)
         return FFHIP_EINVAL;
     const int wide = p->bd > 8 ? 2 : 1; /* int16 entries per dctcoef */
+    if ((d->flags & FFHIP_H264_INTRA_BYPASS) && (p->cfmt == 2 || p->bd != 8)) {
+        ffhip_set_error("ffhip_h264_picture_intra_mb: the transform bypass is taken at 8 bits, 4:2:0 and 4:4:4");
+        return FFHIP_ENOSYS;
+    }
     if (p->cfmt == 2) {
         /* 4:2:2: the luma as a luma-only record of the wavefront, the two 8 x 16 chroma planes as a record of their own */
         FFHipH264IntraMB R = *d;
@@ -649,6 +751,11 @@ extern "C" int ffhip_h264_picture_lists(const FFHipH264Picture *p, FFHipH264Pict
             out->idct_off[pl][k] = p->idct_off[pl][k].data();
             out->idct_coef[pl][k] = p->idct_coef[pl][k].data();
             out->nidct[pl][k] = (int)p->idct_off[pl][k].size();
+        }
+        for (int k = 0; k < 2; k++) {
+            out->addpx_off[pl][k] = p->idct_off[pl][4 + k].data();
+            out->addpx_coef[pl][k] = p->idct_coef[pl][4 + k].data();
+            out->naddpx[pl][k] = (int)p->idct_off[pl][4 + k].size();
         }
         out->intra[pl] = p->intra[pl].data();
         out->nintra[pl] = (int)p->intra[pl].size();
@@ -834,7 +941,7 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
     }
     /* layout of the one staging buffer */
     size_t total = 0;
-    Section s_qpel[3][3], s_cmc[2][3], s_wt[3], s_ioff[3][4], s_icoef[3][4], s_edge[3], s_intra[3], s_irows[3], s_intracoef[3];
+    Section s_qpel[3][3], s_cmc[2][3], s_wt[3], s_ioff[3][6], s_icoef[3][6], s_edge[3], s_intra[3], s_irows[3], s_intracoef[3];
     Section s_c422, s_c422rows, s_c422coef;
     if (!p->intra_c422.empty()) {
         p->intra_c422_sorted = p->intra_c422;
@@ -885,7 +992,7 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
     }
     for (int pl = 0; pl < 3; pl++) {
         place(total, p->wt[pl], s_wt[pl]);
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 6; k++) {
             place(total, p->idct_off[pl][k], s_ioff[pl][k]);
             place(total, p->idct_coef[pl][k], s_icoef[pl][k]);
         }
@@ -952,7 +1059,7 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
         put(s_wt[pl], p->wt[pl].data(), p->wt[pl].size() * sizeof(FFHipWeightBlock));
         for (const FFHipWeightBlock &w : p->wt[pl])
             need_tmp[pl] = need_tmp[pl] || w.bi;
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 6; k++) {
             put(s_ioff[pl][k], p->idct_off[pl][k].data(), p->idct_off[pl][k].size() * sizeof(int32_t));
             put(s_icoef[pl][k], p->idct_coef[pl][k].data(), p->idct_coef[pl][k].size() * sizeof(int16_t));
         }
@@ -1020,7 +1127,7 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
                 r = ffhip_launch_h264_weight_bd(bd, dst[pl], p->tmp[pl] ? p->tmp[pl] : dst[pl], stride[pl], (const FFHipWeightBlock *)(db + s_wt[pl].off),
                                                 s_wt[pl].n, stream);
         for (int pl = 0; pl < 3 && r >= 0; pl++)
-            for (int k = 0; k < 4 && r >= 0; k++)
+            for (int k = 0; k < 6 && r >= 0; k++) /* (4, 5: add_pixels4 / 8_clear of the lossless bypass) */
                 if (s_ioff[pl][k].n)
                     r = ffhip_launch_h264_idct_add_bd(bd, k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off),
                                                       (int16_t *)(db + s_icoef[pl][k].off), s_ioff[pl][k].n, stream);
@@ -1070,6 +1177,12 @@ static int flush_impl(FFHipH264Picture *p, uint8_t *const dst[3], const int stri
                     }
             r = ffhip_launch_h264_idct_multi(M, stream);
         }
+        /* the lossless bypass of inter macroblocks: add_pixels4 / 8_clear (blocks of other macroblocks than the lists above) */
+        for (int pl = 0; pl < 3 && r >= 0; pl++)
+            for (int k = 4; k < 6 && r >= 0; k++)
+                if (s_ioff[pl][k].n)
+                    r = ffhip_launch_h264_idct_add(k, dst[pl], stride[pl], (const int32_t *)(db + s_ioff[pl][k].off), (int16_t *)(db + s_icoef[pl][k].off),
+                                                   (int)s_ioff[pl][k].n, stream);
     }
     if (r < 0)
         return r;

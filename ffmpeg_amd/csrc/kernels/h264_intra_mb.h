@@ -176,6 +176,15 @@ IMB_FN int imb_clip_u8(int v)
 }
 /* av_clip_pixel at the tile's depth: maxv = (1 << bit_depth) - 1 */
 template <typename PIX>
+IMB_FN int imb_clip(int v, int maxv);
+/* prediction + residual as the sample keeps it: clipped by the inverse transforms' adds, modulo the sample type by add_pixels*_clear and
+ * the pred*_add forms of the transform bypass (`dst[i] += src[i]` on pixel, h264addpx_template.c:35-40) */
+template <typename PIX>
+IMB_FN int imb_fin(int v, int maxv, bool bypass)
+{
+    return bypass ? (int)(PIX)v : imb_clip<PIX>(v, maxv);
+}
+template <typename PIX>
 IMB_FN int imb_clip(int v, int maxv)
 {
     if (sizeof(PIX) == 1)
@@ -267,9 +276,16 @@ IMB_FN void imb_idct4_col(const CF *b, int b0, int x, int out[4])
  * when it has none / only its DC counts — ff_h264_idct_add on (dc, 0, 0, ...) adds (dc + 32) >> 6 everywhere, which is
  * ff_h264_idct_dc_add (h264idct_template.c:145-160), and on all zeros adds nothing.  The one difference between the two functions is
  * kept: idct_add stores block[0] + 32 back as dctcoef before it is read, idct_dc_add computes in int. */
+/* bypass (FFHIP_H264_INTRA_BYPASS): the block holds residual samples, row-major — add_pixels4_clear (h264addpx_template.c:30-48) */
 template <typename CF>
-IMB_FN void imb_resid4_col(const CF *b, int dc, bool dconly, int x, int out[4])
+IMB_FN void imb_resid4_col(const CF *b, int dc, bool dconly, int x, int out[4], bool bypass = false)
 {
+    if (bypass) {
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            out[y] = b[x + 4 * y];
+        return;
+    }
     int r[4];
     r[0] = imb_bfly4(x, dconly ? dc + 32 : (int)(CF)(dc + 32), b[4], b[8], b[12]);
     r[0] = dconly ? r[0] : (int)(CF)r[0];
@@ -613,6 +629,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
     typedef typename ImbCoef<PIX>::T CF;
     const int mid = (maxv + 1) >> 1;
     const ImbHead H = { IMB_UNIFORM((int)R.type), IMB_UNIFORM((int)R.cbp), IMB_UNIFORM((int)R.flags), (uint32_t)IMB_UNIFORM((int)R.blocks) };
+    const bool byp = (H.flags & FFHIP_H264_INTRA_BYPASS) != 0; /* the transform bypass: the run holds residual samples (the packer made them so) */
     if (H.type == FFHIP_H264_INTRA_PCM) {
         /* the samples as they stand in the bitstream: 256 luma, 64 Cb, 64 Cr (h264_mb_template.c:98-150; above 8 bits the host side
          * has unpacked the bit_depth-bit fields into uint16_t) */
@@ -671,10 +688,10 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             const int cmode = IMB_UNIFORM((int)R.chroma_pred);
             const ImbPred P = imb_pred_quad<8, true>(cmode, xc, y0, TOP, LEFT, mid);
             int res[4];
-            imb_resid4_col(b, dc, dconly, lane & 3, res);
+            imb_resid4_col(b, dc, dconly, lane & 3, res, byp);
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                T.c[p][imb_ci(y0 + j, xc)] = (PIX)imb_clip<PIX>(imb_pred_px<PIX>(cmode, P, j, xc, y0 + j, maxv) + res[j], maxv);
+                T.c[p][imb_ci(y0 + j, xc)] = (PIX)imb_fin<PIX>(imb_pred_px<PIX>(cmode, P, j, xc, y0 + j, maxv) + res[j], maxv, byp);
         } else if (!(parts & 1)) {
             return;
         } else if (H.type == FFHIP_H264_INTRA_8x8) {
@@ -682,7 +699,12 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
              * of block 4 q, working on block[j + 8 k], results stored as int16 */
             const int q = (lane - 32) >> 3, j = lane & 7, nnz = R.nnz[4 * q];
             const CF *b = nnz ? imb_block(H, coefs, 4 * q) : nullptr;
-            if (b && !(nnz == 1 && b[0])) {
+            if (b && byp) {
+                /* add_pixels8_clear: the samples of column j where the steps read their transform's output */
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    T.t8[q][8 * j + k] = b[j + 8 * k];
+            } else if (b && !(nnz == 1 && b[0])) {
                 int in[8];
                 uint32_t out[8];
 #pragma unroll
@@ -731,10 +753,10 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             const int lmode = IMB_UNIFORM((int)R.pred16);
             const ImbPred P = imb_pred_quad<16, true>(lmode, xc, y0, TOP, LEFT, mid);
             int res[4];
-            imb_resid4_col(full ? bs : T.zero, dc, dconly, lane & 3, res);
+            imb_resid4_col(full ? bs : T.zero, dc, dconly, lane & 3, res, byp);
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                T.y[imb_yi(y0 + j, xc)] = (PIX)imb_clip<PIX>(imb_pred_px<PIX>(lmode, P, j, xc, y0 + j, maxv) + res[j], maxv);
+                T.y[imb_yi(y0 + j, xc)] = (PIX)imb_fin<PIX>(imb_pred_px<PIX>(lmode, P, j, xc, y0 + j, maxv) + res[j], maxv, byp);
         });
         return;
     }
@@ -771,7 +793,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             const int dc = bs[0];
             const bool dconly = nnz == 1 && dc;
             int out[4];
-            imb_resid4_col(dconly ? T.zero : bs, dc, dconly, xx, out);
+            imb_resid4_col(dconly ? T.zero : bs, dc, dconly, xx, out, byp);
 #pragma unroll
             for (int y = 0; y < 4; y++)
                 res[4 * y + xx] = out[y];
@@ -799,7 +821,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
                 const int sh = (ent >> 28) & 1u ? 3 : 2;
                 const int dcv = (((ent >> 26) & 1u ? sl : 0) + ((ent >> 27) & 1u ? st : 0) + ((ent >> 29) & 1u ? 4 * mid : 1 << (sh - 1))) >> sh;
                 int v = kind == 3 ? dcv : dir;
-                const int vr = imb_clip<PIX>(v + res, maxv);
+                const int vr = imb_fin<PIX>(v + res, maxv, byp);
                 v = (ent & IMB_P4_RES) ? vr : v;
                 o[32 * yy + xx] = (PIX)v;
             });
@@ -816,7 +838,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             return;
         const int q = lane >> 3, xx = lane & 7, nnz = R.nnz[4 * q];
         const CF *b = nnz ? imb_block(H, coefs, 4 * q) : nullptr;
-        if (!b || (nnz == 1 && b[0]))
+        if (!b || (nnz == 1 && b[0]) || byp)
             return;
         int in[8];
         uint32_t out[8];
@@ -858,7 +880,7 @@ IMB_FN void imb_reconstruct(X &x, ImbTileT<PIX> &T, const FFHipH264IntraMB &R, c
             }
             if (full) {
                 /* transform xx worked on block[8 xx + k], output yy goes to dst[xx + yy * stride] */
-                v = imb_clip<PIX>(v + T.t8[i >> 2][8 * xx + yy], maxv);
+                v = imb_fin<PIX>(v + T.t8[i >> 2][8 * xx + yy], maxv, byp);
             } else if (dconly) {
                 v = imb_clip<PIX>(v + ((dc + 32) >> 6), maxv);
             }

@@ -775,7 +775,8 @@ int  ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int
  * data flow, whose in-loop filter runs behind reconstruction on samples intra prediction never sees (xchg_mb_border,
  * h264_mb.c:528-597).  Fields are the decoder's H264SliceContext state of the macroblock.  Frame macroblocks, or the field macroblocks of
  * a field picture whose object was made for the field (mb_y = the row inside the field); 4:2:2 / 4:4:4: ffhip_h264_picture_create_fmt();
- * the lossless transform bypass (qscale 0 with sps->transform_bypass) is not taken: keep such a picture on the C path.
+ * the lossless transform bypass (a macroblock with qscale 0 in a stream with sps->transform_bypass; round 6, 8 bits, 4:2:0 and 4:4:4): the
+ * caller sets FFHIP_H264_INTRA_BYPASS (and _DPCM under profile_idc 244) in `flags` — see below.
  */
 #define FFHIP_H264_INTRA_16x16 0   /* IS_INTRA16x16(mb_type)                                                         */
 #define FFHIP_H264_INTRA_4x4   1   /* IS_INTRA4x4(mb_type) && !IS_8x8DCT(mb_type)                                    */
@@ -784,6 +785,14 @@ int  ffhip_h264_picture_deblock_mb(FFHipH264Picture *p, int plane, int mb_x, int
 #define FFHIP_H264_INTRA_LUMA_DC 1 /* flags, set by ffhip_h264_picture_intra_mb() from the cache: nnz[scan8[LUMA_DC_BLOCK_INDEX]] */
 #define FFHIP_H264_INTRA_CB_DC   2 /*   nnz[scan8[CHROMA_DC_BLOCK_INDEX + 0]] */
 #define FFHIP_H264_INTRA_CR_DC   4 /*   nnz[scan8[CHROMA_DC_BLOCK_INDEX + 1]] */
+/* flags the CALLER sets (every other bit of `flags` zero on entry): the macroblock is decoded with the transform bypassed
+ * (hl_decode_mb()'s transform_bypass: sl->qscale == 0 && sps->transform_bypass, h264_mb_template.c:51) — its "coefficients" are residual
+ * samples, added to the prediction as add_pixels4 / 8_clear add them (modulo 256, h264addpx_template.c:30-74), no DC transforms;
+ * _DPCM (sps->profile_idc == 244): blocks predicted vertically / horizontally take the pred*_add forms (h264pred_template.c:1067-1330,
+ * h264_mb.c:638-672,745-750, h264_mb_template.c:198-207): every sample is its neighbour along the direction plus its residual — the packer
+ * turns those residuals into running sums along the direction, which makes them ordinary residuals of the V / H prediction. */
+#define FFHIP_H264_INTRA_BYPASS  8
+#define FFHIP_H264_INTRA_DPCM    16
 typedef struct FFHipH264IntraMB {
     int16_t  mb_x, mb_y;
     uint8_t  type;            /* FFHIP_H264_INTRA_*                                                                  */
@@ -795,7 +804,7 @@ typedef struct FFHipH264IntraMB {
     uint8_t  pred4[16];       /* sl->intra4x4_pred_mode_cache[scan8[i]], i = 0..15 (8x8: entries 0, 4, 8, 12)        */
     int32_t  qmul[3];         /* pps->dequant4_coeff[0][qscale][0], [1][chroma_qp[0]][0], [2][chroma_qp[1]][0]       */
     /* ---- filled in by ffhip_h264_picture_intra_mb() ---- */
-    uint8_t  flags;           /* FFHIP_H264_INTRA_LUMA_DC | _CB_DC | _CR_DC                                          */
+    uint8_t  flags;           /* in: 0, or FFHIP_H264_INTRA_BYPASS [| _DPCM]; out: + FFHIP_H264_INTRA_LUMA_DC | _CB_DC | _CR_DC */
     uint8_t  pad[3];
     uint8_t  nnz[24];         /* non_zero_count_cache[scan8[i]]: luma i = 0..15, Cb 16..19 at [16..19], Cr 32..35 at [20..23] */
     int32_t  coef;            /* the macroblock's run in the picture's packed coefficient array (int16 units)         */
@@ -906,6 +915,11 @@ typedef struct FFHipH264PictureLists {
     int nintra_c422;
     const int16_t *intra_c422_coef;
     int nintra_c422_coef;
+    /* the lossless bypass of inter macroblocks (round 6): add_pixels4_clear ([pl][0], 16 dctcoef each) / add_pixels8_clear ([pl][1], 64)
+     * calls — ffhip_h264_picture_idct_add() kinds FFHIP_H264_ADD_PIXELS4_CLEAR / 8_CLEAR */
+    const int32_t *addpx_off[3][2];
+    const int16_t *addpx_coef[3][2];
+    int naddpx[3][2];
 } FFHipH264PictureLists;
 int  ffhip_h264_picture_lists(const FFHipH264Picture *p, FFHipH264PictureLists *out);
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */

@@ -107,6 +107,16 @@ extern "C" int ffemul_h264_picture_flush(const FFHipH264PictureLists *L, uint8_t
                 ffo_h264_idct_bd(bd, k, dst[pl] + L->idct_off[pl][k][i], blk, stride[pl]);
             }
         }
+    /* (the lossless bypass of inter macroblocks: add_pixels4 / 8_clear) */
+    for (int pl = 0; pl < 3; pl++)
+        for (int k = 0; k < 2; k++) {
+            const int nc = (k ? 64 : 16) * wide;
+            for (int i = 0; i < L->naddpx[pl][k]; i++) {
+                int16_t blk[128];
+                memcpy(blk, L->addpx_coef[pl][k] + (size_t)i * nc, sizeof(int16_t) * nc);
+                ffo_h264_idct_bd(bd, FFHIP_H264_ADD_PIXELS4_CLEAR + k, dst[pl] + L->addpx_off[pl][k][i], blk, stride[pl]);
+            }
+        }
     /* ---- intra macroblocks: sorted by (mb_y, mb_x) as flush() sorts them, through the kernel's per-macroblock phases ---- */
     for (int q = 0; q < (c444 ? 3 : 1); q++) {
         if (!L->nintra[q])

@@ -27,7 +27,8 @@ class Lists(C.Structure):                       # == FFHipH264PictureLists (incl
                 ("wt", C.c_void_p * 3), ("nwt", C.c_int * 3), ("idct_off", (C.c_void_p * 4) * 3), ("idct_coef", (C.c_void_p * 4) * 3),
                 ("nidct", (C.c_int * 4) * 3), ("intra", C.c_void_p * 3), ("nintra", C.c_int * 3), ("intra_coef", C.c_void_p * 3),
                 ("nintra_coef", C.c_int * 3), ("edges", C.c_void_p * 3), ("intra_c422", C.c_void_p), ("nintra_c422", C.c_int),
-                ("intra_c422_coef", C.c_void_p), ("nintra_c422_coef", C.c_int)]
+                ("intra_c422_coef", C.c_void_p), ("nintra_c422_coef", C.c_int),
+                ("addpx_off", (C.c_void_p * 2) * 3), ("addpx_coef", (C.c_void_p * 2) * 3), ("naddpx", (C.c_int * 2) * 3)]
 
 
 def _env():
