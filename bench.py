@@ -1459,6 +1459,9 @@ def main():
     ap.add_argument("--placement-trials", type=int, default=4,
                     help="the frame batches are placed by trial before the timed region: up to this many allocations, the fastest kept "
                          "(1: the first allocation as it comes)")
+    ap.add_argument("--placement-good-frac", type=float, default=0.63,
+                    help="a placement whose trial reaches this fraction of the HBM peak is taken without further trials (the slow layout reads 0.56 - 0.58 "
+                         "in a trial, the others 0.62 - 0.66)")
     ap.add_argument("--torch-alloc", action="store_true",
                     help="frame batches from torch's allocator (one hipMalloc each) instead of libffhip's frame memory (ffhip_frames_alloc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1531,7 +1534,7 @@ def main():
     # launch; --placement-trials 1 takes the first allocation as it comes); not part of the W warmup / K timed steps
     tries = 1 if (args.torch_alloc or args.pmc_child) else args.placement_trials
     (src, dst), placement_ms = place_best(torch, make_batches, trial_ms if tries > 1 else (lambda c: 0.0), lambda c: free_batches(torch, c[0], c[1]), tries,
-                                          n * BYTES_PER_FRAME / (0.63 * HBM_PEAK_GBS * 1e9) * 1e3)
+                                          n * BYTES_PER_FRAME / (args.placement_good_frac * HBM_PEAK_GBS * 1e9) * 1e3)
 
     def barrier():
         if world > 1:
@@ -1662,6 +1665,8 @@ def main():
             roof["placement_frac_first"] = fr[0]
             roof["placement_frac_min"] = min(fr)
             roof["placement_frac_kept"] = max(fr)
+            for i, f in enumerate(fr):
+                roof["placement_frac_%d" % i] = f
         for k, v in (probes or {}).items():
             roof["probe_%s_GBs" % k] = v
         if probes and probes.get("read1_write4"):

@@ -420,8 +420,10 @@ static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_
                     mb[16 * dc_mapping[i]] = mb_luma_dc[i];
             }
             const bool ch = dpcm && (R.pred16 == 2 /* VERT_PRED8x8 */ || R.pred16 == 1 /* HOR_PRED8x8 */);
-            if (ch) /* pred16x16_{vertical,horizontal}_add: the sixteen blocks' pred4x4_*_add run into one another (h264pred_template.c:1305-1330) */
+            if (ch) { /* pred16x16_{vertical,horizontal}_add: the sixteen blocks' pred4x4_*_add run into one another (h264pred_template.c:1305-1330) */
                 chain(mb, 16, R.pred16 == 2, in4);
+                R.pad[0]++;
+            }
             for (int i = 0; i < 16; i++)
                 if (ch ? any(mb + 16 * i, 16) : (nnzc[scan8_luma(i)] || mb[16 * i])) {
                     R.nnz[i] = 16;
@@ -431,8 +433,10 @@ static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_
         } else if (R.type == FFHIP_H264_INTRA_4x4) {
             for (int i = 0; i < 16; i++) {
                 const bool ch = dpcm && R.pred4[i] <= 1; /* VERT_PRED 0, HOR_PRED 1: pred4x4_*_add, whatever the count says */
-                if (ch)
+                if (ch) {
                     chain(mb + 16 * i, 4, R.pred4[i] == 0, [](CF *b, int x, int y) { return b + x + 4 * y; });
+                    R.pad[0]++;
+                }
                 if (ch ? any(mb + 16 * i, 16) : nnzc[scan8_luma(i)] != 0) {
                     R.nnz[i] = 16;
                     R.blocks |= 1u << i;
@@ -442,8 +446,10 @@ static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_
         } else {
             for (int i = 0; i < 16; i += 4) {
                 const bool ch = dpcm && R.pred4[i] <= 1; /* pred8x8l_*_filter_add: the filtered edge sample plus the running sum */
-                if (ch)
+                if (ch) {
                     chain(mb + 16 * i, 8, R.pred4[i] == 0, [](CF *b, int x, int y) { return b + x + 8 * y; });
+                    R.pad[0]++;
+                }
                 if (ch ? any(mb + 16 * i, 64) : nnzc[scan8_luma(i)] != 0) {
                     R.nnz[i] = 16;
                     R.blocks |= 1u << i;
@@ -457,8 +463,10 @@ static int intra_pack(int bd, FFHipH264IntraMB *rec, const uint8_t *nnzc, int16_
             const bool ch = dpcm && (R.chroma_pred == 2 || R.chroma_pred == 1);
             for (int pl = 1; pl < 3; pl++) {
                 CF *base = mb + 256 * pl;
-                if (ch)
+                if (ch) {
                     chain(base, 8, R.chroma_pred == 2, [](CF *b, int x, int y) { return b + 16 * ((x >> 2) + 2 * (y >> 2)) + (x & 3) + 4 * (y & 3); });
+                    R.pad[0]++;
+                }
                 for (int k = 0; k < 4; k++)
                     if (ch ? any(base + 16 * k, 16) : (nnzc[scan8_chroma(pl, k)] || base[16 * k])) {
                         R.nnz[16 + 4 * (pl - 1) + k] = 16;

@@ -805,7 +805,7 @@ typedef struct FFHipH264IntraMB {
     int32_t  qmul[3];         /* pps->dequant4_coeff[0][qscale][0], [1][chroma_qp[0]][0], [2][chroma_qp[1]][0]       */
     /* ---- filled in by ffhip_h264_picture_intra_mb() ---- */
     uint8_t  flags;           /* in: 0, or FFHIP_H264_INTRA_BYPASS [| _DPCM]; out: + FFHIP_H264_INTRA_LUMA_DC | _CB_DC | _CR_DC */
-    uint8_t  pad[3];
+    uint8_t  pad[3];          /* pad[0], out: how many regions of the macroblock (a luma block, the 16x16 block, a chroma plane) were DPCM-coded */
     uint8_t  nnz[24];         /* non_zero_count_cache[scan8[i]]: luma i = 0..15, Cb 16..19 at [16..19], Cr 32..35 at [20..23] */
     int32_t  coef;            /* the macroblock's run in the picture's packed coefficient array (int16 units)         */
     uint32_t blocks;          /* which blocks the run holds, in this order: bit i luma block i (8x8: bits 0, 4, 8, 12, 64

@@ -328,6 +328,21 @@ static void rec_idct_add8(uint8_t **dest, const int *bo, int16_t *block, ptrdiff
     rec_idct_mb(3, dest, bo, block, stride, nnzc);
 }
 
+/* the lossless bypass of an inter macroblock (hl_decode_mb_idct_luma() / hl_decode_mb() with transform_bypass: h264_mb.c:762-772,
+ * h264_mb_template.c:208-221): add_pixels4_clear / add_pixels8_clear per coded block — recorded as they come */
+static void rec_add_pixels(int kind, uint8_t *dst, int16_t *block, ptrdiff_t stride)
+{
+    REC;
+    int pl = classify_dst(r, dst), rc;
+    if (pl < 0 || pl > 2 || stride != r->linesize[pl])
+        FAIL(FFHIP_EINVAL);
+    rc = ffhip_h264_picture_idct_add(r->pic, pl, kind, (int32_t)(dst - r->cur[pl]), block);
+    if (rc < 0)
+        FAIL(rc);
+}
+static void rec_add_pixels4_clear(uint8_t *dst, int16_t *block, ptrdiff_t stride) { rec_add_pixels(FFHIP_H264_ADD_PIXELS4_CLEAR, dst, block, stride); }
+static void rec_add_pixels8_clear(uint8_t *dst, int16_t *block, ptrdiff_t stride) { rec_add_pixels(FFHIP_H264_ADD_PIXELS8_CLEAR, dst, block, stride); }
+
 static void rec_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize, ptrdiff_t src_linesize, int block_w, int block_h,
                                  int src_x, int src_y, int w, int h)
 {
@@ -441,6 +456,8 @@ av_cold void ff_h264_hip_recorder_install(H264Context *h)
     h->h264dsp.idct_add16  = rec_idct_add16;
     h->h264dsp.idct8_add4  = rec_idct8_add4;
     h->h264dsp.idct_add8   = rec_idct_add8;
+    h->h264dsp.add_pixels4_clear = rec_add_pixels4_clear;
+    h->h264dsp.add_pixels8_clear = rec_add_pixels8_clear;
     h->h264dsp.v_loop_filter_luma         = rec_v_loop_filter_luma;
     h->h264dsp.h_loop_filter_luma         = rec_h_loop_filter_luma;
     h->h264dsp.v_loop_filter_luma_intra   = rec_v_loop_filter_luma_intra;
@@ -457,12 +474,16 @@ av_cold void ff_h264_hip_recorder_install(H264Context *h)
     h->vdsp.prefetch = rec_prefetch;
 }
 
-/* What keeps a whole picture on the C path, known before its first macroblock (MBAFF frames above 8 bits or not 4:2:0; lossless streams,
- * where a qpprime_y_zero_transform_bypass macroblock may turn up at any macroblock): a caller asks this BEFORE it begins to record — once
- * macroblocks have been recorded their coefficients are consumed and the pixels exist only as records, there is no way back. */
+/* What keeps a whole picture on the C path, known before its first macroblock (MBAFF frames above 8 bits or not 4:2:0; lossless streams —
+ * a qpprime_y_zero_transform_bypass macroblock may turn up at any macroblock — above 8 bits or at 4:2:2): a caller asks this BEFORE it
+ * begins to record — once macroblocks have been recorded their coefficients are consumed and the pixels exist only as records, there is no
+ * way back. */
 int ff_h264_hip_picture_supported(const H264Context *h)
 {
-    if (h->ps.sps->transform_bypass)
+    if (h->ps.sps->transform_bypass && (h->ps.sps->bit_depth_luma != 8 || h->ps.sps->chroma_format_idc == 2))
+        return 0;
+    /* (streams of x264 before build 151 predict Intra8x8 DPCM blocks from the UNFILTERED edge: h264_mb.c:641-643; libffhip has the filtered form) */
+    if (h->ps.sps->transform_bypass && h->ps.sps->profile_idc == 244 && (unsigned)h->x264_build < 151U)
         return 0;
     return !FRAME_MBAFF(h) || (h->ps.sps->bit_depth_luma == 8 && h->ps.sps->chroma_format_idc == 1 && !(h->mb_height & 1));
 }
@@ -544,10 +565,14 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
     } else if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field) {
         return r->error = FFHIP_ENOSYS;   /* such a picture stays on the C path as a whole */
     }
-    if (sl->qscale == 0 && h->ps.sps->transform_bypass)
-        return r->error = FFHIP_ENOSYS;
+    if (sl->qscale == 0 && h->ps.sps->transform_bypass && (r->pixel_shift || r->cfmt == 2))
+        return r->error = FFHIP_ENOSYS;   /* (ff_h264_hip_picture_supported() said so) */
     if (IS_INTRA(mb_type)) {
         FFHipH264IntraMB m = { 0 };
+        /* hl_decode_mb()'s transform_bypass (h264_mb_template.c:51): the residual is added as samples; profile_idc 244: vertically /
+         * horizontally predicted blocks through the pred*_add forms (libffhip's packer does what that takes) */
+        if (sl->qscale == 0 && h->ps.sps->transform_bypass)
+            m.flags = FFHIP_H264_INTRA_BYPASS | (h->ps.sps->profile_idc == 244 ? FFHIP_H264_INTRA_DPCM : 0);
         const int intra_qmul = 0;
         m.mb_x = (int16_t)sl->mb_x;
         /* a field picture: rows of the field (mb_y = 2 * row + bottom, h264_slice.c:2676-2680); an MBAFF frame: the row in the frame */

@@ -64,12 +64,12 @@ typedef struct FFHipH264Recorder {
 } FFHipH264Recorder;
 
 /* Replaces, in h, the dsp members hl_decode_mb() calls for inter macroblocks (h264qpel, h264chroma, weight / biweight, idct_add16 /
- * idct8_add4 / idct_add8, vdsp.emulated_edge_mc, vdsp.prefetch) and the loop-filter members ff_h264_filter_mb() calls with recording
+ * idct8_add4 / idct_add8, add_pixels4_clear / add_pixels8_clear, vdsp.emulated_edge_mc, vdsp.prefetch) and the loop-filter members ff_h264_filter_mb() calls with recording
  * ones; chroma_dc_dequant_idct and everything else stay what ff_h264dsp_init() left.  Call once after the decoder's own init. */
 void ff_h264_hip_recorder_install(H264Context *h);
 
-/* 1 when the picture the decoder is about to decode can be recorded as a whole: no lossless (transform-bypass) stream; an MBAFF frame
- * (FRAME_MBAFF(h): begin it with ff_h264_hip_recorder_begin_mbaff()) only at 8 bits, 4:2:0.  Ask
+/* 1 when the picture the decoder is about to decode can be recorded as a whole: a lossless (transform-bypass) stream only at 8 bits, 4:2:0 /
+ * 4:4:4; an MBAFF frame (FRAME_MBAFF(h): begin it with ff_h264_hip_recorder_begin_mbaff()) only at 8 bits, 4:2:0.  Ask
  * before ff_h264_hip_recorder_begin(): a refusal in the middle of a picture cannot be undone (the per-macroblock calls still return
  * FFHIP_ENOSYS for such macroblocks, as a guard). */
 int ff_h264_hip_picture_supported(const H264Context *h);

@@ -64,6 +64,7 @@ typedef struct FFRefH264Stream {
     FFHipH264Picture *fpic[2];
     FFHipH264Mbaff *chains;
     long mbaff_pictures;
+    long mbs_bypass;               /* recorded macroblocks decoded with the transform bypassed (qscale 0, sps->transform_bypass) */
     /* the picture being recorded */
     FFHipH264Recorder rec;
     FFHipH264Picture *pic;
@@ -293,6 +294,7 @@ void ffref_hook_hl_decode_mb(const H264Context *h, H264SliceContext *sl)
         }
         s->mbs_class[2] += !!IS_8x8DCT(mt) && (sl->cbp & 15);
         s->mbs_class[7] += !!MB_FIELD(sl);
+        s->mbs_bypass += sl->qscale == 0 && h->ps.sps->transform_bypass;
     }
     note(s, ff_h264_hip_hl_decode_mb(&s->rec, h, sl));
 }
@@ -453,6 +455,7 @@ long ffref_h264stream_stat(const FFRefH264Stream *s, int what)
      * 12 implicit weights, 13 of B slices, 14 Intra8x8, 15 field macroblocks */
     case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: return s->mbs_class[what - 8];
     case 16: return s->mbaff_pictures;   /* MBAFF frames recorded (each counted once in 0 as well) */
+    case 17: return s->mbs_bypass;
     }
     return -1;
 }

@@ -162,7 +162,7 @@ class Params:
     """What a stream is made with."""
 
     def __init__(self, mb_w=6, mb_h=5, bit_depth=8, frame_mbs_only=1, mbaff=0, num_ref_frames=3, init_qp=26, chroma_qp_offset=0,
-                 seed=1, chroma_format=1, t8x8=0, weighted_pred=0, weighted_bipred=0, poc_type=2, reorder=0):
+                 seed=1, chroma_format=1, t8x8=0, weighted_pred=0, weighted_bipred=0, poc_type=2, reorder=0, lossless=0):
         self.mb_w, self.mb_h, self.bit_depth = mb_w, mb_h, bit_depth
         self.frame_mbs_only, self.mbaff = frame_mbs_only, mbaff
         self.num_ref_frames, self.init_qp, self.chroma_qp_offset = num_ref_frames, init_qp, chroma_qp_offset
@@ -172,13 +172,19 @@ class Params:
         # (2: output order = decode order; 0: pic_order_cnt_lsb per picture, `reorder` = VUI max_num_reorder_frames)
         self.chroma_format, self.t8x8, self.weighted_pred, self.weighted_bipred = chroma_format, t8x8, weighted_pred, weighted_bipred
         self.poc_type, self.reorder, self.log2_max_poc_lsb = poc_type, reorder, 8
+        # lossless: qpprime_y_zero_transform_bypass_flag = 1 — macroblocks with QP'Y = 0 are decoded with the transform bypassed; 1: a High
+        # profile (the residual is added as it is), 2: profile_idc 244, High 4:4:4 Predictive (vertically / horizontally predicted intra blocks
+        # are DPCM-coded on top of that).  The running QP stays in 0 .. 6 (init_qp 3) so that both kinds of macroblock turn up in a slice.
+        self.lossless = lossless
+        if lossless:
+            self.init_qp = 3
         assert frame_mbs_only or mb_h % 2 == 0
         assert chroma_format in (1, 2) and poc_type in (0, 2)
 
 
 def sps_nal(p):
     bw = BitWriter()
-    profile = 122 if p.chroma_format == 2 else 100 if p.bit_depth == 8 else 110
+    profile = 244 if p.lossless == 2 else 122 if p.chroma_format == 2 else 100 if p.bit_depth == 8 else 110
     bw.u(8, profile)
     bw.u(8, 0)                      # constraint flags + reserved
     bw.u(8, 40)                     # level_idc
@@ -186,7 +192,7 @@ def sps_nal(p):
     bw.ue(p.chroma_format)          # chroma_format_idc
     bw.ue(p.bit_depth - 8)
     bw.ue(p.bit_depth - 8)
-    bw.u(1, 0)                      # qpprime_y_zero_transform_bypass_flag
+    bw.u(1, 1 if p.lossless else 0) # qpprime_y_zero_transform_bypass_flag
     bw.u(1, 0)                      # seq_scaling_matrix_present_flag
     bw.ue(p.log2_max_frame_num - 4)
     bw.ue(p.poc_type)               # pic_order_cnt_type
@@ -346,8 +352,10 @@ class StreamWriter:
 
     def qp_delta(self, st):
         """keeps the running QP inside a band where random levels stay far from the coefficient range"""
-        lo, hi = self.p.init_qp - 10, self.p.init_qp + 8
+        lo, hi = (0, 6) if self.p.lossless else (self.p.init_qp - 10, self.p.init_qp + 8)
         d = int(self.rng.integers(-3, 4))
+        if self.p.lossless and self.rng.random() < 0.4:
+            d = -st["qp"]               # QP'Y = 0: this macroblock (and those after it, until the next delta) bypasses the transform
         if not lo <= st["qp"] + d <= hi:
             d = 0
         st["qp"] += d

@@ -88,6 +88,11 @@ def cpu_flush(arena_base):
         counts["inter_blocks"] += sum(ls.nqpel[0][k] for k in range(3))
         counts["mbaff_field_inter_blocks"] += sum(ls.nqpel[0][k] for k in range(3)) if field == 3 else 0
         counts["intra_mbs"] += ls.nintra[0]
+        if ls.nintra[0]:   # FFHipH264IntraMB: flags at byte 40 (bit 3: the transform bypass), pad[0] at 41: DPCM-coded regions
+            raw = np.ctypeslib.as_array((C.c_uint8 * (108 * ls.nintra[0])).from_address(ls.intra[0])).reshape(-1, 108)
+            counts["bypass_intra_mbs"] = counts.get("bypass_intra_mbs", 0) + int(((raw[:, 40] >> 3) & 1).sum())
+            counts["dpcm_regions"] = counts.get("dpcm_regions", 0) + int(raw[:, 41].sum())
+        counts["bypass_inter_blocks"] = counts.get("bypass_inter_blocks", 0) + sum(ls.naddpx[pl][k] for pl in range(3) for k in range(2))
         counts["edge_planes"] += sum(1 for k in range(3) if ls.edges[k])
         return E.ffemul_h264_picture_flush(C.byref(ls), dp, st, rp)
 
@@ -139,7 +144,7 @@ def decode(aus, make_flush=None, arena_bytes=48 << 20, read_back=None, base_shif
         assert L.ffref_h264stream_decode(s, None, 0) == 0
         stats = {k: L.ffref_h264stream_stat(s, i) for i, k in enumerate(("pictures", "mbs_hl", "mbs_filter", "refused", "errors",
                                                                         "first_error", "damaged", "plain_pictures", "mbs_bipred", "mbs_direct", "mbs_8x8dct", "mbs_weighted",
-                                                                        "mbs_implicit", "mbs_b", "mbs_intra8x8", "mbs_field", "mbaff_pictures"))}
+                                                                        "mbs_implicit", "mbs_b", "mbs_intra8x8", "mbs_field", "mbaff_pictures", "mbs_bypass"))}
         if read_back is not None:
             used = C.c_size_t()
             L.ffref_h264stream_arena(s, C.byref(used))
@@ -218,13 +223,13 @@ def stream_mbaff_and_fields(seed=7, mb_w=6, mb_h=6):
 
 # ---- round 6: B pictures, weighted prediction, the 8x8 transform, 4:2:2 ---------------------------------------------------------------------
 def stream_b(bit_depth=8, seed=21, mb_w=6, mb_h=5, direct_spatial=1, weighted_bipred=0, weighted_pred=0, t8x8=0, chroma_format=1,
-             slices=1, nonref=False, gops=2, mbaff=0):
+             slices=1, nonref=False, gops=2, mbaff=0, lossless=0):
     """I P B B B | P B B B ...: pic_order_cnt_type 0, B pictures between their references in output order and decoded after them (a small
     pyramid: the middle B is itself a reference of the outer two), every B macroblock type, direct_spatial_mv_pred_flag as given.
     nonref: the outer B pictures of each group are non-reference pictures (nal_ref_idc 0)."""
     p = B.Params(mb_w=mb_w, mb_h=mb_h, bit_depth=bit_depth, seed=seed, num_ref_frames=4, poc_type=0, reorder=3, t8x8=t8x8,
                  weighted_pred=weighted_pred, weighted_bipred=weighted_bipred, chroma_format=chroma_format, frame_mbs_only=0 if mbaff else 1,
-                 mbaff=mbaff)
+                 mbaff=mbaff, lossless=lossless)
     w = B.StreamWriter(p)
     rng = np.random.default_rng(seed + 300)
     n_mb = mb_w * mb_h
@@ -258,11 +263,11 @@ def stream_b(bit_depth=8, seed=21, mb_w=6, mb_h=5, direct_spatial=1, weighted_bi
     return w.stream(pics), w.stats
 
 
-def stream_p_features(bit_depth=8, seed=31, mb_w=6, mb_h=5, weighted_pred=0, t8x8=0, chroma_format=1, n=5, fields=False):
+def stream_p_features(bit_depth=8, seed=31, mb_w=6, mb_h=5, weighted_pred=0, t8x8=0, chroma_format=1, n=5, fields=False, lossless=0):
     """I P P P P (pic_order_cnt_type 2) with PPS features switched on: weighted_pred_flag (a pred_weight_table per P slice),
     transform_8x8_mode_flag (Intra8x8, transform_size_8x8_flag on inter macroblocks), chroma_format_idc 2"""
     p = B.Params(mb_w=mb_w, mb_h=mb_h, bit_depth=bit_depth, seed=seed, weighted_pred=weighted_pred, t8x8=t8x8, chroma_format=chroma_format,
-                 frame_mbs_only=0 if fields else 1)
+                 frame_mbs_only=0 if fields else 1, lossless=lossless)
     w = B.StreamWriter(p)
     rng = np.random.default_rng(seed + 400)
     pics = []
@@ -279,11 +284,11 @@ def stream_p_features(bit_depth=8, seed=31, mb_w=6, mb_h=5, weighted_pred=0, t8x
     return w.stream(pics), w.stats
 
 
-def stream_mbaff_p(seed=41, mb_w=6, mb_h=6, n=5, t8x8=0, weighted_pred=0):
+def stream_mbaff_p(seed=41, mb_w=6, mb_h=6, n=5, t8x8=0, weighted_pred=0, lossless=0):
     """I P P P P, every picture an MBAFF frame: frame and field macroblock pairs mixed (mb_field_decoding_flag per pair), one to three slices
     starting on macroblock pairs, disable_deblocking_filter_idc 0 / 1 / 2, Intra16x16 with every prediction mode its neighbours allow and
     isolated I_NxN macroblocks, one to three reference frames (a field macroblock: twice as many reference fields)"""
-    p = B.Params(mb_w=mb_w, mb_h=mb_h, frame_mbs_only=0, mbaff=1, seed=seed, t8x8=t8x8, weighted_pred=weighted_pred)
+    p = B.Params(mb_w=mb_w, mb_h=mb_h, frame_mbs_only=0, mbaff=1, seed=seed, t8x8=t8x8, weighted_pred=weighted_pred, lossless=lossless)
     w = B.StreamWriter(p)
     rng = np.random.default_rng(seed + 500)
     n_mb = mb_w * mb_h
@@ -313,6 +318,18 @@ MBAFF_CASES = {
                                   ("mbs_field", "mbs_b", "mbs_bipred", "mbs_direct", "mbs_implicit"), ("mbaff_calls_mbaff_member",)),
     "mbaff_b_explicit_8x8": (stream_b, dict(seed=46, mb_h=6, mbaff=1, weighted_bipred=1, weighted_pred=1, t8x8=1), 9,
                              ("mbs_field", "mbs_b", "mbs_weighted", "mbs_8x8dct"), ("mbaff_calls_mbaff_member",)),
+}
+
+# the lossless transform bypass (8 bits, 4:2:0): name -> (generator, kwargs, pictures, DECODER statistics that must be non-zero)
+LOSSLESS_CASES = {
+    "lossless_p_high": (stream_p_features, dict(seed=51, lossless=1), 5, ("mbs_bypass",)),
+    "lossless_p_predictive": (stream_p_features, dict(seed=52, lossless=2), 5, ("mbs_bypass",)),
+    "lossless_p_predictive_8x8": (stream_p_features, dict(seed=53, lossless=2, t8x8=1), 5, ("mbs_bypass", "mbs_intra8x8", "mbs_8x8dct")),
+    "lossless_p_high_8x8": (stream_p_features, dict(seed=54, lossless=1, t8x8=1, weighted_pred=1), 5, ("mbs_bypass", "mbs_intra8x8", "mbs_weighted")),
+    "lossless_fields_predictive": (stream_p_features, dict(seed=55, lossless=2, fields=True, n=3, mb_h=6), 6, ("mbs_bypass", "mbs_field")),
+    "lossless_b_predictive_8x8": (stream_b, dict(seed=56, lossless=2, t8x8=1, weighted_bipred=2), 9, ("mbs_bypass", "mbs_b", "mbs_bipred", "mbs_8x8dct")),
+    "lossless_mbaff_predictive": (stream_mbaff_p, dict(seed=57, lossless=2, t8x8=1), 5, ("mbs_bypass", "mbs_field", "mbaff_pictures")),
+    "lossless_cif_predictive": (stream_p_features, dict(seed=58, lossless=2, t8x8=1, mb_w=22, mb_h=18, n=3), 3, ("mbs_bypass", "mbs_intra8x8")),
 }
 
 # name -> (generator, kwargs, pictures, statistics of the DECODER that must be non-zero in record mode, writer statistics that must be non-zero)

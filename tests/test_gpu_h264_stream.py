@@ -150,6 +150,25 @@ def test_mbaff_1080i():
             assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
 
 
+@pytest.mark.parametrize("name", sorted(D.LOSSLESS_CASES))
+def test_lossless_streams(name):
+    """The lossless transform bypass (see tests/test_h264_stream_cpu.py): intra macroblocks through the bypass form of the reconstruction
+    phases (DPCM under profile_idc 244), inter macroblocks through add_pixels4 / 8_clear records — executed on the device"""
+    gen, kw, npic, dstats = D.LOSSLESS_CASES[name]
+    aus, ws = gen(**kw)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == (npic // 2 if kw.get("fields") else npic)
+    make, read_back = _gpu_flush_factory()
+    got, st, counts = D.decode(aus, make_flush=make, read_back=read_back)
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
+    assert st["pictures"] == npic == counts["pictures"] and st["mbs_bypass"] > 0, (st, counts)
+    for k in dstats:
+        assert st[k] > 0, (k, st)
+    for i, (a, b) in enumerate(zip(plain, got)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+
+
 @pytest.mark.parametrize("name", sorted(D.ROUND6_CASES))
 def test_b_weighted_8x8_transform_and_422_streams(name):
     """Round 6 (see tests/test_h264_stream_cpu.py): B slices with spatial / temporal direct prediction, explicit and implicit weights, the 8x8

@@ -154,6 +154,48 @@ def test_an_mbaff_frame_above_8_bits_stays_on_the_c_path():
             assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
 
 
+@pytest.mark.parametrize("name", sorted(D.LOSSLESS_CASES))
+def test_lossless_streams(name):
+    """qpprime_y_zero_transform_bypass_flag = 1 (round 6; 8 bits, 4:2:0): macroblocks whose QP'Y is 0 are decoded with the transform bypassed
+    (hl_decode_mb()'s transform_bypass, h264_mb_template.c:51,190-221; h264_mb.c:614-772) — the residual added as samples (add_pixels4 /
+    8_clear, modulo 256), no DC transforms — among ordinary macroblocks of the same slice (the writer walks QP through 0 .. 6).  profile_idc
+    100: that is all; profile_idc 244 (High 4:4:4 Predictive): vertically / horizontally predicted Intra4x4, Intra8x8, Intra16x16 blocks and
+    chroma planes are DPCM-coded (pred4x4_add, pred8x8l_filter_add, pred16x16_add, pred8x8_add: h264pred_template.c:1067-1330), which
+    libffhip's packer turns into ordinary residuals of the V / H prediction by running sums.  I / P / B, fields, MBAFF, the 8x8 transform;
+    intra macroblocks through the reconstruction phases' bypass form, inter macroblocks through recorded add_pixels calls."""
+    gen, kw, npic, dstats = D.LOSSLESS_CASES[name]
+    aus, ws = gen(**kw)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == (npic // 2 if kw.get("fields") else npic)
+    rec, st, counts = D.decode(aus, make_flush=lambda base, size: D.cpu_flush(base))
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
+    assert st["pictures"] == npic == counts["pictures"], (st, counts)
+    for k in dstats:
+        assert st[k] > 0, (k, st)
+    assert st["mbs_bypass"] > st["mbs_hl"] // 3 and st["mbs_bypass"] < st["mbs_hl"], st      # both kinds of macroblock in the stream
+    assert counts["bypass_inter_blocks"] > 0, counts
+    if "mbaff" not in name:                                   # (an MBAFF frame's intra macroblocks live in its chains object)
+        assert counts["bypass_intra_mbs"] > 0 and (counts["dpcm_regions"] > 0) == (kw["lossless"] == 2), counts
+    assert len(rec) == len(plain)
+    for i, (a, b) in enumerate(zip(plain, rec)):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
+
+
+def test_a_lossless_stream_above_8_bits_stays_on_the_c_path():
+    """ff_h264_hip_picture_supported(): the transform bypass is taken at 8 bits (4:2:0 / 4:4:4) — a 10-bit lossless stream runs through the
+    reference's functions as a whole"""
+    aus, ws = D.stream_p_features(bit_depth=10, seed=59, lossless=2, n=3)
+    plain, st0, _ = D.decode(aus)
+    assert st0["damaged"] == 0 and len(plain) == 3
+    rec, st, counts = D.decode(aus, make_flush=lambda base, size: D.cpu_flush(base))
+    assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0, st
+    assert st["plain_pictures"] == 3 and st["pictures"] == 0, st
+    for a, b in zip(plain, rec):
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl])
+
+
 @pytest.mark.parametrize("name", sorted(D.ROUND6_CASES))
 def test_b_weighted_8x8_transform_and_422_streams(name):
     """Round 6: what the picture layer accepted with test-written macroblock state, now with the state the DECODER derives — B slices
