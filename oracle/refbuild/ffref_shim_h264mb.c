@@ -342,6 +342,18 @@ void FN(h264dec_set_field)(FFRefH264Dec *d, int picture_structure)
     d->sl->is_complex = picture_structure != PICT_FRAME;   /* h264_cavlc.c / h264_cabac.c: FRAME_MBAFF || picture_structure != PICT_FRAME */
 }
 
+/* The lossless transform bypass (round 6): profile_idc != 0 makes the stream one with qpprime_y_zero_transform_bypass_flag (sps->transform_bypass;
+ * profile_idc 244: the DPCM forms of vertically / horizontally predicted intra blocks as well); `on`: the macroblocks decoded from here on
+ * have QP'Y = 0 — hl_decode_mb()'s transform_bypass (h264_mb_template.c:51) — else 26 as before. */
+void FN(h264dec_set_bypass)(FFRefH264Dec *d, int profile_idc, int on)
+{
+    d->sps->transform_bypass = profile_idc != 0;
+    if (profile_idc)
+        d->sps->profile_idc = profile_idc;
+    d->sl->qscale = on ? 0 : 26;
+    d->h->x264_build = -1;          /* (no x264 SEI: Intra8x8 DPCM blocks start from the filtered edge, h264_mb.c:641-648) */
+}
+
 /* sl->ref_list[list][idx] as a FIELD of a frame whose planes are given (h264_refs.c pic_as_field(), :44-59): the bottom field starts one
  * line down, line sizes double, reference = the parity */
 void FN(h264dec_set_ref_field)(FFRefH264Dec *d, int list, int idx, uint8_t *y, uint8_t *cb, uint8_t *cr, int parity)

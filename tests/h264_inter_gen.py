@@ -49,6 +49,8 @@ class Dec:
             f("h264dec_filter_mb").argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3
         f("h264dec_set_field").argtypes = [C.c_void_p, C.c_int]
         f("h264dec_set_field").restype = None
+        f("h264dec_set_bypass").argtypes = [C.c_void_p, C.c_int, C.c_int]
+        f("h264dec_set_bypass").restype = None
         f("h264dec_set_ref_field").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         f("h264dec_set_ref_field").restype = None
         self.d = f("h264dec_open_fmt")(depth, mb_w, mb_h, linesize, uvlinesize, record, cfmt)
@@ -72,6 +74,10 @@ class Dec:
     def set_field(self, picture_structure):
         """1 top field, 2 bottom field (PAFF: every macroblock a field macroblock, mb_y = 2 * row + bottom), 3 back to frames"""
         self.fn("h264dec_set_field")(self.d, picture_structure)
+
+    def set_bypass(self, profile_idc, on):
+        """profile_idc != 0: the stream has qpprime_y_zero_transform_bypass_flag (244: with the DPCM forms); on: QP'Y = 0 from here on"""
+        self.fn("h264dec_set_bypass")(self.d, profile_idc, int(on))
 
     def set_ref_field(self, lst, idx, ptrs, parity):
         """the field of parity 1 (top) / 2 (bottom) of the frame whose planes are ptrs"""

@@ -36,7 +36,7 @@ def _libs():
     return ffi.ref(), C.CDLL(I.REF_HIP_SO)
 
 
-def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=1, bipred=True, batch=False, cfmt=1):
+def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=1, bipred=True, batch=False, cfmt=1, bypass=0):
     from ffmpeg_amd import h264
     torch = _torch()
     R, RH = _libs()
@@ -85,6 +85,10 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, seed, pictures=
         RH.ffrefhip_h264dec_record_begin(gpu.d, pic._p, *[t.data_ptr() for t in d_refs])
         for my in range(mb_h):
             for mx in range(mb_w):
+                if bypass:                                   # the lossless bypass: about half the macroblocks have QP'Y = 0
+                    on = rng.random() < 0.5
+                    cpu.set_bypass(bypass, on)
+                    gpu.set_bypass(bypass, on)
                 if rng.random() < p_intra:
                     d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=depth, cfmt=cfmt)
                     a, b = cpu.decode_intra(d), gpu.decode_intra(d)
@@ -230,6 +234,18 @@ def test_decoder_driven_pictures_444_flushed_together(depth, mb_w, mb_h, picture
     """several 4:4:4 pictures in one ffhip_h264_pictures_flush: 3 x pictures luma-only wavefronts per launch (13 I-pictures: 39 planes, two
     launches)"""
     _run_picture(depth, mb_w, mb_h, 2, 300, p_intra, 1, 4449100 + pictures, pictures=pictures, batch=True, cfmt=3)
+
+
+@pytest.mark.parametrize("mb_w,mb_h,nref,mvr,p_intra,weights,cfmt,profile,pictures,batch", [
+    (6, 4, 2, 40, .4, 0, 1, 100, 1, False), (11, 7, 3, 600, .3, 2, 1, 244, 1, False), (9, 5, 1, 64, 1.0, 0, 1, 244, 1, False),
+    (40, 22, 2, 120, .3, 0, 1, 244, 1, False), (6, 4, 2, 40, .4, 0, 3, 244, 1, False), (9, 5, 1, 64, 1.0, 0, 3, 244, 1, False),
+    (20, 11, 2, 200, .3, 1, 3, 100, 1, False), (8, 5, 2, 120, .5, 0, 0, 244, 1, False), (12, 7, 2, 100, .4, 0, 1, 244, 4, True)])
+def test_decoder_driven_lossless_picture(mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, profile, pictures, batch):
+    """The lossless transform bypass (round 6; 8 bits; see tests/test_h264_picture_cpu.py): about half the macroblocks of a picture with QP'Y = 0 in
+    a stream with sps->transform_bypass — 4:2:0, monochrome, 4:4:4; profile_idc 100 and 244 (DPCM) — the reference's ff_h264_hl_decode_mb()
+    over the recording members, the picture flushed on the device (alone, and four pictures together)"""
+    _run_picture(8, mb_w, mb_h, nref, mvr, p_intra, weights, seed=6000000 + mb_w * 31 + mvr + weights + cfmt * 7 + profile, cfmt=cfmt, bypass=profile,
+                 pictures=pictures, batch=batch)
 
 
 def test_picture_formats_refused_by_name():

@@ -66,7 +66,7 @@ def _cpu_flush(E, ls, planes, strides, refs):
     assert E.ffemul_h264_picture_flush(C.byref(ls), dp, st, rp) == 0
 
 
-def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed):
+def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed, bypass=0):
     _lib, L, R, RH, E = _env()
     rng = np.random.default_rng(seed)
     px, dt, top = (2, np.uint16, 1 << depth) if depth > 8 else (1, np.uint8, 256)
@@ -96,8 +96,14 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed):
     rec.set_cur([a.ctypes.data for a in got])               # record mode: addresses only, nothing is read or written through them
     pic = HostPicture(_lib, L, mb_w, mb_h, depth, cfmt)
     RH.ffrefhip_h264dec_record_begin(rec.d, pic.p, *[r.ctypes.data for r in refs])
+    nbyp = 0
     for my in range(mb_h):
         for mx in range(mb_w):
+            if bypass:                                       # the lossless bypass: about half the macroblocks have QP'Y = 0
+                on = rng.random() < 0.5
+                nbyp += on
+                cpu.set_bypass(bypass, on)
+                rec.set_bypass(bypass, on)
             if rng.random() < p_intra:
                 d = G.make_intra_mb(rng, mx, my, mb_w, mb_h, depth=depth, cfmt=cfmt)
                 a, b = cpu.decode_intra(d), rec.decode_intra(d)
@@ -108,6 +114,9 @@ def _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed):
     for pl in range(3):
         assert np.array_equal(got[pl], dst0[pl])             # recording touched no sample
     ls = pic.lists()
+    if bypass:
+        assert nbyp > 0 and (p_intra >= 1 or sum(ls.naddpx[pl][k] for pl in range(3) for k in range(2)) > 0)
+        assert cfmt != 3 or p_intra >= 1 or all(ls.naddpx[pl][0] for pl in range(3))     # 4:4:4: add_pixels on Cb / Cr too
     assert (ls.mb_w, ls.mb_h, ls.bit_depth, ls.chroma_format_idc) == (mb_w, mb_h, depth, cfmt or 1)       # monochrome: the 4:2:0 object
     if cfmt == 3:
         assert not any(ls.ncmc[c][s] for c in range(2) for s in range(3))
@@ -317,6 +326,18 @@ def test_recorded_monochrome_picture_executed_on_cpu_equals_reference(depth, mb_
     (DC_128 chroma prediction, chroma MC from mid-grey references, no chroma residual; I_PCM sets the chroma samples to 1 << (bit_depth - 1):
     h264_mb_template.c:112-148) — the same picture object, the recorder appending the mid-grey I_PCM fields"""
     _run_picture(depth, mb_w, mb_h, nref, mvr, p_intra, weights, 0, seed=4000000 + depth * 1000 + mb_w * 31 + mvr + weights)
+
+
+@pytest.mark.parametrize("mb_w,mb_h,nref,mvr,p_intra,weights,cfmt,profile", [
+    (6, 4, 2, 40, .4, 0, 1, 100), (6, 4, 2, 40, .4, 0, 1, 244), (9, 5, 1, 64, 1.0, 0, 1, 244), (11, 7, 3, 600, .3, 2, 1, 244),
+    (6, 4, 2, 40, .4, 0, 3, 244), (9, 5, 1, 64, 1.0, 0, 3, 244), (11, 7, 3, 600, .3, 1, 3, 100), (8, 5, 2, 120, .5, 0, 0, 244)])
+def test_recorded_lossless_picture_executed_on_cpu_equals_reference(mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, profile):
+    """The lossless transform bypass with test-written macroblock state (round 6; 8 bits): ff_h264_hl_decode_mb() compiled in place, about
+    half the macroblocks with QP'Y = 0 in a stream with sps->transform_bypass — 4:2:0, monochrome and 4:4:4 (hl_decode_mb_444: the luma
+    forms on all three planes: the case the whole-decoder streams of tests/test_h264_stream_cpu.py do not reach), profile_idc 100 (the
+    residual added as samples) and 244 (DPCM for vertically / horizontally predicted blocks: pred4x4_add, pred8x8l_filter_add,
+    pred16x16_add, pred8x8_add).  The recorder's lists on the CPU list executor == the reference's reconstruction."""
+    _run_picture(8, mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, seed=5000000 + mb_w * 31 + mvr + weights + cfmt * 7 + profile, bypass=profile)
 
 
 def test_recorder_refuses_what_stays_on_the_c_path_and_stays_refused():
