@@ -167,6 +167,7 @@ def lib():
         "ffhip_h264_picture_flush": (C.c_int, [vp, vp, vp, vp, vp]),
         "ffhip_h264_pictures_flush": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
         "ffhip_h264_mbaff_create": (C.c_int, [vp, C.c_int, C.c_int]),
+        "ffhip_h264_mbaff_create_fmt": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "ffhip_h264_mbaff_free": (None, [vp]),
         "ffhip_h264_mbaff_begin": (None, [vp]),
         "ffhip_h264_mbaff_intra_mb": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),

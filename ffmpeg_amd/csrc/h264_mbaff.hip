@@ -43,6 +43,7 @@
 
 struct FFHipH264Mbaff {
     int mb_w, mb_h;                              /* the frame's macroblocks; mb_h even */
+    int bd = 8;                                  /* 8, or 9 / 10 / 12 / 14: uint16_t samples, int32_t coefficients */
     int device;
     std::vector<FFHipH264IntraMB> recs;          /* intra macroblocks in decoding order: pair rows, pairs left to right, top then bottom */
     std::vector<uint32_t> geo;                   /* per record: mb_x | mb_y (frame row) << 12 | field << 24 */
@@ -68,8 +69,17 @@ static void mbaff_settle(FFHipH264Mbaff *m)
 
 extern "C" int ffhip_h264_mbaff_create(FFHipH264Mbaff **m, int mb_w, int mb_h)
 {
+    return ffhip_h264_mbaff_create_fmt(m, mb_w, mb_h, 8);
+}
+
+extern "C" int ffhip_h264_mbaff_create_fmt(FFHipH264Mbaff **m, int mb_w, int mb_h, int bit_depth)
+{
     if (!m || mb_w <= 0 || mb_h <= 0 || (mb_h & 1) || mb_w > 4095 || mb_h > 4095)
         return FFHIP_EINVAL;
+    if (bit_depth != 8 && bit_depth != 9 && bit_depth != 10 && bit_depth != 12 && bit_depth != 14) {
+        ffhip_set_error("ffhip_h264_mbaff_create_fmt: bit_depth %d (8, 9, 10, 12, 14)", bit_depth);
+        return FFHIP_EINVAL;
+    }
     if (mb_h / 2 > FFHIP_PROGRESS_SLOT_INTS / 3) {
         ffhip_set_error("ffhip_h264_mbaff: %d macroblock pair rows exceed the progress pool", mb_h / 2);
         return FFHIP_EINVAL;
@@ -79,10 +89,12 @@ extern "C" int ffhip_h264_mbaff_create(FFHipH264Mbaff **m, int mb_w, int mb_h)
         return FFHIP_ENOMEM;
     p->mb_w = mb_w;
     p->mb_h = mb_h;
+    p->bd = bit_depth;
     if (hipGetDevice(&p->device) != hipSuccess) {
         (void)hipGetLastError();
         p->device = -1; /* recording needs no device; flush does */
     }
+    ffhip_h264_mbaff_begin(p); /* (the per-pair tables exist from here on: lists() / flush() of an object nothing was recorded into are empty, not wild) */
     *m = p;
     return 0;
 }
@@ -139,9 +151,9 @@ extern "C" int ffhip_h264_mbaff_intra_mb(FFHipH264Mbaff *m, const FFHipH264Intra
     }
     FFHipH264IntraMB r = *desc;
     const size_t at = m->coefs.size();
-    m->coefs.resize(at + 400);
+    m->coefs.resize(at + 832); /* (a run: at most 391 int16 at 8 bits, 2 x (384 + 16) above, from a 16-byte boundary) */
     int32_t n = (int32_t)at;
-    const int rc = ffhip_h264_intra_pack(&r, non_zero_count_cache, mb, mb_luma_dc, pcm, m->coefs.data(), &n, (int32_t)m->coefs.size());
+    const int rc = ffhip_h264_intra_pack_hbd(m->bd, &r, non_zero_count_cache, mb, mb_luma_dc, pcm, m->coefs.data(), &n, (int32_t)m->coefs.size());
     if (rc < 0) {
         m->coefs.resize(at);
         return rc;
@@ -202,6 +214,7 @@ extern "C" int ffhip_h264_mbaff_lists(FFHipH264Mbaff *m, FFHipH264MbaffLists *ou
     memset(out, 0, sizeof(*out));
     out->mb_w = m->mb_w;
     out->mb_h = m->mb_h;
+    out->bit_depth = m->bd;
     out->recs = m->recs.data();
     out->geo = m->geo.data();
     out->coefs = m->coefs.data();
@@ -243,6 +256,19 @@ __device__ __forceinline__ void mb_st(uint8_t *p, uint32_t v)
 {
     __hip_atomic_store(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+/* four samples: a dword at 8 bits, two above */
+template <typename PIX> struct MbQuad { typedef uint32_t T; };
+template <> struct MbQuad<uint16_t> { typedef uint64_t T; };
+template <typename Q>
+__device__ __forceinline__ Q mb_ldq(const uint8_t *p)
+{
+    return __hip_atomic_load(reinterpret_cast<const Q *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename Q>
+__device__ __forceinline__ void mb_stq(uint8_t *p, Q v)
+{
+    __hip_atomic_store(reinterpret_cast<Q *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool mb_wait(const int *counter, int want, int *fail, int lane)
 {
     int spins = 0;
@@ -272,12 +298,17 @@ __device__ __forceinline__ void mb_publish(int *counter, int value, int lane)
 }
 } // namespace
 
-/* one wave per pair row; progress[p] = "every pair left of this one is reconstructed" */
+/* one wave per pair row; progress[p] = "every pair left of this one is reconstructed".  PIX = uint8_t, or uint16_t above 8 bits (strides and
+ * plane pointers in bytes, int32 coefficients: h264_intra_mb.h ImbCoef) */
+template <typename PIX>
 __global__ __launch_bounds__(64) void k_h264_mbaff_intra(uint8_t *py, uint8_t *pcb, uint8_t *pcr, ptrdiff_t sy, ptrdiff_t sc, int mb_w, int mb_h,
                                                          const FFHipH264IntraMB *recs, const uint32_t *geo, const int32_t *row_start,
-                                                         const int16_t *coefs, int *progress, int *fail)
+                                                         const int16_t *coefs, int *progress, int *fail, int maxv)
 {
-    __shared__ __align__(16) ImbTileT<uint8_t> T;
+    typedef typename MbQuad<PIX>::T Q;
+    typedef typename ImbCoef<PIX>::T CF;
+    constexpr int PS = (int)sizeof(PIX);
+    __shared__ __align__(16) ImbTileT<PIX> T;
     __shared__ __align__(16) FFHipH264IntraMB R;
     __shared__ uint32_t p4tab[IMB_TABS];
     const int p = (int)blockIdx.x, lane = (int)threadIdx.x;
@@ -302,45 +333,45 @@ __global__ __launch_bounds__(64) void k_h264_mbaff_intra(uint8_t *py, uint8_t *p
         const int step = field ? 2 : 1;
         const int line0 = field ? 32 * p + (my & 1) : 16 * my;
         const ptrdiff_t ysy = sy * step, csc = sc * step;
-        uint8_t *ymb = py + (ptrdiff_t)line0 * sy + mx * 16;
+        uint8_t *ymb = py + (ptrdiff_t)line0 * sy + mx * 16 * PS;
         const int cline0 = field ? 16 * p + (my & 1) : 8 * my;
-        uint8_t *cmb[2] = { pcb + (ptrdiff_t)cline0 * sc + mx * 8, pcr + (ptrdiff_t)cline0 * sc + mx * 8 };
+        uint8_t *cmb[2] = { pcb + (ptrdiff_t)cline0 * sc + mx * 8 * PS, pcr + (ptrdiff_t)cline0 * sc + mx * 8 * PS };
         const bool has_l = mx > 0, has_t = line0 - step >= 0, has_r = mx + 1 < mb_w;
         /* the tile's neighbours, a quad per lane (what lies outside the picture reads as 0): lanes 0..7 the luma row above over columns
          * -4 .. 27, 8..23 the luma column to the left, 24..29 the chroma rows above (columns -4 .. 7), 30..45 the chroma columns to the left */
         {
-            uint32_t v = 0;
+            Q v = 0;
             if (lane < 8) {
                 const int c = 4 * lane - 4;
                 if (has_t && (c >= 0 || has_l) && (c < 16 || has_r))
-                    v = mb_ld(ymb - ysy + c);
-                *reinterpret_cast<uint32_t *>(&T.y[imb_yi(-1, c)]) = v;
+                    v = mb_ldq<Q>(ymb - ysy + c * PS);
+                *reinterpret_cast<Q *>(&T.y[imb_yi(-1, c)]) = v;
             } else if (lane < 24) {
                 const int r = lane - 8;
                 if (has_l)
-                    v = mb_ld(ymb + (ptrdiff_t)r * ysy - 4);
-                *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, -4)]) = v;
-                *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, 16)]) = 0;
-                *reinterpret_cast<uint32_t *>(&T.y[imb_yi(r, 20)]) = 0;
+                    v = mb_ldq<Q>(ymb + (ptrdiff_t)r * ysy - 4 * PS);
+                *reinterpret_cast<Q *>(&T.y[imb_yi(r, -4)]) = v;
+                *reinterpret_cast<Q *>(&T.y[imb_yi(r, 16)]) = 0;
+                *reinterpret_cast<Q *>(&T.y[imb_yi(r, 20)]) = 0;
             } else if (lane < 30) {
                 const int pl = (lane - 24) / 3, c = 4 * ((lane - 24) % 3) - 4;
                 if (has_t && (c >= 0 || has_l))
-                    v = mb_ld(cmb[pl] - csc + c);
-                *reinterpret_cast<uint32_t *>(&T.c[pl][imb_ci(-1, c)]) = v;
+                    v = mb_ldq<Q>(cmb[pl] - csc + c * PS);
+                *reinterpret_cast<Q *>(&T.c[pl][imb_ci(-1, c)]) = v;
             } else if (lane < 46) {
                 const int pl = (lane - 30) >> 3, r = (lane - 30) & 7;
                 if (has_l)
-                    v = mb_ld(cmb[pl] + (ptrdiff_t)r * csc - 4);
-                *reinterpret_cast<uint32_t *>(&T.c[pl][imb_ci(r, -4)]) = v;
+                    v = mb_ldq<Q>(cmb[pl] + (ptrdiff_t)r * csc - 4 * PS);
+                *reinterpret_cast<Q *>(&T.c[pl][imb_ci(r, -4)]) = v;
             }
         }
         mb_wave_sync();
-        imb_reconstruct<uint8_t>(X, T, R, coefs + R.coef, p4tab, 255, 3);
+        imb_reconstruct<PIX>(X, T, R, reinterpret_cast<const CF *>(coefs + R.coef), p4tab, maxv, 3);
         /* the macroblock back into the picture: 64 luma quads, 32 chroma quads */
-        mb_st(ymb + (ptrdiff_t)(lane >> 2) * ysy + 4 * (lane & 3), *reinterpret_cast<const uint32_t *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]));
+        mb_stq<Q>(ymb + (ptrdiff_t)(lane >> 2) * ysy + 4 * (lane & 3) * PS, *reinterpret_cast<const Q *>(&T.y[imb_yi(lane >> 2, 4 * (lane & 3))]));
         if (lane < 32) {
             const int pl = lane >> 4, r = (lane >> 1) & 7, c = 4 * (lane & 1);
-            mb_st(cmb[pl] + (ptrdiff_t)r * csc + c, *reinterpret_cast<const uint32_t *>(&T.c[pl][imb_ci(r, c)]));
+            mb_stq<Q>(cmb[pl] + (ptrdiff_t)r * csc + c * PS, *reinterpret_cast<const Q *>(&T.c[pl][imb_ci(r, c)]));
         }
         /* the next record: the other macroblock of this pair (the pair is not finished), or a pair further right */
         const int nx = k + 1 < kend ? (int)(geo[k + 1] & 0xFFF) : mb_w;
@@ -502,9 +533,117 @@ __global__ __launch_bounds__(64) void k_h264_mbaff_deblock(MbaffLfArgs A, int *p
     }
 }
 
+/* The same above 8 bits: uint16_t samples (a dword = two of them), alpha / beta / tc0 scaled to the depth (h264dsp_template.c:104-330 with
+ * BIT_DEPTH > 8), the filters' clips at (1 << depth) - 1 */
+__global__ __launch_bounds__(64) void k_h264_mbaff_deblock_hbd(MbaffLfArgs A, int *progress_all, int *fail, int bd)
+{
+    __shared__ __align__(16) uint16_t tile[40 * 20];
+    __shared__ __align__(16) uint32_t C[64 * 3];
+    const int p = (int)blockIdx.x, pl = (int)blockIdx.y, lane = (int)threadIdx.x;
+    MBAFF_TILE(pl != 0, W, H, AB, TP);
+    const int TD = TP / 2, TL = H + AB, ND = TL * TD; /* dwords per tile line (two samples each), lines, dwords (400 / 120) */
+    const int sh = bd - 8, maxv = (1 << bd) - 1;
+    uint8_t *const plane = A.plane[pl];
+    const ptrdiff_t stride = A.stride[pl];
+    const MbaffDevCall *const calls = A.calls[pl];
+    const int32_t *const pair_end = A.pair_end[pl];
+    const int mb_w = A.mb_w;
+    int *const progress = progress_all + pl * A.prow;
+    if (!calls)
+        return;
+    int at = p > 0 ? pair_end[(size_t)p * mb_w - 1] : 0;
+    for (int x = 0; x < mb_w; x++) {
+        const int end = pair_end[(size_t)p * mb_w + x];
+        if (at >= end) {
+            if (lane == 0)
+                __hip_atomic_store(&progress[p], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        int n = min(64, end - at);
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
+        if (lane < n) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(calls + at + lane);
+            c0 = src[0]; c1 = src[1]; c2 = src[2];
+        }
+        if (p > 0 && !mb_wait(&progress[p - 1], min(x + 2, mb_w), fail, lane))
+            return;
+        const int line0 = H * p - AB, col0 = W * x - 4;
+        uint32_t orig[7];
+        bool have[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const int d = lane + 64 * k, tl = d / TD, tc = d - tl * TD;
+            have[k] = d < ND && line0 + tl >= 0 && col0 + 2 * tc >= 0;
+            orig[k] = 0;
+            if (have[k])
+                orig[k] = mb_ld(plane + (ptrdiff_t)(line0 + tl) * stride + 2 * (col0 + 2 * tc));
+        }
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            if (lane + 64 * k < ND)
+                reinterpret_cast<uint32_t *>(tile)[lane + 64 * k] = orig[k];
+        for (;;) {
+            if (lane < n) {
+                C[3 * lane] = c0; C[3 * lane + 1] = c1; C[3 * lane + 2] = c2;
+            }
+            mb_wave_sync();
+            for (int i = 0; i < n; i++) {
+                const uint32_t w0 = C[3 * i], w1 = C[3 * i + 1];
+                const int toff = (int)(w0 & 0xFFFF), kf = (int)(w0 >> 16) & 255, alpha = (int)(w0 >> 24) << sh, beta = (int)(w1 & 255) << sh;
+                const bool chroma = kf & 2, intra = kf & 4, hfilt = kf & 1;
+                const int half = (kf >> 4) & 1;
+                const int step = (kf & 8) ? 2 * TP : TP; /* samples from a line of the call to the next */
+                const int cls = (chroma ? 1 : 0) + (intra ? 2 : 0);
+                const int8_t *tc0 = reinterpret_cast<const int8_t *>(&C[3 * i + 2]);
+                const int nl = hfilt ? (chroma ? 8 : 16) >> half : (chroma ? 8 : 16);
+                const int per = hfilt ? (chroma ? 2 : 4) >> half : (chroma ? 2 : 4);
+                if (lane < nl) {
+                    /* h_: the line = row `lane`, its samples one apart; v_: the line = column `lane`, its samples a tile line (or two) apart */
+                    uint16_t *c = hfilt ? tile + toff + lane * step : tile + toff + lane;
+                    const int xs = hfilt ? 1 : step;
+                    const int t0 = intra ? 0 : (int)tc0[lane / per];
+                    const int tcs = chroma ? (int)(((uint32_t)(t0 - 1) << sh) + 1u) : t0 * (1 << sh);
+                    LfLine v;
+                    v.p1 = c[-2 * xs]; v.p0 = c[-xs]; v.q0 = c[0]; v.q1 = c[xs];
+                    v.p3 = v.p2 = v.q2 = v.q3 = 0;
+                    if (!chroma) {
+                        v.p3 = c[-4 * xs]; v.p2 = c[-3 * xs]; v.q2 = c[2 * xs]; v.q3 = c[3 * xs];
+                    }
+                    const int m = lf_line(v, cls, alpha, beta, tcs, maxv);
+                    if (m & 1)  c[-3 * xs] = (uint16_t)v.p2;
+                    if (m & 2)  c[-2 * xs] = (uint16_t)v.p1;
+                    if (m & 4)  c[-xs] = (uint16_t)v.p0;
+                    if (m & 8)  c[0] = (uint16_t)v.q0;
+                    if (m & 16) c[xs] = (uint16_t)v.q1;
+                    if (m & 32) c[2 * xs] = (uint16_t)v.q2;
+                }
+                mb_wave_sync();
+            }
+            at += n;
+            if (at >= end)
+                break;
+            n = min(64, end - at);
+            if (lane < n) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(calls + at + lane);
+                c0 = src[0]; c1 = src[1]; c2 = src[2];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const int d = lane + 64 * k, tl = d / TD, tc = d - tl * TD;
+            if (have[k]) {
+                const uint32_t cur = reinterpret_cast<const uint32_t *>(tile)[d];
+                if (cur != orig[k])
+                    mb_st(plane + (ptrdiff_t)(line0 + tl) * stride + 2 * (col0 + 2 * tc), cur);
+            }
+        }
+        mb_publish(&progress[p], x + 1, lane);
+    }
+}
+
 /* FFHipH264Edge -> MbaffDevCall for plane pl at line size `stride`: the call of pair (x, p) placed in that pair's tile.  false: the call
  * reaches outside it (not a call ff_h264_filter_mb() issues for a macroblock of that pair). */
-static bool mbaff_place_call(const FFHipH264Edge &e, int pl, int stride, int x, int p, MbaffDevCall *out)
+static bool mbaff_place_call(const FFHipH264Edge &e, int pl, int stride, int ps /* bytes per sample */, int x, int p, MbaffDevCall *out)
 {
     MBAFF_TILE(pl != 0, W, H, AB, TP);
     const int TL = H + AB;
@@ -512,8 +651,10 @@ static bool mbaff_place_call(const FFHipH264Edge &e, int pl, int stride, int x, 
     const int stl = (e.pad & FFHIP_H264_LF_CALL_FIELD) ? 2 : 1;
     if (e.offset < 0 || chroma != (pl != 0))
         return false;
-    const int line = e.offset / stride, col = e.offset - line * stride;
-    const int tl = line - (H * p - AB), tc = col - (W * x - 4);
+    const int line = e.offset / stride, colb = e.offset - line * stride;
+    if (colb % (4 * ps))
+        return false;
+    const int tl = line - (H * p - AB), tc = colb / ps - (W * x - 4); /* tile line, tile column (samples) */
     if (tc < 4 || (tc & 3))
         return false;
     if (hfilt) {
@@ -540,8 +681,8 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         return FFHIP_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     for (int pl = 0; pl < 3; pl++)
-        if (((uintptr_t)dst[pl] | (size_t)stride[pl]) & 3 || stride[pl] <= 0) {
-            ffhip_set_error("ffhip_h264_mbaff_flush: planes and line sizes must be 4-byte aligned and positive");
+        if (((uintptr_t)dst[pl] | (size_t)stride[pl]) & (m->bd > 8 ? 7 : 3) || stride[pl] <= 0) {
+            ffhip_set_error("ffhip_h264_mbaff_flush: planes and line sizes must be aligned to four samples and positive");
             return FFHIP_EINVAL;
         }
     if (stride[1] != stride[2]) {
@@ -558,7 +699,7 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         size_t at = 0;
         for (int q = 0; q < npairs; q++)
             for (; at < (size_t)m->pair_end[pl][(size_t)q]; at++)
-                if (!mbaff_place_call(m->calls[pl][at], pl, stride[pl], q % m->mb_w, q / m->mb_w, &dcalls[pl][at])) {
+                if (!mbaff_place_call(m->calls[pl][at], pl, stride[pl], m->bd > 8 ? 2 : 1, q % m->mb_w, q / m->mb_w, &dcalls[pl][at])) {
                     ffhip_set_error("ffhip_h264_mbaff_flush: plane %d call %zu (offset %d, kind %d, flags %d) lies outside macroblock pair (%d, %d)", pl, at,
                                     m->calls[pl][at].offset, m->calls[pl][at].kind, m->calls[pl][at].pad, q % m->mb_w, q / m->mb_w);
                     return m->last_status = FFHIP_EINVAL;
@@ -623,9 +764,15 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         rc = ffhip_progress_acquire(prow, stream, &ps);
         if (rc < 0)
             return leave(rc);
-        hipLaunchKernelGGL(k_h264_mbaff_intra, dim3(prow), dim3(64), 0, stream, dst[0], dst[1], dst[2], (ptrdiff_t)stride[0], (ptrdiff_t)stride[1], m->mb_w,
-                           m->mb_h, reinterpret_cast<const FFHipH264IntraMB *>(b + off[0]), reinterpret_cast<const uint32_t *>(b + off[1]),
-                           reinterpret_cast<const int32_t *>(b + off[3]), reinterpret_cast<const int16_t *>(b + off[2]), ps.prog, ps.fail);
+        if (m->bd == 8)
+            hipLaunchKernelGGL(k_h264_mbaff_intra<uint8_t>, dim3(prow), dim3(64), 0, stream, dst[0], dst[1], dst[2], (ptrdiff_t)stride[0], (ptrdiff_t)stride[1],
+                               m->mb_w, m->mb_h, reinterpret_cast<const FFHipH264IntraMB *>(b + off[0]), reinterpret_cast<const uint32_t *>(b + off[1]),
+                               reinterpret_cast<const int32_t *>(b + off[3]), reinterpret_cast<const int16_t *>(b + off[2]), ps.prog, ps.fail, 255);
+        else
+            hipLaunchKernelGGL(k_h264_mbaff_intra<uint16_t>, dim3(prow), dim3(64), 0, stream, dst[0], dst[1], dst[2], (ptrdiff_t)stride[0],
+                               (ptrdiff_t)stride[1], m->mb_w, m->mb_h, reinterpret_cast<const FFHipH264IntraMB *>(b + off[0]),
+                               reinterpret_cast<const uint32_t *>(b + off[1]), reinterpret_cast<const int32_t *>(b + off[3]),
+                               reinterpret_cast<const int16_t *>(b + off[2]), ps.prog, ps.fail, (1 << m->bd) - 1);
         const hipError_t e = hipGetLastError();
         const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
         if (e != hipSuccess) {
@@ -649,7 +796,10 @@ extern "C" int ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], 
         rc = ffhip_progress_acquire(3 * prow, stream, &ps);
         if (rc < 0)
             return leave(rc);
-        hipLaunchKernelGGL(k_h264_mbaff_deblock, dim3(prow, 3), dim3(64), 0, stream, A, ps.prog, ps.fail);
+        if (m->bd == 8)
+            hipLaunchKernelGGL(k_h264_mbaff_deblock, dim3(prow, 3), dim3(64), 0, stream, A, ps.prog, ps.fail);
+        else
+            hipLaunchKernelGGL(k_h264_mbaff_deblock_hbd, dim3(prow, 3), dim3(64), 0, stream, A, ps.prog, ps.fail, m->bd);
         const hipError_t e = hipGetLastError();
         const int r2 = ffhip_progress_release(&ps, stream, e == hipSuccess);
         if (e != hipSuccess) {

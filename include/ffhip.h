@@ -925,7 +925,7 @@ int  ffhip_h264_picture_lists(const FFHipH264Picture *p, FFHipH264PictureLists *
 /** One host-to-device copy of everything recorded since begin(), then the launches; asynchronous on `stream`. */
 int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const int stride[3], const uint8_t *const ref[3],
                               void *stream);
-/* ---- MBAFF frames (round 6): mb_adaptive_frame_field_flag, 8 bits, 4:2:0 ------------------------------------------------------------
+/* ---- MBAFF frames (round 6): mb_adaptive_frame_field_flag, 4:2:0, 8 - 14 bits ------------------------------------------------------------
  * A frame whose macroblock pairs mix frame and field macroblocks (libavcodec/h264_mb_template.c:61-78, h264_loopfilter.c:494-560,716-760)
  * is recorded into FOUR objects over the same planes (integration/avcodec_h264_picture_hip.c does it):
  *   - three ordinary FFHipH264Picture objects for the INTER macroblocks' prediction, weight and residual lists: the frame macroblocks
@@ -937,8 +937,10 @@ int  ffhip_h264_picture_flush(FFHipH264Picture *p, uint8_t *const dst[3], const 
  *     ff_h264_filter_mb() issues them.  ffhip_h264_mbaff_flush() runs the intra reconstruction, then the filter, and goes LAST.
  */
 typedef struct FFHipH264Mbaff FFHipH264Mbaff;
-/** mb_w x mb_h: the frame's macroblocks (mb_h even).  FFHIP_EINVAL otherwise. */
+/** mb_w x mb_h: the frame's macroblocks (mb_h even).  FFHIP_EINVAL otherwise.  _fmt: bit_depth 8 / 9 / 10 / 12 / 14 (above 8: uint16_t samples,
+ *  the decoder's arrays as they stand at that depth — see ffhip_h264_intra_pack_hbd()); 4:2:0 at every depth. */
 int  ffhip_h264_mbaff_create(FFHipH264Mbaff **m, int mb_w, int mb_h);
+int  ffhip_h264_mbaff_create_fmt(FFHipH264Mbaff **m, int mb_w, int mb_h, int bit_depth);
 void ffhip_h264_mbaff_free(FFHipH264Mbaff **m);
 void ffhip_h264_mbaff_begin(FFHipH264Mbaff *m);
 /** One intra macroblock, as ffhip_h264_picture_intra_mb(): desc->mb_x, desc->mb_y = the macroblock's position in the FRAME (mb_y odd: the
@@ -964,12 +966,14 @@ typedef struct FFHipH264MbaffLists {
     const FFHipH264Edge *calls[3];  /* per plane: the calls in order */
     const int32_t *pair_end[3];     /* per plane and pair (row-major, mb_w x mb_h / 2): one past the pair's last call */
     int32_t ncalls[3];
+    int bit_depth;
 } FFHipH264MbaffLists;
 int  ffhip_h264_mbaff_lists(FFHipH264Mbaff *m, FFHipH264MbaffLists *out);
 /** The intra reconstruction (one wave per pair row, the tile and phases of every other picture's intra macroblocks at the
  *  macroblock's own line step), then the recorded filter calls in order (one wave per pair row and plane; pair x of row p after pair x + 1
  *  of row p - 1).  dst[] / stride[]: the FRAME's planes and line sizes (4-byte aligned; Cb and Cr share a line size).  Call after the
- *  three inter objects' flushes on the same stream.  Asynchronous on `stream` once the lists are uploaded. */
+ *  three inter objects' flushes on the same stream.  Above 8 bits planes and line sizes are 8-byte aligned.  Asynchronous on `stream` once the
+ *  lists are uploaded. */
 int  ffhip_h264_mbaff_flush(FFHipH264Mbaff *m, uint8_t *const dst[3], const int stride[3], void *stream);
 
 /** n picture objects (one geometry, depth and device; the pictures a decoder's frame threads hold at once) flushed TOGETHER (round 4):

@@ -31,7 +31,7 @@
  * h264_refs.c:39-48); the libffhip picture object is made for the field and never learns the difference.  CAVLC / CABAC alike (entropy
  * decoding stays on the CPU and fills sl-> as ever).
  *
- * MBAFF frames (frame and field macroblock pairs mixed in one picture; round 6, 8 bits, 4:2:0).  A field macroblock of a pair IS the field
+ * MBAFF frames (frame and field macroblock pairs mixed in one picture; round 6; 4:2:0, 8 - 14 bits).  A field macroblock of a pair IS the field
  * case, per macroblock: hl_decode_mb() addresses it at twice the line size from the pair's first or second line (h264_mb_template.c:65-73)
  * and reads its references through the field entries of the list (ref_list[l][16 + 2 i + parity], h264_refs.c h264_fill_mbaff_ref_list; the
  * cache rewritten at h264_mb_template.c:74-91).  The recorder therefore keeps THREE picture objects over the same planes — the frame
@@ -474,7 +474,7 @@ av_cold void ff_h264_hip_recorder_install(H264Context *h)
     h->vdsp.prefetch = rec_prefetch;
 }
 
-/* What keeps a whole picture on the C path, known before its first macroblock (MBAFF frames above 8 bits or not 4:2:0; lossless streams —
+/* What keeps a whole picture on the C path, known before its first macroblock (MBAFF frames that are not 4:2:0; lossless streams —
  * a qpprime_y_zero_transform_bypass macroblock may turn up at any macroblock — above 8 bits or at 4:2:2): a caller asks this BEFORE it
  * begins to record — once macroblocks have been recorded their coefficients are consumed and the pixels exist only as records, there is no
  * way back. */
@@ -485,7 +485,7 @@ int ff_h264_hip_picture_supported(const H264Context *h)
     /* (streams of x264 before build 151 predict Intra8x8 DPCM blocks from the UNFILTERED edge: h264_mb.c:641-643; libffhip has the filtered form) */
     if (h->ps.sps->transform_bypass && h->ps.sps->profile_idc == 244 && (unsigned)h->x264_build < 151U)
         return 0;
-    return !FRAME_MBAFF(h) || (h->ps.sps->bit_depth_luma == 8 && h->ps.sps->chroma_format_idc == 1 && !(h->mb_height & 1));
+    return !FRAME_MBAFF(h) || (h->ps.sps->chroma_format_idc == 1 && !(h->mb_height & 1));
 }
 
 void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, const H264Context *h, const H264SliceContext *sl,
@@ -525,7 +525,7 @@ void ff_h264_hip_recorder_begin_mbaff(FFHipH264Recorder *r, FFHipH264Picture *fr
     memset(r, 0, sizeof(*r));
     r->mbaff = 1;
     r->chains = chains;
-    r->pixel_shift = 0;
+    r->pixel_shift = h->pixel_shift;
     r->cfmt = 1;
     if (!ff_h264_hip_picture_supported(h) || !FRAME_MBAFF(h))
         r->error = FFHIP_ENOSYS;
@@ -649,7 +649,7 @@ int ff_h264_hip_filter_mb(FFHipH264Recorder *r, const H264Context *h, H264SliceC
         for (int pl = 0; pl < 3; pl++) {
             const ptrdiff_t ls = r->linesize[pl];
             const int bh = pl ? 8 : 16;
-            img[pl] = (uint8_t *)r->cur[pl] + (ptrdiff_t)mb_x * bh + (ptrdiff_t)mb_y * bh * ls - (field && (mb_y & 1) ? (bh - 1) * ls : 0);
+            img[pl] = (uint8_t *)r->cur[pl] + (((ptrdiff_t)mb_x * bh) << r->pixel_shift) + (ptrdiff_t)mb_y * bh * ls - (field && (mb_y & 1) ? (bh - 1) * ls : 0);
         }
         memset(&cur_edges, 0, sizeof(cur_edges));
         cur_edges.mb_x = mb_x;

@@ -48,7 +48,7 @@ typedef struct FFHipH264Recorder {
         FFHipChromaBlock c;
     } pend[8];
     int npend;
-    /* an MBAFF frame (round 6; 8 bits, 4:2:0): FOUR objects over the same planes.  view[0] the frame macroblocks, view[1] / view[2] the top- /
+    /* an MBAFF frame (round 6; 4:2:0): FOUR objects over the same planes.  view[0] the frame macroblocks, view[1] / view[2] the top- /
      * bottom-field macroblocks (half the rows at twice the line size; the bottom one a frame line further down) — the object a macroblock is
      * recorded into is chosen per macroblock and copied into pic / cur / linesize / rows above, so everything that serves a frame or a
      * field picture serves a macroblock of either kind; `chains` takes the intra macroblocks and the loop filter's calls */
@@ -69,7 +69,7 @@ typedef struct FFHipH264Recorder {
 void ff_h264_hip_recorder_install(H264Context *h);
 
 /* 1 when the picture the decoder is about to decode can be recorded as a whole: a lossless (transform-bypass) stream only at 8 bits, 4:2:0 /
- * 4:4:4; an MBAFF frame (FRAME_MBAFF(h): begin it with ff_h264_hip_recorder_begin_mbaff()) only at 8 bits, 4:2:0.  Ask
+ * 4:4:4; an MBAFF frame (FRAME_MBAFF(h): begin it with ff_h264_hip_recorder_begin_mbaff()) only at 4:2:0.  Ask
  * before ff_h264_hip_recorder_begin(): a refusal in the middle of a picture cannot be undone (the per-macroblock calls still return
  * FFHIP_ENOSYS for such macroblocks, as a guard). */
 int ff_h264_hip_picture_supported(const H264Context *h);
@@ -82,7 +82,8 @@ void ff_h264_hip_recorder_begin(FFHipH264Recorder *r, FFHipH264Picture *pic, con
                                 const uint8_t *const ref_base[3]);
 
 /* A new MBAFF frame (FRAME_MBAFF(h)): frame_mbs / top_mbs / bottom_mbs are picture objects made for h->mb_width x h->mb_height and (the two
- * field ones) h->mb_width x h->mb_height / 2, `chains` a FFHipH264Mbaff made for h->mb_width x h->mb_height; all four have had begin() called.
+ * field ones) h->mb_width x h->mb_height / 2, `chains` a FFHipH264Mbaff made for h->mb_width x h->mb_height, all at the stream's bit depth; all
+ * four have had begin() called.
  * When the frame is complete: ffhip_h264_picture_flush() of the three — frame_mbs with data[] and the frame's line sizes, top_mbs with data[]
  * and TWICE the line sizes, bottom_mbs with data[] + one line and twice the line sizes — then ffhip_h264_mbaff_flush(chains, data[], the
  * frame's line sizes), on one stream. */

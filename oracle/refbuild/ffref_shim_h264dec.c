@@ -191,9 +191,9 @@ static int begin_picture(FFRefH264Stream *s, const H264Context *h, H264SliceCont
     r = ffhip_h264_picture_create_fmt(&s->pic, h->mb_width, h->mb_height >> field, sps->bit_depth_luma, sps->chroma_format_idc ? sps->chroma_format_idc : 1);
     if (r >= 0 && FRAME_MBAFF(h)) {
         for (int v = 0; v < 2 && r >= 0; v++)
-            r = ffhip_h264_picture_create_fmt(&s->fpic[v], h->mb_width, h->mb_height / 2, 8, 1);
+            r = ffhip_h264_picture_create_fmt(&s->fpic[v], h->mb_width, h->mb_height / 2, sps->bit_depth_luma, 1);
         if (r >= 0)
-            r = ffhip_h264_mbaff_create(&s->chains, h->mb_width, h->mb_height);
+            r = ffhip_h264_mbaff_create_fmt(&s->chains, h->mb_width, h->mb_height, sps->bit_depth_luma);
         if (r < 0) {
             ffhip_h264_picture_free(&s->pic);
             ffhip_h264_picture_free(&s->fpic[0]);

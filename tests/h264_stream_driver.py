@@ -62,7 +62,8 @@ class Lists(C.Structure):                       # == FFHipH264PictureLists (incl
 
 class MbaffLists(C.Structure):                  # == FFHipH264MbaffLists (include/ffhip.h)
     _fields_ = [("mb_w", C.c_int), ("mb_h", C.c_int), ("recs", C.c_void_p), ("geo", C.c_void_p), ("coefs", C.c_void_p), ("intra_row", C.c_void_p),
-                ("nrecs", C.c_int32), ("ncoefs", C.c_int32), ("calls", C.c_void_p * 3), ("pair_end", C.c_void_p * 3), ("ncalls", C.c_int32 * 3)]
+                ("nrecs", C.c_int32), ("ncoefs", C.c_int32), ("calls", C.c_void_p * 3), ("pair_end", C.c_void_p * 3), ("ncalls", C.c_int32 * 3),
+                ("bit_depth", C.c_int)]
 
 
 def cpu_flush(arena_base):
@@ -284,11 +285,12 @@ def stream_p_features(bit_depth=8, seed=31, mb_w=6, mb_h=5, weighted_pred=0, t8x
     return w.stream(pics), w.stats
 
 
-def stream_mbaff_p(seed=41, mb_w=6, mb_h=6, n=5, t8x8=0, weighted_pred=0, lossless=0):
+def stream_mbaff_p(seed=41, mb_w=6, mb_h=6, n=5, t8x8=0, weighted_pred=0, lossless=0, bit_depth=8, chroma_format=1):
     """I P P P P, every picture an MBAFF frame: frame and field macroblock pairs mixed (mb_field_decoding_flag per pair), one to three slices
     starting on macroblock pairs, disable_deblocking_filter_idc 0 / 1 / 2, Intra16x16 with every prediction mode its neighbours allow and
     isolated I_NxN macroblocks, one to three reference frames (a field macroblock: twice as many reference fields)"""
-    p = B.Params(mb_w=mb_w, mb_h=mb_h, frame_mbs_only=0, mbaff=1, seed=seed, t8x8=t8x8, weighted_pred=weighted_pred, lossless=lossless)
+    p = B.Params(mb_w=mb_w, mb_h=mb_h, frame_mbs_only=0, mbaff=1, seed=seed, t8x8=t8x8, weighted_pred=weighted_pred, lossless=lossless,
+                 bit_depth=bit_depth, chroma_format=chroma_format)
     w = B.StreamWriter(p)
     rng = np.random.default_rng(seed + 500)
     n_mb = mb_w * mb_h
@@ -312,6 +314,12 @@ MBAFF_CASES = {
                              ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
     "mbaff_p_wide": (stream_mbaff_p, dict(seed=43, mb_w=11, mb_h=8, n=4), 4, ("mbs_field",), ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
     "mbaff_p_cif": (stream_mbaff_p, dict(seed=48, mb_w=22, mb_h=18, n=3, t8x8=1), 3, ("mbs_field", "mbs_8x8dct"), ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
+    "mbaff_p_10": (stream_mbaff_p, dict(seed=61, bit_depth=10, t8x8=1), 5, ("mbs_field", "mbs_8x8dct"), ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member",
+                                                                                                 "mbaff_field_inter_blocks")),
+    "mbaff_p_cif_10": (stream_mbaff_p, dict(seed=62, bit_depth=10, mb_w=22, mb_h=18, n=3, weighted_pred=1), 3, ("mbs_field", "mbs_weighted"),
+                       ("mbaff_field_intra_mbs", "mbaff_calls_mbaff_member")),
+    "mbaff_b_temporal_implicit_10": (stream_b, dict(seed=63, bit_depth=10, mb_h=6, mbaff=1, direct_spatial=0, weighted_bipred=2, t8x8=1, slices=2), 9,
+                                     ("mbs_field", "mbs_b", "mbs_bipred", "mbs_direct", "mbs_implicit"), ("mbaff_calls_mbaff_member",)),
     "mbaff_b_spatial": (stream_b, dict(seed=44, mb_h=6, mbaff=1, direct_spatial=1), 9, ("mbs_field", "mbs_b", "mbs_bipred", "mbs_direct"),
                         ("mbaff_calls_mbaff_member",)),
     "mbaff_b_temporal_implicit": (stream_b, dict(seed=45, mb_h=6, mbaff=1, direct_spatial=0, weighted_bipred=2, slices=2), 9,

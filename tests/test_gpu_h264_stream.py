@@ -101,7 +101,7 @@ def test_a_larger_picture():
 
 @pytest.mark.parametrize("seed", [7, 8, 9])
 def test_mbaff_frames_between_field_pictures(seed):
-    """MBAFF frames (round 6; 8 bits, 4:2:0) between plain field pictures: the frame's three inter objects through ffhip_h264_picture_flush(),
+    """MBAFF frames (round 6; 4:2:0) between plain field pictures: the frame's three inter objects through ffhip_h264_picture_flush(),
     its intra macroblocks and loop-filter calls through ffhip_h264_mbaff_flush() (ffmpeg_amd/csrc/h264_mbaff.hip), all on the device mirror"""
     aus, ws = D.stream_mbaff_and_fields(seed)
     plain, st0, _ = D.decode(aus)
@@ -134,15 +134,16 @@ def test_mbaff_streams(name):
             assert np.array_equal(a[pl], b[pl]), "frame %d plane %d: %d samples differ" % (i, pl, (a[pl] != b[pl]).sum())
 
 
-def test_mbaff_1080i():
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_mbaff_1080i(bit_depth):
     """1920 x 1088 MBAFF frames (120 x 68 macroblocks: 34 macroblock-pair rows, i.e. 34 waves walking 120 pairs each behind one another in the
     intra and in the filter kernel — the dependency protocol under real concurrency): I + P, ~25 000 macroblocks, half of them field
     macroblocks, ~200 000 recorded filter calls"""
-    aus, ws = D.stream_mbaff_p(seed=47, mb_w=120, mb_h=68, n=2)
-    plain, st0, _ = D.decode(aus, arena_bytes=192 << 20)
+    aus, ws = D.stream_mbaff_p(seed=47, mb_w=120, mb_h=68, n=2, bit_depth=bit_depth)
+    plain, st0, _ = D.decode(aus, arena_bytes=320 << 20)
     assert st0["damaged"] == 0 and len(plain) == 2
     make, read_back = _gpu_flush_factory()
-    got, st, counts = D.decode(aus, make_flush=make, read_back=read_back, arena_bytes=192 << 20)
+    got, st, counts = D.decode(aus, make_flush=make, read_back=read_back, arena_bytes=320 << 20)
     assert st["errors"] == 0 and st["refused"] == 0 and st["damaged"] == 0 and st["plain_pictures"] == 0, st
     assert st["pictures"] == 2 == counts["pictures"] == st["mbaff_pictures"] and st["mbs_field"] > 4000, (st, counts)
     for i, (a, b) in enumerate(zip(plain, got)):

@@ -17,7 +17,8 @@ class Edge(C.Structure):            # == FFHipH264Edge
 
 class MbaffLists(C.Structure):      # == FFHipH264MbaffLists
     _fields_ = [("mb_w", C.c_int), ("mb_h", C.c_int), ("recs", C.c_void_p), ("geo", C.c_void_p), ("coefs", C.c_void_p), ("intra_row", C.c_void_p),
-                ("nrecs", C.c_int32), ("ncoefs", C.c_int32), ("calls", C.c_void_p * 3), ("pair_end", C.c_void_p * 3), ("ncalls", C.c_int32 * 3)]
+                ("nrecs", C.c_int32), ("ncoefs", C.c_int32), ("calls", C.c_void_p * 3), ("pair_end", C.c_void_p * 3), ("ncalls", C.c_int32 * 3),
+                ("bit_depth", C.c_int)]
 
 
 def make(mb_w=4, mb_h=4):
@@ -34,6 +35,12 @@ def test_geometry():
     assert L.ffhip_h264_mbaff_create(C.byref(m), 4, 5) == EINVAL          # macroblock PAIRS: an even number of rows
     assert L.ffhip_h264_mbaff_create(C.byref(m), 0, 4) == EINVAL
     assert L.ffhip_h264_mbaff_create(None, 4, 4) == EINVAL
+    assert L.ffhip_h264_mbaff_create_fmt(C.byref(m), 4, 4, 11) == EINVAL     # 8, 9, 10, 12, 14
+    assert L.ffhip_h264_mbaff_create_fmt(C.byref(m), 4, 4, 10) == 0 and m
+    ls = MbaffLists()
+    assert L.ffhip_h264_mbaff_lists(m, C.byref(ls)) == 0 and ls.bit_depth == 10
+    L.ffhip_h264_mbaff_free(C.byref(m))
+    assert not m
     L.ffhip_h264_mbaff_free(C.byref(m))                                   # (a null object: nothing to do)
 
 

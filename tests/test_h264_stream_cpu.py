@@ -108,7 +108,7 @@ def test_mbaff_frames_between_field_pictures(seed):
 
 @pytest.mark.parametrize("name", sorted(D.MBAFF_CASES))
 def test_mbaff_streams(name):
-    """Streams of MBAFF frames only (8 bits, 4:2:0): I / P / B slices starting on macroblock pairs, every Intra16x16 and chroma prediction mode
+    """Streams of MBAFF frames only (4:2:0; 8 and 10 bits): I / P / B slices starting on macroblock pairs, every Intra16x16 and chroma prediction mode
     the MBAFF neighbour derivation (6.4.12.2) allows, isolated Intra4x4 / Intra8x8 macroblocks with every mode, field macroblocks predicting
     from reference FIELDS (ref_list[l][16 + 2 i + parity]) in and beyond the picture, direct prediction (spatial, temporal), explicit and
     implicit weights, the 8x8 transform, disable_deblocking_filter_idc 0 / 1 / 2.  The decoder derives every macroblock's state; the four
@@ -133,11 +133,11 @@ def test_mbaff_streams(name):
     assert any(not np.array_equal(plain[0][0], f[0]) for f in plain[1:])
 
 
-def test_an_mbaff_frame_above_8_bits_stays_on_the_c_path():
-    """ff_h264_hip_picture_supported(): MBAFF is taken at 8 bits, 4:2:0 only — a 10-bit MBAFF frame is refused BEFORE its first macroblock and
-    runs through the reference's functions on the C tables as a whole, between recorded pictures."""
+def test_an_mbaff_frame_at_422_stays_on_the_c_path():
+    """ff_h264_hip_picture_supported(): MBAFF is taken at 4:2:0 (8 - 14 bits) only — a 4:2:2 MBAFF frame is refused BEFORE its first
+    macroblock and runs through the reference's functions on the C tables as a whole, between recorded pictures."""
     import h264_bitstream as B
-    p = B.Params(mb_w=6, mb_h=6, bit_depth=10, frame_mbs_only=0, mbaff=1, seed=17)
+    p = B.Params(mb_w=6, mb_h=6, bit_depth=8, chroma_format=2, frame_mbs_only=0, mbaff=1, seed=17)
     w = B.StreamWriter(p)
     pics = [{"type": "I", "slices": [0], "deblock": [(0, 0, 0)]},
             {"type": "P", "slices": [0], "deblock": [(0, 1, 0)], "field": "top", "num_ref": 2},
