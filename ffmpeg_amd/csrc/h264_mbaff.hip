@@ -1,7 +1,7 @@
 /*
  * h264_mbaff.hip — MBAFF frames in the H.264 picture layer (round 6): the two DEPENDENCY CHAINS of a frame whose
  * macroblock pairs mix frame and field macroblocks (mb_adaptive_frame_field_flag; libavcodec/h264_mb_template.c:61-78,
- * h264_loopfilter.c:494-560,716-760, h264_slice.c:2480-2505), 8 bits, 4:2:0.
+ * h264_loopfilter.c:494-560,716-760, h264_slice.c:2480-2505), 4:2:0, 8 - 14 bits.
  *
  * How an MBAFF frame is taken apart.  A field macroblock of a pair is the field-picture case per macroblock: its lines are every
  * second line of the frame from the pair's first (top field macroblock) or second (bottom) line on, twice the line size apart — which is
