@@ -626,6 +626,49 @@ static int intra_pack_c422(int bd, FFHipH264IntraC422 *rec, const FFHipH264Intra
     if (!nnzc || !mb_)
         return FFHIP_EINVAL;
     CF *mb = reinterpret_cast<CF *>(mb_);
+    if (d->flags & FFHIP_H264_INTRA_BYPASS) {
+        /* the transform bypass at 4:2:2 (h264_mb_template.c:193-221 with chroma422): residual samples, no DC transform; _DPCM with vertical /
+         * horizontal prediction: pred8x16_{vertical,horizontal}_add chains the plane's eight blocks (h264pred_template.c:1280-1303) — the
+         * residuals become running sums along the direction, as in intra_pack() */
+        if (W != 1)
+            return FFHIP_ENOSYS;
+        R.flags = FFHIP_H264_INTRA_BYPASS;
+        if (R.cbp & 0x30) {
+            const bool ch = (d->flags & FFHIP_H264_INTRA_DPCM) && (R.chroma_pred == 2 || R.chroma_pred == 1), vertical = R.chroma_pred == 2;
+            for (int pl = 1; pl < 3; pl++) {
+                CF *base = mb + 256 * pl;
+                auto at = [&](int x, int y) { return base + 16 * ((x >> 2) + 2 * (y >> 2)) + (x & 3) + 4 * (y & 3); };
+                if (ch)
+                    for (int a = 0; a < (vertical ? 8 : 16); a++) {
+                        CF run = 0;
+                        for (int t = 0; t < (vertical ? 16 : 8); t++) {
+                            CF *c = vertical ? at(a, t) : at(t, a);
+                            run = (CF)(uint16_t)((uint32_t)(uint16_t)run + (uint32_t)(uint16_t)*c);
+                            *c = run;
+                        }
+                    }
+                for (int k = 0; k < 8; k++) {
+                    CF *b = base + 16 * k;
+                    bool present = nnzc[scan8_chroma(pl, k)] || b[0];
+                    if (ch) {
+                        present = false;
+                        for (int i = 0; i < 16; i++)
+                            present = present || b[i];
+                    }
+                    if (present) {
+                        const int bit = 8 * (pl - 1) + k;
+                        R.full |= (uint16_t)(1u << bit);
+                        R.blocks |= (uint16_t)(1u << bit);
+                        const size_t o = coefs.size();
+                        coefs.resize(o + 16 * W);
+                        memcpy(coefs.data() + o, b, sizeof(CF) * 16);
+                        memset(b, 0, sizeof(CF) * 16);
+                    }
+                }
+            }
+        }
+        return 0;
+    }
     if (R.cbp & 0x30)
         for (int pl = 1; pl < 3; pl++) {
             if (nnzc[40 * pl]) /* scan8[CHROMA_DC_BLOCK_INDEX + pl - 1] */
@@ -656,8 +699,8 @@ extern "C" int ffhip_h264_picture_intra_mb(FFHipH264Picture *p, const FFHipH264I
     if (!p || !d || d->mb_x < 0 || d->mb_x >= p->mb_w || d->mb_y < 0 || d->mb_y >= p->mb_h)
         return FFHIP_EINVAL;
     const int wide = p->bd > 8 ? 2 : 1; /* int16 entries per dctcoef */
-    if ((d->flags & FFHIP_H264_INTRA_BYPASS) && (p->cfmt == 2 || p->bd != 8)) {
-        ffhip_set_error("ffhip_h264_picture_intra_mb: the transform bypass is taken at 8 bits, 4:2:0 and 4:4:4");
+    if ((d->flags & FFHIP_H264_INTRA_BYPASS) && p->bd != 8) {
+        ffhip_set_error("ffhip_h264_picture_intra_mb: the transform bypass is taken at 8 bits");
         return FFHIP_ENOSYS;
     }
     if (p->cfmt == 2) {

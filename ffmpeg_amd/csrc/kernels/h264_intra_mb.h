@@ -1011,10 +1011,12 @@ IMB_FN void imb_c422_reconstruct(X &x, ImbTileC422<PIX> &T, const FFHipH264Intra
             b = full ? blk(bit) : T.zero;
             dconly = !full && dc != 0;
         }
+        /* (the transform bypass, FFHIP_H264_INTRA_BYPASS in the record's flags: the run holds residual samples, added modulo the sample type) */
+        const bool byp = (R.flags & FFHIP_H264_INTRA_BYPASS) != 0;
         int res[4];
-        imb_resid4_col(b, dc, dconly, xx, res);
+        imb_resid4_col(b, dc, dconly, xx, res, byp);
         for (int j = 0; j < 4; j++)
-            T.c[p][imb_ci(y0 + j, xc)] = (PIX)imb_clip<PIX>(pred[j] + res[j], maxv);
+            T.c[p][imb_ci(y0 + j, xc)] = (PIX)imb_fin<PIX>(pred[j] + res[j], maxv, byp);
     });
 }
 #endif

@@ -475,12 +475,12 @@ av_cold void ff_h264_hip_recorder_install(H264Context *h)
 }
 
 /* What keeps a whole picture on the C path, known before its first macroblock (MBAFF frames that are not 4:2:0; lossless streams —
- * a qpprime_y_zero_transform_bypass macroblock may turn up at any macroblock — above 8 bits or at 4:2:2): a caller asks this BEFORE it
+ * a qpprime_y_zero_transform_bypass macroblock may turn up at any macroblock — above 8 bits): a caller asks this BEFORE it
  * begins to record — once macroblocks have been recorded their coefficients are consumed and the pixels exist only as records, there is no
  * way back. */
 int ff_h264_hip_picture_supported(const H264Context *h)
 {
-    if (h->ps.sps->transform_bypass && (h->ps.sps->bit_depth_luma != 8 || h->ps.sps->chroma_format_idc == 2))
+    if (h->ps.sps->transform_bypass && h->ps.sps->bit_depth_luma != 8)
         return 0;
     /* (streams of x264 before build 151 predict Intra8x8 DPCM blocks from the UNFILTERED edge: h264_mb.c:641-643; libffhip has the filtered form) */
     if (h->ps.sps->transform_bypass && h->ps.sps->profile_idc == 244 && (unsigned)h->x264_build < 151U)
@@ -565,7 +565,7 @@ int ff_h264_hip_hl_decode_mb(FFHipH264Recorder *r, const H264Context *h, H264Sli
     } else if (FRAME_MBAFF(h) || !!MB_FIELD(sl) != r->field) {
         return r->error = FFHIP_ENOSYS;   /* such a picture stays on the C path as a whole */
     }
-    if (sl->qscale == 0 && h->ps.sps->transform_bypass && (r->pixel_shift || r->cfmt == 2))
+    if (sl->qscale == 0 && h->ps.sps->transform_bypass && r->pixel_shift)
         return r->error = FFHIP_ENOSYS;   /* (ff_h264_hip_picture_supported() said so) */
     if (IS_INTRA(mb_type)) {
         FFHipH264IntraMB m = { 0 };

@@ -68,8 +68,7 @@ typedef struct FFHipH264Recorder {
  * ones; chroma_dc_dequant_idct and everything else stay what ff_h264dsp_init() left.  Call once after the decoder's own init. */
 void ff_h264_hip_recorder_install(H264Context *h);
 
-/* 1 when the picture the decoder is about to decode can be recorded as a whole: a lossless (transform-bypass) stream only at 8 bits, 4:2:0 /
- * 4:4:4; an MBAFF frame (FRAME_MBAFF(h): begin it with ff_h264_hip_recorder_begin_mbaff()) only at 4:2:0.  Ask
+/* 1 when the picture the decoder is about to decode can be recorded as a whole: a lossless (transform-bypass) stream only at 8 bits; an MBAFF frame (FRAME_MBAFF(h): begin it with ff_h264_hip_recorder_begin_mbaff()) only at 4:2:0.  Ask
  * before ff_h264_hip_recorder_begin(): a refusal in the middle of a picture cannot be undone (the per-macroblock calls still return
  * FFHIP_ENOSYS for such macroblocks, as a guard). */
 int ff_h264_hip_picture_supported(const H264Context *h);

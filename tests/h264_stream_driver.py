@@ -337,6 +337,8 @@ LOSSLESS_CASES = {
     "lossless_fields_predictive": (stream_p_features, dict(seed=55, lossless=2, fields=True, n=3, mb_h=6), 6, ("mbs_bypass", "mbs_field")),
     "lossless_b_predictive_8x8": (stream_b, dict(seed=56, lossless=2, t8x8=1, weighted_bipred=2), 9, ("mbs_bypass", "mbs_b", "mbs_bipred", "mbs_8x8dct")),
     "lossless_mbaff_predictive": (stream_mbaff_p, dict(seed=57, lossless=2, t8x8=1), 5, ("mbs_bypass", "mbs_field", "mbaff_pictures")),
+    "lossless_422_predictive": (stream_p_features, dict(seed=64, lossless=2, chroma_format=2, t8x8=1), 5, ("mbs_bypass", "mbs_intra8x8")),
+    "lossless_422_high": (stream_b, dict(seed=65, lossless=1, chroma_format=2, weighted_bipred=1, weighted_pred=1), 9, ("mbs_bypass", "mbs_b", "mbs_weighted")),
     "lossless_cif_predictive": (stream_p_features, dict(seed=58, lossless=2, t8x8=1, mb_w=22, mb_h=18, n=3), 3, ("mbs_bypass", "mbs_intra8x8")),
 }
 

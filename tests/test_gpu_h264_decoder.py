@@ -239,7 +239,8 @@ def test_decoder_driven_pictures_444_flushed_together(depth, mb_w, mb_h, picture
 @pytest.mark.parametrize("mb_w,mb_h,nref,mvr,p_intra,weights,cfmt,profile,pictures,batch", [
     (6, 4, 2, 40, .4, 0, 1, 100, 1, False), (11, 7, 3, 600, .3, 2, 1, 244, 1, False), (9, 5, 1, 64, 1.0, 0, 1, 244, 1, False),
     (40, 22, 2, 120, .3, 0, 1, 244, 1, False), (6, 4, 2, 40, .4, 0, 3, 244, 1, False), (9, 5, 1, 64, 1.0, 0, 3, 244, 1, False),
-    (20, 11, 2, 200, .3, 1, 3, 100, 1, False), (8, 5, 2, 120, .5, 0, 0, 244, 1, False), (12, 7, 2, 100, .4, 0, 1, 244, 4, True)])
+    (20, 11, 2, 200, .3, 1, 3, 100, 1, False), (8, 5, 2, 120, .5, 0, 0, 244, 1, False), (12, 7, 2, 100, .4, 0, 1, 244, 4, True),
+    (6, 4, 2, 40, .4, 0, 2, 244, 1, False), (9, 5, 1, 64, 1.0, 0, 2, 244, 1, False), (20, 11, 3, 300, .3, 2, 2, 100, 1, False)])
 def test_decoder_driven_lossless_picture(mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, profile, pictures, batch):
     """The lossless transform bypass (round 6; 8 bits; see tests/test_h264_picture_cpu.py): about half the macroblocks of a picture with QP'Y = 0 in
     a stream with sps->transform_bypass — 4:2:0, monochrome, 4:4:4; profile_idc 100 and 244 (DPCM) — the reference's ff_h264_hl_decode_mb()

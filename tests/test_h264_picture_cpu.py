@@ -330,10 +330,11 @@ def test_recorded_monochrome_picture_executed_on_cpu_equals_reference(depth, mb_
 
 @pytest.mark.parametrize("mb_w,mb_h,nref,mvr,p_intra,weights,cfmt,profile", [
     (6, 4, 2, 40, .4, 0, 1, 100), (6, 4, 2, 40, .4, 0, 1, 244), (9, 5, 1, 64, 1.0, 0, 1, 244), (11, 7, 3, 600, .3, 2, 1, 244),
-    (6, 4, 2, 40, .4, 0, 3, 244), (9, 5, 1, 64, 1.0, 0, 3, 244), (11, 7, 3, 600, .3, 1, 3, 100), (8, 5, 2, 120, .5, 0, 0, 244)])
+    (6, 4, 2, 40, .4, 0, 3, 244), (9, 5, 1, 64, 1.0, 0, 3, 244), (11, 7, 3, 600, .3, 1, 3, 100), (8, 5, 2, 120, .5, 0, 0, 244),
+    (6, 4, 2, 40, .4, 0, 2, 244), (9, 5, 1, 64, 1.0, 0, 2, 244), (11, 7, 3, 600, .3, 2, 2, 100)])
 def test_recorded_lossless_picture_executed_on_cpu_equals_reference(mb_w, mb_h, nref, mvr, p_intra, weights, cfmt, profile):
     """The lossless transform bypass with test-written macroblock state (round 6; 8 bits): ff_h264_hl_decode_mb() compiled in place, about
-    half the macroblocks with QP'Y = 0 in a stream with sps->transform_bypass — 4:2:0, monochrome and 4:4:4 (hl_decode_mb_444: the luma
+    half the macroblocks with QP'Y = 0 in a stream with sps->transform_bypass — 4:2:0, monochrome, 4:2:2 and 4:4:4 (hl_decode_mb_444: the luma
     forms on all three planes: the case the whole-decoder streams of tests/test_h264_stream_cpu.py do not reach), profile_idc 100 (the
     residual added as samples) and 244 (DPCM for vertically / horizontally predicted blocks: pred4x4_add, pred8x8l_filter_add,
     pred16x16_add, pred8x8_add).  The recorder's lists on the CPU list executor == the reference's reconstruction."""
