@@ -192,7 +192,7 @@ def lib():
         "ffhip_me_cmp_batch_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_ssize_t, vp, C.c_int, vp]),
         "ffhip_me_esa_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_size_t, C.c_int, C.c_int,
                                              C.c_int, C.c_int, vp, vp, vp]),
-        "ffhip_tx_init": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+        "ffhip_tx_init": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_uint64]),
         "ffhip_tx_uninit": (None, [C.POINTER(vp)]),
         "ffhip_tx_batch_dev": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_ssize_t, C.c_int, vp]),

@@ -17,4 +17,14 @@ int ffhip_launch_fft_r(int n, int inv, const float2 *wtab, const float *in, size
 int ffhip_launch_mdct_r(int n, int inv, const float2 *wtab, const float2 *exptab, const float *in, size_t in_pitch, float *out,
                         size_t out_pitch, int nt, hipStream_t stream);
 
+/* kernels/tx_wide.hip: AV_TX_DOUBLE_* / AV_TX_INT32_* FFT and MDCT at power-of-two lengths */
+struct FFHipTxWide;
+int    ffhip_txw_create(FFHipTxWide **w, int is_int, int is_mdct, int inv, int len, double scale);
+void   ffhip_txw_free(FFHipTxWide *w);
+int    ffhip_txw_batch(const FFHipTxWide *w, void *out, size_t out_pitch, const void *in, size_t in_pitch, int nt, hipStream_t stream);
+size_t ffhip_txw_in_elems(const FFHipTxWide *w);
+size_t ffhip_txw_out_elems(const FFHipTxWide *w);
+size_t ffhip_txw_elem_size(const FFHipTxWide *w);
+int    ffhip_txw_device(const FFHipTxWide *w);
+
 #endif

@@ -69,6 +69,7 @@ struct FFHipTXContext {
     void *dev = nullptr;
     size_t blob_bytes = 0;   /* size of the table blob at `dev` (multiple of 16) */
     float2 *wtab = nullptr;  /* exp(-2 pi i k / n), k < n: the register-resident kernels' twiddles (kernels/tx_radix.hip), or null */
+    FFHipTxWide *wide = nullptr; /* AV_TX_DOUBLE_* / AV_TX_INT32_* contexts: everything lives in kernels/tx_wide.hip */
     /* host-pointer shim staging */
     void *stage = nullptr;
     size_t stage_sz = 0;
@@ -1272,6 +1273,8 @@ extern "C" void ffhip_tx_uninit(FFHipTXContext **pctx)
         return;
     FFHipTXContext *c = *pctx;
     FFHipDeviceGuard dg(c->device);
+    if (c->wide)
+        ffhip_txw_free(c->wide);
     if (c->dev)
         (void)hipFree(c->dev);
     if (c->wtab)
@@ -1424,17 +1427,44 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f, int F, bool is_fft)
     return 0;
 }
 
-extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,
+static void tx_single_wide(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
+
+extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, int inv, int len, const void *scale_,
                              uint64_t flags)
 {
     static const float one = 1.0f;
-    if (!pctx || (!scale && type != FFHIP_TX_FLOAT_FFT))
+    const bool any_fft = type == FFHIP_TX_FLOAT_FFT || type == FFHIP_TX_DOUBLE_FFT || type == FFHIP_TX_INT32_FFT;
+    if (!pctx || (!scale_ && !any_fft))
         return FFHIP_EINVAL;
+    *pctx = nullptr;
+    if (type == FFHIP_TX_DOUBLE_FFT || type == FFHIP_TX_DOUBLE_MDCT || type == FFHIP_TX_INT32_FFT || type == FFHIP_TX_INT32_MDCT) {
+        /* the scale is a double for the double types, a float for the int32 ones (SCALE_TYPE, tx_double.c / tx_int32.c) */
+        const bool is_int = type == FFHIP_TX_INT32_FFT || type == FFHIP_TX_INT32_MDCT, is_mdct = !any_fft;
+        const double sc = !scale_ ? 1.0 : is_int ? (double)*static_cast<const float *>(scale_) : *static_cast<const double *>(scale_);
+        if (flags & (FFHIP_TX_FULL_IMDCT | FFHIP_TX_REAL_TO_REAL | FFHIP_TX_REAL_TO_IMAGINARY)) {
+            ffhip_set_error("ffhip_tx_init: AV_TX_FULL_IMDCT and the half-complex RDFTs are float-only on the hip path");
+            return FFHIP_ENOSYS;
+        }
+        FFHipTXContext *c = new (std::nothrow) FFHipTXContext();
+        if (!c)
+            return FFHIP_ENOMEM;
+        const int r = ffhip_txw_create(&c->wide, is_int, is_mdct, inv, len, sc);
+        if (r < 0) {
+            delete c;
+            return r;
+        }
+        c->device = ffhip_txw_device(c->wide);
+        c->type = type; c->inv = !!inv; c->len = len; c->scale = (float)sc;
+        *pctx = c;
+        if (fn)
+            *fn = tx_single_wide;
+        return 0;
+    }
+    const float *scale = static_cast<const float *>(scale_);
     if (!scale)
         scale = &one; /* an FFT takes no scale (av_tx_init accepts NULL there) */
-    *pctx = nullptr;
     if (type != FFHIP_TX_FLOAT_MDCT && type != FFHIP_TX_FLOAT_FFT && type != FFHIP_TX_FLOAT_RDFT && type != FFHIP_TX_FLOAT_DCT) {
-        ffhip_set_error("ffhip_tx_init: only AV_TX_FLOAT_MDCT, AV_TX_FLOAT_FFT, AV_TX_FLOAT_RDFT and AV_TX_FLOAT_DCT are on the hip path");
+        ffhip_set_error("ffhip_tx_init: type %d is not on the hip path (float FFT / MDCT / RDFT / DCT-II/III; double and int32 FFT / MDCT)", type);
         return FFHIP_ENOSYS;
     }
     const bool dct = type == FFHIP_TX_FLOAT_DCT;
@@ -1648,6 +1678,13 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
     if (nt == 0)
         return 0;
     FFHipDeviceGuard dg(c->device);
+    if (c->wide) {
+        if (stride != (ptrdiff_t)ffhip_txw_elem_size(c->wide)) {
+            ffhip_set_error("ffhip_tx: double / int32 batches are contiguous rows (stride == sizeof(sample))");
+            return FFHIP_EINVAL;
+        }
+        return ffhip_txw_batch(c->wide, out, out_pitch, in, in_pitch, nt, (hipStream_t)stream);
+    }
     if (!c->full)
         return tx_batch_half(c, out, out_pitch, in, in_pitch, stride, nt, stream);
     /* full inverse: rows of 2 * len floats; the half transform goes to the middle, then the mirror pass */
@@ -2048,4 +2085,37 @@ static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
     float *fo = (float *)out;
     for (size_t i = 0; i < out_elems; i++)
         fo[(s->inv || fft) ? (ptrdiff_t)i : (ptrdiff_t)i * es] = hout[i];
+}
+
+/* the same for the double / int32 contexts: the strided side (forward MDCT: output, inverse: input; an FFT has none) packed on the host */
+static void tx_single_wide(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
+{
+    FFHipDeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t es = ffhip_txw_elem_size(s->wide), ni = ffhip_txw_in_elems(s->wide), no = ffhip_txw_out_elems(s->wide);
+    const bool mdct = s->type == FFHIP_TX_DOUBLE_MDCT || s->type == FFHIP_TX_INT32_MDCT;
+    std::vector<uint8_t> hin(ni * es), hout(no * es);
+    for (size_t i = 0; i < ni; i++)
+        memcpy(hin.data() + i * es, (const uint8_t *)in + ((mdct && s->inv) ? (ptrdiff_t)i * stride : (ptrdiff_t)(i * es)), es);
+    const size_t in_b = (ni * es + 15) & ~(size_t)15, out_b = (no * es + 15) & ~(size_t)15, need = in_b + out_b;
+    if (need > s->stage_sz) {
+        if (s->stage)
+            (void)hipFree(s->stage);
+        s->stage = nullptr;
+        s->stage_sz = 0;
+        if (hipMalloc(&s->stage, need) != hipSuccess) {
+            ffhip_set_error("ffhip_tx: staging allocation failed");
+            return;
+        }
+        s->stage_sz = need;
+    }
+    uint8_t *din = (uint8_t *)s->stage, *dout = din + in_b;
+    if (hipMemcpy(din, hin.data(), ni * es, hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_txw_batch(s->wide, dout, out_b, din, in_b, 1, 0) < 0)
+        return;
+    if (hipMemcpy(hout.data(), dout, no * es, hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    for (size_t i = 0; i < no; i++)
+        memcpy((uint8_t *)out + ((mdct && !s->inv) ? (ptrdiff_t)i * stride : (ptrdiff_t)(i * es)), hout.data() + i * es, es);
 }

@@ -11,6 +11,7 @@ import numpy as np
 from . import _lib
 
 FLOAT_FFT, FLOAT_MDCT, FLOAT_RDFT, FLOAT_DCT = 0, 1, 6, 9
+DOUBLE_FFT, DOUBLE_MDCT, INT32_FFT, INT32_MDCT = 2, 3, 4, 5   # libavutil/tx.h:48-69: rows of float64 / int32, *scale a double / a float
 FULL_IMDCT, REAL_TO_REAL, REAL_TO_IMAGINARY = 1 << 2, 1 << 3, 1 << 4
 BITEXACT = 1 << 32   # FFHIP_TX_BITEXACT: the C reference's operation order (include/ffhip.h)
 _TXFN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t)
@@ -22,7 +23,8 @@ class TxContext:
         self.type, self.inv, self.len, self.scale = type_, int(bool(inv)), len_, float(scale)
         self._c = _lib.vp()
         fn = _lib.vp()
-        sc = C.c_float(scale)
+        sc = C.c_double(scale) if type_ in (DOUBLE_FFT, DOUBLE_MDCT) else C.c_float(scale)
+        self.dtype = np.float64 if type_ in (DOUBLE_FFT, DOUBLE_MDCT) else np.int32 if type_ in (INT32_FFT, INT32_MDCT) else np.float32
         _lib.check(L.ffhip_tx_init(C.byref(self._c), C.byref(fn), type_, self.inv, len_, C.byref(sc), flags), "ffhip_tx_init")
         self._fn = _TXFN(fn.value)
 
@@ -34,15 +36,18 @@ class TxContext:
     __del__ = close
 
     def fn(self, out, inp, stride=4):
-        """One transform on host float32 arrays, exactly av_tx_fn's (s, out, in, stride)."""
-        assert out.dtype == np.float32 and inp.dtype == np.float32
+        """One transform on host arrays of the context's sample type, exactly av_tx_fn's (s, out, in, stride)."""
+        assert out.dtype == self.dtype and inp.dtype == self.dtype
         self._fn(self._c, out.ctypes.data, inp.ctypes.data, stride)
 
-    def batch(self, out, inp, stride=4, stream=None):
-        """out/inp: 2-D float32 cuda tensors, one transform per row (row pitch = tensor stride)."""
+    def batch(self, out, inp, stride=None, stream=None):
+        """out/inp: 2-D cuda tensors of the context's sample type, one transform per row (row pitch = tensor stride)."""
         import torch
         nt = inp.shape[0]
+        es = inp.element_size()
+        if stride is None:
+            stride = es
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
-        return _lib.check(_lib.lib().ffhip_tx_batch_dev(self._c, out.data_ptr(), out.stride(0) * 4, inp.data_ptr(),
-                                                        inp.stride(0) * 4, stride, nt, stream), "ffhip_tx_batch_dev")
+        return _lib.check(_lib.lib().ffhip_tx_batch_dev(self._c, out.data_ptr(), out.stride(0) * es, inp.data_ptr(),
+                                                        inp.stride(0) * es, stride, nt, stream), "ffhip_tx_batch_dev")

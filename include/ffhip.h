@@ -1711,12 +1711,19 @@ typedef struct FFHipTXContext FFHipTXContext;
 #define FFHIP_TX_FLOAT_RDFT 6   /* == AV_TX_FLOAT_RDFT (r2c forward, c2r inverse; libavutil/tx.h:70-90) */
 #define FFHIP_TX_FLOAT_DCT  9   /* == AV_TX_FLOAT_DCT: DCT-II forward, DCT-III inverse (libavutil/tx.h:95-104), power of two 8..4096; as with av_tx_init the
                                    inverse is initialised with half the number of samples it transforms */
+#define FFHIP_TX_DOUBLE_FFT  2  /* == AV_TX_DOUBLE_FFT,  AV_TX_DOUBLE_MDCT (libavutil/tx.h:48-58; tx_double.c): rows of double, *scale a double */
+#define FFHIP_TX_DOUBLE_MDCT 3
+#define FFHIP_TX_INT32_FFT   4  /* == AV_TX_INT32_FFT, AV_TX_INT32_MDCT (libavutil/tx.h:59-69; tx_int32.c): rows of int32_t, *scale a float; the */
+#define FFHIP_TX_INT32_MDCT  5  /*    fixed-point arithmetic of tx_priv.h:117-147 (64-bit products rounded to nearest, wrapping sums, the MDCT's
+                                 *    input folded with >> 6).  Powers of two only: FFT 4 .. 8192 (double) / 16384 (int32) complex points, MDCT
+                                 *    len 16 .. twice that; contiguous rows aligned to a complex sample; bit-identical to the C codelets
+                                 *    (kernels/tx_wide.hip).  AV_TX_FULL_IMDCT is float-only. */
 /* Refused — ffhip_tx_init() returns FFHIP_ENOSYS and the caller keeps the C / SIMD codelets (the reference's convention for an arch
  * that does not offer a transform: its codelet list simply has no entry, libavutil/tx.c:593-650):
- *   AV_TX_DOUBLE_* (2, 3, 7, 10, 13, 16) and AV_TX_INT32_* (4, 5, 8, 11, 14, 17): libavutil/tx_double.c / tx_int32.c — float only here;
- *   AV_TX_FLOAT_DCT_I (12) and AV_TX_FLOAT_DST_I (15) (libavutil/tx.h:116,128; tx_template.c:2056-2105): the reference runs them as an
- *   RDFT over 2 (len - 1) resp. 2 (len + 1) reals, an odd-length — partly naive — FFT for the lengths codecs use, not a power-of-two
- *   network; no batch user on the path (docs/EXPERIMENTS.md: the reference's own `Transform tree` for them). */
+ *   the RDFT / DCT / DCT-I / DST-I forms of the double and int32 types (7, 8, 10, 11, 13, 14, 16, 17) and their prime-factor lengths;
+ *   AV_TX_FLOAT_DCT_I (12) and AV_TX_FLOAT_DST_I (15) (libavutil/tx.h:116,128; tx_template.c:2006-2105): the codelets take even lengths
+ *   only and run an RDFT over 2 (len - 1) resp. 2 (len + 1) reals, i.e. an ODD-length FFT (wmavoice's len 64: 63 = 7 x 9 and
+ *   65 = 5 x 13 complex points, the latter through the naive codelet) — not a power-of-two network; no batch user on the path. */
 #define FFHIP_TX_FULL_IMDCT        (1ULL << 2)   /* == AV_TX_FULL_IMDCT: an inverse MDCT writes 2 * len outputs (ff_tx_mdct_inv_full,
                                                   * libavutil/tx_template.c:1391-1408); batches: 8-byte aligned rows of 2 * len floats */
 #define FFHIP_TX_REAL_TO_REAL      (1ULL << 3)   /* == AV_TX_REAL_TO_REAL: a forward RDFT writes the len/2 + 1 real parts only (ff_tx_rdft_r2r,
@@ -1746,7 +1753,7 @@ typedef void (*ffhip_tx_fn)(FFHipTXContext *s, void *out, void *in, ptrdiff_t st
  * ff_tx_rdft_r2c / _c2r, libavutil/tx_template.c:1601-1716), *scale (FFT: ignored, may be NULL).  This is what the FFTXCodelet.init of a `ff_tx_codelet_list_float_hip[]` entry runs
  * (libavutil/tx_priv.h:199-237).  *fn receives the single-transform host-pointer shim.
  */
-int  ffhip_tx_init(FFHipTXContext **ctx, ffhip_tx_fn *fn, int type, int inv, int len, const float *scale,
+int  ffhip_tx_init(FFHipTXContext **ctx, ffhip_tx_fn *fn, int type, int inv, int len, const void *scale,
                    uint64_t flags);
 void ffhip_tx_uninit(FFHipTXContext **ctx);
 /**

@@ -50,8 +50,10 @@ static av_cold int hip_tx_init(AVTXContext *s, const FFTXCodelet *cd, uint64_t f
     /* the AVTXFlags libffhip knows by the same bit values (include/ffhip.h); in-place is not offered (FF_TX_OUT_OF_PLACE) */
     const uint64_t f = flags & (AV_TX_FULL_IMDCT | AV_TX_REAL_TO_REAL | AV_TX_REAL_TO_IMAGINARY);
     const float one = 1.0f;
+    const double one_d = 1.0;   /* the double types read *scale as a double (SCALE_TYPE) */
+    const int is_double = cd->type == AV_TX_DOUBLE_FFT || cd->type == AV_TX_DOUBLE_MDCT;
     (void)opts;
-    if (ffhip_tx_init(&h, &fn, cd->type, inv, len, scale ? scale : &one, f) < 0)
+    if (ffhip_tx_init(&h, &fn, cd->type, inv, len, scale ? scale : is_double ? (const void *)&one_d : (const void *)&one, f) < 0)
         return AVERROR(ENOSYS);                 /* next codelet in priority order is tried (tx.c:837-895) */
     if (!(t = av_malloc(sizeof(*t)))) {
         ffhip_tx_uninit(&h);
@@ -101,9 +103,17 @@ HIP_CODELET(ff_tx_rdft_float_hip_def,      AV_TX_FLOAT_RDFT, 0, 4, 2, 2, 8, 4096
 HIP_CODELET(ff_tx_dctII_float_hip_def,     AV_TX_FLOAT_DCT,  FF_TX_FORWARD_ONLY, 2, TX_FACTOR_ANY, 2, 8, 4096);
 HIP_CODELET(ff_tx_dctIII_float_hip_def,    AV_TX_FLOAT_DCT,  FF_TX_INVERSE_ONLY, 2, TX_FACTOR_ANY, 2, 8, 4096);
 
+/* the other two sample types at power-of-two lengths (libffhip's kernels/tx_wide.hip).  They ride in the same list: av_tx walks every
+ * codelet of every list and filters by .type (libavutil/tx.c:367-400), the list's name is a convention of the per-type files */
+HIP_CODELET(ff_tx_fft_double_hip_def,      AV_TX_DOUBLE_FFT,  0, 2, 0, 1, 4, 8192);
+HIP_CODELET(ff_tx_mdct_double_hip_def,     AV_TX_DOUBLE_MDCT, 0, 2, 0, 1, 16, 16384);
+HIP_CODELET(ff_tx_fft_int32_hip_def,       AV_TX_INT32_FFT,   0, 2, 0, 1, 4, 16384);
+HIP_CODELET(ff_tx_mdct_int32_hip_def,      AV_TX_INT32_MDCT,  0, 2, 0, 1, 16, 32768);
+
 const FFTXCodelet * const ff_tx_codelet_list_float_hip[] = {
     &ff_tx_fft_float_hip_def, &ff_tx_fft_pfa_15_float_hip_def, &ff_tx_fft_pfa_3_float_hip_def, &ff_tx_fft_pfa_5_float_hip_def,
     &ff_tx_fft_pfa_7_float_hip_def, &ff_tx_fft_pfa_9_float_hip_def, &ff_tx_mdct_float_hip_def, &ff_tx_mdct_pfa_15_float_hip_def, &ff_tx_mdct_pfa_3_float_hip_def,
     &ff_tx_mdct_pfa_5_float_hip_def, &ff_tx_mdct_pfa_7_float_hip_def, &ff_tx_mdct_pfa_9_float_hip_def, &ff_tx_rdft_float_hip_def,
-    &ff_tx_dctII_float_hip_def, &ff_tx_dctIII_float_hip_def, NULL,
+    &ff_tx_dctII_float_hip_def, &ff_tx_dctIII_float_hip_def,
+    &ff_tx_fft_double_hip_def, &ff_tx_mdct_double_hip_def, &ff_tx_fft_int32_hip_def, &ff_tx_mdct_int32_hip_def, NULL,
 };

@@ -232,6 +232,9 @@ void   ffo_fft_run(int inv, int len, float *out, const float *in);       /* ... 
 int    ffo_fft_pfa_factor(int len);                                      /* the F of such a length, 0 for none */
 /* AV_TX_FLOAT_RDFT, power-of-two: inv == 0: in = len reals, out = len/2 + 1 complex; inv == 1: the other way round */
 void   ffo_rdft_run(int inv, int len, float scale, float *out, const float *in);
+/* ffo_tx_wide.c: AV_TX_DOUBLE_* / AV_TX_INT32_* FFT and MDCT, powers of two; is_int: int32_t samples, else double; contiguous rows */
+void   ffo_txw_fft_run(int is_int, int inv, int len, void *out, const void *in);
+void   ffo_txw_mdct_run(int is_int, int inv, int len, double scale, void *out, const void *in);
 /* mode 1: AV_TX_REAL_TO_REAL (len/2 + 1 floats out), 2: AV_TX_REAL_TO_IMAGINARY (len/2 floats out); forward, len a power of two >= 8 */
 void   ffo_rdft_half_run(int mode, int len, float scale, float *out, const float *in);
 /* AV_TX_FLOAT_DCT: DCT-II (inv 0) / DCT-III (inv 1) of n real samples, n a power of two (tx_template.c:1832-2002) */

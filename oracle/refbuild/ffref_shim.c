@@ -682,6 +682,19 @@ void *ffref_tx_create(int type, int inv, int len, float scale, uint64_t flags)
     }
     return t;
 }
+/* the double types read *scale as a double (SCALE_TYPE, libavutil/tx_double.c) */
+void *ffref_tx_create_d(int type, int inv, int len, double scale, uint64_t flags)
+{
+    pure_c();
+    RefTx *t = av_mallocz(sizeof(*t));
+    if (!t)
+        return NULL;
+    if (av_tx_init(&t->s, &t->fn, type, inv, len, &scale, flags) < 0) {
+        av_free(t);
+        return NULL;
+    }
+    return t;
+}
 void ffref_tx_run(void *ctx, void *out, void *in, ptrdiff_t stride)
 {
     RefTx *t = ctx;

@@ -117,6 +117,10 @@ def oracle():
         L.ffo_fft_run.restype = None
         L.ffo_rdft_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
         L.ffo_rdft_run.restype = None
+        L.ffo_txw_fft_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ffo_txw_fft_run.restype = None
+        L.ffo_txw_mdct_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.ffo_txw_mdct_run.restype = None
         L.ffo_dct_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
         L.ffo_dct_run.restype = None
         L.ffo_rdft_half_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
@@ -426,6 +430,9 @@ def ref():
         L.ffref_me_search_esa.restype = C.c_uint64
         L.ffref_tx_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64]
         L.ffref_tx_create.restype = C.c_void_p
+        if hasattr(L, "ffref_tx_create_d"):
+            L.ffref_tx_create_d.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64]
+            L.ffref_tx_create_d.restype = C.c_void_p
         L.ffref_tx_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t]
         L.ffref_tx_run.restype = None
         L.ffref_tx_free.argtypes = [C.c_void_p]

@@ -788,12 +788,50 @@ def h264pred422():
     np.savez_compressed(os.path.join(OUT, "h264pred422.npz"), **d)
 
 
+TXW_TYPES = {"d_fft": 2, "d_mdct": 3, "i_fft": 4, "i_mdct": 5}   # AVTXType values (libavutil/tx.h:48-69)
+TXW_CASES = [(kind, inv, len_) for kind in ("d_fft", "d_mdct", "i_fft", "i_mdct") for inv in (0, 1)
+             for len_ in ((4, 8, 16, 32, 64, 256) if kind.endswith("fft") else (16, 32, 64, 256, 1024))]
+
+
+def txw_input(kind, inv, len_, nt, rng):
+    """seeded input rows of one wide-type case: doubles ~ N(0, 1) * 10^k, int32 over the whole range for the FFT's wrapping sums and at
+    the codecs' headroom (|x| < 2^24) for the MDCT"""
+    n_in = 2 * len_ if (kind.endswith("fft") or not inv) else len_
+    if kind[0] == "d":
+        return (rng.standard_normal((nt, n_in)) * 10.0 ** rng.integers(-3, 4, (nt, 1))).astype(np.float64)
+    hi = 2 ** 31 - 1 if kind.endswith("fft") else 2 ** 24
+    x = rng.integers(-hi, hi, (nt, n_in), dtype=np.int64).astype(np.int32)
+    x[0, : min(4, n_in)] = [-2 ** 31, 2 ** 31 - 1, -1, 0][: min(4, n_in)]
+    return x
+
+
+def tx_wide():
+    """AV_TX_DOUBLE_* / AV_TX_INT32_* FFT and MDCT (powers of two), both directions: inputs + the reference's outputs
+    (tests/golden/tx_wide.npz)"""
+    d = {}
+    rng = np.random.default_rng(606)
+    for kind, inv, len_ in TXW_CASES:
+        is_int, mdct = kind[0] == "i", kind.endswith("mdct")
+        scale = (1.0 / len_ if inv else 1.0) if not is_int else (1.0 if not inv else 1.0 / 64)
+        rc = (R.ffref_tx_create(TXW_TYPES[kind], inv, len_, scale, 0) if is_int else R.ffref_tx_create_d(TXW_TYPES[kind], inv, len_, scale, 0))
+        assert rc, (kind, inv, len_)
+        x = txw_input(kind, inv, len_, 2, rng)
+        out = np.zeros((2, len_ if mdct else 2 * len_), x.dtype)
+        for t in range(2):
+            xi = x[t].copy()
+            R.ffref_tx_run(rc, out[t].ctypes.data, xi.ctypes.data, x.dtype.itemsize * (1 if mdct else 2))
+        R.ffref_tx_free(rc)
+        key = "%s_%d_%d" % (kind, inv, len_)
+        d[key + "_in"], d[key + "_out"], d[key + "_scale"] = x, out, np.array([scale])
+    np.savez_compressed(os.path.join(OUT, "tx_wide.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422(); round4()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422(); round4(); tx_wide()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
