@@ -86,7 +86,8 @@ __device__ __forceinline__ void mc_hrow4(const uint8_t *p, int clo, int chi, int
 __device__ __forceinline__ uint32_t mc_pk16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 
 /* MODE 0 put (int16), 1 uni, 2 uni_w, 3 bi, 4 bi_w; modes 2..4 read the 24-byte weighted record */
-template <bool CHROMA, int MODE>
+/* SKIP16: the 16 x 16 blocks of the batch are k_hevc_qpel_m's (hevc_qpel_m.hip) — this launch leaves them alone */
+template <bool CHROMA, int MODE, bool SKIP16 = false>
 __global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
                                                  const int16_t *src2, const void *blocks_, int n)
 {
@@ -94,11 +95,13 @@ __global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride
     using Rec = typename std::conditional<(MODE >= 2), FFHipHevcMcWBlock, FFHipHevcMcBlock>::type;
     __shared__ uint32_t tmp_all[4][MC_PAIRS * MC_PITCH];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= n)
-        return;
+    /* SKIP16: a launch of a few thousand workgroups walks the whole batch for the blocks k_hevc_qpel_m left (a wave reads a record and
+     * moves on when it is a 16 x 16 one); otherwise one block per wave */
+    for (int b = blockIdx.x * 4 + wave; b < n; b += SKIP16 ? (int)gridDim.x * 4 : n) {
     const Rec k = static_cast<const Rec *>(blocks_)[b];
     const int w = __builtin_amdgcn_readfirstlane((int)k.width), h = __builtin_amdgcn_readfirstlane((int)k.height);
+    if (SKIP16 && w == 16 && h == 16)
+        continue;
     const int mx = __builtin_amdgcn_readfirstlane((int)k.mx) & FMASK, my = __builtin_amdgcn_readfirstlane((int)k.my) & FMASK;
     const uint8_t *s = src + __builtin_amdgcn_readfirstlane(k.src_offset);
     const int dofs = __builtin_amdgcn_readfirstlane(k.dst_offset);
@@ -239,6 +242,9 @@ __global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride
             emit(y, 4 * xg, o);
         }
     }
+    if (SKIP16)
+        hevc_wave_sync(); /* the next block reuses the plane */
+    }
 }
 
 /*
@@ -365,6 +371,14 @@ int ffhip_launch_hevc_mc(int chroma, int mode, void *dst, ptrdiff_t dststride, c
         return 0;
     const char *e = FFHIP_KNOB("FFHIP_HEVC_MC_OLD");
     const bool old = e && e[0] == '1';
+    const char *em = FFHIP_KNOB("FFHIP_HEVC_MC_M"); /* measured variant: 0 = without the matrix-core kernel */
+    if (!chroma && mode == 1 && !old && !(em && em[0] == '0') && ffhip_hevc_qpel_m_ok(dststride, srcstride)) {
+        /* put_hevc_qpel_uni: the 16 x 16 blocks on the matrix cores, everything else in a second launch that skips those */
+        ffhip_launch_hevc_qpel_m(static_cast<uint8_t *>(dst), dststride, src, srcstride, static_cast<const FFHipHevcMcBlock *>(blocks), n, stream);
+        hipLaunchKernelGGL((k_hevc_mc<false, 1, true>), dim3(min(cdiv(n, 4), 2048)), dim3(256), 0, stream, dst, dststride, src, srcstride, src2, blocks, n);
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (chroma)
         hevc_mc_launch<true>(mode, old, dst, dststride, src, srcstride, src2, blocks, n, stream);
     else

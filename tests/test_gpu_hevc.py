@@ -330,6 +330,59 @@ def test_hevc_mc_batch(chroma, uni, old, monkeypatch):
     assert np.array_equal(d_dst.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("m", ["default", "0"])
+@pytest.mark.parametrize("case", ["all16", "mixed_sizes", "unaligned_dst", "ragged_n"])
+def test_hevc_qpel_uni16_matrix_cores(case, m, monkeypatch):
+    """put_hevc_qpel_uni with a 16-byte-aligned source stride: the batch's 16 x 16 blocks run on k_hevc_qpel_m (hevc_qpel_m.hip), the
+    rest on k_hevc_mc in a second launch that skips them.  Every (mx, my), every source alignment modulo 16, saturating content (0 / 255
+    stripes), blocks of other sizes in between, destinations off the dword grid, batch sizes that leave a wave's group of four partly
+    empty — against the oracle, and against the same batch with the matrix-core kernel switched off (FFHIP_HEVC_MC_M=0)"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    if m != "default":
+        monkeypatch.setenv("FFHIP_HEVC_MC_M", m)
+    rng = np.random.default_rng({"all16": 1, "mixed_sizes": 2, "unaligned_dst": 3, "ragged_n": 4}[case])
+    W, H, P = 512, 512, 24
+    ss = W + 2 * P                       # 560 = 16 * 35
+    ref = rng.integers(0, 256, (H + 2 * P, ss), dtype=np.uint8)
+    ref[:120] = rng.choice(np.array([0, 255], np.uint8), (120, ss))
+    ref[200:230, ::2] = 255; ref[200:230, 1::2] = 0
+    sd = W + (4 if case != "unaligned_dst" else 8)
+    blocks = []
+    i = 0
+    for by in range(0, H, 16):
+        for bx in range(0, W, 16):
+            w = h = 16
+            if case == "mixed_sizes" and rng.integers(0, 3) == 0:
+                w, h = int(rng.choice([4, 8, 12, 16])), int(rng.choice([4, 8, 16]))
+                if w == 16 and h == 16:
+                    h = 8
+            dy, dx = rng.integers(-20, 21, 2)
+            doff = by * sd + bx + (int(rng.integers(0, 4)) if case == "unaligned_dst" and bx + 20 < W else 0)
+            blocks.append((doff, (by + P + int(dy)) * ss + bx + P + int(dx), w, h, i & 3, (i >> 2) & 3))
+            i += 1
+    if case == "ragged_n":
+        blocks = blocks[:1021]
+    if case == "unaligned_dst":
+        blocks = blocks[::2]             # shifted destinations must not overlap their neighbours
+    n = len(blocks)
+    rec = np.zeros(n, hevc.MC_DTYPE)
+    O = ffi.oracle()
+    dst = rng.integers(0, 256, (H + 1, sd), dtype=np.uint8)
+    want = dst.copy()
+    for j, (do, so, w, h, mx, my) in enumerate(blocks):
+        rec[j] = (do, so, w, h, mx, my)
+        O.ffo_hevc_mc(0, 1, want.ctypes.data + do, sd, C.cast(ref.ctypes.data + so, u8p), ss, h, mx, my, w)
+    assert len({(b[1] - 3 - 3 * ss) & 15 for b in blocks}) == 16
+    d_dst = torch.from_numpy(dst.copy()).cuda()
+    hevc.mc_batch(0, 1, d_dst, sd, torch.from_numpy(ref).cuda(), ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 12).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    assert (want != dst).sum() > 100000
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (case, bad[:5], len(bad))
+
+
 def test_hevc_mc_host_faces():
     from ffmpeg_amd import hevc
     _torch()
