@@ -137,10 +137,10 @@ int ffhip_launch_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, p
 int ffhip_launch_vp9_itxfm(int tx, int16_t *coeffs, uint8_t *dst, ptrdiff_t stride, const FFHipVp9TU *tus, int n, hipStream_t stream);
 int ffhip_launch_hevc_sao_restore(uint8_t *dst, ptrdiff_t sd, const uint8_t *src, ptrdiff_t ss, const FFHipHevcSaoRestore *blocks, int n,
                                   hipStream_t stream);
-/* kernels/hevc_qpel_m.hip: put_hevc_qpel_uni for the 16 x 16 blocks of a batch, on the matrix cores */
-bool ffhip_hevc_qpel_m_ok(ptrdiff_t dststride, ptrdiff_t srcstride);
-void ffhip_launch_hevc_qpel_m(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipHevcMcBlock *blocks, int n,
-                              hipStream_t stream);
+/* kernels/hevc_qpel_m.hip: the 16 x 16 luma blocks of a put_hevc_qpel* batch on the matrix cores (mode as ffhip_launch_hevc_mc) */
+bool ffhip_hevc_qpel_m_ok(int mode, ptrdiff_t dststride, ptrdiff_t srcstride);
+void ffhip_launch_hevc_qpel_m(int mode, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
+                              const void *blocks, int n, hipStream_t stream);
 int ffhip_launch_hevc_mc(int chroma, int mode, void *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const int16_t *src2,
                          const void *blocks, int n, hipStream_t stream);
 int ffhip_launch_fdsp(int op, float *dst, size_t pd, const float *s0, size_t p0, const float *s1, size_t p1, const float *s2, size_t p2,

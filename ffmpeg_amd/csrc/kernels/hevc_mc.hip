@@ -372,10 +372,17 @@ int ffhip_launch_hevc_mc(int chroma, int mode, void *dst, ptrdiff_t dststride, c
     const char *e = FFHIP_KNOB("FFHIP_HEVC_MC_OLD");
     const bool old = e && e[0] == '1';
     const char *em = FFHIP_KNOB("FFHIP_HEVC_MC_M"); /* measured variant: 0 = without the matrix-core kernel */
-    if (!chroma && mode == 1 && !old && !(em && em[0] == '0') && ffhip_hevc_qpel_m_ok(dststride, srcstride)) {
-        /* put_hevc_qpel_uni: the 16 x 16 blocks on the matrix cores, everything else in a second launch that skips those */
-        ffhip_launch_hevc_qpel_m(static_cast<uint8_t *>(dst), dststride, src, srcstride, static_cast<const FFHipHevcMcBlock *>(blocks), n, stream);
-        hipLaunchKernelGGL((k_hevc_mc<false, 1, true>), dim3(min(cdiv(n, 4), 2048)), dim3(256), 0, stream, dst, dststride, src, srcstride, src2, blocks, n);
+    if (!chroma && !old && !(em && em[0] == '0') && ffhip_hevc_qpel_m_ok(mode, dststride, srcstride)) {
+        /* luma: the 16 x 16 blocks on the matrix cores, everything else in a second launch that skips those */
+        ffhip_launch_hevc_qpel_m(mode, dst, dststride, src, srcstride, src2, blocks, n, stream);
+        const dim3 grid(min(cdiv(n, 4), 2048)), block(256);
+#define MC_SKIP(M) case M: hipLaunchKernelGGL((k_hevc_mc<false, M, true>), grid, block, 0, stream, dst, dststride, src, srcstride, src2, blocks, n); break;
+        switch (mode) {
+        MC_SKIP(0) MC_SKIP(1) MC_SKIP(2) MC_SKIP(3)
+        default:
+        MC_SKIP(4)
+        }
+#undef MC_SKIP
         LAUNCH_CHECK();
         return 0;
     }

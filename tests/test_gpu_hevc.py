@@ -383,6 +383,74 @@ def test_hevc_qpel_uni16_matrix_cores(case, m, monkeypatch):
     assert bad.size == 0, (case, bad[:5], len(bad))
 
 
+@pytest.mark.parametrize("mode", [0, 2, 3, 4])
+@pytest.mark.parametrize("case", ["all16", "mixed_sizes", "ragged_unaligned"])
+def test_hevc_qpel16_matrix_cores_other_stages(case, mode, monkeypatch):
+    """the other output stages of k_hevc_qpel_m — put (int16 rows of 64), uni_w, bi, bi_w — on batches of 16 x 16 luma blocks with a
+    16-byte-aligned source stride: every (mx, my) and source alignment, saturating content, weights over the slice header's ranges and
+    checkasm's ladders, the other list's block on and off the 8-byte grid, other block sizes mixed in, a ragged batch"""
+    from ffmpeg_amd import hevc
+    torch = _torch()
+    rng = np.random.default_rng(100 + 10 * mode + len(case))
+    W, H, P = 256, 512, 24
+    ss = W + 2 * P + 8                   # 312 = 16 * 19.5 -> make it a multiple of 16
+    ss = (ss + 15) & ~15
+    ref = rng.integers(0, 256, (H + 2 * P, ss), dtype=np.uint8)
+    ref[:120] = rng.choice(np.array([0, 255], np.uint8), (120, ss))
+    ref[200:230, ::2] = 255; ref[200:230, 1::2] = 0
+    sd = W + 4
+    blocks = []
+    i = 0
+    for by in range(0, H, 16):
+        for bx in range(0, W, 16):
+            w = h = 16
+            if case == "mixed_sizes" and rng.integers(0, 3) == 0:
+                w, h = int(rng.choice([4, 8, 12, 16])), int(rng.choice([4, 8, 16]))
+                if w == 16 and h == 16:
+                    w = 8
+            dy, dx = rng.integers(-20, 21, 2)
+            blocks.append((by, bx, (by + P + int(dy)) * ss + bx + P + int(dx), w, h, i & 3, (i >> 2) & 3))
+            i += 1
+    if case == "ragged_unaligned":
+        blocks = blocks[:509]
+    n = len(blocks)
+    O = ffi.oracle()
+    d_ref = torch.from_numpy(ref).cuda()
+    if mode == 0:
+        rec = np.zeros(n, hevc.MC_DTYPE)
+        dst = np.full((n, 17, 64), -7, np.int16)
+        want = dst.copy()
+        for j, (by, bx, so, w, h, mx, my) in enumerate(blocks):
+            do = j * 17 * 64 + ((j & 1) if case == "ragged_unaligned" else 0)
+            rec[j] = (do, so, w, h, mx, my)
+            O.ffo_hevc_mc(0, 0, want.ctypes.data + 2 * do, 0, C.cast(ref.ctypes.data + so, u8p), ss, h, mx, my, w)
+        d_dst = torch.from_numpy(dst.copy()).cuda()
+        hevc.mc_batch(0, 0, d_dst, 0, d_ref, ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 12).copy()).cuda(), n)
+    else:
+        rec = np.zeros(n, hevc.MCW_DTYPE)
+        src2 = rng.integers(-8192, 16384, (n + 1, 16, 64)).astype(np.int16)
+        src2[::5] = 16383
+        src2[1::7] = -8192
+        flat2 = src2.reshape(-1)
+        dst = rng.integers(0, 256, (H + 1, sd), dtype=np.uint8)
+        want = dst.copy()
+        for j, (by, bx, so, w, h, mx, my) in enumerate(blocks):
+            d, wx0, wx1, ox = _weights(rng, j)
+            o2 = j * 1024 + (1 if (case == "ragged_unaligned" and j % 3 == 0) else 0)
+            do = by * sd + bx
+            rec[j] = (do, so, o2, w, h, mx, my, wx0, wx1, ox, d, 0)
+            O.ffo_hevc_mc_w(0, mode, C.cast(want.ctypes.data + do, u8p), sd, C.cast(ref.ctypes.data + so, u8p), ss,
+                            C.cast(flat2.ctypes.data + 2 * o2, ffi.i16p), h, d, wx0, wx1, ox, mx, my, w)
+        d_dst = torch.from_numpy(dst.copy()).cuda()
+        hevc.mc_w_batch(0, mode, d_dst, sd, d_ref, ss, torch.from_numpy(src2).cuda() if mode != 2 else None,
+                        torch.from_numpy(rec.view(np.uint8).reshape(n, 24).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    assert (want != dst).sum() > 50000
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (case, mode, bad[:5], len(bad))
+
+
 def test_hevc_mc_host_faces():
     from ffmpeg_amd import hevc
     _torch()
