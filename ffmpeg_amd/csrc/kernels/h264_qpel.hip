@@ -688,8 +688,15 @@ __device__ __forceinline__ void qm_load(int (&Gsize)[4], int (&Gmc)[4], int (&Gd
         }
         const uint8_t *s0 = src + q.soff - 2 - 2 * stride;
         Gsh16[k] = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 15);
-        const int nch = (int)(Gsh16[k] + q.size + 5 + 15) >> 4;
-        Gf[k] = (fr < q.rows && fc < nch) ? *reinterpret_cast<const qp_u4 *>(s0 - Gsh16[k] + (ptrdiff_t)fr * stride + 16 * fc) : (qp_u4){ 0, 0, 0, 0 };
+        /* the part of the footprint the position reads (round 6): a plane filtered vertically (V, J) wants all size + 5 rows, one filtered
+         * horizontally (H, J) all size + 5 columns; the others only the block's own rows / columns (+ 1 for the positions that average with
+         * the sample one row down / one column right) */
+        const QmFlags F = qm_flags(q.mc);
+        const bool rows_all = F.useV || F.useJ, cols_all = F.useH || F.useJ;
+        const int r_lo = rows_all ? 0 : 2, r_hi = rows_all ? q.rows - 1 : q.size + 2;
+        const int c_lo = (int)Gsh16[k] + (cols_all ? 0 : 2), c_hi = (int)Gsh16[k] + (cols_all ? q.size + 4 : q.size + 2);
+        Gf[k] = (fr >= r_lo && fr <= r_hi && 16 * fc + 15 >= c_lo && 16 * fc <= c_hi)
+                    ? *reinterpret_cast<const qp_u4 *>(s0 - Gsh16[k] + (ptrdiff_t)fr * stride + 16 * fc) : (qp_u4){ 0, 0, 0, 0 };
     }
 }
 

@@ -83,7 +83,6 @@ __device__ __forceinline__ uint32_t hq_transpose(uint32_t c, uint32_t selT1, uin
     const uint32_t t2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)c1, 0x4E, 0xf, 0xf, true);    /* quad_perm [2,3,0,1] */
     return __builtin_amdgcn_perm(t2, c1, selT2);
 }
-__device__ __forceinline__ int hq_clip_u8(int v) { return min(max(v, 0), 255); }
 
 /* MODE 0 put (int16), 1 uni, 2 uni_w, 3 bi, 4 bi_w; modes 2..4 read the 24-byte weighted record */
 template <int MODE>
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(256) void k_hevc_qpel_m(void *dst_, ptrdiff_t dstst
                     else
                         r[j] = (v[j] * wx1 + o2[j] * wx0 + wofs) >> (wsh + 1);
                 }
-                out = (uint32_t)hq_clip_u8(r[0]) | (uint32_t)hq_clip_u8(r[1]) << 8 | (uint32_t)hq_clip_u8(r[2]) << 16 | (uint32_t)hq_clip_u8(r[3]) << 24;
+                out = (uint32_t)clip_u8(r[0]) | (uint32_t)clip_u8(r[1]) << 8 | (uint32_t)clip_u8(r[2]) << 16 | (uint32_t)clip_u8(r[3]) << 24;
             }
             if (tile) {
                 ob[64 * k + 4 * ry + rxg] = out;

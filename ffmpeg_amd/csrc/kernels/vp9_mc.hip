@@ -112,16 +112,18 @@ __device__ __forceinline__ void vm_hrow4(const uint8_t *p, int clo, int chi, int
         o[j] = clip_u8(s[j] >> 7);
 }
 
+/* SKIP16: the 16 x 16 blocks of the batch are k_vp9_mc_m's (below); a launch of a few thousand workgroups walks the batch for the rest */
+template <bool SKIP16>
 __global__ __launch_bounds__(256) void k_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
                                                 const FFHipVp9McBlock *blocks, int n)
 {
     __shared__ uint32_t tmp_all[4][VM_PAIRS * VM_PITCH];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= n)
-        return;
+    for (int b = blockIdx.x * 4 + wave; b < n; b += SKIP16 ? (int)gridDim.x * 4 : n) {
     const FFHipVp9McBlock k = blocks[b];
     const int w = __builtin_amdgcn_readfirstlane((int)k.width), h = __builtin_amdgcn_readfirstlane((int)k.height);
+    if (SKIP16 && w == 16 && h == 16)
+        continue;
     const int filter = __builtin_amdgcn_readfirstlane((int)k.filter) & 3;
     const int mx = __builtin_amdgcn_readfirstlane((int)k.mx) & 15, my = __builtin_amdgcn_readfirstlane((int)k.my) & 15;
     const bool avg = __builtin_amdgcn_readfirstlane((int)k.avg) != 0;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void k_vp9_mc(uint8_t *dst, ptrdiff_t dststrid
             }
             emit(y, 4 * xg, o);
         }
-        return;
+        continue;
     }
     const int before = bil ? 0 : 3, rows = bil ? h + 1 : h + 7;
     const int clo = (int)vp9_h8[fi + mx][0], chi = (int)vp9_h8[fi + mx][1];
@@ -233,6 +235,180 @@ __global__ __launch_bounds__(256) void k_vp9_mc(uint8_t *dst, ptrdiff_t dststrid
         }
         vm_wave_sync(); /* the next tile overwrites the plane */
     }
+    }
+}
+
+/* ================================================================================================================================== */
+/*
+ * k_vp9_mc_m — the 16 x 16 blocks of a batch on the MATRIX CORES: k_hevc_qpel_m's two-stage form (hevc_qpel_m.hip) with VP9's taps.
+ * A VP9 pass ends in clip_u8((sum + 64) >> 7) — the 2-D form goes through 8-BIT temporaries (vp9dsp_template.c:2036-2076) — so the
+ * second stage's B operand is the first stage's clipped bytes: one product per stage and row block, no 16-bit split.  The rounding
+ * constant and the 128 * sum(taps) that undoes the ^0x80 ride in the accumulator; v_ashr_pk_u8_i32 shifts, clips and packs two sums.
+ * The banded operands are not tables (3 filter sets x 15 fractions): a lane cuts its eight bytes out of the block's packed tap row
+ * (vp9_h8) with a 64-bit shift.  Bilinear blocks (a + ((m (b - a) + 8) >> 4) == ((16 - m) a + m b + 8) >> 4, exactly) are the taps
+ * (16 - m, m) at positions 3 and 4 of the same band with >> 4; full-pel directions hand the samples through an identity band.
+ * avg: (dst + v + 1) >> 1 on the packed row.
+ */
+typedef int vq_i4 __attribute__((ext_vector_type(4)));
+typedef uint32_t vq_u4 __attribute__((ext_vector_type(4)));
+
+/* bytes [s, s + 4) of the 8-byte tap row T, zero outside it */
+__device__ __forceinline__ uint32_t vq_win32(unsigned long T, int s)
+{
+    if (s <= -4 || s >= 8)
+        return 0;
+    return s >= 0 ? (uint32_t)(T >> (8 * s)) : (uint32_t)(T << (8 * -s));
+}
+__device__ __forceinline__ long vq_long(uint32_t lo, uint32_t hi) { return (long)(((unsigned long)hi << 32) | lo); }
+__device__ __forceinline__ vq_i4 vq_splat(int v) { return (vq_i4){ v, v, v, v }; }
+/* clip_u8(a >> SH) .. clip_u8(d >> SH) as bytes 0..3.  The builtin, not inline assembly: the operands come straight out of an MFMA and the
+ * compiler counts that hazard's wait states only for instructions it knows; v_perm takes the two low halves (what v_ashr_pk_u8_i32 leaves
+ * in the upper half of its destination is not zero: common.h) */
+template <int SH>
+__device__ __forceinline__ uint32_t vq_pack(int a, int b, int c, int d)
+{
+    const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(a, b, SH), hi = __builtin_amdgcn_ashr_pk_u8_i32(c, d, SH);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+__device__ __forceinline__ uint32_t vq_transpose(uint32_t c, uint32_t selT1, uint32_t selT2)
+{
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)c, 0xB1, 0xf, 0xf, true);     /* quad_perm [1,0,3,2] */
+    const uint32_t c1 = __builtin_amdgcn_perm(t1, c, selT1);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)c1, 0x4E, 0xf, 0xf, true);    /* quad_perm [2,3,0,1] */
+    return __builtin_amdgcn_perm(t2, c1, selT2);
+}
+__device__ __forceinline__ uint32_t vq_rnd_avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) & 0xFEFEFEFEu) >> 1); }
+
+__global__ __launch_bounds__(256) void k_vp9_mc_m(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride,
+                                                  const FFHipVp9McBlock *blocks, int n, int per_xcd)
+{
+    __shared__ __align__(16) uint32_t rawp[4][24 * 12];
+    __shared__ __align__(16) uint32_t obp[4][4 * 64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int wg = per_xcd ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int b0 = (wg * 4 + wave) * 4;
+    if (b0 >= n)
+        return;
+    uint32_t *raw = rawp[wave], *ob = obp[wave];
+    const int fr0 = (lane * 171) >> 9, fc0 = lane - 3 * fr0;          /* chunk `lane`: footprint row lane / 3, 16-byte chunk lane % 3 */
+    const int fr1 = (64 + lane) / 3, fc1 = 64 + lane - 3 * fr1;        /* chunk 64 + lane (lanes 0..4: rows 21, 22) */
+    const uint32_t selT1 = (lane & 1) ? 0x03070105u : 0x06020400u, selT2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+    const int g = lane >> 4, m = lane & 15;
+    const int ry = 4 * g + (lane & 3), rxg = (lane >> 2) & 3;          /* the row and 4-sample group this lane owns after the transposition */
+    const long K80 = (long)0x8080808080808080ull;
+
+    int Gmx[4], Gmy[4], Gfi[4], Gdoff[4];
+    bool Gel[4], Gavg[4], Gbil[4], tile = true;
+    uint32_t Gsh16[4];
+    vq_u4 Gf0[4], Gf1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const FFHipVp9McBlock rec = blocks[min(b0 + k, n - 1)];
+        const int w = __builtin_amdgcn_readfirstlane((int)rec.width), h = __builtin_amdgcn_readfirstlane((int)rec.height);
+        const int filter = __builtin_amdgcn_readfirstlane((int)rec.filter) & 3;
+        Gbil[k] = filter == 3;
+        Gfi[k] = (Gbil[k] ? 0 : filter) * 16;
+        Gmx[k] = __builtin_amdgcn_readfirstlane((int)rec.mx) & 15;
+        Gmy[k] = __builtin_amdgcn_readfirstlane((int)rec.my) & 15;
+        Gavg[k] = __builtin_amdgcn_readfirstlane((int)rec.avg) != 0;
+        Gdoff[k] = __builtin_amdgcn_readfirstlane(rec.dst_offset);
+        Gel[k] = b0 + k < n && w == 16 && h == 16;
+        tile = tile && Gel[k] && !((reinterpret_cast<uintptr_t>(dst) + (uintptr_t)(intptr_t)Gdoff[k]) & 3);
+        const uint8_t *s0 = src + __builtin_amdgcn_readfirstlane(rec.src_offset) - 3 - 3 * srcstride;
+        Gsh16[k] = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 15);
+        const uint8_t *sa = s0 - Gsh16[k];
+        /* the part of the footprint the position reads: 8 taps want all 23 rows / columns, two taps one more than the block, none the block */
+        const int r_lo = Gmy[k] && !Gbil[k] ? 0 : 3, r_hi = Gmy[k] ? (Gbil[k] ? 19 : 22) : 18;
+        const int c_lo = (int)Gsh16[k] + (Gmx[k] && !Gbil[k] ? 0 : 3), c_hi = (int)Gsh16[k] + (Gmx[k] ? (Gbil[k] ? 19 : 22) : 18);
+        const bool want0 = Gel[k] && fr0 >= r_lo && fr0 <= r_hi && 16 * fc0 + 15 >= c_lo && 16 * fc0 <= c_hi;
+        const bool want1 = Gel[k] && lane < 5 && fr1 >= r_lo && fr1 <= r_hi && 16 * fc1 + 15 >= c_lo && 16 * fc1 <= c_hi;
+        Gf0[k] = want0 ? *reinterpret_cast<const vq_u4 *>(sa + (ptrdiff_t)fr0 * srcstride + 16 * fc0) : (vq_u4){ 0, 0, 0, 0 };
+        Gf1[k] = want1 ? *reinterpret_cast<const vq_u4 *>(sa + (ptrdiff_t)fr1 * srcstride + 16 * fc1) : (vq_u4){ 0, 0, 0, 0 };
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!Gel[k])
+            continue; /* k_vp9_mc<true> takes it */
+        *reinterpret_cast<vq_u4 *>(raw + fr0 * 12 + 4 * fc0) = Gf0[k];
+        if (lane < 5)
+            *reinterpret_cast<vq_u4 *>(raw + fr1 * 12 + 4 * fc1) = Gf1[k];
+        __builtin_amdgcn_wave_barrier();
+        const int mx = Gmx[k], my = Gmy[k];
+        const bool bil = Gbil[k];
+        const uint32_t sh = Gsh16[k] & 3;
+        const uint32_t *r0p = raw + (Gsh16[k] >> 2);   /* the dword that holds footprint byte 0 of row 0 */
+        uint32_t out;
+        if (mx | my) {
+            /* the packed tap rows of the two directions: eight int8 of the set, (16 - m, m) at taps 3 and 4, or the identity */
+            const unsigned long Tx = !mx ? 0x01000000ul : bil ? ((unsigned long)(16 - mx) << 24 | (unsigned long)mx << 32)
+                                                             : ((unsigned long)vp9_h8[Gfi[k] + mx][1] << 32 | vp9_h8[Gfi[k] + mx][0]);
+            const unsigned long Ty = bil ? ((unsigned long)(16 - my) << 24 | (unsigned long)my << 32)
+                                         : ((unsigned long)vp9_h8[Gfi[k] + my][1] << 32 | vp9_h8[Gfi[k] + my][0]);
+            const int seed = bil ? 128 * 16 + 8 : 128 * 128 + 64;     /* 128 * sum(taps) + the pass's rounding constant */
+            /* stage 1: B[k = 8g + j][n] = tap[k - n]; my = 0: the lanes feed footprint rows 3 .. 18 and the C layout is the output block */
+            const long cTh = vq_long(vq_win32(Tx, 8 * g - m), vq_win32(Tx, 8 * g - m + 4));
+            const uint32_t *pa = r0p + (my ? m : m + 3) * 12 + 2 * g;
+            const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2];
+            const long fa = vq_long(__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh)) ^ K80;
+            const vq_i4 h0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(fa, cTh, vq_splat(mx ? seed : 128), 0, 0, 0);
+            uint32_t c;
+            if (!my) {
+                c = bil ? vq_pack<4>(h0.x, h0.y, h0.z, h0.w) : vq_pack<7>(h0.x, h0.y, h0.z, h0.w);
+            } else {
+                const uint32_t *pb = r0p + min(16 + m, 22) * 12 + 2 * g;
+                const uint32_t b0_ = pb[0], b1_ = pb[1], b2_ = pb[2];
+                const long fb = vq_long(__builtin_amdgcn_alignbyte(b1_, b0_, sh), __builtin_amdgcn_alignbyte(b2_, b1_, sh)) ^ K80;
+                const vq_i4 h1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(fb, cTh, vq_splat(mx ? seed : 128), 0, 0, 0);
+                /* the 8-bit temporaries (or the raw samples) of column n ARE the stage-2 K slots of this lane: slot 8g + j holds footprint
+                 * row 4g + j (j < 4) or 16 + 4g + j - 4; A[y][slot] = tap[row - y] */
+                uint32_t xlo, xhi;
+                if (!mx) {
+                    xlo = vq_pack<0>(h0.x, h0.y, h0.z, h0.w); xhi = vq_pack<0>(h1.x, h1.y, h1.z, h1.w);
+                } else if (bil) {
+                    xlo = vq_pack<4>(h0.x, h0.y, h0.z, h0.w); xhi = vq_pack<4>(h1.x, h1.y, h1.z, h1.w);
+                } else {
+                    xlo = vq_pack<7>(h0.x, h0.y, h0.z, h0.w); xhi = vq_pack<7>(h1.x, h1.y, h1.z, h1.w);
+                }
+                const long bv = vq_long(xlo, xhi) ^ K80;
+                const long cTv = vq_long(vq_win32(Ty, 4 * g - m), vq_win32(Ty, 16 + 4 * g - m));
+                const vq_i4 vv = __builtin_amdgcn_mfma_i32_16x16x32_i8(cTv, bv, vq_splat(seed), 0, 0, 0);
+                c = bil ? vq_pack<4>(vv.x, vv.y, vv.z, vv.w) : vq_pack<7>(vv.x, vv.y, vv.z, vv.w);
+            }
+            out = vq_transpose(c, selT1, selT2);
+        } else {
+            const uint32_t o = sh + 3;
+            const uint32_t *pf = r0p + (ry + 3) * 12 + rxg + (o >> 2);
+            out = __builtin_amdgcn_alignbyte(pf[1], pf[0], o & 3);
+        }
+        if (tile) {
+            ob[64 * k + 4 * ry + rxg] = out;
+        } else {
+            uint8_t *d = dst + Gdoff[k] + (ptrdiff_t)ry * dststride + 4 * rxg;
+            if (!((reinterpret_cast<uintptr_t>(d)) & 3)) {
+                uint32_t *dw = reinterpret_cast<uint32_t *>(d);
+                *dw = Gavg[k] ? vq_rnd_avg4(*dw, out) : out;
+            } else {
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t v = (out >> (8 * i)) & 0xFF;
+                    d[i] = (uint8_t)(Gavg[k] ? (d[i] + v + 1) >> 1 : v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier(); /* the next block overwrites the plane */
+    }
+    if (tile) {
+        const int y = lane >> 2, c = lane & 3;
+        vq_u4 o = *reinterpret_cast<const vq_u4 *>(ob + 64 * c + 4 * y);
+        const int doff = c == 0 ? Gdoff[0] : c == 1 ? Gdoff[1] : c == 2 ? Gdoff[2] : Gdoff[3];
+        const bool avg = c == 0 ? Gavg[0] : c == 1 ? Gavg[1] : c == 2 ? Gavg[2] : Gavg[3];
+        vq_u4 *dp = reinterpret_cast<vq_u4 *>(dst + doff + (ptrdiff_t)y * dststride);
+        if (avg) {
+            const vq_u4 old = *dp;
+            o.x = vq_rnd_avg4(old.x, o.x); o.y = vq_rnd_avg4(old.y, o.y); o.z = vq_rnd_avg4(old.z, o.z); o.w = vq_rnd_avg4(old.w, o.w);
+        }
+        *dp = o;
+    }
 }
 
 int ffhip_launch_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, ptrdiff_t srcstride, const FFHipVp9McBlock *blocks, int n,
@@ -240,7 +416,16 @@ int ffhip_launch_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, p
 {
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(k_vp9_mc, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
+    const char *em = FFHIP_KNOB("FFHIP_VP9_MC_M"); /* measured variant: 0 = without the matrix-core kernel */
+    if (!(em && em[0] == '0') && !(srcstride & 15) && !(dststride & 3)) {
+        /* the 16 x 16 blocks on the matrix cores (aligned 16-byte footprint chunks: the source stride must keep a row's alignment),
+         * everything else in a second launch that skips those */
+        const int per_xcd = cdiv(cdiv(n, 16), 8);
+        hipLaunchKernelGGL(k_vp9_mc_m, dim3(8 * per_xcd), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n, per_xcd);
+        hipLaunchKernelGGL(k_vp9_mc<true>, dim3(min(cdiv(n, 4), 2048)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
+    } else {
+        hipLaunchKernelGGL(k_vp9_mc<false>, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
+    }
     LAUNCH_CHECK();
     return 0;
 }

@@ -137,6 +137,59 @@ def test_vp9_mc_batch(aligned):
     assert np.array_equal(got, want), "%d mismatches, first %s" % ((got != want).sum(), np.argwhere(got != want)[:3])
 
 
+@pytest.mark.parametrize("m", ["default", "0"])
+@pytest.mark.parametrize("case", ["all16", "mixed_sizes", "unaligned_dst", "ragged_n"])
+def test_vp9_mc16_matrix_cores(case, m, monkeypatch):
+    """a 16-byte-aligned source stride: the batch's 16 x 16 blocks run on k_vp9_mc_m (vp9_mc.hip), the rest on k_vp9_mc in a second
+    launch that skips them.  All four filters x every (mx, my) of the 16 x 16 grid, put and avg, every source alignment modulo 16,
+    saturating content, other block sizes in between, destinations off the dword grid, a batch that leaves a wave's group of four partly
+    empty — against the oracle, with and without the matrix-core kernel (FFHIP_VP9_MC_M=0)"""
+    from ffmpeg_amd import vp9
+    torch = _torch()
+    if m != "default":
+        monkeypatch.setenv("FFHIP_VP9_MC_M", m)
+    rng = np.random.default_rng({"all16": 11, "mixed_sizes": 12, "unaligned_dst": 13, "ragged_n": 14}[case])
+    W, H, P = 1024, 512, 24
+    ss = W + 2 * P                       # 1072 = 16 * 67
+    ref = rng.integers(0, 256, (H + 2 * P, ss), dtype=np.uint8)
+    ref[:120] = rng.choice(np.array([0, 255], np.uint8), (120, ss))
+    ref[200:230, ::2] = 255; ref[200:230, 1::2] = 0
+    sd = W + (4 if case != "unaligned_dst" else 8)
+    blocks = []
+    i = 0
+    for by in range(0, H, 16):
+        for bx in range(0, W, 16):
+            w = h = 16
+            if case == "mixed_sizes" and rng.integers(0, 3) == 0:
+                w, h = int(rng.choice([4, 8, 16])), int(rng.choice([2, 4, 8, 16]))
+                if w == 16 and h == 16:
+                    h = 8
+            dy, dx = rng.integers(-20, 21, 2)
+            doff = by * sd + bx + (int(rng.integers(0, 4)) if case == "unaligned_dst" and bx + 20 < W else 0)
+            f = (i >> 8) & 3
+            blocks.append((doff, (by + P + int(dy)) * ss + bx + P + int(dx), w, h, f, i & 15, (i >> 4) & 15, int(rng.integers(0, 2)), (0, 0)))
+            i += 1
+    if case == "ragged_n":
+        blocks = blocks[:2045]
+    if case == "unaligned_dst":
+        blocks = blocks[::2]             # shifted destinations must not overlap their neighbours
+    n = len(blocks)
+    O = ffi.oracle()
+    dst = rng.integers(0, 256, (H + 1, sd), dtype=np.uint8)
+    want = dst.copy()
+    for (do, so, w, h, f, mx, my, avg, _) in blocks:
+        O.ffo_vp9_mc(f, avg, C.cast(want.ctypes.data + do, u8p), sd, C.cast(ref.ctypes.data + so, u8p), ss, w, h, mx, my)
+    assert len({(b[1] - 3 - 3 * ss) & 15 for b in blocks}) == 16
+    rec = np.array(blocks, vp9.MC_DTYPE)
+    d_dst = torch.from_numpy(dst.copy()).cuda()
+    vp9.mc_batch(d_dst, sd, torch.from_numpy(ref).cuda(), ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 16).copy()).cuda(), n)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    assert (want != dst).sum() > 100000
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (case, bad[:5], len(bad))
+
+
 def test_vp9_mc_host_faces():
     from ffmpeg_amd import vp9
     _torch()
