@@ -782,7 +782,70 @@ def extras(torch, dev, torch_alloc=False):
     out["hevc_qpel_uni16_mixed"] = {"Mpixels/s": round(px / (ms * 1e-3) / 1e6, 1), "GB/s": round(2 * px / (ms * 1e-3) / 1e9, 1),
                                     "hbm_frac": round(2 * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "blocks": int(by.size),
                                     "ms": round(ms, 4)}
-    del refp, pic
+    # VP9 motion compensation (round 6: the 16 x 16 blocks on the matrix cores): the same block grid, the three 8-tap sets mixed, all (mx, my), put
+    from ffmpeg_amd import vp9 as _vp9
+    vmc = np.zeros(by.size, _vp9.MC_DTYPE)
+    vmc["dst_offset"], vmc["src_offset"] = mc["dst_offset"], mc["src_offset"]
+    vmc["width"] = vmc["height"] = 16
+    vmc["filter"] = rng.integers(0, 3, by.size)
+    vmc["mx"], vmc["my"] = rng.integers(0, 16, by.size), rng.integers(0, 16, by.size)
+    dvmc = torch.from_numpy(vmc.view(np.uint8).reshape(-1, 16)).to(dev)
+    _vp9.mc_batch(pic, w, refp, w + 2 * P, dvmc, by.size)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        _vp9.mc_batch(pic, w, refp, w + 2 * P, dvmc, by.size)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    out["vp9_mc16_8tap_mixed"] = {"Mpixels/s": round(px / (ms * 1e-3) / 1e6, 1), "GB/s": round(2 * px / (ms * 1e-3) / 1e9, 1),
+                                  "hbm_frac": round(2 * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "blocks": int(by.size), "ms": round(ms, 4)}
+    # H.264 chroma MC (h264chroma_template.c:28: the bilinear 8 x 8 blocks behind every 16 x 16 luma block of a 4:2:0 picture): one chroma
+    # plane per luma plane, mixed eighth-sample fractions, displacements +-4
+    from ffmpeg_amd import h264 as _h264
+    ch, cw = nf * h // 2, w // 2
+    cref = torch.randint(0, 256, (ch + 2 * P, cw + 2 * P), dtype=torch.uint8, device=dev)
+    cpic = torch.zeros((ch + 2 * P, cw + 2 * P), dtype=torch.uint8, device=dev)
+    cy, cx = np.meshgrid(np.arange(0, ch, 8), np.arange(0, cw, 8), indexing="ij")
+    cmc = np.zeros(cy.size, _h264.CHROMA_DTYPE)
+    cst = cw + 2 * P
+    cmc["dst_offset"] = ((cy + P) * cst + cx + P).reshape(-1)
+    cmc["src_offset"] = ((cy + P + rng.integers(-4, 5, cy.shape)) * cst + cx + P + rng.integers(-4, 5, cy.shape)).reshape(-1)
+    cmc["w_idx"], cmc["h"] = 0, 8
+    cmc["x"], cmc["y"] = rng.integers(0, 8, cy.size), rng.integers(0, 8, cy.size)
+    dcmc = torch.from_numpy(cmc.view(np.uint8).reshape(-1, 20)).to(dev)
+    _h264.chroma_mc_batch(cpic, cref, cst, dcmc, cy.size)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        _h264.chroma_mc_batch(cpic, cref, cst, dcmc, cy.size)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    cpx = cy.size * 64
+    out["h264_chroma_mc8_mixed"] = {"Mpixels/s": round(cpx / (ms * 1e-3) / 1e6, 1), "GB/s": round(2 * cpx / (ms * 1e-3) / 1e9, 1),
+                                    "hbm_frac": round(2 * cpx / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "blocks": int(cy.size), "ms": round(ms, 4)}
+    del refp, pic, cref, cpic
+    # AV_TX_INT32_MDCT (round 6, kernels/tx_wide.hip: the fixed-point codecs' transform), 1024 coefficients forward, 16,384 transforms:
+    # 12,288 B each (8 KiB in, 4 KiB out), bit-exact fixed-point arithmetic
+    from ffmpeg_amd import tx as _tx
+    nti = 16384
+    ctx_i = _tx.TxContext(_tx.INT32_MDCT, 0, 1024, 1.0)
+    ti = torch.randint(-2 ** 24, 2 ** 24, (nti, 2048), dtype=torch.int32, device=dev)
+    to = torch.zeros((nti, 1024), dtype=torch.int32, device=dev)
+    ctx_i.batch(to, ti)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        ctx_i.batch(to, ti)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    gbs = nti * 12288 / (ms * 1e-3) / 1e9
+    out["mdct1024_int32_fwd"] = {"Mtransforms/s": round(nti / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "transforms": nti, "ms": round(ms, 4)}
+    ctx_i.close()
+    del ti, to
     # AAC imdct_and_windowing: 65,536 all-long channel-frames (2 channels), inverse MDCT -> window -> overlap-add resident in HBM:
     # 18,432 B per channel-frame (ffmpeg_amd/csrc/aac_api.hip).  Window tables: the decoder's own, from the committed fixture.
     from ffmpeg_amd import aac
@@ -1716,6 +1779,8 @@ def main():
                                    ("me_esa_sad_r7", "MB-searches/s", "me_esa_sad_r7_MBsearches"), ("me_esa_sad_r7", "sad_issue_roof_frac", "me_esa_sad_r7_issue_frac"),
                                    ("me_esa_satd_r7", "MB-searches/s", "me_esa_satd_r7_MBsearches"),
                                    ("me_esa_satd_r7", "valu_issue_roof_frac", "me_esa_satd_r7_issue_frac"),
+                                   ("hevc_qpel_uni16_mixed", "hbm_frac", "hevc_qpel_uni16_mixed_frac"), ("vp9_mc16_8tap_mixed", "hbm_frac", "vp9_mc16_8tap_mixed_frac"),
+                                   ("h264_chroma_mc8_mixed", "hbm_frac", "h264_chroma_mc8_mixed_frac"), ("mdct1024_int32_fwd", "hbm_frac", "mdct1024_int32_fwd_frac"),
                                    ("sws_host_pointer_end_to_end", "ms_per_frame", "sws_host_pointer_ms_per_frame")):
                 if isinstance(ex.get(key), dict) and fld in ex[key]:
                     roof[name] = ex[key][fld]
