@@ -20,6 +20,8 @@ void ffhip_host_yuv2rgb_coeffs(FFHipSwsTables *t, int fullRange);
  * chroma subsampling shifts.  Returns 0 for any other format (outputs untouched). */
 int  ffhip_pixfmt_hbd(int fmt, int *depth, int *layout, int *hsub, int *vsub);
 /* init_range_convert_constants() (libswscale/swscale.c:591-624) for a source of range `src_range` (1 full) going to the other one */
+int ffhip_sws_rgb_source_plan(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat, int flags, int *half, int32_t table[9],
+                              int *bpp, int ofs[3]);
 void ffhip_sws_range_constants(int src_range, int dst_depth, uint32_t *lum_coeff, int64_t *lum_offset, uint32_t *chr_coeff, int64_t *chr_offset);
 
 #ifdef __cplusplus

@@ -462,6 +462,55 @@ void ffhip_sws_range_constants(int src_range, int dst_depth, uint32_t *lum_coeff
     }
 }
 
+/*
+ * A packed 8-bit RGB source in front of a YUV target (kernels/sws_rgbin.hip): the 14-bit planar format whose context serves it, or 0 when
+ * the conversion is off the hip path.  half: chrSrcHSubSample = 1 (utils.c:1340-1352: "drop every other pixel for chroma calculation
+ * unless user wants full chroma").  table: input_rgb2yuv_table for SWS_CS_DEFAULT and a limited-range target — fill_rgb2yuv_table()'s
+ * closing branch, the same double expressions (utils.c:693-703).  ofs: the R, G, B bytes of a pixel.
+ */
+int ffhip_sws_rgb_source_plan(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat, int flags, int *half, int32_t table[9],
+                              int *bpp, int ofs[3])
+{
+    const int S = 15; /* RGB2YUV_SHIFT */
+    int has_alpha = 0;
+    if (!is_rgb(srcFormat) || is_rgb(dstFormat) || dstFormat == FFHIP_PIX_FMT_GBRP)
+        return 0;
+    if (dstFormat >= FFHIP_PIX_FMT_YUVJ420P && dstFormat <= FFHIP_PIX_FMT_YUVJ444P)
+        return 0; /* a full-range target: the range stage behind the converters (swscale.c:568-660) is not wired to this entry */
+    switch (srcFormat) {
+    case FFHIP_PIX_FMT_RGB24: *bpp = 3; ofs[0] = 0; ofs[1] = 1; ofs[2] = 2; break;
+    case FFHIP_PIX_FMT_BGR24: *bpp = 3; ofs[0] = 2; ofs[1] = 1; ofs[2] = 0; break;
+    case FFHIP_PIX_FMT_RGBA:  *bpp = 4; ofs[0] = 0; ofs[1] = 1; ofs[2] = 2; has_alpha = 1; break;
+    case FFHIP_PIX_FMT_BGRA:  *bpp = 4; ofs[0] = 2; ofs[1] = 1; ofs[2] = 0; has_alpha = 1; break;
+    case FFHIP_PIX_FMT_ARGB:  *bpp = 4; ofs[0] = 1; ofs[1] = 2; ofs[2] = 3; has_alpha = 1; break;
+    case FFHIP_PIX_FMT_ABGR:  *bpp = 4; ofs[0] = 3; ofs[1] = 2; ofs[2] = 1; has_alpha = 1; break;
+    default: return 0;
+    }
+    /* alpha on both sides would run alpToYV12 into the target's alpha plane (needAlpha, utils.c:1398): not built */
+    if (has_alpha && (dstFormat == FFHIP_PIX_FMT_YUVA420P || dstFormat == FFHIP_PIX_FMT_YUVA422P || dstFormat == FFHIP_PIX_FMT_YUVA444P))
+        return 0;
+    /* the one unscaled special converter with an RGB source and a YUV target: bgr24ToYv12Wrapper -> ff_rgb24toyv12 (its own 2 x 2
+     * chroma arithmetic, swscale_unscaled.c:2483-2491) */
+    if (srcFormat == FFHIP_PIX_FMT_BGR24 && (dstFormat == FFHIP_PIX_FMT_YUV420P || dstFormat == FFHIP_PIX_FMT_YUVA420P) && srcW == dstW &&
+        srcH == dstH && !(flags & FFHIP_SWS_ACCURATE_RND) && !(dstW & 1))
+        return 0;
+    {
+        const int df = dstFormat == FFHIP_PIX_FMT_YUVA420P ? FFHIP_PIX_FMT_YUV420P : dstFormat == FFHIP_PIX_FMT_YUVA422P ? FFHIP_PIX_FMT_YUV422P :
+                       dstFormat == FFHIP_PIX_FMT_YUVA444P ? FFHIP_PIX_FMT_YUV444P : dstFormat;
+        *half = !(srcW & 1) && !(flags & FFHIP_SWS_FULL_CHR_H_INP) && (dstW >> chroma_hsub(df)) <= (srcW >> 1);
+    }
+    table[0] =  ((int)(0.299 * 219 / 255 * (1 << S) + 0.5));   /* RY */
+    table[1] =  ((int)(0.587 * 219 / 255 * (1 << S) + 0.5));   /* GY */
+    table[2] =  ((int)(0.114 * 219 / 255 * (1 << S) + 0.5));   /* BY */
+    table[3] = (-(int)(0.169 * 224 / 255 * (1 << S) + 0.5));   /* RU */
+    table[4] = (-(int)(0.331 * 224 / 255 * (1 << S) + 0.5));   /* GU */
+    table[5] =  ((int)(0.500 * 224 / 255 * (1 << S) + 0.5));   /* BU */
+    table[6] =  ((int)(0.500 * 224 / 255 * (1 << S) + 0.5));   /* RV */
+    table[7] = (-(int)(0.419 * 224 / 255 * (1 << S) + 0.5));   /* GV */
+    table[8] = (-(int)(0.081 * 224 / 255 * (1 << S) + 0.5));   /* BV */
+    return *half ? FFHIP_PIX_FMT_YUV422P14LE : FFHIP_PIX_FMT_YUV444P14LE;
+}
+
 FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, int dstW, int dstH,
                                             int dstFormat, int flags)
 {

@@ -426,6 +426,8 @@ struct FFHipW16Args {
     FFHipW16Job job[3];
     int njobs, units_per_frame, nframes, ht, vt;
     int sdepth, ddepth, smsb, dmsb;
+    int flat_dither;                          /* ddepth 8: every dither entry is 64 (c->lumDither8 = ff_sws_pb_64: the source is not one swscale dithers — a
+                                               * packed-RGB source's converter output, swscale.c:291) */
 };
 #ifdef __cplusplus
 bool ffhip_w16_pad_bank(const int16_t *filter, const int32_t *pos, int size, int n, int nsrc, int T, std::vector<int16_t> *of, std::vector<int32_t> *op);
@@ -472,5 +474,15 @@ int ffhip_launch_yuv2packed_line(int mode, const int16_t *lf, const int16_t *lum
                                  const FFHipYuv2RgbK &k, hipStream_t stream);
 int ffhip_launch_yuv2planeX8(const int16_t *filter, int fs, const int16_t *src, ptrdiff_t srcPitch, uint8_t *dest,
                              int dstW, const uint8_t *dither8, int offset, hipStream_t stream);
+
+/* sws_rgbin.hip: a packed 8-bit RGB source's converter pass into 14-bit planar lines (4:2:2 at half chroma width, else 4:4:4) */
+struct FFHipRgbInArgs {
+    const uint8_t *src; ptrdiff_t src_stride; size_t src_fp;
+    uint8_t *dst[3]; ptrdiff_t dst_stride[3]; size_t dst_fp[3];
+    int w, h;                           /* pixels; rows of this call */
+    int ro, go, bo;                     /* byte of the component inside a pixel */
+    int ry, gy, by, ru, gu, bu, rv, gv, bv; /* input_rgb2yuv_table (swscale_internal.h:468-477) */
+};
+int ffhip_launch_sws_rgb_in(const FFHipRgbInArgs &a, int bpp, int half, int nframes, hipStream_t stream);
 
 #endif

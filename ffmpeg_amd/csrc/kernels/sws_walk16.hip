@@ -420,7 +420,7 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                             w16_vdots<false>(t, pp[m % VP], pp[(m + 1) % VP], vc[m % VP], vc[(m + 1) % VP], 0);
                         if (d8) { /* uniform */
                             /* seed dither << 12, >> 19, clip to 8 bits (yuv2planeX_8_c, output.c:468-486): four bytes per lane */
-                            const uint2 drow = *reinterpret_cast<const uint2 *>(w16_dither[yy & 7]);
+                            const uint2 drow = A.flat_dither ? make_uint2(0x40404040u, 0x40404040u) : *reinterpret_cast<const uint2 *>(w16_dither[yy & 7]);
                             uint32_t b01, b23;
                             {
                                 int z[4];

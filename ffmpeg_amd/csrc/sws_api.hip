@@ -16,8 +16,24 @@
 #include "kernels/sws_kernels.h"
 #include "kernels/shim_arena.h"
 
+/* a packed 8-bit RGB source (round 6, kernels/sws_rgbin.hip): the context is that of the 14-bit planar source its converter lines make */
+struct FFHipSwsRgbIn {
+    int bpp = 0;            /* 0: none; 3 / 4 bytes per pixel */
+    int half = 0;           /* the chroma converters average pixel pairs (4:2:2 lines) */
+    int fmt = 0;            /* the caller's source format */
+    int ofs[3] = { 0, 0, 0 };
+    int32_t table[9] = {};
+    void *planes = nullptr; /* device: the converter lines of the batch in flight (Y, U, V, uint16) */
+    size_t planes_sz = 0;
+    void *stage = nullptr;  /* device: the host face's packed source rows */
+    size_t stage_sz = 0;
+};
+static thread_local int g_sws_create_flat_dither = 0; /* ffhip_sws_getContext -> ffhip_sws_from_tables: the context being made is an RGB source's */
+
 struct FFHipSwsContext {
     int device = 0; /* the banks live on this device; every call of the context makes it current for its duration */
+    FFHipSwsRgbIn rgb_in;
+    int flat_dither = 0; /* an 8-bit target's dither entries are all 64 (an RGB source is not dithered: swscale.c:291 looks at the source format) */
     int hbd_sw = 320, hbd_rows = 96; /* LDS shape the banks need: samples per staged source row, source rows per 32-row tile */
     int hbd = 0;    /* a side above 8 bits: the 16-bit scaler (sws_scale16.hip) serves the context, none of the 8-bit fast paths apply */
     FFHipSwsTables t;
@@ -598,6 +614,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
         return nullptr;
     c->device = ffhip_current_device();
     c->t = *t;
+    c->flat_dither = g_sws_create_flat_dither;
     c->chrSrcW = -((-t->srcW) >> fmt_hsub(t->srcFormat));
     c->chrSrcH = -((-t->srcH) >> fmt_vsub(t->srcFormat));
     c->unscaled_yuv2rgb = unscaled_rule(t);
@@ -663,7 +680,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
 
     if (fmt_hbd(t->srcFormat) || fmt_hbd(t->dstFormat)) {
         /* above 8 bits on either side: the 16-bit scaler takes the banks as they are */
-        if (fmt_rgb(t->dstFormat) || (t->srcW == t->dstW && t->srcH == t->dstH && t->src_range == t->dst_range) || t->srcFormat == FFHIP_PIX_FMT_NV21 ||
+        if (fmt_rgb(t->dstFormat) || (t->srcW == t->dstW && t->srcH == t->dstH && t->src_range == t->dst_range && !c->flat_dither /* (an RGB source's converter lines
+             * go through the scaler at equal sizes too: the reference has no special converter for them) */) || t->srcFormat == FFHIP_PIX_FMT_NV21 ||
             t->dstFormat == FFHIP_PIX_FMT_NV21) {
             ffhip_set_error("ffhip_sws: above 8 bits the hip path scales between the YUV formats only (no packed RGB, no equal-size conversion, no NV21 mix)");
             ffhip_sws_freeContext(c);
@@ -718,7 +736,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             /* ... and exact 2:1 (k_sws_down2<1>), banks of up to 8 taps */
             const int cdw = c->d[1].n, cdh = c->d[3].n;
             /* (round 5: also into an 8-bit target laid out alike — P01x -> NV12, planar -> planar — with the ordered dither on the way out) */
-            const bool dn8 = dd == 8 && (sl == 1 ? t->dstFormat == FFHIP_PIX_FMT_NV12 : !fmt_nv(t->dstFormat));
+            const bool dn8 = dd == 8 && !c->flat_dither /* (k_sws_down2 has the ordered dither only) */ && (sl == 1 ? t->dstFormat == FFHIP_PIX_FMT_NV12 : !fmt_nv(t->dstFormat));
             if (sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14 && sl == dl) || dn8) && sl != 2 && t->src_range == t->dst_range &&
                 t->srcW == 2 * t->dstW && t->srcH == 2 * t->dstH && cw == 2 * cdw && chh == 2 * cdh &&
                 !(t->dstW & 3) && t->dstW >= 12 && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
@@ -1031,14 +1049,80 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
 extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat,
                                                  int flags)
 {
+    /* a packed RGB source in front of a YUV target: the context of the 14-bit planar lines its converters make (kernels/sws_rgbin.hip) */
+    FFHipSwsRgbIn ri;
+    const int inner = ffhip_sws_rgb_source_plan(srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags, &ri.half, ri.table, &ri.bpp, ri.ofs);
+    if (inner) {
+        ri.fmt = srcFormat;
+        srcFormat = inner;
+    }
     FFHipSwsHostTables *h = ffhip_sws_tables_create(srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags);
     if (!h)
         return nullptr;
     FFHipSwsTables t;
     ffhip_sws_tables_get(h, &t);
+    g_sws_create_flat_dither = inner != 0;
     FFHipSwsContext *c = ffhip_sws_from_tables(&t);
+    g_sws_create_flat_dither = 0;
     ffhip_sws_tables_free(h);
+    if (c && inner)
+        c->rgb_in = ri;
     return c;
+}
+
+extern "C" FFHipSwsContext *ffhip_sws_from_tables_rgb_source(const FFHipSwsTables *t, int rgbFormat, const int32_t rgb2yuv[9])
+{
+    if (!t || !rgb2yuv || (t->srcFormat != FFHIP_PIX_FMT_YUV422P14LE && t->srcFormat != FFHIP_PIX_FMT_YUV444P14LE) || t->src_range != t->dst_range) {
+        ffhip_set_error("ffhip_sws_from_tables_rgb_source: the tables must describe the converter lines (yuv422p14le / yuv444p14le source, equal ranges)");
+        return nullptr;
+    }
+    FFHipSwsRgbIn ri;
+    int32_t unused[9];
+    int half = 0;
+    /* the formats and the component bytes from the plan the stand-alone constructor uses; half and the table are the caller's */
+    if (!ffhip_sws_rgb_source_plan(t->srcW, t->srcH, rgbFormat, t->dstW, t->dstH, t->dstFormat, t->flags, &half, unused, &ri.bpp, ri.ofs)) {
+        ffhip_set_error("ffhip_sws_from_tables_rgb_source: format pair %d -> %d is not on the hip path", rgbFormat, t->dstFormat);
+        return nullptr;
+    }
+    ri.half = t->srcFormat == FFHIP_PIX_FMT_YUV422P14LE;
+    if (ri.half && (t->srcW & 1)) {
+        ffhip_set_error("ffhip_sws_from_tables_rgb_source: half-width chroma needs an even source width");
+        return nullptr;
+    }
+    ri.fmt = rgbFormat;
+    memcpy(ri.table, rgb2yuv, sizeof(ri.table));
+    g_sws_create_flat_dither = 1;
+    FFHipSwsContext *c = ffhip_sws_from_tables(t);
+    g_sws_create_flat_dither = 0;
+    if (c)
+        c->rgb_in = ri;
+    return c;
+}
+
+extern "C" int ffhip_sws_set_rgb2yuv(FFHipSwsContext *c, const int32_t rgb2yuv[9])
+{
+    if (!c || !rgb2yuv || !c->rgb_in.bpp)
+        return FFHIP_EINVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    memcpy(c->rgb_in.table, rgb2yuv, sizeof(c->rgb_in.table));
+    return 0;
+}
+
+/* the converter pass of an RGB-source context over `rows` source rows of nframes frames: src -> the 14-bit planes at p[] */
+static int rgb_in_launch(const FFHipSwsContext *c, int nframes, const uint8_t *src, ptrdiff_t src_stride, size_t src_fp, int rows, uint8_t *const p[3],
+                         const int pitch[3], const size_t fp[3], hipStream_t stream)
+{
+    FFHipRgbInArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = src; a.src_stride = src_stride; a.src_fp = src_fp;
+    for (int i = 0; i < 3; i++) {
+        a.dst[i] = p[i]; a.dst_stride[i] = pitch[i]; a.dst_fp[i] = fp[i];
+    }
+    a.w = c->t.srcW; a.h = rows;
+    a.ro = c->rgb_in.ofs[0]; a.go = c->rgb_in.ofs[1]; a.bo = c->rgb_in.ofs[2];
+    const int32_t *T = c->rgb_in.table;
+    a.ry = T[0]; a.gy = T[1]; a.by = T[2]; a.ru = T[3]; a.gu = T[4]; a.bu = T[5]; a.rv = T[6]; a.gv = T[7]; a.bv = T[8];
+    return ffhip_launch_sws_rgb_in(a, c->rgb_in.bpp, c->rgb_in.half, nframes, stream);
 }
 
 /* sws_setColorspaceDetails() on a live context (libswscale/utils.c:848-1000 ends in ff_yuv2rgb_c_init_tables() for RGB targets): the
@@ -1141,6 +1225,10 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
     FFHipDeviceGuard dg(c->device);
     if (c->dev_tables)
         (void)hipFree(c->dev_tables);
+    if (c->rgb_in.planes)
+        (void)hipFree(c->rgb_in.planes);
+    if (c->rgb_in.stage)
+        (void)hipFree(c->rgb_in.stage);
     if (c->mf_dev)
         (void)hipFree(c->mf_dev);
     if (c->up2_dev)
@@ -1301,6 +1389,7 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
             W.nframes = nframes;
             W.ht = c->w16_ht; W.vt = c->w16_vt;
             W.sdepth = sd; W.ddepth = dd; W.smsb = sl == 1; W.dmsb = dl == 1;
+            W.flat_dither = c->flat_dither;
             /* rows per strip: 64 when the batch fills the chip several times over; a strip re-filters VT - 1 source rows, but a
              * wave is one dependent chain of rows, and a launch of fewer waves than the chip holds (32 frames of 720p -> 1080p: 6,656
              * against 7,168 slots) runs at the speed of one chain: halve until there are 1.5 slots' worth (measured, 720p -> 1080p:
@@ -1372,7 +1461,7 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
         p.ddepth = dd; p.dmsb = dl == 1; p.dstep = pl && dl ? 2 : 1; p.dchan = pl && dl ? pl - 1 : 0;
         p.h = c->d[pl ? 1 : 0]; p.v = c->d[pl ? 3 : 2];
         p.dstW = p.h.n; p.dstH = p.v.n;
-        p.dither = dd == 8 && sd > 8;       /* swscale.c:291: should_dither = isNBPS(src) || is16BPS(src) */
+        p.dither = dd == 8 && sd > 8 && !c->flat_dither; /* swscale.c:291: should_dither = isNBPS(src) || is16BPS(src) — of the caller's format */
         p.dither_off = pl == 2 ? 3 : 0;     /* vscale.c: the V plane reads the dither row three entries on; yuv2nv12cX_c: (i + 3) & 7 */
         if (t.src_range != t.dst_range) {
             p.rc_coeff = pl ? t.chrConvertRange_coeff : t.lumConvertRange_coeff;
@@ -1414,6 +1503,51 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
                                          const int srcStride[4], const size_t srcFramePitch[4], void *const dst[4],
                                          const int dstStride[4], const size_t dstFramePitch[4], void *stream_)
 {
+    if (c && c->rgb_in.bpp) {
+        /* a packed RGB source: the converter pass into the context's own planes (kept for the next call; one batch in flight per context:
+         * the host face's lock), then the 14-bit planar context on those */
+        if (!src || !src[0] || !srcStride || !srcFramePitch || nframes <= 0)
+            return FFHIP_EINVAL;
+        FFHipDeviceGuard dg(c->device);
+        std::lock_guard<std::mutex> lk(c->mu);
+        const int cw = c->rgb_in.half ? c->t.srcW / 2 : c->t.srcW;
+        const int pitch[3] = { ((c->t.srcW * 2) + 255) & ~255, ((cw * 2) + 255) & ~255, ((cw * 2) + 255) & ~255 };
+        const size_t fp[3] = { (size_t)pitch[0] * c->t.srcH, (size_t)pitch[1] * c->t.srcH, (size_t)pitch[2] * c->t.srcH };
+        const size_t need = (fp[0] + fp[1] + fp[2]) * (size_t)nframes + 256;
+        if (need > c->rgb_in.planes_sz) {
+            if (c->rgb_in.planes) {
+                (void)hipDeviceSynchronize(); /* an earlier batch may still read them */
+                (void)hipFree(c->rgb_in.planes);
+            }
+            c->rgb_in.planes = nullptr;
+            c->rgb_in.planes_sz = 0;
+            if (hipMalloc(&c->rgb_in.planes, need) != hipSuccess) {
+                ffhip_set_error("ffhip_sws_scale_batch_dev: hipMalloc(%zu) for an RGB source's converter lines failed", need);
+                return FFHIP_ENOMEM;
+            }
+            c->rgb_in.planes_sz = need;
+        }
+        uint8_t *b = static_cast<uint8_t *>(c->rgb_in.planes);
+        uint8_t *const p[3] = { b, b + fp[0] * nframes, b + (fp[0] + fp[1]) * nframes };
+        const int r = rgb_in_launch(c, nframes, static_cast<const uint8_t *>(src[0]), srcStride[0], srcFramePitch[0], c->t.srcH, p, pitch, fp, (hipStream_t)stream_);
+        if (r < 0)
+            return r;
+        const void *s2[4] = { p[0], p[1], p[2], nullptr };
+        const int ss2[4] = { pitch[0], pitch[1], pitch[2], 0 };
+        const size_t sf2[4] = { fp[0], fp[1], fp[2], 0 };
+        const int r2 = scale_batch_dev(c, nframes, s2, ss2, sf2, dst, dstStride, dstFramePitch, stream_);
+        if (r2 < 0 || !c->t.dst_alpha_fill)
+            return r2;
+        if (!dst[3]) {
+            ffhip_set_error("ffhip_sws_scale_batch_dev: the format has an alpha plane: plane 3 is NULL");
+            return FFHIP_EINVAL;
+        }
+        for (int f = 0; f < nframes; f++) /* opaque: the source carries no alpha into a planar target here (swscale.c:536-553) */
+            if (hipMemset2DAsync(static_cast<uint8_t *>(dst[3]) + (size_t)f * dstFramePitch[3], (size_t)dstStride[3], 255, (size_t)c->t.dstW, (size_t)c->t.dstH,
+                                 (hipStream_t)stream_) != hipSuccess)
+                return FFHIP_EINVAL;
+        return r2;
+    }
     if (c && (c->unscaled_yuv2rgb || (c->t.dst_alpha_fill == 2 && fmt_rgb(c->t.dstFormat)))) /* one launch; a source alpha plane (src[3]) is read by it */
         return scale_batch_dev(c, nframes, src, srcStride, srcFramePitch, dst, dstStride, dstFramePitch, stream_);
     if (c && c->t.dst_alpha_fill && (!dst || !dst[3] || (c->t.dst_alpha_fill == 2 && (!src || !src[3])))) {
@@ -2374,6 +2508,32 @@ static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], cons
     const void *dsrc[4] = { 0, 0, 0, 0 };
     void *ddst[4] = { 0, 0, 0, 0 };
     size_t fp[4] = { 0, 0, 0, 0 };
+    if (c->rgb_in.bpp) {
+        /* a packed RGB source: the slice's rows go up as they are and the converter pass writes rows [y, y + h) of the three 14-bit planes
+         * (the converters work line by line, and the 4:2:2 / 4:4:4 lines have no vertical subsampling: a slice is a slice of every plane) */
+        const int rows = sliced ? srcSliceH : srcRows, row0 = sliced ? srcSliceY : 0;
+        const int wb = t.srcW * c->rgb_in.bpp, rp = (wb + 255) & ~255;
+        const size_t need = (size_t)rp * rows + 256;
+        if (need > c->rgb_in.stage_sz) {
+            if (c->rgb_in.stage)
+                (void)hipFree(c->rgb_in.stage);
+            c->rgb_in.stage = nullptr;
+            c->rgb_in.stage_sz = 0;
+            if (hipMalloc(&c->rgb_in.stage, need) != hipSuccess) {
+                ffhip_set_error("ffhip_sws_scale: staging hipMalloc(%zu) failed", need);
+                return FFHIP_ENOMEM;
+            }
+            c->rgb_in.stage_sz = need;
+        }
+        HIP_TRY(copy2d(c->rgb_in.stage, rp, src[0], srcStride[0], wb, rows, hipMemcpyHostToDevice));
+        uint8_t *const pp[3] = { base + off_s[0] + (size_t)row0 * pitch_s[0], base + off_s[1] + (size_t)row0 * pitch_s[1],
+                                 base + off_s[2] + (size_t)row0 * pitch_s[2] };
+        const int r = rgb_in_launch(c, 1, static_cast<const uint8_t *>(c->rgb_in.stage), rp, 0, rows, pp, pitch_s, fp, 0);
+        if (r < 0)
+            return r;
+        for (int i = 0; i < 3; i++)
+            dsrc[i] = base + off_s[i];
+    } else
     for (int i = 0; i < ns; i++) {
         /* a slice brings luma rows [y, y + h) and chroma rows [y >> 1, (y + h + 1) >> 1) (swscale.c:280-283) */
         const int vs = fmt_vsub(c->t.srcFormat);

@@ -201,6 +201,7 @@ int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t 
  * converter's tail case and stays there). */
 /* Flags: numeric values are SwsFlags' (libswscale/swscale.h:130-153). */
 #define FFHIP_SWS_FULL_CHR_H_INT 0x2000 /* full chroma interpolation for packed RGB targets (swscale.h:147) */
+#define FFHIP_SWS_FULL_CHR_H_INP 0x4000 /* full chroma input from a packed RGB source (swscale.h:153): no horizontal 2:1 in the converters */
 #define FFHIP_SWS_FAST_BILINEAR 0x1
 #define FFHIP_SWS_BILINEAR      0x2
 #define FFHIP_SWS_BICUBIC       0x4
@@ -271,6 +272,18 @@ FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcFormat,
  *  converter has no banks (ff_sws_init_single_context() returns before initFilter(), libswscale/utils.c:1625-1637): for the
  *  equal-size yuv420p -> packed RGB table converter (swscale_unscaled.c:2425-2431) the four banks may be left NULL. */
 FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t);
+/** The same for a packed 8-bit RGB source (rgb24 / bgr24 / rgba / bgra / argb / abgr) in front of a YUV target (round 6; ffhip_sws_getContext()
+ *  takes these formats directly).  In the reference such a source is its input converters' int16 lines (lumToYV12 / chrToYV12: rgb24ToY_c,
+ *  rgb24ToUV_c, rgb24ToUV_half_c and their twins, libswscale/input.c:264-400,1068-1190) scaled by hScale16To15_c at sh = 13
+ *  (swscale.c:100-128) — the 16-bit path of a 14-bit planar source, undithered (swscale.c:291).  `t` describes that conversion:
+ *  t->srcFormat = FFHIP_PIX_FMT_YUV422P14LE when the chroma converters read pixel pairs (c->chrSrcHSubSample == 1, utils.c:1340-1352),
+ *  FFHIP_PIX_FMT_YUV444P14LE otherwise; the banks, ranges (equal) and flags are the context's own.  rgbFormat: the caller's source
+ *  format; rgb2yuv: c->input_rgb2yuv_table[RY_IDX .. BV_IDX] (swscale_internal.h:468-477; sws_setColorspaceDetails() fills it).
+ *  The context's source is then ONE packed plane, on every face. */
+FFHipSwsContext *ffhip_sws_from_tables_rgb_source(const FFHipSwsTables *t, int rgbFormat, const int32_t rgb2yuv[9]);
+/** sws_setColorspaceDetails() on a live RGB-source context (fill_rgb2yuv_table(), libswscale/utils.c:614-705,1002): the converter table
+ *  replaces the context's.  0, or FFHIP_EINVAL for a context that has no RGB source. */
+int ffhip_sws_set_rgb2yuv(FFHipSwsContext *c, const int32_t rgb2yuv[9]);
 /** The yuv2rgb fields of the tables (yuv2rgb_cy .. yuv2rgb_yoffs, yuv2rgb_full[]) as ff_yuv2rgb_c_init_tables() derives them
  *  (libswscale/yuv2rgb.c:750-797) from what the context stores: inv_table = c->srcColorspaceTable, fullRange = sws->src_range,
  *  c->brightness / c->contrast / c->saturation (sws_setColorspaceDetails(), utils.c:848-905).  No device needed.  0 or FFHIP_EINVAL. */

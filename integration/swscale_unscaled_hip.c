@@ -41,6 +41,8 @@ typedef struct HipUnscaled {
     int              scaled;          /* a scaled context (ff_sws_hip_scaled_hook() below) ... */
     int              graph;           /* ... made by the filter graph (not sws_init_context()): slices arrive in TARGET lines */
     int              cs[4], range, brightness, contrast, saturation; /* what ctx's coefficients were derived from */
+    int              rgb_src;         /* a packed RGB source (ffhip_sws_from_tables_rgb_source) and the converter table the context holds */
+    int32_t          rgb2yuv[9];
     long             calls, fallbacks;
     /* where the frame in flight runs: libffhip converts when a frame's LAST source slice arrives, so a frame must stay with
      * the side that took its first slice.  0: the next call starts a frame; 1: libffhip holds the earlier slices; 2: the C path has it */
@@ -210,6 +212,18 @@ static int hip_convert_scaled(SwsInternal *c, const uint8_t *const src[], const 
         else
             hip_colorspace_note(c, u);
     }
+    if (u->rgb_src) {
+        /* sws_setColorspaceDetails() after the context was made rewrites c->input_rgb2yuv_table (fill_rgb2yuv_table, utils.c:1002) and may
+         * open a range stage behind the converters (ff_sws_init_range_convert): the table is handed over again, the range stage is the C path's */
+        if (c->opts.src_range != c->opts.dst_range)
+            prepared = 0;
+        else if (memcmp(u->rgb2yuv, c->input_rgb2yuv_table, sizeof(u->rgb2yuv))) {
+            if (ffhip_sws_set_rgb2yuv(u->ctx, c->input_rgb2yuv_table) < 0)
+                prepared = 0;
+            else
+                memcpy(u->rgb2yuv, c->input_rgb2yuv_table, sizeof(u->rgb2yuv));
+        }
+    }
     if (u->graph) {
         /* run_legacy_unscaled() (graph.c:394-404): y, h are lines of the pass, i.e. of the TARGET, and the graph runs this pass in one
          * slice (threads == 1 is a condition of the hook): the frame */
@@ -278,9 +292,17 @@ static int hip_scaled_format(enum AVPixelFormat f, int target)
 av_cold void ff_sws_hip_scaled_hook(SwsInternal *c)
 {
     const enum AVPixelFormat src = c->opts.src_format, dst = c->opts.dst_format;
-    const int srcf = hip_scaled_format(src, 0), dstf = hip_scaled_format(dst, 1);
+    int srcf = hip_scaled_format(src, 0), dstf = hip_scaled_format(dst, 1), rgb_src = 0;
     FFHipSwsTables t;
     HipUnscaled *u;
+
+    /* a packed 8-bit RGB source in front of a YUV target: libffhip runs the input converters itself and takes the context as the one of
+     * their 14-bit lines (ffhip_sws_from_tables_rgb_source()); no alpha plane into the target, no vertical chroma drop, equal ranges */
+    if (srcf < 0 && dstf >= 0 && !isAnyRGB(dst) && hip_scaled_format(src, 1) >= 0 && !c->needAlpha && !c->chrSrcVSubSample &&
+        c->opts.src_range == c->opts.dst_range && !c->readLumPlanar && !c->readChrPlanar) {
+        rgb_src = (int)src;
+        srcf = c->chrSrcHSubSample ? AV_PIX_FMT_YUV422P14LE : AV_PIX_FMT_YUV444P14LE;
+    }
 
     if (!(av_get_cpu_flags() & AV_CPU_FLAG_HIP) || c->convert_unscaled || c->hw_priv || c->parent || c->nb_slice_ctx ||
         c->opts.threads != 1 || c->cascaded_context[0] || c->opts.gamma_flag || srcf < 0 || dstf < 0 ||
@@ -310,12 +332,14 @@ av_cold void ff_sws_hip_scaled_hook(SwsInternal *c)
     u = av_refstruct_alloc_ext(sizeof(*u), 0, NULL, hip_unscaled_free);
     if (!u)
         return;
-    u->ctx = ffhip_sws_from_tables(&t);
+    u->ctx = rgb_src ? ffhip_sws_from_tables_rgb_source(&t, rgb_src, c->input_rgb2yuv_table) : ffhip_sws_from_tables(&t);
     if (!u->ctx) {                      /* no device, or a conversion libffhip does not take: ff_swscale() stays */
         av_refstruct_unref(&u);
         return;
     }
     hip_colorspace_note(c, u);
+    u->rgb_src = rgb_src;
+    memcpy(u->rgb2yuv, c->input_rgb2yuv_table, sizeof(u->rgb2yuv));
     u->scaled = 1;
     u->graph  = !c->is_legacy_init;     /* sws_init_context() sets it before it gets here (utils.c:1892); the graph's contexts are not made by it */
     c->hw_priv          = u;

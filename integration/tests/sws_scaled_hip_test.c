@@ -273,6 +273,17 @@ int main(int argc, char **argv)
     CASE("nv12", 640, 360, "nv12", 1280, 720, SWS_BICUBIC, -64, 0, 0, 1);
     CASE("yuv420p", 1280, 720, "rgb24", 640, 360, SWS_BICUBIC, -1, 0, 0, 1);
     CASE("nv12", 640, 360, "rgb24", 640, 360, SWS_BICUBIC, -32, 0, 0, 1);
+    /* packed RGB sources (round 6): a screen capture or an image for an encoder — the input converters run on the device, the context is
+     * the one of their 14-bit lines; every component order, half and full chroma input, slices, a colourspace set after the context was made */
+    CASE("bgra", 1920, 1080, "nv12", 1920, 1080, SWS_BICUBIC, 0, 0, 0, 1);
+    CASE("rgb24", 1280, 720, "yuv420p", 1280, 720, SWS_BICUBIC, 0, 0, 0, 1);
+    CASE("rgba", 1920, 1080, "yuv420p", 1280, 720, SWS_BICUBIC, 0, 0, 0, 1);
+    CASE("argb", 641, 361, "yuv444p", 641, 361, SWS_BILINEAR, 0, 0, 0, 1);
+    CASE("abgr", 640, 360, "yuv420p", 1280, 720, SWS_BICUBIC | SWS_FULL_CHR_H_INP, 64, 0, 0, 1);
+    CASE("bgr24", 1280, 720, "nv12", 1280, 720, SWS_BICUBIC | SWS_ACCURATE_RND, 0, 1, 0, 1);
+    CASE("rgb24", 640, 360, "yuv420p", 640, 360, SWS_BICUBIC, 0, 0, 1, 1);
+    /* ... and bgr24 -> yuv420p at the source's size is the reference's own special converter (ff_rgb24toyv12): the hook finds it installed */
+    CASE("bgr24", 640, 360, "yuv420p", 640, 360, SWS_BICUBIC, 0, 0, 0, 0);
     /* SWS_FAST_BILINEAR scales 8-bit sources through ff_hyscale_fast_c, not through the banks: left to ff_swscale() */
     CASE("yuv420p", 640, 360, "yuv420p", 1280, 720, SWS_FAST_BILINEAR, 0, 0, 0, 0);
     CASE("nv12", 640, 360, "rgb24", 1280, 720, SWS_FAST_BILINEAR, 0, 0, 0, 0);

@@ -297,4 +297,10 @@ void ffo_sws_uops_free(FfoSwsUOps **p);
 int  ffo_sws_uops_block_size(const FfoSwsUOps *p);
 void ffo_sws_uops_func(const struct FFHipSwsOpExec *e, const void *priv, int bx_start, int y_start, int bx_end, int y_end);
 
+/* ffo_sws_rgbin.c: the input stage of packed 8-bit RGB sources (lines for ffo_sws_scale_frame_hbd at sdepth 14 | 0x100) */
+void ffo_sws_rgb2yuv_default(int32_t t[9]);
+int  ffo_sws_rgb_half(int srcW, int dstW, int chrDstHSubSample, int flags);
+void ffo_sws_rgb_in(const uint8_t *src, ptrdiff_t stride, int w, int h, int bpp, int ro, int go, int bo, int half, const int32_t t[9],
+                    uint16_t *Y, ptrdiff_t ys, uint16_t *U, uint16_t *V, ptrdiff_t cs);
+
 #endif

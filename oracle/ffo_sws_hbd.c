@@ -129,7 +129,11 @@ int ffo_sws_scale_frame_hbd(const FfoSwsTables *t, int sdepth, int slayout, int 
     const int chrSrcH = chrDstH == dstH ? /* vChr positions tell: */ 0 : 0;
     (void)chrSrcH;
     const int wide = ddepth == 16;
-    const int dith = ddepth == 8 && sdepth > 8; /* swscale.c should_dither: isNBPS(src) || is16BPS(src) */
+    /* sdepth | 0x100: the lines are a packed RGB source's converter output (ffo_sws_rgbin.c): 14-bit samples, and no dither — swscale.c's
+     * should_dither = isNBPS(src) || is16BPS(src) looks at the caller's source format */
+    const int from_rgb = sdepth & 0x100;
+    sdepth &= 0xff;
+    const int dith = ddepth == 8 && sdepth > 8 && !from_rgb;
     /* chroma source rows: the vertical chroma bank's reach */
     int csh = 0;
     for (int y = 0; y < chrDstH; y++)

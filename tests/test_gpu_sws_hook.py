@@ -48,10 +48,16 @@ def test_sws_scale_of_scaled_contexts_goes_through_the_hip_swsfunc():
     assert lines[0].startswith("OK  ") and "nv12 1920x1080 -> rgb24 1920x1080" in lines[0] and "hip SwsFunc == ff_swscale" in lines[0], lines[0]
     assert any("nv12 1920x1080 -> nv12 3840x2160" in l and l.startswith("OK  ") for l in lines), tail
     m = re.search(r"(\d+) cases, 0 failed", r.stdout)
-    assert m and int(m.group(1)) >= 34, tail
+    assert m and int(m.group(1)) >= 42, tail
     assert any("yuv444p 1920x1080 -> rgb24 1920x1080" in l and "hip SwsFunc == ff_swscale" in l for l in lines), tail
     # round 6: the frame API asking for TARGET slices of a scaled picture (slice -64 / -1 / -32 in the listing) gives the C
     # scaler's picture; SWS_FAST_BILINEAR contexts (flags 0x1) are left to ff_swscale() like the dithered 16-bit target and the gray source
     assert sum(" slice -" in l and l.startswith("OK  ") for l in lines) == 3, tail
     # (counted over the whole output: the runtime's own stderr lines can land inside a line of the listing)
-    assert r.stdout.count("left to C") == 4 and sum("flags 0x1 " in l for l in lines) == 2, tail
+    assert r.stdout.count("left to C") == 5 and sum("flags 0x1 " in l for l in lines) == 2, tail
+    # round 6: packed RGB sources (a capture / an image for an encoder): the input converters run on the device, the context is that of their
+    # 14-bit lines (ffhip_sws_from_tables_rgb_source) — seven conversions through the hook, and bgr24 -> yuv420p at the source's size, the
+    # reference's own special converter, left alone
+    assert sum(l.startswith("OK  ") and re.search(r"^OK   (rgb24|bgr24|rgba|bgra|argb|abgr) ", l) is not None and "hip SwsFunc == ff_swscale" in l
+               for l in lines) == 7, tail
+    assert any("bgr24 640x360 -> yuv420p 640x360" in l and "left to C" in l for l in lines), tail

@@ -53,7 +53,8 @@ ROWS = [
     ("`k_h264_intra_frame`", "1080p I-picture through the picture layer: ms alone; pictures/s at 32 wavefronts per launch", "the dependency chain mb_w + 2 mb_h", "—", "h264_intra_picture_1080p", ("ms_per_picture", "wavefront_pictures_per_s_32_per_launch")),
     ("`FFHipH264Picture` P-pictures 1080p", "MC + weights + IDCT + deblock per picture: ms alone; pictures/s for 16 flushed together", "—", "—", "h264_picture_pipeline_1080p", ("ms_per_picture_alone", "pictures_per_s_batched_flush_of_16")),
     ("`k_hevc_idct`, `k_hevc_idct32_mfma`", "HEVC 8×8 / 16×16 / 32×32 inverse transform + add_residual", "HBM / LDS", "6 B / sample", ("hevc_idct8_add", "hevc_idct16_add", "hevc_idct32_add"), ("hbm_frac",)),
-    ("`k_hevc_mc`", "put_hevc_qpel_uni 16×16, mixed positions", "as block MC", "2 B / sample", "hevc_qpel_uni16_mixed", ("hbm_frac",)),
+    ("`k_hevc_qpel_m` (`hevc_qpel_m.hip`), `k_vp9_mc_m` (`vp9_mc.hip`), `k_h264_chroma_mc`", "round 6, the block-MC family on the matrix cores: put_hevc_qpel_uni 16×16, mixed positions; VP9 8-tap MC 16×16, three sets mixed; H.264 chroma MC 8×8 (VALU)", "as block MC", "2 B / sample", ("hevc_qpel_uni16_mixed", "vp9_mc16_8tap_mixed", "h264_chroma_mc8_mixed"), ("hbm_frac",)),
+    ("`k_txw` (`tx_wide.hip`)", "round 6: AV_TX_INT32_MDCT 1024 forward, 16,384 transforms, bit-exact fixed point", "LDS network + 64-bit products", "12,288 B per MDCT", "mdct1024_int32_fwd", ("hbm_frac",)),
     ("`k_vp9_itxfm`, `k_vp9_lf_frame_wg`", "VP9 32×32 inverse transform + add; superblock-order loop filter of a 4K picture: ms alone / pictures/s at 32 per launch", "HBM / chain", "6 B / sample", ("vp9_itxfm32_add", "vp9_loopfilter_frame_4k"), ("hbm_frac", "ms_per_picture_one_stream")),
     ("`k_me_esa_g` (`me_cmp.hip`)", "exhaustive SAD search 16×16, R = 7, 8 pairs of 4K planes (BASELINE configs[4])", "`v_sad_u8` issue", "57,600 abs-diff / MB", "me_esa_sad_r7", ("MB-searches/s", "sad_issue_roof_frac")),
     ("`k_me_esa_satd_mx` (`me_satd.hip`)", "the same search with the 8×8 Hadamard cost on the matrix cores, 8 / 32 pairs", "VALU issue (one `v_sad_u32` per coefficient)", "—", ("me_esa_satd_r7", "me_esa_satd_r7_32_pairs"), ("MB-searches/s",)),

@@ -826,12 +826,37 @@ def tx_wide():
     np.savez_compressed(os.path.join(OUT, "tx_wide.npz"), **d)
 
 
+def sws_rgbin():
+    """packed 8-bit RGB sources into YUV targets through the reference's sws_scale(): inputs + outputs (tests/golden/sws_rgbin.npz)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_oracle_vs_ref_sws_rgbin as T
+    d = {}
+    cases = [("rgb24", 64, 36, "yuv420p", 64, 36, 4), ("bgra", 96, 54, "nv12", 64, 36, 2), ("argb", 65, 37, "yuv420p", 65, 37, 4),
+             ("abgr", 64, 36, "yuv444p", 100, 36, 4), ("bgr24", 64, 36, "nv12", 64, 36, 4), ("rgba", 64, 36, "yuv420p", 64, 36, 4 | 0x4000),
+             ("rgb24", 48, 32, "yuv422p", 96, 64, 4)]
+    rng = np.random.default_rng(808)
+    for i, (sf, sw, sh, df, dw, dh, fl) in enumerate(cases):
+        rgb = T.make_rgb(sf, sw, sh, rng, pad=0)
+        want = T.alloc_dst(df, dw, dh, pad=0)
+        ctx = R.ffref_sws_create(sw, sh, PIX[sf], dw, dh, T.DST[df][0], fl, 1)
+        sp, ss = T.planes_of([rgb])
+        wp, ws = T.planes_of(want)
+        assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, wp, ws) == dh
+        R.ffref_sws_free(ctx)
+        d["c%d_meta" % i] = np.array([PIX[sf], sw, sh, T.DST[df][0], dw, dh, fl], np.int64)
+        d["c%d_src" % i] = rgb
+        for p, a in enumerate(want):
+            d["c%d_dst%d" % (i, p)] = a
+    d["ncases"] = np.array([len(cases)])
+    np.savez_compressed(os.path.join(OUT, "sws_rgbin.npz"), **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422(); round4(); tx_wide()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422(); round4(); tx_wide(); sws_rgbin()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
