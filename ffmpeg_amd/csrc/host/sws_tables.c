@@ -582,8 +582,10 @@ FFHipSwsHostTables *ffhip_sws_tables_create(int srcW, int srcH, int srcFormat, i
         return NULL;
     }
     if (ffhip_pixfmt_hbd(srcFormat, NULL, NULL, NULL, NULL) || ffhip_pixfmt_hbd(dstFormat, NULL, NULL, NULL, NULL)) {
-        if (rgbt) {
-            ffhip_set_error("ffhip_sws: sources above 8 bits to packed RGB are not on the hip path");
+        /* (round 6: a source above 8 bits into packed 8-bit RGB runs in two stages — the 16-bit walker into a 4:2:2-shaped intermediate with
+         * an unclipped luma, then the RGB writer of sws_y16rgb.hip; ffhip_sws_from_tables() decides whether the banks fit) */
+        if (dstFormat == FFHIP_PIX_FMT_GBRP) {
+            ffhip_set_error("ffhip_sws: sources above 8 bits to planar RGB are not on the hip path");
             return NULL;
         }
         /* (equal sizes without a range change take the reference's special converters — planarCopyWrapper, planarToP01xWrapper, ...:

@@ -418,6 +418,8 @@ struct FFHipW16Job {
     const int16_t *vf; const int32_t *vp;     /* device: dstH x vt taps */
     int ncb, nstrips, strip_rows, unit_begin;
     int dither_off;                           /* ddepth 8, plane jobs: 3 for the V plane (its dither row is read three entries on), else 0 */
+    int y16;                                  /* ddepth 8, a plane job: the vertical sums >> 19 stored UNCLIPPED as int16 (8 bytes per lane): the luma of a
+                                               * packed-RGB target's first stage, as FFHipLwJob.y16 */
     int srcW;                                 /* samples of one channel per source row */
     int stage;                                /* round 6: the span of a wave's windows in a source row fits 1 KiB (and the positions ascend): the row
                                                * segment is loaded ONCE per wave into LDS and the lanes' windows are read from there */
@@ -426,7 +428,7 @@ struct FFHipW16Args {
     FFHipW16Job job[3];
     int njobs, units_per_frame, nframes, ht, vt;
     int sdepth, ddepth, smsb, dmsb;
-    int flat_dither;                          /* ddepth 8: every dither entry is 64 (c->lumDither8 = ff_sws_pb_64: the source is not one swscale dithers — a
+    int flat_dither;                          /* ddepth 8: 1: every dither entry is 64; 2: every entry is 0 (yuv2rgb_2's sums carry no rounding term); 1 is (c->lumDither8 = ff_sws_pb_64: the source is not one swscale dithers — a
                                                * packed-RGB source's converter output, swscale.c:291) */
 };
 #ifdef __cplusplus

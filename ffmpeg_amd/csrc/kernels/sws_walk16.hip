@@ -359,7 +359,8 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
     }
     int yy = y0;
     /* where this lane's samples of output row yy go: advanced by the stride per row (a 64-bit multiply-add per row before) */
-    uint8_t *dq0 = db0 + (ptrdiff_t)y0 * ds0 + (size_t)X0 * ((NCH == 2 && dil ? 4 : 2) >> (d8 ? 1 : 0));
+    const bool y16 = NCH == 1 && d8 && J.y16; /* the luma of a packed-RGB target's first stage: the sums >> 19 unclipped, as int16 (sws_y16rgb.hip) */
+    uint8_t *dq0 = db0 + (ptrdiff_t)y0 * ds0 + (size_t)X0 * (y16 ? 2 : (NCH == 2 && dil ? 4 : 2) >> (d8 ? 1 : 0));
     uint8_t *dq1 = db1 + (ptrdiff_t)y0 * ds1 + (size_t)X0 * (d8 ? 1 : 2);
     /* d8: column c's entry of the dither row — (x + offset) & 7 with offset 3 for the V channel / plane (yuv2nv12cX_c, output.c:503-529;
      * vscale.c's chroma call): which dword of the row's eight bytes and how far in */
@@ -420,13 +421,33 @@ __device__ __forceinline__ void w16_unit(const FFHipW16Job &J, const FFHipW16Arg
                             w16_vdots<false>(t, pp[m % VP], pp[(m + 1) % VP], vc[m % VP], vc[(m + 1) % VP], 0);
                         if (d8) { /* uniform */
                             /* seed dither << 12, >> 19, clip to 8 bits (yuv2planeX_8_c, output.c:468-486): four bytes per lane */
-                            const uint2 drow = A.flat_dither ? make_uint2(0x40404040u, 0x40404040u) : *reinterpret_cast<const uint2 *>(w16_dither[yy & 7]);
+                            const uint2 drow = A.flat_dither == 2 ? make_uint2(0u, 0u) : A.flat_dither ? make_uint2(0x40404040u, 0x40404040u) : *reinterpret_cast<const uint2 *>(w16_dither[yy & 7]);
                             uint32_t b01, b23;
                             {
                                 int z[4];
 #pragma unroll
                                 for (int c = 0; c < 4; c++)
                                     z[c] = t[c] + (int)((((dhi[c] ? drow.y : drow.x) >> dsh[c]) & 255u) << 12);
+                                if (y16) { /* uniform */
+                                    if (in_w) {
+                                        const uint32_t w01 = ((uint32_t)(z[0] >> 19) & 0xffffu) | ((uint32_t)(z[1] >> 19) << 16);
+                                        const uint32_t w23 = ((uint32_t)(z[2] >> 19) & 0xffffu) | ((uint32_t)(z[3] >> 19) << 16);
+                                        if (whole) {
+                                            *reinterpret_cast<uint2 *>(dq0) = make_uint2(w01, w23);
+                                        } else {
+                                            uint16_t *d16 = reinterpret_cast<uint16_t *>(dq0);
+                                            d16[0] = (uint16_t)w01;
+                                            if (X0 + 1 < dstW) d16[1] = (uint16_t)(w01 >> 16);
+                                            if (X0 + 2 < dstW) d16[2] = (uint16_t)w23;
+                                        }
+                                    }
+                                    yy++;
+                                    dq0 += ds0;
+                                    dq1 += ds1;
+                                    if (yy < y1)
+                                        need = __builtin_amdgcn_readlane(vpl, yy - y0) + VT - 1;
+                                    continue;
+                                }
                                 b01 = w16_pk_u8(z[0], z[1]);
                                 b23 = w16_pk_u8(z[2], z[3]);
                             }

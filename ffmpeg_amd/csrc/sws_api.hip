@@ -33,6 +33,7 @@ static thread_local int g_sws_create_flat_dither = 0; /* ffhip_sws_getContext ->
 struct FFHipSwsContext {
     int device = 0; /* the banks live on this device; every call of the context makes it current for its duration */
     FFHipSwsRgbIn rgb_in;
+    int hrgb_seed0 = 0;  /* a deeper source into packed RGB whose rows all take yuv2rgb_2 (two-tap vertical banks): no rounding term in the sums */
     int flat_dither = 0; /* an 8-bit target's dither entries are all 64 (an RGB source is not dithered: swscale.c:291 looks at the source format) */
     int hbd_sw = 320, hbd_rows = 96; /* LDS shape the banks need: samples per staged source row, source rows per 32-row tile */
     int hbd = 0;    /* a side above 8 bits: the 16-bit scaler (sws_scale16.hip) serves the context, none of the 8-bit fast paths apply */
@@ -680,14 +681,23 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
 
     if (fmt_hbd(t->srcFormat) || fmt_hbd(t->dstFormat)) {
         /* above 8 bits on either side: the 16-bit scaler takes the banks as they are */
-        if (fmt_rgb(t->dstFormat) || (t->srcW == t->dstW && t->srcH == t->dstH && t->src_range == t->dst_range && !c->flat_dither /* (an RGB source's converter lines
+        const bool hrgb = fmt_rgb(t->dstFormat);
+        if ((!hrgb && t->srcW == t->dstW && t->srcH == t->dstH && t->src_range == t->dst_range && !c->flat_dither /* (an RGB source's converter lines
              * go through the scaler at equal sizes too: the reference has no special converter for them) */) || t->srcFormat == FFHIP_PIX_FMT_NV21 ||
-            t->dstFormat == FFHIP_PIX_FMT_NV21) {
-            ffhip_set_error("ffhip_sws: above 8 bits the hip path scales between the YUV formats only (no packed RGB, no equal-size conversion, no NV21 mix)");
+            t->dstFormat == FFHIP_PIX_FMT_NV21 || fmt_gbrp(t->dstFormat)) {
+            ffhip_set_error("ffhip_sws: above 8 bits the hip path scales between the YUV formats and into packed RGB (no equal-size YUV conversion, no NV21 mix)");
             ffhip_sws_freeContext(c);
             return nullptr;
         }
-        if (c->d[1].n != -((-t->dstW) >> fmt_hsub(t->dstFormat)) || c->d[3].n != -((-t->dstH) >> fmt_vsub(t->dstFormat)) ||
+        if (hrgb && (t->full_chr_h_int || (t->dstW & 1) || t->dst_alpha_fill == 2 || c->flat_dither)) {
+            /* (round 6) a deeper source into packed RGB: the two-stage form below serves the chroma-subsampled writers (yuv2rgb_X / _2 / _1 on
+             * pixel pairs); the full-chroma writers (an odd width, a 4:4:4 source, SWS_FULL_CHR_H_INT) and a source alpha plane are not built */
+            ffhip_set_error("ffhip_sws: above 8 bits into packed RGB: full-chroma writers (odd width / 4:4:4 source / SWS_FULL_CHR_H_INT) and alpha are not on the hip path");
+            ffhip_sws_freeContext(c);
+            return nullptr;
+        }
+        if (c->d[1].n != (hrgb ? (t->dstW + 1) >> 1 : -((-t->dstW) >> fmt_hsub(t->dstFormat))) ||
+            c->d[3].n != (hrgb ? t->dstH : -((-t->dstH) >> fmt_vsub(t->dstFormat))) ||
             c->d[0].n != t->dstW || c->d[2].n != t->dstH) {
             ffhip_set_error("ffhip_sws: the banks do not match the target's plane sizes");
             ffhip_sws_freeContext(c);
@@ -736,7 +746,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             /* ... and exact 2:1 (k_sws_down2<1>), banks of up to 8 taps */
             const int cdw = c->d[1].n, cdh = c->d[3].n;
             /* (round 5: also into an 8-bit target laid out alike — P01x -> NV12, planar -> planar — with the ordered dither on the way out) */
-            const bool dn8 = dd == 8 && !c->flat_dither /* (k_sws_down2 has the ordered dither only) */ && (sl == 1 ? t->dstFormat == FFHIP_PIX_FMT_NV12 : !fmt_nv(t->dstFormat));
+            const bool dn8 = dd == 8 && !hrgb && !c->flat_dither /* (k_sws_down2 has the ordered dither only) */ && (sl == 1 ? t->dstFormat == FFHIP_PIX_FMT_NV12 : !fmt_nv(t->dstFormat));
             if (sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14 && sl == dl) || dn8) && sl != 2 && t->src_range == t->dst_range &&
                 t->srcW == 2 * t->dstW && t->srcH == 2 * t->dstH && cw == 2 * cdw && chh == 2 * cdh &&
                 !(t->dstW & 3) && t->dstW >= 12 && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
@@ -747,7 +757,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             /* (round 5: also an 8-bit planar / NV12 target fed from a 9..14-bit source — a 10-bit decoder's frames for an 8-bit consumer:
              * the 16-bit horizontal pass, yuv2planeX_8_c / yuv2nv12cX_c with the ordered dither on the way out) */
             const bool to8 = dd == 8 && (t->dstFormat == FFHIP_PIX_FMT_NV12 || !fmt_nv(t->dstFormat));
-            if (!c->up2_ok && !c->dn2_ok && sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14) || to8) && sl != 2 && dl != 2 && t->src_range == t->dst_range &&
+            if (!c->up2_ok && !c->dn2_ok && sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14) || to8) && sl != 2 && dl != 2 &&
+                (t->src_range == t->dst_range || hrgb /* (the source's range lives in the yuv2rgb tables) */) &&
                 c->d[0].size <= 16 && c->d[1].size <= 16 && c->d[2].size <= 16 && c->d[3].size <= 16 &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size)) {
                 const int hmax = c->d[0].size > c->d[1].size ? c->d[0].size : c->d[1].size, vmax = c->d[2].size > c->d[3].size ? c->d[2].size : c->d[3].size;
@@ -786,6 +797,31 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                     }
                 }
             }
+        }
+        if (hrgb) {
+            /* packed_vscale() picks the writer per target row (vscale.c:126-170): yuv2rgb_1 for one luma tap with one chroma tap or a blending
+             * pair, yuv2rgb_2 for blending pairs on both, yuv2rgb_X otherwise.  _X and the one-tap _1 are the walker's sums with the flat 64
+             * (Y = (l * 4096 + (64 << 12)) >> 19 = (l + 64) >> 7); _2 has no rounding term (seed 0); _1 with a chroma pair averages or drops
+             * a line ((u0 + u1 + 128) >> 8 / (u0 + 64) >> 7, output.c:1889-1939): not the sums — refused */
+            const int lfs = c->d[2].size, cfs = c->d[3].size;
+            auto blend = [](const int16_t *f) { return (uint16_t)f[1] + (uint16_t)f[0] == 4096 && (uint16_t)f[1] <= 4096U; };
+            int n2 = 0, n1 = 0;
+            for (int y = 0; y < t->dstH; y++) {
+                const bool cb = cfs == 2 && blend(c->f[3].data() + (size_t)2 * y), lb = lfs == 2 && blend(c->f[2].data() + (size_t)2 * y);
+                n1 += lfs == 1 && cb;
+                n2 += lb && cb;
+            }
+            if (n1 || (n2 && n2 != t->dstH)) {
+                ffhip_set_error("ffhip_sws: above 8 bits into packed RGB: the vertical banks mix yuv2rgb_1 / _2 rows with others (bilinear at this ratio): not on the hip path");
+                ffhip_sws_freeContext(c);
+                return nullptr;
+            }
+            c->hrgb_seed0 = n2 == t->dstH;
+        }
+        if (hrgb && !c->w16_ok) {
+            ffhip_set_error("ffhip_sws: above 8 bits into packed RGB runs on the 16-bit walker: banks of at most 16 taps that cannot wrap (and 9..14-bit sources)");
+            ffhip_sws_freeContext(c);
+            return nullptr;
         }
         return c;
     }
@@ -1276,10 +1312,11 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
     (void)ffhip_pixfmt_hbd(t.srcFormat, &sd, &sl, nullptr, nullptr);
     (void)ffhip_pixfmt_hbd(t.dstFormat, &dd, &dl, nullptr, nullptr);
     const int ssz = sd > 8 ? 2 : 1, dsz = dd > 8 ? 2 : 1;
+    const bool hrgb = fmt_rgb(t.dstFormat); /* (round 6) one packed plane: the walker's planes are the context's intermediate */
     for (int pl = 0; pl < (sl ? 2 : 3); pl++)
         if (!src[pl] || (srcStride[pl] % ssz) || (srcFramePitch[pl] % ssz) || ((uintptr_t)src[pl] % ssz))
             return FFHIP_EINVAL;
-    for (int pl = 0; pl < (dl ? 2 : 3); pl++)
+    for (int pl = 0; pl < (hrgb ? 1 : dl ? 2 : 3); pl++)
         if (!dst[pl] || (dstStride[pl] % dsz) || (dstFramePitch[pl] % dsz) || ((uintptr_t)dst[pl] % dsz))
             return FFHIP_EINVAL;
     {
@@ -1379,17 +1416,53 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
             al |= (uintptr_t)src[pl] | (uintptr_t)srcStride[pl] | srcFramePitch[pl];
             neg = neg || srcStride[pl] < 0;
         }
-        for (int pl = 0; pl < (dl ? 2 : 3); pl++) {
+        for (int pl = 0; pl < (hrgb ? 0 : dl ? 2 : 3); pl++) {
             al |= (uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl];
             neg = neg || dstStride[pl] < 0;
         }
-        if (c->w16_ok && !(al & 3) && !neg && !(ew && ew[0] == '0')) {
+        if (hrgb)
+            neg = neg || dstStride[0] < 0;
+        if (hrgb && !(c->w16_ok && !(al & 3) && !neg)) {
+            ffhip_set_error("ffhip_sws: above 8 bits into packed RGB needs 4-byte aligned planes and pitches, top-down");
+            return FFHIP_EINVAL;
+        }
+        if (c->w16_ok && !(al & 3) && !neg && (hrgb || !(ew && ew[0] == '0'))) {
+            /* a packed-RGB target (round 6): the walker writes the first stage — an int16 luma plane of unclipped sums, 8-bit chroma planes of
+             * half the width with a line per target line, flat dither: what yuv2rgb_X_c_template computes before its tables (output.c:1789-1840) —
+             * into the context's intermediate, and k_y16_rgb (sws_y16rgb.hip) turns it into pixels */
+            void *xdst[4] = { dst[0], dst[1], dst[2], nullptr };
+            int xds[4] = { dstStride[0], dstStride[1], dstStride[2], 0 };
+            size_t xdf[4] = { dstFramePitch[0], dstFramePitch[1], dstFramePitch[2], 0 };
+            std::unique_lock<std::mutex> rlk;
+            size_t ypitch = 0, cpitch = 0, yfp = 0, cfp = 0;
+            if (hrgb) {
+                ypitch = ((size_t)2 * t.dstW + 255) & ~(size_t)255; cpitch = ((size_t)(t.dstW / 2) + 255) & ~(size_t)255;
+                yfp = ypitch * (size_t)t.dstH; cfp = cpitch * (size_t)t.dstH;
+                const size_t need = (yfp + 2 * cfp) * (size_t)nframes;
+                rlk = std::unique_lock<std::mutex>(c->rgb2_mu);
+                if (!c->rgb2_done)
+                    HIP_TRY(hipEventCreateWithFlags(&c->rgb2_done, hipEventDisableTiming));
+                else
+                    HIP_TRY(hipStreamWaitEvent(stream, c->rgb2_done, 0));
+                if (need > c->rgb2_tmp_sz) {
+                    if (c->rgb2_tmp)
+                        HIP_TRY(hipFree(c->rgb2_tmp));
+                    c->rgb2_tmp = nullptr;
+                    c->rgb2_tmp_sz = 0;
+                    HIP_TRY(hipMalloc(&c->rgb2_tmp, need));
+                    c->rgb2_tmp_sz = need;
+                }
+                uint8_t *ty = static_cast<uint8_t *>(c->rgb2_tmp);
+                xdst[0] = ty; xdst[1] = ty + yfp * (size_t)nframes; xdst[2] = ty + (yfp + cfp) * (size_t)nframes;
+                xds[0] = (int)ypitch; xds[1] = xds[2] = (int)cpitch;
+                xdf[0] = yfp; xdf[1] = xdf[2] = cfp;
+            }
             FFHipW16Args W;
             memset(&W, 0, sizeof(W));
             W.nframes = nframes;
             W.ht = c->w16_ht; W.vt = c->w16_vt;
             W.sdepth = sd; W.ddepth = dd; W.smsb = sl == 1; W.dmsb = dl == 1;
-            W.flat_dither = c->flat_dither;
+            W.flat_dither = hrgb ? (c->hrgb_seed0 ? 2 : 1) : c->flat_dither;
             /* rows per strip: 64 when the batch fills the chip several times over; a strip re-filters VT - 1 source rows, but a
              * wave is one dependent chain of rows, and a launch of fewer waves than the chip holds (32 frames of 720p -> 1080p: 6,656
              * against 7,168 slots) runs at the speed of one chain: halve until there are 1.5 slots' worth (measured, 720p -> 1080p:
@@ -1418,11 +1491,12 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                     /* an interleaved side: both channels live in plane 1, the second one sample on; a planar side: planes 1 and 2 */
                     const int sp = which && sl ? 1 : splane0 + k, dp = which && dl ? 1 : dplane0 + k;
                     j.src[k] = static_cast<const uint8_t *>(src[sp]) + (which && sl ? 2 * k : 0);
-                    j.dst[k] = static_cast<uint8_t *>(dst[dp]) + (which && dl ? (dd == 8 ? 1 : 2) * k : 0);
-                    j.sstride[k] = srcStride[sp]; j.dstride[k] = dstStride[dp];
-                    j.sfp[k] = srcFramePitch[sp]; j.dfp[k] = dstFramePitch[dp];
+                    j.dst[k] = static_cast<uint8_t *>(xdst[dp]) + (which && dl ? (dd == 8 ? 1 : 2) * k : 0);
+                    j.sstride[k] = srcStride[sp]; j.dstride[k] = xds[dp];
+                    j.sfp[k] = srcFramePitch[sp]; j.dfp[k] = xdf[dp];
                 }
                 j.srcH = which ? c->chrSrcH : t.srcH;
+                j.y16 = hrgb && !which;
                 j.dstW = c->d[which].n; j.dstH = c->d[2 + which].n;
                 j.hf = c->w16_f[which]; j.hp = c->w16_p[which]; j.vf = c->w16_f[2 + which]; j.vp = c->w16_p[2 + which];
                 j.srcW = which ? c->chrSrcW : t.srcW;
@@ -1444,7 +1518,20 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 job(1, 1, 1, 1);
                 job(1, 1, 2, 2);
             }
-            return ffhip_launch_walk16(W, stream);
+            const int rw = ffhip_launch_walk16(W, stream);
+            if (rw < 0 || !hrgb)
+                return rw;
+            FFHipY16RgbArgs Y;
+            memset(&Y, 0, sizeof(Y));
+            Y.y = static_cast<const uint8_t *>(xdst[0]); Y.u = static_cast<const uint8_t *>(xdst[1]); Y.v = static_cast<const uint8_t *>(xdst[2]);
+            Y.dst = static_cast<uint8_t *>(dst[0]);
+            Y.ystride = (ptrdiff_t)ypitch; Y.cstride = (ptrdiff_t)cpitch; Y.dstride = dstStride[0];
+            Y.yfp = yfp; Y.cfp = cfp; Y.dfp = dstFramePitch[0];
+            Y.w = t.dstW; Y.h = t.dstH; Y.nframes = nframes; Y.lay = rgb_layout(t.dstFormat); Y.k = c->k;
+            const int ry = ffhip_launch_y16_rgb(Y, stream);
+            if (ry >= 0)
+                HIP_TRY(hipEventRecord(c->rgb2_done, stream));
+            return ry;
         }
     }
     FFHipScale16Args a;

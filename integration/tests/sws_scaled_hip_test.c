@@ -282,6 +282,10 @@ int main(int argc, char **argv)
     CASE("abgr", 640, 360, "yuv420p", 1280, 720, SWS_BICUBIC | SWS_FULL_CHR_H_INP, 64, 0, 0, 1);
     CASE("bgr24", 1280, 720, "nv12", 1280, 720, SWS_BICUBIC | SWS_ACCURATE_RND, 0, 1, 0, 1);
     CASE("rgb24", 640, 360, "yuv420p", 640, 360, SWS_BICUBIC, 0, 0, 1, 1);
+    /* 10-bit video for a display (round 6): the 16-bit walker into an intermediate, then the RGB writer; colour details set after the init */
+    CASE("p010le", 1920, 1080, "bgra", 1920, 1080, SWS_BICUBIC, 0, 0, 1, 1);
+    CASE("yuv420p10le", 3840, 2160, "rgb24", 1920, 1080, SWS_BICUBIC, 0, 0, 0, 1);
+    CASE("yuv420p10le", 1280, 720, "rgba", 1920, 1080, SWS_BILINEAR, 0, 0, 2, 1);
     /* ... and bgr24 -> yuv420p at the source's size is the reference's own special converter (ff_rgb24toyv12): the hook finds it installed */
     CASE("bgr24", 640, 360, "yuv420p", 640, 360, SWS_BICUBIC, 0, 0, 0, 0);
     /* SWS_FAST_BILINEAR scales 8-bit sources through ff_hyscale_fast_c, not through the banks: left to ff_swscale() */

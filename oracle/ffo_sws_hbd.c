@@ -120,7 +120,8 @@ static inline void put(uint8_t *row, int depth, int layout, int chan, int i, int
         p[i] = (uint16_t)v;
 }
 
-/* src / dst: plane pointers as the format has them (planar: Y, U, V; semi-planar: Y, UV) */
+/* src / dst: plane pointers as the format has them (planar: Y, U, V; semi-planar: Y, UV); dlayout 3 (round 6): ONE packed 8-bit RGB plane of
+ * t->dstFormat, ddepth 8 */
 int ffo_sws_scale_frame_hbd(const FfoSwsTables *t, int sdepth, int slayout, int ddepth, int dlayout, const uint8_t *const src[3],
                             const int srcStride[3], uint8_t *const dst[3], const int dstStride[3])
 {
@@ -159,6 +160,40 @@ int ffo_sws_scale_frame_hbd(const FfoSwsTables *t, int sdepth, int slayout, int 
             range_line(hu + y * cp, chrDstW, t->chr_rc_coeff, t->chr_rc_offset, !t->src_range, wide);
             range_line(hv + y * cp, chrDstW, t->chr_rc_coeff, t->chr_rc_offset, !t->src_range, wide);
         }
+    }
+    if (dlayout == 3) {
+        /* a packed 8-bit RGB target (t->dstFormat) fed from the deeper source: the 15-bit lines go to the writers packed_vscale() picks per
+         * row (libswscale/vscale.c:126-170; yuv2rgb_X / _2 / _1, output.c:1789-1939) — ffo_sws.c's, on int16 copies of the lines */
+        const int lfs = t->vLum.size, cfs = t->vChr.size;
+        const int lay = t->dstFormat == 2 ? 0 : t->dstFormat == 3 ? 1 : t->dstFormat == 25 ? 2 : t->dstFormat == 26 ? 3 : t->dstFormat == 27 ? 4 : 5;
+        int16_t *l16 = malloc(sizeof(int16_t) * lp * srcH), *u16 = malloc(sizeof(int16_t) * cp * csh), *v16 = malloc(sizeof(int16_t) * cp * csh);
+        const int16_t **lr = malloc(sizeof(*lr) * (size_t)(lfs + 2 * cfs + 6)), **ur = lr + lfs + 1, **vr = ur + cfs + 1;
+        FfoYuv2RgbLuts *luts = malloc(sizeof(*luts));
+        if (!l16 || !u16 || !v16 || !lr || !luts || wide) { free(l16); free(u16); free(v16); free(lr); free(luts); free(hl); free(hu); free(hv); free(rows); return -1; }
+        for (size_t i = 0; i < lp * srcH; i++) l16[i] = (int16_t)hl[i];
+        for (size_t i = 0; i < cp * csh; i++) { u16[i] = (int16_t)hu[i]; v16[i] = (int16_t)hv[i]; }
+        ffo_yuv2rgb_luts_init(luts, &t->k);
+        for (int y = 0; y < dstH; y++) {
+            const uint16_t *lf = (const uint16_t *)t->vLum.filter + (size_t)y * lfs, *cf = (const uint16_t *)t->vChr.filter + (size_t)y * cfs;
+            uint8_t *d = dst[0] + (ptrdiff_t)y * dstStride[0];
+            for (int j = 0; j < lfs; j++)
+                lr[j] = l16 + (size_t)(t->vLum.pos[y] + j) * lp;
+            for (int j = 0; j < cfs; j++) {
+                ur[j] = u16 + (size_t)(t->vChr.pos[y] + j) * cp;
+                vr[j] = v16 + (size_t)(t->vChr.pos[y] + j) * cp;
+            }
+            if (lfs == 1 && cfs == 1)
+                ffo_yuv2rgb_1(luts, lr[0], ur, vr, d, dstW, 0, lay);
+            else if (lfs == 1 && cfs == 2 && cf[1] + cf[0] == 4096 && cf[1] <= 4096U)
+                ffo_yuv2rgb_1(luts, lr[0], ur, vr, d, dstW, cf[1], lay);
+            else if (lfs == 2 && cfs == 2 && lf[1] + lf[0] == 4096 && lf[1] <= 4096U && cf[1] + cf[0] == 4096 && cf[1] <= 4096U)
+                ffo_yuv2rgb_2(luts, lr, ur, vr, d, dstW, lf[1], cf[1], lay);
+            else
+                ffo_yuv2rgb_X(luts, (const int16_t *)lf, lr, lfs, (const int16_t *)cf, ur, vr, cfs, d, dstW, lay);
+        }
+        free(l16); free(u16); free(v16); free(lr); free(luts);
+        free(hl); free(hu); free(hv); free(rows);
+        return 0;
     }
     for (int y = 0; y < dstH; y++) {
         for (int j = 0; j < t->vLum.size; j++)

@@ -222,6 +222,48 @@ def test_yuv420p10_1080p_to_4k_and_back():
 def test_what_is_not_on_the_path_is_refused():
     from ffmpeg_amd import swscale as S
     _torch()
-    for args in ((64, 36, 62, 64, 36, 158), (64, 36, 62, 128, 72, 2)):    # equal-size p010 conversion; 10-bit to rgb24
+    # equal-size p010 conversion (the reference's special converters); 10-bit into planar RGB; into an odd-width RGB picture and from a
+    # 4:4:4 source (the full-chroma writers); one luma tap with a blending chroma pair (yuv2rgb_1's averaged lines)
+    for args in ((64, 36, 62, 64, 36, 158), (64, 36, 62, 128, 72, 71), (64, 36, 62, 127, 72, 2), (64, 36, 68, 128, 72, 2),
+                 (64, 36, 62, 64, 36, 2, ffi.SWS_BILINEAR)):
         with pytest.raises(ValueError):
             S.SwsContext(*args)
+
+
+from test_oracle_vs_ref_sws_hbd import RGB_CASES, RGBT, oracle_hbd_rgb  # noqa: E402
+
+HIP_RGB_CASES = [c for c in RGB_CASES if not (c[0] == "yuv420p10le" and c[3] == "rgb24" and c[6] == ffi.SWS_BILINEAR and c[1] == c[4])] + \
+                [("p010le", 1920, 1080, "bgra", 1920, 1080, ffi.SWS_BICUBIC), ("yuv420p10le", 3840, 2160, "rgb24", 1920, 1080, ffi.SWS_BICUBIC),
+                 ("yuv420p10le", 1280, 720, "rgba", 1920, 1080, ffi.SWS_BILINEAR)]
+
+
+@pytest.mark.parametrize("case", HIP_RGB_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_deeper_source_into_packed_rgb(case):
+    """round 6: a 9..14-bit source into packed 8-bit RGB in two stages — the 16-bit walker into the context's intermediate (an int16 luma
+    plane of unclipped sums, 8-bit chroma of half the width, flat rounding seed or none as the reference's writer has it), then k_y16_rgb —
+    against the oracle (pinned to the reference's sws_scale() on the CPU tier): the host face and the batched device face"""
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    sname, sw, sh, dname, dw, dh, flags = case
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    dfmt, bpp = RGBT[dname]
+    n = 3 if sw < 1000 else 1
+    frames = [make_frame(sname, sw, sh, rng, pad=0) for _ in range(n)]
+    ctx = S.SwsContext(sw, sh, FMT[sname][0], dw, dh, dfmt, flags)
+    want0 = oracle_hbd_rgb(sname, frames[0], sw, sh, dname, dw, dh, flags)[:, :dw * bpp]
+    got = np.zeros((dh, dw * bpp + 3), np.uint8)
+    assert ctx.scale([a.view(np.uint8) for a in frames[0]], [got]) == dh
+    assert np.array_equal(got[:, :dw * bpp], want0), "%d bytes differ" % (got[:, :dw * bpp] != want0).sum()
+    src = S.alloc_batch(FMT[sname][0], sw, sh, n, "cuda:0")
+    dst = S.alloc_batch(dfmt, dw, dh, n, "cuda:0", fill=9)
+    for f in range(n):
+        for p, a in enumerate(frames[f]):
+            b = a.view(np.uint8)
+            src[p][f, :, :b.shape[1]] = torch.from_numpy(b).cuda()
+    for rep in range(2):
+        ctx.scale_batch(src, dst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        want = want0 if f == 0 else oracle_hbd_rgb(sname, frames[f], sw, sh, dname, dw, dh, flags)[:, :dw * bpp]
+        assert np.array_equal(dst[0][f].cpu().numpy()[:, :dw * bpp], want), f
+    ctx.close()

@@ -141,3 +141,58 @@ def test_range_conversion_above_8_bits(case):
     assert O.ffo_sws_scale_frame_hbd(C.byref(t), sd, sl, dd, dl, sp, ss, gp, gs) == 0
     for i, (a, b) in enumerate(zip(want, got)):
         assert np.array_equal(a, b), "plane %d: %d of %d samples differ (max %d)" % (i, (a != b).sum(), a.size, np.abs(a.astype(int) - b.astype(int)).max())
+
+
+# round 6: sources above 8 bits into packed 8-bit RGB (HDR / 10-bit video for a display): name -> (AVPixelFormat, bytes per pixel)
+RGBT = {"rgb24": (2, 3), "bgr24": (3, 3), "argb": (25, 4), "rgba": (26, 4), "abgr": (27, 4), "bgra": (28, 4)}
+RGB_CASES = [("yuv420p10le", 64, 36, "rgb24", 64, 36, ffi.SWS_BICUBIC), ("p010le", 96, 54, "bgra", 192, 108, ffi.SWS_BICUBIC),
+             ("yuv422p10le", 128, 72, "rgba", 64, 36, ffi.SWS_BICUBIC), ("yuv420p12le", 64, 36, "argb", 96, 54, ffi.SWS_BILINEAR),
+             ("yuv420p10le", 64, 36, "bgr24", 128, 72, ffi.SWS_BILINEAR),     # two-tap banks on both: yuv2rgb_2 (no rounding term)
+             ("p010le", 128, 72, "abgr", 100, 40, ffi.SWS_BILINEAR), ("yuv420p9le", 64, 36, "rgb24", 64, 72, ffi.SWS_POINT),
+             ("yuv420p10le", 64, 36, "rgb24", 64, 36, ffi.SWS_BILINEAR),      # one luma tap, a blending chroma pair: yuv2rgb_1 with uvalpha
+             ("yuv420p14le", 62, 34, "bgra", 124, 34, ffi.SWS_BICUBIC)]
+
+
+def oracle_hbd_rgb(sname, src, sw, sh, dname, dw, dh, flags):
+    O = ffi.oracle()
+    dfmt, bpp = RGBT[dname]
+    ht, t = oracle_tables_fmt(sname, sw, sh, dfmt, dw, dh, flags)
+    O.ffo_sws_scale_frame_hbd.argtypes = [C.POINTER(ffi.OSwsTables), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(C.c_int),
+                                          C.POINTER(u8p), C.POINTER(C.c_int)]
+    got = np.zeros((dh, dw * bpp + 5), np.uint8)
+    sp, ss = planes_of(src)
+    gp, gs = planes_of([got])
+    _, sd, sl, _, _ = FMT[sname]
+    assert O.ffo_sws_scale_frame_hbd(C.byref(t), sd, sl, 8, 3, sp, ss, gp, gs) == 0
+    return got
+
+
+def oracle_tables_fmt(sname, sw, sh, dfmt, dw, dh, flags):
+    from ffmpeg_amd import swscale as S
+    ht = S.HostTables(sw, sh, FMT[sname][0], dw, dh, dfmt, flags)
+    return ht, ffi.make_otables(sw, sh, FMT[sname][0], dw, dh, dfmt, flags, ht.banks(), ht.coeffs())
+
+
+@pytest.mark.parametrize("case", RGB_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_deeper_sources_into_packed_rgb(case):
+    """hScale16To15_c lines through yuv2rgb_X / _2 / _1 (libswscale/vscale.c:126-170, output.c:1789-1939): the oracle's RGB branch of
+    ffo_sws_scale_frame_hbd == the reference's sws_scale(), the banks of libffhip's host side == the reference's"""
+    sname, sw, sh, dname, dw, dh, flags = case
+    R = ffi.ref()
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFFF)
+    src = make_frame(sname, sw, sh, rng, pad=6)
+    dfmt, bpp = RGBT[dname]
+    want = np.zeros((dh, dw * bpp + 5), np.uint8)
+    ctx = R.ffref_sws_create(sw, sh, FMT[sname][0], dw, dh, dfmt, flags, 1)
+    assert ctx and not R.ffref_sws_is_unscaled(ctx)
+    sp, ss = planes_of(src)
+    wp, ws = planes_of([want])
+    assert R.ffref_sws_scale(ctx, sp, ss, 0, sh, wp, ws) == dh
+    ht, _ = oracle_tables_fmt(sname, sw, sh, dfmt, dw, dh, flags)
+    rb, ob = ffi.ref_tables(ctx), ht.banks()
+    for k in ("hLum", "hChr", "vLum", "vChr"):
+        assert rb[k][2] == ob[k][2] and rb[k][3] == ob[k][3], k
+        assert np.array_equal(rb[k][0], ob[k][0]) and np.array_equal(rb[k][1], ob[k][1]), k
+    R.ffref_sws_free(ctx)
+    got = oracle_hbd_rgb(sname, src, sw, sh, dname, dw, dh, flags)
+    assert np.array_equal(want, got), "%d of %d bytes differ (max %d)" % ((want != got).sum(), want.size, np.abs(want.astype(int) - got.astype(int)).max())
