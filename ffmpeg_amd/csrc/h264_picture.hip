@@ -1367,6 +1367,17 @@ static int pictures_flush(FFHipH264Picture *const *pics, int n, uint8_t *const *
                 ffhip_set_error("ffhip_h264_pictures_flush: picture %d: %s", i, errs[(size_t)i].c_str());
             }
     }
+    /* from here on the stages are shared by the batch: whichever way the function leaves before its last line, no picture is known to be
+     * complete and every picture that was still good says so (ffhip_h264_picture_status) */
+    struct SharedStageGuard {
+        FFHipH264Picture *const *pics; int n; bool armed = true;
+        ~SharedStageGuard() {
+            if (armed)
+                for (int i = 0; i < n; i++)
+                    if (!pics[i]->last_status)
+                        pics[i]->last_status = FFHIP_EIO;
+        }
+    } shared_guard{ pics, n };
     const bool c444 = p0->cfmt == 3; /* every plane is a luma plane: wavefronts and filters alike */
     const bool c422 = p0->cfmt == 2; /* 8 x 16 chroma: the luma plane through the luma kernels, the chroma planes through kernels/h264_c422.hip */
     std::vector<FFHipH264IntraPic> ip;
@@ -1435,5 +1446,6 @@ static int pictures_flush(FFHipH264Picture *const *pics, int n, uint8_t *const *
                 pics[i]->last_status = r;
         return r;
     }
+    shared_guard.armed = false;
     return first_err;
 }

@@ -498,6 +498,13 @@ extern "C" int ffhip_membw_probe(int pattern, size_t bytes, int reps, double *gb
     double best = 0;
     /* `bytes` is the larger (written, or read for pattern 0) side */
     const int K = pattern == 3 ? 4 : pattern == 4 ? 2 : 1;
+    /* the largest variant's grid footprint is 4096 workgroups x 256 lanes x 8 elements of 16 K bytes: a size that is not a multiple of it
+     * leaves a tail no variant touches while `moved` counts it — round down when the size allows */
+    {
+        const size_t quantum = (size_t)4096 * 256 * 8 * 16 * K;
+        if (bytes >= quantum)
+            bytes -= bytes % quantum;
+    }
     const size_t n_rd = bytes / 16 / K;
     const double moved = pattern == 2 || pattern == 5 ? 2.0 * bytes : pattern == 3 ? 1.25 * bytes : pattern == 4 ? 1.5 * bytes : (double)bytes;
     auto launch = [&](int v) {
