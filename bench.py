@@ -446,6 +446,11 @@ def extras(torch, dev, torch_alloc=False):
     sws_case("sws_nv12_1080p_to_yuv420p_1080p", 23, 1920, 1080, 0, 1920, 1080, 64)
     sws_case("sws_yuv444p_1080p_to_yuv420p_1080p", 5, 1920, 1080, 0, 1920, 1080, 64)
     sws_case("sws_nv12_1080p_to_720p_bicubic", 23, 1920, 1080, 23, 1280, 720, 64)
+    # round 6: a packed RGB source for an encoder (bgra 1080p -> nv12 at the source's size: the input converters as a kernel, then the 16-bit
+    # walker on their 14-bit lines: 5.5 algorithmic B / px, 13.5 moved) and 10-bit video for a display (p010 -> bgra: the walker's first stage
+    # into the context's intermediate, then k_y16_rgb)
+    sws_case("sws_bgra_1080p_to_nv12_1080p_bicubic", 28, 1920, 1080, 23, 1920, 1080, 32)
+    sws_case("sws_p010_1080p_to_bgra_1080p_bicubic", 158, 1920, 1080, 28, 1920, 1080, 32)
     # H.264 8x8 IDCT + add over 32 4K luma planes (129,600 blocks each, 384 B/block)
     planes, stride = 32, 3840
     nb = planes * 129600

@@ -484,6 +484,7 @@ struct FFHipRgbInArgs {
     int w, h;                           /* pixels; rows of this call */
     int ro, go, bo;                     /* byte of the component inside a pixel */
     int ry, gy, by, ru, gu, bu, rv, gv, bv; /* input_rgb2yuv_table (swscale_internal.h:468-477) */
+    uint8_t *y8; ptrdiff_t y8_stride; size_t y8_fp; /* non-null: the target's 8-bit luma plane is written instead of dst[0] (identity luma banks) */
 };
 int ffhip_launch_sws_rgb_in(const FFHipRgbInArgs &a, int bpp, int half, int nframes, hipStream_t stream);
 

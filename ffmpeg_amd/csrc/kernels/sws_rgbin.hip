@@ -37,7 +37,22 @@ __global__ __launch_bounds__(256) void k_sws_rgb_in(FFHipRgbInArgs a)
 #pragma unroll
     for (int i = 0; i < 4; i++)
         yv[i] = (uint16_t)((a.ry * r[i] + a.gy * gg[i] + a.by * b[i] + (32 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
-    if (n == 4) {
+    if (a.y8) {
+        /* the luma banks are the identity (a conversion at the source's size into an 8-bit target): hScale16To15_c on the one tap 1 << 14
+         * is min((Y * 16384) >> 13, 32767), yuv2plane1 / yuv2planeX on the one tap 1 << 12 with the flat dither is (. + 64) >> 7, clipped
+         * (swscale.c:100-128, output.c:468-486) — the target's luma plane is written here and the walker scales the chroma alone */
+        uint8_t *d = a.y8 + (size_t)f * a.y8_fp + (ptrdiff_t)y * a.y8_stride + x0;
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            w |= (uint32_t)clip_u8((min(2 * (int)yv[i], 32767) + 64) >> 7) << (8 * i);
+        if (n == 4 && !(reinterpret_cast<uintptr_t>(d) & 3)) {
+            *reinterpret_cast<uint32_t *>(d) = w;
+        } else {
+            for (int i = 0; i < n; i++)
+                d[i] = (uint8_t)(w >> (8 * i));
+        }
+    } else if (n == 4) {
         *reinterpret_cast<uint2 *>(Y) = make_uint2(yv[0] | (uint32_t)yv[1] << 16, yv[2] | (uint32_t)yv[3] << 16);
     } else {
         for (int i = 0; i < n; i++)

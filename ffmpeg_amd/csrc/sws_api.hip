@@ -20,6 +20,7 @@
 struct FFHipSwsRgbIn {
     int bpp = 0;            /* 0: none; 3 / 4 bytes per pixel */
     int half = 0;           /* the chroma converters average pixel pairs (4:2:2 lines) */
+    int y_direct = 0;       /* identity luma banks into an 8-bit plane on the walker: the converter pass writes the target's luma, the walker the chroma */
     int fmt = 0;            /* the caller's source format */
     int ofs[3] = { 0, 0, 0 };
     int32_t table[9] = {};
@@ -28,12 +29,14 @@ struct FFHipSwsRgbIn {
     void *stage = nullptr;  /* device: the host face's packed source rows */
     size_t stage_sz = 0;
 };
+static void rgb_in_plan_luma(struct FFHipSwsContext *c);
 static thread_local int g_sws_create_flat_dither = 0; /* ffhip_sws_getContext -> ffhip_sws_from_tables: the context being made is an RGB source's */
 
 struct FFHipSwsContext {
     int device = 0; /* the banks live on this device; every call of the context makes it current for its duration */
     FFHipSwsRgbIn rgb_in;
     int hrgb_seed0 = 0;  /* a deeper source into packed RGB whose rows all take yuv2rgb_2 (two-tap vertical banks): no rounding term in the sums */
+    bool rgb_in_luma_done = false; /* the call in flight (under mu): the converter pass wrote the target's luma plane, the walker skips its luma job */
     int flat_dither = 0; /* an 8-bit target's dither entries are all 64 (an RGB source is not dithered: swscale.c:291 looks at the source format) */
     int hbd_sw = 320, hbd_rows = 96; /* LDS shape the banks need: samples per staged source row, source rows per 32-row tile */
     int hbd = 0;    /* a side above 8 bits: the 16-bit scaler (sws_scale16.hip) serves the context, none of the 8-bit fast paths apply */
@@ -1101,8 +1104,10 @@ extern "C" FFHipSwsContext *ffhip_sws_getContext(int srcW, int srcH, int srcForm
     FFHipSwsContext *c = ffhip_sws_from_tables(&t);
     g_sws_create_flat_dither = 0;
     ffhip_sws_tables_free(h);
-    if (c && inner)
+    if (c && inner) {
         c->rgb_in = ri;
+        rgb_in_plan_luma(c);
+    }
     return c;
 }
 
@@ -1130,8 +1135,10 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables_rgb_source(const FFHipSwsTable
     g_sws_create_flat_dither = 1;
     FFHipSwsContext *c = ffhip_sws_from_tables(t);
     g_sws_create_flat_dither = 0;
-    if (c)
+    if (c) {
         c->rgb_in = ri;
+        rgb_in_plan_luma(c);
+    }
     return c;
 }
 
@@ -1144,12 +1151,28 @@ extern "C" int ffhip_sws_set_rgb2yuv(FFHipSwsContext *c, const int32_t rgb2yuv[9
     return 0;
 }
 
+/* identity luma banks into an 8-bit luma plane that the 16-bit walker would produce: the converter pass can write it */
+static void rgb_in_plan_luma(FFHipSwsContext *c)
+{
+    const FFHipSwsTables &t = c->t;
+    int dd = 8, dl = 0;
+    (void)ffhip_pixfmt_hbd(t.dstFormat, &dd, &dl, nullptr, nullptr);
+    bool id = c->w16_ok && dd == 8 && !fmt_rgb(t.dstFormat) && t.srcW == t.dstW && t.srcH == t.dstH && c->d[0].size == 1 && c->d[2].size == 1 &&
+              t.src_range == t.dst_range;
+    for (int x = 0; id && x < t.dstW; x++)
+        id = c->f[0][(size_t)x] == 16384 && c->p[0][(size_t)x] == x;
+    for (int y = 0; id && y < t.dstH; y++)
+        id = c->f[2][(size_t)y] == 4096 && c->p[2][(size_t)y] == y;
+    c->rgb_in.y_direct = id;
+}
+
 /* the converter pass of an RGB-source context over `rows` source rows of nframes frames: src -> the 14-bit planes at p[] */
 static int rgb_in_launch(const FFHipSwsContext *c, int nframes, const uint8_t *src, ptrdiff_t src_stride, size_t src_fp, int rows, uint8_t *const p[3],
-                         const int pitch[3], const size_t fp[3], hipStream_t stream)
+                         const int pitch[3], const size_t fp[3], hipStream_t stream, uint8_t *y8 = nullptr, ptrdiff_t y8_stride = 0, size_t y8_fp = 0)
 {
     FFHipRgbInArgs a;
     memset(&a, 0, sizeof(a));
+    a.y8 = y8; a.y8_stride = y8_stride; a.y8_fp = y8_fp;
     a.src = src; a.src_stride = src_stride; a.src_fp = src_fp;
     for (int i = 0; i < 3; i++) {
         a.dst[i] = p[i]; a.dst_stride[i] = pitch[i]; a.dst_fp[i] = fp[i];
@@ -1511,7 +1534,8 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 }
                 ffhip_w16_plan_job(&j, strip);
             };
-            job(0, 1, 0, 0);
+            if (!c->rgb_in_luma_done)
+                job(0, 1, 0, 0);
             if (sl || dl) {
                 job(1, 2, 1, 1);
             } else {
@@ -1533,6 +1557,10 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 HIP_TRY(hipEventRecord(c->rgb2_done, stream));
             return ry;
         }
+    }
+    if (c->rgb_in_luma_done) {
+        ffhip_set_error("ffhip_sws: internal: the converter pass wrote the luma plane but the walker does not run");
+        return FFHIP_EINVAL;
     }
     FFHipScale16Args a;
     memset(&a, 0, sizeof(a));
@@ -1616,13 +1644,20 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
         }
         uint8_t *b = static_cast<uint8_t *>(c->rgb_in.planes);
         uint8_t *const p[3] = { b, b + fp[0] * nframes, b + (fp[0] + fp[1]) * nframes };
-        const int r = rgb_in_launch(c, nframes, static_cast<const uint8_t *>(src[0]), srcStride[0], srcFramePitch[0], c->t.srcH, p, pitch, fp, (hipStream_t)stream_);
+        /* (the walker — the kernel that can leave the luma out — wants 4-byte aligned planes and pitches, top-down: scale16()) */
+        bool yd = c->rgb_in.y_direct && dst && dstStride && dstFramePitch;
+        for (int pl = 0; yd && pl < (fmt_nv(c->t.dstFormat) ? 2 : 3); pl++)
+            yd = dst[pl] && dstStride[pl] > 0 && !(((uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl]) & 3);
+        const int r = rgb_in_launch(c, nframes, static_cast<const uint8_t *>(src[0]), srcStride[0], srcFramePitch[0], c->t.srcH, p, pitch, fp, (hipStream_t)stream_,
+                                    yd ? static_cast<uint8_t *>(dst[0]) : nullptr, yd ? dstStride[0] : 0, yd ? dstFramePitch[0] : 0);
+        c->rgb_in_luma_done = yd;
         if (r < 0)
             return r;
         const void *s2[4] = { p[0], p[1], p[2], nullptr };
         const int ss2[4] = { pitch[0], pitch[1], pitch[2], 0 };
         const size_t sf2[4] = { fp[0], fp[1], fp[2], 0 };
         const int r2 = scale_batch_dev(c, nframes, s2, ss2, sf2, dst, dstStride, dstFramePitch, stream_);
+        c->rgb_in_luma_done = false;
         if (r2 < 0 || !c->t.dst_alpha_fill)
             return r2;
         if (!dst[3]) {
@@ -2615,9 +2650,13 @@ static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], cons
         HIP_TRY(copy2d(c->rgb_in.stage, rp, src[0], srcStride[0], wb, rows, hipMemcpyHostToDevice));
         uint8_t *const pp[3] = { base + off_s[0] + (size_t)row0 * pitch_s[0], base + off_s[1] + (size_t)row0 * pitch_s[1],
                                  base + off_s[2] + (size_t)row0 * pitch_s[2] };
-        const int r = rgb_in_launch(c, 1, static_cast<const uint8_t *>(c->rgb_in.stage), rp, 0, rows, pp, pitch_s, fp, 0);
+        /* (the target's staging planes lie behind the source's: base + off_d[]) */
+        const bool yd = c->rgb_in.y_direct;
+        const int r = rgb_in_launch(c, 1, static_cast<const uint8_t *>(c->rgb_in.stage), rp, 0, rows, pp, pitch_s, fp, 0,
+                                    yd ? base + off_d[0] + (size_t)row0 * pitch_d[0] : nullptr, yd ? pitch_d[0] : 0, 0);
         if (r < 0)
             return r;
+        c->rgb_in_luma_done = yd;
         for (int i = 0; i < 3; i++)
             dsrc[i] = base + off_s[i];
     } else
@@ -2649,6 +2688,7 @@ static int sws_scale_locked(FFHipSwsContext *c, const uint8_t *const src[], cons
     } else {
         r = scale_batch_dev(c, 1, dsrc, pitch_s, fp, ddst, pitch_d, fp, 0);
     }
+    c->rgb_in_luma_done = false;
     if (r < 0)
         return r;
     HIP_TRY(hipStreamSynchronize(0));

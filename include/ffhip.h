@@ -167,7 +167,13 @@ int   ffhip_batch_gather_ranges(FFHipDeviceSet *s, int root, void *full, size_t 
  * (hScale16To15_c / hScale16To19_c / hScale8To19_c, yuv2plane1 / yuv2planeX at the target depth, the P01x readers and writers:
  * libswscale/swscale.c:69-160, output.c:150-360, input.c p010LEToY_c / p010LEToUV_c), freely mixed with the 8-bit YUV formats above
  * (an 8-bit target fed from a deeper source is dithered with ff_dither_8x8_128, as swscale does: swscale.c:291,519-522).  Equal-size
- * conversions take the reference's special converters (swscale_unscaled.c) and are not on the hip path; nor are packed RGB targets. */
+ * YUV conversions take the reference's special converters (swscale_unscaled.c) and are not on the hip path.  Round 6: 9 .. 14-bit sources into
+ * the packed 8-bit RGB targets (yuv2rgb_X / _2 / _1 from 16-bit lines, vscale.c:126-170) — even widths, subsampled sources, banks of at
+ * most 16 taps; not the full-chroma writers.
+ * Packed 8-bit RGB as a SOURCE (round 6): rgb24, bgr24, argb, rgba, abgr, bgra into any YUV target above — the input converters
+ * (libswscale/input.c:264-400,1068-1190) run as a kernel and the context is the one of their 14-bit lines (ffhip_sws_from_tables_rgb_source);
+ * not into full-range (J) or alpha-carrying targets from an alpha source, not RGB -> RGB, and bgr24 -> yuv420p at the source's size is the
+ * reference's own special converter. */
 #define FFHIP_PIX_FMT_YUV420P16LE 45
 #define FFHIP_PIX_FMT_YUV422P16LE 47
 #define FFHIP_PIX_FMT_YUV444P16LE 49
