@@ -24,10 +24,36 @@ __global__ __launch_bounds__(256) void k_sws_rgb_in(FFHipRgbInArgs a)
     const uint8_t *s = a.src + (size_t)f * a.src_fp + (ptrdiff_t)y * a.src_stride + (size_t)x0 * BPP;
     const int n = min(4, a.w - x0);
     int r[4], gg[4], b[4];
+    if (n == 4 && !(reinterpret_cast<uintptr_t>(s) & 3)) {
+        /* the lane's 12 / 16 bytes as dwords (a row of whole dwords: every lane's piece starts on one); the component bytes sit at
+         * wave-uniform positions of a pixel */
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(s);
+        if (BPP == 4) {
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+            const uint32_t d[4] = { d0, d1, d2, d3 };
+            const int rs = 8 * a.ro, gs = 8 * a.go, bs = 8 * a.bo;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint8_t *p = s + (i < n ? i : n - 1) * BPP;
-        r[i] = p[a.ro]; gg[i] = p[a.go]; b[i] = p[a.bo];
+            for (int i = 0; i < 4; i++) {
+                r[i] = (int)((d[i] >> rs) & 255u); gg[i] = (int)((d[i] >> gs) & 255u); b[i] = (int)((d[i] >> bs) & 255u);
+            }
+        } else {
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+            /* bytes 0..11: pixel i at 3 i; the middle byte is G, the outer two are (R, B) or (B, R) */
+            const int e0[4] = { (int)(d0 & 255u), (int)(d0 >> 24), (int)((d1 >> 16) & 255u), (int)((d2 >> 8) & 255u) };
+            const int e1[4] = { (int)((d0 >> 8) & 255u), (int)(d1 & 255u), (int)(d1 >> 24), (int)((d2 >> 16) & 255u) };
+            const int e2[4] = { (int)((d0 >> 16) & 255u), (int)((d1 >> 8) & 255u), (int)(d2 & 255u), (int)(d2 >> 24) };
+            const bool rfirst = a.ro == 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                r[i] = rfirst ? e0[i] : e2[i]; gg[i] = e1[i]; b[i] = rfirst ? e2[i] : e0[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint8_t *p = s + (i < n ? i : n - 1) * BPP;
+            r[i] = p[a.ro]; gg[i] = p[a.go]; b[i] = p[a.bo];
+        }
     }
     constexpr int S = 15; /* RGB2YUV_SHIFT */
     uint16_t *Y = reinterpret_cast<uint16_t *>(a.dst[0] + (size_t)f * a.dst_fp[0] + (ptrdiff_t)y * a.dst_stride[0]) + x0;
