@@ -487,5 +487,8 @@ struct FFHipRgbInArgs {
     uint8_t *y8; ptrdiff_t y8_stride; size_t y8_fp; /* non-null: the target's 8-bit luma plane is written instead of dst[0] (identity luma banks) */
 };
 int ffhip_launch_sws_rgb_in(const FFHipRgbInArgs &a, int bpp, int half, int nframes, hipStream_t stream);
+/* an 8-bit plane (wbytes bytes per row; an interleaved pair plane: both channels) as 16-bit samples: dst rows of 2 * wbytes bytes, 16-byte aligned */
+int ffhip_launch_sws_widen8(const uint8_t *src, ptrdiff_t sstride, size_t sfp, uint8_t *dst, ptrdiff_t dstride, size_t dfp, int wbytes, int rows,
+                            int nframes, hipStream_t stream);
 
 #endif

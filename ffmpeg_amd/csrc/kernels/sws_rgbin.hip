@@ -124,3 +124,39 @@ int ffhip_launch_sws_rgb_in(const FFHipRgbInArgs &a, int bpp, int half, int nfra
     LAUNCH_CHECK();
     return 0;
 }
+
+/*
+ * k_sws_widen8 — an 8-bit plane as 16-bit samples (round 6): the input side of an 8-bit source into a 9..14-bit target on the 16-bit
+ * walker.  hScale8To15_c (swscale.c:128-142) is hScale16To15_c at depth 8 — the same sums, >> 7 — so the walker runs such a context on
+ * planes whose samples sit in the low byte of a word; an interleaved (u, v) byte plane becomes an interleaved plane of words.
+ * A lane widens 8 bytes of a row.
+ */
+__global__ __launch_bounds__(256) void k_sws_widen8(const uint8_t *src, ptrdiff_t sstride, size_t sfp, uint8_t *dst, ptrdiff_t dstride, size_t dfp,
+                                                    int wbytes)
+{
+    const int x0 = 8 * (blockIdx.x * 256 + threadIdx.x), y = blockIdx.y, f = blockIdx.z;
+    if (x0 >= wbytes)
+        return;
+    const uint8_t *s = src + (size_t)f * sfp + (ptrdiff_t)y * sstride + x0;
+    uint16_t *d = reinterpret_cast<uint16_t *>(dst + (size_t)f * dfp + (ptrdiff_t)y * dstride) + x0;
+    if (x0 + 8 <= wbytes && !(reinterpret_cast<uintptr_t>(s) & 7)) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(s);
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u); o.y = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
+        o.z = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u); o.w = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
+        *reinterpret_cast<uint4 *>(d) = o;
+    } else {
+        for (int i = 0; i < 8 && x0 + i < wbytes; i++)
+            d[i] = s[i];
+    }
+}
+
+int ffhip_launch_sws_widen8(const uint8_t *src, ptrdiff_t sstride, size_t sfp, uint8_t *dst, ptrdiff_t dstride, size_t dfp, int wbytes, int rows,
+                            int nframes, hipStream_t stream)
+{
+    if (wbytes <= 0 || rows <= 0 || nframes <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_sws_widen8, dim3(cdiv(cdiv(wbytes, 8), 256), rows, nframes), dim3(256), 0, stream, src, sstride, sfp, dst, dstride, dfp, wbytes);
+    LAUNCH_CHECK();
+    return 0;
+}

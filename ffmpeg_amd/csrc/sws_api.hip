@@ -36,6 +36,9 @@ struct FFHipSwsContext {
     int device = 0; /* the banks live on this device; every call of the context makes it current for its duration */
     FFHipSwsRgbIn rgb_in;
     int hrgb_seed0 = 0;  /* a deeper source into packed RGB whose rows all take yuv2rgb_2 (two-tap vertical banks): no rounding term in the sums */
+    int widen8 = 0;      /* an 8-bit source into a 9..14-bit target on the 16-bit walker: its planes are widened to 16-bit samples first (k_sws_widen8) */
+    void *widen_tmp = nullptr;
+    size_t widen_tmp_sz = 0;
     bool rgb_in_luma_done = false; /* the call in flight (under mu): the converter pass wrote the target's luma plane, the walker skips its luma job */
     int flat_dither = 0; /* an 8-bit target's dither entries are all 64 (an RGB source is not dithered: swscale.c:291 looks at the source format) */
     int hbd_sw = 320, hbd_rows = 96; /* LDS shape the banks need: samples per staged source row, source rows per 32-row tile */
@@ -740,12 +743,17 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             (void)ffhip_pixfmt_hbd(t->dstFormat, &dd, &dl, nullptr, nullptr);
             const int cw = c->chrSrcW, chh = c->chrSrcH;
             const int limits[4] = { t->srcW, cw, t->srcH, chh };
-            if (sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl == dl && sl != 2 && t->src_range == t->dst_range &&
+            /* (round 6: from an 8-bit source too — planar into planar, NV12 into P01x — on planes widened to 16-bit samples: `widen8`) */
+            const bool w8 = sd == 8 && dd > 8 && dd <= 14 && !c->flat_dither && t->srcFormat != FFHIP_PIX_FMT_NV21 &&
+                            (fmt_nv(t->srcFormat) ? dl == 1 : dl == 0);
+            if (((sd > 8 && sd <= 14 && sl == dl && sl != 2) || w8) && dd > 8 && dd <= 14 && t->src_range == t->dst_range &&
                 t->dstW == 2 * t->srcW && t->dstH == 2 * t->srcH && c->d[1].n == 2 * cw && c->d[3].n == 2 * chh &&
                 !(t->srcW & 3) && t->srcW >= 8 && (sl ? !(cw & 1) && cw >= 4 : !(cw & 3) && cw >= 8) &&
                 build_fast_view(c, limits, false) && bank_nowrap_depth(c->nf[0].data(), c->d[0].n, sd) &&
-                bank_nowrap_depth(c->nf[1].data(), c->d[1].n, sd))
+                bank_nowrap_depth(c->nf[1].data(), c->d[1].n, sd)) {
                 up2_build(c, limits);
+                c->widen8 = c->up2_ok && w8;
+            }
             /* ... and exact 2:1 (k_sws_down2<1>), banks of up to 8 taps */
             const int cdw = c->d[1].n, cdh = c->d[3].n;
             /* (round 5: also into an 8-bit target laid out alike — P01x -> NV12, planar -> planar — with the ordered dither on the way out) */
@@ -760,7 +768,10 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             /* (round 5: also an 8-bit planar / NV12 target fed from a 9..14-bit source — a 10-bit decoder's frames for an 8-bit consumer:
              * the 16-bit horizontal pass, yuv2planeX_8_c / yuv2nv12cX_c with the ordered dither on the way out) */
             const bool to8 = dd == 8 && (t->dstFormat == FFHIP_PIX_FMT_NV12 || !fmt_nv(t->dstFormat));
-            if (!c->up2_ok && !c->dn2_ok && sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14) || to8) && sl != 2 && dl != 2 &&
+            /* (round 6: an 8-bit planar / NV12 source into a 9..14-bit target too — hScale8To15_c is hScale16To15_c at depth 8: the walker on
+             * planes widened to 16-bit samples by a pass of their own; was the tiled k_sws_scale16 at 0.05 of HBM) */
+            const bool widen = sd == 8 && dd > 8 && dd <= 14 && t->srcFormat != FFHIP_PIX_FMT_NV21 && !c->flat_dither;
+            if (!c->up2_ok && !c->dn2_ok && ((sd > 8 && sd <= 14) || widen) && ((dd > 8 && dd <= 14) || to8) && (sl != 2 || widen) && dl != 2 &&
                 (t->src_range == t->dst_range || hrgb /* (the source's range lives in the yuv2rgb tables) */) &&
                 c->d[0].size <= 16 && c->d[1].size <= 16 && c->d[2].size <= 16 && c->d[3].size <= 16 &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size)) {
@@ -792,6 +803,7 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                         c->w16_ht = ht;
                         c->w16_vt = vt;
                         c->w16_ok = 1;
+                        c->widen8 = widen;
                         for (int i = 0; i < 2; i++) {
                             c->w16_span[i][0] = ffhip_w16_span(pp[i].data(), c->d[i].n, 256, 2, ht);
                             c->w16_span[i][1] = ffhip_w16_span(pp[i].data(), c->d[i].n, 128, 2, ht);
@@ -1284,6 +1296,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
     FFHipDeviceGuard dg(c->device);
     if (c->dev_tables)
         (void)hipFree(c->dev_tables);
+    if (c->widen_tmp)
+        (void)hipFree(c->widen_tmp);
     if (c->rgb_in.planes)
         (void)hipFree(c->rgb_in.planes);
     if (c->rgb_in.stage)
@@ -1342,15 +1356,63 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
     for (int pl = 0; pl < (hrgb ? 1 : dl ? 2 : 3); pl++)
         if (!dst[pl] || (dstStride[pl] % dsz) || (dstFramePitch[pl] % dsz) || ((uintptr_t)dst[pl] % dsz))
             return FFHIP_EINVAL;
+    /* (round 6) an 8-bit source on the walker: the planes widened to 16-bit samples in the context's own memory; from here on the source is
+     * "depth 8 in words", planar or an interleaved pair plane.  When the walker cannot run (alignment) the tiled kernel takes the bytes. */
+    const void *wsrc[4] = { src[0], src[1], src[2], nullptr };
+    int wss[4] = { srcStride[0], srcStride[1], srcStride[2], 0 };
+    size_t wsf[4] = { srcFramePitch[0], srcFramePitch[1], srcFramePitch[2], 0 };
+    std::unique_lock<std::mutex> wlk;
+    bool widened = false;
+    if (c->widen8 && (c->w16_ok || c->up2_ok)) {
+        bool ok = true;
+        for (int pl = 0; ok && pl < (dl ? 2 : 3); pl++)
+            ok = dstStride[pl] > 0 && !(((uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl]) & 3);
+        for (int pl = 0; ok && pl < (sl ? 2 : 3); pl++)
+            ok = srcStride[pl] > 0;
+        const char *ew = FFHIP_KNOB(c->up2_ok ? "FFHIP_SWS_UP2" : "FFHIP_SWS_WALK16");
+        if (ok && !(ew && ew[0] == '0')) {
+            const int np = sl ? 2 : 3;
+            const int wb[3] = { t.srcW, sl ? 2 * c->chrSrcW : c->chrSrcW, c->chrSrcW }, rows[3] = { t.srcH, c->chrSrcH, c->chrSrcH };
+            size_t pitch[3], fp[3], off[3], need = 0;
+            for (int pl = 0; pl < np; pl++) {
+                pitch[pl] = ((size_t)2 * wb[pl] + 255) & ~(size_t)255;
+                fp[pl] = pitch[pl] * (size_t)rows[pl];
+                off[pl] = need;
+                need += fp[pl] * (size_t)nframes;
+            }
+            wlk = std::unique_lock<std::mutex>(c->rgb2_mu); /* the planes are the context's: one batch in flight */
+            if (need > c->widen_tmp_sz) {
+                if (c->widen_tmp) {
+                    HIP_TRY(hipDeviceSynchronize());
+                    HIP_TRY(hipFree(c->widen_tmp));
+                }
+                c->widen_tmp = nullptr;
+                c->widen_tmp_sz = 0;
+                HIP_TRY(hipMalloc(&c->widen_tmp, need));
+                c->widen_tmp_sz = need;
+            }
+            for (int pl = 0; pl < np; pl++) {
+                uint8_t *d = static_cast<uint8_t *>(c->widen_tmp) + off[pl];
+                const int r = ffhip_launch_sws_widen8(static_cast<const uint8_t *>(src[pl]), srcStride[pl], srcFramePitch[pl], d, (ptrdiff_t)pitch[pl], fp[pl],
+                                                      wb[pl], rows[pl], nframes, stream);
+                if (r < 0)
+                    return r;
+                wsrc[pl] = d; wss[pl] = (int)pitch[pl]; wsf[pl] = fp[pl];
+            }
+            widened = true;
+            sl = sl ? 1 : 0; /* an interleaved pair plane of words, as P01x has it (samples in the LOW bits: smsb stays off) */
+        }
+    }
+    if (c->widen8 && !widened) { /* falls to the tiled kernel below with the caller's planes */ }
     {
         uintptr_t al = 0;
         bool neg = false;
         for (int pl = 0; pl < (sl ? 2 : 3); pl++) {
-            al |= (uintptr_t)src[pl] | (uintptr_t)srcStride[pl] | srcFramePitch[pl] | (uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl];
-            neg = neg || srcStride[pl] < 0 || dstStride[pl] < 0;
+            al |= (uintptr_t)wsrc[pl] | (uintptr_t)wss[pl] | wsf[pl] | (uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl];
+            neg = neg || wss[pl] < 0 || dstStride[pl] < 0;
         }
         const char *eu = FFHIP_KNOB("FFHIP_SWS_UP2");
-        if (c->up2_ok && !(al & 3) && !neg && !(eu && eu[0] == '0')) {
+        if (c->up2_ok && (widened || !c->widen8) && !(al & 3) && !neg && !(eu && eu[0] == '0')) {
             /* exact 2x above 8 bits: the static-schedule kernel (FFHIP_SWS_UP2=0: the tiled k_sws_scale16) */
             FFHipUp2Args U;
             memset(&U, 0, sizeof(U));
@@ -1359,13 +1421,13 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
             const int cw = c->chrSrcW, chh = c->chrSrcH;
             auto upjob = [&](int which, int plane, int w, int h, int pair) {
                 FFHipUp2Job &j = U.job[U.njobs++];
-                j.src = static_cast<const uint8_t *>(src[plane]); j.dst = static_cast<uint8_t *>(dst[plane]);
-                j.sstride = srcStride[plane]; j.dstride = dstStride[plane]; j.sfp = srcFramePitch[plane]; j.dfp = dstFramePitch[plane];
+                j.src = static_cast<const uint8_t *>(wsrc[plane]); j.dst = static_cast<uint8_t *>(dst[plane]);
+                j.sstride = wss[plane]; j.dstride = dstStride[plane]; j.sfp = wsf[plane]; j.dfp = dstFramePitch[plane];
                 j.pair = pair; j.swap = 0;
                 j.srcW = w; j.srcH = h;
                 j.ngroups = pair ? w / 2 : w / 4;
                 j.hfv = c->up2_h[which]; j.vfv = c->up2_v[which];
-                j.hb_sdepth = sd; j.hb_ddepth = dd; j.hb_smsb = sl == 1; j.hb_dmsb = dl == 1;
+                j.hb_sdepth = sd; j.hb_ddepth = dd; j.hb_smsb = sl == 1 && !widened; j.hb_dmsb = dl == 1;
             };
             upjob(0, 0, t.srcW, t.srcH, 0);
             if (sl) {
@@ -1436,8 +1498,8 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
         uintptr_t al = 0;
         bool neg = false;
         for (int pl = 0; pl < (sl ? 2 : 3); pl++) {
-            al |= (uintptr_t)src[pl] | (uintptr_t)srcStride[pl] | srcFramePitch[pl];
-            neg = neg || srcStride[pl] < 0;
+            al |= (uintptr_t)wsrc[pl] | (uintptr_t)wss[pl] | wsf[pl];
+            neg = neg || wss[pl] < 0;
         }
         for (int pl = 0; pl < (hrgb ? 0 : dl ? 2 : 3); pl++) {
             al |= (uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl];
@@ -1449,7 +1511,7 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
             ffhip_set_error("ffhip_sws: above 8 bits into packed RGB needs 4-byte aligned planes and pitches, top-down");
             return FFHIP_EINVAL;
         }
-        if (c->w16_ok && !(al & 3) && !neg && (hrgb || !(ew && ew[0] == '0'))) {
+        if (c->w16_ok && (widened || !c->widen8) && !(al & 3) && !neg && (hrgb || !(ew && ew[0] == '0'))) {
             /* a packed-RGB target (round 6): the walker writes the first stage — an int16 luma plane of unclipped sums, 8-bit chroma planes of
              * half the width with a line per target line, flat dither: what yuv2rgb_X_c_template computes before its tables (output.c:1789-1840) —
              * into the context's intermediate, and k_y16_rgb (sws_y16rgb.hip) turns it into pixels */
@@ -1484,7 +1546,7 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
             memset(&W, 0, sizeof(W));
             W.nframes = nframes;
             W.ht = c->w16_ht; W.vt = c->w16_vt;
-            W.sdepth = sd; W.ddepth = dd; W.smsb = sl == 1; W.dmsb = dl == 1;
+            W.sdepth = sd; W.ddepth = dd; W.smsb = sl == 1 && !widened; W.dmsb = dl == 1;
             W.flat_dither = hrgb ? (c->hrgb_seed0 ? 2 : 1) : c->flat_dither;
             /* rows per strip: 64 when the batch fills the chip several times over; a strip re-filters VT - 1 source rows, but a
              * wave is one dependent chain of rows, and a launch of fewer waves than the chip holds (32 frames of 720p -> 1080p: 6,656
@@ -1513,10 +1575,10 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 for (int k = 0; k < nch; k++) {
                     /* an interleaved side: both channels live in plane 1, the second one sample on; a planar side: planes 1 and 2 */
                     const int sp = which && sl ? 1 : splane0 + k, dp = which && dl ? 1 : dplane0 + k;
-                    j.src[k] = static_cast<const uint8_t *>(src[sp]) + (which && sl ? 2 * k : 0);
+                    j.src[k] = static_cast<const uint8_t *>(wsrc[sp]) + (which && sl ? 2 * k : 0);
                     j.dst[k] = static_cast<uint8_t *>(xdst[dp]) + (which && dl ? (dd == 8 ? 1 : 2) * k : 0);
-                    j.sstride[k] = srcStride[sp]; j.dstride[k] = xds[dp];
-                    j.sfp[k] = srcFramePitch[sp]; j.dfp[k] = xdf[dp];
+                    j.sstride[k] = wss[sp]; j.dstride[k] = xds[dp];
+                    j.sfp[k] = wsf[sp]; j.dfp[k] = xdf[dp];
                 }
                 j.srcH = which ? c->chrSrcH : t.srcH;
                 j.y16 = hrgb && !which;

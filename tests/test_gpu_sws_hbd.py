@@ -81,6 +81,11 @@ UP2_CASES = [
     ("p012le", 64, 36, "p012le", 128, 72, ffi.SWS_POINT),
     ("yuv420p10le", 1000, 62, "yuv420p10le", 2000, 124, ffi.SWS_BICUBIC),  # 250 groups per row: ragged-end blocks shared by frames
     ("p010le", 520, 70, "p010le", 1040, 140, ffi.SWS_BICUBIC),
+    # round 6: 8-bit sources on planes widened to 16-bit samples (hScale8To15_c == hScale16To15_c at depth 8): planar into planar, NV12 into P01x
+    ("yuv420p", 72, 40, "yuv420p10le", 144, 80, ffi.SWS_BICUBIC),
+    ("nv12", 72, 40, "p010le", 144, 80, ffi.SWS_BICUBIC),
+    ("yuv420p", 1000, 62, "yuv420p12le", 2000, 124, ffi.SWS_BILINEAR),
+    ("nv12", 520, 70, "p012le", 1040, 140, ffi.SWS_BICUBIC),
     ("yuv422p10le", 64, 36, "yuv422p10le", 128, 72, ffi.SWS_BICUBIC),
     ("yuv444p10le", 64, 36, "yuv444p10le", 128, 72, ffi.SWS_BICUBIC),
     ("yuv420p10le", 64, 36, "yuv420p12le", 128, 72, ffi.SWS_BICUBIC),      # depths differ: >> (src depth - 1) across, >> (27 - dst depth) down
@@ -186,6 +191,26 @@ def test_deeper_source_into_8_bits(case, variant, monkeypatch):
 
 
 # banks of 9..16 taps on the 16-bit column walker (round 5): ratios between 1/2 and 1/4 — a 4K HDR frame into 720p
+WIDEN8_CASES = [
+    ("yuv420p", 384, 216, "yuv420p10le", 576, 324, ffi.SWS_BICUBIC),   # 1.5x up: the walker on widened planes
+    ("nv12", 384, 216, "p010le", 256, 144, ffi.SWS_BICUBIC),           # interleaved in and out
+    ("nv12", 384, 216, "yuv420p10le", 288, 162, ffi.SWS_BILINEAR),     # interleaved in, planar out
+    ("yuv422p", 202, 120, "yuv422p10le", 302, 180, ffi.SWS_BICUBIC),   # ragged last groups
+    ("yuv444p", 200, 120, "yuv420p12le", 150, 90, ffi.SWS_BICUBIC),
+    ("yuv420p", 1280, 720, "p010le", 1920, 1080, ffi.SWS_BICUBIC),
+]
+
+
+@pytest.mark.parametrize("variant", ["product", "tiled"])
+@pytest.mark.parametrize("case", WIDEN8_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_8_bit_source_into_deeper_target(case, variant, monkeypatch):
+    """round 6: 8-bit planar / NV12 sources into 9..14-bit targets on the 16-bit walker (planes widened to words by k_sws_widen8), against the
+    oracle — and the tiled kernel (FFHIP_SWS_WALK16=0) that served them before"""
+    if variant == "tiled":
+        monkeypatch.setenv("FFHIP_SWS_WALK16", "0")
+    _run(case, nframes=3 if case[1] < 1000 else 1)
+
+
 WIDE16_CASES = [
     ("p010le", 576, 324, "p010le", 192, 108, ffi.SWS_BICUBIC),         # 3:1: 12 x 12 taps
     ("yuv420p10le", 640, 360, "yuv420p10le", 160, 90, ffi.SWS_BICUBIC),  # 4:1: 16 x 16 taps
