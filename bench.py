@@ -451,6 +451,8 @@ def extras(torch, dev, torch_alloc=False):
     # into the context's intermediate, then k_y16_rgb)
     sws_case("sws_bgra_1080p_to_nv12_1080p_bicubic", 28, 1920, 1080, 23, 1920, 1080, 32)
     sws_case("sws_p010_1080p_to_bgra_1080p_bicubic", 158, 1920, 1080, 28, 1920, 1080, 32)
+    # ... and an 8-bit source for a 10-bit encoder (planes widened to words, then the exact-2x kernel's 16-bit twin; was the tiled kernel at 0.05)
+    sws_case("sws_nv12_1080p_to_p010_4k_bicubic", 23, 1920, 1080, 158, 3840, 2160, 32)
     # H.264 8x8 IDCT + add over 32 4K luma planes (129,600 blocks each, 384 B/block)
     planes, stride = 32, 3840
     nb = planes * 129600

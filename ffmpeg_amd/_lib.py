@@ -102,6 +102,8 @@ def lib():
         "ffhip_memcpy2d_d2h_async": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]),
         "ffhip_sws_getContext": (vp, [C.c_int] * 7),
         "ffhip_sws_from_tables": (vp, [C.POINTER(SwsTables)]),
+        "ffhip_sws_from_tables_rgb_source": (vp, [C.POINTER(SwsTables), C.c_int, C.POINTER(C.c_int32)]),
+        "ffhip_sws_set_rgb2yuv": (C.c_int, [vp, C.POINTER(C.c_int32)]),
         "ffhip_sws_yuv2rgb_coeffs": (C.c_int, [C.POINTER(SwsTables), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]),
         "ffhip_sws_set_yuv2rgb": (C.c_int, [vp, C.POINTER(SwsTables)]),
         "ffhip_sws_freeContext": (None, [vp]),

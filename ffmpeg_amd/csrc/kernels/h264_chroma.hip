@@ -46,23 +46,27 @@ __device__ __forceinline__ void cm_row_emu(const uint8_t *org, ptrdiff_t stride,
 __device__ __forceinline__ void chroma_mc_group(uint8_t *dst, const uint8_t *src, ptrdiff_t stride, const FFHipChromaBlock *blocks, int n, int wg,
                                                 int pic_w, int pic_h)
 {
-    const int b = (wg * 256 + (int)threadIdx.x) >> 4, row = threadIdx.x & 15;
+    const int b = (wg * 256 + (int)threadIdx.x) >> 4;
     if (b >= n)
         return;
     const FFHipChromaBlock blk = blocks[b];
+    /* 8 wide and at most 8 rows (the chroma of a 16 x 16 macroblock at 4:2:0: nearly every block of a picture): the block's sixteen lanes
+     * take half a row each instead of leaving eight idle (round 6: 0.127 -> see docs/KERNELS.md R6.7) */
+    const bool halves = blk.w_idx == 0 && blk.h <= 8;
+    const int row = halves ? threadIdx.x & 7 : threadIdx.x & 15, xo = halves ? 4 * ((threadIdx.x >> 3) & 1) : 0;
     if (row >= blk.h)
         return;
-    const int w = 8 >> blk.w_idx, x = blk.x & 7, y = blk.y & 7;
+    const int w = halves ? 4 : 8 >> blk.w_idx, x = blk.x & 7, y = blk.y & 7;
     const uint32_t A = (8 - x) * (8 - y), B = x * (8 - y), C = (8 - x) * y, D = x * y;
-    const uint8_t *s = src + blk.src_offset + (ptrdiff_t)row * stride;
-    uint8_t *d = dst + blk.dst_offset + (ptrdiff_t)row * stride;
+    const uint8_t *s = src + blk.src_offset + (ptrdiff_t)row * stride + xo;
+    uint8_t *d = dst + blk.dst_offset + (ptrdiff_t)row * stride + xo;
     /* the reference's three cases read only samples with a non-zero weight: the right neighbour if x, the row below if y */
     uint32_t sw[3], tw[3] = { 0, 0, 0 };
     if (pic_w > 0 && (blk.flags & FFHIP_MC_EMU)) {
         const uint8_t *org = src + blk.src_offset;
-        cm_row_emu(org, stride, blk.src_x, blk.src_y + row, w + (x ? 1 : 0), pic_w, pic_h, sw);
+        cm_row_emu(org, stride, blk.src_x + xo, blk.src_y + row, w + (x ? 1 : 0), pic_w, pic_h, sw);
         if (y)
-            cm_row_emu(org, stride, blk.src_x, blk.src_y + row + 1, w + (x ? 1 : 0), pic_w, pic_h, tw);
+            cm_row_emu(org, stride, blk.src_x + xo, blk.src_y + row + 1, w + (x ? 1 : 0), pic_w, pic_h, tw);
     } else {
         cm_row(s, w + (x ? 1 : 0), sw);
         if (y)
