@@ -97,11 +97,20 @@ __global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     /* SKIP16: a launch of a few thousand workgroups walks the whole batch for the blocks k_hevc_qpel_m left (a wave reads a record and
      * moves on when it is a 16 x 16 one); otherwise one block per wave */
-    for (int b = blockIdx.x * 4 + wave; b < n; b += SKIP16 ? (int)gridDim.x * 4 : n) {
+    /* SKIP16: the wave looks at 64 records at a time — a lane each — and works through the ones that are left to this kernel (a record
+     * per dependent load was 45 us for a quarter of a million blocks; now 5) */
+    for (int c0 = (blockIdx.x * 4 + wave) * (SKIP16 ? 64 : 1); c0 < n; c0 += SKIP16 ? (int)gridDim.x * 256 : n) {
+    unsigned long todo = 1;
+    if (SKIP16) {
+        const int bl = c0 + lane;
+        const Rec &rr = static_cast<const Rec *>(blocks_)[min(bl, n - 1)];
+        todo = __ballot(bl < n && !(rr.width == 16 && rr.height == 16));
+    }
+    while (todo) {
+    const int b = SKIP16 ? c0 + (int)__builtin_ctzl(todo) : c0;
+    todo &= todo - 1;
     const Rec k = static_cast<const Rec *>(blocks_)[b];
     const int w = __builtin_amdgcn_readfirstlane((int)k.width), h = __builtin_amdgcn_readfirstlane((int)k.height);
-    if (SKIP16 && w == 16 && h == 16)
-        continue;
     const int mx = __builtin_amdgcn_readfirstlane((int)k.mx) & FMASK, my = __builtin_amdgcn_readfirstlane((int)k.my) & FMASK;
     const uint8_t *s = src + __builtin_amdgcn_readfirstlane(k.src_offset);
     const int dofs = __builtin_amdgcn_readfirstlane(k.dst_offset);
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride
     if (SKIP16)
         hevc_wave_sync(); /* the next block reuses the plane */
     }
+    }
 }
 
 /*
@@ -375,7 +385,7 @@ int ffhip_launch_hevc_mc(int chroma, int mode, void *dst, ptrdiff_t dststride, c
     if (!chroma && !old && !(em && em[0] == '0') && ffhip_hevc_qpel_m_ok(mode, dststride, srcstride)) {
         /* luma: the 16 x 16 blocks on the matrix cores, everything else in a second launch that skips those */
         ffhip_launch_hevc_qpel_m(mode, dst, dststride, src, srcstride, src2, blocks, n, stream);
-        const dim3 grid(min(cdiv(n, 4), 2048)), block(256);
+        const dim3 grid(min(cdiv(n, 256), 8192)), block(256); /* 64 records per wave and step; enough waves for a batch that is all other sizes */
 #define MC_SKIP(M) case M: hipLaunchKernelGGL((k_hevc_mc<false, M, true>), grid, block, 0, stream, dst, dststride, src, srcstride, src2, blocks, n); break;
         switch (mode) {
         MC_SKIP(0) MC_SKIP(1) MC_SKIP(2) MC_SKIP(3)

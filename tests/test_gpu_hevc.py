@@ -331,7 +331,7 @@ def test_hevc_mc_batch(chroma, uni, old, monkeypatch):
 
 
 @pytest.mark.parametrize("m", ["default", "0"])
-@pytest.mark.parametrize("case", ["all16", "mixed_sizes", "unaligned_dst", "ragged_n"])
+@pytest.mark.parametrize("case", ["all16", "mixed_sizes", "unaligned_dst", "ragged_n", "big_blocks"])
 def test_hevc_qpel_uni16_matrix_cores(case, m, monkeypatch):
     """put_hevc_qpel_uni with a 16-byte-aligned source stride: the batch's 16 x 16 blocks run on k_hevc_qpel_m (hevc_qpel_m.hip), the
     rest on k_hevc_mc in a second launch that skips them.  Every (mx, my), every source alignment modulo 16, saturating content (0 / 255
@@ -341,7 +341,7 @@ def test_hevc_qpel_uni16_matrix_cores(case, m, monkeypatch):
     torch = _torch()
     if m != "default":
         monkeypatch.setenv("FFHIP_HEVC_MC_M", m)
-    rng = np.random.default_rng({"all16": 1, "mixed_sizes": 2, "unaligned_dst": 3, "ragged_n": 4}[case])
+    rng = np.random.default_rng({"all16": 1, "mixed_sizes": 2, "unaligned_dst": 3, "ragged_n": 4, "big_blocks": 5}[case])
     W, H, P = 512, 512, 24
     ss = W + 2 * P                       # 560 = 16 * 35
     ref = rng.integers(0, 256, (H + 2 * P, ss), dtype=np.uint8)
@@ -350,13 +350,16 @@ def test_hevc_qpel_uni16_matrix_cores(case, m, monkeypatch):
     sd = W + (4 if case != "unaligned_dst" else 8)
     blocks = []
     i = 0
-    for by in range(0, H, 16):
-        for bx in range(0, W, 16):
+    step = 64 if case == "big_blocks" else 16
+    for by in range(0, H, step):
+        for bx in range(0, W, step):
             w = h = 16
             if case == "mixed_sizes" and rng.integers(0, 3) == 0:
                 w, h = int(rng.choice([4, 8, 12, 16])), int(rng.choice([4, 8, 16]))
                 if w == 16 and h == 16:
                     h = 8
+            if case == "big_blocks":     # every luma width of the reference's tables, tiles cut off at the block's edge (round 6)
+                w, h = int(rng.choice([4, 8, 12, 16, 24, 32, 48, 64])), int(rng.choice([4, 8, 12, 16, 24, 32, 48, 64]))
             dy, dx = rng.integers(-20, 21, 2)
             doff = by * sd + bx + (int(rng.integers(0, 4)) if case == "unaligned_dst" and bx + 20 < W else 0)
             blocks.append((doff, (by + P + int(dy)) * ss + bx + P + int(dx), w, h, i & 3, (i >> 2) & 3))
@@ -373,18 +376,18 @@ def test_hevc_qpel_uni16_matrix_cores(case, m, monkeypatch):
     for j, (do, so, w, h, mx, my) in enumerate(blocks):
         rec[j] = (do, so, w, h, mx, my)
         O.ffo_hevc_mc(0, 1, want.ctypes.data + do, sd, C.cast(ref.ctypes.data + so, u8p), ss, h, mx, my, w)
-    assert len({(b[1] - 3 - 3 * ss) & 15 for b in blocks}) == 16
+    assert len({(b[1] - 3 - 3 * ss) & 15 for b in blocks}) == 16 or case == "big_blocks"
     d_dst = torch.from_numpy(dst.copy()).cuda()
     hevc.mc_batch(0, 1, d_dst, sd, torch.from_numpy(ref).cuda(), ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 12).copy()).cuda(), n)
     torch.cuda.synchronize()
     got = d_dst.cpu().numpy()
-    assert (want != dst).sum() > 100000
+    assert (want != dst).sum() > (20000 if case == "big_blocks" else 100000)
     bad = np.argwhere(got != want)
     assert bad.size == 0, (case, bad[:5], len(bad))
 
 
 @pytest.mark.parametrize("mode", [0, 2, 3, 4])
-@pytest.mark.parametrize("case", ["all16", "mixed_sizes", "ragged_unaligned"])
+@pytest.mark.parametrize("case", ["all16", "mixed_sizes", "ragged_unaligned", "big_blocks"])
 def test_hevc_qpel16_matrix_cores_other_stages(case, mode, monkeypatch):
     """the other output stages of k_hevc_qpel_m — put (int16 rows of 64), uni_w, bi, bi_w — on batches of 16 x 16 luma blocks with a
     16-byte-aligned source stride: every (mx, my) and source alignment, saturating content, weights over the slice header's ranges and
@@ -401,13 +404,16 @@ def test_hevc_qpel16_matrix_cores_other_stages(case, mode, monkeypatch):
     sd = W + 4
     blocks = []
     i = 0
-    for by in range(0, H, 16):
-        for bx in range(0, W, 16):
+    step = 64 if case == "big_blocks" else 16
+    for by in range(0, H, step):
+        for bx in range(0, W, step):
             w = h = 16
             if case == "mixed_sizes" and rng.integers(0, 3) == 0:
                 w, h = int(rng.choice([4, 8, 12, 16])), int(rng.choice([4, 8, 16]))
                 if w == 16 and h == 16:
                     w = 8
+            if case == "big_blocks":
+                w, h = int(rng.choice([4, 8, 12, 16, 24, 32, 48, 64])), int(rng.choice([4, 8, 12, 16, 24, 32, 48, 64]))
             dy, dx = rng.integers(-20, 21, 2)
             blocks.append((by, bx, (by + P + int(dy)) * ss + bx + P + int(dx), w, h, i & 3, (i >> 2) & 3))
             i += 1
@@ -418,17 +424,17 @@ def test_hevc_qpel16_matrix_cores_other_stages(case, mode, monkeypatch):
     d_ref = torch.from_numpy(ref).cuda()
     if mode == 0:
         rec = np.zeros(n, hevc.MC_DTYPE)
-        dst = np.full((n, 17, 64), -7, np.int16)
+        dst = np.full((n, 65, 64), -7, np.int16)
         want = dst.copy()
         for j, (by, bx, so, w, h, mx, my) in enumerate(blocks):
-            do = j * 17 * 64 + ((j & 1) if case == "ragged_unaligned" else 0)
+            do = j * 65 * 64 + ((j & 1) if case == "ragged_unaligned" else 0)
             rec[j] = (do, so, w, h, mx, my)
             O.ffo_hevc_mc(0, 0, want.ctypes.data + 2 * do, 0, C.cast(ref.ctypes.data + so, u8p), ss, h, mx, my, w)
         d_dst = torch.from_numpy(dst.copy()).cuda()
         hevc.mc_batch(0, 0, d_dst, 0, d_ref, ss, torch.from_numpy(rec.view(np.uint8).reshape(n, 12).copy()).cuda(), n)
     else:
         rec = np.zeros(n, hevc.MCW_DTYPE)
-        src2 = rng.integers(-8192, 16384, (n + 1, 16, 64)).astype(np.int16)
+        src2 = rng.integers(-8192, 16384, (n + 1, 64, 64)).astype(np.int16)
         src2[::5] = 16383
         src2[1::7] = -8192
         flat2 = src2.reshape(-1)
@@ -436,7 +442,7 @@ def test_hevc_qpel16_matrix_cores_other_stages(case, mode, monkeypatch):
         want = dst.copy()
         for j, (by, bx, so, w, h, mx, my) in enumerate(blocks):
             d, wx0, wx1, ox = _weights(rng, j)
-            o2 = j * 1024 + (1 if (case == "ragged_unaligned" and j % 3 == 0) else 0)
+            o2 = j * 4096 + (1 if (case == "ragged_unaligned" and j % 3 == 0) else 0)
             do = by * sd + bx
             rec[j] = (do, so, o2, w, h, mx, my, wx0, wx1, ox, d, 0)
             O.ffo_hevc_mc_w(0, mode, C.cast(want.ctypes.data + do, u8p), sd, C.cast(ref.ctypes.data + so, u8p), ss,
@@ -446,7 +452,7 @@ def test_hevc_qpel16_matrix_cores_other_stages(case, mode, monkeypatch):
                         torch.from_numpy(rec.view(np.uint8).reshape(n, 24).copy()).cuda(), n)
     torch.cuda.synchronize()
     got = d_dst.cpu().numpy()
-    assert (want != dst).sum() > 50000
+    assert (want != dst).sum() > (8000 if case == "big_blocks" else 50000)
     bad = np.argwhere(got != want)
     assert bad.size == 0, (case, mode, bad[:5], len(bad))
 

@@ -63,3 +63,49 @@ for k in ("FFHIP_HEVC_QM_FULL", "FFHIP_HEVC_MC_M"):
 for mx, my in ((0, 0), (2, 0), (0, 2), (2, 2), (1, 3)):
     ms = timed(records(mx, my))
     print(json.dumps({"position": [mx, my], "ms": round(ms, 4), "hbm_frac": round(2 * planes * W * H / ms / 1e6 / 8000, 4)}), flush=True)
+
+# a quadtree-like partition (round 6, second step): every 32 x 32 cell is one 32 x 32 block, four 16 x 16, two 32 x 16 / 16 x 32 or sixteen 8 x 8
+cells_y, cells_x = np.meshgrid(np.arange(0, planes * H, 32), np.arange(0, W, 32), indexing="ij")
+kind = rng.integers(0, 5, cells_y.shape)
+recs = []
+for k, parts in enumerate(([(0, 0, 32, 32)], [(0, 0, 16, 16), (0, 16, 16, 16), (16, 0, 16, 16), (16, 16, 16, 16)], [(0, 0, 32, 16), (16, 0, 32, 16)],
+                           [(0, 0, 16, 32), (0, 16, 16, 32)], [(y, x, 8, 8) for y in range(0, 32, 8) for x in range(0, 32, 8)])):
+    cy, cx = cells_y[kind == k], cells_x[kind == k]
+    for (oy, ox, w, h) in parts:
+        m = cy + oy < planes * H
+        recs.append(np.stack([cy[m] + oy, cx[m] + ox, np.full(m.sum(), w), np.full(m.sum(), h)], 1))
+recs = np.concatenate(recs)
+recs = recs[np.lexsort((recs[:, 1], recs[:, 0]))]
+nq = len(recs)
+mcq = np.zeros(nq, hevc.MC_DTYPE)
+mcq["dst_offset"] = recs[:, 0] * W + recs[:, 1]
+mcq["src_offset"] = (recs[:, 0] + P + rng.integers(-8, 9, nq)) * (W + 2 * P) + recs[:, 1] + P + rng.integers(-8, 9, nq)
+mcq["width"], mcq["height"] = recs[:, 2], recs[:, 3]
+mcq["mx"], mcq["my"] = rng.integers(0, 4, nq), rng.integers(0, 4, nq)
+d_q = torch.from_numpy(mcq.view(np.uint8).reshape(-1, 12)).to(dev)
+
+
+def timed_q(iters=20):
+    for _ in range(3):
+        hevc.mc_batch(0, 1, pic, W, ref, W + 2 * P, d_q, nq)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        hevc.mc_batch(0, 1, pic, W, ref, W + 2 * P, d_q, nq)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+want = None
+for p in range(2):
+    for name, env in (("product (16 x 16 on the matrix cores, the rest on k_hevc_mc)", {}), ("k_hevc_mc", {"FFHIP_HEVC_MC_M": "0"})):
+        for k in ("FFHIP_HEVC_QM_FULL", "FFHIP_HEVC_MC_M"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ms = timed_q()
+        got = int(pic.to(torch.int64).sum().item())
+        want = got if want is None else want
+        print(json.dumps({"partition": "8x8 .. 32x32 mixed", "blocks": nq, "pass": p, "kernel": name, "ms": round(ms, 4),
+                          "hbm_frac": round(2 * planes * W * H / ms / 1e6 / 8000, 4), "same_pixels": got == want}), flush=True)
