@@ -99,8 +99,9 @@ __global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride
      * moves on when it is a 16 x 16 one); otherwise one block per wave */
     /* SKIP16: the wave looks at 64 records at a time — a lane each — and works through the ones that are left to this kernel (a record
      * per dependent load was 45 us for a quarter of a million blocks; now 5) */
-    for (int c0 = (blockIdx.x * 4 + wave) * (SKIP16 ? 64 : 1); c0 < n; c0 += SKIP16 ? (int)gridDim.x * 256 : n) {
+    for (int c0 = SKIP16 ? blockIdx.x * 64 : blockIdx.x * 4 + wave; c0 < n; c0 += SKIP16 ? (int)gridDim.x * 64 : n) {
     unsigned long todo = 1;
+    int turn = 0;
     if (SKIP16) {
         const int bl = c0 + lane;
         const Rec &rr = static_cast<const Rec *>(blocks_)[min(bl, n - 1)];
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(256) void k_hevc_mc(void *dst_, ptrdiff_t dststride
     while (todo) {
     const int b = SKIP16 ? c0 + (int)__builtin_ctzl(todo) : c0;
     todo &= todo - 1;
+    if (SKIP16 && (turn++ & 3) != wave)
+        continue; /* the four waves of the workgroup look at the same 64 records and take turns */
     const Rec k = static_cast<const Rec *>(blocks_)[b];
     const int w = __builtin_amdgcn_readfirstlane((int)k.width), h = __builtin_amdgcn_readfirstlane((int)k.height);
     const int mx = __builtin_amdgcn_readfirstlane((int)k.mx) & FMASK, my = __builtin_amdgcn_readfirstlane((int)k.my) & FMASK;
@@ -385,7 +388,7 @@ int ffhip_launch_hevc_mc(int chroma, int mode, void *dst, ptrdiff_t dststride, c
     if (!chroma && !old && !(em && em[0] == '0') && ffhip_hevc_qpel_m_ok(mode, dststride, srcstride)) {
         /* luma: the 16 x 16 blocks on the matrix cores, everything else in a second launch that skips those */
         ffhip_launch_hevc_qpel_m(mode, dst, dststride, src, srcstride, src2, blocks, n, stream);
-        const dim3 grid(min(cdiv(n, 256), 8192)), block(256); /* 64 records per wave and step; enough waves for a batch that is all other sizes */
+        const dim3 grid(min(cdiv(n, 64), 32768)), block(256); /* 64 records per wave and step; enough waves for a batch that is all other sizes */
 #define MC_SKIP(M) case M: hipLaunchKernelGGL((k_hevc_mc<false, M, true>), grid, block, 0, stream, dst, dststride, src, srcstride, src2, blocks, n); break;
         switch (mode) {
         MC_SKIP(0) MC_SKIP(1) MC_SKIP(2) MC_SKIP(3)

@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256) void k_vp9_mc(uint8_t *dst, ptrdiff_t dststrid
     __shared__ uint32_t tmp_all[4][VM_PAIRS * VM_PITCH];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     /* SKIP16: the wave looks at 64 records at a time — a lane each — and works through the ones that are left to this kernel */
-    for (int c0 = (blockIdx.x * 4 + wave) * (SKIP16 ? 64 : 1); c0 < n; c0 += SKIP16 ? (int)gridDim.x * 256 : n) {
+    for (int c0 = SKIP16 ? blockIdx.x * 64 : blockIdx.x * 4 + wave; c0 < n; c0 += SKIP16 ? (int)gridDim.x * 64 : n) {
     unsigned long todo = 1;
+    int turn = 0;
     if (SKIP16) {
         const int bl = c0 + lane;
         const FFHipVp9McBlock &rr = blocks[min(bl, n - 1)];
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(256) void k_vp9_mc(uint8_t *dst, ptrdiff_t dststrid
     while (todo) {
     const int b = SKIP16 ? c0 + (int)__builtin_ctzl(todo) : c0;
     todo &= todo - 1;
+    if (SKIP16 && (turn++ & 3) != wave)
+        continue; /* the four waves of the workgroup look at the same 64 records and take turns */
     const FFHipVp9McBlock k = blocks[b];
     const int w = __builtin_amdgcn_readfirstlane((int)k.width), h = __builtin_amdgcn_readfirstlane((int)k.height);
     const int filter = __builtin_amdgcn_readfirstlane((int)k.filter) & 3;
@@ -431,7 +434,7 @@ int ffhip_launch_vp9_mc(uint8_t *dst, ptrdiff_t dststride, const uint8_t *src, p
          * everything else in a second launch that skips those */
         const int per_xcd = cdiv(cdiv(n, 16), 8);
         hipLaunchKernelGGL(k_vp9_mc_m, dim3(8 * per_xcd), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n, per_xcd);
-        hipLaunchKernelGGL(k_vp9_mc<true>, dim3(min(cdiv(n, 256), 8192)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
+        hipLaunchKernelGGL(k_vp9_mc<true>, dim3(min(cdiv(n, 64), 32768)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
     } else {
         hipLaunchKernelGGL(k_vp9_mc<false>, dim3(cdiv(n, 4)), dim3(256), 0, stream, dst, dststride, src, srcstride, blocks, n);
     }
