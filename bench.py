@@ -853,6 +853,26 @@ def extras(torch, dev, torch_alloc=False):
                                  "transforms": nti, "ms": round(ms, 4)}
     ctx_i.close()
     del ti, to
+    # DCT-I / DST-I at wmavoice's length (libavcodec/wmavoice.c:398-404: 64 reals, scale 1/64): the transform as its 64 x 64 matrix,
+    # summed in double precision (kernels/tx_dcst1.hip) — 512 B and 4096 multiply-adds per transform, bound by the FP64 issue rate
+    for nm, ty in (("dctI_64", _tx.FLOAT_DCT_I), ("dstI_64", _tx.FLOAT_DST_I)):
+        ntd = 1 << 20
+        ctx_d = _tx.TxContext(ty, 0, 64, 1.0 / 64)
+        di = torch.randn((ntd, 64), dtype=torch.float32, device=dev)
+        do = torch.zeros_like(di)
+        ctx_d.batch(do, di)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(5):
+            ctx_d.batch(do, di)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        gbs = ntd * 512 / (ms * 1e-3) / 1e9
+        out[nm] = {"Mtransforms/s": round(ntd / (ms * 1e-3) / 1e6, 2), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                   "fp64_TFLOP/s": round(ntd * 8192 / (ms * 1e-3) / 1e12, 2), "transforms": ntd, "ms": round(ms, 4)}
+        ctx_d.close()
+        del di, do
     # AAC imdct_and_windowing: 65,536 all-long channel-frames (2 channels), inverse MDCT -> window -> overlap-add resident in HBM:
     # 18,432 B per channel-frame (ffmpeg_amd/csrc/aac_api.hip).  Window tables: the decoder's own, from the committed fixture.
     from ffmpeg_amd import aac

@@ -27,4 +27,13 @@ size_t ffhip_txw_out_elems(const FFHipTxWide *w);
 size_t ffhip_txw_elem_size(const FFHipTxWide *w);
 int    ffhip_txw_device(const FFHipTxWide *w);
 
+/* kernels/tx_dcst1.hip: AV_TX_FLOAT_DCT_I / AV_TX_FLOAT_DST_I, forward, even lengths 4..1024 */
+struct FFHipTxDcst1;
+int  ffhip_dcst1_create(FFHipTxDcst1 **w, int is_dst, int len, float scale);
+void ffhip_dcst1_free(FFHipTxDcst1 *w);
+int  ffhip_dcst1_batch(const FFHipTxDcst1 *w, float *out, size_t out_pitch, const float *in, size_t in_pitch, ptrdiff_t istride, int nt,
+                       hipStream_t stream);
+int  ffhip_dcst1_device(const FFHipTxDcst1 *w);
+int  ffhip_dcst1_len(const FFHipTxDcst1 *w);
+
 #endif

@@ -70,6 +70,7 @@ struct FFHipTXContext {
     size_t blob_bytes = 0;   /* size of the table blob at `dev` (multiple of 16) */
     float2 *wtab = nullptr;  /* exp(-2 pi i k / n), k < n: the register-resident kernels' twiddles (kernels/tx_radix.hip), or null */
     FFHipTxWide *wide = nullptr; /* AV_TX_DOUBLE_* / AV_TX_INT32_* contexts: everything lives in kernels/tx_wide.hip */
+    FFHipTxDcst1 *dcst1 = nullptr; /* AV_TX_FLOAT_DCT_I / _DST_I contexts: kernels/tx_dcst1.hip */
     /* host-pointer shim staging */
     void *stage = nullptr;
     size_t stage_sz = 0;
@@ -1275,6 +1276,8 @@ extern "C" void ffhip_tx_uninit(FFHipTXContext **pctx)
     FFHipDeviceGuard dg(c->device);
     if (c->wide)
         ffhip_txw_free(c->wide);
+    if (c->dcst1)
+        ffhip_dcst1_free(c->dcst1);
     if (c->dev)
         (void)hipFree(c->dev);
     if (c->wtab)
@@ -1428,6 +1431,7 @@ static int tx_init_pfa(FFHipTXContext *c, float scale_f, int F, bool is_fft)
 }
 
 static void tx_single_wide(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
+static void tx_single_dcst1(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride);
 
 extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, int inv, int len, const void *scale_,
                              uint64_t flags)
@@ -1463,8 +1467,34 @@ extern "C" int ffhip_tx_init(FFHipTXContext **pctx, ffhip_tx_fn *fn, int type, i
     const float *scale = static_cast<const float *>(scale_);
     if (!scale)
         scale = &one; /* an FFT takes no scale (av_tx_init accepts NULL there) */
+    if (type == FFHIP_TX_FLOAT_DCT_I || type == FFHIP_TX_FLOAT_DST_I) {
+        if (inv) {
+            /* ff_tx_dcstI_init (tx_template.c:2017-2021) doubles the length of an inverse context and halves its scale; its transform
+             * then reads twice the samples the caller asked for — nothing a caller can use, left to the C code */
+            ffhip_set_error("ffhip_tx_init: DCT-I / DST-I are forward transforms on the hip path (their own inverse up to the scale)");
+            return FFHIP_ENOSYS;
+        }
+        if (flags & (FFHIP_TX_FULL_IMDCT | FFHIP_TX_REAL_TO_REAL | FFHIP_TX_REAL_TO_IMAGINARY)) {
+            ffhip_set_error("ffhip_tx_init: AV_TX_FULL_IMDCT / AV_TX_REAL_TO_* do not apply to DCT-I / DST-I");
+            return FFHIP_EINVAL;
+        }
+        FFHipTXContext *c = new (std::nothrow) FFHipTXContext();
+        if (!c)
+            return FFHIP_ENOMEM;
+        const int r = ffhip_dcst1_create(&c->dcst1, type == FFHIP_TX_FLOAT_DST_I, len, *scale);
+        if (r < 0) {
+            delete c;
+            return r;
+        }
+        c->device = ffhip_dcst1_device(c->dcst1);
+        c->type = type; c->inv = 0; c->len = len; c->scale = *scale;
+        *pctx = c;
+        if (fn)
+            *fn = tx_single_dcst1;
+        return 0;
+    }
     if (type != FFHIP_TX_FLOAT_MDCT && type != FFHIP_TX_FLOAT_FFT && type != FFHIP_TX_FLOAT_RDFT && type != FFHIP_TX_FLOAT_DCT) {
-        ffhip_set_error("ffhip_tx_init: type %d is not on the hip path (float FFT / MDCT / RDFT / DCT-II/III; double and int32 FFT / MDCT)", type);
+        ffhip_set_error("ffhip_tx_init: type %d is not on the hip path (float FFT / MDCT / RDFT / DCT-I/II/III / DST-I; double and int32 FFT / MDCT)", type);
         return FFHIP_ENOSYS;
     }
     const bool dct = type == FFHIP_TX_FLOAT_DCT;
@@ -1685,6 +1715,9 @@ extern "C" int ffhip_tx_batch_dev(FFHipTXContext *c, void *out, size_t out_pitch
         }
         return ffhip_txw_batch(c->wide, out, out_pitch, in, in_pitch, nt, (hipStream_t)stream);
     }
+    if (c->dcst1) /* the input side is the strided one (ff_tx_dctI / ff_tx_dstI read src[i * stride]) */
+        return ffhip_dcst1_batch(c->dcst1, (float *)out, out_pitch, (const float *)in, in_pitch, stride / (ptrdiff_t)sizeof(float), nt,
+                                 (hipStream_t)stream);
     if (!c->full)
         return tx_batch_half(c, out, out_pitch, in, in_pitch, stride, nt, stream);
     /* full inverse: rows of 2 * len floats; the half transform goes to the middle, then the mirror pass */
@@ -2085,6 +2118,34 @@ static void tx_single(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
     float *fo = (float *)out;
     for (size_t i = 0; i < out_elems; i++)
         fo[(s->inv || fft) ? (ptrdiff_t)i : (ptrdiff_t)i * es] = hout[i];
+}
+
+/* DCT-I / DST-I: len reals in (strided), len reals out */
+static void tx_single_dcst1(FFHipTXContext *s, void *out, void *in, ptrdiff_t stride)
+{
+    FFHipDeviceGuard dg(s->device);
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t n = (size_t)s->len, row = (n * sizeof(float) + 15) & ~(size_t)15;
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; i++)
+        h[i] = *(const float *)((const uint8_t *)in + (ptrdiff_t)i * stride);
+    if (2 * row > s->stage_sz) {
+        if (s->stage)
+            (void)hipFree(s->stage);
+        s->stage = nullptr;
+        s->stage_sz = 0;
+        if (hipMalloc(&s->stage, 2 * row) != hipSuccess) {
+            ffhip_set_error("ffhip_tx: staging allocation failed");
+            return;
+        }
+        s->stage_sz = 2 * row;
+    }
+    float *din = (float *)s->stage, *dout = (float *)((uint8_t *)s->stage + row);
+    if (hipMemcpy(din, h.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return;
+    if (ffhip_dcst1_batch(s->dcst1, dout, row, din, row, 1, 1, 0) < 0)
+        return;
+    (void)hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost);
 }
 
 /* the same for the double / int32 contexts: the strided side (forward MDCT: output, inverse: input; an FFT has none) packed on the host */

@@ -12,6 +12,7 @@ from . import _lib
 
 FLOAT_FFT, FLOAT_MDCT, FLOAT_RDFT, FLOAT_DCT = 0, 1, 6, 9
 DOUBLE_FFT, DOUBLE_MDCT, INT32_FFT, INT32_MDCT = 2, 3, 4, 5   # libavutil/tx.h:48-69: rows of float64 / int32, *scale a double / a float
+FLOAT_DCT_I, FLOAT_DST_I = 12, 15   # libavutil/tx.h:107-128: forward, even lengths 4..1024
 FULL_IMDCT, REAL_TO_REAL, REAL_TO_IMAGINARY = 1 << 2, 1 << 3, 1 << 4
 BITEXACT = 1 << 32   # FFHIP_TX_BITEXACT: the C reference's operation order (include/ffhip.h)
 _TXFN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t)

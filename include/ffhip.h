@@ -1730,6 +1730,9 @@ typedef struct FFHipTXContext FFHipTXContext;
 #define FFHIP_TX_FLOAT_RDFT 6   /* == AV_TX_FLOAT_RDFT (r2c forward, c2r inverse; libavutil/tx.h:70-90) */
 #define FFHIP_TX_FLOAT_DCT  9   /* == AV_TX_FLOAT_DCT: DCT-II forward, DCT-III inverse (libavutil/tx.h:95-104), power of two 8..4096; as with av_tx_init the
                                    inverse is initialised with half the number of samples it transforms */
+#define FFHIP_TX_FLOAT_DCT_I 12 /* == AV_TX_FLOAT_DCT_I, AV_TX_FLOAT_DST_I (libavutil/tx.h:107-128; ff_tx_dctI / ff_tx_dstI, tx_template.c:2006-2075): forward, */
+#define FFHIP_TX_FLOAT_DST_I 15 /*    even len 4..1024 (64 in libavcodec/wmavoice.c:398-404); len reals in — `stride` bytes apart — len reals out; outputs as the
+                                 *    C code's, its two middle ones at *scale != 1 included (kernels/tx_dcst1.hip); inverse contexts: FFHIP_ENOSYS */
 #define FFHIP_TX_DOUBLE_FFT  2  /* == AV_TX_DOUBLE_FFT,  AV_TX_DOUBLE_MDCT (libavutil/tx.h:48-58; tx_double.c): rows of double, *scale a double */
 #define FFHIP_TX_DOUBLE_MDCT 3
 #define FFHIP_TX_INT32_FFT   4  /* == AV_TX_INT32_FFT, AV_TX_INT32_MDCT (libavutil/tx.h:59-69; tx_int32.c): rows of int32_t, *scale a float; the */
@@ -1740,9 +1743,7 @@ typedef struct FFHipTXContext FFHipTXContext;
 /* Refused — ffhip_tx_init() returns FFHIP_ENOSYS and the caller keeps the C / SIMD codelets (the reference's convention for an arch
  * that does not offer a transform: its codelet list simply has no entry, libavutil/tx.c:593-650):
  *   the RDFT / DCT / DCT-I / DST-I forms of the double and int32 types (7, 8, 10, 11, 13, 14, 16, 17) and their prime-factor lengths;
- *   AV_TX_FLOAT_DCT_I (12) and AV_TX_FLOAT_DST_I (15) (libavutil/tx.h:116,128; tx_template.c:2006-2105): the codelets take even lengths
- *   only and run an RDFT over 2 (len - 1) resp. 2 (len + 1) reals, i.e. an ODD-length FFT (wmavoice's len 64: 63 = 7 x 9 and
- *   65 = 5 x 13 complex points, the latter through the naive codelet) — not a power-of-two network; no batch user on the path. */
+ *   inverse contexts of AV_TX_FLOAT_DCT_I / _DST_I (ff_tx_dcstI_init doubles their length, tx_template.c:2017-2021), their len 2 and len > 1024. */
 #define FFHIP_TX_FULL_IMDCT        (1ULL << 2)   /* == AV_TX_FULL_IMDCT: an inverse MDCT writes 2 * len outputs (ff_tx_mdct_inv_full,
                                                   * libavutil/tx_template.c:1391-1408); batches: 8-byte aligned rows of 2 * len floats */
 #define FFHIP_TX_REAL_TO_REAL      (1ULL << 3)   /* == AV_TX_REAL_TO_REAL: a forward RDFT writes the len/2 + 1 real parts only (ff_tx_rdft_r2r,

@@ -102,6 +102,9 @@ HIP_CODELET(ff_tx_mdct_pfa_9_float_hip_def,  AV_TX_FLOAT_MDCT, 0, 9, 2, 2, 72, 4
 HIP_CODELET(ff_tx_rdft_float_hip_def,      AV_TX_FLOAT_RDFT, 0, 4, 2, 2, 8, 4096);
 HIP_CODELET(ff_tx_dctII_float_hip_def,     AV_TX_FLOAT_DCT,  FF_TX_FORWARD_ONLY, 2, TX_FACTOR_ANY, 2, 8, 4096);
 HIP_CODELET(ff_tx_dctIII_float_hip_def,    AV_TX_FLOAT_DCT,  FF_TX_INVERSE_ONLY, 2, TX_FACTOR_ANY, 2, 8, 4096);
+/* DCT-I / DST-I (wmavoice's 64; tx_template.c:2006-2105): forward contexts only — the C codelets' inverse reads twice the length */
+HIP_CODELET(ff_tx_dctI_float_hip_def,      AV_TX_FLOAT_DCT_I, FF_TX_FORWARD_ONLY, 2, TX_FACTOR_ANY, 2, 4, 1024);
+HIP_CODELET(ff_tx_dstI_float_hip_def,      AV_TX_FLOAT_DST_I, FF_TX_FORWARD_ONLY, 2, TX_FACTOR_ANY, 2, 4, 1024);
 
 /* the other two sample types at power-of-two lengths (libffhip's kernels/tx_wide.hip).  They ride in the same list: av_tx walks every
  * codelet of every list and filters by .type (libavutil/tx.c:367-400), the list's name is a convention of the per-type files */
@@ -114,6 +117,6 @@ const FFTXCodelet * const ff_tx_codelet_list_float_hip[] = {
     &ff_tx_fft_float_hip_def, &ff_tx_fft_pfa_15_float_hip_def, &ff_tx_fft_pfa_3_float_hip_def, &ff_tx_fft_pfa_5_float_hip_def,
     &ff_tx_fft_pfa_7_float_hip_def, &ff_tx_fft_pfa_9_float_hip_def, &ff_tx_mdct_float_hip_def, &ff_tx_mdct_pfa_15_float_hip_def, &ff_tx_mdct_pfa_3_float_hip_def,
     &ff_tx_mdct_pfa_5_float_hip_def, &ff_tx_mdct_pfa_7_float_hip_def, &ff_tx_mdct_pfa_9_float_hip_def, &ff_tx_rdft_float_hip_def,
-    &ff_tx_dctII_float_hip_def, &ff_tx_dctIII_float_hip_def,
+    &ff_tx_dctII_float_hip_def, &ff_tx_dctIII_float_hip_def, &ff_tx_dctI_float_hip_def, &ff_tx_dstI_float_hip_def,
     &ff_tx_fft_double_hip_def, &ff_tx_mdct_double_hip_def, &ff_tx_fft_int32_hip_def, &ff_tx_mdct_int32_hip_def, NULL,
 };

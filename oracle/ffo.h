@@ -237,6 +237,8 @@ void   ffo_txw_fft_run(int is_int, int inv, int len, void *out, const void *in);
 void   ffo_txw_mdct_run(int is_int, int inv, int len, double scale, void *out, const void *in);
 /* mode 1: AV_TX_REAL_TO_REAL (len/2 + 1 floats out), 2: AV_TX_REAL_TO_IMAGINARY (len/2 floats out); forward, len a power of two >= 8 */
 void   ffo_rdft_half_run(int mode, int len, float scale, float *out, const float *in);
+/* AV_TX_FLOAT_DCT_I / _DST_I forward, n even (tx_template.c:2006-2075); the inputs `stride` bytes apart */
+void   ffo_dcst1_run(int is_dst, int n, float scale, float *out, const float *in, ptrdiff_t stride);
 /* AV_TX_FLOAT_DCT: DCT-II (inv 0) / DCT-III (inv 1) of n real samples, n a power of two (tx_template.c:1832-2002) */
 void   ffo_dct_run(int inv, int n, float scale, float *out, const float *in);
 /* double-precision cosine-sum definition (ff_tx_mdct_naive_fwd/_inv, tx_template.c:1144-1193) */

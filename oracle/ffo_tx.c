@@ -827,6 +827,117 @@ void ffo_rdft_half_run(int mode, int len, float scale, float *out, const float *
 }
 
 /*
+ * AV_TX_FLOAT_DCT_I / AV_TX_FLOAT_DST_I, forward (ff_tx_dctI / ff_tx_dstI on ff_tx_dcstI_init, libavutil/tx_template.c:2006-2075): n
+ * even.  The input mirrored into 2 (n - 1) reals resp. 2 (n + 1) reals with the odd symmetry, then the half-complex RDFT of that
+ * length — 2 mod 4, so the _mod2 forms of ff_tx_rdft_r2r / _r2i (:1718-1830) with the pair in the middle handled before the loop
+ * (after data[len4].re took its factor) and, for r2r, out[len4 + 1] = tmp_mid * (1 / scale).  Restated in floats in the reference's
+ * order, in place over the FFT's output as there; the FFT itself has n -+ 1 points, an odd number the reference serves with a
+ * prime-factor or the naive codelet: here the naive sum in double precision, rounded to float (ff_tx_fft_naive, :1016-1046, sums in
+ * float; the difference is rounding, which the tests' tolerance covers).  is_dst: 0 DCT-I, 1 DST-I.
+ */
+void ffo_dcst1_run(int is_dst, int n, float scale, float *out, const float *in, ptrdiff_t stride)
+{
+    const int ln = is_dst ? n + 1 : n - 1, len = 2 * ln, len2 = len >> 1, len4 = len >> 2, al4 = (len + 3) / 4;
+    const int mode = is_dst ? 2 : 1;
+    const double f = 2 * M_PI / len, m = (double)scale;
+    float fact[8];
+    float *tmp = calloc(len + 2, sizeof(float));
+    float *tcos = calloc(2 * al4, sizeof(float)), *tsin = tcos + al4;
+    cpx *data = calloc(len2 + 2, sizeof(cpx));
+    float *o = (float *)data;
+    float tmp_dc, tmp_mid, t[4];
+    cpx sf, sl;
+    stride /= (ptrdiff_t)sizeof(float);
+    if (!is_dst) {
+        for (int i = 0; i < ln; i++)
+            tmp[i] = tmp[2 * ln - i] = in[i * stride];
+        tmp[ln] = in[ln * stride];
+    } else {
+        tmp[0] = 0;
+        for (int i = 1; i < ln; i++) {
+            const float a = in[(i - 1) * stride];
+            tmp[i] = -a;
+            tmp[2 * ln - i] = a;
+        }
+        tmp[ln] = 0;
+    }
+    fact[0] = (float)(1.0 * m);
+    fact[1] = (float)(1.0 * m);
+    fact[2] = (float)m;
+    fact[3] = (float)-m;
+    fact[4] = (float)((0.5 - 0.0) * m);
+    fact[5] = mode == 1 ? 1 / scale : (float)((0.0 - 0.5) * m);
+    fact[6] = (float)((0.5 - 0) * m);
+    fact[7] = (float)(-(0.5 - 0) * m);
+    for (int i = 0; i < al4; i++) {
+        tcos[i] = (float)cos(i * f);
+        tsin[i] = (float)cos(((len - i * 4) / 4.0) * f) * -1;
+    }
+    for (int k = 0; k < len2; k++) {
+        double re = 0, im = 0;
+        for (int j = 0; j < len2; j++) {
+            const double a = -2 * M_PI * (double)((long)j * k % len2) / len2, c = cos(a), sn = sin(a);
+            re += tmp[2 * j] * c - tmp[2 * j + 1] * sn;
+            im += tmp[2 * j] * sn + tmp[2 * j + 1] * c;
+        }
+        data[k].re = (float)re;
+        data[k].im = (float)im;
+    }
+    tmp_dc = data[0].re;
+    data[0].re = tmp_dc + data[0].im;
+    tmp_dc = tmp_dc - data[0].im;
+    data[0].re = fact[0] * data[0].re;
+    tmp_dc = fact[1] * tmp_dc;
+    data[len4].re = fact[2] * data[len4].re;
+    sf = data[len4];
+    sl = data[len4 + 1];
+    if (mode == 1)
+        t[0] = fact[4] * (sf.re + sl.re);
+    else
+        t[0] = fact[5] * (sf.im - sl.im);
+    t[1] = fact[6] * (sf.im + sl.im);
+    t[2] = fact[7] * (sf.re - sl.re);
+    if (mode == 1) {
+        t[3] = t[1] * tcos[len4] - t[2] * tsin[len4];
+        tmp_mid = t[0] - t[3];
+    } else {
+        t[3] = t[1] * tsin[len4] + t[2] * tcos[len4];
+        tmp_mid = t[0] + t[3];
+    }
+    for (int i = 1; i <= len4; i++) {
+        sf = data[i];
+        sl = data[len2 - i];
+        if (mode == 1)
+            t[0] = fact[4] * (sf.re + sl.re);
+        else
+            t[0] = fact[5] * (sf.im - sl.im);
+        t[1] = fact[6] * (sf.im + sl.im);
+        t[2] = fact[7] * (sf.re - sl.re);
+        if (mode == 1) {
+            t[3] = t[1] * tcos[i] - t[2] * tsin[i];
+            o[i] = t[0] + t[3];
+            o[len - i] = t[0] - t[3];
+        } else {
+            t[3] = t[1] * tsin[i] + t[2] * tcos[i];
+            o[i - 1] = t[3] - t[0];
+            o[len - i - 1] = t[0] + t[3];
+        }
+    }
+    for (int i = 1; i < len4 + (mode == 2); i++)
+        o[len2 - i] = o[len - i];
+    if (mode == 1) {
+        o[len2] = tmp_dc;
+        o[len4 + 1] = tmp_mid * fact[5];
+    } else {
+        o[len4] = tmp_mid;
+    }
+    memcpy(out, o, sizeof(float) * n);
+    free(data);
+    free(tcos);
+    free(tmp);
+}
+
+/*
  * AV_TX_FLOAT_DCT, power-of-two: ff_tx_dctII (forward) / ff_tx_dctIII (inverse) on top of the RDFT
  * (libavutil/tx_template.c:1832-2002).  n is the number of real samples (av_tx_init is handed n for the forward and n / 2 for
  * the inverse transform, ff_tx_dct_init doubles it); the RDFT runs with scale resp. scale / 2.  Tables in double, stored as

@@ -123,6 +123,8 @@ def oracle():
         L.ffo_txw_mdct_run.restype = None
         L.ffo_dct_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
         L.ffo_dct_run.restype = None
+        L.ffo_dcst1_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p, C.c_ssize_t]
+        L.ffo_dcst1_run.restype = None
         L.ffo_rdft_half_run.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
         L.ffo_rdft_half_run.restype = None
         L.ffo_aac_sine_window.argtypes = [f32p, C.c_int]

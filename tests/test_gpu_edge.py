@@ -69,16 +69,17 @@ def test_unsupported_arguments_are_errors():
 
 
 def test_av_tx_types_off_the_path_are_refused():
-    """the RDFT / DCT forms of AV_TX_DOUBLE_* / AV_TX_INT32_* and AV_TX_FLOAT_DCT_I / DST_I (libavutil/tx.h:47-132) are not on the hip
+    """the RDFT / DCT / DCT-I / DST-I forms of AV_TX_DOUBLE_* / AV_TX_INT32_* (libavutil/tx.h:47-132) are not on the hip
     path: ENOSYS with the device present (the caller keeps its C codelets), as include/ffhip.h says — not a silent fallback, not a wrong
-    transform.  (The double / int32 FFT and MDCT, types 2 - 5, are on it since round 6: tests/test_gpu_tx_wide.py)"""
+    transform.  (The double / int32 FFT and MDCT, types 2 - 5, and the float DCT-I / DST-I, 12 and 15, are on it since round 6:
+    tests/test_gpu_tx_wide.py, test_gpu_tx_dcst1.py)"""
     import ctypes as C
     from ffmpeg_amd import _lib
     _torch()
     L = _lib.lib()
     ENOSYS = -38
     scale = C.c_float(1.0)
-    for typ in (7, 8, 10, 11, 12, 13, 14, 15, 16, 17):
+    for typ in (7, 8, 10, 11, 13, 14, 16, 17):
         ctx, fn = C.c_void_p(), C.c_void_p()
         assert L.ffhip_tx_init(C.byref(ctx), C.byref(fn), typ, 0, 64, C.byref(scale), 0) == ENOSYS, typ
         assert not ctx.value

@@ -55,6 +55,7 @@ ROWS = [
     ("`k_hevc_idct`, `k_hevc_idct32_mfma`", "HEVC 8×8 / 16×16 / 32×32 inverse transform + add_residual", "HBM / LDS", "6 B / sample", ("hevc_idct8_add", "hevc_idct16_add", "hevc_idct32_add"), ("hbm_frac",)),
     ("`k_hevc_qpel_m` (`hevc_qpel_m.hip`), `k_vp9_mc_m` (`vp9_mc.hip`), `k_h264_chroma_mc`", "round 6, the block-MC family on the matrix cores: put_hevc_qpel_uni 16×16, mixed positions; VP9 8-tap MC 16×16, three sets mixed; H.264 chroma MC 8×8 (VALU)", "as block MC", "2 B / sample", ("hevc_qpel_uni16_mixed", "vp9_mc16_8tap_mixed", "h264_chroma_mc8_mixed"), ("hbm_frac",)),
     ("`k_txw` (`tx_wide.hip`)", "round 6: AV_TX_INT32_MDCT 1024 forward, 16,384 transforms, bit-exact fixed point", "LDS network + 64-bit products", "12,288 B per MDCT", "mdct1024_int32_fwd", ("hbm_frac",)),
+    ("`k_dcst1_m` (`tx_dcst1.hip`)", "round 6: AV_TX_FLOAT_DCT_I / _DST_I of 64 reals (wmavoice), 2^20 transforms: the matrix on `v_mfma_f64_16x16x4_f64`", "FP64 matrix rate (78.6 TFLOP/s: 9.6 G transforms/s)", "512 B, 8,192 flop per transform", ("dctI_64", "dstI_64"), ("fp64_TFLOP/s", "hbm_frac")),
     ("`k_vp9_itxfm`, `k_vp9_lf_frame_wg`", "VP9 32×32 inverse transform + add; superblock-order loop filter of a 4K picture: ms alone / pictures/s at 32 per launch", "HBM / chain", "6 B / sample", ("vp9_itxfm32_add", "vp9_loopfilter_frame_4k"), ("hbm_frac", "ms_per_picture_one_stream")),
     ("`k_me_esa_g` (`me_cmp.hip`)", "exhaustive SAD search 16×16, R = 7, 8 pairs of 4K planes (BASELINE configs[4])", "`v_sad_u8` issue", "57,600 abs-diff / MB", "me_esa_sad_r7", ("MB-searches/s", "sad_issue_roof_frac")),
     ("`k_me_esa_satd_mx` (`me_satd.hip`)", "the same search with the 8×8 Hadamard cost on the matrix cores, 8 / 32 pairs", "VALU issue (one `v_sad_u32` per coefficient)", "—", ("me_esa_satd_r7", "me_esa_satd_r7_32_pairs"), ("MB-searches/s",)),

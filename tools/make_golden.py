@@ -826,6 +826,31 @@ def tx_wide():
     np.savez_compressed(os.path.join(OUT, "tx_wide.npz"), **d)
 
 
+DCST1_CASES = [(12, 64, 1.0 / 64), (15, 64, 1.0 / 64), (12, 4, 1.0), (15, 4, -1.5), (12, 10, 0.75), (15, 66, 2.0), (12, 256, 1.0), (15, 100, 0.75),
+               (12, 1024, 1.0 / 1024), (15, 1024, 1.0)]
+
+
+def tx_dcst1():
+    """AV_TX_FLOAT_DCT_I / AV_TX_FLOAT_DST_I, forward: inputs + the reference's outputs (tests/golden/tx_dcst1.npz)"""
+    d = {}
+    rng = np.random.default_rng(707)
+    for typ, n, scale in DCST1_CASES:
+        rc = R.ffref_tx_create(typ, 0, n, scale, 0)
+        assert rc, (typ, n)
+        x = (rng.standard_normal((3, n)) * 10.0 ** rng.integers(-2, 3, (3, 1))).astype(np.float32)
+        out = np.zeros((3, n), np.float32)
+        for t in range(3):
+            xi = np.zeros(2 * n + 8, np.float32)
+            xi[:n] = x[t]
+            o = np.zeros(2 * n + 8, np.float32)   # (the reference's RDFT uses the output buffer as its work array)
+            R.ffref_tx_run(rc, o.ctypes.data, xi.ctypes.data, 4)
+            out[t] = o[:n]
+        R.ffref_tx_free(rc)
+        key = "t%d_%d" % (typ, n)
+        d[key + "_in"], d[key + "_out"], d[key + "_scale"] = x, out, np.array([scale], np.float32)
+    np.savez_compressed(os.path.join(OUT, "tx_dcst1.npz"), **d)
+
+
 def sws_rgbin():
     """packed 8-bit RGB sources into YUV targets through the reference's sws_scale(): inputs + outputs (tests/golden/sws_rgbin.npz)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -857,6 +882,6 @@ if __name__ == "__main__":
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422(); round4(); tx_wide(); sws_rgbin()
+        sws(); h264(); h264_misc(); me(); tx(); fft(); hevc(); fdsp(); vp9(); h264pred(); aac(); sws_uops(); round2(); round3(); h264pred422(); round4(); tx_wide(); sws_rgbin(); tx_dcst1()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
