@@ -220,6 +220,31 @@ int  ffhip_d32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize
 #endif
 int  ffhip_launch_down32(FFHipD32Args &A, hipStream_t stream);
 
+/*
+ * Exact 3:2 up-scaling of 9..14-bit samples (sws_up32.hip): a job is one plane of words or one interleaved (u, v) plane of words (P01x in
+ * and out).
+ */
+struct FFHipU32Job {
+    const uint8_t *src; uint8_t *dst;
+    ptrdiff_t sstride, dstride;
+    size_t sfp, dfp;
+    int pair;
+    int srcH, dstH;                     /* source rows (even); output rows = srcH * 3 / 2 */
+    int ngroups;                        /* 12-byte destination groups per row: plane dstW / 6, pair dstW / 3 (>= 3) */
+    const uint32_t *hfv;                /* device: virtual horizontal bank, dstW x 2 dwords */
+    const uint32_t *vfv;                /* device: virtual vertical bank, dstH x 2 dwords */
+    int ncb, nstrips, strip_rows, unit_begin;
+};
+struct FFHipU32Args {
+    FFHipU32Job job[3];
+    int njobs, units_per_frame, nframes;
+    int sdepth, ddepth, smsb, dmsb;     /* as FFHipUp2Job.hb_* */
+};
+#ifdef __cplusplus
+int  ffhip_u32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, std::vector<uint32_t> *out);
+#endif
+int  ffhip_launch_up32(FFHipU32Args &A, hipStream_t stream);
+
 /* exact 2:1 from NV12 / NV21 into packed RGB, fused (k_sws_down2_rgb in sws_down2.hip) */
 struct FFHipDn2RgbArgs {
     const uint8_t *ysrc, *csrc;         /* the luma plane; the interleaved chroma plane, or the U plane */

@@ -112,6 +112,9 @@ struct FFHipSwsContext {
     void *dn2_dev = nullptr;
     int d32_ok = 0;   /* exact 3:2 down in both directions: the static-schedule kernel of sws_down32.hip */
     void *d32_dev = nullptr;
+    int u32_ok = 0;   /* exact 3:2 UP between 9..14-bit formats laid out alike: the static-schedule kernel of sws_up32.hip */
+    void *u32_dev = nullptr;
+    const uint32_t *u32_h[2] = { nullptr, nullptr }, *u32_v[2] = { nullptr, nullptr };
     const uint32_t *d32_h[2] = { nullptr, nullptr }, *d32_v[2] = { nullptr, nullptr };
     const uint32_t *dn2_h[2] = { nullptr, nullptr }, *dn2_v[2] = { nullptr, nullptr };
     /* MFMA-horizontal variant (k_sws_mfma): tile records + window-start index tables on the device */
@@ -534,6 +537,32 @@ static void d32_build(FFHipSwsContext *c, const int nsrc[4])
     c->d32_ok = 1;
 }
 
+/* exact 3:2 up above 8 bits: the banks (up to 4 taps) as virtual banks on the windows 2 (x / 3) - 2 + x % 3 .. + 3 of the edge-replicated rows, on
+ * the device; sets c->u32_ok when every bank row is of that shape (sws_up32.hip) */
+static void u32_build(FFHipSwsContext *c, const int nsrc[4])
+{
+    std::vector<uint32_t> vb[4];
+    for (int i = 0; i < 4; i++)
+        if (!ffhip_u32_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], &vb[i]))
+            return;
+    size_t uo[4], ut = 0;
+    for (int i = 0; i < 4; i++) {
+        uo[i] = ut;
+        ut += (vb[i].size() * 4 + 255) & ~(size_t)255;
+    }
+    if (hipMalloc(&c->u32_dev, ut) != hipSuccess)
+        return;
+    uint8_t *b = static_cast<uint8_t *>(c->u32_dev);
+    for (int i = 0; i < 4; i++)
+        if (hipMemcpy(b + uo[i], vb[i].data(), vb[i].size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return;
+    c->u32_h[0] = reinterpret_cast<const uint32_t *>(b + uo[0]);
+    c->u32_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
+    c->u32_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
+    c->u32_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
+    c->u32_ok = 1;
+}
+
 /* the luma banks alone at exact 2:1, for a packed-RGB target's first stage (its chroma goes 2:1 across but 1:1 or 2:1 down by the
  * source's subsampling, and rides the wide-bank walker): sets c->dn2_luma */
 static void dn2_build_luma(FFHipSwsContext *c, int srcW, int srcH)
@@ -763,6 +792,20 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 !(t->dstW & 3) && t->dstW >= 12 && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
                 dn2_build(c, limits);
+            /* exact 3:2 up (720p -> 1080p ...) between formats of 9..14 bits laid out alike, or from an 8-bit source widened to words as for the
+             * walker below (planar into planar, NV12 into P01x): sws_up32.hip; the walker is set up beside it for planes it cannot take */
+            {
+                const bool w8u = sd == 8 && dd > 8 && dd <= 14 && !c->flat_dither && t->srcFormat != FFHIP_PIX_FMT_NV21 &&
+                                 (fmt_nv(t->srcFormat) ? dl == 1 : dl == 0);
+                if (((sd > 8 && sd <= 14 && sl == dl && sl != 2) || w8u) && dd > 8 && dd <= 14 && !hrgb && !c->flat_dither && t->src_range == t->dst_range &&
+                    2 * t->dstW == 3 * t->srcW && 2 * t->dstH == 3 * t->srcH && 2 * c->d[1].n == 3 * cw && 2 * c->d[3].n == 3 * chh &&
+                    !(t->srcW & 3) && t->srcW >= 12 && !(t->srcH & 1) && !(chh & 1) &&
+                    ((sl || fmt_nv(t->srcFormat)) ? !(cw & 1) && cw >= 6 : !(cw & 3) && cw >= 12) &&
+                    bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
+                    u32_build(c, limits);
+                if (c->u32_ok && w8u)
+                    c->widen8 = 1;
+            }
             /* every other ratio between 9..14-bit formats whose banks have at most 8 taps: the 16-bit column walker (sws_walk16.hip);
              * no range change (it carries no range stage), no 8-bit side */
             /* (round 5: also an 8-bit planar / NV12 target fed from a 9..14-bit source — a 10-bit decoder's frames for an 8-bit consumer:
@@ -1222,7 +1265,7 @@ extern "C" int ffhip_sws_set_yuv2rgb(FFHipSwsContext *c, const FFHipSwsTables *t
 
 extern "C" int ffhip_sws_fast_path(const FFHipSwsContext *c)
 {
-    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) + (c->mix_dn2 ? 1024 : 0) + (c->mix_up2 ? 2048 : 0) + (c->d32_ok ? 4096 : 0) : 0;
+    return c ? (c->cw_ok || c->cw_rgb) + (c->mf_ok ? 2 : 0) + (c->lw_ok ? 4 : 0) + (c->up2_ok ? 8 : 0) + (c->dn2_ok ? 16 : 0) + (c->w16_ok ? 32 : 0) + (c->u2r_ok ? 64 : 0) + (c->eqr_ok ? 128 : 0) + (c->f444_ok ? 256 : 0) + (c->c420_ok ? 512 : 0) + (c->mix_dn2 ? 1024 : 0) + (c->mix_up2 ? 2048 : 0) + (c->d32_ok ? 4096 : 0) + (c->u32_ok ? 8192 : 0) : 0;
 }
 
 extern "C" int ffhip_sws_tuned_numbering(const FFHipSwsContext *c)
@@ -1331,6 +1374,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->dn2_dev);
     if (c->d32_dev)
         (void)hipFree(c->d32_dev);
+    if (c->u32_dev)
+        (void)hipFree(c->u32_dev);
     if (c->dev_ntables)
         (void)hipFree(c->dev_ntables);
     if (c->dev_wtables)
@@ -1363,7 +1408,7 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
     size_t wsf[4] = { srcFramePitch[0], srcFramePitch[1], srcFramePitch[2], 0 };
     std::unique_lock<std::mutex> wlk;
     bool widened = false;
-    if (c->widen8 && (c->w16_ok || c->up2_ok)) {
+    if (c->widen8 && (c->w16_ok || c->up2_ok || c->u32_ok)) {
         bool ok = true;
         for (int pl = 0; ok && pl < (dl ? 2 : 3); pl++)
             ok = dstStride[pl] > 0 && !(((uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl]) & 3);
@@ -1510,6 +1555,31 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
         if (hrgb && !(c->w16_ok && !(al & 3) && !neg)) {
             ffhip_set_error("ffhip_sws: above 8 bits into packed RGB needs 4-byte aligned planes and pitches, top-down");
             return FFHIP_EINVAL;
+        }
+        const char *eu3 = FFHIP_KNOB("FFHIP_SWS_UP32");
+        if (c->u32_ok && !hrgb && (widened || !c->widen8) && !(al & 3) && !neg && !(eu3 && eu3[0] == '0')) {
+            /* exact 3:2 up above 8 bits: the static-schedule kernel (FFHIP_SWS_UP32=0: the walker) */
+            FFHipU32Args U;
+            memset(&U, 0, sizeof(U));
+            U.nframes = nframes;
+            U.sdepth = sd; U.ddepth = dd; U.smsb = sl == 1 && !widened; U.dmsb = dl == 1;
+            auto u3job = [&](int which, int plane, int dw_, int sh_, int pair) {
+                FFHipU32Job &j = U.job[U.njobs++];
+                j.src = static_cast<const uint8_t *>(wsrc[plane]); j.dst = static_cast<uint8_t *>(dst[plane]);
+                j.sstride = wss[plane]; j.dstride = dstStride[plane]; j.sfp = wsf[plane]; j.dfp = dstFramePitch[plane];
+                j.pair = pair;
+                j.srcH = sh_; j.dstH = sh_ / 2 * 3;
+                j.ngroups = pair ? dw_ / 3 : dw_ / 6;
+                j.hfv = c->u32_h[which]; j.vfv = c->u32_v[which];
+            };
+            u3job(0, 0, c->d[0].n, t.srcH, 0);
+            if (sl) {
+                u3job(1, 1, c->d[1].n, c->chrSrcH, 1);
+            } else {
+                u3job(1, 1, c->d[1].n, c->chrSrcH, 0);
+                u3job(1, 2, c->d[1].n, c->chrSrcH, 0);
+            }
+            return ffhip_launch_up32(U, stream);
         }
         if (c->w16_ok && (widened || !c->widen8) && !(al & 3) && !neg && (hrgb || !(ew && ew[0] == '0'))) {
             /* a packed-RGB target (round 6): the walker writes the first stage — an int16 luma plane of unclipped sums, 8-bit chroma planes of

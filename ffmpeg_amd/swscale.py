@@ -133,7 +133,7 @@ class SwsContext:
         """the bit set of ffhip_sws_fast_path: 1 column walker, 2 mfma, 4 wide walker, 8 exact 2x, 16 exact 2:1, 32 16-bit walker,
         64 exact 2x of 4:2:0 into packed RGB, 128 the same sources at their own size, 256 planar 4:4:4 into packed RGB at its own size,
         512 4:2:0 between planar and semi-planar layouts at the same size, 1024 / 2048 yuv444p -> yuv420p / yuv420p -> yuv444p at the same size
-        (the luma copied, the chroma planes on the exact-2:1 / exact-2x kernel), 4096 exact 3:2 down"""
+        (the luma copied, the chroma planes on the exact-2:1 / exact-2x kernel), 4096 exact 3:2 down, 8192 exact 3:2 up above 8 bits"""
         return int(_lib.lib().ffhip_sws_fast_path(self._c))
 
     @property

@@ -309,7 +309,7 @@ void             ffhip_sws_freeContext(FFHipSwsContext *c);
  *  (sws_eqrgb.hip); bit 8: planar 4:4:4 into packed RGB at the source's size, the full-chroma writer on one-tap banks (sws_full444.hip); bit 9: 4:2:0
  *  between its planar and semi-planar layouts at the same size (sws_copy420.hip); bits 10 / 11: yuv444p -> yuv420p / yuv420p -> yuv444p at
  *  the same size: the luma plane copied, the chroma planes on the exact-2:1 / exact-2x static-schedule kernels; bit 12: an exact 3:2
- *  down-scale (sws_down32.hip).
+ *  down-scale (sws_down32.hip); bit 13: an exact 3:2 up-scale above 8 bits (sws_up32.hip).
  *  Diagnostic only: results are identical. */
 int              ffhip_sws_fast_path(const FFHipSwsContext *c);
 /** Diagnostic: the workgroup numbering the context's launch tuner settled on for large launches of the table converter

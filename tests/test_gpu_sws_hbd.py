@@ -191,6 +191,53 @@ def test_deeper_source_into_8_bits(case, variant, monkeypatch):
 
 
 # banks of 9..16 taps on the 16-bit column walker (round 5): ratios between 1/2 and 1/4 — a 4K HDR frame into 720p
+# exact 3:2 up between formats of 9..14 bits laid out alike (720p -> 1080p): the static-schedule kernel of sws_up32.hip (fast_path bit 13);
+# "walker" runs the same cases on k_sws_walk16 (FFHIP_SWS_UP32=0, the measure build)
+UP32_CASES = [
+    ("yuv420p10le", 24, 36, "yuv420p10le", 36, 54, ffi.SWS_BICUBIC),        # three groups per chroma row, the least the kernel takes
+    ("yuv420p10le", 96, 40, "yuv420p10le", 144, 60, ffi.SWS_BILINEAR),
+    ("p010le", 96, 40, "p010le", 144, 60, ffi.SWS_BICUBIC),                  # (u, v) columns: the pair path, samples in the high bits
+    ("p012le", 48, 36, "p012le", 72, 54, ffi.SWS_POINT),
+    ("yuv420p10le", 520, 124, "yuv420p10le", 780, 186, ffi.SWS_BICUBIC),    # 130 groups per luma row: two full blocks of lanes and a ragged one
+    ("p010le", 520, 52, "p010le", 780, 78, ffi.SWS_BICUBIC),
+    ("yuv422p10le", 96, 36, "yuv422p10le", 144, 54, ffi.SWS_BICUBIC),
+    ("yuv444p10le", 48, 36, "yuv444p10le", 72, 54, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 96, 36, "yuv420p12le", 144, 54, ffi.SWS_BICUBIC),        # depths differ
+    ("yuv420p14le", 96, 36, "yuv420p9le", 144, 54, ffi.SWS_BICUBIC),
+    ("yuv420p12le", 96, 36, "yuv420p12le", 144, 54, ffi.SWS_AREA),
+    ("yuv420p10le", 96, 300, "yuv420p10le", 144, 450, ffi.SWS_BICUBIC),      # several strips of rows
+    # 8-bit sources on planes widened to words: planar into planar, NV12 into P01x
+    ("yuv420p", 96, 40, "yuv420p10le", 144, 60, ffi.SWS_BICUBIC),
+    ("nv12", 96, 40, "p010le", 144, 60, ffi.SWS_BICUBIC),
+]
+
+
+@pytest.mark.parametrize("variant", ["product", "walker"])
+@pytest.mark.parametrize("case", UP32_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_exact_3to2_up_above_8_bits(case, variant, monkeypatch):
+    from ffmpeg_amd import swscale as S
+    if variant == "walker":
+        monkeypatch.setenv("FFHIP_SWS_UP32", "0")
+    else:
+        _torch()
+        ctx = S.SwsContext(case[1], case[2], FMT[case[0]][0], case[4], case[5], FMT[case[3]][0], case[6])
+        assert ctx.paths & 8192, "the exact-3:2 up-scaler should serve this context"
+        ctx.close()
+    _run(case, nframes=5)
+
+
+def test_3to2_up_shapes_the_static_kernel_leaves_to_the_walker():
+    """widths that are not whole groups, odd heights, a range change: the context is built, on the walker"""
+    from ffmpeg_amd import swscale as S
+    _torch()
+    for case in (("yuv420p10le", 44, 36, "yuv420p10le", 66, 54, ffi.SWS_BICUBIC), ("p010le", 90, 40, "p010le", 135, 60, ffi.SWS_BICUBIC),
+                 ("yuv420p10le", 96, 42, "yuv420p10le", 144, 63, ffi.SWS_BICUBIC)):
+        ctx = S.SwsContext(case[1], case[2], FMT[case[0]][0], case[4], case[5], FMT[case[3]][0], case[6])
+        assert not ctx.paths & 8192
+        ctx.close()
+        _run(case, nframes=2)
+
+
 WIDEN8_CASES = [
     ("yuv420p", 384, 216, "yuv420p10le", 576, 324, ffi.SWS_BICUBIC),   # 1.5x up: the walker on widened planes
     ("nv12", 384, 216, "p010le", 256, 144, ffi.SWS_BICUBIC),           # interleaved in and out
