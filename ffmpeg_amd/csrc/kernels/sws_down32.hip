@@ -17,8 +17,8 @@
  *    filtered samples for EVERY q (an even output row starts on 3m - 2, an odd one on 3m - 1) sit in a ring of six in registers; after
  *    source row r = 0 or 1 (mod 3) an output row is due and reads P(r - 5), P(r - 3), P(r - 1).  Six source rows per loop trip make
  *    every ring index a constant.  The rows' coefficient pairs are wave-uniform (scalar loads).
- * All arithmetic through compiler builtins (the compiler schedules around the DOT hazard); 8 bytes out per lane and row.
- * (Hand-scheduled DOT blocks as in sws_down2.hip were 4 % faster and are not in: the round's GPU budget ended before they were exact.)
+ * Round 6: the dots in hand-scheduled blocks (VOP3P form, no v_mov per chain) and every row straight-line, the strip's bounds on the store
+ * alone (see the loop); 8 bytes out per lane and row.
  */
 #include "common.h"
 #include "sws_kernels.h"
@@ -55,6 +55,76 @@ __device__ __forceinline__ uint32_t d3_pair(const uint32_t (&w)[5])
     constexpr int i = Q >> 2, r = Q & 3;
     constexpr uint32_t sel = 0x0c000c00u | (uint32_t)(r + STEP) << 16 | (uint32_t)r;
     return __builtin_amdgcn_perm(w[i + 1 > 4 ? 4 : i + 1], w[i], sel);
+}
+
+
+/*
+ * Hand-scheduled dot products (round 6, as in sws_up32.hip): the builtin becomes the accumulate-in-place v_dot2c_i32_i16 plus a v_mov per chain;
+ * the VOP3P form takes the seed as a third source.  gfx950: a DOT result may feed the same opcode as src2 at once, any other VALU only
+ * after 3 wait states — four (eight) chains are interleaved and every result is first read three instructions after its last DOT.
+ */
+/* four horizontal samples: d[i] = (p[i][0] . c[i][0] + p[i][1] . c[i][1] + p[i][2] . c[i][2]) >> 7 */
+__device__ __forceinline__ void d3_h4(int &d0, int &d1, int &d2, int &d3, const uint32_t (&p)[4][3], const uint32_t (&c)[4][3])
+{
+    asm("v_dot2_i32_i16 %0, %4, %16, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %17, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %18, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %19, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %20, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %21, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %22, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %23, %3\n\t"
+        "v_dot2_i32_i16 %0, %12, %24, %0\n\t"
+        "v_dot2_i32_i16 %1, %13, %25, %1\n\t"
+        "v_dot2_i32_i16 %2, %14, %26, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %27, %3\n\t"
+        "v_ashrrev_i32 %0, 7, %0\n\t"
+        "v_ashrrev_i32 %1, 7, %1\n\t"
+        "v_ashrrev_i32 %2, 7, %2\n\t"
+        "v_ashrrev_i32 %3, 7, %3"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+        : "v"(p[0][0]), "v"(p[1][0]), "v"(p[2][0]), "v"(p[3][0]), "v"(p[0][1]), "v"(p[1][1]), "v"(p[2][1]), "v"(p[3][1]), "v"(p[0][2]), "v"(p[1][2]),
+          "v"(p[2][2]), "v"(p[3][2]), "v"(c[0][0]), "v"(c[1][0]), "v"(c[2][0]), "v"(c[3][0]), "v"(c[0][1]), "v"(c[1][1]), "v"(c[2][1]), "v"(c[3][1]),
+          "v"(c[0][2]), "v"(c[1][2]), "v"(c[2][2]), "v"(c[3][2]));
+}
+/* one output row of 8 samples: t[i] = seed + pa[i] . c0 + pb[i] . c1 + pc[i] . c2, bytes clip_u8(t[i] >> 19) packed in sample order */
+__device__ __forceinline__ void d3_v8(uint32_t &w0, uint32_t &w1, const uint32_t (&pa)[8], const uint32_t (&pb)[8], const uint32_t (&pc)[8], uint32_t c0,
+                                      uint32_t c1, uint32_t c2, int seed)
+{
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_dot2_i32_i16 %2, %10, %34, %37\n\t"
+        "v_dot2_i32_i16 %3, %11, %34, %37\n\t"
+        "v_dot2_i32_i16 %4, %12, %34, %37\n\t"
+        "v_dot2_i32_i16 %5, %13, %34, %37\n\t"
+        "v_dot2_i32_i16 %6, %14, %34, %37\n\t"
+        "v_dot2_i32_i16 %7, %15, %34, %37\n\t"
+        "v_dot2_i32_i16 %8, %16, %34, %37\n\t"
+        "v_dot2_i32_i16 %9, %17, %34, %37\n\t"
+        "v_dot2_i32_i16 %2, %18, %35, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %35, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %35, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %35, %5\n\t"
+        "v_dot2_i32_i16 %6, %22, %35, %6\n\t"
+        "v_dot2_i32_i16 %7, %23, %35, %7\n\t"
+        "v_dot2_i32_i16 %8, %24, %35, %8\n\t"
+        "v_dot2_i32_i16 %9, %25, %35, %9\n\t"
+        "v_dot2_i32_i16 %2, %26, %36, %2\n\t"
+        "v_dot2_i32_i16 %3, %27, %36, %3\n\t"
+        "v_dot2_i32_i16 %4, %28, %36, %4\n\t"
+        "v_dot2_i32_i16 %5, %29, %36, %5\n\t"
+        "v_dot2_i32_i16 %6, %30, %36, %6\n\t"
+        "v_dot2_i32_i16 %7, %31, %36, %7\n\t"
+        "v_dot2_i32_i16 %8, %32, %36, %8\n\t"
+        "v_dot2_i32_i16 %9, %33, %36, %9\n\t"
+        "v_ashr_pk_u8_i32 %0, %2, %3, 19\n\t"
+        "v_ashr_pk_u8_i32 %1, %6, %7, 19\n\t"
+        "v_ashr_pk_u8_i32 %0, %4, %5, 19 op_sel:[0,0,0,1]\n\t"
+        "v_ashr_pk_u8_i32 %1, %8, %9, 19 op_sel:[0,0,0,1]"
+        : "=&v"(w0), "=&v"(w1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7]),
+          "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]), "v"(pb[6]), "v"(pb[7]),
+          "v"(pc[0]), "v"(pc[1]), "v"(pc[2]), "v"(pc[3]), "v"(pc[4]), "v"(pc[5]), "v"(pc[6]), "v"(pc[7]),
+          "s"(c0), "s"(c1), "s"(c2), "v"(seed));
 }
 
 template <int PAIR>
@@ -110,21 +180,27 @@ __device__ __forceinline__ void d32_unit(const FFHipD32Job &J, int frame, int gb
         /* window start of output j, in bytes from the loaded base (= sample 12g - 4, column 6g - 2):
          *   plane: j -> 2 + 3 (j >> 1) + (j & 1);   pair: sample e = 2 col + ch -> 2 (3 (col >> 1) + (col & 1)) + ch
          * (the windows overlap: the compiler folds the 24 pairs into the 15 / 18 distinct ones) */
-#define D3_OUT(j)                                                                                                                        \
+#define D3_S(j) (PAIR ? 2 * (3 * (((j) >> 1) >> 1) + (((j) >> 1) & 1)) + ((j) & 1) : 2 + 3 * ((j) >> 1) + ((j) & 1))
+#define D3_P(j, k) d3_pair<D3_S(j) + 2 * (k) * (PAIR ? 2 : 1), (PAIR ? 2 : 1)>(w)
+#define D3_Q(j0)                                                                                                                         \
         {                                                                                                                                \
-            constexpr int S = PAIR ? 2 * (3 * (((j) >> 1) >> 1) + (((j) >> 1) & 1)) + ((j) & 1) : 2 + 3 * ((j) >> 1) + ((j) & 1);       \
-            constexpr int ST = PAIR ? 2 : 1; /* the next sample of the same channel */                                                  \
-            int acc = d3_dot(d3_pair<S, ST>(w), cf[j][0], 0);                                                                            \
-            acc = d3_dot(d3_pair<S + 2 * ST, ST>(w), cf[j][1], acc);                                                                     \
-            acc = d3_dot(d3_pair<S + 4 * ST, ST>(w), cf[j][2], acc);                                                                     \
-            h[j] = acc >> 7;                                                                                                             \
+            const uint32_t p[4][3] = { { D3_P(j0, 0), D3_P(j0, 1), D3_P(j0, 2) }, { D3_P(j0 + 1, 0), D3_P(j0 + 1, 1), D3_P(j0 + 1, 2) },  \
+                                       { D3_P(j0 + 2, 0), D3_P(j0 + 2, 1), D3_P(j0 + 2, 2) }, { D3_P(j0 + 3, 0), D3_P(j0 + 3, 1), D3_P(j0 + 3, 2) } }; \
+            const uint32_t c[4][3] = { { cf[j0][0], cf[j0][1], cf[j0][2] }, { cf[j0 + 1][0], cf[j0 + 1][1], cf[j0 + 1][2] },             \
+                                       { cf[j0 + 2][0], cf[j0 + 2][1], cf[j0 + 2][2] }, { cf[j0 + 3][0], cf[j0 + 3][1], cf[j0 + 3][2] } }; \
+            d3_h4(h[j0], h[j0 + 1], h[j0 + 2], h[j0 + 3], p, c);                                                                         \
         }
-        D3_OUT(0) D3_OUT(1) D3_OUT(2) D3_OUT(3) D3_OUT(4) D3_OUT(5) D3_OUT(6) D3_OUT(7)
-#undef D3_OUT
+        D3_Q(0) D3_Q(4)
+#undef D3_Q
+#undef D3_P
+#undef D3_S
     };
 
-    /* source rows in trips of six from rbase = 3 (a / 2) - 6 (a multiple of 6): the first trip only fills the ring */
-    const int rbase0 = 3 * (a >> 1) - 6;
+    /* source rows in trips of six from rbase = 3 (a / 2) - 6 (a multiple of 6); rows rbase + 4, + 5 only fill the ring.  Straight-line code
+     * (round 6): every due row is computed, the store alone looks at the strip's bounds — branches around the arithmetic made the compiler
+     * copy the rows in flight at every join, and wait for them — and the walk ends at uniform exits after the row the strip's last output
+     * ends on */
+    const int rbase0 = 3 * (a >> 1) - 6, r_last = 3 * (b >> 1) + 1, dstH = J.dstH;
     uint32_t ring[6][8];
     int hprev[8];
 #pragma unroll
@@ -138,53 +214,51 @@ __device__ __forceinline__ void d32_unit(const FFHipD32Job &J, int frame, int gb
     uint32_t nxt[2][5];
     load_row(rbase0 + 4, nxt[0]);
     load_row(rbase0 + 5, nxt[1]);
-    const uint32_t *vt = J.vfv;
+    typedef const uint32_t __attribute__((address_space(4))) *d3_cc; /* constant address space: scalar loads */
+    const d3_cc vt = (d3_cc)J.vfv;
     const uint32_t doff = 8u * (uint32_t)g;
 
-    for (int rbase = rbase0; ; rbase += 6) {
-        const bool first = rbase == rbase0; /* uniform */
-#pragma unroll
-        for (int u = 0; u < 6; u++) {
-            if (first && u < 4) /* (rows before 3 (a / 2) - 2 feed no output of this strip) */
-                continue;
-            const int r = rbase + u;
-            uint32_t cur[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++)
-                cur[i] = nxt[u & 1][i];
-            load_row(r + 2, nxt[u & 1]);
-            int h[8];
-            hpass(cur, h);
-            /* P(r - 1) = (row r - 1, row r): int16-saturated = min(., 32767) + truncation (no sum of an admitted bank falls below -32768) */
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                ring[(u + 5) % 6][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));
-                hprev[c] = h[c];
-            }
-            if (u % 3 != 2) {
-                /* r = 3 (m + 1): output row 2m;  r = 3m + 4: output row 2m + 1 */
-                const int y = u % 3 == 0 ? 2 * (r / 3) - 2 : 2 * ((r - 1) / 3) - 1;
-                if (y >= b)
-                    return;
-                if (y >= a) { /* uniform */
-                    const uint32_t c0 = vt[4 * y], c1 = vt[4 * y + 1], c2 = vt[4 * y + 2];
-                    int t[8];
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        int acc = d3_dot(ring[(u + 1) % 6][c], c0, 64 << 12);
-                        acc = d3_dot(ring[(u + 3) % 6][c], c1, acc);
-                        acc = d3_dot(ring[(u + 5) % 6][c], c2, acc);
-                        t[c] = acc >> 19;
-                    }
-                    d3_u2 o;
-                    o.x = d3_pk4(t[0], t[1], t[2], t[3]);
-                    o.y = d3_pk4(t[4], t[5], t[6], t[7]);
-                    if (act)
-                        *(d3_g2)((d3_gp)(dbase + (ptrdiff_t)y * dstride) + doff) = o;
-                }
-            }
-        }
+    /* row r = rbase + u: P(r - 1) = (row r - 1, row r), int16-saturated = min(., 32767) + truncation (no sum of an admitted bank falls below
+     * -32768); then r = 3 (m + 1): output row 2m, r = 3m + 4: output row 2m + 1, on P(r - 5), P(r - 3), P(r - 1) */
+#define D3_STEP(u, EMIT)                                                                                                                 \
+    {                                                                                                                                    \
+        const int r = rbase + (u);                                                                                                       \
+        uint32_t cur[5];                                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 5; i++) cur[i] = nxt[(u) & 1][i];                                                         \
+        load_row(r + 2, nxt[(u) & 1]);                                                                                                   \
+        int h[8];                                                                                                                        \
+        hpass(cur, h);                                                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < 8; c++) {                                                                                 \
+            ring[((u) + 5) % 6][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));                         \
+            hprev[c] = h[c];                                                                                                             \
+        }                                                                                                                                \
+        if (EMIT && (u) % 3 != 2) {                                                                                                      \
+            const int y = (u) % 3 == 0 ? 2 * (r / 3) - 2 : 2 * ((r - 1) / 3) - 1;                                                        \
+            const int yc = min(max(y, 0), dstH - 1);                                                                                     \
+            uint32_t o0, o1;                                                                                                             \
+            d3_v8(o0, o1, ring[((u) + 1) % 6], ring[((u) + 3) % 6], ring[((u) + 5) % 6], vt[4 * yc], vt[4 * yc + 1], vt[4 * yc + 2], 64 << 12); \
+            if (act && y >= a && y < b)                                                                                                  \
+                *(d3_g2)((d3_gp)(dbase + (ptrdiff_t)y * dstride) + doff) = (d3_u2){ o0, o1 };                                            \
+        }                                                                                                                                \
     }
+    {
+        const int rbase = rbase0;
+        D3_STEP(4, false)
+        D3_STEP(5, false)
+    }
+    for (int rbase = rbase0 + 6; ; rbase += 6) {
+        D3_STEP(0, true)
+        D3_STEP(1, true)
+        if (rbase + 2 > r_last)
+            return;
+        D3_STEP(2, true)
+        D3_STEP(3, true)
+        D3_STEP(4, true)
+        if (rbase + 5 > r_last)
+            return;
+        D3_STEP(5, true)
+    }
+#undef D3_STEP
 }
 
 __global__ __launch_bounds__(256) void k_sws_down32(FFHipD32Args A)
