@@ -211,9 +211,10 @@ __device__ __forceinline__ void d32_unit(const FFHipD32Job &J, int frame, int gb
 #pragma unroll
         for (int c = 0; c < 8; c++)
             ring[s][c] = 0;
-    uint32_t nxt[2][5];
-    load_row(rbase0 + 4, nxt[0]);
-    load_row(rbase0 + 5, nxt[1]);
+    uint32_t nxt[3][5]; /* three source rows in flight */
+    load_row(rbase0 + 4, nxt[1]);
+    load_row(rbase0 + 5, nxt[2]);
+    load_row(rbase0 + 6, nxt[0]);
     typedef const uint32_t __attribute__((address_space(4))) *d3_cc; /* constant address space: scalar loads */
     const d3_cc vt = (d3_cc)J.vfv;
     const uint32_t doff = 8u * (uint32_t)g;
@@ -224,8 +225,8 @@ __device__ __forceinline__ void d32_unit(const FFHipD32Job &J, int frame, int gb
     {                                                                                                                                    \
         const int r = rbase + (u);                                                                                                       \
         uint32_t cur[5];                                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 5; i++) cur[i] = nxt[(u) & 1][i];                                                         \
-        load_row(r + 2, nxt[(u) & 1]);                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 5; i++) cur[i] = nxt[(u) % 3][i];                                                         \
+        load_row(r + 3, nxt[(u) % 3]);                                                                                                   \
         int h[8];                                                                                                                        \
         hpass(cur, h);                                                                                                                   \
         _Pragma("unroll") for (int c = 0; c < 8; c++) {                                                                                 \
@@ -280,6 +281,251 @@ __global__ __launch_bounds__(256) void k_sws_down32(FFHipD32Args A)
         d32_unit<1>(J, frame, cb * 64, strip, lane);
     else
         d32_unit<0>(J, frame, cb * 64, strip, lane);
+}
+
+
+/* ================================================================================================== */
+/*
+ * The 16-bit twin (round 6): exact 3:2 down-scaling of 9..14-bit samples — planes of words and interleaved (u, v) planes of words (P01x) in
+ * and out, hScale16To15_c / yuv2planeX_10_c / yuv2p01xlX as in sws_walk16.hip / sws_up32.hip.  A lane owns 4 outputs = 2 periods: a plane's
+ * 10 source samples are the 5 dwords at 12g - 4 (the pairs of the windows that start on an even sample are its dwords, the others one
+ * v_alignbit away), a pair's 7 (u, v) columns the 7 dwords at 12g - 8 (the channels' pairs split with v_perm_b32); 8 bytes out per lane
+ * and row.  Same schedule as above: P(q) for every q in a ring of six, outputs after rows 0 and 1 (mod 3).
+ */
+typedef unsigned short d3_h2 __attribute__((ext_vector_type(2)));
+typedef const d3_u2a __attribute__((address_space(1))) *d3_gc2;
+/* four horizontal samples, 16-bit sources: d[i] = (p[i][0] . c[i][0] + p[i][1] . c[i][1] + p[i][2] . c[i][2]) >> sh */
+__device__ __forceinline__ void d3_h4s(int &d0, int &d1, int &d2, int &d3, const uint32_t (&p)[4][3], const uint32_t (&c)[4][3], int sh)
+{
+    asm("v_dot2_i32_i16 %0, %4, %16, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %17, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %18, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %19, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %20, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %21, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %22, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %23, %3\n\t"
+        "v_dot2_i32_i16 %0, %12, %24, %0\n\t"
+        "v_dot2_i32_i16 %1, %13, %25, %1\n\t"
+        "v_dot2_i32_i16 %2, %14, %26, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %27, %3\n\t"
+        "v_ashrrev_i32 %0, %28, %0\n\t"
+        "v_ashrrev_i32 %1, %28, %1\n\t"
+        "v_ashrrev_i32 %2, %28, %2\n\t"
+        "v_ashrrev_i32 %3, %28, %3"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+        : "v"(p[0][0]), "v"(p[1][0]), "v"(p[2][0]), "v"(p[3][0]), "v"(p[0][1]), "v"(p[1][1]), "v"(p[2][1]), "v"(p[3][1]), "v"(p[0][2]), "v"(p[1][2]),
+          "v"(p[2][2]), "v"(p[3][2]), "v"(c[0][0]), "v"(c[1][0]), "v"(c[2][0]), "v"(c[3][0]), "v"(c[0][1]), "v"(c[1][1]), "v"(c[2][1]), "v"(c[3][1]),
+          "v"(c[0][2]), "v"(c[1][2]), "v"(c[2][2]), "v"(c[3][2]), "s"(sh));
+}
+/* four output samples as two dwords: t[i] = seed + pa[i] . c0 + pb[i] . c1 + pc[i] . c2, >> sh, clipped to 0 .. 2^depth - 1, << msb */
+__device__ __forceinline__ void d3_v4h(uint32_t &w0, uint32_t &w1, const uint32_t (&pa)[4], const uint32_t (&pb)[4], const uint32_t (&pc)[4], uint32_t c0,
+                                       uint32_t c1, uint32_t c2, int seed, int sh, uint32_t maxpk, uint32_t msb)
+{
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %2, %6, %18, %21\n\t"
+        "v_dot2_i32_i16 %3, %7, %18, %21\n\t"
+        "v_dot2_i32_i16 %4, %8, %18, %21\n\t"
+        "v_dot2_i32_i16 %5, %9, %18, %21\n\t"
+        "v_dot2_i32_i16 %2, %10, %19, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %19, %4\n\t"
+        "v_dot2_i32_i16 %5, %13, %19, %5\n\t"
+        "v_dot2_i32_i16 %2, %14, %20, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %20, %3\n\t"
+        "v_dot2_i32_i16 %4, %16, %20, %4\n\t"
+        "v_dot2_i32_i16 %5, %17, %20, %5\n\t"
+        "v_ashrrev_i32 %2, %22, %2\n\t"
+        "v_ashrrev_i32 %3, %22, %3\n\t"
+        "v_ashrrev_i32 %4, %22, %4\n\t"
+        "v_ashrrev_i32 %5, %22, %5\n\t"
+        "v_cvt_pk_i16_i32 %0, %2, %3\n\t"
+        "v_cvt_pk_i16_i32 %1, %4, %5\n\t"
+        "v_pk_max_i16 %0, %0, 0\n\t"
+        "v_pk_max_i16 %1, %1, 0\n\t"
+        "v_pk_min_i16 %0, %0, %23\n\t"
+        "v_pk_min_i16 %1, %1, %23\n\t"
+        "v_pk_lshlrev_b16 %0, %24, %0\n\t"
+        "v_pk_lshlrev_b16 %1, %24, %1"
+        : "=&v"(w0), "=&v"(w1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pc[0]), "v"(pc[1]), "v"(pc[2]), "v"(pc[3]),
+          "s"(c0), "s"(c1), "s"(c2), "v"(seed), "s"(sh), "s"(maxpk), "s"(msb));
+}
+
+template <int PAIR>
+__device__ __forceinline__ void d32h_unit(const FFHipD32Args &A, const FFHipD32Job &J, int frame, int gbase, int strip, int lane)
+{
+    constexpr int NW = PAIR ? 7 : 5; /* dwords of a source row under this lane's windows */
+    const int graw = gbase + lane;
+    const bool act = graw < J.ngroups;
+    const int g = min(graw, J.ngroups - 1);
+    const bool lb = g == 0, rb = g == J.ngroups - 1;
+    const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
+    /* plane: samples 6g - 2 .. 6g + 7; pair: columns 3g - 2 .. 3g + 4.  The first / last lane of a row loads one dword (pair: two)
+     * further inside and rebuilds the replicated ones */
+    const uint32_t soff = PAIR ? (uint32_t)(lb ? 0 : 12 * g - 8 - (rb ? 8 : 0)) : (uint32_t)(lb ? 0 : 12 * g - 4 - (rb ? 4 : 0));
+    const int hsh = A.sdepth - 1, smsb = A.smsb ? 16 - A.sdepth : 0;
+    const uint32_t dmsb = (uint32_t)(A.dmsb ? 16 - A.ddepth : 0) * 0x00010001u;
+    const int vsh = 27 - A.ddepth, vseed = 1 << (26 - A.ddepth);
+    const uint32_t maxpk = (uint32_t)((1 << A.ddepth) - 1) * 0x00010001u;
+    uint32_t cf[4][3];
+    {
+        /* plane: outputs 4g .. 4g + 3; pair: columns 2g, 2g + 1, both channels of a column share its coefficients */
+        const uint32_t *p = J.hfv + (size_t)g * (PAIR ? 6 : 12);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                cf[j][k] = p[3 * (PAIR ? j >> 1 : j) + k];
+    }
+    const int a = strip * J.strip_rows, b = min(a + J.strip_rows, J.dstH);
+    const uint8_t *sbase = J.src + (size_t)frame * J.sfp;
+    uint8_t *dbase = J.dst + (size_t)frame * J.dfp;
+    const ptrdiff_t sstride = J.sstride, dstride = J.dstride;
+    const int srcH = J.srcH;
+
+    auto load_row = [&](int r, uint32_t (&w)[NW]) {
+        const uint8_t *p = sbase + (ptrdiff_t)min(max(r, 0), srcH - 1) * sstride;
+        const d3_u4 v = *(d3_gc4)((d3_gcp)p + soff);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        if (PAIR) {
+            const d3_u2 e = *(d3_gc2)((d3_gcp)p + soff + 16);
+            w[4] = e.x; w[5] = e.y;
+            w[NW - 1] = *(d3_gc1)((d3_gcp)p + soff + 24);
+        } else {
+            w[4] = *(d3_gc1)((d3_gcp)p + soff + 16);
+        }
+    };
+    auto hpass = [&](const uint32_t (&raw)[NW], int (&h)[4]) {
+        uint32_t w[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+            w[i] = raw[i];
+        if (border) {
+            if (PAIR) {
+#pragma unroll
+                for (int i = 0; i < NW; i++)
+                    w[i] = lb ? raw[i < 2 ? 0 : i - 2] : rb ? raw[i + 2 < NW ? i + 2 : NW - 1] : raw[i];
+            } else {
+                const uint32_t f0 = __builtin_amdgcn_perm(raw[0], raw[0], 0x01000100u), fl = __builtin_amdgcn_perm(raw[4], raw[4], 0x03020302u);
+#pragma unroll
+                for (int i = 0; i < NW; i++)
+                    w[i] = lb ? (i ? raw[i - 1] : f0) : rb ? (i + 1 < NW ? raw[i + 1] : fl) : raw[i];
+            }
+        }
+        if (smsb) { /* uniform: P01x keeps its samples in the high bits */
+#pragma unroll
+            for (int i = 0; i < NW; i++)
+                w[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(d3_h2, w[i]) >> (unsigned short)smsb);
+        }
+        uint32_t p[4][3];
+        if (PAIR) {
+            /* column j = 0, 1 of the lane's period reads columns j .. j + 5 from the lane's base */
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    p[2 * j][k] = __builtin_amdgcn_perm(w[j + 2 * k + 1], w[j + 2 * k], 0x05040100u);
+                    p[2 * j + 1][k] = __builtin_amdgcn_perm(w[j + 2 * k + 1], w[j + 2 * k], 0x07060302u);
+                }
+        } else {
+            /* output x = 2k + j of the lane reads samples 3k + j .. 3k + j + 5 from the lane's base: the starts 0, 1, 3, 4 */
+            uint32_t o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                o[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], 16);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                p[0][k] = w[k];
+                p[1][k] = o[k];
+                p[2][k] = o[k + 1];
+                p[3][k] = w[k + 2];
+            }
+        }
+        d3_h4s(h[0], h[1], h[2], h[3], p, cf, hsh);
+    };
+
+    const int rbase0 = 3 * (a >> 1) - 6, r_last = 3 * (b >> 1) + 1, dstH = J.dstH;
+    uint32_t ring[6][4];
+    int hprev[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        hprev[c] = 0;
+#pragma unroll
+    for (int s = 0; s < 6; s++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            ring[s][c] = 0;
+    constexpr int D = 3; /* source rows in flight */
+    uint32_t nxt[D][NW];
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        load_row(rbase0 + 4 + i, nxt[(4 + i) % D]);
+    typedef const uint32_t __attribute__((address_space(4))) *d3_cc;
+    const d3_cc vt = (d3_cc)J.vfv;
+    const uint32_t doff = 8u * (uint32_t)g;
+
+#define D3H_STEP(u, EMIT)                                                                                                                \
+    {                                                                                                                                    \
+        const int r = rbase + (u);                                                                                                       \
+        uint32_t cur[NW];                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NW; i++) cur[i] = nxt[(u) % D][i];                                                        \
+        load_row(r + D, nxt[(u) % D]);                                                                                                   \
+        int h[4];                                                                                                                        \
+        hpass(cur, h);                                                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                                                 \
+            ring[((u) + 5) % 6][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));                         \
+            hprev[c] = h[c];                                                                                                             \
+        }                                                                                                                                \
+        if (EMIT && (u) % 3 != 2) {                                                                                                      \
+            const int y = (u) % 3 == 0 ? 2 * (r / 3) - 2 : 2 * ((r - 1) / 3) - 1;                                                        \
+            const int yc = min(max(y, 0), dstH - 1);                                                                                     \
+            uint32_t o0, o1;                                                                                                             \
+            d3_v4h(o0, o1, ring[((u) + 1) % 6], ring[((u) + 3) % 6], ring[((u) + 5) % 6], vt[4 * yc], vt[4 * yc + 1], vt[4 * yc + 2], vseed, vsh, \
+                   maxpk, dmsb);                                                                                                         \
+            if (act && y >= a && y < b)                                                                                                  \
+                *(d3_g2)((d3_gp)(dbase + (ptrdiff_t)y * dstride) + doff) = (d3_u2){ o0, o1 };                                            \
+        }                                                                                                                                \
+    }
+    {
+        const int rbase = rbase0;
+        D3H_STEP(4, false)
+        D3H_STEP(5, false)
+    }
+    for (int rbase = rbase0 + 6; ; rbase += 6) {
+        D3H_STEP(0, true)
+        D3H_STEP(1, true)
+        if (rbase + 2 > r_last)
+            return;
+        D3H_STEP(2, true)
+        D3H_STEP(3, true)
+        D3H_STEP(4, true)
+        if (rbase + 5 > r_last)
+            return;
+        D3H_STEP(5, true)
+    }
+#undef D3H_STEP
+}
+
+__global__ __launch_bounds__(256) void k_sws_down32h(FFHipD32Args A)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
+    if (gw >= (uint32_t)A.units_per_frame * (uint32_t)A.nframes)
+        return;
+    const int frame = (int)(gw / (uint32_t)A.units_per_frame);
+    const int u = (int)(gw - (uint32_t)frame * (uint32_t)A.units_per_frame);
+    int j = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
+    const FFHipD32Job &J = A.job[j];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.pair)
+        d32h_unit<1>(A, J, frame, cb * 64, strip, lane);
+    else
+        d32h_unit<0>(A, J, frame, cb * 64, strip, lane);
 }
 
 /* ================================================================================================== */
@@ -344,7 +590,7 @@ int ffhip_launch_down32(FFHipD32Args &A, hipStream_t stream)
             j.ncb = cdiv(j.ngroups, 64);
             u += (long long)j.ncb * j.nstrips;
         }
-        if (u * A.nframes >= 4096 || want <= 8)
+        if (u * A.nframes >= (A.hb ? 8192 : 4096) || want <= 8)
             break;
     }
     int u = 0;
@@ -358,7 +604,10 @@ int ffhip_launch_down32(FFHipD32Args &A, hipStream_t stream)
         ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
         return FFHIP_EINVAL;
     }
-    hipLaunchKernelGGL(k_sws_down32, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    if (A.hb)
+        hipLaunchKernelGGL(k_sws_down32h, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    else
+        hipLaunchKernelGGL(k_sws_down32, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
     LAUNCH_CHECK();
     return 0;
 }

@@ -214,6 +214,9 @@ struct FFHipD32Job {
 struct FFHipD32Args {
     FFHipD32Job job[3];
     int njobs, units_per_frame, nframes;
+    /* round 6, the 16-bit twin (k_sws_down32h): samples of 9..14 bits on both sides, as FFHipUp2Job.hb_*; groups are then 8 destination bytes
+     * too — plane dstW / 4, pair dstW / 2 */
+    int hb, sdepth, ddepth, smsb, dmsb;
 };
 #ifdef __cplusplus
 int  ffhip_d32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pitch, std::vector<uint32_t> *out);

@@ -806,6 +806,12 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 if (c->u32_ok && w8u)
                     c->widen8 = 1;
             }
+            /* ... and exact 3:2 DOWN (1080p -> 720p, 4K -> 1440p) between 9..14-bit formats laid out alike: the 16-bit twin of sws_down32.hip */
+            if (sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl == dl && sl != 2 && !hrgb && !c->flat_dither && t->src_range == t->dst_range &&
+                2 * t->srcW == 3 * t->dstW && 2 * t->srcH == 3 * t->dstH && 2 * cw == 3 * cdw && 2 * chh == 3 * cdh &&
+                !(t->dstW & 3) && t->dstW >= 12 && !(t->dstH & 1) && !(cdh & 1) && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
+                bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
+                d32_build(c, limits);
             /* every other ratio between 9..14-bit formats whose banks have at most 8 taps: the 16-bit column walker (sws_walk16.hip);
              * no range change (it carries no range stage), no 8-bit side */
             /* (round 5: also an 8-bit planar / NV12 target fed from a 9..14-bit source — a 10-bit decoder's frames for an 8-bit consumer:
@@ -1555,6 +1561,31 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
         if (hrgb && !(c->w16_ok && !(al & 3) && !neg)) {
             ffhip_set_error("ffhip_sws: above 8 bits into packed RGB needs 4-byte aligned planes and pitches, top-down");
             return FFHIP_EINVAL;
+        }
+        const char *ed3 = FFHIP_KNOB("FFHIP_SWS_DOWN32");
+        if (c->d32_ok && !hrgb && !widened && !c->widen8 && !(al & 3) && !neg && !(ed3 && ed3[0] == '0')) {
+            /* exact 3:2 down above 8 bits: the static-schedule kernel's 16-bit twin (FFHIP_SWS_DOWN32=0: the walker) */
+            FFHipD32Args D;
+            memset(&D, 0, sizeof(D));
+            D.nframes = nframes;
+            D.hb = 1; D.sdepth = sd; D.ddepth = dd; D.smsb = sl == 1; D.dmsb = dl == 1;
+            auto d3job = [&](int which, int plane, int dw_, int sh_, int pair) {
+                FFHipD32Job &j = D.job[D.njobs++];
+                j.src = static_cast<const uint8_t *>(src[plane]); j.dst = static_cast<uint8_t *>(dst[plane]);
+                j.sstride = srcStride[plane]; j.dstride = dstStride[plane]; j.sfp = srcFramePitch[plane]; j.dfp = dstFramePitch[plane];
+                j.pair = pair; j.swap = 0;
+                j.srcH = sh_; j.dstH = sh_ / 3 * 2;
+                j.ngroups = pair ? dw_ / 2 : dw_ / 4;
+                j.hfv = c->d32_h[which]; j.vfv = c->d32_v[which];
+            };
+            d3job(0, 0, c->d[0].n, t.srcH, 0);
+            if (sl) {
+                d3job(1, 1, c->d[1].n, c->chrSrcH, 1);
+            } else {
+                d3job(1, 1, c->d[1].n, c->chrSrcH, 0);
+                d3job(1, 2, c->d[1].n, c->chrSrcH, 0);
+            }
+            return ffhip_launch_down32(D, stream);
         }
         const char *eu3 = FFHIP_KNOB("FFHIP_SWS_UP32");
         if (c->u32_ok && !hrgb && (widened || !c->widen8) && !(al & 3) && !neg && !(eu3 && eu3[0] == '0')) {

@@ -226,6 +226,37 @@ def test_exact_3to2_up_above_8_bits(case, variant, monkeypatch):
     _run(case, nframes=5)
 
 
+# exact 3:2 down between formats of 9..14 bits laid out alike (1080p -> 720p, 4K -> 1440p): the 16-bit twin of sws_down32.hip (fast_path bit 12)
+DOWN32H_CASES = [
+    ("yuv420p10le", 72, 54, "yuv420p10le", 48, 36, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 144, 60, "yuv420p10le", 96, 40, ffi.SWS_BILINEAR),
+    ("p010le", 144, 60, "p010le", 96, 40, ffi.SWS_BICUBIC),                  # (u, v) columns: the pair path, samples in the high bits
+    ("p012le", 72, 54, "p012le", 48, 36, ffi.SWS_POINT),
+    ("yuv420p10le", 1560, 186, "yuv420p10le", 1040, 124, ffi.SWS_BICUBIC),   # 260 groups per luma row, 130 per chroma row (a ragged block)
+    ("p010le", 780, 78, "p010le", 520, 52, ffi.SWS_BICUBIC),
+    ("yuv422p10le", 144, 54, "yuv422p10le", 96, 36, ffi.SWS_BICUBIC),
+    ("yuv444p10le", 72, 54, "yuv444p10le", 48, 36, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 144, 54, "yuv420p12le", 96, 36, ffi.SWS_BICUBIC),        # depths differ
+    ("yuv420p14le", 144, 54, "yuv420p9le", 96, 36, ffi.SWS_BICUBIC),
+    ("yuv420p12le", 144, 54, "yuv420p12le", 96, 36, ffi.SWS_AREA),
+    ("yuv420p10le", 144, 450, "yuv420p10le", 96, 300, ffi.SWS_BICUBIC),      # several strips of rows
+]
+
+
+@pytest.mark.parametrize("variant", ["product", "walker"])
+@pytest.mark.parametrize("case", DOWN32H_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_exact_3to2_down_above_8_bits(case, variant, monkeypatch):
+    from ffmpeg_amd import swscale as S
+    if variant == "walker":
+        monkeypatch.setenv("FFHIP_SWS_DOWN32", "0")
+    else:
+        _torch()
+        ctx = S.SwsContext(case[1], case[2], FMT[case[0]][0], case[4], case[5], FMT[case[3]][0], case[6])
+        assert ctx.paths & 4096, "the exact-3:2 down-scaler should serve this context"
+        ctx.close()
+    _run(case, nframes=5)
+
+
 def test_3to2_up_shapes_the_static_kernel_leaves_to_the_walker():
     """widths that are not whole groups, odd heights, a range change: the context is built, on the walker"""
     from ffmpeg_amd import swscale as S
