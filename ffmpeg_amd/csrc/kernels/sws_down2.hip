@@ -308,7 +308,10 @@ __device__ __forceinline__ void dn_v4y(uint32_t &o0, uint32_t &o1, const uint32_
 /* HB: samples above 8 bits (little-endian uint16, 9..14 bits, P01x's in the high bits).  A lane then reads 32 source bytes per row
  * (plane: the 16 samples from 8g - 4, whose seven (s[2m+1], s[2m+2]) pairs are one v_alignbyte each) or 40 (pair: the ten (u, v)
  * columns from 4g - 3, pairs by v_perm as at 8 bits) and writes 8 destination bytes per row. */
-template <int PAIR, int HB = 0>
+/* OUT 1: the instantiation that carries the rarer output stages — HB 0: a job may write the int16 luma of a packed-RGB target (J.y16); HB 1: the
+ * 8-bit target with the ordered dither.  OUT 0 is straight-line (round 6: uniform branches around a row's arithmetic made the compiler copy
+ * the rows in flight at every join, and wait for them: docs/KERNELS.md R6.8) */
+template <int PAIR, int HB = 0, int OUT = 0>
 __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gbase, int strip, int lane)
 {
     constexpr int NQ = HB ? (PAIR ? 10 : 8) : (PAIR ? 6 : 4), NCF = PAIR ? 8 : 16;
@@ -514,13 +517,14 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
         const dn_u16 c16 = *(dn_cc16)(vt + 4 * y);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (y + k < b) { /* uniform */
+            { /* every row of the trip is computed; the store alone looks at the strip's end */
+                const bool live = act && y + k < b;
                 Raw &w0 = buf[(2 * k + 2) & 3], &w1 = buf[(2 * k + 3) & 3];
                 hpair(w0, w1, ring[(k + 2) & 3]);
                 load_next(w0); load_next(w1);
                 const uint32_t c0 = c16[4 * k], c1 = c16[4 * k + 1], c2 = c16[4 * k + 2], c3 = c16[4 * k + 3];
                 uint32_t off = doff;
-                if (HB && J.hb_ddepth == 8) { /* uniform */
+                if constexpr (HB != 0 && OUT != 0) {
                     /* an 8-bit target (round 5: a 10-bit decoder's 4K frames for a 1080p 8-bit consumer): the ordered dither's entry of
                      * every sample — (x + offset) & 7 with offset 3 for the V channel / plane (yuv2nv12cX_c, vscale.c's chroma call) */
                     const uint2 drow = *reinterpret_cast<const uint2 *>(dn_dither[(y + k) & 7]);
@@ -533,36 +537,34 @@ __device__ __forceinline__ void dn2_unit(const FFHipDn2Job &J, int frame, int gb
                     const uint32_t out = dn_v4d(ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, sdv);
                     uint32_t off8 = 4u * (uint32_t)g;
                     asm volatile("" : "+v"(off8));
-                    if (act)
+                    if (live)
                         *(dn_g1)((dn_gp)dr + off8) = out;
-                } else if (HB) {
+                } else if constexpr (HB != 0) {
                     typedef unsigned short dn_h2 __attribute__((ext_vector_type(2)));
                     typedef dn_u2 __attribute__((address_space(1))) *dn_g2;
                     uint32_t o0, o1;
                     dn_v4h(o0, o1, ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround, vsh, maxpk);
-                    if (dmsb) {
-                        o0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(dn_h2, o0) << (unsigned short)dmsb);
-                        o1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(dn_h2, o1) << (unsigned short)dmsb);
-                    }
+                    o0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(dn_h2, o0) << (unsigned short)dmsb);
+                    o1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(dn_h2, o1) << (unsigned short)dmsb);
                     asm volatile("" : "+v"(off));
-                    if (act) {
+                    if (live) {
                         dn_u2 st; st.x = o0; st.y = o1;
                         *(dn_g2)((dn_gp)dr + off) = st;
                     }
-                } else if (!PAIR && J.y16) { /* uniform */
+                } else if (!PAIR && OUT && J.y16) { /* uniform */
                     typedef dn_u2 __attribute__((address_space(1))) *dn_g2y;
                     uint32_t o0, o1;
                     dn_v4y(o0, o1, ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround);
                     off *= 2; /* four int16 per lane */
                     asm volatile("" : "+v"(off));
-                    if (act) {
+                    if (live) {
                         dn_u2 st; st.x = o0; st.y = o1;
                         *(dn_g2y)((dn_gp)dr + off) = st;
                     }
                 } else {
                     const uint32_t out = dn_v4(ring[(k + 3) & 3], ring[k], ring[(k + 1) & 3], ring[(k + 2) & 3], c0, c1, c2, c3, kround);
                     asm volatile("" : "+v"(off));
-                    if (act)
+                    if (live)
                         *(dn_g1)((dn_gp)dr + off) = out;
                 }
                 dr += dstride;
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(256) void k_sws_down2_rgb(FFHipDn2RgbArgs A)
     dn2rgb_unit<LAY, PL>(A, frame, cb * 64, strip, lane, lut);
 }
 
-template <int HB>
+template <int HB, int OUT>
 __global__ __launch_bounds__(256) void k_sws_down2(FFHipDn2Args A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -906,9 +908,9 @@ __global__ __launch_bounds__(256) void k_sws_down2(FFHipDn2Args A)
     const int local = u - J.unit_begin;
     const int strip = local / J.ncb, cb = local - strip * J.ncb;
     if (J.pair)
-        dn2_unit<1, HB>(J, frame, cb * 64, strip, lane);
+        dn2_unit<1, HB, OUT>(J, frame, cb * 64, strip, lane);
     else
-        dn2_unit<0, HB>(J, frame, cb * 64, strip, lane);
+        dn2_unit<0, HB, OUT>(J, frame, cb * 64, strip, lane);
 }
 
 /* ================================================================================================== */
@@ -978,10 +980,18 @@ int ffhip_launch_down2(FFHipDn2Args &A, hipStream_t stream)
         ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
         return FFHIP_EINVAL;
     }
-    if (A.job[0].hb_sdepth)
-        hipLaunchKernelGGL(k_sws_down2<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    bool y16 = false;
+    for (int i = 0; i < A.njobs; i++)
+        y16 = y16 || A.job[i].y16;
+    if (A.job[0].hb_sdepth && A.job[0].hb_ddepth == 8)
+        hipLaunchKernelGGL((k_sws_down2<1, 1>), grid, dim3(256), 0, stream, A);
+    else if (A.job[0].hb_sdepth)
+        hipLaunchKernelGGL((k_sws_down2<1, 0>), grid, dim3(256), 0, stream, A);
+    else if (y16)
+        hipLaunchKernelGGL((k_sws_down2<0, 1>), grid, dim3(256), 0, stream, A);
     else
-        hipLaunchKernelGGL(k_sws_down2<0>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+        hipLaunchKernelGGL((k_sws_down2<0, 0>), grid, dim3(256), 0, stream, A);
     LAUNCH_CHECK();
     return 0;
 }
