@@ -487,44 +487,43 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             Raw &w = buf[(k + 3) % D];
-            if (r + k < b) { /* uniform */
-                if (HB) {
-                    hpass(w, ring[k % 3]);
-                    const up_u8 cc = c8[k >> 1];
-                    const uint32_t fb01 = k & 1 ? cc.s4 : cc.s0, fb23 = k & 1 ? cc.s5 : cc.s1;
-                    const uint32_t fa01 = k & 1 ? cc.s6 : cc.s2, fa23 = k & 1 ? cc.s7 : cc.s3;
-                    const int y = 2 * (r + k) - 3;
-                    typedef unsigned short up_h2 __attribute__((ext_vector_type(2)));
-                    uint32_t o0[4], o1[4];
-                    up_v8h(o0, ring[(k + 1) % 3], ring[k % 3], fb01, fb23, kround, vsh, maxpk);
-                    uint32_t off = doff;
-                    asm volatile("" : "+v"(off));
-                    if (dmsb) {
+            if constexpr (HB != 0) {
+                /* straight-line (round 6): every row of the trip is computed, the stores alone look at the strip's end — a uniform branch
+                 * around the row made the compiler copy the rows in flight at its join and wait for them (docs/KERNELS.md R6.8) */
+                const bool live = act && r + k < b;
+                hpass(w, ring[k % 3]);
+                const up_u8 cc = c8[k >> 1];
+                const uint32_t fb01 = k & 1 ? cc.s4 : cc.s0, fb23 = k & 1 ? cc.s5 : cc.s1;
+                const uint32_t fa01 = k & 1 ? cc.s6 : cc.s2, fa23 = k & 1 ? cc.s7 : cc.s3;
+                const int y = 2 * (r + k) - 3;
+                typedef unsigned short up_h2 __attribute__((ext_vector_type(2)));
+                uint32_t o0[4], o1[4];
+                up_v8h(o0, ring[(k + 1) % 3], ring[k % 3], fb01, fb23, kround, vsh, maxpk);
+                uint32_t off = doff;
+                asm volatile("" : "+v"(off));
 #pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            o0[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(up_h2, o0[i]) << (unsigned short)dmsb);
-                    }
-                    if (act && y >= 0) {
-                        up_u4 st; st.x = o0[0]; st.y = o0[1]; st.z = o0[2]; st.w = o0[3];
-                        if (NTS) __builtin_nontemporal_store(st, (up_g4)((up_gp)dr + off));
-                        else *(up_g4)((up_gp)dr + off) = st;
-                    }
-                    up_v8h(o1, ring[(k + 1) % 3], ring[k % 3], fa01, fa23, kround, vsh, maxpk);
-                    if (dmsb) {
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            o1[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(up_h2, o1[i]) << (unsigned short)dmsb);
-                    }
-                    if (act && y + 1 < dstH) {
-                        up_u4 st; st.x = o1[0]; st.y = o1[1]; st.z = o1[2]; st.w = o1[3];
-                        if (NTS) __builtin_nontemporal_store(st, (up_g4)((up_gp)(dr + dstride) + off));
-                        else *(up_g4)((up_gp)(dr + dstride) + off) = st;
-                    }
-                    dr += 2 * dstride;
-                    asm("" : "+s"(dr));
-                    load_next(w);
-                    continue;
+                for (int i = 0; i < 4; i++)
+                    o0[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(up_h2, o0[i]) << (unsigned short)dmsb);
+                if (live && y >= 0) {
+                    up_u4 st; st.x = o0[0]; st.y = o0[1]; st.z = o0[2]; st.w = o0[3];
+                    if (NTS) __builtin_nontemporal_store(st, (up_g4)((up_gp)dr + off));
+                    else *(up_g4)((up_gp)dr + off) = st;
                 }
+                up_v8h(o1, ring[(k + 1) % 3], ring[k % 3], fa01, fa23, kround, vsh, maxpk);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    o1[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(up_h2, o1[i]) << (unsigned short)dmsb);
+                if (live && y + 1 < dstH) {
+                    up_u4 st; st.x = o1[0]; st.y = o1[1]; st.z = o1[2]; st.w = o1[3];
+                    if (NTS) __builtin_nontemporal_store(st, (up_g4)((up_gp)(dr + dstride) + off));
+                    else *(up_g4)((up_gp)(dr + dstride) + off) = st;
+                }
+                dr += 2 * dstride;
+                asm("" : "+s"(dr));
+                load_next(w);
+                continue;
+            }
+            if (r + k < b) { /* uniform */
                 if (!DBG_COPY)
                     hpass(w, ring[k % 3]);
                 const up_u8 cc = c8[k >> 1];

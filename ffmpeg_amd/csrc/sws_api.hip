@@ -1511,7 +1511,8 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                     ffhip_up2_plan_job(&U.job[i], 64 >> U.fshift, 60);
                 {
                     const char *ed = FFHIP_KNOB("FFHIP_UP2_DEPTH"), *ev2 = FFHIP_KNOB("FFHIP_UP2_VAR"); /* measure build: rows in flight, 1 = non-temporal stores */
-                    return ffhip_launch_up2(U, ed && ed[0] == '6' ? 6 : 3, ev2 ? atoi(ev2) : 0, stream);
+                    /* six rows in flight (round 6, with the straight-line rows: p010 1080p -> 4K 0.615 -> 0.63, planar unchanged) */
+                    return ffhip_launch_up2(U, ed && ed[0] == '3' ? 3 : 6, ev2 ? atoi(ev2) : 0, stream);
                 }
             }
         }
