@@ -523,7 +523,7 @@ __device__ __forceinline__ void up2_unit(const FFHipUp2Job &J, int frame0, int f
                 load_next(w);
                 continue;
             }
-            if (r + k < b) { /* uniform */
+            if (r + k < b) { /* uniform (the straight-line form measured the same here: tools/ab_headline.py) */
                 if (!DBG_COPY)
                     hpass(w, ring[k % 3]);
                 const up_u8 cc = c8[k >> 1];
