@@ -242,9 +242,10 @@ struct FFHipU32Args {
     FFHipU32Job job[3];
     int njobs, units_per_frame, nframes;
     int sdepth, ddepth, smsb, dmsb;     /* as FFHipUp2Job.hb_* */
+    int ratio43;                        /* 0: 3:2 (period 2 in, 3 out; groups of 6 / 3 outputs); 1: 4:3 (3 in, 4 out; groups of 8 / 4: 16 destination bytes) */
 };
 #ifdef __cplusplus
-int  ffhip_u32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, std::vector<uint32_t> *out);
+int  ffhip_u32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pin, int pout, std::vector<uint32_t> *out);
 #endif
 int  ffhip_launch_up32(FFHipU32Args &A, hipStream_t stream);
 

@@ -23,6 +23,8 @@
  *    constant; the rows' coefficient pairs are wave-uniform (scalar loads).
  * Dots in hand-scheduled blocks of four chains (VOP3P form: no v_mov per chain).  Algorithmic bytes: source in + destination out, 2 bytes per sample: 2.89 B per output sample.
  */
+#include <type_traits>
+
 #include "common.h"
 #include "sws_kernels.h"
 
@@ -40,6 +42,7 @@ typedef const u3_u4a __attribute__((address_space(1))) *u3_gc4;
 typedef const u3_u2a __attribute__((address_space(1))) *u3_gc2;
 typedef u3_u4a __attribute__((address_space(1))) *u3_g4;
 typedef u3_u2a __attribute__((address_space(1))) *u3_g2;
+typedef const uint32_t __attribute__((address_space(1))) *u3_gc1;
 typedef u3_u3a __attribute__((address_space(1))) *u3_g3;
 typedef const uint32_t __attribute__((address_space(4))) *u3_cc; /* constant address space: scalar loads */
 
@@ -123,33 +126,91 @@ __device__ __forceinline__ void u3_v6(uint32_t (&w)[3], const uint32_t (&pa)[6],
           "s"(f01), "s"(f23), "v"(seed), "s"(sh), "s"(maxpk), "s"(msb));
 }
 
-template <int PAIR>
+
+/* the same blocks with four chains (eight outputs per lane = two of them): every result is shifted three instructions after its last DOT */
+__device__ __forceinline__ void u3_h4(int *d, const uint32_t *pa, const uint32_t *pb, const uint32_t (*cf)[2], int sh)
+{
+    asm("v_dot2_i32_i16 %0, %4, %12, 0\n\t"
+        "v_dot2_i32_i16 %1, %5, %13, 0\n\t"
+        "v_dot2_i32_i16 %2, %6, %14, 0\n\t"
+        "v_dot2_i32_i16 %3, %7, %15, 0\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %17, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %18, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %19, %3\n\t"
+        "v_ashrrev_i32 %0, %20, %0\n\t"
+        "v_ashrrev_i32 %1, %20, %1\n\t"
+        "v_ashrrev_i32 %2, %20, %2\n\t"
+        "v_ashrrev_i32 %3, %20, %3"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(cf[0][0]), "v"(cf[1][0]), "v"(cf[2][0]),
+          "v"(cf[3][0]), "v"(cf[0][1]), "v"(cf[1][1]), "v"(cf[2][1]), "v"(cf[3][1]), "s"(sh));
+}
+__device__ __forceinline__ void u3_v4(uint32_t *w, const uint32_t *pa, const uint32_t *pb, uint32_t f01, uint32_t f23, int seed, int sh, uint32_t maxpk,
+                                      uint32_t msb)
+{
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %2, %6, %14, %16\n\t"
+        "v_dot2_i32_i16 %3, %7, %14, %16\n\t"
+        "v_dot2_i32_i16 %4, %8, %14, %16\n\t"
+        "v_dot2_i32_i16 %5, %9, %14, %16\n\t"
+        "v_dot2_i32_i16 %2, %10, %15, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %15, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %15, %4\n\t"
+        "v_dot2_i32_i16 %5, %13, %15, %5\n\t"
+        "v_ashrrev_i32 %2, %17, %2\n\t"
+        "v_ashrrev_i32 %3, %17, %3\n\t"
+        "v_ashrrev_i32 %4, %17, %4\n\t"
+        "v_ashrrev_i32 %5, %17, %5\n\t"
+        "v_cvt_pk_i16_i32 %0, %2, %3\n\t"
+        "v_cvt_pk_i16_i32 %1, %4, %5\n\t"
+        "v_pk_max_i16 %0, %0, 0\n\t"
+        "v_pk_max_i16 %1, %1, 0\n\t"
+        "v_pk_min_i16 %0, %0, %18\n\t"
+        "v_pk_min_i16 %1, %1, %18\n\t"
+        "v_pk_lshlrev_b16 %0, %19, %0\n\t"
+        "v_pk_lshlrev_b16 %1, %19, %1"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "s"(f01), "s"(f23), "v"(seed), "s"(sh),
+          "s"(maxpk), "s"(msb));
+}
+
+/* where the window of output j of a period starts, from the period's first source sample: floor(((2j + 1) PIN - POUT) / (2 POUT)) - 1 */
+template <int PIN, int POUT>
+__host__ __device__ constexpr int u3_off(int j)
+{
+    const int n = (2 * j + 1) * PIN - POUT;
+    return (n >= 0 ? n / (2 * POUT) : -((-n + 2 * POUT - 1) / (2 * POUT))) - 1;
+}
+
+template <int PIN, int POUT, int PAIR>
 __device__ __forceinline__ void u32_unit(const FFHipU32Args &A, const FFHipU32Job &J, int frame, int gbase, int strip, int lane)
 {
-    constexpr int NW = PAIR ? 6 : 4; /* dwords of a source row under this lane's windows */
+    /* a lane owns NO = 2 POUT outputs: two periods of a plane (2 PIN source samples + 4 of halo = PIN + 2 dwords at byte 4 PIN g - 4), one
+     * period x two channels of a pair (PIN columns + 4 of halo = PIN + 4 dwords at byte 4 PIN g - 8) */
+    constexpr int NO = 2 * POUT, NW = PAIR ? PIN + 4 : PIN + 2;
     const int graw = gbase + lane;
     const bool act = graw < J.ngroups;
     const int g = min(graw, J.ngroups - 1);
     const bool lb = g == 0, rb = g == J.ngroups - 1;
     const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
-    /* plane: samples 4g - 2 .. 4g + 5; pair: columns 2g - 2 .. 2g + 3.  The first / last lane of a row loads one dword (pair: two)
-     * further inside and rebuilds the replicated ones */
-    const uint32_t soff = PAIR ? (uint32_t)(lb ? 0 : 8 * g - 8 - (rb ? 8 : 0)) : (uint32_t)(lb ? 0 : 8 * g - 4 - (rb ? 4 : 0));
+    /* the first / last lane of a row loads one dword (pair: two) further inside and rebuilds the replicated ones */
+    const uint32_t soff = PAIR ? (uint32_t)(lb ? 0 : 4 * PIN * g - 8 - (rb ? 8 : 0)) : (uint32_t)(lb ? 0 : 4 * PIN * g - 4 - (rb ? 4 : 0));
     const int hsh = A.sdepth - 1, smsb = A.smsb ? 16 - A.sdepth : 0;
     const uint32_t dmsb = (uint32_t)(A.dmsb ? 16 - A.ddepth : 0) * 0x00010001u;
     const int vsh = 27 - A.ddepth, vseed = 1 << (26 - A.ddepth);
     const uint32_t maxpk = (uint32_t)((1 << A.ddepth) - 1) * 0x00010001u;
-    uint32_t cf[6][2];
+    uint32_t cf[NO][2];
     {
-        /* plane: outputs 6g .. 6g + 5; pair: columns 3g .. 3g + 2, both channels of a column share its coefficients */
-        const uint32_t *p = J.hfv + (size_t)g * (PAIR ? 6 : 12);
+        /* plane: outputs NO g .. NO g + NO - 1; pair: columns POUT g .. + POUT - 1, both channels of a column share its coefficients */
+        const uint32_t *p = J.hfv + (size_t)g * (PAIR ? NO : 2 * NO);
 #pragma unroll
-        for (int j = 0; j < 6; j++)
+        for (int j = 0; j < NO; j++)
 #pragma unroll
             for (int k = 0; k < 2; k++)
                 cf[j][k] = p[2 * (PAIR ? j >> 1 : j) + k];
     }
-    const int a = strip * J.strip_rows, b = min(a + J.strip_rows, J.dstH); /* this strip's output rows; a is a multiple of 9 */
+    const int a = strip * J.strip_rows, b = min(a + J.strip_rows, J.dstH); /* this strip's output rows; a is a multiple of 3 POUT */
     const uint8_t *sbase = J.src + (size_t)frame * J.sfp;
     uint8_t *dbase = J.dst + (size_t)frame * J.dfp;
     const ptrdiff_t sstride = J.sstride, dstride = J.dstride;
@@ -159,13 +220,19 @@ __device__ __forceinline__ void u32_unit(const FFHipU32Args &A, const FFHipU32Jo
         const uint8_t *p = sbase + (ptrdiff_t)min(max(r, 0), srcH - 1) * sstride; /* rows above / below the plane replicate the edge row */
         const u3_u4 v = *(u3_gc4)((u3_gcp)p + soff);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        if (PAIR) {
+        if (NW == 5) {
+            w[NW - 1] = *(u3_gc1)((u3_gcp)p + soff + 16);
+        } else if (NW == 6) {
             const u3_u2 e = *(u3_gc2)((u3_gcp)p + soff + 16);
             w[NW - 2] = e.x; w[NW - 1] = e.y;
+        } else if (NW == 7) {
+            const u3_u2 e = *(u3_gc2)((u3_gcp)p + soff + 16);
+            w[4] = e.x; w[5 % NW] = e.y;
+            w[NW - 1] = *(u3_gc1)((u3_gcp)p + soff + 24);
         }
     };
-    /* the horizontal pass of one source row: this lane's 6 samples (plane: x0 .. x5; pair: u0 v0 u1 v1 u2 v2) */
-    auto hpass = [&](const uint32_t (&raw)[NW], int (&h)[6]) {
+    /* the horizontal pass of one source row: this lane's NO samples (plane: x0 .. ; pair: u0 v0 u1 v1 ..) */
+    auto hpass = [&](const uint32_t (&raw)[NW], int (&h)[NO]) {
         uint32_t w[NW];
 #pragma unroll
         for (int i = 0; i < NW; i++)
@@ -176,7 +243,7 @@ __device__ __forceinline__ void u32_unit(const FFHipU32Args &A, const FFHipU32Jo
                 for (int i = 0; i < NW; i++)
                     w[i] = lb ? raw[i < 2 ? 0 : i - 2] : rb ? raw[i + 2 < NW ? i + 2 : NW - 1] : raw[i];
             } else {
-                const uint32_t f0 = __builtin_amdgcn_perm(raw[0], raw[0], 0x01000100u), fl = __builtin_amdgcn_perm(raw[3], raw[3], 0x03020302u);
+                const uint32_t f0 = __builtin_amdgcn_perm(raw[0], raw[0], 0x01000100u), fl = __builtin_amdgcn_perm(raw[NW - 1], raw[NW - 1], 0x03020302u);
 #pragma unroll
                 for (int i = 0; i < NW; i++)
                     w[i] = lb ? (i ? raw[i - 1] : f0) : rb ? (i + 1 < NW ? raw[i + 1] : fl) : raw[i];
@@ -187,107 +254,132 @@ __device__ __forceinline__ void u32_unit(const FFHipU32Args &A, const FFHipU32Jo
             for (int i = 0; i < NW; i++)
                 w[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u3_h2, w[i]) >> (unsigned short)smsb);
         }
-        uint32_t pa[6], pb[6];
+        uint32_t pa[NO], pb[NO];
         if (PAIR) {
-            /* column j of the lane's period reads columns j .. j + 3 from the lane's base: the channels' pairs (c, c + 1), (c + 2, c + 3) */
+            /* column j of the lane's period reads columns off(j) + 2 .. + 3 more from the lane's base: the channels' pairs (c, c + 1), (c + 2, c + 3) */
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                pa[2 * j] = __builtin_amdgcn_perm(w[j + 1], w[j], 0x05040100u);
-                pa[2 * j + 1] = __builtin_amdgcn_perm(w[j + 1], w[j], 0x07060302u);
-                pb[2 * j] = __builtin_amdgcn_perm(w[j + 3], w[j + 2], 0x05040100u);
-                pb[2 * j + 1] = __builtin_amdgcn_perm(w[j + 3], w[j + 2], 0x07060302u);
+            for (int j = 0; j < POUT; j++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int c0 = u3_off<PIN, POUT>(j) + 2;
+                pa[2 * j] = __builtin_amdgcn_perm(w[c0 + 1], w[c0], 0x05040100u);
+                pa[2 * j + 1] = __builtin_amdgcn_perm(w[c0 + 1], w[c0], 0x07060302u);
+                pb[2 * j] = __builtin_amdgcn_perm(w[c0 + 3], w[c0 + 2], 0x05040100u);
+                pb[2 * j + 1] = __builtin_amdgcn_perm(w[c0 + 3], w[c0 + 2], 0x07060302u);
             }
         } else {
-            /* sample x = 3 k + j of the lane: j = 0: w[k], w[k + 1]; j = 1: o[k], o[k + 1] (the pairs that start on an odd sample);
-             * j = 2: w[k + 1], w[k + 2] */
-            uint32_t o[3];
+            /* output i = POUT k + j of the lane reads samples s .. s + 3, s = PIN k + off(j) + 2 from the lane's base: an even s takes the
+             * dwords w[s / 2], w[s / 2 + 1], an odd one the pairs that start on an odd sample */
+            uint32_t o[NW - 1];
 #pragma unroll
-            for (int k = 0; k < 3; k++)
+            for (int k = 0; k < NW - 1; k++)
                 o[k] = __builtin_amdgcn_alignbit(w[k + 1], w[k], 16);
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                pa[3 * k] = w[k];         pb[3 * k] = w[k + 1];
-                pa[3 * k + 1] = o[k];     pb[3 * k + 1] = o[k + 1];
-                pa[3 * k + 2] = w[k + 1]; pb[3 * k + 2] = w[k + 2];
+            for (int i = 0; i < NO; i++) {
+                const int s0 = PIN * (i / POUT) + u3_off<PIN, POUT>(i % POUT) + 2;
+                pa[i] = (s0 & 1) ? o[s0 >> 1] : w[s0 >> 1];
+                pb[i] = (s0 & 1) ? o[(s0 >> 1) + 1] : w[(s0 >> 1) + 1];
             }
         }
-        u3_h6(h, pa, pb, cf, hsh);
+        if (NO == 6) {
+            u3_h6(reinterpret_cast<int (&)[6]>(h), reinterpret_cast<const uint32_t (&)[6]>(pa), reinterpret_cast<const uint32_t (&)[6]>(pb),
+                  reinterpret_cast<const uint32_t (&)[6][2]>(cf), hsh);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NO / 4; q++)
+                u3_h4(h + 4 * q, pa + 4 * q, pb + 4 * q, cf + 4 * q, hsh);
+        }
     };
 
-    /* source rows in trips of six from rbase = 2 (a / 3) - 6 (a multiple of 6); rows rbase + 4, + 5 only fill the ring.  Straight-line code:
-     * every due row is computed, the store alone looks at the strip's bounds (branches around the arithmetic made the compiler copy the
-     * rows in flight at every join — and wait for them); the walk ends at uniform exits after the row the strip's last output ends on */
-    const int rbase0 = 2 * (a / 3) - 6, r_last = 2 * (b / 3) + 1, dstH = J.dstH;
-    uint32_t ring[3][6];
-    int hprev[6];
+    /* source rows in trips of T = lcm(3, PIN) from rbase = PIN (a / POUT) - T (a multiple of T); its last two rows only fill the ring.
+     * Straight-line code: every due row is computed, the store alone looks at the strip's bounds (branches around the arithmetic made the
+     * compiler copy the rows in flight at every join — and wait for them); the walk ends at uniform exits after the row the strip's last
+     * output ends on.  Output y = POUT m + j ends on source row PIN m + off(j) + 3 and reads P(that - 3), P(that - 1). */
+    constexpr int T = PIN % 3 ? 3 * PIN : PIN;
+    const int rbase0 = PIN * (a / POUT) - T, r_last = PIN * (b / POUT - 1) + u3_off<PIN, POUT>(POUT - 1) + 3, dstH = J.dstH;
+    uint32_t ring[3][NO];
+    int hprev[NO];
 #pragma unroll
-    for (int c = 0; c < 6; c++)
+    for (int c = 0; c < NO; c++)
         hprev[c] = 0;
 #pragma unroll
     for (int s = 0; s < 3; s++)
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+        for (int c = 0; c < NO; c++)
             ring[s][c] = 0;
     constexpr int D = 3; /* source rows in flight */
     uint32_t nxt[D][NW];
 #pragma unroll
     for (int i = 0; i < D; i++)
-        load_row(rbase0 + 4 + i, nxt[(4 + i) % D]);
+        load_row(rbase0 + T - 2 + i, nxt[(T - 2 + i) % D]);
     const u3_cc vt = (u3_cc)J.vfv;
-    const uint32_t doff = 12u * (uint32_t)g;
+    const uint32_t doff = (uint32_t)(2 * NO) * (uint32_t)g;
 
-    auto emit = [&](int y, const uint32_t (&p0)[6], const uint32_t (&p1)[6]) {
+    auto emit = [&](int y, const uint32_t (&p0)[NO], const uint32_t (&p1)[NO]) {
         const int yc = min(max(y, 0), dstH - 1);
         const uint32_t c0 = vt[2 * yc], c1 = vt[2 * yc + 1];
-        uint32_t o[3];
-        u3_v6(o, p0, p1, c0, c1, vseed, vsh, maxpk, dmsb);
-        if (act && y >= a && y < b)
-            *(u3_g3)((u3_gp)(dbase + (ptrdiff_t)y * dstride) + doff) = (u3_u3){ o[0], o[1], o[2] };
+        uint32_t o[NO / 2];
+        if (NO == 6) {
+            u3_v6(reinterpret_cast<uint32_t (&)[3]>(o), reinterpret_cast<const uint32_t (&)[6]>(p0), reinterpret_cast<const uint32_t (&)[6]>(p1), c0, c1,
+                  vseed, vsh, maxpk, dmsb);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NO / 4; q++)
+                u3_v4(o + 2 * q, p0 + 4 * q, p1 + 4 * q, c0, c1, vseed, vsh, maxpk, dmsb);
+        }
+        if (act && y >= a && y < b) {
+            u3_gp d = (u3_gp)(dbase + (ptrdiff_t)y * dstride) + doff;
+            if (NO == 6) {
+                *(u3_g3)d = (u3_u3){ o[0], o[1], o[2] };
+            } else {
+                *(u3_g4)d = (u3_u4){ o[0], o[1], o[2], o[3 % (NO / 2)] };
+            }
+        }
     };
-    /* row r = rbase + u: P(r - 1) = (row r - 1, row r) — v_cvt_pk_i16_i32 saturates = min(., 32767) (no sum of an admitted bank falls below
-     * -32768) — then r = 2m + 1: rows 3m - 1 and 3m;  r = 2m + 2: row 3m + 1 — all on P(r - 3), P(r - 1) */
-#define U3_STEP(u, EMIT)                                                                                                                  \
-    {                                                                                                                                     \
-        const int r = rbase + (u);                                                                                                        \
-        uint32_t cur[NW];                                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < NW; i++) cur[i] = nxt[(u) % D][i];                                                         \
-        load_row(r + D, nxt[(u) % D]);                                                                                                    \
-        int h[6];                                                                                                                         \
-        hpass(cur, h);                                                                                                                    \
-        _Pragma("unroll") for (int c = 0; c < 6; c++) {                                                                                  \
-            ring[((u) + 2) % 3][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));                          \
-            hprev[c] = h[c];                                                                                                              \
-        }                                                                                                                                 \
-        if (EMIT) {                                                                                                                       \
-            if ((u) & 1) {                                                                                                                \
-                const int y1 = 3 * ((r - 1) >> 1) - 1;                                                                                    \
-                emit(y1, ring[(u) % 3], ring[((u) + 2) % 3]);                                                                             \
-                emit(y1 + 1, ring[(u) % 3], ring[((u) + 2) % 3]);                                                                         \
-            } else {                                                                                                                      \
-                emit(3 * ((r - 2) >> 1) + 1, ring[(u) % 3], ring[((u) + 2) % 3]);                                                         \
-            }                                                                                                                             \
-        }                                                                                                                                 \
+    auto step = [&](int rbase, auto uc, auto ec) {
+        constexpr int u = decltype(uc)::value;
+        constexpr bool EMIT = decltype(ec)::value;
+        const int r = rbase + u;
+        uint32_t cur[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+            cur[i] = nxt[u % D][i];
+        load_row(r + D, nxt[u % D]);
+        int h[NO];
+        hpass(cur, h);
+        /* P(r - 1) = (row r - 1, row r): v_cvt_pk_i16_i32 saturates = min(., 32767) (no sum of an admitted bank falls below -32768) */
+#pragma unroll
+        for (int c = 0; c < NO; c++) {
+            ring[(u + 2) % 3][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));
+            hprev[c] = h[c];
+        }
+        if (EMIT) {
+            /* the outputs that end on this row, in ascending order: j with (u - off(j) - 3) a multiple of PIN (rbase is one) */
+#pragma unroll
+            for (int j = 0; j < POUT; j++) {
+                const int e = u - u3_off<PIN, POUT>(j) - 3; /* = PIN m - rbase */
+                if (((e % PIN) + PIN) % PIN == 0)
+                    emit(POUT * ((rbase + e) / PIN) + j, ring[u % 3], ring[(u + 2) % 3]);
+            }
+        }
+    };
+    step(rbase0, std::integral_constant<int, T - 2>(), std::false_type());
+    step(rbase0, std::integral_constant<int, T - 1>(), std::false_type());
+    for (int rbase = rbase0 + T; ; rbase += T) {
+        step(rbase, std::integral_constant<int, 0>(), std::true_type());
+        if (rbase + 1 > r_last) return;
+        step(rbase, std::integral_constant<int, 1>(), std::true_type());
+        if (rbase + 2 > r_last) return;
+        step(rbase, std::integral_constant<int, 2>(), std::true_type());
+        if (rbase + 3 > r_last) return;
+        if constexpr (T == 6) {
+            step(rbase, std::integral_constant<int, 3>(), std::true_type());
+            if (rbase + 4 > r_last) return;
+            step(rbase, std::integral_constant<int, 4>(), std::true_type());
+            if (rbase + 5 > r_last) return;
+            step(rbase, std::integral_constant<int, 5>(), std::true_type());
+            if (rbase + 6 > r_last) return;
+        }
     }
-    {
-        const int rbase = rbase0;
-        U3_STEP(4, false)
-        U3_STEP(5, false)
-    }
-    for (int rbase = rbase0 + 6; ; rbase += 6) {
-        U3_STEP(0, true)
-        U3_STEP(1, true)
-        if (rbase + 2 > r_last)
-            return;
-        U3_STEP(2, true)
-        U3_STEP(3, true)
-        if (rbase + 4 > r_last)
-            return;
-        U3_STEP(4, true)
-        U3_STEP(5, true)
-        if (rbase + 6 > r_last)
-            return;
-    }
-#undef U3_STEP
 }
 
 __global__ __launch_bounds__(256) void k_sws_up32(FFHipU32Args A)
@@ -305,10 +397,16 @@ __global__ __launch_bounds__(256) void k_sws_up32(FFHipU32Args A)
     const FFHipU32Job &J = A.job[j];
     const int local = u - J.unit_begin;
     const int strip = local / J.ncb, cb = local - strip * J.ncb;
-    if (J.pair)
-        u32_unit<1>(A, J, frame, cb * 64, strip, lane);
-    else
-        u32_unit<0>(A, J, frame, cb * 64, strip, lane);
+    if (A.ratio43) { /* 4:3 (1080p -> 1440p): period (3 in, 4 out) */
+        if (J.pair)
+            u32_unit<3, 4, 1>(A, J, frame, cb * 64, strip, lane);
+        else
+            u32_unit<3, 4, 0>(A, J, frame, cb * 64, strip, lane);
+    } else if (J.pair) {
+        u32_unit<2, 3, 1>(A, J, frame, cb * 64, strip, lane);
+    } else {
+        u32_unit<2, 3, 0>(A, J, frame, cb * 64, strip, lane);
+    }
 }
 
 /* ================================================================================================== */
@@ -320,13 +418,13 @@ __global__ __launch_bounds__(256) void k_sws_up32(FFHipU32Args A)
  * samples; taps the reference folded onto the edge sample land on one of the replicas.  Output: n_dst x 2 dwords, (c0, c1) (c2, c3) as
  * int16 pairs.  Returns 0 when the bank is not of this shape.
  */
-int ffhip_u32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, std::vector<uint32_t> *out)
+int ffhip_u32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pin, int pout, std::vector<uint32_t> *out)
 {
-    if (2 * n_dst != 3 * n_src || fsize < 1 || fsize > 16 || (n_dst % 3))
+    if ((long)pin * n_dst != (long)pout * n_src || fsize < 1 || fsize > 16 || (n_dst % pout) || !((pin == 2 && pout == 3) || (pin == 3 && pout == 4)))
         return 0;
     out->assign((size_t)n_dst * 2, 0);
     for (int x = 0; x < n_dst; x++) {
-        const int s0 = 2 * (x / 3) - 2 + x % 3;
+        const int s0 = pin * (x / pout) + (pin == 2 ? u3_off<2, 3>(x % pout) : u3_off<3, 4>(x % pout));
         int16_t v[4] = { 0 };
         bool used[4] = { false };
         for (int i = 0; i < fsize; i++) {
@@ -363,17 +461,18 @@ int ffhip_launch_up32(FFHipU32Args &A, hipStream_t stream)
         long long u = 0;
         for (int i = 0; i < A.njobs; i++) {
             FFHipU32Job &j = A.job[i];
-            if (j.ngroups < 3 || j.dstH <= 0 || (j.dstH % 3)) {
+            const int pout = A.ratio43 ? 4 : 3;
+            if (j.ngroups < 3 || j.dstH <= 0 || (j.dstH % pout)) {
                 ffhip_set_error("ffhip_sws: the exact-3:2 up-scaler takes rows of three groups or more and a multiple of three output rows");
                 return FFHIP_EINVAL;
             }
             const int n = cdiv(j.dstH, want);
-            j.strip_rows = cdiv(cdiv(j.dstH, n), 9) * 9;
+            j.strip_rows = cdiv(cdiv(j.dstH, n), 3 * pout) * 3 * pout;
             j.nstrips = cdiv(j.dstH, j.strip_rows);
             j.ncb = cdiv(j.ngroups, 64);
             u += (long long)j.ncb * j.nstrips;
         }
-        if (u * A.nframes >= 8192 || want <= 9)
+        if (u * A.nframes >= 8192 || want <= 12)
             break;
     }
     int u = 0;

@@ -112,7 +112,7 @@ struct FFHipSwsContext {
     void *dn2_dev = nullptr;
     int d32_ok = 0;   /* exact 3:2 down in both directions: the static-schedule kernel of sws_down32.hip */
     void *d32_dev = nullptr;
-    int u32_ok = 0;   /* exact 3:2 UP between 9..14-bit formats laid out alike: the static-schedule kernel of sws_up32.hip */
+    int u32_ok = 0;   /* exact 3:2 (1) or 4:3 (2) UP between 9..14-bit formats laid out alike: the static-schedule kernel of sws_up32.hip */
     void *u32_dev = nullptr;
     const uint32_t *u32_h[2] = { nullptr, nullptr }, *u32_v[2] = { nullptr, nullptr };
     const uint32_t *d32_h[2] = { nullptr, nullptr }, *d32_v[2] = { nullptr, nullptr };
@@ -539,11 +539,11 @@ static void d32_build(FFHipSwsContext *c, const int nsrc[4])
 
 /* exact 3:2 up above 8 bits: the banks (up to 4 taps) as virtual banks on the windows 2 (x / 3) - 2 + x % 3 .. + 3 of the edge-replicated rows, on
  * the device; sets c->u32_ok when every bank row is of that shape (sws_up32.hip) */
-static void u32_build(FFHipSwsContext *c, const int nsrc[4])
+static void u32_build(FFHipSwsContext *c, const int nsrc[4], int pin, int pout)
 {
     std::vector<uint32_t> vb[4];
     for (int i = 0; i < 4; i++)
-        if (!ffhip_u32_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], &vb[i]))
+        if (!ffhip_u32_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], pin, pout, &vb[i]))
             return;
     size_t uo[4], ut = 0;
     for (int i = 0; i < 4; i++) {
@@ -560,7 +560,7 @@ static void u32_build(FFHipSwsContext *c, const int nsrc[4])
     c->u32_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
     c->u32_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
     c->u32_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
-    c->u32_ok = 1;
+    c->u32_ok = pin == 2 ? 1 : 2;
 }
 
 /* the luma banks alone at exact 2:1, for a packed-RGB target's first stage (its chroma goes 2:1 across but 1:1 or 2:1 down by the
@@ -802,7 +802,14 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                     !(t->srcW & 3) && t->srcW >= 12 && !(t->srcH & 1) && !(chh & 1) &&
                     ((sl || fmt_nv(t->srcFormat)) ? !(cw & 1) && cw >= 6 : !(cw & 3) && cw >= 12) &&
                     bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
-                    u32_build(c, limits);
+                    u32_build(c, limits, 2, 3);
+                /* ... and exact 4:3 (1080p -> 1440p): period (3 in, 4 out) of the same kernel */
+                if (((sd > 8 && sd <= 14 && sl == dl && sl != 2) || w8u) && dd > 8 && dd <= 14 && !hrgb && !c->flat_dither && t->src_range == t->dst_range &&
+                    3 * t->dstW == 4 * t->srcW && 3 * t->dstH == 4 * t->srcH && 3 * c->d[1].n == 4 * cw && 3 * c->d[3].n == 4 * chh &&
+                    !(t->srcW % 6) && t->srcW >= 18 && !(t->srcH % 3) && !(chh % 3) &&
+                    ((sl || fmt_nv(t->srcFormat)) ? !(cw % 3) && cw >= 9 : !(cw % 6) && cw >= 18) &&
+                    bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
+                    u32_build(c, limits, 3, 4);
                 if (c->u32_ok && w8u)
                     c->widen8 = 1;
             }
@@ -1595,13 +1602,15 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
             memset(&U, 0, sizeof(U));
             U.nframes = nframes;
             U.sdepth = sd; U.ddepth = dd; U.smsb = sl == 1 && !widened; U.dmsb = dl == 1;
+            U.ratio43 = c->u32_ok == 2;
+            const int pin = U.ratio43 ? 3 : 2, pout = U.ratio43 ? 4 : 3;
             auto u3job = [&](int which, int plane, int dw_, int sh_, int pair) {
                 FFHipU32Job &j = U.job[U.njobs++];
                 j.src = static_cast<const uint8_t *>(wsrc[plane]); j.dst = static_cast<uint8_t *>(dst[plane]);
                 j.sstride = wss[plane]; j.dstride = dstStride[plane]; j.sfp = wsf[plane]; j.dfp = dstFramePitch[plane];
                 j.pair = pair;
-                j.srcH = sh_; j.dstH = sh_ / 2 * 3;
-                j.ngroups = pair ? dw_ / 3 : dw_ / 6;
+                j.srcH = sh_; j.dstH = sh_ / pin * pout;
+                j.ngroups = pair ? dw_ / pout : dw_ / (2 * pout);
                 j.hfv = c->u32_h[which]; j.vfv = c->u32_v[which];
             };
             u3job(0, 0, c->d[0].n, t.srcH, 0);

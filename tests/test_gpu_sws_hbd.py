@@ -209,6 +209,17 @@ UP32_CASES = [
     # 8-bit sources on planes widened to words: planar into planar, NV12 into P01x
     ("yuv420p", 96, 40, "yuv420p10le", 144, 60, ffi.SWS_BICUBIC),
     ("nv12", 96, 40, "p010le", 144, 60, ffi.SWS_BICUBIC),
+    # exact 4:3 (1080p -> 1440p): period (3 in, 4 out) of the same kernel
+    ("yuv420p10le", 36, 54, "yuv420p10le", 48, 72, ffi.SWS_BICUBIC),        # three groups per chroma row
+    ("yuv420p10le", 144, 60, "yuv420p10le", 192, 80, ffi.SWS_BILINEAR),
+    ("p010le", 144, 60, "p010le", 192, 80, ffi.SWS_BICUBIC),
+    ("p012le", 72, 54, "p012le", 96, 72, ffi.SWS_POINT),
+    ("yuv420p10le", 792, 114, "yuv420p10le", 1056, 152, ffi.SWS_BICUBIC),    # 132 groups per luma row, 66 per chroma row (ragged)
+    ("p010le", 792, 66, "p010le", 1056, 88, ffi.SWS_BICUBIC),
+    ("yuv444p10le", 72, 54, "yuv444p10le", 96, 72, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 144, 54, "yuv420p12le", 192, 72, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 144, 330, "yuv420p10le", 192, 440, ffi.SWS_BICUBIC),     # several strips of rows
+    ("nv12", 144, 60, "p010le", 192, 80, ffi.SWS_BICUBIC),
 ]
 
 

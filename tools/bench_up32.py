@@ -13,7 +13,8 @@ _lib.select("measure")
 dev = torch.device("cuda:0")
 P010, YUV420P10, NV12, YUV420P = 158, 62, 23, 0
 CASES = [("p010 720p->1080p", P010, 1280, 720, P010, 1920, 1080, 64), ("yuv420p10 720p->1080p", YUV420P10, 1280, 720, YUV420P10, 1920, 1080, 64),
-         ("p010 1440p->4K", P010, 2560, 1440, P010, 3840, 2160, 16), ("nv12 720p->p010 1080p", NV12, 1280, 720, P010, 1920, 1080, 64)]
+         ("p010 1440p->4K", P010, 2560, 1440, P010, 3840, 2160, 16), ("yuv420p10 1080p->1440p", YUV420P10, 1920, 1080, YUV420P10, 2560, 1440, 32),
+         ("p010 1080p->1440p", P010, 1920, 1080, P010, 2560, 1440, 32), ("nv12 720p->p010 1080p", NV12, 1280, 720, P010, 1920, 1080, 64)]
 for name, sf, sw, sh, df, dw, dh, n in CASES:
     src = [torch.randint(0, 256, (n, r, c), dtype=torch.uint8, device=dev) for r, c in S.plane_shapes(sf, sw, sh)]
     if sf in (P010, YUV420P10):
