@@ -242,6 +242,7 @@ struct FFHipU32Args {
     FFHipU32Job job[3];
     int njobs, units_per_frame, nframes;
     int sdepth, ddepth, smsb, dmsb;     /* as FFHipUp2Job.hb_* */
+    int bytes;                          /* round 6, the 8-bit twin (k_sws_up32b): planes of bytes / NV12 pairs, groups of 4 POUT destination bytes */
     int ratio43;                        /* 0: 3:2 (period 2 in, 3 out; groups of 6 / 3 outputs); 1: 4:3 (3 in, 4 out; groups of 8 / 4: 16 destination bytes) */
 };
 #ifdef __cplusplus

@@ -382,6 +382,210 @@ __device__ __forceinline__ void u32_unit(const FFHipU32Args &A, const FFHipU32Jo
     }
 }
 
+/* ================================================================================================== */
+/*
+ * The 8-bit twin (round 6): the same periods for planes of bytes and byte-interleaved U/V pairs (NV12 in and out) — hScale8To15_c
+ * (libswscale/swscale.c:128-142), nv12ToUV_c (input.c:936), yuv2planeX_8_c / yuv2nv12cX_c (output.c:468-529) as in sws_up2.hip.  A lane owns
+ * NO = 4 POUT output bytes — four periods of a plane, two periods x two channels of a pair — from the NWD dwords at the dword-aligned byte
+ * 4 PIN g - 4 (the windows start two samples / columns before the lane's first one); every window is a FIXED byte position in them: the
+ * int16 pairs come out of v_perm_b32 with static selectors.  720p -> 1080p and 1080p -> 1440p ran on the general 4-tap column walker at
+ * 0.35 - 0.40 of HBM.
+ */
+template <int Q, int STEP, int N>
+__device__ __forceinline__ uint32_t u3_bpair(const uint32_t (&w)[N])
+{
+    constexpr int i = Q >> 2, r = Q & 3;
+    constexpr uint32_t sel = 0x0c000c00u | (uint32_t)(r + STEP) << 16 | (uint32_t)r;
+    return __builtin_amdgcn_perm(w[i + 1 > N - 1 ? N - 1 : i + 1], w[i], sel);
+}
+/* four output bytes: t[i] = seed + pa[i] . f01 + pb[i] . f23, clip_u8(t[i] >> 19) packed in sample order */
+__device__ __forceinline__ uint32_t u3_v4b(const uint32_t *pa, const uint32_t *pb, uint32_t f01, uint32_t f23, int seed)
+{
+    uint32_t w;
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %1, %5, %13, %15\n\t"
+        "v_dot2_i32_i16 %2, %6, %13, %15\n\t"
+        "v_dot2_i32_i16 %3, %7, %13, %15\n\t"
+        "v_dot2_i32_i16 %4, %8, %13, %15\n\t"
+        "v_dot2_i32_i16 %1, %9, %14, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %14, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %14, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %14, %4\n\t"
+        "s_nop 1\n\t"
+        "v_ashr_pk_u8_i32 %0, %1, %2, 19\n\t"
+        "v_ashr_pk_u8_i32 %0, %3, %4, 19 op_sel:[0,0,0,1]"
+        : "=&v"(w), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "s"(f01), "s"(f23), "v"(seed));
+    return w;
+}
+
+template <int PIN, int POUT, int PAIR>
+__device__ __forceinline__ void u32b_unit(const FFHipU32Job &J, int frame, int gbase, int strip, int lane)
+{
+    constexpr int NO = 4 * POUT, NWD = PIN + 2; /* 4 PIN source bytes + 8 around them */
+    const int graw = gbase + lane;
+    const bool act = graw < J.ngroups;
+    const int g = min(graw, J.ngroups - 1);
+    const bool lb = g == 0, rb = g == J.ngroups - 1;
+    const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
+    /* the first / last lane of a row loads its dwords one further inside and rebuilds the replicated ones */
+    const uint32_t soff = (uint32_t)(lb ? 0 : 4 * PIN * g - 4 - (rb ? 4 : 0));
+    uint32_t cf[NO][2];
+    {
+        /* plane: outputs NO g .. ; pair: columns (NO / 2) g .., both channels of a column share its coefficients */
+        const uint32_t *p = J.hfv + (size_t)g * (PAIR ? NO : 2 * NO);
+#pragma unroll
+        for (int j = 0; j < NO; j++)
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                cf[j][k] = p[2 * (PAIR ? j >> 1 : j) + k];
+    }
+    const int a = strip * J.strip_rows, b = min(a + J.strip_rows, J.dstH);
+    const uint8_t *sbase = J.src + (size_t)frame * J.sfp;
+    uint8_t *dbase = J.dst + (size_t)frame * J.dfp;
+    const ptrdiff_t sstride = J.sstride, dstride = J.dstride;
+    const int srcH = J.srcH;
+
+    auto load_row = [&](int r, uint32_t (&w)[NWD]) {
+        const uint8_t *p = sbase + (ptrdiff_t)min(max(r, 0), srcH - 1) * sstride;
+        const u3_u4 v = *(u3_gc4)((u3_gcp)p + soff);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        if (NWD == 5)
+            w[NWD - 1] = *(u3_gc1)((u3_gcp)p + soff + 16);
+    };
+    auto hpass = [&](const uint32_t (&raw)[NWD], int (&h)[NO]) {
+        uint32_t w[NWD];
+#pragma unroll
+        for (int i = 0; i < NWD; i++)
+            w[i] = raw[i];
+        if (border) {
+            const uint32_t f0 = PAIR ? __builtin_amdgcn_perm(raw[0], raw[0], 0x01000100u) : __builtin_amdgcn_perm(raw[0], raw[0], 0x00000000u);
+            const uint32_t fl = PAIR ? __builtin_amdgcn_perm(raw[NWD - 1], raw[NWD - 1], 0x03020302u) : __builtin_amdgcn_perm(raw[NWD - 1], raw[NWD - 1], 0x03030303u);
+#pragma unroll
+            for (int i = 0; i < NWD; i++)
+                w[i] = lb ? (i ? raw[i - 1] : f0) : rb ? (i + 1 < NWD ? raw[i + 1] : fl) : raw[i];
+        }
+        /* window start of output e, in bytes from the loaded base:
+         *   plane: e = POUT k + j -> PIN k + off(j) + 4;   pair: e = 2 col + ch, col = POUT k + j -> 2 (PIN k + off(j) + 2) + ch */
+#define U3B_S(e) (PAIR ? 2 * (PIN * (((e) >> 1) / POUT) + u3_off<PIN, POUT>(((e) >> 1) % POUT) + 2) + ((e) & 1) : PIN * ((e) / POUT) + u3_off<PIN, POUT>((e) % POUT) + 4)
+#define U3B_Q(e0)                                                                                                                        \
+        {                                                                                                                                \
+            constexpr int ST = PAIR ? 2 : 1;                                                                                             \
+            const uint32_t pa[4] = { u3_bpair<U3B_S(e0), ST>(w), u3_bpair<U3B_S(e0 + 1), ST>(w), u3_bpair<U3B_S(e0 + 2), ST>(w), u3_bpair<U3B_S(e0 + 3), ST>(w) }; \
+            const uint32_t pb[4] = { u3_bpair<U3B_S(e0) + 2 * ST, ST>(w), u3_bpair<U3B_S(e0 + 1) + 2 * ST, ST>(w), u3_bpair<U3B_S(e0 + 2) + 2 * ST, ST>(w),    \
+                                     u3_bpair<U3B_S(e0 + 3) + 2 * ST, ST>(w) };                                                          \
+            u3_h4(h + (e0), pa, pb, cf + (e0), 7);                                                                                       \
+        }
+        U3B_Q(0) U3B_Q(4) U3B_Q(8)
+        if constexpr (NO == 16)
+            U3B_Q(12 % NO)
+#undef U3B_Q
+#undef U3B_S
+    };
+
+    constexpr int T = PIN % 3 ? 3 * PIN : PIN;
+    const int rbase0 = PIN * (a / POUT) - T, r_last = PIN * (b / POUT - 1) + u3_off<PIN, POUT>(POUT - 1) + 3, dstH = J.dstH;
+    uint32_t ring[3][NO];
+    int hprev[NO];
+#pragma unroll
+    for (int c = 0; c < NO; c++)
+        hprev[c] = 0;
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int c = 0; c < NO; c++)
+            ring[s][c] = 0;
+    constexpr int D = T % 2 ? 3 : 2; /* source rows in flight (two keep the 3:2 lanes at 128 registers: four waves per SIMD) */
+    uint32_t nxt[D][NWD];
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        load_row(rbase0 + T - 2 + i, nxt[(T - 2 + i) % D]);
+    const u3_cc vt = (u3_cc)J.vfv;
+    const uint32_t doff = (uint32_t)NO * (uint32_t)g;
+
+    auto emit = [&](int y, const uint32_t (&p0)[NO], const uint32_t (&p1)[NO]) {
+        const int yc = min(max(y, 0), dstH - 1);
+        const uint32_t c0 = vt[2 * yc], c1 = vt[2 * yc + 1];
+        uint32_t o[NO / 4];
+#pragma unroll
+        for (int q = 0; q < NO / 4; q++)
+            o[q] = u3_v4b(p0 + 4 * q, p1 + 4 * q, c0, c1, 64 << 12);
+        if (act && y >= a && y < b) {
+            u3_gp d = (u3_gp)(dbase + (ptrdiff_t)y * dstride) + doff;
+            if (NO == 12) {
+                *(u3_g3)d = (u3_u3){ o[0], o[1], o[2] };
+            } else {
+                *(u3_g4)d = (u3_u4){ o[0], o[1], o[2], o[3 % (NO / 4)] };
+            }
+        }
+    };
+    auto step = [&](int rbase, auto uc, auto ec) {
+        constexpr int u = decltype(uc)::value;
+        constexpr bool EMIT = decltype(ec)::value;
+        const int r = rbase + u;
+        uint32_t cur[NWD];
+#pragma unroll
+        for (int i = 0; i < NWD; i++)
+            cur[i] = nxt[u % D][i];
+        load_row(r + D, nxt[u % D]);
+        int h[NO];
+        hpass(cur, h);
+#pragma unroll
+        for (int c = 0; c < NO; c++) {
+            ring[(u + 2) % 3][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));
+            hprev[c] = h[c];
+        }
+        if (EMIT) {
+#pragma unroll
+            for (int j = 0; j < POUT; j++) {
+                const int e = u - u3_off<PIN, POUT>(j) - 3;
+                if (((e % PIN) + PIN) % PIN == 0)
+                    emit(POUT * ((rbase + e) / PIN) + j, ring[u % 3], ring[(u + 2) % 3]);
+            }
+        }
+    };
+    step(rbase0, std::integral_constant<int, T - 2>(), std::false_type());
+    step(rbase0, std::integral_constant<int, T - 1>(), std::false_type());
+    for (int rbase = rbase0 + T; ; rbase += T) {
+        step(rbase, std::integral_constant<int, 0>(), std::true_type());
+        if (rbase + 1 > r_last) return;
+        step(rbase, std::integral_constant<int, 1>(), std::true_type());
+        if (rbase + 2 > r_last) return;
+        step(rbase, std::integral_constant<int, 2>(), std::true_type());
+        if (rbase + 3 > r_last) return;
+        if constexpr (T == 6) {
+            step(rbase, std::integral_constant<int, 3>(), std::true_type());
+            if (rbase + 4 > r_last) return;
+            step(rbase, std::integral_constant<int, 4>(), std::true_type());
+            if (rbase + 5 > r_last) return;
+            step(rbase, std::integral_constant<int, 5>(), std::true_type());
+            if (rbase + 6 > r_last) return;
+        }
+    }
+}
+
+template <int R43> /* a kernel per period: the (3 in, 4 out) lanes hold a third more registers */
+__global__ __launch_bounds__(256) void k_sws_up32b(FFHipU32Args A)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave;
+    if (gw >= (uint32_t)A.units_per_frame * (uint32_t)A.nframes)
+        return;
+    const int frame = (int)(gw / (uint32_t)A.units_per_frame);
+    const int u = (int)(gw - (uint32_t)frame * (uint32_t)A.units_per_frame);
+    int j = 0;
+    if (A.njobs > 1 && u >= A.job[1].unit_begin) j = 1;
+    if (A.njobs > 2 && u >= A.job[2].unit_begin) j = 2;
+    const FFHipU32Job &J = A.job[j];
+    const int local = u - J.unit_begin;
+    const int strip = local / J.ncb, cb = local - strip * J.ncb;
+    if (J.pair)
+        u32b_unit<R43 ? 3 : 2, R43 ? 4 : 3, 1>(J, frame, cb * 64, strip, lane);
+    else
+        u32b_unit<R43 ? 3 : 2, R43 ? 4 : 3, 0>(J, frame, cb * 64, strip, lane);
+}
+
 __global__ __launch_bounds__(256) void k_sws_up32(FFHipU32Args A)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -486,7 +690,12 @@ int ffhip_launch_up32(FFHipU32Args &A, hipStream_t stream)
         ffhip_set_error("ffhip_sws: batch too large for one launch (%lld waves)", waves);
         return FFHIP_EINVAL;
     }
-    hipLaunchKernelGGL(k_sws_up32, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    if (A.bytes && A.ratio43)
+        hipLaunchKernelGGL(k_sws_up32b<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    else if (A.bytes)
+        hipLaunchKernelGGL(k_sws_up32b<0>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
+    else
+        hipLaunchKernelGGL(k_sws_up32, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, A);
     LAUNCH_CHECK();
     return 0;
 }

@@ -1107,6 +1107,19 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
             const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
             d32_build(c, nsrc);
         }
+        /* exact 3:2 / 4:3 UP (720p -> 1080p, 1080p -> 1440p), chroma laid out alike and in the same order on both sides: the 8-bit twin of
+         * sws_up32.hip (round 6; was the 4-tap column walker at 0.35 - 0.40 of HBM) */
+        for (int q = 0; q < 2 && !c->u32_ok; q++) {
+            const int pin = q ? 3 : 2, pout = q ? 4 : 3, no = 4 * pout;
+            if (ffhip_cw_bank_nowrap(c->f[0].data(), c->d[0].size, c->d[0].n) && ffhip_cw_bank_nowrap(c->f[1].data(), c->d[1].size, c->d[1].n) &&
+                pin * l.dstW == pout * l.srcW && pin * l.dstH == pout * l.srcH && pin * ch.dstW == pout * ch.srcW && pin * ch.dstH == pout * ch.srcH &&
+                t->srcFormat == t->dstFormat /* (the same layout and channel order) */ && !(l.dstW % no) && l.dstW >= 3 * no && !(l.dstH % pout) &&
+                !(ch.dstH % pout) && (fmt_nv(t->srcFormat) ? !(ch.dstW % (no / 2)) && ch.dstW >= 3 * no / 2 : !(ch.dstW % no) && ch.dstW >= 3 * no) &&
+                t->dst_alpha_fill != 2) {
+                const int nsrc[4] = { l.srcW, ch.srcW, l.srcH, ch.srcH };
+                u32_build(c, nsrc, pin, pout);
+            }
+        }
         /* MFMA variant: same banks; chroma either byte-interleaved on both sides or planar on both sides */
         const bool nv_in = fmt_nv(t->srcFormat), nv_out = fmt_nv(t->dstFormat);
         if (c->cw_opt && nv_in == nv_out) {
@@ -2339,6 +2352,41 @@ static int scale_batch_dev(FFHipSwsContext *c, int nframes, const void *const sr
             ffhip_down2_plan_job(&j, 32);
         }
         return ffhip_launch_down2(D, stream);
+    }
+    const char *eu3b = FFHIP_KNOB("FFHIP_SWS_UP32"); /* measure build: 0 keeps the column walker */
+    uintptr_t al3 = (uintptr_t)l.src[0] | (size_t)l.src_stride[0] | l.src_fp[0] | (uintptr_t)l.dst[0] | (size_t)l.dst_stride[0] | l.dst_fp[0];
+    bool neg3 = l.src_stride[0] < 0 || l.dst_stride[0] < 0;
+    for (int i = 0; i < 2; i++) {
+        al3 |= (size_t)ch.src_stride[i] | ch.src_fp[i] | (size_t)ch.dst_stride[i] | ch.dst_fp[i];
+        al3 |= ch.src_step == 2 ? (uintptr_t)(ch.src[0] < ch.src[1] ? ch.src[0] : ch.src[1]) : (uintptr_t)ch.src[i];
+        al3 |= ch.dst_step == 2 ? (uintptr_t)(ch.dst[0] < ch.dst[1] ? ch.dst[0] : ch.dst[1]) : (uintptr_t)ch.dst[i];
+        neg3 = neg3 || ch.src_stride[i] < 0 || ch.dst_stride[i] < 0;
+    }
+    if (!(al3 & 3) && c->u32_ok && !neg3 && !c->luma_pass && !(eu3b && eu3b[0] == '0')) {
+        /* exact 3:2 / 4:3 up: static schedule, no LDS (the 8-bit twin in sws_up32.hip) */
+        FFHipU32Args U;
+        memset(&U, 0, sizeof(U));
+        U.nframes = nframes;
+        U.bytes = 1;
+        U.ratio43 = c->u32_ok == 2;
+        const int no = U.ratio43 ? 16 : 12;
+        auto ujob = [&](const FFHipScalePlaneArgs &p, int which, const uint8_t *src, ptrdiff_t ss, size_t sf, uint8_t *dst, ptrdiff_t dsr, size_t df, int pair) {
+            FFHipU32Job &j = U.job[U.njobs++];
+            j.src = src; j.dst = dst; j.sstride = ss; j.dstride = dsr; j.sfp = sf; j.dfp = df;
+            j.pair = pair;
+            j.srcH = p.srcH; j.dstH = p.dstH;
+            j.ngroups = pair ? p.dstW / (no / 2) : p.dstW / no;
+            j.hfv = c->u32_h[which]; j.vfv = c->u32_v[which];
+        };
+        ujob(l, 0, l.src[0], l.src_stride[0], l.src_fp[0], l.dst[0], l.dst_stride[0], l.dst_fp[0], 0);
+        if (ch.src_step == 2) {
+            ujob(ch, 1, ch.src[1] < ch.src[0] ? ch.src[1] : ch.src[0], ch.src_stride[0], ch.src_fp[0], ch.dst[1] < ch.dst[0] ? ch.dst[1] : ch.dst[0],
+                 ch.dst_stride[0], ch.dst_fp[0], 1);
+        } else {
+            for (int k = 0; k < 2; k++)
+                ujob(ch, 1, ch.src[k], ch.src_stride[k], ch.src_fp[k], ch.dst[k], ch.dst_stride[k], ch.dst_fp[k], 0);
+        }
+        return ffhip_launch_up32(U, stream);
     }
     if (c->cw_ok && !(ev && ev[0] == '0')) {
         uintptr_t al = 0;

@@ -52,7 +52,7 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
     rng = np.random.default_rng(seed)
     for k in ("FFHIP_SWS_UP2", "FFHIP_UP2_FSHIFT", "FFHIP_UP2_STRIP", "FFHIP_UP2_DEPTH", "FFHIP_UP2_VAR", "FFHIP_UP2_XCD",
               "FFHIP_SWS_DOWN2", "FFHIP_DN2_XCD", "FFHIP_DN2_STRIP", "FFHIP_SWS_UP2RGB", "FFHIP_UP2RGB_STEPS", "FFHIP_UP2RGB_FPP", "FFHIP_SWS_RGB2", "FFHIP_SWS_EQRGB", "FFHIP_EQRGB_STEPS",
-              "FFHIP_EQRGB_FPP", "FFHIP_SWS_DOWN32"):
+              "FFHIP_EQRGB_FPP", "FFHIP_SWS_DOWN32", "FFHIP_SWS_UP32"):
         monkeypatch.delenv(k, raising=False)
     # the general kernels at exact 2:1 / 1:2 sizes need the fast paths switched off: a knob, i.e. libffhip_measure.so (conftest.py);
     # every other size runs the product library
@@ -60,6 +60,8 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
         monkeypatch.setenv("FFHIP_SWS_DOWN2", "0")  # test_down2* covers sws_down2.hip
     if need != "down32" and 2 * sw == 3 * dw and 2 * sh == 3 * dh:
         monkeypatch.setenv("FFHIP_SWS_DOWN32", "0")  # test_down32* covers sws_down32.hip
+    if need != "up32" and ((2 * dw == 3 * sw and 2 * dh == 3 * sh) or (3 * dw == 4 * sw and 3 * dh == 4 * sh)):
+        monkeypatch.setenv("FFHIP_SWS_UP32", "0")  # test_up32* covers the 8-bit twin of sws_up32.hip
     if need != "up2" and dw == 2 * sw and dh == 2 * sh:
         monkeypatch.setenv("FFHIP_SWS_UP2", "0")   # these tests are about the general kernels; test_up2* covers sws_up2.hip
     if need != "up2rgb" and dw == 2 * sw and dh == 2 * sh:
@@ -95,6 +97,8 @@ def _run(sf, sw, sh, df, dw, dh, flags, banks=None, env=None, monkeypatch=None, 
         assert ctx.up2rgb_path, "case does not reach the exact-2x kernel with the RGB writer"
     elif need == "down32":
         assert ctx.paths & 4096, "case does not reach the exact-3:2 kernel"
+    elif need == "up32":
+        assert ctx.paths & 8192, "case does not reach the exact-3:2 / 4:3 up-scaler"
     elif need == "fast":
         assert ctx.fast_path, "case does not reach the column walker"
     if (env or {}).get("FFHIP_SWS_MFMA") == "1" and need_mfma:
@@ -696,6 +700,45 @@ def test_down32_is_not_taken_for_other_shapes():
     for sf, sw, sh, df, dw, dh in (("nv12", 384, 216, "yuv420p", 256, 144), ("nv12", 378, 216, "nv12", 252, 144), ("nv12", 384, 216, "nv12", 256, 108)):
         ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], ffi.SWS_BICUBIC)   # layouts differ; 252 is not a multiple of 8; 2:1 down
         assert not ctx.paths & 4096, (sf, sw, sh, df, dw, dh)
+        ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# exact 3:2 and 4:3 up-scaling on the static-schedule kernel's 8-bit twin (sws_up32.hip, round 6)
+UP32_CASES = [
+    ("nv12", 144, 96, "nv12", 216, 144, ffi.SWS_BICUBIC),            # three groups per chroma row... (108 columns / 6 = 18) one column block
+    ("nv21", 144, 96, "nv21", 216, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 144, 96, "yuv420p", 216, 144, ffi.SWS_BICUBIC),      # three plane jobs
+    ("yuv420p", 48, 24, "yuv420p", 72, 36, ffi.SWS_BICUBIC),         # the smallest rows it takes: three groups per chroma row
+    ("yuv420p", 1040, 64, "yuv420p", 1560, 96, ffi.SWS_BICUBIC),     # several lane blocks, ragged last one (130 / 65 groups)
+    ("nv12", 1040, 64, "nv12", 1560, 96, ffi.SWS_BICUBIC),
+    ("nv12", 144, 96, "nv12", 216, 144, ffi.SWS_BILINEAR),           # 2 taps inside the 4-tap window
+    ("yuv420p", 144, 96, "yuv420p", 216, 144, ffi.SWS_POINT),
+    ("yuv422p", 144, 48, "yuv422p", 216, 72, ffi.SWS_BICUBIC),
+    ("yuv444p", 72, 48, "yuv444p", 108, 72, ffi.SWS_BICUBIC),
+    ("nv12", 144, 300, "nv12", 216, 450, ffi.SWS_BICUBIC),           # several strips of rows
+    ("nv12", 1280, 720, "nv12", 1920, 1080, ffi.SWS_BICUBIC),
+    # 4:3: period (3 in, 4 out)
+    ("nv12", 144, 108, "nv12", 192, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 144, 108, "yuv420p", 192, 144, ffi.SWS_BICUBIC),
+    ("yuv420p", 72, 36, "yuv420p", 96, 48, ffi.SWS_BILINEAR),        # three groups per chroma row
+    ("nv21", 792, 66, "nv21", 1056, 88, ffi.SWS_BICUBIC),            # 66 luma groups, 66 chroma groups: a ragged block each
+    ("yuv444p", 72, 54, "yuv444p", 96, 72, ffi.SWS_POINT),
+    ("nv12", 144, 330, "nv12", 192, 440, ffi.SWS_BICUBIC),
+    ("nv12", 1920, 1080, "nv12", 2560, 1440, ffi.SWS_BICUBIC),
+]
+
+
+@pytest.mark.parametrize("case", UP32_CASES, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_up32(case, monkeypatch):
+    _run(*case, monkeypatch=monkeypatch, seed=abs(hash(case)) & 0xFFFF, need="up32")
+
+
+def test_up32_is_not_taken_for_other_shapes():
+    from ffmpeg_amd import swscale as S
+    for sf, sw, sh, df, dw, dh in (("nv12", 144, 96, "yuv420p", 216, 144), ("nv12", 140, 96, "nv12", 210, 144), ("nv12", 144, 96, "nv21", 216, 144)):
+        ctx = S.SwsContext(sw, sh, PIX[sf], dw, dh, PIX[df], ffi.SWS_BICUBIC)   # layouts differ; 210 is not a multiple of 12; the pair turned round
+        assert not ctx.paths & 8192, (sf, sw, sh, df, dw, dh)
         ctx.close()
 
 
