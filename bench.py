@@ -1808,6 +1808,13 @@ def main():
                                    ("me_esa_satd_r7", "valu_issue_roof_frac", "me_esa_satd_r7_issue_frac"),
                                    ("hevc_qpel_uni16_mixed", "hbm_frac", "hevc_qpel_uni16_mixed_frac"), ("vp9_mc16_8tap_mixed", "hbm_frac", "vp9_mc16_8tap_mixed_frac"),
                                    ("h264_chroma_mc8_mixed", "hbm_frac", "h264_chroma_mc8_mixed_frac"), ("mdct1024_int32_fwd", "hbm_frac", "mdct1024_int32_fwd_frac"),
+                                   ("sws_p010_720p_to_1080p_bicubic", "hbm_frac", "sws_p010_720p_to_1080p_frac"),
+                                   ("sws_p010_4k_to_1440p_bicubic", "hbm_frac", "sws_p010_4k_to_1440p_frac"),
+                                   ("sws_yuv420p10_1080p_to_1440p_bicubic", "hbm_frac", "sws_yuv420p10_1080p_to_1440p_frac"),
+                                   ("sws_nv12_1080p_to_720p_bicubic", "hbm_frac", "sws_nv12_1080p_to_720p_frac"),
+                                   ("sws_p010_1080p_to_4k_bicubic", "hbm_frac", "sws_p010_1080p_to_4k_frac"),
+                                   ("sws_p010_4k_to_1080p_bicubic", "hbm_frac", "sws_p010_4k_to_1080p_frac"),
+                                   ("dctI_64", "fp64_TFLOP/s", "dctI_64_fp64_TFLOPs"),
                                    ("sws_host_pointer_end_to_end", "ms_per_frame", "sws_host_pointer_ms_per_frame")):
                 if isinstance(ex.get(key), dict) and fld in ex[key]:
                     roof[name] = ex[key][fld]
