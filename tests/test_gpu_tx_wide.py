@@ -109,7 +109,7 @@ def test_refusals():
     for type_, len_ in ((tx.DOUBLE_FFT, 24), (tx.DOUBLE_FFT, 16384), (tx.INT32_FFT, 32768), (tx.INT32_MDCT, 960), (tx.DOUBLE_MDCT, 8)):
         with pytest.raises(Exception):
             tx.TxContext(type_, 0, len_, 1.0)
-    for type_ in (7, 8, 10, 11, 12, 13, 14, 15, 16, 17):       # the RDFT / DCT forms of the wide types, DCT-I / DST-I
+    for type_ in (7, 8, 10, 11, 13, 14, 16, 17):       # the RDFT / DCT / DCT-I / DST-I forms of the wide types (float DCT-I / DST-I: test_gpu_tx_dcst1.py)
         with pytest.raises(Exception):
             tx.TxContext(type_, 0, 64, 1.0)
     with pytest.raises(Exception):
