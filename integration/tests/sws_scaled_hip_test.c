@@ -264,6 +264,11 @@ int main(int argc, char **argv)
     CASE("yuv420p10le", 1280, 720, "yuv420p10le", 1920, 1080, SWS_BICUBIC, 0, 0, 0, 1);
     CASE("p010le", 3840, 2160, "nv12", 1920, 1080, SWS_BICUBIC, 0, 0, 0, 1);
     CASE("yuv420p10le", 1920, 1080, "yuv420p", 1280, 720, SWS_BICUBIC, 0, 0, 0, 1);
+    /* round 6: 3:2 and 4:3 on the static-schedule kernels, both ways, 8 and 10 bits (sws_up32.hip, sws_down32.hip) */
+    CASE("nv12", 1280, 720, "nv12", 1920, 1080, SWS_BICUBIC, 0, 0, 0, 1);
+    CASE("yuv420p", 1920, 1080, "yuv420p", 2560, 1440, SWS_BICUBIC, 0, 0, 0, 1);
+    CASE("p010le", 1920, 1080, "p010le", 2560, 1440, SWS_BILINEAR, 0, 0, 0, 1);
+    CASE("p010le", 3840, 2160, "p010le", 2560, 1440, SWS_BICUBIC, 0, 0, 0, 1);
     /* source slices (libffhip collects them and scales when the frame is complete), bottom-up pictures */
     CASE("yuv420p", 640, 360, "rgb24", 1280, 720, SWS_BICUBIC, 16, 0, 0, 1);
     CASE("nv12", 1280, 720, "nv12", 640, 360, SWS_BICUBIC, 64, 0, 0, 1);

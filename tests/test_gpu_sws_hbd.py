@@ -328,6 +328,13 @@ def test_p010_1080p_to_4k():
     _run(("p010le", 1920, 1080, "p010le", 3840, 2160, ffi.SWS_BICUBIC), nframes=1, pad=0)
 
 
+def test_the_bench_lines_of_the_3to2_and_4to3_kernels_at_full_size():
+    """p010 720p -> 1080p (k_sws_up32), yuv420p10 1080p -> 1440p (its 4:3 period), p010 4K -> 1440p (k_sws_down32h): the sizes bench.py times"""
+    _run(("p010le", 1280, 720, "p010le", 1920, 1080, ffi.SWS_BICUBIC), nframes=2, pad=0)
+    _run(("yuv420p10le", 1920, 1080, "yuv420p10le", 2560, 1440, ffi.SWS_BICUBIC), nframes=1, pad=0)
+    _run(("p010le", 3840, 2160, "p010le", 2560, 1440, ffi.SWS_BICUBIC), nframes=1, pad=0)
+
+
 def test_yuv420p10_1080p_to_4k_and_back():
     _run(("yuv420p10le", 1920, 1080, "yuv420p10le", 3840, 2160, ffi.SWS_BICUBIC), nframes=1, pad=0)
     _run(("yuv420p10le", 3840, 2160, "yuv420p", 1920, 1080, ffi.SWS_BICUBIC), nframes=1, pad=0)

@@ -48,7 +48,7 @@ def test_sws_scale_of_scaled_contexts_goes_through_the_hip_swsfunc():
     assert lines[0].startswith("OK  ") and "nv12 1920x1080 -> rgb24 1920x1080" in lines[0] and "hip SwsFunc == ff_swscale" in lines[0], lines[0]
     assert any("nv12 1920x1080 -> nv12 3840x2160" in l and l.startswith("OK  ") for l in lines), tail
     m = re.search(r"(\d+) cases, 0 failed", r.stdout)
-    assert m and int(m.group(1)) >= 45, tail
+    assert m and int(m.group(1)) >= 49, tail
     assert any("yuv444p 1920x1080 -> rgb24 1920x1080" in l and "hip SwsFunc == ff_swscale" in l for l in lines), tail
     # round 6: the frame API asking for TARGET slices of a scaled picture (slice -64 / -1 / -32 in the listing) gives the C
     # scaler's picture; SWS_FAST_BILINEAR contexts (flags 0x1) are left to ff_swscale() like the dithered 16-bit target and the gray source
