@@ -439,6 +439,9 @@ def extras(torch, dev, torch_alloc=False):
     sws_case("sws_p010_720p_to_1080p_bicubic", 158, 1280, 720, 158, 1920, 1080, 64)
     sws_case("sws_p010_4k_to_1440p_bicubic", 158, 3840, 2160, 158, 2560, 1440, 16)
     sws_case("sws_yuv420p10_1080p_to_1440p_bicubic", 62, 1920, 1080, 62, 2560, 1440, 32)
+    # round 6: the other static periods — 4:3 down above 8 bits (k_sws_down32h's second period) and the 8-bit twin of the 3:2 up-scaler
+    sws_case("sws_p010_1440p_to_1080p_bicubic", 158, 2560, 1440, 158, 1920, 1080, 32)
+    sws_case("sws_nv12_720p_to_1080p_bicubic", 23, 1280, 720, 23, 1920, 1080, 64)
     # round 5's second survey: conversions at the source's size that sat on general kernels — planar 4:4:4 into RGB (no table converter:
     # the full-chroma writer on one-tap banks, sws_full444.hip), 4:2:0 between its layouts (sws_copy420.hip), 4:4:4 -> 4:2:0 (the luma
     # copied, the chroma on the exact-2:1 kernel) — and the commonest down-scale on the wide walker

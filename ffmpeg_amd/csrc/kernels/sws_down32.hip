@@ -20,6 +20,8 @@
  * Round 6: the dots in hand-scheduled blocks (VOP3P form, no v_mov per chain) and every row straight-line, the strip's bounds on the store
  * alone (see the loop); 8 bytes out per lane and row.
  */
+#include <type_traits>
+
 #include "common.h"
 #include "sws_kernels.h"
 
@@ -33,6 +35,7 @@ typedef uint8_t __attribute__((address_space(1))) *d3_gp;
 typedef const d3_u4a __attribute__((address_space(1))) *d3_gc4;
 typedef const uint32_t __attribute__((address_space(1))) *d3_gc1;
 typedef d3_u2a __attribute__((address_space(1))) *d3_g2;
+typedef uint32_t __attribute__((address_space(1))) *d3_g1;
 
 __device__ __forceinline__ int d3_dot(uint32_t p, uint32_t c, int acc)
 {
@@ -352,28 +355,116 @@ __device__ __forceinline__ void d3_v4h(uint32_t &w0, uint32_t &w1, const uint32_
           "s"(c0), "s"(c1), "s"(c2), "v"(seed), "s"(sh), "s"(maxpk), "s"(msb));
 }
 
-template <int PAIR>
+/* six-chain forms of the two blocks (the 4:3 period: six outputs per lane) */
+__device__ __forceinline__ void d3_h6s(int *d, const uint32_t (*p)[3], const uint32_t (*c)[3], int sh)
+{
+    asm("v_dot2_i32_i16 %0, %6, %24, 0\n\t"
+        "v_dot2_i32_i16 %1, %7, %25, 0\n\t"
+        "v_dot2_i32_i16 %2, %8, %26, 0\n\t"
+        "v_dot2_i32_i16 %3, %9, %27, 0\n\t"
+        "v_dot2_i32_i16 %4, %10, %28, 0\n\t"
+        "v_dot2_i32_i16 %5, %11, %29, 0\n\t"
+        "v_dot2_i32_i16 %0, %12, %30, %0\n\t"
+        "v_dot2_i32_i16 %1, %13, %31, %1\n\t"
+        "v_dot2_i32_i16 %2, %14, %32, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %33, %3\n\t"
+        "v_dot2_i32_i16 %4, %16, %34, %4\n\t"
+        "v_dot2_i32_i16 %5, %17, %35, %5\n\t"
+        "v_dot2_i32_i16 %0, %18, %36, %0\n\t"
+        "v_dot2_i32_i16 %1, %19, %37, %1\n\t"
+        "v_dot2_i32_i16 %2, %20, %38, %2\n\t"
+        "v_dot2_i32_i16 %3, %21, %39, %3\n\t"
+        "v_dot2_i32_i16 %4, %22, %40, %4\n\t"
+        "v_dot2_i32_i16 %5, %23, %41, %5\n\t"
+        "v_ashrrev_i32 %0, %42, %0\n\t"
+        "v_ashrrev_i32 %1, %42, %1\n\t"
+        "v_ashrrev_i32 %2, %42, %2\n\t"
+        "v_ashrrev_i32 %3, %42, %3\n\t"
+        "v_ashrrev_i32 %4, %42, %4\n\t"
+        "v_ashrrev_i32 %5, %42, %5"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+        : "v"(p[0][0]), "v"(p[1][0]), "v"(p[2][0]), "v"(p[3][0]), "v"(p[4][0]), "v"(p[5][0]), "v"(p[0][1]), "v"(p[1][1]), "v"(p[2][1]), "v"(p[3][1]),
+          "v"(p[4][1]), "v"(p[5][1]), "v"(p[0][2]), "v"(p[1][2]), "v"(p[2][2]), "v"(p[3][2]), "v"(p[4][2]), "v"(p[5][2]),
+          "v"(c[0][0]), "v"(c[1][0]), "v"(c[2][0]), "v"(c[3][0]), "v"(c[4][0]), "v"(c[5][0]), "v"(c[0][1]), "v"(c[1][1]), "v"(c[2][1]), "v"(c[3][1]),
+          "v"(c[4][1]), "v"(c[5][1]), "v"(c[0][2]), "v"(c[1][2]), "v"(c[2][2]), "v"(c[3][2]), "v"(c[4][2]), "v"(c[5][2]), "s"(sh));
+}
+__device__ __forceinline__ void d3_v6h(uint32_t *w, const uint32_t *pa, const uint32_t *pb, const uint32_t *pc, uint32_t c0, uint32_t c1, uint32_t c2, int seed,
+                                       int sh, uint32_t maxpk, uint32_t msb)
+{
+    int t0, t1, t2, t3, t4, t5;
+    asm("v_dot2_i32_i16 %3, %9, %27, %30\n\t"
+        "v_dot2_i32_i16 %4, %10, %27, %30\n\t"
+        "v_dot2_i32_i16 %5, %11, %27, %30\n\t"
+        "v_dot2_i32_i16 %6, %12, %27, %30\n\t"
+        "v_dot2_i32_i16 %7, %13, %27, %30\n\t"
+        "v_dot2_i32_i16 %8, %14, %27, %30\n\t"
+        "v_dot2_i32_i16 %3, %15, %28, %3\n\t"
+        "v_dot2_i32_i16 %4, %16, %28, %4\n\t"
+        "v_dot2_i32_i16 %5, %17, %28, %5\n\t"
+        "v_dot2_i32_i16 %6, %18, %28, %6\n\t"
+        "v_dot2_i32_i16 %7, %19, %28, %7\n\t"
+        "v_dot2_i32_i16 %8, %20, %28, %8\n\t"
+        "v_dot2_i32_i16 %3, %21, %29, %3\n\t"
+        "v_dot2_i32_i16 %4, %22, %29, %4\n\t"
+        "v_dot2_i32_i16 %5, %23, %29, %5\n\t"
+        "v_dot2_i32_i16 %6, %24, %29, %6\n\t"
+        "v_dot2_i32_i16 %7, %25, %29, %7\n\t"
+        "v_dot2_i32_i16 %8, %26, %29, %8\n\t"
+        "v_ashrrev_i32 %3, %31, %3\n\t"
+        "v_ashrrev_i32 %4, %31, %4\n\t"
+        "v_ashrrev_i32 %5, %31, %5\n\t"
+        "v_ashrrev_i32 %6, %31, %6\n\t"
+        "v_ashrrev_i32 %7, %31, %7\n\t"
+        "v_ashrrev_i32 %8, %31, %8\n\t"
+        "v_cvt_pk_i16_i32 %0, %3, %4\n\t"
+        "v_cvt_pk_i16_i32 %1, %5, %6\n\t"
+        "v_cvt_pk_i16_i32 %2, %7, %8\n\t"
+        "v_pk_max_i16 %0, %0, 0\n\t"
+        "v_pk_max_i16 %1, %1, 0\n\t"
+        "v_pk_max_i16 %2, %2, 0\n\t"
+        "v_pk_min_i16 %0, %0, %32\n\t"
+        "v_pk_min_i16 %1, %1, %32\n\t"
+        "v_pk_min_i16 %2, %2, %32\n\t"
+        "v_pk_lshlrev_b16 %0, %33, %0\n\t"
+        "v_pk_lshlrev_b16 %1, %33, %1\n\t"
+        "v_pk_lshlrev_b16 %2, %33, %2"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5)
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]),
+          "v"(pc[0]), "v"(pc[1]), "v"(pc[2]), "v"(pc[3]), "v"(pc[4]), "v"(pc[5]), "s"(c0), "s"(c1), "s"(c2), "v"(seed), "s"(sh), "s"(maxpk), "s"(msb));
+}
+
+/* where the 6-tap window of output j of a period starts, from the period's first source sample: floor(((2j + 1) PIN - POUT) / (2 POUT)) - 2 */
+template <int PIN, int POUT>
+__host__ __device__ constexpr int d3_off(int j)
+{
+    const int n = (2 * j + 1) * PIN - POUT;
+    return (n >= 0 ? n / (2 * POUT) : -((-n + 2 * POUT - 1) / (2 * POUT))) - 2;
+}
+
+/* PIN source samples become POUT outputs: (3, 2) — 1080p -> 720p, 4K -> 1440p — and (4, 3) — 1440p -> 1080p.  A lane owns NO = 2 POUT
+ * outputs: two periods of a plane (2 PIN source samples + 4 of halo = PIN + 2 dwords at byte 4 PIN g - 4), one period x two channels of a
+ * pair (PIN columns + 4 of halo = PIN + 4 dwords at byte 4 PIN g - 8).  Output y = POUT m + j ends on source row PIN m + off(j) + 5 and reads
+ * P(that - 5), P(that - 3), P(that - 1); which outputs end on which row of a trip of T = lcm(6, PIN) rows is compile-time arithmetic. */
+template <int PIN, int POUT, int PAIR>
 __device__ __forceinline__ void d32h_unit(const FFHipD32Args &A, const FFHipD32Job &J, int frame, int gbase, int strip, int lane)
 {
-    constexpr int NW = PAIR ? 7 : 5; /* dwords of a source row under this lane's windows */
+    constexpr int NO = 2 * POUT, NW = PAIR ? PIN + 4 : PIN + 2;
     const int graw = gbase + lane;
     const bool act = graw < J.ngroups;
     const int g = min(graw, J.ngroups - 1);
     const bool lb = g == 0, rb = g == J.ngroups - 1;
     const bool border = gbase == 0 || gbase + 64 >= J.ngroups; /* wave-uniform */
-    /* plane: samples 6g - 2 .. 6g + 7; pair: columns 3g - 2 .. 3g + 4.  The first / last lane of a row loads one dword (pair: two)
-     * further inside and rebuilds the replicated ones */
-    const uint32_t soff = PAIR ? (uint32_t)(lb ? 0 : 12 * g - 8 - (rb ? 8 : 0)) : (uint32_t)(lb ? 0 : 12 * g - 4 - (rb ? 4 : 0));
+    /* the first / last lane of a row loads one dword (pair: two) further inside and rebuilds the replicated ones */
+    const uint32_t soff = PAIR ? (uint32_t)(lb ? 0 : 4 * PIN * g - 8 - (rb ? 8 : 0)) : (uint32_t)(lb ? 0 : 4 * PIN * g - 4 - (rb ? 4 : 0));
     const int hsh = A.sdepth - 1, smsb = A.smsb ? 16 - A.sdepth : 0;
     const uint32_t dmsb = (uint32_t)(A.dmsb ? 16 - A.ddepth : 0) * 0x00010001u;
     const int vsh = 27 - A.ddepth, vseed = 1 << (26 - A.ddepth);
     const uint32_t maxpk = (uint32_t)((1 << A.ddepth) - 1) * 0x00010001u;
-    uint32_t cf[4][3];
+    uint32_t cf[NO][3];
     {
-        /* plane: outputs 4g .. 4g + 3; pair: columns 2g, 2g + 1, both channels of a column share its coefficients */
-        const uint32_t *p = J.hfv + (size_t)g * (PAIR ? 6 : 12);
+        const uint32_t *p = J.hfv + (size_t)g * (PAIR ? 3 * POUT : 3 * NO);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NO; j++)
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 cf[j][k] = p[3 * (PAIR ? j >> 1 : j) + k];
@@ -388,15 +479,21 @@ __device__ __forceinline__ void d32h_unit(const FFHipD32Args &A, const FFHipD32J
         const uint8_t *p = sbase + (ptrdiff_t)min(max(r, 0), srcH - 1) * sstride;
         const d3_u4 v = *(d3_gc4)((d3_gcp)p + soff);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        if (PAIR) {
+        if (NW == 5) {
+            w[4] = *(d3_gc1)((d3_gcp)p + soff + 16);
+        } else if (NW == 6) {
             const d3_u2 e = *(d3_gc2)((d3_gcp)p + soff + 16);
-            w[4] = e.x; w[5] = e.y;
+            w[4] = e.x; w[5 % NW] = e.y;
+        } else if (NW == 7) {
+            const d3_u2 e = *(d3_gc2)((d3_gcp)p + soff + 16);
+            w[4] = e.x; w[5 % NW] = e.y;
             w[NW - 1] = *(d3_gc1)((d3_gcp)p + soff + 24);
         } else {
-            w[4] = *(d3_gc1)((d3_gcp)p + soff + 16);
+            const d3_u4 e = *(d3_gc4)((d3_gcp)p + soff + 16);
+            w[4] = e.x; w[5 % NW] = e.y; w[6 % NW] = e.z; w[7 % NW] = e.w;
         }
     };
-    auto hpass = [&](const uint32_t (&raw)[NW], int (&h)[4]) {
+    auto hpass = [&](const uint32_t (&raw)[NW], int (&h)[NO]) {
         uint32_t w[NW];
 #pragma unroll
         for (int i = 0; i < NW; i++)
@@ -407,7 +504,7 @@ __device__ __forceinline__ void d32h_unit(const FFHipD32Args &A, const FFHipD32J
                 for (int i = 0; i < NW; i++)
                     w[i] = lb ? raw[i < 2 ? 0 : i - 2] : rb ? raw[i + 2 < NW ? i + 2 : NW - 1] : raw[i];
             } else {
-                const uint32_t f0 = __builtin_amdgcn_perm(raw[0], raw[0], 0x01000100u), fl = __builtin_amdgcn_perm(raw[4], raw[4], 0x03020302u);
+                const uint32_t f0 = __builtin_amdgcn_perm(raw[0], raw[0], 0x01000100u), fl = __builtin_amdgcn_perm(raw[NW - 1], raw[NW - 1], 0x03020302u);
 #pragma unroll
                 for (int i = 0; i < NW; i++)
                     w[i] = lb ? (i ? raw[i - 1] : f0) : rb ? (i + 1 < NW ? raw[i + 1] : fl) : raw[i];
@@ -418,93 +515,114 @@ __device__ __forceinline__ void d32h_unit(const FFHipD32Args &A, const FFHipD32J
             for (int i = 0; i < NW; i++)
                 w[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(d3_h2, w[i]) >> (unsigned short)smsb);
         }
-        uint32_t p[4][3];
+        uint32_t p[NO][3];
         if (PAIR) {
-            /* column j = 0, 1 of the lane's period reads columns j .. j + 5 from the lane's base */
+            /* column j of the lane's period reads columns off(j) + 2 .. + 5 more from the lane's base */
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < POUT; j++)
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    p[2 * j][k] = __builtin_amdgcn_perm(w[j + 2 * k + 1], w[j + 2 * k], 0x05040100u);
-                    p[2 * j + 1][k] = __builtin_amdgcn_perm(w[j + 2 * k + 1], w[j + 2 * k], 0x07060302u);
+                    const int c0 = d3_off<PIN, POUT>(j) + 2 + 2 * k;
+                    p[2 * j][k] = __builtin_amdgcn_perm(w[c0 + 1], w[c0], 0x05040100u);
+                    p[2 * j + 1][k] = __builtin_amdgcn_perm(w[c0 + 1], w[c0], 0x07060302u);
                 }
         } else {
-            /* output x = 2k + j of the lane reads samples 3k + j .. 3k + j + 5 from the lane's base: the starts 0, 1, 3, 4 */
-            uint32_t o[4];
+            /* output i = POUT k + j of the lane reads samples s .. s + 5, s = PIN k + off(j) + 2 from the lane's base */
+            uint32_t o[NW - 1];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < NW - 1; i++)
                 o[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], 16);
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                p[0][k] = w[k];
-                p[1][k] = o[k];
-                p[2][k] = o[k + 1];
-                p[3][k] = w[k + 2];
-            }
+            for (int i = 0; i < NO; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int s0 = PIN * (i / POUT) + d3_off<PIN, POUT>(i % POUT) + 2 + 2 * k;
+                    p[i][k] = (s0 & 1) ? o[s0 >> 1] : w[s0 >> 1];
+                }
         }
-        d3_h4s(h[0], h[1], h[2], h[3], p, cf, hsh);
+        if (NO == 4)
+            d3_h4s(h[0], h[1], h[2], h[3 % NO], reinterpret_cast<const uint32_t (&)[4][3]>(p), reinterpret_cast<const uint32_t (&)[4][3]>(cf), hsh);
+        else
+            d3_h6s(h, p, cf, hsh);
     };
 
-    const int rbase0 = 3 * (a >> 1) - 6, r_last = 3 * (b >> 1) + 1, dstH = J.dstH;
-    uint32_t ring[6][4];
-    int hprev[4];
+    constexpr int T = PIN % 2 ? 2 * PIN : (PIN % 3 ? 3 * PIN : PIN); /* lcm(6, PIN) for PIN = 3, 4 */
+    const int rbase0 = PIN * (a / POUT) - T, r_last = PIN * (b / POUT - 1) + d3_off<PIN, POUT>(POUT - 1) + 5, dstH = J.dstH;
+    uint32_t ring[6][NO];
+    int hprev[NO];
 #pragma unroll
-    for (int c = 0; c < 4; c++)
+    for (int c = 0; c < NO; c++)
         hprev[c] = 0;
 #pragma unroll
     for (int s = 0; s < 6; s++)
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < NO; c++)
             ring[s][c] = 0;
     constexpr int D = 3; /* source rows in flight */
     uint32_t nxt[D][NW];
 #pragma unroll
     for (int i = 0; i < D; i++)
-        load_row(rbase0 + 4 + i, nxt[(4 + i) % D]);
+        load_row(rbase0 + T - 2 + i, nxt[(T - 2 + i) % D]);
     typedef const uint32_t __attribute__((address_space(4))) *d3_cc;
     const d3_cc vt = (d3_cc)J.vfv;
-    const uint32_t doff = 8u * (uint32_t)g;
+    const uint32_t doff = (uint32_t)(2 * NO) * (uint32_t)g;
 
-#define D3H_STEP(u, EMIT)                                                                                                                \
-    {                                                                                                                                    \
-        const int r = rbase + (u);                                                                                                       \
-        uint32_t cur[NW];                                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < NW; i++) cur[i] = nxt[(u) % D][i];                                                        \
-        load_row(r + D, nxt[(u) % D]);                                                                                                   \
-        int h[4];                                                                                                                        \
-        hpass(cur, h);                                                                                                                   \
-        _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                                                 \
-            ring[((u) + 5) % 6][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));                         \
-            hprev[c] = h[c];                                                                                                             \
-        }                                                                                                                                \
-        if (EMIT && (u) % 3 != 2) {                                                                                                      \
-            const int y = (u) % 3 == 0 ? 2 * (r / 3) - 2 : 2 * ((r - 1) / 3) - 1;                                                        \
-            const int yc = min(max(y, 0), dstH - 1);                                                                                     \
-            uint32_t o0, o1;                                                                                                             \
-            d3_v4h(o0, o1, ring[((u) + 1) % 6], ring[((u) + 3) % 6], ring[((u) + 5) % 6], vt[4 * yc], vt[4 * yc + 1], vt[4 * yc + 2], vseed, vsh, \
-                   maxpk, dmsb);                                                                                                         \
-            if (act && y >= a && y < b)                                                                                                  \
-                *(d3_g2)((d3_gp)(dbase + (ptrdiff_t)y * dstride) + doff) = (d3_u2){ o0, o1 };                                            \
-        }                                                                                                                                \
+    auto emit = [&](int y, const uint32_t (&p0)[NO], const uint32_t (&p1)[NO], const uint32_t (&p2)[NO]) {
+        const int yc = min(max(y, 0), dstH - 1);
+        uint32_t o[NO / 2];
+        if (NO == 4)
+            d3_v4h(o[0], o[1], reinterpret_cast<const uint32_t (&)[4]>(p0), reinterpret_cast<const uint32_t (&)[4]>(p1), reinterpret_cast<const uint32_t (&)[4]>(p2),
+                   vt[4 * yc], vt[4 * yc + 1], vt[4 * yc + 2], vseed, vsh, maxpk, dmsb);
+        else
+            d3_v6h(o, p0, p1, p2, vt[4 * yc], vt[4 * yc + 1], vt[4 * yc + 2], vseed, vsh, maxpk, dmsb);
+        if (act && y >= a && y < b) {
+            d3_gp d = (d3_gp)(dbase + (ptrdiff_t)y * dstride) + doff;
+            if (NO == 4) {
+                *(d3_g2)d = (d3_u2){ o[0], o[1] };
+            } else {
+                *(d3_g2)d = (d3_u2){ o[0], o[1] };
+                *(d3_g1)(d + 8) = o[2 % (NO / 2)];
+            }
+        }
+    };
+    auto step = [&](int rbase, auto uc, auto ec) {
+        constexpr int u = decltype(uc)::value;
+        constexpr bool EMIT = decltype(ec)::value;
+        const int r = rbase + u;
+        uint32_t cur[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+            cur[i] = nxt[u % D][i];
+        load_row(r + D, nxt[u % D]);
+        int h[NO];
+        hpass(cur, h);
+        /* P(r - 1) = (row r - 1, row r), int16-saturated = min(., 32767) + truncation (no sum of an admitted bank falls below -32768) */
+#pragma unroll
+        for (int c = 0; c < NO; c++) {
+            ring[(u + 5) % 6][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(hprev[c], h[c]));
+            hprev[c] = h[c];
+        }
+        if (EMIT) {
+#pragma unroll
+            for (int j = 0; j < POUT; j++) {
+                const int e = u - d3_off<PIN, POUT>(j) - 5; /* = PIN m - rbase */
+                if (((e % PIN) + PIN) % PIN == 0)
+                    emit(POUT * ((rbase + e) / PIN) + j, ring[(u + 1) % 6], ring[(u + 3) % 6], ring[(u + 5) % 6]);
+            }
+        }
+    };
+    step(rbase0, std::integral_constant<int, T - 2>(), std::false_type());
+    step(rbase0, std::integral_constant<int, T - 1>(), std::false_type());
+    for (int rbase = rbase0 + T; ; rbase += T) {
+#define D3H_GO(u)                                                       \
+        step(rbase, std::integral_constant<int, u>(), std::true_type()); \
+        if (rbase + (u) + 1 > r_last) return;
+        D3H_GO(0) D3H_GO(1) D3H_GO(2) D3H_GO(3) D3H_GO(4) D3H_GO(5)
+        if constexpr (T == 12) {
+            D3H_GO(6) D3H_GO(7) D3H_GO(8) D3H_GO(9) D3H_GO(10) D3H_GO(11)
+        }
+#undef D3H_GO
     }
-    {
-        const int rbase = rbase0;
-        D3H_STEP(4, false)
-        D3H_STEP(5, false)
-    }
-    for (int rbase = rbase0 + 6; ; rbase += 6) {
-        D3H_STEP(0, true)
-        D3H_STEP(1, true)
-        if (rbase + 2 > r_last)
-            return;
-        D3H_STEP(2, true)
-        D3H_STEP(3, true)
-        D3H_STEP(4, true)
-        if (rbase + 5 > r_last)
-            return;
-        D3H_STEP(5, true)
-    }
-#undef D3H_STEP
 }
 
 __global__ __launch_bounds__(256) void k_sws_down32h(FFHipD32Args A)
@@ -522,10 +640,16 @@ __global__ __launch_bounds__(256) void k_sws_down32h(FFHipD32Args A)
     const FFHipD32Job &J = A.job[j];
     const int local = u - J.unit_begin;
     const int strip = local / J.ncb, cb = local - strip * J.ncb;
-    if (J.pair)
-        d32h_unit<1>(A, J, frame, cb * 64, strip, lane);
-    else
-        d32h_unit<0>(A, J, frame, cb * 64, strip, lane);
+    if (A.ratio43) {
+        if (J.pair)
+            d32h_unit<4, 3, 1>(A, J, frame, cb * 64, strip, lane);
+        else
+            d32h_unit<4, 3, 0>(A, J, frame, cb * 64, strip, lane);
+    } else if (J.pair) {
+        d32h_unit<3, 2, 1>(A, J, frame, cb * 64, strip, lane);
+    } else {
+        d32h_unit<3, 2, 0>(A, J, frame, cb * 64, strip, lane);
+    }
 }
 
 /* ================================================================================================== */
@@ -537,13 +661,13 @@ __global__ __launch_bounds__(256) void k_sws_down32h(FFHipD32Args A)
  * samples; taps the reference folded onto the edge sample land on one of the replicas.  Output: n_dst x `pitch` dwords (pitch 3 or 4),
  * (c0, c1) (c2, c3) (c4, c5) as int16 pairs.  Returns 0 when the bank is not of this shape.
  */
-int ffhip_d32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pitch, std::vector<uint32_t> *out)
+int ffhip_d32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pitch, std::vector<uint32_t> *out, int pin, int pout)
 {
-    if (2 * n_src != 3 * n_dst || fsize < 1 || fsize > 12 || (n_dst & 1) || pitch < 3)
+    if ((long)pout * n_src != (long)pin * n_dst || fsize < 1 || fsize > 12 || (n_dst % pout) || pitch < 3 || !((pin == 3 && pout == 2) || (pin == 4 && pout == 3)))
         return 0;
     out->assign((size_t)n_dst * pitch, 0);
     for (int x = 0; x < n_dst; x++) {
-        const int s0 = 3 * (x >> 1) - 2 + (x & 1);
+        const int s0 = pin == 3 ? 3 * (x >> 1) - 2 + (x & 1) : 4 * (x / 3) + d3_off<4, 3>(x % 3);
         int16_t v[6] = { 0 };
         bool used[6] = { false };
         for (int i = 0; i < fsize; i++) {
@@ -580,12 +704,13 @@ int ffhip_launch_down32(FFHipD32Args &A, hipStream_t stream)
         long long u = 0;
         for (int i = 0; i < A.njobs; i++) {
             FFHipD32Job &j = A.job[i];
-            if (j.ngroups < 3 || j.dstH <= 0 || (j.dstH & 1)) {
+            const int mult = A.hb && A.ratio43 ? 9 : 4; /* a strip starts on a whole trip of source rows */
+            if (j.ngroups < 3 || j.dstH <= 0 || (j.dstH % (A.hb && A.ratio43 ? 3 : 2))) {
                 ffhip_set_error("ffhip_sws: the exact-3:2 kernel takes rows of three groups or more and an even number of output rows");
                 return FFHIP_EINVAL;
             }
             const int n = cdiv(j.dstH, want);
-            j.strip_rows = cdiv(cdiv(j.dstH, n), 4) * 4;
+            j.strip_rows = cdiv(cdiv(j.dstH, n), mult) * mult;
             j.nstrips = cdiv(j.dstH, j.strip_rows);
             j.ncb = cdiv(j.ngroups, 64);
             u += (long long)j.ncb * j.nstrips;

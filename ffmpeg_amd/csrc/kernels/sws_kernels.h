@@ -217,9 +217,10 @@ struct FFHipD32Args {
     /* round 6, the 16-bit twin (k_sws_down32h): samples of 9..14 bits on both sides, as FFHipUp2Job.hb_*; groups are then 8 destination bytes
      * too — plane dstW / 4, pair dstW / 2 */
     int hb, sdepth, ddepth, smsb, dmsb;
+    int ratio43;                        /* the twin's second period: 4 in, 3 out (1440p -> 1080p); groups of 12 destination bytes */
 };
 #ifdef __cplusplus
-int  ffhip_d32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pitch, std::vector<uint32_t> *out);
+int  ffhip_d32_virtual_bank(const int16_t *filter, const int32_t *pos, int fsize, int n_dst, int n_src, int pitch, std::vector<uint32_t> *out, int pin = 3, int pout = 2);
 #endif
 int  ffhip_launch_down32(FFHipD32Args &A, hipStream_t stream);
 

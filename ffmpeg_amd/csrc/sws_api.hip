@@ -513,11 +513,11 @@ static void dn2_build(FFHipSwsContext *c, const int nsrc[4])
 
 /* exact 3:2: the banks (up to 6 taps) as virtual banks on the windows 3 (x >> 1) - 2 + (x & 1) .. + 5 of the edge-replicated rows, on the
  * device; sets c->d32_ok when every bank row is of that shape (sws_down32.hip) */
-static void d32_build(FFHipSwsContext *c, const int nsrc[4])
+static void d32_build(FFHipSwsContext *c, const int nsrc[4], int pin = 3, int pout = 2)
 {
     std::vector<uint32_t> vb[4];
     for (int i = 0; i < 4; i++)
-        if (!ffhip_d32_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], i < 2 ? 3 : 4, &vb[i]))
+        if (!ffhip_d32_virtual_bank(c->f[i].data(), c->p[i].data(), c->d[i].size, c->d[i].n, nsrc[i], i < 2 ? 3 : 4, &vb[i], pin, pout))
             return;
     size_t uo[4], ut = 0;
     for (int i = 0; i < 4; i++) {
@@ -534,7 +534,7 @@ static void d32_build(FFHipSwsContext *c, const int nsrc[4])
     c->d32_h[1] = reinterpret_cast<const uint32_t *>(b + uo[1]);
     c->d32_v[0] = reinterpret_cast<const uint32_t *>(b + uo[2]);
     c->d32_v[1] = reinterpret_cast<const uint32_t *>(b + uo[3]);
-    c->d32_ok = 1;
+    c->d32_ok = pin == 3 ? 1 : 2;
 }
 
 /* exact 3:2 up above 8 bits: the banks (up to 4 taps) as virtual banks on the windows 2 (x / 3) - 2 + x % 3 .. + 3 of the edge-replicated rows, on
@@ -819,6 +819,12 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                 !(t->dstW & 3) && t->dstW >= 12 && !(t->dstH & 1) && !(cdh & 1) && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
                 d32_build(c, limits);
+            /* ... and exact 4:3 down (1440p -> 1080p): the twin's second period */
+            if (!c->d32_ok && sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl == dl && sl != 2 && !hrgb && !c->flat_dither && t->src_range == t->dst_range &&
+                3 * t->srcW == 4 * t->dstW && 3 * t->srcH == 4 * t->dstH && 3 * cw == 4 * cdw && 3 * chh == 4 * cdh &&
+                !(t->dstW % 6) && t->dstW >= 18 && !(t->dstH % 3) && !(cdh % 3) && (sl ? !(cdw % 3) && cdw >= 9 : !(cdw % 6) && cdw >= 18) &&
+                bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
+                d32_build(c, limits, 4, 3);
             /* every other ratio between 9..14-bit formats whose banks have at most 8 taps: the 16-bit column walker (sws_walk16.hip);
              * no range change (it carries no range stage), no 8-bit side */
             /* (round 5: also an 8-bit planar / NV12 target fed from a 9..14-bit source — a 10-bit decoder's frames for an 8-bit consumer:
@@ -1590,13 +1596,15 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
             memset(&D, 0, sizeof(D));
             D.nframes = nframes;
             D.hb = 1; D.sdepth = sd; D.ddepth = dd; D.smsb = sl == 1; D.dmsb = dl == 1;
+            D.ratio43 = c->d32_ok == 2;
+            const int pin = D.ratio43 ? 4 : 3, pout = D.ratio43 ? 3 : 2;
             auto d3job = [&](int which, int plane, int dw_, int sh_, int pair) {
                 FFHipD32Job &j = D.job[D.njobs++];
                 j.src = static_cast<const uint8_t *>(src[plane]); j.dst = static_cast<uint8_t *>(dst[plane]);
                 j.sstride = srcStride[plane]; j.dstride = dstStride[plane]; j.sfp = srcFramePitch[plane]; j.dfp = dstFramePitch[plane];
                 j.pair = pair; j.swap = 0;
-                j.srcH = sh_; j.dstH = sh_ / 3 * 2;
-                j.ngroups = pair ? dw_ / 2 : dw_ / 4;
+                j.srcH = sh_; j.dstH = sh_ / pin * pout;
+                j.ngroups = pair ? dw_ / pout : dw_ / (2 * pout);
                 j.hfv = c->d32_h[which]; j.vfv = c->d32_v[which];
             };
             d3job(0, 0, c->d[0].n, t.srcH, 0);

@@ -251,6 +251,16 @@ DOWN32H_CASES = [
     ("yuv420p14le", 144, 54, "yuv420p9le", 96, 36, ffi.SWS_BICUBIC),
     ("yuv420p12le", 144, 54, "yuv420p12le", 96, 36, ffi.SWS_AREA),
     ("yuv420p10le", 144, 450, "yuv420p10le", 96, 300, ffi.SWS_BICUBIC),      # several strips of rows
+    # exact 4:3 down (1440p -> 1080p): period (4 in, 3 out) of the same kernel
+    ("yuv420p10le", 48, 72, "yuv420p10le", 36, 54, ffi.SWS_BICUBIC),        # three groups per chroma row
+    ("yuv420p10le", 192, 80, "yuv420p10le", 144, 60, ffi.SWS_BILINEAR),
+    ("p010le", 192, 80, "p010le", 144, 60, ffi.SWS_BICUBIC),
+    ("p012le", 96, 72, "p012le", 72, 54, ffi.SWS_POINT),
+    ("yuv420p10le", 1056, 152, "yuv420p10le", 792, 114, ffi.SWS_BICUBIC),    # 132 / 66 groups: ragged blocks
+    ("p010le", 1056, 88, "p010le", 792, 66, ffi.SWS_BICUBIC),
+    ("yuv444p10le", 96, 72, "yuv444p10le", 72, 54, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 192, 72, "yuv420p12le", 144, 54, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 192, 440, "yuv420p10le", 144, 330, ffi.SWS_BICUBIC),     # several strips of rows
 ]
 
 
