@@ -355,6 +355,41 @@ __device__ __forceinline__ void d3_v4h(uint32_t &w0, uint32_t &w1, const uint32_
           "s"(c0), "s"(c1), "s"(c2), "v"(seed), "s"(sh), "s"(maxpk), "s"(msb));
 }
 
+/* ff_dither_8x8_128 (libswscale/swscale.c:42-52): the ordered dither of an 8-bit target fed from a deeper source (swscale.c:291,519-522) */
+__constant__ __attribute__((aligned(8))) uint8_t d3_dither[8][8] = {
+    {  36, 68,  60, 92,  34, 66,  58, 90, }, { 100,  4, 124, 28,  98,  2, 122, 26, }, {  52, 84,  44, 76,  50, 82,  42, 74, },
+    { 116, 20, 108, 12, 114, 18, 106, 10, }, {  32, 64,  56, 88,  38, 70,  62, 94, }, {  96,  0, 120, 24, 102,  6, 126, 30, },
+    {  48, 80,  40, 72,  54, 86,  46, 78, }, { 112, 16, 104,  8, 118, 22, 110, 14, },
+};
+/* four output BYTES from 15-bit lines (a 10-bit decoder's frames for an 8-bit consumer): t[i] = (dither[i] << 12) + pa[i] . c0 + pb[i] . c1 +
+ * pc[i] . c2, clip_u8(t[i] >> 19) (yuv2planeX_8_c / yuv2nv12cX_c, libswscale/output.c:468-529) */
+__device__ __forceinline__ uint32_t d3_v4d(const uint32_t (&pa)[4], const uint32_t (&pb)[4], const uint32_t (&pc)[4], uint32_t c0, uint32_t c1, uint32_t c2,
+                                           const int (&sd)[4])
+{
+    uint32_t out;
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %1, %5, %17, %20\n\t"
+        "v_dot2_i32_i16 %2, %6, %17, %21\n\t"
+        "v_dot2_i32_i16 %3, %7, %17, %22\n\t"
+        "v_dot2_i32_i16 %4, %8, %17, %23\n\t"
+        "v_dot2_i32_i16 %1, %9, %18, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %18, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %18, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %18, %4\n\t"
+        "v_dot2_i32_i16 %1, %13, %19, %1\n\t"
+        "v_dot2_i32_i16 %2, %14, %19, %2\n\t"
+        "v_dot2_i32_i16 %3, %15, %19, %3\n\t"
+        "v_dot2_i32_i16 %4, %16, %19, %4\n\t"
+        "s_nop 0\n\t"
+        "v_ashr_pk_u8_i32 %0, %1, %2, 19\n\t"
+        "s_nop 1\n\t"
+        "v_ashr_pk_u8_i32 %0, %3, %4, 19 op_sel:[0,0,0,1]"
+        : "=&v"(out), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pc[0]), "v"(pc[1]), "v"(pc[2]), "v"(pc[3]),
+          "s"(c0), "s"(c1), "s"(c2), "v"(sd[0]), "v"(sd[1]), "v"(sd[2]), "v"(sd[3]));
+    return out;
+}
+
 /* six-chain forms of the two blocks (the 4:3 period: six outputs per lane) */
 __device__ __forceinline__ void d3_h6s(int *d, const uint32_t (*p)[3], const uint32_t (*c)[3], int sh)
 {
@@ -457,6 +492,7 @@ __device__ __forceinline__ void d32h_unit(const FFHipD32Args &A, const FFHipD32J
     /* the first / last lane of a row loads one dword (pair: two) further inside and rebuilds the replicated ones */
     const uint32_t soff = PAIR ? (uint32_t)(lb ? 0 : 4 * PIN * g - 8 - (rb ? 8 : 0)) : (uint32_t)(lb ? 0 : 4 * PIN * g - 4 - (rb ? 4 : 0));
     const int hsh = A.sdepth - 1, smsb = A.smsb ? 16 - A.sdepth : 0;
+    const bool to8 = A.ddepth == 8; /* (3, 2) only: the host does not ask for it at (4, 3) */
     const uint32_t dmsb = (uint32_t)(A.dmsb ? 16 - A.ddepth : 0) * 0x00010001u;
     const int vsh = 27 - A.ddepth, vseed = 1 << (26 - A.ddepth);
     const uint32_t maxpk = (uint32_t)((1 << A.ddepth) - 1) * 0x00010001u;
@@ -569,6 +605,21 @@ __device__ __forceinline__ void d32h_unit(const FFHipD32Args &A, const FFHipD32J
 
     auto emit = [&](int y, const uint32_t (&p0)[NO], const uint32_t (&p1)[NO], const uint32_t (&p2)[NO]) {
         const int yc = min(max(y, 0), dstH - 1);
+        if (NO == 4 && to8) { /* uniform: an 8-bit target, four bytes per lane with the ordered dither's entry of every sample — (x + offset) & 7,
+                               * offset 3 for the V channel / plane (yuv2nv12cX_c, vscale.c's chroma call) */
+            const uint2 drow = *reinterpret_cast<const uint2 *>(d3_dither[yc & 7]);
+            int sdv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int idx = (PAIR ? 2 * g + (i >> 1) + ((i & 1) ? 3 : 0) : 4 * g + i + J.dither_off) & 7;
+                sdv[i] = (int)((((idx >= 4 ? drow.y : drow.x) >> (8 * (idx & 3))) & 255u) << 12);
+            }
+            const uint32_t o8 = d3_v4d(reinterpret_cast<const uint32_t (&)[4]>(p0), reinterpret_cast<const uint32_t (&)[4]>(p1),
+                                       reinterpret_cast<const uint32_t (&)[4]>(p2), vt[4 * yc], vt[4 * yc + 1], vt[4 * yc + 2], sdv);
+            if (act && y >= a && y < b)
+                *(d3_g1)((d3_gp)(dbase + (ptrdiff_t)y * dstride) + 4u * (uint32_t)g) = o8;
+            return;
+        }
         uint32_t o[NO / 2];
         if (NO == 4)
             d3_v4h(o[0], o[1], reinterpret_cast<const uint32_t (&)[4]>(p0), reinterpret_cast<const uint32_t (&)[4]>(p1), reinterpret_cast<const uint32_t (&)[4]>(p2),

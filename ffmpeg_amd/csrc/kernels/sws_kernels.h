@@ -210,6 +210,7 @@ struct FFHipD32Job {
     const uint32_t *hfv;                /* device: virtual horizontal bank, dstW x 3 dwords */
     const uint32_t *vfv;                /* device: virtual vertical bank, dstH x 4 dwords */
     int ncb, nstrips, strip_rows, unit_begin;
+    int dither_off;                     /* the 16-bit twin into an 8-bit target, plane jobs: 3 for the V plane (its dither row is read three entries on) */
 };
 struct FFHipD32Args {
     FFHipD32Job job[3];

@@ -814,7 +814,8 @@ extern "C" FFHipSwsContext *ffhip_sws_from_tables(const FFHipSwsTables *t)
                     c->widen8 = 1;
             }
             /* ... and exact 3:2 DOWN (1080p -> 720p, 4K -> 1440p) between 9..14-bit formats laid out alike: the 16-bit twin of sws_down32.hip */
-            if (sd > 8 && sd <= 14 && dd > 8 && dd <= 14 && sl == dl && sl != 2 && !hrgb && !c->flat_dither && t->src_range == t->dst_range &&
+            /* (also into an 8-bit target laid out alike — P01x -> NV12, planar -> planar — with the ordered dither on the way out, as `dn8` above) */
+            if (sd > 8 && sd <= 14 && ((dd > 8 && dd <= 14 && sl == dl) || dn8) && sl != 2 && !hrgb && !c->flat_dither && t->src_range == t->dst_range &&
                 2 * t->srcW == 3 * t->dstW && 2 * t->srcH == 3 * t->dstH && 2 * cw == 3 * cdw && 2 * chh == 3 * cdh &&
                 !(t->dstW & 3) && t->dstW >= 12 && !(t->dstH & 1) && !(cdh & 1) && (sl ? !(cdw & 1) && cdw >= 6 : !(cdw & 3) && cdw >= 12) &&
                 bank_nowrap_depth(c->f[0].data(), c->d[0].n, sd, c->d[0].size) && bank_nowrap_depth(c->f[1].data(), c->d[1].n, sd, c->d[1].size))
@@ -1606,6 +1607,7 @@ static int scale16(FFHipSwsContext *c, int nframes, const void *const src[4], co
                 j.srcH = sh_; j.dstH = sh_ / pin * pout;
                 j.ngroups = pair ? dw_ / pout : dw_ / (2 * pout);
                 j.hfv = c->d32_h[which]; j.vfv = c->d32_v[which];
+                j.dither_off = plane == 2 ? 3 : 0;
             };
             d3job(0, 0, c->d[0].n, t.srcH, 0);
             if (sl) {

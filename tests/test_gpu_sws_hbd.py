@@ -251,6 +251,12 @@ DOWN32H_CASES = [
     ("yuv420p14le", 144, 54, "yuv420p9le", 96, 36, ffi.SWS_BICUBIC),
     ("yuv420p12le", 144, 54, "yuv420p12le", 96, 36, ffi.SWS_AREA),
     ("yuv420p10le", 144, 450, "yuv420p10le", 96, 300, ffi.SWS_BICUBIC),      # several strips of rows
+    # ... into an 8-bit target laid out alike, with the ordered dither (a 10-bit decoder's 1080p frames for a 720p 8-bit consumer)
+    ("p010le", 144, 60, "nv12", 96, 40, ffi.SWS_BICUBIC),
+    ("yuv420p10le", 144, 54, "yuv420p", 96, 36, ffi.SWS_BICUBIC),
+    ("yuv420p12le", 1560, 186, "yuv420p", 1040, 124, ffi.SWS_BILINEAR),
+    ("p010le", 780, 78, "nv12", 520, 52, ffi.SWS_BICUBIC),
+    ("yuv444p10le", 72, 54, "yuv444p", 48, 36, ffi.SWS_BICUBIC),
     # exact 4:3 down (1440p -> 1080p): period (4 in, 3 out) of the same kernel
     ("yuv420p10le", 48, 72, "yuv420p10le", 36, 54, ffi.SWS_BICUBIC),        # three groups per chroma row
     ("yuv420p10le", 192, 80, "yuv420p10le", 144, 60, ffi.SWS_BILINEAR),

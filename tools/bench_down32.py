@@ -11,7 +11,7 @@ from ffmpeg_amd import swscale as S  # noqa: E402
 dev = torch.device("cuda:0")
 for name, sf, sw, sh, df, dw, dh, n in (("nv12 1080p->720p", 23, 1920, 1080, 23, 1280, 720, 64), ("yuv420p 1080p->720p", 0, 1920, 1080, 0, 1280, 720, 64),
                                         ("nv12 4K->1440p", 23, 3840, 2160, 23, 2560, 1440, 16), ("p010 4K->1440p", 158, 3840, 2160, 158, 2560, 1440, 16),
-                                        ("yuv420p10 1080p->720p", 62, 1920, 1080, 62, 1280, 720, 64), ("p010 1440p->1080p", 158, 2560, 1440, 158, 1920, 1080, 32),
+                                        ("yuv420p10 1080p->720p", 62, 1920, 1080, 62, 1280, 720, 64), ("p010 1440p->1080p", 158, 2560, 1440, 158, 1920, 1080, 32), ("p010 1080p->nv12 720p", 158, 1920, 1080, 23, 1280, 720, 64),
                                         ("yuv420p10 1440p->1080p", 62, 2560, 1440, 62, 1920, 1080, 32),
                                         # exact 2:1 (k_sws_down2) beside them
                                         ("nv12 4K->1080p", 23, 3840, 2160, 23, 1920, 1080, 64), ("p010 4K->1080p", 158, 3840, 2160, 158, 1920, 1080, 16),
