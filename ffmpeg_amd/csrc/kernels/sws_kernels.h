@@ -518,6 +518,17 @@ struct FFHipRgbInArgs {
     int ry, gy, by, ru, gu, bu, rv, gv, bv; /* input_rgb2yuv_table (swscale_internal.h:468-477) */
     uint8_t *y8; ptrdiff_t y8_stride; size_t y8_fp; /* non-null: the target's 8-bit luma plane is written instead of dst[0] (identity luma banks) */
 };
+/* k_sws_rgb420 (sws_rgbin.hip): a packed RGB source into yuv420p / NV12 at the source's size, fused; `in` as for k_sws_rgb_in with y8 = the luma plane */
+struct FFHipRgb420Args {
+    FFHipRgbInArgs in;
+    uint8_t *cdst[2];            /* NV12: the interleaved plane; planar: U, V */
+    ptrdiff_t cstride;
+    size_t cfp;
+    int chrH;                    /* chroma rows = h / 2 */
+    const uint32_t *vfv;         /* device: the vertical chroma bank on the windows 2y - 3 .. 2y + 4, (chrH + 8) x 4 dwords */
+    int nframes, ncb, nstrips, steps_per_strip;
+};
+int ffhip_launch_sws_rgb420(FFHipRgb420Args &A, int bpp, int nv, hipStream_t stream);
 int ffhip_launch_sws_rgb_in(const FFHipRgbInArgs &a, int bpp, int half, int nframes, hipStream_t stream);
 /* an 8-bit plane (wbytes bytes per row; an interleaved pair plane: both channels) as 16-bit samples: dst rows of 2 * wbytes bytes, 16-byte aligned */
 int ffhip_launch_sws_widen8(const uint8_t *src, ptrdiff_t sstride, size_t sfp, uint8_t *dst, ptrdiff_t dstride, size_t dfp, int wbytes, int rows,

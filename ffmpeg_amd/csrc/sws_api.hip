@@ -20,6 +20,8 @@
 struct FFHipSwsRgbIn {
     int bpp = 0;            /* 0: none; 3 / 4 bytes per pixel */
     int half = 0;           /* the chroma converters average pixel pairs (4:2:2 lines) */
+    int fused420 = 0;       /* ... and the chroma too: RGB -> yuv420p / NV12 at the source's size in one kernel (k_sws_rgb420); vfv: its vertical chroma bank on the device */
+    uint32_t *vfv = nullptr;
     int y_direct = 0;       /* identity luma banks into an 8-bit plane on the walker: the converter pass writes the target's luma, the walker the chroma */
     int fmt = 0;            /* the caller's source format */
     int ofs[3] = { 0, 0, 0 };
@@ -1252,6 +1254,20 @@ static void rgb_in_plan_luma(FFHipSwsContext *c)
     for (int y = 0; id && y < t.dstH; y++)
         id = c->f[2][(size_t)y] == 4096 && c->p[2][(size_t)y] == y;
     c->rgb_in.y_direct = id;
+    /* the whole conversion in one kernel (round 6): 4:2:0 target, chroma read at half width through the identity bank, 2:1 down the rows on
+     * a bank of the exact-2:1 shape, the flat seed 64 */
+    bool f4 = id && c->rgb_in.half && c->flat_dither == 1 && !(t.srcW & 3) && t.srcW >= 4 && !(t.srcH & 1) && c->chrSrcH == t.srcH &&
+              c->d[3].n * 2 == t.srcH && c->d[1].n * 2 == t.srcW && c->d[1].size == 1 &&
+              (t.dstFormat == FFHIP_PIX_FMT_NV12 || t.dstFormat == FFHIP_PIX_FMT_YUV420P) && !c->rgb_in.vfv;
+    for (int x = 0; f4 && x < c->d[1].n; x++)
+        f4 = c->f[1][(size_t)x] == 16384 && c->p[1][(size_t)x] == x;
+    std::vector<uint32_t> vb;
+    if (f4 && ffhip_down2_virtual_bank(c->f[3].data(), c->p[3].data(), c->d[3].size, c->d[3].n, c->chrSrcH, &vb)) {
+        vb.resize((size_t)(c->d[3].n + 8) * 4, 0);
+        if (hipMalloc(&c->rgb_in.vfv, vb.size() * 4) == hipSuccess &&
+            hipMemcpy(c->rgb_in.vfv, vb.data(), vb.size() * 4, hipMemcpyHostToDevice) == hipSuccess)
+            c->rgb_in.fused420 = 1;
+    }
 }
 
 /* the converter pass of an RGB-source context over `rows` source rows of nframes frames: src -> the 14-bit planes at p[] */
@@ -1374,6 +1390,8 @@ extern "C" void ffhip_sws_freeContext(FFHipSwsContext *c)
         (void)hipFree(c->dev_tables);
     if (c->widen_tmp)
         (void)hipFree(c->widen_tmp);
+    if (c->rgb_in.vfv)
+        (void)hipFree(c->rgb_in.vfv);
     if (c->rgb_in.planes)
         (void)hipFree(c->rgb_in.planes);
     if (c->rgb_in.stage)
@@ -1821,6 +1839,32 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             return FFHIP_EINVAL;
         FFHipDeviceGuard dg(c->device);
         std::lock_guard<std::mutex> lk(c->mu);
+        {
+            /* one kernel for RGB -> yuv420p / NV12 at the source's size (FFHIP_SWS_RGB420=0 in the measure build: the two-stage form) */
+            const char *e4 = FFHIP_KNOB("FFHIP_SWS_RGB420");
+            const bool nv = fmt_nv(c->t.dstFormat);
+            bool ok = c->rgb_in.fused420 && dst && dstStride && dstFramePitch && !(e4 && e4[0] == '0') && srcStride[0] > 0 &&
+                      !(((uintptr_t)src[0] | (uintptr_t)srcStride[0] | srcFramePitch[0]) & 3);
+            for (int pl = 0; ok && pl < (nv ? 2 : 3); pl++)
+                ok = dst[pl] && dstStride[pl] > 0 && !(((uintptr_t)dst[pl] | (uintptr_t)dstStride[pl] | dstFramePitch[pl]) & (pl == 0 || nv ? 3 : 1));
+            ok = ok && (nv || (dstStride[1] == dstStride[2] && dstFramePitch[1] == dstFramePitch[2]));
+            if (ok) {
+                FFHipRgb420Args A;
+                memset(&A, 0, sizeof(A));
+                A.in.src = static_cast<const uint8_t *>(src[0]); A.in.src_stride = srcStride[0]; A.in.src_fp = srcFramePitch[0];
+                A.in.y8 = static_cast<uint8_t *>(dst[0]); A.in.y8_stride = dstStride[0]; A.in.y8_fp = dstFramePitch[0];
+                A.in.w = c->t.srcW; A.in.h = c->t.srcH;
+                A.in.ro = c->rgb_in.ofs[0]; A.in.go = c->rgb_in.ofs[1]; A.in.bo = c->rgb_in.ofs[2];
+                const int32_t *T = c->rgb_in.table;
+                A.in.ry = T[0]; A.in.gy = T[1]; A.in.by = T[2]; A.in.ru = T[3]; A.in.gu = T[4]; A.in.bu = T[5]; A.in.rv = T[6]; A.in.gv = T[7]; A.in.bv = T[8];
+                A.cdst[0] = static_cast<uint8_t *>(dst[1]); A.cdst[1] = nv ? nullptr : static_cast<uint8_t *>(dst[2]);
+                A.cstride = dstStride[1]; A.cfp = dstFramePitch[1];
+                A.chrH = c->t.srcH / 2;
+                A.vfv = c->rgb_in.vfv;
+                A.nframes = nframes;
+                return ffhip_launch_sws_rgb420(A, c->rgb_in.bpp, nv, (hipStream_t)stream_);
+            }
+        }
         const int cw = c->rgb_in.half ? c->t.srcW / 2 : c->t.srcW;
         const int pitch[3] = { ((c->t.srcW * 2) + 255) & ~255, ((cw * 2) + 255) & ~255, ((cw * 2) + 255) & ~255 };
         const size_t fp[3] = { (size_t)pitch[0] * c->t.srcH, (size_t)pitch[1] * c->t.srcH, (size_t)pitch[2] * c->t.srcH };

@@ -79,6 +79,40 @@ def test_batched_device_face(case):
     ctx.close()
 
 
+# RGB -> yuv420p / NV12 at the source's size: one kernel (k_sws_rgb420: luma direct, the chroma's vertical bank on a register ring); "two-stage"
+# runs the same cases on the converter pass + the walker (FFHIP_SWS_RGB420=0, the measure build)
+FUSED = [CASES[0], CASES[6], CASES[8], CASES[13], ("argb", 260, 130, "nv12", 260, 130, ffi.SWS_BICUBIC), ("abgr", 1032, 70, "yuv420p", 1032, 70, ffi.SWS_BICUBIC),
+         ("rgba", 64, 12, "nv12", 64, 12, ffi.SWS_BILINEAR), ("rgb24", 1280, 720, "yuv420p", 1280, 720, ffi.SWS_BICUBIC), ("bgr24", 64, 2, "nv12", 64, 2, ffi.SWS_BICUBIC),
+         ("bgra", 1920, 1080, "yuv420p", 1920, 1080, ffi.SWS_POINT)]
+
+
+@pytest.mark.parametrize("variant", ["product", "two-stage"])
+@pytest.mark.parametrize("case", FUSED, ids=lambda c: "%s_%dx%d_%s_%dx%d_%x" % c)
+def test_rgb_into_420_at_the_source_size(case, variant, monkeypatch):
+    from ffmpeg_amd import swscale as S
+    torch = _torch()
+    if variant == "two-stage":
+        monkeypatch.setenv("FFHIP_SWS_RGB420", "0")
+    sname, sw, sh, dname, dw, dh, flags = case
+    n = 4 if sw < 1000 else 2
+    rng = np.random.default_rng(abs(hash(case)) & 0xFFF)
+    frames = [make_rgb(sname, sw, sh, rng, pad=0) for _ in range(n)]
+    ctx = S.SwsContext(sw, sh, PIX[sname], dw, dh, DST[dname][0], flags)
+    src = S.alloc_batch(PIX[sname], sw, sh, n, "cuda:0")
+    dst = S.alloc_batch(DST[dname][0], dw, dh, n, "cuda:0", fill=7)
+    for f in range(n):
+        src[0][f, :, :frames[f].shape[1]] = torch.from_numpy(frames[f]).cuda()
+    ctx.scale_batch(src, dst)
+    torch.cuda.synchronize()
+    for f in range(n):
+        want, _ = oracle_rgb_scale(sname, frames[f], sw, sh, dname, dw, dh, flags)
+        for i, (a, d) in enumerate(zip(_crop(want, dname, dw, dh), dst)):
+            got = d[f].cpu().numpy()
+            assert np.array_equal(a, got[:, :a.shape[1]]), (f, i)
+            assert (got[:, a.shape[1]:] == 7).all(), (f, i)      # nothing written past the rows' ends
+    ctx.close()
+
+
 def test_golden_vectors_on_the_gpu():
     from ffmpeg_amd import swscale as S
     _torch()
