@@ -517,6 +517,8 @@ struct FFHipRgbInArgs {
     int ro, go, bo;                     /* byte of the component inside a pixel */
     int ry, gy, by, ru, gu, bu, rv, gv, bv; /* input_rgb2yuv_table (swscale_internal.h:468-477) */
     uint8_t *y8; ptrdiff_t y8_stride; size_t y8_fp; /* non-null: the target's 8-bit luma plane is written instead of dst[0] (identity luma banks) */
+    int c8;                             /* with y8: the chroma banks are the identity too (a 4:2:2 / 4:4:4 planar target at the source's size): dst[1], dst[2]
+                                         * are the target's 8-bit chroma planes and nothing else runs */
 };
 /* k_sws_rgb420 (sws_rgbin.hip): a packed RGB source into yuv420p / NV12 at the source's size, fused; `in` as for k_sws_rgb_in with y8 = the luma plane */
 struct FFHipRgb420Args {

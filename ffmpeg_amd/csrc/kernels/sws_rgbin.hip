@@ -92,7 +92,15 @@ __global__ __launch_bounds__(256) void k_sws_rgb_in(FFHipRgbInArgs a)
             u[i] = (uint16_t)((unsigned)(a.ru * r2 + a.gu * g2 + a.bu * b2 + (256 << S) + (1 << (S - 6))) >> (S - 5));
             v[i] = (uint16_t)((unsigned)(a.rv * r2 + a.gv * g2 + a.bv * b2 + (256 << S) + (1 << (S - 6))) >> (S - 5));
         }
-        if (n == 4) {
+        if (a.c8) {
+            /* identity chroma banks: the 8-bit samples as for the luma (min(2 u, 32767) + 64) >> 7, clipped; two bytes per plane */
+            uint8_t *u8 = a.dst[1] + (size_t)f * a.dst_fp[1] + (ptrdiff_t)y * a.dst_stride[1] + 2 * g;
+            uint8_t *v8 = a.dst[2] + (size_t)f * a.dst_fp[2] + (ptrdiff_t)y * a.dst_stride[2] + 2 * g;
+            for (int i = 0; i < n / 2; i++) {
+                u8[i] = clip_u8((min(2 * (int)u[i], 32767) + 64) >> 7);
+                v8[i] = clip_u8((min(2 * (int)v[i], 32767) + 64) >> 7);
+            }
+        } else if (n == 4) {
             *reinterpret_cast<uint32_t *>(U + 2 * g) = u[0] | (uint32_t)u[1] << 16;
             *reinterpret_cast<uint32_t *>(V + 2 * g) = v[0] | (uint32_t)v[1] << 16;
         } else {
@@ -102,7 +110,12 @@ __global__ __launch_bounds__(256) void k_sws_rgb_in(FFHipRgbInArgs a)
     } else {
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (i < n) {
+            if (i < n && a.c8) {
+                const int uu = (int)(uint16_t)((a.ru * r[i] + a.gu * gg[i] + a.bu * b[i] + (256 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
+                const int vv = (int)(uint16_t)((a.rv * r[i] + a.gv * gg[i] + a.bv * b[i] + (256 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
+                (a.dst[1] + (size_t)f * a.dst_fp[1] + (ptrdiff_t)y * a.dst_stride[1])[x0 + i] = clip_u8((min(2 * uu, 32767) + 64) >> 7);
+                (a.dst[2] + (size_t)f * a.dst_fp[2] + (ptrdiff_t)y * a.dst_stride[2])[x0 + i] = clip_u8((min(2 * vv, 32767) + 64) >> 7);
+            } else if (i < n) {
                 U[x0 + i] = (uint16_t)((a.ru * r[i] + a.gu * gg[i] + a.bu * b[i] + (256 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
                 V[x0 + i] = (uint16_t)((a.rv * r[i] + a.gv * gg[i] + a.bv * b[i] + (256 << (S - 1)) + (1 << (S - 7))) >> (S - 6));
             }

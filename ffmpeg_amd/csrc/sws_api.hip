@@ -20,6 +20,7 @@
 struct FFHipSwsRgbIn {
     int bpp = 0;            /* 0: none; 3 / 4 bytes per pixel */
     int half = 0;           /* the chroma converters average pixel pairs (4:2:2 lines) */
+    int direct_c = 0;       /* ... the chroma banks the identity as well (a planar 4:2:2 / 4:4:4 target at the source's size): one elementwise pass */
     int fused420 = 0;       /* ... and the chroma too: RGB -> yuv420p / NV12 at the source's size in one kernel (k_sws_rgb420); vfv: its vertical chroma bank on the device */
     uint32_t *vfv = nullptr;
     int y_direct = 0;       /* identity luma banks into an 8-bit plane on the walker: the converter pass writes the target's luma, the walker the chroma */
@@ -1254,6 +1255,16 @@ static void rgb_in_plan_luma(FFHipSwsContext *c)
     for (int y = 0; id && y < t.dstH; y++)
         id = c->f[2][(size_t)y] == 4096 && c->p[2][(size_t)y] == y;
     c->rgb_in.y_direct = id;
+    /* every bank the identity (round 6): a planar 8-bit target with a chroma sample per converter sample and a chroma row per source row */
+    {
+        bool dc = id && c->flat_dither == 1 && c->chrSrcH == t.srcH && c->d[3].n == t.srcH && c->d[3].size == 1 && c->d[1].size == 1 &&
+                  c->d[1].n == (c->rgb_in.half ? t.srcW / 2 : t.srcW) && !fmt_nv(t.dstFormat) && !t.dst_alpha_fill;
+        for (int x = 0; dc && x < c->d[1].n; x++)
+            dc = c->f[1][(size_t)x] == 16384 && c->p[1][(size_t)x] == x;
+        for (int y = 0; dc && y < c->d[3].n; y++)
+            dc = c->f[3][(size_t)y] == 4096 && c->p[3][(size_t)y] == y;
+        c->rgb_in.direct_c = dc;
+    }
     /* the whole conversion in one kernel (round 6): 4:2:0 target, chroma read at half width through the identity bank, 2:1 down the rows on
      * a bank of the exact-2:1 shape, the flat seed 64 */
     bool f4 = id && c->rgb_in.half && c->flat_dither == 1 && !(t.srcW & 3) && t.srcW >= 4 && !(t.srcH & 1) && c->chrSrcH == t.srcH &&
@@ -1839,6 +1850,23 @@ extern "C" int ffhip_sws_scale_batch_dev(FFHipSwsContext *c, int nframes, const 
             return FFHIP_EINVAL;
         FFHipDeviceGuard dg(c->device);
         std::lock_guard<std::mutex> lk(c->mu);
+        if (c->rgb_in.direct_c && dst && dstStride && dstFramePitch && dst[0] && dst[1] && dst[2] && !FFHIP_KNOB("FFHIP_SWS_RGB_DIRECT_OFF")) {
+            /* every bank the identity: the converter pass writes the three 8-bit planes of the target (FFHipRgbInArgs.c8) */
+            FFHipRgbInArgs a;
+            memset(&a, 0, sizeof(a));
+            a.src = static_cast<const uint8_t *>(src[0]); a.src_stride = srcStride[0]; a.src_fp = srcFramePitch[0];
+            a.y8 = static_cast<uint8_t *>(dst[0]); a.y8_stride = dstStride[0]; a.y8_fp = dstFramePitch[0];
+            a.c8 = 1;
+            for (int i = 1; i < 3; i++) {
+                a.dst[i] = static_cast<uint8_t *>(dst[i]); a.dst_stride[i] = dstStride[i]; a.dst_fp[i] = dstFramePitch[i];
+            }
+            a.dst[0] = a.y8; a.dst_stride[0] = dstStride[0]; a.dst_fp[0] = dstFramePitch[0];
+            a.w = c->t.srcW; a.h = c->t.srcH;
+            a.ro = c->rgb_in.ofs[0]; a.go = c->rgb_in.ofs[1]; a.bo = c->rgb_in.ofs[2];
+            const int32_t *T = c->rgb_in.table;
+            a.ry = T[0]; a.gy = T[1]; a.by = T[2]; a.ru = T[3]; a.gu = T[4]; a.bu = T[5]; a.rv = T[6]; a.gv = T[7]; a.bv = T[8];
+            return ffhip_launch_sws_rgb_in(a, c->rgb_in.bpp, c->rgb_in.half, nframes, (hipStream_t)stream_);
+        }
         {
             /* one kernel for RGB -> yuv420p / NV12 at the source's size (FFHIP_SWS_RGB420=0 in the measure build: the two-stage form) */
             const char *e4 = FFHIP_KNOB("FFHIP_SWS_RGB420");

@@ -83,7 +83,10 @@ def test_batched_device_face(case):
 # runs the same cases on the converter pass + the walker (FFHIP_SWS_RGB420=0, the measure build)
 FUSED = [CASES[0], CASES[6], CASES[8], CASES[13], ("argb", 260, 130, "nv12", 260, 130, ffi.SWS_BICUBIC), ("abgr", 1032, 70, "yuv420p", 1032, 70, ffi.SWS_BICUBIC),
          ("rgba", 64, 12, "nv12", 64, 12, ffi.SWS_BILINEAR), ("rgb24", 1280, 720, "yuv420p", 1280, 720, ffi.SWS_BICUBIC), ("bgr24", 64, 2, "nv12", 64, 2, ffi.SWS_BICUBIC),
-         ("bgra", 1920, 1080, "yuv420p", 1920, 1080, ffi.SWS_POINT)]
+         ("bgra", 1920, 1080, "yuv420p", 1920, 1080, ffi.SWS_POINT),
+         # every bank the identity: planar 4:2:2 / 4:4:4 targets (one elementwise pass; "two-stage": FFHIP_SWS_RGB_DIRECT_OFF in the measure build)
+         CASES[3], ("bgr24", 66, 37, "yuv444p", 66, 37, ffi.SWS_BICUBIC), ("argb", 64, 36, "yuv422p", 64, 36, ffi.SWS_BICUBIC),
+         ("rgb24", 1278, 719, "yuv444p", 1278, 719, ffi.SWS_BILINEAR), ("abgr", 130, 35, "yuv422p", 130, 35, ffi.SWS_BICUBIC)]
 
 
 @pytest.mark.parametrize("variant", ["product", "two-stage"])
@@ -93,6 +96,7 @@ def test_rgb_into_420_at_the_source_size(case, variant, monkeypatch):
     torch = _torch()
     if variant == "two-stage":
         monkeypatch.setenv("FFHIP_SWS_RGB420", "0")
+        monkeypatch.setenv("FFHIP_SWS_RGB_DIRECT_OFF", "1")
     sname, sw, sh, dname, dw, dh, flags = case
     n = 4 if sw < 1000 else 2
     rng = np.random.default_rng(abs(hash(case)) & 0xFFF)
