@@ -453,6 +453,8 @@ def extras(torch, dev, torch_alloc=False):
     # walker on their 14-bit lines: 5.5 algorithmic B / px, 13.5 moved) and 10-bit video for a display (p010 -> bgra: the walker's first stage
     # into the context's intermediate, then k_y16_rgb)
     sws_case("sws_bgra_1080p_to_nv12_1080p_bicubic", 28, 1920, 1080, 23, 1920, 1080, 32)
+    # ... and into a planar 4:4:4 target: every bank the identity, the converter pass writes the target's planes itself (7 B / px)
+    sws_case("sws_bgra_1080p_to_yuv444p_1080p", 28, 1920, 1080, 5, 1920, 1080, 32)
     sws_case("sws_p010_1080p_to_bgra_1080p_bicubic", 158, 1920, 1080, 28, 1920, 1080, 32)
     # ... and an 8-bit source for a 10-bit encoder (planes widened to words, then the exact-2x kernel's 16-bit twin; was the tiled kernel at 0.05)
     sws_case("sws_nv12_1080p_to_p010_4k_bicubic", 23, 1920, 1080, 158, 3840, 2160, 32)

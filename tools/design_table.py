@@ -44,7 +44,8 @@ ROWS = [
     ("`k_sws_up2<…,RC>`, `k_sws_up2` on 4:4:4", "yuvj420p→yuv420p 1080p→4K (range conversion between the passes); yuv444p 1080p→4K", "as the bench kernel", "1.875 / 3.75 B / output px", ("sws_yuvj420p_1080p_to_yuv420p_4k_bicubic", "sws_yuv444p_1080p_to_4k_bicubic"), ("hbm_frac",)),
     ("`k_sws_up2<.,.,1>`, `k_sws_down2<1>`", "exact 2× / 2:1 at 10 bits: p010 1080p→4K, yuv420p10 1080p→4K, p010 4K→1080p, p010 4K→nv12 1080p", "HBM / VALU", "3.75 B / output px (up), 15 (down)", ("sws_p010_1080p_to_4k_bicubic", "sws_yuv420p10_1080p_to_4k_bicubic", "sws_p010_4k_to_1080p_bicubic", "sws_p010_4k_to_nv12_1080p_bicubic"), ("hbm_frac",)),
     ("`k_sws_up32` (`sws_up32.hip`), `k_sws_down32h` (`sws_down32.hip`)", "round 6, exact 3:2 and 4:3 above 8 bits on static schedules: p010 720p→1080p (period 2 in, 3 out; was the walker at 0.36), yuv420p10 1080p→1440p (3 in, 4 out; was 0.40), p010 4K→1440p (3 in, 2 out; was 0.37)", "HBM / latency", "4.33 / 4.69 / 9.75 B per output px", ("sws_p010_720p_to_1080p_bicubic", "sws_yuv420p10_1080p_to_1440p_bicubic", "sws_p010_4k_to_1440p_bicubic", "sws_p010_1440p_to_1080p_bicubic"), ("hbm_frac",)),
-    ("`k_sws_walk16` (`sws_walk16.hip`)", "every other ratio above 8 bits, RGB sources, deeper sources into RGB (first stage); round 6: a wave's source row segment through LDS when the picture grows", "VALU + issue", "by conversion", ("sws_bgra_1080p_to_nv12_1080p_bicubic", "sws_p010_1080p_to_bgra_1080p_bicubic"), ("hbm_frac",)),
+    ("`k_sws_walk16` (`sws_walk16.hip`)", "every other ratio above 8 bits, RGB sources, deeper sources into RGB (first stage); round 6: a wave's source row segment through LDS when the picture grows", "VALU + issue", "by conversion", ("sws_p010_1080p_to_bgra_1080p_bicubic",), ("hbm_frac",)),
+    ("`k_sws_rgb420`, `k_sws_rgb_in` with direct planes (`sws_rgbin.hip`)", "round 6: packed RGB into 4:2:0 / planar 4:4:4 at the source's size in one kernel: bgra 1080p→nv12 (was two stages at 0.19), bgra 1080p→yuv444p (0.17)", "HBM", "5.5 / 7 B / px", ("sws_bgra_1080p_to_nv12_1080p_bicubic", "sws_bgra_1080p_to_yuv444p_1080p"), ("hbm_frac",)),
     ("`k_sws_down32`", "nv12 1080p→720p (exact 3:2); round 6: rows straight-line, dots in hand-scheduled blocks (was 0.31)", "VALU", "4.875 B / output px", "sws_nv12_1080p_to_720p_bicubic", ("hbm_frac",)),
     ("`k_yuv444_rgb_full`, `k_sws_copy420`, yuv444p→yuv420p", "conversions at the source's size on streaming kernels", "HBM", "6 / 3 / 4.5 B / px", ("sws_yuv444p_1080p_to_rgb24_1080p", "sws_nv12_1080p_to_yuv420p_1080p", "sws_yuv444p_1080p_to_yuv420p_1080p"), ("hbm_frac",)),
     ("`sws_uops` generated kernels", "`SwsOpBackend` micro-op lists on 4K pictures: yuv444p→rgb24, rgb24→yuv444p, yuv444p10→rgb48, rgba→argb", "HBM", "by list", ("sws_ops_yuv444p_rgb24_4k", "sws_ops_rgb24_yuv444p_4k", "sws_ops_yuv444p10_rgb48_4k", "sws_ops_rgba_argb_4k"), ("hbm_frac",)),
